@@ -1,0 +1,199 @@
+/*
+ * longsom_hip.h — C-ABI of liblongsom_hip.so, the MI355X (gfx950) implementation of
+ * LongSom's SComatic-derived SNV hot path:
+ *
+ *   SplitBamCellTypes -> BaseCellCounter -> MergeBaseCellCounts -> BaseCellCalling.step1
+ *
+ * The reference has no FFI for this path (it is pure Python): the operator
+ * boundary is the Snakemake rule contract (files in / files out).  This header is the boundary
+ * a maintainer binds with ctypes from the rule scripts; each entry point
+ * names the reference code it replaces (paths relative to /root/reference/workflow/scripts).
+ *
+ * Conventions
+ *   - plain C, pointers + sizes only; no torch / C++ types.
+ *   - every call returns 0 on success, <0 on error; lsg_last_error() gives the message
+ *     (thread-local).  One handle per GPU; a handle is not thread-safe; handles are independent.
+ *   - "on_device" != 0 means the array pointers are device pointers on the handle's GPU
+ *     (e.g. torch tensors' data_ptr()); 0 means host memory, borrowed for the duration of the call.
+ *   - positions are 0-based on the device; text writers add 1 (BaseCellCounter.py:288).
+ *   - there is NO CPU fallback in this library: without a HIP device lsg_create() fails.
+ */
+#ifndef LONGSOM_HIP_H
+#define LONGSOM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lsg_ctx lsg_ctx;
+
+/* Symbol classes of one pileup entry, in the allele order of the reference
+ * (BaseCellCalling.step1.py:20  Alleles = ["A","C","T","G","I","D","N","O"]);
+ * LSG_SYM_NA = the reference's 'NA' (intron '>' '<', IUPAC, '=': EasyReadPileup,
+ * BaseCellCounter.py:152-180) and is never counted. */
+enum { LSG_SYM_A = 0, LSG_SYM_C = 1, LSG_SYM_T = 2, LSG_SYM_G = 3, LSG_SYM_I = 4,
+       LSG_SYM_D = 5, LSG_SYM_N = 6, LSG_SYM_O = 7, LSG_SYM_NA = 15 };
+
+/* One count row = 42 uint32 per (site, cell type):
+ *   [0] DP   [1] NC   [2..9] CC   [10..17] BC   [18..25] BQ   [26..33] BCf   [34..41] BCr
+ * each vector indexed by the symbol class above (the TSV prints classes 0..5 only,
+ * BaseCellCounter.py:300-306). */
+#define LSG_ROW_WORDS 42
+#define LSG_MAX_CELLTYPES 4
+
+/* Pre-decoded read-record arrays ("SoA" form of a coordinate-sorted BAM).
+ * A read is split into SEGMENTS = maximal runs of consecutive reference positions that carry a
+ * pileup entry (M/=/X/D columns; N reference skips break segments).  One EVENT per covered
+ * reference position: uint16 = (symbol_class << 8) | base_quality, where the symbol class and the
+ * quality follow htslib bam_plp + pysam PileupColumn semantics as used by BaseCellCounter.py:191-216
+ * (anchor base of an indel -> I / D, interior deletion column -> O with the quality of the next
+ * query base). */
+typedef struct {
+    int64_t n_reads;
+    int64_t n_segs;
+    int64_t n_events;
+    /* per read */
+    const int32_t*  read_tid;    /* contig index                                  */
+    const int32_t*  read_pos;    /* 0-based leftmost position                     */
+    const uint16_t* read_flag;   /* SAM flag                                      */
+    const uint8_t*  read_mapq;   /* MAPQ                                          */
+    const int32_t*  read_cb;     /* dense barcode id, -1 = no CB tag / not in barcodes.tsv */
+    /* per segment */
+    const uint32_t* seg_read;    /* owning read index                             */
+    const int32_t*  seg_start;   /* 0-based reference start                       */
+    const int32_t*  seg_len;     /* number of reference positions (= events)      */
+    const int64_t*  seg_ev_off;  /* index of the segment's first event            */
+    /* per event */
+    const uint16_t* events;
+    int32_t on_device;
+} lsg_reads;
+
+/* Parameters of the count stage; defaults = the flags LongSom's rules pass
+ * (R:SNVCalling.smk:52-59 + script defaults BaseCellCounter.py:331-339). */
+typedef struct {
+    int32_t min_bq;        /* --min_bq  20 */
+    int32_t min_mq;        /* --min_mq  60 (config.yaml:74) */
+    int32_t min_dp;        /* --min_dp  5  */
+    int32_t min_cc;        /* --min_cc  5  */
+    uint32_t flag_exclude; /* reads with any of these SAM flag bits are dropped:
+                              0x4|0x100|0x200|0x400 (pysam pileup flag_filter) | 0x800
+                              (BaseCellCounter.py:249) = 0xF04 */
+    int32_t ignore_orphans;/* 1: drop paired reads that are not proper pairs (pysam default) */
+} lsg_count_params;
+
+/* Parameters of the step-1 call (BaseCellCalling.step1.py:585-604). */
+typedef struct {
+    double alpha1, beta1, alpha2, beta2;
+    int32_t min_cov;        /* --min_cov 5        */
+    int32_t min_cells;      /* --min_cells 5      */
+    int32_t min_ac_cells;   /* --min_ac_cells 2   */
+    int32_t min_ac_reads;   /* --min_ac_reads 3   */
+    int32_t max_cell_types; /* --max_cell_types 1 */
+    int32_t min_cell_types; /* --min_cell_types 2 */
+} lsg_call_params;
+
+/* One step-1 call record per merged site (fixed size; the host formats the TSV line).
+ * p-values are stored as the integer k with p = k / 10000 after Python round(x, 4)
+ * (round-half-even on the exact binary value). */
+#define LSG_CALL_MAX_ALT 3
+typedef struct {
+    int64_t  key;                       /* (tid << 32) | pos0                                   */
+    uint8_t  ref;                       /* reference base (ASCII, upper)                        */
+    uint8_t  present;                   /* bit c: cell type c has a count row at this site      */
+    uint8_t  considered;                /* bit c: cell type c passed min_cov / min_cells         */
+    uint8_t  has_cand;                  /* bit c: cell type c has >=1 alt candidate             */
+    uint8_t  n_alt[LSG_MAX_CELLTYPES];  /* candidates per cell type                             */
+    uint8_t  alt[LSG_MAX_CELLTYPES][LSG_CALL_MAX_ALT];    /* symbol class, sorted as 'A'<'C'<'G'<'T' */
+    uint8_t  ct_filter[LSG_MAX_CELLTYPES];                /* enum lsg_ct_filter                  */
+    uint32_t alt_bc[LSG_MAX_CELLTYPES][LSG_CALL_MAX_ALT];
+    uint32_t alt_cc[LSG_MAX_CELLTYPES][LSG_CALL_MAX_ALT];
+    int32_t  p_bc[LSG_MAX_CELLTYPES][LSG_CALL_MAX_ALT];   /* round(sf,4) * 1e4                   */
+    int32_t  p_cc[LSG_MAX_CELLTYPES][LSG_CALL_MAX_ALT];
+    uint32_t site_filter;               /* bit set, enum lsg_site_filter                        */
+    int32_t  cell_types_min;            /* Cell_types_min_BC == Cell_types_min_CC               */
+    uint32_t sum_alts_bc, sum_dp, sum_alts_cc, sum_nc;    /* Rest_BC / Rest_CC                  */
+    int32_t  noise_p_bc, noise_p_cc;    /* round(1-cdf,4)*1e4, or -1 when Sum_alts_bc == 0 (prints "1") */
+    uint8_t  up_ctx[5], down_ctx[5];    /* ASCII; up_ctx[0]==0 => "." (POS < 6)                 */
+    uint8_t  pad[2];
+} lsg_call;
+
+enum lsg_ct_filter { LSG_CF_NONE = 0, LSG_CF_NONSIG, LSG_CF_LOWSIG, LSG_CF_MULTI, LSG_CF_LOW_CELLS,
+                     LSG_CF_LOW_READS, LSG_CF_PASS };
+enum lsg_site_filter { LSG_SF_MULTIPLE_CELL_TYPES = 1, LSG_SF_MULTI_ALLELIC = 2, LSG_SF_MIN_CELL_TYPES = 4,
+                       LSG_SF_CELL_TYPE_NOISE = 8, LSG_SF_NOISY_SITE = 16, LSG_SF_LC_UP = 32,
+                       LSG_SF_LC_DOWN = 64, LSG_SF_CANDIDATE = 1u << 31 };
+
+/* ---- lifetime -------------------------------------------------------------------------------*/
+int         lsg_create(int device_id, lsg_ctx** out);
+void        lsg_destroy(lsg_ctx* ctx);
+const char* lsg_last_error(void);
+const char* lsg_version(void);
+/* Launch everything on this hipStream_t (pass torch.cuda.current_stream().cuda_stream);
+ * NULL = the handle's own stream. */
+int         lsg_set_stream(lsg_ctx* ctx, void* hip_stream);
+int         lsg_synchronize(lsg_ctx* ctx);
+
+/* ---- inputs ---------------------------------------------------------------------------------*/
+/* Contig table = pysam.FastaFile.references / get_reference_length (BaseCellCounter.py:84-86). */
+int lsg_set_contigs(lsg_ctx* ctx, int32_t n_contigs, const int64_t* lengths);
+/* Upper-cased reference bases of one contig (inFasta.fetch(...).upper(), BaseCellCounter.py:202-203;
+ * BaseCellCalling.step1.py:98-99). */
+int lsg_load_reference(lsg_ctx* ctx, int32_t tid, const uint8_t* bases, int64_t len, int32_t on_device);
+/* celltype_of[cb] in [0, n_celltypes) or 255 = barcode not used.  Replaces meta_to_dict + the
+ * per-read routing of SplitBamCellTypes.py:16-36,83-90,173: a re-annotation pass only swaps this
+ * table, the reads stay resident. */
+int lsg_set_barcodes(lsg_ctx* ctx, const uint8_t* celltype_of, int32_t n_cb, int32_t n_celltypes);
+/* Copies (or adopts, when on_device) the read-record arrays.  Replaces reading the per-cell-type
+ * BAMs in run_interval (BaseCellCounter.py:190-191). */
+int lsg_load_reads(lsg_ctx* ctx, const lsg_reads* reads);
+
+/* ---- hot path -------------------------------------------------------------------------------*/
+/* Per-cell-type pileup base counting over every covered column of the loaded reads; replaces
+ * split_bam's filter (SplitBamCellTypes.py:65-124), run_interval (BaseCellCounter.py:182-320) for
+ * all windows, and the gates at :211,:221,:282,:294.  Results stay on the device.
+ * n_rows[c] = emitted sites of cell type c; *n_columns = pileup columns with >=1 counted entry,
+ * summed over cell types (the "genomic sites" of BASELINE.json's metric). */
+int lsg_pileup_count(lsg_ctx* ctx, const lsg_count_params* params, int64_t* n_rows, int64_t* n_columns);
+/* Copies cell type ct's rows to the host in genomic order (tid, pos ascending):
+ * keys[n] = (tid<<32)|pos0, ref[n] = reference base, counts[n*42]. */
+int lsg_fetch_counts(lsg_ctx* ctx, int32_t ct, int64_t* keys, uint8_t* ref, uint32_t* counts, int64_t capacity);
+
+/* Outer join of the per-cell-type rows on (tid,pos) + step-1 arithmetic on every merged site;
+ * replaces merge_cell_types_files (MergeBaseCellCounts.py:116-204) and variant_calling_step1
+ * (BaseCellCalling.step1.py:19-476).  *n_sites = merged sites, *n_candidates = sites with ALT != ".". */
+int lsg_call_step1(lsg_ctx* ctx, const lsg_call_params* params, int64_t* n_sites, int64_t* n_candidates);
+/* Copies call records in genomic order; candidates_only != 0 keeps rows with ALT != "." or FILTER != "." */
+int lsg_fetch_calls(lsg_ctx* ctx, lsg_call* out, int64_t capacity, int32_t candidates_only, int64_t* n_out);
+
+/* Position sets (RNA-editing / PoN_SR / PoN_LR; build_dict, BaseCellCalling.step2.py:197-221):
+ * sorted unique keys (tid<<32)|pos1 resident in HBM; kind in [0,3). */
+int lsg_load_posset(lsg_ctx* ctx, int32_t kind, const int64_t* keys, int64_t n, int32_t on_device);
+/* Membership of n query keys in set `kind` (GetExtraFilters, step2.py:142-158). hits[i] = 0/1. */
+int lsg_probe_posset(lsg_ctx* ctx, int32_t kind, const int64_t* keys, int64_t n, uint8_t* hits, int32_t on_device);
+
+/* ---- measurement helpers --------------------------------------------------------------------*/
+/* Statistics of the last lsg_pileup_count: admitted reads / segments / events (events that passed
+ * read admission, before the base-quality gate), tile entries, non-empty units, deep units. */
+typedef struct {
+    int64_t n_reads_admitted, n_segs_admitted, n_events_admitted;
+    int64_t n_entries, n_units, n_deep_units;
+    float   ms_bin, ms_pileup, ms_total;   /* HIP-event times of the last call */
+} lsg_count_stats;
+int lsg_get_count_stats(lsg_ctx* ctx, lsg_count_stats* out);
+
+/* Deterministic synthetic read-record arrays generated directly in HBM (bench / tests); the model
+ * is documented in longsom_amd/synth.py and mirrored on the host by the same counter-based RNG. */
+typedef struct {
+    uint64_t seed;
+    int64_t  n_reads;
+    int32_t  n_genes;
+    int32_t  n_cb;
+    int32_t  reserved[8];
+} lsg_synth_params;
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LONGSOM_HIP_H */

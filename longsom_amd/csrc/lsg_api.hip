@@ -1,0 +1,232 @@
+// C-ABI entry points of liblongsom_hip.so (see include/longsom_hip.h).
+#include "lsg_ctx.h"
+#include <cstdarg>
+#include <cstring>
+
+namespace lsg {
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+}
+const char* get_error() { return g_err; }
+
+int run_count(lsg_ctx* c, const lsg_count_params* p);
+int run_fetch_counts(lsg_ctx* c, int ct, int64_t* keys, uint8_t* ref, uint32_t* counts, int64_t capacity);
+int compute_entries_upper(lsg_ctx* c);
+int run_call(lsg_ctx* c, const lsg_call_params* p);
+int run_fetch_calls(lsg_ctx* c, lsg_call* out, int64_t capacity, int candidates_only, int64_t* n_out);
+int run_probe(lsg_ctx* c, int kind, const int64_t* keys, int64_t n, uint8_t* hits, int on_device);
+
+// copy a host array to a grow-only device buffer, or adopt a device pointer
+template <class T>
+static int put(lsg_ctx* c, DevBuf& buf, const T*& dst, const T* src, int64_t n, int on_device) {
+    if (n <= 0 || !src) { dst = nullptr; return 0; }
+    if (on_device) { dst = src; return 0; }
+    if (buf.reserve((size_t)n * sizeof(T))) return -1;
+    LSG_HIP(hipMemcpyAsync(buf.p, src, (size_t)n * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    dst = buf.as<T>();
+    return 0;
+}
+} // namespace lsg
+
+using namespace lsg;
+
+extern "C" {
+
+const char* lsg_last_error(void) { return get_error(); }
+const char* lsg_version(void) { return "longsom_hip 0.1 (gfx950)"; }
+
+int lsg_create(int device_id, lsg_ctx** out) {
+    if (!out) { set_error("lsg_create: out is NULL"); return -2; }
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        set_error("lsg_create: no HIP device visible (this library has no CPU fallback)");
+        return -1;
+    }
+    if (device_id < 0 || device_id >= n) { set_error("lsg_create: device %d out of range [0,%d)", device_id, n); return -2; }
+    LSG_HIP(hipSetDevice(device_id));
+    lsg_ctx* c = new lsg_ctx();
+    c->device = device_id;
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        set_error("lsg_create: hipStreamCreate failed"); delete c; return -1;
+    }
+    c->stream = c->own_stream;
+    for (auto& e : c->ev)
+        if (hipEventCreate(&e) != hipSuccess) { set_error("lsg_create: hipEventCreate failed"); delete c; return -1; }
+    *out = c;
+    return 0;
+}
+
+void lsg_destroy(lsg_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    DevBuf* bufs[] = {&c->d_tile_base, &c->d_contig_len, &c->d_ref_ptrs, &c->d_celltype_of, &c->b_read_tid, &c->b_read_pos,
+                      &c->b_read_flag, &c->b_read_mapq, &c->b_read_cb, &c->b_seg_read, &c->b_seg_start, &c->b_seg_len,
+                      &c->b_seg_ev_off, &c->b_events, &c->d_read_key, &c->d_unit_cnt, &c->d_unit_off, &c->d_unit_fill,
+                      &c->d_entries, &c->d_ne_units, &c->d_ne_mask, &c->d_ne_rowbase, &c->d_ne_rowoff, &c->d_deep_list,
+                      &c->d_scalars, &c->d_cub_tmp, &c->d_calls, &c->d_site_off};
+    for (auto* b : bufs) b->release();
+    for (auto& b : c->d_rows) b.release();
+    for (auto& b : c->d_rowkey) b.release();
+    for (auto& b : c->ref) b.release();
+    for (auto& s : c->posset) s.keys.release();
+    for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int lsg_set_stream(lsg_ctx* c, void* hip_stream) {
+    if (!c) { set_error("lsg_set_stream: NULL handle"); return -2; }
+    (void)hipStreamSynchronize(c->stream);
+    c->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->own_stream;
+    return 0;
+}
+
+int lsg_synchronize(lsg_ctx* c) {
+    if (!c) { set_error("lsg_synchronize: NULL handle"); return -2; }
+    LSG_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int lsg_set_contigs(lsg_ctx* c, int32_t n_contigs, const int64_t* lengths) {
+    if (!c || n_contigs <= 0 || !lengths) { set_error("lsg_set_contigs: bad arguments"); return -2; }
+    LSG_HIP(hipSetDevice(c->device));
+    c->n_contigs = n_contigs;
+    c->contig_len.assign(lengths, lengths + n_contigs);
+    c->tile_base.assign(n_contigs + 1, 0);
+    uint64_t t = 0;
+    for (int i = 0; i < n_contigs; ++i) {
+        if (lengths[i] < 0 || lengths[i] > 0x7fffffffll) { set_error("lsg_set_contigs: contig %d length %lld unsupported", i, (long long)lengths[i]); return -2; }
+        c->tile_base[i] = (uint32_t)t;
+        t += (uint64_t)((lengths[i] + TILE_W - 1) / TILE_W);
+    }
+    if (t * LSG_MAX_CELLTYPES >= 0x7fffffffull) { set_error("lsg_set_contigs: genome too large (%llu tiles)", (unsigned long long)t); return -2; }
+    c->tile_base[n_contigs] = (uint32_t)t;
+    c->n_tiles = (uint32_t)t;
+    for (auto& b : c->ref) b.release();
+    c->ref.assign(n_contigs, DevBuf());
+    c->ref_ptr.assign(n_contigs, nullptr);
+    if (c->d_tile_base.reserve((size_t)(n_contigs + 1) * 4) || c->d_contig_len.reserve((size_t)n_contigs * 8) ||
+        c->d_ref_ptrs.reserve((size_t)n_contigs * sizeof(void*))) return -1;
+    LSG_HIP(hipMemcpyAsync(c->d_tile_base.p, c->tile_base.data(), (size_t)(n_contigs + 1) * 4, hipMemcpyHostToDevice, c->stream));
+    LSG_HIP(hipMemcpyAsync(c->d_contig_len.p, c->contig_len.data(), (size_t)n_contigs * 8, hipMemcpyHostToDevice, c->stream));
+    LSG_HIP(hipMemsetAsync(c->d_ref_ptrs.p, 0, (size_t)n_contigs * sizeof(void*), c->stream));
+    LSG_HIP(hipStreamSynchronize(c->stream));
+    c->counted = c->called = false;
+    return 0;
+}
+
+int lsg_load_reference(lsg_ctx* c, int32_t tid, const uint8_t* bases, int64_t len, int32_t on_device) {
+    if (!c || !bases) { set_error("lsg_load_reference: bad arguments"); return -2; }
+    if (tid < 0 || tid >= c->n_contigs) { set_error("lsg_load_reference: tid %d out of range", tid); return -2; }
+    if (len != c->contig_len[tid]) { set_error("lsg_load_reference: contig %d has length %lld, got %lld bases", tid, (long long)c->contig_len[tid], (long long)len); return -2; }
+    LSG_HIP(hipSetDevice(c->device));
+    const uint8_t* p = nullptr;
+    if (put<uint8_t>(c, c->ref[tid], p, bases, len > 0 ? len : 1, on_device)) return -1;
+    c->ref_ptr[tid] = p;
+    LSG_HIP(hipMemcpyAsync(c->d_ref_ptrs.as<const uint8_t*>() + tid, &c->ref_ptr[tid], sizeof(void*), hipMemcpyHostToDevice, c->stream));
+    LSG_HIP(hipStreamSynchronize(c->stream));
+    c->counted = c->called = false;
+    return 0;
+}
+
+int lsg_set_barcodes(lsg_ctx* c, const uint8_t* celltype_of, int32_t n_cb, int32_t n_celltypes) {
+    if (!c || !celltype_of || n_cb <= 0) { set_error("lsg_set_barcodes: bad arguments"); return -2; }
+    if (n_celltypes <= 0 || n_celltypes > LSG_MAX_CELLTYPES) { set_error("lsg_set_barcodes: n_celltypes %d not in [1,%d]", n_celltypes, LSG_MAX_CELLTYPES); return -2; }
+    if (n_cb > 0x00FFFFFF) { set_error("lsg_set_barcodes: more than 2^24-1 barcodes"); return -2; }
+    LSG_HIP(hipSetDevice(c->device));
+    if (c->d_celltype_of.reserve((size_t)n_cb)) return -1;
+    LSG_HIP(hipMemcpyAsync(c->d_celltype_of.p, celltype_of, (size_t)n_cb, hipMemcpyHostToDevice, c->stream));
+    LSG_HIP(hipStreamSynchronize(c->stream));
+    c->n_cb = n_cb; c->n_ct = n_celltypes;
+    c->counted = c->called = false;
+    return 0;
+}
+
+int lsg_load_reads(lsg_ctx* c, const lsg_reads* r) {
+    if (!c || !r) { set_error("lsg_load_reads: bad arguments"); return -2; }
+    if (r->n_reads < 0 || r->n_segs < 0 || r->n_events < 0) { set_error("lsg_load_reads: negative sizes"); return -2; }
+    if (r->n_segs >= 0xFFFFFFF0ll || r->n_reads >= 0xFFFFFFF0ll) { set_error("lsg_load_reads: more than 2^32 reads/segments; load in windows"); return -2; }
+    if (r->n_events >= (1ll << 40)) { set_error("lsg_load_reads: more than 2^40 events"); return -2; }
+    LSG_HIP(hipSetDevice(c->device));
+    c->rd = lsg_reads{};
+    c->rd.n_reads = r->n_reads; c->rd.n_segs = r->n_segs; c->rd.n_events = r->n_events; c->rd.on_device = 1;
+    int d = r->on_device;
+    if (put(c, c->b_read_tid, c->rd.read_tid, r->read_tid, r->n_reads, d) ||
+        put(c, c->b_read_pos, c->rd.read_pos, r->read_pos, r->n_reads, d) ||
+        put(c, c->b_read_flag, c->rd.read_flag, r->read_flag, r->n_reads, d) ||
+        put(c, c->b_read_mapq, c->rd.read_mapq, r->read_mapq, r->n_reads, d) ||
+        put(c, c->b_read_cb, c->rd.read_cb, r->read_cb, r->n_reads, d) ||
+        put(c, c->b_seg_read, c->rd.seg_read, r->seg_read, r->n_segs, d) ||
+        put(c, c->b_seg_start, c->rd.seg_start, r->seg_start, r->n_segs, d) ||
+        put(c, c->b_seg_len, c->rd.seg_len, r->seg_len, r->n_segs, d) ||
+        put(c, c->b_seg_ev_off, c->rd.seg_ev_off, r->seg_ev_off, r->n_segs, d) ||
+        put(c, c->b_events, c->rd.events, r->events, r->n_events, d))
+        return -1;
+    if (r->n_reads > 0 && (!c->rd.read_tid || !c->rd.read_flag || !c->rd.read_mapq || !c->rd.read_cb)) { set_error("lsg_load_reads: NULL read array"); return -2; }
+    if (r->n_segs > 0 && (!c->rd.seg_read || !c->rd.seg_start || !c->rd.seg_len || !c->rd.seg_ev_off)) { set_error("lsg_load_reads: NULL segment array"); return -2; }
+    LSG_HIP(hipStreamSynchronize(c->stream));
+    c->counted = c->called = false;
+    return compute_entries_upper(c);
+}
+
+int lsg_pileup_count(lsg_ctx* c, const lsg_count_params* params, int64_t* n_rows, int64_t* n_columns) {
+    if (!c || !params) { set_error("lsg_pileup_count: bad arguments"); return -2; }
+    LSG_HIP(hipSetDevice(c->device));
+    int rc = run_count(c, params);
+    if (rc) return rc;
+    if (n_rows) for (int i = 0; i < c->n_ct; ++i) n_rows[i] = c->n_rows[i];
+    if (n_columns) *n_columns = c->n_columns;
+    return 0;
+}
+
+int lsg_fetch_counts(lsg_ctx* c, int32_t ct, int64_t* keys, uint8_t* ref, uint32_t* counts, int64_t capacity) {
+    if (!c || !keys || !ref || !counts) { set_error("lsg_fetch_counts: bad arguments"); return -2; }
+    LSG_HIP(hipSetDevice(c->device));
+    return run_fetch_counts(c, ct, keys, ref, counts, capacity);
+}
+
+int lsg_get_count_stats(lsg_ctx* c, lsg_count_stats* out) {
+    if (!c || !out) { set_error("lsg_get_count_stats: bad arguments"); return -2; }
+    *out = c->stats;
+    return 0;
+}
+
+int lsg_call_step1(lsg_ctx* c, const lsg_call_params* params, int64_t* n_sites, int64_t* n_candidates) {
+    if (!c || !params) { set_error("lsg_call_step1: bad arguments"); return -2; }
+    LSG_HIP(hipSetDevice(c->device));
+    int rc = run_call(c, params);
+    if (rc) return rc;
+    if (n_sites) *n_sites = c->n_sites;
+    if (n_candidates) *n_candidates = c->n_cand;
+    return 0;
+}
+
+int lsg_fetch_calls(lsg_ctx* c, lsg_call* out, int64_t capacity, int32_t candidates_only, int64_t* n_out) {
+    if (!c || (!out && capacity > 0)) { set_error("lsg_fetch_calls: bad arguments"); return -2; }
+    LSG_HIP(hipSetDevice(c->device));
+    return run_fetch_calls(c, out, capacity, candidates_only, n_out);
+}
+
+int lsg_load_posset(lsg_ctx* c, int32_t kind, const int64_t* keys, int64_t n, int32_t on_device) {
+    if (!c || kind < 0 || kind >= 3 || n < 0 || (n > 0 && !keys)) { set_error("lsg_load_posset: bad arguments"); return -2; }
+    LSG_HIP(hipSetDevice(c->device));
+    PosSet& s = c->posset[kind];
+    s.n = 0;
+    if (n == 0) return 0;
+    if (s.keys.reserve((size_t)n * 8)) return -1;
+    LSG_HIP(hipMemcpyAsync(s.keys.p, keys, (size_t)n * 8, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+    LSG_HIP(hipStreamSynchronize(c->stream));
+    s.n = n;
+    return 0;
+}
+
+int lsg_probe_posset(lsg_ctx* c, int32_t kind, const int64_t* keys, int64_t n, uint8_t* hits, int32_t on_device) {
+    if (!c || kind < 0 || kind >= 3 || n < 0 || (n > 0 && (!keys || !hits))) { set_error("lsg_probe_posset: bad arguments"); return -2; }
+    LSG_HIP(hipSetDevice(c->device));
+    return run_probe(c, kind, keys, n, hits, on_device);
+}
+
+} // extern "C"

@@ -1,0 +1,91 @@
+// Internal state of one liblongsom_hip handle (one per GPU).  Not part of the C-ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+#include "../../include/longsom_hip.h"
+
+namespace lsg {
+
+constexpr int TILE_W = 64;          // reference positions per tile = one lane per position
+constexpr int NCTR = 33;            // accumulators kept per position: NC, CC[8], BC[8], BQ[8], BCf[8]
+
+void set_error(const char* fmt, ...);
+const char* get_error();
+
+#define LSG_HIP(call)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            lsg::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return -1;                                                                         \
+        }                                                                                      \
+    } while (0)
+
+// Grow-only device buffer.
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 16 + 256;
+        LSG_HIP(hipMalloc(&p, want));
+        cap = want;
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct PosSet { DevBuf keys; int64_t n = 0; };
+
+} // namespace lsg
+
+struct lsg_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipStream_t own_stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+
+    // genome
+    int32_t n_contigs = 0;
+    std::vector<int64_t> contig_len;
+    std::vector<uint32_t> tile_base;      // [n_contigs+1] first tile of each contig
+    uint32_t n_tiles = 0;
+    lsg::DevBuf d_tile_base, d_contig_len, d_ref_ptrs;
+    std::vector<lsg::DevBuf> ref;         // per contig, owned copies
+    std::vector<const uint8_t*> ref_ptr;  // per contig device pointer (owned or adopted)
+
+    // barcodes
+    int32_t n_cb = 0, n_ct = 0;
+    lsg::DevBuf d_celltype_of;
+
+    // reads
+    lsg_reads rd{};                       // device pointers
+    lsg::DevBuf b_read_tid, b_read_pos, b_read_flag, b_read_mapq, b_read_cb;
+    lsg::DevBuf b_seg_read, b_seg_start, b_seg_len, b_seg_ev_off, b_events;
+    uint64_t entries_upper = 0;           // sum over segments of tiles overlapped
+
+    // count-stage workspace
+    lsg::DevBuf d_read_key, d_unit_cnt, d_unit_off, d_unit_fill, d_entries;
+    lsg::DevBuf d_ne_units, d_ne_mask, d_ne_rowbase, d_ne_rowoff, d_deep_list, d_scalars, d_cub_tmp;
+    lsg::DevBuf d_rows[LSG_MAX_CELLTYPES]; // SoA planes [42][row_cap]
+    lsg::DevBuf d_rowkey[LSG_MAX_CELLTYPES];
+    uint64_t row_cap = 0;
+    uint32_t n_ne = 0, n_deep = 0;
+    int64_t n_rows[LSG_MAX_CELLTYPES] = {0, 0, 0, 0};
+    int64_t n_columns = 0;
+    lsg_count_params last_params{};
+    lsg_count_stats stats{};
+    bool counted = false;
+
+    // call stage
+    lsg::DevBuf d_calls, d_site_off;
+    int64_t n_sites = 0, n_cand = 0;
+    bool called = false;
+
+    lsg::PosSet posset[3];
+};

@@ -1,0 +1,192 @@
+"""Host-side handle on the HIP hot path (one Engine per GPU).
+
+Mirrors the stages of LongSom's SNV chain as methods:
+  set_barcodes   <- meta_to_dict / split_bam routing   (scripts/PreProcessing/SplitBamCellTypes.py:16-36,83-90)
+  load_reads     <- reading the BAM                     (scripts/SNVCalling/BaseCellCounter.py:190-191)
+  pileup_count   <- run_interval over all windows       (BaseCellCounter.py:182-320)
+  call_step1     <- merge + variant_calling_step1       (MergeBaseCellCounts.py:116-204, BaseCellCalling.step1.py:19-476)
+"""
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+
+from . import _lib
+from ._lib import CallParams, CountParams, CountStats, Reads, ROW_WORDS
+
+
+@dataclass
+class ReadRecords:
+    """Pre-decoded read-record arrays (SoA form of a coordinate-sorted BAM; include/longsom_hip.h)."""
+    read_tid: np.ndarray      # int32 [R]
+    read_pos: np.ndarray      # int32 [R]
+    read_flag: np.ndarray     # uint16 [R]
+    read_mapq: np.ndarray     # uint8 [R]
+    read_cb: np.ndarray       # int32 [R]  dense barcode id, -1 = none
+    seg_read: np.ndarray      # uint32 [S]
+    seg_start: np.ndarray     # int32 [S]
+    seg_len: np.ndarray       # int32 [S]
+    seg_ev_off: np.ndarray    # int64 [S]
+    events: np.ndarray        # uint16 [E]  (sym << 8) | qual
+    read_names: Optional[List[str]] = field(default=None, repr=False)
+
+    _SPEC = (("read_tid", np.int32), ("read_pos", np.int32), ("read_flag", np.uint16), ("read_mapq", np.uint8),
+             ("read_cb", np.int32), ("seg_read", np.uint32), ("seg_start", np.int32), ("seg_len", np.int32),
+             ("seg_ev_off", np.int64), ("events", np.uint16))
+
+    def __post_init__(self):
+        for name, dt in self._SPEC:
+            setattr(self, name, np.ascontiguousarray(getattr(self, name), dtype=dt))
+        assert len(self.read_pos) == len(self.read_tid) == len(self.read_flag) == len(self.read_mapq) == len(self.read_cb)
+        assert len(self.seg_start) == len(self.seg_read) == len(self.seg_len) == len(self.seg_ev_off)
+
+    @property
+    def n_reads(self): return len(self.read_tid)
+    @property
+    def n_segs(self): return len(self.seg_read)
+    @property
+    def n_events(self): return len(self.events)
+
+    def subset(self, read_mask: np.ndarray) -> "ReadRecords":
+        """Records of the reads selected by a boolean mask (events re-packed)."""
+        read_mask = np.asarray(read_mask, dtype=bool)
+        new_idx = np.cumsum(read_mask) - 1
+        seg_keep = read_mask[self.seg_read]
+        seg_len = self.seg_len[seg_keep]
+        seg_off_old = self.seg_ev_off[seg_keep]
+        seg_off_new = np.concatenate([[0], np.cumsum(seg_len)[:-1]]).astype(np.int64) if len(seg_len) else np.zeros(0, np.int64)
+        if len(seg_len):
+            idx = np.repeat(seg_off_old - seg_off_new, seg_len) + np.arange(int(seg_len.sum()), dtype=np.int64)
+            events = self.events[idx]
+        else:
+            events = np.zeros(0, np.uint16)
+        names = [n for n, m in zip(self.read_names, read_mask) if m] if self.read_names is not None else None
+        return ReadRecords(self.read_tid[read_mask], self.read_pos[read_mask], self.read_flag[read_mask],
+                           self.read_mapq[read_mask], self.read_cb[read_mask],
+                           new_idx[self.seg_read[seg_keep]].astype(np.uint32), self.seg_start[seg_keep], seg_len,
+                           seg_off_new, events, names)
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None or a.size == 0 else a.ctypes.data_as(C.c_void_p)
+
+
+class Engine:
+    """One liblongsom_hip handle.  Raises if the HIP library or a GPU is missing (no CPU fallback)."""
+
+    def __init__(self, device: int = 0, stream: Optional[int] = None):
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        _lib.check(self._lib.lsg_create(int(device), C.byref(h)), "lsg_create")
+        self._h = h
+        self.device = device
+        self.n_ct = 0
+        self.n_contigs = 0
+        self.contig_len = None
+        if stream is not None:
+            self.set_stream(stream)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.lsg_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self): return self
+    def __exit__(self, *exc): self.close()
+
+    # ---- inputs ------------------------------------------------------------------------------
+    def set_stream(self, hip_stream: int):
+        _lib.check(self._lib.lsg_set_stream(self._h, C.c_void_p(hip_stream)), "lsg_set_stream")
+
+    def synchronize(self):
+        _lib.check(self._lib.lsg_synchronize(self._h), "lsg_synchronize")
+
+    def set_contigs(self, lengths):
+        lengths = np.ascontiguousarray(lengths, dtype=np.int64)
+        _lib.check(self._lib.lsg_set_contigs(self._h, len(lengths), _ptr(lengths)), "lsg_set_contigs")
+        self.n_contigs = len(lengths)
+        self.contig_len = lengths.copy()
+
+    def load_reference(self, tid: int, bases, on_device: bool = False, length: Optional[int] = None):
+        """bases: uint8 array of upper-cased ASCII bases (host), or a device pointer + length."""
+        if on_device:
+            _lib.check(self._lib.lsg_load_reference(self._h, tid, C.c_void_p(int(bases)), int(length), 1), "lsg_load_reference")
+            return
+        if isinstance(bases, (bytes, bytearray, str)):
+            bases = np.frombuffer(bases.encode() if isinstance(bases, str) else bytes(bases), dtype=np.uint8)
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        _lib.check(self._lib.lsg_load_reference(self._h, tid, _ptr(bases) if bases.size else C.c_void_p(bases.ctypes.data), len(bases), 0),
+                   "lsg_load_reference")
+
+    def set_barcodes(self, celltype_of, n_celltypes: int):
+        ct = np.ascontiguousarray(celltype_of, dtype=np.uint8)
+        _lib.check(self._lib.lsg_set_barcodes(self._h, _ptr(ct), len(ct), int(n_celltypes)), "lsg_set_barcodes")
+        self.n_ct = int(n_celltypes)
+
+    def load_reads(self, rec: ReadRecords):
+        r = Reads(rec.n_reads, rec.n_segs, rec.n_events, *[_ptr(getattr(rec, n)) for n, _ in ReadRecords._SPEC], 0)
+        _lib.check(self._lib.lsg_load_reads(self._h, C.byref(r)), "lsg_load_reads")
+
+    def load_reads_device(self, n_reads, n_segs, n_events, ptrs: dict):
+        """ptrs: name -> device pointer (int) for every array of ReadRecords._SPEC; arrays stay owned by the caller."""
+        r = Reads(n_reads, n_segs, n_events, *[C.c_void_p(int(ptrs[n])) for n, _ in ReadRecords._SPEC], 1)
+        _lib.check(self._lib.lsg_load_reads(self._h, C.byref(r)), "lsg_load_reads")
+
+    # ---- hot path ----------------------------------------------------------------------------
+    def pileup_count(self, params: Optional[CountParams] = None):
+        """Returns (rows per cell type, pileup columns with >= 1 counted entry summed over cell types)."""
+        params = params or CountParams.longsom_defaults()
+        n_rows = (C.c_int64 * _lib.MAX_CELLTYPES)()
+        n_cols = C.c_int64(0)
+        _lib.check(self._lib.lsg_pileup_count(self._h, C.byref(params), n_rows, C.byref(n_cols)), "lsg_pileup_count")
+        self._n_rows = [int(n_rows[i]) for i in range(self.n_ct)]
+        return list(self._n_rows), int(n_cols.value)
+
+    def fetch_counts(self, ct: int):
+        """Rows of one cell type in genomic order: keys int64 (tid<<32|pos0), ref uint8, counts uint32 [n,42]."""
+        n = self._n_rows[ct]
+        keys = np.zeros(n, np.int64); ref = np.zeros(n, np.uint8); counts = np.zeros((n, ROW_WORDS), np.uint32)
+        if n:
+            _lib.check(self._lib.lsg_fetch_counts(self._h, ct, _ptr(keys), _ptr(ref), _ptr(counts), n), "lsg_fetch_counts")
+        return keys, ref, counts
+
+    def count_stats(self) -> CountStats:
+        s = CountStats()
+        _lib.check(self._lib.lsg_get_count_stats(self._h, C.byref(s)), "lsg_get_count_stats")
+        return s
+
+    def call_step1(self, params: Optional[CallParams] = None):
+        params = params or CallParams.longsom_defaults()
+        n_sites = C.c_int64(0); n_cand = C.c_int64(0)
+        _lib.check(self._lib.lsg_call_step1(self._h, C.byref(params), C.byref(n_sites), C.byref(n_cand)), "lsg_call_step1")
+        self._n_sites = int(n_sites.value); self._n_cand = int(n_cand.value)
+        return self._n_sites, self._n_cand
+
+    def fetch_calls(self, candidates_only: bool = False):
+        cap = self._n_sites
+        arr = (_lib.Call * max(cap, 1))()
+        n_out = C.c_int64(0)
+        _lib.check(self._lib.lsg_fetch_calls(self._h, arr, cap, 1 if candidates_only else 0, C.byref(n_out)), "lsg_fetch_calls")
+        dt = np.dtype(_lib.Call)
+        return np.frombuffer(arr, dtype=dt, count=int(n_out.value)).copy()
+
+    def load_posset(self, kind: int, keys, on_device: bool = False, n: Optional[int] = None):
+        if on_device:
+            _lib.check(self._lib.lsg_load_posset(self._h, kind, C.c_void_p(int(keys)), int(n), 1), "lsg_load_posset")
+            return
+        keys = np.ascontiguousarray(keys, dtype=np.int64)
+        _lib.check(self._lib.lsg_load_posset(self._h, kind, _ptr(keys), len(keys), 0), "lsg_load_posset")
+
+    def probe_posset(self, kind: int, keys) -> np.ndarray:
+        keys = np.ascontiguousarray(keys, dtype=np.int64)
+        hits = np.zeros(len(keys), np.uint8)
+        if len(keys):
+            _lib.check(self._lib.lsg_probe_posset(self._h, kind, _ptr(keys), len(keys), _ptr(hits), 0), "lsg_probe_posset")
+        return hits

@@ -1,0 +1,55 @@
+"""ctypes loader of oracle/liblongsom_oracle.so (built by oracle/Makefile).  Test infrastructure only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "liblongsom_oracle.so")
+_lib = None
+
+
+def build(force=False):
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith(".c")]
+    if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_SO)
+        _lib.lso_count.restype = C.c_int64
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None and a.size else None
+
+
+def count(rec, contig_len, refs, celltype_of, ct, min_bq=20, min_mq=60, min_dp=5, min_cc=5,
+          flag_exclude=0xF04, ignore_orphans=1):
+    """Events-level oracle (oracle/count_oracle.c).  refs: list of uint8 arrays per contig.
+    Returns keys, ref, counts[n,42], n_columns."""
+    L = lib()
+    contig_len = np.ascontiguousarray(contig_len, np.int64)
+    celltype_of = np.ascontiguousarray(celltype_of, np.uint8)
+    refs = [np.ascontiguousarray(r, np.uint8) for r in refs]
+    ref_ptrs = (C.c_void_p * len(refs))(*[r.ctypes.data for r in refs])
+    cap = int(rec.n_events) + 1
+    while True:
+        keys = np.zeros(cap, np.int64); ref = np.zeros(cap, np.uint8); counts = np.zeros((cap, 42), np.uint32)
+        ncols = C.c_int64(0)
+        n = L.lso_count(C.c_int64(rec.n_reads), C.c_int64(rec.n_segs), _p(rec.read_tid), _p(rec.read_flag), _p(rec.read_mapq),
+                        _p(rec.read_cb), _p(rec.seg_read), _p(rec.seg_start), _p(rec.seg_len), _p(rec.seg_ev_off), _p(rec.events),
+                        C.c_int32(len(contig_len)), _p(contig_len), ref_ptrs, _p(celltype_of), C.c_int32(len(celltype_of)), C.c_int32(ct),
+                        C.c_int32(min_bq), C.c_int32(min_mq), C.c_int32(min_dp), C.c_int32(min_cc), C.c_uint32(flag_exclude),
+                        C.c_int32(ignore_orphans), _p(keys), _p(ref), _p(counts), C.c_int64(cap), C.byref(ncols))
+        if n < 0:
+            raise MemoryError("oracle allocation failed")
+        if n <= cap:
+            return keys[:n].copy(), ref[:n].copy(), counts[:n].copy(), int(ncols.value)
+        cap = int(n)
