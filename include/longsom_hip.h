@@ -148,6 +148,13 @@ int lsg_set_barcodes(lsg_ctx* ctx, const uint8_t* celltype_of, int32_t n_cb, int
 /* Copies (or adopts, when on_device) the read-record arrays.  Replaces reading the per-cell-type
  * BAMs in run_interval (BaseCellCounter.py:190-191). */
 int lsg_load_reads(lsg_ctx* ctx, const lsg_reads* reads);
+/* Restrict counting to the genomic region [ (tid_lo,pos_lo), (tid_hi,pos_hi) ) in (tid,pos) order;
+ * positions must be multiples of 64.  This is how windows are sharded over GPUs: every rank loads
+ * the reads overlapping its region (reads crossing a boundary are loaded by both ranks) and each
+ * pileup column is counted by exactly one rank — the analogue of the reference's per-window
+ * POS >= START and POS < END test (BaseCellCounter.py:200).  tid_hi == n_contigs, pos_hi == 0
+ * means "to the end".  Reset with (0,0,n_contigs,0). */
+int lsg_set_region(lsg_ctx* ctx, int32_t tid_lo, int64_t pos_lo, int32_t tid_hi, int64_t pos_hi);
 
 /* ---- hot path -------------------------------------------------------------------------------*/
 /* Per-cell-type pileup base counting over every covered column of the loaded reads; replaces
@@ -179,19 +186,40 @@ int lsg_probe_posset(lsg_ctx* ctx, int32_t kind, const int64_t* keys, int64_t n,
 typedef struct {
     int64_t n_reads_admitted, n_segs_admitted, n_events_admitted;
     int64_t n_entries, n_units, n_deep_units;
-    float   ms_bin, ms_pileup, ms_total;   /* HIP-event times of the last call */
+    int64_t n_events_wave, n_events_deep;  /* events loaded by k_pileup_wave / k_pileup_deep      */
+    int64_t n_rows_wave, n_rows_deep;      /* rows emitted by each kernel (all cell types)         */
+    float   ms_bin, ms_deep, ms_wave, ms_total;   /* HIP-event times of the last call             */
 } lsg_count_stats;
 int lsg_get_count_stats(lsg_ctx* ctx, lsg_count_stats* out);
 
-/* Deterministic synthetic read-record arrays generated directly in HBM (bench / tests); the model
- * is documented in longsom_amd/synth.py and mirrored on the host by the same counter-based RNG. */
+/* ---- synthetic workload (bench / tests; not part of the reference's path) --------------------*/
+/* Gene/expression tables of the BASELINE.md §4 workload model (built by longsom_amd/synth.py; the
+ * per-read / per-base draws are counter-based hashes, see longsom_amd/csrc/synth_model.h).
+ * All pointers are HOST pointers; celltype_of is ignored on the device path (lsg_set_barcodes's
+ * table is used). */
 typedef struct {
     uint64_t seed;
-    int64_t  n_reads;
-    int32_t  n_genes;
-    int32_t  n_cb;
-    int32_t  reserved[8];
-} lsg_synth_params;
+    int64_t  n_reads;        /* reads of this (shard of the) model                                 */
+    int64_t  read_base;      /* global index of local read 0: draws are keyed by read_base + i, so a
+                                shard generates exactly the reads the unsharded model would          */
+    int32_t  n_genes, n_cb, n_contigs, snp_mod;
+    const int32_t* gene_tid;        /* [G]                                   */
+    const int32_t* gene_exon_off;   /* [G+1] index into the exon arrays      */
+    const int32_t* exon_start;      /* 0-based reference start of each exon  */
+    const int32_t* exon_len;
+    const int32_t* exon_cum;        /* transcript coordinate of the exon's first base */
+    const int64_t* gene_read_off;   /* [G+1] reads [off[g], off[g+1]) belong to gene g */
+    const uint8_t* celltype_of;     /* [n_cb] 0 = Cancer                     */
+} lsg_synth_model;
+
+/* Fills the reference of every contig with the model's synthetic genome, in HBM. */
+int lsg_synth_reference(lsg_ctx* ctx, uint64_t seed);
+/* Generates the model's read-record arrays directly in HBM and makes them the loaded reads. */
+int lsg_synth_reads(lsg_ctx* ctx, const lsg_synth_model* model);
+int lsg_get_reads_shape(lsg_ctx* ctx, int64_t* n_reads, int64_t* n_segs, int64_t* n_events);
+/* Copies the resident read-record arrays / reference into caller-allocated host arrays. */
+int lsg_copy_reads_to_host(lsg_ctx* ctx, const lsg_reads* out);
+int lsg_copy_reference_to_host(lsg_ctx* ctx, int32_t tid, uint8_t* out);
 
 #ifdef __cplusplus
 }

@@ -92,7 +92,8 @@ class CountStats(C.Structure):
     _fields_ = [
         ("n_reads_admitted", C.c_int64), ("n_segs_admitted", C.c_int64), ("n_events_admitted", C.c_int64),
         ("n_entries", C.c_int64), ("n_units", C.c_int64), ("n_deep_units", C.c_int64),
-        ("ms_bin", C.c_float), ("ms_pileup", C.c_float), ("ms_total", C.c_float),
+        ("n_events_wave", C.c_int64), ("n_events_deep", C.c_int64), ("n_rows_wave", C.c_int64), ("n_rows_deep", C.c_int64),
+        ("ms_bin", C.c_float), ("ms_deep", C.c_float), ("ms_wave", C.c_float), ("ms_total", C.c_float),
     ]
 
 
@@ -108,6 +109,12 @@ SIGNATURES = {
     "lsg_load_reference": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int32]),
     "lsg_set_barcodes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
     "lsg_load_reads": (C.c_int, [C.c_void_p, C.POINTER(Reads)]),
+    "lsg_set_region": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int64]),
+    "lsg_synth_reference": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "lsg_synth_reads": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "lsg_get_reads_shape": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lsg_copy_reads_to_host": (C.c_int, [C.c_void_p, C.POINTER(Reads)]),
+    "lsg_copy_reference_to_host": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "lsg_pileup_count": (C.c_int, [C.c_void_p, C.POINTER(CountParams), C.c_void_p, C.c_void_p]),
     "lsg_fetch_counts": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
     "lsg_call_step1": (C.c_int, [C.c_void_p, C.POINTER(CallParams), C.c_void_p, C.c_void_p]),

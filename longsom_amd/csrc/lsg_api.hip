@@ -48,6 +48,7 @@ int lsg_create(int device_id, lsg_ctx** out) {
     LSG_HIP(hipSetDevice(device_id));
     lsg_ctx* c = new lsg_ctx();
     c->device = device_id;
+    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) c->n_cus = prop.multiProcessorCount; }
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
         set_error("lsg_create: hipStreamCreate failed"); delete c; return -1;
     }
@@ -72,6 +73,8 @@ void lsg_destroy(lsg_ctx* c) {
     for (auto& b : c->d_rowkey) b.release();
     for (auto& b : c->ref) b.release();
     for (auto& s : c->posset) s.keys.release();
+    for (auto& b : c->syn) b.release();
+    for (auto& b : c->ws) b.release();
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -105,6 +108,7 @@ int lsg_set_contigs(lsg_ctx* c, int32_t n_contigs, const int64_t* lengths) {
     if (t * LSG_MAX_CELLTYPES >= 0x7fffffffull) { set_error("lsg_set_contigs: genome too large (%llu tiles)", (unsigned long long)t); return -2; }
     c->tile_base[n_contigs] = (uint32_t)t;
     c->n_tiles = (uint32_t)t;
+    c->tile_lo = 0; c->tile_hi = (uint32_t)t;
     for (auto& b : c->ref) b.release();
     c->ref.assign(n_contigs, DevBuf());
     c->ref_ptr.assign(n_contigs, nullptr);
@@ -170,6 +174,23 @@ int lsg_load_reads(lsg_ctx* c, const lsg_reads* r) {
     LSG_HIP(hipStreamSynchronize(c->stream));
     c->counted = c->called = false;
     return compute_entries_upper(c);
+}
+
+int lsg_set_region(lsg_ctx* c, int32_t tid_lo, int64_t pos_lo, int32_t tid_hi, int64_t pos_hi) {
+    if (!c || c->n_contigs <= 0) { set_error("lsg_set_region: set contigs first"); return -2; }
+    if (tid_lo < 0 || tid_lo > c->n_contigs || tid_hi < 0 || tid_hi > c->n_contigs || (pos_lo & 63) || (pos_hi & 63) || pos_lo < 0 || pos_hi < 0) {
+        set_error("lsg_set_region: bad region (positions must be multiples of 64)"); return -2;
+    }
+    auto tile_of = [&](int32_t tid, int64_t pos) -> uint64_t {
+        if (tid >= c->n_contigs) return c->n_tiles;
+        uint64_t t = (uint64_t)c->tile_base[tid] + (uint64_t)(pos >> 6);
+        return t < c->tile_base[tid + 1] ? t : c->tile_base[tid + 1];
+    };
+    uint64_t lo = tile_of(tid_lo, pos_lo), hi = tile_of(tid_hi, pos_hi);
+    if (hi < lo) { set_error("lsg_set_region: empty or inverted region"); return -2; }
+    c->tile_lo = (uint32_t)lo; c->tile_hi = (uint32_t)hi;
+    c->counted = c->called = false;
+    return 0;
 }
 
 int lsg_pileup_count(lsg_ctx* c, const lsg_count_params* params, int64_t* n_rows, int64_t* n_columns) {

@@ -55,6 +55,7 @@ struct lsg_ctx {
     std::vector<int64_t> contig_len;
     std::vector<uint32_t> tile_base;      // [n_contigs+1] first tile of each contig
     uint32_t n_tiles = 0;
+    uint32_t tile_lo = 0, tile_hi = 0;    // counted tile range (lsg_set_region); default = everything
     lsg::DevBuf d_tile_base, d_contig_len, d_ref_ptrs;
     std::vector<lsg::DevBuf> ref;         // per contig, owned copies
     std::vector<const uint8_t*> ref_ptr;  // per contig device pointer (owned or adopted)
@@ -88,4 +89,8 @@ struct lsg_ctx {
     bool called = false;
 
     lsg::PosSet posset[3];
+    lsg::DevBuf syn[12];                  // synthetic-model tables + scan scratch (synth.hip)
+    lsg::DevBuf ws[32];                   // count-stage workspace (pileup.hip, enum WS_*)
+    int n_cus = 256;
+    uint32_t n_slots = 0, n_multi = 0;
 };

@@ -6,15 +6,19 @@
 //
 // Work decomposition:
 //   unit  = (64-position tile of one contig, cell type); one lane per reference position.
-//   entry = one read segment overlapping a unit; built by a two-pass counting sort (k_count_units,
-//           scan, k_scatter_entries).
-//   A unit's entries are grouped by cell barcode in LDS (open-addressing hash + scan), then walked
-//   barcode-run by barcode-run: every entry is one coalesced 128-byte load of uint16 events
-//   (lane = position), counters live in registers / lane-private LDS words, and the number of
-//   distinct cells (NC, CC[sym]) is the number of barcode runs with the symbol present.  No global
-//   atomics on the event path, integer arithmetic only (HBM-bound; no MFMA).
-//   Units with <= CAPW entries are processed by one wavefront each (no block barriers); deeper
-//   units (highly expressed genes, chrM) by a whole workgroup in barcode-range passes.
+//   entry = one read segment overlapping a unit, self-contained (barcode/strand key, first event
+//           index, lane range), written by a counting sort over the segments (k_count_units,
+//           scan, k_scatter).  Units deeper than CAPB entries are cut by barcode range into
+//           SLOTS of ~SUBT entries, so every work item is bounded and the heavy tail (chrM,
+//           highly expressed genes) spreads over the whole chip; counters are additive over
+//           disjoint barcode sets.
+//   A slot's entries are grouped by barcode in LDS (open-addressing hash + scan) and walked
+//   barcode-run by barcode-run: every entry is one coalesced <=128-byte load of uint16 events
+//   (lane = position); per-symbol counts go to lane-private LDS words with one packed ds_add;
+//   distinct-cell numbers are counts minus within-run duplicates.  No global atomics on the event
+//   path, integer arithmetic only (HBM/VALU-bound; no MFMA).
+//   Slots with <= CAPW entries are processed by one wavefront each (no block barriers), larger
+//   ones by a 512-thread workgroup on run-aligned slices.
 #include "lsg_ctx.h"
 #include <hipcub/hipcub.hpp>
 
@@ -22,16 +26,29 @@ namespace lsg {
 
 constexpr uint32_t KEY_INVALID = 0xFFFFFFFFu;
 constexpr uint32_t CB_MASK = 0x00FFFFFFu;
-constexpr int CAPW = 256;            // max entries of a wave-processed unit
-constexpr int HW = 512;              // hash slots of the wave kernel (2 x CAPW)
-constexpr int CAPB = 2048;           // staged entries per pass of the deep (workgroup) kernel
-constexpr int HB = 4096;             // hash slots of the deep kernel
-constexpr int NBUCKET = 1024;        // coarse barcode buckets of the deep kernel
-constexpr int DEEP_THREADS = 256;
+constexpr int CAPW = 256;            // max entries of a wave-processed slot
+constexpr int HW = 512;              // hash slots of the wave kernel
+constexpr int CAPB = 2048;           // max entries staged at once by the block kernel
+constexpr int HB = 4096;             // hash slots of the block kernel
+constexpr int SUBT = 1024;           // target entries per barcode-range slot of a deep unit
+constexpr int MAXSUB = 2048;         // max slots per unit
+constexpr int NBUCKET = 256;         // coarse barcode buckets of the block kernel's fallback passes
+constexpr int BLOCK_THREADS = 512;
+constexpr int BLOCK_WAVES = BLOCK_THREADS / 64;
+constexpr int WAVES_PER_BLOCK = 4;   // wave kernel
+constexpr int ARENA = 256;           // rows reserved per wave per allocation
+constexpr int QCHUNK = 16;           // slots dequeued at once by a wave
+constexpr int FLUSH_EVERY = 63;      // packed LDS fields: fwd 6 | cnt 6 | dup 6 | bq 14 bits
 
 // device scalars (uint64 each)
-enum { SC_QHEAD = 0, SC_QHEAD_DEEP = 1, SC_NDEEP = 3, SC_ROWS = 4, SC_COLS = 8, SC_OVERFLOW = 9,
-       SC_READS = 10, SC_SEGS = 11, SC_EVENTS = 12, SC_COUNT = 16 };
+enum { SC_QSMALL = 0, SC_QBIG = 1, SC_NNE = 2, SC_NSLOTS = 3, SC_ROWALLOC = 4, SC_COLS = 8, SC_OVERFLOW = 9,
+       SC_READS = 10, SC_SEGS = 11, SC_EVENTS = 12, SC_EV_WAVE = 13, SC_EV_DEEP = 14, SC_ROWS_DEEP = 15,
+       SC_ROWS = 16, SC_NSMALL = 20, SC_NMULTI = 21, SC_NMULTI_SEL = 22, SC_COUNT = 24 };
+
+// workspace buffers (lsg_ctx::ws)
+enum { WS_UNIT_SLOT = 0, WS_UNIT_NSUB, WS_NE_NSLOT, WS_NE_SLOT_BASE, WS_NE_ACC, WS_NE_GEOM, WS_SLOT_W, WS_SLOT_CNT,
+       WS_SLOT_OFF, WS_SLOT_CURSOR, WS_EKEY, WS_EEV, WS_EMETA, WS_SLOT_LIST, WS_MULTI_LIST, WS_MACC, WS_EXPORT_K, WS_EXPORT_R,
+       WS_EXPORT_C };
 
 struct CountArgs {
     // reads
@@ -44,14 +61,18 @@ struct CountArgs {
     const uint8_t* celltype_of;
     int32_t n_contigs, n_cb, n_ct;
     uint32_t n_units;
+    uint32_t tile_lo, tile_hi;          // counted tile range (lsg_set_region)
     // params
     int32_t min_bq, min_mq, min_dp, min_cc, ignore_orphans;
     uint32_t flag_exclude;
     // workspace
-    uint32_t* read_key; uint32_t* unit_cnt; uint32_t* unit_off; uint32_t* unit_cursor;
-    uint2* entries;
-    uint32_t* ne_units; const uint32_t* n_ne; uint64_t* ne_mask; uint32_t* ne_rowbase;
-    uint32_t* deep_list;
+    uint32_t* read_key; uint32_t* unit_cnt; uint32_t* unit_slot; uint32_t* unit_nsub;
+    uint32_t* ne_units; uint32_t* ne_nslot; uint32_t* ne_slot_base; uint32_t* ne_acc; int2* ne_geom;
+    uint64_t* ne_mask; uint32_t* ne_rowbase;
+    uint32_t* slot_w; uint32_t* slot_cnt; uint32_t* slot_off; uint32_t* slot_cursor;
+    uint32_t* ekey; uint32_t* eev; uint32_t* emeta;
+    uint32_t* slot_list; uint32_t* multi_list; uint32_t* macc;
+    uint32_t n_ne, n_slots, n_multi;
     unsigned long long* scalars;
     uint32_t* rows[LSG_MAX_CELLTYPES];
     uint64_t row_cap;
@@ -65,29 +86,56 @@ struct CountArgs {
 // key = cb | reverse<<24 | celltype<<28.
 __global__ void k_read_key(CountArgs a) {
     int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= a.n_reads) return;
     uint32_t key = KEY_INVALID;
-    uint32_t flag = a.read_flag[r];
-    int32_t cb = a.read_cb[r];
-    int32_t tid = a.read_tid[r];
-    bool ok = (flag & a.flag_exclude) == 0 && (int)a.read_mapq[r] >= a.min_mq && cb >= 0 && cb < a.n_cb &&
-              tid >= 0 && tid < a.n_contigs;
-    if (ok && a.ignore_orphans && (flag & 0x1) && !(flag & 0x2)) ok = false;
-    if (ok) {
-        uint32_t ct = a.celltype_of[cb];
-        if (ct < (uint32_t)a.n_ct) key = (uint32_t)cb | (((flag >> 4) & 1u) << 24) | (ct << 28);
+    if (r < a.n_reads) {
+        uint32_t flag = a.read_flag[r];
+        int32_t cb = a.read_cb[r];
+        int32_t tid = a.read_tid[r];
+        bool ok = (flag & a.flag_exclude) == 0 && (int)a.read_mapq[r] >= a.min_mq && cb >= 0 && cb < a.n_cb &&
+                  tid >= 0 && tid < a.n_contigs;
+        if (ok && a.ignore_orphans && (flag & 0x1) && !(flag & 0x2)) ok = false;
+        if (ok) {
+            uint32_t ct = a.celltype_of[cb];
+            if (ct < (uint32_t)a.n_ct) key = (uint32_t)cb | (((flag >> 4) & 1u) << 24) | (ct << 28);
+        }
+        a.read_key[r] = key;
     }
-    a.read_key[r] = key;
     unsigned long long m = __ballot(key != KEY_INVALID);
     if ((threadIdx.x & 63) == 0 && m) atomicAdd(&a.scalars[SC_READS], (unsigned long long)__popcll(m));
 }
 
-template <bool SCATTER>
+// One atomic per run of adjacent lanes with the same target (reads are coordinate sorted, so the
+// segments of a wave mostly hit the same few units).  Returns base + rank within the run.
+__device__ __forceinline__ uint32_t run_atomic_add(uint32_t* arr, uint32_t idx, bool active, int lane) {
+    uint32_t idx_prev = __shfl_up(idx, 1);
+    int act_prev = __shfl_up((int)active, 1);
+    bool head = active && (lane == 0 || !act_prev || idx_prev != idx);
+    unsigned long long hm = __ballot(head);
+    unsigned long long brk = __ballot(head || !active);
+    unsigned long long after = lane == 63 ? 0ull : (brk >> (lane + 1));
+    uint32_t len = after ? (uint32_t)__ffsll((long long)after) : (uint32_t)(64 - lane);
+    uint32_t base = 0;
+    if (head) base = atomicAdd(&arr[idx], len);
+    unsigned long long below = hm & (lane == 63 ? ~0ull : ((1ull << (lane + 1)) - 1ull));
+    int hl = below ? 63 - __clzll((long long)below) : 0;
+    uint32_t b = __shfl(base, hl);
+    return b + (uint32_t)(lane - hl);
+}
+
+__device__ __forceinline__ uint32_t sub_of(uint32_t cb, uint32_t nsub, uint32_t n_cb) {
+    return (uint32_t)(((uint64_t)cb * nsub) / n_cb);
+}
+
+// MODE 0: count entries per unit.  MODE 1: count entries per slot of multi-slot units.
+// MODE 2: scatter the self-contained entries.
+template <int MODE>
 __global__ void k_bin_segments(CountArgs a) {
+    const int lane = threadIdx.x & 63;
     int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool live = s < a.n_segs;
     uint32_t key = KEY_INVALID;
     int32_t tid = 0, st = 0, ln = 0;
+    int64_t evoff = 0;
     if (live) {
         uint32_t r = a.seg_read[s];
         key = a.read_key[r];
@@ -98,40 +146,99 @@ __global__ void k_bin_segments(CountArgs a) {
             int64_t clen = a.contig_len[tid];
             if (st < 0 || ln <= 0 || (int64_t)st + ln > clen) key = KEY_INVALID;   // malformed: never counted
         }
+        if (MODE == 2 && key != KEY_INVALID) evoff = a.seg_ev_off[s];
     }
     bool ok = key != KEY_INVALID;
-    if (!SCATTER) {
+    if (MODE == 0) {
         unsigned long long m = __ballot(ok);
         unsigned long long evs = ok ? (unsigned long long)ln : 0ull;
         for (int o = 32; o > 0; o >>= 1) evs += __shfl_down(evs, o);
-        if ((threadIdx.x & 63) == 0 && m) {
+        if (lane == 0 && m) {
             atomicAdd(&a.scalars[SC_SEGS], (unsigned long long)__popcll(m));
             atomicAdd(&a.scalars[SC_EVENTS], evs);
         }
     }
-    if (!ok) return;
-    uint32_t ct = key >> 28;
-    uint32_t t0 = a.tile_base[tid] + ((uint32_t)st >> 6);
-    uint32_t t1 = a.tile_base[tid] + ((uint32_t)(st + ln - 1) >> 6);
-    for (uint32_t t = t0; t <= t1; ++t) {
+    uint32_t ct = key >> 28, cb = key & CB_MASK;
+    uint32_t tb = ok ? a.tile_base[tid] : 0;
+    uint32_t t0 = tb + ((uint32_t)st >> 6);
+    uint32_t t1 = tb + ((uint32_t)(st + ln - 1) >> 6);
+    if (t0 < a.tile_lo) t0 = a.tile_lo;
+    if (a.tile_hi == 0) ok = false; else if (t1 + 1 > a.tile_hi) t1 = a.tile_hi - 1;
+    if (!ok) { t0 = 1; t1 = 0; }
+    for (uint32_t k = 0;; ++k) {
+        bool act = t0 + k <= t1 && t1 >= t0;
+        if (!__ballot(act)) break;
+        uint32_t t = t0 + k;
         uint32_t u = t * (uint32_t)a.n_ct + ct;
-        if (SCATTER) {
-            uint32_t slot = atomicAdd(&a.unit_cursor[u], 1u);
-            a.entries[slot] = make_uint2(key, (uint32_t)s);
+        if (MODE == 0) {
+            (void)run_atomic_add(a.unit_cnt, act ? u : 0u, act, lane);
         } else {
-            atomicAdd(&a.unit_cnt[u], 1u);
+            uint32_t nsub = act ? a.unit_nsub[u] : 1u;
+            if (MODE == 1) {
+                if (act && nsub > 1) atomicAdd(&a.slot_cnt[a.unit_slot[u] + sub_of(cb, nsub, (uint32_t)a.n_cb)], 1u);
+            } else {
+                uint32_t slot = 0;
+                if (act) slot = a.unit_slot[u] + (nsub > 1 ? sub_of(cb, nsub, (uint32_t)a.n_cb) : 0u);
+                uint32_t pos = run_atomic_add(a.slot_cursor, slot, act, lane);
+                if (act) {
+                    int32_t tstart = (int32_t)((t - tb) << 6);
+                    int32_t lo = st > tstart ? st : tstart;
+                    int32_t hi = st + ln < tstart + TILE_W ? st + ln : tstart + TILE_W;
+                    int64_t ev_first = evoff + (lo - st);
+                    a.ekey[pos] = key;
+                    a.eev[pos] = (uint32_t)ev_first;
+                    a.emeta[pos] = (uint32_t)((ev_first >> 32) & 0xff) | ((uint32_t)(lo - tstart) << 8) | ((uint32_t)(hi - lo - 1) << 16);
+                }
+            }
         }
     }
 }
 
-__global__ void k_deep_list(CountArgs a) {
+__device__ __forceinline__ void unit_geometry(const CountArgs& a, uint32_t u, int& ct, int& tid, int32_t& tstart) {
+    uint32_t tile = u / (uint32_t)a.n_ct;
+    ct = (int)(u - tile * (uint32_t)a.n_ct);
+    int lo = 0, hi = a.n_contigs;                 // largest tid with tile_base[tid] <= tile
+    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (a.tile_base[mid] <= tile) lo = mid; else hi = mid; }
+    tid = lo;
+    tstart = (int32_t)((tile - a.tile_base[tid]) << 6);
+}
+
+// per non-empty unit: slot plan + geometry
+__global__ void k_unit_plan(CountArgs a) {
     uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= *a.n_ne) return;
+    if (w > a.n_ne) return;
+    if (w == a.n_ne) { a.ne_nslot[w] = 0; return; }
     uint32_t u = a.ne_units[w];
-    if (a.unit_cnt[u] > (uint32_t)CAPW) {
-        unsigned long long i = atomicAdd(&a.scalars[SC_NDEEP], 1ull);
-        a.deep_list[i] = w;
+    uint32_t cnt = a.unit_cnt[u];
+    uint32_t nslot = 1;
+    if (cnt > (uint32_t)CAPB) {
+        nslot = (cnt + SUBT - 1) / SUBT;
+        if (nslot > (uint32_t)MAXSUB) nslot = MAXSUB;
+        if (nslot > (uint32_t)a.n_cb) nslot = (uint32_t)a.n_cb;
+        if (nslot < 1) nslot = 1;
     }
+    a.ne_nslot[w] = nslot;
+    if (nslot > 1) atomicAdd(&a.scalars[SC_NMULTI], 1ull);
+    int ct, tid; int32_t tstart;
+    unit_geometry(a, u, ct, tid, tstart);
+    a.ne_geom[w] = make_int2(tstart, tid | (ct << 24));
+}
+
+__global__ void k_slot_init(CountArgs a) {
+    uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= a.n_ne) return;
+    uint32_t u = a.ne_units[w];
+    uint32_t base = a.ne_slot_base[w], nslot = a.ne_nslot[w];
+    a.unit_slot[u] = base;
+    a.unit_nsub[u] = nslot;
+    uint32_t cnt = a.unit_cnt[u];
+    for (uint32_t j = 0; j < nslot; ++j) { a.slot_w[base + j] = w; a.slot_cnt[base + j] = nslot == 1 ? cnt : 0u; }
+    if (w == a.n_ne - 1) a.slot_cnt[base + nslot] = 0;    // scan sentinel
+}
+
+__global__ void k_multi_index(CountArgs a) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < a.n_multi) a.ne_acc[a.multi_list[k]] = k;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -143,121 +250,101 @@ template <bool BLOCK> __device__ __forceinline__ void group_sync() {
     if (BLOCK) __syncthreads(); else lds_fence();
 }
 __device__ __forceinline__ uint32_t hash_cb(uint32_t cb) { return cb * 2654435761u; }
-__device__ __forceinline__ uint32_t spread4(uint32_t m) { return (m * 0x00204081u) & 0x01010101u; }
 __device__ __forceinline__ uint32_t rl(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
 
-// Per-lane (= per reference position) accumulators of one unit.
+// Per-lane (= per reference position) accumulators of one unit.  Distinct-cell numbers come from
+// duplicates: within a barcode run, an entry whose symbol was already seen at this position is a
+// duplicate; CC[sym] = BC[sym] - dup[sym], NC = sum(BC) - ncdup   (= len(set(...)),
+// BaseCellCounter.py:283,292).
 struct Acc {
-    uint32_t bc[8], bq[8], bcf[8], cc[8], nc;
-    uint32_t cclo, cchi, mask, npk, nruns, prev_cb;
+    uint32_t bc[8], bq[8], bcf[8], dup[8], ncdup;
+    uint32_t mask, npk, prev_cb, nev;
     __device__ __forceinline__ void init() {
 #pragma unroll
-        for (int s = 0; s < 8; ++s) bc[s] = bq[s] = bcf[s] = cc[s] = 0;
-        nc = cclo = cchi = mask = npk = nruns = 0; prev_cb = KEY_INVALID;
+        for (int s = 0; s < 8; ++s) bc[s] = bq[s] = bcf[s] = dup[s] = 0;
+        ncdup = mask = npk = nev = 0; prev_cb = KEY_INVALID;
     }
     __device__ __forceinline__ void flush_pk(uint32_t* pk, int lane) {
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             uint32_t v = pk[s * 64 + lane];
             pk[s * 64 + lane] = 0;
-            bcf[s] += v & 0xffu; bc[s] += (v >> 8) & 0xffu; bq[s] += v >> 16;
+            bcf[s] += v & 63u; bc[s] += (v >> 6) & 63u; dup[s] += (v >> 12) & 63u; bq[s] += v >> 18;
         }
         npk = 0;
     }
-    __device__ __forceinline__ void flush_cc() {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) { cc[s] += (cclo >> (8 * s)) & 0xffu; cc[4 + s] += (cchi >> (8 * s)) & 0xffu; }
-        cclo = cchi = 0; nruns = 0;
-    }
-    // A barcode run ends: each symbol seen in the run is one more distinct cell
-    // (len(set(CELL_COUNTS[x])), len(set(CELLS)): BaseCellCounter.py:283,292).
-    __device__ __forceinline__ void close_run() {
-        cclo += spread4(mask & 15u); cchi += spread4(mask >> 4); nc += mask != 0; mask = 0;
-        if (++nruns == 255) flush_cc();
-    }
-    // One pileup entry at this lane's position (BaseCellCounter.py:258-279).
-    __device__ __forceinline__ void add(uint32_t ev, bool in_range, uint32_t fwd, int min_bq, uint32_t* pk, int lane) {
+    __device__ __forceinline__ void new_run() { mask = 0; prev_cb = KEY_INVALID; }
+    // One pileup entry at this lane's position (BaseCellCounter.py:258-279); key is wave-uniform.
+    __device__ __forceinline__ void add(uint32_t key, uint32_t ev, bool in_range, int min_bq, uint32_t* pk, int lane) {
+        uint32_t cb = key & CB_MASK;
+        if (cb != prev_cb) { mask = 0; prev_cb = cb; }
         uint32_t q = ev & 0xffu, sym = ev >> 8;
+        nev += in_range;
         if (in_range && sym < 8 && (int)q >= min_bq) {
-            atomicAdd(&pk[sym * 64 + lane], (q << 16) | 0x100u | fwd);   // ds_add_u32, lane-private word
+            uint32_t seen = (mask >> sym) & 1u;
+            ncdup += mask != 0;
+            uint32_t fwd = ((key >> 24) & 1u) ^ 1u;
+            atomicAdd(&pk[sym * 64 + lane], (q << 18) | (seen << 12) | 64u | fwd);   // ds_add_u32, lane-private word
             mask |= 1u << sym;
         }
-        if (++npk == 255) flush_pk(pk, lane);
+        if (++npk == FLUSH_EVERY) flush_pk(pk, lane);
     }
-    __device__ __forceinline__ void finish(uint32_t* pk, int lane) { close_run(); flush_cc(); flush_pk(pk, lane); }
+    __device__ __forceinline__ void finish(uint32_t* pk, int lane) { flush_pk(pk, lane); }
 };
 
-struct Rec { uint32_t key, ev_lo, meta; };   // meta = ev_hi(8) | lane_lo(6)<<8 | (cnt-1)(6)<<16
-
-__device__ __forceinline__ Rec make_rec(const CountArgs& a, uint2 e, int32_t tstart) {
-    uint32_t s = e.y;
-    int32_t st = a.seg_start[s], ln = a.seg_len[s];
-    int64_t off = a.seg_ev_off[s];
-    int32_t lo = st > tstart ? st : tstart;
-    int32_t hi = st + ln < tstart + TILE_W ? st + ln : tstart + TILE_W;
-    int64_t ev_first = off + (lo - st);
-    Rec r;
-    r.key = e.x;
-    r.ev_lo = (uint32_t)ev_first;
-    r.meta = (uint32_t)((ev_first >> 32) & 0xff) | ((uint32_t)(lo - tstart) << 8) | ((uint32_t)(hi - lo - 1) << 16);
-    return r;
-}
-
-// Walk entries order[j0..j1) (grouped by barcode) with all 64 lanes = 64 positions.
-__device__ __forceinline__ void walk(const CountArgs& a, Acc& acc, const uint16_t* order, const uint32_t* rkey,
-                                     const uint32_t* rev, const uint32_t* rmeta, int j0, int j1, uint32_t* pk, int lane) {
+// Walk grouped entries [j0, j1) with all 64 lanes = 64 positions.  Records are read 64 at a time
+// into registers (lane l holds record jb+l), then 8 event loads are issued before any is consumed.
+__device__ __forceinline__ void walk(const CountArgs& a, Acc& acc, const uint32_t* gkey, const uint32_t* gev, const uint32_t* gmeta,
+                                     int j0, int j1, uint32_t* pk, int lane) {
     const uint16_t* __restrict__ events = a.events;
+    constexpr int U = 8;
     for (int jb = j0; jb < j1; jb += 64) {
         int nb = j1 - jb < 64 ? j1 - jb : 64;
         uint32_t k = 0, e = 0, m = 0;
-        if (lane < nb) { uint32_t idx = order[jb + lane]; k = rkey[idx]; e = rev[idx]; m = rmeta[idx]; }
-        int l = 0;
-        for (; l + 4 <= nb; l += 4) {
-            uint32_t ks[4], evv[4]; bool inr[4];
+        if (lane < nb) { k = gkey[jb + lane]; e = gev[jb + lane]; m = gmeta[jb + lane]; }
+        for (int l = 0; l < nb; l += U) {
+            uint32_t ks[U], evv[U]; bool inr[U];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                ks[u] = rl(k, l + u);
-                uint32_t es = rl(e, l + u), ms = rl(m, l + u);
-                uint32_t rel = (uint32_t)lane - ((ms >> 8) & 63u);
-                inr[u] = rel <= ((ms >> 16) & 63u);
-                uint64_t addr = (((uint64_t)(ms & 0xffu)) << 32 | es) + rel;
-                evv[u] = inr[u] ? (uint32_t)events[addr] : 0xffffu;
+            for (int u = 0; u < U; ++u) {
+                inr[u] = false; evv[u] = 0xffffu; ks[u] = 0;
+                if (l + u < nb) {
+                    ks[u] = rl(k, l + u);
+                    uint32_t es = rl(e, l + u), ms = rl(m, l + u);
+                    uint32_t rel = (uint32_t)lane - ((ms >> 8) & 63u);
+                    inr[u] = rel <= ((ms >> 16) & 63u);
+                    uint64_t addr = (((uint64_t)(ms & 0xffu)) << 32 | es) + rel;
+                    if (inr[u]) evv[u] = (uint32_t)events[addr];
+                }
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                uint32_t cb = ks[u] & CB_MASK;
-                if (cb != acc.prev_cb) { acc.close_run(); acc.prev_cb = cb; }
-                acc.add(evv[u], inr[u], ((ks[u] >> 24) & 1u) ^ 1u, a.min_bq, pk, lane);
-            }
-        }
-        for (; l < nb; ++l) {
-            uint32_t ks = rl(k, l), es = rl(e, l), ms = rl(m, l);
-            uint32_t rel = (uint32_t)lane - ((ms >> 8) & 63u);
-            bool inr = rel <= ((ms >> 16) & 63u);
-            uint64_t addr = (((uint64_t)(ms & 0xffu)) << 32 | es) + rel;
-            uint32_t evv = inr ? (uint32_t)events[addr] : 0xffffu;
-            uint32_t cb = ks & CB_MASK;
-            if (cb != acc.prev_cb) { acc.close_run(); acc.prev_cb = cb; }
-            acc.add(evv, inr, ((ks >> 24) & 1u) ^ 1u, a.min_bq, pk, lane);
+            for (int u = 0; u < U; ++u)
+                if (l + u < nb) acc.add(ks[u], evv[u], inr[u], a.min_bq, pk, lane);
         }
     }
 }
 
-// Group n staged records by barcode: order[] lists record indices with equal barcodes adjacent.
-// T threads cooperate (T = 64: one wave, fences only; T = DEEP_THREADS: __syncthreads).
-template <bool BLOCK, int H>
-__device__ __forceinline__ void group_by_cb(int n, const uint32_t* rkey, uint32_t* tkey, uint32_t* tcnt, uint16_t* order,
-                                            int t, int T, uint32_t* wave_tot) {
+// Group n entries (global SoA arrays at src) by barcode into the LDS arrays gkey/gev/gmeta:
+// entries with equal barcodes become adjacent.  T threads cooperate (T = 64: one wave, fences
+// only; T = BLOCK_THREADS: __syncthreads).  When `filter` is set only entries whose barcode bucket
+// (cb >> shift) lies in [b_lo, b_hi) are taken (fallback passes).
+template <bool BLOCK, int H, int CAP>
+__device__ __forceinline__ int group_by_cb(const CountArgs& a, uint32_t src, int n, uint32_t* gkey, uint32_t* gev, uint32_t* gmeta,
+                                           uint32_t* tkey, uint32_t* tcnt, int t, uint32_t* wave_tot) {
+    constexpr int T = BLOCK ? BLOCK_THREADS : 64;
+    constexpr int RMAX = (CAP + T - 1) / T;
     for (int i = t; i < H; i += T) { tkey[i] = KEY_INVALID; tcnt[i] = 0; }
     group_sync<BLOCK>();
-    constexpr int RMAX = BLOCK ? (CAPB + DEEP_THREADS - 1) / DEEP_THREADS : (CAPW + 63) / 64;
-    uint32_t hs[RMAX];
+    uint32_t ek[RMAX], ee[RMAX], em[RMAX], hs[RMAX];
 #pragma unroll
     for (int r = 0; r < RMAX; ++r) {
         int i = t + r * T;
-        hs[r] = 0;
-        if (i < n) {
-            uint32_t cb = rkey[i] & CB_MASK;
+        hs[r] = 0; ek[r] = KEY_INVALID; ee[r] = 0; em[r] = 0;
+        if (i < n) { ek[r] = a.ekey[src + i]; ee[r] = a.eev[src + i]; em[r] = a.emeta[src + i]; }
+    }
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) {
+        if (t + r * T < n) {
+            uint32_t cb = ek[r] & CB_MASK;
             uint32_t h = hash_cb(cb) >> (32 - __builtin_ctz(H));
             while (true) {
                 uint32_t prev = atomicCAS(&tkey[h], KEY_INVALID, cb);
@@ -270,7 +357,7 @@ __device__ __forceinline__ void group_by_cb(int n, const uint32_t* rkey, uint32_
     }
     group_sync<BLOCK>();
     // exclusive scan of tcnt over H slots; each thread owns H/T consecutive slots
-    constexpr int PER = BLOCK ? H / DEEP_THREADS : H / 64;
+    constexpr int PER = H / T;
     uint32_t loc[PER]; uint32_t sum = 0;
 #pragma unroll
     for (int q = 0; q < PER; ++q) { loc[q] = tcnt[t * PER + q]; sum += loc[q]; }
@@ -291,57 +378,87 @@ __device__ __forceinline__ void group_by_cb(int n, const uint32_t* rkey, uint32_
     group_sync<BLOCK>();
 #pragma unroll
     for (int r = 0; r < RMAX; ++r) {
-        int i = t + r * T;
-        if (i < n) order[tcnt[hs[r] & 0xffffu] + (hs[r] >> 16)] = (uint16_t)i;
+        if (t + r * T < n) {
+            uint32_t p = tcnt[hs[r] & 0xffffu] + (hs[r] >> 16);
+            gkey[p] = ek[r]; gev[p] = ee[r]; gmeta[p] = em[r];
+        }
     }
     group_sync<BLOCK>();
+    return n;
 }
 
-__device__ __forceinline__ void unit_geometry(const CountArgs& a, uint32_t u, int& ct, int& tid, int32_t& tstart) {
-    uint32_t tile = u / (uint32_t)a.n_ct;
-    ct = (int)(u - tile * (uint32_t)a.n_ct);
-    int lo = 0, hi = a.n_contigs;                 // largest tid with tile_base[tid] <= tile
-    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (a.tile_base[mid] <= tile) lo = mid; else hi = mid; }
-    tid = lo;
-    tstart = (int32_t)((tile - a.tile_base[tid]) << 6);
+// wave-private bookkeeping (LDS): row arenas and exact counters
+struct WaveBook {
+    uint32_t arena_next[LSG_MAX_CELLTYPES], arena_end[LSG_MAX_CELLTYPES], rows_true[LSG_MAX_CELLTYPES];
+    uint32_t cols, rows_deep, pad[2];
+};
+__device__ __forceinline__ void book_init(WaveBook& b, int lane) {
+    if (lane < LSG_MAX_CELLTYPES) { b.arena_next[lane] = 0; b.arena_end[lane] = 0; b.rows_true[lane] = 0; }
+    if (lane == 0) { b.cols = 0; b.rows_deep = 0; }
+}
+__device__ __forceinline__ void book_flush(const CountArgs& a, WaveBook& b, int lane) {
+    lds_fence();
+    if (lane < a.n_ct && b.rows_true[lane]) atomicAdd(&a.scalars[SC_ROWS + lane], (unsigned long long)b.rows_true[lane]);
+    if (lane == 0 && b.cols) atomicAdd(&a.scalars[SC_COLS], (unsigned long long)b.cols);
+    if (lane == 0 && b.rows_deep) atomicAdd(&a.scalars[SC_ROWS_DEEP], (unsigned long long)b.rows_deep);
 }
 
 // Gates + row emission for one unit by one wave.  Gates: BaseCellCounter.py:211 (ref != N), :282
 // (count >= MIN_COV), :294 (NC >= MIN_CC); position 0 of a contig is never visited (:86).
-__device__ __forceinline__ void emit_unit(const CountArgs& a, const Acc& acc, uint32_t w, int ct, int tid, int32_t tstart, int lane) {
+// bk != nullptr: rows come from the wave's arena; nullptr: one exact global atomic.
+__device__ __forceinline__ void emit_unit(const CountArgs& a, const Acc& acc, uint32_t w, int ct, int tid, int32_t tstart, int lane,
+                                          WaveBook* bk, bool deep) {
     uint32_t dp = 0;
 #pragma unroll
     for (int s = 0; s < 8; ++s) dp += acc.bc[s];
+    const uint32_t nc = dp - acc.ncdup;
     int64_t pos = (int64_t)tstart + lane;
     bool valid = pos >= 1 && pos < a.contig_len[tid];
     uint8_t refb = 'N';
-    const uint8_t* rp = a.ref_ptr[tid];
-    if (valid) refb = rp ? rp[pos] : (uint8_t)'?';
+    if (valid) refb = a.ref_ptr[tid][pos];
     unsigned long long colm = __ballot(valid && dp > 0);
-    bool emit = valid && dp > 0 && (int)dp >= a.min_dp && (int)acc.nc >= a.min_cc && refb != 'N';
+    bool emit = valid && dp > 0 && (int)dp >= a.min_dp && (int)nc >= a.min_cc && refb != 'N';
     unsigned long long em = __ballot(emit);
+    const uint32_t k = (uint32_t)__popcll(em);
     uint32_t base = 0;
     if (lane == 0) {
-        if (colm) atomicAdd(&a.scalars[SC_COLS], (unsigned long long)__popcll(colm));
-        if (em) base = (uint32_t)atomicAdd(&a.scalars[SC_ROWS + ct], (unsigned long long)__popcll(em));
+        if (bk) {
+            bk->cols += (uint32_t)__popcll(colm);
+            if (k) {
+                uint32_t nx = bk->arena_next[ct];
+                if (nx + k > bk->arena_end[ct]) {
+                    nx = (uint32_t)atomicAdd(&a.scalars[SC_ROWALLOC + ct], (unsigned long long)ARENA);
+                    bk->arena_end[ct] = nx + ARENA;
+                }
+                base = nx; bk->arena_next[ct] = nx + k; bk->rows_true[ct] += k;
+                if (deep) bk->rows_deep += k;
+            }
+        } else {
+            if (colm) atomicAdd(&a.scalars[SC_COLS], (unsigned long long)__popcll(colm));
+            if (k) {
+                base = (uint32_t)atomicAdd(&a.scalars[SC_ROWALLOC + ct], (unsigned long long)k);
+                atomicAdd(&a.scalars[SC_ROWS + ct], (unsigned long long)k);
+                if (deep) atomicAdd(&a.scalars[SC_ROWS_DEEP], (unsigned long long)k);
+            }
+        }
         a.ne_mask[w] = em;
         a.ne_rowbase[w] = base;
     }
     base = rl(base, 0);
     if (!em) return;
-    uint64_t row = (uint64_t)base + __popcll(em & ((1ull << lane) - 1ull));
-    if ((uint64_t)base + __popcll(em) > a.row_cap) {
+    if ((uint64_t)base + k > a.row_cap) {
         if (lane == 0) atomicExch(&a.scalars[SC_OVERFLOW], 1ull);
         return;
     }
     if (!emit) return;
+    uint64_t row = (uint64_t)base + __popcll(em & ((1ull << lane) - 1ull));
     uint32_t* out = a.rows[ct];
     const uint64_t cap = a.row_cap;
     out[0 * cap + row] = dp;
-    out[1 * cap + row] = acc.nc;
+    out[1 * cap + row] = nc;
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-        out[(2 + s) * cap + row] = acc.cc[s];
+        out[(2 + s) * cap + row] = acc.bc[s] - acc.dup[s];
         out[(10 + s) * cap + row] = acc.bc[s];
         out[(18 + s) * cap + row] = acc.bq[s];
         out[(26 + s) * cap + row] = acc.bcf[s];
@@ -350,194 +467,295 @@ __device__ __forceinline__ void emit_unit(const CountArgs& a, const Acc& acc, ui
 }
 
 // ------------------------------------------------------------------------------------------------
-// Wave kernel: each wavefront pulls units with <= CAPW entries from a queue.
-constexpr int WAVES_PER_BLOCK = 4;
+// Wave kernel: each wavefront pulls QCHUNK single-slot units with <= CAPW entries at a time.
 struct WaveLds {
-    uint32_t rkey[CAPW], rev[CAPW], rmeta[CAPW];
-    uint32_t tkey[HW], tcnt[HW];
-    uint32_t pk[8 * 64];
-    uint16_t order[CAPW];
+    uint32_t gkey[CAPW], gev[CAPW], gmeta[CAPW];
+    uint32_t tkey[HW], tcnt[HW];          // pk (8*64 words) aliases tkey after grouping
+    WaveBook book;
 };
 
 __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void k_pileup_wave(CountArgs a) {
     __shared__ WaveLds lds_all[WAVES_PER_BLOCK];
     const int lane = threadIdx.x & 63;
     WaveLds& L = lds_all[threadIdx.x >> 6];
-    for (int i = lane; i < 8 * 64; i += 64) L.pk[i] = 0;
-    const uint32_t n_ne = *a.n_ne;
+    uint32_t* pk = L.tkey;
+    static_assert(HW >= 8 * 64, "pk must fit in the hash key array");
+    book_init(L.book, lane);
+    const uint32_t n_small = (uint32_t)a.scalars[SC_NSMALL];
+    unsigned long long nev_total = 0;
     while (true) {
-        uint32_t w = 0;
-        if (lane == 0) w = (uint32_t)atomicAdd(&a.scalars[SC_QHEAD], 1ull);
-        w = rl(w, 0);
-        if (w >= n_ne) break;
-        uint32_t u = a.ne_units[w];
-        int n = (int)a.unit_cnt[u];
-        if (n > CAPW) continue;                      // deep kernel's job
-        uint32_t base = a.unit_off[u];
-        int ct, tid; int32_t tstart;
-        unit_geometry(a, u, ct, tid, tstart);
-        lds_fence();
-        for (int i = lane; i < n; i += 64) {
-            Rec r = make_rec(a, a.entries[base + i], tstart);
-            L.rkey[i] = r.key; L.rev[i] = r.ev_lo; L.rmeta[i] = r.meta;
+        uint32_t q0 = 0;
+        if (lane == 0) q0 = (uint32_t)atomicAdd(&a.scalars[SC_QSMALL], (unsigned long long)QCHUNK);
+        q0 = rl(q0, 0);
+        if (q0 >= n_small) break;
+        const int nq = n_small - q0 < (uint32_t)QCHUNK ? (int)(n_small - q0) : QCHUNK;
+        // lanes 0..nq-1 fetch their slot's descriptor
+        uint32_t s_w = 0, s_off = 0, s_cnt = 0; int2 s_geom = make_int2(0, 0);
+        if (lane < nq) {
+            uint32_t s = a.slot_list[q0 + lane];
+            s_w = a.slot_w[s]; s_off = a.slot_off[s]; s_cnt = a.slot_cnt[s];
+            s_geom = a.ne_geom[s_w];
         }
-        lds_fence();
-        group_by_cb<false, HW>(n, L.rkey, L.tkey, L.tcnt, L.order, lane, 64, nullptr);
-        Acc acc; acc.init();
-        walk(a, acc, L.order, L.rkey, L.rev, L.rmeta, 0, n, L.pk, lane);
-        acc.finish(L.pk, lane);
-        emit_unit(a, acc, w, ct, tid, tstart, lane);
+        for (int qi = 0; qi < nq; ++qi) {
+            const uint32_t w = rl(s_w, qi), src = rl(s_off, qi);
+            const int n = (int)rl(s_cnt, qi);
+            const int32_t tstart = (int32_t)rl((uint32_t)s_geom.x, qi);
+            const uint32_t g = rl((uint32_t)s_geom.y, qi);
+            const int tid = (int)(g & 0xffffffu), ct = (int)(g >> 24);
+            lds_fence();
+            group_by_cb<false, HW, CAPW>(a, src, n, L.gkey, L.gev, L.gmeta, L.tkey, L.tcnt, lane, nullptr);
+            for (int i = lane; i < 8 * 64; i += 64) pk[i] = 0;
+            Acc acc; acc.init();
+            walk(a, acc, L.gkey, L.gev, L.gmeta, 0, n, pk, lane);
+            acc.finish(pk, lane);
+            nev_total += acc.nev;
+            emit_unit(a, acc, w, ct, tid, tstart, lane, &L.book, false);
+        }
     }
+    book_flush(a, L.book, lane);
+    for (int o = 32; o > 0; o >>= 1) nev_total += __shfl_down(nev_total, o);
+    if (lane == 0 && nev_total) atomicAdd(&a.scalars[SC_EV_WAVE], nev_total);
 }
 
 // ------------------------------------------------------------------------------------------------
-// Deep kernel: one workgroup per unit with > CAPW entries.  Barcodes are split into passes of
-// <= CAPB entries by a coarse histogram; each pass is staged, grouped and walked by 4 waves on
-// run-aligned slices.  Counters are additive over disjoint barcode sets.
-struct DeepLds {
-    uint32_t rkey[CAPB], rev[CAPB], rmeta[CAPB];
-    uint32_t tkey[HB], tcnt[HB];
+// Block kernel: one 512-thread workgroup per slot with > CAPW entries or belonging to a multi-slot
+// unit.  Normal case (<= CAPB entries): one staged pass.  Fallback (a skewed barcode range left
+// more than CAPB entries in a slot): passes over coarse barcode buckets; a bucket that alone
+// exceeds CAPB is streamed barcode by barcode by wave 0.
+struct BlockLds {
+    uint32_t gkey[CAPB], gev[CAPB], gmeta[CAPB];
+    union {
+        struct { uint32_t tkey[HB], tcnt[HB]; } h;
+        struct { uint32_t pk[BLOCK_WAVES][8 * 64]; uint32_t acc[NCTR][64]; } w;
+    } u;
     uint32_t hist[NBUCKET];
-    uint32_t pk[DEEP_THREADS / 64][8 * 64];
-    uint32_t acc[NCTR][64];
-    uint32_t ormask[64];
-    uint32_t wave_tot[DEEP_THREADS / 64];
-    uint32_t pass_lo[NBUCKET + 1];     // pass p covers buckets [pass_lo[p], pass_lo[p+1])
-    uint32_t n_pass, scount;
-    uint16_t order[CAPB];
+    uint32_t pass_lo[NBUCKET + 1];
+    uint32_t wave_tot[BLOCK_WAVES];
+    uint32_t n_pass, scount, slot;
+    WaveBook book;
 };
+static_assert(sizeof(uint32_t) * (BLOCK_WAVES * 8 * 64 + NCTR * 64) <= sizeof(uint32_t) * 2 * HB, "pk+acc must fit in the hash arrays");
 
-__global__ __launch_bounds__(DEEP_THREADS) void k_pileup_deep(CountArgs a) {
-    __shared__ DeepLds L;
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    constexpr int NW = DEEP_THREADS / 64;
-    const uint32_t n_deep = (uint32_t)a.scalars[SC_NDEEP];
-    int shift = 0;
-    while (((uint32_t)(a.n_cb - 1) >> shift) >= (uint32_t)NBUCKET) ++shift;
-
-    for (uint32_t d = blockIdx.x; d < n_deep; d += gridDim.x) {
-        uint32_t w = a.deep_list[d];
-        uint32_t u = a.ne_units[w];
-        const int n = (int)a.unit_cnt[u];
-        const uint32_t base = a.unit_off[u];
-        int ct, tid; int32_t tstart;
-        unit_geometry(a, u, ct, tid, tstart);
-
-        __syncthreads();
-        for (int i = t; i < NBUCKET; i += DEEP_THREADS) L.hist[i] = 0;
-        for (int i = t; i < 8 * 64; i += DEEP_THREADS) { for (int q = 0; q < NW; ++q) L.pk[q][i] = 0; }
-        for (int i = t; i < NCTR * 64; i += DEEP_THREADS) (&L.acc[0][0])[i] = 0;
-        __syncthreads();
-        for (int i = t; i < n; i += DEEP_THREADS) atomicAdd(&L.hist[(a.entries[base + i].x & CB_MASK) >> shift], 1u);
-        __syncthreads();
-        if (t == 0) {
-            // greedy grouping of consecutive buckets into passes of <= CAPB entries; a bucket that
-            // alone exceeds CAPB becomes its own pass (handled per barcode value, stream mode).
-            uint32_t np = 0, cur = 0; bool open = false;
-            for (uint32_t b = 0; b < (uint32_t)NBUCKET; ++b) {
-                uint32_t h = L.hist[b];
-                if (h == 0) continue;
-                if (!open || cur + h > (uint32_t)CAPB || h > (uint32_t)CAPB) { L.pass_lo[np++] = b; cur = 0; open = true; }
-                cur += h;
-                if (h > (uint32_t)CAPB) open = false;       // next non-empty bucket starts a new pass
-            }
-            L.pass_lo[np] = NBUCKET;
-            L.n_pass = np;
-        }
-        __syncthreads();
-        const uint32_t n_pass = L.n_pass;
-        Acc acc; acc.init();
-
-        for (uint32_t p = 0; p < n_pass; ++p) {
-            const uint32_t b_lo = L.pass_lo[p];
-            // the pass ends before the next pass's first bucket; buckets between are empty
-            const uint32_t b_hi = L.pass_lo[p + 1];
-            const bool overflow = L.hist[b_lo] > (uint32_t)CAPB;
-            if (!overflow) {
-                __syncthreads();
-                if (t == 0) L.scount = 0;
-                __syncthreads();
-                for (int i = t; i < n; i += DEEP_THREADS) {
-                    uint2 e = a.entries[base + i];
-                    uint32_t b = (e.x & CB_MASK) >> shift;
-                    if (b >= b_lo && b < b_hi) {
-                        uint32_t slot = atomicAdd(&L.scount, 1u);
-                        Rec r = make_rec(a, e, tstart);
-                        L.rkey[slot] = r.key; L.rev[slot] = r.ev_lo; L.rmeta[slot] = r.meta;
-                    }
-                }
-                __syncthreads();
-                const int ns = (int)L.scount;
-                group_by_cb<true, HB>(ns, L.rkey, L.tkey, L.tcnt, L.order, t, DEEP_THREADS, L.wave_tot);
-                // run-aligned slice of this wave
-                int j0 = (int)((int64_t)ns * wv / NW), j1 = (int)((int64_t)ns * (wv + 1) / NW);
-                while (j0 > 0 && j0 < ns && (L.rkey[L.order[j0]] & CB_MASK) == (L.rkey[L.order[j0 - 1]] & CB_MASK)) ++j0;
-                while (j1 > 0 && j1 < ns && (L.rkey[L.order[j1]] & CB_MASK) == (L.rkey[L.order[j1 - 1]] & CB_MASK)) ++j1;
-                if (j0 > j1) j0 = j1;
-                acc.close_run(); acc.prev_cb = KEY_INVALID;
-                walk(a, acc, L.order, L.rkey, L.rev, L.rmeta, j0, j1, L.pk[wv], lane);
-                acc.close_run(); acc.prev_cb = KEY_INVALID;
-            } else {
-                // stream mode: one barcode value at a time, no staging; the barcode's symbol masks of
-                // the 4 waves are OR-ed before counting it as one cell.
-                const uint32_t c_lo = b_lo << shift, c_hi = (b_lo + 1) << shift;
-                for (uint32_t c = c_lo; c < c_hi && c < (uint32_t)a.n_cb; ++c) {
-                    __syncthreads();
-                    if (t < 64) L.ormask[t] = 0;
-                    __syncthreads();
-                    acc.close_run(); acc.prev_cb = KEY_INVALID;
-                    uint32_t any = 0;
-                    const int per = (n + NW - 1) / NW;
-                    const int i0 = wv * per, i1 = (i0 + per < n) ? i0 + per : n;
-                    for (int ib = i0; ib < i1; ib += 64) {
-                        uint2 e = make_uint2(KEY_INVALID, 0);
-                        if (ib + lane < i1) e = a.entries[base + ib + lane];
-                        bool match = e.x != KEY_INVALID && (e.x & CB_MASK) == c;
-                        Rec r{0, 0, 0};
-                        if (match) r = make_rec(a, e, tstart);
-                        unsigned long long mm = __ballot(match);
-                        while (mm) {
-                            int l = __ffsll((long long)mm) - 1; mm &= mm - 1;
-                            uint32_t ks = rl(r.key, l), es = rl(r.ev_lo, l), ms = rl(r.meta, l);
-                            uint32_t rel = (uint32_t)lane - ((ms >> 8) & 63u);
-                            bool inr = rel <= ((ms >> 16) & 63u);
-                            uint64_t addr = (((uint64_t)(ms & 0xffu)) << 32 | es) + rel;
-                            uint32_t evv = inr ? (uint32_t)a.events[addr] : 0xffffu;
-                            acc.add(evv, inr, ((ks >> 24) & 1u) ^ 1u, a.min_bq, L.pk[wv], lane);
-                            any = 1;
-                        }
-                    }
-                    (void)any;
-                    if (acc.mask) atomicOr(&L.ormask[lane], acc.mask);
-                    acc.mask = 0;
-                    __syncthreads();
-                    if (wv == 0) { acc.mask = L.ormask[lane]; acc.close_run(); }
-                }
-            }
-        }
-        acc.finish(L.pk[wv], lane);
-        // reduce the 4 waves' accumulators
-        __syncthreads();
-        atomicAdd(&L.acc[0][lane], acc.nc);
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            atomicAdd(&L.acc[1 + s][lane], acc.cc[s]);
-            atomicAdd(&L.acc[9 + s][lane], acc.bc[s]);
-            atomicAdd(&L.acc[17 + s][lane], acc.bq[s]);
-            atomicAdd(&L.acc[25 + s][lane], acc.bcf[s]);
-        }
-        __syncthreads();
-        if (wv == 0) {
-            Acc tot; tot.init();
-            tot.nc = L.acc[0][lane];
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                tot.cc[s] = L.acc[1 + s][lane]; tot.bc[s] = L.acc[9 + s][lane];
-                tot.bq[s] = L.acc[17 + s][lane]; tot.bcf[s] = L.acc[25 + s][lane];
-            }
-            emit_unit(a, tot, w, ct, tid, tstart, lane);
+// stage + group the entries of [src, src+n) whose bucket lies in [b_lo, b_hi) (filter) or all of them
+__device__ __forceinline__ int block_stage_filtered(const CountArgs& a, BlockLds& L, uint32_t src, int n, int shift, uint32_t b_lo, uint32_t b_hi, int t) {
+    // compact matching entries into gkey/gev/gmeta (unordered), then regroup in place via a second
+    // buffer-free trick: entries are re-read from LDS into registers by group_by_cb-style code below.
+    __syncthreads();
+    if (t == 0) L.scount = 0;
+    __syncthreads();
+    for (int i = t; i < n; i += BLOCK_THREADS) {
+        uint32_t k = a.ekey[src + i];
+        uint32_t b = (k & CB_MASK) >> shift;
+        if (b >= b_lo && b < b_hi) {
+            uint32_t slot = atomicAdd(&L.scount, 1u);
+            L.gkey[slot] = k; L.gev[slot] = a.eev[src + i]; L.gmeta[slot] = a.emeta[src + i];
         }
     }
+    __syncthreads();
+    const int ns = (int)L.scount;
+    // regroup the staged entries by barcode (registers hold the entries while the hash is built)
+    constexpr int RMAX = CAPB / BLOCK_THREADS;
+    uint32_t ek[RMAX], ee[RMAX], em[RMAX], hs[RMAX];
+    for (int i = t; i < HB; i += BLOCK_THREADS) { L.u.h.tkey[i] = KEY_INVALID; L.u.h.tcnt[i] = 0; }
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) {
+        int i = t + r * BLOCK_THREADS;
+        ek[r] = KEY_INVALID; ee[r] = 0; em[r] = 0; hs[r] = 0;
+        if (i < ns) { ek[r] = L.gkey[i]; ee[r] = L.gev[i]; em[r] = L.gmeta[i]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) {
+        if (t + r * BLOCK_THREADS < ns) {
+            uint32_t cb = ek[r] & CB_MASK;
+            uint32_t h = hash_cb(cb) >> (32 - __builtin_ctz(HB));
+            while (true) {
+                uint32_t prev = atomicCAS(&L.u.h.tkey[h], KEY_INVALID, cb);
+                if (prev == KEY_INVALID || prev == cb) break;
+                h = (h + 1) & (HB - 1);
+            }
+            hs[r] = h | (atomicAdd(&L.u.h.tcnt[h], 1u) << 16);
+        }
+    }
+    __syncthreads();
+    constexpr int PER = HB / BLOCK_THREADS;
+    uint32_t loc[PER]; uint32_t sum = 0;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) { loc[q] = L.u.h.tcnt[t * PER + q]; sum += loc[q]; }
+    uint32_t incl = sum; const int lane = t & 63, wv = t >> 6;
+    for (int o = 1; o < 64; o <<= 1) { uint32_t v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+    uint32_t excl = incl - sum;
+    if (lane == 63) L.wave_tot[wv] = incl;
+    __syncthreads();
+    for (int q = 0; q < wv; ++q) excl += L.wave_tot[q];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) { L.u.h.tcnt[t * PER + q] = excl; excl += loc[q]; }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) {
+        if (t + r * BLOCK_THREADS < ns) {
+            uint32_t p = L.u.h.tcnt[hs[r] & 0xffffu] + (hs[r] >> 16);
+            L.gkey[p] = ek[r]; L.gev[p] = ee[r]; L.gmeta[p] = em[r];
+        }
+    }
+    __syncthreads();
+    return ns;
+}
+
+__device__ __forceinline__ void block_walk_slices(const CountArgs& a, BlockLds& L, Acc& acc, int ns, int wv, int lane) {
+    // run-aligned slice of this wave
+    int j0 = (int)((int64_t)ns * wv / BLOCK_WAVES), j1 = (int)((int64_t)ns * (wv + 1) / BLOCK_WAVES);
+    while (j0 > 0 && j0 < ns && (L.gkey[j0] & CB_MASK) == (L.gkey[j0 - 1] & CB_MASK)) ++j0;
+    while (j1 > 0 && j1 < ns && (L.gkey[j1] & CB_MASK) == (L.gkey[j1 - 1] & CB_MASK)) ++j1;
+    if (j0 > j1) j0 = j1;
+    // the hash arrays are dead now: pk lives there
+    __syncthreads();
+    uint32_t* pk = L.u.w.pk[wv];
+    for (int i = lane; i < 8 * 64; i += 64) pk[i] = 0;
+    acc.new_run();
+    walk(a, acc, L.gkey, L.gev, L.gmeta, j0, j1, pk, lane);
+    acc.finish(pk, lane);
+    acc.new_run();
+}
+
+__global__ __launch_bounds__(BLOCK_THREADS) void k_pileup_block(CountArgs a) {
+    __shared__ BlockLds L;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    if (wv == 0) book_init(L.book, lane);
+    const uint32_t n_small = (uint32_t)a.scalars[SC_NSMALL];
+    const uint32_t n_big = a.n_slots - n_small;
+    int shift = 0;
+    while (((uint32_t)(a.n_cb - 1) >> shift) >= (uint32_t)NBUCKET) ++shift;
+    unsigned long long nev_total = 0;
+
+    while (true) {
+        __syncthreads();
+        if (t == 0) L.slot = (uint32_t)atomicAdd(&a.scalars[SC_QBIG], 1ull);
+        __syncthreads();
+        const uint32_t qi = L.slot;
+        if (qi >= n_big) break;
+        const uint32_t s = a.slot_list[a.n_slots - 1 - qi];      // rejected items sit reversed at the end
+        const uint32_t w = a.slot_w[s], src = a.slot_off[s];
+        const int n = (int)a.slot_cnt[s];
+        const int2 geom = a.ne_geom[w];
+        const int32_t tstart = geom.x; const int tid = geom.y & 0xffffff, ct = (int)((uint32_t)geom.y >> 24);
+        const bool multi = a.ne_nslot[w] > 1;
+        Acc acc; acc.init();
+
+        if (n <= CAPB) {
+            group_by_cb<true, HB, CAPB>(a, src, n, L.gkey, L.gev, L.gmeta, L.u.h.tkey, L.u.h.tcnt, t, L.wave_tot);
+            block_walk_slices(a, L, acc, n, wv, lane);
+        } else {
+            // fallback passes over coarse barcode buckets
+            __syncthreads();
+            for (int i = t; i < NBUCKET; i += BLOCK_THREADS) L.hist[i] = 0;
+            __syncthreads();
+            for (int i = t; i < n; i += BLOCK_THREADS) atomicAdd(&L.hist[(a.ekey[src + i] & CB_MASK) >> shift], 1u);
+            __syncthreads();
+            if (t == 0) {
+                uint32_t np = 0, cur = 0; bool open = false;
+                for (uint32_t b = 0; b < (uint32_t)NBUCKET; ++b) {
+                    uint32_t h = L.hist[b];
+                    if (h == 0) continue;
+                    if (!open || cur + h > (uint32_t)CAPB || h > (uint32_t)CAPB) { L.pass_lo[np++] = b; cur = 0; open = true; }
+                    cur += h;
+                    if (h > (uint32_t)CAPB) open = false;
+                }
+                L.pass_lo[np] = NBUCKET;
+                L.n_pass = np;
+            }
+            __syncthreads();
+            const uint32_t n_pass = L.n_pass;
+            for (uint32_t p = 0; p < n_pass; ++p) {
+                const uint32_t b_lo = L.pass_lo[p], b_hi = L.pass_lo[p + 1];
+                if (L.hist[b_lo] <= (uint32_t)CAPB) {
+                    const int ns = block_stage_filtered(a, L, src, n, shift, b_lo, b_hi, t);
+                    block_walk_slices(a, L, acc, ns, wv, lane);
+                } else {
+                    // stream mode: wave 0 walks the bucket barcode by barcode straight from global memory
+                    __syncthreads();
+                    if (wv == 0) {
+                        uint32_t* pk = L.u.w.pk[0];
+                        for (int i = lane; i < 8 * 64; i += 64) pk[i] = 0;
+                        const uint32_t c_lo = b_lo << shift, c_hi = (b_lo + 1) << shift;
+                        for (uint32_t c = c_lo; c < c_hi && c < (uint32_t)a.n_cb; ++c) {
+                            acc.new_run();
+                            for (int ib = 0; ib < n; ib += 64) {
+                                uint32_t k = KEY_INVALID, e = 0, m = 0;
+                                if (ib + lane < n) { k = a.ekey[src + ib + lane]; }
+                                bool match = k != KEY_INVALID && (k & CB_MASK) == c;
+                                if (match) { e = a.eev[src + ib + lane]; m = a.emeta[src + ib + lane]; }
+                                unsigned long long mm = __ballot(match);
+                                while (mm) {
+                                    int l = __ffsll((long long)mm) - 1; mm &= mm - 1;
+                                    uint32_t ks = rl(k, l), es = rl(e, l), ms = rl(m, l);
+                                    uint32_t rel = (uint32_t)lane - ((ms >> 8) & 63u);
+                                    bool inr = rel <= ((ms >> 16) & 63u);
+                                    uint64_t addr = (((uint64_t)(ms & 0xffu)) << 32 | es) + rel;
+                                    uint32_t evv = inr ? (uint32_t)a.events[addr] : 0xffffu;
+                                    acc.add(ks, evv, inr, a.min_bq, pk, lane);
+                                }
+                            }
+                        }
+                        acc.finish(pk, lane);
+                        acc.new_run();
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+        nev_total += acc.nev;
+        // reduce the waves' accumulators (hash arrays are dead; acc aliases them next to pk)
+        __syncthreads();
+        for (int i = t; i < NCTR * 64; i += BLOCK_THREADS) (&L.u.w.acc[0][0])[i] = 0;
+        __syncthreads();
+        atomicAdd(&L.u.w.acc[0][lane], acc.ncdup);
+#pragma unroll
+        for (int sy = 0; sy < 8; ++sy) {
+            atomicAdd(&L.u.w.acc[1 + sy][lane], acc.dup[sy]);
+            atomicAdd(&L.u.w.acc[9 + sy][lane], acc.bc[sy]);
+            atomicAdd(&L.u.w.acc[17 + sy][lane], acc.bq[sy]);
+            atomicAdd(&L.u.w.acc[25 + sy][lane], acc.bcf[sy]);
+        }
+        __syncthreads();
+        if (multi) {
+            uint32_t* dst = a.macc + (uint64_t)a.ne_acc[w] * (NCTR * 64);
+            for (int i = t; i < NCTR * 64; i += BLOCK_THREADS) {
+                uint32_t v = (&L.u.w.acc[0][0])[i];
+                if (v) atomicAdd(&dst[i], v);
+            }
+        } else if (wv == 0) {
+            Acc tot; tot.init();
+            tot.ncdup = L.u.w.acc[0][lane];
+#pragma unroll
+            for (int sy = 0; sy < 8; ++sy) {
+                tot.dup[sy] = L.u.w.acc[1 + sy][lane]; tot.bc[sy] = L.u.w.acc[9 + sy][lane];
+                tot.bq[sy] = L.u.w.acc[17 + sy][lane]; tot.bcf[sy] = L.u.w.acc[25 + sy][lane];
+            }
+            emit_unit(a, tot, w, ct, tid, tstart, lane, &L.book, true);
+        }
+    }
+    if (wv == 0) book_flush(a, L.book, lane);
+    for (int o = 32; o > 0; o >>= 1) nev_total += __shfl_down(nev_total, o);
+    if (lane == 0 && nev_total) atomicAdd(&a.scalars[SC_EV_DEEP], nev_total);
+}
+
+// multi-slot units: gates + emission from the global accumulators, one wave per unit
+__global__ void k_finalize_multi(CountArgs a) {
+    const int lane = threadIdx.x & 63;
+    uint32_t k = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (k >= a.n_multi) return;
+    uint32_t w = a.multi_list[k];
+    const uint32_t* src = a.macc + (uint64_t)k * (NCTR * 64);
+    Acc tot; tot.init();
+    tot.ncdup = src[lane];
+#pragma unroll
+    for (int sy = 0; sy < 8; ++sy) {
+        tot.dup[sy] = src[(1 + sy) * 64 + lane]; tot.bc[sy] = src[(9 + sy) * 64 + lane];
+        tot.bq[sy] = src[(17 + sy) * 64 + lane]; tot.bcf[sy] = src[(25 + sy) * 64 + lane];
+    }
+    const int2 geom = a.ne_geom[w];
+    emit_unit(a, tot, w, (int)((uint32_t)geom.y >> 24), geom.y & 0xffffff, geom.x, lane, nullptr, true);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -545,12 +763,19 @@ struct NonEmpty {
     const uint32_t* cnt;
     __host__ __device__ bool operator()(const uint32_t& i) const { return cnt[i] != 0; }
 };
+struct SmallSlot {   // slot handled by the wave kernel
+    const uint32_t* slot_cnt; const uint32_t* slot_w; const uint32_t* ne_nslot;
+    __host__ __device__ bool operator()(const uint32_t& s) const { return slot_cnt[s] <= (uint32_t)CAPW && ne_nslot[slot_w[s]] == 1; }
+};
+struct MultiUnit {
+    const uint32_t* ne_nslot;
+    __host__ __device__ bool operator()(const uint32_t& w) const { return ne_nslot[w] > 1; }
+};
 
-static int64_t host_scalar(lsg_ctx* c, int idx) {
-    unsigned long long v = 0;
-    if (hipMemcpyAsync(&v, c->d_scalars.as<unsigned long long>() + idx, 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return -1;
-    if (hipStreamSynchronize(c->stream) != hipSuccess) return -1;
-    return (int64_t)v;
+static int read_scalars(lsg_ctx* c, unsigned long long* sc) {
+    LSG_HIP(hipMemcpyAsync(sc, c->d_scalars.p, SC_COUNT * 8, hipMemcpyDeviceToHost, c->stream));
+    LSG_HIP(hipStreamSynchronize(c->stream));
+    return 0;
 }
 
 static void fill_args(lsg_ctx* c, const lsg_count_params* p, CountArgs& a) {
@@ -562,19 +787,36 @@ static void fill_args(lsg_ctx* c, const lsg_count_params* p, CountArgs& a) {
     a.ref_ptr = c->d_ref_ptrs.as<const uint8_t*>(); a.celltype_of = c->d_celltype_of.as<uint8_t>();
     a.n_contigs = c->n_contigs; a.n_cb = c->n_cb; a.n_ct = c->n_ct;
     a.n_units = c->n_tiles * (uint32_t)c->n_ct;
+    a.tile_lo = c->tile_lo; a.tile_hi = c->tile_hi;
     a.min_bq = p->min_bq; a.min_mq = p->min_mq; a.min_dp = p->min_dp; a.min_cc = p->min_cc;
     a.ignore_orphans = p->ignore_orphans; a.flag_exclude = p->flag_exclude;
     a.read_key = c->d_read_key.as<uint32_t>(); a.unit_cnt = c->d_unit_cnt.as<uint32_t>();
-    a.unit_off = c->d_unit_off.as<uint32_t>(); a.unit_cursor = c->d_unit_fill.as<uint32_t>();
-    a.entries = c->d_entries.as<uint2>();
-    a.ne_units = c->d_ne_units.as<uint32_t>();
-    a.n_ne = reinterpret_cast<const uint32_t*>(c->d_scalars.as<unsigned long long>() + 2);
+    a.unit_slot = c->ws[WS_UNIT_SLOT].as<uint32_t>(); a.unit_nsub = c->ws[WS_UNIT_NSUB].as<uint32_t>();
+    a.ne_units = c->d_ne_units.as<uint32_t>(); a.ne_nslot = c->ws[WS_NE_NSLOT].as<uint32_t>();
+    a.ne_slot_base = c->ws[WS_NE_SLOT_BASE].as<uint32_t>(); a.ne_acc = c->ws[WS_NE_ACC].as<uint32_t>();
+    a.ne_geom = c->ws[WS_NE_GEOM].as<int2>();
     a.ne_mask = c->d_ne_mask.as<uint64_t>(); a.ne_rowbase = c->d_ne_rowbase.as<uint32_t>();
-    a.deep_list = c->d_deep_list.as<uint32_t>();
+    a.slot_w = c->ws[WS_SLOT_W].as<uint32_t>(); a.slot_cnt = c->ws[WS_SLOT_CNT].as<uint32_t>();
+    a.slot_off = c->ws[WS_SLOT_OFF].as<uint32_t>(); a.slot_cursor = c->ws[WS_SLOT_CURSOR].as<uint32_t>();
+    a.ekey = c->ws[WS_EKEY].as<uint32_t>(); a.eev = c->ws[WS_EEV].as<uint32_t>(); a.emeta = c->ws[WS_EMETA].as<uint32_t>();
+    a.slot_list = c->ws[WS_SLOT_LIST].as<uint32_t>(); a.multi_list = c->ws[WS_MULTI_LIST].as<uint32_t>();
+    a.macc = c->ws[WS_MACC].as<uint32_t>();
+    a.n_ne = c->n_ne; a.n_slots = c->n_slots; a.n_multi = c->n_multi;
     a.scalars = c->d_scalars.as<unsigned long long>();
     for (int i = 0; i < LSG_MAX_CELLTYPES; ++i) a.rows[i] = c->d_rows[i].as<uint32_t>();
     a.row_cap = c->row_cap;
 }
+
+static int cub_tmp(lsg_ctx* c, size_t bytes) { return c->d_cub_tmp.reserve(bytes + 256); }
+
+#define SCAN_U32(in, out, n)                                                                              \
+    do {                                                                                                  \
+        size_t tb_ = 0;                                                                                   \
+        LSG_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb_, (in), (out), (int)(n), st));              \
+        if (cub_tmp(c, tb_)) return -1;                                                                   \
+        tb_ = c->d_cub_tmp.cap;                                                                           \
+        LSG_HIP(hipcub::DeviceScan::ExclusiveSum(c->d_cub_tmp.p, tb_, (in), (out), (int)(n), st));       \
+    } while (0)
 
 int run_count(lsg_ctx* c, const lsg_count_params* p) {
     if (c->n_contigs <= 0) { set_error("lsg_pileup_count: no contigs set"); return -2; }
@@ -585,55 +827,95 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
     hipStream_t st = c->stream;
     const uint32_t n_units = c->n_tiles * (uint32_t)c->n_ct;
     const int64_t R = c->rd.n_reads, S = c->rd.n_segs;
+    const uint64_t EU = c->entries_upper;
+    const uint64_t ne_cap = n_units < EU ? n_units : EU;
+    const uint64_t slot_cap = ne_cap + EU / SUBT + 16;
 
-    if (c->d_read_key.reserve((size_t)(R + 1) * 4)) return -1;
-    if (c->d_unit_cnt.reserve(((size_t)n_units + 2) * 4)) return -1;
-    if (c->d_unit_off.reserve(((size_t)n_units + 2) * 4)) return -1;
-    if (c->d_unit_fill.reserve(((size_t)n_units + 2) * 4)) return -1;
-    if (c->d_entries.reserve((size_t)(c->entries_upper + 1) * 8)) return -1;
-    if (c->d_scalars.reserve(SC_COUNT * 8)) return -1;
+    if (c->d_read_key.reserve((size_t)(R + 1) * 4) || c->d_unit_cnt.reserve(((size_t)n_units + 2) * 4) ||
+        c->ws[WS_UNIT_SLOT].reserve(((size_t)n_units + 2) * 4) || c->ws[WS_UNIT_NSUB].reserve(((size_t)n_units + 2) * 4) ||
+        c->d_scalars.reserve(SC_COUNT * 8) || c->d_ne_units.reserve((ne_cap + 2) * 4) || c->d_ne_mask.reserve((ne_cap + 2) * 8) ||
+        c->d_ne_rowbase.reserve((ne_cap + 2) * 4) || c->ws[WS_NE_NSLOT].reserve((ne_cap + 2) * 4) ||
+        c->ws[WS_NE_SLOT_BASE].reserve((ne_cap + 2) * 4) || c->ws[WS_NE_ACC].reserve((ne_cap + 2) * 4) ||
+        c->ws[WS_NE_GEOM].reserve((ne_cap + 2) * 8) || c->ws[WS_SLOT_W].reserve((slot_cap + 2) * 4) ||
+        c->ws[WS_SLOT_CNT].reserve((slot_cap + 2) * 4) || c->ws[WS_SLOT_OFF].reserve((slot_cap + 2) * 4) ||
+        c->ws[WS_SLOT_CURSOR].reserve((slot_cap + 2) * 4) || c->ws[WS_SLOT_LIST].reserve((slot_cap + 2) * 4) ||
+        c->ws[WS_MULTI_LIST].reserve((EU / CAPB + 16) * 4) || c->ws[WS_EKEY].reserve((EU + 1) * 4) ||
+        c->ws[WS_EEV].reserve((EU + 1) * 4) || c->ws[WS_EMETA].reserve((EU + 1) * 4))
+        return -1;
 
     LSG_HIP(hipEventRecord(c->ev[0], st));
     LSG_HIP(hipMemsetAsync(c->d_scalars.p, 0, SC_COUNT * 8, st));
     LSG_HIP(hipMemsetAsync(c->d_unit_cnt.p, 0, ((size_t)n_units + 1) * 4, st));
-
+    c->n_ne = c->n_slots = c->n_multi = 0;
     CountArgs a{};
     fill_args(c, p, a);
+    unsigned seg_grid = (unsigned)((S + 255) / 256);
     if (R > 0) hipLaunchKernelGGL(k_read_key, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, a);
-    if (S > 0) hipLaunchKernelGGL(k_bin_segments<false>, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, st, a);
+    if (S > 0) hipLaunchKernelGGL(k_bin_segments<0>, dim3(seg_grid), dim3(256), 0, st, a);
 
-    // exclusive scan of unit counts (n_units + 1 elements so that off[n_units] = total entries)
-    size_t tmp1 = 0, tmp2 = 0;
-    LSG_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp1, a.unit_cnt, a.unit_off, (int)(n_units + 1), st));
+    // non-empty units, in genomic order
     hipcub::CountingInputIterator<uint32_t> cnt_it(0);
-    NonEmpty pred{a.unit_cnt};
-    // the non-empty list can hold at most min(n_units, entries_upper) units
-    uint64_t ne_cap = n_units < c->entries_upper ? n_units : c->entries_upper;
-    if (c->d_ne_units.reserve((size_t)(ne_cap + 1) * 4)) return -1;
-    if (c->d_ne_mask.reserve((size_t)(ne_cap + 1) * 8)) return -1;
-    if (c->d_ne_rowbase.reserve((size_t)(ne_cap + 1) * 4)) return -1;
-    if (c->d_deep_list.reserve((size_t)(c->entries_upper / (CAPW + 1) + 2) * 4)) return -1;
+    uint32_t* d_nne = reinterpret_cast<uint32_t*>(a.scalars + SC_NNE);
+    {
+        NonEmpty pred{a.unit_cnt};
+        size_t tb = 0;
+        LSG_HIP(hipcub::DeviceSelect::If(nullptr, tb, cnt_it, a.ne_units, d_nne, (int)n_units, pred, st));
+        if (cub_tmp(c, tb)) return -1;
+        tb = c->d_cub_tmp.cap;
+        LSG_HIP(hipcub::DeviceSelect::If(c->d_cub_tmp.p, tb, cnt_it, a.ne_units, d_nne, (int)n_units, pred, st));
+    }
+    unsigned long long sc[SC_COUNT];
+    if (read_scalars(c, sc)) return -1;
+    const uint32_t n_ne = (uint32_t)(sc[SC_NNE] & 0xffffffffull);
+    c->n_ne = n_ne;
     fill_args(c, p, a);
-    uint32_t* d_nsel = reinterpret_cast<uint32_t*>(c->d_scalars.as<unsigned long long>() + 2);
-    LSG_HIP(hipcub::DeviceSelect::If(nullptr, tmp2, cnt_it, a.ne_units, d_nsel, (int)n_units, pred, st));
-    if (c->d_cub_tmp.reserve((tmp1 > tmp2 ? tmp1 : tmp2) + 16)) return -1;
-    size_t tmp = c->d_cub_tmp.cap;
-    LSG_HIP(hipcub::DeviceScan::ExclusiveSum(c->d_cub_tmp.p, tmp, a.unit_cnt, a.unit_off, (int)(n_units + 1), st));
-    tmp = c->d_cub_tmp.cap;
-    LSG_HIP(hipcub::DeviceSelect::If(c->d_cub_tmp.p, tmp, cnt_it, a.ne_units, d_nsel, (int)n_units, pred, st));
-    LSG_HIP(hipMemcpyAsync(c->d_unit_fill.p, c->d_unit_off.p, ((size_t)n_units + 1) * 4, hipMemcpyDeviceToDevice, st));
-    if (S > 0) hipLaunchKernelGGL(k_bin_segments<true>, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, st, a);
 
-    // sizing read-back: number of non-empty units (grid of k_deep_list, row capacity)
-    int64_t n_ne = host_scalar(c, 2) & 0xffffffffll;
-    if (n_ne < 0) { set_error("lsg_pileup_count: scalar read-back failed"); return -1; }
-    c->n_ne = (uint32_t)n_ne;
+    if (n_ne > 0) {
+        // slot plan: deep units are cut into barcode-range slots
+        hipLaunchKernelGGL(k_unit_plan, dim3((n_ne + 1 + 255) / 256), dim3(256), 0, st, a);
+        SCAN_U32(a.ne_nslot, a.ne_slot_base, n_ne + 1);
+        LSG_HIP(hipMemcpyAsync(&c->n_slots, a.ne_slot_base + n_ne, 4, hipMemcpyDeviceToHost, st));
+        if (read_scalars(c, sc)) return -1;
+        c->n_multi = (uint32_t)sc[SC_NMULTI];
+        if (c->n_slots > slot_cap) { set_error("lsg_pileup_count: slot plan exceeds its bound"); return -1; }
+        if (c->ws[WS_MACC].reserve(((size_t)c->n_multi + 1) * NCTR * 64 * 4)) return -1;
+        fill_args(c, p, a);
+        hipLaunchKernelGGL(k_slot_init, dim3((n_ne + 255) / 256), dim3(256), 0, st, a);
+        if (c->n_multi > 0 && S > 0) hipLaunchKernelGGL(k_bin_segments<1>, dim3(seg_grid), dim3(256), 0, st, a);
+        SCAN_U32(a.slot_cnt, a.slot_off, c->n_slots + 1);
+        LSG_HIP(hipMemcpyAsync(a.slot_cursor, a.slot_off, ((size_t)c->n_slots + 1) * 4, hipMemcpyDeviceToDevice, st));
+        if (S > 0) hipLaunchKernelGGL(k_bin_segments<2>, dim3(seg_grid), dim3(256), 0, st, a);
+        // work lists: small slots first, the rest reversed at the end; multi-slot units
+        {
+            SmallSlot pred{a.slot_cnt, a.slot_w, a.ne_nslot};
+            uint32_t* d_nsmall = reinterpret_cast<uint32_t*>(a.scalars + SC_NSMALL);
+            size_t tb = 0;
+            LSG_HIP(hipcub::DevicePartition::If(nullptr, tb, cnt_it, a.slot_list, d_nsmall, (int)c->n_slots, pred, st));
+            if (cub_tmp(c, tb)) return -1;
+            tb = c->d_cub_tmp.cap;
+            LSG_HIP(hipcub::DevicePartition::If(c->d_cub_tmp.p, tb, cnt_it, a.slot_list, d_nsmall, (int)c->n_slots, pred, st));
+        }
+        if (c->n_multi > 0) {
+            MultiUnit pred{a.ne_nslot};
+            uint32_t* d_nm = reinterpret_cast<uint32_t*>(a.scalars + SC_NMULTI_SEL);
+            size_t tb = 0;
+            LSG_HIP(hipcub::DeviceSelect::If(nullptr, tb, cnt_it, a.multi_list, d_nm, (int)n_ne, pred, st));
+            if (cub_tmp(c, tb)) return -1;
+            tb = c->d_cub_tmp.cap;
+            LSG_HIP(hipcub::DeviceSelect::If(c->d_cub_tmp.p, tb, cnt_it, a.multi_list, d_nm, (int)n_ne, pred, st));
+            hipLaunchKernelGGL(k_multi_index, dim3((c->n_multi + 255) / 256), dim3(256), 0, st, a);
+            LSG_HIP(hipMemsetAsync(a.macc, 0, (size_t)c->n_multi * NCTR * 64 * 4, st));
+        }
+    }
+    // row buffers: bound + arena slack
+    const unsigned grid_block = (unsigned)(c->n_cus * 2);
+    const unsigned grid_wave = (unsigned)(c->n_cus * 4);
     uint64_t want_rows = (uint64_t)n_ne * TILE_W;
     if (p->min_dp > 0) {
         uint64_t by_depth = (uint64_t)c->rd.n_events / (uint64_t)p->min_dp + 64;
         if (by_depth < want_rows) want_rows = by_depth;
     }
-    if (want_rows < 64) want_rows = 64;
+    want_rows += (uint64_t)(grid_block + grid_wave * WAVES_PER_BLOCK) * ARENA + 64;
     if (want_rows > c->row_cap) {
         for (int i = 0; i < c->n_ct; ++i)
             if (c->d_rows[i].reserve((size_t)want_rows * LSG_ROW_WORDS * 4)) return -1;
@@ -641,41 +923,40 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
     }
     fill_args(c, p, a);
     LSG_HIP(hipEventRecord(c->ev[1], st));
-
     if (n_ne > 0) {
-        hipLaunchKernelGGL(k_deep_list, dim3((unsigned)((n_ne + 255) / 256)), dim3(256), 0, st, a);
-        hipDeviceProp_t prop;
-        LSG_HIP(hipGetDeviceProperties(&prop, c->device));
-        int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        // deep units first (long-running), then the wave queue fills the machine around them
-        hipLaunchKernelGGL(k_pileup_deep, dim3((unsigned)(cus * 2)), dim3(DEEP_THREADS), 0, st, a);
-        uint64_t wave_blocks = ((uint64_t)n_ne + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
-        uint64_t max_blocks = (uint64_t)cus * 8;
-        hipLaunchKernelGGL(k_pileup_wave, dim3((unsigned)(wave_blocks < max_blocks ? wave_blocks : max_blocks)),
-                           dim3(WAVES_PER_BLOCK * 64), 0, st, a);
+        hipLaunchKernelGGL(k_pileup_block, dim3(grid_block), dim3(BLOCK_THREADS), 0, st, a);
+        if (c->n_multi > 0)
+            hipLaunchKernelGGL(k_finalize_multi, dim3((unsigned)(((uint64_t)c->n_multi * 64 + 255) / 256)), dim3(256), 0, st, a);
     }
     LSG_HIP(hipEventRecord(c->ev[2], st));
+    if (n_ne > 0) hipLaunchKernelGGL(k_pileup_wave, dim3(grid_wave), dim3(WAVES_PER_BLOCK * 64), 0, st, a);
+    LSG_HIP(hipEventRecord(c->ev[3], st));
     LSG_HIP(hipGetLastError());
 
-    unsigned long long sc[SC_COUNT];
-    LSG_HIP(hipMemcpyAsync(sc, c->d_scalars.p, sizeof(sc), hipMemcpyDeviceToHost, st));
-    LSG_HIP(hipStreamSynchronize(st));
+    if (read_scalars(c, sc)) return -1;
     if (sc[SC_OVERFLOW]) { set_error("lsg_pileup_count: row buffer overflow (cap %llu)", (unsigned long long)c->row_cap); return -3; }
     for (int i = 0; i < LSG_MAX_CELLTYPES; ++i) c->n_rows[i] = (int64_t)sc[SC_ROWS + i];
     c->n_columns = (int64_t)sc[SC_COLS];
-    c->n_deep = (uint32_t)sc[SC_NDEEP];
     c->stats.n_reads_admitted = (int64_t)sc[SC_READS];
     c->stats.n_segs_admitted = (int64_t)sc[SC_SEGS];
     c->stats.n_events_admitted = (int64_t)sc[SC_EVENTS];
     c->stats.n_units = n_ne;
-    c->stats.n_deep_units = c->n_deep;
-    uint32_t total_entries = 0;
-    LSG_HIP(hipMemcpy(&total_entries, c->d_unit_off.as<uint32_t>() + n_units, 4, hipMemcpyDeviceToHost));
-    c->stats.n_entries = total_entries;
+    c->stats.n_deep_units = (int64_t)c->n_slots - (int64_t)(sc[SC_NSMALL] & 0xffffffffull);
+    c->stats.n_entries = 0;
+    if (n_ne > 0) {
+        uint32_t total_entries = 0;
+        LSG_HIP(hipMemcpy(&total_entries, c->ws[WS_SLOT_OFF].as<uint32_t>() + c->n_slots, 4, hipMemcpyDeviceToHost));
+        c->stats.n_entries = total_entries;
+    }
     float ms = 0;
     LSG_HIP(hipEventElapsedTime(&ms, c->ev[0], c->ev[1])); c->stats.ms_bin = ms;
-    LSG_HIP(hipEventElapsedTime(&ms, c->ev[1], c->ev[2])); c->stats.ms_pileup = ms;
-    LSG_HIP(hipEventElapsedTime(&ms, c->ev[0], c->ev[2])); c->stats.ms_total = ms;
+    LSG_HIP(hipEventElapsedTime(&ms, c->ev[1], c->ev[2])); c->stats.ms_deep = ms;
+    LSG_HIP(hipEventElapsedTime(&ms, c->ev[2], c->ev[3])); c->stats.ms_wave = ms;
+    LSG_HIP(hipEventElapsedTime(&ms, c->ev[0], c->ev[3])); c->stats.ms_total = ms;
+    c->stats.n_events_wave = (int64_t)sc[SC_EV_WAVE]; c->stats.n_events_deep = (int64_t)sc[SC_EV_DEEP];
+    c->stats.n_rows_deep = (int64_t)sc[SC_ROWS_DEEP];
+    c->stats.n_rows_wave = -c->stats.n_rows_deep;
+    for (int i = 0; i < LSG_MAX_CELLTYPES; ++i) c->stats.n_rows_wave += c->n_rows[i];
     c->last_params = *p;
     c->counted = true;
     c->called = false;
@@ -694,17 +975,16 @@ __global__ void k_unit_rowcount(const uint32_t* ne_units, const uint64_t* ne_mas
 
 __global__ void k_export_rows(CountArgs a, int ct, const uint32_t* rowoff, int64_t* keys, uint8_t* refs, uint32_t* counts) {
     const int lane = threadIdx.x & 63;
-    uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (w >= *a.n_ne) return;
-    uint32_t u = a.ne_units[w];
-    int uct, tid; int32_t tstart;
-    unit_geometry(a, u, uct, tid, tstart);
-    if (uct != ct) return;
+    uint32_t w = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (w >= a.n_ne) return;
+    const int2 geom = a.ne_geom[w];
+    if ((int)((uint32_t)geom.y >> 24) != ct) return;
+    const int tid = geom.y & 0xffffff;
     uint64_t em = a.ne_mask[w];
     if (!((em >> lane) & 1ull)) return;
     uint64_t src = (uint64_t)a.ne_rowbase[w] + __popcll(em & ((1ull << lane) - 1ull));
     uint64_t dst = (uint64_t)rowoff[w] + __popcll(em & ((1ull << lane) - 1ull));
-    int64_t pos = (int64_t)tstart + lane;
+    int64_t pos = (int64_t)geom.x + lane;
     keys[dst] = ((int64_t)tid << 32) | pos;
     refs[dst] = a.ref_ptr[tid][pos];
     for (int k = 0; k < LSG_ROW_WORDS; ++k) counts[dst * LSG_ROW_WORDS + k] = a.rows[ct][(uint64_t)k * a.row_cap + src];
@@ -724,26 +1004,17 @@ int run_fetch_counts(lsg_ctx* c, int ct, int64_t* keys, uint8_t* ref, uint32_t* 
     uint32_t* cnt = c->d_ne_rowoff.as<uint32_t>();
     uint32_t* off = cnt + (n_ne + 2);
     hipLaunchKernelGGL(k_unit_rowcount, dim3((n_ne + 256) / 256), dim3(256), 0, st, a.ne_units, a.ne_mask, n_ne, c->n_ct, ct, cnt);
-    size_t tmp = 0;
-    LSG_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, cnt, off, (int)(n_ne + 1), st));
-    if (c->d_cub_tmp.reserve(tmp + 16)) return -1;
-    tmp = c->d_cub_tmp.cap;
-    LSG_HIP(hipcub::DeviceScan::ExclusiveSum(c->d_cub_tmp.p, tmp, cnt, off, (int)(n_ne + 1), st));
-    DevBuf dk, dr, dc;
-    if (dk.reserve((size_t)n * 8) || dr.reserve((size_t)n) || dc.reserve((size_t)n * LSG_ROW_WORDS * 4)) { dk.release(); dr.release(); dc.release(); return -1; }
+    SCAN_U32(cnt, off, n_ne + 1);
+    DevBuf &dk = c->ws[WS_EXPORT_K], &dr = c->ws[WS_EXPORT_R], &dc = c->ws[WS_EXPORT_C];
+    if (dk.reserve((size_t)n * 8) || dr.reserve((size_t)n) || dc.reserve((size_t)n * LSG_ROW_WORDS * 4)) return -1;
     uint64_t threads = (uint64_t)n_ne * 64;
     hipLaunchKernelGGL(k_export_rows, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, a, ct, off,
                        dk.as<int64_t>(), dr.as<uint8_t>(), dc.as<uint32_t>());
-    int rc = 0;
-    if (hipMemcpyAsync(keys, dk.p, (size_t)n * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
-        hipMemcpyAsync(ref, dr.p, (size_t)n, hipMemcpyDeviceToHost, st) != hipSuccess ||
-        hipMemcpyAsync(counts, dc.p, (size_t)n * LSG_ROW_WORDS * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
-        hipStreamSynchronize(st) != hipSuccess) {
-        set_error("lsg_fetch_counts: copy failed: %s", hipGetErrorString(hipGetLastError()));
-        rc = -1;
-    }
-    dk.release(); dr.release(); dc.release();
-    return rc;
+    LSG_HIP(hipMemcpyAsync(keys, dk.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+    LSG_HIP(hipMemcpyAsync(ref, dr.p, (size_t)n, hipMemcpyDeviceToHost, st));
+    LSG_HIP(hipMemcpyAsync(counts, dc.p, (size_t)n * LSG_ROW_WORDS * 4, hipMemcpyDeviceToHost, st));
+    LSG_HIP(hipStreamSynchronize(st));
+    return 0;
 }
 
 // Upper bound of tile entries (sum over segments of tiles overlapped), computed once at load time.
@@ -765,9 +1036,10 @@ int compute_entries_upper(lsg_ctx* c) {
     if (S > 0)
         hipLaunchKernelGGL(k_entries_upper, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, c->stream, c->rd.seg_start,
                            c->rd.seg_len, S, c->d_scalars.as<unsigned long long>());
-    int64_t v = host_scalar(c, 0);
-    if (v < 0) { set_error("lsg_load_reads: entries bound read-back failed"); return -1; }
-    if ((uint64_t)v >= 0xFFFFFFF0ull) { set_error("lsg_load_reads: %lld tile entries exceed the 32-bit entry index; load the reads in windows", (long long)v); return -2; }
+    unsigned long long v = 0;
+    LSG_HIP(hipMemcpyAsync(&v, c->d_scalars.p, 8, hipMemcpyDeviceToHost, c->stream));
+    LSG_HIP(hipStreamSynchronize(c->stream));
+    if (v >= 0xFFFFFFF0ull) { set_error("lsg_load_reads: %llu tile entries exceed the 32-bit entry index; load the reads in windows", v); return -2; }
     c->entries_upper = (uint64_t)v;
     return 0;
 }

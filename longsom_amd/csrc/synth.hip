@@ -1,0 +1,178 @@
+// Device-side generator of the synthetic workload (synth_model.h) straight into HBM, so that the
+// bench's 10M-read / 1.2e10-event configuration never crosses PCIe.  Not on the timed path.
+#include "lsg_ctx.h"
+#include "synth_model.h"
+#include <hipcub/hipcub.hpp>
+
+namespace lsg {
+int compute_entries_upper(lsg_ctx* c);
+
+__global__ void k_synth_header(lsg_synth_model m, int32_t* read_tid, int32_t* read_pos, uint16_t* read_flag, uint8_t* read_mapq,
+                               int32_t* read_cb, int64_t* ev_cnt, uint32_t* seg_cnt) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > m.n_reads) return;
+    if (i == m.n_reads) { ev_cnt[i] = 0; seg_cnt[i] = 0; return; }
+    sm_read r;
+    sm_read_header(&m, i + m.read_base, &r);
+    read_tid[i] = r.tid;
+    read_pos[i] = m.exon_start[r.e0] + (r.t_off - m.exon_cum[r.e0]);
+    read_flag[i] = r.flag;
+    read_mapq[i] = r.mapq;
+    read_cb[i] = r.cb >= 0 ? r.cb : -1;
+    ev_cnt[i] = r.t_len;
+    seg_cnt[i] = (uint32_t)(r.e1 - r.e0 + 1);
+}
+
+// one workgroup per read: threads stride over the read's transcript coordinates
+__global__ __launch_bounds__(256) void k_synth_fill(lsg_synth_model m, const int64_t* ev_off, const uint32_t* seg_off,
+                                                    uint32_t* seg_read, int32_t* seg_start, int32_t* seg_len, int64_t* seg_ev_off,
+                                                    uint16_t* events) {
+    for (int64_t i = blockIdx.x; i < m.n_reads; i += gridDim.x) {
+        sm_read r;
+        const int64_t ig = i + m.read_base;
+        sm_read_header(&m, ig, &r);
+        const int64_t eo = ev_off[i];
+        const uint32_t so = seg_off[i];
+        const int32_t end = r.t_off + r.t_len;
+        if ((int)threadIdx.x <= r.e1 - r.e0) {
+            const int32_t x = r.e0 + (int)threadIdx.x;
+            const int32_t xt0 = m.exon_cum[x], xt1 = xt0 + m.exon_len[x];
+            const int32_t lo = r.t_off > xt0 ? r.t_off : xt0, hi = end < xt1 ? end : xt1;
+            seg_read[so + threadIdx.x] = (uint32_t)i;
+            seg_start[so + threadIdx.x] = m.exon_start[x] + (lo - xt0);
+            seg_len[so + threadIdx.x] = hi - lo;
+            seg_ev_off[so + threadIdx.x] = eo + (lo - r.t_off);
+        }
+        int32_t x = r.e0;
+        for (int32_t j = r.t_off + (int)threadIdx.x; j < end; j += (int)blockDim.x) {
+            while (m.exon_cum[x] + m.exon_len[x] <= j) ++x;
+            const int32_t xt0 = m.exon_cum[x];
+            events[eo + (j - r.t_off)] = sm_event(&m, ig, &r, j, xt0, xt0 + m.exon_len[x], m.exon_start[x]);
+        }
+    }
+}
+
+__global__ void k_synth_ref(uint64_t seed, int32_t tid, int64_t len, uint8_t* out) {
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < len) out[p] = sm_ref_base(seed, tid, p);
+}
+
+template <class T> static int up(lsg_ctx* c, DevBuf& b, const T* src, size_t n) {
+    if (b.reserve(n * sizeof(T) + 16)) return -1;
+    LSG_HIP(hipMemcpyAsync(b.p, src, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
+} // namespace lsg
+
+using namespace lsg;
+
+extern "C" {
+
+int lsg_synth_reference(lsg_ctx* c, uint64_t seed) {
+    if (!c || c->n_contigs <= 0) { set_error("lsg_synth_reference: set contigs first"); return -2; }
+    LSG_HIP(hipSetDevice(c->device));
+    for (int t = 0; t < c->n_contigs; ++t) {
+        int64_t len = c->contig_len[t];
+        if (c->ref[t].reserve((size_t)(len > 0 ? len : 1))) return -1;
+        if (len > 0)
+            hipLaunchKernelGGL(k_synth_ref, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, c->stream, seed, t, len, c->ref[t].as<uint8_t>());
+        c->ref_ptr[t] = c->ref[t].as<uint8_t>();
+    }
+    LSG_HIP(hipMemcpyAsync(c->d_ref_ptrs.p, c->ref_ptr.data(), (size_t)c->n_contigs * sizeof(void*), hipMemcpyHostToDevice, c->stream));
+    LSG_HIP(hipStreamSynchronize(c->stream));
+    c->counted = c->called = false;
+    return 0;
+}
+
+// model: host pointers (gene tables are copied); celltype_of is taken from lsg_set_barcodes.
+int lsg_synth_reads(lsg_ctx* c, const lsg_synth_model* hm) {
+    if (!c || !hm) { set_error("lsg_synth_reads: bad arguments"); return -2; }
+    if (c->n_cb <= 0 || hm->n_cb != c->n_cb) { set_error("lsg_synth_reads: set barcodes first (n_cb %d vs %d)", hm->n_cb, c->n_cb); return -2; }
+    if (hm->n_genes <= 0 || hm->n_reads < 0) { set_error("lsg_synth_reads: empty model"); return -2; }
+    LSG_HIP(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const int G = hm->n_genes;
+    const int X = hm->gene_exon_off[G];
+    const int64_t R = hm->n_reads;
+    DevBuf &g_tid = c->syn[0], &g_xoff = c->syn[1], &x_start = c->syn[2], &x_len = c->syn[3], &x_cum = c->syn[4], &g_roff = c->syn[5],
+           &evcnt = c->syn[6], &segcnt = c->syn[7], &evoff = c->syn[8], &segoff = c->syn[9], &tmpb = c->syn[10];
+    if (up(c, g_tid, hm->gene_tid, G) || up(c, g_xoff, hm->gene_exon_off, G + 1) || up(c, x_start, hm->exon_start, X) ||
+        up(c, x_len, hm->exon_len, X) || up(c, x_cum, hm->exon_cum, X) || up(c, g_roff, hm->gene_read_off, G + 1)) return -1;
+    lsg_synth_model m = *hm;
+    m.gene_tid = g_tid.as<int32_t>(); m.gene_exon_off = g_xoff.as<int32_t>(); m.exon_start = x_start.as<int32_t>();
+    m.exon_len = x_len.as<int32_t>(); m.exon_cum = x_cum.as<int32_t>(); m.gene_read_off = g_roff.as<int64_t>();
+    m.celltype_of = c->d_celltype_of.as<uint8_t>();
+
+    if (c->b_read_tid.reserve((R + 1) * 4) || c->b_read_pos.reserve((R + 1) * 4) || c->b_read_flag.reserve((R + 1) * 2) ||
+        c->b_read_mapq.reserve(R + 1) || c->b_read_cb.reserve((R + 1) * 4) || evcnt.reserve((R + 1) * 8) || segcnt.reserve((R + 1) * 4) ||
+        evoff.reserve((R + 1) * 8) || segoff.reserve((R + 1) * 4)) return -1;
+    hipLaunchKernelGGL(k_synth_header, dim3((unsigned)((R + 1 + 255) / 256)), dim3(256), 0, st, m, c->b_read_tid.as<int32_t>(),
+                       c->b_read_pos.as<int32_t>(), c->b_read_flag.as<uint16_t>(), c->b_read_mapq.as<uint8_t>(), c->b_read_cb.as<int32_t>(),
+                       evcnt.as<int64_t>(), segcnt.as<uint32_t>());
+    size_t t1 = 0, t2 = 0;
+    LSG_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, t1, evcnt.as<int64_t>(), evoff.as<int64_t>(), (int)(R + 1), st));
+    LSG_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, t2, segcnt.as<uint32_t>(), segoff.as<uint32_t>(), (int)(R + 1), st));
+    if (tmpb.reserve((t1 > t2 ? t1 : t2) + 16)) return -1;
+    size_t t = tmpb.cap;
+    LSG_HIP(hipcub::DeviceScan::ExclusiveSum(tmpb.p, t, evcnt.as<int64_t>(), evoff.as<int64_t>(), (int)(R + 1), st));
+    t = tmpb.cap;
+    LSG_HIP(hipcub::DeviceScan::ExclusiveSum(tmpb.p, t, segcnt.as<uint32_t>(), segoff.as<uint32_t>(), (int)(R + 1), st));
+    int64_t E = 0; uint32_t S = 0;
+    LSG_HIP(hipMemcpyAsync(&E, evoff.as<int64_t>() + R, 8, hipMemcpyDeviceToHost, st));
+    LSG_HIP(hipMemcpyAsync(&S, segoff.as<uint32_t>() + R, 4, hipMemcpyDeviceToHost, st));
+    LSG_HIP(hipStreamSynchronize(st));
+    if (c->b_seg_read.reserve(((size_t)S + 1) * 4) || c->b_seg_start.reserve(((size_t)S + 1) * 4) || c->b_seg_len.reserve(((size_t)S + 1) * 4) ||
+        c->b_seg_ev_off.reserve(((size_t)S + 1) * 8) || c->b_events.reserve(((size_t)E + 1) * 2)) return -1;
+    if (R > 0) {
+        unsigned grid = (unsigned)(R < 65536 * 16 ? R : 65536 * 16);
+        hipLaunchKernelGGL(k_synth_fill, dim3(grid), dim3(256), 0, st, m, evoff.as<int64_t>(), segoff.as<uint32_t>(),
+                           c->b_seg_read.as<uint32_t>(), c->b_seg_start.as<int32_t>(), c->b_seg_len.as<int32_t>(),
+                           c->b_seg_ev_off.as<int64_t>(), c->b_events.as<uint16_t>());
+    }
+    LSG_HIP(hipGetLastError());
+    LSG_HIP(hipStreamSynchronize(st));
+    c->rd = lsg_reads{};
+    c->rd.n_reads = R; c->rd.n_segs = S; c->rd.n_events = E; c->rd.on_device = 1;
+    c->rd.read_tid = c->b_read_tid.as<int32_t>(); c->rd.read_pos = c->b_read_pos.as<int32_t>();
+    c->rd.read_flag = c->b_read_flag.as<uint16_t>(); c->rd.read_mapq = c->b_read_mapq.as<uint8_t>();
+    c->rd.read_cb = c->b_read_cb.as<int32_t>(); c->rd.seg_read = c->b_seg_read.as<uint32_t>();
+    c->rd.seg_start = c->b_seg_start.as<int32_t>(); c->rd.seg_len = c->b_seg_len.as<int32_t>();
+    c->rd.seg_ev_off = c->b_seg_ev_off.as<int64_t>(); c->rd.events = c->b_events.as<uint16_t>();
+    c->counted = c->called = false;
+    return compute_entries_upper(c);
+}
+
+int lsg_get_reads_shape(lsg_ctx* c, int64_t* n_reads, int64_t* n_segs, int64_t* n_events) {
+    if (!c) { set_error("lsg_get_reads_shape: NULL handle"); return -2; }
+    if (n_reads) *n_reads = c->rd.n_reads;
+    if (n_segs) *n_segs = c->rd.n_segs;
+    if (n_events) *n_events = c->rd.n_events;
+    return 0;
+}
+
+// Copies the resident read-record arrays into caller-allocated host arrays (tests / sampling for the CPU baseline).
+int lsg_copy_reads_to_host(lsg_ctx* c, const lsg_reads* out) {
+    if (!c || !out) { set_error("lsg_copy_reads_to_host: bad arguments"); return -2; }
+    if (out->n_reads != c->rd.n_reads || out->n_segs != c->rd.n_segs || out->n_events != c->rd.n_events) {
+        set_error("lsg_copy_reads_to_host: shape mismatch"); return -2;
+    }
+    LSG_HIP(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const int64_t R = c->rd.n_reads, S = c->rd.n_segs, E = c->rd.n_events;
+#define CP(field, n, sz) if ((n) > 0) LSG_HIP(hipMemcpyAsync((void*)out->field, c->rd.field, (size_t)(n) * (sz), hipMemcpyDeviceToHost, st))
+    CP(read_tid, R, 4); if (out->read_pos && c->rd.read_pos) CP(read_pos, R, 4);
+    CP(read_flag, R, 2); CP(read_mapq, R, 1); CP(read_cb, R, 4);
+    CP(seg_read, S, 4); CP(seg_start, S, 4); CP(seg_len, S, 4); CP(seg_ev_off, S, 8); CP(events, E, 2);
+#undef CP
+    LSG_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+int lsg_copy_reference_to_host(lsg_ctx* c, int32_t tid, uint8_t* out) {
+    if (!c || !out || tid < 0 || tid >= c->n_contigs || !c->ref_ptr[tid]) { set_error("lsg_copy_reference_to_host: bad arguments"); return -2; }
+    LSG_HIP(hipSetDevice(c->device));
+    if (c->contig_len[tid] > 0) LSG_HIP(hipMemcpy(out, c->ref_ptr[tid], (size_t)c->contig_len[tid], hipMemcpyDeviceToHost));
+    return 0;
+}
+
+} // extern "C"

@@ -139,6 +139,39 @@ class Engine:
         r = Reads(n_reads, n_segs, n_events, *[C.c_void_p(int(ptrs[n])) for n, _ in ReadRecords._SPEC], 1)
         _lib.check(self._lib.lsg_load_reads(self._h, C.byref(r)), "lsg_load_reads")
 
+    def set_region(self, tid_lo=0, pos_lo=0, tid_hi=None, pos_hi=0):
+        """Count only columns in [(tid_lo,pos_lo), (tid_hi,pos_hi)) — window sharding across GPUs."""
+        tid_hi = self.n_contigs if tid_hi is None else tid_hi
+        _lib.check(self._lib.lsg_set_region(self._h, int(tid_lo), int(pos_lo), int(tid_hi), int(pos_hi)), "lsg_set_region")
+
+    # ---- synthetic workload (bench / tests) -------------------------------------------------------
+    def synth_reference(self, seed: int):
+        _lib.check(self._lib.lsg_synth_reference(self._h, C.c_uint64(seed)), "lsg_synth_reference")
+
+    def synth_reads(self, model):
+        """model: longsom_amd.synth.SynthModel; generates its read-record arrays in HBM and loads them."""
+        mc = model.as_c()
+        _lib.check(self._lib.lsg_synth_reads(self._h, C.byref(mc)), "lsg_synth_reads")
+
+    def reads_shape(self):
+        a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        _lib.check(self._lib.lsg_get_reads_shape(self._h, C.byref(a), C.byref(b), C.byref(c)), "lsg_get_reads_shape")
+        return int(a.value), int(b.value), int(c.value)
+
+    def reads_to_host(self) -> ReadRecords:
+        """Copy the resident read-record arrays back to the host (tests, CPU-baseline sampling)."""
+        R, S, E = self.reads_shape()
+        arrs = {n: np.zeros({"read": R, "seg_": S, "even": E}[n[:4]], dt) for n, dt in ReadRecords._SPEC}
+        r = Reads(R, S, E, *[_ptr(arrs[n]) for n, _ in ReadRecords._SPEC], 0)
+        _lib.check(self._lib.lsg_copy_reads_to_host(self._h, C.byref(r)), "lsg_copy_reads_to_host")
+        return ReadRecords(**arrs)
+
+    def reference_to_host(self, tid: int) -> np.ndarray:
+        out = np.zeros(int(self.contig_len[tid]), np.uint8)
+        if out.size:
+            _lib.check(self._lib.lsg_copy_reference_to_host(self._h, int(tid), _ptr(out)), "lsg_copy_reference_to_host")
+        return out
+
     # ---- hot path ----------------------------------------------------------------------------
     def pileup_count(self, params: Optional[CountParams] = None):
         """Returns (rows per cell type, pileup columns with >= 1 counted entry summed over cell types)."""

@@ -1,0 +1,72 @@
+"""Device-generated workload (synth.hip): counts on the GPU == events-level oracle on the copied-back arrays."""
+import numpy as np
+import pytest
+
+from longsom_amd import synth
+from longsom_amd._lib import CountParams
+
+pytestmark = pytest.mark.gpu
+
+
+def setup_model(engine, model):
+    engine.set_contigs(model.contig_len)
+    engine.synth_reference(model.seed)
+    engine.set_barcodes(model.celltype_of, 2)
+    engine.synth_reads(model)
+
+
+def compare_with_oracle(engine, model, params=None):
+    from oracle import loader
+    params = params or CountParams.longsom_defaults()
+    rec = engine.reads_to_host()
+    refs = [engine.reference_to_host(t) for t in range(len(model.contig_len))]
+    n_rows, n_cols = engine.pileup_count(params)
+    tot = 0
+    for ct in range(2):
+        k, rf, c = engine.fetch_counts(ct)
+        ok, orf, oc, ocols = loader.count(rec, model.contig_len, refs, model.celltype_of, ct, params.min_bq, params.min_mq,
+                                          params.min_dp, params.min_cc, params.flag_exclude, params.ignore_orphans)
+        tot += ocols
+        np.testing.assert_array_equal(k, ok)
+        np.testing.assert_array_equal(rf, orf)
+        np.testing.assert_array_equal(c, oc)
+    assert tot == n_cols
+    return n_rows, n_cols, rec
+
+
+def test_c1_device_generated(engine):
+    model = synth.named("C1")
+    setup_model(engine, model)
+    rows, cols, rec = compare_with_oracle(engine, model)
+    assert rec.n_reads == 50_000 and sum(rows) > 1000
+    st = engine.count_stats()
+    assert st.n_events_wave + st.n_events_deep == st.n_events_admitted
+
+
+def test_c2_small_with_chrM_deep(engine):
+    """C2's genome and expression profile at 1/200 of the reads: chrM and the top genes go through the deep kernel."""
+    model = synth.named("C2", n_reads=50_000, n_genes=2_000, n_cb=500)
+    setup_model(engine, model)
+    rows, cols, rec = compare_with_oracle(engine, model)
+    assert engine.count_stats().n_deep_units > 0
+
+
+def test_region_shards_partition_the_rows(engine):
+    model = synth.named("C1", n_reads=20_000)
+    setup_model(engine, model)
+    engine.set_region()
+    engine.pileup_count()
+    full = [engine.fetch_counts(ct) for ct in range(2)]
+    cut = (int(model.contig_len[0]) // 2) // 64 * 64
+    parts = []
+    for lo, hi in (((0, 0), (0, cut)), ((0, cut), (1, 0))):
+        engine.set_region(lo[0], lo[1], hi[0], hi[1])
+        engine.pileup_count()
+        parts.append([engine.fetch_counts(ct) for ct in range(2)])
+    engine.set_region()
+    for ct in range(2):
+        k = np.concatenate([parts[0][ct][0], parts[1][ct][0]])
+        c = np.concatenate([parts[0][ct][2], parts[1][ct][2]])
+        np.testing.assert_array_equal(k, full[ct][0])
+        np.testing.assert_array_equal(c, full[ct][2])
+        assert (parts[0][ct][0] & 0xffffffff).max() < cut <= (parts[1][ct][0] & 0xffffffff).min()
