@@ -43,12 +43,13 @@ constexpr int FLUSH_EVERY = 63;      // packed LDS fields: fwd 6 | cnt 6 | dup 6
 // device scalars (uint64 each)
 enum { SC_QSMALL = 0, SC_QBIG = 1, SC_NNE = 2, SC_NSLOTS = 3, SC_ROWALLOC = 4, SC_COLS = 8, SC_OVERFLOW = 9,
        SC_READS = 10, SC_SEGS = 11, SC_EVENTS = 12, SC_EV_WAVE = 13, SC_EV_DEEP = 14, SC_ROWS_DEEP = 15,
-       SC_ROWS = 16, SC_NSMALL = 20, SC_NMULTI = 21, SC_NMULTI_SEL = 22, SC_COUNT = 24 };
+       SC_ROWS = 16, SC_NSMALL = 20, SC_NMULTI = 21, SC_NMULTI_SEL = 22, SC_QGROUP = 23, SC_NHUGE = 24, SC_QHUGE = 25,
+       SC_COUNT = 28 };
 
 // workspace buffers (lsg_ctx::ws)
 enum { WS_UNIT_SLOT = 0, WS_UNIT_NSUB, WS_NE_NSLOT, WS_NE_SLOT_BASE, WS_NE_ACC, WS_NE_GEOM, WS_SLOT_W, WS_SLOT_CNT,
        WS_SLOT_OFF, WS_SLOT_CURSOR, WS_EKEY, WS_EEV, WS_EMETA, WS_SLOT_LIST, WS_MULTI_LIST, WS_MACC, WS_EXPORT_K, WS_EXPORT_R,
-       WS_EXPORT_C };
+       WS_EXPORT_C, WS_SLICES, WS_HUGE_LIST };
 
 struct CountArgs {
     // reads
@@ -71,7 +72,7 @@ struct CountArgs {
     uint64_t* ne_mask; uint32_t* ne_rowbase;
     uint32_t* slot_w; uint32_t* slot_cnt; uint32_t* slot_off; uint32_t* slot_cursor;
     uint32_t* ekey; uint32_t* eev; uint32_t* emeta;
-    uint32_t* slot_list; uint32_t* multi_list; uint32_t* macc;
+    uint32_t* slot_list; uint32_t* multi_list; uint32_t* macc; uint32_t* slices; uint32_t* huge_list;
     uint32_t n_ne, n_slots, n_multi;
     unsigned long long* scalars;
     uint32_t* rows[LSG_MAX_CELLTYPES];
@@ -85,9 +86,9 @@ struct CountArgs {
 //   with a cell type (SplitBamCellTypes.py:83-90), MAPQ >= min_MQ (:110-113).
 // key = cb | reverse<<24 | celltype<<28.
 __global__ void k_read_key(CountArgs a) {
-    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t key = KEY_INVALID;
-    if (r < a.n_reads) {
+    unsigned long long n_ok = 0;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < a.n_reads; r += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t key = KEY_INVALID;
         uint32_t flag = a.read_flag[r];
         int32_t cb = a.read_cb[r];
         int32_t tid = a.read_tid[r];
@@ -99,98 +100,125 @@ __global__ void k_read_key(CountArgs a) {
             if (ct < (uint32_t)a.n_ct) key = (uint32_t)cb | (((flag >> 4) & 1u) << 24) | (ct << 28);
         }
         a.read_key[r] = key;
+        n_ok += key != KEY_INVALID;
     }
-    unsigned long long m = __ballot(key != KEY_INVALID);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&a.scalars[SC_READS], (unsigned long long)__popcll(m));
-}
-
-// One atomic per run of adjacent lanes with the same target (reads are coordinate sorted, so the
-// segments of a wave mostly hit the same few units).  Returns base + rank within the run.
-__device__ __forceinline__ uint32_t run_atomic_add(uint32_t* arr, uint32_t idx, bool active, int lane) {
-    uint32_t idx_prev = __shfl_up(idx, 1);
-    int act_prev = __shfl_up((int)active, 1);
-    bool head = active && (lane == 0 || !act_prev || idx_prev != idx);
-    unsigned long long hm = __ballot(head);
-    unsigned long long brk = __ballot(head || !active);
-    unsigned long long after = lane == 63 ? 0ull : (brk >> (lane + 1));
-    uint32_t len = after ? (uint32_t)__ffsll((long long)after) : (uint32_t)(64 - lane);
-    uint32_t base = 0;
-    if (head) base = atomicAdd(&arr[idx], len);
-    unsigned long long below = hm & (lane == 63 ? ~0ull : ((1ull << (lane + 1)) - 1ull));
-    int hl = below ? 63 - __clzll((long long)below) : 0;
-    uint32_t b = __shfl(base, hl);
-    return b + (uint32_t)(lane - hl);
+    for (int o = 32; o > 0; o >>= 1) n_ok += __shfl_down(n_ok, o);
+    if ((threadIdx.x & 63) == 0 && n_ok) atomicAdd(&a.scalars[SC_READS], n_ok);
 }
 
 __device__ __forceinline__ uint32_t sub_of(uint32_t cb, uint32_t nsub, uint32_t n_cb) {
     return (uint32_t)(((uint64_t)cb * nsub) / n_cb);
 }
 
-// MODE 0: count entries per unit.  MODE 1: count entries per slot of multi-slot units.
-// MODE 2: scatter the self-contained entries.
+// Counting sort of (segment, tile) pairs over the segments, with the atomics aggregated per
+// workgroup in an LDS hash: a batch of 256 consecutive segments of a coordinate-sorted BAM hits few
+// distinct units, so one global atomic per distinct target per round replaces one per entry.
+//   MODE 0: count entries per unit.  MODE 1: count entries per slot of multi-slot units.
+//   MODE 2: scatter the self-contained entries (key, first event index, lane range).
+constexpr int BIN_THREADS = 256;
+constexpr int BIN_TPR = 4;             // tiles per segment handled per round
+constexpr int BIN_H = 2048;            // LDS hash slots (>= 2 x BIN_THREADS x BIN_TPR)
 template <int MODE>
-__global__ void k_bin_segments(CountArgs a) {
-    const int lane = threadIdx.x & 63;
-    int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool live = s < a.n_segs;
-    uint32_t key = KEY_INVALID;
-    int32_t tid = 0, st = 0, ln = 0;
-    int64_t evoff = 0;
-    if (live) {
-        uint32_t r = a.seg_read[s];
-        key = a.read_key[r];
-        tid = a.read_tid[r];
-        st = a.seg_start[s];
-        ln = a.seg_len[s];
-        if (key != KEY_INVALID) {
-            int64_t clen = a.contig_len[tid];
-            if (st < 0 || ln <= 0 || (int64_t)st + ln > clen) key = KEY_INVALID;   // malformed: never counted
+__global__ __launch_bounds__(BIN_THREADS) void k_bin_segments(CountArgs a) {
+    __shared__ uint32_t hkey[BIN_H], hcnt[BIN_H], hbase[BIN_H];
+    __shared__ int s_max;
+    const int t = threadIdx.x, lane = t & 63;
+    for (int i = t; i < BIN_H; i += BIN_THREADS) { hkey[i] = KEY_INVALID; hcnt[i] = 0; }
+    unsigned long long st_segs = 0, st_evs = 0;
+    const int64_t n_batches = (a.n_segs + BIN_THREADS - 1) / BIN_THREADS;
+    for (int64_t batch = blockIdx.x; batch < n_batches; batch += gridDim.x) {
+        const int64_t s = batch * BIN_THREADS + t;
+        uint32_t key = KEY_INVALID;
+        int32_t tid = 0, st = 0, ln = 0;
+        int64_t evoff = 0;
+        if (s < a.n_segs) {
+            uint32_t r = a.seg_read[s];
+            key = a.read_key[r];
+            tid = a.read_tid[r];
+            st = a.seg_start[s];
+            ln = a.seg_len[s];
+            if (key != KEY_INVALID) {
+                int64_t clen = a.contig_len[tid];
+                if (st < 0 || ln <= 0 || (int64_t)st + ln > clen) key = KEY_INVALID;   // malformed: never counted
+            }
+            if (MODE == 2 && key != KEY_INVALID) evoff = a.seg_ev_off[s];
         }
-        if (MODE == 2 && key != KEY_INVALID) evoff = a.seg_ev_off[s];
-    }
-    bool ok = key != KEY_INVALID;
-    if (MODE == 0) {
-        unsigned long long m = __ballot(ok);
-        unsigned long long evs = ok ? (unsigned long long)ln : 0ull;
-        for (int o = 32; o > 0; o >>= 1) evs += __shfl_down(evs, o);
-        if (lane == 0 && m) {
-            atomicAdd(&a.scalars[SC_SEGS], (unsigned long long)__popcll(m));
-            atomicAdd(&a.scalars[SC_EVENTS], evs);
-        }
-    }
-    uint32_t ct = key >> 28, cb = key & CB_MASK;
-    uint32_t tb = ok ? a.tile_base[tid] : 0;
-    uint32_t t0 = tb + ((uint32_t)st >> 6);
-    uint32_t t1 = tb + ((uint32_t)(st + ln - 1) >> 6);
-    if (t0 < a.tile_lo) t0 = a.tile_lo;
-    if (a.tile_hi == 0) ok = false; else if (t1 + 1 > a.tile_hi) t1 = a.tile_hi - 1;
-    if (!ok) { t0 = 1; t1 = 0; }
-    for (uint32_t k = 0;; ++k) {
-        bool act = t0 + k <= t1 && t1 >= t0;
-        if (!__ballot(act)) break;
-        uint32_t t = t0 + k;
-        uint32_t u = t * (uint32_t)a.n_ct + ct;
-        if (MODE == 0) {
-            (void)run_atomic_add(a.unit_cnt, act ? u : 0u, act, lane);
-        } else {
-            uint32_t nsub = act ? a.unit_nsub[u] : 1u;
-            if (MODE == 1) {
-                if (act && nsub > 1) atomicAdd(&a.slot_cnt[a.unit_slot[u] + sub_of(cb, nsub, (uint32_t)a.n_cb)], 1u);
-            } else {
-                uint32_t slot = 0;
-                if (act) slot = a.unit_slot[u] + (nsub > 1 ? sub_of(cb, nsub, (uint32_t)a.n_cb) : 0u);
-                uint32_t pos = run_atomic_add(a.slot_cursor, slot, act, lane);
-                if (act) {
-                    int32_t tstart = (int32_t)((t - tb) << 6);
-                    int32_t lo = st > tstart ? st : tstart;
-                    int32_t hi = st + ln < tstart + TILE_W ? st + ln : tstart + TILE_W;
-                    int64_t ev_first = evoff + (lo - st);
-                    a.ekey[pos] = key;
-                    a.eev[pos] = (uint32_t)ev_first;
-                    a.emeta[pos] = (uint32_t)((ev_first >> 32) & 0xff) | ((uint32_t)(lo - tstart) << 8) | ((uint32_t)(hi - lo - 1) << 16);
+        bool ok = key != KEY_INVALID;
+        if (MODE == 0 && ok) { ++st_segs; st_evs += (unsigned long long)ln; }
+        const uint32_t ct = key >> 28, cb = key & CB_MASK;
+        const uint32_t tb = ok ? a.tile_base[tid] : 0;
+        uint32_t t0 = tb + ((uint32_t)st >> 6);
+        uint32_t t1 = tb + ((uint32_t)(st + ln - 1) >> 6);
+        if (t0 < a.tile_lo) t0 = a.tile_lo;
+        if (a.tile_hi == 0) ok = false; else if (t1 + 1 > a.tile_hi) t1 = a.tile_hi - 1;
+        int ntile = (ok && t1 >= t0) ? (int)(t1 - t0 + 1) : 0;
+        __syncthreads();
+        if (t == 0) s_max = 0;
+        __syncthreads();
+        int wmax = ntile;
+        for (int o = 32; o > 0; o >>= 1) { int v = __shfl_down(wmax, o); wmax = v > wmax ? v : wmax; }
+        if (lane == 0 && wmax) atomicMax(&s_max, wmax);
+        __syncthreads();
+        const int n_rounds = (s_max + BIN_TPR - 1) / BIN_TPR;
+        for (int rd = 0; rd < n_rounds; ++rd) {
+            uint32_t hr[BIN_TPR];
+#pragma unroll
+            for (int j = 0; j < BIN_TPR; ++j) {
+                const int k = rd * BIN_TPR + j;
+                hr[j] = KEY_INVALID;
+                if (k < ntile) {
+                    const uint32_t u = (t0 + (uint32_t)k) * (uint32_t)a.n_ct + ct;
+                    uint32_t x = u;
+                    bool act = true;
+                    if (MODE != 0) {
+                        const uint32_t nsub = a.unit_nsub[u];
+                        x = a.unit_slot[u] + (nsub > 1 ? sub_of(cb, nsub, (uint32_t)a.n_cb) : 0u);
+                        if (MODE == 1 && nsub <= 1) act = false;
+                    }
+                    if (act) {
+                        uint32_t h = (x * 2654435761u) >> (32 - __builtin_ctz(BIN_H));
+                        while (true) {
+                            uint32_t prev = atomicCAS(&hkey[h], KEY_INVALID, x);
+                            if (prev == KEY_INVALID || prev == x) break;
+                            h = (h + 1) & (BIN_H - 1);
+                        }
+                        hr[j] = h | (atomicAdd(&hcnt[h], 1u) << 16);
+                    }
+                }
+            }
+            __syncthreads();
+            for (int i = t; i < BIN_H; i += BIN_THREADS) {
+                const uint32_t cnt = hcnt[i];
+                if (cnt) {
+                    const uint32_t x = hkey[i];
+                    if (MODE == 0) atomicAdd(&a.unit_cnt[x], cnt);
+                    else if (MODE == 1) atomicAdd(&a.slot_cnt[x], cnt);
+                    else hbase[i] = atomicAdd(&a.slot_cursor[x], cnt);
+                    hkey[i] = KEY_INVALID; hcnt[i] = 0;
+                }
+            }
+            __syncthreads();
+            if (MODE == 2) {
+#pragma unroll
+                for (int j = 0; j < BIN_TPR; ++j) {
+                    if (hr[j] != KEY_INVALID) {
+                        const uint32_t pos = hbase[hr[j] & 0xffffu] + (hr[j] >> 16);
+                        const uint32_t tt = t0 + (uint32_t)(rd * BIN_TPR + j);
+                        const int32_t tstart = (int32_t)((tt - tb) << 6);
+                        const int32_t lo = st > tstart ? st : tstart;
+                        const int32_t hi = st + ln < tstart + TILE_W ? st + ln : tstart + TILE_W;
+                        const int64_t ev_first = evoff + (lo - st);
+                        a.ekey[pos] = key;
+                        a.eev[pos] = (uint32_t)ev_first;
+                        a.emeta[pos] = (uint32_t)((ev_first >> 32) & 0xff) | ((uint32_t)(lo - tstart) << 8) | ((uint32_t)(hi - lo - 1) << 16);
+                    }
                 }
             }
         }
+    }
+    if (MODE == 0) {
+        for (int o = 32; o > 0; o >>= 1) { st_segs += __shfl_down(st_segs, o); st_evs += __shfl_down(st_evs, o); }
+        if (lane == 0 && st_segs) { atomicAdd(&a.scalars[SC_SEGS], st_segs); atomicAdd(&a.scalars[SC_EVENTS], st_evs); }
     }
 }
 
@@ -287,39 +315,53 @@ struct Acc {
             atomicAdd(&pk[sym * 64 + lane], (q << 18) | (seen << 12) | 64u | fwd);   // ds_add_u32, lane-private word
             mask |= 1u << sym;
         }
-        if (++npk == FLUSH_EVERY) flush_pk(pk, lane);
+        ++npk;
+    }
+    // call before adding up to `next` more entries: keeps the packed 6-bit fields from overflowing
+    __device__ __forceinline__ void reserve(uint32_t next, uint32_t* pk, int lane) {
+        if (npk + next > (uint32_t)FLUSH_EVERY) flush_pk(pk, lane);
     }
     __device__ __forceinline__ void finish(uint32_t* pk, int lane) { flush_pk(pk, lane); }
 };
 
-// Walk grouped entries [j0, j1) with all 64 lanes = 64 positions.  Records are read 64 at a time
-// into registers (lane l holds record jb+l), then 8 event loads are issued before any is consumed.
+// One group of up to U entries of the register-held record batch (k,e,m): issue all event loads
+// first (branch-free: out-of-range lanes re-read the entry's last event, same cache line), then
+// consume them.  FULL = exactly U entries (the hot case, no guards at all).
+template <int U, bool FULL>
+__device__ __forceinline__ void walk_group(const uint16_t* __restrict__ events, Acc& acc, uint32_t k, uint32_t e, uint32_t m, int l, int cnt,
+                                           int min_bq, uint32_t* pk, int lane) {
+    uint32_t ks[U], evv[U]; bool inr[U];
+    acc.reserve(U, pk, lane);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if (FULL || u < cnt) {
+            ks[u] = rl(k, l + u);
+            const uint32_t es = rl(e, l + u), ms = rl(m, l + u);
+            const uint32_t rel = (uint32_t)lane - ((ms >> 8) & 63u);
+            const uint32_t cm1 = (ms >> 16) & 63u;
+            inr[u] = rel <= cm1;
+            const uint32_t relc = inr[u] ? rel : cm1;
+            const uint64_t addr = (((uint64_t)(ms & 0xffu)) << 32 | es) + relc;
+            evv[u] = (uint32_t)events[addr];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+        if (FULL || u < cnt) acc.add(ks[u], evv[u], inr[u], min_bq, pk, lane);
+}
+
+// Walk grouped entries [j0, j1) held in LDS with all 64 lanes = 64 positions.  Records are read 64
+// at a time into registers (lane l holds record jb+l).  j0/j1 must be wave-uniform.
 __device__ __forceinline__ void walk(const CountArgs& a, Acc& acc, const uint32_t* gkey, const uint32_t* gev, const uint32_t* gmeta,
                                      int j0, int j1, uint32_t* pk, int lane) {
-    const uint16_t* __restrict__ events = a.events;
     constexpr int U = 8;
     for (int jb = j0; jb < j1; jb += 64) {
-        int nb = j1 - jb < 64 ? j1 - jb : 64;
+        const int nb = j1 - jb < 64 ? j1 - jb : 64;
         uint32_t k = 0, e = 0, m = 0;
         if (lane < nb) { k = gkey[jb + lane]; e = gev[jb + lane]; m = gmeta[jb + lane]; }
-        for (int l = 0; l < nb; l += U) {
-            uint32_t ks[U], evv[U]; bool inr[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                inr[u] = false; evv[u] = 0xffffu; ks[u] = 0;
-                if (l + u < nb) {
-                    ks[u] = rl(k, l + u);
-                    uint32_t es = rl(e, l + u), ms = rl(m, l + u);
-                    uint32_t rel = (uint32_t)lane - ((ms >> 8) & 63u);
-                    inr[u] = rel <= ((ms >> 16) & 63u);
-                    uint64_t addr = (((uint64_t)(ms & 0xffu)) << 32 | es) + rel;
-                    if (inr[u]) evv[u] = (uint32_t)events[addr];
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (l + u < nb) acc.add(ks[u], evv[u], inr[u], a.min_bq, pk, lane);
-        }
+        int l = 0;
+        for (; l + U <= nb; l += U) walk_group<U, true>(a.events, acc, k, e, m, l, U, a.min_bq, pk, lane);
+        if (l < nb) walk_group<U, false>(a.events, acc, k, e, m, l, nb - l, a.min_bq, pk, lane);
     }
 }
 
@@ -327,7 +369,7 @@ __device__ __forceinline__ void walk(const CountArgs& a, Acc& acc, const uint32_
 // entries with equal barcodes become adjacent.  T threads cooperate (T = 64: one wave, fences
 // only; T = BLOCK_THREADS: __syncthreads).  When `filter` is set only entries whose barcode bucket
 // (cb >> shift) lies in [b_lo, b_hi) are taken (fallback passes).
-template <bool BLOCK, int H, int CAP>
+template <bool BLOCK, int H, int CAP, bool TO_GLOBAL = false>
 __device__ __forceinline__ int group_by_cb(const CountArgs& a, uint32_t src, int n, uint32_t* gkey, uint32_t* gev, uint32_t* gmeta,
                                            uint32_t* tkey, uint32_t* tcnt, int t, uint32_t* wave_tot) {
     constexpr int T = BLOCK ? BLOCK_THREADS : 64;
@@ -380,7 +422,12 @@ __device__ __forceinline__ int group_by_cb(const CountArgs& a, uint32_t src, int
     for (int r = 0; r < RMAX; ++r) {
         if (t + r * T < n) {
             uint32_t p = tcnt[hs[r] & 0xffffu] + (hs[r] >> 16);
-            gkey[p] = ek[r]; gev[p] = ee[r]; gmeta[p] = em[r];
+            if (TO_GLOBAL) {   // in place: every thread holds its entries in registers since before the first barrier
+                a.ekey[src + p] = ek[r]; a.eev[src + p] = ee[r]; a.emeta[src + p] = em[r];
+                gkey[p] = ek[r] & CB_MASK;
+            } else {
+                gkey[p] = ek[r]; gev[p] = ee[r]; gmeta[p] = em[r];
+            }
         }
     }
     group_sync<BLOCK>();
@@ -518,7 +565,131 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void k_pileup_wave(CountArgs 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Block kernel: one 512-thread workgroup per slot with > CAPW entries or belonging to a multi-slot
+// Block path for slots with more than CAPW entries (or belonging to a multi-slot unit), in two
+// kernels so that the event walk runs at full occupancy:
+//   k_group_block  groups a slot's entries by barcode IN PLACE in global memory (LDS hash + scan)
+//                  and records NSLICE run-aligned slice boundaries;
+//   k_walk_block   4 waves walk one slice each straight from the grouped global arrays (coalesced
+//                  record batches, 8 event loads in flight per wave), reduce in LDS, then emit the
+//                  unit's rows or add into the multi-slot unit's global accumulators.
+// Slots left with more than CAPB entries by a skewed barcode range go to k_pileup_huge.
+constexpr int NSLICE = 4;
+struct GroupLds {
+    uint32_t tkey[HB], tcnt[HB];
+    uint32_t gcb[CAPB];
+    uint32_t wave_tot[BLOCK_WAVES];
+    uint32_t slot;
+};
+
+__global__ __launch_bounds__(BLOCK_THREADS) void k_group_block(CountArgs a) {
+    __shared__ GroupLds L;
+    const int t = threadIdx.x;
+    const uint32_t n_big = a.n_slots - (uint32_t)a.scalars[SC_NSMALL];
+    while (true) {
+        __syncthreads();
+        if (t == 0) L.slot = (uint32_t)atomicAdd(&a.scalars[SC_QGROUP], 1ull);
+        __syncthreads();
+        const uint32_t qi = L.slot;
+        if (qi >= n_big) break;
+        const uint32_t s = a.slot_list[a.n_slots - 1 - qi];      // rejected items sit reversed at the end
+        const int n = (int)a.slot_cnt[s];
+        if (n > CAPB) {
+            if (t == 0) a.huge_list[atomicAdd(&a.scalars[SC_NHUGE], 1ull)] = s;
+            continue;
+        }
+        const uint32_t src = a.slot_off[s];
+        group_by_cb<true, HB, CAPB, true>(a, src, n, L.gcb, nullptr, nullptr, L.tkey, L.tcnt, t, L.wave_tot);
+        if (t <= NSLICE) {
+            int j = (int)((int64_t)n * t / NSLICE);
+            while (j > 0 && j < n && L.gcb[j] == L.gcb[j - 1]) ++j;
+            a.slices[(uint64_t)s * (NSLICE + 1) + t] = (uint32_t)j;
+        }
+    }
+}
+
+// Walk grouped entries [j0, j1) of the global arrays starting at src (all three wave-uniform).
+__device__ __forceinline__ void walk_global(const CountArgs& a, Acc& acc, uint32_t src, int j0, int j1, uint32_t* pk, int lane) {
+    constexpr int U = 8;
+    uint32_t k = 0, e = 0, m = 0;
+    if (j0 + lane < j1) { k = a.ekey[src + j0 + lane]; e = a.eev[src + j0 + lane]; m = a.emeta[src + j0 + lane]; }
+    for (int jb = j0; jb < j1; jb += 64) {
+        const int nb = j1 - jb < 64 ? j1 - jb : 64;
+        // prefetch the next batch of records while this one is consumed
+        uint32_t k2 = 0, e2 = 0, m2 = 0;
+        if (jb + 64 + lane < j1) { k2 = a.ekey[src + jb + 64 + lane]; e2 = a.eev[src + jb + 64 + lane]; m2 = a.emeta[src + jb + 64 + lane]; }
+        int l = 0;
+        for (; l + U <= nb; l += U) walk_group<U, true>(a.events, acc, k, e, m, l, U, a.min_bq, pk, lane);
+        if (l < nb) walk_group<U, false>(a.events, acc, k, e, m, l, nb - l, a.min_bq, pk, lane);
+        k = k2; e = e2; m = m2;
+    }
+}
+
+constexpr int WALK_THREADS = NSLICE * 64;
+struct WalkLds {
+    uint32_t pk[NSLICE][8 * 64];
+    uint32_t acc[NCTR][64];
+    uint32_t slot;
+    WaveBook book;
+};
+
+__global__ __launch_bounds__(WALK_THREADS) void k_walk_block(CountArgs a) {
+    __shared__ WalkLds L;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    if (wv == 0) book_init(L.book, lane);
+    uint32_t* pk = L.pk[wv];
+    for (int i = lane; i < 8 * 64; i += 64) pk[i] = 0;
+    const uint32_t n_big = a.n_slots - (uint32_t)a.scalars[SC_NSMALL];
+    unsigned long long nev_total = 0;
+    while (true) {
+        __syncthreads();
+        if (t == 0) L.slot = (uint32_t)atomicAdd(&a.scalars[SC_QBIG], 1ull);
+        for (int i = t; i < NCTR * 64; i += WALK_THREADS) (&L.acc[0][0])[i] = 0;
+        __syncthreads();
+        const uint32_t qi = rl(L.slot, 0);
+        if (qi >= n_big) break;
+        const uint32_t s = rl(a.slot_list[a.n_slots - 1 - qi], 0);
+        const int n = (int)rl(a.slot_cnt[s], 0);
+        if (n > CAPB) continue;                                   // k_pileup_huge's slot
+        const uint32_t w = rl(a.slot_w[s], 0), src = rl(a.slot_off[s], 0);
+        const int j0 = (int)rl(a.slices[(uint64_t)s * (NSLICE + 1) + wv], 0), j1 = (int)rl(a.slices[(uint64_t)s * (NSLICE + 1) + wv + 1], 0);
+        Acc acc; acc.init();
+        walk_global(a, acc, src, j0, j1, pk, lane);
+        acc.finish(pk, lane);
+        nev_total += acc.nev;
+        atomicAdd(&L.acc[0][lane], acc.ncdup);
+#pragma unroll
+        for (int sy = 0; sy < 8; ++sy) {
+            atomicAdd(&L.acc[1 + sy][lane], acc.dup[sy]);
+            atomicAdd(&L.acc[9 + sy][lane], acc.bc[sy]);
+            atomicAdd(&L.acc[17 + sy][lane], acc.bq[sy]);
+            atomicAdd(&L.acc[25 + sy][lane], acc.bcf[sy]);
+        }
+        __syncthreads();
+        if (a.ne_nslot[w] > 1) {
+            uint32_t* dst = a.macc + (uint64_t)a.ne_acc[w] * (NCTR * 64);
+            for (int i = t; i < NCTR * 64; i += WALK_THREADS) {
+                uint32_t v = (&L.acc[0][0])[i];
+                if (v) atomicAdd(&dst[i], v);
+            }
+        } else if (wv == 0) {
+            Acc tot; tot.init();
+            tot.ncdup = L.acc[0][lane];
+#pragma unroll
+            for (int sy = 0; sy < 8; ++sy) {
+                tot.dup[sy] = L.acc[1 + sy][lane]; tot.bc[sy] = L.acc[9 + sy][lane];
+                tot.bq[sy] = L.acc[17 + sy][lane]; tot.bcf[sy] = L.acc[25 + sy][lane];
+            }
+            const int2 geom = a.ne_geom[w];
+            emit_unit(a, tot, w, (int)((uint32_t)geom.y >> 24), geom.y & 0xffffff, geom.x, lane, &L.book, true);
+        }
+    }
+    if (wv == 0) book_flush(a, L.book, lane);
+    for (int o = 32; o > 0; o >>= 1) nev_total += __shfl_down(nev_total, o);
+    if (lane == 0 && nev_total) atomicAdd(&a.scalars[SC_EV_DEEP], nev_total);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Huge-slot kernel: one 512-thread workgroup per slot with > CAPW entries or belonging to a multi-slot
 // unit.  Normal case (<= CAPB entries): one staged pass.  Fallback (a skewed barcode range left
 // more than CAPB entries in a slot): passes over coarse barcode buckets; a bucket that alone
 // exceeds CAPB is streamed barcode by barcode by wave 0.
@@ -608,6 +779,7 @@ __device__ __forceinline__ void block_walk_slices(const CountArgs& a, BlockLds& 
     while (j0 > 0 && j0 < ns && (L.gkey[j0] & CB_MASK) == (L.gkey[j0 - 1] & CB_MASK)) ++j0;
     while (j1 > 0 && j1 < ns && (L.gkey[j1] & CB_MASK) == (L.gkey[j1 - 1] & CB_MASK)) ++j1;
     if (j0 > j1) j0 = j1;
+    j0 = (int)rl((uint32_t)j0, 0); j1 = (int)rl((uint32_t)j1, 0);
     // the hash arrays are dead now: pk lives there
     __syncthreads();
     uint32_t* pk = L.u.w.pk[wv];
@@ -618,23 +790,22 @@ __device__ __forceinline__ void block_walk_slices(const CountArgs& a, BlockLds& 
     acc.new_run();
 }
 
-__global__ __launch_bounds__(BLOCK_THREADS) void k_pileup_block(CountArgs a) {
+__global__ __launch_bounds__(BLOCK_THREADS) void k_pileup_huge(CountArgs a) {
     __shared__ BlockLds L;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     if (wv == 0) book_init(L.book, lane);
-    const uint32_t n_small = (uint32_t)a.scalars[SC_NSMALL];
-    const uint32_t n_big = a.n_slots - n_small;
+    const uint32_t n_huge = (uint32_t)a.scalars[SC_NHUGE];
     int shift = 0;
     while (((uint32_t)(a.n_cb - 1) >> shift) >= (uint32_t)NBUCKET) ++shift;
     unsigned long long nev_total = 0;
 
     while (true) {
         __syncthreads();
-        if (t == 0) L.slot = (uint32_t)atomicAdd(&a.scalars[SC_QBIG], 1ull);
+        if (t == 0) L.slot = (uint32_t)atomicAdd(&a.scalars[SC_QHUGE], 1ull);
         __syncthreads();
         const uint32_t qi = L.slot;
-        if (qi >= n_big) break;
-        const uint32_t s = a.slot_list[a.n_slots - 1 - qi];      // rejected items sit reversed at the end
+        if (qi >= n_huge) break;
+        const uint32_t s = a.huge_list[qi];
         const uint32_t w = a.slot_w[s], src = a.slot_off[s];
         const int n = (int)a.slot_cnt[s];
         const int2 geom = a.ne_geom[w];
@@ -693,6 +864,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_pileup_block(CountArgs a) {
                                     bool inr = rel <= ((ms >> 16) & 63u);
                                     uint64_t addr = (((uint64_t)(ms & 0xffu)) << 32 | es) + rel;
                                     uint32_t evv = inr ? (uint32_t)a.events[addr] : 0xffffu;
+                                    acc.reserve(1, pk, lane);
                                     acc.add(ks, evv, inr, a.min_bq, pk, lane);
                                 }
                             }
@@ -801,6 +973,7 @@ static void fill_args(lsg_ctx* c, const lsg_count_params* p, CountArgs& a) {
     a.ekey = c->ws[WS_EKEY].as<uint32_t>(); a.eev = c->ws[WS_EEV].as<uint32_t>(); a.emeta = c->ws[WS_EMETA].as<uint32_t>();
     a.slot_list = c->ws[WS_SLOT_LIST].as<uint32_t>(); a.multi_list = c->ws[WS_MULTI_LIST].as<uint32_t>();
     a.macc = c->ws[WS_MACC].as<uint32_t>();
+    a.slices = c->ws[WS_SLICES].as<uint32_t>(); a.huge_list = c->ws[WS_HUGE_LIST].as<uint32_t>();
     a.n_ne = c->n_ne; a.n_slots = c->n_slots; a.n_multi = c->n_multi;
     a.scalars = c->d_scalars.as<unsigned long long>();
     for (int i = 0; i < LSG_MAX_CELLTYPES; ++i) a.rows[i] = c->d_rows[i].as<uint32_t>();
@@ -840,7 +1013,8 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
         c->ws[WS_SLOT_CNT].reserve((slot_cap + 2) * 4) || c->ws[WS_SLOT_OFF].reserve((slot_cap + 2) * 4) ||
         c->ws[WS_SLOT_CURSOR].reserve((slot_cap + 2) * 4) || c->ws[WS_SLOT_LIST].reserve((slot_cap + 2) * 4) ||
         c->ws[WS_MULTI_LIST].reserve((EU / CAPB + 16) * 4) || c->ws[WS_EKEY].reserve((EU + 1) * 4) ||
-        c->ws[WS_EEV].reserve((EU + 1) * 4) || c->ws[WS_EMETA].reserve((EU + 1) * 4))
+        c->ws[WS_EEV].reserve((EU + 1) * 4) || c->ws[WS_EMETA].reserve((EU + 1) * 4) ||
+        c->ws[WS_SLICES].reserve((slot_cap + 2) * (NSLICE + 1) * 4) || c->ws[WS_HUGE_LIST].reserve((EU / CAPB + 16) * 4))
         return -1;
 
     LSG_HIP(hipEventRecord(c->ev[0], st));
@@ -850,7 +1024,8 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
     CountArgs a{};
     fill_args(c, p, a);
     unsigned seg_grid = (unsigned)((S + 255) / 256);
-    if (R > 0) hipLaunchKernelGGL(k_read_key, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, a);
+    if (seg_grid > (unsigned)(c->n_cus * 8)) seg_grid = (unsigned)(c->n_cus * 8);
+    if (R > 0) { unsigned g = (unsigned)((R + 255) / 256); if (g > (unsigned)(c->n_cus * 8)) g = (unsigned)(c->n_cus * 8); hipLaunchKernelGGL(k_read_key, dim3(g), dim3(256), 0, st, a); }
     if (S > 0) hipLaunchKernelGGL(k_bin_segments<0>, dim3(seg_grid), dim3(256), 0, st, a);
 
     // non-empty units, in genomic order
@@ -908,23 +1083,26 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
         }
     }
     // row buffers: bound + arena slack
-    const unsigned grid_block = (unsigned)(c->n_cus * 2);
+    const unsigned grid_block = (unsigned)(c->n_cus * 2);      // k_pileup_huge
+    const unsigned grid_walk = (unsigned)(c->n_cus * 4);       // k_walk_block
     const unsigned grid_wave = (unsigned)(c->n_cus * 4);
     uint64_t want_rows = (uint64_t)n_ne * TILE_W;
     if (p->min_dp > 0) {
         uint64_t by_depth = (uint64_t)c->rd.n_events / (uint64_t)p->min_dp + 64;
         if (by_depth < want_rows) want_rows = by_depth;
     }
-    want_rows += (uint64_t)(grid_block + grid_wave * WAVES_PER_BLOCK) * ARENA + 64;
+    want_rows += (uint64_t)(grid_block + grid_walk + grid_wave * WAVES_PER_BLOCK) * ARENA + 64;
     if (want_rows > c->row_cap) {
         for (int i = 0; i < c->n_ct; ++i)
             if (c->d_rows[i].reserve((size_t)want_rows * LSG_ROW_WORDS * 4)) return -1;
         c->row_cap = want_rows;
     }
     fill_args(c, p, a);
+    if (n_ne > 0) hipLaunchKernelGGL(k_group_block, dim3((unsigned)(c->n_cus * 4)), dim3(BLOCK_THREADS), 0, st, a);
     LSG_HIP(hipEventRecord(c->ev[1], st));
     if (n_ne > 0) {
-        hipLaunchKernelGGL(k_pileup_block, dim3(grid_block), dim3(BLOCK_THREADS), 0, st, a);
+        hipLaunchKernelGGL(k_walk_block, dim3(grid_walk), dim3(WALK_THREADS), 0, st, a);
+        hipLaunchKernelGGL(k_pileup_huge, dim3(grid_block), dim3(BLOCK_THREADS), 0, st, a);
         if (c->n_multi > 0)
             hipLaunchKernelGGL(k_finalize_multi, dim3((unsigned)(((uint64_t)c->n_multi * 64 + 255) / 256)), dim3(256), 0, st, a);
     }
@@ -1019,11 +1197,10 @@ int run_fetch_counts(lsg_ctx* c, int ct, int64_t* keys, uint8_t* ref, uint32_t* 
 
 // Upper bound of tile entries (sum over segments of tiles overlapped), computed once at load time.
 __global__ void k_entries_upper(const int32_t* seg_start, const int32_t* seg_len, int64_t n_segs, unsigned long long* out) {
-    int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long v = 0;
-    if (s < n_segs) {
+    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n_segs; s += (int64_t)gridDim.x * blockDim.x) {
         int32_t st = seg_start[s], ln = seg_len[s];
-        if (st >= 0 && ln > 0) v = (unsigned long long)(((uint32_t)(st + ln - 1) >> 6) - ((uint32_t)st >> 6) + 1);
+        if (st >= 0 && ln > 0) v += (unsigned long long)(((uint32_t)(st + ln - 1) >> 6) - ((uint32_t)st >> 6) + 1);
     }
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
     if ((threadIdx.x & 63) == 0 && v) atomicAdd(out, v);
@@ -1034,7 +1211,7 @@ int compute_entries_upper(lsg_ctx* c) {
     LSG_HIP(hipMemsetAsync(c->d_scalars.p, 0, SC_COUNT * 8, c->stream));
     int64_t S = c->rd.n_segs;
     if (S > 0)
-        hipLaunchKernelGGL(k_entries_upper, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, c->stream, c->rd.seg_start,
+        hipLaunchKernelGGL(k_entries_upper, dim3((unsigned)((S + 255) / 256 < 2048 ? (S + 255) / 256 : 2048)), dim3(256), 0, c->stream, c->rd.seg_start,
                            c->rd.seg_len, S, c->d_scalars.as<unsigned long long>());
     unsigned long long v = 0;
     LSG_HIP(hipMemcpyAsync(&v, c->d_scalars.p, 8, hipMemcpyDeviceToHost, c->stream));
