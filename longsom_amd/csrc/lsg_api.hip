@@ -63,7 +63,7 @@ void lsg_destroy(lsg_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf* bufs[] = {&c->d_tile_base, &c->d_contig_len, &c->d_ref_ptrs, &c->d_celltype_of, &c->b_read_tid, &c->b_read_pos,
+    DevBuf* bufs[] = {&c->d_tile_base, &c->d_contig_len, &c->d_ref_ptrs, &c->d_celltype_of, &c->d_ct_rank, &c->b_read_tid, &c->b_read_pos,
                       &c->b_read_flag, &c->b_read_mapq, &c->b_read_cb, &c->b_seg_read, &c->b_seg_start, &c->b_seg_len,
                       &c->b_seg_ev_off, &c->b_events, &c->d_read_key, &c->d_unit_cnt, &c->d_unit_off, &c->d_unit_fill,
                       &c->d_entries, &c->d_ne_units, &c->d_ne_mask, &c->d_ne_rowbase, &c->d_ne_rowoff, &c->d_deep_list,
@@ -143,6 +143,15 @@ int lsg_set_barcodes(lsg_ctx* c, const uint8_t* celltype_of, int32_t n_cb, int32
     LSG_HIP(hipSetDevice(c->device));
     if (c->d_celltype_of.reserve((size_t)n_cb)) return -1;
     LSG_HIP(hipMemcpyAsync(c->d_celltype_of.p, celltype_of, (size_t)n_cb, hipMemcpyHostToDevice, c->stream));
+    {
+        std::vector<uint32_t> rank((size_t)n_cb, 0u);
+        for (auto& v : c->ct_size) v = 0;
+        for (int32_t i = 0; i < n_cb; ++i)
+            if (celltype_of[i] < n_celltypes) rank[i] = c->ct_size[celltype_of[i]]++;
+        if (c->d_ct_rank.reserve((size_t)n_cb * 4)) return -1;
+        LSG_HIP(hipMemcpyAsync(c->d_ct_rank.p, rank.data(), (size_t)n_cb * 4, hipMemcpyHostToDevice, c->stream));
+        LSG_HIP(hipStreamSynchronize(c->stream));
+    }
     LSG_HIP(hipStreamSynchronize(c->stream));
     c->n_cb = n_cb; c->n_ct = n_celltypes;
     c->counted = c->called = false;

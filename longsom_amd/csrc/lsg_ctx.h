@@ -62,7 +62,8 @@ struct lsg_ctx {
 
     // barcodes
     int32_t n_cb = 0, n_ct = 0;
-    lsg::DevBuf d_celltype_of;
+    lsg::DevBuf d_celltype_of, d_ct_rank;   // ct_rank[cb] = rank of the barcode within its cell type
+    uint32_t ct_size[LSG_MAX_CELLTYPES] = {0, 0, 0, 0};
 
     // reads
     lsg_reads rd{};                       // device pointers

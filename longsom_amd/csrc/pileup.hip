@@ -47,8 +47,8 @@ enum { SC_QSMALL = 0, SC_QBIG = 1, SC_NNE = 2, SC_NSLOTS = 3, SC_ROWALLOC = 4, S
        SC_COUNT = 28 };
 
 // workspace buffers (lsg_ctx::ws)
-enum { WS_UNIT_SLOT = 0, WS_UNIT_NSUB, WS_NE_NSLOT, WS_NE_SLOT_BASE, WS_NE_ACC, WS_NE_GEOM, WS_SLOT_W, WS_SLOT_CNT,
-       WS_SLOT_OFF, WS_SLOT_CURSOR, WS_EKEY, WS_EEV, WS_EMETA, WS_SLOT_LIST, WS_MULTI_LIST, WS_MACC, WS_EXPORT_K, WS_EXPORT_R,
+enum { WS_UNIT_PLAN = 0, WS_UNUSED1, WS_NE_NSLOT, WS_NE_SLOT_BASE, WS_NE_ACC, WS_NE_GEOM, WS_SLOT_W, WS_SLOT_CNT,
+       WS_SLOT_OFF, WS_SLOT_CURSOR, WS_ENT, WS_UNUSED2, WS_UNUSED3, WS_SLOT_LIST, WS_MULTI_LIST, WS_MACC, WS_EXPORT_K, WS_EXPORT_R,
        WS_EXPORT_C, WS_SLICES, WS_HUGE_LIST };
 
 struct CountArgs {
@@ -67,11 +67,12 @@ struct CountArgs {
     int32_t min_bq, min_mq, min_dp, min_cc, ignore_orphans;
     uint32_t flag_exclude;
     // workspace
-    uint32_t* read_key; uint32_t* unit_cnt; uint32_t* unit_slot; uint32_t* unit_nsub;
+    uint32_t* read_key; uint32_t* unit_cnt; uint2* unit_plan;    // unit_plan[u] = {first slot, number of slots}
+    const uint32_t* ct_rank; uint32_t ct_size[LSG_MAX_CELLTYPES];   // rank of a barcode within its cell type
     uint32_t* ne_units; uint32_t* ne_nslot; uint32_t* ne_slot_base; uint32_t* ne_acc; int2* ne_geom;
     uint64_t* ne_mask; uint32_t* ne_rowbase;
     uint32_t* slot_w; uint32_t* slot_cnt; uint32_t* slot_off; uint32_t* slot_cursor;
-    uint32_t* ekey; uint32_t* eev; uint32_t* emeta;
+    uint4* ent;                           // entries {key, first event index lo, meta, 0}
     uint32_t* slot_list; uint32_t* multi_list; uint32_t* macc; uint32_t* slices; uint32_t* huge_list;
     uint32_t n_ne, n_slots, n_multi;
     unsigned long long* scalars;
@@ -145,7 +146,8 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_segments(CountArgs a) {
         }
         bool ok = key != KEY_INVALID;
         if (MODE == 0 && ok) { ++st_segs; st_evs += (unsigned long long)ln; }
-        const uint32_t ct = key >> 28, cb = key & CB_MASK;
+        const uint32_t ct = key >> 28;
+        const uint32_t rank = (MODE != 0 && ok) ? a.ct_rank[key & CB_MASK] : 0u;
         const uint32_t tb = ok ? a.tile_base[tid] : 0;
         uint32_t t0 = tb + ((uint32_t)st >> 6);
         uint32_t t1 = tb + ((uint32_t)(st + ln - 1) >> 6);
@@ -171,9 +173,9 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_segments(CountArgs a) {
                     uint32_t x = u;
                     bool act = true;
                     if (MODE != 0) {
-                        const uint32_t nsub = a.unit_nsub[u];
-                        x = a.unit_slot[u] + (nsub > 1 ? sub_of(cb, nsub, (uint32_t)a.n_cb) : 0u);
-                        if (MODE == 1 && nsub <= 1) act = false;
+                        const uint2 plan = a.unit_plan[u];
+                        x = plan.x + (plan.y > 1 ? sub_of(rank, plan.y, a.ct_size[ct]) : 0u);
+                        if (MODE == 1 && plan.y <= 1) act = false;
                     }
                     if (act) {
                         uint32_t h = (x * 2654435761u) >> (32 - __builtin_ctz(BIN_H));
@@ -208,9 +210,8 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_segments(CountArgs a) {
                         const int32_t lo = st > tstart ? st : tstart;
                         const int32_t hi = st + ln < tstart + TILE_W ? st + ln : tstart + TILE_W;
                         const int64_t ev_first = evoff + (lo - st);
-                        a.ekey[pos] = key;
-                        a.eev[pos] = (uint32_t)ev_first;
-                        a.emeta[pos] = (uint32_t)((ev_first >> 32) & 0xff) | ((uint32_t)(lo - tstart) << 8) | ((uint32_t)(hi - lo - 1) << 16);
+                        a.ent[pos] = make_uint4(key, (uint32_t)ev_first,
+                                                (uint32_t)((ev_first >> 32) & 0xff) | ((uint32_t)(lo - tstart) << 8) | ((uint32_t)(hi - lo - 1) << 16), 0u);
                     }
                 }
             }
@@ -242,7 +243,7 @@ __global__ void k_unit_plan(CountArgs a) {
     if (cnt > (uint32_t)CAPB) {
         nslot = (cnt + SUBT - 1) / SUBT;
         if (nslot > (uint32_t)MAXSUB) nslot = MAXSUB;
-        if (nslot > (uint32_t)a.n_cb) nslot = (uint32_t)a.n_cb;
+        { int ct0 = (int)(u % (uint32_t)a.n_ct); if (nslot > a.ct_size[ct0]) nslot = a.ct_size[ct0]; }
         if (nslot < 1) nslot = 1;
     }
     a.ne_nslot[w] = nslot;
@@ -257,8 +258,7 @@ __global__ void k_slot_init(CountArgs a) {
     if (w >= a.n_ne) return;
     uint32_t u = a.ne_units[w];
     uint32_t base = a.ne_slot_base[w], nslot = a.ne_nslot[w];
-    a.unit_slot[u] = base;
-    a.unit_nsub[u] = nslot;
+    a.unit_plan[u] = make_uint2(base, nslot);
     uint32_t cnt = a.unit_cnt[u];
     for (uint32_t j = 0; j < nslot; ++j) { a.slot_w[base + j] = w; a.slot_cnt[base + j] = nslot == 1 ? cnt : 0u; }
     if (w == a.n_ne - 1) a.slot_cnt[base + nslot] = 0;    // scan sentinel
@@ -381,7 +381,7 @@ __device__ __forceinline__ int group_by_cb(const CountArgs& a, uint32_t src, int
     for (int r = 0; r < RMAX; ++r) {
         int i = t + r * T;
         hs[r] = 0; ek[r] = KEY_INVALID; ee[r] = 0; em[r] = 0;
-        if (i < n) { ek[r] = a.ekey[src + i]; ee[r] = a.eev[src + i]; em[r] = a.emeta[src + i]; }
+        if (i < n) { const uint4 v = a.ent[src + i]; ek[r] = v.x; ee[r] = v.y; em[r] = v.z; }
     }
 #pragma unroll
     for (int r = 0; r < RMAX; ++r) {
@@ -423,7 +423,7 @@ __device__ __forceinline__ int group_by_cb(const CountArgs& a, uint32_t src, int
         if (t + r * T < n) {
             uint32_t p = tcnt[hs[r] & 0xffffu] + (hs[r] >> 16);
             if (TO_GLOBAL) {   // in place: every thread holds its entries in registers since before the first barrier
-                a.ekey[src + p] = ek[r]; a.eev[src + p] = ee[r]; a.emeta[src + p] = em[r];
+                a.ent[src + p] = make_uint4(ek[r], ee[r], em[r], 0u);
                 gkey[p] = ek[r] & CB_MASK;
             } else {
                 gkey[p] = ek[r]; gev[p] = ee[r]; gmeta[p] = em[r];
@@ -611,12 +611,12 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_group_block(CountArgs a) {
 __device__ __forceinline__ void walk_global(const CountArgs& a, Acc& acc, uint32_t src, int j0, int j1, uint32_t* pk, int lane) {
     constexpr int U = 8;
     uint32_t k = 0, e = 0, m = 0;
-    if (j0 + lane < j1) { k = a.ekey[src + j0 + lane]; e = a.eev[src + j0 + lane]; m = a.emeta[src + j0 + lane]; }
+    if (j0 + lane < j1) { const uint4 v = a.ent[src + j0 + lane]; k = v.x; e = v.y; m = v.z; }
     for (int jb = j0; jb < j1; jb += 64) {
         const int nb = j1 - jb < 64 ? j1 - jb : 64;
         // prefetch the next batch of records while this one is consumed
         uint32_t k2 = 0, e2 = 0, m2 = 0;
-        if (jb + 64 + lane < j1) { k2 = a.ekey[src + jb + 64 + lane]; e2 = a.eev[src + jb + 64 + lane]; m2 = a.emeta[src + jb + 64 + lane]; }
+        if (jb + 64 + lane < j1) { const uint4 v = a.ent[src + jb + 64 + lane]; k2 = v.x; e2 = v.y; m2 = v.z; }
         int l = 0;
         for (; l + U <= nb; l += U) walk_group<U, true>(a.events, acc, k, e, m, l, U, a.min_bq, pk, lane);
         if (l < nb) walk_group<U, false>(a.events, acc, k, e, m, l, nb - l, a.min_bq, pk, lane);
@@ -715,11 +715,11 @@ __device__ __forceinline__ int block_stage_filtered(const CountArgs& a, BlockLds
     if (t == 0) L.scount = 0;
     __syncthreads();
     for (int i = t; i < n; i += BLOCK_THREADS) {
-        uint32_t k = a.ekey[src + i];
-        uint32_t b = (k & CB_MASK) >> shift;
+        const uint4 v = a.ent[src + i];
+        uint32_t b = (v.x & CB_MASK) >> shift;
         if (b >= b_lo && b < b_hi) {
             uint32_t slot = atomicAdd(&L.scount, 1u);
-            L.gkey[slot] = k; L.gev[slot] = a.eev[src + i]; L.gmeta[slot] = a.emeta[src + i];
+            L.gkey[slot] = v.x; L.gev[slot] = v.y; L.gmeta[slot] = v.z;
         }
     }
     __syncthreads();
@@ -821,7 +821,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_pileup_huge(CountArgs a) {
             __syncthreads();
             for (int i = t; i < NBUCKET; i += BLOCK_THREADS) L.hist[i] = 0;
             __syncthreads();
-            for (int i = t; i < n; i += BLOCK_THREADS) atomicAdd(&L.hist[(a.ekey[src + i] & CB_MASK) >> shift], 1u);
+            for (int i = t; i < n; i += BLOCK_THREADS) atomicAdd(&L.hist[(a.ent[src + i].x & CB_MASK) >> shift], 1u);
             __syncthreads();
             if (t == 0) {
                 uint32_t np = 0, cur = 0; bool open = false;
@@ -853,9 +853,8 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_pileup_huge(CountArgs a) {
                             acc.new_run();
                             for (int ib = 0; ib < n; ib += 64) {
                                 uint32_t k = KEY_INVALID, e = 0, m = 0;
-                                if (ib + lane < n) { k = a.ekey[src + ib + lane]; }
+                                if (ib + lane < n) { const uint4 v = a.ent[src + ib + lane]; k = v.x; e = v.y; m = v.z; }
                                 bool match = k != KEY_INVALID && (k & CB_MASK) == c;
-                                if (match) { e = a.eev[src + ib + lane]; m = a.emeta[src + ib + lane]; }
                                 unsigned long long mm = __ballot(match);
                                 while (mm) {
                                     int l = __ffsll((long long)mm) - 1; mm &= mm - 1;
@@ -963,14 +962,15 @@ static void fill_args(lsg_ctx* c, const lsg_count_params* p, CountArgs& a) {
     a.min_bq = p->min_bq; a.min_mq = p->min_mq; a.min_dp = p->min_dp; a.min_cc = p->min_cc;
     a.ignore_orphans = p->ignore_orphans; a.flag_exclude = p->flag_exclude;
     a.read_key = c->d_read_key.as<uint32_t>(); a.unit_cnt = c->d_unit_cnt.as<uint32_t>();
-    a.unit_slot = c->ws[WS_UNIT_SLOT].as<uint32_t>(); a.unit_nsub = c->ws[WS_UNIT_NSUB].as<uint32_t>();
+    a.unit_plan = c->ws[WS_UNIT_PLAN].as<uint2>(); a.ct_rank = c->d_ct_rank.as<uint32_t>();
+    for (int i = 0; i < LSG_MAX_CELLTYPES; ++i) a.ct_size[i] = c->ct_size[i] ? c->ct_size[i] : 1u;
     a.ne_units = c->d_ne_units.as<uint32_t>(); a.ne_nslot = c->ws[WS_NE_NSLOT].as<uint32_t>();
     a.ne_slot_base = c->ws[WS_NE_SLOT_BASE].as<uint32_t>(); a.ne_acc = c->ws[WS_NE_ACC].as<uint32_t>();
     a.ne_geom = c->ws[WS_NE_GEOM].as<int2>();
     a.ne_mask = c->d_ne_mask.as<uint64_t>(); a.ne_rowbase = c->d_ne_rowbase.as<uint32_t>();
     a.slot_w = c->ws[WS_SLOT_W].as<uint32_t>(); a.slot_cnt = c->ws[WS_SLOT_CNT].as<uint32_t>();
     a.slot_off = c->ws[WS_SLOT_OFF].as<uint32_t>(); a.slot_cursor = c->ws[WS_SLOT_CURSOR].as<uint32_t>();
-    a.ekey = c->ws[WS_EKEY].as<uint32_t>(); a.eev = c->ws[WS_EEV].as<uint32_t>(); a.emeta = c->ws[WS_EMETA].as<uint32_t>();
+    a.ent = c->ws[WS_ENT].as<uint4>();
     a.slot_list = c->ws[WS_SLOT_LIST].as<uint32_t>(); a.multi_list = c->ws[WS_MULTI_LIST].as<uint32_t>();
     a.macc = c->ws[WS_MACC].as<uint32_t>();
     a.slices = c->ws[WS_SLICES].as<uint32_t>(); a.huge_list = c->ws[WS_HUGE_LIST].as<uint32_t>();
@@ -1005,15 +1005,14 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
     const uint64_t slot_cap = ne_cap + EU / SUBT + 16;
 
     if (c->d_read_key.reserve((size_t)(R + 1) * 4) || c->d_unit_cnt.reserve(((size_t)n_units + 2) * 4) ||
-        c->ws[WS_UNIT_SLOT].reserve(((size_t)n_units + 2) * 4) || c->ws[WS_UNIT_NSUB].reserve(((size_t)n_units + 2) * 4) ||
+        c->ws[WS_UNIT_PLAN].reserve(((size_t)n_units + 2) * 8) ||
         c->d_scalars.reserve(SC_COUNT * 8) || c->d_ne_units.reserve((ne_cap + 2) * 4) || c->d_ne_mask.reserve((ne_cap + 2) * 8) ||
         c->d_ne_rowbase.reserve((ne_cap + 2) * 4) || c->ws[WS_NE_NSLOT].reserve((ne_cap + 2) * 4) ||
         c->ws[WS_NE_SLOT_BASE].reserve((ne_cap + 2) * 4) || c->ws[WS_NE_ACC].reserve((ne_cap + 2) * 4) ||
         c->ws[WS_NE_GEOM].reserve((ne_cap + 2) * 8) || c->ws[WS_SLOT_W].reserve((slot_cap + 2) * 4) ||
         c->ws[WS_SLOT_CNT].reserve((slot_cap + 2) * 4) || c->ws[WS_SLOT_OFF].reserve((slot_cap + 2) * 4) ||
         c->ws[WS_SLOT_CURSOR].reserve((slot_cap + 2) * 4) || c->ws[WS_SLOT_LIST].reserve((slot_cap + 2) * 4) ||
-        c->ws[WS_MULTI_LIST].reserve((EU / CAPB + 16) * 4) || c->ws[WS_EKEY].reserve((EU + 1) * 4) ||
-        c->ws[WS_EEV].reserve((EU + 1) * 4) || c->ws[WS_EMETA].reserve((EU + 1) * 4) ||
+        c->ws[WS_MULTI_LIST].reserve((EU / CAPB + 16) * 4) || c->ws[WS_ENT].reserve((EU + 1) * 16) ||
         c->ws[WS_SLICES].reserve((slot_cap + 2) * (NSLICE + 1) * 4) || c->ws[WS_HUGE_LIST].reserve((EU / CAPB + 16) * 4))
         return -1;
 
