@@ -97,7 +97,7 @@ typedef struct {
 /* One step-1 call record per merged site (fixed size; the host formats the TSV line).
  * p-values are stored as the integer k with p = k / 10000 after Python round(x, 4)
  * (round-half-even on the exact binary value). */
-#define LSG_CALL_MAX_ALT 3
+#define LSG_CALL_MAX_ALT 4   /* 4 when REF is not one of A,C,G,T (IUPAC reference base) */
 typedef struct {
     int64_t  key;                       /* (tid << 32) | pos0                                   */
     uint8_t  ref;                       /* reference base (ASCII, upper)                        */
@@ -113,8 +113,8 @@ typedef struct {
     int32_t  p_cc[LSG_MAX_CELLTYPES][LSG_CALL_MAX_ALT];
     uint32_t site_filter;               /* bit set, enum lsg_site_filter                        */
     int32_t  cell_types_min;            /* Cell_types_min_BC == Cell_types_min_CC               */
-    uint32_t sum_alts_bc, sum_dp, sum_alts_cc, sum_nc;    /* Rest_BC / Rest_CC                  */
-    int32_t  noise_p_bc, noise_p_cc;    /* round(1-cdf,4)*1e4, or -1 when Sum_alts_bc == 0 (prints "1") */
+    int32_t  sum_alts_bc, sum_dp, sum_alts_cc, sum_nc;    /* Rest_BC / Rest_CC; sum_nc can be negative (step1.py:256) */
+    int32_t  noise_p_bc, noise_p_cc;    /* round(1-cdf,4)*1e4; -1 when Sum_alts_bc == 0 (prints "1"); -2 = nan (negative n) */
     uint8_t  up_ctx[5], down_ctx[5];    /* ASCII; up_ctx[0]==0 => "." (POS < 6)                 */
     uint8_t  pad[2];
 } lsg_call;
@@ -166,6 +166,13 @@ int lsg_pileup_count(lsg_ctx* ctx, const lsg_count_params* params, int64_t* n_ro
 /* Copies cell type ct's rows to the host in genomic order (tid, pos ascending):
  * keys[n] = (tid<<32)|pos0, ref[n] = reference base, counts[n*42]. */
 int lsg_fetch_counts(lsg_ctx* ctx, int32_t ct, int64_t* keys, uint8_t* ref, uint32_t* counts, int64_t capacity);
+
+/* Installs per-cell-type count rows (keys[c][i] = (tid<<32)|pos0 strictly ascending, counts[c] =
+ * n_rows[c] x 42 words) as if lsg_pileup_count had produced them: the file-level entry of the
+ * MergeCounts / BaseCellCalling_step1 rules, whose inputs are BaseCellCounter TSVs
+ * (R:SNVCalling.smk:62-156; merge_cell_types_files reads them at MergeBaseCellCounts.py:139-161). */
+int lsg_load_counts(lsg_ctx* ctx, int32_t n_celltypes, const int64_t* const* keys, const uint32_t* const* counts,
+                    const int64_t* n_rows);
 
 /* Outer join of the per-cell-type rows on (tid,pos) + step-1 arithmetic on every merged site;
  * replaces merge_cell_types_files (MergeBaseCellCounts.py:116-204) and variant_calling_step1

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "liblongsom_hip.so")
 
 ROW_WORDS = 42
 MAX_CELLTYPES = 4
-CALL_MAX_ALT = 3
+CALL_MAX_ALT = 4
 
 SYM_NAMES = ["A", "C", "T", "G", "I", "D", "N", "O"]
 SYM_NA = 15
@@ -81,7 +81,7 @@ class Call(C.Structure):
         ("p_cc", (C.c_int32 * CALL_MAX_ALT) * MAX_CELLTYPES),
         ("site_filter", C.c_uint32),
         ("cell_types_min", C.c_int32),
-        ("sum_alts_bc", C.c_uint32), ("sum_dp", C.c_uint32), ("sum_alts_cc", C.c_uint32), ("sum_nc", C.c_uint32),
+        ("sum_alts_bc", C.c_int32), ("sum_dp", C.c_int32), ("sum_alts_cc", C.c_int32), ("sum_nc", C.c_int32),
         ("noise_p_bc", C.c_int32), ("noise_p_cc", C.c_int32),
         ("up_ctx", C.c_uint8 * 5), ("down_ctx", C.c_uint8 * 5),
         ("pad", C.c_uint8 * 2),
@@ -117,6 +117,7 @@ SIGNATURES = {
     "lsg_copy_reference_to_host": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "lsg_pileup_count": (C.c_int, [C.c_void_p, C.POINTER(CountParams), C.c_void_p, C.c_void_p]),
     "lsg_fetch_counts": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
+    "lsg_load_counts": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "lsg_call_step1": (C.c_int, [C.c_void_p, C.POINTER(CallParams), C.c_void_p, C.c_void_p]),
     "lsg_fetch_calls": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
     "lsg_load_posset": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int32]),

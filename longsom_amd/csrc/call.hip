@@ -1,7 +1,356 @@
-// placeholder TU replaced below in this round (step-1 call kernel + position-set probe)
+// Outer join of the per-cell-type count rows + step-1 beta-binomial call, and position-set probes.
+//
+// Replaces
+//   merge_cell_types_files     workflow/scripts/SNVCalling/MergeBaseCellCounts.py:116-204
+//   variant_calling_step1      workflow/scripts/SNVCalling/BaseCellCalling.step1.py:19-476
+//   build_dict / membership    workflow/scripts/SNVCalling/BaseCellCalling.step2.py:142-158,197-221
+//
+// One lane per merged site: the units (tile, cell type) of one tile are adjacent in the non-empty
+// unit list, their 64-bit emit masks OR-ed give the tile's sites, and a site's row of cell type c is
+// rowbase_c + popcount(mask_c below the lane).  The beta-binomial upper tail P(X >= k) that scipy's
+// generic rv_discrete.sf evaluates as 1 - sum_{m<k} exp(logpmf(m)) (step1.py:196,201,329-330) is
+// summed here in fp64 from the shorter side with the pmf ratio recurrence, re-anchored with lgamma
+// every 1024 terms; p-values are stored as Python round(p, 4) * 1e4 (exact half-even on the binary
+// value).  Arithmetic type f64; the text the host prints is identical whenever |p - tie| > ~1e-13.
 #include "lsg_ctx.h"
+#include <hipcub/hipcub.hpp>
+
 namespace lsg {
-int run_call(lsg_ctx*, const lsg_call_params*) { set_error("lsg_call_step1: not built yet"); return -9; }
-int run_fetch_calls(lsg_ctx*, lsg_call*, int64_t, int, int64_t*) { set_error("lsg_fetch_calls: not built yet"); return -9; }
-int run_probe(lsg_ctx*, int, const int64_t*, int64_t, uint8_t*, int) { set_error("lsg_probe_posset: not built yet"); return -9; }
+
+struct CallArgs {
+    const uint32_t* ne_units; const uint64_t* ne_mask; const uint32_t* ne_rowbase; const int2* ne_geom;
+    uint32_t n_ne; int32_t n_ct;
+    const uint32_t* rows[LSG_MAX_CELLTYPES]; uint64_t row_cap;
+    const uint8_t* const* ref_ptr; const int64_t* contig_len;
+    lsg_call_params p;
+    uint32_t* site_cnt; uint32_t* site_off;
+    lsg_call* out;
+    unsigned long long* counters;    // [0] candidates
+};
+
+// log of the beta-binomial pmf at m (scipy betabinom._logpmf written with lgamma)
+__device__ __forceinline__ double bb_logpmf(double m, double n, double a, double b) {
+    return lgamma(n + 1.0) - lgamma(m + 1.0) - lgamma(n - m + 1.0) + lgamma(m + a) + lgamma(n - m + b) - lgamma(n + a + b) +
+           lgamma(a + b) - lgamma(a) - lgamma(b);
 }
+
+// P(X >= k) for X ~ BetaBinomial(n, a, b), k >= 1 integer, n >= 0.
+__device__ double bb_upper_tail(uint32_t k, uint32_t n, double a, double b) {
+    if (k == 0) return 1.0;
+    if (k > n) return 0.0;                         // 1 - sum of the whole pmf; canonical 0.0
+    const double dn = (double)n;
+    if ((uint64_t)k <= (uint64_t)n - k + 1) {      // lower side is shorter: 1 - sum_{m<k} pmf(m)
+        double sum = 0.0, pm = 0.0;
+        for (uint32_t m = 0; m < k; ++m) {
+            if ((m & 1023u) == 0) pm = exp(bb_logpmf((double)m, dn, a, b));
+            else { const double mm = (double)(m - 1); pm *= (dn - mm) * (mm + a) / ((mm + 1.0) * (dn - mm - 1.0 + b)); }
+            sum += pm;
+        }
+        return 1.0 - sum;
+    }
+    double sum = 0.0, pm = 0.0;                    // upper side: sum_{m=k}^{n} pmf(m), descending from n
+    uint32_t cnt = 0;
+    for (uint32_t m = n;; --m) {
+        if ((cnt & 1023u) == 0) pm = exp(bb_logpmf((double)m, dn, a, b));
+        else { const double mm = (double)m; pm *= (mm + 1.0) * (dn - mm - 1.0 + b) / ((dn - mm) * (mm + a)); }
+        sum += pm;
+        ++cnt;
+        if (m == k) break;
+    }
+    return sum;
+}
+
+// Python round(x, 4) * 10^4 as an integer: half-even on the exact binary value of x.
+__device__ __forceinline__ int32_t round4(double x) {
+    if (!(x > 0.0)) return 0;                      // negative fp noise and -0.0 print as 0.0 (canonical)
+    const double hi = x * 1e4;
+    const double lo = fma(x, 1e4, -hi);
+    double k = rint(hi);                           // half-even
+    const double d = (hi - k) + lo;                // exact distance to k unless |lo| is absorbed (then irrelevant)
+    if (d > 0.5) k += 1.0;
+    else if (d < -0.5) k -= 1.0;
+    else if (d == 0.5 && (hi - k) != 0.5) { if (fmod(k, 2.0) != 0.0) k += 1.0; }
+    else if (d == -0.5 && (hi - k) != -0.5) { if (fmod(k, 2.0) != 0.0) k -= 1.0; }
+    return (int32_t)k;
+}
+
+__device__ __forceinline__ int sym_of_ref(uint8_t b) { return b == 'A' ? 0 : b == 'C' ? 1 : b == 'T' ? 2 : b == 'G' ? 3 : -1; }
+__device__ __forceinline__ uint8_t base_of_sym(int s) { return s == 0 ? 'A' : s == 1 ? 'C' : s == 2 ? 'T' : 'G'; }
+
+__global__ void k_site_count(CallArgs a) {
+    uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w > a.n_ne) return;
+    uint32_t v = 0;
+    if (w < a.n_ne) {
+        const uint32_t tile = a.ne_units[w] / (uint32_t)a.n_ct;
+        const bool head = w == 0 || a.ne_units[w - 1] / (uint32_t)a.n_ct != tile;
+        if (head) {
+            uint64_t m = 0;
+            for (uint32_t q = w; q < a.n_ne && a.ne_units[q] / (uint32_t)a.n_ct == tile; ++q) m |= a.ne_mask[q];
+            v = (uint32_t)__popcll(m);
+        }
+    }
+    a.site_cnt[w] = v;
+}
+
+__global__ __launch_bounds__(256) void k_call(CallArgs a) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t w = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (w >= a.n_ne) return;
+    const uint32_t tile = a.ne_units[w] / (uint32_t)a.n_ct;
+    if (w > 0 && a.ne_units[w - 1] / (uint32_t)a.n_ct == tile) return;      // not the head of its tile
+    uint64_t mask[LSG_MAX_CELLTYPES] = {0, 0, 0, 0};
+    uint32_t rbase[LSG_MAX_CELLTYPES] = {0, 0, 0, 0};
+    uint64_t any = 0;
+    for (uint32_t q = w; q < a.n_ne && a.ne_units[q] / (uint32_t)a.n_ct == tile; ++q) {
+        const int ct = (int)(a.ne_units[q] % (uint32_t)a.n_ct);
+        mask[ct] = a.ne_mask[q]; rbase[ct] = a.ne_rowbase[q]; any |= mask[ct];
+    }
+    if (!((any >> lane) & 1ull)) return;
+    const uint64_t below = (1ull << lane) - 1ull;
+    const uint64_t idx = (uint64_t)a.site_off[w] + __popcll(any & below);
+    const int2 geom = a.ne_geom[w];
+    const int tid = geom.y & 0xffffff;
+    const int64_t pos = (int64_t)geom.x + lane;
+    const uint8_t* ref = a.ref_ptr[tid];
+    const uint8_t refb = ref[pos];
+    const int rsym = sym_of_ref(refb);
+    const lsg_call_params& P = a.p;
+
+    lsg_call c;
+    memset(&c, 0, sizeof(c));
+    c.key = ((int64_t)tid << 32) | pos;
+    c.ref = refb;
+    int32_t sum_alts_bc = 0, sum_alts_cc = 0, sum_dp = 0, sum_nc = 0;
+    int n_considered = 0, n_pass = 0, n_nonsig = 0, n_with_cand = 0;
+    bool any_multi = false, alts_differ = false;
+    uint32_t first_altset = 0; bool have_first = false;
+    // letter order A < C < G < T over symbol classes (A,C,T,G) = (0,1,2,3)
+    const int order[4] = {0, 1, 3, 2};
+    // homopolymer context (step1.py:95-107): up = ref[pos-5..pos-1], down = ref[pos+1..pos+5]
+    const int64_t clen = a.contig_len[tid];
+    const bool have_ctx = pos >= 5;
+    int down_len = 0;
+    if (have_ctx) {
+        for (int i = 0; i < 5; ++i) c.up_ctx[i] = ref[pos - 5 + i];
+        down_len = (int)((clen - (pos + 1)) < 5 ? (clen - (pos + 1)) : 5);
+        if (down_len < 0) down_len = 0;
+        for (int i = 0; i < down_len; ++i) c.down_ctx[i] = ref[pos + 1 + i];
+    }
+    int lc_up = 0, lc_down = 0;
+
+    for (int ct = 0; ct < a.n_ct; ++ct) {
+        if (!((mask[ct] >> lane) & 1ull)) continue;
+        c.present |= (uint8_t)(1u << ct);
+        const uint64_t row = (uint64_t)rbase[ct] + __popcll(mask[ct] & below);
+        const uint32_t* R = a.rows[ct];
+        const uint64_t cap = a.row_cap;
+        const uint32_t dp = R[0 * cap + row], nc = R[1 * cap + row];
+        if (!((int)dp >= P.min_cov && (int)nc >= P.min_cells)) continue;      // step1.py:174
+        c.considered |= (uint8_t)(1u << ct);
+        ++n_considered;
+        uint32_t cc[6], bc[6];
+#pragma unroll
+        for (int s = 0; s < 6; ++s) { cc[s] = R[(2 + s) * cap + row]; bc[s] = R[(10 + s) * cap + row]; }
+        uint32_t alts2 = 0, cc2 = 0;                                           // :187-190 (I and D included)
+#pragma unroll
+        for (int s = 0; s < 6; ++s) if (s != rsym) { alts2 += bc[s]; cc2 += cc[s]; }
+        sum_alts_bc += (int32_t)alts2; sum_alts_cc += (int32_t)cc2; sum_dp += (int32_t)dp; sum_nc += (int32_t)nc;
+        // candidates: every observed A/C/T/G alt (:195-208), in letter order
+        int na = 0; uint32_t altset = 0;
+        int32_t min_pbc = 100000, min_pcc = 100000;
+        uint32_t b0 = 0, c0 = 0;
+#pragma unroll
+        for (int oi = 0; oi < 4; ++oi) {
+            const int s = order[oi];
+            if (s == rsym || bc[s] == 0) continue;
+            const int32_t pb = round4(bb_upper_tail(bc[s], dp, P.alpha1, P.beta1));
+            const int32_t pc = round4(bb_upper_tail(cc[s], nc, P.alpha2, P.beta2));
+            if (na < LSG_CALL_MAX_ALT) {
+                c.alt[ct][na] = (uint8_t)s; c.alt_bc[ct][na] = bc[s]; c.alt_cc[ct][na] = cc[s];
+                c.p_bc[ct][na] = pb; c.p_cc[ct][na] = pc;
+            }
+            ++na; altset |= 1u << s;
+            min_pbc = pb < min_pbc ? pb : min_pbc; min_pcc = pc < min_pcc ? pc : min_pcc;
+            b0 += bc[s]; c0 += cc[s];
+        }
+        c.n_alt[ct] = (uint8_t)na;
+        if (na == 0) continue;
+        c.has_cand |= (uint8_t)(1u << ct);
+        ++n_with_cand;
+        if (!have_first) { first_altset = altset; have_first = true; } else if (altset != first_altset) alts_differ = true;
+        sum_dp -= (int32_t)b0; sum_nc -= (int32_t)c0; sum_alts_bc -= (int32_t)b0; sum_alts_cc -= (int32_t)c0;     // :253-258
+        // per-cell-type filter chain (:263-277); thresholds on the rounded values
+        uint8_t f;
+        if (min_pbc >= 500 || min_pcc >= 500) f = LSG_CF_NONSIG;
+        else if ((min_pbc > 10 && min_pbc < 500) || (min_pcc > 10 && min_pcc < 500)) f = LSG_CF_LOWSIG;
+        else if (na > 1) f = LSG_CF_MULTI;
+        else if ((int)c.alt_cc[ct][0] < P.min_ac_cells) f = LSG_CF_LOW_CELLS;
+        else if ((int)c.alt_bc[ct][0] < P.min_ac_reads) f = LSG_CF_LOW_READS;
+        else f = LSG_CF_PASS;
+        c.ct_filter[ct] = f;
+        n_pass += f == LSG_CF_PASS; n_nonsig += f == LSG_CF_NONSIG; any_multi |= f == LSG_CF_MULTI;
+        // homopolymer runs including the alt string "A" or "A|C|.." (:511-529): only the first / last
+        // letter of the string touches the context
+        if (have_ctx) {
+            int first_s = -1, last_s = -1;
+            for (int oi = 0; oi < 4; ++oi) { const int s = order[oi]; if ((altset >> s) & 1u) { if (first_s < 0) first_s = s; last_s = s; } }
+            // upstream: longestRun(up + x)
+            int best = 1, run = 1;
+            for (int i = 1; i < 5; ++i) { run = c.up_ctx[i] == c.up_ctx[i - 1] ? run + 1 : 1; best = run > best ? run : best; }
+            run = base_of_sym(first_s) == c.up_ctx[4] ? run + 1 : 1; best = run > best ? run : best;
+            lc_up = best > lc_up ? best : lc_up;
+            // downstream: longestRun(x + down)
+            best = 1; run = 1;
+            uint8_t prev = base_of_sym(last_s);
+            for (int i = 0; i < down_len; ++i) { run = c.down_ctx[i] == prev ? run + 1 : 1; best = run > best ? run : best; prev = c.down_ctx[i]; }
+            lc_down = best > lc_down ? best : lc_down;
+        }
+    }
+    c.cell_types_min = n_considered;
+    c.sum_alts_bc = sum_alts_bc; c.sum_dp = sum_dp; c.sum_alts_cc = sum_alts_cc; c.sum_nc = sum_nc;
+    c.noise_p_bc = -1; c.noise_p_cc = -1;
+    if (sum_alts_bc > 0) {                                                     // :328-337 / :426-435
+        // a negative n (cells carrying several alleles make Sum_nc - c0 negative) is outside scipy's
+        // support: betabinom.cdf returns nan, which prints as "nan" and fails every "<" test
+        c.noise_p_bc = sum_dp < 0 ? -2 : round4(bb_upper_tail((uint32_t)sum_alts_bc, (uint32_t)sum_dp, P.alpha1, P.beta1));
+        c.noise_p_cc = (sum_nc < 0 || sum_alts_cc < 0) ? -2 : round4(bb_upper_tail((uint32_t)sum_alts_cc, (uint32_t)sum_nc, P.alpha2, P.beta2));
+    }
+    const bool bc_lt05 = c.noise_p_bc >= 0 && c.noise_p_bc < 500, cc_lt05 = c.noise_p_cc >= 0 && c.noise_p_cc < 500;
+    const bool bc_lt001 = c.noise_p_bc >= 0 && c.noise_p_bc < 10, cc_lt001 = c.noise_p_cc >= 0 && c.noise_p_cc < 10;
+    uint32_t sf = 0;
+    if (n_with_cand > 0) {
+        sf |= LSG_SF_CANDIDATE;
+        if (n_pass > P.max_cell_types) sf |= LSG_SF_MULTIPLE_CELL_TYPES;       // :309
+        if (alts_differ || any_multi) sf |= LSG_SF_MULTI_ALLELIC;              // :313-315
+        if (n_considered < P.min_cell_types) sf |= LSG_SF_MIN_CELL_TYPES;      // :318
+        if (n_with_cand - n_pass - n_nonsig > 0) sf |= LSG_SF_CELL_TYPE_NOISE; // :322
+        if (sum_alts_bc > 0 && (bc_lt05 || cc_lt05)) sf |= LSG_SF_NOISY_SITE;   // :342
+        if (have_ctx && lc_up >= 4) sf |= LSG_SF_LC_UP;                        // :347-354
+        if (have_ctx && lc_down >= 4) sf |= LSG_SF_LC_DOWN;
+        atomicAdd(&a.counters[0], 1ull);
+    } else if (sum_alts_bc > 0 && (bc_lt001 || cc_lt001)) {
+        sf |= LSG_SF_NOISY_SITE;                                               // :440-442
+    }
+    c.site_filter = sf;
+    a.out[idx] = c;
+}
+
+__global__ void k_probe(const int64_t* set, int64_t n_set, const int64_t* keys, int64_t n, uint8_t* hits) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t key = keys[i];
+    int64_t lo = 0, hi = n_set;
+    while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (set[mid] < key) lo = mid + 1; else hi = mid; }
+    hits[i] = (lo < n_set && set[lo] == key) ? 1 : 0;
+}
+
+int run_call(lsg_ctx* c, const lsg_call_params* p) {
+    if (!c->counted) { set_error("lsg_call_step1: call lsg_pileup_count first"); return -2; }
+    hipStream_t st = c->stream;
+    const uint32_t n_ne = c->n_ne;
+    c->n_sites = 0; c->n_cand = 0;
+    if (n_ne == 0) { c->called = true; return 0; }
+    if (c->d_site_off.reserve((size_t)(n_ne + 2) * 8 + 64)) return -1;
+    CallArgs a{};
+    a.ne_units = c->d_ne_units.as<uint32_t>(); a.ne_mask = c->d_ne_mask.as<uint64_t>(); a.ne_rowbase = c->d_ne_rowbase.as<uint32_t>();
+    a.ne_geom = c->ws[WS_NE_GEOM].as<int2>();
+    a.n_ne = n_ne; a.n_ct = c->n_ct;
+    for (int i = 0; i < LSG_MAX_CELLTYPES; ++i) a.rows[i] = c->d_rows[i].as<uint32_t>();
+    a.row_cap = c->row_cap;
+    a.ref_ptr = c->d_ref_ptrs.as<const uint8_t*>(); a.contig_len = c->d_contig_len.as<int64_t>();
+    a.p = *p;
+    a.site_cnt = c->d_site_off.as<uint32_t>();
+    a.site_off = a.site_cnt + (n_ne + 2);
+    a.counters = reinterpret_cast<unsigned long long*>(a.site_off + (n_ne + 2));   // 2*(n_ne+2) words: 8-byte aligned
+    LSG_HIP(hipMemsetAsync(a.counters, 0, 16, st));
+    hipLaunchKernelGGL(k_site_count, dim3((n_ne + 256) / 256), dim3(256), 0, st, a);
+    size_t tb = 0;
+    LSG_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, a.site_cnt, a.site_off, (int)(n_ne + 1), st));
+    if (c->d_cub_tmp.reserve(tb + 256)) return -1;
+    tb = c->d_cub_tmp.cap;
+    LSG_HIP(hipcub::DeviceScan::ExclusiveSum(c->d_cub_tmp.p, tb, a.site_cnt, a.site_off, (int)(n_ne + 1), st));
+    uint32_t n_sites = 0;
+    LSG_HIP(hipMemcpyAsync(&n_sites, a.site_off + n_ne, 4, hipMemcpyDeviceToHost, st));
+    LSG_HIP(hipStreamSynchronize(st));
+    if (n_sites > 0) {
+        if (c->d_calls.reserve((size_t)n_sites * sizeof(lsg_call))) return -1;
+        a.out = c->d_calls.as<lsg_call>();
+        const uint64_t threads = (uint64_t)n_ne * 64;
+        hipLaunchKernelGGL(k_call, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, a);
+        LSG_HIP(hipGetLastError());
+    }
+    unsigned long long cand = 0;
+    LSG_HIP(hipMemcpyAsync(&cand, a.counters, 8, hipMemcpyDeviceToHost, st));
+    LSG_HIP(hipStreamSynchronize(st));
+    c->n_sites = n_sites; c->n_cand = (int64_t)cand;
+    c->called = true;
+    return 0;
+}
+
+__global__ void k_flag_keep(const lsg_call* calls, int64_t n, uint8_t* keep) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) keep[i] = calls[i].site_filter != 0;      // ALT != "." or FILTER != "."
+}
+
+int run_fetch_calls(lsg_ctx* c, lsg_call* out, int64_t capacity, int candidates_only, int64_t* n_out) {
+    if (!c->called) { set_error("lsg_fetch_calls: call lsg_call_step1 first"); return -2; }
+    hipStream_t st = c->stream;
+    const int64_t n = c->n_sites;
+    if (n_out) *n_out = 0;
+    if (n == 0) return 0;
+    if (!candidates_only) {
+        if (capacity < n) { set_error("lsg_fetch_calls: capacity %lld < %lld sites", (long long)capacity, (long long)n); return -2; }
+        LSG_HIP(hipMemcpyAsync(out, c->d_calls.p, (size_t)n * sizeof(lsg_call), hipMemcpyDeviceToHost, st));
+        LSG_HIP(hipStreamSynchronize(st));
+        if (n_out) *n_out = n;
+        return 0;
+    }
+    DevBuf flags, sel, nsel;
+    int rc = 0;
+    if (flags.reserve((size_t)n) || sel.reserve((size_t)n * sizeof(lsg_call)) || nsel.reserve(16)) rc = -1;
+    int64_t k = 0;
+    if (!rc) {
+        hipLaunchKernelGGL(k_flag_keep, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, c->d_calls.as<lsg_call>(), n, flags.as<uint8_t>());
+        size_t tb = 0;
+        hipError_t e = hipcub::DeviceSelect::Flagged(nullptr, tb, c->d_calls.as<lsg_call>(), flags.as<uint8_t>(), sel.as<lsg_call>(), nsel.as<int64_t>(), (int)n, st);
+        if (e == hipSuccess && c->d_cub_tmp.reserve(tb + 256) == 0) {
+            tb = c->d_cub_tmp.cap;
+            e = hipcub::DeviceSelect::Flagged(c->d_cub_tmp.p, tb, c->d_calls.as<lsg_call>(), flags.as<uint8_t>(), sel.as<lsg_call>(), nsel.as<int64_t>(), (int)n, st);
+        }
+        if (e != hipSuccess || hipMemcpyAsync(&k, nsel.p, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+            set_error("lsg_fetch_calls: select failed: %s", hipGetErrorString(hipGetLastError())); rc = -1;
+        }
+    }
+    if (!rc && k > capacity) { set_error("lsg_fetch_calls: capacity %lld < %lld rows", (long long)capacity, (long long)k); rc = -2; }
+    if (!rc && k > 0 && (hipMemcpyAsync(out, sel.p, (size_t)k * sizeof(lsg_call), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)) {
+        set_error("lsg_fetch_calls: copy failed"); rc = -1;
+    }
+    if (!rc && n_out) *n_out = k;
+    flags.release(); sel.release(); nsel.release();
+    return rc;
+}
+
+int run_probe(lsg_ctx* c, int kind, const int64_t* keys, int64_t n, uint8_t* hits, int on_device) {
+    PosSet& s = c->posset[kind];
+    hipStream_t st = c->stream;
+    if (n == 0) return 0;
+    DevBuf dk, dh;
+    const int64_t* k = keys; uint8_t* h = hits;
+    int rc = 0;
+    if (!on_device) {
+        if (dk.reserve((size_t)n * 8) || dh.reserve((size_t)n)) { dk.release(); dh.release(); return -1; }
+        if (hipMemcpyAsync(dk.p, keys, (size_t)n * 8, hipMemcpyHostToDevice, st) != hipSuccess) rc = -1;
+        k = dk.as<int64_t>(); h = dh.as<uint8_t>();
+    }
+    if (!rc) {
+        hipLaunchKernelGGL(k_probe, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s.keys.as<int64_t>(), s.n, k, n, h);
+        if (!on_device && hipMemcpyAsync(hits, dh.p, (size_t)n, hipMemcpyDeviceToHost, st) != hipSuccess) rc = -1;
+        if (hipStreamSynchronize(st) != hipSuccess) rc = -1;
+    }
+    if (rc) set_error("lsg_probe_posset: %s", hipGetErrorString(hipGetLastError()));
+    dk.release(); dh.release();
+    return rc;
+}
+
+} // namespace lsg

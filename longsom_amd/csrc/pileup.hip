@@ -46,11 +46,6 @@ enum { SC_QSMALL = 0, SC_QBIG = 1, SC_NNE = 2, SC_NSLOTS = 3, SC_ROWALLOC = 4, S
        SC_ROWS = 16, SC_NSMALL = 20, SC_NMULTI = 21, SC_NMULTI_SEL = 22, SC_QGROUP = 23, SC_NHUGE = 24, SC_QHUGE = 25,
        SC_COUNT = 28 };
 
-// workspace buffers (lsg_ctx::ws)
-enum { WS_UNIT_PLAN = 0, WS_UNUSED1, WS_NE_NSLOT, WS_NE_SLOT_BASE, WS_NE_ACC, WS_NE_GEOM, WS_SLOT_W, WS_SLOT_CNT,
-       WS_SLOT_OFF, WS_SLOT_CURSOR, WS_ENT, WS_UNUSED2, WS_UNUSED3, WS_SLOT_LIST, WS_MULTI_LIST, WS_MACC, WS_EXPORT_K, WS_EXPORT_R,
-       WS_EXPORT_C, WS_SLICES, WS_HUGE_LIST };
-
 struct CountArgs {
     // reads
     int64_t n_reads, n_segs;

@@ -190,6 +190,18 @@ class Engine:
             _lib.check(self._lib.lsg_fetch_counts(self._h, ct, _ptr(keys), _ptr(ref), _ptr(counts), n), "lsg_fetch_counts")
         return keys, ref, counts
 
+    def load_counts(self, keys_per_ct, counts_per_ct):
+        """Install per-cell-type count rows (parsed from BaseCellCounter TSVs) instead of running the pileup."""
+        n_ct = len(keys_per_ct)
+        ks = [np.ascontiguousarray(k, dtype=np.int64) for k in keys_per_ct]
+        cs = [np.ascontiguousarray(c, dtype=np.uint32).reshape(-1, ROW_WORDS) for c in counts_per_ct]
+        kp = (C.c_void_p * n_ct)(*[k.ctypes.data for k in ks])
+        cp = (C.c_void_p * n_ct)(*[c.ctypes.data for c in cs])
+        nr = (C.c_int64 * n_ct)(*[len(k) for k in ks])
+        _lib.check(self._lib.lsg_load_counts(self._h, n_ct, kp, cp, nr), "lsg_load_counts")
+        self.n_ct = n_ct
+        self._n_rows = [len(k) for k in ks]
+
     def count_stats(self) -> CountStats:
         s = CountStats()
         _lib.check(self._lib.lsg_get_count_stats(self._h, C.byref(s)), "lsg_get_count_stats")

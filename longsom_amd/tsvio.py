@@ -1,0 +1,225 @@
+"""Text side of the rule contract: the TSVs LongSom's SNV rules exchange.
+
+Writers reproduce, byte for byte (except the wall-clock ##fileDate line):
+  BaseCellCounter output      workflow/scripts/SNVCalling/BaseCellCounter.py:54-61,297-312 (rows in
+                              python-string chromosome order then position, :64-70)
+  MergeBaseCellCounts output  workflow/scripts/SNVCalling/MergeBaseCellCounts.py:59-86,134-137,170-172
+  BaseCellCalling.step1 out   workflow/scripts/SNVCalling/BaseCellCalling.step1.py:48-76,398-401,464-467
+Parsers read the same files back into the arrays the C-ABI takes (lsg_load_counts).
+"""
+import time
+from typing import List, Sequence
+
+import numpy as np
+
+from ._lib import ROW_WORDS
+
+ALLELES = ["A", "C", "T", "G", "I", "D", "N", "O"]
+INFO_FIELD = "DP|NC|CC|BC|BQ|BCf|BCr"
+_CONCEPTS = (
+    '##INFO=DP,Description="Depth of coverage">\n'
+    '##INFO=NC,Description="Number of different cells">\n'
+    '##INFO=CC,Description="Cell counts [A:C:T:G:I:D:N:O], where D means deletion, I insertion and O other type of character">\n'
+    '##INFO=BC,Description="Base counts [A:C:T:G:I:D:N:O], where D means deletion, I insertion and O other type of character">\n'
+    '##INFO=BQ,Description="Base quality sums [A:C:T:G:I:D:N:O], where D means deletion, I insertion and O other type of character">\n'
+    '##INFO=BCf,Description="Base counts in forward reads [A:C:T:G:I:D:N:O], where D means deletion, I insertion and O other type of character">\n'
+    '##INFO=BCr,Description="Base counts in reverse reads [A:C:T:G:I:D:N:O], where D means deletion, I insertion and O other type of character">\n')
+
+STEP1_INFO_LINES = [
+    "##INFO=ALT,Description=Alternative alleles found",
+    "##INFO=FILTER,Description=Filter status of the variant site",
+    "##INFO=Cell_types,Description=Cell type/s with the variant",
+    "##INFO=Up_context,Description=Up-stream bases in reference (4 bases)",
+    "##INFO=Down_context,Description=Down-stream bases in reference (4 bases)",
+    "##INFO=N_ALT,Description=Cell type/s with the variant",
+    "##INFO=Dp,Description=Depth of coverage (reads) in the cell type supporting the variant",
+    "##INFO=Nc,Description=Number of distinct cells found in the cell type with the mutation",
+    "##INFO=Bc,Description=Number of reads (base count) supporting the variants in the cell type with the mutation",
+    "##INFO=Cc,Description=Number of distinct cells supporting the variant in the cell type with the mutation",
+    "##INFO=VAF,Description=Variant allele frequency of variant in the cell type with the mutation",
+    "##INFO=MCF,Description=Cancer cell fraction (fraction of ditinct cells) supporting the alternative allele in the cell type with the mutation",
+    "##INFO=BCp,Description=Beta-binomial p-value for the variant allele (considering read counts)",
+    "##INFO=CCp,Description=Beta-binomial p-value for the variant allele (considering cell counts)",
+    "##INFO=Cell_types_min_BC,Description=Number of cell types with a minimum number of reads covering a site",
+    "##INFO=Cell_types_min_CC,Description=Number of cell types with a minimum number of distinct cells found in a specific site",
+    "##INFO=Rest_BC,Description=Base counts (reads) supporting other alternative alleles in this site. BC;DP;P-value (betabin)",
+    "##INFO=Rest_CC,Description=Cell counts supporting other alternative alleles in this site. CC;NC;P-value (betabin)",
+    "##INFO=Fisher_p,Description=Strand bias test. Fisher exact test p-value between forward and reverse reads in variant and reference allele",
+    "##INFO=Cell_type_Filter,Description=Filter status of the variant site in each cell type",
+]
+STEP1_COLUMNS = ["ALT", "FILTER", "Cell_types", "Up_context", "Down_context", "N_ALT", "Dp", "Nc", "Bc", "Cc", "VAF", "MCF", "BCp",
+                 "CCp", "Cell_types_min_BC", "Cell_types_min_CC", "Rest_BC", "Rest_CC", "Fisher_p", "Cell_type_Filter"]
+CT_FILTER_NAMES = ["", "Non-Significant", "Low-Significance", "Multi-allelic", "Low_cells", "Low_reads", "PASS"]
+SITE_FILTER_NAMES = [(1, "Multiple_cell_types"), (2, "Multi-allelic"), (4, "Min_cell_types"), (8, "Cell_type_noise"),
+                     (16, "Noisy_site"), (32, "LC_Upstream"), (64, "LC_Downstream")]
+SF_CANDIDATE = 1 << 31
+
+
+def file_date() -> str:
+    return "##fileDate=%s\n" % time.strftime("%d/%m/%Y")
+
+
+def chrom_order(contig_names: Sequence[str]) -> np.ndarray:
+    """rank[tid] of each contig in python string order (BaseCellCounter.py:64, MergeBaseCellCounts.py:111)."""
+    order = sorted(range(len(contig_names)), key=lambda i: contig_names[i])
+    rank = np.empty(len(contig_names), np.int64)
+    rank[order] = np.arange(len(contig_names))
+    return rank
+
+
+def sort_like_reference(keys: np.ndarray, contig_names: Sequence[str]) -> np.ndarray:
+    """permutation putting (tid,pos) keys into the reference's (chrom string, position) order"""
+    rank = chrom_order(contig_names)
+    tid = (keys >> 32).astype(np.int64)
+    pos = keys & 0xFFFFFFFF
+    return np.lexsort((pos, rank[tid]))
+
+
+def row_text(c: np.ndarray) -> str:
+    """'DP|NC|CC|BC|BQ|BCf|BCr' value string of one 42-word row (6 printed classes, BaseCellCounter.py:300-308)."""
+    j = lambda o: ":".join(map(str, c[o:o + 6].tolist()))
+    return "%d|%d|%s|%s|%s|%s|%s" % (c[0], c[1], j(2), j(10), j(18), j(26), j(34))
+
+
+def format_counts_tsv(keys, refs, counts, contig_names, sample_id, date_line=None) -> str:
+    out = [date_line or file_date(), _CONCEPTS, "\t".join(["#CHROM", "POS", "REF", "INFO", str(sample_id)]) + "\n"]
+    perm = sort_like_reference(keys, contig_names)
+    for i in perm.tolist():
+        k = int(keys[i])
+        out.append("%s\t%d\t%s\t%s\t%s\n" % (contig_names[k >> 32], (k & 0xFFFFFFFF) + 1, chr(int(refs[i])), INFO_FIELD, row_text(counts[i])))
+    return "".join(out)
+
+
+def parse_counts_tsv(path, contig_names):
+    """BaseCellCounter TSV -> keys int64 (tid<<32|pos0) ascending in (tid,pos), refs uint8, counts uint32 [n,42], sample id."""
+    tid_of = {n: i for i, n in enumerate(contig_names)}
+    keys, refs, rows = [], [], []
+    sample_id = None
+    with open(path) as f:
+        for line in f:
+            if line.startswith("##"):
+                continue
+            if line.startswith("#CHROM"):
+                sample_id = line.rstrip("\n").split("\t")[-1]
+                continue
+            line = line.rstrip("\n")
+            if not line:
+                continue
+            chrom, pos, ref, _info, data = line.split("\t")
+            dp, nc, cc, bc, bq, bcf, bcr = data.split("|")
+            r = np.zeros(ROW_WORDS, np.uint32)
+            r[0] = int(dp); r[1] = int(nc)
+            for off, vec in ((2, cc), (10, bc), (18, bq), (26, bcf), (34, bcr)):
+                v = [int(x) for x in vec.split(":")]
+                r[off:off + len(v)] = v
+            keys.append((tid_of[chrom] << 32) | (int(pos) - 1)); refs.append(ord(ref[0])); rows.append(r)
+    keys = np.asarray(keys, np.int64); refs = np.asarray(refs, np.uint8)
+    counts = np.stack(rows) if rows else np.zeros((0, ROW_WORDS), np.uint32)
+    perm = np.argsort(keys, kind="stable")
+    return keys[perm], refs[perm], counts[perm], sample_id
+
+
+def format_merged_tsv(per_ct, contig_names, celltype_names, date_line=None) -> str:
+    """per_ct: list of (keys, refs, counts) in (tid,pos) order.  Outer join on the site, 'NA' where a cell
+    type has no row (MergeBaseCellCounts.py:71-84)."""
+    out = [date_line or file_date(), _CONCEPTS, "\t".join(["#CHROM", "Start", "End", "REF", "INFO"] + list(celltype_names)) + "\n"]
+    all_keys = np.unique(np.concatenate([k for k, _, _ in per_ct])) if per_ct else np.zeros(0, np.int64)
+    idx = [dict(zip(k.tolist(), range(len(k)))) for k, _, _ in per_ct]
+    perm = sort_like_reference(all_keys, contig_names)
+    for i in perm.tolist():
+        k = int(all_keys[i])
+        cols, ref = [], None
+        refs_seen = []
+        for ct, (keys, refs, counts) in enumerate(per_ct):
+            j = idx[ct].get(k)
+            if j is None:
+                cols.append("NA")
+            else:
+                cols.append(row_text(counts[j])); refs_seen.append(chr(int(refs[j])))
+        # sort_set (MergeBaseCellCounts.py:48-57): distinct REFs by decreasing count, first-seen order on ties
+        ref = "|".join(sorted(dict.fromkeys(refs_seen), key=lambda r: -refs_seen.count(r)))
+        p1 = (k & 0xFFFFFFFF) + 1
+        out.append("%s\t%d\t%d\t%s\t%s\t%s\n" % (contig_names[k >> 32], p1, p1, ref, INFO_FIELD, "\t".join(cols)))
+    return "".join(out)
+
+
+def _p(k: int) -> str:
+    """text of Python round(p, 4) given k = round(p,4)*1e4 (str() of the rounded float)"""
+    return repr(k / 10000.0)
+
+
+def _ratio(a: int, b: int) -> str:
+    return str(round(a / float(b), 4))
+
+
+def format_step1_tsv(calls, per_ct, contig_names, celltype_names, header_lines: List[str]) -> str:
+    """calls: structured array of lsg_call records for EVERY merged site; per_ct as in format_merged_tsv.
+    header_lines: the '##' lines of the merged file (copied through, step1.py:34-35)."""
+    out = list(header_lines)
+    out += [l + "\n" for l in STEP1_INFO_LINES]
+    out.append("\t".join(["#CHROM", "Start", "End", "REF", "\t".join(STEP1_COLUMNS), "INFO"] + list(celltype_names)) + "\n")
+    n_ct = len(celltype_names)
+    idx = [dict(zip(k.tolist(), range(len(k)))) for k, _, _ in per_ct]
+    keys = calls["key"]
+    perm = sort_like_reference(keys, contig_names)
+    base = "ACTG"
+    for i in perm.tolist():
+        c = calls[i]
+        k = int(c["key"])
+        p1 = (k & 0xFFFFFFFF) + 1
+        cols = []
+        for ct in range(n_ct):
+            j = idx[ct].get(k)
+            cols.append("NA" if j is None else row_text(per_ct[ct][2][j]))
+        up = bytes(c["up_ctx"]).split(b"\0")[0].decode()
+        if not up:
+            up, down = ".", "."
+        else:
+            down = bytes(c["down_ctx"]).split(b"\0")[0].decode()
+        sf = int(c["site_filter"])
+        rest = []
+        for s_alt, s_tot, pk in ((c["sum_alts_bc"], c["sum_dp"], c["noise_p_bc"]), (c["sum_alts_cc"], c["sum_nc"], c["noise_p_cc"])):
+            rest.append("%d;%d;%s" % (s_alt, s_tot, "1" if int(c["sum_alts_bc"]) == 0 else ("nan" if int(pk) == -2 else _p(int(pk)))))
+        ctmin = str(int(c["cell_types_min"]))
+        if sf & SF_CANDIDATE:
+            alts, cts, dps, ncs, bcs, ccs, vafs, mcfs, bcps, ccps, flt = [], [], [], [], [], [], [], [], [], [], []
+            for ct in range(n_ct):
+                if not (int(c["has_cand"]) >> ct) & 1:
+                    continue
+                na = int(c["n_alt"][ct])
+                row = per_ct[ct][2][idx[ct][k]]
+                dp, nc = int(row[0]), int(row[1])
+                a = [base[int(c["alt"][ct][q])] for q in range(na)]
+                bc = [int(c["alt_bc"][ct][q]) for q in range(na)]
+                cc = [int(c["alt_cc"][ct][q]) for q in range(na)]
+                alts.append("|".join(a)); cts.append(celltype_names[ct]); dps.append(str(dp)); ncs.append(str(nc))
+                bcs.append("|".join(map(str, bc))); ccs.append("|".join(map(str, cc)))
+                vafs.append("|".join(_ratio(b, dp) for b in bc)); mcfs.append("|".join(_ratio(x, nc) for x in cc))
+                bcps.append("|".join(_p(int(c["p_bc"][ct][q])) for q in range(na)))
+                ccps.append("|".join(_p(int(c["p_cc"][ct][q])) for q in range(na)))
+                flt.append(CT_FILTER_NAMES[int(c["ct_filter"][ct])])
+            site = [name for bit, name in SITE_FILTER_NAMES if sf & bit]
+            if site:
+                FILTER = ",".join(site)
+            else:
+                FILTER = "PASS" if "PASS" in flt else ",".join(flt)
+            info = [",".join(alts), FILTER, ",".join(cts), up, down, str(len(set(alts))), ",".join(dps), ",".join(ncs), ",".join(bcs),
+                    ",".join(ccs), ",".join(vafs), ",".join(mcfs), ",".join(bcps), ",".join(ccps), ctmin, ctmin, rest[0], rest[1], ".",
+                    ",".join(flt)]
+        else:
+            FILTER = "Noisy_site" if sf & 16 else "."
+            info = [".", FILTER, ".", up, down, ".", ".", ".", ".", ".", ".", ".", ".", ".", ctmin, ctmin, rest[0], rest[1], ".", "."]
+        out.append("%s\t%d\t%d\t%s\t%s\t%s\t%s\n" % (contig_names[k >> 32], p1, p1, chr(int(c["ref"])), "\t".join(info), INFO_FIELD, "\t".join(cols)))
+    return "".join(out)
+
+
+def read_fasta(path):
+    """Whole FASTA -> (names, list of upper-cased uint8 arrays).  inFasta.fetch(...).upper(), BaseCellCounter.py:202-203."""
+    names, seqs, cur = [], [], None
+    with open(path, "rb") as f:
+        for line in f:
+            if line.startswith(b">"):
+                names.append(line[1:].split()[0].decode()); cur = []; seqs.append(cur)
+            elif cur is not None:
+                cur.append(line.strip())
+    return names, [np.frombuffer(b"".join(s).upper(), dtype=np.uint8).copy() for s in seqs]

@@ -1,0 +1,60 @@
+"""GPU: merge + step-1 call kernel against the golden step1 TSV written by the reference's own code."""
+import os
+
+import numpy as np
+import pytest
+
+from longsom_amd import tsvio
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def strip_date(text):
+    return "\n".join(l for l in text.split("\n") if not l.startswith("##fileDate="))
+
+
+def test_step1_matches_reference_golden(engine):
+    names, seqs = tsvio.read_fasta(os.path.join(G, "calling.ref.fa"))
+    engine.set_contigs([len(s) for s in seqs])
+    for t, s in enumerate(seqs):
+        engine.load_reference(t, s)
+    per_ct = [tsvio.parse_counts_tsv(os.path.join(G, "counts.sample.%s.tsv" % ct), names)[:3] for ct in ("Cancer", "Non-Cancer")]
+    engine.load_counts([p[0] for p in per_ct], [p[2] for p in per_ct])
+    n_sites, n_cand = engine.call_step1()
+    calls = engine.fetch_calls()
+    assert len(calls) == n_sites == len(np.unique(np.concatenate([p[0] for p in per_ct])))
+    header = [l for l in open(os.path.join(G, "merged.tsv")) if l.startswith("##")]
+    text = tsvio.format_step1_tsv(calls, per_ct, names, ["Cancer", "Non-Cancer"], header)
+    want = open(os.path.join(G, "sample.calling.step1.tsv")).read().replace("-0.0", "0.0")   # sign of fp noise
+    got_lines, want_lines = strip_date(text).split("\n"), strip_date(want).split("\n")
+    assert len(got_lines) == len(want_lines)
+    bad = [(g, w) for g, w in zip(got_lines, want_lines) if g != w]
+    assert not bad, "first mismatch:\n%s\n%s" % bad[0]
+    # the fetch filter keeps exactly the rows step2's awk keeps (ALT != "." and FILTER != "."), step2.py:23
+    cand = engine.fetch_calls(candidates_only=True)
+    n_awk = sum(1 for l in want_lines if l and not l.startswith("#") and l.split("\t")[4] != "." and l.split("\t")[5] != ".")
+    n_noisy_only = sum(1 for l in want_lines if l and not l.startswith("#") and l.split("\t")[4] == "." and l.split("\t")[5] != ".")
+    assert len(cand) == n_awk + n_noisy_only and n_cand == n_awk
+
+
+def test_betabinom_table(engine):
+    """k_call's tail sums against scipy (the reference's third-party arithmetic) through single-site inputs."""
+    import json
+    tab = json.load(open(os.path.join(G, "betabinom_table.json")))
+    a1, b1 = tab[0][0], tab[0][1]
+    rows = [t for t in tab if t[0] == a1 and t[1] == b1 and t[2] >= 5]
+    L = 64 * (len(rows) + 2)
+    engine.set_contigs([L]); engine.load_reference(0, np.full(L, ord("A"), np.uint8))
+    keys = np.arange(len(rows), dtype=np.int64) * 64 + 10
+    counts = np.zeros((len(rows), 42), np.uint32)
+    for i, (_, _, n, k, _, _) in enumerate(rows):
+        counts[i, 0] = n; counts[i, 1] = 5
+        counts[i, 10 + 0] = n - k; counts[i, 10 + 1] = k      # ref A, alt C
+        counts[i, 2 + 0] = 1 if n > k else 0; counts[i, 2 + 1] = 1
+    engine.load_counts([keys], [counts])
+    engine.call_step1()
+    calls = engine.fetch_calls()
+    for c, (_, _, n, k, sf, _) in zip(calls, rows):
+        got = repr(int(c["p_bc"][0][0]) / 10000.0)
+        assert got == sf.replace("-0.0", "0.0"), (n, k, got, sf)
