@@ -181,6 +181,12 @@ int lsg_call_step1(lsg_ctx* ctx, const lsg_call_params* params, int64_t* n_sites
 /* Copies call records in genomic order; candidates_only != 0 keeps rows with ALT != "." or FILTER != "." */
 int lsg_fetch_calls(lsg_ctx* ctx, lsg_call* out, int64_t capacity, int32_t candidates_only, int64_t* n_out);
 
+/* Compacts call records, in genomic order, into a caller-owned DEVICE buffer (e.g. a torch tensor
+ * handed to an RCCL all-gather): kind 0 = every site, 1 = rows step 2 keeps (ALT != "." or
+ * FILTER != "."), 2 = PASS candidates only (no site filter and a PASS cell type).  dst_device may be
+ * NULL to only count; *n_out receives the number of selected rows. */
+int lsg_export_calls(lsg_ctx* ctx, int32_t kind, void* dst_device, int64_t capacity, int64_t* n_out);
+
 /* Position sets (RNA-editing / PoN_SR / PoN_LR; build_dict, BaseCellCalling.step2.py:197-221):
  * sorted unique keys (tid<<32)|pos1 resident in HBM; kind in [0,3). */
 int lsg_load_posset(lsg_ctx* ctx, int32_t kind, const int64_t* keys, int64_t n, int32_t on_device);
@@ -196,6 +202,10 @@ typedef struct {
     int64_t n_events_wave, n_events_deep;  /* events loaded by k_pileup_wave / k_pileup_deep      */
     int64_t n_rows_wave, n_rows_deep;      /* rows emitted by each kernel (all cell types)         */
     float   ms_bin, ms_deep, ms_wave, ms_total;   /* HIP-event times of the last call             */
+    float   ms_walk;                       /* k_walk_block alone (HIP events around the launch)    */
+    float   pad_;
+    int64_t rows_by_kernel[4];             /* rows emitted by: 0 k_pileup_wave, 1 k_walk_block, 2 k_pileup_huge, 3 k_finalize_multi */
+    int64_t events_by_kernel[4];           /* events loaded by the same kernels (3 = 0)            */
 } lsg_count_stats;
 int lsg_get_count_stats(lsg_ctx* ctx, lsg_count_stats* out);
 

@@ -94,6 +94,8 @@ class CountStats(C.Structure):
         ("n_entries", C.c_int64), ("n_units", C.c_int64), ("n_deep_units", C.c_int64),
         ("n_events_wave", C.c_int64), ("n_events_deep", C.c_int64), ("n_rows_wave", C.c_int64), ("n_rows_deep", C.c_int64),
         ("ms_bin", C.c_float), ("ms_deep", C.c_float), ("ms_wave", C.c_float), ("ms_total", C.c_float),
+        ("ms_walk", C.c_float), ("pad_", C.c_float),
+        ("rows_by_kernel", C.c_int64 * 4), ("events_by_kernel", C.c_int64 * 4),
     ]
 
 
@@ -120,6 +122,7 @@ SIGNATURES = {
     "lsg_load_counts": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "lsg_call_step1": (C.c_int, [C.c_void_p, C.POINTER(CallParams), C.c_void_p, C.c_void_p]),
     "lsg_fetch_calls": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
+    "lsg_export_calls": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     "lsg_load_posset": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int32]),
     "lsg_probe_posset": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32]),
     "lsg_get_count_stats": (C.c_int, [C.c_void_p, C.POINTER(CountStats)]),

@@ -1,0 +1,245 @@
+"""Steps 2 and 3 of the SNV call (host side; the data are the candidate rows only).
+
+step2  <- variant_calling_step2 / GetExtraFilters   workflow/scripts/SNVCalling/BaseCellCalling.step2.py:14-235
+          position-set membership (RNA editing, PoN_SR, PoN_LR) is probed on the GPU against sorted
+          key arrays resident in HBM (lsg_load_posset / lsg_probe_posset).
+step3  <- variant_calling_step3 + helpers           workflow/scripts/SNVCalling/BaseCellCalling.step3.py:8-316
+          LongSom's final filters; the table goes through pandas exactly where the reference does, so
+          the text (float formatting, empty cells) is the same.
+"""
+import gzip
+import io
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+import pandas as pd
+
+KIND_EDITING, KIND_PON_SR, KIND_PON_LR = 0, 1, 2
+
+
+def read_posset_keys(path: Optional[str], contig_names: Sequence[str], reference_gz_compat: bool = False) -> np.ndarray:
+    """Position-set file (col 0 chrom, col 1 1-based pos, '#' comments; build_dict, step2.py:197-221) ->
+    sorted unique int64 keys (tid << 32) | pos1.  Unreadable / missing file -> empty (the reference's bare
+    except).  reference_gz_compat=True reproduces SURVEY quirk Q1: a .gz path is opened as text by the
+    reference, fails to decode and silently yields the empty set."""
+    if not path:
+        return np.zeros(0, np.int64)
+    tid_of = {n: i for i, n in enumerate(contig_names)}
+    keys = []
+    try:
+        if str(path).endswith(".gz"):
+            if reference_gz_compat:
+                return np.zeros(0, np.int64)
+            fh = io.TextIOWrapper(gzip.open(path, "rb"))
+        else:
+            fh = open(path, "r")
+        with fh:
+            for line in fh:
+                if line.startswith("#"):
+                    continue
+                el = line.split("\t")
+                t = tid_of.get(el[0])
+                p = int(el[1])
+                if t is not None:
+                    keys.append((t << 32) | p)
+    except Exception:
+        return np.zeros(0, np.int64)
+    return np.unique(np.asarray(keys, np.int64))
+
+
+def step2(step1_text: str, engine, contig_names: Sequence[str], editing_keys, pon_sr_keys, pon_lr_keys, distance: int = 0,
+          gnomad_af: Optional[Dict[str, float]] = None, gnomad_max: float = 0.01) -> str:
+    """Returns the text of <prefix>.calling.step2.tsv.  gnomad_af: {"chrom:pos:ref:alt": AF}; the gnomAD
+    database itself is not part of this repository — absent entries count as AF 0."""
+    gnomad_af = gnomad_af or {}
+    comments, header, rows = [], None, []
+    for line in step1_text.split("\n"):
+        if line.startswith("#"):
+            if "#CHROM" in line:
+                header = line
+            else:
+                comments.append(line)
+        elif line:
+            el = line.split("\t")
+            if el[4] != "." and el[5] != ".":           # awk filter, step2.py:23
+                rows.append(el)
+    tid_of = {n: i for i, n in enumerate(contig_names)}
+    q = np.asarray([((tid_of.get(el[0], 0x7FFFFFFF)) << 32) | int(el[1]) for el in rows], np.int64)
+    hits = []
+    for kind, keys in ((KIND_EDITING, editing_keys), (KIND_PON_SR, pon_sr_keys), (KIND_PON_LR, pon_lr_keys)):
+        engine.load_posset(kind, keys)
+        hits.append(engine.probe_posset(kind, q) if len(keys) and len(q) else np.zeros(len(q), np.uint8))
+    n = len(rows)
+    out = []
+    for i, el in enumerate(rows):
+        chrom, pos = el[0], int(el[1])
+        lo, hi = (0, n) if n < 3 else ((0, 3) if i == 0 else (i - 1, min(n, i + 2)))    # the 3-row window of step2.py:59-92
+        close = 0
+        for j in range(lo, hi):
+            pj = int(rows[j][1])
+            if rows[j][0] == chrom and pj != pos and abs(pj - pos) <= distance:
+                close += 1
+        tags = []
+        if hits[0][i]: tags.append("RNA_editing_db")
+        if close > 0: tags.append("Clustered")
+        if hits[1][i]: tags.append("PoN_SR")
+        if hits[2][i]: tags.append("PoN_LR")
+        af = gnomad_af.get("%s:%s:%s:%s" % (chrom, el[1], el[3], el[4]), 0.0)
+        if af == af and af >= gnomad_max:
+            tags.append("gnomAD")
+        F = el[5]
+        for t in tags:
+            F = t if F == "PASS" else F + "," + t
+        out.append("\t".join([el[0], el[1], el[2], el[3], el[4], F] + ["" if x == "NA" else x for x in el[6:]]))
+    return "\n".join(comments + [header] + out) + "\n"
+
+
+# ---- step 3 ---------------------------------------------------------------------------------------
+_ACTG = "ACTG"
+FINAL_FILTER_LINE = "##INFO=FINAL_FILTER,Description=Final ilter status, including chrM contaminants and clustered sites\n"
+
+
+def _tag(cur: str, t: str) -> str:
+    return t if cur == "PASS" else cur + "," + t
+
+
+def _cancer_index(ctypes):
+    return (0, 1) if ctypes[0] == "Cancer" else (1, 0)
+
+
+def _multiallelic(row):
+    """MultiAllelic_filtering (step3.py:163-231): at multi-allelic sites keep the dominant A/C/T/G alt of the
+    Cancer column, recompute its counts, tag 'Multi-Allelic' unless the runner-up is < 5 % of it."""
+    ALT, FILTER, CT = row["ALT"], row["FILTER"], row["Cell_types"]
+    if not ("Multi-allelic" in FILTER or "|" in ALT):
+        return ALT, FILTER, CT, row["Bc"], row["Cc"], row["VAF"], row["MCF"], "PASS"
+    i_ref = _ACTG.index(row["REF"])
+    ctypes = CT.split(",")
+    cinfo = row["Cancer"].split("|")
+    bcs = [int(x) for x in cinfo[3].split(":")[:4]]
+    bcs[i_ref] = 0
+    top = int(np.argmax(bcs)); mx = bcs[top]
+    bcs[top] = 0
+    mx2 = max(bcs)
+    step3 = "PASS" if mx2 / mx < 0.05 else "Multi-Allelic"
+    alt = _ACTG[top]
+    bc_c = int(cinfo[3].split(":")[top]); cc_c = int(cinfo[2].split(":")[top])
+    if len(ctypes) > 1:
+        i_c, i_n = _cancer_index(ctypes)
+        ninfo = row["Non-Cancer"].split("|")
+        bc_n = int(ninfo[3].split(":")[top]); cc_n = int(ninfo[2].split(":")[top])
+        dps, ncs = row["Dp"].split(","), row["Nc"].split(",")
+        vaf_c, mcf_c = round(bc_c / int(dps[i_c]), 4), round(cc_c / int(ncs[i_c]), 4)
+        vaf_n, mcf_n = round(bc_n / int(dps[i_n]), 4), round(cc_n / int(ncs[i_n]), 4)
+        # the reference writes the pair as (Non-Cancer, Cancer) whatever the order of Cell_types (:196-200)
+        return (",".join([alt, alt]), FILTER, CT, "%d,%d" % (bc_n, bc_c), "%d,%d" % (cc_n, cc_c), "%s,%s" % (vaf_n, vaf_c),
+                "%s,%s" % (mcf_n, mcf_c), step3)
+    FILTER = FILTER.replace("Multi-allelic,", "").replace(",Multi-allelic", "").replace("Multi-allelic", "")
+    return alt, FILTER, CT, bc_c, cc_c, round(bc_c / int(row["Dp"]), 4), round(cc_c / int(row["Nc"]), 4), step3
+
+
+def _chrm(row, dvaf_min, dmcf_min):
+    """chrM_filtering (step3.py:101-161)"""
+    s3 = row["STEP3FILTER"]
+    ctypes = row["Cell_types"].split(",")
+    if len(ctypes) > 1:
+        i_c, i_n = _cancer_index(ctypes)
+        d1, d2 = str(row["Dp"]).split(",")
+        if int(d1) < 100 or int(d2) < 100:
+            return _tag(s3, "LowDepth")
+        v = [float(x) for x in str(row["VAF"]).split(",")]; m = [float(x) for x in str(row["MCF"]).split(",")]
+        if v[i_c] - v[i_n] < dvaf_min:
+            return _tag(s3, "LowDeltaVAF")
+        if m[i_c] - m[i_n] < dmcf_min:
+            return _tag(s3, "LowDeltaMCF")
+        return s3
+    if int(row["Dp"]) < 100:
+        return _tag(s3, "LowDepth")
+    if float(row["VAF"]) < 0.05:
+        return _tag(s3, "LowVAF")
+    if float(row["MCF"]) < 0.05:
+        return _tag(s3, "LowMCF")
+    return s3
+
+
+def _bc_cc(row, min_ac_reads, min_ac_cells):
+    """BC_CC_filtering (step3.py:233-251): alt reads / cells in the Cancer column; a missing column (NaN after
+    the pandas round trip) -> NoCov."""
+    s3 = row["STEP3FILTER"]
+    i_alt = _ACTG.index(row["ALT"][0])
+    cancer = row["Cancer"]
+    if not isinstance(cancer, str):
+        return _tag(s3, "NoCov")
+    info = cancer.split("|")
+    if int(info[3].split(":")[i_alt]) < min_ac_reads or int(info[2].split(":")[i_alt]) < min_ac_cells:
+        return _tag(s3, "LowDepth")
+    return s3
+
+
+def _betabin(row):
+    """BetaBino_filtering (step3.py:254-280)"""
+    s3 = row["STEP3FILTER"]
+    ctypes = row["Cell_types"].split(",")
+    flt = row["Cell_type_Filter"]
+    weak = ("Non-Significant", "Low-Significance")
+    if len(ctypes) == 1:
+        return _tag(s3, "CancerNonSig") if flt in weak else s3
+    i_c, i_n = _cancer_index(ctypes)
+    f = flt.split(",")
+    if f[i_c] in weak:
+        return _tag(s3, "CancerNonSig")
+    if f[i_n] in ("PASS", "Low-Significance"):
+        return _tag(s3, "NonCancerSig")
+    return s3
+
+
+def step3(step2_text: str, delta_vaf: float, delta_mcf: float, min_ac_reads: int, min_ac_cells: int, clust_dist: int):
+    """Returns (text of .calling.step3.tsv, text of .calling.step3.unfiltered.tsv)."""
+    comments, cols = [], None
+    for line in step2_text.split("\n"):
+        if not line.startswith("#"):
+            break
+        if "#CHROM" in line:
+            cols = line.split("\t")
+        else:
+            comments.append(line + "\n")
+    head = "".join(comments) + FINAL_FILTER_LINE
+    df = pd.read_csv(io.StringIO(step2_text), sep="\t", comment="#", names=cols)
+    df = df[df["Cell_types"] != "Non-Cancer"]
+    out_cols = cols + ["STEP3FILTER", "INDEX"]
+    if len(df) == 0:
+        # the reference crashes on an empty frame under pandas 2; emit header-only files instead
+        empty = head + "\t".join(out_cols) + "\n"
+        return empty, empty
+    res = [_multiallelic(r) for _, r in df.iterrows()]
+    upd = ["ALT", "FILTER", "Cell_types", "Bc", "Cc", "VAF", "MCF", "STEP3FILTER"]
+    newvals = pd.DataFrame(res, columns=upd, index=df.index)
+    for c in upd:
+        df[c] = newvals[c]
+    df["INDEX"] = df["#CHROM"].astype(str) + ":" + df["Start"].astype(str) + ":" + df["ALT"].str.split(",", n=1, expand=True)[0]
+    chrm = df[df["#CHROM"] == "chrM"].copy()
+    df = df[df["#CHROM"] != "chrM"]
+    chrm = chrm[~chrm["FILTER"].str.contains("Min|LR|gnomAD|LC|RNA", regex=True)]
+    if len(chrm) > 0:
+        chrm["STEP3FILTER"] = [_chrm(r, delta_vaf, delta_mcf) for _, r in chrm.iterrows()]
+    df = df[~df["FILTER"].str.contains("Min_cell_types")]
+    if len(df) > 0:
+        df["STEP3FILTER"] = [_bc_cc(r, min_ac_reads, min_ac_cells) for _, r in df.iterrows()]
+        df["STEP3FILTER"] = [_betabin(r) for _, r in df.iterrows()]
+    for pat in ("Noisy_site", "LC_Upstream|LC_Downstream", "RNA_editing_db", "PoN", "Cell_type_noise", "gnomAD"):
+        df = df[~df["FILTER"].str.contains(pat, regex=True)]
+    df = pd.concat([df, chrm])
+    # 10 kb cluster filter among PASS rows, neighbours in STRING-sorted (chr, pos) order (step3.py:283-306)
+    idx = [tuple(i.split(":")) for i in df[df["STEP3FILTER"] == "PASS"]["INDEX"]]
+    idx.sort(key=lambda x: (x[0], x[1]))
+    trash = set()
+    for (c1, p1, b1), (c2, p2, b2) in zip(idx, idx[1:]):
+        if c1 == c2 and c1 != "chrM" and abs(int(p1) - int(p2)) < clust_dist:
+            trash.add(":".join([c1, p1, b1])); trash.add(":".join([c2, p2, b2]))
+    tag = "Clust_dist_%s" % clust_dist
+    if len(df) > 0:
+        df["STEP3FILTER"] = [(_tag(f, tag) if i in trash else f) for i, f in zip(df["INDEX"], df["STEP3FILTER"])]
+    unfiltered = head + df.to_csv(sep="\t", index=False)
+    keep = df[~df["STEP3FILTER"].str.contains("dist", regex=True)] if len(df) else df
+    keep = keep[keep["STEP3FILTER"] == "PASS"]
+    return head + keep.to_csv(sep="\t", index=False), unfiltered

@@ -288,9 +288,56 @@ int run_call(lsg_ctx* c, const lsg_call_params* p) {
     return 0;
 }
 
-__global__ void k_flag_keep(const lsg_call* calls, int64_t n, uint8_t* keep) {
+// kind 1: rows step 2 keeps (ALT != "." or FILTER != ".", step2.py:23 + the Noisy_site-only rows);
+// kind 2: PASS candidates only = rows that can still become a somatic call (no site filter, a PASS
+// cell type) — the table exchanged between GPUs.
+__global__ void k_flag_keep(const lsg_call* calls, int64_t n, int kind, uint8_t* keep) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) keep[i] = calls[i].site_filter != 0;      // ALT != "." or FILTER != "."
+    if (i >= n) return;
+    const lsg_call& c = calls[i];
+    bool k = c.site_filter != 0;
+    if (kind == 2) {
+        k = c.site_filter == (uint32_t)LSG_SF_CANDIDATE;
+        bool pass = false;
+        for (int ct = 0; ct < LSG_MAX_CELLTYPES; ++ct) pass |= c.ct_filter[ct] == LSG_CF_PASS;
+        k = k && pass;
+    }
+    keep[i] = k;
+}
+
+// Compacts the selected call records (genomic order kept) into a DEVICE buffer.
+int run_select_calls(lsg_ctx* c, int kind, lsg_call* dst_device, int64_t capacity, int64_t* n_out) {
+    if (!c->called) { set_error("lsg_export_calls: call lsg_call_step1 first"); return -2; }
+    hipStream_t st = c->stream;
+    const int64_t n = c->n_sites;
+    if (n_out) *n_out = 0;
+    if (n == 0) return 0;
+    if (kind == 0) {
+        if (capacity < n) { set_error("lsg_export_calls: capacity %lld < %lld sites", (long long)capacity, (long long)n); return -2; }
+        LSG_HIP(hipMemcpyAsync(dst_device, c->d_calls.p, (size_t)n * sizeof(lsg_call), hipMemcpyDeviceToDevice, st));
+        LSG_HIP(hipStreamSynchronize(st));
+        if (n_out) *n_out = n;
+        return 0;
+    }
+    DevBuf& flags = c->ws[WS_CALL_FLAGS]; DevBuf& sel = c->ws[WS_CALL_SEL];
+    if (flags.reserve((size_t)n + 64) || sel.reserve((size_t)n * sizeof(lsg_call))) return -1;
+    int64_t* d_nsel = reinterpret_cast<int64_t*>(flags.as<uint8_t>() + ((n + 15) / 16) * 16);
+    if (flags.reserve((size_t)((n + 15) / 16) * 16 + 64)) return -1;
+    d_nsel = reinterpret_cast<int64_t*>(flags.as<uint8_t>() + ((n + 15) / 16) * 16);
+    hipLaunchKernelGGL(k_flag_keep, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, c->d_calls.as<lsg_call>(), n, kind, flags.as<uint8_t>());
+    size_t tb = 0;
+    LSG_HIP(hipcub::DeviceSelect::Flagged(nullptr, tb, c->d_calls.as<lsg_call>(), flags.as<uint8_t>(), sel.as<lsg_call>(), d_nsel, (int)n, st));
+    if (c->d_cub_tmp.reserve(tb + 256)) return -1;
+    tb = c->d_cub_tmp.cap;
+    LSG_HIP(hipcub::DeviceSelect::Flagged(c->d_cub_tmp.p, tb, c->d_calls.as<lsg_call>(), flags.as<uint8_t>(), sel.as<lsg_call>(), d_nsel, (int)n, st));
+    int64_t k = 0;
+    LSG_HIP(hipMemcpyAsync(&k, d_nsel, 8, hipMemcpyDeviceToHost, st));
+    LSG_HIP(hipStreamSynchronize(st));
+    if (n_out) *n_out = k;
+    if (dst_device && k > capacity) { set_error("lsg_export_calls: capacity %lld < %lld rows", (long long)capacity, (long long)k); return -2; }
+    if (k > 0 && dst_device) LSG_HIP(hipMemcpyAsync(dst_device, sel.p, (size_t)k * sizeof(lsg_call), hipMemcpyDeviceToDevice, st));
+    LSG_HIP(hipStreamSynchronize(st));
+    return 0;
 }
 
 int run_fetch_calls(lsg_ctx* c, lsg_call* out, int64_t capacity, int candidates_only, int64_t* n_out) {
@@ -306,29 +353,16 @@ int run_fetch_calls(lsg_ctx* c, lsg_call* out, int64_t capacity, int candidates_
         if (n_out) *n_out = n;
         return 0;
     }
-    DevBuf flags, sel, nsel;
-    int rc = 0;
-    if (flags.reserve((size_t)n) || sel.reserve((size_t)n * sizeof(lsg_call)) || nsel.reserve(16)) rc = -1;
     int64_t k = 0;
-    if (!rc) {
-        hipLaunchKernelGGL(k_flag_keep, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, c->d_calls.as<lsg_call>(), n, flags.as<uint8_t>());
-        size_t tb = 0;
-        hipError_t e = hipcub::DeviceSelect::Flagged(nullptr, tb, c->d_calls.as<lsg_call>(), flags.as<uint8_t>(), sel.as<lsg_call>(), nsel.as<int64_t>(), (int)n, st);
-        if (e == hipSuccess && c->d_cub_tmp.reserve(tb + 256) == 0) {
-            tb = c->d_cub_tmp.cap;
-            e = hipcub::DeviceSelect::Flagged(c->d_cub_tmp.p, tb, c->d_calls.as<lsg_call>(), flags.as<uint8_t>(), sel.as<lsg_call>(), nsel.as<int64_t>(), (int)n, st);
-        }
-        if (e != hipSuccess || hipMemcpyAsync(&k, nsel.p, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
-            set_error("lsg_fetch_calls: select failed: %s", hipGetErrorString(hipGetLastError())); rc = -1;
-        }
+    int rc = run_select_calls(c, candidates_only, nullptr, n, &k);     // selection stays in ws[WS_CALL_SEL]
+    if (rc) return rc;
+    if (k > capacity) { set_error("lsg_fetch_calls: capacity %lld < %lld rows", (long long)capacity, (long long)k); return -2; }
+    if (k > 0) {
+        LSG_HIP(hipMemcpyAsync(out, c->ws[WS_CALL_SEL].p, (size_t)k * sizeof(lsg_call), hipMemcpyDeviceToHost, st));
+        LSG_HIP(hipStreamSynchronize(st));
     }
-    if (!rc && k > capacity) { set_error("lsg_fetch_calls: capacity %lld < %lld rows", (long long)capacity, (long long)k); rc = -2; }
-    if (!rc && k > 0 && (hipMemcpyAsync(out, sel.p, (size_t)k * sizeof(lsg_call), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)) {
-        set_error("lsg_fetch_calls: copy failed"); rc = -1;
-    }
-    if (!rc && n_out) *n_out = k;
-    flags.release(); sel.release(); nsel.release();
-    return rc;
+    if (n_out) *n_out = k;
+    return 0;
 }
 
 int run_probe(lsg_ctx* c, int kind, const int64_t* keys, int64_t n, uint8_t* hits, int on_device) {

@@ -15,6 +15,7 @@ int run_fetch_counts(lsg_ctx* c, int ct, int64_t* keys, uint8_t* ref, uint32_t* 
 int compute_entries_upper(lsg_ctx* c);
 int run_call(lsg_ctx* c, const lsg_call_params* p);
 int run_fetch_calls(lsg_ctx* c, lsg_call* out, int64_t capacity, int candidates_only, int64_t* n_out);
+int run_select_calls(lsg_ctx* c, int kind, lsg_call* dst_device, int64_t capacity, int64_t* n_out);
 int run_probe(lsg_ctx* c, int kind, const int64_t* keys, int64_t n, uint8_t* hits, int on_device);
 
 // copy a host array to a grow-only device buffer, or adopt a device pointer
@@ -238,6 +239,12 @@ int lsg_fetch_calls(lsg_ctx* c, lsg_call* out, int64_t capacity, int32_t candida
     if (!c || (!out && capacity > 0)) { set_error("lsg_fetch_calls: bad arguments"); return -2; }
     LSG_HIP(hipSetDevice(c->device));
     return run_fetch_calls(c, out, capacity, candidates_only, n_out);
+}
+
+int lsg_export_calls(lsg_ctx* c, int32_t kind, void* dst_device, int64_t capacity, int64_t* n_out) {
+    if (!c || kind < 0 || kind > 2) { set_error("lsg_export_calls: bad arguments"); return -2; }
+    LSG_HIP(hipSetDevice(c->device));
+    return run_select_calls(c, kind, reinterpret_cast<lsg_call*>(dst_device), capacity, n_out);
 }
 
 int lsg_load_posset(lsg_ctx* c, int32_t kind, const int64_t* keys, int64_t n, int32_t on_device) {

@@ -44,7 +44,7 @@ constexpr int FLUSH_EVERY = 63;      // packed LDS fields: fwd 6 | cnt 6 | dup 6
 enum { SC_QSMALL = 0, SC_QBIG = 1, SC_NNE = 2, SC_NSLOTS = 3, SC_ROWALLOC = 4, SC_COLS = 8, SC_OVERFLOW = 9,
        SC_READS = 10, SC_SEGS = 11, SC_EVENTS = 12, SC_EV_WAVE = 13, SC_EV_DEEP = 14, SC_ROWS_DEEP = 15,
        SC_ROWS = 16, SC_NSMALL = 20, SC_NMULTI = 21, SC_NMULTI_SEL = 22, SC_QGROUP = 23, SC_NHUGE = 24, SC_QHUGE = 25,
-       SC_COUNT = 28 };
+       SC_ROWS_SRC = 28, SC_EV_SRC = 32, SC_COUNT = 36 };   // *_SRC[4]: 0 wave, 1 walk_block, 2 huge, 3 finalize
 
 struct CountArgs {
     // reads
@@ -432,17 +432,18 @@ __device__ __forceinline__ int group_by_cb(const CountArgs& a, uint32_t src, int
 // wave-private bookkeeping (LDS): row arenas and exact counters
 struct WaveBook {
     uint32_t arena_next[LSG_MAX_CELLTYPES], arena_end[LSG_MAX_CELLTYPES], rows_true[LSG_MAX_CELLTYPES];
-    uint32_t cols, rows_deep, pad[2];
+    uint32_t cols, rows_deep, rows_src, src;
 };
 __device__ __forceinline__ void book_init(WaveBook& b, int lane) {
     if (lane < LSG_MAX_CELLTYPES) { b.arena_next[lane] = 0; b.arena_end[lane] = 0; b.rows_true[lane] = 0; }
-    if (lane == 0) { b.cols = 0; b.rows_deep = 0; }
+    if (lane == 0) { b.cols = 0; b.rows_deep = 0; b.rows_src = 0; b.src = 0; }
 }
 __device__ __forceinline__ void book_flush(const CountArgs& a, WaveBook& b, int lane) {
     lds_fence();
     if (lane < a.n_ct && b.rows_true[lane]) atomicAdd(&a.scalars[SC_ROWS + lane], (unsigned long long)b.rows_true[lane]);
     if (lane == 0 && b.cols) atomicAdd(&a.scalars[SC_COLS], (unsigned long long)b.cols);
     if (lane == 0 && b.rows_deep) atomicAdd(&a.scalars[SC_ROWS_DEEP], (unsigned long long)b.rows_deep);
+    if (lane == 0 && b.rows_src) atomicAdd(&a.scalars[SC_ROWS_SRC + b.src], (unsigned long long)b.rows_src);
 }
 
 // Gates + row emission for one unit by one wave.  Gates: BaseCellCounter.py:211 (ref != N), :282
@@ -474,6 +475,7 @@ __device__ __forceinline__ void emit_unit(const CountArgs& a, const Acc& acc, ui
                 }
                 base = nx; bk->arena_next[ct] = nx + k; bk->rows_true[ct] += k;
                 if (deep) bk->rows_deep += k;
+                bk->rows_src += k;
             }
         } else {
             if (colm) atomicAdd(&a.scalars[SC_COLS], (unsigned long long)__popcll(colm));
@@ -481,6 +483,7 @@ __device__ __forceinline__ void emit_unit(const CountArgs& a, const Acc& acc, ui
                 base = (uint32_t)atomicAdd(&a.scalars[SC_ROWALLOC + ct], (unsigned long long)k);
                 atomicAdd(&a.scalars[SC_ROWS + ct], (unsigned long long)k);
                 if (deep) atomicAdd(&a.scalars[SC_ROWS_DEEP], (unsigned long long)k);
+                atomicAdd(&a.scalars[SC_ROWS_SRC + 3], (unsigned long long)k);
             }
         }
         a.ne_mask[w] = em;
@@ -556,7 +559,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void k_pileup_wave(CountArgs 
     }
     book_flush(a, L.book, lane);
     for (int o = 32; o > 0; o >>= 1) nev_total += __shfl_down(nev_total, o);
-    if (lane == 0 && nev_total) atomicAdd(&a.scalars[SC_EV_WAVE], nev_total);
+    if (lane == 0 && nev_total) { atomicAdd(&a.scalars[SC_EV_WAVE], nev_total); atomicAdd(&a.scalars[SC_EV_SRC + 0], nev_total); }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -630,7 +633,7 @@ struct WalkLds {
 __global__ __launch_bounds__(WALK_THREADS) void k_walk_block(CountArgs a) {
     __shared__ WalkLds L;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    if (wv == 0) book_init(L.book, lane);
+    if (wv == 0) { book_init(L.book, lane); if (lane == 0) L.book.src = 1; }
     uint32_t* pk = L.pk[wv];
     for (int i = lane; i < 8 * 64; i += 64) pk[i] = 0;
     const uint32_t n_big = a.n_slots - (uint32_t)a.scalars[SC_NSMALL];
@@ -680,7 +683,7 @@ __global__ __launch_bounds__(WALK_THREADS) void k_walk_block(CountArgs a) {
     }
     if (wv == 0) book_flush(a, L.book, lane);
     for (int o = 32; o > 0; o >>= 1) nev_total += __shfl_down(nev_total, o);
-    if (lane == 0 && nev_total) atomicAdd(&a.scalars[SC_EV_DEEP], nev_total);
+    if (lane == 0 && nev_total) { atomicAdd(&a.scalars[SC_EV_DEEP], nev_total); atomicAdd(&a.scalars[SC_EV_SRC + 1], nev_total); }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -788,7 +791,7 @@ __device__ __forceinline__ void block_walk_slices(const CountArgs& a, BlockLds& 
 __global__ __launch_bounds__(BLOCK_THREADS) void k_pileup_huge(CountArgs a) {
     __shared__ BlockLds L;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    if (wv == 0) book_init(L.book, lane);
+    if (wv == 0) { book_init(L.book, lane); if (lane == 0) L.book.src = 2; }
     const uint32_t n_huge = (uint32_t)a.scalars[SC_NHUGE];
     int shift = 0;
     while (((uint32_t)(a.n_cb - 1) >> shift) >= (uint32_t)NBUCKET) ++shift;
@@ -903,7 +906,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_pileup_huge(CountArgs a) {
     }
     if (wv == 0) book_flush(a, L.book, lane);
     for (int o = 32; o > 0; o >>= 1) nev_total += __shfl_down(nev_total, o);
-    if (lane == 0 && nev_total) atomicAdd(&a.scalars[SC_EV_DEEP], nev_total);
+    if (lane == 0 && nev_total) { atomicAdd(&a.scalars[SC_EV_DEEP], nev_total); atomicAdd(&a.scalars[SC_EV_SRC + 2], nev_total); }
 }
 
 // multi-slot units: gates + emission from the global accumulators, one wave per unit
@@ -1096,6 +1099,7 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
     LSG_HIP(hipEventRecord(c->ev[1], st));
     if (n_ne > 0) {
         hipLaunchKernelGGL(k_walk_block, dim3(grid_walk), dim3(WALK_THREADS), 0, st, a);
+        LSG_HIP(hipEventRecord(c->ev[4], st));
         hipLaunchKernelGGL(k_pileup_huge, dim3(grid_block), dim3(BLOCK_THREADS), 0, st, a);
         if (c->n_multi > 0)
             hipLaunchKernelGGL(k_finalize_multi, dim3((unsigned)(((uint64_t)c->n_multi * 64 + 255) / 256)), dim3(256), 0, st, a);
@@ -1123,6 +1127,9 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
     float ms = 0;
     LSG_HIP(hipEventElapsedTime(&ms, c->ev[0], c->ev[1])); c->stats.ms_bin = ms;
     LSG_HIP(hipEventElapsedTime(&ms, c->ev[1], c->ev[2])); c->stats.ms_deep = ms;
+    c->stats.ms_walk = 0;
+    if (n_ne > 0) { LSG_HIP(hipEventElapsedTime(&ms, c->ev[1], c->ev[4])); c->stats.ms_walk = ms; }
+    for (int i = 0; i < 4; ++i) { c->stats.rows_by_kernel[i] = (int64_t)sc[SC_ROWS_SRC + i]; c->stats.events_by_kernel[i] = (int64_t)sc[SC_EV_SRC + i]; }
     LSG_HIP(hipEventElapsedTime(&ms, c->ev[2], c->ev[3])); c->stats.ms_wave = ms;
     LSG_HIP(hipEventElapsedTime(&ms, c->ev[0], c->ev[3])); c->stats.ms_total = ms;
     c->stats.n_events_wave = (int64_t)sc[SC_EV_WAVE]; c->stats.n_events_deep = (int64_t)sc[SC_EV_DEEP];

@@ -222,6 +222,14 @@ class Engine:
         dt = np.dtype(_lib.Call)
         return np.frombuffer(arr, dtype=dt, count=int(n_out.value)).copy()
 
+    def export_calls(self, kind: int, dst_device_ptr: int = 0, capacity: int = 0) -> int:
+        """Compact call records into a caller-owned device buffer (kind: 0 all, 1 step-2 rows, 2 PASS
+        candidates); dst 0 = count only.  Returns the number of selected rows."""
+        n_out = C.c_int64(0)
+        _lib.check(self._lib.lsg_export_calls(self._h, int(kind), C.c_void_p(int(dst_device_ptr)) if dst_device_ptr else None,
+                                              int(capacity), C.byref(n_out)), "lsg_export_calls")
+        return int(n_out.value)
+
     def load_posset(self, kind: int, keys, on_device: bool = False, n: Optional[int] = None):
         if on_device:
             _lib.check(self._lib.lsg_load_posset(self._h, kind, C.c_void_p(int(keys)), int(n), 1), "lsg_load_posset")

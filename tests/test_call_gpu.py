@@ -58,3 +58,17 @@ def test_betabinom_table(engine):
     for c, (_, _, n, k, sf, _) in zip(calls, rows):
         got = repr(int(c["p_bc"][0][0]) / 10000.0)
         assert got == sf.replace("-0.0", "0.0"), (n, k, got, sf)
+
+
+def test_step2_matches_reference_golden(engine):
+    import json
+    from longsom_amd import calling
+    names, seqs = tsvio.read_fasta(os.path.join(G, "calling.ref.fa"))
+    engine.set_contigs([len(s) for s in seqs])
+    ed, sr, lr = (calling.read_posset_keys(os.path.join(G, "calling.%s.tsv" % k), names) for k in ("editing", "pon_SR", "pon_LR"))
+    af = json.load(open(os.path.join(G, "calling.gnomad_af.json")))
+    s1 = open(os.path.join(G, "sample.calling.step1.tsv")).read()
+    got = calling.step2(s1, engine, names, ed, sr, lr, 0, af, 0.01)
+    assert got == open(os.path.join(G, "sample.calling.step2.tsv")).read()
+    got = calling.step2(s1, engine, names, ed, sr, calling.read_posset_keys("", names), 150, af, 0.01)
+    assert got == open(os.path.join(G, "sample.dist150.calling.step2.tsv")).read()
