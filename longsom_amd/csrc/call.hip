@@ -12,10 +12,31 @@
 // summed here in fp64 from the shorter side with the pmf ratio recurrence, re-anchored with lgamma
 // every 1024 terms; p-values are stored as Python round(p, 4) * 1e4 (exact half-even on the binary
 // value).  Arithmetic type f64; the text the host prints is identical whenever |p - tie| > ~1e-13.
+//
+// Device storage is compact (48 B per site + 56 B per (candidate site, cell type)); lsg_fetch_calls /
+// lsg_export_calls expand it into the C-ABI's lsg_call records.
 #include "lsg_ctx.h"
 #include <hipcub/hipcub.hpp>
 
 namespace lsg {
+
+struct SiteRec {                      // every merged site
+    int64_t key;
+    uint8_t ref, present, considered, has_cand;
+    uint32_t site_filter;
+    int32_t sum_alts_bc, sum_dp, sum_alts_cc, sum_nc;
+    int16_t noise_p_bc, noise_p_cc;
+    uint8_t cell_types_min, pad[3];
+    uint32_t cand;                    // index of the candidate detail block
+    uint32_t pad2;
+};
+static_assert(sizeof(SiteRec) == 48, "SiteRec layout");
+struct CandCt {                       // one per (candidate site, cell type)
+    uint8_t n_alt, ct_filter, alt[LSG_CALL_MAX_ALT], pad[2];
+    uint32_t alt_bc[LSG_CALL_MAX_ALT], alt_cc[LSG_CALL_MAX_ALT];
+    int16_t p_bc[LSG_CALL_MAX_ALT], p_cc[LSG_CALL_MAX_ALT];
+};
+static_assert(sizeof(CandCt) == 56, "CandCt layout");
 
 struct CallArgs {
     const uint32_t* ne_units; const uint64_t* ne_mask; const uint32_t* ne_rowbase; const int2* ne_geom;
@@ -23,41 +44,48 @@ struct CallArgs {
     const uint32_t* rows[LSG_MAX_CELLTYPES]; uint64_t row_cap;
     const uint8_t* const* ref_ptr; const int64_t* contig_len;
     lsg_call_params p;
+    double lgc0[2], lgcn[2];          // lgamma(a+b) - lgamma(b), lgamma(a+b) - lgamma(a) for (a1,b1), (a2,b2)
     uint32_t* site_cnt; uint32_t* site_off;
-    lsg_call* out;
-    unsigned long long* counters;    // [0] candidates
+    SiteRec* sites; CandCt* cands; uint64_t cand_cap;
+    unsigned long long* counters;     // [0] candidate sites
 };
 
 // log of the beta-binomial pmf at m (scipy betabinom._logpmf written with lgamma)
-__device__ __forceinline__ double bb_logpmf(double m, double n, double a, double b) {
+__device__ __noinline__ double bb_logpmf(double m, double n, double a, double b) {
     return lgamma(n + 1.0) - lgamma(m + 1.0) - lgamma(n - m + 1.0) + lgamma(m + a) + lgamma(n - m + b) - lgamma(n + a + b) +
            lgamma(a + b) - lgamma(a) - lgamma(b);
 }
 
-// P(X >= k) for X ~ BetaBinomial(n, a, b), k >= 1 integer, n >= 0.
-__device__ double bb_upper_tail(uint32_t k, uint32_t n, double a, double b) {
+// P(X >= k) for X ~ BetaBinomial(n, a, b), integer k.  pm0 = pmf(0), shared by the alts of one cell type.
+__device__ __noinline__ double bb_upper_tail(uint32_t k, uint32_t n, double a, double b, double pm0, double lgcn) {
     if (k == 0) return 1.0;
     if (k > n) return 0.0;                         // 1 - sum of the whole pmf; canonical 0.0
     const double dn = (double)n;
     if ((uint64_t)k <= (uint64_t)n - k + 1) {      // lower side is shorter: 1 - sum_{m<k} pmf(m)
-        double sum = 0.0, pm = 0.0;
-        for (uint32_t m = 0; m < k; ++m) {
+        double sum = pm0, pm = pm0;
+        for (uint32_t m = 1; m < k; ++m) {
             if ((m & 1023u) == 0) pm = exp(bb_logpmf((double)m, dn, a, b));
             else { const double mm = (double)(m - 1); pm *= (dn - mm) * (mm + a) / ((mm + 1.0) * (dn - mm - 1.0 + b)); }
             sum += pm;
         }
         return 1.0 - sum;
     }
-    double sum = 0.0, pm = 0.0;                    // upper side: sum_{m=k}^{n} pmf(m), descending from n
-    uint32_t cnt = 0;
-    for (uint32_t m = n;; --m) {
+    // upper side: sum_{m=k}^{n} pmf(m), descending from pmf(n) = G(n+a) G(a+b) / (G(n+a+b) G(a))
+    double pm = exp(lgamma(dn + a) - lgamma(dn + a + b) + lgcn);
+    double sum = pm;
+    uint32_t cnt = 1;
+    for (uint32_t m = n; m > k;) {
+        --m;
         if ((cnt & 1023u) == 0) pm = exp(bb_logpmf((double)m, dn, a, b));
         else { const double mm = (double)m; pm *= (mm + 1.0) * (dn - mm - 1.0 + b) / ((dn - mm) * (mm + a)); }
         sum += pm;
         ++cnt;
-        if (m == k) break;
     }
     return sum;
+}
+__device__ __noinline__ double bb_pm0(uint32_t n, double a, double b, double lgc0) {
+    const double dn = (double)n;                   // pmf(0) = G(n+b) G(a+b) / (G(n+a+b) G(b))
+    return exp(lgamma(dn + b) - lgamma(dn + a + b) + lgc0);
 }
 
 // Python round(x, 4) * 10^4 as an integer: half-even on the exact binary value of x.
@@ -96,9 +124,9 @@ __global__ void k_site_count(CallArgs a) {
 __global__ __launch_bounds__(256) void k_call(CallArgs a) {
     const int lane = threadIdx.x & 63;
     const uint32_t w = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-    if (w >= a.n_ne) return;
+    if (w >= a.n_ne) return;                                                  // whole wave
     const uint32_t tile = a.ne_units[w] / (uint32_t)a.n_ct;
-    if (w > 0 && a.ne_units[w - 1] / (uint32_t)a.n_ct == tile) return;      // not the head of its tile
+    if (w > 0 && a.ne_units[w - 1] / (uint32_t)a.n_ct == tile) return;        // whole wave: not the head of its tile
     uint64_t mask[LSG_MAX_CELLTYPES] = {0, 0, 0, 0};
     uint32_t rbase[LSG_MAX_CELLTYPES] = {0, 0, 0, 0};
     uint64_t any = 0;
@@ -106,118 +134,147 @@ __global__ __launch_bounds__(256) void k_call(CallArgs a) {
         const int ct = (int)(a.ne_units[q] % (uint32_t)a.n_ct);
         mask[ct] = a.ne_mask[q]; rbase[ct] = a.ne_rowbase[q]; any |= mask[ct];
     }
-    if (!((any >> lane) & 1ull)) return;
+    const bool site = (any >> lane) & 1ull;
     const uint64_t below = (1ull << lane) - 1ull;
     const uint64_t idx = (uint64_t)a.site_off[w] + __popcll(any & below);
     const int2 geom = a.ne_geom[w];
     const int tid = geom.y & 0xffffff;
     const int64_t pos = (int64_t)geom.x + lane;
     const uint8_t* ref = a.ref_ptr[tid];
-    const uint8_t refb = ref[pos];
+    const uint8_t refb = site ? ref[pos] : (uint8_t)'N';
     const int rsym = sym_of_ref(refb);
     const lsg_call_params& P = a.p;
+    const uint64_t cap = a.row_cap;
+    const int order[4] = {0, 1, 3, 2};              // letter order A < C < G < T over classes (A,C,T,G) = (0,1,2,3)
 
-    lsg_call c;
-    memset(&c, 0, sizeof(c));
-    c.key = ((int64_t)tid << 32) | pos;
-    c.ref = refb;
+    // pass 1: is the site a candidate (any considered cell type with an observed A/C/T/G alt)?  One
+    // wave-aggregated allocation of the detail blocks.
+    bool has_any = false;
+    if (site) {
+        for (int ct = 0; ct < a.n_ct; ++ct) {
+            if (!((mask[ct] >> lane) & 1ull)) continue;
+            const uint64_t row = (uint64_t)rbase[ct] + __popcll(mask[ct] & below);
+            const uint32_t* R = a.rows[ct];
+            if (!((int)R[row] >= P.min_cov && (int)R[cap + row] >= P.min_cells)) continue;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) has_any |= (s != rsym) && R[(10 + s) * cap + row] > 0;
+        }
+    }
+    const unsigned long long cm = __ballot(has_any);
+    uint32_t cbase = 0;
+    if (lane == 0 && cm) cbase = (uint32_t)atomicAdd(&a.counters[0], (unsigned long long)__popcll(cm));
+    cbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)cbase);
+    if (!site) return;
+    const uint32_t cand = cbase + (uint32_t)__popcll(cm & below);
+
+    SiteRec sr;
+    sr.key = ((int64_t)tid << 32) | pos; sr.ref = refb; sr.present = 0; sr.considered = 0; sr.has_cand = 0;
+    sr.pad[0] = sr.pad[1] = sr.pad[2] = 0; sr.pad2 = 0; sr.cand = has_any ? cand : 0xFFFFFFFFu;
     int32_t sum_alts_bc = 0, sum_alts_cc = 0, sum_dp = 0, sum_nc = 0;
     int n_considered = 0, n_pass = 0, n_nonsig = 0, n_with_cand = 0;
     bool any_multi = false, alts_differ = false;
     uint32_t first_altset = 0; bool have_first = false;
-    // letter order A < C < G < T over symbol classes (A,C,T,G) = (0,1,2,3)
-    const int order[4] = {0, 1, 3, 2};
     // homopolymer context (step1.py:95-107): up = ref[pos-5..pos-1], down = ref[pos+1..pos+5]
     const int64_t clen = a.contig_len[tid];
     const bool have_ctx = pos >= 5;
+    uint8_t up[5] = {0, 0, 0, 0, 0}, down[5] = {0, 0, 0, 0, 0};
     int down_len = 0;
     if (have_ctx) {
-        for (int i = 0; i < 5; ++i) c.up_ctx[i] = ref[pos - 5 + i];
+        for (int i = 0; i < 5; ++i) up[i] = ref[pos - 5 + i];
         down_len = (int)((clen - (pos + 1)) < 5 ? (clen - (pos + 1)) : 5);
         if (down_len < 0) down_len = 0;
-        for (int i = 0; i < down_len; ++i) c.down_ctx[i] = ref[pos + 1 + i];
+        for (int i = 0; i < down_len; ++i) down[i] = ref[pos + 1 + i];
     }
     int lc_up = 0, lc_down = 0;
 
     for (int ct = 0; ct < a.n_ct; ++ct) {
-        if (!((mask[ct] >> lane) & 1ull)) continue;
-        c.present |= (uint8_t)(1u << ct);
-        const uint64_t row = (uint64_t)rbase[ct] + __popcll(mask[ct] & below);
-        const uint32_t* R = a.rows[ct];
-        const uint64_t cap = a.row_cap;
-        const uint32_t dp = R[0 * cap + row], nc = R[1 * cap + row];
-        if (!((int)dp >= P.min_cov && (int)nc >= P.min_cells)) continue;      // step1.py:174
-        c.considered |= (uint8_t)(1u << ct);
-        ++n_considered;
-        uint32_t cc[6], bc[6];
+        CandCt cd;
+        cd.n_alt = 0; cd.ct_filter = 0; cd.pad[0] = cd.pad[1] = 0;
 #pragma unroll
-        for (int s = 0; s < 6; ++s) { cc[s] = R[(2 + s) * cap + row]; bc[s] = R[(10 + s) * cap + row]; }
-        uint32_t alts2 = 0, cc2 = 0;                                           // :187-190 (I and D included)
+        for (int q = 0; q < LSG_CALL_MAX_ALT; ++q) { cd.alt[q] = 0; cd.alt_bc[q] = 0; cd.alt_cc[q] = 0; cd.p_bc[q] = 0; cd.p_cc[q] = 0; }
+        if ((mask[ct] >> lane) & 1ull) {
+            sr.present |= (uint8_t)(1u << ct);
+            const uint64_t row = (uint64_t)rbase[ct] + __popcll(mask[ct] & below);
+            const uint32_t* R = a.rows[ct];
+            const uint32_t dp = R[row], nc = R[cap + row];
+            if ((int)dp >= P.min_cov && (int)nc >= P.min_cells) {                 // step1.py:174
+                sr.considered |= (uint8_t)(1u << ct);
+                ++n_considered;
+                uint32_t cc[6], bc[6];
 #pragma unroll
-        for (int s = 0; s < 6; ++s) if (s != rsym) { alts2 += bc[s]; cc2 += cc[s]; }
-        sum_alts_bc += (int32_t)alts2; sum_alts_cc += (int32_t)cc2; sum_dp += (int32_t)dp; sum_nc += (int32_t)nc;
-        // candidates: every observed A/C/T/G alt (:195-208), in letter order
-        int na = 0; uint32_t altset = 0;
-        int32_t min_pbc = 100000, min_pcc = 100000;
-        uint32_t b0 = 0, c0 = 0;
+                for (int s = 0; s < 6; ++s) { cc[s] = R[(2 + s) * cap + row]; bc[s] = R[(10 + s) * cap + row]; }
+                uint32_t alts2 = 0, cc2 = 0;                                       // :187-190 (I and D included)
 #pragma unroll
-        for (int oi = 0; oi < 4; ++oi) {
-            const int s = order[oi];
-            if (s == rsym || bc[s] == 0) continue;
-            const int32_t pb = round4(bb_upper_tail(bc[s], dp, P.alpha1, P.beta1));
-            const int32_t pc = round4(bb_upper_tail(cc[s], nc, P.alpha2, P.beta2));
-            if (na < LSG_CALL_MAX_ALT) {
-                c.alt[ct][na] = (uint8_t)s; c.alt_bc[ct][na] = bc[s]; c.alt_cc[ct][na] = cc[s];
-                c.p_bc[ct][na] = pb; c.p_cc[ct][na] = pc;
+                for (int s = 0; s < 6; ++s) if (s != rsym) { alts2 += bc[s]; cc2 += cc[s]; }
+                sum_alts_bc += (int32_t)alts2; sum_alts_cc += (int32_t)cc2; sum_dp += (int32_t)dp; sum_nc += (int32_t)nc;
+                // candidates: every observed A/C/T/G alt (:195-208), in letter order
+                int na = 0; uint32_t altset = 0;
+                int32_t min_pbc = 100000, min_pcc = 100000;
+                uint32_t b0 = 0, c0 = 0;
+                double pm0_bc = -1.0, pm0_cc = -1.0;
+#pragma unroll
+                for (int oi = 0; oi < 4; ++oi) {
+                    const int s = order[oi];
+                    if (s == rsym || bc[s] == 0) continue;
+                    if (pm0_bc < 0.0) { pm0_bc = bb_pm0(dp, P.alpha1, P.beta1, a.lgc0[0]); pm0_cc = bb_pm0(nc, P.alpha2, P.beta2, a.lgc0[1]); }
+                    const int32_t pb = round4(bb_upper_tail(bc[s], dp, P.alpha1, P.beta1, pm0_bc, a.lgcn[0]));
+                    const int32_t pc = round4(bb_upper_tail(cc[s], nc, P.alpha2, P.beta2, pm0_cc, a.lgcn[1]));
+                    if (na < LSG_CALL_MAX_ALT) {
+                        cd.alt[na] = (uint8_t)s; cd.alt_bc[na] = bc[s]; cd.alt_cc[na] = cc[s]; cd.p_bc[na] = (int16_t)pb; cd.p_cc[na] = (int16_t)pc;
+                    }
+                    ++na; altset |= 1u << s;
+                    min_pbc = pb < min_pbc ? pb : min_pbc; min_pcc = pc < min_pcc ? pc : min_pcc;
+                    b0 += bc[s]; c0 += cc[s];
+                }
+                cd.n_alt = (uint8_t)na;
+                if (na > 0) {
+                    sr.has_cand |= (uint8_t)(1u << ct);
+                    ++n_with_cand;
+                    if (!have_first) { first_altset = altset; have_first = true; } else if (altset != first_altset) alts_differ = true;
+                    sum_dp -= (int32_t)b0; sum_nc -= (int32_t)c0; sum_alts_bc -= (int32_t)b0; sum_alts_cc -= (int32_t)c0;   // :253-258
+                    // per-cell-type filter chain (:263-277); thresholds on the rounded values
+                    uint8_t f;
+                    if (min_pbc >= 500 || min_pcc >= 500) f = LSG_CF_NONSIG;
+                    else if ((min_pbc > 10 && min_pbc < 500) || (min_pcc > 10 && min_pcc < 500)) f = LSG_CF_LOWSIG;
+                    else if (na > 1) f = LSG_CF_MULTI;
+                    else if ((int)cd.alt_cc[0] < P.min_ac_cells) f = LSG_CF_LOW_CELLS;
+                    else if ((int)cd.alt_bc[0] < P.min_ac_reads) f = LSG_CF_LOW_READS;
+                    else f = LSG_CF_PASS;
+                    cd.ct_filter = f;
+                    n_pass += f == LSG_CF_PASS; n_nonsig += f == LSG_CF_NONSIG; any_multi |= f == LSG_CF_MULTI;
+                    // homopolymer runs including the alt string "A" or "A|C|.." (:511-529): only the first /
+                    // last letter of the string touches the context
+                    if (have_ctx) {
+                        int first_s = -1, last_s = -1;
+                        for (int oi = 0; oi < 4; ++oi) { const int s = order[oi]; if ((altset >> s) & 1u) { if (first_s < 0) first_s = s; last_s = s; } }
+                        int best = 1, run = 1;                                     // upstream: longestRun(up + x)
+                        for (int i = 1; i < 5; ++i) { run = up[i] == up[i - 1] ? run + 1 : 1; best = run > best ? run : best; }
+                        run = base_of_sym(first_s) == up[4] ? run + 1 : 1; best = run > best ? run : best;
+                        lc_up = best > lc_up ? best : lc_up;
+                        best = 1; run = 1;                                         // downstream: longestRun(x + down)
+                        uint8_t prev = base_of_sym(last_s);
+                        for (int i = 0; i < down_len; ++i) { run = down[i] == prev ? run + 1 : 1; best = run > best ? run : best; prev = down[i]; }
+                        lc_down = best > lc_down ? best : lc_down;
+                    }
+                }
             }
-            ++na; altset |= 1u << s;
-            min_pbc = pb < min_pbc ? pb : min_pbc; min_pcc = pc < min_pcc ? pc : min_pcc;
-            b0 += bc[s]; c0 += cc[s];
         }
-        c.n_alt[ct] = (uint8_t)na;
-        if (na == 0) continue;
-        c.has_cand |= (uint8_t)(1u << ct);
-        ++n_with_cand;
-        if (!have_first) { first_altset = altset; have_first = true; } else if (altset != first_altset) alts_differ = true;
-        sum_dp -= (int32_t)b0; sum_nc -= (int32_t)c0; sum_alts_bc -= (int32_t)b0; sum_alts_cc -= (int32_t)c0;     // :253-258
-        // per-cell-type filter chain (:263-277); thresholds on the rounded values
-        uint8_t f;
-        if (min_pbc >= 500 || min_pcc >= 500) f = LSG_CF_NONSIG;
-        else if ((min_pbc > 10 && min_pbc < 500) || (min_pcc > 10 && min_pcc < 500)) f = LSG_CF_LOWSIG;
-        else if (na > 1) f = LSG_CF_MULTI;
-        else if ((int)c.alt_cc[ct][0] < P.min_ac_cells) f = LSG_CF_LOW_CELLS;
-        else if ((int)c.alt_bc[ct][0] < P.min_ac_reads) f = LSG_CF_LOW_READS;
-        else f = LSG_CF_PASS;
-        c.ct_filter[ct] = f;
-        n_pass += f == LSG_CF_PASS; n_nonsig += f == LSG_CF_NONSIG; any_multi |= f == LSG_CF_MULTI;
-        // homopolymer runs including the alt string "A" or "A|C|.." (:511-529): only the first / last
-        // letter of the string touches the context
-        if (have_ctx) {
-            int first_s = -1, last_s = -1;
-            for (int oi = 0; oi < 4; ++oi) { const int s = order[oi]; if ((altset >> s) & 1u) { if (first_s < 0) first_s = s; last_s = s; } }
-            // upstream: longestRun(up + x)
-            int best = 1, run = 1;
-            for (int i = 1; i < 5; ++i) { run = c.up_ctx[i] == c.up_ctx[i - 1] ? run + 1 : 1; best = run > best ? run : best; }
-            run = base_of_sym(first_s) == c.up_ctx[4] ? run + 1 : 1; best = run > best ? run : best;
-            lc_up = best > lc_up ? best : lc_up;
-            // downstream: longestRun(x + down)
-            best = 1; run = 1;
-            uint8_t prev = base_of_sym(last_s);
-            for (int i = 0; i < down_len; ++i) { run = c.down_ctx[i] == prev ? run + 1 : 1; best = run > best ? run : best; prev = c.down_ctx[i]; }
-            lc_down = best > lc_down ? best : lc_down;
-        }
+        if (has_any && cand < a.cand_cap) a.cands[(uint64_t)cand * a.n_ct + ct] = cd;
     }
-    c.cell_types_min = n_considered;
-    c.sum_alts_bc = sum_alts_bc; c.sum_dp = sum_dp; c.sum_alts_cc = sum_alts_cc; c.sum_nc = sum_nc;
-    c.noise_p_bc = -1; c.noise_p_cc = -1;
+    sr.cell_types_min = (uint8_t)n_considered;
+    sr.sum_alts_bc = sum_alts_bc; sr.sum_dp = sum_dp; sr.sum_alts_cc = sum_alts_cc; sr.sum_nc = sum_nc;
+    int32_t npb = -1, npc = -1;
     if (sum_alts_bc > 0) {                                                     // :328-337 / :426-435
         // a negative n (cells carrying several alleles make Sum_nc - c0 negative) is outside scipy's
         // support: betabinom.cdf returns nan, which prints as "nan" and fails every "<" test
-        c.noise_p_bc = sum_dp < 0 ? -2 : round4(bb_upper_tail((uint32_t)sum_alts_bc, (uint32_t)sum_dp, P.alpha1, P.beta1));
-        c.noise_p_cc = (sum_nc < 0 || sum_alts_cc < 0) ? -2 : round4(bb_upper_tail((uint32_t)sum_alts_cc, (uint32_t)sum_nc, P.alpha2, P.beta2));
+        npb = sum_dp < 0 ? -2 : round4(bb_upper_tail((uint32_t)sum_alts_bc, (uint32_t)sum_dp, P.alpha1, P.beta1,
+                                                     bb_pm0((uint32_t)sum_dp, P.alpha1, P.beta1, a.lgc0[0]), a.lgcn[0]));
+        npc = (sum_nc < 0 || sum_alts_cc < 0) ? -2 : round4(bb_upper_tail((uint32_t)sum_alts_cc, (uint32_t)sum_nc, P.alpha2, P.beta2,
+                                                                         bb_pm0((uint32_t)sum_nc, P.alpha2, P.beta2, a.lgc0[1]), a.lgcn[1]));
     }
-    const bool bc_lt05 = c.noise_p_bc >= 0 && c.noise_p_bc < 500, cc_lt05 = c.noise_p_cc >= 0 && c.noise_p_cc < 500;
-    const bool bc_lt001 = c.noise_p_bc >= 0 && c.noise_p_bc < 10, cc_lt001 = c.noise_p_cc >= 0 && c.noise_p_cc < 10;
+    sr.noise_p_bc = (int16_t)npb; sr.noise_p_cc = (int16_t)npc;
+    const bool bc_lt05 = npb >= 0 && npb < 500, cc_lt05 = npc >= 0 && npc < 500;
+    const bool bc_lt001 = npb >= 0 && npb < 10, cc_lt001 = npc >= 0 && npc < 10;
     uint32_t sf = 0;
     if (n_with_cand > 0) {
         sf |= LSG_SF_CANDIDATE;
@@ -225,15 +282,58 @@ __global__ __launch_bounds__(256) void k_call(CallArgs a) {
         if (alts_differ || any_multi) sf |= LSG_SF_MULTI_ALLELIC;              // :313-315
         if (n_considered < P.min_cell_types) sf |= LSG_SF_MIN_CELL_TYPES;      // :318
         if (n_with_cand - n_pass - n_nonsig > 0) sf |= LSG_SF_CELL_TYPE_NOISE; // :322
-        if (sum_alts_bc > 0 && (bc_lt05 || cc_lt05)) sf |= LSG_SF_NOISY_SITE;   // :342
+        if (sum_alts_bc > 0 && (bc_lt05 || cc_lt05)) sf |= LSG_SF_NOISY_SITE;  // :342
         if (have_ctx && lc_up >= 4) sf |= LSG_SF_LC_UP;                        // :347-354
         if (have_ctx && lc_down >= 4) sf |= LSG_SF_LC_DOWN;
-        atomicAdd(&a.counters[0], 1ull);
     } else if (sum_alts_bc > 0 && (bc_lt001 || cc_lt001)) {
         sf |= LSG_SF_NOISY_SITE;                                               // :440-442
     }
-    c.site_filter = sf;
-    a.out[idx] = c;
+    sr.site_filter = sf;
+    a.sites[idx] = sr;
+}
+
+// Expansion of compact records into the C-ABI's lsg_call; kind selects rows (see lsg_export_calls).
+__device__ __forceinline__ bool keep_site(const SiteRec& s, const CandCt* cands, int n_ct, int kind) {
+    if (kind == 0) return true;
+    if (kind == 1) return s.site_filter != 0;
+    if (s.site_filter != (uint32_t)LSG_SF_CANDIDATE) return false;
+    bool pass = false;
+    for (int ct = 0; ct < n_ct; ++ct) pass |= cands[(uint64_t)s.cand * n_ct + ct].ct_filter == LSG_CF_PASS;
+    return pass;
+}
+__global__ void k_flag_keep(const SiteRec* sites, const CandCt* cands, int n_ct, int64_t n, int kind, uint32_t* keep) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= n) keep[i] = (i < n && keep_site(sites[i], cands, n_ct, kind)) ? 1u : 0u;
+}
+__global__ void k_expand(const SiteRec* sites, const CandCt* cands, int n_ct, int64_t n, const uint32_t* keep, const uint32_t* off,
+                         const uint8_t* const* ref_ptr, const int64_t* contig_len, lsg_call* out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !keep[i]) return;
+    const SiteRec& s = sites[i];
+    lsg_call c;
+    memset(&c, 0, sizeof(c));
+    c.key = s.key; c.ref = s.ref; c.present = s.present; c.considered = s.considered; c.has_cand = s.has_cand;
+    c.site_filter = s.site_filter; c.cell_types_min = s.cell_types_min;
+    c.sum_alts_bc = s.sum_alts_bc; c.sum_dp = s.sum_dp; c.sum_alts_cc = s.sum_alts_cc; c.sum_nc = s.sum_nc;
+    c.noise_p_bc = s.noise_p_bc; c.noise_p_cc = s.noise_p_cc;
+    if (s.cand != 0xFFFFFFFFu) {
+        for (int ct = 0; ct < n_ct; ++ct) {
+            const CandCt& d = cands[(uint64_t)s.cand * n_ct + ct];
+            c.n_alt[ct] = d.n_alt; c.ct_filter[ct] = d.ct_filter;
+            for (int q = 0; q < LSG_CALL_MAX_ALT; ++q) {
+                c.alt[ct][q] = d.alt[q]; c.alt_bc[ct][q] = d.alt_bc[q]; c.alt_cc[ct][q] = d.alt_cc[q];
+                c.p_bc[ct][q] = d.p_bc[q]; c.p_cc[ct][q] = d.p_cc[q];
+            }
+        }
+    }
+    const int tid = (int)(s.key >> 32);
+    const int64_t pos = s.key & 0xffffffffll;
+    if (pos >= 5) {
+        const uint8_t* ref = ref_ptr[tid];
+        for (int q = 0; q < 5; ++q) c.up_ctx[q] = ref[pos - 5 + q];
+        for (int q = 0; q < 5 && pos + 1 + q < contig_len[tid]; ++q) c.down_ctx[q] = ref[pos + 1 + q];
+    }
+    out[off[i]] = c;
 }
 
 __global__ void k_probe(const int64_t* set, int64_t n_set, const int64_t* keys, int64_t n, uint8_t* hits) {
@@ -260,6 +360,8 @@ int run_call(lsg_ctx* c, const lsg_call_params* p) {
     a.row_cap = c->row_cap;
     a.ref_ptr = c->d_ref_ptrs.as<const uint8_t*>(); a.contig_len = c->d_contig_len.as<int64_t>();
     a.p = *p;
+    a.lgc0[0] = lgamma(p->alpha1 + p->beta1) - lgamma(p->beta1); a.lgcn[0] = lgamma(p->alpha1 + p->beta1) - lgamma(p->alpha1);
+    a.lgc0[1] = lgamma(p->alpha2 + p->beta2) - lgamma(p->beta2); a.lgcn[1] = lgamma(p->alpha2 + p->beta2) - lgamma(p->alpha2);
     a.site_cnt = c->d_site_off.as<uint32_t>();
     a.site_off = a.site_cnt + (n_ne + 2);
     a.counters = reinterpret_cast<unsigned long long*>(a.site_off + (n_ne + 2));   // 2*(n_ne+2) words: 8-byte aligned
@@ -274,8 +376,9 @@ int run_call(lsg_ctx* c, const lsg_call_params* p) {
     LSG_HIP(hipMemcpyAsync(&n_sites, a.site_off + n_ne, 4, hipMemcpyDeviceToHost, st));
     LSG_HIP(hipStreamSynchronize(st));
     if (n_sites > 0) {
-        if (c->d_calls.reserve((size_t)n_sites * sizeof(lsg_call))) return -1;
-        a.out = c->d_calls.as<lsg_call>();
+        if (c->d_calls.reserve((size_t)n_sites * sizeof(SiteRec))) return -1;
+        if (c->ws[WS_CALL_CANDS].reserve((size_t)n_sites * sizeof(CandCt) * (size_t)c->n_ct)) return -1;   // every site could be a candidate
+        a.sites = c->d_calls.as<SiteRec>(); a.cands = c->ws[WS_CALL_CANDS].as<CandCt>(); a.cand_cap = n_sites;
         const uint64_t threads = (uint64_t)n_ne * 64;
         hipLaunchKernelGGL(k_call, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, a);
         LSG_HIP(hipGetLastError());
@@ -288,54 +391,34 @@ int run_call(lsg_ctx* c, const lsg_call_params* p) {
     return 0;
 }
 
-// kind 1: rows step 2 keeps (ALT != "." or FILTER != ".", step2.py:23 + the Noisy_site-only rows);
-// kind 2: PASS candidates only = rows that can still become a somatic call (no site filter, a PASS
-// cell type) — the table exchanged between GPUs.
-__global__ void k_flag_keep(const lsg_call* calls, int64_t n, int kind, uint8_t* keep) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const lsg_call& c = calls[i];
-    bool k = c.site_filter != 0;
-    if (kind == 2) {
-        k = c.site_filter == (uint32_t)LSG_SF_CANDIDATE;
-        bool pass = false;
-        for (int ct = 0; ct < LSG_MAX_CELLTYPES; ++ct) pass |= c.ct_filter[ct] == LSG_CF_PASS;
-        k = k && pass;
-    }
-    keep[i] = k;
-}
-
-// Compacts the selected call records (genomic order kept) into a DEVICE buffer.
+// Compacts + expands the selected call records (genomic order kept) into a DEVICE buffer of lsg_call.
 int run_select_calls(lsg_ctx* c, int kind, lsg_call* dst_device, int64_t capacity, int64_t* n_out) {
     if (!c->called) { set_error("lsg_export_calls: call lsg_call_step1 first"); return -2; }
     hipStream_t st = c->stream;
     const int64_t n = c->n_sites;
     if (n_out) *n_out = 0;
     if (n == 0) return 0;
-    if (kind == 0) {
-        if (capacity < n) { set_error("lsg_export_calls: capacity %lld < %lld sites", (long long)capacity, (long long)n); return -2; }
-        LSG_HIP(hipMemcpyAsync(dst_device, c->d_calls.p, (size_t)n * sizeof(lsg_call), hipMemcpyDeviceToDevice, st));
-        LSG_HIP(hipStreamSynchronize(st));
-        if (n_out) *n_out = n;
-        return 0;
-    }
-    DevBuf& flags = c->ws[WS_CALL_FLAGS]; DevBuf& sel = c->ws[WS_CALL_SEL];
-    if (flags.reserve((size_t)n + 64) || sel.reserve((size_t)n * sizeof(lsg_call))) return -1;
-    int64_t* d_nsel = reinterpret_cast<int64_t*>(flags.as<uint8_t>() + ((n + 15) / 16) * 16);
-    if (flags.reserve((size_t)((n + 15) / 16) * 16 + 64)) return -1;
-    d_nsel = reinterpret_cast<int64_t*>(flags.as<uint8_t>() + ((n + 15) / 16) * 16);
-    hipLaunchKernelGGL(k_flag_keep, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, c->d_calls.as<lsg_call>(), n, kind, flags.as<uint8_t>());
+    DevBuf& flags = c->ws[WS_CALL_FLAGS];
+    if (flags.reserve((size_t)(n + 2) * 8)) return -1;
+    uint32_t* keep = flags.as<uint32_t>();
+    uint32_t* off = keep + (n + 2);
+    const SiteRec* sites = c->d_calls.as<SiteRec>();
+    const CandCt* cands = c->ws[WS_CALL_CANDS].as<CandCt>();
+    hipLaunchKernelGGL(k_flag_keep, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, st, sites, cands, c->n_ct, n, kind, keep);
     size_t tb = 0;
-    LSG_HIP(hipcub::DeviceSelect::Flagged(nullptr, tb, c->d_calls.as<lsg_call>(), flags.as<uint8_t>(), sel.as<lsg_call>(), d_nsel, (int)n, st));
+    LSG_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, keep, off, (int)(n + 1), st));
     if (c->d_cub_tmp.reserve(tb + 256)) return -1;
     tb = c->d_cub_tmp.cap;
-    LSG_HIP(hipcub::DeviceSelect::Flagged(c->d_cub_tmp.p, tb, c->d_calls.as<lsg_call>(), flags.as<uint8_t>(), sel.as<lsg_call>(), d_nsel, (int)n, st));
-    int64_t k = 0;
-    LSG_HIP(hipMemcpyAsync(&k, d_nsel, 8, hipMemcpyDeviceToHost, st));
+    LSG_HIP(hipcub::DeviceScan::ExclusiveSum(c->d_cub_tmp.p, tb, keep, off, (int)(n + 1), st));
+    uint32_t k = 0;
+    LSG_HIP(hipMemcpyAsync(&k, off + n, 4, hipMemcpyDeviceToHost, st));
     LSG_HIP(hipStreamSynchronize(st));
     if (n_out) *n_out = k;
-    if (dst_device && k > capacity) { set_error("lsg_export_calls: capacity %lld < %lld rows", (long long)capacity, (long long)k); return -2; }
-    if (k > 0 && dst_device) LSG_HIP(hipMemcpyAsync(dst_device, sel.p, (size_t)k * sizeof(lsg_call), hipMemcpyDeviceToDevice, st));
+    if (!dst_device || k == 0) return 0;
+    if ((int64_t)k > capacity) { set_error("lsg_export_calls: capacity %lld < %lld rows", (long long)capacity, (long long)k); return -2; }
+    hipLaunchKernelGGL(k_expand, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, sites, cands, c->n_ct, n, keep, off,
+                       c->d_ref_ptrs.as<const uint8_t*>(), c->d_contig_len.as<int64_t>(), dst_device);
+    LSG_HIP(hipGetLastError());
     LSG_HIP(hipStreamSynchronize(st));
     return 0;
 }
@@ -343,22 +426,18 @@ int run_select_calls(lsg_ctx* c, int kind, lsg_call* dst_device, int64_t capacit
 int run_fetch_calls(lsg_ctx* c, lsg_call* out, int64_t capacity, int candidates_only, int64_t* n_out) {
     if (!c->called) { set_error("lsg_fetch_calls: call lsg_call_step1 first"); return -2; }
     hipStream_t st = c->stream;
-    const int64_t n = c->n_sites;
     if (n_out) *n_out = 0;
-    if (n == 0) return 0;
-    if (!candidates_only) {
-        if (capacity < n) { set_error("lsg_fetch_calls: capacity %lld < %lld sites", (long long)capacity, (long long)n); return -2; }
-        LSG_HIP(hipMemcpyAsync(out, c->d_calls.p, (size_t)n * sizeof(lsg_call), hipMemcpyDeviceToHost, st));
-        LSG_HIP(hipStreamSynchronize(st));
-        if (n_out) *n_out = n;
-        return 0;
-    }
+    if (c->n_sites == 0) return 0;
     int64_t k = 0;
-    int rc = run_select_calls(c, candidates_only, nullptr, n, &k);     // selection stays in ws[WS_CALL_SEL]
+    int rc = run_select_calls(c, candidates_only, nullptr, 0, &k);
     if (rc) return rc;
     if (k > capacity) { set_error("lsg_fetch_calls: capacity %lld < %lld rows", (long long)capacity, (long long)k); return -2; }
     if (k > 0) {
-        LSG_HIP(hipMemcpyAsync(out, c->ws[WS_CALL_SEL].p, (size_t)k * sizeof(lsg_call), hipMemcpyDeviceToHost, st));
+        DevBuf& sel = c->ws[WS_CALL_SEL];
+        if (sel.reserve((size_t)k * sizeof(lsg_call))) return -1;
+        rc = run_select_calls(c, candidates_only, sel.as<lsg_call>(), k, &k);
+        if (rc) return rc;
+        LSG_HIP(hipMemcpyAsync(out, sel.p, (size_t)k * sizeof(lsg_call), hipMemcpyDeviceToHost, st));
         LSG_HIP(hipStreamSynchronize(st));
     }
     if (n_out) *n_out = k;
