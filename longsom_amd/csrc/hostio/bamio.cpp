@@ -1,0 +1,463 @@
+// liblongsom_io.so — host side of the hot path: BGZF/BAM decode into the read-record arrays of
+// include/longsom_hip.h, and a BAM writer for the synthetic workload.  Plain C ABI for ctypes.
+//
+// What the decode replaces in the reference (all pysam/htslib, not in the reference tree):
+//   reading + routing records    workflow/scripts/PreProcessing/SplitBamCellTypes.py:51-124
+//   CIGAR walk of the pileup     htslib bam_plp / resolve_cigar2 behind bam.pileup(...)
+//                                (workflow/scripts/SNVCalling/BaseCellCounter.py:190-191)
+//   per-entry symbol + quality   pysam PileupColumn.get_query_sequences(add_indels=True) +
+//                                EasyReadPileup (BaseCellCounter.py:152-180,214-216)
+// The per-read event classification is documented in SURVEY.md §8a ("Event classification
+// restated from CIGAR") and cross-checked against oracle/plp_oracle.c, which iterates columns the
+// way bam_plp does.
+#include <zlib.h>
+#include <algorithm>
+#include <atomic>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+#include "../synth_model.h"
+
+namespace {
+thread_local char g_err[512] = "";
+void set_err(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap); }
+
+inline uint16_t rd16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
+inline uint32_t rd32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+inline int32_t rdi32(const uint8_t* p) { return (int32_t)rd32(p); }
+
+struct Block { size_t off; uint32_t csize, usize; size_t uoff; };
+
+// symbol class of a 4-bit BAM base code: A C G T N -> 0 1 3 2 6, everything else ('=', IUPAC) -> NA
+const uint8_t NT16_SYM[16] = {15, 0, 1, 15, 3, 15, 15, 15, 2, 15, 15, 15, 15, 15, 15, 6};
+
+struct Local {   // per-thread decode output
+    std::vector<int32_t> read_tid, read_pos, read_cb; std::vector<uint16_t> read_flag; std::vector<uint8_t> read_mapq;
+    std::vector<uint32_t> seg_read; std::vector<int32_t> seg_start, seg_len; std::vector<int64_t> seg_ev_off;
+    std::vector<uint16_t> events;
+    int64_t total = 0, pass = 0, cb_not_found = 0, cb_not_matched = 0, mapq = 0;
+};
+
+inline bool is_ref_op(uint32_t op) { return op == 0 || op == 2 || op == 3 || op == 7 || op == 8; }
+
+// Decode one BAM record (rec points at refID, i.e. after block_size) into L.
+void decode_record(const uint8_t* rec, uint32_t len, const std::unordered_map<std::string, int32_t>& cbmap, int min_mapq, Local& L) {
+    const int32_t tid = rdi32(rec), pos = rdi32(rec + 4);
+    const uint32_t l_name = rec[8], mapq = rec[9], n_cigar = rd16(rec + 12), flag = rd16(rec + 14), l_seq = rd32(rec + 16);
+    if (tid < 0) return;                              // infile.fetch() iterates reads placed on a reference
+    ++L.total;
+    const uint8_t* p = rec + 32 + l_name;
+    const uint8_t* cigar = p; p += 4ull * n_cigar;
+    const uint8_t* seq = p; p += (l_seq + 1) / 2;
+    const uint8_t* qual = p; p += l_seq;
+    const uint8_t* aux = p; const uint8_t* end = rec + len;
+    // CB:Z tag (read.opt("CB"), SplitBamCellTypes.py:74-79)
+    const char* cb = nullptr; size_t cb_len = 0;
+    while (aux + 3 <= end) {
+        const char t0 = (char)aux[0], t1 = (char)aux[1], ty = (char)aux[2];
+        aux += 3;
+        size_t sz = 0;
+        switch (ty) {
+            case 'A': case 'c': case 'C': sz = 1; break;
+            case 's': case 'S': sz = 2; break;
+            case 'i': case 'I': case 'f': sz = 4; break;
+            case 'Z': case 'H': { const uint8_t* z = aux; while (z < end && *z) ++z; sz = (size_t)(z - aux) + 1;
+                                  if (t0 == 'C' && t1 == 'B' && ty == 'Z') { cb = (const char*)aux; cb_len = sz - 1; } break; }
+            case 'B': { if (aux + 5 > end) { aux = end; continue; } const char st = (char)aux[0]; const uint32_t cnt = rd32(aux + 1);
+                        const size_t es = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : 4; sz = 5 + es * cnt; break; }
+            default: aux = end; continue;
+        }
+        aux += sz;
+    }
+    if (!cb) { ++L.cb_not_found; return; }
+    size_t clean = 0; while (clean < cb_len && cb[clean] != '-') ++clean;          // barcode.split("-")[0] (:83)
+    auto it = cbmap.find(std::string(cb, clean));
+    if (it == cbmap.end()) { ++L.cb_not_matched; return; }
+    if ((int)mapq < min_mapq) ++L.mapq; else ++L.pass;                             // report only; the device re-applies min_mq
+    if ((flag & 0x4) || n_cigar == 0) return;                                      // no alignment: nothing to pile up
+    const uint32_t r = (uint32_t)L.read_tid.size();
+    L.read_tid.push_back(tid); L.read_pos.push_back(pos); L.read_flag.push_back((uint16_t)flag); L.read_mapq.push_back((uint8_t)mapq);
+    L.read_cb.push_back(it->second);
+    // CIGAR walk (htslib resolve_cigar2 semantics)
+    int64_t x = pos; uint32_t y = 0;
+    int64_t last_pos = -2;
+    auto emit = [&](int64_t refpos, uint32_t sym, uint32_t q) {
+        if (refpos != last_pos + 1 || L.seg_read.empty() || L.seg_read.back() != r) {
+            L.seg_read.push_back(r); L.seg_start.push_back((int32_t)refpos); L.seg_len.push_back(0); L.seg_ev_off.push_back((int64_t)L.events.size());
+        }
+        ++L.seg_len.back();
+        L.events.push_back((uint16_t)((sym << 8) | (q & 0xff)));
+        last_pos = refpos;
+    };
+    auto qual_at = [&](uint32_t q) -> uint32_t { return q < l_seq ? qual[q] : 0u; };
+    auto base_sym = [&](uint32_t q) -> uint32_t { return q < l_seq ? NT16_SYM[(seq[q >> 1] >> ((~q & 1) << 2)) & 0xf] : 6u; };   // beyond l_qseq pysam prints 'N'
+    for (uint32_t k = 0; k < n_cigar; ++k) {
+        const uint32_t c = rd32(cigar + 4ull * k), op = c & 0xf, len_op = c >> 4;
+        if (op == 1 || op == 4) { y += len_op; continue; }                       // I, S consume the query only
+        if (!is_ref_op(op)) continue;                                             // H, P
+        // indel flag of the LAST reference position of this op (peek at the next operations)
+        uint32_t over = 15;                                                       // 15 = none, 4 = I, 5 = D
+        if (k + 1 < n_cigar) {
+            const uint32_t op2 = rd32(cigar + 4ull * (k + 1)) & 0xf;
+            if (op2 == 2 && op != 2) over = 5;
+            else if (op2 == 1) over = 4;
+            else if (op2 == 6 && k + 2 < n_cigar) {
+                uint32_t l3 = 0;
+                for (uint32_t j = k + 2; j < n_cigar; ++j) {
+                    const uint32_t cj = rd32(cigar + 4ull * j), oj = cj & 0xf;
+                    if (oj == 1) l3 += cj >> 4;
+                    else if (oj == 2 || oj == 0 || oj == 3 || oj == 7 || oj == 8) break;
+                }
+                if (l3 > 0) over = 4;
+            }
+        }
+        if (op == 0 || op == 7 || op == 8) {
+            for (uint32_t i = 0; i < len_op; ++i) {
+                uint32_t sym = base_sym(y + i);
+                if (i + 1 == len_op && over != 15) sym = over;
+                emit(x + i, sym, qual_at(y + i));
+            }
+            x += len_op; y += len_op;
+        } else if (op == 2) {                                                     // deletion: '*' -> O, quality of the next query base
+            for (uint32_t i = 0; i < len_op; ++i) {
+                uint32_t sym = 7;
+                if (i + 1 == len_op && over != 15) sym = over;
+                emit(x + i, sym, qual_at(y));
+            }
+            x += len_op;
+        } else {                                                                  // N: '>' '<' are NA, except an indel flag on its last column
+            if (len_op > 0 && over != 15) emit(x + len_op - 1, over, qual_at(y));
+            x += len_op;
+        }
+    }
+}
+template <class T> T* dup_vec(const std::vector<T>& v) {
+    T* p = (T*)malloc(sizeof(T) * (v.size() ? v.size() : 1));
+    if (p && !v.empty()) memcpy(p, v.data(), sizeof(T) * v.size());
+    return p;
+}
+
+} // namespace
+
+extern "C" {
+
+typedef struct {
+    int64_t n_reads, n_segs, n_events;
+    int32_t* read_tid; int32_t* read_pos; uint16_t* read_flag; uint8_t* read_mapq; int32_t* read_cb;
+    uint32_t* seg_read; int32_t* seg_start; int32_t* seg_len; int64_t* seg_ev_off; uint16_t* events;
+    int32_t n_contigs; char* contig_names;   /* '\n'-joined */ int64_t* contig_len;
+    int64_t total_reads, pass_reads, cb_not_found, cb_not_matched, mapq_filtered;
+} lsio_decoded;
+
+const char* lsio_last_error(void) { return g_err; }
+
+void lsio_free_decoded(lsio_decoded* d) {
+    if (!d) return;
+    free(d->read_tid); free(d->read_pos); free(d->read_flag); free(d->read_mapq); free(d->read_cb);
+    free(d->seg_read); free(d->seg_start); free(d->seg_len); free(d->seg_ev_off); free(d->events);
+    free(d->contig_names); free(d->contig_len);
+    free(d);
+}
+
+// barcodes: n_barcodes cleaned barcode strings joined by '\n'; ids[i] = dense id of barcode i.
+int lsio_decode_bam(const char* path, const char* barcodes, int32_t n_barcodes, const int32_t* ids, int32_t min_mapq, int32_t n_threads,
+                    lsio_decoded** out) {
+    if (!path || !out) { set_err("lsio_decode_bam: bad arguments"); return -2; }
+    *out = nullptr;
+    std::unordered_map<std::string, int32_t> cbmap;
+    cbmap.reserve((size_t)n_barcodes * 2 + 16);
+    {
+        const char* s = barcodes ? barcodes : "";
+        for (int32_t i = 0; i < n_barcodes; ++i) {
+            const char* e = strchr(s, '\n'); size_t l = e ? (size_t)(e - s) : strlen(s);
+            cbmap[std::string(s, l)] = ids ? ids[i] : i;                          // duplicates: last wins (to_dict, :31)
+            s += l + (e ? 1 : 0);
+        }
+    }
+    FILE* f = fopen(path, "rb");
+    if (!f) { set_err("lsio_decode_bam: cannot open %s", path); return -1; }
+    fseek(f, 0, SEEK_END); const size_t fsize = (size_t)ftell(f); fseek(f, 0, SEEK_SET);
+    std::vector<uint8_t> file(fsize);
+    if (fsize && fread(file.data(), 1, fsize, f) != fsize) { fclose(f); set_err("lsio_decode_bam: short read on %s", path); return -1; }
+    fclose(f);
+    // BGZF block table
+    std::vector<Block> blocks;
+    size_t off = 0, utotal = 0;
+    while (off + 18 <= fsize) {
+        const uint8_t* h = file.data() + off;
+        if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) { set_err("lsio_decode_bam: %s is not BGZF (offset %zu)", path, off); return -1; }
+        const uint32_t xlen = rd16(h + 10);
+        uint32_t bsize = 0; bool found = false;
+        for (uint32_t q = 0; q + 4 <= xlen;) {
+            const uint8_t* sf = h + 12 + q; const uint32_t slen = rd16(sf + 2);
+            if (sf[0] == 'B' && sf[1] == 'C' && slen == 2) { bsize = rd16(sf + 4) + 1u; found = true; }
+            q += 4 + slen;
+        }
+        if (!found || off + bsize > fsize) { set_err("lsio_decode_bam: corrupt BGZF block at %zu", off); return -1; }
+        const uint32_t usize = rd32(h + bsize - 4);
+        blocks.push_back(Block{off + 12 + xlen, bsize - xlen - 20, usize, utotal});
+        utotal += usize; off += bsize;
+    }
+    if (n_threads <= 0) n_threads = (int)std::max(1u, std::thread::hardware_concurrency());
+    // inflate in parallel (chunks of blocks; the whole stream is kept: sized for the host RAM of a GPU node)
+    std::vector<uint8_t> data(utotal + 8);
+    std::atomic<size_t> next{0}; std::atomic<int> bad{0};
+    auto inflate_worker = [&]() {
+        z_stream zs;
+        for (;;) {
+            const size_t b = next.fetch_add(1);
+            if (b >= blocks.size()) break;
+            if (blocks[b].usize == 0) continue;
+            memset(&zs, 0, sizeof(zs));
+            if (inflateInit2(&zs, -15) != Z_OK) { bad = 1; break; }
+            zs.next_in = file.data() + blocks[b].off; zs.avail_in = blocks[b].csize;
+            zs.next_out = data.data() + blocks[b].uoff; zs.avail_out = blocks[b].usize;
+            const int rc = inflate(&zs, Z_FINISH);
+            inflateEnd(&zs);
+            if (rc != Z_STREAM_END || zs.avail_out != 0) { bad = 1; break; }
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (int t = 0; t < n_threads; ++t) th.emplace_back(inflate_worker);
+        for (auto& t : th) t.join();
+    }
+    if (bad) { set_err("lsio_decode_bam: inflate failed in %s", path); return -1; }
+    std::vector<uint8_t>().swap(file);
+    // header
+    const uint8_t* d = data.data();
+    if (utotal < 12 || memcmp(d, "BAM\1", 4) != 0) { set_err("lsio_decode_bam: %s has no BAM magic", path); return -1; }
+    size_t p = 4; const uint32_t l_text = rd32(d + p); p += 4 + l_text;
+    const uint32_t n_ref = rd32(d + p); p += 4;
+    std::string names; std::vector<int64_t> lens;
+    for (uint32_t i = 0; i < n_ref; ++i) {
+        const uint32_t l_name = rd32(d + p); p += 4;
+        names.append((const char*)d + p, l_name ? l_name - 1 : 0); names.push_back('\n'); p += l_name;
+        lens.push_back((int64_t)rd32(d + p)); p += 4;
+    }
+    // record offsets
+    std::vector<size_t> recs;
+    while (p + 4 <= utotal) {
+        const uint32_t bs = rd32(d + p);
+        if (bs < 32 || p + 4 + bs > utotal) { set_err("lsio_decode_bam: truncated record at %zu", p); return -1; }
+        recs.push_back(p); p += 4 + bs;
+    }
+    // parallel decode of contiguous record ranges
+    const int T = (int)std::min<size_t>((size_t)n_threads, std::max<size_t>(1, recs.size() / 1024));
+    std::vector<Local> loc((size_t)T);
+    {
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; ++t)
+            th.emplace_back([&, t]() {
+                const size_t a = recs.size() * (size_t)t / (size_t)T, b = recs.size() * (size_t)(t + 1) / (size_t)T;
+                for (size_t i = a; i < b; ++i) decode_record(d + recs[i] + 4, rd32(d + recs[i]), cbmap, min_mapq, loc[(size_t)t]);
+            });
+        for (auto& t : th) t.join();
+    }
+    lsio_decoded* o = (lsio_decoded*)calloc(1, sizeof(lsio_decoded));
+    int64_t R = 0, S = 0, E = 0;
+    for (auto& l : loc) { R += (int64_t)l.read_tid.size(); S += (int64_t)l.seg_read.size(); E += (int64_t)l.events.size(); }
+    o->n_reads = R; o->n_segs = S; o->n_events = E;
+    auto al = [](size_t n, size_t sz) { return malloc(sz * (n ? n : 1)); };
+    o->read_tid = (int32_t*)al(R, 4); o->read_pos = (int32_t*)al(R, 4); o->read_flag = (uint16_t*)al(R, 2); o->read_mapq = (uint8_t*)al(R, 1);
+    o->read_cb = (int32_t*)al(R, 4); o->seg_read = (uint32_t*)al(S, 4); o->seg_start = (int32_t*)al(S, 4); o->seg_len = (int32_t*)al(S, 4);
+    o->seg_ev_off = (int64_t*)al(S, 8); o->events = (uint16_t*)al(E, 2);
+    int64_t r0 = 0, s0 = 0, e0 = 0;
+    for (auto& l : loc) {
+        const size_t nr = l.read_tid.size(), ns = l.seg_read.size(), ne = l.events.size();
+        if (nr) { memcpy(o->read_tid + r0, l.read_tid.data(), nr * 4); memcpy(o->read_pos + r0, l.read_pos.data(), nr * 4);
+                  memcpy(o->read_flag + r0, l.read_flag.data(), nr * 2); memcpy(o->read_mapq + r0, l.read_mapq.data(), nr);
+                  memcpy(o->read_cb + r0, l.read_cb.data(), nr * 4); }
+        for (size_t i = 0; i < ns; ++i) {
+            o->seg_read[s0 + i] = l.seg_read[i] + (uint32_t)r0; o->seg_start[s0 + i] = l.seg_start[i]; o->seg_len[s0 + i] = l.seg_len[i];
+            o->seg_ev_off[s0 + i] = l.seg_ev_off[i] + e0;
+        }
+        if (ne) memcpy(o->events + e0, l.events.data(), ne * 2);
+        r0 += (int64_t)nr; s0 += (int64_t)ns; e0 += (int64_t)ne;
+        o->total_reads += l.total; o->pass_reads += l.pass; o->cb_not_found += l.cb_not_found; o->cb_not_matched += l.cb_not_matched;
+        o->mapq_filtered += l.mapq;
+    }
+    o->n_contigs = (int32_t)n_ref;
+    o->contig_names = (char*)malloc(names.size() + 1); memcpy(o->contig_names, names.c_str(), names.size() + 1);
+    o->contig_len = dup_vec(lens);
+    *out = o;
+    return 0;
+}
+
+// ---- BGZF / BAM writing -------------------------------------------------------------------------
+struct BgzfWriter {
+    FILE* f = nullptr; std::vector<uint8_t> buf; bool ok = true;
+    void flush_block(const uint8_t* src, size_t n) {
+        uint8_t out[70000];
+        z_stream zs; memset(&zs, 0, sizeof(zs));
+        deflateInit2(&zs, 1, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
+        zs.next_in = (Bytef*)src; zs.avail_in = (uInt)n; zs.next_out = out + 18; zs.avail_out = sizeof(out) - 26;
+        if (deflate(&zs, Z_FINISH) != Z_STREAM_END) ok = false;
+        const uint32_t clen = (uint32_t)zs.total_out; deflateEnd(&zs);
+        const uint8_t hdr[16] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 'B', 'C', 2, 0};
+        memcpy(out, hdr, 16);
+        const uint32_t bsize = clen + 25;
+        out[16] = (uint8_t)(bsize & 0xff); out[17] = (uint8_t)(bsize >> 8);
+        const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), src, (uInt)n);
+        uint8_t* t = out + 18 + clen;
+        for (int i = 0; i < 4; ++i) { t[i] = (uint8_t)(crc >> (8 * i)); t[4 + i] = (uint8_t)((uint32_t)n >> (8 * i)); }
+        if (fwrite(out, 1, 18 + clen + 8, f) != 18 + clen + 8) ok = false;
+    }
+    void write(const void* p, size_t n) {
+        const uint8_t* s = (const uint8_t*)p;
+        while (n) {
+            const size_t room = 0xff00 - buf.size(), take = n < room ? n : room;
+            buf.insert(buf.end(), s, s + take); s += take; n -= take;
+            if (buf.size() >= 0xff00) { flush_block(buf.data(), buf.size()); buf.clear(); }
+        }
+    }
+    void close() {
+        if (!buf.empty()) { flush_block(buf.data(), buf.size()); buf.clear(); }
+        flush_block(nullptr, 0);                                                 // EOF marker block
+        if (f) fclose(f);
+        f = nullptr;
+    }
+};
+
+static void put32(std::vector<uint8_t>& v, uint32_t x) { for (int i = 0; i < 4; ++i) v.push_back((uint8_t)(x >> (8 * i))); }
+
+// Writes the model's reads as a coordinate-sorted BAM (CB:Z tags, soft clips, indels, introns) and,
+// optionally, the reference FASTA.  barcode_suffix (e.g. "-1") is appended to every CB value.
+int lsio_synth_bam(const lsg_synth_model* m, const char* contig_names /* '\n'-joined */, const int64_t* contig_len, const char* bam_path,
+                   const char* fasta_path, const char* barcode_suffix) {
+    if (!m || !bam_path) { set_err("lsio_synth_bam: bad arguments"); return -2; }
+    std::vector<std::string> names;
+    { const char* s = contig_names; for (int i = 0; i < m->n_contigs; ++i) { const char* e = strchr(s, '\n'); size_t l = e ? (size_t)(e - s) : strlen(s); names.emplace_back(s, l); s += l + (e ? 1 : 0); } }
+    if (fasta_path && *fasta_path) {
+        FILE* ff = fopen(fasta_path, "w");
+        if (!ff) { set_err("lsio_synth_bam: cannot write %s", fasta_path); return -1; }
+        for (int t = 0; t < m->n_contigs; ++t) {
+            fprintf(ff, ">%s\n", names[(size_t)t].c_str());
+            std::string line;
+            for (int64_t p = 0; p < contig_len[t]; ++p) {
+                line.push_back((char)sm_ref_base(m->seed, t, p));
+                if (line.size() == 60 || p + 1 == contig_len[t]) { line.push_back('\n'); fputs(line.c_str(), ff); line.clear(); }
+            }
+        }
+        fclose(ff);
+    }
+    const int64_t R = m->n_reads;
+    std::vector<sm_read> hdr((size_t)R);
+    std::vector<int32_t> pos((size_t)R);
+    std::vector<int64_t> order((size_t)R);
+    for (int64_t i = 0; i < R; ++i) {
+        sm_read_header(m, i + m->read_base, &hdr[(size_t)i]);
+        const sm_read& r = hdr[(size_t)i];
+        pos[(size_t)i] = m->exon_start[r.e0] + (r.t_off - m->exon_cum[r.e0]);
+        order[(size_t)i] = i;
+    }
+    std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) {
+        if (hdr[(size_t)a].tid != hdr[(size_t)b].tid) return hdr[(size_t)a].tid < hdr[(size_t)b].tid;
+        return pos[(size_t)a] < pos[(size_t)b];
+    });
+    BgzfWriter w; w.f = fopen(bam_path, "wb");
+    if (!w.f) { set_err("lsio_synth_bam: cannot write %s", bam_path); return -1; }
+    {
+        std::vector<uint8_t> h; h.insert(h.end(), {'B', 'A', 'M', 1});
+        std::string text = "@HD\tVN:1.6\tSO:coordinate\n";
+        for (int t = 0; t < m->n_contigs; ++t) text += "@SQ\tSN:" + names[(size_t)t] + "\tLN:" + std::to_string(contig_len[t]) + "\n";
+        put32(h, (uint32_t)text.size()); h.insert(h.end(), text.begin(), text.end());
+        put32(h, (uint32_t)m->n_contigs);
+        for (int t = 0; t < m->n_contigs; ++t) { put32(h, (uint32_t)names[(size_t)t].size() + 1); h.insert(h.end(), names[(size_t)t].begin(), names[(size_t)t].end()); h.push_back(0); put32(h, (uint32_t)contig_len[t]); }
+        w.write(h.data(), h.size());
+    }
+    const char acgt[4] = {'A', 'C', 'G', 'T'};
+    auto code_of = [](char c) -> uint8_t { return c == 'A' ? 1 : c == 'C' ? 2 : c == 'G' ? 4 : c == 'T' ? 8 : 15; };
+    std::vector<uint32_t> cig; std::string seq; std::vector<uint8_t> qual, rec;
+    for (int64_t oi = 0; oi < R; ++oi) {
+        const int64_t i = order[(size_t)oi], ig = i + m->read_base;
+        const sm_read& r = hdr[(size_t)i];
+        cig.clear(); seq.clear(); qual.clear();
+        auto push_op = [&](uint32_t op, uint32_t len) { if (!len) return; if (!cig.empty() && (cig.back() & 0xf) == op) cig.back() += len << 4; else cig.push_back((len << 4) | op); };
+        for (int32_t c = 0; c < r.clip5; ++c) { const uint64_t h = sm_hash(m->seed, (uint64_t)ig, (uint64_t)(100000 + c), SM_D_INS); seq.push_back(acgt[h & 3]); qual.push_back((uint8_t)(2 + (h >> 8) % 39)); }
+        push_op(4, (uint32_t)r.clip5);
+        const int32_t end = r.t_off + r.t_len;
+        for (int32_t x = r.e0; x <= r.e1; ++x) {
+            const int32_t xt0 = m->exon_cum[x], xt1 = xt0 + m->exon_len[x];
+            const int32_t lo = r.t_off > xt0 ? r.t_off : xt0, hi = end < xt1 ? end : xt1;
+            if (x > r.e0) push_op(3, (uint32_t)(m->exon_start[x] - (m->exon_start[x - 1] + m->exon_len[x - 1])));
+            for (int32_t j = lo; j < hi; ++j) {
+                const int32_t blk = j >> 3, k = j & 7;
+                const int32_t ind = sm_block_indel(m, ig, blk, lo, hi);
+                if (ind > 0 && k >= 2 && k <= 1 + ind) { push_op(2, 1); continue; }      // deleted base
+                const uint32_t s = sm_base_call(m, ig, &r, j, (int64_t)m->exon_start[x] + (j - xt0));
+                seq.push_back((char)sm_base_of_sym(s)); qual.push_back((uint8_t)sm_qual(m, ig, j));
+                push_op(0, 1);
+                if (ind < 0 && k == 3) {
+                    for (int32_t c = 0; c < -ind; ++c) { const uint64_t h = sm_hash(m->seed, (uint64_t)ig, (uint64_t)((uint32_t)j * 4u + (uint32_t)c), SM_D_INS); seq.push_back(acgt[h & 3]); qual.push_back((uint8_t)(2 + (h >> 8) % 39)); }
+                    push_op(1, (uint32_t)(-ind));
+                }
+            }
+        }
+        for (int32_t c = 0; c < r.clip3; ++c) { const uint64_t h = sm_hash(m->seed, (uint64_t)ig, (uint64_t)(200000 + c), SM_D_INS); seq.push_back(acgt[h & 3]); qual.push_back((uint8_t)(2 + (h >> 8) % 39)); }
+        push_op(4, (uint32_t)r.clip3);
+        char name[32]; const int ln = snprintf(name, sizeof(name), "r%lld", (long long)ig) + 1;
+        rec.clear();
+        put32(rec, 0);                                                           // block_size placeholder
+        put32(rec, (uint32_t)r.tid); put32(rec, (uint32_t)pos[(size_t)i]);
+        rec.push_back((uint8_t)ln); rec.push_back(r.mapq); rec.push_back(0x48); rec.push_back(0x12);   // bin (unused)
+        rec.push_back((uint8_t)(cig.size() & 0xff)); rec.push_back((uint8_t)(cig.size() >> 8));
+        rec.push_back((uint8_t)(r.flag & 0xff)); rec.push_back((uint8_t)(r.flag >> 8));
+        put32(rec, (uint32_t)seq.size()); put32(rec, 0xffffffffu); put32(rec, 0xffffffffu); put32(rec, 0);
+        rec.insert(rec.end(), name, name + ln);
+        for (uint32_t c : cig) put32(rec, c);
+        for (size_t q = 0; q < seq.size(); q += 2) rec.push_back((uint8_t)((code_of(seq[q]) << 4) | (q + 1 < seq.size() ? code_of(seq[q + 1]) : 0)));
+        rec.insert(rec.end(), qual.begin(), qual.end());
+        const uint8_t nh[7] = {'N', 'H', 'C', 1, 0, 0, 0}; rec.insert(rec.end(), nh, nh + 4);
+        if (r.cb != -1) {
+            char bc[17]; sm_barcode(m->seed, r.cb >= 0 ? r.cb : ig, r.cb < 0, bc);
+            rec.push_back('C'); rec.push_back('B'); rec.push_back('Z'); rec.insert(rec.end(), bc, bc + 16);
+            if (barcode_suffix) rec.insert(rec.end(), barcode_suffix, barcode_suffix + strlen(barcode_suffix));
+            rec.push_back(0);
+        }
+        const uint32_t bs = (uint32_t)rec.size() - 4;
+        for (int b = 0; b < 4; ++b) rec[(size_t)b] = (uint8_t)(bs >> (8 * b));
+        w.write(rec.data(), rec.size());
+    }
+    w.close();
+    if (!w.ok) { set_err("lsio_synth_bam: write failed"); return -1; }
+    return 0;
+}
+
+// Host evaluation of the model's read-record arrays (the same arrays lsg_synth_reads generates in HBM).
+int lsio_synth_records(const lsg_synth_model* m, lsio_decoded** out) {
+    if (!m || !out) { set_err("lsio_synth_records: bad arguments"); return -2; }
+    Local L;
+    for (int64_t i = 0; i < m->n_reads; ++i) {
+        const int64_t ig = i + m->read_base;
+        sm_read r; sm_read_header(m, ig, &r);
+        L.read_tid.push_back(r.tid); L.read_pos.push_back(m->exon_start[r.e0] + (r.t_off - m->exon_cum[r.e0]));
+        L.read_flag.push_back(r.flag); L.read_mapq.push_back(r.mapq); L.read_cb.push_back(r.cb >= 0 ? r.cb : -1);
+        const int32_t end = r.t_off + r.t_len;
+        for (int32_t x = r.e0; x <= r.e1; ++x) {
+            const int32_t xt0 = m->exon_cum[x], xt1 = xt0 + m->exon_len[x];
+            const int32_t lo = r.t_off > xt0 ? r.t_off : xt0, hi = end < xt1 ? end : xt1;
+            L.seg_read.push_back((uint32_t)i); L.seg_start.push_back(m->exon_start[x] + (lo - xt0)); L.seg_len.push_back(hi - lo);
+            L.seg_ev_off.push_back((int64_t)L.events.size());
+            for (int32_t j = lo; j < hi; ++j) L.events.push_back(sm_event(m, ig, &r, j, xt0, xt1, m->exon_start[x]));
+        }
+    }
+    lsio_decoded* o = (lsio_decoded*)calloc(1, sizeof(lsio_decoded));
+    o->n_reads = (int64_t)L.read_tid.size(); o->n_segs = (int64_t)L.seg_read.size(); o->n_events = (int64_t)L.events.size();
+    o->read_tid = dup_vec(L.read_tid); o->read_pos = dup_vec(L.read_pos); o->read_flag = dup_vec(L.read_flag); o->read_mapq = dup_vec(L.read_mapq);
+    o->read_cb = dup_vec(L.read_cb); o->seg_read = dup_vec(L.seg_read); o->seg_start = dup_vec(L.seg_start); o->seg_len = dup_vec(L.seg_len);
+    o->seg_ev_off = dup_vec(L.seg_ev_off); o->events = dup_vec(L.events);
+    *out = o;
+    return 0;
+}
+
+void lsio_barcode(uint64_t seed, int64_t cb, char* out17) { sm_barcode(seed, cb, 0, out17); }
+
+} // extern "C"

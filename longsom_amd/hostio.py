@@ -1,0 +1,159 @@
+"""ctypes binding of liblongsom_io.so (longsom_amd/csrc/hostio/bamio.cpp): BAM -> read-record arrays,
+barcodes.tsv -> barcode table, synthetic BAM / FASTA writer.
+
+  read_barcodes   <- meta_to_dict   workflow/scripts/PreProcessing/SplitBamCellTypes.py:16-36
+  decode_bam      <- split_bam's record loop (:65-124) + the CIGAR walk of pysam's pileup
+"""
+import ctypes as C
+import os
+import re
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from .engine import ReadRecords
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "liblongsom_io.so")
+_lib = None
+
+
+class Decoded(C.Structure):
+    _fields_ = [
+        ("n_reads", C.c_int64), ("n_segs", C.c_int64), ("n_events", C.c_int64),
+        ("read_tid", C.c_void_p), ("read_pos", C.c_void_p), ("read_flag", C.c_void_p), ("read_mapq", C.c_void_p), ("read_cb", C.c_void_p),
+        ("seg_read", C.c_void_p), ("seg_start", C.c_void_p), ("seg_len", C.c_void_p), ("seg_ev_off", C.c_void_p), ("events", C.c_void_p),
+        ("n_contigs", C.c_int32), ("contig_names", C.c_char_p), ("contig_len", C.c_void_p),
+        ("total_reads", C.c_int64), ("pass_reads", C.c_int64), ("cb_not_found", C.c_int64), ("cb_not_matched", C.c_int64),
+        ("mapq_filtered", C.c_int64),
+    ]
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} not found: build it with `make -C longsom_amd/csrc/hostio`")
+        lib = C.CDLL(LIB_PATH)
+        lib.lsio_last_error.restype = C.c_char_p
+        lib.lsio_decode_bam.restype = C.c_int
+        lib.lsio_decode_bam.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.POINTER(Decoded))]
+        lib.lsio_free_decoded.argtypes = [C.POINTER(Decoded)]
+        lib.lsio_synth_bam.restype = C.c_int
+        lib.lsio_synth_bam.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p]
+        lib.lsio_synth_records.restype = C.c_int
+        lib.lsio_synth_records.argtypes = [C.c_void_p, C.POINTER(C.POINTER(Decoded))]
+        lib.lsio_barcode.argtypes = [C.c_uint64, C.c_int64, C.c_char_p]
+        _lib = lib
+    return _lib
+
+
+def _err(what):
+    raise RuntimeError("%s: %s" % (what, load().lsio_last_error().decode("utf-8", "replace")))
+
+
+@dataclass
+class BarcodeTable:
+    """barcodes.tsv as the device sees it: cleaned barcode -> dense id -> cell-type index."""
+    barcodes: List[str]            # cleaned, unique, dense id = position
+    celltype_of: np.ndarray        # uint8 [n_cb]
+    celltype_names: List[str]      # index -> name, python-sorted (fixed column order)
+
+
+def read_barcodes(path: str) -> BarcodeTable:
+    """meta_to_dict: tab-separated with header, columns Index and Cell_type; Index loses everything from the
+    first '-' (regex '-.*$', :20), spaces in Cell_type become '_' (:24); duplicated cleaned barcodes: the last
+    row wins (dict semantics of to_dict, :31)."""
+    import pandas as pd
+    meta = pd.read_csv(path, delimiter="\t")
+    clean = [re.sub("-.*$", "", str(x)) for x in meta["Index"]]
+    ctype = [str(x).replace(" ", "_") for x in meta["Cell_type"]]
+    mapping: Dict[str, str] = {}
+    for b, c in zip(clean, ctype):
+        mapping[b] = c
+    names = sorted(set(mapping.values()))
+    idx = {n: i for i, n in enumerate(names)}
+    barcodes = list(mapping)
+    return BarcodeTable(barcodes, np.asarray([idx[mapping[b]] for b in barcodes], np.uint8), names)
+
+
+def _take(d: Decoded) -> ReadRecords:
+    def arr(ptr, n, dt):
+        if n == 0 or not ptr:
+            return np.zeros(0, dt)
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(np.ctypeslib.as_ctypes_type(dt))), shape=(n,)).copy()
+    R, S, E = d.n_reads, d.n_segs, d.n_events
+    return ReadRecords(arr(d.read_tid, R, np.int32), arr(d.read_pos, R, np.int32), arr(d.read_flag, R, np.uint16), arr(d.read_mapq, R, np.uint8),
+                       arr(d.read_cb, R, np.int32), arr(d.seg_read, S, np.uint32), arr(d.seg_start, S, np.int32), arr(d.seg_len, S, np.int32),
+                       arr(d.seg_ev_off, S, np.int64), arr(d.events, E, np.uint16))
+
+
+@dataclass
+class DecodedBam:
+    records: ReadRecords
+    contig_names: List[str]
+    contig_len: np.ndarray
+    report: Dict[str, int]         # the counters of SplitBamCellTypes' report.txt (:62,117-124)
+
+
+def decode_bam(path: str, barcodes: Sequence[str], min_mapq: int = 60, threads: int = 0) -> DecodedBam:
+    """BAM -> read-record arrays.  Reads without a CB tag or whose cleaned CB is not in `barcodes` are dropped
+    (they can never be counted); flags and MAPQ are kept for the device-side admission."""
+    lib = load()
+    out = C.POINTER(Decoded)()
+    joined = "\n".join(barcodes).encode()
+    if lib.lsio_decode_bam(os.fsencode(path), joined, len(barcodes), None, int(min_mapq), int(threads), C.byref(out)) != 0:
+        _err("lsio_decode_bam")
+    try:
+        d = out.contents
+        rec = _take(d)
+        names = d.contig_names.decode().split("\n")[: d.n_contigs] if d.n_contigs else []
+        lens = np.ctypeslib.as_array(C.cast(d.contig_len, C.POINTER(C.c_int64)), shape=(d.n_contigs,)).copy() if d.n_contigs else np.zeros(0, np.int64)
+        rep = {"Total_reads": d.total_reads, "Pass_reads": d.pass_reads, "CB_not_found": d.cb_not_found, "CB_not_matched": d.cb_not_matched}
+        if d.mapq_filtered:
+            rep["MAPQ"] = d.mapq_filtered
+        return DecodedBam(rec, names, lens, rep)
+    finally:
+        lib.lsio_free_decoded(out)
+
+
+def synth_barcodes(model) -> List[str]:
+    lib = load()
+    buf = C.create_string_buffer(17)
+    res = []
+    for cb in range(model.n_cb):
+        lib.lsio_barcode(C.c_uint64(model.seed), cb, buf)
+        res.append(buf.value.decode())
+    return res
+
+
+def synth_bam(model, bam_path: str, fasta_path: Optional[str] = None, barcode_suffix: str = "") -> None:
+    """Write the model's reads as a coordinate-sorted BAM (+ the synthetic reference as FASTA)."""
+    lib = load()
+    mc = model.as_c()
+    names = "\n".join(model.contig_names).encode()
+    lens = np.ascontiguousarray(model.contig_len, np.int64)
+    if lib.lsio_synth_bam(C.byref(mc), names, lens.ctypes.data_as(C.c_void_p), os.fsencode(bam_path),
+                          os.fsencode(fasta_path) if fasta_path else None, barcode_suffix.encode() if barcode_suffix else None) != 0:
+        _err("lsio_synth_bam")
+
+
+def synth_records(model) -> ReadRecords:
+    """Host evaluation of the model (same arrays the GPU generator produces)."""
+    lib = load()
+    out = C.POINTER(Decoded)()
+    mc = model.as_c()
+    if lib.lsio_synth_records(C.byref(mc), C.byref(out)) != 0:
+        _err("lsio_synth_records")
+    try:
+        return _take(out.contents)
+    finally:
+        lib.lsio_free_decoded(out)
+
+
+def write_barcodes_tsv(path: str, barcodes: Sequence[str], celltype_of, celltype_names: Sequence[str], suffix: str = "") -> None:
+    with open(path, "w") as f:
+        f.write("Index\tCell_type\n")
+        for b, c in zip(barcodes, celltype_of):
+            f.write("%s%s\t%s\n" % (b, suffix, celltype_names[int(c)]))

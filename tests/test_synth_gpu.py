@@ -70,3 +70,14 @@ def test_region_shards_partition_the_rows(engine):
         np.testing.assert_array_equal(k, full[ct][0])
         np.testing.assert_array_equal(c, full[ct][2])
         assert (parts[0][ct][0] & 0xffffffff).max() < cut <= (parts[1][ct][0] & 0xffffffff).min()
+
+
+def test_device_generator_equals_host_model(engine):
+    """synth.hip and the host evaluation of synth_model.h produce the same arrays, bit for bit."""
+    from longsom_amd import hostio
+    model = synth.named("C1", n_reads=3000, n_genes=60, n_cb=50)
+    setup_model(engine, model)
+    dev = engine.reads_to_host()
+    host = hostio.synth_records(model)
+    for name, _ in dev._SPEC:
+        np.testing.assert_array_equal(getattr(dev, name), getattr(host, name), err_msg=name)
