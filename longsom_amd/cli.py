@@ -1,0 +1,161 @@
+"""Command-line entry points with the flag surface of the reference's rule scripts, so that
+a rule's `shell:` line keeps working when only its `script=` path changes.  Each function names the
+reference CLI it stands in for.  `snv` is the fused entry (one decode, everything resident in HBM)."""
+import argparse
+import glob
+import json
+import os
+import time
+
+from . import calling, hostio, pipeline, tsvio
+from ._lib import CallParams, CountParams
+from .engine import Engine
+
+
+def split_bam(argv=None):
+    """SplitBamCellTypes.py --bam --meta --id --outdir --min_MQ  (SplitBamCellTypes.py:194-204)"""
+    ap = argparse.ArgumentParser(description="Split a BAM into one BAM per cell type by CB tag")
+    ap.add_argument("--bam", required=True); ap.add_argument("--meta", required=True); ap.add_argument("--id", default="Sample")
+    ap.add_argument("--max_nM", type=int, default=None); ap.add_argument("--max_NH", type=int, default=None)
+    ap.add_argument("--min_MQ", type=int, default=255); ap.add_argument("--n_trim", type=int, default=0); ap.add_argument("--outdir", default=".")
+    a = ap.parse_args(argv)
+    if a.max_nM is not None or a.max_NH is not None or a.n_trim:
+        raise SystemExit("--max_nM / --max_NH / --n_trim are not used by LongSom's rules and are not implemented")
+    t0 = time.time()
+    table = hostio.read_barcodes(a.meta)
+    outs = [os.path.join(a.outdir, "%s.%s.bam" % (a.id, ct)) for ct in table.celltype_names]
+    rep = hostio.split_bam(a.bam, table, outs, a.min_MQ)
+    pipeline.write_report(os.path.join(a.outdir, a.id + ".report.txt"), rep, time.time() - t0)
+
+
+def base_cell_counter(argv=None):
+    """BaseCellCounter.py --bam --ref --chrom --out_folder --nprocs --min_mq --tmp_dir [...]  (BaseCellCounter.py:323-342).
+    --bam is one cell type's BAM: every CB in it is a cell of that type."""
+    ap = argparse.ArgumentParser(description="Per-cell-type pileup base counting on the GPU")
+    ap.add_argument("--bam", required=True); ap.add_argument("--ref", required=True); ap.add_argument("--chrom", required=True)
+    ap.add_argument("--out_folder", default="."); ap.add_argument("--id"); ap.add_argument("--nprocs", type=int, default=1)
+    ap.add_argument("--bin", type=int, default=50000); ap.add_argument("--bed", default=""); ap.add_argument("--bed_out", default="")
+    ap.add_argument("--min_ac", type=int, default=0); ap.add_argument("--min_af", type=float, default=0); ap.add_argument("--min_dp", type=int, default=5)
+    ap.add_argument("--min_cc", type=int, default=5); ap.add_argument("--min_bq", type=int, default=20); ap.add_argument("--min_mq", type=int, default=255)
+    ap.add_argument("--tmp_dir", default="."); ap.add_argument("--device", type=int, default=0)
+    a = ap.parse_args(argv)
+    if a.bed or a.bed_out or a.min_ac:
+        raise SystemExit("--bed / --bed_out / --min_ac are not used by LongSom's rules and are not implemented")
+    sid = a.id or os.path.basename(a.bam).replace(".bam", "")
+    if a.tmp_dir != ".":
+        os.makedirs(a.tmp_dir, exist_ok=True)          # the rule declares it as an output (R:SNVCalling.smk:36)
+    dec = hostio.decode_bam(a.bam, None, min_mapq=a.min_mq)
+    names, seqs = tsvio.read_fasta(a.ref)
+    seq_of = dict(zip(names, seqs))
+    with Engine(a.device) as eng:
+        eng.set_contigs(dec.contig_len)
+        for tid, n in enumerate(dec.contig_names):
+            eng.load_reference(tid, seq_of[n])
+        import numpy as np
+        eng.set_barcodes(np.zeros(max(1, len(dec.barcodes)), np.uint8), 1)
+        if a.chrom != "all":
+            tid = dec.contig_names.index(a.chrom)
+            eng.set_region(tid, 0, tid + 1, 0)
+        eng.load_reads(dec.records)
+        eng.pileup_count(CountParams.longsom_defaults(min_bq=a.min_bq, min_mq=a.min_mq, min_dp=a.min_dp, min_cc=a.min_cc))
+        k, r, c = eng.fetch_counts(0)
+    out = os.path.join(a.out_folder, sid + ".tsv")
+    print("Outfile: ", out, "\n")
+    with open(out, "w") as f:
+        f.write(tsvio.format_counts_tsv(k, r, c, dec.contig_names, sid))
+
+
+def merge_counts(argv=None):
+    """MergeBaseCellCounts.py --tsv_folder --outfile  (MergeBaseCellCounts.py:206-210); columns in sorted file order."""
+    ap = argparse.ArgumentParser(description="Merge per-cell-type base count TSVs")
+    ap.add_argument("--tsv_folder", required=True); ap.add_argument("--outfile", required=True)
+    a = ap.parse_args(argv)
+    files = sorted(glob.glob(a.tsv_folder + "/*.tsv"))
+    if not files:
+        raise RuntimeError("No tsv files found")
+    contigs = tsvio.contigs_of_tsv(files)
+    per_ct = [tsvio.parse_counts_tsv(f, contigs)[:3] for f in files]
+    cts = [os.path.basename(f).split(".")[-2] for f in files]
+    with open(a.outfile, "w") as f:
+        f.write(tsvio.format_merged_tsv(per_ct, contigs, cts))
+
+
+def calling_step1(argv=None):
+    """BaseCellCalling.step1.py --infile --outfile --ref --min_cell_types --min_ac_reads --min_ac_cells --alpha1 ...  (step1.py:585-604)"""
+    ap = argparse.ArgumentParser(description="Beta-binomial somatic test on the GPU")
+    ap.add_argument("--infile", required=True); ap.add_argument("--outfile", required=True); ap.add_argument("--ref", required=True)
+    ap.add_argument("--editing"); ap.add_argument("--pon")
+    ap.add_argument("--min_cov", type=int, default=5); ap.add_argument("--min_cells", type=int, default=5)
+    ap.add_argument("--min_ac_cells", type=int, default=2); ap.add_argument("--min_ac_reads", type=int, default=3)
+    ap.add_argument("--max_cell_types", type=int, default=1); ap.add_argument("--min_cell_types", type=int, default=2)
+    ap.add_argument("--fisher_cutoff", type=float, default=1); ap.add_argument("--min_distance", type=int, default=5)
+    ap.add_argument("--alpha1", type=float, default=0.21356677091082193); ap.add_argument("--beta1", type=float, default=104.95163748636298)
+    ap.add_argument("--alpha2", type=float, default=0.2474528917555431); ap.add_argument("--beta2", type=float, default=162.03696139428595)
+    ap.add_argument("--device", type=int, default=0)
+    a = ap.parse_args(argv)
+    if a.fisher_cutoff != 1:
+        raise SystemExit("--fisher_cutoff other than 1 (strand test off) is not implemented")
+    names, seqs = tsvio.read_fasta(a.ref)
+    cts, per_ct, header = tsvio.parse_merged_tsv(a.infile, names)
+    with Engine(a.device) as eng:
+        eng.set_contigs([len(s) for s in seqs])
+        for t, s in enumerate(seqs):
+            eng.load_reference(t, s)
+        eng.load_counts([p[0] for p in per_ct], [p[2] for p in per_ct])
+        eng.call_step1(CallParams.longsom_defaults(alpha1=a.alpha1, beta1=a.beta1, alpha2=a.alpha2, beta2=a.beta2, min_cov=a.min_cov,
+                                                   min_cells=a.min_cells, min_ac_cells=a.min_ac_cells, min_ac_reads=a.min_ac_reads,
+                                                   max_cell_types=a.max_cell_types, min_cell_types=a.min_cell_types))
+        calls = eng.fetch_calls()
+    with open(a.outfile + ".calling.step1.tsv", "w") as f:
+        f.write(tsvio.format_step1_tsv(calls, per_ct, names, cts, header))
+
+
+def calling_step2(argv=None):
+    """BaseCellCalling.step2.py --infile --outfile --editing --pon_SR --pon_LR --gnomAD_db --gnomAD_max --min_distance  (step2.py:237-248).
+    --gnomAD_db: a JSON {"chrom:pos:ref:alt": AF} (the gnomAD sqlite is not part of this repository); anything else = AF 0."""
+    ap = argparse.ArgumentParser(description="Position-set / distance / gnomAD tags")
+    ap.add_argument("--infile", required=True); ap.add_argument("--outfile", required=True); ap.add_argument("--editing")
+    ap.add_argument("--pon_SR", required=True); ap.add_argument("--pon_LR", nargs="?", const="", default="")
+    ap.add_argument("--min_distance", type=int, default=5); ap.add_argument("--gnomAD_db"); ap.add_argument("--gnomAD_max", type=float, default=0.01)
+    ap.add_argument("--reference-gz-compat", action="store_true"); ap.add_argument("--device", type=int, default=0)
+    a = ap.parse_args(argv)
+    text = open(a.infile).read()
+    contigs = tsvio.contigs_of_tsv([a.infile])
+    af = json.load(open(a.gnomAD_db)) if a.gnomAD_db and a.gnomAD_db.endswith(".json") and os.path.exists(a.gnomAD_db) else None
+    keys = [calling.read_posset_keys(p, contigs, a.reference_gz_compat) for p in (a.editing, a.pon_SR, a.pon_LR)]
+    with Engine(a.device) as eng:
+        out = calling.step2(text, eng, contigs, keys[0], keys[1], keys[2], a.min_distance, af, a.gnomAD_max)
+    with open(a.outfile + ".calling.step2.tsv", "w") as f:
+        f.write(out)
+
+
+def calling_step3(argv=None):
+    """BaseCellCalling.step3.py --infile --outfile --deltaVAF --deltaMCF --chrM_contaminant --min_ac_reads --min_ac_cells --clust_dist  (step3.py:318-328)"""
+    ap = argparse.ArgumentParser(description="LongSom final filters")
+    ap.add_argument("--infile", required=True); ap.add_argument("--outfile", required=True)
+    ap.add_argument("--deltaVAF", type=float, required=True); ap.add_argument("--deltaMCF", type=float, required=True)
+    ap.add_argument("--chrM_contaminant", default="True"); ap.add_argument("--min_ac_reads", type=int, default=2)
+    ap.add_argument("--min_ac_cells", type=int, default=3); ap.add_argument("--clust_dist", type=int, default=5)
+    a = ap.parse_args(argv)
+    final, unfiltered = calling.step3(open(a.infile).read(), a.deltaVAF, a.deltaMCF, a.min_ac_reads, a.min_ac_cells, a.clust_dist)
+    open(a.outfile + ".calling.step3.tsv", "w").write(final)
+    open(a.outfile + ".calling.step3.unfiltered.tsv", "w").write(unfiltered)
+
+
+def snv(argv=None):
+    """Fused chain: one process from BAM to calling.step3.tsv (workflow/rules/SNVCalling.gpu.smk)."""
+    ap = argparse.ArgumentParser(description="SplitBam -> BaseCellCounter -> MergeCounts -> BaseCellCalling step1-3 on one GPU")
+    ap.add_argument("--bam", required=True); ap.add_argument("--meta", required=True); ap.add_argument("--ref", required=True)
+    ap.add_argument("--id", required=True); ap.add_argument("--outdir", required=True)
+    ap.add_argument("--editing"); ap.add_argument("--pon_SR"); ap.add_argument("--pon_LR"); ap.add_argument("--gnomAD_json")
+    ap.add_argument("--device", type=int, default=0)
+    d = pipeline.SnvParams()
+    for k, v in vars(d).items():
+        if isinstance(v, bool):
+            ap.add_argument("--" + k, action="store_true")
+        else:
+            ap.add_argument("--" + k, type=type(v), default=v)
+    a = ap.parse_args(argv)
+    params = pipeline.SnvParams(**{k: getattr(a, k) for k in vars(d)})
+    out = pipeline.run_snv(a.bam, a.meta, a.ref, a.outdir, a.id, params, a.editing, a.pon_SR, a.pon_LR, a.gnomAD_json, a.device)
+    print(json.dumps({"outputs": {k: v for k, v in vars(out).items() if k != "timings"}, "seconds": out.timings}))

@@ -47,6 +47,33 @@ struct Local {   // per-thread decode output
 
 inline bool is_ref_op(uint32_t op) { return op == 0 || op == 2 || op == 3 || op == 7 || op == 8; }
 
+// CB:Z value of a record, cleaned like barcode.split("-")[0]; false when the tag is missing.
+bool find_cb(const uint8_t* rec, uint32_t len, const char** cb_out, size_t* len_out) {
+    const uint32_t l_name = rec[8], n_cigar = rd16(rec + 12), l_seq = rd32(rec + 16);
+    const uint8_t* aux = rec + 32 + l_name + 4ull * n_cigar + (l_seq + 1) / 2 + l_seq;
+    const uint8_t* end = rec + len;
+    while (aux + 3 <= end) {
+        const char t0 = (char)aux[0], t1 = (char)aux[1], ty = (char)aux[2];
+        aux += 3;
+        size_t sz = 0;
+        switch (ty) {
+            case 'A': case 'c': case 'C': sz = 1; break;
+            case 's': case 'S': sz = 2; break;
+            case 'i': case 'I': case 'f': sz = 4; break;
+            case 'Z': case 'H': { const uint8_t* z = aux; while (z < end && *z) ++z; sz = (size_t)(z - aux) + 1;
+                                  if (t0 == 'C' && t1 == 'B' && ty == 'Z') {
+                                      size_t clean = 0; while (clean < sz - 1 && aux[clean] != '-') ++clean;
+                                      *cb_out = (const char*)aux; *len_out = clean; return true;
+                                  } break; }
+            case 'B': { if (aux + 5 > end) return false; const char st = (char)aux[0]; const uint32_t cnt = rd32(aux + 1);
+                        sz = 5 + (size_t)cnt * ((st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : 4); break; }
+            default: return false;
+        }
+        aux += sz;
+    }
+    return false;
+}
+
 // Decode one BAM record (rec points at refID, i.e. after block_size) into L.
 void decode_record(const uint8_t* rec, uint32_t len, const std::unordered_map<std::string, int32_t>& cbmap, int min_mapq, Local& L) {
     const int32_t tid = rdi32(rec), pos = rdi32(rec + 4);
@@ -154,6 +181,7 @@ typedef struct {
     uint32_t* seg_read; int32_t* seg_start; int32_t* seg_len; int64_t* seg_ev_off; uint16_t* events;
     int32_t n_contigs; char* contig_names;   /* '\n'-joined */ int64_t* contig_len;
     int64_t total_reads, pass_reads, cb_not_found, cb_not_matched, mapq_filtered;
+    int32_t n_barcodes; char* barcodes;      /* auto-barcode mode: the distinct cleaned CBs found, '\n'-joined, id = order of first appearance */
 } lsio_decoded;
 
 const char* lsio_last_error(void) { return g_err; }
@@ -162,7 +190,7 @@ void lsio_free_decoded(lsio_decoded* d) {
     if (!d) return;
     free(d->read_tid); free(d->read_pos); free(d->read_flag); free(d->read_mapq); free(d->read_cb);
     free(d->seg_read); free(d->seg_start); free(d->seg_len); free(d->seg_ev_off); free(d->events);
-    free(d->contig_names); free(d->contig_len);
+    free(d->contig_names); free(d->contig_len); free(d->barcodes);
     free(d);
 }
 
@@ -249,6 +277,17 @@ int lsio_decode_bam(const char* path, const char* barcodes, int32_t n_barcodes, 
         if (bs < 32 || p + 4 + bs > utotal) { set_err("lsio_decode_bam: truncated record at %zu", p); return -1; }
         recs.push_back(p); p += 4 + bs;
     }
+    // auto-barcode mode (n_barcodes < 0): every distinct cleaned CB of the file is a cell (a per-cell-type BAM
+    // written by SplitBamCellTypes carries only its own cells)
+    std::string auto_joined; int32_t auto_n = 0;
+    if (n_barcodes < 0) {
+        for (size_t i = 0; i < recs.size(); ++i) {
+            const char* cb; size_t cl;
+            if (rdi32(d + recs[i] + 4) < 0 || !find_cb(d + recs[i] + 4, rd32(d + recs[i]), &cb, &cl)) continue;
+            auto ins = cbmap.emplace(std::string(cb, cl), auto_n);
+            if (ins.second) { auto_joined.append(cb, cl); auto_joined.push_back('\n'); ++auto_n; }
+        }
+    }
     // parallel decode of contiguous record ranges
     const int T = (int)std::min<size_t>((size_t)n_threads, std::max<size_t>(1, recs.size() / 1024));
     std::vector<Local> loc((size_t)T);
@@ -287,6 +326,8 @@ int lsio_decode_bam(const char* path, const char* barcodes, int32_t n_barcodes, 
     o->n_contigs = (int32_t)n_ref;
     o->contig_names = (char*)malloc(names.size() + 1); memcpy(o->contig_names, names.c_str(), names.size() + 1);
     o->contig_len = dup_vec(lens);
+    o->n_barcodes = auto_n;
+    o->barcodes = (char*)malloc(auto_joined.size() + 1); memcpy(o->barcodes, auto_joined.c_str(), auto_joined.size() + 1);
     *out = o;
     return 0;
 }
@@ -428,6 +469,62 @@ int lsio_synth_bam(const lsg_synth_model* m, const char* contig_names /* '\n'-jo
     }
     w.close();
     if (!w.ok) { set_err("lsio_synth_bam: write failed"); return -1; }
+    return 0;
+}
+
+// SplitBamCellTypes' BAM outputs (split_bam, SplitBamCellTypes.py:39-192): one BAM per cell type with the
+// records whose cleaned CB maps to it and whose MAPQ >= min_mapq; header copied (template=infile, :57).
+// celltype_of_barcode[i] in [0, n_ct) for barcode i of the '\n'-joined list; out_paths '\n'-joined.
+int lsio_split_bam(const char* path, const char* barcodes, int32_t n_barcodes, const uint8_t* celltype_of_barcode, int32_t n_ct,
+                   const char* out_paths, int32_t min_mapq, int64_t* counters /* total, pass, cb_not_found, cb_not_matched, mapq */) {
+    if (!path || !barcodes || !out_paths || n_ct <= 0) { set_err("lsio_split_bam: bad arguments"); return -2; }
+    std::unordered_map<std::string, int32_t> ctmap;
+    { const char* s = barcodes; for (int32_t i = 0; i < n_barcodes; ++i) { const char* e = strchr(s, '\n'); size_t l = e ? (size_t)(e - s) : strlen(s); ctmap[std::string(s, l)] = celltype_of_barcode[i]; s += l + (e ? 1 : 0); } }
+    std::vector<std::string> outs;
+    { const char* s = out_paths; for (int i = 0; i < n_ct; ++i) { const char* e = strchr(s, '\n'); size_t l = e ? (size_t)(e - s) : strlen(s); outs.emplace_back(s, l); s += l + (e ? 1 : 0); } }
+    FILE* f = fopen(path, "rb");
+    if (!f) { set_err("lsio_split_bam: cannot open %s", path); return -1; }
+    fseek(f, 0, SEEK_END); const size_t fsize = (size_t)ftell(f); fseek(f, 0, SEEK_SET);
+    std::vector<uint8_t> file(fsize);
+    if (fsize && fread(file.data(), 1, fsize, f) != fsize) { fclose(f); set_err("lsio_split_bam: short read"); return -1; }
+    fclose(f);
+    std::vector<uint8_t> data;
+    for (size_t off = 0; off + 18 <= fsize;) {
+        const uint8_t* h = file.data() + off;
+        const uint32_t xlen = rd16(h + 10), bsize = rd16(h + 16) + 1u, usize = rd32(h + bsize - 4);
+        const size_t at = data.size(); data.resize(at + usize);
+        if (usize) {
+            z_stream zs; memset(&zs, 0, sizeof(zs)); inflateInit2(&zs, -15);
+            zs.next_in = (Bytef*)(h + 12 + xlen); zs.avail_in = bsize - xlen - 20; zs.next_out = data.data() + at; zs.avail_out = usize;
+            const int rc = inflate(&zs, Z_FINISH); inflateEnd(&zs);
+            if (rc != Z_STREAM_END) { set_err("lsio_split_bam: inflate failed"); return -1; }
+        }
+        off += bsize;
+    }
+    const uint8_t* d = data.data(); const size_t total = data.size();
+    if (total < 12 || memcmp(d, "BAM\1", 4) != 0) { set_err("lsio_split_bam: no BAM magic"); return -1; }
+    size_t p = 8 + rd32(d + 4); const uint32_t n_ref = rd32(d + p); p += 4;
+    for (uint32_t i = 0; i < n_ref; ++i) { p += 4 + rd32(d + p); p += 4; }
+    std::vector<BgzfWriter> w((size_t)n_ct);
+    for (int i = 0; i < n_ct; ++i) { w[(size_t)i].f = fopen(outs[(size_t)i].c_str(), "wb"); if (!w[(size_t)i].f) { set_err("lsio_split_bam: cannot write %s", outs[(size_t)i].c_str()); return -1; } w[(size_t)i].write(d, p); }
+    int64_t cnt[5] = {0, 0, 0, 0, 0};
+    while (p + 4 <= total) {
+        const uint32_t bs = rd32(d + p); const uint8_t* rec = d + p + 4;
+        const size_t rec_at = p; p += 4 + bs;
+        if (rdi32(rec) < 0) continue;
+        ++cnt[0];
+        const char* cb; size_t cl;
+        if (!find_cb(rec, bs, &cb, &cl)) { ++cnt[2]; continue; }
+        auto it = ctmap.find(std::string(cb, cl));
+        if (it == ctmap.end()) { ++cnt[3]; continue; }
+        if (min_mapq > 0 && (int)rec[9] < min_mapq) { ++cnt[4]; continue; }
+        ++cnt[1];
+        w[(size_t)it->second].write(d + rec_at, 4 + bs);
+    }
+    bool ok = true;
+    for (auto& x : w) { x.close(); ok = ok && x.ok; }
+    if (counters) memcpy(counters, cnt, sizeof(cnt));
+    if (!ok) { set_err("lsio_split_bam: write failed"); return -1; }
     return 0;
 }
 

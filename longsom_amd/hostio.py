@@ -27,6 +27,7 @@ class Decoded(C.Structure):
         ("n_contigs", C.c_int32), ("contig_names", C.c_char_p), ("contig_len", C.c_void_p),
         ("total_reads", C.c_int64), ("pass_reads", C.c_int64), ("cb_not_found", C.c_int64), ("cb_not_matched", C.c_int64),
         ("mapq_filtered", C.c_int64),
+        ("n_barcodes", C.c_int32), ("barcodes", C.c_char_p),
     ]
 
 
@@ -45,6 +46,8 @@ def load():
         lib.lsio_synth_records.restype = C.c_int
         lib.lsio_synth_records.argtypes = [C.c_void_p, C.POINTER(C.POINTER(Decoded))]
         lib.lsio_barcode.argtypes = [C.c_uint64, C.c_int64, C.c_char_p]
+        lib.lsio_split_bam.restype = C.c_int
+        lib.lsio_split_bam.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.c_void_p, C.c_int32, C.c_char_p, C.c_int32, C.c_void_p]
         _lib = lib
     return _lib
 
@@ -95,15 +98,21 @@ class DecodedBam:
     contig_names: List[str]
     contig_len: np.ndarray
     report: Dict[str, int]         # the counters of SplitBamCellTypes' report.txt (:62,117-124)
+    barcodes: Optional[List[str]] = None   # auto-barcode mode: the distinct cleaned CBs found (dense id = index)
 
 
-def decode_bam(path: str, barcodes: Sequence[str], min_mapq: int = 60, threads: int = 0) -> DecodedBam:
+def decode_bam(path: str, barcodes: Optional[Sequence[str]], min_mapq: int = 60, threads: int = 0) -> DecodedBam:
     """BAM -> read-record arrays.  Reads without a CB tag or whose cleaned CB is not in `barcodes` are dropped
-    (they can never be counted); flags and MAPQ are kept for the device-side admission."""
+    (they can never be counted); flags and MAPQ are kept for the device-side admission.  barcodes=None: every
+    distinct cleaned CB of the file is a cell (how BaseCellCounter sees a per-cell-type BAM)."""
     lib = load()
     out = C.POINTER(Decoded)()
-    joined = "\n".join(barcodes).encode()
-    if lib.lsio_decode_bam(os.fsencode(path), joined, len(barcodes), None, int(min_mapq), int(threads), C.byref(out)) != 0:
+    if barcodes is None:
+        rc = lib.lsio_decode_bam(os.fsencode(path), None, -1, None, int(min_mapq), int(threads), C.byref(out))
+    else:
+        joined = "\n".join(barcodes).encode()
+        rc = lib.lsio_decode_bam(os.fsencode(path), joined, len(barcodes), None, int(min_mapq), int(threads), C.byref(out))
+    if rc != 0:
         _err("lsio_decode_bam")
     try:
         d = out.contents
@@ -113,9 +122,25 @@ def decode_bam(path: str, barcodes: Sequence[str], min_mapq: int = 60, threads: 
         rep = {"Total_reads": d.total_reads, "Pass_reads": d.pass_reads, "CB_not_found": d.cb_not_found, "CB_not_matched": d.cb_not_matched}
         if d.mapq_filtered:
             rep["MAPQ"] = d.mapq_filtered
-        return DecodedBam(rec, names, lens, rep)
+        found = d.barcodes.decode().split("\n")[: d.n_barcodes] if barcodes is None else None
+        return DecodedBam(rec, names, lens, rep, found)
     finally:
         lib.lsio_free_decoded(out)
+
+
+def split_bam(path: str, table: "BarcodeTable", out_paths: Sequence[str], min_mapq: int = 60) -> Dict[str, int]:
+    """SplitBamCellTypes' BAM outputs: one BAM per cell type (out_paths in table.celltype_names order); returns the
+    report counters."""
+    lib = load()
+    ct = np.ascontiguousarray(table.celltype_of, np.uint8)
+    cnt = (C.c_int64 * 5)()
+    if lib.lsio_split_bam(os.fsencode(path), "\n".join(table.barcodes).encode(), len(table.barcodes), ct.ctypes.data_as(C.c_void_p),
+                          len(table.celltype_names), "\n".join(out_paths).encode(), int(min_mapq), cnt) != 0:
+        _err("lsio_split_bam")
+    rep = {"Total_reads": cnt[0], "Pass_reads": cnt[1], "CB_not_found": cnt[2], "CB_not_matched": cnt[3]}
+    if cnt[4]:
+        rep["MAPQ"] = cnt[4]
+    return rep
 
 
 def synth_barcodes(model) -> List[str]:

@@ -213,6 +213,55 @@ def format_step1_tsv(calls, per_ct, contig_names, celltype_names, header_lines: 
     return "".join(out)
 
 
+def _row_from_text(data: str) -> np.ndarray:
+    dp, nc, cc, bc, bq, bcf, bcr = data.split("|")
+    r = np.zeros(ROW_WORDS, np.uint32)
+    r[0] = int(dp); r[1] = int(nc)
+    for off, vec in ((2, cc), (10, bc), (18, bq), (26, bcf), (34, bcr)):
+        v = [int(x) for x in vec.split(":")]
+        r[off:off + len(v)] = v
+    return r
+
+
+def parse_merged_tsv(path, contig_names):
+    """MergeBaseCellCounts TSV -> (celltype names, per_ct [(keys, refs, counts)], '##' header lines)."""
+    tid_of = {n: i for i, n in enumerate(contig_names)}
+    header, cts, acc = [], None, None
+    with open(path) as f:
+        for line in f:
+            if line.startswith("##"):
+                header.append(line); continue
+            line = line.rstrip("\n")
+            if line.startswith("#CHROM"):
+                cts = line.split("\t")[5:]
+                acc = [([], [], []) for _ in cts]
+                continue
+            if not line:
+                continue
+            el = line.split("\t")
+            key = (tid_of[el[0]] << 32) | (int(el[1]) - 1)
+            for ct, data in enumerate(el[5:]):
+                if not data.startswith("NA"):
+                    acc[ct][0].append(key); acc[ct][1].append(ord(el[3][0])); acc[ct][2].append(_row_from_text(data))
+    per_ct = []
+    for k, r, c in acc or []:
+        k = np.asarray(k, np.int64); perm = np.argsort(k, kind="stable")
+        c = np.stack(c) if c else np.zeros((0, ROW_WORDS), np.uint32)
+        per_ct.append((k[perm], np.asarray(r, np.uint8)[perm], c[perm]))
+    return cts or [], per_ct, header
+
+
+def contigs_of_tsv(paths) -> List[str]:
+    """chromosome names of count / merged TSVs in order of first appearance (when no FASTA is at hand)."""
+    seen = {}
+    for p in paths:
+        with open(p) as f:
+            for line in f:
+                if line and not line.startswith("#"):
+                    seen.setdefault(line.split("\t", 1)[0], None)
+    return list(seen)
+
+
 def read_fasta(path):
     """Whole FASTA -> (names, list of upper-cased uint8 arrays).  inFasta.fetch(...).upper(), BaseCellCounter.py:202-203."""
     names, seqs, cur = [], [], None

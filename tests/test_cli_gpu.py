@@ -1,0 +1,53 @@
+"""GPU: the rule-level CLI shims (workflow/scripts_gpu) give the same files as the fused run."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from longsom_amd import hostio, synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+S = os.path.join(ROOT, "workflow", "scripts_gpu")
+
+
+def run(script, *args):
+    subprocess.check_call([sys.executable, os.path.join(S, script)] + [str(a) for a in args], cwd=ROOT)
+
+
+def strip_date(path):
+    return "\n".join(l for l in open(path).read().split("\n") if not l.startswith("##fileDate="))
+
+
+def test_rule_chain_equals_fused_run(tmp_path):
+    m = synth.named("C1", n_reads=4000, n_genes=25, n_cb=60, snp_mod=300)
+    bam, fa, bct = str(tmp_path / "S1.bam"), str(tmp_path / "ref.fa"), str(tmp_path / "barcodes.tsv")
+    hostio.synth_bam(m, bam, fa)
+    hostio.write_barcodes_tsv(bct, hostio.synth_barcodes(m), m.celltype_of, ["Cancer", "Non-Cancer"])
+    fused = tmp_path / "fused"
+    run("SNVCalling/longsom_gpu_snv.py", "--bam", bam, "--meta", bct, "--ref", fa, "--id", "S1", "--outdir", fused)
+    # the reference's rule chain, script by script
+    w = tmp_path / "chain"
+    for d in ("SplitBam", "BaseCellCounter/S1", "MergeCounts", "BaseCellCalling"):
+        os.makedirs(w / d)
+    run("PreProcessing/SplitBamCellTypes.py", "--bam", bam, "--meta", bct, "--id", "S1", "--outdir", w / "SplitBam", "--min_MQ", 60)
+    for ct in ("Cancer", "Non-Cancer"):
+        run("SNVCalling/BaseCellCounter.py", "--bam", w / "SplitBam" / ("S1.%s.bam" % ct), "--ref", fa, "--chrom", "all", "--out_folder",
+            w / "BaseCellCounter" / "S1", "--nprocs", 4, "--min_mq", 60, "--tmp_dir", w / "BaseCellCounter" / "S1" / ("temp_" + ct))
+    merged = w / "MergeCounts" / "S1.BaseCellCounts.AllCellTypes.tsv"
+    run("SNVCalling/MergeBaseCellCounts.py", "--tsv_folder", w / "BaseCellCounter" / "S1", "--outfile", merged)
+    pre = w / "BaseCellCalling" / "S1"
+    run("SNVCalling/BaseCellCalling.step1.py", "--infile", merged, "--ref", fa, "--outfile", pre, "--min_cell_types", 2, "--min_ac_reads", 3,
+        "--min_ac_cells", 2, "--alpha1", 0.21356677091082193, "--beta1", 104.95163748636298, "--alpha2", 0.2474528917555431, "--beta2", 162.03696139428595)
+    run("SNVCalling/BaseCellCalling.step2.py", "--infile", str(pre) + ".calling.step1.tsv", "--outfile", pre, "--editing", "/nonexistent", "--pon_SR",
+        "/nonexistent", "--pon_LR", "--gnomAD_db", "/nonexistent", "--gnomAD_max", 0.01, "--min_distance", 0)
+    run("SNVCalling/BaseCellCalling.step3.py", "--infile", str(pre) + ".calling.step2.tsv", "--outfile", pre, "--chrM_contaminant", "True", "--deltaVAF",
+        0.05, "--deltaMCF", 0.3, "--min_ac_reads", 3, "--min_ac_cells", 2, "--clust_dist", 10000)
+    for rel in ("BaseCellCounter/S1/S1.Cancer.tsv", "BaseCellCounter/S1/S1.Non-Cancer.tsv", "MergeCounts/S1.BaseCellCounts.AllCellTypes.tsv",
+                "BaseCellCalling/S1.calling.step1.tsv", "BaseCellCalling/S1.calling.step2.tsv", "BaseCellCalling/S1.calling.step3.tsv",
+                "BaseCellCalling/S1.calling.step3.unfiltered.tsv"):
+        assert strip_date(str(fused / rel)) == strip_date(str(w / rel)), rel
+    a = open(fused / "SplitBam" / "S1.report.txt").read().split("\n")[1].split("\t")[:4]
+    b = open(w / "SplitBam" / "S1.report.txt").read().split("\n")[1].split("\t")[:4]
+    assert a == b
