@@ -36,46 +36,7 @@ CALL_BYTES = 336          # sizeof(lsg_call)
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def region_shards(model, world):
-    """Tile-aligned region boundaries at gene starts balancing the read count, and for every rank the
-    contiguous gene range that contains all genes overlapping its region."""
-    g0 = model.gene_exon_off[:-1]; g1 = model.gene_exon_off[1:] - 1
-    tid = model.gene_tid.astype(np.int64)
-    start = model.exon_start[g0].astype(np.int64)
-    end = (model.exon_start[g1] + model.exon_len[g1]).astype(np.int64)
-    off = np.concatenate([[0], np.cumsum(model.contig_len)])[:-1]
-    lin_s, lin_e = off[tid] + start, off[tid] + end
-    reads = np.diff(model.gene_read_off)
-    cum = np.concatenate([[0], np.cumsum(reads)])
-    total = int(cum[-1])
-    bounds = [(0, 0)]
-    for r in range(1, world):
-        g = int(np.searchsorted(cum, total * r // world, side="left"))
-        g = min(max(g, 0), model.n_genes - 1)
-        b = (int(tid[g]), int(start[g]) // 64 * 64)
-        bounds.append(max(b, bounds[-1]))
-    bounds.append((len(model.contig_len), 0))
-    shards = []
-    for r in range(world):
-        lo, hi = bounds[r], bounds[r + 1]
-        lin_lo = off[lo[0]] + lo[1] if lo[0] < len(off) else int(model.contig_len.sum())
-        lin_hi = off[hi[0]] + hi[1] if hi[0] < len(off) else int(model.contig_len.sum())
-        ov = np.nonzero((lin_e > lin_lo) & (lin_s < lin_hi))[0]
-        if len(ov) == 0:
-            g_lo, g_hi = 0, 0
-        else:
-            g_lo, g_hi = int(ov.min()), int(ov.max()) + 1
-        shards.append((lo, hi, g_lo, g_hi))
-    return shards
-
-
-def sub_model(model, g_lo, g_hi):
-    x0, x1 = int(model.gene_exon_off[g_lo]), int(model.gene_exon_off[g_hi])
-    offr = model.gene_read_off[g_lo:g_hi + 1] - model.gene_read_off[g_lo]
-    return synth.SynthModel(model.seed, model.contig_names, model.contig_len, model.gene_tid[g_lo:g_hi].copy(),
-                            (model.gene_exon_off[g_lo:g_hi + 1] - x0).astype(np.int32), model.exon_start[x0:x1].copy(),
-                            model.exon_len[x0:x1].copy(), model.exon_cum[x0:x1].copy(), offr.astype(np.int64), model.celltype_of,
-                            int(offr[-1]), model.n_cb, model.snp_mod, int(model.read_base + model.gene_read_off[g_lo]))
+from longsom_amd.shard import region_shards, sub_model  # noqa: E402
 
 
 def cpu_baseline(eng, model, target_reads=40_000, call_sites=2500):

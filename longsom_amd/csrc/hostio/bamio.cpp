@@ -557,4 +557,9 @@ int lsio_synth_records(const lsg_synth_model* m, lsio_decoded** out) {
 
 void lsio_barcode(uint64_t seed, int64_t cb, char* out17) { sm_barcode(seed, cb, 0, out17); }
 
+// reference bases of one contig of the synthetic genome (host twin of lsg_synth_reference)
+void lsio_ref_bases(uint64_t seed, int32_t tid, int64_t len, uint8_t* out) {
+    for (int64_t p = 0; p < len; ++p) out[p] = sm_ref_base(seed, tid, p);
+}
+
 } // extern "C"

@@ -153,6 +153,16 @@ def synth_barcodes(model) -> List[str]:
     return res
 
 
+def ref_bases(seed: int, tid: int, length: int) -> np.ndarray:
+    """Reference bases of one contig of the synthetic genome (host twin of Engine.synth_reference)."""
+    lib = load()
+    out = np.empty(int(length), np.uint8)
+    lib.lsio_ref_bases.argtypes = [C.c_uint64, C.c_int32, C.c_int64, C.c_void_p]
+    if length:
+        lib.lsio_ref_bases(C.c_uint64(seed), int(tid), int(length), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
 def synth_bam(model, bam_path: str, fasta_path: Optional[str] = None, barcode_suffix: str = "") -> None:
     """Write the model's reads as a coordinate-sorted BAM (+ the synthetic reference as FASTA)."""
     lib = load()
