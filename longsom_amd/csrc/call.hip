@@ -47,7 +47,8 @@ struct CallArgs {
     double lgc0[2], lgcn[2];          // lgamma(a+b) - lgamma(b), lgamma(a+b) - lgamma(a) for (a1,b1), (a2,b2)
     uint32_t* site_cnt; uint32_t* site_off;
     SiteRec* sites; CandCt* cands; uint64_t cand_cap;
-    unsigned long long* counters;     // [0] candidate sites
+    struct TailTask* light; struct TailTask* heavy; uint64_t task_cap;
+    unsigned long long* counters;     // [0] candidate sites, [2] light tail tasks, [3] heavy tail tasks
 };
 
 // log of the beta-binomial pmf at m (scipy betabinom._logpmf written with lgamma)
@@ -121,7 +122,22 @@ __global__ void k_site_count(CallArgs a) {
     a.site_cnt[w] = v;
 }
 
-__global__ __launch_bounds__(256) void k_call(CallArgs a) {
+// ---- step 1 in three kernels ---------------------------------------------------------------------
+//  k_call_gather  one lane per merged site: joins the cell types' rows, finds the alt candidates, the
+//                 Rest_* sums and the homopolymer flags, writes the records WITHOUT p-values and emits
+//                 one task (k, n, parameter set, destination) per beta-binomial tail;
+//  k_call_tails   one thread per light task (<= 64 terms), one wavefront per heavy task (lanes sum
+//                 strided chunks, each re-anchored by lgamma);
+//  k_call_finish  the filter chains, which depend on the rounded p-values.
+struct TailTask { uint32_t k, n; uint64_t dst; };     // dst = address of the int16 result | parameter set in bit 0
+
+__device__ __forceinline__ uint32_t tail_work(uint32_t k, uint32_t n) {
+    if (k == 0 || k > n) return 0;
+    const uint32_t up = n - k + 1;
+    return k < up ? k : up;
+}
+
+__global__ __launch_bounds__(256) void k_call_gather(CallArgs a) {
     const int lane = threadIdx.x & 63;
     const uint32_t w = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     if (w >= a.n_ne) return;                                                  // whole wave
@@ -147,32 +163,64 @@ __global__ __launch_bounds__(256) void k_call(CallArgs a) {
     const uint64_t cap = a.row_cap;
     const int order[4] = {0, 1, 3, 2};              // letter order A < C < G < T over classes (A,C,T,G) = (0,1,2,3)
 
-    // pass 1: is the site a candidate (any considered cell type with an observed A/C/T/G alt)?  One
-    // wave-aggregated allocation of the detail blocks.
+    // pass 1: candidate? number of tail tasks?  (one wave-aggregated allocation each)
     bool has_any = false;
+    uint32_t n_light = 0, n_heavy = 0;
+    int32_t s_alts_bc = 0, s_alts_cc = 0, s_dp = 0, s_nc = 0;
     if (site) {
         for (int ct = 0; ct < a.n_ct; ++ct) {
             if (!((mask[ct] >> lane) & 1ull)) continue;
             const uint64_t row = (uint64_t)rbase[ct] + __popcll(mask[ct] & below);
             const uint32_t* R = a.rows[ct];
-            if (!((int)R[row] >= P.min_cov && (int)R[cap + row] >= P.min_cells)) continue;
+            const uint32_t dp = R[row], nc = R[cap + row];
+            if (!((int)dp >= P.min_cov && (int)nc >= P.min_cells)) continue;
+            s_dp += (int32_t)dp; s_nc += (int32_t)nc;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) has_any |= (s != rsym) && R[(10 + s) * cap + row] > 0;
+            for (int s = 0; s < 6; ++s) {
+                const uint32_t b = R[(10 + s) * cap + row], c = R[(2 + s) * cap + row];
+                if (s == rsym) continue;
+                s_alts_bc += (int32_t)b; s_alts_cc += (int32_t)c;
+                if (s < 4 && b > 0) {
+                    has_any = true;
+                    s_dp -= (int32_t)b; s_nc -= (int32_t)c; s_alts_bc -= (int32_t)b; s_alts_cc -= (int32_t)c;
+                    if (tail_work(b, dp) > 64) ++n_heavy; else ++n_light;
+                    if (tail_work(c, nc) > 64) ++n_heavy; else ++n_light;
+                }
+            }
+        }
+        if (s_alts_bc > 0) {
+            if (s_dp >= 0) { if (tail_work((uint32_t)s_alts_bc, (uint32_t)s_dp) > 64) ++n_heavy; else ++n_light; }
+            if (s_nc >= 0 && s_alts_cc >= 0) { if (tail_work((uint32_t)s_alts_cc, (uint32_t)s_nc) > 64) ++n_heavy; else ++n_light; }
         }
     }
     const unsigned long long cm = __ballot(has_any);
-    uint32_t cbase = 0;
-    if (lane == 0 && cm) cbase = (uint32_t)atomicAdd(&a.counters[0], (unsigned long long)__popcll(cm));
+    // wave-inclusive prefix sums of the task counts
+    uint32_t pl = n_light, ph = n_heavy;
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t vl = __shfl_up(pl, o), vh = __shfl_up(ph, o); if (lane >= o) { pl += vl; ph += vh; } }
+    const uint32_t tot_l = __shfl(pl, 63), tot_h = __shfl(ph, 63);
+    uint32_t cbase = 0, lbase = 0, hbase = 0;
+    if (lane == 0) {
+        if (cm) cbase = (uint32_t)atomicAdd(&a.counters[0], (unsigned long long)__popcll(cm));
+        if (tot_l) lbase = (uint32_t)atomicAdd(&a.counters[2], (unsigned long long)tot_l);
+        if (tot_h) hbase = (uint32_t)atomicAdd(&a.counters[3], (unsigned long long)tot_h);
+    }
     cbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)cbase);
+    lbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)lbase);
+    hbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)hbase);
     if (!site) return;
     const uint32_t cand = cbase + (uint32_t)__popcll(cm & below);
+    uint32_t li = lbase + pl - n_light, hi = hbase + ph - n_heavy;
+    auto emit_task = [&](uint32_t k, uint32_t n, int set, int16_t* dst) {
+        TailTask t; t.k = k; t.n = n; t.dst = (uint64_t)dst | (uint64_t)set;
+        if (tail_work(k, n) > 64) { if (hi < a.task_cap) a.heavy[hi] = t; ++hi; } else { if (li < a.task_cap) a.light[li] = t; ++li; }
+    };
 
     SiteRec sr;
     sr.key = ((int64_t)tid << 32) | pos; sr.ref = refb; sr.present = 0; sr.considered = 0; sr.has_cand = 0;
     sr.pad[0] = sr.pad[1] = sr.pad[2] = 0; sr.pad2 = 0; sr.cand = has_any ? cand : 0xFFFFFFFFu;
-    int32_t sum_alts_bc = 0, sum_alts_cc = 0, sum_dp = 0, sum_nc = 0;
-    int n_considered = 0, n_pass = 0, n_nonsig = 0, n_with_cand = 0;
-    bool any_multi = false, alts_differ = false;
+    sr.site_filter = 0;
+    int n_considered = 0;
+    bool alts_differ = false;
     uint32_t first_altset = 0; bool have_first = false;
     // homopolymer context (step1.py:95-107): up = ref[pos-5..pos-1], down = ref[pos+1..pos+5]
     const int64_t clen = a.contig_len[tid];
@@ -186,12 +234,14 @@ __global__ __launch_bounds__(256) void k_call(CallArgs a) {
         for (int i = 0; i < down_len; ++i) down[i] = ref[pos + 1 + i];
     }
     int lc_up = 0, lc_down = 0;
+    SiteRec* srp = &a.sites[idx];
 
     for (int ct = 0; ct < a.n_ct; ++ct) {
         CandCt cd;
         cd.n_alt = 0; cd.ct_filter = 0; cd.pad[0] = cd.pad[1] = 0;
 #pragma unroll
         for (int q = 0; q < LSG_CALL_MAX_ALT; ++q) { cd.alt[q] = 0; cd.alt_bc[q] = 0; cd.alt_cc[q] = 0; cd.p_bc[q] = 0; cd.p_cc[q] = 0; }
+        CandCt* cdp = has_any && cand < a.cand_cap ? &a.cands[(uint64_t)cand * a.n_ct + ct] : nullptr;
         if ((mask[ct] >> lane) & 1ull) {
             sr.present |= (uint8_t)(1u << ct);
             const uint64_t row = (uint64_t)rbase[ct] + __popcll(mask[ct] & below);
@@ -200,48 +250,24 @@ __global__ __launch_bounds__(256) void k_call(CallArgs a) {
             if ((int)dp >= P.min_cov && (int)nc >= P.min_cells) {                 // step1.py:174
                 sr.considered |= (uint8_t)(1u << ct);
                 ++n_considered;
-                uint32_t cc[6], bc[6];
-#pragma unroll
-                for (int s = 0; s < 6; ++s) { cc[s] = R[(2 + s) * cap + row]; bc[s] = R[(10 + s) * cap + row]; }
-                uint32_t alts2 = 0, cc2 = 0;                                       // :187-190 (I and D included)
-#pragma unroll
-                for (int s = 0; s < 6; ++s) if (s != rsym) { alts2 += bc[s]; cc2 += cc[s]; }
-                sum_alts_bc += (int32_t)alts2; sum_alts_cc += (int32_t)cc2; sum_dp += (int32_t)dp; sum_nc += (int32_t)nc;
                 // candidates: every observed A/C/T/G alt (:195-208), in letter order
                 int na = 0; uint32_t altset = 0;
-                int32_t min_pbc = 100000, min_pcc = 100000;
-                uint32_t b0 = 0, c0 = 0;
-                double pm0_bc = -1.0, pm0_cc = -1.0;
 #pragma unroll
                 for (int oi = 0; oi < 4; ++oi) {
                     const int s = order[oi];
-                    if (s == rsym || bc[s] == 0) continue;
-                    if (pm0_bc < 0.0) { pm0_bc = bb_pm0(dp, P.alpha1, P.beta1, a.lgc0[0]); pm0_cc = bb_pm0(nc, P.alpha2, P.beta2, a.lgc0[1]); }
-                    const int32_t pb = round4(bb_upper_tail(bc[s], dp, P.alpha1, P.beta1, pm0_bc, a.lgcn[0]));
-                    const int32_t pc = round4(bb_upper_tail(cc[s], nc, P.alpha2, P.beta2, pm0_cc, a.lgcn[1]));
+                    const uint32_t b = R[(10 + s) * cap + row];
+                    if (s == rsym || b == 0) continue;
+                    const uint32_t c = R[(2 + s) * cap + row];
                     if (na < LSG_CALL_MAX_ALT) {
-                        cd.alt[na] = (uint8_t)s; cd.alt_bc[na] = bc[s]; cd.alt_cc[na] = cc[s]; cd.p_bc[na] = (int16_t)pb; cd.p_cc[na] = (int16_t)pc;
+                        cd.alt[na] = (uint8_t)s; cd.alt_bc[na] = b; cd.alt_cc[na] = c;
+                        if (cdp) { emit_task(b, dp, 0, &cdp->p_bc[na]); emit_task(c, nc, 1, &cdp->p_cc[na]); }
                     }
                     ++na; altset |= 1u << s;
-                    min_pbc = pb < min_pbc ? pb : min_pbc; min_pcc = pc < min_pcc ? pc : min_pcc;
-                    b0 += bc[s]; c0 += cc[s];
                 }
                 cd.n_alt = (uint8_t)na;
                 if (na > 0) {
                     sr.has_cand |= (uint8_t)(1u << ct);
-                    ++n_with_cand;
                     if (!have_first) { first_altset = altset; have_first = true; } else if (altset != first_altset) alts_differ = true;
-                    sum_dp -= (int32_t)b0; sum_nc -= (int32_t)c0; sum_alts_bc -= (int32_t)b0; sum_alts_cc -= (int32_t)c0;   // :253-258
-                    // per-cell-type filter chain (:263-277); thresholds on the rounded values
-                    uint8_t f;
-                    if (min_pbc >= 500 || min_pcc >= 500) f = LSG_CF_NONSIG;
-                    else if ((min_pbc > 10 && min_pbc < 500) || (min_pcc > 10 && min_pcc < 500)) f = LSG_CF_LOWSIG;
-                    else if (na > 1) f = LSG_CF_MULTI;
-                    else if ((int)cd.alt_cc[0] < P.min_ac_cells) f = LSG_CF_LOW_CELLS;
-                    else if ((int)cd.alt_bc[0] < P.min_ac_reads) f = LSG_CF_LOW_READS;
-                    else f = LSG_CF_PASS;
-                    cd.ct_filter = f;
-                    n_pass += f == LSG_CF_PASS; n_nonsig += f == LSG_CF_NONSIG; any_multi |= f == LSG_CF_MULTI;
                     // homopolymer runs including the alt string "A" or "A|C|.." (:511-529): only the first /
                     // last letter of the string touches the context
                     if (have_ctx) {
@@ -259,37 +285,108 @@ __global__ __launch_bounds__(256) void k_call(CallArgs a) {
                 }
             }
         }
-        if (has_any && cand < a.cand_cap) a.cands[(uint64_t)cand * a.n_ct + ct] = cd;
+        if (cdp) *cdp = cd;
     }
     sr.cell_types_min = (uint8_t)n_considered;
-    sr.sum_alts_bc = sum_alts_bc; sr.sum_dp = sum_dp; sr.sum_alts_cc = sum_alts_cc; sr.sum_nc = sum_nc;
-    int32_t npb = -1, npc = -1;
-    if (sum_alts_bc > 0) {                                                     // :328-337 / :426-435
-        // a negative n (cells carrying several alleles make Sum_nc - c0 negative) is outside scipy's
-        // support: betabinom.cdf returns nan, which prints as "nan" and fails every "<" test
-        npb = sum_dp < 0 ? -2 : round4(bb_upper_tail((uint32_t)sum_alts_bc, (uint32_t)sum_dp, P.alpha1, P.beta1,
-                                                     bb_pm0((uint32_t)sum_dp, P.alpha1, P.beta1, a.lgc0[0]), a.lgcn[0]));
-        npc = (sum_nc < 0 || sum_alts_cc < 0) ? -2 : round4(bb_upper_tail((uint32_t)sum_alts_cc, (uint32_t)sum_nc, P.alpha2, P.beta2,
-                                                                         bb_pm0((uint32_t)sum_nc, P.alpha2, P.beta2, a.lgc0[1]), a.lgcn[1]));
+    sr.sum_alts_bc = s_alts_bc; sr.sum_dp = s_dp; sr.sum_alts_cc = s_alts_cc; sr.sum_nc = s_nc;
+    // noise tails (:328-337 / :426-435); a negative n is outside scipy's support -> nan
+    sr.noise_p_bc = -1; sr.noise_p_cc = -1;
+    if (s_alts_bc > 0) {
+        sr.noise_p_bc = -2; sr.noise_p_cc = -2;
+        if (s_dp >= 0) emit_task((uint32_t)s_alts_bc, (uint32_t)s_dp, 0, &srp->noise_p_bc);
+        if (s_nc >= 0 && s_alts_cc >= 0) emit_task((uint32_t)s_alts_cc, (uint32_t)s_nc, 1, &srp->noise_p_cc);
     }
-    sr.noise_p_bc = (int16_t)npb; sr.noise_p_cc = (int16_t)npc;
-    const bool bc_lt05 = npb >= 0 && npb < 500, cc_lt05 = npc >= 0 && npc < 500;
-    const bool bc_lt001 = npb >= 0 && npb < 10, cc_lt001 = npc >= 0 && npc < 10;
+    // flags that do not depend on p-values; k_call_finish adds the rest
     uint32_t sf = 0;
-    if (n_with_cand > 0) {
+    if (sr.has_cand) {
         sf |= LSG_SF_CANDIDATE;
-        if (n_pass > P.max_cell_types) sf |= LSG_SF_MULTIPLE_CELL_TYPES;       // :309
-        if (alts_differ || any_multi) sf |= LSG_SF_MULTI_ALLELIC;              // :313-315
+        if (alts_differ) sf |= LSG_SF_MULTI_ALLELIC;                           // :313
         if (n_considered < P.min_cell_types) sf |= LSG_SF_MIN_CELL_TYPES;      // :318
-        if (n_with_cand - n_pass - n_nonsig > 0) sf |= LSG_SF_CELL_TYPE_NOISE; // :322
-        if (sum_alts_bc > 0 && (bc_lt05 || cc_lt05)) sf |= LSG_SF_NOISY_SITE;  // :342
         if (have_ctx && lc_up >= 4) sf |= LSG_SF_LC_UP;                        // :347-354
         if (have_ctx && lc_down >= 4) sf |= LSG_SF_LC_DOWN;
-    } else if (sum_alts_bc > 0 && (bc_lt001 || cc_lt001)) {
-        sf |= LSG_SF_NOISY_SITE;                                               // :440-442
     }
     sr.site_filter = sf;
-    a.sites[idx] = sr;
+    *srp = sr;
+}
+
+__device__ __forceinline__ double tail_of_task(const TailTask& t, const CallArgs& a) {
+    const int set = (int)(t.dst & 1ull);
+    const double al = set ? a.p.alpha2 : a.p.alpha1, be = set ? a.p.beta2 : a.p.beta1;
+    return bb_upper_tail(t.k, t.n, al, be, bb_pm0(t.n, al, be, a.lgc0[set]), a.lgcn[set]);
+}
+
+__global__ __launch_bounds__(256) void k_call_tails(CallArgs a) {
+    const uint64_t n = a.counters[2] < a.task_cap ? a.counters[2] : a.task_cap;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const TailTask t = a.light[i];
+        *reinterpret_cast<int16_t*>(t.dst & ~1ull) = (int16_t)round4(tail_of_task(t, a));
+    }
+}
+
+// heavy tasks: one wavefront each; lane l sums the terms [l*chunk, (l+1)*chunk) of the shorter side
+__global__ __launch_bounds__(256) void k_call_tails_heavy(CallArgs a) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t n_tasks = a.counters[3] < a.task_cap ? a.counters[3] : a.task_cap;
+    for (uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; i < n_tasks; i += ((uint64_t)gridDim.x * blockDim.x) >> 6) {
+        const TailTask t = a.heavy[i];
+        const int set = (int)(t.dst & 1ull);
+        const double al = set ? a.p.alpha2 : a.p.alpha1, be = set ? a.p.beta2 : a.p.beta1;
+        const double dn = (double)t.n;
+        const bool lower = (uint64_t)t.k <= (uint64_t)t.n - t.k + 1;
+        const uint32_t m_lo = lower ? 0u : t.k, m_hi = lower ? t.k : t.n + 1;        // terms m in [m_lo, m_hi)
+        const uint32_t cnt = m_hi - m_lo, chunk = (cnt + 63) / 64;
+        const uint32_t b = m_lo + (uint32_t)lane * chunk;
+        const uint32_t e = b + chunk < m_hi ? b + chunk : m_hi;
+        double sum = 0.0;
+        if (b < e) {
+            double pm = exp(bb_logpmf((double)b, dn, al, be));
+            sum = pm;
+            for (uint32_t m = b + 1; m < e; ++m) {
+                if (((m - b) & 1023u) == 0) pm = exp(bb_logpmf((double)m, dn, al, be));
+                else { const double mm = (double)(m - 1); pm *= (dn - mm) * (mm + al) / ((mm + 1.0) * (dn - mm - 1.0 + be)); }
+                sum += pm;
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o);
+        if (lane == 0) *reinterpret_cast<int16_t*>(t.dst & ~1ull) = (int16_t)round4(lower ? 1.0 - sum : sum);
+    }
+}
+
+__global__ void k_call_finish(CallArgs a, uint32_t n_sites) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_sites) return;
+    SiteRec s = a.sites[i];
+    const lsg_call_params& P = a.p;
+    const int32_t npb = s.noise_p_bc, npc = s.noise_p_cc;
+    const bool bc_lt05 = npb >= 0 && npb < 500, cc_lt05 = npc >= 0 && npc < 500;
+    const bool bc_lt001 = npb >= 0 && npb < 10, cc_lt001 = npc >= 0 && npc < 10;
+    uint32_t sf = s.site_filter;
+    if (s.has_cand) {
+        int n_pass = 0, n_nonsig = 0, n_with = 0; bool any_multi = false;
+        for (int ct = 0; ct < a.n_ct; ++ct) {
+            if (!((s.has_cand >> ct) & 1u)) continue;
+            CandCt* d = &a.cands[(uint64_t)s.cand * a.n_ct + ct];
+            const int na = d->n_alt;
+            int32_t min_pbc = 100000, min_pcc = 100000;
+            for (int q = 0; q < na && q < LSG_CALL_MAX_ALT; ++q) { min_pbc = d->p_bc[q] < min_pbc ? d->p_bc[q] : min_pbc; min_pcc = d->p_cc[q] < min_pcc ? d->p_cc[q] : min_pcc; }
+            uint8_t f;                                                         // per-cell-type chain (:263-277), rounded values
+            if (min_pbc >= 500 || min_pcc >= 500) f = LSG_CF_NONSIG;
+            else if ((min_pbc > 10 && min_pbc < 500) || (min_pcc > 10 && min_pcc < 500)) f = LSG_CF_LOWSIG;
+            else if (na > 1) f = LSG_CF_MULTI;
+            else if ((int)d->alt_cc[0] < P.min_ac_cells) f = LSG_CF_LOW_CELLS;
+            else if ((int)d->alt_bc[0] < P.min_ac_reads) f = LSG_CF_LOW_READS;
+            else f = LSG_CF_PASS;
+            d->ct_filter = f;
+            ++n_with; n_pass += f == LSG_CF_PASS; n_nonsig += f == LSG_CF_NONSIG; any_multi |= f == LSG_CF_MULTI;
+        }
+        if (n_pass > P.max_cell_types) sf |= LSG_SF_MULTIPLE_CELL_TYPES;       // :309
+        if (any_multi) sf |= LSG_SF_MULTI_ALLELIC;                             // :314
+        if (n_with - n_pass - n_nonsig > 0) sf |= LSG_SF_CELL_TYPE_NOISE;      // :322
+        if (s.sum_alts_bc > 0 && (bc_lt05 || cc_lt05)) sf |= LSG_SF_NOISY_SITE;   // :342
+    } else if (s.sum_alts_bc > 0 && (bc_lt001 || cc_lt001)) {
+        sf |= LSG_SF_NOISY_SITE;                                               // :440-442
+    }
+    a.sites[i].site_filter = sf;
 }
 
 // Expansion of compact records into the C-ABI's lsg_call; kind selects rows (see lsg_export_calls).
@@ -351,7 +448,7 @@ int run_call(lsg_ctx* c, const lsg_call_params* p) {
     const uint32_t n_ne = c->n_ne;
     c->n_sites = 0; c->n_cand = 0;
     if (n_ne == 0) { c->called = true; return 0; }
-    if (c->d_site_off.reserve((size_t)(n_ne + 2) * 8 + 64)) return -1;
+    if (c->d_site_off.reserve((size_t)(n_ne + 2) * 8 + 128)) return -1;
     CallArgs a{};
     a.ne_units = c->d_ne_units.as<uint32_t>(); a.ne_mask = c->d_ne_mask.as<uint64_t>(); a.ne_rowbase = c->d_ne_rowbase.as<uint32_t>();
     a.ne_geom = c->ws[WS_NE_GEOM].as<int2>();
@@ -365,7 +462,7 @@ int run_call(lsg_ctx* c, const lsg_call_params* p) {
     a.site_cnt = c->d_site_off.as<uint32_t>();
     a.site_off = a.site_cnt + (n_ne + 2);
     a.counters = reinterpret_cast<unsigned long long*>(a.site_off + (n_ne + 2));   // 2*(n_ne+2) words: 8-byte aligned
-    LSG_HIP(hipMemsetAsync(a.counters, 0, 16, st));
+    LSG_HIP(hipMemsetAsync(a.counters, 0, 32, st));
     hipLaunchKernelGGL(k_site_count, dim3((n_ne + 256) / 256), dim3(256), 0, st, a);
     size_t tb = 0;
     LSG_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, a.site_cnt, a.site_off, (int)(n_ne + 1), st));
@@ -379,13 +476,25 @@ int run_call(lsg_ctx* c, const lsg_call_params* p) {
         if (c->d_calls.reserve((size_t)n_sites * sizeof(SiteRec))) return -1;
         if (c->ws[WS_CALL_CANDS].reserve((size_t)n_sites * sizeof(CandCt) * (size_t)c->n_ct)) return -1;   // every site could be a candidate
         a.sites = c->d_calls.as<SiteRec>(); a.cands = c->ws[WS_CALL_CANDS].as<CandCt>(); a.cand_cap = n_sites;
+        // at most 2 tails per alt (<= 4 alts) per cell type + 2 noise tails per site
+        a.task_cap = (uint64_t)n_sites * (uint64_t)(8 * c->n_ct + 2);
+        if (a.task_cap > 0x7fffffffull) a.task_cap = 0x7fffffffull;
+        // candidates rarely exceed a few tasks per site: size for 8 per site, checked below
+        if (a.task_cap > (uint64_t)n_sites * 8 + 1024) a.task_cap = (uint64_t)n_sites * 8 + 1024;
+        if (c->ws[WS_CALL_TASKS].reserve((size_t)a.task_cap * sizeof(TailTask) * 2)) return -1;
+        a.light = c->ws[WS_CALL_TASKS].as<TailTask>(); a.heavy = a.light + a.task_cap;
         const uint64_t threads = (uint64_t)n_ne * 64;
-        hipLaunchKernelGGL(k_call, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_call_gather, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_call_tails, dim3((unsigned)(c->n_cus * 16)), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_call_tails_heavy, dim3((unsigned)(c->n_cus * 8)), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_call_finish, dim3((n_sites + 255) / 256), dim3(256), 0, st, a, n_sites);
         LSG_HIP(hipGetLastError());
     }
-    unsigned long long cand = 0;
-    LSG_HIP(hipMemcpyAsync(&cand, a.counters, 8, hipMemcpyDeviceToHost, st));
+    unsigned long long cnt4[4] = {0, 0, 0, 0};
+    LSG_HIP(hipMemcpyAsync(cnt4, a.counters, 32, hipMemcpyDeviceToHost, st));
     LSG_HIP(hipStreamSynchronize(st));
+    const unsigned long long cand = cnt4[0];
+    if (n_sites > 0 && (cnt4[2] > a.task_cap || cnt4[3] > a.task_cap)) { set_error("lsg_call_step1: tail task buffer too small (%llu/%llu tasks)", cnt4[2], cnt4[3]); return -3; }
     c->n_sites = n_sites; c->n_cand = (int64_t)cand;
     c->called = true;
     return 0;
