@@ -137,23 +137,28 @@ __device__ __forceinline__ uint32_t tail_work(uint32_t k, uint32_t n) {
     return k < up ? k : up;
 }
 
-__global__ __launch_bounds__(256) void k_call_gather(CallArgs a) {
-    const int lane = threadIdx.x & 63;
+constexpr int GATHER_WAVES = 16;
+__global__ __launch_bounds__(GATHER_WAVES * 64) void k_call_gather(CallArgs a) {
+    __shared__ uint32_t s_tot[3][GATHER_WAVES];
+    __shared__ uint32_t s_base[3];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t w = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-    if (w >= a.n_ne) return;                                                  // whole wave
-    const uint32_t tile = a.ne_units[w] / (uint32_t)a.n_ct;
-    if (w > 0 && a.ne_units[w - 1] / (uint32_t)a.n_ct == tile) return;        // whole wave: not the head of its tile
+    // a wave works only if its unit is the first of its tile (the units of a tile are adjacent)
+    bool head = w < a.n_ne;
+    uint32_t tile = 0;
+    if (head) { tile = a.ne_units[w] / (uint32_t)a.n_ct; if (w > 0 && a.ne_units[w - 1] / (uint32_t)a.n_ct == tile) head = false; }
     uint64_t mask[LSG_MAX_CELLTYPES] = {0, 0, 0, 0};
     uint32_t rbase[LSG_MAX_CELLTYPES] = {0, 0, 0, 0};
     uint64_t any = 0;
-    for (uint32_t q = w; q < a.n_ne && a.ne_units[q] / (uint32_t)a.n_ct == tile; ++q) {
-        const int ct = (int)(a.ne_units[q] % (uint32_t)a.n_ct);
-        mask[ct] = a.ne_mask[q]; rbase[ct] = a.ne_rowbase[q]; any |= mask[ct];
-    }
+    if (head)
+        for (uint32_t q = w; q < a.n_ne && a.ne_units[q] / (uint32_t)a.n_ct == tile; ++q) {
+            const int ct = (int)(a.ne_units[q] % (uint32_t)a.n_ct);
+            mask[ct] = a.ne_mask[q]; rbase[ct] = a.ne_rowbase[q]; any |= mask[ct];
+        }
     const bool site = (any >> lane) & 1ull;
     const uint64_t below = (1ull << lane) - 1ull;
-    const uint64_t idx = (uint64_t)a.site_off[w] + __popcll(any & below);
-    const int2 geom = a.ne_geom[w];
+    const uint64_t idx = head ? (uint64_t)a.site_off[w] + __popcll(any & below) : 0;
+    const int2 geom = head ? a.ne_geom[w] : make_int2(0, 0);
     const int tid = geom.y & 0xffffff;
     const int64_t pos = (int64_t)geom.x + lane;
     const uint8_t* ref = a.ref_ptr[tid];
@@ -163,21 +168,35 @@ __global__ __launch_bounds__(256) void k_call_gather(CallArgs a) {
     const uint64_t cap = a.row_cap;
     const int order[4] = {0, 1, 3, 2};              // letter order A < C < G < T over classes (A,C,T,G) = (0,1,2,3)
 
+    // all loads first (independent, one latency): DP, NC, CC[0..5], BC[0..5] of every present cell type
+    uint32_t v_dp[LSG_MAX_CELLTYPES], v_nc[LSG_MAX_CELLTYPES], v_cc[LSG_MAX_CELLTYPES][6], v_bc[LSG_MAX_CELLTYPES][6];
+#pragma unroll
+    for (int ct = 0; ct < LSG_MAX_CELLTYPES; ++ct) {
+        v_dp[ct] = 0; v_nc[ct] = 0;
+#pragma unroll
+        for (int s = 0; s < 6; ++s) { v_cc[ct][s] = 0; v_bc[ct][s] = 0; }
+        if (ct < a.n_ct && site && ((mask[ct] >> lane) & 1ull)) {
+            const uint64_t row = (uint64_t)rbase[ct] + __popcll(mask[ct] & below);
+            const uint32_t* R = a.rows[ct];
+            v_dp[ct] = R[row]; v_nc[ct] = R[cap + row];
+#pragma unroll
+            for (int s = 0; s < 6; ++s) { v_cc[ct][s] = R[(2 + s) * cap + row]; v_bc[ct][s] = R[(10 + s) * cap + row]; }
+        }
+    }
     // pass 1: candidate? number of tail tasks?  (one wave-aggregated allocation each)
     bool has_any = false;
     uint32_t n_light = 0, n_heavy = 0;
     int32_t s_alts_bc = 0, s_alts_cc = 0, s_dp = 0, s_nc = 0;
     if (site) {
-        for (int ct = 0; ct < a.n_ct; ++ct) {
-            if (!((mask[ct] >> lane) & 1ull)) continue;
-            const uint64_t row = (uint64_t)rbase[ct] + __popcll(mask[ct] & below);
-            const uint32_t* R = a.rows[ct];
-            const uint32_t dp = R[row], nc = R[cap + row];
+#pragma unroll
+        for (int ct = 0; ct < LSG_MAX_CELLTYPES; ++ct) {
+            if (ct >= a.n_ct || !((mask[ct] >> lane) & 1ull)) continue;
+            const uint32_t dp = v_dp[ct], nc = v_nc[ct];
             if (!((int)dp >= P.min_cov && (int)nc >= P.min_cells)) continue;
             s_dp += (int32_t)dp; s_nc += (int32_t)nc;
 #pragma unroll
             for (int s = 0; s < 6; ++s) {
-                const uint32_t b = R[(10 + s) * cap + row], c = R[(2 + s) * cap + row];
+                const uint32_t b = v_bc[ct][s], c = v_cc[ct][s];
                 if (s == rsym) continue;
                 s_alts_bc += (int32_t)b; s_alts_cc += (int32_t)c;
                 if (s < 4 && b > 0) {
@@ -198,15 +217,18 @@ __global__ __launch_bounds__(256) void k_call_gather(CallArgs a) {
     uint32_t pl = n_light, ph = n_heavy;
     for (int o = 1; o < 64; o <<= 1) { const uint32_t vl = __shfl_up(pl, o), vh = __shfl_up(ph, o); if (lane >= o) { pl += vl; ph += vh; } }
     const uint32_t tot_l = __shfl(pl, 63), tot_h = __shfl(ph, 63);
-    uint32_t cbase = 0, lbase = 0, hbase = 0;
-    if (lane == 0) {
-        if (cm) cbase = (uint32_t)atomicAdd(&a.counters[0], (unsigned long long)__popcll(cm));
-        if (tot_l) lbase = (uint32_t)atomicAdd(&a.counters[2], (unsigned long long)tot_l);
-        if (tot_h) hbase = (uint32_t)atomicAdd(&a.counters[3], (unsigned long long)tot_h);
+    // one global atomic per counter per WORKGROUP (a single word takes only ~90 atomics/us)
+    if (lane == 0) { s_tot[0][wv] = (uint32_t)__popcll(cm); s_tot[1][wv] = tot_l; s_tot[2][wv] = tot_h; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        uint32_t t = 0;
+        for (int q = 0; q < GATHER_WAVES; ++q) t += s_tot[threadIdx.x][q];
+        const int slot = threadIdx.x == 0 ? 0 : (int)threadIdx.x + 1;
+        s_base[threadIdx.x] = t ? (uint32_t)atomicAdd(&a.counters[slot], (unsigned long long)t) : 0u;
     }
-    cbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)cbase);
-    lbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)lbase);
-    hbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)hbase);
+    __syncthreads();
+    uint32_t cbase = s_base[0], lbase = s_base[1], hbase = s_base[2];
+    for (int q = 0; q < wv; ++q) { cbase += s_tot[0][q]; lbase += s_tot[1][q]; hbase += s_tot[2][q]; }
     if (!site) return;
     const uint32_t cand = cbase + (uint32_t)__popcll(cm & below);
     uint32_t li = lbase + pl - n_light, hi = hbase + ph - n_heavy;
@@ -236,7 +258,9 @@ __global__ __launch_bounds__(256) void k_call_gather(CallArgs a) {
     int lc_up = 0, lc_down = 0;
     SiteRec* srp = &a.sites[idx];
 
-    for (int ct = 0; ct < a.n_ct; ++ct) {
+#pragma unroll
+    for (int ct = 0; ct < LSG_MAX_CELLTYPES; ++ct) {
+        if (ct >= a.n_ct) continue;
         CandCt cd;
         cd.n_alt = 0; cd.ct_filter = 0; cd.pad[0] = cd.pad[1] = 0;
 #pragma unroll
@@ -244,9 +268,7 @@ __global__ __launch_bounds__(256) void k_call_gather(CallArgs a) {
         CandCt* cdp = has_any && cand < a.cand_cap ? &a.cands[(uint64_t)cand * a.n_ct + ct] : nullptr;
         if ((mask[ct] >> lane) & 1ull) {
             sr.present |= (uint8_t)(1u << ct);
-            const uint64_t row = (uint64_t)rbase[ct] + __popcll(mask[ct] & below);
-            const uint32_t* R = a.rows[ct];
-            const uint32_t dp = R[row], nc = R[cap + row];
+            const uint32_t dp = v_dp[ct], nc = v_nc[ct];
             if ((int)dp >= P.min_cov && (int)nc >= P.min_cells) {                 // step1.py:174
                 sr.considered |= (uint8_t)(1u << ct);
                 ++n_considered;
@@ -255,9 +277,9 @@ __global__ __launch_bounds__(256) void k_call_gather(CallArgs a) {
 #pragma unroll
                 for (int oi = 0; oi < 4; ++oi) {
                     const int s = order[oi];
-                    const uint32_t b = R[(10 + s) * cap + row];
+                    const uint32_t b = v_bc[ct][s];
                     if (s == rsym || b == 0) continue;
-                    const uint32_t c = R[(2 + s) * cap + row];
+                    const uint32_t c = v_cc[ct][s];
                     if (na < LSG_CALL_MAX_ALT) {
                         cd.alt[na] = (uint8_t)s; cd.alt_bc[na] = b; cd.alt_cc[na] = c;
                         if (cdp) { emit_task(b, dp, 0, &cdp->p_bc[na]); emit_task(c, nc, 1, &cdp->p_cc[na]); }
@@ -484,7 +506,7 @@ int run_call(lsg_ctx* c, const lsg_call_params* p) {
         if (c->ws[WS_CALL_TASKS].reserve((size_t)a.task_cap * sizeof(TailTask) * 2)) return -1;
         a.light = c->ws[WS_CALL_TASKS].as<TailTask>(); a.heavy = a.light + a.task_cap;
         const uint64_t threads = (uint64_t)n_ne * 64;
-        hipLaunchKernelGGL(k_call_gather, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_call_gather, dim3((unsigned)((threads + GATHER_WAVES * 64 - 1) / (GATHER_WAVES * 64))), dim3(GATHER_WAVES * 64), 0, st, a);
         hipLaunchKernelGGL(k_call_tails, dim3((unsigned)(c->n_cus * 16)), dim3(256), 0, st, a);
         hipLaunchKernelGGL(k_call_tails_heavy, dim3((unsigned)(c->n_cus * 8)), dim3(256), 0, st, a);
         hipLaunchKernelGGL(k_call_finish, dim3((n_sites + 255) / 256), dim3(256), 0, st, a, n_sites);
