@@ -62,7 +62,8 @@ struct CountArgs {
     int32_t min_bq, min_mq, min_dp, min_cc, ignore_orphans;
     uint32_t flag_exclude;
     // workspace
-    uint32_t* read_key; uint32_t* unit_cnt; uint2* unit_plan;    // unit_plan[u] = {first slot, number of slots}
+    uint32_t* read_key; uint32_t* unit_cnt; uint32_t* unit_off; uint32_t* unit_cursor;   // dense per unit: entry region of buffer A
+    uint64_t ent_half;                    // entries of buffer B (barcode-split deep units) start here
     const uint32_t* ct_rank; uint32_t ct_size[LSG_MAX_CELLTYPES];   // rank of a barcode within its cell type
     uint32_t* ne_units; uint32_t* ne_nslot; uint32_t* ne_slot_base; uint32_t* ne_acc; int2* ne_geom;
     uint64_t* ne_mask; uint32_t* ne_rowbase;
@@ -109,8 +110,8 @@ __device__ __forceinline__ uint32_t sub_of(uint32_t cb, uint32_t nsub, uint32_t 
 // Counting sort of (segment, tile) pairs over the segments, with the atomics aggregated per
 // workgroup in an LDS hash: a batch of 256 consecutive segments of a coordinate-sorted BAM hits few
 // distinct units, so one global atomic per distinct target per round replaces one per entry.
-//   MODE 0: count entries per unit.  MODE 1: count entries per slot of multi-slot units.
-//   MODE 2: scatter the self-contained entries (key, first event index, lane range).
+//   MODE 0: count entries per unit.  MODE 2: scatter the self-contained entries (key, first event
+//   index, lane range) into the units' regions of entry buffer A.
 constexpr int BIN_THREADS = 256;
 constexpr int BIN_TPR = 4;             // tiles per segment handled per round
 constexpr int BIN_H = 2048;            // LDS hash slots (>= 2 x BIN_THREADS x BIN_TPR)
@@ -142,7 +143,6 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_segments(CountArgs a) {
         bool ok = key != KEY_INVALID;
         if (MODE == 0 && ok) { ++st_segs; st_evs += (unsigned long long)ln; }
         const uint32_t ct = key >> 28;
-        const uint32_t rank = (MODE != 0 && ok) ? a.ct_rank[key & CB_MASK] : 0u;
         const uint32_t tb = ok ? a.tile_base[tid] : 0;
         uint32_t t0 = tb + ((uint32_t)st >> 6);
         uint32_t t1 = tb + ((uint32_t)(st + ln - 1) >> 6);
@@ -165,14 +165,8 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_segments(CountArgs a) {
                 hr[j] = KEY_INVALID;
                 if (k < ntile) {
                     const uint32_t u = (t0 + (uint32_t)k) * (uint32_t)a.n_ct + ct;
-                    uint32_t x = u;
-                    bool act = true;
-                    if (MODE != 0) {
-                        const uint2 plan = a.unit_plan[u];
-                        x = plan.x + (plan.y > 1 ? sub_of(rank, plan.y, a.ct_size[ct]) : 0u);
-                        if (MODE == 1 && plan.y <= 1) act = false;
-                    }
-                    if (act) {
+                    const uint32_t x = u;
+                    {
                         uint32_t h = (x * 2654435761u) >> (32 - __builtin_ctz(BIN_H));
                         while (true) {
                             uint32_t prev = atomicCAS(&hkey[h], KEY_INVALID, x);
@@ -189,8 +183,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_segments(CountArgs a) {
                 if (cnt) {
                     const uint32_t x = hkey[i];
                     if (MODE == 0) atomicAdd(&a.unit_cnt[x], cnt);
-                    else if (MODE == 1) atomicAdd(&a.slot_cnt[x], cnt);
-                    else hbase[i] = atomicAdd(&a.slot_cursor[x], cnt);
+                    else hbase[i] = atomicAdd(&a.unit_cursor[x], cnt);
                     hkey[i] = KEY_INVALID; hcnt[i] = 0;
                 }
             }
@@ -253,15 +246,58 @@ __global__ void k_slot_init(CountArgs a) {
     if (w >= a.n_ne) return;
     uint32_t u = a.ne_units[w];
     uint32_t base = a.ne_slot_base[w], nslot = a.ne_nslot[w];
-    a.unit_plan[u] = make_uint2(base, nslot);
-    uint32_t cnt = a.unit_cnt[u];
-    for (uint32_t j = 0; j < nslot; ++j) { a.slot_w[base + j] = w; a.slot_cnt[base + j] = nslot == 1 ? cnt : 0u; }
-    if (w == a.n_ne - 1) a.slot_cnt[base + nslot] = 0;    // scan sentinel
+    for (uint32_t j = 0; j < nslot; ++j) a.slot_w[base + j] = w;
+    if (nslot == 1) { a.slot_cnt[base] = a.unit_cnt[u]; a.slot_off[base] = a.unit_off[u]; }   // multi-slot units: k_split_deep
 }
 
 __global__ void k_multi_index(CountArgs a) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < a.n_multi) a.ne_acc[a.multi_list[k]] = k;
+}
+
+// Deep units (more than CAPB entries) are cut into slots by barcode rank: counting sort of the unit's
+// entries from buffer A into buffer B (same unit offset), one workgroup per unit, LDS histogram.
+constexpr int SPLIT_THREADS = 512;
+__global__ __launch_bounds__(SPLIT_THREADS) void k_split_deep(CountArgs a) {
+    __shared__ uint32_t hist[MAXSUB];
+    __shared__ uint32_t wave_tot[SPLIT_THREADS / 64];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    for (uint32_t k = blockIdx.x; k < a.n_multi; k += gridDim.x) {
+        const uint32_t w = a.multi_list[k], u = a.ne_units[w];
+        const uint32_t n = a.unit_cnt[u], src = a.unit_off[u], nsub = a.ne_nslot[w], base = a.ne_slot_base[w];
+        const uint32_t ct = (uint32_t)a.ne_geom[w].y >> 24;
+        const uint32_t ctn = a.ct_size[ct];
+        __syncthreads();
+        for (int i = t; i < MAXSUB; i += SPLIT_THREADS) hist[i] = 0;
+        __syncthreads();
+        for (uint32_t i = t; i < n; i += SPLIT_THREADS)
+            atomicAdd(&hist[sub_of(a.ct_rank[a.ent[src + i].x & CB_MASK], nsub, ctn)], 1u);
+        __syncthreads();
+        // exclusive scan over MAXSUB = 4 x SPLIT_THREADS counters
+        constexpr int PER = MAXSUB / SPLIT_THREADS;
+        uint32_t loc[PER], sum = 0;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) { loc[q] = hist[t * PER + q]; sum += loc[q]; }
+        uint32_t incl = sum;
+        for (int o = 1; o < 64; o <<= 1) { uint32_t v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+        if (lane == 63) wave_tot[wv] = incl;
+        __syncthreads();
+        uint32_t excl = incl - sum;
+        for (int q = 0; q < wv; ++q) excl += wave_tot[q];
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const uint32_t j = (uint32_t)(t * PER + q);
+            if (j < nsub) { a.slot_cnt[base + j] = loc[q]; a.slot_off[base + j] = (uint32_t)(a.ent_half + src + excl); }
+            hist[j] = excl;                        // becomes the slot's write cursor
+            excl += loc[q];
+        }
+        __syncthreads();
+        for (uint32_t i = t; i < n; i += SPLIT_THREADS) {
+            const uint4 e = a.ent[src + i];
+            const uint32_t pos = atomicAdd(&hist[sub_of(a.ct_rank[e.x & CB_MASK], nsub, ctn)], 1u);
+            a.ent[a.ent_half + src + pos] = e;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -583,12 +619,8 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_group_block(CountArgs a) {
     __shared__ GroupLds L;
     const int t = threadIdx.x;
     const uint32_t n_big = a.n_slots - (uint32_t)a.scalars[SC_NSMALL];
-    while (true) {
+    for (uint32_t qi = blockIdx.x; qi < n_big; qi += gridDim.x) {     // static striding: slots are bounded, a shared queue word would cap the rate
         __syncthreads();
-        if (t == 0) L.slot = (uint32_t)atomicAdd(&a.scalars[SC_QGROUP], 1ull);
-        __syncthreads();
-        const uint32_t qi = L.slot;
-        if (qi >= n_big) break;
         const uint32_t s = a.slot_list[a.n_slots - 1 - qi];      // rejected items sit reversed at the end
         const int n = (int)a.slot_cnt[s];
         if (n > CAPB) {
@@ -960,7 +992,8 @@ static void fill_args(lsg_ctx* c, const lsg_count_params* p, CountArgs& a) {
     a.min_bq = p->min_bq; a.min_mq = p->min_mq; a.min_dp = p->min_dp; a.min_cc = p->min_cc;
     a.ignore_orphans = p->ignore_orphans; a.flag_exclude = p->flag_exclude;
     a.read_key = c->d_read_key.as<uint32_t>(); a.unit_cnt = c->d_unit_cnt.as<uint32_t>();
-    a.unit_plan = c->ws[WS_UNIT_PLAN].as<uint2>(); a.ct_rank = c->d_ct_rank.as<uint32_t>();
+    a.unit_off = c->d_unit_off.as<uint32_t>(); a.unit_cursor = c->d_unit_fill.as<uint32_t>(); a.ent_half = c->entries_upper + 1;
+    a.ct_rank = c->d_ct_rank.as<uint32_t>();
     for (int i = 0; i < LSG_MAX_CELLTYPES; ++i) a.ct_size[i] = c->ct_size[i] ? c->ct_size[i] : 1u;
     a.ne_units = c->d_ne_units.as<uint32_t>(); a.ne_nslot = c->ws[WS_NE_NSLOT].as<uint32_t>();
     a.ne_slot_base = c->ws[WS_NE_SLOT_BASE].as<uint32_t>(); a.ne_acc = c->ws[WS_NE_ACC].as<uint32_t>();
@@ -1003,14 +1036,14 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
     const uint64_t slot_cap = ne_cap + EU / SUBT + 16;
 
     if (c->d_read_key.reserve((size_t)(R + 1) * 4) || c->d_unit_cnt.reserve(((size_t)n_units + 2) * 4) ||
-        c->ws[WS_UNIT_PLAN].reserve(((size_t)n_units + 2) * 8) ||
+        c->d_unit_off.reserve(((size_t)n_units + 2) * 4) || c->d_unit_fill.reserve(((size_t)n_units + 2) * 4) ||
         c->d_scalars.reserve(SC_COUNT * 8) || c->d_ne_units.reserve((ne_cap + 2) * 4) || c->d_ne_mask.reserve((ne_cap + 2) * 8) ||
         c->d_ne_rowbase.reserve((ne_cap + 2) * 4) || c->ws[WS_NE_NSLOT].reserve((ne_cap + 2) * 4) ||
         c->ws[WS_NE_SLOT_BASE].reserve((ne_cap + 2) * 4) || c->ws[WS_NE_ACC].reserve((ne_cap + 2) * 4) ||
         c->ws[WS_NE_GEOM].reserve((ne_cap + 2) * 8) || c->ws[WS_SLOT_W].reserve((slot_cap + 2) * 4) ||
         c->ws[WS_SLOT_CNT].reserve((slot_cap + 2) * 4) || c->ws[WS_SLOT_OFF].reserve((slot_cap + 2) * 4) ||
         c->ws[WS_SLOT_CURSOR].reserve((slot_cap + 2) * 4) || c->ws[WS_SLOT_LIST].reserve((slot_cap + 2) * 4) ||
-        c->ws[WS_MULTI_LIST].reserve((EU / CAPB + 16) * 4) || c->ws[WS_ENT].reserve((EU + 1) * 16) ||
+        c->ws[WS_MULTI_LIST].reserve((EU / CAPB + 16) * 4) || c->ws[WS_ENT].reserve((EU + 1) * 32 + 64) ||
         c->ws[WS_SLICES].reserve((slot_cap + 2) * (NSLICE + 1) * 4) || c->ws[WS_HUGE_LIST].reserve((EU / CAPB + 16) * 4))
         return -1;
 
@@ -1024,6 +1057,7 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
     if (seg_grid > (unsigned)(c->n_cus * 8)) seg_grid = (unsigned)(c->n_cus * 8);
     if (R > 0) { unsigned g = (unsigned)((R + 255) / 256); if (g > (unsigned)(c->n_cus * 8)) g = (unsigned)(c->n_cus * 8); hipLaunchKernelGGL(k_read_key, dim3(g), dim3(256), 0, st, a); }
     if (S > 0) hipLaunchKernelGGL(k_bin_segments<0>, dim3(seg_grid), dim3(256), 0, st, a);
+    SCAN_U32(a.unit_cnt, a.unit_off, n_units + 1);          // entry regions of buffer A, unit by unit
 
     // non-empty units, in genomic order
     hipcub::CountingInputIterator<uint32_t> cnt_it(0);
@@ -1053,20 +1087,8 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
         if (c->ws[WS_MACC].reserve(((size_t)c->n_multi + 1) * NCTR * 64 * 4)) return -1;
         fill_args(c, p, a);
         hipLaunchKernelGGL(k_slot_init, dim3((n_ne + 255) / 256), dim3(256), 0, st, a);
-        if (c->n_multi > 0 && S > 0) hipLaunchKernelGGL(k_bin_segments<1>, dim3(seg_grid), dim3(256), 0, st, a);
-        SCAN_U32(a.slot_cnt, a.slot_off, c->n_slots + 1);
-        LSG_HIP(hipMemcpyAsync(a.slot_cursor, a.slot_off, ((size_t)c->n_slots + 1) * 4, hipMemcpyDeviceToDevice, st));
+        LSG_HIP(hipMemcpyAsync(a.unit_cursor, a.unit_off, ((size_t)n_units + 1) * 4, hipMemcpyDeviceToDevice, st));
         if (S > 0) hipLaunchKernelGGL(k_bin_segments<2>, dim3(seg_grid), dim3(256), 0, st, a);
-        // work lists: small slots first, the rest reversed at the end; multi-slot units
-        {
-            SmallSlot pred{a.slot_cnt, a.slot_w, a.ne_nslot};
-            uint32_t* d_nsmall = reinterpret_cast<uint32_t*>(a.scalars + SC_NSMALL);
-            size_t tb = 0;
-            LSG_HIP(hipcub::DevicePartition::If(nullptr, tb, cnt_it, a.slot_list, d_nsmall, (int)c->n_slots, pred, st));
-            if (cub_tmp(c, tb)) return -1;
-            tb = c->d_cub_tmp.cap;
-            LSG_HIP(hipcub::DevicePartition::If(c->d_cub_tmp.p, tb, cnt_it, a.slot_list, d_nsmall, (int)c->n_slots, pred, st));
-        }
         if (c->n_multi > 0) {
             MultiUnit pred{a.ne_nslot};
             uint32_t* d_nm = reinterpret_cast<uint32_t*>(a.scalars + SC_NMULTI_SEL);
@@ -1077,6 +1099,18 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
             LSG_HIP(hipcub::DeviceSelect::If(c->d_cub_tmp.p, tb, cnt_it, a.multi_list, d_nm, (int)n_ne, pred, st));
             hipLaunchKernelGGL(k_multi_index, dim3((c->n_multi + 255) / 256), dim3(256), 0, st, a);
             LSG_HIP(hipMemsetAsync(a.macc, 0, (size_t)c->n_multi * NCTR * 64 * 4, st));
+            unsigned sg = c->n_multi < (unsigned)(c->n_cus * 4) ? c->n_multi : (unsigned)(c->n_cus * 4);
+            hipLaunchKernelGGL(k_split_deep, dim3(sg), dim3(SPLIT_THREADS), 0, st, a);
+        }
+        // work lists: small slots first, the rest reversed at the end
+        {
+            SmallSlot pred{a.slot_cnt, a.slot_w, a.ne_nslot};
+            uint32_t* d_nsmall = reinterpret_cast<uint32_t*>(a.scalars + SC_NSMALL);
+            size_t tb = 0;
+            LSG_HIP(hipcub::DevicePartition::If(nullptr, tb, cnt_it, a.slot_list, d_nsmall, (int)c->n_slots, pred, st));
+            if (cub_tmp(c, tb)) return -1;
+            tb = c->d_cub_tmp.cap;
+            LSG_HIP(hipcub::DevicePartition::If(c->d_cub_tmp.p, tb, cnt_it, a.slot_list, d_nsmall, (int)c->n_slots, pred, st));
         }
     }
     // row buffers: bound + arena slack
@@ -1121,7 +1155,7 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
     c->stats.n_entries = 0;
     if (n_ne > 0) {
         uint32_t total_entries = 0;
-        LSG_HIP(hipMemcpy(&total_entries, c->ws[WS_SLOT_OFF].as<uint32_t>() + c->n_slots, 4, hipMemcpyDeviceToHost));
+        LSG_HIP(hipMemcpy(&total_entries, c->d_unit_off.as<uint32_t>() + n_units, 4, hipMemcpyDeviceToHost));
         c->stats.n_entries = total_entries;
     }
     float ms = 0;
@@ -1217,7 +1251,7 @@ int compute_entries_upper(lsg_ctx* c) {
     unsigned long long v = 0;
     LSG_HIP(hipMemcpyAsync(&v, c->d_scalars.p, 8, hipMemcpyDeviceToHost, c->stream));
     LSG_HIP(hipStreamSynchronize(c->stream));
-    if (v >= 0xFFFFFFF0ull) { set_error("lsg_load_reads: %llu tile entries exceed the 32-bit entry index; load the reads in windows", v); return -2; }
+    if (v >= 0x7FFFFFF0ull) { set_error("lsg_load_reads: %llu tile entries exceed the 31-bit entry index (two entry buffers); load the reads in windows", v); return -2; }
     c->entries_upper = (uint64_t)v;
     return 0;
 }
