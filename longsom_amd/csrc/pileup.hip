@@ -26,6 +26,7 @@ namespace lsg {
 
 constexpr uint32_t KEY_INVALID = 0xFFFFFFFFu;
 constexpr uint32_t CB_MASK = 0x00FFFFFFu;
+constexpr uint32_t KEY_NEWRUN = 1u << 25;    // set by the grouping step: first entry of a barcode run
 constexpr int CAPW = 256;            // max entries of a wave-processed slot
 constexpr int HW = 512;              // hash slots of the wave kernel
 constexpr int CAPB = 2048;           // max entries staged at once by the block kernel
@@ -198,8 +199,11 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_segments(CountArgs a) {
                         const int32_t lo = st > tstart ? st : tstart;
                         const int32_t hi = st + ln < tstart + TILE_W ? st + ln : tstart + TILE_W;
                         const int64_t ev_first = evoff + (lo - st);
-                        a.ent[pos] = make_uint4(key, (uint32_t)ev_first,
-                                                (uint32_t)((ev_first >> 32) & 0xff) | ((uint32_t)(lo - tstart) << 8) | ((uint32_t)(hi - lo - 1) << 16), 0u);
+                        // entry = {key, byte offset of the first event (41 bits: y + 9 bits of z), lane range pre-doubled
+                        // (2*first lane at z[16..22], 2*(count-1) at z[24..30])}: the walk needs no per-entry arithmetic beyond adds
+                        const uint64_t boff = (uint64_t)ev_first * 2ull;
+                        a.ent[pos] = make_uint4(key, (uint32_t)boff,
+                                                (uint32_t)(boff >> 32) | ((uint32_t)(2 * (lo - tstart)) << 16) | ((uint32_t)(2 * (hi - lo - 1)) << 24), 0u);
                     }
                 }
             }
@@ -224,7 +228,7 @@ __device__ __forceinline__ void unit_geometry(const CountArgs& a, uint32_t u, in
 __global__ void k_unit_plan(CountArgs a) {
     uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w > a.n_ne) return;
-    if (w == a.n_ne) { a.ne_nslot[w] = 0; return; }
+    if (w == a.n_ne) { a.ne_nslot[w] = 0; a.ne_acc[w] = 0; return; }
     uint32_t u = a.ne_units[w];
     uint32_t cnt = a.unit_cnt[u];
     uint32_t nslot = 1;
@@ -235,6 +239,7 @@ __global__ void k_unit_plan(CountArgs a) {
         if (nslot < 1) nslot = 1;
     }
     a.ne_nslot[w] = nslot;
+    a.ne_acc[w] = nslot > 1 ? nslot : 0u;          // scanned afterwards: first partial-sum slab of the unit
     if (nslot > 1) atomicAdd(&a.scalars[SC_NMULTI], 1ull);
     int ct, tid; int32_t tstart;
     unit_geometry(a, u, ct, tid, tstart);
@@ -317,11 +322,11 @@ __device__ __forceinline__ uint32_t rl(uint32_t v, int l) { return (uint32_t)__b
 // BaseCellCounter.py:283,292).
 struct Acc {
     uint32_t bc[8], bq[8], bcf[8], dup[8], ncdup;
-    uint32_t mask, npk, prev_cb, nev;
+    uint32_t mask, npk, nev;
     __device__ __forceinline__ void init() {
 #pragma unroll
         for (int s = 0; s < 8; ++s) bc[s] = bq[s] = bcf[s] = dup[s] = 0;
-        ncdup = mask = npk = nev = 0; prev_cb = KEY_INVALID;
+        ncdup = mask = npk = nev = 0;
     }
     __device__ __forceinline__ void flush_pk(uint32_t* pk, int lane) {
 #pragma unroll
@@ -332,20 +337,25 @@ struct Acc {
         }
         npk = 0;
     }
-    __device__ __forceinline__ void new_run() { mask = 0; prev_cb = KEY_INVALID; }
-    // One pileup entry at this lane's position (BaseCellCounter.py:258-279); key is wave-uniform.
-    __device__ __forceinline__ void add(uint32_t key, uint32_t ev, bool in_range, int min_bq, uint32_t* pk, int lane) {
-        uint32_t cb = key & CB_MASK;
-        if (cb != prev_cb) { mask = 0; prev_cb = cb; }
-        uint32_t q = ev & 0xffu, sym = ev >> 8;
-        nev += in_range;
-        if (in_range && sym < 8 && (int)q >= min_bq) {
-            uint32_t seen = (mask >> sym) & 1u;
-            ncdup += mask != 0;
-            uint32_t fwd = ((key >> 24) & 1u) ^ 1u;
-            atomicAdd(&pk[sym * 64 + lane], (q << 18) | (seen << 12) | 64u | fwd);   // ds_add_u32, lane-private word
-            mask |= 1u << sym;
-        }
+    __device__ __forceinline__ void new_run() { mask = 0; }
+    // One pileup entry at this lane's position (BaseCellCounter.py:258-279).  key is wave-uniform; its
+    // KEY_NEWRUN bit starts a new barcode run.  Branch-free and free of scalar mask arithmetic: the
+    // scalar unit (one per CU) is the scarce issue slot of this loop.
+    __device__ __forceinline__ void add(uint32_t key, uint32_t ev, uint32_t in_range, int min_bq, uint32_t* pk, int lane) {
+        mask &= (key & KEY_NEWRUN) ? 0u : 0xFFFFFFFFu;
+        const uint32_t evp = ev | (in_range - 1u);                     // out of range -> all ones ('NA', row 7, value 0)
+        const uint32_t sym = (evp >> 8) & 0xffu, q = evp & 0xffu;
+        // invalid: symbol class >= 8 ('NA') or quality below the gate
+        const uint32_t inval = ((evp >> 11) & 1u) | ((uint32_t)((int32_t)q - (int32_t)min_bq) >> 31);
+        const uint32_t vm = inval - 1u;                                 // all ones when counted
+        const uint32_t valid = vm & 1u;
+        const uint32_t seen = (mask >> (sym & 31u)) & 1u;
+        const uint32_t fwdc = 64u | (((key >> 24) & 1u) ^ 1u);
+        const uint32_t val = ((q << 18) | (seen << 12) | fwdc) & vm;
+        // ds_add_u32 on the lane-private word of the symbol's row (row 7 with value 0 when not counted)
+        atomicAdd(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(pk + lane) + (evp & 0x700u)), val);
+        ncdup += valid & (mask != 0 ? 1u : 0u);
+        mask |= valid << (sym & 31u);
         ++npk;
     }
     // call before adding up to `next` more entries: keeps the packed 6-bit fields from overflowing
@@ -355,30 +365,70 @@ struct Acc {
     __device__ __forceinline__ void finish(uint32_t* pk, int lane) { flush_pk(pk, lane); }
 };
 
+// event load of one entry (es, ms wave-uniform): returns the event at this lane's position; lanes outside
+// the entry's range re-read its last event (same cache line) and report in_range = false.
+__device__ __forceinline__ uint32_t load_event(const uint16_t* __restrict__ events, uint32_t es, uint32_t ms, int lane, uint32_t& in_range) {
+    const uint32_t lo2 = (ms >> 16) & 0x7fu, cm12 = ms >> 24;
+    const char* base = reinterpret_cast<const char*>(events) + ((((uint64_t)(ms & 0x1ffu)) << 32) | es);
+    const uint32_t rel2 = 2u * (uint32_t)lane - lo2;
+    in_range = rel2 <= cm12 ? 1u : 0u;
+    const uint32_t voff = rel2 < cm12 ? rel2 : cm12;
+    return (uint32_t)*reinterpret_cast<const uint16_t*>(base + voff);
+}
+
 // One group of up to U entries of the register-held record batch (k,e,m): issue all event loads
 // first (branch-free: out-of-range lanes re-read the entry's last event, same cache line), then
 // consume them.  FULL = exactly U entries (the hot case, no guards at all).
 template <int U, bool FULL>
 __device__ __forceinline__ void walk_group(const uint16_t* __restrict__ events, Acc& acc, uint32_t k, uint32_t e, uint32_t m, int l, int cnt,
                                            int min_bq, uint32_t* pk, int lane) {
-    uint32_t ks[U], evv[U]; bool inr[U];
+    uint32_t ks[U], evv[U]; uint32_t inb = 0;                       // bit u of inb: lane in range of entry u
     acc.reserve(U, pk, lane);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         if (FULL || u < cnt) {
-            ks[u] = rl(k, l + u);
-            const uint32_t es = rl(e, l + u), ms = rl(m, l + u);
-            const uint32_t rel = (uint32_t)lane - ((ms >> 8) & 63u);
-            const uint32_t cm1 = (ms >> 16) & 63u;
-            inr[u] = rel <= cm1;
-            const uint32_t relc = inr[u] ? rel : cm1;
-            const uint64_t addr = (((uint64_t)(ms & 0xffu)) << 32 | es) + relc;
-            evv[u] = (uint32_t)events[addr];
+            uint32_t in; ks[u] = rl(k, l + u);
+            evv[u] = load_event(events, rl(e, l + u), rl(m, l + u), lane, in);
+            inb |= in << u;
         }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u)
-        if (FULL || u < cnt) acc.add(ks[u], evv[u], inr[u], min_bq, pk, lane);
+        if (FULL || u < cnt) acc.add(ks[u], evv[u], (inb >> u) & 1u, min_bq, pk, lane);
+}
+
+// A full batch of 64 register-held records, software pipelined: the event loads of group g+1 are
+// in flight while group g is consumed (two groups = 16 loads outstanding per wave).
+template <int U>
+__device__ __forceinline__ void issue_group(const uint16_t* __restrict__ events, uint32_t k, uint32_t e, uint32_t m, int l,
+                                            uint32_t (&ks)[U], uint32_t (&evv)[U], uint32_t& inb, int lane) {
+    inb = 0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        uint32_t in; ks[u] = rl(k, l + u);
+        evv[u] = load_event(events, rl(e, l + u), rl(m, l + u), lane, in);
+        inb |= in << u;
+    }
+}
+template <int U>
+__device__ __forceinline__ void consume_group(Acc& acc, const uint32_t (&ks)[U], const uint32_t (&evv)[U], uint32_t inb, int min_bq,
+                                              uint32_t* pk, int lane) {
+    acc.reserve(U, pk, lane);
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc.add(ks[u], evv[u], (inb >> u) & 1u, min_bq, pk, lane);
+}
+template <int U>
+__device__ __forceinline__ void walk_batch64(const uint16_t* __restrict__ events, Acc& acc, uint32_t k, uint32_t e, uint32_t m, int min_bq,
+                                             uint32_t* pk, int lane) {
+    uint32_t ksA[U], evA[U], ksB[U], evB[U], inA, inB;
+    issue_group<U>(events, k, e, m, 0, ksA, evA, inA, lane);
+#pragma unroll
+    for (int g = 0; g < 64 / U; g += 2) {
+        issue_group<U>(events, k, e, m, (g + 1) * U, ksB, evB, inB, lane);
+        consume_group<U>(acc, ksA, evA, inA, min_bq, pk, lane);
+        if (g + 2 < 64 / U) issue_group<U>(events, k, e, m, (g + 2) * U, ksA, evA, inA, lane);
+        consume_group<U>(acc, ksB, evB, inB, min_bq, pk, lane);
+    }
 }
 
 // Walk grouped entries [j0, j1) held in LDS with all 64 lanes = 64 positions.  Records are read 64
@@ -389,7 +439,7 @@ __device__ __forceinline__ void walk(const CountArgs& a, Acc& acc, const uint32_
     for (int jb = j0; jb < j1; jb += 64) {
         const int nb = j1 - jb < 64 ? j1 - jb : 64;
         uint32_t k = 0, e = 0, m = 0;
-        if (lane < nb) { k = gkey[jb + lane]; e = gev[jb + lane]; m = gmeta[jb + lane]; }
+        if (lane < nb) { k = gkey[jb + lane]; e = gev[jb + lane]; m = gmeta[jb + lane]; acc.nev += (m >> 25) + 1u; }
         int l = 0;
         for (; l + U <= nb; l += U) walk_group<U, true>(a.events, acc, k, e, m, l, U, a.min_bq, pk, lane);
         if (l < nb) walk_group<U, false>(a.events, acc, k, e, m, l, nb - l, a.min_bq, pk, lane);
@@ -453,12 +503,24 @@ __device__ __forceinline__ int group_by_cb(const CountArgs& a, uint32_t src, int
     for (int r = 0; r < RMAX; ++r) {
         if (t + r * T < n) {
             uint32_t p = tcnt[hs[r] & 0xffffu] + (hs[r] >> 16);
-            if (TO_GLOBAL) {   // in place: every thread holds its entries in registers since before the first barrier
-                a.ent[src + p] = make_uint4(ek[r], ee[r], em[r], 0u);
+            hs[r] = p;
+            if (TO_GLOBAL) {
                 gkey[p] = ek[r] & CB_MASK;
             } else {
-                gkey[p] = ek[r]; gev[p] = ee[r]; gmeta[p] = em[r];
+                gkey[p] = ek[r] & ~KEY_NEWRUN; gev[p] = ee[r]; gmeta[p] = em[r];
             }
+        }
+    }
+    group_sync<BLOCK>();
+    // mark the first entry of every barcode run (the walk resets its per-run symbol mask there)
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) {
+        if (t + r * T < n) {
+            const uint32_t p = hs[r];
+            const bool first = p == 0 || (gkey[p - 1] & CB_MASK) != (ek[r] & CB_MASK);
+            const uint32_t key = (ek[r] & ~KEY_NEWRUN) | (first ? KEY_NEWRUN : 0u);
+            if (TO_GLOBAL) a.ent[src + p] = make_uint4(key, ee[r], em[r], 0u);   // in place: all entries are in registers since before the first barrier
+            else if (first) atomicOr(&gkey[p], KEY_NEWRUN);
         }
     }
     group_sync<BLOCK>();
@@ -644,12 +706,17 @@ __device__ __forceinline__ void walk_global(const CountArgs& a, Acc& acc, uint32
     if (j0 + lane < j1) { const uint4 v = a.ent[src + j0 + lane]; k = v.x; e = v.y; m = v.z; }
     for (int jb = j0; jb < j1; jb += 64) {
         const int nb = j1 - jb < 64 ? j1 - jb : 64;
+        if (lane < nb) acc.nev += (m >> 25) + 1u;                    // events of this batch's entries (statistics)
         // prefetch the next batch of records while this one is consumed
         uint32_t k2 = 0, e2 = 0, m2 = 0;
         if (jb + 64 + lane < j1) { const uint4 v = a.ent[src + jb + 64 + lane]; k2 = v.x; e2 = v.y; m2 = v.z; }
-        int l = 0;
-        for (; l + U <= nb; l += U) walk_group<U, true>(a.events, acc, k, e, m, l, U, a.min_bq, pk, lane);
-        if (l < nb) walk_group<U, false>(a.events, acc, k, e, m, l, nb - l, a.min_bq, pk, lane);
+        if (false && nb == 64) {
+            walk_batch64<U>(a.events, acc, k, e, m, a.min_bq, pk, lane);
+        } else {
+            int l = 0;
+            for (; l + U <= nb; l += U) walk_group<U, true>(a.events, acc, k, e, m, l, U, a.min_bq, pk, lane);
+            if (l < nb) walk_group<U, false>(a.events, acc, k, e, m, l, nb - l, a.min_bq, pk, lane);
+        }
         k = k2; e = e2; m = m2;
     }
 }
@@ -696,11 +763,10 @@ __global__ __launch_bounds__(WALK_THREADS) void k_walk_block(CountArgs a) {
         }
         __syncthreads();
         if (a.ne_nslot[w] > 1) {
-            uint32_t* dst = a.macc + (uint64_t)a.ne_acc[w] * (NCTR * 64);
-            for (int i = t; i < NCTR * 64; i += WALK_THREADS) {
-                uint32_t v = (&L.acc[0][0])[i];
-                if (v) atomicAdd(&dst[i], v);
-            }
+            // multi-slot unit: this slot's partial sums go to its own slab with plain coalesced stores;
+            // k_finalize_multi adds the unit's slabs (global atomics here cost more than the whole walk)
+            uint32_t* dst = a.macc + (uint64_t)(a.ne_acc[w] + (s - a.ne_slot_base[w])) * (NCTR * 64);
+            for (int i = t; i < NCTR * 64; i += WALK_THREADS) dst[i] = (&L.acc[0][0])[i];
         } else if (wv == 0) {
             Acc tot; tot.init();
             tot.ncdup = L.acc[0][lane];
@@ -796,9 +862,12 @@ __device__ __forceinline__ int block_stage_filtered(const CountArgs& a, BlockLds
     for (int r = 0; r < RMAX; ++r) {
         if (t + r * BLOCK_THREADS < ns) {
             uint32_t p = L.u.h.tcnt[hs[r] & 0xffffu] + (hs[r] >> 16);
-            L.gkey[p] = ek[r]; L.gev[p] = ee[r]; L.gmeta[p] = em[r];
+            L.gkey[p] = ek[r] & ~KEY_NEWRUN; L.gev[p] = ee[r]; L.gmeta[p] = em[r];
         }
     }
+    __syncthreads();
+    for (int q = t; q < ns; q += BLOCK_THREADS)                       // first entry of every barcode run
+        if (q == 0 || (L.gkey[q - 1] & CB_MASK) != (L.gkey[q] & CB_MASK)) atomicOr(&L.gkey[q], KEY_NEWRUN);
     __syncthreads();
     return ns;
 }
@@ -885,14 +954,13 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_pileup_huge(CountArgs a) {
                                 uint32_t k = KEY_INVALID, e = 0, m = 0;
                                 if (ib + lane < n) { const uint4 v = a.ent[src + ib + lane]; k = v.x; e = v.y; m = v.z; }
                                 bool match = k != KEY_INVALID && (k & CB_MASK) == c;
+                                if (match) acc.nev += (m >> 25) + 1u;
                                 unsigned long long mm = __ballot(match);
                                 while (mm) {
                                     int l = __ffsll((long long)mm) - 1; mm &= mm - 1;
-                                    uint32_t ks = rl(k, l), es = rl(e, l), ms = rl(m, l);
-                                    uint32_t rel = (uint32_t)lane - ((ms >> 8) & 63u);
-                                    bool inr = rel <= ((ms >> 16) & 63u);
-                                    uint64_t addr = (((uint64_t)(ms & 0xffu)) << 32 | es) + rel;
-                                    uint32_t evv = inr ? (uint32_t)a.events[addr] : 0xffffu;
+                                    uint32_t inr;
+                                    const uint32_t ks = rl(k, l) & ~KEY_NEWRUN;          // the run is the whole barcode: reset by new_run() above
+                                    const uint32_t evv = load_event(a.events, rl(e, l), rl(m, l), lane, inr);
                                     acc.reserve(1, pk, lane);
                                     acc.add(ks, evv, inr, a.min_bq, pk, lane);
                                 }
@@ -920,11 +988,8 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_pileup_huge(CountArgs a) {
         }
         __syncthreads();
         if (multi) {
-            uint32_t* dst = a.macc + (uint64_t)a.ne_acc[w] * (NCTR * 64);
-            for (int i = t; i < NCTR * 64; i += BLOCK_THREADS) {
-                uint32_t v = (&L.u.w.acc[0][0])[i];
-                if (v) atomicAdd(&dst[i], v);
-            }
+            uint32_t* dst = a.macc + (uint64_t)(a.ne_acc[w] + (s - a.ne_slot_base[w])) * (NCTR * 64);
+            for (int i = t; i < NCTR * 64; i += BLOCK_THREADS) dst[i] = (&L.u.w.acc[0][0])[i];
         } else if (wv == 0) {
             Acc tot; tot.init();
             tot.ncdup = L.u.w.acc[0][lane];
@@ -947,13 +1012,16 @@ __global__ void k_finalize_multi(CountArgs a) {
     uint32_t k = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     if (k >= a.n_multi) return;
     uint32_t w = a.multi_list[k];
-    const uint32_t* src = a.macc + (uint64_t)k * (NCTR * 64);
+    const uint32_t nslot = a.ne_nslot[w];
     Acc tot; tot.init();
-    tot.ncdup = src[lane];
+    for (uint32_t j = 0; j < nslot; ++j) {                        // the unit's slabs are contiguous
+        const uint32_t* src = a.macc + (uint64_t)(a.ne_acc[w] + j) * (NCTR * 64);
+        tot.ncdup += src[lane];
 #pragma unroll
-    for (int sy = 0; sy < 8; ++sy) {
-        tot.dup[sy] = src[(1 + sy) * 64 + lane]; tot.bc[sy] = src[(9 + sy) * 64 + lane];
-        tot.bq[sy] = src[(17 + sy) * 64 + lane]; tot.bcf[sy] = src[(25 + sy) * 64 + lane];
+        for (int sy = 0; sy < 8; ++sy) {
+            tot.dup[sy] += src[(1 + sy) * 64 + lane]; tot.bc[sy] += src[(9 + sy) * 64 + lane];
+            tot.bq[sy] += src[(17 + sy) * 64 + lane]; tot.bcf[sy] += src[(25 + sy) * 64 + lane];
+        }
     }
     const int2 geom = a.ne_geom[w];
     emit_unit(a, tot, w, (int)((uint32_t)geom.y >> 24), geom.y & 0xffffff, geom.x, lane, nullptr, true);
@@ -1080,11 +1148,14 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
         // slot plan: deep units are cut into barcode-range slots
         hipLaunchKernelGGL(k_unit_plan, dim3((n_ne + 1 + 255) / 256), dim3(256), 0, st, a);
         SCAN_U32(a.ne_nslot, a.ne_slot_base, n_ne + 1);
+        SCAN_U32(a.ne_acc, a.ne_acc, n_ne + 1);
+        uint32_t n_slabs = 0;
+        LSG_HIP(hipMemcpyAsync(&n_slabs, a.ne_acc + n_ne, 4, hipMemcpyDeviceToHost, st));
         LSG_HIP(hipMemcpyAsync(&c->n_slots, a.ne_slot_base + n_ne, 4, hipMemcpyDeviceToHost, st));
         if (read_scalars(c, sc)) return -1;
         c->n_multi = (uint32_t)sc[SC_NMULTI];
         if (c->n_slots > slot_cap) { set_error("lsg_pileup_count: slot plan exceeds its bound"); return -1; }
-        if (c->ws[WS_MACC].reserve(((size_t)c->n_multi + 1) * NCTR * 64 * 4)) return -1;
+        if (c->ws[WS_MACC].reserve(((size_t)n_slabs + 1) * NCTR * 64 * 4)) return -1;
         fill_args(c, p, a);
         hipLaunchKernelGGL(k_slot_init, dim3((n_ne + 255) / 256), dim3(256), 0, st, a);
         LSG_HIP(hipMemcpyAsync(a.unit_cursor, a.unit_off, ((size_t)n_units + 1) * 4, hipMemcpyDeviceToDevice, st));
@@ -1097,8 +1168,6 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
             if (cub_tmp(c, tb)) return -1;
             tb = c->d_cub_tmp.cap;
             LSG_HIP(hipcub::DeviceSelect::If(c->d_cub_tmp.p, tb, cnt_it, a.multi_list, d_nm, (int)n_ne, pred, st));
-            hipLaunchKernelGGL(k_multi_index, dim3((c->n_multi + 255) / 256), dim3(256), 0, st, a);
-            LSG_HIP(hipMemsetAsync(a.macc, 0, (size_t)c->n_multi * NCTR * 64 * 4, st));
             unsigned sg = c->n_multi < (unsigned)(c->n_cus * 4) ? c->n_multi : (unsigned)(c->n_cus * 4);
             hipLaunchKernelGGL(k_split_deep, dim3(sg), dim3(SPLIT_THREADS), 0, st, a);
         }
