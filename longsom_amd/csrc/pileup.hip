@@ -114,8 +114,8 @@ __device__ __forceinline__ uint32_t sub_of(uint32_t cb, uint32_t nsub, uint32_t 
 //   MODE 0: count entries per unit.  MODE 2: scatter the self-contained entries (key, first event
 //   index, lane range) into the units' regions of entry buffer A.
 constexpr int BIN_THREADS = 256;
-constexpr int BIN_TPR = 4;             // tiles per segment handled per round
-constexpr int BIN_H = 2048;            // LDS hash slots (>= 2 x BIN_THREADS x BIN_TPR)
+constexpr int BIN_TPR = 8;             // tiles per segment handled per round
+constexpr int BIN_H = 4096;            // LDS hash slots (>= 2 x BIN_THREADS x BIN_TPR)
 template <int MODE>
 __global__ __launch_bounds__(BIN_THREADS) void k_bin_segments(CountArgs a) {
     __shared__ uint32_t hkey[BIN_H], hcnt[BIN_H], hbase[BIN_H];
