@@ -96,11 +96,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal on a 1-GPU box: LSG_BENCH_DEVICE pins every rank to one device, LSG_BENCH_BACKEND=gloo moves the
+    # collectives to the CPU (RCCL refuses two ranks on one GPU); the driver's runs use neither
+    if "LSG_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["LSG_BENCH_DEVICE"])
+    backend = os.environ.get("LSG_BENCH_BACKEND", "nccl")
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
     else:
         torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -130,8 +135,9 @@ def main():
         n_pass = 0
         if world > 1:
             n_pass = eng.export_calls(2)
-            cnt = torch.tensor([n_pass], dtype=torch.int64, device=dev)
-            allc = torch.empty(world, dtype=torch.int64, device=dev)
+            cdev = dev if backend == "nccl" else torch.device("cpu")
+            cnt = torch.tensor([n_pass], dtype=torch.int64, device=cdev)
+            allc = torch.empty(world, dtype=torch.int64, device=cdev)
             dist.all_gather_into_tensor(allc, cnt)
             mx = max(1, int(allc.max().item()))
             if gather_buf is None or gather_buf[0].numel() < mx * CALL_BYTES:
@@ -139,7 +145,12 @@ def main():
                               torch.zeros(world * mx * CALL_BYTES, dtype=torch.uint8, device=dev))
             eng.export_calls(2, gather_buf[0].data_ptr(), gather_buf[0].numel() // CALL_BYTES)
             per = gather_buf[0].numel()
-            dist.all_gather_into_tensor(gather_buf[1][: world * per], gather_buf[0])
+            if backend == "nccl":
+                dist.all_gather_into_tensor(gather_buf[1][: world * per], gather_buf[0])
+            else:
+                out_cpu = torch.empty(world * per, dtype=torch.uint8)
+                dist.all_gather_into_tensor(out_cpu, gather_buf[0].cpu())
+                gather_buf[1][: world * per].copy_(out_cpu)
         return rows, cols, n_sites, n_cand, n_pass
 
     for _ in range(args.warmup):
@@ -164,6 +175,8 @@ def main():
     vals = torch.tensor([dt, float(cols), float(n_sites), float(n_cand), float(n_reads), float(n_events), float(sum(rows))],
                         dtype=torch.float64, device=dev)
     if world > 1:
+        if backend != "nccl":
+            vals = vals.cpu()
         mx = vals.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = vals.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
         dt = float(mx[0].item()); tot = sm.tolist()
