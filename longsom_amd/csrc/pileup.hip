@@ -44,7 +44,7 @@ constexpr int FLUSH_EVERY = 63;      // packed LDS fields: fwd 6 | cnt 6 | dup 6
 // device scalars (uint64 each)
 enum { SC_QSMALL = 0, SC_QBIG = 1, SC_NNE = 2, SC_NSLOTS = 3, SC_ROWALLOC = 4, SC_COLS = 8, SC_OVERFLOW = 9,
        SC_READS = 10, SC_SEGS = 11, SC_EVENTS = 12, SC_EV_WAVE = 13, SC_EV_DEEP = 14, SC_ROWS_DEEP = 15,
-       SC_ROWS = 16, SC_NSMALL = 20, SC_NMULTI = 21, SC_NMULTI_SEL = 22, SC_QGROUP = 23, SC_NHUGE = 24, SC_QHUGE = 25,
+       SC_ROWS = 16, SC_NSMALL = 20, SC_NMULTI = 21, SC_NMULTI_SEL = 22, SC_QGROUP = 23, SC_NHUGE = 24, SC_QHUGE = 25, SC_QBIN0 = 26, SC_QBIN2 = 27,
        SC_ROWS_SRC = 28, SC_EV_SRC = 32, SC_COUNT = 36 };   // *_SRC[4]: 0 wave, 1 walk_block, 2 huge, 3 finalize
 
 struct CountArgs {
@@ -109,104 +109,158 @@ __device__ __forceinline__ uint32_t sub_of(uint32_t cb, uint32_t nsub, uint32_t 
 }
 
 // Counting sort of (segment, tile) pairs over the segments, with the atomics aggregated per
-// workgroup in an LDS hash: a batch of 256 consecutive segments of a coordinate-sorted BAM hits few
-// distinct units, so one global atomic per distinct target per round replaces one per entry.
-//   MODE 0: count entries per unit.  MODE 2: scatter the self-contained entries (key, first event
-//   index, lane range) into the units' regions of entry buffer A.
+// workgroup in an LDS hash.  The segments of a coordinate-sorted BAM arrive gene by gene, so consecutive
+// batches of 256 segments hit the same few units: a workgroup dequeues BIN_SUPER consecutive batches and
+// keeps accumulating (batch, 8-tile round) items in the hash until it is 3/4 full, then issues ONE global
+// atomic per distinct unit for the whole chunk.  (A deep gene funnels thousands of batches into a few
+// cache lines of unit_cnt / unit_cursor; same-line atomics serialise in L2, so their number is what counts.)
+//   MODE 0: count entries per unit.  MODE 2: claim a range per unit, then replay the chunk's items and
+//   scatter the self-contained entries (key, first event byte offset, lane range) into buffer A.
 constexpr int BIN_THREADS = 256;
-constexpr int BIN_TPR = 8;             // tiles per segment handled per round
-constexpr int BIN_H = 4096;            // LDS hash slots (>= 2 x BIN_THREADS x BIN_TPR)
+constexpr int BIN_TPR = 8;             // tiles per segment handled per item
+constexpr int BIN_H = 4096;            // LDS hash slots
+constexpr int BIN_SUPER = 16;          // batches per dequeue
+constexpr int BIN_MAXI = 32;           // items per chunk
+constexpr uint32_t BIN_FILL = BIN_H * 5 / 8;
+
+struct BinSeg { uint32_t key, tb, t0; int32_t st, ln, ntile; int64_t evoff; };
+
+template <int MODE>
+__device__ __forceinline__ BinSeg bin_load(const CountArgs& a, int64_t s) {
+    BinSeg g; g.key = KEY_INVALID; g.tb = 0; g.t0 = 0; g.st = 0; g.ln = 0; g.ntile = 0; g.evoff = 0;
+    int32_t tid = 0;
+    if (s < a.n_segs) {
+        uint32_t r = a.seg_read[s];
+        g.key = a.read_key[r];
+        tid = a.read_tid[r];
+        g.st = a.seg_start[s];
+        g.ln = a.seg_len[s];
+        if (g.key != KEY_INVALID) {
+            int64_t clen = a.contig_len[tid];
+            if (g.st < 0 || g.ln <= 0 || (int64_t)g.st + g.ln > clen) g.key = KEY_INVALID;   // malformed: never counted
+        }
+        if (MODE == 2 && g.key != KEY_INVALID) g.evoff = a.seg_ev_off[s];
+    }
+    bool ok = g.key != KEY_INVALID;
+    g.tb = ok ? a.tile_base[tid] : 0;
+    uint32_t t0 = g.tb + ((uint32_t)g.st >> 6);
+    uint32_t t1 = g.tb + ((uint32_t)(g.st + g.ln - 1) >> 6);
+    if (t0 < a.tile_lo) t0 = a.tile_lo;
+    if (a.tile_hi == 0) ok = false; else if (t1 + 1 > a.tile_hi) t1 = a.tile_hi - 1;
+    g.t0 = t0;
+    g.ntile = (ok && t1 >= t0) ? (int)(t1 - t0 + 1) : 0;
+    return g;
+}
+
 template <int MODE>
 __global__ __launch_bounds__(BIN_THREADS) void k_bin_segments(CountArgs a) {
-    __shared__ uint32_t hkey[BIN_H], hcnt[BIN_H], hbase[BIN_H];
-    __shared__ int s_max;
+    __shared__ uint32_t hkey[BIN_H], hcnt[BIN_H], hbase[MODE == 2 ? BIN_H : 1];
+    __shared__ uint32_t s_newb[BIN_MAXI], s_ib[BIN_MAXI], s_ir[BIN_MAXI];
+    __shared__ int s_maxb[BIN_MAXI];
+    __shared__ uint32_t s_super;
     const int t = threadIdx.x, lane = t & 63;
+    constexpr int HSHIFT = 32 - __builtin_ctz(BIN_H);
     for (int i = t; i < BIN_H; i += BIN_THREADS) { hkey[i] = KEY_INVALID; hcnt[i] = 0; }
     unsigned long long st_segs = 0, st_evs = 0;
     const int64_t n_batches = (a.n_segs + BIN_THREADS - 1) / BIN_THREADS;
-    for (int64_t batch = blockIdx.x; batch < n_batches; batch += gridDim.x) {
-        const int64_t s = batch * BIN_THREADS + t;
-        uint32_t key = KEY_INVALID;
-        int32_t tid = 0, st = 0, ln = 0;
-        int64_t evoff = 0;
-        if (s < a.n_segs) {
-            uint32_t r = a.seg_read[s];
-            key = a.read_key[r];
-            tid = a.read_tid[r];
-            st = a.seg_start[s];
-            ln = a.seg_len[s];
-            if (key != KEY_INVALID) {
-                int64_t clen = a.contig_len[tid];
-                if (st < 0 || ln <= 0 || (int64_t)st + ln > clen) key = KEY_INVALID;   // malformed: never counted
-            }
-            if (MODE == 2 && key != KEY_INVALID) evoff = a.seg_ev_off[s];
-        }
-        bool ok = key != KEY_INVALID;
-        if (MODE == 0 && ok) { ++st_segs; st_evs += (unsigned long long)ln; }
-        const uint32_t ct = key >> 28;
-        const uint32_t tb = ok ? a.tile_base[tid] : 0;
-        uint32_t t0 = tb + ((uint32_t)st >> 6);
-        uint32_t t1 = tb + ((uint32_t)(st + ln - 1) >> 6);
-        if (t0 < a.tile_lo) t0 = a.tile_lo;
-        if (a.tile_hi == 0) ok = false; else if (t1 + 1 > a.tile_hi) t1 = a.tile_hi - 1;
-        int ntile = (ok && t1 >= t0) ? (int)(t1 - t0 + 1) : 0;
+    const int64_t n_super = (n_batches + BIN_SUPER - 1) / BIN_SUPER;
+    unsigned long long* qhead = &a.scalars[MODE == 0 ? SC_QBIN0 : SC_QBIN2];
+    for (;;) {
         __syncthreads();
-        if (t == 0) s_max = 0;
+        if (t == 0) s_super = (uint32_t)atomicAdd(qhead, 1ull);
         __syncthreads();
-        int wmax = ntile;
-        for (int o = 32; o > 0; o >>= 1) { int v = __shfl_down(wmax, o); wmax = v > wmax ? v : wmax; }
-        if (lane == 0 && wmax) atomicMax(&s_max, wmax);
-        __syncthreads();
-        const int n_rounds = (s_max + BIN_TPR - 1) / BIN_TPR;
-        for (int rd = 0; rd < n_rounds; ++rd) {
-            uint32_t hr[BIN_TPR];
+        const int64_t sup = s_super;
+        if (sup >= n_super) break;
+        const int64_t b0 = sup * BIN_SUPER;
+        const int64_t b1 = b0 + BIN_SUPER < n_batches ? b0 + BIN_SUPER : n_batches;
+        int64_t cb = b0; int cr = 0;                 // next item: round cr of batch cb
+        while (cb < b1) {
+            // ---- pass A: accumulate items in the hash
+            if (t < BIN_MAXI) { s_newb[t] = 0; s_maxb[t] = 0; }
+            __syncthreads();
+            int ni = 0; uint32_t tot = 0;
+            int64_t b = cb; int r = cr;
+            bool stop = false;
+            while (!stop && b < b1) {
+                const BinSeg g = bin_load<MODE>(a, b * BIN_THREADS + t);
+                if (MODE == 0 && r == 0 && g.key != KEY_INVALID) { ++st_segs; st_evs += (unsigned long long)g.ln; }
+                const uint32_t ct = g.key >> 28;
+                const int ni_first = ni;
+                int wmax = g.ntile;
+                for (int o = 32; o > 0; o >>= 1) { int v = __shfl_down(wmax, o); wmax = v > wmax ? v : wmax; }
+                if (lane == 0 && wmax) atomicMax(&s_maxb[ni_first], wmax);
+                int R = -1;
+                for (;;) {
+                    uint32_t newc = 0;
 #pragma unroll
-            for (int j = 0; j < BIN_TPR; ++j) {
-                const int k = rd * BIN_TPR + j;
-                hr[j] = KEY_INVALID;
-                if (k < ntile) {
-                    const uint32_t u = (t0 + (uint32_t)k) * (uint32_t)a.n_ct + ct;
-                    const uint32_t x = u;
-                    {
-                        uint32_t h = (x * 2654435761u) >> (32 - __builtin_ctz(BIN_H));
-                        while (true) {
-                            uint32_t prev = atomicCAS(&hkey[h], KEY_INVALID, x);
-                            if (prev == KEY_INVALID || prev == x) break;
-                            h = (h + 1) & (BIN_H - 1);
+                    for (int j = 0; j < BIN_TPR; ++j) {
+                        const int k = r * BIN_TPR + j;
+                        if (k < g.ntile) {
+                            const uint32_t x = (g.t0 + (uint32_t)k) * (uint32_t)a.n_ct + ct;
+                            uint32_t h = (x * 2654435761u) >> HSHIFT;
+                            while (true) {
+                                uint32_t prev = atomicCAS(&hkey[h], KEY_INVALID, x);
+                                if (prev == KEY_INVALID) { ++newc; break; }
+                                if (prev == x) break;
+                                h = (h + 1) & (BIN_H - 1);
+                            }
+                            atomicAdd(&hcnt[h], 1u);
                         }
-                        hr[j] = h | (atomicAdd(&hcnt[h], 1u) << 16);
                     }
+                    for (int o = 32; o > 0; o >>= 1) newc += __shfl_down(newc, o);
+                    if (lane == 0 && newc) atomicAdd(&s_newb[ni], newc);
+                    if (t == 0) { s_ib[ni] = (uint32_t)(b - b0); s_ir[ni] = (uint32_t)r; }
+                    __syncthreads();
+                    if (R < 0) R = (s_maxb[ni_first] + BIN_TPR - 1) / BIN_TPR;
+                    tot += s_newb[ni];
+                    ++ni; ++r;
+                    if (r >= R) { ++b; r = 0; }
+                    if (ni >= BIN_MAXI || tot + BIN_THREADS * BIN_TPR > BIN_FILL) { stop = true; break; }
+                    if (r == 0) break;
                 }
             }
-            __syncthreads();
+            // ---- one global atomic per distinct unit of the chunk
             for (int i = t; i < BIN_H; i += BIN_THREADS) {
                 const uint32_t cnt = hcnt[i];
                 if (cnt) {
-                    const uint32_t x = hkey[i];
-                    if (MODE == 0) atomicAdd(&a.unit_cnt[x], cnt);
-                    else hbase[i] = atomicAdd(&a.unit_cursor[x], cnt);
-                    hkey[i] = KEY_INVALID; hcnt[i] = 0;
+                    if (MODE == 0) { atomicAdd(&a.unit_cnt[hkey[i]], cnt); hkey[i] = KEY_INVALID; }
+                    else hbase[i] = atomicAdd(&a.unit_cursor[hkey[i]], cnt);
+                    hcnt[i] = 0;
                 }
             }
             __syncthreads();
             if (MODE == 2) {
+                // ---- pass B: replay the items, write the entries
+                for (int it = 0; it < ni; ++it) {
+                    const int64_t bb = b0 + s_ib[it];
+                    const int rr = (int)s_ir[it];
+                    const BinSeg g = bin_load<MODE>(a, bb * BIN_THREADS + t);
+                    const uint32_t ct = g.key >> 28;
 #pragma unroll
-                for (int j = 0; j < BIN_TPR; ++j) {
-                    if (hr[j] != KEY_INVALID) {
-                        const uint32_t pos = hbase[hr[j] & 0xffffu] + (hr[j] >> 16);
-                        const uint32_t tt = t0 + (uint32_t)(rd * BIN_TPR + j);
-                        const int32_t tstart = (int32_t)((tt - tb) << 6);
-                        const int32_t lo = st > tstart ? st : tstart;
-                        const int32_t hi = st + ln < tstart + TILE_W ? st + ln : tstart + TILE_W;
-                        const int64_t ev_first = evoff + (lo - st);
-                        // entry = {key, byte offset of the first event (41 bits: y + 9 bits of z), lane range pre-doubled
-                        // (2*first lane at z[16..22], 2*(count-1) at z[24..30])}: the walk needs no per-entry arithmetic beyond adds
-                        const uint64_t boff = (uint64_t)ev_first * 2ull;
-                        a.ent[pos] = make_uint4(key, (uint32_t)boff,
-                                                (uint32_t)(boff >> 32) | ((uint32_t)(2 * (lo - tstart)) << 16) | ((uint32_t)(2 * (hi - lo - 1)) << 24), 0u);
+                    for (int j = 0; j < BIN_TPR; ++j) {
+                        const int k = rr * BIN_TPR + j;
+                        if (k < g.ntile) {
+                            const uint32_t tt = g.t0 + (uint32_t)k;
+                            const uint32_t x = tt * (uint32_t)a.n_ct + ct;
+                            uint32_t h = (x * 2654435761u) >> HSHIFT;
+                            while (hkey[h] != x) h = (h + 1) & (BIN_H - 1);
+                            const uint32_t pos = hbase[h] + atomicAdd(&hcnt[h], 1u);
+                            const int32_t tstart = (int32_t)((tt - g.tb) << 6);
+                            const int32_t lo = g.st > tstart ? g.st : tstart;
+                            const int32_t hi = g.st + g.ln < tstart + TILE_W ? g.st + g.ln : tstart + TILE_W;
+                            // entry = {key, byte offset of the first event (41 bits: y + 9 bits of z), lane range pre-doubled
+                            // (2*first lane at z[16..22], 2*(count-1) at z[24..30])}: the walk needs no per-entry arithmetic beyond adds
+                            const uint64_t boff = (uint64_t)(g.evoff + (lo - g.st)) * 2ull;
+                            a.ent[pos] = make_uint4(g.key, (uint32_t)boff,
+                                                    (uint32_t)(boff >> 32) | ((uint32_t)(2 * (lo - tstart)) << 16) | ((uint32_t)(2 * (hi - lo - 1)) << 24), 0u);
+                        }
                     }
                 }
+                __syncthreads();
+                for (int i = t; i < BIN_H; i += BIN_THREADS)
+                    if (hkey[i] != KEY_INVALID) { hkey[i] = KEY_INVALID; hcnt[i] = 0; }
             }
+            cb = b; cr = r;
         }
     }
     if (MODE == 0) {
@@ -1121,7 +1175,7 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
     c->n_ne = c->n_slots = c->n_multi = 0;
     CountArgs a{};
     fill_args(c, p, a);
-    unsigned seg_grid = (unsigned)((S + 255) / 256);
+    unsigned seg_grid = (unsigned)((S + 256 * BIN_SUPER - 1) / (256 * BIN_SUPER));
     if (seg_grid > (unsigned)(c->n_cus * 8)) seg_grid = (unsigned)(c->n_cus * 8);
     if (R > 0) { unsigned g = (unsigned)((R + 255) / 256); if (g > (unsigned)(c->n_cus * 8)) g = (unsigned)(c->n_cus * 8); hipLaunchKernelGGL(k_read_key, dim3(g), dim3(256), 0, st, a); }
     if (S > 0) hipLaunchKernelGGL(k_bin_segments<0>, dim3(seg_grid), dim3(256), 0, st, a);
