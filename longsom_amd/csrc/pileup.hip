@@ -100,8 +100,13 @@ __global__ void k_read_key(CountArgs a) {
         a.read_key[r] = key;
         n_ok += key != KEY_INVALID;
     }
+    __shared__ unsigned long long s_ok;
+    if (threadIdx.x == 0) s_ok = 0;
+    __syncthreads();
     for (int o = 32; o > 0; o >>= 1) n_ok += __shfl_down(n_ok, o);
-    if ((threadIdx.x & 63) == 0 && n_ok) atomicAdd(&a.scalars[SC_READS], n_ok);
+    if ((threadIdx.x & 63) == 0 && n_ok) atomicAdd(&s_ok, n_ok);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_ok) atomicAdd(&a.scalars[SC_READS], s_ok);       // one same-address global atomic per workgroup
 }
 
 __device__ __forceinline__ uint32_t sub_of(uint32_t cb, uint32_t nsub, uint32_t n_cb) {
@@ -264,8 +269,13 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_segments(CountArgs a) {
         }
     }
     if (MODE == 0) {
+        __shared__ unsigned long long s_st[2];
+        if (t == 0) { s_st[0] = 0; s_st[1] = 0; }
+        __syncthreads();
         for (int o = 32; o > 0; o >>= 1) { st_segs += __shfl_down(st_segs, o); st_evs += __shfl_down(st_evs, o); }
-        if (lane == 0 && st_segs) { atomicAdd(&a.scalars[SC_SEGS], st_segs); atomicAdd(&a.scalars[SC_EVENTS], st_evs); }
+        if (lane == 0 && st_segs) { atomicAdd(&s_st[0], st_segs); atomicAdd(&s_st[1], st_evs); }
+        __syncthreads();
+        if (t == 0 && s_st[0]) { atomicAdd(&a.scalars[SC_SEGS], s_st[0]); atomicAdd(&a.scalars[SC_EVENTS], s_st[1]); }
     }
 }
 
@@ -585,6 +595,7 @@ __device__ __forceinline__ int group_by_cb(const CountArgs& a, uint32_t src, int
 struct WaveBook {
     uint32_t arena_next[LSG_MAX_CELLTYPES], arena_end[LSG_MAX_CELLTYPES], rows_true[LSG_MAX_CELLTYPES];
     uint32_t cols, rows_deep, rows_src, src;
+    unsigned long long nev;
 };
 __device__ __forceinline__ void book_init(WaveBook& b, int lane) {
     if (lane < LSG_MAX_CELLTYPES) { b.arena_next[lane] = 0; b.arena_end[lane] = 0; b.rows_true[lane] = 0; }
@@ -709,9 +720,27 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void k_pileup_wave(CountArgs 
             emit_unit(a, acc, w, ct, tid, tstart, lane, &L.book, false);
         }
     }
-    book_flush(a, L.book, lane);
+    // exact counters: summed over the workgroup's waves first (all waves of the grid finish together, and
+    // same-line global atomics serialise: one set per workgroup instead of one per wave)
     for (int o = 32; o > 0; o >>= 1) nev_total += __shfl_down(nev_total, o);
-    if (lane == 0 && nev_total) { atomicAdd(&a.scalars[SC_EV_WAVE], nev_total); atomicAdd(&a.scalars[SC_EV_SRC + 0], nev_total); }
+    if (lane == 0) L.book.nev = nev_total;
+    lds_fence();
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        unsigned long long nev = 0; uint32_t rt = 0, cols = 0, rdeep = 0, rsrc = 0;
+        for (int w = 0; w < WAVES_PER_BLOCK; ++w) {
+            const WaveBook& b = lds_all[w].book;
+            if (lane < a.n_ct) rt += b.rows_true[lane];
+            cols += b.cols; rdeep += b.rows_deep; rsrc += b.rows_src; nev += b.nev;
+        }
+        if (lane < a.n_ct && rt) atomicAdd(&a.scalars[SC_ROWS + lane], (unsigned long long)rt);
+        if (lane == 0) {
+            if (cols) atomicAdd(&a.scalars[SC_COLS], (unsigned long long)cols);
+            if (rdeep) atomicAdd(&a.scalars[SC_ROWS_DEEP], (unsigned long long)rdeep);
+            if (rsrc) atomicAdd(&a.scalars[SC_ROWS_SRC + 0], (unsigned long long)rsrc);
+            if (nev) { atomicAdd(&a.scalars[SC_EV_WAVE], nev); atomicAdd(&a.scalars[SC_EV_SRC + 0], nev); }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -833,9 +862,17 @@ __global__ __launch_bounds__(WALK_THREADS) void k_walk_block(CountArgs a) {
             emit_unit(a, tot, w, (int)((uint32_t)geom.y >> 24), geom.y & 0xffffff, geom.x, lane, &L.book, true);
         }
     }
-    if (wv == 0) book_flush(a, L.book, lane);
     for (int o = 32; o > 0; o >>= 1) nev_total += __shfl_down(nev_total, o);
-    if (lane == 0 && nev_total) { atomicAdd(&a.scalars[SC_EV_DEEP], nev_total); atomicAdd(&a.scalars[SC_EV_SRC + 1], nev_total); }
+    __syncthreads();
+    if (t == 0) L.book.nev = 0;
+    __syncthreads();
+    if (lane == 0 && nev_total) atomicAdd(&L.book.nev, nev_total);
+    __syncthreads();
+    if (wv == 0) {
+        book_flush(a, L.book, lane);
+        const unsigned long long nev = L.book.nev;
+        if (lane == 0 && nev) { atomicAdd(&a.scalars[SC_EV_DEEP], nev); atomicAdd(&a.scalars[SC_EV_SRC + 1], nev); }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1060,25 +1097,47 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_pileup_huge(CountArgs a) {
     if (lane == 0 && nev_total) { atomicAdd(&a.scalars[SC_EV_DEEP], nev_total); atomicAdd(&a.scalars[SC_EV_SRC + 2], nev_total); }
 }
 
-// multi-slot units: gates + emission from the global accumulators, one wave per unit
-__global__ void k_finalize_multi(CountArgs a) {
-    const int lane = threadIdx.x & 63;
-    uint32_t k = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-    if (k >= a.n_multi) return;
-    uint32_t w = a.multi_list[k];
-    const uint32_t nslot = a.ne_nslot[w];
-    Acc tot; tot.init();
-    for (uint32_t j = 0; j < nslot; ++j) {                        // the unit's slabs are contiguous
-        const uint32_t* src = a.macc + (uint64_t)(a.ne_acc[w] + j) * (NCTR * 64);
-        tot.ncdup += src[lane];
+// multi-slot units: sum the unit's partial-sum slabs (8 waves, each a stride of the slots), gates + emission by wave 0
+constexpr int FIN_THREADS = 512;
+__global__ __launch_bounds__(FIN_THREADS) void k_finalize_multi(CountArgs a) {
+    __shared__ uint32_t sacc[NCTR][64];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    for (uint32_t k = blockIdx.x; k < a.n_multi; k += gridDim.x) {
+        const uint32_t w = a.multi_list[k];
+        const uint32_t nslot = a.ne_nslot[w];
+        __syncthreads();
+        for (int i = t; i < NCTR * 64; i += FIN_THREADS) (&sacc[0][0])[i] = 0;
+        __syncthreads();
+        Acc tot; tot.init();
+        for (uint32_t j = wv; j < nslot; j += FIN_THREADS / 64) {      // the unit's slabs are contiguous
+            const uint32_t* src = a.macc + (uint64_t)(a.ne_acc[w] + j) * (NCTR * 64);
+            tot.ncdup += src[lane];
 #pragma unroll
-        for (int sy = 0; sy < 8; ++sy) {
-            tot.dup[sy] += src[(1 + sy) * 64 + lane]; tot.bc[sy] += src[(9 + sy) * 64 + lane];
-            tot.bq[sy] += src[(17 + sy) * 64 + lane]; tot.bcf[sy] += src[(25 + sy) * 64 + lane];
+            for (int sy = 0; sy < 8; ++sy) {
+                tot.dup[sy] += src[(1 + sy) * 64 + lane]; tot.bc[sy] += src[(9 + sy) * 64 + lane];
+                tot.bq[sy] += src[(17 + sy) * 64 + lane]; tot.bcf[sy] += src[(25 + sy) * 64 + lane];
+            }
+        }
+        if ((uint32_t)wv < nslot) {
+            atomicAdd(&sacc[0][lane], tot.ncdup);
+#pragma unroll
+            for (int sy = 0; sy < 8; ++sy) {
+                atomicAdd(&sacc[1 + sy][lane], tot.dup[sy]); atomicAdd(&sacc[9 + sy][lane], tot.bc[sy]);
+                atomicAdd(&sacc[17 + sy][lane], tot.bq[sy]); atomicAdd(&sacc[25 + sy][lane], tot.bcf[sy]);
+            }
+        }
+        __syncthreads();
+        if (wv == 0) {
+            tot.ncdup = sacc[0][lane];
+#pragma unroll
+            for (int sy = 0; sy < 8; ++sy) {
+                tot.dup[sy] = sacc[1 + sy][lane]; tot.bc[sy] = sacc[9 + sy][lane];
+                tot.bq[sy] = sacc[17 + sy][lane]; tot.bcf[sy] = sacc[25 + sy][lane];
+            }
+            const int2 geom = a.ne_geom[w];
+            emit_unit(a, tot, w, (int)((uint32_t)geom.y >> 24), geom.y & 0xffffff, geom.x, lane, nullptr, true);
         }
     }
-    const int2 geom = a.ne_geom[w];
-    emit_unit(a, tot, w, (int)((uint32_t)geom.y >> 24), geom.y & 0xffffff, geom.x, lane, nullptr, true);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1171,7 +1230,11 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
 
     LSG_HIP(hipEventRecord(c->ev[0], st));
     LSG_HIP(hipMemsetAsync(c->d_scalars.p, 0, SC_COUNT * 8, st));
-    LSG_HIP(hipMemsetAsync(c->d_unit_cnt.p, 0, ((size_t)n_units + 1) * 4, st));
+    // only the units of the counted region (lsg_set_region) are ever touched
+    const uint32_t u_lo = c->tile_lo * (uint32_t)c->n_ct;
+    const uint32_t u_hi = (c->tile_hi < c->n_tiles ? c->tile_hi : c->n_tiles) * (uint32_t)c->n_ct;
+    const uint32_t n_range = u_hi > u_lo ? u_hi - u_lo : 0;
+    LSG_HIP(hipMemsetAsync(c->d_unit_cnt.as<uint32_t>() + u_lo, 0, ((size_t)n_range + 1) * 4, st));
     c->n_ne = c->n_slots = c->n_multi = 0;
     CountArgs a{};
     fill_args(c, p, a);
@@ -1179,18 +1242,18 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
     if (seg_grid > (unsigned)(c->n_cus * 8)) seg_grid = (unsigned)(c->n_cus * 8);
     if (R > 0) { unsigned g = (unsigned)((R + 255) / 256); if (g > (unsigned)(c->n_cus * 8)) g = (unsigned)(c->n_cus * 8); hipLaunchKernelGGL(k_read_key, dim3(g), dim3(256), 0, st, a); }
     if (S > 0) hipLaunchKernelGGL(k_bin_segments<0>, dim3(seg_grid), dim3(256), 0, st, a);
-    SCAN_U32(a.unit_cnt, a.unit_off, n_units + 1);          // entry regions of buffer A, unit by unit
+    SCAN_U32(a.unit_cnt + u_lo, a.unit_off + u_lo, n_range + 1);          // entry regions of buffer A, unit by unit
 
     // non-empty units, in genomic order
-    hipcub::CountingInputIterator<uint32_t> cnt_it(0);
+    hipcub::CountingInputIterator<uint32_t> cnt_it(0), unit_it(u_lo);
     uint32_t* d_nne = reinterpret_cast<uint32_t*>(a.scalars + SC_NNE);
     {
         NonEmpty pred{a.unit_cnt};
         size_t tb = 0;
-        LSG_HIP(hipcub::DeviceSelect::If(nullptr, tb, cnt_it, a.ne_units, d_nne, (int)n_units, pred, st));
+        LSG_HIP(hipcub::DeviceSelect::If(nullptr, tb, unit_it, a.ne_units, d_nne, (int)n_range, pred, st));
         if (cub_tmp(c, tb)) return -1;
         tb = c->d_cub_tmp.cap;
-        LSG_HIP(hipcub::DeviceSelect::If(c->d_cub_tmp.p, tb, cnt_it, a.ne_units, d_nne, (int)n_units, pred, st));
+        LSG_HIP(hipcub::DeviceSelect::If(c->d_cub_tmp.p, tb, unit_it, a.ne_units, d_nne, (int)n_range, pred, st));
     }
     unsigned long long sc[SC_COUNT];
     if (read_scalars(c, sc)) return -1;
@@ -1212,7 +1275,7 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
         if (c->ws[WS_MACC].reserve(((size_t)n_slabs + 1) * NCTR * 64 * 4)) return -1;
         fill_args(c, p, a);
         hipLaunchKernelGGL(k_slot_init, dim3((n_ne + 255) / 256), dim3(256), 0, st, a);
-        LSG_HIP(hipMemcpyAsync(a.unit_cursor, a.unit_off, ((size_t)n_units + 1) * 4, hipMemcpyDeviceToDevice, st));
+        LSG_HIP(hipMemcpyAsync(a.unit_cursor + u_lo, a.unit_off + u_lo, ((size_t)n_range + 1) * 4, hipMemcpyDeviceToDevice, st));
         if (S > 0) hipLaunchKernelGGL(k_bin_segments<2>, dim3(seg_grid), dim3(256), 0, st, a);
         if (c->n_multi > 0) {
             MultiUnit pred{a.ne_nslot};
@@ -1259,7 +1322,7 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
         LSG_HIP(hipEventRecord(c->ev[4], st));
         hipLaunchKernelGGL(k_pileup_huge, dim3(grid_block), dim3(BLOCK_THREADS), 0, st, a);
         if (c->n_multi > 0)
-            hipLaunchKernelGGL(k_finalize_multi, dim3((unsigned)(((uint64_t)c->n_multi * 64 + 255) / 256)), dim3(256), 0, st, a);
+            hipLaunchKernelGGL(k_finalize_multi, dim3(c->n_multi < (unsigned)(c->n_cus * 8) ? c->n_multi : (unsigned)(c->n_cus * 8)), dim3(FIN_THREADS), 0, st, a);
     }
     LSG_HIP(hipEventRecord(c->ev[2], st));
     if (n_ne > 0) hipLaunchKernelGGL(k_pileup_wave, dim3(grid_wave), dim3(WAVES_PER_BLOCK * 64), 0, st, a);
@@ -1278,7 +1341,7 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
     c->stats.n_entries = 0;
     if (n_ne > 0) {
         uint32_t total_entries = 0;
-        LSG_HIP(hipMemcpy(&total_entries, c->d_unit_off.as<uint32_t>() + n_units, 4, hipMemcpyDeviceToHost));
+        LSG_HIP(hipMemcpy(&total_entries, c->d_unit_off.as<uint32_t>() + u_hi, 4, hipMemcpyDeviceToHost));
         c->stats.n_entries = total_entries;
     }
     float ms = 0;
