@@ -38,14 +38,14 @@ constexpr int BLOCK_THREADS = 512;
 constexpr int BLOCK_WAVES = BLOCK_THREADS / 64;
 constexpr int WAVES_PER_BLOCK = 4;   // wave kernel
 constexpr int ARENA = 256;           // rows reserved per wave per allocation
-constexpr int QCHUNK = 16;           // slots dequeued at once by a wave
+constexpr int QCHUNK = 64;          // slots dequeued at once by a wave
 constexpr int FLUSH_EVERY = 63;      // packed LDS fields: fwd 6 | cnt 6 | dup 6 | bq 14 bits
 
 // device scalars (uint64 each)
 enum { SC_QSMALL = 0, SC_QBIG = 1, SC_NNE = 2, SC_NSLOTS = 3, SC_ROWALLOC = 4, SC_COLS = 8, SC_OVERFLOW = 9,
        SC_READS = 10, SC_SEGS = 11, SC_EVENTS = 12, SC_EV_WAVE = 13, SC_EV_DEEP = 14, SC_ROWS_DEEP = 15,
        SC_ROWS = 16, SC_NSMALL = 20, SC_NMULTI = 21, SC_NMULTI_SEL = 22, SC_QGROUP = 23, SC_NHUGE = 24, SC_QHUGE = 25, SC_QBIN0 = 26, SC_QBIN2 = 27,
-       SC_ROWS_SRC = 28, SC_EV_SRC = 32, SC_COUNT = 36 };   // *_SRC[4]: 0 wave, 1 walk_block, 2 huge, 3 finalize
+       SC_ROWS_SRC = 28, SC_EV_SRC = 32, SC_NCHUNK = 36, SC_COUNT = 40 };   // *_SRC[4]: 0 wave, 1 walk_block, 2 huge, 3 finalize
 
 struct CountArgs {
     // reads
@@ -70,6 +70,7 @@ struct CountArgs {
     uint64_t* ne_mask; uint32_t* ne_rowbase;
     uint32_t* slot_w; uint32_t* slot_cnt; uint32_t* slot_off; uint32_t* slot_cursor;
     uint4* ent;                           // entries {key, first event index lo, meta, 0}
+    uint32_t* slot_pex; uint32_t* chunk_start;   // wave kernel: work prefix over the small-slot list, first slot of every chunk
     uint32_t* slot_list; uint32_t* multi_list; uint32_t* macc; uint32_t* slices; uint32_t* huge_list;
     uint32_t n_ne, n_slots, n_multi;
     unsigned long long* scalars;
@@ -689,14 +690,16 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void k_pileup_wave(CountArgs 
     uint32_t* pk = L.tkey;
     static_assert(HW >= 8 * 64, "pk must fit in the hash key array");
     book_init(L.book, lane);
-    const uint32_t n_small = (uint32_t)a.scalars[SC_NSMALL];
+    const uint32_t n_chunks = (uint32_t)a.scalars[SC_NCHUNK];
     unsigned long long nev_total = 0;
     while (true) {
-        uint32_t q0 = 0;
-        if (lane == 0) q0 = (uint32_t)atomicAdd(&a.scalars[SC_QSMALL], (unsigned long long)QCHUNK);
-        q0 = rl(q0, 0);
-        if (q0 >= n_small) break;
-        const int nq = n_small - q0 < (uint32_t)QCHUNK ? (int)(n_small - q0) : QCHUNK;
+        // chunks hold about the same WORK (entries + a per-slot constant), not the same number of slots
+        uint32_t ck = 0;
+        if (lane == 0) ck = (uint32_t)atomicAdd(&a.scalars[SC_QSMALL], 1ull);
+        ck = rl(ck, 0);
+        if (ck >= n_chunks) break;
+        const uint32_t q0 = a.chunk_start[ck];
+        const int nq = (int)(a.chunk_start[ck + 1] - q0);
         // lanes 0..nq-1 fetch their slot's descriptor
         uint32_t s_w = 0, s_off = 0, s_cnt = 0; int2 s_geom = make_int2(0, 0);
         if (lane < nq) {
@@ -1140,6 +1143,28 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize_multi(CountArgs a) {
     }
 }
 
+// Work-balanced chunks of the wave kernel's slot list.  work(slot) = entries + WORK_W0; chunk k holds the
+// slots whose exclusive work prefix lies in [k*E, (k+1)*E), E chosen so that every wave gets several chunks.
+constexpr uint32_t WORK_W0 = 16;
+constexpr uint32_t CHUNK_EMIN = CAPW + WORK_W0, CHUNK_EMAX = (uint32_t)QCHUNK * (WORK_W0 + 1) - 1;
+struct SlotWork {
+    const uint32_t* slot_list; const uint32_t* slot_cnt; const unsigned long long* scalars;
+    __host__ __device__ uint32_t operator()(const uint32_t& i) const {
+        return i < (uint32_t)scalars[SC_NSMALL] ? slot_cnt[slot_list[i]] + WORK_W0 : 0u;
+    }
+};
+__global__ void k_chunk_starts(CountArgs a, uint32_t n_waves) {
+    const uint32_t n_small = (uint32_t)a.scalars[SC_NSMALL];
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_small) return;
+    uint32_t E = a.slot_pex[a.n_slots] / (n_waves * 4u);
+    E = E < CHUNK_EMIN ? CHUNK_EMIN : (E > CHUNK_EMAX ? CHUNK_EMAX : E);
+    const uint32_t c = a.slot_pex[i] / E;
+    const int64_t cp = i ? (int64_t)(a.slot_pex[i - 1] / E) : -1;
+    for (int64_t k = cp + 1; k <= (int64_t)c; ++k) a.chunk_start[k] = i;
+    if (i == n_small - 1) { a.chunk_start[c + 1] = n_small; a.scalars[SC_NCHUNK] = (unsigned long long)c + 1; }
+}
+
 // ------------------------------------------------------------------------------------------------
 struct NonEmpty {
     const uint32_t* cnt;
@@ -1185,6 +1210,7 @@ static void fill_args(lsg_ctx* c, const lsg_count_params* p, CountArgs& a) {
     a.ent = c->ws[WS_ENT].as<uint4>();
     a.slot_list = c->ws[WS_SLOT_LIST].as<uint32_t>(); a.multi_list = c->ws[WS_MULTI_LIST].as<uint32_t>();
     a.macc = c->ws[WS_MACC].as<uint32_t>();
+    a.slot_pex = c->ws[WS_SLOT_PEX].as<uint32_t>(); a.chunk_start = c->ws[WS_CHUNK_START].as<uint32_t>();
     a.slices = c->ws[WS_SLICES].as<uint32_t>(); a.huge_list = c->ws[WS_HUGE_LIST].as<uint32_t>();
     a.n_ne = c->n_ne; a.n_slots = c->n_slots; a.n_multi = c->n_multi;
     a.scalars = c->d_scalars.as<unsigned long long>();
@@ -1225,7 +1251,8 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
         c->ws[WS_SLOT_CNT].reserve((slot_cap + 2) * 4) || c->ws[WS_SLOT_OFF].reserve((slot_cap + 2) * 4) ||
         c->ws[WS_SLOT_CURSOR].reserve((slot_cap + 2) * 4) || c->ws[WS_SLOT_LIST].reserve((slot_cap + 2) * 4) ||
         c->ws[WS_MULTI_LIST].reserve((EU / CAPB + 16) * 4) || c->ws[WS_ENT].reserve((EU + 1) * 32 + 64) ||
-        c->ws[WS_SLICES].reserve((slot_cap + 2) * (NSLICE + 1) * 4) || c->ws[WS_HUGE_LIST].reserve((EU / CAPB + 16) * 4))
+        c->ws[WS_SLICES].reserve((slot_cap + 2) * (NSLICE + 1) * 4) || c->ws[WS_SLOT_PEX].reserve((slot_cap + 2) * 4) ||
+        c->ws[WS_CHUNK_START].reserve(((EU + WORK_W0 * slot_cap) / CHUNK_EMIN + 4) * 4) || c->ws[WS_HUGE_LIST].reserve((EU / CAPB + 16) * 4))
         return -1;
 
     LSG_HIP(hipEventRecord(c->ev[0], st));
@@ -1297,6 +1324,12 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
             if (cub_tmp(c, tb)) return -1;
             tb = c->d_cub_tmp.cap;
             LSG_HIP(hipcub::DevicePartition::If(c->d_cub_tmp.p, tb, cnt_it, a.slot_list, d_nsmall, (int)c->n_slots, pred, st));
+        }
+        {
+            SlotWork wf{a.slot_list, a.slot_cnt, a.scalars};
+            hipcub::TransformInputIterator<uint32_t, SlotWork, hipcub::CountingInputIterator<uint32_t>> work_it(cnt_it, wf);
+            SCAN_U32(work_it, a.slot_pex, c->n_slots + 1);
+            hipLaunchKernelGGL(k_chunk_starts, dim3((c->n_slots + 255) / 256), dim3(256), 0, st, a, (uint32_t)(c->n_cus * 4 * WAVES_PER_BLOCK));
         }
     }
     // row buffers: bound + arena slack
