@@ -40,13 +40,19 @@ enum { LSG_SYM_A = 0, LSG_SYM_C = 1, LSG_SYM_T = 2, LSG_SYM_G = 3, LSG_SYM_I = 4
  *   [0] DP   [1] NC   [2..9] CC   [10..17] BC   [18..25] BQ   [26..33] BCf   [34..41] BCr
  * each vector indexed by the symbol class above (the TSV prints classes 0..5 only,
  * BaseCellCounter.py:300-306). */
+#define LSG_EVENT_VALID 0x0800u
+#define LSG_EVENT(sym, qual) ((uint16_t)((sym) < 8 ? (LSG_EVENT_VALID | ((sym) << 8) | ((qual) & 0xffu)) : 0u))
+#define LSG_EVENT_SYM(ev) (((ev) & LSG_EVENT_VALID) ? (((ev) >> 8) & 7u) : (unsigned)LSG_SYM_NA)
+#define LSG_EVENT_QUAL(ev) ((ev) & 0xffu)
 #define LSG_ROW_WORDS 42
 #define LSG_MAX_CELLTYPES 4
 
 /* Pre-decoded read-record arrays ("SoA" form of a coordinate-sorted BAM).
  * A read is split into SEGMENTS = maximal runs of consecutive reference positions that carry a
  * pileup entry (M/=/X/D columns; N reference skips break segments).  One EVENT per covered
- * reference position: uint16 = (symbol_class << 8) | base_quality, where the symbol class and the
+ * reference position: uint16 = LSG_EVENT(symbol_class, base_quality) = 0x0800 | class << 8 | quality for the
+ * eight countable classes and 0 for LSG_SYM_NA (so that "no event" and "not countable" are both 0: the
+ * kernels read lanes outside an entry's range as 0), where the symbol class and the
  * quality follow htslib bam_plp + pysam PileupColumn semantics as used by BaseCellCounter.py:191-216
  * (anchor base of an indel -> I / D, interior deletion column -> O with the quality of the next
  * query base). */

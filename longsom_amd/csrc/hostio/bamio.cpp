@@ -120,7 +120,7 @@ void decode_record(const uint8_t* rec, uint32_t len, const std::unordered_map<st
             L.seg_read.push_back(r); L.seg_start.push_back((int32_t)refpos); L.seg_len.push_back(0); L.seg_ev_off.push_back((int64_t)L.events.size());
         }
         ++L.seg_len.back();
-        L.events.push_back((uint16_t)((sym << 8) | (q & 0xff)));
+        L.events.push_back(LSG_EVENT(sym, q));
         last_pos = refpos;
     };
     auto qual_at = [&](uint32_t q) -> uint32_t { return q < l_seq ? qual[q] : 0u; };

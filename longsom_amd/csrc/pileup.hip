@@ -26,7 +26,13 @@ namespace lsg {
 
 constexpr uint32_t KEY_INVALID = 0xFFFFFFFFu;
 constexpr uint32_t CB_MASK = 0x00FFFFFFu;
-constexpr uint32_t KEY_NEWRUN = 1u << 25;    // set by the grouping step: first entry of a barcode run
+// entry = {key, e, m, 0}: e = low 32 bits of the ADDRESS of the entry's first event, m = [0..15] address bits 32..47,
+// [16..22] 2 * first lane, [23] first entry of a barcode run (set by the grouping step), [24] forward strand,
+// [25..31] number of events.  m >> 24 = 2 * events + strand is the entry's buffer size for the bounds-checked loads
+// (the odd byte never admits another 2-byte event).
+constexpr uint32_t META_NEWRUN = 1u << 23, META_FWD = 1u << 24;
+#define LSG_AS3 __attribute__((address_space(3)))
+__device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(LSG_AS3 const void*)p; }
 constexpr int CAPW = 256;            // max entries of a wave-processed slot
 constexpr int HW = 512;              // hash slots of the wave kernel
 constexpr int CAPB = 2048;           // max entries staged at once by the block kernel
@@ -39,7 +45,7 @@ constexpr int BLOCK_WAVES = BLOCK_THREADS / 64;
 constexpr int WAVES_PER_BLOCK = 4;   // wave kernel
 constexpr int ARENA = 256;           // rows reserved per wave per allocation
 constexpr int QCHUNK = 64;          // slots dequeued at once by a wave
-constexpr int FLUSH_EVERY = 63;      // packed LDS fields: fwd 6 | cnt 6 | dup 6 | bq 14 bits
+constexpr int FLUSH_EVERY = 63;      // packed LDS fields: bq 14 | fwd 6 | cnt 6 | dup 6 bits
 
 // device scalars (uint64 each)
 enum { SC_QSMALL = 0, SC_QBIG = 1, SC_NNE = 2, SC_NSLOTS = 3, SC_ROWALLOC = 4, SC_COLS = 8, SC_OVERFLOW = 9,
@@ -70,6 +76,7 @@ struct CountArgs {
     uint64_t* ne_mask; uint32_t* ne_rowbase;
     uint32_t* slot_w; uint32_t* slot_cnt; uint32_t* slot_off; uint32_t* slot_cursor;
     uint4* ent;                           // entries {key, first event index lo, meta, 0}
+    uint2* rec;                           // grouped 8-byte records {event byte offset lo, meta} of the block path, same indexing as ent
     uint32_t* slot_pex; uint32_t* chunk_start;   // wave kernel: work prefix over the small-slot list, first slot of every chunk
     uint32_t* slot_list; uint32_t* multi_list; uint32_t* macc; uint32_t* slices; uint32_t* huge_list;
     uint32_t n_ne, n_slots, n_multi;
@@ -254,11 +261,10 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_segments(CountArgs a) {
                             const int32_t tstart = (int32_t)((tt - g.tb) << 6);
                             const int32_t lo = g.st > tstart ? g.st : tstart;
                             const int32_t hi = g.st + g.ln < tstart + TILE_W ? g.st + g.ln : tstart + TILE_W;
-                            // entry = {key, byte offset of the first event (41 bits: y + 9 bits of z), lane range pre-doubled
-                            // (2*first lane at z[16..22], 2*(count-1) at z[24..30])}: the walk needs no per-entry arithmetic beyond adds
-                            const uint64_t boff = (uint64_t)(g.evoff + (lo - g.st)) * 2ull;
-                            a.ent[pos] = make_uint4(g.key, (uint32_t)boff,
-                                                    (uint32_t)(boff >> 32) | ((uint32_t)(2 * (lo - tstart)) << 16) | ((uint32_t)(2 * (hi - lo - 1)) << 24), 0u);
+                            const uint64_t addr = (uint64_t)(uintptr_t)(a.events + (g.evoff + (lo - g.st)));
+                            a.ent[pos] = make_uint4(g.key, (uint32_t)addr,
+                                                    (uint32_t)((addr >> 32) & 0xffffu) | (((g.key >> 24) & 1u) ? 0u : META_FWD) |
+                                                        ((uint32_t)(2 * (lo - tstart)) << 16) | ((uint32_t)(hi - lo) << 25), 0u);
                         }
                     }
                 }
@@ -398,29 +404,28 @@ struct Acc {
         for (int s = 0; s < 8; ++s) {
             uint32_t v = pk[s * 64 + lane];
             pk[s * 64 + lane] = 0;
-            bcf[s] += v & 63u; bc[s] += (v >> 6) & 63u; dup[s] += (v >> 12) & 63u; bq[s] += v >> 18;
+            bq[s] += v & 0x3fffu; bcf[s] += (v >> 14) & 63u; bc[s] += (v >> 20) & 63u; dup[s] += v >> 26;
         }
         npk = 0;
     }
     __device__ __forceinline__ void new_run() { mask = 0; }
-    // One pileup entry at this lane's position (BaseCellCounter.py:258-279).  key is wave-uniform; its
-    // KEY_NEWRUN bit starts a new barcode run.  Branch-free and free of scalar mask arithmetic: the
-    // scalar unit (one per CU) is the scarce issue slot of this loop.
-    __device__ __forceinline__ void add(uint32_t key, uint32_t ev, uint32_t in_range, int min_bq, uint32_t* pk, int lane) {
-        mask &= (key & KEY_NEWRUN) ? 0u : 0xFFFFFFFFu;
-        const uint32_t evp = ev | (in_range - 1u);                     // out of range -> all ones ('NA', row 7, value 0)
-        const uint32_t sym = (evp >> 8) & 0xffu, q = evp & 0xffu;
-        // invalid: symbol class >= 8 ('NA') or quality below the gate
-        const uint32_t inval = ((evp >> 11) & 1u) | ((uint32_t)((int32_t)q - (int32_t)min_bq) >> 31);
-        const uint32_t vm = inval - 1u;                                 // all ones when counted
-        const uint32_t valid = vm & 1u;
-        const uint32_t seen = (mask >> (sym & 31u)) & 1u;
-        const uint32_t fwdc = 64u | (((key >> 24) & 1u) ^ 1u);
-        const uint32_t val = ((q << 18) | (seen << 12) | fwdc) & vm;
-        // ds_add_u32 on the lane-private word of the symbol's row (row 7 with value 0 when not counted)
-        atomicAdd(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(pk + lane) + (evp & 0x700u)), val);
-        ncdup += valid & (mask != 0 ? 1u : 0u);
-        mask |= valid << (sym & 31u);
+    // One pileup entry at this lane's position (BaseCellCounter.py:258-279).  m = the entry's meta word (wave-uniform:
+    // META_NEWRUN starts a new barcode run, META_FWD is the strand), ev = the event (0 when the lane is outside the
+    // entry: the bounds-checked buffer load returns 0 there), thr = 0x800 + min_bq: an event is counted iff its valid bit
+    // is set and its quality passes the gate, i.e. (ev & 0x8ff) >= thr.  pkl = LDS byte address of this lane's word in
+    // row 0 of the wave's packed counters (2048-byte aligned rows block, so the row offset is OR-ed in).
+    // mask: bit 0 = any symbol seen in this barcode run, bit 8 + class = that class seen.  Branch-free.
+    __device__ __forceinline__ void add(uint32_t m, uint32_t ev, uint32_t thr, uint32_t pkl) {
+        mask &= (m & META_NEWRUN) ? 0u : 0xFFFFFFFFu;
+        const uint32_t vm = (uint32_t)((int32_t)(thr - 1u - (ev & 0x8ffu)) >> 31);      // all ones when counted
+        const uint32_t sym8 = __builtin_amdgcn_ubfe(ev, 8, 4);                          // 8 + class for a valid event
+        const uint32_t seen = __builtin_amdgcn_ubfe(mask, sym8, 1);
+        const uint32_t cst = (1u << 20) | ((m & META_FWD) ? (1u << 14) : 0u);          // scalar: count + strand
+        const uint32_t val = ((seen << 26) | ((ev & 0xffu) | cst)) & vm;
+        // ds_add_u32 on the lane-private word of the symbol's row (value 0 when not counted)
+        __hip_atomic_fetch_add((LSG_AS3 uint32_t*)(uintptr_t)(pkl | (ev & 0x700u)), val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        ncdup += mask & vm & 1u;
+        mask |= vm & ((1u << sym8) | 1u);
         ++npk;
     }
     // call before adding up to `next` more entries: keeps the packed 6-bit fields from overflowing
@@ -430,84 +435,50 @@ struct Acc {
     __device__ __forceinline__ void finish(uint32_t* pk, int lane) { flush_pk(pk, lane); }
 };
 
-// event load of one entry (es, ms wave-uniform): returns the event at this lane's position; lanes outside
-// the entry's range re-read its last event (same cache line) and report in_range = false.
-__device__ __forceinline__ uint32_t load_event(const uint16_t* __restrict__ events, uint32_t es, uint32_t ms, int lane, uint32_t& in_range) {
-    const uint32_t lo2 = (ms >> 16) & 0x7fu, cm12 = ms >> 24;
-    const char* base = reinterpret_cast<const char*>(events) + ((((uint64_t)(ms & 0x1ffu)) << 32) | es);
-    const uint32_t rel2 = 2u * (uint32_t)lane - lo2;
-    in_range = rel2 <= cm12 ? 1u : 0u;
-    const uint32_t voff = rel2 < cm12 ? rel2 : cm12;
-    return (uint32_t)*reinterpret_cast<const uint16_t*>(base + voff);
+// Event load of one entry (es, ms wave-uniform; lane2 = 2 * lane): a bounds-checked raw buffer load over exactly the
+// entry's event bytes, so lanes before or after the entry's range read 0 (= not countable) with no per-lane arithmetic.
+__device__ __forceinline__ uint32_t load_event(uint32_t es, uint32_t ms, uint32_t lane2) {
+    char* base = reinterpret_cast<char*>((uintptr_t)((((uint64_t)(ms & 0xffffu)) << 32) | es));
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)(ms >> 24), 0x00020000);
+    return (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(rs, (int)(lane2 - ((ms >> 16) & 0x7fu)), 0, 0);
 }
 
-// One group of up to U entries of the register-held record batch (k,e,m): issue all event loads
-// first (branch-free: out-of-range lanes re-read the entry's last event, same cache line), then
+// One group of up to U entries of the register-held record batch (e,m): issue all event loads first, then
 // consume them.  FULL = exactly U entries (the hot case, no guards at all).
 template <int U, bool FULL>
-__device__ __forceinline__ void walk_group(const uint16_t* __restrict__ events, Acc& acc, uint32_t k, uint32_t e, uint32_t m, int l, int cnt,
-                                           int min_bq, uint32_t* pk, int lane) {
-    uint32_t ks[U], evv[U]; uint32_t inb = 0;                       // bit u of inb: lane in range of entry u
+__device__ __forceinline__ void walk_group(Acc& acc, uint32_t e, uint32_t m, int l, int cnt, uint32_t thr, uint32_t* pk, int lane) {
+    uint32_t ms[U], evv[U];
     acc.reserve(U, pk, lane);
+    const uint32_t lane2 = 2u * (uint32_t)lane, pkl = lds_addr(pk + lane);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         if (FULL || u < cnt) {
-            uint32_t in; ks[u] = rl(k, l + u);
-            evv[u] = load_event(events, rl(e, l + u), rl(m, l + u), lane, in);
-            inb |= in << u;
+            ms[u] = rl(m, l + u);
+            evv[u] = load_event(rl(e, l + u), ms[u], lane2);
         }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u)
-        if (FULL || u < cnt) acc.add(ks[u], evv[u], (inb >> u) & 1u, min_bq, pk, lane);
-}
-
-// A full batch of 64 register-held records, software pipelined: the event loads of group g+1 are
-// in flight while group g is consumed (two groups = 16 loads outstanding per wave).
-template <int U>
-__device__ __forceinline__ void issue_group(const uint16_t* __restrict__ events, uint32_t k, uint32_t e, uint32_t m, int l,
-                                            uint32_t (&ks)[U], uint32_t (&evv)[U], uint32_t& inb, int lane) {
-    inb = 0;
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        uint32_t in; ks[u] = rl(k, l + u);
-        evv[u] = load_event(events, rl(e, l + u), rl(m, l + u), lane, in);
-        inb |= in << u;
-    }
-}
-template <int U>
-__device__ __forceinline__ void consume_group(Acc& acc, const uint32_t (&ks)[U], const uint32_t (&evv)[U], uint32_t inb, int min_bq,
-                                              uint32_t* pk, int lane) {
-    acc.reserve(U, pk, lane);
-#pragma unroll
-    for (int u = 0; u < U; ++u) acc.add(ks[u], evv[u], (inb >> u) & 1u, min_bq, pk, lane);
-}
-template <int U>
-__device__ __forceinline__ void walk_batch64(const uint16_t* __restrict__ events, Acc& acc, uint32_t k, uint32_t e, uint32_t m, int min_bq,
-                                             uint32_t* pk, int lane) {
-    uint32_t ksA[U], evA[U], ksB[U], evB[U], inA, inB;
-    issue_group<U>(events, k, e, m, 0, ksA, evA, inA, lane);
-#pragma unroll
-    for (int g = 0; g < 64 / U; g += 2) {
-        issue_group<U>(events, k, e, m, (g + 1) * U, ksB, evB, inB, lane);
-        consume_group<U>(acc, ksA, evA, inA, min_bq, pk, lane);
-        if (g + 2 < 64 / U) issue_group<U>(events, k, e, m, (g + 2) * U, ksA, evA, inA, lane);
-        consume_group<U>(acc, ksB, evB, inB, min_bq, pk, lane);
-    }
+        if (FULL || u < cnt) acc.add(ms[u], evv[u], thr, pkl);
 }
 
 // Walk grouped entries [j0, j1) held in LDS with all 64 lanes = 64 positions.  Records are read 64
 // at a time into registers (lane l holds record jb+l).  j0/j1 must be wave-uniform.
-__device__ __forceinline__ void walk(const CountArgs& a, Acc& acc, const uint32_t* gkey, const uint32_t* gev, const uint32_t* gmeta,
+__device__ __forceinline__ uint32_t bq_threshold(const CountArgs& a) {
+    const int q = a.min_bq < 0 ? 0 : (a.min_bq > 256 ? 256 : a.min_bq);
+    return 0x800u + (uint32_t)q;
+}
+__device__ __forceinline__ void walk(const CountArgs& a, Acc& acc, const uint32_t* gev, const uint32_t* gmeta,
                                      int j0, int j1, uint32_t* pk, int lane) {
     constexpr int U = 8;
+    const uint32_t thr = bq_threshold(a);
     for (int jb = j0; jb < j1; jb += 64) {
         const int nb = j1 - jb < 64 ? j1 - jb : 64;
-        uint32_t k = 0, e = 0, m = 0;
-        if (lane < nb) { k = gkey[jb + lane]; e = gev[jb + lane]; m = gmeta[jb + lane]; acc.nev += (m >> 25) + 1u; }
+        uint32_t e = 0, m = 0;
+        if (lane < nb) { e = gev[jb + lane]; m = gmeta[jb + lane]; acc.nev += m >> 25; }
         int l = 0;
-        for (; l + U <= nb; l += U) walk_group<U, true>(a.events, acc, k, e, m, l, U, a.min_bq, pk, lane);
-        if (l < nb) walk_group<U, false>(a.events, acc, k, e, m, l, nb - l, a.min_bq, pk, lane);
+        for (; l + U <= nb; l += U) walk_group<U, true>(acc, e, m, l, U, thr, pk, lane);
+        if (l < nb) walk_group<U, false>(acc, e, m, l, nb - l, thr, pk, lane);
     }
 }
 
@@ -572,7 +543,7 @@ __device__ __forceinline__ int group_by_cb(const CountArgs& a, uint32_t src, int
             if (TO_GLOBAL) {
                 gkey[p] = ek[r] & CB_MASK;
             } else {
-                gkey[p] = ek[r] & ~KEY_NEWRUN; gev[p] = ee[r]; gmeta[p] = em[r];
+                gkey[p] = ek[r]; gev[p] = ee[r]; gmeta[p] = em[r];
             }
         }
     }
@@ -583,9 +554,8 @@ __device__ __forceinline__ int group_by_cb(const CountArgs& a, uint32_t src, int
         if (t + r * T < n) {
             const uint32_t p = hs[r];
             const bool first = p == 0 || (gkey[p - 1] & CB_MASK) != (ek[r] & CB_MASK);
-            const uint32_t key = (ek[r] & ~KEY_NEWRUN) | (first ? KEY_NEWRUN : 0u);
-            if (TO_GLOBAL) a.ent[src + p] = make_uint4(key, ee[r], em[r], 0u);   // in place: all entries are in registers since before the first barrier
-            else if (first) atomicOr(&gkey[p], KEY_NEWRUN);
+            if (TO_GLOBAL) a.rec[src + p] = make_uint2(ee[r], em[r] | (first ? META_NEWRUN : 0u));   // the walk's 8-byte records
+            else if (first) atomicOr(&gmeta[p], META_NEWRUN);
         }
     }
     group_sync<BLOCK>();
@@ -677,9 +647,9 @@ __device__ __forceinline__ void emit_unit(const CountArgs& a, const Acc& acc, ui
 
 // ------------------------------------------------------------------------------------------------
 // Wave kernel: each wavefront pulls QCHUNK single-slot units with <= CAPW entries at a time.
-struct WaveLds {
+struct alignas(2048) WaveLds {
+    uint32_t tkey[HW], tcnt[HW];          // pk (8*64 words, 2048-byte aligned) aliases tkey after grouping
     uint32_t gkey[CAPW], gev[CAPW], gmeta[CAPW];
-    uint32_t tkey[HW], tcnt[HW];          // pk (8*64 words) aliases tkey after grouping
     WaveBook book;
 };
 
@@ -717,7 +687,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void k_pileup_wave(CountArgs 
             group_by_cb<false, HW, CAPW>(a, src, n, L.gkey, L.gev, L.gmeta, L.tkey, L.tcnt, lane, nullptr);
             for (int i = lane; i < 8 * 64; i += 64) pk[i] = 0;
             Acc acc; acc.init();
-            walk(a, acc, L.gkey, L.gev, L.gmeta, 0, n, pk, lane);
+            walk(a, acc, L.gev, L.gmeta, 0, n, pk, lane);
             acc.finish(pk, lane);
             nev_total += acc.nev;
             emit_unit(a, acc, w, ct, tid, tstart, lane, &L.book, false);
@@ -785,30 +755,27 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_group_block(CountArgs a) {
     }
 }
 
-// Walk grouped entries [j0, j1) of the global arrays starting at src (all three wave-uniform).
+// Walk grouped records [j0, j1) of the slot whose records start at src (all three wave-uniform).
 __device__ __forceinline__ void walk_global(const CountArgs& a, Acc& acc, uint32_t src, int j0, int j1, uint32_t* pk, int lane) {
     constexpr int U = 8;
-    uint32_t k = 0, e = 0, m = 0;
-    if (j0 + lane < j1) { const uint4 v = a.ent[src + j0 + lane]; k = v.x; e = v.y; m = v.z; }
+    const uint32_t thr = bq_threshold(a);
+    uint32_t e = 0, m = 0;
+    if (j0 + lane < j1) { const uint2 v = a.rec[src + j0 + lane]; e = v.x; m = v.y; }
     for (int jb = j0; jb < j1; jb += 64) {
         const int nb = j1 - jb < 64 ? j1 - jb : 64;
-        if (lane < nb) acc.nev += (m >> 25) + 1u;                    // events of this batch's entries (statistics)
+        if (lane < nb) acc.nev += m >> 25;                             // events of this batch's entries (statistics)
         // prefetch the next batch of records while this one is consumed
-        uint32_t k2 = 0, e2 = 0, m2 = 0;
-        if (jb + 64 + lane < j1) { const uint4 v = a.ent[src + jb + 64 + lane]; k2 = v.x; e2 = v.y; m2 = v.z; }
-        if (false && nb == 64) {
-            walk_batch64<U>(a.events, acc, k, e, m, a.min_bq, pk, lane);
-        } else {
-            int l = 0;
-            for (; l + U <= nb; l += U) walk_group<U, true>(a.events, acc, k, e, m, l, U, a.min_bq, pk, lane);
-            if (l < nb) walk_group<U, false>(a.events, acc, k, e, m, l, nb - l, a.min_bq, pk, lane);
-        }
-        k = k2; e = e2; m = m2;
+        uint32_t e2 = 0, m2 = 0;
+        if (jb + 64 + lane < j1) { const uint2 v = a.rec[src + jb + 64 + lane]; e2 = v.x; m2 = v.y; }
+        int l = 0;
+        for (; l + U <= nb; l += U) walk_group<U, true>(acc, e, m, l, U, thr, pk, lane);
+        if (l < nb) walk_group<U, false>(acc, e, m, l, nb - l, thr, pk, lane);
+        e = e2; m = m2;
     }
 }
 
 constexpr int WALK_THREADS = NSLICE * 64;
-struct WalkLds {
+struct alignas(2048) WalkLds {
     uint32_t pk[NSLICE][8 * 64];
     uint32_t acc[NCTR][64];
     uint32_t slot;
@@ -883,7 +850,7 @@ __global__ __launch_bounds__(WALK_THREADS) void k_walk_block(CountArgs a) {
 // unit.  Normal case (<= CAPB entries): one staged pass.  Fallback (a skewed barcode range left
 // more than CAPB entries in a slot): passes over coarse barcode buckets; a bucket that alone
 // exceeds CAPB is streamed barcode by barcode by wave 0.
-struct BlockLds {
+struct alignas(2048) BlockLds {
     uint32_t gkey[CAPB], gev[CAPB], gmeta[CAPB];
     union {
         struct { uint32_t tkey[HB], tcnt[HB]; } h;
@@ -956,12 +923,12 @@ __device__ __forceinline__ int block_stage_filtered(const CountArgs& a, BlockLds
     for (int r = 0; r < RMAX; ++r) {
         if (t + r * BLOCK_THREADS < ns) {
             uint32_t p = L.u.h.tcnt[hs[r] & 0xffffu] + (hs[r] >> 16);
-            L.gkey[p] = ek[r] & ~KEY_NEWRUN; L.gev[p] = ee[r]; L.gmeta[p] = em[r];
+            L.gkey[p] = ek[r]; L.gev[p] = ee[r]; L.gmeta[p] = em[r];
         }
     }
     __syncthreads();
     for (int q = t; q < ns; q += BLOCK_THREADS)                       // first entry of every barcode run
-        if (q == 0 || (L.gkey[q - 1] & CB_MASK) != (L.gkey[q] & CB_MASK)) atomicOr(&L.gkey[q], KEY_NEWRUN);
+        if (q == 0 || (L.gkey[q - 1] & CB_MASK) != (L.gkey[q] & CB_MASK)) atomicOr(&L.gmeta[q], META_NEWRUN);
     __syncthreads();
     return ns;
 }
@@ -978,7 +945,7 @@ __device__ __forceinline__ void block_walk_slices(const CountArgs& a, BlockLds& 
     uint32_t* pk = L.u.w.pk[wv];
     for (int i = lane; i < 8 * 64; i += 64) pk[i] = 0;
     acc.new_run();
-    walk(a, acc, L.gkey, L.gev, L.gmeta, j0, j1, pk, lane);
+    walk(a, acc, L.gev, L.gmeta, j0, j1, pk, lane);
     acc.finish(pk, lane);
     acc.new_run();
 }
@@ -1048,15 +1015,14 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_pileup_huge(CountArgs a) {
                                 uint32_t k = KEY_INVALID, e = 0, m = 0;
                                 if (ib + lane < n) { const uint4 v = a.ent[src + ib + lane]; k = v.x; e = v.y; m = v.z; }
                                 bool match = k != KEY_INVALID && (k & CB_MASK) == c;
-                                if (match) acc.nev += (m >> 25) + 1u;
+                                if (match) acc.nev += m >> 25;
                                 unsigned long long mm = __ballot(match);
                                 while (mm) {
                                     int l = __ffsll((long long)mm) - 1; mm &= mm - 1;
-                                    uint32_t inr;
-                                    const uint32_t ks = rl(k, l) & ~KEY_NEWRUN;          // the run is the whole barcode: reset by new_run() above
-                                    const uint32_t evv = load_event(a.events, rl(e, l), rl(m, l), lane, inr);
+                                    const uint32_t ms = rl(m, l);                        // no META_NEWRUN here: the run is the whole barcode, reset by new_run() above
+                                    const uint32_t evv = load_event(rl(e, l), ms, 2u * (uint32_t)lane);
                                     acc.reserve(1, pk, lane);
-                                    acc.add(ks, evv, inr, a.min_bq, pk, lane);
+                                    acc.add(ms, evv, bq_threshold(a), lds_addr(pk + lane));
                                 }
                             }
                         }
@@ -1207,7 +1173,7 @@ static void fill_args(lsg_ctx* c, const lsg_count_params* p, CountArgs& a) {
     a.ne_mask = c->d_ne_mask.as<uint64_t>(); a.ne_rowbase = c->d_ne_rowbase.as<uint32_t>();
     a.slot_w = c->ws[WS_SLOT_W].as<uint32_t>(); a.slot_cnt = c->ws[WS_SLOT_CNT].as<uint32_t>();
     a.slot_off = c->ws[WS_SLOT_OFF].as<uint32_t>(); a.slot_cursor = c->ws[WS_SLOT_CURSOR].as<uint32_t>();
-    a.ent = c->ws[WS_ENT].as<uint4>();
+    a.ent = c->ws[WS_ENT].as<uint4>(); a.rec = c->ws[WS_REC].as<uint2>();
     a.slot_list = c->ws[WS_SLOT_LIST].as<uint32_t>(); a.multi_list = c->ws[WS_MULTI_LIST].as<uint32_t>();
     a.macc = c->ws[WS_MACC].as<uint32_t>();
     a.slot_pex = c->ws[WS_SLOT_PEX].as<uint32_t>(); a.chunk_start = c->ws[WS_CHUNK_START].as<uint32_t>();
@@ -1250,7 +1216,7 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
         c->ws[WS_NE_GEOM].reserve((ne_cap + 2) * 8) || c->ws[WS_SLOT_W].reserve((slot_cap + 2) * 4) ||
         c->ws[WS_SLOT_CNT].reserve((slot_cap + 2) * 4) || c->ws[WS_SLOT_OFF].reserve((slot_cap + 2) * 4) ||
         c->ws[WS_SLOT_CURSOR].reserve((slot_cap + 2) * 4) || c->ws[WS_SLOT_LIST].reserve((slot_cap + 2) * 4) ||
-        c->ws[WS_MULTI_LIST].reserve((EU / CAPB + 16) * 4) || c->ws[WS_ENT].reserve((EU + 1) * 32 + 64) ||
+        c->ws[WS_MULTI_LIST].reserve((EU / CAPB + 16) * 4) || c->ws[WS_ENT].reserve((EU + 1) * 32 + 64) || c->ws[WS_REC].reserve((EU + 1) * 16 + 256) ||
         c->ws[WS_SLICES].reserve((slot_cap + 2) * (NSLICE + 1) * 4) || c->ws[WS_SLOT_PEX].reserve((slot_cap + 2) * 4) ||
         c->ws[WS_CHUNK_START].reserve(((EU + WORK_W0 * slot_cap) / CHUNK_EMIN + 4) * 4) || c->ws[WS_HUGE_LIST].reserve((EU / CAPB + 16) * 4))
         return -1;

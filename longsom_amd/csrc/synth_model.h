@@ -134,7 +134,7 @@ LSG_HD uint32_t sm_base_call(const lsg_synth_model* m, int64_t i, const sm_read*
 }
 
 /* Pileup event of read i at transcript coordinate j inside exon x (transcript interval
- * [xt0, xt1), reference start xs).  Returns (sym << 8) | qual. */
+ * [xt0, xt1), reference start xs).  Returns LSG_EVENT(sym, qual). */
 LSG_HD uint16_t sm_event(const lsg_synth_model* m, int64_t i, const sm_read* r, int32_t j, int32_t xt0, int32_t xt1, int32_t xs) {
     int32_t lo = r->t_off > xt0 ? r->t_off : xt0;
     int32_t hi = r->t_off + r->t_len < xt1 ? r->t_off + r->t_len : xt1;
@@ -149,7 +149,7 @@ LSG_HD uint16_t sm_event(const lsg_synth_model* m, int64_t i, const sm_read* r, 
         else if (ind < 0 && k == 3) sym = 4u;             /* anchor before an insertion */
         else sym = sm_base_call(m, i, r, j, (int64_t)xs + (j - xt0));
     }
-    return (uint16_t)((sym << 8) | q);
+    return LSG_EVENT(sym, q);
 }
 
 /* 16-mer barcode string of dense id cb (cb >= 0), or of an unlisted barcode (cb == -2, keyed by read) */

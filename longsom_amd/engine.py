@@ -28,7 +28,7 @@ class ReadRecords:
     seg_start: np.ndarray     # int32 [S]
     seg_len: np.ndarray       # int32 [S]
     seg_ev_off: np.ndarray    # int64 [S]
-    events: np.ndarray        # uint16 [E]  (sym << 8) | qual
+    events: np.ndarray        # uint16 [E]  LSG_EVENT: 0x0800 | sym << 8 | qual, 0 for 'NA'
     read_names: Optional[List[str]] = field(default=None, repr=False)
 
     _SPEC = (("read_tid", np.int32), ("read_pos", np.int32), ("read_flag", np.uint16), ("read_mapq", np.uint8),

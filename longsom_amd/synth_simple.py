@@ -75,5 +75,5 @@ def random_records(seed, n_reads, contig_lens, n_cb, hot_regions=(), hot_frac=0.
     sym = rng.choice(np.array([0, 1, 2, 3, 4, 5, 6, 7, 15], dtype=np.uint16), size=n_ev,
                      p=[0.235, 0.235, 0.235, 0.235, 0.01, 0.01, 0.005, 0.025, 0.01])
     qual = np.where(rng.random(n_ev) < 0.9, rng.integers(20, 61, n_ev), rng.integers(2, 20, n_ev)).astype(np.uint16)
-    events = ((sym << 8) | qual).astype(np.uint16)
+    events = np.where(sym < 8, 0x0800 | (sym << 8) | qual, 0).astype(np.uint16)      # LSG_EVENT(sym, qual)
     return ReadRecords(read_tid, read_pos, read_flag, read_mapq, read_cb, seg_read, seg_start, seg_len, seg_ev_off, events)

@@ -91,9 +91,9 @@ int64_t lso_count(int64_t n_reads, int64_t n_segs,
             if (st < 0 || ln <= 0 || (int64_t)st + ln > contig_len[tid]) continue;
             for (int32_t i = 0; i < ln; ++i) {
                 uint16_t ev = events[seg_ev_off[s] + i];
-                int q = ev & 0xff, sym = ev >> 8;
+                int q = ev & 0xff, sym = (ev >> 8) & 7;   /* LSG_EVENT: 0x0800 | class << 8 | qual, 0 = 'NA' */
+                if (!(ev & 0x0800)) continue;      /* 'NA' symbols: not in BASE_COUNTS.keys() (:258) */
                 if (q < min_bq) continue;          /* pileup_base_qual_skip: every accessor drops it */
-                if (sym >= 8) continue;            /* 'NA' symbols: not in BASE_COUNTS.keys() (:258) */
                 if (pass == 1) {
                     entry_t* e = &ents[w];
                     e->key = ((int64_t)tid << 32) | (int64_t)(st + i);
