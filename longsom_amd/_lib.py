@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "liblongsom_hip.so")
+LIB_PATH = os.environ.get("LSG_LIB_OVERRIDE") or os.path.join(_HERE, "lib", "liblongsom_hip.so")   # override: tuning builds only
 
 ROW_WORDS = 42
 MAX_CELLTYPES = 4

@@ -21,6 +21,7 @@
 //   ones by a 512-thread workgroup on run-aligned slices.
 #include "lsg_ctx.h"
 #include <hipcub/hipcub.hpp>
+#include <cstdlib>
 
 namespace lsg {
 
@@ -45,6 +46,10 @@ constexpr int BLOCK_WAVES = BLOCK_THREADS / 64;
 constexpr int WAVES_PER_BLOCK = 4;   // wave kernel
 constexpr int ARENA = 256;           // rows reserved per wave per allocation
 constexpr int QCHUNK = 64;          // slots dequeued at once by a wave
+#ifndef LSG_WALK_U
+#define LSG_WALK_U 8
+#endif
+constexpr int WALK_U = LSG_WALK_U;   // event loads in flight per wave
 constexpr int FLUSH_EVERY = 63;      // packed LDS fields: bq 14 | fwd 6 | cnt 6 | dup 6 bits
 
 // device scalars (uint64 each)
@@ -470,7 +475,7 @@ __device__ __forceinline__ uint32_t bq_threshold(const CountArgs& a) {
 }
 __device__ __forceinline__ void walk(const CountArgs& a, Acc& acc, const uint32_t* gev, const uint32_t* gmeta,
                                      int j0, int j1, uint32_t* pk, int lane) {
-    constexpr int U = 8;
+    constexpr int U = WALK_U;
     const uint32_t thr = bq_threshold(a);
     for (int jb = j0; jb < j1; jb += 64) {
         const int nb = j1 - jb < 64 ? j1 - jb : 64;
@@ -731,12 +736,14 @@ struct GroupLds {
     uint32_t gcb[CAPB];
     uint32_t wave_tot[BLOCK_WAVES];
     uint32_t slot;
+    unsigned long long nev;
 };
 
 __global__ __launch_bounds__(BLOCK_THREADS) void k_group_block(CountArgs a) {
     __shared__ GroupLds L;
     const int t = threadIdx.x;
     const uint32_t n_big = a.n_slots - (uint32_t)a.scalars[SC_NSMALL];
+    unsigned long long nev = 0;
     for (uint32_t qi = blockIdx.x; qi < n_big; qi += gridDim.x) {     // static striding: slots are bounded, a shared queue word would cap the rate
         __syncthreads();
         const uint32_t s = a.slot_list[a.n_slots - 1 - qi];      // rejected items sit reversed at the end
@@ -746,6 +753,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_group_block(CountArgs a) {
             continue;
         }
         const uint32_t src = a.slot_off[s];
+        for (int i = t; i < n; i += BLOCK_THREADS) nev += a.ent[src + i].z >> 25;      // events k_walk_block will read (statistics)
         group_by_cb<true, HB, CAPB, true>(a, src, n, L.gcb, nullptr, nullptr, L.tkey, L.tcnt, t, L.wave_tot);
         if (t <= NSLICE) {
             int j = (int)((int64_t)n * t / NSLICE);
@@ -753,24 +761,62 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_group_block(CountArgs a) {
             a.slices[(uint64_t)s * (NSLICE + 1) + t] = (uint32_t)j;
         }
     }
+    for (int o = 32; o > 0; o >>= 1) nev += __shfl_down(nev, o);
+    __syncthreads();
+    if (t == 0) L.nev = 0;
+    __syncthreads();
+    if ((t & 63) == 0 && nev) atomicAdd(&L.nev, nev);
+    __syncthreads();
+    if (t == 0 && L.nev) { atomicAdd(&a.scalars[SC_EV_DEEP], L.nev); atomicAdd(&a.scalars[SC_EV_SRC + 1], L.nev); }
 }
 
-// Walk grouped records [j0, j1) of the slot whose records start at src (all three wave-uniform).
+// Walk grouped records [j0, j1) of the slot whose records start at src (all three wave-uniform).  The records are
+// wave-uniform data: they are fetched eight at a time with SCALAR loads (constant address space: written by
+// k_group_block, read-only here), so no vector register or readlane is spent on them, and the event loads of group
+// g+1 are issued before group g is consumed (16 loads in flight per wave).
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+#define LSG_AS4 __attribute__((address_space(4)))
+template <bool FULL>
+__device__ __forceinline__ void issue8(const u32x16& R, int cnt, uint32_t lane2, uint32_t (&ev)[8]) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const uint32_t m = (FULL || u < cnt) ? R[2 * u + 1] : 0u;      // size 0: every lane reads 0
+        ev[u] = load_event(R[2 * u], m, lane2);
+    }
+}
+template <bool FULL>
+__device__ __forceinline__ void consume8(Acc& acc, const u32x16& R, int cnt, const uint32_t (&ev)[8], uint32_t thr, uint32_t* pk, int lane) {
+    acc.reserve(8, pk, lane);
+    const uint32_t pkl = lds_addr(pk + lane);
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+        if (FULL || u < cnt) acc.add(R[2 * u + 1], ev[u], thr, pkl);
+}
 __device__ __forceinline__ void walk_global(const CountArgs& a, Acc& acc, uint32_t src, int j0, int j1, uint32_t* pk, int lane) {
-    constexpr int U = 8;
-    const uint32_t thr = bq_threshold(a);
-    uint32_t e = 0, m = 0;
-    if (j0 + lane < j1) { const uint2 v = a.rec[src + j0 + lane]; e = v.x; m = v.y; }
-    for (int jb = j0; jb < j1; jb += 64) {
-        const int nb = j1 - jb < 64 ? j1 - jb : 64;
-        if (lane < nb) acc.nev += m >> 25;                             // events of this batch's entries (statistics)
-        // prefetch the next batch of records while this one is consumed
-        uint32_t e2 = 0, m2 = 0;
-        if (jb + 64 + lane < j1) { const uint2 v = a.rec[src + jb + 64 + lane]; e2 = v.x; m2 = v.y; }
-        int l = 0;
-        for (; l + U <= nb; l += U) walk_group<U, true>(acc, e, m, l, U, thr, pk, lane);
-        if (l < nb) walk_group<U, false>(acc, e, m, l, nb - l, thr, pk, lane);
-        e = e2; m = m2;
+    const uint32_t thr = bq_threshold(a), lane2 = 2u * (uint32_t)lane;
+    const int n = j1 - j0;
+    if (n <= 0) return;
+    const LSG_AS4 u32x16* p = (const LSG_AS4 u32x16*)(uintptr_t)(a.rec + src + j0);
+    const int ngf = n >> 3, rem = n & 7;                              // full groups, entries of the partial last group
+    if (ngf > 0) {
+        u32x16 RA = p[0], RB;
+        uint32_t evA[8], evB[8];
+        issue8<true>(RA, 8, lane2, evA);
+        int g = 0;
+        while (true) {
+            if (g + 1 < ngf) { RB = p[g + 1]; issue8<true>(RB, 8, lane2, evB); }      // A = group g, its loads in flight
+            consume8<true>(acc, RA, 8, evA, thr, pk, lane);
+            if (++g >= ngf) break;
+            if (g + 1 < ngf) { RA = p[g + 1]; issue8<true>(RA, 8, lane2, evA); }      // B = group g
+            consume8<true>(acc, RB, 8, evB, thr, pk, lane);
+            if (++g >= ngf) break;
+        }
+    }
+    if (rem) {
+        const u32x16 R = p[ngf];
+        uint32_t ev[8];
+        issue8<false>(R, rem, lane2, ev);
+        consume8<false>(acc, R, rem, ev, thr, pk, lane);
     }
 }
 
@@ -789,7 +835,6 @@ __global__ __launch_bounds__(WALK_THREADS) void k_walk_block(CountArgs a) {
     uint32_t* pk = L.pk[wv];
     for (int i = lane; i < 8 * 64; i += 64) pk[i] = 0;
     const uint32_t n_big = a.n_slots - (uint32_t)a.scalars[SC_NSMALL];
-    unsigned long long nev_total = 0;
     while (true) {
         __syncthreads();
         if (t == 0) L.slot = (uint32_t)atomicAdd(&a.scalars[SC_QBIG], 1ull);
@@ -805,7 +850,6 @@ __global__ __launch_bounds__(WALK_THREADS) void k_walk_block(CountArgs a) {
         Acc acc; acc.init();
         walk_global(a, acc, src, j0, j1, pk, lane);
         acc.finish(pk, lane);
-        nev_total += acc.nev;
         atomicAdd(&L.acc[0][lane], acc.ncdup);
 #pragma unroll
         for (int sy = 0; sy < 8; ++sy) {
@@ -832,17 +876,7 @@ __global__ __launch_bounds__(WALK_THREADS) void k_walk_block(CountArgs a) {
             emit_unit(a, tot, w, (int)((uint32_t)geom.y >> 24), geom.y & 0xffffff, geom.x, lane, &L.book, true);
         }
     }
-    for (int o = 32; o > 0; o >>= 1) nev_total += __shfl_down(nev_total, o);
-    __syncthreads();
-    if (t == 0) L.book.nev = 0;
-    __syncthreads();
-    if (lane == 0 && nev_total) atomicAdd(&L.book.nev, nev_total);
-    __syncthreads();
-    if (wv == 0) {
-        book_flush(a, L.book, lane);
-        const unsigned long long nev = L.book.nev;
-        if (lane == 0 && nev) { atomicAdd(&a.scalars[SC_EV_DEEP], nev); atomicAdd(&a.scalars[SC_EV_SRC + 1], nev); }
-    }
+    if (wv == 0) book_flush(a, L.book, lane);                      // the events this kernel reads are counted by k_group_block
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1184,6 +1218,14 @@ static void fill_args(lsg_ctx* c, const lsg_count_params* p, CountArgs& a) {
     a.row_cap = c->row_cap;
 }
 
+// launch-shape knobs for tuning runs (environment overrides; the defaults are what ships)
+static int tune_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    if (!v || !*v) return dflt;
+    const int x = atoi(v);
+    return x > 0 && x <= 64 ? x : dflt;
+}
+
 static int cub_tmp(lsg_ctx* c, size_t bytes) { return c->d_cub_tmp.reserve(bytes + 256); }
 
 #define SCAN_U32(in, out, n)                                                                              \
@@ -1295,13 +1337,13 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
             SlotWork wf{a.slot_list, a.slot_cnt, a.scalars};
             hipcub::TransformInputIterator<uint32_t, SlotWork, hipcub::CountingInputIterator<uint32_t>> work_it(cnt_it, wf);
             SCAN_U32(work_it, a.slot_pex, c->n_slots + 1);
-            hipLaunchKernelGGL(k_chunk_starts, dim3((c->n_slots + 255) / 256), dim3(256), 0, st, a, (uint32_t)(c->n_cus * 4 * WAVES_PER_BLOCK));
+            hipLaunchKernelGGL(k_chunk_starts, dim3((c->n_slots + 255) / 256), dim3(256), 0, st, a, (uint32_t)(c->n_cus * tune_int("LSG_GRID_WAVE", 4) * WAVES_PER_BLOCK));
         }
     }
     // row buffers: bound + arena slack
     const unsigned grid_block = (unsigned)(c->n_cus * 2);      // k_pileup_huge
-    const unsigned grid_walk = (unsigned)(c->n_cus * 4);       // k_walk_block
-    const unsigned grid_wave = (unsigned)(c->n_cus * 4);
+    const unsigned grid_walk = (unsigned)(c->n_cus * tune_int("LSG_GRID_WALK", 6));       // k_walk_block
+    const unsigned grid_wave = (unsigned)(c->n_cus * tune_int("LSG_GRID_WAVE", 4));
     uint64_t want_rows = (uint64_t)n_ne * TILE_W;
     if (p->min_dp > 0) {
         uint64_t by_depth = (uint64_t)c->rd.n_events / (uint64_t)p->min_dp + 64;
