@@ -46,10 +46,6 @@ constexpr int BLOCK_WAVES = BLOCK_THREADS / 64;
 constexpr int WAVES_PER_BLOCK = 4;   // wave kernel
 constexpr int ARENA = 256;           // rows reserved per wave per allocation
 constexpr int QCHUNK = 64;          // slots dequeued at once by a wave
-#ifndef LSG_WALK_U
-#define LSG_WALK_U 8
-#endif
-constexpr int WALK_U = LSG_WALK_U;   // event loads in flight per wave
 constexpr int FLUSH_EVERY = 63;      // packed LDS fields: bq 14 | fwd 6 | cnt 6 | dup 6 bits
 
 // device scalars (uint64 each)
@@ -448,42 +444,46 @@ __device__ __forceinline__ uint32_t load_event(uint32_t es, uint32_t ms, uint32_
     return (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(rs, (int)(lane2 - ((ms >> 16) & 0x7fu)), 0, 0);
 }
 
-// One group of up to U entries of the register-held record batch (e,m): issue all event loads first, then
-// consume them.  FULL = exactly U entries (the hot case, no guards at all).
-template <int U, bool FULL>
-__device__ __forceinline__ void walk_group(Acc& acc, uint32_t e, uint32_t m, int l, int cnt, uint32_t thr, uint32_t* pk, int lane) {
-    uint32_t ms[U], evv[U];
-    acc.reserve(U, pk, lane);
-    const uint32_t lane2 = 2u * (uint32_t)lane, pkl = lds_addr(pk + lane);
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        if (FULL || u < cnt) {
-            ms[u] = rl(m, l + u);
-            evv[u] = load_event(rl(e, l + u), ms[u], lane2);
-        }
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-        if (FULL || u < cnt) acc.add(ms[u], evv[u], thr, pkl);
-}
-
-// Walk grouped entries [j0, j1) held in LDS with all 64 lanes = 64 positions.  Records are read 64
-// at a time into registers (lane l holds record jb+l).  j0/j1 must be wave-uniform.
 __device__ __forceinline__ uint32_t bq_threshold(const CountArgs& a) {
     const int q = a.min_bq < 0 ? 0 : (a.min_bq > 256 ? 256 : a.min_bq);
     return 0x800u + (uint32_t)q;
 }
+// Up to 64 records held one per lane (e, m; lanes past the last record hold 0 = an empty entry): groups of 8 with the
+// event loads of group g+1 issued before group g is consumed.
+__device__ __forceinline__ void issue8r(uint32_t e, uint32_t m, int l0, uint32_t lane2, uint32_t (&ms)[8], uint32_t (&ev)[8]) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { ms[u] = rl(m, l0 + u); ev[u] = load_event(rl(e, l0 + u), ms[u], lane2); }
+}
+__device__ __forceinline__ void consume8r(Acc& acc, const uint32_t (&ms)[8], const uint32_t (&ev)[8], uint32_t thr, uint32_t* pk, int lane) {
+    acc.reserve(8, pk, lane);
+    const uint32_t pkl = lds_addr(pk + lane);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc.add(ms[u], ev[u], thr, pkl);
+}
+__device__ __forceinline__ void walk_regs(Acc& acc, uint32_t e, uint32_t m, int nb, uint32_t thr, uint32_t* pk, int lane) {
+    const uint32_t lane2 = 2u * (uint32_t)lane;
+    const int ng = (nb + 7) >> 3;
+    if (ng <= 0) return;
+    uint32_t msA[8], evA[8], msB[8], evB[8];
+    issue8r(e, m, 0, lane2, msA, evA);
+    int g = 0;
+    while (true) {
+        if (g + 1 < ng) issue8r(e, m, (g + 1) * 8, lane2, msB, evB);
+        consume8r(acc, msA, evA, thr, pk, lane);
+        if (++g >= ng) break;
+        if (g + 1 < ng) issue8r(e, m, (g + 1) * 8, lane2, msA, evA);
+        consume8r(acc, msB, evB, thr, pk, lane);
+        if (++g >= ng) break;
+    }
+}
 __device__ __forceinline__ void walk(const CountArgs& a, Acc& acc, const uint32_t* gev, const uint32_t* gmeta,
                                      int j0, int j1, uint32_t* pk, int lane) {
-    constexpr int U = WALK_U;
     const uint32_t thr = bq_threshold(a);
     for (int jb = j0; jb < j1; jb += 64) {
         const int nb = j1 - jb < 64 ? j1 - jb : 64;
         uint32_t e = 0, m = 0;
         if (lane < nb) { e = gev[jb + lane]; m = gmeta[jb + lane]; acc.nev += m >> 25; }
-        int l = 0;
-        for (; l + U <= nb; l += U) walk_group<U, true>(acc, e, m, l, U, thr, pk, lane);
-        if (l < nb) walk_group<U, false>(acc, e, m, l, nb - l, thr, pk, lane);
+        walk_regs(acc, e, m, nb, thr, pk, lane);
     }
 }
 
@@ -589,7 +589,7 @@ __device__ __forceinline__ void book_flush(const CountArgs& a, WaveBook& b, int 
 // (count >= MIN_COV), :294 (NC >= MIN_CC); position 0 of a contig is never visited (:86).
 // bk != nullptr: rows come from the wave's arena; nullptr: one exact global atomic.
 __device__ __forceinline__ void emit_unit(const CountArgs& a, const Acc& acc, uint32_t w, int ct, int tid, int32_t tstart, int lane,
-                                          WaveBook* bk, bool deep) {
+                                          WaveBook* bk, bool deep, int ref_prefetched = -1) {
     uint32_t dp = 0;
 #pragma unroll
     for (int s = 0; s < 8; ++s) dp += acc.bc[s];
@@ -597,7 +597,8 @@ __device__ __forceinline__ void emit_unit(const CountArgs& a, const Acc& acc, ui
     int64_t pos = (int64_t)tstart + lane;
     bool valid = pos >= 1 && pos < a.contig_len[tid];
     uint8_t refb = 'N';
-    if (valid) refb = a.ref_ptr[tid][pos];
+    if (ref_prefetched >= 0) refb = (uint8_t)ref_prefetched;
+    else if (valid) refb = a.ref_ptr[tid][pos];
     unsigned long long colm = __ballot(valid && dp > 0);
     bool emit = valid && dp > 0 && (int)dp >= a.min_dp && (int)nc >= a.min_cc && refb != 'N';
     unsigned long long em = __ballot(emit);
@@ -665,6 +666,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void k_pileup_wave(CountArgs 
     uint32_t* pk = L.tkey;
     static_assert(HW >= 8 * 64, "pk must fit in the hash key array");
     book_init(L.book, lane);
+    for (int i = lane; i < 8 * 64; i += 64) pk[i] = 0;
     const uint32_t n_chunks = (uint32_t)a.scalars[SC_NCHUNK];
     unsigned long long nev_total = 0;
     while (true) {
@@ -682,20 +684,60 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void k_pileup_wave(CountArgs 
             s_w = a.slot_w[s]; s_off = a.slot_off[s]; s_cnt = a.slot_cnt[s];
             s_geom = a.ne_geom[s_w];
         }
+        // slot 0's entries (one per lane) when it is a one-batch slot; later slots are prefetched one slot ahead
+        uint4 cur = make_uint4(KEY_INVALID, 0u, 0u, 0u);
+        {
+            const int n0 = (int)rl(s_cnt, 0);
+            if (n0 <= 64 && lane < n0) cur = a.ent[rl(s_off, 0) + lane];
+        }
         for (int qi = 0; qi < nq; ++qi) {
             const uint32_t w = rl(s_w, qi), src = rl(s_off, qi);
             const int n = (int)rl(s_cnt, qi);
             const int32_t tstart = (int32_t)rl((uint32_t)s_geom.x, qi);
             const uint32_t g = rl((uint32_t)s_geom.y, qi);
             const int tid = (int)(g & 0xffffffu), ct = (int)(g >> 24);
-            lds_fence();
-            group_by_cb<false, HW, CAPW>(a, src, n, L.gkey, L.gev, L.gmeta, L.tkey, L.tcnt, lane, nullptr);
-            for (int i = lane; i < 8 * 64; i += 64) pk[i] = 0;
+            // memory the slot will want later: the next slot's entries, this slot's reference bases
+            uint4 nxt = make_uint4(KEY_INVALID, 0u, 0u, 0u);
+            if (qi + 1 < nq) {
+                const int nn = (int)rl(s_cnt, qi + 1);
+                if (nn <= 64 && lane < nn) nxt = a.ent[rl(s_off, qi + 1) + lane];
+            }
+            int refb = 'N';
+            { const int64_t pos = (int64_t)tstart + lane; if (pos >= 1 && pos < a.contig_len[tid]) refb = a.ref_ptr[tid][pos]; }
             Acc acc; acc.init();
-            walk(a, acc, L.gev, L.gmeta, 0, n, pk, lane);
-            acc.finish(pk, lane);
+            bool general = n > 64;
+            if (!general) {
+                // one batch: if no barcode occurs twice every entry is its own run and no grouping is needed
+                L.tcnt[lane] = KEY_INVALID; L.tcnt[lane + 64] = KEY_INVALID;
+                lds_fence();
+                bool dup = false;
+                if (lane < n) {
+                    const uint32_t cb = cur.x & CB_MASK;
+                    uint32_t h = hash_cb(cb) >> 25;
+                    while (true) {
+                        const uint32_t prev = atomicCAS(&L.tcnt[h], KEY_INVALID, cb);
+                        if (prev == KEY_INVALID) break;
+                        if (prev == cb) { dup = true; break; }
+                        h = (h + 1) & 127u;
+                    }
+                }
+                general = __ballot(dup) != 0ull;
+                if (!general) {
+                    const uint32_t m = lane < n ? (cur.z | META_NEWRUN) : 0u;
+                    acc.nev += m >> 25;
+                    walk_regs(acc, cur.y, m, n, bq_threshold(a), pk, lane);
+                }
+            }
+            if (general) {
+                lds_fence();
+                group_by_cb<false, HW, CAPW>(a, src, n, L.gkey, L.gev, L.gmeta, L.tkey, L.tcnt, lane, nullptr);
+                for (int i = lane; i < 8 * 64; i += 64) pk[i] = 0;
+                walk(a, acc, L.gev, L.gmeta, 0, n, pk, lane);
+            }
+            acc.finish(pk, lane);                                     // leaves the packed counters zeroed for the next slot
             nev_total += acc.nev;
-            emit_unit(a, acc, w, ct, tid, tstart, lane, &L.book, false);
+            emit_unit(a, acc, w, ct, tid, tstart, lane, &L.book, false, refb);
+            cur = nxt;
         }
     }
     // exact counters: summed over the workgroup's waves first (all waves of the grid finish together, and

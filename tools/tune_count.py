@@ -16,4 +16,4 @@ for i in range(4):
     s = eng.count_stats()
     cur = (s.ms_total, s.ms_bin, s.ms_walk, s.ms_wave)
     best = cur if best is None or cur[0] < best[0] else best
-print("total %.2f bin %.2f walk %.2f wave %.2f" % best, flush=True)
+print("total %.2f bin %.2f walk %.2f wave %.2f" % best, "rows by kernel", list(s.rows_by_kernel), "events by kernel", list(s.events_by_kernel), flush=True)
