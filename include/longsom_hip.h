@@ -152,7 +152,11 @@ int lsg_load_reference(lsg_ctx* ctx, int32_t tid, const uint8_t* bases, int64_t 
  * table, the reads stay resident. */
 int lsg_set_barcodes(lsg_ctx* ctx, const uint8_t* celltype_of, int32_t n_cb, int32_t n_celltypes);
 /* Copies (or adopts, when on_device) the read-record arrays.  Replaces reading the per-cell-type
- * BAMs in run_interval (BaseCellCounter.py:190-191). */
+ * BAMs in run_interval (BaseCellCounter.py:190-191).  The events are always copied: whatever offsets
+ * seg_ev_off holds, the library keeps its own TILE-ALIGNED copy (the event of reference position q of a
+ * segment at slot * 64 + (q & 63), padding = 0), so that one pileup entry = one aligned 128-byte line;
+ * lsg_get_reads_shape / lsg_copy_reads_to_host report that resident layout.  A segment whose event
+ * range lies outside [0, n_events) is an error. */
 int lsg_load_reads(lsg_ctx* ctx, const lsg_reads* reads);
 /* Restrict counting to the genomic region [ (tid_lo,pos_lo), (tid_hi,pos_hi) ) in (tid,pos) order;
  * positions must be multiples of 64.  This is how windows are sharded over GPUs: every rank loads

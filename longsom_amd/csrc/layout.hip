@@ -1,0 +1,73 @@
+// Event layout in HBM.  The C-ABI takes the events of a segment at any offset (seg_ev_off); on load the library
+// re-lays them out TILE-ALIGNED in its own buffer: a segment starting at reference position p gets whole 64-position
+// tiles, and the event of position q sits at  tile_slot * 64 + (q & 63).  A pileup entry (= one segment x one 64-position
+// tile) then lies inside exactly one aligned 128-byte line, so the walk kernels fetch one line per entry instead of the
+// ~1.7 lines an arbitrary 2-byte alignment costs (measured: 31.5 GB -> see DESIGN.md), and neighbouring tiles of a
+// segment never share a line.  Padding events are 0 (= not countable) and are never read.
+#include "lsg_ctx.h"
+#include <hipcub/hipcub.hpp>
+
+namespace lsg {
+
+__global__ void k_seg_slots(const int32_t* seg_start, const int32_t* seg_len, int64_t n_segs, int64_t* slot_events) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s > n_segs) return;
+    int64_t v = 0;
+    if (s < n_segs) {
+        const int64_t st = seg_start[s], ln = seg_len[s];
+        if (ln > 0) v = (((st & 63) + ln + 63) >> 6) << 6;
+    }
+    slot_events[s] = v;
+}
+
+// one wavefront per segment: coalesced copy of its events to the aligned slot
+__global__ __launch_bounds__(256) void k_relayout(const uint16_t* src, int64_t n_src, const int32_t* seg_start, const int32_t* seg_len,
+                                                  const int64_t* old_off, const int64_t* slot_base, int64_t n_segs,
+                                                  uint16_t* dst, int64_t* new_off, uint32_t* bad) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t s = wave; s < n_segs; s += n_waves) {
+        const int64_t o = old_off[s], ln = seg_len[s], st = seg_start[s];
+        const int64_t d = slot_base[s] + (st & 63);
+        if (lane == 0) new_off[s] = d;
+        if (ln <= 0) continue;
+        if (o < 0 || o + ln > n_src) { if (lane == 0) atomicOr(bad, 1u); continue; }
+        for (int64_t i = lane; i < ln; i += 64) dst[d + i] = src[o + i];
+    }
+}
+
+int relayout_events(lsg_ctx* c) {
+    const int64_t S = c->rd.n_segs;
+    if (S <= 0) { c->rd.n_events = 0; return 0; }
+    hipStream_t st = c->stream;
+    DevBuf slots, base, noff, tmp, flag, aligned;
+    auto fail = [&](int rc) { slots.release(); base.release(); noff.release(); tmp.release(); flag.release(); aligned.release(); return rc; };
+    if (slots.reserve((size_t)(S + 1) * 8) || base.reserve((size_t)(S + 1) * 8) || noff.reserve((size_t)(S + 1) * 8) || flag.reserve(64)) return fail(-1);
+    hipLaunchKernelGGL(k_seg_slots, dim3((unsigned)((S + 1 + 255) / 256)), dim3(256), 0, st, c->rd.seg_start, c->rd.seg_len, S, slots.as<int64_t>());
+    size_t tb = 0;
+    if (hipcub::DeviceScan::ExclusiveSum(nullptr, tb, slots.as<int64_t>(), base.as<int64_t>(), (int)(S + 1), st) != hipSuccess || tmp.reserve(tb + 256)) return fail(-1);
+    tb = tmp.cap;
+    if (hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, slots.as<int64_t>(), base.as<int64_t>(), (int)(S + 1), st) != hipSuccess) { set_error("relayout: scan failed"); return fail(-1); }
+    int64_t E2 = 0;
+    if (hipMemcpyAsync(&E2, base.as<int64_t>() + S, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { set_error("relayout: copy failed"); return fail(-1); }
+    if (E2 >= (1ll << 40)) { set_error("lsg_load_reads: more than 2^40 events after tile alignment"); return fail(-2); }
+    if (aligned.reserve((size_t)E2 * 2 + 256)) return fail(-1);
+    if (hipMemsetAsync(aligned.p, 0, (size_t)E2 * 2 + 256, st) != hipSuccess || hipMemsetAsync(flag.p, 0, 64, st) != hipSuccess) { set_error("relayout: memset failed"); return fail(-1); }
+    unsigned grid = (unsigned)((S + 3) / 4 < (int64_t)c->n_cus * 32 ? (S + 3) / 4 : (int64_t)c->n_cus * 32);
+    hipLaunchKernelGGL(k_relayout, dim3(grid), dim3(256), 0, st, c->rd.events, c->rd.n_events, c->rd.seg_start, c->rd.seg_len, c->rd.seg_ev_off,
+                       base.as<int64_t>(), S, aligned.as<uint16_t>(), noff.as<int64_t>(), flag.as<uint32_t>());
+    uint32_t bad = 0;
+    if (hipMemcpyAsync(&bad, flag.p, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { set_error("relayout: kernel failed: %s", hipGetErrorString(hipGetLastError())); return fail(-1); }
+    if (bad) { set_error("lsg_load_reads: a segment's event range lies outside the events array"); return fail(-2); }
+    // the library's own copies replace whatever the caller handed over
+    if (c->b_seg_ev_off.reserve((size_t)(S + 1) * 8)) return fail(-1);
+    if (hipMemcpyAsync(c->b_seg_ev_off.p, noff.p, (size_t)S * 8, hipMemcpyDeviceToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { set_error("relayout: copy failed"); return fail(-1); }
+    c->b_events.release();
+    c->b_events = aligned; aligned.p = nullptr; aligned.cap = 0;
+    c->rd.events = c->b_events.as<uint16_t>();
+    c->rd.seg_ev_off = c->b_seg_ev_off.as<int64_t>();
+    c->rd.n_events = E2;
+    return fail(0);
+}
+
+} // namespace lsg

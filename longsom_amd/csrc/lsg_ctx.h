@@ -50,6 +50,9 @@ enum { WS_UNIT_PLAN = 0, WS_SLOT_PEX, WS_NE_NSLOT, WS_NE_SLOT_BASE, WS_NE_ACC, W
 
 } // namespace lsg
 
+struct lsg_ctx;
+namespace lsg { int relayout_events(lsg_ctx* c); }   // layout.hip: tile-aligned copy of the resident events
+
 struct lsg_ctx {
     int device = 0;
     hipStream_t stream = nullptr;

@@ -388,6 +388,25 @@ template <bool BLOCK> __device__ __forceinline__ void group_sync() {
 __device__ __forceinline__ uint32_t hash_cb(uint32_t cb) { return cb * 2654435761u; }
 __device__ __forceinline__ uint32_t rl(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
 
+// One pileup entry at a lane's position (BaseCellCounter.py:258-279).  m = the entry's meta word (wave-uniform:
+// META_NEWRUN starts a new barcode run, META_FWD is the strand), ev = the event (0 when the lane is outside the
+// entry: the bounds-checked buffer load returns 0 there), thr = 0x800 + min_bq: an event is counted iff its valid bit
+// is set and its quality passes the gate, i.e. (ev & 0x8ff) >= thr.  pkl = LDS byte address of this lane's word in
+// row 0 of the wave's packed counters (2048-byte aligned rows block, so the row offset is OR-ed in).
+// mask: bit 0 = any symbol seen in this barcode run, bit 8 + class = that class seen.  Branch-free.
+__device__ __forceinline__ void pile_add(uint32_t& mask, uint32_t& ncdup, uint32_t m, uint32_t ev, uint32_t thr, uint32_t pkl) {
+    mask &= (m & META_NEWRUN) ? 0u : 0xFFFFFFFFu;
+    const uint32_t vm = (uint32_t)((int32_t)(thr - 1u - (ev & 0x8ffu)) >> 31);      // all ones when counted
+    const uint32_t sym8 = __builtin_amdgcn_ubfe(ev, 8, 4);                          // 8 + class for a valid event
+    const uint32_t seen = __builtin_amdgcn_ubfe(mask, sym8, 1);
+    const uint32_t cst = (1u << 20) | ((m & META_FWD) ? (1u << 14) : 0u);          // scalar: count + strand
+    const uint32_t val = ((seen << 26) | ((ev & 0xffu) | cst)) & vm;
+    // ds_add_u32 on the lane-private word of the symbol's row (value 0 when not counted)
+    __hip_atomic_fetch_add((LSG_AS3 uint32_t*)(uintptr_t)(pkl | (ev & 0x700u)), val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    ncdup += mask & vm & 1u;
+    mask |= vm & ((1u << sym8) | 1u);
+}
+
 // Per-lane (= per reference position) accumulators of one unit.  Distinct-cell numbers come from
 // duplicates: within a barcode run, an entry whose symbol was already seen at this position is a
 // duplicate; CC[sym] = BC[sym] - dup[sym], NC = sum(BC) - ncdup   (= len(set(...)),
@@ -410,30 +429,53 @@ struct Acc {
         npk = 0;
     }
     __device__ __forceinline__ void new_run() { mask = 0; }
-    // One pileup entry at this lane's position (BaseCellCounter.py:258-279).  m = the entry's meta word (wave-uniform:
-    // META_NEWRUN starts a new barcode run, META_FWD is the strand), ev = the event (0 when the lane is outside the
-    // entry: the bounds-checked buffer load returns 0 there), thr = 0x800 + min_bq: an event is counted iff its valid bit
-    // is set and its quality passes the gate, i.e. (ev & 0x8ff) >= thr.  pkl = LDS byte address of this lane's word in
-    // row 0 of the wave's packed counters (2048-byte aligned rows block, so the row offset is OR-ed in).
-    // mask: bit 0 = any symbol seen in this barcode run, bit 8 + class = that class seen.  Branch-free.
-    __device__ __forceinline__ void add(uint32_t m, uint32_t ev, uint32_t thr, uint32_t pkl) {
-        mask &= (m & META_NEWRUN) ? 0u : 0xFFFFFFFFu;
-        const uint32_t vm = (uint32_t)((int32_t)(thr - 1u - (ev & 0x8ffu)) >> 31);      // all ones when counted
-        const uint32_t sym8 = __builtin_amdgcn_ubfe(ev, 8, 4);                          // 8 + class for a valid event
-        const uint32_t seen = __builtin_amdgcn_ubfe(mask, sym8, 1);
-        const uint32_t cst = (1u << 20) | ((m & META_FWD) ? (1u << 14) : 0u);          // scalar: count + strand
-        const uint32_t val = ((seen << 26) | ((ev & 0xffu) | cst)) & vm;
-        // ds_add_u32 on the lane-private word of the symbol's row (value 0 when not counted)
-        __hip_atomic_fetch_add((LSG_AS3 uint32_t*)(uintptr_t)(pkl | (ev & 0x700u)), val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        ncdup += mask & vm & 1u;
-        mask |= vm & ((1u << sym8) | 1u);
-        ++npk;
-    }
+    __device__ __forceinline__ uint32_t BC(int s) const { return bc[s]; }
+    __device__ __forceinline__ uint32_t BQ(int s) const { return bq[s]; }
+    __device__ __forceinline__ uint32_t BCF(int s) const { return bcf[s]; }
+    __device__ __forceinline__ uint32_t DUP(int s) const { return dup[s]; }
+    __device__ __forceinline__ uint32_t NCDUP() const { return ncdup; }
+    __device__ __forceinline__ void add(uint32_t m, uint32_t ev, uint32_t thr, uint32_t pkl) { pile_add(mask, ncdup, m, ev, thr, pkl); ++npk; }
     // call before adding up to `next` more entries: keeps the packed 6-bit fields from overflowing
     __device__ __forceinline__ void reserve(uint32_t next, uint32_t* pk, int lane) {
         if (npk + next > (uint32_t)FLUSH_EVERY) flush_pk(pk, lane);
     }
     __device__ __forceinline__ void finish(uint32_t* pk, int lane) { flush_pk(pk, lane); }
+};
+
+// The block path's accumulator: only the run state lives in registers; the packed counters are flushed straight
+// into the workgroup's LDS accumulators [NCTR][64] (shared by its waves, hence ds_add), which keeps the walk loop
+// at ~55 VGPRs = 8 waves per SIMD, and the event loads in flight are what hides HBM latency there.
+struct WalkAcc {
+    uint32_t ncdup, mask, npk;
+    uint32_t* sink;                      // [NCTR][64] words in LDS
+    __device__ __forceinline__ void init(uint32_t* s) { ncdup = mask = npk = 0; sink = s; }
+    __device__ __forceinline__ void flush_pk(uint32_t* pk, int lane) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const uint32_t v = pk[s * 64 + lane];
+            pk[s * 64 + lane] = 0;
+            if (v) {
+                atomicAdd(&sink[(17 + s) * 64 + lane], v & 0x3fffu); atomicAdd(&sink[(25 + s) * 64 + lane], (v >> 14) & 63u);
+                atomicAdd(&sink[(9 + s) * 64 + lane], (v >> 20) & 63u); atomicAdd(&sink[(1 + s) * 64 + lane], v >> 26);
+            }
+        }
+        npk = 0;
+    }
+    __device__ __forceinline__ void add(uint32_t m, uint32_t ev, uint32_t thr, uint32_t pkl) { pile_add(mask, ncdup, m, ev, thr, pkl); ++npk; }
+    __device__ __forceinline__ void reserve(uint32_t next, uint32_t* pk, int lane) {
+        if (npk + next > (uint32_t)FLUSH_EVERY) flush_pk(pk, lane);
+    }
+    __device__ __forceinline__ void finish(uint32_t* pk, int lane) { flush_pk(pk, lane); atomicAdd(&sink[lane], ncdup); }
+};
+
+// a unit's finished counters read straight from an LDS accumulator block [NCTR][64] (no register copy)
+struct LdsCounters {
+    const uint32_t* s; int lane;
+    __device__ __forceinline__ uint32_t BC(int k) const { return s[(9 + k) * 64 + lane]; }
+    __device__ __forceinline__ uint32_t BQ(int k) const { return s[(17 + k) * 64 + lane]; }
+    __device__ __forceinline__ uint32_t BCF(int k) const { return s[(25 + k) * 64 + lane]; }
+    __device__ __forceinline__ uint32_t DUP(int k) const { return s[(1 + k) * 64 + lane]; }
+    __device__ __forceinline__ uint32_t NCDUP() const { return s[lane]; }
 };
 
 // Event load of one entry (es, ms wave-uniform; lane2 = 2 * lane): a bounds-checked raw buffer load over exactly the
@@ -588,12 +630,13 @@ __device__ __forceinline__ void book_flush(const CountArgs& a, WaveBook& b, int 
 // Gates + row emission for one unit by one wave.  Gates: BaseCellCounter.py:211 (ref != N), :282
 // (count >= MIN_COV), :294 (NC >= MIN_CC); position 0 of a contig is never visited (:86).
 // bk != nullptr: rows come from the wave's arena; nullptr: one exact global atomic.
-__device__ __forceinline__ void emit_unit(const CountArgs& a, const Acc& acc, uint32_t w, int ct, int tid, int32_t tstart, int lane,
+template <class CNT>
+__device__ __forceinline__ void emit_unit(const CountArgs& a, const CNT& acc, uint32_t w, int ct, int tid, int32_t tstart, int lane,
                                           WaveBook* bk, bool deep, int ref_prefetched = -1) {
     uint32_t dp = 0;
 #pragma unroll
-    for (int s = 0; s < 8; ++s) dp += acc.bc[s];
-    const uint32_t nc = dp - acc.ncdup;
+    for (int s = 0; s < 8; ++s) dp += acc.BC(s);
+    const uint32_t nc = dp - acc.NCDUP();
     int64_t pos = (int64_t)tstart + lane;
     bool valid = pos >= 1 && pos < a.contig_len[tid];
     uint8_t refb = 'N';
@@ -643,11 +686,12 @@ __device__ __forceinline__ void emit_unit(const CountArgs& a, const Acc& acc, ui
     out[1 * cap + row] = nc;
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-        out[(2 + s) * cap + row] = acc.bc[s] - acc.dup[s];
-        out[(10 + s) * cap + row] = acc.bc[s];
-        out[(18 + s) * cap + row] = acc.bq[s];
-        out[(26 + s) * cap + row] = acc.bcf[s];
-        out[(34 + s) * cap + row] = acc.bc[s] - acc.bcf[s];
+        const uint32_t b = acc.BC(s), f = acc.BCF(s);
+        out[(2 + s) * cap + row] = b - acc.DUP(s);
+        out[(10 + s) * cap + row] = b;
+        out[(18 + s) * cap + row] = acc.BQ(s);
+        out[(26 + s) * cap + row] = f;
+        out[(34 + s) * cap + row] = b - f;
     }
 }
 
@@ -827,14 +871,14 @@ __device__ __forceinline__ void issue8(const u32x16& R, int cnt, uint32_t lane2,
     }
 }
 template <bool FULL>
-__device__ __forceinline__ void consume8(Acc& acc, const u32x16& R, int cnt, const uint32_t (&ev)[8], uint32_t thr, uint32_t* pk, int lane) {
+__device__ __forceinline__ void consume8(WalkAcc& acc, const u32x16& R, int cnt, const uint32_t (&ev)[8], uint32_t thr, uint32_t* pk, int lane) {
     acc.reserve(8, pk, lane);
     const uint32_t pkl = lds_addr(pk + lane);
 #pragma unroll
     for (int u = 0; u < 8; ++u)
         if (FULL || u < cnt) acc.add(R[2 * u + 1], ev[u], thr, pkl);
 }
-__device__ __forceinline__ void walk_global(const CountArgs& a, Acc& acc, uint32_t src, int j0, int j1, uint32_t* pk, int lane) {
+__device__ __forceinline__ void walk_global(const CountArgs& a, WalkAcc& acc, uint32_t src, int j0, int j1, uint32_t* pk, int lane) {
     const uint32_t thr = bq_threshold(a), lane2 = 2u * (uint32_t)lane;
     const int n = j1 - j0;
     if (n <= 0) return;
@@ -889,17 +933,9 @@ __global__ __launch_bounds__(WALK_THREADS) void k_walk_block(CountArgs a) {
         if (n > CAPB) continue;                                   // k_pileup_huge's slot
         const uint32_t w = rl(a.slot_w[s], 0), src = rl(a.slot_off[s], 0);
         const int j0 = (int)rl(a.slices[(uint64_t)s * (NSLICE + 1) + wv], 0), j1 = (int)rl(a.slices[(uint64_t)s * (NSLICE + 1) + wv + 1], 0);
-        Acc acc; acc.init();
+        WalkAcc acc; acc.init(&L.acc[0][0]);
         walk_global(a, acc, src, j0, j1, pk, lane);
         acc.finish(pk, lane);
-        atomicAdd(&L.acc[0][lane], acc.ncdup);
-#pragma unroll
-        for (int sy = 0; sy < 8; ++sy) {
-            atomicAdd(&L.acc[1 + sy][lane], acc.dup[sy]);
-            atomicAdd(&L.acc[9 + sy][lane], acc.bc[sy]);
-            atomicAdd(&L.acc[17 + sy][lane], acc.bq[sy]);
-            atomicAdd(&L.acc[25 + sy][lane], acc.bcf[sy]);
-        }
         __syncthreads();
         if (a.ne_nslot[w] > 1) {
             // multi-slot unit: this slot's partial sums go to its own slab with plain coalesced stores;
@@ -907,13 +943,7 @@ __global__ __launch_bounds__(WALK_THREADS) void k_walk_block(CountArgs a) {
             uint32_t* dst = a.macc + (uint64_t)(a.ne_acc[w] + (s - a.ne_slot_base[w])) * (NCTR * 64);
             for (int i = t; i < NCTR * 64; i += WALK_THREADS) dst[i] = (&L.acc[0][0])[i];
         } else if (wv == 0) {
-            Acc tot; tot.init();
-            tot.ncdup = L.acc[0][lane];
-#pragma unroll
-            for (int sy = 0; sy < 8; ++sy) {
-                tot.dup[sy] = L.acc[1 + sy][lane]; tot.bc[sy] = L.acc[9 + sy][lane];
-                tot.bq[sy] = L.acc[17 + sy][lane]; tot.bcf[sy] = L.acc[25 + sy][lane];
-            }
+            const LdsCounters tot{&L.acc[0][0], lane};
             const int2 geom = a.ne_geom[w];
             emit_unit(a, tot, w, (int)((uint32_t)geom.y >> 24), geom.y & 0xffffff, geom.x, lane, &L.book, true);
         }
@@ -1384,7 +1414,7 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
     }
     // row buffers: bound + arena slack
     const unsigned grid_block = (unsigned)(c->n_cus * 2);      // k_pileup_huge
-    const unsigned grid_walk = (unsigned)(c->n_cus * tune_int("LSG_GRID_WALK", 6));       // k_walk_block
+    const unsigned grid_walk = (unsigned)(c->n_cus * tune_int("LSG_GRID_WALK", 8));       // k_walk_block
     const unsigned grid_wave = (unsigned)(c->n_cus * tune_int("LSG_GRID_WAVE", 4));
     uint64_t want_rows = (uint64_t)n_ne * TILE_W;
     if (p->min_dp > 0) {

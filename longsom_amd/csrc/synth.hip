@@ -139,6 +139,7 @@ int lsg_synth_reads(lsg_ctx* c, const lsg_synth_model* hm) {
     c->rd.seg_start = c->b_seg_start.as<int32_t>(); c->rd.seg_len = c->b_seg_len.as<int32_t>();
     c->rd.seg_ev_off = c->b_seg_ev_off.as<int64_t>(); c->rd.events = c->b_events.as<uint16_t>();
     c->counted = c->called = false;
+    if (int rc = lsg::relayout_events(c)) return rc;
     return compute_entries_upper(c);
 }
 

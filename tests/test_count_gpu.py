@@ -102,3 +102,18 @@ def test_read_order_invariance(engine):
     b = [engine.fetch_counts(ct) for ct in range(2)]
     for (k1, r1, c1), (k2, r2, c2) in zip(a, b):
         np.testing.assert_array_equal(k1, k2); np.testing.assert_array_equal(c1, c2)
+
+
+def test_bad_event_range_is_an_error(engine):
+    """a segment pointing outside the events array is refused at load time (no out-of-bounds read on the device)"""
+    import dataclasses
+    lens = np.array([3000], np.int64)
+    rec, refs, celltype_of = make_case(5, 60, lens, 8)
+    engine.set_contigs(lens)
+    engine.load_reference(0, refs[0])
+    engine.set_barcodes(celltype_of, 2)
+    off = rec.seg_ev_off.copy()
+    off[-1] = rec.n_events
+    with pytest.raises(RuntimeError, match="outside the events array"):
+        engine.load_reads(dataclasses.replace(rec, seg_ev_off=off))
+    run_both(engine, rec, lens, refs, celltype_of, 2)

@@ -73,11 +73,23 @@ def test_region_shards_partition_the_rows(engine):
 
 
 def test_device_generator_equals_host_model(engine):
-    """synth.hip and the host evaluation of synth_model.h produce the same arrays, bit for bit."""
+    """synth.hip and the host evaluation of synth_model.h produce the same records, bit for bit (events compared segment by
+    segment: the library keeps them tile-aligned)."""
     from longsom_amd import hostio
     model = synth.named("C1", n_reads=3000, n_genes=60, n_cb=50)
     setup_model(engine, model)
     dev = engine.reads_to_host()
     host = hostio.synth_records(model)
     for name, _ in dev._SPEC:
-        np.testing.assert_array_equal(getattr(dev, name), getattr(host, name), err_msg=name)
+        if name not in ("seg_ev_off", "events"):
+            np.testing.assert_array_equal(getattr(dev, name), getattr(host, name), err_msg=name)
+    # the resident events are tile-aligned (layout.hip): event of position q at slot*64 + (q & 63), padding = 0
+    assert np.all(dev.seg_ev_off % 64 == dev.seg_start % 64)
+    assert dev.n_events % 64 == 0 and dev.n_events >= host.n_events
+    used = np.zeros(dev.n_events, bool)
+    for s in range(dev.n_segs):
+        d0, h0, ln = int(dev.seg_ev_off[s]), int(host.seg_ev_off[s]), int(dev.seg_len[s])
+        np.testing.assert_array_equal(dev.events[d0:d0 + ln], host.events[h0:h0 + ln], err_msg="segment %d" % s)
+        assert not used[d0:d0 + ln].any()
+        used[d0:d0 + ln] = True
+    assert not dev.events[~used].any()
