@@ -183,6 +183,18 @@ def main():
     else:
         tot = vals.tolist()
     if rank == 0:
+        # HBM-side bytes of the dominant kernel per launch: PMC counters cannot be read from inside this process, so the
+        # number comes from the committed rocprofv3 --pmc passes of this same command (profiles/, tools/collect_profiles.sh)
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if world == 1 and args.reads is None and os.path.exists(pmc):
+            try:
+                k = json.load(open(pmc))["kernels"].get("lsg::k_walk_block")
+                if k and k.get("traffic_bytes"):
+                    traffic = k["traffic_bytes"]
+                    traffic_src = "profiles/r01_pmc_traffic.json: FETCH_SIZE (x calibrated gfx950 correction) + WRITE_SIZE, separate --pmc passes, bytes per launch"
+            except (OSError, ValueError, KeyError):
+                pass
         ms_step = dt / args.steps * 1e3
         sites = tot[1]
         achieved = walk_bytes / max(walk_ms, 1e-9) / 1e6         # GB/s
@@ -197,7 +209,7 @@ def main():
                        "sharding": "genomic regions balanced by read count" if world > 1 else "none",
                        "path_algorithmic_GBps_rank0": path_bytes / dt / 1e9},
             "roofline": {"bound": "hbm", "kernel": "k_walk_block", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_ms": walk_ms / args.steps, "algorithmic_bytes_per_launch": walk_bytes / args.steps},
         }
         if base is not None:

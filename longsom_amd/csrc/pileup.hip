@@ -81,6 +81,7 @@ struct CountArgs {
     uint32_t* slot_pex; uint32_t* chunk_start;   // wave kernel: work prefix over the small-slot list, first slot of every chunk
     uint32_t* slot_list; uint32_t* multi_list; uint32_t* macc; uint32_t* slices; uint32_t* huge_list;
     uint32_t n_ne, n_slots, n_multi;
+    uint32_t presorted;                   // multi-slot units' records were written grouped by k_sort_deep (no k_group_block pass, any slot size)
     unsigned long long* scalars;
     uint32_t* rows[LSG_MAX_CELLTYPES];
     uint64_t row_cap;
@@ -334,6 +335,7 @@ __global__ void k_multi_index(CountArgs a) {
 
 // Deep units (more than CAPB entries) are cut into slots by barcode rank: counting sort of the unit's
 // entries from buffer A into buffer B (same unit offset), one workgroup per unit, LDS histogram.
+constexpr int NSLICE = 4;             // run-aligned slices of a block-path slot = waves of k_walk_block
 constexpr int SPLIT_THREADS = 512;
 __global__ __launch_bounds__(SPLIT_THREADS) void k_split_deep(CountArgs a) {
     __shared__ uint32_t hist[MAXSUB];
@@ -375,6 +377,100 @@ __global__ __launch_bounds__(SPLIT_THREADS) void k_split_deep(CountArgs a) {
             a.ent[a.ent_half + src + pos] = e;
         }
     }
+}
+
+// Deep units when a cell type's barcodes fit an LDS table (SORT_RMAX): ONE counting sort by exact barcode rank
+// replaces the split-by-range + per-slot grouping pair.  The unit's entries leave this kernel as the walk's 8-byte
+// records, grouped by barcode with the run-start flags set (a record is the first of its run iff its position is
+// the start of its barcode's range), cut into slots of ~n/nsub entries and NSLICE run-aligned slices per slot
+// straight from the prefix sums.  Slots can be of any size here: the walk reads records, it stages nothing.
+constexpr int SORT_RMAX = 16384;
+#ifndef LSG_SORT_THREADS
+#define LSG_SORT_THREADS 1024
+#endif
+constexpr int SORT_THREADS = LSG_SORT_THREADS;
+__device__ __forceinline__ uint32_t lower_bound_lds(const uint32_t* start, uint32_t lo, uint32_t hi, uint32_t R, uint32_t n, uint32_t target) {
+    // smallest r in [lo, hi] with start(r) >= target, start(R) = n
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        const uint32_t v = mid < R ? start[mid] : n;
+        if (v >= target) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+__global__ __launch_bounds__(SORT_THREADS) void k_sort_deep(CountArgs a, uint32_t r_cap) {
+    extern __shared__ uint32_t sort_lds[];
+    uint32_t* start = sort_lds;                  // [r_cap] exclusive prefix of the per-barcode counts
+    uint32_t* cur = sort_lds + r_cap;            // [r_cap] histogram, then scatter cursor
+    uint32_t* sb = cur + r_cap;                  // [MAXSUB + 1] first rank of every slot
+    uint32_t* wave_tot = sb + MAXSUB + 1;        // [SORT_THREADS / 64]
+    unsigned long long* s_nev = reinterpret_cast<unsigned long long*>(wave_tot + SORT_THREADS / 64 + ((MAXSUB + 1 + SORT_THREADS / 64) & 1));
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    unsigned long long nev = 0;
+    for (uint32_t k = blockIdx.x; k < a.n_multi; k += gridDim.x) {
+        const uint32_t w = a.multi_list[k], u = a.ne_units[w];
+        const uint32_t n = a.unit_cnt[u], src = a.unit_off[u], nsub = a.ne_nslot[w], base = a.ne_slot_base[w];
+        const uint32_t ct = (uint32_t)a.ne_geom[w].y >> 24;
+        const uint32_t R = a.ct_size[ct];
+        __syncthreads();
+        for (uint32_t i = t; i < R; i += SORT_THREADS) cur[i] = 0;
+        __syncthreads();
+        for (uint32_t i = t; i < n; i += SORT_THREADS) {
+            const uint4 e = a.ent[src + i];
+            atomicAdd(&cur[a.ct_rank[e.x & CB_MASK]], 1u);
+            nev += e.z >> 25;
+        }
+        __syncthreads();
+        // exclusive scan of cur[0..R) -> start; every thread owns a contiguous chunk
+        const uint32_t chunk = (R + SORT_THREADS - 1) / SORT_THREADS;
+        const uint32_t c_lo = (uint32_t)t * chunk < R ? (uint32_t)t * chunk : R, c_hi = c_lo + chunk < R ? c_lo + chunk : R;
+        uint32_t sum = 0;
+        for (uint32_t i = c_lo; i < c_hi; ++i) sum += cur[i];
+        uint32_t incl = sum;
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+        if (lane == 63) wave_tot[wv] = incl;
+        __syncthreads();
+        uint32_t run = incl - sum;
+        for (int q = 0; q < wv; ++q) run += wave_tot[q];
+        for (uint32_t i = c_lo; i < c_hi; ++i) { const uint32_t c = cur[i]; start[i] = run; cur[i] = run; run += c; }
+        __syncthreads();
+        // slots: slot j starts at the first barcode whose range begins at or after j * n / nsub
+        for (uint32_t j = t; j <= nsub; j += SORT_THREADS)
+            sb[j] = j == nsub ? R : lower_bound_lds(start, 0, R, R, n, (uint32_t)(((uint64_t)n * j) / nsub));
+        __syncthreads();
+        for (uint32_t j = t; j < nsub; j += SORT_THREADS) {
+            const uint32_t r0 = sb[j], r1 = sb[j + 1];
+            const uint32_t s0 = r0 < R ? start[r0] : n, s1 = r1 < R ? start[r1] : n;
+            const uint32_t slot = base + j;
+            a.slot_cnt[slot] = s1 - s0;
+            a.slot_off[slot] = (uint32_t)(a.ent_half + src + s0);
+            for (int q = 0; q <= NSLICE; ++q) {
+                uint32_t b = 0;
+                if (q == NSLICE) b = s1 - s0;
+                else if (q > 0) {
+                    const uint32_t r = lower_bound_lds(start, r0, r1, R, n, s0 + (uint32_t)(((uint64_t)(s1 - s0) * q) / NSLICE));
+                    b = (r < R ? start[r] : n) - s0;
+                    if (b > s1 - s0) b = s1 - s0;
+                }
+                a.slices[(uint64_t)slot * (NSLICE + 1) + q] = b;
+            }
+        }
+        // scatter the records (cur = cursor; start stays put)
+        for (uint32_t i = t; i < n; i += SORT_THREADS) {
+            const uint4 e = a.ent[src + i];
+            const uint32_t r = a.ct_rank[e.x & CB_MASK];
+            const uint32_t pos = atomicAdd(&cur[r], 1u);
+            a.rec[a.ent_half + src + pos] = make_uint2(e.y, e.z | (pos == start[r] ? META_NEWRUN : 0u));
+        }
+    }
+    // events k_walk_block will read (statistics)
+    for (int o = 32; o > 0; o >>= 1) nev += __shfl_down(nev, o);
+    __syncthreads();
+    if (t == 0) *s_nev = 0;
+    __syncthreads();
+    if (lane == 0 && nev) atomicAdd(s_nev, nev);
+    __syncthreads();
+    if (t == 0 && *s_nev) { atomicAdd(&a.scalars[SC_EV_DEEP], *s_nev); atomicAdd(&a.scalars[SC_EV_SRC + 1], *s_nev); }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -816,7 +912,6 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void k_pileup_wave(CountArgs 
 //                  record batches, 8 event loads in flight per wave), reduce in LDS, then emit the
 //                  unit's rows or add into the multi-slot unit's global accumulators.
 // Slots left with more than CAPB entries by a skewed barcode range go to k_pileup_huge.
-constexpr int NSLICE = 4;
 struct GroupLds {
     uint32_t tkey[HB], tcnt[HB];
     uint32_t gcb[CAPB];
@@ -834,6 +929,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_group_block(CountArgs a) {
         __syncthreads();
         const uint32_t s = a.slot_list[a.n_slots - 1 - qi];      // rejected items sit reversed at the end
         const int n = (int)a.slot_cnt[s];
+        if (a.presorted && a.ne_nslot[a.slot_w[s]] > 1) continue;      // k_sort_deep wrote its records, slices and statistics
         if (n > CAPB) {
             if (t == 0) a.huge_list[atomicAdd(&a.scalars[SC_NHUGE], 1ull)] = s;
             continue;
@@ -930,8 +1026,8 @@ __global__ __launch_bounds__(WALK_THREADS) void k_walk_block(CountArgs a) {
         if (qi >= n_big) break;
         const uint32_t s = rl(a.slot_list[a.n_slots - 1 - qi], 0);
         const int n = (int)rl(a.slot_cnt[s], 0);
-        if (n > CAPB) continue;                                   // k_pileup_huge's slot
         const uint32_t w = rl(a.slot_w[s], 0), src = rl(a.slot_off[s], 0);
+        if (n > CAPB && !(a.presorted && a.ne_nslot[w] > 1)) continue;   // k_pileup_huge's slot
         const int j0 = (int)rl(a.slices[(uint64_t)s * (NSLICE + 1) + wv], 0), j1 = (int)rl(a.slices[(uint64_t)s * (NSLICE + 1) + wv + 1], 0);
         WalkAcc acc; acc.init(&L.acc[0][0]);
         walk_global(a, acc, src, j0, j1, pk, lane);
@@ -1285,6 +1381,7 @@ static void fill_args(lsg_ctx* c, const lsg_count_params* p, CountArgs& a) {
     a.slot_pex = c->ws[WS_SLOT_PEX].as<uint32_t>(); a.chunk_start = c->ws[WS_CHUNK_START].as<uint32_t>();
     a.slices = c->ws[WS_SLICES].as<uint32_t>(); a.huge_list = c->ws[WS_HUGE_LIST].as<uint32_t>();
     a.n_ne = c->n_ne; a.n_slots = c->n_slots; a.n_multi = c->n_multi;
+    { uint32_t mx = 0; for (int i = 0; i < c->n_ct; ++i) mx = c->ct_size[i] > mx ? c->ct_size[i] : mx; a.presorted = mx <= (uint32_t)SORT_RMAX && !getenv("LSG_NO_PRESORT") ? 1u : 0u; }
     a.scalars = c->d_scalars.as<unsigned long long>();
     for (int i = 0; i < LSG_MAX_CELLTYPES; ++i) a.rows[i] = c->d_rows[i].as<uint32_t>();
     a.row_cap = c->row_cap;
@@ -1318,6 +1415,7 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
     hipStream_t st = c->stream;
     const uint32_t n_units = c->n_tiles * (uint32_t)c->n_ct;
     const int64_t R = c->rd.n_reads, S = c->rd.n_segs;
+    uint32_t max_ct = 1; for (int i = 0; i < c->n_ct; ++i) max_ct = c->ct_size[i] > max_ct ? c->ct_size[i] : max_ct;
     const uint64_t EU = c->entries_upper;
     const uint64_t ne_cap = n_units < EU ? n_units : EU;
     const uint64_t slot_cap = ne_cap + EU / SUBT + 16;
@@ -1393,7 +1491,14 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
             tb = c->d_cub_tmp.cap;
             LSG_HIP(hipcub::DeviceSelect::If(c->d_cub_tmp.p, tb, cnt_it, a.multi_list, d_nm, (int)n_ne, pred, st));
             unsigned sg = c->n_multi < (unsigned)(c->n_cus * 4) ? c->n_multi : (unsigned)(c->n_cus * 4);
-            hipLaunchKernelGGL(k_split_deep, dim3(sg), dim3(SPLIT_THREADS), 0, st, a);
+            if (a.presorted) {
+                const uint32_t r_cap = (max_ct + 63u) & ~63u;
+                const size_t lds = ((size_t)2 * r_cap + MAXSUB + 1 + SORT_THREADS / 64 + 4) * 4 + 16;
+                LSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort_deep), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(k_sort_deep, dim3(sg), dim3(SORT_THREADS), lds, st, a, r_cap);
+            } else {
+                hipLaunchKernelGGL(k_split_deep, dim3(sg), dim3(SPLIT_THREADS), 0, st, a);
+            }
         }
         // work lists: small slots first, the rest reversed at the end
         {
