@@ -134,22 +134,34 @@ def main():
         n_sites, n_cand = eng.call_step1(kp)
         n_pass = 0
         if world > 1:
-            n_pass = eng.export_calls(2)
+            # PASS-candidate rows of this rank -> device buffer (grown on demand), then the two-step all-gather of SURVEY §8e:
+            # counts first, then the buffers cut to the largest count
+            if gather_buf is None:
+                gather_buf = [torch.zeros(4096 * CALL_BYTES, dtype=torch.uint8, device=dev), None]
+            while True:
+                try:
+                    n_pass = eng.export_calls(2, gather_buf[0].data_ptr(), gather_buf[0].numel() // CALL_BYTES)
+                    break
+                except RuntimeError as e:
+                    if "capacity" not in str(e):
+                        raise
+                    gather_buf[0] = torch.zeros(2 * gather_buf[0].numel(), dtype=torch.uint8, device=dev)
             cdev = dev if backend == "nccl" else torch.device("cpu")
             cnt = torch.tensor([n_pass], dtype=torch.int64, device=cdev)
             allc = torch.empty(world, dtype=torch.int64, device=cdev)
             dist.all_gather_into_tensor(allc, cnt)
-            mx = max(1, int(allc.max().item()))
-            if gather_buf is None or gather_buf[0].numel() < mx * CALL_BYTES:
-                gather_buf = (torch.zeros(mx * CALL_BYTES, dtype=torch.uint8, device=dev),
-                              torch.zeros(world * mx * CALL_BYTES, dtype=torch.uint8, device=dev))
-            eng.export_calls(2, gather_buf[0].data_ptr(), gather_buf[0].numel() // CALL_BYTES)
-            per = gather_buf[0].numel()
+            per = max(1, int(allc.max().item())) * CALL_BYTES
+            if per > gather_buf[0].numel():                     # another rank has more rows than this rank's buffer holds
+                grown = torch.zeros(per, dtype=torch.uint8, device=dev)
+                grown[: gather_buf[0].numel()] = gather_buf[0]
+                gather_buf[0] = grown
+            if gather_buf[1] is None or gather_buf[1].numel() < world * per:
+                gather_buf[1] = torch.zeros(world * per, dtype=torch.uint8, device=dev)
             if backend == "nccl":
-                dist.all_gather_into_tensor(gather_buf[1][: world * per], gather_buf[0])
+                dist.all_gather_into_tensor(gather_buf[1][: world * per], gather_buf[0][:per])
             else:
                 out_cpu = torch.empty(world * per, dtype=torch.uint8)
-                dist.all_gather_into_tensor(out_cpu, gather_buf[0].cpu())
+                dist.all_gather_into_tensor(out_cpu, gather_buf[0][:per].cpu())
                 gather_buf[1][: world * per].copy_(out_cpu)
         return rows, cols, n_sites, n_cand, n_pass
 
@@ -204,7 +216,7 @@ def main():
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": "C2: whole-genome synthetic long-read workload (hg38/10 + chrM), %d reads x %d barcodes, 2 cell types, "
                                    "pileup count + merge + step-1 call%s" % (model.n_reads, model.n_cb, ", RCCL all-gather of PASS-candidate call rows" if world > 1 else ""),
-                       "reads": model.n_reads, "barcodes": model.n_cb, "reads_loaded_all_ranks": int(tot[4]), "events_loaded_all_ranks": int(tot[5]),
+                       "reads": model.n_reads, "barcodes": model.n_cb, "reads_loaded_all_ranks": int(tot[4]), "event_slots_resident_all_ranks": int(tot[5]),
                        "sites_counted": int(sites), "rows_emitted": int(tot[6]), "merged_sites": int(tot[2]), "step1_candidates": int(tot[3]),
                        "sharding": "genomic regions balanced by read count" if world > 1 else "none",
                        "path_algorithmic_GBps_rank0": path_bytes / dt / 1e9},

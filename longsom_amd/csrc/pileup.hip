@@ -1461,6 +1461,8 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
         LSG_HIP(hipcub::DeviceSelect::If(c->d_cub_tmp.p, tb, unit_it, a.ne_units, d_nne, (int)n_range, pred, st));
     }
     unsigned long long sc[SC_COUNT];
+    uint32_t total_entries = 0;                               // statistics; rides on this synchronisation
+    LSG_HIP(hipMemcpyAsync(&total_entries, c->d_unit_off.as<uint32_t>() + u_hi, 4, hipMemcpyDeviceToHost, st));
     if (read_scalars(c, sc)) return -1;
     const uint32_t n_ne = (uint32_t)(sc[SC_NNE] & 0xffffffffull);
     c->n_ne = n_ne;
@@ -1556,12 +1558,7 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
     c->stats.n_events_admitted = (int64_t)sc[SC_EVENTS];
     c->stats.n_units = n_ne;
     c->stats.n_deep_units = (int64_t)c->n_slots - (int64_t)(sc[SC_NSMALL] & 0xffffffffull);
-    c->stats.n_entries = 0;
-    if (n_ne > 0) {
-        uint32_t total_entries = 0;
-        LSG_HIP(hipMemcpy(&total_entries, c->d_unit_off.as<uint32_t>() + u_hi, 4, hipMemcpyDeviceToHost));
-        c->stats.n_entries = total_entries;
-    }
+    c->stats.n_entries = n_ne > 0 ? total_entries : 0;
     float ms = 0;
     LSG_HIP(hipEventElapsedTime(&ms, c->ev[0], c->ev[1])); c->stats.ms_bin = ms;
     LSG_HIP(hipEventElapsedTime(&ms, c->ev[1], c->ev[2])); c->stats.ms_deep = ms;

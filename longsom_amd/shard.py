@@ -14,6 +14,7 @@ import numpy as np
 from . import synth
 
 CALL_BYTES = 336          # sizeof(lsg_call)
+COLUMN_COST = 0.036       # one emitted (site, cell type) column costs about this many reads of kernel time (MI355X, C2)
 
 
 def region_shards(model, world: int) -> List[Tuple[Tuple[int, int], Tuple[int, int], int, int]]:
@@ -26,11 +27,15 @@ def region_shards(model, world: int) -> List[Tuple[Tuple[int, int], Tuple[int, i
     end = (model.exon_start[g1] + model.exon_len[g1]).astype(np.int64)
     off = np.concatenate([[0], np.cumsum(model.contig_len)])[:-1]
     lin_s, lin_e = off[tid] + start, off[tid] + end
-    cum = np.concatenate([[0], np.cumsum(np.diff(model.gene_read_off))])
-    total = int(cum[-1])
+    # cost of a gene = its reads (events: read lengths are iid) + its pileup columns (~2 cell types x exon bases), the
+    # latter weighted by the measured per-column / per-read kernel time ratio (row emission + call stage vs walk)
+    exon_bases = np.add.reduceat(model.exon_len.astype(np.int64), model.gene_exon_off[:-1]) if model.n_genes else np.zeros(0, np.int64)
+    cost = np.diff(model.gene_read_off).astype(np.float64) + COLUMN_COST * 2.0 * exon_bases
+    cum = np.concatenate([[0.0], np.cumsum(cost)])
+    total = float(cum[-1])
     bounds = [(0, 0)]
     for r in range(1, world):
-        g = int(np.searchsorted(cum, total * r // world, side="left"))
+        g = int(np.searchsorted(cum, total * r / world, side="left"))
         g = min(max(g, 0), model.n_genes - 1)
         bounds.append(max((int(tid[g]), int(start[g]) // 64 * 64), bounds[-1]))
     bounds.append((len(model.contig_len), 0))
