@@ -48,7 +48,9 @@ struct CallArgs {
     uint32_t* site_cnt; uint32_t* site_off;
     SiteRec* sites; CandCt* cands; uint64_t cand_cap;
     struct TailTask* light; struct TailTask* heavy; uint64_t task_cap;
-    unsigned long long* counters;     // [0] candidate sites, [2] light tail tasks, [3] heavy tail tasks
+    unsigned long long* counters;     // [0] candidate blocks allocated, [1] candidate sites (exact), [2] light, [3] heavy tail task slots, [4] heads
+    const uint32_t* heads;            // units that are the first of a tile with at least one site
+    uint32_t* head_recs;              // 16 words per head: unit, first site index, tile start, tid, masks[4] (lo, hi), row bases[4]
 };
 
 // log of the beta-binomial pmf at m (scipy betabinom._logpmf written with lgamma)
@@ -137,28 +139,55 @@ __device__ __forceinline__ uint32_t tail_work(uint32_t k, uint32_t n) {
     return k < up ? k : up;
 }
 
-constexpr int GATHER_WAVES = 16;
-__global__ __launch_bounds__(GATHER_WAVES * 64) void k_call_gather(CallArgs a) {
-    __shared__ uint32_t s_tot[3][GATHER_WAVES];
-    __shared__ uint32_t s_base[3];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const uint32_t w = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-    // a wave works only if its unit is the first of its tile (the units of a tile are adjacent)
-    bool head = w < a.n_ne;
-    uint32_t tile = 0;
-    if (head) { tile = a.ne_units[w] / (uint32_t)a.n_ct; if (w > 0 && a.ne_units[w - 1] / (uint32_t)a.n_ct == tile) head = false; }
+// One 64-byte record per tile head: everything k_call_gather needs to know about the tile, so that a wave fetches it
+// with ONE scalar load, a tile ahead of its use (the chain heads -> units -> masks -> row bases was 4 dependent round trips).
+__global__ void k_head_recs(CallArgs a) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (uint32_t)a.counters[4]) return;
+    const uint32_t w = a.heads[i];
+    const uint32_t tile = a.ne_units[w] / (uint32_t)a.n_ct;
     uint64_t mask[LSG_MAX_CELLTYPES] = {0, 0, 0, 0};
     uint32_t rbase[LSG_MAX_CELLTYPES] = {0, 0, 0, 0};
+    for (uint32_t q = w; q < a.n_ne && q < w + (uint32_t)a.n_ct && a.ne_units[q] / (uint32_t)a.n_ct == tile; ++q) {
+        const int ct = (int)(a.ne_units[q] % (uint32_t)a.n_ct);
+        mask[ct] = a.ne_mask[q]; rbase[ct] = a.ne_rowbase[q];
+    }
+    const int2 geom = a.ne_geom[w];
+    uint32_t* r = a.head_recs + (uint64_t)i * 16;
+    r[0] = w; r[1] = a.site_off[w]; r[2] = (uint32_t)geom.x; r[3] = (uint32_t)geom.y;
+    for (int ct = 0; ct < LSG_MAX_CELLTYPES; ++ct) { r[4 + 2 * ct] = (uint32_t)mask[ct]; r[5 + 2 * ct] = (uint32_t)(mask[ct] >> 32); r[12 + ct] = rbase[ct]; }
+}
+
+// Persistent waves: every wave walks tile heads (heads[]) with a stride and allocates candidate blocks and tail tasks
+// from wave-private arenas refilled in chunks (a single counter word takes only ~90 atomics/us; per-site or even
+// per-workgroup atomics would cap the kernel).  Task arenas are split across chunks so that only the LAST chunk of a
+// wave has unused slots; those are written as null tasks (dst = 0) which the tail kernels skip.
+constexpr int GATHER_WAVES = 4;
+constexpr uint32_t CAND_CHUNK = 256, TASK_CHUNK = 512, HEAVY_CHUNK = 32;   // heavy tasks are rare and a null heavy slot costs a wave a memory round trip
+__global__ __launch_bounds__(GATHER_WAVES * 64) void k_call_gather(CallArgs a) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const uint32_t n_waves = (uint32_t)(((uint64_t)gridDim.x * blockDim.x) >> 6);
+    const uint32_t n_heads = (uint32_t)a.counters[4];
+    uint32_t c_next = 0, c_end = 0;                       // candidate blocks
+    uint32_t l_next = 0, l_end = 0, h_next = 0, h_end = 0;  // light / heavy task slots
+    uint32_t n_cand_exact = 0;
+    typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+    const __attribute__((address_space(4))) u32x16* H = (const __attribute__((address_space(4))) u32x16*)(uintptr_t)a.head_recs;
+    u32x16 nxt = {};
+    if (wave < n_heads) nxt = H[wave];
+    for (uint32_t hi_ = wave; hi_ < n_heads; hi_ += n_waves) {
+    const u32x16 rec = nxt;
+    if (hi_ + n_waves < n_heads) nxt = H[hi_ + n_waves];      // the next tile's record travels while this tile is worked on
+    uint64_t mask[LSG_MAX_CELLTYPES];
+    uint32_t rbase[LSG_MAX_CELLTYPES];
     uint64_t any = 0;
-    if (head)
-        for (uint32_t q = w; q < a.n_ne && a.ne_units[q] / (uint32_t)a.n_ct == tile; ++q) {
-            const int ct = (int)(a.ne_units[q] % (uint32_t)a.n_ct);
-            mask[ct] = a.ne_mask[q]; rbase[ct] = a.ne_rowbase[q]; any |= mask[ct];
-        }
+#pragma unroll
+    for (int ct = 0; ct < LSG_MAX_CELLTYPES; ++ct) { mask[ct] = (uint64_t)rec[4 + 2 * ct] | ((uint64_t)rec[5 + 2 * ct] << 32); rbase[ct] = rec[12 + ct]; any |= mask[ct]; }
     const bool site = (any >> lane) & 1ull;
     const uint64_t below = (1ull << lane) - 1ull;
-    const uint64_t idx = head ? (uint64_t)a.site_off[w] + __popcll(any & below) : 0;
-    const int2 geom = head ? a.ne_geom[w] : make_int2(0, 0);
+    const uint64_t idx = (uint64_t)rec[1] + __popcll(any & below);
+    const int2 geom = make_int2((int)rec[2], (int)rec[3]);
     const int tid = geom.y & 0xffffff;
     const int64_t pos = (int64_t)geom.x + lane;
     const uint8_t* ref = a.ref_ptr[tid];
@@ -217,24 +246,37 @@ __global__ __launch_bounds__(GATHER_WAVES * 64) void k_call_gather(CallArgs a) {
     uint32_t pl = n_light, ph = n_heavy;
     for (int o = 1; o < 64; o <<= 1) { const uint32_t vl = __shfl_up(pl, o), vh = __shfl_up(ph, o); if (lane >= o) { pl += vl; ph += vh; } }
     const uint32_t tot_l = __shfl(pl, 63), tot_h = __shfl(ph, 63);
-    // one global atomic per counter per WORKGROUP (a single word takes only ~90 atomics/us)
-    if (lane == 0) { s_tot[0][wv] = (uint32_t)__popcll(cm); s_tot[1][wv] = tot_l; s_tot[2][wv] = tot_h; }
-    __syncthreads();
-    if (threadIdx.x < 3) {
-        uint32_t t = 0;
-        for (int q = 0; q < GATHER_WAVES; ++q) t += s_tot[threadIdx.x][q];
-        const int slot = threadIdx.x == 0 ? 0 : (int)threadIdx.x + 1;
-        s_base[threadIdx.x] = t ? (uint32_t)atomicAdd(&a.counters[slot], (unsigned long long)t) : 0u;
+    // wave-private arenas
+    const uint32_t n_c = (uint32_t)__popcll(cm);
+    n_cand_exact += n_c;
+    if (c_next + n_c > c_end) {                              // candidate blocks may leave holes: they are reached through sr.cand only
+        uint32_t nb = 0;
+        if (lane == 0) nb = (uint32_t)atomicAdd(&a.counters[0], (unsigned long long)CAND_CHUNK);
+        c_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb); c_end = c_next + CAND_CHUNK;
     }
-    __syncthreads();
-    uint32_t cbase = s_base[0], lbase = s_base[1], hbase = s_base[2];
-    for (int q = 0; q < wv; ++q) { cbase += s_tot[0][q]; lbase += s_tot[1][q]; hbase += s_tot[2][q]; }
-    if (!site) return;
+    const uint32_t cbase = c_next; c_next += n_c;
+    // task slots: positions [pos, pos + tot) of the wave's stream; a request that does not fit continues in a new chunk
+    uint32_t l_old = l_next, l_room = l_end - l_next, l_new = 0;
+    if (tot_l > l_room) {
+        uint32_t nb = 0;
+        if (lane == 0) nb = (uint32_t)atomicAdd(&a.counters[2], (unsigned long long)TASK_CHUNK * ((tot_l - l_room + TASK_CHUNK - 1) / TASK_CHUNK));
+        l_new = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb);
+        l_next = l_new + (tot_l - l_room); l_end = l_new + TASK_CHUNK * ((tot_l - l_room + TASK_CHUNK - 1) / TASK_CHUNK);
+    } else l_next += tot_l;
+    uint32_t h_old = h_next, h_room = h_end - h_next, h_new = 0;
+    if (tot_h > h_room) {
+        uint32_t nb = 0;
+        if (lane == 0) nb = (uint32_t)atomicAdd(&a.counters[3], (unsigned long long)HEAVY_CHUNK * ((tot_h - h_room + HEAVY_CHUNK - 1) / HEAVY_CHUNK));
+        h_new = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb);
+        h_next = h_new + (tot_h - h_room); h_end = h_new + HEAVY_CHUNK * ((tot_h - h_room + HEAVY_CHUNK - 1) / HEAVY_CHUNK);
+    } else h_next += tot_h;
+    if (!site) continue;
     const uint32_t cand = cbase + (uint32_t)__popcll(cm & below);
-    uint32_t li = lbase + pl - n_light, hi = hbase + ph - n_heavy;
+    uint32_t li = pl - n_light, hi = ph - n_heavy;           // this lane's first slot, as an offset into the wave's request
     auto emit_task = [&](uint32_t k, uint32_t n, int set, int16_t* dst) {
         TailTask t; t.k = k; t.n = n; t.dst = (uint64_t)dst | (uint64_t)set;
-        if (tail_work(k, n) > 64) { if (hi < a.task_cap) a.heavy[hi] = t; ++hi; } else { if (li < a.task_cap) a.light[li] = t; ++li; }
+        if (tail_work(k, n) > 64) { const uint32_t p = hi < h_room ? h_old + hi : h_new + (hi - h_room); if (p < a.task_cap) a.heavy[p] = t; ++hi; }
+        else { const uint32_t p = li < l_room ? l_old + li : l_new + (li - l_room); if (p < a.task_cap) a.light[p] = t; ++li; }
     };
 
     SiteRec sr;
@@ -329,6 +371,12 @@ __global__ __launch_bounds__(GATHER_WAVES * 64) void k_call_gather(CallArgs a) {
     }
     sr.site_filter = sf;
     *srp = sr;
+    }
+    // unused tail of the wave's last task chunks: null tasks
+    TailTask nul; nul.k = 0; nul.n = 0; nul.dst = 0;
+    for (uint32_t p = l_next + (uint32_t)lane; p < l_end; p += 64) if (p < a.task_cap) a.light[p] = nul;
+    for (uint32_t p = h_next + (uint32_t)lane; p < h_end; p += 64) if (p < a.task_cap) a.heavy[p] = nul;
+    if (lane == 0 && n_cand_exact) atomicAdd(&a.counters[1], (unsigned long long)n_cand_exact);
 }
 
 __device__ __forceinline__ double tail_of_task(const TailTask& t, const CallArgs& a) {
@@ -341,6 +389,7 @@ __global__ __launch_bounds__(256) void k_call_tails(CallArgs a) {
     const uint64_t n = a.counters[2] < a.task_cap ? a.counters[2] : a.task_cap;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         const TailTask t = a.light[i];
+        if (!(t.dst & ~1ull)) continue;                        // unused arena slot
         *reinterpret_cast<int16_t*>(t.dst & ~1ull) = (int16_t)round4(tail_of_task(t, a));
     }
 }
@@ -351,6 +400,7 @@ __global__ __launch_bounds__(256) void k_call_tails_heavy(CallArgs a) {
     const uint64_t n_tasks = a.counters[3] < a.task_cap ? a.counters[3] : a.task_cap;
     for (uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; i < n_tasks; i += ((uint64_t)gridDim.x * blockDim.x) >> 6) {
         const TailTask t = a.heavy[i];
+        if (!(t.dst & ~1ull)) continue;                        // unused arena slot
         const int set = (int)(t.dst & 1ull);
         const double al = set ? a.p.alpha2 : a.p.alpha1, be = set ? a.p.beta2 : a.p.beta1;
         const double dn = (double)t.n;
@@ -464,13 +514,18 @@ __global__ void k_probe(const int64_t* set, int64_t n_set, const int64_t* keys, 
     hits[i] = (lo < n_set && set[lo] == key) ? 1 : 0;
 }
 
+struct HasSites {
+    const uint32_t* cnt;
+    __host__ __device__ bool operator()(const uint32_t& w) const { return cnt[w] != 0; }
+};
+
 int run_call(lsg_ctx* c, const lsg_call_params* p) {
     if (!c->counted) { set_error("lsg_call_step1: call lsg_pileup_count first"); return -2; }
     hipStream_t st = c->stream;
     const uint32_t n_ne = c->n_ne;
     c->n_sites = 0; c->n_cand = 0;
     if (n_ne == 0) { c->called = true; return 0; }
-    if (c->d_site_off.reserve((size_t)(n_ne + 2) * 8 + 128)) return -1;
+    if (c->d_site_off.reserve((size_t)(n_ne + 2) * 12 + 192 + (size_t)n_ne * 64 + 64)) return -1;     // site_cnt, site_off, counters (8 u64), heads, head records
     CallArgs a{};
     a.ne_units = c->d_ne_units.as<uint32_t>(); a.ne_mask = c->d_ne_mask.as<uint64_t>(); a.ne_rowbase = c->d_ne_rowbase.as<uint32_t>();
     a.ne_geom = c->ws[WS_NE_GEOM].as<int2>();
@@ -484,29 +539,45 @@ int run_call(lsg_ctx* c, const lsg_call_params* p) {
     a.site_cnt = c->d_site_off.as<uint32_t>();
     a.site_off = a.site_cnt + (n_ne + 2);
     a.counters = reinterpret_cast<unsigned long long*>(a.site_off + (n_ne + 2));   // 2*(n_ne+2) words: 8-byte aligned
-    LSG_HIP(hipMemsetAsync(a.counters, 0, 32, st));
+    uint32_t* heads = reinterpret_cast<uint32_t*>(a.counters + 8);
+    a.heads = heads;
+    a.head_recs = reinterpret_cast<uint32_t*>((reinterpret_cast<uintptr_t>(heads + n_ne) + 63) & ~(uintptr_t)63);
+    LSG_HIP(hipMemsetAsync(a.counters, 0, 64, st));
     hipLaunchKernelGGL(k_site_count, dim3((n_ne + 256) / 256), dim3(256), 0, st, a);
     size_t tb = 0;
     LSG_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, a.site_cnt, a.site_off, (int)(n_ne + 1), st));
     if (c->d_cub_tmp.reserve(tb + 256)) return -1;
     tb = c->d_cub_tmp.cap;
     LSG_HIP(hipcub::DeviceScan::ExclusiveSum(c->d_cub_tmp.p, tb, a.site_cnt, a.site_off, (int)(n_ne + 1), st));
+    {   // the tile heads with at least one site, in order
+        HasSites pred{a.site_cnt};
+        hipcub::CountingInputIterator<uint32_t> it(0);
+        uint32_t* d_nh = reinterpret_cast<uint32_t*>(a.counters + 4);
+        size_t tb2 = 0;
+        LSG_HIP(hipcub::DeviceSelect::If(nullptr, tb2, it, heads, d_nh, (int)n_ne, pred, st));
+        if (c->d_cub_tmp.reserve(tb2 + 256)) return -1;
+        tb2 = c->d_cub_tmp.cap;
+        LSG_HIP(hipcub::DeviceSelect::If(c->d_cub_tmp.p, tb2, it, heads, d_nh, (int)n_ne, pred, st));
+    }
+    hipLaunchKernelGGL(k_head_recs, dim3((n_ne + 255) / 256), dim3(256), 0, st, a);
     uint32_t n_sites = 0;
     LSG_HIP(hipMemcpyAsync(&n_sites, a.site_off + n_ne, 4, hipMemcpyDeviceToHost, st));
     LSG_HIP(hipStreamSynchronize(st));
     if (n_sites > 0) {
         if (c->d_calls.reserve((size_t)n_sites * sizeof(SiteRec))) return -1;
-        if (c->ws[WS_CALL_CANDS].reserve((size_t)n_sites * sizeof(CandCt) * (size_t)c->n_ct)) return -1;   // every site could be a candidate
-        a.sites = c->d_calls.as<SiteRec>(); a.cands = c->ws[WS_CALL_CANDS].as<CandCt>(); a.cand_cap = n_sites;
+        if (c->ws[WS_CALL_CANDS].reserve(((size_t)n_sites + (size_t)c->n_cus * 4 * GATHER_WAVES * CAND_CHUNK) * sizeof(CandCt) * (size_t)c->n_ct)) return -1;   // every site could be a candidate + arena slack
+        const unsigned gather_grid = (unsigned)(c->n_cus * 4);
+        const uint64_t gather_waves = (uint64_t)gather_grid * GATHER_WAVES;
+        a.sites = c->d_calls.as<SiteRec>(); a.cands = c->ws[WS_CALL_CANDS].as<CandCt>(); a.cand_cap = n_sites + gather_waves * CAND_CHUNK;
         // at most 2 tails per alt (<= 4 alts) per cell type + 2 noise tails per site
         a.task_cap = (uint64_t)n_sites * (uint64_t)(8 * c->n_ct + 2);
         if (a.task_cap > 0x7fffffffull) a.task_cap = 0x7fffffffull;
         // candidates rarely exceed a few tasks per site: size for 8 per site, checked below
         if (a.task_cap > (uint64_t)n_sites * 8 + 1024) a.task_cap = (uint64_t)n_sites * 8 + 1024;
+        a.task_cap += gather_waves * TASK_CHUNK * 2;                                  // arena slack
         if (c->ws[WS_CALL_TASKS].reserve((size_t)a.task_cap * sizeof(TailTask) * 2)) return -1;
         a.light = c->ws[WS_CALL_TASKS].as<TailTask>(); a.heavy = a.light + a.task_cap;
-        const uint64_t threads = (uint64_t)n_ne * 64;
-        hipLaunchKernelGGL(k_call_gather, dim3((unsigned)((threads + GATHER_WAVES * 64 - 1) / (GATHER_WAVES * 64))), dim3(GATHER_WAVES * 64), 0, st, a);
+        hipLaunchKernelGGL(k_call_gather, dim3(gather_grid), dim3(GATHER_WAVES * 64), 0, st, a);
         hipLaunchKernelGGL(k_call_tails, dim3((unsigned)(c->n_cus * 16)), dim3(256), 0, st, a);
         hipLaunchKernelGGL(k_call_tails_heavy, dim3((unsigned)(c->n_cus * 8)), dim3(256), 0, st, a);
         hipLaunchKernelGGL(k_call_finish, dim3((n_sites + 255) / 256), dim3(256), 0, st, a, n_sites);
@@ -515,7 +586,7 @@ int run_call(lsg_ctx* c, const lsg_call_params* p) {
     unsigned long long cnt4[4] = {0, 0, 0, 0};
     LSG_HIP(hipMemcpyAsync(cnt4, a.counters, 32, hipMemcpyDeviceToHost, st));
     LSG_HIP(hipStreamSynchronize(st));
-    const unsigned long long cand = cnt4[0];
+    const unsigned long long cand = cnt4[1];
     if (n_sites > 0 && (cnt4[2] > a.task_cap || cnt4[3] > a.task_cap)) { set_error("lsg_call_step1: tail task buffer too small (%llu/%llu tasks)", cnt4[2], cnt4[3]); return -3; }
     c->n_sites = n_sites; c->n_cand = (int64_t)cand;
     c->called = true;
