@@ -164,6 +164,7 @@ __global__ void k_head_recs(CallArgs a) {
 // wave has unused slots; those are written as null tasks (dst = 0) which the tail kernels skip.
 constexpr int GATHER_WAVES = 4;
 constexpr uint32_t CAND_CHUNK = 256, TASK_CHUNK = 512, HEAVY_CHUNK = 32;   // heavy tasks are rare and a null heavy slot costs a wave a memory round trip
+template <int NCT>
 __global__ __launch_bounds__(GATHER_WAVES * 64) void k_call_gather(CallArgs a) {
     const int lane = threadIdx.x & 63;
     const uint32_t wave = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
@@ -179,11 +180,11 @@ __global__ __launch_bounds__(GATHER_WAVES * 64) void k_call_gather(CallArgs a) {
     for (uint32_t hi_ = wave; hi_ < n_heads; hi_ += n_waves) {
     const u32x16 rec = nxt;
     if (hi_ + n_waves < n_heads) nxt = H[hi_ + n_waves];      // the next tile's record travels while this tile is worked on
-    uint64_t mask[LSG_MAX_CELLTYPES];
-    uint32_t rbase[LSG_MAX_CELLTYPES];
+    uint64_t mask[NCT];
+    uint32_t rbase[NCT];
     uint64_t any = 0;
 #pragma unroll
-    for (int ct = 0; ct < LSG_MAX_CELLTYPES; ++ct) { mask[ct] = (uint64_t)rec[4 + 2 * ct] | ((uint64_t)rec[5 + 2 * ct] << 32); rbase[ct] = rec[12 + ct]; any |= mask[ct]; }
+    for (int ct = 0; ct < NCT; ++ct) { mask[ct] = (uint64_t)rec[4 + 2 * ct] | ((uint64_t)rec[5 + 2 * ct] << 32); rbase[ct] = rec[12 + ct]; any |= mask[ct]; }
     const bool site = (any >> lane) & 1ull;
     const uint64_t below = (1ull << lane) - 1ull;
     const uint64_t idx = (uint64_t)rec[1] + __popcll(any & below);
@@ -198,13 +199,13 @@ __global__ __launch_bounds__(GATHER_WAVES * 64) void k_call_gather(CallArgs a) {
     const int order[4] = {0, 1, 3, 2};              // letter order A < C < G < T over classes (A,C,T,G) = (0,1,2,3)
 
     // all loads first (independent, one latency): DP, NC, CC[0..5], BC[0..5] of every present cell type
-    uint32_t v_dp[LSG_MAX_CELLTYPES], v_nc[LSG_MAX_CELLTYPES], v_cc[LSG_MAX_CELLTYPES][6], v_bc[LSG_MAX_CELLTYPES][6];
+    uint32_t v_dp[NCT], v_nc[NCT], v_cc[NCT][6], v_bc[NCT][6];
 #pragma unroll
-    for (int ct = 0; ct < LSG_MAX_CELLTYPES; ++ct) {
+    for (int ct = 0; ct < NCT; ++ct) {
         v_dp[ct] = 0; v_nc[ct] = 0;
 #pragma unroll
         for (int s = 0; s < 6; ++s) { v_cc[ct][s] = 0; v_bc[ct][s] = 0; }
-        if (ct < a.n_ct && site && ((mask[ct] >> lane) & 1ull)) {
+        if (site && ((mask[ct] >> lane) & 1ull)) {
             const uint64_t row = (uint64_t)rbase[ct] + __popcll(mask[ct] & below);
             const uint32_t* R = a.rows[ct];
             v_dp[ct] = R[row]; v_nc[ct] = R[cap + row];
@@ -218,8 +219,8 @@ __global__ __launch_bounds__(GATHER_WAVES * 64) void k_call_gather(CallArgs a) {
     int32_t s_alts_bc = 0, s_alts_cc = 0, s_dp = 0, s_nc = 0;
     if (site) {
 #pragma unroll
-        for (int ct = 0; ct < LSG_MAX_CELLTYPES; ++ct) {
-            if (ct >= a.n_ct || !((mask[ct] >> lane) & 1ull)) continue;
+        for (int ct = 0; ct < NCT; ++ct) {
+            if (!((mask[ct] >> lane) & 1ull)) continue;
             const uint32_t dp = v_dp[ct], nc = v_nc[ct];
             if (!((int)dp >= P.min_cov && (int)nc >= P.min_cells)) continue;
             s_dp += (int32_t)dp; s_nc += (int32_t)nc;
@@ -301,13 +302,12 @@ __global__ __launch_bounds__(GATHER_WAVES * 64) void k_call_gather(CallArgs a) {
     SiteRec* srp = &a.sites[idx];
 
 #pragma unroll
-    for (int ct = 0; ct < LSG_MAX_CELLTYPES; ++ct) {
-        if (ct >= a.n_ct) continue;
+    for (int ct = 0; ct < NCT; ++ct) {
         CandCt cd;
         cd.n_alt = 0; cd.ct_filter = 0; cd.pad[0] = cd.pad[1] = 0;
 #pragma unroll
         for (int q = 0; q < LSG_CALL_MAX_ALT; ++q) { cd.alt[q] = 0; cd.alt_bc[q] = 0; cd.alt_cc[q] = 0; cd.p_bc[q] = 0; cd.p_cc[q] = 0; }
-        CandCt* cdp = has_any && cand < a.cand_cap ? &a.cands[(uint64_t)cand * a.n_ct + ct] : nullptr;
+        CandCt* cdp = has_any && cand < a.cand_cap ? &a.cands[(uint64_t)cand * NCT + ct] : nullptr;
         if ((mask[ct] >> lane) & 1ull) {
             sr.present |= (uint8_t)(1u << ct);
             const uint32_t dp = v_dp[ct], nc = v_nc[ct];
@@ -577,7 +577,12 @@ int run_call(lsg_ctx* c, const lsg_call_params* p) {
         a.task_cap += gather_waves * TASK_CHUNK * 2;                                  // arena slack
         if (c->ws[WS_CALL_TASKS].reserve((size_t)a.task_cap * sizeof(TailTask) * 2)) return -1;
         a.light = c->ws[WS_CALL_TASKS].as<TailTask>(); a.heavy = a.light + a.task_cap;
-        hipLaunchKernelGGL(k_call_gather, dim3(gather_grid), dim3(GATHER_WAVES * 64), 0, st, a);
+        switch (c->n_ct) {                                                            // the cell-type loops are compile-time
+            case 1: hipLaunchKernelGGL(k_call_gather<1>, dim3(gather_grid), dim3(GATHER_WAVES * 64), 0, st, a); break;
+            case 2: hipLaunchKernelGGL(k_call_gather<2>, dim3(gather_grid), dim3(GATHER_WAVES * 64), 0, st, a); break;
+            case 3: hipLaunchKernelGGL(k_call_gather<3>, dim3(gather_grid), dim3(GATHER_WAVES * 64), 0, st, a); break;
+            default: hipLaunchKernelGGL(k_call_gather<4>, dim3(gather_grid), dim3(GATHER_WAVES * 64), 0, st, a); break;
+        }
         hipLaunchKernelGGL(k_call_tails, dim3((unsigned)(c->n_cus * 16)), dim3(256), 0, st, a);
         hipLaunchKernelGGL(k_call_tails_heavy, dim3((unsigned)(c->n_cus * 8)), dim3(256), 0, st, a);
         hipLaunchKernelGGL(k_call_finish, dim3((n_sites + 255) / 256), dim3(256), 0, st, a, n_sites);
