@@ -169,7 +169,7 @@ __device__ __forceinline__ BinSeg bin_load(const CountArgs& a, int64_t s) {
 
 template <int MODE>
 __global__ __launch_bounds__(BIN_THREADS) void k_bin_segments(CountArgs a) {
-    __shared__ uint32_t hkey[BIN_H], hcnt[BIN_H], hbase[MODE == 2 ? BIN_H : 1];
+    __shared__ uint32_t hkey[BIN_H], hcnt[BIN_H];      // MODE 2: hcnt turns into the unit's write cursor after the flush
     __shared__ uint32_t s_newb[BIN_MAXI], s_ib[BIN_MAXI], s_ir[BIN_MAXI];
     __shared__ int s_maxb[BIN_MAXI];
     __shared__ uint32_t s_super;
@@ -238,9 +238,8 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_segments(CountArgs a) {
             for (int i = t; i < BIN_H; i += BIN_THREADS) {
                 const uint32_t cnt = hcnt[i];
                 if (cnt) {
-                    if (MODE == 0) { atomicAdd(&a.unit_cnt[hkey[i]], cnt); hkey[i] = KEY_INVALID; }
-                    else hbase[i] = atomicAdd(&a.unit_cursor[hkey[i]], cnt);
-                    hcnt[i] = 0;
+                    if (MODE == 0) { atomicAdd(&a.unit_cnt[hkey[i]], cnt); hkey[i] = KEY_INVALID; hcnt[i] = 0; }
+                    else hcnt[i] = atomicAdd(&a.unit_cursor[hkey[i]], cnt);       // first position of this workgroup's range in the unit
                 }
             }
             __syncthreads();
@@ -259,7 +258,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_segments(CountArgs a) {
                             const uint32_t x = tt * (uint32_t)a.n_ct + ct;
                             uint32_t h = (x * 2654435761u) >> HSHIFT;
                             while (hkey[h] != x) h = (h + 1) & (BIN_H - 1);
-                            const uint32_t pos = hbase[h] + atomicAdd(&hcnt[h], 1u);
+                            const uint32_t pos = atomicAdd(&hcnt[h], 1u);
                             const int32_t tstart = (int32_t)((tt - g.tb) << 6);
                             const int32_t lo = g.st > tstart ? g.st : tstart;
                             const int32_t hi = g.st + g.ln < tstart + TILE_W ? g.st + g.ln : tstart + TILE_W;
