@@ -203,6 +203,33 @@ int lsg_load_posset(lsg_ctx* ctx, int32_t kind, const int64_t* keys, int64_t n, 
 /* Membership of n query keys in set `kind` (GetExtraFilters, step2.py:142-158). hits[i] = 0/1. */
 int lsg_probe_posset(lsg_ctx* ctx, int32_t kind, const int64_t* keys, int64_t n, uint8_t* hits, int32_t on_device);
 
+/* ---- per-cell genotyping at target sites ---------------------------------
+ * HCCVSingleCellGenotype.py:82-220 (twin: SNVCalling/SingleCellGenotype.py:84-228): for every target
+ * site and every barcode of barcodes.tsv
+ *   Dp  = pileup entries of that cell at the site whose symbol is one of A,C,T,G,I,D,N (:147-149; 'O'
+ *         and 'NA' are not counted) and whose base quality is >= min_bq (pileup min_base_quality, :123),
+ *   Alt = those whose symbol equals the site's expected alt (:171-175).
+ * alt_only != 0 is --alt_flag Alt (:150-151): only reads carrying the expected alt are looked at.
+ * Read admission: pileup's flag filter and ignore_orphans, min_mq (:123), not secondary / duplicate /
+ * supplementary (:168), CB present and listed (:160-164); strict_cb != 0 also drops reads whose raw CB
+ * tag carried a "-suffix" (the reference looks the raw tag up in the cleaned table, :160-161;
+ * liblongsom_io marks such reads with LSG_FLAG_CB_SUFFIX in read_flag).
+ * site_keys = (tid << 32) | pos0, strictly ascending; alt_sym = symbol class 0..6 per site (255 = none).
+ * dp / alt: [n_sites][n_cb] uint32, zeroed by the call.  Needs contigs, barcodes and reads. */
+#define LSG_FLAG_CB_SUFFIX 0x8000u
+typedef struct {
+    int32_t  min_bq, min_mq;
+    uint32_t flag_exclude;      /* 0xF04 */
+    int32_t  ignore_orphans;
+    int32_t  alt_only;
+    int32_t  strict_cb;
+} lsg_genotype_params;
+int lsg_genotype_cells(lsg_ctx* ctx, const lsg_genotype_params* params, int64_t n_sites, const int64_t* site_keys,
+                       const uint8_t* alt_sym, uint32_t* dp, uint32_t* alt, int32_t on_device);
+/* round(betabinom.sf(k - 0.001, n, alpha, beta), 4) * 1e4 for n_items integer (k, n) pairs, evaluated on the
+ * device with the step-1 tail code (HCCVSingleCellGenotype.py:204; k[i] <= 0 gives 10000). */
+int lsg_betabinom_sf4(lsg_ctx* ctx, int64_t n_items, const uint32_t* k, const uint32_t* n, double alpha, double beta, int32_t* out_p4);
+
 /* ---- measurement helpers --------------------------------------------------------------------*/
 /* Statistics of the last lsg_pileup_count: admitted reads / segments / events (events that passed
  * read admission, before the base-quality gate), tile entries, non-empty units, deep units. */

@@ -50,6 +50,19 @@ class CountParams(C.Structure):
         return p
 
 
+class GenotypeParams(C.Structure):
+    _fields_ = [("min_bq", C.c_int32), ("min_mq", C.c_int32), ("flag_exclude", C.c_uint32), ("ignore_orphans", C.c_int32),
+                ("alt_only", C.c_int32), ("strict_cb", C.c_int32)]
+
+    @classmethod
+    def longsom_defaults(cls, **kw):
+        """HCCVSingleCellGenotype.py:327-329 (min_bq 30) with the rule's --min_mq (R:CellTypeReannotation.smk:320,344)."""
+        p = cls(min_bq=30, min_mq=60, flag_exclude=0xF04, ignore_orphans=1, alt_only=0, strict_cb=1)
+        for k, v in kw.items():
+            setattr(p, k, v)
+        return p
+
+
 class CallParams(C.Structure):
     _fields_ = [
         ("alpha1", C.c_double), ("beta1", C.c_double), ("alpha2", C.c_double), ("beta2", C.c_double),
@@ -125,6 +138,8 @@ SIGNATURES = {
     "lsg_export_calls": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     "lsg_load_posset": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int32]),
     "lsg_probe_posset": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32]),
+    "lsg_genotype_cells": (C.c_int, [C.c_void_p, C.POINTER(GenotypeParams), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
+    "lsg_betabinom_sf4": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p]),
     "lsg_get_count_stats": (C.c_int, [C.c_void_p, C.POINTER(CountStats)]),
 }
 

@@ -142,6 +142,58 @@ def calling_step3(argv=None):
     open(a.outfile + ".calling.step3.unfiltered.tsv", "w").write(unfiltered)
 
 
+def hccv(argv=None):
+    """HighConfidenceCancerVariants.py --SNVs --outfile PREFIX --min_dp --deltaVAF --deltaMCF [--clust_dist]  (:259-267)."""
+    from . import reanno
+    ap = argparse.ArgumentParser(description="High-confidence cancer variants for the cell-type re-annotation")
+    ap.add_argument("--SNVs", required=True); ap.add_argument("--outfile", required=True)
+    ap.add_argument("--min_dp", type=float, required=True); ap.add_argument("--deltaVAF", type=float, required=True)
+    ap.add_argument("--deltaMCF", type=float, required=True); ap.add_argument("--clust_dist", type=int, default=10000)
+    a = ap.parse_args(argv)
+    print("\n- High Confidence Cancer Variants calling\n")
+    reanno.hccv_filter(a.SNVs, a.outfile, a.min_dp, a.deltaVAF, a.deltaMCF, a.clust_dist)
+
+
+def single_cell_genotype(argv=None):
+    """HCCVSingleCellGenotype.py --bam --infile --ref --meta --outfile [--alt_flag --nprocs --bin --min_bq --min_mq --tissue
+    --tmp_dir --alpha2 --beta2 --pvalue --chrM_contaminant]  (:317-337).  --ref is accepted and not needed (the reference only
+    uses it for a count it never reads, :138-145)."""
+    from . import reanno
+    ap = argparse.ArgumentParser(description="Alleles observed in every cell at the variant sites, on the GPU")
+    ap.add_argument("--bam", required=True); ap.add_argument("--infile", required=True); ap.add_argument("--ref", required=True)
+    ap.add_argument("--meta", required=True); ap.add_argument("--outfile", default="Matrix.tsv")
+    ap.add_argument("--alt_flag", default="All", choices=["Alt", "All"]); ap.add_argument("--nprocs", type=int, default=1)
+    ap.add_argument("--bin", type=int, default=50000); ap.add_argument("--min_bq", type=int, default=30); ap.add_argument("--min_mq", type=int, default=255)
+    ap.add_argument("--tissue", default=None); ap.add_argument("--tmp_dir", default="tmpDir")
+    ap.add_argument("--alpha2", type=float, default=0.260288007167716); ap.add_argument("--beta2", type=float, default=173.94711910763732)
+    ap.add_argument("--pvalue", type=float, default=0.01); ap.add_argument("--chrM_contaminant", default="True")
+    ap.add_argument("--device", type=int, default=0)
+    a = ap.parse_args(argv)
+    if a.tissue is not None:
+        raise SystemExit("--tissue is not used by LongSom's rules and is not implemented")
+    print("Outfile: ", a.outfile, "\n")
+    os.makedirs(a.tmp_dir, exist_ok=True)              # the rule declares it as an output (R:CellTypeReannotation.smk:316)
+    table = hostio.read_barcodes(a.meta)
+    dec = hostio.decode_bam(a.bam, table.barcodes, min_mapq=0)
+    with Engine(a.device) as eng:
+        eng.set_contigs(dec.contig_len)
+        eng.set_barcodes(table.celltype_of, len(table.celltype_names))
+        eng.load_reads(dec.records)
+        reanno.single_cell_genotype(eng, a.infile, table, dec.contig_names, a.outfile, alt_flag=a.alt_flag, window=a.bin, min_bq=a.min_bq,
+                                    min_mq=a.min_mq, alpha2=a.alpha2, beta2=a.beta2, pvalue=a.pvalue, chrm_contaminant=a.chrM_contaminant)
+
+
+def celltype_reannotation(argv=None):
+    """CellTypeReannotation.py --SNVs --fusions --outfile --meta [--min_variants --min_frac]  (:67-77)."""
+    from . import reanno
+    ap = argparse.ArgumentParser(description="Cancer / non-cancer re-annotation of the cells from their HCCV genotypes")
+    ap.add_argument("--SNVs", required=True); ap.add_argument("--fusions", required=True); ap.add_argument("--outfile", required=True)
+    ap.add_argument("--meta", required=True); ap.add_argument("--min_variants", type=int, default=3); ap.add_argument("--min_frac", type=float, default=0.2)
+    a = ap.parse_args(argv)
+    print("Outfile: ", a.outfile, "\n")
+    reanno.celltype_reannotation(a.SNVs, a.fusions, a.meta, a.outfile, a.min_variants, a.min_frac)
+
+
 def snv(argv=None):
     """Fused chain: one process from BAM to calling.step3.tsv (workflow/rules/SNVCalling.gpu.smk)."""
     ap = argparse.ArgumentParser(description="SplitBam -> BaseCellCounter -> MergeCounts -> BaseCellCalling step1-3 on one GPU")

@@ -110,7 +110,8 @@ void decode_record(const uint8_t* rec, uint32_t len, const std::unordered_map<st
     if ((int)mapq < min_mapq) ++L.mapq; else ++L.pass;                             // report only; the device re-applies min_mq
     if ((flag & 0x4) || n_cigar == 0) return;                                      // no alignment: nothing to pile up
     const uint32_t r = (uint32_t)L.read_tid.size();
-    L.read_tid.push_back(tid); L.read_pos.push_back(pos); L.read_flag.push_back((uint16_t)flag); L.read_mapq.push_back((uint8_t)mapq);
+    // SAM flags use 12 bits; bit 15 records that the raw CB carried a "-suffix" (the genotyping script looks the RAW tag up, lsg_genotype_cells)
+    L.read_tid.push_back(tid); L.read_pos.push_back(pos); L.read_flag.push_back((uint16_t)((flag & 0x0fffu) | (clean < cb_len ? LSG_FLAG_CB_SUFFIX : 0u))); L.read_mapq.push_back((uint8_t)mapq);
     L.read_cb.push_back(it->second);
     // CIGAR walk (htslib resolve_cigar2 semantics)
     int64_t x = pos; uint32_t y = 0;

@@ -17,6 +17,9 @@ int run_call(lsg_ctx* c, const lsg_call_params* p);
 int run_fetch_calls(lsg_ctx* c, lsg_call* out, int64_t capacity, int candidates_only, int64_t* n_out);
 int run_select_calls(lsg_ctx* c, int kind, lsg_call* dst_device, int64_t capacity, int64_t* n_out);
 int run_probe(lsg_ctx* c, int kind, const int64_t* keys, int64_t n, uint8_t* hits, int on_device);
+int run_genotype(lsg_ctx* c, const lsg_genotype_params* p, int64_t n_sites, const int64_t* site_keys, const uint8_t* alt_sym,
+                 uint32_t* dp, uint32_t* alt, int on_device);
+int run_sf4(lsg_ctx* c, int64_t items, const uint32_t* k, const uint32_t* n, double al, double be, int32_t* out);
 
 // copy a host array to a grow-only device buffer, or adopt a device pointer
 template <class T>
@@ -265,6 +268,19 @@ int lsg_probe_posset(lsg_ctx* c, int32_t kind, const int64_t* keys, int64_t n, u
     if (!c || kind < 0 || kind >= 3 || n < 0 || (n > 0 && (!keys || !hits))) { set_error("lsg_probe_posset: bad arguments"); return -2; }
     LSG_HIP(hipSetDevice(c->device));
     return run_probe(c, kind, keys, n, hits, on_device);
+}
+
+int lsg_genotype_cells(lsg_ctx* c, const lsg_genotype_params* params, int64_t n_sites, const int64_t* site_keys,
+                       const uint8_t* alt_sym, uint32_t* dp, uint32_t* alt, int32_t on_device) {
+    if (!c || !params) { set_error("lsg_genotype_cells: bad arguments"); return -2; }
+    LSG_HIP(hipSetDevice(c->device));
+    return run_genotype(c, params, n_sites, site_keys, alt_sym, dp, alt, on_device);
+}
+
+int lsg_betabinom_sf4(lsg_ctx* c, int64_t n_items, const uint32_t* k, const uint32_t* n, double alpha, double beta, int32_t* out_p4) {
+    if (!c) { set_error("lsg_betabinom_sf4: NULL handle"); return -2; }
+    LSG_HIP(hipSetDevice(c->device));
+    return run_sf4(c, n_items, k, n, alpha, beta, out_p4);
 }
 
 } // extern "C"

@@ -129,6 +129,7 @@ class Engine:
         ct = np.ascontiguousarray(celltype_of, dtype=np.uint8)
         _lib.check(self._lib.lsg_set_barcodes(self._h, _ptr(ct), len(ct), int(n_celltypes)), "lsg_set_barcodes")
         self.n_ct = int(n_celltypes)
+        self.n_cb = len(ct)
 
     def load_reads(self, rec: ReadRecords):
         r = Reads(rec.n_reads, rec.n_segs, rec.n_events, *[_ptr(getattr(rec, n)) for n, _ in ReadRecords._SPEC], 0)
@@ -236,6 +237,29 @@ class Engine:
             return
         keys = np.ascontiguousarray(keys, dtype=np.int64)
         _lib.check(self._lib.lsg_load_posset(self._h, kind, _ptr(keys), len(keys), 0), "lsg_load_posset")
+
+    def genotype_cells(self, site_keys, alt_sym, params=None):
+        """Per-cell (Dp, Alt) at target sites (HCCVSingleCellGenotype.py:82-220).  site_keys = (tid << 32) | pos0, strictly
+        ascending; alt_sym = expected alt symbol class per site.  Returns two uint32 arrays [n_sites, n_cb]."""
+        from ._lib import GenotypeParams
+        params = params or GenotypeParams.longsom_defaults()
+        site_keys = np.ascontiguousarray(site_keys, dtype=np.int64)
+        alt_sym = np.ascontiguousarray(alt_sym, dtype=np.uint8)
+        assert len(site_keys) == len(alt_sym)
+        dp = np.zeros((len(site_keys), self.n_cb), np.uint32)
+        alt = np.zeros((len(site_keys), self.n_cb), np.uint32)
+        if len(site_keys):
+            _lib.check(self._lib.lsg_genotype_cells(self._h, C.byref(params), len(site_keys), _ptr(site_keys), _ptr(alt_sym), _ptr(dp), _ptr(alt), 0),
+                       "lsg_genotype_cells")
+        return dp, alt
+
+    def betabinom_sf4(self, k, n, alpha: float, beta: float) -> np.ndarray:
+        """round(betabinom.sf(k - 0.001, n, alpha, beta), 4) * 1e4 as int32, evaluated on the device."""
+        k = np.ascontiguousarray(k, dtype=np.uint32); n = np.ascontiguousarray(n, dtype=np.uint32)
+        out = np.zeros(len(k), np.int32)
+        if len(k):
+            _lib.check(self._lib.lsg_betabinom_sf4(self._h, len(k), _ptr(k), _ptr(n), float(alpha), float(beta), _ptr(out)), "lsg_betabinom_sf4")
+        return out
 
     def probe_posset(self, kind: int, keys) -> np.ndarray:
         keys = np.ascontiguousarray(keys, dtype=np.int64)

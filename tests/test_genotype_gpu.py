@@ -1,0 +1,169 @@
+"""GPU parity of the per-cell genotyping path (HCCVSingleCellGenotype.py) against the events-level
+oracle (bit-exact counts; text compared with scipy-built rows), through the C-ABI and the CLI shim."""
+import dataclasses
+import json
+import math
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from longsom_amd import hostio, reanno, synth
+from longsom_amd._lib import GenotypeParams
+from longsom_amd.synth_simple import random_records
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+A2, B2 = 0.260288007167716, 173.94711910763732
+
+
+def case(seed, n_reads=3000, n_cb=40):
+    rng = np.random.default_rng(seed)
+    lens = np.array([5000, 2500], np.int64)
+    rec = random_records(seed, n_reads, lens, n_cb, hot_regions=[(0, 1000, 1400)], hot_frac=0.5)
+    flag = rec.read_flag.copy()
+    flag[rng.random(rec.n_reads) < 0.1] |= 0x8000          # raw CB carried a "-suffix"
+    rec = dataclasses.replace(rec, read_flag=flag)
+    celltype_of = rng.integers(0, 2, n_cb).astype(np.uint8)
+    celltype_of[rng.random(n_cb) < 0.1] = 255
+    sites = sorted(set([(0, int(p)) for p in rng.integers(1000, 1400, 40)] + [(0, int(p)) for p in rng.integers(0, 5000, 15)] +
+                       [(1, int(p)) for p in rng.integers(0, 2500, 15)] + [(0, 0), (1, 2499)]))
+    keys = np.array([(t << 32) | p for t, p in sites], np.int64)
+    alt = rng.integers(0, 7, len(keys)).astype(np.uint8)
+    return rec, lens, celltype_of, keys, alt
+
+
+def load(engine, rec, lens, celltype_of):
+    engine.set_contigs(lens)
+    engine.set_barcodes(celltype_of, 2)
+    engine.load_reads(rec)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(alt_only=1), dict(strict_cb=0, min_bq=0), dict(min_mq=0, min_bq=45, ignore_orphans=0)])
+def test_counts_match_oracle(engine, kw):
+    from oracle import genotype_oracle as go
+    rec, lens, celltype_of, keys, alt = case(11)
+    load(engine, rec, lens, celltype_of)
+    p = GenotypeParams.longsom_defaults(**kw)
+    dp, al = engine.genotype_cells(keys, alt, p)
+    odp, oal = go.genotype(rec, lens, celltype_of, keys, alt, p.min_bq, p.min_mq, p.flag_exclude, p.ignore_orphans, p.alt_only, p.strict_cb)
+    np.testing.assert_array_equal(dp, odp)
+    np.testing.assert_array_equal(al, oal)
+    assert dp.sum() > 1000 and 0 < al.sum() < dp.sum() or p.alt_only
+
+
+def test_empty_and_bad_arguments(engine):
+    rec, lens, celltype_of, keys, alt = case(12, n_reads=200)
+    load(engine, rec, lens, celltype_of)
+    dp, al = engine.genotype_cells(np.zeros(0, np.int64), np.zeros(0, np.uint8))
+    assert dp.shape == (0, len(celltype_of))
+    with pytest.raises(RuntimeError, match="strictly ascending"):
+        engine.genotype_cells(np.array([5, 5], np.int64), np.array([0, 0], np.uint8))
+
+
+def test_betabinom_sf4_equals_scipy_table(engine):
+    t = json.load(open(os.path.join(G, "betabinom_sf_table.json")))
+    n = np.array([r[0] for r in t["rows"]]); k = np.array([r[1] for r in t["rows"]])
+    got = engine.betabinom_sf4(k, n, t["alpha2"], t["beta2"])
+    assert [str(v / 10000.0) for v in got] == [r[2] for r in t["rows"]]
+
+
+def write_variants(path, contig_names, keys, alt):
+    """an HCCV-like table: only the columns the genotyping script reads are meaningful (0,1,3,4,6,13)"""
+    rng = np.random.default_rng(5)
+    order = rng.permutation(len(keys))                     # file order is not sorted
+    with open(path, "w") as f:
+        f.write("##comment\n#CHROM\tStart\tEnd\tREF\tALT\tFILTER\tCell_types\n")
+        for i in order:
+            tid, pos = int(keys[i] >> 32), int(keys[i] & 0xffffffff)
+            a = "ACTGIDN"[alt[i]]
+            f.write("\t".join([contig_names[tid], str(pos + 1), str(pos + 1), "N", a + ",X", "PASS", "Cancer"] + ["."] * 6 + [str(3 + i)] + ["."] * 3) + "\n")
+    return order
+
+
+def expected_text(contig_names, keys, alt, order, table, dp, al, window, chrm_conta):
+    """the reference's loop nest (HCCVSingleCellGenotype.py:243-265,82-216,268-311) over oracle counts"""
+    from oracle import genotype_oracle as go
+    names = [table.celltype_names[int(c)] for c in table.celltype_of]
+    groups = {}
+    for i in order:
+        tid, pos = int(keys[i] >> 32), int(keys[i] & 0xffffffff)
+        groups.setdefault(contig_names[tid] + "_" + str(math.floor((pos + 1) / float(window))), []).append(i)
+    files = {}
+    for code, idx in groups.items():
+        chrom = contig_names[int(keys[idx[0]] >> 32)]
+        target = {}
+        for i in idx:
+            target[int(keys[i] & 0xffffffff)] = i
+        positions = set(target.keys())
+        cells = {pos: None for pos in positions}
+        lines = []
+        for pos in cells.keys():
+            i = target[pos]
+            for cb, bc in enumerate(table.barcodes):
+                lines.append(go.cell_row(chrom, pos, "N", "ACTGIDN"[alt[i]], "Cancer", str(3 + i), bc, names[cb], int(dp[i, cb]), int(al[i, cb]),
+                                         A2, B2, 0.01, chrm_conta))
+        files.setdefault(chrom, {})[min(positions)] = lines
+    out = ["\t".join(reanno.GENOTYPE_HEADER)]
+    for chrom in sorted(files):
+        for start in sorted(files[chrom]):
+            out += files[chrom][start]
+    return "\n".join(out) + "\n"
+
+
+@pytest.mark.parametrize("chrm_conta", ["True", "False"])
+def test_genotype_table_text(engine, tmp_path, chrm_conta):
+    from oracle import genotype_oracle as go
+    rec, lens, celltype_of, keys, alt = case(13)
+    celltype_of = np.where(celltype_of == 255, 1, celltype_of).astype(np.uint8)       # barcodes.tsv lists only typed cells
+    names = ["chr7", "chrM"]
+    load(engine, rec, lens, celltype_of)
+    table = hostio.BarcodeTable(["BC%04d" % i for i in range(len(celltype_of))], celltype_of, ["Cancer", "Non-Cancer"])
+    vf = str(tmp_path / "v.HCCV.tsv")
+    order = write_variants(vf, names, keys, alt)
+    out = str(tmp_path / "g.tsv")
+    n = reanno.single_cell_genotype(engine, vf, table, names, out, window=300, min_bq=30, min_mq=60, alpha2=A2, beta2=B2, pvalue=0.01,
+                                    chrm_contaminant=chrm_conta)
+    odp, oal = go.genotype(rec, lens, celltype_of, keys, alt, 30, 60)
+    want = expected_text(names, keys, alt, order, table, odp, oal, 300, chrm_conta)
+    got = open(out).read()
+    assert n == len(keys) * len(celltype_of) and got == want
+    assert "\tPASS\n" in got and "\tNoAltReads\n" in got and "\tNoCoverage\n" in got
+    if chrm_conta == "True":
+        assert "LowVAFChrM" in got
+
+
+def test_cli_shim_on_a_bam(tmp_path):
+    """HCCVSingleCellGenotype.py on a BAM: every barcode of barcodes.tsv gets a row per site; CB tags carrying a "-1" that the
+    barcodes file does not have are NOT matched by the reference's raw-tag lookup (:160-161) -> no coverage at all."""
+    m = synth.named("C1", n_reads=3000, n_genes=20, n_cb=30, snp_mod=300)
+    bct = str(tmp_path / "barcodes.tsv")
+    hostio.write_barcodes_tsv(bct, hostio.synth_barcodes(m), m.celltype_of, ["Cancer", "Non-Cancer"])
+    rec = hostio.synth_records(m)
+    # target sites: the 12 best covered positions of the first contig with reads
+    tid = int(rec.read_tid[0])
+    cover = np.zeros(int(m.contig_len[tid]) + 1, np.int64)
+    for s in range(rec.n_segs):
+        if rec.read_tid[rec.seg_read[s]] == tid:
+            cover[rec.seg_start[s]] += 1; cover[rec.seg_start[s] + rec.seg_len[s]] -= 1
+    pos = np.sort(np.argsort(np.cumsum(cover)[:-1])[-12:])
+    vf = str(tmp_path / "S1.HCCV.tsv")
+    with open(vf, "w") as f:
+        f.write("#CHROM\tStart\n")
+        for p in pos:
+            f.write("\t".join([m.contig_names[tid], str(p + 1), str(p + 1), "A", "G", "PASS", "Cancer"] + ["."] * 6 + ["4"]) + "\n")
+    outs = {}
+    for tag, suffix in (("plain", ""), ("suffix", "-1")):
+        bam = str(tmp_path / (tag + ".bam"))
+        hostio.synth_bam(m, bam, None, barcode_suffix=suffix)
+        out = str(tmp_path / (tag + ".tsv"))
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "workflow", "scripts_gpu", "CellTypeReannotation", "HCCVSingleCellGenotype.py"), "--bam", bam,
+                               "--infile", vf, "--ref", "/unused.fa", "--meta", bct, "--outfile", out, "--min_mq", "60", "--tmp_dir", str(tmp_path / ("tmp_" + tag)),
+                               "--nprocs", "4", "--alpha2", str(A2), "--beta2", str(B2), "--pvalue", "0.01", "--chrM_contaminant", "True", "--alt_flag", "All"], cwd=ROOT)
+        outs[tag] = open(out).read().split("\n")
+    assert len(outs["plain"]) == 1 + 12 * 30 + 1
+    assert sum(1 for l in outs["plain"][1:] if l and not l.endswith("NoCoverage")) > 50
+    assert all(l.endswith("NoCoverage") for l in outs["suffix"][1:] if l)

@@ -247,5 +247,77 @@ def main():
     print("wrote", sorted(os.listdir(OUT)))
 
 
+def reanno_goldens():
+    """G5-G7: the re-annotation pass, by running the reference's own pandas code.
+      G5  HighConfidenceCancerVariants.HCCV_SNV on sample.calling.step2.tsv, LongSom's config values and a loose variant
+      G6  CellTypeReannotation (collect_* / write_*) on a synthetic per-cell genotype table + barcodes + fusion table
+      G7  scipy's betabinom.sf(k - 0.001, n, alpha2, beta2), the per-cell test of HCCVSingleCellGenotype.py:204"""
+    import contextlib, io
+    import pandas as pd
+    hccv = load("CellTypeReannotation/HighConfidenceCancerVariants.py", "ref_hccv")
+    rean = load("CellTypeReannotation/CellTypeReannotation.py", "ref_reanno")
+    s2 = os.path.join(OUT, "sample.calling.step2.tsv")
+    for tag, args in (("sample", (50, 0.2, 0.25, 10000)), ("sample.loose", (5, 0.05, 0.1, 400))):
+        out = os.path.join(OUT, tag + ".HCCV.tsv")
+        for suffix in ("", "2", "3"):
+            if os.path.exists(out + suffix):
+                os.remove(out + suffix)
+        with contextlib.redirect_stdout(io.StringIO()):
+            hccv.HCCV_SNV(s2, out, *args)
+    # G6: a genotype table over 12 sites x 60 cells
+    rng = np.random.default_rng(77)
+    cells = ["".join(rng.choice(list("ACGT"), size=16)) for _ in range(60)]
+    bar = os.path.join(OUT, "reanno.barcodes.tsv")
+    with open(bar, "w") as f:
+        f.write("Index\tCell_type\tNote\n")
+        for i, c in enumerate(cells):
+            f.write("%s\t%s\tn%d\n" % (c, "Cancer" if rng.random() < 0.4 else "Non-Cancer", i))
+    geno = os.path.join(OUT, "reanno.SNVs.SingleCellGenotype.tsv")
+    with open(geno, "w") as f:
+        f.write("\t".join(["#CHROM", "Start", "End", "REF", "ALT_expected", "Cell_type_expected", "Num_cells_expected", "CB",
+                           "Cell_type_observed", "Dp", "ALT", "VAF", "BetaBin", "MutationStatus"]) + "\n")
+        for site in range(12):
+            chrom = "chrM" if site >= 10 else "chr%d" % (1 + site % 3)
+            pos = 1000 + 37 * site
+            for ci, c in enumerate(cells):
+                cov = rng.random() < (0.15 + 0.7 * (ci % 5) / 4)
+                if not cov:
+                    row = ["0", "0", ".", ".", "NoCoverage"]
+                else:
+                    dp = int(rng.integers(1, 30)); alt = int(rng.binomial(dp, 0.5)) if rng.random() < 0.45 else 0
+                    if alt == 0:
+                        row = [str(dp), "0", "0.0", ".", "NoAltReads"]
+                    else:
+                        st = rng.choice(["PASS", "BetaBin_problem", "LowVAFChrM"], p=[0.7, 0.2, 0.1])
+                        row = [str(dp), str(alt), str(round(alt / dp, 4)), "." if st == "LowVAFChrM" else str(round(float(rng.random()) * 0.02, 4)), str(st)]
+                f.write("\t".join([chrom, str(pos), str(pos), "A", "G", "Cancer", "7", c, "Cancer"] + row) + "\n")
+    fus = os.path.join(OUT, "reanno.Fusions.SingleCellGenotype.tsv")
+    with open(fus, "w") as f:
+        f.write("#FusionName\tBC\tLeftBreakpoint\n")
+        for i in (3, 3, 8, 21, 21, 40, 59):
+            f.write("GENEA--GENEB\t%s\tchr1:%d\n" % (cells[i], i))
+        f.write("GENEC--GENED\t%s\tchr2:5\n" % cells[3])
+        f.write("GENEC--GENED\tTTTTTTTTTTTTTTTT\tchr2:5\n")
+    for tag, fusion_file, mv, mf in (("reanno", fus, 3, 0.25), ("reanno.nofusion", "", 2, 0.5)):
+        mutated, cov, cov_min = rean.collect_cells_with_SNVs(geno, mv)
+        with_f = rean.collect_cells_with_fusions(fusion_file) if fusion_file else []
+        cancer = rean.collect_cancer_cells(mutated, with_f, cov, mv, mf)
+        rean.write_reannotated_cell_types(cancer, cov_min, bar, os.path.join(OUT, tag + ".ReannotatedCellTypes.tsv"))
+    # G7
+    from scipy.stats import betabinom
+    a2, b2 = 0.260288007167716, 173.94711910763732
+    tab = []
+    for n in (1, 2, 3, 5, 8, 13, 30, 64, 65, 200, 1500, 40000):
+        for k in sorted(set([1, 2, 3, n // 4 + 1, n // 2, n // 2 + 1, n - 1, n])):
+            if 1 <= k <= n:
+                tab.append([n, k, str(round(betabinom.sf(k - 0.001, n, a2, b2), 4))])
+    json.dump({"alpha2": a2, "beta2": b2, "rows": tab}, open(os.path.join(OUT, "betabinom_sf_table.json"), "w"))
+    print("wrote the re-annotation goldens")
+
+
 if __name__ == "__main__":
-    main()
+    if "--reanno-only" in sys.argv:
+        reanno_goldens()
+    else:
+        main()
+        reanno_goldens()
