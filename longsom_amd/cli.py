@@ -211,3 +211,18 @@ def snv(argv=None):
     params = pipeline.SnvParams(**{k: getattr(a, k) for k in vars(d)})
     out = pipeline.run_snv(a.bam, a.meta, a.ref, a.outdir, a.id, params, a.editing, a.pon_SR, a.pon_LR, a.gnomAD_json, a.device)
     print(json.dumps({"outputs": {k: v for k, v in vars(out).items() if k != "timings"}, "seconds": out.timings}))
+
+
+def reannotation(argv=None):
+    """Fused two-pass loop: pass-1 calling, HCCV, per-cell genotyping, re-annotation, pass-2 calling; the BAM is decoded and loaded
+    once (workflow/rules/CellTypeReannotation.gpu.smk)."""
+    ap = argparse.ArgumentParser(description="CellTypeReannotation + SNVCalling of LongSom on one GPU, reads resident across both passes")
+    ap.add_argument("--bam", required=True); ap.add_argument("--meta", required=True); ap.add_argument("--ref", required=True)
+    ap.add_argument("--id", required=True); ap.add_argument("--outdir", required=True); ap.add_argument("--fusions")
+    ap.add_argument("--editing"); ap.add_argument("--pon_SR"); ap.add_argument("--pon_LR"); ap.add_argument("--gnomAD_json")
+    ap.add_argument("--device", type=int, default=0)
+    a = ap.parse_args(argv)
+    out = pipeline.run_reannotation(a.bam, a.meta, a.ref, a.outdir, a.id, fusions_tsv=a.fusions, editing=a.editing, pon_sr=a.pon_SR, pon_lr=a.pon_LR,
+                                    gnomad_af_json=a.gnomAD_json, device=a.device)
+    print(json.dumps({"hccv": out.hccv, "genotype": out.genotype, "barcodes": out.barcodes, "cells_kept": out.n_cells_kept, "cancer_cells": out.n_cancer,
+                      "pass2_step3": out.pass2.step3 if out.pass2 else None, "seconds": out.timings}))

@@ -43,6 +43,7 @@ struct Local {   // per-thread decode output
     std::vector<uint32_t> seg_read; std::vector<int32_t> seg_start, seg_len; std::vector<int64_t> seg_ev_off;
     std::vector<uint16_t> events;
     int64_t total = 0, pass = 0, cb_not_found = 0, cb_not_matched = 0, mapq = 0;
+    std::vector<int64_t> cb_pass, cb_low;      // per dense barcode id: matched reads with MAPQ >= / < min_mapq (report of a later table)
 };
 
 inline bool is_ref_op(uint32_t op) { return op == 0 || op == 2 || op == 3 || op == 7 || op == 8; }
@@ -108,6 +109,7 @@ void decode_record(const uint8_t* rec, uint32_t len, const std::unordered_map<st
     auto it = cbmap.find(std::string(cb, clean));
     if (it == cbmap.end()) { ++L.cb_not_matched; return; }
     if ((int)mapq < min_mapq) ++L.mapq; else ++L.pass;                             // report only; the device re-applies min_mq
+    if ((size_t)it->second < L.cb_pass.size()) { if ((int)mapq < min_mapq) ++L.cb_low[(size_t)it->second]; else ++L.cb_pass[(size_t)it->second]; }
     if ((flag & 0x4) || n_cigar == 0) return;                                      // no alignment: nothing to pile up
     const uint32_t r = (uint32_t)L.read_tid.size();
     // SAM flags use 12 bits; bit 15 records that the raw CB carried a "-suffix" (the genotyping script looks the RAW tag up, lsg_genotype_cells)
@@ -183,6 +185,7 @@ typedef struct {
     int32_t n_contigs; char* contig_names;   /* '\n'-joined */ int64_t* contig_len;
     int64_t total_reads, pass_reads, cb_not_found, cb_not_matched, mapq_filtered;
     int32_t n_barcodes; char* barcodes;      /* auto-barcode mode: the distinct cleaned CBs found, '\n'-joined, id = order of first appearance */
+    int64_t n_tally; int64_t* cb_pass; int64_t* cb_low;   /* per dense barcode id (listed-barcode mode): matched reads with MAPQ >= / < min_mapq */
 } lsio_decoded;
 
 const char* lsio_last_error(void) { return g_err; }
@@ -191,7 +194,7 @@ void lsio_free_decoded(lsio_decoded* d) {
     if (!d) return;
     free(d->read_tid); free(d->read_pos); free(d->read_flag); free(d->read_mapq); free(d->read_cb);
     free(d->seg_read); free(d->seg_start); free(d->seg_len); free(d->seg_ev_off); free(d->events);
-    free(d->contig_names); free(d->contig_len); free(d->barcodes);
+    free(d->contig_names); free(d->contig_len); free(d->barcodes); free(d->cb_pass); free(d->cb_low);
     free(d);
 }
 
@@ -292,6 +295,8 @@ int lsio_decode_bam(const char* path, const char* barcodes, int32_t n_barcodes, 
     // parallel decode of contiguous record ranges
     const int T = (int)std::min<size_t>((size_t)n_threads, std::max<size_t>(1, recs.size() / 1024));
     std::vector<Local> loc((size_t)T);
+    int64_t n_tally = 0;
+    if (n_barcodes > 0) { for (auto& kv : cbmap) n_tally = kv.second + 1 > n_tally ? kv.second + 1 : n_tally; for (auto& l : loc) { l.cb_pass.assign((size_t)n_tally, 0); l.cb_low.assign((size_t)n_tally, 0); } }
     {
         std::vector<std::thread> th;
         for (int t = 0; t < T; ++t)
@@ -324,6 +329,9 @@ int lsio_decode_bam(const char* path, const char* barcodes, int32_t n_barcodes, 
         o->total_reads += l.total; o->pass_reads += l.pass; o->cb_not_found += l.cb_not_found; o->cb_not_matched += l.cb_not_matched;
         o->mapq_filtered += l.mapq;
     }
+    o->n_tally = n_tally;
+    o->cb_pass = (int64_t*)calloc((size_t)(n_tally ? n_tally : 1), 8); o->cb_low = (int64_t*)calloc((size_t)(n_tally ? n_tally : 1), 8);
+    for (auto& l : loc) for (size_t i = 0; i < l.cb_pass.size(); ++i) { o->cb_pass[i] += l.cb_pass[i]; o->cb_low[i] += l.cb_low[i]; }
     o->n_contigs = (int32_t)n_ref;
     o->contig_names = (char*)malloc(names.size() + 1); memcpy(o->contig_names, names.c_str(), names.size() + 1);
     o->contig_len = dup_vec(lens);

@@ -28,6 +28,7 @@ class Decoded(C.Structure):
         ("total_reads", C.c_int64), ("pass_reads", C.c_int64), ("cb_not_found", C.c_int64), ("cb_not_matched", C.c_int64),
         ("mapq_filtered", C.c_int64),
         ("n_barcodes", C.c_int32), ("barcodes", C.c_char_p),
+        ("n_tally", C.c_int64), ("cb_pass", C.c_void_p), ("cb_low", C.c_void_p),
     ]
 
 
@@ -99,6 +100,19 @@ class DecodedBam:
     contig_len: np.ndarray
     report: Dict[str, int]         # the counters of SplitBamCellTypes' report.txt (:62,117-124)
     barcodes: Optional[List[str]] = None   # auto-barcode mode: the distinct cleaned CBs found (dense id = index)
+    cb_pass: Optional[np.ndarray] = None   # listed-barcode mode: per barcode id, matched reads with MAPQ >= min_mapq ...
+    cb_low: Optional[np.ndarray] = None    # ... and below it (for the report of a re-annotated barcode table)
+
+    def report_for(self, keep: np.ndarray) -> Dict[str, int]:
+        """SplitBamCellTypes' report had the barcode table listed only the barcodes where `keep` is set (re-annotation pass 2)."""
+        keep = np.asarray(keep, bool)
+        dropped = int(self.cb_pass[~keep].sum() + self.cb_low[~keep].sum())
+        rep = {"Total_reads": self.report["Total_reads"], "Pass_reads": int(self.cb_pass[keep].sum()), "CB_not_found": self.report["CB_not_found"],
+               "CB_not_matched": self.report["CB_not_matched"] + dropped}
+        low = int(self.cb_low[keep].sum())
+        if low:
+            rep["MAPQ"] = low
+        return rep
 
 
 def decode_bam(path: str, barcodes: Optional[Sequence[str]], min_mapq: int = 60, threads: int = 0) -> DecodedBam:
@@ -123,7 +137,8 @@ def decode_bam(path: str, barcodes: Optional[Sequence[str]], min_mapq: int = 60,
         if d.mapq_filtered:
             rep["MAPQ"] = d.mapq_filtered
         found = d.barcodes.decode().split("\n")[: d.n_barcodes] if barcodes is None else None
-        return DecodedBam(rec, names, lens, rep, found)
+        tally = lambda ptr: np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_int64)), shape=(len(barcodes),)).copy() if barcodes is not None and d.n_tally >= len(barcodes) and len(barcodes) else None
+        return DecodedBam(rec, names, lens, rep, found, tally(d.cb_pass), tally(d.cb_low))
     finally:
         lib.lsio_free_decoded(out)
 

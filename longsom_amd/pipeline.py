@@ -68,14 +68,21 @@ def write_report(path: str, report: Dict[str, int], seconds: float) -> None:
     pd.DataFrame([d]).to_csv(path, index=False, sep="\t")
 
 
-def run_snv(bam: str, barcodes_tsv: str, ref_fasta: str, out_dir: str, sample_id: str, params: Optional[SnvParams] = None,
-            editing: Optional[str] = None, pon_sr: Optional[str] = None, pon_lr: Optional[str] = None,
-            gnomad_af_json: Optional[str] = None, device: int = 0, engine: Optional[Engine] = None) -> SnvOutputs:
-    params = params or SnvParams()
+@dataclass
+class Resident:
+    """One sample decoded once and resident on the GPU: contigs, reference, reads; the barcode table is swapped per pass."""
+    engine: Engine
+    dec: "hostio.DecodedBam"
+    table: "hostio.BarcodeTable"           # the table the BAM was decoded against (dense barcode ids)
+    contig_names: List[str]
+    seconds: Dict[str, float]
+
+
+def load_sample(bam: str, barcodes_tsv: str, ref_fasta: str, engine: Engine, min_mapq: int) -> Resident:
     t = {}
     t0 = time.time()
     bc = hostio.read_barcodes(barcodes_tsv)
-    dec = hostio.decode_bam(bam, bc.barcodes, min_mapq=params.min_mapping_quality)
+    dec = hostio.decode_bam(bam, bc.barcodes, min_mapq=min_mapq)
     names_fa, seqs = tsvio.read_fasta(ref_fasta)
     seq_of = dict(zip(names_fa, seqs))
     # the pileup is driven by the FASTA's contigs (MakeWindows, BaseCellCounter.py:84-86); BAM tids index dec.contig_names
@@ -84,57 +91,161 @@ def run_snv(bam: str, barcodes_tsv: str, ref_fasta: str, out_dir: str, sample_id
         if n not in seq_of or len(seq_of[n]) != int(l):
             raise ValueError("contig %s of the BAM header is missing from %s or has another length" % (n, ref_fasta))
     t["decode"] = time.time() - t0
+    t0 = time.time()
+    engine.set_contigs(dec.contig_len)
+    for tid, n in enumerate(contig_names):
+        engine.load_reference(tid, seq_of[n])
+    engine.set_barcodes(bc.celltype_of, len(bc.celltype_names))
+    engine.set_region()
+    engine.load_reads(dec.records)
+    t["load"] = time.time() - t0
+    return Resident(engine, dec, bc, contig_names, t)
+
+
+def run_chain(res: Resident, celltype_of: np.ndarray, celltype_names: List[str], report: Dict[str, int], out_dir: str, sample_id: str,
+              params: SnvParams, editing: Optional[str] = None, pon_sr: Optional[str] = None, pon_lr: Optional[str] = None,
+              gnomad_af_json: Optional[str] = None) -> SnvOutputs:
+    """SplitBam report -> BaseCellCounter -> MergeCounts -> BaseCellCalling step 1-3 for one barcode -> cell-type table over the
+    resident reads (celltype_of[barcode id] = index into celltype_names, 255 = barcode not listed)."""
+    eng, contig_names = res.engine, res.contig_names
+    t = dict(res.seconds)
+    t0 = time.time()
+    eng.set_barcodes(celltype_of, len(celltype_names))
+    eng.pileup_count(params.count())
+    n_sites, n_cand = eng.call_step1(params.call())
+    t["gpu_count_call"] = time.time() - t0
+    t0 = time.time()
+    per_ct = [eng.fetch_counts(ct) for ct in range(len(celltype_names))]
+    calls = eng.fetch_calls()
+    t["fetch"] = time.time() - t0
+    t0 = time.time()
+    d = {k: os.path.join(out_dir, k) for k in ("SplitBam", "BaseCellCounter/" + sample_id, "MergeCounts", "BaseCellCalling")}
+    for p in d.values():
+        os.makedirs(p, exist_ok=True)
+    out = SnvOutputs(report=os.path.join(d["SplitBam"], sample_id + ".report.txt"), counts={}, merged="", step1="", step2="", step3="",
+                     step3_unfiltered="")
+    write_report(out.report, report, t["decode"])
+    date = tsvio.file_date()
+    for ct, name in enumerate(celltype_names):
+        p = os.path.join(d["BaseCellCounter/" + sample_id], "%s.%s.tsv" % (sample_id, name))
+        with open(p, "w") as f:
+            f.write(tsvio.format_counts_tsv(*per_ct[ct], contig_names, "%s.%s" % (sample_id, name), date))
+        out.counts[name] = p
+    merged_text = tsvio.format_merged_tsv(per_ct, contig_names, celltype_names, date)
+    out.merged = os.path.join(d["MergeCounts"], sample_id + ".BaseCellCounts.AllCellTypes.tsv")
+    open(out.merged, "w").write(merged_text)
+    header = [l + "\n" for l in merged_text.split("\n") if l.startswith("##")]
+    s1 = tsvio.format_step1_tsv(calls, per_ct, contig_names, celltype_names, header)
+    out.step1 = os.path.join(d["BaseCellCalling"], sample_id + ".calling.step1.tsv")
+    open(out.step1, "w").write(s1)
+    keys = [calling.read_posset_keys(p, contig_names, params.reference_gz_compat) for p in (editing, pon_sr, pon_lr)]
+    af = json.load(open(gnomad_af_json)) if gnomad_af_json else None
+    s2 = calling.step2(s1, eng, contig_names, keys[0], keys[1], keys[2], params.min_distance, af, params.max_gnomad_vaf)
+    out.step2 = os.path.join(d["BaseCellCalling"], sample_id + ".calling.step2.tsv")
+    open(out.step2, "w").write(s2)
+    final, unfiltered = calling.step3(s2, params.delta_vaf, params.delta_mcf, params.min_ac_reads, params.min_ac_cells, params.clust_dist)
+    out.step3 = os.path.join(d["BaseCellCalling"], sample_id + ".calling.step3.tsv")
+    out.step3_unfiltered = os.path.join(d["BaseCellCalling"], sample_id + ".calling.step3.unfiltered.tsv")
+    open(out.step3, "w").write(final)
+    open(out.step3_unfiltered, "w").write(unfiltered)
+    t["format_write"] = time.time() - t0
+    out.timings = t
+    return out
+
+
+def run_snv(bam: str, barcodes_tsv: str, ref_fasta: str, out_dir: str, sample_id: str, params: Optional[SnvParams] = None,
+            editing: Optional[str] = None, pon_sr: Optional[str] = None, pon_lr: Optional[str] = None,
+            gnomad_af_json: Optional[str] = None, device: int = 0, engine: Optional[Engine] = None) -> SnvOutputs:
+    params = params or SnvParams()
     own = engine is None
     eng = engine or Engine(device)
     try:
+        res = load_sample(bam, barcodes_tsv, ref_fasta, eng, params.min_mapping_quality)
+        return run_chain(res, res.table.celltype_of, res.table.celltype_names, res.dec.report, out_dir, sample_id, params, editing, pon_sr, pon_lr,
+                         gnomad_af_json)
+    finally:
+        if own:
+            eng.close()
+
+
+@dataclass
+class ReannoParams:
+    """config/config.yaml:40-68 (Reanno block): pass-1 chain parameters + HCCV + re-annotation."""
+    chain: SnvParams = field(default_factory=lambda: SnvParams(min_ac_cells=5, min_ac_reads=20))     # Reanno.BaseCellCalling
+    hccv_min_depth: float = 50
+    hccv_delta_vaf: float = 0.2
+    hccv_delta_mcf: float = 0.25
+    hccv_clust_dist: int = 10000
+    chrm_contaminant: str = "False"
+    alt_flag: str = "All"
+    pvalue: float = 0.01
+    genotype_min_bq: int = 30
+    min_variants: int = 3
+    min_fraction: float = 0.25
+
+
+@dataclass
+class ReannoOutputs:
+    pass1: SnvOutputs
+    hccv: str
+    genotype: str
+    barcodes: str
+    pass2: Optional[SnvOutputs]
+    n_cells_kept: int = 0
+    n_cancer: int = 0
+    timings: Dict[str, float] = field(default_factory=dict)
+
+
+def run_reannotation(bam: str, barcodes_tsv: str, ref_fasta: str, out_dir: str, sample_id: str, reanno_params: Optional[ReannoParams] = None,
+                     snv_params: Optional[SnvParams] = None, fusions_tsv: Optional[str] = None, editing: Optional[str] = None,
+                     pon_sr: Optional[str] = None, pon_lr: Optional[str] = None, gnomad_af_json: Optional[str] = None, device: int = 0,
+                     engine: Optional[Engine] = None) -> ReannoOutputs:
+    """The two-pass loop of the workflow (rules/CellTypeReannotation.smk + rules/SNVCalling.smk) in one process: the BAM is
+    decoded and loaded ONCE; pass 1 calls with the automated annotation, the HCCV sites are genotyped per cell on the resident
+    reads, the cells are re-annotated, and pass 2 re-counts the same resident reads under the new barcode table.
+    Files: <out>/CellTypeReannotation/{SplitBam,BaseCellCounter,MergeCounts,BaseCellCalling,HCCV,ReannotatedCellTypes}/... and
+    <out>/SNVCalling/{SplitBam,BaseCellCounter,MergeCounts,BaseCellCalling}/..."""
+    from . import reanno
+    rp = reanno_params or ReannoParams()
+    sp = snv_params or SnvParams()
+    own = engine is None
+    eng = engine or Engine(device)
+    t = {}
+    try:
+        res = load_sample(bam, barcodes_tsv, ref_fasta, eng, rp.chain.min_mapping_quality)
+        d1 = os.path.join(out_dir, "CellTypeReannotation")
+        p1 = run_chain(res, res.table.celltype_of, res.table.celltype_names, res.dec.report, d1, sample_id, rp.chain, editing, pon_sr, pon_lr, gnomad_af_json)
         t0 = time.time()
-        eng.set_contigs(dec.contig_len)
-        for tid, n in enumerate(contig_names):
-            eng.load_reference(tid, seq_of[n])
-        eng.set_barcodes(bc.celltype_of, len(bc.celltype_names))
-        eng.set_region()
-        eng.load_reads(dec.records)
-        t["load"] = time.time() - t0
+        os.makedirs(os.path.join(d1, "HCCV"), exist_ok=True)
+        hccv = reanno.hccv_filter(p1.step2, os.path.join(d1, "HCCV", sample_id), rp.hccv_min_depth, rp.hccv_delta_vaf, rp.hccv_delta_mcf, rp.hccv_clust_dist)
+        t["hccv"] = time.time() - t0
         t0 = time.time()
-        eng.pileup_count(params.count())
-        n_sites, n_cand = eng.call_step1(params.call())
-        t["gpu_count_call"] = time.time() - t0
+        eng.set_barcodes(res.table.celltype_of, len(res.table.celltype_names))
+        geno = os.path.join(d1, "HCCV", sample_id + ".SNVs.SingleCellGenotype.tsv")
+        n_rows = reanno.single_cell_genotype(eng, hccv, res.table, res.contig_names, geno, alt_flag=rp.alt_flag, min_bq=rp.genotype_min_bq,
+                                             min_mq=rp.chain.min_mapping_quality, alpha2=rp.chain.alpha2, beta2=rp.chain.beta2, pvalue=rp.pvalue,
+                                             chrm_contaminant=rp.chrm_contaminant)
+        t["genotype"] = time.time() - t0
+        out = ReannoOutputs(p1, hccv, geno, "", None, timings=t)
+        if n_rows == 0:                                   # no HCCV: the reference writes no genotype table and the workflow stops here
+            return out
         t0 = time.time()
-        per_ct = [eng.fetch_counts(ct) for ct in range(len(bc.celltype_names))]
-        calls = eng.fetch_calls()
-        t["fetch"] = time.time() - t0
-        t0 = time.time()
-        d = {k: os.path.join(out_dir, k) for k in ("SplitBam", "BaseCellCounter/" + sample_id, "MergeCounts", "BaseCellCalling")}
-        for p in d.values():
-            os.makedirs(p, exist_ok=True)
-        out = SnvOutputs(report=os.path.join(d["SplitBam"], sample_id + ".report.txt"), counts={}, merged="", step1="", step2="", step3="",
-                         step3_unfiltered="")
-        write_report(out.report, dec.report, t["decode"])
-        date = tsvio.file_date()
-        for ct, name in enumerate(bc.celltype_names):
-            p = os.path.join(d["BaseCellCounter/" + sample_id], "%s.%s.tsv" % (sample_id, name))
-            with open(p, "w") as f:
-                f.write(tsvio.format_counts_tsv(*per_ct[ct], contig_names, "%s.%s" % (sample_id, name), date))
-            out.counts[name] = p
-        merged_text = tsvio.format_merged_tsv(per_ct, contig_names, bc.celltype_names, date)
-        out.merged = os.path.join(d["MergeCounts"], sample_id + ".BaseCellCounts.AllCellTypes.tsv")
-        open(out.merged, "w").write(merged_text)
-        header = [l + "\n" for l in merged_text.split("\n") if l.startswith("##")]
-        s1 = tsvio.format_step1_tsv(calls, per_ct, contig_names, bc.celltype_names, header)
-        out.step1 = os.path.join(d["BaseCellCalling"], sample_id + ".calling.step1.tsv")
-        open(out.step1, "w").write(s1)
-        keys = [calling.read_posset_keys(p, contig_names, params.reference_gz_compat) for p in (editing, pon_sr, pon_lr)]
-        af = json.load(open(gnomad_af_json)) if gnomad_af_json else None
-        s2 = calling.step2(s1, eng, contig_names, keys[0], keys[1], keys[2], params.min_distance, af, params.max_gnomad_vaf)
-        out.step2 = os.path.join(d["BaseCellCalling"], sample_id + ".calling.step2.tsv")
-        open(out.step2, "w").write(s2)
-        final, unfiltered = calling.step3(s2, params.delta_vaf, params.delta_mcf, params.min_ac_reads, params.min_ac_cells, params.clust_dist)
-        out.step3 = os.path.join(d["BaseCellCalling"], sample_id + ".calling.step3.tsv")
-        out.step3_unfiltered = os.path.join(d["BaseCellCalling"], sample_id + ".calling.step3.unfiltered.tsv")
-        open(out.step3, "w").write(final)
-        open(out.step3_unfiltered, "w").write(unfiltered)
-        t["format_write"] = time.time() - t0
-        out.timings = t
+        os.makedirs(os.path.join(d1, "ReannotatedCellTypes"), exist_ok=True)
+        out.barcodes = os.path.join(d1, "ReannotatedCellTypes", sample_id + ".tsv")
+        out.n_cells_kept, out.n_cancer = reanno.celltype_reannotation(geno, fusions_tsv or "", barcodes_tsv, out.barcodes, rp.min_variants, rp.min_fraction)
+        t["reannotation"] = time.time() - t0
+        # pass 2: same resident reads, new barcode -> cell-type table (cells below coverage are no longer listed)
+        if sp.min_mapping_quality != rp.chain.min_mapping_quality:
+            raise ValueError("the two passes must share min_mapping_quality to share one decode (SplitBam report)")
+        if out.n_cells_kept == 0:
+            return out
+        new = hostio.read_barcodes(out.barcodes)
+        idx = {b: i for i, b in enumerate(res.table.barcodes)}
+        ct2 = np.full(len(res.table.barcodes), 255, np.uint8)
+        for b, c in zip(new.barcodes, new.celltype_of):
+            ct2[idx[b]] = c
+        out.pass2 = run_chain(res, ct2, new.celltype_names, res.dec.report_for(ct2 != 255), os.path.join(out_dir, "SNVCalling"), sample_id, sp, editing,
+                              pon_sr, pon_lr, gnomad_af_json)
         return out
     finally:
         if own:

@@ -1,0 +1,82 @@
+### MI355X replacement of the SNV branch of LongSom's workflow/rules/CellTypeReannotation.smk (same OUTPUT files).
+#
+# Option A (fused, recommended): rule Reannotation_gpu runs pass-1 calling -> HCCV -> per-cell genotyping -> re-annotation
+# AND the pass-2 SNV calling (rules/SNVCalling.smk) in ONE process: the BAM is decoded once, the reads stay in HBM, pass 2 only
+# swaps the barcode -> cell-type table.  Option B: the per-rule drop-ins below (same rule names as the reference with a
+# _gpu suffix) keep the reference's rule graph; every script under scripts_gpu/CellTypeReannotation/ has the flag surface
+# of the script it replaces.  The fusion branch (ctat-LR-fusion, HCCVFusions) is unchanged and optional here.
+
+GPU_SCRIPTS = str(workflow.basedir) + "/scripts_gpu"
+
+rule Reannotation_gpu:
+    input:
+        bam=f"{INPUT}/bam/{{id}}.bam",
+        barcodes="Barcodes/{id}.tsv",
+        ref=str(workflow.basedir)+config['Reference']['genome'],
+        pon_LR="PoN/PoN/PoN_LR.tsv" if PON else [],
+        pon_SR=str(workflow.basedir)+config['Reference']['PoN_SR'],
+        RNA_editing=str(workflow.basedir)+config['Reference']['RNA_editing'],
+        fusions="CellTypeReannotation/HCCV/{id}.Fusions.SingleCellGenotype.tsv",
+    output:
+        hccv="CellTypeReannotation/HCCV/{id}.HCCV.tsv",
+        genotype="CellTypeReannotation/HCCV/{id}.SNVs.SingleCellGenotype.tsv",
+        barcodes="CellTypeReannotation/ReannotatedCellTypes/{id}.tsv",
+        step3="SNVCalling/BaseCellCalling/{id}.calling.step3.tsv",
+    params:
+        script=GPU_SCRIPTS+"/CellTypeReannotation/longsom_gpu_reannotation.py",
+    resources:
+        gpu=1
+    log:
+        "logs/Reannotation_gpu/{id}.log",
+    shell:
+        r"""
+        python {params.script} --bam {input.bam} --meta {input.barcodes} --ref {input.ref} --id {wildcards.id} --outdir . \
+        --fusions {input.fusions} --editing {input.RNA_editing} --pon_SR {input.pon_SR} --pon_LR {input.pon_LR} > {log}
+        """
+
+rule HighConfidenceCancerVariants_gpu:
+    input:
+        tsv="CellTypeReannotation/BaseCellCalling/{id}.calling.step2.tsv"
+    output:
+        tsv="CellTypeReannotation/HCCV/{id}.HCCV.tsv"
+    params:
+        script=GPU_SCRIPTS+"/CellTypeReannotation/HighConfidenceCancerVariants.py",
+        h=config['Reanno']['HCCV'],
+    shell:
+        "python {params.script} --SNVs {input.tsv} --outfile CellTypeReannotation/HCCV/{wildcards.id} --min_dp {params.h[min_depth]} "
+        "--deltaVAF {params.h[deltaVAF]} --deltaMCF {params.h[deltaMCF]} --clust_dist {params.h[clust_dist]}"
+
+rule HCCVSingleCellGenotype_gpu:
+    input:
+        tsv="CellTypeReannotation/HCCV/{id}.HCCV.tsv",
+        bam=f"{INPUT}/bam/{{id}}.bam",
+        barcodes="Barcodes/{id}.tsv",
+        ref=str(workflow.basedir)+config['Reference']['genome'],
+    output:
+        tsv="CellTypeReannotation/HCCV/{id}.SNVs.SingleCellGenotype.tsv",
+        tmp=temp(directory("CellTypeReannotation/HCCV/{id}/"))
+    params:
+        script=GPU_SCRIPTS+"/CellTypeReannotation/HCCVSingleCellGenotype.py",
+        h=config['Reanno']['HCCV'],
+        c=config['Reanno']['BaseCellCalling'],
+        mapq=config['Reanno']['BaseCellCounter']['min_mapping_quality'],
+    resources:
+        gpu=1
+    shell:
+        "python {params.script} --bam {input.bam} --infile {input.tsv} --ref {input.ref} --outfile {output.tsv} --meta {input.barcodes} "
+        "--alt_flag {params.h[alt_flag]} --nprocs {threads} --min_mq {params.mapq} --pvalue {params.h[pvalue]} --alpha2 {params.c[alpha2]} "
+        "--beta2 {params.c[beta2]} --chrM_contaminant {params.h[chrM_contaminant]} --tmp_dir {output.tmp}"
+
+rule CellTypeReannotation_gpu:
+    input:
+        SNVs="CellTypeReannotation/HCCV/{id}.SNVs.SingleCellGenotype.tsv",
+        fusions="CellTypeReannotation/HCCV/{id}.Fusions.SingleCellGenotype.tsv",
+        barcodes="Barcodes/{id}.tsv"
+    output:
+        barcodes="CellTypeReannotation/ReannotatedCellTypes/{id}.tsv"
+    params:
+        script=GPU_SCRIPTS+"/CellTypeReannotation/CellTypeReannotation.py",
+        r=config['Reanno']['Reannotation'],
+    shell:
+        "python {params.script} --SNVs {input.SNVs} --fusions {input.fusions} --outfile {output.barcodes} --meta {input.barcodes} "
+        "--min_variants {params.r[min_variants]} --min_frac {params.r[min_fraction]}"
