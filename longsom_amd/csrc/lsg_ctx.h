@@ -45,7 +45,7 @@ struct PosSet { DevBuf keys; int64_t n = 0; };
 // workspace buffers (lsg_ctx::ws)
 enum { WS_UNIT_PLAN = 0, WS_SLOT_PEX, WS_NE_NSLOT, WS_NE_SLOT_BASE, WS_NE_ACC, WS_NE_GEOM, WS_SLOT_W, WS_SLOT_CNT,
        WS_SLOT_OFF, WS_SLOT_CURSOR, WS_ENT, WS_CHUNK_START, WS_REC, WS_SLOT_LIST, WS_MULTI_LIST, WS_MACC, WS_EXPORT_K, WS_EXPORT_R,
-       WS_EXPORT_C, WS_SLICES, WS_HUGE_LIST, WS_CALL_FLAGS, WS_CALL_SEL, WS_CALL_CANDS, WS_CALL_TASKS };
+       WS_EXPORT_C, WS_SLICES, WS_HUGE_LIST, WS_CALL_FLAGS, WS_CALL_SEL, WS_CALL_CANDS, WS_CALL_TASKS, WS_SEG_INFO };
 
 
 } // namespace lsg

@@ -77,6 +77,7 @@ struct CountArgs {
     uint64_t* ne_mask; uint32_t* ne_rowbase;
     uint32_t* slot_w; uint32_t* slot_cnt; uint32_t* slot_off; uint32_t* slot_cursor;
     uint4* ent;                           // entries {key, first event index lo, meta, 0}
+    uint2* seg_info;                      // per segment {admission key, first tile of its contig} (k_seg_info)
     uint2* rec;                           // grouped 8-byte records {event byte offset lo, meta} of the block path, same indexing as ent
     uint32_t* slot_pex; uint32_t* chunk_start;   // wave kernel: work prefix over the small-slot list, first slot of every chunk
     uint32_t* slot_list; uint32_t* multi_list; uint32_t* macc; uint32_t* slices; uint32_t* huge_list;
@@ -140,24 +141,42 @@ constexpr uint32_t BIN_FILL = BIN_H * 5 / 8;
 
 struct BinSeg { uint32_t key, tb, t0; int32_t st, ln, ntile; int64_t evoff; };
 
+// Per-segment admission record {key, first tile of the contig}: the three-level gather segment -> read -> contig tables is
+// done ONCE per count by this streaming kernel; the binning passes (one for the counts, two for the scatter) then read 8
+// coalesced bytes per segment instead of chasing it again with a workgroup's few waves.
+__global__ void k_seg_info(CountArgs a) {
+    unsigned long long n_seg = 0, n_ev = 0;
+    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < a.n_segs; s += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t r = a.seg_read[s];
+        uint32_t key = a.read_key[r], tb = 0;
+        if (key != KEY_INVALID) {
+            const int32_t tid = a.read_tid[r];
+            const int64_t st = a.seg_start[s], ln = a.seg_len[s];
+            if (st < 0 || ln <= 0 || st + ln > a.contig_len[tid]) key = KEY_INVALID;   // malformed: never counted
+            else { tb = a.tile_base[tid]; ++n_seg; n_ev += (unsigned long long)ln; }
+        }
+        a.seg_info[s] = make_uint2(key, tb);
+    }
+    __shared__ unsigned long long s_st[2];
+    if (threadIdx.x == 0) { s_st[0] = 0; s_st[1] = 0; }
+    __syncthreads();
+    for (int o = 32; o > 0; o >>= 1) { n_seg += __shfl_down(n_seg, o); n_ev += __shfl_down(n_ev, o); }
+    if ((threadIdx.x & 63) == 0 && n_seg) { atomicAdd(&s_st[0], n_seg); atomicAdd(&s_st[1], n_ev); }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_st[0]) { atomicAdd(&a.scalars[SC_SEGS], s_st[0]); atomicAdd(&a.scalars[SC_EVENTS], s_st[1]); }
+}
+
 template <int MODE>
 __device__ __forceinline__ BinSeg bin_load(const CountArgs& a, int64_t s) {
     BinSeg g; g.key = KEY_INVALID; g.tb = 0; g.t0 = 0; g.st = 0; g.ln = 0; g.ntile = 0; g.evoff = 0;
-    int32_t tid = 0;
     if (s < a.n_segs) {
-        uint32_t r = a.seg_read[s];
-        g.key = a.read_key[r];
-        tid = a.read_tid[r];
+        const uint2 info = a.seg_info[s];
+        g.key = info.x; g.tb = info.y;
         g.st = a.seg_start[s];
         g.ln = a.seg_len[s];
-        if (g.key != KEY_INVALID) {
-            int64_t clen = a.contig_len[tid];
-            if (g.st < 0 || g.ln <= 0 || (int64_t)g.st + g.ln > clen) g.key = KEY_INVALID;   // malformed: never counted
-        }
         if (MODE == 2 && g.key != KEY_INVALID) g.evoff = a.seg_ev_off[s];
     }
     bool ok = g.key != KEY_INVALID;
-    g.tb = ok ? a.tile_base[tid] : 0;
     uint32_t t0 = g.tb + ((uint32_t)g.st >> 6);
     uint32_t t1 = g.tb + ((uint32_t)(g.st + g.ln - 1) >> 6);
     if (t0 < a.tile_lo) t0 = a.tile_lo;
@@ -176,7 +195,6 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_segments(CountArgs a) {
     const int t = threadIdx.x, lane = t & 63;
     constexpr int HSHIFT = 32 - __builtin_ctz(BIN_H);
     for (int i = t; i < BIN_H; i += BIN_THREADS) { hkey[i] = KEY_INVALID; hcnt[i] = 0; }
-    unsigned long long st_segs = 0, st_evs = 0;
     const int64_t n_batches = (a.n_segs + BIN_THREADS - 1) / BIN_THREADS;
     const int64_t n_super = (n_batches + BIN_SUPER - 1) / BIN_SUPER;
     unsigned long long* qhead = &a.scalars[MODE == 0 ? SC_QBIN0 : SC_QBIN2];
@@ -198,7 +216,6 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_segments(CountArgs a) {
             bool stop = false;
             while (!stop && b < b1) {
                 const BinSeg g = bin_load<MODE>(a, b * BIN_THREADS + t);
-                if (MODE == 0 && r == 0 && g.key != KEY_INVALID) { ++st_segs; st_evs += (unsigned long long)g.ln; }
                 const uint32_t ct = g.key >> 28;
                 const int ni_first = ni;
                 int wmax = g.ntile;
@@ -275,15 +292,6 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_segments(CountArgs a) {
             }
             cb = b; cr = r;
         }
-    }
-    if (MODE == 0) {
-        __shared__ unsigned long long s_st[2];
-        if (t == 0) { s_st[0] = 0; s_st[1] = 0; }
-        __syncthreads();
-        for (int o = 32; o > 0; o >>= 1) { st_segs += __shfl_down(st_segs, o); st_evs += __shfl_down(st_evs, o); }
-        if (lane == 0 && st_segs) { atomicAdd(&s_st[0], st_segs); atomicAdd(&s_st[1], st_evs); }
-        __syncthreads();
-        if (t == 0 && s_st[0]) { atomicAdd(&a.scalars[SC_SEGS], s_st[0]); atomicAdd(&a.scalars[SC_EVENTS], s_st[1]); }
     }
 }
 
@@ -1374,7 +1382,7 @@ static void fill_args(lsg_ctx* c, const lsg_count_params* p, CountArgs& a) {
     a.ne_mask = c->d_ne_mask.as<uint64_t>(); a.ne_rowbase = c->d_ne_rowbase.as<uint32_t>();
     a.slot_w = c->ws[WS_SLOT_W].as<uint32_t>(); a.slot_cnt = c->ws[WS_SLOT_CNT].as<uint32_t>();
     a.slot_off = c->ws[WS_SLOT_OFF].as<uint32_t>(); a.slot_cursor = c->ws[WS_SLOT_CURSOR].as<uint32_t>();
-    a.ent = c->ws[WS_ENT].as<uint4>(); a.rec = c->ws[WS_REC].as<uint2>();
+    a.ent = c->ws[WS_ENT].as<uint4>(); a.rec = c->ws[WS_REC].as<uint2>(); a.seg_info = c->ws[WS_SEG_INFO].as<uint2>();
     a.slot_list = c->ws[WS_SLOT_LIST].as<uint32_t>(); a.multi_list = c->ws[WS_MULTI_LIST].as<uint32_t>();
     a.macc = c->ws[WS_MACC].as<uint32_t>();
     a.slot_pex = c->ws[WS_SLOT_PEX].as<uint32_t>(); a.chunk_start = c->ws[WS_CHUNK_START].as<uint32_t>();
@@ -1427,7 +1435,7 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
         c->ws[WS_NE_GEOM].reserve((ne_cap + 2) * 8) || c->ws[WS_SLOT_W].reserve((slot_cap + 2) * 4) ||
         c->ws[WS_SLOT_CNT].reserve((slot_cap + 2) * 4) || c->ws[WS_SLOT_OFF].reserve((slot_cap + 2) * 4) ||
         c->ws[WS_SLOT_CURSOR].reserve((slot_cap + 2) * 4) || c->ws[WS_SLOT_LIST].reserve((slot_cap + 2) * 4) ||
-        c->ws[WS_MULTI_LIST].reserve((EU / CAPB + 16) * 4) || c->ws[WS_ENT].reserve((EU + 1) * 32 + 64) || c->ws[WS_REC].reserve((EU + 1) * 16 + 256) ||
+        c->ws[WS_MULTI_LIST].reserve((EU / CAPB + 16) * 4) || c->ws[WS_ENT].reserve((EU + 1) * 32 + 64) || c->ws[WS_SEG_INFO].reserve(((size_t)S + 1) * 8) || c->ws[WS_REC].reserve((EU + 1) * 16 + 256) ||
         c->ws[WS_SLICES].reserve((slot_cap + 2) * (NSLICE + 1) * 4) || c->ws[WS_SLOT_PEX].reserve((slot_cap + 2) * 4) ||
         c->ws[WS_CHUNK_START].reserve(((EU + WORK_W0 * slot_cap) / CHUNK_EMIN + 4) * 4) || c->ws[WS_HUGE_LIST].reserve((EU / CAPB + 16) * 4))
         return -1;
@@ -1445,6 +1453,7 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
     unsigned seg_grid = (unsigned)((S + 256 * BIN_SUPER - 1) / (256 * BIN_SUPER));
     if (seg_grid > (unsigned)(c->n_cus * 8)) seg_grid = (unsigned)(c->n_cus * 8);
     if (R > 0) { unsigned g = (unsigned)((R + 255) / 256); if (g > (unsigned)(c->n_cus * 8)) g = (unsigned)(c->n_cus * 8); hipLaunchKernelGGL(k_read_key, dim3(g), dim3(256), 0, st, a); }
+    if (S > 0) { unsigned g = (unsigned)((S + 255) / 256); if (g > (unsigned)(c->n_cus * 16)) g = (unsigned)(c->n_cus * 16); hipLaunchKernelGGL(k_seg_info, dim3(g), dim3(256), 0, st, a); }
     if (S > 0) hipLaunchKernelGGL(k_bin_segments<0>, dim3(seg_grid), dim3(256), 0, st, a);
     SCAN_U32(a.unit_cnt + u_lo, a.unit_off + u_lo, n_range + 1);          // entry regions of buffer A, unit by unit
 
