@@ -10,6 +10,7 @@
 namespace lsg {
 
 constexpr int TILE_W = 64;          // reference positions per tile = one lane per position
+constexpr int ROW_PLANES = 34;      // count-row planes kept in HBM: DP, NC, CC[8], BC[8], BQ[8], BCf[8]; BCr = BC - BCf is derived on export
 constexpr int NCTR = 33;            // accumulators kept per position: NC, CC[8], BC[8], BQ[8], BCf[8]
 
 void set_error(const char* fmt, ...);
@@ -83,7 +84,7 @@ struct lsg_ctx {
     // count-stage workspace
     lsg::DevBuf d_read_key, d_unit_cnt, d_unit_off, d_unit_fill, d_entries;
     lsg::DevBuf d_ne_units, d_ne_mask, d_ne_rowbase, d_ne_rowoff, d_deep_list, d_scalars, d_cub_tmp;
-    lsg::DevBuf d_rows[LSG_MAX_CELLTYPES]; // SoA planes [42][row_cap]
+    lsg::DevBuf d_rows[LSG_MAX_CELLTYPES]; // SoA planes [ROW_PLANES][row_cap]
     lsg::DevBuf d_rowkey[LSG_MAX_CELLTYPES];
     uint64_t row_cap = 0;
     uint32_t n_ne = 0, n_deep = 0;

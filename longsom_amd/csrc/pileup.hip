@@ -794,7 +794,6 @@ __device__ __forceinline__ void emit_unit(const CountArgs& a, const CNT& acc, ui
         out[(10 + s) * cap + row] = b;
         out[(18 + s) * cap + row] = acc.BQ(s);
         out[(26 + s) * cap + row] = f;
-        out[(34 + s) * cap + row] = b - f;
     }
 }
 
@@ -1539,7 +1538,7 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
     want_rows += (uint64_t)(grid_block + grid_walk + grid_wave * WAVES_PER_BLOCK) * ARENA + 64;
     if (want_rows > c->row_cap) {
         for (int i = 0; i < c->n_ct; ++i)
-            if (c->d_rows[i].reserve((size_t)want_rows * LSG_ROW_WORDS * 4)) return -1;
+            if (c->d_rows[i].reserve((size_t)want_rows * ROW_PLANES * 4)) return -1;
         c->row_cap = want_rows;
     }
     fill_args(c, p, a);
@@ -1609,7 +1608,9 @@ __global__ void k_export_rows(CountArgs a, int ct, const uint32_t* rowoff, int64
     int64_t pos = (int64_t)geom.x + lane;
     keys[dst] = ((int64_t)tid << 32) | pos;
     refs[dst] = a.ref_ptr[tid][pos];
-    for (int k = 0; k < LSG_ROW_WORDS; ++k) counts[dst * LSG_ROW_WORDS + k] = a.rows[ct][(uint64_t)k * a.row_cap + src];
+    for (int k = 0; k < ROW_PLANES; ++k) counts[dst * LSG_ROW_WORDS + k] = a.rows[ct][(uint64_t)k * a.row_cap + src];
+    for (int sy = 0; sy < 8; ++sy)                             // BCr = BC - BCf is not stored
+        counts[dst * LSG_ROW_WORDS + 34 + sy] = counts[dst * LSG_ROW_WORDS + 10 + sy] - counts[dst * LSG_ROW_WORDS + 26 + sy];
 }
 
 int run_fetch_counts(lsg_ctx* c, int ct, int64_t* keys, uint8_t* ref, uint32_t* counts, int64_t capacity) {
