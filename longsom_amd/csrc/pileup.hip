@@ -782,18 +782,24 @@ __device__ __forceinline__ void emit_unit(const CountArgs& a, const CNT& acc, ui
         return;
     }
     if (!emit) return;
-    uint64_t row = (uint64_t)base + __popcll(em & ((1ull << lane) - 1ull));
-    uint32_t* out = a.rows[ct];
-    const uint64_t cap = a.row_cap;
-    out[0 * cap + row] = dp;
-    out[1 * cap + row] = nc;
+    // plane p of this unit starts at a wave-uniform address (scalar registers); the lane only adds its 32-bit row offset
+    const uint32_t off4 = 4u * (uint32_t)__popcll(em & ((1ull << lane) - 1ull));
+    const uint64_t plane_bytes = a.row_cap * 4ull;
+    const uint64_t first = (uint64_t)(uintptr_t)a.rows[ct] + (uint64_t)base * 4ull;
+    const uint64_t p0 = ((uint64_t)rl((uint32_t)(first >> 32), 0) << 32) | rl((uint32_t)first, 0);
+    auto put = [&](int plane, uint32_t v) {                          // buffer store: scalar descriptor per plane, no per-lane address arithmetic
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>((uintptr_t)(p0 + (uint64_t)plane * plane_bytes)), 0, (int)(k * 4u), 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b32(v, rs, (int)off4, 0, 0);
+    };
+    put(0, dp);
+    put(1, nc);
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
         const uint32_t b = acc.BC(s), f = acc.BCF(s);
-        out[(2 + s) * cap + row] = b - acc.DUP(s);
-        out[(10 + s) * cap + row] = b;
-        out[(18 + s) * cap + row] = acc.BQ(s);
-        out[(26 + s) * cap + row] = f;
+        put(2 + s, b - acc.DUP(s));
+        put(10 + s, b);
+        put(18 + s, acc.BQ(s));
+        put(26 + s, f);
     }
 }
 
@@ -1536,6 +1542,10 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
         if (by_depth < want_rows) want_rows = by_depth;
     }
     want_rows += (uint64_t)(grid_block + grid_walk + grid_wave * WAVES_PER_BLOCK) * ARENA + 64;
+    // plane stride: a row's 34 stores go to addresses one stride apart; keep the stride off every power-of-two multiple
+    // (17 x 256 B modulo 8 KB) so that the planes of a unit spread over the HBM channels whatever their interleave
+    want_rows = (want_rows + 63) / 64 * 64;
+    want_rows += ((17 + 32 - (want_rows / 64) % 32) % 32) * 64;
     if (want_rows > c->row_cap) {
         for (int i = 0; i < c->n_ct; ++i)
             if (c->d_rows[i].reserve((size_t)want_rows * ROW_PLANES * 4)) return -1;
