@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 from longsom_amd import tsvio
+from longsom_amd._lib import CallParams
 
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(__file__), "golden")
@@ -72,3 +73,35 @@ def test_step2_matches_reference_golden(engine):
     assert got == open(os.path.join(G, "sample.calling.step2.tsv")).read()
     got = calling.step2(s1, engine, names, ed, sr, calling.read_posset_keys("", names), 150, af, 0.01)
     assert got == open(os.path.join(G, "sample.dist150.calling.step2.tsv")).read()
+
+
+@pytest.mark.parametrize("n_ct", [1, 3, 4])
+def test_step1_other_cell_type_counts_match_oracle(engine, n_ct):
+    """k_call_gather is compiled per cell-type count: 1, 3 and 4 cell types against the oracle (itself byte-identical to the
+    reference on the two-cell-type golden)."""
+    from oracle import calling_oracle
+    names, seqs = tsvio.read_fasta(os.path.join(G, "calling.ref.fa"))
+    engine.set_contigs([len(s) for s in seqs])
+    for t, s in enumerate(seqs):
+        engine.load_reference(t, s)
+    base = [tsvio.parse_counts_tsv(os.path.join(G, "counts.sample.%s.tsv" % ct), names)[:3] for ct in ("Cancer", "Non-Cancer")]
+    rng = np.random.default_rng(n_ct)
+    per_ct, ct_names = [], ["T%d" % i for i in range(n_ct)]
+    for i in range(n_ct):
+        k, r, c = base[i % 2]
+        keep = rng.random(len(k)) < 0.8                     # different site sets per cell type
+        per_ct.append((k[keep], r[keep], c[keep]))
+    engine.load_counts([p[0] for p in per_ct], [p[2] for p in per_ct])
+    n_sites, _ = engine.call_step1(CallParams.longsom_defaults(min_cell_types=min(2, n_ct)))
+    calls = engine.fetch_calls()
+    assert len(calls) == n_sites
+    merged = tsvio.format_merged_tsv(per_ct, names, ct_names)
+    header = [l + "\n" for l in merged.split("\n") if l.startswith("##")]
+    got = tsvio.format_step1_tsv(calls, per_ct, names, ct_names, header)
+    want = calling_oracle.step1(merged, dict(zip(names, [s.tobytes().decode() if hasattr(s, "tobytes") else s for s in seqs])),
+                                min_cell_types=min(2, n_ct), info_lines=tsvio.STEP1_INFO_LINES).replace("-0.0", "0.0")
+    g, w = strip_date(got).split("\n"), strip_date(want).split("\n")
+    if w and w[-1] != "" and g and g[-1] == "":
+        g = g[:-1]
+    bad = [(a, b) for a, b in zip(g, w) if a != b]
+    assert len(g) == len(w) and not bad, "first mismatch:\n%s\n%s" % (bad[0] if bad else (len(g), len(w)))

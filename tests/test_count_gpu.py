@@ -117,3 +117,14 @@ def test_bad_event_range_is_an_error(engine):
     with pytest.raises(RuntimeError, match="outside the events array"):
         engine.load_reads(dataclasses.replace(rec, seg_ev_off=off))
     run_both(engine, rec, lens, refs, celltype_of, 2)
+
+
+def test_fallback_split_path(engine, monkeypatch):
+    """LSG_NO_PRESORT forces the path used when a cell type has more barcodes than k_sort_deep's LDS table holds
+    (split by barcode range + per-slot grouping): same counts."""
+    monkeypatch.setenv("LSG_NO_PRESORT", "1")
+    lens = np.array([4000], np.int64)
+    rec, refs, celltype_of = make_case(21, 9000, lens, 300, hot_regions=[(0, 500, 900)], hot_frac=0.9)
+    run_both(engine, rec, lens, refs, celltype_of, 2)
+    rec, refs, celltype_of = make_case(22, 7000, lens, 6, hot_regions=[(0, 500, 900)], hot_frac=0.9, cb_skew=0.7)
+    run_both(engine, rec, lens, refs, celltype_of, 2)
