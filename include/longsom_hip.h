@@ -174,7 +174,8 @@ int lsg_set_region(lsg_ctx* ctx, int32_t tid_lo, int64_t pos_lo, int32_t tid_hi,
  * summed over cell types (the "genomic sites" of BASELINE.json's metric). */
 int lsg_pileup_count(lsg_ctx* ctx, const lsg_count_params* params, int64_t* n_rows, int64_t* n_columns);
 /* Copies cell type ct's rows to the host in genomic order (tid, pos ascending):
- * keys[n] = (tid<<32)|pos0, ref[n] = reference base, counts[n*42]. */
+ * keys[n] = (tid<<32)|pos0, ref[n] = reference base, counts[n*42].  The resident rows keep 34 of the 42
+ * words; BCr[8] is delivered as BC - BCf (what BaseCellCounter.py:271-279 counts: every read is forward or reverse). */
 int lsg_fetch_counts(lsg_ctx* ctx, int32_t ct, int64_t* keys, uint8_t* ref, uint32_t* counts, int64_t capacity);
 
 /* Installs per-cell-type count rows (keys[c][i] = (tid<<32)|pos0 strictly ascending, counts[c] =
