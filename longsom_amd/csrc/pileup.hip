@@ -1022,7 +1022,7 @@ struct alignas(2048) WalkLds {
     WaveBook book;
 };
 
-__global__ __launch_bounds__(WALK_THREADS) void k_walk_block(CountArgs a) {
+__global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_num_sgpr(96))) void k_walk_block(CountArgs a) {
     __shared__ WalkLds L;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     if (wv == 0) { book_init(L.book, lane); if (lane == 0) L.book.src = 1; }
