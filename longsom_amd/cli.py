@@ -61,8 +61,7 @@ def base_cell_counter(argv=None):
         k, r, c = eng.fetch_counts(0)
     out = os.path.join(a.out_folder, sid + ".tsv")
     print("Outfile: ", out, "\n")
-    with open(out, "w") as f:
-        f.write(tsvio.format_counts_tsv(k, r, c, dec.contig_names, sid))
+    tsvio.write_counts_tsv(out, k, r, c, dec.contig_names, sid)
 
 
 def merge_counts(argv=None):
@@ -76,8 +75,7 @@ def merge_counts(argv=None):
     contigs = tsvio.contigs_of_tsv(files)
     per_ct = [tsvio.parse_counts_tsv(f, contigs)[:3] for f in files]
     cts = [os.path.basename(f).split(".")[-2] for f in files]
-    with open(a.outfile, "w") as f:
-        f.write(tsvio.format_merged_tsv(per_ct, contigs, cts))
+    tsvio.write_merged_tsv(a.outfile, per_ct, contigs, cts)
 
 
 def calling_step1(argv=None):
@@ -106,8 +104,7 @@ def calling_step1(argv=None):
                                                    min_cells=a.min_cells, min_ac_cells=a.min_ac_cells, min_ac_reads=a.min_ac_reads,
                                                    max_cell_types=a.max_cell_types, min_cell_types=a.min_cell_types))
         calls = eng.fetch_calls()
-    with open(a.outfile + ".calling.step1.tsv", "w") as f:
-        f.write(tsvio.format_step1_tsv(calls, per_ct, names, cts, header))
+    tsvio.write_step1_tsv(a.outfile + ".calling.step1.tsv", calls, per_ct, names, cts, header)
 
 
 def calling_step2(argv=None):

@@ -1,0 +1,312 @@
+// Native writers of the three big tables of the SNV chain (liblongsom_io.so): the BaseCellCounter TSV
+// (BaseCellCounter.py:300-308), the merged TSV (MergeBaseCellCounts.py:59-84,116-204) and the step-1 TSV
+// (BaseCellCalling.step1.py:430-476).  At 24 M sites these are tens of GB of text; formatting them in Python took
+// 26 s for a 300 k-read sample and dominated the end-to-end run by two orders of magnitude over the GPU work.
+// Rows only: the caller (longsom_amd/tsvio.py) writes the header lines, these functions append.  Output order is the
+// reference's: contigs in Python string order, positions ascending.  Sites are formatted in parallel chunks and
+// written in order.  The text rules mirror tsvio.py's Python formatters (kept as the test reference).
+#include <algorithm>
+#include <atomic>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../../include/longsom_hip.h"
+
+namespace {
+
+const char* const INFO_FIELD = "DP|NC|CC|BC|BQ|BCf|BCr";
+const char* const CT_FILTER_NAMES[7] = {"", "Non-Significant", "Low-Significance", "Multi-allelic", "Low_cells", "Low_reads", "PASS"};
+const struct { uint32_t bit; const char* name; } SITE_FILTER_NAMES[7] = {
+    {1, "Multiple_cell_types"}, {2, "Multi-allelic"}, {4, "Min_cell_types"}, {8, "Cell_type_noise"},
+    {16, "Noisy_site"}, {32, "LC_Upstream"}, {64, "LC_Downstream"}};
+const uint32_t SF_CANDIDATE = 1u << 31;
+
+thread_local char g_err[256] = "";
+void set_err(const char* m) { snprintf(g_err, sizeof(g_err), "%s", m); }
+
+inline void put_u64(std::string& s, uint64_t v) {
+    char b[24]; int n = 0;
+    do { b[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+    while (n) s.push_back(b[--n]);
+}
+inline void put_i64(std::string& s, int64_t v) { if (v < 0) { s.push_back('-'); put_u64(s, (uint64_t)(-v)); } else put_u64(s, (uint64_t)v); }
+
+// 'DP|NC|CC|BC|BQ|BCf|BCr' values of one 42-word row: six printed classes per vector
+inline void put_row(std::string& s, const uint32_t* c) {
+    put_u64(s, c[0]); s.push_back('|'); put_u64(s, c[1]);
+    for (int o : {2, 10, 18, 26, 34}) {
+        s.push_back('|');
+        for (int k = 0; k < 6; ++k) { if (k) s.push_back(':'); put_u64(s, c[o + k]); }
+    }
+}
+
+// repr(k / 10000.0) for the integer k = round(p, 4) * 1e4 (0 <= k): shortest text, at least one decimal
+inline void put_p4(std::string& s, int64_t k) {
+    if (k < 0) { s.push_back('-'); k = -k; }
+    put_u64(s, (uint64_t)(k / 10000));
+    s.push_back('.');
+    int f = (int)(k % 10000);
+    char d[4] = {(char)('0' + f / 1000), (char)('0' + f / 100 % 10), (char)('0' + f / 10 % 10), (char)('0' + f % 10)};
+    int n = 4; while (n > 1 && d[n - 1] == '0') --n;
+    s.append(d, (size_t)n);
+}
+
+// str(round(a / float(b), 4)): the exact binary quotient correctly rounded (half-even) to 4 decimals, trailing zeros cut
+inline void put_ratio(std::string& s, int64_t a, int64_t b) {
+    char buf[64];
+    const double x = (double)a / (double)b;
+    int n = snprintf(buf, sizeof(buf), "%.4f", x);              // glibc rounds the exact binary value correctly
+    while (n > 0 && buf[n - 1] == '0' && buf[n - 2] != '.') --n;
+    s.append(buf, (size_t)n);
+}
+
+std::vector<std::string> split_lines(const char* joined, int n) {
+    std::vector<std::string> out;
+    const char* p = joined;
+    for (int i = 0; i < n; ++i) {
+        const char* e = strchr(p, '\n');
+        if (!e) e = p + strlen(p);
+        out.emplace_back(p, (size_t)(e - p));
+        p = *e ? e + 1 : e;
+    }
+    return out;
+}
+
+// contigs in Python string order
+std::vector<int> contig_order(const std::vector<std::string>& names) {
+    std::vector<int> o(names.size());
+    for (size_t i = 0; i < o.size(); ++i) o[i] = (int)i;
+    std::stable_sort(o.begin(), o.end(), [&](int a, int b) { return names[(size_t)a] < names[(size_t)b]; });
+    return o;
+}
+
+// [lo, hi) of the keys (sorted by (tid, pos)) that belong to contig tid
+inline void contig_range(const int64_t* keys, int64_t n, int tid, int64_t& lo, int64_t& hi) {
+    lo = std::lower_bound(keys, keys + n, (int64_t)tid << 32) - keys;
+    hi = std::lower_bound(keys, keys + n, ((int64_t)tid + 1) << 32) - keys;
+}
+
+// Runs fmt(i, text) for i in [0, n) over `order` (a permutation of site indices in output order) in parallel chunks and
+// appends the texts to `path` in order.
+template <class F>
+int write_chunks(const char* path, const std::vector<int64_t>& order, int n_threads, F fmt) {
+    FILE* f = fopen(path, "ab");
+    if (!f) { set_err("cannot open the output file"); return -1; }
+    const int64_t n = (int64_t)order.size();
+    const int T = n_threads > 0 ? n_threads : (int)std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    const int64_t CH = 16384;
+    const int64_t n_chunks = (n + CH - 1) / CH;
+    bool ok = true;
+    for (int64_t c0 = 0; c0 < n_chunks && ok; c0 += (int64_t)T * 4) {
+        const int64_t c1 = std::min(n_chunks, c0 + (int64_t)T * 4);
+        std::vector<std::string> text((size_t)(c1 - c0));
+        std::atomic<int64_t> next(c0);
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; ++t)
+            th.emplace_back([&]() {
+                for (int64_t c = next.fetch_add(1); c < c1; c = next.fetch_add(1)) {
+                    std::string& s = text[(size_t)(c - c0)];
+                    s.reserve(1u << 22);
+                    const int64_t e = std::min(n, (c + 1) * CH);
+                    for (int64_t i = c * CH; i < e; ++i) fmt(order[(size_t)i], s);
+                }
+            });
+        for (auto& t : th) t.join();
+        for (auto& s : text)
+            if (!s.empty() && fwrite(s.data(), 1, s.size(), f) != s.size()) ok = false;
+    }
+    if (fclose(f) != 0) ok = false;
+    if (!ok) { set_err("write failed"); return -1; }
+    return 0;
+}
+
+// the merged site list of n_ct sorted key arrays: site keys and, per cell type, the row index or -1
+struct Joined { std::vector<int64_t> key; std::vector<int64_t> row[LSG_MAX_CELLTYPES]; };
+Joined outer_join(int n_ct, const int64_t* const* keys, const int64_t* n) {
+    Joined j;
+    int64_t p[LSG_MAX_CELLTYPES] = {0, 0, 0, 0};
+    while (true) {
+        int64_t k = INT64_MAX;
+        for (int c = 0; c < n_ct; ++c) if (p[c] < n[c] && keys[c][p[c]] < k) k = keys[c][p[c]];
+        if (k == INT64_MAX) break;
+        j.key.push_back(k);
+        for (int c = 0; c < n_ct; ++c) {
+            if (p[c] < n[c] && keys[c][p[c]] == k) j.row[c].push_back(p[c]++); else j.row[c].push_back(-1);
+        }
+    }
+    return j;
+}
+
+std::vector<int64_t> output_order(const int64_t* keys, int64_t n, const std::vector<std::string>& names) {
+    std::vector<int64_t> order; order.reserve((size_t)n);
+    for (int tid : contig_order(names)) {
+        int64_t lo, hi; contig_range(keys, n, tid, lo, hi);
+        for (int64_t i = lo; i < hi; ++i) order.push_back(i);
+    }
+    return order;
+}
+
+bool keys_ok(const int64_t* keys, int64_t n, int n_contigs) {
+    for (int64_t i = 0; i < n; ++i) {
+        if (keys[i] < 0 || (keys[i] >> 32) >= n_contigs) return false;
+        if (i && keys[i] <= keys[i - 1]) return false;
+    }
+    return true;
+}
+
+} // namespace
+
+extern "C" {
+
+const char* lsio_tsv_last_error(void) { return g_err; }
+void lsio_free_text(char* p) { free(p); }
+
+int lsio_write_count_rows(const char* path, const char* contig_names, int32_t n_contigs, const int64_t* keys, const uint8_t* refs,
+                          const uint32_t* counts, int64_t n, int32_t n_threads) {
+    const auto names = split_lines(contig_names, n_contigs);
+    if (!keys_ok(keys, n, n_contigs)) { set_err("keys must be strictly ascending (tid << 32 | pos0) of known contigs"); return -2; }
+    const auto order = output_order(keys, n, names);
+    return write_chunks(path, order, n_threads, [&](int64_t i, std::string& s) {
+        const int64_t k = keys[i];
+        s += names[(size_t)(k >> 32)]; s.push_back('\t'); put_u64(s, (uint64_t)(k & 0xFFFFFFFF) + 1); s.push_back('\t');
+        s.push_back((char)refs[i]); s.push_back('\t'); s += INFO_FIELD; s.push_back('\t');
+        put_row(s, counts + i * LSG_ROW_WORDS); s.push_back('\n');
+    });
+}
+
+int lsio_write_merged_rows(const char* path, const char* contig_names, int32_t n_contigs, int32_t n_ct, const int64_t* const* keys,
+                           const uint8_t* const* refs, const uint32_t* const* counts, const int64_t* n, int32_t n_threads) {
+    if (n_ct < 1 || n_ct > LSG_MAX_CELLTYPES) { set_err("bad number of cell types"); return -2; }
+    const auto names = split_lines(contig_names, n_contigs);
+    for (int c = 0; c < n_ct; ++c) if (!keys_ok(keys[c], n[c], n_contigs)) { set_err("keys must be strictly ascending (tid << 32 | pos0) of known contigs"); return -2; }
+    const Joined j = outer_join(n_ct, keys, n);
+    const auto order = output_order(j.key.data(), (int64_t)j.key.size(), names);
+    return write_chunks(path, order, n_threads, [&](int64_t i, std::string& s) {
+        const int64_t k = j.key[(size_t)i];
+        s += names[(size_t)(k >> 32)]; s.push_back('\t');
+        put_u64(s, (uint64_t)(k & 0xFFFFFFFF) + 1); s.push_back('\t'); put_u64(s, (uint64_t)(k & 0xFFFFFFFF) + 1); s.push_back('\t');
+        // sort_set (MergeBaseCellCounts.py:48-57): distinct REFs by decreasing count, first-seen order on ties
+        char seen[LSG_MAX_CELLTYPES]; int cnt[LSG_MAX_CELLTYPES]; int ns = 0;
+        for (int c = 0; c < n_ct; ++c) {
+            const int64_t r = j.row[c][(size_t)i];
+            if (r < 0) continue;
+            const char b = (char)refs[c][r];
+            int q = 0; while (q < ns && seen[q] != b) ++q;
+            if (q == ns) { seen[ns] = b; cnt[ns++] = 1; } else ++cnt[q];
+        }
+        int idx[LSG_MAX_CELLTYPES] = {0, 1, 2, 3};
+        std::stable_sort(idx, idx + ns, [&](int a, int b) { return cnt[a] > cnt[b]; });
+        for (int q = 0; q < ns; ++q) { if (q) s.push_back('|'); s.push_back(seen[idx[q]]); }
+        s.push_back('\t'); s += INFO_FIELD;
+        for (int c = 0; c < n_ct; ++c) {
+            s.push_back('\t');
+            const int64_t r = j.row[c][(size_t)i];
+            if (r < 0) s += "NA"; else put_row(s, counts[c] + r * LSG_ROW_WORDS);
+        }
+        s.push_back('\n');
+    });
+}
+
+// Step-1 rows for EVERY merged site (calls[i] <-> i-th site of the outer join).  *cand_text receives (malloc) the rows
+// step 2 keeps (ALT != "." and FILTER != ".", the awk filter of BaseCellCalling.step2.py:23), in output order.
+int lsio_write_step1_rows(const char* path, const char* contig_names, int32_t n_contigs, int32_t n_ct, const char* celltype_names,
+                          const lsg_call* calls, int64_t n_calls, const int64_t* const* keys, const uint32_t* const* counts, const int64_t* n,
+                          int32_t n_threads, char** cand_text, int64_t* cand_len) {
+    if (n_ct < 1 || n_ct > LSG_MAX_CELLTYPES) { set_err("bad number of cell types"); return -2; }
+    const auto names = split_lines(contig_names, n_contigs);
+    const auto ctn = split_lines(celltype_names, n_ct);
+    for (int c = 0; c < n_ct; ++c) if (!keys_ok(keys[c], n[c], n_contigs)) { set_err("keys must be strictly ascending (tid << 32 | pos0) of known contigs"); return -2; }
+    const Joined j = outer_join(n_ct, keys, n);
+    if ((int64_t)j.key.size() != n_calls) { set_err("the call records do not cover the merged sites"); return -2; }
+    for (int64_t i = 0; i < n_calls; ++i) if (calls[i].key != j.key[(size_t)i]) { set_err("call records and count rows disagree on the sites"); return -2; }
+    const auto order = output_order(j.key.data(), n_calls, names);
+    // candidate rows are collected per chunk through a side buffer keyed by the site's output rank
+    std::vector<int64_t> rank((size_t)n_calls);
+    for (size_t r = 0; r < order.size(); ++r) rank[(size_t)order[r]] = (int64_t)r;
+    std::vector<std::string> cand_rows((size_t)((n_calls + 16383) / 16384));
+    // (a chunk is formatted by exactly one thread: its candidate buffer needs no lock)
+    const int rc = write_chunks(path, order, n_threads, [&](int64_t i, std::string& s) {
+        const lsg_call& c = calls[i];
+        const int64_t k = c.key;
+        const size_t row_start = s.size();
+        s += names[(size_t)(k >> 32)]; s.push_back('\t');
+        put_u64(s, (uint64_t)(k & 0xFFFFFFFF) + 1); s.push_back('\t'); put_u64(s, (uint64_t)(k & 0xFFFFFFFF) + 1); s.push_back('\t');
+        s.push_back((char)c.ref); s.push_back('\t');
+        std::string up, down;
+        for (int q = 0; q < 5 && c.up_ctx[q]; ++q) up.push_back((char)c.up_ctx[q]);
+        if (up.empty()) { up = "."; down = "."; } else for (int q = 0; q < 5 && c.down_ctx[q]; ++q) down.push_back((char)c.down_ctx[q]);
+        const uint32_t sf = c.site_filter;
+        std::string rest[2];
+        for (int q = 0; q < 2; ++q) {
+            const int64_t s_alt = q ? c.sum_alts_cc : c.sum_alts_bc, s_tot = q ? c.sum_nc : c.sum_dp, pk = q ? c.noise_p_cc : c.noise_p_bc;
+            put_i64(rest[q], s_alt); rest[q].push_back(';'); put_i64(rest[q], s_tot); rest[q].push_back(';');
+            if (c.sum_alts_bc == 0) rest[q] += "1"; else if (pk == -2) rest[q] += "nan"; else put_p4(rest[q], pk);
+        }
+        bool is_cand_row;
+        if (sf & SF_CANDIDATE) {
+            std::string alts, cts, dps, ncs, bcs, ccs, vafs, mcfs, bcps, ccps, flt;
+            std::string alt_of[LSG_MAX_CELLTYPES]; int n_alt_str = 0; bool any_pass = false; bool first = true;
+            for (int ct = 0; ct < n_ct; ++ct) {
+                if (!((c.has_cand >> ct) & 1)) continue;
+                const int na = c.n_alt[ct];
+                const uint32_t* row = counts[ct] + j.row[ct][(size_t)i] * LSG_ROW_WORDS;
+                const int64_t dp = row[0], nc = row[1];
+                if (!first) { for (std::string* x : {&alts, &cts, &dps, &ncs, &bcs, &ccs, &vafs, &mcfs, &bcps, &ccps, &flt}) x->push_back(','); }
+                first = false;
+                std::string a;
+                for (int q = 0; q < na; ++q) {
+                    if (q) { for (std::string* x : {&a, &bcs, &ccs, &vafs, &mcfs, &bcps, &ccps}) x->push_back('|'); }
+                    a.push_back("ACTG"[c.alt[ct][q] & 3]);
+                    put_u64(bcs, c.alt_bc[ct][q]); put_u64(ccs, c.alt_cc[ct][q]);
+                    put_ratio(vafs, c.alt_bc[ct][q], dp); put_ratio(mcfs, c.alt_cc[ct][q], nc);
+                    put_p4(bcps, c.p_bc[ct][q]); put_p4(ccps, c.p_cc[ct][q]);
+                }
+                alts += a; cts += ctn[(size_t)ct]; put_i64(dps, dp); put_i64(ncs, nc);
+                const char* fn = CT_FILTER_NAMES[c.ct_filter[ct] < 7 ? c.ct_filter[ct] : 0];
+                flt += fn; if (!strcmp(fn, "PASS")) any_pass = true;
+                bool dup = false; for (int q = 0; q < n_alt_str; ++q) dup |= alt_of[q] == a;
+                if (!dup) alt_of[n_alt_str++] = a;
+            }
+            std::string FILTER;
+            for (const auto& e : SITE_FILTER_NAMES) if (sf & e.bit) { if (!FILTER.empty()) FILTER.push_back(','); FILTER += e.name; }
+            if (FILTER.empty()) FILTER = any_pass ? std::string("PASS") : flt;
+            s += alts; s.push_back('\t'); s += FILTER; s.push_back('\t'); s += cts; s.push_back('\t'); s += up; s.push_back('\t'); s += down; s.push_back('\t');
+            put_u64(s, (uint64_t)n_alt_str);
+            for (const std::string* x : {&dps, &ncs, &bcs, &ccs, &vafs, &mcfs, &bcps, &ccps}) { s.push_back('\t'); s += *x; }
+            s.push_back('\t'); put_i64(s, c.cell_types_min); s.push_back('\t'); put_i64(s, c.cell_types_min);
+            s.push_back('\t'); s += rest[0]; s.push_back('\t'); s += rest[1]; s += "\t.\t"; s += flt;
+            is_cand_row = alts != "." && FILTER != ".";
+        } else {
+            const bool noisy = (sf & 16) != 0;
+            s += ".\t"; s += noisy ? "Noisy_site" : "."; s += "\t.\t"; s += up; s.push_back('\t'); s += down;
+            s += "\t.\t.\t.\t.\t.\t.\t.\t.\t.\t"; put_i64(s, c.cell_types_min); s.push_back('\t'); put_i64(s, c.cell_types_min);
+            s.push_back('\t'); s += rest[0]; s.push_back('\t'); s += rest[1]; s += "\t.\t.";
+            is_cand_row = false;                                             // ALT is "."
+        }
+        s.push_back('\t'); s += INFO_FIELD;
+        for (int ct = 0; ct < n_ct; ++ct) {
+            s.push_back('\t');
+            const int64_t r = j.row[ct][(size_t)i];
+            if (r < 0) s += "NA"; else put_row(s, counts[ct] + r * LSG_ROW_WORDS);
+        }
+        s.push_back('\n');
+        if (is_cand_row) cand_rows[(size_t)(rank[(size_t)i] / 16384)].append(s, row_start, std::string::npos);
+    });
+    if (rc) return rc;
+    if (cand_text) {
+        size_t tot = 0; for (auto& r : cand_rows) tot += r.size();
+        char* out = (char*)malloc(tot + 1);
+        if (!out) { set_err("out of memory"); return -1; }
+        size_t o = 0; for (auto& r : cand_rows) { memcpy(out + o, r.data(), r.size()); o += r.size(); }
+        out[tot] = 0;
+        *cand_text = out; if (cand_len) *cand_len = (int64_t)tot;
+    }
+    return 0;
+}
+
+} // extern "C"

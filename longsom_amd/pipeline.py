@@ -128,27 +128,27 @@ def run_chain(res: Resident, celltype_of: np.ndarray, celltype_names: List[str],
     date = tsvio.file_date()
     for ct, name in enumerate(celltype_names):
         p = os.path.join(d["BaseCellCounter/" + sample_id], "%s.%s.tsv" % (sample_id, name))
-        with open(p, "w") as f:
-            f.write(tsvio.format_counts_tsv(*per_ct[ct], contig_names, "%s.%s" % (sample_id, name), date))
+        tsvio.write_counts_tsv(p, *per_ct[ct], contig_names, "%s.%s" % (sample_id, name), date)
         out.counts[name] = p
-    merged_text = tsvio.format_merged_tsv(per_ct, contig_names, celltype_names, date)
     out.merged = os.path.join(d["MergeCounts"], sample_id + ".BaseCellCounts.AllCellTypes.tsv")
-    open(out.merged, "w").write(merged_text)
-    header = [l + "\n" for l in merged_text.split("\n") if l.startswith("##")]
-    s1 = tsvio.format_step1_tsv(calls, per_ct, contig_names, celltype_names, header)
+    header = tsvio.write_merged_tsv(out.merged, per_ct, contig_names, celltype_names, date)
     out.step1 = os.path.join(d["BaseCellCalling"], sample_id + ".calling.step1.tsv")
-    open(out.step1, "w").write(s1)
+    s1 = tsvio.write_step1_tsv(out.step1, calls, per_ct, contig_names, celltype_names, header)      # s1 = header + the rows step 2 keeps
+    t["write_tables"] = time.time() - t0
+    t0 = time.time()
     keys = [calling.read_posset_keys(p, contig_names, params.reference_gz_compat) for p in (editing, pon_sr, pon_lr)]
     af = json.load(open(gnomad_af_json)) if gnomad_af_json else None
     s2 = calling.step2(s1, eng, contig_names, keys[0], keys[1], keys[2], params.min_distance, af, params.max_gnomad_vaf)
     out.step2 = os.path.join(d["BaseCellCalling"], sample_id + ".calling.step2.tsv")
     open(out.step2, "w").write(s2)
+    t["step2"] = time.time() - t0
+    t0 = time.time()
     final, unfiltered = calling.step3(s2, params.delta_vaf, params.delta_mcf, params.min_ac_reads, params.min_ac_cells, params.clust_dist)
     out.step3 = os.path.join(d["BaseCellCalling"], sample_id + ".calling.step3.tsv")
     out.step3_unfiltered = os.path.join(d["BaseCellCalling"], sample_id + ".calling.step3.unfiltered.tsv")
     open(out.step3, "w").write(final)
     open(out.step3_unfiltered, "w").write(unfiltered)
-    t["format_write"] = time.time() - t0
+    t["step3"] = time.time() - t0
     out.timings = t
     return out
 

@@ -7,6 +7,7 @@ Writers reproduce, byte for byte (except the wall-clock ##fileDate line, SURVEY 
   BaseCellCalling.step1 out   workflow/scripts/SNVCalling/BaseCellCalling.step1.py:48-76,398-401,464-467
 Parsers read the same files back into the arrays the C-ABI takes (lsg_load_counts).
 """
+import os
 import time
 from typing import List, Sequence
 
@@ -141,6 +142,85 @@ def format_merged_tsv(per_ct, contig_names, celltype_names, date_line=None) -> s
         p1 = (k & 0xFFFFFFFF) + 1
         out.append("%s\t%d\t%d\t%s\t%s\t%s\n" % (contig_names[k >> 32], p1, p1, ref, INFO_FIELD, "\t".join(cols)))
     return "".join(out)
+
+
+# ---- native writers (liblongsom_io.so, csrc/hostio/tsvwrite.cpp): same bytes as the format_* functions above, written straight
+# to the file by a thread pool; the Python formatters stay as their test reference and for small in-memory uses ----------------
+def _io():
+    import ctypes as C
+    from . import hostio
+    lib = hostio.load()
+    if not getattr(lib, "_tsv_ready", False):
+        PP = C.POINTER(C.c_void_p)
+        lib.lsio_tsv_last_error.restype = C.c_char_p
+        lib.lsio_write_count_rows.restype = C.c_int
+        lib.lsio_write_count_rows.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
+        lib.lsio_write_merged_rows.restype = C.c_int
+        lib.lsio_write_merged_rows.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.c_int32, PP, PP, PP, C.c_void_p, C.c_int32]
+        lib.lsio_write_step1_rows.restype = C.c_int
+        lib.lsio_write_step1_rows.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.c_int32, C.c_char_p, C.c_void_p, C.c_int64, PP, PP, C.c_void_p, C.c_int32,
+                                              C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+        lib.lsio_free_text.argtypes = [C.c_void_p]
+        lib._tsv_ready = True
+    return lib
+
+
+def _check(lib, rc, what):
+    if rc != 0:
+        raise RuntimeError("%s: %s" % (what, lib.lsio_tsv_last_error().decode("utf-8", "replace")))
+
+
+def _per_ct_ptrs(per_ct):
+    import ctypes as C
+    ks = [np.ascontiguousarray(k, np.int64) for k, _, _ in per_ct]
+    rs = [np.ascontiguousarray(r, np.uint8) for _, r, _ in per_ct]
+    cs = [np.ascontiguousarray(c, np.uint32).reshape(-1, 42) for _, _, c in per_ct]
+    arr = lambda xs: (C.c_void_p * len(xs))(*[x.ctypes.data for x in xs])
+    n = np.asarray([len(k) for k in ks], np.int64)
+    return ks, rs, cs, arr(ks), arr(rs), arr(cs), n
+
+
+def write_counts_tsv(path, keys, refs, counts, contig_names, sample_id, date_line=None, threads: int = 0) -> None:
+    """format_counts_tsv straight to `path` (BaseCellCounter.py:300-308)."""
+    lib = _io()
+    with open(path, "w") as f:
+        f.write("".join([date_line or file_date(), _CONCEPTS, "\t".join(["#CHROM", "POS", "REF", "INFO", str(sample_id)]) + "\n"]))
+    k = np.ascontiguousarray(keys, np.int64); r = np.ascontiguousarray(refs, np.uint8); c = np.ascontiguousarray(counts, np.uint32).reshape(-1, 42)
+    _check(lib, lib.lsio_write_count_rows(os.fsencode(path), "\n".join(contig_names).encode(), len(contig_names), k.ctypes.data, r.ctypes.data, c.ctypes.data,
+                                          len(k), threads), "lsio_write_count_rows")
+
+
+def write_merged_tsv(path, per_ct, contig_names, celltype_names, date_line=None, threads: int = 0) -> List[str]:
+    """format_merged_tsv straight to `path`; returns the '##' header lines (step 1 copies them through)."""
+    lib = _io()
+    head = [date_line or file_date(), _CONCEPTS]
+    with open(path, "w") as f:
+        f.write("".join(head + ["\t".join(["#CHROM", "Start", "End", "REF", "INFO"] + list(celltype_names)) + "\n"]))
+    ks, rs, cs, pk, pr, pc, n = _per_ct_ptrs(per_ct)
+    _check(lib, lib.lsio_write_merged_rows(os.fsencode(path), "\n".join(contig_names).encode(), len(contig_names), len(per_ct), pk, pr, pc, n.ctypes.data, threads),
+           "lsio_write_merged_rows")
+    return [l + "\n" for l in "".join(head).split("\n") if l.startswith("##")]
+
+
+def write_step1_tsv(path, calls, per_ct, contig_names, celltype_names, header_lines: List[str], threads: int = 0) -> str:
+    """format_step1_tsv straight to `path`.  Returns the SMALL text step 2 needs: the comment lines, the column header and the
+    rows its awk filter keeps (ALT != "." and FILTER != ".", BaseCellCalling.step2.py:23)."""
+    import ctypes as C
+    lib = _io()
+    head = "".join(list(header_lines) + [l + "\n" for l in STEP1_INFO_LINES] +
+                   ["\t".join(["#CHROM", "Start", "End", "REF", "\t".join(STEP1_COLUMNS), "INFO"] + list(celltype_names)) + "\n"])
+    with open(path, "w") as f:
+        f.write(head)
+    ks, rs, cs, pk, pr, pc, n = _per_ct_ptrs(per_ct)
+    calls = np.ascontiguousarray(calls)
+    txt = C.c_void_p(); ln = C.c_int64(0)
+    _check(lib, lib.lsio_write_step1_rows(os.fsencode(path), "\n".join(contig_names).encode(), len(contig_names), len(per_ct), "\n".join(celltype_names).encode(),
+                                          calls.ctypes.data, len(calls), pk, pc, n.ctypes.data, threads, C.byref(txt), C.byref(ln)), "lsio_write_step1_rows")
+    try:
+        rows = C.string_at(txt.value, ln.value).decode() if ln.value else ""
+    finally:
+        lib.lsio_free_text(txt)
+    return head + rows
 
 
 def _p(k: int) -> str:
