@@ -49,6 +49,7 @@ struct CallArgs {
     SiteRec* sites; CandCt* cands; uint64_t cand_cap;
     struct TailTask* light; struct TailTask* heavy; uint64_t task_cap;
     unsigned long long* counters;     // [0] candidate blocks allocated, [1] candidate sites (exact), [2] light, [3] heavy tail task slots, [4] heads
+    uint32_t arena_waves;             // waves of k_call_gather (each owns chunk number `wave` of every arena list)
     const uint32_t* heads;            // units that are the first of a tile with at least one site
     uint32_t* head_recs;              // 16 words per head: unit, first site index, tile start, tid, masks[4] (lo, hi), row bases[4]
 };
@@ -170,8 +171,11 @@ __global__ __launch_bounds__(GATHER_WAVES * 64) void k_call_gather(CallArgs a) {
     const uint32_t wave = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const uint32_t n_waves = (uint32_t)(((uint64_t)gridDim.x * blockDim.x) >> 6);
     const uint32_t n_heads = (uint32_t)a.counters[4];
-    uint32_t c_next = 0, c_end = 0;                       // candidate blocks
-    uint32_t l_next = 0, l_end = 0, h_next = 0, h_end = 0;  // light / heavy task slots
+    // arenas: every wave starts with chunk number `wave` of each list (no storm of same-line atomics at launch); the
+    // counters count the chunks taken AFTER those, so list positions and lengths are offset by n_waves chunks
+    const uint32_t c_base = n_waves * CAND_CHUNK, l_base = n_waves * TASK_CHUNK, h_base = n_waves * HEAVY_CHUNK;
+    uint32_t c_next = wave * CAND_CHUNK, c_end = c_next + CAND_CHUNK;                      // candidate blocks
+    uint32_t l_next = wave * TASK_CHUNK, l_end = l_next + TASK_CHUNK, h_next = wave * HEAVY_CHUNK, h_end = h_next + HEAVY_CHUNK;  // light / heavy task slots
     uint32_t n_cand_exact = 0;
     typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
     const __attribute__((address_space(4))) u32x16* H = (const __attribute__((address_space(4))) u32x16*)(uintptr_t)a.head_recs;
@@ -252,7 +256,7 @@ __global__ __launch_bounds__(GATHER_WAVES * 64) void k_call_gather(CallArgs a) {
     n_cand_exact += n_c;
     if (c_next + n_c > c_end) {                              // candidate blocks may leave holes: they are reached through sr.cand only
         uint32_t nb = 0;
-        if (lane == 0) nb = (uint32_t)atomicAdd(&a.counters[0], (unsigned long long)CAND_CHUNK);
+        if (lane == 0) nb = (uint32_t)atomicAdd(&a.counters[0], (unsigned long long)CAND_CHUNK) + c_base;
         c_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb); c_end = c_next + CAND_CHUNK;
     }
     const uint32_t cbase = c_next; c_next += n_c;
@@ -260,14 +264,14 @@ __global__ __launch_bounds__(GATHER_WAVES * 64) void k_call_gather(CallArgs a) {
     uint32_t l_old = l_next, l_room = l_end - l_next, l_new = 0;
     if (tot_l > l_room) {
         uint32_t nb = 0;
-        if (lane == 0) nb = (uint32_t)atomicAdd(&a.counters[2], (unsigned long long)TASK_CHUNK * ((tot_l - l_room + TASK_CHUNK - 1) / TASK_CHUNK));
+        if (lane == 0) nb = (uint32_t)atomicAdd(&a.counters[2], (unsigned long long)TASK_CHUNK * ((tot_l - l_room + TASK_CHUNK - 1) / TASK_CHUNK)) + l_base;
         l_new = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb);
         l_next = l_new + (tot_l - l_room); l_end = l_new + TASK_CHUNK * ((tot_l - l_room + TASK_CHUNK - 1) / TASK_CHUNK);
     } else l_next += tot_l;
     uint32_t h_old = h_next, h_room = h_end - h_next, h_new = 0;
     if (tot_h > h_room) {
         uint32_t nb = 0;
-        if (lane == 0) nb = (uint32_t)atomicAdd(&a.counters[3], (unsigned long long)HEAVY_CHUNK * ((tot_h - h_room + HEAVY_CHUNK - 1) / HEAVY_CHUNK));
+        if (lane == 0) nb = (uint32_t)atomicAdd(&a.counters[3], (unsigned long long)HEAVY_CHUNK * ((tot_h - h_room + HEAVY_CHUNK - 1) / HEAVY_CHUNK)) + h_base;
         h_new = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb);
         h_next = h_new + (tot_h - h_room); h_end = h_new + HEAVY_CHUNK * ((tot_h - h_room + HEAVY_CHUNK - 1) / HEAVY_CHUNK);
     } else h_next += tot_h;
@@ -386,7 +390,8 @@ __device__ __forceinline__ double tail_of_task(const TailTask& t, const CallArgs
 }
 
 __global__ __launch_bounds__(256) void k_call_tails(CallArgs a) {
-    const uint64_t n = a.counters[2] < a.task_cap ? a.counters[2] : a.task_cap;
+    const uint64_t n_all = a.counters[2] + (uint64_t)a.arena_waves * TASK_CHUNK;      // the waves' first chunks + the chunks taken later
+    const uint64_t n = n_all < a.task_cap ? n_all : a.task_cap;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         const TailTask t = a.light[i];
         if (!(t.dst & ~1ull)) continue;                        // unused arena slot
@@ -397,7 +402,8 @@ __global__ __launch_bounds__(256) void k_call_tails(CallArgs a) {
 // heavy tasks: one wavefront each; lane l sums the terms [l*chunk, (l+1)*chunk) of the shorter side
 __global__ __launch_bounds__(256) void k_call_tails_heavy(CallArgs a) {
     const int lane = threadIdx.x & 63;
-    const uint64_t n_tasks = a.counters[3] < a.task_cap ? a.counters[3] : a.task_cap;
+    const uint64_t n_all = a.counters[3] + (uint64_t)a.arena_waves * HEAVY_CHUNK;
+    const uint64_t n_tasks = n_all < a.task_cap ? n_all : a.task_cap;
     for (uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; i < n_tasks; i += ((uint64_t)gridDim.x * blockDim.x) >> 6) {
         const TailTask t = a.heavy[i];
         if (!(t.dst & ~1ull)) continue;                        // unused arena slot
@@ -588,16 +594,17 @@ int run_call(lsg_ctx* c, const lsg_call_params* p) {
     LSG_HIP(hipStreamSynchronize(st));
     if (n_sites > 0) {
         if (c->d_calls.reserve((size_t)n_sites * sizeof(SiteRec))) return -1;
-        if (c->ws[WS_CALL_CANDS].reserve(((size_t)n_sites + (size_t)c->n_cus * 4 * GATHER_WAVES * CAND_CHUNK) * sizeof(CandCt) * (size_t)c->n_ct)) return -1;   // every site could be a candidate + arena slack
+        if (c->ws[WS_CALL_CANDS].reserve(((size_t)n_sites + (size_t)2 * c->n_cus * 4 * GATHER_WAVES * CAND_CHUNK) * sizeof(CandCt) * (size_t)c->n_ct)) return -1;   // every site could be a candidate + arena slack
         const unsigned gather_grid = (unsigned)(c->n_cus * 4);
         const uint64_t gather_waves = (uint64_t)gather_grid * GATHER_WAVES;
-        a.sites = c->d_calls.as<SiteRec>(); a.cands = c->ws[WS_CALL_CANDS].as<CandCt>(); a.cand_cap = n_sites + gather_waves * CAND_CHUNK;
+        a.arena_waves = (uint32_t)gather_waves;
+        a.sites = c->d_calls.as<SiteRec>(); a.cands = c->ws[WS_CALL_CANDS].as<CandCt>(); a.cand_cap = n_sites + 2 * gather_waves * CAND_CHUNK;
         // at most 2 tails per alt (<= 4 alts) per cell type + 2 noise tails per site
         a.task_cap = (uint64_t)n_sites * (uint64_t)(8 * c->n_ct + 2);
         if (a.task_cap > 0x7fffffffull) a.task_cap = 0x7fffffffull;
         // candidates rarely exceed a few tasks per site: size for 8 per site, checked below
         if (a.task_cap > (uint64_t)n_sites * 8 + 1024) a.task_cap = (uint64_t)n_sites * 8 + 1024;
-        a.task_cap += gather_waves * TASK_CHUNK * 2;                                  // arena slack
+        a.task_cap += gather_waves * TASK_CHUNK * 3;                                  // arena slack (first chunks + last partial chunks)
         if (c->ws[WS_CALL_TASKS].reserve((size_t)a.task_cap * sizeof(TailTask) * 2)) return -1;
         a.light = c->ws[WS_CALL_TASKS].as<TailTask>(); a.heavy = a.light + a.task_cap;
         switch (c->n_ct) {                                                            // the cell-type loops are compile-time
@@ -615,7 +622,7 @@ int run_call(lsg_ctx* c, const lsg_call_params* p) {
     LSG_HIP(hipMemcpyAsync(cnt4, a.counters, 32, hipMemcpyDeviceToHost, st));
     LSG_HIP(hipStreamSynchronize(st));
     const unsigned long long cand = cnt4[1];
-    if (n_sites > 0 && (cnt4[2] > a.task_cap || cnt4[3] > a.task_cap)) { set_error("lsg_call_step1: tail task buffer too small (%llu/%llu tasks)", cnt4[2], cnt4[3]); return -3; }
+    if (n_sites > 0 && (cnt4[2] + (uint64_t)a.arena_waves * TASK_CHUNK > a.task_cap || cnt4[3] + (uint64_t)a.arena_waves * HEAVY_CHUNK > a.task_cap)) { set_error("lsg_call_step1: tail task buffer too small (%llu/%llu tasks)", cnt4[2], cnt4[3]); return -3; }
     c->n_sites = n_sites; c->n_cand = (int64_t)cand;
     c->called = true;
     return 0;

@@ -198,9 +198,10 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_segments(CountArgs a) {
     const int64_t n_batches = (a.n_segs + BIN_THREADS - 1) / BIN_THREADS;
     const int64_t n_super = (n_batches + BIN_SUPER - 1) / BIN_SUPER;
     unsigned long long* qhead = &a.scalars[MODE == 0 ? SC_QBIN0 : SC_QBIN2];
-    for (;;) {
+    for (bool first = true;; first = false) {
         __syncthreads();
-        if (t == 0) s_super = (uint32_t)atomicAdd(qhead, 1ull);
+        // every workgroup's first item is its own index: no storm of same-address atomics at launch (~90 per us serialise)
+        if (t == 0) s_super = first ? blockIdx.x : (uint32_t)atomicAdd(qhead, 1ull) + gridDim.x;
         __syncthreads();
         const int64_t sup = s_super;
         if (sup >= n_super) break;
@@ -821,11 +822,15 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void k_pileup_wave(CountArgs 
     for (int i = lane; i < 8 * 64; i += 64) pk[i] = 0;
     const uint32_t n_chunks = (uint32_t)a.scalars[SC_NCHUNK];
     unsigned long long nev_total = 0;
-    while (true) {
-        // chunks hold about the same WORK (entries + a per-slot constant), not the same number of slots
-        uint32_t ck = 0;
-        if (lane == 0) ck = (uint32_t)atomicAdd(&a.scalars[SC_QSMALL], 1ull);
-        ck = rl(ck, 0);
+    const uint32_t n_waves_all = gridDim.x * WAVES_PER_BLOCK;
+    for (bool first = true;; first = false) {
+        // chunks hold about the same WORK (entries + a per-slot constant), not the same number of slots; a wave's first
+        // chunk is its own index, later ones come off the queue
+        uint32_t ck = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+        if (!first) {
+            if (lane == 0) ck = (uint32_t)atomicAdd(&a.scalars[SC_QSMALL], 1ull) + n_waves_all;
+            ck = rl(ck, 0);
+        }
         if (ck >= n_chunks) break;
         const uint32_t q0 = a.chunk_start[ck];
         const int nq = (int)(a.chunk_start[ck + 1] - q0);
@@ -1029,9 +1034,9 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_num_sgpr(96))) 
     uint32_t* pk = L.pk[wv];
     for (int i = lane; i < 8 * 64; i += 64) pk[i] = 0;
     const uint32_t n_big = a.n_slots - (uint32_t)a.scalars[SC_NSMALL];
-    while (true) {
+    for (bool first = true;; first = false) {
         __syncthreads();
-        if (t == 0) L.slot = (uint32_t)atomicAdd(&a.scalars[SC_QBIG], 1ull);
+        if (t == 0) L.slot = first ? blockIdx.x : (uint32_t)atomicAdd(&a.scalars[SC_QBIG], 1ull) + gridDim.x;   // first item = own index
         for (int i = t; i < NCTR * 64; i += WALK_THREADS) (&L.acc[0][0])[i] = 0;
         __syncthreads();
         const uint32_t qi = rl(L.slot, 0);
