@@ -16,6 +16,7 @@
 // Device storage is compact (48 B per site + 56 B per (candidate site, cell type)); lsg_fetch_calls /
 // lsg_export_calls expand it into the C-ABI's lsg_call records.
 #include "lsg_ctx.h"
+#include <cstring>
 #include <hipcub/hipcub.hpp>
 
 namespace lsg {
@@ -589,9 +590,9 @@ int run_call(lsg_ctx* c, const lsg_call_params* p) {
         LSG_HIP(hipcub::DeviceSelect::If(c->d_cub_tmp.p, tb2, it, heads, d_nh, (int)n_ne, pred, st));
     }
     hipLaunchKernelGGL(k_head_recs, dim3((n_ne + 255) / 256), dim3(256), 0, st, a);
-    uint32_t n_sites = 0;
-    LSG_HIP(hipMemcpyAsync(&n_sites, a.site_off + n_ne, 4, hipMemcpyDeviceToHost, st));
+    LSG_HIP(hipMemcpyAsync(c->h_pin, a.site_off + n_ne, 4, hipMemcpyDeviceToHost, st));     // pinned landing zone
     LSG_HIP(hipStreamSynchronize(st));
+    const uint32_t n_sites = *reinterpret_cast<const uint32_t*>(c->h_pin);
     if (n_sites > 0) {
         if (c->d_calls.reserve((size_t)n_sites * sizeof(SiteRec))) return -1;
         if (c->ws[WS_CALL_CANDS].reserve(((size_t)n_sites + (size_t)2 * c->n_cus * 4 * GATHER_WAVES * CAND_CHUNK) * sizeof(CandCt) * (size_t)c->n_ct)) return -1;   // every site could be a candidate + arena slack
@@ -619,8 +620,9 @@ int run_call(lsg_ctx* c, const lsg_call_params* p) {
         LSG_HIP(hipGetLastError());
     }
     unsigned long long cnt4[4] = {0, 0, 0, 0};
-    LSG_HIP(hipMemcpyAsync(cnt4, a.counters, 32, hipMemcpyDeviceToHost, st));
+    LSG_HIP(hipMemcpyAsync(c->h_pin, a.counters, 32, hipMemcpyDeviceToHost, st));
     LSG_HIP(hipStreamSynchronize(st));
+    memcpy(cnt4, c->h_pin, 32);
     const unsigned long long cand = cnt4[1];
     if (n_sites > 0 && (cnt4[2] + (uint64_t)a.arena_waves * TASK_CHUNK > a.task_cap || cnt4[3] + (uint64_t)a.arena_waves * HEAVY_CHUNK > a.task_cap)) { set_error("lsg_call_step1: tail task buffer too small (%llu/%llu tasks)", cnt4[2], cnt4[3]); return -3; }
     c->n_sites = n_sites; c->n_cand = (int64_t)cand;
@@ -647,9 +649,9 @@ int run_select_calls(lsg_ctx* c, int kind, lsg_call* dst_device, int64_t capacit
     if (c->d_cub_tmp.reserve(tb + 256)) return -1;
     tb = c->d_cub_tmp.cap;
     LSG_HIP(hipcub::DeviceScan::ExclusiveSum(c->d_cub_tmp.p, tb, keep, off, (int)(n + 1), st));
-    uint32_t k = 0;
-    LSG_HIP(hipMemcpyAsync(&k, off + n, 4, hipMemcpyDeviceToHost, st));
+    LSG_HIP(hipMemcpyAsync(c->h_pin, off + n, 4, hipMemcpyDeviceToHost, st));
     LSG_HIP(hipStreamSynchronize(st));
+    const uint32_t k = *reinterpret_cast<const uint32_t*>(c->h_pin);
     if (n_out) *n_out = k;
     if (!dst_device || k == 0) return 0;
     if ((int64_t)k > capacity) { set_error("lsg_export_calls: capacity %lld < %lld rows", (long long)capacity, (long long)k); return -2; }

@@ -57,6 +57,7 @@ int lsg_create(int device_id, lsg_ctx** out) {
         set_error("lsg_create: hipStreamCreate failed"); delete c; return -1;
     }
     c->stream = c->own_stream;
+    if (hipHostMalloc(reinterpret_cast<void**>(&c->h_pin), 4096, hipHostMallocDefault) != hipSuccess) { set_error("lsg_create: hipHostMalloc failed"); delete c; return -1; }
     for (auto& e : c->ev)
         if (hipEventCreate(&e) != hipSuccess) { set_error("lsg_create: hipEventCreate failed"); delete c; return -1; }
     *out = c;
@@ -81,6 +82,7 @@ void lsg_destroy(lsg_ctx* c) {
     for (auto& b : c->ws) b.release();
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    if (c->h_pin) (void)hipHostFree(c->h_pin);
     delete c;
 }
 

@@ -103,5 +103,6 @@ struct lsg_ctx {
     lsg::DevBuf syn[12];                  // synthetic-model tables + scan scratch (synth.hip)
     lsg::DevBuf ws[32];                   // count-stage workspace (pileup.hip, enum WS_*)
     int n_cus = 256;
+    unsigned long long* h_pin = nullptr;  // 4 KB of pinned host memory: landing zone of the small device -> host reads between phases
     uint32_t n_slots = 0, n_multi = 0;
 };

@@ -22,6 +22,7 @@
 #include "lsg_ctx.h"
 #include <hipcub/hipcub.hpp>
 #include <cstdlib>
+#include <cstring>
 
 namespace lsg {
 
@@ -1365,8 +1366,10 @@ struct MultiUnit {
 };
 
 static int read_scalars(lsg_ctx* c, unsigned long long* sc) {
-    LSG_HIP(hipMemcpyAsync(sc, c->d_scalars.p, SC_COUNT * 8, hipMemcpyDeviceToHost, c->stream));
+    // pinned landing zone: a pageable destination costs a staging copy and tens of microseconds per read
+    LSG_HIP(hipMemcpyAsync(c->h_pin, c->d_scalars.p, SC_COUNT * 8, hipMemcpyDeviceToHost, c->stream));
     LSG_HIP(hipStreamSynchronize(c->stream));
+    memcpy(sc, c->h_pin, SC_COUNT * 8);
     return 0;
 }
 
@@ -1479,9 +1482,10 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
         LSG_HIP(hipcub::DeviceSelect::If(c->d_cub_tmp.p, tb, unit_it, a.ne_units, d_nne, (int)n_range, pred, st));
     }
     unsigned long long sc[SC_COUNT];
-    uint32_t total_entries = 0;                               // statistics; rides on this synchronisation
-    LSG_HIP(hipMemcpyAsync(&total_entries, c->d_unit_off.as<uint32_t>() + u_hi, 4, hipMemcpyDeviceToHost, st));
+    uint32_t* pin32 = reinterpret_cast<uint32_t*>(c->h_pin + SC_COUNT + 8);   // small reads that ride on read_scalars' synchronisation
+    LSG_HIP(hipMemcpyAsync(pin32, c->d_unit_off.as<uint32_t>() + u_hi, 4, hipMemcpyDeviceToHost, st));
     if (read_scalars(c, sc)) return -1;
+    const uint32_t total_entries = pin32[0];                  // statistics
     const uint32_t n_ne = (uint32_t)(sc[SC_NNE] & 0xffffffffull);
     c->n_ne = n_ne;
     fill_args(c, p, a);
@@ -1491,10 +1495,11 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
         hipLaunchKernelGGL(k_unit_plan, dim3((n_ne + 1 + 255) / 256), dim3(256), 0, st, a);
         SCAN_U32(a.ne_nslot, a.ne_slot_base, n_ne + 1);
         SCAN_U32(a.ne_acc, a.ne_acc, n_ne + 1);
-        uint32_t n_slabs = 0;
-        LSG_HIP(hipMemcpyAsync(&n_slabs, a.ne_acc + n_ne, 4, hipMemcpyDeviceToHost, st));
-        LSG_HIP(hipMemcpyAsync(&c->n_slots, a.ne_slot_base + n_ne, 4, hipMemcpyDeviceToHost, st));
+        LSG_HIP(hipMemcpyAsync(pin32 + 2, a.ne_acc + n_ne, 4, hipMemcpyDeviceToHost, st));
+        LSG_HIP(hipMemcpyAsync(pin32 + 4, a.ne_slot_base + n_ne, 4, hipMemcpyDeviceToHost, st));
         if (read_scalars(c, sc)) return -1;
+        const uint32_t n_slabs = pin32[2];
+        c->n_slots = pin32[4];
         c->n_multi = (uint32_t)sc[SC_NMULTI];
         if (c->n_slots > slot_cap) { set_error("lsg_pileup_count: slot plan exceeds its bound"); return -1; }
         if (c->ws[WS_MACC].reserve(((size_t)n_slabs + 1) * NCTR * 64 * 4)) return -1;
