@@ -13,6 +13,7 @@
 #include <zlib.h>
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -213,12 +214,17 @@ int lsio_decode_bam(const char* path, const char* barcodes, int32_t n_barcodes, 
             s += l + (e ? 1 : 0);
         }
     }
+    const bool timing = getenv("LSIO_TIMING") != nullptr;
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_prev = now();
+    auto lap = [&](const char* what) { if (timing) { const double t = now(); fprintf(stderr, "[lsio_decode_bam] %-18s %.3f s\n", what, t - t_prev); t_prev = t; } };
     FILE* f = fopen(path, "rb");
     if (!f) { set_err("lsio_decode_bam: cannot open %s", path); return -1; }
     fseek(f, 0, SEEK_END); const size_t fsize = (size_t)ftell(f); fseek(f, 0, SEEK_SET);
     std::vector<uint8_t> file(fsize);
     if (fsize && fread(file.data(), 1, fsize, f) != fsize) { fclose(f); set_err("lsio_decode_bam: short read on %s", path); return -1; }
     fclose(f);
+    lap("read file");
     // BGZF block table
     std::vector<Block> blocks;
     size_t off = 0, utotal = 0;
@@ -238,6 +244,7 @@ int lsio_decode_bam(const char* path, const char* barcodes, int32_t n_barcodes, 
         utotal += usize; off += bsize;
     }
     if (n_threads <= 0) n_threads = (int)std::max(1u, std::thread::hardware_concurrency());
+    lap("block table");
     // inflate in parallel (chunks of blocks; the whole stream is kept: sized for the host RAM of a GPU node)
     std::vector<uint8_t> data(utotal + 8);
     std::atomic<size_t> next{0}; std::atomic<int> bad{0};
@@ -263,6 +270,7 @@ int lsio_decode_bam(const char* path, const char* barcodes, int32_t n_barcodes, 
     }
     if (bad) { set_err("lsio_decode_bam: inflate failed in %s", path); return -1; }
     std::vector<uint8_t>().swap(file);
+    lap("inflate");
     // header
     const uint8_t* d = data.data();
     if (utotal < 12 || memcmp(d, "BAM\1", 4) != 0) { set_err("lsio_decode_bam: %s has no BAM magic", path); return -1; }
@@ -292,6 +300,7 @@ int lsio_decode_bam(const char* path, const char* barcodes, int32_t n_barcodes, 
             if (ins.second) { auto_joined.append(cb, cl); auto_joined.push_back('\n'); ++auto_n; }
         }
     }
+    lap("record offsets");
     // parallel decode of contiguous record ranges
     const int T = (int)std::min<size_t>((size_t)n_threads, std::max<size_t>(1, recs.size() / 1024));
     std::vector<Local> loc((size_t)T);
@@ -306,6 +315,7 @@ int lsio_decode_bam(const char* path, const char* barcodes, int32_t n_barcodes, 
             });
         for (auto& t : th) t.join();
     }
+    lap("decode records");
     lsio_decoded* o = (lsio_decoded*)calloc(1, sizeof(lsio_decoded));
     int64_t R = 0, S = 0, E = 0;
     for (auto& l : loc) { R += (int64_t)l.read_tid.size(); S += (int64_t)l.seg_read.size(); E += (int64_t)l.events.size(); }
@@ -314,18 +324,31 @@ int lsio_decode_bam(const char* path, const char* barcodes, int32_t n_barcodes, 
     o->read_tid = (int32_t*)al(R, 4); o->read_pos = (int32_t*)al(R, 4); o->read_flag = (uint16_t*)al(R, 2); o->read_mapq = (uint8_t*)al(R, 1);
     o->read_cb = (int32_t*)al(R, 4); o->seg_read = (uint32_t*)al(S, 4); o->seg_start = (int32_t*)al(S, 4); o->seg_len = (int32_t*)al(S, 4);
     o->seg_ev_off = (int64_t*)al(S, 8); o->events = (uint16_t*)al(E, 2);
-    int64_t r0 = 0, s0 = 0, e0 = 0;
+    // every thread copies its own part to its place in the merged arrays (first touch of the big buffers in parallel too)
+    std::vector<int64_t> r_at(loc.size() + 1, 0), s_at(loc.size() + 1, 0), e_at(loc.size() + 1, 0);
+    for (size_t q = 0; q < loc.size(); ++q) {
+        r_at[q + 1] = r_at[q] + (int64_t)loc[q].read_tid.size(); s_at[q + 1] = s_at[q] + (int64_t)loc[q].seg_read.size();
+        e_at[q + 1] = e_at[q] + (int64_t)loc[q].events.size();
+    }
+    {
+        std::vector<std::thread> th;
+        for (size_t q = 0; q < loc.size(); ++q)
+            th.emplace_back([&, q]() {
+                const Local& l = loc[q];
+                const int64_t r0 = r_at[q], s0 = s_at[q], e0 = e_at[q];
+                const size_t nr = l.read_tid.size(), ns = l.seg_read.size(), ne = l.events.size();
+                if (nr) { memcpy(o->read_tid + r0, l.read_tid.data(), nr * 4); memcpy(o->read_pos + r0, l.read_pos.data(), nr * 4);
+                          memcpy(o->read_flag + r0, l.read_flag.data(), nr * 2); memcpy(o->read_mapq + r0, l.read_mapq.data(), nr);
+                          memcpy(o->read_cb + r0, l.read_cb.data(), nr * 4); }
+                for (size_t i = 0; i < ns; ++i) {
+                    o->seg_read[s0 + i] = l.seg_read[i] + (uint32_t)r0; o->seg_start[s0 + i] = l.seg_start[i]; o->seg_len[s0 + i] = l.seg_len[i];
+                    o->seg_ev_off[s0 + i] = l.seg_ev_off[i] + e0;
+                }
+                if (ne) memcpy(o->events + e0, l.events.data(), ne * 2);
+            });
+        for (auto& t : th) t.join();
+    }
     for (auto& l : loc) {
-        const size_t nr = l.read_tid.size(), ns = l.seg_read.size(), ne = l.events.size();
-        if (nr) { memcpy(o->read_tid + r0, l.read_tid.data(), nr * 4); memcpy(o->read_pos + r0, l.read_pos.data(), nr * 4);
-                  memcpy(o->read_flag + r0, l.read_flag.data(), nr * 2); memcpy(o->read_mapq + r0, l.read_mapq.data(), nr);
-                  memcpy(o->read_cb + r0, l.read_cb.data(), nr * 4); }
-        for (size_t i = 0; i < ns; ++i) {
-            o->seg_read[s0 + i] = l.seg_read[i] + (uint32_t)r0; o->seg_start[s0 + i] = l.seg_start[i]; o->seg_len[s0 + i] = l.seg_len[i];
-            o->seg_ev_off[s0 + i] = l.seg_ev_off[i] + e0;
-        }
-        if (ne) memcpy(o->events + e0, l.events.data(), ne * 2);
-        r0 += (int64_t)nr; s0 += (int64_t)ns; e0 += (int64_t)ne;
         o->total_reads += l.total; o->pass_reads += l.pass; o->cb_not_found += l.cb_not_found; o->cb_not_matched += l.cb_not_matched;
         o->mapq_filtered += l.mapq;
     }
@@ -337,6 +360,7 @@ int lsio_decode_bam(const char* path, const char* barcodes, int32_t n_barcodes, 
     o->contig_len = dup_vec(lens);
     o->n_barcodes = auto_n;
     o->barcodes = (char*)malloc(auto_joined.size() + 1); memcpy(o->barcodes, auto_joined.c_str(), auto_joined.size() + 1);
+    lap("merge");
     *out = o;
     return 0;
 }
