@@ -71,11 +71,10 @@ void lsg_destroy(lsg_ctx* c) {
     DevBuf* bufs[] = {&c->d_tile_base, &c->d_contig_len, &c->d_ref_ptrs, &c->d_celltype_of, &c->d_ct_rank, &c->b_read_tid, &c->b_read_pos,
                       &c->b_read_flag, &c->b_read_mapq, &c->b_read_cb, &c->b_seg_read, &c->b_seg_start, &c->b_seg_len,
                       &c->b_seg_ev_off, &c->b_events, &c->d_read_key, &c->d_unit_cnt, &c->d_unit_off, &c->d_unit_fill,
-                      &c->d_entries, &c->d_ne_units, &c->d_ne_mask, &c->d_ne_rowbase, &c->d_ne_rowoff, &c->d_deep_list,
+                      &c->d_ne_units, &c->d_ne_mask, &c->d_ne_rowbase, &c->d_ne_rowoff,
                       &c->d_scalars, &c->d_cub_tmp, &c->d_calls, &c->d_site_off};
     for (auto* b : bufs) b->release();
     for (auto& b : c->d_rows) b.release();
-    for (auto& b : c->d_rowkey) b.release();
     for (auto& b : c->ref) b.release();
     for (auto& s : c->posset) s.keys.release();
     for (auto& b : c->syn) b.release();

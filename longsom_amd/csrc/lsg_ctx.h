@@ -44,8 +44,8 @@ struct DevBuf {
 struct PosSet { DevBuf keys; int64_t n = 0; };
 
 // workspace buffers (lsg_ctx::ws)
-enum { WS_UNIT_PLAN = 0, WS_SLOT_PEX, WS_NE_NSLOT, WS_NE_SLOT_BASE, WS_NE_ACC, WS_NE_GEOM, WS_SLOT_W, WS_SLOT_CNT,
-       WS_SLOT_OFF, WS_SLOT_CURSOR, WS_ENT, WS_CHUNK_START, WS_REC, WS_SLOT_LIST, WS_MULTI_LIST, WS_MACC, WS_EXPORT_K, WS_EXPORT_R,
+enum { WS_SLOT_PEX = 0, WS_NE_NSLOT, WS_NE_SLOT_BASE, WS_NE_ACC, WS_NE_GEOM, WS_SLOT_W, WS_SLOT_CNT,
+       WS_SLOT_OFF, WS_ENT, WS_CHUNK_START, WS_REC, WS_SLOT_LIST, WS_MULTI_LIST, WS_MACC, WS_EXPORT_K, WS_EXPORT_R,
        WS_EXPORT_C, WS_SLICES, WS_HUGE_LIST, WS_CALL_FLAGS, WS_CALL_SEL, WS_CALL_CANDS, WS_CALL_TASKS, WS_SEG_INFO };
 
 
@@ -82,10 +82,9 @@ struct lsg_ctx {
     uint64_t entries_upper = 0;           // sum over segments of tiles overlapped
 
     // count-stage workspace
-    lsg::DevBuf d_read_key, d_unit_cnt, d_unit_off, d_unit_fill, d_entries;
-    lsg::DevBuf d_ne_units, d_ne_mask, d_ne_rowbase, d_ne_rowoff, d_deep_list, d_scalars, d_cub_tmp;
+    lsg::DevBuf d_read_key, d_unit_cnt, d_unit_off, d_unit_fill;
+    lsg::DevBuf d_ne_units, d_ne_mask, d_ne_rowbase, d_ne_rowoff, d_scalars, d_cub_tmp;
     lsg::DevBuf d_rows[LSG_MAX_CELLTYPES]; // SoA planes [ROW_PLANES][row_cap]
-    lsg::DevBuf d_rowkey[LSG_MAX_CELLTYPES];
     uint64_t row_cap = 0;
     uint32_t n_ne = 0, n_deep = 0;
     int64_t n_rows[LSG_MAX_CELLTYPES] = {0, 0, 0, 0};

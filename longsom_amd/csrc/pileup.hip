@@ -50,9 +50,9 @@ constexpr int QCHUNK = 64;          // slots dequeued at once by a wave
 constexpr int FLUSH_EVERY = 63;      // packed LDS fields: bq 14 | fwd 6 | cnt 6 | dup 6 bits
 
 // device scalars (uint64 each)
-enum { SC_QSMALL = 0, SC_QBIG = 1, SC_NNE = 2, SC_NSLOTS = 3, SC_ROWALLOC = 4, SC_COLS = 8, SC_OVERFLOW = 9,
+enum { SC_QSMALL = 0, SC_QBIG = 1, SC_NNE = 2, SC_ROWALLOC = 4, SC_COLS = 8, SC_OVERFLOW = 9,
        SC_READS = 10, SC_SEGS = 11, SC_EVENTS = 12, SC_EV_WAVE = 13, SC_EV_DEEP = 14, SC_ROWS_DEEP = 15,
-       SC_ROWS = 16, SC_NSMALL = 20, SC_NMULTI = 21, SC_NMULTI_SEL = 22, SC_QGROUP = 23, SC_NHUGE = 24, SC_QHUGE = 25, SC_QBIN0 = 26, SC_QBIN2 = 27,
+       SC_ROWS = 16, SC_NSMALL = 20, SC_NMULTI = 21, SC_NMULTI_SEL = 22, SC_NHUGE = 24, SC_QHUGE = 25, SC_QBIN0 = 26, SC_QBIN2 = 27,
        SC_ROWS_SRC = 28, SC_EV_SRC = 32, SC_NCHUNK = 36, SC_COUNT = 40 };   // *_SRC[4]: 0 wave, 1 walk_block, 2 huge, 3 finalize
 
 struct CountArgs {
@@ -76,7 +76,7 @@ struct CountArgs {
     const uint32_t* ct_rank; uint32_t ct_size[LSG_MAX_CELLTYPES];   // rank of a barcode within its cell type
     uint32_t* ne_units; uint32_t* ne_nslot; uint32_t* ne_slot_base; uint32_t* ne_acc; int2* ne_geom;
     uint64_t* ne_mask; uint32_t* ne_rowbase;
-    uint32_t* slot_w; uint32_t* slot_cnt; uint32_t* slot_off; uint32_t* slot_cursor;
+    uint32_t* slot_w; uint32_t* slot_cnt; uint32_t* slot_off;
     uint4* ent;                           // entries {key, first event index lo, meta, 0}
     uint2* seg_info;                      // per segment {admission key, first tile of its contig} (k_seg_info)
     uint2* rec;                           // grouped 8-byte records {event byte offset lo, meta} of the block path, same indexing as ent
@@ -335,11 +335,6 @@ __global__ void k_slot_init(CountArgs a) {
     uint32_t base = a.ne_slot_base[w], nslot = a.ne_nslot[w];
     for (uint32_t j = 0; j < nslot; ++j) a.slot_w[base + j] = w;
     if (nslot == 1) { a.slot_cnt[base] = a.unit_cnt[u]; a.slot_off[base] = a.unit_off[u]; }   // multi-slot units: k_split_deep
-}
-
-__global__ void k_multi_index(CountArgs a) {
-    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < a.n_multi) a.ne_acc[a.multi_list[k]] = k;
 }
 
 // Deep units (more than CAPB entries) are cut into slots by barcode rank: counting sort of the unit's
@@ -1394,7 +1389,7 @@ static void fill_args(lsg_ctx* c, const lsg_count_params* p, CountArgs& a) {
     a.ne_geom = c->ws[WS_NE_GEOM].as<int2>();
     a.ne_mask = c->d_ne_mask.as<uint64_t>(); a.ne_rowbase = c->d_ne_rowbase.as<uint32_t>();
     a.slot_w = c->ws[WS_SLOT_W].as<uint32_t>(); a.slot_cnt = c->ws[WS_SLOT_CNT].as<uint32_t>();
-    a.slot_off = c->ws[WS_SLOT_OFF].as<uint32_t>(); a.slot_cursor = c->ws[WS_SLOT_CURSOR].as<uint32_t>();
+    a.slot_off = c->ws[WS_SLOT_OFF].as<uint32_t>();
     a.ent = c->ws[WS_ENT].as<uint4>(); a.rec = c->ws[WS_REC].as<uint2>(); a.seg_info = c->ws[WS_SEG_INFO].as<uint2>();
     a.slot_list = c->ws[WS_SLOT_LIST].as<uint32_t>(); a.multi_list = c->ws[WS_MULTI_LIST].as<uint32_t>();
     a.macc = c->ws[WS_MACC].as<uint32_t>();
@@ -1447,7 +1442,7 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
         c->ws[WS_NE_SLOT_BASE].reserve((ne_cap + 2) * 4) || c->ws[WS_NE_ACC].reserve((ne_cap + 2) * 4) ||
         c->ws[WS_NE_GEOM].reserve((ne_cap + 2) * 8) || c->ws[WS_SLOT_W].reserve((slot_cap + 2) * 4) ||
         c->ws[WS_SLOT_CNT].reserve((slot_cap + 2) * 4) || c->ws[WS_SLOT_OFF].reserve((slot_cap + 2) * 4) ||
-        c->ws[WS_SLOT_CURSOR].reserve((slot_cap + 2) * 4) || c->ws[WS_SLOT_LIST].reserve((slot_cap + 2) * 4) ||
+        c->ws[WS_SLOT_LIST].reserve((slot_cap + 2) * 4) ||
         c->ws[WS_MULTI_LIST].reserve((EU / CAPB + 16) * 4) || c->ws[WS_ENT].reserve((EU + 1) * 32 + 64) || c->ws[WS_SEG_INFO].reserve(((size_t)S + 1) * 8) || c->ws[WS_REC].reserve((EU + 1) * 16 + 256) ||
         c->ws[WS_SLICES].reserve((slot_cap + 2) * (NSLICE + 1) * 4) || c->ws[WS_SLOT_PEX].reserve((slot_cap + 2) * 4) ||
         c->ws[WS_CHUNK_START].reserve(((EU + WORK_W0 * slot_cap) / CHUNK_EMIN + 4) * 4) || c->ws[WS_HUGE_LIST].reserve((EU / CAPB + 16) * 4))
