@@ -1,0 +1,41 @@
+"""GPU: bench.py's contract line, and its N=2 path (two ranks sharing the one GPU of this box, collectives on gloo) against the
+N=1 run of the same workload: region sharding must not change what is counted or called."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(args, env=None, launcher=None):
+    cmd = (launcher or [sys.executable]) + [os.path.join(ROOT, "bench.py")] + args
+    out = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, **(env or {})), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.split("\n") if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_contract_line_and_sharded_run():
+    one = run_bench(["--reads", "3e5", "--steps", "2", "--warmup", "1"])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline"):
+        assert k in one, k
+    assert one["n_gpus"] == 1 and one["steps"] == 2 and one["unit"] == "sites/s" and one["vs_baseline"] is None
+    r = one["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    cb = one["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["gpu_matches_oracle_on_sample"] is True
+    assert abs(one["value"] - one["config"]["sites_counted"] / (one["ms_per_step"] / 1e3)) < 1e-3 * one["value"]
+
+    two = run_bench(["--gpus", "2", "--reads", "3e5", "--steps", "2", "--warmup", "1"], env={"LSG_BENCH_DEVICE": "0", "LSG_BENCH_BACKEND": "gloo"},
+                    launcher=[sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                              "--master-port", "29533"])
+    assert two["n_gpus"] == 2 and "cpu_baseline" not in two
+    for k in ("sites_counted", "rows_emitted", "merged_sites", "step1_candidates"):
+        assert two["config"][k] == one["config"][k], k
+    assert two["config"]["reads_loaded_all_ranks"] >= one["config"]["reads_loaded_all_ranks"]          # boundary-crossing reads are loaded twice
