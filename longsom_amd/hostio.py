@@ -82,11 +82,27 @@ def read_barcodes(path: str) -> BarcodeTable:
     return BarcodeTable(barcodes, np.asarray([idx[mapping[b]] for b in barcodes], np.uint8), names)
 
 
-def _take(d: Decoded) -> ReadRecords:
+class _DecodedOwner:
+    """Keeps a lsio_decoded block alive for as long as any array that views its memory exists."""
+    def __init__(self, lib, handle):
+        self._lib, self._handle = lib, handle
+
+    def __del__(self):
+        try:
+            self._lib.lsio_free_decoded(self._handle)
+        except Exception:
+            pass
+
+
+def _take(d: Decoded, owner: "_DecodedOwner") -> ReadRecords:
+    """The decoder's arrays as numpy views (no copy: at BAM scale the copies cost as much as the decode); every view holds the
+    owner through its ctypes buffer, the C memory is freed when the last of them goes away."""
     def arr(ptr, n, dt):
         if n == 0 or not ptr:
             return np.zeros(0, dt)
-        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(np.ctypeslib.as_ctypes_type(dt))), shape=(n,)).copy()
+        buf = (C.c_char * (int(n) * np.dtype(dt).itemsize)).from_address(ptr)
+        buf._owner = owner
+        return np.frombuffer(buf, dtype=dt)
     R, S, E = d.n_reads, d.n_segs, d.n_events
     return ReadRecords(arr(d.read_tid, R, np.int32), arr(d.read_pos, R, np.int32), arr(d.read_flag, R, np.uint16), arr(d.read_mapq, R, np.uint8),
                        arr(d.read_cb, R, np.int32), arr(d.seg_read, S, np.uint32), arr(d.seg_start, S, np.int32), arr(d.seg_len, S, np.int32),
@@ -128,19 +144,17 @@ def decode_bam(path: str, barcodes: Optional[Sequence[str]], min_mapq: int = 60,
         rc = lib.lsio_decode_bam(os.fsencode(path), joined, len(barcodes), None, int(min_mapq), int(threads), C.byref(out))
     if rc != 0:
         _err("lsio_decode_bam")
-    try:
-        d = out.contents
-        rec = _take(d)
-        names = d.contig_names.decode().split("\n")[: d.n_contigs] if d.n_contigs else []
-        lens = np.ctypeslib.as_array(C.cast(d.contig_len, C.POINTER(C.c_int64)), shape=(d.n_contigs,)).copy() if d.n_contigs else np.zeros(0, np.int64)
-        rep = {"Total_reads": d.total_reads, "Pass_reads": d.pass_reads, "CB_not_found": d.cb_not_found, "CB_not_matched": d.cb_not_matched}
-        if d.mapq_filtered:
-            rep["MAPQ"] = d.mapq_filtered
-        found = d.barcodes.decode().split("\n")[: d.n_barcodes] if barcodes is None else None
-        tally = lambda ptr: np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_int64)), shape=(len(barcodes),)).copy() if barcodes is not None and d.n_tally >= len(barcodes) and len(barcodes) else None
-        return DecodedBam(rec, names, lens, rep, found, tally(d.cb_pass), tally(d.cb_low))
-    finally:
-        lib.lsio_free_decoded(out)
+    owner = _DecodedOwner(lib, out)
+    d = out.contents
+    rec = _take(d, owner)
+    names = d.contig_names.decode().split("\n")[: d.n_contigs] if d.n_contigs else []
+    lens = np.ctypeslib.as_array(C.cast(d.contig_len, C.POINTER(C.c_int64)), shape=(d.n_contigs,)).copy() if d.n_contigs else np.zeros(0, np.int64)
+    rep = {"Total_reads": d.total_reads, "Pass_reads": d.pass_reads, "CB_not_found": d.cb_not_found, "CB_not_matched": d.cb_not_matched}
+    if d.mapq_filtered:
+        rep["MAPQ"] = d.mapq_filtered
+    found = d.barcodes.decode().split("\n")[: d.n_barcodes] if barcodes is None else None
+    tally = lambda ptr: np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_int64)), shape=(len(barcodes),)).copy() if barcodes is not None and d.n_tally >= len(barcodes) and len(barcodes) else None
+    return DecodedBam(rec, names, lens, rep, found, tally(d.cb_pass), tally(d.cb_low))
 
 
 def split_bam(path: str, table: "BarcodeTable", out_paths: Sequence[str], min_mapq: int = 60) -> Dict[str, int]:
@@ -196,10 +210,7 @@ def synth_records(model) -> ReadRecords:
     mc = model.as_c()
     if lib.lsio_synth_records(C.byref(mc), C.byref(out)) != 0:
         _err("lsio_synth_records")
-    try:
-        return _take(out.contents)
-    finally:
-        lib.lsio_free_decoded(out)
+    return _take(out.contents, _DecodedOwner(lib, out))
 
 
 def write_barcodes_tsv(path: str, barcodes: Sequence[str], celltype_of, celltype_names: Sequence[str], suffix: str = "") -> None:
