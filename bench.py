@@ -39,7 +39,7 @@ HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 from longsom_amd.shard import region_shards, sub_model  # noqa: E402
 
 
-def cpu_baseline(eng, model, target_reads=40_000, call_sites=2500):
+def cpu_baseline(eng, model, target_reads=150_000, call_sites=10_000):
     """Oracle (C count + Python/scipy step 1, single thread) on a contiguous-gene sample of the workload.
     Also checks the GPU result on that sample against the oracle (a parity check at bench time)."""
     from oracle import calling_oracle, loader
