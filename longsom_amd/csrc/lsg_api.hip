@@ -224,6 +224,11 @@ int lsg_fetch_counts(lsg_ctx* c, int32_t ct, int64_t* keys, uint8_t* ref, uint32
     return run_fetch_counts(c, ct, keys, ref, counts, capacity);
 }
 
+int64_t lsg_max_live_reads(lsg_ctx* c) {
+    if (!c) { set_error("lsg_max_live_reads: bad arguments"); return -1; }
+    return c->max_live_reads;
+}
+
 int lsg_get_count_stats(lsg_ctx* c, lsg_count_stats* out) {
     if (!c || !out) { set_error("lsg_get_count_stats: bad arguments"); return -2; }
     *out = c->stats;

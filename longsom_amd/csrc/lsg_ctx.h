@@ -80,6 +80,7 @@ struct lsg_ctx {
     lsg::DevBuf b_read_tid, b_read_pos, b_read_flag, b_read_mapq, b_read_cb;
     lsg::DevBuf b_seg_read, b_seg_start, b_seg_len, b_seg_ev_off, b_events;
     uint64_t entries_upper = 0;           // sum over segments of tiles overlapped
+    int64_t max_live_reads = 0;           // layout.hip: bound on the reads live at once in the reference's pileup buffer
 
     // count-stage workspace
     lsg::DevBuf d_read_key, d_unit_cnt, d_unit_off, d_unit_fill;

@@ -1551,11 +1551,11 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
     // (17 x 256 B modulo 8 KB) so that the planes of a unit spread over the HBM channels whatever their interleave
     want_rows = (want_rows + 63) / 64 * 64;
     want_rows += ((17 + 32 - (want_rows / 64) % 32) % 32) * 64;
-    if (want_rows > c->row_cap) {
-        for (int i = 0; i < c->n_ct; ++i)
-            if (c->d_rows[i].reserve((size_t)want_rows * ROW_PLANES * 4)) return -1;
-        c->row_cap = want_rows;
-    }
+    // every cell type of THIS run needs planes of the current stride (a run with more cell types than any before it
+    // finds row_cap large enough but its new buffers still empty)
+    if (want_rows > c->row_cap) c->row_cap = want_rows;
+    for (int i = 0; i < c->n_ct; ++i)
+        if (c->d_rows[i].reserve((size_t)c->row_cap * ROW_PLANES * 4)) return -1;
     fill_args(c, p, a);
     if (n_ne > 0) hipLaunchKernelGGL(k_group_block, dim3((unsigned)(c->n_cus * 4)), dim3(BLOCK_THREADS), 0, st, a);
     LSG_HIP(hipEventRecord(c->ev[1], st));

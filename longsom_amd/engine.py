@@ -203,6 +203,12 @@ class Engine:
         self.n_ct = n_ct
         self._n_rows = [len(k) for k in ks]
 
+    def max_live_reads(self) -> int:
+        """Upper bound on the reads simultaneously live in the reference's pileup buffer (see lsg_max_live_reads)."""
+        v = int(self._lib.lsg_max_live_reads(self._h))
+        _lib.check(-1 if v < 0 else 0, "lsg_max_live_reads")
+        return v
+
     def count_stats(self) -> CountStats:
         s = CountStats()
         _lib.check(self._lib.lsg_get_count_stats(self._h, C.byref(s)), "lsg_get_count_stats")

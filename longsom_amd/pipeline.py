@@ -8,6 +8,7 @@ the wall-clock ##fileDate line).
 """
 import json
 import os
+import sys
 import time
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional
@@ -78,7 +79,14 @@ class Resident:
     seconds: Dict[str, float]
 
 
-def load_sample(bam: str, barcodes_tsv: str, ref_fasta: str, engine: Engine, min_mapq: int) -> Resident:
+PILEUP_MAX_DEPTH = 200000   # bam.pileup(..., max_depth = 200000), BaseCellCounter.py:191 / HCCVSingleCellGenotype.py:122
+
+
+class DepthCapExceeded(ValueError):
+    """More reads can be live at one position than the reference's pileup admits; its cap is not modelled here."""
+
+
+def load_sample(bam: str, barcodes_tsv: str, ref_fasta: str, engine: Engine, min_mapq: int, allow_depth_overflow: Optional[bool] = None) -> Resident:
     t = {}
     t0 = time.time()
     bc = hostio.read_barcodes(barcodes_tsv)
@@ -98,6 +106,15 @@ def load_sample(bam: str, barcodes_tsv: str, ref_fasta: str, engine: Engine, min
     engine.set_barcodes(bc.celltype_of, len(bc.celltype_names))
     engine.set_region()
     engine.load_reads(dec.records)
+    live = engine.max_live_reads()
+    if live > PILEUP_MAX_DEPTH:
+        msg = ("%s: up to %d reads overlap one 64-position tile; the reference's pileup stops admitting reads above max_depth = %d, "
+               "which this library does not model, so counts there could differ" % (bam, live, PILEUP_MAX_DEPTH))
+        if allow_depth_overflow is None:
+            allow_depth_overflow = os.environ.get("LONGSOM_ALLOW_DEPTH_OVERFLOW", "0") == "1"
+        if not allow_depth_overflow:
+            raise DepthCapExceeded(msg + " (set LONGSOM_ALLOW_DEPTH_OVERFLOW=1 to count every read anyway)")
+        sys.stderr.write("warning: " + msg + "\n")
     t["load"] = time.time() - t0
     return Resident(engine, dec, bc, contig_names, t)
 

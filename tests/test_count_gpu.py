@@ -75,6 +75,19 @@ def test_three_cell_types_and_min_mq(engine):
     run_both(engine, rec, lens, refs, ct_of, 3, CountParams.longsom_defaults(min_mq=30, min_bq=10, min_dp=3, min_cc=2))
 
 
+def test_more_cell_types_than_the_run_before():
+    """a handle that counted a large two-cell-type sample then gets a small one with three: the third cell type's row planes
+    must exist although the row capacity did not have to grow (own handle: the shared one has seen four cell types already)."""
+    from longsom_amd.engine import Engine
+    eng = Engine(0)
+    lens = [6000, 300]
+    rec, refs, ct_of = make_case(7, 6000, lens, 80, n_ct=2)
+    run_both(eng, rec, lens, refs, ct_of, 2)
+    rec, refs, ct_of = make_case(5, 600, lens, 80, n_ct=3)
+    run_both(eng, rec, lens, refs, ct_of, 3, CountParams.longsom_defaults(min_dp=3, min_cc=2))
+    eng.close()
+
+
 def test_empty_and_tiny(engine):
     lens = [1000]
     rec, refs, ct_of = make_case(6, 1, lens, 5)
