@@ -160,10 +160,12 @@ int lsg_set_barcodes(lsg_ctx* ctx, const uint8_t* celltype_of, int32_t n_cb, int
 int lsg_load_reads(lsg_ctx* ctx, const lsg_reads* reads);
 /* The reference counts through bam.pileup(..., max_depth = 200000) (BaseCellCounter.py:191,
  * HCCVSingleCellGenotype.py:122): htslib stops admitting reads at a position while more than max_depth are
- * live in its buffer.  That cap is NOT modelled here; instead the load computes an upper bound on the live
- * reads of ANY cell-type BAM (reads with a known barcode whose span touches a 64-position tile, maximum over
- * tiles).  While the bound stays <= 200000 the cap can never have fired in the reference and results are
- * identical; above it the caller must decide (the host mirror raises).  Returns the bound, -1 on a bad handle. */
+ * live in its buffer.  That cap is NOT modelled here; instead this call evaluates an upper bound on the live
+ * reads of every cell-type BAM under the current barcode table (reads of one cell type whose span touches a
+ * 64-position tile, maximum over tiles and cell types; before lsg_set_barcodes: all reads with a barcode).
+ * While the bound stays <= 200000 the cap can never have fired in the reference and results are identical;
+ * above it the caller must decide (the host mirror raises).  Off the hot path: computed on request and cached
+ * until the reads or the barcode table change.  Returns the bound, -1 on error. */
 int64_t lsg_max_live_reads(lsg_ctx* ctx);
 /* Restrict counting to the genomic region [ (tid_lo,pos_lo), (tid_hi,pos_hi) ) in (tid,pos) order;
  * positions must be multiples of 64.  This is how windows are sharded over GPUs: every rank loads

@@ -36,15 +36,18 @@ __global__ __launch_bounds__(256) void k_relayout(const uint16_t* src, int64_t n
     }
 }
 
-// +1 at the tile a read's first segment starts in, -1 past the tile its last segment ends in (reads with a known barcode)
+// +1 at the tile a read's first segment starts in, -1 past the tile its last segment ends in; reads of cell type ct
+// (celltype_of == nullptr: every read with a known barcode)
 __global__ void k_span_marks(const uint32_t* seg_read, const int32_t* seg_start, const int32_t* seg_len, int64_t n_segs,
-                             const int32_t* read_tid, const int32_t* read_cb, const uint32_t* tile_base, int32_t n_contigs,
-                             uint32_t n_tiles, int32_t* diff) {
+                             const int32_t* read_tid, const int32_t* read_cb, const uint8_t* celltype_of, int32_t n_cb, int32_t ct,
+                             const uint32_t* tile_base, int32_t n_contigs, int32_t* diff) {
     const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_segs) return;
     const uint32_t r = seg_read[s];
     const int32_t tid = read_tid[r];
-    if (read_cb[r] < 0 || tid < 0 || tid >= n_contigs) return;
+    const int32_t cb = read_cb[r];
+    if (cb < 0 || tid < 0 || tid >= n_contigs) return;
+    if (celltype_of && (cb >= n_cb || celltype_of[cb] != ct)) return;
     const bool first = s == 0 || seg_read[s - 1] != r, last = s + 1 == n_segs || seg_read[s + 1] != r;
     if (!first && !last) return;
     int64_t st = seg_start[s], en = st + (seg_len[s] > 0 ? seg_len[s] - 1 : 0);
@@ -57,37 +60,44 @@ __global__ void k_span_marks(const uint32_t* seg_read, const int32_t* seg_start,
     if (last) { uint32_t t = tb + (uint32_t)(en >> 6) + 1; if (t > te) t = te; atomicSub(diff + t, 1); }
 }
 
-// Upper bound on the reads the reference's pileup engine holds at once (bam.pileup(..., max_depth = 200000),
-// BaseCellCounter.py:191): reads with a known barcode whose span overlaps a 64-position tile, maximum over tiles.
-static int live_read_bound(lsg_ctx* c) {
+// Upper bound on the reads the reference's pileup engine holds at once while it walks one cell type's BAM
+// (bam.pileup(..., max_depth = 200000), BaseCellCounter.py:191): reads of that cell type whose span overlaps a 64-position
+// tile, maximum over tiles and cell types.  Evaluated on request (lsg_max_live_reads), cached until reads or barcodes change.
+int live_read_bound(lsg_ctx* c) {
+    if (c->max_live_reads >= 0) return 0;
     const int64_t S = c->rd.n_segs;
-    c->max_live_reads = 0;
-    if (S <= 0 || c->n_tiles == 0) return 0;
+    if (S <= 0 || c->n_tiles == 0) { c->max_live_reads = 0; return 0; }
     hipStream_t st = c->stream;
     const size_t T = (size_t)c->n_tiles + 1;
     DevBuf diff, run, tmp, mx;
     auto fail = [&](int rc) { diff.release(); run.release(); tmp.release(); mx.release(); return rc; };
     if (diff.reserve(T * 4) || run.reserve(T * 4) || mx.reserve(64)) return fail(-1);
-    if (hipMemsetAsync(diff.p, 0, T * 4, st) != hipSuccess) { set_error("live bound: memset failed"); return fail(-1); }
-    hipLaunchKernelGGL(k_span_marks, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, st, c->rd.seg_read, c->rd.seg_start, c->rd.seg_len, S,
-                       c->rd.read_tid, c->rd.read_cb, c->d_tile_base.as<uint32_t>(), c->n_contigs, c->n_tiles, diff.as<int32_t>());
     size_t tb = 0, tb2 = 0;
     if (hipcub::DeviceScan::InclusiveSum(nullptr, tb, diff.as<int32_t>(), run.as<int32_t>(), (int)T, st) != hipSuccess ||
         hipcub::DeviceReduce::Max(nullptr, tb2, run.as<int32_t>(), mx.as<int32_t>(), (int)T, st) != hipSuccess ||
         tmp.reserve((tb > tb2 ? tb : tb2) + 256)) return fail(-1);
-    tb = tb2 = tmp.cap;
-    if (hipcub::DeviceScan::InclusiveSum(tmp.p, tb, diff.as<int32_t>(), run.as<int32_t>(), (int)T, st) != hipSuccess ||
-        hipcub::DeviceReduce::Max(tmp.p, tb2, run.as<int32_t>(), mx.as<int32_t>(), (int)T, st) != hipSuccess) { set_error("live bound: scan failed"); return fail(-1); }
-    int32_t m = 0;
-    if (hipMemcpyAsync(&m, mx.p, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { set_error("live bound: %s", hipGetErrorString(hipGetLastError())); return fail(-1); }
-    c->max_live_reads = m;
+    const bool by_ct = c->n_ct > 0 && c->n_cb > 0;
+    int64_t best = 0;
+    for (int ct = 0; ct < (by_ct ? c->n_ct : 1); ++ct) {
+        if (hipMemsetAsync(diff.p, 0, T * 4, st) != hipSuccess) { set_error("live bound: memset failed"); return fail(-1); }
+        hipLaunchKernelGGL(k_span_marks, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, st, c->rd.seg_read, c->rd.seg_start, c->rd.seg_len, S,
+                           c->rd.read_tid, c->rd.read_cb, by_ct ? c->d_celltype_of.as<uint8_t>() : (const uint8_t*)nullptr, c->n_cb, ct,
+                           c->d_tile_base.as<uint32_t>(), c->n_contigs, diff.as<int32_t>());
+        tb = tb2 = tmp.cap;
+        if (hipcub::DeviceScan::InclusiveSum(tmp.p, tb, diff.as<int32_t>(), run.as<int32_t>(), (int)T, st) != hipSuccess ||
+            hipcub::DeviceReduce::Max(tmp.p, tb2, run.as<int32_t>(), mx.as<int32_t>(), (int)T, st) != hipSuccess) { set_error("live bound: scan failed"); return fail(-1); }
+        int32_t m = 0;
+        if (hipMemcpyAsync(&m, mx.p, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { set_error("live bound: %s", hipGetErrorString(hipGetLastError())); return fail(-1); }
+        if (m > best) best = m;
+    }
+    c->max_live_reads = best;
     return fail(0);
 }
 
 int relayout_events(lsg_ctx* c) {
     const int64_t S = c->rd.n_segs;
-    if (S <= 0) { c->rd.n_events = 0; c->max_live_reads = 0; return 0; }
-    if (int rc = live_read_bound(c)) return rc;
+    c->max_live_reads = -1;
+    if (S <= 0) { c->rd.n_events = 0; return 0; }
     hipStream_t st = c->stream;
     DevBuf slots, base, noff, tmp, flag, aligned;
     auto fail = [&](int rc) { slots.release(); base.release(); noff.release(); tmp.release(); flag.release(); aligned.release(); return rc; };

@@ -159,6 +159,7 @@ int lsg_set_barcodes(lsg_ctx* c, const uint8_t* celltype_of, int32_t n_cb, int32
     }
     LSG_HIP(hipStreamSynchronize(c->stream));
     c->n_cb = n_cb; c->n_ct = n_celltypes;
+    c->max_live_reads = -1;
     c->counted = c->called = false;
     return 0;
 }
@@ -226,6 +227,8 @@ int lsg_fetch_counts(lsg_ctx* c, int32_t ct, int64_t* keys, uint8_t* ref, uint32
 
 int64_t lsg_max_live_reads(lsg_ctx* c) {
     if (!c) { set_error("lsg_max_live_reads: bad arguments"); return -1; }
+    if (hipSetDevice(c->device) != hipSuccess) { set_error("lsg_max_live_reads: hipSetDevice failed"); return -1; }
+    if (lsg::live_read_bound(c)) return -1;
     return c->max_live_reads;
 }
 

@@ -52,7 +52,10 @@ enum { WS_SLOT_PEX = 0, WS_NE_NSLOT, WS_NE_SLOT_BASE, WS_NE_ACC, WS_NE_GEOM, WS_
 } // namespace lsg
 
 struct lsg_ctx;
-namespace lsg { int relayout_events(lsg_ctx* c); }   // layout.hip: tile-aligned copy of the resident events
+namespace lsg {
+int relayout_events(lsg_ctx* c);   // layout.hip: tile-aligned copy of the resident events
+int live_read_bound(lsg_ctx* c);   // layout.hip: fills max_live_reads when it is stale (-1)
+}
 
 struct lsg_ctx {
     int device = 0;
@@ -80,7 +83,7 @@ struct lsg_ctx {
     lsg::DevBuf b_read_tid, b_read_pos, b_read_flag, b_read_mapq, b_read_cb;
     lsg::DevBuf b_seg_read, b_seg_start, b_seg_len, b_seg_ev_off, b_events;
     uint64_t entries_upper = 0;           // sum over segments of tiles overlapped
-    int64_t max_live_reads = 0;           // layout.hip: bound on the reads live at once in the reference's pileup buffer
+    int64_t max_live_reads = -1;          // layout.hip: bound on the reads live at once in the reference's pileup buffer (-1 = stale)
 
     // count-stage workspace
     lsg::DevBuf d_read_key, d_unit_cnt, d_unit_off, d_unit_fill;

@@ -86,6 +86,21 @@ class DepthCapExceeded(ValueError):
     """More reads can be live at one position than the reference's pileup admits; its cap is not modelled here."""
 
 
+def check_depth_cap(engine: Engine, what: str, allow_depth_overflow: Optional[bool] = None) -> int:
+    """Raise when, under the engine's current barcode table, some cell type can hold more live reads at one position than the
+    reference's pileup admits (its cap is not modelled; below the cap it never fires and the counts are identical)."""
+    live = engine.max_live_reads()
+    if live > PILEUP_MAX_DEPTH:
+        msg = ("%s: up to %d reads of one cell type overlap one 64-position tile; the reference's pileup stops admitting reads above "
+               "max_depth = %d, which this library does not model, so counts there could differ" % (what, live, PILEUP_MAX_DEPTH))
+        if allow_depth_overflow is None:
+            allow_depth_overflow = os.environ.get("LONGSOM_ALLOW_DEPTH_OVERFLOW", "0") == "1"
+        if not allow_depth_overflow:
+            raise DepthCapExceeded(msg + " (set LONGSOM_ALLOW_DEPTH_OVERFLOW=1 to count every read anyway)")
+        sys.stderr.write("warning: " + msg + "\n")
+    return live
+
+
 def load_sample(bam: str, barcodes_tsv: str, ref_fasta: str, engine: Engine, min_mapq: int, allow_depth_overflow: Optional[bool] = None) -> Resident:
     t = {}
     t0 = time.time()
@@ -106,15 +121,7 @@ def load_sample(bam: str, barcodes_tsv: str, ref_fasta: str, engine: Engine, min
     engine.set_barcodes(bc.celltype_of, len(bc.celltype_names))
     engine.set_region()
     engine.load_reads(dec.records)
-    live = engine.max_live_reads()
-    if live > PILEUP_MAX_DEPTH:
-        msg = ("%s: up to %d reads overlap one 64-position tile; the reference's pileup stops admitting reads above max_depth = %d, "
-               "which this library does not model, so counts there could differ" % (bam, live, PILEUP_MAX_DEPTH))
-        if allow_depth_overflow is None:
-            allow_depth_overflow = os.environ.get("LONGSOM_ALLOW_DEPTH_OVERFLOW", "0") == "1"
-        if not allow_depth_overflow:
-            raise DepthCapExceeded(msg + " (set LONGSOM_ALLOW_DEPTH_OVERFLOW=1 to count every read anyway)")
-        sys.stderr.write("warning: " + msg + "\n")
+    check_depth_cap(engine, bam, allow_depth_overflow)
     t["load"] = time.time() - t0
     return Resident(engine, dec, bc, contig_names, t)
 
@@ -128,6 +135,7 @@ def run_chain(res: Resident, celltype_of: np.ndarray, celltype_names: List[str],
     t = dict(res.seconds)
     t0 = time.time()
     eng.set_barcodes(celltype_of, len(celltype_names))
+    check_depth_cap(eng, sample_id)
     eng.pileup_count(params.count())
     n_sites, n_cand = eng.call_step1(params.call())
     t["gpu_count_call"] = time.time() - t0

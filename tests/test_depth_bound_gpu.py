@@ -10,8 +10,8 @@ from longsom_amd.synth_simple import random_records, random_reference
 pytestmark = pytest.mark.gpu
 
 
-def tile_bound(rec, contig_lens):
-    """numpy restatement: reads with a barcode, span = first segment start .. last segment end, counted per 64-position tile."""
+def tile_bound(rec, contig_lens, keep):
+    """numpy restatement: reads selected by keep[read], span = first segment start .. last segment end, counted per 64-position tile."""
     best = 0
     exact = 0
     sr = rec.seg_read.astype(np.int64)
@@ -19,7 +19,7 @@ def tile_bound(rec, contig_lens):
         nt = (int(L) + 63) // 64
         diff = np.zeros(nt + 1, np.int64)
         pdiff = np.zeros(int(L) + 2, np.int64)
-        for r in np.flatnonzero((rec.read_tid == tid) & (rec.read_cb >= 0)):
+        for r in np.flatnonzero((rec.read_tid == tid) & keep):
             segs = np.flatnonzero(sr == r)
             if len(segs) == 0:
                 continue
@@ -39,12 +39,19 @@ def test_bound_equals_the_tile_restatement_and_covers_the_true_depth(engine, see
     engine.set_contigs(lens)
     for t, L in enumerate(lens):
         engine.load_reference(t, random_reference(rng, int(L)))
-    engine.set_barcodes(np.zeros(40, np.uint8), 1)
+    ct_of = rng.integers(0, 3, 40).astype(np.uint8)
+    ct_of[ct_of == 2] = 255                                      # a third of the barcodes unused
+    engine.set_barcodes(ct_of, 2)
     engine.load_reads(rec)
-    want, exact = tile_bound(rec, lens)
+    has_cb = rec.read_cb >= 0
+    ct_read = np.where(has_cb, ct_of[np.maximum(rec.read_cb, 0)], 255)
+    per_ct = [tile_bound(rec, lens, ct_read == ct) for ct in range(2)]
     got = engine.max_live_reads()
-    assert got == want
-    assert got >= exact > 0
+    assert got == max(b for b, _ in per_ct)
+    assert got >= max(e for _, e in per_ct) > 0
+    # the bound follows the barcode table: everything in one cell type = the union of the reads with a barcode
+    engine.set_barcodes(np.zeros(40, np.uint8), 1)
+    assert engine.max_live_reads() == tile_bound(rec, lens, has_cb)[0] >= got
 
 
 def test_pipeline_refuses_a_sample_above_the_cap(engine, tmp_path, monkeypatch, capsys):
