@@ -223,3 +223,34 @@ def reannotation(argv=None):
                                     gnomad_af_json=a.gnomAD_json, device=a.device)
     print(json.dumps({"hccv": out.hccv, "genotype": out.genotype, "barcodes": out.barcodes, "cells_kept": out.n_cells_kept, "cancer_cells": out.n_cancer,
                       "pass2_step3": out.pass2.step3 if out.pass2 else None, "seconds": out.timings}))
+
+
+def pon(argv=None):
+    """PoN.py --in_tsv LIST --out_file OUT [--min_samples 2] [--rm_prefix Yes|No]  (scripts/PoN/PoN.py:10-16)."""
+    from . import pon as _pon
+    ap = argparse.ArgumentParser(description="Script to build a SComatic Panel Of Normals (PoNs)")
+    ap.add_argument("--in_tsv", required=True); ap.add_argument("--out_file", required=True)
+    ap.add_argument("--min_samples", type=int, default=2); ap.add_argument("--rm_prefix", choices=["Yes", "No"], default="Yes")
+    a = ap.parse_args(argv)
+    print("-----------------------------------------------------------\n1. Building Panel Of Normals ...\n"
+          "-----------------------------------------------------------\n")
+    _pon.build_from_files(a.in_tsv, a.out_file, a.min_samples, a.rm_prefix)
+
+
+def pon_chain(argv=None):
+    """rules/PoN.smk SplitBam_PoN .. PoN fused: --normals is a TSV of id, bam, barcodes.tsv (workflow/rules/PoN.gpu.smk)."""
+    ap = argparse.ArgumentParser(description="Panel of normals of LongSom on one GPU: count + step-1 call of every normal, then the PoN table")
+    ap.add_argument("--normals", required=True); ap.add_argument("--ref", required=True); ap.add_argument("--outdir", required=True)
+    ap.add_argument("--alpha1", type=float, required=True); ap.add_argument("--beta1", type=float, required=True)
+    ap.add_argument("--alpha2", type=float, required=True); ap.add_argument("--beta2", type=float, required=True)
+    ap.add_argument("--min_ac_cells", type=int, default=1); ap.add_argument("--min_ac_reads", type=int, default=1)
+    ap.add_argument("--min_cells", type=int, default=1); ap.add_argument("--min_cell_types", type=int, default=1)
+    ap.add_argument("--min_mq", type=int, default=60); ap.add_argument("--min_samples", type=int, default=1)
+    ap.add_argument("--rm_prefix", choices=["Yes", "No"], default="No"); ap.add_argument("--no_tables", action="store_true")
+    ap.add_argument("--device", type=int, default=0)
+    a = ap.parse_args(argv)
+    normals = [tuple(l.rstrip("\n").split("\t")[:3]) for l in open(a.normals) if l.strip() and not l.startswith("#")]
+    p = pipeline.pon_params(alpha1=a.alpha1, beta1=a.beta1, alpha2=a.alpha2, beta2=a.beta2, min_ac_cells=a.min_ac_cells, min_ac_reads=a.min_ac_reads,
+                            min_cells=a.min_cells, min_cell_types=a.min_cell_types, min_mapping_quality=a.min_mq)
+    out = pipeline.run_pon(normals, a.ref, a.outdir, p, a.min_samples, a.rm_prefix, not a.no_tables, device=a.device)
+    print(json.dumps({"pon": out.pon, "sites": out.n_sites, "seconds": out.timings}))

@@ -16,7 +16,7 @@ from typing import Dict, List, Optional
 import numpy as np
 import pandas as pd
 
-from . import calling, hostio, tsvio
+from . import calling, hostio, pon, tsvio
 from ._lib import CallParams, CountParams
 from .engine import Engine
 
@@ -29,6 +29,7 @@ class SnvParams:
     min_dp: int = 5
     min_cc: int = 5
     min_cell_types: int = 2
+    min_cells: int = 5                     # BaseCellCalling.step1.py --min_cells (the PoN rules set 1)
     min_distance: int = 0
     max_gnomad_vaf: float = 0.01
     delta_vaf: float = 0.05
@@ -48,7 +49,7 @@ class SnvParams:
     def call(self) -> CallParams:
         return CallParams.longsom_defaults(alpha1=self.alpha1, beta1=self.beta1, alpha2=self.alpha2, beta2=self.beta2,
                                            min_ac_cells=self.min_ac_cells, min_ac_reads=self.min_ac_reads,
-                                           min_cell_types=self.min_cell_types)
+                                           min_cell_types=self.min_cell_types, min_cells=self.min_cells)
 
 
 @dataclass
@@ -126,11 +127,10 @@ def load_sample(bam: str, barcodes_tsv: str, ref_fasta: str, engine: Engine, min
     return Resident(engine, dec, bc, contig_names, t)
 
 
-def run_chain(res: Resident, celltype_of: np.ndarray, celltype_names: List[str], report: Dict[str, int], out_dir: str, sample_id: str,
-              params: SnvParams, editing: Optional[str] = None, pon_sr: Optional[str] = None, pon_lr: Optional[str] = None,
-              gnomad_af_json: Optional[str] = None) -> SnvOutputs:
-    """SplitBam report -> BaseCellCounter -> MergeCounts -> BaseCellCalling step 1-3 for one barcode -> cell-type table over the
-    resident reads (celltype_of[barcode id] = index into celltype_names, 255 = barcode not listed)."""
+def chain_step1(res: Resident, celltype_of: np.ndarray, celltype_names: List[str], report: Dict[str, int], out_dir: str, sample_id: str,
+                params: SnvParams, write_tables: bool = True):
+    """SplitBam report -> BaseCellCounter -> MergeCounts -> BaseCellCalling step 1 over the resident reads.  Returns (outputs, text of
+    the rows step 2 keeps, call records, timings); write_tables=False keeps everything off the disk except the report."""
     eng, contig_names = res.engine, res.contig_names
     t = dict(res.seconds)
     t0 = time.time()
@@ -140,16 +140,20 @@ def run_chain(res: Resident, celltype_of: np.ndarray, celltype_names: List[str],
     n_sites, n_cand = eng.call_step1(params.call())
     t["gpu_count_call"] = time.time() - t0
     t0 = time.time()
-    per_ct = [eng.fetch_counts(ct) for ct in range(len(celltype_names))]
-    calls = eng.fetch_calls()
-    t["fetch"] = time.time() - t0
-    t0 = time.time()
     d = {k: os.path.join(out_dir, k) for k in ("SplitBam", "BaseCellCounter/" + sample_id, "MergeCounts", "BaseCellCalling")}
     for p in d.values():
         os.makedirs(p, exist_ok=True)
     out = SnvOutputs(report=os.path.join(d["SplitBam"], sample_id + ".report.txt"), counts={}, merged="", step1="", step2="", step3="",
                      step3_unfiltered="")
     write_report(out.report, report, t["decode"])
+    if not write_tables:
+        calls = eng.fetch_calls(candidates_only=True)
+        t["fetch"] = time.time() - t0
+        return out, None, calls, t
+    per_ct = [eng.fetch_counts(ct) for ct in range(len(celltype_names))]
+    calls = eng.fetch_calls()
+    t["fetch"] = time.time() - t0
+    t0 = time.time()
     date = tsvio.file_date()
     for ct, name in enumerate(celltype_names):
         p = os.path.join(d["BaseCellCounter/" + sample_id], "%s.%s.tsv" % (sample_id, name))
@@ -160,6 +164,17 @@ def run_chain(res: Resident, celltype_of: np.ndarray, celltype_names: List[str],
     out.step1 = os.path.join(d["BaseCellCalling"], sample_id + ".calling.step1.tsv")
     s1 = tsvio.write_step1_tsv(out.step1, calls, per_ct, contig_names, celltype_names, header)      # s1 = header + the rows step 2 keeps
     t["write_tables"] = time.time() - t0
+    return out, s1, calls, t
+
+
+def run_chain(res: Resident, celltype_of: np.ndarray, celltype_names: List[str], report: Dict[str, int], out_dir: str, sample_id: str,
+              params: SnvParams, editing: Optional[str] = None, pon_sr: Optional[str] = None, pon_lr: Optional[str] = None,
+              gnomad_af_json: Optional[str] = None) -> SnvOutputs:
+    """SplitBam report -> BaseCellCounter -> MergeCounts -> BaseCellCalling step 1-3 for one barcode -> cell-type table over the
+    resident reads (celltype_of[barcode id] = index into celltype_names, 255 = barcode not listed)."""
+    eng, contig_names = res.engine, res.contig_names
+    out, s1, _, t = chain_step1(res, celltype_of, celltype_names, report, out_dir, sample_id, params)
+    d = {"BaseCellCalling": os.path.join(out_dir, "BaseCellCalling")}
     t0 = time.time()
     keys = [calling.read_posset_keys(p, contig_names, params.reference_gz_compat) for p in (editing, pon_sr, pon_lr)]
     af = json.load(open(gnomad_af_json)) if gnomad_af_json else None
@@ -275,3 +290,49 @@ def run_reannotation(bam: str, barcodes_tsv: str, ref_fasta: str, out_dir: str, 
     finally:
         if own:
             eng.close()
+
+
+@dataclass
+class PonOutputs:
+    pon: str
+    step1: Dict[str, str]
+    n_sites: int = 0
+    timings: Dict[str, Dict[str, float]] = field(default_factory=dict)
+
+
+def pon_params(**kw) -> SnvParams:
+    """config/config.yaml:33-37 (PoN block) over the BaseCellCalling step-1 defaults (rules/PoN.smk BaseCellCalling_step1_PoN)."""
+    base = dict(min_ac_cells=1, min_ac_reads=1, min_cells=1, min_cell_types=1)
+    base.update(kw)
+    return SnvParams(**base)
+
+
+def run_pon(normals, ref_fasta: str, out_dir: str, params: Optional[SnvParams] = None, min_samples: int = 1, rm_prefix: str = "No",
+            write_tables: bool = True, out_name: str = "PoN_LR.tsv", device: int = 0, engine: Optional[Engine] = None) -> PonOutputs:
+    """rules/PoN.smk from SplitBam_PoN to PoN in one process: for every normal (id, bam, barcodes.tsv) the count + step-1 call
+    chain, then scripts/PoN/PoN.py over the sites with a filter status.  The beta-binomial parameters come in through `params`
+    (BetaBinEstimation.py's VGAM fit stays outside).  write_tables=False skips the per-normal tables (the PoN needs only the call
+    records); the PoN file is the same either way.  Output layout: <out_dir>/PoN/{SplitBam,BaseCellCounter,MergeCounts,
+    BaseCellCalling,PoN}/ as in the rule file."""
+    params = params or pon_params()
+    own = engine is None
+    eng = engine or Engine(device)
+    root = os.path.join(out_dir, "PoN")
+    entries, step1, timings = [], {}, {}
+    try:
+        for sample_id, bam, barcodes_tsv in normals:
+            res = load_sample(bam, barcodes_tsv, ref_fasta, eng, params.min_mapping_quality)
+            out, _, calls, t = chain_step1(res, res.table.celltype_of, res.table.celltype_names, res.dec.report, root, sample_id, params, write_tables)
+            label = sample_id + ".calling.step1.tsv"          # basename of the table, the sample id of PoN.py:55
+            entries += pon.sites_of_calls(calls, res.contig_names, label)
+            step1[sample_id] = out.step1
+            timings[sample_id] = t
+    finally:
+        if own:
+            eng.close()
+    os.makedirs(os.path.join(root, "PoN"), exist_ok=True)
+    path = os.path.join(root, "PoN", out_name)
+    text = pon.pon_text(entries, min_samples, rm_prefix)
+    with open(path, "w") as f:
+        f.write(text)
+    return PonOutputs(path, step1, sum(1 for l in text.split("\n") if l and not l.startswith("#")), timings)
