@@ -28,11 +28,15 @@ namespace lsg {
 
 constexpr uint32_t KEY_INVALID = 0xFFFFFFFFu;
 constexpr uint32_t CB_MASK = 0x00FFFFFFu;
-// entry = {key, e, m, 0}: e = low 32 bits of the ADDRESS of the entry's first event, m = [0..15] address bits 32..47,
-// [16..22] 2 * first lane, [23] first entry of a barcode run (set by the grouping step), [24] forward strand,
-// [25..31] number of events.  m >> 24 = 2 * events + strand is the entry's buffer size for the bounds-checked loads
-// (the odd byte never admits another 2-byte event).
-constexpr uint32_t META_NEWRUN = 1u << 23, META_FWD = 1u << 24;
+// entry = {key, e, m, 0}: e = low 32 bits of the ADDRESS of the 128-byte line that holds the entry's 64-position tile slot
+// (events are resident tile-aligned, layout.hip: lane = position within the tile, positions outside the segment are
+// zero padding, so an entry is loaded as one whole line with no bounds and no first-lane arithmetic);
+// m = [0..14] address bits 32..46, [15] the barcode run has exactly this one entry, [16..23] zero, [24..29] events - 1,
+// [30] forward strand, [31] first entry of a barcode run (both run bits are set by the grouping step).  The layout lets
+// the walk take "strand bit at packed position 14" straight from the upper half of m (bits 8..13 and 15 of that half are
+// masked off again) and mask the address half with the one s_and that also drops bit 15.
+constexpr uint32_t META_NEWRUN = 1u << 31, META_FWD = 1u << 30, META_SINGLE = 1u << 15;
+__host__ __device__ __forceinline__ uint32_t meta_events(uint32_t m) { return ((m >> 24) & 63u) + 1u; }
 #define LSG_AS3 __attribute__((address_space(3)))
 __device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(LSG_AS3 const void*)p; }
 constexpr int CAPW = 256;            // max entries of a wave-processed slot
@@ -83,6 +87,7 @@ struct CountArgs {
     uint32_t* slot_pex; uint32_t* chunk_start;   // wave kernel: work prefix over the small-slot list, first slot of every chunk
     uint32_t* slot_list; uint32_t* multi_list; uint32_t* macc; uint32_t* slices; uint32_t* huge_list;
     uint32_t n_ne, n_slots, n_multi;
+    uint32_t zero_lo, zero_hi;            // address (e, m form) of a 128-byte line of zeros behind the resident events
     uint32_t presorted;                   // multi-slot units' records were written grouped by k_sort_deep (no k_group_block pass, any slot size)
     unsigned long long* scalars;
     uint32_t* rows[LSG_MAX_CELLTYPES];
@@ -281,10 +286,11 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_segments(CountArgs a) {
                             const int32_t tstart = (int32_t)((tt - g.tb) << 6);
                             const int32_t lo = g.st > tstart ? g.st : tstart;
                             const int32_t hi = g.st + g.ln < tstart + TILE_W ? g.st + g.ln : tstart + TILE_W;
-                            const uint64_t addr = (uint64_t)(uintptr_t)(a.events + (g.evoff + (lo - g.st)));
+                            // the line of this tile slot: the event of (lo) sits at lane (lo - tstart) of it
+                            const uint64_t addr = (uint64_t)(uintptr_t)(a.events + (g.evoff + (lo - g.st) - (lo - tstart)));
                             a.ent[pos] = make_uint4(g.key, (uint32_t)addr,
-                                                    (uint32_t)((addr >> 32) & 0xffffu) | (((g.key >> 24) & 1u) ? 0u : META_FWD) |
-                                                        ((uint32_t)(2 * (lo - tstart)) << 16) | ((uint32_t)(hi - lo) << 25), 0u);
+                                                    (uint32_t)((addr >> 32) & 0x7fffu) | (((g.key >> 24) & 1u) ? 0u : META_FWD) |
+                                                        ((uint32_t)(hi - lo - 1) << 24), 0u);
                         }
                     }
                 }
@@ -422,7 +428,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_deep(CountArgs a, uint32_
         for (uint32_t i = t; i < n; i += SORT_THREADS) {
             const uint4 e = a.ent[src + i];
             atomicAdd(&cur[a.ct_rank[e.x & CB_MASK]], 1u);
-            nev += e.z >> 25;
+            nev += meta_events(e.z);
         }
         __syncthreads();
         // exclusive scan of cur[0..R) -> start; every thread owns a contiguous chunk
@@ -464,7 +470,9 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_deep(CountArgs a, uint32_
             const uint4 e = a.ent[src + i];
             const uint32_t r = a.ct_rank[e.x & CB_MASK];
             const uint32_t pos = atomicAdd(&cur[r], 1u);
-            a.rec[a.ent_half + src + pos] = make_uint2(e.y, e.z | (pos == start[r] ? META_NEWRUN : 0u));
+            const uint32_t r_end = r + 1 < R ? start[r + 1] : n;
+            const uint32_t run = pos != start[r] ? 0u : (r_end - pos == 1u ? (META_NEWRUN | META_SINGLE) : META_NEWRUN);
+            a.rec[a.ent_half + src + pos] = make_uint2(e.y, e.z | run);
         }
     }
     // events k_walk_block will read (statistics)
@@ -546,26 +554,90 @@ struct Acc {
 // into the workgroup's LDS accumulators [NCTR][64] (shared by its waves, hence ds_add), which keeps the walk loop
 // at ~55 VGPRs = 8 waves per SIMD, and the event loads in flight are what hides HBM latency there.
 struct WalkAcc {
-    uint32_t ncdup, mask, npk;
+    uint32_t nc, mask, npk, tot;         // nc: barcode runs with a counted event at this lane; tot: counted events flushed so far
+    uint32_t open;                       // wave-uniform: a run of several entries is open (mask == 0 whenever it is not)
     uint32_t* sink;                      // [NCTR][64] words in LDS
-    __device__ __forceinline__ void init(uint32_t* s) { ncdup = mask = npk = 0; sink = s; }
+    __device__ __forceinline__ void init(uint32_t* s) { nc = mask = npk = tot = 0; open = 0; sink = s; }
     __device__ __forceinline__ void flush_pk(uint32_t* pk, int lane) {
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             const uint32_t v = pk[s * 64 + lane];
             pk[s * 64 + lane] = 0;
             if (v) {
+                const uint32_t bc = (v >> 20) & 63u;
+                tot += bc;
                 atomicAdd(&sink[(17 + s) * 64 + lane], v & 0x3fffu); atomicAdd(&sink[(25 + s) * 64 + lane], (v >> 14) & 63u);
-                atomicAdd(&sink[(9 + s) * 64 + lane], (v >> 20) & 63u); atomicAdd(&sink[(1 + s) * 64 + lane], v >> 26);
+                atomicAdd(&sink[(9 + s) * 64 + lane], bc); atomicAdd(&sink[(1 + s) * 64 + lane], v >> 26);
             }
         }
         npk = 0;
     }
-    __device__ __forceinline__ void add(uint32_t m, uint32_t ev, uint32_t thr, uint32_t pkl) { pile_add(mask, ncdup, m, ev, thr, pkl); ++npk; }
+    __device__ __forceinline__ void close_run() { nc += mask & 1u; mask = 0; }
+    // One record (m wave-uniform, held in an SGPR by the scalar record loads): every decision below is a SCALAR branch.
+    // A run of ONE entry cannot hold a duplicate (7 vector operations), the first entry of a longer run has nothing to compare
+    // with (9), the others carry the seen-symbol mask and the duplicate bit (12); a run of several entries is closed when the
+    // next run starts (3).  Written as one asm block: left to the compiler the branches become per-lane selects plus register
+    // shuffles between the unrolled copies and cost more than the branch-free form (pile_add, 15.75 per entry) they replace.
+    //   vm   = all ones when the event is counted: valid bit set and quality >= min_bq   (thr1 = 0x800 + min_bq - 1)
+    //   base = quality | count 1 | strand (cst: bit 20, bit 14 when forward); addr = this lane's word in the symbol's row
+    __device__ __forceinline__ void add(uint32_t m, uint32_t ev, uint32_t thr, uint32_t pkl) {
+        uint32_t t0, t1, vm, base, addr;
+        open = (uint32_t)__builtin_amdgcn_readfirstlane((int)open);        // uniform by construction; says so to the compiler
+        // base = quality | upper half of m: the strand bit lands on packed bit 14; what else the half carries (events - 1 in
+        // bits 8..13, the run bit in 15) is cleared by k1 / k2, which also add the count (bit 20) and keep the duplicate bit (26)
+        asm volatile(
+            "v_and_b32 %[t0], 0x8ff, %[ev]\n\t"
+            "v_sub_u32 %[t0], %[thr1], %[t0]\n\t"
+            "v_ashrrev_i32 %[vm], 31, %[t0]\n\t"
+            "v_or_b32_sdwa %[base], %[m], %[ev] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:BYTE_0\n\t"
+            "v_and_or_b32 %[addr], %[ev], %[c700], %[pkl]\n\t"
+            "s_bitcmp0_b32 %[m], 31\n\t"
+            "s_cbranch_scc1 3f\n\t"                                  // not the start of a run
+            "s_cmp_eq_u32 %[open], 0\n\t"
+            "s_cbranch_scc1 1f\n\t"
+            "v_and_b32 %[t0], 1, %[mask]\n\t"                          // close the run of several entries before this one
+            "v_add_u32 %[nc], %[nc], %[t0]\n\t"
+            "v_mov_b32 %[mask], 0\n"
+            "1:\n\t"
+            "v_and_or_b32 %[t0], %[base], %[k1], %[k20]\n\t"           // (base & 0x40ff) | 1 << 20
+            "v_and_b32 %[t0], %[vm], %[t0]\n\t"
+            "ds_add_u32 %[addr], %[t0]\n\t"
+            "s_bitcmp0_b32 %[m], 15\n\t"
+            "s_cbranch_scc1 2f\n\t"
+            "v_sub_u32 %[nc], %[nc], %[vm]\n\t"                        // a run of one entry: counted once if counted
+            "s_mov_b32 %[open], 0\n\t"
+            "s_branch 4f\n"
+            "2:\n\t"
+            "v_bfe_u32 %[t0], %[ev], 8, 4\n\t"                         // first entry of a longer run: mask = its symbol
+            "v_lshl_or_b32 %[t0], 1, %[t0], 1\n\t"
+            "v_and_b32 %[mask], %[vm], %[t0]\n\t"
+            "s_mov_b32 %[open], 1\n\t"
+            "s_branch 4f\n"
+            "3:\n\t"
+            "v_bfe_u32 %[t0], %[ev], 8, 4\n\t"                         // 8 + class
+            "v_bfe_u32 %[t1], %[mask], %[t0], 1\n\t"                   // symbol already seen in this run: duplicate
+            "v_and_or_b32 %[base], %[base], %[k1], %[k20]\n\t"
+            "v_lshl_or_b32 %[t1], %[t1], 26, %[base]\n\t"
+            "v_and_b32 %[t1], %[vm], %[t1]\n\t"
+            "ds_add_u32 %[addr], %[t1]\n\t"
+            "v_lshl_or_b32 %[t0], 1, %[t0], 1\n\t"
+            "v_and_or_b32 %[mask], %[t0], %[vm], %[mask]\n"
+            "4:"
+            : [t0] "=&v"(t0), [t1] "=&v"(t1), [vm] "=&v"(vm), [base] "=&v"(base), [addr] "=&v"(addr),
+              [mask] "+v"(mask), [nc] "+v"(nc), [open] "+s"(open)
+            : [ev] "v"(ev), [m] "s"(m), [thr1] "s"(thr - 1u), [c700] "s"(0x700u), [k1] "s"(0x40ffu), [k20] "v"(1u << 20), [pkl] "v"(pkl)
+            : "scc", "memory");
+        ++npk;
+    }
     __device__ __forceinline__ void reserve(uint32_t next, uint32_t* pk, int lane) {
         if (npk + next > (uint32_t)FLUSH_EVERY) flush_pk(pk, lane);
     }
-    __device__ __forceinline__ void finish(uint32_t* pk, int lane) { flush_pk(pk, lane); atomicAdd(&sink[lane], ncdup); }
+    // duplicates within barcode runs = counted events - runs that counted one (NC = sum(BC) - this, see Acc)
+    __device__ __forceinline__ void finish(uint32_t* pk, int lane) {
+        if (open) { close_run(); open = 0; }
+        flush_pk(pk, lane);
+        atomicAdd(&sink[lane], tot - nc);
+    }
 };
 
 // a unit's finished counters read straight from an LDS accumulator block [NCTR][64] (no register copy)
@@ -578,12 +650,12 @@ struct LdsCounters {
     __device__ __forceinline__ uint32_t NCDUP() const { return s[lane]; }
 };
 
-// Event load of one entry (es, ms wave-uniform; lane2 = 2 * lane): a bounds-checked raw buffer load over exactly the
-// entry's event bytes, so lanes before or after the entry's range read 0 (= not countable) with no per-lane arithmetic.
+// Event load of one entry (es, ms wave-uniform; lane2 = 2 * lane): the entry's whole 128-byte line through a raw buffer
+// descriptor {line address, 128 bytes}.  Lanes outside the segment read the layout's zero padding (= not countable).
 __device__ __forceinline__ uint32_t load_event(uint32_t es, uint32_t ms, uint32_t lane2) {
-    char* base = reinterpret_cast<char*>((uintptr_t)((((uint64_t)(ms & 0xffffu)) << 32) | es));
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)(ms >> 24), 0x00020000);
-    return (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(rs, (int)(lane2 - ((ms >> 16) & 0x7fu)), 0, 0);
+    char* base = reinterpret_cast<char*>((uintptr_t)((((uint64_t)(ms & 0x7fffu)) << 32) | es));
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, 128, 0x00020000);
+    return (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(rs, (int)lane2, 0, 0);
 }
 
 __device__ __forceinline__ uint32_t bq_threshold(const CountArgs& a) {
@@ -623,8 +695,8 @@ __device__ __forceinline__ void walk(const CountArgs& a, Acc& acc, const uint32_
     const uint32_t thr = bq_threshold(a);
     for (int jb = j0; jb < j1; jb += 64) {
         const int nb = j1 - jb < 64 ? j1 - jb : 64;
-        uint32_t e = 0, m = 0;
-        if (lane < nb) { e = gev[jb + lane]; m = gmeta[jb + lane]; acc.nev += m >> 25; }
+        uint32_t e = a.zero_lo, m = a.zero_hi;                      // lanes past the last record: a line of zeros
+        if (lane < nb) { e = gev[jb + lane]; m = gmeta[jb + lane]; acc.nev += meta_events(m); }
         walk_regs(acc, e, m, nb, thr, pk, lane);
     }
 }
@@ -701,7 +773,10 @@ __device__ __forceinline__ int group_by_cb(const CountArgs& a, uint32_t src, int
         if (t + r * T < n) {
             const uint32_t p = hs[r];
             const bool first = p == 0 || (gkey[p - 1] & CB_MASK) != (ek[r] & CB_MASK);
-            if (TO_GLOBAL) a.rec[src + p] = make_uint2(ee[r], em[r] | (first ? META_NEWRUN : 0u));   // the walk's 8-byte records
+            if (TO_GLOBAL) {                                                                       // the walk's 8-byte records
+                const bool last = p + 1 == (uint32_t)n || (gkey[p + 1] & CB_MASK) != (ek[r] & CB_MASK);
+                a.rec[src + p] = make_uint2(ee[r], em[r] | (first ? (last ? (META_NEWRUN | META_SINGLE) : META_NEWRUN) : 0u));
+            }
             else if (first) atomicOr(&gmeta[p], META_NEWRUN);
         }
     }
@@ -876,9 +951,9 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void k_pileup_wave(CountArgs 
                 }
                 general = __ballot(dup) != 0ull;
                 if (!general) {
-                    const uint32_t m = lane < n ? (cur.z | META_NEWRUN) : 0u;
-                    acc.nev += m >> 25;
-                    walk_regs(acc, cur.y, m, n, bq_threshold(a), pk, lane);
+                    const uint32_t m = lane < n ? (cur.z | META_NEWRUN) : a.zero_hi;      // lanes past the last entry: a line of zeros
+                    if (lane < n) acc.nev += meta_events(m);
+                    walk_regs(acc, lane < n ? cur.y : a.zero_lo, m, n, bq_threshold(a), pk, lane);
                 }
             }
             if (general) {
@@ -948,7 +1023,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_group_block(CountArgs a) {
             continue;
         }
         const uint32_t src = a.slot_off[s];
-        for (int i = t; i < n; i += BLOCK_THREADS) nev += a.ent[src + i].z >> 25;      // events k_walk_block will read (statistics)
+        for (int i = t; i < n; i += BLOCK_THREADS) nev += meta_events(a.ent[src + i].z);      // events k_walk_block will read (statistics)
         group_by_cb<true, HB, CAPB, true>(a, src, n, L.gcb, nullptr, nullptr, L.tkey, L.tcnt, t, L.wave_tot);
         if (t <= NSLICE) {
             int j = (int)((int64_t)n * t / NSLICE);
@@ -975,8 +1050,8 @@ template <bool FULL>
 __device__ __forceinline__ void issue8(const u32x16& R, int cnt, uint32_t lane2, uint32_t (&ev)[8]) {
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-        const uint32_t m = (FULL || u < cnt) ? R[2 * u + 1] : 0u;      // size 0: every lane reads 0
-        ev[u] = load_event(R[2 * u], m, lane2);
+        ev[u] = 0;
+        if (FULL || u < cnt) ev[u] = load_event(R[2 * u], R[2 * u + 1], lane2);      // (words past the slice are not records)
     }
 }
 template <bool FULL>
@@ -1230,7 +1305,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_pileup_huge(CountArgs a) {
                                 uint32_t k = KEY_INVALID, e = 0, m = 0;
                                 if (ib + lane < n) { const uint4 v = a.ent[src + ib + lane]; k = v.x; e = v.y; m = v.z; }
                                 bool match = k != KEY_INVALID && (k & CB_MASK) == c;
-                                if (match) acc.nev += m >> 25;
+                                if (match) acc.nev += meta_events(m);
                                 unsigned long long mm = __ballot(match);
                                 while (mm) {
                                     int l = __ffsll((long long)mm) - 1; mm &= mm - 1;
@@ -1373,6 +1448,10 @@ static void fill_args(lsg_ctx* c, const lsg_count_params* p, CountArgs& a) {
     a.read_tid = c->rd.read_tid; a.read_flag = c->rd.read_flag; a.read_mapq = c->rd.read_mapq; a.read_cb = c->rd.read_cb;
     a.seg_read = c->rd.seg_read; a.seg_start = c->rd.seg_start; a.seg_len = c->rd.seg_len; a.seg_ev_off = c->rd.seg_ev_off;
     a.events = c->rd.events;
+    {   // layout.hip leaves >= 256 zero bytes behind the last tile slot: a whole line of "no event here"
+        const uint64_t z = (uint64_t)(uintptr_t)(c->rd.events + c->rd.n_events);
+        a.zero_lo = (uint32_t)z; a.zero_hi = (uint32_t)(z >> 32) & 0x7fffu;
+    }
     a.tile_base = c->d_tile_base.as<uint32_t>(); a.contig_len = c->d_contig_len.as<int64_t>();
     a.ref_ptr = c->d_ref_ptrs.as<const uint8_t*>(); a.celltype_of = c->d_celltype_of.as<uint8_t>();
     a.n_contigs = c->n_contigs; a.n_cb = c->n_cb; a.n_ct = c->n_ct;
@@ -1425,6 +1504,9 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
     if (c->n_contigs <= 0) { set_error("lsg_pileup_count: no contigs set"); return -2; }
     if (c->n_ct <= 0) { set_error("lsg_pileup_count: no barcodes set"); return -2; }
     if (!c->rd.events && c->rd.n_events > 0) { set_error("lsg_pileup_count: no reads loaded"); return -2; }
+    if ((((uint64_t)(uintptr_t)(c->rd.events + c->rd.n_events) + 256) >> 47) != 0) {      // entry meta keeps address bits 32..46
+        set_error("lsg_pileup_count: resident events lie above the 47-bit address range"); return -1;
+    }
     for (int t = 0; t < c->n_contigs; ++t)
         if (!c->ref_ptr[t]) { set_error("lsg_pileup_count: reference of contig %d not loaded", t); return -2; }
     hipStream_t st = c->stream;
