@@ -668,12 +668,25 @@ __device__ __forceinline__ void issue8r(uint32_t e, uint32_t m, int l0, uint32_t
 #pragma unroll
     for (int u = 0; u < 8; ++u) { ms[u] = rl(m, l0 + u); ev[u] = load_event(rl(e, l0 + u), ms[u], lane2); }
 }
+// ALONE: every entry is a barcode run of its own (the caller checked that no barcode repeats), so there is nothing a
+// duplicate could be compared with: count + quality + strand only
+template <bool ALONE>
 __device__ __forceinline__ void consume8r(Acc& acc, const uint32_t (&ms)[8], const uint32_t (&ev)[8], uint32_t thr, uint32_t* pk, int lane) {
     acc.reserve(8, pk, lane);
     const uint32_t pkl = lds_addr(pk + lane);
 #pragma unroll
-    for (int u = 0; u < 8; ++u) acc.add(ms[u], ev[u], thr, pkl);
+    for (int u = 0; u < 8; ++u) {
+        if (ALONE) {
+            const uint32_t vm = (uint32_t)((int32_t)(thr - 1u - (ev[u] & 0x8ffu)) >> 31);
+            const uint32_t cst = (1u << 20) | ((ms[u] & META_FWD) ? (1u << 14) : 0u);
+            __hip_atomic_fetch_add((LSG_AS3 uint32_t*)(uintptr_t)(pkl | (ev[u] & 0x700u)), ((ev[u] & 0xffu) | cst) & vm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            ++acc.npk;
+        } else {
+            acc.add(ms[u], ev[u], thr, pkl);
+        }
+    }
 }
+template <bool ALONE = false>
 __device__ __forceinline__ void walk_regs(Acc& acc, uint32_t e, uint32_t m, int nb, uint32_t thr, uint32_t* pk, int lane) {
     const uint32_t lane2 = 2u * (uint32_t)lane;
     const int ng = (nb + 7) >> 3;
@@ -683,10 +696,10 @@ __device__ __forceinline__ void walk_regs(Acc& acc, uint32_t e, uint32_t m, int 
     int g = 0;
     while (true) {
         if (g + 1 < ng) issue8r(e, m, (g + 1) * 8, lane2, msB, evB);
-        consume8r(acc, msA, evA, thr, pk, lane);
+        consume8r<ALONE>(acc, msA, evA, thr, pk, lane);
         if (++g >= ng) break;
         if (g + 1 < ng) issue8r(e, m, (g + 1) * 8, lane2, msA, evA);
-        consume8r(acc, msB, evB, thr, pk, lane);
+        consume8r<ALONE>(acc, msB, evB, thr, pk, lane);
         if (++g >= ng) break;
     }
 }
@@ -953,7 +966,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void k_pileup_wave(CountArgs 
                 if (!general) {
                     const uint32_t m = lane < n ? (cur.z | META_NEWRUN) : a.zero_hi;      // lanes past the last entry: a line of zeros
                     if (lane < n) acc.nev += meta_events(m);
-                    walk_regs(acc, lane < n ? cur.y : a.zero_lo, m, n, bq_threshold(a), pk, lane);
+                    walk_regs<true>(acc, lane < n ? cur.y : a.zero_lo, m, n, bq_threshold(a), pk, lane);
                 }
             }
             if (general) {
