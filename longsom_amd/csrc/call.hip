@@ -200,7 +200,6 @@ __global__ __launch_bounds__(GATHER_WAVES * 64) void k_call_gather(CallArgs a) {
     const uint8_t refb = site ? ref[pos] : (uint8_t)'N';
     const int rsym = sym_of_ref(refb);
     const lsg_call_params& P = a.p;
-    const uint64_t cap = a.row_cap;
     const int order[4] = {0, 1, 3, 2};              // letter order A < C < G < T over classes (A,C,T,G) = (0,1,2,3)
 
     // all loads first (independent, one latency): DP, NC, CC[0..5], BC[0..5] of every present cell type
@@ -212,10 +211,10 @@ __global__ __launch_bounds__(GATHER_WAVES * 64) void k_call_gather(CallArgs a) {
         for (int s = 0; s < 6; ++s) { v_cc[ct][s] = 0; v_bc[ct][s] = 0; }
         if (site && ((mask[ct] >> lane) & 1ull)) {
             const uint64_t row = (uint64_t)rbase[ct] + __popcll(mask[ct] & below);
-            const uint32_t* R = a.rows[ct];
-            v_dp[ct] = R[row]; v_nc[ct] = R[cap + row];
+            const uint32_t* R = a.rows[ct] + row_word(row, 0);          // plane p of this row: R[p * 64]
+            v_dp[ct] = R[0]; v_nc[ct] = R[64];
 #pragma unroll
-            for (int s = 0; s < 6; ++s) { v_cc[ct][s] = R[(2 + s) * cap + row]; v_bc[ct][s] = R[(10 + s) * cap + row]; }
+            for (int s = 0; s < 6; ++s) { v_cc[ct][s] = R[(2 + s) * 64]; v_bc[ct][s] = R[(10 + s) * 64]; }
         }
     }
     // pass 1: candidate? number of tail tasks?  (one wave-aggregated allocation each)

@@ -13,6 +13,12 @@ constexpr int TILE_W = 64;          // reference positions per tile = one lane p
 constexpr int ROW_PLANES = 34;      // count-row planes kept in HBM: DP, NC, CC[8], BC[8], BQ[8], BCf[8]; BCr = BC - BCf is derived on export
 constexpr int NCTR = 33;            // accumulators kept per position: NC, CC[8], BC[8], BQ[8], BCf[8]
 
+// Resident count rows of one cell type: blocks of 64 rows, [block][plane][64 rows].  All 34 words of a row lie inside one
+// 8704-byte block (a unit's rows, <= 64 and consecutive, inside two), so a unit is written and read around ONE place in memory
+// instead of 34 places one plane stride apart.  row_cap is a multiple of 64.
+constexpr uint64_t ROW_BLOCK_WORDS = (uint64_t)ROW_PLANES * 64;
+__host__ __device__ inline uint64_t row_word(uint64_t row, int plane) { return (row >> 6) * ROW_BLOCK_WORDS + (uint64_t)plane * 64 + (row & 63); }
+
 void set_error(const char* fmt, ...);
 const char* get_error();
 
@@ -88,7 +94,7 @@ struct lsg_ctx {
     // count-stage workspace
     lsg::DevBuf d_read_key, d_unit_cnt, d_unit_off, d_unit_fill;
     lsg::DevBuf d_ne_units, d_ne_mask, d_ne_rowbase, d_ne_rowoff, d_scalars, d_cub_tmp;
-    lsg::DevBuf d_rows[LSG_MAX_CELLTYPES]; // SoA planes [ROW_PLANES][row_cap]
+    lsg::DevBuf d_rows[LSG_MAX_CELLTYPES]; // blocked planes, see lsg::row_word
     uint64_t row_cap = 0;
     uint32_t n_ne = 0, n_deep = 0;
     int64_t n_rows[LSG_MAX_CELLTYPES] = {0, 0, 0, 0};

@@ -867,15 +867,15 @@ __device__ __forceinline__ void emit_unit(const CountArgs& a, const CNT& acc, ui
         return;
     }
     if (!emit) return;
-    // plane p of this unit starts at a wave-uniform address (scalar registers); the lane only adds its 32-bit row offset
-    const uint32_t off4 = 4u * (uint32_t)__popcll(em & ((1ull << lane) - 1ull));
-    const uint64_t plane_bytes = a.row_cap * 4ull;
-    const uint64_t first = (uint64_t)(uintptr_t)a.rows[ct] + (uint64_t)base * 4ull;
+    // the unit's rows lie in at most two consecutive 64-row blocks: ONE descriptor over those blocks (scalar registers), the
+    // lane adds its row's offset inside them, the plane is a scalar offset of 256 bytes per plane
+    const uint32_t row = base + (uint32_t)__popcll(em & ((1ull << lane) - 1ull));
+    const uint32_t b0 = base >> 6;
+    const uint32_t off4 = (((row >> 6) - b0) * (uint32_t)ROW_BLOCK_WORDS + (row & 63u)) * 4u;
+    const uint64_t first = (uint64_t)(uintptr_t)a.rows[ct] + (uint64_t)b0 * (ROW_BLOCK_WORDS * 4ull);
     const uint64_t p0 = ((uint64_t)rl((uint32_t)(first >> 32), 0) << 32) | rl((uint32_t)first, 0);
-    auto put = [&](int plane, uint32_t v) {                          // buffer store: scalar descriptor per plane, no per-lane address arithmetic
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>((uintptr_t)(p0 + (uint64_t)plane * plane_bytes)), 0, (int)(k * 4u), 0x00020000);
-        __builtin_amdgcn_raw_buffer_store_b32(v, rs, (int)off4, 0, 0);
-    };
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>((uintptr_t)p0), 0, (int)(2 * ROW_BLOCK_WORDS * 4), 0x00020000);
+    auto put = [&](int plane, uint32_t v) { __builtin_amdgcn_raw_buffer_store_b32(v, rs, (int)off4, plane * 256, 0); };
     put(0, dp);
     put(1, nc);
 #pragma unroll
@@ -1642,10 +1642,7 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
         if (by_depth < want_rows) want_rows = by_depth;
     }
     want_rows += (uint64_t)(grid_block + grid_walk + grid_wave * WAVES_PER_BLOCK) * ARENA + 64;
-    // plane stride: a row's 34 stores go to addresses one stride apart; keep the stride off every power-of-two multiple
-    // (17 x 256 B modulo 8 KB) so that the planes of a unit spread over the HBM channels whatever their interleave
-    want_rows = (want_rows + 63) / 64 * 64;
-    want_rows += ((17 + 32 - (want_rows / 64) % 32) % 32) * 64;
+    want_rows = (want_rows + 63) / 64 * 64 + 64;        // whole 64-row blocks (lsg::row_word), one spare: a unit's descriptor spans two
     // every cell type of THIS run needs planes of the current stride (a run with more cell types than any before it
     // finds row_cap large enough but its new buffers still empty)
     if (want_rows > c->row_cap) c->row_cap = want_rows;
@@ -1718,7 +1715,7 @@ __global__ void k_export_rows(CountArgs a, int ct, const uint32_t* rowoff, int64
     int64_t pos = (int64_t)geom.x + lane;
     keys[dst] = ((int64_t)tid << 32) | pos;
     refs[dst] = a.ref_ptr[tid][pos];
-    for (int k = 0; k < ROW_PLANES; ++k) counts[dst * LSG_ROW_WORDS + k] = a.rows[ct][(uint64_t)k * a.row_cap + src];
+    for (int k = 0; k < ROW_PLANES; ++k) counts[dst * LSG_ROW_WORDS + k] = a.rows[ct][row_word(src, k)];
     for (int sy = 0; sy < 8; ++sy)                             // BCr = BC - BCf is not stored
         counts[dst * LSG_ROW_WORDS + 34 + sy] = counts[dst * LSG_ROW_WORDS + 10 + sy] - counts[dst * LSG_ROW_WORDS + 26 + sy];
 }
