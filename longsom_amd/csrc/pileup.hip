@@ -57,7 +57,7 @@ constexpr int FLUSH_EVERY = 63;      // packed LDS fields: bq 14 | fwd 6 | cnt 6
 enum { SC_QSMALL = 0, SC_QBIG = 1, SC_NNE = 2, SC_ROWALLOC = 4, SC_COLS = 8, SC_OVERFLOW = 9,
        SC_READS = 10, SC_SEGS = 11, SC_EVENTS = 12, SC_EV_WAVE = 13, SC_EV_DEEP = 14, SC_ROWS_DEEP = 15,
        SC_ROWS = 16, SC_NSMALL = 20, SC_NMULTI = 21, SC_NMULTI_SEL = 22, SC_NHUGE = 24, SC_QHUGE = 25, SC_QBIN0 = 26, SC_QBIN2 = 27,
-       SC_ROWS_SRC = 28, SC_EV_SRC = 32, SC_NCHUNK = 36, SC_COUNT = 40 };   // *_SRC[4]: 0 wave, 1 walk_block, 2 huge, 3 finalize
+       SC_ROWS_SRC = 28, SC_EV_SRC = 32, SC_NCHUNK = 36, SC_QSORT = 37, SC_COUNT = 40 };   // *_SRC[4]: 0 wave, 1 walk_block, 2 huge, 3 finalize
 
 struct CountArgs {
     // reads
@@ -417,7 +417,13 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_deep(CountArgs a, uint32_
     unsigned long long* s_nev = reinterpret_cast<unsigned long long*>(wave_tot + SORT_THREADS / 64 + ((MAXSUB + 1 + SORT_THREADS / 64) & 1));
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     unsigned long long nev = 0;
-    for (uint32_t k = blockIdx.x; k < a.n_multi; k += gridDim.x) {
+    // units differ in size by orders of magnitude: taken off a queue (first one = own index), not strided
+    for (bool first = true;; first = false) {
+        __syncthreads();
+        if (t == 0) *reinterpret_cast<uint32_t*>(s_nev + 1) = first ? blockIdx.x : (uint32_t)atomicAdd(&a.scalars[SC_QSORT], 1ull) + gridDim.x;
+        __syncthreads();
+        const uint32_t k = *reinterpret_cast<uint32_t*>(s_nev + 1);
+        if (k >= a.n_multi) break;
         const uint32_t w = a.multi_list[k], u = a.ne_units[w];
         const uint32_t n = a.unit_cnt[u], src = a.unit_off[u], nsub = a.ne_nslot[w], base = a.ne_slot_base[w];
         const uint32_t ct = (uint32_t)a.ne_geom[w].y >> 24;
@@ -425,10 +431,17 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_deep(CountArgs a, uint32_
         __syncthreads();
         for (uint32_t i = t; i < R; i += SORT_THREADS) cur[i] = 0;
         __syncthreads();
-        for (uint32_t i = t; i < n; i += SORT_THREADS) {
-            const uint4 e = a.ent[src + i];
-            atomicAdd(&cur[a.ct_rank[e.x & CB_MASK]], 1u);
-            nev += meta_events(e.z);
+        // four entries per thread and round: entry load -> rank lookup -> LDS add is a chain of dependent latencies, and the
+        // deepest unit of a sample (10^5 entries) is sorted by ONE workgroup: independent chains side by side shorten that tail
+        for (uint32_t i0 = t; i0 < n; i0 += 4 * SORT_THREADS) {
+            uint4 e[4]; uint32_t r[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const uint32_t i = i0 + q * SORT_THREADS; e[q] = a.ent[src + (i < n ? i : i0)]; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) r[q] = a.ct_rank[e[q].x & CB_MASK];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (i0 + q * SORT_THREADS < n) { atomicAdd(&cur[r[q]], 1u); nev += meta_events(e[q].z); }
         }
         __syncthreads();
         // exclusive scan of cur[0..R) -> start; every thread owns a contiguous chunk
@@ -466,13 +479,20 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_deep(CountArgs a, uint32_
             }
         }
         // scatter the records (cur = cursor; start stays put)
-        for (uint32_t i = t; i < n; i += SORT_THREADS) {
-            const uint4 e = a.ent[src + i];
-            const uint32_t r = a.ct_rank[e.x & CB_MASK];
-            const uint32_t pos = atomicAdd(&cur[r], 1u);
-            const uint32_t r_end = r + 1 < R ? start[r + 1] : n;
-            const uint32_t run = pos != start[r] ? 0u : (r_end - pos == 1u ? (META_NEWRUN | META_SINGLE) : META_NEWRUN);
-            a.rec[a.ent_half + src + pos] = make_uint2(e.y, e.z | run);
+        for (uint32_t i0 = t; i0 < n; i0 += 4 * SORT_THREADS) {
+            uint4 e[4]; uint32_t r[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const uint32_t i = i0 + q * SORT_THREADS; e[q] = a.ent[src + (i < n ? i : i0)]; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) r[q] = a.ct_rank[e[q].x & CB_MASK];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (i0 + q * SORT_THREADS >= n) continue;
+                const uint32_t pos = atomicAdd(&cur[r[q]], 1u);
+                const uint32_t r_end = r[q] + 1 < R ? start[r[q] + 1] : n;
+                const uint32_t run = pos != start[r[q]] ? 0u : (r_end - pos == 1u ? (META_NEWRUN | META_SINGLE) : META_NEWRUN);
+                a.rec[a.ent_half + src + pos] = make_uint2(e[q].y, e[q].z | run);
+            }
         }
     }
     // events k_walk_block will read (statistics)
@@ -1608,7 +1628,7 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
             unsigned sg = c->n_multi < (unsigned)(c->n_cus * 4) ? c->n_multi : (unsigned)(c->n_cus * 4);
             if (a.presorted) {
                 const uint32_t r_cap = (max_ct + 63u) & ~63u;
-                const size_t lds = ((size_t)2 * r_cap + MAXSUB + 1 + SORT_THREADS / 64 + 4) * 4 + 16;
+                const size_t lds = ((size_t)2 * r_cap + MAXSUB + 1 + SORT_THREADS / 64 + 4) * 4 + 32;
                 LSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort_deep), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 hipLaunchKernelGGL(k_sort_deep, dim3(sg), dim3(SORT_THREADS), lds, st, a, r_cap);
             } else {

@@ -11,10 +11,12 @@ from typing import List, Tuple
 
 import numpy as np
 
+import os
+
 from . import synth
 
 CALL_BYTES = 336          # sizeof(lsg_call)
-COLUMN_COST = 0.036       # one emitted (site, cell type) column costs about this many reads of kernel time (MI355X, C2)
+COLUMN_COST = float(os.environ.get("LSG_COLUMN_COST", "0.036"))       # one emitted (site, cell type) column costs about this many reads of kernel time (MI355X, C2)
 
 
 def region_shards(model, world: int) -> List[Tuple[Tuple[int, int], Tuple[int, int], int, int]]:
