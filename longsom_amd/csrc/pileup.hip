@@ -28,6 +28,8 @@ namespace lsg {
 
 constexpr uint32_t KEY_INVALID = 0xFFFFFFFFu;
 constexpr uint32_t CB_MASK = 0x00FFFFFFu;
+// Entries are stored PACKED in 8 bytes {cb | (events - 1) << 24 | forward << 30, index of the 128-byte line within the resident
+// events}; unpack_entry() gives the working form used below:
 // entry = {key, e, m, 0}: e = low 32 bits of the ADDRESS of the 128-byte line that holds the entry's 64-position tile slot
 // (events are resident tile-aligned, layout.hip: lane = position within the tile, positions outside the segment are
 // zero padding, so an entry is loaded as one whole line with no bounds and no first-lane arithmetic);
@@ -59,6 +61,9 @@ enum { SC_QSMALL = 0, SC_QBIG = 1, SC_NNE = 2, SC_ROWALLOC = 4, SC_COLS = 8, SC_
        SC_ROWS = 16, SC_NSMALL = 20, SC_NMULTI = 21, SC_NMULTI_SEL = 22, SC_NHUGE = 24, SC_QHUGE = 25, SC_QBIN0 = 26, SC_QBIN2 = 27,
        SC_ROWS_SRC = 28, SC_EV_SRC = 32, SC_NCHUNK = 36, SC_QSORT = 37, SC_COUNT = 40 };   // *_SRC[4]: 0 wave, 1 walk_block, 2 huge, 3 finalize
 
+struct CountArgs;
+__device__ __forceinline__ uint4 unpack_entry(const CountArgs& a, uint2 p);
+
 struct CountArgs {
     // reads
     int64_t n_reads, n_segs;
@@ -81,7 +86,7 @@ struct CountArgs {
     uint32_t* ne_units; uint32_t* ne_nslot; uint32_t* ne_slot_base; uint32_t* ne_acc; int2* ne_geom;
     uint64_t* ne_mask; uint32_t* ne_rowbase;
     uint32_t* slot_w; uint32_t* slot_cnt; uint32_t* slot_off;
-    uint4* ent;                           // entries {key, first event index lo, meta, 0}
+    uint2* ent;                           // packed entries, see unpack_entry
     uint2* seg_info;                      // per segment {admission key, first tile of its contig} (k_seg_info)
     uint2* rec;                           // grouped 8-byte records {event byte offset lo, meta} of the block path, same indexing as ent
     uint32_t* slot_pex; uint32_t* chunk_start;   // wave kernel: work prefix over the small-slot list, first slot of every chunk
@@ -93,6 +98,13 @@ struct CountArgs {
     uint32_t* rows[LSG_MAX_CELLTYPES];
     uint64_t row_cap;
 };
+
+// packed entry -> {barcode, line address lo, meta (address bits 32..46 | events - 1 | strand), 0}
+__device__ __forceinline__ uint4 unpack_entry(const CountArgs& a, uint2 p) {
+    const uint64_t addr = (uint64_t)(uintptr_t)a.events + ((uint64_t)p.y << 7);
+    return make_uint4(p.x & CB_MASK, (uint32_t)addr, ((uint32_t)(addr >> 32) & 0x7fffu) | (p.x & 0x7f000000u), 0u);
+}
+
 
 // ------------------------------------------------------------------------------------------------
 // Read admission = the union of the reference's filters on the count path:
@@ -287,10 +299,8 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_segments(CountArgs a) {
                             const int32_t lo = g.st > tstart ? g.st : tstart;
                             const int32_t hi = g.st + g.ln < tstart + TILE_W ? g.st + g.ln : tstart + TILE_W;
                             // the line of this tile slot: the event of (lo) sits at lane (lo - tstart) of it
-                            const uint64_t addr = (uint64_t)(uintptr_t)(a.events + (g.evoff + (lo - g.st) - (lo - tstart)));
-                            a.ent[pos] = make_uint4(g.key, (uint32_t)addr,
-                                                    (uint32_t)((addr >> 32) & 0x7fffu) | (((g.key >> 24) & 1u) ? 0u : META_FWD) |
-                                                        ((uint32_t)(hi - lo - 1) << 24), 0u);
+                            const uint64_t line = (uint64_t)(g.evoff + (lo - g.st) - (lo - tstart)) >> 6;      // 64 events = 128 bytes
+                            a.ent[pos] = make_uint2((g.key & CB_MASK) | ((uint32_t)(hi - lo - 1) << 24) | (((g.key >> 24) & 1u) ? 0u : META_FWD), (uint32_t)line);
                         }
                     }
                 }
@@ -382,7 +392,7 @@ __global__ __launch_bounds__(SPLIT_THREADS) void k_split_deep(CountArgs a) {
         }
         __syncthreads();
         for (uint32_t i = t; i < n; i += SPLIT_THREADS) {
-            const uint4 e = a.ent[src + i];
+            const uint2 e = a.ent[src + i];
             const uint32_t pos = atomicAdd(&hist[sub_of(a.ct_rank[e.x & CB_MASK], nsub, ctn)], 1u);
             a.ent[a.ent_half + src + pos] = e;
         }
@@ -436,7 +446,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_deep(CountArgs a, uint32_
         for (uint32_t i0 = t; i0 < n; i0 += 4 * SORT_THREADS) {
             uint4 e[4]; uint32_t r[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { const uint32_t i = i0 + q * SORT_THREADS; e[q] = a.ent[src + (i < n ? i : i0)]; }
+            for (int q = 0; q < 4; ++q) { const uint32_t i = i0 + q * SORT_THREADS; e[q] = unpack_entry(a, a.ent[src + (i < n ? i : i0)]); }
 #pragma unroll
             for (int q = 0; q < 4; ++q) r[q] = a.ct_rank[e[q].x & CB_MASK];
 #pragma unroll
@@ -482,7 +492,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_deep(CountArgs a, uint32_
         for (uint32_t i0 = t; i0 < n; i0 += 4 * SORT_THREADS) {
             uint4 e[4]; uint32_t r[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { const uint32_t i = i0 + q * SORT_THREADS; e[q] = a.ent[src + (i < n ? i : i0)]; }
+            for (int q = 0; q < 4; ++q) { const uint32_t i = i0 + q * SORT_THREADS; e[q] = unpack_entry(a, a.ent[src + (i < n ? i : i0)]); }
 #pragma unroll
             for (int q = 0; q < 4; ++q) r[q] = a.ct_rank[e[q].x & CB_MASK];
 #pragma unroll
@@ -750,7 +760,7 @@ __device__ __forceinline__ int group_by_cb(const CountArgs& a, uint32_t src, int
     for (int r = 0; r < RMAX; ++r) {
         int i = t + r * T;
         hs[r] = 0; ek[r] = KEY_INVALID; ee[r] = 0; em[r] = 0;
-        if (i < n) { const uint4 v = a.ent[src + i]; ek[r] = v.x; ee[r] = v.y; em[r] = v.z; }
+        if (i < n) { const uint4 v = unpack_entry(a, a.ent[src + i]); ek[r] = v.x; ee[r] = v.y; em[r] = v.z; }
     }
 #pragma unroll
     for (int r = 0; r < RMAX; ++r) {
@@ -949,7 +959,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void k_pileup_wave(CountArgs 
         uint4 cur = make_uint4(KEY_INVALID, 0u, 0u, 0u);
         {
             const int n0 = (int)rl(s_cnt, 0);
-            if (n0 <= 64 && lane < n0) cur = a.ent[rl(s_off, 0) + lane];
+            if (n0 <= 64 && lane < n0) cur = unpack_entry(a, a.ent[rl(s_off, 0) + lane]);
         }
         for (int qi = 0; qi < nq; ++qi) {
             const uint32_t w = rl(s_w, qi), src = rl(s_off, qi);
@@ -961,7 +971,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void k_pileup_wave(CountArgs 
             uint4 nxt = make_uint4(KEY_INVALID, 0u, 0u, 0u);
             if (qi + 1 < nq) {
                 const int nn = (int)rl(s_cnt, qi + 1);
-                if (nn <= 64 && lane < nn) nxt = a.ent[rl(s_off, qi + 1) + lane];
+                if (nn <= 64 && lane < nn) nxt = unpack_entry(a, a.ent[rl(s_off, qi + 1) + lane]);
             }
             int refb = 'N';
             { const int64_t pos = (int64_t)tstart + lane; if (pos >= 1 && pos < a.contig_len[tid]) refb = a.ref_ptr[tid][pos]; }
@@ -1056,7 +1066,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_group_block(CountArgs a) {
             continue;
         }
         const uint32_t src = a.slot_off[s];
-        for (int i = t; i < n; i += BLOCK_THREADS) nev += meta_events(a.ent[src + i].z);      // events k_walk_block will read (statistics)
+        for (int i = t; i < n; i += BLOCK_THREADS) nev += meta_events(a.ent[src + i].x);      // events k_walk_block will read (statistics)
         group_by_cb<true, HB, CAPB, true>(a, src, n, L.gcb, nullptr, nullptr, L.tkey, L.tcnt, t, L.wave_tot);
         if (t <= NSLICE) {
             int j = (int)((int64_t)n * t / NSLICE);
@@ -1195,7 +1205,7 @@ __device__ __forceinline__ int block_stage_filtered(const CountArgs& a, BlockLds
     if (t == 0) L.scount = 0;
     __syncthreads();
     for (int i = t; i < n; i += BLOCK_THREADS) {
-        const uint4 v = a.ent[src + i];
+        const uint4 v = unpack_entry(a, a.ent[src + i]);
         uint32_t b = (v.x & CB_MASK) >> shift;
         if (b >= b_lo && b < b_hi) {
             uint32_t slot = atomicAdd(&L.scount, 1u);
@@ -1336,7 +1346,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_pileup_huge(CountArgs a) {
                             acc.new_run();
                             for (int ib = 0; ib < n; ib += 64) {
                                 uint32_t k = KEY_INVALID, e = 0, m = 0;
-                                if (ib + lane < n) { const uint4 v = a.ent[src + ib + lane]; k = v.x; e = v.y; m = v.z; }
+                                if (ib + lane < n) { const uint4 v = unpack_entry(a, a.ent[src + ib + lane]); k = v.x; e = v.y; m = v.z; }
                                 bool match = k != KEY_INVALID && (k & CB_MASK) == c;
                                 if (match) acc.nev += meta_events(m);
                                 unsigned long long mm = __ballot(match);
@@ -1502,7 +1512,7 @@ static void fill_args(lsg_ctx* c, const lsg_count_params* p, CountArgs& a) {
     a.ne_mask = c->d_ne_mask.as<uint64_t>(); a.ne_rowbase = c->d_ne_rowbase.as<uint32_t>();
     a.slot_w = c->ws[WS_SLOT_W].as<uint32_t>(); a.slot_cnt = c->ws[WS_SLOT_CNT].as<uint32_t>();
     a.slot_off = c->ws[WS_SLOT_OFF].as<uint32_t>();
-    a.ent = c->ws[WS_ENT].as<uint4>(); a.rec = c->ws[WS_REC].as<uint2>(); a.seg_info = c->ws[WS_SEG_INFO].as<uint2>();
+    a.ent = c->ws[WS_ENT].as<uint2>(); a.rec = c->ws[WS_REC].as<uint2>(); a.seg_info = c->ws[WS_SEG_INFO].as<uint2>();
     a.slot_list = c->ws[WS_SLOT_LIST].as<uint32_t>(); a.multi_list = c->ws[WS_MULTI_LIST].as<uint32_t>();
     a.macc = c->ws[WS_MACC].as<uint32_t>();
     a.slot_pex = c->ws[WS_SLOT_PEX].as<uint32_t>(); a.chunk_start = c->ws[WS_CHUNK_START].as<uint32_t>();
@@ -1558,7 +1568,7 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
         c->ws[WS_NE_GEOM].reserve((ne_cap + 2) * 8) || c->ws[WS_SLOT_W].reserve((slot_cap + 2) * 4) ||
         c->ws[WS_SLOT_CNT].reserve((slot_cap + 2) * 4) || c->ws[WS_SLOT_OFF].reserve((slot_cap + 2) * 4) ||
         c->ws[WS_SLOT_LIST].reserve((slot_cap + 2) * 4) ||
-        c->ws[WS_MULTI_LIST].reserve((EU / CAPB + 16) * 4) || c->ws[WS_ENT].reserve((EU + 1) * 32 + 64) || c->ws[WS_SEG_INFO].reserve(((size_t)S + 1) * 8) || c->ws[WS_REC].reserve((EU + 1) * 16 + 256) ||
+        c->ws[WS_MULTI_LIST].reserve((EU / CAPB + 16) * 4) || c->ws[WS_ENT].reserve((EU + 1) * 16 + 64) || c->ws[WS_SEG_INFO].reserve(((size_t)S + 1) * 8) || c->ws[WS_REC].reserve((EU + 1) * 16 + 256) ||
         c->ws[WS_SLICES].reserve((slot_cap + 2) * (NSLICE + 1) * 4) || c->ws[WS_SLOT_PEX].reserve((slot_cap + 2) * 4) ||
         c->ws[WS_CHUNK_START].reserve(((EU + WORK_W0 * slot_cap) / CHUNK_EMIN + 4) * 4) || c->ws[WS_HUGE_LIST].reserve((EU / CAPB + 16) * 4))
         return -1;
