@@ -46,6 +46,7 @@ struct CallArgs {
     const uint8_t* const* ref_ptr; const int64_t* contig_len;
     lsg_call_params p;
     double lgc0[2], lgcn[2];          // lgamma(a+b) - lgamma(b), lgamma(a+b) - lgamma(a) for (a1,b1), (a2,b2)
+    const int16_t* tail_table;        // [2][TAIL_ENTRIES] rounded tails of every (k <= n <= TAIL_NT), see k_tail_table
     uint32_t* site_cnt; uint32_t* site_off;
     SiteRec* sites; CandCt* cands; uint64_t cand_cap;
     struct TailTask* light; struct TailTask* heavy; uint64_t task_cap;
@@ -134,6 +135,14 @@ __global__ void k_site_count(CallArgs a) {
 //                 strided chunks, each re-anchored by lgamma);
 //  k_call_finish  the filter chains, which depend on the rounded p-values.
 struct TailTask { uint32_t k, n; uint64_t dst; };     // dst = address of the int16 result | parameter set in bit 0
+
+// Most tail requests have a small n (depth or cell count of one cell type at one site) and the same (k, n) pairs recur
+// millions of times: all pairs k <= n <= TAIL_NT are evaluated once per parameter set (k_tail_table, with exactly the code a
+// task of that pair would run, so the rounded values are the same bits) and looked up by k_call_gather instead of becoming tasks.
+constexpr uint32_t TAIL_NT = 511;
+constexpr uint32_t TAIL_ENTRIES = (TAIL_NT + 1) * (TAIL_NT + 2) / 2;
+__host__ __device__ __forceinline__ uint32_t tail_index(uint32_t k, uint32_t n) { return n * (n + 1) / 2 + k; }
+__device__ __forceinline__ bool tail_in_table(uint32_t k, uint32_t n) { return n <= TAIL_NT && k <= n; }
 
 __device__ __forceinline__ uint32_t tail_work(uint32_t k, uint32_t n) {
     if (k == 0 || k > n) return 0;
@@ -236,14 +245,14 @@ __global__ __launch_bounds__(GATHER_WAVES * 64) void k_call_gather(CallArgs a) {
                 if (s < 4 && b > 0) {
                     has_any = true;
                     s_dp -= (int32_t)b; s_nc -= (int32_t)c; s_alts_bc -= (int32_t)b; s_alts_cc -= (int32_t)c;
-                    if (tail_work(b, dp) > 64) ++n_heavy; else ++n_light;
-                    if (tail_work(c, nc) > 64) ++n_heavy; else ++n_light;
+                    if (!tail_in_table(b, dp)) { if (tail_work(b, dp) > 64) ++n_heavy; else ++n_light; }
+                    if (!tail_in_table(c, nc)) { if (tail_work(c, nc) > 64) ++n_heavy; else ++n_light; }
                 }
             }
         }
         if (s_alts_bc > 0) {
-            if (s_dp >= 0) { if (tail_work((uint32_t)s_alts_bc, (uint32_t)s_dp) > 64) ++n_heavy; else ++n_light; }
-            if (s_nc >= 0 && s_alts_cc >= 0) { if (tail_work((uint32_t)s_alts_cc, (uint32_t)s_nc) > 64) ++n_heavy; else ++n_light; }
+            if (s_dp >= 0 && !tail_in_table((uint32_t)s_alts_bc, (uint32_t)s_dp)) { if (tail_work((uint32_t)s_alts_bc, (uint32_t)s_dp) > 64) ++n_heavy; else ++n_light; }
+            if (s_nc >= 0 && s_alts_cc >= 0 && !tail_in_table((uint32_t)s_alts_cc, (uint32_t)s_nc)) { if (tail_work((uint32_t)s_alts_cc, (uint32_t)s_nc) > 64) ++n_heavy; else ++n_light; }
         }
     }
     const unsigned long long cm = __ballot(has_any);
@@ -278,7 +287,9 @@ __global__ __launch_bounds__(GATHER_WAVES * 64) void k_call_gather(CallArgs a) {
     if (!site) continue;
     const uint32_t cand = cbase + (uint32_t)__popcll(cm & below);
     uint32_t li = pl - n_light, hi = ph - n_heavy;           // this lane's first slot, as an offset into the wave's request
-    auto emit_task = [&](uint32_t k, uint32_t n, int set, int16_t* dst) {
+    // loc = the field of the record still being assembled in registers (stored whole afterwards), dst = the same field in memory
+    auto emit_task = [&](uint32_t k, uint32_t n, int set, int16_t* dst, int16_t* loc) {
+        if (tail_in_table(k, n)) { *loc = a.tail_table[(uint32_t)set * TAIL_ENTRIES + tail_index(k, n)]; return; }
         TailTask t; t.k = k; t.n = n; t.dst = (uint64_t)dst | (uint64_t)set;
         if (tail_work(k, n) > 64) { const uint32_t p = hi < h_room ? h_old + hi : h_new + (hi - h_room); if (p < a.task_cap) a.heavy[p] = t; ++hi; }
         else { const uint32_t p = li < l_room ? l_old + li : l_new + (li - l_room); if (p < a.task_cap) a.light[p] = t; ++li; }
@@ -328,7 +339,7 @@ __global__ __launch_bounds__(GATHER_WAVES * 64) void k_call_gather(CallArgs a) {
                     const uint32_t c = v_cc[ct][s];
                     if (na < LSG_CALL_MAX_ALT) {
                         cd.alt[na] = (uint8_t)s; cd.alt_bc[na] = b; cd.alt_cc[na] = c;
-                        if (cdp) { emit_task(b, dp, 0, &cdp->p_bc[na]); emit_task(c, nc, 1, &cdp->p_cc[na]); }
+                        if (cdp) { emit_task(b, dp, 0, &cdp->p_bc[na], &cd.p_bc[na]); emit_task(c, nc, 1, &cdp->p_cc[na], &cd.p_cc[na]); }
                     }
                     ++na; altset |= 1u << s;
                 }
@@ -361,8 +372,8 @@ __global__ __launch_bounds__(GATHER_WAVES * 64) void k_call_gather(CallArgs a) {
     sr.noise_p_bc = -1; sr.noise_p_cc = -1;
     if (s_alts_bc > 0) {
         sr.noise_p_bc = -2; sr.noise_p_cc = -2;
-        if (s_dp >= 0) emit_task((uint32_t)s_alts_bc, (uint32_t)s_dp, 0, &srp->noise_p_bc);
-        if (s_nc >= 0 && s_alts_cc >= 0) emit_task((uint32_t)s_alts_cc, (uint32_t)s_nc, 1, &srp->noise_p_cc);
+        if (s_dp >= 0) emit_task((uint32_t)s_alts_bc, (uint32_t)s_dp, 0, &srp->noise_p_bc, &sr.noise_p_bc);
+        if (s_nc >= 0 && s_alts_cc >= 0) emit_task((uint32_t)s_alts_cc, (uint32_t)s_nc, 1, &srp->noise_p_cc, &sr.noise_p_cc);
     }
     // flags that do not depend on p-values; k_call_finish adds the rest
     uint32_t sf = 0;
@@ -399,7 +410,59 @@ __global__ __launch_bounds__(256) void k_call_tails(CallArgs a) {
     }
 }
 
-// heavy tasks: one wavefront each; lane l sums the terms [l*chunk, (l+1)*chunk) of the shorter side
+// one wavefront, one tail: lane l sums the terms [l*chunk, (l+1)*chunk) of the shorter side; the value is valid on lane 0
+__device__ __forceinline__ double heavy_tail(uint32_t k, uint32_t n, int set, const CallArgs& a, int lane) {
+    const double al = set ? a.p.alpha2 : a.p.alpha1, be = set ? a.p.beta2 : a.p.beta1;
+    const double dn = (double)n;
+    const bool lower = (uint64_t)k <= (uint64_t)n - k + 1;
+    const uint32_t m_lo = lower ? 0u : k, m_hi = lower ? k : n + 1;        // terms m in [m_lo, m_hi)
+    const uint32_t cnt = m_hi - m_lo, chunk = (cnt + 63) / 64;
+    const uint32_t b = m_lo + (uint32_t)lane * chunk;
+    const uint32_t e = b + chunk < m_hi ? b + chunk : m_hi;
+    double sum = 0.0;
+    if (b < e) {
+        double pm = exp(bb_logpmf((double)b, dn, al, be));
+        sum = pm;
+        for (uint32_t m = b + 1; m < e; ++m) {
+            if (((m - b) & 1023u) == 0) pm = exp(bb_logpmf((double)m, dn, al, be));
+            else { const double mm = (double)(m - 1); pm *= (dn - mm) * (mm + al) / ((mm + 1.0) * (dn - mm - 1.0 + be)); }
+            sum += pm;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o);
+    return lower ? 1.0 - sum : sum;
+}
+
+// every (k, n) with k <= n <= TAIL_NT for both parameter sets: pairs a light task would take by one thread each, pairs a heavy
+// task would take by one wavefront each (the same functions the task kernels call)
+__global__ __launch_bounds__(256) void k_tail_table(CallArgs a, int16_t* table) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t n_thr = (uint64_t)gridDim.x * blockDim.x, tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (uint64_t i = tid; i < 2ull * TAIL_ENTRIES; i += n_thr) {
+        const int set = i >= TAIL_ENTRIES;
+        const uint32_t idx = (uint32_t)(i - (set ? TAIL_ENTRIES : 0));
+        uint32_t n = (uint32_t)((sqrt(8.0 * (double)idx + 1.0) - 1.0) * 0.5);
+        while (tail_index(0, n + 1) <= idx) ++n;
+        while (tail_index(0, n) > idx) --n;
+        const uint32_t k = idx - tail_index(0, n);
+        if (tail_work(k, n) > 64) continue;
+        TailTask t; t.k = k; t.n = n; t.dst = (uint64_t)set;
+        table[i] = (int16_t)round4(tail_of_task(t, a));
+    }
+    for (uint64_t i = tid >> 6; i < 2ull * TAIL_ENTRIES; i += n_thr >> 6) {
+        const int set = i >= TAIL_ENTRIES;
+        const uint32_t idx = (uint32_t)(i - (set ? TAIL_ENTRIES : 0));
+        uint32_t n = (uint32_t)((sqrt(8.0 * (double)idx + 1.0) - 1.0) * 0.5);
+        while (tail_index(0, n + 1) <= idx) ++n;
+        while (tail_index(0, n) > idx) --n;
+        const uint32_t k = idx - tail_index(0, n);
+        if (tail_work(k, n) <= 64) continue;
+        const double tail = heavy_tail(k, n, set, a, lane);
+        if (lane == 0) table[i] = (int16_t)round4(tail);
+    }
+}
+
+// heavy tasks: one wavefront each
 __global__ __launch_bounds__(256) void k_call_tails_heavy(CallArgs a) {
     const int lane = threadIdx.x & 63;
     const uint64_t n_all = a.counters[3] + (uint64_t)a.arena_waves * HEAVY_CHUNK;
@@ -407,26 +470,8 @@ __global__ __launch_bounds__(256) void k_call_tails_heavy(CallArgs a) {
     for (uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; i < n_tasks; i += ((uint64_t)gridDim.x * blockDim.x) >> 6) {
         const TailTask t = a.heavy[i];
         if (!(t.dst & ~1ull)) continue;                        // unused arena slot
-        const int set = (int)(t.dst & 1ull);
-        const double al = set ? a.p.alpha2 : a.p.alpha1, be = set ? a.p.beta2 : a.p.beta1;
-        const double dn = (double)t.n;
-        const bool lower = (uint64_t)t.k <= (uint64_t)t.n - t.k + 1;
-        const uint32_t m_lo = lower ? 0u : t.k, m_hi = lower ? t.k : t.n + 1;        // terms m in [m_lo, m_hi)
-        const uint32_t cnt = m_hi - m_lo, chunk = (cnt + 63) / 64;
-        const uint32_t b = m_lo + (uint32_t)lane * chunk;
-        const uint32_t e = b + chunk < m_hi ? b + chunk : m_hi;
-        double sum = 0.0;
-        if (b < e) {
-            double pm = exp(bb_logpmf((double)b, dn, al, be));
-            sum = pm;
-            for (uint32_t m = b + 1; m < e; ++m) {
-                if (((m - b) & 1023u) == 0) pm = exp(bb_logpmf((double)m, dn, al, be));
-                else { const double mm = (double)(m - 1); pm *= (dn - mm) * (mm + al) / ((mm + 1.0) * (dn - mm - 1.0 + be)); }
-                sum += pm;
-            }
-        }
-        for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o);
-        if (lane == 0) *reinterpret_cast<int16_t*>(t.dst & ~1ull) = (int16_t)round4(lower ? 1.0 - sum : sum);
+        const double tail = heavy_tail(t.k, t.n, (int)(t.dst & 1ull), a, lane);
+        if (lane == 0) *reinterpret_cast<int16_t*>(t.dst & ~1ull) = (int16_t)round4(tail);
     }
 }
 
@@ -565,6 +610,15 @@ int run_call(lsg_ctx* c, const lsg_call_params* p) {
     a.p = *p;
     a.lgc0[0] = lgamma(p->alpha1 + p->beta1) - lgamma(p->beta1); a.lgcn[0] = lgamma(p->alpha1 + p->beta1) - lgamma(p->alpha1);
     a.lgc0[1] = lgamma(p->alpha2 + p->beta2) - lgamma(p->beta2); a.lgcn[1] = lgamma(p->alpha2 + p->beta2) - lgamma(p->alpha2);
+    {   // small-n tails, once per parameter set
+        const double key[4] = {p->alpha1, p->beta1, p->alpha2, p->beta2};
+        if (!c->tail_table_valid || memcmp(key, c->tail_table_key, sizeof key) != 0) {
+            if (c->d_tail_table.reserve((size_t)2 * TAIL_ENTRIES * 2)) return -1;
+            hipLaunchKernelGGL(k_tail_table, dim3((unsigned)(c->n_cus * 8)), dim3(256), 0, st, a, c->d_tail_table.as<int16_t>());
+            memcpy(c->tail_table_key, key, sizeof key); c->tail_table_valid = true;
+        }
+        a.tail_table = c->d_tail_table.as<int16_t>();
+    }
     a.site_cnt = c->d_site_off.as<uint32_t>();
     a.site_off = a.site_cnt + (n_ne + 2);
     a.counters = reinterpret_cast<unsigned long long*>(a.site_off + (n_ne + 2));   // 2*(n_ne+2) words: 8-byte aligned

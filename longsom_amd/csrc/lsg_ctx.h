@@ -104,7 +104,8 @@ struct lsg_ctx {
     bool counted = false;
 
     // call stage
-    lsg::DevBuf d_calls, d_site_off;
+    lsg::DevBuf d_calls, d_site_off, d_tail_table;      // d_tail_table: call.hip, memo of the small-n beta-binomial tails
+    double tail_table_key[4] = {0, 0, 0, 0}; bool tail_table_valid = false;
     int64_t n_sites = 0, n_cand = 0;
     bool called = false;
 
