@@ -467,11 +467,21 @@ __global__ __launch_bounds__(256) void k_call_tails_heavy(CallArgs a) {
     const int lane = threadIdx.x & 63;
     const uint64_t n_all = a.counters[3] + (uint64_t)a.arena_waves * HEAVY_CHUNK;
     const uint64_t n_tasks = n_all < a.task_cap ? n_all : a.task_cap;
-    for (uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; i < n_tasks; i += ((uint64_t)gridDim.x * blockDim.x) >> 6) {
-        const TailTask t = a.heavy[i];
-        if (!(t.dst & ~1ull)) continue;                        // unused arena slot
-        const double tail = heavy_tail(t.k, t.n, (int)(t.dst & 1ull), a, lane);
-        if (lane == 0) *reinterpret_cast<int16_t*>(t.dst & ~1ull) = (int16_t)round4(tail);
+    // tasks differ by three orders of magnitude in their number of terms: batches of 8 slots off a queue (a wave's first batch
+    // is its own index), not a stride
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    uint64_t batch = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    while (batch * 8 < n_tasks) {
+        const uint64_t i1 = batch * 8 + 8 < n_tasks ? batch * 8 + 8 : n_tasks;
+        for (uint64_t i = batch * 8; i < i1; ++i) {
+            const TailTask t = a.heavy[i];
+            if (!(t.dst & ~1ull)) continue;                        // unused arena slot
+            const double tail = heavy_tail(t.k, t.n, (int)(t.dst & 1ull), a, lane);
+            if (lane == 0) *reinterpret_cast<int16_t*>(t.dst & ~1ull) = (int16_t)round4(tail);
+        }
+        unsigned long long nb = 0;
+        if (lane == 0) nb = atomicAdd(&a.counters[5], 1ull) + n_waves;
+        batch = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(nb >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)nb);
     }
 }
 
