@@ -467,17 +467,25 @@ __global__ __launch_bounds__(256) void k_call_tails_heavy(CallArgs a) {
     const int lane = threadIdx.x & 63;
     const uint64_t n_all = a.counters[3] + (uint64_t)a.arena_waves * HEAVY_CHUNK;
     const uint64_t n_tasks = n_all < a.task_cap ? n_all : a.task_cap;
-    // tasks differ by three orders of magnitude in their number of terms: batches of 8 slots off a queue (a wave's first batch
-    // is its own index), not a stride
+    // tasks differ by three orders of magnitude in their number of terms and most arena slots are empty: a wave takes 16
+    // slots at a time off a queue (its first batch is its own index: a small job never touches the queue word), one slot per
+    // lane, and works through the live ones
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     uint64_t batch = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    while (batch * 8 < n_tasks) {
-        const uint64_t i1 = batch * 8 + 8 < n_tasks ? batch * 8 + 8 : n_tasks;
-        for (uint64_t i = batch * 8; i < i1; ++i) {
-            const TailTask t = a.heavy[i];
-            if (!(t.dst & ~1ull)) continue;                        // unused arena slot
-            const double tail = heavy_tail(t.k, t.n, (int)(t.dst & 1ull), a, lane);
-            if (lane == 0) *reinterpret_cast<int16_t*>(t.dst & ~1ull) = (int16_t)round4(tail);
+    const uint64_t n_batches = (n_tasks + 15) / 16;
+    while (batch < n_batches) {
+        // the 16 slots of a batch lie n_batches apart: live slots come in dense runs (one gather wave's chunk, one deep region)
+        // and would otherwise all land on the same few waves
+        const uint64_t i = (uint64_t)lane * n_batches + batch;
+        TailTask t; t.k = 0; t.n = 0; t.dst = 0;
+        if (lane < 16 && i < n_tasks) t = a.heavy[i];
+        unsigned long long live = __ballot((t.dst & ~1ull) != 0);
+        while (live) {
+            const int l = __ffsll((long long)live) - 1; live &= live - 1;
+            const uint32_t k = (uint32_t)__shfl((int)t.k, l), n = (uint32_t)__shfl((int)t.n, l);
+            const uint64_t dst = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(t.dst >> 32), l) << 32) | (uint32_t)__shfl((int)(uint32_t)t.dst, l);
+            const double tail = heavy_tail(k, n, (int)(dst & 1ull), a, lane);
+            if (lane == 0) *reinterpret_cast<int16_t*>(dst & ~1ull) = (int16_t)round4(tail);
         }
         unsigned long long nb = 0;
         if (lane == 0) nb = atomicAdd(&a.counters[5], 1ull) + n_waves;
