@@ -126,47 +126,56 @@ def main():
     eng.set_region(lo[0], lo[1], hi[0], hi[1])
     n_reads, n_segs, n_events = eng.reads_shape()
     cp, kp = CountParams.longsom_defaults(), CallParams.longsom_defaults()
-    gather_buf = None
+    # N > 1: ONE all-gather per step.  Every rank sends a message of the same agreed size: a header slot holding its number of
+    # PASS-candidate rows, then room for cap_rows rows (SURVEY §8e's counts-then-buffers exchange needs two collectives and a host
+    # read between them on every step).  The capacity is agreed during warm-up (the headers are read there) and checked once more
+    # on the last timed step's buffer after the clock has stopped; a rank whose rows do not fit sends its count and no rows, so
+    # every rank sees the overflow and the step is repeated with a larger capacity.
+    gather = {"cap": int(os.environ.get("LSG_BENCH_GATHER_CAP", "64")), "send": None, "recv": None, "counts": None}
 
-    def step():
-        nonlocal gather_buf
+    def exchange(n_pass_hint=None):
+        cap = gather["cap"]
+        per = (cap + 1) * CALL_BYTES
+        if gather["send"] is None or gather["send"].numel() != per:
+            gather["send"] = torch.zeros(per, dtype=torch.uint8, device=dev)
+            gather["recv"] = torch.zeros(world * per, dtype=torch.uint8, device=dev)
+        send, recv = gather["send"], gather["recv"]
+        try:
+            n_pass = eng.export_calls(2, send.data_ptr() + CALL_BYTES, cap)
+        except RuntimeError as e:
+            if "capacity" not in str(e):
+                raise
+            n_pass = eng.export_calls(2)                         # count only: the header tells every rank to grow
+        send[:8].view(torch.int64)[0] = n_pass
+        if backend == "nccl":
+            dist.all_gather_into_tensor(recv, send)
+        else:
+            out_cpu = torch.empty(world * per, dtype=torch.uint8)
+            dist.all_gather_into_tensor(out_cpu, send.cpu())
+            recv.copy_(out_cpu)
+        return n_pass
+
+    def gathered_counts():
+        per = (gather["cap"] + 1) * CALL_BYTES
+        return gather["recv"].view(world, per)[:, :8].contiguous().view(torch.int64).flatten().cpu().tolist()
+
+    def step(check=False):
         rows, cols = eng.pileup_count(cp)
         n_sites, n_cand = eng.call_step1(kp)
         n_pass = 0
         if world > 1:
-            # PASS-candidate rows of this rank -> device buffer (grown on demand), then the two-step all-gather of SURVEY §8e:
-            # counts first, then the buffers cut to the largest count
-            if gather_buf is None:
-                gather_buf = [torch.zeros(4096 * CALL_BYTES, dtype=torch.uint8, device=dev), None]
-            while True:
-                try:
-                    n_pass = eng.export_calls(2, gather_buf[0].data_ptr(), gather_buf[0].numel() // CALL_BYTES)
-                    break
-                except RuntimeError as e:
-                    if "capacity" not in str(e):
-                        raise
-                    gather_buf[0] = torch.zeros(2 * gather_buf[0].numel(), dtype=torch.uint8, device=dev)
-            cdev = dev if backend == "nccl" else torch.device("cpu")
-            cnt = torch.tensor([n_pass], dtype=torch.int64, device=cdev)
-            allc = torch.empty(world, dtype=torch.int64, device=cdev)
-            dist.all_gather_into_tensor(allc, cnt)
-            per = max(1, int(allc.max().item())) * CALL_BYTES
-            if per > gather_buf[0].numel():                     # another rank has more rows than this rank's buffer holds
-                grown = torch.zeros(per, dtype=torch.uint8, device=dev)
-                grown[: gather_buf[0].numel()] = gather_buf[0]
-                gather_buf[0] = grown
-            if gather_buf[1] is None or gather_buf[1].numel() < world * per:
-                gather_buf[1] = torch.zeros(world * per, dtype=torch.uint8, device=dev)
-            if backend == "nccl":
-                dist.all_gather_into_tensor(gather_buf[1][: world * per], gather_buf[0][:per])
-            else:
-                out_cpu = torch.empty(world * per, dtype=torch.uint8)
-                dist.all_gather_into_tensor(out_cpu, gather_buf[0][:per].cpu())
-                gather_buf[1][: world * per].copy_(out_cpu)
+            n_pass = exchange()
+            if check:
+                counts = gathered_counts()
+                while max(counts) > gather["cap"]:                 # same decision on every rank: the headers are identical everywhere
+                    gather["cap"] = 2 * max(counts)
+                    n_pass = exchange()
+                    counts = gathered_counts()
+                gather["counts"] = counts
         return rows, cols, n_sites, n_cand, n_pass
 
-    for _ in range(args.warmup):
-        step()
+    for _ in range(max(args.warmup, 1) if world > 1 else args.warmup):
+        step(check=True)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -184,6 +193,11 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    if world > 1:
+        counts = gathered_counts()                                 # after the clock: the timed exchanges all fitted
+        if max(counts) > gather["cap"]:
+            raise RuntimeError("PASS-candidate rows outgrew the agreed all-gather capacity during the timed steps: %s > %d" % (counts, gather["cap"]))
+        gather["counts"] = counts
     vals = torch.tensor([dt, float(cols), float(n_sites), float(n_cand), float(n_reads), float(n_events), float(sum(rows))],
                         dtype=torch.float64, device=dev)
     if world > 1:
@@ -219,6 +233,8 @@ def main():
                        "reads": model.n_reads, "barcodes": model.n_cb, "reads_loaded_all_ranks": int(tot[4]), "event_slots_resident_all_ranks": int(tot[5]),
                        "sites_counted": int(sites), "rows_emitted": int(tot[6]), "merged_sites": int(tot[2]), "step1_candidates": int(tot[3]),
                        "sharding": "genomic regions balanced by read count" if world > 1 else "none",
+                       "pass_rows_gathered": int(sum(gather["counts"])) if world > 1 and gather["counts"] else None,
+                       "exchange": "one all-gather per step, %d-row slots agreed in warm-up" % gather["cap"] if world > 1 else None,
                        "path_algorithmic_GBps_rank0": path_bytes / dt / 1e9},
             "roofline": {"bound": "hbm", "kernel": "k_walk_block", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

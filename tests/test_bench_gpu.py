@@ -39,3 +39,10 @@ def test_contract_line_and_sharded_run():
     for k in ("sites_counted", "rows_emitted", "merged_sites", "step1_candidates"):
         assert two["config"][k] == one["config"][k], k
     assert two["config"]["reads_loaded_all_ranks"] >= one["config"]["reads_loaded_all_ranks"]          # boundary-crossing reads are loaded twice
+    # the single fixed-capacity all-gather: a capacity that is too small at first is grown in warm-up and moves the same rows
+    assert two["config"]["pass_rows_gathered"] is not None and two["config"]["pass_rows_gathered"] >= 0
+    tight = run_bench(["--gpus", "2", "--reads", "3e5", "--steps", "1", "--warmup", "1"],
+                      env={"LSG_BENCH_DEVICE": "0", "LSG_BENCH_BACKEND": "gloo", "LSG_BENCH_GATHER_CAP": "1"},
+                      launcher=[sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                                "--master-port", "29534"])
+    assert tight["config"]["pass_rows_gathered"] == two["config"]["pass_rows_gathered"]
