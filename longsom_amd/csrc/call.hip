@@ -17,6 +17,7 @@
 // lsg_export_calls expand it into the C-ABI's lsg_call records.
 #include "lsg_ctx.h"
 #include <cstring>
+#include <cstdlib>
 #include <hipcub/hipcub.hpp>
 
 namespace lsg {
@@ -46,6 +47,7 @@ struct CallArgs {
     const uint8_t* const* ref_ptr; const int64_t* contig_len;
     lsg_call_params p;
     double lgc0[2], lgcn[2];          // lgamma(a+b) - lgamma(b), lgamma(a+b) - lgamma(a) for (a1,b1), (a2,b2)
+    uint32_t* pass_list;              // site indices of the PASS candidates (k_call_finish appends, counters[6] counts; PASS_CAP slots)
     const int16_t* tail_table;        // [2][TAIL_ENTRIES] rounded tails of every (k <= n <= TAIL_NT), see k_tail_table
     uint32_t* site_cnt; uint32_t* site_off;
     SiteRec* sites; CandCt* cands; uint64_t cand_cap;
@@ -139,6 +141,7 @@ struct TailTask { uint32_t k, n; uint64_t dst; };     // dst = address of the in
 // Most tail requests have a small n (depth or cell count of one cell type at one site) and the same (k, n) pairs recur
 // millions of times: all pairs k <= n <= TAIL_NT are evaluated once per parameter set (k_tail_table, with exactly the code a
 // task of that pair would run, so the rounded values are the same bits) and looked up by k_call_gather instead of becoming tasks.
+constexpr uint32_t PASS_CAP = 4096;      // PASS candidates are a few hundred per sample: list + in-block sort; more fall back to the scan
 constexpr uint32_t TAIL_NT = 511;
 constexpr uint32_t TAIL_ENTRIES = (TAIL_NT + 1) * (TAIL_NT + 2) / 2;
 __host__ __device__ __forceinline__ uint32_t tail_index(uint32_t k, uint32_t n) { return n * (n + 1) / 2 + k; }
@@ -524,6 +527,10 @@ __global__ void k_call_finish(CallArgs a, uint32_t n_sites) {
         if (any_multi) sf |= LSG_SF_MULTI_ALLELIC;                             // :314
         if (n_with - n_pass - n_nonsig > 0) sf |= LSG_SF_CELL_TYPE_NOISE;      // :322
         if (s.sum_alts_bc > 0 && (bc_lt05 || cc_lt05)) sf |= LSG_SF_NOISY_SITE;   // :342
+        if (sf == (uint32_t)LSG_SF_CANDIDATE && n_pass > 0) {                   // = keep_site(kind 2): what step 3 can keep
+            const unsigned long long idx = atomicAdd(&a.counters[6], 1ull);
+            if (idx < PASS_CAP) a.pass_list[idx] = i;
+        }
     } else if (s.sum_alts_bc > 0 && (bc_lt001 || cc_lt001)) {
         sf |= LSG_SF_NOISY_SITE;                                               // :440-442
     }
@@ -543,11 +550,8 @@ __global__ void k_flag_keep(const SiteRec* sites, const CandCt* cands, int n_ct,
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i <= n) keep[i] = (i < n && keep_site(sites[i], cands, n_ct, kind)) ? 1u : 0u;
 }
-__global__ void k_expand(const SiteRec* sites, const CandCt* cands, int n_ct, int64_t n, const uint32_t* keep, const uint32_t* off,
-                         const uint8_t* const* ref_ptr, const int64_t* contig_len, lsg_call* out) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || !keep[i]) return;
-    const SiteRec& s = sites[i];
+__device__ __forceinline__ void expand_site(const SiteRec& s, const CandCt* cands, int n_ct, const uint8_t* const* ref_ptr, const int64_t* contig_len,
+                                            lsg_call* dst) {
     lsg_call c;
     memset(&c, 0, sizeof(c));
     c.key = s.key; c.ref = s.ref; c.present = s.present; c.considered = s.considered; c.has_cand = s.has_cand;
@@ -571,7 +575,35 @@ __global__ void k_expand(const SiteRec* sites, const CandCt* cands, int n_ct, in
         for (int q = 0; q < 5; ++q) c.up_ctx[q] = ref[pos - 5 + q];
         for (int q = 0; q < 5 && pos + 1 + q < contig_len[tid]; ++q) c.down_ctx[q] = ref[pos + 1 + q];
     }
-    out[off[i]] = c;
+    *dst = c;
+}
+__global__ void k_expand(const SiteRec* sites, const CandCt* cands, int n_ct, int64_t n, const uint32_t* keep, const uint32_t* off,
+                         const uint8_t* const* ref_ptr, const int64_t* contig_len, lsg_call* out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !keep[i]) return;
+    expand_site(sites[i], cands, n_ct, ref_ptr, contig_len, out + off[i]);
+}
+// PASS candidates from the list k_call_finish wrote (append order): ONE workgroup sorts the <= PASS_CAP site indices back into
+// genomic order (bitonic, LDS) and expands them
+__global__ __launch_bounds__(1024) void k_expand_list(const SiteRec* sites, const CandCt* cands, int n_ct, const uint32_t* list, uint32_t n,
+                                                      const uint8_t* const* ref_ptr, const int64_t* contig_len, lsg_call* out) {
+    __shared__ uint32_t v[PASS_CAP];
+    const uint32_t t = threadIdx.x;
+    uint32_t m = 1; while (m < n) m <<= 1;
+    for (uint32_t i = t; i < m; i += 1024) v[i] = i < n ? list[i] : 0xFFFFFFFFu;
+    __syncthreads();
+    for (uint32_t k = 2; k <= m; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = t; i < m; i += 1024) {
+                const uint32_t l = i ^ j;
+                if (l > i) {
+                    const uint32_t x = v[i], y = v[l];
+                    if (((i & k) == 0) == (x > y)) { v[i] = y; v[l] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    for (uint32_t i = t; i < n; i += 1024) expand_site(sites[v[i]], cands, n_ct, ref_ptr, contig_len, out + i);
 }
 
 __global__ void k_probe(const int64_t* set, int64_t n_set, const int64_t* keys, int64_t n, uint8_t* hits) {
@@ -615,7 +647,7 @@ int run_call(lsg_ctx* c, const lsg_call_params* p) {
     if (!c->counted) { set_error("lsg_call_step1: call lsg_pileup_count first"); return -2; }
     hipStream_t st = c->stream;
     const uint32_t n_ne = c->n_ne;
-    c->n_sites = 0; c->n_cand = 0;
+    c->n_sites = 0; c->n_cand = 0; c->n_pass = -1;
     if (n_ne == 0) { c->called = true; return 0; }
     if (c->d_site_off.reserve((size_t)(n_ne + 2) * 12 + 192 + (size_t)n_ne * 64 + 64)) return -1;     // site_cnt, site_off, counters (8 u64), heads, head records
     CallArgs a{};
@@ -637,6 +669,8 @@ int run_call(lsg_ctx* c, const lsg_call_params* p) {
         }
         a.tail_table = c->d_tail_table.as<int16_t>();
     }
+    if (c->d_pass_list.reserve((size_t)PASS_CAP * 4)) return -1;
+    a.pass_list = c->d_pass_list.as<uint32_t>();
     a.site_cnt = c->d_site_off.as<uint32_t>();
     a.site_off = a.site_cnt + (n_ne + 2);
     a.counters = reinterpret_cast<unsigned long long*>(a.site_off + (n_ne + 2));   // 2*(n_ne+2) words: 8-byte aligned
@@ -690,10 +724,11 @@ int run_call(lsg_ctx* c, const lsg_call_params* p) {
         hipLaunchKernelGGL(k_call_finish, dim3((n_sites + 255) / 256), dim3(256), 0, st, a, n_sites);
         LSG_HIP(hipGetLastError());
     }
-    unsigned long long cnt4[4] = {0, 0, 0, 0};
-    LSG_HIP(hipMemcpyAsync(c->h_pin, a.counters, 32, hipMemcpyDeviceToHost, st));
+    unsigned long long cnt4[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    LSG_HIP(hipMemcpyAsync(c->h_pin, a.counters, 64, hipMemcpyDeviceToHost, st));
     LSG_HIP(hipStreamSynchronize(st));
-    memcpy(cnt4, c->h_pin, 32);
+    memcpy(cnt4, c->h_pin, 64);
+    c->n_pass = (int64_t)cnt4[6];
     const unsigned long long cand = cnt4[1];
     if (n_sites > 0 && (cnt4[2] + (uint64_t)a.arena_waves * TASK_CHUNK > a.task_cap || cnt4[3] + (uint64_t)a.arena_waves * HEAVY_CHUNK > a.task_cap)) { set_error("lsg_call_step1: tail task buffer too small (%llu/%llu tasks)", cnt4[2], cnt4[3]); return -3; }
     c->n_sites = n_sites; c->n_cand = (int64_t)cand;
@@ -708,6 +743,18 @@ int run_select_calls(lsg_ctx* c, int kind, lsg_call* dst_device, int64_t capacit
     const int64_t n = c->n_sites;
     if (n_out) *n_out = 0;
     if (n == 0) return 0;
+    if (kind == 2 && c->n_pass >= 0 && c->n_pass <= (int64_t)PASS_CAP && !getenv("LSG_NO_PASS_LIST")) {
+        // the call stage left the PASS candidates' site indices and their number behind: no scan over the sites, no count read
+        const int64_t k = c->n_pass;
+        if (n_out) *n_out = k;
+        if (!dst_device || k == 0) return 0;
+        if (k > capacity) { set_error("lsg_export_calls: capacity %lld < %lld rows", (long long)capacity, (long long)k); return -2; }
+        hipLaunchKernelGGL(k_expand_list, dim3(1), dim3(1024), 0, st, c->d_calls.as<SiteRec>(), c->ws[WS_CALL_CANDS].as<CandCt>(), c->n_ct,
+                           c->d_pass_list.as<uint32_t>(), (uint32_t)k, c->d_ref_ptrs.as<const uint8_t*>(), c->d_contig_len.as<int64_t>(), dst_device);
+        LSG_HIP(hipGetLastError());
+        LSG_HIP(hipStreamSynchronize(st));
+        return 0;
+    }
     DevBuf& flags = c->ws[WS_CALL_FLAGS];
     if (flags.reserve((size_t)(n + 2) * 8)) return -1;
     uint32_t* keep = flags.as<uint32_t>();

@@ -24,8 +24,7 @@ for world in worlds:
         def step():
             rows, cols = eng.pileup_count(cp)
             ns, nc = eng.call_step1(kp)
-            npass = eng.export_calls(2)
-            eng.export_calls(2, buf.data_ptr(), buf.numel() // CALL_BYTES)
+            npass = eng.export_calls(2, buf.data_ptr(), buf.numel() // CALL_BYTES)      # as bench.py does: rows straight into the send buffer
             return cols, ns, nc, npass
         step(); torch.cuda.synchronize()
         t0 = time.perf_counter()
