@@ -23,13 +23,14 @@ __global__ void k_seg_slots(const int32_t* seg_start, const int32_t* seg_len, in
 // one wavefront per segment: coalesced copy of its events to the aligned slot
 __global__ __launch_bounds__(256) void k_relayout(const uint16_t* src, int64_t n_src, const int32_t* seg_start, const int32_t* seg_len,
                                                   const int64_t* old_off, const int64_t* slot_base, int64_t n_segs,
+                                                  const uint32_t* seg_read, int64_t n_reads,
                                                   uint16_t* dst, int64_t* new_off, uint32_t* bad) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     for (int64_t s = wave; s < n_segs; s += n_waves) {
         const int64_t o = old_off[s], ln = seg_len[s], st = seg_start[s];
         const int64_t d = slot_base[s] + (st & 63);
-        if (lane == 0) new_off[s] = d;
+        if (lane == 0) { new_off[s] = d; if ((int64_t)seg_read[s] >= n_reads) atomicOr(bad, 2u); }
         if (ln <= 0) continue;
         if (o < 0 || o + ln > n_src) { if (lane == 0) atomicOr(bad, 1u); continue; }
         for (int64_t i = lane; i < ln; i += 64) dst[d + i] = src[o + i];
@@ -114,9 +115,10 @@ int relayout_events(lsg_ctx* c) {
     if (hipMemsetAsync(aligned.p, 0, (size_t)E2 * 2 + 256, st) != hipSuccess || hipMemsetAsync(flag.p, 0, 64, st) != hipSuccess) { set_error("relayout: memset failed"); return fail(-1); }
     unsigned grid = (unsigned)((S + 3) / 4 < (int64_t)c->n_cus * 32 ? (S + 3) / 4 : (int64_t)c->n_cus * 32);
     hipLaunchKernelGGL(k_relayout, dim3(grid), dim3(256), 0, st, c->rd.events, c->rd.n_events, c->rd.seg_start, c->rd.seg_len, c->rd.seg_ev_off,
-                       base.as<int64_t>(), S, aligned.as<uint16_t>(), noff.as<int64_t>(), flag.as<uint32_t>());
+                       base.as<int64_t>(), S, c->rd.seg_read, c->rd.n_reads, aligned.as<uint16_t>(), noff.as<int64_t>(), flag.as<uint32_t>());
     uint32_t bad = 0;
     if (hipMemcpyAsync(&bad, flag.p, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { set_error("relayout: kernel failed: %s", hipGetErrorString(hipGetLastError())); return fail(-1); }
+    if (bad & 2u) { set_error("lsg_load_reads: a segment's read index lies outside the read arrays"); return fail(-2); }
     if (bad) { set_error("lsg_load_reads: a segment's event range lies outside the events array"); return fail(-2); }
     // the library's own copies replace whatever the caller handed over
     if (c->b_seg_ev_off.reserve((size_t)(S + 1) * 8)) return fail(-1);

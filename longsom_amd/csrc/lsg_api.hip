@@ -188,7 +188,7 @@ int lsg_load_reads(lsg_ctx* c, const lsg_reads* r) {
     if (r->n_segs > 0 && (!c->rd.seg_read || !c->rd.seg_start || !c->rd.seg_len || !c->rd.seg_ev_off)) { set_error("lsg_load_reads: NULL segment array"); return -2; }
     LSG_HIP(hipStreamSynchronize(c->stream));
     c->counted = c->called = false;
-    if (int rc = lsg::relayout_events(c)) return rc;
+    if (int rc = lsg::relayout_events(c)) { c->rd = lsg_reads{}; c->entries_upper = 0; return rc; }      // a refused load leaves no reads behind
     return compute_entries_upper(c);
 }
 

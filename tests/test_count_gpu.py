@@ -129,6 +129,11 @@ def test_bad_event_range_is_an_error(engine):
     off[-1] = rec.n_events
     with pytest.raises(RuntimeError, match="outside the events array"):
         engine.load_reads(dataclasses.replace(rec, seg_ev_off=off))
+    assert engine.reads_shape() == (0, 0, 0)                      # a refused load leaves no reads behind
+    sr = rec.seg_read.copy()
+    sr[0] = rec.n_reads                                           # a segment owned by a read that does not exist
+    with pytest.raises(RuntimeError, match="read index"):
+        engine.load_reads(dataclasses.replace(rec, seg_read=sr))
     run_both(engine, rec, lens, refs, celltype_of, 2)
 
 
