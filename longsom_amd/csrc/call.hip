@@ -534,7 +534,7 @@ __global__ void k_call_finish(CallArgs a, uint32_t n_sites) {
     } else if (s.sum_alts_bc > 0 && (bc_lt001 || cc_lt001)) {
         sf |= LSG_SF_NOISY_SITE;                                               // :440-442
     }
-    a.sites[i].site_filter = sf;
+    if (sf != s.site_filter) a.sites[i].site_filter = sf;        // most sites keep the flags the gather kernel gave them
 }
 
 // Expansion of compact records into the C-ABI's lsg_call; kind selects rows (see lsg_export_calls).
