@@ -1403,7 +1403,9 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_pileup_huge(CountArgs a) {
 constexpr int FIN_THREADS = 512;
 __global__ __launch_bounds__(FIN_THREADS) void k_finalize_multi(CountArgs a) {
     __shared__ uint32_t sacc[NCTR][64];
+    __shared__ WaveBook book;             // rows from a workgroup arena, exact counters flushed once (not five global atomics per unit)
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    if (wv == 0) { book_init(book, lane); if (lane == 0) book.src = 3; }
     for (uint32_t k = blockIdx.x; k < a.n_multi; k += gridDim.x) {
         const uint32_t w = a.multi_list[k];
         const uint32_t nslot = a.ne_nslot[w];
@@ -1437,9 +1439,10 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize_multi(CountArgs a) {
                 tot.bq[sy] = sacc[17 + sy][lane]; tot.bcf[sy] = sacc[25 + sy][lane];
             }
             const int2 geom = a.ne_geom[w];
-            emit_unit(a, tot, w, (int)((uint32_t)geom.y >> 24), geom.y & 0xffffff, geom.x, lane, nullptr, true);
+            emit_unit(a, tot, w, (int)((uint32_t)geom.y >> 24), geom.y & 0xffffff, geom.x, lane, &book, true);
         }
     }
+    if (wv == 0) book_flush(a, book, lane);
 }
 
 // Work-balanced chunks of the wave kernel's slot list.  work(slot) = entries + WORK_W0; chunk k holds the
@@ -1671,7 +1674,7 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
         uint64_t by_depth = (uint64_t)c->rd.n_events / (uint64_t)p->min_dp + 64;
         if (by_depth < want_rows) want_rows = by_depth;
     }
-    want_rows += (uint64_t)(grid_block + grid_walk + grid_wave * WAVES_PER_BLOCK) * ARENA + 64;
+    want_rows += (uint64_t)(grid_block + grid_walk + grid_wave * WAVES_PER_BLOCK + (unsigned)(c->n_cus * 8)) * ARENA + 64;      // one open arena per emitting wave
     want_rows = (want_rows + 63) / 64 * 64 + 64;        // whole 64-row blocks (lsg::row_word), one spare: a unit's descriptor spans two
     // every cell type of THIS run needs planes of the current stride (a run with more cell types than any before it
     // finds row_cap large enough but its new buffers still empty)
