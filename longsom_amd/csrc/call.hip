@@ -413,14 +413,17 @@ __global__ __launch_bounds__(256) void k_call_tails(CallArgs a) {
     }
 }
 
-// one wavefront, one tail: lane l sums the terms [l*chunk, (l+1)*chunk) of the shorter side; the value is valid on lane 0
-__device__ __forceinline__ double heavy_tail(uint32_t k, uint32_t n, int set, const CallArgs& a, int lane) {
+// G lanes, one tail (G = 64: the whole wavefront; G = 8: eight tails side by side, each lane group with its own k, n, set): lane g
+// of a group sums the terms [g*chunk, (g+1)*chunk) of the shorter side; the value is valid on the group's first lane.  Every lane
+// pays one log-pmf (nine lgamma) to anchor its chunk, so a tail of a few hundred terms is cheaper on 8 lanes than on 64.
+template <int G>
+__device__ __forceinline__ double group_tail(uint32_t k, uint32_t n, int set, const CallArgs& a, int lane, bool live = true) {
     const double al = set ? a.p.alpha2 : a.p.alpha1, be = set ? a.p.beta2 : a.p.beta1;
     const double dn = (double)n;
     const bool lower = (uint64_t)k <= (uint64_t)n - k + 1;
-    const uint32_t m_lo = lower ? 0u : k, m_hi = lower ? k : n + 1;        // terms m in [m_lo, m_hi)
-    const uint32_t cnt = m_hi - m_lo, chunk = (cnt + 63) / 64;
-    const uint32_t b = m_lo + (uint32_t)lane * chunk;
+    const uint32_t m_lo = lower ? 0u : k, m_hi = live ? (lower ? k : n + 1) : m_lo;        // terms m in [m_lo, m_hi)
+    const uint32_t cnt = m_hi - m_lo, chunk = (cnt + G - 1) / G;
+    const uint32_t b = m_lo + (uint32_t)(lane & (G - 1)) * chunk;
     const uint32_t e = b + chunk < m_hi ? b + chunk : m_hi;
     double sum = 0.0;
     if (b < e) {
@@ -432,9 +435,11 @@ __device__ __forceinline__ double heavy_tail(uint32_t k, uint32_t n, int set, co
             sum += pm;
         }
     }
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o);
+    for (int o = G / 2; o > 0; o >>= 1) sum += __shfl_down(sum, o, G);
     return lower ? 1.0 - sum : sum;
 }
+__device__ __forceinline__ uint32_t tail_terms(uint32_t k, uint32_t n) { return (uint64_t)k <= (uint64_t)n - k + 1 ? k : n + 1 - k; }
+constexpr uint32_t GROUP8_MAX_TERMS = 1024;       // above this a tail gets the whole wavefront
 
 // every (k, n) with k <= n <= TAIL_NT for both parameter sets: pairs a light task would take by one thread each, pairs a heavy
 // task would take by one wavefront each (the same functions the task kernels call)
@@ -452,20 +457,20 @@ __global__ __launch_bounds__(256) void k_tail_table(CallArgs a, int16_t* table) 
         TailTask t; t.k = k; t.n = n; t.dst = (uint64_t)set;
         table[i] = (int16_t)round4(tail_of_task(t, a));
     }
-    for (uint64_t i = tid >> 6; i < 2ull * TAIL_ENTRIES; i += n_thr >> 6) {
+    for (uint64_t i = tid >> 3; i < 2ull * TAIL_ENTRIES; i += n_thr >> 3) {          // n <= TAIL_NT: at most 256 terms, 8 lanes each
         const int set = i >= TAIL_ENTRIES;
         const uint32_t idx = (uint32_t)(i - (set ? TAIL_ENTRIES : 0));
         uint32_t n = (uint32_t)((sqrt(8.0 * (double)idx + 1.0) - 1.0) * 0.5);
         while (tail_index(0, n + 1) <= idx) ++n;
         while (tail_index(0, n) > idx) --n;
         const uint32_t k = idx - tail_index(0, n);
-        if (tail_work(k, n) <= 64) continue;
-        const double tail = heavy_tail(k, n, set, a, lane);
-        if (lane == 0) table[i] = (int16_t)round4(tail);
+        const bool heavy = tail_work(k, n) > 64;
+        const double tail = group_tail<8>(k, n, set, a, lane, heavy);
+        if (heavy && (lane & 7) == 0) table[i] = (int16_t)round4(tail);
     }
 }
 
-// heavy tasks: one wavefront each
+// heavy tasks: eight lanes or one wavefront each
 __global__ __launch_bounds__(256) void k_call_tails_heavy(CallArgs a) {
     const int lane = threadIdx.x & 63;
     const uint64_t n_all = a.counters[3] + (uint64_t)a.arena_waves * HEAVY_CHUNK;
@@ -482,12 +487,25 @@ __global__ __launch_bounds__(256) void k_call_tails_heavy(CallArgs a) {
         const uint64_t i = (uint64_t)lane * n_batches + batch;
         TailTask t; t.k = 0; t.n = 0; t.dst = 0;
         if (lane < 16 && i < n_tasks) t = a.heavy[i];
-        unsigned long long live = __ballot((t.dst & ~1ull) != 0);
-        while (live) {
-            const int l = __ffsll((long long)live) - 1; live &= live - 1;
+        const bool is_live = (t.dst & ~1ull) != 0;
+        const bool is_big = is_live && tail_terms(t.k, t.n) > GROUP8_MAX_TERMS;
+        // tails of up to GROUP8_MAX_TERMS terms: eight at a time, lane group g takes slot 8 * round + g of the batch
+#pragma unroll
+        for (int round = 0; round < 2; ++round) {
+            const int l = 8 * round + (lane >> 3);
             const uint32_t k = (uint32_t)__shfl((int)t.k, l), n = (uint32_t)__shfl((int)t.n, l);
             const uint64_t dst = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(t.dst >> 32), l) << 32) | (uint32_t)__shfl((int)(uint32_t)t.dst, l);
-            const double tail = heavy_tail(k, n, (int)(dst & 1ull), a, lane);
+            const bool mine = (dst & ~1ull) != 0 && tail_terms(k, n) <= GROUP8_MAX_TERMS;
+            if (__ballot(mine) == 0ull) continue;
+            const double tail = group_tail<8>(k, n, (int)(dst & 1ull), a, lane, mine);
+            if (mine && (lane & 7) == 0) *reinterpret_cast<int16_t*>(dst & ~1ull) = (int16_t)round4(tail);
+        }
+        unsigned long long big = __ballot(is_big);
+        while (big) {                                                  // the long ones: the whole wavefront each
+            const int l = __ffsll((long long)big) - 1; big &= big - 1;
+            const uint32_t k = (uint32_t)__shfl((int)t.k, l), n = (uint32_t)__shfl((int)t.n, l);
+            const uint64_t dst = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(t.dst >> 32), l) << 32) | (uint32_t)__shfl((int)(uint32_t)t.dst, l);
+            const double tail = group_tail<64>(k, n, (int)(dst & 1ull), a, lane);
             if (lane == 0) *reinterpret_cast<int16_t*>(dst & ~1ull) = (int16_t)round4(tail);
         }
         unsigned long long nb = 0;
