@@ -149,7 +149,7 @@ __device__ __forceinline__ uint32_t sub_of(uint32_t cb, uint32_t nsub, uint32_t 
 // atomic per distinct unit for the whole chunk.  (A deep gene funnels thousands of batches into a few
 // cache lines of unit_cnt / unit_cursor; same-line atomics serialise in L2, so their number is what counts.)
 //   MODE 0: count entries per unit.  MODE 2: claim a range per unit, then replay the chunk's items and
-//   scatter the self-contained entries (key, first event byte offset, lane range) into buffer A.
+//   scatter the packed entries (barcode | count | strand, line index) into buffer A.
 constexpr int BIN_THREADS = 256;
 constexpr int BIN_TPR = 8;             // tiles per segment handled per item
 constexpr int BIN_H = 4096;            // LDS hash slots
@@ -528,7 +528,7 @@ __device__ __forceinline__ uint32_t rl(uint32_t v, int l) { return (uint32_t)__b
 
 // One pileup entry at a lane's position (BaseCellCounter.py:258-279).  m = the entry's meta word (wave-uniform:
 // META_NEWRUN starts a new barcode run, META_FWD is the strand), ev = the event (0 when the lane is outside the
-// entry: the bounds-checked buffer load returns 0 there), thr = 0x800 + min_bq: an event is counted iff its valid bit
+// segment: the tile-aligned layout holds zero padding there), thr = 0x800 + min_bq: an event is counted iff its valid bit
 // is set and its quality passes the gate, i.e. (ev & 0x8ff) >= thr.  pkl = LDS byte address of this lane's word in
 // row 0 of the wave's packed counters (2048-byte aligned rows block, so the row offset is OR-ed in).
 // mask: bit 0 = any symbol seen in this barcode run, bit 8 + class = that class seen.  Branch-free.
