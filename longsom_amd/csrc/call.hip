@@ -223,10 +223,12 @@ __global__ __launch_bounds__(GATHER_WAVES * 64) void k_call_gather(CallArgs a) {
         for (int s = 0; s < 6; ++s) { v_cc[ct][s] = 0; v_bc[ct][s] = 0; }
         if (site && ((mask[ct] >> lane) & 1ull)) {
             const uint64_t row = (uint64_t)rbase[ct] + __popcll(mask[ct] & below);
-            const uint32_t* R = a.rows[ct] + row_word(row, 0);          // plane p of this row: R[p * 64]
-            v_dp[ct] = R[0]; v_nc[ct] = R[64];
-#pragma unroll
-            for (int s = 0; s < 6; ++s) { v_cc[ct][s] = R[(2 + s) * 64]; v_bc[ct][s] = R[(10 + s) * 64]; }
+            // planes 0..15 of the row = DP, NC, CC[0..7], BC[0..5] in four 16-byte loads (quad q at 256 words from quad q - 1)
+            const uint4* R = reinterpret_cast<const uint4*>(a.rows[ct] + row_word(row, 0));
+            const uint4 q0 = R[0], q1 = R[64], q2 = R[128], q3 = R[192];
+            v_dp[ct] = q0.x; v_nc[ct] = q0.y;
+            v_cc[ct][0] = q0.z; v_cc[ct][1] = q0.w; v_cc[ct][2] = q1.x; v_cc[ct][3] = q1.y; v_cc[ct][4] = q1.z; v_cc[ct][5] = q1.w;
+            v_bc[ct][0] = q2.z; v_bc[ct][1] = q2.w; v_bc[ct][2] = q3.x; v_bc[ct][3] = q3.y; v_bc[ct][4] = q3.z; v_bc[ct][5] = q3.w;
         }
     }
     // pass 1: candidate? number of tail tasks?  (one wave-aggregated allocation each)

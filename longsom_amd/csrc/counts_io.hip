@@ -50,13 +50,13 @@ int install_counts(lsg_ctx* c, int32_t n_ct, const int64_t* const* keys, const u
     // blocked planes (lsg::row_word; the reverse-strand plane is derived: BCr = BC - BCf)
     max_rows = (max_rows + 63) / 64 * 64;
     c->row_cap = max_rows;
-    std::vector<uint32_t> planes((size_t)max_rows * lsg::ROW_PLANES);
+    std::vector<uint32_t> planes((size_t)max_rows * lsg::ROW_STORED_WORDS, 0u);
     for (int ct = 0; ct < n_ct; ++ct) {
         const int64_t n = n_rows[ct];
-        if (c->d_rows[ct].reserve((size_t)max_rows * lsg::ROW_PLANES * 4)) return -1;
+        if (c->d_rows[ct].reserve((size_t)max_rows * lsg::ROW_STORED_WORDS * 4)) return -1;
         for (int64_t i = 0; i < n; ++i)
             for (int k = 0; k < lsg::ROW_PLANES; ++k) planes[(size_t)lsg::row_word((uint64_t)i, k)] = counts[ct][i * LSG_ROW_WORDS + k];
-        if (n) LSG_HIP(hipMemcpyAsync(c->d_rows[ct].p, planes.data(), (size_t)max_rows * lsg::ROW_PLANES * 4, hipMemcpyHostToDevice, st));
+        if (n) LSG_HIP(hipMemcpyAsync(c->d_rows[ct].p, planes.data(), (size_t)max_rows * lsg::ROW_STORED_WORDS * 4, hipMemcpyHostToDevice, st));
         LSG_HIP(hipStreamSynchronize(st));
         c->n_rows[ct] = n;
     }

@@ -13,11 +13,16 @@ constexpr int TILE_W = 64;          // reference positions per tile = one lane p
 constexpr int ROW_PLANES = 34;      // count-row planes kept in HBM: DP, NC, CC[8], BC[8], BQ[8], BCf[8]; BCr = BC - BCf is derived on export
 constexpr int NCTR = 33;            // accumulators kept per position: NC, CC[8], BC[8], BQ[8], BCf[8]
 
-// Resident count rows of one cell type: blocks of 64 rows, [block][plane][64 rows].  All 34 words of a row lie inside one
-// 8704-byte block (a unit's rows, <= 64 and consecutive, inside two), so a unit is written and read around ONE place in memory
-// instead of 34 places one plane stride apart.  row_cap is a multiple of 64.
-constexpr uint64_t ROW_BLOCK_WORDS = (uint64_t)ROW_PLANES * 64;
-__host__ __device__ inline uint64_t row_word(uint64_t row, int plane) { return (row >> 6) * ROW_BLOCK_WORDS + (uint64_t)plane * 64 + (row & 63); }
+// Resident count rows of one cell type: blocks of 64 rows, [block][quad][64 rows][4 planes] with quad = plane / 4 (34 planes in
+// 9 quads, the last two words unused).  All words of a row lie inside one 9216-byte block (a unit's rows, <= 64 and consecutive,
+// inside two), so a unit is written and read around ONE place in memory, and a lane moves four planes of its row with one 16-byte
+// access: 9 stores per unit instead of 34, 4 loads per row for the call stage instead of 14.  row_cap is a multiple of 64.
+constexpr int ROW_QUADS = (ROW_PLANES + 3) / 4;
+constexpr uint64_t ROW_BLOCK_WORDS = (uint64_t)ROW_QUADS * 256;
+constexpr uint64_t ROW_STORED_WORDS = (uint64_t)ROW_QUADS * 4;          // words of HBM per row (36)
+__host__ __device__ inline uint64_t row_word(uint64_t row, int plane) {
+    return (row >> 6) * ROW_BLOCK_WORDS + (uint64_t)(plane >> 2) * 256 + (row & 63) * 4 + (uint64_t)(plane & 3);
+}
 
 void set_error(const char* fmt, ...);
 const char* get_error();

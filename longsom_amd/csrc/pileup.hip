@@ -898,23 +898,28 @@ __device__ __forceinline__ void emit_unit(const CountArgs& a, const CNT& acc, ui
     }
     if (!emit) return;
     // the unit's rows lie in at most two consecutive 64-row blocks: ONE descriptor over those blocks (scalar registers), the
-    // lane adds its row's offset inside them, the plane is a scalar offset of 256 bytes per plane
+    // lane adds its row's offset inside them and moves four planes per 16-byte store (quad = scalar offset of 1024 bytes)
     const uint32_t row = base + (uint32_t)__popcll(em & ((1ull << lane) - 1ull));
     const uint32_t b0 = base >> 6;
-    const uint32_t off4 = (((row >> 6) - b0) * (uint32_t)ROW_BLOCK_WORDS + (row & 63u)) * 4u;
+    const uint32_t off16 = (((row >> 6) - b0) * (uint32_t)ROW_BLOCK_WORDS + (row & 63u) * 4u) * 4u;
     const uint64_t first = (uint64_t)(uintptr_t)a.rows[ct] + (uint64_t)b0 * (ROW_BLOCK_WORDS * 4ull);
     const uint64_t p0 = ((uint64_t)rl((uint32_t)(first >> 32), 0) << 32) | rl((uint32_t)first, 0);
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>((uintptr_t)p0), 0, (int)(2 * ROW_BLOCK_WORDS * 4), 0x00020000);
-    auto put = [&](int plane, uint32_t v) { __builtin_amdgcn_raw_buffer_store_b32(v, rs, (int)off4, plane * 256, 0); };
-    put(0, dp);
-    put(1, nc);
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    auto plane = [&](int p) -> uint32_t {                             // the row in plane order: DP, NC, CC[8], BC[8], BQ[8], BCf[8], 0, 0
+        if (p == 0) return dp;
+        if (p == 1) return nc;
+        if (p < 10) return acc.BC(p - 2) - acc.DUP(p - 2);
+        if (p < 18) return acc.BC(p - 10);
+        if (p < 26) return acc.BQ(p - 18);
+        if (p < 34) return acc.BCF(p - 26);
+        return 0u;
+    };
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        const uint32_t b = acc.BC(s), f = acc.BCF(s);
-        put(2 + s, b - acc.DUP(s));
-        put(10 + s, b);
-        put(18 + s, acc.BQ(s));
-        put(26 + s, f);
+    for (int q = 0; q < ROW_QUADS; ++q) {
+        u32x4 v; v.x = plane(4 * q); v.y = plane(4 * q + 1); v.z = plane(4 * q + 2); v.w = plane(4 * q + 3);
+        __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)off16, q * 1024, 0);
+        __builtin_amdgcn_sched_barrier(0);                             // one quad's values live at a time (counters read from LDS stay there until needed)
     }
 }
 
@@ -1680,7 +1685,7 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
     // finds row_cap large enough but its new buffers still empty)
     if (want_rows > c->row_cap) c->row_cap = want_rows;
     for (int i = 0; i < c->n_ct; ++i)
-        if (c->d_rows[i].reserve((size_t)c->row_cap * ROW_PLANES * 4)) return -1;
+        if (c->d_rows[i].reserve((size_t)c->row_cap * ROW_STORED_WORDS * 4)) return -1;
     fill_args(c, p, a);
     if (n_ne > 0) hipLaunchKernelGGL(k_group_block, dim3((unsigned)(c->n_cus * 4)), dim3(BLOCK_THREADS), 0, st, a);
     LSG_HIP(hipEventRecord(c->ev[1], st));
