@@ -9,6 +9,7 @@ step3  <- variant_calling_step3 + helpers           workflow/scripts/SNVCalling/
 """
 import gzip
 import io
+import re
 from typing import Dict, Optional, Sequence
 
 import numpy as np
@@ -60,38 +61,57 @@ def step2(step1_text: str, engine, contig_names: Sequence[str], editing_keys, po
             else:
                 comments.append(line)
         elif line:
-            el = line.split("\t")
+            el = line.split("\t", 6)                    # CHROM Start End REF ALT FILTER | the rest stays one string
             if el[4] != "." and el[5] != ".":           # awk filter, step2.py:23
                 rows.append(el)
     tid_of = {n: i for i, n in enumerate(contig_names)}
-    q = np.asarray([((tid_of.get(el[0], 0x7FFFFFFF)) << 32) | int(el[1]) for el in rows], np.int64)
+    pos = [int(el[1]) for el in rows]
+    q = np.asarray([(tid_of.get(el[0], 0x7FFFFFFF) << 32) | p for el, p in zip(rows, pos)], np.int64)
     hits = []
     for kind, keys in ((KIND_EDITING, editing_keys), (KIND_PON_SR, pon_sr_keys), (KIND_PON_LR, pon_lr_keys)):
         engine.load_posset(kind, keys)
-        hits.append(engine.probe_posset(kind, q) if len(keys) and len(q) else np.zeros(len(q), np.uint8))
+        hits.append((engine.probe_posset(kind, q) if len(keys) and len(q) else np.zeros(len(q), np.uint8)).tolist())
     n = len(rows)
+    # the 3-row window of step2.py:59-92 (rows 0..2 for the first row); a neighbour at the SAME position never counts, so
+    # distance 0 (LongSom's setting) tags nothing
+    close = [0] * n
+    if distance > 0:
+        for i in range(n):
+            lo, hi = (0, n) if n < 3 else ((0, 3) if i == 0 else (i - 1, min(n, i + 2)))
+            chrom, p = rows[i][0], pos[i]
+            c = 0
+            for j in range(lo, hi):
+                if rows[j][0] == chrom and pos[j] != p and abs(pos[j] - p) <= distance:
+                    c += 1
+            close[i] = c
+    have_af = bool(gnomad_af)
+    h_ed, h_sr, h_lr = hits
     out = []
     for i, el in enumerate(rows):
-        chrom, pos = el[0], int(el[1])
-        lo, hi = (0, n) if n < 3 else ((0, 3) if i == 0 else (i - 1, min(n, i + 2)))    # the 3-row window of step2.py:59-92
-        close = 0
-        for j in range(lo, hi):
-            pj = int(rows[j][1])
-            if rows[j][0] == chrom and pj != pos and abs(pj - pos) <= distance:
-                close += 1
-        tags = []
-        if hits[0][i]: tags.append("RNA_editing_db")
-        if close > 0: tags.append("Clustered")
-        if hits[1][i]: tags.append("PoN_SR")
-        if hits[2][i]: tags.append("PoN_LR")
-        af = gnomad_af.get("%s:%s:%s:%s" % (chrom, el[1], el[3], el[4]), 0.0)
-        if af == af and af >= gnomad_max:
-            tags.append("gnomAD")
         F = el[5]
-        for t in tags:
-            F = t if F == "PASS" else F + "," + t
-        out.append("\t".join([el[0], el[1], el[2], el[3], el[4], F] + ["" if x == "NA" else x for x in el[6:]]))
+        if h_ed[i] or close[i] or h_sr[i] or h_lr[i] or have_af:
+            tags = []
+            if h_ed[i]: tags.append("RNA_editing_db")
+            if close[i] > 0: tags.append("Clustered")
+            if h_sr[i]: tags.append("PoN_SR")
+            if h_lr[i]: tags.append("PoN_LR")
+            if have_af:
+                af = gnomad_af.get("%s:%s:%s:%s" % (el[0], el[1], el[3], el[4]), 0.0)
+                if af == af and af >= gnomad_max:
+                    tags.append("gnomAD")
+            for t in tags:
+                F = t if F == "PASS" else F + "," + t
+        rest = el[6] if len(el) > 6 else None
+        if rest is not None and "NA" in rest:            # pandas writes a missing field (the reference reads "NA" as NaN) as ""
+            rest = _NA_FIELD.sub("", rest)
+        if rest is None:
+            out.append("\t".join((el[0], el[1], el[2], el[3], el[4], F)))
+        else:
+            out.append("\t".join((el[0], el[1], el[2], el[3], el[4], F, rest)))
     return "\n".join(comments + [header] + out) + "\n"
+
+
+_NA_FIELD = re.compile(r"(?:(?<=\t)|^)NA(?=\t|$)")     # a whole field equal to NA
 
 
 # ---- step 3 ---------------------------------------------------------------------------------------
