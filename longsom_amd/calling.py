@@ -238,11 +238,19 @@ def step3(step2_text: str, delta_vaf: float, delta_mcf: float, min_ac_reads: int
         # the reference crashes on an empty frame under pandas 2; emit header-only files instead
         empty = head + "\t".join(out_cols) + "\n"
         return empty, empty
-    res = [_multiallelic(r) for r in _records(df, ("ALT", "FILTER", "Cell_types", "Bc", "Cc", "VAF", "MCF", "REF", "Dp", "Nc", "Cancer", "Non-Cancer"))]
+    # MultiAllelic_filtering touches only rows flagged Multi-allelic or with several alts; every other row keeps its values and
+    # gets STEP3FILTER = PASS (the per-row function's early return), so only the touched rows go through Python
     upd = ["ALT", "FILTER", "Cell_types", "Bc", "Cc", "VAF", "MCF", "STEP3FILTER"]
-    newvals = pd.DataFrame(res, columns=upd, index=df.index)
-    for c in upd:
-        df[c] = newvals[c]
+    df["STEP3FILTER"] = "PASS"
+    multi = (df["FILTER"].astype(str).str.contains("Multi-allelic", regex=False) | df["ALT"].astype(str).str.contains("|", regex=False)).to_numpy()
+    if multi.any():
+        sub = df[multi]
+        res = [_multiallelic(r) for r in _records(sub, ("ALT", "FILTER", "Cell_types", "Bc", "Cc", "VAF", "MCF", "REF", "Dp", "Nc", "Cancer", "Non-Cancer"))]
+        newvals = pd.DataFrame(res, columns=upd, index=sub.index)
+        for c in upd:
+            col = df[c].astype(object)
+            col[multi] = newvals[c].astype(object)
+            df[c] = col
     df["INDEX"] = df["#CHROM"].astype(str) + ":" + df["Start"].astype(str) + ":" + df["ALT"].str.split(",", n=1, expand=True)[0]
     chrm = df[df["#CHROM"] == "chrM"].copy()
     df = df[df["#CHROM"] != "chrM"]
