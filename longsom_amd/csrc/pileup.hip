@@ -919,7 +919,11 @@ __device__ __forceinline__ void emit_unit(const CountArgs& a, const CNT& acc, ui
     for (int q = 0; q < ROW_QUADS; ++q) {
         u32x4 v; v.x = plane(4 * q); v.y = plane(4 * q + 1); v.z = plane(4 * q + 2); v.w = plane(4 * q + 3);
         __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)off16, q * 1024, 0);
-        __builtin_amdgcn_sched_barrier(0);                             // one quad's values live at a time (counters read from LDS stay there until needed)
+        // gfx950 reads the data registers of a 128-bit buffer store late; the compiler guards that with wait states only when the
+        // store has no SGPR offset, and reuses the registers for the next quad at once.  Measured without the s_nop: word 0 of a quad
+        // took the next quad's value in ~1e-4 of the rows (tools/row_diff.py).  The barrier keeps the next quad's moves behind the nop.
+        asm volatile("s_nop 3");
+        __builtin_amdgcn_sched_barrier(0);                             // also: one quad's values live at a time (counters read from LDS stay there until needed)
     }
 }
 

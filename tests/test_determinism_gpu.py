@@ -1,0 +1,31 @@
+"""GPU: counting the same resident reads twice gives the same rows, word for word, on a sample large enough to load the whole
+chip (several million rows).  Parity against the oracle is checked on samples the CPU finishes in seconds; a timing-dependent fault
+— this test exists because of one: 128-bit buffer stores whose data registers were reused too early on gfx950 corrupted ~1e-4 of the
+rows under load and nothing else noticed — only shows at scale, where run-to-run identity is the property that can be checked."""
+import numpy as np
+import pytest
+
+from longsom_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_two_counts_of_the_same_reads_are_identical(engine):
+    m = synth.named("C4", n_reads=2_500_000)
+    engine.set_contigs(m.contig_len); engine.synth_reference(m.seed); engine.set_barcodes(m.celltype_of, 2)
+    engine.set_region()
+    engine.synth_reads(m)
+    ref = None
+    for it in range(3):
+        rows, cols = engine.pileup_count()
+        n_sites, n_cand = engine.call_step1()
+        got = [engine.fetch_counts(ct) for ct in range(2)]
+        if ref is None:
+            ref = (rows, cols, n_sites, n_cand, got)
+            assert sum(rows) > 5_000_000
+            continue
+        assert (rows, cols, n_sites, n_cand) == ref[:4]
+        for ct in range(2):
+            assert np.array_equal(got[ct][0], ref[4][ct][0])
+            bad = np.nonzero((got[ct][2] != ref[4][ct][2]).any(axis=1))[0]
+            assert len(bad) == 0, "cell type %d: %d rows differ between two counts, first at key %d" % (ct, len(bad), int(got[ct][0][bad[0]]))
