@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void k_wide(const T* p, uint64_t n_elems, uint
     for (uint64_t i = 0; i < per_wave; i += U) {
         T v[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) v[u] = p[((wave * per_wave + i + u) * 64 + lane) % n_elems];
+        for (int u = 0; u < U; ++u) v[u] = p[(wave * per_wave + i + u) * 64 + lane];      // stays inside the buffer: checked on the host
 #pragma unroll
         for (int u = 0; u < U; ++u) acc += ((const uint32_t*)&v[u])[0];
     }
@@ -50,6 +50,8 @@ template <int U, typename T>
 static void run_wide(const void* buf, uint64_t bytes, uint32_t* out, int waves_per_simd) {
     const unsigned blocks = 256u * (unsigned)waves_per_simd;
     const uint64_t per_wave = 4096 * 2 / sizeof(T) * 2;              // same bytes per wave as the line test x 2
+    const double total = (double)blocks * 4 * per_wave * 64 * sizeof(T);
+    if (total > (double)bytes) { printf("buffer too small for the %zu-byte test\n", sizeof(T)); return; }
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     float best = 1e30f;
     for (int rep = 0; rep < 3; ++rep) {
@@ -60,7 +62,6 @@ static void run_wide(const void* buf, uint64_t bytes, uint32_t* out, int waves_p
         float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
         if (ms < best) best = ms;
     }
-    const double total = (double)blocks * 4 * per_wave * 64 * sizeof(T);
     printf("sequential %2zu B/lane U=%2d waves/SIMD=%d  %.2f ms  %.0f GB/s\n", sizeof(T), U, waves_per_simd, best, total / best / 1e6);
 }
 
