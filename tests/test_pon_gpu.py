@@ -44,3 +44,19 @@ def test_fused_panel_equals_the_table_route(engine, tmp_path):
     pon.build_from_files(str(lst), str(by_files2), 2, "Yes")
     assert body(by_files2) == body(lean.pon)
     assert 0 < lean.n_sites < out.n_sites
+
+    # the rule file's command line (workflow/rules/PoN.gpu.smk): a process of its own, parameters from flags
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tsv = tmp_path / "normals.tsv"
+    tsv.write_text("".join("%s\t%s\t%s\n" % n for n in normals))
+    p = pipeline.pon_params()
+    subprocess.check_call([sys.executable, os.path.join(root, "workflow", "scripts_gpu", "PoN", "longsom_gpu_pon.py"), "--normals", str(tsv), "--ref", ref,
+                           "--outdir", str(tmp_path / "cli"), "--alpha1", repr(p.alpha1), "--beta1", repr(p.beta1), "--alpha2", repr(p.alpha2),
+                           "--beta2", repr(p.beta2), "--no_tables"], cwd=root, stdout=subprocess.DEVNULL)
+    assert body(tmp_path / "cli" / "PoN" / "PoN" / "PoN_LR.tsv") == rows
+    # ... and the datamash-free PoN.py with the reference's flags
+    subprocess.check_call([sys.executable, os.path.join(root, "workflow", "scripts_gpu", "PoN", "PoN.py"), "--in_tsv", str(lst), "--out_file",
+                           str(tmp_path / "PoN.shim.tsv"), "--min_samples", "1", "--rm_prefix", "No"], cwd=root, stdout=subprocess.DEVNULL)
+    assert body(tmp_path / "PoN.shim.tsv") == rows
