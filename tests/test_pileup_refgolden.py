@@ -1,0 +1,159 @@
+"""The pileup half against files WRITTEN BY THE REFERENCE'S OWN CODE (tools/make_pileup_goldens.py ran
+SplitBamCellTypes.py and BaseCellCounter.py from /root/reference over column-replay stand-ins for pysam / pybedtools
+and committed their outputs under tests/golden/pileup.*).  What these fixtures pin: meta_to_dict and split_bam's routing
+and report (a1, a2), MakeWindows / position 0 / the 50 001 window edge (a3), EasyReadPileup's symbol mapping (a6), the
+counting loop (a7), the gates and the row text (a8), temp files and the file order chr1, chr10, chr2, chrM (a9).  Only the
+CIGAR -> column step (a4-a5: htslib / pysam, absent from the reference tree) stays hand-derived; it is stated three times
+independently (tools/minipysam.py, oracle/plp_oracle.c, csrc/hostio/bamio.cpp) and all three must agree here.
+
+CPU (not gpu): both C oracles and the decoder reproduce the reference's bytes.  GPU: the HIP path does."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from longsom_amd import bamwrite, hostio, tsvio
+from longsom_amd._lib import CountParams
+from oracle import loader
+from tests import kat_pileup_cases as K
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+KAT = json.load(open(os.path.join(G, "pileup.kat.json")))
+DATE = "##fileDate=x\n"
+
+
+def no_date(text):
+    return "".join(l for l in text.splitlines(True) if not l.startswith("##fileDate="))
+
+
+def table(keys, refs, counts, names, sample_id):
+    """the product's text form of one cell type's rows, minus the date line; None when there is no row (the reference then
+    writes no file at all: 'No temporary files found', BaseCellCounter.py:76-79)"""
+    if len(keys) == 0:
+        return None
+    return no_date(tsvio.format_counts_tsv(keys, refs, counts, names, sample_id, DATE))
+
+
+def report_text(rep):
+    keys = ["Total_reads", "Pass_reads", "CB_not_found", "CB_not_matched"] + (["MAPQ"] if "MAPQ" in rep else [])
+    return "\t".join(keys) + "\n" + "\t".join(str(rep[k]) for k in keys) + "\n"
+
+
+# ---- known-answer cases: reference-written tables == hand-derived expectations == oracles ------------------------
+KREF = np.frombuffer(K.REF.encode(), dtype=np.uint8)
+KBC = [b for b, _ in K.BARCODES]
+KCT = np.array([0 if t == "Cancer" else 1 for _, t in K.BARCODES], np.uint8)
+
+
+def kat_bam(tmp_path, name):
+    p = str(tmp_path / (name + ".bam"))
+    bamwrite.write_bam(p, [K.CONTIG], sorted(K.CASES[name]["reads"], key=lambda r: r["pos"]))
+    return p
+
+
+@pytest.mark.parametrize("name", sorted(K.CASES))
+def test_reference_tables_equal_hand_derived_rows(name):
+    """the reference's own code, fed the columns of the known-answer records, prints what was worked out by hand"""
+    for ct, key in (("Cancer", "cancer"), ("Non-Cancer", "noncancer")):
+        want = K.expected_rows(K.CASES[name].get(key, {}))
+        text = KAT[name]["tables"].get(ct)
+        got = {}
+        for line in (text or "").split("\n"):
+            if line and not line.startswith("#"):
+                f = line.split("\t")
+                dp, nc, cc, bc, bq, bcf, bcr = f[4].split("|")
+                row = [int(dp), int(nc)] + [int(x) for v in (cc, bc, bq, bcf, bcr) for x in v.split(":")]
+                got[int(f[1]) - 1] = row
+        assert sorted(got) == sorted(want)
+        for pos, row in want.items():
+            assert got[pos] == [row[i] for i in K.PRINTED], (name, ct, pos + 1)
+
+
+@pytest.mark.parametrize("name", sorted(K.CASES))
+def test_oracles_write_the_reference_tables_kat(tmp_path, name):
+    bam = kat_bam(tmp_path, name)
+    p = KAT[name]["params"]
+    dec = hostio.decode_bam(bam, KBC, min_mapq=p["min_mq"])
+    assert report_text(dec.report) == KAT[name]["report"]
+    for ct, cname in enumerate(("Cancer", "Non-Cancer")):
+        want = KAT[name]["tables"].get(cname)
+        k, r, c = loader.plp_count(bam, KBC, KCT, ct, [K.CONTIG[1]], [KREF], **p)
+        assert table(k, r, c, [K.CONTIG[0]], "kat." + cname) == want, "plp_oracle"
+        k, r, c, _ = loader.count(dec.records, [K.CONTIG[1]], [KREF], KCT, ct, p["min_bq"], p["min_mq"], p["min_dp"], p["min_cc"])
+        assert table(k, r, c, [K.CONTIG[0]], "kat." + cname) == want, "decoder + count_oracle"
+
+
+# ---- random multi-contig sample --------------------------------------------------------------------------------
+def rand_inputs(tag):
+    bc = hostio.read_barcodes(os.path.join(G, "pileup.%s.barcodes.tsv" % tag))
+    names, seqs = tsvio.read_fasta(os.path.join(G, "pileup.rand.fa"))
+    refs = [np.frombuffer(s.encode() if isinstance(s, str) else bytes(s), dtype=np.uint8) for s in seqs]
+    return bc, names, refs
+
+
+@pytest.mark.parametrize("tag", ["rand", "randsfx"])
+def test_oracles_write_the_reference_tables_rand(tag):
+    bc, names, refs = rand_inputs(tag)
+    assert bc.celltype_names == ["Cancer", "Non-Cancer"]
+    bam = os.path.join(G, "pileup.%s.bam" % tag)
+    dec = hostio.decode_bam(bam, bc.barcodes, min_mapq=60)
+    assert dec.contig_names == names == ["chr1", "chr10", "chr2", "chrM"]
+    assert report_text(dec.report) == open(os.path.join(G, "pileup.%s.report.txt" % tag)).read()
+    lens = [len(r) for r in refs]
+    for ct, cname in enumerate(bc.celltype_names):
+        want = open(os.path.join(G, "pileup.%s.%s.tsv" % (tag, cname))).read()
+        k, r, c = loader.plp_count(bam, bc.barcodes, bc.celltype_of, ct, lens, refs)
+        assert table(k, r, c, names, "s." + cname) == want, "plp_oracle"
+        k, r, c, _ = loader.count(dec.records, lens, refs, bc.celltype_of, ct)
+        assert table(k, r, c, names, "s." + cname) == want, "decoder + count_oracle"
+    # the fixture does what it was built for
+    text = open(os.path.join(G, "pileup.%s.Cancer.tsv" % tag)).read()
+    chroms = [l.split("\t")[0] for l in text.split("\n") if l and not l.startswith("#")]
+    assert sorted(set(chroms), key=chroms.index) == ["chr1", "chr10", "chr2", "chrM"]             # python string order of the windows
+    pos1 = {int(l.split("\t")[1]) for l in text.split("\n") if l.startswith("chr1\t")}
+    assert {50000, 50001, 50002} <= pos1 and 1 not in pos1 and 2 in pos1                              # window edge, position 0 skipped
+
+
+# ---- GPU ------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(K.CASES))
+def test_gpu_writes_the_reference_tables_kat(tmp_path, engine, name):
+    p = KAT[name]["params"]
+    dec = hostio.decode_bam(kat_bam(tmp_path, name), KBC, min_mapq=p["min_mq"])
+    engine.set_contigs([K.CONTIG[1]]); engine.load_reference(0, KREF); engine.set_barcodes(KCT, 2); engine.set_region()
+    engine.load_reads(dec.records)
+    engine.pileup_count(CountParams.longsom_defaults(**p))
+    for ct, cname in enumerate(("Cancer", "Non-Cancer")):
+        k, r, c = engine.fetch_counts(ct)
+        assert table(k, r, c, [K.CONTIG[0]], "kat." + cname) == KAT[name]["tables"].get(cname)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["rand", "randsfx"])
+def test_gpu_writes_the_reference_tables_rand(engine, tag):
+    bc, names, refs = rand_inputs(tag)
+    dec = hostio.decode_bam(os.path.join(G, "pileup.%s.bam" % tag), bc.barcodes, min_mapq=60)
+    engine.set_contigs([len(r) for r in refs])
+    for t, r in enumerate(refs):
+        engine.load_reference(t, r)
+    engine.set_barcodes(bc.celltype_of, 2); engine.set_region()
+    engine.load_reads(dec.records)
+    engine.pileup_count(CountParams.longsom_defaults())
+    for ct, cname in enumerate(bc.celltype_names):
+        k, r, c = engine.fetch_counts(ct)
+        assert table(k, r, c, names, "s." + cname) == open(os.path.join(G, "pileup.%s.%s.tsv" % (tag, cname))).read()
+
+
+@pytest.mark.gpu
+def test_gpu_pipeline_files_equal_reference_chain(tmp_path):
+    """the fused rule (BAM + barcodes.tsv + FASTA in) writes the SplitBam report and the per-cell-type tables the reference chain wrote"""
+    from longsom_amd import pipeline
+    out = pipeline.run_snv(os.path.join(G, "pileup.rand.bam"), os.path.join(G, "pileup.rand.barcodes.tsv"), os.path.join(G, "pileup.rand.fa"),
+                           str(tmp_path), "s")
+    for cname in ("Cancer", "Non-Cancer"):
+        assert no_date(open(out.counts[cname]).read()) == open(os.path.join(G, "pileup.rand.%s.tsv" % cname)).read()
+    rep = open(out.report).read().split("\n")
+    want = open(os.path.join(G, "pileup.rand.report.txt")).read().split("\n")
+    h, r = rep[0].split("\t"), rep[1].split("\t")
+    assert h[-1] == "Total_time" and "\t".join(h[:-1]) == want[0] and "\t".join(r[:-1]) == want[1]

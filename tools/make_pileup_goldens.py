@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""Pileup-stage goldens: RUN the reference's own SplitBamCellTypes.py and BaseCellCounter.py (unmodified, imported from
+/root/reference, no bytecode written) on small BAMs and commit what they write.  Runs only in the build container.
+
+pysam / pybedtools are not installed: tools/minipysam.py provides column-replay stand-ins (its header says exactly which
+third-party semantics it restates: SURVEY §8a rows a4-a5 — the CIGAR -> column step — stay hand-derived; everything the
+reference itself does with a column is the reference's code: EasyReadPileup, the counting loop and gates, the row text,
+the window temp files and their concatenation order, meta_to_dict, split_bam's routing and report).
+
+Writes under tests/golden/:
+  pileup.kat.json              per known-answer case (tests/kat_pileup_cases.py): the two per-cell-type tables and the
+                               SplitBam report exactly as the reference wrote them (null = the reference wrote no file)
+  pileup.rand.bam/.fa/.barcodes.tsv   a seeded random multi-contig sample (chr1 crosses the 50 001 window edge; contigs
+                               chr1, chr10, chr2, chrM for the file order; every CIGAR op, N / IUPAC bases, low qualities,
+                               all flags, MAPQ 0-60, CB missing / unknown / with "-1")
+  pileup.rand.<celltype>.tsv, pileup.rand.report.txt      what the reference chain wrote for it
+  pileup.randsfx.*             the same reads with "-1"-suffixed CB tags and barcodes.tsv entries
+  pileup.cap.*                 a small deep pile counted with max_depth = 8 (reference's pileup call patched ONLY in that
+                               one keyword through the stand-in, see run_counter(max_depth=...))
+"""
+import contextlib
+import importlib.util
+import io
+import json
+import os
+import shutil
+import sys
+import tempfile
+
+import numpy as np
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+REF = "/root/reference/workflow/scripts"
+OUT = os.path.join(ROOT, "tests", "golden")
+
+import minipysam  # noqa: E402
+from longsom_amd import bamwrite  # noqa: E402
+from tests import kat_pileup_cases as K  # noqa: E402
+
+
+def load(relpath, name):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, relpath))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def write_fasta(path, seqs):
+    with open(path, "w") as f:
+        for k, v in seqs.items():
+            f.write(">%s\n" % k)
+            for i in range(0, len(v), 60):
+                f.write(v[i:i + 60] + "\n")
+
+
+def run_chain(split, counter, bam, barcodes_tsv, fasta, sample, work, min_mq=60, extra=(), max_depth=None):
+    """SplitBamCellTypes.split_bam then BaseCellCounter.main per cell type, as rules/SNVCalling.smk runs them.
+    Returns ({celltype: table text or None}, report text)."""
+    sdir = os.path.join(work, "SplitBam"); os.makedirs(sdir)
+    with contextlib.redirect_stdout(io.StringIO()):
+        split.split_bam(bam, barcodes_tsv, sdir, sample, None, None, None, min_mq, 0)
+    report = open(os.path.join(sdir, sample + ".report.txt")).read()
+    tables = {}
+    cts = sorted(f[len(sample) + 1:-4] for f in os.listdir(sdir) if f.endswith(".bam"))
+    for ct in cts:
+        odir = os.path.join(work, "BaseCellCounter", ct); os.makedirs(odir)
+        tmp = os.path.join(odir, "temp")
+        argv = ["BaseCellCounter.py", "--bam", os.path.join(sdir, "%s.%s.bam" % (sample, ct)), "--ref", fasta, "--chrom", "all",
+                "--out_folder", odir, "--nprocs", "1", "--min_mq", str(min_mq), "--tmp_dir", tmp] + list(extra)
+        old_argv, old_pileup = sys.argv, minipysam.AlignmentFile.pileup
+        if max_depth is not None:          # the reference hard-codes max_depth = 200000 (BaseCellCounter.py:191): the cap fixture lowers it
+            def capped(self, *a, **k):
+                k["max_depth"] = max_depth
+                return old_pileup(self, *a, **k)
+            minipysam.AlignmentFile.pileup = capped
+        try:
+            sys.argv = argv
+            with contextlib.redirect_stdout(io.StringIO()):
+                counter.main()
+        finally:
+            sys.argv = old_argv
+            minipysam.AlignmentFile.pileup = old_pileup
+        p = os.path.join(odir, "%s.%s.tsv" % (sample, ct))
+        tables[ct] = open(p).read() if os.path.exists(p) else None
+    return tables, report
+
+
+def strip_report(text):
+    """drop the wall-clock Total_time column"""
+    head, row = text.rstrip("\n").split("\n")
+    h, r = head.split("\t"), row.split("\t")
+    keep = [i for i, n in enumerate(h) if n != "Total_time"]
+    return "\t".join(h[i] for i in keep) + "\n" + "\t".join(r[i] for i in keep) + "\n"
+
+
+def strip_date(text):
+    return None if text is None else "".join(l for l in text.splitlines(True) if not l.startswith("##fileDate="))
+
+
+# ---- random sample ----------------------------------------------------------------------------------
+def random_reads(rng, contigs, seqs, barcodes, n_clusters=9, per_cluster=34):
+    reads = []
+    bases = "ACGT"
+    for tid, (name, length) in enumerate(contigs):
+        centres = [int(c) for c in rng.integers(200, max(201, length - 400), size=n_clusters)]
+        if name == "chr1":
+            centres += [0, 49_960, 49_990, length - 160]
+        if name == "chrM":
+            centres += [0, length - 120]
+        for c in centres:
+            for _ in range(per_cluster):
+                pos = max(0, c + int(rng.integers(-30, 40)))
+                # CIGAR: leading clips, then M/=/X blocks separated by I / D / N / P, trailing clips
+                ops, ref_len, q_len = [], 0, 0
+                if rng.random() < 0.15: ops.append(("H", int(rng.integers(1, 5))))
+                if rng.random() < 0.25: l = int(rng.integers(1, 7)); ops.append(("S", l)); q_len += l
+                n_blocks = int(rng.integers(1, 5))
+                for b in range(n_blocks):
+                    l = int(rng.integers(1, 45)); op = "M" if rng.random() < 0.8 else ("=" if rng.random() < 0.5 else "X")
+                    ops.append((op, l)); ref_len += l; q_len += l
+                    if b + 1 < n_blocks:
+                        r = rng.random()
+                        if r < 0.25: l = int(rng.integers(1, 4)); ops.append(("I", l)); q_len += l
+                        elif r < 0.5: l = int(rng.integers(1, 5)); ops.append(("D", l)); ref_len += l
+                        elif r < 0.62: l = int(rng.integers(5, 60)); ops.append(("N", l)); ref_len += l
+                        elif r < 0.70: ops.append(("D", 1)); ops.append(("D", 2)); ref_len += 3
+                        elif r < 0.78: ops.append(("P", 1)); l = int(rng.integers(1, 3)); ops.append(("I", l)); q_len += l
+                        elif r < 0.84: ops.append(("D", 2)); ops.append(("I", 1)); ref_len += 2; q_len += 1
+                        elif r < 0.90: ops.append(("I", 1)); ops.append(("D", 2)); ref_len += 2; q_len += 1
+                        elif r < 0.95: ops.append(("N", int(rng.integers(5, 30)))); ops.append(("I", 1)); ref_len += ops[-2][1]; q_len += 1
+                        # else: two match blocks back to back (e.g. 5M3X)
+                if rng.random() < 0.25: l = int(rng.integers(1, 7)); ops.append(("S", l)); q_len += l
+                if pos + ref_len > length:
+                    continue
+                # sequence: mostly the reference with mismatches, a few N and IUPAC letters
+                seq, x = [], pos
+                for op, l in ops:
+                    if op in "M=X":
+                        for j in range(l):
+                            r = rng.random(); rb = seqs[name][x + j].upper()
+                            seq.append(rb if (r < 0.9 and rb in bases) else (bases[int(rng.integers(0, 4))] if r < 0.97 else ("N" if r < 0.985 else "RYKM"[int(rng.integers(0, 4))])))
+                        x += l
+                    elif op in "DN":
+                        x += l
+                    elif op in "IS":
+                        seq += [bases[int(rng.integers(0, 4))] for _ in range(l)]
+                qual = [int(rng.integers(20, 61)) if rng.random() < 0.88 else int(rng.integers(2, 20)) for _ in range(q_len)]
+                r = rng.random()
+                flag = 0x10 if rng.random() < 0.5 else 0
+                if r < 0.03: flag |= 0x800
+                elif r < 0.05: flag |= 0x100
+                elif r < 0.065: flag |= 0x400
+                elif r < 0.075: flag |= 0x200
+                elif r < 0.085: flag |= 0x1
+                elif r < 0.10: flag |= 0x3
+                mapq = 60 if rng.random() < 0.9 else int(rng.integers(0, 60))
+                r = rng.random()
+                cb = None if r < 0.03 else ("ZZTOP" if r < 0.06 else barcodes[int(rng.integers(0, len(barcodes)))])
+                reads.append(dict(tid=tid, pos=pos, cigar="".join("%d%s" % (l, op) for op, l in ops), seq="".join(seq), qual=qual, flag=flag, mapq=mapq,
+                                  tags={} if cb is None else {"CB": cb}, name="q%d" % len(reads)))
+    reads.sort(key=lambda r: (r["tid"], r["pos"]))
+    return reads
+
+
+def main():
+    minipysam.install()
+    split = load("PreProcessing/SplitBamCellTypes.py", "ref_splitbam")
+    counter = load("SNVCalling/BaseCellCounter.py", "ref_counter")
+    os.makedirs(OUT, exist_ok=True)
+    work = tempfile.mkdtemp(prefix="plpgold_")
+    try:
+        # ---- 1. the known-answer cases through the reference's code
+        kdir = os.path.join(work, "kat"); os.makedirs(kdir)
+        fa = os.path.join(kdir, "chrK.fa"); write_fasta(fa, {K.CONTIG[0]: K.REF})
+        bc = os.path.join(kdir, "barcodes.tsv")
+        with open(bc, "w") as f:
+            f.write("Index\tCell_type\n" + "".join("%s\t%s\n" % b for b in K.BARCODES))
+        kat = {}
+        for name, case in sorted(K.CASES.items()):
+            bam = os.path.join(kdir, name + ".bam")
+            bamwrite.write_bam(bam, [K.CONTIG], sorted(case["reads"], key=lambda r: r["pos"]))
+            p = case["params"]
+            extra = ["--min_dp", str(p["min_dp"]), "--min_cc", str(p["min_cc"]), "--min_bq", str(p["min_bq"])]
+            tables, report = run_chain(split, counter, bam, bc, fa, "kat", os.path.join(kdir, name), p["min_mq"], extra)
+            kat[name] = {"params": p, "report": strip_report(report), "tables": {ct: strip_date(t) for ct, t in tables.items()}}
+        json.dump(kat, open(os.path.join(OUT, "pileup.kat.json"), "w"), indent=1, sort_keys=True)
+
+        # ---- 2. the random multi-contig sample (and its "-1" suffix twin)
+        rng = np.random.default_rng(20251004)
+        contigs = [("chr1", 60_000), ("chr10", 2_400), ("chr2", 3_000), ("chrM", 1_800)]
+        seqs = {}
+        for name, length in contigs:
+            s = rng.choice(list("ACGT"), size=length)
+            for _ in range(length // 300):
+                p = int(rng.integers(0, length - 4)); s[p:p + int(rng.integers(1, 4))] = "N"
+            s = "".join(s)
+            seqs[name] = "".join(ch.lower() if (i // 97) % 5 == 0 else ch for i, ch in enumerate(s))      # soft-masked stretches: the reference upper-cases
+        cells = ["AAAC%04dGG" % i for i in range(14)] + ["TTTG%04dCC" % i for i in range(11)]
+        types = ["Cancer"] * 14 + ["Non-Cancer"] * 11
+        reads = random_reads(rng, contigs, seqs, cells)
+        for tag, sfx in (("rand", ""), ("randsfx", "-1")):
+            rs = [dict(r, tags={k: v + sfx for k, v in r["tags"].items()}) for r in reads]
+            bam = os.path.join(OUT, "pileup.%s.bam" % tag)
+            bamwrite.write_bam(bam, contigs, rs)
+            fa = os.path.join(OUT, "pileup.rand.fa"); write_fasta(fa, seqs)
+            bc = os.path.join(OUT, "pileup.%s.barcodes.tsv" % tag)
+            with open(bc, "w") as f:
+                f.write("Index\tCell_type\n" + "".join("%s%s\t%s\n" % (c, sfx, t) for c, t in zip(cells, types)))
+                f.write("%s%s\t%s\n" % (cells[3], sfx, "Non-Cancer"))          # a duplicated barcode: the last row wins (to_dict)
+            tables, report = run_chain(split, counter, bam, bc, fa, "s", os.path.join(work, tag))
+            for ct, t in tables.items():
+                open(os.path.join(OUT, "pileup.%s.%s.tsv" % (tag, ct)), "w").write(strip_date(t))
+            open(os.path.join(OUT, "pileup.%s.report.txt" % tag), "w").write(strip_report(report))
+            print(tag, {ct: (t.count("\n") - 8 if t else None) for ct, t in tables.items()}, strip_report(report).split("\n")[1])
+
+        # ---- 3. depth cap: 30 reads on one spot, max_depth = 8
+        cap_reads = []
+        for i in range(40):
+            pos = 100 + (i // 4)                       # four reads start at every position 100..109
+            cap_reads.append(dict(tid=0, pos=pos, cigar="30M", seq=seqs["chr2"][pos:pos + 30].upper().replace("N", "A"), qual=[30] * 30, flag=0x10 if i % 3 == 0 else 0,
+                                  mapq=60, tags={"CB": cells[i % 14]}, name="c%d" % i))
+        bam = os.path.join(OUT, "pileup.cap.bam")
+        bamwrite.write_bam(bam, contigs, cap_reads)
+        bc = os.path.join(OUT, "pileup.rand.barcodes.tsv")
+        tables, report = run_chain(split, counter, bam, bc, os.path.join(OUT, "pileup.rand.fa"), "s", os.path.join(work, "cap"), max_depth=8)
+        open(os.path.join(OUT, "pileup.cap.Cancer.tsv"), "w").write(strip_date(tables["Cancer"]))
+        tables_u, _ = run_chain(split, counter, bam, bc, os.path.join(OUT, "pileup.rand.fa"), "s", os.path.join(work, "cap_u"))
+        open(os.path.join(OUT, "pileup.capoff.Cancer.tsv"), "w").write(strip_date(tables_u["Cancer"]))
+        print("cap rows", tables["Cancer"].count("\n") - 9, "uncapped", tables_u["Cancer"].count("\n") - 9)
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()
