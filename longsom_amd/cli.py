@@ -109,7 +109,8 @@ def calling_step1(argv=None):
 
 def calling_step2(argv=None):
     """BaseCellCalling.step2.py --infile --outfile --editing --pon_SR --pon_LR --gnomAD_db --gnomAD_max --min_distance  (step2.py:237-248).
-    --gnomAD_db: a JSON {"chrom:pos:ref:alt": AF} (the gnomAD sqlite is not part of this repository); anything else = AF 0."""
+    --gnomAD_db: the gnomad_db directory the reference's rule passes (read with sqlite3) or a JSON {"chrom:pos:ref:alt": AF};
+    a source that cannot be used switches the filter off WITH a warning on stderr."""
     ap = argparse.ArgumentParser(description="Position-set / distance / gnomAD tags")
     ap.add_argument("--infile", required=True); ap.add_argument("--outfile", required=True); ap.add_argument("--editing")
     ap.add_argument("--pon_SR", required=True); ap.add_argument("--pon_LR", nargs="?", const="", default="")
@@ -118,7 +119,7 @@ def calling_step2(argv=None):
     a = ap.parse_args(argv)
     text = open(a.infile).read()
     contigs = tsvio.contigs_of_tsv([a.infile])
-    af = json.load(open(a.gnomAD_db)) if a.gnomAD_db and a.gnomAD_db.endswith(".json") and os.path.exists(a.gnomAD_db) else None
+    af = calling.open_gnomad(a.gnomAD_db)               # JSON table, gnomad_db directory / sqlite; unusable -> warning, filter off
     keys = [calling.read_posset_keys(p, contigs, a.reference_gz_compat) for p in (a.editing, a.pon_SR, a.pon_LR)]
     with Engine(a.device) as eng:
         out = calling.step2(text, eng, contigs, keys[0], keys[1], keys[2], a.min_distance, af, a.gnomAD_max)
@@ -191,22 +192,34 @@ def celltype_reannotation(argv=None):
     reanno.celltype_reannotation(a.SNVs, a.fusions, a.meta, a.outfile, a.min_variants, a.min_frac)
 
 
+def _optional_paths(ap, *flags):
+    """File options a rule may render with an EMPTY value (`--pon_LR {input.pon_LR}` when Run.PoN is False, the reference's
+    default config): like the reference's own `--pon_LR` (step2.py:245, nargs='?'), a bare flag means "no file"."""
+    for f in flags:
+        ap.add_argument(f, nargs="?", const="", default="")
+
+
+def _add_dataclass_flags(ap, obj, prefix=""):
+    for k, v in vars(obj).items():
+        if isinstance(v, bool):
+            ap.add_argument("--" + prefix + k, action="store_true")
+        elif isinstance(v, (int, float, str)):
+            ap.add_argument("--" + prefix + k, type=type(v), default=v)
+
+
 def snv(argv=None):
     """Fused chain: one process from BAM to calling.step3.tsv (workflow/rules/SNVCalling.gpu.smk)."""
     ap = argparse.ArgumentParser(description="SplitBam -> BaseCellCounter -> MergeCounts -> BaseCellCalling step1-3 on one GPU")
     ap.add_argument("--bam", required=True); ap.add_argument("--meta", required=True); ap.add_argument("--ref", required=True)
     ap.add_argument("--id", required=True); ap.add_argument("--outdir", required=True)
-    ap.add_argument("--editing"); ap.add_argument("--pon_SR"); ap.add_argument("--pon_LR"); ap.add_argument("--gnomAD_json")
+    _optional_paths(ap, "--editing", "--pon_SR", "--pon_LR", "--gnomAD_json", "--gnomAD_db")
     ap.add_argument("--device", type=int, default=0)
     d = pipeline.SnvParams()
-    for k, v in vars(d).items():
-        if isinstance(v, bool):
-            ap.add_argument("--" + k, action="store_true")
-        else:
-            ap.add_argument("--" + k, type=type(v), default=v)
+    _add_dataclass_flags(ap, d)
     a = ap.parse_args(argv)
     params = pipeline.SnvParams(**{k: getattr(a, k) for k in vars(d)})
-    out = pipeline.run_snv(a.bam, a.meta, a.ref, a.outdir, a.id, params, a.editing, a.pon_SR, a.pon_LR, a.gnomAD_json, a.device)
+    out = pipeline.run_snv(a.bam, a.meta, a.ref, a.outdir, a.id, params, a.editing or None, a.pon_SR or None, a.pon_LR or None,
+                           a.gnomAD_json or a.gnomAD_db or None, a.device)
     print(json.dumps({"outputs": {k: v for k, v in vars(out).items() if k != "timings"}, "seconds": out.timings}))
 
 
@@ -215,12 +228,19 @@ def reannotation(argv=None):
     once (workflow/rules/CellTypeReannotation.gpu.smk)."""
     ap = argparse.ArgumentParser(description="CellTypeReannotation + SNVCalling of LongSom on one GPU, reads resident across both passes")
     ap.add_argument("--bam", required=True); ap.add_argument("--meta", required=True); ap.add_argument("--ref", required=True)
-    ap.add_argument("--id", required=True); ap.add_argument("--outdir", required=True); ap.add_argument("--fusions")
-    ap.add_argument("--editing"); ap.add_argument("--pon_SR"); ap.add_argument("--pon_LR"); ap.add_argument("--gnomAD_json")
+    ap.add_argument("--id", required=True); ap.add_argument("--outdir", required=True)
+    _optional_paths(ap, "--fusions", "--editing", "--pon_SR", "--pon_LR", "--gnomAD_json", "--gnomAD_db")
     ap.add_argument("--device", type=int, default=0)
+    # config['Reanno'] (pass 1: --reanno_* for the HCCV / re-annotation block, --p1_* for its BaseCellCounter / BaseCellCalling
+    # block) and config['SNVCalling'] (pass 2: --p2_*); defaults = config/config.yaml
+    rp0, sp0 = pipeline.ReannoParams(), pipeline.SnvParams()
+    _add_dataclass_flags(ap, rp0, "reanno_"); _add_dataclass_flags(ap, rp0.chain, "p1_"); _add_dataclass_flags(ap, sp0, "p2_")
     a = ap.parse_args(argv)
-    out = pipeline.run_reannotation(a.bam, a.meta, a.ref, a.outdir, a.id, fusions_tsv=a.fusions, editing=a.editing, pon_sr=a.pon_SR, pon_lr=a.pon_LR,
-                                    gnomad_af_json=a.gnomAD_json, device=a.device)
+    chain = pipeline.SnvParams(**{k: getattr(a, "p1_" + k) for k in vars(rp0.chain)})
+    rp = pipeline.ReannoParams(chain=chain, **{k: getattr(a, "reanno_" + k) for k, v in vars(rp0).items() if k != "chain"})
+    sp = pipeline.SnvParams(**{k: getattr(a, "p2_" + k) for k in vars(sp0)})
+    out = pipeline.run_reannotation(a.bam, a.meta, a.ref, a.outdir, a.id, rp, sp, fusions_tsv=a.fusions or None, editing=a.editing or None,
+                                    pon_sr=a.pon_SR or None, pon_lr=a.pon_LR or None, gnomad_af_json=a.gnomAD_json or a.gnomAD_db or None, device=a.device)
     print(json.dumps({"hccv": out.hccv, "genotype": out.genotype, "barcodes": out.barcodes, "cells_kept": out.n_cells_kept, "cancer_cells": out.n_cancer,
                       "pass2_step3": out.pass2.step3 if out.pass2 else None, "seconds": out.timings}))
 

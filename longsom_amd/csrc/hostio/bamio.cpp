@@ -49,6 +49,14 @@ struct Local {   // per-thread decode output
 
 inline bool is_ref_op(uint32_t op) { return op == 0 || op == 2 || op == 3 || op == 7 || op == 8; }
 
+// A record's own length fields must stay inside its block_size: name + CIGAR + packed sequence + qualities.  Everything
+// that walks a record (decode_record, find_cb, the split writer) runs only on records that passed this test.
+inline bool record_ok(const uint8_t* rec, uint32_t len) {
+    if (len < 32) return false;
+    const uint64_t l_name = rec[8], n_cigar = rd16(rec + 12), l_seq = rd32(rec + 16);
+    return 32 + l_name + 4 * n_cigar + (l_seq + 1) / 2 + l_seq <= (uint64_t)len;
+}
+
 // CB:Z value of a record, cleaned like barcode.split("-")[0]; false when the tag is missing.
 bool find_cb(const uint8_t* rec, uint32_t len, const char** cb_out, size_t* len_out) {
     const uint32_t l_name = rec[8], n_cigar = rd16(rec + 12), l_seq = rd32(rec + 16);
@@ -63,7 +71,7 @@ bool find_cb(const uint8_t* rec, uint32_t len, const char** cb_out, size_t* len_
             case 's': case 'S': sz = 2; break;
             case 'i': case 'I': case 'f': sz = 4; break;
             case 'Z': case 'H': { const uint8_t* z = aux; while (z < end && *z) ++z; sz = (size_t)(z - aux) + 1;
-                                  if (t0 == 'C' && t1 == 'B' && ty == 'Z') {
+                                  if (t0 == 'C' && t1 == 'B' && ty == 'Z' && z < end) {
                                       size_t clean = 0; while (clean < sz - 1 && aux[clean] != '-') ++clean;
                                       *cb_out = (const char*)aux; *len_out = clean; return true;
                                   } break; }
@@ -71,6 +79,7 @@ bool find_cb(const uint8_t* rec, uint32_t len, const char** cb_out, size_t* len_
                         sz = 5 + (size_t)cnt * ((st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : 4); break; }
             default: return false;
         }
+        if (sz > (size_t)(end - aux)) return false;          // a field that claims more bytes than the record has
         aux += sz;
     }
     return false;
@@ -98,11 +107,12 @@ void decode_record(const uint8_t* rec, uint32_t len, const std::unordered_map<st
             case 's': case 'S': sz = 2; break;
             case 'i': case 'I': case 'f': sz = 4; break;
             case 'Z': case 'H': { const uint8_t* z = aux; while (z < end && *z) ++z; sz = (size_t)(z - aux) + 1;
-                                  if (t0 == 'C' && t1 == 'B' && ty == 'Z') { cb = (const char*)aux; cb_len = sz - 1; } break; }
+                                  if (t0 == 'C' && t1 == 'B' && ty == 'Z' && z < end) { cb = (const char*)aux; cb_len = sz - 1; } break; }
             case 'B': { if (aux + 5 > end) { aux = end; continue; } const char st = (char)aux[0]; const uint32_t cnt = rd32(aux + 1);
                         const size_t es = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : 4; sz = 5 + es * cnt; break; }
             default: aux = end; continue;
         }
+        if (sz > (size_t)(end - aux)) break;                  // a field that claims more bytes than the record has
         aux += sz;
     }
     if (!cb) { ++L.cb_not_found; return; }
@@ -199,56 +209,61 @@ void lsio_free_decoded(lsio_decoded* d) {
     free(d);
 }
 
-// barcodes: n_barcodes cleaned barcode strings joined by '\n'; ids[i] = dense id of barcode i.
-int lsio_decode_bam(const char* path, const char* barcodes, int32_t n_barcodes, const int32_t* ids, int32_t min_mapq, int32_t n_threads,
-                    lsio_decoded** out) {
-    if (!path || !out) { set_err("lsio_decode_bam: bad arguments"); return -2; }
-    *out = nullptr;
+// ---- streaming BAM reader ----------------------------------------------------------------------------------------------------
+// The compressed file is mapped, not copied; BGZF blocks are inflated a batch at a time (in parallel), records are cut out of the
+// batch and the bytes of a record that continues in the next batch are carried over.  Every length field read from the file is
+// checked against the bytes that are there before it is used (block sizes, header fields, record sizes, the fields inside a
+// record): a truncated or corrupt file ends in an error message, never in a read past a buffer.
+} // extern "C"
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+struct lsio_stream {
+    std::string path;
+    const uint8_t* file = nullptr; size_t fsize = 0; int fd = -1;
+    size_t off = 0;                       // next BGZF block
+    std::vector<uint8_t> tail;            // bytes of an incomplete record (or of the incomplete header) from the batches so far
+    bool header_done = false, eof = false;
+    std::string names; std::vector<int64_t> lens; uint32_t n_ref = 0;
+    std::vector<uint8_t> header_bytes;    // BAM magic .. end of the reference table (what a "wb" copy of the header writes)
     std::unordered_map<std::string, int32_t> cbmap;
-    cbmap.reserve((size_t)n_barcodes * 2 + 16);
-    {
-        const char* s = barcodes ? barcodes : "";
-        for (int32_t i = 0; i < n_barcodes; ++i) {
-            const char* e = strchr(s, '\n'); size_t l = e ? (size_t)(e - s) : strlen(s);
-            cbmap[std::string(s, l)] = ids ? ids[i] : i;                          // duplicates: last wins (to_dict, :31)
-            s += l + (e ? 1 : 0);
-        }
-    }
-    const bool timing = getenv("LSIO_TIMING") != nullptr;
-    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    double t_prev = now();
-    auto lap = [&](const char* what) { if (timing) { const double t = now(); fprintf(stderr, "[lsio_decode_bam] %-18s %.3f s\n", what, t - t_prev); t_prev = t; } };
-    FILE* f = fopen(path, "rb");
-    if (!f) { set_err("lsio_decode_bam: cannot open %s", path); return -1; }
-    fseek(f, 0, SEEK_END); const size_t fsize = (size_t)ftell(f); fseek(f, 0, SEEK_SET);
-    std::vector<uint8_t> file(fsize);
-    if (fsize && fread(file.data(), 1, fsize, f) != fsize) { fclose(f); set_err("lsio_decode_bam: short read on %s", path); return -1; }
-    fclose(f);
-    lap("read file");
-    // BGZF block table
+    bool auto_barcodes = false; std::string auto_joined; int32_t auto_n = 0; int64_t n_tally = 0;
+    int min_mapq = 0, n_threads = 1;
+    ~lsio_stream() { if (file && file != (const uint8_t*)MAP_FAILED && fsize) munmap((void*)file, fsize); if (fd >= 0) close(fd); }
+};
+
+namespace {
+// next batch of blocks: appends their uncompressed bytes to `data` (which starts with st.tail).  Returns -1 on a corrupt file.
+int inflate_batch(lsio_stream& st, size_t max_ubytes, std::vector<uint8_t>& data) {
     std::vector<Block> blocks;
-    size_t off = 0, utotal = 0;
-    while (off + 18 <= fsize) {
-        const uint8_t* h = file.data() + off;
-        if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) { set_err("lsio_decode_bam: %s is not BGZF (offset %zu)", path, off); return -1; }
+    size_t utotal = 0;
+    const size_t base = st.tail.size();
+    while (st.off < st.fsize && (utotal < max_ubytes || blocks.empty())) {
+        if (st.off + 18 > st.fsize) { set_err("%s: truncated BGZF block header at offset %zu", st.path.c_str(), st.off); return -1; }
+        const uint8_t* h = st.file + st.off;
+        if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) { set_err("%s is not BGZF (offset %zu)", st.path.c_str(), st.off); return -1; }
         const uint32_t xlen = rd16(h + 10);
+        if (st.off + 12 + (size_t)xlen > st.fsize) { set_err("%s: truncated BGZF extra field at offset %zu", st.path.c_str(), st.off); return -1; }
         uint32_t bsize = 0; bool found = false;
         for (uint32_t q = 0; q + 4 <= xlen;) {
             const uint8_t* sf = h + 12 + q; const uint32_t slen = rd16(sf + 2);
-            if (sf[0] == 'B' && sf[1] == 'C' && slen == 2) { bsize = rd16(sf + 4) + 1u; found = true; }
+            if (sf[0] == 'B' && sf[1] == 'C' && slen == 2 && q + 6 <= xlen) { bsize = rd16(sf + 4) + 1u; found = true; }
             q += 4 + slen;
         }
-        if (!found || off + bsize > fsize) { set_err("lsio_decode_bam: corrupt BGZF block at %zu", off); return -1; }
+        if (!found || bsize < xlen + 20u || st.off + bsize > st.fsize) { set_err("%s: corrupt BGZF block at offset %zu", st.path.c_str(), st.off); return -1; }
         const uint32_t usize = rd32(h + bsize - 4);
-        blocks.push_back(Block{off + 12 + xlen, bsize - xlen - 20, usize, utotal});
-        utotal += usize; off += bsize;
+        if (usize > 65536u) { set_err("%s: BGZF block at offset %zu claims %u uncompressed bytes", st.path.c_str(), st.off, usize); return -1; }
+        blocks.push_back(Block{st.off + 12 + xlen, bsize - xlen - 20, usize, base + utotal});
+        utotal += usize; st.off += bsize;
     }
-    if (n_threads <= 0) n_threads = (int)std::max(1u, std::thread::hardware_concurrency());
-    lap("block table");
-    // inflate in parallel (chunks of blocks; the whole stream is kept: sized for the host RAM of a GPU node)
-    std::vector<uint8_t> data(utotal + 8);
+    if (st.off >= st.fsize) st.eof = true;
+    data.resize(base + utotal + 8);
+    if (base) memcpy(data.data(), st.tail.data(), base);
+    st.tail.clear();
     std::atomic<size_t> next{0}; std::atomic<int> bad{0};
-    auto inflate_worker = [&]() {
+    auto worker = [&]() {
         z_stream zs;
         for (;;) {
             const size_t b = next.fetch_add(1);
@@ -256,66 +271,121 @@ int lsio_decode_bam(const char* path, const char* barcodes, int32_t n_barcodes, 
             if (blocks[b].usize == 0) continue;
             memset(&zs, 0, sizeof(zs));
             if (inflateInit2(&zs, -15) != Z_OK) { bad = 1; break; }
-            zs.next_in = file.data() + blocks[b].off; zs.avail_in = blocks[b].csize;
+            zs.next_in = (Bytef*)(st.file + blocks[b].off); zs.avail_in = blocks[b].csize;
             zs.next_out = data.data() + blocks[b].uoff; zs.avail_out = blocks[b].usize;
             const int rc = inflate(&zs, Z_FINISH);
             inflateEnd(&zs);
             if (rc != Z_STREAM_END || zs.avail_out != 0) { bad = 1; break; }
         }
     };
-    {
-        std::vector<std::thread> th;
-        for (int t = 0; t < n_threads; ++t) th.emplace_back(inflate_worker);
-        for (auto& t : th) t.join();
-    }
-    if (bad) { set_err("lsio_decode_bam: inflate failed in %s", path); return -1; }
-    std::vector<uint8_t>().swap(file);
-    lap("inflate");
-    // header
-    const uint8_t* d = data.data();
-    if (utotal < 12 || memcmp(d, "BAM\1", 4) != 0) { set_err("lsio_decode_bam: %s has no BAM magic", path); return -1; }
-    size_t p = 4; const uint32_t l_text = rd32(d + p); p += 4 + l_text;
+    const int T = (int)std::min<size_t>((size_t)st.n_threads, std::max<size_t>(1, blocks.size()));
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t) th.emplace_back(worker);
+    for (auto& t : th) t.join();
+    if (bad) { set_err("inflate failed in %s", st.path.c_str()); return -1; }
+    data.resize(base + utotal);
+    return 0;
+}
+
+// parse the BAM header out of `data` starting at 0; returns bytes consumed, 0 when more bytes are needed, -1 on a corrupt header
+int64_t parse_header(lsio_stream& st, const std::vector<uint8_t>& data) {
+    const uint8_t* d = data.data(); const size_t n = data.size();
+    if (n < 12) return 0;
+    if (memcmp(d, "BAM\1", 4) != 0) { set_err("%s has no BAM magic", st.path.c_str()); return -1; }
+    const uint64_t l_text = rd32(d + 4);
+    uint64_t p = 8 + l_text;
+    if (p + 4 > n) return 0;
     const uint32_t n_ref = rd32(d + p); p += 4;
     std::string names; std::vector<int64_t> lens;
     for (uint32_t i = 0; i < n_ref; ++i) {
-        const uint32_t l_name = rd32(d + p); p += 4;
-        names.append((const char*)d + p, l_name ? l_name - 1 : 0); names.push_back('\n'); p += l_name;
+        if (p + 4 > n) return 0;
+        const uint64_t l_name = rd32(d + p); p += 4;
+        if (l_name > (1u << 20)) { set_err("%s: reference name of %llu bytes in the BAM header", st.path.c_str(), (unsigned long long)l_name); return -1; }
+        if (p + l_name + 4 > n) return 0;
+        names.append((const char*)d + p, l_name ? strnlen((const char*)d + p, l_name - 1) : 0); names.push_back('\n'); p += l_name;
         lens.push_back((int64_t)rd32(d + p)); p += 4;
     }
-    // record offsets
-    std::vector<size_t> recs;
-    while (p + 4 <= utotal) {
-        const uint32_t bs = rd32(d + p);
-        if (bs < 32 || p + 4 + bs > utotal) { set_err("lsio_decode_bam: truncated record at %zu", p); return -1; }
-        recs.push_back(p); p += 4 + bs;
+    st.names = names; st.lens = lens; st.n_ref = n_ref; st.header_done = true;
+    st.header_bytes.assign(d, d + p);
+    return (int64_t)p;
+}
+
+// one batch -> record offsets (into data) of the complete records; the rest goes to st.tail.  Returns -1 on error, 0 at EOF with nothing left.
+int next_records(lsio_stream& st, size_t max_ubytes, std::vector<uint8_t>& data, std::vector<size_t>& recs) {
+    recs.clear();
+    for (;;) {
+        if (st.eof && st.tail.empty()) return 0;
+        const size_t before = st.tail.size();
+        if (!st.eof) { if (inflate_batch(st, max_ubytes, data) != 0) return -1; }
+        else { data.assign(st.tail.begin(), st.tail.end()); st.tail.clear(); }
+        size_t p = 0;
+        if (!st.header_done) {
+            const int64_t used = parse_header(st, data);
+            if (used < 0) return -1;
+            if (used == 0) {
+                if (st.eof) { set_err("%s: truncated BAM header", st.path.c_str()); return -1; }
+                st.tail.assign(data.begin(), data.end()); continue;
+            }
+            p = (size_t)used;
+        }
+        const uint8_t* d = data.data(); const size_t n = data.size();
+        while (p + 4 <= n) {
+            const uint64_t bs = rd32(d + p);
+            if (bs < 32 || bs > (1u << 30)) { set_err("%s: record with block_size %llu", st.path.c_str(), (unsigned long long)bs); return -1; }
+            if (p + 4 + bs > n) break;
+            if (!record_ok(d + p + 4, (uint32_t)bs)) { set_err("%s: record whose fields exceed its block_size %llu", st.path.c_str(), (unsigned long long)bs); return -1; }
+            if (rdi32(d + p + 4) >= (int32_t)st.n_ref) { set_err("%s: record on reference %d of %u", st.path.c_str(), rdi32(d + p + 4), st.n_ref); return -1; }
+            {   // the CIGAR must describe the stored sequence and stay on its reference (a damaged length would otherwise be expanded
+                // into up to 2^28 events per operation)
+                const uint8_t* rec = d + p + 4;
+                const int32_t tid = rdi32(rec), pos = rdi32(rec + 4);
+                const uint32_t n_cigar = rd16(rec + 12), l_seq = rd32(rec + 16), flag = rd16(rec + 14);
+                const uint8_t* cg = rec + 32 + rec[8];
+                uint64_t qlen = 0, rlen = 0;
+                for (uint32_t k = 0; k < n_cigar; ++k) {
+                    const uint32_t c = rd32(cg + 4ull * k), op = c & 0xf, l = c >> 4;
+                    if (op > 8) { set_err("%s: CIGAR operation %u", st.path.c_str(), op); return -1; }
+                    if (op == 0 || op == 1 || op == 4 || op == 7 || op == 8) qlen += l;
+                    if (is_ref_op(op)) rlen += l;
+                }
+                if (tid >= 0 && n_cigar && !(flag & 0x4)) {
+                    if (l_seq && qlen != l_seq) { set_err("%s: CIGAR covers %llu query bases, the record stores %u", st.path.c_str(), (unsigned long long)qlen, l_seq); return -1; }
+                    if (pos < 0 || (uint64_t)pos + rlen > (uint64_t)st.lens[(size_t)tid]) { set_err("%s: alignment at %d + %llu leaves reference %d (%lld bp)", st.path.c_str(), pos, (unsigned long long)rlen, tid, (long long)st.lens[(size_t)tid]); return -1; }
+                }
+            }
+            recs.push_back(p); p += 4 + (size_t)bs;
+        }
+        if (p < n) {
+            if (st.eof) { set_err("%s: truncated record at the end of the file", st.path.c_str()); return -1; }
+            st.tail.assign(d + p, d + n);
+        }
+        if (!recs.empty() || (st.eof && st.tail.empty())) return recs.empty() ? 0 : 1;
+        if (st.eof && st.tail.size() == before) { set_err("%s: truncated record at the end of the file", st.path.c_str()); return -1; }
     }
-    // auto-barcode mode (n_barcodes < 0): every distinct cleaned CB of the file is a cell (a per-cell-type BAM
-    // written by SplitBamCellTypes carries only its own cells)
-    std::string auto_joined; int32_t auto_n = 0;
-    if (n_barcodes < 0) {
+}
+
+lsio_decoded* decode_records(lsio_stream& st, const uint8_t* d, const std::vector<size_t>& recs) {
+    if (st.auto_barcodes) {
         for (size_t i = 0; i < recs.size(); ++i) {
             const char* cb; size_t cl;
             if (rdi32(d + recs[i] + 4) < 0 || !find_cb(d + recs[i] + 4, rd32(d + recs[i]), &cb, &cl)) continue;
-            auto ins = cbmap.emplace(std::string(cb, cl), auto_n);
-            if (ins.second) { auto_joined.append(cb, cl); auto_joined.push_back('\n'); ++auto_n; }
+            auto ins = st.cbmap.emplace(std::string(cb, cl), st.auto_n);
+            if (ins.second) { st.auto_joined.append(cb, cl); st.auto_joined.push_back('\n'); ++st.auto_n; }
         }
     }
-    lap("record offsets");
-    // parallel decode of contiguous record ranges
-    const int T = (int)std::min<size_t>((size_t)n_threads, std::max<size_t>(1, recs.size() / 1024));
+    const int T = (int)std::min<size_t>((size_t)st.n_threads, std::max<size_t>(1, recs.size() / 1024));
     std::vector<Local> loc((size_t)T);
-    int64_t n_tally = 0;
-    if (n_barcodes > 0) { for (auto& kv : cbmap) n_tally = kv.second + 1 > n_tally ? kv.second + 1 : n_tally; for (auto& l : loc) { l.cb_pass.assign((size_t)n_tally, 0); l.cb_low.assign((size_t)n_tally, 0); } }
+    const int64_t n_tally = st.n_tally;
+    if (n_tally > 0) for (auto& l : loc) { l.cb_pass.assign((size_t)n_tally, 0); l.cb_low.assign((size_t)n_tally, 0); }
     {
         std::vector<std::thread> th;
         for (int t = 0; t < T; ++t)
             th.emplace_back([&, t]() {
                 const size_t a = recs.size() * (size_t)t / (size_t)T, b = recs.size() * (size_t)(t + 1) / (size_t)T;
-                for (size_t i = a; i < b; ++i) decode_record(d + recs[i] + 4, rd32(d + recs[i]), cbmap, min_mapq, loc[(size_t)t]);
+                for (size_t i = a; i < b; ++i) decode_record(d + recs[i] + 4, rd32(d + recs[i]), st.cbmap, st.min_mapq, loc[(size_t)t]);
             });
         for (auto& t : th) t.join();
     }
-    lap("decode records");
     lsio_decoded* o = (lsio_decoded*)calloc(1, sizeof(lsio_decoded));
     int64_t R = 0, S = 0, E = 0;
     for (auto& l : loc) { R += (int64_t)l.read_tid.size(); S += (int64_t)l.seg_read.size(); E += (int64_t)l.events.size(); }
@@ -355,13 +425,79 @@ int lsio_decode_bam(const char* path, const char* barcodes, int32_t n_barcodes, 
     o->n_tally = n_tally;
     o->cb_pass = (int64_t*)calloc((size_t)(n_tally ? n_tally : 1), 8); o->cb_low = (int64_t*)calloc((size_t)(n_tally ? n_tally : 1), 8);
     for (auto& l : loc) for (size_t i = 0; i < l.cb_pass.size(); ++i) { o->cb_pass[i] += l.cb_pass[i]; o->cb_low[i] += l.cb_low[i]; }
-    o->n_contigs = (int32_t)n_ref;
-    o->contig_names = (char*)malloc(names.size() + 1); memcpy(o->contig_names, names.c_str(), names.size() + 1);
-    o->contig_len = dup_vec(lens);
-    o->n_barcodes = auto_n;
-    o->barcodes = (char*)malloc(auto_joined.size() + 1); memcpy(o->barcodes, auto_joined.c_str(), auto_joined.size() + 1);
-    lap("merge");
-    *out = o;
+    o->n_contigs = (int32_t)st.n_ref;
+    o->contig_names = (char*)malloc(st.names.size() + 1); memcpy(o->contig_names, st.names.c_str(), st.names.size() + 1);
+    o->contig_len = dup_vec(st.lens);
+    o->n_barcodes = st.auto_n;
+    o->barcodes = (char*)malloc(st.auto_joined.size() + 1); memcpy(o->barcodes, st.auto_joined.c_str(), st.auto_joined.size() + 1);
+    return o;
+}
+} // namespace
+
+extern "C" {
+
+// barcodes: n_barcodes cleaned barcode strings joined by '\n' (n_barcodes < 0: every distinct cleaned CB of the file is a cell, the
+// way BaseCellCounter sees a per-cell-type BAM); ids[i] = dense id of barcode i (NULL: i).
+int lsio_stream_open(const char* path, const char* barcodes, int32_t n_barcodes, const int32_t* ids, int32_t min_mapq, int32_t n_threads,
+                     lsio_stream** out) {
+    if (!path || !out) { set_err("lsio_stream_open: bad arguments"); return -2; }
+    *out = nullptr;
+    lsio_stream* st = new lsio_stream();
+    st->path = path; st->min_mapq = min_mapq;
+    st->n_threads = n_threads > 0 ? n_threads : (int)std::max(1u, std::thread::hardware_concurrency());
+    st->cbmap.reserve((size_t)(n_barcodes > 0 ? n_barcodes : 0) * 2 + 16);
+    const char* s = barcodes ? barcodes : "";
+    for (int32_t i = 0; i < n_barcodes; ++i) {
+        const char* e = strchr(s, '\n'); size_t l = e ? (size_t)(e - s) : strlen(s);
+        st->cbmap[std::string(s, l)] = ids ? ids[i] : i;                          // duplicates: last wins (to_dict, :31)
+        s += l + (e ? 1 : 0);
+    }
+    st->auto_barcodes = n_barcodes < 0;
+    if (n_barcodes > 0) for (auto& kv : st->cbmap) st->n_tally = kv.second + 1 > st->n_tally ? kv.second + 1 : st->n_tally;
+    st->fd = open(path, O_RDONLY);
+    struct stat sb;
+    if (st->fd < 0 || fstat(st->fd, &sb) != 0) { set_err("cannot open %s", path); delete st; return -1; }
+    st->fsize = (size_t)sb.st_size;
+    if (st->fsize) {
+        st->file = (const uint8_t*)mmap(nullptr, st->fsize, PROT_READ, MAP_PRIVATE, st->fd, 0);
+        if (st->file == (const uint8_t*)MAP_FAILED) { st->file = nullptr; set_err("cannot map %s", path); delete st; return -1; }
+        (void)madvise((void*)st->file, st->fsize, MADV_SEQUENTIAL);
+    }
+    *out = st;
+    return 0;
+}
+
+void lsio_stream_close(lsio_stream* st) { delete st; }
+
+// Decodes the next batch (about max_ubytes of uncompressed BAM, at least one record; <= 0: everything that is left).  Returns 1 with
+// *out set, 0 at the end of the file (*out = NULL), < 0 on error.  The counters of the batch are in *out; the barcode list of the
+// auto-barcode mode grows from batch to batch (ids stay stable).
+int lsio_stream_next(lsio_stream* st, int64_t max_ubytes, lsio_decoded** out) {
+    if (!st || !out) { set_err("lsio_stream_next: bad arguments"); return -2; }
+    *out = nullptr;
+    std::vector<uint8_t> data; std::vector<size_t> recs;
+    const int rc = next_records(*st, max_ubytes > 0 ? (size_t)max_ubytes : (size_t)-1, data, recs);
+    if (rc < 0) return -1;
+    if (rc == 0) {
+        if (!st->header_done) { set_err("%s: no BAM header", st->path.c_str()); return -1; }
+        return 0;
+    }
+    *out = decode_records(*st, data.data(), recs);
+    return 1;
+}
+
+int lsio_decode_bam(const char* path, const char* barcodes, int32_t n_barcodes, const int32_t* ids, int32_t min_mapq, int32_t n_threads,
+                    lsio_decoded** out) {
+    if (!path || !out) { set_err("lsio_decode_bam: bad arguments"); return -2; }
+    *out = nullptr;
+    lsio_stream* st = nullptr;
+    int rc = lsio_stream_open(path, barcodes, n_barcodes, ids, min_mapq, n_threads, &st);
+    if (rc != 0) return rc;
+    std::vector<uint8_t> data; std::vector<size_t> recs;
+    rc = next_records(*st, (size_t)-1, data, recs);
+    if (rc < 0 || !st->header_done) { if (rc >= 0) set_err("%s: no BAM header", path); delete st; return -1; }
+    *out = decode_records(*st, data.data(), recs);
+    delete st;
     return 0;
 }
 
@@ -515,35 +651,19 @@ int lsio_split_bam(const char* path, const char* barcodes, int32_t n_barcodes, c
     { const char* s = barcodes; for (int32_t i = 0; i < n_barcodes; ++i) { const char* e = strchr(s, '\n'); size_t l = e ? (size_t)(e - s) : strlen(s); ctmap[std::string(s, l)] = celltype_of_barcode[i]; s += l + (e ? 1 : 0); } }
     std::vector<std::string> outs;
     { const char* s = out_paths; for (int i = 0; i < n_ct; ++i) { const char* e = strchr(s, '\n'); size_t l = e ? (size_t)(e - s) : strlen(s); outs.emplace_back(s, l); s += l + (e ? 1 : 0); } }
-    FILE* f = fopen(path, "rb");
-    if (!f) { set_err("lsio_split_bam: cannot open %s", path); return -1; }
-    fseek(f, 0, SEEK_END); const size_t fsize = (size_t)ftell(f); fseek(f, 0, SEEK_SET);
-    std::vector<uint8_t> file(fsize);
-    if (fsize && fread(file.data(), 1, fsize, f) != fsize) { fclose(f); set_err("lsio_split_bam: short read"); return -1; }
-    fclose(f);
-    std::vector<uint8_t> data;
-    for (size_t off = 0; off + 18 <= fsize;) {
-        const uint8_t* h = file.data() + off;
-        const uint32_t xlen = rd16(h + 10), bsize = rd16(h + 16) + 1u, usize = rd32(h + bsize - 4);
-        const size_t at = data.size(); data.resize(at + usize);
-        if (usize) {
-            z_stream zs; memset(&zs, 0, sizeof(zs)); inflateInit2(&zs, -15);
-            zs.next_in = (Bytef*)(h + 12 + xlen); zs.avail_in = bsize - xlen - 20; zs.next_out = data.data() + at; zs.avail_out = usize;
-            const int rc = inflate(&zs, Z_FINISH); inflateEnd(&zs);
-            if (rc != Z_STREAM_END) { set_err("lsio_split_bam: inflate failed"); return -1; }
-        }
-        off += bsize;
-    }
-    const uint8_t* d = data.data(); const size_t total = data.size();
-    if (total < 12 || memcmp(d, "BAM\1", 4) != 0) { set_err("lsio_split_bam: no BAM magic"); return -1; }
-    size_t p = 8 + rd32(d + 4); const uint32_t n_ref = rd32(d + p); p += 4;
-    for (uint32_t i = 0; i < n_ref; ++i) { p += 4 + rd32(d + p); p += 4; }
+    lsio_stream* st = nullptr;
+    if (lsio_stream_open(path, nullptr, 0, nullptr, min_mapq, 0, &st) != 0) return -1;
+    std::vector<uint8_t> data; std::vector<size_t> recs;
+    const int rcs = next_records(*st, (size_t)-1, data, recs);           // validated: block sizes, header, every record's fields
+    if (rcs < 0 || !st->header_done) { if (rcs >= 0) set_err("lsio_split_bam: %s has no BAM header", path); delete st; return -1; }
+    const std::vector<uint8_t> header = st->header_bytes;
+    delete st;
+    const uint8_t* d = data.data();
     std::vector<BgzfWriter> w((size_t)n_ct);
-    for (int i = 0; i < n_ct; ++i) { w[(size_t)i].f = fopen(outs[(size_t)i].c_str(), "wb"); if (!w[(size_t)i].f) { set_err("lsio_split_bam: cannot write %s", outs[(size_t)i].c_str()); return -1; } w[(size_t)i].write(d, p); }
+    for (int i = 0; i < n_ct; ++i) { w[(size_t)i].f = fopen(outs[(size_t)i].c_str(), "wb"); if (!w[(size_t)i].f) { set_err("lsio_split_bam: cannot write %s", outs[(size_t)i].c_str()); return -1; } w[(size_t)i].write(header.data(), header.size()); }
     int64_t cnt[5] = {0, 0, 0, 0, 0};
-    while (p + 4 <= total) {
-        const uint32_t bs = rd32(d + p); const uint8_t* rec = d + p + 4;
-        const size_t rec_at = p; p += 4 + bs;
+    for (const size_t rec_at : recs) {
+        const uint32_t bs = rd32(d + rec_at); const uint8_t* rec = d + rec_at + 4;
         if (rdi32(rec) < 0) continue;
         ++cnt[0];
         const char* cb; size_t cl;

@@ -42,6 +42,11 @@ def load():
         lib.lsio_decode_bam.restype = C.c_int
         lib.lsio_decode_bam.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.POINTER(Decoded))]
         lib.lsio_free_decoded.argtypes = [C.POINTER(Decoded)]
+        lib.lsio_stream_open.restype = C.c_int
+        lib.lsio_stream_open.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+        lib.lsio_stream_next.restype = C.c_int
+        lib.lsio_stream_next.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.POINTER(Decoded))]
+        lib.lsio_stream_close.argtypes = [C.c_void_p]
         lib.lsio_synth_bam.restype = C.c_int
         lib.lsio_synth_bam.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p]
         lib.lsio_synth_records.restype = C.c_int
@@ -131,6 +136,58 @@ class DecodedBam:
         return rep
 
 
+def _wrap(lib, out, barcodes) -> DecodedBam:
+    owner = _DecodedOwner(lib, out)
+    d = out.contents
+    rec = _take(d, owner)
+    names = d.contig_names.decode().split("\n")[: d.n_contigs] if d.n_contigs else []
+    lens = np.ctypeslib.as_array(C.cast(d.contig_len, C.POINTER(C.c_int64)), shape=(d.n_contigs,)).copy() if d.n_contigs else np.zeros(0, np.int64)
+    rep = {"Total_reads": d.total_reads, "Pass_reads": d.pass_reads, "CB_not_found": d.cb_not_found, "CB_not_matched": d.cb_not_matched}
+    if d.mapq_filtered:
+        rep["MAPQ"] = d.mapq_filtered
+    found = d.barcodes.decode().split("\n")[: d.n_barcodes] if barcodes is None else None
+    tally = lambda ptr: np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_int64)), shape=(len(barcodes),)).copy() if barcodes is not None and d.n_tally >= len(barcodes) and len(barcodes) else None
+    return DecodedBam(rec, names, lens, rep, found, tally(d.cb_pass), tally(d.cb_low))
+
+
+def stream_bam(path: str, barcodes: Optional[Sequence[str]], min_mapq: int = 60, threads: int = 0, batch_bytes: int = 1 << 30):
+    """The BAM in file order, a batch at a time (about batch_bytes of uncompressed BAM each): yields DecodedBam objects whose
+    records, counters and per-barcode tallies cover one batch.  The compressed file is mapped, a batch is inflated and decoded by
+    `threads` host threads while the caller works on the previous one (the ctypes call releases the GIL).  This is the reference's
+    window-by-window reading (BaseCellCounter.py:81-113,190-191) without an index: file order is coordinate order."""
+    lib = load()
+    h = C.c_void_p()
+    joined = None if barcodes is None else "\n".join(barcodes).encode()
+    if lib.lsio_stream_open(os.fsencode(path), joined, -1 if barcodes is None else len(barcodes), None, int(min_mapq), int(threads), C.byref(h)) != 0:
+        _err("lsio_stream_open")
+    try:
+        while True:
+            out = C.POINTER(Decoded)()
+            rc = lib.lsio_stream_next(h, int(batch_bytes), C.byref(out))
+            if rc < 0:
+                _err("lsio_stream_next")
+            if rc == 0:
+                return
+            yield _wrap(lib, out, barcodes)
+    finally:
+        lib.lsio_stream_close(h)
+
+
+def concat_records(parts: Sequence[ReadRecords]) -> ReadRecords:
+    """Read-record arrays of several batches as one (read and event indices re-based)."""
+    parts = [p for p in parts if p.n_reads or p.n_segs]
+    if not parts:
+        z = lambda dt: np.zeros(0, dt)
+        return ReadRecords(*[z(dt) for _, dt in ReadRecords._SPEC])
+    if len(parts) == 1:
+        return parts[0]
+    r0 = np.cumsum([0] + [p.n_reads for p in parts]); e0 = np.cumsum([0] + [p.n_events for p in parts])
+    cat = lambda n: np.concatenate([getattr(p, n) for p in parts])
+    return ReadRecords(cat("read_tid"), cat("read_pos"), cat("read_flag"), cat("read_mapq"), cat("read_cb"),
+                       np.concatenate([p.seg_read.astype(np.int64) + r0[i] for i, p in enumerate(parts)]).astype(np.uint32), cat("seg_start"), cat("seg_len"),
+                       np.concatenate([p.seg_ev_off + e0[i] for i, p in enumerate(parts)]), cat("events"))
+
+
 def decode_bam(path: str, barcodes: Optional[Sequence[str]], min_mapq: int = 60, threads: int = 0) -> DecodedBam:
     """BAM -> read-record arrays.  Reads without a CB tag or whose cleaned CB is not in `barcodes` are dropped
     (they can never be counted); flags and MAPQ are kept for the device-side admission.  barcodes=None: every
@@ -144,17 +201,7 @@ def decode_bam(path: str, barcodes: Optional[Sequence[str]], min_mapq: int = 60,
         rc = lib.lsio_decode_bam(os.fsencode(path), joined, len(barcodes), None, int(min_mapq), int(threads), C.byref(out))
     if rc != 0:
         _err("lsio_decode_bam")
-    owner = _DecodedOwner(lib, out)
-    d = out.contents
-    rec = _take(d, owner)
-    names = d.contig_names.decode().split("\n")[: d.n_contigs] if d.n_contigs else []
-    lens = np.ctypeslib.as_array(C.cast(d.contig_len, C.POINTER(C.c_int64)), shape=(d.n_contigs,)).copy() if d.n_contigs else np.zeros(0, np.int64)
-    rep = {"Total_reads": d.total_reads, "Pass_reads": d.pass_reads, "CB_not_found": d.cb_not_found, "CB_not_matched": d.cb_not_matched}
-    if d.mapq_filtered:
-        rep["MAPQ"] = d.mapq_filtered
-    found = d.barcodes.decode().split("\n")[: d.n_barcodes] if barcodes is None else None
-    tally = lambda ptr: np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_int64)), shape=(len(barcodes),)).copy() if barcodes is not None and d.n_tally >= len(barcodes) and len(barcodes) else None
-    return DecodedBam(rec, names, lens, rep, found, tally(d.cb_pass), tally(d.cb_low))
+    return _wrap(lib, out, barcodes)
 
 
 def split_bam(path: str, table: "BarcodeTable", out_paths: Sequence[str], min_mapq: int = 60) -> Dict[str, int]:

@@ -169,19 +169,23 @@ def chain_step1(res: Resident, celltype_of: np.ndarray, celltype_names: List[str
 
 def run_chain(res: Resident, celltype_of: np.ndarray, celltype_names: List[str], report: Dict[str, int], out_dir: str, sample_id: str,
               params: SnvParams, editing: Optional[str] = None, pon_sr: Optional[str] = None, pon_lr: Optional[str] = None,
-              gnomad_af_json: Optional[str] = None) -> SnvOutputs:
+              gnomad_af_json: Optional[str] = None, step3: bool = True) -> SnvOutputs:
     """SplitBam report -> BaseCellCounter -> MergeCounts -> BaseCellCalling step 1-3 for one barcode -> cell-type table over the
-    resident reads (celltype_of[barcode id] = index into celltype_names, 255 = barcode not listed)."""
+    resident reads (celltype_of[barcode id] = index into celltype_names, 255 = barcode not listed).  step3=False stops after
+    step 2, as pass 1 of the reference does (rules/CellTypeReannotation.smk has no step-3 rule: HCCV reads calling.step2.tsv)."""
     eng, contig_names = res.engine, res.contig_names
     out, s1, _, t = chain_step1(res, celltype_of, celltype_names, report, out_dir, sample_id, params)
     d = {"BaseCellCalling": os.path.join(out_dir, "BaseCellCalling")}
     t0 = time.time()
     keys = [calling.read_posset_keys(p, contig_names, params.reference_gz_compat) for p in (editing, pon_sr, pon_lr)]
-    af = json.load(open(gnomad_af_json)) if gnomad_af_json else None
+    af = calling.open_gnomad(gnomad_af_json)              # a JSON table or a gnomad_db directory / sqlite file
     s2 = calling.step2(s1, eng, contig_names, keys[0], keys[1], keys[2], params.min_distance, af, params.max_gnomad_vaf)
     out.step2 = os.path.join(d["BaseCellCalling"], sample_id + ".calling.step2.tsv")
     open(out.step2, "w").write(s2)
     t["step2"] = time.time() - t0
+    if not step3:
+        out.timings = t
+        return out
     t0 = time.time()
     final, unfiltered = calling.step3(s2, params.delta_vaf, params.delta_mcf, params.min_ac_reads, params.min_ac_cells, params.clust_dist)
     out.step3 = os.path.join(d["BaseCellCalling"], sample_id + ".calling.step3.tsv")
@@ -211,7 +215,10 @@ def run_snv(bam: str, barcodes_tsv: str, ref_fasta: str, out_dir: str, sample_id
 @dataclass
 class ReannoParams:
     """config/config.yaml:40-68 (Reanno block): pass-1 chain parameters + HCCV + re-annotation."""
-    chain: SnvParams = field(default_factory=lambda: SnvParams(min_ac_cells=5, min_ac_reads=20))     # Reanno.BaseCellCalling
+    # Reanno.BaseCellCalling.  config.yaml:50-51 lists min_ac_cells 5 / min_ac_reads 20, but the reference's pass-1 step-1 rule never
+    # forwards them (rules/CellTypeReannotation.smk:208-238) and pass 1 has no step 3, so the script defaults 2 / 3
+    # (BaseCellCalling.step1.py:594-595) are what runs (SURVEY quirk Q10); the fused pass 1 does the same
+    chain: SnvParams = field(default_factory=SnvParams)
     hccv_min_depth: float = 50
     hccv_delta_vaf: float = 0.2
     hccv_delta_mcf: float = 0.25
@@ -239,7 +246,7 @@ class ReannoOutputs:
 def run_reannotation(bam: str, barcodes_tsv: str, ref_fasta: str, out_dir: str, sample_id: str, reanno_params: Optional[ReannoParams] = None,
                      snv_params: Optional[SnvParams] = None, fusions_tsv: Optional[str] = None, editing: Optional[str] = None,
                      pon_sr: Optional[str] = None, pon_lr: Optional[str] = None, gnomad_af_json: Optional[str] = None, device: int = 0,
-                     engine: Optional[Engine] = None) -> ReannoOutputs:
+                     engine: Optional[Engine] = None, pass1_step3: bool = False) -> ReannoOutputs:
     """The two-pass loop of the workflow (rules/CellTypeReannotation.smk + rules/SNVCalling.smk) in one process: the BAM is
     decoded and loaded ONCE; pass 1 calls with the automated annotation, the HCCV sites are genotyped per cell on the resident
     reads, the cells are re-annotated, and pass 2 re-counts the same resident reads under the new barcode table.
@@ -254,7 +261,8 @@ def run_reannotation(bam: str, barcodes_tsv: str, ref_fasta: str, out_dir: str, 
     try:
         res = load_sample(bam, barcodes_tsv, ref_fasta, eng, rp.chain.min_mapping_quality)
         d1 = os.path.join(out_dir, "CellTypeReannotation")
-        p1 = run_chain(res, res.table.celltype_of, res.table.celltype_names, res.dec.report, d1, sample_id, rp.chain, editing, pon_sr, pon_lr, gnomad_af_json)
+        p1 = run_chain(res, res.table.celltype_of, res.table.celltype_names, res.dec.report, d1, sample_id, rp.chain, editing, pon_sr, pon_lr, gnomad_af_json,
+                       step3=pass1_step3)
         t0 = time.time()
         os.makedirs(os.path.join(d1, "HCCV"), exist_ok=True)
         hccv = reanno.hccv_filter(p1.step2, os.path.join(d1, "HCCV", sample_id), rp.hccv_min_depth, rp.hccv_delta_vaf, rp.hccv_delta_mcf, rp.hccv_clust_dist)

@@ -49,23 +49,25 @@ def _p(a):
 
 
 def count(rec, contig_len, refs, celltype_of, ct, min_bq=20, min_mq=60, min_dp=5, min_cc=5,
-          flag_exclude=0xF04, ignore_orphans=1):
+          flag_exclude=0xF04, ignore_orphans=1, threads=1, region_w=512, cap=None):
     """Events-level oracle (oracle/count_oracle.c).  refs: list of uint8 arrays per contig.
-    Returns keys, ref, counts[n,42], n_columns."""
+    Returns keys, ref, counts[n,42], n_columns.  threads > 1: the region-parallel form (lso_count_mt, same per-column code)."""
     L = lib()
+    L.lso_count_mt.restype = C.c_int64
     contig_len = np.ascontiguousarray(contig_len, np.int64)
     celltype_of = np.ascontiguousarray(celltype_of, np.uint8)
     refs = [np.ascontiguousarray(r, np.uint8) for r in refs]
     ref_ptrs = (C.c_void_p * len(refs))(*[r.ctypes.data for r in refs])
-    cap = int(rec.n_events) + 1
+    cap = int(cap) if cap else min(int(rec.n_events), int(sum(contig_len))) + 1
     while True:
-        keys = np.zeros(cap, np.int64); ref = np.zeros(cap, np.uint8); counts = np.zeros((cap, 42), np.uint32)
+        keys = np.empty(cap, np.int64); ref = np.empty(cap, np.uint8); counts = np.empty((cap, 42), np.uint32)
         ncols = C.c_int64(0)
-        n = L.lso_count(C.c_int64(rec.n_reads), C.c_int64(rec.n_segs), _p(rec.read_tid), _p(rec.read_flag), _p(rec.read_mapq),
+        fn, extra = (L.lso_count, ()) if threads <= 1 else (L.lso_count_mt, (C.c_int32(int(threads)), C.c_int32(int(region_w))))
+        n = fn(C.c_int64(rec.n_reads), C.c_int64(rec.n_segs), _p(rec.read_tid), _p(rec.read_flag), _p(rec.read_mapq),
                         _p(rec.read_cb), _p(rec.seg_read), _p(rec.seg_start), _p(rec.seg_len), _p(rec.seg_ev_off), _p(rec.events),
                         C.c_int32(len(contig_len)), _p(contig_len), ref_ptrs, _p(celltype_of), C.c_int32(len(celltype_of)), C.c_int32(ct),
                         C.c_int32(min_bq), C.c_int32(min_mq), C.c_int32(min_dp), C.c_int32(min_cc), C.c_uint32(flag_exclude),
-                        C.c_int32(ignore_orphans), _p(keys), _p(ref), _p(counts), C.c_int64(cap), C.byref(ncols))
+                        C.c_int32(ignore_orphans), _p(keys), _p(ref), _p(counts), C.c_int64(cap), C.byref(ncols), *extra)
         if n < 0:
             raise MemoryError("oracle allocation failed")
         if n <= cap:

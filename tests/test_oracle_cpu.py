@@ -35,3 +35,18 @@ def test_step2_oracle():
     assert got == rd("sample.calling.step2.tsv")
     got = co.step2(rd("sample.calling.step1.tsv"), ed, sr, co.read_posset(""), 150, af, 0.01)
     assert got == rd("sample.dist150.calling.step2.tsv")
+
+
+def test_region_parallel_count_oracle_equals_the_single_threaded_one():
+    """lso_count_mt (regions over threads, the form that writes the scale pins and the all-cores CPU baseline) == lso_count"""
+    import numpy as np
+    from longsom_amd import hostio, synth
+    from oracle import loader
+    m = synth.named("C1", n_reads=6000, n_genes=40)
+    rec = hostio.synth_records(m)
+    refs = [hostio.ref_bases(m.seed, t, int(l)) for t, l in enumerate(m.contig_len)]
+    for ct in range(2):
+        a = loader.count(rec, m.contig_len, refs, m.celltype_of, ct)
+        for threads, w in ((3, 512), (8, 64), (2, 100000)):
+            b = loader.count(rec, m.contig_len, refs, m.celltype_of, ct, threads=threads, region_w=w)
+            assert all(np.array_equal(x, y) for x, y in zip(a[:3], b[:3])) and a[3] == b[3] and len(a[0]) > 100

@@ -31,7 +31,7 @@ def test_two_pass_loop(engine, tmp_path):
                                hccv_clust_dist=5, chrm_contaminant="True", min_variants=2, min_fraction=0.2)
     sp = pipeline.SnvParams()
     fused = tmp_path / "fused"
-    out = pipeline.run_reannotation(bam, bct, fa, str(fused), "S1", rp, sp, engine=engine)
+    out = pipeline.run_reannotation(bam, bct, fa, str(fused), "S1", rp, sp, engine=engine, pass1_step3=True)
     n_hccv = sum(1 for l in open(out.hccv) if not l.startswith("#"))
     assert n_hccv >= 3, "the synthetic sample must yield HCCVs for this test to mean anything"
     assert out.pass2 is not None and 0 < out.n_cancer < out.n_cells_kept <= 80

@@ -24,6 +24,16 @@ rule Reannotation_gpu:
         step3="SNVCalling/BaseCellCalling/{id}.calling.step3.tsv",
     params:
         script=GPU_SCRIPTS+"/CellTypeReannotation/longsom_gpu_reannotation.py",
+        gnomAD_db=str(workflow.basedir)+config['Reference']['gnomAD_db'],
+        gz_compat="--p1_reference_gz_compat --p2_reference_gz_compat" if config['Run'].get('reference_gz_compat', False) else "",
+        # pass 1 = config['Reanno'], pass 2 = config['SNVCalling'].  Pass 1 deliberately gets NO min_ac_reads / min_ac_cells: the
+        # reference's pass-1 step-1 rule does not forward them either (rules/CellTypeReannotation.smk:208-238)
+        r1=config['Reanno']['BaseCellCalling'],
+        m1=config['Reanno']['BaseCellCounter']['min_mapping_quality'],
+        h=config['Reanno']['HCCV'],
+        r=config['Reanno']['Reannotation'],
+        c2=config['SNVCalling']['BaseCellCalling'],
+        m2=config['SNVCalling']['BaseCellCounter']['min_mapping_quality'],
     resources:
         gpu=1
     log:
@@ -31,7 +41,17 @@ rule Reannotation_gpu:
     shell:
         r"""
         python {params.script} --bam {input.bam} --meta {input.barcodes} --ref {input.ref} --id {wildcards.id} --outdir . \
-        --fusions {input.fusions} --editing {input.RNA_editing} --pon_SR {input.pon_SR} --pon_LR {input.pon_LR} > {log}
+        --fusions {input.fusions} --editing {input.RNA_editing} --pon_SR {input.pon_SR} --pon_LR {input.pon_LR} --gnomAD_db {params.gnomAD_db} {params.gz_compat} \
+        --p1_min_mapping_quality {params.m1} --p1_min_cell_types {params.r1[Min_cell_types]} --p1_min_distance {params.r1[min_distance]} \
+        --p1_max_gnomad_vaf {params.r1[max_gnomAD_VAF]} \
+        --p1_alpha1 {params.r1[alpha1]} --p1_beta1 {params.r1[beta1]} --p1_alpha2 {params.r1[alpha2]} --p1_beta2 {params.r1[beta2]} \
+        --reanno_hccv_min_depth {params.h[min_depth]} --reanno_hccv_delta_vaf {params.h[deltaVAF]} --reanno_hccv_delta_mcf {params.h[deltaMCF]} \
+        --reanno_hccv_clust_dist {params.h[clust_dist]} --reanno_chrm_contaminant {params.h[chrM_contaminant]} --reanno_alt_flag {params.h[alt_flag]} \
+        --reanno_pvalue {params.h[pvalue]} --reanno_min_variants {params.r[min_variants]} --reanno_min_fraction {params.r[min_fraction]} \
+        --p2_min_mapping_quality {params.m2} --p2_min_cell_types {params.c2[Min_cell_types]} --p2_min_distance {params.c2[min_distance]} \
+        --p2_max_gnomad_vaf {params.c2[max_gnomAD_VAF]} --p2_delta_vaf {params.c2[deltaVAF]} --p2_delta_mcf {params.c2[deltaMCF]} \
+        --p2_min_ac_reads {params.c2[min_ac_reads]} --p2_min_ac_cells {params.c2[min_ac_cells]} --p2_clust_dist {params.c2[clust_dist]} \
+        --p2_alpha1 {params.c2[alpha1]} --p2_beta1 {params.c2[beta1]} --p2_alpha2 {params.c2[alpha2]} --p2_beta2 {params.c2[beta2]} > {log}
         """
 
 rule HighConfidenceCancerVariants_gpu:

@@ -28,17 +28,23 @@ rule SNVCalling_gpu:
         script=GPU_SCRIPTS+"/SNVCalling/longsom_gpu_snv.py",
         c=config['SNVCalling']['BaseCellCalling'],
         mapq=config['SNVCalling']['BaseCellCounter']['min_mapping_quality'],
+        gnomAD_db=str(workflow.basedir)+config['Reference']['gnomAD_db'],
+        # Run.reference_gz_compat: True reproduces the reference's reading of the .gz position sets (opened as text, the
+        # decode error is swallowed, the sets are EMPTY: SURVEY quirk Q1); default False = the sets are read
+        gz_compat="--reference_gz_compat" if config['Run'].get('reference_gz_compat', False) else "",
+        # GPUs of this node used by the rule: one rank per GPU, genomic regions sharded over the ranks
+        launcher=lambda wc, resources: "python" if resources.gpu == 1 else f"python -m torch.distributed.run --nnodes=1 --nproc-per-node {resources.gpu} --master-addr 127.0.0.1 --master-port 29517",
     resources:
-        gpu=1
+        gpu=config['Run'].get('gpus', 1)
     log:
         "logs/SNVCalling_gpu/{id}.log",
     benchmark:
         "benchmarks/SNVCalling_gpu/{id}.benchmark.txt"
     shell:
         r"""
-        python {params.script} \
+        {params.launcher} {params.script} \
         --bam {input.bam} --meta {input.barcodes} --ref {input.ref} --id {wildcards.id} --outdir SNVCalling \
-        --editing {input.RNA_editing} --pon_SR {input.pon_SR} --pon_LR {input.pon_LR} \
+        --editing {input.RNA_editing} --pon_SR {input.pon_SR} --pon_LR {input.pon_LR} --gnomAD_db {params.gnomAD_db} {params.gz_compat} \
         --min_mapping_quality {params.mapq} \
         --min_cell_types {params.c[Min_cell_types]} --min_distance {params.c[min_distance]} \
         --max_gnomad_vaf {params.c[max_gnomAD_VAF]} --delta_vaf {params.c[deltaVAF]} --delta_mcf {params.c[deltaMCF]} \
