@@ -214,13 +214,23 @@ def snv(argv=None):
     ap.add_argument("--id", required=True); ap.add_argument("--outdir", required=True)
     _optional_paths(ap, "--editing", "--pon_SR", "--pon_LR", "--gnomAD_json", "--gnomAD_db")
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--window_gb", type=float, default=0.0, help="stream the BAM in batches of about this many GiB of uncompressed BAM and count "
+                    "window by window (for a BAM whose reads do not fit in HBM); 0 = the whole BAM at once")
     d = pipeline.SnvParams()
     _add_dataclass_flags(ap, d)
     a = ap.parse_args(argv)
     params = pipeline.SnvParams(**{k: getattr(a, k) for k in vars(d)})
-    out = pipeline.run_snv(a.bam, a.meta, a.ref, a.outdir, a.id, params, a.editing or None, a.pon_SR or None, a.pon_LR or None,
-                           a.gnomAD_json or a.gnomAD_db or None, a.device)
-    print(json.dumps({"outputs": {k: v for k, v in vars(out).items() if k != "timings"}, "seconds": out.timings}))
+    # under torch.distributed.run (WORLD_SIZE > 1): one rank per GPU, regions sharded over the ranks; the process group comes up
+    # before anything touches the GPU
+    from . import regions
+    comm = regions.Comm.from_env()
+    try:
+        out = pipeline.run_snv(a.bam, a.meta, a.ref, a.outdir, a.id, params, a.editing or None, a.pon_SR or None, a.pon_LR or None,
+                               a.gnomAD_json or a.gnomAD_db or None, a.device, comm=comm, window_bytes=int(a.window_gb * (1 << 30)) or None)
+        if comm.rank == 0:
+            print(json.dumps({"outputs": {k: v for k, v in vars(out).items() if k != "timings"}, "seconds": out.timings, "ranks": comm.world}))
+    finally:
+        comm.close()
 
 
 def reannotation(argv=None):

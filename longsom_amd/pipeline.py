@@ -16,7 +16,7 @@ from typing import Dict, List, Optional
 import numpy as np
 import pandas as pd
 
-from . import calling, hostio, pon, tsvio
+from . import calling, hostio, pon, regions, tsvio
 from ._lib import CallParams, CountParams
 from .engine import Engine
 
@@ -199,17 +199,210 @@ def run_chain(res: Resident, celltype_of: np.ndarray, celltype_names: List[str],
 
 def run_snv(bam: str, barcodes_tsv: str, ref_fasta: str, out_dir: str, sample_id: str, params: Optional[SnvParams] = None,
             editing: Optional[str] = None, pon_sr: Optional[str] = None, pon_lr: Optional[str] = None,
-            gnomad_af_json: Optional[str] = None, device: int = 0, engine: Optional[Engine] = None) -> SnvOutputs:
+            gnomad_af_json: Optional[str] = None, device: int = 0, engine: Optional[Engine] = None,
+            comm: Optional["regions.Comm"] = None, window_bytes: Optional[int] = None) -> SnvOutputs:
+    """One sample through the whole chain.  comm (world > 1): one rank per GPU, genomic regions sharded over the ranks, call
+    `regions.Comm.from_env()` before anything touches the GPU.  window_bytes: stream the BAM in batches of about that many
+    uncompressed bytes and count window by window (a BAM whose reads do not fit in HBM; decode overlaps the GPU work)."""
     params = params or SnvParams()
+    comm = comm or regions.Comm()
     own = engine is None
-    eng = engine or Engine(device)
+    eng = engine or Engine(comm.local_device_index if comm.world > 1 else device)
     try:
+        if comm.world > 1 or window_bytes:
+            return _run_snv_regions(bam, barcodes_tsv, ref_fasta, out_dir, sample_id, params, editing, pon_sr, pon_lr, gnomad_af_json, eng, comm, window_bytes)
         res = load_sample(bam, barcodes_tsv, ref_fasta, eng, params.min_mapping_quality)
         return run_chain(res, res.table.celltype_of, res.table.celltype_names, res.dec.report, out_dir, sample_id, params, editing, pon_sr, pon_lr,
                          gnomad_af_json)
     finally:
         if own:
             eng.close()
+
+
+def _key(p) -> int:
+    return (int(p[0]) << 32) | int(p[1])
+
+
+def _windows(batches, n_contigs: int):
+    """(lo, hi, records) per window from a stream of decoded batches in file (= coordinate) order: a window's region ends at the
+    start tile of the next batch's first read — every read that can cover a column below that point has been seen — and the reads
+    that reach past it are carried into the next window."""
+    carry = None
+    lo = (0, 0)
+    prev = next(batches, None)
+    while prev is not None:
+        nxt = next(batches, None)
+        while nxt is not None and nxt.records.n_reads == 0:          # a batch whose records were all dropped at decode: merge its counters forward
+            for k, v in nxt.report.items():
+                prev.report[k] = prev.report.get(k, 0) + v
+            nxt = next(batches, None)
+        rec = prev.records if carry is None else hostio.concat_records([carry, prev.records])
+        hi = (n_contigs, 0)
+        if nxt is not None:
+            hi = (int(nxt.records.read_tid[0]), (int(nxt.records.read_pos[0]) // regions.TILE) * regions.TILE)
+        if _key(hi) < _key(lo):
+            raise ValueError("the BAM is not coordinate sorted: a batch starts at %s, before %s" % (hi, lo))
+        yield lo, hi, rec, prev
+        carry = None
+        if nxt is not None and rec.n_reads:
+            ends = regions.read_ends(rec)
+            mask = ((rec.read_tid.astype(np.int64) << 32) | ends) > _key(hi)
+            if mask.any():
+                carry = rec.subset(mask)
+        lo, prev = hi, nxt
+
+
+def _prefetch(gen, depth: int = 1):
+    """run a generator in a background thread, `depth` items ahead (the decode of the next batch overlaps the GPU and the writers)"""
+    import queue
+    import threading
+    q: "queue.Queue" = queue.Queue(maxsize=depth)
+    end = object()
+
+    def work():
+        try:
+            for item in gen:
+                q.put(item)
+            q.put(end)
+        except BaseException as e:            # noqa: BLE001 - handed to the consumer
+            q.put(e)
+    threading.Thread(target=work, daemon=True).start()
+    while True:
+        item = q.get()
+        if item is end:
+            return
+        if isinstance(item, BaseException):
+            raise item
+        yield item
+
+
+def _run_snv_regions(bam, barcodes_tsv, ref_fasta, out_dir, sample_id, params, editing, pon_sr, pon_lr, gnomad_af_json, eng, comm, window_bytes) -> SnvOutputs:
+    t: Dict[str, float] = {"decode": 0.0, "load": 0.0, "gpu_count_call": 0.0, "fetch": 0.0, "write_tables": 0.0}
+    t_all = time.time()
+    bc = hostio.read_barcodes(barcodes_tsv)
+    names_fa, seqs = tsvio.read_fasta(ref_fasta)
+    seq_of = dict(zip(names_fa, seqs))
+    cts = bc.celltype_names
+    d = {k: os.path.join(out_dir, k) for k in ("SplitBam", "BaseCellCounter/" + sample_id, "MergeCounts", "BaseCellCalling")}
+    tmp = os.path.join(out_dir, "_pieces." + sample_id)
+    if comm.rank == 0:
+        import shutil
+        shutil.rmtree(tmp, ignore_errors=True)
+        for p in list(d.values()) + [tmp]:
+            os.makedirs(p, exist_ok=True)
+    comm.barrier()
+    report: Dict[str, int] = {}
+    contig = {}
+
+    def setup(dec):
+        for n, l in zip(dec.contig_names, dec.contig_len):
+            if n not in seq_of or len(seq_of[n]) != int(l):
+                raise ValueError("contig %s of the BAM header is missing from %s or has another length" % (n, ref_fasta))
+        eng.set_contigs(dec.contig_len)
+        for tid, n in enumerate(dec.contig_names):
+            eng.load_reference(tid, seq_of[n])
+        eng.set_barcodes(bc.celltype_of, len(cts))
+        contig["names"] = dec.contig_names
+
+    if comm.world > 1:
+        t0 = time.time()
+        dec = hostio.decode_bam(bam, bc.barcodes, min_mapq=params.min_mapping_quality, threads=max(1, (os.cpu_count() or 1) // comm.world))
+        bounds = regions.balanced_boundaries(dec.records, len(dec.contig_names), comm.world)
+        lo, hi = bounds[comm.rank], bounds[comm.rank + 1]
+        mine = dec.records.subset(regions.reads_overlapping(dec.records, lo, hi))
+        t["decode"] = time.time() - t0
+        work = iter([(lo, hi, mine, dec)])
+        report = dict(dec.report)
+    else:
+        batches = hostio.stream_bam(bam, bc.barcodes, min_mapq=params.min_mapping_quality, batch_bytes=int(window_bytes))
+        first = next(batches, None)
+        if first is None:
+            raise ValueError("%s holds no BAM records" % bam)
+
+        def chained():
+            yield first
+            yield from batches
+        work = _prefetch(_windows(chained(), len(first.contig_names)))
+    kept: Dict[tuple, str] = {}
+    n_windows = 0
+    for lo, hi, rec, dec in work:
+        if not contig:
+            setup(dec)
+        names = contig["names"]
+        if comm.world == 1:
+            for k, v in dec.report.items():
+                report[k] = report.get(k, 0) + v
+        n_windows += 1
+        t0 = time.time()
+        eng.load_reads(rec)
+        eng.set_region(lo[0], lo[1], hi[0], hi[1])
+        check_depth_cap(eng, "%s %s-%s" % (sample_id, lo, hi))
+        t["load"] += time.time() - t0
+        t0 = time.time()
+        eng.pileup_count(params.count())
+        eng.call_step1(params.call())
+        t["gpu_count_call"] += time.time() - t0
+        t0 = time.time()
+        per_ct = [eng.fetch_counts(ct) for ct in range(len(cts))]
+        calls = eng.fetch_calls()
+        t["fetch"] += time.time() - t0
+        t0 = time.time()
+        ckeys = calls["key"] if len(calls) else np.zeros(0, np.int64)
+        for tid in np.unique(ckeys >> 32).tolist():
+            k_lo, k_hi = tid << 32, (tid + 1) << 32
+            sl = [slice(int(np.searchsorted(k, k_lo)), int(np.searchsorted(k, k_hi))) for k, _, _ in per_ct]
+            sub = [(k[s_], r[s_], c[s_]) for (k, r, c), s_ in zip(per_ct, sl)]
+            c0, c1 = int(np.searchsorted(ckeys, k_lo)), int(np.searchsorted(ckeys, k_hi))
+            start1 = int(ckeys[c0] & 0xFFFFFFFF) + 1
+            chrom = names[tid]
+            for ct, name in enumerate(cts):
+                if len(sub[ct][0]):
+                    tsvio.write_counts_tsv(regions.piece_path(tmp, chrom, start1, "counts." + name), *sub[ct], names, "", header=False)
+            tsvio.write_merged_tsv(regions.piece_path(tmp, chrom, start1, "merged"), sub, names, cts, header=False)
+            kept[(chrom, start1)] = tsvio.write_step1_tsv(regions.piece_path(tmp, chrom, start1, "step1"), calls[c0:c1], sub, names, cts, [], header=False)
+        t["write_tables"] += time.time() - t0
+    if not contig:                                     # a rank (or a file) without reads: still needs the contig names for the headers
+        setup(dec if comm.world > 1 else first)
+    names = contig["names"]
+    # the candidate rows of every region on every rank (RCCL all-gather over xGMI when world > 1); then the pieces are complete
+    payloads = comm.allgather_bytes(regions.pack_rows(kept))
+    comm.barrier()
+    out = SnvOutputs(report=os.path.join(d["SplitBam"], sample_id + ".report.txt"), counts={}, merged="", step1="", step2="", step3="", step3_unfiltered="")
+    for name in cts:
+        out.counts[name] = os.path.join(d["BaseCellCounter/" + sample_id], "%s.%s.tsv" % (sample_id, name))
+    out.merged = os.path.join(d["MergeCounts"], sample_id + ".BaseCellCounts.AllCellTypes.tsv")
+    out.step1 = os.path.join(d["BaseCellCalling"], sample_id + ".calling.step1.tsv")
+    out.step2 = os.path.join(d["BaseCellCalling"], sample_id + ".calling.step2.tsv")
+    out.step3 = os.path.join(d["BaseCellCalling"], sample_id + ".calling.step3.tsv")
+    out.step3_unfiltered = os.path.join(d["BaseCellCalling"], sample_id + ".calling.step3.unfiltered.tsv")
+    t["windows"] = n_windows
+    if comm.rank == 0:
+        t0 = time.time()
+        date = tsvio.file_date()
+        write_report(out.report, report, t["decode"] if comm.world > 1 else time.time() - t_all)
+        for name in cts:
+            regions.concatenate_pieces(tmp, "counts." + name, tsvio.counts_header("%s.%s" % (sample_id, name), date), out.counts[name])
+        mh = tsvio.merged_header(cts, date)
+        regions.concatenate_pieces(tmp, "merged", mh, out.merged)
+        s1h = tsvio.step1_header([l + "\n" for l in mh.split("\n") if l.startswith("##")], cts)
+        regions.concatenate_pieces(tmp, "step1", s1h, out.step1)
+        t["concatenate"] = time.time() - t0
+        t0 = time.time()
+        s1 = s1h + regions.unpack_rows(payloads)
+        keys = [calling.read_posset_keys(p, names, params.reference_gz_compat) for p in (editing, pon_sr, pon_lr)]
+        s2 = calling.step2(s1, eng, names, keys[0], keys[1], keys[2], params.min_distance, calling.open_gnomad(gnomad_af_json), params.max_gnomad_vaf)
+        open(out.step2, "w").write(s2)
+        t["step2"] = time.time() - t0
+        t0 = time.time()
+        final, unfiltered = calling.step3(s2, params.delta_vaf, params.delta_mcf, params.min_ac_reads, params.min_ac_cells, params.clust_dist)
+        open(out.step3, "w").write(final)
+        open(out.step3_unfiltered, "w").write(unfiltered)
+        t["step3"] = time.time() - t0
+        import shutil
+        shutil.rmtree(tmp, ignore_errors=True)
+    comm.barrier()
+    out.timings = t
+    return out
 
 
 @dataclass

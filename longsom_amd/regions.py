@@ -1,0 +1,175 @@
+"""Genomic regions as the unit of parallelism of the SNV chain: over GPUs (one rank per GPU) and over time (windows).
+
+The reference fans 50 kb windows out to a process pool, every worker writes `<chrom>__<start>__<end>.BaseCellCounts.temp`
+and the parent concatenates the temp files in (chrom string, start) order (workflow/scripts/SNVCalling/BaseCellCounter.py:
+12-19 collect_result, :22-79 concatenate_sort_temp_files_and_write, :392-402 the pool).  Here a region is a contiguous range
+of 64-position tiles in (contig, position) order, much larger than 50 kb:
+  * N GPUs: the decoded reads are cut into N regions of about equal EVENT count; rank r loads the reads that overlap its
+    region (reads crossing a boundary are loaded on both sides), lsg_set_region makes every column belong to exactly one
+    rank (the analogue of `POS >= START and POS < END`, :200), the rank writes its rows as per-contig piece files and the
+    ranks all-gather (RCCL) the candidate rows step 2 and step 3 need; rank 0 concatenates the pieces and runs steps 2-3.
+  * one GPU, a BAM larger than HBM: the BAM is streamed in batches (hostio.stream_bam); a window's region ends where the
+    next batch's first read starts, reads that reach past that point are carried into the next window.
+"""
+import os
+import re
+import shutil
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .engine import ReadRecords
+
+TILE = 64
+Pos = Tuple[int, int]          # (tid, 0-based position)
+
+
+def read_ends(rec: ReadRecords) -> np.ndarray:
+    """first reference position after the last pileup column of every read (pos + 1 for a read without columns)"""
+    end = rec.read_pos.astype(np.int64) + 1
+    if rec.n_segs:
+        # a read's segments are adjacent and ascending: its last segment ends the read
+        last = np.flatnonzero(np.diff(rec.seg_read.astype(np.int64), append=-1) != 0)
+        end[rec.seg_read[last]] = rec.seg_start[last].astype(np.int64) + rec.seg_len[last]
+    return end
+
+
+def read_events(rec: ReadRecords) -> np.ndarray:
+    if not rec.n_segs:
+        return np.zeros(rec.n_reads, np.int64)
+    return np.bincount(rec.seg_read, weights=rec.seg_len, minlength=rec.n_reads).astype(np.int64)
+
+
+def balanced_boundaries(rec: ReadRecords, n_contigs: int, world: int) -> List[Pos]:
+    """world + 1 boundaries (tid, pos) with pos a multiple of 64: region r = [b[r], b[r+1]).  The reads arrive in coordinate
+    order; boundary r sits at the start tile of the read at which the running EVENT count passes r/world of the total, so every
+    rank walks about the same number of events whatever the expression profile (a chromosome-wise split would leave chr1 and
+    chrM on one rank each).  Deterministic in the read arrays: every rank computes the same list."""
+    bounds: List[Pos] = [(0, 0)]
+    if rec.n_reads and world > 1:
+        cum = np.cumsum(read_events(rec) + 24)                       # + the per-read header cost, so that empty reads still count
+        tot = int(cum[-1])
+        for r in range(1, world):
+            i = int(np.searchsorted(cum, tot * r // world, side="left"))
+            i = min(i, rec.n_reads - 1)
+            b = (int(rec.read_tid[i]), (int(rec.read_pos[i]) // TILE) * TILE)
+            bounds.append(max(b, bounds[-1]))
+    else:
+        bounds += [(n_contigs, 0)] * (world - 1)
+    bounds.append((n_contigs, 0))
+    return bounds
+
+
+def reads_overlapping(rec: ReadRecords, lo: Pos, hi: Pos, ends: Optional[np.ndarray] = None) -> np.ndarray:
+    """mask of the reads with a pileup column in [lo, hi) — a superset is fine (the device counts only the region's columns)"""
+    ends = read_ends(rec) if ends is None else ends
+    tid = rec.read_tid.astype(np.int64)
+    start_key = (tid << 32) | rec.read_pos.astype(np.int64).clip(0)
+    end_key = (tid << 32) | ends
+    return (start_key < ((hi[0] << 32) | hi[1])) & (end_key > ((lo[0] << 32) | lo[1]))
+
+
+# ---- piece files -----------------------------------------------------------------------------------------------------------------
+_PIECE = re.compile(r"^(?P<chrom>.+)__(?P<start>\d+)\.(?P<table>[^.]+(?:\.[^.]+)*)\.temp$")
+
+
+def piece_path(tmp_dir: str, chrom: str, start1: int, table: str) -> str:
+    """<tmp>/<chrom>__<start>.<table>.temp — the reference's temp-file naming (BaseCellCounter.py:318-319) minus the end coordinate"""
+    return os.path.join(tmp_dir, "%s__%d.%s.temp" % (chrom, start1, table))
+
+
+def concatenate_pieces(tmp_dir: str, table: str, header: str, out_path: str) -> int:
+    """header + the table's pieces in (chrom string, start) order (BaseCellCounter.py:64-70); pieces hold rows only, so this is a
+    byte copy.  Returns the number of pieces."""
+    found = []
+    for name in os.listdir(tmp_dir):
+        m = _PIECE.match(name)
+        if m and m.group("table") == table:
+            found.append((m.group("chrom"), int(m.group("start")), os.path.join(tmp_dir, name)))
+    found.sort()
+    with open(out_path, "wb") as out:
+        out.write(header.encode())
+        for _, _, p in found:
+            with open(p, "rb") as f:
+                shutil.copyfileobj(f, out, 1 << 24)
+    return len(found)
+
+
+# ---- exchange --------------------------------------------------------------------------------------------------------------------
+@dataclass
+class Comm:
+    """The process group of one run (torch.distributed; backend nccl = RCCL over xGMI on the GPU node, gloo in CPU tests)."""
+    world: int = 1
+    rank: int = 0
+    device: Optional[object] = None        # torch.device the collectives' tensors live on (cuda:<local rank> for nccl)
+
+    @classmethod
+    def from_env(cls, device_index: Optional[int] = None) -> "Comm":
+        """WORLD_SIZE / RANK / LOCAL_RANK as torch.distributed.run sets them.  Must run BEFORE the first HIP call of the process
+        when RCCL is the backend.  LSG_DIST_BACKEND=gloo (+ LSG_DIST_DEVICE) rehearses several ranks on one GPU."""
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        if world <= 1:
+            return cls()
+        import torch
+        import torch.distributed as dist
+        rank = int(os.environ.get("RANK", "0"))
+        backend = os.environ.get("LSG_DIST_BACKEND", "nccl")
+        local = int(os.environ.get("LSG_DIST_DEVICE", os.environ.get("LOCAL_RANK", "0"))) if device_index is None else device_index
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        if not dist.is_initialized():
+            dist.init_process_group(backend, rank=rank, world_size=world)
+        return cls(world, rank, torch.device("cuda", local) if backend == "nccl" else torch.device("cpu"))
+
+    @property
+    def local_device_index(self) -> int:
+        return int(os.environ.get("LSG_DIST_DEVICE", os.environ.get("LOCAL_RANK", "0"))) if self.world > 1 else 0
+
+    def barrier(self) -> None:
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    def allgather_bytes(self, payload: bytes) -> List[bytes]:
+        """every rank's payload on every rank: one all-gather of the lengths, one of the padded bytes"""
+        if self.world == 1:
+            return [payload]
+        import torch
+        import torch.distributed as dist
+        n = torch.tensor([len(payload)], dtype=torch.int64, device=self.device)
+        sizes = torch.zeros(self.world, dtype=torch.int64, device=self.device)
+        dist.all_gather_into_tensor(sizes, n)
+        sizes = sizes.cpu().tolist()
+        cap = max(1, max(sizes))
+        send = torch.zeros(cap, dtype=torch.uint8, device=self.device)
+        if payload:
+            send[: len(payload)] = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(self.device)
+        recv = torch.zeros(self.world * cap, dtype=torch.uint8, device=self.device)
+        dist.all_gather_into_tensor(recv, send)
+        recv = recv.cpu().numpy()
+        return [recv[r * cap: r * cap + sizes[r]].tobytes() for r in range(self.world)]
+
+    def close(self) -> None:
+        if self.world > 1:
+            import torch.distributed as dist
+            if dist.is_initialized():
+                dist.destroy_process_group()
+
+
+def pack_rows(pieces: Dict[Tuple[str, int], str]) -> bytes:
+    """{(chrom, start): text of the rows step 2 keeps} -> bytes for allgather_bytes"""
+    import json
+    return json.dumps([[c, s, t] for (c, s), t in sorted(pieces.items())]).encode()
+
+
+def unpack_rows(payloads: Sequence[bytes]) -> str:
+    """all ranks' kept rows in (chrom string, start) order — file order of the step-1 table they were cut from"""
+    import json
+    allp = []
+    for b in payloads:
+        allp += [tuple(x) for x in json.loads(b.decode())] if b else []
+    allp.sort(key=lambda x: (x[0], x[1]))
+    return "".join(t for _, _, t in allp)

@@ -180,35 +180,49 @@ def _per_ct_ptrs(per_ct):
     return ks, rs, cs, arr(ks), arr(rs), arr(cs), n
 
 
-def write_counts_tsv(path, keys, refs, counts, contig_names, sample_id, date_line=None, threads: int = 0) -> None:
-    """format_counts_tsv straight to `path` (BaseCellCounter.py:300-308)."""
+def counts_header(sample_id, date_line=None) -> str:
+    return "".join([date_line or file_date(), _CONCEPTS, "\t".join(["#CHROM", "POS", "REF", "INFO", str(sample_id)]) + "\n"])
+
+
+def merged_header(celltype_names, date_line=None) -> str:
+    return "".join([date_line or file_date(), _CONCEPTS, "\t".join(["#CHROM", "Start", "End", "REF", "INFO"] + list(celltype_names)) + "\n"])
+
+
+def step1_header(header_lines: List[str], celltype_names) -> str:
+    return "".join(list(header_lines) + [l + "\n" for l in STEP1_INFO_LINES] +
+                   ["\t".join(["#CHROM", "Start", "End", "REF", "\t".join(STEP1_COLUMNS), "INFO"] + list(celltype_names)) + "\n"])
+
+
+def write_counts_tsv(path, keys, refs, counts, contig_names, sample_id, date_line=None, threads: int = 0, header: bool = True) -> None:
+    """format_counts_tsv straight to `path` (BaseCellCounter.py:300-308).  header=False: the rows only (a window's piece of the
+    table, the analogue of the reference's <chrom>__<start>__<end>.BaseCellCounts.temp, :12-19)."""
     lib = _io()
     with open(path, "w") as f:
-        f.write("".join([date_line or file_date(), _CONCEPTS, "\t".join(["#CHROM", "POS", "REF", "INFO", str(sample_id)]) + "\n"]))
+        f.write(counts_header(sample_id, date_line) if header else "")
     k = np.ascontiguousarray(keys, np.int64); r = np.ascontiguousarray(refs, np.uint8); c = np.ascontiguousarray(counts, np.uint32).reshape(-1, 42)
     _check(lib, lib.lsio_write_count_rows(os.fsencode(path), "\n".join(contig_names).encode(), len(contig_names), k.ctypes.data, r.ctypes.data, c.ctypes.data,
                                           len(k), threads), "lsio_write_count_rows")
 
 
-def write_merged_tsv(path, per_ct, contig_names, celltype_names, date_line=None, threads: int = 0) -> List[str]:
+def write_merged_tsv(path, per_ct, contig_names, celltype_names, date_line=None, threads: int = 0, header: bool = True) -> List[str]:
     """format_merged_tsv straight to `path`; returns the '##' header lines (step 1 copies them through)."""
     lib = _io()
     head = [date_line or file_date(), _CONCEPTS]
     with open(path, "w") as f:
-        f.write("".join(head + ["\t".join(["#CHROM", "Start", "End", "REF", "INFO"] + list(celltype_names)) + "\n"]))
+        f.write(merged_header(celltype_names, head[0]) if header else "")
     ks, rs, cs, pk, pr, pc, n = _per_ct_ptrs(per_ct)
     _check(lib, lib.lsio_write_merged_rows(os.fsencode(path), "\n".join(contig_names).encode(), len(contig_names), len(per_ct), pk, pr, pc, n.ctypes.data, threads),
            "lsio_write_merged_rows")
     return [l + "\n" for l in "".join(head).split("\n") if l.startswith("##")]
 
 
-def write_step1_tsv(path, calls, per_ct, contig_names, celltype_names, header_lines: List[str], threads: int = 0) -> str:
+def write_step1_tsv(path, calls, per_ct, contig_names, celltype_names, header_lines: List[str], threads: int = 0, header: bool = True) -> str:
     """format_step1_tsv straight to `path`.  Returns the SMALL text step 2 needs: the comment lines, the column header and the
-    rows its awk filter keeps (ALT != "." and FILTER != ".", BaseCellCalling.step2.py:23)."""
+    rows its awk filter keeps (ALT != "." and FILTER != ".", BaseCellCalling.step2.py:23); header=False: the file gets the rows only
+    and the kept rows come back without the header."""
     import ctypes as C
     lib = _io()
-    head = "".join(list(header_lines) + [l + "\n" for l in STEP1_INFO_LINES] +
-                   ["\t".join(["#CHROM", "Start", "End", "REF", "\t".join(STEP1_COLUMNS), "INFO"] + list(celltype_names)) + "\n"])
+    head = step1_header(header_lines, celltype_names) if header else ""
     with open(path, "w") as f:
         f.write(head)
     ks, rs, cs, pk, pr, pc, n = _per_ct_ptrs(per_ct)

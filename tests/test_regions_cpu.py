@@ -1,0 +1,117 @@
+"""CPU: the region machinery of the sharded / windowed SNV chain (longsom_amd/regions.py, pipeline._windows), checked with the CPU
+oracle standing in for the device: counting region by region — with the boundary-crossing reads loaded on both sides — gives the rows
+of one count over everything; pieces are concatenated in the reference's (chrom string, start) order; the byte all-gather works over
+a 2-rank gloo group."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from longsom_amd import hostio, pipeline, regions, tsvio
+from oracle import loader
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+BAM = os.path.join(G, "pileup.rand.bam")
+
+
+def inputs():
+    bc = hostio.read_barcodes(os.path.join(G, "pileup.rand.barcodes.tsv"))
+    names, seqs = tsvio.read_fasta(os.path.join(G, "pileup.rand.fa"))
+    return bc, names, seqs, [len(s) for s in seqs]
+
+
+def rows_in(rec, lens, refs, bc, ct, lo, hi):
+    k, r, c, _ = loader.count(rec, lens, refs, bc.celltype_of, ct)
+    m = (k >= pipeline._key(lo)) & (k < pipeline._key(hi))
+    return k[m], r[m], c[m]
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_event_balanced_regions_reproduce_the_whole_count(world):
+    bc, names, refs, lens = inputs()
+    dec = hostio.decode_bam(BAM, bc.barcodes)
+    b = regions.balanced_boundaries(dec.records, len(names), world)
+    assert b[0] == (0, 0) and b[-1] == (len(names), 0) and len(b) == world + 1
+    assert all(pipeline._key(x) <= pipeline._key(y) for x, y in zip(b, b[1:])) and all(p % 64 == 0 for _, p in b)
+    ev = regions.read_events(dec.records)
+    for ct in range(2):
+        whole = loader.count(dec.records, lens, refs, bc.celltype_of, ct)
+        parts = []
+        for r in range(world):
+            mine = dec.records.subset(regions.reads_overlapping(dec.records, b[r], b[r + 1]))
+            parts.append(rows_in(mine, lens, refs, bc, ct, b[r], b[r + 1]))
+        for i in range(3):
+            assert np.array_equal(np.concatenate([p[i] for p in parts]), whole[i])
+    # balance: no rank holds more than twice its share of the events (the sample has a 60 kb contig and three small ones)
+    if world <= 3:
+        start = (dec.records.read_tid.astype(np.int64) << 32) | dec.records.read_pos
+        share = [ev[(start >= pipeline._key(b[r])) & (start < pipeline._key(b[r + 1]))].sum() for r in range(world)]
+        assert max(share) < 2.0 * ev.sum() / world
+
+
+@pytest.mark.parametrize("batch", [2000, 70000, 140000])
+def test_windows_with_carried_reads_reproduce_the_whole_count(batch):
+    bc, names, refs, lens = inputs()
+    whole_dec = hostio.decode_bam(BAM, bc.barcodes)
+    wins = list(pipeline._windows(hostio.stream_bam(BAM, bc.barcodes, batch_bytes=batch), len(names)))
+    assert len(wins) > 1 and wins[0][0] == (0, 0) and wins[-1][1] == (len(names), 0)
+    assert all(a[1] == b[0] for a, b in zip(wins, wins[1:]))
+    report = {}
+    for _, _, _, dec in wins:
+        for k, v in dec.report.items():
+            report[k] = report.get(k, 0) + v
+    assert report == whole_dec.report
+    for ct in range(2):
+        whole = loader.count(whole_dec.records, lens, refs, bc.celltype_of, ct)
+        parts = [rows_in(rec, lens, refs, bc, ct, lo, hi) for lo, hi, rec, _ in wins]
+        for i in range(3):
+            assert np.array_equal(np.concatenate([p[i] for p in parts]), whole[i])
+
+
+def test_prefetch_hands_over_items_and_errors():
+    assert list(pipeline._prefetch(iter(range(5)))) == [0, 1, 2, 3, 4]
+
+    def boom():
+        yield 1
+        raise KeyError("x")
+    g = pipeline._prefetch(boom())
+    assert next(g) == 1
+    with pytest.raises(KeyError):
+        next(g)
+
+
+def test_pieces_are_concatenated_in_chrom_string_then_start_order(tmp_path):
+    for chrom, start in (("chr2", 5), ("chr10", 700), ("chr1", 50001), ("chr1", 2), ("chrM", 1), ("chr10", 64)):
+        open(regions.piece_path(str(tmp_path), chrom, start, "counts.Non-Cancer"), "w").write("%s\t%d\n" % (chrom, start))
+    open(regions.piece_path(str(tmp_path), "chr1", 1, "merged"), "w").write("other table\n")
+    out = tmp_path / "o.tsv"
+    assert regions.concatenate_pieces(str(tmp_path), "counts.Non-Cancer", "#h\n", str(out)) == 6
+    assert out.read_text() == "#h\nchr1\t2\nchr1\t50001\nchr10\t64\nchr10\t700\nchr2\t5\nchrM\t1\n"        # BaseCellCounter.py:64-70
+
+
+def _rank_main(rank, world, port, q):
+    os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LSG_DIST_BACKEND="gloo")
+    comm = regions.Comm.from_env()
+    kept = {("chr%d" % (rank + 1), 100 * rank + 1): "row of rank %d\n" % rank, ("chr1", 5000 + rank): "late row %d\n" % rank} if rank else {}
+    got = comm.allgather_bytes(regions.pack_rows(kept))
+    comm.barrier()
+    q.put((rank, regions.unpack_rows(got)))
+    comm.close()
+
+
+def test_allgather_bytes_over_gloo():
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world = 3
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    want = "late row 1\nlate row 2\nrow of rank 1\nrow of rank 2\n"       # (chr1, 5001), (chr1, 5002), (chr2, 101), (chr3, 201)
+    assert res == {0: want, 1: want, 2: want}

@@ -1,0 +1,79 @@
+"""GPU: the sharded and the windowed forms of the fused SNV run write, byte for byte, the files of the single-pass run.
+  * windows: the BAM streamed in small batches, counted window by window with carried reads (a BAM larger than HBM);
+  * ranks: two ranks under torch.distributed.run, regions balanced by events, candidate rows all-gathered — rehearsed on the
+    one-GPU box with both ranks on device 0 and the collectives over gloo (RCCL refuses two ranks on one GPU; on the 8-GPU node
+    the same code path runs with LSG_DIST_BACKEND unset = nccl)."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from longsom_amd import hostio, pipeline, synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+RELS = ["BaseCellCounter/S1/S1.Cancer.tsv", "BaseCellCounter/S1/S1.Non-Cancer.tsv", "MergeCounts/S1.BaseCellCounts.AllCellTypes.tsv",
+        "BaseCellCalling/S1.calling.step1.tsv", "BaseCellCalling/S1.calling.step2.tsv", "BaseCellCalling/S1.calling.step3.tsv",
+        "BaseCellCalling/S1.calling.step3.unfiltered.tsv"]
+
+
+def strip_date(path):
+    return "\n".join(l for l in open(path).read().split("\n") if not l.startswith("##fileDate="))
+
+
+def same_outputs(a, b):
+    for rel in RELS:
+        assert strip_date(os.path.join(a, rel)) == strip_date(os.path.join(b, rel)), rel
+    ra = open(os.path.join(a, "SplitBam/S1.report.txt")).read().split("\n")
+    rb = open(os.path.join(b, "SplitBam/S1.report.txt")).read().split("\n")
+    assert ra[0] == rb[0] and ra[1].split("\t")[:-1] == rb[1].split("\t")[:-1]
+
+
+@pytest.fixture(scope="module")
+def sample(tmp_path_factory):
+    d = tmp_path_factory.mktemp("regions")
+    m = synth.named("C1", n_reads=24000, n_genes=60, n_cb=90, snp_mod=200)
+    bam, fa, bct = str(d / "S1.bam"), str(d / "ref.fa"), str(d / "barcodes.tsv")
+    hostio.synth_bam(m, bam, fa)
+    hostio.write_barcodes_tsv(bct, hostio.synth_barcodes(m), m.celltype_of, ["Cancer", "Non-Cancer"])
+    whole = str(d / "whole")
+    pipeline.run_snv(bam, bct, fa, whole, "S1")
+    assert sum(1 for l in open(os.path.join(whole, RELS[5])) if not l.startswith("#")) > 0
+    return bam, fa, bct, whole, d
+
+
+@pytest.mark.parametrize("window_bytes", [300_000, 4_000_000])
+def test_windowed_run_equals_whole_run(sample, window_bytes):
+    bam, fa, bct, whole, d = sample
+    out_dir = str(d / ("win%d" % window_bytes))
+    out = pipeline.run_snv(bam, bct, fa, out_dir, "S1", window_bytes=window_bytes)
+    assert out.timings["windows"] >= (20 if window_bytes < 1_000_000 else 2)
+    same_outputs(out_dir, whole)
+    assert not os.path.exists(os.path.join(out_dir, "_pieces.S1"))
+
+
+def test_windowed_run_of_the_reference_pinned_sample(tmp_path):
+    """the multi-contig fixture (file order chr1, chr10, chr2, chrM): windows == the tables the reference's code wrote"""
+    out = pipeline.run_snv(os.path.join(G, "pileup.rand.bam"), os.path.join(G, "pileup.rand.barcodes.tsv"), os.path.join(G, "pileup.rand.fa"),
+                           str(tmp_path), "s", window_bytes=50_000)
+    assert out.timings["windows"] > 3
+    for cname in ("Cancer", "Non-Cancer"):
+        got = "".join(l for l in open(out.counts[cname]).read().splitlines(True) if not l.startswith("##fileDate="))
+        assert got == open(os.path.join(G, "pileup.rand.%s.tsv" % cname)).read()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_sharded_run_equals_whole_run(sample, world):
+    bam, fa, bct, whole, d = sample
+    out_dir = str(d / ("ranks%d" % world))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, LSG_DIST_BACKEND="gloo", LSG_DIST_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "workflow", "scripts_gpu", "SNVCalling", "longsom_gpu_snv.py"), "--bam", bam, "--meta", bct, "--ref", fa, "--id", "S1", "--outdir", out_dir]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert '"ranks": %d' % world in r.stdout
+    same_outputs(out_dir, whole)
