@@ -87,6 +87,11 @@ typedef struct {
                               0x4|0x100|0x200|0x400 (pysam pileup flag_filter) | 0x800
                               (BaseCellCounter.py:249) = 0xF04 */
     int32_t ignore_orphans;/* 1: drop paired reads that are not proper pairs (pysam default) */
+    int32_t max_depth;     /* bam.pileup(..., max_depth = 200000), BaseCellCounter.py:191 — htslib's bam_plp_push rule, applied to
+                              every cell type's read stream (= its SplitBam output): a read that is not the first of its start
+                              position is dropped while the reads still buffered (end >= that position, counting secondary-free,
+                              MAPQ- and orphan-filtered reads INCLUDING supplementary ones) + 1 exceed max_depth.  0 = no cap.
+                              Costs nothing while lsg_max_live_reads() <= max_depth (no read can be dropped then). */
 } lsg_count_params;
 
 /* Parameters of the step-1 call (BaseCellCalling.step1.py:585-604). */
@@ -160,12 +165,13 @@ int lsg_set_barcodes(lsg_ctx* ctx, const uint8_t* celltype_of, int32_t n_cb, int
 int lsg_load_reads(lsg_ctx* ctx, const lsg_reads* reads);
 /* The reference counts through bam.pileup(..., max_depth = 200000) (BaseCellCounter.py:191,
  * HCCVSingleCellGenotype.py:122): htslib stops admitting reads at a position while more than max_depth are
- * live in its buffer.  That cap is NOT modelled here; instead this call evaluates an upper bound on the live
- * reads of every cell-type BAM under the current barcode table (reads of one cell type whose span touches a
- * 64-position tile, maximum over tiles and cell types; before lsg_set_barcodes: all reads with a barcode).
- * While the bound stays <= 200000 the cap can never have fired in the reference and results are identical;
- * above it the caller must decide (the host mirror raises).  Off the hot path: computed on request and cached
- * until the reads or the barcode table change.  Returns the bound, -1 on error. */
+ * live in its buffer.  lsg_pileup_count models that cap exactly (lsg_count_params.max_depth); this call evaluates
+ * the upper bound it uses to skip the work: the live reads of every cell-type BAM under the current barcode table
+ * (reads of one cell type whose span touches a 64-position tile, maximum over tiles and cell types; before
+ * lsg_set_barcodes: all reads with a barcode).  While the bound stays <= max_depth the cap cannot fire.
+ * lsg_genotype_cells does NOT model the cap (its pileup runs over the unsplit BAM, HCCVSingleCellGenotype.py:122):
+ * there the host mirror checks this bound and warns or raises.  Computed on request and cached until the reads or
+ * the barcode table change.  Returns the bound, -1 on error. */
 int64_t lsg_max_live_reads(lsg_ctx* ctx);
 /* Restrict counting to the genomic region [ (tid_lo,pos_lo), (tid_hi,pos_hi) ) in (tid,pos) order;
  * positions must be multiples of 64.  This is how windows are sharded over GPUs: every rank loads

@@ -38,13 +38,13 @@ class Reads(C.Structure):
 class CountParams(C.Structure):
     _fields_ = [
         ("min_bq", C.c_int32), ("min_mq", C.c_int32), ("min_dp", C.c_int32), ("min_cc", C.c_int32),
-        ("flag_exclude", C.c_uint32), ("ignore_orphans", C.c_int32),
+        ("flag_exclude", C.c_uint32), ("ignore_orphans", C.c_int32), ("max_depth", C.c_int32),
     ]
 
     @classmethod
     def longsom_defaults(cls, **kw):
-        """Flags as LongSom's rules run BaseCellCounter (R:SNVCalling.smk:52-59, BaseCellCounter.py:331-339)."""
-        p = cls(min_bq=20, min_mq=60, min_dp=5, min_cc=5, flag_exclude=0xF04, ignore_orphans=1)
+        """Flags as LongSom's rules run BaseCellCounter (R:SNVCalling.smk:52-59, BaseCellCounter.py:331-339; max_depth :191)."""
+        p = cls(min_bq=20, min_mq=60, min_dp=5, min_cc=5, flag_exclude=0xF04, ignore_orphans=1, max_depth=200000)
         for k, v in kw.items():
             setattr(p, k, v)
         return p

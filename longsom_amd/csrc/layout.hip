@@ -5,6 +5,8 @@
 // ~1.7 lines an arbitrary 2-byte alignment costs (measured: 31.5 GB -> see DESIGN.md), and neighbouring tiles of a
 // segment never share a line.  Padding events are 0 (= not countable) and are never read.
 #include "lsg_ctx.h"
+#include <algorithm>
+#include <vector>
 #include <hipcub/hipcub.hpp>
 
 namespace lsg {
@@ -51,7 +53,8 @@ __global__ void k_span_marks(const uint32_t* seg_read, const int32_t* seg_start,
     if (celltype_of && (cb >= n_cb || celltype_of[cb] != ct)) return;
     const bool first = s == 0 || seg_read[s - 1] != r, last = s + 1 == n_segs || seg_read[s + 1] != r;
     if (!first && !last) return;
-    int64_t st = seg_start[s], en = st + (seg_len[s] > 0 ? seg_len[s] - 1 : 0);
+    // the read is still buffered while the column AFTER its last one is entered (freed by that column's sweep): span end inclusive
+    int64_t st = seg_start[s], en = st + (seg_len[s] > 0 ? seg_len[s] : 0);
     const uint32_t tb = tile_base[tid], te = tile_base[tid + 1];
     if (te <= tb) return;
     if (st < 0) st = 0;
@@ -93,6 +96,79 @@ int live_read_bound(lsg_ctx* c) {
     }
     c->max_live_reads = best;
     return fail(0);
+}
+
+// first reference position after a read's last pileup column (its last segment's end; pos + 1 without segments)
+__global__ void k_read_end(const uint32_t* seg_read, const int32_t* seg_start, const int32_t* seg_len, int64_t n_segs, int32_t* read_end) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_segs) return;
+    const uint32_t r = seg_read[s];
+    if (s + 1 == n_segs || seg_read[s + 1] != r) read_end[r] = seg_start[s] + seg_len[s];
+}
+__global__ void k_read_end_init(const int32_t* read_pos, int64_t n_reads, int32_t* read_end) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n_reads) read_end[r] = read_pos[r] + 1;
+}
+
+// bam.pileup(..., max_depth) as htslib applies it (sam.c bam_plp_push / bam_plp_next; BaseCellCounter.py:191), per cell type's read
+// stream.  Stream of cell type c = the records SplitBamCellTypes wrote to its BAM (barcode of that type, MAPQ >= min_mq) that the
+// pileup's read filter lets in (flag_exclude without the supplementary bit, which only BaseCellCounter.py:249 tests later;
+// ignore_orphans; min_mq).  In coordinate order: the first read of a start position P always enters the buffer; every later read
+// starting at P is dropped iff (reads buffered, i.e. entered and ending at or after P) + 1 > max_depth — mp->cnt counts the spare
+// tail node, and reads whose last column was P - 1 are only freed while column P is swept.  Sequential by nature (what was dropped
+// decides what is buffered), so it runs on the host — but only when lsg_max_live_reads() says a buffer can reach max_depth at all.
+int depth_cap_drops(lsg_ctx* c, const lsg_count_params* p) {
+    c->has_drops = false; c->n_depth_dropped = 0;
+    if (p->max_depth <= 0 || c->rd.n_reads <= 0 || c->n_ct <= 0) return 0;
+    if (live_read_bound(c)) return -1;
+    if (c->max_live_reads + 1 <= (int64_t)p->max_depth) return 0;          // no buffer can exceed the cap: nothing is ever dropped
+    hipStream_t st = c->stream;
+    const int64_t R = c->rd.n_reads, S = c->rd.n_segs;
+    DevBuf d_end;
+    if (d_end.reserve((size_t)R * 4)) return -1;
+    hipLaunchKernelGGL(k_read_end_init, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, c->rd.read_pos, R, d_end.as<int32_t>());
+    if (S > 0) hipLaunchKernelGGL(k_read_end, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, st, c->rd.seg_read, c->rd.seg_start, c->rd.seg_len, S, d_end.as<int32_t>());
+    std::vector<int32_t> tid((size_t)R), pos((size_t)R), end((size_t)R), cb((size_t)R); std::vector<uint16_t> flag((size_t)R); std::vector<uint8_t> mapq((size_t)R);
+    std::vector<uint8_t> ctof((size_t)c->n_cb);
+    auto cp = [&](void* dst, const void* src, size_t n) { return hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, st) != hipSuccess; };
+    if (cp(tid.data(), c->rd.read_tid, (size_t)R * 4) || cp(pos.data(), c->rd.read_pos, (size_t)R * 4) || cp(end.data(), d_end.p, (size_t)R * 4) ||
+        cp(cb.data(), c->rd.read_cb, (size_t)R * 4) || cp(flag.data(), c->rd.read_flag, (size_t)R * 2) || cp(mapq.data(), c->rd.read_mapq, (size_t)R) ||
+        cp(ctof.data(), c->d_celltype_of.p, (size_t)c->n_cb) || hipStreamSynchronize(st) != hipSuccess) { d_end.release(); set_error("depth cap: copy failed"); return -1; }
+    d_end.release();
+    // coordinate order (a decoded BAM already is; the synthetic generator's read index is gene order)
+    std::vector<uint32_t> order((size_t)R);
+    for (int64_t i = 0; i < R; ++i) order[(size_t)i] = (uint32_t)i;
+    auto key = [&](uint32_t i) { return ((uint64_t)(uint32_t)tid[i] << 32) | (uint32_t)pos[i]; };
+    bool sorted = true;
+    for (int64_t i = 1; i < R && sorted; ++i) sorted = key((uint32_t)(i - 1)) <= key((uint32_t)i);
+    if (!sorted) std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return key(a) < key(b); });
+    std::vector<uint8_t> drop((size_t)R, 0);
+    const uint32_t pool_flags = p->flag_exclude & ~0x800u;
+    int64_t n_drop = 0;
+    for (int ct = 0; ct < c->n_ct; ++ct) {
+        std::vector<int32_t> heap;                                         // min-heap of the buffered reads' ends
+        auto cmp = [](int32_t a, int32_t b) { return a > b; };
+        int32_t cur_tid = -1, cur_pos = -1; bool first_here = true;
+        for (int64_t k = 0; k < R; ++k) {
+            const uint32_t i = order[(size_t)k];
+            if (tid[i] < 0 || tid[i] >= c->n_contigs || cb[i] < 0 || cb[i] >= c->n_cb || ctof[(size_t)cb[i]] != ct) continue;
+            if ((int)mapq[i] < p->min_mq || (flag[i] & pool_flags)) continue;
+            if (p->ignore_orphans && (flag[i] & 1u) && !(flag[i] & 2u)) continue;
+            if (tid[i] != cur_tid) { heap.clear(); cur_tid = tid[i]; cur_pos = -1; }
+            if (pos[i] != cur_pos) {
+                cur_pos = pos[i]; first_here = true;
+                while (!heap.empty() && heap.front() < cur_pos) { std::pop_heap(heap.begin(), heap.end(), cmp); heap.pop_back(); }      // ended before P: freed
+            }
+            if (!first_here && (int64_t)heap.size() + 1 > (int64_t)p->max_depth) { drop[i] = 1; ++n_drop; continue; }
+            first_here = false;
+            heap.push_back(end[i]); std::push_heap(heap.begin(), heap.end(), cmp);
+        }
+    }
+    if (n_drop == 0) return 0;
+    if (c->d_read_drop.reserve((size_t)R)) return -1;
+    if (hipMemcpyAsync(c->d_read_drop.p, drop.data(), (size_t)R, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { set_error("depth cap: upload failed"); return -1; }
+    c->has_drops = true; c->n_depth_dropped = n_drop;
+    return 0;
 }
 
 int relayout_events(lsg_ctx* c) {

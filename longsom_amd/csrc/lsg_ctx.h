@@ -66,6 +66,7 @@ struct lsg_ctx;
 namespace lsg {
 int relayout_events(lsg_ctx* c);   // layout.hip: tile-aligned copy of the resident events
 int live_read_bound(lsg_ctx* c);   // layout.hip: fills max_live_reads when it is stale (-1)
+int depth_cap_drops(lsg_ctx* c, const lsg_count_params* p);   // layout.hip: htslib's max_depth rule -> d_read_drop (or none)
 }
 
 struct lsg_ctx {
@@ -94,7 +95,14 @@ struct lsg_ctx {
     lsg::DevBuf b_read_tid, b_read_pos, b_read_flag, b_read_mapq, b_read_cb;
     lsg::DevBuf b_seg_read, b_seg_start, b_seg_len, b_seg_ev_off, b_events;
     uint64_t entries_upper = 0;           // sum over segments of tiles overlapped
+    // static per load: entries a tile can ever hold (segments of reads with a barcode that touch it) and their exclusive prefix = the
+    // tile's region of the entry buffer; with <= 2 cell types the scatter fills a region from both ends and needs no counting pass
+    lsg::DevBuf d_tile_cap, d_tile_off, d_cur_lo, d_cur_hi;
+    bool tile_caps_valid = false;
     int64_t max_live_reads = -1;          // layout.hip: bound on the reads live at once in the reference's pileup buffer (-1 = stale)
+    lsg::DevBuf d_read_drop;              // layout.hip: per read, 1 = dropped by the pileup's max_depth rule under the last count's parameters
+    bool has_drops = false;
+    int64_t n_depth_dropped = 0;
 
     // count-stage workspace
     lsg::DevBuf d_read_key, d_unit_cnt, d_unit_off, d_unit_fill;

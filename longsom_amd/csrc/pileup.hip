@@ -59,7 +59,7 @@ constexpr int FLUSH_EVERY = 63;      // packed LDS fields: bq 14 | fwd 6 | cnt 6
 enum { SC_QSMALL = 0, SC_QBIG = 1, SC_NNE = 2, SC_ROWALLOC = 4, SC_COLS = 8, SC_OVERFLOW = 9,
        SC_READS = 10, SC_SEGS = 11, SC_EVENTS = 12, SC_EV_WAVE = 13, SC_EV_DEEP = 14, SC_ROWS_DEEP = 15,
        SC_ROWS = 16, SC_NSMALL = 20, SC_NMULTI = 21, SC_NMULTI_SEL = 22, SC_NHUGE = 24, SC_QHUGE = 25, SC_QBIN0 = 26, SC_QBIN2 = 27,
-       SC_ROWS_SRC = 28, SC_EV_SRC = 32, SC_NCHUNK = 36, SC_QSORT = 37, SC_COUNT = 40 };   // *_SRC[4]: 0 wave, 1 walk_block, 2 huge, 3 finalize
+       SC_ROWS_SRC = 28, SC_EV_SRC = 32, SC_NCHUNK = 36, SC_QSORT = 37, SC_NENT = 38, SC_COUNT = 40 };   // *_SRC[4]: 0 wave, 1 walk_block, 2 huge, 3 finalize
 
 struct CountArgs;
 __device__ __forceinline__ uint4 unpack_entry(const CountArgs& a, uint2 p);
@@ -94,6 +94,9 @@ struct CountArgs {
     uint32_t n_ne, n_slots, n_multi;
     uint32_t zero_lo, zero_hi;            // address (e, m form) of a 128-byte line of zeros behind the resident events
     uint32_t presorted;                   // multi-slot units' records were written grouped by k_sort_deep (no k_group_block pass, any slot size)
+    uint32_t two_ended;                   // <= 2 cell types: a tile's static entry region is filled from both ends, no counting pass
+    const uint32_t* tile_off; uint32_t* cur_lo; uint32_t* cur_hi;      // [n_tiles + 1] static region starts; cursors of this count
+    const uint8_t* read_drop;             // reads the pileup's max_depth rule drops (layout.hip depth_cap_drops), or null
     unsigned long long* scalars;
     uint32_t* rows[LSG_MAX_CELLTYPES];
     uint64_t row_cap;
@@ -122,6 +125,7 @@ __global__ void k_read_key(CountArgs a) {
         bool ok = (flag & a.flag_exclude) == 0 && (int)a.read_mapq[r] >= a.min_mq && cb >= 0 && cb < a.n_cb &&
                   tid >= 0 && tid < a.n_contigs;
         if (ok && a.ignore_orphans && (flag & 0x1) && !(flag & 0x2)) ok = false;
+        if (ok && a.read_drop && a.read_drop[r]) ok = false;          // bam.pileup(..., max_depth): never entered the pileup buffer
         if (ok) {
             uint32_t ct = a.celltype_of[cb];
             if (ct < (uint32_t)a.n_ct) key = (uint32_t)cb | (((flag >> 4) & 1u) << 24) | (ct << 28);
@@ -275,6 +279,12 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_segments(CountArgs a) {
                 const uint32_t cnt = hcnt[i];
                 if (cnt) {
                     if (MODE == 0) { atomicAdd(&a.unit_cnt[hkey[i]], cnt); hkey[i] = KEY_INVALID; hcnt[i] = 0; }
+                    else if (a.two_ended) {
+                        // cell type 0 grows up from the start of the tile's region, cell type 1 down from its end: the two units of a
+                        // tile need no sizes in advance (the region holds every entry the tile can ever get)
+                        const uint32_t u = hkey[i], tile = u / (uint32_t)a.n_ct;
+                        hcnt[i] = u == tile * (uint32_t)a.n_ct ? atomicAdd(&a.cur_lo[tile], cnt) : atomicSub(&a.cur_hi[tile], cnt) - cnt;
+                    }
                     else hcnt[i] = atomicAdd(&a.unit_cursor[hkey[i]], cnt);       // first position of this workgroup's range in the unit
                 }
             }
@@ -311,6 +321,40 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_segments(CountArgs a) {
             cb = b; cr = r;
         }
     }
+}
+
+// Static per load: how many entries a tile can ever hold = the (segment, tile) overlaps of the reads that carry a barcode and lie on
+// their contig (what k_seg_info can admit under ANY parameters or barcode table).
+__global__ void k_tile_caps(int64_t n_segs, const uint32_t* seg_read, const int32_t* seg_start, const int32_t* seg_len, const int32_t* read_tid,
+                            const int32_t* read_cb, const uint32_t* tile_base, const int64_t* contig_len, int32_t n_contigs, uint32_t* cap) {
+    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n_segs; s += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t r = seg_read[s];
+        const int32_t tid = read_tid[r];
+        if (tid < 0 || tid >= n_contigs || read_cb[r] < 0) continue;
+        const int64_t st = seg_start[s], ln = seg_len[s];
+        if (st < 0 || ln <= 0 || st + ln > contig_len[tid]) continue;
+        const uint32_t t0 = tile_base[tid] + ((uint32_t)st >> 6), t1 = tile_base[tid] + ((uint32_t)(st + ln - 1) >> 6);
+        for (uint32_t t = t0; t <= t1; ++t) atomicAdd(&cap[t], 1u);
+    }
+}
+
+// The units' sizes and places after a two-ended scatter: unit (tile, 0) = [region start, low cursor), unit (tile, 1) = [high cursor, region end).
+__global__ void k_units_from_cursors(CountArgs a) {
+    unsigned long long tot = 0;
+    // grid-stride: a few thousand workgroups, each ending in ONE atomic on the shared total (a word takes ~90 atomics per microsecond)
+    for (uint32_t t = a.tile_lo + blockIdx.x * blockDim.x + threadIdx.x; t < a.tile_hi; t += gridDim.x * blockDim.x) {
+        const uint32_t off = a.tile_off[t], end = a.tile_off[t + 1], lo = a.cur_lo[t], hi = a.cur_hi[t];
+        if (lo > hi) atomicExch(&a.scalars[SC_OVERFLOW], 2ull);          // cannot happen while the capacities bound the entries
+        if (a.n_ct == 1) { a.unit_cnt[t] = lo - off; a.unit_off[t] = off; tot += lo - off; }
+        else { a.unit_cnt[2 * t] = lo - off; a.unit_off[2 * t] = off; a.unit_cnt[2 * t + 1] = end - hi; a.unit_off[2 * t + 1] = hi; tot += (lo - off) + (end - hi); }
+    }
+    for (int o = 32; o > 0; o >>= 1) tot += __shfl_down(tot, o);
+    __shared__ unsigned long long s_tot;
+    if (threadIdx.x == 0) s_tot = 0;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0 && tot) atomicAdd(&s_tot, tot);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_tot) atomicAdd(&a.scalars[SC_NENT], s_tot);
 }
 
 __device__ __forceinline__ void unit_geometry(const CountArgs& a, uint32_t u, int& ct, int& tid, int32_t& tstart) {
@@ -1534,6 +1578,9 @@ static void fill_args(lsg_ctx* c, const lsg_count_params* p, CountArgs& a) {
     a.scalars = c->d_scalars.as<unsigned long long>();
     for (int i = 0; i < LSG_MAX_CELLTYPES; ++i) a.rows[i] = c->d_rows[i].as<uint32_t>();
     a.row_cap = c->row_cap;
+    a.two_ended = c->n_ct <= 2 && !getenv("LSG_COUNT_PASS") ? 1u : 0u;
+    a.tile_off = c->d_tile_off.as<uint32_t>(); a.cur_lo = c->d_cur_lo.as<uint32_t>(); a.cur_hi = c->d_cur_hi.as<uint32_t>();
+    a.read_drop = c->has_drops ? c->d_read_drop.as<uint8_t>() : nullptr;
 }
 
 // launch-shape knobs for tuning runs (environment overrides; the defaults are what ships)
@@ -1554,6 +1601,24 @@ static int cub_tmp(lsg_ctx* c, size_t bytes) { return c->d_cub_tmp.reserve(bytes
         tb_ = c->d_cub_tmp.cap;                                                                           \
         LSG_HIP(hipcub::DeviceScan::ExclusiveSum(c->d_cub_tmp.p, tb_, (in), (out), (int)(n), st));       \
     } while (0)
+
+// entries a tile can ever hold + their prefix (static until the reads or the contigs change)
+static int tile_capacities(lsg_ctx* c) {
+    if (c->tile_caps_valid) return 0;
+    hipStream_t st = c->stream;
+    const size_t nt = (size_t)c->n_tiles + 2;
+    if (c->d_tile_cap.reserve(nt * 4) || c->d_tile_off.reserve(nt * 4) || c->d_cur_lo.reserve(nt * 4) || c->d_cur_hi.reserve(nt * 4)) return -1;
+    LSG_HIP(hipMemsetAsync(c->d_tile_cap.p, 0, nt * 4, st));
+    const int64_t S = c->rd.n_segs;
+    if (S > 0)
+        hipLaunchKernelGGL(k_tile_caps, dim3((unsigned)((S + 255) / 256 < 4096 ? (S + 255) / 256 : 4096)), dim3(256), 0, st, S, c->rd.seg_read, c->rd.seg_start,
+                           c->rd.seg_len, c->rd.read_tid, c->rd.read_cb, c->d_tile_base.as<uint32_t>(), c->d_contig_len.as<int64_t>(), c->n_contigs,
+                           c->d_tile_cap.as<uint32_t>());
+    SCAN_U32(c->d_tile_cap.as<uint32_t>(), c->d_tile_off.as<uint32_t>(), c->n_tiles + 1);
+    LSG_HIP(hipGetLastError());
+    c->tile_caps_valid = true;
+    return 0;
+}
 
 int run_count(lsg_ctx* c, const lsg_count_params* p) {
     if (c->n_contigs <= 0) { set_error("lsg_pileup_count: no contigs set"); return -2; }
@@ -1585,22 +1650,38 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
         c->ws[WS_CHUNK_START].reserve(((EU + WORK_W0 * slot_cap) / CHUNK_EMIN + 4) * 4) || c->ws[WS_HUGE_LIST].reserve((EU / CAPB + 16) * 4))
         return -1;
 
+    if (tile_capacities(c)) return -1;
+    if (depth_cap_drops(c, p)) return -1;           // free unless some cell type's pileup buffer can reach max_depth (cached bound)
     LSG_HIP(hipEventRecord(c->ev[0], st));
     LSG_HIP(hipMemsetAsync(c->d_scalars.p, 0, SC_COUNT * 8, st));
     // only the units of the counted region (lsg_set_region) are ever touched
     const uint32_t u_lo = c->tile_lo * (uint32_t)c->n_ct;
-    const uint32_t u_hi = (c->tile_hi < c->n_tiles ? c->tile_hi : c->n_tiles) * (uint32_t)c->n_ct;
+    const uint32_t t_hi = c->tile_hi < c->n_tiles ? c->tile_hi : c->n_tiles;
+    const uint32_t u_hi = t_hi * (uint32_t)c->n_ct;
     const uint32_t n_range = u_hi > u_lo ? u_hi - u_lo : 0;
-    LSG_HIP(hipMemsetAsync(c->d_unit_cnt.as<uint32_t>() + u_lo, 0, ((size_t)n_range + 1) * 4, st));
+    const uint32_t n_trange = t_hi > c->tile_lo ? t_hi - c->tile_lo : 0;
     c->n_ne = c->n_slots = c->n_multi = 0;
     CountArgs a{};
     fill_args(c, p, a);
+    const bool two_ended = a.two_ended != 0;
     unsigned seg_grid = (unsigned)((S + 256 * BIN_SUPER - 1) / (256 * BIN_SUPER));
     if (seg_grid > (unsigned)(c->n_cus * 8)) seg_grid = (unsigned)(c->n_cus * 8);
     if (R > 0) { unsigned g = (unsigned)((R + 255) / 256); if (g > (unsigned)(c->n_cus * 8)) g = (unsigned)(c->n_cus * 8); hipLaunchKernelGGL(k_read_key, dim3(g), dim3(256), 0, st, a); }
     if (S > 0) { unsigned g = (unsigned)((S + 255) / 256); if (g > (unsigned)(c->n_cus * 16)) g = (unsigned)(c->n_cus * 16); hipLaunchKernelGGL(k_seg_info, dim3(g), dim3(256), 0, st, a); }
-    if (S > 0) hipLaunchKernelGGL(k_bin_segments<0>, dim3(seg_grid), dim3(256), 0, st, a);
-    SCAN_U32(a.unit_cnt + u_lo, a.unit_off + u_lo, n_range + 1);          // entry regions of buffer A, unit by unit
+    if (two_ended) {
+        // ONE pass over the segments: every tile owns a static region of the entry buffer (tile_capacities), cell type 0 fills it
+        // from the front and cell type 1 from the back, the units' sizes fall out of the cursors
+        if (n_trange) {
+            LSG_HIP(hipMemcpyAsync(a.cur_lo + c->tile_lo, a.tile_off + c->tile_lo, (size_t)n_trange * 4, hipMemcpyDeviceToDevice, st));
+            LSG_HIP(hipMemcpyAsync(a.cur_hi + c->tile_lo, a.tile_off + c->tile_lo + 1, (size_t)n_trange * 4, hipMemcpyDeviceToDevice, st));
+            if (S > 0) hipLaunchKernelGGL(k_bin_segments<2>, dim3(seg_grid), dim3(256), 0, st, a);
+            { unsigned g = (n_trange + 255) / 256; if (g > (unsigned)(c->n_cus * 8)) g = (unsigned)(c->n_cus * 8); hipLaunchKernelGGL(k_units_from_cursors, dim3(g), dim3(256), 0, st, a); }
+        }
+    } else {
+        LSG_HIP(hipMemsetAsync(c->d_unit_cnt.as<uint32_t>() + u_lo, 0, ((size_t)n_range + 1) * 4, st));
+        if (S > 0) hipLaunchKernelGGL(k_bin_segments<0>, dim3(seg_grid), dim3(256), 0, st, a);
+        SCAN_U32(a.unit_cnt + u_lo, a.unit_off + u_lo, n_range + 1);          // entry regions of buffer A, unit by unit
+    }
 
     // non-empty units, in genomic order
     hipcub::CountingInputIterator<uint32_t> cnt_it(0), unit_it(u_lo);
@@ -1615,12 +1696,18 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
     }
     unsigned long long sc[SC_COUNT];
     uint32_t* pin32 = reinterpret_cast<uint32_t*>(c->h_pin + SC_COUNT + 8);   // small reads that ride on read_scalars' synchronisation
-    LSG_HIP(hipMemcpyAsync(pin32, c->d_unit_off.as<uint32_t>() + u_hi, 4, hipMemcpyDeviceToHost, st));
+    if (!two_ended) LSG_HIP(hipMemcpyAsync(pin32, c->d_unit_off.as<uint32_t>() + u_hi, 4, hipMemcpyDeviceToHost, st));
     if (read_scalars(c, sc)) return -1;
-    const uint32_t total_entries = pin32[0];                  // statistics
+    if (sc[SC_OVERFLOW]) { set_error("lsg_pileup_count: a tile got more entries than its static capacity"); return -1; }
+    const uint32_t total_entries = two_ended ? (uint32_t)sc[SC_NENT] : pin32[0];                  // statistics
     const uint32_t n_ne = (uint32_t)(sc[SC_NNE] & 0xffffffffull);
     c->n_ne = n_ne;
     fill_args(c, p, a);
+
+    // launch-shape knobs
+    const unsigned grid_block = (unsigned)(c->n_cus * 2);      // k_pileup_huge
+    const unsigned grid_walk = (unsigned)(c->n_cus * tune_int("LSG_GRID_WALK", 8));       // k_walk_block
+    const unsigned grid_wave = (unsigned)(c->n_cus * tune_int("LSG_GRID_WAVE", 4));
 
     if (n_ne > 0) {
         // slot plan: deep units are cut into barcode-range slots
@@ -1635,10 +1722,51 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
         c->n_multi = (uint32_t)sc[SC_NMULTI];
         if (c->n_slots > slot_cap) { set_error("lsg_pileup_count: slot plan exceeds its bound"); return -1; }
         if (c->ws[WS_MACC].reserve(((size_t)n_slabs + 1) * NCTR * 64 * 4)) return -1;
-        fill_args(c, p, a);
+    }
+    // row buffers: bound + arena slack
+    {
+        uint64_t want_rows = (uint64_t)n_ne * TILE_W;
+        if (p->min_dp > 0) {
+            uint64_t by_depth = (uint64_t)c->rd.n_events / (uint64_t)p->min_dp + 64;
+            if (by_depth < want_rows) want_rows = by_depth;
+        }
+        want_rows += (uint64_t)(grid_block + grid_walk + grid_wave * WAVES_PER_BLOCK + (unsigned)(c->n_cus * 8)) * ARENA + 64;      // one open arena per emitting wave
+        want_rows = (want_rows + 63) / 64 * 64 + 64;        // whole 64-row blocks (lsg::row_word), one spare: a unit's descriptor spans two
+        // every cell type of THIS run needs planes of the current stride (a run with more cell types than any before it
+        // finds row_cap large enough but its new buffers still empty)
+        if (want_rows > c->row_cap) c->row_cap = want_rows;
+        for (int i = 0; i < c->n_ct; ++i)
+            if (c->d_rows[i].reserve((size_t)c->row_cap * ROW_STORED_WORDS * 4)) return -1;
+    }
+    fill_args(c, p, a);
+    if (n_ne > 0) {
         hipLaunchKernelGGL(k_slot_init, dim3((n_ne + 255) / 256), dim3(256), 0, st, a);
-        LSG_HIP(hipMemcpyAsync(a.unit_cursor + u_lo, a.unit_off + u_lo, ((size_t)n_range + 1) * 4, hipMemcpyDeviceToDevice, st));
-        if (S > 0) hipLaunchKernelGGL(k_bin_segments<2>, dim3(seg_grid), dim3(256), 0, st, a);
+        if (!two_ended) {
+            LSG_HIP(hipMemcpyAsync(a.unit_cursor + u_lo, a.unit_off + u_lo, ((size_t)n_range + 1) * 4, hipMemcpyDeviceToDevice, st));
+            if (S > 0) hipLaunchKernelGGL(k_bin_segments<2>, dim3(seg_grid), dim3(256), 0, st, a);
+        }
+        // ---- work lists: small slots first, the rest reversed at the end
+        {
+            SmallSlot pred{a.slot_cnt, a.slot_w, a.ne_nslot};
+            uint32_t* d_nsmall = reinterpret_cast<uint32_t*>(a.scalars + SC_NSMALL);
+            size_t tb = 0;
+            LSG_HIP(hipcub::DevicePartition::If(nullptr, tb, cnt_it, a.slot_list, d_nsmall, (int)c->n_slots, pred, st));
+            if (cub_tmp(c, tb)) return -1;
+            tb = c->d_cub_tmp.cap;
+            LSG_HIP(hipcub::DevicePartition::If(c->d_cub_tmp.p, tb, cnt_it, a.slot_list, d_nsmall, (int)c->n_slots, pred, st));
+        }
+        {
+            SlotWork wf{a.slot_list, a.slot_cnt, a.scalars};
+            hipcub::TransformInputIterator<uint32_t, SlotWork, hipcub::CountingInputIterator<uint32_t>> work_it(cnt_it, wf);
+            SCAN_U32(work_it, a.slot_pex, c->n_slots + 1);
+            hipLaunchKernelGGL(k_chunk_starts, dim3((c->n_slots + 255) / 256), dim3(256), 0, st, a, (uint32_t)(c->n_cus * tune_int("LSG_GRID_WAVE", 4) * WAVES_PER_BLOCK));
+        }
+        // small units (one wavefront each).  Measured (round 2): running this kernel on a second stream beside the deep units' sort and
+        // grouping buys nothing — its persistent workgroups hold 128 KB of LDS and half the wave slots of every CU, k_sort_deep's
+        // 1024-thread workgroups the other half, and whichever starts first starves the other — so everything stays on one stream.
+        LSG_HIP(hipEventRecord(c->ev[2], st));
+        hipLaunchKernelGGL(k_pileup_wave, dim3(grid_wave), dim3(WAVES_PER_BLOCK * 64), 0, st, a);
+        LSG_HIP(hipEventRecord(c->ev[3], st));
         if (c->n_multi > 0) {
             MultiUnit pred{a.ne_nslot};
             uint32_t* d_nm = reinterpret_cast<uint32_t*>(a.scalars + SC_NMULTI_SEL);
@@ -1657,41 +1785,8 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
                 hipLaunchKernelGGL(k_split_deep, dim3(sg), dim3(SPLIT_THREADS), 0, st, a);
             }
         }
-        // work lists: small slots first, the rest reversed at the end
-        {
-            SmallSlot pred{a.slot_cnt, a.slot_w, a.ne_nslot};
-            uint32_t* d_nsmall = reinterpret_cast<uint32_t*>(a.scalars + SC_NSMALL);
-            size_t tb = 0;
-            LSG_HIP(hipcub::DevicePartition::If(nullptr, tb, cnt_it, a.slot_list, d_nsmall, (int)c->n_slots, pred, st));
-            if (cub_tmp(c, tb)) return -1;
-            tb = c->d_cub_tmp.cap;
-            LSG_HIP(hipcub::DevicePartition::If(c->d_cub_tmp.p, tb, cnt_it, a.slot_list, d_nsmall, (int)c->n_slots, pred, st));
-        }
-        {
-            SlotWork wf{a.slot_list, a.slot_cnt, a.scalars};
-            hipcub::TransformInputIterator<uint32_t, SlotWork, hipcub::CountingInputIterator<uint32_t>> work_it(cnt_it, wf);
-            SCAN_U32(work_it, a.slot_pex, c->n_slots + 1);
-            hipLaunchKernelGGL(k_chunk_starts, dim3((c->n_slots + 255) / 256), dim3(256), 0, st, a, (uint32_t)(c->n_cus * tune_int("LSG_GRID_WAVE", 4) * WAVES_PER_BLOCK));
-        }
+        hipLaunchKernelGGL(k_group_block, dim3((unsigned)(c->n_cus * 4)), dim3(BLOCK_THREADS), 0, st, a);
     }
-    // row buffers: bound + arena slack
-    const unsigned grid_block = (unsigned)(c->n_cus * 2);      // k_pileup_huge
-    const unsigned grid_walk = (unsigned)(c->n_cus * tune_int("LSG_GRID_WALK", 8));       // k_walk_block
-    const unsigned grid_wave = (unsigned)(c->n_cus * tune_int("LSG_GRID_WAVE", 4));
-    uint64_t want_rows = (uint64_t)n_ne * TILE_W;
-    if (p->min_dp > 0) {
-        uint64_t by_depth = (uint64_t)c->rd.n_events / (uint64_t)p->min_dp + 64;
-        if (by_depth < want_rows) want_rows = by_depth;
-    }
-    want_rows += (uint64_t)(grid_block + grid_walk + grid_wave * WAVES_PER_BLOCK + (unsigned)(c->n_cus * 8)) * ARENA + 64;      // one open arena per emitting wave
-    want_rows = (want_rows + 63) / 64 * 64 + 64;        // whole 64-row blocks (lsg::row_word), one spare: a unit's descriptor spans two
-    // every cell type of THIS run needs planes of the current stride (a run with more cell types than any before it
-    // finds row_cap large enough but its new buffers still empty)
-    if (want_rows > c->row_cap) c->row_cap = want_rows;
-    for (int i = 0; i < c->n_ct; ++i)
-        if (c->d_rows[i].reserve((size_t)c->row_cap * ROW_STORED_WORDS * 4)) return -1;
-    fill_args(c, p, a);
-    if (n_ne > 0) hipLaunchKernelGGL(k_group_block, dim3((unsigned)(c->n_cus * 4)), dim3(BLOCK_THREADS), 0, st, a);
     LSG_HIP(hipEventRecord(c->ev[1], st));
     if (n_ne > 0) {
         hipLaunchKernelGGL(k_walk_block, dim3(grid_walk), dim3(WALK_THREADS), 0, st, a);
@@ -1700,9 +1795,7 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
         if (c->n_multi > 0)
             hipLaunchKernelGGL(k_finalize_multi, dim3(c->n_multi < (unsigned)(c->n_cus * 8) ? c->n_multi : (unsigned)(c->n_cus * 8)), dim3(FIN_THREADS), 0, st, a);
     }
-    LSG_HIP(hipEventRecord(c->ev[2], st));
-    if (n_ne > 0) hipLaunchKernelGGL(k_pileup_wave, dim3(grid_wave), dim3(WAVES_PER_BLOCK * 64), 0, st, a);
-    LSG_HIP(hipEventRecord(c->ev[3], st));
+    LSG_HIP(hipEventRecord(c->ev[5], st));
     LSG_HIP(hipGetLastError());
 
     if (read_scalars(c, sc)) return -1;
@@ -1715,14 +1808,18 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
     c->stats.n_units = n_ne;
     c->stats.n_deep_units = (int64_t)c->n_slots - (int64_t)(sc[SC_NSMALL] & 0xffffffffull);
     c->stats.n_entries = n_ne > 0 ? total_entries : 0;
+    // ms_bin: admission, scatter, plan, the small units and the deep units' sort and grouping, up to the walk's launch;
+    // ms_deep: k_walk_block + k_pileup_huge + k_finalize_multi; ms_wave: k_pileup_wave (inside ms_bin)
     float ms = 0;
     LSG_HIP(hipEventElapsedTime(&ms, c->ev[0], c->ev[1])); c->stats.ms_bin = ms;
-    LSG_HIP(hipEventElapsedTime(&ms, c->ev[1], c->ev[2])); c->stats.ms_deep = ms;
-    c->stats.ms_walk = 0;
-    if (n_ne > 0) { LSG_HIP(hipEventElapsedTime(&ms, c->ev[1], c->ev[4])); c->stats.ms_walk = ms; }
+    LSG_HIP(hipEventElapsedTime(&ms, c->ev[1], c->ev[5])); c->stats.ms_deep = ms;
+    c->stats.ms_walk = 0; c->stats.ms_wave = 0;
+    if (n_ne > 0) {
+        LSG_HIP(hipEventElapsedTime(&ms, c->ev[1], c->ev[4])); c->stats.ms_walk = ms;
+        LSG_HIP(hipEventElapsedTime(&ms, c->ev[2], c->ev[3])); c->stats.ms_wave = ms;
+    }
     for (int i = 0; i < 4; ++i) { c->stats.rows_by_kernel[i] = (int64_t)sc[SC_ROWS_SRC + i]; c->stats.events_by_kernel[i] = (int64_t)sc[SC_EV_SRC + i]; }
-    LSG_HIP(hipEventElapsedTime(&ms, c->ev[2], c->ev[3])); c->stats.ms_wave = ms;
-    LSG_HIP(hipEventElapsedTime(&ms, c->ev[0], c->ev[3])); c->stats.ms_total = ms;
+    LSG_HIP(hipEventElapsedTime(&ms, c->ev[0], c->ev[5])); c->stats.ms_total = ms;
     c->stats.n_events_wave = (int64_t)sc[SC_EV_WAVE]; c->stats.n_events_deep = (int64_t)sc[SC_EV_DEEP];
     c->stats.n_rows_deep = (int64_t)sc[SC_ROWS_DEEP];
     c->stats.n_rows_wave = -c->stats.n_rows_deep;
@@ -1801,6 +1898,7 @@ __global__ void k_entries_upper(const int32_t* seg_start, const int32_t* seg_len
 }
 
 int compute_entries_upper(lsg_ctx* c) {
+    c->tile_caps_valid = false;            // new reads: the tiles' static capacities are recomputed by the next count
     if (c->d_scalars.reserve(SC_COUNT * 8)) return -1;
     LSG_HIP(hipMemsetAsync(c->d_scalars.p, 0, SC_COUNT * 8, c->stream));
     int64_t S = c->rd.n_segs;

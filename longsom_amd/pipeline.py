@@ -28,6 +28,7 @@ class SnvParams:
     min_bq: int = 20
     min_dp: int = 5
     min_cc: int = 5
+    max_depth: int = 200000                # bam.pileup(..., max_depth = 200000), BaseCellCounter.py:191 (hard-coded there)
     min_cell_types: int = 2
     min_cells: int = 5                     # BaseCellCalling.step1.py --min_cells (the PoN rules set 1)
     min_distance: int = 0
@@ -44,7 +45,8 @@ class SnvParams:
     reference_gz_compat: bool = False      # True reproduces SURVEY quirk Q1 (.gz position sets read as empty)
 
     def count(self) -> CountParams:
-        return CountParams.longsom_defaults(min_bq=self.min_bq, min_mq=self.min_mapping_quality, min_dp=self.min_dp, min_cc=self.min_cc)
+        return CountParams.longsom_defaults(min_bq=self.min_bq, min_mq=self.min_mapping_quality, min_dp=self.min_dp, min_cc=self.min_cc,
+                                            max_depth=self.max_depth)
 
     def call(self) -> CallParams:
         return CallParams.longsom_defaults(alpha1=self.alpha1, beta1=self.beta1, alpha2=self.alpha2, beta2=self.beta2,
@@ -84,12 +86,14 @@ PILEUP_MAX_DEPTH = 200000   # bam.pileup(..., max_depth = 200000), BaseCellCount
 
 
 class DepthCapExceeded(ValueError):
-    """More reads can be live at one position than the reference's pileup admits; its cap is not modelled here."""
+    """More reads can be live at one position than the reference's pileup admits, on a path that does not model its cap."""
 
 
 def check_depth_cap(engine: Engine, what: str, allow_depth_overflow: Optional[bool] = None) -> int:
-    """Raise when, under the engine's current barcode table, some cell type can hold more live reads at one position than the
-    reference's pileup admits (its cap is not modelled; below the cap it never fires and the counts are identical)."""
+    """For the per-cell GENOTYPING pileup only (lsg_genotype_cells: the reference piles up the unsplit BAM there,
+    HCCVSingleCellGenotype.py:122, and that path does not model max_depth): raise when more reads can be live at one position
+    than the reference's pileup admits.  The COUNT path needs no such guard: lsg_pileup_count applies htslib's max_depth rule
+    itself (lsg_count_params.max_depth)."""
     live = engine.max_live_reads()
     if live > PILEUP_MAX_DEPTH:
         msg = ("%s: up to %d reads of one cell type overlap one 64-position tile; the reference's pileup stops admitting reads above "
@@ -122,7 +126,6 @@ def load_sample(bam: str, barcodes_tsv: str, ref_fasta: str, engine: Engine, min
     engine.set_barcodes(bc.celltype_of, len(bc.celltype_names))
     engine.set_region()
     engine.load_reads(dec.records)
-    check_depth_cap(engine, bam, allow_depth_overflow)
     t["load"] = time.time() - t0
     return Resident(engine, dec, bc, contig_names, t)
 
@@ -135,7 +138,6 @@ def chain_step1(res: Resident, celltype_of: np.ndarray, celltype_names: List[str
     t = dict(res.seconds)
     t0 = time.time()
     eng.set_barcodes(celltype_of, len(celltype_names))
-    check_depth_cap(eng, sample_id)
     eng.pileup_count(params.count())
     n_sites, n_cand = eng.call_step1(params.call())
     t["gpu_count_call"] = time.time() - t0
@@ -336,7 +338,6 @@ def _run_snv_regions(bam, barcodes_tsv, ref_fasta, out_dir, sample_id, params, e
         t0 = time.time()
         eng.load_reads(rec)
         eng.set_region(lo[0], lo[1], hi[0], hi[1])
-        check_depth_cap(eng, "%s %s-%s" % (sample_id, lo, hi))
         t["load"] += time.time() - t0
         t0 = time.time()
         eng.pileup_count(params.count())
@@ -462,6 +463,7 @@ def run_reannotation(bam: str, barcodes_tsv: str, ref_fasta: str, out_dir: str, 
         t["hccv"] = time.time() - t0
         t0 = time.time()
         eng.set_barcodes(res.table.celltype_of, len(res.table.celltype_names))
+        check_depth_cap(eng, sample_id + " (per-cell genotyping)")
         geno = os.path.join(d1, "HCCV", sample_id + ".SNVs.SingleCellGenotype.tsv")
         n_rows = reanno.single_cell_genotype(eng, hccv, res.table, res.contig_names, geno, alt_flag=rp.alt_flag, min_bq=rp.genotype_min_bq,
                                              min_mq=rp.chain.min_mapping_quality, alpha2=rp.chain.alpha2, beta2=rp.chain.beta2, pvalue=rp.pvalue,

@@ -15,8 +15,10 @@
  *
  * Parity status: "parity unpinned" against the reference itself for this stage — pysam/htslib are
  * not installed here and the reference ships no test vectors; the pin is the hand-derived known
- * answers in tests/golden/kat_pileup.json.  Not modelled: max_depth = 200000
- * (BaseCellCounter.py:191), which only drops reads beyond 200 000 buffered alignments.
+ * answers in tests/golden/kat_pileup.json and by the tables the reference's own BaseCellCounter.py wrote over the column-replay
+ * stand-in (tests/golden/pileup.*, tests/test_pileup_refgolden.py).  max_depth (BaseCellCounter.py:191: 200000) is
+ * htslib's bam_plp_push rule: a read that starts at the iterator's current column — i.e. any read but the first of its start
+ * position — is dropped while the buffer (reads not yet freed + the spare tail node) exceeds max_depth.
  */
 #include <stdint.h>
 #include <stdio.h>
@@ -150,7 +152,7 @@ static int easy_read_pileup(const read_t* r, uint32_t qpos, int is_del, int is_r
 int64_t plp_count(const char* bam_path, const char* barcodes, int32_t n_cb, const uint8_t* celltype_of, int32_t ct,
                   int32_t n_contigs, const int64_t* contig_len, const uint8_t* const* ref,
                   int32_t min_bq, int32_t min_mq, int32_t min_dp, int32_t min_cc,
-                  int64_t* out_keys, uint8_t* out_ref, uint32_t* out_counts, int64_t capacity)
+                  int64_t* out_keys, uint8_t* out_ref, uint32_t* out_counts, int64_t capacity, int32_t max_depth)
 {
     size_t len = 0;
     uint8_t* d = inflate_all(bam_path, &len);
@@ -211,7 +213,15 @@ int64_t plp_count(const char* bam_path, const char* barcodes, int32_t n_cb, cons
     int32_t cur_tid = -1; int64_t pos = 0;
     while (head < n || n_act) {
         if (!n_act) { cur_tid = rd[head].tid; pos = rd[head].pos; }
-        while (head < n && rd[head].tid == cur_tid && rd[head].pos <= pos) act[n_act++] = &rd[head++];
+        {   /* bam_plp_push: the first read of a start position always enters; later ones only while mp->cnt (= buffered + 1) <= maxcnt.
+               The buffer still holds the reads that ended on the previous column (freed by the sweep below). */
+            int first_here = 1;
+            while (head < n && rd[head].tid == cur_tid && rd[head].pos <= pos) {
+                if (max_depth > 0 && rd[head].pos == pos && !first_here && (int64_t)n_act + 1 > (int64_t)max_depth) { ++head; continue; }
+                first_here = 0;
+                act[n_act++] = &rd[head++];
+            }
+        }
         /* drop finished reads */
         size_t w = 0;
         for (size_t i = 0; i < n_act; ++i) if (act[i]->end > pos) act[w++] = act[i];

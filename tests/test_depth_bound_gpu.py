@@ -1,6 +1,9 @@
-"""GPU: the load-time bound that stands in for the reference's pileup depth cap (bam.pileup(..., max_depth = 200000),
-BaseCellCounter.py:191).  The bound must never under-count the reads live at one position, and the host mirror must refuse a
-sample above the cap unless told otherwise."""
+"""GPU: the reference's pileup depth cap (bam.pileup(..., max_depth = 200000), BaseCellCounter.py:191).
+  * lsg_max_live_reads: the bound that tells the count path whether the cap can fire at all must never under-count the reads
+    buffered at one position (a read stays buffered through the column after its last one);
+  * lsg_pileup_count with max_depth below the depth of the sample drops exactly the reads htslib's rule drops: rows equal the
+    BAM-level oracle's (oracle/plp_oracle.c, whose rule is pinned by the reference-written tests/golden/pileup.cap.* tables);
+  * the genotyping path does not model the cap: its guard refuses a sample above it unless told otherwise."""
 import numpy as np
 import pytest
 
@@ -23,9 +26,9 @@ def tile_bound(rec, contig_lens, keep):
             segs = np.flatnonzero(sr == r)
             if len(segs) == 0:
                 continue
-            st = int(rec.seg_start[segs[0]]); en = int(rec.seg_start[segs[-1]] + rec.seg_len[segs[-1]] - 1)
+            st = int(rec.seg_start[segs[0]]); en = int(rec.seg_start[segs[-1]] + rec.seg_len[segs[-1]])      # buffered through column `en`
             diff[min(st >> 6, nt - 1)] += 1; diff[min((en >> 6) + 1, nt)] -= 1
-            pdiff[st] += 1; pdiff[en + 1] -= 1
+            pdiff[st] += 1; pdiff[min(en, int(L)) + 1] -= 1
         best = max(best, int(np.cumsum(diff).max()))
         exact = max(exact, int(np.cumsum(pdiff).max()))
     return best, exact
@@ -54,19 +57,49 @@ def test_bound_equals_the_tile_restatement_and_covers_the_true_depth(engine, see
     assert engine.max_live_reads() == tile_bound(rec, lens, has_cb)[0] >= got
 
 
-def test_pipeline_refuses_a_sample_above_the_cap(engine, tmp_path, monkeypatch, capsys):
-    m = synth.named("C1", n_reads=4000, n_genes=4, n_cb=20, snp_mod=120)
-    bam, fa, bct = str(tmp_path / "S1.bam"), str(tmp_path / "ref.fa"), str(tmp_path / "barcodes.tsv")
+@pytest.fixture(scope="module")
+def deep_sample(tmp_path_factory):
+    d = tmp_path_factory.mktemp("deep")
+    m = synth.named("C1", n_reads=6000, n_genes=5, n_cb=40, snp_mod=120)
+    bam, fa, bct = str(d / "S1.bam"), str(d / "ref.fa"), str(d / "barcodes.tsv")
     hostio.synth_bam(m, bam, fa)
     hostio.write_barcodes_tsv(bct, hostio.synth_barcodes(m), m.celltype_of, ["Cancer", "Non-Cancer"])
-    res = pipeline.load_sample(bam, bct, fa, engine, 60)          # far below 200000: loads
+    return m, bam, fa, bct
+
+
+@pytest.mark.parametrize("max_depth", [1, 37, 150, 400, 200000])
+def test_count_with_a_depth_cap_equals_the_bam_level_oracle(engine, deep_sample, max_depth):
+    from longsom_amd import tsvio
+    from longsom_amd._lib import CountParams
+    from oracle import loader
+    m, bam, fa, bct = deep_sample
+    res = pipeline.load_sample(bam, bct, fa, engine, 60)
+    names, seqs = tsvio.read_fasta(fa)
     live = engine.max_live_reads()
-    assert 0 < live <= 4000
+    assert live > 400                                             # the caps above bite
+    rows, _ = engine.pileup_count(CountParams.longsom_defaults(max_depth=max_depth))
+    uncapped, _ = engine.pileup_count(CountParams.longsom_defaults(max_depth=0))
+    if max_depth >= live:
+        assert rows == uncapped
+    engine.pileup_count(CountParams.longsom_defaults(max_depth=max_depth))
+    for ct in range(2):
+        k, r, c = engine.fetch_counts(ct)
+        ok, orf, oc = loader.plp_count(bam, res.table.barcodes, res.table.celltype_of, ct, [len(s) for s in seqs], seqs, max_depth=max_depth)
+        assert np.array_equal(k, ok) and np.array_equal(r, orf) and np.array_equal(c, oc), "cell type %d, max_depth %d" % (ct, max_depth)
+    if max_depth <= 150:
+        assert sum(rows) < sum(uncapped)
+
+
+def test_genotyping_guard_refuses_a_sample_above_the_cap(engine, deep_sample, monkeypatch, capsys):
+    m, bam, fa, bct = deep_sample
+    res = pipeline.load_sample(bam, bct, fa, engine, 60)
+    live = pipeline.check_depth_cap(engine, "S1")                 # far below 200000: passes
+    assert 0 < live <= 6000
     monkeypatch.setattr(pipeline, "PILEUP_MAX_DEPTH", live - 1)
     monkeypatch.delenv("LONGSOM_ALLOW_DEPTH_OVERFLOW", raising=False)
     with pytest.raises(pipeline.DepthCapExceeded):
-        pipeline.load_sample(bam, bct, fa, engine, 60)
+        pipeline.check_depth_cap(engine, "S1")
     monkeypatch.setenv("LONGSOM_ALLOW_DEPTH_OVERFLOW", "1")
-    res = pipeline.load_sample(bam, bct, fa, engine, 60)
+    assert pipeline.check_depth_cap(engine, "S1") == live
     assert "max_depth" in capsys.readouterr().err
     assert res.engine is engine

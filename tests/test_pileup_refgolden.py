@@ -115,6 +115,30 @@ def test_oracles_write_the_reference_tables_rand(tag):
     assert {50000, 50001, 50002} <= pos1 and 1 not in pos1 and 2 in pos1                              # window edge, position 0 skipped
 
 
+# ---- depth cap: bam.pileup(..., max_depth) as the reference's run saw it (the stand-in applied htslib's bam_plp_push rule) ----------
+@pytest.mark.parametrize("max_depth,golden", [(8, "pileup.cap.Cancer.tsv"), (200000, "pileup.capoff.Cancer.tsv")])
+def test_bam_level_oracle_applies_the_depth_cap(max_depth, golden):
+    bc, names, refs = rand_inputs("rand")
+    k, r, c = loader.plp_count(os.path.join(G, "pileup.cap.bam"), bc.barcodes, bc.celltype_of, 0, [len(x) for x in refs], refs, max_depth=max_depth)
+    assert table(k, r, c, names, "s.Cancer") == open(os.path.join(G, golden)).read()
+    assert open(os.path.join(G, "pileup.cap.Cancer.tsv")).read() != open(os.path.join(G, "pileup.capoff.Cancer.tsv")).read()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("max_depth,golden", [(8, "pileup.cap.Cancer.tsv"), (200000, "pileup.capoff.Cancer.tsv")])
+def test_gpu_applies_the_depth_cap(engine, max_depth, golden):
+    bc, names, refs = rand_inputs("rand")
+    dec = hostio.decode_bam(os.path.join(G, "pileup.cap.bam"), bc.barcodes, min_mapq=60)
+    engine.set_contigs([len(r) for r in refs])
+    for t, r in enumerate(refs):
+        engine.load_reference(t, r)
+    engine.set_barcodes(bc.celltype_of, 2); engine.set_region()
+    engine.load_reads(dec.records)
+    engine.pileup_count(CountParams.longsom_defaults(max_depth=max_depth))
+    k, r, c = engine.fetch_counts(0)
+    assert table(k, r, c, names, "s.Cancer") == open(os.path.join(G, golden)).read()
+
+
 # ---- GPU ------------------------------------------------------------------------------------------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", sorted(K.CASES))

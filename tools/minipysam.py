@@ -267,13 +267,17 @@ class AlignmentFile:
         while head < len(reads) or active:
             if not active:
                 pos = reads[head].pos
-            # htslib bam_plp_push: a read that starts at the iterator's current column is dropped while mp->cnt > maxcnt;
-            # mp->cnt = buffered reads + the pre-allocated tail node, and the buffer still holds the reads whose last
-            # base was the previous column (they are freed while the current column is swept)
+            # htslib bam_plp_push drops a read iff it starts at the iterator's current column (iter->tid == tid && iter->pos == pos)
+            # while mp->cnt > maxcnt.  The iterator only reaches column P once a read starting at P has been pushed (bam_plp_next
+            # emits columns below max_pos and then waits for more input), so the FIRST read of a start position is never tested;
+            # the later ones are, against mp->cnt = buffered reads + the pre-allocated tail node, where the buffer still holds the
+            # reads whose last base was column P - 1 (they are freed while column P is swept)
+            first_here = True
             while head < len(reads) and reads[head].pos <= pos:
-                if reads[head].pos == pos and len(active) + 1 > max_depth:
+                if reads[head].pos == pos and not first_here and len(active) + 1 > max_depth:
                     head += 1
                     continue
+                first_here = False
                 active.append(reads[head]); head += 1
             active = [r for r in active if r.reference_end > pos]
             if not active:
