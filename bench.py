@@ -14,7 +14,9 @@
 One JSON line on rank 0.  `roofline` is for the dominant kernel (k_walk_block): algorithmic bytes
 (2 B/event + 24 B/read + 168 B/emitted row, restricted to what that kernel processes)
 over its HIP-event time on its own stream.  `cpu_baseline` times the CPU oracle (oracle/, kind
-"port") on a bounded sample of the same workload, single thread, on this box's host cores.
+"port") on a bounded sample of the same workload on ALL of this box's host cores (one core and the
+reference-shaped Python loop beside it).  `roofline.traffic` is quoted from the newest profiles/
+file only when that file was recorded for this build of the kernels (else null + traffic_stale).
 """
 import argparse
 import json
@@ -39,11 +41,33 @@ HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 from longsom_amd.shard import region_shards, sub_model  # noqa: E402
 
 
+def host_cores(cap=16):
+    """host threads this process may really use: the scheduler affinity, the cgroup CPU quota, and the GPU box's share per GPU
+    (16; os.cpu_count() reports the whole machine there)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            quota = int(txt[0]) if txt[0] != "max" else -1
+            period = int(txt[1]) if len(txt) > 1 else int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, -(-quota // period)))
+        except (OSError, ValueError, IndexError):
+            pass
+    return max(1, min(n, int(os.environ.get("LSG_HOST_CORES", cap))))
+
+
 def cpu_baseline(eng, model, target_reads=150_000, call_sites=10_000):
-    """Oracle (C count + Python/scipy step 1, single thread) on a contiguous-gene sample of the workload.
-    Also checks the GPU result on that sample against the oracle (a parity check at bench time)."""
-    from oracle import calling_oracle, loader
-    from longsom_amd import tsvio
+    """The CPU side of BASELINE.md §3 on this box's host cores, bounded to ~20 s:
+      cpu_native  oracle/count_oracle.c (region-parallel, ALL host cores) on a contiguous-gene sample of the C2 workload, plus the
+                  step-1 oracle (Python + scipy, one process, as the reference's step 1 is) scaled from a bounded number of sites;
+                  the same count on ONE core on a third of the sample beside it.  `value` is the all-cores figure.
+      cpu_pyloop  oracle/pyloop.py: the reference's per-read Python loop structure (BaseCellCounter.py:198-312) on 50 kb windows of
+                  the C1 workload, one core and a process pool over all cores (the reference's mp.Pool, :392-402).
+    Also checks the GPU rows of the sample against the oracle (a parity check at bench time)."""
+    from oracle import calling_oracle, loader, pyloop
+    from longsom_amd import hostio, tsvio
+    cores = host_cores()
     reads = np.diff(model.gene_read_off)
     g_lo = model.n_genes // 3
     g_hi = g_lo
@@ -59,13 +83,18 @@ def cpu_baseline(eng, model, target_reads=150_000, call_sites=10_000):
     t0 = time.time()
     ok, per_ct, n_cols = True, [], 0
     for ct in range(2):
-        k, rf, c, ncol = loader.count(rec, model.contig_len, refs, model.celltype_of, ct)
+        k, rf, c, ncol = loader.count(rec, model.contig_len, refs, model.celltype_of, ct, threads=cores)
         per_ct.append((k, rf, c)); n_cols += ncol
     t_count = time.time() - t0
     for ct in range(2):
         gk, gr, gc = eng.fetch_counts(ct)
         ok &= bool(np.array_equal(gk, per_ct[ct][0]) and np.array_equal(gc, per_ct[ct][2]))
     ok &= n_cols == cols
+    # one core, a third of the sample (the single-threaded form of the same oracle)
+    third = rec.subset(np.arange(rec.n_reads) < rec.n_reads // 3)
+    t0 = time.time()
+    cols1 = sum(loader.count(third, model.contig_len, refs, model.celltype_of, ct)[3] for ct in range(2))
+    t_count1 = time.time() - t0
     # step 1 on a bounded number of merged sites (scipy betabinom per alt, as the reference does)
     sub = [(k[:call_sites], r[:call_sites], c[:call_sites]) for k, r, c in per_ct]
     merged = tsvio.format_merged_tsv(sub, model.contig_names, ["Cancer", "Non-Cancer"])
@@ -76,18 +105,76 @@ def cpu_baseline(eng, model, target_reads=150_000, call_sites=10_000):
     t_call_site = (time.time() - t0) / max(1, n_call)
     n_merged = len(np.unique(np.concatenate([p[0] for p in per_ct]))) if n_cols else 0
     t_total = t_count + t_call_site * n_merged
-    return {"value": n_cols / t_total if t_total > 0 else 0.0, "unit": "sites/s", "cores": 1, "kind": "port",
-            "sample": "%d reads of %d contiguous genes of the C2 workload (%d events, %d columns): oracle/count_oracle.c timed on all of "
-                      "it (%.1f s), oracle/calling_oracle.py step1 timed on %d merged sites (%.2f ms/site) and scaled to the sample's %d sites"
-                      % (rec.n_reads, g_hi - g_lo, rec.n_events, n_cols, t_count, n_call, t_call_site * 1e3, n_merged),
+    # cpu_pyloop on C1 (chr22-only, 50 k reads, 200 barcodes): the reference's loop structure on its 50 kb windows
+    c1 = synth.named("C1")
+    rec1 = hostio.synth_records(c1)
+    refs1 = [hostio.ref_bases(c1.seed, t, int(l)) for t, l in enumerate(c1.contig_len)]
+    bcs = hostio.synth_barcodes(c1)
+    span_lo = int(rec1.seg_start.min()) // 50000 * 50000 + 1
+    wins = [(0, x, x + 50000) for x in range(span_lo, int(c1.contig_len[0]), 50000)]
+    seg_tile = (rec1.seg_start // 50000)
+    busy = sorted(wins, key=lambda w: -int(((seg_tile == (w[1] // 50000))).sum()))      # the busiest windows first
+    adm = [pyloop.admitted_reads(rec1, c1.celltype_of, ct) for ct in range(2)]
+
+    def cols_of(jobs):
+        return sum(sum(1 for _ in pyloop.columns_of(rec1, tid, lo, hi, 20, adm[ct])) for ct, tid, lo, hi in jobs)
+    jobs1 = [(ct, *w) for w in busy[:1] for ct in range(2)]
+    t0 = time.time(); rows_py1 = pyloop.count_windows(rec1, bcs, refs1, c1.contig_names, c1.celltype_of, jobs1, 1); t_py1 = time.time() - t0
+    cols_py1 = cols_of(jobs1)
+    jobsn = [(ct, *w) for w in busy[:max(1, min(len(busy), cores))] for ct in range(2)]
+    t0 = time.time(); rows_pyn = pyloop.count_windows(rec1, bcs, refs1, c1.contig_names, c1.celltype_of, jobsn, cores); t_pyn = time.time() - t0
+    cols_pyn = cols_of(jobsn)
+    return {"value": n_cols / t_total if t_total > 0 else 0.0, "unit": "sites/s", "cores": cores, "kind": "port",
+            "sample": "cpu_native: %d reads of %d contiguous genes of the C2 workload (%d events, %d columns): oracle/count_oracle.c (lso_count_mt) on %d "
+                      "threads (%.1f s) + oracle/calling_oracle.py step1 in one process timed on %d merged sites (%.2f ms/site) scaled to the sample's %d sites"
+                      % (rec.n_reads, g_hi - g_lo, rec.n_events, n_cols, cores, t_count, n_call, t_call_site * 1e3, n_merged),
+            "native_1core": {"value": cols1 / (t_count1 + t_call_site * n_merged / 3) if t_count1 > 0 else 0.0, "unit": "sites/s",
+                             "sample": "%d reads (a third of the sample), lso_count single-threaded %.1f s" % (third.n_reads, t_count1)},
+            "pyloop": {"kind": "port", "unit": "sites/s", "workload": "C1 (chr22-only, 50 k reads, 200 barcodes), the busiest 50 kb windows x 2 cell types",
+                       "value_1core": cols_py1 / t_py1 if t_py1 > 0 else 0.0, "value_allcores": cols_pyn / t_pyn if t_pyn > 0 else 0.0, "cores": cores,
+                       "sample": "1 core: %d jobs, %d columns, %d rows, %.1f s; pool of %d: %d jobs, %d columns, %d rows, %.1f s" % (len(jobs1), cols_py1, rows_py1, t_py1, cores, len(jobsn), cols_pyn, rows_pyn, t_pyn),
+                       "note": "per-read Python loop with the structure of BaseCellCounter.py:198-312 on columns cut from the decoded arrays; pysam's per-read object "
+                               "construction is not included, so this is an upper bound on the reference's own columns/s"},
             "gpu_matches_oracle_on_sample": ok}
+
+
+def csrc_digest():
+    """content hash of the kernel sources: profiles recorded for another build are not quoted as this build's traffic"""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    for f in sorted(glob.glob(os.path.join(ROOT, "longsom_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "longsom_amd", "csrc", "*.h"))):
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
+def recorded_traffic():
+    """roofline.traffic: PMC counters cannot be read from inside this process, so the number comes from the newest committed
+    rocprofv3 --pmc passes of this same command (profiles/rNN_pmc_traffic.json, tools/collect_profiles.sh) — but only when they
+    were taken with THIS build of the kernels; otherwise traffic is null and traffic_stale says so."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None, None, None
+    f = files[-1]
+    try:
+        d = json.load(open(f))
+        k = d["kernels"].get("lsg::k_walk_block")
+        rel = os.path.relpath(f, ROOT)
+        if d.get("_csrc_sha1") != csrc_digest():
+            return None, "%s was recorded for another build of longsom_amd/csrc (sha1 %s)" % (rel, str(d.get("_csrc_sha1"))[:12]), True
+        if k and k.get("traffic_bytes"):
+            return k["traffic_bytes"], rel + ": FETCH_SIZE (x calibrated gfx950 correction) + WRITE_SIZE, separate --pmc passes, bytes per launch", False
+    except (OSError, ValueError, KeyError):
+        pass
+    return None, None, None
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--reads", type=float, default=None, help="override the read count (development only; the reported config changes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -209,18 +296,16 @@ def main():
     else:
         tot = vals.tolist()
     if rank == 0:
-        # HBM-side bytes of the dominant kernel per launch: PMC counters cannot be read from inside this process, so the
-        # number comes from the committed rocprofv3 --pmc passes of this same command (profiles/, tools/collect_profiles.sh)
-        traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if world == 1 and args.reads is None and os.path.exists(pmc):
-            try:
-                k = json.load(open(pmc))["kernels"].get("lsg::k_walk_block")
-                if k and k.get("traffic_bytes"):
-                    traffic = k["traffic_bytes"]
-                    traffic_src = "profiles/r01_pmc_traffic.json: FETCH_SIZE (x calibrated gfx950 correction) + WRITE_SIZE, separate --pmc passes, bytes per launch"
-            except (OSError, ValueError, KeyError):
-                pass
+        traffic, traffic_src, traffic_stale = (None, None, None)
+        if world == 1 and args.reads is None:
+            traffic, traffic_src, traffic_stale = recorded_traffic()
+        e2e = None
+        try:
+            import glob
+            f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_end_to_end.json")))[-1]
+            e2e = dict(json.load(open(f)), source=os.path.relpath(f, ROOT))
+        except (IndexError, OSError, ValueError):
+            pass
         ms_step = dt / args.steps * 1e3
         sites = tot[1]
         achieved = walk_bytes / max(walk_ms, 1e-9) / 1e6         # GB/s
@@ -235,9 +320,10 @@ def main():
                        "sharding": "genomic regions balanced by read count" if world > 1 else "none",
                        "pass_rows_gathered": int(sum(gather["counts"])) if world > 1 and gather["counts"] else None,
                        "exchange": "one all-gather per step, %d-row slots agreed in warm-up" % gather["cap"] if world > 1 else None,
-                       "path_algorithmic_GBps_rank0": path_bytes / dt / 1e9},
+                       "path_algorithmic_GBps_rank0": path_bytes / dt / 1e9,
+                       "end_to_end": e2e},
             "roofline": {"bound": "hbm", "kernel": "k_walk_block", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale,
                          "avg_launch_ms": walk_ms / args.steps, "algorithmic_bytes_per_launch": walk_bytes / args.steps},
         }
         if base is not None:

@@ -245,6 +245,9 @@ int lsg_genotype_cells(lsg_ctx* ctx, const lsg_genotype_params* params, int64_t 
 /* round(betabinom.sf(k - 0.001, n, alpha, beta), 4) * 1e4 for n_items integer (k, n) pairs, evaluated on the
  * device with the step-1 tail code (HCCVSingleCellGenotype.py:204; k[i] <= 0 gives 10000). */
 int lsg_betabinom_sf4(lsg_ctx* ctx, int64_t n_items, const uint32_t* k, const uint32_t* n, double alpha, double beta, int32_t* out_p4);
+/* The same tails with the UNROUNDED fp64 value beside the rounded one: what the exactness audit measures (how far every p of a
+ * workload lies from a 4-decimal rounding tie of round(betabinom.sf(...), 4), BaseCellCalling.step1.py:196,201; tools/p_margins.py). */
+int lsg_betabinom_sf(lsg_ctx* ctx, int64_t n_items, const uint32_t* k, const uint32_t* n, double alpha, double beta, int32_t* out_p4, double* out_p);
 
 /* ---- measurement helpers --------------------------------------------------------------------*/
 /* Statistics of the last lsg_pileup_count: admitted reads / segments / events (events that passed

@@ -636,24 +636,28 @@ __global__ void k_probe(const int64_t* set, int64_t n_set, const int64_t* keys, 
 }
 
 // round(betabinom.sf(k - 0.001, n, a, b), 4) * 1e4 for a batch of (k, n) pairs (lsg_betabinom_sf4)
-__global__ void k_sf4_batch(const uint32_t* k, const uint32_t* n, int64_t items, double al, double be, double lgc0, double lgcn, int32_t* out) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < items; i += (int64_t)gridDim.x * blockDim.x)
-        out[i] = round4(bb_upper_tail(k[i], n[i], al, be, bb_pm0(n[i], al, be, lgc0), lgcn));
+__global__ void k_sf4_batch(const uint32_t* k, const uint32_t* n, int64_t items, double al, double be, double lgc0, double lgcn, int32_t* out, double* raw) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < items; i += (int64_t)gridDim.x * blockDim.x) {
+        const double p = bb_upper_tail(k[i], n[i], al, be, bb_pm0(n[i], al, be, lgc0), lgcn);
+        out[i] = round4(p);
+        if (raw) raw[i] = p;
+    }
 }
 
-int run_sf4(lsg_ctx* c, int64_t items, const uint32_t* k, const uint32_t* n, double al, double be, int32_t* out) {
+int run_sf4(lsg_ctx* c, int64_t items, const uint32_t* k, const uint32_t* n, double al, double be, int32_t* out, double* raw) {
     if (items < 0 || (items > 0 && (!k || !n || !out))) { set_error("lsg_betabinom_sf4: bad arguments"); return -2; }
     if (!(al > 0.0) || !(be > 0.0)) { set_error("lsg_betabinom_sf4: alpha and beta must be positive"); return -2; }
     if (items == 0) return 0;
     hipStream_t st = c->stream;
-    DevBuf dk, dn, dout;
-    auto done = [&](int rc) { dk.release(); dn.release(); dout.release(); return rc; };
-    if (dk.reserve((size_t)items * 4) || dn.reserve((size_t)items * 4) || dout.reserve((size_t)items * 4)) return done(-1);
+    DevBuf dk, dn, dout, draw;
+    auto done = [&](int rc) { dk.release(); dn.release(); dout.release(); draw.release(); return rc; };
+    if (dk.reserve((size_t)items * 4) || dn.reserve((size_t)items * 4) || dout.reserve((size_t)items * 4) || (raw && draw.reserve((size_t)items * 8))) return done(-1);
     if (hipMemcpyAsync(dk.p, k, (size_t)items * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
         hipMemcpyAsync(dn.p, n, (size_t)items * 4, hipMemcpyHostToDevice, st) != hipSuccess) { set_error("lsg_betabinom_sf4: upload failed"); return done(-1); }
     unsigned g = (unsigned)((items + 255) / 256); if (g > (unsigned)(c->n_cus * 16)) g = (unsigned)(c->n_cus * 16);
     hipLaunchKernelGGL(k_sf4_batch, dim3(g), dim3(256), 0, st, dk.as<uint32_t>(), dn.as<uint32_t>(), items, al, be,
-                       lgamma(al + be) - lgamma(be), lgamma(al + be) - lgamma(al), dout.as<int32_t>());
+                       lgamma(al + be) - lgamma(be), lgamma(al + be) - lgamma(al), dout.as<int32_t>(), raw ? draw.as<double>() : (double*)nullptr);
+    if (raw && hipMemcpyAsync(raw, draw.p, (size_t)items * 8, hipMemcpyDeviceToHost, st) != hipSuccess) { set_error("lsg_betabinom_sf4: failed"); return done(-1); }
     if (hipMemcpyAsync(out, dout.p, (size_t)items * 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { set_error("lsg_betabinom_sf4: failed"); return done(-1); }
     return done(0);
 }

@@ -19,7 +19,7 @@ int run_select_calls(lsg_ctx* c, int kind, lsg_call* dst_device, int64_t capacit
 int run_probe(lsg_ctx* c, int kind, const int64_t* keys, int64_t n, uint8_t* hits, int on_device);
 int run_genotype(lsg_ctx* c, const lsg_genotype_params* p, int64_t n_sites, const int64_t* site_keys, const uint8_t* alt_sym,
                  uint32_t* dp, uint32_t* alt, int on_device);
-int run_sf4(lsg_ctx* c, int64_t items, const uint32_t* k, const uint32_t* n, double al, double be, int32_t* out);
+int run_sf4(lsg_ctx* c, int64_t items, const uint32_t* k, const uint32_t* n, double al, double be, int32_t* out, double* raw);
 
 // copy a host array to a grow-only device buffer, or adopt a device pointer
 template <class T>
@@ -290,7 +290,13 @@ int lsg_genotype_cells(lsg_ctx* c, const lsg_genotype_params* params, int64_t n_
 int lsg_betabinom_sf4(lsg_ctx* c, int64_t n_items, const uint32_t* k, const uint32_t* n, double alpha, double beta, int32_t* out_p4) {
     if (!c) { set_error("lsg_betabinom_sf4: NULL handle"); return -2; }
     LSG_HIP(hipSetDevice(c->device));
-    return run_sf4(c, n_items, k, n, alpha, beta, out_p4);
+    return run_sf4(c, n_items, k, n, alpha, beta, out_p4, nullptr);
+}
+
+int lsg_betabinom_sf(lsg_ctx* c, int64_t n_items, const uint32_t* k, const uint32_t* n, double alpha, double beta, int32_t* out_p4, double* out_p) {
+    if (!c || !out_p) { set_error("lsg_betabinom_sf: bad arguments"); return -2; }
+    LSG_HIP(hipSetDevice(c->device));
+    return run_sf4(c, n_items, k, n, alpha, beta, out_p4, out_p);
 }
 
 } // extern "C"

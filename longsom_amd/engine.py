@@ -267,6 +267,18 @@ class Engine:
             _lib.check(self._lib.lsg_betabinom_sf4(self._h, len(k), _ptr(k), _ptr(n), float(alpha), float(beta), _ptr(out)), "lsg_betabinom_sf4")
         return out
 
+    def betabinom_sf(self, k, n, alpha: float, beta: float):
+        """(round(p, 4) * 1e4 as int32, p as float64) with p = betabinom.sf(k - 0.001, n, alpha, beta) evaluated on the device"""
+        k = np.ascontiguousarray(k, dtype=np.uint32); n = np.ascontiguousarray(n, dtype=np.uint32)
+        out = np.zeros(len(k), np.int32); raw = np.zeros(len(k), np.float64)
+        if len(k):
+            _lib.check(self._lib.lsg_betabinom_sf(self._h, len(k), _ptr(k), _ptr(n), float(alpha), float(beta), _ptr(out), _ptr(raw)), "lsg_betabinom_sf")
+        return out, raw
+
+    def probe_posset_device(self, kind: int, keys_ptr: int, n: int, hits_ptr: int) -> None:
+        """membership of n device-resident int64 keys in set `kind`, hits (uint8) written to device memory (both caller-owned)"""
+        _lib.check(self._lib.lsg_probe_posset(self._h, kind, C.c_void_p(int(keys_ptr)), int(n), C.c_void_p(int(hits_ptr)), 1), "lsg_probe_posset")
+
     def probe_posset(self, kind: int, keys) -> np.ndarray:
         keys = np.ascontiguousarray(keys, dtype=np.int64)
         hits = np.zeros(len(keys), np.uint8)

@@ -5,6 +5,8 @@ off, odd quality / MAPQ thresholds, hot spots with skewed barcodes, call thresho
 import numpy as np
 import pytest
 
+from tests.util import neg_zero
+
 from longsom_amd import tsvio
 from longsom_amd._lib import CallParams, CountParams
 from longsom_amd.synth_simple import random_records, random_reference
@@ -61,9 +63,9 @@ def test_random_configuration(engine, seed):
     header = [l + "\n" for l in merged.split("\n") if l.startswith("##")]
     got = tsvio.format_step1_tsv(calls, per_ct, names, ct_names, header)
     fasta = {n: r.tobytes().decode() for n, r in zip(names, refs)}
-    want = calling_oracle.step1(merged, fasta, alpha1=call["alpha1"], beta2=call["beta2"], min_ac_cells=call["min_ac_cells"],
-                                min_ac_reads=call["min_ac_reads"], min_cells=call["min_cells"], min_cell_types=call["min_cell_types"],
-                                info_lines=tsvio.STEP1_INFO_LINES).replace("-0.0", "0.0")
+    want = neg_zero(calling_oracle.step1(merged, fasta, alpha1=call["alpha1"], beta2=call["beta2"], min_ac_cells=call["min_ac_cells"],
+                                         min_ac_reads=call["min_ac_reads"], min_cells=call["min_cells"], min_cell_types=call["min_cell_types"],
+                                         info_lines=tsvio.STEP1_INFO_LINES))
     g = [l for l in got.split("\n") if l and not l.startswith("##fileDate=")]
     w = [l for l in want.split("\n") if l and not l.startswith("##fileDate=")]
     bad = [(a, b) for a, b in zip(g, w) if a != b]

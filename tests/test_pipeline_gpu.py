@@ -5,6 +5,8 @@ import os
 import numpy as np
 import pytest
 
+from tests.util import neg_zero
+
 from longsom_amd import hostio, pipeline, synth, tsvio
 from oracle import calling_oracle as co
 from oracle import loader
@@ -45,9 +47,13 @@ def test_fused_chain_matches_oracle_chain(tmp_path, engine):
     for ct, ctn in enumerate(("Cancer", "Non-Cancer")):
         assert strip_date(open(out.counts[ctn]).read()) == strip_date(texts[ct])
     assert strip_date(open(out.merged).read()) == strip_date(merged)
-    assert strip_date(open(out.step1).read()) == strip_date(s1.replace("-0.0", "0.0"))
-    assert strip_date(open(out.step2).read()) == strip_date(s2.replace("-0.0", "0.0"))
-    assert os.path.getsize(out.step3) > 0 and os.path.getsize(out.step3_unfiltered) > 0
+    assert strip_date(open(out.step1).read()) == strip_date(neg_zero(s1))
+    assert strip_date(open(out.step2).read()) == strip_date(neg_zero(s2))
+    # step 3: the host code pinned to the reference's own outputs (tests/test_calling_cpu.py), applied to the ORACLE's step-2 table
+    from longsom_amd import calling
+    final, unfiltered = calling.step3(neg_zero(s2), 0.05, 0.3, 3, 2, 10000)
+    assert open(out.step3).read() == final and open(out.step3_unfiltered).read() == unfiltered
+    assert sum(1 for l in final.split("\n") if l and not l.startswith("#")) > 1
     rep = open(out.report).read().split("\n")
     assert rep[0].split("\t")[:4] == ["Total_reads", "Pass_reads", "CB_not_found", "CB_not_matched"]
     assert int(rep[1].split("\t")[0]) == m.n_reads

@@ -23,3 +23,36 @@ for lo, hi in (((0, 0), (tid_mid, 0)), ((tid_mid, 0), (len(model.contig_len), 0)
     eng.set_region(lo[0], lo[1], hi[0], hi[1]); r, c = eng.pileup_count(); s_, _ = eng.call_step1()
     tot_rows = [a + b for a, b in zip(tot_rows, r)]; tot_cols += c; tot_sites += s_
 print("split totals", tot_rows, tot_cols, tot_sites, "match" if (tot_rows == list(full[0])[:2] and tot_cols == full[1] and tot_sites == full[2]) else "MISMATCH", flush=True)
+
+# ---- C4 as specified: the position sets resident in HBM beside the reads, every step-1 candidate probed (GetExtraFilters' membership
+# tests, BaseCellCalling.step2.py:142-158).  Queries and hits stay on the device; the probe is timed with CUDA events on the engine's stream.
+import json
+import numpy as np
+from longsom_amd import possets
+eng.set_region()
+rows, cols = eng.pileup_count(); ns, nc = eng.call_step1()
+n_q = eng.export_calls(1)
+from longsom_amd import _lib
+buf = torch.zeros(n_q * 336, dtype=torch.uint8, device="cuda")
+assert eng.export_calls(1, buf.data_ptr(), n_q) == n_q
+keys = buf.view(n_q, 336)[:, :8].contiguous().view(torch.int64).flatten() + 1          # lsg_call.key is the record's first field
+q_host = keys.cpu().numpy()
+res = {"reads": n, "step2_rows_probed": int(n_q), "sets": {}}
+hits = torch.zeros(n_q, dtype=torch.uint8, device="cuda")
+for kind, (name, seed, size, frac) in enumerate((("editing", 40, possets.C4_SIZES["editing"], 0.01), ("pon_SR", 41, possets.C4_SIZES["pon"], 0.03))):
+    ks = possets.random_keys(seed, size, model.contig_len, salt=q_host, salt_frac=frac)
+    t0 = time.time(); eng.load_posset(kind, ks); t_load = time.time() - t0
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    best = 1e9
+    for rep in range(3):
+        e0.record(); eng.probe_posset_device(kind, keys.data_ptr(), n_q, hits.data_ptr()); e1.record(); torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1))
+    want = np.zeros(n_q, np.uint8); at = np.searchsorted(ks, q_host); ok = at < len(ks); want[ok] = ks[at[ok]] == q_host[ok]
+    got = hits.cpu().numpy()
+    res["sets"][name] = {"keys": int(len(ks)), "load_s": round(t_load, 3), "probe_ms": round(best, 3), "hits": int(got.sum()), "equals_numpy": bool(np.array_equal(got, want)),
+                         "queries_per_s": n_q / (best / 1e3), "GBps_keys_touched": n_q * np.log2(max(2, len(ks))) * 8 / (best / 1e3) / 1e9}
+    print(name, res["sets"][name], flush=True)
+print("free HBM with reads + sets resident: %.0f GB" % (torch.cuda.mem_get_info()[0] / 1e9))
+import os
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump(res, open("gpurun_out/c4_possets.json", "w"), indent=1)

@@ -35,6 +35,10 @@ out = {"_method": "separate rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | TC
                   "corrected by the factor measured with tools/pmc_calib.hip on the walk kernel's own access pattern (2-byte-per-lane buffer "
                   "loads) and cross-checked against 32*RDREQ_32B + 64*RDREQ_64B + 128*RDREQ_128B.  WRITE_SIZE is taken as reported.",
        "_calibration": cal, "_fetch_correction": factor, "kernels": {}}
+# which build of the kernels this was measured on: bench.py quotes the traffic only for the same sources (bench.csrc_digest)
+sys.path.insert(0, ".")
+import bench
+out["_csrc_sha1"] = bench.csrc_digest()
 for k in sorted(set(fetch) | set(write) | set(rdreq)):
     f, w = avg(fetch[k]["FETCH_SIZE"]), avg(write[k]["WRITE_SIZE"])
     r = rdreq.get(k, {})
