@@ -226,6 +226,7 @@ def main():
         if gather["send"] is None or gather["send"].numel() != per:
             gather["send"] = torch.zeros(per, dtype=torch.uint8, device=dev)
             gather["recv"] = torch.zeros(world * per, dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize()                               # the engine's launches do not queue behind torch's fill
         send, recv = gather["send"], gather["recv"]
         try:
             n_pass = eng.export_calls(2, send.data_ptr() + CALL_BYTES, cap)

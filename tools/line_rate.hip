@@ -46,6 +46,44 @@ __global__ __launch_bounds__(256) void k_wide(const T* p, uint64_t n_elems, uint
     }
     if (acc == 0xdeadbeefu) out[0] = acc;
 }
+// Two DIFFERENT 128-byte lines per load instruction: lanes 0-31 read line i of one stream as dwords, lanes 32-63 line i of a second
+// stream `gap` lines away (what pairing two pileup entries in one instruction would look like: 256 bytes per instruction, but the
+// two lines are not adjacent in memory).  Tells instruction shape apart from DRAM adjacency.
+template <int U>
+__global__ __launch_bounds__(256) void k_pairs(const uint32_t* p, uint64_t n_lines, uint64_t per_wave, uint64_t gap, uint32_t* out) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    uint32_t acc = 0;
+    for (uint64_t i = 0; i < per_wave; i += U) {
+        uint32_t v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint64_t a = (wave * 2 * per_wave + i + u) % n_lines, b = (a + per_wave + gap) % n_lines;
+            v[u] = p[((lane < 32) ? a : b) * 32 + (lane & 31)];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc += v[u];
+    }
+    if (acc == 0xdeadbeefu) out[0] = acc;
+}
+template <int U>
+static void run_pairs(const void* buf, uint64_t n_lines, uint32_t* out, int waves_per_simd, uint64_t gap) {
+    const unsigned blocks = 256u * (unsigned)waves_per_simd;
+    const uint64_t per_wave = 2048;                                   // instructions per wave = 2 x 2048 lines
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+        (void)hipEventRecord(e0, 0);
+        hipLaunchKernelGGL((k_pairs<U>), dim3(blocks), dim3(256), 0, 0, (const uint32_t*)buf, n_lines, per_wave, gap, out);
+        (void)hipEventRecord(e1, 0);
+        (void)hipEventSynchronize(e1);
+        float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) best = ms;
+    }
+    const double bytes = (double)blocks * 4 * per_wave * 256;
+    printf("two lines per instruction, second stream %llu lines away, U=%2d waves/SIMD=%d  %.2f ms  %.0f GB/s\n", (unsigned long long)gap, U, waves_per_simd, best, bytes / best / 1e6);
+}
+
 template <int U, typename T>
 static void run_wide(const void* buf, uint64_t bytes, uint32_t* out, int waves_per_simd) {
     const unsigned blocks = 256u * (unsigned)waves_per_simd;
@@ -98,6 +136,9 @@ int main(int argc, char** argv) {
         run_wide<16, uint32_t>(buf, BYTES, out, w);
         run_wide<16, uint2>(buf, BYTES, out, w);
         run_wide<8, uint4>(buf, BYTES, out, w);
+        run_pairs<16>(buf, n_lines, out, w, 0);
+        run_pairs<16>(buf, n_lines, out, w, 19);
+        run_pairs<16>(buf, n_lines, out, w, 1000003);
     }
     if (hipDeviceSynchronize() != hipSuccess) { fprintf(stderr, "kernel failed\n"); return 1; }
     return 0;
