@@ -324,17 +324,18 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_segments(CountArgs a) {
 }
 
 // Static per load: how many entries a tile can ever hold = the (segment, tile) overlaps of the reads that carry a barcode and lie on
-// their contig (what k_seg_info can admit under ANY parameters or barcode table).
-__global__ void k_tile_caps(int64_t n_segs, const uint32_t* seg_read, const int32_t* seg_start, const int32_t* seg_len, const int32_t* read_tid,
-                            const int32_t* read_cb, const uint32_t* tile_base, const int64_t* contig_len, int32_t n_contigs, uint32_t* cap) {
-    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n_segs; s += (int64_t)gridDim.x * blockDim.x) {
-        const uint32_t r = seg_read[s];
-        const int32_t tid = read_tid[r];
-        if (tid < 0 || tid >= n_contigs || read_cb[r] < 0) continue;
-        const int64_t st = seg_start[s], ln = seg_len[s];
-        if (st < 0 || ln <= 0 || st + ln > contig_len[tid]) continue;
-        const uint32_t t0 = tile_base[tid] + ((uint32_t)st >> 6), t1 = tile_base[tid] + ((uint32_t)(st + ln - 1) >> 6);
-        for (uint32_t t = t0; t <= t1; ++t) atomicAdd(&cap[t], 1u);
+// their contig (what k_seg_info can admit under ANY parameters or barcode table).  Counted by the counting pass itself
+// (k_bin_segments<0>, atomics aggregated per workgroup) over this parameter-free admission record, as ONE cell type.
+__global__ void k_seg_info_static(CountArgs a) {
+    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < a.n_segs; s += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t r = a.seg_read[s];
+        const int32_t tid = a.read_tid[r];
+        uint32_t key = KEY_INVALID, tb = 0;
+        if (tid >= 0 && tid < a.n_contigs && a.read_cb[r] >= 0) {
+            const int64_t st = a.seg_start[s], ln = a.seg_len[s];
+            if (!(st < 0 || ln <= 0 || st + ln > a.contig_len[tid])) { key = 0; tb = a.tile_base[tid]; }
+        }
+        a.seg_info[s] = make_uint2(key, tb);
     }
 }
 
@@ -1607,13 +1608,26 @@ static int tile_capacities(lsg_ctx* c) {
     if (c->tile_caps_valid) return 0;
     hipStream_t st = c->stream;
     const size_t nt = (size_t)c->n_tiles + 2;
-    if (c->d_tile_cap.reserve(nt * 4) || c->d_tile_off.reserve(nt * 4) || c->d_cur_lo.reserve(nt * 4) || c->d_cur_hi.reserve(nt * 4)) return -1;
-    LSG_HIP(hipMemsetAsync(c->d_tile_cap.p, 0, nt * 4, st));
     const int64_t S = c->rd.n_segs;
-    if (S > 0)
-        hipLaunchKernelGGL(k_tile_caps, dim3((unsigned)((S + 255) / 256 < 4096 ? (S + 255) / 256 : 4096)), dim3(256), 0, st, S, c->rd.seg_read, c->rd.seg_start,
-                           c->rd.seg_len, c->rd.read_tid, c->rd.read_cb, c->d_tile_base.as<uint32_t>(), c->d_contig_len.as<int64_t>(), c->n_contigs,
-                           c->d_tile_cap.as<uint32_t>());
+    if (c->d_tile_cap.reserve(nt * 4) || c->d_tile_off.reserve(nt * 4) || c->d_cur_lo.reserve(nt * 4) || c->d_cur_hi.reserve(nt * 4) ||
+        c->ws[WS_SEG_INFO].reserve(((size_t)S + 1) * 8) || c->d_scalars.reserve(SC_COUNT * 8)) return -1;
+    LSG_HIP(hipMemsetAsync(c->d_tile_cap.p, 0, nt * 4, st));
+    LSG_HIP(hipMemsetAsync(c->d_scalars.p, 0, SC_COUNT * 8, st));
+    if (S > 0) {
+        CountArgs a{};
+        a.n_reads = c->rd.n_reads; a.n_segs = S;
+        a.read_tid = c->rd.read_tid; a.read_cb = c->rd.read_cb;
+        a.seg_read = c->rd.seg_read; a.seg_start = c->rd.seg_start; a.seg_len = c->rd.seg_len;
+        a.tile_base = c->d_tile_base.as<uint32_t>(); a.contig_len = c->d_contig_len.as<int64_t>(); a.n_contigs = c->n_contigs;
+        a.n_ct = 1; a.tile_lo = 0; a.tile_hi = c->n_tiles;
+        a.seg_info = c->ws[WS_SEG_INFO].as<uint2>(); a.unit_cnt = c->d_tile_cap.as<uint32_t>();
+        a.scalars = c->d_scalars.as<unsigned long long>();
+        unsigned g = (unsigned)((S + 255) / 256); if (g > (unsigned)(c->n_cus * 16)) g = (unsigned)(c->n_cus * 16);
+        hipLaunchKernelGGL(k_seg_info_static, dim3(g), dim3(256), 0, st, a);
+        unsigned seg_grid = (unsigned)((S + 256 * BIN_SUPER - 1) / (256 * BIN_SUPER));
+        if (seg_grid > (unsigned)(c->n_cus * 8)) seg_grid = (unsigned)(c->n_cus * 8);
+        hipLaunchKernelGGL(k_bin_segments<0>, dim3(seg_grid), dim3(256), 0, st, a);
+    }
     SCAN_U32(c->d_tile_cap.as<uint32_t>(), c->d_tile_off.as<uint32_t>(), c->n_tiles + 1);
     LSG_HIP(hipGetLastError());
     c->tile_caps_valid = true;

@@ -29,7 +29,9 @@ def test_contract_line_and_sharded_run():
     r = one["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     cb = one["cpu_baseline"]
-    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["gpu_matches_oracle_on_sample"] is True
+    assert cb["kind"] == "port" and 1 <= cb["cores"] <= 16 and cb["value"] > 0 and cb["gpu_matches_oracle_on_sample"] is True
+    assert cb["native_1core"]["value"] > 0 and cb["pyloop"]["value_1core"] > 0 and cb["pyloop"]["value_allcores"] > 0 and cb["pyloop"]["cores"] == cb["cores"]
+    assert "traffic_stale" in r and (r["traffic"] is None or r["traffic_stale"] is False)
     assert abs(one["value"] - one["config"]["sites_counted"] / (one["ms_per_step"] / 1e3)) < 1e-3 * one["value"]
 
     two = run_bench(["--gpus", "2", "--reads", "3e5", "--steps", "2", "--warmup", "1"], env={"LSG_BENCH_DEVICE": "0", "LSG_BENCH_BACKEND": "gloo"},

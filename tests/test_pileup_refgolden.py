@@ -139,6 +139,52 @@ def test_gpu_applies_the_depth_cap(engine, max_depth, golden):
     assert table(k, r, c, names, "s.Cancer") == open(os.path.join(G, golden)).read()
 
 
+# ---- per-cell genotyping: the reference's HCCVSingleCellGenotype.py over the same stand-in -------------------
+def genotype_targets():
+    rows = [l.rstrip("\n").split("\t") for l in open(os.path.join(G, "pileup.rand.HCCV.tsv")) if not l.startswith("#")]
+    return rows
+
+
+@pytest.mark.parametrize("tag,flag", [("rand", "All"), ("rand", "Alt"), ("randsfx", "All")])
+def test_genotype_oracle_writes_the_reference_rows(tag, flag):
+    from oracle import genotype_oracle as go
+    from longsom_amd.reanno import SYM_OF_BASE
+    bc, names, refs = rand_inputs(tag)
+    dec = hostio.decode_bam(os.path.join(G, "pileup.%s.bam" % tag), bc.barcodes, min_mapq=0)
+    tid_of = {n: i for i, n in enumerate(names)}
+    sites = {}
+    for r in genotype_targets():                                  # a later line naming the same site wins (:105)
+        sites[(tid_of[r[0]] << 32) | (int(r[1]) - 1)] = r
+    keys = np.asarray(sorted(sites), np.int64)
+    alt_sym = np.asarray([SYM_OF_BASE.get(sites[k][4].split(",")[0], 255) for k in keys.tolist()], np.uint8)
+    dp, alt = go.genotype(dec.records, [len(r) for r in refs], bc.celltype_of, keys, alt_sym, min_bq=30, min_mq=60, alt_only=1 if flag == "Alt" else 0)
+    got = set()
+    for i, k in enumerate(keys.tolist()):
+        r = sites[k]
+        for b, name in enumerate(bc.barcodes):
+            got.add(go.cell_row(r[0], k & 0xFFFFFFFF, r[3], r[4].split(",")[0], r[6], r[13], name, bc.celltype_names[int(bc.celltype_of[b])], int(dp[i, b]), int(alt[i, b]),
+                                0.260288007167716, 173.94711910763732, 0.01, "True"))
+    want = [l for l in open(os.path.join(G, "pileup.%s.genotype.%s.tsv" % (tag, flag))).read().split("\n")[1:] if l]
+    assert len(want) == len(got) == len(keys) * len(bc.barcodes) and set(want) == got
+    assert (tag == "randsfx") == (not any(l.split("\t")[9] != "0" for l in want))      # raw "-1" CBs are not keys of the cleaned table (:160-161)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,flag", [("rand", "All"), ("rand", "Alt"), ("randsfx", "All")])
+def test_gpu_genotype_table_equals_the_reference_file(engine, tmp_path, tag, flag):
+    from longsom_amd import reanno
+    bc, names, refs = rand_inputs(tag)
+    dec = hostio.decode_bam(os.path.join(G, "pileup.%s.bam" % tag), bc.barcodes, min_mapq=0)
+    engine.set_contigs([len(r) for r in refs])
+    engine.set_barcodes(bc.celltype_of, 2); engine.set_region()
+    engine.load_reads(dec.records)
+    out = str(tmp_path / "geno.tsv")
+    n = reanno.single_cell_genotype(engine, os.path.join(G, "pileup.rand.HCCV.tsv"), bc, names, out, alt_flag=flag, min_bq=30, min_mq=60)
+    want = open(os.path.join(G, "pileup.%s.genotype.%s.tsv" % (tag, flag))).read()
+    assert n == want.count("\n") - 1
+    assert open(out).read() == want
+
+
 # ---- GPU ------------------------------------------------------------------------------------------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", sorted(K.CASES))

@@ -17,6 +17,10 @@ Writes under tests/golden/:
   pileup.randsfx.*             the same reads with "-1"-suffixed CB tags and barcodes.tsv entries
   pileup.cap.*                 a small deep pile counted with max_depth = 8 (reference's pileup call patched ONLY in that
                                one keyword through the stand-in, see run_counter(max_depth=...))
+  pileup.rand.HCCV.tsv, pileup.rand.genotype.{All,Alt}.tsv, pileup.randsfx.genotype.All.tsv
+                               per-cell genotyping: the reference's HCCVSingleCellGenotype.py run on the UNSPLIT
+                               random BAM at target sites drawn from its own count tables (every printed class as the expected
+                               alt, chrM sites, sites either side of the 50 kb bin edge)
 """
 import contextlib
 import importlib.util
@@ -231,6 +235,40 @@ def main():
         tables_u, _ = run_chain(split, counter, bam, bc, os.path.join(OUT, "pileup.rand.fa"), "s", os.path.join(work, "cap_u"))
         open(os.path.join(OUT, "pileup.capoff.Cancer.tsv"), "w").write(strip_date(tables_u["Cancer"]))
         print("cap rows", tables["Cancer"].count("\n") - 9, "uncapped", tables_u["Cancer"].count("\n") - 9)
+        # ---- 4. per-cell genotyping at target sites: HCCVSingleCellGenotype.py on the unsplit BAMs
+        geno = load("CellTypeReannotation/HCCVSingleCellGenotype.py", "ref_genotype")
+        rng = np.random.default_rng(7)
+        rows = [l.split("\t") for l in open(os.path.join(OUT, "pileup.rand.Cancer.tsv")).read().split("\n") if l and not l.startswith("#")]
+        pick = sorted(set(rng.choice(len(rows), size=70, replace=False).tolist()) |
+                      {i for i, r in enumerate(rows) if r[0] == "chr1" and int(r[1]) in (49999, 50000, 50001)} |
+                      {i for i, r in enumerate(rows) if r[0] == "chrM" and int(r[1]) % 7 == 0})
+        hccv = os.path.join(OUT, "pileup.rand.HCCV.tsv")
+        cols = ["#CHROM", "Start", "End", "REF", "ALT", "FILTER", "Cell_types", "Up_context", "Down_context", "N_ALT", "Dp", "Nc", "Bc", "Cc", "VAF", "MCF"]
+        with open(hccv, "w") as f:
+            f.write("##INFO=HCCV_FILTER,Description=targets for the genotyping fixture\n" + "\t".join(cols) + "\n")
+            for n, i in enumerate(pick):
+                r = rows[i]
+                bc = [int(x) for x in r[4].split("|")[3].split(":")]                     # BC of the six printed classes
+                order = [j for j in np.argsort(bc)[::-1].tolist() if "ACTGID"[j] != r[2]]
+                alt = "ACTGID"[order[0]] if bc[order[0]] > 0 and n % 3 else "ACTGIDN"[n % 7]
+                if alt == r[2]:
+                    alt = "N"
+                f.write("\t".join([r[0], r[1], r[1], r[2], alt + (",X" if n % 5 == 0 else ""), "PASS", "Cancer", ".", ".", "1", "9", "9", "3", str(2 + n % 4), "0.3", "0.3"]) + "\n")
+        for tag, flag in (("rand", "All"), ("rand", "Alt"), ("randsfx", "All")):
+            out = os.path.join(OUT, "pileup.%s.genotype.%s.tsv" % (tag, flag))
+            tmp = os.path.join(work, "geno_%s_%s" % (tag, flag))
+            old = sys.argv
+            sys.argv = ["HCCVSingleCellGenotype.py", "--bam", os.path.join(OUT, "pileup.%s.bam" % tag), "--infile", hccv, "--ref", os.path.join(OUT, "pileup.rand.fa"),
+                        "--meta", os.path.join(OUT, "pileup.%s.barcodes.tsv" % tag), "--outfile", out, "--alt_flag", flag, "--nprocs", "1", "--min_mq", "60",
+                        "--tmp_dir", tmp, "--chrM_contaminant", "True"]
+            try:
+                with contextlib.redirect_stdout(io.StringIO()):
+                    geno.main()
+            finally:
+                sys.argv = old
+            text = open(out).read()
+            print("genotype", tag, flag, text.count("\n") - 1, "rows,", sum(1 for l in text.split("\n") if l.endswith("PASS")), "PASS,",
+                  sum(1 for l in text.split("\n")[1:] if l and l.split("\t")[9] != "0"), "covered")
     finally:
         shutil.rmtree(work, ignore_errors=True)
 
