@@ -188,9 +188,13 @@ def main():
     if "LSG_BENCH_DEVICE" in os.environ:
         local_rank = int(os.environ["LSG_BENCH_DEVICE"])
     backend = os.environ.get("LSG_BENCH_BACKEND", "nccl")
-    if world > 1:
+    # LSG_BENCH_FORCE_DIST=1: bring the process group up and run the per-step all-gather even with ONE rank — the only way to put the
+    # RCCL code path (device tensors, all_gather_into_tensor, barrier, all_reduce) through its paces on a one-GPU box
+    dist_on = world > 1 or os.environ.get("LSG_BENCH_FORCE_DIST") == "1"
+    if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend, rank=rank, world_size=world)
     else:
@@ -251,7 +255,7 @@ def main():
         rows, cols = eng.pileup_count(cp)
         n_sites, n_cand = eng.call_step1(kp)
         n_pass = 0
-        if world > 1:
+        if dist_on:
             n_pass = exchange()
             if check:
                 counts = gathered_counts()
@@ -262,9 +266,9 @@ def main():
                 gather["counts"] = counts
         return rows, cols, n_sites, n_cand, n_pass
 
-    for _ in range(max(args.warmup, 1) if world > 1 else args.warmup):
+    for _ in range(max(args.warmup, 1) if dist_on else args.warmup):
         step(check=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -278,17 +282,17 @@ def main():
         walk_bytes += 2.0 * e_walk + 24.0 * st.n_reads_admitted * (e_walk / e_tot) + 168.0 * r_walk
         path_bytes += 2.0 * st.n_events_admitted + 24.0 * st.n_reads_admitted + 168.0 * sum(rows)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         counts = gathered_counts()                                 # after the clock: the timed exchanges all fitted
         if max(counts) > gather["cap"]:
             raise RuntimeError("PASS-candidate rows outgrew the agreed all-gather capacity during the timed steps: %s > %d" % (counts, gather["cap"]))
         gather["counts"] = counts
     vals = torch.tensor([dt, float(cols), float(n_sites), float(n_cand), float(n_reads), float(n_events), float(sum(rows))],
                         dtype=torch.float64, device=dev)
-    if world > 1:
+    if dist_on:
         if backend != "nccl":
             vals = vals.cpu()
         mx = vals.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
@@ -319,8 +323,8 @@ def main():
                        "reads": model.n_reads, "barcodes": model.n_cb, "reads_loaded_all_ranks": int(tot[4]), "event_slots_resident_all_ranks": int(tot[5]),
                        "sites_counted": int(sites), "rows_emitted": int(tot[6]), "merged_sites": int(tot[2]), "step1_candidates": int(tot[3]),
                        "sharding": "genomic regions balanced by read count" if world > 1 else "none",
-                       "pass_rows_gathered": int(sum(gather["counts"])) if world > 1 and gather["counts"] else None,
-                       "exchange": "one all-gather per step, %d-row slots agreed in warm-up" % gather["cap"] if world > 1 else None,
+                       "pass_rows_gathered": int(sum(gather["counts"])) if dist_on and gather["counts"] else None,
+                       "exchange": "one all-gather per step (%s), %d-row slots agreed in warm-up" % (backend, gather["cap"]) if dist_on else None,
                        "path_algorithmic_GBps_rank0": path_bytes / dt / 1e9,
                        "end_to_end": e2e},
             "roofline": {"bound": "hbm", "kernel": "k_walk_block", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -330,7 +334,7 @@ def main():
         if base is not None:
             out["cpu_baseline"] = base
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

@@ -103,13 +103,14 @@ class Comm:
     world: int = 1
     rank: int = 0
     device: Optional[object] = None        # torch.device the collectives' tensors live on (cuda:<local rank> for nccl)
+    grouped: bool = False                  # a process group is up (world > 1, or a forced one-rank group)
 
     @classmethod
     def from_env(cls, device_index: Optional[int] = None) -> "Comm":
         """WORLD_SIZE / RANK / LOCAL_RANK as torch.distributed.run sets them.  Must run BEFORE the first HIP call of the process
         when RCCL is the backend.  LSG_DIST_BACKEND=gloo (+ LSG_DIST_DEVICE) rehearses several ranks on one GPU."""
         world = int(os.environ.get("WORLD_SIZE", "1"))
-        if world <= 1:
+        if world <= 1 and os.environ.get("LSG_DIST_FORCE") != "1":       # LSG_DIST_FORCE=1: a one-rank group (RCCL on a one-GPU box)
             return cls()
         import torch
         import torch.distributed as dist
@@ -122,20 +123,22 @@ class Comm:
             torch.cuda.set_device(local)
         if not dist.is_initialized():
             dist.init_process_group(backend, rank=rank, world_size=world)
-        return cls(world, rank, torch.device("cuda", local) if backend == "nccl" else torch.device("cpu"))
+        c = cls(world, rank, torch.device("cuda", local) if backend == "nccl" else torch.device("cpu"))
+        c.grouped = True
+        return c
 
     @property
     def local_device_index(self) -> int:
         return int(os.environ.get("LSG_DIST_DEVICE", os.environ.get("LOCAL_RANK", "0"))) if self.world > 1 else 0
 
     def barrier(self) -> None:
-        if self.world > 1:
+        if self.grouped:
             import torch.distributed as dist
             dist.barrier()
 
     def allgather_bytes(self, payload: bytes) -> List[bytes]:
         """every rank's payload on every rank: one all-gather of the lengths, one of the padded bytes"""
-        if self.world == 1:
+        if not self.grouped:
             return [payload]
         import torch
         import torch.distributed as dist
@@ -153,7 +156,7 @@ class Comm:
         return [recv[r * cap: r * cap + sizes[r]].tobytes() for r in range(self.world)]
 
     def close(self) -> None:
-        if self.world > 1:
+        if self.grouped:
             import torch.distributed as dist
             if dist.is_initialized():
                 dist.destroy_process_group()

@@ -48,3 +48,33 @@ def test_contract_line_and_sharded_run():
                       launcher=[sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                                 "--master-port", "29534"])
     assert tight["config"]["pass_rows_gathered"] == two["config"]["pass_rows_gathered"]
+
+
+def test_rccl_code_path_with_one_rank():
+    """RCCL cannot host two ranks on one GPU, but a ONE-rank nccl group can: the bench's collective code (device tensors through
+    all_gather_into_tensor, barrier, all_reduce on backend nccl = RCCL) runs for real, and moves the rows the gloo rehearsal moves"""
+    forced = run_bench(["--reads", "3e5", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], env={"LSG_BENCH_FORCE_DIST": "1"})
+    plain = run_bench(["--reads", "3e5", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"])
+    assert forced["n_gpus"] == 1 and "nccl" in forced["config"]["exchange"] and forced["config"]["pass_rows_gathered"] is not None
+    for k in ("sites_counted", "rows_emitted", "merged_sites", "step1_candidates"):
+        assert forced["config"][k] == plain["config"][k], k
+
+
+def test_product_allgather_over_rccl_with_one_rank(tmp_path):
+    """regions.Comm on backend nccl with a single rank: the product's byte all-gather (candidate rows of the sharded SNV run)"""
+    import subprocess, textwrap
+    code = textwrap.dedent("""
+        import os, sys
+        sys.path.insert(0, %r)
+        os.environ.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", LSG_DIST_FORCE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+        from longsom_amd import regions
+        comm = regions.Comm.from_env()
+        assert comm.device is not None and comm.device.type == "cuda"
+        got = comm.allgather_bytes(regions.pack_rows({("chr1", 7): "row\\n"}))
+        comm.barrier()
+        assert regions.unpack_rows(got) == "row\\n"
+        comm.close()
+        print("rccl one-rank ok")
+    """ % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "rccl one-rank ok" in r.stdout, r.stderr[-2000:]
