@@ -95,6 +95,7 @@ struct CountArgs {
     uint32_t zero_lo, zero_hi;            // address (e, m form) of a 128-byte line of zeros behind the resident events
     uint32_t presorted;                   // multi-slot units' records were written grouped by k_sort_deep (no k_group_block pass, any slot size)
     uint32_t two_ended;                   // <= 2 cell types: a tile's static entry region is filled from both ends, no counting pass
+    uint32_t inline_seg_info;             // k_bin_segments computes the admission record itself (no k_seg_info launch)
     const uint32_t* tile_off; uint32_t* cur_lo; uint32_t* cur_hi;      // [n_tiles + 1] static region starts; cursors of this count
     const uint8_t* read_drop;             // reads the pileup's max_depth rule drops (layout.hip depth_cap_drops), or null
     unsigned long long* scalars;
@@ -192,10 +193,22 @@ template <int MODE>
 __device__ __forceinline__ BinSeg bin_load(const CountArgs& a, int64_t s) {
     BinSeg g; g.key = KEY_INVALID; g.tb = 0; g.t0 = 0; g.st = 0; g.ln = 0; g.ntile = 0; g.evoff = 0;
     if (s < a.n_segs) {
-        const uint2 info = a.seg_info[s];
-        g.key = info.x; g.tb = info.y;
         g.st = a.seg_start[s];
         g.ln = a.seg_len[s];
+        if (a.inline_seg_info) {
+            // the admission record computed here instead of by k_seg_info: with one binning pass left (two-ended scatter) it is read
+            // twice, and the gathers segment -> read -> contig table run along the coordinate-sorted reads
+            const uint32_t r = a.seg_read[s];
+            g.key = a.read_key[r];
+            if (g.key != KEY_INVALID) {
+                const int32_t tid = a.read_tid[r];
+                if (g.st < 0 || g.ln <= 0 || (int64_t)g.st + g.ln > a.contig_len[tid]) g.key = KEY_INVALID;
+                else g.tb = a.tile_base[tid];
+            }
+        } else {
+            const uint2 info = a.seg_info[s];
+            g.key = info.x; g.tb = info.y;
+        }
         if (MODE == 2 && g.key != KEY_INVALID) g.evoff = a.seg_ev_off[s];
     }
     bool ok = g.key != KEY_INVALID;
@@ -220,6 +233,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_segments(CountArgs a) {
     const int64_t n_batches = (a.n_segs + BIN_THREADS - 1) / BIN_THREADS;
     const int64_t n_super = (n_batches + BIN_SUPER - 1) / BIN_SUPER;
     unsigned long long* qhead = &a.scalars[MODE == 0 ? SC_QBIN0 : SC_QBIN2];
+    unsigned long long st_seg = 0, st_ev = 0;
     for (bool first = true;; first = false) {
         __syncthreads();
         // every workgroup's first item is its own index: no storm of same-address atomics at launch (~90 per us serialise)
@@ -239,6 +253,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_segments(CountArgs a) {
             bool stop = false;
             while (!stop && b < b1) {
                 const BinSeg g = bin_load<MODE>(a, b * BIN_THREADS + t);
+                if (MODE == 2 && r == 0 && g.key != KEY_INVALID) { ++st_seg; st_ev += (unsigned long long)g.ln; }      // k_seg_info's statistics when it does not run
                 const uint32_t ct = g.key >> 28;
                 const int ni_first = ni;
                 int wmax = g.ntile;
@@ -320,6 +335,16 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_segments(CountArgs a) {
             }
             cb = b; cr = r;
         }
+    }
+    if (MODE == 2 && a.inline_seg_info) {
+        for (int o = 32; o > 0; o >>= 1) { st_seg += __shfl_down(st_seg, o); st_ev += __shfl_down(st_ev, o); }
+        __shared__ unsigned long long s_st[2];
+        __syncthreads();
+        if (t == 0) { s_st[0] = 0; s_st[1] = 0; }
+        __syncthreads();
+        if (lane == 0 && st_seg) { atomicAdd(&s_st[0], st_seg); atomicAdd(&s_st[1], st_ev); }
+        __syncthreads();
+        if (t == 0 && s_st[0]) { atomicAdd(&a.scalars[SC_SEGS], s_st[0]); atomicAdd(&a.scalars[SC_EVENTS], s_st[1]); }
     }
 }
 
@@ -1580,6 +1605,7 @@ static void fill_args(lsg_ctx* c, const lsg_count_params* p, CountArgs& a) {
     for (int i = 0; i < LSG_MAX_CELLTYPES; ++i) a.rows[i] = c->d_rows[i].as<uint32_t>();
     a.row_cap = c->row_cap;
     a.two_ended = c->n_ct <= 2 && !getenv("LSG_COUNT_PASS") ? 1u : 0u;
+    a.inline_seg_info = a.two_ended && !getenv("LSG_SEG_INFO_KERNEL") ? 1u : 0u;
     a.tile_off = c->d_tile_off.as<uint32_t>(); a.cur_lo = c->d_cur_lo.as<uint32_t>(); a.cur_hi = c->d_cur_hi.as<uint32_t>();
     a.read_drop = c->has_drops ? c->d_read_drop.as<uint8_t>() : nullptr;
 }
@@ -1681,7 +1707,7 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
     unsigned seg_grid = (unsigned)((S + 256 * BIN_SUPER - 1) / (256 * BIN_SUPER));
     if (seg_grid > (unsigned)(c->n_cus * 8)) seg_grid = (unsigned)(c->n_cus * 8);
     if (R > 0) { unsigned g = (unsigned)((R + 255) / 256); if (g > (unsigned)(c->n_cus * 8)) g = (unsigned)(c->n_cus * 8); hipLaunchKernelGGL(k_read_key, dim3(g), dim3(256), 0, st, a); }
-    if (S > 0) { unsigned g = (unsigned)((S + 255) / 256); if (g > (unsigned)(c->n_cus * 16)) g = (unsigned)(c->n_cus * 16); hipLaunchKernelGGL(k_seg_info, dim3(g), dim3(256), 0, st, a); }
+    if (S > 0 && !a.inline_seg_info) { unsigned g = (unsigned)((S + 255) / 256); if (g > (unsigned)(c->n_cus * 16)) g = (unsigned)(c->n_cus * 16); hipLaunchKernelGGL(k_seg_info, dim3(g), dim3(256), 0, st, a); }
     if (two_ended) {
         // ONE pass over the segments: every tile owns a static region of the entry buffer (tile_capacities), cell type 0 fills it
         // from the front and cell type 1 from the back, the units' sizes fall out of the cursors
