@@ -173,7 +173,7 @@ def recorded_traffic():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--reads", type=float, default=None, help="override the read count (development only; the reported config changes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

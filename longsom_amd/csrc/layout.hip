@@ -67,10 +67,23 @@ __global__ void k_span_marks(const uint32_t* seg_read, const int32_t* seg_start,
 // Upper bound on the reads the reference's pileup engine holds at once while it walks one cell type's BAM
 // (bam.pileup(..., max_depth = 200000), BaseCellCounter.py:191): reads of that cell type whose span overlaps a 64-position
 // tile, maximum over tiles and cell types.  Evaluated on request (lsg_max_live_reads), cached until reads or barcodes change.
+static int live_read_bound_impl(lsg_ctx* c, bool by_ct, int64_t* out);
+
 int live_read_bound(lsg_ctx* c) {
     if (c->max_live_reads >= 0) return 0;
+    return live_read_bound_impl(c, c->n_ct > 0 && c->n_cb > 0, &c->max_live_reads);
+}
+
+// the same bound over every read that carries a barcode, whatever its cell type: does not depend on the barcode table (cached per
+// load) and is >= the per-cell-type bound, so "all reads <= max_depth" settles the question for every table
+int live_read_bound_all(lsg_ctx* c) {
+    if (c->max_live_all >= 0) return 0;
+    return live_read_bound_impl(c, false, &c->max_live_all);
+}
+
+static int live_read_bound_impl(lsg_ctx* c, bool by_ct, int64_t* out) {
     const int64_t S = c->rd.n_segs;
-    if (S <= 0 || c->n_tiles == 0) { c->max_live_reads = 0; return 0; }
+    if (S <= 0 || c->n_tiles == 0) { *out = 0; return 0; }
     hipStream_t st = c->stream;
     const size_t T = (size_t)c->n_tiles + 1;
     DevBuf diff, run, tmp, mx;
@@ -80,7 +93,6 @@ int live_read_bound(lsg_ctx* c) {
     if (hipcub::DeviceScan::InclusiveSum(nullptr, tb, diff.as<int32_t>(), run.as<int32_t>(), (int)T, st) != hipSuccess ||
         hipcub::DeviceReduce::Max(nullptr, tb2, run.as<int32_t>(), mx.as<int32_t>(), (int)T, st) != hipSuccess ||
         tmp.reserve((tb > tb2 ? tb : tb2) + 256)) return fail(-1);
-    const bool by_ct = c->n_ct > 0 && c->n_cb > 0;
     int64_t best = 0;
     for (int ct = 0; ct < (by_ct ? c->n_ct : 1); ++ct) {
         if (hipMemsetAsync(diff.p, 0, T * 4, st) != hipSuccess) { set_error("live bound: memset failed"); return fail(-1); }
@@ -94,7 +106,7 @@ int live_read_bound(lsg_ctx* c) {
         if (hipMemcpyAsync(&m, mx.p, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { set_error("live bound: %s", hipGetErrorString(hipGetLastError())); return fail(-1); }
         if (m > best) best = m;
     }
-    c->max_live_reads = best;
+    *out = best;
     return fail(0);
 }
 
@@ -120,8 +132,10 @@ __global__ void k_read_end_init(const int32_t* read_pos, int64_t n_reads, int32_
 int depth_cap_drops(lsg_ctx* c, const lsg_count_params* p) {
     c->has_drops = false; c->n_depth_dropped = 0;
     if (p->max_depth <= 0 || c->rd.n_reads <= 0 || c->n_ct <= 0) return 0;
+    if (live_read_bound_all(c)) return -1;
+    if (c->max_live_all + 1 <= (int64_t)p->max_depth) return 0;           // not even all reads together fill a buffer: nothing is ever dropped
     if (live_read_bound(c)) return -1;
-    if (c->max_live_reads + 1 <= (int64_t)p->max_depth) return 0;          // no buffer can exceed the cap: nothing is ever dropped
+    if (c->max_live_reads + 1 <= (int64_t)p->max_depth) return 0;          // no cell type's buffer can exceed the cap
     hipStream_t st = c->stream;
     const int64_t R = c->rd.n_reads, S = c->rd.n_segs;
     DevBuf d_end;
@@ -173,7 +187,7 @@ int depth_cap_drops(lsg_ctx* c, const lsg_count_params* p) {
 
 int relayout_events(lsg_ctx* c) {
     const int64_t S = c->rd.n_segs;
-    c->max_live_reads = -1;
+    c->max_live_reads = -1; c->max_live_all = -1;
     if (S <= 0) { c->rd.n_events = 0; return 0; }
     hipStream_t st = c->stream;
     DevBuf slots, base, noff, tmp, flag, aligned;

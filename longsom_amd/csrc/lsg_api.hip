@@ -115,6 +115,7 @@ int lsg_set_contigs(lsg_ctx* c, int32_t n_contigs, const int64_t* lengths) {
     c->n_tiles = (uint32_t)t;
     c->tile_lo = 0; c->tile_hi = (uint32_t)t;
     c->tile_caps_valid = false;
+    c->max_live_reads = -1; c->max_live_all = -1;
     for (auto& b : c->ref) b.release();
     c->ref.assign(n_contigs, DevBuf());
     c->ref_ptr.assign(n_contigs, nullptr);

@@ -100,6 +100,7 @@ struct lsg_ctx {
     lsg::DevBuf d_tile_cap, d_tile_off, d_cur_lo, d_cur_hi;
     bool tile_caps_valid = false;
     int64_t max_live_reads = -1;          // layout.hip: bound on the reads live at once in the reference's pileup buffer (-1 = stale)
+    int64_t max_live_all = -1;            // the same over all reads with a barcode: table-independent, cached per load
     lsg::DevBuf d_read_drop;              // layout.hip: per read, 1 = dropped by the pileup's max_depth rule under the last count's parameters
     bool has_drops = false;
     int64_t n_depth_dropped = 0;
