@@ -72,7 +72,7 @@ void lsg_destroy(lsg_ctx* c) {
                       &c->b_read_flag, &c->b_read_mapq, &c->b_read_cb, &c->b_seg_read, &c->b_seg_start, &c->b_seg_len,
                       &c->b_seg_ev_off, &c->b_events, &c->d_read_key, &c->d_unit_cnt, &c->d_unit_off, &c->d_unit_fill,
                       &c->d_ne_units, &c->d_ne_mask, &c->d_ne_rowbase, &c->d_ne_rowoff,
-                      &c->d_scalars, &c->d_cub_tmp, &c->d_tile_cap, &c->d_tile_off, &c->d_cur_lo, &c->d_cur_hi, &c->d_calls, &c->d_site_off, &c->d_tail_table, &c->d_pass_list};
+                      &c->d_scalars, &c->d_cub_tmp, &c->d_ix0, &c->d_ix1, &c->d_ix2, &c->d_ix_netile, &c->d_ix_chunk, &c->d_ix_carry, &c->d_ix_stat, &c->d_tile_cap, &c->d_tile_off, &c->d_cur_lo, &c->d_cur_hi, &c->d_calls, &c->d_site_off, &c->d_tail_table, &c->d_pass_list};
     for (auto* b : bufs) b->release();
     for (auto& b : c->d_rows) b.release();
     for (auto& b : c->ref) b.release();
@@ -114,7 +114,7 @@ int lsg_set_contigs(lsg_ctx* c, int32_t n_contigs, const int64_t* lengths) {
     c->tile_base[n_contigs] = (uint32_t)t;
     c->n_tiles = (uint32_t)t;
     c->tile_lo = 0; c->tile_hi = (uint32_t)t;
-    c->tile_caps_valid = false;
+    c->tile_caps_valid = false; c->index_valid = false;
     c->max_live_reads = -1; c->max_live_all = -1;
     for (auto& b : c->ref) b.release();
     c->ref.assign(n_contigs, DevBuf());

@@ -99,6 +99,13 @@ struct lsg_ctx {
     // tile's region of the entry buffer; with <= 2 cell types the scatter fills a region from both ends and needs no counting pass
     lsg::DevBuf d_tile_cap, d_tile_off, d_cur_lo, d_cur_hi;
     bool tile_caps_valid = false;
+    // pileup.hip "tile index": every tile's entries sorted by barcode ONCE per load (independent of parameters and of the barcode ->
+    // cell-type table); a count then resolves admission and cell type in one streaming pass instead of scattering and sorting again
+    lsg::DevBuf d_ix0, d_ix1, d_ix2, d_ix_netile, d_ix_chunk, d_ix_carry, d_ix_stat;
+    uint64_t ix_n = 0;                    // static entries
+    uint32_t ix_n_netile = 0;             // tiles that hold any
+    bool index_valid = false;
+    bool index_path = false;              // the last / current count runs on the tile index
     int64_t max_live_reads = -1;          // layout.hip: bound on the reads live at once in the reference's pileup buffer (-1 = stale)
     int64_t max_live_all = -1;            // the same over all reads with a barcode: table-independent, cached per load
     lsg::DevBuf d_read_drop;              // layout.hip: per read, 1 = dropped by the pileup's max_depth rule under the last count's parameters

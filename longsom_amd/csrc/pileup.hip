@@ -98,6 +98,12 @@ struct CountArgs {
     uint32_t inline_seg_info;             // k_bin_segments computes the admission record itself (no k_seg_info launch)
     const uint32_t* tile_off; uint32_t* cur_lo; uint32_t* cur_hi;      // [n_tiles + 1] static region starts; cursors of this count
     const uint8_t* read_drop;             // reads the pileup's max_depth rule drops (layout.hip depth_cap_drops), or null
+    // tile index (static per load): entries in (tile, barcode) order
+    const uint32_t* ix0; const uint32_t* ix1; const uint32_t* ix2;      // cb | events-1 << 24 | fwd << 30 | run start << 31; line; flag12 | mapq << 12 | tile start << 20 | segment start << 21
+    const uint32_t* ix_netile; const int32_t* ix_chunk; unsigned long long* ix_carry;
+    uint64_t ix_n;
+    uint32_t index_path;                  // this count runs on the tile index (k_resolve) instead of the scatter + sort + group
+    uint64_t* ixb_key; uint32_t* ixb_read;      // index build only: the scatter also writes (tile << 24 | cb) and the read of every entry
     unsigned long long* scalars;
     uint32_t* rows[LSG_MAX_CELLTYPES];
     uint64_t row_cap;
@@ -162,7 +168,7 @@ constexpr int BIN_SUPER = 16;          // batches per dequeue
 constexpr int BIN_MAXI = 32;           // items per chunk
 constexpr uint32_t BIN_FILL = BIN_H * 5 / 8;
 
-struct BinSeg { uint32_t key, tb, t0; int32_t st, ln, ntile; int64_t evoff; };
+struct BinSeg { uint32_t key, tb, t0, rd; int32_t st, ln, ntile; int64_t evoff; };
 
 // Per-segment admission record {key, first tile of the contig}: the three-level gather segment -> read -> contig tables is
 // done ONCE per count by this streaming kernel; the binning passes (one for the counts, two for the scatter) then read 8
@@ -191,7 +197,7 @@ __global__ void k_seg_info(CountArgs a) {
 
 template <int MODE>
 __device__ __forceinline__ BinSeg bin_load(const CountArgs& a, int64_t s) {
-    BinSeg g; g.key = KEY_INVALID; g.tb = 0; g.t0 = 0; g.st = 0; g.ln = 0; g.ntile = 0; g.evoff = 0;
+    BinSeg g; g.key = KEY_INVALID; g.tb = 0; g.t0 = 0; g.rd = 0; g.st = 0; g.ln = 0; g.ntile = 0; g.evoff = 0;
     if (s < a.n_segs) {
         g.st = a.seg_start[s];
         g.ln = a.seg_len[s];
@@ -209,7 +215,7 @@ __device__ __forceinline__ BinSeg bin_load(const CountArgs& a, int64_t s) {
             const uint2 info = a.seg_info[s];
             g.key = info.x; g.tb = info.y;
         }
-        if (MODE == 2 && g.key != KEY_INVALID) g.evoff = a.seg_ev_off[s];
+        if (MODE == 2 && g.key != KEY_INVALID) { g.evoff = a.seg_ev_off[s]; if (a.ixb_read) g.rd = a.seg_read[s]; }
     }
     bool ok = g.key != KEY_INVALID;
     uint32_t t0 = g.tb + ((uint32_t)g.st >> 6);
@@ -326,6 +332,10 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_segments(CountArgs a) {
                             // the line of this tile slot: the event of (lo) sits at lane (lo - tstart) of it
                             const uint64_t line = (uint64_t)(g.evoff + (lo - g.st) - (lo - tstart)) >> 6;      // 64 events = 128 bytes
                             a.ent[pos] = make_uint2((g.key & CB_MASK) | ((uint32_t)(hi - lo - 1) << 24) | (((g.key >> 24) & 1u) ? 0u : META_FWD), (uint32_t)line);
+                            if (a.ixb_key) {          // index build: sort key and owner of the entry; bit 31 of the read word = first entry of its segment
+                                a.ixb_key[pos] = ((uint64_t)tt << 24) | (g.key & CB_MASK);
+                                a.ixb_read[pos] = g.rd | (lo == g.st ? 0x80000000u : 0u);
+                            }
                         }
                     }
                 }
@@ -358,7 +368,7 @@ __global__ void k_seg_info_static(CountArgs a) {
         uint32_t key = KEY_INVALID, tb = 0;
         if (tid >= 0 && tid < a.n_contigs && a.read_cb[r] >= 0) {
             const int64_t st = a.seg_start[s], ln = a.seg_len[s];
-            if (!(st < 0 || ln <= 0 || st + ln > a.contig_len[tid])) { key = 0; tb = a.tile_base[tid]; }
+            if (!(st < 0 || ln <= 0 || st + ln > a.contig_len[tid])) { key = (uint32_t)a.read_cb[r] | (((uint32_t)a.read_flag[r] >> 4 & 1u) << 24); tb = a.tile_base[tid]; }
         }
         a.seg_info[s] = make_uint2(key, tb);
     }
@@ -814,6 +824,17 @@ __device__ __forceinline__ void walk(const CountArgs& a, Acc& acc, const uint32_
     }
 }
 
+// the same over grouped 8-byte records in global memory (tile index path: the records arrive grouped, nothing is staged)
+__device__ __forceinline__ void walk_rec(const CountArgs& a, Acc& acc, const uint2* rec, int j0, int j1, uint32_t* pk, int lane) {
+    const uint32_t thr = bq_threshold(a);
+    for (int jb = j0; jb < j1; jb += 64) {
+        const int nb = j1 - jb < 64 ? j1 - jb : 64;
+        uint32_t e = a.zero_lo, m = a.zero_hi;
+        if (lane < nb) { const uint2 r = rec[jb + lane]; e = r.x; m = r.y; acc.nev += meta_events(m); }
+        walk_regs(acc, e, m, nb, thr, pk, lane);
+    }
+}
+
 // Group n entries (global SoA arrays at src) by barcode into the LDS arrays gkey/gev/gmeta:
 // entries with equal barcodes become adjacent.  T threads cooperate (T = 64: one wave, fences
 // only; T = BLOCK_THREADS: __syncthreads).  When `filter` is set only entries whose barcode bucket
@@ -1036,9 +1057,13 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void k_pileup_wave(CountArgs 
         }
         // slot 0's entries (one per lane) when it is a one-batch slot; later slots are prefetched one slot ahead
         uint4 cur = make_uint4(KEY_INVALID, 0u, 0u, 0u);
+        auto fetch = [&](uint32_t off) -> uint4 {              // tile index path: grouped records {line address, meta with the run flags}
+            if (a.index_path) { const uint2 r = a.rec[off + lane]; return make_uint4(0u, r.x, r.y, 0u); }
+            return unpack_entry(a, a.ent[off + lane]);
+        };
         {
             const int n0 = (int)rl(s_cnt, 0);
-            if (n0 <= 64 && lane < n0) cur = unpack_entry(a, a.ent[rl(s_off, 0) + lane]);
+            if (n0 <= 64 && lane < n0) cur = fetch(rl(s_off, 0));
         }
         for (int qi = 0; qi < nq; ++qi) {
             const uint32_t w = rl(s_w, qi), src = rl(s_off, qi);
@@ -1050,13 +1075,21 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void k_pileup_wave(CountArgs 
             uint4 nxt = make_uint4(KEY_INVALID, 0u, 0u, 0u);
             if (qi + 1 < nq) {
                 const int nn = (int)rl(s_cnt, qi + 1);
-                if (nn <= 64 && lane < nn) nxt = unpack_entry(a, a.ent[rl(s_off, qi + 1) + lane]);
+                if (nn <= 64 && lane < nn) nxt = fetch(rl(s_off, qi + 1));
             }
             int refb = 'N';
             { const int64_t pos = (int64_t)tstart + lane; if (pos >= 1 && pos < a.contig_len[tid]) refb = a.ref_ptr[tid][pos]; }
             Acc acc; acc.init();
             bool general = n > 64;
-            if (!general) {
+            if (!general && a.index_path) {
+                // the records say it themselves: every entry starts a run of its own <=> no barcode occurs twice
+                general = __ballot(lane < n && !(cur.z & META_NEWRUN)) != 0ull;
+                if (!general) {
+                    const uint32_t m = lane < n ? cur.z : a.zero_hi;
+                    if (lane < n) acc.nev += meta_events(m);
+                    walk_regs<true>(acc, lane < n ? cur.y : a.zero_lo, m, n, bq_threshold(a), pk, lane);
+                }
+            } else if (!general) {
                 // one batch: if no barcode occurs twice every entry is its own run and no grouping is needed
                 L.tcnt[lane] = KEY_INVALID; L.tcnt[lane + 64] = KEY_INVALID;
                 lds_fence();
@@ -1078,7 +1111,9 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void k_pileup_wave(CountArgs 
                     walk_regs<true>(acc, lane < n ? cur.y : a.zero_lo, m, n, bq_threshold(a), pk, lane);
                 }
             }
-            if (general) {
+            if (general && a.index_path) {
+                walk_rec(a, acc, a.rec + src, 0, n, pk, lane);               // grouped already
+            } else if (general) {
                 lds_fence();
                 group_by_cb<false, HW, CAPW>(a, src, n, L.gkey, L.gev, L.gmeta, L.tkey, L.tcnt, lane, nullptr);
                 for (int i = lane; i < 8 * 64; i += 64) pk[i] = 0;
@@ -1608,6 +1643,11 @@ static void fill_args(lsg_ctx* c, const lsg_count_params* p, CountArgs& a) {
     a.inline_seg_info = a.two_ended && !getenv("LSG_SEG_INFO_KERNEL") ? 1u : 0u;
     a.tile_off = c->d_tile_off.as<uint32_t>(); a.cur_lo = c->d_cur_lo.as<uint32_t>(); a.cur_hi = c->d_cur_hi.as<uint32_t>();
     a.read_drop = c->has_drops ? c->d_read_drop.as<uint8_t>() : nullptr;
+    a.ix0 = c->d_ix0.as<uint32_t>(); a.ix1 = c->d_ix1.as<uint32_t>(); a.ix2 = c->d_ix2.as<uint32_t>();
+    a.ix_netile = c->d_ix_netile.as<uint32_t>(); a.ix_chunk = c->d_ix_chunk.as<int32_t>(); a.ix_carry = c->d_ix_carry.as<unsigned long long>();
+    a.ix_n = c->ix_n; a.index_path = c->index_path ? 1u : 0u;
+    a.ixb_key = nullptr; a.ixb_read = nullptr;
+    if (c->index_path) a.presorted = 1u;                  // the records arrive grouped by barcode: no k_sort_deep / k_group_block
 }
 
 // launch-shape knobs for tuning runs (environment overrides; the defaults are what ships)
@@ -1642,7 +1682,7 @@ static int tile_capacities(lsg_ctx* c) {
     if (S > 0) {
         CountArgs a{};
         a.n_reads = c->rd.n_reads; a.n_segs = S;
-        a.read_tid = c->rd.read_tid; a.read_cb = c->rd.read_cb;
+        a.read_tid = c->rd.read_tid; a.read_cb = c->rd.read_cb; a.read_flag = c->rd.read_flag;
         a.seg_read = c->rd.seg_read; a.seg_start = c->rd.seg_start; a.seg_len = c->rd.seg_len;
         a.tile_base = c->d_tile_base.as<uint32_t>(); a.contig_len = c->d_contig_len.as<int64_t>(); a.n_contigs = c->n_contigs;
         a.n_ct = 1; a.tile_lo = 0; a.tile_hi = c->n_tiles;
@@ -1658,6 +1698,355 @@ static int tile_capacities(lsg_ctx* c) {
     LSG_HIP(hipGetLastError());
     c->tile_caps_valid = true;
     return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Tile index (static per load).  A tile's entries in barcode order do not depend on the count's parameters or on the barcode ->
+// cell-type table, so they are sorted ONCE: the scatter of k_bin_segments<2> over the parameter-free admission record (every read
+// with a barcode, one cell type) fills the tiles' regions in arrival order and writes a sort key (tile << 24 | barcode) and the
+// owning read beside every entry; a radix sort of the keys gives the permutation; k_ix_gather writes the entries in that order
+// together with what a count needs to decide admission on its own: the read's SAM flag bits and MAPQ.
+constexpr int IX_CHUNK = 2048;            // static entries resolved by one workgroup of k_resolve
+constexpr uint32_t IX_RUNSTART = 1u << 31, IX_TILESTART = 1u << 20, IX_SEGSTART = 1u << 21;
+
+__global__ void k_ix_gather(const uint64_t* key, const uint32_t* perm, const uint2* ent, const uint32_t* eread, const uint16_t* read_flag,
+                            const uint8_t* read_mapq, uint64_t n, uint32_t* ix0, uint32_t* ix1, uint32_t* ix2) {
+    const uint64_t n_pad = (n + IX_CHUNK - 1) / IX_CHUNK * IX_CHUNK + 16;       // whole chunks + the look-ahead word: entries no count admits
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pad; i += (uint64_t)gridDim.x * blockDim.x) {
+        if (i >= n) { ix0[i] = CB_MASK | IX_RUNSTART; ix1[i] = 0; ix2[i] = IX_TILESTART; continue; }
+        const uint32_t p = perm[i];
+        const uint2 e = ent[p];
+        const uint32_t rr = eread[p], r = rr & 0x7fffffffu;
+        const uint64_t k = key[i], kp = i ? key[i - 1] : ~0ull;
+        ix0[i] = (e.x & 0x7fffffffu) | (k != kp ? IX_RUNSTART : 0u);
+        ix1[i] = e.y;
+        ix2[i] = ((uint32_t)read_flag[r] & 0xfffu) | ((uint32_t)read_mapq[r] << 12) | ((k >> 24) != (kp >> 24) ? IX_TILESTART : 0u) | (rr >> 31 ? IX_SEGSTART : 0u);
+    }
+}
+struct CapNonZero {
+    const uint32_t* cap;
+    __host__ __device__ bool operator()(const uint32_t& t) const { return cap[t] != 0; }
+};
+// chunk k starts at static entry k * IX_CHUNK: index (into the list of non-empty tiles) of the tile holding that entry, minus one when
+// the entry is the tile's first, so that tile(entry) = netile[chunk[k] + tile starts among the chunk's entries up to and including it]
+__global__ void k_ix_chunks(const uint32_t* netile, uint32_t n_netile, const uint32_t* tile_off, uint64_t n, int32_t* chunk) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t i = k * IX_CHUNK;
+    if (i >= n) return;
+    uint32_t lo = 0, hi = n_netile;                  // last non-empty tile whose region starts at or before i
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if ((uint64_t)tile_off[netile[mid]] <= i) lo = mid; else hi = mid; }
+    chunk[k] = (int32_t)lo - ((uint64_t)tile_off[netile[lo]] == i ? 1 : 0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_resolve: one streaming pass over the tile index per count.  For every static entry: admission from the read's flag bits and MAPQ
+// under THIS count's parameters, cell type from THIS barcode table; the admitted entries of a tile are written, order-preserving, as
+// the walk's 8-byte records into the tile's region of cell type 0 or 1 (position = tile-relative exclusive count of that cell type: a
+// segmented prefix sum over the static order), with the run flags the grouping kernels used to compute (first admitted entry of its
+// barcode's run; run of exactly one entry).  The units' sizes fall out at every tile's last entry.  Workgroup = chunk of IX_CHUNK
+// consecutive entries; a chunk that begins inside a tile takes the running counts from its predecessor's carry word (a chunk that
+// contains a tile start publishes its own carry without waiting: only the chunks inside one deep tile form a chain).
+struct RScan { uint32_t v, f; };          // v: c0 [0..11] | c1 [12..23] | admitted entry since the run start [24];  f: tile start seen [0] | run start seen [1] | tile starts [8..]
+__device__ __forceinline__ RScan rs_combine(RScan a, RScan b) {      // a earlier, b later
+    RScan r;
+    const uint32_t cnt = (b.f & 1u) ? (b.v & 0xffffffu) : ((a.v + b.v) & 0xffffffu);
+    const uint32_t run = (b.f & 2u) ? (b.v & (1u << 24)) : ((a.v | b.v) & (1u << 24));
+    r.v = cnt | run;
+    r.f = ((a.f | b.f) & 3u) | ((a.f & ~0xffu) + (b.f & ~0xffu));
+    return r;
+}
+constexpr int RES_THREADS = 256, RES_PER = IX_CHUNK / RES_THREADS;
+constexpr int IX_STAT_SLOTS = 256;
+
+// the front half both passes share: the chunk's entries, their classes, the thread-sequential and workgroup-wide segmented scans
+struct ResFront {
+    uint32_t x0[RES_PER], x2[RES_PER + 1], cls[RES_PER];
+    RScan incl[RES_PER];          // inclusive scan inside the thread
+    RScan ex, all;                // everything of the chunk before this thread; the whole chunk
+    unsigned long long ev, sg, ne;
+};
+__device__ __forceinline__ void resolve_front(const CountArgs& a, uint64_t k, int t, RScan* s_wave, ResFront& r) {
+    const int lane = t & 63, wv = t >> 6;
+    const uint64_t base = k * IX_CHUNK + (uint64_t)t * RES_PER, N = a.ix_n;
+    {   // the index arrays are padded to whole chunks (k_ix_gather): 2 x 16 bytes per array and thread
+        const uint4* p0 = reinterpret_cast<const uint4*>(a.ix0 + base);
+        const uint4* p2 = reinterpret_cast<const uint4*>(a.ix2 + base);
+        static_assert(RES_PER == 8, "two uint4 per thread");
+        const uint4 a0 = p0[0], a1 = p0[1], c0 = p2[0], c1 = p2[1];
+        r.x0[0] = a0.x; r.x0[1] = a0.y; r.x0[2] = a0.z; r.x0[3] = a0.w; r.x0[4] = a1.x; r.x0[5] = a1.y; r.x0[6] = a1.z; r.x0[7] = a1.w;
+        r.x2[0] = c0.x; r.x2[1] = c0.y; r.x2[2] = c0.z; r.x2[3] = c0.w; r.x2[4] = c1.x; r.x2[5] = c1.y; r.x2[6] = c1.z; r.x2[7] = c1.w;
+        r.x2[RES_PER] = a.ix2[base + RES_PER];
+    }
+    RScan run{0u, 0u};
+    r.ev = 0; r.sg = 0; r.ne = 0;
+#pragma unroll
+    for (int q = 0; q < RES_PER; ++q) {
+        const uint32_t flag = r.x2[q] & 0xfffu, mapq = (r.x2[q] >> 12) & 0xffu, cb = r.x0[q] & CB_MASK;
+        bool ok = base + q < N && (flag & a.flag_exclude) == 0 && (int)mapq >= a.min_mq && cb < (uint32_t)a.n_cb;
+        if (ok && a.ignore_orphans && (flag & 1u) && !(flag & 2u)) ok = false;
+        uint32_t c = 2;          // cell type (0 / 1) or 2 = not counted
+        if (ok) { const uint32_t ct = a.celltype_of[cb]; if (ct < (uint32_t)a.n_ct) c = ct; }
+        r.cls[q] = c;
+        if (c < 2) { r.ev += ((r.x0[q] >> 24) & 63u) + 1u; r.sg += (r.x2[q] & IX_SEGSTART) ? 1u : 0u; ++r.ne; }
+        RScan e;
+        e.v = (c == 0 ? 1u : 0u) | (c == 1 ? 1u << 12 : 0u) | (c < 2 ? 1u << 24 : 0u);
+        e.f = ((r.x2[q] & IX_TILESTART) ? 0x101u : 0u) | ((r.x0[q] & IX_RUNSTART) ? 2u : 0u);
+        run = q ? rs_combine(run, e) : e;
+        r.incl[q] = run;
+    }
+    RScan sc = run;
+    for (int o = 1; o < 64; o <<= 1) {
+        RScan up; up.v = __shfl_up(sc.v, o); up.f = __shfl_up(sc.f, o);
+        if (lane >= o) sc = rs_combine(up, sc);
+    }
+    if (lane == 63) s_wave[wv] = sc;
+    RScan ex; ex.v = __shfl_up(sc.v, 1); ex.f = __shfl_up(sc.f, 1);
+    if (lane == 0) { ex.v = 0; ex.f = 0; }
+    __syncthreads();
+    RScan wpre{0u, 0u};
+    for (int w = 0; w < wv; ++w) wpre = w ? rs_combine(wpre, s_wave[w]) : s_wave[0];
+    if (wv > 0) ex = lane == 0 ? wpre : rs_combine(wpre, ex);
+    RScan all = s_wave[0];
+    for (int w = 1; w < RES_THREADS / 64; ++w) all = rs_combine(all, s_wave[w]);
+    r.ex = ex; r.all = all;
+}
+// aggregate word of a chunk: admitted entries of cell type 0 / 1 since the chunk's last tile start (or its beginning) [0..23] [24..47],
+// an admitted entry since its last run start [48], a run start seen [49], a tile start seen [50]
+constexpr unsigned long long IXA_RUN = 1ull << 48, IXA_RUNSTART = 1ull << 49, IXA_TILESTART = 1ull << 50;
+
+// pass 1: every chunk's aggregate
+__global__ __launch_bounds__(RES_THREADS) void k_resolve_agg(CountArgs a) {
+    __shared__ RScan s_wave[RES_THREADS / 64];
+    ResFront r;
+    resolve_front(a, blockIdx.x, threadIdx.x, s_wave, r);
+    if (threadIdx.x == 0)
+        a.ix_carry[blockIdx.x] = (unsigned long long)(r.all.v & 0xfffu) | ((unsigned long long)((r.all.v >> 12) & 0xfffu) << 24) | ((r.all.v >> 24) & 1u ? IXA_RUN : 0ull) |
+                                 ((r.all.f & 2u) ? IXA_RUNSTART : 0ull) | ((r.all.f & 1u) ? IXA_TILESTART : 0ull);
+}
+
+// pass 2
+__global__ __launch_bounds__(RES_THREADS) void k_resolve(CountArgs a, unsigned long long* stat_slots) {
+    __shared__ RScan s_wave[RES_THREADS / 64];
+    __shared__ unsigned long long s_carry;
+    __shared__ uint8_t s_first[RES_THREADS + 1];          // per thread: 0 no admitted entry, 1 its first admitted entry starts a run, 2 it does not
+    __shared__ unsigned long long s_stat[3];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const uint64_t k = blockIdx.x, base = k * IX_CHUNK + (uint64_t)t * RES_PER;
+    const uint64_t N = a.ix_n;
+    ResFront r;
+    resolve_front(a, k, t, s_wave, r);
+    uint32_t (&x0)[RES_PER] = r.x0; uint32_t (&x2)[RES_PER + 1] = r.x2; uint32_t (&cls)[RES_PER] = r.cls; RScan (&incl)[RES_PER] = r.incl;
+    const RScan ex = r.ex;
+    unsigned long long ev = r.ev, sg = r.sg, ne = r.ne;
+    // the running counts this chunk starts from: the aggregates of the chunks before it, back to the nearest one holding a tile start
+    // (all final after pass 1: a look-back without waiting), 64 chunks per step
+    if (wv == 0) {
+        unsigned long long c0 = 0, c1 = 0, run = 0;
+        bool run_closed = false;
+        const bool need = k > 0 && !(x2[0] & IX_TILESTART);           // lane 0 of wave 0 holds the chunk's first entry
+        bool go = __shfl((int)need, 0) != 0;
+        int64_t j = (int64_t)k;
+        while (go) {
+            const int64_t idx = j - 1 - lane;
+            const unsigned long long w = idx >= 0 ? a.ix_carry[idx] : IXA_TILESTART;
+            const unsigned long long tmask = __ballot((w & IXA_TILESTART) != 0);
+            const int nearest = tmask ? __ffsll((long long)tmask) - 1 : 63;
+            const bool part = lane <= nearest;
+            if (!run_closed) {
+                const unsigned long long rmask = __ballot(part && (w & IXA_RUNSTART) != 0);
+                const int rnear = rmask ? __ffsll((long long)rmask) - 1 : nearest;
+                if (__ballot(part && lane <= rnear && (w & IXA_RUN) != 0)) run = 1;
+                if (rmask) run_closed = true;
+            }
+            unsigned long long s0 = part ? (w & 0xffffffull) : 0ull, s1 = part ? ((w >> 24) & 0xffffffull) : 0ull;
+            for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); }
+            c0 += s0; c1 += s1;
+            if (tmask) break;
+            j -= 64;
+        }
+        if (lane == 0) { s_carry = c0 | (c1 << 24) | (run << 48); s_stat[0] = 0; s_stat[1] = 0; s_stat[2] = 0; }
+    }
+    __syncthreads();
+    unsigned long long cin;
+    cin = s_carry;
+    const uint32_t cin0 = (uint32_t)(cin & 0xffffffull), cin1 = (uint32_t)((cin >> 24) & 0xffffffull), cinr = (uint32_t)((cin >> 48) & 1ull);
+    // per entry: is it the first admitted entry of its run?
+    bool newrun[RES_PER];
+    uint8_t first_code = 0;
+#pragma unroll
+    for (int q = 0; q < RES_PER; ++q) {
+        const RScan before = q ? rs_combine(ex, incl[q - 1]) : ex;                 // everything of the chunk before this entry
+        uint32_t adm_before;
+        if (x0[q] & IX_RUNSTART) adm_before = 0;
+        else adm_before = (before.f & 2u) ? ((before.v >> 24) & 1u) : (((before.v >> 24) & 1u) | cinr);
+        newrun[q] = cls[q] < 2 && !adm_before;
+        if (cls[q] < 2 && !first_code) first_code = newrun[q] ? 1 : 2;
+    }
+    s_first[t] = first_code;
+    if (t == 0) s_first[RES_THREADS] = 0;
+    __syncthreads();
+    const int32_t ctile = a.ix_chunk[k];
+    const uint64_t ev_base = (uint64_t)(uintptr_t)a.events;
+#pragma unroll
+    for (int q = 0; q < RES_PER; ++q) {
+        const uint64_t i = base + q;
+        if (i >= N) break;
+        const RScan upto = rs_combine(ex, incl[q]);                                  // the chunk up to and including this entry
+        const uint32_t tile = a.ix_netile[ctile + (int32_t)(upto.f >> 8)];
+        const bool in_region = tile >= a.tile_lo && tile < a.tile_hi;
+        const uint32_t c0 = (upto.v & 0xfffu) + ((upto.f & 1u) ? 0u : cin0), c1 = ((upto.v >> 12) & 0xfffu) + ((upto.f & 1u) ? 0u : cin1);      // tile-relative, inclusive
+        const uint32_t off = a.tile_off[tile], cap = a.tile_off[tile + 1] - off;
+        const uint32_t b0 = a.n_ct == 1 ? off : 2u * off, b1 = 2u * off + cap;
+        if (cls[q] < 2 && in_region) {
+            // a run of exactly one entry: the next admitted entry of the chunk starts a run (conservative at the chunk's end)
+            bool single = false;
+            if (newrun[q]) {
+                int nx = 0;
+#pragma unroll
+                for (int r = RES_PER - 1; r > q; --r) if (cls[r] < 2) nx = newrun[r] ? 1 : 2;
+                if (!nx) { int tt = t + 1; while (tt < RES_THREADS && !s_first[tt]) ++tt; nx = s_first[tt]; }
+                single = nx == 1;
+            }
+            const uint64_t addr = ev_base + ((uint64_t)a.ix1[i] << 7);
+            const uint32_t meta = ((uint32_t)(addr >> 32) & 0x7fffu) | (x0[q] & 0x7f000000u) | (newrun[q] ? (single ? (META_NEWRUN | META_SINGLE) : META_NEWRUN) : 0u);
+            const uint32_t pos = cls[q] == 0 ? b0 + c0 - 1u : b1 + c1 - 1u;
+            a.rec[pos] = make_uint2((uint32_t)addr, meta);
+        }
+        if (x2[q + 1] & IX_TILESTART) {                                             // last static entry of its tile: the units' sizes and places
+            if (in_region) {
+                if (a.n_ct == 1) { a.unit_cnt[tile] = c0; a.unit_off[tile] = b0; }
+                else { a.unit_cnt[2 * tile] = c0; a.unit_off[2 * tile] = b0; a.unit_cnt[2 * tile + 1] = c1; a.unit_off[2 * tile + 1] = b1; }
+            }
+        }
+        if (cls[q] < 2 && !in_region) { ev -= ((x0[q] >> 24) & 63u) + 1u; sg -= (x2[q] & IX_SEGSTART) ? 1u : 0u; --ne; }
+    }
+    // statistics: admitted events and segments, spread over IX_STAT_SLOTS words (one word takes ~90 atomics per microsecond)
+    for (int o = 32; o > 0; o >>= 1) { ev += __shfl_down(ev, o); sg += __shfl_down(sg, o); ne += __shfl_down(ne, o); }
+    if (lane == 0 && ne) { atomicAdd(&s_stat[0], ev); atomicAdd(&s_stat[1], sg); atomicAdd(&s_stat[2], ne); }
+    __syncthreads();
+    if (t == 0 && s_stat[2]) {
+        unsigned long long* slot = stat_slots + (size_t)(blockIdx.x % IX_STAT_SLOTS) * 8;      // 64 bytes apart
+        atomicAdd(&slot[0], s_stat[0]); atomicAdd(&slot[1], s_stat[1]); atomicAdd(&slot[2], s_stat[2]);
+    }
+}
+__global__ void k_resolve_stats(CountArgs a, const unsigned long long* stat_slots) {
+    unsigned long long ev = 0, sg = 0, ne = 0;
+    for (int i = threadIdx.x; i < IX_STAT_SLOTS; i += blockDim.x) { ev += stat_slots[(size_t)i * 8]; sg += stat_slots[(size_t)i * 8 + 1]; ne += stat_slots[(size_t)i * 8 + 2]; }
+    for (int o = 32; o > 0; o >>= 1) { ev += __shfl_down(ev, o); sg += __shfl_down(sg, o); ne += __shfl_down(ne, o); }
+    __shared__ unsigned long long s[3];
+    if (threadIdx.x == 0) { s[0] = 0; s[1] = 0; s[2] = 0; }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&s[0], ev); atomicAdd(&s[1], sg); atomicAdd(&s[2], ne); }
+    __syncthreads();
+    if (threadIdx.x == 0) { a.scalars[SC_EVENTS] = s[0]; a.scalars[SC_SEGS] = s[1]; a.scalars[SC_NENT] = s[2]; }
+}
+
+// Work lists of the deep and the mid units when their records arrive grouped (tile index): a big slot j of a unit of n records and
+// nsub slots is [cut(n j / nsub), cut(n (j + 1) / nsub)) with cut(x) = the first record at or after x that starts a barcode run (or n),
+// its NSLICE run-aligned slices likewise.  One thread per (big slot, cut); every cut is found on its own by walking forward over at
+// most one run.
+__global__ void k_cut(CountArgs a) {
+    const uint32_t n_big = a.n_slots - (uint32_t)a.scalars[SC_NSMALL];
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t qi = id / (NSLICE + 1), q = id % (NSLICE + 1);
+    if (qi >= n_big) return;
+    const uint32_t s = a.slot_list[a.n_slots - 1 - qi];
+    const uint32_t w = a.slot_w[s], u = a.ne_units[w];
+    const uint32_t n = a.unit_cnt[u], uoff = a.unit_off[u], nsub = a.ne_nslot[w], j = s - a.ne_slot_base[w];
+    auto cut = [&](uint32_t x) -> uint32_t { while (x < n && !(a.rec[uoff + x].y & META_NEWRUN)) ++x; return x < n ? x : n; };
+    const uint32_t lo = j == 0 ? 0u : cut((uint32_t)(((uint64_t)n * j) / nsub));
+    const uint32_t hi = j + 1 == nsub ? n : cut((uint32_t)(((uint64_t)n * (j + 1)) / nsub));
+    uint32_t b;
+    if (q == 0) b = lo; else if (q == NSLICE) b = hi;
+    else { b = cut(lo + (uint32_t)(((uint64_t)(hi - lo) * q) / NSLICE)); if (b > hi) b = hi; if (b < lo) b = lo; }
+    a.slices[(uint64_t)s * (NSLICE + 1) + q] = b - lo;
+    if (q == 0) { a.slot_cnt[s] = hi - lo; a.slot_off[s] = uoff + lo; }
+}
+
+static int build_index(lsg_ctx* c) {
+    if (c->index_valid) return 0;
+    if (tile_capacities(c)) return -1;
+    hipStream_t st = c->stream;
+    const int64_t S = c->rd.n_segs;
+    DevBuf key_a, key_b, val_a, val_b, eread, tmp;
+    auto done = [&](int rc) { key_a.release(); key_b.release(); val_a.release(); val_b.release(); eread.release(); tmp.release(); return rc; };
+    uint32_t total = 0, max_cap = 0;
+    {   // k_resolve carries a tile's running counts in 24-bit fields: a tile of 2^24 entries or more leaves the counts to the scatter path
+        uint32_t* d_max = reinterpret_cast<uint32_t*>(c->d_scalars.as<unsigned long long>() + SC_NNE);
+        size_t tb = 0;
+        LSG_HIP(hipcub::DeviceReduce::Max(nullptr, tb, c->d_tile_cap.as<uint32_t>(), d_max, (int)c->n_tiles, st));
+        if (tmp.reserve(tb + 256)) return done(-1);
+        tb = tmp.cap;
+        LSG_HIP(hipcub::DeviceReduce::Max(tmp.p, tb, c->d_tile_cap.as<uint32_t>(), d_max, (int)c->n_tiles, st));
+        LSG_HIP(hipMemcpyAsync(&max_cap, d_max, 4, hipMemcpyDeviceToHost, st));
+    }
+    LSG_HIP(hipMemcpyAsync(&total, c->d_tile_off.as<uint32_t>() + c->n_tiles, 4, hipMemcpyDeviceToHost, st));
+    LSG_HIP(hipStreamSynchronize(st));
+    const uint64_t N = max_cap < (1u << 24) ? total : 0;
+    c->ix_n = N; c->ix_n_netile = 0;
+    if (N == 0 || S == 0) { c->index_valid = true; return done(0); }
+    if (key_a.reserve(N * 8) || key_b.reserve(N * 8) || val_a.reserve(N * 4) || val_b.reserve(N * 4) || eread.reserve(N * 4) ||
+        c->ws[WS_ENT].reserve((c->entries_upper + 1) * 16 + 64) || c->ws[WS_SEG_INFO].reserve(((size_t)S + 1) * 8) ||
+        c->d_ix0.reserve((N + IX_CHUNK + 16) * 4) || c->d_ix1.reserve((N + IX_CHUNK + 16) * 4) || c->d_ix2.reserve((N + IX_CHUNK + 16) * 4) ||
+        c->d_ix_netile.reserve(((size_t)c->n_tiles + 2) * 4) || c->d_ix_chunk.reserve((N / IX_CHUNK + 2) * 4) || c->d_ix_carry.reserve((N / IX_CHUNK + 2) * 8))
+        return done(-1);
+    {   // the scatter, as ONE cell type over every read with a barcode
+        LSG_HIP(hipMemsetAsync(c->d_scalars.p, 0, SC_COUNT * 8, st));
+        CountArgs a{};
+        a.n_reads = c->rd.n_reads; a.n_segs = S;
+        a.read_tid = c->rd.read_tid; a.read_cb = c->rd.read_cb; a.read_flag = c->rd.read_flag;
+        a.seg_read = c->rd.seg_read; a.seg_start = c->rd.seg_start; a.seg_len = c->rd.seg_len; a.seg_ev_off = c->rd.seg_ev_off;
+        a.tile_base = c->d_tile_base.as<uint32_t>(); a.contig_len = c->d_contig_len.as<int64_t>(); a.n_contigs = c->n_contigs;
+        a.n_ct = 1; a.tile_lo = 0; a.tile_hi = c->n_tiles; a.two_ended = 1;
+        a.seg_info = c->ws[WS_SEG_INFO].as<uint2>(); a.ent = c->ws[WS_ENT].as<uint2>();
+        a.tile_off = c->d_tile_off.as<uint32_t>(); a.cur_lo = c->d_cur_lo.as<uint32_t>(); a.cur_hi = c->d_cur_hi.as<uint32_t>();
+        a.scalars = c->d_scalars.as<unsigned long long>();
+        a.ixb_key = key_a.as<uint64_t>(); a.ixb_read = eread.as<uint32_t>();
+        LSG_HIP(hipMemcpyAsync(a.cur_lo, a.tile_off, (size_t)c->n_tiles * 4, hipMemcpyDeviceToDevice, st));
+        unsigned g = (unsigned)((S + 255) / 256); if (g > (unsigned)(c->n_cus * 16)) g = (unsigned)(c->n_cus * 16);
+        hipLaunchKernelGGL(k_seg_info_static, dim3(g), dim3(256), 0, st, a);
+        unsigned seg_grid = (unsigned)((S + 256 * BIN_SUPER - 1) / (256 * BIN_SUPER));
+        if (seg_grid > (unsigned)(c->n_cus * 8)) seg_grid = (unsigned)(c->n_cus * 8);
+        hipLaunchKernelGGL(k_bin_segments<2>, dim3(seg_grid), dim3(256), 0, st, a);
+    }
+    {   // permutation that orders the entries by (tile, barcode)
+        hipcub::CountingInputIterator<uint32_t> iota(0);
+        int tile_bits = 1; while ((1ull << tile_bits) < (uint64_t)c->n_tiles + 1) ++tile_bits;
+        LSG_HIP(hipMemsetAsync(val_a.p, 0, 4, st));
+        {   // val_a = 0, 1, 2, ...
+            size_t tb = 0;
+            LSG_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, hipcub::ConstantInputIterator<uint32_t>(1u), val_a.as<uint32_t>(), (int)N, st));
+            if (tmp.reserve(tb + 256)) return done(-1);
+            tb = tmp.cap;
+            LSG_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, hipcub::ConstantInputIterator<uint32_t>(1u), val_a.as<uint32_t>(), (int)N, st));
+        }
+        size_t tb = 0;
+        LSG_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, key_a.as<uint64_t>(), key_b.as<uint64_t>(), val_a.as<uint32_t>(), val_b.as<uint32_t>(), (int)N, 0, 24 + tile_bits, st));
+        if (tmp.reserve(tb + 256)) return done(-1);
+        tb = tmp.cap;
+        LSG_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, key_a.as<uint64_t>(), key_b.as<uint64_t>(), val_a.as<uint32_t>(), val_b.as<uint32_t>(), (int)N, 0, 24 + tile_bits, st));
+    }
+    hipLaunchKernelGGL(k_ix_gather, dim3((unsigned)(c->n_cus * 16)), dim3(256), 0, st, key_b.as<uint64_t>(), val_b.as<uint32_t>(), c->ws[WS_ENT].as<uint2>(), eread.as<uint32_t>(),
+                       c->rd.read_flag, c->rd.read_mapq, N, c->d_ix0.as<uint32_t>(), c->d_ix1.as<uint32_t>(), c->d_ix2.as<uint32_t>());
+    {   // the tiles that hold entries, in order; every chunk's first tile
+        hipcub::CountingInputIterator<uint32_t> tile_it(0);
+        CapNonZero pred{c->d_tile_cap.as<uint32_t>()};
+        uint32_t* d_n = reinterpret_cast<uint32_t*>(c->d_scalars.as<unsigned long long>() + SC_NNE);
+        size_t tb = 0;
+        LSG_HIP(hipcub::DeviceSelect::If(nullptr, tb, tile_it, c->d_ix_netile.as<uint32_t>(), d_n, (int)c->n_tiles, pred, st));
+        if (tmp.reserve(tb + 256)) return done(-1);
+        tb = tmp.cap;
+        LSG_HIP(hipcub::DeviceSelect::If(tmp.p, tb, tile_it, c->d_ix_netile.as<uint32_t>(), d_n, (int)c->n_tiles, pred, st));
+        LSG_HIP(hipMemcpyAsync(&c->ix_n_netile, d_n, 4, hipMemcpyDeviceToHost, st));
+        LSG_HIP(hipStreamSynchronize(st));
+        const uint64_t n_chunks = (N + IX_CHUNK - 1) / IX_CHUNK;
+        hipLaunchKernelGGL(k_ix_chunks, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, st, c->d_ix_netile.as<uint32_t>(), c->ix_n_netile,
+                           c->d_tile_off.as<uint32_t>(), N, c->d_ix_chunk.as<int32_t>());
+    }
+    LSG_HIP(hipGetLastError());
+    LSG_HIP(hipStreamSynchronize(st));
+    c->index_valid = true;
+    return done(0);
 }
 
 int run_count(lsg_ctx* c, const lsg_count_params* p) {
@@ -1692,6 +2081,10 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
 
     if (tile_capacities(c)) return -1;
     if (depth_cap_drops(c, p)) return -1;           // free unless some cell type's pileup buffer can reach max_depth (cached bound)
+    // the tile index serves <= 2 cell types and counts without depth-cap drops (those are per read and rare: the scatter path takes them)
+    c->index_path = c->n_ct <= 2 && !c->has_drops && c->rd.n_reads < 0x7fffffffll && !getenv("LSG_COUNT_PASS") && !getenv("LSG_NO_INDEX");
+    if (c->index_path && build_index(c)) return -1;
+    if (c->index_path && (c->ix_n == 0 || c->d_ix_stat.reserve(IX_STAT_SLOTS * 64))) c->index_path = false;
     LSG_HIP(hipEventRecord(c->ev[0], st));
     LSG_HIP(hipMemsetAsync(c->d_scalars.p, 0, SC_COUNT * 8, st));
     // only the units of the counted region (lsg_set_region) are ever touched
@@ -1707,8 +2100,16 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
     unsigned seg_grid = (unsigned)((S + 256 * BIN_SUPER - 1) / (256 * BIN_SUPER));
     if (seg_grid > (unsigned)(c->n_cus * 8)) seg_grid = (unsigned)(c->n_cus * 8);
     if (R > 0) { unsigned g = (unsigned)((R + 255) / 256); if (g > (unsigned)(c->n_cus * 8)) g = (unsigned)(c->n_cus * 8); hipLaunchKernelGGL(k_read_key, dim3(g), dim3(256), 0, st, a); }
-    if (S > 0 && !a.inline_seg_info) { unsigned g = (unsigned)((S + 255) / 256); if (g > (unsigned)(c->n_cus * 16)) g = (unsigned)(c->n_cus * 16); hipLaunchKernelGGL(k_seg_info, dim3(g), dim3(256), 0, st, a); }
-    if (two_ended) {
+    if (S > 0 && !a.inline_seg_info && !a.index_path) { unsigned g = (unsigned)((S + 255) / 256); if (g > (unsigned)(c->n_cus * 16)) g = (unsigned)(c->n_cus * 16); hipLaunchKernelGGL(k_seg_info, dim3(g), dim3(256), 0, st, a); }
+    if (a.index_path) {
+        // ONE streaming pass over the tile index: admission, cell type, order-preserving compaction into the walk's records
+        const uint64_t n_chunks = (c->ix_n + IX_CHUNK - 1) / IX_CHUNK;
+        if (n_range) LSG_HIP(hipMemsetAsync(c->d_unit_cnt.as<uint32_t>() + u_lo, 0, ((size_t)n_range + 1) * 4, st));
+        LSG_HIP(hipMemsetAsync(c->d_ix_stat.p, 0, IX_STAT_SLOTS * 64, st));
+        hipLaunchKernelGGL(k_resolve_agg, dim3((unsigned)n_chunks), dim3(RES_THREADS), 0, st, a);
+        hipLaunchKernelGGL(k_resolve, dim3((unsigned)n_chunks), dim3(RES_THREADS), 0, st, a, c->d_ix_stat.as<unsigned long long>());
+        hipLaunchKernelGGL(k_resolve_stats, dim3(1), dim3(256), 0, st, a, c->d_ix_stat.as<unsigned long long>());
+    } else if (two_ended) {
         // ONE pass over the segments: every tile owns a static region of the entry buffer (tile_capacities), cell type 0 fills it
         // from the front and cell type 1 from the back, the units' sizes fall out of the cursors
         if (n_trange) {
@@ -1736,10 +2137,10 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
     }
     unsigned long long sc[SC_COUNT];
     uint32_t* pin32 = reinterpret_cast<uint32_t*>(c->h_pin + SC_COUNT + 8);   // small reads that ride on read_scalars' synchronisation
-    if (!two_ended) LSG_HIP(hipMemcpyAsync(pin32, c->d_unit_off.as<uint32_t>() + u_hi, 4, hipMemcpyDeviceToHost, st));
+    if (!two_ended && !a.index_path) LSG_HIP(hipMemcpyAsync(pin32, c->d_unit_off.as<uint32_t>() + u_hi, 4, hipMemcpyDeviceToHost, st));
     if (read_scalars(c, sc)) return -1;
     if (sc[SC_OVERFLOW]) { set_error("lsg_pileup_count: a tile got more entries than its static capacity"); return -1; }
-    const uint32_t total_entries = two_ended ? (uint32_t)sc[SC_NENT] : pin32[0];                  // statistics
+    const uint32_t total_entries = (two_ended || a.index_path) ? (uint32_t)sc[SC_NENT] : pin32[0];                  // statistics
     const uint32_t n_ne = (uint32_t)(sc[SC_NNE] & 0xffffffffull);
     c->n_ne = n_ne;
     fill_args(c, p, a);
@@ -1781,7 +2182,7 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
     fill_args(c, p, a);
     if (n_ne > 0) {
         hipLaunchKernelGGL(k_slot_init, dim3((n_ne + 255) / 256), dim3(256), 0, st, a);
-        if (!two_ended) {
+        if (!two_ended && !a.index_path) {
             LSG_HIP(hipMemcpyAsync(a.unit_cursor + u_lo, a.unit_off + u_lo, ((size_t)n_range + 1) * 4, hipMemcpyDeviceToDevice, st));
             if (S > 0) hipLaunchKernelGGL(k_bin_segments<2>, dim3(seg_grid), dim3(256), 0, st, a);
         }
@@ -1816,7 +2217,9 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
             tb = c->d_cub_tmp.cap;
             LSG_HIP(hipcub::DeviceSelect::If(c->d_cub_tmp.p, tb, cnt_it, a.multi_list, d_nm, (int)n_ne, pred, st));
             unsigned sg = c->n_multi < (unsigned)(c->n_cus * 4) ? c->n_multi : (unsigned)(c->n_cus * 4);
-            if (a.presorted) {
+            if (a.index_path) {
+                // nothing to sort: the records are grouped already
+            } else if (a.presorted) {
                 const uint32_t r_cap = (max_ct + 63u) & ~63u;
                 const size_t lds = ((size_t)2 * r_cap + MAXSUB + 1 + SORT_THREADS / 64 + 4) * 4 + 32;
                 LSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort_deep), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1825,7 +2228,8 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
                 hipLaunchKernelGGL(k_split_deep, dim3(sg), dim3(SPLIT_THREADS), 0, st, a);
             }
         }
-        hipLaunchKernelGGL(k_group_block, dim3((unsigned)(c->n_cus * 4)), dim3(BLOCK_THREADS), 0, st, a);
+        if (a.index_path) hipLaunchKernelGGL(k_cut, dim3((unsigned)(((uint64_t)c->n_slots * (NSLICE + 1) + 255) / 256)), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(k_group_block, dim3((unsigned)(c->n_cus * 4)), dim3(BLOCK_THREADS), 0, st, a);
     }
     LSG_HIP(hipEventRecord(c->ev[1], st));
     if (n_ne > 0) {
@@ -1859,6 +2263,10 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
         LSG_HIP(hipEventElapsedTime(&ms, c->ev[2], c->ev[3])); c->stats.ms_wave = ms;
     }
     for (int i = 0; i < 4; ++i) { c->stats.rows_by_kernel[i] = (int64_t)sc[SC_ROWS_SRC + i]; c->stats.events_by_kernel[i] = (int64_t)sc[SC_EV_SRC + i]; }
+    if (c->index_path) {      // no grouping kernel counted the walk's events: they are what the small units and the huge path did not read
+        c->stats.events_by_kernel[1] = (int64_t)sc[SC_EVENTS] - (int64_t)sc[SC_EV_SRC + 0] - (int64_t)sc[SC_EV_SRC + 2];
+        sc[SC_EV_DEEP] = (unsigned long long)c->stats.events_by_kernel[1] + sc[SC_EV_SRC + 2];
+    }
     LSG_HIP(hipEventElapsedTime(&ms, c->ev[0], c->ev[5])); c->stats.ms_total = ms;
     c->stats.n_events_wave = (int64_t)sc[SC_EV_WAVE]; c->stats.n_events_deep = (int64_t)sc[SC_EV_DEEP];
     c->stats.n_rows_deep = (int64_t)sc[SC_ROWS_DEEP];
@@ -1938,7 +2346,7 @@ __global__ void k_entries_upper(const int32_t* seg_start, const int32_t* seg_len
 }
 
 int compute_entries_upper(lsg_ctx* c) {
-    c->tile_caps_valid = false;            // new reads: the tiles' static capacities are recomputed by the next count
+    c->tile_caps_valid = false; c->index_valid = false;      // new reads: static capacities and the tile index are rebuilt by the next count
     if (c->d_scalars.reserve(SC_COUNT * 8)) return -1;
     LSG_HIP(hipMemsetAsync(c->d_scalars.p, 0, SC_COUNT * 8, c->stream));
     int64_t S = c->rd.n_segs;
