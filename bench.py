@@ -285,6 +285,8 @@ def main():
     if dist_on:
         dist.barrier()
     dt = time.perf_counter() - t0
+    if os.environ.get("LSG_BENCH_STATS"):                           # the last step's counters, for whoever tunes the kernels
+        print({f: (list(getattr(st, f)) if f.endswith("by_kernel") else getattr(st, f)) for f, _ in st._fields_ if f != "pad_"}, file=sys.stderr)
     if dist_on:
         counts = gathered_counts()                                 # after the clock: the timed exchanges all fitted
         if max(counts) > gather["cap"]:

@@ -40,6 +40,9 @@ struct CandCt {                       // one per (candidate site, cell type)
 };
 static_assert(sizeof(CandCt) == 56, "CandCt layout");
 
+// counter words of the call stage; the ones the kernels allocate from while they run sit on cache lines of their own (atomics on one
+// line serialise at ~90 per microsecond whichever of its words they name)
+enum { CT_CAND = 0, CT_NCAND = 1, CT_HEADS = 4, CT_PASS = 6, CT_LIGHT = 16, CT_HEAVY = 32, CT_QTAIL = 48, CT_WORDS = 64 };
 struct CallArgs {
     const uint32_t* ne_units; const uint64_t* ne_mask; const uint32_t* ne_rowbase; const int2* ne_geom;
     uint32_t n_ne; int32_t n_ct;
@@ -47,12 +50,12 @@ struct CallArgs {
     const uint8_t* const* ref_ptr; const int64_t* contig_len;
     lsg_call_params p;
     double lgc0[2], lgcn[2];          // lgamma(a+b) - lgamma(b), lgamma(a+b) - lgamma(a) for (a1,b1), (a2,b2)
-    uint32_t* pass_list;              // site indices of the PASS candidates (k_call_finish appends, counters[6] counts; PASS_CAP slots)
+    uint32_t* pass_list;              // site indices of the PASS candidates (k_call_finish appends, counters[CT_PASS] counts; PASS_CAP slots)
     const int16_t* tail_table;        // [2][TAIL_ENTRIES] rounded tails of every (k <= n <= TAIL_NT), see k_tail_table
     uint32_t* site_cnt; uint32_t* site_off;
     SiteRec* sites; CandCt* cands; uint64_t cand_cap;
     struct TailTask* light; struct TailTask* heavy; uint64_t task_cap;
-    unsigned long long* counters;     // [0] candidate blocks allocated, [1] candidate sites (exact), [2] light, [3] heavy tail task slots, [4] heads
+    unsigned long long* counters;     // CT_*: candidate blocks allocated, candidate sites (exact), light / heavy tail task slots, heads, ...
     uint32_t arena_waves;             // waves of k_call_gather (each owns chunk number `wave` of every arena list)
     const uint32_t* heads;            // units that are the first of a tile with at least one site
     uint32_t* head_recs;              // 16 words per head: unit, first site index, tile start, tid, masks[4] (lo, hi), row bases[4]
@@ -157,7 +160,7 @@ __device__ __forceinline__ uint32_t tail_work(uint32_t k, uint32_t n) {
 // with ONE scalar load, a tile ahead of its use (the chain heads -> units -> masks -> row bases was 4 dependent round trips).
 __global__ void k_head_recs(CallArgs a) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (uint32_t)a.counters[4]) return;
+    if (i >= (uint32_t)a.counters[CT_HEADS]) return;
     const uint32_t w = a.heads[i];
     const uint32_t tile = a.ne_units[w] / (uint32_t)a.n_ct;
     uint64_t mask[LSG_MAX_CELLTYPES] = {0, 0, 0, 0};
@@ -183,7 +186,7 @@ __global__ __launch_bounds__(GATHER_WAVES * 64) void k_call_gather(CallArgs a) {
     const int lane = threadIdx.x & 63;
     const uint32_t wave = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const uint32_t n_waves = (uint32_t)(((uint64_t)gridDim.x * blockDim.x) >> 6);
-    const uint32_t n_heads = (uint32_t)a.counters[4];
+    const uint32_t n_heads = (uint32_t)a.counters[CT_HEADS];
     // arenas: every wave starts with chunk number `wave` of each list (no storm of same-line atomics at launch); the
     // counters count the chunks taken AFTER those, so list positions and lengths are offset by n_waves chunks
     const uint32_t c_base = n_waves * CAND_CHUNK, l_base = n_waves * TASK_CHUNK, h_base = n_waves * HEAVY_CHUNK;
@@ -222,10 +225,19 @@ __global__ __launch_bounds__(GATHER_WAVES * 64) void k_call_gather(CallArgs a) {
 #pragma unroll
         for (int s = 0; s < 6; ++s) { v_cc[ct][s] = 0; v_bc[ct][s] = 0; }
         if (site && ((mask[ct] >> lane) & 1ull)) {
-            const uint64_t row = (uint64_t)rbase[ct] + __popcll(mask[ct] & below);
-            // planes 0..15 of the row = DP, NC, CC[0..7], BC[0..5] in four 16-byte loads (quad q at 256 words from quad q - 1)
-            const uint4* R = reinterpret_cast<const uint4*>(a.rows[ct] + row_word(row, 0));
-            const uint4 q0 = R[0], q1 = R[64], q2 = R[128], q3 = R[192];
+            const uint64_t row = (uint64_t)(rbase[ct] & ~ROW_NARROW) + __popcll(mask[ct] & below);
+            // planes 0..15 of the row = DP, NC, CC[0..7], BC[0..5] in four 16-byte loads (quad q at 256 words from quad q - 1);
+            // a narrow row (small unit): the same planes as 16-bit values, four 8-byte loads
+            uint4 q0, q1, q2, q3;
+            if (rbase[ct] & ROW_NARROW) {
+                const uint2* R = reinterpret_cast<const uint2*>(a.rows[ct] + (row >> 6) * ROW_BLOCK_WORDS) + (row & 63);
+                const uint2 h0 = R[0], h1 = R[64], h2 = R[128], h3 = R[192];
+                q0 = make_uint4(h0.x & 0xffffu, h0.x >> 16, h0.y & 0xffffu, h0.y >> 16); q1 = make_uint4(h1.x & 0xffffu, h1.x >> 16, h1.y & 0xffffu, h1.y >> 16);
+                q2 = make_uint4(h2.x & 0xffffu, h2.x >> 16, h2.y & 0xffffu, h2.y >> 16); q3 = make_uint4(h3.x & 0xffffu, h3.x >> 16, h3.y & 0xffffu, h3.y >> 16);
+            } else {
+                const uint4* R = reinterpret_cast<const uint4*>(a.rows[ct] + row_word(row, 0));
+                q0 = R[0]; q1 = R[64]; q2 = R[128]; q3 = R[192];
+            }
             v_dp[ct] = q0.x; v_nc[ct] = q0.y;
             v_cc[ct][0] = q0.z; v_cc[ct][1] = q0.w; v_cc[ct][2] = q1.x; v_cc[ct][3] = q1.y; v_cc[ct][4] = q1.z; v_cc[ct][5] = q1.w;
             v_bc[ct][0] = q2.z; v_bc[ct][1] = q2.w; v_bc[ct][2] = q3.x; v_bc[ct][3] = q3.y; v_bc[ct][4] = q3.z; v_bc[ct][5] = q3.w;
@@ -270,7 +282,7 @@ __global__ __launch_bounds__(GATHER_WAVES * 64) void k_call_gather(CallArgs a) {
     n_cand_exact += n_c;
     if (c_next + n_c > c_end) {                              // candidate blocks may leave holes: they are reached through sr.cand only
         uint32_t nb = 0;
-        if (lane == 0) nb = (uint32_t)atomicAdd(&a.counters[0], (unsigned long long)CAND_CHUNK) + c_base;
+        if (lane == 0) nb = (uint32_t)atomicAdd(&a.counters[CT_CAND], (unsigned long long)CAND_CHUNK) + c_base;
         c_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb); c_end = c_next + CAND_CHUNK;
     }
     const uint32_t cbase = c_next; c_next += n_c;
@@ -278,14 +290,14 @@ __global__ __launch_bounds__(GATHER_WAVES * 64) void k_call_gather(CallArgs a) {
     uint32_t l_old = l_next, l_room = l_end - l_next, l_new = 0;
     if (tot_l > l_room) {
         uint32_t nb = 0;
-        if (lane == 0) nb = (uint32_t)atomicAdd(&a.counters[2], (unsigned long long)TASK_CHUNK * ((tot_l - l_room + TASK_CHUNK - 1) / TASK_CHUNK)) + l_base;
+        if (lane == 0) nb = (uint32_t)atomicAdd(&a.counters[CT_LIGHT], (unsigned long long)TASK_CHUNK * ((tot_l - l_room + TASK_CHUNK - 1) / TASK_CHUNK)) + l_base;
         l_new = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb);
         l_next = l_new + (tot_l - l_room); l_end = l_new + TASK_CHUNK * ((tot_l - l_room + TASK_CHUNK - 1) / TASK_CHUNK);
     } else l_next += tot_l;
     uint32_t h_old = h_next, h_room = h_end - h_next, h_new = 0;
     if (tot_h > h_room) {
         uint32_t nb = 0;
-        if (lane == 0) nb = (uint32_t)atomicAdd(&a.counters[3], (unsigned long long)HEAVY_CHUNK * ((tot_h - h_room + HEAVY_CHUNK - 1) / HEAVY_CHUNK)) + h_base;
+        if (lane == 0) nb = (uint32_t)atomicAdd(&a.counters[CT_HEAVY], (unsigned long long)HEAVY_CHUNK * ((tot_h - h_room + HEAVY_CHUNK - 1) / HEAVY_CHUNK)) + h_base;
         h_new = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb);
         h_next = h_new + (tot_h - h_room); h_end = h_new + HEAVY_CHUNK * ((tot_h - h_room + HEAVY_CHUNK - 1) / HEAVY_CHUNK);
     } else h_next += tot_h;
@@ -396,7 +408,7 @@ __global__ __launch_bounds__(GATHER_WAVES * 64) void k_call_gather(CallArgs a) {
     TailTask nul; nul.k = 0; nul.n = 0; nul.dst = 0;
     for (uint32_t p = l_next + (uint32_t)lane; p < l_end; p += 64) if (p < a.task_cap) a.light[p] = nul;
     for (uint32_t p = h_next + (uint32_t)lane; p < h_end; p += 64) if (p < a.task_cap) a.heavy[p] = nul;
-    if (lane == 0 && n_cand_exact) atomicAdd(&a.counters[1], (unsigned long long)n_cand_exact);
+    if (lane == 0 && n_cand_exact) atomicAdd(&a.counters[CT_NCAND], (unsigned long long)n_cand_exact);
 }
 
 __device__ __forceinline__ double tail_of_task(const TailTask& t, const CallArgs& a) {
@@ -406,7 +418,7 @@ __device__ __forceinline__ double tail_of_task(const TailTask& t, const CallArgs
 }
 
 __global__ __launch_bounds__(256) void k_call_tails(CallArgs a) {
-    const uint64_t n_all = a.counters[2] + (uint64_t)a.arena_waves * TASK_CHUNK;      // the waves' first chunks + the chunks taken later
+    const uint64_t n_all = a.counters[CT_LIGHT] + (uint64_t)a.arena_waves * TASK_CHUNK;      // the waves' first chunks + the chunks taken later
     const uint64_t n = n_all < a.task_cap ? n_all : a.task_cap;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         const TailTask t = a.light[i];
@@ -475,7 +487,7 @@ __global__ __launch_bounds__(256) void k_tail_table(CallArgs a, int16_t* table) 
 // heavy tasks: eight lanes or one wavefront each
 __global__ __launch_bounds__(256) void k_call_tails_heavy(CallArgs a) {
     const int lane = threadIdx.x & 63;
-    const uint64_t n_all = a.counters[3] + (uint64_t)a.arena_waves * HEAVY_CHUNK;
+    const uint64_t n_all = a.counters[CT_HEAVY] + (uint64_t)a.arena_waves * HEAVY_CHUNK;
     const uint64_t n_tasks = n_all < a.task_cap ? n_all : a.task_cap;
     // tasks differ by three orders of magnitude in their number of terms and most arena slots are empty: a wave takes 16
     // slots at a time off a queue (its first batch is its own index: a small job never touches the queue word), one slot per
@@ -511,7 +523,7 @@ __global__ __launch_bounds__(256) void k_call_tails_heavy(CallArgs a) {
             if (lane == 0) *reinterpret_cast<int16_t*>(dst & ~1ull) = (int16_t)round4(tail);
         }
         unsigned long long nb = 0;
-        if (lane == 0) nb = atomicAdd(&a.counters[5], 1ull) + n_waves;
+        if (lane == 0) nb = atomicAdd(&a.counters[CT_QTAIL], 1ull) + n_waves;
         batch = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(nb >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)nb);
     }
 }
@@ -548,7 +560,7 @@ __global__ void k_call_finish(CallArgs a, uint32_t n_sites) {
         if (n_with - n_pass - n_nonsig > 0) sf |= LSG_SF_CELL_TYPE_NOISE;      // :322
         if (s.sum_alts_bc > 0 && (bc_lt05 || cc_lt05)) sf |= LSG_SF_NOISY_SITE;   // :342
         if (sf == (uint32_t)LSG_SF_CANDIDATE && n_pass > 0) {                   // = keep_site(kind 2): what step 3 can keep
-            const unsigned long long idx = atomicAdd(&a.counters[6], 1ull);
+            const unsigned long long idx = atomicAdd(&a.counters[CT_PASS], 1ull);
             if (idx < PASS_CAP) a.pass_list[idx] = i;
         }
     } else if (s.sum_alts_bc > 0 && (bc_lt001 || cc_lt001)) {
@@ -673,7 +685,7 @@ int run_call(lsg_ctx* c, const lsg_call_params* p) {
     const uint32_t n_ne = c->n_ne;
     c->n_sites = 0; c->n_cand = 0; c->n_pass = -1;
     if (n_ne == 0) { c->called = true; return 0; }
-    if (c->d_site_off.reserve((size_t)(n_ne + 2) * 12 + 192 + (size_t)n_ne * 64 + 64)) return -1;     // site_cnt, site_off, counters (8 u64), heads, head records
+    if (c->d_site_off.reserve((size_t)(n_ne + 2) * 12 + 128 + CT_WORDS * 8 + (size_t)n_ne * 64 + 64)) return -1;     // site_cnt, site_off, counters, heads, head records
     CallArgs a{};
     a.ne_units = c->d_ne_units.as<uint32_t>(); a.ne_mask = c->d_ne_mask.as<uint64_t>(); a.ne_rowbase = c->d_ne_rowbase.as<uint32_t>();
     a.ne_geom = c->ws[WS_NE_GEOM].as<int2>();
@@ -698,10 +710,10 @@ int run_call(lsg_ctx* c, const lsg_call_params* p) {
     a.site_cnt = c->d_site_off.as<uint32_t>();
     a.site_off = a.site_cnt + (n_ne + 2);
     a.counters = reinterpret_cast<unsigned long long*>(a.site_off + (n_ne + 2));   // 2*(n_ne+2) words: 8-byte aligned
-    uint32_t* heads = reinterpret_cast<uint32_t*>(a.counters + 8);
+    uint32_t* heads = reinterpret_cast<uint32_t*>(a.counters + CT_WORDS);
     a.heads = heads;
     a.head_recs = reinterpret_cast<uint32_t*>((reinterpret_cast<uintptr_t>(heads + n_ne) + 63) & ~(uintptr_t)63);
-    LSG_HIP(hipMemsetAsync(a.counters, 0, 64, st));
+    LSG_HIP(hipMemsetAsync(a.counters, 0, CT_WORDS * 8, st));
     hipLaunchKernelGGL(k_site_count, dim3((n_ne + 256) / 256), dim3(256), 0, st, a);
     size_t tb = 0;
     LSG_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, a.site_cnt, a.site_off, (int)(n_ne + 1), st));
@@ -711,7 +723,7 @@ int run_call(lsg_ctx* c, const lsg_call_params* p) {
     {   // the tile heads with at least one site, in order
         HasSites pred{a.site_cnt};
         hipcub::CountingInputIterator<uint32_t> it(0);
-        uint32_t* d_nh = reinterpret_cast<uint32_t*>(a.counters + 4);
+        uint32_t* d_nh = reinterpret_cast<uint32_t*>(a.counters + CT_HEADS);
         size_t tb2 = 0;
         LSG_HIP(hipcub::DeviceSelect::If(nullptr, tb2, it, heads, d_nh, (int)n_ne, pred, st));
         if (c->d_cub_tmp.reserve(tb2 + 256)) return -1;
@@ -748,13 +760,13 @@ int run_call(lsg_ctx* c, const lsg_call_params* p) {
         hipLaunchKernelGGL(k_call_finish, dim3((n_sites + 255) / 256), dim3(256), 0, st, a, n_sites);
         LSG_HIP(hipGetLastError());
     }
-    unsigned long long cnt4[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    LSG_HIP(hipMemcpyAsync(c->h_pin, a.counters, 64, hipMemcpyDeviceToHost, st));
+    unsigned long long cnt4[CT_WORDS];
+    LSG_HIP(hipMemcpyAsync(c->h_pin, a.counters, CT_WORDS * 8, hipMemcpyDeviceToHost, st));
     LSG_HIP(hipStreamSynchronize(st));
-    memcpy(cnt4, c->h_pin, 64);
-    c->n_pass = (int64_t)cnt4[6];
-    const unsigned long long cand = cnt4[1];
-    if (n_sites > 0 && (cnt4[2] + (uint64_t)a.arena_waves * TASK_CHUNK > a.task_cap || cnt4[3] + (uint64_t)a.arena_waves * HEAVY_CHUNK > a.task_cap)) { set_error("lsg_call_step1: tail task buffer too small (%llu/%llu tasks)", cnt4[2], cnt4[3]); return -3; }
+    memcpy(cnt4, c->h_pin, CT_WORDS * 8);
+    c->n_pass = (int64_t)cnt4[CT_PASS];
+    const unsigned long long cand = cnt4[CT_NCAND];
+    if (n_sites > 0 && (cnt4[CT_LIGHT] + (uint64_t)a.arena_waves * TASK_CHUNK > a.task_cap || cnt4[CT_HEAVY] + (uint64_t)a.arena_waves * HEAVY_CHUNK > a.task_cap)) { set_error("lsg_call_step1: tail task buffer too small (%llu/%llu tasks)", cnt4[CT_LIGHT], cnt4[CT_HEAVY]); return -3; }
     c->n_sites = n_sites; c->n_cand = (int64_t)cand;
     c->called = true;
     return 0;

@@ -20,6 +20,7 @@ constexpr int NCTR = 33;            // accumulators kept per position: NC, CC[8]
 constexpr int ROW_QUADS = (ROW_PLANES + 3) / 4;
 constexpr uint64_t ROW_BLOCK_WORDS = (uint64_t)ROW_QUADS * 256;
 constexpr uint64_t ROW_STORED_WORDS = (uint64_t)ROW_QUADS * 4;          // words of HBM per row (36)
+constexpr uint32_t ROW_NARROW = 1u << 31;     // in a unit's row base: its rows are 16-bit planes in the first half of their blocks (emit_unit)
 __host__ __device__ inline uint64_t row_word(uint64_t row, int plane) {
     return (row >> 6) * ROW_BLOCK_WORDS + (uint64_t)(plane >> 2) * 256 + (row & 63) * 4 + (uint64_t)(plane & 3);
 }
@@ -117,6 +118,7 @@ struct lsg_ctx {
     lsg::DevBuf d_ne_units, d_ne_mask, d_ne_rowbase, d_ne_rowoff, d_scalars, d_cub_tmp;
     lsg::DevBuf d_rows[LSG_MAX_CELLTYPES]; // blocked planes, see lsg::row_word
     uint64_t row_cap = 0;
+    uint32_t arena = 256;                  // rows a wave reserves per allocation in the current count (multiple of 256)
     uint32_t n_ne = 0, n_deep = 0;
     int64_t n_rows[LSG_MAX_CELLTYPES] = {0, 0, 0, 0};
     int64_t n_columns = 0;

@@ -51,15 +51,19 @@ constexpr int NBUCKET = 256;         // coarse barcode buckets of the block kern
 constexpr int BLOCK_THREADS = 512;
 constexpr int BLOCK_WAVES = BLOCK_THREADS / 64;
 constexpr int WAVES_PER_BLOCK = 4;   // wave kernel
-constexpr int ARENA = 256;           // rows reserved per wave per allocation
+constexpr int ARENA = 256;           // rows reserved per wave per allocation: this many or a multiple (lsg_ctx::arena)
 constexpr int QCHUNK = 64;          // slots dequeued at once by a wave
 constexpr int FLUSH_EVERY = 63;      // packed LDS fields: bq 14 | fwd 6 | cnt 6 | dup 6 bits
 
 // device scalars (uint64 each)
-enum { SC_QSMALL = 0, SC_QBIG = 1, SC_NNE = 2, SC_ROWALLOC = 4, SC_COLS = 8, SC_OVERFLOW = 9,
+// The words kernels hammer while they run (work queues, row allocators) sit 128 bytes apart: atomics on one cache line serialise at
+// ~90 per microsecond whichever of its words they name, and k_wave_ix alone issued 250 000 of them on the line all of these shared.
+enum { SC_NNE = 2, SC_COLS = 8, SC_OVERFLOW = 9,
        SC_READS = 10, SC_SEGS = 11, SC_EVENTS = 12, SC_EV_WAVE = 13, SC_EV_DEEP = 14, SC_ROWS_DEEP = 15,
-       SC_ROWS = 16, SC_NSMALL = 20, SC_NMULTI = 21, SC_NMULTI_SEL = 22, SC_NHUGE = 24, SC_QHUGE = 25, SC_QBIN0 = 26, SC_QBIN2 = 27,
-       SC_ROWS_SRC = 28, SC_EV_SRC = 32, SC_NCHUNK = 36, SC_QSORT = 37, SC_NENT = 38, SC_COUNT = 40 };   // *_SRC[4]: 0 wave, 1 walk_block, 2 huge, 3 finalize
+       SC_ROWS = 16, SC_NSMALL = 20, SC_NMULTI = 21, SC_NMULTI_SEL = 22, SC_NHUGE = 24,
+       SC_ROWS_SRC = 28, SC_EV_SRC = 32, SC_NCHUNK = 36, SC_NENT = 38,
+       SC_QSMALL = 48, SC_QBIG = 64, SC_QHUGE = 80, SC_QBIN0 = 96, SC_QBIN2 = 112, SC_QSORT = 128,
+       SC_ROWALLOC = 144, SC_ROWALLOC_STRIDE = 16, SC_COUNT = SC_ROWALLOC + SC_ROWALLOC_STRIDE * LSG_MAX_CELLTYPES };   // *_SRC[4]: 0 wave, 1 walk_block, 2 huge, 3 finalize
 
 struct CountArgs;
 __device__ __forceinline__ uint4 unpack_entry(const CountArgs& a, uint2 p);
@@ -92,6 +96,7 @@ struct CountArgs {
     uint32_t* slot_pex; uint32_t* chunk_start;   // wave kernel: work prefix over the small-slot list, first slot of every chunk
     uint32_t* slot_list; uint32_t* multi_list; uint32_t* macc; uint32_t* slices; uint32_t* huge_list;
     uint32_t n_ne, n_slots, n_multi;
+    uint32_t arena;                       // rows a wave reserves per allocation (multiple of 256)
     uint32_t zero_lo, zero_hi;            // address (e, m form) of a 128-byte line of zeros behind the resident events
     uint32_t presorted;                   // multi-slot units' records were written grouped by k_sort_deep (no k_group_block pass, any slot size)
     uint32_t two_ended;                   // <= 2 cell types: a tile's static entry region is filled from both ends, no counting pass
@@ -939,7 +944,10 @@ __device__ __forceinline__ void book_flush(const CountArgs& a, WaveBook& b, int 
 // Gates + row emission for one unit by one wave.  Gates: BaseCellCounter.py:211 (ref != N), :282
 // (count >= MIN_COV), :294 (NC >= MIN_CC); position 0 of a contig is never visited (:86).
 // bk != nullptr: rows come from the wave's arena; nullptr: one exact global atomic.
-template <class CNT>
+// NARROW (the caller guarantees every value < 2^16, and that its arenas are whole 64-row blocks of its own): the unit's rows are
+// written as 16-bit planes into the first half of their blocks (same row numbering, half the bytes moved here and in the call
+// stage's gather); bit 31 of the unit's row base says so (ROW_NARROW).
+template <class CNT, bool NARROW = false>
 __device__ __forceinline__ void emit_unit(const CountArgs& a, const CNT& acc, uint32_t w, int ct, int tid, int32_t tstart, int lane,
                                           WaveBook* bk, bool deep, int ref_prefetched = -1) {
     uint32_t dp = 0;
@@ -962,8 +970,8 @@ __device__ __forceinline__ void emit_unit(const CountArgs& a, const CNT& acc, ui
             if (k) {
                 uint32_t nx = bk->arena_next[ct];
                 if (nx + k > bk->arena_end[ct]) {
-                    nx = (uint32_t)atomicAdd(&a.scalars[SC_ROWALLOC + ct], (unsigned long long)ARENA);
-                    bk->arena_end[ct] = nx + ARENA;
+                    nx = (uint32_t)atomicAdd(&a.scalars[SC_ROWALLOC + SC_ROWALLOC_STRIDE * ct], (unsigned long long)a.arena);
+                    bk->arena_end[ct] = nx + a.arena;
                 }
                 base = nx; bk->arena_next[ct] = nx + k; bk->rows_true[ct] += k;
                 if (deep) bk->rows_deep += k;
@@ -972,14 +980,14 @@ __device__ __forceinline__ void emit_unit(const CountArgs& a, const CNT& acc, ui
         } else {
             if (colm) atomicAdd(&a.scalars[SC_COLS], (unsigned long long)__popcll(colm));
             if (k) {
-                base = (uint32_t)atomicAdd(&a.scalars[SC_ROWALLOC + ct], (unsigned long long)k);
+                base = (uint32_t)atomicAdd(&a.scalars[SC_ROWALLOC + SC_ROWALLOC_STRIDE * ct], (unsigned long long)k);
                 atomicAdd(&a.scalars[SC_ROWS + ct], (unsigned long long)k);
                 if (deep) atomicAdd(&a.scalars[SC_ROWS_DEEP], (unsigned long long)k);
                 atomicAdd(&a.scalars[SC_ROWS_SRC + 3], (unsigned long long)k);
             }
         }
         a.ne_mask[w] = em;
-        a.ne_rowbase[w] = base;
+        a.ne_rowbase[w] = base | (NARROW ? ROW_NARROW : 0u);
     }
     base = rl(base, 0);
     if (!em) return;
@@ -1006,6 +1014,18 @@ __device__ __forceinline__ void emit_unit(const CountArgs& a, const CNT& acc, ui
         if (p < 34) return acc.BCF(p - 26);
         return 0u;
     };
+    if (NARROW) {
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        const uint32_t off8 = ((row >> 6) - b0) * (uint32_t)ROW_BLOCK_WORDS * 4u + (row & 63u) * 8u;
+#pragma unroll
+        for (int q = 0; q < ROW_QUADS; ++q) {
+            u32x2 v; v.x = plane(4 * q) | (plane(4 * q + 1) << 16); v.y = plane(4 * q + 2) | (plane(4 * q + 3) << 16);
+            __builtin_amdgcn_raw_buffer_store_b64(v, rs, (int)off8, q * 512, 0);
+            asm volatile("s_nop 3");                                       // as below
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        return;
+    }
 #pragma unroll
     for (int q = 0; q < ROW_QUADS; ++q) {
         u32x4 v; v.x = plane(4 * q); v.y = plane(4 * q + 1); v.z = plane(4 * q + 2); v.w = plane(4 * q + 3);
@@ -1135,6 +1155,184 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void k_pileup_wave(CountArgs 
         unsigned long long nev = 0; uint32_t rt = 0, cols = 0, rdeep = 0, rsrc = 0;
         for (int w = 0; w < WAVES_PER_BLOCK; ++w) {
             const WaveBook& b = lds_all[w].book;
+            if (lane < a.n_ct) rt += b.rows_true[lane];
+            cols += b.cols; rdeep += b.rows_deep; rsrc += b.rows_src; nev += b.nev;
+        }
+        if (lane < a.n_ct && rt) atomicAdd(&a.scalars[SC_ROWS + lane], (unsigned long long)rt);
+        if (lane == 0) {
+            if (cols) atomicAdd(&a.scalars[SC_COLS], (unsigned long long)cols);
+            if (rdeep) atomicAdd(&a.scalars[SC_ROWS_DEEP], (unsigned long long)rdeep);
+            if (rsrc) atomicAdd(&a.scalars[SC_ROWS_SRC + 0], (unsigned long long)rsrc);
+            if (nev) { atomicAdd(&a.scalars[SC_EV_WAVE], nev); atomicAdd(&a.scalars[SC_EV_SRC + 0], nev); }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Wave kernel of the tile index path.  The records arrive grouped and carry their run flags, so nothing is staged or hashed: the
+// wave's LDS is its packed counters alone, in two planes wide enough for a whole small unit (<= CAPW = 256 entries, 256 x 255 < 2^16)
+// without a flush:   plane 0: quality sum [0..15] | forward count [16..31]      plane 1: count [0..15] | duplicates [16..31]
+// 4 KB of LDS per wave and the run state in ~60 VGPRs instead of 32 KB per workgroup and 143: 8 waves per SIMD instead of 3.
+// Per entry the lanes that count the event are selected with EXEC (v_cmpx) instead of a mask word, which takes the "& vm" operations
+// out of every path:  run of one entry 5 vector operations, first entry of a longer run 6 (+3 when a run is closed), others 9.
+struct IxAcc {
+    uint32_t nc, mask, open;             // nc: barcode runs with a counted event at this lane; open: wave-uniform, a run of several entries is open
+    __device__ __forceinline__ void init() { nc = mask = 0; open = 0; }
+    // m: the record's meta word (SGPR), ev: the lane's event, thr = 0x800 + min_bq, pkl: LDS byte address of this lane's word in row 0
+    // of plane 0 (4096-byte aligned block: the row and the plane are OR-ed / offset in), one: a VGPR holding 1
+    __device__ __forceinline__ void add(uint32_t m, uint32_t ev, uint32_t thr, uint32_t pkl, uint32_t one) {
+        uint32_t t0, t1, addr, lo;
+        unsigned long long sv;
+        open = (uint32_t)__builtin_amdgcn_readfirstlane((int)open);
+        const uint32_t sfwd = (m >> 14) & 0x10000u;                       // forward strand: one in the upper half of plane 0
+        asm volatile(
+            "s_mov_b64 %[sv], exec\n\t"
+            "v_and_b32 %[t0], 0x8ff, %[ev]\n\t"
+            "v_and_or_b32 %[addr], %[ev], %[c700], %[pkl]\n\t"
+            "v_or_b32_sdwa %[lo], %[sfwd], %[ev] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
+            "s_bitcmp0_b32 %[m], 31\n\t"
+            "s_cbranch_scc1 3f\n\t"                                  // not the start of a run
+            "s_cmp_eq_u32 %[open], 0\n\t"
+            "s_cbranch_scc1 1f\n\t"
+            "v_and_b32 %[t1], 1, %[mask]\n\t"                          // close the run of several entries before this one (every lane)
+            "v_add_u32 %[nc], %[nc], %[t1]\n\t"
+            "v_mov_b32 %[mask], 0\n"
+            "1:\n\t"
+            "v_cmpx_le_u32 vcc, %[thr], %[t0]\n\t"                     // EXEC = the lanes that count this event
+            "ds_add_u32 %[addr], %[lo]\n\t"
+            "ds_add_u32 %[addr], %[one] offset:2048\n\t"
+            "s_bitcmp0_b32 %[m], 15\n\t"
+            "s_cbranch_scc1 2f\n\t"
+            "v_add_u32 %[nc], 1, %[nc]\n\t"                            // a run of one entry: counted once if counted
+            "s_mov_b32 %[open], 0\n\t"
+            "s_branch 4f\n"
+            "2:\n\t"
+            "v_bfe_u32 %[t1], %[ev], 8, 4\n\t"                         // first entry of a longer run: mask = its symbol (8 + class) and bit 0
+            "v_lshl_or_b32 %[mask], %[one], %[t1], %[one]\n\t"
+            "s_mov_b32 %[open], 1\n\t"
+            "s_branch 4f\n"
+            "3:\n\t"
+            "v_cmpx_le_u32 vcc, %[thr], %[t0]\n\t"
+            "v_bfe_u32 %[t1], %[ev], 8, 4\n\t"
+            "v_bfe_u32 %[t0], %[mask], %[t1], 1\n\t"                   // symbol already seen in this run: duplicate
+            "v_lshl_or_b32 %[t0], %[t0], 16, %[one]\n\t"
+            "ds_add_u32 %[addr], %[lo]\n\t"
+            "ds_add_u32 %[addr], %[t0] offset:2048\n\t"
+            "v_lshl_or_b32 %[t1], %[one], %[t1], %[one]\n\t"
+            "v_or_b32 %[mask], %[mask], %[t1]\n"
+            "4:\n\t"
+            "s_mov_b64 exec, %[sv]"
+            : [t0] "=&v"(t0), [t1] "=&v"(t1), [addr] "=&v"(addr), [lo] "=&v"(lo), [sv] "=&s"(sv),
+              [mask] "+v"(mask), [nc] "+v"(nc), [open] "+s"(open)
+            : [ev] "v"(ev), [m] "s"(m), [thr] "s"(thr), [c700] "s"(0x700u), [sfwd] "s"(sfwd), [one] "v"(one), [pkl] "v"(pkl)
+            : "scc", "vcc", "memory");
+    }
+    __device__ __forceinline__ void finish() { if (open) { nc += mask & 1u; mask = 0; open = 0; } }
+};
+// a small unit's finished counters read from the two planes
+struct IxCounters {
+    const uint32_t* pk; int lane; uint32_t ncdup;
+    __device__ __forceinline__ uint32_t BC(int k) const { return pk[512 + k * 64 + lane] & 0xffffu; }
+    __device__ __forceinline__ uint32_t DUP(int k) const { return pk[512 + k * 64 + lane] >> 16; }
+    __device__ __forceinline__ uint32_t BQ(int k) const { return pk[k * 64 + lane] & 0xffffu; }
+    __device__ __forceinline__ uint32_t BCF(int k) const { return pk[k * 64 + lane] >> 16; }
+    __device__ __forceinline__ uint32_t NCDUP() const { return ncdup; }
+};
+__device__ __forceinline__ void issue8x(uint32_t e, uint32_t m, int l0, uint32_t lane2, uint32_t (&ev)[8]) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) ev[u] = load_event(rl(e, l0 + u), rl(m, l0 + u), lane2);
+}
+__device__ __forceinline__ void walk_regs_ix(IxAcc& acc, uint32_t e, uint32_t m, int nb, uint32_t thr, uint32_t pkl, uint32_t one, uint32_t lane2) {
+    const int ng = (nb + 7) >> 3;
+    if (ng <= 0) return;
+    uint32_t evA[8], evB[8];
+    issue8x(e, m, 0, lane2, evA);
+    int g = 0;
+    while (true) {
+        if (g + 1 < ng) issue8x(e, m, (g + 1) * 8, lane2, evB);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc.add(rl(m, g * 8 + u), evA[u], thr, pkl, one);      // the meta word straight from the lane into an SGPR
+        if (++g >= ng) break;
+        if (g + 1 < ng) issue8x(e, m, (g + 1) * 8, lane2, evA);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc.add(rl(m, g * 8 + u), evB[u], thr, pkl, one);
+        if (++g >= ng) break;
+    }
+}
+
+constexpr int WIX_WAVES = 4;
+__global__ __launch_bounds__(WIX_WAVES * 64) void k_wave_ix(CountArgs a) {
+    __shared__ __attribute__((aligned(4096))) uint32_t pk_all[WIX_WAVES][2 * 8 * 64];
+    __shared__ WaveBook books[WIX_WAVES];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t* pk = pk_all[wv];
+    WaveBook& book = books[wv];
+    book_init(book, lane);
+    for (int i = lane; i < 2 * 8 * 64; i += 64) pk[i] = 0;
+    const uint32_t n_chunks = (uint32_t)a.scalars[SC_NCHUNK];
+    const uint32_t thr = bq_threshold(a), pkl = lds_addr(pk + lane), lane2 = 2u * (uint32_t)lane;
+    uint32_t one = 1u;
+    asm volatile("" : "+v"(one));                  // a register, not an inline constant (the asm block names it as an LDS data operand)
+    unsigned long long nev_total = 0;
+    const uint32_t n_waves_all = gridDim.x * WIX_WAVES;
+    // a wave's first chunk is its own index, later ones come off the queue, several per dequeue (about 8 dequeues per wave)
+    uint32_t qb = n_chunks / (n_waves_all * 8u);
+    qb = qb < 1u ? 1u : (qb > 16u ? 16u : qb);
+    uint32_t ck = blockIdx.x * WIX_WAVES + wv, ck_end = ck + 1;
+    for (;; ++ck) {
+        if (ck >= ck_end) {
+            if (lane == 0) ck = (uint32_t)atomicAdd(&a.scalars[SC_QSMALL], (unsigned long long)qb) + n_waves_all;
+            ck = rl(ck, 0); ck_end = ck + qb;
+        }
+        if (ck >= n_chunks) break;
+        const uint32_t q0 = a.chunk_start[ck];
+        const int nq = (int)(a.chunk_start[ck + 1] - q0);
+        uint32_t s_w = 0, s_off = 0, s_cnt = 0; int2 s_geom = make_int2(0, 0);
+        if (lane < nq) {
+            const uint32_t s = a.slot_list[q0 + lane];
+            s_w = a.slot_w[s]; s_off = a.slot_off[s]; s_cnt = a.slot_cnt[s];
+            s_geom = a.ne_geom[s_w];
+        }
+        // the first 64 records of a slot are fetched one slot ahead
+        uint2 cur = make_uint2(a.zero_lo, a.zero_hi);
+        { const int n0 = (int)rl(s_cnt, 0); if (lane < n0) cur = a.rec[rl(s_off, 0) + lane]; }
+        for (int qi = 0; qi < nq; ++qi) {
+            const uint32_t w = rl(s_w, qi), src = rl(s_off, qi);
+            const int n = (int)rl(s_cnt, qi);
+            const int32_t tstart = (int32_t)rl((uint32_t)s_geom.x, qi);
+            const uint32_t g = rl((uint32_t)s_geom.y, qi);
+            const int tid = (int)(g & 0xffffffu), ct = (int)(g >> 24);
+            uint2 nxt = make_uint2(a.zero_lo, a.zero_hi);
+            if (qi + 1 < nq) { const int nn = (int)rl(s_cnt, qi + 1); if (lane < nn) nxt = a.rec[rl(s_off, qi + 1) + lane]; }
+            int refb = 'N';
+            { const int64_t pos = (int64_t)tstart + lane; if (pos >= 1 && pos < a.contig_len[tid]) refb = a.ref_ptr[tid][pos]; }
+            IxAcc acc; acc.init();
+            for (int jb = 0; jb < n; jb += 64) {
+                const int nb = n - jb < 64 ? n - jb : 64;
+                uint2 r = cur;
+                if (jb > 0) { r = make_uint2(a.zero_lo, a.zero_hi); if (lane < nb) r = a.rec[src + jb + lane]; }
+                if (lane < nb) nev_total += meta_events(r.y);
+                walk_regs_ix(acc, r.x, r.y, nb, thr, pkl, one, lane2);
+            }
+            acc.finish();
+            uint32_t dp = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) dp += pk[512 + k * 64 + lane] & 0xffffu;
+            const IxCounters tot{pk, lane, dp - acc.nc};
+            emit_unit<IxCounters, true>(a, tot, w, ct, tid, tstart, lane, &book, false, refb);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) pk[k * 64 + lane] = 0;
+            cur = nxt;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) nev_total += __shfl_down(nev_total, o);
+    if (lane == 0) book.nev = nev_total;
+    lds_fence();
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        unsigned long long nev = 0; uint32_t rt = 0, cols = 0, rdeep = 0, rsrc = 0;
+        for (int w = 0; w < WIX_WAVES; ++w) {
+            const WaveBook& b = books[w];
             if (lane < a.n_ct) rt += b.rows_true[lane];
             cols += b.cols; rdeep += b.rows_deep; rsrc += b.rows_src; nev += b.nev;
         }
@@ -1638,7 +1836,7 @@ static void fill_args(lsg_ctx* c, const lsg_count_params* p, CountArgs& a) {
     { uint32_t mx = 0; for (int i = 0; i < c->n_ct; ++i) mx = c->ct_size[i] > mx ? c->ct_size[i] : mx; a.presorted = mx <= (uint32_t)SORT_RMAX && !getenv("LSG_NO_PRESORT") ? 1u : 0u; }
     a.scalars = c->d_scalars.as<unsigned long long>();
     for (int i = 0; i < LSG_MAX_CELLTYPES; ++i) a.rows[i] = c->d_rows[i].as<uint32_t>();
-    a.row_cap = c->row_cap;
+    a.row_cap = c->row_cap; a.arena = c->arena;
     a.two_ended = c->n_ct <= 2 && !getenv("LSG_COUNT_PASS") ? 1u : 0u;
     a.inline_seg_info = a.two_ended && !getenv("LSG_SEG_INFO_KERNEL") ? 1u : 0u;
     a.tile_off = c->d_tile_off.as<uint32_t>(); a.cur_lo = c->d_cur_lo.as<uint32_t>(); a.cur_hi = c->d_cur_hi.as<uint32_t>();
@@ -2148,7 +2346,7 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
     // launch-shape knobs
     const unsigned grid_block = (unsigned)(c->n_cus * 2);      // k_pileup_huge
     const unsigned grid_walk = (unsigned)(c->n_cus * tune_int("LSG_GRID_WALK", 8));       // k_walk_block
-    const unsigned grid_wave = (unsigned)(c->n_cus * tune_int("LSG_GRID_WAVE", 4));
+    const unsigned grid_wave = (unsigned)(c->n_cus * tune_int("LSG_GRID_WAVE", c->index_path && !getenv("LSG_OLD_WAVE") ? 8 : 4));
 
     if (n_ne > 0) {
         // slot plan: deep units are cut into barcode-range slots
@@ -2171,7 +2369,12 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
             uint64_t by_depth = (uint64_t)c->rd.n_events / (uint64_t)p->min_dp + 64;
             if (by_depth < want_rows) want_rows = by_depth;
         }
-        want_rows += (uint64_t)(grid_block + grid_walk + grid_wave * WAVES_PER_BLOCK + (unsigned)(c->n_cus * 8)) * ARENA + 64;      // one open arena per emitting wave
+        // rows a wave reserves per allocation: large enough that the allocator words see few atomics (each takes ~90 per microsecond),
+        // small enough that the open arenas stay a fraction of the rows themselves
+        const uint64_t emitters = (uint64_t)grid_block + grid_walk + (uint64_t)grid_wave * WAVES_PER_BLOCK + (unsigned)(c->n_cus * 8);
+        uint64_t arena = want_rows / (emitters * 8) / ARENA * ARENA;
+        c->arena = (uint32_t)(arena < (uint64_t)ARENA ? (uint64_t)ARENA : (arena > 8ull * ARENA ? 8ull * ARENA : arena));
+        want_rows += emitters * c->arena + 64;      // one open arena per emitting wave
         want_rows = (want_rows + 63) / 64 * 64 + 64;        // whole 64-row blocks (lsg::row_word), one spare: a unit's descriptor spans two
         // every cell type of THIS run needs planes of the current stride (a run with more cell types than any before it
         // finds row_cap large enough but its new buffers still empty)
@@ -2200,13 +2403,15 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
             SlotWork wf{a.slot_list, a.slot_cnt, a.scalars};
             hipcub::TransformInputIterator<uint32_t, SlotWork, hipcub::CountingInputIterator<uint32_t>> work_it(cnt_it, wf);
             SCAN_U32(work_it, a.slot_pex, c->n_slots + 1);
-            hipLaunchKernelGGL(k_chunk_starts, dim3((c->n_slots + 255) / 256), dim3(256), 0, st, a, (uint32_t)(c->n_cus * tune_int("LSG_GRID_WAVE", 4) * WAVES_PER_BLOCK));
+            hipLaunchKernelGGL(k_chunk_starts, dim3((c->n_slots + 255) / 256), dim3(256), 0, st, a, (uint32_t)(grid_wave * WAVES_PER_BLOCK));
         }
         // small units (one wavefront each).  Measured (round 2): running this kernel on a second stream beside the deep units' sort and
         // grouping buys nothing — its persistent workgroups hold 128 KB of LDS and half the wave slots of every CU, k_sort_deep's
         // 1024-thread workgroups the other half, and whichever starts first starves the other — so everything stays on one stream.
         LSG_HIP(hipEventRecord(c->ev[2], st));
-        hipLaunchKernelGGL(k_pileup_wave, dim3(grid_wave), dim3(WAVES_PER_BLOCK * 64), 0, st, a);
+        static_assert(WIX_WAVES == WAVES_PER_BLOCK, "one grid size for both wave kernels");
+        if (a.index_path && !getenv("LSG_OLD_WAVE")) hipLaunchKernelGGL(k_wave_ix, dim3(grid_wave), dim3(WIX_WAVES * 64), 0, st, a);
+        else hipLaunchKernelGGL(k_pileup_wave, dim3(grid_wave), dim3(WAVES_PER_BLOCK * 64), 0, st, a);
         LSG_HIP(hipEventRecord(c->ev[3], st));
         if (c->n_multi > 0) {
             MultiUnit pred{a.ne_nslot};
@@ -2297,12 +2502,18 @@ __global__ void k_export_rows(CountArgs a, int ct, const uint32_t* rowoff, int64
     const int tid = geom.y & 0xffffff;
     uint64_t em = a.ne_mask[w];
     if (!((em >> lane) & 1ull)) return;
-    uint64_t src = (uint64_t)a.ne_rowbase[w] + __popcll(em & ((1ull << lane) - 1ull));
+    const uint32_t rb = a.ne_rowbase[w];
+    uint64_t src = (uint64_t)(rb & ~ROW_NARROW) + __popcll(em & ((1ull << lane) - 1ull));
     uint64_t dst = (uint64_t)rowoff[w] + __popcll(em & ((1ull << lane) - 1ull));
     int64_t pos = (int64_t)geom.x + lane;
     keys[dst] = ((int64_t)tid << 32) | pos;
     refs[dst] = a.ref_ptr[tid][pos];
-    for (int k = 0; k < ROW_PLANES; ++k) counts[dst * LSG_ROW_WORDS + k] = a.rows[ct][row_word(src, k)];
+    if (rb & ROW_NARROW) {
+        const uint16_t* h = reinterpret_cast<const uint16_t*>(a.rows[ct] + (src >> 6) * ROW_BLOCK_WORDS);
+        for (int k = 0; k < ROW_PLANES; ++k) counts[dst * LSG_ROW_WORDS + k] = h[(k >> 2) * 256 + (src & 63) * 4 + (k & 3)];
+    } else {
+        for (int k = 0; k < ROW_PLANES; ++k) counts[dst * LSG_ROW_WORDS + k] = a.rows[ct][row_word(src, k)];
+    }
     for (int sy = 0; sy < 8; ++sy)                             // BCr = BC - BCf is not stored
         counts[dst * LSG_ROW_WORDS + 34 + sy] = counts[dst * LSG_ROW_WORDS + 10 + sy] - counts[dst * LSG_ROW_WORDS + 26 + sy];
 }
