@@ -79,6 +79,7 @@ void lsg_destroy(lsg_ctx* c) {
     for (auto& s : c->posset) s.keys.release();
     for (auto& b : c->syn) b.release();
     for (auto& b : c->ws) b.release();
+    for (auto& b : c->tm) b.release();
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
@@ -114,7 +115,7 @@ int lsg_set_contigs(lsg_ctx* c, int32_t n_contigs, const int64_t* lengths) {
     c->tile_base[n_contigs] = (uint32_t)t;
     c->n_tiles = (uint32_t)t;
     c->tile_lo = 0; c->tile_hi = (uint32_t)t;
-    c->tile_caps_valid = false; c->index_valid = false;
+    c->tile_caps_valid = false; c->index_valid = false; c->tm_valid = false;
     c->max_live_reads = -1; c->max_live_all = -1;
     for (auto& b : c->ref) b.release();
     c->ref.assign(n_contigs, DevBuf());

@@ -107,6 +107,14 @@ struct lsg_ctx {
     uint32_t ix_n_netile = 0;             // tiles that hold any
     bool index_valid = false;
     bool index_path = false;              // the last / current count runs on the tile index
+    // pileup.hip "tile-major store": the admitted entries' events in index order, eight entries to a transposed 1 KB block, with the
+    // static job / unit / slab tables of a count over it; keyed on the read filters and the number of cell types
+    lsg::DevBuf tm[16];
+    uint64_t tm_np = 0;                   // padded entries
+    uint32_t tm_nblk = 0, tm_njobs = 0, tm_nchunks = 0, tm_n_ne = 0, tm_n_multi = 0, tm_n_slabs = 0;
+    int64_t tm_key[4] = {0, 0, 0, 0};     // min_mq, flag_exclude, ignore_orphans, n_ct
+    bool tm_valid = false, tm_usable = false;
+    bool tm_path = false;                 // the last / current count runs on the tile-major store
     int64_t max_live_reads = -1;          // layout.hip: bound on the reads live at once in the reference's pileup buffer (-1 = stale)
     int64_t max_live_all = -1;            // the same over all reads with a barcode: table-independent, cached per load
     lsg::DevBuf d_read_drop;              // layout.hip: per read, 1 = dropped by the pileup's max_depth rule under the last count's parameters

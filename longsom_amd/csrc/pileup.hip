@@ -21,6 +21,8 @@
 //   ones by a 512-thread workgroup on run-aligned slices.
 #include "lsg_ctx.h"
 #include <hipcub/hipcub.hpp>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -61,9 +63,9 @@ constexpr int FLUSH_EVERY = 63;      // packed LDS fields: bq 14 | fwd 6 | cnt 6
 enum { SC_NNE = 2, SC_COLS = 8, SC_OVERFLOW = 9,
        SC_READS = 10, SC_SEGS = 11, SC_EVENTS = 12, SC_EV_WAVE = 13, SC_EV_DEEP = 14, SC_ROWS_DEEP = 15,
        SC_ROWS = 16, SC_NSMALL = 20, SC_NMULTI = 21, SC_NMULTI_SEL = 22, SC_NHUGE = 24,
-       SC_ROWS_SRC = 28, SC_EV_SRC = 32, SC_NCHUNK = 36, SC_NENT = 38,
-       SC_QSMALL = 48, SC_QBIG = 64, SC_QHUGE = 80, SC_QBIN0 = 96, SC_QBIN2 = 112, SC_QSORT = 128,
-       SC_ROWALLOC = 144, SC_ROWALLOC_STRIDE = 16, SC_COUNT = SC_ROWALLOC + SC_ROWALLOC_STRIDE * LSG_MAX_CELLTYPES };   // *_SRC[4]: 0 wave, 1 walk_block, 2 huge, 3 finalize
+       SC_NREST = 25, SC_ROWS_SRC = 28, SC_EV_SRC = 32, SC_NCHUNK = 36, SC_NENT = 38,
+       SC_QSMALL = 48, SC_QBIG = 64, SC_QHUGE = 80, SC_QBIN0 = 96, SC_QBIN2 = 112, SC_QSORT = 128, SC_QREST = 144,
+       SC_ROWALLOC = 160, SC_ROWALLOC_STRIDE = 16, SC_COUNT = SC_ROWALLOC + SC_ROWALLOC_STRIDE * LSG_MAX_CELLTYPES };   // *_SRC[4]: 0 wave, 1 walk_block, 2 huge, 3 finalize
 
 struct CountArgs;
 __device__ __forceinline__ uint4 unpack_entry(const CountArgs& a, uint2 p);
@@ -94,7 +96,7 @@ struct CountArgs {
     uint2* seg_info;                      // per segment {admission key, first tile of its contig} (k_seg_info)
     uint2* rec;                           // grouped 8-byte records {event byte offset lo, meta} of the block path, same indexing as ent
     uint32_t* slot_pex; uint32_t* chunk_start;   // wave kernel: work prefix over the small-slot list, first slot of every chunk
-    uint32_t* slot_list; uint32_t* multi_list; uint32_t* macc; uint32_t* slices; uint32_t* huge_list;
+    uint32_t* slot_list; uint32_t* multi_list; uint32_t* macc; uint32_t* slices; uint32_t* huge_list; uint32_t* rest_list;
     uint32_t n_ne, n_slots, n_multi;
     uint32_t arena;                       // rows a wave reserves per allocation (multiple of 256)
     uint32_t zero_lo, zero_hi;            // address (e, m form) of a 128-byte line of zeros behind the resident events
@@ -949,7 +951,8 @@ __device__ __forceinline__ void book_flush(const CountArgs& a, WaveBook& b, int 
 // stage's gather); bit 31 of the unit's row base says so (ROW_NARROW).
 template <class CNT, bool NARROW = false>
 __device__ __forceinline__ void emit_unit(const CountArgs& a, const CNT& acc, uint32_t w, int ct, int tid, int32_t tstart, int lane,
-                                          WaveBook* bk, bool deep, int ref_prefetched = -1) {
+                                          WaveBook* bk, bool deep, int ref_prefetched = -1, int arena_slot = -1) {
+    const int as = arena_slot < 0 ? ct : arena_slot;          // a wave that writes narrow AND wide rows keeps an arena per format (whole blocks of one format)
     uint32_t dp = 0;
 #pragma unroll
     for (int s = 0; s < 8; ++s) dp += acc.BC(s);
@@ -968,12 +971,12 @@ __device__ __forceinline__ void emit_unit(const CountArgs& a, const CNT& acc, ui
         if (bk) {
             bk->cols += (uint32_t)__popcll(colm);
             if (k) {
-                uint32_t nx = bk->arena_next[ct];
-                if (nx + k > bk->arena_end[ct]) {
+                uint32_t nx = bk->arena_next[as];
+                if (nx + k > bk->arena_end[as]) {
                     nx = (uint32_t)atomicAdd(&a.scalars[SC_ROWALLOC + SC_ROWALLOC_STRIDE * ct], (unsigned long long)a.arena);
-                    bk->arena_end[ct] = nx + a.arena;
+                    bk->arena_end[as] = nx + a.arena;
                 }
-                base = nx; bk->arena_next[ct] = nx + k; bk->rows_true[ct] += k;
+                base = nx; bk->arena_next[as] = nx + k; bk->rows_true[ct] += k;
                 if (deep) bk->rows_deep += k;
                 bk->rows_src += k;
             }
@@ -1175,7 +1178,8 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void k_pileup_wave(CountArgs 
 // 4 KB of LDS per wave and the run state in ~60 VGPRs instead of 32 KB per workgroup and 143: 8 waves per SIMD instead of 3.
 // Per entry the lanes that count the event are selected with EXEC (v_cmpx) instead of a mask word, which takes the "& vm" operations
 // out of every path:  run of one entry 5 vector operations, first entry of a longer run 6 (+3 when a run is closed), others 9.
-struct IxAcc {
+template <int FWD_BIT>                  // where plane 0 counts the forward strand: above the quality sum's field
+struct PlaneAcc {
     uint32_t nc, mask, open;             // nc: barcode runs with a counted event at this lane; open: wave-uniform, a run of several entries is open
     __device__ __forceinline__ void init() { nc = mask = 0; open = 0; }
     // m: the record's meta word (SGPR), ev: the lane's event, thr = 0x800 + min_bq, pkl: LDS byte address of this lane's word in row 0
@@ -1184,7 +1188,7 @@ struct IxAcc {
         uint32_t t0, t1, addr, lo;
         unsigned long long sv;
         open = (uint32_t)__builtin_amdgcn_readfirstlane((int)open);
-        const uint32_t sfwd = (m >> 14) & 0x10000u;                       // forward strand: one in the upper half of plane 0
+        const uint32_t sfwd = ((m >> 30) & 1u) << FWD_BIT;                // forward strand: one in the upper field of plane 0
         asm volatile(
             "s_mov_b64 %[sv], exec\n\t"
             "v_and_b32 %[t0], 0x8ff, %[ev]\n\t"
@@ -1229,6 +1233,7 @@ struct IxAcc {
     }
     __device__ __forceinline__ void finish() { if (open) { nc += mask & 1u; mask = 0; open = 0; } }
 };
+typedef PlaneAcc<16> IxAcc;              // small units: 256 x 255 < 2^16
 // a small unit's finished counters read from the two planes
 struct IxCounters {
     const uint32_t* pk; int lane; uint32_t ncdup;
@@ -1417,7 +1422,21 @@ __device__ __forceinline__ void consume8(WalkAcc& acc, const u32x16& R, int cnt,
     for (int u = 0; u < 8; ++u)
         if (FULL || u < cnt) acc.add(R[2 * u + 1], ev[u], thr, pkl);
 }
-__device__ __forceinline__ void walk_global(const CountArgs& a, WalkAcc& acc, uint32_t src, int j0, int j1, uint32_t* pk, int lane) {
+// the workgroup's shared planes (WalkLds): plane 0 quality sum [0..19] | forward count [20..31], plane 1 count [0..15] | duplicates
+// [16..31]; good for slots of at most WALK_PLANE_MAX entries, never flushed, added to by all four waves at once
+typedef PlaneAcc<20> WalkPlaneAcc;
+constexpr int WALK_PLANE_MAX = 4095;
+template <bool FULL>
+__device__ __forceinline__ void consume8(WalkPlaneAcc& acc, const u32x16& R, int cnt, const uint32_t (&ev)[8], uint32_t thr, uint32_t* pk, int lane) {
+    const uint32_t pkl = lds_addr(pk + lane);
+    uint32_t one = 1u;
+    asm volatile("" : "+v"(one));
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+        if (FULL || u < cnt) acc.add(R[2 * u + 1], ev[u], thr, pkl, one);
+}
+template <class ACC>
+__device__ __forceinline__ void walk_global(const CountArgs& a, ACC& acc, uint32_t src, int j0, int j1, uint32_t* pk, int lane) {
     const uint32_t thr = bq_threshold(a), lane2 = 2u * (uint32_t)lane;
     const int n = j1 - j0;
     if (n <= 0) return;
@@ -1446,45 +1465,92 @@ __device__ __forceinline__ void walk_global(const CountArgs& a, WalkAcc& acc, ui
 }
 
 constexpr int WALK_THREADS = NSLICE * 64;
-struct alignas(2048) WalkLds {
-    uint32_t pk[NSLICE][8 * 64];
-    uint32_t acc[NCTR][64];
-    uint32_t slot;
-    WaveBook book;
+struct WalkLdsW { uint32_t pk[NSLICE][8 * 64]; uint32_t acc[NCTR][64]; };      // slots of more than WALK_PLANE_MAX entries: per-wave packed counters, flushed
+struct WalkLdsP { uint32_t plane[2][8 * 64]; uint32_t nc[64]; };                  // everything else: two shared planes
+template <bool PLANES> struct WalkLds;
+template <> struct alignas(4096) WalkLds<true> { WalkLdsP p; uint32_t slot; WaveBook book; };
+template <> struct alignas(4096) WalkLds<false> { WalkLdsW w; uint32_t slot; WaveBook book; };
+// a slot's finished counters read from the shared planes
+struct PlaneCounters {
+    const uint32_t* pl; const uint32_t* ncw; int lane;
+    __device__ __forceinline__ uint32_t BC(int k) const { return pl[512 + k * 64 + lane] & 0xffffu; }
+    __device__ __forceinline__ uint32_t DUP(int k) const { return pl[512 + k * 64 + lane] >> 16; }
+    __device__ __forceinline__ uint32_t BQ(int k) const { return pl[k * 64 + lane] & 0xfffffu; }
+    __device__ __forceinline__ uint32_t BCF(int k) const { return pl[k * 64 + lane] >> 20; }
+    __device__ __forceinline__ uint32_t NCDUP() const {
+        uint32_t dp = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dp += pl[512 + k * 64 + lane] & 0xffffu;
+        return dp - ncw[lane];
+    }
 };
 
+// PLANES: every slot of the big list with at most WALK_PLANE_MAX entries; the others are handed to the second launch (!PLANES: the
+// flushing per-wave counters, any size) through rest_list.
+template <bool PLANES>
 __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_num_sgpr(96))) void k_walk_block(CountArgs a) {
-    __shared__ WalkLds L;
+    __shared__ WalkLds<PLANES> L;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     if (wv == 0) { book_init(L.book, lane); if (lane == 0) L.book.src = 1; }
-    uint32_t* pk = L.pk[wv];
-    for (int i = lane; i < 8 * 64; i += 64) pk[i] = 0;
-    const uint32_t n_big = a.n_slots - (uint32_t)a.scalars[SC_NSMALL];
+    const uint32_t n_big = PLANES ? a.n_slots - (uint32_t)a.scalars[SC_NSMALL] : (uint32_t)a.scalars[SC_NREST];
     for (bool first = true;; first = false) {
         __syncthreads();
-        if (t == 0) L.slot = first ? blockIdx.x : (uint32_t)atomicAdd(&a.scalars[SC_QBIG], 1ull) + gridDim.x;   // first item = own index
-        for (int i = t; i < NCTR * 64; i += WALK_THREADS) (&L.acc[0][0])[i] = 0;
+        if (t == 0) L.slot = first ? blockIdx.x : (uint32_t)atomicAdd(&a.scalars[PLANES ? SC_QBIG : SC_QREST], 1ull) + gridDim.x;   // first item = own index
         __syncthreads();
         const uint32_t qi = rl(L.slot, 0);
         if (qi >= n_big) break;
-        const uint32_t s = rl(a.slot_list[a.n_slots - 1 - qi], 0);
+        const uint32_t s = rl(PLANES ? a.slot_list[a.n_slots - 1 - qi] : a.rest_list[qi], 0);
         const int n = (int)rl(a.slot_cnt[s], 0);
         const uint32_t w = rl(a.slot_w[s], 0), src = rl(a.slot_off[s], 0);
         if (n > CAPB && !(a.presorted && a.ne_nslot[w] > 1)) continue;   // k_pileup_huge's slot
+        if (PLANES && n > WALK_PLANE_MAX) {
+            if (t == 0) a.rest_list[atomicAdd(&a.scalars[SC_NREST], 1ull)] = s;
+            continue;
+        }
         const int j0 = (int)rl(a.slices[(uint64_t)s * (NSLICE + 1) + wv], 0), j1 = (int)rl(a.slices[(uint64_t)s * (NSLICE + 1) + wv + 1], 0);
-        WalkAcc acc; acc.init(&L.acc[0][0]);
-        walk_global(a, acc, src, j0, j1, pk, lane);
-        acc.finish(pk, lane);
-        __syncthreads();
-        if (a.ne_nslot[w] > 1) {
-            // multi-slot unit: this slot's partial sums go to its own slab with plain coalesced stores;
-            // k_finalize_multi adds the unit's slabs (global atomics here cost more than the whole walk)
-            uint32_t* dst = a.macc + (uint64_t)(a.ne_acc[w] + (s - a.ne_slot_base[w])) * (NCTR * 64);
-            for (int i = t; i < NCTR * 64; i += WALK_THREADS) dst[i] = (&L.acc[0][0])[i];
-        } else if (wv == 0) {
-            const LdsCounters tot{&L.acc[0][0], lane};
-            const int2 geom = a.ne_geom[w];
-            emit_unit(a, tot, w, (int)((uint32_t)geom.y >> 24), geom.y & 0xffffff, geom.x, lane, &L.book, true);
+        const bool multi = a.ne_nslot[w] > 1;
+        if constexpr (PLANES) {
+            // the four waves add straight into the workgroup's two planes: no per-wave counters, no flush, no merge
+            for (int i = t; i < 2 * 8 * 64 + 64; i += WALK_THREADS) (&L.p.plane[0][0])[i] = 0;
+            __syncthreads();
+            WalkPlaneAcc acc; acc.init();
+            walk_global(a, acc, src, j0, j1, &L.p.plane[0][0], lane);
+            acc.finish();
+            if (acc.nc) atomicAdd(&L.p.nc[lane], acc.nc);
+            __syncthreads();
+            const PlaneCounters tot{&L.p.plane[0][0], L.p.nc, lane};
+            if (multi) {
+                // multi-slot unit: this slot's partial sums go to its own slab (the accumulator rows k_finalize_multi adds up;
+                // global atomics here cost more than the whole walk)
+                uint32_t* dst = a.macc + (uint64_t)(a.ne_acc[w] + (s - a.ne_slot_base[w])) * (NCTR * 64);
+                const uint32_t* pl = &L.p.plane[0][0];
+                if (wv == 0) dst[lane] = tot.NCDUP();
+                for (int r = 1 + wv; r < NCTR; r += NSLICE) {
+                    const int k = (r - 1) & 7, grp = (r - 1) >> 3;                      // rows 1..8 dup, 9..16 count, 17..24 quality, 25..32 forward
+                    const uint32_t lo = pl[k * 64 + lane], hi = pl[512 + k * 64 + lane];
+                    dst[r * 64 + lane] = grp == 0 ? hi >> 16 : grp == 1 ? hi & 0xffffu : grp == 2 ? lo & 0xfffffu : lo >> 20;
+                }
+            } else if (wv == 0) {
+                const int2 geom = a.ne_geom[w];
+                emit_unit(a, tot, w, (int)((uint32_t)geom.y >> 24), geom.y & 0xffffff, geom.x, lane, &L.book, true);
+            }
+        } else {
+            uint32_t* pk = L.w.pk[wv];
+            for (int i = lane; i < 8 * 64; i += 64) pk[i] = 0;
+            for (int i = t; i < NCTR * 64; i += WALK_THREADS) (&L.w.acc[0][0])[i] = 0;
+            __syncthreads();
+            WalkAcc acc; acc.init(&L.w.acc[0][0]);
+            walk_global(a, acc, src, j0, j1, pk, lane);
+            acc.finish(pk, lane);
+            __syncthreads();
+            if (multi) {
+                uint32_t* dst = a.macc + (uint64_t)(a.ne_acc[w] + (s - a.ne_slot_base[w])) * (NCTR * 64);
+                for (int i = t; i < NCTR * 64; i += WALK_THREADS) dst[i] = (&L.w.acc[0][0])[i];
+            } else if (wv == 0) {
+                const LdsCounters tot{&L.w.acc[0][0], lane};
+                const int2 geom = a.ne_geom[w];
+                emit_unit(a, tot, w, (int)((uint32_t)geom.y >> 24), geom.y & 0xffffff, geom.x, lane, &L.book, true);
+            }
         }
     }
     if (wv == 0) book_flush(a, L.book, lane);                      // the events this kernel reads are counted by k_group_block
@@ -1721,6 +1787,7 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize_multi(CountArgs a) {
     for (uint32_t k = blockIdx.x; k < a.n_multi; k += gridDim.x) {
         const uint32_t w = a.multi_list[k];
         const uint32_t nslot = a.ne_nslot[w];
+        { const uint32_t tile = a.ne_units[w] / (uint32_t)a.n_ct; if (tile < a.tile_lo || tile >= a.tile_hi) continue; }   // (the tile-major lists are static: all tiles)
         __syncthreads();
         for (int i = t; i < NCTR * 64; i += FIN_THREADS) (&sacc[0][0])[i] = 0;
         __syncthreads();
@@ -1832,6 +1899,7 @@ static void fill_args(lsg_ctx* c, const lsg_count_params* p, CountArgs& a) {
     a.macc = c->ws[WS_MACC].as<uint32_t>();
     a.slot_pex = c->ws[WS_SLOT_PEX].as<uint32_t>(); a.chunk_start = c->ws[WS_CHUNK_START].as<uint32_t>();
     a.slices = c->ws[WS_SLICES].as<uint32_t>(); a.huge_list = c->ws[WS_HUGE_LIST].as<uint32_t>();
+    a.rest_list = a.huge_list + (c->entries_upper / CAPB + 16);      // second half: slots the plane walk hands on
     a.n_ne = c->n_ne; a.n_slots = c->n_slots; a.n_multi = c->n_multi;
     { uint32_t mx = 0; for (int i = 0; i < c->n_ct; ++i) mx = c->ct_size[i] > mx ? c->ct_size[i] : mx; a.presorted = mx <= (uint32_t)SORT_RMAX && !getenv("LSG_NO_PRESORT") ? 1u : 0u; }
     a.scalars = c->d_scalars.as<unsigned long long>();
@@ -2247,6 +2315,593 @@ static int build_index(lsg_ctx* c) {
     return done(0);
 }
 
+// ================================================================================================
+// Tile-major store.  Built once per (load, read filters, number of cell types) on top of the tile index: the admitted entries' events
+// are copied out of the read-major lines into the index order (tile, barcode), eight entries to a 1 KB block held TRANSPOSED
+// ([position 0..63][entry 0..7], 16 bytes per position), every tile padded to whole blocks.  A count then streams each tile's blocks
+// front to back: one 16-byte load per lane brings the lane's position of eight entries, a kilobyte per wave instruction instead of the
+// 128-byte gathers of the read-major layout (which stop at ~4 TB/s whatever their shape; contiguous kilobytes reach ~6).  What a count
+// still decides per entry is the cell type of its barcode (k_tm_resolve: one byte per entry); both cell types of a tile are counted in
+// the same pass (a barcode's run belongs to one cell type), into two pairs of LDS planes per wave.
+//   s0[p]   cb [0..23] | forward << 30 | first entry of its barcode's run in the tile << 31          (pad entries: cb = CB_MASK, run start)
+//   b[p]    events - 1 [0..5] | first line of its segment << 6 | run of exactly one entry << 7
+//   meta[p] (per count, 32 bits laid out so that the walk uses them as operands): cell type << 4 and << 12 | forward << 20 |
+//           not counted or not there << 29 | run of one entry << 30 | run start << 31
+// Tiles of more than TM_JOB_MAX entries are cut at run starts into jobs of about TM_JOB_TGT entries (one wave each, partial sums to
+// slabs that k_finalize_multi adds up: 8 KB per job and cell type, so jobs are as long as the planes' fields allow); everything about jobs, units and slabs is static too, so a count has no planning step and
+// one host synchronisation (its final read of the counters).
+#ifndef LSG_TM_ASM
+#define LSG_TM_ASM true
+#endif
+constexpr int TM_JOB_MAX = 3072, TM_JOB_TGT = 3072, TM_JOB_LIMIT = 4095;      // LIMIT: what the planes' 12-bit forward field holds; a cut moves forward to the next run start
+constexpr uint32_t TM_PAD_S0 = CB_MASK | IX_RUNSTART;
+enum { TM_STORE = 0, TM_S0, TM_B, TM_LINE, TM_META, TM_BLK_TILE, TM_JOBS, TM_NE_UNITS, TM_NE_GEOM, TM_NE_NSLOT, TM_NE_ACC, TM_MULTI, TM_CHUNKS, TM_NBUF };
+constexpr uint32_t TM_CHUNK_WORK = 4096, TM_JOB_W0 = 32;      // a wave dequeues about this much work (entries + a constant per job) at a time
+struct TmJob { uint32_t e0, e1, w0, slab, nj, cnt, tile, pad; };      // padded-entry range; unit of (tile, cell type 0); slab of (job, cell type 0) or ~0; jobs and entries of the tile
+constexpr uint32_t TMM_CT4 = 1u << 4, TMM_CT12 = 1u << 12, TMM_FWD = 1u << 20, TMM_SKIP = 1u << 29, TMM_SINGLE = 1u << 30, TMM_RS = 1u << 31;
+struct TmArgs {
+    const uint4* store; const uint32_t* s0; const uint8_t* b; uint32_t* meta; const uint32_t* blk_tile; const TmJob* jobs;
+    const uint32_t* chunk_start;          // static: first job of every chunk of about TM_CHUNK_WORK work
+    uint64_t np; uint32_t nblk, njobs, nchunks;
+};
+
+struct TmAdm {      // an index entry passes the key's read filters (ix2: flag12 | mapq << 12 | ...)
+    const uint32_t* ix2; uint32_t flag_exclude; int32_t min_mq, ignore_orphans;
+    __host__ __device__ uint32_t operator()(const uint32_t& i) const {
+        const uint32_t x = ix2[i], flag = x & 0xfffu;
+        bool ok = (flag & flag_exclude) == 0 && (int)((x >> 12) & 0xffu) >= min_mq;
+        if (ok && ignore_orphans && (flag & 1u) && !(flag & 2u)) ok = false;
+        return ok ? 1u : 0u;
+    }
+};
+// per tile: admitted entries, blocks, non-empty, jobs, slabs, multi-job (inputs of five exclusive scans)
+__global__ void k_tm_tiles(const uint32_t* tile_off, const uint32_t* S, uint32_t n_tiles, int n_ct, uint32_t* cnt, uint32_t* blk, uint32_t* ne,
+                           uint32_t* nj, uint32_t* slabs, uint32_t* multi) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > n_tiles) return;
+    uint32_t c = 0;
+    if (t < n_tiles) c = S[tile_off[t + 1]] - S[tile_off[t]];
+    const uint32_t j = c == 0 ? 0u : (c <= (uint32_t)TM_JOB_MAX ? 1u : (c + TM_JOB_TGT - 1) / TM_JOB_TGT);
+    cnt[t] = c; blk[t] = (c + 7) / 8; ne[t] = c ? 1u : 0u; nj[t] = j; slabs[t] = j > 1 ? j * (uint32_t)n_ct : 0u; multi[t] = j > 1 ? 1u : 0u;
+}
+// largest t in [0, n) with off[t] <= x (off non-decreasing, off[0] <= x): the tile whose region holds x, skipping empty ones
+__device__ __forceinline__ uint32_t tm_owner(const uint32_t* off, uint32_t n, uint32_t x) {
+    uint32_t lo = 0, hi = n;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (off[mid] <= x) lo = mid; else hi = mid; }
+    return lo;
+}
+__global__ void k_tm_blk_tile(const uint32_t* blk_off, uint32_t n_tiles, uint32_t nblk, uint32_t* blk_tile) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < nblk) blk_tile[b] = tm_owner(blk_off, n_tiles, b);
+}
+__global__ void k_tm_fill(TmAdm adm, const uint32_t* ix0, const uint32_t* ix1, const uint32_t* ix2, uint64_t n, const uint32_t* tile_off, uint32_t n_tiles,
+                          const uint32_t* S, const uint32_t* blk_off, uint32_t* s0, uint32_t* line, uint8_t* b) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        if (!adm((uint32_t)i)) continue;
+        const uint32_t t = tm_owner(tile_off, n_tiles, (uint32_t)i);
+        const uint64_t p = (uint64_t)blk_off[t] * 8 + (S[i] - S[tile_off[t]]);
+        const uint32_t x = ix0[i];
+        s0[p] = x & (CB_MASK | META_FWD);
+        line[p] = ix1[i];
+        b[p] = (uint8_t)(((x >> 24) & 63u) | ((ix2[i] & IX_SEGSTART) ? 64u : 0u));
+    }
+}
+__device__ __forceinline__ bool tm_first_of_tile(uint64_t p, const uint32_t* blk_off, const uint32_t* blk_tile) {
+    return (p & 7) == 0 && (uint64_t)blk_off[blk_tile[p >> 3]] * 8 == p;
+}
+// run flags over the admitted entries: first entry of its barcode in the tile; run of exactly one
+__global__ void k_tm_runs(uint32_t* s0, uint8_t* b, uint64_t np, const uint32_t* blk_off, const uint32_t* blk_tile) {
+    for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < np; p += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t x = s0[p], cb = x & CB_MASK;
+        if (cb == CB_MASK) continue;                                   // pad: a run start already
+        const bool rs = tm_first_of_tile(p, blk_off, blk_tile) || (s0[p - 1] & CB_MASK) != cb;
+        const bool next_rs = p + 1 >= np || (s0[p + 1] & CB_MASK) != cb || tm_first_of_tile(p + 1, blk_off, blk_tile);
+        if (rs) s0[p] = x | IX_RUNSTART;                               // (neighbours read bits 0..23 only)
+        if (rs && next_rs) b[p] |= 128u;
+    }
+}
+// one wave per block: lane = position; eight 128-byte lines in, one transposed kilobyte out
+__global__ void k_tm_gather(const uint16_t* events, const uint32_t* s0, const uint32_t* line, uint32_t nblk, uint4* store) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t blk = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (blk >= nblk) return;
+    uint32_t e[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const uint64_t p = (uint64_t)blk * 8 + u;
+        e[u] = (s0[p] & CB_MASK) != CB_MASK ? (uint32_t)events[(uint64_t)line[p] * 64 + lane] : 0u;
+    }
+    store[(uint64_t)blk * 64 + lane] = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+}
+// per non-empty tile: its units (one per cell type), its jobs cut at run starts
+__global__ void k_tm_jobs(CountArgs a, const uint32_t* s0, const uint32_t* cnt, const uint32_t* blk_off, const uint32_t* ne_off, const uint32_t* nj,
+                          const uint32_t* job_off, const uint32_t* slab_off, const uint32_t* multi_off, uint32_t n_tiles, TmJob* jobs,
+                          uint32_t* ne_units, int2* ne_geom, uint32_t* ne_nslot, uint32_t* ne_acc, uint32_t* multi, uint32_t* max_job) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tiles) return;
+    const uint32_t n = cnt[t];
+    if (!n) return;
+    const uint32_t J = nj[t], ord = ne_off[t];
+    const uint64_t base = (uint64_t)blk_off[t] * 8;
+    for (int ct = 0; ct < a.n_ct; ++ct) {
+        const uint32_t w = ord * (uint32_t)a.n_ct + ct, u = t * (uint32_t)a.n_ct + ct;
+        ne_units[w] = u;
+        int c2, tid; int32_t tstart;
+        unit_geometry(a, u, c2, tid, tstart);
+        ne_geom[w] = make_int2(tstart, tid | (ct << 24));
+        ne_nslot[w] = J;
+        ne_acc[w] = J > 1 ? slab_off[t] + (uint32_t)ct * J : 0u;
+        if (J > 1) multi[multi_off[t] * (uint32_t)a.n_ct + ct] = w;
+    }
+    auto cut = [&](uint32_t x) -> uint32_t { while (x < n && !(s0[base + x] & IX_RUNSTART)) ++x; return x < n ? x : n; };
+    uint32_t e0 = 0;
+    for (uint32_t j = 0; j < J; ++j) {
+        const uint32_t e1 = j + 1 == J ? n : cut((uint32_t)(((uint64_t)n * (j + 1)) / J));
+        TmJob jb;
+        jb.e0 = (uint32_t)(base + e0); jb.e1 = (uint32_t)(base + (e1 < e0 ? e0 : e1)); jb.w0 = ord * (uint32_t)a.n_ct;
+        jb.slab = J > 1 ? slab_off[t] + j : 0xFFFFFFFFu; jb.nj = J; jb.cnt = n; jb.tile = t; jb.pad = 0;
+        jobs[job_off[t] + j] = jb;
+        if (jb.e1 - jb.e0 > (uint32_t)TM_JOB_LIMIT) atomicMax(max_job, jb.e1 - jb.e0);
+        e0 = e1 < e0 ? e0 : e1;
+    }
+}
+
+struct TmJobWork {
+    const TmJob* jobs;
+    __host__ __device__ uint32_t operator()(const uint32_t& j) const { return jobs[j].e1 - jobs[j].e0 + TM_JOB_W0; }
+};
+// chunk k = the jobs whose exclusive work prefix lies in [k E, (k + 1) E)
+__global__ void k_tm_chunks(const uint32_t* pex, uint32_t njobs, uint32_t* chunk_start, uint32_t* n_chunks) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= njobs) return;
+    const uint32_t ck = pex[j] / TM_CHUNK_WORK;
+    const int64_t prev = j ? (int64_t)(pex[j - 1] / TM_CHUNK_WORK) : -1;
+    for (int64_t k = prev + 1; k <= (int64_t)ck; ++k) chunk_start[k] = j;
+    if (j == njobs - 1) { chunk_start[ck + 1] = njobs; *n_chunks = ck + 1; }
+}
+
+// per count: the byte the walk reads per entry
+__global__ __launch_bounds__(256) void k_tm_resolve(CountArgs a, TmArgs tm, unsigned long long* stat_slots) {
+    __shared__ unsigned long long s_stat[3];
+    if (threadIdx.x == 0) { s_stat[0] = 0; s_stat[1] = 0; s_stat[2] = 0; }
+    __syncthreads();
+    unsigned long long ev = 0, sg = 0, ne = 0;
+    const uint32_t blk = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blk < tm.nblk) {
+        const uint32_t tile = tm.blk_tile[blk];
+        const bool in_region = tile >= a.tile_lo && tile < a.tile_hi;
+        const uint4* sp = reinterpret_cast<const uint4*>(tm.s0 + (uint64_t)blk * 8);
+        const uint4 s_lo = sp[0], s_hi = sp[1];
+        const uint2 bb = *reinterpret_cast<const uint2*>(tm.b + (uint64_t)blk * 8);
+        const uint32_t sv[8] = {s_lo.x, s_lo.y, s_lo.z, s_lo.w, s_hi.x, s_hi.y, s_hi.z, s_hi.w};
+        uint32_t mv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t s = sv[u], b8 = ((u < 4 ? bb.x : bb.y) >> (8 * (u & 3))) & 0xffu, cb = s & CB_MASK;
+            uint32_t cls = 3;
+            if (in_region) {
+                cls = 2;
+                if (cb < (uint32_t)a.n_cb) { const uint32_t ct = a.celltype_of[cb]; if (ct < (uint32_t)a.n_ct) cls = ct; }
+            }
+            if (cls < 2) { ev += (b8 & 63u) + 1u; sg += (b8 >> 6) & 1u; ++ne; }
+            uint32_t m = cls < 2 ? (cls ? (TMM_CT4 | TMM_CT12) : 0u) | ((s & META_FWD) ? TMM_FWD : 0u) | ((b8 & 128u) ? TMM_SINGLE : 0u) : TMM_SKIP;
+            if (cls != 3 && (s & IX_RUNSTART)) m |= TMM_RS;              // (an entry that is not there starts nothing)
+            mv[u] = m;
+        }
+        uint4* mp = reinterpret_cast<uint4*>(tm.meta + (uint64_t)blk * 8);
+        mp[0] = make_uint4(mv[0], mv[1], mv[2], mv[3]); mp[1] = make_uint4(mv[4], mv[5], mv[6], mv[7]);
+    }
+    for (int o = 32; o > 0; o >>= 1) { ev += __shfl_down(ev, o); sg += __shfl_down(sg, o); ne += __shfl_down(ne, o); }
+    if ((threadIdx.x & 63) == 0 && ne) { atomicAdd(&s_stat[0], ev); atomicAdd(&s_stat[1], sg); atomicAdd(&s_stat[2], ne); }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_stat[2]) {
+        unsigned long long* slot = stat_slots + (size_t)(blockIdx.x % IX_STAT_SLOTS) * 8;
+        atomicAdd(&slot[0], s_stat[0]); atomicAdd(&slot[1], s_stat[1]); atomicAdd(&slot[2], s_stat[2]);
+    }
+}
+
+// run state of a wave over a tile's entries, both cell types: nc packs the runs that counted an event per cell type (16 bits each)
+struct TmState { uint32_t nc, mask, open, open_sh; };
+__device__ __forceinline__ void tm_lds_add(uint32_t addr, uint32_t v) {
+    __hip_atomic_fetch_add((LSG_AS3 uint32_t*)(uintptr_t)addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// One entry at the lane's position.  m: the entry's meta word in an SGPR (TMM_*); evw: the register holding the lane's events of an
+// entry pair, HI picks the half.  Planes of cell type c at pkl0 + 4096 c: plane 0 quality sum [0..19] | forward count [20..31], plane 1
+// (+2048) count [0..15] | duplicates [16..31].  Every decision is a scalar branch; the lanes that count the event are selected with
+// EXEC.  A run of one entry: 6 vector operations; first entry of a longer run 7 (+4 when it closes the run before it); others 10.
+constexpr bool TM_ASM = LSG_TM_ASM;
+template <bool HI>
+__device__ __forceinline__ void tm_add(TmState& s, uint32_t m, uint32_t evw, uint32_t thr, uint32_t pkl0, uint32_t one) {
+    if (!TM_ASM) {                                   // the same in plain C++ (what the asm block is checked against when it is touched)
+        const uint32_t ev = HI ? evw >> 16 : evw & 0xffffu;
+        if (m & TMM_RS) { if (s.open) { s.nc += (s.mask & 1u) << s.open_sh; s.mask = 0; s.open = 0; } }
+        if (m & TMM_SKIP) return;
+        const bool counted = (ev & 0x8ffu) >= thr;
+        const uint32_t addr = (pkl0 | (ev & 0x700u)) + (m & TMM_CT12);
+        const uint32_t lo = (ev & 0xffu) | (m & TMM_FWD);
+        const uint32_t sym8 = (ev >> 8) & 15u;
+        if (m & TMM_SINGLE) {
+            if (counted) { tm_lds_add(addr, lo); tm_lds_add(addr + 2048u, 1u); s.nc += 1u << (m & TMM_CT4); }
+        } else if (!s.open) {
+            if (counted) { tm_lds_add(addr, lo); tm_lds_add(addr + 2048u, 1u); s.mask = (1u << sym8) | 1u; }
+            s.open = 1; s.open_sh = m & TMM_CT4;
+        } else if (counted) {
+            const uint32_t seen = (s.mask >> sym8) & 1u;
+            tm_lds_add(addr, lo); tm_lds_add(addr + 2048u, 1u | (seen << 16));
+            s.mask |= (1u << sym8) | 1u;
+        }
+        return;
+    }
+    uint32_t t0, t1, addr, lo, sa, sb;
+    unsigned long long sv;
+    s.open = (uint32_t)__builtin_amdgcn_readfirstlane((int)s.open);
+    s.open_sh = (uint32_t)__builtin_amdgcn_readfirstlane((int)s.open_sh);
+#define LSG_TM_ADD(WSEL, BSEL, SYMPOS)                                                                                                        \
+    asm volatile(                                                                                                                    \
+        "s_bitcmp1_b32 %[m], 31\n\t"                                                                                                  \
+        "s_cbranch_scc0 1f\n\t"                                   /* not a run start */                                             \
+        "s_cmp_eq_u32 %[open], 0\n\t"                                                                                                 \
+        "s_cbranch_scc1 1f\n\t"                                                                                                       \
+        "v_and_b32 %[t1], 1, %[mask]\n\t"                           /* close the run of several entries before this one */          \
+        "v_lshlrev_b32 %[t1], %[osh], %[t1]\n\t"                                                                                      \
+        "v_add_u32 %[nc], %[nc], %[t1]\n\t"                                                                                           \
+        "v_mov_b32 %[mask], 0\n\t"                                                                                                    \
+        "s_mov_b32 %[open], 0\n"                                                                                                      \
+        "1:\n\t"                                                                                                                      \
+        "s_bitcmp1_b32 %[m], 29\n\t"                                                                                                  \
+        "s_cbranch_scc1 5f\n\t"                                   /* not counted / not there */                                     \
+        "v_and_b32_sdwa %[t0], %[k8ff], %[ev] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:" WSEL "\n\t"               \
+        "s_and_b32 %[sa], %[m], 0x1000\n\t"                                                                                           \
+        "v_and_b32_sdwa %[addr], %[c700], %[ev] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:" WSEL "\n\t"             \
+        "s_and_b32 %[sb], %[m], 0x100000\n\t"                                                                                         \
+        "v_or3_b32 %[addr], %[addr], %[pkl], %[sa]\n\t"             /* symbol row | lane word | the cell type's planes */           \
+        "v_or_b32_sdwa %[lo], %[sb], %[ev] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:" BSEL "\n\t"                  \
+        "s_mov_b64 %[sv], exec\n\t"                                                                                                   \
+        "v_cmpx_le_u32 vcc, %[thr], %[t0]\n\t"                      /* EXEC = the lanes that count this event */                    \
+        "s_bitcmp1_b32 %[m], 30\n\t"                                                                                                  \
+        "s_cbranch_scc0 2f\n\t"                                                                                                       \
+        "ds_add_u32 %[addr], %[lo]\n\t"                             /* a run of one entry */                                        \
+        "ds_add_u32 %[addr], %[one] offset:2048\n\t"                                                                                  \
+        "s_and_b32 %[sa], %[m], 16\n\t"                                                                                               \
+        "s_lshl_b32 %[sa], 1, %[sa]\n\t"                                                                                              \
+        "v_add_u32 %[nc], %[sa], %[nc]\n\t"                                                                                           \
+        "s_branch 4f\n"                                                                                                               \
+        "2:\n\t"                                                                                                                      \
+        "v_bfe_u32 %[t1], %[ev], " SYMPOS ", 4\n\t"                 /* 8 + class */                                                 \
+        "s_cmp_eq_u32 %[open], 0\n\t"                                                                                                 \
+        "s_cbranch_scc0 3f\n\t"                                                                                                       \
+        "ds_add_u32 %[addr], %[lo]\n\t"                             /* first entry of a longer run that is there */                 \
+        "ds_add_u32 %[addr], %[one] offset:2048\n\t"                                                                                  \
+        "v_lshl_or_b32 %[mask], %[one], %[t1], %[one]\n\t"                                                                            \
+        "s_mov_b32 %[open], 1\n\t"                                                                                                    \
+        "s_and_b32 %[osh], %[m], 16\n\t"                                                                                              \
+        "s_branch 4f\n"                                                                                                               \
+        "3:\n\t"                                                                                                                      \
+        "v_bfe_u32 %[t0], %[mask], %[t1], 1\n\t"                    /* symbol already seen in this run: duplicate */                \
+        "v_lshl_or_b32 %[t0], %[t0], 16, %[one]\n\t"                                                                                  \
+        "ds_add_u32 %[addr], %[lo]\n\t"                                                                                               \
+        "ds_add_u32 %[addr], %[t0] offset:2048\n\t"                                                                                   \
+        "v_lshl_or_b32 %[t1], %[one], %[t1], %[one]\n\t"                                                                              \
+        "v_or_b32 %[mask], %[mask], %[t1]\n"                                                                                          \
+        "4:\n\t"                                                                                                                      \
+        "s_mov_b64 exec, %[sv]\n"                                                                                                     \
+        "5:"                                                                                                                          \
+        : [t0] "=&v"(t0), [t1] "=&v"(t1), [addr] "=&v"(addr), [lo] "=&v"(lo), [sv] "=&s"(sv), [sa] "=&s"(sa), [sb] "=&s"(sb),        \
+          [mask] "+v"(s.mask), [nc] "+v"(s.nc), [open] "+s"(s.open), [osh] "+s"(s.open_sh)                                           \
+        : [ev] "v"(evw), [m] "s"(m), [thr] "s"(thr), [c700] "s"(0x700u), [k8ff] "s"(0x8ffu), [one] "v"(one), [pkl] "v"(pkl0)           \
+        : "scc", "vcc", "memory")
+    if (HI) LSG_TM_ADD("WORD_1", "BYTE_2", "24"); else LSG_TM_ADD("WORD_0", "BYTE_0", "8");
+#undef LSG_TM_ADD
+}
+struct TmCounters {
+    const uint32_t* pl; int lane; uint32_t ncdup;
+    __device__ __forceinline__ uint32_t BC(int k) const { return pl[512 + k * 64 + lane] & 0xffffu; }
+    __device__ __forceinline__ uint32_t DUP(int k) const { return pl[512 + k * 64 + lane] >> 16; }
+    __device__ __forceinline__ uint32_t BQ(int k) const { return pl[k * 64 + lane] & 0xfffffu; }
+    __device__ __forceinline__ uint32_t BCF(int k) const { return pl[k * 64 + lane] >> 20; }
+    __device__ __forceinline__ uint32_t NCDUP() const { return ncdup; }
+};
+
+constexpr int TMW_WAVES = 4, TM_GROUP = 4;       // blocks per load group: 4 KB in flight per wave and group
+typedef uint32_t tm_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t tm_u32x8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(TMW_WAVES * 64) void k_tm_walk(CountArgs a, TmArgs tm) {
+    __shared__ __attribute__((aligned(8192))) uint32_t planes_all[TMW_WAVES][2][2][8 * 64];      // [wave][cell type][plane][symbol row x lane]; 8 KB per wave: the cell type is bit 12 of an address
+    __shared__ WaveBook books[TMW_WAVES];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t* pl = &planes_all[wv][0][0][0];
+    WaveBook& book = books[wv];
+    book_init(book, lane);
+    if (lane == 0) book.src = 1;
+    for (int i = lane; i < 2 * 2 * 8 * 64; i += 64) pl[i] = 0;
+    const uint32_t thr = bq_threshold(a), pkl0 = lds_addr(pl + lane);
+    uint32_t one = 1u;
+    asm volatile("" : "+v"(one));
+    const uint32_t n_waves_all = gridDim.x * TMW_WAVES;
+    // a wave's first chunk is its own index, later ones come off the queue; a chunk = consecutive jobs of about TM_CHUNK_WORK work
+    uint32_t ck = blockIdx.x * TMW_WAVES + wv;
+    for (bool first = true;; first = false) {
+        if (!first) { if (lane == 0) ck = (uint32_t)atomicAdd(&a.scalars[SC_QSMALL], 1ull) + n_waves_all; ck = rl(ck, 0); }
+        if (ck >= tm.nchunks) break;
+        const uint32_t jx_end = rl(tm.chunk_start[ck + 1], 0);
+        for (uint32_t jx = rl(tm.chunk_start[ck], 0); jx < jx_end; ++jx) {
+        uint32_t jw = 0;
+        if (lane < 8) jw = reinterpret_cast<const uint32_t*>(tm.jobs + jx)[lane];
+        const uint32_t e0 = rl(jw, 0), e1 = rl(jw, 1), w0 = rl(jw, 2), slab = rl(jw, 3), nj = rl(jw, 4), tcnt = rl(jw, 5), tile = rl(jw, 6);
+        if (tile < a.tile_lo || tile >= a.tile_hi) continue;
+        const int2 geom = a.ne_geom[w0];
+        const int tid = rl((uint32_t)geom.y, 0) & 0xffffff;
+        const int32_t tstart = (int32_t)rl((uint32_t)geom.x, 0);
+        int refb = 'N';
+        if (nj == 1) { const int64_t pos = (int64_t)tstart + lane; if (pos >= 1 && pos < a.contig_len[tid]) refb = a.ref_ptr[tid][pos]; }
+        const uint32_t b0 = e0 >> 3, nblk = e1 > e0 ? ((e1 + 7) >> 3) - b0 : 0u;
+        TmState st; st.nc = 0; st.mask = 0; st.open = 0; st.open_sh = 0;
+        if (nblk) {
+            const uint32_t* mp = tm.meta + (uint64_t)b0 * 8;
+            const uint64_t sbase = (uint64_t)(uintptr_t)(tm.store + (uint64_t)b0 * 64);
+            const uint64_t sb = ((uint64_t)rl((uint32_t)(sbase >> 32), 0) << 32) | rl((uint32_t)sbase, 0);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>((uintptr_t)sb), 0, (int)(nblk * 1024u), 0x00020000);
+            const uint32_t lane16 = 16u * (uint32_t)lane;
+            const int ng = (int)((nblk + TM_GROUP - 1) / TM_GROUP);
+            const uint32_t pe0 = e0 - b0 * 8u, pe1 = e1 - b0 * 8u;                // the job's entries, relative to its first block
+            // a group = TM_GROUP blocks: 16 bytes per lane and block of events, and the meta words of its 8 TM_GROUP entries one per lane
+            // (read back lane by lane into an SGPR when the entry's turn comes); the entries of the neighbouring jobs are not there
+            tm_u32x4 EA[TM_GROUP], EB[TM_GROUP];
+            uint32_t MA, MB;
+            auto issue = [&](int g, tm_u32x4 (&E)[TM_GROUP], uint32_t& M) {
+#pragma unroll
+                for (int k = 0; k < TM_GROUP; ++k)
+                    E[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)lane16, (int)(((uint32_t)g * TM_GROUP + k) * 1024u), 0);       // past the job: zeros
+                const uint32_t pr = (uint32_t)g * (8u * TM_GROUP) + (uint32_t)lane;
+                M = TMM_SKIP;
+                if (lane < 8 * TM_GROUP && pr >= pe0 && pr < pe1) M = mp[pr];
+            };
+            auto consume = [&](int g, const tm_u32x4 (&E)[TM_GROUP], uint32_t M) {
+#pragma unroll
+                for (int k = 0; k < TM_GROUP; ++k) {
+                    if ((uint32_t)g * TM_GROUP + k >= nblk) break;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const uint32_t m = rl(M, k * 8 + u);
+                        if (u & 1) tm_add<true>(st, m, E[k][u >> 1], thr, pkl0, one);
+                        else tm_add<false>(st, m, E[k][u >> 1], thr, pkl0, one);
+                    }
+                }
+            };
+            issue(0, EA, MA);
+            int g = 0;
+            while (true) {
+                if (g + 1 < ng) issue(g + 1, EB, MB);
+                consume(g, EA, MA);
+                if (++g >= ng) break;
+                if (g + 1 < ng) issue(g + 1, EA, MA);
+                consume(g, EB, MB);
+                if (++g >= ng) break;
+            }
+            if (st.open) { st.nc += (st.mask & 1u) << st.open_sh; st.mask = 0; st.open = 0; }
+        }
+        // the tile's units, one per cell type
+        for (int ct = 0; ct < a.n_ct; ++ct) {
+            const uint32_t* pc = pl + ct * 1024;
+            uint32_t dp = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) dp += pc[512 + k * 64 + lane] & 0xffffu;
+            const TmCounters tot{pc, lane, dp - ((st.nc >> (16 * ct)) & 0xffffu)};
+            if (nj == 1) {
+                if (tcnt <= 256u) emit_unit<TmCounters, true>(a, tot, w0 + ct, ct, tid, tstart, lane, &book, false, refb, ct);
+                else emit_unit<TmCounters, false>(a, tot, w0 + ct, ct, tid, tstart, lane, &book, false, refb, ct + 2);
+            } else {
+                uint32_t* dst = a.macc + (uint64_t)(slab + (uint32_t)ct * nj) * (NCTR * 64);
+                dst[lane] = tot.NCDUP();
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const uint32_t lo = pc[k * 64 + lane], hi = pc[512 + k * 64 + lane];
+                    dst[(1 + k) * 64 + lane] = hi >> 16; dst[(9 + k) * 64 + lane] = hi & 0xffffu;
+                    dst[(17 + k) * 64 + lane] = lo & 0xfffffu; dst[(25 + k) * 64 + lane] = lo >> 20;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2 * 2 * 8 * 64 / 256; ++i) reinterpret_cast<uint4*>(pl)[i * 64 + lane] = make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
+    lds_fence();
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        uint32_t rt = 0, cols = 0, rsrc = 0;
+        for (int w = 0; w < TMW_WAVES; ++w) {
+            const WaveBook& b = books[w];
+            if (lane < a.n_ct) rt += b.rows_true[lane];
+            cols += b.cols; rsrc += b.rows_src;
+        }
+        if (lane < a.n_ct && rt) atomicAdd(&a.scalars[SC_ROWS + lane], (unsigned long long)rt);
+        if (lane == 0) {
+            if (cols) atomicAdd(&a.scalars[SC_COLS], (unsigned long long)cols);
+            if (rsrc) atomicAdd(&a.scalars[SC_ROWS_SRC + 1], (unsigned long long)rsrc);
+        }
+    }
+}
+
+static bool tm_key_matches(const lsg_ctx* c, const lsg_count_params* p) {
+    return c->tm_valid && c->tm_key[0] == (int64_t)p->min_mq && c->tm_key[1] == (int64_t)p->flag_exclude && c->tm_key[2] == (int64_t)p->ignore_orphans &&
+           c->tm_key[3] == (int64_t)c->n_ct;
+}
+
+static int build_tm(lsg_ctx* c, const lsg_count_params* p) {
+    if (tm_key_matches(c, p)) return 0;
+    c->tm_valid = false; c->tm_usable = false;
+    if (build_index(c)) return -1;
+    hipStream_t st = c->stream;
+    const uint64_t N = c->ix_n;
+    const uint32_t T = c->n_tiles;
+    c->tm_key[0] = p->min_mq; c->tm_key[1] = p->flag_exclude; c->tm_key[2] = p->ignore_orphans; c->tm_key[3] = c->n_ct;
+    if (N == 0 || N >= 0x7fffffffull) { c->tm_valid = true; return 0; }
+    DevBuf S, per_tile, offs;
+    auto done = [&](int rc) { S.release(); per_tile.release(); offs.release(); return rc; };
+    if (S.reserve((N + 2) * 4) || per_tile.reserve((size_t)(T + 2) * 4 * 6) || offs.reserve((size_t)(T + 2) * 4 * 5 + 64)) return done(-1);      // (offs: + two words behind the five arrays)
+    TmAdm adm{c->d_ix2.as<uint32_t>(), p->flag_exclude, p->min_mq, p->ignore_orphans};
+    {
+        hipcub::CountingInputIterator<uint32_t> iota(0);
+        hipcub::TransformInputIterator<uint32_t, TmAdm, hipcub::CountingInputIterator<uint32_t>> it(iota, adm);
+        SCAN_U32(it, S.as<uint32_t>(), N + 1);
+    }
+    uint32_t* cnt = per_tile.as<uint32_t>(); uint32_t* blk = cnt + (T + 2); uint32_t* ne = blk + (T + 2); uint32_t* nj = ne + (T + 2);
+    uint32_t* slabs = nj + (T + 2); uint32_t* multi = slabs + (T + 2);
+    uint32_t* blk_off = offs.as<uint32_t>(); uint32_t* ne_off = blk_off + (T + 2); uint32_t* job_off = ne_off + (T + 2);
+    uint32_t* slab_off = job_off + (T + 2); uint32_t* multi_off = slab_off + (T + 2);
+    uint32_t* d_maxjob = multi_off + (T + 2);
+    hipLaunchKernelGGL(k_tm_tiles, dim3((T + 256) / 256), dim3(256), 0, st, c->d_tile_off.as<uint32_t>(), S.as<uint32_t>(), T, c->n_ct, cnt, blk, ne, nj, slabs, multi);
+    SCAN_U32(blk, blk_off, T + 1); SCAN_U32(ne, ne_off, T + 1); SCAN_U32(nj, job_off, T + 1); SCAN_U32(slabs, slab_off, T + 1); SCAN_U32(multi, multi_off, T + 1);
+    LSG_HIP(hipMemsetAsync(d_maxjob, 0, 8, st));
+    uint32_t tot[5] = {0, 0, 0, 0, 0};
+    uint32_t* srcs[5] = {blk_off, ne_off, job_off, slab_off, multi_off};
+    for (int i = 0; i < 5; ++i) LSG_HIP(hipMemcpyAsync(&tot[i], srcs[i] + T, 4, hipMemcpyDeviceToHost, st));
+    LSG_HIP(hipStreamSynchronize(st));
+    const uint32_t nblk = tot[0], n_net = tot[1], njobs = tot[2], n_slabs = tot[3], n_mt = tot[4];
+    const uint64_t np = (uint64_t)nblk * 8;
+    c->tm_np = np; c->tm_nblk = nblk; c->tm_njobs = njobs; c->tm_n_ne = n_net * (uint32_t)c->n_ct; c->tm_n_multi = n_mt * (uint32_t)c->n_ct; c->tm_n_slabs = n_slabs;
+    if (nblk == 0) { c->tm_valid = true; return done(0); }
+    const size_t n_ne = c->tm_n_ne;
+    if (c->tm[TM_STORE].reserve(((size_t)nblk + TM_GROUP) * 1024) || c->tm[TM_S0].reserve((np + 16) * 4) || c->tm[TM_B].reserve(np + 16) ||
+        c->tm[TM_LINE].reserve((np + 16) * 4) || c->tm[TM_META].reserve((np + 8 * (TM_GROUP + 1)) * 4) || c->tm[TM_BLK_TILE].reserve(((size_t)nblk + 2) * 4) ||
+        c->tm[TM_JOBS].reserve(((size_t)njobs + 1) * sizeof(TmJob)) || c->tm[TM_NE_UNITS].reserve((n_ne + 2) * 4) || c->tm[TM_NE_GEOM].reserve((n_ne + 2) * 8) ||
+        c->tm[TM_NE_NSLOT].reserve((n_ne + 2) * 4) || c->tm[TM_NE_ACC].reserve((n_ne + 2) * 4) || c->tm[TM_MULTI].reserve(((size_t)c->tm_n_multi + 2) * 4))
+        return done(-1);
+    uint32_t* s0 = c->tm[TM_S0].as<uint32_t>(); uint32_t* line = c->tm[TM_LINE].as<uint32_t>(); uint8_t* b8 = c->tm[TM_B].as<uint8_t>();
+    uint32_t* blk_tile = c->tm[TM_BLK_TILE].as<uint32_t>();
+    LSG_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(s0), (int)TM_PAD_S0, np + 16, st));
+    LSG_HIP(hipMemsetAsync(b8, 0, np + 16, st));
+    LSG_HIP(hipMemsetAsync(line, 0, (np + 16) * 4, st));
+    LSG_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c->tm[TM_META].p), (int)TMM_SKIP, np + 8 * (TM_GROUP + 1), st));
+    LSG_HIP(hipMemsetAsync(c->tm[TM_NE_NSLOT].p, 0, (n_ne + 2) * 4, st));
+    LSG_HIP(hipMemsetAsync(c->tm[TM_NE_ACC].p, 0, (n_ne + 2) * 4, st));
+    hipLaunchKernelGGL(k_tm_blk_tile, dim3((nblk + 255) / 256), dim3(256), 0, st, blk_off, T, nblk, blk_tile);
+    hipLaunchKernelGGL(k_tm_fill, dim3((unsigned)(c->n_cus * 16)), dim3(256), 0, st, adm, c->d_ix0.as<uint32_t>(), c->d_ix1.as<uint32_t>(), c->d_ix2.as<uint32_t>(), N,
+                       c->d_tile_off.as<uint32_t>(), T, S.as<uint32_t>(), blk_off, s0, line, b8);
+    hipLaunchKernelGGL(k_tm_runs, dim3((unsigned)(c->n_cus * 16)), dim3(256), 0, st, s0, b8, np, blk_off, blk_tile);
+    hipLaunchKernelGGL(k_tm_gather, dim3((unsigned)(((uint64_t)nblk * 64 + 255) / 256)), dim3(256), 0, st, c->rd.events, s0, line, nblk, c->tm[TM_STORE].as<uint4>());
+    {
+        CountArgs a{};
+        a.tile_base = c->d_tile_base.as<uint32_t>(); a.n_contigs = c->n_contigs; a.n_ct = c->n_ct;
+        hipLaunchKernelGGL(k_tm_jobs, dim3((T + 255) / 256), dim3(256), 0, st, a, s0, cnt, blk_off, ne_off, nj, job_off, slab_off, multi_off, T,
+                           c->tm[TM_JOBS].as<TmJob>(), c->tm[TM_NE_UNITS].as<uint32_t>(), c->tm[TM_NE_GEOM].as<int2>(), c->tm[TM_NE_NSLOT].as<uint32_t>(),
+                           c->tm[TM_NE_ACC].as<uint32_t>(), c->tm[TM_MULTI].as<uint32_t>(), d_maxjob);
+    }
+    uint32_t n_chunks = 0;
+    {   // static work-balanced chunks of the job list
+        DevBuf pex;
+        if (pex.reserve(((size_t)njobs + 2) * 4) || c->tm[TM_CHUNKS].reserve(((size_t)(((uint64_t)np + (uint64_t)njobs * TM_JOB_W0) / TM_CHUNK_WORK) + 4) * 4)) { pex.release(); return done(-1); }
+        hipcub::CountingInputIterator<uint32_t> iota(0);
+        TmJobWork wf{c->tm[TM_JOBS].as<TmJob>()};
+        hipcub::TransformInputIterator<uint32_t, TmJobWork, hipcub::CountingInputIterator<uint32_t>> it(iota, wf);
+        size_t tb_ = 0;
+        hipError_t e1 = hipcub::DeviceScan::ExclusiveSum(nullptr, tb_, it, pex.as<uint32_t>(), (int)njobs, st);
+        if (e1 != hipSuccess || cub_tmp(c, tb_)) { pex.release(); return done(-1); }
+        tb_ = c->d_cub_tmp.cap;
+        e1 = hipcub::DeviceScan::ExclusiveSum(c->d_cub_tmp.p, tb_, it, pex.as<uint32_t>(), (int)njobs, st);
+        hipLaunchKernelGGL(k_tm_chunks, dim3((njobs + 255) / 256), dim3(256), 0, st, pex.as<uint32_t>(), njobs, c->tm[TM_CHUNKS].as<uint32_t>(), d_maxjob + 1);
+        hipError_t e2 = hipMemcpyAsync(&n_chunks, d_maxjob + 1, 4, hipMemcpyDeviceToHost, st);
+        hipError_t e3 = hipStreamSynchronize(st);
+        pex.release();
+        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { set_error("lsg_pileup_count: tile-major chunk table failed"); return done(-1); }
+    }
+    c->tm_nchunks = n_chunks;
+    uint32_t max_job = 0;
+    LSG_HIP(hipMemcpyAsync(&max_job, d_maxjob, 4, hipMemcpyDeviceToHost, st));
+    LSG_HIP(hipGetLastError());
+    LSG_HIP(hipStreamSynchronize(st));
+    c->tm_usable = max_job == 0;                  // a job a single barcode's run stretched past the planes' fields: the index path counts this load
+    c->tm_valid = true;
+    return done(0);
+}
+
+static int run_count_tm(lsg_ctx* c, const lsg_count_params* p) {
+    hipStream_t st = c->stream;
+    const uint32_t n_ne = c->tm_n_ne;
+    const int64_t R = c->rd.n_reads;
+    if (c->d_read_key.reserve((size_t)(R + 1) * 4) || c->d_scalars.reserve(SC_COUNT * 8) || c->d_ne_units.reserve(((size_t)n_ne + 2) * 4) ||
+        c->d_ne_mask.reserve(((size_t)n_ne + 2) * 8) || c->d_ne_rowbase.reserve(((size_t)n_ne + 2) * 4) || c->ws[WS_NE_NSLOT].reserve(((size_t)n_ne + 2) * 4) ||
+        c->ws[WS_NE_ACC].reserve(((size_t)n_ne + 2) * 4) || c->ws[WS_NE_GEOM].reserve(((size_t)n_ne + 2) * 8) || c->ws[WS_MULTI_LIST].reserve(((size_t)c->tm_n_multi + 2) * 4) ||
+        c->ws[WS_MACC].reserve(((size_t)c->tm_n_slabs + 1) * NCTR * 64 * 4) || c->d_ix_stat.reserve(IX_STAT_SLOTS * 64))
+        return -1;
+    const unsigned grid_walk = (unsigned)(c->n_cus * tune_int("LSG_GRID_TM", 5));
+    const unsigned grid_fin = (unsigned)(c->n_cus * 8);
+    {   // row buffers: bound + one open arena per emitting wave and format
+        uint64_t want_rows = (uint64_t)n_ne * TILE_W;
+        if (p->min_dp > 0) {
+            const uint64_t by_depth = (uint64_t)c->rd.n_events / (uint64_t)p->min_dp + 64;
+            if (by_depth < want_rows) want_rows = by_depth;
+        }
+        const uint64_t emitters = (uint64_t)grid_walk * TMW_WAVES * 2 + grid_fin;
+        uint64_t arena = want_rows / (emitters * 8) / ARENA * ARENA;
+        c->arena = (uint32_t)(arena < (uint64_t)ARENA ? (uint64_t)ARENA : (arena > 8ull * ARENA ? 8ull * ARENA : arena));
+        want_rows += emitters * c->arena + 64;
+        want_rows = (want_rows + 63) / 64 * 64 + 64;
+        if (want_rows > c->row_cap) c->row_cap = want_rows;
+        for (int i = 0; i < c->n_ct; ++i)
+            if (c->d_rows[i].reserve((size_t)c->row_cap * ROW_STORED_WORDS * 4)) return -1;
+    }
+    c->n_ne = n_ne; c->n_slots = 0; c->n_multi = c->tm_n_multi;
+    CountArgs a{};
+    fill_args(c, p, a);
+    TmArgs tm{};
+    tm.store = c->tm[TM_STORE].as<uint4>(); tm.s0 = c->tm[TM_S0].as<uint32_t>(); tm.b = c->tm[TM_B].as<uint8_t>(); tm.meta = c->tm[TM_META].as<uint32_t>();
+    tm.blk_tile = c->tm[TM_BLK_TILE].as<uint32_t>(); tm.jobs = c->tm[TM_JOBS].as<TmJob>(); tm.np = c->tm_np; tm.nblk = c->tm_nblk; tm.njobs = c->tm_njobs; tm.nchunks = c->tm_nchunks; tm.chunk_start = c->tm[TM_CHUNKS].as<uint32_t>();
+    LSG_HIP(hipEventRecord(c->ev[0], st));
+    LSG_HIP(hipMemsetAsync(c->d_scalars.p, 0, SC_COUNT * 8, st));
+    LSG_HIP(hipMemsetAsync(c->d_ix_stat.p, 0, IX_STAT_SLOTS * 64, st));
+    if (n_ne) {
+        // the static unit tables in the places the call stage and the exports read
+        LSG_HIP(hipMemcpyAsync(c->d_ne_units.p, c->tm[TM_NE_UNITS].p, (size_t)n_ne * 4, hipMemcpyDeviceToDevice, st));
+        LSG_HIP(hipMemcpyAsync(c->ws[WS_NE_GEOM].p, c->tm[TM_NE_GEOM].p, (size_t)n_ne * 8, hipMemcpyDeviceToDevice, st));
+        LSG_HIP(hipMemcpyAsync(c->ws[WS_NE_NSLOT].p, c->tm[TM_NE_NSLOT].p, ((size_t)n_ne + 1) * 4, hipMemcpyDeviceToDevice, st));
+        LSG_HIP(hipMemcpyAsync(c->ws[WS_NE_ACC].p, c->tm[TM_NE_ACC].p, ((size_t)n_ne + 1) * 4, hipMemcpyDeviceToDevice, st));
+        if (c->tm_n_multi) LSG_HIP(hipMemcpyAsync(c->ws[WS_MULTI_LIST].p, c->tm[TM_MULTI].p, (size_t)c->tm_n_multi * 4, hipMemcpyDeviceToDevice, st));
+        LSG_HIP(hipMemsetAsync(c->d_ne_mask.p, 0, ((size_t)n_ne + 1) * 8, st));
+        LSG_HIP(hipMemsetAsync(c->d_ne_rowbase.p, 0, ((size_t)n_ne + 1) * 4, st));
+    }
+    if (R > 0) { unsigned g = (unsigned)((R + 255) / 256); if (g > (unsigned)(c->n_cus * 8)) g = (unsigned)(c->n_cus * 8); hipLaunchKernelGGL(k_read_key, dim3(g), dim3(256), 0, st, a); }
+    if (c->tm_nblk) {
+        hipLaunchKernelGGL(k_tm_resolve, dim3((c->tm_nblk + 255) / 256), dim3(256), 0, st, a, tm, c->d_ix_stat.as<unsigned long long>());
+        hipLaunchKernelGGL(k_resolve_stats, dim3(1), dim3(256), 0, st, a, c->d_ix_stat.as<unsigned long long>());
+    }
+    LSG_HIP(hipEventRecord(c->ev[1], st));
+    LSG_HIP(hipEventRecord(c->ev[2], st));
+    LSG_HIP(hipEventRecord(c->ev[3], st));
+    if (c->tm_njobs) hipLaunchKernelGGL(k_tm_walk, dim3(grid_walk), dim3(TMW_WAVES * 64), 0, st, a, tm);
+    LSG_HIP(hipEventRecord(c->ev[4], st));
+    if (c->tm_n_multi) hipLaunchKernelGGL(k_finalize_multi, dim3(c->tm_n_multi < grid_fin ? c->tm_n_multi : grid_fin), dim3(FIN_THREADS), 0, st, a);
+    LSG_HIP(hipEventRecord(c->ev[5], st));
+    LSG_HIP(hipGetLastError());
+    unsigned long long sc[SC_COUNT];
+    if (read_scalars(c, sc)) return -1;
+    if (sc[SC_OVERFLOW]) { set_error("lsg_pileup_count: row buffer overflow (cap %llu)", (unsigned long long)c->row_cap); return -3; }
+    for (int i = 0; i < LSG_MAX_CELLTYPES; ++i) c->n_rows[i] = (int64_t)sc[SC_ROWS + i];
+    c->n_columns = (int64_t)sc[SC_COLS];
+    c->stats.n_reads_admitted = (int64_t)sc[SC_READS];
+    c->stats.n_segs_admitted = (int64_t)sc[SC_SEGS];
+    c->stats.n_events_admitted = (int64_t)sc[SC_EVENTS];
+    c->stats.n_units = n_ne;
+    c->stats.n_deep_units = c->tm_n_multi;
+    c->stats.n_entries = (int64_t)sc[SC_NENT];
+    float ms = 0;
+    LSG_HIP(hipEventElapsedTime(&ms, c->ev[0], c->ev[1])); c->stats.ms_bin = ms;
+    LSG_HIP(hipEventElapsedTime(&ms, c->ev[1], c->ev[5])); c->stats.ms_deep = ms;
+    LSG_HIP(hipEventElapsedTime(&ms, c->ev[3], c->ev[4])); c->stats.ms_walk = ms;
+    c->stats.ms_wave = 0;
+    LSG_HIP(hipEventElapsedTime(&ms, c->ev[0], c->ev[5])); c->stats.ms_total = ms;
+    for (int i = 0; i < 4; ++i) { c->stats.rows_by_kernel[i] = (int64_t)sc[SC_ROWS_SRC + i]; c->stats.events_by_kernel[i] = 0; }
+    c->stats.events_by_kernel[1] = (int64_t)sc[SC_EVENTS];           // one kernel reads every event
+    c->stats.n_events_wave = 0; c->stats.n_events_deep = (int64_t)sc[SC_EVENTS];
+    c->stats.n_rows_deep = (int64_t)sc[SC_ROWS_DEEP];
+    c->stats.n_rows_wave = -c->stats.n_rows_deep;
+    for (int i = 0; i < LSG_MAX_CELLTYPES; ++i) c->stats.n_rows_wave += c->n_rows[i];
+    c->last_params = *p;
+    c->counted = true;
+    c->called = false;
+    return 0;
+}
+
 int run_count(lsg_ctx* c, const lsg_count_params* p) {
     if (c->n_contigs <= 0) { set_error("lsg_pileup_count: no contigs set"); return -2; }
     if (c->n_ct <= 0) { set_error("lsg_pileup_count: no barcodes set"); return -2; }
@@ -2257,6 +2912,23 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
     for (int t = 0; t < c->n_contigs; ++t)
         if (!c->ref_ptr[t]) { set_error("lsg_pileup_count: reference of contig %d not loaded", t); return -2; }
     hipStream_t st = c->stream;
+    // the tile-major store serves <= 2 cell types and counts without depth-cap drops (those are per read and rare)
+    c->tm_path = false;
+    if (c->n_ct <= 2 && c->rd.n_reads < 0x7fffffffll && !getenv("LSG_COUNT_PASS") && !getenv("LSG_NO_INDEX") && !getenv("LSG_NO_TM")) {
+        if (tile_capacities(c)) return -1;
+        if (depth_cap_drops(c, p)) return -1;
+        if (!c->has_drops) {
+            if (!tm_key_matches(c, p) && getenv("LSG_TIMING")) {
+                const auto t0 = std::chrono::steady_clock::now();
+                if (build_tm(c, p)) return -1;
+                LSG_HIP(hipStreamSynchronize(st));
+                fprintf(stderr, "[lsg] tile index + tile-major store of %llu entries (%u blocks, %u jobs) built in %.2f ms\n", (unsigned long long)c->ix_n, c->tm_nblk,
+                        c->tm_njobs, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+            }
+            if (build_tm(c, p)) return -1;
+            if (c->tm_usable) { c->tm_path = true; c->index_path = false; return run_count_tm(c, p); }
+        }
+    }
     const uint32_t n_units = c->n_tiles * (uint32_t)c->n_ct;
     const int64_t R = c->rd.n_reads, S = c->rd.n_segs;
     uint32_t max_ct = 1; for (int i = 0; i < c->n_ct; ++i) max_ct = c->ct_size[i] > max_ct ? c->ct_size[i] : max_ct;
@@ -2274,13 +2946,20 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
         c->ws[WS_SLOT_LIST].reserve((slot_cap + 2) * 4) ||
         c->ws[WS_MULTI_LIST].reserve((EU / CAPB + 16) * 4) || c->ws[WS_ENT].reserve((EU + 1) * 16 + 64) || c->ws[WS_SEG_INFO].reserve(((size_t)S + 1) * 8) || c->ws[WS_REC].reserve((EU + 1) * 16 + 256) ||
         c->ws[WS_SLICES].reserve((slot_cap + 2) * (NSLICE + 1) * 4) || c->ws[WS_SLOT_PEX].reserve((slot_cap + 2) * 4) ||
-        c->ws[WS_CHUNK_START].reserve(((EU + WORK_W0 * slot_cap) / CHUNK_EMIN + 4) * 4) || c->ws[WS_HUGE_LIST].reserve((EU / CAPB + 16) * 4))
+        c->ws[WS_CHUNK_START].reserve(((EU + WORK_W0 * slot_cap) / CHUNK_EMIN + 4) * 4) || c->ws[WS_HUGE_LIST].reserve((EU / CAPB + 16) * 8))
         return -1;
 
     if (tile_capacities(c)) return -1;
     if (depth_cap_drops(c, p)) return -1;           // free unless some cell type's pileup buffer can reach max_depth (cached bound)
     // the tile index serves <= 2 cell types and counts without depth-cap drops (those are per read and rare: the scatter path takes them)
     c->index_path = c->n_ct <= 2 && !c->has_drops && c->rd.n_reads < 0x7fffffffll && !getenv("LSG_COUNT_PASS") && !getenv("LSG_NO_INDEX");
+    if (c->index_path && !c->index_valid && getenv("LSG_TIMING")) {
+        const auto t0 = std::chrono::steady_clock::now();
+        if (build_index(c)) return -1;
+        LSG_HIP(hipStreamSynchronize(c->stream));
+        fprintf(stderr, "[lsg] tile index of %llu entries built in %.2f ms\n", (unsigned long long)c->ix_n,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    }
     if (c->index_path && build_index(c)) return -1;
     if (c->index_path && (c->ix_n == 0 || c->d_ix_stat.reserve(IX_STAT_SLOTS * 64))) c->index_path = false;
     LSG_HIP(hipEventRecord(c->ev[0], st));
@@ -2438,7 +3117,8 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
     }
     LSG_HIP(hipEventRecord(c->ev[1], st));
     if (n_ne > 0) {
-        hipLaunchKernelGGL(k_walk_block, dim3(grid_walk), dim3(WALK_THREADS), 0, st, a);
+        hipLaunchKernelGGL(k_walk_block<true>, dim3(grid_walk), dim3(WALK_THREADS), 0, st, a);
+        hipLaunchKernelGGL(k_walk_block<false>, dim3((unsigned)c->n_cus), dim3(WALK_THREADS), 0, st, a);      // slots of more than WALK_PLANE_MAX entries: usually none
         LSG_HIP(hipEventRecord(c->ev[4], st));
         hipLaunchKernelGGL(k_pileup_huge, dim3(grid_block), dim3(BLOCK_THREADS), 0, st, a);
         if (c->n_multi > 0)
@@ -2557,7 +3237,7 @@ __global__ void k_entries_upper(const int32_t* seg_start, const int32_t* seg_len
 }
 
 int compute_entries_upper(lsg_ctx* c) {
-    c->tile_caps_valid = false; c->index_valid = false;      // new reads: static capacities and the tile index are rebuilt by the next count
+    c->tile_caps_valid = false; c->index_valid = false; c->tm_valid = false;      // new reads: static capacities, the tile index and the tile-major store are rebuilt by the next count
     if (c->d_scalars.reserve(SC_COUNT * 8)) return -1;
     LSG_HIP(hipMemsetAsync(c->d_scalars.p, 0, SC_COUNT * 8, c->stream));
     int64_t S = c->rd.n_segs;
