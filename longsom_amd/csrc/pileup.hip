@@ -2337,12 +2337,12 @@ constexpr int TM_JOB_MAX = 3072, TM_JOB_TGT = 3072, TM_JOB_LIMIT = 4095;      //
 constexpr uint32_t TM_PAD_S0 = CB_MASK | IX_RUNSTART;
 enum { TM_STORE = 0, TM_S0, TM_B, TM_LINE, TM_META, TM_BLK_TILE, TM_JOBS, TM_NE_UNITS, TM_NE_GEOM, TM_NE_NSLOT, TM_NE_ACC, TM_MULTI, TM_CHUNKS, TM_NBUF };
 constexpr uint32_t TM_CHUNK_WORK = 4096, TM_JOB_W0 = 32;      // a wave dequeues about this much work (entries + a constant per job) at a time
-struct TmJob { uint32_t e0, e1, w0, slab, nj, cnt, tile, pad; };      // padded-entry range; unit of (tile, cell type 0); slab of (job, cell type 0) or ~0; jobs and entries of the tile
+struct TmJob { uint32_t e0, e1, w0, slab, nj, cnt, tile, emid; };     // padded-entry range; unit of (tile, cell type 0); slab of (job, cell type 0) or ~0; jobs and entries of the tile; where the job's second wave starts (a run start, or e1)
 constexpr uint32_t TMM_CT4 = 1u << 4, TMM_CT12 = 1u << 12, TMM_FWD = 1u << 20, TMM_SKIP = 1u << 29, TMM_SINGLE = 1u << 30, TMM_RS = 1u << 31;
 struct TmArgs {
     const uint4* store; const uint32_t* s0; const uint8_t* b; uint32_t* meta; const uint32_t* blk_tile; const TmJob* jobs;
     const uint32_t* chunk_start;          // static: first job of every chunk of about TM_CHUNK_WORK work
-    uint64_t np; uint32_t nblk, njobs, nchunks;
+    uint64_t np; uint32_t nblk, njobs, nchunks, dbg;
 };
 
 struct TmAdm {      // an index entry passes the key's read filters (ix2: flag12 | mapq << 12 | ...)
@@ -2439,7 +2439,13 @@ __global__ void k_tm_jobs(CountArgs a, const uint32_t* s0, const uint32_t* cnt, 
         const uint32_t e1 = j + 1 == J ? n : cut((uint32_t)(((uint64_t)n * (j + 1)) / J));
         TmJob jb;
         jb.e0 = (uint32_t)(base + e0); jb.e1 = (uint32_t)(base + (e1 < e0 ? e0 : e1)); jb.w0 = ord * (uint32_t)a.n_ct;
-        jb.slab = J > 1 ? slab_off[t] + j : 0xFFFFFFFFu; jb.nj = J; jb.cnt = n; jb.tile = t; jb.pad = 0;
+        jb.slab = J > 1 ? slab_off[t] + j : 0xFFFFFFFFu; jb.nj = J; jb.cnt = n; jb.tile = t;
+        {   // two waves share the job: the second starts at the run start at or after its middle (short jobs: one wave)
+            const uint32_t a0 = e0, a1 = e1 < e0 ? e0 : e1;
+            uint32_t mid = a1;
+            if (a1 - a0 >= 64u) { mid = cut(a0 + (a1 - a0) / 2u); if (mid > a1) mid = a1; }
+            jb.emid = (uint32_t)(base + mid);
+        }
         jobs[job_off[t] + j] = jb;
         if (jb.e1 - jb.e0 > (uint32_t)TM_JOB_LIMIT) atomicMax(max_job, jb.e1 - jb.e0);
         e0 = e1 < e0 ? e0 : e1;
@@ -2500,53 +2506,51 @@ __global__ __launch_bounds__(256) void k_tm_resolve(CountArgs a, TmArgs tm, unsi
     }
 }
 
-// run state of a wave over a tile's entries, both cell types: nc packs the runs that counted an event per cell type (16 bits each)
-struct TmState { uint32_t nc, mask, open, open_sh; };
+// run state of a wave over a tile's entries, both cell types.  nc packs the runs that counted an event per cell type (16 bits each);
+// mask: bits 8..15 = symbols seen in the open run at this lane, bit 0 / bit 16 = the run (of cell type 0 / 1) counted an event here
+struct TmState { uint32_t nc, mask; };
 __device__ __forceinline__ void tm_lds_add(uint32_t addr, uint32_t v) {
     __hip_atomic_fetch_add((LSG_AS3 uint32_t*)(uintptr_t)addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+// What happens to the run state at an entry depends on the meta words before it only, so a wave works it out for a whole group of
+// entries at once (one lane per entry, tm_walk_range) and hands every entry its verdict in two more bits of its meta word:
+constexpr uint32_t TMM_CLOSE = 1u << 27;      // a run of several entries is open when this run start arrives: close it first
+constexpr uint32_t TMM_FIRST = 1u << 28;      // first entry that is there of a run of several (else: compare with the run's mask)
 // One entry at the lane's position.  m: the entry's meta word in an SGPR (TMM_*); evw: the register holding the lane's events of an
 // entry pair, HI picks the half.  Planes of cell type c at pkl0 + 4096 c: plane 0 quality sum [0..19] | forward count [20..31], plane 1
-// (+2048) count [0..15] | duplicates [16..31].  Every decision is a scalar branch; the lanes that count the event are selected with
-// EXEC.  A run of one entry: 6 vector operations; first entry of a longer run 7 (+4 when it closes the run before it); others 10.
+// (+2048) count [0..15] | duplicates [16..31].  Every decision is a scalar branch on a bit of m; the lanes that count the event are
+// selected with EXEC (all lanes are active around the block).  A run of one entry: 7 vector operations; first entry of a longer
+// run 8 (+3 when it closes the run before it); others 10.
 constexpr bool TM_ASM = LSG_TM_ASM;
 template <bool HI>
 __device__ __forceinline__ void tm_add(TmState& s, uint32_t m, uint32_t evw, uint32_t thr, uint32_t pkl0, uint32_t one) {
     if (!TM_ASM) {                                   // the same in plain C++ (what the asm block is checked against when it is touched)
         const uint32_t ev = HI ? evw >> 16 : evw & 0xffffu;
-        if (m & TMM_RS) { if (s.open) { s.nc += (s.mask & 1u) << s.open_sh; s.mask = 0; s.open = 0; } }
+        if (m & TMM_CLOSE) { s.nc += s.mask & 0x10001u; s.mask = 0; }
         if (m & TMM_SKIP) return;
         const bool counted = (ev & 0x8ffu) >= thr;
         const uint32_t addr = (pkl0 | (ev & 0x700u)) + (m & TMM_CT12);
         const uint32_t lo = (ev & 0xffu) | (m & TMM_FWD);
-        const uint32_t sym8 = (ev >> 8) & 15u;
+        const uint32_t sym8 = (ev >> 8) & 15u, ctone = 1u << (m & TMM_CT4);
         if (m & TMM_SINGLE) {
-            if (counted) { tm_lds_add(addr, lo); tm_lds_add(addr + 2048u, 1u); s.nc += 1u << (m & TMM_CT4); }
-        } else if (!s.open) {
-            if (counted) { tm_lds_add(addr, lo); tm_lds_add(addr + 2048u, 1u); s.mask = (1u << sym8) | 1u; }
-            s.open = 1; s.open_sh = m & TMM_CT4;
+            if (counted) { tm_lds_add(addr, lo); tm_lds_add(addr + 2048u, 1u); s.nc += ctone; }
+        } else if (m & TMM_FIRST) {
+            if (counted) { tm_lds_add(addr, lo); tm_lds_add(addr + 2048u, 1u); s.mask = (1u << sym8) | ctone; }
         } else if (counted) {
             const uint32_t seen = (s.mask >> sym8) & 1u;
             tm_lds_add(addr, lo); tm_lds_add(addr + 2048u, 1u | (seen << 16));
-            s.mask |= (1u << sym8) | 1u;
+            s.mask |= (1u << sym8) | ctone;
         }
         return;
     }
     uint32_t t0, t1, addr, lo, sa, sb;
-    unsigned long long sv;
-    s.open = (uint32_t)__builtin_amdgcn_readfirstlane((int)s.open);
-    s.open_sh = (uint32_t)__builtin_amdgcn_readfirstlane((int)s.open_sh);
-#define LSG_TM_ADD(WSEL, BSEL, SYMPOS)                                                                                                        \
+#define LSG_TM_ADD(WSEL, BSEL, SYMPOS)                                                                                               \
     asm volatile(                                                                                                                    \
-        "s_bitcmp1_b32 %[m], 31\n\t"                                                                                                  \
-        "s_cbranch_scc0 1f\n\t"                                   /* not a run start */                                             \
-        "s_cmp_eq_u32 %[open], 0\n\t"                                                                                                 \
-        "s_cbranch_scc1 1f\n\t"                                                                                                       \
-        "v_and_b32 %[t1], 1, %[mask]\n\t"                           /* close the run of several entries before this one */          \
-        "v_lshlrev_b32 %[t1], %[osh], %[t1]\n\t"                                                                                      \
+        "s_bitcmp1_b32 %[m], 27\n\t"                                                                                                  \
+        "s_cbranch_scc0 1f\n\t"                                                                                                       \
+        "v_and_b32 %[t1], 0x10001, %[mask]\n\t"                     /* close the run of several entries before this one */          \
         "v_add_u32 %[nc], %[nc], %[t1]\n\t"                                                                                           \
-        "v_mov_b32 %[mask], 0\n\t"                                                                                                    \
-        "s_mov_b32 %[open], 0\n"                                                                                                      \
+        "v_mov_b32 %[mask], 0\n"                                                                                                      \
         "1:\n\t"                                                                                                                      \
         "s_bitcmp1_b32 %[m], 29\n\t"                                                                                                  \
         "s_cbranch_scc1 5f\n\t"                                   /* not counted / not there */                                     \
@@ -2556,38 +2560,35 @@ __device__ __forceinline__ void tm_add(TmState& s, uint32_t m, uint32_t evw, uin
         "s_and_b32 %[sb], %[m], 0x100000\n\t"                                                                                         \
         "v_or3_b32 %[addr], %[addr], %[pkl], %[sa]\n\t"             /* symbol row | lane word | the cell type's planes */           \
         "v_or_b32_sdwa %[lo], %[sb], %[ev] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:" BSEL "\n\t"                  \
-        "s_mov_b64 %[sv], exec\n\t"                                                                                                   \
+        "s_and_b32 %[sa], %[m], 16\n\t"                                                                                               \
         "v_cmpx_le_u32 vcc, %[thr], %[t0]\n\t"                      /* EXEC = the lanes that count this event */                    \
+        "s_lshl_b32 %[sa], 1, %[sa]\n\t"                            /* bit 0 or bit 16: the cell type's run counter */              \
         "s_bitcmp1_b32 %[m], 30\n\t"                                                                                                  \
         "s_cbranch_scc0 2f\n\t"                                                                                                       \
         "ds_add_u32 %[addr], %[lo]\n\t"                             /* a run of one entry */                                        \
         "ds_add_u32 %[addr], %[one] offset:2048\n\t"                                                                                  \
-        "s_and_b32 %[sa], %[m], 16\n\t"                                                                                               \
-        "s_lshl_b32 %[sa], 1, %[sa]\n\t"                                                                                              \
         "v_add_u32 %[nc], %[sa], %[nc]\n\t"                                                                                           \
         "s_branch 4f\n"                                                                                                               \
         "2:\n\t"                                                                                                                      \
         "v_bfe_u32 %[t1], %[ev], " SYMPOS ", 4\n\t"                 /* 8 + class */                                                 \
-        "s_cmp_eq_u32 %[open], 0\n\t"                                                                                                 \
+        "s_bitcmp1_b32 %[m], 28\n\t"                                                                                                  \
         "s_cbranch_scc0 3f\n\t"                                                                                                       \
         "ds_add_u32 %[addr], %[lo]\n\t"                             /* first entry of a longer run that is there */                 \
         "ds_add_u32 %[addr], %[one] offset:2048\n\t"                                                                                  \
-        "v_lshl_or_b32 %[mask], %[one], %[t1], %[one]\n\t"                                                                            \
-        "s_mov_b32 %[open], 1\n\t"                                                                                                    \
-        "s_and_b32 %[osh], %[m], 16\n\t"                                                                                              \
+        "v_lshl_or_b32 %[mask], %[one], %[t1], %[sa]\n\t"                                                                             \
         "s_branch 4f\n"                                                                                                               \
         "3:\n\t"                                                                                                                      \
         "v_bfe_u32 %[t0], %[mask], %[t1], 1\n\t"                    /* symbol already seen in this run: duplicate */                \
         "v_lshl_or_b32 %[t0], %[t0], 16, %[one]\n\t"                                                                                  \
         "ds_add_u32 %[addr], %[lo]\n\t"                                                                                               \
         "ds_add_u32 %[addr], %[t0] offset:2048\n\t"                                                                                   \
-        "v_lshl_or_b32 %[t1], %[one], %[t1], %[one]\n\t"                                                                              \
+        "v_lshl_or_b32 %[t1], %[one], %[t1], %[sa]\n\t"                                                                               \
         "v_or_b32 %[mask], %[mask], %[t1]\n"                                                                                          \
         "4:\n\t"                                                                                                                      \
-        "s_mov_b64 exec, %[sv]\n"                                                                                                     \
+        "s_mov_b64 exec, -1\n"                                                                                                        \
         "5:"                                                                                                                          \
-        : [t0] "=&v"(t0), [t1] "=&v"(t1), [addr] "=&v"(addr), [lo] "=&v"(lo), [sv] "=&s"(sv), [sa] "=&s"(sa), [sb] "=&s"(sb),        \
-          [mask] "+v"(s.mask), [nc] "+v"(s.nc), [open] "+s"(s.open), [osh] "+s"(s.open_sh)                                           \
+        : [t0] "=&v"(t0), [t1] "=&v"(t1), [addr] "=&v"(addr), [lo] "=&v"(lo), [sa] "=&s"(sa), [sb] "=&s"(sb),                        \
+          [mask] "+v"(s.mask), [nc] "+v"(s.nc)                                                                                       \
         : [ev] "v"(evw), [m] "s"(m), [thr] "s"(thr), [c700] "s"(0x700u), [k8ff] "s"(0x8ffu), [one] "v"(one), [pkl] "v"(pkl0)           \
         : "scc", "vcc", "memory")
     if (HI) LSG_TM_ADD("WORD_1", "BYTE_2", "24"); else LSG_TM_ADD("WORD_0", "BYTE_0", "8");
@@ -2602,107 +2603,142 @@ struct TmCounters {
     __device__ __forceinline__ uint32_t NCDUP() const { return ncdup; }
 };
 
-constexpr int TMW_WAVES = 4, TM_GROUP = 4;       // blocks per load group: 4 KB in flight per wave and group
+constexpr int TMW_WAVES = 2, TM_GROUP = 4;       // two waves share a job (and its planes); blocks per load group: 4 KB in flight per wave and group
 typedef uint32_t tm_u32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t tm_u32x8 __attribute__((ext_vector_type(8)));
-__global__ __launch_bounds__(TMW_WAVES * 64) void k_tm_walk(CountArgs a, TmArgs tm) {
-    __shared__ __attribute__((aligned(8192))) uint32_t planes_all[TMW_WAVES][2][2][8 * 64];      // [wave][cell type][plane][symbol row x lane]; 8 KB per wave: the cell type is bit 12 of an address
+// entries [s0, s1) of the store walked by one wave into the planes at pkl0
+__device__ __forceinline__ void tm_walk_range(const TmArgs& tm, TmState& st, uint32_t s0, uint32_t s1, uint32_t thr, uint32_t pkl0, uint32_t one, int lane) {
+    const uint32_t b0 = s0 >> 3, nblk = ((s1 + 7) >> 3) - b0;
+    const uint32_t* mp = tm.meta + (uint64_t)b0 * 8;
+    const uint64_t sbase = (uint64_t)(uintptr_t)(tm.store + (uint64_t)b0 * 64);
+    const uint64_t sb = ((uint64_t)rl((uint32_t)(sbase >> 32), 0) << 32) | rl((uint32_t)sbase, 0);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>((uintptr_t)sb), 0, (int)(nblk * 1024u), 0x00020000);
+    const uint32_t lane16 = 16u * (uint32_t)lane;
+    const int ng = (int)((nblk + TM_GROUP - 1) / TM_GROUP);
+    const uint32_t pe0 = s0 - b0 * 8u, pe1 = s1 - b0 * 8u;                // the range, relative to its first block
+    // a group = TM_GROUP blocks: 16 bytes per lane and block of events, and the meta words of its 8 TM_GROUP entries one per lane
+    // (read back lane by lane into an SGPR when the entry's turn comes); the entries of the neighbouring ranges are not there
+    tm_u32x4 EA[TM_GROUP], EB[TM_GROUP];
+    uint32_t MA, MB;
+    auto issue = [&](int g, tm_u32x4 (&E)[TM_GROUP], uint32_t& M) {
+#pragma unroll
+        for (int k = 0; k < TM_GROUP; ++k)
+            E[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)lane16, (int)(((uint32_t)g * TM_GROUP + k) * 1024u), 0);       // past the range: zeros
+        const uint32_t pr = (uint32_t)g * (8u * TM_GROUP) + (uint32_t)lane;
+        M = TMM_SKIP;
+        if (lane < 8 * TM_GROUP && pr >= pe0 && pr < pe1) M = mp[pr];
+    };
+    static_assert(8 * TM_GROUP == 32, "one 32-bit mask per group");
+    uint32_t open_in = 0;                            // wave-uniform: a run of several entries is open when the group begins
+    // the run state before every entry of the group, from the meta words alone: entry i sees an open run iff an entry that is there
+    // and not a run of one lies between the last run start before i (inclusive) and i - or none starts in the group and one was open
+    auto verdicts = [&](uint32_t M) -> uint32_t {
+        const bool there = !(M & TMM_SKIP), multi = there && !(M & TMM_SINGLE), rs = (M & TMM_RS) != 0;
+        const uint32_t A = (uint32_t)__ballot(lane < 32 && multi), R = (uint32_t)__ballot(lane < 32 && rs);
+        const uint32_t below = lane < 32 ? (1u << lane) - 1u : 0xffffffffu;
+        const uint32_t rb = R & below;
+        const uint32_t seg = rb ? below & ~((1u << (31 - __clz(rb))) - 1u) : below;
+        const bool ob = (A & seg) != 0u || (!rb && open_in);
+        if (rs && ob) M |= TMM_CLOSE;
+        if (multi && (rs || !ob)) M |= TMM_FIRST;
+        const uint32_t segl = R ? ~((1u << (31 - __clz(R))) - 1u) : 0xffffffffu;      // what the next group inherits
+        open_in = ((A & segl) != 0u || (!R && open_in)) ? 1u : 0u;
+        return M;
+    };
+    auto consume = [&](int g, const tm_u32x4 (&E)[TM_GROUP], uint32_t M0) {
+        const uint32_t M = verdicts(M0);
+#pragma unroll
+        for (int k = 0; k < TM_GROUP; ++k) {
+            if ((uint32_t)g * TM_GROUP + k >= nblk) break;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t m = rl(M, k * 8 + u);
+                if (u & 1) tm_add<true>(st, m, E[k][u >> 1], thr, pkl0, one);
+                else tm_add<false>(st, m, E[k][u >> 1], thr, pkl0, one);
+            }
+        }
+    };
+    issue(0, EA, MA);
+    int g = 0;
+    while (true) {
+        if (g + 1 < ng) issue(g + 1, EB, MB);
+        consume(g, EA, MA);
+        if (++g >= ng) break;
+        if (g + 1 < ng) issue(g + 1, EA, MA);
+        consume(g, EB, MB);
+        if (++g >= ng) break;
+    }
+    st.nc += st.mask & 0x10001u; st.mask = 0;                  // the run left open at the end (mask is 0 when none is)
+}
+
+// Workgroup = two waves = one job at a time: each wave walks half of the job's entries (cut at a run start) into the job's planes
+// (8 KB per workgroup: 4 KB per wave, which is what lets 6-8 waves per SIMD be resident), then each wave finishes one cell type's unit.
+__global__ __launch_bounds__(TMW_WAVES * 64) __attribute__((amdgpu_waves_per_eu(8))) void k_tm_walk(CountArgs a, TmArgs tm) {
+    __shared__ __attribute__((aligned(8192))) uint32_t planes[2][2][8 * 64];      // [cell type][plane][symbol row x lane]: the cell type is bit 12 of an address
+    __shared__ uint32_t nc_sh[2][64];                                              // per cell type and lane: runs that counted an event
     __shared__ WaveBook books[TMW_WAVES];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    uint32_t* pl = &planes_all[wv][0][0][0];
+    __shared__ uint32_t s_ck;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // (uniform: says so to the compiler)
+    uint32_t* pl = &planes[0][0][0];
     WaveBook& book = books[wv];
     book_init(book, lane);
     if (lane == 0) book.src = 1;
-    for (int i = lane; i < 2 * 2 * 8 * 64; i += 64) pl[i] = 0;
     const uint32_t thr = bq_threshold(a), pkl0 = lds_addr(pl + lane);
     uint32_t one = 1u;
     asm volatile("" : "+v"(one));
-    const uint32_t n_waves_all = gridDim.x * TMW_WAVES;
-    // a wave's first chunk is its own index, later ones come off the queue; a chunk = consecutive jobs of about TM_CHUNK_WORK work
-    uint32_t ck = blockIdx.x * TMW_WAVES + wv;
+    // a workgroup's first chunk is its own index, later ones come off the queue; a chunk = consecutive jobs of about TM_CHUNK_WORK work
     for (bool first = true;; first = false) {
-        if (!first) { if (lane == 0) ck = (uint32_t)atomicAdd(&a.scalars[SC_QSMALL], 1ull) + n_waves_all; ck = rl(ck, 0); }
+        __syncthreads();
+        if (threadIdx.x == 0) s_ck = first ? blockIdx.x : (uint32_t)atomicAdd(&a.scalars[SC_QSMALL], 1ull) + gridDim.x;
+        __syncthreads();
+        const uint32_t ck = rl(s_ck, 0);
         if (ck >= tm.nchunks) break;
         const uint32_t jx_end = rl(tm.chunk_start[ck + 1], 0);
         for (uint32_t jx = rl(tm.chunk_start[ck], 0); jx < jx_end; ++jx) {
-        uint32_t jw = 0;
-        if (lane < 8) jw = reinterpret_cast<const uint32_t*>(tm.jobs + jx)[lane];
-        const uint32_t e0 = rl(jw, 0), e1 = rl(jw, 1), w0 = rl(jw, 2), slab = rl(jw, 3), nj = rl(jw, 4), tcnt = rl(jw, 5), tile = rl(jw, 6);
-        if (tile < a.tile_lo || tile >= a.tile_hi) continue;
-        const int2 geom = a.ne_geom[w0];
-        const int tid = rl((uint32_t)geom.y, 0) & 0xffffff;
-        const int32_t tstart = (int32_t)rl((uint32_t)geom.x, 0);
-        int refb = 'N';
-        if (nj == 1) { const int64_t pos = (int64_t)tstart + lane; if (pos >= 1 && pos < a.contig_len[tid]) refb = a.ref_ptr[tid][pos]; }
-        const uint32_t b0 = e0 >> 3, nblk = e1 > e0 ? ((e1 + 7) >> 3) - b0 : 0u;
-        TmState st; st.nc = 0; st.mask = 0; st.open = 0; st.open_sh = 0;
-        if (nblk) {
-            const uint32_t* mp = tm.meta + (uint64_t)b0 * 8;
-            const uint64_t sbase = (uint64_t)(uintptr_t)(tm.store + (uint64_t)b0 * 64);
-            const uint64_t sb = ((uint64_t)rl((uint32_t)(sbase >> 32), 0) << 32) | rl((uint32_t)sbase, 0);
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>((uintptr_t)sb), 0, (int)(nblk * 1024u), 0x00020000);
-            const uint32_t lane16 = 16u * (uint32_t)lane;
-            const int ng = (int)((nblk + TM_GROUP - 1) / TM_GROUP);
-            const uint32_t pe0 = e0 - b0 * 8u, pe1 = e1 - b0 * 8u;                // the job's entries, relative to its first block
-            // a group = TM_GROUP blocks: 16 bytes per lane and block of events, and the meta words of its 8 TM_GROUP entries one per lane
-            // (read back lane by lane into an SGPR when the entry's turn comes); the entries of the neighbouring jobs are not there
-            tm_u32x4 EA[TM_GROUP], EB[TM_GROUP];
-            uint32_t MA, MB;
-            auto issue = [&](int g, tm_u32x4 (&E)[TM_GROUP], uint32_t& M) {
+            uint32_t jw = 0;
+            if (lane < 8) jw = reinterpret_cast<const uint32_t*>(tm.jobs + jx)[lane];
+            const uint32_t e0 = rl(jw, 0), e1 = rl(jw, 1), w0 = rl(jw, 2), slab = rl(jw, 3), nj = rl(jw, 4), tcnt = rl(jw, 5), tile = rl(jw, 6), emid = rl(jw, 7);
+            if (tile < a.tile_lo || tile >= a.tile_hi) continue;
+            const int2 geom = a.ne_geom[w0];
+            const int tid = rl((uint32_t)geom.y, 0) & 0xffffff;
+            const int32_t tstart = (int32_t)rl((uint32_t)geom.x, 0);
+            int refb = 'N';
+            if (nj == 1) { const int64_t pos = (int64_t)tstart + lane; if (pos >= 1 && pos < a.contig_len[tid]) refb = a.ref_ptr[tid][pos]; }
+            __syncthreads();                                   // both waves are done with the job before
 #pragma unroll
-                for (int k = 0; k < TM_GROUP; ++k)
-                    E[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)lane16, (int)(((uint32_t)g * TM_GROUP + k) * 1024u), 0);       // past the job: zeros
-                const uint32_t pr = (uint32_t)g * (8u * TM_GROUP) + (uint32_t)lane;
-                M = TMM_SKIP;
-                if (lane < 8 * TM_GROUP && pr >= pe0 && pr < pe1) M = mp[pr];
-            };
-            auto consume = [&](int g, const tm_u32x4 (&E)[TM_GROUP], uint32_t M) {
+            for (int i = 0; i < 2 * 2 * 8 * 64 / (4 * TMW_WAVES * 64); ++i) reinterpret_cast<uint4*>(pl)[i * (TMW_WAVES * 64) + threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);
+            (&nc_sh[0][0])[threadIdx.x] = 0;
+            __syncthreads();
+            TmState st; st.nc = 0; st.mask = 0;
+            const uint32_t emid2 = (tm.dbg & 1u) ? e1 : emid;
+            const uint32_t s0 = wv ? emid2 : e0, s1 = wv ? e1 : emid2;
+            if (s1 > s0) {
+                tm_walk_range(tm, st, s0, s1, thr, pkl0, one, lane);
+                if (st.nc & 0xffffu) atomicAdd(&nc_sh[0][lane], st.nc & 0xffffu);
+                if (st.nc >> 16) atomicAdd(&nc_sh[1][lane], st.nc >> 16);
+            }
+            __syncthreads();
+            // the tile's units: wave = cell type
+            if (wv < a.n_ct) {
+                const int ct = wv;
+                const uint32_t* pc = pl + ct * 1024;
+                uint32_t dp = 0;
 #pragma unroll
-                for (int k = 0; k < TM_GROUP; ++k) {
-                    if ((uint32_t)g * TM_GROUP + k >= nblk) break;
+                for (int k = 0; k < 8; ++k) dp += pc[512 + k * 64 + lane] & 0xffffu;
+                const TmCounters tot{pc, lane, dp - nc_sh[ct][lane]};
+                if (nj == 1) {
+                    if (tcnt <= 256u) emit_unit<TmCounters, true>(a, tot, w0 + ct, ct, tid, tstart, lane, &book, false, refb, 0);
+                    else emit_unit<TmCounters, false>(a, tot, w0 + ct, ct, tid, tstart, lane, &book, false, refb, 1);
+                } else {
+                    uint32_t* dst = a.macc + (uint64_t)(slab + (uint32_t)ct * nj) * (NCTR * 64);
+                    dst[lane] = tot.NCDUP();
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const uint32_t m = rl(M, k * 8 + u);
-                        if (u & 1) tm_add<true>(st, m, E[k][u >> 1], thr, pkl0, one);
-                        else tm_add<false>(st, m, E[k][u >> 1], thr, pkl0, one);
+                    for (int k = 0; k < 8; ++k) {
+                        const uint32_t lo = pc[k * 64 + lane], hi = pc[512 + k * 64 + lane];
+                        dst[(1 + k) * 64 + lane] = hi >> 16; dst[(9 + k) * 64 + lane] = hi & 0xffffu;
+                        dst[(17 + k) * 64 + lane] = lo & 0xfffffu; dst[(25 + k) * 64 + lane] = lo >> 20;
                     }
                 }
-            };
-            issue(0, EA, MA);
-            int g = 0;
-            while (true) {
-                if (g + 1 < ng) issue(g + 1, EB, MB);
-                consume(g, EA, MA);
-                if (++g >= ng) break;
-                if (g + 1 < ng) issue(g + 1, EA, MA);
-                consume(g, EB, MB);
-                if (++g >= ng) break;
             }
-            if (st.open) { st.nc += (st.mask & 1u) << st.open_sh; st.mask = 0; st.open = 0; }
-        }
-        // the tile's units, one per cell type
-        for (int ct = 0; ct < a.n_ct; ++ct) {
-            const uint32_t* pc = pl + ct * 1024;
-            uint32_t dp = 0;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) dp += pc[512 + k * 64 + lane] & 0xffffu;
-            const TmCounters tot{pc, lane, dp - ((st.nc >> (16 * ct)) & 0xffffu)};
-            if (nj == 1) {
-                if (tcnt <= 256u) emit_unit<TmCounters, true>(a, tot, w0 + ct, ct, tid, tstart, lane, &book, false, refb, ct);
-                else emit_unit<TmCounters, false>(a, tot, w0 + ct, ct, tid, tstart, lane, &book, false, refb, ct + 2);
-            } else {
-                uint32_t* dst = a.macc + (uint64_t)(slab + (uint32_t)ct * nj) * (NCTR * 64);
-                dst[lane] = tot.NCDUP();
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const uint32_t lo = pc[k * 64 + lane], hi = pc[512 + k * 64 + lane];
-                    dst[(1 + k) * 64 + lane] = hi >> 16; dst[(9 + k) * 64 + lane] = hi & 0xffffu;
-                    dst[(17 + k) * 64 + lane] = lo & 0xfffffu; dst[(25 + k) * 64 + lane] = lo >> 20;
-                }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 2 * 2 * 8 * 64 / 256; ++i) reinterpret_cast<uint4*>(pl)[i * 64 + lane] = make_uint4(0u, 0u, 0u, 0u);
         }
     }
     lds_fence();
@@ -2824,7 +2860,7 @@ static int run_count_tm(lsg_ctx* c, const lsg_count_params* p) {
         c->ws[WS_NE_ACC].reserve(((size_t)n_ne + 2) * 4) || c->ws[WS_NE_GEOM].reserve(((size_t)n_ne + 2) * 8) || c->ws[WS_MULTI_LIST].reserve(((size_t)c->tm_n_multi + 2) * 4) ||
         c->ws[WS_MACC].reserve(((size_t)c->tm_n_slabs + 1) * NCTR * 64 * 4) || c->d_ix_stat.reserve(IX_STAT_SLOTS * 64))
         return -1;
-    const unsigned grid_walk = (unsigned)(c->n_cus * tune_int("LSG_GRID_TM", 5));
+    const unsigned grid_walk = (unsigned)(c->n_cus * tune_int("LSG_GRID_TM", 14));
     const unsigned grid_fin = (unsigned)(c->n_cus * 8);
     {   // row buffers: bound + one open arena per emitting wave and format
         uint64_t want_rows = (uint64_t)n_ne * TILE_W;
@@ -2846,7 +2882,7 @@ static int run_count_tm(lsg_ctx* c, const lsg_count_params* p) {
     fill_args(c, p, a);
     TmArgs tm{};
     tm.store = c->tm[TM_STORE].as<uint4>(); tm.s0 = c->tm[TM_S0].as<uint32_t>(); tm.b = c->tm[TM_B].as<uint8_t>(); tm.meta = c->tm[TM_META].as<uint32_t>();
-    tm.blk_tile = c->tm[TM_BLK_TILE].as<uint32_t>(); tm.jobs = c->tm[TM_JOBS].as<TmJob>(); tm.np = c->tm_np; tm.nblk = c->tm_nblk; tm.njobs = c->tm_njobs; tm.nchunks = c->tm_nchunks; tm.chunk_start = c->tm[TM_CHUNKS].as<uint32_t>();
+    tm.blk_tile = c->tm[TM_BLK_TILE].as<uint32_t>(); tm.jobs = c->tm[TM_JOBS].as<TmJob>(); tm.np = c->tm_np; tm.nblk = c->tm_nblk; tm.njobs = c->tm_njobs; tm.nchunks = c->tm_nchunks; tm.chunk_start = c->tm[TM_CHUNKS].as<uint32_t>(); tm.dbg = (uint32_t)tune_int("LSG_TM_DBG", 0);
     LSG_HIP(hipEventRecord(c->ev[0], st));
     LSG_HIP(hipMemsetAsync(c->d_scalars.p, 0, SC_COUNT * 8, st));
     LSG_HIP(hipMemsetAsync(c->d_ix_stat.p, 0, IX_STAT_SLOTS * 64, st));
