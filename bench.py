@@ -11,7 +11,7 @@
            read count; every rank loads the reads overlapping its region, counts only its own
            columns and the ranks all-gather their PASS-candidate call rows over RCCL.
 
-One JSON line on rank 0.  `roofline` is for the dominant kernel (k_walk_block): algorithmic bytes
+One JSON line on rank 0.  `roofline` is for the dominant kernel (k_tm_walk on the tile-major path, k_walk_block otherwise): algorithmic bytes
 (2 B/event + 24 B/read + 168 B/emitted row, restricted to what that kernel processes)
 over its HIP-event time on its own stream.  `cpu_baseline` times the CPU oracle (oracle/, kind
 "port") on a bounded sample of the same workload on ALL of this box's host cores (one core and the
@@ -138,6 +138,13 @@ def cpu_baseline(eng, model, target_reads=150_000, call_sites=10_000):
             "gpu_matches_oracle_on_sample": ok}
 
 
+# the dominant kernel by count path (Engine.layout_info): its name in the bench line and in rocprofv3's counter tables
+KERNEL_NAME = {0: "k_walk_block", 1: "k_walk_block", 2: "k_tm_walk"}
+PMC_KERNEL = {0: "void lsg::k_walk_block<true>", 1: "void lsg::k_walk_block<true>", 2: "lsg::k_tm_walk"}
+PATH_NAME = {0: "scatter + sort per count", 1: "tile index (entries sorted once per load)", 2: "tile-major event store (built once per load and read filters)"}
+COUNT_PATH = [2]
+
+
 def csrc_digest():
     """content hash of the kernel sources: profiles recorded for another build are not quoted as this build's traffic"""
     import glob
@@ -159,7 +166,7 @@ def recorded_traffic():
     f = files[-1]
     try:
         d = json.load(open(f))
-        k = d["kernels"].get("lsg::k_walk_block")
+        k = d["kernels"].get(PMC_KERNEL[COUNT_PATH[0]])
         rel = os.path.relpath(f, ROOT)
         if d.get("_csrc_sha1") != csrc_digest():
             return None, "%s was recorded for another build of longsom_amd/csrc (sha1 %s)" % (rel, str(d.get("_csrc_sha1"))[:12]), True
@@ -285,6 +292,7 @@ def main():
     if dist_on:
         dist.barrier()
     dt = time.perf_counter() - t0
+    COUNT_PATH[0], layout_ms, layout_bytes = eng.layout_info()
     if os.environ.get("LSG_BENCH_STATS"):                           # the last step's counters, for whoever tunes the kernels
         print({f: (list(getattr(st, f)) if f.endswith("by_kernel") else getattr(st, f)) for f, _ in st._fields_ if f != "pad_"}, file=sys.stderr)
     if dist_on:
@@ -328,8 +336,11 @@ def main():
                        "pass_rows_gathered": int(sum(gather["counts"])) if dist_on and gather["counts"] else None,
                        "exchange": "one all-gather per step (%s), %d-row slots agreed in warm-up" % (backend, gather["cap"]) if dist_on else None,
                        "path_algorithmic_GBps_rank0": path_bytes / dt / 1e9,
+                       "count_path_rank0": PATH_NAME[COUNT_PATH[0]],
+                       "per_load_build_ms_rank0": round(layout_ms, 2),      # once per load, before the first count: NOT inside ms_per_step
+                       "per_load_store_GB_rank0": round(layout_bytes / 1e9, 2),
                        "end_to_end": e2e},
-            "roofline": {"bound": "hbm", "kernel": "k_walk_block", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": KERNEL_NAME[COUNT_PATH[0]], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale,
                          "avg_launch_ms": walk_ms / args.steps, "algorithmic_bytes_per_launch": walk_bytes / args.steps},
         }

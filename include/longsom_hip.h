@@ -265,6 +265,14 @@ typedef struct {
 } lsg_count_stats;
 int lsg_get_count_stats(lsg_ctx* ctx, lsg_count_stats* out);
 
+/* How the last lsg_pileup_count ran, and what the per-load structures behind it cost.  path: 0 = scatter + sort per count (more than
+ * two cell types, or reads dropped by max_depth), 1 = tile index (entries sorted once per load), 2 = tile-major event store (the
+ * admitted entries' events re-laid in index order once per load and read filters; k_tm_walk streams them).  build_ms: wall time the
+ * counts on the current reads have spent building the index / store (0 when none was built: a one-off per lsg_load_reads, outside the
+ * steady-state count).  store_bytes: device memory those structures hold.  No reference counterpart: the reference re-reads the BAM
+ * per window (BaseCellCounter.py:198-225). */
+int lsg_get_layout_info(lsg_ctx* ctx, int32_t* path, double* build_ms, int64_t* store_bytes);
+
 /* ---- synthetic workload (bench / tests; not part of the reference's path) --------------------*/
 /* Gene/expression tables of the BASELINE.md §4 workload model (built by longsom_amd/synth.py; the
  * per-read / per-base draws are counter-based hashes, see longsom_amd/csrc/synth_model.h).

@@ -143,6 +143,7 @@ SIGNATURES = {
     "lsg_betabinom_sf": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p]),
     "lsg_max_live_reads": (C.c_int64, [C.c_void_p]),
     "lsg_get_count_stats": (C.c_int, [C.c_void_p, C.POINTER(CountStats)]),
+    "lsg_get_layout_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }
 
 _lib = None

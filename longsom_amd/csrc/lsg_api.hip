@@ -115,7 +115,7 @@ int lsg_set_contigs(lsg_ctx* c, int32_t n_contigs, const int64_t* lengths) {
     c->tile_base[n_contigs] = (uint32_t)t;
     c->n_tiles = (uint32_t)t;
     c->tile_lo = 0; c->tile_hi = (uint32_t)t;
-    c->tile_caps_valid = false; c->index_valid = false; c->tm_valid = false;
+    c->tile_caps_valid = false; c->index_valid = false; c->tm_valid = false; c->layout_build_ms = 0;
     c->max_live_reads = -1; c->max_live_all = -1;
     for (auto& b : c->ref) b.release();
     c->ref.assign(n_contigs, DevBuf());
@@ -238,6 +238,19 @@ int64_t lsg_max_live_reads(lsg_ctx* c) {
 int lsg_get_count_stats(lsg_ctx* c, lsg_count_stats* out) {
     if (!c || !out) { set_error("lsg_get_count_stats: bad arguments"); return -2; }
     *out = c->stats;
+    return 0;
+}
+
+int lsg_get_layout_info(lsg_ctx* c, int32_t* path, double* build_ms, int64_t* store_bytes) {
+    if (!c) { set_error("lsg_get_layout_info: NULL handle"); return -2; }
+    if (path) *path = c->tm_path ? 2 : (c->index_path ? 1 : 0);
+    if (build_ms) *build_ms = c->layout_build_ms;
+    if (store_bytes) {
+        int64_t b = 0;
+        for (auto& x : c->tm) b += (int64_t)x.cap;
+        for (DevBuf* x : {&c->d_ix0, &c->d_ix1, &c->d_ix2, &c->d_ix_netile, &c->d_ix_chunk, &c->d_tile_cap, &c->d_tile_off}) b += (int64_t)x->cap;
+        *store_bytes = b;
+    }
     return 0;
 }
 

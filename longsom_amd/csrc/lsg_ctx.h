@@ -115,6 +115,7 @@ struct lsg_ctx {
     int64_t tm_key[4] = {0, 0, 0, 0};     // min_mq, flag_exclude, ignore_orphans, n_ct
     bool tm_valid = false, tm_usable = false;
     bool tm_path = false;                 // the last / current count runs on the tile-major store
+    double layout_build_ms = 0;           // wall time spent building the index / store for the current reads (lsg_get_layout_info)
     int64_t max_live_reads = -1;          // layout.hip: bound on the reads live at once in the reference's pileup buffer (-1 = stale)
     int64_t max_live_all = -1;            // the same over all reads with a barcode: table-independent, cached per load
     lsg::DevBuf d_read_drop;              // layout.hip: per read, 1 = dropped by the pileup's max_depth rule under the last count's parameters

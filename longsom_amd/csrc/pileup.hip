@@ -2954,14 +2954,15 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
         if (tile_capacities(c)) return -1;
         if (depth_cap_drops(c, p)) return -1;
         if (!c->has_drops) {
-            if (!tm_key_matches(c, p) && getenv("LSG_TIMING")) {
+            if (!tm_key_matches(c, p)) {
                 const auto t0 = std::chrono::steady_clock::now();
                 if (build_tm(c, p)) return -1;
                 LSG_HIP(hipStreamSynchronize(st));
-                fprintf(stderr, "[lsg] tile index + tile-major store of %llu entries (%u blocks, %u jobs) built in %.2f ms\n", (unsigned long long)c->ix_n, c->tm_nblk,
-                        c->tm_njobs, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+                const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                c->layout_build_ms += ms;
+                if (getenv("LSG_TIMING"))
+                    fprintf(stderr, "[lsg] tile index + tile-major store of %llu entries (%u blocks, %u jobs) built in %.2f ms\n", (unsigned long long)c->ix_n, c->tm_nblk, c->tm_njobs, ms);
             }
-            if (build_tm(c, p)) return -1;
             if (c->tm_usable) { c->tm_path = true; c->index_path = false; return run_count_tm(c, p); }
         }
     }
@@ -2989,14 +2990,14 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
     if (depth_cap_drops(c, p)) return -1;           // free unless some cell type's pileup buffer can reach max_depth (cached bound)
     // the tile index serves <= 2 cell types and counts without depth-cap drops (those are per read and rare: the scatter path takes them)
     c->index_path = c->n_ct <= 2 && !c->has_drops && c->rd.n_reads < 0x7fffffffll && !getenv("LSG_COUNT_PASS") && !getenv("LSG_NO_INDEX");
-    if (c->index_path && !c->index_valid && getenv("LSG_TIMING")) {
+    if (c->index_path && !c->index_valid) {
         const auto t0 = std::chrono::steady_clock::now();
         if (build_index(c)) return -1;
         LSG_HIP(hipStreamSynchronize(c->stream));
-        fprintf(stderr, "[lsg] tile index of %llu entries built in %.2f ms\n", (unsigned long long)c->ix_n,
-                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        c->layout_build_ms += ms;
+        if (getenv("LSG_TIMING")) fprintf(stderr, "[lsg] tile index of %llu entries built in %.2f ms\n", (unsigned long long)c->ix_n, ms);
     }
-    if (c->index_path && build_index(c)) return -1;
     if (c->index_path && (c->ix_n == 0 || c->d_ix_stat.reserve(IX_STAT_SLOTS * 64))) c->index_path = false;
     LSG_HIP(hipEventRecord(c->ev[0], st));
     LSG_HIP(hipMemsetAsync(c->d_scalars.p, 0, SC_COUNT * 8, st));
@@ -3273,7 +3274,7 @@ __global__ void k_entries_upper(const int32_t* seg_start, const int32_t* seg_len
 }
 
 int compute_entries_upper(lsg_ctx* c) {
-    c->tile_caps_valid = false; c->index_valid = false; c->tm_valid = false;      // new reads: static capacities, the tile index and the tile-major store are rebuilt by the next count
+    c->tile_caps_valid = false; c->index_valid = false; c->tm_valid = false; c->layout_build_ms = 0;      // new reads: static capacities, the tile index and the tile-major store are rebuilt by the next count
     if (c->d_scalars.reserve(SC_COUNT * 8)) return -1;
     LSG_HIP(hipMemsetAsync(c->d_scalars.p, 0, SC_COUNT * 8, c->stream));
     int64_t S = c->rd.n_segs;

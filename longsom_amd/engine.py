@@ -214,6 +214,13 @@ class Engine:
         _lib.check(self._lib.lsg_get_count_stats(self._h, C.byref(s)), "lsg_get_count_stats")
         return s
 
+    def layout_info(self):
+        """(path, build_ms, store_bytes) of the last count: 0 scatter per count / 1 tile index / 2 tile-major store; what the per-load
+        index and store cost to build and hold (lsg_get_layout_info)"""
+        path = C.c_int32(0); ms = C.c_double(0.0); nbytes = C.c_int64(0)
+        _lib.check(self._lib.lsg_get_layout_info(self._h, C.byref(path), C.byref(ms), C.byref(nbytes)), "lsg_get_layout_info")
+        return int(path.value), float(ms.value), int(nbytes.value)
+
     def call_step1(self, params: Optional[CallParams] = None):
         params = params or CallParams.longsom_defaults()
         n_sites = C.c_int64(0); n_cand = C.c_int64(0)
