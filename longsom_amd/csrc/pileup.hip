@@ -2955,8 +2955,23 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
         if (depth_cap_drops(c, p)) return -1;
         if (!c->has_drops) {
             if (!tm_key_matches(c, p)) {
+                // index + store + the build's temporaries take ~200 bytes of device memory per entry: a load that leaves less free
+                // is counted without them (the scatter path needs ~50), and so is one whose build fails half-way
+                size_t mem_free = 0, mem_total = 0;
+                (void)hipMemGetInfo(&mem_free, &mem_total);
+                size_t held = 0;
+                for (auto& b : c->tm) held += b.cap;
+                const char* bpe_env = getenv("LSG_TM_BYTES_PER_ENTRY");          // (tests: pretend the store is larger than it is)
+                const uint64_t bpe = bpe_env && *bpe_env ? strtoull(bpe_env, nullptr, 10) : 200ull;
+                const bool fits = (uint64_t)c->entries_upper * bpe < (uint64_t)mem_free + held;
                 const auto t0 = std::chrono::steady_clock::now();
-                if (build_tm(c, p)) return -1;
+                if (!fits || build_tm(c, p)) {
+                    (void)hipGetLastError();
+                    for (auto& b : c->tm) b.release();
+                    c->tm_key[0] = p->min_mq; c->tm_key[1] = p->flag_exclude; c->tm_key[2] = p->ignore_orphans; c->tm_key[3] = c->n_ct;
+                    c->tm_valid = true; c->tm_usable = false;          // (until the reads or the filters change)
+                    if (getenv("LSG_TIMING")) fprintf(stderr, "[lsg] tile-major store not built (%s): counting without it\n", fits ? "build failed" : "device memory");
+                }
                 LSG_HIP(hipStreamSynchronize(st));
                 const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
                 c->layout_build_ms += ms;
@@ -2990,6 +3005,11 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
     if (depth_cap_drops(c, p)) return -1;           // free unless some cell type's pileup buffer can reach max_depth (cached bound)
     // the tile index serves <= 2 cell types and counts without depth-cap drops (those are per read and rare: the scatter path takes them)
     c->index_path = c->n_ct <= 2 && !c->has_drops && c->rd.n_reads < 0x7fffffffll && !getenv("LSG_COUNT_PASS") && !getenv("LSG_NO_INDEX");
+    if (c->index_path && !c->index_valid) {
+        size_t mem_free = 0, mem_total = 0;
+        (void)hipMemGetInfo(&mem_free, &mem_total);
+        if ((uint64_t)c->entries_upper * 64ull >= (uint64_t)mem_free) c->index_path = false;      // ~12 bytes per entry to keep, ~50 while it is sorted
+    }
     if (c->index_path && !c->index_valid) {
         const auto t0 = std::chrono::steady_clock::now();
         if (build_index(c)) return -1;

@@ -25,7 +25,7 @@ def rows_of(engine, n_ct, params):
 
 
 def count_with(engine, n_ct, params, env):
-    old = {k: os.environ.get(k) for k in ("LSG_NO_TM", "LSG_NO_INDEX")}
+    old = {k: os.environ.get(k) for k in ("LSG_NO_TM", "LSG_NO_INDEX", "LSG_TM_BYTES_PER_ENTRY")}
     try:
         for k in old:
             os.environ.pop(k, None)
@@ -115,3 +115,20 @@ def test_region_counts_on_the_store_add_up(engine):
     for ct in range(2):
         k = np.concatenate([pr[0][ct][0] for pr in parts]); c = np.concatenate([pr[0][ct][2] for pr in parts])
         np.testing.assert_array_equal(k, whole[0][ct][0]); np.testing.assert_array_equal(c, whole[0][ct][2])
+
+
+def test_a_load_too_large_for_the_store_is_counted_without_it(engine):
+    """the store needs ~200 bytes of device memory per entry: when that is not free the count runs on the index (or the scatter)"""
+    lens = [3000]
+    rec, refs, ct_of = make_case(16, 8000, lens, 80)
+    load(engine, rec, lens, refs, ct_of, 2)
+    p = CountParams.longsom_defaults()
+    a, path = count_with(engine, 2, p, {"LSG_TM_BYTES_PER_ENTRY": "2000000000"})
+    assert path in (0, 1)
+    b, path_b = count_with(engine, 2, p, {"LSG_NO_INDEX": "1"})
+    assert path_b == 0
+    same(a, b)
+    engine.load_reads(rec)                      # the same reads again: nothing is remembered about the refusal
+    c, path_c = count_with(engine, 2, p, {})
+    assert path_c == 2
+    same(a, c)
