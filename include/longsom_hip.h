@@ -273,6 +273,20 @@ int lsg_get_count_stats(lsg_ctx* ctx, lsg_count_stats* out);
  * per window (BaseCellCounter.py:198-225). */
 int lsg_get_layout_info(lsg_ctx* ctx, int32_t* path, double* build_ms, int64_t* store_bytes);
 
+/* The per-load structures (tile index, tile-major store) cost more to build than one count without them, so by default
+ * (LSG_LAYOUT_AUTO) the first lsg_pileup_count of a load under given read filters (min_mq, flag_exclude, ignore_orphans) runs on
+ * the scatter path and the second builds them: a pipeline that counts its reads once (BaseCellCounter.py, one pass per BAM) pays
+ * nothing, one that counts them again (the re-annotation loop, parameter sweeps, benchmarks) gets the streaming count from then on.
+ * lsg_prepare_counts builds them now, for these filters, when they can serve the counts (<= 2 cell types, no max_depth drops, enough
+ * free device memory: otherwise it returns 0 and the counts run as before); LSG_LAYOUT_EAGER does that at every first count,
+ * LSG_LAYOUT_NEVER keeps every count on the scatter path.  The environment variable LSG_LAYOUT=auto|eager|never overrides the policy.
+ * Results do not depend on any of this (tests/test_paths_gpu.py). */
+#define LSG_LAYOUT_AUTO 0
+#define LSG_LAYOUT_EAGER 1
+#define LSG_LAYOUT_NEVER 2
+int lsg_prepare_counts(lsg_ctx* ctx, const lsg_count_params* params);
+int lsg_set_layout_policy(lsg_ctx* ctx, int32_t policy);
+
 /* ---- synthetic workload (bench / tests; not part of the reference's path) --------------------*/
 /* Gene/expression tables of the BASELINE.md §4 workload model (built by longsom_amd/synth.py; the
  * per-read / per-base draws are counter-based hashes, see longsom_amd/csrc/synth_model.h).

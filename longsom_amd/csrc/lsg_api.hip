@@ -11,6 +11,7 @@ void set_error(const char* fmt, ...) {
 const char* get_error() { return g_err; }
 
 int run_count(lsg_ctx* c, const lsg_count_params* p);
+int prepare_layout(lsg_ctx* c, const lsg_count_params* p);
 int run_fetch_counts(lsg_ctx* c, int ct, int64_t* keys, uint8_t* ref, uint32_t* counts, int64_t capacity);
 int compute_entries_upper(lsg_ctx* c);
 int run_call(lsg_ctx* c, const lsg_call_params* p);
@@ -115,7 +116,7 @@ int lsg_set_contigs(lsg_ctx* c, int32_t n_contigs, const int64_t* lengths) {
     c->tile_base[n_contigs] = (uint32_t)t;
     c->n_tiles = (uint32_t)t;
     c->tile_lo = 0; c->tile_hi = (uint32_t)t;
-    c->tile_caps_valid = false; c->index_valid = false; c->tm_valid = false; c->layout_build_ms = 0;
+    c->tile_caps_valid = false; c->index_valid = false; c->tm_valid = false; c->layout_build_ms = 0; c->seen_counts = 0;
     c->max_live_reads = -1; c->max_live_all = -1;
     for (auto& b : c->ref) b.release();
     c->ref.assign(n_contigs, DevBuf());
@@ -219,6 +220,19 @@ int lsg_pileup_count(lsg_ctx* c, const lsg_count_params* params, int64_t* n_rows
     if (rc) return rc;
     if (n_rows) for (int i = 0; i < c->n_ct; ++i) n_rows[i] = c->n_rows[i];
     if (n_columns) *n_columns = c->n_columns;
+    return 0;
+}
+
+int lsg_prepare_counts(lsg_ctx* c, const lsg_count_params* params) {
+    if (!c || !params) { set_error("lsg_prepare_counts: bad arguments"); return -2; }
+    if (c->n_contigs <= 0 || c->n_ct <= 0 || (!c->rd.events && c->rd.n_events > 0)) { set_error("lsg_prepare_counts: contigs, barcodes and reads must be set first"); return -2; }
+    LSG_HIP(hipSetDevice(c->device));
+    return prepare_layout(c, params);
+}
+
+int lsg_set_layout_policy(lsg_ctx* c, int32_t policy) {
+    if (!c || policy < 0 || policy > 2) { set_error("lsg_set_layout_policy: bad arguments"); return -2; }
+    c->layout_policy = policy;
     return 0;
 }
 

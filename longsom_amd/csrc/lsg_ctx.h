@@ -116,6 +116,8 @@ struct lsg_ctx {
     bool tm_valid = false, tm_usable = false;
     bool tm_path = false;                 // the last / current count runs on the tile-major store
     double layout_build_ms = 0;           // wall time spent building the index / store for the current reads (lsg_get_layout_info)
+    int layout_policy = 0;                // lsg_set_layout_policy: 0 auto (from the second count of a load), 1 eager, 2 never
+    int64_t seen_key[4] = {-1, -1, -1, -1}; uint32_t seen_counts = 0;      // read filters of the last count and how many counts of this load used them
     int64_t max_live_reads = -1;          // layout.hip: bound on the reads live at once in the reference's pileup buffer (-1 = stale)
     int64_t max_live_all = -1;            // the same over all reads with a barcode: table-independent, cached per load
     lsg::DevBuf d_read_drop;              // layout.hip: per read, 1 = dropped by the pileup's max_depth rule under the last count's parameters

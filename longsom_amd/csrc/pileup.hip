@@ -2938,6 +2938,44 @@ static int run_count_tm(lsg_ctx* c, const lsg_count_params* p) {
     return 0;
 }
 
+// 0 auto (second count of a load), 1 eager, 2 never; LSG_LAYOUT=auto|eager|never overrides what lsg_set_layout_policy left
+static int layout_policy(const lsg_ctx* c) {
+    const char* e = getenv("LSG_LAYOUT");
+    if (e && *e) return e[0] == 'e' ? 1 : (e[0] == 'n' ? 2 : 0);
+    return c->layout_policy;
+}
+// builds the tile index and the tile-major store for these read filters when they can serve the counts (rc != 0: a real failure)
+int prepare_layout(lsg_ctx* c, const lsg_count_params* p) {
+    hipStream_t st = c->stream;
+    if (!(c->n_ct <= 2 && c->n_ct > 0 && c->rd.n_reads < 0x7fffffffll) || getenv("LSG_COUNT_PASS") || getenv("LSG_NO_INDEX") || getenv("LSG_NO_TM")) return 0;
+    if (tile_capacities(c)) return -1;
+    if (depth_cap_drops(c, p)) return -1;
+    if (c->has_drops || tm_key_matches(c, p)) return 0;
+    // index + store + the build's temporaries take ~200 bytes of device memory per entry: a load that leaves less free
+    // is counted without them (the scatter path needs ~50), and so is one whose build fails half-way
+    size_t mem_free = 0, mem_total = 0;
+    (void)hipMemGetInfo(&mem_free, &mem_total);
+    size_t held = 0;
+    for (auto& b : c->tm) held += b.cap;
+    const char* bpe_env = getenv("LSG_TM_BYTES_PER_ENTRY");          // (tests: pretend the store is larger than it is)
+    const uint64_t bpe = bpe_env && *bpe_env ? strtoull(bpe_env, nullptr, 10) : 200ull;
+    const bool fits = (uint64_t)c->entries_upper * bpe < (uint64_t)mem_free + held;
+    const auto t0 = std::chrono::steady_clock::now();
+    if (!fits || build_tm(c, p)) {
+        (void)hipGetLastError();
+        for (auto& b : c->tm) b.release();
+        c->tm_key[0] = p->min_mq; c->tm_key[1] = p->flag_exclude; c->tm_key[2] = p->ignore_orphans; c->tm_key[3] = c->n_ct;
+        c->tm_valid = true; c->tm_usable = false;          // (until the reads or the filters change)
+        if (getenv("LSG_TIMING")) fprintf(stderr, "[lsg] tile-major store not built (%s): counting without it\n", fits ? "build failed" : "device memory");
+    }
+    LSG_HIP(hipStreamSynchronize(st));
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    c->layout_build_ms += ms;
+    if (getenv("LSG_TIMING"))
+        fprintf(stderr, "[lsg] tile index + tile-major store of %llu entries (%u blocks, %u jobs) built in %.2f ms\n", (unsigned long long)c->ix_n, c->tm_nblk, c->tm_njobs, ms);
+    return 0;
+}
+
 int run_count(lsg_ctx* c, const lsg_count_params* p) {
     if (c->n_contigs <= 0) { set_error("lsg_pileup_count: no contigs set"); return -2; }
     if (c->n_ct <= 0) { set_error("lsg_pileup_count: no barcodes set"); return -2; }
@@ -2948,38 +2986,23 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
     for (int t = 0; t < c->n_contigs; ++t)
         if (!c->ref_ptr[t]) { set_error("lsg_pileup_count: reference of contig %d not loaded", t); return -2; }
     hipStream_t st = c->stream;
-    // the tile-major store serves <= 2 cell types and counts without depth-cap drops (those are per read and rare)
+    // Per-load structures (tile index, tile-major store) serve <= 2 cell types and counts without depth-cap drops.  They cost more to
+    // build than one count on the scatter path, so (policy auto) the FIRST count of a load under given read filters runs without
+    // them and the second builds them; lsg_prepare_counts or policy eager build at once, policy never leaves them out.
     c->tm_path = false;
-    if (c->n_ct <= 2 && c->rd.n_reads < 0x7fffffffll && !getenv("LSG_COUNT_PASS") && !getenv("LSG_NO_INDEX") && !getenv("LSG_NO_TM")) {
-        if (tile_capacities(c)) return -1;
-        if (depth_cap_drops(c, p)) return -1;
-        if (!c->has_drops) {
-            if (!tm_key_matches(c, p)) {
-                // index + store + the build's temporaries take ~200 bytes of device memory per entry: a load that leaves less free
-                // is counted without them (the scatter path needs ~50), and so is one whose build fails half-way
-                size_t mem_free = 0, mem_total = 0;
-                (void)hipMemGetInfo(&mem_free, &mem_total);
-                size_t held = 0;
-                for (auto& b : c->tm) held += b.cap;
-                const char* bpe_env = getenv("LSG_TM_BYTES_PER_ENTRY");          // (tests: pretend the store is larger than it is)
-                const uint64_t bpe = bpe_env && *bpe_env ? strtoull(bpe_env, nullptr, 10) : 200ull;
-                const bool fits = (uint64_t)c->entries_upper * bpe < (uint64_t)mem_free + held;
-                const auto t0 = std::chrono::steady_clock::now();
-                if (!fits || build_tm(c, p)) {
-                    (void)hipGetLastError();
-                    for (auto& b : c->tm) b.release();
-                    c->tm_key[0] = p->min_mq; c->tm_key[1] = p->flag_exclude; c->tm_key[2] = p->ignore_orphans; c->tm_key[3] = c->n_ct;
-                    c->tm_valid = true; c->tm_usable = false;          // (until the reads or the filters change)
-                    if (getenv("LSG_TIMING")) fprintf(stderr, "[lsg] tile-major store not built (%s): counting without it\n", fits ? "build failed" : "device memory");
-                }
-                LSG_HIP(hipStreamSynchronize(st));
-                const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-                c->layout_build_ms += ms;
-                if (getenv("LSG_TIMING"))
-                    fprintf(stderr, "[lsg] tile index + tile-major store of %llu entries (%u blocks, %u jobs) built in %.2f ms\n", (unsigned long long)c->ix_n, c->tm_nblk, c->tm_njobs, ms);
-            }
-            if (c->tm_usable) { c->tm_path = true; c->index_path = false; return run_count_tm(c, p); }
-        }
+    bool want_layout = false, want_store = false;
+    if (c->n_ct <= 2 && c->rd.n_reads < 0x7fffffffll && !getenv("LSG_COUNT_PASS") && !getenv("LSG_NO_INDEX")) {
+        const bool same_key = c->seen_key[0] == (int64_t)p->min_mq && c->seen_key[1] == (int64_t)p->flag_exclude && c->seen_key[2] == (int64_t)p->ignore_orphans &&
+                              c->seen_key[3] == (int64_t)c->n_ct;
+        if (!same_key) { c->seen_key[0] = p->min_mq; c->seen_key[1] = p->flag_exclude; c->seen_key[2] = p->ignore_orphans; c->seen_key[3] = c->n_ct; c->seen_counts = 0; }
+        const int policy = layout_policy(c);
+        want_store = policy == 1 || (policy == 0 && (c->seen_counts >= 1 || tm_key_matches(c, p)));
+        want_layout = want_store || (policy == 0 && c->index_valid);      // an index that exists already serves other filters too
+        ++c->seen_counts;
+    }
+    if (want_store && !getenv("LSG_NO_TM")) {
+        if (int rc = prepare_layout(c, p)) return rc;
+        if (!c->has_drops && c->tm_usable) { c->tm_path = true; c->index_path = false; return run_count_tm(c, p); }
     }
     const uint32_t n_units = c->n_tiles * (uint32_t)c->n_ct;
     const int64_t R = c->rd.n_reads, S = c->rd.n_segs;
@@ -3004,7 +3027,7 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
     if (tile_capacities(c)) return -1;
     if (depth_cap_drops(c, p)) return -1;           // free unless some cell type's pileup buffer can reach max_depth (cached bound)
     // the tile index serves <= 2 cell types and counts without depth-cap drops (those are per read and rare: the scatter path takes them)
-    c->index_path = c->n_ct <= 2 && !c->has_drops && c->rd.n_reads < 0x7fffffffll && !getenv("LSG_COUNT_PASS") && !getenv("LSG_NO_INDEX");
+    c->index_path = want_layout && !c->has_drops;
     if (c->index_path && !c->index_valid) {
         size_t mem_free = 0, mem_total = 0;
         (void)hipMemGetInfo(&mem_free, &mem_total);
@@ -3294,7 +3317,7 @@ __global__ void k_entries_upper(const int32_t* seg_start, const int32_t* seg_len
 }
 
 int compute_entries_upper(lsg_ctx* c) {
-    c->tile_caps_valid = false; c->index_valid = false; c->tm_valid = false; c->layout_build_ms = 0;      // new reads: static capacities, the tile index and the tile-major store are rebuilt by the next count
+    c->tile_caps_valid = false; c->index_valid = false; c->tm_valid = false; c->layout_build_ms = 0; c->seen_counts = 0;      // new reads: static capacities, the tile index and the tile-major store are rebuilt by the next count
     if (c->d_scalars.reserve(SC_COUNT * 8)) return -1;
     LSG_HIP(hipMemsetAsync(c->d_scalars.p, 0, SC_COUNT * 8, c->stream));
     int64_t S = c->rd.n_segs;

@@ -214,6 +214,16 @@ class Engine:
         _lib.check(self._lib.lsg_get_count_stats(self._h, C.byref(s)), "lsg_get_count_stats")
         return s
 
+    def prepare_counts(self, params: Optional[CountParams] = None):
+        """Build the per-load structures (tile index, tile-major store) for these read filters now: for callers that will count
+        the resident reads more than once (lsg_prepare_counts).  Without it the second count of a load builds them."""
+        params = params or CountParams.longsom_defaults()
+        _lib.check(self._lib.lsg_prepare_counts(self._h, C.byref(params)), "lsg_prepare_counts")
+
+    def set_layout_policy(self, policy: int):
+        """0 auto (from the second count of a load), 1 eager, 2 never (lsg_set_layout_policy)"""
+        _lib.check(self._lib.lsg_set_layout_policy(self._h, int(policy)), "lsg_set_layout_policy")
+
     def layout_info(self):
         """(path, build_ms, store_bytes) of the last count: 0 scatter per count / 1 tile index / 2 tile-major store; what the per-load
         index and store cost to build and hold (lsg_get_layout_info)"""

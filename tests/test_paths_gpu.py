@@ -25,10 +25,11 @@ def rows_of(engine, n_ct, params):
 
 
 def count_with(engine, n_ct, params, env):
-    old = {k: os.environ.get(k) for k in ("LSG_NO_TM", "LSG_NO_INDEX", "LSG_TM_BYTES_PER_ENTRY")}
+    old = {k: os.environ.get(k) for k in ("LSG_NO_TM", "LSG_NO_INDEX", "LSG_TM_BYTES_PER_ENTRY", "LSG_LAYOUT")}
     try:
         for k in old:
             os.environ.pop(k, None)
+        os.environ["LSG_LAYOUT"] = "eager"
         os.environ.update(env)
         out = rows_of(engine, n_ct, params)
         return out, engine.layout_info()[0]
@@ -132,3 +133,39 @@ def test_a_load_too_large_for_the_store_is_counted_without_it(engine):
     c, path_c = count_with(engine, 2, p, {})
     assert path_c == 2
     same(a, c)
+
+
+def test_default_policy_builds_the_store_at_the_second_count(engine):
+    """auto: a load counted once never pays for the store; counted again under the same read filters it gets it; lsg_prepare_counts
+    builds it at once; never keeps every count on the scatter path"""
+    lens = [3000, 500]
+    rec, refs, ct_of = make_case(17, 9000, lens, 90)
+    load(engine, rec, lens, refs, ct_of, 2)
+    p = CountParams.longsom_defaults()
+    first, path1 = count_with(engine, 2, p, {"LSG_LAYOUT": "auto"})
+    assert path1 == 0 and engine.layout_info()[1] == 0.0
+    second, path2 = count_with(engine, 2, p, {"LSG_LAYOUT": "auto"})
+    third, path3 = count_with(engine, 2, p, {"LSG_LAYOUT": "auto"})
+    assert (path2, path3) == (2, 2) and engine.layout_info()[1] > 0.0
+    same(first, second); same(first, third)
+    other = CountParams.longsom_defaults(min_mq=20)                      # other read filters, counted for the first time: no new store,
+    o1, path4 = count_with(engine, 2, other, {"LSG_LAYOUT": "auto"})     # but the index (parameter-free) is there already
+    assert path4 == 1
+    same(o1, count_with(engine, 2, other, {"LSG_NO_INDEX": "1"})[0])
+    engine.load_reads(rec)
+    old = os.environ.pop("LSG_LAYOUT", None)
+    try:
+        os.environ["LSG_LAYOUT"] = "auto"
+        engine.prepare_counts(p)
+    finally:
+        os.environ.pop("LSG_LAYOUT", None)
+        if old is not None:
+            os.environ["LSG_LAYOUT"] = old
+    prepared, path5 = count_with(engine, 2, p, {"LSG_LAYOUT": "auto"})
+    assert path5 == 2
+    same(first, prepared)
+    engine.load_reads(rec)
+    for _ in range(3):
+        never, path6 = count_with(engine, 2, p, {"LSG_LAYOUT": "never"})
+        assert path6 == 0
+    same(first, never)
