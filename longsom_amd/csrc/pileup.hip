@@ -2947,7 +2947,7 @@ static int layout_policy(const lsg_ctx* c) {
 // builds the tile index and the tile-major store for these read filters when they can serve the counts (rc != 0: a real failure)
 int prepare_layout(lsg_ctx* c, const lsg_count_params* p) {
     hipStream_t st = c->stream;
-    if (!(c->n_ct <= 2 && c->n_ct > 0 && c->rd.n_reads < 0x7fffffffll) || getenv("LSG_COUNT_PASS") || getenv("LSG_NO_INDEX") || getenv("LSG_NO_TM")) return 0;
+    if (!(c->n_ct <= 2 && c->n_ct > 0 && c->rd.n_reads < 0x7fffffffll) || getenv("LSG_COUNT_PASS") || getenv("LSG_NO_INDEX") || getenv("LSG_NO_TM") || layout_policy(c) == 2) return 0;
     if (tile_capacities(c)) return -1;
     if (depth_cap_drops(c, p)) return -1;
     if (c->has_drops || tm_key_matches(c, p)) return 0;

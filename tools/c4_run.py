@@ -10,11 +10,11 @@ model = synth.named("C4", n_reads=n)
 eng = Engine(0, stream=torch.cuda.current_stream().cuda_stream)
 eng.set_contigs(model.contig_len); eng.synth_reference(model.seed); eng.set_barcodes(model.celltype_of, 2)
 t0 = time.time(); eng.synth_reads(model); torch.cuda.synchronize(); print("generated + aligned in %.1f s, shape %s, free %.0f GB" % (time.time() - t0, eng.reads_shape(), torch.cuda.mem_get_info()[0] / 1e9), flush=True)
-for i in range(2):
+for i in range(3):
     t0 = time.perf_counter(); rows, cols = eng.pileup_count(); ns, nc = eng.call_step1(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
     s = eng.count_stats()
-    print("pass %d: %.1f ms  rows %s cols %d sites %d cand %d | events %d entries %d units %d deep %d | bin %.1f walk %.1f wave %.1f" %
-          (i, dt * 1e3, rows, cols, ns, nc, s.n_events_admitted, s.n_entries, s.n_units, s.n_deep_units, s.ms_bin, s.ms_walk, s.ms_wave), flush=True)
+    print("pass %d: %.1f ms  rows %s cols %d sites %d cand %d | events %d entries %d units %d deep %d | bin %.1f walk %.1f wave %.1f | count form %d (0 scatter, 1 index, 2 store), per-load structures %.1f GB" %
+          (i, dt * 1e3, rows, cols, ns, nc, s.n_events_admitted, s.n_entries, s.n_units, s.n_deep_units, s.ms_bin, s.ms_walk, s.ms_wave, eng.layout_info()[0], eng.layout_info()[2] / 1e9), flush=True)
 full = (rows, cols, ns)
 # property: counting two halves of the genome separately gives the same totals
 tid_mid = len(model.contig_len) // 2
