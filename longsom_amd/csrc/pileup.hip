@@ -2971,7 +2971,7 @@ int prepare_layout(lsg_ctx* c, const lsg_count_params* p) {
     LSG_HIP(hipStreamSynchronize(st));
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     c->layout_build_ms += ms;
-    if (getenv("LSG_TIMING"))
+    if (getenv("LSG_TIMING") && c->tm_usable)
         fprintf(stderr, "[lsg] tile index + tile-major store of %llu entries (%u blocks, %u jobs) built in %.2f ms\n", (unsigned long long)c->ix_n, c->tm_nblk, c->tm_njobs, ms);
     return 0;
 }
