@@ -2336,7 +2336,7 @@ static int build_index(lsg_ctx* c) {
 constexpr int TM_JOB_MAX = 3072, TM_JOB_TGT = 3072, TM_JOB_LIMIT = 4095;      // LIMIT: what the planes' 12-bit forward field holds; a cut moves forward to the next run start
 constexpr uint32_t TM_PAD_S0 = CB_MASK | IX_RUNSTART;
 enum { TM_STORE = 0, TM_S0, TM_B, TM_LINE, TM_META, TM_BLK_TILE, TM_JOBS, TM_NE_UNITS, TM_NE_GEOM, TM_NE_NSLOT, TM_NE_ACC, TM_MULTI, TM_CHUNKS, TM_NBUF };
-constexpr uint32_t TM_CHUNK_WORK = 4096, TM_JOB_W0 = 32;      // a wave dequeues about this much work (entries + a constant per job) at a time
+constexpr uint32_t TM_CHUNK_WORK = 4096, TM_JOB_W0 = 32;      // a workgroup dequeues at most this much work (entries + a constant per job) at a time
 struct TmJob { uint32_t e0, e1, w0, slab, nj, cnt, tile, emid; };     // padded-entry range; unit of (tile, cell type 0); slab of (job, cell type 0) or ~0; jobs and entries of the tile; where the job's second wave starts (a run start, or e1)
 constexpr uint32_t TMM_CT4 = 1u << 4, TMM_CT12 = 1u << 12, TMM_FWD = 1u << 20, TMM_SKIP = 1u << 29, TMM_SINGLE = 1u << 30, TMM_RS = 1u << 31;
 struct TmArgs {
@@ -2457,11 +2457,11 @@ struct TmJobWork {
     __host__ __device__ uint32_t operator()(const uint32_t& j) const { return jobs[j].e1 - jobs[j].e0 + TM_JOB_W0; }
 };
 // chunk k = the jobs whose exclusive work prefix lies in [k E, (k + 1) E)
-__global__ void k_tm_chunks(const uint32_t* pex, uint32_t njobs, uint32_t* chunk_start, uint32_t* n_chunks) {
+__global__ void k_tm_chunks(const uint32_t* pex, uint32_t njobs, uint32_t chunk_work, uint32_t* chunk_start, uint32_t* n_chunks) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= njobs) return;
-    const uint32_t ck = pex[j] / TM_CHUNK_WORK;
-    const int64_t prev = j ? (int64_t)(pex[j - 1] / TM_CHUNK_WORK) : -1;
+    const uint32_t ck = pex[j] / chunk_work;
+    const int64_t prev = j ? (int64_t)(pex[j - 1] / chunk_work) : -1;
     for (int64_t k = prev + 1; k <= (int64_t)ck; ++k) chunk_start[k] = j;
     if (j == njobs - 1) { chunk_start[ck + 1] = njobs; *n_chunks = ck + 1; }
 }
@@ -2826,7 +2826,11 @@ static int build_tm(lsg_ctx* c, const lsg_count_params* p) {
     uint32_t n_chunks = 0;
     {   // static work-balanced chunks of the job list
         DevBuf pex;
-        if (pex.reserve(((size_t)njobs + 2) * 4) || c->tm[TM_CHUNKS].reserve(((size_t)(((uint64_t)np + (uint64_t)njobs * TM_JOB_W0) / TM_CHUNK_WORK) + 4) * 4)) { pex.release(); return done(-1); }
+        // every workgroup of the walk should get several chunks: a small load (one rank's share of a sharded job) is cut finer
+        const uint64_t total_work = (uint64_t)np + (uint64_t)njobs * TM_JOB_W0;
+        uint64_t cw = total_work / ((uint64_t)c->n_cus * 14 * 6);
+        const uint32_t chunk_work = (uint32_t)(cw < 256 ? 256 : (cw > TM_CHUNK_WORK ? TM_CHUNK_WORK : cw));
+        if (pex.reserve(((size_t)njobs + 2) * 4) || c->tm[TM_CHUNKS].reserve(((size_t)(total_work / chunk_work) + 4) * 4)) { pex.release(); return done(-1); }
         hipcub::CountingInputIterator<uint32_t> iota(0);
         TmJobWork wf{c->tm[TM_JOBS].as<TmJob>()};
         hipcub::TransformInputIterator<uint32_t, TmJobWork, hipcub::CountingInputIterator<uint32_t>> it(iota, wf);
@@ -2835,7 +2839,7 @@ static int build_tm(lsg_ctx* c, const lsg_count_params* p) {
         if (e1 != hipSuccess || cub_tmp(c, tb_)) { pex.release(); return done(-1); }
         tb_ = c->d_cub_tmp.cap;
         e1 = hipcub::DeviceScan::ExclusiveSum(c->d_cub_tmp.p, tb_, it, pex.as<uint32_t>(), (int)njobs, st);
-        hipLaunchKernelGGL(k_tm_chunks, dim3((njobs + 255) / 256), dim3(256), 0, st, pex.as<uint32_t>(), njobs, c->tm[TM_CHUNKS].as<uint32_t>(), d_maxjob + 1);
+        hipLaunchKernelGGL(k_tm_chunks, dim3((njobs + 255) / 256), dim3(256), 0, st, pex.as<uint32_t>(), njobs, chunk_work, c->tm[TM_CHUNKS].as<uint32_t>(), d_maxjob + 1);
         hipError_t e2 = hipMemcpyAsync(&n_chunks, d_maxjob + 1, 4, hipMemcpyDeviceToHost, st);
         hipError_t e3 = hipStreamSynchronize(st);
         pex.release();

@@ -21,6 +21,7 @@ for world in worlds:
     for rank, (lo, hi, g_lo, g_hi) in enumerate(region_shards(model, world)):
         eng.synth_reads(sub_model(model, g_lo, g_hi) if world > 1 else model)
         eng.set_region(lo[0], lo[1], hi[0], hi[1])
+        eng.prepare_counts(cp)                  # as bench.py does: the per-load store, outside the timed steps
         def step():
             rows, cols = eng.pileup_count(cp)
             ns, nc = eng.call_step1(kp)
