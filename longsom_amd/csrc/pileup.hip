@@ -2342,7 +2342,7 @@ constexpr uint32_t TMM_CT4 = 1u << 4, TMM_CT12 = 1u << 12, TMM_FWD = 1u << 20, T
 struct TmArgs {
     const uint4* store; const uint32_t* s0; const uint8_t* b; uint32_t* meta; const uint32_t* blk_tile; const TmJob* jobs;
     const uint32_t* chunk_start;          // static: first job of every chunk of about TM_CHUNK_WORK work
-    uint64_t np; uint32_t nblk, njobs, nchunks, dbg;
+    uint64_t np; uint32_t nblk, njobs, nchunks;
 };
 
 struct TmAdm {      // an index entry passes the key's read filters (ix2: flag12 | mapq << 12 | ...)
@@ -2709,8 +2709,7 @@ __global__ __launch_bounds__(TMW_WAVES * 64) __attribute__((amdgpu_waves_per_eu(
             (&nc_sh[0][0])[threadIdx.x] = 0;
             __syncthreads();
             TmState st; st.nc = 0; st.mask = 0;
-            const uint32_t emid2 = (tm.dbg & 1u) ? e1 : emid;
-            const uint32_t s0 = wv ? emid2 : e0, s1 = wv ? e1 : emid2;
+            const uint32_t s0 = wv ? emid : e0, s1 = wv ? e1 : emid;
             if (s1 > s0) {
                 tm_walk_range(tm, st, s0, s1, thr, pkl0, one, lane);
                 if (st.nc & 0xffffu) atomicAdd(&nc_sh[0][lane], st.nc & 0xffffu);
@@ -2886,7 +2885,7 @@ static int run_count_tm(lsg_ctx* c, const lsg_count_params* p) {
     fill_args(c, p, a);
     TmArgs tm{};
     tm.store = c->tm[TM_STORE].as<uint4>(); tm.s0 = c->tm[TM_S0].as<uint32_t>(); tm.b = c->tm[TM_B].as<uint8_t>(); tm.meta = c->tm[TM_META].as<uint32_t>();
-    tm.blk_tile = c->tm[TM_BLK_TILE].as<uint32_t>(); tm.jobs = c->tm[TM_JOBS].as<TmJob>(); tm.np = c->tm_np; tm.nblk = c->tm_nblk; tm.njobs = c->tm_njobs; tm.nchunks = c->tm_nchunks; tm.chunk_start = c->tm[TM_CHUNKS].as<uint32_t>(); tm.dbg = (uint32_t)tune_int("LSG_TM_DBG", 0);
+    tm.blk_tile = c->tm[TM_BLK_TILE].as<uint32_t>(); tm.jobs = c->tm[TM_JOBS].as<TmJob>(); tm.np = c->tm_np; tm.nblk = c->tm_nblk; tm.njobs = c->tm_njobs; tm.nchunks = c->tm_nchunks; tm.chunk_start = c->tm[TM_CHUNKS].as<uint32_t>();
     LSG_HIP(hipEventRecord(c->ev[0], st));
     LSG_HIP(hipMemsetAsync(c->d_scalars.p, 0, SC_COUNT * 8, st));
     LSG_HIP(hipMemsetAsync(c->d_ix_stat.p, 0, IX_STAT_SLOTS * 64, st));
