@@ -2335,13 +2335,14 @@ static int build_index(lsg_ctx* c) {
 #endif
 constexpr int TM_JOB_MAX = 3072, TM_JOB_TGT = 3072, TM_JOB_LIMIT = 4095;      // LIMIT: what the planes' 12-bit forward field holds; a cut moves forward to the next run start
 constexpr uint32_t TM_PAD_S0 = CB_MASK | IX_RUNSTART;
-enum { TM_STORE = 0, TM_S0, TM_B, TM_LINE, TM_META, TM_BLK_TILE, TM_JOBS, TM_NE_UNITS, TM_NE_GEOM, TM_NE_NSLOT, TM_NE_ACC, TM_MULTI, TM_CHUNKS, TM_NBUF };
+enum { TM_STORE = 0, TM_S0, TM_B, TM_LINE, TM_META, TM_BLK_TILE, TM_JOBS, TM_NE_UNITS, TM_NE_GEOM, TM_NE_NSLOT, TM_NE_ACC, TM_MULTI, TM_CHUNKS, TM_EXT, TM_NBUF };
 constexpr uint32_t TM_CHUNK_WORK = 4096, TM_JOB_W0 = 32;      // a workgroup dequeues at most this much work (entries + a constant per job) at a time
 struct TmJob { uint32_t e0, e1, w0, slab, nj, cnt, tile, emid; };     // padded-entry range; unit of (tile, cell type 0); slab of (job, cell type 0) or ~0; jobs and entries of the tile; where the job's second wave starts (a run start, or e1)
 constexpr uint32_t TMM_CT4 = 1u << 4, TMM_CT12 = 1u << 12, TMM_FWD = 1u << 20, TMM_SKIP = 1u << 29, TMM_SINGLE = 1u << 30, TMM_RS = 1u << 31;
 struct TmArgs {
     const uint4* store; const uint32_t* s0; const uint8_t* b; uint32_t* meta; const uint32_t* blk_tile; const TmJob* jobs;
     const uint32_t* chunk_start;          // static: first job of every chunk of about TM_CHUNK_WORK work
+    const uint16_t* ext;                  // static, per block: first position any of its entries has an event at | one past the last << 8
     uint64_t np; uint32_t nblk, njobs, nchunks;
 };
 
@@ -2401,17 +2402,22 @@ __global__ void k_tm_runs(uint32_t* s0, uint8_t* b, uint64_t np, const uint32_t*
     }
 }
 // one wave per block: lane = position; eight 128-byte lines in, one transposed kilobyte out
-__global__ void k_tm_gather(const uint16_t* events, const uint32_t* s0, const uint32_t* line, uint32_t nblk, uint4* store) {
+__global__ void k_tm_gather(const uint16_t* events, const uint32_t* s0, const uint32_t* line, uint32_t nblk, uint4* store, uint16_t* ext) {
     const int lane = threadIdx.x & 63;
     const uint32_t blk = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     if (blk >= nblk) return;
-    uint32_t e[8];
+    uint32_t e[8], any = 0;
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
         const uint64_t p = (uint64_t)blk * 8 + u;
         e[u] = (s0[p] & CB_MASK) != CB_MASK ? (uint32_t)events[(uint64_t)line[p] * 64 + lane] : 0u;
+        any |= e[u];
     }
     store[(uint64_t)blk * 64 + lane] = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+    // the positions outside [first, last] of the block's events are zeros in all eight entries (exon and read ends shared by the
+    // tile's reads): the walk does not fetch them (its buffer descriptor ends there, lanes outside read zeros)
+    const unsigned long long m = __ballot(any != 0u);
+    if (lane == 0) ext[blk] = m ? (uint16_t)(__ffsll((long long)m) - 1) | (uint16_t)((64 - __clzll((long long)m)) << 8) : (uint16_t)0;
 }
 // per non-empty tile: its units (one per cell type), its jobs cut at run starts
 __global__ void k_tm_jobs(CountArgs a, const uint32_t* s0, const uint32_t* cnt, const uint32_t* blk_off, const uint32_t* ne_off, const uint32_t* nj,
@@ -2609,20 +2615,33 @@ typedef uint32_t tm_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void tm_walk_range(const TmArgs& tm, TmState& st, uint32_t s0, uint32_t s1, uint32_t thr, uint32_t pkl0, uint32_t one, int lane) {
     const uint32_t b0 = s0 >> 3, nblk = ((s1 + 7) >> 3) - b0;
     const uint32_t* mp = tm.meta + (uint64_t)b0 * 8;
+    const uint16_t* xp = tm.ext + b0;
     const uint64_t sbase = (uint64_t)(uintptr_t)(tm.store + (uint64_t)b0 * 64);
     const uint64_t sb = ((uint64_t)rl((uint32_t)(sbase >> 32), 0) << 32) | rl((uint32_t)sbase, 0);
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>((uintptr_t)sb), 0, (int)(nblk * 1024u), 0x00020000);
     const uint32_t lane16 = 16u * (uint32_t)lane;
     const int ng = (int)((nblk + TM_GROUP - 1) / TM_GROUP);
     const uint32_t pe0 = s0 - b0 * 8u, pe1 = s1 - b0 * 8u;                // the range, relative to its first block
     // a group = TM_GROUP blocks: 16 bytes per lane and block of events, and the meta words of its 8 TM_GROUP entries one per lane
-    // (read back lane by lane into an SGPR when the entry's turn comes); the entries of the neighbouring ranges are not there
+    // (read back lane by lane into an SGPR when the entry's turn comes); the entries of the neighbouring ranges are not there.
+    // Every block is fetched through a descriptor of its own that covers the positions its entries have events at (ext): the lanes
+    // outside it read zeros without a memory request.  The extents of the NEXT group's blocks travel one group ahead, in lanes 0..3.
     tm_u32x4 EA[TM_GROUP], EB[TM_GROUP];
     uint32_t MA, MB;
+    auto extents = [&](int g) -> uint32_t {
+        const uint32_t blk = (uint32_t)g * TM_GROUP + (uint32_t)lane;
+        return lane < TM_GROUP && blk < nblk ? (uint32_t)xp[blk] : 0u;
+    };
+    uint32_t X = extents(0);
     auto issue = [&](int g, tm_u32x4 (&E)[TM_GROUP], uint32_t& M) {
+        const uint32_t Xg = X;
+        X = extents(g + 1);
 #pragma unroll
-        for (int k = 0; k < TM_GROUP; ++k)
-            E[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)lane16, (int)(((uint32_t)g * TM_GROUP + k) * 1024u), 0);       // past the range: zeros
+        for (int k = 0; k < TM_GROUP; ++k) {
+            const uint32_t x = rl(Xg, k), plo = x & 0xffu, phi = x >> 8;
+            const uint64_t base = sb + (uint64_t)((uint32_t)g * TM_GROUP + k) * 1024u + plo * 16u;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>((uintptr_t)base), 0, (int)((phi - plo) * 16u), 0x00020000);
+            E[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(lane16 - plo * 16u), 0, 0);       // before plo: the offset wraps, out of range = zeros
+        }
         const uint32_t pr = (uint32_t)g * (8u * TM_GROUP) + (uint32_t)lane;
         M = TMM_SKIP;
         if (lane < 8 * TM_GROUP && pr >= pe0 && pr < pe1) M = mp[pr];
@@ -2799,7 +2818,7 @@ static int build_tm(lsg_ctx* c, const lsg_count_params* p) {
     const size_t n_ne = c->tm_n_ne;
     if (c->tm[TM_STORE].reserve(((size_t)nblk + TM_GROUP) * 1024) || c->tm[TM_S0].reserve((np + 16) * 4) || c->tm[TM_B].reserve(np + 16) ||
         c->tm[TM_LINE].reserve((np + 16) * 4) || c->tm[TM_META].reserve((np + 8 * (TM_GROUP + 1)) * 4) || c->tm[TM_BLK_TILE].reserve(((size_t)nblk + 2) * 4) ||
-        c->tm[TM_JOBS].reserve(((size_t)njobs + 1) * sizeof(TmJob)) || c->tm[TM_NE_UNITS].reserve((n_ne + 2) * 4) || c->tm[TM_NE_GEOM].reserve((n_ne + 2) * 8) ||
+        c->tm[TM_JOBS].reserve(((size_t)njobs + 1) * sizeof(TmJob)) || c->tm[TM_EXT].reserve(((size_t)nblk + TM_GROUP + 2) * 2) || c->tm[TM_NE_UNITS].reserve((n_ne + 2) * 4) || c->tm[TM_NE_GEOM].reserve((n_ne + 2) * 8) ||
         c->tm[TM_NE_NSLOT].reserve((n_ne + 2) * 4) || c->tm[TM_NE_ACC].reserve((n_ne + 2) * 4) || c->tm[TM_MULTI].reserve(((size_t)c->tm_n_multi + 2) * 4))
         return done(-1);
     uint32_t* s0 = c->tm[TM_S0].as<uint32_t>(); uint32_t* line = c->tm[TM_LINE].as<uint32_t>(); uint8_t* b8 = c->tm[TM_B].as<uint8_t>();
@@ -2814,7 +2833,7 @@ static int build_tm(lsg_ctx* c, const lsg_count_params* p) {
     hipLaunchKernelGGL(k_tm_fill, dim3((unsigned)(c->n_cus * 16)), dim3(256), 0, st, adm, c->d_ix0.as<uint32_t>(), c->d_ix1.as<uint32_t>(), c->d_ix2.as<uint32_t>(), N,
                        c->d_tile_off.as<uint32_t>(), T, S.as<uint32_t>(), blk_off, s0, line, b8);
     hipLaunchKernelGGL(k_tm_runs, dim3((unsigned)(c->n_cus * 16)), dim3(256), 0, st, s0, b8, np, blk_off, blk_tile);
-    hipLaunchKernelGGL(k_tm_gather, dim3((unsigned)(((uint64_t)nblk * 64 + 255) / 256)), dim3(256), 0, st, c->rd.events, s0, line, nblk, c->tm[TM_STORE].as<uint4>());
+    hipLaunchKernelGGL(k_tm_gather, dim3((unsigned)(((uint64_t)nblk * 64 + 255) / 256)), dim3(256), 0, st, c->rd.events, s0, line, nblk, c->tm[TM_STORE].as<uint4>(), c->tm[TM_EXT].as<uint16_t>());
     {
         CountArgs a{};
         a.tile_base = c->d_tile_base.as<uint32_t>(); a.n_contigs = c->n_contigs; a.n_ct = c->n_ct;
@@ -2885,7 +2904,7 @@ static int run_count_tm(lsg_ctx* c, const lsg_count_params* p) {
     fill_args(c, p, a);
     TmArgs tm{};
     tm.store = c->tm[TM_STORE].as<uint4>(); tm.s0 = c->tm[TM_S0].as<uint32_t>(); tm.b = c->tm[TM_B].as<uint8_t>(); tm.meta = c->tm[TM_META].as<uint32_t>();
-    tm.blk_tile = c->tm[TM_BLK_TILE].as<uint32_t>(); tm.jobs = c->tm[TM_JOBS].as<TmJob>(); tm.np = c->tm_np; tm.nblk = c->tm_nblk; tm.njobs = c->tm_njobs; tm.nchunks = c->tm_nchunks; tm.chunk_start = c->tm[TM_CHUNKS].as<uint32_t>();
+    tm.blk_tile = c->tm[TM_BLK_TILE].as<uint32_t>(); tm.jobs = c->tm[TM_JOBS].as<TmJob>(); tm.np = c->tm_np; tm.nblk = c->tm_nblk; tm.njobs = c->tm_njobs; tm.nchunks = c->tm_nchunks; tm.chunk_start = c->tm[TM_CHUNKS].as<uint32_t>(); tm.ext = c->tm[TM_EXT].as<uint16_t>();
     LSG_HIP(hipEventRecord(c->ev[0], st));
     LSG_HIP(hipMemsetAsync(c->d_scalars.p, 0, SC_COUNT * 8, st));
     LSG_HIP(hipMemsetAsync(c->d_ix_stat.p, 0, IX_STAT_SLOTS * 64, st));
