@@ -145,7 +145,7 @@ struct TailTask { uint32_t k, n; uint64_t dst; };     // dst = address of the in
 // millions of times: all pairs k <= n <= TAIL_NT are evaluated once per parameter set (k_tail_table, with exactly the code a
 // task of that pair would run, so the rounded values are the same bits) and looked up by k_call_gather instead of becoming tasks.
 constexpr uint32_t PASS_CAP = 4096;      // PASS candidates are a few hundred per sample: list + in-block sort; more fall back to the scan
-constexpr uint32_t TAIL_NT = 511;
+constexpr uint32_t TAIL_NT = 2047;
 constexpr uint32_t TAIL_ENTRIES = (TAIL_NT + 1) * (TAIL_NT + 2) / 2;
 __host__ __device__ __forceinline__ uint32_t tail_index(uint32_t k, uint32_t n) { return n * (n + 1) / 2 + k; }
 __device__ __forceinline__ bool tail_in_table(uint32_t k, uint32_t n) { return n <= TAIL_NT && k <= n; }
