@@ -831,17 +831,6 @@ __device__ __forceinline__ void walk(const CountArgs& a, Acc& acc, const uint32_
     }
 }
 
-// the same over grouped 8-byte records in global memory (tile index path: the records arrive grouped, nothing is staged)
-__device__ __forceinline__ void walk_rec(const CountArgs& a, Acc& acc, const uint2* rec, int j0, int j1, uint32_t* pk, int lane) {
-    const uint32_t thr = bq_threshold(a);
-    for (int jb = j0; jb < j1; jb += 64) {
-        const int nb = j1 - jb < 64 ? j1 - jb : 64;
-        uint32_t e = a.zero_lo, m = a.zero_hi;
-        if (lane < nb) { const uint2 r = rec[jb + lane]; e = r.x; m = r.y; acc.nev += meta_events(m); }
-        walk_regs(acc, e, m, nb, thr, pk, lane);
-    }
-}
-
 // Group n entries (global SoA arrays at src) by barcode into the LDS arrays gkey/gev/gmeta:
 // entries with equal barcodes become adjacent.  T threads cooperate (T = 64: one wave, fences
 // only; T = BLOCK_THREADS: __syncthreads).  When `filter` is set only entries whose barcode bucket
@@ -1080,10 +1069,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void k_pileup_wave(CountArgs 
         }
         // slot 0's entries (one per lane) when it is a one-batch slot; later slots are prefetched one slot ahead
         uint4 cur = make_uint4(KEY_INVALID, 0u, 0u, 0u);
-        auto fetch = [&](uint32_t off) -> uint4 {              // tile index path: grouped records {line address, meta with the run flags}
-            if (a.index_path) { const uint2 r = a.rec[off + lane]; return make_uint4(0u, r.x, r.y, 0u); }
-            return unpack_entry(a, a.ent[off + lane]);
-        };
+        auto fetch = [&](uint32_t off) -> uint4 { return unpack_entry(a, a.ent[off + lane]); };
         {
             const int n0 = (int)rl(s_cnt, 0);
             if (n0 <= 64 && lane < n0) cur = fetch(rl(s_off, 0));
@@ -1104,15 +1090,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void k_pileup_wave(CountArgs 
             { const int64_t pos = (int64_t)tstart + lane; if (pos >= 1 && pos < a.contig_len[tid]) refb = a.ref_ptr[tid][pos]; }
             Acc acc; acc.init();
             bool general = n > 64;
-            if (!general && a.index_path) {
-                // the records say it themselves: every entry starts a run of its own <=> no barcode occurs twice
-                general = __ballot(lane < n && !(cur.z & META_NEWRUN)) != 0ull;
-                if (!general) {
-                    const uint32_t m = lane < n ? cur.z : a.zero_hi;
-                    if (lane < n) acc.nev += meta_events(m);
-                    walk_regs<true>(acc, lane < n ? cur.y : a.zero_lo, m, n, bq_threshold(a), pk, lane);
-                }
-            } else if (!general) {
+            if (!general) {
                 // one batch: if no barcode occurs twice every entry is its own run and no grouping is needed
                 L.tcnt[lane] = KEY_INVALID; L.tcnt[lane + 64] = KEY_INVALID;
                 lds_fence();
@@ -1134,9 +1112,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void k_pileup_wave(CountArgs 
                     walk_regs<true>(acc, lane < n ? cur.y : a.zero_lo, m, n, bq_threshold(a), pk, lane);
                 }
             }
-            if (general && a.index_path) {
-                walk_rec(a, acc, a.rec + src, 0, n, pk, lane);               // grouped already
-            } else if (general) {
+            if (general) {
                 lds_fence();
                 group_by_cb<false, HW, CAPW>(a, src, n, L.gkey, L.gev, L.gmeta, L.tkey, L.tcnt, lane, nullptr);
                 for (int i = lane; i < 8 * 64; i += 64) pk[i] = 0;
@@ -3127,7 +3103,7 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
     // launch-shape knobs
     const unsigned grid_block = (unsigned)(c->n_cus * 2);      // k_pileup_huge
     const unsigned grid_walk = (unsigned)(c->n_cus * tune_int("LSG_GRID_WALK", 8));       // k_walk_block
-    const unsigned grid_wave = (unsigned)(c->n_cus * tune_int("LSG_GRID_WAVE", c->index_path && !getenv("LSG_OLD_WAVE") ? 8 : 4));
+    const unsigned grid_wave = (unsigned)(c->n_cus * tune_int("LSG_GRID_WAVE", c->index_path ? 8 : 4));
 
     if (n_ne > 0) {
         // slot plan: deep units are cut into barcode-range slots
@@ -3155,6 +3131,7 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
         const uint64_t emitters = (uint64_t)grid_block + grid_walk + (uint64_t)grid_wave * WAVES_PER_BLOCK + (unsigned)(c->n_cus * 8);
         uint64_t arena = want_rows / (emitters * 8) / ARENA * ARENA;
         c->arena = (uint32_t)(arena < (uint64_t)ARENA ? (uint64_t)ARENA : (arena > 8ull * ARENA ? 8ull * ARENA : arena));
+        if (getenv("LSG_ARENA_BLOCKS")) c->arena = (uint32_t)(tune_int("LSG_ARENA_BLOCKS", 1) * ARENA);
         want_rows += emitters * c->arena + 64;      // one open arena per emitting wave
         want_rows = (want_rows + 63) / 64 * 64 + 64;        // whole 64-row blocks (lsg::row_word), one spare: a unit's descriptor spans two
         // every cell type of THIS run needs planes of the current stride (a run with more cell types than any before it
@@ -3191,7 +3168,7 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
         // 1024-thread workgroups the other half, and whichever starts first starves the other — so everything stays on one stream.
         LSG_HIP(hipEventRecord(c->ev[2], st));
         static_assert(WIX_WAVES == WAVES_PER_BLOCK, "one grid size for both wave kernels");
-        if (a.index_path && !getenv("LSG_OLD_WAVE")) hipLaunchKernelGGL(k_wave_ix, dim3(grid_wave), dim3(WIX_WAVES * 64), 0, st, a);
+        if (a.index_path) hipLaunchKernelGGL(k_wave_ix, dim3(grid_wave), dim3(WIX_WAVES * 64), 0, st, a);
         else hipLaunchKernelGGL(k_pileup_wave, dim3(grid_wave), dim3(WAVES_PER_BLOCK * 64), 0, st, a);
         LSG_HIP(hipEventRecord(c->ev[3], st));
         if (c->n_multi > 0) {
