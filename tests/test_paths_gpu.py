@@ -59,6 +59,11 @@ def test_three_count_paths_write_the_same_rows(engine, n_ct):
     assert (path_tm, path_ix, path_sc) == (2, 1, 0)
     same(tm, ix); same(tm, sc)
     assert sum(len(k) for k, _, _ in tm[0]) > 0
+    from oracle import loader                     # and all of them what the CPU oracle counts (the session's other tests reach the store form only)
+    for ct in range(n_ct):
+        ok, orf, oc, _ = loader.count(rec, lens, refs, ct_of, ct, p.min_bq, p.min_mq, p.min_dp, p.min_cc, p.flag_exclude, p.ignore_orphans)
+        k, rf, c = sc[0][ct]
+        np.testing.assert_array_equal(k, ok); np.testing.assert_array_equal(rf, orf); np.testing.assert_array_equal(c, oc)
     path, build_ms, store_bytes = engine.layout_info()
     assert build_ms > 0 and store_bytes > 0
 
