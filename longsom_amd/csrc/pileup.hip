@@ -4,21 +4,23 @@
 //   split_bam's read routing            workflow/scripts/PreProcessing/SplitBamCellTypes.py:65-124
 //   run_interval (pileup + counting)    workflow/scripts/SNVCalling/BaseCellCounter.py:182-320
 //
-// Work decomposition:
-//   unit  = (64-position tile of one contig, cell type); one lane per reference position.
-//   entry = one read segment overlapping a unit, self-contained (barcode/strand key, first event
-//           index, lane range), written by a counting sort over the segments (k_count_units,
-//           scan, k_scatter).  Units deeper than CAPB entries are cut by barcode range into
-//           SLOTS of ~SUBT entries, so every work item is bounded and the heavy tail (chrM,
-//           highly expressed genes) spreads over the whole chip; counters are additive over
-//           disjoint barcode sets.
-//   A slot's entries are grouped by barcode in LDS (open-addressing hash + scan) and walked
-//   barcode-run by barcode-run: every entry is one coalesced <=128-byte load of uint16 events
-//   (lane = position); per-symbol counts go to lane-private LDS words with one packed ds_add;
-//   distinct-cell numbers are counts minus within-run duplicates.  No global atomics on the event
-//   path, integer arithmetic only (HBM/VALU-bound; no MFMA).
-//   Slots with <= CAPW entries are processed by one wavefront each (no block barriers), larger
-//   ones by a 512-thread workgroup on run-aligned slices.
+// Three forms of the same count (identical rows: tests/test_paths_gpu.py), chosen per count by run_count:
+//   scatter + sort   (a load's first count; > 2 cell types; reads dropped by max_depth)
+//       unit  = (64-position tile of one contig, cell type); one lane per reference position.
+//       entry = one read segment overlapping a unit, self-contained (barcode / strand key, line of its events), scattered into the
+//               tile's static region (k_bin_segments).  Units deeper than CAPB entries are cut by barcode range into SLOTS of ~SUBT
+//               entries (k_sort_deep), so every work item is bounded and the heavy tail (chrM, highly expressed genes) spreads
+//               over the whole chip; counters are additive over disjoint barcode sets.  A slot's entries are grouped by barcode and
+//               walked run by run: every entry is one 128-byte line of uint16 events (lane = position); per-symbol counts go to
+//               LDS words with packed ds_adds; distinct-cell numbers are counts minus within-run duplicates.  Slots with <= CAPW
+//               entries are processed by one wavefront each (k_pileup_wave), larger ones by 4 waves on run-aligned slices
+//               (k_walk_block), partial sums of multi-slot units to slabs (k_finalize_multi).
+//   tile index       (per load: every tile's entries sorted by barcode once, build_index)
+//       k_resolve_agg + k_resolve write the walks' records in that order; k_wave_ix / k_cut + k_walk_block walk them.
+//   tile-major store (per load and read filters: the admitted entries' events re-laid in index order, 8 entries to a transposed
+//                     1 KB block, build_tm; the default from a load's second count)
+//       k_tm_resolve (cell type per entry -> a meta word) + k_tm_walk (streams the blocks, both cell types in one pass).
+//   No global atomics on the event path, integer arithmetic only (HBM- and issue-bound; no MFMA).
 #include "lsg_ctx.h"
 #include <hipcub/hipcub.hpp>
 #include <chrono>
