@@ -273,10 +273,11 @@ int lsg_get_count_stats(lsg_ctx* ctx, lsg_count_stats* out);
  * per window (BaseCellCounter.py:198-225). */
 int lsg_get_layout_info(lsg_ctx* ctx, int32_t* path, double* build_ms, int64_t* store_bytes);
 
-/* The per-load structures (tile index, tile-major store) cost more to build than one count without them, so by default
- * (LSG_LAYOUT_AUTO) the first lsg_pileup_count of a load under given read filters (min_mq, flag_exclude, ignore_orphans) runs on
- * the scatter path and the second builds them: a pipeline that counts its reads once (BaseCellCounter.py, one pass per BAM) pays
- * nothing, one that counts them again (the re-annotation loop, parameter sweeps, benchmarks) gets the streaming count from then on.
+/* The per-load structures (tile index, tile-major store) cost about as much to build as ten counts save (10 M reads: 60 ms against
+ * 6 ms per count), so by default (LSG_LAYOUT_AUTO) the first three lsg_pileup_count calls of a load under given read filters (min_mq,
+ * flag_exclude, ignore_orphans) run on the scatter path and the fourth builds them: a pipeline that counts its reads once or twice
+ * (BaseCellCounter.py, one pass per BAM; the two passes of the re-annotation loop) pays nothing, one that keeps counting them
+ * (parameter sweeps, benchmarks) gets the streaming count.  A caller that knows it will count many times says so:
  * lsg_prepare_counts builds them now, for these filters, when they can serve the counts (<= 2 cell types, no max_depth drops, enough
  * free device memory: otherwise it returns 0 and the counts run as before); LSG_LAYOUT_EAGER does that at every first count,
  * LSG_LAYOUT_NEVER keeps every count on the scatter path.  The environment variable LSG_LAYOUT=auto|eager|never overrides the policy.

@@ -18,7 +18,7 @@
 //   tile index       (per load: every tile's entries sorted by barcode once, build_index)
 //       k_resolve_agg + k_resolve write the walks' records in that order; k_wave_ix / k_cut + k_walk_block walk them.
 //   tile-major store (per load and read filters: the admitted entries' events re-laid in index order, 8 entries to a transposed
-//                     1 KB block, build_tm; the default from a load's second count)
+//                     1 KB block, build_tm; after lsg_prepare_counts, or once a load has been counted three times)
 //       k_tm_resolve (cell type per entry -> a meta word) + k_tm_walk (streams the blocks, both cell types in one pass).
 //   No global atomics on the event path, integer arithmetic only (HBM- and issue-bound; no MFMA).
 #include "lsg_ctx.h"
@@ -2938,7 +2938,11 @@ static int run_count_tm(lsg_ctx* c, const lsg_count_params* p) {
     return 0;
 }
 
-// 0 auto (second count of a load), 1 eager, 2 never; LSG_LAYOUT=auto|eager|never overrides what lsg_set_layout_policy left
+// 0 auto (a load counted LAYOUT_AUTO_AFTER times under the same read filters gets them at the next count), 1 eager, 2 never;
+// LSG_LAYOUT=auto|eager|never overrides what lsg_set_layout_policy left.  Building costs about as much as ten counts save (C2: 60 ms
+// against 6 ms per count), so auto waits for evidence that the load is being counted over and over; callers that know say so
+// (lsg_prepare_counts).
+constexpr uint32_t LAYOUT_AUTO_AFTER = 3;
 static int layout_policy(const lsg_ctx* c) {
     const char* e = getenv("LSG_LAYOUT");
     if (e && *e) return e[0] == 'e' ? 1 : (e[0] == 'n' ? 2 : 0);
@@ -2987,8 +2991,8 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
         if (!c->ref_ptr[t]) { set_error("lsg_pileup_count: reference of contig %d not loaded", t); return -2; }
     hipStream_t st = c->stream;
     // Per-load structures (tile index, tile-major store) serve <= 2 cell types and counts without depth-cap drops.  They cost more to
-    // build than one count on the scatter path, so (policy auto) the FIRST count of a load under given read filters runs without
-    // them and the second builds them; lsg_prepare_counts or policy eager build at once, policy never leaves them out.
+    // build than several counts on the scatter path, so (policy auto) the first LAYOUT_AUTO_AFTER counts of a load under given read
+    // filters run without them and the next one builds them; lsg_prepare_counts or policy eager build at once, never leaves them out.
     c->tm_path = false;
     bool want_layout = false, want_store = false;
     if (c->n_ct <= 2 && c->rd.n_reads < 0x7fffffffll && !getenv("LSG_COUNT_PASS") && !getenv("LSG_NO_INDEX")) {
@@ -2996,7 +3000,7 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
                               c->seen_key[3] == (int64_t)c->n_ct;
         if (!same_key) { c->seen_key[0] = p->min_mq; c->seen_key[1] = p->flag_exclude; c->seen_key[2] = p->ignore_orphans; c->seen_key[3] = c->n_ct; c->seen_counts = 0; }
         const int policy = layout_policy(c);
-        want_store = policy == 1 || (policy == 0 && (c->seen_counts >= 1 || tm_key_matches(c, p)));
+        want_store = policy == 1 || (policy == 0 && (c->seen_counts >= LAYOUT_AUTO_AFTER || tm_key_matches(c, p)));
         want_layout = want_store || (policy == 0 && c->index_valid);      // an index that exists already serves other filters too
         ++c->seen_counts;
     }

@@ -216,12 +216,13 @@ class Engine:
 
     def prepare_counts(self, params: Optional[CountParams] = None):
         """Build the per-load structures (tile index, tile-major store) for these read filters now: for callers that will count
-        the resident reads more than once (lsg_prepare_counts).  Without it the second count of a load builds them."""
+        the resident reads many times (lsg_prepare_counts: the build costs about ten counts' worth of savings).  Without it the fourth
+        count of a load under the same read filters builds them."""
         params = params or CountParams.longsom_defaults()
         _lib.check(self._lib.lsg_prepare_counts(self._h, C.byref(params)), "lsg_prepare_counts")
 
     def set_layout_policy(self, policy: int):
-        """0 auto (from the second count of a load), 1 eager, 2 never (lsg_set_layout_policy)"""
+        """0 auto (from the fourth count of a load), 1 eager, 2 never (lsg_set_layout_policy)"""
         _lib.check(self._lib.lsg_set_layout_policy(self._h, int(policy)), "lsg_set_layout_policy")
 
     def layout_info(self):

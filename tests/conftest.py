@@ -8,7 +8,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-# The library builds its per-load structures (tile index, tile-major store) at the SECOND count of a load (lsg_set_layout_policy); most
+# The library builds its per-load structures (tile index, tile-major store) at the FOURTH count of a load (lsg_set_layout_policy); most
 # tests count a load once.  The suite runs with the eager policy so that every GPU test goes through the streaming count — the form
 # the benchmark measures — while tests/test_paths_gpu.py pins all three forms of the count, and the default policy, against each other.
 os.environ.setdefault("LSG_LAYOUT", "eager")

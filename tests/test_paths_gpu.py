@@ -140,15 +140,19 @@ def test_a_load_too_large_for_the_store_is_counted_without_it(engine):
     same(a, c)
 
 
-def test_default_policy_builds_the_store_at_the_second_count(engine):
-    """auto: a load counted once never pays for the store; counted again under the same read filters it gets it; lsg_prepare_counts
-    builds it at once; never keeps every count on the scatter path"""
+def test_default_policy_builds_the_store_for_a_load_that_keeps_being_counted(engine):
+    """auto: a load counted one to three times never pays for the store; the fourth count under the same read filters builds it;
+    lsg_prepare_counts builds it at once; never keeps every count on the scatter path"""
     lens = [3000, 500]
     rec, refs, ct_of = make_case(17, 9000, lens, 90)
     load(engine, rec, lens, refs, ct_of, 2)
     p = CountParams.longsom_defaults()
     first, path1 = count_with(engine, 2, p, {"LSG_LAYOUT": "auto"})
     assert path1 == 0 and engine.layout_info()[1] == 0.0
+    for _ in range(2):
+        again, path = count_with(engine, 2, p, {"LSG_LAYOUT": "auto"})
+        assert path == 0 and engine.layout_info()[1] == 0.0
+        same(first, again)
     second, path2 = count_with(engine, 2, p, {"LSG_LAYOUT": "auto"})
     third, path3 = count_with(engine, 2, p, {"LSG_LAYOUT": "auto"})
     assert (path2, path3) == (2, 2) and engine.layout_info()[1] > 0.0
