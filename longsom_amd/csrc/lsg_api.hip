@@ -81,6 +81,7 @@ void lsg_destroy(lsg_ctx* c) {
     for (auto& b : c->syn) b.release();
     for (auto& b : c->ws) b.release();
     for (auto& b : c->tm) b.release();
+    for (auto& b : c->bt) b.release();
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
@@ -262,6 +263,7 @@ int lsg_get_layout_info(lsg_ctx* c, int32_t* path, double* build_ms, int64_t* st
     if (store_bytes) {
         int64_t b = 0;
         for (auto& x : c->tm) b += (int64_t)x.cap;
+        for (auto& x : c->bt) b += (int64_t)x.cap;
         for (DevBuf* x : {&c->d_ix0, &c->d_ix1, &c->d_ix2, &c->d_ix_netile, &c->d_ix_chunk, &c->d_tile_cap, &c->d_tile_off}) b += (int64_t)x->cap;
         *store_bytes = b;
     }

@@ -110,6 +110,7 @@ struct lsg_ctx {
     // pileup.hip "tile-major store": the admitted entries' events in index order, eight entries to a transposed 1 KB block, with the
     // static job / unit / slab tables of a count over it; keyed on the read filters and the number of cell types
     lsg::DevBuf tm[16];
+    lsg::DevBuf bt[10];                   // temporaries of the index / store build (kept: device allocation is what a rebuild would wait for)
     uint64_t tm_np = 0;                   // padded entries
     uint32_t tm_nblk = 0, tm_njobs = 0, tm_nchunks = 0, tm_n_ne = 0, tm_n_multi = 0, tm_n_slabs = 0;
     int64_t tm_key[4] = {0, 0, 0, 0};     // min_mq, flag_exclude, ignore_orphans, n_ct

@@ -2212,8 +2212,10 @@ static int build_index(lsg_ctx* c) {
     if (tile_capacities(c)) return -1;
     hipStream_t st = c->stream;
     const int64_t S = c->rd.n_segs;
-    DevBuf key_a, key_b, val_a, val_b, eread, tmp;
-    auto done = [&](int rc) { key_a.release(); key_b.release(); val_a.release(); val_b.release(); eread.release(); tmp.release(); return rc; };
+    // the build's temporaries live in the context (grow-only, like every other workspace): allocating and freeing ~9 GB per build costs
+    // more wall time (0.9 s) than the build's kernels (60 ms)
+    DevBuf &key_a = c->bt[0], &key_b = c->bt[1], &val_a = c->bt[2], &val_b = c->bt[3], &eread = c->bt[4], &tmp = c->bt[5];
+    auto done = [&](int rc) { return rc; };
     uint32_t total = 0, max_cap = 0;
     {   // k_resolve carries a tile's running counts in 24-bit fields: a tile of 2^24 entries or more leaves the counts to the scatter path
         uint32_t* d_max = reinterpret_cast<uint32_t*>(c->d_scalars.as<unsigned long long>() + SC_NNE);
@@ -2380,22 +2382,33 @@ __global__ void k_tm_runs(uint32_t* s0, uint8_t* b, uint64_t np, const uint32_t*
     }
 }
 // one wave per block: lane = position; eight 128-byte lines in, one transposed kilobyte out
+constexpr int TMG_BLOCKS = 4;          // blocks per wave: 32 line loads in flight
 __global__ void k_tm_gather(const uint16_t* events, const uint32_t* s0, const uint32_t* line, uint32_t nblk, uint4* store, uint16_t* ext) {
     const int lane = threadIdx.x & 63;
-    const uint32_t blk = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-    if (blk >= nblk) return;
-    uint32_t e[8], any = 0;
+    const uint32_t blk0 = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * TMG_BLOCKS;
+    if (blk0 >= nblk) return;
+    uint32_t e[TMG_BLOCKS][8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const uint64_t p = (uint64_t)blk * 8 + u;
-        e[u] = (s0[p] & CB_MASK) != CB_MASK ? (uint32_t)events[(uint64_t)line[p] * 64 + lane] : 0u;
-        any |= e[u];
+    for (int q = 0; q < TMG_BLOCKS; ++q) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint64_t p = (uint64_t)(blk0 + q) * 8 + u;                    // (the entry arrays are padded past the last block)
+            e[q][u] = blk0 + q < nblk && (s0[p] & CB_MASK) != CB_MASK ? (uint32_t)events[(uint64_t)line[p] * 64 + lane] : 0u;
+        }
     }
-    store[(uint64_t)blk * 64 + lane] = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
-    // the positions outside [first, last] of the block's events are zeros in all eight entries (exon and read ends shared by the
-    // tile's reads): the walk does not fetch them (its buffer descriptor ends there, lanes outside read zeros)
-    const unsigned long long m = __ballot(any != 0u);
-    if (lane == 0) ext[blk] = m ? (uint16_t)(__ffsll((long long)m) - 1) | (uint16_t)((64 - __clzll((long long)m)) << 8) : (uint16_t)0;
+#pragma unroll
+    for (int q = 0; q < TMG_BLOCKS; ++q) {
+        const uint32_t blk = blk0 + q;
+        if (blk >= nblk) break;
+        uint32_t any = 0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) any |= e[q][u];
+        store[(uint64_t)blk * 64 + lane] = make_uint4(e[q][0] | (e[q][1] << 16), e[q][2] | (e[q][3] << 16), e[q][4] | (e[q][5] << 16), e[q][6] | (e[q][7] << 16));
+        // the positions outside [first, last] of the block's events are zeros in all eight entries (exon and read ends shared by the
+        // tile's reads): the walk does not fetch them (its buffer descriptor ends there, lanes outside read zeros)
+        const unsigned long long m = __ballot(any != 0u);
+        if (lane == 0) ext[blk] = m ? (uint16_t)(__ffsll((long long)m) - 1) | (uint16_t)((64 - __clzll((long long)m)) << 8) : (uint16_t)0;
+    }
 }
 // per non-empty tile: its units (one per cell type), its jobs cut at run starts
 __global__ void k_tm_jobs(CountArgs a, const uint32_t* s0, const uint32_t* cnt, const uint32_t* blk_off, const uint32_t* ne_off, const uint32_t* nj,
@@ -2768,8 +2781,8 @@ static int build_tm(lsg_ctx* c, const lsg_count_params* p) {
     const uint32_t T = c->n_tiles;
     c->tm_key[0] = p->min_mq; c->tm_key[1] = p->flag_exclude; c->tm_key[2] = p->ignore_orphans; c->tm_key[3] = c->n_ct;
     if (N == 0 || N >= 0x7fffffffull) { c->tm_valid = true; return 0; }
-    DevBuf S, per_tile, offs;
-    auto done = [&](int rc) { S.release(); per_tile.release(); offs.release(); return rc; };
+    DevBuf &S = c->bt[6], &per_tile = c->bt[7], &offs = c->bt[8];
+    auto done = [&](int rc) { return rc; };
     if (S.reserve((N + 2) * 4) || per_tile.reserve((size_t)(T + 2) * 4 * 6) || offs.reserve((size_t)(T + 2) * 4 * 5 + 64)) return done(-1);      // (offs: + two words behind the five arrays)
     TmAdm adm{c->d_ix2.as<uint32_t>(), p->flag_exclude, p->min_mq, p->ignore_orphans};
     {
@@ -2811,7 +2824,7 @@ static int build_tm(lsg_ctx* c, const lsg_count_params* p) {
     hipLaunchKernelGGL(k_tm_fill, dim3((unsigned)(c->n_cus * 16)), dim3(256), 0, st, adm, c->d_ix0.as<uint32_t>(), c->d_ix1.as<uint32_t>(), c->d_ix2.as<uint32_t>(), N,
                        c->d_tile_off.as<uint32_t>(), T, S.as<uint32_t>(), blk_off, s0, line, b8);
     hipLaunchKernelGGL(k_tm_runs, dim3((unsigned)(c->n_cus * 16)), dim3(256), 0, st, s0, b8, np, blk_off, blk_tile);
-    hipLaunchKernelGGL(k_tm_gather, dim3((unsigned)(((uint64_t)nblk * 64 + 255) / 256)), dim3(256), 0, st, c->rd.events, s0, line, nblk, c->tm[TM_STORE].as<uint4>(), c->tm[TM_EXT].as<uint16_t>());
+    hipLaunchKernelGGL(k_tm_gather, dim3((unsigned)((((uint64_t)nblk + TMG_BLOCKS - 1) / TMG_BLOCKS * 64 + 255) / 256)), dim3(256), 0, st, c->rd.events, s0, line, nblk, c->tm[TM_STORE].as<uint4>(), c->tm[TM_EXT].as<uint16_t>());
     {
         CountArgs a{};
         a.tile_base = c->d_tile_base.as<uint32_t>(); a.n_contigs = c->n_contigs; a.n_ct = c->n_ct;
@@ -2821,24 +2834,23 @@ static int build_tm(lsg_ctx* c, const lsg_count_params* p) {
     }
     uint32_t n_chunks = 0;
     {   // static work-balanced chunks of the job list
-        DevBuf pex;
+        DevBuf& pex = c->bt[9];
         // every workgroup of the walk should get several chunks: a small load (one rank's share of a sharded job) is cut finer
         const uint64_t total_work = (uint64_t)np + (uint64_t)njobs * TM_JOB_W0;
         uint64_t cw = total_work / ((uint64_t)c->n_cus * 14 * 6);
         const uint32_t chunk_work = (uint32_t)(cw < 256 ? 256 : (cw > TM_CHUNK_WORK ? TM_CHUNK_WORK : cw));
-        if (pex.reserve(((size_t)njobs + 2) * 4) || c->tm[TM_CHUNKS].reserve(((size_t)(total_work / chunk_work) + 4) * 4)) { pex.release(); return done(-1); }
+        if (pex.reserve(((size_t)njobs + 2) * 4) || c->tm[TM_CHUNKS].reserve(((size_t)(total_work / chunk_work) + 4) * 4)) { return done(-1); }
         hipcub::CountingInputIterator<uint32_t> iota(0);
         TmJobWork wf{c->tm[TM_JOBS].as<TmJob>()};
         hipcub::TransformInputIterator<uint32_t, TmJobWork, hipcub::CountingInputIterator<uint32_t>> it(iota, wf);
         size_t tb_ = 0;
         hipError_t e1 = hipcub::DeviceScan::ExclusiveSum(nullptr, tb_, it, pex.as<uint32_t>(), (int)njobs, st);
-        if (e1 != hipSuccess || cub_tmp(c, tb_)) { pex.release(); return done(-1); }
+        if (e1 != hipSuccess || cub_tmp(c, tb_)) { return done(-1); }
         tb_ = c->d_cub_tmp.cap;
         e1 = hipcub::DeviceScan::ExclusiveSum(c->d_cub_tmp.p, tb_, it, pex.as<uint32_t>(), (int)njobs, st);
         hipLaunchKernelGGL(k_tm_chunks, dim3((njobs + 255) / 256), dim3(256), 0, st, pex.as<uint32_t>(), njobs, chunk_work, c->tm[TM_CHUNKS].as<uint32_t>(), d_maxjob + 1);
         hipError_t e2 = hipMemcpyAsync(&n_chunks, d_maxjob + 1, 4, hipMemcpyDeviceToHost, st);
         hipError_t e3 = hipStreamSynchronize(st);
-        pex.release();
         if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { set_error("lsg_pileup_count: tile-major chunk table failed"); return done(-1); }
     }
     c->tm_nchunks = n_chunks;
