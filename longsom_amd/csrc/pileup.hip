@@ -3149,7 +3149,6 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
         const uint64_t emitters = (uint64_t)grid_block + grid_walk + (uint64_t)grid_wave * WAVES_PER_BLOCK + (unsigned)(c->n_cus * 8);
         uint64_t arena = want_rows / (emitters * 8) / ARENA * ARENA;
         c->arena = (uint32_t)(arena < (uint64_t)ARENA ? (uint64_t)ARENA : (arena > 8ull * ARENA ? 8ull * ARENA : arena));
-        if (getenv("LSG_ARENA_BLOCKS")) c->arena = (uint32_t)(tune_int("LSG_ARENA_BLOCKS", 1) * ARENA);
         want_rows += emitters * c->arena + 64;      // one open arena per emitting wave
         want_rows = (want_rows + 63) / 64 * 64 + 64;        // whole 64-row blocks (lsg::row_word), one spare: a unit's descriptor spans two
         // every cell type of THIS run needs planes of the current stride (a run with more cell types than any before it
