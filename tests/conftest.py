@@ -25,3 +25,17 @@ def engine():
     eng = Engine(0)
     yield eng
     eng.close()
+
+
+FORMS = {"store": {"LSG_LAYOUT": "eager"}, "index": {"LSG_LAYOUT": "eager", "LSG_NO_TM": "1"}, "scatter": {"LSG_LAYOUT": "never"}}
+
+
+@pytest.fixture(params=sorted(FORMS))
+def count_form(request, monkeypatch):
+    """runs the test once per form of the count (tile-major store / tile index / scatter + sort): the library reads these variables
+    at every lsg_pileup_count"""
+    for k in ("LSG_LAYOUT", "LSG_NO_TM", "LSG_NO_INDEX"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in FORMS[request.param].items():
+        monkeypatch.setenv(k, v)
+    return request.param
