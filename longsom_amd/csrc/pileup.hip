@@ -2307,13 +2307,13 @@ static int build_index(lsg_ctx* c) {
 //   b[p]    events - 1 [0..5] | first line of its segment << 6 | run of exactly one entry << 7
 //   meta[p] (per count, 32 bits laid out so that the walk uses them as operands): cell type << 4 and << 12 | forward << 20 |
 //           not counted or not there << 29 | run of one entry << 30 | run start << 31
-// Tiles of more than TM_JOB_MAX entries are cut at run starts into jobs of about TM_JOB_TGT entries (one wave each, partial sums to
+// Tiles of more than TM_JOB_TGT entries are cut at run starts into jobs of about TM_JOB_TGT entries (one wave each, partial sums to
 // slabs that k_finalize_multi adds up: 8 KB per job and cell type, so jobs are as long as the planes' fields allow); everything about jobs, units and slabs is static too, so a count has no planning step and
 // one host synchronisation (its final read of the counters).
 #ifndef LSG_TM_ASM
 #define LSG_TM_ASM true
 #endif
-constexpr int TM_JOB_MAX = 3072, TM_JOB_TGT = 3072, TM_JOB_LIMIT = 4095;      // LIMIT: what the planes' 12-bit forward field holds; a cut moves forward to the next run start
+constexpr int TM_JOB_TGT = 3072, TM_JOB_LIMIT = 4095;      // LIMIT: what the planes' 12-bit forward field holds; a cut moves forward to the next run start
 constexpr uint32_t TM_PAD_S0 = CB_MASK | IX_RUNSTART;
 enum { TM_STORE = 0, TM_S0, TM_B, TM_LINE, TM_META, TM_BLK_TILE, TM_JOBS, TM_NE_UNITS, TM_NE_GEOM, TM_NE_NSLOT, TM_NE_ACC, TM_MULTI, TM_CHUNKS, TM_EXT, TM_NBUF };
 constexpr uint32_t TM_CHUNK_WORK = 4096, TM_JOB_W0 = 32;      // a workgroup dequeues at most this much work (entries + a constant per job) at a time
@@ -2336,13 +2336,13 @@ struct TmAdm {      // an index entry passes the key's read filters (ix2: flag12
     }
 };
 // per tile: admitted entries, blocks, non-empty, jobs, slabs, multi-job (inputs of five exclusive scans)
-__global__ void k_tm_tiles(const uint32_t* tile_off, const uint32_t* S, uint32_t n_tiles, int n_ct, uint32_t* cnt, uint32_t* blk, uint32_t* ne,
+__global__ void k_tm_tiles(const uint32_t* tile_off, const uint32_t* S, uint32_t n_tiles, int n_ct, uint32_t job_tgt, uint32_t* cnt, uint32_t* blk, uint32_t* ne,
                            uint32_t* nj, uint32_t* slabs, uint32_t* multi) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t > n_tiles) return;
     uint32_t c = 0;
     if (t < n_tiles) c = S[tile_off[t + 1]] - S[tile_off[t]];
-    const uint32_t j = c == 0 ? 0u : (c <= (uint32_t)TM_JOB_MAX ? 1u : (c + TM_JOB_TGT - 1) / TM_JOB_TGT);
+    const uint32_t j = c == 0 ? 0u : (c <= job_tgt ? 1u : (c + job_tgt - 1) / job_tgt);
     cnt[t] = c; blk[t] = (c + 7) / 8; ne[t] = c ? 1u : 0u; nj[t] = j; slabs[t] = j > 1 ? j * (uint32_t)n_ct : 0u; multi[t] = j > 1 ? 1u : 0u;
 }
 // largest t in [0, n) with off[t] <= x (off non-decreasing, off[0] <= x): the tile whose region holds x, skipping empty ones
@@ -2795,7 +2795,11 @@ static int build_tm(lsg_ctx* c, const lsg_count_params* p) {
     uint32_t* blk_off = offs.as<uint32_t>(); uint32_t* ne_off = blk_off + (T + 2); uint32_t* job_off = ne_off + (T + 2);
     uint32_t* slab_off = job_off + (T + 2); uint32_t* multi_off = slab_off + (T + 2);
     uint32_t* d_maxjob = multi_off + (T + 2);
-    hipLaunchKernelGGL(k_tm_tiles, dim3((T + 256) / 256), dim3(256), 0, st, c->d_tile_off.as<uint32_t>(), S.as<uint32_t>(), T, c->n_ct, cnt, blk, ne, nj, slabs, multi);
+    // jobs as long as the planes' fields allow (fewer slabs) — unless the load is small (one rank's share of a sharded job): then every
+    // resident pair of waves should still get several
+    uint32_t job_tgt = TM_JOB_TGT;
+    { const uint64_t per = N / ((uint64_t)c->n_cus * 14 * 4); if (per < job_tgt) job_tgt = (uint32_t)(per < 768 ? 768 : per); }
+    hipLaunchKernelGGL(k_tm_tiles, dim3((T + 256) / 256), dim3(256), 0, st, c->d_tile_off.as<uint32_t>(), S.as<uint32_t>(), T, c->n_ct, job_tgt, cnt, blk, ne, nj, slabs, multi);
     SCAN_U32(blk, blk_off, T + 1); SCAN_U32(ne, ne_off, T + 1); SCAN_U32(nj, job_off, T + 1); SCAN_U32(slabs, slab_off, T + 1); SCAN_U32(multi, multi_off, T + 1);
     LSG_HIP(hipMemsetAsync(d_maxjob, 0, 8, st));
     uint32_t tot[5] = {0, 0, 0, 0, 0};
