@@ -29,16 +29,29 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from longsom_amd import synth  # noqa: E402
-from longsom_amd._lib import CallParams, CountParams  # noqa: E402
-from longsom_amd.engine import Engine  # noqa: E402
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: this process has touched neither torch nor HIP yet,
+    so it starts the N ranks itself — `python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py ...` as a CHILD process
+    (never an exec) — relays rank 0's JSON line and exits with the child's code.  The fan-out this replaces is the reference's
+    mp.Pool(CORE) over windows (BaseCellCounter.py:392-402)."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:
+        sys.stdout.write(line); sys.stdout.flush()
+    return proc.wait()
 
 METRIC = "genomic sites/s pileup+call, 10M-read BAM x 5k barcodes, 1/2/4/8 MI355X"
 CALL_BYTES = 336          # sizeof(lsg_call)
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
-
-from longsom_amd.shard import region_shards, sub_model  # noqa: E402
 
 
 def host_cores(cap=16):
@@ -185,9 +198,18 @@ def main():
     ap.add_argument("--reads", type=float, default=None, help="override the read count (development only; the reported config changes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
 
+    global synth, CallParams, CountParams, Engine, region_shards, sub_model
+    from longsom_amd import synth
+    from longsom_amd._lib import CallParams, CountParams
+    from longsom_amd.engine import Engine
+    from longsom_amd.shard import region_shards, sub_model
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: start it as `python bench.py --gpus N` or under torch.distributed.run with N ranks" % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # rehearsal on a 1-GPU box: LSG_BENCH_DEVICE pins every rank to one device, LSG_BENCH_BACKEND=gloo moves the

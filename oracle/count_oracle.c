@@ -197,6 +197,7 @@ typedef struct {
     int64_t n_regions; const int64_t* region_base;      /* first region of every contig */
     const int64_t* seg_off; const int64_t* seg_list;    /* segments per region */
     region_out_t* out; int64_t next; pthread_mutex_t mu; int failed;
+    int64_t key_lo, key_hi;                             /* counted span [(tid << 32 | pos) lo, hi): lso_count_span_mt */
 } mt_t;
 
 static void* mt_worker(void* arg) {
@@ -212,6 +213,12 @@ static void* mt_worker(void* arg) {
         int32_t tid = 0;
         while (tid + 1 < m->a->n_contigs && m->region_base[tid + 1] <= rg) ++tid;
         int64_t lo = (rg - m->region_base[tid]) * (int64_t)m->region_w, hi = lo + m->region_w;
+        {   /* columns outside the counted span belong to another shard (POS >= START and POS < END, BaseCellCounter.py:200) */
+            const int64_t klo = ((int64_t)tid << 32) | lo, khi = ((int64_t)tid << 32) | hi;
+            if (khi <= m->key_lo || klo >= m->key_hi) continue;
+            if (klo < m->key_lo) lo = m->key_lo & 0xffffffffll;
+            if (khi > m->key_hi) hi = m->key_hi & 0xffffffffll;
+        }
         int64_t n_ent = 0;
         for (int64_t i = s0; i < s1; ++i) n_ent += expand_segment(m->a, m->seg_list[i], lo, hi, NULL);
         if (n_ent == 0) continue;
@@ -234,7 +241,9 @@ static void* mt_worker(void* arg) {
     return NULL;
 }
 
-int64_t lso_count_mt(int64_t n_reads, int64_t n_segs,
+/* the same, restricted to the columns with key (tid << 32 | pos) in [key_lo, key_hi): one shard of a job whose reads are
+   generated shard by shard (tools/oracle_hashes.py streams the full-size workloads through it) */
+int64_t lso_count_span_mt(int64_t n_reads, int64_t n_segs,
                      const int32_t* read_tid, const uint16_t* read_flag, const uint8_t* read_mapq, const int32_t* read_cb,
                      const uint32_t* seg_read, const int32_t* seg_start, const int32_t* seg_len, const int64_t* seg_ev_off,
                      const uint16_t* events,
@@ -242,7 +251,7 @@ int64_t lso_count_mt(int64_t n_reads, int64_t n_segs,
                      const uint8_t* celltype_of, int32_t n_cb, int32_t ct,
                      int32_t min_bq, int32_t min_mq, int32_t min_dp, int32_t min_cc, uint32_t flag_exclude, int32_t ignore_orphans,
                      int64_t* out_keys, uint8_t* out_ref, uint32_t* out_counts, int64_t capacity, int64_t* n_columns,
-                     int32_t n_threads, int32_t region_w)
+                     int32_t n_threads, int32_t region_w, int64_t key_lo, int64_t key_hi)
 {
     (void)n_reads;
     if (n_threads < 1) n_threads = 1;
@@ -277,7 +286,7 @@ int64_t lso_count_mt(int64_t n_reads, int64_t n_segs,
             if (!out) { free(list); free(off); free(base); return -1; }
             mt_t m; memset(&m, 0, sizeof(m));
             m.a = &a; m.ref = ref; m.min_dp = min_dp; m.min_cc = min_cc; m.region_w = region_w; m.n_regions = n_regions; m.region_base = base;
-            m.seg_off = off; m.seg_list = list; m.out = out; m.next = 0; m.failed = 0;
+            m.seg_off = off; m.seg_list = list; m.out = out; m.next = 0; m.failed = 0; m.key_lo = key_lo; m.key_hi = key_hi;
             pthread_mutex_init(&m.mu, NULL);
             pthread_t th[256];
             int started = 0;
@@ -310,4 +319,19 @@ int64_t lso_count_mt(int64_t n_reads, int64_t n_segs,
         }
     }
     return -1;
+}
+
+int64_t lso_count_mt(int64_t n_reads, int64_t n_segs,
+                     const int32_t* read_tid, const uint16_t* read_flag, const uint8_t* read_mapq, const int32_t* read_cb,
+                     const uint32_t* seg_read, const int32_t* seg_start, const int32_t* seg_len, const int64_t* seg_ev_off,
+                     const uint16_t* events,
+                     int32_t n_contigs, const int64_t* contig_len, const uint8_t* const* ref,
+                     const uint8_t* celltype_of, int32_t n_cb, int32_t ct,
+                     int32_t min_bq, int32_t min_mq, int32_t min_dp, int32_t min_cc, uint32_t flag_exclude, int32_t ignore_orphans,
+                     int64_t* out_keys, uint8_t* out_ref, uint32_t* out_counts, int64_t capacity, int64_t* n_columns,
+                     int32_t n_threads, int32_t region_w)
+{
+    return lso_count_span_mt(n_reads, n_segs, read_tid, read_flag, read_mapq, read_cb, seg_read, seg_start, seg_len, seg_ev_off, events,
+                             n_contigs, contig_len, ref, celltype_of, n_cb, ct, min_bq, min_mq, min_dp, min_cc, flag_exclude, ignore_orphans,
+                             out_keys, out_ref, out_counts, capacity, n_columns, n_threads, region_w, 0, INT64_MAX);
 }

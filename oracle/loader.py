@@ -49,11 +49,13 @@ def _p(a):
 
 
 def count(rec, contig_len, refs, celltype_of, ct, min_bq=20, min_mq=60, min_dp=5, min_cc=5,
-          flag_exclude=0xF04, ignore_orphans=1, threads=1, region_w=512, cap=None):
+          flag_exclude=0xF04, ignore_orphans=1, threads=1, region_w=512, cap=None, span=None):
     """Events-level oracle (oracle/count_oracle.c).  refs: list of uint8 arrays per contig.
-    Returns keys, ref, counts[n,42], n_columns.  threads > 1: the region-parallel form (lso_count_mt, same per-column code)."""
+    Returns keys, ref, counts[n,42], n_columns.  threads > 1: the region-parallel form (lso_count_mt, same per-column code).
+    span = ((tid, pos), (tid, pos)): only the columns of that half-open region (lso_count_span_mt; one shard of a larger job)."""
     L = lib()
     L.lso_count_mt.restype = C.c_int64
+    L.lso_count_span_mt.restype = C.c_int64
     contig_len = np.ascontiguousarray(contig_len, np.int64)
     celltype_of = np.ascontiguousarray(celltype_of, np.uint8)
     refs = [np.ascontiguousarray(r, np.uint8) for r in refs]
@@ -63,6 +65,9 @@ def count(rec, contig_len, refs, celltype_of, ct, min_bq=20, min_mq=60, min_dp=5
         keys = np.empty(cap, np.int64); ref = np.empty(cap, np.uint8); counts = np.empty((cap, 42), np.uint32)
         ncols = C.c_int64(0)
         fn, extra = (L.lso_count, ()) if threads <= 1 else (L.lso_count_mt, (C.c_int32(int(threads)), C.c_int32(int(region_w))))
+        if span is not None:
+            (t0, p0), (t1, p1) = span
+            fn, extra = L.lso_count_span_mt, (C.c_int32(max(1, int(threads))), C.c_int32(int(region_w)), C.c_int64((int(t0) << 32) | int(p0)), C.c_int64((int(t1) << 32) | int(p1)))
         n = fn(C.c_int64(rec.n_reads), C.c_int64(rec.n_segs), _p(rec.read_tid), _p(rec.read_flag), _p(rec.read_mapq),
                         _p(rec.read_cb), _p(rec.seg_read), _p(rec.seg_start), _p(rec.seg_len), _p(rec.seg_ev_off), _p(rec.events),
                         C.c_int32(len(contig_len)), _p(contig_len), ref_ptrs, _p(celltype_of), C.c_int32(len(celltype_of)), C.c_int32(ct),

@@ -43,10 +43,10 @@ def test_contract_line_and_sharded_run():
     assert two["config"]["reads_loaded_all_ranks"] >= one["config"]["reads_loaded_all_ranks"]          # boundary-crossing reads are loaded twice
     # the single fixed-capacity all-gather: a capacity that is too small at first is grown in warm-up and moves the same rows
     assert two["config"]["pass_rows_gathered"] is not None and two["config"]["pass_rows_gathered"] >= 0
+    # ... and started the documented way: `python bench.py --gpus 2` with no WORLD_SIZE launches its own ranks (a child torch.distributed.run)
     tight = run_bench(["--gpus", "2", "--reads", "3e5", "--steps", "1", "--warmup", "1"],
-                      env={"LSG_BENCH_DEVICE": "0", "LSG_BENCH_BACKEND": "gloo", "LSG_BENCH_GATHER_CAP": "1"},
-                      launcher=[sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                                "--master-port", "29534"])
+                      env={"LSG_BENCH_DEVICE": "0", "LSG_BENCH_BACKEND": "gloo", "LSG_BENCH_GATHER_CAP": "1"})
+    assert tight["n_gpus"] == 2 and "gloo" in tight["config"]["exchange"]
     assert tight["config"]["pass_rows_gathered"] == two["config"]["pass_rows_gathered"]
 
 
