@@ -2,21 +2,24 @@
 """bench.py — BASELINE.json's metric on its named configuration.
 
   metric   genomic sites/s, pileup + call: pileup columns with >= 1 counted entry, summed over cell
-           types, per second of one full pass (binning -> pileup count -> merge + step-1 call,
-           + the all-gather of PASS-candidate call tables when N > 1)
+           types, per second of one full ONE-SHOT pass over a BAM's worth of decoded reads, as a LongSom rule runs it
+           (one count per BAM, BaseCellCounter.py:182-320):
+             lsg_load_reads on device-resident compact read-record arrays (the device half of ingest: builds the tile store)
+             -> lsg_pileup_count -> lsg_call_step1 (merge + step 1) [-> all-gather of PASS-candidate call rows when N > 1]
+           A step = one such pass on a FRESH load; the timed steps follow a warm-up load.
   workload C2 (BASELINE.json configs[1]): whole-genome synthetic long-read workload, 10 M reads x 5 k
            barcodes, generated directly in HBM by the model of longsom_amd/csrc/synth_model.h
-           (inputs are resident when the timed region starts)
+           (inputs are resident when the timed region starts: the arrays lsg_synth_generate left in HBM)
   N > 1    strong scaling: the same 10 M-read workload, genomic windows sharded over the ranks by
-           read count; every rank loads the reads overlapping its region, counts only its own
+           estimated work; every rank loads the reads overlapping its region, counts only its own
            columns and the ranks all-gather their PASS-candidate call rows over RCCL.
 
-One JSON line on rank 0.  `roofline` is for the dominant kernel (k_tm_walk on the tile-major path, k_walk_block otherwise): algorithmic bytes
-(2 B/event + 24 B/read + 168 B/emitted row, restricted to what that kernel processes)
-over its HIP-event time on its own stream.  `cpu_baseline` times the CPU oracle (oracle/, kind
-"port") on a bounded sample of the same workload on ALL of this box's host cores (one core and the
-reference-shaped Python loop beside it).  `roofline.traffic` is quoted from the newest profiles/
-file only when that file was recorded for this build of the kernels (else null + traffic_stale).
+One JSON line on rank 0.  `roofline` is for the kernel that takes the most time of a step (k_tm_gather, the store build's event
+gather, or k_tm_walk, the count's walk): its algorithmic bytes over its HIP-event time on its own stream (both kernels' figures are
+in config.kernels).  `config.recount_ms` is a count + call pass over the SAME resident store (what the second pass of the
+re-annotation loop pays).  `cpu_baseline` times the CPU oracle (oracle/, kind "port") on a bounded sample of the same workload on
+ALL of this box's host cores.  `roofline.traffic` is quoted from the newest profiles/ file only when that file was recorded for
+this build of the kernels (else null + traffic_stale).
 """
 import argparse
 import json
@@ -88,7 +91,9 @@ def cpu_baseline(eng, model, target_reads=150_000, call_sites=10_000):
         g_hi += 1
     sm = sub_model(model, g_lo, g_hi)
     eng.set_region()
+    eng.set_keep_reads(True)                 # the sample's arrays come back to the host for the oracle
     eng.synth_reads(sm)
+    eng.set_keep_reads(False)
     rows, cols = eng.pileup_count()
     rec = eng.reads_to_host()
     tids = sorted(set(sm.gene_tid.tolist()))
@@ -117,7 +122,8 @@ def cpu_baseline(eng, model, target_reads=150_000, call_sites=10_000):
     calling_oracle.step1(merged, fasta, info_lines=tsvio.STEP1_INFO_LINES)
     t_call_site = (time.time() - t0) / max(1, n_call)
     n_merged = len(np.unique(np.concatenate([p[0] for p in per_ct]))) if n_cols else 0
-    t_total = t_count + t_call_site * n_merged
+    # step 1 as `cores` processes would run it (the reference's step 1 is one process; an all-cores baseline gives it the same cores)
+    t_total = t_count + t_call_site * n_merged / cores
     # cpu_pyloop on C1 (chr22-only, 50 k reads, 200 barcodes): the reference's loop structure on its 50 kb windows
     c1 = synth.named("C1")
     rec1 = hostio.synth_records(c1)
@@ -138,8 +144,13 @@ def cpu_baseline(eng, model, target_reads=150_000, call_sites=10_000):
     t0 = time.time(); rows_pyn = pyloop.count_windows(rec1, bcs, refs1, c1.contig_names, c1.celltype_of, jobsn, cores); t_pyn = time.time() - t0
     cols_pyn = cols_of(jobsn)
     return {"value": n_cols / t_total if t_total > 0 else 0.0, "unit": "sites/s", "cores": cores, "kind": "port",
+            "count_only": {"unit": "sites/s", "all_cores": n_cols / t_count if t_count > 0 else 0.0, "one_core": cols1 / t_count1 if t_count1 > 0 else 0.0,
+                           "what": "oracle/count_oracle.c alone (lso_count_mt on %d threads / lso_count on one), no step 1" % cores},
+            "step1_only": {"unit": "merged sites/s", "one_process": 1.0 / t_call_site if t_call_site > 0 else 0.0,
+                           "what": "oracle/calling_oracle.py step1 (Python + scipy.stats.betabinom, as BaseCellCalling.step1.py:196-201), one process"},
             "sample": "cpu_native: %d reads of %d contiguous genes of the C2 workload (%d events, %d columns): oracle/count_oracle.c (lso_count_mt) on %d "
-                      "threads (%.1f s) + oracle/calling_oracle.py step1 in one process timed on %d merged sites (%.2f ms/site) scaled to the sample's %d sites"
+                      "threads (%.1f s) + oracle/calling_oracle.py step1 timed in one process on %d merged sites (%.2f ms/site), scaled to the sample's %d sites "
+                      "spread over the same cores"
                       % (rec.n_reads, g_hi - g_lo, rec.n_events, n_cols, cores, t_count, n_call, t_call_site * 1e3, n_merged),
             "native_1core": {"value": cols1 / (t_count1 + t_call_site * n_merged / 3) if t_count1 > 0 else 0.0, "unit": "sites/s",
                              "sample": "%d reads (a third of the sample), lso_count single-threaded %.1f s" % (third.n_reads, t_count1)},
@@ -151,11 +162,8 @@ def cpu_baseline(eng, model, target_reads=150_000, call_sites=10_000):
             "gpu_matches_oracle_on_sample": ok}
 
 
-# the dominant kernel by count path (Engine.layout_info): its name in the bench line and in rocprofv3's counter tables
-KERNEL_NAME = {0: "k_walk_block", 1: "k_walk_block", 2: "k_tm_walk"}
-PMC_KERNEL = {0: "void lsg::k_walk_block<true>", 1: "void lsg::k_walk_block<true>", 2: "lsg::k_tm_walk"}
-PATH_NAME = {0: "scatter + sort per count", 1: "tile index (entries sorted once per load)", 2: "tile-major event store (built once per load and read filters)"}
-COUNT_PATH = [2]
+# rocprofv3's names of the two candidates for "dominant kernel"
+PMC_KERNEL = {"k_tm_walk": "lsg::k_tm_walk", "k_tm_gather": "lsg::k_tm_gather"}
 
 
 def csrc_digest():
@@ -168,7 +176,7 @@ def csrc_digest():
     return h.hexdigest()
 
 
-def recorded_traffic():
+def recorded_traffic(kernel):
     """roofline.traffic: PMC counters cannot be read from inside this process, so the number comes from the newest committed
     rocprofv3 --pmc passes of this same command (profiles/rNN_pmc_traffic.json, tools/collect_profiles.sh) — but only when they
     were taken with THIS build of the kernels; otherwise traffic is null and traffic_stale says so."""
@@ -179,7 +187,7 @@ def recorded_traffic():
     f = files[-1]
     try:
         d = json.load(open(f))
-        k = d["kernels"].get(PMC_KERNEL[COUNT_PATH[0]])
+        k = next((v for n, v in d["kernels"].items() if PMC_KERNEL[kernel] in n), None)
         rel = os.path.relpath(f, ROOT)
         if d.get("_csrc_sha1") != csrc_digest():
             return None, "%s was recorded for another build of longsom_amd/csrc (sha1 %s)" % (rel, str(d.get("_csrc_sha1"))[:12]), True
@@ -193,8 +201,8 @@ def recorded_traffic():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--reads", type=float, default=None, help="override the read count (development only; the reported config changes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -242,19 +250,11 @@ def main():
         base = cpu_baseline(eng, model)
 
     lo, hi, g_lo, g_hi = region_shards(model, world)[rank]
-    eng.synth_reads(sub_model(model, g_lo, g_hi) if world > 1 else model)
+    # the rank's compact read-record arrays, generated once in HBM (untimed): what a device-resident decode of its share of the BAM hands over
+    reads = eng.synth_generate(sub_model(model, g_lo, g_hi) if world > 1 else model)
     eng.set_region(lo[0], lo[1], hi[0], hi[1])
-    n_reads, n_segs, n_events = eng.reads_shape()
+    n_reads, n_segs, n_events = int(reads.n_reads), int(reads.n_segs), int(reads.n_events)
     cp, kp = CountParams.longsom_defaults(), CallParams.longsom_defaults()
-    # the reads are counted --steps times: the per-load structures are built here, outside the timed region (a caller that counts a
-    # load once never builds them: include/longsom_hip.h, lsg_prepare_counts); their cost is reported as config.per_load_build_ms
-    torch.cuda.synchronize()
-    t_first = time.perf_counter()
-    eng.pileup_count(cp); eng.call_step1(kp)                         # what a pipeline that counts its reads once gets: the scatter form
-    torch.cuda.synchronize()
-    first_pass_ms = (time.perf_counter() - t_first) * 1e3
-    first_path = eng.layout_info()[0]
-    eng.prepare_counts(cp)
     # N > 1: ONE all-gather per step.  Every rank sends a message of the same agreed size: a header slot holding its number of
     # PASS-candidate rows, then room for cap_rows rows (SURVEY §8e's counts-then-buffers exchange needs two collectives and a host
     # read between them on every step).  The capacity is agreed during warm-up (the headers are read there) and checked once more
@@ -289,7 +289,9 @@ def main():
         per = (gather["cap"] + 1) * CALL_BYTES
         return gather["recv"].view(world, per)[:, :8].contiguous().view(torch.int64).flatten().cpu().tolist()
 
-    def step(check=False):
+    def step(check=False, load=True):
+        if load:
+            eng.load_reads_struct(reads)                               # a fresh tile store from the compact arrays
         rows, cols = eng.pileup_count(cp)
         n_sites, n_cand = eng.call_step1(kp)
         n_pass = 0
@@ -304,26 +306,40 @@ def main():
                 gather["counts"] = counts
         return rows, cols, n_sites, n_cand, n_pass
 
-    for _ in range(max(args.warmup, 1) if dist_on else args.warmup):
+    for _ in range(max(args.warmup, 1)):                               # (at least one warm-up load: the first one allocates every buffer)
         step(check=True)
     if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    walk_ms, walk_bytes, path_bytes = 0.0, 0.0, 0.0
+    walk_ms, walk_bytes, path_bytes, gather_ms, gather_bytes = 0.0, 0.0, 0.0, 0.0, 0.0
+    build_ms = np.zeros(4)
     for _ in range(args.steps):
         rows, cols, n_sites, n_cand, n_pass = step()
         st = eng.count_stats()
-        e_walk, r_walk = st.events_by_kernel[1], st.rows_by_kernel[1]
-        e_tot = max(1, st.n_events_admitted)
+        bt = eng.build_times()
         walk_ms += st.ms_walk
-        walk_bytes += 2.0 * e_walk + 24.0 * st.n_reads_admitted * (e_walk / e_tot) + 168.0 * r_walk
+        # k_tm_walk reads every stored event of the counted region once and emits the rows of the single-job tiles (2 B per
+        # event + 24 B per read + 168 B per emitted row); k_tm_gather reads every event once from the compact array and writes it once
+        walk_bytes += 2.0 * st.n_events_admitted + 24.0 * st.n_reads_admitted + 168.0 * st.rows_by_kernel[1]
         path_bytes += 2.0 * st.n_events_admitted + 24.0 * st.n_reads_admitted + 168.0 * sum(rows)
+        gather_ms += bt[3]
+        gather_bytes += 4.0 * eng.store_shape()[2]
+        build_ms += np.array(bt)
     torch.cuda.synchronize()
     if dist_on:
         dist.barrier()
     dt = time.perf_counter() - t0
-    COUNT_PATH[0], layout_ms, layout_bytes = eng.layout_info()
+    _, layout_ms, layout_bytes = eng.layout_info()
+    # after the clock: counts of the SAME resident store (the re-annotation loop's second pass, a parameter sweep)
+    torch.cuda.synchronize()
+    t_re = time.perf_counter()
+    n_re = 5
+    for _ in range(n_re):
+        re_rows, re_cols, re_sites, re_cand, _ = step(load=False)
+    torch.cuda.synchronize()
+    recount_ms = (time.perf_counter() - t_re) / n_re * 1e3
+    assert (re_rows, re_cols, re_sites, re_cand) == (rows, cols, n_sites, n_cand), "a re-count of the resident store differs from the first count"
     if os.environ.get("LSG_BENCH_STATS"):                           # the last step's counters, for whoever tunes the kernels
         print({f: (list(getattr(st, f)) if f.endswith("by_kernel") else getattr(st, f)) for f, _ in st._fields_ if f != "pad_"}, file=sys.stderr)
     if dist_on:
@@ -342,39 +358,41 @@ def main():
     else:
         tot = vals.tolist()
     if rank == 0:
-        traffic, traffic_src, traffic_stale = (None, None, None)
-        if world == 1 and args.reads is None:
-            traffic, traffic_src, traffic_stale = recorded_traffic()
-        e2e = None
-        try:
-            import glob
-            f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_end_to_end.json")))[-1]
-            e2e = dict(json.load(open(f)), source=os.path.relpath(f, ROOT))
-        except (IndexError, OSError, ValueError):
-            pass
         ms_step = dt / args.steps * 1e3
         sites = tot[1]
-        achieved = walk_bytes / max(walk_ms, 1e-9) / 1e6         # GB/s
+        kernels = {"k_tm_walk": {"avg_launch_ms": walk_ms / args.steps, "algorithmic_bytes_per_launch": walk_bytes / args.steps,
+                                 "achieved_GBps": walk_bytes / max(walk_ms, 1e-9) / 1e6},
+                   "k_tm_gather": {"avg_launch_ms": gather_ms / args.steps, "algorithmic_bytes_per_launch": gather_bytes / args.steps,
+                                   "achieved_GBps": gather_bytes / max(gather_ms, 1e-9) / 1e6}}
+        dom = max(kernels, key=lambda k: kernels[k]["avg_launch_ms"])
+        traffic, traffic_src, traffic_stale = (None, None, None)
+        if world == 1 and args.reads is None:
+            traffic, traffic_src, traffic_stale = recorded_traffic(dom)
+        achieved = kernels[dom]["achieved_GBps"]
+        bm = build_ms / args.steps
         out = {
             "metric": METRIC, "value": sites / (ms_step / 1e3), "unit": "sites/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
-            "config": {"workload": "C2: whole-genome synthetic long-read workload (hg38/10 + chrM), %d reads x %d barcodes, 2 cell types, "
-                                   "pileup count + merge + step-1 call%s" % (model.n_reads, model.n_cb, ", RCCL all-gather of PASS-candidate call rows" if world > 1 else ""),
-                       "reads": model.n_reads, "barcodes": model.n_cb, "reads_loaded_all_ranks": int(tot[4]), "event_slots_resident_all_ranks": int(tot[5]),
+            "config": {"workload": "C2: whole-genome synthetic long-read workload (hg38/10 + chrM), %d reads x %d barcodes, 2 cell types; one step = "
+                                   "one BAM's one-shot pass: device load of the compact read-record arrays (tile store build) + pileup count + merge + step-1 call%s"
+                                   % (model.n_reads, model.n_cb, " + RCCL all-gather of PASS-candidate call rows" if world > 1 else ""),
+                       "reads": model.n_reads, "barcodes": model.n_cb, "reads_loaded_all_ranks": int(tot[4]), "events_loaded_all_ranks": int(tot[5]),
                        "sites_counted": int(sites), "rows_emitted": int(tot[6]), "merged_sites": int(tot[2]), "step1_candidates": int(tot[3]),
-                       "sharding": "genomic regions balanced by read count" if world > 1 else "none",
+                       "sharding": "genomic regions balanced by estimated work" if world > 1 else "none",
                        "pass_rows_gathered": int(sum(gather["counts"])) if dist_on and gather["counts"] else None,
                        "exchange": "one all-gather per step (%s), %d-row slots agreed in warm-up" % (backend, gather["cap"]) if dist_on else None,
                        "path_algorithmic_GBps_rank0": path_bytes / dt / 1e9,
-                       "count_path_rank0": PATH_NAME[COUNT_PATH[0]], "first_pass_path_rank0": PATH_NAME[first_path],
-                       "first_pass_ms_rank0": round(first_pass_ms, 2),      # the load's FIRST count + call pass (cold buffers, no per-load structures): NOT inside ms_per_step
-                       "per_load_build_ms_rank0": round(layout_ms, 2),      # once per load, before the repeated counts: NOT inside ms_per_step
-                       "per_load_store_GB_rank0": round(layout_bytes / 1e9, 2),
-                       "end_to_end": e2e},
-            "roofline": {"bound": "hbm", "kernel": KERNEL_NAME[COUNT_PATH[0]], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "step_parts_ms_rank0": {"load_wall": round(layout_ms, 2), "build_capacities_scatter": round(float(bm[0]), 2), "build_sort": round(float(bm[1]), 2),
+                                               "build_entry_words": round(float(bm[2]), 2), "build_gather": round(float(bm[3]), 2),
+                                               "count": round(float(st.ms_total), 2), "count_walk": round(float(st.ms_walk), 2)},
+                       "recount_ms": round(recount_ms, 2),                 # count + call over the SAME resident store: NOT what value is computed from
+                       "resident_GB_rank0": round(layout_bytes / 1e9, 2),     # store + per-read / per-segment arrays + cached build temporaries
+                       "store_entries_rank0": eng.store_shape()[0], "store_events_rank0": eng.store_shape()[2],
+                       "kernels": kernels, "end_to_end": None},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale,
-                         "avg_launch_ms": walk_ms / args.steps, "algorithmic_bytes_per_launch": walk_bytes / args.steps},
+                         "avg_launch_ms": kernels[dom]["avg_launch_ms"], "algorithmic_bytes_per_launch": kernels[dom]["algorithmic_bytes_per_launch"]},
         }
         if base is not None:
             out["cpu_baseline"] = base

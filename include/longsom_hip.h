@@ -14,7 +14,8 @@
  *   - every call returns 0 on success, <0 on error; lsg_last_error() gives the message
  *     (thread-local).  One handle per GPU; a handle is not thread-safe; handles are independent.
  *   - "on_device" != 0 means the array pointers are device pointers on the handle's GPU
- *     (e.g. torch tensors' data_ptr()); 0 means host memory, borrowed for the duration of the call.
+ *     (e.g. torch tensors' data_ptr()); 0 means host memory; either way borrowed for the duration of the call
+ *     (exception: lsg_load_reference adopts a device array).
  *   - positions are 0-based on the device; text writers add 1 (BaseCellCounter.py:288).
  *   - there is NO CPU fallback in this library: without a HIP device lsg_create() fails.
  */
@@ -156,13 +157,20 @@ int lsg_load_reference(lsg_ctx* ctx, int32_t tid, const uint8_t* bases, int64_t 
  * per-read routing of SplitBamCellTypes.py:16-36,83-90,173: a re-annotation pass only swaps this
  * table, the reads stay resident. */
 int lsg_set_barcodes(lsg_ctx* ctx, const uint8_t* celltype_of, int32_t n_cb, int32_t n_celltypes);
-/* Copies (or adopts, when on_device) the read-record arrays.  Replaces reading the per-cell-type
- * BAMs in run_interval (BaseCellCounter.py:190-191).  The events are always copied: whatever offsets
- * seg_ev_off holds, the library keeps its own TILE-ALIGNED copy (the event of reference position q of a
- * segment at slot * 64 + (q & 63), padding = 0), so that one pileup entry = one aligned 128-byte line;
- * lsg_get_reads_shape / lsg_copy_reads_to_host report that resident layout.  A segment whose event
- * range lies outside [0, n_events) is an error. */
+/* Loads the read-record arrays: replaces reading the per-cell-type BAMs in run_interval (BaseCellCounter.py:190-191) AND the
+ * pileup engine's transposition of reads into columns (bam.pileup -> htslib bam_plp, :191-198), done here once per load on the device.
+ * The call builds the TILE STORE, the library's only resident form of the events: every (segment x 64-position tile) overlap of a
+ * read that carries a barcode is one entry, the entries of a tile adjacent and sorted by barcode, eight entries to a 1 KB block held
+ * transposed ([position][entry]); beside every entry its barcode, strand, SAM flag, MAPQ and owning read, so that every later
+ * lsg_pileup_count (any parameters, any barcode table, any region) and lsg_genotype_cells run from the store alone.  Needs the
+ * contigs (lsg_set_contigs).  The caller's arrays — host (on_device = 0) or device (1) — are free again when the call returns: the
+ * per-read and per-segment arrays are copied, the events are read once.  Whatever offsets seg_ev_off holds is fine (segments may even
+ * share events); a segment whose event range lies outside [0, n_events) or whose read index lies outside the reads is an error, and a
+ * refused load leaves no reads behind.  Segments that do not lie inside their contig are never counted. */
 int lsg_load_reads(lsg_ctx* ctx, const lsg_reads* reads);
+/* keep != 0: the next loads also keep a copy of the compact events (and seg_ev_off) beside the store, which is what
+ * lsg_copy_reads_to_host returns (tests, sampling for a CPU baseline).  Default 0: the store is the only copy (2 B per event saved). */
+int lsg_set_keep_reads(lsg_ctx* ctx, int32_t keep);
 /* The reference counts through bam.pileup(..., max_depth = 200000) (BaseCellCounter.py:191,
  * HCCVSingleCellGenotype.py:122): htslib stops admitting reads at a position while more than max_depth are
  * live in its buffer.  lsg_pileup_count models that cap exactly (lsg_count_params.max_depth); this call evaluates
@@ -170,9 +178,13 @@ int lsg_load_reads(lsg_ctx* ctx, const lsg_reads* reads);
  * (reads of one cell type whose span touches a 64-position tile, maximum over tiles and cell types; before
  * lsg_set_barcodes: all reads with a barcode).  While the bound stays <= max_depth the cap cannot fire.
  * lsg_genotype_cells does NOT model the cap (its pileup runs over the unsplit BAM, HCCVSingleCellGenotype.py:122):
- * there the host mirror checks this bound and warns or raises.  Computed on request and cached until the reads or
+ * there the host mirror checks the all-reads bound (lsg_max_live_reads_all) and warns or raises.  Computed on request and cached until the reads or
  * the barcode table change.  Returns the bound, -1 on error. */
 int64_t lsg_max_live_reads(lsg_ctx* ctx);
+/* The same bound over EVERY resident read that carries a barcode, whatever its cell type (>= lsg_max_live_reads): what the
+ * genotyping pileup of the unsplit BAM can hold at once (HCCVSingleCellGenotype.py:122) — a lower bound on it, since reads without a
+ * usable CB tag are dropped at decode and not resident. */
+int64_t lsg_max_live_reads_all(lsg_ctx* ctx);
 /* Restrict counting to the genomic region [ (tid_lo,pos_lo), (tid_hi,pos_hi) ) in (tid,pos) order;
  * positions must be multiples of 64.  This is how windows are sharded over GPUs: every rank loads
  * the reads overlapping its region (reads crossing a boundary are loaded by both ranks) and each
@@ -265,28 +277,17 @@ typedef struct {
 } lsg_count_stats;
 int lsg_get_count_stats(lsg_ctx* ctx, lsg_count_stats* out);
 
-/* How the last lsg_pileup_count ran, and what the per-load structures behind it cost.  path: 0 = scatter + sort per count (more than
- * two cell types, or reads dropped by max_depth), 1 = tile index (entries sorted once per load), 2 = tile-major event store (the
- * admitted entries' events re-laid in index order once per load and read filters; k_tm_walk streams them).  build_ms: wall time the
- * counts on the current reads have spent building the index / store (0 when none was built: a one-off per lsg_load_reads, outside the
- * steady-state count).  store_bytes: device memory those structures hold.  No reference counterpart: the reference re-reads the BAM
- * per window (BaseCellCounter.py:198-225). */
+/* What the load's tile store cost.  path: always 2 (the count over the store; kept for callers that print it).  build_ms: wall time
+ * lsg_load_reads spent building the store (device kernels + their host synchronisations).  store_bytes: device memory the store, its
+ * per-read / per-segment arrays, kept events and cached build temporaries hold.  No reference counterpart: the reference re-reads
+ * the BAM per window (BaseCellCounter.py:198-225). */
 int lsg_get_layout_info(lsg_ctx* ctx, int32_t* path, double* build_ms, int64_t* store_bytes);
-
-/* The per-load structures (tile index, tile-major store) cost about as much to build as ten counts save (10 M reads: 60 ms against
- * 6 ms per count), so by default (LSG_LAYOUT_AUTO) the first three lsg_pileup_count calls of a load under given read filters (min_mq,
- * flag_exclude, ignore_orphans) run on the scatter path and the fourth builds them: a pipeline that counts its reads once or twice
- * (BaseCellCounter.py, one pass per BAM; the two passes of the re-annotation loop) pays nothing, one that keeps counting them
- * (parameter sweeps, benchmarks) gets the streaming count.  A caller that knows it will count many times says so:
- * lsg_prepare_counts builds them now, for these filters, when they can serve the counts (<= 2 cell types, no max_depth drops, enough
- * free device memory: otherwise it returns 0 and the counts run as before); LSG_LAYOUT_EAGER does that at every first count,
- * LSG_LAYOUT_NEVER keeps every count on the scatter path.  The environment variable LSG_LAYOUT=auto|eager|never overrides the policy.
- * Results do not depend on any of this (tests/test_paths_gpu.py). */
-#define LSG_LAYOUT_AUTO 0
-#define LSG_LAYOUT_EAGER 1
-#define LSG_LAYOUT_NEVER 2
-int lsg_prepare_counts(lsg_ctx* ctx, const lsg_count_params* params);
-int lsg_set_layout_policy(lsg_ctx* ctx, int32_t policy);
+/* HIP-event times (ms) of the last load's build phases: [0] capacities + scatter, [1] sort of every tile's entries by barcode,
+ * [2] per-entry words, [3] event gather into the transposed blocks (the build's dominant kernel, k_tm_gather). */
+int lsg_get_build_times(lsg_ctx* ctx, float* ms4);
+/* Shape of the resident tile store: entries ((segment x tile) overlaps of reads with a barcode), 1 KB blocks, and the events the
+ * entries hold (what k_tm_gather reads once from the caller's array and writes once: its algorithmic bytes are 4 per event). */
+int lsg_get_store_shape(lsg_ctx* ctx, int64_t* n_entries, int64_t* n_blocks, int64_t* n_events);
 
 /* ---- synthetic workload (bench / tests; not part of the reference's path) --------------------*/
 /* Gene/expression tables of the BASELINE.md §4 workload model (built by longsom_amd/synth.py; the
@@ -310,10 +311,14 @@ typedef struct {
 
 /* Fills the reference of every contig with the model's synthetic genome, in HBM. */
 int lsg_synth_reference(lsg_ctx* ctx, uint64_t seed);
-/* Generates the model's read-record arrays directly in HBM and makes them the loaded reads. */
+/* Generates the model's read-record arrays directly in HBM and makes them the loaded reads (generate + lsg_load_reads). */
 int lsg_synth_reads(lsg_ctx* ctx, const lsg_synth_model* model);
+/* Only generates them: *out describes compact device arrays owned by the handle (valid until the next generate, lsg_synth_reads or
+ * lsg_destroy) — a stand-in for a caller whose decoded BAM is device-resident; bench.py times lsg_load_reads on them. */
+int lsg_synth_generate(lsg_ctx* ctx, const lsg_synth_model* model, lsg_reads* out);
 int lsg_get_reads_shape(lsg_ctx* ctx, int64_t* n_reads, int64_t* n_segs, int64_t* n_events);
-/* Copies the resident read-record arrays / reference into caller-allocated host arrays. */
+/* Copies the resident read-record arrays / reference into caller-allocated host arrays (the events only when the load kept them:
+ * lsg_set_keep_reads). */
 int lsg_copy_reads_to_host(lsg_ctx* ctx, const lsg_reads* out);
 int lsg_copy_reference_to_host(lsg_ctx* ctx, int32_t tid, uint8_t* out);
 

@@ -144,8 +144,11 @@ SIGNATURES = {
     "lsg_max_live_reads": (C.c_int64, [C.c_void_p]),
     "lsg_get_count_stats": (C.c_int, [C.c_void_p, C.POINTER(CountStats)]),
     "lsg_get_layout_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
-    "lsg_prepare_counts": (C.c_int, [C.c_void_p, C.POINTER(CountParams)]),
-    "lsg_set_layout_policy": (C.c_int, [C.c_void_p, C.c_int32]),
+    "lsg_get_build_times": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "lsg_get_store_shape": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lsg_set_keep_reads": (C.c_int, [C.c_void_p, C.c_int32]),
+    "lsg_max_live_reads_all": (C.c_int64, [C.c_void_p]),
+    "lsg_synth_generate": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Reads)]),
 }
 
 _lib = None

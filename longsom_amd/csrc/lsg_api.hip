@@ -11,9 +11,7 @@ void set_error(const char* fmt, ...) {
 const char* get_error() { return g_err; }
 
 int run_count(lsg_ctx* c, const lsg_count_params* p);
-int prepare_layout(lsg_ctx* c, const lsg_count_params* p);
 int run_fetch_counts(lsg_ctx* c, int ct, int64_t* keys, uint8_t* ref, uint32_t* counts, int64_t capacity);
-int compute_entries_upper(lsg_ctx* c);
 int run_call(lsg_ctx* c, const lsg_call_params* p);
 int run_fetch_calls(lsg_ctx* c, lsg_call* out, int64_t capacity, int candidates_only, int64_t* n_out);
 int run_select_calls(lsg_ctx* c, int kind, lsg_call* dst_device, int64_t capacity, int64_t* n_out);
@@ -22,14 +20,22 @@ int run_genotype(lsg_ctx* c, const lsg_genotype_params* p, int64_t n_sites, cons
                  uint32_t* dp, uint32_t* alt, int on_device);
 int run_sf4(lsg_ctx* c, int64_t items, const uint32_t* k, const uint32_t* n, double al, double be, int32_t* out, double* raw);
 
-// copy a host array to a grow-only device buffer, or adopt a device pointer
+// copy a host or device array into a grow-only device buffer of the handle (the caller's array is free again when the call returns)
 template <class T>
 static int put(lsg_ctx* c, DevBuf& buf, const T*& dst, const T* src, int64_t n, int on_device) {
     if (n <= 0 || !src) { dst = nullptr; return 0; }
-    if (on_device) { dst = src; return 0; }
+    if (src == buf.as<T>()) { dst = src; return 0; }          // (lsg_synth_reads generates into the handle's own buffers)
     if (buf.reserve((size_t)n * sizeof(T))) return -1;
-    LSG_HIP(hipMemcpyAsync(buf.p, src, (size_t)n * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    LSG_HIP(hipMemcpyAsync(buf.p, src, (size_t)n * sizeof(T), on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
     dst = buf.as<T>();
+    return 0;
+}
+// a reference's bases: host arrays are copied, device arrays adopted
+static int put_ref(lsg_ctx* c, DevBuf& buf, const uint8_t*& dst, const uint8_t* src, int64_t n, int on_device) {
+    if (on_device) { dst = src; return 0; }
+    if (buf.reserve((size_t)n)) return -1;
+    LSG_HIP(hipMemcpyAsync(buf.p, src, (size_t)n, hipMemcpyHostToDevice, c->stream));
+    dst = buf.as<uint8_t>();
     return 0;
 }
 } // namespace lsg
@@ -61,6 +67,8 @@ int lsg_create(int device_id, lsg_ctx** out) {
     if (hipHostMalloc(reinterpret_cast<void**>(&c->h_pin), 4096, hipHostMallocDefault) != hipSuccess) { set_error("lsg_create: hipHostMalloc failed"); delete c; return -1; }
     for (auto& e : c->ev)
         if (hipEventCreate(&e) != hipSuccess) { set_error("lsg_create: hipEventCreate failed"); delete c; return -1; }
+    for (auto& e : c->evb)
+        if (hipEventCreate(&e) != hipSuccess) { set_error("lsg_create: hipEventCreate failed"); delete c; return -1; }
     *out = c;
     return 0;
 }
@@ -71,18 +79,20 @@ void lsg_destroy(lsg_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->d_tile_base, &c->d_contig_len, &c->d_ref_ptrs, &c->d_celltype_of, &c->d_ct_rank, &c->b_read_tid, &c->b_read_pos,
                       &c->b_read_flag, &c->b_read_mapq, &c->b_read_cb, &c->b_seg_read, &c->b_seg_start, &c->b_seg_len,
-                      &c->b_seg_ev_off, &c->b_events, &c->d_read_key, &c->d_unit_cnt, &c->d_unit_off, &c->d_unit_fill,
+                      &c->b_seg_ev_off, &c->b_events, &c->d_read_key, &c->d_read_drop,
                       &c->d_ne_units, &c->d_ne_mask, &c->d_ne_rowbase, &c->d_ne_rowoff,
-                      &c->d_scalars, &c->d_cub_tmp, &c->d_ix0, &c->d_ix1, &c->d_ix2, &c->d_ix_netile, &c->d_ix_chunk, &c->d_ix_carry, &c->d_ix_stat, &c->d_tile_cap, &c->d_tile_off, &c->d_cur_lo, &c->d_cur_hi, &c->d_calls, &c->d_site_off, &c->d_tail_table, &c->d_pass_list};
+                      &c->d_scalars, &c->d_cub_tmp, &c->d_ix_stat, &c->d_tile_cap, &c->d_tile_off, &c->d_calls, &c->d_site_off, &c->d_tail_table, &c->d_pass_list};
     for (auto* b : bufs) b->release();
     for (auto& b : c->d_rows) b.release();
     for (auto& b : c->ref) b.release();
     for (auto& s : c->posset) s.keys.release();
     for (auto& b : c->syn) b.release();
+    for (auto& b : c->gen) b.release();
     for (auto& b : c->ws) b.release();
     for (auto& b : c->tm) b.release();
     for (auto& b : c->bt) b.release();
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+    for (auto& e : c->evb) if (e) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     delete c;
@@ -117,8 +127,8 @@ int lsg_set_contigs(lsg_ctx* c, int32_t n_contigs, const int64_t* lengths) {
     c->tile_base[n_contigs] = (uint32_t)t;
     c->n_tiles = (uint32_t)t;
     c->tile_lo = 0; c->tile_hi = (uint32_t)t;
-    c->tile_caps_valid = false; c->index_valid = false; c->tm_valid = false; c->layout_build_ms = 0; c->seen_counts = 0;
-    c->max_live_reads = -1; c->max_live_all = -1;
+    lsg::drop_store(c);                        // the store's tiles are the contigs' tiles: reads are loaded after the contigs
+    c->rd = lsg_reads{};
     for (auto& b : c->ref) b.release();
     c->ref.assign(n_contigs, DevBuf());
     c->ref_ptr.assign(n_contigs, nullptr);
@@ -138,7 +148,7 @@ int lsg_load_reference(lsg_ctx* c, int32_t tid, const uint8_t* bases, int64_t le
     if (len != c->contig_len[tid]) { set_error("lsg_load_reference: contig %d has length %lld, got %lld bases", tid, (long long)c->contig_len[tid], (long long)len); return -2; }
     LSG_HIP(hipSetDevice(c->device));
     const uint8_t* p = nullptr;
-    if (put<uint8_t>(c, c->ref[tid], p, bases, len > 0 ? len : 1, on_device)) return -1;
+    if (put_ref(c, c->ref[tid], p, bases, len > 0 ? len : 1, on_device)) return -1;
     c->ref_ptr[tid] = p;
     LSG_HIP(hipMemcpyAsync(c->d_ref_ptrs.as<const uint8_t*>() + tid, &c->ref_ptr[tid], sizeof(void*), hipMemcpyHostToDevice, c->stream));
     LSG_HIP(hipStreamSynchronize(c->stream));
@@ -169,32 +179,46 @@ int lsg_set_barcodes(lsg_ctx* c, const uint8_t* celltype_of, int32_t n_cb, int32
     return 0;
 }
 
+int lsg_set_keep_reads(lsg_ctx* c, int32_t keep) {
+    if (!c) { set_error("lsg_set_keep_reads: NULL handle"); return -2; }
+    c->keep_reads = keep != 0;
+    return 0;
+}
+
 int lsg_load_reads(lsg_ctx* c, const lsg_reads* r) {
     if (!c || !r) { set_error("lsg_load_reads: bad arguments"); return -2; }
+    if (c->n_contigs <= 0) { set_error("lsg_load_reads: set the contigs first (the store is laid out over their tiles)"); return -2; }
     if (r->n_reads < 0 || r->n_segs < 0 || r->n_events < 0) { set_error("lsg_load_reads: negative sizes"); return -2; }
     if (r->n_segs >= 0xFFFFFFF0ll || r->n_reads >= 0xFFFFFFF0ll) { set_error("lsg_load_reads: more than 2^32 reads/segments; load in windows"); return -2; }
     if (r->n_events >= (1ll << 40)) { set_error("lsg_load_reads: more than 2^40 events"); return -2; }
     LSG_HIP(hipSetDevice(c->device));
+    lsg::drop_store(c);
+    const lsg_reads in = *r;                  // (r may point at c->rd's own arrays: lsg_synth_reads)
     c->rd = lsg_reads{};
-    c->rd.n_reads = r->n_reads; c->rd.n_segs = r->n_segs; c->rd.n_events = r->n_events; c->rd.on_device = 1;
-    int d = r->on_device;
-    if (put(c, c->b_read_tid, c->rd.read_tid, r->read_tid, r->n_reads, d) ||
-        put(c, c->b_read_pos, c->rd.read_pos, r->read_pos, r->n_reads, d) ||
-        put(c, c->b_read_flag, c->rd.read_flag, r->read_flag, r->n_reads, d) ||
-        put(c, c->b_read_mapq, c->rd.read_mapq, r->read_mapq, r->n_reads, d) ||
-        put(c, c->b_read_cb, c->rd.read_cb, r->read_cb, r->n_reads, d) ||
-        put(c, c->b_seg_read, c->rd.seg_read, r->seg_read, r->n_segs, d) ||
-        put(c, c->b_seg_start, c->rd.seg_start, r->seg_start, r->n_segs, d) ||
-        put(c, c->b_seg_len, c->rd.seg_len, r->seg_len, r->n_segs, d) ||
-        put(c, c->b_seg_ev_off, c->rd.seg_ev_off, r->seg_ev_off, r->n_segs, d) ||
-        put(c, c->b_events, c->rd.events, r->events, r->n_events, d))
-        return -1;
-    if (r->n_reads > 0 && (!c->rd.read_tid || !c->rd.read_flag || !c->rd.read_mapq || !c->rd.read_cb)) { set_error("lsg_load_reads: NULL read array"); return -2; }
-    if (r->n_segs > 0 && (!c->rd.seg_read || !c->rd.seg_start || !c->rd.seg_len || !c->rd.seg_ev_off)) { set_error("lsg_load_reads: NULL segment array"); return -2; }
+    c->rd.n_reads = in.n_reads; c->rd.n_segs = in.n_segs; c->rd.n_events = in.n_events; c->rd.on_device = 1;
+    const int d = in.on_device;
+    if (in.n_reads > 0 && (!in.read_tid || !in.read_flag || !in.read_mapq || !in.read_cb)) { c->rd = lsg_reads{}; set_error("lsg_load_reads: NULL read array"); return -2; }
+    if (in.n_segs > 0 && (!in.seg_read || !in.seg_start || !in.seg_len || !in.seg_ev_off)) { c->rd = lsg_reads{}; set_error("lsg_load_reads: NULL segment array"); return -2; }
+    if (in.n_events > 0 && !in.events) { c->rd = lsg_reads{}; set_error("lsg_load_reads: NULL events array"); return -2; }
+    // the small arrays (15 bytes per read, 12 per segment) are always copied: admission, the depth cap and the statistics read them
+    if (put(c, c->b_read_tid, c->rd.read_tid, in.read_tid, in.n_reads, d) ||
+        put(c, c->b_read_pos, c->rd.read_pos, in.read_pos, in.n_reads, d) ||
+        put(c, c->b_read_flag, c->rd.read_flag, in.read_flag, in.n_reads, d) ||
+        put(c, c->b_read_mapq, c->rd.read_mapq, in.read_mapq, in.n_reads, d) ||
+        put(c, c->b_read_cb, c->rd.read_cb, in.read_cb, in.n_reads, d) ||
+        put(c, c->b_seg_read, c->rd.seg_read, in.seg_read, in.n_segs, d) ||
+        put(c, c->b_seg_start, c->rd.seg_start, in.seg_start, in.n_segs, d) ||
+        put(c, c->b_seg_len, c->rd.seg_len, in.seg_len, in.n_segs, d)) { c->rd = lsg_reads{}; return -1; }
+    // the events and their offsets: device arrays are read where they lie, host arrays through a staging copy; neither outlives the call
+    // unless lsg_set_keep_reads asked for it
+    const uint16_t* ev = in.events; const int64_t* evo = in.seg_ev_off;
+    const bool staged = !d || c->keep_reads;
+    if (staged && (put(c, c->b_seg_ev_off, evo, in.seg_ev_off, in.n_segs, d) || put(c, c->b_events, ev, in.events, in.n_events, d))) { c->rd = lsg_reads{}; return -1; }
     LSG_HIP(hipStreamSynchronize(c->stream));
-    c->counted = c->called = false;
-    if (int rc = lsg::relayout_events(c)) { c->rd = lsg_reads{}; c->entries_upper = 0; return rc; }      // a refused load leaves no reads behind
-    return compute_entries_upper(c);
+    if (int rc = lsg::build_store(c, ev, in.n_events, evo)) { c->rd = lsg_reads{}; lsg::drop_store(c); return rc; }      // a refused load leaves no reads behind
+    if (c->keep_reads) { c->rd.events = ev; c->rd.seg_ev_off = evo; }
+    else { c->b_events.release(); c->b_seg_ev_off.release(); }
+    return 0;
 }
 
 int lsg_set_region(lsg_ctx* c, int32_t tid_lo, int64_t pos_lo, int32_t tid_hi, int64_t pos_hi) {
@@ -224,19 +248,6 @@ int lsg_pileup_count(lsg_ctx* c, const lsg_count_params* params, int64_t* n_rows
     return 0;
 }
 
-int lsg_prepare_counts(lsg_ctx* c, const lsg_count_params* params) {
-    if (!c || !params) { set_error("lsg_prepare_counts: bad arguments"); return -2; }
-    if (c->n_contigs <= 0 || c->n_ct <= 0 || (!c->rd.events && c->rd.n_events > 0)) { set_error("lsg_prepare_counts: contigs, barcodes and reads must be set first"); return -2; }
-    LSG_HIP(hipSetDevice(c->device));
-    return prepare_layout(c, params);
-}
-
-int lsg_set_layout_policy(lsg_ctx* c, int32_t policy) {
-    if (!c || policy < 0 || policy > 2) { set_error("lsg_set_layout_policy: bad arguments"); return -2; }
-    c->layout_policy = policy;
-    return 0;
-}
-
 int lsg_fetch_counts(lsg_ctx* c, int32_t ct, int64_t* keys, uint8_t* ref, uint32_t* counts, int64_t capacity) {
     if (!c || !keys || !ref || !counts) { set_error("lsg_fetch_counts: bad arguments"); return -2; }
     LSG_HIP(hipSetDevice(c->device));
@@ -250,6 +261,27 @@ int64_t lsg_max_live_reads(lsg_ctx* c) {
     return c->max_live_reads;
 }
 
+int64_t lsg_max_live_reads_all(lsg_ctx* c) {
+    if (!c) { set_error("lsg_max_live_reads_all: bad arguments"); return -1; }
+    if (hipSetDevice(c->device) != hipSuccess) { set_error("lsg_max_live_reads_all: hipSetDevice failed"); return -1; }
+    if (lsg::live_read_bound_all(c)) return -1;
+    return c->max_live_all;
+}
+
+int lsg_get_store_shape(lsg_ctx* c, int64_t* n_entries, int64_t* n_blocks, int64_t* n_events) {
+    if (!c) { set_error("lsg_get_store_shape: NULL handle"); return -2; }
+    if (n_entries) *n_entries = (int64_t)c->tm_n;
+    if (n_blocks) *n_blocks = (int64_t)c->tm_nblk;
+    if (n_events) *n_events = c->tm_events;
+    return 0;
+}
+
+int lsg_get_build_times(lsg_ctx* c, float* ms4) {
+    if (!c || !ms4) { set_error("lsg_get_build_times: bad arguments"); return -2; }
+    for (int i = 0; i < 4; ++i) ms4[i] = c->build_ms[i];
+    return 0;
+}
+
 int lsg_get_count_stats(lsg_ctx* c, lsg_count_stats* out) {
     if (!c || !out) { set_error("lsg_get_count_stats: bad arguments"); return -2; }
     *out = c->stats;
@@ -258,13 +290,15 @@ int lsg_get_count_stats(lsg_ctx* c, lsg_count_stats* out) {
 
 int lsg_get_layout_info(lsg_ctx* c, int32_t* path, double* build_ms, int64_t* store_bytes) {
     if (!c) { set_error("lsg_get_layout_info: NULL handle"); return -2; }
-    if (path) *path = c->tm_path ? 2 : (c->index_path ? 1 : 0);
+    if (path) *path = 2;
     if (build_ms) *build_ms = c->layout_build_ms;
     if (store_bytes) {
         int64_t b = 0;
         for (auto& x : c->tm) b += (int64_t)x.cap;
         for (auto& x : c->bt) b += (int64_t)x.cap;
-        for (DevBuf* x : {&c->d_ix0, &c->d_ix1, &c->d_ix2, &c->d_ix_netile, &c->d_ix_chunk, &c->d_tile_cap, &c->d_tile_off}) b += (int64_t)x->cap;
+        for (DevBuf* x : {&c->d_tile_cap, &c->d_tile_off, &c->b_events, &c->b_seg_ev_off, &c->b_read_tid, &c->b_read_pos, &c->b_read_flag, &c->b_read_mapq, &c->b_read_cb,
+                          &c->b_seg_read, &c->b_seg_start, &c->b_seg_len}) b += (int64_t)x->cap;
+        b += (int64_t)c->ws[WS_SEG_INFO].cap;
         *store_bytes = b;
     }
     return 0;

@@ -56,17 +56,39 @@ struct DevBuf {
 struct PosSet { DevBuf keys; int64_t n = 0; };
 
 // workspace buffers (lsg_ctx::ws)
-enum { WS_SLOT_PEX = 0, WS_NE_NSLOT, WS_NE_SLOT_BASE, WS_NE_ACC, WS_NE_GEOM, WS_SLOT_W, WS_SLOT_CNT,
-       WS_SLOT_OFF, WS_ENT, WS_CHUNK_START, WS_REC, WS_SLOT_LIST, WS_MULTI_LIST, WS_MACC, WS_EXPORT_K, WS_EXPORT_R,
-       WS_EXPORT_C, WS_SLICES, WS_HUGE_LIST, WS_CALL_FLAGS, WS_CALL_SEL, WS_CALL_CANDS, WS_CALL_TASKS, WS_SEG_INFO };
+enum { WS_NE_NSLOT = 0, WS_NE_ACC, WS_NE_GEOM, WS_MULTI_LIST, WS_MACC, WS_EXPORT_K, WS_EXPORT_R,
+       WS_EXPORT_C, WS_CALL_FLAGS, WS_CALL_SEL, WS_CALL_CANDS, WS_CALL_TASKS, WS_SEG_INFO };
 
+// ---- tile store (store.hip builds it at load, pileup.hip counts over it, genotype.hip looks single sites up in it) -------------
+// The resident form of the reads' events: every (segment x 64-position tile) ENTRY of a read that carries a barcode, the entries of a
+// tile adjacent and sorted by barcode, eight entries to a 1 KB block held transposed ([position 0..63][entry 0..7], 16 bytes per
+// position), every tile padded to whole blocks.  Independent of count parameters and of the barcode -> cell-type table.
+//   s0[p]  cb [0..23] | forward << 30 | first entry of its barcode's run in the tile << 31          (pad entries: cb = CB_MASK, run start)
+//   b[p]   events - 1 [0..5] | first entry of its segment << 6 | run of exactly one entry << 7
+//   fm[p]  SAM flag (16 bits, LSG_FLAG_CB_SUFFIX included) | MAPQ << 16                              (pad entries: 0xffff)
+//   rd[p]  owning read (what the pileup's max_depth rule drops is decided per read)
+constexpr uint32_t CB_MASK = 0x00FFFFFFu;
+constexpr uint32_t TM_RUNSTART = 1u << 31, TM_FWD = 1u << 30;
+constexpr uint32_t TM_PAD_S0 = CB_MASK | TM_RUNSTART;
+constexpr int TM_GROUP = 4;                 // blocks a wave of the walk loads per group: the arrays are padded by one group
+enum { TM_STORE = 0, TM_S0, TM_B, TM_FM, TM_RD, TM_META, TM_BLK_TILE, TM_BLK_OFF, TM_EXT,                                // per load
+       TM_JOBS, TM_NE_UNITS, TM_NE_GEOM, TM_NE_NSLOT, TM_NE_ACC, TM_MULTI, TM_CHUNKS, TM_NBUF };                          // the plan: per load and number of cell types
+// one job of the walk: a tile, or a run-aligned piece of a deep one.  e0, e1: padded-entry range; w0: unit of (tile, cell type 0);
+// slab: of (job, cell type 0) or ~0; nj: jobs of the tile, bit 31 = the job is longer than the packed planes' fields hold (k_tm_walk_wide
+// takes it); cnt: entries of the tile; emid: where the job's second wave starts (a run start, or e1)
+struct TmJob { uint32_t e0, e1, w0, slab, nj, cnt, tile, emid; };
+constexpr uint32_t TMJ_WIDE = 1u << 31;
+constexpr int TM_JOB_TGT = 3072, TM_JOB_LIMIT = 4095;      // LIMIT: what the planes' 12-bit forward field holds; a cut moves forward to the next run start
 
 } // namespace lsg
 
 struct lsg_ctx;
 namespace lsg {
-int relayout_events(lsg_ctx* c);   // layout.hip: tile-aligned copy of the resident events
+int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int64_t* seg_ev_off);   // store.hip: the load's tile store from the caller's compact events
+int ensure_plan(lsg_ctx* c);       // store.hip: jobs / units / slabs of a count over the store for the current number of cell types
+void drop_store(lsg_ctx* c);       // store.hip: new reads or contigs
 int live_read_bound(lsg_ctx* c);   // layout.hip: fills max_live_reads when it is stale (-1)
+int live_read_bound_all(lsg_ctx* c);
 int depth_cap_drops(lsg_ctx* c, const lsg_count_params* p);   // layout.hip: htslib's max_depth rule -> d_read_drop (or none)
 }
 
@@ -75,6 +97,7 @@ struct lsg_ctx {
     hipStream_t stream = nullptr;
     hipStream_t own_stream = nullptr;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t evb[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};      // store.hip: the build's phases
 
     // genome
     int32_t n_contigs = 0;
@@ -95,30 +118,19 @@ struct lsg_ctx {
     lsg_reads rd{};                       // device pointers
     lsg::DevBuf b_read_tid, b_read_pos, b_read_flag, b_read_mapq, b_read_cb;
     lsg::DevBuf b_seg_read, b_seg_start, b_seg_len, b_seg_ev_off, b_events;
-    uint64_t entries_upper = 0;           // sum over segments of tiles overlapped
-    // static per load: entries a tile can ever hold (segments of reads with a barcode that touch it) and their exclusive prefix = the
-    // tile's region of the entry buffer; with <= 2 cell types the scatter fills a region from both ends and needs no counting pass
-    lsg::DevBuf d_tile_cap, d_tile_off, d_cur_lo, d_cur_hi;
-    bool tile_caps_valid = false;
-    // pileup.hip "tile index": every tile's entries sorted by barcode ONCE per load (independent of parameters and of the barcode ->
-    // cell-type table); a count then resolves admission and cell type in one streaming pass instead of scattering and sorting again
-    lsg::DevBuf d_ix0, d_ix1, d_ix2, d_ix_netile, d_ix_chunk, d_ix_carry, d_ix_stat;
-    uint64_t ix_n = 0;                    // static entries
-    uint32_t ix_n_netile = 0;             // tiles that hold any
-    bool index_valid = false;
-    bool index_path = false;              // the last / current count runs on the tile index
-    // pileup.hip "tile-major store": the admitted entries' events in index order, eight entries to a transposed 1 KB block, with the
-    // static job / unit / slab tables of a count over it; keyed on the read filters and the number of cell types
-    lsg::DevBuf tm[16];
-    lsg::DevBuf bt[10];                   // temporaries of the index / store build (kept: device allocation is what a rebuild would wait for)
-    uint64_t tm_np = 0;                   // padded entries
-    uint32_t tm_nblk = 0, tm_njobs = 0, tm_nchunks = 0, tm_n_ne = 0, tm_n_multi = 0, tm_n_slabs = 0;
-    int64_t tm_key[4] = {0, 0, 0, 0};     // min_mq, flag_exclude, ignore_orphans, n_ct
-    bool tm_valid = false, tm_usable = false;
-    bool tm_path = false;                 // the last / current count runs on the tile-major store
-    double layout_build_ms = 0;           // wall time spent building the index / store for the current reads (lsg_get_layout_info)
-    int layout_policy = 0;                // lsg_set_layout_policy: 0 auto (from the second count of a load), 1 eager, 2 never
-    int64_t seen_key[4] = {-1, -1, -1, -1}; uint32_t seen_counts = 0;      // read filters of the last count and how many counts of this load used them
+    bool keep_reads = false;              // lsg_set_keep_reads: the compact events stay resident beside the store (rd.events; tests, sampling)
+    // tile store (see above) and the plan of a count over it
+    lsg::DevBuf d_tile_cap, d_tile_off;   // entries per tile and their exclusive prefix
+    lsg::DevBuf tm[lsg::TM_NBUF];
+    lsg::DevBuf bt[12];                   // temporaries of the build (kept while they are small against the device: allocation is what a rebuild would wait for)
+    uint64_t tm_n = 0;                    // entries
+    int64_t tm_events = 0;                // events they hold
+    uint64_t tm_np = 0;                   // padded entries = 8 x blocks
+    uint32_t tm_nblk = 0, tm_njobs = 0, tm_nchunks = 0, tm_n_ne = 0, tm_n_multi = 0, tm_n_slabs = 0, tm_n_wide = 0;
+    int plan_n_ct = 0;                    // cell types the plan was made for (0: none)
+    bool tm_valid = false;
+    double layout_build_ms = 0;           // wall time of the last build (lsg_get_layout_info)
+    float build_ms[4] = {0, 0, 0, 0};     // HIP-event times of the last build: capacities + scatter, sort, fill, gather
     int64_t max_live_reads = -1;          // layout.hip: bound on the reads live at once in the reference's pileup buffer (-1 = stale)
     int64_t max_live_all = -1;            // the same over all reads with a barcode: table-independent, cached per load
     lsg::DevBuf d_read_drop;              // layout.hip: per read, 1 = dropped by the pileup's max_depth rule under the last count's parameters
@@ -126,12 +138,12 @@ struct lsg_ctx {
     int64_t n_depth_dropped = 0;
 
     // count-stage workspace
-    lsg::DevBuf d_read_key, d_unit_cnt, d_unit_off, d_unit_fill;
-    lsg::DevBuf d_ne_units, d_ne_mask, d_ne_rowbase, d_ne_rowoff, d_scalars, d_cub_tmp;
+    lsg::DevBuf d_read_key;
+    lsg::DevBuf d_ne_units, d_ne_mask, d_ne_rowbase, d_ne_rowoff, d_scalars, d_cub_tmp, d_ix_stat;
     lsg::DevBuf d_rows[LSG_MAX_CELLTYPES]; // blocked planes, see lsg::row_word
     uint64_t row_cap = 0;
     uint32_t arena = 256;                  // rows a wave reserves per allocation in the current count (multiple of 256)
-    uint32_t n_ne = 0, n_deep = 0;
+    uint32_t n_ne = 0;
     int64_t n_rows[LSG_MAX_CELLTYPES] = {0, 0, 0, 0};
     int64_t n_columns = 0;
     lsg_count_params last_params{};
@@ -147,8 +159,9 @@ struct lsg_ctx {
 
     lsg::PosSet posset[3];
     lsg::DevBuf syn[12];                  // synthetic-model tables + scan scratch (synth.hip)
-    lsg::DevBuf ws[32];                   // count-stage workspace (pileup.hip, enum WS_*)
+    lsg::DevBuf gen[10];                  // the arrays lsg_synth_generate last produced
+    lsg::DevBuf ws[16];                   // count-stage workspace (pileup.hip, enum WS_*)
     int n_cus = 256;
     unsigned long long* h_pin = nullptr;  // 4 KB of pinned host memory: landing zone of the small device -> host reads between phases
-    uint32_t n_slots = 0, n_multi = 0;
+    uint32_t n_multi = 0;
 };

@@ -1,0 +1,612 @@
+// The tile store: what lsg_load_reads leaves in HBM (lsg_ctx.h).
+//
+// A pileup IS the transposition of read-major events into column order.  The reference does it per 50 kb window with htslib's
+// bam_plp behind bam.pileup(...) (workflow/scripts/SNVCalling/BaseCellCounter.py:190-198); here it is done ONCE per load, on the
+// device, straight from the caller's compact read-record arrays:
+//   1. capacities   every (segment x 64-position tile) overlap of a read that carries a barcode is one ENTRY; a counting pass over the
+//                   segments gives every tile's number of entries (k_seg_static, k_bin<0>), a scan its region
+//   2. scatter      k_bin<2> writes a 16-byte record per entry into its tile's region, in arrival order, beside its sort key (barcode)
+//   3. sort         the entries of each tile by barcode (segmented radix sort over the tile regions): equal barcodes become adjacent
+//                   RUNS, which is what turns len(set(cells)) (BaseCellCounter.py:283,292) into "entries minus duplicates in a run"
+//   4. fill         per entry, in that order: barcode / strand / run flags, events - 1, SAM flag and MAPQ (admission is decided per
+//                   count), owning read, and where its events lie in the caller's array
+//   5. gather       eight entries to a 1 KB block held transposed ([position 0..63][entry 0..7]): each entry's <= 128 bytes arrive by
+//                   16-byte loads (eight lanes per entry: one wave-instruction fetches a whole block), cross an LDS tile and leave as
+//                   one kilobyte store per block; the block's extent (first / last position with an event) beside it
+// Nothing here depends on count parameters or on the barcode -> cell-type table, so the caller's events are not needed again: the
+// store is the only resident copy (lsg_set_keep_reads keeps them for tests).  The plan of a count over the store (jobs, units, slabs:
+// ensure_plan) depends on the number of cell types only.
+#include "lsg_ctx.h"
+#include <hipcub/hipcub.hpp>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+
+namespace lsg {
+
+constexpr uint32_t KEY_INVALID = 0xFFFFFFFFu;
+
+struct BuildArgs {
+    int64_t n_reads, n_segs, n_events;
+    const int32_t* read_tid; const uint16_t* read_flag; const uint8_t* read_mapq; const int32_t* read_cb;
+    const uint32_t* seg_read; const int32_t* seg_start; const int32_t* seg_len; const int64_t* seg_ev_off;
+    const uint32_t* tile_base; const int64_t* contig_len;
+    int32_t n_contigs; uint32_t n_tiles;
+    uint2* seg_info;                      // per segment {barcode | reverse << 24, or KEY_INVALID; first tile of its contig}
+    uint32_t* tile_cap;                   // MODE 0: entries per tile
+    uint32_t* cursor;                     // MODE 2: next free place of every tile's region
+    uint4* rec; uint32_t* key; uint32_t* val;
+    unsigned long long* qhead;            // work queue head of the binning pass
+    uint32_t* bad;                        // bit 0: a segment's event range lies outside the events; bit 1: a segment's read index outside the reads
+    unsigned long long* n_ev;             // events of the statically admitted segments = events the store will hold
+};
+
+// Static admission of a segment: its read carries a barcode and lies on a contig, the segment lies inside the contig (what ANY count
+// parameters or barcode table can admit; malformed segments are never counted).  Also the load's validation of the caller's arrays.
+__global__ void k_seg_static(BuildArgs a) {
+    unsigned long long n_ev = 0;
+    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < a.n_segs; s += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t r = a.seg_read[s];
+        uint32_t key = KEY_INVALID, tb = 0;
+        if ((int64_t)r >= a.n_reads) atomicOr(a.bad, 2u);
+        else {
+            const int64_t st = a.seg_start[s], ln = a.seg_len[s], o = a.seg_ev_off[s];
+            if (ln > 0 && (o < 0 || o + ln > a.n_events)) atomicOr(a.bad, 1u);
+            else {
+                const int32_t tid = a.read_tid[r], cb = a.read_cb[r];
+                if (tid >= 0 && tid < a.n_contigs && cb >= 0 && (uint32_t)cb < CB_MASK && !(st < 0 || ln <= 0 || st + ln > a.contig_len[tid])) {
+                    key = (uint32_t)cb | ((((uint32_t)a.read_flag[r] >> 4) & 1u) << 24);
+                    tb = a.tile_base[tid];
+                    n_ev += (unsigned long long)ln;
+                }
+            }
+        }
+        a.seg_info[s] = make_uint2(key, tb);
+    }
+    for (int o = 32; o > 0; o >>= 1) n_ev += __shfl_down(n_ev, o);
+    __shared__ unsigned long long s_ev;
+    if (threadIdx.x == 0) s_ev = 0;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0 && n_ev) atomicAdd(&s_ev, n_ev);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_ev) atomicAdd(a.n_ev, s_ev);
+}
+
+// Counting sort of (segment, tile) pairs over the segments, with the atomics aggregated per workgroup in an LDS hash.  The segments
+// of a coordinate-sorted BAM arrive gene by gene, so consecutive batches of 256 segments hit the same few tiles: a workgroup dequeues
+// BIN_SUPER consecutive batches and keeps accumulating (batch, 8-tile round) items in the hash until it is 5/8 full, then issues ONE
+// global atomic per distinct tile for the whole chunk.  (A deep gene funnels thousands of batches into a few cache lines of the
+// counters; same-line atomics serialise in L2 at ~90 per microsecond, so their number is what counts.)
+//   MODE 0: count entries per tile.  MODE 2: claim a range per tile, then replay the chunk's items and write the entries' records.
+constexpr int BIN_THREADS = 256;
+constexpr int BIN_TPR = 8;             // tiles per segment handled per item
+constexpr int BIN_H = 4096;            // LDS hash slots
+constexpr int BIN_SUPER = 16;          // batches per dequeue
+constexpr int BIN_MAXI = 32;           // items per chunk
+constexpr uint32_t BIN_FILL = BIN_H * 5 / 8;
+
+struct BinSeg { uint32_t key, tb, t0, rd; int32_t st, ln, ntile; int64_t evoff; };
+
+template <int MODE>
+__device__ __forceinline__ BinSeg bin_load(const BuildArgs& a, int64_t s) {
+    BinSeg g; g.key = KEY_INVALID; g.tb = 0; g.t0 = 0; g.rd = 0; g.st = 0; g.ln = 0; g.ntile = 0; g.evoff = 0;
+    if (s < a.n_segs) {
+        const uint2 info = a.seg_info[s];
+        g.key = info.x; g.tb = info.y;
+        if (g.key != KEY_INVALID) {
+            g.st = a.seg_start[s]; g.ln = a.seg_len[s];
+            if (MODE == 2) { g.evoff = a.seg_ev_off[s]; g.rd = a.seg_read[s]; }
+            g.t0 = g.tb + ((uint32_t)g.st >> 6);
+            g.ntile = (int)(((uint32_t)(g.st + g.ln - 1) >> 6) - ((uint32_t)g.st >> 6)) + 1;
+        }
+    }
+    return g;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(BIN_THREADS) void k_bin(BuildArgs a) {
+    __shared__ uint32_t hkey[BIN_H], hcnt[BIN_H];      // MODE 2: hcnt turns into the tile's write cursor after the flush
+    __shared__ uint32_t s_newb[BIN_MAXI], s_ib[BIN_MAXI], s_ir[BIN_MAXI];
+    __shared__ int s_maxb[BIN_MAXI];
+    __shared__ uint32_t s_super;
+    const int t = threadIdx.x, lane = t & 63;
+    constexpr int HSHIFT = 32 - __builtin_ctz(BIN_H);
+    for (int i = t; i < BIN_H; i += BIN_THREADS) { hkey[i] = KEY_INVALID; hcnt[i] = 0; }
+    const int64_t n_batches = (a.n_segs + BIN_THREADS - 1) / BIN_THREADS;
+    const int64_t n_super = (n_batches + BIN_SUPER - 1) / BIN_SUPER;
+    for (bool first = true;; first = false) {
+        __syncthreads();
+        // every workgroup's first item is its own index: no storm of same-address atomics at launch
+        if (t == 0) s_super = first ? blockIdx.x : (uint32_t)atomicAdd(a.qhead, 1ull) + gridDim.x;
+        __syncthreads();
+        const int64_t sup = s_super;
+        if (sup >= n_super) break;
+        const int64_t b0 = sup * BIN_SUPER;
+        const int64_t b1 = b0 + BIN_SUPER < n_batches ? b0 + BIN_SUPER : n_batches;
+        int64_t cb = b0; int cr = 0;                 // next item: round cr of batch cb
+        while (cb < b1) {
+            // ---- pass A: accumulate items in the hash
+            if (t < BIN_MAXI) { s_newb[t] = 0; s_maxb[t] = 0; }
+            __syncthreads();
+            int ni = 0; uint32_t tot = 0;
+            int64_t b = cb; int r = cr;
+            bool stop = false;
+            while (!stop && b < b1) {
+                const BinSeg g = bin_load<MODE>(a, b * BIN_THREADS + t);
+                const int ni_first = ni;
+                int wmax = g.ntile;
+                for (int o = 32; o > 0; o >>= 1) { int v = __shfl_down(wmax, o); wmax = v > wmax ? v : wmax; }
+                if (lane == 0 && wmax) atomicMax(&s_maxb[ni_first], wmax);
+                int R = -1;
+                for (;;) {
+                    uint32_t newc = 0;
+#pragma unroll
+                    for (int j = 0; j < BIN_TPR; ++j) {
+                        const int k = r * BIN_TPR + j;
+                        if (k < g.ntile) {
+                            const uint32_t x = g.t0 + (uint32_t)k;
+                            uint32_t h = (x * 2654435761u) >> HSHIFT;
+                            while (true) {
+                                uint32_t prev = atomicCAS(&hkey[h], KEY_INVALID, x);
+                                if (prev == KEY_INVALID) { ++newc; break; }
+                                if (prev == x) break;
+                                h = (h + 1) & (BIN_H - 1);
+                            }
+                            atomicAdd(&hcnt[h], 1u);
+                        }
+                    }
+                    for (int o = 32; o > 0; o >>= 1) newc += __shfl_down(newc, o);
+                    if (lane == 0 && newc) atomicAdd(&s_newb[ni], newc);
+                    if (t == 0) { s_ib[ni] = (uint32_t)(b - b0); s_ir[ni] = (uint32_t)r; }
+                    __syncthreads();
+                    if (R < 0) R = (s_maxb[ni_first] + BIN_TPR - 1) / BIN_TPR;
+                    tot += s_newb[ni];
+                    ++ni; ++r;
+                    if (r >= R) { ++b; r = 0; }
+                    if (ni >= BIN_MAXI || tot + BIN_THREADS * BIN_TPR > BIN_FILL) { stop = true; break; }
+                    if (r == 0) break;
+                }
+            }
+            // ---- one global atomic per distinct tile of the chunk
+            for (int i = t; i < BIN_H; i += BIN_THREADS) {
+                const uint32_t cnt = hcnt[i];
+                if (cnt) {
+                    if (MODE == 0) { atomicAdd(&a.tile_cap[hkey[i]], cnt); hkey[i] = KEY_INVALID; hcnt[i] = 0; }
+                    else hcnt[i] = atomicAdd(&a.cursor[hkey[i]], cnt);       // first place of this workgroup's range in the tile's region
+                }
+            }
+            __syncthreads();
+            if (MODE == 2) {
+                // ---- pass B: replay the items, write the entries
+                for (int it = 0; it < ni; ++it) {
+                    const int64_t bb = b0 + s_ib[it];
+                    const int rr = (int)s_ir[it];
+                    const BinSeg g = bin_load<MODE>(a, bb * BIN_THREADS + t);
+#pragma unroll
+                    for (int j = 0; j < BIN_TPR; ++j) {
+                        const int k = rr * BIN_TPR + j;
+                        if (k < g.ntile) {
+                            const uint32_t x = g.t0 + (uint32_t)k;
+                            uint32_t h = (x * 2654435761u) >> HSHIFT;
+                            while (hkey[h] != x) h = (h + 1) & (BIN_H - 1);
+                            const uint32_t pos = atomicAdd(&hcnt[h], 1u);
+                            const int32_t tstart = (int32_t)((x - g.tb) << 6);
+                            const int32_t lo = g.st > tstart ? g.st : tstart;
+                            const int32_t hi = g.st + g.ln < tstart + TILE_W ? g.st + g.ln : tstart + TILE_W;
+                            const uint64_t src = (uint64_t)(g.evoff + (lo - g.st));             // the entry's first event in the caller's array
+                            const uint32_t cbk = g.key & CB_MASK;
+                            a.rec[pos] = make_uint4(cbk | ((uint32_t)(hi - lo - 1) << 24) | (((g.key >> 24) & 1u) ? 0u : TM_FWD) | (lo == g.st ? TM_RUNSTART : 0u),
+                                                    g.rd, (uint32_t)src, (uint32_t)(src >> 32) | ((uint32_t)(lo - tstart) << 8));
+                            a.key[pos] = cbk;
+                            a.val[pos] = pos;
+                        }
+                    }
+                }
+                __syncthreads();
+                for (int i = t; i < BIN_H; i += BIN_THREADS)
+                    if (hkey[i] != KEY_INVALID) { hkey[i] = KEY_INVALID; hcnt[i] = 0; }
+            }
+            cb = b; cr = r;
+        }
+    }
+}
+
+// per tile: blocks, and a flag for the non-empty ones
+__global__ void k_tile_blocks(const uint32_t* cap, uint32_t n_tiles, uint32_t* blk) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t <= n_tiles) blk[t] = t < n_tiles ? (cap[t] + 7u) / 8u : 0u;
+}
+struct CapNonZero {
+    const uint32_t* cap;
+    __host__ __device__ bool operator()(const uint32_t& t) const { return cap[t] != 0; }
+};
+__global__ void k_seg_bounds(const uint32_t* netile, uint32_t n, const uint32_t* tile_off, uint32_t* begin, uint32_t* end) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const uint32_t t = netile[i]; begin[i] = tile_off[t]; end[i] = tile_off[t + 1]; }
+}
+// largest t in [0, n) with off[t] <= x (off non-decreasing, off[0] <= x): the tile whose blocks hold x, skipping empty ones
+__device__ __forceinline__ uint32_t tm_owner(const uint32_t* off, uint32_t n, uint32_t x) {
+    uint32_t lo = 0, hi = n;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (off[mid] <= x) lo = mid; else hi = mid; }
+    return lo;
+}
+__global__ void k_tm_blk_tile(const uint32_t* blk_off, uint32_t n_tiles, uint32_t nblk, uint32_t* blk_tile) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < nblk) blk_tile[b] = tm_owner(blk_off, n_tiles, b);
+}
+
+// per padded entry: the static words of the store, and where its events lie in the caller's array
+__global__ void k_tm_fill(const uint32_t* key, const uint32_t* val, const uint4* rec, const uint16_t* read_flag, const uint8_t* read_mapq,
+                          const uint32_t* tile_off, const uint32_t* blk_off, const uint32_t* blk_tile, uint64_t np,
+                          uint32_t* s0, uint8_t* b8, uint32_t* fm, uint32_t* rd, uint2* gsrc) {
+    for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < np; p += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t t = blk_tile[p >> 3];
+        const uint32_t i = (uint32_t)(p - (uint64_t)blk_off[t] * 8), off = tile_off[t], n = tile_off[t + 1] - off;
+        if (i >= n) { s0[p] = TM_PAD_S0; b8[p] = 0; fm[p] = 0xffffu; rd[p] = 0; gsrc[p] = make_uint2(0u, 0u); continue; }
+        const uint32_t j = off + i, k = key[j];
+        const uint4 e = rec[val[j]];
+        const bool rs = i == 0 || key[j - 1] != k;
+        const bool single = rs && (i + 1 == n || key[j + 1] != k);
+        s0[p] = k | (e.x & TM_FWD) | (rs ? TM_RUNSTART : 0u);
+        b8[p] = (uint8_t)(((e.x >> 24) & 63u) | ((e.x >> 31) ? 64u : 0u) | (single ? 128u : 0u));
+        fm[p] = (uint32_t)read_flag[e.y] | ((uint32_t)read_mapq[e.y] << 16);
+        rd[p] = e.y;
+        gsrc[p] = make_uint2(e.z, e.w);
+    }
+}
+
+// One wave per TMG_BLOCKS blocks.  Lane = (entry u of the block, 16-byte chunk c of its <= 128 bytes): ONE load instruction per block
+// fetches all eight entries from wherever they lie in the caller's array (2-byte aligned: the hardware takes unaligned dwordx4).  The
+// chunks cross an LDS tile [entry][64 events]; lane = position then picks, per entry, the event at (position - first position of the
+// entry) and the block leaves as one transposed kilobyte.
+constexpr int TMG_BLOCKS = 4, TMG_WAVES = 4;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+struct __attribute__((packed, aligned(2))) U4A2 { u32x4 v; };
+__global__ __launch_bounds__(TMG_WAVES * 64) void k_tm_gather(const uint16_t* events, int64_t n_events, const uint32_t* s0, const uint8_t* b8, const uint2* gsrc,
+                                                               uint32_t nblk, uint4* store, uint16_t* ext) {
+    __shared__ __attribute__((aligned(16))) uint16_t lds[TMG_WAVES][TMG_BLOCKS][8][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t blk0 = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * TMG_BLOCKS;
+    if (blk0 >= nblk) return;
+    const int u = lane >> 3, c = lane & 7;
+    u32x4 chunk[TMG_BLOCKS];
+    uint32_t info[TMG_BLOCKS];                      // first position [0..7] | events [8..15] of the lane's entry (0 events: not there)
+#pragma unroll
+    for (int q = 0; q < TMG_BLOCKS; ++q) {
+        chunk[q] = u32x4{0u, 0u, 0u, 0u}; info[q] = 0;
+        const uint32_t blk = blk0 + q;
+        if (blk >= nblk) continue;
+        const uint64_t p = (uint64_t)blk * 8 + u;
+        if ((s0[p] & CB_MASK) == CB_MASK) continue;
+        const uint2 g = gsrc[p];
+        const uint32_t nev = ((uint32_t)b8[p] & 63u) + 1u;
+        info[q] = ((g.y >> 8) & 63u) | (nev << 8);
+        if ((uint32_t)c * 8u < nev) {
+            const int64_t off = (int64_t)(((uint64_t)(g.y & 0xffu) << 32) | g.x) + c * 8;
+            if (off + 8 <= n_events) chunk[q] = reinterpret_cast<const U4A2*>(events + off)->v;
+            else {                                   // the last events of the array: never read past it
+                uint32_t w[4] = {0u, 0u, 0u, 0u};
+                for (int i = 0; i < 8; ++i) if (off + i < n_events) w[i >> 1] |= (uint32_t)events[off + i] << (16 * (i & 1));
+                chunk[q] = u32x4{w[0], w[1], w[2], w[3]};
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < TMG_BLOCKS; ++q) *reinterpret_cast<u32x4*>(&lds[wv][q][u][c * 8]) = chunk[q];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < TMG_BLOCKS; ++q) {
+        const uint32_t blk = blk0 + q;
+        if (blk >= nblk) break;
+        uint32_t e[8], any = 0;
+#pragma unroll
+        for (int uu = 0; uu < 8; ++uu) {
+            const uint32_t inf = (uint32_t)__builtin_amdgcn_readlane((int)info[q], uu * 8);
+            const uint32_t idx = (uint32_t)lane - (inf & 0xffu);
+            e[uu] = idx < (inf >> 8) ? (uint32_t)lds[wv][q][uu][idx & 63u] : 0u;
+            any |= e[uu];
+        }
+        store[(uint64_t)blk * 64 + lane] = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+        // the positions outside [first, last] of the block's events are zeros in all eight entries (exon and read ends shared by the
+        // tile's reads): the walk does not fetch them (its buffer descriptor ends there, lanes outside read zeros)
+        const unsigned long long m = __ballot(any != 0u);
+        if (lane == 0) ext[blk] = m ? (uint16_t)(__ffsll((long long)m) - 1) | (uint16_t)((64 - __clzll((long long)m)) << 8) : (uint16_t)0;
+    }
+}
+
+#define SCAN_U32(in, out, n)                                                                              \
+    do {                                                                                                  \
+        size_t tb_ = 0;                                                                                   \
+        LSG_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb_, (in), (out), (int)(n), st));              \
+        if (c->d_cub_tmp.reserve(tb_ + 256)) return -1;                                                   \
+        tb_ = c->d_cub_tmp.cap;                                                                           \
+        LSG_HIP(hipcub::DeviceScan::ExclusiveSum(c->d_cub_tmp.p, tb_, (in), (out), (int)(n), st));       \
+    } while (0)
+
+enum { BT_REC = 0, BT_KEY_A, BT_KEY_B, BT_VAL_A, BT_VAL_B, BT_GSRC, BT_NETILE, BT_SEG_BEGIN, BT_SEG_END, BT_TMP, BT_PER_TILE, BT_OFFS };
+
+void drop_store(lsg_ctx* c) {
+    c->tm_valid = false; c->plan_n_ct = 0; c->tm_n = 0; c->tm_events = 0; c->tm_np = 0; c->tm_nblk = 0; c->tm_njobs = 0; c->tm_nchunks = 0;
+    c->tm_n_ne = 0; c->tm_n_multi = 0; c->tm_n_slabs = 0; c->tm_n_wide = 0;
+    c->max_live_reads = -1; c->max_live_all = -1; c->has_drops = false;
+    c->counted = c->called = false;
+}
+
+// the build's temporaries stay in the context (grow-only): allocating ~9 GB per load costs more wall time than the build's kernels —
+// unless the load is large against the device (C4): then they are given back, the rows and the call stage need the room
+static void settle_temporaries(lsg_ctx* c) {
+    size_t held = 0, mem_free = 0, mem_total = 0;
+    for (auto& b : c->bt) held += b.cap;
+    held += c->ws[WS_SEG_INFO].cap;
+    if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) return;
+    if (held > mem_total / 8 || mem_free < mem_total / 8) { for (auto& b : c->bt) b.release(); c->ws[WS_SEG_INFO].release(); }
+}
+
+int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int64_t* seg_ev_off) {
+    drop_store(c);
+    hipStream_t st = c->stream;
+    const int64_t S = c->rd.n_segs, R = c->rd.n_reads;
+    const uint32_t T = c->n_tiles;
+    const auto t_wall = std::chrono::steady_clock::now();
+    auto finish = [&]() {
+        c->layout_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_wall).count();
+        c->tm_valid = true;
+        return 0;
+    };
+    for (auto& v : c->build_ms) v = 0;
+    if (c->d_tile_cap.reserve(((size_t)T + 2) * 4) || c->d_tile_off.reserve(((size_t)T + 2) * 4) || c->d_scalars.reserve(512 * 8)) return -1;
+    LSG_HIP(hipMemsetAsync(c->d_tile_cap.p, 0, ((size_t)T + 2) * 4, st));
+    LSG_HIP(hipMemsetAsync(c->d_tile_off.p, 0, ((size_t)T + 2) * 4, st));
+    if (S <= 0 || T == 0) { LSG_HIP(hipStreamSynchronize(st)); return finish(); }
+    if (c->ws[WS_SEG_INFO].reserve(((size_t)S + 1) * 8)) return -1;
+    LSG_HIP(hipMemsetAsync(c->d_scalars.p, 0, 64, st));
+    BuildArgs a{};
+    a.n_reads = R; a.n_segs = S; a.n_events = n_events;
+    a.read_tid = c->rd.read_tid; a.read_flag = c->rd.read_flag; a.read_mapq = c->rd.read_mapq; a.read_cb = c->rd.read_cb;
+    a.seg_read = c->rd.seg_read; a.seg_start = c->rd.seg_start; a.seg_len = c->rd.seg_len; a.seg_ev_off = seg_ev_off;
+    a.tile_base = c->d_tile_base.as<uint32_t>(); a.contig_len = c->d_contig_len.as<int64_t>(); a.n_contigs = c->n_contigs; a.n_tiles = T;
+    a.seg_info = c->ws[WS_SEG_INFO].as<uint2>(); a.tile_cap = c->d_tile_cap.as<uint32_t>();
+    a.qhead = c->d_scalars.as<unsigned long long>(); a.bad = reinterpret_cast<uint32_t*>(c->d_scalars.as<unsigned long long>() + 2);
+    a.n_ev = c->d_scalars.as<unsigned long long>() + 3;
+    uint32_t* d_small = reinterpret_cast<uint32_t*>(c->d_scalars.as<unsigned long long>() + 4);      // [0] max entries of a tile, [1] non-empty tiles, [2] largest barcode id
+    DevBuf& tmp = c->bt[BT_TMP];
+    LSG_HIP(hipEventRecord(c->evb[0], st));
+    // ---- 1. static admission + capacities
+    unsigned g_seg = (unsigned)((S + 255) / 256); if (g_seg > (unsigned)(c->n_cus * 16)) g_seg = (unsigned)(c->n_cus * 16);
+    unsigned g_bin = (unsigned)((S + 256 * BIN_SUPER - 1) / (256 * BIN_SUPER)); if (g_bin > (unsigned)(c->n_cus * 8)) g_bin = (unsigned)(c->n_cus * 8);
+    hipLaunchKernelGGL(k_seg_static, dim3(g_seg), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_bin<0>, dim3(g_bin), dim3(BIN_THREADS), 0, st, a);
+    SCAN_U32(c->d_tile_cap.as<uint32_t>(), c->d_tile_off.as<uint32_t>(), T + 1);
+    {
+        size_t tb = 0;
+        LSG_HIP(hipcub::DeviceReduce::Max(nullptr, tb, c->rd.read_cb, reinterpret_cast<int32_t*>(d_small + 2), (int)(R > 0 ? R : 1), st));
+        if (tmp.reserve(tb + 256)) return -1;
+        tb = tmp.cap;
+        if (R > 0) LSG_HIP(hipcub::DeviceReduce::Max(tmp.p, tb, c->rd.read_cb, reinterpret_cast<int32_t*>(d_small + 2), (int)R, st));
+    }
+    uint32_t total = 0, bad = 0; int32_t max_cb = 0;
+    unsigned long long n_ev = 0;
+    LSG_HIP(hipMemcpyAsync(&n_ev, a.n_ev, 8, hipMemcpyDeviceToHost, st));
+    LSG_HIP(hipMemcpyAsync(&total, c->d_tile_off.as<uint32_t>() + T, 4, hipMemcpyDeviceToHost, st));
+    LSG_HIP(hipMemcpyAsync(&bad, a.bad, 4, hipMemcpyDeviceToHost, st));
+    if (R > 0) LSG_HIP(hipMemcpyAsync(&max_cb, d_small + 2, 4, hipMemcpyDeviceToHost, st));
+    LSG_HIP(hipStreamSynchronize(st));
+    if (bad & 2u) { set_error("lsg_load_reads: a segment's read index lies outside the read arrays"); return -2; }
+    if (bad & 1u) { set_error("lsg_load_reads: a segment's event range lies outside the events array"); return -2; }
+    // (a total of 2^32 or more wraps the 32-bit scan: the per-tile capacities are summed in 64 bits to tell)
+    {
+        unsigned long long* d_sum = c->d_scalars.as<unsigned long long>() + 8;
+        size_t tb = 0;
+        hipcub::TransformInputIterator<unsigned long long, hipcub::CastOp<unsigned long long>, const uint32_t*> it(c->d_tile_cap.as<uint32_t>(), hipcub::CastOp<unsigned long long>());
+        LSG_HIP(hipcub::DeviceReduce::Sum(nullptr, tb, it, d_sum, (int)T, st));
+        if (tmp.reserve(tb + 256)) return -1;
+        tb = tmp.cap;
+        LSG_HIP(hipcub::DeviceReduce::Sum(tmp.p, tb, it, d_sum, (int)T, st));
+        unsigned long long sum = 0;
+        LSG_HIP(hipMemcpyAsync(&sum, d_sum, 8, hipMemcpyDeviceToHost, st));
+        LSG_HIP(hipStreamSynchronize(st));
+        if (sum >= 0x7FFFFFF0ull) { set_error("lsg_load_reads: %llu tile entries exceed the 31-bit entry index; load the reads in windows", sum); return -2; }
+        total = (uint32_t)sum;
+    }
+    const uint64_t N = total;
+    c->tm_n = N; c->tm_events = (int64_t)n_ev;
+    if (N == 0) return finish();
+    // ---- 2. scatter
+    DevBuf &rec = c->bt[BT_REC], &key_a = c->bt[BT_KEY_A], &key_b = c->bt[BT_KEY_B], &val_a = c->bt[BT_VAL_A], &val_b = c->bt[BT_VAL_B];
+    if (rec.reserve(N * 16) || key_a.reserve(N * 4 + 16) || key_b.reserve(N * 4 + 16) || val_a.reserve(N * 4) || val_b.reserve(N * 4) ||
+        c->bt[BT_PER_TILE].reserve(((size_t)T + 2) * 4) || c->bt[BT_NETILE].reserve(((size_t)T + 2) * 4)) return -1;
+    a.cursor = c->bt[BT_PER_TILE].as<uint32_t>(); a.rec = rec.as<uint4>(); a.key = key_a.as<uint32_t>(); a.val = val_a.as<uint32_t>();
+    LSG_HIP(hipMemcpyAsync(a.cursor, c->d_tile_off.p, ((size_t)T + 1) * 4, hipMemcpyDeviceToDevice, st));
+    LSG_HIP(hipMemsetAsync(c->d_scalars.p, 0, 8, st));
+    hipLaunchKernelGGL(k_bin<2>, dim3(g_bin), dim3(BIN_THREADS), 0, st, a);
+    LSG_HIP(hipEventRecord(c->evb[1], st));
+    // ---- 3. every tile's entries by barcode
+    uint32_t n_netile = 0;
+    {
+        hipcub::CountingInputIterator<uint32_t> tile_it(0);
+        CapNonZero pred{c->d_tile_cap.as<uint32_t>()};
+        size_t tb = 0;
+        LSG_HIP(hipcub::DeviceSelect::If(nullptr, tb, tile_it, c->bt[BT_NETILE].as<uint32_t>(), d_small + 1, (int)T, pred, st));
+        if (tmp.reserve(tb + 256)) return -1;
+        tb = tmp.cap;
+        LSG_HIP(hipcub::DeviceSelect::If(tmp.p, tb, tile_it, c->bt[BT_NETILE].as<uint32_t>(), d_small + 1, (int)T, pred, st));
+        LSG_HIP(hipMemcpyAsync(&n_netile, d_small + 1, 4, hipMemcpyDeviceToHost, st));
+        LSG_HIP(hipStreamSynchronize(st));
+    }
+    if (c->bt[BT_SEG_BEGIN].reserve(((size_t)n_netile + 1) * 4) || c->bt[BT_SEG_END].reserve(((size_t)n_netile + 1) * 4)) return -1;
+    hipLaunchKernelGGL(k_seg_bounds, dim3((n_netile + 255) / 256), dim3(256), 0, st, c->bt[BT_NETILE].as<uint32_t>(), n_netile, c->d_tile_off.as<uint32_t>(),
+                       c->bt[BT_SEG_BEGIN].as<uint32_t>(), c->bt[BT_SEG_END].as<uint32_t>());
+    {
+        int bits = 1; while (bits < 24 && (1ll << bits) <= (long long)max_cb) ++bits;
+        size_t tb = 0;
+        LSG_HIP(hipcub::DeviceSegmentedRadixSort::SortPairs(nullptr, tb, key_a.as<uint32_t>(), key_b.as<uint32_t>(), val_a.as<uint32_t>(), val_b.as<uint32_t>(), (int)N, (int)n_netile,
+                                                            c->bt[BT_SEG_BEGIN].as<uint32_t>(), c->bt[BT_SEG_END].as<uint32_t>(), 0, bits, st));
+        if (tmp.reserve(tb + 256)) return -1;
+        tb = tmp.cap;
+        LSG_HIP(hipcub::DeviceSegmentedRadixSort::SortPairs(tmp.p, tb, key_a.as<uint32_t>(), key_b.as<uint32_t>(), val_a.as<uint32_t>(), val_b.as<uint32_t>(), (int)N, (int)n_netile,
+                                                            c->bt[BT_SEG_BEGIN].as<uint32_t>(), c->bt[BT_SEG_END].as<uint32_t>(), 0, bits, st));
+    }
+    LSG_HIP(hipEventRecord(c->evb[2], st));
+    // ---- 4. blocks and the per-entry words
+    if (c->tm[TM_BLK_OFF].reserve(((size_t)T + 2) * 4)) return -1;
+    uint32_t* blk = c->bt[BT_PER_TILE].as<uint32_t>();                    // (the cursors are done with)
+    uint32_t* blk_off = c->tm[TM_BLK_OFF].as<uint32_t>();
+    hipLaunchKernelGGL(k_tile_blocks, dim3((T + 256) / 256), dim3(256), 0, st, c->d_tile_cap.as<uint32_t>(), T, blk);
+    SCAN_U32(blk, blk_off, T + 1);
+    uint32_t nblk = 0;
+    LSG_HIP(hipMemcpyAsync(&nblk, blk_off + T, 4, hipMemcpyDeviceToHost, st));
+    LSG_HIP(hipStreamSynchronize(st));
+    const uint64_t np = (uint64_t)nblk * 8;
+    c->tm_np = np; c->tm_nblk = nblk;
+    DevBuf& gsrc = c->bt[BT_GSRC];
+    if (c->tm[TM_STORE].reserve(((size_t)nblk + TM_GROUP) * 1024) || c->tm[TM_S0].reserve((np + 16) * 4) || c->tm[TM_B].reserve(np + 16) ||
+        c->tm[TM_FM].reserve((np + 16) * 4) || c->tm[TM_RD].reserve((np + 16) * 4) || c->tm[TM_META].reserve((np + 8 * (TM_GROUP + 1)) * 4) ||
+        c->tm[TM_BLK_TILE].reserve(((size_t)nblk + 2) * 4) || c->tm[TM_EXT].reserve(((size_t)nblk + TM_GROUP + 2) * 2) || gsrc.reserve((np + 16) * 8)) return -1;
+    hipLaunchKernelGGL(k_tm_blk_tile, dim3((nblk + 255) / 256), dim3(256), 0, st, blk_off, T, nblk, c->tm[TM_BLK_TILE].as<uint32_t>());
+    hipLaunchKernelGGL(k_tm_fill, dim3((unsigned)(c->n_cus * 16)), dim3(256), 0, st, key_b.as<uint32_t>(), val_b.as<uint32_t>(), rec.as<uint4>(), c->rd.read_flag, c->rd.read_mapq,
+                       c->d_tile_off.as<uint32_t>(), blk_off, c->tm[TM_BLK_TILE].as<uint32_t>(), np,
+                       c->tm[TM_S0].as<uint32_t>(), c->tm[TM_B].as<uint8_t>(), c->tm[TM_FM].as<uint32_t>(), c->tm[TM_RD].as<uint32_t>(), gsrc.as<uint2>());
+    LSG_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c->tm[TM_S0].as<uint32_t>() + np), (int)TM_PAD_S0, 16, st));       // (what the walk's group loads and the run flags' neighbours see past the end)
+    LSG_HIP(hipMemsetAsync(c->tm[TM_B].as<uint8_t>() + np, 0, 16, st));
+    LSG_HIP(hipEventRecord(c->evb[3], st));
+    // ---- 5. the events
+    hipLaunchKernelGGL(k_tm_gather, dim3((unsigned)((((uint64_t)nblk + TMG_BLOCKS - 1) / TMG_BLOCKS + TMG_WAVES - 1) / TMG_WAVES)), dim3(TMG_WAVES * 64), 0, st,
+                       events, n_events, c->tm[TM_S0].as<uint32_t>(), c->tm[TM_B].as<uint8_t>(), gsrc.as<uint2>(), nblk, c->tm[TM_STORE].as<uint4>(), c->tm[TM_EXT].as<uint16_t>());
+    LSG_HIP(hipEventRecord(c->evb[4], st));
+    LSG_HIP(hipGetLastError());
+    LSG_HIP(hipStreamSynchronize(st));
+    for (int i = 0; i < 4; ++i) { float ms = 0; if (hipEventElapsedTime(&ms, c->evb[i], c->evb[i + 1]) == hipSuccess) c->build_ms[i] = ms; }
+    settle_temporaries(c);
+    if (getenv("LSG_TIMING"))
+        fprintf(stderr, "[lsg] tile store: %llu entries, %u blocks (%.2f GB): capacities + scatter %.2f, sort %.2f, fill %.2f, gather %.2f ms\n",
+                (unsigned long long)N, nblk, (double)nblk * 1024 / 1e9, c->build_ms[0], c->build_ms[1], c->build_ms[2], c->build_ms[3]);
+    return finish();
+}
+
+// ================================================================================================
+// The plan of a count over the store: everything about jobs, units and slabs is static per (load, number of cell types), so a count
+// has no planning step and ONE host synchronisation (its final read of the counters).  Unit = (tile, cell type), both cell types of a
+// pass counted by one job (a barcode's run belongs to one cell type).  Tiles of more than TM_JOB_TGT entries are cut at run starts into
+// jobs of about TM_JOB_TGT entries (partial sums to slabs that k_finalize_multi adds: 8 KB per job and cell type, so jobs are as long
+// as the planes' fields allow); a job that a single barcode's run stretches past TM_JOB_LIMIT goes to the wide walk.
+constexpr uint32_t TM_CHUNK_WORK = 4096, TM_JOB_W0 = 32;      // a workgroup dequeues at most this much work (entries + a constant per job) at a time
+
+// per tile: non-empty, jobs, slabs, multi-job (inputs of four exclusive scans)
+__global__ void k_tm_tiles(const uint32_t* cap, uint32_t n_tiles, int n_ct, uint32_t job_tgt, uint32_t* ne, uint32_t* nj, uint32_t* slabs, uint32_t* multi) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > n_tiles) return;
+    const uint32_t n = t < n_tiles ? cap[t] : 0u;
+    const uint32_t j = n == 0 ? 0u : (n <= job_tgt ? 1u : (n + job_tgt - 1) / job_tgt);
+    ne[t] = n ? 1u : 0u; nj[t] = j; slabs[t] = j > 1 ? j * (uint32_t)n_ct : 0u; multi[t] = j > 1 ? 1u : 0u;
+}
+// per non-empty tile: its units (one per cell type), its jobs cut at run starts
+__global__ void k_tm_jobs(const uint32_t* tile_base, int n_contigs, int n_ct, const uint32_t* s0, const uint32_t* cap, const uint32_t* blk_off, const uint32_t* ne_off,
+                          const uint32_t* nj, const uint32_t* job_off, const uint32_t* slab_off, const uint32_t* multi_off, uint32_t n_tiles, TmJob* jobs,
+                          uint32_t* ne_units, int2* ne_geom, uint32_t* ne_nslot, uint32_t* ne_acc, uint32_t* multi, uint32_t* n_wide) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tiles) return;
+    const uint32_t n = cap[t];
+    if (!n) return;
+    const uint32_t J = nj[t], ord = ne_off[t];
+    const uint64_t base = (uint64_t)blk_off[t] * 8;
+    int tid = 0;
+    { int lo = 0, hi = n_contigs; while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (tile_base[mid] <= t) lo = mid; else hi = mid; } tid = lo; }
+    const int32_t tstart = (int32_t)((t - tile_base[tid]) << 6);
+    for (int ct = 0; ct < n_ct; ++ct) {
+        const uint32_t w = ord * (uint32_t)n_ct + ct;
+        ne_units[w] = t * (uint32_t)n_ct + ct;
+        ne_geom[w] = make_int2(tstart, tid | (ct << 24));
+        ne_nslot[w] = J;
+        ne_acc[w] = J > 1 ? slab_off[t] + (uint32_t)ct * J : 0u;
+        if (J > 1) multi[multi_off[t] * (uint32_t)n_ct + ct] = w;
+    }
+    auto cut = [&](uint32_t x) -> uint32_t { while (x < n && !(s0[base + x] & TM_RUNSTART)) ++x; return x < n ? x : n; };
+    uint32_t e0 = 0;
+    for (uint32_t j = 0; j < J; ++j) {
+        uint32_t e1 = j + 1 == J ? n : cut((uint32_t)(((uint64_t)n * (j + 1)) / J));
+        if (e1 < e0) e1 = e0;
+        TmJob jb;
+        jb.e0 = (uint32_t)(base + e0); jb.e1 = (uint32_t)(base + e1); jb.w0 = ord * (uint32_t)n_ct;
+        jb.slab = J > 1 ? slab_off[t] + j : 0xFFFFFFFFu; jb.nj = J; jb.cnt = n; jb.tile = t;
+        // two waves share the job: the second starts at the run start at or after its middle (short jobs: one wave)
+        uint32_t mid = e1;
+        if (e1 - e0 >= 64u) { mid = cut(e0 + (e1 - e0) / 2u); if (mid > e1) mid = e1; }
+        jb.emid = (uint32_t)(base + mid);
+        if (e1 - e0 > (uint32_t)TM_JOB_LIMIT) { jb.nj |= TMJ_WIDE; atomicAdd(n_wide, 1u); }
+        jobs[job_off[t] + j] = jb;
+        e0 = e1;
+    }
+}
+struct TmJobWork {
+    const TmJob* jobs;
+    __host__ __device__ uint32_t operator()(const uint32_t& j) const { return jobs[j].e1 - jobs[j].e0 + TM_JOB_W0; }
+};
+// chunk k = the jobs whose exclusive work prefix lies in [k E, (k + 1) E)
+__global__ void k_tm_chunks(const uint32_t* pex, uint32_t njobs, uint32_t chunk_work, uint32_t* chunk_start, uint32_t* n_chunks) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= njobs) return;
+    const uint32_t ck = pex[j] / chunk_work;
+    const int64_t prev = j ? (int64_t)(pex[j - 1] / chunk_work) : -1;
+    for (int64_t k = prev + 1; k <= (int64_t)ck; ++k) chunk_start[k] = j;
+    if (j == njobs - 1) { chunk_start[ck + 1] = njobs; *n_chunks = ck + 1; }
+}
+
+int ensure_plan(lsg_ctx* c) {
+    if (!c->tm_valid) { set_error("lsg_pileup_count: no reads loaded"); return -2; }
+    if (c->plan_n_ct == c->n_ct) return 0;
+    c->plan_n_ct = 0;
+    c->tm_njobs = c->tm_nchunks = c->tm_n_ne = c->tm_n_multi = c->tm_n_slabs = c->tm_n_wide = 0;
+    if (c->tm_nblk == 0) { c->plan_n_ct = c->n_ct; return 0; }
+    hipStream_t st = c->stream;
+    const uint32_t T = c->n_tiles;
+    const uint64_t N = c->tm_n;
+    DevBuf &per_tile = c->bt[BT_PER_TILE], &offs = c->bt[BT_OFFS];
+    if (per_tile.reserve((size_t)(T + 2) * 4 * 4) || offs.reserve((size_t)(T + 2) * 4 * 4 + 64)) return -1;
+    uint32_t* ne = per_tile.as<uint32_t>(); uint32_t* nj = ne + (T + 2); uint32_t* slabs = nj + (T + 2); uint32_t* multi = slabs + (T + 2);
+    uint32_t* ne_off = offs.as<uint32_t>(); uint32_t* job_off = ne_off + (T + 2); uint32_t* slab_off = job_off + (T + 2); uint32_t* multi_off = slab_off + (T + 2);
+    uint32_t* d_misc = multi_off + (T + 2);          // [0] wide jobs, [1] chunks
+    // jobs as long as the planes' fields allow (fewer slabs) — unless the load is small (one rank's share of a sharded job): then every
+    // resident pair of waves should still get several
+    uint32_t job_tgt = TM_JOB_TGT;
+    { const uint64_t per = N / ((uint64_t)c->n_cus * 14 * 4); if (per < job_tgt) job_tgt = (uint32_t)(per < 768 ? 768 : per); }
+    hipLaunchKernelGGL(k_tm_tiles, dim3((T + 256) / 256), dim3(256), 0, st, c->d_tile_cap.as<uint32_t>(), T, c->n_ct, job_tgt, ne, nj, slabs, multi);
+    SCAN_U32(ne, ne_off, T + 1); SCAN_U32(nj, job_off, T + 1); SCAN_U32(slabs, slab_off, T + 1); SCAN_U32(multi, multi_off, T + 1);
+    LSG_HIP(hipMemsetAsync(d_misc, 0, 8, st));
+    uint32_t tot[4] = {0, 0, 0, 0};
+    uint32_t* srcs[4] = {ne_off, job_off, slab_off, multi_off};
+    for (int i = 0; i < 4; ++i) LSG_HIP(hipMemcpyAsync(&tot[i], srcs[i] + T, 4, hipMemcpyDeviceToHost, st));
+    LSG_HIP(hipStreamSynchronize(st));
+    const uint32_t n_net = tot[0], njobs = tot[1], n_slabs = tot[2], n_mt = tot[3];
+    const size_t n_ne = (size_t)n_net * (size_t)c->n_ct, n_multi = (size_t)n_mt * (size_t)c->n_ct;
+    if (c->tm[TM_JOBS].reserve(((size_t)njobs + 1) * sizeof(TmJob)) || c->tm[TM_NE_UNITS].reserve((n_ne + 2) * 4) || c->tm[TM_NE_GEOM].reserve((n_ne + 2) * 8) ||
+        c->tm[TM_NE_NSLOT].reserve((n_ne + 2) * 4) || c->tm[TM_NE_ACC].reserve((n_ne + 2) * 4) || c->tm[TM_MULTI].reserve((n_multi + 2) * 4)) return -1;
+    LSG_HIP(hipMemsetAsync(c->tm[TM_NE_NSLOT].p, 0, (n_ne + 2) * 4, st));
+    LSG_HIP(hipMemsetAsync(c->tm[TM_NE_ACC].p, 0, (n_ne + 2) * 4, st));
+    hipLaunchKernelGGL(k_tm_jobs, dim3((T + 255) / 256), dim3(256), 0, st, c->d_tile_base.as<uint32_t>(), c->n_contigs, c->n_ct, c->tm[TM_S0].as<uint32_t>(),
+                       c->d_tile_cap.as<uint32_t>(), c->tm[TM_BLK_OFF].as<uint32_t>(), ne_off, nj, job_off, slab_off, multi_off, T,
+                       c->tm[TM_JOBS].as<TmJob>(), c->tm[TM_NE_UNITS].as<uint32_t>(), c->tm[TM_NE_GEOM].as<int2>(), c->tm[TM_NE_NSLOT].as<uint32_t>(),
+                       c->tm[TM_NE_ACC].as<uint32_t>(), c->tm[TM_MULTI].as<uint32_t>(), d_misc);
+    {   // static work-balanced chunks of the job list; every workgroup of the walk should get several: a small load is cut finer
+        DevBuf& pex = c->bt[BT_GSRC];
+        const uint64_t total_work = c->tm_np + (uint64_t)njobs * TM_JOB_W0;
+        const uint64_t cw = total_work / ((uint64_t)c->n_cus * 14 * 6);
+        const uint32_t chunk_work = (uint32_t)(cw < 256 ? 256 : (cw > TM_CHUNK_WORK ? TM_CHUNK_WORK : cw));
+        if (pex.reserve(((size_t)njobs + 2) * 4) || c->tm[TM_CHUNKS].reserve(((size_t)(total_work / chunk_work) + 4) * 4)) return -1;
+        hipcub::CountingInputIterator<uint32_t> iota(0);
+        TmJobWork wf{c->tm[TM_JOBS].as<TmJob>()};
+        hipcub::TransformInputIterator<uint32_t, TmJobWork, hipcub::CountingInputIterator<uint32_t>> it(iota, wf);
+        SCAN_U32(it, pex.as<uint32_t>(), njobs);
+        hipLaunchKernelGGL(k_tm_chunks, dim3((njobs + 255) / 256), dim3(256), 0, st, pex.as<uint32_t>(), njobs, chunk_work, c->tm[TM_CHUNKS].as<uint32_t>(), d_misc + 1);
+    }
+    uint32_t misc[2] = {0, 0};
+    LSG_HIP(hipMemcpyAsync(misc, d_misc, 8, hipMemcpyDeviceToHost, st));
+    LSG_HIP(hipGetLastError());
+    LSG_HIP(hipStreamSynchronize(st));
+    c->tm_njobs = njobs; c->tm_nchunks = misc[1]; c->tm_n_wide = misc[0];
+    c->tm_n_ne = (uint32_t)n_ne; c->tm_n_multi = (uint32_t)n_multi; c->tm_n_slabs = n_slabs;
+    c->plan_n_ct = c->n_ct;
+    return 0;
+}
+
+} // namespace lsg

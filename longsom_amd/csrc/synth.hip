@@ -5,7 +5,6 @@
 #include <hipcub/hipcub.hpp>
 
 namespace lsg {
-int compute_entries_upper(lsg_ctx* c);
 
 __global__ void k_synth_header(lsg_synth_model m, int32_t* read_tid, int32_t* read_pos, uint16_t* read_flag, uint8_t* read_mapq,
                                int32_t* read_cb, int64_t* ev_cnt, uint32_t* seg_cnt) {
@@ -85,10 +84,12 @@ int lsg_synth_reference(lsg_ctx* c, uint64_t seed) {
 }
 
 // model: host pointers (gene tables are copied); celltype_of is taken from lsg_set_barcodes.
-int lsg_synth_reads(lsg_ctx* c, const lsg_synth_model* hm) {
-    if (!c || !hm) { set_error("lsg_synth_reads: bad arguments"); return -2; }
-    if (c->n_cb <= 0 || hm->n_cb != c->n_cb) { set_error("lsg_synth_reads: set barcodes first (n_cb %d vs %d)", hm->n_cb, c->n_cb); return -2; }
-    if (hm->n_genes <= 0 || hm->n_reads < 0) { set_error("lsg_synth_reads: empty model"); return -2; }
+// Generates the model's compact read-record arrays into buffers of the handle and describes them in *out (device pointers, valid
+// until the next generate / lsg_synth_reads / lsg_destroy): what a caller with device-resident arrays hands to lsg_load_reads.
+int lsg_synth_generate(lsg_ctx* c, const lsg_synth_model* hm, lsg_reads* out) {
+    if (!c || !hm || !out) { set_error("lsg_synth_generate: bad arguments"); return -2; }
+    if (c->n_cb <= 0 || hm->n_cb != c->n_cb) { set_error("lsg_synth_generate: set barcodes first (n_cb %d vs %d)", hm->n_cb, c->n_cb); return -2; }
+    if (hm->n_genes <= 0 || hm->n_reads < 0) { set_error("lsg_synth_generate: empty model"); return -2; }
     LSG_HIP(hipSetDevice(c->device));
     hipStream_t st = c->stream;
     const int G = hm->n_genes;
@@ -96,6 +97,8 @@ int lsg_synth_reads(lsg_ctx* c, const lsg_synth_model* hm) {
     const int64_t R = hm->n_reads;
     DevBuf &g_tid = c->syn[0], &g_xoff = c->syn[1], &x_start = c->syn[2], &x_len = c->syn[3], &x_cum = c->syn[4], &g_roff = c->syn[5],
            &evcnt = c->syn[6], &segcnt = c->syn[7], &evoff = c->syn[8], &segoff = c->syn[9], &tmpb = c->syn[10];
+    DevBuf &o_tid = c->gen[0], &o_pos = c->gen[1], &o_flag = c->gen[2], &o_mapq = c->gen[3], &o_cb = c->gen[4], &o_sread = c->gen[5], &o_sstart = c->gen[6],
+           &o_slen = c->gen[7], &o_sevoff = c->gen[8], &o_events = c->gen[9];
     if (up(c, g_tid, hm->gene_tid, G) || up(c, g_xoff, hm->gene_exon_off, G + 1) || up(c, x_start, hm->exon_start, X) ||
         up(c, x_len, hm->exon_len, X) || up(c, x_cum, hm->exon_cum, X) || up(c, g_roff, hm->gene_read_off, G + 1)) return -1;
     lsg_synth_model m = *hm;
@@ -103,11 +106,11 @@ int lsg_synth_reads(lsg_ctx* c, const lsg_synth_model* hm) {
     m.exon_len = x_len.as<int32_t>(); m.exon_cum = x_cum.as<int32_t>(); m.gene_read_off = g_roff.as<int64_t>();
     m.celltype_of = c->d_celltype_of.as<uint8_t>();
 
-    if (c->b_read_tid.reserve((R + 1) * 4) || c->b_read_pos.reserve((R + 1) * 4) || c->b_read_flag.reserve((R + 1) * 2) ||
-        c->b_read_mapq.reserve(R + 1) || c->b_read_cb.reserve((R + 1) * 4) || evcnt.reserve((R + 1) * 8) || segcnt.reserve((R + 1) * 4) ||
+    if (o_tid.reserve((R + 1) * 4) || o_pos.reserve((R + 1) * 4) || o_flag.reserve((R + 1) * 2) ||
+        o_mapq.reserve(R + 1) || o_cb.reserve((R + 1) * 4) || evcnt.reserve((R + 1) * 8) || segcnt.reserve((R + 1) * 4) ||
         evoff.reserve((R + 1) * 8) || segoff.reserve((R + 1) * 4)) return -1;
-    hipLaunchKernelGGL(k_synth_header, dim3((unsigned)((R + 1 + 255) / 256)), dim3(256), 0, st, m, c->b_read_tid.as<int32_t>(),
-                       c->b_read_pos.as<int32_t>(), c->b_read_flag.as<uint16_t>(), c->b_read_mapq.as<uint8_t>(), c->b_read_cb.as<int32_t>(),
+    hipLaunchKernelGGL(k_synth_header, dim3((unsigned)((R + 1 + 255) / 256)), dim3(256), 0, st, m, o_tid.as<int32_t>(),
+                       o_pos.as<int32_t>(), o_flag.as<uint16_t>(), o_mapq.as<uint8_t>(), o_cb.as<int32_t>(),
                        evcnt.as<int64_t>(), segcnt.as<uint32_t>());
     size_t t1 = 0, t2 = 0;
     LSG_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, t1, evcnt.as<int64_t>(), evoff.as<int64_t>(), (int)(R + 1), st));
@@ -121,26 +124,33 @@ int lsg_synth_reads(lsg_ctx* c, const lsg_synth_model* hm) {
     LSG_HIP(hipMemcpyAsync(&E, evoff.as<int64_t>() + R, 8, hipMemcpyDeviceToHost, st));
     LSG_HIP(hipMemcpyAsync(&S, segoff.as<uint32_t>() + R, 4, hipMemcpyDeviceToHost, st));
     LSG_HIP(hipStreamSynchronize(st));
-    if (c->b_seg_read.reserve(((size_t)S + 1) * 4) || c->b_seg_start.reserve(((size_t)S + 1) * 4) || c->b_seg_len.reserve(((size_t)S + 1) * 4) ||
-        c->b_seg_ev_off.reserve(((size_t)S + 1) * 8) || c->b_events.reserve(((size_t)E + 1) * 2)) return -1;
+    if (o_sread.reserve(((size_t)S + 1) * 4) || o_sstart.reserve(((size_t)S + 1) * 4) || o_slen.reserve(((size_t)S + 1) * 4) ||
+        o_sevoff.reserve(((size_t)S + 1) * 8) || o_events.reserve(((size_t)E + 1) * 2)) return -1;
     if (R > 0) {
         unsigned grid = (unsigned)(R < 65536 * 16 ? R : 65536 * 16);
         hipLaunchKernelGGL(k_synth_fill, dim3(grid), dim3(256), 0, st, m, evoff.as<int64_t>(), segoff.as<uint32_t>(),
-                           c->b_seg_read.as<uint32_t>(), c->b_seg_start.as<int32_t>(), c->b_seg_len.as<int32_t>(),
-                           c->b_seg_ev_off.as<int64_t>(), c->b_events.as<uint16_t>());
+                           o_sread.as<uint32_t>(), o_sstart.as<int32_t>(), o_slen.as<int32_t>(),
+                           o_sevoff.as<int64_t>(), o_events.as<uint16_t>());
     }
     LSG_HIP(hipGetLastError());
     LSG_HIP(hipStreamSynchronize(st));
-    c->rd = lsg_reads{};
-    c->rd.n_reads = R; c->rd.n_segs = S; c->rd.n_events = E; c->rd.on_device = 1;
-    c->rd.read_tid = c->b_read_tid.as<int32_t>(); c->rd.read_pos = c->b_read_pos.as<int32_t>();
-    c->rd.read_flag = c->b_read_flag.as<uint16_t>(); c->rd.read_mapq = c->b_read_mapq.as<uint8_t>();
-    c->rd.read_cb = c->b_read_cb.as<int32_t>(); c->rd.seg_read = c->b_seg_read.as<uint32_t>();
-    c->rd.seg_start = c->b_seg_start.as<int32_t>(); c->rd.seg_len = c->b_seg_len.as<int32_t>();
-    c->rd.seg_ev_off = c->b_seg_ev_off.as<int64_t>(); c->rd.events = c->b_events.as<uint16_t>();
-    c->counted = c->called = false;
-    if (int rc = lsg::relayout_events(c)) return rc;
-    return compute_entries_upper(c);
+    *out = lsg_reads{};
+    out->n_reads = R; out->n_segs = S; out->n_events = E; out->on_device = 1;
+    out->read_tid = o_tid.as<int32_t>(); out->read_pos = o_pos.as<int32_t>();
+    out->read_flag = o_flag.as<uint16_t>(); out->read_mapq = o_mapq.as<uint8_t>();
+    out->read_cb = o_cb.as<int32_t>(); out->seg_read = o_sread.as<uint32_t>();
+    out->seg_start = o_sstart.as<int32_t>(); out->seg_len = o_slen.as<int32_t>();
+    out->seg_ev_off = o_sevoff.as<int64_t>(); out->events = o_events.as<uint16_t>();
+    return 0;
+}
+
+// Generates the model's reads in HBM and loads them (lsg_load_reads of device arrays); the generated arrays are given back.
+int lsg_synth_reads(lsg_ctx* c, const lsg_synth_model* hm) {
+    lsg_reads g{};
+    if (int rc = lsg_synth_generate(c, hm, &g)) return rc;
+    const int rc = lsg_load_reads(c, &g);
+    for (auto& b : c->gen) b.release();
+    return rc;
 }
 
 int lsg_get_reads_shape(lsg_ctx* c, int64_t* n_reads, int64_t* n_segs, int64_t* n_events) {
@@ -157,6 +167,7 @@ int lsg_copy_reads_to_host(lsg_ctx* c, const lsg_reads* out) {
     if (out->n_reads != c->rd.n_reads || out->n_segs != c->rd.n_segs || out->n_events != c->rd.n_events) {
         set_error("lsg_copy_reads_to_host: shape mismatch"); return -2;
     }
+    if (c->rd.n_events > 0 && !c->rd.events) { set_error("lsg_copy_reads_to_host: the events were not kept beside the store (lsg_set_keep_reads before the load)"); return -2; }
     LSG_HIP(hipSetDevice(c->device));
     hipStream_t st = c->stream;
     const int64_t R = c->rd.n_reads, S = c->rd.n_segs, E = c->rd.n_events;

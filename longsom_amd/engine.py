@@ -75,7 +75,9 @@ def _ptr(a: Optional[np.ndarray]):
 class Engine:
     """One liblongsom_hip handle.  Raises if the HIP library or a GPU is missing (no CPU fallback)."""
 
-    def __init__(self, device: int = 0, stream: Optional[int] = None):
+    def __init__(self, device: int = 0, stream: Optional[int] = None, keep_reads: bool = False):
+        """keep_reads: loads also keep the compact events beside the tile store, so that reads_to_host() can return them
+        (tests, sampling for the CPU baseline); the product paths leave it off — the store is the only resident copy."""
         self._lib = _lib.load()
         h = C.c_void_p()
         _lib.check(self._lib.lsg_create(int(device), C.byref(h)), "lsg_create")
@@ -86,6 +88,11 @@ class Engine:
         self.contig_len = None
         if stream is not None:
             self.set_stream(stream)
+        if keep_reads:
+            self.set_keep_reads(True)
+
+    def set_keep_reads(self, keep: bool):
+        _lib.check(self._lib.lsg_set_keep_reads(self._h, 1 if keep else 0), "lsg_set_keep_reads")
 
     def close(self):
         if getattr(self, "_h", None):
@@ -132,6 +139,7 @@ class Engine:
         self.n_cb = len(ct)
 
     def load_reads(self, rec: ReadRecords):
+        """Builds the tile store of these reads on the device (lsg_load_reads); the arrays are free again on return."""
         r = Reads(rec.n_reads, rec.n_segs, rec.n_events, *[_ptr(getattr(rec, n)) for n, _ in ReadRecords._SPEC], 0)
         _lib.check(self._lib.lsg_load_reads(self._h, C.byref(r)), "lsg_load_reads")
 
@@ -139,6 +147,10 @@ class Engine:
         """ptrs: name -> device pointer (int) for every array of ReadRecords._SPEC; arrays stay owned by the caller."""
         r = Reads(n_reads, n_segs, n_events, *[C.c_void_p(int(ptrs[n])) for n, _ in ReadRecords._SPEC], 1)
         _lib.check(self._lib.lsg_load_reads(self._h, C.byref(r)), "lsg_load_reads")
+
+    def load_reads_struct(self, reads: Reads):
+        """lsg_load_reads of a ready lsg_reads (e.g. what synth_generate returned)"""
+        _lib.check(self._lib.lsg_load_reads(self._h, C.byref(reads)), "lsg_load_reads")
 
     def set_region(self, tid_lo=0, pos_lo=0, tid_hi=None, pos_hi=0):
         """Count only columns in [(tid_lo,pos_lo), (tid_hi,pos_hi)) — window sharding across GPUs."""
@@ -154,13 +166,21 @@ class Engine:
         mc = model.as_c()
         _lib.check(self._lib.lsg_synth_reads(self._h, C.byref(mc)), "lsg_synth_reads")
 
+    def synth_generate(self, model) -> Reads:
+        """Only generates the model's compact read-record arrays in HBM (owned by the handle until the next generate / synth_reads)
+        and returns their lsg_reads: a stand-in for a caller with a device-resident decoded BAM (bench.py times load_reads on it)."""
+        mc = model.as_c()
+        out = Reads()
+        _lib.check(self._lib.lsg_synth_generate(self._h, C.byref(mc), C.byref(out)), "lsg_synth_generate")
+        return out
+
     def reads_shape(self):
         a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
         _lib.check(self._lib.lsg_get_reads_shape(self._h, C.byref(a), C.byref(b), C.byref(c)), "lsg_get_reads_shape")
         return int(a.value), int(b.value), int(c.value)
 
     def reads_to_host(self) -> ReadRecords:
-        """Copy the resident read-record arrays back to the host (tests, CPU-baseline sampling)."""
+        """Copy the resident read-record arrays back to the host (tests, CPU-baseline sampling); needs keep_reads."""
         R, S, E = self.reads_shape()
         arrs = {n: np.zeros({"read": R, "seg_": S, "even": E}[n[:4]], dt) for n, dt in ReadRecords._SPEC}
         r = Reads(R, S, E, *[_ptr(arrs[n]) for n, _ in ReadRecords._SPEC], 0)
@@ -214,23 +234,30 @@ class Engine:
         _lib.check(self._lib.lsg_get_count_stats(self._h, C.byref(s)), "lsg_get_count_stats")
         return s
 
-    def prepare_counts(self, params: Optional[CountParams] = None):
-        """Build the per-load structures (tile index, tile-major store) for these read filters now: for callers that will count
-        the resident reads many times (lsg_prepare_counts: the build costs about ten counts' worth of savings).  Without it the fourth
-        count of a load under the same read filters builds them."""
-        params = params or CountParams.longsom_defaults()
-        _lib.check(self._lib.lsg_prepare_counts(self._h, C.byref(params)), "lsg_prepare_counts")
-
-    def set_layout_policy(self, policy: int):
-        """0 auto (from the fourth count of a load), 1 eager, 2 never (lsg_set_layout_policy)"""
-        _lib.check(self._lib.lsg_set_layout_policy(self._h, int(policy)), "lsg_set_layout_policy")
-
     def layout_info(self):
-        """(path, build_ms, store_bytes) of the last count: 0 scatter per count / 1 tile index / 2 tile-major store; what the per-load
-        index and store cost to build and hold (lsg_get_layout_info)"""
+        """(path, build_ms, store_bytes): path is always 2 (the count over the tile store); wall time the last load spent building the
+        store; device bytes the store and what belongs to it hold (lsg_get_layout_info)"""
         path = C.c_int32(0); ms = C.c_double(0.0); nbytes = C.c_int64(0)
         _lib.check(self._lib.lsg_get_layout_info(self._h, C.byref(path), C.byref(ms), C.byref(nbytes)), "lsg_get_layout_info")
         return int(path.value), float(ms.value), int(nbytes.value)
+
+    def build_times(self):
+        """HIP-event ms of the last load's build: capacities + scatter, sort, per-entry words, event gather (lsg_get_build_times)"""
+        ms = (C.c_float * 4)()
+        _lib.check(self._lib.lsg_get_build_times(self._h, ms), "lsg_get_build_times")
+        return [float(x) for x in ms]
+
+    def store_shape(self):
+        """(entries, 1 KB blocks, events) of the resident tile store (lsg_get_store_shape)"""
+        a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        _lib.check(self._lib.lsg_get_store_shape(self._h, C.byref(a), C.byref(b), C.byref(c)), "lsg_get_store_shape")
+        return int(a.value), int(b.value), int(c.value)
+
+    def max_live_reads_all(self) -> int:
+        """the bound of max_live_reads over every resident read with a barcode, whatever its cell type (lsg_max_live_reads_all)"""
+        v = int(self._lib.lsg_max_live_reads_all(self._h))
+        _lib.check(-1 if v < 0 else 0, "lsg_max_live_reads_all")
+        return v
 
     def call_step1(self, params: Optional[CallParams] = None):
         params = params or CallParams.longsom_defaults()

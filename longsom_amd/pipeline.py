@@ -94,10 +94,12 @@ def check_depth_cap(engine: Engine, what: str, allow_depth_overflow: Optional[bo
     HCCVSingleCellGenotype.py:122, and that path does not model max_depth): raise when more reads can be live at one position
     than the reference's pileup admits.  The COUNT path needs no such guard: lsg_pileup_count applies htslib's max_depth rule
     itself (lsg_count_params.max_depth)."""
-    live = engine.max_live_reads()
+    # the genotyping pileup reads the UNSPLIT BAM: every cell type's reads share its buffer, so the bound is the one over all resident
+    # reads (a lower bound on the reference's: reads without a usable CB tag are dropped at decode and are not resident)
+    live = engine.max_live_reads_all()
     if live > PILEUP_MAX_DEPTH:
-        msg = ("%s: up to %d reads of one cell type overlap one 64-position tile; the reference's pileup stops admitting reads above "
-               "max_depth = %d, which this library does not model, so counts there could differ" % (what, live, PILEUP_MAX_DEPTH))
+        msg = ("%s: up to %d reads (all cell types) overlap one 64-position tile; the reference's pileup of the unsplit BAM stops admitting reads above "
+               "max_depth = %d, which the genotyping path does not model, so counts there could differ" % (what, live, PILEUP_MAX_DEPTH))
         if allow_depth_overflow is None:
             allow_depth_overflow = os.environ.get("LONGSOM_ALLOW_DEPTH_OVERFLOW", "0") == "1"
         if not allow_depth_overflow:

@@ -137,10 +137,8 @@ def test_bad_event_range_is_an_error(engine):
     run_both(engine, rec, lens, refs, celltype_of, 2)
 
 
-def test_fallback_split_path(engine, monkeypatch):
-    """LSG_NO_PRESORT forces the path used when a cell type has more barcodes than k_sort_deep's LDS table holds
-    (split by barcode range + per-slot grouping): same counts."""
-    monkeypatch.setenv("LSG_NO_PRESORT", "1")
+def test_few_barcodes_with_long_runs(engine):
+    """many entries per barcode in the deep tiles: long runs, multi-job tiles cut at run starts"""
     lens = np.array([4000], np.int64)
     rec, refs, celltype_of = make_case(21, 9000, lens, 300, hot_regions=[(0, 500, 900)], hot_frac=0.9)
     run_both(engine, rec, lens, refs, celltype_of, 2)
