@@ -255,6 +255,9 @@ def main():
     eng.set_region(lo[0], lo[1], hi[0], hi[1])
     n_reads, n_segs, n_events = int(reads.n_reads), int(reads.n_segs), int(reads.n_events)
     cp, kp = CountParams.longsom_defaults(), CallParams.longsom_defaults()
+    # the load drops what SplitBam's MAPQ filter and the pileup's read filter drop (SplitBamCellTypes.py:110-113, BaseCellCounter.py:191,249):
+    # in the product the host decode does (hostio.decode_bam(min_mapq=...)); the generated arrays hold every read of the BAM
+    eng.set_load_filter(cp.min_mq, cp.flag_exclude, cp.ignore_orphans)
     # N > 1: ONE all-gather per step.  Every rank sends a message of the same agreed size: a header slot holding its number of
     # PASS-candidate rows, then room for cap_rows rows (SURVEY §8e's counts-then-buffers exchange needs two collectives and a host
     # read between them on every step).  The capacity is agreed during warm-up (the headers are read there) and checked once more

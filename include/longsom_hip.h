@@ -168,6 +168,12 @@ int lsg_set_barcodes(lsg_ctx* ctx, const uint8_t* celltype_of, int32_t n_cb, int
  * share events); a segment whose event range lies outside [0, n_events) or whose read index lies outside the reads is an error, and a
  * refused load leaves no reads behind.  Segments that do not lie inside their contig are never counted. */
 int lsg_load_reads(lsg_ctx* ctx, const lsg_reads* reads);
+/* Load filter: reads with MAPQ < min_mq, any SAM flag bit of flag_exclude, or (ignore_orphans) paired without proper pair are not
+ * stored by the NEXT lsg_load_reads calls — what SplitBamCellTypes.py:110-113 does to the BAM before BaseCellCounter sees it
+ * (LongSom passes the same min_MQ to both, R:SNVCalling.smk:22-27,52-59).  Default: none (0, 0, 0), every read with a barcode is
+ * stored and any count parameters can be resolved later; with a filter the store is smaller by the dropped reads' share and a count or
+ * genotyping pass whose own filters would admit a dropped read is refused.  The per-read arrays (depth cap, statistics) keep every read. */
+int lsg_set_load_filter(lsg_ctx* ctx, int32_t min_mq, uint32_t flag_exclude, int32_t ignore_orphans);
 /* keep != 0: the next loads also keep a copy of the compact events (and seg_ev_off) beside the store, which is what
  * lsg_copy_reads_to_host returns (tests, sampling for a CPU baseline).  Default 0: the store is the only copy (2 B per event saved). */
 int lsg_set_keep_reads(lsg_ctx* ctx, int32_t keep);

@@ -185,6 +185,23 @@ int lsg_set_keep_reads(lsg_ctx* c, int32_t keep) {
     return 0;
 }
 
+int lsg_set_load_filter(lsg_ctx* c, int32_t min_mq, uint32_t flag_exclude, int32_t ignore_orphans) {
+    if (!c) { set_error("lsg_set_load_filter: NULL handle"); return -2; }
+    c->lf_min_mq = min_mq; c->lf_flag_exclude = flag_exclude; c->lf_ignore_orphans = ignore_orphans ? 1 : 0;
+    return 0;
+}
+
+// the resident store holds only reads that passed the load filter: a count (or a genotyping pass) that would admit more is refused
+static int check_load_filter(lsg_ctx* c, const char* who, int32_t min_mq, uint32_t flag_exclude, int32_t ignore_orphans) {
+    if (min_mq < c->st_min_mq || (c->st_flag_exclude & ~flag_exclude) != 0 || (c->st_ignore_orphans && !ignore_orphans)) {
+        set_error("%s: these read filters (min_mq %d, flag_exclude 0x%x, ignore_orphans %d) admit reads the load filter dropped (min_mq %d, flag_exclude 0x%x, ignore_orphans %d): "
+                  "load the reads again under a filter no stricter than the counts' (lsg_set_load_filter)", who, min_mq, flag_exclude, ignore_orphans,
+                  c->st_min_mq, c->st_flag_exclude, c->st_ignore_orphans);
+        return -2;
+    }
+    return 0;
+}
+
 int lsg_load_reads(lsg_ctx* c, const lsg_reads* r) {
     if (!c || !r) { set_error("lsg_load_reads: bad arguments"); return -2; }
     if (c->n_contigs <= 0) { set_error("lsg_load_reads: set the contigs first (the store is laid out over their tiles)"); return -2; }
@@ -241,6 +258,7 @@ int lsg_set_region(lsg_ctx* c, int32_t tid_lo, int64_t pos_lo, int32_t tid_hi, i
 int lsg_pileup_count(lsg_ctx* c, const lsg_count_params* params, int64_t* n_rows, int64_t* n_columns) {
     if (!c || !params) { set_error("lsg_pileup_count: bad arguments"); return -2; }
     LSG_HIP(hipSetDevice(c->device));
+    if (int rc = check_load_filter(c, "lsg_pileup_count", params->min_mq, params->flag_exclude, params->ignore_orphans)) return rc;
     int rc = run_count(c, params);
     if (rc) return rc;
     if (n_rows) for (int i = 0; i < c->n_ct; ++i) n_rows[i] = c->n_rows[i];
@@ -349,6 +367,7 @@ int lsg_genotype_cells(lsg_ctx* c, const lsg_genotype_params* params, int64_t n_
                        const uint8_t* alt_sym, uint32_t* dp, uint32_t* alt, int32_t on_device) {
     if (!c || !params) { set_error("lsg_genotype_cells: bad arguments"); return -2; }
     LSG_HIP(hipSetDevice(c->device));
+    if (int rc = check_load_filter(c, "lsg_genotype_cells", params->min_mq, params->flag_exclude, params->ignore_orphans)) return rc;
     return run_genotype(c, params, n_sites, site_keys, alt_sym, dp, alt, on_device);
 }
 

@@ -118,6 +118,8 @@ struct lsg_ctx {
     lsg_reads rd{};                       // device pointers
     lsg::DevBuf b_read_tid, b_read_pos, b_read_flag, b_read_mapq, b_read_cb;
     lsg::DevBuf b_seg_read, b_seg_start, b_seg_len, b_seg_ev_off, b_events;
+    int32_t lf_min_mq = 0, lf_ignore_orphans = 0; uint32_t lf_flag_exclude = 0;      // lsg_set_load_filter: reads failing it are not stored by the next loads
+    int32_t st_min_mq = 0, st_ignore_orphans = 0; uint32_t st_flag_exclude = 0;      // ... and the filter the resident store was built under
     bool keep_reads = false;              // lsg_set_keep_reads: the compact events stay resident beside the store (rd.events; tests, sampling)
     // tile store (see above) and the plan of a count over it
     lsg::DevBuf d_tile_cap, d_tile_off;   // entries per tile and their exclusive prefix

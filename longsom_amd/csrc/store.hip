@@ -37,6 +37,7 @@ struct BuildArgs {
     uint32_t* cursor;                     // MODE 2: next free place of every tile's region
     uint4* rec; uint32_t* key; uint32_t* val;
     unsigned long long* qhead;            // work queue head of the binning pass
+    int32_t lf_min_mq, lf_ignore_orphans; uint32_t lf_flag_exclude;      // the load filter (lsg_set_load_filter)
     uint32_t* bad;                        // bit 0: a segment's event range lies outside the events; bit 1: a segment's read index outside the reads
     unsigned long long* n_ev;             // events of the statically admitted segments = events the store will hold
 };
@@ -54,8 +55,12 @@ __global__ void k_seg_static(BuildArgs a) {
             if (ln > 0 && (o < 0 || o + ln > a.n_events)) atomicOr(a.bad, 1u);
             else {
                 const int32_t tid = a.read_tid[r], cb = a.read_cb[r];
-                if (tid >= 0 && tid < a.n_contigs && cb >= 0 && (uint32_t)cb < CB_MASK && !(st < 0 || ln <= 0 || st + ln > a.contig_len[tid])) {
-                    key = (uint32_t)cb | ((((uint32_t)a.read_flag[r] >> 4) & 1u) << 24);
+                const uint32_t flag = a.read_flag[r];
+                // the load filter: what SplitBamCellTypes.py:110-113 does to the BAM before BaseCellCounter ever sees it
+                bool pool = (int)a.read_mapq[r] >= a.lf_min_mq && (flag & a.lf_flag_exclude) == 0;
+                if (pool && a.lf_ignore_orphans && (flag & 1u) && !(flag & 2u)) pool = false;
+                if (pool && tid >= 0 && tid < a.n_contigs && cb >= 0 && (uint32_t)cb < CB_MASK && !(st < 0 || ln <= 0 || st + ln > a.contig_len[tid])) {
+                    key = (uint32_t)cb | (((flag >> 4) & 1u) << 24);
                     tb = a.tile_base[tid];
                     n_ev += (unsigned long long)ln;
                 }
@@ -85,17 +90,20 @@ constexpr int BIN_SUPER = 16;          // batches per dequeue
 constexpr int BIN_MAXI = 32;           // items per chunk
 constexpr uint32_t BIN_FILL = BIN_H * 5 / 8;
 
-struct BinSeg { uint32_t key, tb, t0, rd; int32_t st, ln, ntile; int64_t evoff; };
+struct BinSeg { uint32_t key, tb, t0, rd, fm; int32_t st, ln, ntile; int64_t evoff; };
 
 template <int MODE>
 __device__ __forceinline__ BinSeg bin_load(const BuildArgs& a, int64_t s) {
-    BinSeg g; g.key = KEY_INVALID; g.tb = 0; g.t0 = 0; g.rd = 0; g.st = 0; g.ln = 0; g.ntile = 0; g.evoff = 0;
+    BinSeg g; g.key = KEY_INVALID; g.tb = 0; g.t0 = 0; g.rd = 0; g.fm = 0; g.st = 0; g.ln = 0; g.ntile = 0; g.evoff = 0;
     if (s < a.n_segs) {
         const uint2 info = a.seg_info[s];
         g.key = info.x; g.tb = info.y;
         if (g.key != KEY_INVALID) {
             g.st = a.seg_start[s]; g.ln = a.seg_len[s];
-            if (MODE == 2) { g.evoff = a.seg_ev_off[s]; g.rd = a.seg_read[s]; }
+            if (MODE == 2) {          // (a read's segments are consecutive and the reads coordinate-sorted: these gathers run along the arrays)
+                g.evoff = a.seg_ev_off[s]; g.rd = a.seg_read[s];
+                g.fm = (uint32_t)a.read_flag[g.rd] | ((uint32_t)a.read_mapq[g.rd] << 16);
+            }
             g.t0 = g.tb + ((uint32_t)g.st >> 6);
             g.ntile = (int)(((uint32_t)(g.st + g.ln - 1) >> 6) - ((uint32_t)g.st >> 6)) + 1;
         }
@@ -195,8 +203,9 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(BuildArgs a) {
                             const int32_t hi = g.st + g.ln < tstart + TILE_W ? g.st + g.ln : tstart + TILE_W;
                             const uint64_t src = (uint64_t)(g.evoff + (lo - g.st));             // the entry's first event in the caller's array
                             const uint32_t cbk = g.key & CB_MASK;
-                            a.rec[pos] = make_uint4(cbk | ((uint32_t)(hi - lo - 1) << 24) | (((g.key >> 24) & 1u) ? 0u : TM_FWD) | (lo == g.st ? TM_RUNSTART : 0u),
-                                                    g.rd, (uint32_t)src, (uint32_t)(src >> 32) | ((uint32_t)(lo - tstart) << 8));
+                            // record: owning read | SAM flag, MAPQ | source of the events (40 bits), first position in the tile, events - 1, strand, first of its segment
+                            a.rec[pos] = make_uint4(g.rd, g.fm, (uint32_t)src,
+                                                    (uint32_t)(src >> 32) | ((uint32_t)(lo - tstart) << 8) | ((uint32_t)(hi - lo - 1) << 16) | (((g.key >> 24) & 1u) ? 0u : TM_FWD) | (lo == g.st ? TM_RUNSTART : 0u));
                             a.key[pos] = cbk;
                             a.val[pos] = pos;
                         }
@@ -236,7 +245,7 @@ __global__ void k_tm_blk_tile(const uint32_t* blk_off, uint32_t n_tiles, uint32_
 }
 
 // per padded entry: the static words of the store, and where its events lie in the caller's array
-__global__ void k_tm_fill(const uint32_t* key, const uint32_t* val, const uint4* rec, const uint16_t* read_flag, const uint8_t* read_mapq,
+__global__ void k_tm_fill(const uint32_t* key, const uint32_t* val, const uint4* rec,
                           const uint32_t* tile_off, const uint32_t* blk_off, const uint32_t* blk_tile, uint64_t np,
                           uint32_t* s0, uint8_t* b8, uint32_t* fm, uint32_t* rd, uint2* gsrc) {
     for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < np; p += (uint64_t)gridDim.x * blockDim.x) {
@@ -247,11 +256,11 @@ __global__ void k_tm_fill(const uint32_t* key, const uint32_t* val, const uint4*
         const uint4 e = rec[val[j]];
         const bool rs = i == 0 || key[j - 1] != k;
         const bool single = rs && (i + 1 == n || key[j + 1] != k);
-        s0[p] = k | (e.x & TM_FWD) | (rs ? TM_RUNSTART : 0u);
-        b8[p] = (uint8_t)(((e.x >> 24) & 63u) | ((e.x >> 31) ? 64u : 0u) | (single ? 128u : 0u));
-        fm[p] = (uint32_t)read_flag[e.y] | ((uint32_t)read_mapq[e.y] << 16);
-        rd[p] = e.y;
-        gsrc[p] = make_uint2(e.z, e.w);
+        s0[p] = k | (e.w & TM_FWD) | (rs ? TM_RUNSTART : 0u);
+        b8[p] = (uint8_t)(((e.w >> 16) & 63u) | ((e.w >> 31) ? 64u : 0u) | (single ? 128u : 0u));
+        fm[p] = e.y;
+        rd[p] = e.x;
+        gsrc[p] = make_uint2(e.z, e.w & 0x3fffu);
     }
 }
 
@@ -355,6 +364,7 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
         return 0;
     };
     for (auto& v : c->build_ms) v = 0;
+    c->st_min_mq = c->lf_min_mq; c->st_flag_exclude = c->lf_flag_exclude; c->st_ignore_orphans = c->lf_ignore_orphans;
     if (c->d_tile_cap.reserve(((size_t)T + 2) * 4) || c->d_tile_off.reserve(((size_t)T + 2) * 4) || c->d_scalars.reserve(512 * 8)) return -1;
     LSG_HIP(hipMemsetAsync(c->d_tile_cap.p, 0, ((size_t)T + 2) * 4, st));
     LSG_HIP(hipMemsetAsync(c->d_tile_off.p, 0, ((size_t)T + 2) * 4, st));
@@ -367,6 +377,7 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
     a.seg_read = c->rd.seg_read; a.seg_start = c->rd.seg_start; a.seg_len = c->rd.seg_len; a.seg_ev_off = seg_ev_off;
     a.tile_base = c->d_tile_base.as<uint32_t>(); a.contig_len = c->d_contig_len.as<int64_t>(); a.n_contigs = c->n_contigs; a.n_tiles = T;
     a.seg_info = c->ws[WS_SEG_INFO].as<uint2>(); a.tile_cap = c->d_tile_cap.as<uint32_t>();
+    a.lf_min_mq = c->lf_min_mq; a.lf_flag_exclude = c->lf_flag_exclude; a.lf_ignore_orphans = c->lf_ignore_orphans;
     a.qhead = c->d_scalars.as<unsigned long long>(); a.bad = reinterpret_cast<uint32_t*>(c->d_scalars.as<unsigned long long>() + 2);
     a.n_ev = c->d_scalars.as<unsigned long long>() + 3;
     uint32_t* d_small = reinterpret_cast<uint32_t*>(c->d_scalars.as<unsigned long long>() + 4);      // [0] max entries of a tile, [1] non-empty tiles, [2] largest barcode id
@@ -460,17 +471,26 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
     const uint64_t np = (uint64_t)nblk * 8;
     c->tm_np = np; c->tm_nblk = nblk;
     DevBuf& gsrc = c->bt[BT_GSRC];
-    if (c->tm[TM_STORE].reserve(((size_t)nblk + TM_GROUP) * 1024) || c->tm[TM_S0].reserve((np + 16) * 4) || c->tm[TM_B].reserve(np + 16) ||
+    if (c->tm[TM_S0].reserve((np + 16) * 4) || c->tm[TM_B].reserve(np + 16) ||
         c->tm[TM_FM].reserve((np + 16) * 4) || c->tm[TM_RD].reserve((np + 16) * 4) || c->tm[TM_META].reserve((np + 8 * (TM_GROUP + 1)) * 4) ||
         c->tm[TM_BLK_TILE].reserve(((size_t)nblk + 2) * 4) || c->tm[TM_EXT].reserve(((size_t)nblk + TM_GROUP + 2) * 2) || gsrc.reserve((np + 16) * 8)) return -1;
     hipLaunchKernelGGL(k_tm_blk_tile, dim3((nblk + 255) / 256), dim3(256), 0, st, blk_off, T, nblk, c->tm[TM_BLK_TILE].as<uint32_t>());
-    hipLaunchKernelGGL(k_tm_fill, dim3((unsigned)(c->n_cus * 16)), dim3(256), 0, st, key_b.as<uint32_t>(), val_b.as<uint32_t>(), rec.as<uint4>(), c->rd.read_flag, c->rd.read_mapq,
+    hipLaunchKernelGGL(k_tm_fill, dim3((unsigned)(c->n_cus * 16)), dim3(256), 0, st, key_b.as<uint32_t>(), val_b.as<uint32_t>(), rec.as<uint4>(),
                        c->d_tile_off.as<uint32_t>(), blk_off, c->tm[TM_BLK_TILE].as<uint32_t>(), np,
                        c->tm[TM_S0].as<uint32_t>(), c->tm[TM_B].as<uint8_t>(), c->tm[TM_FM].as<uint32_t>(), c->tm[TM_RD].as<uint32_t>(), gsrc.as<uint2>());
     LSG_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c->tm[TM_S0].as<uint32_t>() + np), (int)TM_PAD_S0, 16, st));       // (what the walk's group loads and the run flags' neighbours see past the end)
     LSG_HIP(hipMemsetAsync(c->tm[TM_B].as<uint8_t>() + np, 0, 16, st));
     LSG_HIP(hipEventRecord(c->evb[3], st));
-    // ---- 5. the events
+    // ---- 5. the events.  The blocks are the load's largest allocation: when they are not there yet and the load is large against the
+    // device (C4: 124 GB of blocks beside 91 GB of the caller's events), the sort's buffers go first
+    if (c->tm[TM_STORE].cap < ((size_t)nblk + TM_GROUP) * 1024) {
+        size_t mem_free = 0, mem_total = 0;
+        if (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess && ((size_t)nblk + TM_GROUP) * 1024 + (size_t)nblk * 64 > mem_free / 2) {
+            LSG_HIP(hipStreamSynchronize(st));
+            rec.release(); key_a.release(); key_b.release(); val_a.release(); val_b.release(); c->ws[WS_SEG_INFO].release();
+        }
+        if (c->tm[TM_STORE].reserve(((size_t)nblk + TM_GROUP) * 1024)) return -1;
+    }
     hipLaunchKernelGGL(k_tm_gather, dim3((unsigned)((((uint64_t)nblk + TMG_BLOCKS - 1) / TMG_BLOCKS + TMG_WAVES - 1) / TMG_WAVES)), dim3(TMG_WAVES * 64), 0, st,
                        events, n_events, c->tm[TM_S0].as<uint32_t>(), c->tm[TM_B].as<uint8_t>(), gsrc.as<uint2>(), nblk, c->tm[TM_STORE].as<uint4>(), c->tm[TM_EXT].as<uint16_t>());
     LSG_HIP(hipEventRecord(c->evb[4], st));

@@ -91,6 +91,11 @@ class Engine:
         if keep_reads:
             self.set_keep_reads(True)
 
+    def set_load_filter(self, min_mq: int = 0, flag_exclude: int = 0, ignore_orphans: int = 0):
+        """Reads failing these are not stored by the next loads (what SplitBamCellTypes.py:110-113 does before BaseCellCounter sees the
+        BAM); later counts must be at least as strict.  Default: no filter (lsg_set_load_filter)."""
+        _lib.check(self._lib.lsg_set_load_filter(self._h, int(min_mq), int(flag_exclude), int(ignore_orphans)), "lsg_set_load_filter")
+
     def set_keep_reads(self, keep: bool):
         _lib.check(self._lib.lsg_set_keep_reads(self._h, 1 if keep else 0), "lsg_set_keep_reads")
 

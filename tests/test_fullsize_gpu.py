@@ -1,0 +1,37 @@
+"""GPU: BASELINE's C2 workload at its FULL size (10 M reads, 47.5 M count rows) against digests the CPU oracle wrote.
+
+tools/oracle_hashes.py evaluated the synthetic model on the host region by region (hostio.synth_records == the device generator,
+tests/test_synth_gpu.py), counted every region's columns with oracle/count_oracle.c (lso_count_span_mt) on the build container's cores
+and streamed the rows into xxhash digests (tests/golden/rows_hash_oracle_c2_10000000.json; 14 min on 6 threads).  Nothing the GPU wrote
+is part of the pin.  The HIP rows are fetched cell type by cell type (4 GB of rows each) and hashed the same way."""
+import json
+import os
+
+import numpy as np
+import pytest
+import xxhash
+
+from longsom_amd import synth
+from longsom_amd._lib import CountParams
+
+pytestmark = pytest.mark.gpu
+PIN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rows_hash_oracle_c2_10000000.json")
+
+
+def test_c2_full_size_rows_equal_the_cpu_oracle():
+    from longsom_amd.engine import Engine
+    want = json.load(open(PIN))
+    m = synth.named("C2")
+    assert m.n_reads == want["n_reads"] == 10_000_000
+    p = CountParams.longsom_defaults()
+    with Engine(0) as eng:
+        eng.set_contigs(m.contig_len); eng.synth_reference(m.seed); eng.set_barcodes(m.celltype_of, 2)
+        eng.set_load_filter(p.min_mq, p.flag_exclude, p.ignore_orphans)          # as bench.py loads it
+        eng.synth_reads(m)
+        rows, cols = eng.pileup_count(p)
+        assert rows == want["rows"] and cols == want["columns"]
+        for ct in range(2):
+            k, r, c = eng.fetch_counts(ct)
+            got = [xxhash.xxh64(np.ascontiguousarray(x).tobytes()).hexdigest() for x in (k, r, c)]
+            del k, r, c
+            assert got == want["ct%d" % ct], "cell type %d: rows of the full C2 workload differ from the CPU oracle's" % ct

@@ -150,3 +150,34 @@ def test_unsorted_barcode_ids_and_sparse_ids(engine):
     ct_of[:] = 255
     ct_of[[1, 17, 1024, 2999]] = [0, 1, 0, 1]
     run_both(engine, rec, lens, refs, ct_of, 2, CountParams.longsom_defaults(min_dp=1, min_cc=1))
+
+
+def test_load_filter_drops_reads_like_splitbam(engine):
+    """lsg_set_load_filter: reads that fail it never reach the store (SplitBamCellTypes.py:110-113 filters the BAM before
+    BaseCellCounter); counts at least as strict equal the oracle, a looser count is refused"""
+    from longsom_amd._lib import LsgError
+    lens = [3000, 800]
+    rec, refs, ct_of = make_case(51, 12000, lens, 100, hot_regions=[(0, 700, 760)], hot_frac=0.5)
+    engine.set_contigs(lens)
+    for t, r in enumerate(refs):
+        engine.load_reference(t, r)
+    engine.set_barcodes(ct_of, 2)
+    engine.set_load_filter()
+    engine.load_reads(rec)
+    full = engine.store_shape()
+    p = CountParams.longsom_defaults()
+    try:
+        engine.set_load_filter(p.min_mq, p.flag_exclude, p.ignore_orphans)
+        engine.load_reads(rec)
+        small = engine.store_shape()
+        assert small[0] < full[0] and small[2] < full[2]
+        check(engine, rec, lens, refs, ct_of, 2, p)
+        check(engine, rec, lens, refs, ct_of, 2, CountParams.longsom_defaults(min_mq=61, min_bq=25))
+        with pytest.raises(LsgError, match="load filter"):
+            engine.pileup_count(CountParams.longsom_defaults(min_mq=30))
+        with pytest.raises(LsgError, match="load filter"):
+            engine.pileup_count(CountParams.longsom_defaults(flag_exclude=0x704))
+    finally:
+        engine.set_load_filter()
+    engine.load_reads(rec)
+    check(engine, rec, lens, refs, ct_of, 2, CountParams.longsom_defaults(min_mq=30))
