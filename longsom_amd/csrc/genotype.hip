@@ -7,7 +7,7 @@
 namespace lsg {
 
 struct GenoArgs {
-    const uint4* store; const uint32_t* s0; const uint32_t* fm;
+    const uint4* store; const uint16_t* ext; const uint32_t* s0; const uint32_t* fm;
     const uint32_t* tile_base; const uint32_t* tile_off; const uint32_t* blk_off;
     const uint8_t* celltype_of; const int64_t* contig_len;
     int32_t n_contigs, n_cb;
@@ -27,6 +27,8 @@ __global__ __launch_bounds__(256) void k_geno_sites(GenoArgs a) {
     const uint32_t n = a.tile_off[t + 1] - a.tile_off[t], b0 = a.blk_off[t];
     const uint32_t alt_sym = a.alt_sym[i];
     for (uint32_t k = threadIdx.x; k < (n + 7u) / 8u; k += blockDim.x) {
+        const uint32_t x = a.ext[b0 + k];                                          // rows outside the block's extent hold no event (and were never written)
+        if (q < (x & 0xffu) || q >= (x >> 8)) continue;
         const uint4 row = a.store[(uint64_t)(b0 + k) * 64 + q];
         const uint32_t w[4] = {row.x, row.y, row.z, row.w};
 #pragma unroll
@@ -65,7 +67,7 @@ int run_genotype(lsg_ctx* c, const lsg_genotype_params* p, int64_t n_sites, cons
     auto done = [&](int rc) { d_keys.release(); d_alt_sym.release(); d_dp.release(); d_alt.release(); return rc; };
     if (!c->tm_valid) { set_error("lsg_genotype_cells: no reads loaded"); return -2; }
     GenoArgs a{};
-    a.store = c->tm[TM_STORE].as<uint4>(); a.s0 = c->tm[TM_S0].as<uint32_t>(); a.fm = c->tm[TM_FM].as<uint32_t>();
+    a.store = c->tm[TM_STORE].as<uint4>(); a.ext = c->tm[TM_EXT].as<uint16_t>(); a.s0 = c->tm[TM_S0].as<uint32_t>(); a.fm = c->tm[TM_FM].as<uint32_t>();
     a.tile_base = c->d_tile_base.as<uint32_t>(); a.tile_off = c->d_tile_off.as<uint32_t>(); a.blk_off = c->tm[TM_BLK_OFF].as<uint32_t>();
     a.celltype_of = c->d_celltype_of.as<uint8_t>(); a.contig_len = c->d_contig_len.as<int64_t>();
     a.n_contigs = c->n_contigs; a.n_cb = c->n_cb; a.p = *p; a.n_sites = n_sites;

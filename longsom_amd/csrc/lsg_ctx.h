@@ -124,7 +124,7 @@ struct lsg_ctx {
     // tile store (see above) and the plan of a count over it
     lsg::DevBuf d_tile_cap, d_tile_off;   // entries per tile and their exclusive prefix
     lsg::DevBuf tm[lsg::TM_NBUF];
-    lsg::DevBuf bt[12];                   // temporaries of the build (kept while they are small against the device: allocation is what a rebuild would wait for)
+    lsg::DevBuf bt[14];                   // temporaries of the build (kept while they are small against the device: allocation is what a rebuild would wait for)
     uint64_t tm_n = 0;                    // entries
     int64_t tm_events = 0;                // events they hold
     uint64_t tm_np = 0;                   // padded entries = 8 x blocks

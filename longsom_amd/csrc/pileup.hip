@@ -699,7 +699,8 @@ __global__ __launch_bounds__(64) void k_tm_walk_wide(CountArgs a, TmArgs tm) {
             if (m & TMM_RS) { nc[run_ct] += mask ? 1u : 0u; mask = 0; }
             if (m & TMM_SKIP) continue;
             run_ct = (m & TMM_CT4) ? 1u : 0u;
-            const uint32_t ev = ev16[((uint64_t)(p >> 3) * 64 + lane) * 8 + (p & 7u)];
+            const uint32_t x = tm.ext[p >> 3];                                        // rows outside the block's extent hold no event (and were never written)
+            const uint32_t ev = (uint32_t)lane >= (x & 0xffu) && (uint32_t)lane < (x >> 8) ? ev16[((uint64_t)(p >> 3) * 64 + lane) * 8 + (p & 7u)] : 0u;
             if ((ev & 0x8ffu) >= thr) {
                 const uint32_t sym = (ev >> 8) & 7u;
                 uint32_t* q = &pl[run_ct][0][sym * 64 + lane];

@@ -40,37 +40,78 @@ struct BuildArgs {
     int32_t lf_min_mq, lf_ignore_orphans; uint32_t lf_flag_exclude;      // the load filter (lsg_set_load_filter)
     uint32_t* bad;                        // bit 0: a segment's event range lies outside the events; bit 1: a segment's read index outside the reads
     unsigned long long* n_ev;             // events of the statically admitted segments = events the store will hold
+    int32_t* span_diff;                   // [n_tiles + 1] marks of the reads' spans (the depth cap's bound), or null
 };
 
-// Static admission of a segment: its read carries a barcode and lies on a contig, the segment lies inside the contig (what ANY count
-// parameters or barcode table can admit; malformed segments are never counted).  Also the load's validation of the caller's arrays.
-__global__ void k_seg_static(BuildArgs a) {
+// Static admission of a segment: its read carries a barcode, passes the load filter and lies on a contig, the segment lies inside the
+// contig (what ANY count parameters or barcode table can admit; malformed segments are never counted).  Also the load's validation of
+// the caller's arrays — and the marks of the depth cap's bound (layout.hip): +1 at the tile a read's first segment starts in, -1 past
+// the tile its last segment ends in, for every read with a barcode.  The reads of a deep gene start and end in the same few tiles and a
+// word takes ~90 atomics per microsecond, so a workgroup merges the marks of a batch of 256 consecutive segments in an LDS hash and
+// issues one global atomic per distinct tile.
+constexpr int SEG_THREADS = 256, SEG_H = 1024;
+__global__ __launch_bounds__(SEG_THREADS) void k_seg_static(BuildArgs a) {
+    __shared__ uint32_t hkey[SEG_H];
+    __shared__ int32_t hval[SEG_H];
+    __shared__ unsigned long long s_ev;
+    for (int i = threadIdx.x; i < SEG_H; i += SEG_THREADS) { hkey[i] = KEY_INVALID; hval[i] = 0; }
+    if (threadIdx.x == 0) s_ev = 0;
+    auto mark = [&](uint32_t t, int32_t v) {
+        uint32_t h = (t * 2654435761u) >> 22;
+        while (true) {
+            const uint32_t prev = atomicCAS(&hkey[h], KEY_INVALID, t);
+            if (prev == KEY_INVALID || prev == t) break;
+            h = (h + 1) & (SEG_H - 1);
+        }
+        atomicAdd(&hval[h], v);
+    };
     unsigned long long n_ev = 0;
-    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < a.n_segs; s += (int64_t)gridDim.x * blockDim.x) {
-        const uint32_t r = a.seg_read[s];
-        uint32_t key = KEY_INVALID, tb = 0;
-        if ((int64_t)r >= a.n_reads) atomicOr(a.bad, 2u);
-        else {
-            const int64_t st = a.seg_start[s], ln = a.seg_len[s], o = a.seg_ev_off[s];
-            if (ln > 0 && (o < 0 || o + ln > a.n_events)) atomicOr(a.bad, 1u);
+    const int64_t n_batches = (a.n_segs + SEG_THREADS - 1) / SEG_THREADS;
+    for (int64_t bt = blockIdx.x; bt < n_batches; bt += gridDim.x) {
+        __syncthreads();
+        const int64_t s = bt * SEG_THREADS + threadIdx.x;
+        if (s < a.n_segs) {
+            const uint32_t r = a.seg_read[s];
+            uint32_t key = KEY_INVALID, tb = 0;
+            if ((int64_t)r >= a.n_reads) atomicOr(a.bad, 2u);
             else {
+                const int64_t st = a.seg_start[s], ln = a.seg_len[s], o = a.seg_ev_off[s];
                 const int32_t tid = a.read_tid[r], cb = a.read_cb[r];
-                const uint32_t flag = a.read_flag[r];
-                // the load filter: what SplitBamCellTypes.py:110-113 does to the BAM before BaseCellCounter ever sees it
-                bool pool = (int)a.read_mapq[r] >= a.lf_min_mq && (flag & a.lf_flag_exclude) == 0;
-                if (pool && a.lf_ignore_orphans && (flag & 1u) && !(flag & 2u)) pool = false;
-                if (pool && tid >= 0 && tid < a.n_contigs && cb >= 0 && (uint32_t)cb < CB_MASK && !(st < 0 || ln <= 0 || st + ln > a.contig_len[tid])) {
-                    key = (uint32_t)cb | (((flag >> 4) & 1u) << 24);
-                    tb = a.tile_base[tid];
-                    n_ev += (unsigned long long)ln;
+                const bool on_contig = tid >= 0 && tid < a.n_contigs;
+                if (ln > 0 && (o < 0 || o + ln > a.n_events)) atomicOr(a.bad, 1u);
+                else {
+                    const uint32_t flag = a.read_flag[r];
+                    // the load filter: what SplitBamCellTypes.py:110-113 does to the BAM before BaseCellCounter ever sees it
+                    bool pool = (int)a.read_mapq[r] >= a.lf_min_mq && (flag & a.lf_flag_exclude) == 0;
+                    if (pool && a.lf_ignore_orphans && (flag & 1u) && !(flag & 2u)) pool = false;
+                    if (pool && on_contig && cb >= 0 && (uint32_t)cb < CB_MASK && !(st < 0 || ln <= 0 || st + ln > a.contig_len[tid])) {
+                        key = (uint32_t)cb | (((flag >> 4) & 1u) << 24);
+                        tb = a.tile_base[tid];
+                        n_ev += (unsigned long long)ln;
+                    }
+                }
+                if (a.span_diff && on_contig && cb >= 0) {          // (every read with a barcode, whatever the load filter: a bound never under-counts)
+                    const bool first = s == 0 || a.seg_read[s - 1] != r, last = s + 1 == a.n_segs || a.seg_read[s + 1] != r;
+                    const uint32_t t0 = a.tile_base[tid], te = a.tile_base[tid + 1];
+                    if ((first || last) && te > t0) {
+                        // the read is still buffered while the column AFTER its last one is entered (freed by that column's sweep): span end inclusive;
+                        // both marks are clamped into the contig so that every +1 has its -1
+                        int64_t b = st < 0 ? 0 : st, e = st + (ln > 0 ? ln : 0);
+                        if (e < 0) e = 0;
+                        if (first) { uint32_t t = t0 + (uint32_t)(b >> 6); if (t >= te) t = te - 1; mark(t, 1); }
+                        if (last) { uint32_t t = t0 + (uint32_t)(e >> 6) + 1; if (t > te) t = te; mark(t, -1); }
+                    }
                 }
             }
+            a.seg_info[s] = make_uint2(key, tb);
         }
-        a.seg_info[s] = make_uint2(key, tb);
+        if (a.span_diff) {
+            __syncthreads();
+            for (int i = threadIdx.x; i < SEG_H; i += SEG_THREADS)
+                if (hkey[i] != KEY_INVALID) { if (hval[i] != 0) atomicAdd(a.span_diff + hkey[i], hval[i]); hkey[i] = KEY_INVALID; hval[i] = 0; }
+        }
     }
     for (int o = 32; o > 0; o >>= 1) n_ev += __shfl_down(n_ev, o);
-    __shared__ unsigned long long s_ev;
-    if (threadIdx.x == 0) s_ev = 0;
     __syncthreads();
     if ((threadIdx.x & 63) == 0 && n_ev) atomicAdd(&s_ev, n_ev);
     __syncthreads();
@@ -244,54 +285,59 @@ __global__ void k_tm_blk_tile(const uint32_t* blk_off, uint32_t n_tiles, uint32_
     if (b < nblk) blk_tile[b] = tm_owner(blk_off, n_tiles, b);
 }
 
-// per padded entry: the static words of the store, and where its events lie in the caller's array
-__global__ void k_tm_fill(const uint32_t* key, const uint32_t* val, const uint4* rec,
-                          const uint32_t* tile_off, const uint32_t* blk_off, const uint32_t* blk_tile, uint64_t np,
-                          uint32_t* s0, uint8_t* b8, uint32_t* fm, uint32_t* rd, uint2* gsrc) {
-    for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < np; p += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t t = blk_tile[p >> 3];
-        const uint32_t i = (uint32_t)(p - (uint64_t)blk_off[t] * 8), off = tile_off[t], n = tile_off[t + 1] - off;
-        if (i >= n) { s0[p] = TM_PAD_S0; b8[p] = 0; fm[p] = 0xffffu; rd[p] = 0; gsrc[p] = make_uint2(0u, 0u); continue; }
-        const uint32_t j = off + i, k = key[j];
-        const uint4 e = rec[val[j]];
-        const bool rs = i == 0 || key[j - 1] != k;
-        const bool single = rs && (i + 1 == n || key[j + 1] != k);
-        s0[p] = k | (e.w & TM_FWD) | (rs ? TM_RUNSTART : 0u);
-        b8[p] = (uint8_t)(((e.w >> 16) & 63u) | ((e.w >> 31) ? 64u : 0u) | (single ? 128u : 0u));
-        fm[p] = e.y;
-        rd[p] = e.x;
-        gsrc[p] = make_uint2(e.z, e.w & 0x3fffu);
-    }
-}
-
-// One wave per TMG_BLOCKS blocks.  Lane = (entry u of the block, 16-byte chunk c of its <= 128 bytes): ONE load instruction per block
-// fetches all eight entries from wherever they lie in the caller's array (2-byte aligned: the hardware takes unaligned dwordx4).  The
-// chunks cross an LDS tile [entry][64 events]; lane = position then picks, per entry, the event at (position - first position of the
-// entry) and the block leaves as one transposed kilobyte.
+// One wave per TMG_BLOCKS blocks = 8 TMG_BLOCKS entries, in two steps.
+// (a) Lanes 0 .. 8 TMG_BLOCKS - 1, one entry each, in sorted order: the entry's record (gathered through the sort's permutation), its run
+//     flags (neighbouring sort keys) -> the store's per-entry words s0, b, fm, rd; where its events lie stays in the lane's registers.
+// (b) Lane = (entry u of a block, 16-byte chunk c of its <= 128 bytes): ONE load instruction per block fetches all eight entries from
+//     wherever they lie in the caller's array (2-byte aligned: the hardware takes unaligned dwordx4).  The chunks cross an LDS tile
+//     [entry][64 events]; lane = position then picks, per entry, the event at (position - first position of the entry), and the rows
+//     between the block's first and last position with an event leave as one transposed kilobyte (rows outside that extent are never
+//     read: the walk's buffer descriptor ends there, genotype.hip tests it).
 constexpr int TMG_BLOCKS = 4, TMG_WAVES = 4;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 struct __attribute__((packed, aligned(2))) U4A2 { u32x4 v; };
-__global__ __launch_bounds__(TMG_WAVES * 64) void k_tm_gather(const uint16_t* events, int64_t n_events, const uint32_t* s0, const uint8_t* b8, const uint2* gsrc,
-                                                               uint32_t nblk, uint4* store, uint16_t* ext) {
+__global__ __launch_bounds__(TMG_WAVES * 64) void k_tm_gather(const uint16_t* events, int64_t n_events, const uint32_t* key, const uint32_t* val, const uint4* rec,
+                                                               const uint32_t* tile_off, const uint32_t* blk_off, const uint32_t* blk_tile, uint32_t nblk,
+                                                               uint32_t* s0, uint8_t* b8, uint32_t* fm, uint32_t* rd, uint4* store, uint16_t* ext) {
     __shared__ __attribute__((aligned(16))) uint16_t lds[TMG_WAVES][TMG_BLOCKS][8][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t blk0 = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * TMG_BLOCKS;
     if (blk0 >= nblk) return;
+    // ---- (a)
+    uint32_t e_src = 0, e_info = 0;                 // source of the entry's events, low 32 bits; high 8 bits [0..7] | first position [8..13] | events [16..22] (0: not there)
+    if (lane < 8 * TMG_BLOCKS) {
+        const uint32_t blk = blk0 + ((uint32_t)lane >> 3);
+        if (blk < nblk) {
+            const uint64_t p = (uint64_t)blk * 8 + (lane & 7);
+            const uint32_t t = blk_tile[blk];
+            const uint32_t i = (uint32_t)(p - (uint64_t)blk_off[t] * 8), off = tile_off[t], n = tile_off[t + 1] - off;
+            if (i >= n) { s0[p] = TM_PAD_S0; b8[p] = 0; fm[p] = 0xffffu; rd[p] = 0; }
+            else {
+                const uint32_t j = off + i, k = key[j];
+                const uint4 e = rec[val[j]];
+                const bool rs = i == 0 || key[j - 1] != k;
+                const bool single = rs && (i + 1 == n || key[j + 1] != k);
+                const uint32_t nev1 = (e.w >> 16) & 63u;
+                s0[p] = k | (e.w & TM_FWD) | (rs ? TM_RUNSTART : 0u);
+                b8[p] = (uint8_t)(nev1 | ((e.w >> 31) ? 64u : 0u) | (single ? 128u : 0u));
+                fm[p] = e.y;
+                rd[p] = e.x;
+                e_src = e.z; e_info = (e.w & 0x3fffu) | ((nev1 + 1u) << 16);
+            }
+        }
+    }
+    // ---- (b)
     const int u = lane >> 3, c = lane & 7;
     u32x4 chunk[TMG_BLOCKS];
-    uint32_t info[TMG_BLOCKS];                      // first position [0..7] | events [8..15] of the lane's entry (0 events: not there)
+    uint32_t info[TMG_BLOCKS];
 #pragma unroll
     for (int q = 0; q < TMG_BLOCKS; ++q) {
-        chunk[q] = u32x4{0u, 0u, 0u, 0u}; info[q] = 0;
-        const uint32_t blk = blk0 + q;
-        if (blk >= nblk) continue;
-        const uint64_t p = (uint64_t)blk * 8 + u;
-        if ((s0[p] & CB_MASK) == CB_MASK) continue;
-        const uint2 g = gsrc[p];
-        const uint32_t nev = ((uint32_t)b8[p] & 63u) + 1u;
-        info[q] = ((g.y >> 8) & 63u) | (nev << 8);
+        chunk[q] = u32x4{0u, 0u, 0u, 0u};
+        const uint32_t lo32 = (uint32_t)__shfl((int)e_src, q * 8 + u), inf = (uint32_t)__shfl((int)e_info, q * 8 + u);
+        info[q] = inf;
+        const uint32_t nev = inf >> 16;
         if ((uint32_t)c * 8u < nev) {
-            const int64_t off = (int64_t)(((uint64_t)(g.y & 0xffu) << 32) | g.x) + c * 8;
+            const int64_t off = (int64_t)(((uint64_t)(inf & 0xffu) << 32) | lo32) + c * 8;
             if (off + 8 <= n_events) chunk[q] = reinterpret_cast<const U4A2*>(events + off)->v;
             else {                                   // the last events of the array: never read past it
                 uint32_t w[4] = {0u, 0u, 0u, 0u};
@@ -312,15 +358,15 @@ __global__ __launch_bounds__(TMG_WAVES * 64) void k_tm_gather(const uint16_t* ev
 #pragma unroll
         for (int uu = 0; uu < 8; ++uu) {
             const uint32_t inf = (uint32_t)__builtin_amdgcn_readlane((int)info[q], uu * 8);
-            const uint32_t idx = (uint32_t)lane - (inf & 0xffu);
-            e[uu] = idx < (inf >> 8) ? (uint32_t)lds[wv][q][uu][idx & 63u] : 0u;
+            const uint32_t idx = (uint32_t)lane - ((inf >> 8) & 63u);
+            e[uu] = idx < (inf >> 16) ? (uint32_t)lds[wv][q][uu][idx & 63u] : 0u;
             any |= e[uu];
         }
-        store[(uint64_t)blk * 64 + lane] = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
-        // the positions outside [first, last] of the block's events are zeros in all eight entries (exon and read ends shared by the
-        // tile's reads): the walk does not fetch them (its buffer descriptor ends there, lanes outside read zeros)
         const unsigned long long m = __ballot(any != 0u);
-        if (lane == 0) ext[blk] = m ? (uint16_t)(__ffsll((long long)m) - 1) | (uint16_t)((64 - __clzll((long long)m)) << 8) : (uint16_t)0;
+        const int first = m ? __ffsll((long long)m) - 1 : 0, last = m ? 64 - __clzll((long long)m) : 0;
+        if (lane >= first && lane < last)
+            store[(uint64_t)blk * 64 + lane] = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+        if (lane == 0) ext[blk] = (uint16_t)(first | (last << 8));
     }
 }
 
@@ -333,7 +379,7 @@ __global__ __launch_bounds__(TMG_WAVES * 64) void k_tm_gather(const uint16_t* ev
         LSG_HIP(hipcub::DeviceScan::ExclusiveSum(c->d_cub_tmp.p, tb_, (in), (out), (int)(n), st));       \
     } while (0)
 
-enum { BT_REC = 0, BT_KEY_A, BT_KEY_B, BT_VAL_A, BT_VAL_B, BT_GSRC, BT_NETILE, BT_SEG_BEGIN, BT_SEG_END, BT_TMP, BT_PER_TILE, BT_OFFS };
+enum { BT_REC = 0, BT_KEY_A, BT_KEY_B, BT_VAL_A, BT_VAL_B, BT_PEX, BT_NETILE, BT_SEG_BEGIN, BT_SEG_END, BT_TMP, BT_PER_TILE, BT_OFFS, BT_SPAN, BT_SPAN_RUN };
 
 void drop_store(lsg_ctx* c) {
     c->tm_valid = false; c->plan_n_ct = 0; c->tm_n = 0; c->tm_events = 0; c->tm_np = 0; c->tm_nblk = 0; c->tm_njobs = 0; c->tm_nchunks = 0;
@@ -380,7 +426,10 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
     a.lf_min_mq = c->lf_min_mq; a.lf_flag_exclude = c->lf_flag_exclude; a.lf_ignore_orphans = c->lf_ignore_orphans;
     a.qhead = c->d_scalars.as<unsigned long long>(); a.bad = reinterpret_cast<uint32_t*>(c->d_scalars.as<unsigned long long>() + 2);
     a.n_ev = c->d_scalars.as<unsigned long long>() + 3;
-    uint32_t* d_small = reinterpret_cast<uint32_t*>(c->d_scalars.as<unsigned long long>() + 4);      // [0] max entries of a tile, [1] non-empty tiles, [2] largest barcode id
+    if (c->bt[BT_SPAN].reserve(((size_t)T + 2) * 4) || c->bt[BT_SPAN_RUN].reserve(((size_t)T + 2) * 4)) return -1;
+    LSG_HIP(hipMemsetAsync(c->bt[BT_SPAN].p, 0, ((size_t)T + 2) * 4, st));
+    a.span_diff = c->bt[BT_SPAN].as<int32_t>();
+    uint32_t* d_small = reinterpret_cast<uint32_t*>(c->d_scalars.as<unsigned long long>() + 4);      // [0] max entries of a tile, [1] non-empty tiles, [2] largest barcode id, [3] the live-reads bound
     DevBuf& tmp = c->bt[BT_TMP];
     LSG_HIP(hipEventRecord(c->evb[0], st));
     // ---- 1. static admission + capacities
@@ -389,6 +438,16 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
     hipLaunchKernelGGL(k_seg_static, dim3(g_seg), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_bin<0>, dim3(g_bin), dim3(BIN_THREADS), 0, st, a);
     SCAN_U32(c->d_tile_cap.as<uint32_t>(), c->d_tile_off.as<uint32_t>(), T + 1);
+    {   // the depth cap's table-independent bound (layout.hip live_read_bound_all): reads of any cell type whose span touches a tile, maximum over tiles
+        int32_t* run = c->bt[BT_SPAN_RUN].as<int32_t>();
+        size_t tb = 0, tb2 = 0;
+        LSG_HIP(hipcub::DeviceScan::InclusiveSum(nullptr, tb, a.span_diff, run, (int)(T + 1), st));
+        LSG_HIP(hipcub::DeviceReduce::Max(nullptr, tb2, run, reinterpret_cast<int32_t*>(d_small + 3), (int)(T + 1), st));
+        if (tmp.reserve((tb > tb2 ? tb : tb2) + 256)) return -1;
+        tb = tb2 = tmp.cap;
+        LSG_HIP(hipcub::DeviceScan::InclusiveSum(tmp.p, tb, a.span_diff, run, (int)(T + 1), st));
+        LSG_HIP(hipcub::DeviceReduce::Max(tmp.p, tb2, run, reinterpret_cast<int32_t*>(d_small + 3), (int)(T + 1), st));
+    }
     {
         size_t tb = 0;
         LSG_HIP(hipcub::DeviceReduce::Max(nullptr, tb, c->rd.read_cb, reinterpret_cast<int32_t*>(d_small + 2), (int)(R > 0 ? R : 1), st));
@@ -396,7 +455,8 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
         tb = tmp.cap;
         if (R > 0) LSG_HIP(hipcub::DeviceReduce::Max(tmp.p, tb, c->rd.read_cb, reinterpret_cast<int32_t*>(d_small + 2), (int)R, st));
     }
-    uint32_t total = 0, bad = 0; int32_t max_cb = 0;
+    uint32_t total = 0, bad = 0; int32_t max_cb = 0, max_live = 0;
+    LSG_HIP(hipMemcpyAsync(&max_live, d_small + 3, 4, hipMemcpyDeviceToHost, st));
     unsigned long long n_ev = 0;
     LSG_HIP(hipMemcpyAsync(&n_ev, a.n_ev, 8, hipMemcpyDeviceToHost, st));
     LSG_HIP(hipMemcpyAsync(&total, c->d_tile_off.as<uint32_t>() + T, 4, hipMemcpyDeviceToHost, st));
@@ -422,6 +482,7 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
     }
     const uint64_t N = total;
     c->tm_n = N; c->tm_events = (int64_t)n_ev;
+    c->max_live_all = max_live > 0 ? max_live : 0;
     if (N == 0) return finish();
     // ---- 2. scatter
     DevBuf &rec = c->bt[BT_REC], &key_a = c->bt[BT_KEY_A], &key_b = c->bt[BT_KEY_B], &val_a = c->bt[BT_VAL_A], &val_b = c->bt[BT_VAL_B];
@@ -470,29 +531,27 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
     LSG_HIP(hipStreamSynchronize(st));
     const uint64_t np = (uint64_t)nblk * 8;
     c->tm_np = np; c->tm_nblk = nblk;
-    DevBuf& gsrc = c->bt[BT_GSRC];
     if (c->tm[TM_S0].reserve((np + 16) * 4) || c->tm[TM_B].reserve(np + 16) ||
         c->tm[TM_FM].reserve((np + 16) * 4) || c->tm[TM_RD].reserve((np + 16) * 4) || c->tm[TM_META].reserve((np + 8 * (TM_GROUP + 1)) * 4) ||
-        c->tm[TM_BLK_TILE].reserve(((size_t)nblk + 2) * 4) || c->tm[TM_EXT].reserve(((size_t)nblk + TM_GROUP + 2) * 2) || gsrc.reserve((np + 16) * 8)) return -1;
+        c->tm[TM_BLK_TILE].reserve(((size_t)nblk + 2) * 4) || c->tm[TM_EXT].reserve(((size_t)nblk + TM_GROUP + 2) * 2)) return -1;
     hipLaunchKernelGGL(k_tm_blk_tile, dim3((nblk + 255) / 256), dim3(256), 0, st, blk_off, T, nblk, c->tm[TM_BLK_TILE].as<uint32_t>());
-    hipLaunchKernelGGL(k_tm_fill, dim3((unsigned)(c->n_cus * 16)), dim3(256), 0, st, key_b.as<uint32_t>(), val_b.as<uint32_t>(), rec.as<uint4>(),
-                       c->d_tile_off.as<uint32_t>(), blk_off, c->tm[TM_BLK_TILE].as<uint32_t>(), np,
-                       c->tm[TM_S0].as<uint32_t>(), c->tm[TM_B].as<uint8_t>(), c->tm[TM_FM].as<uint32_t>(), c->tm[TM_RD].as<uint32_t>(), gsrc.as<uint2>());
     LSG_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c->tm[TM_S0].as<uint32_t>() + np), (int)TM_PAD_S0, 16, st));       // (what the walk's group loads and the run flags' neighbours see past the end)
     LSG_HIP(hipMemsetAsync(c->tm[TM_B].as<uint8_t>() + np, 0, 16, st));
-    LSG_HIP(hipEventRecord(c->evb[3], st));
-    // ---- 5. the events.  The blocks are the load's largest allocation: when they are not there yet and the load is large against the
-    // device (C4: 124 GB of blocks beside 91 GB of the caller's events), the sort's buffers go first
+    // ---- 5. the per-entry words and the events.  The blocks are the load's largest allocation (C4: 124 GB beside 106 GB of the caller's
+    // events): they are reserved once and kept; when the device is nearly full what the build no longer needs goes first
     if (c->tm[TM_STORE].cap < ((size_t)nblk + TM_GROUP) * 1024) {
         size_t mem_free = 0, mem_total = 0;
-        if (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess && ((size_t)nblk + TM_GROUP) * 1024 + (size_t)nblk * 64 > mem_free / 2) {
+        if (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess && ((size_t)nblk + TM_GROUP) * 1088 + (mem_total >> 5) > mem_free) {
             LSG_HIP(hipStreamSynchronize(st));
-            rec.release(); key_a.release(); key_b.release(); val_a.release(); val_b.release(); c->ws[WS_SEG_INFO].release();
+            key_a.release(); val_a.release(); c->ws[WS_SEG_INFO].release(); c->bt[BT_SPAN].release(); c->bt[BT_SPAN_RUN].release(); c->bt[BT_PEX].release(); c->bt[BT_OFFS].release();
         }
         if (c->tm[TM_STORE].reserve(((size_t)nblk + TM_GROUP) * 1024)) return -1;
     }
+    LSG_HIP(hipEventRecord(c->evb[3], st));
     hipLaunchKernelGGL(k_tm_gather, dim3((unsigned)((((uint64_t)nblk + TMG_BLOCKS - 1) / TMG_BLOCKS + TMG_WAVES - 1) / TMG_WAVES)), dim3(TMG_WAVES * 64), 0, st,
-                       events, n_events, c->tm[TM_S0].as<uint32_t>(), c->tm[TM_B].as<uint8_t>(), gsrc.as<uint2>(), nblk, c->tm[TM_STORE].as<uint4>(), c->tm[TM_EXT].as<uint16_t>());
+                       events, n_events, key_b.as<uint32_t>(), val_b.as<uint32_t>(), rec.as<uint4>(), c->d_tile_off.as<uint32_t>(), blk_off, c->tm[TM_BLK_TILE].as<uint32_t>(), nblk,
+                       c->tm[TM_S0].as<uint32_t>(), c->tm[TM_B].as<uint8_t>(), c->tm[TM_FM].as<uint32_t>(), c->tm[TM_RD].as<uint32_t>(),
+                       c->tm[TM_STORE].as<uint4>(), c->tm[TM_EXT].as<uint16_t>());
     LSG_HIP(hipEventRecord(c->evb[4], st));
     LSG_HIP(hipGetLastError());
     LSG_HIP(hipStreamSynchronize(st));
@@ -608,7 +667,7 @@ int ensure_plan(lsg_ctx* c) {
                        c->tm[TM_JOBS].as<TmJob>(), c->tm[TM_NE_UNITS].as<uint32_t>(), c->tm[TM_NE_GEOM].as<int2>(), c->tm[TM_NE_NSLOT].as<uint32_t>(),
                        c->tm[TM_NE_ACC].as<uint32_t>(), c->tm[TM_MULTI].as<uint32_t>(), d_misc);
     {   // static work-balanced chunks of the job list; every workgroup of the walk should get several: a small load is cut finer
-        DevBuf& pex = c->bt[BT_GSRC];
+        DevBuf& pex = c->bt[BT_PEX];
         const uint64_t total_work = c->tm_np + (uint64_t)njobs * TM_JOB_W0;
         const uint64_t cw = total_work / ((uint64_t)c->n_cus * 14 * 6);
         const uint32_t chunk_work = (uint32_t)(cw < 256 ? 256 : (cw > TM_CHUNK_WORK ? TM_CHUNK_WORK : cw));

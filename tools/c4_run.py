@@ -9,12 +9,20 @@ n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 50_000_000
 model = synth.named("C4", n_reads=n)
 eng = Engine(0, stream=torch.cuda.current_stream().cuda_stream)
 eng.set_contigs(model.contig_len); eng.synth_reference(model.seed); eng.set_barcodes(model.celltype_of, 2)
-t0 = time.time(); eng.synth_reads(model); torch.cuda.synchronize(); print("generated + aligned in %.1f s, shape %s, free %.0f GB" % (time.time() - t0, eng.reads_shape(), torch.cuda.mem_get_info()[0] / 1e9), flush=True)
+from longsom_amd._lib import CountParams
+cp = CountParams.longsom_defaults()
+eng.set_load_filter(cp.min_mq, cp.flag_exclude, cp.ignore_orphans)          # as the product's decode and bench.py do
+t0 = time.perf_counter(); eng.synth_reads(model); torch.cuda.synchronize(); dt = time.perf_counter() - t0      # generate + load + give the generated arrays back
+n_reads, n_segs, n_events = eng.reads_shape()
+print("generated and loaded in %.2f s: %d reads %d segments %d events (%.1f GB of compact events, not kept)" % (dt, n_reads, n_segs, n_events, n_events * 2 / 1e9), flush=True)
+print("load: %.1f ms wall in lsg_load_reads (first load of the process: allocates the store); build kernels (capacities + scatter, sort, entry words, gather) %s ms; "
+      "store %s (entries, blocks, events); resident %.1f GB; free %.0f GB" %
+      (eng.layout_info()[1], [round(x, 2) for x in eng.build_times()], eng.store_shape(), eng.layout_info()[2] / 1e9, torch.cuda.mem_get_info()[0] / 1e9), flush=True)
 for i in range(3):
     t0 = time.perf_counter(); rows, cols = eng.pileup_count(); ns, nc = eng.call_step1(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
     s = eng.count_stats()
-    print("pass %d: %.1f ms  rows %s cols %d sites %d cand %d | events %d entries %d units %d deep %d | bin %.1f walk %.1f wave %.1f | count form %d (0 scatter, 1 index, 2 store), per-load structures %.1f GB" %
-          (i, dt * 1e3, rows, cols, ns, nc, s.n_events_admitted, s.n_entries, s.n_units, s.n_deep_units, s.ms_bin, s.ms_walk, s.ms_wave, eng.layout_info()[0], eng.layout_info()[2] / 1e9), flush=True)
+    print("pass %d (count + call over the resident store): %.1f ms  rows %s cols %d sites %d cand %d | events %d entries %d units %d multi-job %d | resolve %.1f walk %.1f count %.1f ms | resident %.1f GB" %
+          (i, dt * 1e3, rows, cols, ns, nc, s.n_events_admitted, s.n_entries, s.n_units, s.n_deep_units, s.ms_bin, s.ms_walk, s.ms_total, eng.layout_info()[2] / 1e9), flush=True)
 full = (rows, cols, ns)
 # property: counting two halves of the genome separately gives the same totals
 tid_mid = len(model.contig_len) // 2

@@ -1,12 +1,12 @@
 """Timeline of the LAST pass of a rocprofv3 --kernel-trace run of bench.py: kernel, queue, start and duration in microseconds relative to the
-pass's first kernel (lsg::k_read_key).  usage: python tools/timeline.py <dir holding *_kernel_trace.csv>"""
+step's first kernel (lsg::k_seg_static, the start of lsg_load_reads).  usage: python tools/timeline.py <dir holding *_kernel_trace.csv>"""
 import csv, glob, sys
 rows = []
 for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "?")))
 rows.sort()
-starts = [i for i, r in enumerate(rows) if "k_read_key" in r[2]]
+starts = [i for i, r in enumerate(rows) if "k_seg_static" in r[2]]
 lo = starts[-1]
 t0 = rows[lo][0]
 end = 0
