@@ -38,7 +38,9 @@ def base_cell_counter(argv=None):
     ap.add_argument("--min_ac", type=int, default=0); ap.add_argument("--min_af", type=float, default=0); ap.add_argument("--min_dp", type=int, default=5)
     ap.add_argument("--min_cc", type=int, default=5); ap.add_argument("--min_bq", type=int, default=20); ap.add_argument("--min_mq", type=int, default=255)
     ap.add_argument("--tmp_dir", default="."); ap.add_argument("--device", type=int, default=0)
+    _add_htslib_flag(ap)
     a = ap.parse_args(argv)
+    _apply_htslib_flag(a)
     if a.bed or a.bed_out or a.min_ac:
         raise SystemExit("--bed / --bed_out / --min_ac are not used by LongSom's rules and are not implemented")
     sid = a.id or os.path.basename(a.bam).replace(".bam", "")
@@ -166,7 +168,9 @@ def single_cell_genotype(argv=None):
     ap.add_argument("--alpha2", type=float, default=0.260288007167716); ap.add_argument("--beta2", type=float, default=173.94711910763732)
     ap.add_argument("--pvalue", type=float, default=0.01); ap.add_argument("--chrM_contaminant", default="True")
     ap.add_argument("--device", type=int, default=0)
+    _add_htslib_flag(ap)
     a = ap.parse_args(argv)
+    _apply_htslib_flag(a)
     if a.tissue is not None:
         raise SystemExit("--tissue is not used by LongSom's rules and is not implemented")
     print("Outfile: ", a.outfile, "\n")
@@ -190,6 +194,17 @@ def celltype_reannotation(argv=None):
     a = ap.parse_args(argv)
     print("Outfile: ", a.outfile, "\n")
     reanno.celltype_reannotation(a.SNVs, a.fusions, a.meta, a.outfile, a.min_variants, a.min_frac)
+
+
+def _add_htslib_flag(ap):
+    ap.add_argument("--htslib_legacy_del_merge", action="store_true",
+                    help="count the first column of a deletion that is followed by another deletion (CIGAR 1D2D) as 'D', as pysam over htslib <= 1.10 "
+                         "does; default: htslib >= 1.11 ('O').  The reference's conda environment pins neither (workflow/envs/SComatic.yaml:9,23)")
+
+
+def _apply_htslib_flag(a):
+    if getattr(a, "htslib_legacy_del_merge", False):
+        hostio.set_legacy_del_merge(True)
 
 
 def _optional_paths(ap, *flags):
@@ -218,7 +233,9 @@ def snv(argv=None):
                     "window by window (for a BAM whose reads do not fit in HBM); 0 = the whole BAM at once")
     d = pipeline.SnvParams()
     _add_dataclass_flags(ap, d)
+    _add_htslib_flag(ap)
     a = ap.parse_args(argv)
+    _apply_htslib_flag(a)
     params = pipeline.SnvParams(**{k: getattr(a, k) for k in vars(d)})
     # under torch.distributed.run (WORLD_SIZE > 1): one rank per GPU, regions sharded over the ranks; the process group comes up
     # before anything touches the GPU
@@ -245,7 +262,9 @@ def reannotation(argv=None):
     # block) and config['SNVCalling'] (pass 2: --p2_*); defaults = config/config.yaml
     rp0, sp0 = pipeline.ReannoParams(), pipeline.SnvParams()
     _add_dataclass_flags(ap, rp0, "reanno_"); _add_dataclass_flags(ap, rp0.chain, "p1_"); _add_dataclass_flags(ap, sp0, "p2_")
+    _add_htslib_flag(ap)
     a = ap.parse_args(argv)
+    _apply_htslib_flag(a)
     chain = pipeline.SnvParams(**{k: getattr(a, "p1_" + k) for k in vars(rp0.chain)})
     rp = pipeline.ReannoParams(chain=chain, **{k: getattr(a, "reanno_" + k) for k, v in vars(rp0).items() if k != "chain"})
     sp = pipeline.SnvParams(**{k: getattr(a, "p2_" + k) for k in vars(sp0)})
@@ -278,7 +297,9 @@ def pon_chain(argv=None):
     ap.add_argument("--min_mq", type=int, default=60); ap.add_argument("--min_samples", type=int, default=1)
     ap.add_argument("--rm_prefix", choices=["Yes", "No"], default="No"); ap.add_argument("--no_tables", action="store_true")
     ap.add_argument("--device", type=int, default=0)
+    _add_htslib_flag(ap)
     a = ap.parse_args(argv)
+    _apply_htslib_flag(a)
     normals = [tuple(l.rstrip("\n").split("\t")[:3]) for l in open(a.normals) if l.strip() and not l.startswith("#")]
     p = pipeline.pon_params(alpha1=a.alpha1, beta1=a.beta1, alpha2=a.alpha2, beta2=a.beta2, min_ac_cells=a.min_ac_cells, min_ac_reads=a.min_ac_reads,
                             min_cells=a.min_cells, min_cell_types=a.min_cell_types, min_mapping_quality=a.min_mq)

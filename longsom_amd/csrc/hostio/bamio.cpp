@@ -47,6 +47,10 @@ struct Local {   // per-thread decode output
     std::vector<int64_t> cb_pass, cb_low;      // per dense barcode id: matched reads with MAPQ >= / < min_mapq (report of a later table)
 };
 
+// htslib <= 1.10: the last column of a D operation followed by another D is a deletion anchor too ("1D2D": 'D' where htslib >= 1.11
+// gives 'O'); lsio_set_legacy_del_merge, default off = htslib >= 1.11
+std::atomic<int> g_legacy_del_merge{0};
+
 inline bool is_ref_op(uint32_t op) { return op == 0 || op == 2 || op == 3 || op == 7 || op == 8; }
 
 // A record's own length fields must stay inside its block_size: name + CIGAR + packed sequence + qualities.  Everything
@@ -147,7 +151,7 @@ void decode_record(const uint8_t* rec, uint32_t len, const std::unordered_map<st
         uint32_t over = 15;                                                       // 15 = none, 4 = I, 5 = D
         if (k + 1 < n_cigar) {
             const uint32_t op2 = rd32(cigar + 4ull * (k + 1)) & 0xf;
-            if (op2 == 2 && op != 2) over = 5;
+            if (op2 == 2 && (op != 2 || g_legacy_del_merge.load(std::memory_order_relaxed))) over = 5;
             else if (op2 == 1) over = 4;
             else if (op2 == 6 && k + 2 < n_cigar) {
                 uint32_t l3 = 0;
@@ -200,6 +204,8 @@ typedef struct {
 } lsio_decoded;
 
 const char* lsio_last_error(void) { return g_err; }
+void lsio_set_legacy_del_merge(int on) { g_legacy_del_merge.store(on ? 1 : 0); }
+int lsio_get_legacy_del_merge(void) { return g_legacy_del_merge.load(); }
 
 void lsio_free_decoded(lsio_decoded* d) {
     if (!d) return;

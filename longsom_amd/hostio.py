@@ -54,8 +54,24 @@ def load():
         lib.lsio_barcode.argtypes = [C.c_uint64, C.c_int64, C.c_char_p]
         lib.lsio_split_bam.restype = C.c_int
         lib.lsio_split_bam.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.c_void_p, C.c_int32, C.c_char_p, C.c_int32, C.c_void_p]
+        lib.lsio_set_legacy_del_merge.argtypes = [C.c_int]
+        lib.lsio_get_legacy_del_merge.restype = C.c_int
         _lib = lib
+        if os.environ.get("LONGSOM_HTSLIB_LEGACY_DEL_MERGE", "0") == "1":
+            lib.lsio_set_legacy_del_merge(1)
     return _lib
+
+
+def set_legacy_del_merge(on: bool) -> bool:
+    """htslib <= 1.10 compatibility of the CIGAR -> column step (process-wide; returns the previous setting).  Before htslib 1.11,
+    bam_plp's resolve_cigar2 flagged the last column of ANY operation followed by a deletion — also of a D operation itself — so inside
+    "1D2D" the first deletion's column is printed "*-2NN" by pysam and counted as 'D' by EasyReadPileup (BaseCellCounter.py:167-170),
+    where htslib >= 1.11 (the default here) merges consecutive D's and leaves that column 'O'.  The reference's conda environment pins
+    neither pysam nor htslib (workflow/envs/SComatic.yaml:9,23).  Also settable with LONGSOM_HTSLIB_LEGACY_DEL_MERGE=1."""
+    lib = load()
+    old = bool(lib.lsio_get_legacy_del_merge())
+    lib.lsio_set_legacy_del_merge(1 if on else 0)
+    return old
 
 
 def _err(what):

@@ -26,6 +26,11 @@ def lib():
     return _lib
 
 
+def plp_set_legacy_del_merge(on):
+    """htslib <= 1.10 behaviour of the BAM-level oracle's CIGAR step (see plp_oracle.c g_legacy_del_merge)"""
+    lib().plp_set_legacy_del_merge(C.c_int(1 if on else 0))
+
+
 def plp_count(bam_path, barcodes, celltype_of, ct, contig_len, refs, min_bq=20, min_mq=60, min_dp=5, min_cc=5, max_depth=200000):
     """BAM-level column-major oracle (oracle/plp_oracle.c).  Returns keys, ref, counts[n,42]."""
     L = lib()

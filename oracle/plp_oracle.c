@@ -26,6 +26,13 @@
 #include <string.h>
 #include <zlib.h>
 
+/* htslib <= 1.10 (resolve_cigar2 before the 1.11 rewrite of its indel peek): the last column of a D operation that is followed by
+   another D carries indel < 0 too, so pysam prints "*-<n>N.." there and EasyReadPileup (BaseCellCounter.py:167-170) calls it 'D'
+   instead of 'O'.  0 (default) = htslib >= 1.11. */
+static int g_legacy_del_merge = 0;
+void plp_set_legacy_del_merge(int on) { g_legacy_del_merge = on ? 1 : 0; }
+
+
 typedef struct {
     int32_t tid, pos, end;          /* end = first reference position after the alignment */
     uint32_t flag, mapq, n_cigar, l_seq;
@@ -109,7 +116,9 @@ static void resolve(read_t* r, int64_t pos, uint32_t* qpos, int* is_del, int* is
     *is_del = *is_refskip = *indel = 0;
     if (r->x + (int64_t)l - 1 == pos && (uint32_t)r->k + 1 < r->n_cigar) {     /* last column of the op: peek */
         uint32_t c2 = rd32(cg + 4 * (r->k + 1)), op2 = COP(c2);
-        if (op2 == 2 && op != 2) {                    /* a deletion starts after this column (1D2D counts as 3D) */
+        if (op2 == 2 && g_legacy_del_merge) {         /* htslib <= 1.10: any operation's last column before a D, consecutive D's not summed */
+            *indel = -(int)CLN(c2);
+        } else if (op2 == 2 && op != 2) {             /* a deletion starts after this column (1D2D counts as 3D) */
             int d = (int)CLN(c2);
             for (uint32_t k = (uint32_t)r->k + 2; k < r->n_cigar; ++k) { uint32_t c3 = rd32(cg + 4 * k); if (COP(c3) == 2) d += (int)CLN(c3); else break; }
             *indel = -d;

@@ -105,10 +105,26 @@ CASES = {
     "iupac": dict(
         reads=[rd(8, "2M", "RC", [30, 30])], params=LOOSE,
         cancer={10: one("C", 30)}),
+    # 3M1D2D3M: consecutive deletions are ONE deletion of 3 since htslib 1.11 (the M's last column is its anchor, all three deleted
+    # columns are interior: O with the quality of the next base); htslib <= 1.10: see LEGACY_CASES
+    "consecutive_deletions": dict(
+        reads=[rd(30, "3M1D2D3M", "GTATAC", [30, 31, 32, 20, 34, 35])], params=LOOSE,
+        cancer={31: one("G", 30), 32: one("T", 31), 33: one("D", 32), 34: (1, 1, {}, {}, {}, {}, {}), 35: (1, 1, {}, {}, {}, {}, {}),
+                36: (1, 1, {}, {}, {}, {}, {}), 37: one("T", 20), 38: one("A", 34), 39: one("C", 35)}),
     # a pad between the anchor and an insertion: the anchor is still an insertion anchor
     "pad_insertion": dict(
         reads=[rd(20, "3M1P1I3M", "ACGATAC", [40, 41, 42, 10, 43, 44, 45])], params=LOOSE,
         cancer={21: one("A", 40), 22: one("C", 41), 23: one("I", 42), 24: one("T", 43), 25: one("A", 44), 26: one("C", 45)}),
+}
+
+# htslib <= 1.10 (hostio.set_legacy_del_merge / plp_set_legacy_del_merge / minipysam.LEGACY_DEL_MERGE): the last column of a D
+# operation that is followed by another D is flagged too — pysam prints "*-2NN" there and EasyReadPileup counts a D (quality of the
+# next query base, like every deleted column)
+LEGACY_CASES = {
+    "consecutive_deletions": dict(
+        reads=CASES["consecutive_deletions"]["reads"], params=LOOSE,
+        cancer={31: one("G", 30), 32: one("T", 31), 33: one("D", 32), 34: one("D", 20), 35: (1, 1, {}, {}, {}, {}, {}),
+                36: (1, 1, {}, {}, {}, {}, {}), 37: one("T", 20), 38: one("A", 34), 39: one("C", 35)}),
 }
 
 ORDER = "ACTGID"

@@ -84,6 +84,68 @@ def test_oracles_write_the_reference_tables_kat(tmp_path, name):
         assert table(k, r, c, [K.CONTIG[0]], "kat." + cname) == want, "decoder + count_oracle"
 
 
+# ---- htslib <= 1.10: the one place where the CIGAR -> column step depends on the library version --------------------------------
+KAT_LEGACY = json.load(open(os.path.join(G, "pileup.kat_legacy.json")))
+
+
+@pytest.fixture
+def legacy_del_merge():
+    """htslib <= 1.10 mode of the decoder and of the BAM-level oracle for the duration of a test"""
+    old = hostio.set_legacy_del_merge(True)
+    loader.plp_set_legacy_del_merge(True)
+    yield
+    hostio.set_legacy_del_merge(old)
+    loader.plp_set_legacy_del_merge(False)
+
+
+def parse_table(text):
+    got = {}
+    for line in (text or "").split("\n"):
+        if line and not line.startswith("#"):
+            f = line.split("\t")
+            dp, nc, cc, bc, bq, bcf, bcr = f[4].split("|")
+            got[int(f[1]) - 1] = [int(dp), int(nc)] + [int(x) for v in (cc, bc, bq, bcf, bcr) for x in v.split(":")]
+    return got
+
+
+@pytest.mark.parametrize("name", sorted(K.LEGACY_CASES))
+def test_legacy_del_merge_tables(tmp_path, name, legacy_del_merge):
+    """inside "1D2D" htslib <= 1.10 flags the first deletion's column as a deletion anchor: the reference (over the stand-in's legacy
+    mode) prints a D there, htslib >= 1.11 an O; the hand-derived rows, the reference-written table, both oracles and the decoder agree
+    in BOTH modes (the default mode is the ordinary consecutive_deletions case)"""
+    want_rows = K.expected_rows(K.LEGACY_CASES[name]["cancer"])
+    got = parse_table(KAT_LEGACY[name]["tables"].get("Cancer"))
+    assert sorted(got) == sorted(want_rows)
+    for pos, row in want_rows.items():
+        assert got[pos] == [row[i] for i in K.PRINTED], (name, pos + 1)
+    assert KAT_LEGACY[name]["tables"]["Cancer"] != KAT[name]["tables"]["Cancer"]              # the version dependence is real
+    bam = str(tmp_path / (name + ".bam"))
+    bamwrite.write_bam(bam, [K.CONTIG], sorted(K.LEGACY_CASES[name]["reads"], key=lambda r: r["pos"]))
+    p = KAT_LEGACY[name]["params"]
+    dec = hostio.decode_bam(bam, KBC, min_mapq=p["min_mq"])
+    for ct, cname in enumerate(("Cancer", "Non-Cancer")):
+        want = KAT_LEGACY[name]["tables"].get(cname)
+        k, r, c = loader.plp_count(bam, KBC, KCT, ct, [K.CONTIG[1]], [KREF], **p)
+        assert table(k, r, c, [K.CONTIG[0]], "kat." + cname) == want, "plp_oracle (legacy)"
+        k, r, c, _ = loader.count(dec.records, [K.CONTIG[1]], [KREF], KCT, ct, p["min_bq"], p["min_mq"], p["min_dp"], p["min_cc"])
+        assert table(k, r, c, [K.CONTIG[0]], "kat." + cname) == want, "decoder + count_oracle (legacy)"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(K.LEGACY_CASES))
+def test_gpu_writes_the_legacy_tables(tmp_path, engine, name, legacy_del_merge):
+    bam = str(tmp_path / (name + ".bam"))
+    bamwrite.write_bam(bam, [K.CONTIG], sorted(K.LEGACY_CASES[name]["reads"], key=lambda r: r["pos"]))
+    p = KAT_LEGACY[name]["params"]
+    dec = hostio.decode_bam(bam, KBC, min_mapq=p["min_mq"])
+    engine.set_contigs([K.CONTIG[1]]); engine.load_reference(0, KREF); engine.set_barcodes(KCT, 2); engine.set_region()
+    engine.load_reads(dec.records)
+    engine.pileup_count(CountParams.longsom_defaults(**p))
+    for ct, cname in enumerate(("Cancer", "Non-Cancer")):
+        k, r, c = engine.fetch_counts(ct)
+        assert table(k, r, c, [K.CONTIG[0]], "kat." + cname) == KAT_LEGACY[name]["tables"].get(cname)
+
+
 # ---- random multi-contig sample --------------------------------------------------------------------------------
 def rand_inputs(tag):
     bc = hostio.read_barcodes(os.path.join(G, "pileup.%s.barcodes.tsv" % tag))

@@ -86,7 +86,7 @@ def render(shell, empty=()):
         key = m.group(1)
         if key in empty:
             return ""
-        if key.startswith("params.") and ("compat" in key or "launcher" in key or key == "params.tables"):
+        if key.startswith("params.") and ("compat" in key or "htslib" in key or "launcher" in key or key == "params.tables"):
             return "python" if "launcher" in key else ""      # switches that render as a flag or as nothing
         if "alt_flag" in key:
             return "All"                                      # config.yaml:66 (a choice option)

@@ -10,6 +10,7 @@ the window temp files and their concatenation order, meta_to_dict, split_bam's r
 Writes under tests/golden/:
   pileup.kat.json              per known-answer case (tests/kat_pileup_cases.py): the two per-cell-type tables and the
                                SplitBam report exactly as the reference wrote them (null = the reference wrote no file)
+  pileup.kat_legacy.json       the cases of LEGACY_CASES through the stand-in's htslib <= 1.10 mode (minipysam.LEGACY_DEL_MERGE)
   pileup.rand.bam/.fa/.barcodes.tsv   a seeded random multi-contig sample (chr1 crosses the 50 001 window edge; contigs
                                chr1, chr10, chr2, chrM for the file order; every CIGAR op, N / IUPAC bases, low qualities,
                                all flags, MAPQ 0-60, CB missing / unknown / with "-1")
@@ -192,6 +193,20 @@ def main():
             tables, report = run_chain(split, counter, bam, bc, fa, "kat", os.path.join(kdir, name), p["min_mq"], extra)
             kat[name] = {"params": p, "report": strip_report(report), "tables": {ct: strip_date(t) for ct, t in tables.items()}}
         json.dump(kat, open(os.path.join(OUT, "pileup.kat.json"), "w"), indent=1, sort_keys=True)
+        # ... and the cases whose tables depend on the htslib version, through the stand-in's htslib <= 1.10 mode
+        minipysam.LEGACY_DEL_MERGE = True
+        try:
+            legacy = {}
+            for name, case in sorted(K.LEGACY_CASES.items()):
+                bam = os.path.join(kdir, name + ".legacy.bam")
+                bamwrite.write_bam(bam, [K.CONTIG], sorted(case["reads"], key=lambda r: r["pos"]))
+                p = case["params"]
+                extra = ["--min_dp", str(p["min_dp"]), "--min_cc", str(p["min_cc"]), "--min_bq", str(p["min_bq"])]
+                tables, report = run_chain(split, counter, bam, bc, fa, "kat", os.path.join(kdir, name + ".legacy"), p["min_mq"], extra)
+                legacy[name] = {"params": p, "report": strip_report(report), "tables": {ct: strip_date(t) for ct, t in tables.items()}}
+            json.dump(legacy, open(os.path.join(OUT, "pileup.kat_legacy.json"), "w"), indent=1, sort_keys=True)
+        finally:
+            minipysam.LEGACY_DEL_MERGE = False
 
         # ---- 2. the random multi-contig sample (and its "-1" suffix twin)
         rng = np.random.default_rng(20251004)

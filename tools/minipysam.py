@@ -23,6 +23,11 @@ import types
 import zlib
 
 _NT16 = "=ACMGRSVTWYHKDBN"
+# htslib's resolve_cigar2 changed in 1.11: before it, the LAST column of ANY operation that is followed by a deletion carried
+# indel = -(length of that next D) — also the last column of a D operation itself, so inside "1D2D" the first deletion's column is
+# printed "*-2NN" (EasyReadPileup: 'D') where htslib >= 1.11 prints "*" ('O').  The reference's environment pins neither pysam nor
+# htslib (workflow/envs/SComatic.yaml:9,23: python=3.7 resolves pysam 0.15-0.22, i.e. htslib 1.9-1.18).  Default: >= 1.11.
+LEGACY_DEL_MERGE = False
 REF_OPS = (0, 2, 3, 7, 8)          # M D N = X consume the reference
 MATCH_OPS = (0, 7, 8)
 
@@ -127,7 +132,9 @@ class AlignedSegment:
         indel = 0
         if self._x + ln - 1 == pos and self._k + 1 < len(cg):          # last column of this op: what follows?
             op2, l2 = cg[self._k + 1]
-            if op2 == 2 and op != 2:
+            if op2 == 2 and LEGACY_DEL_MERGE:
+                indel = -l2                     # htslib <= 1.10: whatever the current operation is, consecutive D's not summed
+            elif op2 == 2 and op != 2:
                 indel = -l2
                 for o3, l3 in cg[self._k + 2:]:
                     if o3 == 2:
