@@ -301,7 +301,13 @@ __global__ __launch_bounds__(TMG_WAVES * 64) void k_tm_gather(const uint16_t* ev
                                                                uint32_t* s0, uint8_t* b8, uint32_t* fm, uint32_t* rd, uint4* store, uint16_t* ext) {
     __shared__ __attribute__((aligned(16))) uint16_t lds[TMG_WAVES][TMG_BLOCKS][8][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const uint32_t blk0 = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * TMG_BLOCKS;
+    // Workgroups are dealt to the 8 XCDs round-robin, each with its own L2.  An entry's <= 128 source bytes sit at a 2-byte alignment,
+    // so the 128-byte line they end in is also the line the SAME read's entry of the NEXT tile starts in: give every XCD one contiguous
+    // eighth of the blocks, so that neighbouring tiles pass through one L2 shortly after one another (measured: 54 GB of fabric reads
+    // per launch for 17.6 GB of events with the plain mapping).  A speed heuristic only: nothing depends on the placement.
+    const uint32_t per_xcd = gridDim.x >> 3;                 // (the grid is a multiple of 8)
+    const uint32_t vwg = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    const uint32_t blk0 = (vwg * TMG_WAVES + (uint32_t)wv) * TMG_BLOCKS;
     if (blk0 >= nblk) return;
     // ---- (a)
     uint32_t e_src = 0, e_info = 0;                 // source of the entry's events, low 32 bits; high 8 bits [0..7] | first position [8..13] | events [16..22] (0: not there)
@@ -548,7 +554,7 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
         if (c->tm[TM_STORE].reserve(((size_t)nblk + TM_GROUP) * 1024)) return -1;
     }
     LSG_HIP(hipEventRecord(c->evb[3], st));
-    hipLaunchKernelGGL(k_tm_gather, dim3((unsigned)((((uint64_t)nblk + TMG_BLOCKS - 1) / TMG_BLOCKS + TMG_WAVES - 1) / TMG_WAVES)), dim3(TMG_WAVES * 64), 0, st,
+    hipLaunchKernelGGL(k_tm_gather, dim3((unsigned)(((((uint64_t)nblk + TMG_BLOCKS - 1) / TMG_BLOCKS + TMG_WAVES - 1) / TMG_WAVES + 7) / 8 * 8)), dim3(TMG_WAVES * 64), 0, st,
                        events, n_events, key_b.as<uint32_t>(), val_b.as<uint32_t>(), rec.as<uint4>(), c->d_tile_off.as<uint32_t>(), blk_off, c->tm[TM_BLK_TILE].as<uint32_t>(), nblk,
                        c->tm[TM_S0].as<uint32_t>(), c->tm[TM_B].as<uint8_t>(), c->tm[TM_FM].as<uint32_t>(), c->tm[TM_RD].as<uint32_t>(),
                        c->tm[TM_STORE].as<uint4>(), c->tm[TM_EXT].as<uint16_t>());
