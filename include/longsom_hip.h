@@ -174,6 +174,23 @@ int lsg_load_reads(lsg_ctx* ctx, const lsg_reads* reads);
  * stored and any count parameters can be resolved later; with a filter the store is smaller by the dropped reads' share and a count or
  * genotyping pass whose own filters would admit a dropped read is refused.  The per-read arrays (depth cap, statistics) keep every read. */
 int lsg_set_load_filter(lsg_ctx* ctx, int32_t min_mq, uint32_t flag_exclude, int32_t ignore_orphans);
+/* Device-side ingest of a whole BAM: the file's bytes in (host memory), the tile store out — BGZF inflate, record
+ * chain, CB lookup, SplitBam's counters and the CIGAR walk all run on the GPU (csrc/ingest.hip), then lsg_load_reads on the device
+ * arrays.  Replaces pysam.AlignmentFile + infile.fetch() + read.opt("CB") + the MAPQ counters of split_bam
+ * (SplitBamCellTypes.py:51-124) and the record decode behind bam.pileup (BaseCellCounter.py:190-191).  Needs the contigs = the BAM
+ * header's reference table (the caller parses the header: hostio.bam_header) and first_record_offset = the header's length in the
+ * uncompressed stream.  barcodes: n_barcodes cleaned strings joined by '\n', ids[i] = dense id of barcode i (NULL: i); duplicated
+ * strings: the last wins.  cb_pass / cb_low (may be NULL): per dense id, matched reads with MAPQ >= / < min_mapq (what the report of a
+ * re-annotated table needs).  legacy_del_merge: htslib <= 1.10's 1D2D rule.  Returns -4 when the file's records
+ * straddle its BGZF blocks so badly that the record chain did not settle (not written by htslib): decode such a file on the host. */
+typedef struct {
+    int64_t total_reads, pass_reads, cb_not_found, cb_not_matched, mapq_filtered;      /* {id}.report.txt, SplitBamCellTypes.py:181-187 */
+    int64_t n_records, n_blocks, n_ubytes;
+    float   ms_h2d, ms_inflate, ms_chain, ms_decode, ms_store, ms_total;               /* HIP-event / wall times of the phases */
+    int32_t chain_rounds, pad_;
+} lsg_bam_info;
+int lsg_load_bam(lsg_ctx* ctx, const uint8_t* file_bytes, int64_t n_bytes, int64_t first_record_offset, const char* barcodes, int32_t n_barcodes,
+                 const int32_t* ids, int32_t min_mapq, int32_t legacy_del_merge, lsg_bam_info* info, int64_t* cb_pass, int64_t* cb_low, int64_t n_tally);
 /* keep != 0: the next loads also keep a copy of the compact events (and seg_ev_off) beside the store, which is what
  * lsg_copy_reads_to_host returns (tests, sampling for a CPU baseline).  Default 0: the store is the only copy (2 B per event saved). */
 int lsg_set_keep_reads(lsg_ctx* ctx, int32_t keep);

@@ -101,6 +101,15 @@ class Call(C.Structure):
     ]
 
 
+class BamInfo(C.Structure):
+    _fields_ = [
+        ("total_reads", C.c_int64), ("pass_reads", C.c_int64), ("cb_not_found", C.c_int64), ("cb_not_matched", C.c_int64), ("mapq_filtered", C.c_int64),
+        ("n_records", C.c_int64), ("n_blocks", C.c_int64), ("n_ubytes", C.c_int64),
+        ("ms_h2d", C.c_float), ("ms_inflate", C.c_float), ("ms_chain", C.c_float), ("ms_decode", C.c_float), ("ms_store", C.c_float), ("ms_total", C.c_float),
+        ("chain_rounds", C.c_int32), ("pad_", C.c_int32),
+    ]
+
+
 class CountStats(C.Structure):
     _fields_ = [
         ("n_reads_admitted", C.c_int64), ("n_segs_admitted", C.c_int64), ("n_events_admitted", C.c_int64),
@@ -147,6 +156,7 @@ SIGNATURES = {
     "lsg_get_build_times": (C.c_int, [C.c_void_p, C.c_void_p]),
     "lsg_get_store_shape": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "lsg_set_keep_reads": (C.c_int, [C.c_void_p, C.c_int32]),
+    "lsg_load_bam": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_char_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(BamInfo), C.c_void_p, C.c_void_p, C.c_int64]),
     "lsg_set_load_filter": (C.c_int, [C.c_void_p, C.c_int32, C.c_uint32, C.c_int32]),
     "lsg_max_live_reads_all": (C.c_int64, [C.c_void_p]),
     "lsg_synth_generate": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Reads)]),

@@ -534,6 +534,12 @@ struct BgzfWriter {
             if (buf.size() >= 0xff00) { flush_block(buf.data(), buf.size()); buf.clear(); }
         }
     }
+    // one BAM record, the way htslib's bam_write1 does it (bgzf_flush_try): a record that does not fit the open block starts a new
+    // one, so that every block begins on a record boundary unless a record is longer than a block
+    void write_record(const void* p, size_t n) {
+        if (!buf.empty() && buf.size() + n > 0xff00) { flush_block(buf.data(), buf.size()); buf.clear(); }
+        write(p, n);
+    }
     void close() {
         if (!buf.empty()) { flush_block(buf.data(), buf.size()); buf.clear(); }
         flush_block(nullptr, 0);                                                 // EOF marker block
@@ -640,7 +646,7 @@ int lsio_synth_bam(const lsg_synth_model* m, const char* contig_names /* '\n'-jo
         }
         const uint32_t bs = (uint32_t)rec.size() - 4;
         for (int b = 0; b < 4; ++b) rec[(size_t)b] = (uint8_t)(bs >> (8 * b));
-        w.write(rec.data(), rec.size());
+        w.write_record(rec.data(), rec.size());
     }
     w.close();
     if (!w.ok) { set_err("lsio_synth_bam: write failed"); return -1; }
@@ -678,7 +684,7 @@ int lsio_split_bam(const char* path, const char* barcodes, int32_t n_barcodes, c
         if (it == ctmap.end()) { ++cnt[3]; continue; }
         if (min_mapq > 0 && (int)rec[9] < min_mapq) { ++cnt[4]; continue; }
         ++cnt[1];
-        w[(size_t)it->second].write(d + rec_at, 4 + bs);
+        w[(size_t)it->second].write_record(d + rec_at, 4 + bs);
     }
     bool ok = true;
     for (auto& x : w) { x.close(); ok = ok && x.ok; }

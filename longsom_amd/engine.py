@@ -7,6 +7,7 @@ Mirrors the stages of LongSom's SNV chain as methods:
   call_step1     <- merge + variant_calling_step1       (MergeBaseCellCounts.py:116-204, BaseCellCalling.step1.py:19-476)
 """
 import ctypes as C
+import os
 from dataclasses import dataclass, field
 from typing import List, Optional
 
@@ -156,6 +157,35 @@ class Engine:
     def load_reads_struct(self, reads: Reads):
         """lsg_load_reads of a ready lsg_reads (e.g. what synth_generate returned)"""
         _lib.check(self._lib.lsg_load_reads(self._h, C.byref(reads)), "lsg_load_reads")
+
+    def load_bam(self, path: str, barcodes, min_mapq: int = 60, first_record_offset: Optional[int] = None, legacy_del_merge: Optional[bool] = None):
+        """Device-side ingest (lsg_load_bam): the BAM's bytes go to the GPU as they are; BGZF inflate, record decode, CB lookup, SplitBam's
+        counters and the CIGAR walk run there and the tile store is built from the device arrays.  Set the contigs (hostio.bam_header)
+        first.  Returns (info dict with the report counters and the phases' times, cb_pass, cb_low per dense barcode id).  Raises
+        _lib.LsgError with rc -4 in its text ("straddle") for a BAM whose records are not aligned to its BGZF blocks: decode that one on
+        the host (hostio.decode_bam)."""
+        import mmap
+        from . import hostio
+        from ._lib import BamInfo
+        if first_record_offset is None:
+            first_record_offset = hostio.bam_header(path)[2]
+        if legacy_del_merge is None:
+            legacy_del_merge = bool(hostio.load().lsio_get_legacy_del_merge())
+        joined = "\n".join(barcodes).encode()
+        n_cb = len(barcodes)
+        info = BamInfo()
+        cb_pass = np.zeros(n_cb, np.int64); cb_low = np.zeros(n_cb, np.int64)
+        with open(path, "rb") as f:
+            size = os.fstat(f.fileno()).st_size
+            with mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ) as mm:
+                buf = np.frombuffer(mm, dtype=np.uint8)
+                try:
+                    _lib.check(self._lib.lsg_load_bam(self._h, C.c_void_p(buf.ctypes.data), size, int(first_record_offset), joined, n_cb, None, int(min_mapq),
+                                                      1 if legacy_del_merge else 0, C.byref(info), _ptr(cb_pass), _ptr(cb_low), n_cb), "lsg_load_bam")
+                finally:
+                    del buf
+        d = {k: getattr(info, k) for k, _ in BamInfo._fields_ if k != "pad_"}
+        return d, cb_pass, cb_low
 
     def set_region(self, tid_lo=0, pos_lo=0, tid_hi=None, pos_hi=0):
         """Count only columns in [(tid_lo,pos_lo), (tid_hi,pos_hi)) — window sharding across GPUs."""

@@ -166,6 +166,53 @@ def _wrap(lib, out, barcodes) -> DecodedBam:
     return DecodedBam(rec, names, lens, rep, found, tally(d.cb_pass), tally(d.cb_low))
 
 
+def bam_header(path: str):
+    """(contig names, contig lengths int64, length of the header in the uncompressed stream = offset of the first record): the BAM
+    header parsed on the host — the first BGZF block(s) only — for the device-side ingest (lsg_load_bam), which needs the reference
+    table before it starts (pysam.AlignmentFile's header, SplitBamCellTypes.py:51)."""
+    import struct
+    import zlib
+    data = b""
+    with open(path, "rb") as f:
+        def more():
+            nonlocal data
+            h = f.read(18)
+            if len(h) < 18 or h[:3] != b"\x1f\x8b\x08" or not (h[3] & 4):
+                raise RuntimeError("%s is not BGZF" % path)
+            xlen = struct.unpack_from("<H", h, 10)[0]
+            extra = h[12:18] + f.read(xlen - 6)
+            bsize, q = None, 0
+            while q + 4 <= xlen:
+                slen = struct.unpack_from("<H", extra, q + 2)[0]
+                if extra[q:q + 2] == b"BC" and slen == 2:
+                    bsize = struct.unpack_from("<H", extra, q + 4)[0] + 1
+                q += 4 + slen
+            if bsize is None or bsize < xlen + 20:
+                raise RuntimeError("%s: corrupt BGZF block" % path)
+            body = f.read(bsize - xlen - 12)
+            if len(body) != bsize - xlen - 12:
+                raise RuntimeError("%s: truncated BGZF block" % path)
+            data += zlib.decompress(body[:-8], -15)
+
+        def need(n):
+            while len(data) < n:
+                more()
+        need(12)
+        if data[:4] != b"BAM\x01":
+            raise RuntimeError("%s has no BAM magic" % path)
+        p = 8 + struct.unpack_from("<I", data, 4)[0]
+        need(p + 4)
+        n_ref = struct.unpack_from("<I", data, p)[0]; p += 4
+        names, lens = [], []
+        for _ in range(n_ref):
+            need(p + 4)
+            l_name = struct.unpack_from("<I", data, p)[0]; p += 4
+            need(p + l_name + 4)
+            names.append(data[p:p + l_name].split(b"\0")[0].decode()); p += l_name
+            lens.append(struct.unpack_from("<I", data, p)[0]); p += 4
+    return names, np.asarray(lens, np.int64), p
+
+
 def stream_bam(path: str, barcodes: Optional[Sequence[str]], min_mapq: int = 60, threads: int = 0, batch_bytes: int = 1 << 30):
     """The BAM in file order, a batch at a time (about batch_bytes of uncompressed BAM each): yields DecodedBam objects whose
     records, counters and per-barcode tallies cover one batch.  The compressed file is mapped, a batch is inflated and decoded by

@@ -1,0 +1,105 @@
+"""GPU: device-side BAM ingest (lsg_load_bam: BGZF inflate, record chain, CB lookup, SplitBam's counters, CIGAR walk on the GPU)
+against the host decoder (hostio.decode_bam), which is pinned to the reference-run goldens: same report, same per-barcode tallies,
+same read-record arrays, same count tables."""
+import os
+
+import numpy as np
+import pytest
+
+from longsom_amd import hostio, synth
+from longsom_amd._lib import CountParams, LsgError
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def both_ways(engine, bam, barcodes, celltype_of, refs, min_mapq=60):
+    """loads `bam` on the device and through the host decoder; returns (device info, cb_pass, cb_low, DecodedBam)"""
+    names, lens, first = hostio.bam_header(bam)
+    dec = hostio.decode_bam(bam, barcodes, min_mapq=min_mapq)
+    assert names == dec.contig_names and list(lens) == list(dec.contig_len)
+    engine.set_contigs(lens)
+    for t, r in enumerate(refs):
+        engine.load_reference(t, r)
+    engine.set_barcodes(celltype_of, 2)
+    engine.set_region()
+    engine.set_keep_reads(True)
+    try:
+        info, cb_pass, cb_low = engine.load_bam(bam, barcodes, min_mapq=min_mapq, first_record_offset=first)
+        dev = engine.reads_to_host()
+    finally:
+        engine.set_keep_reads(False)
+    rep = {"Total_reads": info["total_reads"], "Pass_reads": info["pass_reads"], "CB_not_found": info["cb_not_found"], "CB_not_matched": info["cb_not_matched"]}
+    if info["mapq_filtered"]:
+        rep["MAPQ"] = info["mapq_filtered"]
+    assert rep == dec.report
+    np.testing.assert_array_equal(cb_pass, dec.cb_pass); np.testing.assert_array_equal(cb_low, dec.cb_low)
+    for name, _ in dev._SPEC:
+        np.testing.assert_array_equal(getattr(dev, name), getattr(dec.records, name), err_msg=name)
+    rows_dev = (engine.pileup_count(), [engine.fetch_counts(ct) for ct in range(2)])
+    engine.load_reads(dec.records)
+    rows_host = (engine.pileup_count(), [engine.fetch_counts(ct) for ct in range(2)])
+    assert rows_dev[0] == rows_host[0]
+    for (k1, r1, c1), (k2, r2, c2) in zip(rows_dev[1], rows_host[1]):
+        np.testing.assert_array_equal(k1, k2); np.testing.assert_array_equal(c1, c2)
+    return info, dec
+
+
+@pytest.mark.parametrize("tag", ["rand", "randsfx"])
+def test_reference_pinned_sample(engine, tag):
+    """the multi-contig sample of the reference-run goldens (every CIGAR operation, all flags, CB missing / unknown / suffixed); written by
+    the Python BAM writer, whose records straddle its BGZF blocks: the record chain needs its fix-up rounds"""
+    from longsom_amd import tsvio
+    bc = hostio.read_barcodes(os.path.join(G, "pileup.%s.barcodes.tsv" % tag))
+    names, seqs = tsvio.read_fasta(os.path.join(G, "pileup.rand.fa"))
+    refs = [np.frombuffer(s.encode() if isinstance(s, str) else bytes(s), dtype=np.uint8) for s in seqs]
+    info, dec = both_ways(engine, os.path.join(G, "pileup.%s.bam" % tag), bc.barcodes, bc.celltype_of, refs)
+    assert info["n_records"] == 1418 and info["chain_rounds"] >= 1
+
+
+def test_synthetic_bam_like_htslib(engine, tmp_path):
+    """a BAM written the way htslib writes (no record straddles a block): one round settles the chain; C1's model, 20 k reads"""
+    m = synth.named("C1", n_reads=20_000)
+    bam = str(tmp_path / "c1.bam")
+    hostio.synth_bam(m, bam)
+    barcodes = hostio.synth_barcodes(m)
+    refs = [hostio.ref_bases(m.seed, t, int(l)) for t, l in enumerate(m.contig_len)]
+    info, dec = both_ways(engine, bam, barcodes, m.celltype_of, refs)
+    assert info["chain_rounds"] <= 2 and info["n_blocks"] > 100
+    assert info["n_records"] == 20_000
+
+
+def test_legacy_del_merge_and_low_mapq(engine, tmp_path):
+    m = synth.named("C1", n_reads=3_000)
+    bam = str(tmp_path / "c1.bam")
+    hostio.synth_bam(m, bam)
+    barcodes = hostio.synth_barcodes(m)
+    refs = [hostio.ref_bases(m.seed, t, int(l)) for t, l in enumerate(m.contig_len)]
+    old = hostio.set_legacy_del_merge(True)
+    try:
+        both_ways(engine, bam, barcodes, m.celltype_of, refs, min_mapq=30)
+    finally:
+        hostio.set_legacy_del_merge(old)
+
+
+def test_damaged_files_are_errors(engine, tmp_path):
+    raw = open(os.path.join(G, "pileup.rand.bam"), "rb").read()
+    bc = hostio.read_barcodes(os.path.join(G, "pileup.rand.barcodes.tsv"))
+    names, lens, first = hostio.bam_header(os.path.join(G, "pileup.rand.bam"))
+    engine.set_contigs(lens); engine.set_barcodes(bc.celltype_of, 2)
+    rng = np.random.default_rng(3)
+    cases = {"cut.bam": raw[: len(raw) // 2], "cut2.bam": raw[:-40]}
+    for k in range(6):                                  # bit flips inside the compressed payload of some block
+        b = bytearray(raw); at = int(rng.integers(200, len(raw) - 60)); b[at] ^= 1 << int(rng.integers(0, 8)); cases["flip%d.bam" % k] = bytes(b)
+    n_err = 0
+    for name, data in cases.items():
+        p = tmp_path / name
+        p.write_bytes(data)
+        try:
+            engine.load_bam(str(p), bc.barcodes, first_record_offset=first)
+        except LsgError:
+            n_err += 1
+    assert n_err >= 2                                   # the truncated ones always; a flipped bit may land in a CRC or in padding
+    # the handle is usable afterwards
+    engine.load_bam(os.path.join(G, "pileup.rand.bam"), bc.barcodes, first_record_offset=first)
+    assert engine.reads_shape()[0] == 1333
