@@ -99,6 +99,91 @@ def step2(step1_text: str, engine, contig_names: Sequence[str], editing_keys, po
     database itself is not part of this repository — absent entries count as AF 0."""
     if gnomad_af is None:
         gnomad_af = {}
+    comments, header, rows, kept = [], None, [], []
+    for line in step1_text.split("\n"):
+        if line.startswith("#"):
+            if "#CHROM" in line:
+                header = line
+            else:
+                comments.append(line)
+        elif line:
+            el = line.split("\t", 6)                    # CHROM Start End REF ALT FILTER | the rest stays one string
+            if el[4] != "." and el[5] != ".":           # awk filter, step2.py:23
+                rows.append(el); kept.append(line)
+    tid_of = {n: i for i, n in enumerate(contig_names)}
+    keys = []
+    try:
+        if str(path).endswith(".gz"):
+            if reference_gz_compat:
+                return np.zeros(0, np.int64)
+            fh = io.TextIOWrapper(gzip.open(path, "rb"))
+        else:
+            fh = open(path, "r")
+        with fh:
+            for line in fh:
+                if line.startswith("#"):
+                    continue
+                el = line.split("\t")
+                t = tid_of.get(el[0])
+                p = int(el[1])
+                if t is not None:
+                    keys.append((t << 32) | p)
+    except Exception:
+        return np.zeros(0, np.int64)
+    return np.unique(np.asarray(keys, np.int64))
+
+
+class GnomadSqlite:
+    """AF lookups in a gnomad_db sqlite (the database the reference's step 2 queries through the gnomad_db package,
+    step2.py:100-108: gnomAD_DB(dir, gnomad_version="v4").get_info_from_df(df, "AF")): table gnomad_db keyed by
+    (chrom without "chr", pos, ref, alt).  Read with the standard library; the package itself is not needed.  The database is
+    not part of either repository, so this reader is unpinned; it exists so that the drop-in's gnomAD filter
+    runs wherever the reference's does."""
+
+    def __init__(self, path: str):
+        import os
+        import sqlite3
+        f = os.path.join(path, "gnomad_db.sqlite3") if os.path.isdir(path) else path
+        if not os.path.exists(f):
+            raise FileNotFoundError(f)
+        self._db = sqlite3.connect("file:%s?mode=ro" % f, uri=True)
+        self._db.execute("SELECT AF FROM gnomad_db LIMIT 1")
+
+    def get(self, key: str, default: float = 0.0) -> float:
+        chrom, pos, ref, alt = key.split(":", 3)
+        row = self._db.execute("SELECT AF FROM gnomad_db WHERE chrom = ? AND pos = ? AND ref = ? AND alt = ?",
+                               (chrom[3:] if chrom.startswith("chr") else chrom, int(pos), ref, alt)).fetchone()
+        return default if row is None or row[0] is None else float(row[0])
+
+    def __bool__(self):
+        return True
+
+
+def open_gnomad(source: Optional[str]):
+    """--gnomAD_db / --gnomAD_json of the shims: a JSON {"chrom:pos:ref:alt": AF}, a gnomad_db directory or sqlite file, or
+    nothing.  A source that is named but cannot be used is NOT silently ignored: the caller gets None and a warning on stderr
+    says that the gnomAD filter is off (the reference would have crashed in gnomAD_DB())."""
+    import json
+    import os
+    import sys
+    if not source:
+        return None
+    try:
+        if str(source).endswith(".json"):
+            return json.load(open(source))
+        return GnomadSqlite(source)
+    except Exception as e:                                      # noqa: BLE001 - every failure ends in the same warning
+        sys.stderr.write("warning: gnomAD source %r cannot be used (%s: %s): the gnomAD filter of step 2 is OFF, germline sites the "
+                         "reference would tag 'gnomAD' stay in the call set\n" % (source, type(e).__name__, e))
+        return None
+
+
+def step2(step1_text: str, engine, contig_names: Sequence[str], editing_keys, pon_sr_keys, pon_lr_keys, distance: int = 0,
+          gnomad_af: Optional[Dict[str, float]] = None, gnomad_max: float = 0.01) -> str:
+    """Returns the text of <prefix>.calling.step2.tsv.  gnomad_af: {"chrom:pos:ref:alt": AF}; the gnomAD
+    database itself is not part of this repository — absent entries count as AF 0."""
+    if gnomad_af is None:
+        gnomad_af = {}
     comments, header, rows = [], None, []
     for line in step1_text.split("\n"):
         if line.startswith("#"):
@@ -132,8 +217,16 @@ def step2(step1_text: str, engine, contig_names: Sequence[str], editing_keys, po
             close[i] = c
     have_af = isinstance(gnomad_af, GnomadSqlite) or bool(gnomad_af)
     h_ed, h_sr, h_lr = hits
-    out = []
-    for i, el in enumerate(rows):
+    # a row that gets no tag and holds no "NA" field leaves exactly as it came: only the others are taken apart (a handful among the
+    # hundreds of thousands of candidate rows of a real sample; every row when a gnomAD source is given)
+    out = list(kept)
+    if have_af:
+        todo = range(n)
+    else:
+        tagged = np.asarray(h_ed, bool) | np.asarray(h_sr, bool) | np.asarray(h_lr, bool) | (np.asarray(close) > 0)
+        todo = sorted(set(np.nonzero(tagged)[0].tolist()) | {i for i, l in enumerate(kept) if "NA" in l})
+    for i in todo:
+        el = rows[i]
         F = el[5]
         if h_ed[i] or close[i] or h_sr[i] or h_lr[i] or have_af:
             tags = []
@@ -151,9 +244,9 @@ def step2(step1_text: str, engine, contig_names: Sequence[str], editing_keys, po
         if rest is not None and "NA" in rest:            # pandas writes a missing field (the reference reads "NA" as NaN) as ""
             rest = _NA_FIELD.sub("", rest)
         if rest is None:
-            out.append("\t".join((el[0], el[1], el[2], el[3], el[4], F)))
+            out[i] = "\t".join((el[0], el[1], el[2], el[3], el[4], F))
         else:
-            out.append("\t".join((el[0], el[1], el[2], el[3], el[4], F, rest)))
+            out[i] = "\t".join((el[0], el[1], el[2], el[3], el[4], F, rest))
     return "\n".join(comments + [header] + out) + "\n"
 
 
@@ -282,6 +375,19 @@ def step3(step2_text: str, delta_vaf: float, delta_mcf: float, min_ac_reads: int
     out_cols = cols + ["STEP3FILTER", "INDEX"]
     if len(df) == 0:
         # the reference crashes on an empty frame under pandas 2; emit header-only files instead
+        empty = head + "\t".join(out_cols) + "\n"
+        return empty, empty
+    # Every filter below is row-local except the final cluster test, and the rows dropped by the FILTER patterns (step3.py:49-84: chrM
+    # rows with Min|LR|gnomAD|LC|RNA; other rows with Min_cell_types, Noisy_site, LC_*, RNA_editing_db, PoN, Cell_type_noise, gnomAD) are
+    # dropped whatever the row-wise functions did to them before — MultiAllelic_filtering only ever REMOVES "Multi-allelic" from FILTER,
+    # which none of the patterns can match — so they are dropped FIRST and the Python row functions see the survivors only (the
+    # reference runs them over every candidate row: 7 of the 7.7 s of step 3 on a 780 k-row step-2 table).
+    is_m = (df["#CHROM"] == "chrM").to_numpy()
+    flt = df["FILTER"].astype(str)
+    dead_m = flt.str.contains("Min|LR|gnomAD|LC|RNA", regex=True).to_numpy()
+    dead_o = flt.str.contains("Min_cell_types|Noisy_site|LC_Upstream|LC_Downstream|RNA_editing_db|PoN|Cell_type_noise|gnomAD", regex=True).to_numpy()
+    df = df[np.where(is_m, ~dead_m, ~dead_o)]
+    if len(df) == 0:
         empty = head + "\t".join(out_cols) + "\n"
         return empty, empty
     # MultiAllelic_filtering touches only rows flagged Multi-allelic or with several alts; every other row keeps its values and

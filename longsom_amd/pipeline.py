@@ -18,6 +18,7 @@ import pandas as pd
 
 from . import calling, hostio, pon, regions, tsvio
 from ._lib import CallParams, CountParams
+from . import _lib
 from .engine import Engine
 
 
@@ -108,13 +109,51 @@ def check_depth_cap(engine: Engine, what: str, allow_depth_overflow: Optional[bo
     return live
 
 
-def load_sample(bam: str, barcodes_tsv: str, ref_fasta: str, engine: Engine, min_mapq: int, allow_depth_overflow: Optional[bool] = None) -> Resident:
+def load_sample(bam: str, barcodes_tsv: str, ref_fasta: str, engine: Engine, min_mapq: int, allow_depth_overflow: Optional[bool] = None,
+                ingest: Optional[str] = None) -> Resident:
+    """ingest: "device" = the BAM's bytes go to the GPU and are inflated, decoded and laid out there (lsg_load_bam); "host" = the host
+    decoder (liblongsom_io) + lsg_load_reads; "auto" (default, or LONGSOM_INGEST) = device, and host for a BAM whose records are not
+    aligned to its BGZF blocks (not written by htslib).  Same store, same report either way (tests/test_ingest_gpu.py)."""
+    ingest = ingest or os.environ.get("LONGSOM_INGEST", "auto")
     t = {}
     t0 = time.time()
     bc = hostio.read_barcodes(barcodes_tsv)
-    dec = hostio.decode_bam(bam, bc.barcodes, min_mapq=min_mapq)
     names_fa, seqs = tsvio.read_fasta(ref_fasta)
     seq_of = dict(zip(names_fa, seqs))
+    if ingest in ("device", "auto"):
+        names, lens, first = hostio.bam_header(bam)
+        for n, l in zip(names, lens):
+            if n not in seq_of or len(seq_of[n]) != int(l):
+                raise ValueError("contig %s of the BAM header is missing from %s or has another length" % (n, ref_fasta))
+        t["header_fasta"] = time.time() - t0
+        t0 = time.time()
+        engine.set_contigs(lens)
+        for tid, n in enumerate(names):
+            engine.load_reference(tid, seq_of[n])
+        engine.set_barcodes(bc.celltype_of, len(bc.celltype_names))
+        engine.set_region()
+        t["reference"] = time.time() - t0
+        t0 = time.time()
+        try:
+            info, cb_pass, cb_low = engine.load_bam(bam, bc.barcodes, min_mapq=min_mapq, first_record_offset=first)
+        except _lib.LsgError as e:
+            if ingest == "device" or "straddle" not in str(e):
+                raise
+            info = None
+        if info is not None:
+            rep = {"Total_reads": int(info["total_reads"]), "Pass_reads": int(info["pass_reads"]), "CB_not_found": int(info["cb_not_found"]),
+                   "CB_not_matched": int(info["cb_not_matched"])}
+            if info["mapq_filtered"]:
+                rep["MAPQ"] = int(info["mapq_filtered"])
+            dec = hostio.DecodedBam(None, names, np.asarray(lens, np.int64), rep, None, cb_pass, cb_low)
+            t["decode"] = time.time() - t0                 # device ingest: H2D + inflate + decode + store build (info has the phases)
+            t["load"] = 0.0
+            for k, v in info.items():                      # the phases of the device ingest, in seconds like everything else here
+                if k.startswith("ms_") and k != "ms_total":
+                    t["ingest_" + k[3:]] = float(v) / 1e3
+            return Resident(engine, dec, bc, names, t)
+        t0 = time.time()
+    dec = hostio.decode_bam(bam, bc.barcodes, min_mapq=min_mapq)
     # the pileup is driven by the FASTA's contigs (MakeWindows, BaseCellCounter.py:84-86); BAM tids index dec.contig_names
     contig_names = dec.contig_names
     for n, l in zip(contig_names, dec.contig_len):
