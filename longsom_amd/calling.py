@@ -111,91 +111,6 @@ def step2(step1_text: str, engine, contig_names: Sequence[str], editing_keys, po
             if el[4] != "." and el[5] != ".":           # awk filter, step2.py:23
                 rows.append(el); kept.append(line)
     tid_of = {n: i for i, n in enumerate(contig_names)}
-    keys = []
-    try:
-        if str(path).endswith(".gz"):
-            if reference_gz_compat:
-                return np.zeros(0, np.int64)
-            fh = io.TextIOWrapper(gzip.open(path, "rb"))
-        else:
-            fh = open(path, "r")
-        with fh:
-            for line in fh:
-                if line.startswith("#"):
-                    continue
-                el = line.split("\t")
-                t = tid_of.get(el[0])
-                p = int(el[1])
-                if t is not None:
-                    keys.append((t << 32) | p)
-    except Exception:
-        return np.zeros(0, np.int64)
-    return np.unique(np.asarray(keys, np.int64))
-
-
-class GnomadSqlite:
-    """AF lookups in a gnomad_db sqlite (the database the reference's step 2 queries through the gnomad_db package,
-    step2.py:100-108: gnomAD_DB(dir, gnomad_version="v4").get_info_from_df(df, "AF")): table gnomad_db keyed by
-    (chrom without "chr", pos, ref, alt).  Read with the standard library; the package itself is not needed.  The database is
-    not part of either repository, so this reader is unpinned; it exists so that the drop-in's gnomAD filter
-    runs wherever the reference's does."""
-
-    def __init__(self, path: str):
-        import os
-        import sqlite3
-        f = os.path.join(path, "gnomad_db.sqlite3") if os.path.isdir(path) else path
-        if not os.path.exists(f):
-            raise FileNotFoundError(f)
-        self._db = sqlite3.connect("file:%s?mode=ro" % f, uri=True)
-        self._db.execute("SELECT AF FROM gnomad_db LIMIT 1")
-
-    def get(self, key: str, default: float = 0.0) -> float:
-        chrom, pos, ref, alt = key.split(":", 3)
-        row = self._db.execute("SELECT AF FROM gnomad_db WHERE chrom = ? AND pos = ? AND ref = ? AND alt = ?",
-                               (chrom[3:] if chrom.startswith("chr") else chrom, int(pos), ref, alt)).fetchone()
-        return default if row is None or row[0] is None else float(row[0])
-
-    def __bool__(self):
-        return True
-
-
-def open_gnomad(source: Optional[str]):
-    """--gnomAD_db / --gnomAD_json of the shims: a JSON {"chrom:pos:ref:alt": AF}, a gnomad_db directory or sqlite file, or
-    nothing.  A source that is named but cannot be used is NOT silently ignored: the caller gets None and a warning on stderr
-    says that the gnomAD filter is off (the reference would have crashed in gnomAD_DB())."""
-    import json
-    import os
-    import sys
-    if not source:
-        return None
-    try:
-        if str(source).endswith(".json"):
-            return json.load(open(source))
-        return GnomadSqlite(source)
-    except Exception as e:                                      # noqa: BLE001 - every failure ends in the same warning
-        sys.stderr.write("warning: gnomAD source %r cannot be used (%s: %s): the gnomAD filter of step 2 is OFF, germline sites the "
-                         "reference would tag 'gnomAD' stay in the call set\n" % (source, type(e).__name__, e))
-        return None
-
-
-def step2(step1_text: str, engine, contig_names: Sequence[str], editing_keys, pon_sr_keys, pon_lr_keys, distance: int = 0,
-          gnomad_af: Optional[Dict[str, float]] = None, gnomad_max: float = 0.01) -> str:
-    """Returns the text of <prefix>.calling.step2.tsv.  gnomad_af: {"chrom:pos:ref:alt": AF}; the gnomAD
-    database itself is not part of this repository — absent entries count as AF 0."""
-    if gnomad_af is None:
-        gnomad_af = {}
-    comments, header, rows = [], None, []
-    for line in step1_text.split("\n"):
-        if line.startswith("#"):
-            if "#CHROM" in line:
-                header = line
-            else:
-                comments.append(line)
-        elif line:
-            el = line.split("\t", 6)                    # CHROM Start End REF ALT FILTER | the rest stays one string
-            if el[4] != "." and el[5] != ".":           # awk filter, step2.py:23
-                rows.append(el)
-    tid_of = {n: i for i, n in enumerate(contig_names)}
     pos = [int(el[1]) for el in rows]
     q = np.asarray([(tid_of.get(el[0], 0x7FFFFFFF) << 32) | p for el, p in zip(rows, pos)], np.int64)
     hits = []
@@ -217,8 +132,8 @@ def step2(step1_text: str, engine, contig_names: Sequence[str], editing_keys, po
             close[i] = c
     have_af = isinstance(gnomad_af, GnomadSqlite) or bool(gnomad_af)
     h_ed, h_sr, h_lr = hits
-    # a row that gets no tag and holds no "NA" field leaves exactly as it came: only the others are taken apart (a handful among the
-    # hundreds of thousands of candidate rows of a real sample; every row when a gnomAD source is given)
+    # a row that gets no tag and holds no "NA" field leaves exactly as it came: only the others are taken apart (every row when a
+    # gnomAD source is given)
     out = list(kept)
     if have_af:
         todo = range(n)

@@ -1,9 +1,10 @@
 """CPU: step 3 (host side, pandas) against the reference's golden outputs."""
 import os
 
+import numpy as np
 import pytest
 
-from longsom_amd import calling
+from longsom_amd import calling, tsvio
 
 G = os.path.join(os.path.dirname(__file__), "golden")
 
@@ -37,3 +38,30 @@ def test_posset_reader(tmp_path):
     assert (calling.read_posset_keys(str(gz), names) == keys).all()
     assert len(calling.read_posset_keys(str(gz), names, reference_gz_compat=True)) == 0
     assert len(calling.read_posset_keys("", names)) == 0 and len(calling.read_posset_keys("/nonexistent", names)) == 0
+
+
+class _NumpyProbe:
+    """stands in for the device position sets of step 2 (Engine.load_posset / probe_posset): membership by numpy, so that the host
+    half of step 2 — the row handling, the tags, the NA fields, the gnomAD lookup — is pinned to the reference's files without a GPU"""
+    def __init__(self):
+        self.sets = {}
+
+    def load_posset(self, kind, keys):
+        self.sets[kind] = np.asarray(keys, np.int64)
+
+    def probe_posset(self, kind, q):
+        return np.isin(np.asarray(q, np.int64), self.sets[kind]).astype(np.uint8)
+
+
+def test_step2_host_half_matches_reference_golden():
+    import json
+    names, _ = tsvio.read_fasta(os.path.join(G, "calling.ref.fa"))
+    ed, sr, lr = (calling.read_posset_keys(os.path.join(G, "calling.%s.tsv" % k), names) for k in ("editing", "pon_SR", "pon_LR"))
+    af = json.load(open(os.path.join(G, "calling.gnomad_af.json")))
+    s1 = rd("sample.calling.step1.tsv")
+    assert calling.step2(s1, _NumpyProbe(), names, ed, sr, lr, 0, af, 0.01) == rd("sample.calling.step2.tsv")
+    assert calling.step2(s1, _NumpyProbe(), names, ed, sr, calling.read_posset_keys("", names), 150, af, 0.01) == rd("sample.dist150.calling.step2.tsv")
+    # without a gnomAD source most rows pass through verbatim: the same rows as with an empty table of allele frequencies
+    class _Empty(dict):
+        def __bool__(self): return True
+    assert calling.step2(s1, _NumpyProbe(), names, ed, sr, lr, 0, None, 0.01) == calling.step2(s1, _NumpyProbe(), names, ed, sr, lr, 0, _Empty(), 0.01)
