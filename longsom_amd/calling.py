@@ -9,6 +9,7 @@ step3  <- variant_calling_step3 + helpers           workflow/scripts/SNVCalling/
 """
 import gzip
 import io
+import os
 import re
 from typing import Dict, Optional, Sequence
 
@@ -132,37 +133,41 @@ def step2(step1_text: str, engine, contig_names: Sequence[str], editing_keys, po
             close[i] = c
     have_af = isinstance(gnomad_af, GnomadSqlite) or bool(gnomad_af)
     h_ed, h_sr, h_lr = hits
-    # a row that gets no tag and holds no "NA" field leaves exactly as it came: only the others are taken apart (every row when a
-    # gnomAD source is given)
+    # a row that gets no tag leaves as it came; the tagged ones (a handful among the hundreds of thousands of candidate rows of a real
+    # sample; every row when a gnomAD source is given) get their FILTER rebuilt
     out = list(kept)
     if have_af:
         todo = range(n)
     else:
         tagged = np.asarray(h_ed, bool) | np.asarray(h_sr, bool) | np.asarray(h_lr, bool) | (np.asarray(close) > 0)
-        todo = sorted(set(np.nonzero(tagged)[0].tolist()) | {i for i, l in enumerate(kept) if "NA" in l})
+        todo = np.nonzero(tagged)[0].tolist()
     for i in todo:
         el = rows[i]
         F = el[5]
-        if h_ed[i] or close[i] or h_sr[i] or h_lr[i] or have_af:
-            tags = []
-            if h_ed[i]: tags.append("RNA_editing_db")
-            if close[i] > 0: tags.append("Clustered")
-            if h_sr[i]: tags.append("PoN_SR")
-            if h_lr[i]: tags.append("PoN_LR")
-            if have_af:
-                af = gnomad_af.get("%s:%s:%s:%s" % (el[0], el[1], el[3], el[4]), 0.0)
-                if af == af and af >= gnomad_max:
-                    tags.append("gnomAD")
-            for t in tags:
-                F = t if F == "PASS" else F + "," + t
-        rest = el[6] if len(el) > 6 else None
-        if rest is not None and "NA" in rest:            # pandas writes a missing field (the reference reads "NA" as NaN) as ""
-            rest = _NA_FIELD.sub("", rest)
-        if rest is None:
-            out[i] = "\t".join((el[0], el[1], el[2], el[3], el[4], F))
-        else:
-            out[i] = "\t".join((el[0], el[1], el[2], el[3], el[4], F, rest))
-    return "\n".join(comments + [header] + out) + "\n"
+        tags = []
+        if h_ed[i]: tags.append("RNA_editing_db")
+        if close[i] > 0: tags.append("Clustered")
+        if h_sr[i]: tags.append("PoN_SR")
+        if h_lr[i]: tags.append("PoN_LR")
+        if have_af:
+            af = gnomad_af.get("%s:%s:%s:%s" % (el[0], el[1], el[3], el[4]), 0.0)
+            if af == af and af >= gnomad_max:
+                tags.append("gnomAD")
+        if not tags:
+            continue
+        for t in tags:
+            F = t if F == "PASS" else F + "," + t
+        out[i] = "\t".join(el[:5] + [F] + el[6:])
+    # pandas writes a missing field (the reference's read_csv takes a whole field "NA" for NaN, step2.py:96) as "": done on the whole
+    # text at once — the first six fields of a row (CHROM Start End REF ALT FILTER) are never "NA", so only the per-cell-type columns
+    # and their kin are touched, as before
+    body = "\n".join(out)
+    if "\tNA" in body:
+        body = (body + "\n").replace("\tNA\n", "\t\n")
+        while "\tNA\t" in body:                          # ("\tNA\tNA\t": the second one only matches once the first is gone)
+            body = body.replace("\tNA\t", "\t\t")
+        body = body[:-1]
+    return "\n".join(comments + [header]) + "\n" + (body + "\n" if out else "")
 
 
 _NA_FIELD = re.compile(r"(?:(?<=\t)|^)NA(?=\t|$)")     # a whole field equal to NA
@@ -285,6 +290,26 @@ def step3(step2_text: str, delta_vaf: float, delta_mcf: float, min_ac_reads: int
         else:
             comments.append(line + "\n")
     head = "".join(comments) + FINAL_FILTER_LINE
+    # Only the rows that survive step 3's FILTER patterns (below) are parsed: a numeric field of this table is the shortest repr of
+    # its value (Python's str() in step 1, pandas' in the reference's step 2), which pandas prints back unchanged whatever dtype the
+    # column got, and "NA" / empty fields print as "" either way, so the dtypes pandas would infer from the dropped rows do not reach
+    # the output.  LONGSOM_STEP3_FULL_PARSE=1 parses every row like the reference does (tests compare the two).
+    if os.environ.get("LONGSOM_STEP3_FULL_PARSE", "0") != "1":
+        dead_m, dead_o = re.compile("Min|LR|gnomAD|LC|RNA"), re.compile("Min_cell_types|Noisy_site|LC_Upstream|LC_Downstream|RNA_editing_db|PoN|Cell_type_noise|gnomAD")
+        i_ct = cols.index("Cell_types") if cols and "Cell_types" in cols else 6
+        keep_lines = []
+        for line in step2_text.split("\n"):
+            if not line or line.startswith("#"):
+                continue
+            el = line.split("\t", i_ct + 1)
+            if len(el) <= i_ct or el[i_ct] == "Non-Cancer":
+                continue
+            if (dead_m if el[0] == "chrM" else dead_o).search(el[5]) is None:
+                keep_lines.append(line)
+        if not keep_lines:
+            empty = head + "\t".join(cols + ["STEP3FILTER", "INDEX"]) + "\n"
+            return empty, empty
+        step2_text = "\n".join(keep_lines) + "\n"
     df = pd.read_csv(io.StringIO(step2_text), sep="\t", comment="#", names=cols)
     df = df[df["Cell_types"] != "Non-Cancer"]
     out_cols = cols + ["STEP3FILTER", "INDEX"]

@@ -65,3 +65,24 @@ def test_step2_host_half_matches_reference_golden():
     class _Empty(dict):
         def __bool__(self): return True
     assert calling.step2(s1, _NumpyProbe(), names, ed, sr, lr, 0, None, 0.01) == calling.step2(s1, _NumpyProbe(), names, ed, sr, lr, 0, _Empty(), 0.01)
+
+
+def test_step3_prefilter_equals_full_parse(monkeypatch):
+    """step 3 parses only the rows its FILTER patterns let through; LONGSOM_STEP3_FULL_PARSE=1 parses every row like the reference:
+    same files, on the goldens and on a 60 k-row table replicated from them (mixed single- and two-cell-type rows in every chunk)"""
+    texts = [rd("sample.calling.step2.tsv"), rd("sample.dist150.calling.step2.tsv")]
+    lines = texts[0].split("\n")
+    comments = [l for l in lines if l.startswith("#")]
+    body = [l for l in lines if l and not l.startswith("#")]
+    big, k = [], 0
+    while len(big) < 60000:
+        for l in body:
+            f = l.split("\t"); f[1] = str(int(f[1]) + 1000 * k); f[2] = f[1]; big.append("\t".join(f))
+        k += 1
+    texts.append("\n".join(comments + big) + "\n")
+    texts.append("\n".join(comments + [l for l in big if "Noisy_site" in l][:100]) + "\n")          # nothing survives
+    for t in texts:
+        monkeypatch.setenv("LONGSOM_STEP3_FULL_PARSE", "1")
+        want = calling.step3(t, 0.05, 0.3, 3, 2, 10000)
+        monkeypatch.setenv("LONGSOM_STEP3_FULL_PARSE", "0")
+        assert calling.step3(t, 0.05, 0.3, 3, 2, 10000) == want
