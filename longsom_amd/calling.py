@@ -75,10 +75,15 @@ class GnomadSqlite:
         return True
 
 
-def open_gnomad(source: Optional[str]):
+class GnomadUnusable(RuntimeError):
+    """a gnomAD source was named but cannot be read (the reference stops in gnomAD_DB() then, BaseCellCalling.step2.py:100)"""
+
+
+def open_gnomad(source: Optional[str], allow_missing: Optional[bool] = None):
     """--gnomAD_db / --gnomAD_json of the shims: a JSON {"chrom:pos:ref:alt": AF}, a gnomad_db directory or sqlite file, or
-    nothing.  A source that is named but cannot be used is NOT silently ignored: the caller gets None and a warning on stderr
-    says that the gnomAD filter is off (the reference would have crashed in gnomAD_DB())."""
+    nothing.  A source that is named but cannot be used STOPS the run, as the reference's gnomAD_DB() does — running step 2 without
+    its germline filter is a different call set, not a degraded one.  allow_missing=True (--allow_missing_gnomad,
+    Run.allow_missing_gnomad, LONGSOM_ALLOW_MISSING_GNOMAD=1): warn on stderr and run with the filter off."""
     import json
     import os
     import sys
@@ -88,9 +93,14 @@ def open_gnomad(source: Optional[str]):
         if str(source).endswith(".json"):
             return json.load(open(source))
         return GnomadSqlite(source)
-    except Exception as e:                                      # noqa: BLE001 - every failure ends in the same warning
-        sys.stderr.write("warning: gnomAD source %r cannot be used (%s: %s): the gnomAD filter of step 2 is OFF, germline sites the "
-                         "reference would tag 'gnomAD' stay in the call set\n" % (source, type(e).__name__, e))
+    except Exception as e:                                      # noqa: BLE001 - every failure ends the same way
+        if allow_missing is None:
+            allow_missing = os.environ.get("LONGSOM_ALLOW_MISSING_GNOMAD", "0") == "1"
+        msg = "gnomAD source %r cannot be used (%s: %s)" % (source, type(e).__name__, e)
+        if not allow_missing:
+            raise GnomadUnusable(msg + ": step 2 needs it for its germline filter; pass --allow_missing_gnomad (Run.allow_missing_gnomad: True, "
+                                 "LONGSOM_ALLOW_MISSING_GNOMAD=1) to run without") from e
+        sys.stderr.write("warning: " + msg + ": the gnomAD filter of step 2 is OFF, germline sites the reference would tag 'gnomAD' stay in the call set\n")
         return None
 
 

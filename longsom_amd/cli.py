@@ -118,10 +118,11 @@ def calling_step2(argv=None):
     ap.add_argument("--pon_SR", required=True); ap.add_argument("--pon_LR", nargs="?", const="", default="")
     ap.add_argument("--min_distance", type=int, default=5); ap.add_argument("--gnomAD_db"); ap.add_argument("--gnomAD_max", type=float, default=0.01)
     ap.add_argument("--reference-gz-compat", action="store_true"); ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--allow_missing_gnomad", action="store_true", help="run without the gnomAD filter when --gnomAD_db cannot be read (default: stop, as the reference does)")
     a = ap.parse_args(argv)
     text = open(a.infile).read()
     contigs = tsvio.contigs_of_tsv([a.infile])
-    af = calling.open_gnomad(a.gnomAD_db)               # JSON table, gnomad_db directory / sqlite; unusable -> warning, filter off
+    af = calling.open_gnomad(a.gnomAD_db, a.allow_missing_gnomad or None)               # JSON table, gnomad_db directory / sqlite
     keys = [calling.read_posset_keys(p, contigs, a.reference_gz_compat) for p in (a.editing, a.pon_SR, a.pon_LR)]
     with Engine(a.device) as eng:
         out = calling.step2(text, eng, contigs, keys[0], keys[1], keys[2], a.min_distance, af, a.gnomAD_max)
@@ -196,6 +197,15 @@ def celltype_reannotation(argv=None):
     reanno.celltype_reannotation(a.SNVs, a.fusions, a.meta, a.outfile, a.min_variants, a.min_frac)
 
 
+def _add_gnomad_flag(ap):
+    ap.add_argument("--allow_missing_gnomad", action="store_true", help="run without the gnomAD filter when the named source cannot be read (default: stop, as the reference does)")
+
+
+def _apply_gnomad_flag(a):
+    if getattr(a, "allow_missing_gnomad", False):
+        os.environ["LONGSOM_ALLOW_MISSING_GNOMAD"] = "1"
+
+
 def _add_htslib_flag(ap):
     ap.add_argument("--htslib_legacy_del_merge", action="store_true",
                     help="count the first column of a deletion that is followed by another deletion (CIGAR 1D2D) as 'D', as pysam over htslib <= 1.10 "
@@ -233,9 +243,9 @@ def snv(argv=None):
                     "window by window (for a BAM whose reads do not fit in HBM); 0 = the whole BAM at once")
     d = pipeline.SnvParams()
     _add_dataclass_flags(ap, d)
-    _add_htslib_flag(ap)
+    _add_htslib_flag(ap); _add_gnomad_flag(ap)
     a = ap.parse_args(argv)
-    _apply_htslib_flag(a)
+    _apply_htslib_flag(a); _apply_gnomad_flag(a)
     params = pipeline.SnvParams(**{k: getattr(a, k) for k in vars(d)})
     # under torch.distributed.run (WORLD_SIZE > 1): one rank per GPU, regions sharded over the ranks; the process group comes up
     # before anything touches the GPU
@@ -262,9 +272,9 @@ def reannotation(argv=None):
     # block) and config['SNVCalling'] (pass 2: --p2_*); defaults = config/config.yaml
     rp0, sp0 = pipeline.ReannoParams(), pipeline.SnvParams()
     _add_dataclass_flags(ap, rp0, "reanno_"); _add_dataclass_flags(ap, rp0.chain, "p1_"); _add_dataclass_flags(ap, sp0, "p2_")
-    _add_htslib_flag(ap)
+    _add_htslib_flag(ap); _add_gnomad_flag(ap)
     a = ap.parse_args(argv)
-    _apply_htslib_flag(a)
+    _apply_htslib_flag(a); _apply_gnomad_flag(a)
     chain = pipeline.SnvParams(**{k: getattr(a, "p1_" + k) for k in vars(rp0.chain)})
     rp = pipeline.ReannoParams(chain=chain, **{k: getattr(a, "reanno_" + k) for k, v in vars(rp0).items() if k != "chain"})
     sp = pipeline.SnvParams(**{k: getattr(a, "p2_" + k) for k in vars(sp0)})

@@ -41,7 +41,7 @@ def test_rule_chain_equals_fused_run(tmp_path):
     run("SNVCalling/BaseCellCalling.step1.py", "--infile", merged, "--ref", fa, "--outfile", pre, "--min_cell_types", 2, "--min_ac_reads", 3,
         "--min_ac_cells", 2, "--alpha1", 0.21356677091082193, "--beta1", 104.95163748636298, "--alpha2", 0.2474528917555431, "--beta2", 162.03696139428595)
     run("SNVCalling/BaseCellCalling.step2.py", "--infile", str(pre) + ".calling.step1.tsv", "--outfile", pre, "--editing", "/nonexistent", "--pon_SR",
-        "/nonexistent", "--pon_LR", "--gnomAD_db", "/nonexistent", "--gnomAD_max", 0.01, "--min_distance", 0)
+        "/nonexistent", "--pon_LR", "--gnomAD_db", "/nonexistent", "--allow_missing_gnomad", "--gnomAD_max", 0.01, "--min_distance", 0)
     run("SNVCalling/BaseCellCalling.step3.py", "--infile", str(pre) + ".calling.step2.tsv", "--outfile", pre, "--chrM_contaminant", "True", "--deltaVAF",
         0.05, "--deltaMCF", 0.3, "--min_ac_reads", 3, "--min_ac_cells", 2, "--clust_dist", 10000)
     for rel in ("BaseCellCounter/S1/S1.Cancer.tsv", "BaseCellCounter/S1/S1.Non-Cancer.tsv", "MergeCounts/S1.BaseCellCounts.AllCellTypes.tsv",

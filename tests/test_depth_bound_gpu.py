@@ -52,6 +52,8 @@ def test_bound_equals_the_tile_restatement_and_covers_the_true_depth(engine, see
     got = engine.max_live_reads()
     assert got == max(b for b, _ in per_ct)
     assert got >= max(e for _, e in per_ct) > 0
+    # the bound over ALL reads with a barcode (what the genotyping pileup of the unsplit BAM holds): table-independent, falls out of the load
+    assert engine.max_live_reads_all() == tile_bound(rec, lens, has_cb)[0] >= got
     # the bound follows the barcode table: everything in one cell type = the union of the reads with a barcode
     engine.set_barcodes(np.zeros(40, np.uint8), 1)
     assert engine.max_live_reads() == tile_bound(rec, lens, has_cb)[0] >= got
@@ -108,3 +110,21 @@ def test_genotyping_guard_refuses_a_sample_above_the_cap(engine, deep_sample, mo
     assert pipeline.check_depth_cap(engine, "S1") == live
     assert "max_depth" in capsys.readouterr().err
     assert res.engine is engine
+
+
+def test_genotyping_guard_counts_every_cell_type(engine, monkeypatch):
+    """the genotyping pileup reads the UNSPLIT BAM (HCCVSingleCellGenotype.py:122): two cell types whose SUM exceeds the cap, though
+    neither does alone, must trip the guard (it used the per-cell-type bound)"""
+    lens = [3000]
+    rec = random_records(21, 4000, lens, 60, hot_regions=[(0, 1000, 1060)], hot_frac=0.9)
+    rng = np.random.default_rng(21)
+    engine.set_contigs(lens); engine.load_reference(0, random_reference(rng, lens[0]))
+    ct_of = (np.arange(60) % 2).astype(np.uint8)                 # the barcodes alternate between the two cell types
+    engine.set_barcodes(ct_of, 2)
+    engine.load_reads(rec)
+    per_ct, both = engine.max_live_reads(), engine.max_live_reads_all()
+    assert per_ct < both <= 2 * per_ct + 64
+    monkeypatch.delenv("LONGSOM_ALLOW_DEPTH_OVERFLOW", raising=False)
+    monkeypatch.setattr(pipeline, "PILEUP_MAX_DEPTH", (per_ct + both) // 2)      # above either cell type, below their sum
+    with pytest.raises(pipeline.DepthCapExceeded):
+        pipeline.check_depth_cap(engine, "S1")

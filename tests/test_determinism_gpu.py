@@ -29,6 +29,30 @@ def digest(eng):
 pytestmark = pytest.mark.gpu
 
 
+def oracle_calls(tag):
+    d = json.load(open(os.path.join(G, "calls_hash_oracle_%s.json" % tag)))
+    return d["candidate_rows"], d["xxh64_of_candidate_row_text"]
+
+
+def candidate_text_digest(eng, m):
+    """(rows, xxhash) of the step-1 text of the rows step 2 keeps, for the counts and calls resident in eng"""
+    from longsom_amd import tsvio
+    per_ct = [eng.fetch_counts(ct) for ct in range(2)]
+    calls = eng.fetch_calls()
+    text = tsvio.write_step1_tsv("/dev/null", calls, per_ct, m.contig_names, ["Cancer", "Non-Cancer"], [], header=False)
+    return text.count("\n"), xxhash.xxh64(text.encode()).hexdigest()
+
+
+def test_candidate_call_records_equal_the_cpu_oracles_small(engine):
+    """C1 at 20 k reads (263 k merged sites, 33.6 k candidate rows): count + merge + step 1 on the GPU == the CPU oracles' text"""
+    m = synth.named("C1", n_reads=20_000)
+    engine.set_contigs(m.contig_len); engine.synth_reference(m.seed); engine.set_barcodes(m.celltype_of, 2)
+    engine.set_region()
+    engine.synth_reads(m)
+    engine.pileup_count(); engine.call_step1()
+    assert candidate_text_digest(engine, m) == oracle_calls("c1_20000")
+
+
 def test_two_counts_of_the_same_reads_are_identical(engine):
     m = synth.named("C4", n_reads=2_500_000)
     engine.set_contigs(m.contig_len); engine.synth_reference(m.seed); engine.set_barcodes(m.celltype_of, 2)
@@ -55,8 +79,11 @@ def test_two_counts_of_the_same_reads_are_identical(engine):
     want = json.load(open(ORACLE_C4))
     assert rows == want["rows"] and cols == want["columns"]
     assert d["ct0"] == want["ct0"] and d["ct1"] == want["ct1"], "count rows of the 2.5 M-read sample differ from the CPU oracle's"
-    # the candidate call records of the sample: a self-written pin (the step-1 oracle is Python + scipy, minutes at this size; the call
-    # stage is pinned to the reference's own outputs in tests/test_call_gpu.py).  LSG_WRITE_PIN=1 rewrites it after a deliberate change
+    # the candidate call records of the sample: their step-1 text (the product's native writer, pinned byte for byte to the reference's
+    # goldens) hashes to what the CPU oracles wrote for this sample — count_oracle.c + calling_oracle.py step 1 (scipy) in 6 processes,
+    # tools/oracle_call_hash.py; nothing the GPU wrote is part of the pin
+    assert candidate_text_digest(engine, m) == oracle_calls("c4_2500000")
+    # (the digest of the raw call records the HIP path itself wrote in round 1: kept as a cross-build check)
     if os.environ.get("LSG_WRITE_PIN") == "1":
         json.dump({"calls": d["calls"]}, open(PIN, "w"), indent=1)
     assert d["calls"] == json.load(open(PIN))["calls"]

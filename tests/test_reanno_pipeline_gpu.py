@@ -54,7 +54,7 @@ def test_two_pass_loop(engine, tmp_path):
         run("SNVCalling/BaseCellCalling.step1.py", "--infile", merged, "--ref", fa, "--outfile", pre, "--min_cell_types", p.min_cell_types, "--min_ac_reads",
             p.min_ac_reads, "--min_ac_cells", p.min_ac_cells, "--alpha1", p.alpha1, "--beta1", p.beta1, "--alpha2", p.alpha2, "--beta2", p.beta2)
         run("SNVCalling/BaseCellCalling.step2.py", "--infile", str(pre) + ".calling.step1.tsv", "--outfile", pre, "--editing", "/nonexistent", "--pon_SR",
-            "/nonexistent", "--pon_LR", "--gnomAD_db", "/nonexistent", "--gnomAD_max", p.max_gnomad_vaf, "--min_distance", p.min_distance)
+            "/nonexistent", "--pon_LR", "--gnomAD_db", "/nonexistent", "--allow_missing_gnomad", "--gnomAD_max", p.max_gnomad_vaf, "--min_distance", p.min_distance)
         run("SNVCalling/BaseCellCalling.step3.py", "--infile", str(pre) + ".calling.step2.tsv", "--outfile", pre, "--chrM_contaminant", "True", "--deltaVAF",
             p.delta_vaf, "--deltaMCF", p.delta_mcf, "--min_ac_reads", p.min_ac_reads, "--min_ac_cells", p.min_ac_cells, "--clust_dist", p.clust_dist)
         return d

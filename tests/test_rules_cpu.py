@@ -86,7 +86,7 @@ def render(shell, empty=()):
         key = m.group(1)
         if key in empty:
             return ""
-        if key.startswith("params.") and ("compat" in key or "htslib" in key or "launcher" in key or key == "params.tables"):
+        if key.startswith("params.") and ("compat" in key or "htslib" in key or "no_gnomad" in key or "launcher" in key or key == "params.tables"):
             return "python" if "launcher" in key else ""      # switches that render as a flag or as nothing
         if "alt_flag" in key:
             return "All"                                      # config.yaml:66 (a choice option)
@@ -116,11 +116,16 @@ def test_bare_optional_file_flags():
         assert a.pon_LR == "" and a.pon_SR == "" and a.editing == "e" and a.gnomAD_db == ""
 
 
-def test_unusable_gnomad_source_warns(capsys, tmp_path):
+def test_unusable_gnomad_source_stops_unless_allowed(capsys, tmp_path, monkeypatch):
     from longsom_amd import calling
+    monkeypatch.delenv("LONGSOM_ALLOW_MISSING_GNOMAD", raising=False)
     assert calling.open_gnomad(None) is None and capsys.readouterr().err == ""
-    assert calling.open_gnomad(str(tmp_path / "nowhere")) is None
+    with pytest.raises(calling.GnomadUnusable, match="allow_missing_gnomad"):          # the reference stops in gnomAD_DB(); so does this
+        calling.open_gnomad(str(tmp_path / "nowhere"))
+    assert calling.open_gnomad(str(tmp_path / "nowhere"), allow_missing=True) is None
     assert "gnomAD filter of step 2 is OFF" in capsys.readouterr().err
+    monkeypatch.setenv("LONGSOM_ALLOW_MISSING_GNOMAD", "1")
+    assert calling.open_gnomad(str(tmp_path / "nowhere")) is None
 
 
 def test_gnomad_sqlite_reader(tmp_path):

@@ -28,6 +28,8 @@ rule Reannotation_gpu:
         gz_compat="--p1_reference_gz_compat --p2_reference_gz_compat" if config['Run'].get('reference_gz_compat', False) else "",
         # Run.htslib_legacy_del_merge: True counts CIGAR 1D2D's first deleted column as 'D' (pysam over htslib <= 1.10); default: htslib >= 1.11
         htslib="--htslib_legacy_del_merge" if config['Run'].get('htslib_legacy_del_merge', False) else "",
+        # Run.allow_missing_gnomad: True runs step 2 without its gnomAD filter when the database cannot be read (default: the rule fails, as the reference's gnomAD_DB() does)
+        no_gnomad="--allow_missing_gnomad" if config['Run'].get('allow_missing_gnomad', False) else "",
         # pass 1 = config['Reanno'], pass 2 = config['SNVCalling'].  Pass 1 deliberately gets NO min_ac_reads / min_ac_cells: the
         # reference's pass-1 step-1 rule does not forward them either (rules/CellTypeReannotation.smk:208-238)
         r1=config['Reanno']['BaseCellCalling'],
@@ -43,7 +45,7 @@ rule Reannotation_gpu:
     shell:
         r"""
         python {params.script} --bam {input.bam} --meta {input.barcodes} --ref {input.ref} --id {wildcards.id} --outdir . \
-        --fusions {input.fusions} --editing {input.RNA_editing} --pon_SR {input.pon_SR} --pon_LR {input.pon_LR} --gnomAD_db {params.gnomAD_db} {params.gz_compat} {params.htslib} \
+        --fusions {input.fusions} --editing {input.RNA_editing} --pon_SR {input.pon_SR} --pon_LR {input.pon_LR} --gnomAD_db {params.gnomAD_db} {params.gz_compat} {params.htslib} {params.no_gnomad} \
         --p1_min_mapping_quality {params.m1} --p1_min_cell_types {params.r1[Min_cell_types]} --p1_min_distance {params.r1[min_distance]} \
         --p1_max_gnomad_vaf {params.r1[max_gnomAD_VAF]} \
         --p1_alpha1 {params.r1[alpha1]} --p1_beta1 {params.r1[beta1]} --p1_alpha2 {params.r1[alpha2]} --p1_beta2 {params.r1[beta2]} \

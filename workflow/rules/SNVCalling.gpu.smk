@@ -34,6 +34,8 @@ rule SNVCalling_gpu:
         gz_compat="--reference_gz_compat" if config['Run'].get('reference_gz_compat', False) else "",
         # Run.htslib_legacy_del_merge: True counts CIGAR 1D2D's first deleted column as 'D' (pysam over htslib <= 1.10); default: htslib >= 1.11
         htslib="--htslib_legacy_del_merge" if config['Run'].get('htslib_legacy_del_merge', False) else "",
+        # Run.allow_missing_gnomad: True runs step 2 without its gnomAD filter when the database cannot be read (default: the rule fails, as the reference's gnomAD_DB() does)
+        no_gnomad="--allow_missing_gnomad" if config['Run'].get('allow_missing_gnomad', False) else "",
         # GPUs of this node used by the rule: one rank per GPU, genomic regions sharded over the ranks
         launcher=lambda wc, resources: "python" if resources.gpu == 1 else f"python -m torch.distributed.run --standalone --local-addr 127.0.0.1 --nnodes=1 --nproc-per-node {resources.gpu}",
     resources:
@@ -46,7 +48,7 @@ rule SNVCalling_gpu:
         r"""
         {params.launcher} {params.script} \
         --bam {input.bam} --meta {input.barcodes} --ref {input.ref} --id {wildcards.id} --outdir SNVCalling \
-        --editing {input.RNA_editing} --pon_SR {input.pon_SR} --pon_LR {input.pon_LR} --gnomAD_db {params.gnomAD_db} {params.gz_compat} {params.htslib} \
+        --editing {input.RNA_editing} --pon_SR {input.pon_SR} --pon_LR {input.pon_LR} --gnomAD_db {params.gnomAD_db} {params.gz_compat} {params.htslib} {params.no_gnomad} \
         --min_mapping_quality {params.mapq} \
         --min_cell_types {params.c[Min_cell_types]} --min_distance {params.c[min_distance]} \
         --max_gnomad_vaf {params.c[max_gnomAD_VAF]} --delta_vaf {params.c[deltaVAF]} --delta_mcf {params.c[deltaMCF]} \
