@@ -340,8 +340,9 @@ int lsg_synth_reads(lsg_ctx* ctx, const lsg_synth_model* model);
  * lsg_destroy) — a stand-in for a caller whose decoded BAM is device-resident; bench.py times lsg_load_reads on them. */
 int lsg_synth_generate(lsg_ctx* ctx, const lsg_synth_model* model, lsg_reads* out);
 int lsg_get_reads_shape(lsg_ctx* ctx, int64_t* n_reads, int64_t* n_segs, int64_t* n_events);
-/* Copies the resident read-record arrays / reference into caller-allocated host arrays (the events only when the load kept them:
- * lsg_set_keep_reads). */
+/* Copies the resident read-record arrays / reference into caller-allocated host arrays.  out->events and out->seg_ev_off both NULL:
+ * the per-read and per-segment arrays only (always resident: what a sharded run cuts its regions from); otherwise the events too, which
+ * are there only when the load kept them (lsg_set_keep_reads). */
 int lsg_copy_reads_to_host(lsg_ctx* ctx, const lsg_reads* out);
 int lsg_copy_reference_to_host(lsg_ctx* ctx, int32_t tid, uint8_t* out);
 

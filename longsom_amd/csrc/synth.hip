@@ -167,14 +167,16 @@ int lsg_copy_reads_to_host(lsg_ctx* c, const lsg_reads* out) {
     if (out->n_reads != c->rd.n_reads || out->n_segs != c->rd.n_segs || out->n_events != c->rd.n_events) {
         set_error("lsg_copy_reads_to_host: shape mismatch"); return -2;
     }
-    if (c->rd.n_events > 0 && !c->rd.events) { set_error("lsg_copy_reads_to_host: the events were not kept beside the store (lsg_set_keep_reads before the load)"); return -2; }
+    const bool want_events = out->events != nullptr || out->seg_ev_off != nullptr;      // (both NULL: the per-read and per-segment arrays only — they are always resident)
+    if (want_events && c->rd.n_events > 0 && !c->rd.events) { set_error("lsg_copy_reads_to_host: the events were not kept beside the store (lsg_set_keep_reads before the load)"); return -2; }
     LSG_HIP(hipSetDevice(c->device));
     hipStream_t st = c->stream;
     const int64_t R = c->rd.n_reads, S = c->rd.n_segs, E = c->rd.n_events;
 #define CP(field, n, sz) if ((n) > 0) LSG_HIP(hipMemcpyAsync((void*)out->field, c->rd.field, (size_t)(n) * (sz), hipMemcpyDeviceToHost, st))
     CP(read_tid, R, 4); if (out->read_pos && c->rd.read_pos) CP(read_pos, R, 4);
     CP(read_flag, R, 2); CP(read_mapq, R, 1); CP(read_cb, R, 4);
-    CP(seg_read, S, 4); CP(seg_start, S, 4); CP(seg_len, S, 4); CP(seg_ev_off, S, 8); CP(events, E, 2);
+    CP(seg_read, S, 4); CP(seg_start, S, 4); CP(seg_len, S, 4);
+    if (want_events) { CP(seg_ev_off, S, 8); CP(events, E, 2); }
 #undef CP
     LSG_HIP(hipStreamSynchronize(st));
     return 0;

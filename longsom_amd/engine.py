@@ -214,11 +214,13 @@ class Engine:
         _lib.check(self._lib.lsg_get_reads_shape(self._h, C.byref(a), C.byref(b), C.byref(c)), "lsg_get_reads_shape")
         return int(a.value), int(b.value), int(c.value)
 
-    def reads_to_host(self) -> ReadRecords:
-        """Copy the resident read-record arrays back to the host (tests, CPU-baseline sampling); needs keep_reads."""
+    def reads_to_host(self, events: bool = True) -> ReadRecords:
+        """Copy the resident read-record arrays back to the host (tests, CPU-baseline sampling); the events need keep_reads.
+        events=False: the per-read and per-segment arrays only (always resident; events and seg_ev_off come back empty / zero)."""
         R, S, E = self.reads_shape()
-        arrs = {n: np.zeros({"read": R, "seg_": S, "even": E}[n[:4]], dt) for n, dt in ReadRecords._SPEC}
-        r = Reads(R, S, E, *[_ptr(arrs[n]) for n, _ in ReadRecords._SPEC], 0)
+        arrs = {n: np.zeros({"read": R, "seg_": S, "even": E if events else 0}[n[:4]], dt) for n, dt in ReadRecords._SPEC}
+        ptrs = [(_ptr(arrs[n]) if events or n not in ("events", "seg_ev_off") else None) for n, _ in ReadRecords._SPEC]
+        r = Reads(R, S, E, *ptrs, 0)
         _lib.check(self._lib.lsg_copy_reads_to_host(self._h, C.byref(r)), "lsg_copy_reads_to_host")
         return ReadRecords(**arrs)
 

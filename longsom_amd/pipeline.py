@@ -349,10 +349,32 @@ def _run_snv_regions(bam, barcodes_tsv, ref_fasta, out_dir, sample_id, params, e
 
     if comm.world > 1:
         t0 = time.time()
-        dec = hostio.decode_bam(bam, bc.barcodes, min_mapq=params.min_mapping_quality, threads=max(1, (os.cpu_count() or 1) // comm.world))
-        bounds = regions.balanced_boundaries(dec.records, len(dec.contig_names), comm.world)
-        lo, hi = bounds[comm.rank], bounds[comm.rank + 1]
-        mine = dec.records.subset(regions.reads_overlapping(dec.records, lo, hi))
+        dec = None
+        if os.environ.get("LONGSOM_INGEST", "auto") in ("device", "auto"):
+            # every rank ingests the file on its OWN GPU (inflate, decode, store: 0.5 s per GB, nothing on the host's threads, which the
+            # ranks used to share); the regions are cut from the resident per-read / per-segment arrays, the same on every rank
+            names_b, lens_b, first_rec = hostio.bam_header(bam)
+            hdr = hostio.DecodedBam(None, names_b, np.asarray(lens_b, np.int64), {})
+            setup(hdr)
+            try:
+                info, cb_pass, cb_low = eng.load_bam(bam, bc.barcodes, min_mapq=params.min_mapping_quality, first_record_offset=first_rec)
+                rep = {"Total_reads": int(info["total_reads"]), "Pass_reads": int(info["pass_reads"]), "CB_not_found": int(info["cb_not_found"]),
+                       "CB_not_matched": int(info["cb_not_matched"])}
+                if info["mapq_filtered"]:
+                    rep["MAPQ"] = int(info["mapq_filtered"])
+                dec = hostio.DecodedBam(None, names_b, np.asarray(lens_b, np.int64), rep, None, cb_pass, cb_low)
+                bounds = regions.balanced_boundaries(eng.reads_to_host(events=False), len(names_b), comm.world)
+                lo, hi = bounds[comm.rank], bounds[comm.rank + 1]
+                mine = None                                   # the rank's store holds the whole file; lsg_set_region makes the columns its own
+            except _lib.LsgError as e:
+                if os.environ.get("LONGSOM_INGEST", "auto") == "device" or "straddle" not in str(e):
+                    raise
+                dec = None
+        if dec is None:
+            dec = hostio.decode_bam(bam, bc.barcodes, min_mapq=params.min_mapping_quality, threads=max(1, (os.cpu_count() or 1) // comm.world))
+            bounds = regions.balanced_boundaries(dec.records, len(dec.contig_names), comm.world)
+            lo, hi = bounds[comm.rank], bounds[comm.rank + 1]
+            mine = dec.records.subset(regions.reads_overlapping(dec.records, lo, hi))
         t["decode"] = time.time() - t0
         work = iter([(lo, hi, mine, dec)])
         report = dict(dec.report)
@@ -377,7 +399,8 @@ def _run_snv_regions(bam, barcodes_tsv, ref_fasta, out_dir, sample_id, params, e
                 report[k] = report.get(k, 0) + v
         n_windows += 1
         t0 = time.time()
-        eng.load_reads(rec)
+        if rec is not None:                                # (None: the device ingest loaded the reads already)
+            eng.load_reads(rec)
         eng.set_region(lo[0], lo[1], hi[0], hi[1])
         t["load"] += time.time() - t0
         t0 = time.time()

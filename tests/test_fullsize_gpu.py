@@ -1,4 +1,4 @@
-"""GPU: BASELINE's C2 workload at its FULL size (10 M reads, 47.5 M count rows) against digests the CPU oracle wrote.
+"""GPU: BASELINE's C2 and C4 workloads at their FULL sizes (10 M and 50 M reads) against digests the CPU oracle wrote.
 
 tools/oracle_hashes.py evaluated the synthetic model on the host region by region (hostio.synth_records == the device generator,
 tests/test_synth_gpu.py), counted every region's columns with oracle/count_oracle.c (lso_count_span_mt) on the build container's cores
@@ -15,14 +15,17 @@ from longsom_amd import synth
 from longsom_amd._lib import CountParams
 
 pytestmark = pytest.mark.gpu
-PIN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rows_hash_oracle_c2_10000000.json")
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def test_c2_full_size_rows_equal_the_cpu_oracle():
+@pytest.mark.parametrize("cfg,n_reads", [("C2", 10_000_000), ("C4", 50_000_000)])
+def test_full_size_rows_equal_the_cpu_oracle(cfg, n_reads):
+    """C2: 10 M reads x 5 k barcodes, 47.5 M rows.  C4: 50 M reads x 20 k barcodes, 48.0 M rows out of 4.6e10 events (71 min of the
+    build container's CPU for the oracle; 124 GB of store on the device)."""
     from longsom_amd.engine import Engine
-    want = json.load(open(PIN))
-    m = synth.named("C2")
-    assert m.n_reads == want["n_reads"] == 10_000_000
+    want = json.load(open(os.path.join(G, "rows_hash_oracle_%s_%d.json" % (cfg.lower(), n_reads))))
+    m = synth.named(cfg)
+    assert m.n_reads == want["n_reads"] == n_reads
     p = CountParams.longsom_defaults()
     with Engine(0) as eng:
         eng.set_contigs(m.contig_len); eng.synth_reference(m.seed); eng.set_barcodes(m.celltype_of, 2)
@@ -34,4 +37,4 @@ def test_c2_full_size_rows_equal_the_cpu_oracle():
             k, r, c = eng.fetch_counts(ct)
             got = [xxhash.xxh64(np.ascontiguousarray(x).tobytes()).hexdigest() for x in (k, r, c)]
             del k, r, c
-            assert got == want["ct%d" % ct], "cell type %d: rows of the full C2 workload differ from the CPU oracle's" % ct
+            assert got == want["ct%d" % ct], "cell type %d: rows of the full %s workload differ from the CPU oracle's" % (ct, cfg)
