@@ -44,7 +44,8 @@ struct DevBuf {
     int reserve(size_t bytes) {
         if (bytes <= cap) return 0;
         if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
-        size_t want = bytes + bytes / 16 + 256;
+        const size_t slack = bytes / 16 < ((size_t)64 << 20) ? bytes / 16 : ((size_t)64 << 20);      // (a 124 GB buffer must not ask for 8 more)
+        size_t want = bytes + slack + 256;
         LSG_HIP(hipMalloc(&p, want));
         cap = want;
         return 0;
