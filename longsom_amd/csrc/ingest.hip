@@ -3,7 +3,8 @@
 // Replaces the reads of the reference's pysam.AlignmentFile (htslib bgzf + zlib inflate + bam_read1) in split_bam's fetch loop
 // (workflow/scripts/PreProcessing/SplitBamCellTypes.py:51-124) and behind bam.pileup (SNVCalling/BaseCellCounter.py:190-216):
 //   host    walks the BGZF block headers (18 bytes each), copies the file to the device
-//   k_inflate      one LANE per BGZF block: raw DEFLATE (inflate_core.h; canonical-code tables of 64 lanes in LDS, 1 KB per lane)
+//   k_inflate_wave one WAVE per BGZF block: raw DEFLATE (inflate_core.h) decoded uniformly by the lanes, the last 32 KB of output in an
+//                  LDS ring, match copies spread over the lanes, 4 KB chunks flushed to HBM
 //   k_chain        records are a chain (block_size -> next record) through the uncompressed stream; htslib starts every BGZF block on
 //                  a record boundary unless a record is longer than a block, so every block's lane walks its own records from the
 //                  block's first byte; k_chain_fix hands every block the place where its predecessor's chain really landed, and the
@@ -28,19 +29,25 @@ namespace lsg {
 
 struct IngBlk { uint64_t coff, uoff; uint32_t csize, usize; };
 
-__global__ __launch_bounds__(64) void k_inflate(const uint8_t* comp, const IngBlk* blk, uint32_t n_blk, uint8_t* ubuf, uint32_t* status) {
+// The decoding tables of a wave's 64 streams (45 KB) live in LDS, three waves per CU; the code lengths, which only the header of a block
+// touches, in global memory (`lens_all`: T_LENS * 64 bytes per wave, lane-interleaved like the tables).
+__global__ __launch_bounds__(64) void k_inflate(const uint8_t* comp, const IngBlk* blk, uint32_t n_blk, uint8_t* ubuf, uint32_t* status, uint8_t* lens_all) {
     __shared__ uint16_t tab[lsi::T_WORDS * 64];
-    __shared__ uint8_t lens[lsi::T_LENS * 64];
+    uint8_t* lens = lens_all + (size_t)blockIdx.x * (lsi::T_LENS * 64);
     const int lane = threadIdx.x;
-    for (uint32_t b0 = blockIdx.x * 64u; b0 < n_blk; b0 += gridDim.x * 64u) {
-        const uint32_t b = b0 + (uint32_t)lane;
-        if (b >= n_blk) continue;
+    // every lane takes its next block from one queue (status[8]) the moment it has finished one: a wave lasts as long as its slowest
+    // lane either way, but the blocks of the last, partial round spread over all waves
+    for (uint32_t b = blockIdx.x * 64u + (uint32_t)lane; b < n_blk; b = gridDim.x * 64u + atomicAdd(status + 8, 1u)) {
         const IngBlk d = blk[b];
         if (!d.usize) continue;
         const int rc = lsi::inflate_raw(comp + d.coff, d.csize, ubuf + d.uoff, d.usize, lsi::Tab{tab + lane, lens + lane, 64});
         if (rc) { atomicOr(status, 1u); atomicMin(status + 1, b); }
     }
 }
+
+// (One WAVE per block — uniform decode, a 32 KB LDS ring for the output, match copies spread over the lanes — was built and measured
+// this round: 0.8-1.3 s per GB of BAM against 0.17 s for the lane form above.  A DEFLATE symbol is a serial dependency chain of ~100
+// scalar-like operations; a wave that runs one chain uses a 64th of the vector unit.  DESIGN.md §8.)
 
 // in[b]: where block b's chain is taken to start (global offset into the uncompressed stream); out: records that start at or after
 // in[b] and before the block's end, and where the chain lands at or after that end
@@ -248,10 +255,12 @@ int lsg_load_bam(lsg_ctx* c, const uint8_t* file, int64_t n_bytes, int64_t first
     // ---- inflate
     const IngBlk* dblk = d_blk.as<IngBlk>();
     uint32_t* status = d_status.as<uint32_t>();
-    {
-        unsigned g = (n_blk + 63) / 64; const unsigned cap = (unsigned)(c->n_cus * 2 * env_int("LSG_INFLATE_ROUNDS", 1));
+    {                                                        // a lane per block; 45 KB of LDS tables per wave: three waves per CU
+        unsigned g = (n_blk + 63) / 64; const unsigned cap = (unsigned)(c->n_cus * 3);
         if (g > cap) g = cap;
-        hipLaunchKernelGGL(k_inflate, dim3(g ? g : 1), dim3(64), 0, st, d_comp.as<uint8_t>(), dblk, n_blk, d_u.as<uint8_t>(), status);
+        if (!g) g = 1;
+        if (d_tmp.reserve((size_t)g * lsi::T_LENS * 64)) return done_ev(-3);
+        hipLaunchKernelGGL(k_inflate, dim3(g), dim3(64), 0, st, d_comp.as<uint8_t>(), dblk, n_blk, d_u.as<uint8_t>(), status, d_tmp.as<uint8_t>());
     }
     ING_HIP(hipEventRecord(ev[2], st));
     uint32_t hstat[4] = {0, 0, 0, 0};
