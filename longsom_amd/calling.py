@@ -104,6 +104,84 @@ def open_gnomad(source: Optional[str], allow_missing: Optional[bool] = None):
         return None
 
 
+def _blank_na_fields(line: bytes) -> bytes:
+    f = line.split(b"\t")
+    return b"\t".join([f[0]] + [b"" if x == b"NA" else x for x in f[1:]])
+
+
+def _step2_scanned(text: bytes, engine, contig_names, editing_keys, pon_sr_keys, pon_lr_keys, distance: int) -> Optional[bytes]:
+    """step2 without a gnomAD source, over the row scanner (csrc/hostio/tsvscan.cpp): the keys of the probes come from the scan, the
+    rows that get no tag (all but a handful) are moved as bytes, never split.  None = a table the scanner does not vouch for (short
+    rows, a Start that is not a plain number, comment lines among the rows, unknown contigs with a distance filter): the caller then
+    takes the row-by-row path below, which is also what tests compare this one with."""
+    from . import tsvio
+    if not text.endswith(b"\n"):
+        text = text + b"\n"
+    sc = tsvio.scan_rows(text, contig_names)
+    if sc.n_rows and (sc.flags & (tsvio.SCAN_SHORT | tsvio.SCAN_BAD_POS)).any():
+        return None
+    head = text[:int(sc.off[0])] if sc.n_rows else text
+    head_lines = [l for l in head.split(b"\n") if l]
+    if len(head_lines) != sc.n_comment_lines or any(not l.startswith(b"#") for l in head_lines):
+        return None
+    comments = [l for l in head_lines if b"#CHROM" not in l]
+    headers = [l for l in head_lines if b"#CHROM" in l]
+    if not headers:
+        return None
+    kept = np.nonzero((sc.flags & (tsvio.SCAN_ALT_DOT | tsvio.SCAN_FILTER_DOT)) == 0)[0]         # awk filter, step2.py:23
+    n = len(kept)
+    q = np.ascontiguousarray(sc.key[kept])
+    if distance > 0 and n and (sc.flags[kept] & tsvio.SCAN_UNKNOWN_CHROM).any():
+        return None
+    hits = []
+    for kind, keys in ((KIND_EDITING, editing_keys), (KIND_PON_SR, pon_sr_keys), (KIND_PON_LR, pon_lr_keys)):
+        engine.load_posset(kind, keys)
+        hits.append(np.asarray(engine.probe_posset(kind, q) if len(keys) and n else np.zeros(n, np.uint8)).astype(bool))
+    close = np.zeros(n, np.int64)
+    if distance > 0 and n > 1:
+        tid, pos = q >> 32, q & 0xFFFFFFFF
+
+        def near(i, j):                                  # step2.py:59-92: same contig, another position, within `distance`
+            return ((tid[i] == tid[j]) & (pos[i] != pos[j]) & (np.abs(pos[i] - pos[j]) <= distance)).astype(np.int64)
+        if n < 3:
+            close[0] += near(np.array([0]), np.array([1]))[0]; close[1] += near(np.array([1]), np.array([0]))[0]
+        else:
+            i = np.arange(n)
+            close[1:] += near(i[1:], i[1:] - 1)
+            close[:-1] += near(i[:-1], i[:-1] + 1)
+            close[0] += near(np.array([0]), np.array([2]))[0]                                      # the first row's window is rows 0..2
+    tagged = np.nonzero(hits[0] | hits[1] | hits[2] | (close > 0))[0]
+    body, new_off = tsvio.gather_lines(text, sc.off[kept], sc.len[kept], blank_na=True)
+    if len(tagged):
+        pieces, at = [], 0
+        for i in tagged.tolist():
+            r = int(kept[i])
+            line = text[int(sc.off[r]):int(sc.off[r]) + int(sc.len[r])]
+            fo, fl = int(sc.filt_off[r]), int(sc.filt_len[r])
+            F = line[fo:fo + fl]
+            for on, t in ((hits[0][i], b"RNA_editing_db"), (close[i] > 0, b"Clustered"), (hits[1][i], b"PoN_SR"), (hits[2][i], b"PoN_LR")):
+                if on:
+                    F = t if F == b"PASS" else F + b"," + t
+            pieces.append(body[at:int(new_off[i])])
+            pieces.append(_blank_na_fields(line[:fo] + F + line[fo + fl:]) + b"\n")
+            at = int(new_off[i + 1])
+        pieces.append(body[at:])
+        body = b"".join(pieces)
+    return b"\n".join(comments + [headers[-1]]) + b"\n" + body
+
+
+def step2_bytes(step1_text: bytes, engine, contig_names: Sequence[str], editing_keys, pon_sr_keys, pon_lr_keys, distance: int = 0,
+                gnomad_af: Optional[Dict[str, float]] = None, gnomad_max: float = 0.01) -> bytes:
+    """step2 on the bytes of the table (what the fused pipeline and the CLI hold): the scanned path when there is no gnomAD source
+    (LONGSOM_STEP2_ROW_PATH=1 forces the row-by-row one), else step2() below."""
+    have_af = isinstance(gnomad_af, GnomadSqlite) or bool(gnomad_af)
+    if not have_af and os.environ.get("LONGSOM_STEP2_ROW_PATH", "0") != "1":
+        out = _step2_scanned(step1_text, engine, contig_names, editing_keys, pon_sr_keys, pon_lr_keys, distance)
+        if out is not None:
+            return out
+    return step2(step1_text.decode(), engine, contig_names, editing_keys, pon_sr_keys, pon_lr_keys, distance, gnomad_af, gnomad_max).encode()
+
+
 def step2(step1_text: str, engine, contig_names: Sequence[str], editing_keys, pon_sr_keys, pon_lr_keys, distance: int = 0,
           gnomad_af: Optional[Dict[str, float]] = None, gnomad_max: float = 0.01) -> str:
     """Returns the text of <prefix>.calling.step2.tsv.  gnomad_af: {"chrom:pos:ref:alt": AF}; the gnomAD
@@ -289,38 +367,72 @@ def _records(df, cols):
     return [dict(zip(cols, vals)) for vals in zip(*arrays)]
 
 
-def step3(step2_text: str, delta_vaf: float, delta_mcf: float, min_ac_reads: int, min_ac_cells: int, clust_dist: int):
-    """Returns (text of .calling.step3.tsv, text of .calling.step3.unfiltered.tsv)."""
+_DEAD_M = "Min|LR|gnomAD|LC|RNA"                       # step3.py:49-52, chrM rows
+_DEAD_O = "Min_cell_types|Noisy_site|LC_Upstream|LC_Downstream|RNA_editing_db|PoN|Cell_type_noise|gnomAD"      # step3.py:60-84, the others
+
+
+def _step3_survivors(text: bytes, i_ct: int) -> Optional[bytes]:
+    """the rows of a step-2 table that step 3's FILTER patterns and its Cell_types test let through, found by the row scanner
+    (csrc/hostio/tsvscan.cpp); None = rows the scanner does not vouch for (the caller then splits the lines itself)"""
+    from . import tsvio
+    if not 5 <= i_ct <= 7:
+        return None
+    if not text.endswith(b"\n"):
+        text = text + b"\n"
+    sc = tsvio.scan_rows(text, ["chrM"], _DEAD_M, _DEAD_O, i_ct, "Non-Cancer")
+    fl = sc.flags
+    is_m = (fl & tsvio.SCAN_UNKNOWN_CHROM) == 0
+    dead = np.where(is_m, fl & tsvio.SCAN_PAT_A, fl & tsvio.SCAN_PAT_B) != 0
+    keep = np.nonzero(((fl & (tsvio.SCAN_SHORT | tsvio.SCAN_CT_MATCH)) == 0) & ~dead)[0]
+    return tsvio.gather_lines(text, sc.off[keep], sc.len[keep])[0]
+
+
+def step3(step2_text, delta_vaf: float, delta_mcf: float, min_ac_reads: int, min_ac_cells: int, clust_dist: int):
+    """Returns (text of .calling.step3.tsv, text of .calling.step3.unfiltered.tsv).  step2_text: str or bytes."""
+    as_bytes = isinstance(step2_text, (bytes, bytearray, memoryview))
     comments, cols = [], None
-    for line in step2_text.split("\n"):
-        if not line.startswith("#"):
+    at = 0
+    nl, hash_, tag = (b"\n", b"#", b"#CHROM") if as_bytes else ("\n", "#", "#CHROM")
+    while at < len(step2_text):                           # the comment lines at the top of the table
+        e = step2_text.find(nl, at)
+        e = len(step2_text) if e < 0 else e
+        line = step2_text[at:e]
+        if not line.startswith(hash_):
             break
+        line = line.decode() if as_bytes else line
         if "#CHROM" in line:
             cols = line.split("\t")
         else:
             comments.append(line + "\n")
+        at = e + 1
     head = "".join(comments) + FINAL_FILTER_LINE
     # Only the rows that survive step 3's FILTER patterns (below) are parsed: a numeric field of this table is the shortest repr of
     # its value (Python's str() in step 1, pandas' in the reference's step 2), which pandas prints back unchanged whatever dtype the
     # column got, and "NA" / empty fields print as "" either way, so the dtypes pandas would infer from the dropped rows do not reach
     # the output.  LONGSOM_STEP3_FULL_PARSE=1 parses every row like the reference does (tests compare the two).
     if os.environ.get("LONGSOM_STEP3_FULL_PARSE", "0") != "1":
-        dead_m, dead_o = re.compile("Min|LR|gnomAD|LC|RNA"), re.compile("Min_cell_types|Noisy_site|LC_Upstream|LC_Downstream|RNA_editing_db|PoN|Cell_type_noise|gnomAD")
         i_ct = cols.index("Cell_types") if cols and "Cell_types" in cols else 6
-        keep_lines = []
-        for line in step2_text.split("\n"):
-            if not line or line.startswith("#"):
-                continue
-            el = line.split("\t", i_ct + 1)
-            if len(el) <= i_ct or el[i_ct] == "Non-Cancer":
-                continue
-            if (dead_m if el[0] == "chrM" else dead_o).search(el[5]) is None:
-                keep_lines.append(line)
-        if not keep_lines:
+        survivors = None
+        if os.environ.get("LONGSOM_STEP3_ROW_PATH", "0") != "1":
+            survivors = _step3_survivors(step2_text if as_bytes else step2_text.encode(), i_ct)
+        if survivors is None:
+            dead_m, dead_o = re.compile(_DEAD_M), re.compile(_DEAD_O)
+            keep_lines = []
+            for line in (step2_text.decode() if as_bytes else step2_text).split("\n"):
+                if not line or line.startswith("#"):
+                    continue
+                el = line.split("\t", i_ct + 1)
+                if len(el) <= i_ct or el[i_ct] == "Non-Cancer":
+                    continue
+                if (dead_m if el[0] == "chrM" else dead_o).search(el[5]) is None:
+                    keep_lines.append(line)
+            survivors = ("\n".join(keep_lines) + "\n").encode() if keep_lines else b""
+        if not survivors:
             empty = head + "\t".join(cols + ["STEP3FILTER", "INDEX"]) + "\n"
             return empty, empty
-        step2_text = "\n".join(keep_lines) + "\n"
-    df = pd.read_csv(io.StringIO(step2_text), sep="\t", comment="#", names=cols)
+        step2_text = survivors
+        as_bytes = True
+    df = pd.read_csv(io.BytesIO(step2_text) if as_bytes else io.StringIO(step2_text), sep="\t", comment="#", names=cols)
     df = df[df["Cell_types"] != "Non-Cancer"]
     out_cols = cols + ["STEP3FILTER", "INDEX"]
     if len(df) == 0:

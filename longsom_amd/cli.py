@@ -120,13 +120,13 @@ def calling_step2(argv=None):
     ap.add_argument("--reference-gz-compat", action="store_true"); ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--allow_missing_gnomad", action="store_true", help="run without the gnomAD filter when --gnomAD_db cannot be read (default: stop, as the reference does)")
     a = ap.parse_args(argv)
-    text = open(a.infile).read()
+    text = open(a.infile, "rb").read()
     contigs = tsvio.contigs_of_tsv([a.infile])
     af = calling.open_gnomad(a.gnomAD_db, a.allow_missing_gnomad or None)               # JSON table, gnomad_db directory / sqlite
     keys = [calling.read_posset_keys(p, contigs, a.reference_gz_compat) for p in (a.editing, a.pon_SR, a.pon_LR)]
     with Engine(a.device) as eng:
-        out = calling.step2(text, eng, contigs, keys[0], keys[1], keys[2], a.min_distance, af, a.gnomAD_max)
-    with open(a.outfile + ".calling.step2.tsv", "w") as f:
+        out = calling.step2_bytes(text, eng, contigs, keys[0], keys[1], keys[2], a.min_distance, af, a.gnomAD_max)
+    with open(a.outfile + ".calling.step2.tsv", "wb") as f:
         f.write(out)
 
 
@@ -138,7 +138,7 @@ def calling_step3(argv=None):
     ap.add_argument("--chrM_contaminant", default="True"); ap.add_argument("--min_ac_reads", type=int, default=2)
     ap.add_argument("--min_ac_cells", type=int, default=3); ap.add_argument("--clust_dist", type=int, default=5)
     a = ap.parse_args(argv)
-    final, unfiltered = calling.step3(open(a.infile).read(), a.deltaVAF, a.deltaMCF, a.min_ac_reads, a.min_ac_cells, a.clust_dist)
+    final, unfiltered = calling.step3(open(a.infile, "rb").read(), a.deltaVAF, a.deltaMCF, a.min_ac_reads, a.min_ac_cells, a.clust_dist)
     open(a.outfile + ".calling.step3.tsv", "w").write(final)
     open(a.outfile + ".calling.step3.unfiltered.tsv", "w").write(unfiltered)
 

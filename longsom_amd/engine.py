@@ -243,7 +243,7 @@ class Engine:
     def fetch_counts(self, ct: int):
         """Rows of one cell type in genomic order: keys int64 (tid<<32|pos0), ref uint8, counts uint32 [n,42]."""
         n = self._n_rows[ct]
-        keys = np.zeros(n, np.int64); ref = np.zeros(n, np.uint8); counts = np.zeros((n, ROW_WORDS), np.uint32)
+        keys = np.empty(n, np.int64); ref = np.empty(n, np.uint8); counts = np.empty((n, ROW_WORDS), np.uint32)
         if n:
             _lib.check(self._lib.lsg_fetch_counts(self._h, ct, _ptr(keys), _ptr(ref), _ptr(counts), n), "lsg_fetch_counts")
         return keys, ref, counts
@@ -305,11 +305,10 @@ class Engine:
 
     def fetch_calls(self, candidates_only: bool = False):
         cap = self._n_sites
-        arr = (_lib.Call * max(cap, 1))()
+        arr = np.empty(max(cap, 1), np.dtype(_lib.Call))
         n_out = C.c_int64(0)
-        _lib.check(self._lib.lsg_fetch_calls(self._h, arr, cap, 1 if candidates_only else 0, C.byref(n_out)), "lsg_fetch_calls")
-        dt = np.dtype(_lib.Call)
-        return np.frombuffer(arr, dtype=dt, count=int(n_out.value)).copy()
+        _lib.check(self._lib.lsg_fetch_calls(self._h, C.c_void_p(arr.ctypes.data), cap, 1 if candidates_only else 0, C.byref(n_out)), "lsg_fetch_calls")
+        return arr[:int(n_out.value)]
 
     def export_calls(self, kind: int, dst_device_ptr: int = 0, capacity: int = 0) -> int:
         """Compact call records into a caller-owned device buffer (kind: 0 all, 1 step-2 rows, 2 PASS

@@ -205,7 +205,7 @@ def chain_step1(res: Resident, celltype_of: np.ndarray, celltype_names: List[str
     out.merged = os.path.join(d["MergeCounts"], sample_id + ".BaseCellCounts.AllCellTypes.tsv")
     header = tsvio.write_merged_tsv(out.merged, per_ct, contig_names, celltype_names, date)
     out.step1 = os.path.join(d["BaseCellCalling"], sample_id + ".calling.step1.tsv")
-    s1 = tsvio.write_step1_tsv(out.step1, calls, per_ct, contig_names, celltype_names, header)      # s1 = header + the rows step 2 keeps
+    s1 = tsvio.write_step1_tsv(out.step1, calls, per_ct, contig_names, celltype_names, header, as_bytes=True)      # s1 = header + the rows step 2 keeps
     t["write_tables"] = time.time() - t0
     return out, s1, calls, t
 
@@ -222,9 +222,9 @@ def run_chain(res: Resident, celltype_of: np.ndarray, celltype_names: List[str],
     t0 = time.time()
     keys = [calling.read_posset_keys(p, contig_names, params.reference_gz_compat) for p in (editing, pon_sr, pon_lr)]
     af = calling.open_gnomad(gnomad_af_json)              # a JSON table or a gnomad_db directory / sqlite file
-    s2 = calling.step2(s1, eng, contig_names, keys[0], keys[1], keys[2], params.min_distance, af, params.max_gnomad_vaf)
+    s2 = calling.step2_bytes(s1, eng, contig_names, keys[0], keys[1], keys[2], params.min_distance, af, params.max_gnomad_vaf)
     out.step2 = os.path.join(d["BaseCellCalling"], sample_id + ".calling.step2.tsv")
-    open(out.step2, "w").write(s2)
+    open(out.step2, "wb").write(s2)
     t["step2"] = time.time() - t0
     if not step3:
         out.timings = t
@@ -453,10 +453,10 @@ def _run_snv_regions(bam, barcodes_tsv, ref_fasta, out_dir, sample_id, params, e
         regions.concatenate_pieces(tmp, "step1", s1h, out.step1)
         t["concatenate"] = time.time() - t0
         t0 = time.time()
-        s1 = s1h + regions.unpack_rows(payloads)
+        s1 = (s1h + regions.unpack_rows(payloads)).encode()
         keys = [calling.read_posset_keys(p, names, params.reference_gz_compat) for p in (editing, pon_sr, pon_lr)]
-        s2 = calling.step2(s1, eng, names, keys[0], keys[1], keys[2], params.min_distance, calling.open_gnomad(gnomad_af_json), params.max_gnomad_vaf)
-        open(out.step2, "w").write(s2)
+        s2 = calling.step2_bytes(s1, eng, names, keys[0], keys[1], keys[2], params.min_distance, calling.open_gnomad(gnomad_af_json), params.max_gnomad_vaf)
+        open(out.step2, "wb").write(s2)
         t["step2"] = time.time() - t0
         t0 = time.time()
         final, unfiltered = calling.step3(s2, params.delta_vaf, params.delta_mcf, params.min_ac_reads, params.min_ac_cells, params.clust_dist)

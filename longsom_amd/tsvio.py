@@ -161,8 +161,67 @@ def _io():
         lib.lsio_write_step1_rows.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.c_int32, C.c_char_p, C.c_void_p, C.c_int64, PP, PP, C.c_void_p, C.c_int32,
                                               C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
         lib.lsio_free_text.argtypes = [C.c_void_p]
+        lib.lsio_scan_last_error.restype = C.c_char_p
+        lib.lsio_scan_rows.restype = C.c_int
+        lib.lsio_scan_rows.argtypes = [C.c_char_p, C.c_int64, C.c_char_p, C.c_int32, C.c_char_p, C.c_char_p, C.c_int32, C.c_char_p, C.c_int32, C.c_void_p]
+        lib.lsio_free_row_scan.argtypes = [C.c_void_p]
+        lib.lsio_gather_lines.restype = C.c_int
+        lib.lsio_gather_lines.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_void_p]
         lib._tsv_ready = True
     return lib
+
+
+SCAN_ALT_DOT, SCAN_FILTER_DOT, SCAN_PAT_A, SCAN_PAT_B, SCAN_CT_MATCH, SCAN_SHORT, SCAN_BAD_POS, SCAN_UNKNOWN_CHROM = 1, 2, 4, 8, 16, 32, 64, 128
+
+
+class RowScan:
+    """what lsio_scan_rows (csrc/hostio/tsvscan.cpp) found in every row of a step-1 / step-2 table: off / len of the line in the text,
+    key = tid << 32 | Start, the FILTER field's place inside the line, flags (SCAN_*); n_comment_lines = lines starting with '#'."""
+    __slots__ = ("n_rows", "n_comment_lines", "off", "len", "key", "filt_off", "filt_len", "flags")
+
+
+def scan_rows(text: bytes, contig_names, patterns_a: str = "", patterns_b: str = "", ct_col: int = -1, ct_value: str = "", threads: int = 0) -> RowScan:
+    import ctypes as C
+
+    class _S(C.Structure):
+        _fields_ = [("n_rows", C.c_int64), ("n_comment_lines", C.c_int64), ("off", C.c_void_p), ("key", C.c_void_p), ("len", C.c_void_p),
+                    ("filt_off", C.c_void_p), ("filt_len", C.c_void_p), ("flags", C.c_void_p)]
+    lib = _io()
+    st = _S()
+    rc = lib.lsio_scan_rows(text, len(text), "\n".join(contig_names).encode(), len(contig_names), patterns_a.encode(), patterns_b.encode(), ct_col,
+                            ct_value.encode() if ct_col >= 0 else None, threads, C.byref(st))
+    if rc != 0:
+        raise RuntimeError("lsio_scan_rows: %s" % lib.lsio_scan_last_error().decode("utf-8", "replace"))
+    try:
+        r = RowScan()
+        n = r.n_rows = int(st.n_rows)
+        r.n_comment_lines = int(st.n_comment_lines)
+        for name, dt in (("off", np.int64), ("key", np.int64), ("len", np.int32), ("filt_off", np.int32), ("filt_len", np.int32), ("flags", np.uint32)):
+            a = np.empty(n, dt)
+            if n:
+                C.memmove(a.ctypes.data, getattr(st, name), n * a.itemsize)
+            setattr(r, name, a)
+        return r
+    finally:
+        lib.lsio_free_row_scan(C.byref(st))
+
+
+def gather_lines(text: bytes, off: np.ndarray, length: np.ndarray, blank_na: bool = False, threads: int = 0):
+    """(the lines text[off[i] : off[i] + length[i]] + b"\\n", concatenated; start of every line in the result, n + 1 entries).
+    blank_na: fields other than a line's first that are exactly "NA" come out empty (lsio_gather_lines)."""
+    import ctypes as C
+    lib = _io()
+    off = np.ascontiguousarray(off, np.int64); length = np.ascontiguousarray(length, np.int32)
+    n = len(off)
+    new_off = np.zeros(n + 1, np.int64)
+    txt = C.c_void_p(); ln = C.c_int64(0)
+    rc = lib.lsio_gather_lines(text, off.ctypes.data, length.ctypes.data, n, 1 if blank_na else 0, threads, C.byref(txt), C.byref(ln), new_off.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("lsio_gather_lines: %s" % lib.lsio_scan_last_error().decode("utf-8", "replace"))
+    try:
+        return (C.string_at(txt.value, ln.value) if ln.value else b""), new_off
+    finally:
+        lib.lsio_free_text(txt)
 
 
 def _check(lib, rc, what):
@@ -216,10 +275,11 @@ def write_merged_tsv(path, per_ct, contig_names, celltype_names, date_line=None,
     return [l + "\n" for l in "".join(head).split("\n") if l.startswith("##")]
 
 
-def write_step1_tsv(path, calls, per_ct, contig_names, celltype_names, header_lines: List[str], threads: int = 0, header: bool = True) -> str:
+def write_step1_tsv(path, calls, per_ct, contig_names, celltype_names, header_lines: List[str], threads: int = 0, header: bool = True,
+                    as_bytes: bool = False):
     """format_step1_tsv straight to `path`.  Returns the SMALL text step 2 needs: the comment lines, the column header and the
     rows its awk filter keeps (ALT != "." and FILTER != ".", BaseCellCalling.step2.py:23); header=False: the file gets the rows only
-    and the kept rows come back without the header."""
+    and the kept rows come back without the header; as_bytes: as bytes (what calling.step2_bytes takes), not str."""
     import ctypes as C
     lib = _io()
     head = step1_header(header_lines, celltype_names) if header else ""
@@ -231,10 +291,10 @@ def write_step1_tsv(path, calls, per_ct, contig_names, celltype_names, header_li
     _check(lib, lib.lsio_write_step1_rows(os.fsencode(path), "\n".join(contig_names).encode(), len(contig_names), len(per_ct), "\n".join(celltype_names).encode(),
                                           calls.ctypes.data, len(calls), pk, pc, n.ctypes.data, threads, C.byref(txt), C.byref(ln)), "lsio_write_step1_rows")
     try:
-        rows = C.string_at(txt.value, ln.value).decode() if ln.value else ""
+        rows = C.string_at(txt.value, ln.value) if ln.value else b""
     finally:
         lib.lsio_free_text(txt)
-    return head + rows
+    return head.encode() + rows if as_bytes else head + rows.decode()
 
 
 def _p(k: int) -> str:
@@ -358,11 +418,18 @@ def contigs_of_tsv(paths) -> List[str]:
 
 def read_fasta(path):
     """Whole FASTA -> (names, list of upper-cased uint8 arrays).  inFasta.fetch(...).upper(), BaseCellCounter.py:202-203."""
-    names, seqs, cur = [], [], None
     with open(path, "rb") as f:
-        for line in f:
-            if line.startswith(b">"):
-                names.append(line[1:].split()[0].decode()); cur = []; seqs.append(cur)
-            elif cur is not None:
-                cur.append(line.strip())
-    return names, [np.frombuffer(b"".join(s).upper(), dtype=np.uint8).copy() for s in seqs]
+        data = f.read()
+    names, seqs = [], []
+    at = 0 if data.startswith(b">") else data.find(b"\n>") + 1          # (0 when there is no record at all: the loop below then ends at once)
+    if not data.startswith(b">") and at == 0:
+        return names, seqs
+    while at < len(data):                                               # data[at] == '>'
+        e = data.find(b"\n", at)
+        e = len(data) if e < 0 else e
+        names.append(data[at + 1:e].split()[0].decode())
+        nxt = data.find(b"\n>", e)
+        nxt = len(data) if nxt < 0 else nxt + 1
+        seqs.append(np.frombuffer(data[e + 1:nxt].translate(None, b" \t\r\n\v\f").upper(), dtype=np.uint8).copy())
+        at = nxt
+    return names, seqs

@@ -67,6 +67,40 @@ def test_step2_host_half_matches_reference_golden():
     assert calling.step2(s1, _NumpyProbe(), names, ed, sr, lr, 0, None, 0.01) == calling.step2(s1, _NumpyProbe(), names, ed, sr, lr, 0, _Empty(), 0.01)
 
 
+def test_step2_scanned_path_equals_row_path(monkeypatch):
+    """step2_bytes without a gnomAD source goes over the native row scanner (csrc/hostio/tsvscan.cpp) and moves untagged rows as bytes;
+    the row-by-row path (pinned to the reference's files above) must give the same table: goldens, both distances, a table with
+    dropped rows / blank lines / no trailing newline, a replicated 40 k-row table, and the cases the scanner hands back"""
+    names, _ = tsvio.read_fasta(os.path.join(G, "calling.ref.fa"))
+    ed, sr, lr = (calling.read_posset_keys(os.path.join(G, "calling.%s.tsv" % k), names) for k in ("editing", "pon_SR", "pon_LR"))
+    s1 = rd("sample.calling.step1.tsv")
+    lines = s1.split("\n")
+    comments = [l for l in lines if l.startswith("#")]
+    body = [l for l in lines if l and not l.startswith("#")]
+    big, k = [], 0
+    while len(big) < 40000:
+        for l in body:
+            f = l.split("\t"); f[1] = str(int(f[1]) + 7 * k); f[2] = f[1]; big.append("\t".join(f))
+        k += 1
+    texts = [s1, s1.rstrip("\n"), "\n".join(comments + body[:3]) + "\n\n" + "\n".join(body[3:]) + "\n", "\n".join(comments + big) + "\n",
+             "\n".join(comments) + "\n", "\n".join(comments + body[:1]) + "\n", "\n".join(comments + body[:2]) + "\n"]
+    for t in texts:
+        for dist in (0, 150, 5):
+            for sets in ((ed, sr, lr), (ed, sr, calling.read_posset_keys("", names))):
+                monkeypatch.setenv("LONGSOM_STEP2_ROW_PATH", "1")
+                want = calling.step2_bytes(t.encode(), _NumpyProbe(), names, *sets, dist)
+                assert want.decode() == calling.step2(t, _NumpyProbe(), names, *sets, dist)
+                monkeypatch.setenv("LONGSOM_STEP2_ROW_PATH", "0")
+                assert calling._step2_scanned(t.encode(), _NumpyProbe(), names, *sets, dist) is not None
+                assert calling.step2_bytes(t.encode(), _NumpyProbe(), names, *sets, dist) == want
+    # handed back: a Start that is not a plain number, a comment line among the rows
+    bad = "\n".join(comments + [body[0].replace("\t" + body[0].split("\t")[1] + "\t", "\t+5\t", 1)] + body[1:]) + "\n"
+    assert calling._step2_scanned(bad.encode(), _NumpyProbe(), names, ed, sr, lr, 0) is None
+    late = "\n".join(comments + body[:2] + ["#late"] + body[2:]) + "\n"
+    assert calling._step2_scanned(late.encode(), _NumpyProbe(), names, ed, sr, lr, 0) is None
+    assert calling.step2_bytes(late.encode(), _NumpyProbe(), names, ed, sr, lr, 0).decode() == calling.step2(late, _NumpyProbe(), names, ed, sr, lr, 0)
+
+
 def test_step3_prefilter_equals_full_parse(monkeypatch):
     """step 3 parses only the rows its FILTER patterns let through; LONGSOM_STEP3_FULL_PARSE=1 parses every row like the reference:
     same files, on the goldens and on a 60 k-row table replicated from them (mixed single- and two-cell-type rows in every chunk)"""
@@ -85,4 +119,8 @@ def test_step3_prefilter_equals_full_parse(monkeypatch):
         monkeypatch.setenv("LONGSOM_STEP3_FULL_PARSE", "1")
         want = calling.step3(t, 0.05, 0.3, 3, 2, 10000)
         monkeypatch.setenv("LONGSOM_STEP3_FULL_PARSE", "0")
-        assert calling.step3(t, 0.05, 0.3, 3, 2, 10000) == want
+        assert calling.step3(t, 0.05, 0.3, 3, 2, 10000) == want                    # the native row scanner picks the survivors
+        assert calling.step3(t.encode(), 0.05, 0.3, 3, 2, 10000) == want
+        monkeypatch.setenv("LONGSOM_STEP3_ROW_PATH", "1")
+        assert calling.step3(t, 0.05, 0.3, 3, 2, 10000) == want                    # the Python line loop does
+        monkeypatch.setenv("LONGSOM_STEP3_ROW_PATH", "0")
