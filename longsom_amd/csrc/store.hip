@@ -304,7 +304,11 @@ __global__ __launch_bounds__(TMG_WAVES * 64) void k_tm_gather(const uint16_t* ev
     // Workgroups are dealt to the 8 XCDs round-robin, each with its own L2.  An entry's <= 128 source bytes sit at a 2-byte alignment,
     // so the 128-byte line they end in is also the line the SAME read's entry of the NEXT tile starts in: give every XCD one contiguous
     // eighth of the blocks, so that neighbouring tiles pass through one L2 shortly after one another (measured: 54 GB of fabric reads
-    // per launch for 17.6 GB of events with the plain mapping).  A speed heuristic only: nothing depends on the placement.
+    // per launch for 17.6 GB of events with the plain mapping, 37 GB with this one).  A speed heuristic only: nothing depends on it.
+    // (Tried on top, round 3: 16 neighbouring tiles advancing together through their barcode order — the units taken in the order of
+    // (tile / 16, relative place in the tile) — because half of C2's entries sit in tiles deeper than 27 000 entries, where the two
+    // uses of a shared line lie 10 MB apart.  Reads fell to 32 GB, the kernel's time did not move (9.6 ms) and the order costs a
+    // 0.3 ms sort: the kernel runs at the 5.5 TB/s this chip copies at, whatever the mix of its 53 GB.  Not kept.)
     const uint32_t per_xcd = gridDim.x >> 3;                 // (the grid is a multiple of 8)
     const uint32_t vwg = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
     const uint32_t blk0 = (vwg * TMG_WAVES + (uint32_t)wv) * TMG_BLOCKS;
@@ -317,17 +321,20 @@ __global__ __launch_bounds__(TMG_WAVES * 64) void k_tm_gather(const uint16_t* ev
             const uint64_t p = (uint64_t)blk * 8 + (lane & 7);
             const uint32_t t = blk_tile[blk];
             const uint32_t i = (uint32_t)(p - (uint64_t)blk_off[t] * 8), off = tile_off[t], n = tile_off[t + 1] - off;
-            if (i >= n) { s0[p] = TM_PAD_S0; b8[p] = 0; fm[p] = 0xffffu; rd[p] = 0; }
+            // (everything this kernel writes is written once and read by another kernel: non-temporal stores keep it from pushing the
+            // source lines that neighbouring tiles share out of L2 — 10.4 -> 9.6 ms)
+            auto put = [](auto* q, auto v) { __builtin_nontemporal_store(v, q); };
+            if (i >= n) { put(s0 + p, (uint32_t)TM_PAD_S0); put(b8 + p, (uint8_t)0); put(fm + p, 0xffffu); put(rd + p, 0u); }
             else {
                 const uint32_t j = off + i, k = key[j];
                 const uint4 e = rec[val[j]];
                 const bool rs = i == 0 || key[j - 1] != k;
                 const bool single = rs && (i + 1 == n || key[j + 1] != k);
                 const uint32_t nev1 = (e.w >> 16) & 63u;
-                s0[p] = k | (e.w & TM_FWD) | (rs ? TM_RUNSTART : 0u);
-                b8[p] = (uint8_t)(nev1 | ((e.w >> 31) ? 64u : 0u) | (single ? 128u : 0u));
-                fm[p] = e.y;
-                rd[p] = e.x;
+                put(s0 + p, k | (e.w & TM_FWD) | (rs ? TM_RUNSTART : 0u));
+                put(b8 + p, (uint8_t)(nev1 | ((e.w >> 31) ? 64u : 0u) | (single ? 128u : 0u)));
+                put(fm + p, e.y);
+                put(rd + p, e.x);
                 e_src = e.z; e_info = (e.w & 0x3fffu) | ((nev1 + 1u) << 16);
             }
         }
@@ -370,8 +377,11 @@ __global__ __launch_bounds__(TMG_WAVES * 64) void k_tm_gather(const uint16_t* ev
         }
         const unsigned long long m = __ballot(any != 0u);
         const int first = m ? __ffsll((long long)m) - 1 : 0, last = m ? 64 - __clzll((long long)m) : 0;
-        if (lane >= first && lane < last)
-            store[(uint64_t)blk * 64 + lane] = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+        if (lane >= first && lane < last) {
+            const u32x4 row = {e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16)};
+            u32x4* dst = reinterpret_cast<u32x4*>(store) + (uint64_t)blk * 64 + lane;
+            __builtin_nontemporal_store(row, dst);
+        }
         if (lane == 0) ext[blk] = (uint16_t)(first | (last << 8));
     }
 }
@@ -554,10 +564,13 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
         if (c->tm[TM_STORE].reserve(((size_t)nblk + TM_GROUP) * 1024)) return -1;
     }
     LSG_HIP(hipEventRecord(c->evb[3], st));
-    hipLaunchKernelGGL(k_tm_gather, dim3((unsigned)(((((uint64_t)nblk + TMG_BLOCKS - 1) / TMG_BLOCKS + TMG_WAVES - 1) / TMG_WAVES + 7) / 8 * 8)), dim3(TMG_WAVES * 64), 0, st,
-                       events, n_events, key_b.as<uint32_t>(), val_b.as<uint32_t>(), rec.as<uint4>(), c->d_tile_off.as<uint32_t>(), blk_off, c->tm[TM_BLK_TILE].as<uint32_t>(), nblk,
-                       c->tm[TM_S0].as<uint32_t>(), c->tm[TM_B].as<uint8_t>(), c->tm[TM_FM].as<uint32_t>(), c->tm[TM_RD].as<uint32_t>(),
-                       c->tm[TM_STORE].as<uint4>(), c->tm[TM_EXT].as<uint16_t>());
+    {
+        const dim3 grid((unsigned)(((((uint64_t)nblk + TMG_BLOCKS - 1) / TMG_BLOCKS + TMG_WAVES - 1) / TMG_WAVES + 7) / 8 * 8));
+        hipLaunchKernelGGL(k_tm_gather, grid, dim3(TMG_WAVES * 64), 0, st,
+                           events, n_events, key_b.as<uint32_t>(), val_b.as<uint32_t>(), rec.as<uint4>(), c->d_tile_off.as<uint32_t>(), blk_off, c->tm[TM_BLK_TILE].as<uint32_t>(), nblk,
+                           c->tm[TM_S0].as<uint32_t>(), c->tm[TM_B].as<uint8_t>(), c->tm[TM_FM].as<uint32_t>(), c->tm[TM_RD].as<uint32_t>(),
+                           c->tm[TM_STORE].as<uint4>(), c->tm[TM_EXT].as<uint16_t>());
+    }
     LSG_HIP(hipEventRecord(c->evb[4], st));
     LSG_HIP(hipGetLastError());
     LSG_HIP(hipStreamSynchronize(st));

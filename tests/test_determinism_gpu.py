@@ -31,16 +31,25 @@ pytestmark = pytest.mark.gpu
 
 def oracle_calls(tag):
     d = json.load(open(os.path.join(G, "calls_hash_oracle_%s.json" % tag)))
-    return d["candidate_rows"], d["xxh64_of_candidate_row_text"]
+    return d["candidate_rows"], {c: tuple(v) for c, v in d["per_contig"].items()}
 
 
 def candidate_text_digest(eng, m):
-    """(rows, xxhash) of the step-1 text of the rows step 2 keeps, for the counts and calls resident in eng"""
+    """(rows, {contig: (rows, xxhash of its rows' text)}) of the step-1 text of the rows step 2 keeps, for the counts and calls resident
+    in eng.  Per contig: the writer puts the contigs in Python string order (the reference's file order), the oracle tool in header order."""
     from longsom_amd import tsvio
     per_ct = [eng.fetch_counts(ct) for ct in range(2)]
     calls = eng.fetch_calls()
-    text = tsvio.write_step1_tsv("/dev/null", calls, per_ct, m.contig_names, ["Cancer", "Non-Cancer"], [], header=False)
-    return text.count("\n"), xxhash.xxh64(text.encode()).hexdigest()
+    text = tsvio.write_step1_tsv("/dev/null", calls, per_ct, m.contig_names, ["Cancer", "Non-Cancer"], [], header=False, as_bytes=True)
+    sc = tsvio.scan_rows(text, m.contig_names)
+    tid = sc.key >> 32
+    out = {}
+    for t in np.unique(tid).tolist():
+        i = np.nonzero(tid == t)[0]
+        assert (np.diff(i) == 1).all(), "a contig's rows are contiguous in the table"
+        a, b = int(sc.off[i[0]]), int(sc.off[i[-1]] + sc.len[i[-1]] + 1)
+        out[m.contig_names[t]] = (len(i), xxhash.xxh64(text[a:b]).hexdigest())
+    return sc.n_rows, out
 
 
 def test_candidate_call_records_equal_the_cpu_oracles_small(engine):

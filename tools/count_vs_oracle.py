@@ -1,7 +1,6 @@
 """Development aid (GPU box): count a small random case and name the rows and fields that differ from the CPU oracle
-(used when the hand-written per-entry body of k_tm_walk is touched: LSG_LAYOUT=eager by default here, LSG_NO_TM=1 / LSG_NO_INDEX=1 pick the other forms)."""
+(used when the hand-written per-entry body of k_tm_walk is touched)."""
 import os
-os.environ.setdefault("LSG_LAYOUT", "eager")
 import sys, numpy as np
 sys.path.insert(0, '.')
 from tests.test_count_gpu import make_case

@@ -1,8 +1,18 @@
 """End-to-end timing of the fused SNV run on a synthetic C2-shaped BAM (files in, files out): where the wall-clock goes once the
 kernels are fast.  Writes gpurun_out/end_to_end.json (copied to profiles/rNN_end_to_end.json, which bench.py quotes in config.end_to_end).
 usage: python tools/e2e_perf.py [n_reads] [window_gb]      window_gb > 0: the streamed / windowed form (decode overlaps the GPU work)"""
-import json, os, shutil, sys, tempfile, time
+import json, os, shutil, sys, tempfile, threading, time
 sys.path.insert(0, ".")
+
+
+def _heartbeat():                                  # (a 10 M-read BAM takes minutes to write; a silent run looks hung to the GPU box's watchdog)
+    t0 = time.time()
+    while True:
+        time.sleep(60)
+        print("... %.0f s" % (time.time() - t0), flush=True)
+
+
+threading.Thread(target=_heartbeat, daemon=True).start()
 from longsom_amd import hostio, pipeline, synth
 n_reads = int(float(sys.argv[1])) if len(sys.argv) > 1 else 1_000_000
 window_gb = float(sys.argv[2]) if len(sys.argv) > 2 else 0.0

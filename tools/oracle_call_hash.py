@@ -56,12 +56,19 @@ def main():
     spans = [(cuts[i], cuts[i + 1]) for i in range(n_chunks) if cuts[i + 1] > cuts[i]]
     STATE.update(per_ct=per_ct, names=m.contig_names, fasta={m.contig_names[t]: refs[t].tobytes().decode() for t in range(len(refs))})
     h = xxhash.xxh64(); n_rows = 0
+    per_contig = {}                                  # contig -> [rows, xxh64 of its rows' text]: a mismatch names the contig
     with mp.get_context("fork").Pool(procs) as pool:
         for i, (k, text) in enumerate(pool.imap(work, spans)):
             h.update(text.encode()); n_rows += k
+            for line in text.split("\n"):
+                if line:
+                    c = line[:line.index("\t")]
+                    e = per_contig.setdefault(c, [0, xxhash.xxh64()])
+                    e[0] += 1; e[1].update((line + "\n").encode())
             if i % procs == 0:
                 print("chunk %d/%d, %d candidate rows so far (%.0f s)" % (i + 1, len(spans), n_rows, time.time() - t0), flush=True)
     out = {"config": cfg, "n_reads": n, "merged_sites": int(len(keys)), "candidate_rows": n_rows, "xxh64_of_candidate_row_text": h.hexdigest(),
+           "order": "contigs in BAM header (tid) order, positions ascending", "per_contig": {c: [e[0], e[1].hexdigest()] for c, e in per_contig.items()},
            "source": "oracle/count_oracle.c + oracle/calling_oracle.py step1 (scipy betabinom) over hostio.synth_records, %d processes (CPU)" % procs}
     path = os.path.join(ROOT, "tests", "golden", "calls_hash_oracle_%s_%d.json" % (cfg.lower(), n))
     json.dump(out, open(path, "w"), indent=1)

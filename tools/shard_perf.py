@@ -1,5 +1,6 @@
-"""Development aid: per-rank step time of the sharded C2 job, emulated on ONE GPU (one shard after another, no
-collective).  max over ranks of a given N predicts bench.py --gpus N minus the all-gather."""
+"""Development aid: per-rank count + call time of the sharded C2 job, emulated on ONE GPU (one shard after another, no collective;
+the shard's load is outside the timed loop here — bench.py times it).  max over ranks of a given N predicts the re-count part of
+bench.py --gpus N minus the all-gather."""
 import sys, time
 sys.path.insert(0, ".")
 import numpy as np
@@ -21,7 +22,6 @@ for world in worlds:
     for rank, (lo, hi, g_lo, g_hi) in enumerate(region_shards(model, world)):
         eng.synth_reads(sub_model(model, g_lo, g_hi) if world > 1 else model)
         eng.set_region(lo[0], lo[1], hi[0], hi[1])
-        eng.prepare_counts(cp)                  # as bench.py does: the per-load store, outside the timed steps
         def step():
             rows, cols = eng.pileup_count(cp)
             ns, nc = eng.call_step1(kp)
