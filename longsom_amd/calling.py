@@ -432,6 +432,14 @@ def step3(step2_text, delta_vaf: float, delta_mcf: float, min_ac_reads: int, min
             return empty, empty
         step2_text = survivors
         as_bytes = True
+        if cols and os.environ.get("LONGSOM_STEP3_PANDAS", "0") != "1":
+            # the row functions, the drops, the cluster filter and the two tables natively (csrc/hostio/tsvstep3.cpp); None = a table whose
+            # printed form could depend on pandas' dtypes, or on which a row function raises: the pandas path below decides
+            from . import tsvio
+            done = tsvio.step3_rows(survivors, cols, delta_vaf, delta_mcf, min_ac_reads, min_ac_cells, clust_dist)
+            if done is not None:
+                header = head + "\t".join(cols + ["STEP3FILTER", "INDEX"]) + "\n"
+                return header + done[1].decode(), header + done[0].decode()
     df = pd.read_csv(io.BytesIO(step2_text) if as_bytes else io.StringIO(step2_text), sep="\t", comment="#", names=cols)
     df = df[df["Cell_types"] != "Non-Cancer"]
     out_cols = cols + ["STEP3FILTER", "INDEX"]

@@ -1,0 +1,398 @@
+// BaseCellCalling.step3.py:41-316 over the rows of a step-2 table that survive its FILTER patterns (calling._step3_survivors picks them
+// with tsvscan.cpp): MultiAllelic_filtering (:163-231), chrM_filtering (:101-161), BC_CC_filtering (:233-251), BetaBino_filtering
+// (:254-280), the FILTER drops (:49-84), the cluster filter over string-sorted PASS rows (:283-306) and the two output tables — native,
+// so that the reference's pandas round trip (read_csv -> row-wise apply -> to_csv) over ~1e5 surviving rows is not what the fused run
+// spends its time on.  longsom_amd/calling.py keeps the pandas implementation, which is what the reference-generated goldens pin and
+// what tests/test_calling_cpu.py compares this file with.
+//
+// A table cell reaches the output as the TEXT it had unless step 3 rewrites it, which is what pandas does too as long as a column's
+// dtype does not change how a value prints.  Where it could (an integer column with a missing value turns float and prints "12.0"; a
+// number that is not the shortest repr of itself; quotes; a '#', which read_csv(comment="#") cuts the line at; a row function that
+// would raise in Python), this code does not guess: it returns 1 and the caller takes the pandas path.
+#include <algorithm>
+#include <cerrno>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <string_view>
+#include <atomic>
+#include <thread>
+#include <unordered_set>
+#include <vector>
+
+namespace {
+
+using sv = std::string_view;
+
+thread_local char g_s3_err[256];
+
+// the strings pandas.read_csv takes for a missing value (pandas/_libs/parsers STR_NA_VALUES)
+bool is_na(sv f) {
+    if (f.empty()) return true;
+    if (f.size() > 8) return false;
+    switch (f[0]) { case '#': case '-': case '1': case '<': case 'N': case 'n': break; default: return false; }
+    static const char* const NA[] = {"#N/A", "#N/A N/A", "#NA", "-1.#IND", "-1.#QNAN", "-NaN", "-nan", "1.#IND", "1.#QNAN", "<NA>", "N/A", "NA", "NULL", "NaN", "None", "n/a", "nan", "null"};
+    for (const char* s : NA) if (f == s) return true;
+    return false;
+}
+
+enum Kind { K_NA, K_INT, K_FLOAT, K_NUM_ODD, K_OTHER };     // K_NUM_ODD: pandas may read it as a number but would not print it back as it is
+
+bool all_digits(sv s) { if (s.empty()) return false; for (char c : s) if (c < '0' || c > '9') return false; return true; }
+
+Kind classify(sv f) {
+    if (is_na(f)) return K_NA;
+    sv s = f;
+    bool neg = false;
+    if (!s.empty() && s[0] == '-') { neg = true; s.remove_prefix(1); }
+    if (all_digits(s)) {                                    // canonical integer: no leading zero, not "-0", fits int64 comfortably
+        if ((s.size() > 1 && s[0] == '0') || (neg && s == "0") || s.size() > 18) return K_NUM_ODD;
+        return K_INT;
+    }
+    const size_t dot = s.find('.');
+    if (dot != sv::npos && all_digits(s.substr(0, dot)) && all_digits(s.substr(dot + 1))) {
+        // digits.digits: the shortest repr of itself iff <= 15 significant digits, no leading zero before a non-zero integer part, no
+        // trailing zero except the one of "x.0", and in the range repr prints without an exponent (>= 1e-4 or zero; < 1e16)
+        const sv ip = s.substr(0, dot), fp = s.substr(dot + 1);
+        if (ip.size() > 1 && ip[0] == '0') return K_NUM_ODD;
+        if (fp.size() > 1 && fp.back() == '0') return K_NUM_ODD;
+        std::string digits(ip); digits += fp;
+        size_t lead = 0; while (lead < digits.size() && digits[lead] == '0') ++lead;
+        const size_t sig = digits.size() - lead;
+        if (sig > 15 || ip.size() > 15) return K_NUM_ODD;
+        if (sig == 0) return (fp == "0" && ip == "0") ? K_FLOAT : K_NUM_ODD;          // "0.0" / "-0.0"
+        if (ip == "0") { size_t z = 0; while (z < fp.size() && fp[z] == '0') ++z; if (z >= 4) return K_NUM_ODD; }      // < 1e-4: repr uses an exponent
+        return K_FLOAT;
+    }
+    if (s == "inf") return K_FLOAT;
+    // anything else a float parser accepts (exponents, a sign, a bare dot, Infinity, hex, surrounding blanks): pandas would convert it
+    // and print it differently; so would a column of booleans
+    {
+        const char c0 = f[0];
+        const bool maybe = (c0 >= '0' && c0 <= '9') || c0 == '+' || c0 == '-' || c0 == '.' || c0 == ' ' || c0 == 'i' || c0 == 'I' || c0 == 'n' || c0 == 'N';
+        if (maybe) {
+            char buf[72];
+            if (f.size() >= sizeof buf) return K_OTHER;     // (no number of this table is that long; digits only were caught above)
+            memcpy(buf, f.data(), f.size()); buf[f.size()] = 0;
+            char* end = nullptr;
+            (void)strtod(buf, &end);
+            while (end && *end == ' ') ++end;
+            if (end && *end == 0 && end != buf) return K_NUM_ODD;
+        }
+        if (f == "True" || f == "False" || f == "TRUE" || f == "FALSE" || f == "true" || f == "false") return K_NUM_ODD;
+    }
+    return K_OTHER;
+}
+
+std::vector<sv> split(sv s, char sep) {
+    std::vector<sv> out;
+    size_t a = 0;
+    while (true) {
+        const size_t e = s.find(sep, a);
+        if (e == sv::npos) { out.push_back(s.substr(a)); break; }
+        out.push_back(s.substr(a, e - a));
+        a = e + 1;
+    }
+    return out;
+}
+
+bool to_i64(sv s, int64_t* v) {                             // what int() takes here: optional sign, digits (no spaces, no underscores)
+    if (s.empty() || s.size() > 19) return false;
+    size_t i = 0; bool neg = false;
+    if (s[0] == '-' || s[0] == '+') { neg = s[0] == '-'; i = 1; }
+    if (i >= s.size()) return false;
+    int64_t x = 0;
+    for (; i < s.size(); ++i) { if (s[i] < '0' || s[i] > '9') return false; x = x * 10 + (s[i] - '0'); }
+    *v = neg ? -x : x;
+    return true;
+}
+bool to_f64(sv s, double* v) {
+    if (s.empty()) return false;
+    std::string z(s);
+    if (z[0] == ' ' || z.back() == ' ') return false;
+    char* end = nullptr;
+    *v = strtod(z.c_str(), &end);
+    return end && *end == 0;
+}
+
+// str(round(a / float(b), 4)) (tsvwrite.cpp put_ratio)
+std::string ratio4(int64_t a, int64_t b) {
+    char buf[64];
+    int n = snprintf(buf, sizeof buf, "%.4f", (double)a / (double)b);
+    while (n > 0 && buf[n - 1] == '0' && buf[n - 2] != '.') --n;
+    return std::string(buf, (size_t)n);
+}
+
+bool contains(sv s, sv p) { return s.find(p) != sv::npos; }
+std::string replace_all(std::string s, const std::string& a, const std::string& b) {
+    size_t p = 0;
+    while ((p = s.find(a, p)) != std::string::npos) { s.replace(p, a.size(), b); p += b.size(); }
+    return s;
+}
+std::string tag(const std::string& cur, const char* t) { return cur == "PASS" ? std::string(t) : cur + "," + t; }
+
+enum Col { C_CHROM, C_START, C_REF, C_ALT, C_FILTER, C_CT, C_DP, C_NC, C_BC, C_CC, C_VAF, C_MCF, C_CTF, C_CANCER, C_NONCANCER, N_COLS_USED };
+
+struct Row {
+    std::vector<sv> f;                                      // the fields as they came
+    std::string alt, filter, bc, cc, vaf, mcf;              // the rewritten ones of a multi-allelic row
+    bool rewritten = false, is_m = false, dropped = false;
+    std::string s3, index;
+};
+
+struct NotHandled {};
+
+int actg(char c) { const char* p = strchr("ACTG", c); if (!p || !c) throw NotHandled{}; return (int)(p - "ACTG"); }
+int64_t need_int(sv s) { int64_t v; if (!to_i64(s, &v)) throw NotHandled{}; return v; }
+double need_float(sv s) { double v; if (is_na(s) || !to_f64(s, &v)) throw NotHandled{}; return v; }
+sv need(const std::vector<sv>& v, size_t i) { if (i >= v.size()) throw NotHandled{}; return v[i]; }
+
+// fn(lo, hi) over [0, n) in up to 16 threads; an exception in a worker is a NotHandled for the whole call
+template <class F>
+void parallel_rows(size_t n, F fn) {
+    unsigned T = std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (n < 4096) T = 1;
+    if (T == 1) { fn((size_t)0, n); return; }
+    std::atomic<bool> failed{false};
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < T; ++t)
+        th.emplace_back([&, t] {
+            try { fn(n * t / T, n * (t + 1) / T); } catch (...) { failed = true; }
+        });
+    for (auto& x : th) x.join();
+    if (failed) throw NotHandled{};
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* lsio_step3_last_error(void) { return g_s3_err; }
+
+// text: the surviving rows ('\n'-terminated lines of n_cols tab-separated fields, no header).  col[N_COLS_USED]: where #CHROM, Start,
+// REF, ALT, FILTER, Cell_types, Dp, Nc, Bc, Cc, VAF, MCF, Cell_type_Filter, Cancer, Non-Cancer are (Non-Cancer may be -1).
+// out_all / out_pass: the rows of .calling.step3.unfiltered.tsv / .calling.step3.tsv (lsio_free_text).  Returns 0, 1 = this table is
+// for the pandas path (see the head of the file), < 0 = error.
+int lsio_step3_rows(const char* text, int64_t n_bytes, int32_t n_cols, const int32_t* col, double delta_vaf, double delta_mcf, int64_t min_ac_reads,
+                    int64_t min_ac_cells, int64_t clust_dist, char** out_all, int64_t* out_all_len, char** out_pass, int64_t* out_pass_len) {
+    *out_all = *out_pass = nullptr; *out_all_len = *out_pass_len = 0;
+    if (n_bytes < 0 || n_cols < 7 || n_cols > 4096) { snprintf(g_s3_err, sizeof g_s3_err, "lsio_step3_rows: bad arguments"); return -1; }
+    for (int i = 0; i < N_COLS_USED; ++i)
+        if (col[i] >= n_cols || (col[i] < 0 && i != C_NONCANCER)) return 1;
+    try {
+        const sv all(text, (size_t)n_bytes);
+        if (all.find_first_of("#\"\r") != sv::npos) return 1;
+        std::vector<sv> lines;
+        for (size_t a = 0; a < all.size();) {
+            size_t e = all.find('\n', a);
+            if (e == sv::npos) e = all.size();
+            if (e > a) lines.push_back(all.substr(a, e - a));
+            a = e + 1;
+        }
+        std::vector<Row> rows(lines.size());
+        // ---- the fields, and what pandas' dtypes could change (see the head of the file): per column, which kinds of cell it holds
+        struct Seen { bool other = false, na = false, i = false, f = false, odd = false; };
+        std::vector<Seen> seen((size_t)n_cols);
+        std::atomic<bool> ragged{false};
+        std::atomic<unsigned> seen_lock{0};
+        parallel_rows(rows.size(), [&](size_t lo, size_t hi) {
+            std::vector<Seen> mine((size_t)n_cols);
+            for (size_t i = lo; i < hi; ++i) {
+                rows[i].f = split(lines[i], '\t');
+                if ((int32_t)rows[i].f.size() != n_cols) { ragged = true; return; }
+                for (int32_t c = 0; c < n_cols; ++c) {
+                    Seen& m = mine[(size_t)c];
+                    if (m.other) continue;                       // a column of strings: every cell prints as it came (a missing one as "")
+                    switch (classify(rows[i].f[(size_t)c])) {
+                        case K_NA: m.na = true; break;
+                        case K_INT: m.i = true; break;
+                        case K_FLOAT: m.f = true; break;
+                        case K_NUM_ODD: m.odd = true; break;
+                        default: m.other = true;
+                    }
+                }
+            }
+            while (seen_lock.exchange(1)) {}
+            for (int32_t c = 0; c < n_cols; ++c) {
+                Seen& a = seen[(size_t)c]; const Seen& m = mine[(size_t)c];
+                a.other |= m.other; a.na |= m.na; a.i |= m.i; a.f |= m.f; a.odd |= m.odd;
+            }
+            seen_lock = 0;
+        });
+        if (ragged) return 1;
+        for (const Seen& a : seen)
+            if (!a.other && (a.odd || (a.i && (a.na || a.f)))) return 1;
+        auto F = [&](const Row& r, Col c) -> sv { return col[c] < 0 ? sv() : r.f[(size_t)col[c]]; };
+        parallel_rows(rows.size(), [&](size_t lo_, size_t hi_) {
+        for (size_t ri = lo_; ri < hi_; ++ri) {
+            Row& r = rows[ri];
+            const sv chrom = F(r, C_CHROM), ct = F(r, C_CT), alt0 = F(r, C_ALT), filt0 = F(r, C_FILTER);
+            // (a missing FILTER: `"Multi-allelic" in FILTER` / the boolean index over .str.contains raise in the reference)
+            if (is_na(chrom) || is_na(ct) || is_na(alt0) || is_na(filt0) || contains(chrom, ":") || is_na(F(r, C_START))) throw NotHandled{};
+            if (ct == "Non-Cancer") { r.dropped = true; continue; }          // step3.py:41 (the caller's scanner has dropped them already)
+            r.is_m = chrom == "chrM";
+            r.s3 = "PASS";
+            // MultiAllelic_filtering
+            if ((!is_na(filt0) && contains(filt0, "Multi-allelic")) || contains(alt0, "|")) {
+                if (is_na(F(r, C_REF)) || F(r, C_REF).size() != 1 || is_na(F(r, C_CANCER))) throw NotHandled{};
+                const int i_ref = actg(F(r, C_REF)[0]);
+                const auto ctypes = split(ct, ',');
+                const auto cinfo = split(F(r, C_CANCER), '|');
+                const auto bcf = split(need(cinfo, 3), ':'), ccf = split(need(cinfo, 2), ':');
+                int64_t bcs[4];
+                for (int k = 0; k < 4; ++k) bcs[k] = need_int(need(bcf, (size_t)k));
+                bcs[i_ref] = 0;
+                int top = 0; for (int k = 1; k < 4; ++k) if (bcs[k] > bcs[top]) top = k;
+                const int64_t mx = bcs[top];
+                bcs[top] = 0;
+                const int64_t mx2 = *std::max_element(bcs, bcs + 4);
+                if (mx == 0) throw NotHandled{};                          // ZeroDivisionError in the reference
+                r.s3 = (double)mx2 / (double)mx < 0.05 ? "PASS" : "Multi-Allelic";
+                const char altc = "ACTG"[top];
+                const int64_t bc_c = need_int(need(bcf, (size_t)top)), cc_c = need_int(need(ccf, (size_t)top));
+                r.rewritten = true;
+                if (ctypes.size() > 1) {
+                    const int i_c = ctypes[0] == "Cancer" ? 0 : 1, i_n = 1 - i_c;
+                    if (col[C_NONCANCER] < 0 || is_na(F(r, C_NONCANCER))) throw NotHandled{};
+                    const auto ninfo = split(F(r, C_NONCANCER), '|');
+                    const int64_t bc_n = need_int(need(split(need(ninfo, 3), ':'), (size_t)top)), cc_n = need_int(need(split(need(ninfo, 2), ':'), (size_t)top));
+                    const auto dps = split(F(r, C_DP), ','), ncs = split(F(r, C_NC), ',');
+                    const int64_t dc = need_int(need(dps, (size_t)i_c)), dn = need_int(need(dps, (size_t)i_n)), nc = need_int(need(ncs, (size_t)i_c)), nn = need_int(need(ncs, (size_t)i_n));
+                    if (!dc || !dn || !nc || !nn) throw NotHandled{};
+                    r.alt = std::string(1, altc) + "," + altc;
+                    r.filter = is_na(filt0) ? std::string() : std::string(filt0);
+                    r.bc = std::to_string(bc_n) + "," + std::to_string(bc_c); r.cc = std::to_string(cc_n) + "," + std::to_string(cc_c);
+                    r.vaf = ratio4(bc_n, dn) + "," + ratio4(bc_c, dc); r.mcf = ratio4(cc_n, nn) + "," + ratio4(cc_c, nc);
+                } else {
+                    const int64_t d = need_int(F(r, C_DP)), n = need_int(F(r, C_NC));
+                    if (!d || !n) throw NotHandled{};
+                    if (is_na(filt0)) throw NotHandled{};                  // (a FILTER that is missing: .replace on NaN raises)
+                    r.filter = replace_all(replace_all(replace_all(std::string(filt0), "Multi-allelic,", ""), ",Multi-allelic", ""), "Multi-allelic", "");
+                    r.alt = std::string(1, altc);
+                    r.bc = std::to_string(bc_c); r.cc = std::to_string(cc_c); r.vaf = ratio4(bc_c, d); r.mcf = ratio4(cc_c, n);
+                }
+            }
+            const std::string alt = r.rewritten ? r.alt : std::string(alt0);
+            const std::string filt = r.rewritten ? r.filter : (is_na(filt0) ? std::string() : std::string(filt0));
+            if (!r.rewritten && is_na(filt0)) throw NotHandled{};          // .str.contains on a missing FILTER gives NaN, the boolean index raises
+            r.index = std::string(chrom) + ":" + std::string(F(r, C_START)) + ":" + alt.substr(0, alt.find(','));
+            const sv vaf = r.rewritten ? sv(r.vaf) : F(r, C_VAF), mcf = r.rewritten ? sv(r.mcf) : F(r, C_MCF);
+            const auto ctypes = split(ct, ',');
+            if (r.is_m) {
+                for (const char* p : {"Min", "LR", "gnomAD", "LC", "RNA"}) if (contains(filt, p)) r.dropped = true;
+                if (r.dropped) continue;
+                // chrM_filtering
+                if (ctypes.size() > 1) {
+                    const int i_c = ctypes[0] == "Cancer" ? 0 : 1, i_n = 1 - i_c;
+                    const auto d = split(F(r, C_DP), ',');
+                    if (d.size() != 2) throw NotHandled{};
+                    if (need_int(d[0]) < 100 || need_int(d[1]) < 100) r.s3 = tag(r.s3, "LowDepth");
+                    else {
+                        const auto v = split(vaf, ','), m = split(mcf, ',');
+                        std::vector<double> vv, mm;
+                        for (sv x : v) vv.push_back(need_float(x));
+                        for (sv x : m) mm.push_back(need_float(x));
+                        if (vv.size() < 2 || mm.size() < 2) throw NotHandled{};
+                        if (vv[(size_t)i_c] - vv[(size_t)i_n] < delta_vaf) r.s3 = tag(r.s3, "LowDeltaVAF");
+                        else if (mm[(size_t)i_c] - mm[(size_t)i_n] < delta_mcf) r.s3 = tag(r.s3, "LowDeltaMCF");
+                    }
+                } else {
+                    if (need_int(r.rewritten ? F(r, C_DP) : F(r, C_DP)) < 100) r.s3 = tag(r.s3, "LowDepth");
+                    else if (need_float(vaf) < 0.05) r.s3 = tag(r.s3, "LowVAF");
+                    else if (need_float(mcf) < 0.05) r.s3 = tag(r.s3, "LowMCF");
+                }
+            } else {
+                if (contains(filt, "Min_cell_types")) { r.dropped = true; continue; }
+                // BC_CC_filtering
+                const int i_alt = actg(alt.empty() ? 0 : alt[0]);
+                if (is_na(F(r, C_CANCER))) r.s3 = tag(r.s3, "NoCov");
+                else {
+                    const auto info = split(F(r, C_CANCER), '|');
+                    if (need_int(need(split(need(info, 3), ':'), (size_t)i_alt)) < min_ac_reads || need_int(need(split(need(info, 2), ':'), (size_t)i_alt)) < min_ac_cells)
+                        r.s3 = tag(r.s3, "LowDepth");
+                }
+                // BetaBino_filtering
+                const sv flt = F(r, C_CTF);
+                auto weak = [](sv x) { return x == "Non-Significant" || x == "Low-Significance"; };
+                if (ctypes.size() == 1) { if (!is_na(flt) && weak(flt)) r.s3 = tag(r.s3, "CancerNonSig"); }
+                else {
+                    if (is_na(flt)) throw NotHandled{};
+                    const int i_c = ctypes[0] == "Cancer" ? 0 : 1, i_n = 1 - i_c;
+                    const auto f = split(flt, ',');
+                    if (weak(need(f, (size_t)i_c))) r.s3 = tag(r.s3, "CancerNonSig");
+                    else if (need(f, (size_t)i_n) == "PASS" || need(f, (size_t)i_n) == "Low-Significance") r.s3 = tag(r.s3, "NonCancerSig");
+                }
+                for (const char* p : {"Noisy_site", "LC_Upstream", "LC_Downstream", "RNA_editing_db", "PoN", "Cell_type_noise", "gnomAD"}) if (contains(filt, p)) r.dropped = true;
+            }
+        }
+        });
+        // ---- the table's order: the other contigs' rows, then chrM's (pd.concat([df, chrm]))
+        std::vector<const Row*> order;
+        for (const Row& r : rows) if (!r.dropped && !r.is_m) order.push_back(&r);
+        for (const Row& r : rows) if (!r.dropped && r.is_m) order.push_back(&r);
+        // ---- cluster filter among the PASS rows, neighbours in string-sorted (contig, position) order (step3.py:283-306)
+        struct Idx { sv c, p; const std::string* index; };
+        std::vector<Idx> idx;
+        for (const Row* r : order)
+            if (r->s3 == "PASS") idx.push_back(Idx{r->f[(size_t)col[C_CHROM]], r->f[(size_t)col[C_START]], &r->index});
+        std::stable_sort(idx.begin(), idx.end(), [](const Idx& a, const Idx& b) { return a.c != b.c ? a.c < b.c : a.p < b.p; });
+        std::unordered_set<std::string> trash;
+        for (size_t i = 0; i + 1 < idx.size(); ++i)
+            if (idx[i].c == idx[i + 1].c && idx[i].c != "chrM") {
+                const int64_t p1 = need_int(idx[i].p), p2 = need_int(idx[i + 1].p);
+                if (std::llabs(p1 - p2) < clust_dist) { trash.insert(*idx[i].index); trash.insert(*idx[i + 1].index); }
+            }
+        const std::string ctag = "Clust_dist_" + std::to_string(clust_dist);
+        const size_t CH = 4096, n_ch = (order.size() + CH - 1) / CH;
+        std::vector<std::string> all_ch(n_ch), pass_ch(n_ch);
+        parallel_rows(n_ch, [&](size_t lo, size_t hi) {
+            std::string line;
+            for (size_t ch = lo; ch < hi; ++ch) {
+                std::string& all_txt = all_ch[ch]; std::string& pass_txt = pass_ch[ch];
+                for (size_t k = ch * CH; k < std::min(order.size(), (ch + 1) * CH); ++k) {
+                    const Row* r = order[k];
+                    std::string s3 = r->s3;
+                    if (trash.count(r->index)) s3 = tag(s3, ctag.c_str());
+                    line.clear();
+                    for (int32_t c = 0; c < n_cols; ++c) {
+                        if (c) line.push_back('\t');
+                        if (r->rewritten && c == col[C_ALT]) line += r->alt;
+                        else if (r->rewritten && c == col[C_FILTER]) line += r->filter;
+                        else if (r->rewritten && c == col[C_BC]) line += r->bc;
+                        else if (r->rewritten && c == col[C_CC]) line += r->cc;
+                        else if (r->rewritten && c == col[C_VAF]) line += r->vaf;
+                        else if (r->rewritten && c == col[C_MCF]) line += r->mcf;
+                        else if (!is_na(r->f[(size_t)c])) line.append(r->f[(size_t)c].data(), r->f[(size_t)c].size());
+                    }
+                    line.push_back('\t'); line += s3; line.push_back('\t'); line += r->index; line.push_back('\n');
+                    all_txt += line;
+                    if (s3 == "PASS") pass_txt += line;
+                }
+            }
+        });
+        std::string all_txt, pass_txt;
+        { size_t na = 0, np = 0; for (auto& x : all_ch) na += x.size(); for (auto& x : pass_ch) np += x.size(); all_txt.reserve(na); pass_txt.reserve(np); }
+        for (auto& x : all_ch) all_txt += x;
+        for (auto& x : pass_ch) pass_txt += x;
+        auto give = [](const std::string& s, char** out, int64_t* n) {
+            *out = (char*)malloc(s.size() ? s.size() : 1);
+            if (!*out) return false;
+            memcpy(*out, s.data(), s.size()); *n = (int64_t)s.size();
+            return true;
+        };
+        if (!give(all_txt, out_all, out_all_len) || !give(pass_txt, out_pass, out_pass_len)) {
+            free(*out_all); free(*out_pass); *out_all = *out_pass = nullptr;
+            snprintf(g_s3_err, sizeof g_s3_err, "lsio_step3_rows: out of memory"); return -2;
+        }
+        return 0;
+    } catch (const NotHandled&) {
+        return 1;
+    } catch (const std::exception& e) {
+        snprintf(g_s3_err, sizeof g_s3_err, "lsio_step3_rows: %s", e.what()); return -2;
+    }
+}
+
+}  // extern "C"

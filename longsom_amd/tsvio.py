@@ -165,6 +165,10 @@ def _io():
         lib.lsio_scan_rows.restype = C.c_int
         lib.lsio_scan_rows.argtypes = [C.c_char_p, C.c_int64, C.c_char_p, C.c_int32, C.c_char_p, C.c_char_p, C.c_int32, C.c_char_p, C.c_int32, C.c_void_p]
         lib.lsio_free_row_scan.argtypes = [C.c_void_p]
+        lib.lsio_step3_last_error.restype = C.c_char_p
+        lib.lsio_step3_rows.restype = C.c_int
+        lib.lsio_step3_rows.argtypes = [C.c_char_p, C.c_int64, C.c_int32, C.c_void_p, C.c_double, C.c_double, C.c_int64, C.c_int64, C.c_int64,
+                                        C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
         lib.lsio_gather_lines.restype = C.c_int
         lib.lsio_gather_lines.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_void_p]
         lib._tsv_ready = True
@@ -204,6 +208,36 @@ def scan_rows(text: bytes, contig_names, patterns_a: str = "", patterns_b: str =
         return r
     finally:
         lib.lsio_free_row_scan(C.byref(st))
+
+
+STEP3_COLUMNS = ("#CHROM", "Start", "REF", "ALT", "FILTER", "Cell_types", "Dp", "Nc", "Bc", "Cc", "VAF", "MCF", "Cell_type_Filter", "Cancer", "Non-Cancer")
+
+
+def step3_rows(rows: bytes, cols, delta_vaf: float, delta_mcf: float, min_ac_reads: int, min_ac_cells: int, clust_dist: int):
+    """lsio_step3_rows (csrc/hostio/tsvstep3.cpp) over the surviving rows of a step-2 table whose header is `cols`: (rows of the
+    unfiltered table, rows of the final table) as bytes, or None when the table is one for the pandas path."""
+    import ctypes as C
+    lib = _io()
+    idx = []
+    for name in STEP3_COLUMNS:
+        if name in cols:
+            idx.append(cols.index(name))
+        elif name == "Non-Cancer":
+            idx.append(-1)
+        else:
+            return None
+    col = (C.c_int32 * len(idx))(*idx)
+    a = C.c_void_p(); na = C.c_int64(0); b = C.c_void_p(); nb = C.c_int64(0)
+    rc = lib.lsio_step3_rows(rows, len(rows), len(cols), col, float(delta_vaf), float(delta_mcf), int(min_ac_reads), int(min_ac_cells), int(clust_dist),
+                             C.byref(a), C.byref(na), C.byref(b), C.byref(nb))
+    if rc == 1:
+        return None
+    if rc != 0:
+        raise RuntimeError(lib.lsio_step3_last_error().decode("utf-8", "replace"))
+    try:
+        return (C.string_at(a.value, na.value) if na.value else b""), (C.string_at(b.value, nb.value) if nb.value else b"")
+    finally:
+        lib.lsio_free_text(a); lib.lsio_free_text(b)
 
 
 def gather_lines(text: bytes, off: np.ndarray, length: np.ndarray, blank_na: bool = False, threads: int = 0):

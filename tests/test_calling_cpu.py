@@ -124,3 +124,130 @@ def test_step3_prefilter_equals_full_parse(monkeypatch):
         monkeypatch.setenv("LONGSOM_STEP3_ROW_PATH", "1")
         assert calling.step3(t, 0.05, 0.3, 3, 2, 10000) == want                    # the Python line loop does
         monkeypatch.setenv("LONGSOM_STEP3_ROW_PATH", "0")
+
+
+def _step3_tables():
+    texts = [rd("sample.calling.step2.tsv"), rd("sample.dist150.calling.step2.tsv")]
+    lines = texts[0].split("\n")
+    comments = [l for l in lines if l.startswith("#")]
+    body = [l for l in lines if l and not l.startswith("#")]
+    big, k = [], 0
+    while len(big) < 30000:
+        for l in body:
+            f = l.split("\t"); f[1] = str(int(f[1]) + 1000 * k); f[2] = f[1]; big.append("\t".join(f))
+        k += 1
+    texts.append("\n".join(comments + big) + "\n")
+    # one cell type only: the Cancer rows without the Non-Cancer column — Dp, Nc, Bc, Cc, VAF, MCF are then NUMERIC columns for pandas
+    cols = [l for l in comments if l.startswith("#CHROM")][0].split("\t")
+    i_nc = cols.index("Non-Cancer")
+    one = [l for l in comments if not l.startswith("#CHROM")] + ["\t".join(c for i, c in enumerate(cols) if i != i_nc)]
+    for l in big:
+        f = l.split("\t")
+        if f[cols.index("Cell_types")] == "Cancer":
+            one.append("\t".join(x for i, x in enumerate(f) if i != i_nc))
+    texts.append("\n".join(one) + "\n")
+    return texts, comments, body, cols
+
+
+def test_step3_native_rows_equal_the_pandas_path(monkeypatch):
+    """csrc/hostio/tsvstep3.cpp does step 3's row functions, drops, cluster filter and both tables natively; the pandas implementation
+    (pinned to the reference's files by test_step3 above) must give the same bytes — on the goldens (which the native path handles: it is
+    what test_step3 now pins), a 30 k-row table, a one-cell-type table whose count columns are numeric for pandas, three cluster distances"""
+    texts, _, _, _ = _step3_tables()
+    for t in texts:
+        sv = calling._step3_survivors(t.encode(), 6)
+        cols = [l for l in t.split("\n") if l.startswith("#CHROM")][0].split("\t")
+        for clust in (10000, 150, 1):
+            args = (0.05, 0.3, 3, 2, clust)
+            assert tsvio.step3_rows(sv, cols, *args) is not None, "the native path hands this table back"
+            monkeypatch.setenv("LONGSOM_STEP3_PANDAS", "1")
+            want = calling.step3(t, *args)
+            monkeypatch.setenv("LONGSOM_STEP3_PANDAS", "0")
+            assert calling.step3(t, *args) == want
+            assert calling.step3(t.encode(), *args) == want
+
+
+def test_step3_native_hands_back_what_pandas_dtypes_could_change(monkeypatch):
+    """an integer column with a missing value (pandas prints 12.0), a number that is not its own shortest repr, a '#', a quote, a row
+    function that raises in Python: tsvstep3.cpp returns 'not mine' and the result (or the exception) is the pandas path's"""
+    texts, comments, body, cols = _step3_tables()
+    i_ct, i_f = cols.index("Cell_types"), cols.index("FILTER")
+    live = [l for l in body if l.split("\t")[i_ct] != "Non-Cancer" and "PASS" in l.split("\t")[i_f]]
+    assert len(live) >= 3
+
+    def table(edit):
+        rows = list(live)
+        f = rows[1].split("\t"); edit(f); rows[1] = "\t".join(f)
+        return "\n".join(comments + rows) + "\n"
+
+    def setcol(name, value):
+        def e(f): f[cols.index(name)] = value
+        return e
+    args = (0.05, 0.3, 3, 2, 10000)
+
+    def outcome(t):
+        try:
+            return calling.step3(t, *args)
+        except Exception as e:                          # (a table the reference's script dies on: the same death on both paths)
+            return type(e)
+    plain = table(lambda f: None)
+    assert tsvio.step3_rows(calling._step3_survivors(plain.encode(), 6), cols, *args) is not None
+    for name, value in (("N_ALT", ""), ("N_ALT", "01"), ("N_ALT", "1.50"), ("N_ALT", "1e3"), ("Up_context", "AC#GT"), ("Up_context", '"ACGT'), ("Cell_types_min_BC", "nan")):
+        t = table(setcol(name, value))
+        assert tsvio.step3_rows(calling._step3_survivors(t.encode(), 6), cols, *args) is None, (name, value)
+        monkeypatch.setenv("LONGSOM_STEP3_PANDAS", "1")
+        want = outcome(t)
+        monkeypatch.setenv("LONGSOM_STEP3_PANDAS", "0")
+        assert outcome(t) == want
+    # a missing value in a column of strings prints as "" on both paths, and "nan" in one is a missing value for pandas
+    for name, value in (("Up_context", ""), ("Up_context", "nan"), ("Fisher_p", "NULL")):
+        t = table(setcol(name, value))
+        assert tsvio.step3_rows(calling._step3_survivors(t.encode(), 6), cols, *args) is not None, (name, value)
+        monkeypatch.setenv("LONGSOM_STEP3_PANDAS", "1")
+        want = calling.step3(t, *args)
+        monkeypatch.setenv("LONGSOM_STEP3_PANDAS", "0")
+        assert calling.step3(t, *args) == want
+    # an ALT the reference's BC_CC_filtering cannot index: both paths raise
+    t = table(setcol("ALT", "N"))
+    assert tsvio.step3_rows(calling._step3_survivors(t.encode(), 6), cols, *args) is None
+    with pytest.raises(ValueError):
+        calling.step3(t, *args)
+
+
+def test_step3_native_differential_fuzz(monkeypatch):
+    """random cells of random rows replaced by values that steer every branch of step 3 (missing values, one / two cell types in either
+    order, multi-allelic ALTs, depths around the chrM thresholds, numbers that are not their own repr, all rows moved to chrM): whatever
+    the native path does not hand back must come out as the pandas path prints it, and what kills the reference's script kills both"""
+    import random
+    texts, _, _, _ = _step3_tables()
+    vals = ["", "NA", "nan", "0", "1", "12", "0.5", "1.0", "0.25", "PASS", "Multi-allelic", "A", "T", "A|C", "C,C", "Cancer", "Cancer,Non-Cancer", "Non-Cancer,Cancer", "7,3",
+            "100,200", "99,100", "0.9,0.1", "chrM", "chr1", "Low-Significance", "PASS,Non-Significant", "Non-Significant,PASS", "LC_Upstream", "x",
+            "5|5|1:2:3:4:0:0|5:6:7:8:0:0|1:1:1:1:0:0|1:1:1:1:0:0|1:1:1:1:0:0", "130|120|0:0:0:0:0:0|0:0:0:0:0:0", "0.00001", "1e-05", "-1", "00", "None"]
+    args = (0.05, 0.3, 3, 2, 10000)
+
+    def outcome(t):
+        try:
+            return calling.step3(t, *args)
+        except Exception as e:
+            return type(e).__name__
+    handled = 0
+    for seed in range(120):
+        rng = random.Random(seed)
+        lines = texts[rng.choice([0, 1, 3])].split("\n")
+        head = [l for l in lines if l.startswith("#")]
+        rows = [l for l in lines if l and not l.startswith("#")]
+        rows = rng.sample(rows, min(len(rows), 300))
+        hdr = [l for l in head if l.startswith("#CHROM")][0].split("\t")
+        for _ in range(rng.choice([0, 1, 1, 2, 5, 40])):
+            i = rng.randrange(len(rows)); f = rows[i].split("\t")
+            f[rng.randrange(len(f))] = rng.choice(vals); rows[i] = "\t".join(f)
+        if rng.random() < 0.3:
+            rows = ["\t".join(["chrM"] + l.split("\t")[1:]) for l in rows]
+        t = "\n".join(head + rows) + "\n"
+        monkeypatch.setenv("LONGSOM_STEP3_PANDAS", "1")
+        want = outcome(t)
+        monkeypatch.setenv("LONGSOM_STEP3_PANDAS", "0")
+        assert outcome(t) == want, "seed %d" % seed
+        sv = calling._step3_survivors(t.encode(), hdr.index("Cell_types"))
+        handled += bool(sv) and tsvio.step3_rows(sv, hdr, *args) is not None
+    assert handled > 60                                  # (most of the tables are the native path's own)
