@@ -235,7 +235,7 @@ def step3_rows(rows: bytes, cols, delta_vaf: float, delta_mcf: float, min_ac_rea
     if rc != 0:
         raise RuntimeError(lib.lsio_step3_last_error().decode("utf-8", "replace"))
     try:
-        return (C.string_at(a.value, na.value) if na.value else b""), (C.string_at(b.value, nb.value) if nb.value else b"")
+        return _take_bytes(a.value, na.value), _take_bytes(b.value, nb.value)
     finally:
         lib.lsio_free_text(a); lib.lsio_free_text(b)
 
@@ -253,9 +253,17 @@ def gather_lines(text: bytes, off: np.ndarray, length: np.ndarray, blank_na: boo
     if rc != 0:
         raise RuntimeError("lsio_gather_lines: %s" % lib.lsio_scan_last_error().decode("utf-8", "replace"))
     try:
-        return (C.string_at(txt.value, ln.value) if ln.value else b""), new_off
+        return _take_bytes(txt.value, ln.value), new_off
     finally:
         lib.lsio_free_text(txt)
+
+
+def _take_bytes(ptr, n: int) -> bytes:
+    """n bytes at ptr as a bytes object (ctypes.string_at takes a C int: the kept rows of a 10 M-read step-1 table are 2.7 GB)"""
+    import ctypes as C
+    if not n:
+        return b""
+    return bytes(memoryview((C.c_char * n).from_address(ptr)))
 
 
 def _check(lib, rc, what):
@@ -325,7 +333,7 @@ def write_step1_tsv(path, calls, per_ct, contig_names, celltype_names, header_li
     _check(lib, lib.lsio_write_step1_rows(os.fsencode(path), "\n".join(contig_names).encode(), len(contig_names), len(per_ct), "\n".join(celltype_names).encode(),
                                           calls.ctypes.data, len(calls), pk, pc, n.ctypes.data, threads, C.byref(txt), C.byref(ln)), "lsio_write_step1_rows")
     try:
-        rows = C.string_at(txt.value, ln.value) if ln.value else b""
+        rows = _take_bytes(txt.value, ln.value)
     finally:
         lib.lsio_free_text(txt)
     return head.encode() + rows if as_bytes else head + rows.decode()
