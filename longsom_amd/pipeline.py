@@ -252,6 +252,9 @@ def run_snv(bam: str, barcodes_tsv: str, ref_fasta: str, out_dir: str, sample_id
     own = engine is None
     eng = engine or Engine(comm.local_device_index if comm.world > 1 else device)
     try:
+        if comm.world > 1 and window_bytes:
+            raise ValueError("window_bytes (--window_gb) streams one process's BAM window by window; with %d ranks every rank holds its region's reads at once: "
+                             "use one or the other" % comm.world)
         if comm.world > 1 or window_bytes:
             return _run_snv_regions(bam, barcodes_tsv, ref_fasta, out_dir, sample_id, params, editing, pon_sr, pon_lr, gnomad_af_json, eng, comm, window_bytes)
         res = load_sample(bam, barcodes_tsv, ref_fasta, eng, params.min_mapping_quality)
@@ -424,7 +427,7 @@ def _run_snv_regions(bam, barcodes_tsv, ref_fasta, out_dir, sample_id, params, e
                 if len(sub[ct][0]):
                     tsvio.write_counts_tsv(regions.piece_path(tmp, chrom, start1, "counts." + name), *sub[ct], names, "", header=False)
             tsvio.write_merged_tsv(regions.piece_path(tmp, chrom, start1, "merged"), sub, names, cts, header=False)
-            kept[(chrom, start1)] = tsvio.write_step1_tsv(regions.piece_path(tmp, chrom, start1, "step1"), calls[c0:c1], sub, names, cts, [], header=False)
+            kept[(chrom, start1)] = tsvio.write_step1_tsv(regions.piece_path(tmp, chrom, start1, "step1"), calls[c0:c1], sub, names, cts, [], header=False, as_bytes=True)
         t["write_tables"] += time.time() - t0
     if not contig:                                     # a rank (or a file) without reads: still needs the contig names for the headers
         setup(dec if comm.world > 1 else first)
@@ -453,7 +456,7 @@ def _run_snv_regions(bam, barcodes_tsv, ref_fasta, out_dir, sample_id, params, e
         regions.concatenate_pieces(tmp, "step1", s1h, out.step1)
         t["concatenate"] = time.time() - t0
         t0 = time.time()
-        s1 = (s1h + regions.unpack_rows(payloads)).encode()
+        s1 = s1h.encode() + regions.unpack_rows_bytes(payloads)
         keys = [calling.read_posset_keys(p, names, params.reference_gz_compat) for p in (editing, pon_sr, pon_lr)]
         s2 = calling.step2_bytes(s1, eng, names, keys[0], keys[1], keys[2], params.min_distance, calling.open_gnomad(gnomad_af_json), params.max_gnomad_vaf)
         open(out.step2, "wb").write(s2)

@@ -162,17 +162,35 @@ class Comm:
                 dist.destroy_process_group()
 
 
-def pack_rows(pieces: Dict[Tuple[str, int], str]) -> bytes:
-    """{(chrom, start): text of the rows step 2 keeps} -> bytes for allgather_bytes"""
-    import json
-    return json.dumps([[c, s, t] for (c, s), t in sorted(pieces.items())]).encode()
+def pack_rows(pieces) -> bytes:
+    """{(chrom, start): text (str or bytes) of the rows step 2 keeps} -> bytes for allgather_bytes: a count, per piece
+    (len(chrom), start, len(text)) as three little-endian int64, the chrom names, then the texts as they are (no escaping: at
+    C2 a rank's kept rows are hundreds of MB)"""
+    import struct
+    items = sorted(pieces.items())
+    enc = [(c.encode(), int(s), t.encode() if isinstance(t, str) else bytes(t)) for (c, s), t in items]
+    head = struct.pack("<q", len(enc)) + b"".join(struct.pack("<qqq", len(c), s, len(t)) for c, s, t in enc)
+    return head + b"".join(c for c, _, _ in enc) + b"".join(t for _, _, t in enc)
+
+
+def unpack_rows_bytes(payloads: Sequence[bytes]) -> bytes:
+    """all ranks' kept rows in (chrom string, start) order — file order of the step-1 table they were cut from"""
+    import struct
+    allp = []
+    for b in payloads:
+        if not b:
+            continue
+        (n,) = struct.unpack_from("<q", b, 0)
+        meta = [struct.unpack_from("<qqq", b, 8 + 24 * i) for i in range(n)]
+        at = 8 + 24 * n
+        names = []
+        for lc, _, _ in meta:
+            names.append(b[at:at + lc].decode()); at += lc
+        for name, (_, start, lt) in zip(names, meta):
+            allp.append((name, start, b[at:at + lt])); at += lt
+    allp.sort(key=lambda x: (x[0], x[1]))
+    return b"".join(t for _, _, t in allp)
 
 
 def unpack_rows(payloads: Sequence[bytes]) -> str:
-    """all ranks' kept rows in (chrom string, start) order — file order of the step-1 table they were cut from"""
-    import json
-    allp = []
-    for b in payloads:
-        allp += [tuple(x) for x in json.loads(b.decode())] if b else []
-    allp.sort(key=lambda x: (x[0], x[1]))
-    return "".join(t for _, _, t in allp)
+    return unpack_rows_bytes(payloads).decode()
