@@ -194,6 +194,11 @@ int lsg_load_bam(lsg_ctx* ctx, const uint8_t* file_bytes, int64_t n_bytes, int64
 /* keep != 0: the next loads also keep a copy of the compact events (and seg_ev_off) beside the store, which is what
  * lsg_copy_reads_to_host returns (tests, sampling for a CPU baseline).  Default 0: the store is the only copy (2 B per event saved). */
 int lsg_set_keep_reads(lsg_ctx* ctx, int32_t keep);
+/* Gives back everything a load and its counts hold on the device (reads, the tile store, the build's cached temporaries, count rows,
+ * call records): the handle is as after lsg_set_barcodes, ready for the next lsg_load_reads / lsg_load_bam.  What a worker process of the
+ * reference does by ending (BaseCellCounter.py:392-402 starts a pool per BAM); here a long-lived handle moves from one sample to the next,
+ * and a sample of C4's size (155 GB resident) needs the room of the one before it. */
+int lsg_unload_reads(lsg_ctx* ctx);
 /* The reference counts through bam.pileup(..., max_depth = 200000) (BaseCellCounter.py:191,
  * HCCVSingleCellGenotype.py:122): htslib stops admitting reads at a position while more than max_depth are
  * live in its buffer.  lsg_pileup_count models that cap exactly (lsg_count_params.max_depth); this call evaluates

@@ -156,6 +156,7 @@ SIGNATURES = {
     "lsg_get_build_times": (C.c_int, [C.c_void_p, C.c_void_p]),
     "lsg_get_store_shape": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "lsg_set_keep_reads": (C.c_int, [C.c_void_p, C.c_int32]),
+    "lsg_unload_reads": (C.c_int, [C.c_void_p]),
     "lsg_load_bam": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_char_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(BamInfo), C.c_void_p, C.c_void_p, C.c_int64]),
     "lsg_set_load_filter": (C.c_int, [C.c_void_p, C.c_int32, C.c_uint32, C.c_int32]),
     "lsg_max_live_reads_all": (C.c_int64, [C.c_void_p]),

@@ -98,6 +98,26 @@ void lsg_destroy(lsg_ctx* c) {
     delete c;
 }
 
+int lsg_unload_reads(lsg_ctx* c) {
+    if (!c) { set_error("lsg_unload_reads: NULL handle"); return -2; }
+    LSG_HIP(hipSetDevice(c->device));
+    LSG_HIP(hipStreamSynchronize(c->stream));
+    DevBuf* bufs[] = {&c->b_read_tid, &c->b_read_pos, &c->b_read_flag, &c->b_read_mapq, &c->b_read_cb, &c->b_seg_read, &c->b_seg_start, &c->b_seg_len,
+                      &c->b_seg_ev_off, &c->b_events, &c->d_read_key, &c->d_read_drop, &c->d_ne_units, &c->d_ne_mask, &c->d_ne_rowbase, &c->d_ne_rowoff,
+                      &c->d_cub_tmp, &c->d_ix_stat, &c->d_tile_cap, &c->d_tile_off, &c->d_calls, &c->d_site_off, &c->d_pass_list};
+    for (auto* b : bufs) b->release();
+    for (auto& b : c->d_rows) b.release();
+    for (auto& b : c->gen) b.release();
+    for (auto& b : c->ws) b.release();
+    for (auto& b : c->tm) b.release();
+    for (auto& b : c->bt) b.release();
+    c->rd = lsg_reads{};
+    lsg::drop_store(c);
+    c->row_cap = 0; c->n_ne = 0; c->n_columns = 0; c->n_sites = 0; c->n_cand = 0; c->n_pass = -1;
+    for (auto& n : c->n_rows) n = 0;
+    return 0;
+}
+
 int lsg_set_stream(lsg_ctx* c, void* hip_stream) {
     if (!c) { set_error("lsg_set_stream: NULL handle"); return -2; }
     (void)hipStreamSynchronize(c->stream);

@@ -97,6 +97,12 @@ class Engine:
         BAM); later counts must be at least as strict.  Default: no filter (lsg_set_load_filter)."""
         _lib.check(self._lib.lsg_set_load_filter(self._h, int(min_mq), int(flag_exclude), int(ignore_orphans)), "lsg_set_load_filter")
 
+    def unload_reads(self):
+        """give the device memory of the resident load (reads, store, rows, call records, cached temporaries) back: lsg_unload_reads"""
+        _lib.check(self._lib.lsg_unload_reads(self._h), "lsg_unload_reads")
+        self._n_rows = [0] * max(1, self.n_ct)
+        self._n_sites = 0
+
     def set_keep_reads(self, keep: bool):
         _lib.check(self._lib.lsg_set_keep_reads(self._h, 1 if keep else 0), "lsg_set_keep_reads")
 

@@ -181,3 +181,27 @@ def test_load_filter_drops_reads_like_splitbam(engine):
         engine.set_load_filter()
     engine.load_reads(rec)
     check(engine, rec, lens, refs, ct_of, 2, CountParams.longsom_defaults(min_mq=30))
+
+
+def test_unload_gives_the_memory_back_and_the_handle_stays_usable():
+    """lsg_unload_reads: the load's device memory returns (within the allocator's granularity), counting without reads is an error,
+    the next load counts as the first one did"""
+    import torch
+    from longsom_amd import synth
+    from longsom_amd._lib import LsgError
+    from longsom_amd.engine import Engine
+    m = synth.named("C1", n_reads=200_000)
+    with Engine(0) as eng:
+        eng.set_contigs(m.contig_len); eng.synth_reference(m.seed); eng.set_barcodes(m.celltype_of, 2)
+        free0 = torch.cuda.mem_get_info(0)[0]
+        eng.synth_reads(m)
+        first = eng.pileup_count()
+        eng.call_step1()
+        used = free0 - torch.cuda.mem_get_info(0)[0]
+        assert used > 50 << 20
+        eng.unload_reads()
+        assert free0 - torch.cuda.mem_get_info(0)[0] < used // 8
+        with pytest.raises(LsgError):
+            eng.pileup_count()
+        eng.synth_reads(m)
+        assert eng.pileup_count() == first
