@@ -65,6 +65,31 @@ class SnvOutputs:
     step3: str
     step3_unfiltered: str
     timings: Dict[str, float] = field(default_factory=dict)
+    _pending: list = field(default_factory=list, repr=False, compare=False)
+
+    def start_background(self, fn) -> None:
+        """run fn() (table writers) on a thread of its own; wait_for_tables joins it and re-raises what it raised"""
+        import threading
+        box = {}
+
+        def work():
+            try:
+                fn()
+            except BaseException as e:                   # noqa: BLE001 — handed to the joining thread
+                box["error"] = e
+        th = threading.Thread(target=work, name="longsom-tables")
+        th.start()
+        self._pending.append((th, box))
+
+    def wait_for_tables(self) -> float:
+        t0 = time.time()
+        pending, self._pending = self._pending, []
+        for th, box in pending:
+            th.join()
+        for th, box in pending:
+            if "error" in box:
+                raise box["error"]
+        return time.time() - t0
 
 
 def write_report(path: str, report: Dict[str, int], seconds: float) -> None:
@@ -172,7 +197,7 @@ def load_sample(bam: str, barcodes_tsv: str, ref_fasta: str, engine: Engine, min
 
 
 def chain_step1(res: Resident, celltype_of: np.ndarray, celltype_names: List[str], report: Dict[str, int], out_dir: str, sample_id: str,
-                params: SnvParams, write_tables: bool = True):
+                params: SnvParams, write_tables: bool = True, background_tables: bool = False):
     """SplitBam report -> BaseCellCounter -> MergeCounts -> BaseCellCalling step 1 over the resident reads.  Returns (outputs, text of
     the rows step 2 keeps, call records, timings); write_tables=False keeps everything off the disk except the report."""
     eng, contig_names = res.engine, res.contig_names
@@ -199,12 +224,23 @@ def chain_step1(res: Resident, celltype_of: np.ndarray, celltype_names: List[str
     t0 = time.time()
     date = tsvio.file_date()
     for ct, name in enumerate(celltype_names):
-        p = os.path.join(d["BaseCellCounter/" + sample_id], "%s.%s.tsv" % (sample_id, name))
-        tsvio.write_counts_tsv(p, *per_ct[ct], contig_names, "%s.%s" % (sample_id, name), date)
-        out.counts[name] = p
+        out.counts[name] = os.path.join(d["BaseCellCounter/" + sample_id], "%s.%s.tsv" % (sample_id, name))
     out.merged = os.path.join(d["MergeCounts"], sample_id + ".BaseCellCounts.AllCellTypes.tsv")
-    header = tsvio.write_merged_tsv(out.merged, per_ct, contig_names, celltype_names, date)
     out.step1 = os.path.join(d["BaseCellCalling"], sample_id + ".calling.step1.tsv")
+
+    def count_tables():
+        for ct, name in enumerate(celltype_names):
+            tsvio.write_counts_tsv(out.counts[name], *per_ct[ct], contig_names, "%s.%s" % (sample_id, name), date)
+        tsvio.write_merged_tsv(out.merged, per_ct, contig_names, celltype_names, date)
+    header = [l + "\n" for l in tsvio.merged_header(celltype_names, date).split("\n") if l.startswith("##")]
+    if background_tables:
+        # the per-cell-type and merged tables are written by a thread of their own (native writers, no GIL) beside the step-1 table
+        # (step 2 waits for its kept rows) and steps 2 and 3: the caller joins it (SnvOutputs.wait_for_tables)
+        out.start_background(count_tables)
+        s1 = tsvio.write_step1_tsv(out.step1, calls, per_ct, contig_names, celltype_names, header, as_bytes=True)
+        t["write_tables"] = time.time() - t0
+        return out, s1, calls, t
+    count_tables()
     s1 = tsvio.write_step1_tsv(out.step1, calls, per_ct, contig_names, celltype_names, header, as_bytes=True)      # s1 = header + the rows step 2 keeps
     t["write_tables"] = time.time() - t0
     return out, s1, calls, t
@@ -217,7 +253,7 @@ def run_chain(res: Resident, celltype_of: np.ndarray, celltype_names: List[str],
     resident reads (celltype_of[barcode id] = index into celltype_names, 255 = barcode not listed).  step3=False stops after
     step 2, as pass 1 of the reference does (rules/CellTypeReannotation.smk has no step-3 rule: HCCV reads calling.step2.tsv)."""
     eng, contig_names = res.engine, res.contig_names
-    out, s1, _, t = chain_step1(res, celltype_of, celltype_names, report, out_dir, sample_id, params)
+    out, s1, _, t = chain_step1(res, celltype_of, celltype_names, report, out_dir, sample_id, params, background_tables=True)
     d = {"BaseCellCalling": os.path.join(out_dir, "BaseCellCalling")}
     t0 = time.time()
     keys = [calling.read_posset_keys(p, contig_names, params.reference_gz_compat) for p in (editing, pon_sr, pon_lr)]
@@ -227,6 +263,7 @@ def run_chain(res: Resident, celltype_of: np.ndarray, celltype_names: List[str],
     open(out.step2, "wb").write(s2)
     t["step2"] = time.time() - t0
     if not step3:
+        t["tables_wait"] = out.wait_for_tables()
         out.timings = t
         return out
     t0 = time.time()
@@ -236,6 +273,7 @@ def run_chain(res: Resident, celltype_of: np.ndarray, celltype_names: List[str],
     open(out.step3, "w").write(final)
     open(out.step3_unfiltered, "w").write(unfiltered)
     t["step3"] = time.time() - t0
+    t["tables_wait"] = out.wait_for_tables()              # (what of the background writers' time steps 2 and 3 did not cover)
     out.timings = t
     return out
 

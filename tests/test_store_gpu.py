@@ -186,21 +186,27 @@ def test_load_filter_drops_reads_like_splitbam(engine):
 def test_unload_gives_the_memory_back_and_the_handle_stays_usable():
     """lsg_unload_reads: the load's device memory returns (within the allocator's granularity), counting without reads is an error,
     the next load counts as the first one did"""
-    import torch
+    import ctypes as C
     from longsom_amd import synth
     from longsom_amd._lib import LsgError
     from longsom_amd.engine import Engine
+    hip = C.CDLL("libamdhip64.so")
+
+    def free_bytes():
+        f, t = C.c_size_t(0), C.c_size_t(0)
+        assert hip.hipMemGetInfo(C.byref(f), C.byref(t)) == 0
+        return f.value
     m = synth.named("C1", n_reads=200_000)
     with Engine(0) as eng:
         eng.set_contigs(m.contig_len); eng.synth_reference(m.seed); eng.set_barcodes(m.celltype_of, 2)
-        free0 = torch.cuda.mem_get_info(0)[0]
+        free0 = free_bytes()
         eng.synth_reads(m)
         first = eng.pileup_count()
         eng.call_step1()
-        used = free0 - torch.cuda.mem_get_info(0)[0]
+        used = free0 - free_bytes()
         assert used > 50 << 20
         eng.unload_reads()
-        assert free0 - torch.cuda.mem_get_info(0)[0] < used // 8
+        assert free0 - free_bytes() < used // 8
         with pytest.raises(LsgError):
             eng.pileup_count()
         eng.synth_reads(m)
