@@ -35,7 +35,7 @@ struct BuildArgs {
     uint2* seg_info;                      // per segment {barcode | reverse << 24, or KEY_INVALID; first tile of its contig}
     uint32_t* tile_cap;                   // MODE 0: entries per tile
     uint32_t* cursor;                     // MODE 2: next free place of every tile's region
-    uint4* rec; uint32_t* key; uint32_t* val;
+    uint4* rec; uint32_t* key;
     unsigned long long* qhead;            // work queue head of the binning pass
     int32_t lf_min_mq, lf_ignore_orphans; uint32_t lf_flag_exclude;      // the load filter (lsg_set_load_filter)
     uint32_t* bad;                        // bit 0: a segment's event range lies outside the events; bit 1: a segment's read index outside the reads
@@ -248,7 +248,6 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(BuildArgs a) {
                             a.rec[pos] = make_uint4(g.rd, g.fm, (uint32_t)src,
                                                     (uint32_t)(src >> 32) | ((uint32_t)(lo - tstart) << 8) | ((uint32_t)(hi - lo - 1) << 16) | (((g.key >> 24) & 1u) ? 0u : TM_FWD) | (lo == g.st ? TM_RUNSTART : 0u));
                             a.key[pos] = cbk;
-                            a.val[pos] = pos;
                         }
                     }
                 }
@@ -501,10 +500,10 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
     c->max_live_all = max_live > 0 ? max_live : 0;
     if (N == 0) return finish();
     // ---- 2. scatter
-    DevBuf &rec = c->bt[BT_REC], &key_a = c->bt[BT_KEY_A], &key_b = c->bt[BT_KEY_B], &val_a = c->bt[BT_VAL_A], &val_b = c->bt[BT_VAL_B];
-    if (rec.reserve(N * 16) || key_a.reserve(N * 4 + 16) || key_b.reserve(N * 4 + 16) || val_a.reserve(N * 4) || val_b.reserve(N * 4) ||
+    DevBuf &rec = c->bt[BT_REC], &key_a = c->bt[BT_KEY_A], &key_b = c->bt[BT_KEY_B], &val_b = c->bt[BT_VAL_B];
+    if (rec.reserve(N * 16) || key_a.reserve(N * 4 + 16) || key_b.reserve(N * 4 + 16) || val_b.reserve(N * 4) ||
         c->bt[BT_PER_TILE].reserve(((size_t)T + 2) * 4) || c->bt[BT_NETILE].reserve(((size_t)T + 2) * 4)) return -1;
-    a.cursor = c->bt[BT_PER_TILE].as<uint32_t>(); a.rec = rec.as<uint4>(); a.key = key_a.as<uint32_t>(); a.val = val_a.as<uint32_t>();
+    a.cursor = c->bt[BT_PER_TILE].as<uint32_t>(); a.rec = rec.as<uint4>(); a.key = key_a.as<uint32_t>();
     LSG_HIP(hipMemcpyAsync(a.cursor, c->d_tile_off.p, ((size_t)T + 1) * 4, hipMemcpyDeviceToDevice, st));
     LSG_HIP(hipMemsetAsync(c->d_scalars.p, 0, 8, st));
     hipLaunchKernelGGL(k_bin<2>, dim3(g_bin), dim3(BIN_THREADS), 0, st, a);
@@ -528,12 +527,14 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
     {
         int bits = 1; while (bits < 24 && (1ll << bits) <= (long long)max_cb) ++bits;
         size_t tb = 0;
-        LSG_HIP(hipcub::DeviceSegmentedRadixSort::SortPairs(nullptr, tb, key_a.as<uint32_t>(), key_b.as<uint32_t>(), val_a.as<uint32_t>(), val_b.as<uint32_t>(), (int)N, (int)n_netile,
-                                                            c->bt[BT_SEG_BEGIN].as<uint32_t>(), c->bt[BT_SEG_END].as<uint32_t>(), 0, bits, st));
+        // (values in = the entries' arrival places, an iterator: rocprim's own entry point takes one where hipcub wants an array)
+        rocprim::counting_iterator<uint32_t> place(0u);
+        LSG_HIP(rocprim::segmented_radix_sort_pairs(nullptr, tb, key_a.as<uint32_t>(), key_b.as<uint32_t>(), place, val_b.as<uint32_t>(), (unsigned)N, (unsigned)n_netile,
+                                                    c->bt[BT_SEG_BEGIN].as<uint32_t>(), c->bt[BT_SEG_END].as<uint32_t>(), 0u, (unsigned)bits, st));
         if (tmp.reserve(tb + 256)) return -1;
         tb = tmp.cap;
-        LSG_HIP(hipcub::DeviceSegmentedRadixSort::SortPairs(tmp.p, tb, key_a.as<uint32_t>(), key_b.as<uint32_t>(), val_a.as<uint32_t>(), val_b.as<uint32_t>(), (int)N, (int)n_netile,
-                                                            c->bt[BT_SEG_BEGIN].as<uint32_t>(), c->bt[BT_SEG_END].as<uint32_t>(), 0, bits, st));
+        LSG_HIP(rocprim::segmented_radix_sort_pairs(tmp.p, tb, key_a.as<uint32_t>(), key_b.as<uint32_t>(), place, val_b.as<uint32_t>(), (unsigned)N, (unsigned)n_netile,
+                                                    c->bt[BT_SEG_BEGIN].as<uint32_t>(), c->bt[BT_SEG_END].as<uint32_t>(), 0u, (unsigned)bits, st));
     }
     LSG_HIP(hipEventRecord(c->evb[2], st));
     // ---- 4. blocks and the per-entry words
@@ -559,7 +560,7 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
         size_t mem_free = 0, mem_total = 0;
         if (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess && ((size_t)nblk + TM_GROUP) * 1088 + (mem_total >> 5) > mem_free) {
             LSG_HIP(hipStreamSynchronize(st));
-            key_a.release(); val_a.release(); c->ws[WS_SEG_INFO].release(); c->bt[BT_SPAN].release(); c->bt[BT_SPAN_RUN].release(); c->bt[BT_PEX].release(); c->bt[BT_OFFS].release();
+            key_a.release(); c->ws[WS_SEG_INFO].release(); c->bt[BT_SPAN].release(); c->bt[BT_SPAN_RUN].release(); c->bt[BT_PEX].release(); c->bt[BT_OFFS].release();
         }
         if (c->tm[TM_STORE].reserve(((size_t)nblk + TM_GROUP) * 1024)) return -1;
     }
