@@ -188,9 +188,21 @@ typedef struct {
     int64_t n_records, n_blocks, n_ubytes;
     float   ms_h2d, ms_inflate, ms_chain, ms_decode, ms_store, ms_total;               /* HIP-event / wall times of the phases */
     int32_t chain_rounds, pad_;
+    int64_t last_key;           /* (tid << 32 | pos) of the last complete record, 2^63 - 1 for one without a reference, -1: no record */
 } lsg_bam_info;
 int lsg_load_bam(lsg_ctx* ctx, const uint8_t* file_bytes, int64_t n_bytes, int64_t first_record_offset, const char* barcodes, int32_t n_barcodes,
                  const int32_t* ids, int32_t min_mapq, int32_t legacy_del_merge, lsg_bam_info* info, int64_t* cb_pass, int64_t* cb_low, int64_t n_tally);
+/* The same for a SLICE of a coordinate-sorted BAM — whole BGZF blocks cut out of the file, starting with a block in which a record starts
+ * at first_record_offset (what the .bai's linear index gives: virtual offset = block start << 16 | offset in the block): what one rank of
+ * a sharded run ingests, as the reference's workers fetch their window through the index (BaseCellCounter.py:190-191; the .bai is a
+ * rule input, rules/SNVCalling.smk:6-7).  A record cut by the end of the slice is skipped.  SplitBam's counters and the per-barcode
+ * tallies take only the records whose (tid << 32 | pos) lies in [count_lo_key, count_hi_key): neighbouring slices overlap (a rank
+ * also needs the reads that reach into its region), the sum over the ranks counts every record once.  info->last_key tells the caller
+ * whether the slice reached the first read starting at or after its region's end (every read before it in the file starts earlier:
+ * nothing that overlaps the region is missing); if not it asks again with a longer slice (longsom_amd/regions.py). */
+int lsg_load_bam_range(lsg_ctx* ctx, const uint8_t* slice_bytes, int64_t n_bytes, int64_t first_record_offset, const char* barcodes, int32_t n_barcodes,
+                       const int32_t* ids, int32_t min_mapq, int32_t legacy_del_merge, int64_t count_lo_key, int64_t count_hi_key, lsg_bam_info* info,
+                       int64_t* cb_pass, int64_t* cb_low, int64_t n_tally);
 /* keep != 0: the next loads also keep a copy of the compact events (and seg_ev_off) beside the store, which is what
  * lsg_copy_reads_to_host returns (tests, sampling for a CPU baseline).  Default 0: the store is the only copy (2 B per event saved). */
 int lsg_set_keep_reads(lsg_ctx* ctx, int32_t keep);

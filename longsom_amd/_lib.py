@@ -107,6 +107,7 @@ class BamInfo(C.Structure):
         ("n_records", C.c_int64), ("n_blocks", C.c_int64), ("n_ubytes", C.c_int64),
         ("ms_h2d", C.c_float), ("ms_inflate", C.c_float), ("ms_chain", C.c_float), ("ms_decode", C.c_float), ("ms_store", C.c_float), ("ms_total", C.c_float),
         ("chain_rounds", C.c_int32), ("pad_", C.c_int32),
+        ("last_key", C.c_int64),
     ]
 
 
@@ -158,6 +159,7 @@ SIGNATURES = {
     "lsg_set_keep_reads": (C.c_int, [C.c_void_p, C.c_int32]),
     "lsg_unload_reads": (C.c_int, [C.c_void_p]),
     "lsg_load_bam": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_char_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(BamInfo), C.c_void_p, C.c_void_p, C.c_int64]),
+    "lsg_load_bam_range": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_char_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.POINTER(BamInfo), C.c_void_p, C.c_void_p, C.c_int64]),
     "lsg_set_load_filter": (C.c_int, [C.c_void_p, C.c_int32, C.c_uint32, C.c_int32]),
     "lsg_max_live_reads_all": (C.c_int64, [C.c_void_p]),
     "lsg_synth_generate": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Reads)]),

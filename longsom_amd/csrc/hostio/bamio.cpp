@@ -728,3 +728,122 @@ void lsio_ref_bases(uint64_t seed, int32_t tid, int64_t len, uint8_t* out) {
 }
 
 } // extern "C"
+
+// ---- a BAM index with a linear index only (BAI: SAM specification section 5.2), for BAMs this repository writes ----------------------------
+// The sharded run (longsom_amd/regions.py) cuts a coordinate-sorted BAM by its .bai's linear index — per reference and 16 kb window the
+// smallest virtual offset (compressed block start << 16 | offset inside the block) of the alignments overlapping the window — which is
+// what the reference's workers use too when they fetch their window through the index (BaseCellCounter.py:190-191; the .bai is a rule
+// input, rules/SNVCalling.smk:6-7).  samtools writes that file for real data; this builder writes one for the synthetic and fixture BAMs
+// (no binning index: n_bin = 0 — the reader here needs the linear index only).  Unset windows are filled as htslib fills them (with the
+// window before; leading ones with the reference's first offset).
+namespace {
+struct BaiBuild {
+    std::vector<std::vector<uint64_t>> lin;           // per reference
+    void add(int32_t tid, int64_t beg, int64_t end, uint64_t voff) {
+        if (tid < 0 || (size_t)tid >= lin.size()) return;
+        if (end <= beg) end = beg + 1;
+        auto& v = lin[(size_t)tid];
+        const size_t w0 = (size_t)(beg >> 14), w1 = (size_t)((end - 1) >> 14);
+        if (v.size() <= w1) v.resize(w1 + 1, 0);
+        for (size_t w = w0; w <= w1; ++w) if (v[w] == 0 || voff < v[w]) v[w] = voff;
+    }
+};
+}
+extern "C" int lsio_build_bai(const char* bam_path, const char* bai_path) {
+    int fd = open(bam_path, O_RDONLY);
+    if (fd < 0) { set_err("cannot open %s", bam_path); return -1; }
+    struct stat sb;
+    if (fstat(fd, &sb) != 0 || sb.st_size <= 0) { close(fd); set_err("cannot stat %s", bam_path); return -1; }
+    const size_t fsize = (size_t)sb.st_size;
+    const uint8_t* file = (const uint8_t*)mmap(nullptr, fsize, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (file == (const uint8_t*)MAP_FAILED) { close(fd); set_err("cannot map %s", bam_path); return -1; }
+    auto bail = [&](int rc) { munmap((void*)file, fsize); close(fd); return rc; };
+    std::vector<uint8_t> buf; uint64_t buf_g0 = 0;           // unconsumed uncompressed bytes and the stream offset of the first of them
+    std::vector<uint64_t> blk_ustart, blk_coff;              // per block: where it starts in the uncompressed stream / in the file
+    size_t bptr = 0;
+    uint64_t utotal = 0; size_t off = 0;
+    bool header_done = false; uint32_t n_ref = 0;
+    BaiBuild bb;
+    std::vector<uint8_t> out(65536);
+    auto voffset = [&](uint64_t g) {
+        while (bptr + 1 < blk_ustart.size() && blk_ustart[bptr + 1] <= g) ++bptr;
+        return (blk_coff[bptr] << 16) | (g - blk_ustart[bptr]);
+    };
+    size_t p = 0;                                            // parse position inside buf
+    while (off < fsize) {
+        if (off + 18 > fsize) { set_err("%s: truncated BGZF block header", bam_path); return bail(-1); }
+        const uint8_t* h = file + off;
+        if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) { set_err("%s is not BGZF", bam_path); return bail(-1); }
+        const uint32_t xlen = rd16(h + 10);
+        uint32_t bsize = 0; bool found = false;
+        if (off + 12 + (size_t)xlen > fsize) { set_err("%s: truncated BGZF extra field", bam_path); return bail(-1); }
+        for (uint32_t q = 0; q + 4 <= xlen;) {
+            const uint8_t* sf = h + 12 + q; const uint32_t slen = rd16(sf + 2);
+            if (sf[0] == 'B' && sf[1] == 'C' && slen == 2 && q + 6 <= xlen) { bsize = rd16(sf + 4) + 1u; found = true; }
+            q += 4 + slen;
+        }
+        if (!found || bsize < xlen + 20u || off + bsize > fsize) { set_err("%s: corrupt BGZF block", bam_path); return bail(-1); }
+        const uint32_t usize = rd32(h + bsize - 4);
+        if (usize > 65536u) { set_err("%s: BGZF block of %u bytes", bam_path, usize); return bail(-1); }
+        if (usize) {
+            z_stream zs; memset(&zs, 0, sizeof zs);
+            if (inflateInit2(&zs, -15) != Z_OK) { set_err("zlib"); return bail(-1); }
+            zs.next_in = (Bytef*)(h + 12 + xlen); zs.avail_in = bsize - xlen - 20; zs.next_out = out.data(); zs.avail_out = usize;
+            const int rc = inflate(&zs, Z_FINISH); inflateEnd(&zs);
+            if (rc != Z_STREAM_END || zs.avail_out != 0) { set_err("%s: inflate failed", bam_path); return bail(-1); }
+            blk_ustart.push_back(utotal); blk_coff.push_back((uint64_t)off);
+            buf.insert(buf.end(), out.begin(), out.begin() + usize);
+            utotal += usize;
+        }
+        off += bsize;
+        // ---- what is complete in buf
+        const uint8_t* d = buf.data(); const size_t n = buf.size();
+        if (!header_done) {
+            if (n < 12) continue;
+            if (memcmp(d, "BAM\1", 4) != 0) { set_err("%s has no BAM magic", bam_path); return bail(-1); }
+            uint64_t q = 8 + (uint64_t)rd32(d + 4);
+            if (q + 4 > n) continue;
+            n_ref = rd32(d + q); q += 4;
+            bool complete = true;
+            for (uint32_t i = 0; i < n_ref; ++i) {
+                if (q + 4 > n) { complete = false; break; }
+                const uint64_t l_name = rd32(d + q);
+                if (q + 4 + l_name + 4 > n) { complete = false; break; }
+                q += 4 + l_name + 4;
+            }
+            if (!complete) continue;
+            bb.lin.assign(n_ref, {});
+            header_done = true; p = (size_t)q;
+        }
+        while (p + 4 <= n) {
+            const uint64_t bs = rd32(d + p);
+            if (bs < 32 || bs > (1u << 30)) { set_err("%s: record with block_size %llu", bam_path, (unsigned long long)bs); return bail(-1); }
+            if (p + 4 + bs > n) break;
+            const uint8_t* rec = d + p + 4;
+            if (!record_ok(rec, (uint32_t)bs)) { set_err("%s: record whose fields exceed its block_size", bam_path); return bail(-1); }
+            const int32_t tid = rdi32(rec), pos = rdi32(rec + 4);
+            const uint32_t n_cigar = rd16(rec + 12);
+            const uint8_t* cg = rec + 32 + rec[8];
+            int64_t rlen = 0;
+            for (uint32_t k = 0; k < n_cigar; ++k) { const uint32_t c = rd32(cg + 4ull * k); if (is_ref_op(c & 0xf)) rlen += c >> 4; }
+            if (tid >= 0 && pos >= 0) bb.add(tid, pos, (int64_t)pos + (rlen > 0 ? rlen : 1), voffset(buf_g0 + p));
+            p += 4 + (size_t)bs;
+        }
+        if (p > (1u << 22)) { buf.erase(buf.begin(), buf.begin() + (long)p); buf_g0 += p; p = 0; }
+    }
+    if (!header_done) { set_err("%s: truncated BAM header", bam_path); return bail(-1); }
+    FILE* f = fopen(bai_path, "wb");
+    if (!f) { set_err("cannot write %s", bai_path); return bail(-1); }
+    auto w32 = [&](uint32_t x) { fwrite(&x, 4, 1, f); };
+    fwrite("BAI\1", 1, 4, f); w32(n_ref);
+    for (uint32_t r = 0; r < n_ref; ++r) {
+        auto& v = bb.lin[r];
+        uint64_t first = 0; for (uint64_t x : v) if (x) { first = x; break; }
+        for (size_t w = 0; w < v.size(); ++w) if (v[w] == 0) v[w] = w ? v[w - 1] : first;
+        w32(0); w32((uint32_t)v.size());
+        if (!v.empty()) fwrite(v.data(), 8, v.size(), f);
+    }
+    const bool ok = fclose(f) == 0;
+    if (!ok) set_err("write to %s failed", bai_path);
+    return bail(ok ? 0 : -1);
+}

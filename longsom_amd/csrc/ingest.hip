@@ -51,14 +51,15 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t* comp, const IngBl
 
 // in[b]: where block b's chain is taken to start (global offset into the uncompressed stream); out: records that start at or after
 // in[b] and before the block's end, and where the chain lands at or after that end
-__global__ void k_chain(const uint8_t* u, uint64_t total, const IngBlk* blk, uint32_t n_blk, const uint64_t* in, uint64_t* land, uint32_t* nrec, uint32_t* status) {
+// (range: the buffer is a slice of a file — its last record may be cut, which is not an error: lsg_load_bam_range)
+__global__ void k_chain(const uint8_t* u, uint64_t total, const IngBlk* blk, uint32_t n_blk, const uint64_t* in, uint64_t* land, uint32_t* nrec, uint32_t* status, int range) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= n_blk) return;
     const uint64_t end = blk[b].uoff + blk[b].usize;
     uint64_t p = in[b];
     uint32_t n = 0;
     while (p < end) {
-        if (p + 4 > total) { atomicOr(status, 2u); break; }
+        if (p + 4 > total) { if (!range) atomicOr(status, 2u); break; }
         const uint32_t bs = lsr::rd32(u + p);
         if (bs < 32 || bs > (1u << 30)) { atomicOr(status, 4u); break; }      // (only a wrong guess of in[b] or a corrupt file gets here)
         ++n; p += 4ull + bs;
@@ -87,29 +88,36 @@ struct RecArgs {
     unsigned long long* counters;         // total, pass, cb_not_found, cb_not_matched, mapq
     unsigned long long* cb_pass; unsigned long long* cb_low; int64_t n_tally;
     uint32_t* status;
+    int32_t range;                        // lsg_load_bam_range: a record cut by the end of the slice is skipped; SplitBam's counters and the tallies take the
+    int64_t count_lo, count_hi;           //   records whose (tid << 32 | pos) lies in [count_lo, count_hi) only (the neighbouring slices count the others)
+    unsigned long long* last_key;         // largest (tid << 32 | pos) of a complete record (2^63 - 1 for a read without a reference: they end the file)
 };
 __global__ void k_rec_info(RecArgs a) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned long long c_total = 0, c_pass = 0, c_nf = 0, c_nm = 0, c_low = 0;
+    unsigned long long c_total = 0, c_pass = 0, c_nf = 0, c_nm = 0, c_low = 0, my_key = 0;
     if (i < a.n_rec) {
         const uint64_t p = a.rec_off[i];
         const uint32_t bs = lsr::rd32(a.u + p);
         const uint8_t* rec = a.u + p + 4;
         uint8_t keep = 0; int32_t id = -1; uint32_t nseg = 0, nev = 0;
-        if (p + 4ull + bs > a.total) atomicOr(a.status, 2u);
+        if (p + 4ull + bs > a.total) { if (!a.range) atomicOr(a.status, 2u); }
         else {
             const int v = lsr::validate(rec, bs, a.n_ref, a.ref_len);
+            const int32_t tid = (int32_t)lsr::rd32(rec);
+            const int64_t key = tid >= 0 ? ((int64_t)tid << 32) | (int64_t)(uint32_t)lsr::rd32(rec + 4) : INT64_MAX;
+            my_key = (unsigned long long)key;
+            const bool mine = key >= a.count_lo && key < a.count_hi;
             if (v != lsr::REC_OK) { atomicOr(a.status, 8u); atomicMin(a.status + 2, (uint32_t)v); }
-            else if ((int32_t)lsr::rd32(rec) >= 0) {                     // infile.fetch() iterates reads placed on a reference
-                ++c_total;
+            else if (tid >= 0) {                                          // infile.fetch() iterates reads placed on a reference
+                if (mine) ++c_total;
                 const uint32_t mapq = rec[9], n_cigar = lsr::rd16(rec + 12), flag = lsr::rd16(rec + 14);
                 uint32_t cb = 0, raw = 0, clean = 0;
-                if (!lsr::find_cb(rec, bs, &cb, &raw, &clean)) ++c_nf;                      // read.opt("CB"), SplitBamCellTypes.py:74-79
-                else if ((id = lsr::cb_lookup(a.cbt, rec + cb, clean)) < 0) ++c_nm;         // DICT[barcode], :83-90
+                if (!lsr::find_cb(rec, bs, &cb, &raw, &clean)) c_nf += mine;                // read.opt("CB"), SplitBamCellTypes.py:74-79
+                else if ((id = lsr::cb_lookup(a.cbt, rec + cb, clean)) < 0) c_nm += mine;   // DICT[barcode], :83-90
                 else {
                     const bool low = (int)mapq < a.min_mapq;                                 // report only: the store's load filter / the counts re-apply min_mq
-                    if (low) ++c_low; else ++c_pass;
-                    if ((int64_t)id < a.n_tally) atomicAdd(low ? &a.cb_low[id] : &a.cb_pass[id], 1ull);
+                    if (low) c_low += mine; else c_pass += mine;
+                    if (mine && (int64_t)id < a.n_tally) atomicAdd(low ? &a.cb_low[id] : &a.cb_pass[id], 1ull);
                     if (!(flag & 0x4) && n_cigar) {
                         const lsr::Shape sh = lsr::walk<false>(rec, a.legacy, 0, 1, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr);
                         if (sh.n_events >= (1ull << 31)) atomicOr(a.status, 16u);
@@ -123,8 +131,10 @@ __global__ void k_rec_info(RecArgs a) {
     // SplitBam's counters (SplitBamCellTypes.py:62,117-124): one atomic per wave and counter
     for (int o = 32; o > 0; o >>= 1) {
         c_total += __shfl_down(c_total, o); c_pass += __shfl_down(c_pass, o); c_nf += __shfl_down(c_nf, o); c_nm += __shfl_down(c_nm, o); c_low += __shfl_down(c_low, o);
+        const unsigned long long k2 = __shfl_down(my_key, o); my_key = k2 > my_key ? k2 : my_key;
     }
     if ((threadIdx.x & 63) == 0) {
+        if (my_key) atomicMax(a.last_key, my_key);
         if (c_total) atomicAdd(&a.counters[0], c_total);
         if (c_pass) atomicAdd(&a.counters[1], c_pass);
         if (c_nf) atomicAdd(&a.counters[2], c_nf);
@@ -169,9 +179,10 @@ using namespace lsg;
 
 extern "C" {
 
-int lsg_load_bam(lsg_ctx* c, const uint8_t* file, int64_t n_bytes, int64_t first_record_offset, const char* barcodes, int32_t n_barcodes, const int32_t* ids,
-                 int32_t min_mapq, int32_t legacy_del_merge, lsg_bam_info* info, int64_t* cb_pass_out, int64_t* cb_low_out, int64_t n_tally_out) {
-    if (!c || !file || n_bytes < 28 || !info || first_record_offset < 12) { set_error("lsg_load_bam: bad arguments"); return -2; }
+static int load_bam_impl(lsg_ctx* c, const uint8_t* file, int64_t n_bytes, int64_t first_record_offset, const char* barcodes, int32_t n_barcodes, const int32_t* ids,
+                         int32_t min_mapq, int32_t legacy_del_merge, int range, int64_t count_lo, int64_t count_hi, lsg_bam_info* info, int64_t* cb_pass_out, int64_t* cb_low_out,
+                         int64_t n_tally_out) {
+    if (!c || !file || n_bytes < 28 || !info || first_record_offset < (range ? 0 : 12)) { set_error("lsg_load_bam: bad arguments"); return -2; }
     if (c->n_contigs <= 0) { set_error("lsg_load_bam: set the contigs (the BAM header's reference table) first"); return -2; }
     if (n_barcodes <= 0) { set_error("lsg_load_bam: a barcode list is needed (the every-CB-is-a-cell mode is the host decoder's)"); return -2; }
     LSG_HIP(hipSetDevice(c->device));
@@ -287,7 +298,7 @@ int lsg_load_bam(lsg_ctx* c, const uint8_t* file, int64_t n_bytes, int64_t first
         }
         ING_HIP(hipMemsetAsync(status, 0, 4, st));
         ING_HIP(hipMemsetAsync(changed, 0, 4, st));
-        hipLaunchKernelGGL(k_chain, dim3((n_blk + 255) / 256), dim3(256), 0, st, u, utotal, dblk, n_blk, in, land, d_nrec.as<uint32_t>(), status);
+        hipLaunchKernelGGL(k_chain, dim3((n_blk + 255) / 256), dim3(256), 0, st, u, utotal, dblk, n_blk, in, land, d_nrec.as<uint32_t>(), status, range);
         hipLaunchKernelGGL(k_chain_fix, dim3((n_blk + 255) / 256), dim3(256), 0, st, dblk, n_blk, (uint64_t)first_record_offset, in, land, changed);
         ING_HIP(hipMemcpyAsync(hstat, status, 16, hipMemcpyDeviceToHost, st));
         ING_HIP(hipStreamSynchronize(st));
@@ -298,7 +309,7 @@ int lsg_load_bam(lsg_ctx* c, const uint8_t* file, int64_t n_bytes, int64_t first
         uint64_t last_land = 0;
         ING_HIP(hipMemcpyAsync(&last_land, land + (n_blk - 1), 8, hipMemcpyDeviceToHost, st));
         ING_HIP(hipStreamSynchronize(st));
-        if (last_land != utotal) { set_error("lsg_load_bam: truncated record at the end of the file"); return done_ev(-1); }
+        if (!range && last_land != utotal) { set_error("lsg_load_bam: truncated record at the end of the file"); return done_ev(-1); }
     }
     ING_HIP(hipEventRecord(ev[3], st));
     uint32_t n_rec32 = 0;
@@ -326,6 +337,7 @@ int lsg_load_bam(lsg_ctx* c, const uint8_t* file, int64_t n_bytes, int64_t first
         ra.keep = d_keep.as<uint8_t>(); ra.cb = d_cb.as<int32_t>(); ra.nseg = d_nseg.as<uint32_t>(); ra.nev = d_nev.as<uint32_t>();
         ra.counters = d_cnt.as<unsigned long long>(); ra.cb_pass = d_tpass.as<unsigned long long>(); ra.cb_low = d_tlow.as<unsigned long long>(); ra.n_tally = n_tally;
         ra.status = status;
+        ra.range = range; ra.count_lo = count_lo; ra.count_hi = count_hi; ra.last_key = d_cnt.as<unsigned long long>() + 6;
         ING_HIP(hipMemsetAsync(status, 0, 4, st));
         hipLaunchKernelGGL(k_rec_info, dim3((unsigned)((n_rec + 255) / 256)), dim3(256), 0, st, ra);
         ING_HIP(hipMemcpyAsync(hstat, status, 16, hipMemcpyDeviceToHost, st));
@@ -385,7 +397,7 @@ int lsg_load_bam(lsg_ctx* c, const uint8_t* file, int64_t n_bytes, int64_t first
     }
     ING_HIP(hipEventRecord(ev[4], st));
     unsigned long long cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    ING_HIP(hipMemcpyAsync(cnt, d_cnt.p, 40, hipMemcpyDeviceToHost, st));
+    ING_HIP(hipMemcpyAsync(cnt, d_cnt.p, 56, hipMemcpyDeviceToHost, st));
     if (cb_pass_out && cb_low_out) {
         const int64_t n_copy = n_tally < n_tally_out ? n_tally : n_tally_out;
         for (int64_t i = 0; i < n_tally_out; ++i) { cb_pass_out[i] = 0; cb_low_out[i] = 0; }
@@ -413,8 +425,20 @@ int lsg_load_bam(lsg_ctx* c, const uint8_t* file, int64_t n_bytes, int64_t first
     info->ms_h2d = ms[0]; info->ms_inflate = ms[1]; info->ms_chain = ms[2]; info->ms_decode = ms[3];
     info->ms_store = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_store).count();
     info->ms_total = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_all).count();
+    info->last_key = n_rec ? (int64_t)cnt[6] : -1;
     return done_ev(0);
 #undef ING_HIP
+}
+
+int lsg_load_bam(lsg_ctx* c, const uint8_t* file, int64_t n_bytes, int64_t first_record_offset, const char* barcodes, int32_t n_barcodes, const int32_t* ids,
+                 int32_t min_mapq, int32_t legacy_del_merge, lsg_bam_info* info, int64_t* cb_pass_out, int64_t* cb_low_out, int64_t n_tally_out) {
+    return load_bam_impl(c, file, n_bytes, first_record_offset, barcodes, n_barcodes, ids, min_mapq, legacy_del_merge, 0, INT64_MIN, INT64_MAX, info, cb_pass_out, cb_low_out, n_tally_out);
+}
+
+int lsg_load_bam_range(lsg_ctx* c, const uint8_t* slice, int64_t n_bytes, int64_t first_record_offset, const char* barcodes, int32_t n_barcodes, const int32_t* ids,
+                       int32_t min_mapq, int32_t legacy_del_merge, int64_t count_lo_key, int64_t count_hi_key, lsg_bam_info* info, int64_t* cb_pass_out, int64_t* cb_low_out,
+                       int64_t n_tally_out) {
+    return load_bam_impl(c, slice, n_bytes, first_record_offset, barcodes, n_barcodes, ids, min_mapq, legacy_del_merge, 1, count_lo_key, count_hi_key, info, cb_pass_out, cb_low_out, n_tally_out);
 }
 
 } // extern "C"

@@ -42,6 +42,10 @@ class ReadRecords:
         assert len(self.read_pos) == len(self.read_tid) == len(self.read_flag) == len(self.read_mapq) == len(self.read_cb)
         assert len(self.seg_start) == len(self.seg_read) == len(self.seg_len) == len(self.seg_ev_off)
 
+    @classmethod
+    def empty(cls) -> "ReadRecords":
+        return cls(*[np.zeros(0, dt) for _, dt in cls._SPEC])
+
     @property
     def n_reads(self): return len(self.read_tid)
     @property
@@ -192,6 +196,25 @@ class Engine:
                     del buf
         d = {k: getattr(info, k) for k, _ in BamInfo._fields_ if k != "pad_"}
         return d, cb_pass, cb_low
+
+    def load_bam_range(self, slice_bytes: np.ndarray, first_record_offset: int, barcodes, min_mapq: int, count_lo_key: int, count_hi_key: int,
+                       legacy_del_merge: Optional[bool] = None):
+        """lsg_load_bam_range: a slice of whole BGZF blocks of a coordinate-sorted BAM (uint8 array, e.g. a view of a memory map), a record
+        starting at first_record_offset of its first block; the counters and tallies take the records with (tid << 32 | pos) in
+        [count_lo_key, count_hi_key).  Returns what load_bam returns; info["last_key"] = key of the slice's last complete record."""
+        from . import hostio
+        from ._lib import BamInfo
+        if legacy_del_merge is None:
+            legacy_del_merge = bool(hostio.load().lsio_get_legacy_del_merge())
+        joined = "\n".join(barcodes).encode()
+        n_cb = len(barcodes)
+        info = BamInfo()
+        cb_pass = np.zeros(n_cb, np.int64); cb_low = np.zeros(n_cb, np.int64)
+        buf = np.ascontiguousarray(slice_bytes, dtype=np.uint8)
+        _lib.check(self._lib.lsg_load_bam_range(self._h, C.c_void_p(buf.ctypes.data), len(buf), int(first_record_offset), joined, n_cb, None, int(min_mapq),
+                                                1 if legacy_del_merge else 0, int(count_lo_key), int(count_hi_key), C.byref(info), _ptr(cb_pass), _ptr(cb_low), n_cb),
+                   "lsg_load_bam_range")
+        return {k: getattr(info, k) for k, _ in BamInfo._fields_ if k != "pad_"}, cb_pass, cb_low
 
     def set_region(self, tid_lo=0, pos_lo=0, tid_hi=None, pos_hi=0):
         """Count only columns in [(tid_lo,pos_lo), (tid_hi,pos_hi)) — window sharding across GPUs."""

@@ -54,6 +54,8 @@ def load():
         lib.lsio_barcode.argtypes = [C.c_uint64, C.c_int64, C.c_char_p]
         lib.lsio_split_bam.restype = C.c_int
         lib.lsio_split_bam.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.c_void_p, C.c_int32, C.c_char_p, C.c_int32, C.c_void_p]
+        lib.lsio_build_bai.restype = C.c_int
+        lib.lsio_build_bai.argtypes = [C.c_char_p, C.c_char_p]
         lib.lsio_set_legacy_del_merge.argtypes = [C.c_int]
         lib.lsio_get_legacy_del_merge.restype = C.c_int
         _lib = lib
@@ -328,3 +330,43 @@ def write_barcodes_tsv(path: str, barcodes: Sequence[str], celltype_of, celltype
         f.write("Index\tCell_type\n")
         for b, c in zip(barcodes, celltype_of):
             f.write("%s%s\t%s\n" % (b, suffix, celltype_names[int(c)]))
+
+
+# ---- the BAM index (.bai): linear index only ---------------------------------------------------------------------------------------
+def build_bai(bam: str, bai: Optional[str] = None) -> str:
+    """writes <bam>.bai with the linear index of a coordinate-sorted BAM (lsio_build_bai; no binning index — what samtools index
+    writes has both, read_bai takes either).  For the synthetic and fixture BAMs: real data comes with its .bai (rules/SNVCalling.smk:6-7)."""
+    lib = load()
+    bai = bai or bam + ".bai"
+    if lib.lsio_build_bai(os.fsencode(bam), os.fsencode(bai)) != 0:
+        raise RuntimeError(lib.lsio_last_error().decode("utf-8", "replace"))
+    return bai
+
+
+def find_bai(bam: str) -> Optional[str]:
+    for p in (bam + ".bai", os.path.splitext(bam)[0] + ".bai"):
+        if os.path.exists(p):
+            return p
+    return None
+
+
+def read_bai(path: str) -> List[np.ndarray]:
+    """per reference, the linear index of a .bai (SAM specification 5.2): ioffset[w] = smallest virtual offset (block start << 16 |
+    offset inside the block) of the alignments overlapping the 16 kb window w, 0 = none recorded.  The binning index is skipped."""
+    import struct
+    with open(path, "rb") as f:
+        data = f.read()
+    if data[:4] != b"BAI\x01":
+        raise ValueError("%s is not a BAI file" % path)
+    (n_ref,) = struct.unpack_from("<i", data, 4)
+    at = 8
+    out = []
+    for _ in range(n_ref):
+        (n_bin,) = struct.unpack_from("<i", data, at); at += 4
+        for _ in range(n_bin):
+            _, n_chunk = struct.unpack_from("<Ii", data, at); at += 8 + 16 * n_chunk
+        (n_intv,) = struct.unpack_from("<i", data, at); at += 4
+        out.append(np.frombuffer(data, dtype="<u8", count=n_intv, offset=at).copy()); at += 8 * n_intv
+        if at > len(data):
+            raise ValueError("%s is truncated" % path)
+    return out

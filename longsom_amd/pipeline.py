@@ -397,20 +397,54 @@ def _run_snv_regions(bam, barcodes_tsv, ref_fasta, out_dir, sample_id, params, e
             names_b, lens_b, first_rec = hostio.bam_header(bam)
             hdr = hostio.DecodedBam(None, names_b, np.asarray(lens_b, np.int64), {})
             setup(hdr)
-            try:
-                info, cb_pass, cb_low = eng.load_bam(bam, bc.barcodes, min_mapq=params.min_mapping_quality, first_record_offset=first_rec)
-                rep = {"Total_reads": int(info["total_reads"]), "Pass_reads": int(info["pass_reads"]), "CB_not_found": int(info["cb_not_found"]),
-                       "CB_not_matched": int(info["cb_not_matched"])}
-                if info["mapq_filtered"]:
-                    rep["MAPQ"] = int(info["mapq_filtered"])
-                dec = hostio.DecodedBam(None, names_b, np.asarray(lens_b, np.int64), rep, None, cb_pass, cb_low)
-                bounds = regions.balanced_boundaries(eng.reads_to_host(events=False), len(names_b), comm.world)
+            keys = ("total_reads", "pass_reads", "cb_not_found", "cb_not_matched", "mapq_filtered")
+
+            def report_of(counts):
+                rep = {"Total_reads": int(counts[0]), "Pass_reads": int(counts[1]), "CB_not_found": int(counts[2]), "CB_not_matched": int(counts[3])}
+                if counts[4]:
+                    rep["MAPQ"] = int(counts[4])
+                return rep
+            bai = hostio.find_bai(bam) if os.environ.get("LONGSOM_SHARD_INGEST", "1") != "0" else None
+            if bai is not None:
+                # every rank ingests the SLICE of the file its region needs, found through the .bai's linear index (regions.BaiPlan), as the
+                # reference's workers fetch their window through the index; SplitBam's counters are summed over the ranks (each record is
+                # counted by the rank whose region holds its start).  Any rank that cannot (records not aligned to the blocks of its
+                # slice) takes every rank to the whole-file path below: the ranks agree first.
+                plan = regions.BaiPlan(hostio.read_bai(bai), len(names_b), comm.world, os.path.getsize(bam))
+                bounds = plan.bounds
                 lo, hi = bounds[comm.rank], bounds[comm.rank + 1]
-                mine = None                                   # the rank's store holds the whole file; lsg_set_region makes the columns its own
-            except _lib.LsgError as e:
-                if os.environ.get("LONGSOM_INGEST", "auto") == "device" or "straddle" not in str(e):
-                    raise
-                dec = None
+                got, ok = None, 1
+                try:
+                    got = regions.ingest_slice(eng, bam, plan, lo, hi, bc.barcodes, params.min_mapping_quality)
+                except _lib.LsgError as e:
+                    if "straddle" not in str(e):
+                        raise
+                    ok = 0
+                n_cb = len(bc.barcodes)
+                if int(comm.allreduce_sum(np.asarray([ok], np.int64))[0]) == comm.world:
+                    counts = np.zeros(5 + 2 * n_cb + 2 * comm.world, np.int64)      # SplitBam's counters, the tallies, and per rank: records and bytes of its slice
+                    if got is not None:
+                        info, cb_pass, cb_low = got
+                        counts[:5] = [info[k] for k in keys]; counts[5:5 + n_cb] = cb_pass; counts[5 + n_cb:5 + 2 * n_cb] = cb_low
+                        counts[5 + 2 * n_cb + comm.rank] = info["n_records"]; counts[5 + 2 * n_cb + comm.world + comm.rank] = info["slice_bytes"]
+                    else:
+                        eng.load_reads(hostio.ReadRecords.empty())      # (no alignment in this rank's region)
+                    counts = comm.allreduce_sum(counts)
+                    t["ingest_records_by_rank"] = counts[5 + 2 * n_cb:5 + 2 * n_cb + comm.world].tolist()
+                    t["ingest_slice_MB_by_rank"] = [round(x / 1e6, 3) for x in counts[5 + 2 * n_cb + comm.world:].tolist()]
+                    dec = hostio.DecodedBam(None, names_b, np.asarray(lens_b, np.int64), report_of(counts), None, counts[5:5 + n_cb].copy(), counts[5 + n_cb:5 + 2 * n_cb].copy())
+                    mine = None
+            if dec is None:
+                try:
+                    info, cb_pass, cb_low = eng.load_bam(bam, bc.barcodes, min_mapq=params.min_mapping_quality, first_record_offset=first_rec)
+                    dec = hostio.DecodedBam(None, names_b, np.asarray(lens_b, np.int64), report_of([info[k] for k in keys]), None, cb_pass, cb_low)
+                    bounds = regions.balanced_boundaries(eng.reads_to_host(events=False), len(names_b), comm.world)
+                    lo, hi = bounds[comm.rank], bounds[comm.rank + 1]
+                    mine = None                                   # the rank's store holds the whole file; lsg_set_region makes the columns its own
+                except _lib.LsgError as e:
+                    if os.environ.get("LONGSOM_INGEST", "auto") == "device" or "straddle" not in str(e):
+                        raise
+                    dec = None
         if dec is None:
             dec = hostio.decode_bam(bam, bc.barcodes, min_mapq=params.min_mapping_quality, threads=max(1, (os.cpu_count() or 1) // comm.world))
             bounds = regions.balanced_boundaries(dec.records, len(dec.contig_names), comm.world)

@@ -61,6 +61,97 @@ def balanced_boundaries(rec: ReadRecords, n_contigs: int, world: int) -> List[Po
     return bounds
 
 
+# ---- a coordinate-sorted BAM cut by its .bai ------------------------------------------------------------------------------------------
+BAI_WINDOW = 16384
+
+
+class BaiPlan:
+    """The ranks' regions and file slices from the linear index of a .bai (hostio.read_bai): ioffset[tid][w] = smallest virtual offset
+    (BGZF block start << 16 | offset inside the block) of the alignments overlapping the 16 kb window w.  Because the file is sorted by
+    start, that offset is also at or before every alignment that overlaps any LATER window: a slice that starts there misses nothing a
+    region starting at window w needs.  Regions are balanced by compressed bytes (the offsets themselves), boundaries at window starts
+    (multiples of 64, as lsg_set_region wants).  What replaces: the reference's workers fetching their 50 kb window through the index
+    (BaseCellCounter.py:190-191)."""
+
+    def __init__(self, lin, n_contigs: int, world: int, file_size: int):
+        tid, w, voff = [], [], []
+        for t, v in enumerate(lin[:n_contigs]):
+            nz = np.nonzero(v)[0]
+            tid.append(np.full(len(nz), t, np.int64)); w.append(nz.astype(np.int64)); voff.append(np.asarray(v)[nz].astype(np.uint64))
+        self.tid = np.concatenate(tid) if tid else np.zeros(0, np.int64)
+        self.w = np.concatenate(w) if w else np.zeros(0, np.int64)
+        self.voff = np.concatenate(voff) if voff else np.zeros(0, np.uint64)
+        self.key = (self.tid << 32) | self.w
+        self.n_contigs, self.world, self.file_size = n_contigs, world, int(file_size)
+        coff = (self.voff >> np.uint64(16)).astype(np.int64)
+        bounds: List[Pos] = [(0, 0)]
+        for r in range(1, world):
+            i = int(np.searchsorted(coff, self.file_size * r // world, side="left")) if len(coff) else 0
+            b = (int(self.tid[i]), int(self.w[i]) * BAI_WINDOW) if i < len(coff) else (n_contigs, 0)
+            bounds.append(max(b, bounds[-1]))
+        bounds.append((n_contigs, 0))
+        self.bounds = bounds
+
+    def _at_or_after(self, tid: int, w: int) -> Optional[int]:
+        i = int(np.searchsorted(self.key, (int(tid) << 32) | int(w), side="left"))
+        return i if i < len(self.key) else None
+
+    def start(self, lo: Pos) -> Optional[int]:
+        """virtual offset at which the slice of a region starting at lo begins (None: no alignment at or after lo)"""
+        i = self._at_or_after(lo[0], lo[1] // BAI_WINDOW)
+        return None if i is None else int(self.voff[i])
+
+    def end(self, hi: Pos, attempt: int) -> Optional[int]:
+        """a virtual offset expected to lie past the first alignment starting at or after hi (None: go to the end of the file); the
+        caller checks (lsg_bam_info.last_key) and comes back with the next attempt when a long alignment made it too short"""
+        if hi[0] >= self.n_contigs:
+            return None
+        i = self._at_or_after(hi[0], hi[1] // BAI_WINDOW + (4 << attempt))
+        return None if i is None else int(self.voff[i])
+
+
+def _bgzf_block_end(mm, coff: int) -> int:
+    """end (file offset) of the BGZF block that starts at coff"""
+    h = bytes(mm[coff:coff + 18 + 64])
+    if len(h) < 18 or h[0] != 31 or h[1] != 139 or not (h[3] & 4):
+        raise ValueError("the .bai points at offset %d, which is not a BGZF block: index and BAM do not belong together" % coff)
+    xlen = h[10] | (h[11] << 8)
+    q = 0
+    while q + 4 <= xlen and 12 + q + 4 <= len(h):
+        sf = h[12 + q:12 + q + 4]
+        slen = sf[2] | (sf[3] << 8)
+        if sf[0:2] == b"BC" and slen == 2:
+            return coff + (h[12 + q + 4] | (h[12 + q + 5] << 8)) + 1
+        q += 4 + slen
+    raise ValueError("BGZF block at offset %d has no BC field" % coff)
+
+
+def ingest_slice(engine, bam: str, plan: BaiPlan, lo: Pos, hi: Pos, barcodes, min_mapq: int):
+    """the reads a rank needs for the region [lo, hi), from the slice of the BAM the index points at, ingested on the rank's GPU
+    (lsg_load_bam_range).  Returns (info, cb_pass, cb_low) as Engine.load_bam; info["slice_bytes"] = bytes of the file that were read."""
+    import mmap
+    lo_key, hi_key = (lo[0] << 32) | lo[1], (hi[0] << 32) | hi[1]
+    v0 = plan.start(lo) if lo < hi else None
+    if v0 is None:
+        return None
+    with open(bam, "rb") as f, mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ) as mm:
+        c0, u0 = v0 >> 16, v0 & 0xFFFF
+        attempt = 0
+        while True:
+            v1 = plan.end(hi, attempt)
+            c1 = len(mm) if v1 is None else _bgzf_block_end(mm, v1 >> 16)
+            buf = np.frombuffer(mm, dtype=np.uint8, count=c1 - c0, offset=c0)
+            try:
+                info, cb_pass, cb_low = engine.load_bam_range(buf, u0, barcodes, min_mapq, lo_key, hi_key)
+            finally:
+                del buf
+            if v1 is None or info["last_key"] >= hi_key:
+                info["slice_bytes"] = c1 - c0
+                info["attempts"] = attempt + 1
+                return info, cb_pass, cb_low
+            attempt += 1
+
+
 def reads_overlapping(rec: ReadRecords, lo: Pos, hi: Pos, ends: Optional[np.ndarray] = None) -> np.ndarray:
     """mask of the reads with a pileup column in [lo, hi) — a superset is fine (the device counts only the region's columns)"""
     ends = read_ends(rec) if ends is None else ends
@@ -135,6 +226,17 @@ class Comm:
         if self.grouped:
             import torch.distributed as dist
             dist.barrier()
+
+    def allreduce_sum(self, values: np.ndarray) -> np.ndarray:
+        """element-wise sum over the ranks of an int64 array (SplitBam's counters of a sharded ingest); every rank gets the result"""
+        values = np.ascontiguousarray(values, np.int64)
+        if not self.grouped:
+            return values
+        import torch
+        import torch.distributed as dist
+        t = torch.from_numpy(values.copy()).to(self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t.cpu().numpy()
 
     def allgather_bytes(self, payload: bytes) -> List[bytes]:
         """every rank's payload on every rank: one all-gather of the lengths, one of the padded bytes"""

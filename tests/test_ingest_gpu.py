@@ -103,3 +103,58 @@ def test_damaged_files_are_errors(engine, tmp_path):
     # the handle is usable afterwards
     engine.load_bam(os.path.join(G, "pileup.rand.bam"), bc.barcodes, first_record_offset=first)
     assert engine.reads_shape()[0] == 1333
+
+
+@pytest.mark.parametrize("source", ["rand", "synth"])
+@pytest.mark.parametrize("world", [2, 5])
+def test_slices_of_an_indexed_bam_add_up_to_the_whole(engine, tmp_path, source, world):
+    """lsg_load_bam_range over the slices regions.BaiPlan cuts from the .bai's linear index: every region's rows are the whole file's
+    rows inside the region, SplitBam's counters and the per-barcode tallies add up to the whole file's — on the reference-pinned sample
+    (records straddle its blocks: a slice starts INSIDE a block, its last record is cut) and on an htslib-like 20 k-read BAM"""
+    import shutil
+    from longsom_amd import regions, tsvio
+    bam = str(tmp_path / "a.bam")
+    if source == "rand":
+        shutil.copy(os.path.join(G, "pileup.rand.bam"), bam)
+        bc = hostio.read_barcodes(os.path.join(G, "pileup.rand.barcodes.tsv"))
+        barcodes, celltype_of = bc.barcodes, bc.celltype_of
+        _, seqs = tsvio.read_fasta(os.path.join(G, "pileup.rand.fa"))
+        refs = [np.frombuffer(bytes(x), dtype=np.uint8) for x in seqs]
+    else:
+        m = synth.named("C1", n_reads=20000, n_genes=50, n_cb=80, snp_mod=150)
+        hostio.synth_bam(m, bam, str(tmp_path / "ref.fa"))
+        barcodes, celltype_of = hostio.synth_barcodes(m), m.celltype_of
+        _, seqs = tsvio.read_fasta(str(tmp_path / "ref.fa"))
+        refs = [np.frombuffer(bytes(x), dtype=np.uint8) for x in seqs]
+    names, lens, first = hostio.bam_header(bam)
+    engine.set_contigs(lens)
+    for t, r in enumerate(refs):
+        engine.load_reference(t, r)
+    engine.set_barcodes(celltype_of, 2)
+    engine.set_region()
+    info_w, pass_w, low_w = engine.load_bam(bam, barcodes, min_mapq=60, first_record_offset=first)
+    engine.pileup_count()
+    whole = [engine.fetch_counts(ct) for ct in range(2)]
+    plan = regions.BaiPlan(hostio.read_bai(hostio.build_bai(bam)), len(names), world, os.path.getsize(bam))
+    keys = ("total_reads", "pass_reads", "cb_not_found", "cb_not_matched", "mapq_filtered")
+    tot = dict.fromkeys(keys, 0); cb_pass = np.zeros_like(pass_w); cb_low = np.zeros_like(low_w)
+    parts = [[], []]
+    for r in range(world):
+        lo, hi = plan.bounds[r], plan.bounds[r + 1]
+        got = regions.ingest_slice(engine, bam, plan, lo, hi, barcodes, 60)
+        if got is None:
+            continue
+        info, p, l = got
+        for k in keys:
+            tot[k] += info[k]
+        cb_pass += p; cb_low += l
+        engine.set_region(lo[0], lo[1], hi[0], hi[1])
+        engine.pileup_count()
+        for ct in range(2):
+            parts[ct].append(engine.fetch_counts(ct))
+    engine.set_region()
+    assert tot == {k: info_w[k] for k in keys}
+    np.testing.assert_array_equal(cb_pass, pass_w); np.testing.assert_array_equal(cb_low, low_w)
+    for ct in range(2):
+        for j in range(3):
+            np.testing.assert_array_equal(np.concatenate([x[j] for x in parts[ct]]), whole[ct][j])

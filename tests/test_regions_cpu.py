@@ -115,3 +115,42 @@ def test_allgather_bytes_over_gloo():
         assert p.exitcode == 0
     want = "late row 1\nlate row 2\nrow of rank 1\nrow of rank 2\n"       # (chr1, 5001), (chr1, 5002), (chr2, 101), (chr3, 201)
     assert res == {0: want, 1: want, 2: want}
+
+
+def test_bai_reader_skips_the_binning_index_and_the_builder_round_trips(tmp_path):
+    """read_bai on a hand-made .bai as samtools writes it (bins with chunks, the metadata pseudo-bin, n_no_coor at the end), and
+    build_bai -> read_bai on the reference-pinned multi-contig BAM: the first window of the first contig points at the first record"""
+    import struct
+    from longsom_amd import hostio
+    raw = b"BAI\x01" + struct.pack("<i", 2)
+    raw += struct.pack("<i", 2) + struct.pack("<Ii", 4681, 1) + struct.pack("<QQ", 100 << 16, 200 << 16) + struct.pack("<Ii", 37450, 2) + struct.pack("<QQQQ", 1, 2, 3, 4)
+    raw += struct.pack("<i", 3) + struct.pack("<QQQ", (100 << 16) | 7, (100 << 16) | 7, (150 << 16) | 9)
+    raw += struct.pack("<i", 0) + struct.pack("<i", 0)
+    raw += struct.pack("<Q", 5)
+    p = tmp_path / "x.bai"
+    p.write_bytes(raw)
+    lin = hostio.read_bai(str(p))
+    assert [v.tolist() for v in lin] == [[(100 << 16) | 7, (100 << 16) | 7, (150 << 16) | 9], []]
+    import shutil
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    bam = str(tmp_path / "a.bam")
+    shutil.copy(os.path.join(G, "pileup.rand.bam"), bam)
+    lin = hostio.read_bai(hostio.build_bai(bam))
+    names, lens, first = hostio.bam_header(bam)
+    assert len(lin) == len(names) and [len(v) for v in lin] == [(int(l) + 16383) // 16384 for l in lens]
+    assert int(lin[0][0]) == first                                   # block 0, offset of the first record
+    flat = np.concatenate(lin)
+    assert (np.diff(flat.astype(np.int64)) >= 0).all()              # a sorted file: the windows' first alignments come in file order
+
+
+def test_bai_plan_regions_and_slices():
+    lin = [np.array([(10 << 16) | 5, (10 << 16) | 5, (400 << 16) | 1, (900 << 16) | 0], np.uint64), np.zeros(0, np.uint64), np.array([(1500 << 16) | 3], np.uint64)]
+    plan = regions.BaiPlan(lin, 3, 4, 2000)
+    assert plan.bounds[0] == (0, 0) and plan.bounds[-1] == (3, 0) and plan.bounds == sorted(plan.bounds)
+    assert plan.bounds[1] == (0, 3 * 16384) and plan.bounds[2] == (2, 0) and plan.bounds[3] == (2, 0)        # bytes 500, 1000, 1500 of 2000
+    assert plan.start((0, 0)) == (10 << 16) | 5 and plan.start((0, 3 * 16384)) == 900 << 16
+    assert plan.start((1, 0)) == (1500 << 16) | 3                   # nothing on contig 1: the next alignment in the file
+    assert plan.start((2, 16384)) is None and plan.end((3, 0), 0) is None
+    assert plan.end((0, 16384), 0) == (1500 << 16) | 3              # 4 windows further on contig 0 there is none: the next contig's first
+    one = regions.BaiPlan(lin, 3, 1, 2000)
+    assert one.bounds == [(0, 0), (3, 0)]

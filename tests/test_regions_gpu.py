@@ -77,3 +77,30 @@ def test_ranks_sharded_run_equals_whole_run(sample, world):
     assert r.returncode == 0, r.stderr[-3000:]
     assert '"ranks": %d' % world in r.stdout
     same_outputs(out_dir, whole)
+
+
+def test_ranks_ingest_only_their_slice_of_an_indexed_bam(sample, tmp_path):
+    """with a .bai beside the BAM every rank ingests the slice of the file its region needs (regions.BaiPlan, lsg_load_bam_range) — the
+    three ranks together read about the file once plus the reads that reach across the two boundaries, not three times the file —
+    SplitBam's counters are summed over the ranks, and every output file is the single-rank run's, byte for byte"""
+    import json
+    import shutil
+    bam0, fa, bct, whole, d = sample
+    bam = str(tmp_path / "S1.bam")
+    shutil.copy(bam0, bam)
+    hostio.build_bai(bam)
+    n_records = sum(int(x) for x in open(os.path.join(whole, "SplitBam/S1.report.txt")).read().split("\n")[1].split("\t")[:1])      # Total_reads
+    world = 3
+    out_dir = str(tmp_path / "ranks")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, LSG_DIST_BACKEND="gloo", LSG_DIST_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "workflow", "scripts_gpu", "SNVCalling", "longsom_gpu_snv.py"), "--bam", bam, "--meta", bct, "--ref", fa, "--id", "S1", "--outdir", out_dir]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    summary = json.loads([l for l in r.stdout.split("\n") if l.startswith("{")][-1])
+    by_rank = summary["seconds"]["ingest_records_by_rank"]
+    assert len(by_rank) == world and all(x > 0 for x in by_rank)
+    assert max(by_rank) < 0.6 * n_records and sum(by_rank) < 1.5 * n_records, (by_rank, n_records)
+    assert sum(summary["seconds"]["ingest_slice_MB_by_rank"]) < 1.5 * os.path.getsize(bam) / 1e6
+    same_outputs(out_dir, whole)
