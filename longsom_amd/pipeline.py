@@ -453,6 +453,32 @@ def _run_snv_regions(bam, barcodes_tsv, ref_fasta, out_dir, sample_id, params, e
         t["decode"] = time.time() - t0
         work = iter([(lo, hi, mine, dec)])
         report = dict(dec.report)
+    elif (os.environ.get("LONGSOM_INGEST", "auto") in ("device", "auto") and os.environ.get("LONGSOM_SHARD_INGEST", "1") != "0"
+          and hostio.find_bai(bam) is not None):
+        # windows of an INDEXED BAM: the regions a sharded run would give its ranks, taken one after the other by this one GPU — every
+        # window's slice of the file goes to the device as it is (regions.ingest_slice: no host decode, no carried reads: a slice
+        # holds every read that reaches into its region)
+        names_b, lens_b, first_rec = hostio.bam_header(bam)
+        first = hostio.DecodedBam(None, names_b, np.asarray(lens_b, np.int64), {})
+        n_win = max(1, -(-os.path.getsize(bam) * 3 // int(window_bytes)))          # (window_bytes counts uncompressed bytes: about a third as many in the file)
+        plan = regions.BaiPlan(hostio.read_bai(hostio.find_bai(bam)), len(names_b), n_win, os.path.getsize(bam))
+
+        def device_windows():
+            setup(first)
+            for r in range(n_win):
+                lo, hi = plan.bounds[r], plan.bounds[r + 1]
+                t0 = time.time()
+                got = regions.ingest_slice(eng, bam, plan, lo, hi, bc.barcodes, params.min_mapping_quality)
+                t["decode"] += time.time() - t0
+                if got is None:
+                    continue
+                info = got[0]
+                rep = {"Total_reads": int(info["total_reads"]), "Pass_reads": int(info["pass_reads"]), "CB_not_found": int(info["cb_not_found"]),
+                       "CB_not_matched": int(info["cb_not_matched"])}
+                if info["mapq_filtered"]:
+                    rep["MAPQ"] = int(info["mapq_filtered"])
+                yield lo, hi, None, hostio.DecodedBam(None, names_b, np.asarray(lens_b, np.int64), rep)
+        work = device_windows()
     else:
         batches = hostio.stream_bam(bam, bc.barcodes, min_mapq=params.min_mapping_quality, batch_bytes=int(window_bytes))
         first = next(batches, None)

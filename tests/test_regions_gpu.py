@@ -104,3 +104,18 @@ def test_ranks_ingest_only_their_slice_of_an_indexed_bam(sample, tmp_path):
     assert max(by_rank) < 0.6 * n_records and sum(by_rank) < 1.5 * n_records, (by_rank, n_records)
     assert sum(summary["seconds"]["ingest_slice_MB_by_rank"]) < 1.5 * os.path.getsize(bam) / 1e6
     same_outputs(out_dir, whole)
+
+
+@pytest.mark.parametrize("window_bytes", [300_000, 4_000_000])
+def test_windowed_run_of_an_indexed_bam_ingests_on_the_device(sample, tmp_path, window_bytes):
+    """with a .bai the windows are regions of the index and every window's slice of the file is ingested on the GPU (no host decode, no
+    carried reads): the files of the single-pass run"""
+    import shutil
+    bam0, fa, bct, whole, d = sample
+    bam = str(tmp_path / "S1.bam")
+    shutil.copy(bam0, bam)
+    hostio.build_bai(bam)
+    out_dir = str(tmp_path / "win")
+    out = pipeline.run_snv(bam, bct, fa, out_dir, "S1", window_bytes=window_bytes)
+    assert out.timings["windows"] >= (5 if window_bytes < 1_000_000 else 1)
+    same_outputs(out_dir, whole)
