@@ -387,7 +387,14 @@ def _step3_survivors(text: bytes, i_ct: int) -> Optional[bytes]:
     return tsvio.gather_lines(text, sc.off[keep], sc.len[keep])[0]
 
 
-def step3(step2_text, delta_vaf: float, delta_mcf: float, min_ac_reads: int, min_ac_cells: int, clust_dist: int):
+def step3_bytes(step2_text, delta_vaf: float, delta_mcf: float, min_ac_reads: int, min_ac_cells: int, clust_dist: int):
+    """step3 with both tables as bytes (what the fused pipeline writes: at C2's size the unfiltered table is 0.8 GB, not worth a decode
+    and an encode)"""
+    final, unfiltered = step3(step2_text, delta_vaf, delta_mcf, min_ac_reads, min_ac_cells, clust_dist, _as_bytes=True)
+    return (final if isinstance(final, bytes) else final.encode()), (unfiltered if isinstance(unfiltered, bytes) else unfiltered.encode())
+
+
+def step3(step2_text, delta_vaf: float, delta_mcf: float, min_ac_reads: int, min_ac_cells: int, clust_dist: int, _as_bytes: bool = False):
     """Returns (text of .calling.step3.tsv, text of .calling.step3.unfiltered.tsv).  step2_text: str or bytes."""
     as_bytes = isinstance(step2_text, (bytes, bytearray, memoryview))
     comments, cols = [], None
@@ -439,6 +446,8 @@ def step3(step2_text, delta_vaf: float, delta_mcf: float, min_ac_reads: int, min
             done = tsvio.step3_rows(survivors, cols, delta_vaf, delta_mcf, min_ac_reads, min_ac_cells, clust_dist)
             if done is not None:
                 header = head + "\t".join(cols + ["STEP3FILTER", "INDEX"]) + "\n"
+                if _as_bytes:
+                    return header.encode() + done[1], header.encode() + done[0]
                 return header + done[1].decode(), header + done[0].decode()
     df = pd.read_csv(io.BytesIO(step2_text) if as_bytes else io.StringIO(step2_text), sep="\t", comment="#", names=cols)
     df = df[df["Cell_types"] != "Non-Cancer"]

@@ -373,20 +373,14 @@ int lsio_step3_rows(const char* text, int64_t n_bytes, int32_t n_cols, const int
                 }
             }
         });
-        std::string all_txt, pass_txt;
-        { size_t na = 0, np = 0; for (auto& x : all_ch) na += x.size(); for (auto& x : pass_ch) np += x.size(); all_txt.reserve(na); pass_txt.reserve(np); }
-        for (auto& x : all_ch) all_txt += x;
-        for (auto& x : pass_ch) pass_txt += x;
-        auto give = [](const std::string& s, char** out, int64_t* n) {
-            *out = (char*)malloc(s.size() ? s.size() : 1);
-            if (!*out) return false;
-            memcpy(*out, s.data(), s.size()); *n = (int64_t)s.size();
-            return true;
-        };
-        if (!give(all_txt, out_all, out_all_len) || !give(pass_txt, out_pass, out_pass_len)) {
-            free(*out_all); free(*out_pass); *out_all = *out_pass = nullptr;
-            snprintf(g_s3_err, sizeof g_s3_err, "lsio_step3_rows: out of memory"); return -2;
-        }
+        size_t na = 0, np = 0;
+        for (auto& x : all_ch) na += x.size();
+        for (auto& x : pass_ch) np += x.size();
+        char* oa = (char*)malloc(na ? na : 1); char* op = (char*)malloc(np ? np : 1);
+        if (!oa || !op) { free(oa); free(op); snprintf(g_s3_err, sizeof g_s3_err, "lsio_step3_rows: out of memory"); return -2; }
+        { size_t at = 0; for (auto& x : all_ch) { memcpy(oa + at, x.data(), x.size()); at += x.size(); std::string().swap(x); } }
+        { size_t at = 0; for (auto& x : pass_ch) { memcpy(op + at, x.data(), x.size()); at += x.size(); } }
+        *out_all = oa; *out_all_len = (int64_t)na; *out_pass = op; *out_pass_len = (int64_t)np;
         return 0;
     } catch (const NotHandled&) {
         return 1;

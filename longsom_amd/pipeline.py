@@ -267,11 +267,11 @@ def run_chain(res: Resident, celltype_of: np.ndarray, celltype_names: List[str],
         out.timings = t
         return out
     t0 = time.time()
-    final, unfiltered = calling.step3(s2, params.delta_vaf, params.delta_mcf, params.min_ac_reads, params.min_ac_cells, params.clust_dist)
+    final, unfiltered = calling.step3_bytes(s2, params.delta_vaf, params.delta_mcf, params.min_ac_reads, params.min_ac_cells, params.clust_dist)
     out.step3 = os.path.join(d["BaseCellCalling"], sample_id + ".calling.step3.tsv")
     out.step3_unfiltered = os.path.join(d["BaseCellCalling"], sample_id + ".calling.step3.unfiltered.tsv")
-    open(out.step3, "w").write(final)
-    open(out.step3_unfiltered, "w").write(unfiltered)
+    open(out.step3, "wb").write(final)
+    open(out.step3_unfiltered, "wb").write(unfiltered)
     t["step3"] = time.time() - t0
     t["tables_wait"] = out.wait_for_tables()              # (what of the background writers' time steps 2 and 3 did not cover)
     out.timings = t
@@ -560,9 +560,9 @@ def _run_snv_regions(bam, barcodes_tsv, ref_fasta, out_dir, sample_id, params, e
         open(out.step2, "wb").write(s2)
         t["step2"] = time.time() - t0
         t0 = time.time()
-        final, unfiltered = calling.step3(s2, params.delta_vaf, params.delta_mcf, params.min_ac_reads, params.min_ac_cells, params.clust_dist)
-        open(out.step3, "w").write(final)
-        open(out.step3_unfiltered, "w").write(unfiltered)
+        final, unfiltered = calling.step3_bytes(s2, params.delta_vaf, params.delta_mcf, params.min_ac_reads, params.min_ac_cells, params.clust_dist)
+        open(out.step3, "wb").write(final)
+        open(out.step3_unfiltered, "wb").write(unfiltered)
         t["step3"] = time.time() - t0
         import shutil
         shutil.rmtree(tmp, ignore_errors=True)

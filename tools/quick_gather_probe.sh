@@ -1,4 +1,4 @@
-# scratch: step time + k_tm_gather fabric reads for build variants selected by environment (usage: gpurun -- 'bash tools/quick_gather_probe.sh "LSG_GATHER_NT=0" "LSG_GATHER_NT=1"')
+# scratch: step time + fabric traffic and L2 hit counters of k_tm_gather / k_tm_walk, once per environment setting given (usage: gpurun -- 'bash tools/quick_gather_probe.sh "A=0" "A=1"'; what the gather experiments of DESIGN.md §9 were measured with)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 for V in "$@"; do
   export $V
