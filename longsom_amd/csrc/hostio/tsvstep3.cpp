@@ -152,9 +152,10 @@ sv need(const std::vector<sv>& v, size_t i) { if (i >= v.size()) throw NotHandle
 
 // fn(lo, hi) over [0, n) in up to 16 threads; an exception in a worker is a NotHandled for the whole call
 template <class F>
-void parallel_rows(size_t n, F fn) {
+void parallel_rows(size_t n, F fn, unsigned force_threads = 0) {
     unsigned T = std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
     if (n < 4096) T = 1;
+    if (force_threads) T = (unsigned)std::min<size_t>(force_threads, n ? n : 1);
     if (T == 1) { fn((size_t)0, n); return; }
     std::atomic<bool> failed{false};
     std::vector<std::thread> th;
@@ -186,11 +187,28 @@ int lsio_step3_rows(const char* text, int64_t n_bytes, int32_t n_cols, const int
         const sv all(text, (size_t)n_bytes);
         if (all.find_first_of("#\"\r") != sv::npos) return 1;
         std::vector<sv> lines;
-        for (size_t a = 0; a < all.size();) {
-            size_t e = all.find('\n', a);
-            if (e == sv::npos) e = all.size();
-            if (e > a) lines.push_back(all.substr(a, e - a));
-            a = e + 1;
+        {   // the lines, found by the threads in pieces of the text cut at newlines
+            const unsigned T = all.size() < (1u << 22) ? 1u : std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+            std::vector<size_t> cut(T + 1, all.size());
+            cut[0] = 0;
+            for (unsigned t = 1; t < T; ++t) {
+                size_t c = std::max(cut[t - 1], all.size() * t / T);
+                const size_t nl = c < all.size() ? all.find('\n', c) : sv::npos;
+                cut[t] = nl == sv::npos ? all.size() : nl + 1;
+            }
+            std::vector<std::vector<sv>> part(T);
+            parallel_rows(T, [&](size_t lo, size_t hi) {
+                for (size_t t = lo; t < hi; ++t)
+                    for (size_t a = cut[t]; a < cut[t + 1];) {
+                        const void* nl = memchr(all.data() + a, '\n', cut[t + 1] - a);
+                        const size_t e = nl ? (size_t)((const char*)nl - all.data()) : cut[t + 1];
+                        if (e > a) part[t].push_back(all.substr(a, e - a));
+                        a = e + 1;
+                    }
+            }, T);
+            size_t n = 0; for (auto& v : part) n += v.size();
+            lines.reserve(n);
+            for (auto& v : part) lines.insert(lines.end(), v.begin(), v.end());
         }
         std::vector<Row> rows(lines.size());
         // ---- the fields, and what pandas' dtypes could change (see the head of the file): per column, which kinds of cell it holds
@@ -352,6 +370,7 @@ int lsio_step3_rows(const char* text, int64_t n_bytes, int32_t n_cols, const int
             std::string line;
             for (size_t ch = lo; ch < hi; ++ch) {
                 std::string& all_txt = all_ch[ch]; std::string& pass_txt = pass_ch[ch];
+                { size_t est = 0; for (size_t k = ch * CH; k < std::min(order.size(), (ch + 1) * CH); ++k) for (const sv& f : order[k]->f) est += f.size() + 1; all_txt.reserve(est + CH * 64); }
                 for (size_t k = ch * CH; k < std::min(order.size(), (ch + 1) * CH); ++k) {
                     const Row* r = order[k];
                     std::string s3 = r->s3;
@@ -378,7 +397,13 @@ int lsio_step3_rows(const char* text, int64_t n_bytes, int32_t n_cols, const int
         for (auto& x : pass_ch) np += x.size();
         char* oa = (char*)malloc(na ? na : 1); char* op = (char*)malloc(np ? np : 1);
         if (!oa || !op) { free(oa); free(op); snprintf(g_s3_err, sizeof g_s3_err, "lsio_step3_rows: out of memory"); return -2; }
-        { size_t at = 0; for (auto& x : all_ch) { memcpy(oa + at, x.data(), x.size()); at += x.size(); std::string().swap(x); } }
+        {
+            std::vector<size_t> at(all_ch.size() + 1, 0);
+            for (size_t i = 0; i < all_ch.size(); ++i) at[i + 1] = at[i] + all_ch[i].size();
+            parallel_rows(all_ch.size(), [&](size_t lo, size_t hi) {
+                for (size_t i = lo; i < hi; ++i) { memcpy(oa + at[i], all_ch[i].data(), all_ch[i].size()); std::string().swap(all_ch[i]); }
+            }, 16);
+        }
         { size_t at = 0; for (auto& x : pass_ch) { memcpy(op + at, x.data(), x.size()); at += x.size(); } }
         *out_all = oa; *out_all_len = (int64_t)na; *out_pass = op; *out_pass_len = (int64_t)np;
         return 0;
