@@ -344,8 +344,14 @@ def build_bai(bam: str, bai: Optional[str] = None) -> str:
 
 
 def find_bai(bam: str) -> Optional[str]:
+    """the BAM's index if there is one that is not older than the BAM (samtools warns about such a pair; here it is not used: a slice
+    cut by a stale index would be counted without any sign of trouble)"""
+    import sys
     for p in (bam + ".bai", os.path.splitext(bam)[0] + ".bai"):
         if os.path.exists(p):
+            if os.path.getmtime(p) + 1.0 < os.path.getmtime(bam):
+                sys.stderr.write("warning: %s is older than %s: the index is not used (the whole file is ingested)\n" % (p, bam))
+                return None
             return p
     return None
 
