@@ -95,6 +95,8 @@ def _rank_main(rank, world, port, q):
     comm = regions.Comm.from_env()
     kept = {("chr%d" % (rank + 1), 100 * rank + 1): "row of rank %d\n" % rank, ("chr1", 5000 + rank): "late row %d\n" % rank} if rank else {}
     got = comm.allgather_bytes(regions.pack_rows(kept))
+    total = comm.allreduce_sum(np.asarray([rank + 1, 10 * (rank + 1), 0], np.int64))       # (SplitBam's counters of a sliced ingest are summed this way)
+    assert total.tolist() == [world * (world + 1) // 2, 10 * world * (world + 1) // 2, 0]
     comm.barrier()
     q.put((rank, regions.unpack_rows(got)))
     comm.close()
