@@ -750,7 +750,9 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
         c->ws[WS_NE_ACC].reserve(((size_t)n_ne + 2) * 4) || c->ws[WS_NE_GEOM].reserve(((size_t)n_ne + 2) * 8) || c->ws[WS_MULTI_LIST].reserve(((size_t)c->tm_n_multi + 2) * 4) ||
         c->ws[WS_MACC].reserve(((size_t)c->tm_n_slabs + 1) * NCTR * 64 * 4) || c->d_ix_stat.reserve(IX_STAT_SLOTS * 64))
         return -1;
-    const unsigned grid_walk = (unsigned)(c->n_cus * tune_int("LSG_GRID_TM", 14));
+    // 16 workgroups = 32 waves per CU = the 8 waves per SIMD the hardware holds (8 KB of LDS each): the walk waits on its own dependency
+    // chains (a scalar decision per entry), so every resident wave counts — 14 per CU: 5.7 ms, 16: 5.4 (round 3)
+    const unsigned grid_walk = (unsigned)(c->n_cus * tune_int("LSG_GRID_TM", 16));
     const unsigned grid_fin = (unsigned)(c->n_cus * 8);
     const unsigned grid_wide = c->tm_n_wide ? (c->tm_n_wide < (unsigned)(c->n_cus * 4) ? c->tm_n_wide : (unsigned)(c->n_cus * 4)) : 0u;
     const int n_pass = (c->n_ct + 1) / 2;
