@@ -101,7 +101,10 @@ int write_chunks(const char* path, const std::vector<int64_t>& order, int n_thre
     const int T = n_threads > 0 ? n_threads : (int)std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
     const int64_t CH = 16384;
     const int64_t n_chunks = (n + CH - 1) / CH;
-    bool ok = true;
+    // a batch of chunks is formatted by the threads while the batch before it is being written (one writer: the file's order)
+    std::atomic<bool> ok{true};
+    std::thread writer;
+    std::vector<std::string> writing;
     for (int64_t c0 = 0; c0 < n_chunks && ok; c0 += (int64_t)T * 4) {
         const int64_t c1 = std::min(n_chunks, c0 + (int64_t)T * 4);
         std::vector<std::string> text((size_t)(c1 - c0));
@@ -117,9 +120,14 @@ int write_chunks(const char* path, const std::vector<int64_t>& order, int n_thre
                 }
             });
         for (auto& t : th) t.join();
-        for (auto& s : text)
-            if (!s.empty() && fwrite(s.data(), 1, s.size(), f) != s.size()) ok = false;
+        if (writer.joinable()) writer.join();
+        writing.swap(text);
+        writer = std::thread([&writing, &ok, f]() {
+            for (auto& s : writing)
+                if (!s.empty() && fwrite(s.data(), 1, s.size(), f) != s.size()) ok = false;
+        });
     }
+    if (writer.joinable()) writer.join();
     if (fclose(f) != 0) ok = false;
     if (!ok) { set_err("write failed"); return -1; }
     return 0;
