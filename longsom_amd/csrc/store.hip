@@ -273,15 +273,11 @@ __global__ void k_seg_bounds(const uint32_t* netile, uint32_t n, const uint32_t*
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { const uint32_t t = netile[i]; begin[i] = tile_off[t]; end[i] = tile_off[t + 1]; }
 }
-// largest t in [0, n) with off[t] <= x (off non-decreasing, off[0] <= x): the tile whose blocks hold x, skipping empty ones
-__device__ __forceinline__ uint32_t tm_owner(const uint32_t* off, uint32_t n, uint32_t x) {
-    uint32_t lo = 0, hi = n;
-    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (off[mid] <= x) lo = mid; else hi = mid; }
-    return lo;
-}
-__global__ void k_tm_blk_tile(const uint32_t* blk_off, uint32_t n_tiles, uint32_t nblk, uint32_t* blk_tile) {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < nblk) blk_tile[b] = tm_owner(blk_off, n_tiles, b);
+// the tile of every block: a non-empty tile writes its number at its first block, a running maximum over the blocks carries it on
+// (the tiles' numbers grow with the blocks; a binary search per block over the tiles' offsets took 0.27 ms at C2)
+__global__ void k_tm_blk_mark(const uint32_t* cap, const uint32_t* blk_off, uint32_t n_tiles, uint32_t* blk_tile) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n_tiles && cap[t]) blk_tile[blk_off[t]] = t;
 }
 
 // One wave per TMG_BLOCKS blocks = 8 TMG_BLOCKS entries, in two steps.
@@ -551,7 +547,16 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
     if (c->tm[TM_S0].reserve((np + 16) * 4) || c->tm[TM_B].reserve(np + 16) ||
         c->tm[TM_FM].reserve((np + 16) * 4) || c->tm[TM_RD].reserve((np + 16) * 4) || c->tm[TM_META].reserve((np + 8 * (TM_GROUP + 1)) * 4) ||
         c->tm[TM_BLK_TILE].reserve(((size_t)nblk + 2) * 4) || c->tm[TM_EXT].reserve(((size_t)nblk + TM_GROUP + 2) * 2)) return -1;
-    hipLaunchKernelGGL(k_tm_blk_tile, dim3((nblk + 255) / 256), dim3(256), 0, st, blk_off, T, nblk, c->tm[TM_BLK_TILE].as<uint32_t>());
+    {
+        uint32_t* bt_ = c->tm[TM_BLK_TILE].as<uint32_t>();
+        LSG_HIP(hipMemsetAsync(bt_, 0, (size_t)nblk * 4, st));
+        hipLaunchKernelGGL(k_tm_blk_mark, dim3((T + 255) / 256), dim3(256), 0, st, c->d_tile_cap.as<uint32_t>(), blk_off, T, bt_);
+        size_t tb = 0;
+        LSG_HIP(hipcub::DeviceScan::InclusiveScan(nullptr, tb, bt_, bt_, hipcub::Max(), (int)nblk, st));
+        if (tmp.reserve(tb + 256)) return -1;
+        tb = tmp.cap;
+        LSG_HIP(hipcub::DeviceScan::InclusiveScan(tmp.p, tb, bt_, bt_, hipcub::Max(), (int)nblk, st));
+    }
     LSG_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c->tm[TM_S0].as<uint32_t>() + np), (int)TM_PAD_S0, 16, st));       // (what the walk's group loads and the run flags' neighbours see past the end)
     LSG_HIP(hipMemsetAsync(c->tm[TM_B].as<uint8_t>() + np, 0, 16, st));
     // ---- 5. the per-entry words and the events.  The blocks are the load's largest allocation (C4: 124 GB beside 106 GB of the caller's
@@ -599,7 +604,24 @@ __global__ void k_tm_tiles(const uint32_t* cap, uint32_t n_tiles, int n_ct, uint
     const uint32_t j = n == 0 ? 0u : (n <= job_tgt ? 1u : (n + job_tgt - 1) / job_tgt);
     ne[t] = n ? 1u : 0u; nj[t] = j; slabs[t] = j > 1 ? j * (uint32_t)n_ct : 0u; multi[t] = j > 1 ? 1u : 0u;
 }
-// per non-empty tile: its units (one per cell type), its jobs cut at run starts
+// job j of J of a tile of n entries at `base`: [first run start at or after n j / J, first run start at or after n (j + 1) / J)
+__device__ __forceinline__ void tm_make_job(const uint32_t* s0, uint64_t base, uint32_t n, uint32_t J, uint32_t j, uint32_t w0, uint32_t slab, uint32_t tile, TmJob* out,
+                                            uint32_t* n_wide) {
+    auto cut = [&](uint32_t x) -> uint32_t { while (x < n && !(s0[base + x] & TM_RUNSTART)) ++x; return x < n ? x : n; };
+    const uint32_t e0 = j == 0 ? 0u : cut((uint32_t)(((uint64_t)n * j) / J));
+    uint32_t e1 = j + 1 == J ? n : cut((uint32_t)(((uint64_t)n * (j + 1)) / J));
+    if (e1 < e0) e1 = e0;
+    TmJob jb;
+    jb.e0 = (uint32_t)(base + e0); jb.e1 = (uint32_t)(base + e1); jb.w0 = w0;
+    jb.slab = J > 1 ? slab : 0xFFFFFFFFu; jb.nj = J; jb.cnt = n; jb.tile = tile;
+    // two waves share the job: the second starts at the run start at or after its middle (short jobs: one wave)
+    uint32_t mid = e1;
+    if (e1 - e0 >= 64u) { mid = cut(e0 + (e1 - e0) / 2u); if (mid > e1) mid = e1; }
+    jb.emid = (uint32_t)(base + mid);
+    if (e1 - e0 > (uint32_t)TM_JOB_LIMIT) { jb.nj |= TMJ_WIDE; atomicAdd(n_wide, 1u); }
+    *out = jb;
+}
+// per non-empty tile: its units (one per cell type) and, for a tile that is one job, the job
 __global__ void k_tm_jobs(const uint32_t* tile_base, int n_contigs, int n_ct, const uint32_t* s0, const uint32_t* cap, const uint32_t* blk_off, const uint32_t* ne_off,
                           const uint32_t* nj, const uint32_t* job_off, const uint32_t* slab_off, const uint32_t* multi_off, uint32_t n_tiles, TmJob* jobs,
                           uint32_t* ne_units, int2* ne_geom, uint32_t* ne_nslot, uint32_t* ne_acc, uint32_t* multi, uint32_t* n_wide) {
@@ -620,22 +642,21 @@ __global__ void k_tm_jobs(const uint32_t* tile_base, int n_contigs, int n_ct, co
         ne_acc[w] = J > 1 ? slab_off[t] + (uint32_t)ct * J : 0u;
         if (J > 1) multi[multi_off[t] * (uint32_t)n_ct + ct] = w;
     }
-    auto cut = [&](uint32_t x) -> uint32_t { while (x < n && !(s0[base + x] & TM_RUNSTART)) ++x; return x < n ? x : n; };
-    uint32_t e0 = 0;
-    for (uint32_t j = 0; j < J; ++j) {
-        uint32_t e1 = j + 1 == J ? n : cut((uint32_t)(((uint64_t)n * (j + 1)) / J));
-        if (e1 < e0) e1 = e0;
-        TmJob jb;
-        jb.e0 = (uint32_t)(base + e0); jb.e1 = (uint32_t)(base + e1); jb.w0 = ord * (uint32_t)n_ct;
-        jb.slab = J > 1 ? slab_off[t] + j : 0xFFFFFFFFu; jb.nj = J; jb.cnt = n; jb.tile = t;
-        // two waves share the job: the second starts at the run start at or after its middle (short jobs: one wave)
-        uint32_t mid = e1;
-        if (e1 - e0 >= 64u) { mid = cut(e0 + (e1 - e0) / 2u); if (mid > e1) mid = e1; }
-        jb.emid = (uint32_t)(base + mid);
-        if (e1 - e0 > (uint32_t)TM_JOB_LIMIT) { jb.nj |= TMJ_WIDE; atomicAdd(n_wide, 1u); }
-        jobs[job_off[t] + j] = jb;
-        e0 = e1;
-    }
+    if (J > 1) return;                                   // its jobs: k_tm_jobs_multi (a lane per job; here one thread would walk them one after the other)
+    tm_make_job(s0, base, n, 1u, 0u, ord * (uint32_t)n_ct, 0xFFFFFFFFu, t, jobs + job_off[t], n_wide);
+}
+// the jobs of the tiles cut into several: a wave per tile, a lane per job (a job's ends are run starts found from its own nominal ends:
+// no job waits for the one before it)
+__global__ __launch_bounds__(64) void k_tm_jobs_multi(int n_ct, const uint32_t* s0, const uint32_t* cap, const uint32_t* blk_off, const uint32_t* ne_off, const uint32_t* nj,
+                                                      const uint32_t* job_off, const uint32_t* slab_off, const uint32_t* multi, const uint32_t* ne_units, uint32_t n_mt, TmJob* jobs,
+                                                      uint32_t* n_wide) {
+    const uint32_t i = blockIdx.x;
+    if (i >= n_mt) return;
+    const uint32_t t = ne_units[multi[(size_t)i * (uint32_t)n_ct]] / (uint32_t)n_ct;
+    const uint32_t n = cap[t], J = nj[t];
+    const uint64_t base = (uint64_t)blk_off[t] * 8;
+    for (uint32_t j = threadIdx.x; j < J; j += 64u)
+        tm_make_job(s0, base, n, J, j, ne_off[t] * (uint32_t)n_ct, slab_off[t] + j, t, jobs + job_off[t] + j, n_wide);
 }
 struct TmJobWork {
     const TmJob* jobs;
@@ -686,6 +707,8 @@ int ensure_plan(lsg_ctx* c) {
                        c->d_tile_cap.as<uint32_t>(), c->tm[TM_BLK_OFF].as<uint32_t>(), ne_off, nj, job_off, slab_off, multi_off, T,
                        c->tm[TM_JOBS].as<TmJob>(), c->tm[TM_NE_UNITS].as<uint32_t>(), c->tm[TM_NE_GEOM].as<int2>(), c->tm[TM_NE_NSLOT].as<uint32_t>(),
                        c->tm[TM_NE_ACC].as<uint32_t>(), c->tm[TM_MULTI].as<uint32_t>(), d_misc);
+    if (n_mt) hipLaunchKernelGGL(k_tm_jobs_multi, dim3(n_mt), dim3(64), 0, st, c->n_ct, c->tm[TM_S0].as<uint32_t>(), c->d_tile_cap.as<uint32_t>(), c->tm[TM_BLK_OFF].as<uint32_t>(),
+                                 ne_off, nj, job_off, slab_off, c->tm[TM_MULTI].as<uint32_t>(), c->tm[TM_NE_UNITS].as<uint32_t>(), n_mt, c->tm[TM_JOBS].as<TmJob>(), d_misc);
     {   // static work-balanced chunks of the job list; every workgroup of the walk should get several: a small load is cut finer
         DevBuf& pex = c->bt[BT_PEX];
         const uint64_t total_work = c->tm_np + (uint64_t)njobs * TM_JOB_W0;
