@@ -1,7 +1,7 @@
 // CPU fuzz driver of the BAM reader (longsom_amd/csrc/hostio/bamio.cpp), built with -fsanitize=address,undefined by
 // tests/test_bamio_fuzz_cpu.py.  Takes a valid BAM, and for N seeded iterations damages it — truncation, bit flips and
 // overwritten length fields in the UNCOMPRESSED stream (re-framed as BGZF so the damage reaches the record parser), and flips in
-// the BGZF framing itself — then runs lsio_decode_bam / lsio_stream_next / lsio_split_bam on the result.  Every call must return
+// the BGZF framing itself — then runs lsio_decode_bam / lsio_stream_next / lsio_split_bam / lsio_build_bai on the result.  Every call must return
 // (0 or an error code); the sanitizers turn any read past a buffer into a failure of this program.
 #include <zlib.h>
 #include <cstdint>
@@ -19,6 +19,7 @@ int lsio_stream_open(const char*, const char*, int32_t, const int32_t*, int32_t,
 int lsio_stream_next(lsio_stream*, int64_t, lsio_decoded**);
 void lsio_stream_close(lsio_stream*);
 int lsio_split_bam(const char*, const char*, int32_t, const uint8_t*, int32_t, const char*, int32_t, int64_t*);
+int lsio_build_bai(const char*, const char*);
 }
 
 static uint64_t rng_state = 1;
@@ -98,6 +99,7 @@ int main(int argc, char** argv) {
         }
         int64_t cnt[5];
         (void)lsio_split_bam(tmp.c_str(), "AAAC0001GG\nTTTG0002CC", 2, ct, 2, outs.c_str(), 60, cnt);
+        (void)lsio_build_bai(tmp.c_str(), (work + "/fuzz.bam.bai").c_str());
     }
     printf("fuzz_bamio: %d inputs decoded, %d rejected\n", ok, failed);
     return 0;
