@@ -156,3 +156,14 @@ def test_bai_plan_regions_and_slices():
     assert plan.end((0, 16384), 0) == (1500 << 16) | 3              # 4 windows further on contig 0 there is none: the next contig's first
     one = regions.BaiPlan(lin, 3, 1, 2000)
     assert one.bounds == [(0, 0), (3, 0)]
+
+
+def test_an_index_older_than_its_bam_is_not_used(tmp_path, capsys):
+    from longsom_amd import hostio
+    bam, bai = tmp_path / "a.bam", tmp_path / "a.bam.bai"
+    bai.write_bytes(b"BAI\x01\x00\x00\x00\x00"); bam.write_bytes(b"x")
+    os.utime(bai, (1_000_000, 1_000_000)); os.utime(bam, (2_000_000, 2_000_000))
+    assert hostio.find_bai(str(bam)) is None and "older" in capsys.readouterr().err
+    os.utime(bai, (3_000_000, 3_000_000))
+    assert hostio.find_bai(str(bam)) == str(bai)
+    assert hostio.find_bai(str(tmp_path / "none.bam")) is None

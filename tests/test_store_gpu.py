@@ -211,3 +211,17 @@ def test_unload_gives_the_memory_back_and_the_handle_stays_usable():
             eng.pileup_count()
         eng.synth_reads(m)
         assert eng.pileup_count() == first
+
+
+def test_a_load_without_reads_counts_nothing(engine):
+    """what a rank of a sharded run does when no alignment falls into its region (pipeline._run_snv_regions): an empty load, a count, a
+    call, fetches — all of them empty, none of them an error"""
+    from longsom_amd import hostio
+    m = synth.named("C1", n_reads=1000)
+    engine.set_contigs(m.contig_len); engine.synth_reference(m.seed); engine.set_barcodes(m.celltype_of, 2)
+    engine.set_region()
+    engine.load_reads(hostio.ReadRecords.empty())
+    rows, cols = engine.pileup_count()
+    assert rows == [0, 0] and cols == 0
+    assert engine.call_step1() == (0, 0)
+    assert all(len(x) == 0 for x in engine.fetch_counts(0)) and len(engine.fetch_calls()) == 0
