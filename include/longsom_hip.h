@@ -217,9 +217,9 @@ int lsg_unload_reads(lsg_ctx* ctx);
  * the upper bound it uses to skip the work: the live reads of every cell-type BAM under the current barcode table
  * (reads of one cell type whose span touches a 64-position tile, maximum over tiles and cell types; before
  * lsg_set_barcodes: all reads with a barcode).  While the bound stays <= max_depth the cap cannot fire.
- * lsg_genotype_cells does NOT model the cap (its pileup runs over the unsplit BAM, HCCVSingleCellGenotype.py:122):
- * there the host mirror checks the all-reads bound (lsg_max_live_reads_all) and warns or raises.  Computed on request and cached until the reads or
- * the barcode table change.  Returns the bound, -1 on error. */
+ * lsg_genotype_cells_grouped models it for the genotyping pileup of the unsplit BAM (HCCVSingleCellGenotype.py:122) with the all-reads
+ * bound (lsg_max_live_reads_all).  Computed on request and cached until the reads or the barcode table change.  Returns the bound, -1 on
+ * error. */
 int64_t lsg_max_live_reads(lsg_ctx* ctx);
 /* The same bound over EVERY resident read that carries a barcode, whatever its cell type (>= lsg_max_live_reads): what the
  * genotyping pileup of the unsplit BAM can hold at once (HCCVSingleCellGenotype.py:122) — a lower bound on it, since reads without a
@@ -294,6 +294,16 @@ typedef struct {
 } lsg_genotype_params;
 int lsg_genotype_cells(lsg_ctx* ctx, const lsg_genotype_params* params, int64_t n_sites, const int64_t* site_keys,
                        const uint8_t* alt_sym, uint32_t* dp, uint32_t* alt, int32_t on_device);
+/* The same with the pileup's depth cap (HCCVSingleCellGenotype.py:122: bam.pileup(CHROM, START, END, ..., max_depth = 200000), one call
+ * per window of target sites, build_dict_variants :245-265): the sites [group_off[g], group_off[g + 1]) are one such window (same
+ * contig), its region [first site - 1, last site + 1).  For every window whose region can hold more than max_depth reads, htslib's rule
+ * (a read that is not the first of its start position is dropped while the buffer exceeds max_depth; lsg_count_params.max_depth states
+ * it) is replayed over the resident reads that overlap the region and the reads it drops are left out of that window's sites.  The
+ * stream is the reads of the resident load — all cell types, reads with a listed barcode (the decoders keep no others): for a BAM
+ * whose reads all carry listed barcodes this is the reference's buffer, otherwise a lower bound on it.  max_depth <= 0 or n_groups == 0:
+ * lsg_genotype_cells.  Free while lsg_max_live_reads_all() stays below the cap. */
+int lsg_genotype_cells_grouped(lsg_ctx* ctx, const lsg_genotype_params* params, int32_t max_depth, int64_t n_sites, const int64_t* site_keys,
+                               const uint8_t* alt_sym, int64_t n_groups, const int64_t* group_off, uint32_t* dp, uint32_t* alt, int32_t on_device);
 /* round(betabinom.sf(k - 0.001, n, alpha, beta), 4) * 1e4 for n_items integer (k, n) pairs, evaluated on the
  * device with the step-1 tail code (HCCVSingleCellGenotype.py:204; k[i] <= 0 gives 10000). */
 int lsg_betabinom_sf4(lsg_ctx* ctx, int64_t n_items, const uint32_t* k, const uint32_t* n, double alpha, double beta, int32_t* out_p4);

@@ -149,6 +149,7 @@ SIGNATURES = {
     "lsg_load_posset": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int32]),
     "lsg_probe_posset": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32]),
     "lsg_genotype_cells": (C.c_int, [C.c_void_p, C.POINTER(GenotypeParams), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
+    "lsg_genotype_cells_grouped": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
     "lsg_betabinom_sf4": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p]),
     "lsg_betabinom_sf": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p]),
     "lsg_max_live_reads": (C.c_int64, [C.c_void_p]),

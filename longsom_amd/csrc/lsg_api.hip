@@ -17,7 +17,7 @@ int run_fetch_calls(lsg_ctx* c, lsg_call* out, int64_t capacity, int candidates_
 int run_select_calls(lsg_ctx* c, int kind, lsg_call* dst_device, int64_t capacity, int64_t* n_out);
 int run_probe(lsg_ctx* c, int kind, const int64_t* keys, int64_t n, uint8_t* hits, int on_device);
 int run_genotype(lsg_ctx* c, const lsg_genotype_params* p, int64_t n_sites, const int64_t* site_keys, const uint8_t* alt_sym,
-                 uint32_t* dp, uint32_t* alt, int on_device);
+                 uint32_t* dp, uint32_t* alt, int on_device, int32_t max_depth, int64_t n_groups, const int64_t* group_off);
 int run_sf4(lsg_ctx* c, int64_t items, const uint32_t* k, const uint32_t* n, double al, double be, int32_t* out, double* raw);
 
 // copy a host or device array into a grow-only device buffer of the handle (the caller's array is free again when the call returns)
@@ -388,7 +388,16 @@ int lsg_genotype_cells(lsg_ctx* c, const lsg_genotype_params* params, int64_t n_
     if (!c || !params) { set_error("lsg_genotype_cells: bad arguments"); return -2; }
     LSG_HIP(hipSetDevice(c->device));
     if (int rc = check_load_filter(c, "lsg_genotype_cells", params->min_mq, params->flag_exclude, params->ignore_orphans)) return rc;
-    return run_genotype(c, params, n_sites, site_keys, alt_sym, dp, alt, on_device);
+    return run_genotype(c, params, n_sites, site_keys, alt_sym, dp, alt, on_device, 0, 0, nullptr);
+}
+
+int lsg_genotype_cells_grouped(lsg_ctx* c, const lsg_genotype_params* params, int32_t max_depth, int64_t n_sites, const int64_t* site_keys, const uint8_t* alt_sym,
+                               int64_t n_groups, const int64_t* group_off, uint32_t* dp, uint32_t* alt, int32_t on_device) {
+    if (!c || !params || n_groups < 0 || (n_groups > 0 && !group_off)) { set_error("lsg_genotype_cells_grouped: bad arguments"); return -2; }
+    LSG_HIP(hipSetDevice(c->device));
+    if (int rc = check_load_filter(c, "lsg_genotype_cells_grouped", params->min_mq, params->flag_exclude, params->ignore_orphans)) return rc;
+    if (n_groups > 0 && (group_off[0] != 0 || group_off[n_groups] != n_sites)) { set_error("lsg_genotype_cells_grouped: the groups must cover the sites"); return -2; }
+    return run_genotype(c, params, n_sites, site_keys, alt_sym, dp, alt, on_device, max_depth, n_groups, group_off);
 }
 
 int lsg_betabinom_sf4(lsg_ctx* c, int64_t n_items, const uint32_t* k, const uint32_t* n, double alpha, double beta, int32_t* out_p4) {

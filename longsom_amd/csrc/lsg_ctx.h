@@ -90,6 +90,8 @@ int ensure_plan(lsg_ctx* c);       // store.hip: jobs / units / slabs of a count
 void drop_store(lsg_ctx* c);       // store.hip: new reads or contigs
 int live_read_bound(lsg_ctx* c);   // layout.hip: fills max_live_reads when it is stale (-1)
 int live_read_bound_all(lsg_ctx* c);
+__global__ void k_read_end(const uint32_t* seg_read, const int32_t* seg_start, const int32_t* seg_len, int64_t n_segs, int32_t* read_end);      // layout.hip
+__global__ void k_read_end_init(const int32_t* read_pos, int64_t n_reads, int32_t* read_end);
 int depth_cap_drops(lsg_ctx* c, const lsg_count_params* p);   // layout.hip: htslib's max_depth rule -> d_read_drop (or none)
 }
 

@@ -369,6 +369,22 @@ class Engine:
                        "lsg_genotype_cells")
         return dp, alt
 
+    def genotype_cells_grouped(self, site_keys, alt_sym, group_off, params=None, max_depth: int = 200000):
+        """genotype_cells with the pileup's depth cap replayed per window of target sites (lsg_genotype_cells_grouped): the sites
+        [group_off[g], group_off[g + 1]) are one pileup call of the reference (HCCVSingleCellGenotype.py:109-122)."""
+        from ._lib import GenotypeParams
+        params = params or GenotypeParams.longsom_defaults()
+        site_keys = np.ascontiguousarray(site_keys, dtype=np.int64)
+        alt_sym = np.ascontiguousarray(alt_sym, dtype=np.uint8)
+        group_off = np.ascontiguousarray(group_off, dtype=np.int64)
+        assert len(site_keys) == len(alt_sym)
+        dp = np.zeros((len(site_keys), self.n_cb), np.uint32)
+        alt = np.zeros((len(site_keys), self.n_cb), np.uint32)
+        if len(site_keys):
+            _lib.check(self._lib.lsg_genotype_cells_grouped(self._h, C.byref(params), int(max_depth), len(site_keys), _ptr(site_keys), _ptr(alt_sym),
+                                                            len(group_off) - 1, _ptr(group_off), _ptr(dp), _ptr(alt), 0), "lsg_genotype_cells_grouped")
+        return dp, alt
+
     def betabinom_sf4(self, k, n, alpha: float, beta: float) -> np.ndarray:
         """round(betabinom.sf(k - 0.001, n, alpha, beta), 4) * 1e4 as int32, evaluated on the device."""
         k = np.ascontiguousarray(k, dtype=np.uint32); n = np.ascontiguousarray(n, dtype=np.uint32)

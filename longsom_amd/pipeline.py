@@ -111,29 +111,6 @@ class Resident:
 PILEUP_MAX_DEPTH = 200000   # bam.pileup(..., max_depth = 200000), BaseCellCounter.py:191 / HCCVSingleCellGenotype.py:122
 
 
-class DepthCapExceeded(ValueError):
-    """More reads can be live at one position than the reference's pileup admits, on a path that does not model its cap."""
-
-
-def check_depth_cap(engine: Engine, what: str, allow_depth_overflow: Optional[bool] = None) -> int:
-    """For the per-cell GENOTYPING pileup only (lsg_genotype_cells: the reference piles up the unsplit BAM there,
-    HCCVSingleCellGenotype.py:122, and that path does not model max_depth): raise when more reads can be live at one position
-    than the reference's pileup admits.  The COUNT path needs no such guard: lsg_pileup_count applies htslib's max_depth rule
-    itself (lsg_count_params.max_depth)."""
-    # the genotyping pileup reads the UNSPLIT BAM: every cell type's reads share its buffer, so the bound is the one over all resident
-    # reads (a lower bound on the reference's: reads without a usable CB tag are dropped at decode and are not resident)
-    live = engine.max_live_reads_all()
-    if live > PILEUP_MAX_DEPTH:
-        msg = ("%s: up to %d reads (all cell types) overlap one 64-position tile; the reference's pileup of the unsplit BAM stops admitting reads above "
-               "max_depth = %d, which the genotyping path does not model, so counts there could differ" % (what, live, PILEUP_MAX_DEPTH))
-        if allow_depth_overflow is None:
-            allow_depth_overflow = os.environ.get("LONGSOM_ALLOW_DEPTH_OVERFLOW", "0") == "1"
-        if not allow_depth_overflow:
-            raise DepthCapExceeded(msg + " (set LONGSOM_ALLOW_DEPTH_OVERFLOW=1 to count every read anyway)")
-        sys.stderr.write("warning: " + msg + "\n")
-    return live
-
-
 def load_sample(bam: str, barcodes_tsv: str, ref_fasta: str, engine: Engine, min_mapq: int, allow_depth_overflow: Optional[bool] = None,
                 ingest: Optional[str] = None) -> Resident:
     """ingest: "device" = the BAM's bytes go to the GPU and are inflated, decoded and laid out there (lsg_load_bam); "host" = the host
@@ -628,7 +605,6 @@ def run_reannotation(bam: str, barcodes_tsv: str, ref_fasta: str, out_dir: str, 
         t["hccv"] = time.time() - t0
         t0 = time.time()
         eng.set_barcodes(res.table.celltype_of, len(res.table.celltype_names))
-        check_depth_cap(eng, sample_id + " (per-cell genotyping)")
         geno = os.path.join(d1, "HCCV", sample_id + ".SNVs.SingleCellGenotype.tsv")
         n_rows = reanno.single_cell_genotype(eng, hccv, res.table, res.contig_names, geno, alt_flag=rp.alt_flag, min_bq=rp.genotype_min_bq,
                                              min_mq=rp.chain.min_mapping_quality, alpha2=rp.chain.alpha2, beta2=rp.chain.beta2, pvalue=rp.pvalue,

@@ -185,7 +185,7 @@ def _p4_text(k: int) -> str:
 def single_cell_genotype(engine, variant_file: str, table, contig_names: Sequence[str], out_path: str, *, alt_flag: str = "All",
                          window: int = 50000, min_bq: int = 30, min_mq: int = 255, alpha2: float = 0.260288007167716,
                          beta2: float = 173.94711910763732, pvalue: float = 0.01, chrm_contaminant: str = "True",
-                         strict_cb: bool = True) -> int:
+                         strict_cb: bool = True, max_depth: int = 200000) -> int:
     """The reads, contigs and `table` (hostio.BarcodeTable) must be resident in `engine`.  Returns the number of rows written.
     Row order = the reference's: windows by (chromosome text, smallest position), inside a window the positions in the
     iteration order of Python's set of them (:111,131 — reproduced by building that very set), per position every barcode
@@ -220,7 +220,12 @@ def single_cell_genotype(engine, variant_file: str, table, contig_names: Sequenc
             alt_sym[row_of[key_of[(chrom, p)]]] = SYM_OF_BASE.get(sites[p][1], 255)
     params = GenotypeParams.longsom_defaults(min_bq=int(min_bq), min_mq=int(min_mq), alt_only=1 if alt_flag == "Alt" else 0,
                                              strict_cb=1 if strict_cb else 0)
-    dp, alt = engine.genotype_cells(np.asarray(uniq, np.int64), alt_sym, params)
+    # the windows of target sites are the reference's pileup calls (bam.pileup(CHROM, START, END, ..., max_depth = 200000), :109-122):
+    # consecutive in the sorted site list; the device replays the depth cap per window where a region can hold that many reads
+    keys = np.asarray(uniq, np.int64)
+    code = (keys >> 32) * (1 << 40) + ((keys & 0xFFFFFFFF) + 1) // int(window) if len(keys) else keys
+    group_off = np.concatenate([[0], np.nonzero(np.diff(code))[0] + 1, [len(keys)]]).astype(np.int64)
+    dp, alt = engine.genotype_cells_grouped(keys, alt_sym, group_off, params, max_depth)
     # beta-binomial tails of the covered, mutated cells outside chrM
     need = []
     for chrom, _, order, _ in blocks:

@@ -10,13 +10,53 @@ uses scipy.stats.betabinom like the reference (:204).
 import numpy as np
 
 
+def depth_cap_drops(rec, tid, start, end, min_mq, flag_exclude, ignore_orphans, max_depth):
+    """reads the pileup of (tid, [start, end)) with max_depth drops (HCCVSingleCellGenotype.py:122; htslib bam_plp_push): the reads that
+    overlap the region arrive in file (coordinate) order; the first read of a start position always enters the buffer, a later one of
+    the same position is dropped while (reads that entered and end at or after that position) + 1 > max_depth.  The pileup's own read
+    filter (flag filter without the supplementary bit, which only :168 tests later; ignore_orphans; min_mapping_quality) comes first."""
+    R = rec.n_reads
+    ends = rec.read_pos.astype(np.int64) + 1
+    for s in range(rec.n_segs):                               # a read's last pileup column + 1 (its last segment's end; pos + 1 without segments)
+        ends[int(rec.seg_read[s])] = int(rec.seg_start[s]) + int(rec.seg_len[s])
+    order = sorted(range(R), key=lambda i: (int(rec.read_tid[i]), int(rec.read_pos[i])))
+    pool = flag_exclude & ~0x800
+    dropped, buffered, cur, first = set(), [], None, True
+    for i in order:
+        if int(rec.read_tid[i]) != tid or int(rec.read_pos[i]) >= end or ends[i] <= start:
+            continue
+        f = int(rec.read_flag[i])
+        if int(rec.read_mapq[i]) < min_mq or (f & pool) or (ignore_orphans and (f & 1) and not (f & 2)):
+            continue
+        p = int(rec.read_pos[i])
+        if p != cur:
+            cur, first = p, True
+            buffered = [e for e in buffered if e >= p]
+        if not first and len(buffered) + 1 > max_depth:
+            dropped.add(i)
+            continue
+        first = False
+        buffered.append(int(ends[i]))
+    return dropped
+
+
 def genotype(rec, contig_len, celltype_of, site_keys, alt_sym, min_bq=30, min_mq=60, flag_exclude=0xF04, ignore_orphans=1,
-             alt_only=0, strict_cb=1):
-    """-> (dp, alt) uint32 [n_sites, n_cb].  Plain loops over segments (small inputs only)."""
+             alt_only=0, strict_cb=1, group_off=None, max_depth=0):
+    """-> (dp, alt) uint32 [n_sites, n_cb].  Plain loops over segments (small inputs only).  group_off + max_depth: the sites
+    [group_off[g], group_off[g + 1]) are one pileup call over [first site - 1, last site + 1) with that depth cap (:109-122)."""
     n_cb = len(celltype_of)
     site_keys = np.asarray(site_keys, np.int64)
     dp = np.zeros((len(site_keys), n_cb), np.uint32)
     alt = np.zeros((len(site_keys), n_cb), np.uint32)
+    dropped_at = [set()] * len(site_keys)
+    if group_off is not None and max_depth > 0:
+        for g in range(len(group_off) - 1):
+            a, b = int(group_off[g]), int(group_off[g + 1])
+            if b > a:
+                d = depth_cap_drops(rec, int(site_keys[a]) >> 32, (int(site_keys[a]) & 0xFFFFFFFF) - 1, (int(site_keys[b - 1]) & 0xFFFFFFFF) + 1,
+                                    min_mq, flag_exclude, ignore_orphans, max_depth)
+                for i in range(a, b):
+                    dropped_at[i] = d
     for s in range(rec.n_segs):
         r = int(rec.seg_read[s])
         flag = int(rec.read_flag[r]); cb = int(rec.read_cb[r]); tid = int(rec.read_tid[r])
@@ -40,6 +80,8 @@ def genotype(rec, contig_len, celltype_of, site_keys, alt_sym, min_bq=30, min_mq
         while i < len(site_keys) and site_keys[i] < k_lo + ln:
             ev = int(rec.events[int(rec.seg_ev_off[s]) + int(site_keys[i]) - k_lo])
             i += 1
+            if r in dropped_at[i - 1]:                                # the pileup of this site's window never saw the read
+                continue
             if not (ev & 0x0800) or (ev & 0xff) < min_bq:          # 'NA'; pileup min_base_quality (:123)
                 continue
             sym = (ev >> 8) & 7

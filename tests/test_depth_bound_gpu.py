@@ -95,36 +95,3 @@ def test_count_with_a_depth_cap_equals_the_bam_level_oracle(engine, deep_sample,
         assert dp < dp_uncapped                                   # the cap really dropped reads
     else:
         assert dp <= dp_uncapped
-
-
-def test_genotyping_guard_refuses_a_sample_above_the_cap(engine, deep_sample, monkeypatch, capsys):
-    m, bam, fa, bct = deep_sample
-    res = pipeline.load_sample(bam, bct, fa, engine, 60)
-    live = pipeline.check_depth_cap(engine, "S1")                 # far below 200000: passes
-    assert 0 < live <= 6000
-    monkeypatch.setattr(pipeline, "PILEUP_MAX_DEPTH", live - 1)
-    monkeypatch.delenv("LONGSOM_ALLOW_DEPTH_OVERFLOW", raising=False)
-    with pytest.raises(pipeline.DepthCapExceeded):
-        pipeline.check_depth_cap(engine, "S1")
-    monkeypatch.setenv("LONGSOM_ALLOW_DEPTH_OVERFLOW", "1")
-    assert pipeline.check_depth_cap(engine, "S1") == live
-    assert "max_depth" in capsys.readouterr().err
-    assert res.engine is engine
-
-
-def test_genotyping_guard_counts_every_cell_type(engine, monkeypatch):
-    """the genotyping pileup reads the UNSPLIT BAM (HCCVSingleCellGenotype.py:122): two cell types whose SUM exceeds the cap, though
-    neither does alone, must trip the guard (it used the per-cell-type bound)"""
-    lens = [3000]
-    rec = random_records(21, 4000, lens, 60, hot_regions=[(0, 1000, 1060)], hot_frac=0.9)
-    rng = np.random.default_rng(21)
-    engine.set_contigs(lens); engine.load_reference(0, random_reference(rng, lens[0]))
-    ct_of = (np.arange(60) % 2).astype(np.uint8)                 # the barcodes alternate between the two cell types
-    engine.set_barcodes(ct_of, 2)
-    engine.load_reads(rec)
-    per_ct, both = engine.max_live_reads(), engine.max_live_reads_all()
-    assert per_ct < both <= 2 * per_ct + 64
-    monkeypatch.delenv("LONGSOM_ALLOW_DEPTH_OVERFLOW", raising=False)
-    monkeypatch.setattr(pipeline, "PILEUP_MAX_DEPTH", (per_ct + both) // 2)      # above either cell type, below their sum
-    with pytest.raises(pipeline.DepthCapExceeded):
-        pipeline.check_depth_cap(engine, "S1")

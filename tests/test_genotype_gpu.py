@@ -55,6 +55,30 @@ def test_counts_match_oracle(engine, kw):
     assert dp.sum() > 1000 and 0 < al.sum() < dp.sum() or p.alt_only
 
 
+@pytest.mark.parametrize("max_depth", [3, 25, 120, 100000])
+@pytest.mark.parametrize("window", [150, 5000])
+def test_depth_cap_of_the_genotyping_pileup(engine, max_depth, window):
+    """lsg_genotype_cells_grouped: the reference piles up every window of target sites with max_depth (HCCVSingleCellGenotype.py:109-122);
+    the device replays htslib's rule per window over the resident reads of ALL cell types and leaves the dropped reads out — against
+    the Python restatement (oracle/genotype_oracle.depth_cap_drops) on a sample whose hot region holds hundreds of reads at once"""
+    from oracle import genotype_oracle as go
+    rec, lens, celltype_of, keys, alt = case(13, n_reads=4000)
+    load(engine, rec, lens, celltype_of)
+    p = GenotypeParams.longsom_defaults(min_mq=0)
+    code = (keys >> 32) * (1 << 40) + ((keys & 0xFFFFFFFF) + 1) // window
+    group_off = np.concatenate([[0], np.nonzero(np.diff(code))[0] + 1, [len(keys)]]).astype(np.int64)
+    dp, al = engine.genotype_cells_grouped(keys, alt, group_off, p, max_depth)
+    odp, oal = go.genotype(rec, lens, celltype_of, keys, alt, p.min_bq, p.min_mq, p.flag_exclude, p.ignore_orphans, p.alt_only, p.strict_cb,
+                           group_off=group_off, max_depth=max_depth)
+    np.testing.assert_array_equal(dp, odp)
+    np.testing.assert_array_equal(al, oal)
+    free_dp, _ = engine.genotype_cells(keys, alt, p)
+    if max_depth <= 120:
+        assert dp.sum() < free_dp.sum()                          # the cap really dropped reads
+    else:
+        np.testing.assert_array_equal(dp, free_dp)
+
+
 def test_empty_and_bad_arguments(engine):
     rec, lens, celltype_of, keys, alt = case(12, n_reads=200)
     load(engine, rec, lens, celltype_of)
