@@ -251,3 +251,43 @@ def test_step3_native_differential_fuzz(monkeypatch):
         sv = calling._step3_survivors(t.encode(), hdr.index("Cell_types"))
         handled += bool(sv) and tsvio.step3_rows(sv, hdr, *args) is not None
     assert handled > 60                                  # (most of the tables are the native path's own)
+
+
+def test_step2_scanned_differential_fuzz(monkeypatch):
+    """random subsets of the golden step-1 rows with cells replaced by missing values, dots, odd numbers and unknown contigs, blank and
+    stray comment lines, with and without a final newline, four distances: the scanned path (or whatever it hands back) gives the
+    row-by-row path's bytes, and what kills one kills the other"""
+    import random
+    names, _ = tsvio.read_fasta(os.path.join(G, "calling.ref.fa"))
+    ed, sr, lr = (calling.read_posset_keys(os.path.join(G, "calling.%s.tsv" % k), names) for k in ("editing", "pon_SR", "pon_LR"))
+    lines = rd("sample.calling.step1.tsv").split("\n")
+    comments = [l for l in lines if l.startswith("#")]
+    body = [l for l in lines if l and not l.startswith("#")]
+    vals = ["", "NA", ".", "PASS", "0", "12", "chrM", "chr1", "chrZ", "A", "A|C", "NA\tNA", "x", "-5", "+7", "1e3", "Multi-allelic", "00012"]
+
+    def outcome(t, sets, dist):
+        try:
+            return calling.step2_bytes(t.encode(), _NumpyProbe(), names, *sets, dist)
+        except Exception as e:
+            return type(e).__name__
+    for seed in range(150):
+        rng = random.Random(seed)
+        rows = rng.sample(body, min(len(body), rng.choice([0, 1, 2, 3, 50, 400])))
+        if rng.random() < 0.7:
+            rows.sort(key=body.index)
+        for _ in range(rng.choice([0, 0, 1, 2, 8])):
+            if not rows:
+                break
+            i = rng.randrange(len(rows)); f = rows[i].split("\t")
+            f[rng.randrange(len(f))] = rng.choice(vals); rows[i] = "\t".join(f)
+        if rng.random() < 0.1 and rows:
+            rows.insert(rng.randrange(len(rows) + 1), "")
+        if rng.random() < 0.05 and rows:
+            rows.insert(rng.randrange(len(rows) + 1), "#stray")
+        t = "\n".join(comments + rows) + ("\n" if rng.random() < 0.8 else "")
+        dist = rng.choice([0, 0, 5, 150, 100000])
+        sets = (ed, sr, lr) if rng.random() < 0.7 else (ed, sr, calling.read_posset_keys("", names))
+        monkeypatch.setenv("LONGSOM_STEP2_ROW_PATH", "1")
+        want = outcome(t, sets, dist)
+        monkeypatch.setenv("LONGSOM_STEP2_ROW_PATH", "0")
+        assert outcome(t, sets, dist) == want, "seed %d" % seed
