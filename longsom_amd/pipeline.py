@@ -467,6 +467,26 @@ def _run_snv_regions(bam, barcodes_tsv, ref_fasta, out_dir, sample_id, params, e
             yield from batches
         work = _prefetch(_windows(chained(), len(first.contig_names)))
     kept: Dict[tuple, str] = {}
+    # Step 2 is row-local when its distance filter is off (LongSom's setting: min_distance 0) — position-set probes, the gnomAD lookup, the
+    # FILTER tags and the blanked NA fields all look at one row — so every rank (every window) runs it over its own rows on its own GPU,
+    # writes its pieces of the step-2 table, and only the rows that survive step 3's FILTER patterns travel to rank 0, whose step 3 needs
+    # the candidates of every region for its cluster filter (step3.py:283-306).  With a distance filter the rows' neighbours matter and
+    # rank 0 runs step 2 over all kept rows, as before.
+    local_step2 = int(params.min_distance) == 0 and os.environ.get("LONGSOM_LOCAL_STEP2", "1") != "0"
+    s2_state: Dict[str, object] = {}
+
+    def step2_piece(rows: bytes) -> bytes:
+        """the step-2 rows of a piece of the step-1 table (rows only in, rows only out)"""
+        if "keys" not in s2_state:
+            s2_state["keys"] = [calling.read_posset_keys(p, contig["names"], params.reference_gz_compat) for p in (editing, pon_sr, pon_lr)]
+            s2_state["af"] = calling.open_gnomad(gnomad_af_json)
+            mh_ = tsvio.merged_header(cts, "##fileDate=x\n")
+            s2_state["head"] = tsvio.step1_header([l + "\n" for l in mh_.split("\n") if l.startswith("##")], cts).encode()
+            k = s2_state["keys"]
+            s2_state["head_out"] = len(calling.step2_bytes(s2_state["head"], eng, contig["names"], k[0], k[1], k[2], 0, s2_state["af"], params.max_gnomad_vaf))
+        k = s2_state["keys"]
+        out2 = calling.step2_bytes(s2_state["head"] + rows, eng, contig["names"], k[0], k[1], k[2], 0, s2_state["af"], params.max_gnomad_vaf)
+        return out2[s2_state["head_out"]:]
     n_windows = 0
     for lo, hi, rec, dec in work:
         if not contig:
@@ -502,7 +522,17 @@ def _run_snv_regions(bam, barcodes_tsv, ref_fasta, out_dir, sample_id, params, e
                 if len(sub[ct][0]):
                     tsvio.write_counts_tsv(regions.piece_path(tmp, chrom, start1, "counts." + name), *sub[ct], names, "", header=False)
             tsvio.write_merged_tsv(regions.piece_path(tmp, chrom, start1, "merged"), sub, names, cts, header=False)
-            kept[(chrom, start1)] = tsvio.write_step1_tsv(regions.piece_path(tmp, chrom, start1, "step1"), calls[c0:c1], sub, names, cts, [], header=False, as_bytes=True)
+            rows1 = tsvio.write_step1_tsv(regions.piece_path(tmp, chrom, start1, "step1"), calls[c0:c1], sub, names, cts, [], header=False, as_bytes=True)
+            if local_step2:
+                t1 = time.time()
+                rows2 = step2_piece(rows1) if rows1 else b""
+                with open(regions.piece_path(tmp, chrom, start1, "step2"), "wb") as f:
+                    f.write(rows2)
+                surv = calling._step3_survivors(rows2, 6) if rows2 and os.environ.get("LONGSOM_STEP3_FULL_PARSE", "0") != "1" else None
+                kept[(chrom, start1)] = rows2 if surv is None else surv      # (Cell_types is column 6 of the step-1 / step-2 tables)
+                t["step2"] = t.get("step2", 0.0) + time.time() - t1
+            else:
+                kept[(chrom, start1)] = rows1
         t["write_tables"] += time.time() - t0
     if not contig:                                     # a rank (or a file) without reads: still needs the contig names for the headers
         setup(dec if comm.world > 1 else first)
@@ -531,11 +561,19 @@ def _run_snv_regions(bam, barcodes_tsv, ref_fasta, out_dir, sample_id, params, e
         regions.concatenate_pieces(tmp, "step1", s1h, out.step1)
         t["concatenate"] = time.time() - t0
         t0 = time.time()
-        s1 = s1h.encode() + regions.unpack_rows_bytes(payloads)
-        keys = [calling.read_posset_keys(p, names, params.reference_gz_compat) for p in (editing, pon_sr, pon_lr)]
-        s2 = calling.step2_bytes(s1, eng, names, keys[0], keys[1], keys[2], params.min_distance, calling.open_gnomad(gnomad_af_json), params.max_gnomad_vaf)
-        open(out.step2, "wb").write(s2)
-        t["step2"] = time.time() - t0
+        if local_step2:
+            # the pieces of the step-2 table are on disk; what came over the wire is the rows step 3 still looks at
+            keys = [calling.read_posset_keys(p, names, params.reference_gz_compat) for p in (editing, pon_sr, pon_lr)]
+            s2h = calling.step2_bytes(s1h.encode(), eng, names, keys[0], keys[1], keys[2], 0, calling.open_gnomad(gnomad_af_json), params.max_gnomad_vaf)
+            regions.concatenate_pieces(tmp, "step2", s2h.decode(), out.step2)
+            s2 = s2h + regions.unpack_rows_bytes(payloads)
+            t["step2"] = t.get("step2", 0.0) + time.time() - t0
+        else:
+            s1 = s1h.encode() + regions.unpack_rows_bytes(payloads)
+            keys = [calling.read_posset_keys(p, names, params.reference_gz_compat) for p in (editing, pon_sr, pon_lr)]
+            s2 = calling.step2_bytes(s1, eng, names, keys[0], keys[1], keys[2], params.min_distance, calling.open_gnomad(gnomad_af_json), params.max_gnomad_vaf)
+            open(out.step2, "wb").write(s2)
+            t["step2"] = time.time() - t0
         t0 = time.time()
         final, unfiltered = calling.step3_bytes(s2, params.delta_vaf, params.delta_mcf, params.min_ac_reads, params.min_ac_cells, params.clust_dist)
         open(out.step3, "wb").write(final)

@@ -119,3 +119,35 @@ def test_windowed_run_of_an_indexed_bam_ingests_on_the_device(sample, tmp_path, 
     out = pipeline.run_snv(bam, bct, fa, out_dir, "S1", window_bytes=window_bytes)
     assert out.timings["windows"] >= (5 if window_bytes < 1_000_000 else 1)
     same_outputs(out_dir, whole)
+
+
+@pytest.mark.parametrize("distance", [0, 150])
+def test_sharded_and_windowed_runs_with_position_sets_and_gnomad(sample, tmp_path, distance):
+    """step 2 with an RNA-editing set, a PoN and a gnomAD table: with the distance filter off every rank / window tags its own rows
+    on its own GPU and only step 3's survivors travel; with it on, rank 0 tags all kept rows as before — both write the files of the
+    single-pass run"""
+    import json
+    bam, fa, bct, whole, d = sample
+    cand = [l.split("\t") for l in open(os.path.join(whole, RELS[3])) if not l.startswith("#") and l.split("\t")[4] != "." and l.split("\t")[5] != "."]
+    assert len(cand) > 50
+    ed, sr, af = str(tmp_path / "editing.tsv"), str(tmp_path / "pon.tsv"), str(tmp_path / "gnomad.json")
+    open(ed, "w").write("#c\tp\n" + "".join("%s\t%s\n" % (c[0], c[1]) for c in cand[::7]))
+    open(sr, "w").write("".join("%s\t%s\n" % (c[0], c[1]) for c in cand[3::9]))
+    json.dump({"%s:%s:%s:%s" % (c[0], c[1], c[3], c[4].split(",")[0].split("|")[0]): (0.2 if i % 2 else 0.001) for i, c in enumerate(cand[5::11])}, open(af, "w"))
+    params = pipeline.SnvParams(min_distance=distance)
+    ref_dir = str(tmp_path / "whole")
+    pipeline.run_snv(bam, bct, fa, ref_dir, "S1", params, editing=ed, pon_sr=sr, gnomad_af_json=af)
+    tagged = open(os.path.join(ref_dir, RELS[4])).read()
+    assert "RNA_editing_db" in tagged and "PoN_SR" in tagged and "gnomAD" in tagged and (distance == 0 or "Clustered" in tagged)
+    win_dir = str(tmp_path / "win")
+    pipeline.run_snv(bam, bct, fa, win_dir, "S1", params, editing=ed, pon_sr=sr, gnomad_af_json=af, window_bytes=500_000)
+    same_outputs(win_dir, ref_dir)
+    out_dir = str(tmp_path / "ranks")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, LSG_DIST_BACKEND="gloo", LSG_DIST_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "workflow", "scripts_gpu", "SNVCalling", "longsom_gpu_snv.py"), "--bam", bam, "--meta", bct, "--ref", fa, "--id", "S1", "--outdir", out_dir,
+           "--editing", ed, "--pon_SR", sr, "--gnomAD_json", af, "--min_distance", str(distance)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    same_outputs(out_dir, ref_dir)
