@@ -181,9 +181,20 @@ def concatenate_pieces(tmp_dir: str, table: str, header: str, out_path: str) -> 
     found.sort()
     with open(out_path, "wb") as out:
         out.write(header.encode())
+        out.flush()
         for _, _, p in found:
             with open(p, "rb") as f:
-                shutil.copyfileobj(f, out, 1 << 24)
+                left = os.fstat(f.fileno()).st_size
+                try:                                      # the kernel copies file to file (no trip through this process's memory)
+                    while left > 0:
+                        n = os.sendfile(out.fileno(), f.fileno(), None, min(left, 1 << 30))
+                        if n <= 0:
+                            raise OSError("sendfile made no progress")
+                        left -= n
+                except OSError:
+                    f.seek(os.fstat(f.fileno()).st_size - left)
+                    out.seek(0, os.SEEK_END)
+                    shutil.copyfileobj(f, out, 1 << 24)
     return len(found)
 
 
