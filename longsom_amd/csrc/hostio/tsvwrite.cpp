@@ -15,10 +15,6 @@
 #include <thread>
 #include <vector>
 
-#include <fcntl.h>
-#include <sys/stat.h>
-#include <unistd.h>
-
 #include "../../../include/longsom_hip.h"
 
 namespace {
@@ -99,23 +95,16 @@ inline void contig_range(const int64_t* keys, int64_t n, int tid, int64_t& lo, i
 // appends the texts to `path` in order.
 template <class F>
 int write_chunks(const char* path, const std::vector<int64_t>& order, int n_threads, F fmt) {
-    const int fd = open(path, O_WRONLY | O_CREAT, 0644);          // (not O_APPEND: the writers place their chunks with pwrite)
-    if (fd < 0) { set_err("cannot open the output file"); return -1; }
-    struct stat sb;
-    if (fstat(fd, &sb) != 0) { close(fd); set_err("cannot stat the output file"); return -1; }
-    int64_t file_at = (int64_t)sb.st_size;                        // the rows go behind what the caller wrote (the header)
+    FILE* f = fopen(path, "ab");
+    if (!f) { set_err("cannot open the output file"); return -1; }
     const int64_t n = (int64_t)order.size();
     const int T = n_threads > 0 ? n_threads : (int)std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
-    const int W = std::max(1, std::min(4, T / 2));                // writers of a batch
     const int64_t CH = 16384;
     const int64_t n_chunks = (n + CH - 1) / CH;
-    // a batch of chunks is formatted by the threads while the batch before it is being written, W chunks at a time at their places
+    // a batch of chunks is formatted by the threads while the batch before it is being written (one writer: the file's order)
     std::atomic<bool> ok{true};
-    std::vector<std::thread> writers;
+    std::thread writer;
     std::vector<std::string> writing;
-    std::vector<int64_t> at;
-    std::atomic<size_t> wnext{0};
-    auto join_writers = [&]() { for (auto& w : writers) w.join(); writers.clear(); };
     for (int64_t c0 = 0; c0 < n_chunks && ok; c0 += (int64_t)T * 4) {
         const int64_t c1 = std::min(n_chunks, c0 + (int64_t)T * 4);
         std::vector<std::string> text((size_t)(c1 - c0));
@@ -131,26 +120,15 @@ int write_chunks(const char* path, const std::vector<int64_t>& order, int n_thre
                 }
             });
         for (auto& t : th) t.join();
-        join_writers();
+        if (writer.joinable()) writer.join();
         writing.swap(text);
-        at.assign(writing.size() + 1, file_at);
-        for (size_t i = 0; i < writing.size(); ++i) at[i + 1] = at[i] + (int64_t)writing[i].size();
-        file_at = at[writing.size()];
-        wnext = 0;
-        for (int w = 0; w < W; ++w)
-            writers.emplace_back([&writing, &at, &wnext, &ok, fd]() {
-                for (size_t i = wnext.fetch_add(1); i < writing.size(); i = wnext.fetch_add(1)) {
-                    const char* p = writing[i].data(); size_t left = writing[i].size(); int64_t o = at[i];
-                    while (left) {
-                        const ssize_t k = pwrite(fd, p, left, (off_t)o);
-                        if (k <= 0) { ok = false; return; }
-                        p += k; left -= (size_t)k; o += k;
-                    }
-                }
-            });
+        writer = std::thread([&writing, &ok, f]() {
+            for (auto& s : writing)
+                if (!s.empty() && fwrite(s.data(), 1, s.size(), f) != s.size()) ok = false;
+        });
     }
-    join_writers();
-    if (close(fd) != 0) ok = false;
+    if (writer.joinable()) writer.join();
+    if (fclose(f) != 0) ok = false;
     if (!ok) { set_err("write failed"); return -1; }
     return 0;
 }
