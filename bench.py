@@ -162,6 +162,34 @@ def cpu_baseline(eng, model, target_reads=150_000, call_sites=10_000):
             "gpu_matches_oracle_on_sample": ok}
 
 
+def end_to_end(n_reads):
+    """files in -> every output file (pipeline.run_snv: ingest, count, merge, steps 1-3, all tables written), measured in THIS run on a
+    BAM written in this run: C2's model at n_reads reads.  After the timed steps, on rank 0 at N=1; never part of `value`."""
+    import shutil
+    import tempfile
+    from longsom_amd import hostio, pipeline
+    d = tempfile.mkdtemp(prefix="lsg_bench_e2e_")
+    try:
+        m = synth.named("C2", n_reads=n_reads)
+        bam, fa, bct = os.path.join(d, "S.bam"), os.path.join(d, "ref.fa"), os.path.join(d, "bc.tsv")
+        t0 = time.time(); hostio.synth_bam(m, bam, fa); t_bam = time.time() - t0
+        hostio.write_barcodes_tsv(bct, hostio.synth_barcodes(m), m.celltype_of, ["Cancer", "Non-Cancer"])
+        t0 = time.time()
+        out = pipeline.run_snv(bam, bct, fa, os.path.join(d, "out"), "S")
+        wall = time.time() - t0
+        mb = lambda ps: round(sum(os.path.getsize(q) for q in ps) / 1e6, 1)
+        return {"measured": "in this run", "workload": "C2's model at %d reads x %d barcodes as a BAM of %.0f MB + FASTA + barcodes.tsv, written in this run (%.1f s, not counted); "
+                                                       "BAM -> per-cell-type count tables, merged table, step-1/2/3 tables on disk" % (n_reads, m.n_cb, os.path.getsize(bam) / 1e6, t_bam),
+                "wall_s": round(wall, 2), "seconds": {k: round(float(v), 3) for k, v in out.timings.items()},
+                "out_MB": {"counts": mb(out.counts.values()), "merged": mb([out.merged]), "step1": mb([out.step1])},
+                "step3_rows": max(0, sum(1 for l in open(out.step3) if not l.startswith("#")) - 1), "host_threads": os.cpu_count()}
+    except Exception as e:                                           # the contract line is still printed; the failure is in it and on stderr
+        print("bench.py: end-to-end leg failed: %r" % (e,), file=sys.stderr)
+        return {"measured": "failed", "error": repr(e)}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 # rocprofv3's names of the two candidates for "dominant kernel"
 PMC_KERNEL = {"k_tm_walk": "lsg::k_tm_walk", "k_tm_gather": "lsg::k_tm_gather"}
 
@@ -205,6 +233,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--reads", type=float, default=None, help="override the read count (development only; the reported config changes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--e2e-reads", type=float, default=None,
+                    help="reads of the end-to-end leg (files in -> files out, after the timed steps, N=1 only); 0 = none; default 1e6 (none with --reads)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))
@@ -345,6 +375,10 @@ def main():
     assert (re_rows, re_cols, re_sites, re_cand) == (rows, cols, n_sites, n_cand), "a re-count of the resident store differs from the first count"
     if os.environ.get("LSG_BENCH_STATS"):                           # the last step's counters, for whoever tunes the kernels
         print({f: (list(getattr(st, f)) if f.endswith("by_kernel") else getattr(st, f)) for f, _ in st._fields_ if f != "pad_"}, file=sys.stderr)
+    e2e = None
+    e2e_reads = int(args.e2e_reads) if args.e2e_reads is not None else (1_000_000 if args.reads is None else 0)
+    if rank == 0 and world == 1 and e2e_reads > 0:
+        e2e = end_to_end(e2e_reads)
     if dist_on:
         counts = gathered_counts()                                 # after the clock: the timed exchanges all fitted
         if max(counts) > gather["cap"]:
@@ -392,7 +426,7 @@ def main():
                        "recount_ms": round(recount_ms, 2),                 # count + call over the SAME resident store: NOT what value is computed from
                        "resident_GB_rank0": round(layout_bytes / 1e9, 2),     # store + per-read / per-segment arrays + cached build temporaries
                        "store_entries_rank0": eng.store_shape()[0], "store_events_rank0": eng.store_shape()[2],
-                       "kernels": kernels, "end_to_end": None},
+                       "kernels": kernels, "end_to_end": e2e},                # measured in this run (or null): never a quoted file
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale,
                          "avg_launch_ms": kernels[dom]["avg_launch_ms"], "algorithmic_bytes_per_launch": kernels[dom]["algorithmic_bytes_per_launch"]},

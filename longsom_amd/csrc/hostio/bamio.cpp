@@ -550,6 +550,97 @@ struct BgzfWriter {
 
 static void put32(std::vector<uint8_t>& v, uint32_t x) { for (int i = 0; i < 4; ++i) v.push_back((uint8_t)(x >> (8 * i))); }
 
+// ---- the synthetic BAM, written on every host thread -------------------------------------------------------------------------------
+// The file is the one a single BgzfWriter fed record by record would write (same block cuts: a record that does not fit the open block
+// starts a new one); the work is spread: read headers, the records of a round, the deflate of its blocks and the FASTA lines are
+// each done by all threads, the file is written in order.  (The C2 BAM of 10 M reads is 9.9 GB: one thread took 7 minutes.)
+extern "C++" {
+static int synth_threads() { const unsigned h = std::thread::hardware_concurrency(); return (int)std::min(64u, std::max(1u, h)); }
+
+template <class F> static void synth_parallel(int64_t n_items, int64_t grain, F&& fn) {   // fn(lo, hi) over [0, n_items) in grains
+    const int64_t n_chunks = (n_items + grain - 1) / grain;
+    const int T = (int)std::min<int64_t>(synth_threads(), n_chunks);
+    if (T <= 1) { if (n_items > 0) fn((int64_t)0, n_items); return; }
+    std::atomic<int64_t> next(0);
+    auto worker = [&]() { for (;;) { const int64_t c = next.fetch_add(1); if (c >= n_chunks) return; fn(c * grain, std::min(n_items, (c + 1) * grain)); } };
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t) th.emplace_back(worker);
+    for (auto& t : th) t.join();
+}
+
+static void bgzf_block(const uint8_t* src, size_t n, uint8_t* out /* >= 70000 */, uint32_t* out_len, bool* ok) {
+    z_stream zs; memset(&zs, 0, sizeof(zs));
+    deflateInit2(&zs, 1, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
+    zs.next_in = (Bytef*)src; zs.avail_in = (uInt)n; zs.next_out = out + 18; zs.avail_out = 70000 - 26;
+    if (deflate(&zs, Z_FINISH) != Z_STREAM_END) *ok = false;
+    const uint32_t clen = (uint32_t)zs.total_out; deflateEnd(&zs);
+    const uint8_t hdr[16] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 'B', 'C', 2, 0};
+    memcpy(out, hdr, 16);
+    const uint32_t bsize = clen + 25;
+    out[16] = (uint8_t)(bsize & 0xff); out[17] = (uint8_t)(bsize >> 8);
+    const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), src, (uInt)n);
+    uint8_t* t = out + 18 + clen;
+    for (int i = 0; i < 4; ++i) { t[i] = (uint8_t)(crc >> (8 * i)); t[4 + i] = (uint8_t)((uint32_t)n >> (8 * i)); }
+    *out_len = 18 + clen + 8;
+}
+
+struct SynthScratch { std::vector<uint32_t> cig; std::string seq; std::vector<uint8_t> qual; };
+
+// one read of the model as a BAM record appended to `rec` (CB:Z tag, soft clips, indels, introns)
+static void synth_record(const lsg_synth_model* m, int64_t ig, const sm_read& r, int32_t pos, const char* barcode_suffix, SynthScratch& sc,
+                         std::vector<uint8_t>& rec) {
+    static const char acgt[4] = {'A', 'C', 'G', 'T'};
+    auto code_of = [](char c) -> uint8_t { return c == 'A' ? 1 : c == 'C' ? 2 : c == 'G' ? 4 : c == 'T' ? 8 : 15; };
+    std::vector<uint32_t>& cig = sc.cig; std::string& seq = sc.seq; std::vector<uint8_t>& qual = sc.qual;
+    cig.clear(); seq.clear(); qual.clear();
+    auto push_op = [&](uint32_t op, uint32_t len) { if (!len) return; if (!cig.empty() && (cig.back() & 0xf) == op) cig.back() += len << 4; else cig.push_back((len << 4) | op); };
+    for (int32_t c = 0; c < r.clip5; ++c) { const uint64_t h = sm_hash(m->seed, (uint64_t)ig, (uint64_t)(100000 + c), SM_D_INS); seq.push_back(acgt[h & 3]); qual.push_back((uint8_t)(2 + (h >> 8) % 39)); }
+    push_op(4, (uint32_t)r.clip5);
+    const int32_t end = r.t_off + r.t_len;
+    for (int32_t x = r.e0; x <= r.e1; ++x) {
+        const int32_t xt0 = m->exon_cum[x], xt1 = xt0 + m->exon_len[x];
+        const int32_t lo = r.t_off > xt0 ? r.t_off : xt0, hi = end < xt1 ? end : xt1;
+        if (x > r.e0) push_op(3, (uint32_t)(m->exon_start[x] - (m->exon_start[x - 1] + m->exon_len[x - 1])));
+        for (int32_t j = lo; j < hi; ++j) {
+            const int32_t blk = j >> 3, k = j & 7;
+            const int32_t ind = sm_block_indel(m, ig, blk, lo, hi);
+            if (ind > 0 && k >= 2 && k <= 1 + ind) { push_op(2, 1); continue; }      // deleted base
+            const uint32_t s = sm_base_call(m, ig, &r, j, (int64_t)m->exon_start[x] + (j - xt0));
+            seq.push_back((char)sm_base_of_sym(s)); qual.push_back((uint8_t)sm_qual(m, ig, j));
+            push_op(0, 1);
+            if (ind < 0 && k == 3) {
+                for (int32_t c = 0; c < -ind; ++c) { const uint64_t h = sm_hash(m->seed, (uint64_t)ig, (uint64_t)((uint32_t)j * 4u + (uint32_t)c), SM_D_INS); seq.push_back(acgt[h & 3]); qual.push_back((uint8_t)(2 + (h >> 8) % 39)); }
+                push_op(1, (uint32_t)(-ind));
+            }
+        }
+    }
+    for (int32_t c = 0; c < r.clip3; ++c) { const uint64_t h = sm_hash(m->seed, (uint64_t)ig, (uint64_t)(200000 + c), SM_D_INS); seq.push_back(acgt[h & 3]); qual.push_back((uint8_t)(2 + (h >> 8) % 39)); }
+    push_op(4, (uint32_t)r.clip3);
+    char name[32]; const int ln = snprintf(name, sizeof(name), "r%lld", (long long)ig) + 1;
+    const size_t at = rec.size();
+    put32(rec, 0);                                                           // block_size placeholder
+    put32(rec, (uint32_t)r.tid); put32(rec, (uint32_t)pos);
+    rec.push_back((uint8_t)ln); rec.push_back(r.mapq); rec.push_back(0x48); rec.push_back(0x12);   // bin (unused)
+    rec.push_back((uint8_t)(cig.size() & 0xff)); rec.push_back((uint8_t)(cig.size() >> 8));
+    rec.push_back((uint8_t)(r.flag & 0xff)); rec.push_back((uint8_t)(r.flag >> 8));
+    put32(rec, (uint32_t)seq.size()); put32(rec, 0xffffffffu); put32(rec, 0xffffffffu); put32(rec, 0);
+    rec.insert(rec.end(), name, name + ln);
+    for (uint32_t c : cig) put32(rec, c);
+    for (size_t q = 0; q < seq.size(); q += 2) rec.push_back((uint8_t)((code_of(seq[q]) << 4) | (q + 1 < seq.size() ? code_of(seq[q + 1]) : 0)));
+    rec.insert(rec.end(), qual.begin(), qual.end());
+    const uint8_t nh[7] = {'N', 'H', 'C', 1, 0, 0, 0}; rec.insert(rec.end(), nh, nh + 4);
+    if (r.cb != -1) {
+        char bc[17]; sm_barcode(m->seed, r.cb >= 0 ? r.cb : ig, r.cb < 0, bc);
+        rec.push_back('C'); rec.push_back('B'); rec.push_back('Z'); rec.insert(rec.end(), bc, bc + 16);
+        if (barcode_suffix) rec.insert(rec.end(), barcode_suffix, barcode_suffix + strlen(barcode_suffix));
+        rec.push_back(0);
+    }
+    const uint32_t bs = (uint32_t)(rec.size() - at) - 4;
+    for (int b = 0; b < 4; ++b) rec[at + (size_t)b] = (uint8_t)(bs >> (8 * b));
+}
+
+}  // extern "C++"
+
 // Writes the model's reads as a coordinate-sorted BAM (CB:Z tags, soft clips, indels, introns) and,
 // optionally, the reference FASTA.  barcode_suffix (e.g. "-1") is appended to every CB value.
 int lsio_synth_bam(const lsg_synth_model* m, const char* contig_names /* '\n'-joined */, const int64_t* contig_len, const char* bam_path,
@@ -560,96 +651,93 @@ int lsio_synth_bam(const lsg_synth_model* m, const char* contig_names /* '\n'-jo
     if (fasta_path && *fasta_path) {
         FILE* ff = fopen(fasta_path, "w");
         if (!ff) { set_err("lsio_synth_bam: cannot write %s", fasta_path); return -1; }
+        std::vector<char> text;
         for (int t = 0; t < m->n_contigs; ++t) {
             fprintf(ff, ">%s\n", names[(size_t)t].c_str());
-            std::string line;
-            for (int64_t p = 0; p < contig_len[t]; ++p) {
-                line.push_back((char)sm_ref_base(m->seed, t, p));
-                if (line.size() == 60 || p + 1 == contig_len[t]) { line.push_back('\n'); fputs(line.c_str(), ff); line.clear(); }
-            }
+            const int64_t len = contig_len[t], n_lines = (len + 59) / 60;
+            text.resize((size_t)(len + n_lines));
+            synth_parallel(n_lines, 1 << 14, [&](int64_t l0, int64_t l1) {      // line l: bases [60 l, 60 l + 60) at text offset 61 l
+                for (int64_t l = l0; l < l1; ++l) {
+                    char* o = text.data() + 61 * l;
+                    const int64_t p1 = std::min(len, 60 * l + 60);
+                    for (int64_t p = 60 * l; p < p1; ++p) *o++ = (char)sm_ref_base(m->seed, t, p);
+                    *o = '\n';
+                }
+            });
+            if (fwrite(text.data(), 1, text.size(), ff) != text.size()) { fclose(ff); set_err("lsio_synth_bam: write failed (%s)", fasta_path); return -1; }
         }
         fclose(ff);
     }
     const int64_t R = m->n_reads;
     std::vector<sm_read> hdr((size_t)R);
     std::vector<int32_t> pos((size_t)R);
-    std::vector<int64_t> order((size_t)R);
-    for (int64_t i = 0; i < R; ++i) {
-        sm_read_header(m, i + m->read_base, &hdr[(size_t)i]);
-        const sm_read& r = hdr[(size_t)i];
-        pos[(size_t)i] = m->exon_start[r.e0] + (r.t_off - m->exon_cum[r.e0]);
-        order[(size_t)i] = i;
-    }
-    std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) {
-        if (hdr[(size_t)a].tid != hdr[(size_t)b].tid) return hdr[(size_t)a].tid < hdr[(size_t)b].tid;
-        return pos[(size_t)a] < pos[(size_t)b];
+    struct Key { uint64_t k; int64_t i; };
+    std::vector<Key> order((size_t)R);
+    synth_parallel(R, 1 << 14, [&](int64_t lo, int64_t hi) {
+        for (int64_t i = lo; i < hi; ++i) {
+            sm_read_header(m, i + m->read_base, &hdr[(size_t)i]);
+            const sm_read& r = hdr[(size_t)i];
+            pos[(size_t)i] = m->exon_start[r.e0] + (r.t_off - m->exon_cum[r.e0]);
+            order[(size_t)i] = Key{((uint64_t)(uint32_t)r.tid << 32) | (uint32_t)pos[(size_t)i], i};
+        }
     });
-    BgzfWriter w; w.f = fopen(bam_path, "wb");
-    if (!w.f) { set_err("lsio_synth_bam: cannot write %s", bam_path); return -1; }
+    std::sort(order.begin(), order.end(), [](const Key& a, const Key& b) { return a.k != b.k ? a.k < b.k : a.i < b.i; });   // (tid, pos), ties in read order
+    FILE* f = fopen(bam_path, "wb");
+    if (!f) { set_err("lsio_synth_bam: cannot write %s", bam_path); return -1; }
+    std::vector<uint8_t> pending;                                                // the bytes not yet in a closed block: starts with the open block
     {
-        std::vector<uint8_t> h; h.insert(h.end(), {'B', 'A', 'M', 1});
+        std::vector<uint8_t>& h = pending; h.insert(h.end(), {'B', 'A', 'M', 1});
         std::string text = "@HD\tVN:1.6\tSO:coordinate\n";
         for (int t = 0; t < m->n_contigs; ++t) text += "@SQ\tSN:" + names[(size_t)t] + "\tLN:" + std::to_string(contig_len[t]) + "\n";
         put32(h, (uint32_t)text.size()); h.insert(h.end(), text.begin(), text.end());
         put32(h, (uint32_t)m->n_contigs);
         for (int t = 0; t < m->n_contigs; ++t) { put32(h, (uint32_t)names[(size_t)t].size() + 1); h.insert(h.end(), names[(size_t)t].begin(), names[(size_t)t].end()); h.push_back(0); put32(h, (uint32_t)contig_len[t]); }
-        w.write(h.data(), h.size());
     }
-    const char acgt[4] = {'A', 'C', 'G', 'T'};
-    auto code_of = [](char c) -> uint8_t { return c == 'A' ? 1 : c == 'C' ? 2 : c == 'G' ? 4 : c == 'T' ? 8 : 15; };
-    std::vector<uint32_t> cig; std::string seq; std::vector<uint8_t> qual, rec;
-    for (int64_t oi = 0; oi < R; ++oi) {
-        const int64_t i = order[(size_t)oi], ig = i + m->read_base;
-        const sm_read& r = hdr[(size_t)i];
-        cig.clear(); seq.clear(); qual.clear();
-        auto push_op = [&](uint32_t op, uint32_t len) { if (!len) return; if (!cig.empty() && (cig.back() & 0xf) == op) cig.back() += len << 4; else cig.push_back((len << 4) | op); };
-        for (int32_t c = 0; c < r.clip5; ++c) { const uint64_t h = sm_hash(m->seed, (uint64_t)ig, (uint64_t)(100000 + c), SM_D_INS); seq.push_back(acgt[h & 3]); qual.push_back((uint8_t)(2 + (h >> 8) % 39)); }
-        push_op(4, (uint32_t)r.clip5);
-        const int32_t end = r.t_off + r.t_len;
-        for (int32_t x = r.e0; x <= r.e1; ++x) {
-            const int32_t xt0 = m->exon_cum[x], xt1 = xt0 + m->exon_len[x];
-            const int32_t lo = r.t_off > xt0 ? r.t_off : xt0, hi = end < xt1 ? end : xt1;
-            if (x > r.e0) push_op(3, (uint32_t)(m->exon_start[x] - (m->exon_start[x - 1] + m->exon_len[x - 1])));
-            for (int32_t j = lo; j < hi; ++j) {
-                const int32_t blk = j >> 3, k = j & 7;
-                const int32_t ind = sm_block_indel(m, ig, blk, lo, hi);
-                if (ind > 0 && k >= 2 && k <= 1 + ind) { push_op(2, 1); continue; }      // deleted base
-                const uint32_t s = sm_base_call(m, ig, &r, j, (int64_t)m->exon_start[x] + (j - xt0));
-                seq.push_back((char)sm_base_of_sym(s)); qual.push_back((uint8_t)sm_qual(m, ig, j));
-                push_op(0, 1);
-                if (ind < 0 && k == 3) {
-                    for (int32_t c = 0; c < -ind; ++c) { const uint64_t h = sm_hash(m->seed, (uint64_t)ig, (uint64_t)((uint32_t)j * 4u + (uint32_t)c), SM_D_INS); seq.push_back(acgt[h & 3]); qual.push_back((uint8_t)(2 + (h >> 8) % 39)); }
-                    push_op(1, (uint32_t)(-ind));
+    // block cuts of a stream of writes, as BgzfWriter makes them: `open` bytes are in the open block, which starts at `start`
+    std::vector<std::pair<size_t, uint32_t>> blocks;                             // (offset in pending, bytes)
+    size_t start = 0, open = 0;
+    auto close_block = [&]() { blocks.emplace_back(start, (uint32_t)open); start += open; open = 0; };
+    auto cut_write = [&](size_t n) { while (n) { const size_t room = 0xff00 - open, take = n < room ? n : room; open += take; n -= take; if (open >= 0xff00) close_block(); } };
+    auto cut_record = [&](size_t n) { if (open && open + n > 0xff00) close_block(); cut_write(n); };
+    cut_write(pending.size());
+    bool ok = true;
+    const int64_t BATCH = 512, ROUND = std::max<int64_t>(65536, (int64_t)synth_threads() * 2048);
+    std::vector<std::vector<uint8_t>> bb; std::vector<std::vector<uint32_t>> bs;
+    std::vector<uint8_t> zout; std::vector<uint32_t> zlen; std::vector<uint8_t> okv;
+    for (int64_t r0 = 0; r0 < R || r0 == 0; r0 += ROUND) {
+        const int64_t r1 = std::min(R, r0 + ROUND), nb = (r1 - r0 + BATCH - 1) / BATCH;
+        bb.assign((size_t)nb, {}); bs.assign((size_t)nb, {});
+        synth_parallel(nb, 1, [&](int64_t b0, int64_t b1) {
+            SynthScratch sc;
+            for (int64_t b = b0; b < b1; ++b) {
+                std::vector<uint8_t>& out = bb[(size_t)b]; std::vector<uint32_t>& sz = bs[(size_t)b];
+                for (int64_t oi = r0 + b * BATCH; oi < std::min(r1, r0 + (b + 1) * BATCH); ++oi) {
+                    const int64_t i = order[(size_t)oi].i; const size_t at = out.size();
+                    synth_record(m, i + m->read_base, hdr[(size_t)i], pos[(size_t)i], barcode_suffix, sc, out);
+                    sz.push_back((uint32_t)(out.size() - at));
                 }
             }
-        }
-        for (int32_t c = 0; c < r.clip3; ++c) { const uint64_t h = sm_hash(m->seed, (uint64_t)ig, (uint64_t)(200000 + c), SM_D_INS); seq.push_back(acgt[h & 3]); qual.push_back((uint8_t)(2 + (h >> 8) % 39)); }
-        push_op(4, (uint32_t)r.clip3);
-        char name[32]; const int ln = snprintf(name, sizeof(name), "r%lld", (long long)ig) + 1;
-        rec.clear();
-        put32(rec, 0);                                                           // block_size placeholder
-        put32(rec, (uint32_t)r.tid); put32(rec, (uint32_t)pos[(size_t)i]);
-        rec.push_back((uint8_t)ln); rec.push_back(r.mapq); rec.push_back(0x48); rec.push_back(0x12);   // bin (unused)
-        rec.push_back((uint8_t)(cig.size() & 0xff)); rec.push_back((uint8_t)(cig.size() >> 8));
-        rec.push_back((uint8_t)(r.flag & 0xff)); rec.push_back((uint8_t)(r.flag >> 8));
-        put32(rec, (uint32_t)seq.size()); put32(rec, 0xffffffffu); put32(rec, 0xffffffffu); put32(rec, 0);
-        rec.insert(rec.end(), name, name + ln);
-        for (uint32_t c : cig) put32(rec, c);
-        for (size_t q = 0; q < seq.size(); q += 2) rec.push_back((uint8_t)((code_of(seq[q]) << 4) | (q + 1 < seq.size() ? code_of(seq[q + 1]) : 0)));
-        rec.insert(rec.end(), qual.begin(), qual.end());
-        const uint8_t nh[7] = {'N', 'H', 'C', 1, 0, 0, 0}; rec.insert(rec.end(), nh, nh + 4);
-        if (r.cb != -1) {
-            char bc[17]; sm_barcode(m->seed, r.cb >= 0 ? r.cb : ig, r.cb < 0, bc);
-            rec.push_back('C'); rec.push_back('B'); rec.push_back('Z'); rec.insert(rec.end(), bc, bc + 16);
-            if (barcode_suffix) rec.insert(rec.end(), barcode_suffix, barcode_suffix + strlen(barcode_suffix));
-            rec.push_back(0);
-        }
-        const uint32_t bs = (uint32_t)rec.size() - 4;
-        for (int b = 0; b < 4; ++b) rec[(size_t)b] = (uint8_t)(bs >> (8 * b));
-        w.write_record(rec.data(), rec.size());
+        });
+        std::vector<size_t> at((size_t)nb + 1, pending.size());
+        for (int64_t b = 0; b < nb; ++b) at[(size_t)b + 1] = at[(size_t)b] + bb[(size_t)b].size();
+        pending.resize(at[(size_t)nb]);
+        synth_parallel(nb, 16, [&](int64_t b0, int64_t b1) { for (int64_t b = b0; b < b1; ++b) if (!bb[(size_t)b].empty()) memcpy(pending.data() + at[(size_t)b], bb[(size_t)b].data(), bb[(size_t)b].size()); });
+        for (int64_t b = 0; b < nb; ++b) for (uint32_t n : bs[(size_t)b]) cut_record(n);
+        if (r1 >= R && open) close_block();
+        const int64_t nblk = (int64_t)blocks.size();
+        zout.resize((size_t)nblk * 70000); zlen.assign((size_t)nblk, 0); okv.assign((size_t)nblk, 1);
+        synth_parallel(nblk, 4, [&](int64_t b0, int64_t b1) {
+            for (int64_t b = b0; b < b1; ++b) { bool k = true; bgzf_block(pending.data() + blocks[(size_t)b].first, blocks[(size_t)b].second, zout.data() + (size_t)b * 70000, &zlen[(size_t)b], &k); okv[(size_t)b] = k; }
+        });
+        for (int64_t b = 0; b < nblk; ++b) { ok = ok && okv[(size_t)b]; if (fwrite(zout.data() + (size_t)b * 70000, 1, zlen[(size_t)b], f) != zlen[(size_t)b]) ok = false; }
+        blocks.clear();
+        pending.erase(pending.begin(), pending.begin() + (ptrdiff_t)start);     // keep the open block
+        start = 0;
+        if (r1 >= R) break;
     }
-    w.close();
-    if (!w.ok) { set_err("lsio_synth_bam: write failed"); return -1; }
+    { uint8_t eof[70000]; uint32_t n = 0; bgzf_block(nullptr, 0, eof, &n, &ok); if (fwrite(eof, 1, n, f) != n) ok = false; }   // EOF marker block
+    if (fclose(f) != 0) ok = false;
+    if (!ok) { set_err("lsio_synth_bam: write failed"); return -1; }
     return 0;
 }
 

@@ -78,3 +78,13 @@ def test_product_allgather_over_rccl_with_one_rank(tmp_path):
     """ % ROOT)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "rccl one-rank ok" in r.stdout, r.stderr[-2000:]
+
+
+def test_end_to_end_leg_is_measured_in_the_run():
+    """config.end_to_end is a measurement of this run (a BAM written in the run, files in -> files out) or null: never a quoted file"""
+    one = run_bench(["--reads", "3e5", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--e2e-reads", "2e4"])
+    e = one["config"]["end_to_end"]
+    assert e["measured"] == "in this run" and e["wall_s"] > 0 and e["step3_rows"] >= 0 and e["out_MB"]["step1"] > 0
+    assert {"gpu_count_call", "step2", "step3"} <= set(e["seconds"])
+    none = run_bench(["--reads", "3e5", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"])
+    assert none["config"]["end_to_end"] is None
