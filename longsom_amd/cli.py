@@ -255,7 +255,7 @@ def snv(argv=None):
         out = pipeline.run_snv(a.bam, a.meta, a.ref, a.outdir, a.id, params, a.editing or None, a.pon_SR or None, a.pon_LR or None,
                                a.gnomAD_json or a.gnomAD_db or None, a.device, comm=comm, window_bytes=int(a.window_gb * (1 << 30)) or None)
         if comm.rank == 0:
-            print(json.dumps({"outputs": {k: v for k, v in vars(out).items() if k != "timings"}, "seconds": out.timings, "ranks": comm.world}))
+            print(json.dumps({"outputs": {k: v for k, v in vars(out).items() if k not in ("timings", "resident", "_pending")}, "seconds": out.timings, "ranks": comm.world}))
     finally:
         comm.close()
 
@@ -268,6 +268,7 @@ def reannotation(argv=None):
     ap.add_argument("--id", required=True); ap.add_argument("--outdir", required=True)
     _optional_paths(ap, "--fusions", "--editing", "--pon_SR", "--pon_LR", "--gnomAD_json", "--gnomAD_db")
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--pass1_step3", action="store_true", help="also write pass 1's calling.step3.tsv (the reference's pass 1 stops at step 2)")
     # config['Reanno'] (pass 1: --reanno_* for the HCCV / re-annotation block, --p1_* for its BaseCellCounter / BaseCellCalling
     # block) and config['SNVCalling'] (pass 2: --p2_*); defaults = config/config.yaml
     rp0, sp0 = pipeline.ReannoParams(), pipeline.SnvParams()
@@ -278,10 +279,18 @@ def reannotation(argv=None):
     chain = pipeline.SnvParams(**{k: getattr(a, "p1_" + k) for k in vars(rp0.chain)})
     rp = pipeline.ReannoParams(chain=chain, **{k: getattr(a, "reanno_" + k) for k, v in vars(rp0).items() if k != "chain"})
     sp = pipeline.SnvParams(**{k: getattr(a, "p2_" + k) for k in vars(sp0)})
-    out = pipeline.run_reannotation(a.bam, a.meta, a.ref, a.outdir, a.id, rp, sp, fusions_tsv=a.fusions or None, editing=a.editing or None,
-                                    pon_sr=a.pon_SR or None, pon_lr=a.pon_LR or None, gnomad_af_json=a.gnomAD_json or a.gnomAD_db or None, device=a.device)
-    print(json.dumps({"hccv": out.hccv, "genotype": out.genotype, "barcodes": out.barcodes, "cells_kept": out.n_cells_kept, "cancer_cells": out.n_cancer,
-                      "pass2_step3": out.pass2.step3 if out.pass2 else None, "seconds": out.timings}))
+    # under torch.distributed.run (WORLD_SIZE > 1): one rank per GPU, every rank keeps its region's reads resident across both passes
+    from . import regions
+    comm = regions.Comm.from_env()
+    try:
+        out = pipeline.run_reannotation(a.bam, a.meta, a.ref, a.outdir, a.id, rp, sp, fusions_tsv=a.fusions or None, editing=a.editing or None,
+                                        pon_sr=a.pon_SR or None, pon_lr=a.pon_LR or None, gnomad_af_json=a.gnomAD_json or a.gnomAD_db or None, device=a.device,
+                                        pass1_step3=a.pass1_step3, comm=comm)
+        if comm.rank == 0:
+            print(json.dumps({"hccv": out.hccv, "genotype": out.genotype, "barcodes": out.barcodes, "cells_kept": out.n_cells_kept, "cancer_cells": out.n_cancer,
+                              "pass2_step3": out.pass2.step3 if out.pass2 else None, "seconds": out.timings, "ranks": comm.world}))
+    finally:
+        comm.close()
 
 
 def pon(argv=None):

@@ -66,6 +66,7 @@ class SnvOutputs:
     step3_unfiltered: str
     timings: Dict[str, float] = field(default_factory=dict)
     _pending: list = field(default_factory=list, repr=False, compare=False)
+    resident: Optional[dict] = field(default=None, repr=False, compare=False)      # a rank's region and decode summary (sharded two-pass loop)
 
     def start_background(self, fn) -> None:
         """run fn() (table writers) on a thread of its own; wait_for_tables joins it and re-raises what it raised"""
@@ -337,13 +338,18 @@ def _prefetch(gen, depth: int = 1):
         yield item
 
 
-def _run_snv_regions(bam, barcodes_tsv, ref_fasta, out_dir, sample_id, params, editing, pon_sr, pon_lr, gnomad_af_json, eng, comm, window_bytes) -> SnvOutputs:
+def _run_snv_regions(bam, barcodes_tsv, ref_fasta, out_dir, sample_id, params, editing, pon_sr, pon_lr, gnomad_af_json, eng, comm, window_bytes,
+                     step3: bool = True, resident: Optional[dict] = None, table=None) -> SnvOutputs:
+    """resident / table / step3 serve the sharded two-pass loop (run_reannotation with several ranks): `resident` = SnvOutputs.resident of
+    an earlier call on the same engine (the rank's reads stay in HBM, nothing is ingested again), `table` = (celltype_of per barcode
+    id, cell-type names, SplitBam report) of the pass, step3=False stops after the step-2 table (pass 1 of the reference has no step 3)."""
     t: Dict[str, float] = {"decode": 0.0, "load": 0.0, "gpu_count_call": 0.0, "fetch": 0.0, "write_tables": 0.0}
     t_all = time.time()
     bc = hostio.read_barcodes(barcodes_tsv)
     names_fa, seqs = tsvio.read_fasta(ref_fasta)
     seq_of = dict(zip(names_fa, seqs))
-    cts = bc.celltype_names
+    cts = list(table[1]) if table is not None else bc.celltype_names
+    ct_of = np.asarray(table[0], np.uint8) if table is not None else bc.celltype_of
     d = {k: os.path.join(out_dir, k) for k in ("SplitBam", "BaseCellCounter/" + sample_id, "MergeCounts", "BaseCellCalling")}
     tmp = os.path.join(out_dir, "_pieces." + sample_id)
     if comm.rank == 0:
@@ -362,10 +368,19 @@ def _run_snv_regions(bam, barcodes_tsv, ref_fasta, out_dir, sample_id, params, e
         eng.set_contigs(dec.contig_len)
         for tid, n in enumerate(dec.contig_names):
             eng.load_reference(tid, seq_of[n])
-        eng.set_barcodes(bc.celltype_of, len(cts))
+        eng.set_barcodes(ct_of, len(cts))
         contig["names"] = dec.contig_names
 
-    if comm.world > 1:
+    if resident is not None:
+        # the reads of this rank's region are in HBM already: the pass differs by its barcode -> cell-type table only
+        if comm.world <= 1:
+            raise ValueError("a resident pass belongs to a run with several ranks")
+        lo, hi, dec = resident["lo"], resident["hi"], resident["dec"]
+        contig["names"] = dec.contig_names
+        eng.set_barcodes(ct_of, len(cts))
+        work = iter([(lo, hi, None, dec)])
+        report = dict(table[2]) if table is not None and table[2] is not None else dict(dec.report)
+    elif comm.world > 1:
         t0 = time.time()
         dec = None
         if os.environ.get("LONGSOM_INGEST", "auto") in ("device", "auto"):
@@ -574,15 +589,20 @@ def _run_snv_regions(bam, barcodes_tsv, ref_fasta, out_dir, sample_id, params, e
             s2 = calling.step2_bytes(s1, eng, names, keys[0], keys[1], keys[2], params.min_distance, calling.open_gnomad(gnomad_af_json), params.max_gnomad_vaf)
             open(out.step2, "wb").write(s2)
             t["step2"] = time.time() - t0
-        t0 = time.time()
-        final, unfiltered = calling.step3_bytes(s2, params.delta_vaf, params.delta_mcf, params.min_ac_reads, params.min_ac_cells, params.clust_dist)
-        open(out.step3, "wb").write(final)
-        open(out.step3_unfiltered, "wb").write(unfiltered)
-        t["step3"] = time.time() - t0
+        if step3:
+            t0 = time.time()
+            final, unfiltered = calling.step3_bytes(s2, params.delta_vaf, params.delta_mcf, params.min_ac_reads, params.min_ac_cells, params.clust_dist)
+            open(out.step3, "wb").write(final)
+            open(out.step3_unfiltered, "wb").write(unfiltered)
+            t["step3"] = time.time() - t0
         import shutil
         shutil.rmtree(tmp, ignore_errors=True)
     comm.barrier()
     out.timings = t
+    if not step3:
+        out.step3 = out.step3_unfiltered = ""
+    if comm.world > 1:
+        out.resident = {"lo": lo, "hi": hi, "dec": dec, "table": bc}
     return out
 
 
@@ -620,15 +640,26 @@ class ReannoOutputs:
 def run_reannotation(bam: str, barcodes_tsv: str, ref_fasta: str, out_dir: str, sample_id: str, reanno_params: Optional[ReannoParams] = None,
                      snv_params: Optional[SnvParams] = None, fusions_tsv: Optional[str] = None, editing: Optional[str] = None,
                      pon_sr: Optional[str] = None, pon_lr: Optional[str] = None, gnomad_af_json: Optional[str] = None, device: int = 0,
-                     engine: Optional[Engine] = None, pass1_step3: bool = False) -> ReannoOutputs:
+                     engine: Optional[Engine] = None, pass1_step3: bool = False, comm: Optional["regions.Comm"] = None) -> ReannoOutputs:
     """The two-pass loop of the workflow (rules/CellTypeReannotation.smk + rules/SNVCalling.smk) in one process: the BAM is
     decoded and loaded ONCE; pass 1 calls with the automated annotation, the HCCV sites are genotyped per cell on the resident
     reads, the cells are re-annotated, and pass 2 re-counts the same resident reads under the new barcode table.
     Files: <out>/CellTypeReannotation/{SplitBam,BaseCellCounter,MergeCounts,BaseCellCalling,HCCV,ReannotatedCellTypes}/... and
-    <out>/SNVCalling/{SplitBam,BaseCellCounter,MergeCounts,BaseCellCalling}/..."""
+    <out>/SNVCalling/{SplitBam,BaseCellCounter,MergeCounts,BaseCellCalling}/...
+    comm (world > 1, BASELINE config 5 on several GPUs): one rank per GPU, every rank keeps the reads of its region resident across
+    both passes (_run_reannotation_ranks)."""
     from . import reanno
     rp = reanno_params or ReannoParams()
     sp = snv_params or SnvParams()
+    if comm is not None and comm.world > 1:
+        own = engine is None
+        eng = engine or Engine(comm.local_device_index)
+        try:
+            return _run_reannotation_ranks(bam, barcodes_tsv, ref_fasta, out_dir, sample_id, rp, sp, fusions_tsv, editing, pon_sr, pon_lr, gnomad_af_json, eng, comm,
+                                           pass1_step3)
+        finally:
+            if own:
+                eng.close()
     own = engine is None
     eng = engine or Engine(device)
     t = {}
@@ -672,6 +703,61 @@ def run_reannotation(bam: str, barcodes_tsv: str, ref_fasta: str, out_dir: str, 
     finally:
         if own:
             eng.close()
+
+
+def _run_reannotation_ranks(bam, barcodes_tsv, ref_fasta, out_dir, sample_id, rp, sp, fusions_tsv, editing, pon_sr, pon_lr, gnomad_af_json, eng, comm,
+                            pass1_step3) -> ReannoOutputs:
+    """The two-pass loop over several ranks: pass 1 is the sharded SNV run (every rank ingests and keeps its
+    region's slice of the BAM, writes its pieces of the tables, rank 0 assembles them); rank 0 filters the HCCVs (a small host step
+    over the step-2 table); every rank genotypes the HCCV sites of its own region on its resident reads and the per-(site, barcode)
+    tables are summed over the ranks (one all-reduce: sites x barcodes x 2 integers); rank 0 re-annotates the cells; the new barcode ->
+    cell-type table reaches the ranks as the file the rule graph writes anyway; pass 2 re-counts the SAME resident reads on every rank.
+    No BAM byte is read twice, no read crosses a link: what travels is the candidate rows of both passes and the genotype tables."""
+    from . import reanno
+    if sp.min_mapping_quality != rp.chain.min_mapping_quality:
+        raise ValueError("the two passes must share min_mapping_quality to share one decode (SplitBam report)")
+    t: Dict[str, float] = {}
+    d1 = os.path.join(out_dir, "CellTypeReannotation")
+    p1 = _run_snv_regions(bam, barcodes_tsv, ref_fasta, d1, sample_id, rp.chain, editing, pon_sr, pon_lr, gnomad_af_json, eng, comm, None, step3=pass1_step3)
+    state = p1.resident
+    table, dec = state["table"], state["dec"]
+    hccv = os.path.join(d1, "HCCV", sample_id + ".HCCV.tsv")
+    geno = os.path.join(d1, "HCCV", sample_id + ".SNVs.SingleCellGenotype.tsv")
+    t0 = time.time()
+    if comm.rank == 0:
+        os.makedirs(os.path.join(d1, "HCCV"), exist_ok=True)
+        made = reanno.hccv_filter(p1.step2, os.path.join(d1, "HCCV", sample_id), rp.hccv_min_depth, rp.hccv_delta_vaf, rp.hccv_delta_mcf, rp.hccv_clust_dist)
+        assert os.path.abspath(made) == os.path.abspath(hccv), (made, hccv)
+    comm.barrier()                                          # the HCCV file is there for every rank
+    t["hccv"] = time.time() - t0
+    t0 = time.time()
+    eng.set_barcodes(table.celltype_of, len(table.celltype_names))
+    n_rows = reanno.single_cell_genotype(eng, hccv, table, dec.contig_names, geno, alt_flag=rp.alt_flag, min_bq=rp.genotype_min_bq,
+                                         min_mq=rp.chain.min_mapping_quality, alpha2=rp.chain.alpha2, beta2=rp.chain.beta2, pvalue=rp.pvalue,
+                                         chrm_contaminant=rp.chrm_contaminant, comm=comm, region=(state["lo"], state["hi"]))
+    t["genotype"] = time.time() - t0
+    out = ReannoOutputs(p1, hccv, geno, "", None, timings=t)
+    if n_rows == 0:
+        return out
+    t0 = time.time()
+    out.barcodes = os.path.join(d1, "ReannotatedCellTypes", sample_id + ".tsv")
+    kept = np.zeros(2, np.int64)
+    if comm.rank == 0:
+        os.makedirs(os.path.join(d1, "ReannotatedCellTypes"), exist_ok=True)
+        kept[:] = reanno.celltype_reannotation(geno, fusions_tsv or "", barcodes_tsv, out.barcodes, rp.min_variants, rp.min_fraction)
+    kept = comm.allreduce_sum(kept)                          # (also the barrier behind which the new table is on disk)
+    out.n_cells_kept, out.n_cancer = int(kept[0]), int(kept[1])
+    t["reannotation"] = time.time() - t0
+    if out.n_cells_kept == 0:
+        return out
+    new = hostio.read_barcodes(out.barcodes)
+    idx = {b: i for i, b in enumerate(table.barcodes)}
+    ct2 = np.full(len(table.barcodes), 255, np.uint8)
+    for b, c in zip(new.barcodes, new.celltype_of):
+        ct2[idx[b]] = c
+    out.pass2 = _run_snv_regions(bam, barcodes_tsv, ref_fasta, os.path.join(out_dir, "SNVCalling"), sample_id, sp, editing, pon_sr, pon_lr, gnomad_af_json, eng, comm,
+                                 None, resident=state, table=(ct2, new.celltype_names, dec.report_for(ct2 != 255)))
+    return out
 
 
 @dataclass

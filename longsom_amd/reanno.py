@@ -185,8 +185,11 @@ def _p4_text(k: int) -> str:
 def single_cell_genotype(engine, variant_file: str, table, contig_names: Sequence[str], out_path: str, *, alt_flag: str = "All",
                          window: int = 50000, min_bq: int = 30, min_mq: int = 255, alpha2: float = 0.260288007167716,
                          beta2: float = 173.94711910763732, pvalue: float = 0.01, chrm_contaminant: str = "True",
-                         strict_cb: bool = True, max_depth: int = 200000) -> int:
+                         strict_cb: bool = True, max_depth: int = 200000, comm=None, region=None) -> int:
     """The reads, contigs and `table` (hostio.BarcodeTable) must be resident in `engine`.  Returns the number of rows written.
+    comm (regions.Comm of several ranks) + region ((tid, pos) lo, hi of this rank): every rank genotypes the target sites of its
+    own region on its own resident reads (its slice of the BAM holds every read that reaches into the region), the per-(site,
+    barcode) depth / alt tables are summed over the ranks, and rank 0 writes the file (the other ranks' out_path is not touched).
     Row order = the reference's: windows by (chromosome text, smallest position), inside a window the positions in the
     iteration order of Python's set of them (:111,131 — reproduced by building that very set), per position every barcode
     of barcodes.tsv in file order."""
@@ -225,7 +228,22 @@ def single_cell_genotype(engine, variant_file: str, table, contig_names: Sequenc
     keys = np.asarray(uniq, np.int64)
     code = (keys >> 32) * (1 << 40) + ((keys & 0xFFFFFFFF) + 1) // int(window) if len(keys) else keys
     group_off = np.concatenate([[0], np.nonzero(np.diff(code))[0] + 1, [len(keys)]]).astype(np.int64)
-    dp, alt = engine.genotype_cells_grouped(keys, alt_sym, group_off, params, max_depth)
+    if comm is not None and comm.world > 1:
+        k_lo, k_hi = (int(region[0][0]) << 32) | int(region[0][1]), (int(region[1][0]) << 32) | int(region[1][1])
+        mine = np.nonzero((keys >= k_lo) & (keys < k_hi))[0]
+        n_cb = len(table.barcodes)
+        both = np.zeros((2, len(keys), n_cb), np.int64)
+        if len(mine):
+            sub_code = code[mine]
+            sub_off = np.concatenate([[0], np.nonzero(np.diff(sub_code))[0] + 1, [len(mine)]]).astype(np.int64)
+            d_, a_ = engine.genotype_cells_grouped(keys[mine], alt_sym[mine], sub_off, params, max_depth)
+            both[0, mine] = d_; both[1, mine] = a_
+        both = comm.allreduce_sum(both.reshape(-1)).reshape(2, len(keys), n_cb)          # (a site belongs to one rank: the sum places the rows)
+        dp, alt = both[0].astype(np.uint32), both[1].astype(np.uint32)
+        if comm.rank != 0:
+            out_path = os.devnull
+    else:
+        dp, alt = engine.genotype_cells_grouped(keys, alt_sym, group_off, params, max_depth)
     # beta-binomial tails of the covered, mutated cells outside chrM
     need = []
     for chrom, _, order, _ in blocks:

@@ -85,3 +85,47 @@ def test_two_pass_loop(engine, tmp_path):
         assert a[0] == b[0] and a[1].split("\t")[:-1] == b[1].split("\t")[:-1], sub
     # pass 2 really ran under another table
     assert open(fused / "SNVCalling/MergeCounts/S1.BaseCellCounts.AllCellTypes.tsv").read() != open(fused / "CellTypeReannotation/MergeCounts/S1.BaseCellCounts.AllCellTypes.tsv").read()
+
+
+@pytest.mark.parametrize("world,indexed", [(2, False), (3, True)])
+def test_two_pass_loop_over_ranks(tmp_path, world, indexed):
+    """BASELINE config 5 over several ranks (torch.distributed.run, both ranks on device 0 with the collectives over gloo — RCCL
+    refuses two ranks on one GPU; on the 8-GPU node the same code runs with LSG_DIST_BACKEND unset = nccl): every rank keeps its
+    region's reads resident across both passes, the HCCV sites are genotyped where their reads are, and every file of both
+    passes is the single-process fused run's, byte for byte"""
+    import json
+    import socket
+    m = synth.named("C1", n_reads=30000, n_genes=12, n_cb=80, snp_mod=120)
+    bam, fa, bct = str(tmp_path / "S1.bam"), str(tmp_path / "ref.fa"), str(tmp_path / "barcodes.tsv")
+    hostio.synth_bam(m, bam, fa)
+    if indexed:
+        hostio.build_bai(bam)                      # every rank ingests only its slice of the file
+    hostio.write_barcodes_tsv(bct, hostio.synth_barcodes(m), m.celltype_of, ["Cancer", "Non-Cancer"])
+    flags = ["--p1_min_ac_cells", "2", "--p1_min_ac_reads", "3", "--reanno_hccv_min_depth", "10", "--reanno_hccv_delta_vaf", "0.05", "--reanno_hccv_delta_mcf", "0.05",
+             "--reanno_hccv_clust_dist", "5", "--reanno_chrm_contaminant", "True", "--reanno_min_variants", "2", "--reanno_min_fraction", "0.2", "--pass1_step3"]
+    script = os.path.join(S, "CellTypeReannotation", "longsom_gpu_reannotation.py")
+    base = ["--bam", bam, "--meta", bct, "--ref", fa, "--id", "S1"] + flags
+    one = tmp_path / "one"
+    r1 = subprocess.run([sys.executable, script] + base + ["--outdir", str(one)], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    s1 = json.loads([l for l in r1.stdout.split("\n") if l.startswith("{")][-1])
+    assert s1["pass2_step3"] and 0 < s1["cancer_cells"] < s1["cells_kept"]
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, LSG_DIST_BACKEND="gloo", LSG_DIST_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    many = tmp_path / "ranks"
+    rn = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+                         "--master-port", str(port), script] + base + ["--outdir", str(many)], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert rn.returncode == 0, rn.stderr[-3000:]
+    sn = json.loads([l for l in rn.stdout.split("\n") if l.startswith("{")][-1])
+    assert sn["ranks"] == world and (sn["cells_kept"], sn["cancer_cells"]) == (s1["cells_kept"], s1["cancer_cells"])
+    rels = ["CellTypeReannotation/HCCV/S1.HCCV.tsv", "CellTypeReannotation/HCCV/S1.SNVs.SingleCellGenotype.tsv", "CellTypeReannotation/ReannotatedCellTypes/S1.tsv"]
+    for sub in ("CellTypeReannotation", "SNVCalling"):
+        rels += [sub + "/" + r for r in ("BaseCellCounter/S1/S1.Cancer.tsv", "BaseCellCounter/S1/S1.Non-Cancer.tsv", "MergeCounts/S1.BaseCellCounts.AllCellTypes.tsv",
+                                         "BaseCellCalling/S1.calling.step1.tsv", "BaseCellCalling/S1.calling.step2.tsv", "BaseCellCalling/S1.calling.step3.tsv",
+                                         "BaseCellCalling/S1.calling.step3.unfiltered.tsv")]
+    for rel in rels:
+        assert strip_date(str(many / rel)) == strip_date(str(one / rel)), rel
+    for sub in ("CellTypeReannotation", "SNVCalling"):
+        a = open(many / sub / "SplitBam" / "S1.report.txt").read().split("\n")
+        b = open(one / sub / "SplitBam" / "S1.report.txt").read().split("\n")
+        assert a[0] == b[0] and a[1].split("\t")[:-1] == b[1].split("\t")[:-1], sub

@@ -38,13 +38,15 @@ rule Reannotation_gpu:
         r=config['Reanno']['Reannotation'],
         c2=config['SNVCalling']['BaseCellCalling'],
         m2=config['SNVCalling']['BaseCellCounter']['min_mapping_quality'],
+        # GPUs of this node used by the rule: one rank per GPU, every rank keeps its region's reads in HBM across both passes
+        launcher=lambda wc, resources: "python" if resources.gpu == 1 else f"python -m torch.distributed.run --standalone --local-addr 127.0.0.1 --nnodes=1 --nproc-per-node {resources.gpu}",
     resources:
-        gpu=1
+        gpu=config['Run'].get('gpus', 1)
     log:
         "logs/Reannotation_gpu/{id}.log",
     shell:
         r"""
-        python {params.script} --bam {input.bam} --meta {input.barcodes} --ref {input.ref} --id {wildcards.id} --outdir . \
+        {params.launcher} {params.script} --bam {input.bam} --meta {input.barcodes} --ref {input.ref} --id {wildcards.id} --outdir . \
         --fusions {input.fusions} --editing {input.RNA_editing} --pon_SR {input.pon_SR} --pon_LR {input.pon_LR} --gnomAD_db {params.gnomAD_db} {params.gz_compat} {params.htslib} {params.no_gnomad} \
         --p1_min_mapping_quality {params.m1} --p1_min_cell_types {params.r1[Min_cell_types]} --p1_min_distance {params.r1[min_distance]} \
         --p1_max_gnomad_vaf {params.r1[max_gnomAD_VAF]} \
