@@ -322,5 +322,12 @@ def pon_chain(argv=None):
     normals = [tuple(l.rstrip("\n").split("\t")[:3]) for l in open(a.normals) if l.strip() and not l.startswith("#")]
     p = pipeline.pon_params(alpha1=a.alpha1, beta1=a.beta1, alpha2=a.alpha2, beta2=a.beta2, min_ac_cells=a.min_ac_cells, min_ac_reads=a.min_ac_reads,
                             min_cells=a.min_cells, min_cell_types=a.min_cell_types, min_mapping_quality=a.min_mq)
-    out = pipeline.run_pon(normals, a.ref, a.outdir, p, a.min_samples, a.rm_prefix, not a.no_tables, device=a.device)
-    print(json.dumps({"pon": out.pon, "sites": out.n_sites, "seconds": out.timings}))
+    # under torch.distributed.run: the normals are spread over the ranks (one GPU each)
+    from . import regions
+    comm = regions.Comm.from_env()
+    try:
+        out = pipeline.run_pon(normals, a.ref, a.outdir, p, a.min_samples, a.rm_prefix, not a.no_tables, device=a.device, comm=comm)
+        if comm.rank == 0:
+            print(json.dumps({"pon": out.pon, "sites": out.n_sites, "seconds": out.timings, "ranks": comm.world}))
+    finally:
+        comm.close()

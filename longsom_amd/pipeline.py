@@ -776,19 +776,24 @@ def pon_params(**kw) -> SnvParams:
 
 
 def run_pon(normals, ref_fasta: str, out_dir: str, params: Optional[SnvParams] = None, min_samples: int = 1, rm_prefix: str = "No",
-            write_tables: bool = True, out_name: str = "PoN_LR.tsv", device: int = 0, engine: Optional[Engine] = None) -> PonOutputs:
+            write_tables: bool = True, out_name: str = "PoN_LR.tsv", device: int = 0, engine: Optional[Engine] = None,
+            comm: Optional["regions.Comm"] = None) -> PonOutputs:
     """rules/PoN.smk from SplitBam_PoN to PoN in one process: for every normal (id, bam, barcodes.tsv) the count + step-1 call
     chain, then scripts/PoN/PoN.py over the sites with a filter status.  The beta-binomial parameters come in through `params`
     (BetaBinEstimation.py's VGAM fit stays outside).  write_tables=False skips the per-normal tables (the PoN needs only the call
     records); the PoN file is the same either way.  Output layout: <out_dir>/PoN/{SplitBam,BaseCellCounter,MergeCounts,
-    BaseCellCalling,PoN}/ as in the rule file."""
+    BaseCellCalling,PoN}/ as in the rule file.  comm (world > 1): the normals are independent samples — rank r takes every world-th one
+    on its own GPU, the sites of their call records are gathered (one all-gather of a few MB) and rank 0 writes the panel."""
+    import pickle
     params = params or pon_params()
+    comm = comm or regions.Comm()
     own = engine is None
-    eng = engine or Engine(device)
+    eng = engine or Engine(comm.local_device_index if comm.world > 1 else device)
     root = os.path.join(out_dir, "PoN")
     entries, step1, timings = [], {}, {}
+    normals = list(normals)
     try:
-        for sample_id, bam, barcodes_tsv in normals:
+        for sample_id, bam, barcodes_tsv in normals[comm.rank::comm.world]:
             res = load_sample(bam, barcodes_tsv, ref_fasta, eng, params.min_mapping_quality)
             out, _, calls, t = chain_step1(res, res.table.celltype_of, res.table.celltype_names, res.dec.report, root, sample_id, params, write_tables)
             label = sample_id + ".calling.step1.tsv"          # basename of the table, the sample id of PoN.py:55
@@ -798,9 +803,17 @@ def run_pon(normals, ref_fasta: str, out_dir: str, params: Optional[SnvParams] =
     finally:
         if own:
             eng.close()
-    os.makedirs(os.path.join(root, "PoN"), exist_ok=True)
+    if comm.world > 1:
+        blobs = comm.allgather_bytes(pickle.dumps((entries, step1, timings)))
+        entries, step1, timings = [], {}, {}
+        for blob in blobs:
+            e, s1, tm = pickle.loads(blob)
+            entries += e; step1.update(s1); timings.update(tm)
     path = os.path.join(root, "PoN", out_name)
-    text = pon.pon_text(entries, min_samples, rm_prefix)
-    with open(path, "w") as f:
-        f.write(text)
+    text = pon.pon_text(entries, min_samples, rm_prefix)          # (sorted inside: the panel does not depend on which rank took which normal)
+    if comm.rank == 0:
+        os.makedirs(os.path.join(root, "PoN"), exist_ok=True)
+        with open(path, "w") as f:
+            f.write(text)
+    comm.barrier()
     return PonOutputs(path, step1, sum(1 for l in text.split("\n") if l and not l.startswith("#")), timings)

@@ -60,3 +60,17 @@ def test_fused_panel_equals_the_table_route(engine, tmp_path):
     subprocess.check_call([sys.executable, os.path.join(root, "workflow", "scripts_gpu", "PoN", "PoN.py"), "--in_tsv", str(lst), "--out_file",
                            str(tmp_path / "PoN.shim.tsv"), "--min_samples", "1", "--rm_prefix", "No"], cwd=root, stdout=subprocess.DEVNULL)
     assert body(tmp_path / "PoN.shim.tsv") == rows
+
+    # ... and over two ranks (the normals spread over the ranks; both on device 0 here, the gather over gloo): the same panel
+    import socket
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    env = dict(os.environ, LSG_DIST_BACKEND="gloo", LSG_DIST_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(root, "workflow", "scripts_gpu", "PoN", "longsom_gpu_pon.py"), "--normals", str(tsv), "--ref", ref,
+                        "--outdir", str(tmp_path / "ranks"), "--alpha1", repr(p.alpha1), "--beta1", repr(p.beta1), "--alpha2", repr(p.alpha2),
+                        "--beta2", repr(p.beta2)], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert '"ranks": 2' in r.stdout
+    assert body(tmp_path / "ranks" / "PoN" / "PoN" / "PoN_LR.tsv") == rows
+    for n in normals:                                      # every normal's tables were written by the rank that took it
+        assert body(tmp_path / "ranks" / "PoN" / "BaseCellCalling" / (n[0] + ".calling.step1.tsv")) == body(out.step1[n[0]])

@@ -36,10 +36,12 @@ rule PoN_gpu:
         beta2=lambda w, input: get_BetaBinEstimates(input.bb, 'beta2'),
         p=config['PoN'],
         tables="" if config['PoN'].get('tables', True) else "--no_tables",
+        # GPUs of this node used by the rule: the normals are spread over one rank per GPU
+        launcher=lambda wc, resources: "python" if resources.gpu == 1 else f"python -m torch.distributed.run --standalone --local-addr 127.0.0.1 --nnodes=1 --nproc-per-node {resources.gpu}",
     resources:
-        gpu=1
+        gpu=config.get('Run', {}).get('gpus', 1)
     shell:
-        "python {params.script} --normals {input.normals} --ref {params.hg38} --outdir {OUTDIR} --min_mq {params.mapq} "
+        "{params.launcher} {params.script} --normals {input.normals} --ref {params.hg38} --outdir {OUTDIR} --min_mq {params.mapq} "
         "--alpha1 {params.alpha1} --beta1 {params.beta1} --alpha2 {params.alpha2} --beta2 {params.beta2} "
         "--min_ac_cells {params.p[min_ac_cells]} --min_ac_reads {params.p[min_ac_reads]} --min_cells {params.p[min_cells]} "
         "--min_cell_types {params.p[min_cell_types]} --min_samples 1 --rm_prefix No {params.tables}"
