@@ -124,7 +124,77 @@ def _cluster_tags(index: pd.Series, flt: pd.Series, clust_dist: int) -> pd.Serie
 
 
 def hccv_filter(step2_tsv: str, out_prefix: str, min_dp: float = 20, delta_vaf: float = 0.1, delta_mcf: float = 0.4, clust_dist: int = 10000) -> str:
-    """Writes <out_prefix>.HCCV.tsv (and the reference's two intermediate tables, .HCCV.tsv2 / .HCCV.tsv3); returns its path."""
+    """Writes <out_prefix>.HCCV.tsv (and the reference's two intermediate tables, .HCCV.tsv2 / .HCCV.tsv3); returns its path.
+    The reference applies three Python row functions to every row of the step-2 table (14 s for the 1.6 M rows of a 1 M-read sample,
+    against 3 s for the whole SNV chain before it); here MultiAllelic_filtering runs on the rows it can change (FILTER naming
+    Multi-allelic, or an ALT with '|'; every other row is returned as it came, :92-93), DP_filtering is two column operations, and
+    MCF_filtering runs after the FILTER patterns, on the rows that are still there, as in the reference.  Same three files, byte
+    for byte (tests/test_reanno_cpu.py: the goldens, and the row-wise form on shuffled, replicated and single-cell-type tables)."""
+    if os.environ.get("LONGSOM_HCCV_ROW_PATH", "0") == "1":
+        return _hccv_filter_rowwise(step2_tsv, out_prefix, min_dp, delta_vaf, delta_mcf, clust_dist)
+    out = out_prefix + ".HCCV.tsv"
+    cols = None
+    with open(out, "w") as dst, open(step2_tsv) as src:
+        for line in src:
+            if not line.startswith("#"):
+                break
+            if "#CHROM" in line:
+                cols = line.rstrip("\n").split("\t")
+            else:
+                dst.write(line)
+        dst.write(HCCV_INFO_LINE)
+    df = pd.read_csv(step2_tsv, sep="\t", comment="#", names=cols)
+    df["INDEX"] = df["#CHROM"].astype(str) + ":" + df["Start"].astype(str) + ":" + df["ALT"].str.split(",", n=1, expand=True)[0]
+    df = df[df["Cell_types"] != "Non-Cancer"]
+    changed = ["ALT", "FILTER", "Cell_types", "Bc", "Cc", "VAF", "MCF"]
+    if len(df) and not (df["FILTER"].map(type).eq(str).all() and df["ALT"].map(type).eq(str).all()):
+        return _hccv_filter_rowwise(step2_tsv, out_prefix, min_dp, delta_vaf, delta_mcf, clust_dist)      # (a FILTER / ALT that is not text: the row functions decide)
+    touch = df["FILTER"].str.contains("Multi-allelic", regex=False) | df["ALT"].str.contains("|", regex=False) if len(df) else pd.Series([], dtype=bool)
+    if len(df) and touch.any():
+        sub = df[touch]
+        need = ["ALT", "FILTER", "Cell_types", "Bc", "Cc", "VAF", "MCF", "Cancer", "Non-Cancer", "REF", "Dp", "Nc"]
+        lists = [sub[c].tolist() for c in need]
+        res = [_resolve_multiallelic(dict(zip(need, vals))) for vals in zip(*lists)]      # (the row as a dict: a Series per row costs ten times the function)
+        good = np.fromiter((r is not None and r[7] == "KEEP" for r in res), bool, len(res))      # (None: the reference's row of NaN, not KEEP)
+        for c in changed:                                   # the reference's columns are object after its expand-assignment: the same values, as objects
+            df[c] = df[c].astype(object)
+        ok = sub.index[good]
+        kept_res = [r for r, g in zip(res, good) if g]
+        for j, c in enumerate(changed):
+            df.loc[ok, c] = pd.Series([r[j] for r in kept_res], index=ok, dtype=object)
+        df = df.drop(index=sub.index[~good])
+    df = df[cols + ["INDEX"]]
+    # DP_filtering (:202-212): the first field of both cell types' columns; a missing column is NoCov
+    if len(df):
+        def depth(col):
+            return pd.to_numeric(df[col].where(df[col].map(type).eq(str)).str.split("|", n=1).str[0], errors="coerce")
+        d_c, d_n = depth("Cancer"), depth("Non-Cancer")
+        df = df[(d_c >= min_dp) & (d_n >= min_dp)]
+    df["DP_FILTER"] = pd.Series("PASS", index=df.index, dtype=object)
+    df.to_csv(out + "2", sep="\t", index=False, mode="a")
+    # chrM keeps its own, shorter filter list (contaminants, :52-58)
+    chrm = df[df["#CHROM"] == "chrM"].copy()
+    df = df[df["#CHROM"] != "chrM"]
+    chrm = chrm[~chrm["FILTER"].str.contains("Min|LR|gnomAD|LC|RNA", regex=True)]
+    for pat in ("Noisy_site", "LC_Upstream|LC_Downstream", "gnomAD", "RNA_editing_db", "PoN"):      # filters 2-6 (:60-73)
+        df = df[~df["FILTER"].str.contains(pat, regex=True)]
+    df = pd.concat([df, chrm])
+    if not len(df):
+        df["HCCV_FILTER"] = df.apply(lambda r: _delta_verdict(r["Cell_types"], r["VAF"], r["MCF"], delta_vaf, delta_mcf), axis=1)      # (what the reference does with an empty frame)
+    else:
+        df["HCCV_FILTER"] = pd.Series([_delta_verdict(c, v, m, delta_vaf, delta_mcf) for c, v, m in zip(df["Cell_types"].tolist(), df["VAF"].tolist(), df["MCF"].tolist())],
+                                      index=df.index, dtype=object)
+    df.to_csv(out + "3", sep="\t", index=False, mode="a")
+    df = df[df["HCCV_FILTER"] == "PASS"]
+    df["FILTER"] = _cluster_tags(df["INDEX"], df["FILTER"], clust_dist)
+    df = df[~df["FILTER"].str.contains("dist", regex=True)]
+    df.to_csv(out, sep="\t", index=False, mode="a")
+    return out
+
+
+def _hccv_filter_rowwise(step2_tsv: str, out_prefix: str, min_dp: float = 20, delta_vaf: float = 0.1, delta_mcf: float = 0.4, clust_dist: int = 10000) -> str:
+    """hccv_filter with every row function applied to every row, in the reference's order (HighConfidenceCancerVariants.py:8-88): what the
+    reference-generated goldens pin directly, and what tests compare the column-wise form below with (LONGSOM_HCCV_ROW_PATH=1 selects it)."""
     out = out_prefix + ".HCCV.tsv"
     cols = None
     with open(out, "w") as dst, open(step2_tsv) as src:

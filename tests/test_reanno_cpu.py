@@ -24,6 +24,49 @@ def test_hccv_filter_equals_reference(tmp_path, tag, args):
     assert n >= 3                                        # the fixture keeps real rows through every filter
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_hccv_filter_column_form_equals_the_row_form(tmp_path, seed, monkeypatch):
+    """the column-wise hccv_filter (row functions only where they can change a row) against the reference-shaped row-wise one — which the
+    goldens above pin — on tables made of the golden's rows: replicated with shifted positions, some moved to chrM, and cut down to one
+    kind of row (single cell type, Cancer only, multi-allelic only, none multi-allelic: the column dtypes pandas infers differ)"""
+    import filecmp
+    lines = open(os.path.join(G, "sample.calling.step2.tsv")).read().split("\n")
+    head = [l for l in lines if l.startswith("#")]
+    rows = [l.split("\t") for l in lines if l and not l.startswith("#")]
+    rng = np.random.default_rng(seed)
+    cases = [("all", None), ("single", lambda r: "," not in r[6]), ("cancer_only", lambda r: r[6] == "Cancer"), ("multi", lambda r: "Multi" in r[5]),
+             ("nomulti", lambda r: "Multi" not in r[5] and "|" not in r[4]), ("noncancer", lambda r: r[6] == "Non-Cancer")]
+    args = [(50, 0.2, 0.25, 10000), (5, 0.05, 0.1, 400), (20, 0.1, 0.4, 10000)][seed % 3]
+    for name, pick in cases:
+        out = list(head)
+        for k in range(int(rng.integers(1, 4))):
+            for r in (rows if pick is None else [r for r in rows if pick(r)]):
+                if rng.random() < 0.15:
+                    continue
+                r2 = list(r)
+                shift = k * 1_000_000 + int(rng.integers(0, 3)) * 7
+                r2[1] = str(int(r[1]) + shift); r2[2] = str(int(r[2]) + shift)
+                if rng.random() < 0.05:
+                    r2[0] = "chrM"
+                out.append("\t".join(r2))
+        table = tmp_path / ("%s.tsv" % name)
+        table.write_text("\n".join(out) + "\n")
+        got = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("LONGSOM_HCCV_ROW_PATH", mode)
+            try:
+                got[mode] = reanno.hccv_filter(str(table), str(tmp_path / ("%s.%s" % (name, mode))), *args)
+            except Exception as e:                            # noqa: BLE001 - (a table with no row left: the reference's frame operations raise; both forms must)
+                got[mode] = type(e)
+        if isinstance(got["1"], type) or isinstance(got["0"], type):
+            assert got["1"] == got["0"], (name, got)
+            continue
+        for sfx in ("", "2", "3"):
+            assert filecmp.cmp(got["1"] + sfx, got["0"] + sfx, shallow=False), (name, sfx)
+        if name == "all":
+            assert sum(1 for l in open(got["0"]) if not l.startswith("#")) > 3
+
+
 @pytest.mark.parametrize("tag,fusions,mv,mf", [("reanno", "reanno.Fusions.SingleCellGenotype.tsv", 3, 0.25), ("reanno.nofusion", "", 2, 0.5)])
 def test_celltype_reannotation_equals_reference(tmp_path, tag, fusions, mv, mf):
     out = str(tmp_path / "out.tsv")
