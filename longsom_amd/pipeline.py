@@ -675,9 +675,10 @@ def run_reannotation(bam: str, barcodes_tsv: str, ref_fasta: str, out_dir: str, 
         t0 = time.time()
         eng.set_barcodes(res.table.celltype_of, len(res.table.celltype_names))
         geno = os.path.join(d1, "HCCV", sample_id + ".SNVs.SingleCellGenotype.tsv")
+        gstats: Dict[str, dict] = {}
         n_rows = reanno.single_cell_genotype(eng, hccv, res.table, res.contig_names, geno, alt_flag=rp.alt_flag, min_bq=rp.genotype_min_bq,
                                              min_mq=rp.chain.min_mapping_quality, alpha2=rp.chain.alpha2, beta2=rp.chain.beta2, pvalue=rp.pvalue,
-                                             chrm_contaminant=rp.chrm_contaminant)
+                                             chrm_contaminant=rp.chrm_contaminant, stats=gstats)
         t["genotype"] = time.time() - t0
         out = ReannoOutputs(p1, hccv, geno, "", None, timings=t)
         if n_rows == 0:                                   # no HCCV: the reference writes no genotype table and the workflow stops here
@@ -685,7 +686,8 @@ def run_reannotation(bam: str, barcodes_tsv: str, ref_fasta: str, out_dir: str, 
         t0 = time.time()
         os.makedirs(os.path.join(d1, "ReannotatedCellTypes"), exist_ok=True)
         out.barcodes = os.path.join(d1, "ReannotatedCellTypes", sample_id + ".tsv")
-        out.n_cells_kept, out.n_cancer = reanno.celltype_reannotation(geno, fusions_tsv or "", barcodes_tsv, out.barcodes, rp.min_variants, rp.min_fraction)
+        out.n_cells_kept, out.n_cancer = reanno.celltype_reannotation(geno, fusions_tsv or "", barcodes_tsv, out.barcodes, rp.min_variants, rp.min_fraction,
+                                                                      stats=gstats if os.environ.get("LONGSOM_REANNO_FROM_FILE", "0") != "1" else None)
         t["reannotation"] = time.time() - t0
         # pass 2: same resident reads, new barcode -> cell-type table (cells below coverage are no longer listed)
         if sp.min_mapping_quality != rp.chain.min_mapping_quality:
@@ -732,9 +734,10 @@ def _run_reannotation_ranks(bam, barcodes_tsv, ref_fasta, out_dir, sample_id, rp
     t["hccv"] = time.time() - t0
     t0 = time.time()
     eng.set_barcodes(table.celltype_of, len(table.celltype_names))
+    gstats: Dict[str, dict] = {}
     n_rows = reanno.single_cell_genotype(eng, hccv, table, dec.contig_names, geno, alt_flag=rp.alt_flag, min_bq=rp.genotype_min_bq,
                                          min_mq=rp.chain.min_mapping_quality, alpha2=rp.chain.alpha2, beta2=rp.chain.beta2, pvalue=rp.pvalue,
-                                         chrm_contaminant=rp.chrm_contaminant, comm=comm, region=(state["lo"], state["hi"]))
+                                         chrm_contaminant=rp.chrm_contaminant, comm=comm, region=(state["lo"], state["hi"]), stats=gstats)
     t["genotype"] = time.time() - t0
     out = ReannoOutputs(p1, hccv, geno, "", None, timings=t)
     if n_rows == 0:
@@ -744,7 +747,8 @@ def _run_reannotation_ranks(bam, barcodes_tsv, ref_fasta, out_dir, sample_id, rp
     kept = np.zeros(2, np.int64)
     if comm.rank == 0:
         os.makedirs(os.path.join(d1, "ReannotatedCellTypes"), exist_ok=True)
-        kept[:] = reanno.celltype_reannotation(geno, fusions_tsv or "", barcodes_tsv, out.barcodes, rp.min_variants, rp.min_fraction)
+        kept[:] = reanno.celltype_reannotation(geno, fusions_tsv or "", barcodes_tsv, out.barcodes, rp.min_variants, rp.min_fraction,
+                                               stats=gstats if os.environ.get("LONGSOM_REANNO_FROM_FILE", "0") != "1" else None)
     kept = comm.allreduce_sum(kept)                          # (also the barrier behind which the new table is on disk)
     out.n_cells_kept, out.n_cancer = int(kept[0]), int(kept[1])
     t["reannotation"] = time.time() - t0

@@ -255,11 +255,13 @@ def _p4_text(k: int) -> str:
 def single_cell_genotype(engine, variant_file: str, table, contig_names: Sequence[str], out_path: str, *, alt_flag: str = "All",
                          window: int = 50000, min_bq: int = 30, min_mq: int = 255, alpha2: float = 0.260288007167716,
                          beta2: float = 173.94711910763732, pvalue: float = 0.01, chrm_contaminant: str = "True",
-                         strict_cb: bool = True, max_depth: int = 200000, comm=None, region=None) -> int:
+                         strict_cb: bool = True, max_depth: int = 200000, comm=None, region=None, stats: Optional[dict] = None) -> int:
     """The reads, contigs and `table` (hostio.BarcodeTable) must be resident in `engine`.  Returns the number of rows written.
     comm (regions.Comm of several ranks) + region ((tid, pos) lo, hi of this rank): every rank genotypes the target sites of its
     own region on its own resident reads (its slice of the BAM holds every read that reaches into the region), the per-(site,
     barcode) depth / alt tables are summed over the ranks, and rank 0 writes the file (the other ranks' out_path is not touched).
+    stats (a dict, filled in): per barcode string, the rows written with coverage ("covered") and with MutationStatus PASS ("mutated")
+    — what CellTypeReannotation.py:9-18 counts when it reads the table back (celltype_reannotation takes them instead of the file).
     Row order = the reference's: windows by (chromosome text, smallest position), inside a window the positions in the
     iteration order of Python's set of them (:111,131 — reproduced by building that very set), per position every barcode
     of barcodes.tsv in file order."""
@@ -330,6 +332,11 @@ def single_cell_genotype(engine, variant_file: str, table, contig_names: Sequenc
         p4 = {(a, b): int(v) for (a, b), v in zip(need, vals)}
     names = [table.celltype_names[int(c)] for c in table.celltype_of]
     n_rows = 0
+    n_cb = len(table.barcodes)
+    # a site's table is mostly cells without a read there: those rows differ by the barcode only and are made once
+    cell_cols = ["\t" + bc + "\t" + names[cb] + "\t" for cb, bc in enumerate(table.barcodes)]
+    no_cov = [c + "0\t0\t.\t.\tNoCoverage\n" for c in cell_cols]
+    n_cov, n_pass = np.zeros(n_cb, np.int64), np.zeros(n_cb, np.int64)
     with open(out_path, "w") as out:
         out.write("\t".join(GENOTYPE_HEADER) + "\n")
         by_chrom: Dict[str, Dict[int, tuple]] = {}
@@ -343,37 +350,59 @@ def single_cell_genotype(engine, variant_file: str, table, contig_names: Sequenc
                     ref_e, alt_e, ct_e, nc_e = sites[p]
                     head = "\t".join([str(chrom), str(p + 1), str(p + 1), ref_e, alt_e, str(ct_e), str(nc_e)])
                     d_row, a_row = dp[i], alt[i]
-                    for cb, bc in enumerate(table.barcodes):
+                    lines = [head + t for t in no_cov]
+                    seen = np.nonzero(d_row)[0]
+                    n_cov[seen] += 1
+                    for cb in seen.tolist():
                         DP, ALT = int(d_row[cb]), int(a_row[cb])
-                        vaf, bb, status = ".", ".", "NoCoverage"
-                        if DP > 0:
-                            if ALT > 0:
-                                v = round(ALT / DP, 4)
-                                vaf = str(v)
-                                if chrm_contaminant == "True" and str(chrom) == "chrM":
-                                    status = "LowVAFChrM" if v < 0.3 else "PASS"
-                                else:
-                                    k = p4[(i, cb)]
-                                    bb = _p4_text(k)
-                                    status = "PASS" if k / 10000.0 < pvalue else "BetaBin_problem"
+                        bb = "."
+                        if ALT > 0:
+                            v = round(ALT / DP, 4)
+                            vaf = str(v)
+                            if chrm_contaminant == "True" and str(chrom) == "chrM":
+                                status = "LowVAFChrM" if v < 0.3 else "PASS"
                             else:
-                                vaf, status = str(float(0)), "NoAltReads"
-                        out.write(head + "\t" + "\t".join([bc, names[cb], str(DP), str(ALT), vaf, bb, status]) + "\n")
-                        n_rows += 1
+                                k = p4[(i, cb)]
+                                bb = _p4_text(k)
+                                status = "PASS" if k / 10000.0 < pvalue else "BetaBin_problem"
+                            if status == "PASS":
+                                n_pass[cb] += 1
+                        else:
+                            vaf, status = str(float(0)), "NoAltReads"
+                        lines[cb] = head + cell_cols[cb] + "\t".join([str(DP), str(ALT), vaf, bb, status]) + "\n"
+                    out.write("".join(lines))
+                    n_rows += n_cb
+    if stats is not None:
+        cov_by, pass_by = {}, {}
+        for cb, bc in enumerate(table.barcodes):              # (keyed by the string the rows carry, as a reader of the table would count)
+            if n_cov[cb]:
+                cov_by[bc] = cov_by.get(bc, 0) + int(n_cov[cb])
+            if n_pass[cb]:
+                pass_by[bc] = pass_by.get(bc, 0) + int(n_pass[cb])
+        stats["covered"], stats["mutated"] = cov_by, pass_by
     return n_rows
 
 
 # ---------------------------------------------------------------------------------------------------------------------
 # Re-annotation
 # ---------------------------------------------------------------------------------------------------------------------
-def celltype_reannotation(snv_file: str, fusion_file: Optional[str], meta_file: str, out_file: str, min_variants: int = 3, min_frac: float = 0.2):
+def celltype_reannotation(snv_file: str, fusion_file: Optional[str], meta_file: str, out_file: str, min_variants: int = 3, min_frac: float = 0.2,
+                          stats: Optional[dict] = None):
     """CellTypeReannotation.py:6-65: a cell is Cancer iff it has >= min_variants covered HCCVs and mutated / covered >= min_frac;
-    cells with fewer covered HCCVs are dropped from the barcodes file."""
-    snv = pd.read_csv(snv_file, sep="\t")
-    covered = Counter(snv[snv["VAF"] != "."]["CB"])
-    enough = [k for k, v in covered.items() if v >= min_variants]
-    snv = snv[snv["CB"].isin(enough)]
-    mutated = list(snv[snv["MutationStatus"] == "PASS"]["CB"])
+    cells with fewer covered HCCVs are dropped from the barcodes file.  stats = what single_cell_genotype counted while it wrote
+    snv_file (rows with coverage and PASS rows per barcode): the table — sites x every barcode rows, 1.2 GB for 3 000 sites x 5 000
+    cells — is then not read back (the fused loop; the script's drop-in reads the file, and a test holds the two together)."""
+    if stats is not None:
+        covered = Counter(stats["covered"])
+        enough = [k for k, v in covered.items() if v >= min_variants]
+        ok = set(enough)
+        mutated = [k for k, v in stats["mutated"].items() if k in ok for _ in range(v)]
+    else:
+        snv = pd.read_csv(snv_file, sep="\t")
+        covered = Counter(snv[snv["VAF"] != "."]["CB"])
+        enough = [k for k, v in covered.items() if v >= min_variants]
+        snv = snv[snv["CB"].isin(enough)]
+        mutated = list(snv[snv["MutationStatus"] == "PASS"]["CB"])
     if fusion_file:
         fus = pd.read_csv(fusion_file, sep="\t")
         fus["INDEX"] = fus["#FusionName"] + ":" + fus["BC"]
@@ -385,6 +414,7 @@ def celltype_reannotation(snv_file: str, fusion_file: Optional[str], meta_file: 
     bcs = pd.read_csv(meta_file, sep="\t")
     bcs = bcs[bcs["Index"].isin(enough)]
     bcs["Before_Reannotation_cell_type"] = bcs["Cell_type"]
+    cancer = set(cancer)
     bcs["Reannotated_cell_type"] = ["Cancer" if i in cancer else "Non-Cancer" for i in bcs["Index"]]
     bcs["Cell_type"] = bcs["Reannotated_cell_type"]
     bcs.to_csv(out_file, sep="\t", index=False)
