@@ -123,6 +123,17 @@ def _cluster_tags(index: pd.Series, flt: pd.Series, clust_dist: int) -> pd.Serie
     return pd.Series([(tag if f == "PASS" else f + "," + tag) if i in bad else f for i, f in zip(index, flt)], index=flt.index, dtype=object)
 
 
+def _first_field(col: pd.Series, sep: str) -> pd.Series:
+    """col.str.split(sep, n=1).str[0] without building the pieces (the cell-type columns are 60-character strings, a million of them):
+    text up to the first sep, NaN where the value is not text"""
+    def cut(x):
+        if type(x) is not str:
+            return np.nan
+        i = x.find(sep)
+        return x if i < 0 else x[:i]
+    return pd.Series([cut(x) for x in col.tolist()], index=col.index, dtype=object)
+
+
 def hccv_filter(step2_tsv: str, out_prefix: str, min_dp: float = 20, delta_vaf: float = 0.1, delta_mcf: float = 0.4, clust_dist: int = 10000) -> str:
     """Writes <out_prefix>.HCCV.tsv (and the reference's two intermediate tables, .HCCV.tsv2 / .HCCV.tsv3); returns its path.
     The reference applies three Python row functions to every row of the step-2 table (14 s for the 1.6 M rows of a 1 M-read sample,
@@ -144,7 +155,7 @@ def hccv_filter(step2_tsv: str, out_prefix: str, min_dp: float = 20, delta_vaf: 
                 dst.write(line)
         dst.write(HCCV_INFO_LINE)
     df = pd.read_csv(step2_tsv, sep="\t", comment="#", names=cols)
-    df["INDEX"] = df["#CHROM"].astype(str) + ":" + df["Start"].astype(str) + ":" + df["ALT"].str.split(",", n=1, expand=True)[0]
+    df["INDEX"] = df["#CHROM"].astype(str) + ":" + df["Start"].astype(str) + ":" + _first_field(df["ALT"], ",")
     df = df[df["Cell_types"] != "Non-Cancer"]
     changed = ["ALT", "FILTER", "Cell_types", "Bc", "Cc", "VAF", "MCF"]
     if len(df) and not (df["FILTER"].map(type).eq(str).all() and df["ALT"].map(type).eq(str).all()):
@@ -167,7 +178,7 @@ def hccv_filter(step2_tsv: str, out_prefix: str, min_dp: float = 20, delta_vaf: 
     # DP_filtering (:202-212): the first field of both cell types' columns; a missing column is NoCov
     if len(df):
         def depth(col):
-            return pd.to_numeric(df[col].where(df[col].map(type).eq(str)).str.split("|", n=1).str[0], errors="coerce")
+            return pd.to_numeric(_first_field(df[col], "|"), errors="coerce")
         d_c, d_n = depth("Cancer"), depth("Non-Cancer")
         df = df[(d_c >= min_dp) & (d_n >= min_dp)]
     df["DP_FILTER"] = pd.Series("PASS", index=df.index, dtype=object)
@@ -300,6 +311,8 @@ def single_cell_genotype(engine, variant_file: str, table, contig_names: Sequenc
     keys = np.asarray(uniq, np.int64)
     code = (keys >> 32) * (1 << 40) + ((keys & 0xFFFFFFFF) + 1) // int(window) if len(keys) else keys
     group_off = np.concatenate([[0], np.nonzero(np.diff(code))[0] + 1, [len(keys)]]).astype(np.int64)
+    import time
+    tm = {"t0": time.time()}
     if comm is not None and comm.world > 1:
         k_lo, k_hi = (int(region[0][0]) << 32) | int(region[0][1]), (int(region[1][0]) << 32) | int(region[1][1])
         mine = np.nonzero((keys >= k_lo) & (keys < k_hi))[0]
@@ -316,6 +329,7 @@ def single_cell_genotype(engine, variant_file: str, table, contig_names: Sequenc
             out_path = os.devnull
     else:
         dp, alt = engine.genotype_cells_grouped(keys, alt_sym, group_off, params, max_depth)
+    tm["device"] = time.time()
     # beta-binomial tails of the covered, mutated cells outside chrM
     need = []
     for chrom, _, order, _ in blocks:
@@ -330,6 +344,7 @@ def single_cell_genotype(engine, variant_file: str, table, contig_names: Sequenc
         ii = np.array([a for a, _ in need]); cc = np.array([b for _, b in need])
         vals = engine.betabinom_sf4(alt[ii, cc], dp[ii, cc], alpha2, beta2)
         p4 = {(a, b): int(v) for (a, b), v in zip(need, vals)}
+    tm["tails"] = time.time()
     names = [table.celltype_names[int(c)] for c in table.celltype_of]
     n_rows = 0
     n_cb = len(table.barcodes)
@@ -372,6 +387,10 @@ def single_cell_genotype(engine, variant_file: str, table, contig_names: Sequenc
                         lines[cb] = head + cell_cols[cb] + "\t".join([str(DP), str(ALT), vaf, bb, status]) + "\n"
                     out.write("".join(lines))
                     n_rows += n_cb
+    if os.environ.get("LSG_TIMING"):
+        import sys
+        sys.stderr.write("[lsg] single_cell_genotype: %d sites x %d cells: device %.2f s, tails of %d cells %.2f s, table %.2f s\n"
+                         % (len(keys), n_cb, tm["device"] - tm["t0"], len(need), tm["tails"] - tm["device"], time.time() - tm["tails"]))
     if stats is not None:
         cov_by, pass_by = {}, {}
         for cb, bc in enumerate(table.barcodes):              # (keyed by the string the rows carry, as a reader of the table would count)
