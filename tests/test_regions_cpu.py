@@ -167,3 +167,62 @@ def test_an_index_older_than_its_bam_is_not_used(tmp_path, capsys):
     os.utime(bai, (3_000_000, 3_000_000))
     assert hostio.find_bai(str(bam)) == str(bai)
     assert hostio.find_bai(str(tmp_path / "none.bam")) is None
+
+
+# ---- the sharded per-cell genotyping (config 5 over several ranks), the CPU oracle standing in for each rank's device ----------------
+class _OracleEngine:
+    """what reanno.single_cell_genotype asks of an engine, answered by oracle/genotype_oracle.py over the reads a rank holds"""
+    def __init__(self, rec, lens, celltype_of):
+        self.rec, self.lens, self.celltype_of = rec, lens, celltype_of
+
+    def genotype_cells_grouped(self, keys, alt_sym, group_off, params, max_depth):
+        from oracle import genotype_oracle as go
+        return go.genotype(self.rec, self.lens, self.celltype_of, keys, alt_sym, min_bq=params.min_bq, min_mq=params.min_mq, alt_only=params.alt_only,
+                           strict_cb=params.strict_cb)
+
+    def betabinom_sf4(self, k, n, alpha, beta):
+        from scipy.stats import betabinom
+        return np.asarray([int(round(round(float(betabinom.sf(int(a) - 0.001, int(b), alpha, beta)), 4) * 10000)) for a, b in zip(k, n)], np.int32)
+
+
+def _geno_rank_main(rank, world, port, out_dir, q):
+    os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LSG_DIST_BACKEND="gloo")
+    from longsom_amd import reanno
+    comm = regions.Comm.from_env()
+    bc = hostio.read_barcodes(os.path.join(G, "pileup.rand.barcodes.tsv"))
+    dec = hostio.decode_bam(os.path.join(G, "pileup.rand.bam"), bc.barcodes, min_mapq=0)
+    n_contigs = len(dec.contig_names)
+    bounds = regions.balanced_boundaries(dec.records, n_contigs, world)
+    lo, hi = bounds[rank], bounds[rank + 1]
+    mine = dec.records.subset(regions.reads_overlapping(dec.records, lo, hi))         # the rank holds the reads that reach into its region, no others
+    eng = _OracleEngine(mine, [int(x) for x in dec.contig_len], bc.celltype_of)
+    out = os.path.join(out_dir, "geno.rank%d.tsv" % rank)
+    stats = {}
+    n = reanno.single_cell_genotype(eng, os.path.join(G, "pileup.rand.HCCV.tsv"), bc, dec.contig_names, out, alt_flag="All", min_bq=30, min_mq=60,
+                                    comm=comm, region=(lo, hi), stats=stats)
+    comm.barrier()
+    q.put((rank, n, int(mine.n_reads), int(dec.records.n_reads), os.path.exists(out), sum(stats["covered"].values())))
+    comm.close()
+
+
+def test_sharded_genotyping_writes_the_reference_table(tmp_path):
+    """two gloo ranks, each holding only its region's reads: the sites are genotyped where their reads are, one all-reduce places the rows,
+    rank 0 writes the table the reference's HCCVSingleCellGenotype.py wrote for the whole BAM (tests/golden/pileup.rand.genotype.All.tsv)"""
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world = 2
+    procs = [ctx.Process(target=_geno_rank_main, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    want = open(os.path.join(G, "pileup.rand.genotype.All.tsv")).read()
+    assert open(tmp_path / "geno.rank0.tsv").read() == want
+    assert res[0][4] and not res[1][4]                                   # only rank 0 writes
+    assert res[0][1] == res[1][1] == want.count("\n") - 1
+    assert all(0 < r[2] < r[3] for r in res)                             # each rank really held a part of the reads only
+    assert res[0][5] == res[1][5] == sum(1 for l in want.split("\n")[1:] if l and l.split("\t")[11] != ".")      # rows with coverage, as the re-annotation counts them
