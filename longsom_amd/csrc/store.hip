@@ -3,9 +3,10 @@
 // A pileup IS the transposition of read-major events into column order.  The reference does it per 50 kb window with htslib's
 // bam_plp behind bam.pileup(...) (workflow/scripts/SNVCalling/BaseCellCounter.py:190-198); here it is done ONCE per load, on the
 // device, straight from the caller's compact read-record arrays:
-//   1. capacities   every (segment x 64-position tile) overlap of a read that carries a barcode is one ENTRY; a counting pass over the
-//                   segments gives every tile's number of entries (k_seg_static, k_bin<0>), a scan its region
-//   2. scatter      k_bin<2> writes a 16-byte record per entry into its tile's region, in arrival order, beside its sort key (barcode)
+//   1. capacities   every (segment x 64-position tile) overlap of a read that carries a barcode is one ENTRY; a segment's entries are a
+//                   contiguous range of tiles, so k_seg_static marks +1 at its first tile and -1 past its last, a running sum gives
+//                   every tile's number of entries and a second scan its region
+//   2. scatter      k_bin writes a 16-byte record per entry into its tile's region, in arrival order, beside its sort key (barcode)
 //   3. sort         the entries of each tile by barcode (segmented radix sort over the tile regions): equal barcodes become adjacent
 //                   RUNS, which is what turns len(set(cells)) (BaseCellCounter.py:283,292) into "entries minus duplicates in a run"
 //   4. fill         per entry, in that order: barcode / strand / run flags, events - 1, SAM flag and MAPQ (admission is decided per
@@ -33,14 +34,15 @@ struct BuildArgs {
     const uint32_t* tile_base; const int64_t* contig_len;
     int32_t n_contigs; uint32_t n_tiles;
     uint2* seg_info;                      // per segment {barcode | reverse << 24, or KEY_INVALID; first tile of its contig}
-    uint32_t* tile_cap;                   // MODE 0: entries per tile
-    uint32_t* cursor;                     // MODE 2: next free place of every tile's region
+    uint32_t* tile_cap;                   // entries per tile
+    uint32_t* cursor;                     // next free place of every tile's region
     uint4* rec; uint32_t* key;
     unsigned long long* qhead;            // work queue head of the binning pass
     int32_t lf_min_mq, lf_ignore_orphans; uint32_t lf_flag_exclude;      // the load filter (lsg_set_load_filter)
     uint32_t* bad;                        // bit 0: a segment's event range lies outside the events; bit 1: a segment's read index outside the reads
     unsigned long long* n_ev;             // events of the statically admitted segments = events the store will hold
     int32_t* span_diff;                   // [n_tiles + 1] marks of the reads' spans (the depth cap's bound), or null
+    int32_t* cap_diff;                    // [n_tiles + 1] marks of the admitted segments' tile ranges: +1 at the first tile, -1 past the last; their running sum = entries per tile
 };
 
 // Static admission of a segment: its read carries a barcode, passes the load filter and lies on a contig, the segment lies inside the
@@ -49,22 +51,27 @@ struct BuildArgs {
 // the tile its last segment ends in, for every read with a barcode.  The reads of a deep gene start and end in the same few tiles and a
 // word takes ~90 atomics per microsecond, so a workgroup merges the marks of a batch of 256 consecutive segments in an LDS hash and
 // issues one global atomic per distinct tile.
-constexpr int SEG_THREADS = 256, SEG_H = 1024;
+// The tiles' CAPACITIES come out of the same pass the same way: a segment's entries are the tiles of one contiguous range, so +1 at its
+// first tile and -1 past its last one, summed along the tiles, is the number of entries of every tile — two marks per segment where a
+// counting pass over the entries (0.9 ms of LDS atomics for C2's 185 M entries) made one per entry.
+constexpr int SEG_THREADS = 256, SEG_H = 2048;
 __global__ __launch_bounds__(SEG_THREADS) void k_seg_static(BuildArgs a) {
     __shared__ uint32_t hkey[SEG_H];
-    __shared__ int32_t hval[SEG_H];
+    __shared__ int32_t hval[SEG_H], hcap[SEG_H];
     __shared__ unsigned long long s_ev;
-    for (int i = threadIdx.x; i < SEG_H; i += SEG_THREADS) { hkey[i] = KEY_INVALID; hval[i] = 0; }
+    for (int i = threadIdx.x; i < SEG_H; i += SEG_THREADS) { hkey[i] = KEY_INVALID; hval[i] = 0; hcap[i] = 0; }
     if (threadIdx.x == 0) s_ev = 0;
-    auto mark = [&](uint32_t t, int32_t v) {
-        uint32_t h = (t * 2654435761u) >> 22;
+    auto slot = [&](uint32_t t) {
+        uint32_t h = (t * 2654435761u) >> 21;
         while (true) {
             const uint32_t prev = atomicCAS(&hkey[h], KEY_INVALID, t);
             if (prev == KEY_INVALID || prev == t) break;
             h = (h + 1) & (SEG_H - 1);
         }
-        atomicAdd(&hval[h], v);
+        return h;
     };
+    auto mark = [&](uint32_t t, int32_t v) { atomicAdd(&hval[slot(t)], v); };
+    auto mark_cap = [&](uint32_t t, int32_t v) { atomicAdd(&hcap[slot(t)], v); };
     unsigned long long n_ev = 0;
     const int64_t n_batches = (a.n_segs + SEG_THREADS - 1) / SEG_THREADS;
     for (int64_t bt = blockIdx.x; bt < n_batches; bt += gridDim.x) {
@@ -88,6 +95,8 @@ __global__ __launch_bounds__(SEG_THREADS) void k_seg_static(BuildArgs a) {
                         key = (uint32_t)cb | (((flag >> 4) & 1u) << 24);
                         tb = a.tile_base[tid];
                         n_ev += (unsigned long long)ln;
+                        mark_cap(tb + ((uint32_t)st >> 6), 1);
+                        mark_cap(tb + ((uint32_t)(st + ln - 1) >> 6) + 1, -1);
                     }
                 }
                 if (a.span_diff && on_contig && cb >= 0) {          // (every read with a barcode, whatever the load filter: a bound never under-counts)
@@ -105,11 +114,13 @@ __global__ __launch_bounds__(SEG_THREADS) void k_seg_static(BuildArgs a) {
             }
             a.seg_info[s] = make_uint2(key, tb);
         }
-        if (a.span_diff) {
-            __syncthreads();
-            for (int i = threadIdx.x; i < SEG_H; i += SEG_THREADS)
-                if (hkey[i] != KEY_INVALID) { if (hval[i] != 0) atomicAdd(a.span_diff + hkey[i], hval[i]); hkey[i] = KEY_INVALID; hval[i] = 0; }
-        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < SEG_H; i += SEG_THREADS)
+            if (hkey[i] != KEY_INVALID) {
+                if (hval[i] != 0) atomicAdd(a.span_diff + hkey[i], hval[i]);       // (marks of the spans are made only when span_diff is there)
+                if (hcap[i] != 0) atomicAdd(a.cap_diff + hkey[i], hcap[i]);
+                hkey[i] = KEY_INVALID; hval[i] = 0; hcap[i] = 0;
+            }
     }
     for (int o = 32; o > 0; o >>= 1) n_ev += __shfl_down(n_ev, o);
     __syncthreads();
@@ -118,12 +129,12 @@ __global__ __launch_bounds__(SEG_THREADS) void k_seg_static(BuildArgs a) {
     if (threadIdx.x == 0 && s_ev) atomicAdd(a.n_ev, s_ev);
 }
 
-// Counting sort of (segment, tile) pairs over the segments, with the atomics aggregated per workgroup in an LDS hash.  The segments
-// of a coordinate-sorted BAM arrive gene by gene, so consecutive batches of 256 segments hit the same few tiles: a workgroup dequeues
-// BIN_SUPER consecutive batches and keeps accumulating (batch, 8-tile round) items in the hash until it is 5/8 full, then issues ONE
-// global atomic per distinct tile for the whole chunk.  (A deep gene funnels thousands of batches into a few cache lines of the
-// counters; same-line atomics serialise in L2 at ~90 per microsecond, so their number is what counts.)
-//   MODE 0: count entries per tile.  MODE 2: claim a range per tile, then replay the chunk's items and write the entries' records.
+// The scatter of the (segment, tile) entries into their tiles' regions, with the atomics aggregated per workgroup in an LDS hash.  The
+// segments of a coordinate-sorted BAM arrive gene by gene, so consecutive batches of 256 segments hit the same few tiles: a workgroup
+// dequeues BIN_SUPER consecutive batches and keeps accumulating (batch, 8-tile round) items in the hash until it is 5/8 full, then
+// claims a range per distinct tile with ONE global atomic for the whole chunk, replays the chunk's items and writes the entries'
+// records.  (A deep gene funnels thousands of batches into a few cache lines of the cursors; same-line atomics serialise in L2 at
+// ~90 per microsecond, so their number is what counts.)
 constexpr int BIN_THREADS = 256;
 constexpr int BIN_TPR = 8;             // tiles per segment handled per item
 constexpr int BIN_H = 4096;            // LDS hash slots
@@ -133,7 +144,6 @@ constexpr uint32_t BIN_FILL = BIN_H * 5 / 8;
 
 struct BinSeg { uint32_t key, tb, t0, rd, fm; int32_t st, ln, ntile; int64_t evoff; };
 
-template <int MODE>
 __device__ __forceinline__ BinSeg bin_load(const BuildArgs& a, int64_t s) {
     BinSeg g; g.key = KEY_INVALID; g.tb = 0; g.t0 = 0; g.rd = 0; g.fm = 0; g.st = 0; g.ln = 0; g.ntile = 0; g.evoff = 0;
     if (s < a.n_segs) {
@@ -141,10 +151,8 @@ __device__ __forceinline__ BinSeg bin_load(const BuildArgs& a, int64_t s) {
         g.key = info.x; g.tb = info.y;
         if (g.key != KEY_INVALID) {
             g.st = a.seg_start[s]; g.ln = a.seg_len[s];
-            if (MODE == 2) {          // (a read's segments are consecutive and the reads coordinate-sorted: these gathers run along the arrays)
-                g.evoff = a.seg_ev_off[s]; g.rd = a.seg_read[s];
-                g.fm = (uint32_t)a.read_flag[g.rd] | ((uint32_t)a.read_mapq[g.rd] << 16);
-            }
+            g.evoff = a.seg_ev_off[s]; g.rd = a.seg_read[s];          // (a read's segments are consecutive and the reads coordinate-sorted: these gathers run along the arrays)
+            g.fm = (uint32_t)a.read_flag[g.rd] | ((uint32_t)a.read_mapq[g.rd] << 16);
             g.t0 = g.tb + ((uint32_t)g.st >> 6);
             g.ntile = (int)(((uint32_t)(g.st + g.ln - 1) >> 6) - ((uint32_t)g.st >> 6)) + 1;
         }
@@ -152,9 +160,8 @@ __device__ __forceinline__ BinSeg bin_load(const BuildArgs& a, int64_t s) {
     return g;
 }
 
-template <int MODE>
 __global__ __launch_bounds__(BIN_THREADS) void k_bin(BuildArgs a) {
-    __shared__ uint32_t hkey[BIN_H], hcnt[BIN_H];      // MODE 2: hcnt turns into the tile's write cursor after the flush
+    __shared__ uint32_t hkey[BIN_H], hcnt[BIN_H];      // hcnt turns into the tile's write cursor after the claim
     __shared__ uint32_t s_newb[BIN_MAXI], s_ib[BIN_MAXI], s_ir[BIN_MAXI];
     __shared__ int s_maxb[BIN_MAXI];
     __shared__ uint32_t s_super;
@@ -181,7 +188,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(BuildArgs a) {
             int64_t b = cb; int r = cr;
             bool stop = false;
             while (!stop && b < b1) {
-                const BinSeg g = bin_load<MODE>(a, b * BIN_THREADS + t);
+                const BinSeg g = bin_load(a, b * BIN_THREADS + t);
                 const int ni_first = ni;
                 int wmax = g.ntile;
                 for (int o = 32; o > 0; o >>= 1) { int v = __shfl_down(wmax, o); wmax = v > wmax ? v : wmax; }
@@ -219,18 +226,15 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(BuildArgs a) {
             // ---- one global atomic per distinct tile of the chunk
             for (int i = t; i < BIN_H; i += BIN_THREADS) {
                 const uint32_t cnt = hcnt[i];
-                if (cnt) {
-                    if (MODE == 0) { atomicAdd(&a.tile_cap[hkey[i]], cnt); hkey[i] = KEY_INVALID; hcnt[i] = 0; }
-                    else hcnt[i] = atomicAdd(&a.cursor[hkey[i]], cnt);       // first place of this workgroup's range in the tile's region
-                }
+                if (cnt) hcnt[i] = atomicAdd(&a.cursor[hkey[i]], cnt);       // first place of this workgroup's range in the tile's region
             }
             __syncthreads();
-            if (MODE == 2) {
+            {
                 // ---- pass B: replay the items, write the entries
                 for (int it = 0; it < ni; ++it) {
                     const int64_t bb = b0 + s_ib[it];
                     const int rr = (int)s_ir[it];
-                    const BinSeg g = bin_load<MODE>(a, bb * BIN_THREADS + t);
+                    const BinSeg g = bin_load(a, bb * BIN_THREADS + t);
 #pragma unroll
                     for (int j = 0; j < BIN_TPR; ++j) {
                         const int k = rr * BIN_TPR + j;
@@ -446,8 +450,18 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
     // ---- 1. static admission + capacities
     unsigned g_seg = (unsigned)((S + 255) / 256); if (g_seg > (unsigned)(c->n_cus * 16)) g_seg = (unsigned)(c->n_cus * 16);
     unsigned g_bin = (unsigned)((S + 256 * BIN_SUPER - 1) / (256 * BIN_SUPER)); if (g_bin > (unsigned)(c->n_cus * 8)) g_bin = (unsigned)(c->n_cus * 8);
+    if (c->bt[BT_PER_TILE].reserve(((size_t)T + 2) * 4)) return -1;
+    LSG_HIP(hipMemsetAsync(c->bt[BT_PER_TILE].p, 0, ((size_t)T + 2) * 4, st));
+    a.cap_diff = c->bt[BT_PER_TILE].as<int32_t>();
     hipLaunchKernelGGL(k_seg_static, dim3(g_seg), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(k_bin<0>, dim3(g_bin), dim3(BIN_THREADS), 0, st, a);
+    {   // entries per tile = running sum of the segments' range marks
+        size_t tb = 0;
+        int32_t* cap = reinterpret_cast<int32_t*>(c->d_tile_cap.as<uint32_t>());
+        LSG_HIP(hipcub::DeviceScan::InclusiveSum(nullptr, tb, a.cap_diff, cap, (int)(T + 1), st));
+        if (c->d_cub_tmp.reserve(tb + 256)) return -1;
+        tb = c->d_cub_tmp.cap;
+        LSG_HIP(hipcub::DeviceScan::InclusiveSum(c->d_cub_tmp.p, tb, a.cap_diff, cap, (int)(T + 1), st));
+    }
     SCAN_U32(c->d_tile_cap.as<uint32_t>(), c->d_tile_off.as<uint32_t>(), T + 1);
     {   // the depth cap's table-independent bound (layout.hip live_read_bound_all): reads of any cell type whose span touches a tile, maximum over tiles
         int32_t* run = c->bt[BT_SPAN_RUN].as<int32_t>();
@@ -502,7 +516,7 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
     a.cursor = c->bt[BT_PER_TILE].as<uint32_t>(); a.rec = rec.as<uint4>(); a.key = key_a.as<uint32_t>();
     LSG_HIP(hipMemcpyAsync(a.cursor, c->d_tile_off.p, ((size_t)T + 1) * 4, hipMemcpyDeviceToDevice, st));
     LSG_HIP(hipMemsetAsync(c->d_scalars.p, 0, 8, st));
-    hipLaunchKernelGGL(k_bin<2>, dim3(g_bin), dim3(BIN_THREADS), 0, st, a);
+    hipLaunchKernelGGL(k_bin, dim3(g_bin), dim3(BIN_THREADS), 0, st, a);
     LSG_HIP(hipEventRecord(c->evb[1], st));
     // ---- 3. every tile's entries by barcode
     uint32_t n_netile = 0;
