@@ -57,9 +57,9 @@ struct BuildArgs {
 constexpr int SEG_THREADS = 256, SEG_H = 2048;
 __global__ __launch_bounds__(SEG_THREADS) void k_seg_static(BuildArgs a) {
     __shared__ uint32_t hkey[SEG_H];
-    __shared__ int32_t hval[SEG_H], hcap[SEG_H];
+    __shared__ int32_t hval[SEG_H];       // both sums of a tile in one word: span marks in the low half, capacity marks x 65536 (each at most 512 in size per batch)
     __shared__ unsigned long long s_ev;
-    for (int i = threadIdx.x; i < SEG_H; i += SEG_THREADS) { hkey[i] = KEY_INVALID; hval[i] = 0; hcap[i] = 0; }
+    for (int i = threadIdx.x; i < SEG_H; i += SEG_THREADS) { hkey[i] = KEY_INVALID; hval[i] = 0; }
     if (threadIdx.x == 0) s_ev = 0;
     auto slot = [&](uint32_t t) {
         uint32_t h = (t * 2654435761u) >> 21;
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(SEG_THREADS) void k_seg_static(BuildArgs a) {
         return h;
     };
     auto mark = [&](uint32_t t, int32_t v) { atomicAdd(&hval[slot(t)], v); };
-    auto mark_cap = [&](uint32_t t, int32_t v) { atomicAdd(&hcap[slot(t)], v); };
+    auto mark_cap = [&](uint32_t t, int32_t v) { atomicAdd(&hval[slot(t)], v * 65536); };
     unsigned long long n_ev = 0;
     const int64_t n_batches = (a.n_segs + SEG_THREADS - 1) / SEG_THREADS;
     for (int64_t bt = blockIdx.x; bt < n_batches; bt += gridDim.x) {
@@ -117,9 +117,10 @@ __global__ __launch_bounds__(SEG_THREADS) void k_seg_static(BuildArgs a) {
         __syncthreads();
         for (int i = threadIdx.x; i < SEG_H; i += SEG_THREADS)
             if (hkey[i] != KEY_INVALID) {
-                if (hval[i] != 0) atomicAdd(a.span_diff + hkey[i], hval[i]);       // (marks of the spans are made only when span_diff is there)
-                if (hcap[i] != 0) atomicAdd(a.cap_diff + hkey[i], hcap[i]);
-                hkey[i] = KEY_INVALID; hval[i] = 0; hcap[i] = 0;
+                const int32_t w = hval[i], v = (int32_t)(int16_t)(w & 0xffff), cp = (w - v) >> 16;       // (w = cp * 65536 + v exactly)
+                if (v != 0) atomicAdd(a.span_diff + hkey[i], v);       // (marks of the spans are made only when span_diff is there)
+                if (cp != 0) atomicAdd(a.cap_diff + hkey[i], cp);
+                hkey[i] = KEY_INVALID; hval[i] = 0;
             }
     }
     for (int o = 32; o > 0; o >>= 1) n_ev += __shfl_down(n_ev, o);
@@ -482,14 +483,10 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
     }
     uint32_t total = 0, bad = 0; int32_t max_cb = 0, max_live = 0;
     LSG_HIP(hipMemcpyAsync(&max_live, d_small + 3, 4, hipMemcpyDeviceToHost, st));
-    unsigned long long n_ev = 0;
+    unsigned long long n_ev = 0, sum = 0;
     LSG_HIP(hipMemcpyAsync(&n_ev, a.n_ev, 8, hipMemcpyDeviceToHost, st));
-    LSG_HIP(hipMemcpyAsync(&total, c->d_tile_off.as<uint32_t>() + T, 4, hipMemcpyDeviceToHost, st));
     LSG_HIP(hipMemcpyAsync(&bad, a.bad, 4, hipMemcpyDeviceToHost, st));
     if (R > 0) LSG_HIP(hipMemcpyAsync(&max_cb, d_small + 2, 4, hipMemcpyDeviceToHost, st));
-    LSG_HIP(hipStreamSynchronize(st));
-    if (bad & 2u) { set_error("lsg_load_reads: a segment's read index lies outside the read arrays"); return -2; }
-    if (bad & 1u) { set_error("lsg_load_reads: a segment's event range lies outside the events array"); return -2; }
     // (a total of 2^32 or more wraps the 32-bit scan: the per-tile capacities are summed in 64 bits to tell)
     {
         unsigned long long* d_sum = c->d_scalars.as<unsigned long long>() + 8;
@@ -499,12 +496,13 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
         if (tmp.reserve(tb + 256)) return -1;
         tb = tmp.cap;
         LSG_HIP(hipcub::DeviceReduce::Sum(tmp.p, tb, it, d_sum, (int)T, st));
-        unsigned long long sum = 0;
         LSG_HIP(hipMemcpyAsync(&sum, d_sum, 8, hipMemcpyDeviceToHost, st));
-        LSG_HIP(hipStreamSynchronize(st));
-        if (sum >= 0x7FFFFFF0ull) { set_error("lsg_load_reads: %llu tile entries exceed the 31-bit entry index; load the reads in windows", sum); return -2; }
-        total = (uint32_t)sum;
     }
+    LSG_HIP(hipStreamSynchronize(st));                    // the load's first look at the device: sizes of everything that follows
+    if (bad & 2u) { set_error("lsg_load_reads: a segment's read index lies outside the read arrays"); return -2; }
+    if (bad & 1u) { set_error("lsg_load_reads: a segment's event range lies outside the events array"); return -2; }
+    if (sum >= 0x7FFFFFF0ull) { set_error("lsg_load_reads: %llu tile entries exceed the 31-bit entry index; load the reads in windows", sum); return -2; }
+    total = (uint32_t)sum;
     const uint64_t N = total;
     c->tm_n = N; c->tm_events = (int64_t)n_ev;
     c->max_live_all = max_live > 0 ? max_live : 0;
