@@ -37,7 +37,7 @@ def _dominant_alt(ref: str, info: str):
     """The cancer column's strongest non-reference A/C/T/G read count; None unless it is > 20x the runner-up (:108-117)."""
     counts = [int(v) for v in info.split("|")[3].split(":")[:4]]
     counts["ACTG".index(ref)] = 0
-    top = int(np.argmax(counts))
+    top = counts.index(max(counts))                      # (np.argmax: the first of equal maxima)
     best = counts[top]
     counts[top] = 0
     second = max(counts)
