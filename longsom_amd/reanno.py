@@ -137,8 +137,9 @@ def _first_field(col: pd.Series, sep: str) -> pd.Series:
 def hccv_filter(step2_tsv: str, out_prefix: str, min_dp: float = 20, delta_vaf: float = 0.1, delta_mcf: float = 0.4, clust_dist: int = 10000) -> str:
     """Writes <out_prefix>.HCCV.tsv (and the reference's two intermediate tables, .HCCV.tsv2 / .HCCV.tsv3); returns its path.
     The reference applies three Python row functions to every row of the step-2 table (14 s for the 1.6 M rows of a 1 M-read sample,
-    against 3 s for the whole SNV chain before it); here MultiAllelic_filtering runs on the rows it can change (FILTER naming
-    Multi-allelic, or an ALT with '|'; every other row is returned as it came, :92-93), DP_filtering is two column operations, and
+    against 3 s for the whole SNV chain before it); here DP_filtering is two column operations and runs first,
+    MultiAllelic_filtering runs on the rows it can change (FILTER naming
+    Multi-allelic, or an ALT with '|'; every other row is returned as it came, :92-93), and
     MCF_filtering runs after the FILTER patterns, on the rows that are still there, as in the reference.  Same three files, byte
     for byte (tests/test_reanno_cpu.py: the goldens, and the row-wise form on shuffled, replicated and single-cell-type tables)."""
     if os.environ.get("LONGSOM_HCCV_ROW_PATH", "0") == "1":
@@ -155,8 +156,16 @@ def hccv_filter(step2_tsv: str, out_prefix: str, min_dp: float = 20, delta_vaf: 
                 dst.write(line)
         dst.write(HCCV_INFO_LINE)
     df = pd.read_csv(step2_tsv, sep="\t", comment="#", names=cols)
-    df["INDEX"] = df["#CHROM"].astype(str) + ":" + df["Start"].astype(str) + ":" + _first_field(df["ALT"], ",")
     df = df[df["Cell_types"] != "Non-Cancer"]
+    # DP_filtering (:202-212) FIRST: the first field of both cell types' columns, a missing column is NoCov.  The reference runs it after
+    # MultiAllelic_filtering, which neither reads nor writes those two columns and only drops rows: the rows that fail are gone either
+    # way, and seven of eight fail (a row function that raises on such a row — the reference then stops — is not reached here).
+    if len(df):
+        def depth(col):
+            return pd.to_numeric(_first_field(df[col], "|"), errors="coerce")
+        d_c, d_n = depth("Cancer"), depth("Non-Cancer")
+        df = df[(d_c >= min_dp) & (d_n >= min_dp)]
+    df["INDEX"] = df["#CHROM"].astype(str) + ":" + df["Start"].astype(str) + ":" + _first_field(df["ALT"], ",")
     changed = ["ALT", "FILTER", "Cell_types", "Bc", "Cc", "VAF", "MCF"]
     if len(df) and not (df["FILTER"].map(type).eq(str).all() and df["ALT"].map(type).eq(str).all()):
         return _hccv_filter_rowwise(step2_tsv, out_prefix, min_dp, delta_vaf, delta_mcf, clust_dist)      # (a FILTER / ALT that is not text: the row functions decide)
@@ -175,12 +184,6 @@ def hccv_filter(step2_tsv: str, out_prefix: str, min_dp: float = 20, delta_vaf: 
             df.loc[ok, c] = pd.Series([r[j] for r in kept_res], index=ok, dtype=object)
         df = df.drop(index=sub.index[~good])
     df = df[cols + ["INDEX"]]
-    # DP_filtering (:202-212): the first field of both cell types' columns; a missing column is NoCov
-    if len(df):
-        def depth(col):
-            return pd.to_numeric(_first_field(df[col], "|"), errors="coerce")
-        d_c, d_n = depth("Cancer"), depth("Non-Cancer")
-        df = df[(d_c >= min_dp) & (d_n >= min_dp)]
     df["DP_FILTER"] = pd.Series("PASS", index=df.index, dtype=object)
     df.to_csv(out + "2", sep="\t", index=False, mode="a")
     # chrM keeps its own, shorter filter list (contaminants, :52-58)
