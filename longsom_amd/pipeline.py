@@ -788,7 +788,7 @@ def run_pon(normals, ref_fasta: str, out_dir: str, params: Optional[SnvParams] =
     records); the PoN file is the same either way.  Output layout: <out_dir>/PoN/{SplitBam,BaseCellCounter,MergeCounts,
     BaseCellCalling,PoN}/ as in the rule file.  comm (world > 1): the normals are independent samples — rank r takes every world-th one
     on its own GPU, the sites of their call records are gathered (one all-gather of a few MB) and rank 0 writes the panel."""
-    import pickle
+    import json
     params = params or pon_params()
     comm = comm or regions.Comm()
     own = engine is None
@@ -808,11 +808,13 @@ def run_pon(normals, ref_fasta: str, out_dir: str, params: Optional[SnvParams] =
         if own:
             eng.close()
     if comm.world > 1:
-        blobs = comm.allgather_bytes(pickle.dumps((entries, step1, timings)))
+        # (plain JSON over the wire, the sites' byte fields as latin-1 text: nothing a peer sends is executed on arrival)
+        mine = json.dumps({"entries": [[f.decode("latin-1") for f in e] for e in entries], "step1": step1, "timings": timings})
         entries, step1, timings = [], {}, {}
-        for blob in blobs:
-            e, s1, tm = pickle.loads(blob)
-            entries += e; step1.update(s1); timings.update(tm)
+        for blob in comm.allgather_bytes(mine.encode("latin-1")):
+            d = json.loads(blob.decode("latin-1"))
+            entries += [tuple(f.encode("latin-1") for f in e) for e in d["entries"]]
+            step1.update(d["step1"]); timings.update(d["timings"])
     path = os.path.join(root, "PoN", out_name)
     text = pon.pon_text(entries, min_samples, rm_prefix)          # (sorted inside: the panel does not depend on which rank took which normal)
     if comm.rank == 0:
