@@ -329,7 +329,7 @@ def single_cell_genotype(engine, variant_file: str, table, contig_names: Sequenc
         both = comm.allreduce_sum(both.reshape(-1)).reshape(2, len(keys), n_cb)          # (a site belongs to one rank: the sum places the rows)
         dp, alt = both[0].astype(np.uint32), both[1].astype(np.uint32)
         if comm.rank != 0:
-            out_path = os.devnull
+            out_path = os.devnull                      # (and no row is built for it, below)
     else:
         dp, alt = engine.genotype_cells_grouped(keys, alt_sym, group_off, params, max_depth)
     tm["device"] = time.time()
@@ -364,6 +364,9 @@ def single_cell_genotype(engine, variant_file: str, table, contig_names: Sequenc
             for start in sorted(by_chrom[chrom]):
                 _, _, order, sites = by_chrom[chrom][start]
                 for p in order:
+                    if out_path == os.devnull:             # a rank that does not write the table: the count of its rows is all it needs
+                        n_rows += n_cb
+                        continue
                     i = row_of[key_of[(chrom, p)]]
                     ref_e, alt_e, ct_e, nc_e = sites[p]
                     head = "\t".join([str(chrom), str(p + 1), str(p + 1), ref_e, alt_e, str(ct_e), str(nc_e)])
