@@ -54,18 +54,20 @@ struct BuildArgs {
 // The tiles' CAPACITIES come out of the same pass the same way: a segment's entries are the tiles of one contiguous range, so +1 at its
 // first tile and -1 past its last one, summed along the tiles, is the number of entries of every tile — two marks per segment where a
 // counting pass over the entries (0.9 ms of LDS atomics for C2's 185 M entries) made one per entry.
-constexpr int SEG_THREADS = 256, SEG_H = 2048;
+constexpr int SEG_THREADS = 256, SEG_H = 2048, SEG_MAX_SINCE = 24;       // (24 x 512 marks of one sign at most per half word)
 __global__ __launch_bounds__(SEG_THREADS) void k_seg_static(BuildArgs a) {
     __shared__ uint32_t hkey[SEG_H];
-    __shared__ int32_t hval[SEG_H];       // both sums of a tile in one word: span marks in the low half, capacity marks x 65536 (each at most 512 in size per batch)
+    __shared__ int32_t hval[SEG_H];       // both sums of a tile in one word: span marks in the low half, capacity marks x 65536 (each at most 512 in size per batch, SEG_MAX_SINCE batches per flush)
     __shared__ unsigned long long s_ev;
+    __shared__ uint32_t s_new, s_flush;        // tiles in the hash since its last flush; this batch ends with one
     for (int i = threadIdx.x; i < SEG_H; i += SEG_THREADS) { hkey[i] = KEY_INVALID; hval[i] = 0; }
-    if (threadIdx.x == 0) s_ev = 0;
+    if (threadIdx.x == 0) { s_ev = 0; s_new = 0; s_flush = 0; }
     auto slot = [&](uint32_t t) {
         uint32_t h = (t * 2654435761u) >> 21;
         while (true) {
             const uint32_t prev = atomicCAS(&hkey[h], KEY_INVALID, t);
-            if (prev == KEY_INVALID || prev == t) break;
+            if (prev == KEY_INVALID) { atomicAdd(&s_new, 1u); break; }
+            if (prev == t) break;
             h = (h + 1) & (SEG_H - 1);
         }
         return h;
@@ -73,9 +75,15 @@ __global__ __launch_bounds__(SEG_THREADS) void k_seg_static(BuildArgs a) {
     auto mark = [&](uint32_t t, int32_t v) { atomicAdd(&hval[slot(t)], v); };
     auto mark_cap = [&](uint32_t t, int32_t v) { atomicAdd(&hval[slot(t)], v * 65536); };
     unsigned long long n_ev = 0;
+    // A workgroup takes CONSECUTIVE batches (the segments of a coordinate-sorted BAM arrive gene by gene: the next batch marks the same
+    // few tiles) and flushes the hash only when the next batch might not fit any more (4 marks per segment at worst), or after
+    // SEG_MAX_SINCE batches (the packed sums stay inside their 16 bits), or at its end.
     const int64_t n_batches = (a.n_segs + SEG_THREADS - 1) / SEG_THREADS;
-    for (int64_t bt = blockIdx.x; bt < n_batches; bt += gridDim.x) {
-        __syncthreads();
+    const int64_t per_wg = (n_batches + gridDim.x - 1) / gridDim.x;
+    const int64_t b_lo = (int64_t)blockIdx.x * per_wg, b_hi = b_lo + per_wg < n_batches ? b_lo + per_wg : n_batches;
+    int since = 0;
+    __syncthreads();
+    for (int64_t bt = b_lo; bt < b_hi; ++bt) {
         const int64_t s = bt * SEG_THREADS + threadIdx.x;
         if (s < a.n_segs) {
             const uint32_t r = a.seg_read[s];
@@ -114,14 +122,24 @@ __global__ __launch_bounds__(SEG_THREADS) void k_seg_static(BuildArgs a) {
             }
             a.seg_info[s] = make_uint2(key, tb);
         }
-        __syncthreads();
-        for (int i = threadIdx.x; i < SEG_H; i += SEG_THREADS)
-            if (hkey[i] != KEY_INVALID) {
-                const int32_t w = hval[i], v = (int32_t)(int16_t)(w & 0xffff), cp = (w - v) >> 16;       // (w = cp * 65536 + v exactly)
-                if (v != 0) atomicAdd(a.span_diff + hkey[i], v);       // (marks of the spans are made only when span_diff is there)
-                if (cp != 0) atomicAdd(a.cap_diff + hkey[i], cp);
-                hkey[i] = KEY_INVALID; hval[i] = 0;
-            }
+        ++since;
+        __syncthreads();                                  // the batch's marks are in
+        if (threadIdx.x == 0) {
+            s_flush = (bt + 1 == b_hi || s_new + 4 * SEG_THREADS > SEG_H * 3 / 4 || since >= SEG_MAX_SINCE) ? 1u : 0u;
+            if (s_flush) s_new = 0;
+        }
+        __syncthreads();                                  // every thread sees the same decision; nobody marks meanwhile
+        if (s_flush) {
+            since = 0;
+            for (int i = threadIdx.x; i < SEG_H; i += SEG_THREADS)
+                if (hkey[i] != KEY_INVALID) {
+                    const int32_t w = hval[i], v = (int32_t)(int16_t)(w & 0xffff), cp = (w - v) >> 16;       // (w = cp * 65536 + v exactly)
+                    if (v != 0) atomicAdd(a.span_diff + hkey[i], v);       // (marks of the spans are made only when span_diff is there)
+                    if (cp != 0) atomicAdd(a.cap_diff + hkey[i], cp);
+                    hkey[i] = KEY_INVALID; hval[i] = 0;
+                }
+            __syncthreads();                              // the hash is empty before the next batch marks
+        }
     }
     for (int o = 32; o > 0; o >>= 1) n_ev += __shfl_down(n_ev, o);
     __syncthreads();
