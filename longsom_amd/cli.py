@@ -28,6 +28,52 @@ def split_bam(argv=None):
     pipeline.write_report(os.path.join(a.outdir, a.id + ".report.txt"), rep, time.time() - t0)
 
 
+def _read_bed(path):
+    out = {}
+    for line in open(path):
+        f = line.rstrip("\n").split("\t")
+        if len(f) < 3 or line.startswith(("#", "track", "browser")):
+            continue
+        out.setdefault(f[0], []).append((int(f[1]), int(f[2])))
+    return out
+
+
+def bed_mask(keys, contig_names, contig_len, bed: str, bed_out: str):
+    """Which rows (keys = tid << 32 | 0-based position) lie in the regions MakeWindows leaves (BaseCellCounter.py:81-113): the --bed
+    intervals merged when at most 1 bp apart (`merge(d=1)`), clipped to [1, contig length) (`intersect` with the (x, 1, len) list: position 0
+    of a contig is never visited, with or without a bed), minus the --bed_out intervals (`subtract`); without --bed, whole contigs.
+    window_maker then only cuts the regions into pieces.  bedtools' interval arithmetic restated (pybedtools is not in the reference
+    tree nor in this image: unpinned, tests/test_cli_cpu.py holds hand-derived cases)."""
+    import numpy as np
+    keys = np.asarray(keys, np.int64)
+    keep = np.zeros(len(keys), bool)
+    want = _read_bed(bed) if bed else None
+    drop = _read_bed(bed_out) if bed_out else {}
+    tid_of, pos = keys >> 32, keys & 0xFFFFFFFF
+    for tid, (name, length) in enumerate(zip(contig_names, contig_len)):
+        if want is None:
+            ivs = [(1, int(length))]
+        else:
+            merged = []
+            for s0, e0 in sorted(want.get(name, [])):
+                if merged and s0 - merged[-1][1] <= 1:
+                    merged[-1][1] = max(merged[-1][1], e0)
+                else:
+                    merged.append([s0, e0])
+            ivs = [(max(s0, 1), min(e0, int(length))) for s0, e0 in merged if min(e0, int(length)) > max(s0, 1)]
+        sel = np.nonzero(tid_of == tid)[0]
+        if not len(sel) or not ivs:
+            continue
+        p = pos[sel]
+        starts = np.asarray([x for x, _ in ivs], np.int64); ends = np.asarray([y for _, y in ivs], np.int64)
+        j = np.searchsorted(starts, p, side="right") - 1
+        inside = (j >= 0) & (p < ends[np.maximum(j, 0)])
+        for s0, e0 in drop.get(name, []):
+            inside &= ~((p >= s0) & (p < e0))
+        keep[sel] = inside
+    return keep
+
+
 def base_cell_counter(argv=None):
     """BaseCellCounter.py --bam --ref --chrom --out_folder --nprocs --min_mq --tmp_dir [...]  (BaseCellCounter.py:323-342).
     --bam is one cell type's BAM: every CB in it is a cell of that type."""
@@ -41,8 +87,9 @@ def base_cell_counter(argv=None):
     _add_htslib_flag(ap)
     a = ap.parse_args(argv)
     _apply_htslib_flag(a)
-    if a.bed or a.bed_out or a.min_ac:
-        raise SystemExit("--bed / --bed_out / --min_ac are not used by LongSom's rules and are not implemented")
+    if a.min_ac:
+        raise SystemExit("--min_ac counts alternative alleles over every read of the pileup column, supplementary ones included (BaseCellCounter.py:152-180,221); "
+                         "LongSom's rules never pass it and it is not implemented")
     sid = a.id or os.path.basename(a.bam).replace(".bam", "")
     if a.tmp_dir != ".":
         os.makedirs(a.tmp_dir, exist_ok=True)          # the rule declares it as an output (R:SNVCalling.smk:36)
@@ -61,6 +108,9 @@ def base_cell_counter(argv=None):
         eng.load_reads(dec.records)
         eng.pileup_count(CountParams.longsom_defaults(min_bq=a.min_bq, min_mq=a.min_mq, min_dp=a.min_dp, min_cc=a.min_cc))
         k, r, c = eng.fetch_counts(0)
+    if a.bed or a.bed_out:                                # MakeWindows' interval arithmetic (BaseCellCounter.py:88-106): only rows inside are written
+        keep = bed_mask(k, dec.contig_names, [len(seq_of[n]) for n in dec.contig_names], a.bed, a.bed_out)
+        k, r, c = k[keep], r[keep], c[keep]
     out = os.path.join(a.out_folder, sid + ".tsv")
     print("Outfile: ", out, "\n")
     tsvio.write_counts_tsv(out, k, r, c, dec.contig_names, sid)

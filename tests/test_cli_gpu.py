@@ -51,3 +51,21 @@ def test_rule_chain_equals_fused_run(tmp_path):
     a = open(fused / "SplitBam" / "S1.report.txt").read().split("\n")[1].split("\t")[:4]
     b = open(w / "SplitBam" / "S1.report.txt").read().split("\n")[1].split("\t")[:4]
     assert a == b
+
+    # --bed / --bed_out (MakeWindows, BaseCellCounter.py:81-113): the rows of the whole-genome table that lie in the regions left
+    whole = [l for l in open(w / "BaseCellCounter" / "S1" / "S1.Cancer.tsv").read().split("\n") if l]
+    rows = [l.split("\t") for l in whole if not l.startswith("#")]
+    chrom = rows[len(rows) // 2][0]
+    ps = sorted(int(r[1]) for r in rows if r[0] == chrom)                      # 1-based Start of the table = 0-based position + 1
+    lo, mid, hi = ps[len(ps) // 4], ps[len(ps) // 2], ps[3 * len(ps) // 4]
+    bed, bed_out = tmp_path / "in.bed", tmp_path / "out.bed"
+    bed.write_text("%s\t%d\t%d\n%s\t%d\t%d\n" % (chrom, mid, hi, chrom, lo - 1, mid - 1))      # two intervals one base apart: merged, the base between is in
+    bed_out.write_text("%s\t%d\t%d\n" % (chrom, mid + 4, mid + 9))
+    os.makedirs(w / "bed")
+    run("SNVCalling/BaseCellCounter.py", "--bam", w / "SplitBam" / "S1.Cancer.bam", "--ref", fa, "--chrom", "all", "--out_folder", w / "bed", "--min_mq", 60,
+        "--tmp_dir", w / "bed" / "tmp", "--bed", bed, "--bed_out", bed_out)
+    got = [l for l in open(w / "bed" / "S1.Cancer.tsv").read().split("\n") if l and not l.startswith("#")]
+    want = [l for l in whole if not l.startswith("#") and l.split("\t")[0] == chrom and lo - 1 <= int(l.split("\t")[1]) - 1 < hi
+            and not (mid + 4 <= int(l.split("\t")[1]) - 1 < mid + 9)]
+    assert got == want and 0 < len(got) < len(rows)
+    assert any(int(l.split("\t")[1]) - 1 == mid - 1 for l in got) == any(int(r[1]) - 1 == mid - 1 for r in rows if r[0] == chrom)
