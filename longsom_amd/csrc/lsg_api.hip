@@ -22,11 +22,11 @@ int run_sf4(lsg_ctx* c, int64_t items, const uint32_t* k, const uint32_t* n, dou
 
 // copy a host or device array into a grow-only device buffer of the handle (the caller's array is free again when the call returns)
 template <class T>
-static int put(lsg_ctx* c, DevBuf& buf, const T*& dst, const T* src, int64_t n, int on_device) {
+static int put(lsg_ctx* c, DevBuf& buf, const T*& dst, const T* src, int64_t n, int on_device, hipStream_t st = nullptr) {
     if (n <= 0 || !src) { dst = nullptr; return 0; }
     if (src == buf.as<T>()) { dst = src; return 0; }          // (lsg_synth_reads generates into the handle's own buffers)
     if (buf.reserve((size_t)n * sizeof(T))) return -1;
-    LSG_HIP(hipMemcpyAsync(buf.p, src, (size_t)n * sizeof(T), on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+    LSG_HIP(hipMemcpyAsync(buf.p, src, (size_t)n * sizeof(T), on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st ? st : c->stream));
     dst = buf.as<T>();
     return 0;
 }
@@ -60,7 +60,8 @@ int lsg_create(int device_id, lsg_ctx** out) {
     lsg_ctx* c = new lsg_ctx();
     c->device = device_id;
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) c->n_cus = prop.multiProcessorCount; }
-    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+    if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
         set_error("lsg_create: hipStreamCreate failed"); delete c; return -1;
     }
     c->stream = c->own_stream;
@@ -94,6 +95,8 @@ void lsg_destroy(lsg_ctx* c) {
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->evb) if (e) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->ev_copy) (void)hipEventDestroy(c->ev_copy);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     delete c;
 }
@@ -237,22 +240,31 @@ int lsg_load_reads(lsg_ctx* c, const lsg_reads* r) {
     if (in.n_reads > 0 && (!in.read_tid || !in.read_flag || !in.read_mapq || !in.read_cb)) { c->rd = lsg_reads{}; set_error("lsg_load_reads: NULL read array"); return -2; }
     if (in.n_segs > 0 && (!in.seg_read || !in.seg_start || !in.seg_len || !in.seg_ev_off)) { c->rd = lsg_reads{}; set_error("lsg_load_reads: NULL segment array"); return -2; }
     if (in.n_events > 0 && !in.events) { c->rd = lsg_reads{}; set_error("lsg_load_reads: NULL events array"); return -2; }
-    // the small arrays (15 bytes per read, 12 per segment) are always copied: admission, the depth cap and the statistics read them
-    if (put(c, c->b_read_tid, c->rd.read_tid, in.read_tid, in.n_reads, d) ||
-        put(c, c->b_read_pos, c->rd.read_pos, in.read_pos, in.n_reads, d) ||
-        put(c, c->b_read_flag, c->rd.read_flag, in.read_flag, in.n_reads, d) ||
-        put(c, c->b_read_mapq, c->rd.read_mapq, in.read_mapq, in.n_reads, d) ||
-        put(c, c->b_read_cb, c->rd.read_cb, in.read_cb, in.n_reads, d) ||
-        put(c, c->b_seg_read, c->rd.seg_read, in.seg_read, in.n_segs, d) ||
-        put(c, c->b_seg_start, c->rd.seg_start, in.seg_start, in.n_segs, d) ||
-        put(c, c->b_seg_len, c->rd.seg_len, in.seg_len, in.n_segs, d)) { c->rd = lsg_reads{}; return -1; }
+    // the small arrays (15 bytes per read, 12 per segment) are always copied: admission, the depth cap and the statistics read them.
+    // Device arrays travel on a stream of their own (after whatever the caller queued on the handle's stream) while the build's first
+    // kernels read the caller's arrays where they lie: a gigabyte of copies beside a kernel that waits on dependent loads.
+    hipStream_t cs = nullptr;
+    if (d && !c->keep_reads) {
+        LSG_HIP(hipEventRecord(c->ev_copy, c->stream));
+        LSG_HIP(hipStreamWaitEvent(c->copy_stream, c->ev_copy, 0));
+        cs = c->copy_stream;
+    }
+    if (put(c, c->b_read_tid, c->rd.read_tid, in.read_tid, in.n_reads, d, cs) ||
+        put(c, c->b_read_pos, c->rd.read_pos, in.read_pos, in.n_reads, d, cs) ||
+        put(c, c->b_read_flag, c->rd.read_flag, in.read_flag, in.n_reads, d, cs) ||
+        put(c, c->b_read_mapq, c->rd.read_mapq, in.read_mapq, in.n_reads, d, cs) ||
+        put(c, c->b_read_cb, c->rd.read_cb, in.read_cb, in.n_reads, d, cs) ||
+        put(c, c->b_seg_read, c->rd.seg_read, in.seg_read, in.n_segs, d, cs) ||
+        put(c, c->b_seg_start, c->rd.seg_start, in.seg_start, in.n_segs, d, cs) ||
+        put(c, c->b_seg_len, c->rd.seg_len, in.seg_len, in.n_segs, d, cs)) { if (cs) (void)hipStreamSynchronize(cs); c->rd = lsg_reads{}; return -1; }
     // the events and their offsets: device arrays are read where they lie, host arrays through a staging copy; neither outlives the call
     // unless lsg_set_keep_reads asked for it
     const uint16_t* ev = in.events; const int64_t* evo = in.seg_ev_off;
     const bool staged = !d || c->keep_reads;
     if (staged && (put(c, c->b_seg_ev_off, evo, in.seg_ev_off, in.n_segs, d) || put(c, c->b_events, ev, in.events, in.n_events, d))) { c->rd = lsg_reads{}; return -1; }
-    LSG_HIP(hipStreamSynchronize(c->stream));
-    if (int rc = lsg::build_store(c, ev, in.n_events, evo)) { c->rd = lsg_reads{}; lsg::drop_store(c); return rc; }      // a refused load leaves no reads behind
+    const int rc = lsg::build_store(c, ev, in.n_events, evo, cs ? &in : nullptr);
+    if (cs) LSG_HIP(hipStreamSynchronize(cs));                 // the handle's copies are whole before anyone counts (or the caller frees its arrays)
+    if (rc) { c->rd = lsg_reads{}; lsg::drop_store(c); return rc; }      // a refused load leaves no reads behind
     if (c->keep_reads) { c->rd.events = ev; c->rd.seg_ev_off = evo; }
     else { c->b_events.release(); c->b_seg_ev_off.release(); }
     return 0;

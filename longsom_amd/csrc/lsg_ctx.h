@@ -85,7 +85,7 @@ constexpr int TM_JOB_TGT = 3072, TM_JOB_LIMIT = 4095;      // LIMIT: what the pl
 
 struct lsg_ctx;
 namespace lsg {
-int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int64_t* seg_ev_off);   // store.hip: the load's tile store from the caller's compact events
+int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int64_t* seg_ev_off, const lsg_reads* src = nullptr);   // store.hip: the load's tile store from the caller's compact events (src: read the per-read / per-segment arrays there instead of the handle's copies, which may still be under way)
 int ensure_plan(lsg_ctx* c);       // store.hip: jobs / units / slabs of a count over the store for the current number of cell types
 void drop_store(lsg_ctx* c);       // store.hip: new reads or contigs
 int live_read_bound(lsg_ctx* c);   // layout.hip: fills max_live_reads when it is stale (-1)
@@ -99,6 +99,8 @@ struct lsg_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t own_stream = nullptr;
+    hipStream_t copy_stream = nullptr;      // the load's copies of the caller's device arrays run here, beside the build's first kernels
+    hipEvent_t ev_copy = nullptr;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t evb[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};      // store.hip: the build's phases
 

@@ -432,7 +432,7 @@ static void settle_temporaries(lsg_ctx* c) {
     if (held > mem_total / 8 || mem_free < mem_total / 8) { for (auto& b : c->bt) b.release(); c->ws[WS_SEG_INFO].release(); }
 }
 
-int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int64_t* seg_ev_off) {
+int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int64_t* seg_ev_off, const lsg_reads* src) {
     drop_store(c);
     hipStream_t st = c->stream;
     const int64_t S = c->rd.n_segs, R = c->rd.n_reads;
@@ -453,8 +453,9 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
     LSG_HIP(hipMemsetAsync(c->d_scalars.p, 0, 64, st));
     BuildArgs a{};
     a.n_reads = R; a.n_segs = S; a.n_events = n_events;
-    a.read_tid = c->rd.read_tid; a.read_flag = c->rd.read_flag; a.read_mapq = c->rd.read_mapq; a.read_cb = c->rd.read_cb;
-    a.seg_read = c->rd.seg_read; a.seg_start = c->rd.seg_start; a.seg_len = c->rd.seg_len; a.seg_ev_off = seg_ev_off;
+    const lsg_reads& in = src ? *src : c->rd;          // (same contents: the handle's copies of a caller's device arrays may still be travelling on the copy stream)
+    a.read_tid = in.read_tid; a.read_flag = in.read_flag; a.read_mapq = in.read_mapq; a.read_cb = in.read_cb;
+    a.seg_read = in.seg_read; a.seg_start = in.seg_start; a.seg_len = in.seg_len; a.seg_ev_off = seg_ev_off;
     a.tile_base = c->d_tile_base.as<uint32_t>(); a.contig_len = c->d_contig_len.as<int64_t>(); a.n_contigs = c->n_contigs; a.n_tiles = T;
     a.seg_info = c->ws[WS_SEG_INFO].as<uint2>(); a.tile_cap = c->d_tile_cap.as<uint32_t>();
     a.lf_min_mq = c->lf_min_mq; a.lf_flag_exclude = c->lf_flag_exclude; a.lf_ignore_orphans = c->lf_ignore_orphans;
@@ -494,10 +495,10 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
     }
     {
         size_t tb = 0;
-        LSG_HIP(hipcub::DeviceReduce::Max(nullptr, tb, c->rd.read_cb, reinterpret_cast<int32_t*>(d_small + 2), (int)(R > 0 ? R : 1), st));
+        LSG_HIP(hipcub::DeviceReduce::Max(nullptr, tb, in.read_cb, reinterpret_cast<int32_t*>(d_small + 2), (int)(R > 0 ? R : 1), st));
         if (tmp.reserve(tb + 256)) return -1;
         tb = tmp.cap;
-        if (R > 0) LSG_HIP(hipcub::DeviceReduce::Max(tmp.p, tb, c->rd.read_cb, reinterpret_cast<int32_t*>(d_small + 2), (int)R, st));
+        if (R > 0) LSG_HIP(hipcub::DeviceReduce::Max(tmp.p, tb, in.read_cb, reinterpret_cast<int32_t*>(d_small + 2), (int)R, st));
     }
     uint32_t total = 0, bad = 0; int32_t max_cb = 0, max_live = 0;
     LSG_HIP(hipMemcpyAsync(&max_live, d_small + 3, 4, hipMemcpyDeviceToHost, st));
