@@ -135,6 +135,8 @@ struct lsg_ctx {
     uint64_t tm_np = 0;                   // padded entries = 8 x blocks
     uint32_t tm_nblk = 0, tm_njobs = 0, tm_nchunks = 0, tm_n_ne = 0, tm_n_multi = 0, tm_n_slabs = 0, tm_n_wide = 0;
     int plan_n_ct = 0;                    // cell types the plan was made for (0: none)
+    int plan1_n_ct = 0;                   // ... and its tile-level half (units, jobs, slabs per tile and their totals), which the load can make beside its gather
+    uint32_t plan1_tot[4] = {0, 0, 0, 0};
     bool tm_valid = false;
     double layout_build_ms = 0;           // wall time of the last build (lsg_get_layout_info)
     float build_ms[4] = {0, 0, 0, 0};     // HIP-event times of the last build: capacities + scatter, sort, fill, gather

@@ -416,7 +416,7 @@ __global__ __launch_bounds__(TMG_WAVES * 64) void k_tm_gather(const uint16_t* ev
 enum { BT_REC = 0, BT_KEY_A, BT_KEY_B, BT_VAL_A, BT_VAL_B, BT_PEX, BT_NETILE, BT_SEG_BEGIN, BT_SEG_END, BT_TMP, BT_PER_TILE, BT_OFFS, BT_SPAN, BT_SPAN_RUN };
 
 void drop_store(lsg_ctx* c) {
-    c->tm_valid = false; c->plan_n_ct = 0; c->tm_n = 0; c->tm_events = 0; c->tm_np = 0; c->tm_nblk = 0; c->tm_njobs = 0; c->tm_nchunks = 0;
+    c->tm_valid = false; c->plan_n_ct = 0; c->plan1_n_ct = 0; c->tm_n = 0; c->tm_events = 0; c->tm_np = 0; c->tm_nblk = 0; c->tm_njobs = 0; c->tm_nchunks = 0;
     c->tm_n_ne = 0; c->tm_n_multi = 0; c->tm_n_slabs = 0; c->tm_n_wide = 0;
     c->max_live_reads = -1; c->max_live_all = -1; c->has_drops = false;
     c->counted = c->called = false;
@@ -429,8 +429,10 @@ static void settle_temporaries(lsg_ctx* c) {
     for (auto& b : c->bt) held += b.cap;
     held += c->ws[WS_SEG_INFO].cap;
     if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) return;
-    if (held > mem_total / 8 || mem_free < mem_total / 8) { for (auto& b : c->bt) b.release(); c->ws[WS_SEG_INFO].release(); }
+    if (held > mem_total / 8 || mem_free < mem_total / 8) { for (auto& b : c->bt) b.release(); c->ws[WS_SEG_INFO].release(); c->plan1_n_ct = 0; }      // (the plan's tile-level half lived there: the first count makes it again)
 }
+
+static int plan_tiles(lsg_ctx* c, hipStream_t st);
 
 int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int64_t* seg_ev_off, const lsg_reads* src) {
     drop_store(c);
@@ -601,6 +603,8 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
         if (c->tm[TM_STORE].reserve(((size_t)nblk + TM_GROUP) * 1024)) return -1;
     }
     LSG_HIP(hipEventRecord(c->evb[3], st));
+    const bool plan_early = c->n_ct > 0 && c->copy_stream && c->ev_copy;
+    if (plan_early) LSG_HIP(hipEventRecord(c->ev_copy, st));       // everything the gather waits for is what the plan's tile-level half waits for
     {
         const dim3 grid((unsigned)(((((uint64_t)nblk + TMG_BLOCKS - 1) / TMG_BLOCKS + TMG_WAVES - 1) / TMG_WAVES + 7) / 8 * 8));
         hipLaunchKernelGGL(k_tm_gather, grid, dim3(TMG_WAVES * 64), 0, st,
@@ -610,7 +614,14 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
     }
     LSG_HIP(hipEventRecord(c->evb[4], st));
     LSG_HIP(hipGetLastError());
+    int plan_rc = 0;
+    if (plan_early) {       // beside the gather, on the copy stream: a dozen small kernels and two host round trips that the first count would otherwise pay
+        LSG_HIP(hipStreamWaitEvent(c->copy_stream, c->ev_copy, 0));
+        plan_rc = plan_tiles(c, c->copy_stream);
+    }
     LSG_HIP(hipStreamSynchronize(st));
+    if (plan_early) LSG_HIP(hipStreamSynchronize(c->copy_stream));
+    if (plan_rc) return plan_rc;
     for (int i = 0; i < 4; ++i) { float ms = 0; if (hipEventElapsedTime(&ms, c->evb[i], c->evb[i + 1]) == hipSuccess) c->build_ms[i] = ms; }
     settle_temporaries(c);
     if (getenv("LSG_TIMING"))
@@ -703,13 +714,10 @@ __global__ void k_tm_chunks(const uint32_t* pex, uint32_t njobs, uint32_t chunk_
     if (j == njobs - 1) { chunk_start[ck + 1] = njobs; *n_chunks = ck + 1; }
 }
 
-int ensure_plan(lsg_ctx* c) {
-    if (!c->tm_valid) { set_error("lsg_pileup_count: no reads loaded"); return -2; }
-    if (c->plan_n_ct == c->n_ct) return 0;
-    c->plan_n_ct = 0;
-    c->tm_njobs = c->tm_nchunks = c->tm_n_ne = c->tm_n_multi = c->tm_n_slabs = c->tm_n_wide = 0;
-    if (c->tm_nblk == 0) { c->plan_n_ct = c->n_ct; return 0; }
-    hipStream_t st = c->stream;
+// The plan's tile-level half: units, jobs, slabs and multi-job marks per tile, their running sums and totals, the buffers those totals
+// size.  It reads the tiles' capacities only, so the load makes it on the copy stream BESIDE its gather (which then is all the device
+// is waiting for) when the number of cell types is already known; else the first count makes it.
+static int plan_tiles(lsg_ctx* c, hipStream_t st) {
     const uint32_t T = c->n_tiles;
     const uint64_t N = c->tm_n;
     DevBuf &per_tile = c->bt[BT_PER_TILE], &offs = c->bt[BT_OFFS];
@@ -724,16 +732,37 @@ int ensure_plan(lsg_ctx* c) {
     hipLaunchKernelGGL(k_tm_tiles, dim3((T + 256) / 256), dim3(256), 0, st, c->d_tile_cap.as<uint32_t>(), T, c->n_ct, job_tgt, ne, nj, slabs, multi);
     SCAN_U32(ne, ne_off, T + 1); SCAN_U32(nj, job_off, T + 1); SCAN_U32(slabs, slab_off, T + 1); SCAN_U32(multi, multi_off, T + 1);
     LSG_HIP(hipMemsetAsync(d_misc, 0, 8, st));
-    uint32_t tot[4] = {0, 0, 0, 0};
     uint32_t* srcs[4] = {ne_off, job_off, slab_off, multi_off};
-    for (int i = 0; i < 4; ++i) LSG_HIP(hipMemcpyAsync(&tot[i], srcs[i] + T, 4, hipMemcpyDeviceToHost, st));
+    for (int i = 0; i < 4; ++i) LSG_HIP(hipMemcpyAsync(&c->plan1_tot[i], srcs[i] + T, 4, hipMemcpyDeviceToHost, st));
     LSG_HIP(hipStreamSynchronize(st));
-    const uint32_t n_net = tot[0], njobs = tot[1], n_slabs = tot[2], n_mt = tot[3];
+    const uint32_t n_net = c->plan1_tot[0], njobs = c->plan1_tot[1], n_mt = c->plan1_tot[3];
     const size_t n_ne = (size_t)n_net * (size_t)c->n_ct, n_multi = (size_t)n_mt * (size_t)c->n_ct;
     if (c->tm[TM_JOBS].reserve(((size_t)njobs + 1) * sizeof(TmJob)) || c->tm[TM_NE_UNITS].reserve((n_ne + 2) * 4) || c->tm[TM_NE_GEOM].reserve((n_ne + 2) * 8) ||
         c->tm[TM_NE_NSLOT].reserve((n_ne + 2) * 4) || c->tm[TM_NE_ACC].reserve((n_ne + 2) * 4) || c->tm[TM_MULTI].reserve((n_multi + 2) * 4)) return -1;
     LSG_HIP(hipMemsetAsync(c->tm[TM_NE_NSLOT].p, 0, (n_ne + 2) * 4, st));
     LSG_HIP(hipMemsetAsync(c->tm[TM_NE_ACC].p, 0, (n_ne + 2) * 4, st));
+    LSG_HIP(hipStreamSynchronize(st));
+    c->plan1_n_ct = c->n_ct;
+    return 0;
+}
+
+int ensure_plan(lsg_ctx* c) {
+    if (!c->tm_valid) { set_error("lsg_pileup_count: no reads loaded"); return -2; }
+    if (c->plan_n_ct == c->n_ct) return 0;
+    c->plan_n_ct = 0;
+    c->tm_njobs = c->tm_nchunks = c->tm_n_ne = c->tm_n_multi = c->tm_n_slabs = c->tm_n_wide = 0;
+    if (c->tm_nblk == 0) { c->plan_n_ct = c->n_ct; return 0; }
+    hipStream_t st = c->stream;
+    const uint32_t T = c->n_tiles;
+    if (c->plan1_n_ct != c->n_ct) { if (int rc = plan_tiles(c, st)) return rc; }
+    DevBuf &per_tile = c->bt[BT_PER_TILE], &offs = c->bt[BT_OFFS];
+    uint32_t* ne = per_tile.as<uint32_t>(); uint32_t* nj = ne + (T + 2);
+    uint32_t* ne_off = offs.as<uint32_t>(); uint32_t* job_off = ne_off + (T + 2); uint32_t* slab_off = job_off + (T + 2); uint32_t* multi_off = slab_off + (T + 2);
+    uint32_t* d_misc = multi_off + (T + 2);          // [0] wide jobs, [1] chunks
+    (void)ne;
+    const uint32_t* tot = c->plan1_tot;
+    const uint32_t n_net = tot[0], njobs = tot[1], n_slabs = tot[2], n_mt = tot[3];
+    const size_t n_ne = (size_t)n_net * (size_t)c->n_ct, n_multi = (size_t)n_mt * (size_t)c->n_ct;
     hipLaunchKernelGGL(k_tm_jobs, dim3((T + 255) / 256), dim3(256), 0, st, c->d_tile_base.as<uint32_t>(), c->n_contigs, c->n_ct, c->tm[TM_S0].as<uint32_t>(),
                        c->d_tile_cap.as<uint32_t>(), c->tm[TM_BLK_OFF].as<uint32_t>(), ne_off, nj, job_off, slab_off, multi_off, T,
                        c->tm[TM_JOBS].as<TmJob>(), c->tm[TM_NE_UNITS].as<uint32_t>(), c->tm[TM_NE_GEOM].as<int2>(), c->tm[TM_NE_NSLOT].as<uint32_t>(),
