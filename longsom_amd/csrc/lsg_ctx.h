@@ -137,6 +137,7 @@ struct lsg_ctx {
     int plan_n_ct = 0;                    // cell types the plan was made for (0: none)
     int plan1_n_ct = 0;                   // ... and its tile-level half (units, jobs, slabs per tile and their totals), which the load can make beside its gather
     uint32_t plan1_tot[4] = {0, 0, 0, 0};
+    uint32_t plan_misc[2] = {0, 0};       // wide jobs, chunks (read back from the job-level half)
     bool tm_valid = false;
     double layout_build_ms = 0;           // wall time of the last build (lsg_get_layout_info)
     float build_ms[4] = {0, 0, 0, 0};     // HIP-event times of the last build: capacities + scatter, sort, fill, gather

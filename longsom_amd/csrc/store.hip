@@ -433,6 +433,8 @@ static void settle_temporaries(lsg_ctx* c) {
 }
 
 static int plan_tiles(lsg_ctx* c, hipStream_t st);
+static int plan_jobs(lsg_ctx* c, bool finish);
+static void plan_finish(lsg_ctx* c);
 
 int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int64_t* seg_ev_off, const lsg_reads* src) {
     drop_store(c);
@@ -618,10 +620,15 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
     if (plan_early) {       // beside the gather, on the copy stream: a dozen small kernels and two host round trips that the first count would otherwise pay
         LSG_HIP(hipStreamWaitEvent(c->copy_stream, c->ev_copy, 0));
         plan_rc = plan_tiles(c, c->copy_stream);
+        if (!plan_rc) {        // ... and its job-level half right behind the gather: the load's last synchronisation is the plan's too
+            c->tm_np = np; c->tm_nblk = nblk;
+            plan_rc = plan_jobs(c, false);
+        }
     }
     LSG_HIP(hipStreamSynchronize(st));
     if (plan_early) LSG_HIP(hipStreamSynchronize(c->copy_stream));
     if (plan_rc) return plan_rc;
+    if (plan_early) plan_finish(c);
     for (int i = 0; i < 4; ++i) { float ms = 0; if (hipEventElapsedTime(&ms, c->evb[i], c->evb[i + 1]) == hipSuccess) c->build_ms[i] = ms; }
     settle_temporaries(c);
     if (getenv("LSG_TIMING"))
@@ -746,23 +753,18 @@ static int plan_tiles(lsg_ctx* c, hipStream_t st) {
     return 0;
 }
 
-int ensure_plan(lsg_ctx* c) {
-    if (!c->tm_valid) { set_error("lsg_pileup_count: no reads loaded"); return -2; }
-    if (c->plan_n_ct == c->n_ct) return 0;
-    c->plan_n_ct = 0;
-    c->tm_njobs = c->tm_nchunks = c->tm_n_ne = c->tm_n_multi = c->tm_n_slabs = c->tm_n_wide = 0;
-    if (c->tm_nblk == 0) { c->plan_n_ct = c->n_ct; return 0; }
+// The plan's job-level half: jobs cut at the run starts the gather wrote, the units' tables, the walk's work-balanced chunks.  Queued
+// behind the gather by the load when the tile-level half is there (finish = false: the load's own final synchronisation covers it and
+// plan_finish reads the two counters), else made by the first count.
+static int plan_jobs(lsg_ctx* c, bool finish) {
     hipStream_t st = c->stream;
     const uint32_t T = c->n_tiles;
-    if (c->plan1_n_ct != c->n_ct) { if (int rc = plan_tiles(c, st)) return rc; }
     DevBuf &per_tile = c->bt[BT_PER_TILE], &offs = c->bt[BT_OFFS];
-    uint32_t* ne = per_tile.as<uint32_t>(); uint32_t* nj = ne + (T + 2);
+    uint32_t* nj = per_tile.as<uint32_t>() + (T + 2);
     uint32_t* ne_off = offs.as<uint32_t>(); uint32_t* job_off = ne_off + (T + 2); uint32_t* slab_off = job_off + (T + 2); uint32_t* multi_off = slab_off + (T + 2);
     uint32_t* d_misc = multi_off + (T + 2);          // [0] wide jobs, [1] chunks
-    (void)ne;
     const uint32_t* tot = c->plan1_tot;
-    const uint32_t n_net = tot[0], njobs = tot[1], n_slabs = tot[2], n_mt = tot[3];
-    const size_t n_ne = (size_t)n_net * (size_t)c->n_ct, n_multi = (size_t)n_mt * (size_t)c->n_ct;
+    const uint32_t njobs = tot[1], n_mt = tot[3];
     hipLaunchKernelGGL(k_tm_jobs, dim3((T + 255) / 256), dim3(256), 0, st, c->d_tile_base.as<uint32_t>(), c->n_contigs, c->n_ct, c->tm[TM_S0].as<uint32_t>(),
                        c->d_tile_cap.as<uint32_t>(), c->tm[TM_BLK_OFF].as<uint32_t>(), ne_off, nj, job_off, slab_off, multi_off, T,
                        c->tm[TM_JOBS].as<TmJob>(), c->tm[TM_NE_UNITS].as<uint32_t>(), c->tm[TM_NE_GEOM].as<int2>(), c->tm[TM_NE_NSLOT].as<uint32_t>(),
@@ -781,13 +783,28 @@ int ensure_plan(lsg_ctx* c) {
         SCAN_U32(it, pex.as<uint32_t>(), njobs);
         hipLaunchKernelGGL(k_tm_chunks, dim3((njobs + 255) / 256), dim3(256), 0, st, pex.as<uint32_t>(), njobs, chunk_work, c->tm[TM_CHUNKS].as<uint32_t>(), d_misc + 1);
     }
-    uint32_t misc[2] = {0, 0};
-    LSG_HIP(hipMemcpyAsync(misc, d_misc, 8, hipMemcpyDeviceToHost, st));
+    LSG_HIP(hipMemcpyAsync(c->plan_misc, d_misc, 8, hipMemcpyDeviceToHost, st));
     LSG_HIP(hipGetLastError());
-    LSG_HIP(hipStreamSynchronize(st));
-    c->tm_njobs = njobs; c->tm_nchunks = misc[1]; c->tm_n_wide = misc[0];
-    c->tm_n_ne = (uint32_t)n_ne; c->tm_n_multi = (uint32_t)n_multi; c->tm_n_slabs = n_slabs;
+    if (finish) LSG_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+static void plan_finish(lsg_ctx* c) {          // (after the stream plan_jobs ran on has been synchronised)
+    const uint32_t* tot = c->plan1_tot;
+    c->tm_njobs = tot[1]; c->tm_nchunks = c->plan_misc[1]; c->tm_n_wide = c->plan_misc[0];
+    c->tm_n_ne = (uint32_t)((size_t)tot[0] * (size_t)c->n_ct); c->tm_n_multi = (uint32_t)((size_t)tot[3] * (size_t)c->n_ct); c->tm_n_slabs = tot[2];
     c->plan_n_ct = c->n_ct;
+}
+
+int ensure_plan(lsg_ctx* c) {
+    if (!c->tm_valid) { set_error("lsg_pileup_count: no reads loaded"); return -2; }
+    if (c->plan_n_ct == c->n_ct) return 0;
+    c->plan_n_ct = 0;
+    c->tm_njobs = c->tm_nchunks = c->tm_n_ne = c->tm_n_multi = c->tm_n_slabs = c->tm_n_wide = 0;
+    if (c->tm_nblk == 0) { c->plan_n_ct = c->n_ct; return 0; }
+    if (c->plan1_n_ct != c->n_ct) { if (int rc = plan_tiles(c, c->stream)) return rc; }
+    if (int rc = plan_jobs(c, true)) return rc;
+    plan_finish(c);
     return 0;
 }
 
