@@ -440,7 +440,7 @@ static void plan_finish(lsg_ctx* c);
 // rocprim's segmented radix sort with a configuration of its own.  gfx950 gets rocprim's generic default (3.7 ms for C2's 185 M pairs in
 // 5 * 10^5 segments); measured on the MI355X over radix bits 6-8, blocks of 256 / 512 threads with 4-24 items per thread and four
 // warp-sort shapes: 7 bits per pass (13-bit barcodes: 7 + 6), 256 x 8 items in the block sort, segments of up to 64 / 256 pairs to the
-// small / medium warp sorts: 2.3 ms.  More than 14 key bits (C4's 20 000 barcodes: 15): 8 bits per pass keeps it at two passes.
+// small / medium warp sorts: 2.3 ms.  Where 8 bits per pass save a pass (C4's 20 000 barcodes: 15 key bits in two passes) they are taken.
 template <unsigned RB>
 using LsgSortConfig = rocprim::segmented_radix_sort_config<RB, rocprim::kernel_config<256, 8>, rocprim::WarpSortConfig<16, 4, 256, 64, 32, 8, 256>>;
 template <unsigned RB, class... Args>
@@ -571,7 +571,7 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
         // (values in = the entries' arrival places, an iterator: rocprim's own entry point takes one where hipcub wants an array)
         rocprim::counting_iterator<uint32_t> place(0u);
         auto sort = [&](void* tmp_p, size_t& tmp_n) {
-            return bits <= 14 ? lsg_segmented_sort<7>(tmp_p, tmp_n, key_a.as<uint32_t>(), key_b.as<uint32_t>(), place, val_b.as<uint32_t>(), (unsigned)N, (unsigned)n_netile,
+            return (bits + 6) / 7 <= (bits + 7) / 8 ? lsg_segmented_sort<7>(tmp_p, tmp_n, key_a.as<uint32_t>(), key_b.as<uint32_t>(), place, val_b.as<uint32_t>(), (unsigned)N, (unsigned)n_netile,
                                                       c->bt[BT_SEG_BEGIN].as<uint32_t>(), c->bt[BT_SEG_END].as<uint32_t>(), 0u, (unsigned)bits, st, false)
                               : lsg_segmented_sort<8>(tmp_p, tmp_n, key_a.as<uint32_t>(), key_b.as<uint32_t>(), place, val_b.as<uint32_t>(), (unsigned)N, (unsigned)n_netile,
                                                       c->bt[BT_SEG_BEGIN].as<uint32_t>(), c->bt[BT_SEG_END].as<uint32_t>(), 0u, (unsigned)bits, st, false);
