@@ -229,7 +229,7 @@ def recorded_traffic(kernel):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--steps", type=int, default=80)          # (80 x 25.6 ms: the timed region keeps the GPU busy for 2 s)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--reads", type=float, default=None, help="override the read count (development only; the reported config changes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
