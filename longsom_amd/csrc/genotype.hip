@@ -10,7 +10,7 @@
 namespace lsg {
 
 struct GenoArgs {
-    const uint4* store; const uint16_t* ext; const uint32_t* s0; const uint32_t* fm;
+    const uint4* store; const uint16_t* ext; const uint32_t* s0; const uint16_t* read_flag; const uint8_t* read_mapq;
     const uint32_t* tile_base; const uint32_t* tile_off; const uint32_t* blk_off;
     const uint8_t* celltype_of; const int64_t* contig_len;
     int32_t n_contigs, n_cb;
@@ -45,12 +45,14 @@ __global__ __launch_bounds__(256) void k_geno_sites(GenoArgs a) {
             const bool is_alt = sym == alt_sym;
             if (a.p.alt_only && !is_alt) continue;
             const uint64_t p = (uint64_t)(b0 + k) * 8 + u;
-            const uint32_t cb = a.s0[p] & CB_MASK, f = a.fm[p], flag = f & 0xffffu;
-            bool ok = cb < (uint32_t)a.n_cb && (flag & a.p.flag_exclude) == 0 && (int)(f >> 16) >= a.p.min_mq;
+            const uint32_t cb = a.s0[p] & CB_MASK;
+            if (cb >= (uint32_t)a.n_cb || a.celltype_of[cb] == 255) continue;       // (pad entries carry CB_MASK)
+            const uint32_t r = a.rd[p], flag = a.read_flag[r];                       // the entry's read: its SAM flag (LSG_FLAG_CB_SUFFIX included) and MAPQ
+            bool ok = (flag & a.p.flag_exclude) == 0 && (int)a.read_mapq[r] >= a.p.min_mq;
             if (ok && a.p.ignore_orphans && (flag & 0x1) && !(flag & 0x2)) ok = false;
             if (ok && a.p.strict_cb && (flag & LSG_FLAG_CB_SUFFIX)) ok = false;
-            if (!ok || a.celltype_of[cb] == 255) continue;
-            if (a.read_drop && a.read_drop[a.rd[p]]) continue;
+            if (!ok) continue;
+            if (a.read_drop && a.read_drop[r]) continue;
             const uint64_t cell = (uint64_t)i * (uint64_t)a.n_cb + cb;
             atomicAdd(&a.dp[cell], 1u);
             if (is_alt) atomicAdd(&a.alt[cell], 1u);
@@ -142,7 +144,7 @@ int run_genotype(lsg_ctx* c, const lsg_genotype_params* p, int64_t n_sites, cons
     auto done = [&](int rc) { d_keys.release(); d_alt_sym.release(); d_dp.release(); d_alt.release(); return rc; };
     if (!c->tm_valid) { set_error("lsg_genotype_cells: no reads loaded"); return -2; }
     GenoArgs a{};
-    a.store = c->tm[TM_STORE].as<uint4>(); a.ext = c->tm[TM_EXT].as<uint16_t>(); a.s0 = c->tm[TM_S0].as<uint32_t>(); a.fm = c->tm[TM_FM].as<uint32_t>();
+    a.store = c->tm[TM_STORE].as<uint4>(); a.ext = c->tm[TM_EXT].as<uint16_t>(); a.s0 = c->tm[TM_S0].as<uint32_t>(); a.read_flag = c->rd.read_flag; a.read_mapq = c->rd.read_mapq;
     a.tile_base = c->d_tile_base.as<uint32_t>(); a.tile_off = c->d_tile_off.as<uint32_t>(); a.blk_off = c->tm[TM_BLK_OFF].as<uint32_t>();
     a.celltype_of = c->d_celltype_of.as<uint8_t>(); a.contig_len = c->d_contig_len.as<int64_t>();
     a.n_contigs = c->n_contigs; a.n_cb = c->n_cb; a.p = *p; a.n_sites = n_sites;

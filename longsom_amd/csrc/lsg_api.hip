@@ -80,7 +80,7 @@ void lsg_destroy(lsg_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->d_tile_base, &c->d_contig_len, &c->d_ref_ptrs, &c->d_celltype_of, &c->d_ct_rank, &c->b_read_tid, &c->b_read_pos,
                       &c->b_read_flag, &c->b_read_mapq, &c->b_read_cb, &c->b_seg_read, &c->b_seg_start, &c->b_seg_len,
-                      &c->b_seg_ev_off, &c->b_events, &c->d_read_key, &c->d_read_drop,
+                      &c->b_seg_ev_off, &c->b_events, &c->d_read_key, &c->d_read_drop, &c->d_read_adm,
                       &c->d_ne_units, &c->d_ne_mask, &c->d_ne_rowbase, &c->d_ne_rowoff,
                       &c->d_scalars, &c->d_cub_tmp, &c->d_ix_stat, &c->d_tile_cap, &c->d_tile_off, &c->d_calls, &c->d_site_off, &c->d_tail_table, &c->d_pass_list};
     for (auto* b : bufs) b->release();
@@ -106,7 +106,7 @@ int lsg_unload_reads(lsg_ctx* c) {
     LSG_HIP(hipSetDevice(c->device));
     LSG_HIP(hipStreamSynchronize(c->stream));
     DevBuf* bufs[] = {&c->b_read_tid, &c->b_read_pos, &c->b_read_flag, &c->b_read_mapq, &c->b_read_cb, &c->b_seg_read, &c->b_seg_start, &c->b_seg_len,
-                      &c->b_seg_ev_off, &c->b_events, &c->d_read_key, &c->d_read_drop, &c->d_ne_units, &c->d_ne_mask, &c->d_ne_rowbase, &c->d_ne_rowoff,
+                      &c->b_seg_ev_off, &c->b_events, &c->d_read_key, &c->d_read_drop, &c->d_read_adm, &c->d_ne_units, &c->d_ne_mask, &c->d_ne_rowbase, &c->d_ne_rowoff,
                       &c->d_cub_tmp, &c->d_ix_stat, &c->d_tile_cap, &c->d_tile_off, &c->d_calls, &c->d_site_off, &c->d_pass_list};
     for (auto* b : bufs) b->release();
     for (auto& b : c->d_rows) b.release();
@@ -229,7 +229,7 @@ int lsg_load_reads(lsg_ctx* c, const lsg_reads* r) {
     if (!c || !r) { set_error("lsg_load_reads: bad arguments"); return -2; }
     if (c->n_contigs <= 0) { set_error("lsg_load_reads: set the contigs first (the store is laid out over their tiles)"); return -2; }
     if (r->n_reads < 0 || r->n_segs < 0 || r->n_events < 0) { set_error("lsg_load_reads: negative sizes"); return -2; }
-    if (r->n_segs >= 0xFFFFFFF0ll || r->n_reads >= 0xFFFFFFF0ll) { set_error("lsg_load_reads: more than 2^32 reads/segments; load in windows"); return -2; }
+    if (r->n_segs >= 0xFFFFFFF0ll || r->n_reads >= (1ll << 30)) { set_error("lsg_load_reads: more than 2^32 segments or 2^30 reads; load in windows"); return -2; }
     if (r->n_events >= (1ll << 40)) { set_error("lsg_load_reads: more than 2^40 events"); return -2; }
     LSG_HIP(hipSetDevice(c->device));
     lsg::drop_store(c);

@@ -66,13 +66,13 @@ enum { WS_NE_NSLOT = 0, WS_NE_ACC, WS_NE_GEOM, WS_MULTI_LIST, WS_MACC, WS_EXPORT
 // position), every tile padded to whole blocks.  Independent of count parameters and of the barcode -> cell-type table.
 //   s0[p]  cb [0..23] | forward << 30 | first entry of its barcode's run in the tile << 31          (pad entries: cb = CB_MASK, run start)
 //   b[p]   events - 1 [0..5] | first entry of its segment << 6 | run of exactly one entry << 7
-//   fm[p]  SAM flag (16 bits, LSG_FLAG_CB_SUFFIX included) | MAPQ << 16                              (pad entries: 0xffff)
-//   rd[p]  owning read (what the pileup's max_depth rule drops is decided per read)
+//   rd[p]  owning read: admission under a count's read filters (SAM flag, MAPQ) and the pileup's max_depth rule are decided per READ
+//          (a bit per read, made per count: pileup.hip k_read_admit) and looked up through it
 constexpr uint32_t CB_MASK = 0x00FFFFFFu;
 constexpr uint32_t TM_RUNSTART = 1u << 31, TM_FWD = 1u << 30;
 constexpr uint32_t TM_PAD_S0 = CB_MASK | TM_RUNSTART;
 constexpr int TM_GROUP = 4;                 // blocks a wave of the walk loads per group: the arrays are padded by one group
-enum { TM_STORE = 0, TM_S0, TM_B, TM_FM, TM_RD, TM_META, TM_BLK_TILE, TM_BLK_OFF, TM_EXT,                                // per load
+enum { TM_STORE = 0, TM_S0, TM_B, TM_RD, TM_META, TM_BLK_TILE, TM_BLK_OFF, TM_EXT,                                // per load
        TM_JOBS, TM_NE_UNITS, TM_NE_GEOM, TM_NE_NSLOT, TM_NE_ACC, TM_MULTI, TM_CHUNKS, TM_NBUF };                          // the plan: per load and number of cell types
 // one job of the walk: a tile, or a run-aligned piece of a deep one.  e0, e1: padded-entry range; w0: unit of (tile, cell type 0);
 // slab: of (job, cell type 0) or ~0; nj: jobs of the tile, bit 31 = the job is longer than the packed planes' fields hold (k_tm_walk_wide
@@ -129,7 +129,7 @@ struct lsg_ctx {
     // tile store (see above) and the plan of a count over it
     lsg::DevBuf d_tile_cap, d_tile_off;   // entries per tile and their exclusive prefix
     lsg::DevBuf tm[lsg::TM_NBUF];
-    lsg::DevBuf bt[14];                   // temporaries of the build (kept while they are small against the device: allocation is what a rebuild would wait for)
+    lsg::DevBuf bt[15];                   // temporaries of the build (kept while they are small against the device: allocation is what a rebuild would wait for)
     uint64_t tm_n = 0;                    // entries
     int64_t tm_events = 0;                // events they hold
     uint64_t tm_np = 0;                   // padded entries = 8 x blocks
@@ -144,6 +144,7 @@ struct lsg_ctx {
     int64_t max_live_reads = -1;          // layout.hip: bound on the reads live at once in the reference's pileup buffer (-1 = stale)
     int64_t max_live_all = -1;            // the same over all reads with a barcode: table-independent, cached per load
     lsg::DevBuf d_read_drop;              // layout.hip: per read, 1 = dropped by the pileup's max_depth rule under the last count's parameters
+    lsg::DevBuf d_read_adm;               // pileup.hip: a bit per read, admitted under the current count's read filters (made only when some stored read can fail them)
     bool has_drops = false;
     int64_t n_depth_dropped = 0;
 

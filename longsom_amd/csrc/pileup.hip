@@ -49,6 +49,8 @@ struct CountArgs {
     int32_t min_bq, min_mq, min_dp, min_cc, ignore_orphans;
     uint32_t flag_exclude;
     const uint8_t* read_drop;             // reads the pileup's max_depth rule drops (layout.hip depth_cap_drops), or null
+    unsigned long long* adm;              // a bit per read: admitted under THIS count's read filters and not dropped (k_read_stats writes it, k_tm_resolve looks the
+                                          // entries' reads up in it), or null when every stored read is admitted: the load filter already was this count's filter and nothing is dropped
     // units of the plan (copies the call stage and the exports read), rows
     uint32_t* ne_units; uint32_t* ne_nslot; uint32_t* ne_acc; int2* ne_geom;
     uint64_t* ne_mask; uint32_t* ne_rowbase;
@@ -65,16 +67,23 @@ struct CountArgs {
 //   pysam pileup flag_filter (UNMAP|SECONDARY|QCFAIL|DUP) and min_mapping_quality, ignore_orphans
 //   (BaseCellCounter.py:191), is_supplementary (:249), CB tag present (:240-243), CB in barcodes.tsv
 //   with a cell type (SplitBamCellTypes.py:83-90), MAPQ >= min_MQ (:110-113).
-// The entries carry their read's flag and MAPQ (k_tm_resolve applies the same tests per entry); this pass only counts the admitted
-// READS (a statistic: lsg_count_stats.n_reads_admitted, the 24 B/read term of the algorithmic bytes).
-__global__ void k_read_stats(CountArgs a) {
+// The read-level half (SAM flag, MAPQ, orphans, the depth cap's drops) is decided HERE, once per read and count, and left as a bit per
+// read; the entries of the store carry their read's index and k_tm_resolve looks the bit up (the barcode's cell type is the entry's own
+// business).  The pass also counts the admitted READS (a statistic: lsg_count_stats.n_reads_admitted, the 24 B/read term of the
+// algorithmic bytes).  Lanes of a wave take consecutive reads, the wave's first one a multiple of 64: one ballot = one word of the bitmap.
+__global__ __launch_bounds__(256) void k_read_stats(CountArgs a) {
     unsigned long long n_ok = 0;
     for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < a.n_reads; r += (int64_t)gridDim.x * blockDim.x) {
         const uint32_t flag = a.read_flag[r];
         const int32_t cb = a.read_cb[r], tid = a.read_tid[r];
-        bool ok = (flag & a.flag_exclude) == 0 && (int)a.read_mapq[r] >= a.min_mq && cb >= 0 && cb < a.n_cb && tid >= 0 && tid < a.n_contigs;
-        if (ok && a.ignore_orphans && (flag & 0x1) && !(flag & 0x2)) ok = false;
-        if (ok && a.read_drop && a.read_drop[r]) ok = false;          // bam.pileup(..., max_depth): never entered the pileup buffer
+        bool pass = (flag & a.flag_exclude) == 0 && (int)a.read_mapq[r] >= a.min_mq;
+        if (pass && a.ignore_orphans && (flag & 0x1) && !(flag & 0x2)) pass = false;
+        if (pass && a.read_drop && a.read_drop[r]) pass = false;          // bam.pileup(..., max_depth): never entered the pileup buffer
+        if (a.adm) {
+            const unsigned long long m = __ballot(pass);
+            if ((threadIdx.x & 63) == 0) a.adm[r >> 6] = m;
+        }
+        bool ok = pass && cb >= 0 && cb < a.n_cb && tid >= 0 && tid < a.n_contigs;
         if (ok && a.celltype_of[cb] >= (uint32_t)a.n_ct) ok = false;
         n_ok += ok;
     }
@@ -296,6 +305,9 @@ static void fill_args(lsg_ctx* c, const lsg_count_params* p, CountArgs& a) {
     a.min_bq = p->min_bq; a.min_mq = p->min_mq; a.min_dp = p->min_dp; a.min_cc = p->min_cc;
     a.ignore_orphans = p->ignore_orphans; a.flag_exclude = p->flag_exclude;
     a.read_drop = c->has_drops ? c->d_read_drop.as<uint8_t>() : nullptr;
+    // every stored read passed the load filter: a count under exactly that filter, with nothing dropped, admits them all
+    const bool all_in = !c->has_drops && p->min_mq <= c->st_min_mq && (p->flag_exclude & ~c->st_flag_exclude) == 0 && (!p->ignore_orphans || c->st_ignore_orphans);
+    a.adm = all_in ? nullptr : c->d_read_adm.as<unsigned long long>();
     a.ne_units = c->d_ne_units.as<uint32_t>(); a.ne_nslot = c->ws[WS_NE_NSLOT].as<uint32_t>();
     a.ne_acc = c->ws[WS_NE_ACC].as<uint32_t>(); a.ne_geom = c->ws[WS_NE_GEOM].as<int2>();
     a.ne_mask = c->d_ne_mask.as<uint64_t>(); a.ne_rowbase = c->d_ne_rowbase.as<uint32_t>();
@@ -333,15 +345,15 @@ static int tune_int(const char* name, int dflt) {
 constexpr int IX_STAT_SLOTS = 256;
 constexpr uint32_t TMM_CT4 = 1u << 4, TMM_CT12 = 1u << 12, TMM_FWD = 1u << 20, TMM_SKIP = 1u << 29, TMM_SINGLE = 1u << 30, TMM_RS = 1u << 31;
 struct TmArgs {
-    const uint4* store; const uint32_t* s0; const uint8_t* b; const uint32_t* fm; const uint32_t* rd; uint32_t* meta; const uint32_t* blk_tile; const TmJob* jobs;
+    const uint4* store; const uint32_t* s0; const uint8_t* b; const uint32_t* rd; uint32_t* meta; const uint32_t* blk_tile; const TmJob* jobs;
     const uint32_t* chunk_start;          // static: first job of every chunk of about TM_CHUNK_WORK work
     const uint16_t* ext;                  // static, per block: first position any of its entries has an event at | one past the last << 8
     uint64_t np; uint32_t nblk, njobs, nchunks;
     int32_t ct_base;                      // the pass counts cell types ct_base and ct_base + 1
 };
 
-// per count and pass: the word the walk reads per entry.  Admission under THIS count's parameters (the entry's read: SAM flag, MAPQ,
-// the depth cap's drops), cell type under THIS barcode table, region.
+// per count and pass: the word the walk reads per entry.  Admission under THIS count's parameters (the entry's read: its bit of
+// k_read_stats' bitmap - SAM flag, MAPQ, the depth cap's drops), cell type under THIS barcode table, region.
 __global__ __launch_bounds__(256) void k_tm_resolve(CountArgs a, TmArgs tm, unsigned long long* stat_slots) {
     __shared__ unsigned long long s_stat[3];
     if (threadIdx.x == 0) { s_stat[0] = 0; s_stat[1] = 0; s_stat[2] = 0; }
@@ -355,11 +367,11 @@ __global__ __launch_bounds__(256) void k_tm_resolve(CountArgs a, TmArgs tm, unsi
         const uint4 s_lo = sp[0], s_hi = sp[1];
         const uint2 bb = *reinterpret_cast<const uint2*>(tm.b + (uint64_t)blk * 8);
         const uint32_t sv[8] = {s_lo.x, s_lo.y, s_lo.z, s_lo.w, s_hi.x, s_hi.y, s_hi.z, s_hi.w};
-        uint32_t fv[8] = {0xffffu, 0xffffu, 0xffffu, 0xffffu, 0xffffu, 0xffffu, 0xffffu, 0xffffu};
-        if (in_region) {
-            const uint4* fp = reinterpret_cast<const uint4*>(tm.fm + (uint64_t)blk * 8);
-            const uint4 f_lo = fp[0], f_hi = fp[1];
-            fv[0] = f_lo.x; fv[1] = f_lo.y; fv[2] = f_lo.z; fv[3] = f_lo.w; fv[4] = f_hi.x; fv[5] = f_hi.y; fv[6] = f_hi.z; fv[7] = f_hi.w;
+        uint32_t rv[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+        if (in_region && a.adm) {
+            const uint4* rp = reinterpret_cast<const uint4*>(tm.rd + (uint64_t)blk * 8);
+            const uint4 r_lo = rp[0], r_hi = rp[1];
+            rv[0] = r_lo.x; rv[1] = r_lo.y; rv[2] = r_lo.z; rv[3] = r_lo.w; rv[4] = r_hi.x; rv[5] = r_hi.y; rv[6] = r_hi.z; rv[7] = r_hi.w;
         }
         uint32_t mv[8];
 #pragma unroll
@@ -368,10 +380,8 @@ __global__ __launch_bounds__(256) void k_tm_resolve(CountArgs a, TmArgs tm, unsi
             uint32_t cls = 3;
             if (in_region) {
                 cls = 2;
-                const uint32_t flag = fv[u] & 0xffffu;
-                bool ok = cb < (uint32_t)a.n_cb && (flag & a.flag_exclude) == 0 && (int)(fv[u] >> 16) >= a.min_mq;
-                if (ok && a.ignore_orphans && (flag & 1u) && !(flag & 2u)) ok = false;
-                if (ok && a.read_drop && a.read_drop[tm.rd[(uint64_t)blk * 8 + u]]) ok = false;
+                bool ok = cb < (uint32_t)a.n_cb;             // (pad entries carry CB_MASK)
+                if (ok && a.adm) ok = (reinterpret_cast<const uint32_t*>(a.adm)[rv[u] >> 5] >> (rv[u] & 31u)) & 1u;
                 if (ok) { const uint32_t ct = a.celltype_of[cb]; if (ct < (uint32_t)a.n_ct && (ct >> 1) == (uint32_t)(tm.ct_base >> 1)) cls = ct & 1u; }
             }
             if (cls < 2) { ev += (b8 & 63u) + 1u; sg += (b8 >> 6) & 1u; ++ne; }
@@ -748,7 +758,8 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
     if (c->d_scalars.reserve(SC_COUNT * 8) || c->d_ne_units.reserve(((size_t)n_ne + 2) * 4) ||
         c->d_ne_mask.reserve(((size_t)n_ne + 2) * 8) || c->d_ne_rowbase.reserve(((size_t)n_ne + 2) * 4) || c->ws[WS_NE_NSLOT].reserve(((size_t)n_ne + 2) * 4) ||
         c->ws[WS_NE_ACC].reserve(((size_t)n_ne + 2) * 4) || c->ws[WS_NE_GEOM].reserve(((size_t)n_ne + 2) * 8) || c->ws[WS_MULTI_LIST].reserve(((size_t)c->tm_n_multi + 2) * 4) ||
-        c->ws[WS_MACC].reserve(((size_t)c->tm_n_slabs + 1) * NCTR * 64 * 4) || c->d_ix_stat.reserve(IX_STAT_SLOTS * 64))
+        c->ws[WS_MACC].reserve(((size_t)c->tm_n_slabs + 1) * NCTR * 64 * 4) || c->d_ix_stat.reserve(IX_STAT_SLOTS * 64) ||
+        c->d_read_adm.reserve(((size_t)c->rd.n_reads / 64 + 2) * 8))
         return -1;
     // 16 workgroups = 32 waves per CU = the 8 waves per SIMD the hardware holds (8 KB of LDS each): the walk waits on its own dependency
     // chains (a scalar decision per entry), so every resident wave counts — 14 per CU: 5.7 ms, 16: 5.4 (round 3)
@@ -775,7 +786,7 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
     CountArgs a{};
     fill_args(c, p, a);
     TmArgs tm{};
-    tm.store = c->tm[TM_STORE].as<uint4>(); tm.s0 = c->tm[TM_S0].as<uint32_t>(); tm.b = c->tm[TM_B].as<uint8_t>(); tm.fm = c->tm[TM_FM].as<uint32_t>(); tm.rd = c->tm[TM_RD].as<uint32_t>();
+    tm.store = c->tm[TM_STORE].as<uint4>(); tm.s0 = c->tm[TM_S0].as<uint32_t>(); tm.b = c->tm[TM_B].as<uint8_t>(); tm.rd = c->tm[TM_RD].as<uint32_t>();
     tm.meta = c->tm[TM_META].as<uint32_t>(); tm.blk_tile = c->tm[TM_BLK_TILE].as<uint32_t>(); tm.jobs = c->tm[TM_JOBS].as<TmJob>(); tm.np = c->tm_np; tm.nblk = c->tm_nblk;
     tm.njobs = c->tm_njobs; tm.nchunks = c->tm_nchunks; tm.chunk_start = c->tm[TM_CHUNKS].as<uint32_t>(); tm.ext = c->tm[TM_EXT].as<uint16_t>();
     LSG_HIP(hipEventRecord(c->ev[0], st));

@@ -28,6 +28,14 @@ namespace lsg {
 
 constexpr uint32_t KEY_INVALID = 0xFFFFFFFFu;
 
+// An entry on its way through the sort.  Key (64 bits): barcode [0 .. cb_bits) | first position in the tile, 6 bits | events - 1, 6 bits |
+// offset of its first event in the caller's array, the remaining 52 - cb_bits bits (build_store checks that the events fit).  Only the
+// barcode bits are sorted on.  Value (32 bits): owning read [0 .. 30) | first entry of its segment << 30 | forward strand << 31.
+constexpr uint32_t RV_SEGFIRST = 1u << 30, RV_FWD = 1u << 31, RV_READ = RV_SEGFIRST - 1u;
+__host__ __device__ __forceinline__ uint64_t sort_key(uint32_t cb, uint32_t first, uint32_t nev1, uint64_t src, int cb_bits) {
+    return (uint64_t)cb | ((uint64_t)(first | (nev1 << 6) ) << cb_bits) | (src << (cb_bits + 12));
+}
+
 struct BuildArgs {
     int64_t n_reads, n_segs, n_events;
     const int32_t* read_tid; const uint16_t* read_flag; const uint8_t* read_mapq; const int32_t* read_cb;
@@ -37,7 +45,8 @@ struct BuildArgs {
     uint2* seg_info;                      // per segment {barcode | reverse << 24, or KEY_INVALID; first tile of its contig}
     uint32_t* tile_cap;                   // entries per tile
     uint32_t* cursor;                     // next free place of every tile's region
-    uint4* rec; uint32_t* key;
+    uint64_t* key; uint32_t* rdv;         // per entry: the packed sort key (barcode in its low cb_bits bits, below) and the owning read | flags
+    int32_t cb_bits;                      // bits of the largest barcode id
     unsigned long long* qhead;            // work queue head of the binning pass
     int32_t lf_min_mq, lf_ignore_orphans; uint32_t lf_flag_exclude;      // the load filter (lsg_set_load_filter)
     uint32_t* bad;                        // bit 0: a segment's event range lies outside the events; bit 1: a segment's read index outside the reads
@@ -162,17 +171,16 @@ constexpr int BIN_SUPER = 16;          // batches per dequeue
 constexpr int BIN_MAXI = 32;           // items per chunk
 constexpr uint32_t BIN_FILL = BIN_H * 5 / 8;
 
-struct BinSeg { uint32_t key, tb, t0, rd, fm; int32_t st, ln, ntile; int64_t evoff; };
+struct BinSeg { uint32_t key, tb, t0, rd; int32_t st, ln, ntile; int64_t evoff; };
 
 __device__ __forceinline__ BinSeg bin_load(const BuildArgs& a, int64_t s) {
-    BinSeg g; g.key = KEY_INVALID; g.tb = 0; g.t0 = 0; g.rd = 0; g.fm = 0; g.st = 0; g.ln = 0; g.ntile = 0; g.evoff = 0;
+    BinSeg g; g.key = KEY_INVALID; g.tb = 0; g.t0 = 0; g.rd = 0; g.st = 0; g.ln = 0; g.ntile = 0; g.evoff = 0;
     if (s < a.n_segs) {
         const uint2 info = a.seg_info[s];
         g.key = info.x; g.tb = info.y;
         if (g.key != KEY_INVALID) {
             g.st = a.seg_start[s]; g.ln = a.seg_len[s];
-            g.evoff = a.seg_ev_off[s]; g.rd = a.seg_read[s];          // (a read's segments are consecutive and the reads coordinate-sorted: these gathers run along the arrays)
-            g.fm = (uint32_t)a.read_flag[g.rd] | ((uint32_t)a.read_mapq[g.rd] << 16);
+            g.evoff = a.seg_ev_off[s]; g.rd = a.seg_read[s];
             g.t0 = g.tb + ((uint32_t)g.st >> 6);
             g.ntile = (int)(((uint32_t)(g.st + g.ln - 1) >> 6) - ((uint32_t)g.st >> 6)) + 1;
         }
@@ -267,11 +275,11 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(BuildArgs a) {
                             const int32_t lo = g.st > tstart ? g.st : tstart;
                             const int32_t hi = g.st + g.ln < tstart + TILE_W ? g.st + g.ln : tstart + TILE_W;
                             const uint64_t src = (uint64_t)(g.evoff + (lo - g.st));             // the entry's first event in the caller's array
-                            const uint32_t cbk = g.key & CB_MASK;
-                            // record: owning read | SAM flag, MAPQ | source of the events (40 bits), first position in the tile, events - 1, strand, first of its segment
-                            a.rec[pos] = make_uint4(g.rd, g.fm, (uint32_t)src,
-                                                    (uint32_t)(src >> 32) | ((uint32_t)(lo - tstart) << 8) | ((uint32_t)(hi - lo - 1) << 16) | (((g.key >> 24) & 1u) ? 0u : TM_FWD) | (lo == g.st ? TM_RUNSTART : 0u));
-                            a.key[pos] = cbk;
+                            // everything the gather needs of an entry travels THROUGH the sort (no record fetched through the sort's
+                            // permutation afterwards): key = barcode | first position in the tile | events - 1 | source of the events,
+                            // sorted on its barcode bits only; value = owning read | first of its segment | forward strand
+                            a.key[pos] = sort_key(g.key & CB_MASK, (uint32_t)(lo - tstart), (uint32_t)(hi - lo - 1), src, a.cb_bits);
+                            a.rdv[pos] = g.rd | (lo == g.st ? RV_SEGFIRST : 0u) | (((g.key >> 24) & 1u) ? 0u : RV_FWD);
                         }
                     }
                 }
@@ -305,8 +313,9 @@ __global__ void k_tm_blk_mark(const uint32_t* cap, const uint32_t* blk_off, uint
 }
 
 // One wave per TMG_BLOCKS blocks = 8 TMG_BLOCKS entries, in two steps.
-// (a) Lanes 0 .. 8 TMG_BLOCKS - 1, one entry each, in sorted order: the entry's record (gathered through the sort's permutation), its run
-//     flags (neighbouring sort keys) -> the store's per-entry words s0, b, fm, rd; where its events lie stays in the lane's registers.
+// (a) Lanes 0 .. 8 TMG_BLOCKS - 1, one entry each, in sorted order: the entry's packed key and value as the sort left them (read in
+//     place: nothing is fetched through a permutation), its run flags (neighbouring keys' barcodes) -> the store's per-entry words s0, b,
+//     rd; where its events lie stays in the lane's registers.
 // (b) Lane = (entry u of a block, 16-byte chunk c of its <= 128 bytes): ONE load instruction per block fetches all eight entries from
 //     wherever they lie in the caller's array (2-byte aligned: the hardware takes unaligned dwordx4).  The chunks cross an LDS tile
 //     [entry][64 events]; lane = position then picks, per entry, the event at (position - first position of the entry), and the rows
@@ -315,9 +324,9 @@ __global__ void k_tm_blk_mark(const uint32_t* cap, const uint32_t* blk_off, uint
 constexpr int TMG_BLOCKS = 4, TMG_WAVES = 4;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 struct __attribute__((packed, aligned(2))) U4A2 { u32x4 v; };
-__global__ __launch_bounds__(TMG_WAVES * 64) void k_tm_gather(const uint16_t* events, int64_t n_events, const uint32_t* key, const uint32_t* val, const uint4* rec,
+__global__ __launch_bounds__(TMG_WAVES * 64) void k_tm_gather(const uint16_t* events, int64_t n_events, const uint64_t* key, const uint32_t* rdv, int cb_bits,
                                                                const uint32_t* tile_off, const uint32_t* blk_off, const uint32_t* blk_tile, uint32_t nblk,
-                                                               uint32_t* s0, uint8_t* b8, uint32_t* fm, uint32_t* rd, uint4* store, uint16_t* ext) {
+                                                               uint32_t* s0, uint8_t* b8, uint32_t* rd, uint4* store, uint16_t* ext) {
     __shared__ __attribute__((aligned(16))) uint16_t lds[TMG_WAVES][TMG_BLOCKS][8][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     // Workgroups are dealt to the 8 XCDs round-robin, each with its own L2.  An entry's <= 128 source bytes sit at a 2-byte alignment,
@@ -343,18 +352,19 @@ __global__ __launch_bounds__(TMG_WAVES * 64) void k_tm_gather(const uint16_t* ev
             // (everything this kernel writes is written once and read by another kernel: non-temporal stores keep it from pushing the
             // source lines that neighbouring tiles share out of L2 — 10.4 -> 9.6 ms)
             auto put = [](auto* q, auto v) { __builtin_nontemporal_store(v, q); };
-            if (i >= n) { put(s0 + p, (uint32_t)TM_PAD_S0); put(b8 + p, (uint8_t)0); put(fm + p, 0xffffu); put(rd + p, 0u); }
+            if (i >= n) { put(s0 + p, (uint32_t)TM_PAD_S0); put(b8 + p, (uint8_t)0); put(rd + p, 0u); }
             else {
-                const uint32_t j = off + i, k = key[j];
-                const uint4 e = rec[val[j]];
-                const bool rs = i == 0 || key[j - 1] != k;
-                const bool single = rs && (i + 1 == n || key[j + 1] != k);
-                const uint32_t nev1 = (e.w >> 16) & 63u;
-                put(s0 + p, k | (e.w & TM_FWD) | (rs ? TM_RUNSTART : 0u));
-                put(b8 + p, (uint8_t)(nev1 | ((e.w >> 31) ? 64u : 0u) | (single ? 128u : 0u)));
-                put(fm + p, e.y);
-                put(rd + p, e.x);
-                e_src = e.z; e_info = (e.w & 0x3fffu) | ((nev1 + 1u) << 16);
+                const uint32_t j = off + i, cbm = (1u << cb_bits) - 1u;
+                const uint64_t k64 = key[j];
+                const uint32_t k = (uint32_t)k64 & cbm, v = rdv[j];
+                const bool rs = i == 0 || ((uint32_t)key[j - 1] & cbm) != k;
+                const bool single = rs && (i + 1 == n || ((uint32_t)key[j + 1] & cbm) != k);
+                const uint32_t geom = (uint32_t)(k64 >> cb_bits), first = geom & 63u, nev1 = (geom >> 6) & 63u;
+                const uint64_t src = k64 >> (cb_bits + 12);
+                put(s0 + p, k | ((v & RV_FWD) ? TM_FWD : 0u) | (rs ? TM_RUNSTART : 0u));
+                put(b8 + p, (uint8_t)(nev1 | ((v & RV_SEGFIRST) ? 64u : 0u) | (single ? 128u : 0u)));
+                put(rd + p, v & RV_READ);
+                e_src = (uint32_t)src; e_info = (uint32_t)(src >> 32) | (first << 8) | ((nev1 + 1u) << 16);
             }
         }
     }
@@ -414,7 +424,7 @@ __global__ __launch_bounds__(TMG_WAVES * 64) void k_tm_gather(const uint16_t* ev
         LSG_HIP(hipcub::DeviceScan::ExclusiveSum(c->d_cub_tmp.p, tb_, (in), (out), (int)(n), st));       \
     } while (0)
 
-enum { BT_REC = 0, BT_KEY_A, BT_KEY_B, BT_VAL_A, BT_VAL_B, BT_PEX, BT_NETILE, BT_SEG_BEGIN, BT_SEG_END, BT_TMP, BT_PER_TILE, BT_OFFS, BT_SPAN, BT_SPAN_RUN };
+enum { BT_KEY_A = 0, BT_KEY_B, BT_VAL_A, BT_VAL_B, BT_PEX, BT_NETILE, BT_SEG_BEGIN, BT_SEG_END, BT_TMP, BT_PER_TILE, BT_OFFS, BT_SPAN, BT_SPAN_RUN, BT_BLK, BT_N };
 
 void drop_store(lsg_ctx* c) {
     c->tm_valid = false; c->plan_n_ct = 0; c->plan1_n_ct = 0; c->tm_n = 0; c->tm_events = 0; c->tm_np = 0; c->tm_nblk = 0; c->tm_njobs = 0; c->tm_nchunks = 0;
@@ -441,10 +451,10 @@ static void plan_finish(lsg_ctx* c);
 // 5 * 10^5 segments); measured on the MI355X over radix bits 6-8, blocks of 256 / 512 threads with 4-24 items per thread and four
 // warp-sort shapes: 7 bits per pass (13-bit barcodes: 7 + 6), 256 x 8 items in the block sort, segments of up to 64 / 256 pairs to the
 // small / medium warp sorts: 2.3 ms.  Where 8 bits per pass save a pass (C4's 20 000 barcodes: 15 key bits in two passes) they are taken.
-template <unsigned RB>
-using LsgSortConfig = rocprim::segmented_radix_sort_config<RB, rocprim::kernel_config<256, 8>, rocprim::WarpSortConfig<16, 4, 256, 64, 32, 8, 256>>;
-template <unsigned RB, class... Args>
-static hipError_t lsg_segmented_sort(Args&&... args) { return rocprim::segmented_radix_sort_pairs<LsgSortConfig<RB>>(std::forward<Args>(args)...); }
+template <unsigned RB, unsigned BS = 256, unsigned IPT = 8>
+using LsgSortConfig = rocprim::segmented_radix_sort_config<RB, rocprim::kernel_config<BS, IPT>, rocprim::WarpSortConfig<16, 4, 256, 64, 32, 8, 256>>;
+template <unsigned RB, unsigned BS, unsigned IPT, class... Args>
+static hipError_t lsg_segmented_sort(Args&&... args) { return rocprim::segmented_radix_sort_pairs<LsgSortConfig<RB, BS, IPT>>(std::forward<Args>(args)...); }
 
 int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int64_t* seg_ev_off, const lsg_reads* src) {
     drop_store(c);
@@ -514,7 +524,24 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
         tb = tmp.cap;
         if (R > 0) LSG_HIP(hipcub::DeviceReduce::Max(tmp.p, tb, in.read_cb, reinterpret_cast<int32_t*>(d_small + 2), (int)R, st));
     }
-    uint32_t total = 0, bad = 0; int32_t max_cb = 0, max_live = 0;
+    // the non-empty tiles (the sort's segments) and the blocks of every tile: all of it follows from the capacities, so the sizes below
+    // reach the host in the load's ONE early look (the scatter, the sort and the gather are then queued without waiting for one another)
+    if (c->bt[BT_NETILE].reserve(((size_t)T + 2) * 4) || c->bt[BT_BLK].reserve(((size_t)T + 2) * 4) || c->tm[TM_BLK_OFF].reserve(((size_t)T + 2) * 4)) return -1;
+    {
+        hipcub::CountingInputIterator<uint32_t> tile_it(0);
+        CapNonZero pred{c->d_tile_cap.as<uint32_t>()};
+        size_t tb = 0;
+        LSG_HIP(hipcub::DeviceSelect::If(nullptr, tb, tile_it, c->bt[BT_NETILE].as<uint32_t>(), d_small + 1, (int)T, pred, st));
+        if (tmp.reserve(tb + 256)) return -1;
+        tb = tmp.cap;
+        LSG_HIP(hipcub::DeviceSelect::If(tmp.p, tb, tile_it, c->bt[BT_NETILE].as<uint32_t>(), d_small + 1, (int)T, pred, st));
+    }
+    uint32_t* blk_off = c->tm[TM_BLK_OFF].as<uint32_t>();
+    hipLaunchKernelGGL(k_tile_blocks, dim3((T + 256) / 256), dim3(256), 0, st, c->d_tile_cap.as<uint32_t>(), T, c->bt[BT_BLK].as<uint32_t>());
+    SCAN_U32(c->bt[BT_BLK].as<uint32_t>(), blk_off, T + 1);
+    uint32_t total = 0, bad = 0, n_netile = 0, nblk = 0; int32_t max_cb = 0, max_live = 0;
+    LSG_HIP(hipMemcpyAsync(&n_netile, d_small + 1, 4, hipMemcpyDeviceToHost, st));
+    LSG_HIP(hipMemcpyAsync(&nblk, blk_off + T, 4, hipMemcpyDeviceToHost, st));
     LSG_HIP(hipMemcpyAsync(&max_live, d_small + 3, 4, hipMemcpyDeviceToHost, st));
     unsigned long long n_ev = 0, sum = 0;
     LSG_HIP(hipMemcpyAsync(&n_ev, a.n_ev, 8, hipMemcpyDeviceToHost, st));
@@ -541,40 +568,42 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
     c->max_live_all = max_live > 0 ? max_live : 0;
     if (N == 0) return finish();
     // ---- 2. scatter
-    DevBuf &rec = c->bt[BT_REC], &key_a = c->bt[BT_KEY_A], &key_b = c->bt[BT_KEY_B], &val_b = c->bt[BT_VAL_B];
-    if (rec.reserve(N * 16) || key_a.reserve(N * 4 + 16) || key_b.reserve(N * 4 + 16) || val_b.reserve(N * 4) ||
-        c->bt[BT_PER_TILE].reserve(((size_t)T + 2) * 4) || c->bt[BT_NETILE].reserve(((size_t)T + 2) * 4)) return -1;
-    a.cursor = c->bt[BT_PER_TILE].as<uint32_t>(); a.rec = rec.as<uint4>(); a.key = key_a.as<uint32_t>();
+    DevBuf &key_a = c->bt[BT_KEY_A], &key_b = c->bt[BT_KEY_B], &val_a = c->bt[BT_VAL_A], &val_b = c->bt[BT_VAL_B];
+    int bits = 1; while (bits < 24 && (1ll << bits) <= (long long)max_cb) ++bits;
+    if (n_events >= (1ll << (52 - bits))) {
+        set_error("lsg_load_reads: %lld events with %d-bit barcode ids do not fit the packed sort key (events < 2^%d): load the reads in windows", (long long)n_events, bits, 52 - bits);
+        return -2;
+    }
+    if (key_a.reserve(N * 8 + 16) || key_b.reserve(N * 8 + 16) || val_a.reserve(N * 4 + 16) || val_b.reserve(N * 4 + 16) ||
+        c->bt[BT_PER_TILE].reserve(((size_t)T + 2) * 4)) return -1;
+    a.cursor = c->bt[BT_PER_TILE].as<uint32_t>(); a.key = key_a.as<uint64_t>(); a.rdv = val_a.as<uint32_t>(); a.cb_bits = bits;
     LSG_HIP(hipMemcpyAsync(a.cursor, c->d_tile_off.p, ((size_t)T + 1) * 4, hipMemcpyDeviceToDevice, st));
     LSG_HIP(hipMemsetAsync(c->d_scalars.p, 0, 8, st));
     hipLaunchKernelGGL(k_bin, dim3(g_bin), dim3(BIN_THREADS), 0, st, a);
     LSG_HIP(hipEventRecord(c->evb[1], st));
     // ---- 3. every tile's entries by barcode
-    uint32_t n_netile = 0;
-    {
-        hipcub::CountingInputIterator<uint32_t> tile_it(0);
-        CapNonZero pred{c->d_tile_cap.as<uint32_t>()};
+    if (n_netile) {
+        if (c->bt[BT_SEG_BEGIN].reserve(((size_t)n_netile + 1) * 4) || c->bt[BT_SEG_END].reserve(((size_t)n_netile + 1) * 4)) return -1;
+        hipLaunchKernelGGL(k_seg_bounds, dim3((n_netile + 255) / 256), dim3(256), 0, st, c->bt[BT_NETILE].as<uint32_t>(), n_netile, c->d_tile_off.as<uint32_t>(),
+                           c->bt[BT_SEG_BEGIN].as<uint32_t>(), c->bt[BT_SEG_END].as<uint32_t>());
         size_t tb = 0;
-        LSG_HIP(hipcub::DeviceSelect::If(nullptr, tb, tile_it, c->bt[BT_NETILE].as<uint32_t>(), d_small + 1, (int)T, pred, st));
-        if (tmp.reserve(tb + 256)) return -1;
-        tb = tmp.cap;
-        LSG_HIP(hipcub::DeviceSelect::If(tmp.p, tb, tile_it, c->bt[BT_NETILE].as<uint32_t>(), d_small + 1, (int)T, pred, st));
-        LSG_HIP(hipMemcpyAsync(&n_netile, d_small + 1, 4, hipMemcpyDeviceToHost, st));
-        LSG_HIP(hipStreamSynchronize(st));
-    }
-    if (c->bt[BT_SEG_BEGIN].reserve(((size_t)n_netile + 1) * 4) || c->bt[BT_SEG_END].reserve(((size_t)n_netile + 1) * 4)) return -1;
-    hipLaunchKernelGGL(k_seg_bounds, dim3((n_netile + 255) / 256), dim3(256), 0, st, c->bt[BT_NETILE].as<uint32_t>(), n_netile, c->d_tile_off.as<uint32_t>(),
-                       c->bt[BT_SEG_BEGIN].as<uint32_t>(), c->bt[BT_SEG_END].as<uint32_t>());
-    {
-        int bits = 1; while (bits < 24 && (1ll << bits) <= (long long)max_cb) ++bits;
-        size_t tb = 0;
-        // (values in = the entries' arrival places, an iterator: rocprim's own entry point takes one where hipcub wants an array)
-        rocprim::counting_iterator<uint32_t> place(0u);
+        // (64-bit keys sorted on their barcode bits only, begin_bit 0 .. end_bit `bits`: the rest of the key is payload)
+        static const int cfg = getenv("LSG_SORT_CFG") ? atoi(getenv("LSG_SORT_CFG")) : 0;
         auto sort = [&](void* tmp_p, size_t& tmp_n) {
-            return (bits + 6) / 7 <= (bits + 7) / 8 ? lsg_segmented_sort<7>(tmp_p, tmp_n, key_a.as<uint32_t>(), key_b.as<uint32_t>(), place, val_b.as<uint32_t>(), (unsigned)N, (unsigned)n_netile,
+#define LSG_SORT_CALL(RB, BS, IPT) lsg_segmented_sort<RB, BS, IPT>(tmp_p, tmp_n, key_a.as<uint64_t>(), key_b.as<uint64_t>(), val_a.as<uint32_t>(), val_b.as<uint32_t>(), (unsigned)N, (unsigned)n_netile, \
                                                       c->bt[BT_SEG_BEGIN].as<uint32_t>(), c->bt[BT_SEG_END].as<uint32_t>(), 0u, (unsigned)bits, st, false)
-                              : lsg_segmented_sort<8>(tmp_p, tmp_n, key_a.as<uint32_t>(), key_b.as<uint32_t>(), place, val_b.as<uint32_t>(), (unsigned)N, (unsigned)n_netile,
-                                                      c->bt[BT_SEG_BEGIN].as<uint32_t>(), c->bt[BT_SEG_END].as<uint32_t>(), 0u, (unsigned)bits, st, false);
+            switch (cfg) {
+                case 1: return LSG_SORT_CALL(7, 256, 16);
+                case 2: return LSG_SORT_CALL(7, 512, 8);
+                case 3: return LSG_SORT_CALL(7, 512, 16);
+                case 4: return LSG_SORT_CALL(7, 1024, 8);
+                case 5: return LSG_SORT_CALL(8, 256, 16);
+                case 6: return LSG_SORT_CALL(8, 512, 8);
+                case 7: return LSG_SORT_CALL(7, 1024, 4);
+                case 8: return LSG_SORT_CALL(8, 256, 8);
+                default: return LSG_SORT_CALL(7, 256, 8);
+            }
+#undef LSG_SORT_CALL
         };
         LSG_HIP(sort(nullptr, tb));
         if (tmp.reserve(tb + 256)) return -1;
@@ -582,19 +611,11 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
         LSG_HIP(sort(tmp.p, tb));
     }
     LSG_HIP(hipEventRecord(c->evb[2], st));
-    // ---- 4. blocks and the per-entry words
-    if (c->tm[TM_BLK_OFF].reserve(((size_t)T + 2) * 4)) return -1;
-    uint32_t* blk = c->bt[BT_PER_TILE].as<uint32_t>();                    // (the cursors are done with)
-    uint32_t* blk_off = c->tm[TM_BLK_OFF].as<uint32_t>();
-    hipLaunchKernelGGL(k_tile_blocks, dim3((T + 256) / 256), dim3(256), 0, st, c->d_tile_cap.as<uint32_t>(), T, blk);
-    SCAN_U32(blk, blk_off, T + 1);
-    uint32_t nblk = 0;
-    LSG_HIP(hipMemcpyAsync(&nblk, blk_off + T, 4, hipMemcpyDeviceToHost, st));
-    LSG_HIP(hipStreamSynchronize(st));
+    // ---- 4. blocks and the per-entry words (the blocks' offsets and their number came with the load's early look)
     const uint64_t np = (uint64_t)nblk * 8;
     c->tm_np = np; c->tm_nblk = nblk;
     if (c->tm[TM_S0].reserve((np + 16) * 4) || c->tm[TM_B].reserve(np + 16) ||
-        c->tm[TM_FM].reserve((np + 16) * 4) || c->tm[TM_RD].reserve((np + 16) * 4) || c->tm[TM_META].reserve((np + 8 * (TM_GROUP + 1)) * 4) ||
+        c->tm[TM_RD].reserve((np + 16) * 4) || c->tm[TM_META].reserve((np + 8 * (TM_GROUP + 1)) * 4) ||
         c->tm[TM_BLK_TILE].reserve(((size_t)nblk + 2) * 4) || c->tm[TM_EXT].reserve(((size_t)nblk + TM_GROUP + 2) * 2)) return -1;
     {
         uint32_t* bt_ = c->tm[TM_BLK_TILE].as<uint32_t>();
@@ -614,7 +635,7 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
         size_t mem_free = 0, mem_total = 0;
         if (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess && ((size_t)nblk + TM_GROUP) * 1088 + (mem_total >> 5) > mem_free) {
             LSG_HIP(hipStreamSynchronize(st));
-            key_a.release(); c->ws[WS_SEG_INFO].release(); c->bt[BT_SPAN].release(); c->bt[BT_SPAN_RUN].release(); c->bt[BT_PEX].release(); c->bt[BT_OFFS].release();
+            key_a.release(); val_a.release(); c->ws[WS_SEG_INFO].release(); c->bt[BT_SPAN].release(); c->bt[BT_SPAN_RUN].release(); c->bt[BT_PEX].release(); c->bt[BT_OFFS].release();
         }
         if (c->tm[TM_STORE].reserve(((size_t)nblk + TM_GROUP) * 1024)) return -1;
     }
@@ -624,8 +645,8 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
     {
         const dim3 grid((unsigned)(((((uint64_t)nblk + TMG_BLOCKS - 1) / TMG_BLOCKS + TMG_WAVES - 1) / TMG_WAVES + 7) / 8 * 8));
         hipLaunchKernelGGL(k_tm_gather, grid, dim3(TMG_WAVES * 64), 0, st,
-                           events, n_events, key_b.as<uint32_t>(), val_b.as<uint32_t>(), rec.as<uint4>(), c->d_tile_off.as<uint32_t>(), blk_off, c->tm[TM_BLK_TILE].as<uint32_t>(), nblk,
-                           c->tm[TM_S0].as<uint32_t>(), c->tm[TM_B].as<uint8_t>(), c->tm[TM_FM].as<uint32_t>(), c->tm[TM_RD].as<uint32_t>(),
+                           events, n_events, key_b.as<uint64_t>(), val_b.as<uint32_t>(), bits, c->d_tile_off.as<uint32_t>(), blk_off, c->tm[TM_BLK_TILE].as<uint32_t>(), nblk,
+                           c->tm[TM_S0].as<uint32_t>(), c->tm[TM_B].as<uint8_t>(), c->tm[TM_RD].as<uint32_t>(),
                            c->tm[TM_STORE].as<uint4>(), c->tm[TM_EXT].as<uint16_t>());
     }
     LSG_HIP(hipEventRecord(c->evb[4], st));
