@@ -34,12 +34,14 @@ def oracle_calls(tag):
     return d["candidate_rows"], {c: tuple(v) for c, v in d["per_contig"].items()}
 
 
-def candidate_text_digest(eng, m):
+def candidate_text_digest(eng, m, candidates_only=False):
     """(rows, {contig: (rows, xxhash of its rows' text)}) of the step-1 text of the rows step 2 keeps, for the counts and calls resident
-    in eng.  Per contig: the writer puts the contigs in Python string order (the reference's file order), the oracle tool in header order."""
+    in eng.  Per contig: the writer puts the contigs in Python string order (the reference's file order), the oracle tool in header order.
+    candidates_only: fetch and format the candidate sites' records only (the rows step 2 keeps are among them: a row without an ALT is
+    dropped by its awk filter, step2.py:23) - what the full-size workloads can afford."""
     from longsom_amd import tsvio
     per_ct = [eng.fetch_counts(ct) for ct in range(2)]
-    calls = eng.fetch_calls()
+    calls = eng.fetch_calls(candidates_only=candidates_only)
     text = tsvio.write_step1_tsv("/dev/null", calls, per_ct, m.contig_names, ["Cancer", "Non-Cancer"], [], header=False, as_bytes=True)
     sc = tsvio.scan_rows(text, m.contig_names)
     tid = sc.key >> 32
@@ -91,7 +93,9 @@ def test_two_counts_of_the_same_reads_are_identical(engine):
     # the candidate call records of the sample: their step-1 text (the product's native writer, pinned byte for byte to the reference's
     # goldens) hashes to what the CPU oracles wrote for this sample — count_oracle.c + calling_oracle.py step 1 (scipy) in 6 processes,
     # tools/oracle_call_hash.py; nothing the GPU wrote is part of the pin
-    assert candidate_text_digest(engine, m) == oracle_calls("c4_2500000")
+    want_calls = oracle_calls("c4_2500000")
+    assert candidate_text_digest(engine, m) == want_calls
+    assert candidate_text_digest(engine, m, candidates_only=True) == want_calls          # (the form the full-size test uses)
     # (the digest of the raw call records the HIP path itself wrote in round 1: kept as a cross-build check)
     if os.environ.get("LSG_WRITE_PIN") == "1":
         json.dump({"calls": d["calls"]}, open(PIN, "w"), indent=1)

@@ -39,3 +39,13 @@ def test_full_size_rows_equal_the_cpu_oracle(engine, cfg, n_reads):
             got = [xxhash.xxh64(np.ascontiguousarray(x).tobytes()).hexdigest() for x in (k, r, c)]
             del k, r, c
             assert got == want["ct%d" % ct], "cell type %d: rows of the full %s workload differ from the CPU oracle's" % (ct, cfg)
+        calls_pin = os.path.join(G, "calls_hash_oracle_%s_%d.json" % (cfg.lower(), n_reads))
+        if os.path.exists(calls_pin):
+            # ... and merge + step 1 of the FULL workload: the step-1 text of every row step 2 keeps (7.69 M candidate rows of C2's 23.9 M merged
+            # sites) hashes, contig by contig, to what the CPU oracles wrote (count_oracle.c + calling_oracle.py step 1 with scipy's betabinom
+            # over 40 region shards: tools/oracle_call_hash.py C2 1e7 6 40, 27 min of the build container's CPU); nothing the GPU wrote is in the pin
+            from tests.test_determinism_gpu import candidate_text_digest, oracle_calls
+            n_sites, n_cand = eng.call_step1()
+            pin = json.load(open(calls_pin))
+            assert n_sites == pin["merged_sites"] and n_cand == pin["candidate_rows"]
+            assert candidate_text_digest(eng, m, candidates_only=True) == oracle_calls("%s_%d" % (cfg.lower(), n_reads))
