@@ -288,6 +288,10 @@ def main():
     # the load drops what SplitBam's MAPQ filter and the pileup's read filter drop (SplitBamCellTypes.py:110-113, BaseCellCounter.py:191,249):
     # in the product the host decode does (hostio.decode_bam(min_mapq=...)); the generated arrays hold every read of the BAM
     eng.set_load_filter(cp.min_mq, cp.flag_exclude, cp.ignore_orphans)
+    # ... and, as in every fused rule, the count's parameters are known when the reads are loaded: the load makes the BAM's one count in the
+    # pass that builds the store (lsg_set_count_at_load); LSG_BENCH_TWO_PASS=1 keeps the load and the count apart (round 3's step)
+    if os.environ.get("LSG_BENCH_TWO_PASS") != "1":
+        eng.set_count_at_load(cp)
     # N > 1: ONE all-gather per step.  Every rank sends a message of the same agreed size: a header slot holding its number of
     # PASS-candidate rows, then room for cap_rows rows (SURVEY §8e's counts-then-buffers exchange needs two collectives and a host
     # read between them on every step).  The capacity is agreed during warm-up (the headers are read there) and checked once more

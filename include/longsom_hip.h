@@ -232,6 +232,16 @@ int64_t lsg_max_live_reads_all(lsg_ctx* ctx);
  * POS >= START and POS < END test (BaseCellCounter.py:200).  tid_hi == n_contigs, pos_hi == 0
  * means "to the end".  Reset with (0,0,n_contigs,0). */
 int lsg_set_region(lsg_ctx* ctx, int32_t tid_lo, int64_t pos_lo, int32_t tid_hi, int64_t pos_hi);
+/* One pass for a BAM's load AND its first count.  A rule of the reference counts every BAM exactly once
+ * (bam.pileup over all windows, BaseCellCounter.py:182-320, after SplitBamCellTypes.py:65-124 routed the reads); when the
+ * count's parameters are known while the reads are loaded - they are in every fused rule - the loads that follow
+ * (lsg_load_reads, lsg_load_bam, lsg_load_bam_range) count in the same pass that lays the events out per column: the wave that
+ * transposes a block of the store adds its events into the per-position counters while it holds them.  Requires the barcode
+ * table (lsg_set_barcodes, at most two cell types), every reference and the region to be set before the load; a load for which
+ * the pileup's depth cap could fire (lsg_max_live_reads_all() >= max_depth) is made without the count.  The first
+ * lsg_pileup_count after the load with EQUAL parameters, the same barcode table and region returns that count's result without
+ * another pass; any other call counts over the resident store as always.  params == NULL switches it off (default). */
+int lsg_set_count_at_load(lsg_ctx* ctx, const lsg_count_params* params);
 
 /* ---- hot path -------------------------------------------------------------------------------*/
 /* Per-cell-type pileup base counting over every covered column of the loaded reads; replaces
@@ -327,7 +337,8 @@ typedef struct {
 } lsg_count_stats;
 int lsg_get_count_stats(lsg_ctx* ctx, lsg_count_stats* out);
 
-/* What the load's tile store cost.  path: always 2 (the count over the store; kept for callers that print it).  build_ms: wall time
+/* What the load's tile store cost.  path: 2 = the store was built by the load alone, 3 = in the pass that also made the first count
+ * (lsg_set_count_at_load).  build_ms: wall time
  * lsg_load_reads spent building the store (device kernels + their host synchronisations).  store_bytes: device memory the store, its
  * per-read / per-segment arrays, kept events and cached build temporaries hold.  No reference counterpart: the reference re-reads
  * the BAM per window (BaseCellCounter.py:198-225). */

@@ -93,6 +93,8 @@ int live_read_bound_all(lsg_ctx* c);
 __global__ void k_read_end(const uint32_t* seg_read, const int32_t* seg_start, const int32_t* seg_len, int64_t n_segs, int32_t* read_end);      // layout.hip
 __global__ void k_read_end_init(const int32_t* read_pos, int64_t n_reads, int32_t* read_end);
 int depth_cap_drops(lsg_ctx* c, const lsg_count_params* p);   // layout.hip: htslib's max_depth rule -> d_read_drop (or none)
+struct GatherCountSrc { const uint16_t* events; int64_t n_events; const uint64_t* key; const uint32_t* rdv; int32_t cb_bits; };
+int run_gather_count(lsg_ctx* c, const lsg_count_params* p, const GatherCountSrc& src);      // pileup.hip: the load's gather and the first count in one pass (k_tm_gather_count)
 }
 
 struct lsg_ctx {
@@ -129,7 +131,7 @@ struct lsg_ctx {
     // tile store (see above) and the plan of a count over it
     lsg::DevBuf d_tile_cap, d_tile_off;   // entries per tile and their exclusive prefix
     lsg::DevBuf tm[lsg::TM_NBUF];
-    lsg::DevBuf bt[15];                   // temporaries of the build (kept while they are small against the device: allocation is what a rebuild would wait for)
+    lsg::DevBuf bt[16];                   // temporaries of the build (kept while they are small against the device: allocation is what a rebuild would wait for)
     uint64_t tm_n = 0;                    // entries
     int64_t tm_events = 0;                // events they hold
     uint64_t tm_np = 0;                   // padded entries = 8 x blocks
@@ -138,6 +140,11 @@ struct lsg_ctx {
     int plan1_n_ct = 0;                   // ... and its tile-level half (units, jobs, slabs per tile and their totals), which the load can make beside its gather
     uint32_t plan1_tot[4] = {0, 0, 0, 0};
     uint32_t plan_misc[2] = {0, 0};       // wide jobs, chunks (read back from the job-level half)
+    uint32_t* d_plan_misc = nullptr;      // ... where they lie on the device
+    // lsg_set_count_at_load: the next load also makes the first count under these parameters, in the pass that builds the store
+    bool cal_enabled = false; lsg_count_params cal_params{};
+    bool counted_at_load = false;         // the resident count is that one and nobody has asked for it yet
+    bool load_was_fused = false;          // the last load built its store in the pass that counted (lsg_get_layout_info path 3)
     bool tm_valid = false;
     double layout_build_ms = 0;           // wall time of the last build (lsg_get_layout_info)
     float build_ms[4] = {0, 0, 0, 0};     // HIP-event times of the last build: capacities + scatter, sort, fill, gather

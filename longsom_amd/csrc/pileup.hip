@@ -395,7 +395,7 @@ __global__ __launch_bounds__(256) void k_tm_resolve(CountArgs a, TmArgs tm, unsi
     for (int o = 32; o > 0; o >>= 1) { ev += __shfl_down(ev, o); sg += __shfl_down(sg, o); ne += __shfl_down(ne, o); }
     if ((threadIdx.x & 63) == 0 && ne) { atomicAdd(&s_stat[0], ev); atomicAdd(&s_stat[1], sg); atomicAdd(&s_stat[2], ne); }
     __syncthreads();
-    if (threadIdx.x == 0 && s_stat[2]) {
+    if (threadIdx.x == 0 && s_stat[2] && stat_slots) {
         unsigned long long* slot = stat_slots + (size_t)(blockIdx.x % IX_STAT_SLOTS) * 8;      // 64 bytes apart: one word takes ~90 atomics per microsecond
         atomicAdd(&slot[0], s_stat[0]); atomicAdd(&slot[1], s_stat[1]); atomicAdd(&slot[2], s_stat[2]);
     }
@@ -676,6 +676,282 @@ __global__ __launch_bounds__(TMW_WAVES * 64) __attribute__((amdgpu_waves_per_eu(
     }
 }
 
+// ================================================================================================
+// The load's gather and the FIRST count in one pass (lsg_set_count_at_load).  A rule of the reference counts a BAM once
+// (BaseCellCounter.py:182-320); when the count's parameters and the barcode table are known while the reads are loaded, the wave that
+// transposes a block of the store (store.hip k_tm_gather: eight entries' events from the caller's compact array -> [position][entry])
+// holds exactly the registers the walk would fetch again from HBM a moment later, so it adds them into the job's planes right there:
+// no k_tm_resolve, no second pass over the 24 GB of blocks.  Same jobs, planes, run logic (tm_add), units and rows as k_tm_walk; what
+// differs is where a group's rows come from.  Per group of TM_GROUP blocks a wave
+//   K  loads the sorted (key, value) of its 32 entries in place (lanes 0..31; lanes 32 / 33: the keys on either side of the group)
+//   W  makes the store's per-entry words s0, b, rd (run flags from the neighbouring keys' barcodes) and THIS count's meta word
+//      (admission bit of the entry's read, cell type of its barcode: what k_tm_resolve would write)
+//   E  fetches the events: lane = (entry u of a block, 16-byte chunk c), the chunk ALIGNED TO THE TILE (events at positions 8c .. 8c+7,
+//      from source offset - first position + 8c), so that an entry's row of the LDS tile is indexed by position
+//   T  crosses the LDS tile: lane = position reads one event per entry, kept where the entry's position mask (an SGPR pair) says so;
+//      the rows leave as the block's kilobyte (non-temporal) AND stay in registers for the walk's consume step
+// software-pipelined: the keys of group g + 2 and the events of group g + 1 are in flight while group g is counted.
+// A block whose entries belong to two ranges (a job's cut is not a multiple of eight) is written by the range its first entry lies in;
+// the other range gathers it too, for its own entries' events only.  Jobs outside the counted region or too long for the packed planes
+// (TMJ_WIDE) are gathered without counting (the wide walk takes the latter from the store afterwards).
+struct TgArgs {
+    const uint16_t* events; int64_t n_events;
+    const uint64_t* key; const uint32_t* rdv; int32_t cb_bits;      // the sort's output (store.hip sort_key): read in place
+    const uint32_t* tile_off; const uint32_t* blk_off;
+    uint32_t* s0; uint8_t* b8; uint32_t* rd; uint4* store; uint16_t* ext;
+    const uint32_t* nchunks;                                          // the plan's number of chunks, still on the device
+    unsigned long long* stat_slots;
+};
+typedef uint32_t tg_u32x4 __attribute__((ext_vector_type(4)));
+struct __attribute__((packed, aligned(2))) TgU4A2 { tg_u32x4 v; };
+constexpr uint32_t TG_RV_SEGFIRST = 1u << 30, TG_RV_FWD = 1u << 31, TG_RV_READ = TG_RV_SEGFIRST - 1u;      // (store.hip RV_*)
+struct TgKeys { uint64_t k; uint32_t v; };
+struct TgStat { uint32_t ev, sg, ne; };
+
+__device__ __forceinline__ void tg_range(const CountArgs& a, const TmArgs& tm, const TgArgs& tg, TmState& st, TgStat& stat, uint32_t s0r, uint32_t s1r, uint32_t base, uint32_t off,
+                                         uint32_t n, bool in_region, bool counting, uint32_t thr, uint32_t pkl0, uint32_t one, int lane, uint16_t (*xt)[8][64]) {
+    const uint32_t b0 = s0r >> 3, nblk = ((s1r + 7) >> 3) - b0;
+    const int ng = (int)((nblk + TM_GROUP - 1) / TM_GROUP);
+    const bool tail = s1r == base + n;                                    // the range that ends its tile also writes the tile's pad entries
+    const uint32_t cbm = (1u << tg.cb_bits) - 1u;
+    const int eu = lane >> 3, ec = lane & 7;
+    auto nt_put = [](auto* q, auto v) { __builtin_nontemporal_store(v, q); };
+    // ---- K
+    auto load_keys = [&](int g) -> TgKeys {
+        TgKeys r; r.k = 0ull; r.v = 0u;
+        const int64_t i = (int64_t)(b0 + (uint32_t)g * TM_GROUP) * 8 - (int64_t)base + (lane < 32 ? lane : (lane == 32 ? -1 : 32));
+        if (lane < 34 && i >= 0 && i < (int64_t)n) {
+            r.k = __builtin_nontemporal_load(tg.key + off + i);
+            if (lane < 32) r.v = __builtin_nontemporal_load(tg.rdv + off + i);
+        }
+        return r;
+    };
+    // ---- W + E: the entries' words, meta, position masks; the event loads
+    auto words_events = [&](int g, const TgKeys& K, tg_u32x4 (&chunk)[TM_GROUP], uint32_t& M, uint32_t& mlo, uint32_t& mhi) {
+        const uint32_t p = (b0 + (uint32_t)g * TM_GROUP) * 8 + (uint32_t)lane, i = p - base;
+        const bool valid = lane < 32 && i < n;
+        const uint32_t cb = (uint32_t)K.k & cbm;
+        const uint32_t cb_prev = (uint32_t)__shfl((int)cb, lane == 0 ? 32 : lane - 1), cb_next = (uint32_t)__shfl((int)cb, lane == 31 ? 33 : lane + 1);
+        const uint32_t geom = (uint32_t)(K.k >> tg.cb_bits), first = geom & 63u, nev1 = (geom >> 6) & 63u;
+        const uint64_t src = K.k >> (tg.cb_bits + 12);
+        const bool rs = i == 0 || cb_prev != cb;
+        const bool single = rs && (i + 1 == n || cb_next != cb);
+        const bool own = valid && p >= s0r && p < s1r;
+        if (own) {
+            nt_put(tg.s0 + p, cb | ((K.v & TG_RV_FWD) ? TM_FWD : 0u) | (rs ? TM_RUNSTART : 0u));
+            nt_put(tg.b8 + p, (uint8_t)(nev1 | ((K.v & TG_RV_SEGFIRST) ? 64u : 0u) | (single ? 128u : 0u)));
+            nt_put(tg.rd + p, K.v & TG_RV_READ);
+        } else if (lane < 32 && !valid && tail && p < (b0 + nblk) * 8) {
+            nt_put(tg.s0 + p, (uint32_t)TM_PAD_S0); nt_put(tg.b8 + p, (uint8_t)0); nt_put(tg.rd + p, 0u);
+        }
+        // what k_tm_resolve writes for the entry under this count (an entry of another range is not there)
+        M = TMM_SKIP;
+        if (own && in_region) {
+            uint32_t cls = 2;
+            bool ok = cb < (uint32_t)a.n_cb;
+            if (ok && a.adm) { const uint32_t r = K.v & TG_RV_READ; ok = (reinterpret_cast<const uint32_t*>(a.adm)[r >> 5] >> (r & 31u)) & 1u; }
+            if (ok) { const uint32_t ct = a.celltype_of[cb]; if (ct < (uint32_t)a.n_ct && (ct >> 1) == (uint32_t)(tm.ct_base >> 1)) cls = ct & 1u; }
+            if (cls < 2) { stat.ev += nev1 + 1u; stat.sg += (K.v & TG_RV_SEGFIRST) ? 1u : 0u; ++stat.ne; }
+            M = cls < 2 ? (cls ? (TMM_CT4 | TMM_CT12) : 0u) | ((K.v & TG_RV_FWD) ? TMM_FWD : 0u) | (single ? TMM_SINGLE : 0u) : TMM_SKIP;
+            if (rs) M |= TMM_RS;
+        }
+        if (!counting) M = TMM_SKIP;
+        // positions [first, first + events) of the tile
+        const uint64_t pm = valid ? ((nev1 == 63u ? ~0ull : ((1ull << (nev1 + 1u)) - 1ull)) << first) : 0ull;
+        mlo = (uint32_t)pm; mhi = (uint32_t)(pm >> 32);
+        const uint32_t e_src = (uint32_t)src, e_info = valid ? ((uint32_t)(src >> 32) | (first << 8) | ((nev1 + 1u) << 16)) : 0u;
+#pragma unroll
+        for (int q = 0; q < TM_GROUP; ++q) {
+            chunk[q] = tg_u32x4{0u, 0u, 0u, 0u};
+            const uint32_t lo32 = (uint32_t)__shfl((int)e_src, q * 8 + eu), inf = (uint32_t)__shfl((int)e_info, q * 8 + eu);
+            const uint32_t fp = (inf >> 8) & 63u, nev = inf >> 16, c8 = (uint32_t)ec * 8u;
+            if (c8 < fp + nev && c8 + 8u > fp) {                          // the tile-aligned chunk holds events of the entry
+                const int64_t A = (int64_t)(((uint64_t)(inf & 0xffu) << 32) | lo32) - (int64_t)fp + (int64_t)c8;
+                if (A >= 0 && A + 8 <= tg.n_events) chunk[q] = reinterpret_cast<const TgU4A2*>(tg.events + A)->v;
+                else {                                                    // the first / last events of the array: never read outside it
+                    uint32_t w[4] = {0u, 0u, 0u, 0u};
+                    for (int k = 0; k < 8; ++k) if (A + k >= 0 && A + k < tg.n_events) w[k >> 1] |= (uint32_t)tg.events[A + k] << (16 * (k & 1));
+                    chunk[q] = tg_u32x4{w[0], w[1], w[2], w[3]};
+                }
+            }
+        }
+    };
+    // ---- T: through the LDS tile; the rows to the store and into E
+    auto transpose = [&](int g, const tg_u32x4 (&chunk)[TM_GROUP], uint32_t mlo, uint32_t mhi, tg_u32x4 (&E)[TM_GROUP]) {
+#pragma unroll
+        for (int q = 0; q < TM_GROUP; ++q) *reinterpret_cast<tg_u32x4*>(&xt[q][eu][ec * 8]) = chunk[q];
+        lds_fence();
+#pragma unroll
+        for (int q = 0; q < TM_GROUP; ++q) {
+            E[q] = tg_u32x4{0u, 0u, 0u, 0u};
+            const uint32_t blk = (uint32_t)g * TM_GROUP + q;               // relative to b0
+            if (blk >= nblk) continue;
+            uint32_t e[8], any = 0;
+#pragma unroll
+            for (int uu = 0; uu < 8; ++uu) {
+                const uint64_t pm = ((uint64_t)rl(mhi, q * 8 + uu) << 32) | rl(mlo, q * 8 + uu);
+                const uint32_t raw = xt[q][uu][lane];
+                asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(e[uu]) : "v"(raw), "s"(pm));
+                any |= e[uu];
+            }
+            const unsigned long long m = __ballot(any != 0u);
+            const int first = m ? __ffsll((long long)m) - 1 : 0, last = m ? 64 - __clzll((long long)m) : 0;
+            const tg_u32x4 row = {e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16)};
+            E[q] = row;
+            if ((b0 + blk) * 8 >= s0r) {                                     // this range writes the block
+                if (lane >= first && lane < last) __builtin_nontemporal_store(row, reinterpret_cast<tg_u32x4*>(tg.store) + (uint64_t)(b0 + blk) * 64 + lane);
+                if (lane == 0) tg.ext[b0 + blk] = (uint16_t)(first | (last << 8));
+            }
+        }
+        lds_fence();
+    };
+    static_assert(8 * TM_GROUP == 32, "one 32-bit mask per group");
+    uint32_t open_in = 0;
+    auto verdicts = [&](uint32_t M) -> uint32_t {                           // (as in tm_walk_range)
+        const bool there = !(M & TMM_SKIP), multi = there && !(M & TMM_SINGLE), rs = (M & TMM_RS) != 0;
+        const uint32_t A = (uint32_t)__ballot(lane < 32 && multi), R = (uint32_t)__ballot(lane < 32 && rs);
+        const uint32_t below = lane < 32 ? (1u << lane) - 1u : 0xffffffffu;
+        const uint32_t rb = R & below;
+        const uint32_t seg = rb ? below & ~((1u << (31 - __clz(rb))) - 1u) : below;
+        const bool ob = (A & seg) != 0u || (!rb && open_in);
+        if (rs && ob) M |= TMM_CLOSE;
+        if (multi && (rs || !ob)) M |= TMM_FIRST;
+        const uint32_t segl = R ? ~((1u << (31 - __clz(R))) - 1u) : 0xffffffffu;
+        open_in = ((A & segl) != 0u || (!R && open_in)) ? 1u : 0u;
+        return M;
+    };
+    auto consume = [&](int g, const tg_u32x4 (&E)[TM_GROUP], uint32_t M0) {
+        const uint32_t M = verdicts(M0);
+#pragma unroll
+        for (int k = 0; k < TM_GROUP; ++k) {
+            if ((uint32_t)g * TM_GROUP + k >= nblk) break;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t m = rl(M, k * 8 + u);
+                if (u & 1) tm_add<true>(st, m, E[k][u >> 1], thr, pkl0, one);
+                else tm_add<false>(st, m, E[k][u >> 1], thr, pkl0, one);
+            }
+        }
+    };
+    tg_u32x4 chunk[TM_GROUP], E[TM_GROUP];
+    uint32_t Mc = TMM_SKIP, Mn = TMM_SKIP, mlo = 0, mhi = 0;
+    TgKeys K = load_keys(0);
+    words_events(0, K, chunk, Mn, mlo, mhi);
+    if (ng > 1) K = load_keys(1);
+    for (int g = 0; g < ng; ++g) {
+        transpose(g, chunk, mlo, mhi, E);
+        Mc = Mn;
+        if (g + 1 < ng) {
+            words_events(g + 1, K, chunk, Mn, mlo, mhi);
+            if (g + 2 < ng) K = load_keys(g + 2);
+        }
+        if (counting) consume(g, E, Mc);
+    }
+    if (counting) { st.nc += st.mask & 0x10001u; st.mask = 0; }
+}
+
+#ifndef LSG_TG_WAVES_PER_EU
+#define LSG_TG_WAVES_PER_EU 5
+#endif
+__global__ __launch_bounds__(TMW_WAVES * 64) __attribute__((amdgpu_waves_per_eu(LSG_TG_WAVES_PER_EU))) void k_tm_gather_count(CountArgs a, TmArgs tm, TgArgs tg) {
+    __shared__ __attribute__((aligned(8192))) uint32_t planes[2][2][8 * 64];
+    __shared__ uint32_t nc_sh[2][64];
+    __shared__ __attribute__((aligned(16))) uint16_t xts[TMW_WAVES][TM_GROUP][8][64];      // the waves' transposition tiles
+    __shared__ WaveBook books[TMW_WAVES];
+    __shared__ uint32_t s_ck;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint32_t* pl = &planes[0][0][0];
+    WaveBook& book = books[wv];
+    book_init(book, lane);
+    if (lane == 0) book.src = 1;
+    const uint32_t thr = bq_threshold(a), pkl0 = lds_addr(pl + lane);
+    uint32_t one = 1u;
+    asm volatile("" : "+v"(one));
+    const uint32_t nchunks = rl(*tg.nchunks, 0);
+    TgStat stat; stat.ev = 0; stat.sg = 0; stat.ne = 0;
+    for (bool first = true;; first = false) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_ck = first ? blockIdx.x : (uint32_t)atomicAdd(&a.scalars[SC_QWALK], 1ull) + gridDim.x;
+        __syncthreads();
+        const uint32_t ck = rl(s_ck, 0);
+        if (ck >= nchunks) break;
+        const uint32_t jx_end = rl(tm.chunk_start[ck + 1], 0);
+        for (uint32_t jx = rl(tm.chunk_start[ck], 0); jx < jx_end; ++jx) {
+            uint32_t jw = 0;
+            if (lane < 8) jw = reinterpret_cast<const uint32_t*>(tm.jobs + jx)[lane];
+            const uint32_t e0 = rl(jw, 0), e1 = rl(jw, 1), w0 = rl(jw, 2), slab = rl(jw, 3), nj = rl(jw, 4), tcnt = rl(jw, 5), tile = rl(jw, 6), emid = rl(jw, 7);
+            const bool in_region = tile >= a.tile_lo && tile < a.tile_hi, counting = in_region && !(nj & TMJ_WIDE);
+            const uint32_t base = rl(tg.blk_off[tile], 0) * 8u, off = rl(tg.tile_off[tile], 0);
+            const int2 geom = a.ne_geom[w0];
+            const int tid = rl((uint32_t)geom.y, 0) & 0xffffff;
+            const int32_t tstart = (int32_t)rl((uint32_t)geom.x, 0);
+            int refb = 'N';
+            if (nj == 1 && counting) { const int64_t pos = (int64_t)tstart + lane; if (pos >= 1 && pos < a.contig_len[tid]) refb = a.ref_ptr[tid][pos]; }
+            __syncthreads();                                   // both waves are done with the job before
+            if (counting) {
+#pragma unroll
+                for (int i = 0; i < 2 * 2 * 8 * 64 / (4 * TMW_WAVES * 64); ++i) reinterpret_cast<uint4*>(pl)[i * (TMW_WAVES * 64) + threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);
+                (&nc_sh[0][0])[threadIdx.x] = 0;
+            }
+            __syncthreads();
+            TmState st; st.nc = 0; st.mask = 0;
+            const uint32_t s0r = wv ? emid : e0, s1r = wv ? e1 : emid;
+            if (s1r > s0r) {
+                tg_range(a, tm, tg, st, stat, s0r, s1r, base, off, tcnt, in_region, counting, thr, pkl0, one, lane, xts[wv]);
+                if (counting) {
+                    if (st.nc & 0xffffu) atomicAdd(&nc_sh[0][lane], st.nc & 0xffffu);
+                    if (st.nc >> 16) atomicAdd(&nc_sh[1][lane], st.nc >> 16);
+                }
+            }
+            __syncthreads();
+            const int ct = tm.ct_base + wv;
+            if (counting && ct < a.n_ct) {                   // the tile's units of this pass: wave = cell type (as in k_tm_walk)
+                const uint32_t* pc = pl + wv * 1024;
+                uint32_t dp = 0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) dp += pc[512 + k * 64 + lane] & 0xffffu;
+                const TmCounters tot{pc, lane, dp - nc_sh[wv][lane]};
+                if (nj == 1) {
+                    if (tcnt <= 256u) emit_unit<TmCounters, true>(a, tot, w0 + ct, ct, tid, tstart, lane, &book, false, refb, 0);
+                    else emit_unit<TmCounters, false>(a, tot, w0 + ct, ct, tid, tstart, lane, &book, false, refb, 1);
+                } else {
+                    uint32_t* dst = a.macc + (uint64_t)(slab + (uint32_t)ct * nj) * (NCTR * 64);
+                    dst[lane] = tot.NCDUP();
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const uint32_t lo = pc[k * 64 + lane], hi = pc[512 + k * 64 + lane];
+                        dst[(1 + k) * 64 + lane] = hi >> 16; dst[(9 + k) * 64 + lane] = hi & 0xffffu;
+                        dst[(17 + k) * 64 + lane] = lo & 0xfffffu; dst[(25 + k) * 64 + lane] = lo >> 20;
+                    }
+                }
+            }
+        }
+    }
+    lds_fence();
+    __syncthreads();
+    {   // admitted events / segments / entries of this workgroup (k_resolve_stats adds the slots up)
+        unsigned long long ev = stat.ev, sg = stat.sg, ne = stat.ne;
+        for (int o = 32; o > 0; o >>= 1) { ev += __shfl_down(ev, o); sg += __shfl_down(sg, o); ne += __shfl_down(ne, o); }
+        if (lane == 0 && ne) {
+            unsigned long long* slot = tg.stat_slots + (size_t)((blockIdx.x * TMW_WAVES + wv) % IX_STAT_SLOTS) * 8;
+            atomicAdd(&slot[0], ev); atomicAdd(&slot[1], sg); atomicAdd(&slot[2], ne);
+        }
+    }
+    if (threadIdx.x < 64) {
+        uint32_t rt = 0, cols = 0, rsrc = 0;
+        for (int w = 0; w < TMW_WAVES; ++w) {
+            const WaveBook& b = books[w];
+            if (lane < a.n_ct) rt += b.rows_true[lane];
+            cols += b.cols; rsrc += b.rows_src;
+        }
+        if (lane < a.n_ct && rt) atomicAdd(&a.scalars[SC_ROWS + lane], (unsigned long long)rt);
+        if (lane == 0) {
+            if (cols) atomicAdd(&a.scalars[SC_COLS], (unsigned long long)cols);
+            if (rsrc) atomicAdd(&a.scalars[SC_ROWS_SRC + 1], (unsigned long long)rsrc);
+        }
+    }
+}
+
 // A job longer than TM_JOB_LIMIT entries (a single barcode owning thousands of a tile's entries: its run cannot be cut) does not fit the
 // packed planes of k_tm_walk.  One wave per such job, 32-bit planes (quality sum, forward, count, duplicates per symbol and cell type),
 // the run logic spelled out: a run start closes the run before it; an entry that is there adds its event where the lane counts it and
@@ -688,10 +964,24 @@ struct WideCounters {
     __device__ __forceinline__ uint32_t DUP(int k) const { return pl[1536 + k * 64 + lane]; }
     __device__ __forceinline__ uint32_t NCDUP() const { return ncdup; }
 };
-__global__ __launch_bounds__(64) void k_tm_walk_wide(CountArgs a, TmArgs tm) {
+// one entry's meta word as k_tm_resolve makes it (the wide walk right after a fused load: nobody has resolved the store yet)
+__device__ __forceinline__ uint32_t tm_meta_one(const CountArgs& a, const TmArgs& tm, uint64_t p) {
+    const uint32_t s = tm.s0[p], b8 = tm.b[p], cb = s & CB_MASK;
+    uint32_t cls = 2;
+    bool ok = cb < (uint32_t)a.n_cb;
+    if (ok && a.adm) { const uint32_t r = tm.rd[p]; ok = (reinterpret_cast<const uint32_t*>(a.adm)[r >> 5] >> (r & 31u)) & 1u; }
+    if (ok) { const uint32_t ct = a.celltype_of[cb]; if (ct < (uint32_t)a.n_ct && (ct >> 1) == (uint32_t)(tm.ct_base >> 1)) cls = ct & 1u; }
+    uint32_t m = cls < 2 ? (cls ? (TMM_CT4 | TMM_CT12) : 0u) | ((s & TM_FWD) ? TMM_FWD : 0u) | ((b8 & 128u) ? TMM_SINGLE : 0u) : TMM_SKIP;
+    if (s & TM_RUNSTART) m |= TMM_RS;
+    return m;
+}
+// n_wide: the plan's number of such jobs where it lies on the device (a launch that does not know it yet ends at once when there are
+// none), or null; inline_meta: no k_tm_resolve has run for this count
+__global__ __launch_bounds__(64) void k_tm_walk_wide(CountArgs a, TmArgs tm, const uint32_t* n_wide, int inline_meta) {
     __shared__ uint32_t pl[2][4][8 * 64];
     __shared__ WaveBook book;
     const int lane = threadIdx.x;
+    if (n_wide && rl(*n_wide, 0) == 0u) return;
     book_init(book, lane);
     if (lane == 0) book.src = 2;
     const uint32_t thr = bq_threshold(a);
@@ -705,7 +995,7 @@ __global__ __launch_bounds__(64) void k_tm_walk_wide(CountArgs a, TmArgs tm) {
         lds_fence();
         uint32_t nc[2] = {0u, 0u}, mask = 0, run_ct = 0;
         for (uint32_t p = jb.e0; p < jb.e1; ++p) {
-            const uint32_t m = rl(tm.meta[p], 0);
+            const uint32_t m = rl(inline_meta ? tm_meta_one(a, tm, p) : tm.meta[p], 0);
             if (m & TMM_RS) { nc[run_ct] += mask ? 1u : 0u; mask = 0; }
             if (m & TMM_SKIP) continue;
             run_ct = (m & TMM_CT4) ? 1u : 0u;
@@ -745,15 +1035,12 @@ __global__ __launch_bounds__(64) void k_tm_walk_wide(CountArgs a, TmArgs tm) {
     book_flush(a, book, lane);
 }
 
-int run_count(lsg_ctx* c, const lsg_count_params* p) {
-    if (c->n_contigs <= 0) { set_error("lsg_pileup_count: no contigs set"); return -2; }
-    if (c->n_ct <= 0) { set_error("lsg_pileup_count: no barcodes set"); return -2; }
-    if (!c->tm_valid) { set_error("lsg_pileup_count: no reads loaded"); return -2; }
-    for (int t = 0; t < c->n_contigs; ++t)
-        if (!c->ref_ptr[t]) { set_error("lsg_pileup_count: reference of contig %d not loaded", t); return -2; }
+// Everything a count needs before its first kernel: the plan's unit tables where the call stage and the exports read them, row
+// buffers, zeroed counters, the kernels' arguments; k_read_stats is queued (the admitted reads, and the bit per read the entries'
+// admission is looked up in when some stored read can fail THIS count's read filters).
+struct CountLaunch { CountArgs a; TmArgs tm; unsigned grid_walk, grid_fin; int n_pass; };
+static int count_prepare(lsg_ctx* c, const lsg_count_params* p, CountLaunch& L) {
     hipStream_t st = c->stream;
-    if (int rc = ensure_plan(c)) return rc;
-    if (depth_cap_drops(c, p)) return -1;           // free unless some cell type's pileup buffer can reach max_depth (cached bound)
     const uint32_t n_ne = c->tm_n_ne;
     if (c->d_scalars.reserve(SC_COUNT * 8) || c->d_ne_units.reserve(((size_t)n_ne + 2) * 4) ||
         c->d_ne_mask.reserve(((size_t)n_ne + 2) * 8) || c->d_ne_rowbase.reserve(((size_t)n_ne + 2) * 4) || c->ws[WS_NE_NSLOT].reserve(((size_t)n_ne + 2) * 4) ||
@@ -763,17 +1050,16 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
         return -1;
     // 16 workgroups = 32 waves per CU = the 8 waves per SIMD the hardware holds (8 KB of LDS each): the walk waits on its own dependency
     // chains (a scalar decision per entry), so every resident wave counts — 14 per CU: 5.7 ms, 16: 5.4 (round 3)
-    const unsigned grid_walk = (unsigned)(c->n_cus * tune_int("LSG_GRID_TM", 16));
-    const unsigned grid_fin = (unsigned)(c->n_cus * 8);
-    const unsigned grid_wide = c->tm_n_wide ? (c->tm_n_wide < (unsigned)(c->n_cus * 4) ? c->tm_n_wide : (unsigned)(c->n_cus * 4)) : 0u;
-    const int n_pass = (c->n_ct + 1) / 2;
+    L.grid_walk = (unsigned)(c->n_cus * tune_int("LSG_GRID_TM", 16));
+    L.grid_fin = (unsigned)(c->n_cus * 8);
+    L.n_pass = (c->n_ct + 1) / 2;
     {   // row buffers: bound + one open arena per emitting wave and format
         uint64_t want_rows = (uint64_t)n_ne / (uint64_t)c->n_ct * TILE_W;
         if (p->min_dp > 0) {
             const uint64_t by_depth = (uint64_t)c->rd.n_events / (uint64_t)p->min_dp + 64;
             if (by_depth < want_rows) want_rows = by_depth;
         }
-        const uint64_t emitters = (uint64_t)grid_walk * TMW_WAVES * 2 + grid_fin + grid_wide;
+        const uint64_t emitters = (uint64_t)L.grid_walk * TMW_WAVES * 2 + L.grid_fin + (uint64_t)c->n_cus * 4;
         uint64_t arena = want_rows / (emitters * 8) / ARENA * ARENA;
         c->arena = (uint32_t)(arena < (uint64_t)ARENA ? (uint64_t)ARENA : (arena > 8ull * ARENA ? 8ull * ARENA : arena));
         want_rows += emitters * c->arena + 64;
@@ -783,9 +1069,10 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
             if (c->d_rows[i].reserve((size_t)c->row_cap * ROW_STORED_WORDS * 4)) return -1;
     }
     c->n_ne = n_ne; c->n_multi = c->tm_n_multi;
-    CountArgs a{};
-    fill_args(c, p, a);
-    TmArgs tm{};
+    L.a = CountArgs{};
+    fill_args(c, p, L.a);
+    TmArgs& tm = L.tm;
+    tm = TmArgs{};
     tm.store = c->tm[TM_STORE].as<uint4>(); tm.s0 = c->tm[TM_S0].as<uint32_t>(); tm.b = c->tm[TM_B].as<uint8_t>(); tm.rd = c->tm[TM_RD].as<uint32_t>();
     tm.meta = c->tm[TM_META].as<uint32_t>(); tm.blk_tile = c->tm[TM_BLK_TILE].as<uint32_t>(); tm.jobs = c->tm[TM_JOBS].as<TmJob>(); tm.np = c->tm_np; tm.nblk = c->tm_nblk;
     tm.njobs = c->tm_njobs; tm.nchunks = c->tm_nchunks; tm.chunk_start = c->tm[TM_CHUNKS].as<uint32_t>(); tm.ext = c->tm[TM_EXT].as<uint16_t>();
@@ -803,19 +1090,32 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
         LSG_HIP(hipMemsetAsync(c->d_ne_rowbase.p, 0, ((size_t)n_ne + 1) * 4, st));
     }
     const int64_t R = c->rd.n_reads;
-    if (R > 0) { unsigned g = (unsigned)((R + 255) / 256); if (g > (unsigned)(c->n_cus * 8)) g = (unsigned)(c->n_cus * 8); hipLaunchKernelGGL(k_read_stats, dim3(g), dim3(256), 0, st, a); }
-    for (int pass = 0; pass < n_pass && c->tm_nblk; ++pass) {
-        tm.ct_base = 2 * pass;
-        if (pass) LSG_HIP(hipMemsetAsync(a.scalars + SC_QWALK, 0, 8, st));          // the walk's chunk queue starts over
-        hipLaunchKernelGGL(k_tm_resolve, dim3((c->tm_nblk + 255) / 256), dim3(256), 0, st, a, tm, c->d_ix_stat.as<unsigned long long>());
+    if (R > 0) { unsigned g = (unsigned)((R + 255) / 256); if (g > (unsigned)(c->n_cus * 8)) g = (unsigned)(c->n_cus * 8); hipLaunchKernelGGL(k_read_stats, dim3(g), dim3(256), 0, st, L.a); }
+    return 0;
+}
+// the passes over the resident store: resolve + walk per pair of cell types (from pass `first_pass` on), the wide walk where the plan has
+// jobs for it
+static int count_passes(lsg_ctx* c, CountLaunch& L, int first_pass, bool wide_of_pass0) {
+    hipStream_t st = c->stream;
+    const unsigned grid_wide = c->tm_n_wide ? (c->tm_n_wide < (unsigned)(c->n_cus * 4) ? c->tm_n_wide : (unsigned)(c->n_cus * 4)) : 0u;
+    for (int pass = wide_of_pass0 ? 0 : first_pass; pass < L.n_pass && c->tm_nblk; ++pass) {
+        const bool wide_only = pass < first_pass;             // (the fused load counted this pass's jobs but the wide ones)
+        if (wide_only && !grid_wide) continue;
+        L.tm.ct_base = 2 * pass;
+        if (pass) LSG_HIP(hipMemsetAsync(L.a.scalars + SC_QWALK, 0, 8, st));          // the walk's chunk queue starts over
+        hipLaunchKernelGGL(k_tm_resolve, dim3((c->tm_nblk + 255) / 256), dim3(256), 0, st, L.a, L.tm, wide_only ? (unsigned long long*)nullptr : c->d_ix_stat.as<unsigned long long>());
         if (pass == 0) { LSG_HIP(hipEventRecord(c->ev[1], st)); LSG_HIP(hipEventRecord(c->ev[3], st)); }
-        if (c->tm_njobs) hipLaunchKernelGGL(k_tm_walk, dim3(grid_walk), dim3(TMW_WAVES * 64), 0, st, a, tm);
+        if (c->tm_njobs && !wide_only) hipLaunchKernelGGL(k_tm_walk, dim3(L.grid_walk), dim3(TMW_WAVES * 64), 0, st, L.a, L.tm);
         if (pass == 0) LSG_HIP(hipEventRecord(c->ev[4], st));
-        if (grid_wide) hipLaunchKernelGGL(k_tm_walk_wide, dim3(grid_wide), dim3(64), 0, st, a, tm);
+        if (grid_wide) hipLaunchKernelGGL(k_tm_walk_wide, dim3(grid_wide), dim3(64), 0, st, L.a, L.tm, (const uint32_t*)nullptr, 0);
     }
-    if (!c->tm_nblk) { LSG_HIP(hipEventRecord(c->ev[1], st)); LSG_HIP(hipEventRecord(c->ev[3], st)); LSG_HIP(hipEventRecord(c->ev[4], st)); }
-    if (c->tm_nblk) hipLaunchKernelGGL(k_resolve_stats, dim3(1), dim3(256), 0, st, a, c->d_ix_stat.as<unsigned long long>());
-    if (c->tm_n_multi) hipLaunchKernelGGL(k_finalize_multi, dim3(c->tm_n_multi < grid_fin ? c->tm_n_multi : grid_fin), dim3(FIN_THREADS), 0, st, a);
+    return 0;
+}
+// the count's tail: statistics, multi-job tiles, the counters' way to the host
+static int count_finish(lsg_ctx* c, const lsg_count_params* p, CountLaunch& L) {
+    hipStream_t st = c->stream;
+    if (c->tm_nblk) hipLaunchKernelGGL(k_resolve_stats, dim3(1), dim3(256), 0, st, L.a, c->d_ix_stat.as<unsigned long long>());
+    if (c->tm_n_multi) hipLaunchKernelGGL(k_finalize_multi, dim3(c->tm_n_multi < L.grid_fin ? c->tm_n_multi : L.grid_fin), dim3(FIN_THREADS), 0, st, L.a);
     LSG_HIP(hipEventRecord(c->ev[5], st));
     LSG_HIP(hipGetLastError());
     unsigned long long sc[SC_COUNT];
@@ -826,7 +1126,7 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
     c->stats.n_reads_admitted = (int64_t)sc[SC_READS];
     c->stats.n_segs_admitted = (int64_t)sc[SC_SEGS];
     c->stats.n_events_admitted = (int64_t)sc[SC_EVENTS];
-    c->stats.n_units = n_ne;
+    c->stats.n_units = c->n_ne;
     c->stats.n_deep_units = c->tm_n_multi;
     c->stats.n_entries = (int64_t)sc[SC_NENT];
     float ms = 0;
@@ -845,6 +1145,54 @@ int run_count(lsg_ctx* c, const lsg_count_params* p) {
     c->counted = true;
     c->called = false;
     return 0;
+}
+
+// The fused pass of a load (store.hip build_store when lsg_set_count_at_load is on): the plan is made (its chunk and wide-job counters
+// still on the device), the sort's output lies in src; queues everything a count queues around k_tm_gather_count and ends with the
+// count's one synchronisation.  At most two cell types (one pass), no depth-cap drops (the caller has checked the bound).
+int run_gather_count(lsg_ctx* c, const lsg_count_params* p, const GatherCountSrc& src) {
+    hipStream_t st = c->stream;
+    c->has_drops = false; c->n_depth_dropped = 0;
+    CountLaunch L;
+    if (int rc = count_prepare(c, p, L)) return rc;
+    TgArgs tg{};
+    tg.events = src.events; tg.n_events = src.n_events; tg.key = src.key; tg.rdv = src.rdv; tg.cb_bits = src.cb_bits;
+    tg.tile_off = c->d_tile_off.as<uint32_t>(); tg.blk_off = c->tm[TM_BLK_OFF].as<uint32_t>();
+    tg.s0 = c->tm[TM_S0].as<uint32_t>(); tg.b8 = c->tm[TM_B].as<uint8_t>(); tg.rd = c->tm[TM_RD].as<uint32_t>();
+    tg.store = c->tm[TM_STORE].as<uint4>(); tg.ext = c->tm[TM_EXT].as<uint16_t>();
+    tg.nchunks = c->d_plan_misc + 1; tg.stat_slots = c->d_ix_stat.as<unsigned long long>();
+    L.tm.ct_base = 0;
+    const bool dbg = getenv("LSG_DEBUG_SYNC") != nullptr;
+    auto stage = [&](const char* what) { if (dbg) { const hipError_t e = hipStreamSynchronize(st); fprintf(stderr, "[lsg] fused load: %s: %s\n", what, hipGetErrorString(e)); fflush(stderr); } };
+    stage("count prepared");
+    LSG_HIP(hipEventRecord(c->ev[1], st)); LSG_HIP(hipEventRecord(c->ev[3], st));
+    // 17 KB of LDS per workgroup (planes + the two waves' transposition tiles): 9 workgroups per CU
+    const unsigned grid = (unsigned)(c->n_cus * tune_int("LSG_GRID_TG", 9));
+    hipLaunchKernelGGL(k_tm_gather_count, dim3(grid), dim3(TMW_WAVES * 64), 0, st, L.a, L.tm, tg);
+    LSG_HIP(hipEventRecord(c->ev[4], st));
+    LSG_HIP(hipEventRecord(c->evb[4], st));
+    stage("k_tm_gather_count");
+    // jobs too long for the packed planes were gathered, not counted: the wide walk takes them from the store (it ends at once when the plan has none)
+    hipLaunchKernelGGL(k_tm_walk_wide, dim3((unsigned)(c->n_cus * 2)), dim3(64), 0, st, L.a, L.tm, (const uint32_t*)c->d_plan_misc, 1);
+    stage("wide walk");
+    return count_finish(c, p, L);
+}
+
+int run_count(lsg_ctx* c, const lsg_count_params* p) {
+    if (c->n_contigs <= 0) { set_error("lsg_pileup_count: no contigs set"); return -2; }
+    if (c->n_ct <= 0) { set_error("lsg_pileup_count: no barcodes set"); return -2; }
+    if (!c->tm_valid) { set_error("lsg_pileup_count: no reads loaded"); return -2; }
+    for (int t = 0; t < c->n_contigs; ++t)
+        if (!c->ref_ptr[t]) { set_error("lsg_pileup_count: reference of contig %d not loaded", t); return -2; }
+    if (int rc = ensure_plan(c)) return rc;
+    if (depth_cap_drops(c, p)) return -1;           // free unless some cell type's pileup buffer can reach max_depth (cached bound)
+    CountLaunch L;
+    if (int rc = count_prepare(c, p, L)) return rc;
+    hipStream_t st = c->stream;
+    if (int rc = count_passes(c, L, 0, false)) return rc;
+    if (!c->tm_nblk) { LSG_HIP(hipEventRecord(c->ev[1], st)); LSG_HIP(hipEventRecord(c->ev[3], st)); LSG_HIP(hipEventRecord(c->ev[4], st)); }
+    c->counted_at_load = false;
+    return count_finish(c, p, L);
 }
 
 // ------------------------------------------------------------------------------------------------

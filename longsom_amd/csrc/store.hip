@@ -424,13 +424,13 @@ __global__ __launch_bounds__(TMG_WAVES * 64) void k_tm_gather(const uint16_t* ev
         LSG_HIP(hipcub::DeviceScan::ExclusiveSum(c->d_cub_tmp.p, tb_, (in), (out), (int)(n), st));       \
     } while (0)
 
-enum { BT_KEY_A = 0, BT_KEY_B, BT_VAL_A, BT_VAL_B, BT_PEX, BT_NETILE, BT_SEG_BEGIN, BT_SEG_END, BT_TMP, BT_PER_TILE, BT_OFFS, BT_SPAN, BT_SPAN_RUN, BT_BLK, BT_N };
+enum { BT_KEY_A = 0, BT_KEY_B, BT_VAL_A, BT_VAL_B, BT_PEX, BT_NETILE, BT_SEG_BEGIN, BT_SEG_END, BT_TMP, BT_PER_TILE, BT_OFFS, BT_SPAN, BT_SPAN_RUN, BT_BLK, BT_CURSOR, BT_N };
 
 void drop_store(lsg_ctx* c) {
     c->tm_valid = false; c->plan_n_ct = 0; c->plan1_n_ct = 0; c->tm_n = 0; c->tm_events = 0; c->tm_np = 0; c->tm_nblk = 0; c->tm_njobs = 0; c->tm_nchunks = 0;
     c->tm_n_ne = 0; c->tm_n_multi = 0; c->tm_n_slabs = 0; c->tm_n_wide = 0;
     c->max_live_reads = -1; c->max_live_all = -1; c->has_drops = false;
-    c->counted = c->called = false;
+    c->counted = c->called = false; c->counted_at_load = false; c->load_was_fused = false;
 }
 
 // the build's temporaries stay in the context (grow-only): allocating ~9 GB per load costs more wall time than the build's kernels —
@@ -444,8 +444,9 @@ static void settle_temporaries(lsg_ctx* c) {
 }
 
 static int plan_tiles(lsg_ctx* c, hipStream_t st);
-static int plan_jobs(lsg_ctx* c, bool finish);
+static int plan_jobs(lsg_ctx* c, bool finish, const uint64_t* skey = nullptr, int cb_bits = 0);
 static void plan_finish(lsg_ctx* c);
+static void plan_finish_tiles(lsg_ctx* c);
 
 // rocprim's segmented radix sort with a configuration of its own.  gfx950 gets rocprim's generic default (3.7 ms for C2's 185 M pairs in
 // 5 * 10^5 segments); measured on the MI355X over radix bits 6-8, blocks of 256 / 512 threads with 4-24 items per thread and four
@@ -575,8 +576,9 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
         return -2;
     }
     if (key_a.reserve(N * 8 + 16) || key_b.reserve(N * 8 + 16) || val_a.reserve(N * 4 + 16) || val_b.reserve(N * 4 + 16) ||
-        c->bt[BT_PER_TILE].reserve(((size_t)T + 2) * 4)) return -1;
-    a.cursor = c->bt[BT_PER_TILE].as<uint32_t>(); a.key = key_a.as<uint64_t>(); a.rdv = val_a.as<uint32_t>(); a.cb_bits = bits;
+        c->bt[BT_CURSOR].reserve(((size_t)T + 2) * 4)) return -1;
+    // (the cursors in a buffer of their own: the plan's tile-level half may be at work in BT_PER_TILE beside the scatter)
+    a.cursor = c->bt[BT_CURSOR].as<uint32_t>(); a.key = key_a.as<uint64_t>(); a.rdv = val_a.as<uint32_t>(); a.cb_bits = bits;
     LSG_HIP(hipMemcpyAsync(a.cursor, c->d_tile_off.p, ((size_t)T + 1) * 4, hipMemcpyDeviceToDevice, st));
     LSG_HIP(hipMemsetAsync(c->d_scalars.p, 0, 8, st));
     hipLaunchKernelGGL(k_bin, dim3(g_bin), dim3(BIN_THREADS), 0, st, a);
@@ -640,6 +642,38 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
         if (c->tm[TM_STORE].reserve(((size_t)nblk + TM_GROUP) * 1024)) return -1;
     }
     LSG_HIP(hipEventRecord(c->evb[3], st));
+    // The first count in the same pass (lsg_set_count_at_load): when its parameters and the barcode table are known now, the depth cap
+    // cannot fire (the all-reads bound came with the early look) and one pass covers the cell types, the gather below is replaced by
+    // pileup.hip's k_tm_gather_count, which builds the same store and counts while each block is in registers.
+    bool fused = c->cal_enabled && c->n_ct >= 1 && c->n_ct <= 2 && c->n_cb > 0 && c->copy_stream && !getenv("LSG_NO_FUSED_LOAD");
+    if (fused) {
+        const lsg_count_params& q = c->cal_params;
+        if (q.min_mq < c->st_min_mq || (c->st_flag_exclude & ~q.flag_exclude) != 0 || (c->st_ignore_orphans && !q.ignore_orphans)) fused = false;       // (the count would be refused)
+        if (q.max_depth > 0 && c->max_live_all + 1 > (int64_t)q.max_depth) fused = false;                                                                 // (the depth cap may drop reads: decided per count)
+        for (int t = 0; t < c->n_contigs && fused; ++t) if (!c->ref_ptr[t]) fused = false;
+    }
+    if (fused) {
+        // the plan: its tile-level half on the copy stream while the scatter and the sort are at work (two small host round trips that
+        // wait for the copy stream only), its job-level half behind the sort - the jobs are cut at run starts read from the sorted keys
+        const bool dbg = getenv("LSG_DEBUG_SYNC") != nullptr;
+        auto stage = [&](const char* what) { if (dbg) { const hipError_t e = hipStreamSynchronize(st); fprintf(stderr, "[lsg] fused load: %s: %s\n", what, hipGetErrorString(e)); fflush(stderr); } };
+        stage("scatter + sort + block tables");
+        int rc = plan_tiles(c, c->copy_stream);
+        if (rc) return rc;
+        plan_finish_tiles(c);
+        c->tm_np = np; c->tm_nblk = nblk;
+        if ((rc = plan_jobs(c, false, key_b.as<uint64_t>(), bits))) return rc;
+        stage("plan");
+        c->tm_valid = true;                                   // (what the count's preparation looks at; the blocks are written by the pass itself)
+        const GatherCountSrc src{events, n_events, key_b.as<uint64_t>(), val_b.as<uint32_t>(), bits};
+        rc = run_gather_count(c, &c->cal_params, src);
+        LSG_HIP(hipStreamSynchronize(st));
+        if (hipGetLastError() != hipSuccess) { c->tm_valid = false; set_error("lsg_load_reads: the fused gather + count pass failed"); return -1; }
+        plan_finish(c);
+        c->load_was_fused = true;
+        c->counted_at_load = rc == 0;                         // (a count that could not be kept - rows outgrew their buffer - is made again on request; the store is whole either way)
+        if (rc) c->counted = false;
+    } else {
     const bool plan_early = c->n_ct > 0 && c->copy_stream && c->ev_copy;
     if (plan_early) LSG_HIP(hipEventRecord(c->ev_copy, st));       // everything the gather waits for is what the plan's tile-level half waits for
     {
@@ -664,6 +698,7 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
     if (plan_early) LSG_HIP(hipStreamSynchronize(c->copy_stream));
     if (plan_rc) return plan_rc;
     if (plan_early) plan_finish(c);
+    }
     for (int i = 0; i < 4; ++i) { float ms = 0; if (hipEventElapsedTime(&ms, c->evb[i], c->evb[i + 1]) == hipSuccess) c->build_ms[i] = ms; }
     settle_temporaries(c);
     if (getenv("LSG_TIMING"))
@@ -689,9 +724,15 @@ __global__ void k_tm_tiles(const uint32_t* cap, uint32_t n_tiles, int n_ct, uint
     ne[t] = n ? 1u : 0u; nj[t] = j; slabs[t] = j > 1 ? j * (uint32_t)n_ct : 0u; multi[t] = j > 1 ? 1u : 0u;
 }
 // job j of J of a tile of n entries at `base`: [first run start at or after n j / J, first run start at or after n (j + 1) / J)
-__device__ __forceinline__ void tm_make_job(const uint32_t* s0, uint64_t base, uint32_t n, uint32_t J, uint32_t j, uint32_t w0, uint32_t slab, uint32_t tile, TmJob* out,
+// (run starts: the store's s0 words, or - before the gather has written them - the sorted keys' barcodes; RunSrc)
+struct RunSrc { const uint32_t* s0; const uint64_t* key; uint32_t cbm; };
+__device__ __forceinline__ void tm_make_job(const RunSrc& rs, uint64_t base, uint32_t off, uint32_t n, uint32_t J, uint32_t j, uint32_t w0, uint32_t slab, uint32_t tile, TmJob* out,
                                             uint32_t* n_wide) {
-    auto cut = [&](uint32_t x) -> uint32_t { while (x < n && !(s0[base + x] & TM_RUNSTART)) ++x; return x < n ? x : n; };
+    auto starts = [&](uint32_t x) -> bool {
+        if (!rs.key) return (rs.s0[base + x] & TM_RUNSTART) != 0;
+        return x == 0 || (((uint32_t)rs.key[off + x] ^ (uint32_t)rs.key[off + x - 1]) & rs.cbm) != 0;
+    };
+    auto cut = [&](uint32_t x) -> uint32_t { while (x < n && !starts(x)) ++x; return x < n ? x : n; };
     const uint32_t e0 = j == 0 ? 0u : cut((uint32_t)(((uint64_t)n * j) / J));
     uint32_t e1 = j + 1 == J ? n : cut((uint32_t)(((uint64_t)n * (j + 1)) / J));
     if (e1 < e0) e1 = e0;
@@ -706,7 +747,7 @@ __device__ __forceinline__ void tm_make_job(const uint32_t* s0, uint64_t base, u
     *out = jb;
 }
 // per non-empty tile: its units (one per cell type) and, for a tile that is one job, the job
-__global__ void k_tm_jobs(const uint32_t* tile_base, int n_contigs, int n_ct, const uint32_t* s0, const uint32_t* cap, const uint32_t* blk_off, const uint32_t* ne_off,
+__global__ void k_tm_jobs(const uint32_t* tile_base, int n_contigs, int n_ct, RunSrc rs, const uint32_t* tile_off, const uint32_t* cap, const uint32_t* blk_off, const uint32_t* ne_off,
                           const uint32_t* nj, const uint32_t* job_off, const uint32_t* slab_off, const uint32_t* multi_off, uint32_t n_tiles, TmJob* jobs,
                           uint32_t* ne_units, int2* ne_geom, uint32_t* ne_nslot, uint32_t* ne_acc, uint32_t* multi, uint32_t* n_wide) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -727,11 +768,11 @@ __global__ void k_tm_jobs(const uint32_t* tile_base, int n_contigs, int n_ct, co
         if (J > 1) multi[multi_off[t] * (uint32_t)n_ct + ct] = w;
     }
     if (J > 1) return;                                   // its jobs: k_tm_jobs_multi (a lane per job; here one thread would walk them one after the other)
-    tm_make_job(s0, base, n, 1u, 0u, ord * (uint32_t)n_ct, 0xFFFFFFFFu, t, jobs + job_off[t], n_wide);
+    tm_make_job(rs, base, tile_off[t], n, 1u, 0u, ord * (uint32_t)n_ct, 0xFFFFFFFFu, t, jobs + job_off[t], n_wide);
 }
 // the jobs of the tiles cut into several: a wave per tile, a lane per job (a job's ends are run starts found from its own nominal ends:
 // no job waits for the one before it)
-__global__ __launch_bounds__(64) void k_tm_jobs_multi(int n_ct, const uint32_t* s0, const uint32_t* cap, const uint32_t* blk_off, const uint32_t* ne_off, const uint32_t* nj,
+__global__ __launch_bounds__(64) void k_tm_jobs_multi(int n_ct, RunSrc rs, const uint32_t* tile_off, const uint32_t* cap, const uint32_t* blk_off, const uint32_t* ne_off, const uint32_t* nj,
                                                       const uint32_t* job_off, const uint32_t* slab_off, const uint32_t* multi, const uint32_t* ne_units, uint32_t n_mt, TmJob* jobs,
                                                       uint32_t* n_wide) {
     const uint32_t i = blockIdx.x;
@@ -740,7 +781,7 @@ __global__ __launch_bounds__(64) void k_tm_jobs_multi(int n_ct, const uint32_t* 
     const uint32_t n = cap[t], J = nj[t];
     const uint64_t base = (uint64_t)blk_off[t] * 8;
     for (uint32_t j = threadIdx.x; j < J; j += 64u)
-        tm_make_job(s0, base, n, J, j, ne_off[t] * (uint32_t)n_ct, slab_off[t] + j, t, jobs + job_off[t] + j, n_wide);
+        tm_make_job(rs, base, tile_off[t], n, J, j, ne_off[t] * (uint32_t)n_ct, slab_off[t] + j, t, jobs + job_off[t] + j, n_wide);
 }
 struct TmJobWork {
     const TmJob* jobs;
@@ -791,8 +832,9 @@ static int plan_tiles(lsg_ctx* c, hipStream_t st) {
 // The plan's job-level half: jobs cut at the run starts the gather wrote, the units' tables, the walk's work-balanced chunks.  Queued
 // behind the gather by the load when the tile-level half is there (finish = false: the load's own final synchronisation covers it and
 // plan_finish reads the two counters), else made by the first count.
-static int plan_jobs(lsg_ctx* c, bool finish) {
+static int plan_jobs(lsg_ctx* c, bool finish, const uint64_t* skey, int cb_bits) {
     hipStream_t st = c->stream;
+    const RunSrc rs{c->tm[TM_S0].as<uint32_t>(), skey, skey ? (1u << cb_bits) - 1u : 0u};
     const uint32_t T = c->n_tiles;
     DevBuf &per_tile = c->bt[BT_PER_TILE], &offs = c->bt[BT_OFFS];
     uint32_t* nj = per_tile.as<uint32_t>() + (T + 2);
@@ -800,11 +842,11 @@ static int plan_jobs(lsg_ctx* c, bool finish) {
     uint32_t* d_misc = multi_off + (T + 2);          // [0] wide jobs, [1] chunks
     const uint32_t* tot = c->plan1_tot;
     const uint32_t njobs = tot[1], n_mt = tot[3];
-    hipLaunchKernelGGL(k_tm_jobs, dim3((T + 255) / 256), dim3(256), 0, st, c->d_tile_base.as<uint32_t>(), c->n_contigs, c->n_ct, c->tm[TM_S0].as<uint32_t>(),
+    hipLaunchKernelGGL(k_tm_jobs, dim3((T + 255) / 256), dim3(256), 0, st, c->d_tile_base.as<uint32_t>(), c->n_contigs, c->n_ct, rs, c->d_tile_off.as<uint32_t>(),
                        c->d_tile_cap.as<uint32_t>(), c->tm[TM_BLK_OFF].as<uint32_t>(), ne_off, nj, job_off, slab_off, multi_off, T,
                        c->tm[TM_JOBS].as<TmJob>(), c->tm[TM_NE_UNITS].as<uint32_t>(), c->tm[TM_NE_GEOM].as<int2>(), c->tm[TM_NE_NSLOT].as<uint32_t>(),
                        c->tm[TM_NE_ACC].as<uint32_t>(), c->tm[TM_MULTI].as<uint32_t>(), d_misc);
-    if (n_mt) hipLaunchKernelGGL(k_tm_jobs_multi, dim3(n_mt), dim3(64), 0, st, c->n_ct, c->tm[TM_S0].as<uint32_t>(), c->d_tile_cap.as<uint32_t>(), c->tm[TM_BLK_OFF].as<uint32_t>(),
+    if (n_mt) hipLaunchKernelGGL(k_tm_jobs_multi, dim3(n_mt), dim3(64), 0, st, c->n_ct, rs, c->d_tile_off.as<uint32_t>(), c->d_tile_cap.as<uint32_t>(), c->tm[TM_BLK_OFF].as<uint32_t>(),
                                  ne_off, nj, job_off, slab_off, c->tm[TM_MULTI].as<uint32_t>(), c->tm[TM_NE_UNITS].as<uint32_t>(), n_mt, c->tm[TM_JOBS].as<TmJob>(), d_misc);
     {   // static work-balanced chunks of the job list; every workgroup of the walk should get several: a small load is cut finer
         DevBuf& pex = c->bt[BT_PEX];
@@ -819,15 +861,20 @@ static int plan_jobs(lsg_ctx* c, bool finish) {
         hipLaunchKernelGGL(k_tm_chunks, dim3((njobs + 255) / 256), dim3(256), 0, st, pex.as<uint32_t>(), njobs, chunk_work, c->tm[TM_CHUNKS].as<uint32_t>(), d_misc + 1);
     }
     LSG_HIP(hipMemcpyAsync(c->plan_misc, d_misc, 8, hipMemcpyDeviceToHost, st));
+    c->d_plan_misc = d_misc;
     LSG_HIP(hipGetLastError());
     if (finish) LSG_HIP(hipStreamSynchronize(st));
     return 0;
 }
 
-static void plan_finish(lsg_ctx* c) {          // (after the stream plan_jobs ran on has been synchronised)
+static void plan_finish_tiles(lsg_ctx* c) {    // what the plan's tile-level half knows on the host
     const uint32_t* tot = c->plan1_tot;
-    c->tm_njobs = tot[1]; c->tm_nchunks = c->plan_misc[1]; c->tm_n_wide = c->plan_misc[0];
+    c->tm_njobs = tot[1];
     c->tm_n_ne = (uint32_t)((size_t)tot[0] * (size_t)c->n_ct); c->tm_n_multi = (uint32_t)((size_t)tot[3] * (size_t)c->n_ct); c->tm_n_slabs = tot[2];
+}
+static void plan_finish(lsg_ctx* c) {          // (after the stream plan_jobs ran on has been synchronised)
+    plan_finish_tiles(c);
+    c->tm_nchunks = c->plan_misc[1]; c->tm_n_wide = c->plan_misc[0];
     c->plan_n_ct = c->n_ct;
 }
 

@@ -101,6 +101,13 @@ class Engine:
         BAM); later counts must be at least as strict.  Default: no filter (lsg_set_load_filter)."""
         _lib.check(self._lib.lsg_set_load_filter(self._h, int(min_mq), int(flag_exclude), int(ignore_orphans)), "lsg_set_load_filter")
 
+    def set_count_at_load(self, params=None):
+        """The loads that follow also make the first count under `params` (a CountParams), in the pass that builds the store; the
+        first pileup_count(params) after such a load returns that count without another pass.  None switches it off
+        (lsg_set_count_at_load).  Barcodes, references and region must be set before the load."""
+        import ctypes as C
+        _lib.check(self._lib.lsg_set_count_at_load(self._h, C.byref(params) if params is not None else None), "lsg_set_count_at_load")
+
     def unload_reads(self):
         """give the device memory of the resident load (reads, store, rows, call records, cached temporaries) back: lsg_unload_reads"""
         _lib.check(self._lib.lsg_unload_reads(self._h), "lsg_unload_reads")
@@ -301,7 +308,7 @@ class Engine:
         return s
 
     def layout_info(self):
-        """(path, build_ms, store_bytes): path is always 2 (the count over the tile store); wall time the last load spent building the
+        """(path, build_ms, store_bytes): path 2 = the load built the store alone, 3 = in the pass that also made the first count (set_count_at_load); wall time the last load spent building the
         store; device bytes the store and what belongs to it hold (lsg_get_layout_info)"""
         path = C.c_int32(0); ms = C.c_double(0.0); nbytes = C.c_int64(0)
         _lib.check(self._lib.lsg_get_layout_info(self._h, C.byref(path), C.byref(ms), C.byref(nbytes)), "lsg_get_layout_info")

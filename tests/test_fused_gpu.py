@@ -1,0 +1,143 @@
+"""GPU: a load that also makes the first count (lsg_set_count_at_load: pileup.hip k_tm_gather_count builds the store's blocks and adds
+their events into the counters in one pass) — the count it hands out, AND every later count over the store it wrote, equal the
+events-level CPU oracle bit for bit; loads it cannot serve (more than two cell types, a depth cap that could fire) take the plain
+gather and count on request."""
+import numpy as np
+import pytest
+
+from longsom_amd import synth
+from longsom_amd._lib import CountParams
+from longsom_amd.synth_simple import random_records, random_reference
+from tests.test_count_gpu import make_case
+from tests.test_fuzz_gpu import draw
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_rows(rec, lens, refs, ct_of, n_ct, p):
+    from oracle import loader
+    out, tot = [], 0
+    for ct in range(n_ct):
+        k, rf, c, ncol = loader.count(rec, lens, refs, ct_of, ct, p.min_bq, p.min_mq, p.min_dp, p.min_cc, p.flag_exclude, p.ignore_orphans)
+        out.append((k, rf, c)); tot += ncol
+    return out, tot
+
+
+def fused_vs_oracle(engine, rec, lens, refs, ct_of, n_ct, p, expect_fused=True, recount_params=()):
+    engine.set_contigs(lens)
+    for t, r in enumerate(refs):
+        engine.load_reference(t, r)
+    engine.set_barcodes(ct_of, n_ct)
+    engine.set_count_at_load(p)
+    try:
+        engine.load_reads(rec)
+    finally:
+        engine.set_count_at_load(None)
+    assert engine.layout_info()[0] == (3 if expect_fused else 2)
+    want, want_cols = oracle_rows(rec, lens, refs, ct_of, n_ct, p)
+    for what in ("the count made by the load", "a count over the store that load wrote"):
+        rows, cols = engine.pileup_count(p)
+        assert cols == want_cols, what
+        for ct in range(n_ct):
+            k, rf, c = engine.fetch_counts(ct)
+            assert rows[ct] == len(want[ct][0]), what
+            np.testing.assert_array_equal(k, want[ct][0], err_msg=what); np.testing.assert_array_equal(rf, want[ct][1], err_msg=what)
+            np.testing.assert_array_equal(c, want[ct][2], err_msg=what)
+    for q in recount_params:                                  # other parameters over the same store
+        w2, c2 = oracle_rows(rec, lens, refs, ct_of, n_ct, q)
+        rows, cols = engine.pileup_count(q)
+        assert cols == c2
+        for ct in range(n_ct):
+            k, rf, c = engine.fetch_counts(ct)
+            np.testing.assert_array_equal(k, w2[ct][0]); np.testing.assert_array_equal(c, w2[ct][2])
+    return rows, cols
+
+
+def test_small_and_deep_and_pads(engine):
+    p = CountParams.longsom_defaults()
+    lens = [5000, 1200, 70]
+    rec, refs, ct_of = make_case(1, 3000, lens, 50)
+    fused_vs_oracle(engine, rec, lens, refs, ct_of, 2, p, recount_params=[CountParams.longsom_defaults(min_mq=30, min_bq=30)])
+    lens = [4000, 2000]                                       # deep tiles: several jobs, slabs, both waves of a job, cuts off a multiple of eight
+    rec, refs, ct_of = make_case(3, 30000, lens, 3000, hot_regions=[(0, 1000, 1100), (1, 500, 520)], hot_frac=0.9)
+    fused_vs_oracle(engine, rec, lens, refs, ct_of, 2, p)
+    assert engine.count_stats().n_deep_units > 0
+    rec, refs, ct_of = make_case(12, 15000, [3000, 800], 120, hot_regions=[(0, 700, 760)], hot_frac=0.7)      # few barcodes: long runs
+    fused_vs_oracle(engine, rec, [3000, 800], refs, ct_of, 2, CountParams.longsom_defaults(min_dp=0, min_cc=0, min_bq=0, min_mq=0))
+
+
+def test_one_cell_type_and_gates_and_strict_filters(engine):
+    lens = [3000, 800]
+    rec, refs, ct_of = make_case(12, 9000, lens, 120)
+    one = np.zeros(len(ct_of), np.uint8); one[3] = 255
+    fused_vs_oracle(engine, rec, lens, refs, one, 1, CountParams.longsom_defaults())
+    # the count is stricter than the load filter (none here): admission through the per-read bitmap, in the fused pass too
+    fused_vs_oracle(engine, rec, lens, refs, ct_of, 2, CountParams.longsom_defaults(min_mq=60, flag_exclude=0xF04, ignore_orphans=1, min_bq=33))
+    engine.set_load_filter(60, 0x704, 1)
+    try:
+        fused_vs_oracle(engine, rec, lens, refs, ct_of, 2, CountParams.longsom_defaults(), recount_params=[CountParams.longsom_defaults(min_bq=5)])
+    finally:
+        engine.set_load_filter()
+
+
+def test_one_barcode_owning_a_tile_is_left_to_the_wide_walk(engine):
+    lens = [2500]
+    rec, refs, ct_of = make_case(14, 30000, lens, 30, hot_regions=[(0, 700, 760)], hot_frac=0.97, cb_skew=0.9)
+    ct_of[0] = 0
+    fused_vs_oracle(engine, rec, lens, refs, ct_of, 2, CountParams.longsom_defaults())
+
+
+def test_more_than_two_cell_types_and_a_capped_pile_take_the_plain_gather(engine):
+    lens = [5000, 700]
+    rec, refs, ct_of = make_case(31, 20000, lens, 200, n_ct=4, hot_regions=[(0, 2000, 2100)], hot_frac=0.6)
+    fused_vs_oracle(engine, rec, lens, refs, ct_of, 4, CountParams.longsom_defaults(min_dp=3, min_cc=2), expect_fused=False)
+    rec, refs, ct_of = make_case(3, 6000, [4000], 300, hot_regions=[(0, 1000, 1100)], hot_frac=0.9)
+    engine.set_contigs([4000]); engine.load_reference(0, refs[0]); engine.set_barcodes(ct_of, 2)
+    p = CountParams.longsom_defaults(); p.max_depth = 50
+    engine.set_count_at_load(p)
+    try:
+        engine.load_reads(rec)
+    finally:
+        engine.set_count_at_load(None)
+    assert engine.layout_info()[0] == 2                       # the cap could fire: decided by the count itself
+
+
+@pytest.mark.parametrize("seed", range(14))
+def test_random_configuration(engine, seed):
+    rng, lens, n_reads, n_cb, n_ct, kw, cp, call = draw(seed)
+    refs = [random_reference(rng, L) for L in lens]
+    ct_of = rng.integers(0, n_ct, n_cb).astype(np.uint8)
+    if n_cb > 4:
+        ct_of[rng.random(n_cb) < 0.05] = 255
+    rec = random_records(seed + 77, n_reads, lens, n_cb, **kw)
+    fused_vs_oracle(engine, rec, lens, refs, ct_of, n_ct, cp, expect_fused=n_ct <= 2)
+
+
+def test_region_and_device_arrays(engine):
+    """a rank's share: the region is set before the load (tiles outside it are gathered, not counted); arrays generated in HBM"""
+    m = synth.named("C1", n_reads=20_000)
+    engine.set_contigs(m.contig_len); engine.synth_reference(m.seed); engine.set_barcodes(m.celltype_of, 2)
+    p = CountParams.longsom_defaults()
+    engine.set_region()
+    engine.synth_reads(m)
+    whole = engine.pileup_count(p)
+    ref_rows = [engine.fetch_counts(ct) for ct in range(2)]
+    mid = int(m.contig_len[0]) // 2 // 64 * 64
+    parts = []
+    for lo, hi in (((0, 0), (0, mid)), ((0, mid), (len(m.contig_len), 0))):
+        engine.set_region(lo[0], lo[1], hi[0], hi[1])
+        engine.set_count_at_load(p)
+        try:
+            engine.synth_reads(m)
+        finally:
+            engine.set_count_at_load(None)
+        assert engine.layout_info()[0] == 3
+        rows, cols = engine.pileup_count(p)
+        parts.append((rows, cols, [engine.fetch_counts(ct) for ct in range(2)]))
+    engine.set_region()
+    assert parts[0][1] + parts[1][1] == whole[1]
+    for ct in range(2):
+        for j in range(3):
+            np.testing.assert_array_equal(np.concatenate([parts[0][2][ct][j], parts[1][2][ct][j]]), ref_rows[ct][j])
+    rows, cols = engine.pileup_count(p)                       # the whole genome over the store the second (regional) load wrote
+    assert (rows, cols) == whole
