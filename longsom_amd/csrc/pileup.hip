@@ -700,6 +700,7 @@ struct TgArgs {
     const uint32_t* tile_off; const uint32_t* blk_off;
     uint32_t* s0; uint8_t* b8; uint32_t* rd; uint4* store; uint16_t* ext;
     const uint32_t* nchunks;                                          // the plan's number of chunks, still on the device
+    int dbg;                                                          // timing experiments (LSG_TG_DEBUG; results are wrong): 1 no counting, 2 no block stores, 4 no event loads, 8 no LDS crossing
     unsigned long long* stat_slots;
 };
 typedef uint32_t tg_u32x4 __attribute__((ext_vector_type(4)));
@@ -707,103 +708,123 @@ struct __attribute__((packed, aligned(2))) TgU4A2 { tg_u32x4 v; };
 constexpr uint32_t TG_RV_SEGFIRST = 1u << 30, TG_RV_FWD = 1u << 31, TG_RV_READ = TG_RV_SEGFIRST - 1u;      // (store.hip RV_*)
 struct TgKeys { uint64_t k; uint32_t v; };
 struct TgStat { uint32_t ev, sg, ne; };
+struct TgPre { uint32_t bits, ctv, admw; };      // an entry's meta word in the making: flags | bit of its read | events, and the two table words looked up for it
 
 __device__ __forceinline__ void tg_range(const CountArgs& a, const TmArgs& tm, const TgArgs& tg, TmState& st, TgStat& stat, uint32_t s0r, uint32_t s1r, uint32_t base, uint32_t off,
-                                         uint32_t n, bool in_region, bool counting, uint32_t thr, uint32_t pkl0, uint32_t one, int lane, uint16_t (*xt)[8][64]) {
+                                         uint32_t n, bool in_region, bool counting, uint32_t thr, uint32_t pkl0, uint32_t one, int lane, uint16_t (*xt)[8][64], const tg_u32x4 (*tmask)[9]) {
     const uint32_t b0 = s0r >> 3, nblk = ((s1r + 7) >> 3) - b0;
     const int ng = (int)((nblk + TM_GROUP - 1) / TM_GROUP);
     const bool tail = s1r == base + n;                                    // the range that ends its tile also writes the tile's pad entries
     const uint32_t cbm = (1u << tg.cb_bits) - 1u;
     const int eu = lane >> 3, ec = lane & 7;
     auto nt_put = [](auto* q, auto v) { __builtin_nontemporal_store(v, q); };
-    // ---- K
+    // ---- K  (every lane loads, lanes past 33 and entries that are not there from a clamped place: loads outside branches let the
+    //          compiler count them, so that waiting for one group's data leaves the next group's in flight)
     auto load_keys = [&](int g) -> TgKeys {
-        TgKeys r; r.k = 0ull; r.v = 0u;
+        TgKeys r;
         const int64_t i = (int64_t)(b0 + (uint32_t)g * TM_GROUP) * 8 - (int64_t)base + (lane < 32 ? lane : (lane == 32 ? -1 : 32));
-        if (lane < 34 && i >= 0 && i < (int64_t)n) {
-            r.k = __builtin_nontemporal_load(tg.key + off + i);
-            if (lane < 32) r.v = __builtin_nontemporal_load(tg.rdv + off + i);
-        }
+        const uint32_t ic = i < 0 ? 0u : (i >= (int64_t)n ? n - 1u : (uint32_t)i);
+        r.k = __builtin_nontemporal_load(tg.key + off + ic);
+        r.v = __builtin_nontemporal_load(tg.rdv + off + ic);
         return r;
     };
-    // ---- W + E: the entries' words, meta, position masks; the event loads
-    auto words_events = [&](int g, const TgKeys& K, tg_u32x4 (&chunk)[TM_GROUP], uint32_t& M, uint32_t& mlo, uint32_t& mhi) {
+    // ---- W + E: the entries' words, what the meta word needs (its two table look-ups are ISSUED here and read an iteration later:
+    //      finish_meta), the blocks' extents; the event loads.  A chunk is fetched whole from the caller's array, so what it holds beside the
+    //      entry's own events (the read's neighbouring segment) is cleared before it crosses the LDS tile: lh keeps, per block, the
+    //      half-words [lo, hi) of the lane's chunk that are the entry's
+    auto words_events = [&](int g, const TgKeys& K, tg_u32x4 (&chunk)[TM_GROUP], TgPre& pre, uint32_t& lh, uint32_t& xe) {
         const uint32_t p = (b0 + (uint32_t)g * TM_GROUP) * 8 + (uint32_t)lane, i = p - base;
         const bool valid = lane < 32 && i < n;
         const uint32_t cb = (uint32_t)K.k & cbm;
         const uint32_t cb_prev = (uint32_t)__shfl((int)cb, lane == 0 ? 32 : lane - 1), cb_next = (uint32_t)__shfl((int)cb, lane == 31 ? 33 : lane + 1);
-        const uint32_t geom = (uint32_t)(K.k >> tg.cb_bits), first = geom & 63u, nev1 = (geom >> 6) & 63u;
+        const uint32_t geom = (uint32_t)(K.k >> tg.cb_bits), first = valid ? geom & 63u : 0u, nev = valid ? ((geom >> 6) & 63u) + 1u : 0u;
         const uint64_t src = K.k >> (tg.cb_bits + 12);
         const bool rs = i == 0 || cb_prev != cb;
         const bool single = rs && (i + 1 == n || cb_next != cb);
         const bool own = valid && p >= s0r && p < s1r;
         if (own) {
             nt_put(tg.s0 + p, cb | ((K.v & TG_RV_FWD) ? TM_FWD : 0u) | (rs ? TM_RUNSTART : 0u));
-            nt_put(tg.b8 + p, (uint8_t)(nev1 | ((K.v & TG_RV_SEGFIRST) ? 64u : 0u) | (single ? 128u : 0u)));
+            nt_put(tg.b8 + p, (uint8_t)((nev - 1u) | ((K.v & TG_RV_SEGFIRST) ? 64u : 0u) | (single ? 128u : 0u)));
             nt_put(tg.rd + p, K.v & TG_RV_READ);
         } else if (lane < 32 && !valid && tail && p < (b0 + nblk) * 8) {
             nt_put(tg.s0 + p, (uint32_t)TM_PAD_S0); nt_put(tg.b8 + p, (uint8_t)0); nt_put(tg.rd + p, 0u);
         }
-        // what k_tm_resolve writes for the entry under this count (an entry of another range is not there)
-        M = TMM_SKIP;
-        if (own && in_region) {
-            uint32_t cls = 2;
-            bool ok = cb < (uint32_t)a.n_cb;
-            if (ok && a.adm) { const uint32_t r = K.v & TG_RV_READ; ok = (reinterpret_cast<const uint32_t*>(a.adm)[r >> 5] >> (r & 31u)) & 1u; }
-            if (ok) { const uint32_t ct = a.celltype_of[cb]; if (ct < (uint32_t)a.n_ct && (ct >> 1) == (uint32_t)(tm.ct_base >> 1)) cls = ct & 1u; }
-            if (cls < 2) { stat.ev += nev1 + 1u; stat.sg += (K.v & TG_RV_SEGFIRST) ? 1u : 0u; ++stat.ne; }
-            M = cls < 2 ? (cls ? (TMM_CT4 | TMM_CT12) : 0u) | ((K.v & TG_RV_FWD) ? TMM_FWD : 0u) | (single ? TMM_SINGLE : 0u) : TMM_SKIP;
-            if (rs) M |= TMM_RS;
+        const uint32_t r = K.v & TG_RV_READ;
+        // (the aligned word that holds the barcode's cell type: its byte is picked when the word is used, an iteration later - nothing here waits for it)
+        pre.ctv = reinterpret_cast<const uint32_t*>(a.celltype_of)[(cb < (uint32_t)a.n_cb ? cb : 0u) >> 2];
+        pre.admw = a.adm ? reinterpret_cast<const uint32_t*>(a.adm)[(r < (uint32_t)a.n_reads ? r : 0u) >> 5] : 0xffffffffu;
+        pre.bits = (own && in_region && counting ? 1u : 0u) | (cb < (uint32_t)a.n_cb ? 2u : 0u) | ((K.v & TG_RV_FWD) ? 4u : 0u) | (single ? 8u : 0u) | (rs ? 16u : 0u) |
+                   ((r & 31u) << 8) | (nev << 16) | ((K.v & TG_RV_SEGFIRST) ? (1u << 24) : 0u) | (own && in_region ? (1u << 25) : 0u) | ((cb & 3u) << 26);
+        // a block's extent: the positions its entries' ranges cover (lanes 8 q hold block q's)
+        uint32_t xlo = valid ? first : 64u, xhi = first + nev;
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+            const uint32_t l2 = (uint32_t)__shfl_xor((int)xlo, o), h2 = (uint32_t)__shfl_xor((int)xhi, o);
+            xlo = l2 < xlo ? l2 : xlo; xhi = h2 > xhi ? h2 : xhi;
         }
-        if (!counting) M = TMM_SKIP;
-        // positions [first, first + events) of the tile
-        const uint64_t pm = valid ? ((nev1 == 63u ? ~0ull : ((1ull << (nev1 + 1u)) - 1ull)) << first) : 0ull;
-        mlo = (uint32_t)pm; mhi = (uint32_t)(pm >> 32);
-        const uint32_t e_src = (uint32_t)src, e_info = valid ? ((uint32_t)(src >> 32) | (first << 8) | ((nev1 + 1u) << 16)) : 0u;
+        xe = xlo | (xhi << 8);
+        // where position 0 of the tile would lie in the caller's array (the entry's events start `first` further on)
+        const int64_t abase = (int64_t)src - (int64_t)first;
+        const uint32_t e_lo = (uint32_t)abase, e_inf = ((uint32_t)((uint64_t)abase >> 32) & 0xffu) | (first << 8) | ((first + nev) << 16);
+        // the first / last events of the array: a group that holds one of them loads its chunks element by element, never outside the array
+        const bool edge = __ballot(valid && (src < 64ull || (int64_t)src + 128 > tg.n_events)) != 0ull;
+        lh = 0;
 #pragma unroll
         for (int q = 0; q < TM_GROUP; ++q) {
-            chunk[q] = tg_u32x4{0u, 0u, 0u, 0u};
-            const uint32_t lo32 = (uint32_t)__shfl((int)e_src, q * 8 + eu), inf = (uint32_t)__shfl((int)e_info, q * 8 + eu);
-            const uint32_t fp = (inf >> 8) & 63u, nev = inf >> 16, c8 = (uint32_t)ec * 8u;
-            if (c8 < fp + nev && c8 + 8u > fp) {                          // the tile-aligned chunk holds events of the entry
-                const int64_t A = (int64_t)(((uint64_t)(inf & 0xffu) << 32) | lo32) - (int64_t)fp + (int64_t)c8;
-                if (A >= 0 && A + 8 <= tg.n_events) chunk[q] = reinterpret_cast<const TgU4A2*>(tg.events + A)->v;
-                else {                                                    // the first / last events of the array: never read outside it
-                    uint32_t w[4] = {0u, 0u, 0u, 0u};
+            const uint32_t lo32 = (uint32_t)__shfl((int)e_lo, q * 8 + eu), inf = (uint32_t)__shfl((int)e_inf, q * 8 + eu);
+            const int c8 = ec * 8, d0 = (int)((inf >> 8) & 0xffu) - c8, d1 = (int)(inf >> 16) - c8;
+            const uint32_t lok = (uint32_t)(d0 < 0 ? 0 : (d0 > 8 ? 8 : d0)), hik = (uint32_t)(d1 < 0 ? 0 : (d1 > 8 ? 8 : d1));
+            const bool need = lok < hik;                                      // the tile-aligned chunk holds events of the entry
+            lh |= (lok | (hik << 4)) << (8 * q);
+            const int64_t A = (int64_t)(int8_t)(inf & 0xffu) * (1ll << 32) + (int64_t)lo32 + c8;      // (abase may be a little below zero: its bits 32..39 sign-extended)
+            if (__builtin_expect(!edge, 1)) {
+                // chunks nobody needs read the array's first line (one cached line, no branch: the compiler can count the loads in flight)
+                chunk[q] = reinterpret_cast<const TgU4A2*>(tg.events + (need && !(tg.dbg & 4) ? A : 0))->v;
+            } else {
+                uint32_t w[4] = {0u, 0u, 0u, 0u};
+                if (need)
                     for (int k = 0; k < 8; ++k) if (A + k >= 0 && A + k < tg.n_events) w[k >> 1] |= (uint32_t)tg.events[A + k] << (16 * (k & 1));
-                    chunk[q] = tg_u32x4{w[0], w[1], w[2], w[3]};
-                }
+                chunk[q] = tg_u32x4{w[0], w[1], w[2], w[3]};
             }
         }
     };
-    // ---- T: through the LDS tile; the rows to the store and into E
-    auto transpose = [&](int g, const tg_u32x4 (&chunk)[TM_GROUP], uint32_t mlo, uint32_t mhi, tg_u32x4 (&E)[TM_GROUP]) {
-#pragma unroll
-        for (int q = 0; q < TM_GROUP; ++q) *reinterpret_cast<tg_u32x4*>(&xt[q][eu][ec * 8]) = chunk[q];
-        lds_fence();
-#pragma unroll
-        for (int q = 0; q < TM_GROUP; ++q) {
-            E[q] = tg_u32x4{0u, 0u, 0u, 0u};
-            const uint32_t blk = (uint32_t)g * TM_GROUP + q;               // relative to b0
-            if (blk >= nblk) continue;
-            uint32_t e[8], any = 0;
-#pragma unroll
-            for (int uu = 0; uu < 8; ++uu) {
-                const uint64_t pm = ((uint64_t)rl(mhi, q * 8 + uu) << 32) | rl(mlo, q * 8 + uu);
-                const uint32_t raw = xt[q][uu][lane];
-                asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(e[uu]) : "v"(raw), "s"(pm));
-                any |= e[uu];
-            }
-            const unsigned long long m = __ballot(any != 0u);
-            const int first = m ? __ffsll((long long)m) - 1 : 0, last = m ? 64 - __clzll((long long)m) : 0;
-            const tg_u32x4 row = {e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16)};
-            E[q] = row;
-            if ((b0 + blk) * 8 >= s0r) {                                     // this range writes the block
-                if (lane >= first && lane < last) __builtin_nontemporal_store(row, reinterpret_cast<tg_u32x4*>(tg.store) + (uint64_t)(b0 + blk) * 64 + lane);
-                if (lane == 0) tg.ext[b0 + blk] = (uint16_t)(first | (last << 8));
+    // what k_tm_resolve writes for the entry under this count (an entry of another range, or outside the counted region, is not there)
+    auto finish_meta = [&](const TgPre& pre) -> uint32_t {
+        uint32_t M = TMM_SKIP;
+        if (pre.bits & (1u << 25)) {
+            uint32_t cls = 2;
+            bool ok = (pre.bits & 2u) != 0 && ((pre.admw >> ((pre.bits >> 8) & 31u)) & 1u);
+            if (ok) { const uint32_t ct = (pre.ctv >> (((pre.bits >> 26) & 3u) * 8u)) & 0xffu; if (ct < (uint32_t)a.n_ct && (ct >> 1) == (uint32_t)(tm.ct_base >> 1)) cls = ct & 1u; }
+            if (cls < 2) { stat.ev += (pre.bits >> 16) & 0xffu; stat.sg += (pre.bits >> 24) & 1u; ++stat.ne; }
+            if (pre.bits & 1u) {
+                M = cls < 2 ? (cls ? (TMM_CT4 | TMM_CT12) : 0u) | ((pre.bits & 4u) ? TMM_FWD : 0u) | ((pre.bits & 8u) ? TMM_SINGLE : 0u) : TMM_SKIP;
+                if (pre.bits & 16u) M |= TMM_RS;
             }
         }
+        return M;
+    };
+    // ---- T: the chunks, cleared outside their entries, into the LDS tile ([entry][position]); then block by block: lane = position reads
+    //      one event per entry (no index arithmetic, nothing to mask), the row goes to the store and, still in registers, to the counters
+    auto tile_write = [&](tg_u32x4 (&chunk)[TM_GROUP], uint32_t lh) {
+#pragma unroll
+        for (int q = 0; q < TM_GROUP; ++q) {
+            const tg_u32x4 keep = tmask[0][(lh >> (8 * q + 4)) & 15u] & tmask[1][(lh >> (8 * q)) & 15u];      // half-words below hi, and not below lo
+            *reinterpret_cast<tg_u32x4*>(&xt[q][eu][ec * 8]) = chunk[q] & keep;
+        }
         lds_fence();
+    };
+    auto block_row = [&](int g, int q, uint32_t xe) -> tg_u32x4 {
+        const uint32_t blk = (uint32_t)g * TM_GROUP + q;                   // relative to b0 (the caller has checked blk < nblk)
+        uint32_t e[8];
+#pragma unroll
+        for (int uu = 0; uu < 8; ++uu) e[uu] = xt[q][uu][lane];
+        const tg_u32x4 row = {e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16)};
+        if ((b0 + blk) * 8 >= s0r && !(tg.dbg & 2)) {                     // this range writes the block: the rows of its extent
+            const uint32_t x = rl(xe, q * 8), first = x & 0xffu, last = x >> 8;
+            if ((uint32_t)lane - first < last - first) __builtin_nontemporal_store(row, reinterpret_cast<tg_u32x4*>(tg.store) + (uint64_t)(b0 + blk) * 64 + lane);
+            if (lane == 0) tg.ext[b0 + blk] = (uint16_t)x;
+        }
+        return row;
     };
     static_assert(8 * TM_GROUP == 32, "one 32-bit mask per group");
     uint32_t open_in = 0;
@@ -820,32 +841,38 @@ __device__ __forceinline__ void tg_range(const CountArgs& a, const TmArgs& tm, c
         open_in = ((A & segl) != 0u || (!R && open_in)) ? 1u : 0u;
         return M;
     };
-    auto consume = [&](int g, const tg_u32x4 (&E)[TM_GROUP], uint32_t M0) {
-        const uint32_t M = verdicts(M0);
+    auto consume_block = [&](int q, const tg_u32x4& row, uint32_t M) {
 #pragma unroll
-        for (int k = 0; k < TM_GROUP; ++k) {
-            if ((uint32_t)g * TM_GROUP + k >= nblk) break;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const uint32_t m = rl(M, k * 8 + u);
-                if (u & 1) tm_add<true>(st, m, E[k][u >> 1], thr, pkl0, one);
-                else tm_add<false>(st, m, E[k][u >> 1], thr, pkl0, one);
-            }
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t m = rl(M, q * 8 + u);
+            if (u & 1) tm_add<true>(st, m, row[u >> 1], thr, pkl0, one);
+            else tm_add<false>(st, m, row[u >> 1], thr, pkl0, one);
         }
     };
-    tg_u32x4 chunk[TM_GROUP], E[TM_GROUP];
-    uint32_t Mc = TMM_SKIP, Mn = TMM_SKIP, mlo = 0, mhi = 0;
+    // One set of registers per stage and this order: a stage's loads are issued after the previous use of their registers and first read an
+    // iteration later (a copy of a freshly loaded register would make the wave wait for it - and for every load issued before it).  A
+    // group's rows leave the LDS tile one block at a time: four registers of events alive beside the sixteen in flight.
+    tg_u32x4 chunk[TM_GROUP];
+    uint32_t lh = 0, xe = 0;
+    TgPre pre;
     TgKeys K = load_keys(0);
-    words_events(0, K, chunk, Mn, mlo, mhi);
-    if (ng > 1) K = load_keys(1);
+    words_events(0, K, chunk, pre, lh, xe);
+    K = load_keys(ng > 1 ? 1 : 0);
     for (int g = 0; g < ng; ++g) {
-        transpose(g, chunk, mlo, mhi, E);
-        Mc = Mn;
+        tile_write(chunk, lh);                                // waits for the events of group g (issued an iteration ago)
+        const uint32_t Mc = verdicts(finish_meta(pre));    // ... whose look-ups were issued with them
+        const uint32_t xe_g = xe;
         if (g + 1 < ng) {
-            words_events(g + 1, K, chunk, Mn, mlo, mhi);
-            if (g + 2 < ng) K = load_keys(g + 2);
+            words_events(g + 1, K, chunk, pre, lh, xe);
+            K = load_keys(g + 2 < ng ? g + 2 : ng - 1);
         }
-        if (counting) consume(g, E, Mc);
+#pragma unroll
+        for (int q = 0; q < TM_GROUP; ++q) {
+            if ((uint32_t)g * TM_GROUP + q >= nblk) break;
+            const tg_u32x4 row = block_row(g, q, xe_g);
+            if (counting && !(tg.dbg & 1)) consume_block(q, row, Mc);
+        }
+        lds_fence();                                          // the tile is read before the next group's chunks are written into it
     }
     if (counting) { st.nc += st.mask & 0x10001u; st.mask = 0; }
 }
@@ -857,6 +884,7 @@ __global__ __launch_bounds__(TMW_WAVES * 64) __attribute__((amdgpu_waves_per_eu(
     __shared__ __attribute__((aligned(8192))) uint32_t planes[2][2][8 * 64];
     __shared__ uint32_t nc_sh[2][64];
     __shared__ __attribute__((aligned(16))) uint16_t xts[TMW_WAVES][TM_GROUP][8][64];      // the waves' transposition tiles
+    __shared__ __attribute__((aligned(16))) tg_u32x4 tmask[2][9];                         // [0][x]: the first x half-words of a chunk; [1][x]: all but them
     __shared__ WaveBook books[TMW_WAVES];
     __shared__ uint32_t s_ck;
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -864,6 +892,12 @@ __global__ __launch_bounds__(TMW_WAVES * 64) __attribute__((amdgpu_waves_per_eu(
     WaveBook& book = books[wv];
     book_init(book, lane);
     if (lane == 0) book.src = 1;
+    if (threadIdx.x < 18) {
+        const uint32_t x = threadIdx.x % 9u, inv = threadIdx.x >= 9 ? 0xffffffffu : 0u;
+        uint32_t w[4];
+        for (uint32_t d = 0; d < 4; ++d) w[d] = ((2u * d < x ? 0xffffu : 0u) | (2u * d + 1u < x ? 0xffff0000u : 0u)) ^ inv;
+        tmask[threadIdx.x / 9u][x] = tg_u32x4{w[0], w[1], w[2], w[3]};
+    }
     const uint32_t thr = bq_threshold(a), pkl0 = lds_addr(pl + lane);
     uint32_t one = 1u;
     asm volatile("" : "+v"(one));
@@ -897,7 +931,7 @@ __global__ __launch_bounds__(TMW_WAVES * 64) __attribute__((amdgpu_waves_per_eu(
             TmState st; st.nc = 0; st.mask = 0;
             const uint32_t s0r = wv ? emid : e0, s1r = wv ? e1 : emid;
             if (s1r > s0r) {
-                tg_range(a, tm, tg, st, stat, s0r, s1r, base, off, tcnt, in_region, counting, thr, pkl0, one, lane, xts[wv]);
+                tg_range(a, tm, tg, st, stat, s0r, s1r, base, off, tcnt, in_region, counting, thr, pkl0, one, lane, xts[wv], tmask);
                 if (counting) {
                     if (st.nc & 0xffffu) atomicAdd(&nc_sh[0][lane], st.nc & 0xffffu);
                     if (st.nc >> 16) atomicAdd(&nc_sh[1][lane], st.nc >> 16);
@@ -1161,6 +1195,7 @@ int run_gather_count(lsg_ctx* c, const lsg_count_params* p, const GatherCountSrc
     tg.s0 = c->tm[TM_S0].as<uint32_t>(); tg.b8 = c->tm[TM_B].as<uint8_t>(); tg.rd = c->tm[TM_RD].as<uint32_t>();
     tg.store = c->tm[TM_STORE].as<uint4>(); tg.ext = c->tm[TM_EXT].as<uint16_t>();
     tg.nchunks = c->d_plan_misc + 1; tg.stat_slots = c->d_ix_stat.as<unsigned long long>();
+    tg.dbg = getenv("LSG_TG_DEBUG") ? atoi(getenv("LSG_TG_DEBUG")) : 0;
     L.tm.ct_base = 0;
     const bool dbg = getenv("LSG_DEBUG_SYNC") != nullptr;
     auto stage = [&](const char* what) { if (dbg) { const hipError_t e = hipStreamSynchronize(st); fprintf(stderr, "[lsg] fused load: %s: %s\n", what, hipGetErrorString(e)); fflush(stderr); } };

@@ -645,7 +645,7 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
     // The first count in the same pass (lsg_set_count_at_load): when its parameters and the barcode table are known now, the depth cap
     // cannot fire (the all-reads bound came with the early look) and one pass covers the cell types, the gather below is replaced by
     // pileup.hip's k_tm_gather_count, which builds the same store and counts while each block is in registers.
-    bool fused = c->cal_enabled && c->n_ct >= 1 && c->n_ct <= 2 && c->n_cb > 0 && c->copy_stream && !getenv("LSG_NO_FUSED_LOAD");
+    bool fused = c->cal_enabled && c->n_ct >= 1 && c->n_ct <= 2 && c->n_cb > 0 && c->copy_stream && n_events >= 64 && n_events < (1ll << 39) && !getenv("LSG_NO_FUSED_LOAD");
     if (fused) {
         const lsg_count_params& q = c->cal_params;
         if (q.min_mq < c->st_min_mq || (c->st_flag_exclude & ~q.flag_exclude) != 0 || (c->st_ignore_orphans && !q.ignore_orphans)) fused = false;       // (the count would be refused)
