@@ -14,10 +14,13 @@
            estimated work; every rank loads the reads overlapping its region, counts only its own
            columns and the ranks all-gather their PASS-candidate call rows over RCCL.
 
-One JSON line on rank 0.  `roofline` is for the kernel that takes the most time of a step (k_tm_gather, the store build's event
-gather, or k_tm_walk, the count's walk): its algorithmic bytes over its HIP-event time on its own stream (both kernels' figures are
-in config.kernels).  `config.recount_ms` is a count + call pass over the SAME resident store (what the second pass of the
-re-annotation loop pays).  `cpu_baseline` times the CPU oracle (oracle/, kind "port") on a bounded sample of the same workload on
+One JSON line on rank 0.  `roofline` is for the kernel that takes the most time of a step - k_tm_gather_count, the pass that lays the
+events out per column and counts them while it holds them (lsg_set_count_at_load) - priced by SURVEY 8(d)'s bytes alone: 2 B per
+admitted event + 24 B per admitted read + 168 B per row it emits (the store it also writes, sort scratch and re-reads are NOT
+algorithmic), over its HIP-event time on its own stream.  `roofline.path_frac` prices the WHOLE step the same way: (2 E + 24 R +
+168 S_emit) / ms_per_step / peak.  `roofline.step_traffic` is the fabric traffic of every kernel of a step from the newest profiles/
+file recorded for this build (sum and its ratio to the algorithmic bytes).  `config.recount_ms` is a count + call pass over the SAME
+resident store (what the second pass of the re-annotation loop pays).  `cpu_baseline` times the CPU oracle (oracle/, kind "port") on a bounded sample of the same workload on
 ALL of this box's host cores.  `roofline.traffic` is quoted from the newest profiles/ file only when that file was recorded for
 this build of the kernels (else null + traffic_stale).
 """
@@ -164,7 +167,10 @@ def cpu_baseline(eng, model, target_reads=150_000, call_sites=10_000):
 
 def end_to_end(n_reads):
     """files in -> every output file (pipeline.run_snv: ingest, count, merge, steps 1-3, all tables written), measured in THIS run on a
-    BAM written in this run: C2's model at n_reads reads.  After the timed steps, on rank 0 at N=1; never part of `value`."""
+    BAM written in this run: C2's model at n_reads reads (default: all 10 M of the metric's BAM).  The count rows that come back from
+    the device on their way to the tables are hashed and compared with the digests the CPU oracle wrote for this workload
+    (tests/golden/rows_hash_oracle_c2_<reads>.json: tools/oracle_hashes.py; calls_hash_oracle_*.json's totals): `tables_match_oracle`.
+    After the timed steps, on rank 0 at N=1; never part of `value`."""
     import shutil
     import tempfile
     from longsom_amd import hostio, pipeline
@@ -175,10 +181,21 @@ def end_to_end(n_reads):
         t0 = time.time(); hostio.synth_bam(m, bam, fa); t_bam = time.time() - t0
         hostio.write_barcodes_tsv(bct, hostio.synth_barcodes(m), m.celltype_of, ["Cancer", "Non-Cancer"])
         t0 = time.time()
-        out = pipeline.run_snv(bam, bct, fa, os.path.join(d, "out"), "S")
-        wall = time.time() - t0
+        out = pipeline.run_snv(bam, bct, fa, os.path.join(d, "out"), "S", params=pipeline.SnvParams(row_digests=True))
+        wall = time.time() - t0 - float(out.timings.get("row_digests", 0.0))          # (the check itself is not part of the run)
         mb = lambda ps: round(sum(os.path.getsize(q) for q in ps) / 1e6, 1)
-        return {"measured": "in this run", "workload": "C2's model at %d reads x %d barcodes as a BAM of %.0f MB + FASTA + barcodes.tsv, written in this run (%.1f s, not counted); "
+        match, pin_of = None, None
+        pin = os.path.join(ROOT, "tests", "golden", "rows_hash_oracle_c2_%d.json" % n_reads)
+        if os.path.exists(pin) and out.row_digests:
+            want = json.load(open(pin)); got = out.row_digests
+            match = got["rows"] == want["rows"] and got["columns"] == want["columns"] and all(got["ct%d" % ct] == want["ct%d" % ct] for ct in range(2))
+            pin_of = os.path.relpath(pin, ROOT)
+            cpin = os.path.join(ROOT, "tests", "golden", "calls_hash_oracle_c2_%d.json" % n_reads)
+            if os.path.exists(cpin):
+                cw = json.load(open(cpin))
+                match = match and got["merged_sites"] == cw["merged_sites"] and got["candidate_rows"] == cw["candidate_rows"]
+                pin_of += " + " + os.path.relpath(cpin, ROOT) + " (merged sites, candidate rows)"
+        return {"measured": "in this run", "tables_match_oracle": match, "oracle_pin": pin_of, "workload": "C2's model at %d reads x %d barcodes as a BAM of %.0f MB + FASTA + barcodes.tsv, written in this run (%.1f s, not counted); "
                                                        "BAM -> per-cell-type count tables, merged table, step-1/2/3 tables on disk" % (n_reads, m.n_cb, os.path.getsize(bam) / 1e6, t_bam),
                 "wall_s": round(wall, 2), "seconds": {k: round(float(v), 3) for k, v in out.timings.items()},
                 "out_MB": {"counts": mb(out.counts.values()), "merged": mb([out.merged]), "step1": mb([out.step1])},
@@ -190,8 +207,10 @@ def end_to_end(n_reads):
         shutil.rmtree(d, ignore_errors=True)
 
 
-# rocprofv3's names of the two candidates for "dominant kernel"
-PMC_KERNEL = {"k_tm_walk": "lsg::k_tm_walk", "k_tm_gather": "lsg::k_tm_gather"}
+# rocprofv3's names of the candidates for "dominant kernel"
+PMC_KERNEL = {"k_tm_walk": "lsg::k_tm_walk", "k_tm_gather": "lsg::k_tm_gather", "k_tm_gather_count": "lsg::k_tm_gather_count"}
+# kernels that are not part of a step (the generator, the memo table of the call stage: once per process)
+NOT_IN_A_STEP = ("k_synth", "k_tail_table", "calib_")
 
 
 def csrc_digest():
@@ -211,19 +230,25 @@ def recorded_traffic(kernel):
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
     if not files:
-        return None, None, None
+        return None, None, None, None
     f = files[-1]
     try:
         d = json.load(open(f))
-        k = next((v for n, v in d["kernels"].items() if PMC_KERNEL[kernel] in n), None)
+        k = next((v for n, v in d["kernels"].items() if n.split("#")[0] == PMC_KERNEL[kernel]), None)
         rel = os.path.relpath(f, ROOT)
         if d.get("_csrc_sha1") != csrc_digest():
-            return None, "%s was recorded for another build of longsom_amd/csrc (sha1 %s)" % (rel, str(d.get("_csrc_sha1"))[:12]), True
+            return None, "%s was recorded for another build of longsom_amd/csrc (sha1 %s)" % (rel, str(d.get("_csrc_sha1"))[:12]), True, None
+        step = None
+        loads = d.get("_loads")
+        if loads:                                                  # every kernel of a step, launches per step x bytes per launch
+            per = {n.split("#")[0] + ("#" + n.split("#")[1] if n.startswith("rocprim") else ""): v["traffic_bytes"] * v["launches"] / loads
+                   for n, v in d["kernels"].items() if v.get("traffic_bytes") and not any(x in n for x in NOT_IN_A_STEP)}
+            step = {"kernels_GB": {n: round(b / 1e9, 3) for n, b in sorted(per.items(), key=lambda kv: -kv[1])}, "sum_bytes": sum(per.values())}
         if k and k.get("traffic_bytes"):
-            return k["traffic_bytes"], rel + ": FETCH_SIZE (x calibrated gfx950 correction) + WRITE_SIZE, separate --pmc passes, bytes per launch", False
+            return k["traffic_bytes"], rel + ": FETCH_SIZE (x calibrated gfx950 correction) + WRITE_SIZE, separate --pmc passes, bytes per launch", False, step
     except (OSError, ValueError, KeyError):
         pass
-    return None, None, None
+    return None, None, None, None
 
 
 def main():
@@ -233,8 +258,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--reads", type=float, default=None, help="override the read count (development only; the reported config changes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-recount", action="store_true", help="leave the re-counts of the resident store after the timed steps out (profiling runs: every kernel launch then belongs to a step)")
     ap.add_argument("--e2e-reads", type=float, default=None,
-                    help="reads of the end-to-end leg (files in -> files out, after the timed steps, N=1 only); 0 = none; default 1e6 (none with --reads)")
+                    help="reads of the end-to-end leg (files in -> files out, after the timed steps, N=1 only); 0 = none; default 1e7 = the metric's whole BAM (none with --reads)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))
@@ -351,17 +377,19 @@ def main():
     t0 = time.perf_counter()
     walk_ms, walk_bytes, path_bytes, gather_ms, gather_bytes = 0.0, 0.0, 0.0, 0.0, 0.0
     build_ms = np.zeros(4)
+    fused = False
     for _ in range(args.steps):
         rows, cols, n_sites, n_cand, n_pass = step()
         st = eng.count_stats()
         bt = eng.build_times()
-        walk_ms += st.ms_walk
-        # k_tm_walk reads every stored event of the counted region once and emits the rows of the single-job tiles (2 B per
-        # event + 24 B per read + 168 B per emitted row); k_tm_gather reads every event once from the compact array and writes it once
+        fused = eng.layout_info()[0] == 3                          # the load made the count (k_tm_gather_count)
+        walk_ms += st.ms_walk                                      # HIP events around the counting kernel: k_tm_gather_count, or k_tm_walk after a plain load
+        # 2 B per admitted event + 24 B per admitted read + 168 B per emitted row - the counting kernel reads every event of
+        # the counted region once and emits the rows of the single-job tiles; the plain gather (two-pass loads) reads every stored event once
         walk_bytes += 2.0 * st.n_events_admitted + 24.0 * st.n_reads_admitted + 168.0 * st.rows_by_kernel[1]
         path_bytes += 2.0 * st.n_events_admitted + 24.0 * st.n_reads_admitted + 168.0 * sum(rows)
         gather_ms += bt[3]
-        gather_bytes += 4.0 * eng.store_shape()[2]
+        gather_bytes += 2.0 * eng.store_shape()[2]
         build_ms += np.array(bt)
     torch.cuda.synchronize()
     if dist_on:
@@ -371,17 +399,19 @@ def main():
     # after the clock: counts of the SAME resident store (the re-annotation loop's second pass, a parameter sweep)
     torch.cuda.synchronize()
     t_re = time.perf_counter()
-    n_re = 5
+    n_re = 0 if args.no_recount else 5
+    re_walk_ms = 0.0
     for _ in range(n_re):
         re_rows, re_cols, re_sites, re_cand, _ = step(load=False)
+        re_walk_ms += eng.count_stats().ms_walk
     torch.cuda.synchronize()
-    recount_ms = (time.perf_counter() - t_re) / n_re * 1e3
-    if not os.environ.get("LSG_TG_DEBUG"):                          # (kernel timing experiments give wrong counts on purpose)
+    recount_ms = (time.perf_counter() - t_re) / max(n_re, 1) * 1e3 if n_re else None
+    if n_re and not os.environ.get("LSG_TG_DEBUG"):                 # (kernel timing experiments give wrong counts on purpose)
         assert (re_rows, re_cols, re_sites, re_cand) == (rows, cols, n_sites, n_cand), "a re-count of the resident store differs from the first count"
     if os.environ.get("LSG_BENCH_STATS"):                           # the last step's counters, for whoever tunes the kernels
         print({f: (list(getattr(st, f)) if f.endswith("by_kernel") else getattr(st, f)) for f, _ in st._fields_ if f != "pad_"}, file=sys.stderr)
     e2e = None
-    e2e_reads = int(args.e2e_reads) if args.e2e_reads is not None else (1_000_000 if args.reads is None else 0)
+    e2e_reads = int(args.e2e_reads) if args.e2e_reads is not None else (10_000_000 if args.reads is None else 0)
     if rank == 0 and world == 1 and e2e_reads > 0:
         e2e = end_to_end(e2e_reads)
     if dist_on:
@@ -402,14 +432,22 @@ def main():
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         sites = tot[1]
-        kernels = {"k_tm_walk": {"avg_launch_ms": walk_ms / args.steps, "algorithmic_bytes_per_launch": walk_bytes / args.steps,
-                                 "achieved_GBps": walk_bytes / max(walk_ms, 1e-9) / 1e6},
-                   "k_tm_gather": {"avg_launch_ms": gather_ms / args.steps, "algorithmic_bytes_per_launch": gather_bytes / args.steps,
-                                   "achieved_GBps": gather_bytes / max(gather_ms, 1e-9) / 1e6}}
-        dom = max(kernels, key=lambda k: kernels[k]["avg_launch_ms"])
-        traffic, traffic_src, traffic_stale = (None, None, None)
+        count_kernel = "k_tm_gather_count" if fused else "k_tm_walk"
+        kernels = {count_kernel: {"avg_launch_ms": walk_ms / args.steps, "algorithmic_bytes_per_launch": walk_bytes / args.steps,
+                                  "achieved_GBps": walk_bytes / max(walk_ms, 1e-9) / 1e6,
+                                  "what": "SURVEY 8(d) bytes of the count it makes: 2 B x admitted events + 24 B x admitted reads + 168 B x rows it emits"}}
+        if not fused:                                              # two-pass loads: the store build's gather is a kernel of its own (priced at the 2 B per stored event it reads)
+            kernels["k_tm_gather"] = {"avg_launch_ms": gather_ms / args.steps, "algorithmic_bytes_per_launch": gather_bytes / args.steps,
+                                      "achieved_GBps": gather_bytes / max(gather_ms, 1e-9) / 1e6}
+        elif n_re:                                                 # the walk of the re-counts after the clock (same bytes, read from the store)
+            kernels["k_tm_walk (re-count of the resident store, after the timed steps)"] = {
+                "avg_launch_ms": re_walk_ms / n_re, "algorithmic_bytes_per_launch": walk_bytes / args.steps, "achieved_GBps": walk_bytes / args.steps / max(re_walk_ms / n_re, 1e-9) / 1e6}
+        dom = max((k for k in kernels if "re-count" not in k), key=lambda k: kernels[k]["avg_launch_ms"])
+        traffic, traffic_src, traffic_stale, step_traffic = (None, None, None, None)
         if world == 1 and args.reads is None:
-            traffic, traffic_src, traffic_stale = recorded_traffic(dom)
+            traffic, traffic_src, traffic_stale, step_traffic = recorded_traffic(dom)
+        if step_traffic:
+            step_traffic["over_algorithmic"] = step_traffic["sum_bytes"] / (path_bytes / args.steps)
         achieved = kernels[dom]["achieved_GBps"]
         bm = build_ms / args.steps
         out = {
@@ -426,15 +464,21 @@ def main():
                        "exchange": "one all-gather per step (%s), %d-row slots agreed in warm-up" % (backend, gather["cap"]) if dist_on else None,
                        "path_algorithmic_GBps_rank0": path_bytes / dt / 1e9,
                        "step_parts_ms_rank0": {"load_wall": round(layout_ms, 2), "build_capacities_scatter": round(float(bm[0]), 2), "build_sort": round(float(bm[1]), 2),
-                                               "build_entry_words": round(float(bm[2]), 2), "build_gather": round(float(bm[3]), 2),
-                                               "count": round(float(st.ms_total), 2), "count_walk": round(float(st.ms_walk), 2)},
-                       "recount_ms": round(recount_ms, 2),                 # count + call over the SAME resident store: NOT what value is computed from
+                                               "build_block_tables": round(float(bm[2]), 2),
+                                               ("build_plan_gather_count" if fused else "build_gather"): round(float(bm[3]), 2),
+                                               ("count_kernel_inside_the_load" if fused else "count_walk"): round(float(st.ms_walk), 2),
+                                               "count_total": round(float(st.ms_total), 2)},
+                       "one_pass_load_and_count": bool(fused),
+                       "recount_ms": None if recount_ms is None else round(recount_ms, 2),                 # count + call over the SAME resident store: NOT what value is computed from
                        "resident_GB_rank0": round(layout_bytes / 1e9, 2),     # store + per-read / per-segment arrays + cached build temporaries
                        "store_entries_rank0": eng.store_shape()[0], "store_events_rank0": eng.store_shape()[2],
                        "kernels": kernels, "end_to_end": e2e},                # measured in this run (or null): never a quoted file
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale,
-                         "avg_launch_ms": kernels[dom]["avg_launch_ms"], "algorithmic_bytes_per_launch": kernels[dom]["algorithmic_bytes_per_launch"]},
+                         "avg_launch_ms": kernels[dom]["avg_launch_ms"], "algorithmic_bytes_per_launch": kernels[dom]["algorithmic_bytes_per_launch"],
+                         # the whole step by SURVEY 8(d)'s bytes: (2 E + 24 R + 168 S_emit) / ms_per_step
+                         "path_algorithmic_bytes_per_step": path_bytes / args.steps, "path_achieved": path_bytes / dt / 1e9, "path_frac": path_bytes / dt / 1e9 / HBM_PEAK_GBS,
+                         "step_traffic": step_traffic},
         }
         if base is not None:
             out["cpu_baseline"] = base

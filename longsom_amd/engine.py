@@ -157,7 +157,13 @@ class Engine:
 
     def set_barcodes(self, celltype_of, n_celltypes: int):
         ct = np.ascontiguousarray(celltype_of, dtype=np.uint8)
+        # the table that is already set stays as it is (setting one drops the resident count: the one a load made under
+        # set_count_at_load would be counted again)
+        last = getattr(self, "_table", None)
+        if last is not None and last[1] == int(n_celltypes) and np.array_equal(last[0], ct):
+            return
         _lib.check(self._lib.lsg_set_barcodes(self._h, _ptr(ct), len(ct), int(n_celltypes)), "lsg_set_barcodes")
+        self._table = (ct.copy(), int(n_celltypes))
         self.n_ct = int(n_celltypes)
         self.n_cb = len(ct)
 

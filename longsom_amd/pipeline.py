@@ -44,6 +44,7 @@ class SnvParams:
     alpha2: float = 0.2474528917555431
     beta2: float = 162.03696139428595
     reference_gz_compat: bool = False      # True reproduces SURVEY quirk Q1 (.gz position sets read as empty)
+    row_digests: bool = False              # also hash the count rows as they come back from the device (SnvOutputs.row_digests; bench.py checks them against the CPU oracle's)
 
     def count(self) -> CountParams:
         return CountParams.longsom_defaults(min_bq=self.min_bq, min_mq=self.min_mapping_quality, min_dp=self.min_dp, min_cc=self.min_cc,
@@ -65,6 +66,7 @@ class SnvOutputs:
     step3: str
     step3_unfiltered: str
     timings: Dict[str, float] = field(default_factory=dict)
+    row_digests: Optional[dict] = None     # SnvParams.row_digests: rows, columns and xxhash of (keys, reference bases, counters) per cell type, as tools/oracle_hashes.py writes them
     _pending: list = field(default_factory=list, repr=False, compare=False)
     resident: Optional[dict] = field(default=None, repr=False, compare=False)      # a rank's region and decode summary (sharded two-pass loop)
 
@@ -113,11 +115,21 @@ PILEUP_MAX_DEPTH = 200000   # bam.pileup(..., max_depth = 200000), BaseCellCount
 
 
 def load_sample(bam: str, barcodes_tsv: str, ref_fasta: str, engine: Engine, min_mapq: int, allow_depth_overflow: Optional[bool] = None,
-                ingest: Optional[str] = None) -> Resident:
-    """ingest: "device" = the BAM's bytes go to the GPU and are inflated, decoded and laid out there (lsg_load_bam); "host" = the host
+                ingest: Optional[str] = None, count_params: Optional[CountParams] = None) -> Resident:
+    """count_params: the parameters of the count that follows, when the caller knows them (every fused rule does): the load then makes
+    that count in the pass that builds the store (Engine.set_count_at_load) and the first pileup_count under them costs nothing.
+    ingest: "device" = the BAM's bytes go to the GPU and are inflated, decoded and laid out there (lsg_load_bam); "host" = the host
     decoder (liblongsom_io) + lsg_load_reads; "auto" (default, or LONGSOM_INGEST) = device, and host for a BAM whose records are not
     aligned to its BGZF blocks (not written by htslib).  Same store, same report either way (tests/test_ingest_gpu.py)."""
     ingest = ingest or os.environ.get("LONGSOM_INGEST", "auto")
+    engine.set_count_at_load(count_params)
+    try:
+        return _load_sample(bam, barcodes_tsv, ref_fasta, engine, min_mapq, ingest)
+    finally:
+        engine.set_count_at_load(None)
+
+
+def _load_sample(bam: str, barcodes_tsv: str, ref_fasta: str, engine: Engine, min_mapq: int, ingest: str) -> Resident:
     t = {}
     t0 = time.time()
     bc = hostio.read_barcodes(barcodes_tsv)
@@ -182,7 +194,7 @@ def chain_step1(res: Resident, celltype_of: np.ndarray, celltype_names: List[str
     t = dict(res.seconds)
     t0 = time.time()
     eng.set_barcodes(celltype_of, len(celltype_names))
-    eng.pileup_count(params.count())
+    n_rows, n_cols = eng.pileup_count(params.count())
     n_sites, n_cand = eng.call_step1(params.call())
     t["gpu_count_call"] = time.time() - t0
     t0 = time.time()
@@ -199,6 +211,13 @@ def chain_step1(res: Resident, celltype_of: np.ndarray, celltype_names: List[str
     per_ct = [eng.fetch_counts(ct) for ct in range(len(celltype_names))]
     calls = eng.fetch_calls()
     t["fetch"] = time.time() - t0
+    if params.row_digests:
+        import xxhash
+        t0 = time.time()
+        out.row_digests = {"rows": [int(x) for x in n_rows], "columns": int(n_cols), "merged_sites": int(n_sites), "candidate_rows": int(n_cand)}
+        for ct in range(len(celltype_names)):
+            out.row_digests["ct%d" % ct] = [xxhash.xxh64(np.ascontiguousarray(x).tobytes() if x.size < (1 << 20) else memoryview(np.ascontiguousarray(x)).cast("B")).hexdigest() for x in per_ct[ct]]
+        t["row_digests"] = time.time() - t0
     t0 = time.time()
     date = tsvio.file_date()
     for ct, name in enumerate(celltype_names):
@@ -273,7 +292,7 @@ def run_snv(bam: str, barcodes_tsv: str, ref_fasta: str, out_dir: str, sample_id
                              "use one or the other" % comm.world)
         if comm.world > 1 or window_bytes:
             return _run_snv_regions(bam, barcodes_tsv, ref_fasta, out_dir, sample_id, params, editing, pon_sr, pon_lr, gnomad_af_json, eng, comm, window_bytes)
-        res = load_sample(bam, barcodes_tsv, ref_fasta, eng, params.min_mapping_quality)
+        res = load_sample(bam, barcodes_tsv, ref_fasta, eng, params.min_mapping_quality, count_params=params.count())
         return run_chain(res, res.table.celltype_of, res.table.celltype_names, res.dec.report, out_dir, sample_id, params, editing, pon_sr, pon_lr,
                          gnomad_af_json)
     finally:

@@ -42,6 +42,14 @@ def candidate_text_digest(eng, m, candidates_only=False):
     from longsom_amd import tsvio
     per_ct = [eng.fetch_counts(ct) for ct in range(2)]
     calls = eng.fetch_calls(candidates_only=candidates_only)
+    if candidates_only:                                            # (the writer wants a call record for every merged site of the rows it is given: the candidate sites' rows)
+        ck = np.ascontiguousarray(calls["key"])
+        sub = []
+        for k, r, c in per_ct:
+            i = np.searchsorted(ck, k)
+            keep = (i < len(ck)) & (ck[np.minimum(i, len(ck) - 1)] == k)
+            sub.append((k[keep], r[keep], c[keep]))
+        per_ct = sub
     text = tsvio.write_step1_tsv("/dev/null", calls, per_ct, m.contig_names, ["Cancer", "Non-Cancer"], [], header=False, as_bytes=True)
     sc = tsvio.scan_rows(text, m.contig_names)
     tid = sc.key >> 32

@@ -6,10 +6,17 @@
 usage: python tools/summarize_profiles.py r01"""
 import collections, csv, json, os, shutil, sys
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from kernel_names import short_kernel_name
+
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src, dst = "gpurun_out/prof", "profiles"
 os.makedirs(dst, exist_ok=True)
-shutil.copy(f"{src}/trace/bench_kernel_stats.csv", f"{dst}/{tag}_bench_kernel_stats.csv")
+with open(f"{dst}/{tag}_bench_kernel_stats.csv", "w", newline="") as fo:      # rocprofv3 --stats, the kernels under short unique names (tools/kernel_names.py)
+    w = csv.writer(fo)
+    w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+    for r in csv.DictReader(open(f"{src}/trace/bench_kernel_stats.csv")):
+        w.writerow([short_kernel_name(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
 line = [l for l in open(f"{src}/bench_under_rocprof.json") if l.startswith("{")][-1]
 json.dump(json.loads(line), open(f"{dst}/{tag}_bench_under_rocprof.json", "w"), indent=1)
 
@@ -39,15 +46,17 @@ out = {"_method": "separate rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | TC
 sys.path.insert(0, ".")
 import bench
 out["_csrc_sha1"] = bench.csrc_digest()
+# loads (= steps incl. warm-up) of the profiled run: launches / _loads = a kernel's launches per step (the run makes no re-counts: --no-recount)
+out["_loads"] = max((len(v["FETCH_SIZE"]) for k, v in fetch.items() if "k_seg_static" in k), default=None)
 for k in sorted(set(fetch) | set(write) | set(rdreq)):
     f, w = avg(fetch[k]["FETCH_SIZE"]), avg(write[k]["WRITE_SIZE"])
     r = rdreq.get(k, {})
     sized = None
     if r:
         sized = 32 * avg(r["TCC_EA0_RDREQ_32B_sum"]) + 64 * avg(r["TCC_EA0_RDREQ_64B_sum"]) + 128 * avg(r["TCC_EA0_RDREQ_128B_sum"])
-    if (f or 0) * 1024 < 5e7 and (w or 0) * 1024 < 5e7:
+    if (f or 0) * 1024 < 2e6 and (w or 0) * 1024 < 2e6:
         continue
-    out["kernels"][k.split("(")[0]] = {
+    out["kernels"][short_kernel_name(k)] = {
         "launches": len(fetch[k]["FETCH_SIZE"]), "FETCH_SIZE_KB_avg": f, "WRITE_SIZE_KB_avg": w,
         "read_bytes_corrected": None if f is None else f * 1024 * factor, "read_bytes_from_sized_rdreq": sized,
         "write_bytes": None if w is None else w * 1024,
