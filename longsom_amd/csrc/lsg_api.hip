@@ -289,6 +289,7 @@ int lsg_set_region(lsg_ctx* c, int32_t tid_lo, int64_t pos_lo, int32_t tid_hi, i
     };
     uint64_t lo = tile_of(tid_lo, pos_lo), hi = tile_of(tid_hi, pos_hi);
     if (hi < lo) { set_error("lsg_set_region: empty or inverted region"); return -2; }
+    if (c->tile_lo == (uint32_t)lo && c->tile_hi == (uint32_t)hi) return 0;      // (the region that is set: a resident count stays)
     c->tile_lo = (uint32_t)lo; c->tile_hi = (uint32_t)hi;
     c->counted = c->called = false;
     return 0;

@@ -424,13 +424,23 @@ def _run_snv_regions(bam, barcodes_tsv, ref_fasta, out_dir, sample_id, params, e
                 plan = regions.BaiPlan(hostio.read_bai(bai), len(names_b), comm.world, os.path.getsize(bam))
                 bounds = plan.bounds
                 lo, hi = bounds[comm.rank], bounds[comm.rank + 1]
-                got, ok = None, 1
+                got, ok, fatal = None, 1, None
                 try:
-                    got = regions.ingest_slice(eng, bam, plan, lo, hi, bc.barcodes, params.min_mapping_quality)
+                    # the rank's region and the count's parameters are known before its slice is loaded: the load counts in the same pass
+                    eng.set_region(lo[0], lo[1], hi[0], hi[1])
+                    eng.set_count_at_load(params.count())
+                    try:
+                        got = regions.ingest_slice(eng, bam, plan, lo, hi, bc.barcodes, params.min_mapping_quality)
+                    finally:
+                        eng.set_count_at_load(None)
                 except _lib.LsgError as e:
-                    if "straddle" not in str(e):
-                        raise
-                    ok = 0
+                    if "straddle" in str(e):
+                        ok = 0
+                    else:
+                        fatal = e
+                except BaseException as e:                     # noqa: BLE001 - an index that is not this BAM's, a corrupt block, no memory ...
+                    fatal = e
+                comm.agree(fatal, "the ingest of a rank's slice of %s" % bam)      # (every rank raises when one did: nobody waits in the all-reduce below)
                 n_cb = len(bc.barcodes)
                 if int(comm.allreduce_sum(np.asarray([ok], np.int64))[0]) == comm.world:
                     counts = np.zeros(5 + 2 * n_cb + 2 * comm.world, np.int64)      # SplitBam's counters, the tallies, and per rank: records and bytes of its slice
@@ -522,52 +532,58 @@ def _run_snv_regions(bam, barcodes_tsv, ref_fasta, out_dir, sample_id, params, e
         out2 = calling.step2_bytes(s2_state["head"] + rows, eng, contig["names"], k[0], k[1], k[2], 0, s2_state["af"], params.max_gnomad_vaf)
         return out2[s2_state["head_out"]:]
     n_windows = 0
-    for lo, hi, rec, dec in work:
-        if not contig:
-            setup(dec)
-        names = contig["names"]
-        if comm.world == 1:
-            for k, v in dec.report.items():
-                report[k] = report.get(k, 0) + v
-        n_windows += 1
-        t0 = time.time()
-        if rec is not None:                                # (None: the device ingest loaded the reads already)
-            eng.load_reads(rec)
-        eng.set_region(lo[0], lo[1], hi[0], hi[1])
-        t["load"] += time.time() - t0
-        t0 = time.time()
-        eng.pileup_count(params.count())
-        eng.call_step1(params.call())
-        t["gpu_count_call"] += time.time() - t0
-        t0 = time.time()
-        per_ct = [eng.fetch_counts(ct) for ct in range(len(cts))]
-        calls = eng.fetch_calls()
-        t["fetch"] += time.time() - t0
-        t0 = time.time()
-        ckeys = calls["key"] if len(calls) else np.zeros(0, np.int64)
-        for tid in np.unique(ckeys >> 32).tolist():
-            k_lo, k_hi = tid << 32, (tid + 1) << 32
-            sl = [slice(int(np.searchsorted(k, k_lo)), int(np.searchsorted(k, k_hi))) for k, _, _ in per_ct]
-            sub = [(k[s_], r[s_], c[s_]) for (k, r, c), s_ in zip(per_ct, sl)]
-            c0, c1 = int(np.searchsorted(ckeys, k_lo)), int(np.searchsorted(ckeys, k_hi))
-            start1 = int(ckeys[c0] & 0xFFFFFFFF) + 1
-            chrom = names[tid]
-            for ct, name in enumerate(cts):
-                if len(sub[ct][0]):
-                    tsvio.write_counts_tsv(regions.piece_path(tmp, chrom, start1, "counts." + name), *sub[ct], names, "", header=False)
-            tsvio.write_merged_tsv(regions.piece_path(tmp, chrom, start1, "merged"), sub, names, cts, header=False)
-            rows1 = tsvio.write_step1_tsv(regions.piece_path(tmp, chrom, start1, "step1"), calls[c0:c1], sub, names, cts, [], header=False, as_bytes=True)
-            if local_step2:
-                t1 = time.time()
-                rows2 = step2_piece(rows1) if rows1 else b""
-                with open(regions.piece_path(tmp, chrom, start1, "step2"), "wb") as f:
-                    f.write(rows2)
-                surv = calling._step3_survivors(rows2, 6) if rows2 and os.environ.get("LONGSOM_STEP3_FULL_PARSE", "0") != "1" else None
-                kept[(chrom, start1)] = rows2 if surv is None else surv      # (Cell_types is column 6 of the step-1 / step-2 tables)
-                t["step2"] = t.get("step2", 0.0) + time.time() - t1
-            else:
-                kept[(chrom, start1)] = rows1
-        t["write_tables"] += time.time() - t0
+    region_error = None
+    try:
+      for lo, hi, rec, dec in work:
+          if not contig:
+              setup(dec)
+          names = contig["names"]
+          if comm.world == 1:
+              for k, v in dec.report.items():
+                  report[k] = report.get(k, 0) + v
+          n_windows += 1
+          t0 = time.time()
+          if rec is not None:                                # (None: the device ingest loaded the reads already)
+              eng.load_reads(rec)
+          eng.set_region(lo[0], lo[1], hi[0], hi[1])
+          t["load"] += time.time() - t0
+          t0 = time.time()
+          eng.pileup_count(params.count())
+          eng.call_step1(params.call())
+          t["gpu_count_call"] += time.time() - t0
+          t0 = time.time()
+          per_ct = [eng.fetch_counts(ct) for ct in range(len(cts))]
+          calls = eng.fetch_calls()
+          t["fetch"] += time.time() - t0
+          t0 = time.time()
+          ckeys = calls["key"] if len(calls) else np.zeros(0, np.int64)
+          for tid in np.unique(ckeys >> 32).tolist():
+              k_lo, k_hi = tid << 32, (tid + 1) << 32
+              sl = [slice(int(np.searchsorted(k, k_lo)), int(np.searchsorted(k, k_hi))) for k, _, _ in per_ct]
+              sub = [(k[s_], r[s_], c[s_]) for (k, r, c), s_ in zip(per_ct, sl)]
+              c0, c1 = int(np.searchsorted(ckeys, k_lo)), int(np.searchsorted(ckeys, k_hi))
+              start1 = int(ckeys[c0] & 0xFFFFFFFF) + 1
+              chrom = names[tid]
+              for ct, name in enumerate(cts):
+                  if len(sub[ct][0]):
+                      tsvio.write_counts_tsv(regions.piece_path(tmp, chrom, start1, "counts." + name), *sub[ct], names, "", header=False)
+              tsvio.write_merged_tsv(regions.piece_path(tmp, chrom, start1, "merged"), sub, names, cts, header=False)
+              rows1 = tsvio.write_step1_tsv(regions.piece_path(tmp, chrom, start1, "step1"), calls[c0:c1], sub, names, cts, [], header=False, as_bytes=True)
+              if local_step2:
+                  t1 = time.time()
+                  rows2 = step2_piece(rows1) if rows1 else b""
+                  with open(regions.piece_path(tmp, chrom, start1, "step2"), "wb") as f:
+                      f.write(rows2)
+                  surv = calling._step3_survivors(rows2, 6) if rows2 and os.environ.get("LONGSOM_STEP3_FULL_PARSE", "0") != "1" else None
+                  kept[(chrom, start1)] = rows2 if surv is None else surv      # (Cell_types is column 6 of the step-1 / step-2 tables)
+                  t["step2"] = t.get("step2", 0.0) + time.time() - t1
+              else:
+                  kept[(chrom, start1)] = rows1
+          t["write_tables"] += time.time() - t0
+    except BaseException as e:                              # noqa: BLE001 - raised again by the vote below, on every rank
+        region_error = e
+    # (no collective inside the loop above: a rank that failed there is heard of here, before anybody waits for its rows)
+    comm.agree(region_error, "counting / writing a rank's region of %s" % bam)
     if not contig:                                     # a rank (or a file) without reads: still needs the contig names for the headers
         setup(dec if comm.world > 1 else first)
     names = contig["names"]

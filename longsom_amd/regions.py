@@ -224,7 +224,11 @@ class Comm:
         if backend == "nccl":
             torch.cuda.set_device(local)
         if not dist.is_initialized():
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            # a finite time limit on every collective: a rank that dies between two of them (an exception nobody voted on) makes its
+            # peers fail after this long instead of waiting for ever (LONGSOM_COLLECTIVE_TIMEOUT_MIN, default 30)
+            import datetime
+            dist.init_process_group(backend, rank=rank, world_size=world,
+                                    timeout=datetime.timedelta(minutes=float(os.environ.get("LONGSOM_COLLECTIVE_TIMEOUT_MIN", "30"))))
         c = cls(world, rank, torch.device("cuda", local) if backend == "nccl" else torch.device("cpu"))
         c.grouped = True
         return c
@@ -237,6 +241,16 @@ class Comm:
         if self.grouped:
             import torch.distributed as dist
             dist.barrier()
+
+    def agree(self, error: Optional[BaseException], what: str) -> None:
+        """A vote before the ranks go on: every rank calls it with the exception its own part of `what` raised (or None); when any rank
+        failed, EVERY rank raises - the failing ones their own error, the others a RuntimeError naming how many failed - instead of
+        the healthy ranks blocking in the next collective for a peer that has left."""
+        n_bad = int(self.allreduce_sum(np.asarray([0 if error is None else 1], np.int64))[0])
+        if error is not None:
+            raise error
+        if n_bad:
+            raise RuntimeError("%s failed on %d of the %d ranks (their own errors say why)" % (what, n_bad, self.world))
 
     def allreduce_sum(self, values: np.ndarray) -> np.ndarray:
         """element-wise sum over the ranks of an int64 array (SplitBam's counters of a sharded ingest); every rank gets the result"""

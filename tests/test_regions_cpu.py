@@ -119,6 +119,39 @@ def test_allgather_bytes_over_gloo():
     assert res == {0: want, 1: want, 2: want}
 
 
+def _rank_agree(rank, world, port, q):
+    os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LSG_DIST_BACKEND="gloo")
+    comm = regions.Comm.from_env()
+    comm.agree(None, "a part nobody fails")                          # a vote everybody passes
+    try:
+        comm.agree(ValueError("index of another BAM") if rank == 1 else None, "the ingest of a rank's slice")
+        q.put((rank, "went on"))
+    except ValueError as e:
+        q.put((rank, "own error: %s" % e))
+    except RuntimeError as e:
+        q.put((rank, "told: %s" % e))
+    comm.barrier()                                                    # every rank is still in step: nobody waits for one that left
+    comm.close()
+
+
+def test_a_rank_that_fails_between_collectives_takes_every_rank_out_together():
+    """regions.Comm.agree: the vote before the ranks go on (a failed slice ingest, a failed region) - no rank blocks in the next collective"""
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world = 3
+    procs = [ctx.Process(target=_rank_agree, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[1] == "own error: index of another BAM"
+    assert res[0] == res[2] == "told: the ingest of a rank's slice failed on 1 of the 3 ranks (their own errors say why)"
+
+
 def test_bai_reader_skips_the_binning_index_and_the_builder_round_trips(tmp_path):
     """read_bai on a hand-made .bai as samtools writes it (bins with chunks, the metadata pseudo-bin, n_no_coor at the end), and
     build_bai -> read_bai on the reference-pinned multi-contig BAM: the first window of the first contig points at the first record"""
