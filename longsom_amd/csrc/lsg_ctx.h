@@ -77,7 +77,11 @@ enum { TM_STORE = 0, TM_S0, TM_B, TM_RD, TM_META, TM_BLK_TILE, TM_BLK_OFF, TM_EX
 // one job of the walk: a tile, or a run-aligned piece of a deep one.  e0, e1: padded-entry range; w0: unit of (tile, cell type 0);
 // slab: of (job, cell type 0) or ~0; nj: jobs of the tile, bit 31 = the job is longer than the packed planes' fields hold (k_tm_walk_wide
 // takes it); cnt: entries of the tile; emid: where the job's second wave starts (a run start, or e1)
-struct TmJob { uint32_t e0, e1, w0, slab, nj, cnt, tile, emid; };
+// base, off: the tile's first padded entry (8 x blocks before it) and its first entry in the sort's output; tstart, tid: the tile's
+// first position and contig - everything a job's workgroup needs in ONE record (k_tm_gather_count fetches the next job's while it works)
+struct TmJob { uint32_t e0, e1, w0, slab, nj, cnt, tile, emid, base, off; int32_t tstart, tid; };
+constexpr int TM_JOB_WORDS = 12;
+static_assert(sizeof(TmJob) == 4 * TM_JOB_WORDS, "TmJob layout");
 constexpr uint32_t TMJ_WIDE = 1u << 31;
 constexpr int TM_JOB_TGT = 3072, TM_JOB_LIMIT = 4095;      // LIMIT: what the planes' 12-bit forward field holds; a cut moves forward to the next run start
 

@@ -710,24 +710,29 @@ struct TgKeys { uint64_t k; uint32_t v; };
 struct TgStat { uint32_t ev, sg, ne; };
 struct TgPre { uint32_t bits, ctv, admw; };      // an entry's meta word in the making: flags | bit of its read | events, and the two table words looked up for it
 
+// ---- K  the sorted (key, value) of the 32 entries from padded entry p0 on (lanes 0..31), and the keys on either side (lanes 32, 33).
+//         Every lane loads, lanes past 33 and entries that are not there from a clamped place: loads outside branches let the compiler
+//         count them, so that waiting for one group's data leaves the next group's in flight.
+__device__ __forceinline__ TgKeys tg_load_keys(const TgArgs& tg, uint32_t p0, uint32_t base, uint32_t off, uint32_t n, int lane) {
+    TgKeys r;
+    const int64_t i = (int64_t)p0 - (int64_t)base + (lane < 32 ? lane : (lane == 32 ? -1 : 32));
+    const uint32_t ic = i < 0 ? 0u : (i >= (int64_t)n ? n - 1u : (uint32_t)i);
+    r.k = __builtin_nontemporal_load(tg.key + off + ic);
+    r.v = __builtin_nontemporal_load(tg.rdv + off + ic);
+    return r;
+}
+
+// K0: the keys of the range's first group (the caller has them on their way: loaded while the job before was finishing)
 __device__ __forceinline__ void tg_range(const CountArgs& a, const TmArgs& tm, const TgArgs& tg, TmState& st, TgStat& stat, uint32_t s0r, uint32_t s1r, uint32_t base, uint32_t off,
-                                         uint32_t n, bool in_region, bool counting, uint32_t thr, uint32_t pkl0, uint32_t one, int lane, uint16_t (*xt)[8][64], const tg_u32x4 (*tmask)[9]) {
+                                         uint32_t n, bool in_region, bool counting, uint32_t thr, uint32_t pkl0, uint32_t one, int lane, uint16_t (*xt)[8][64], const tg_u32x4 (*tmask)[9],
+                                         TgKeys K) {
     const uint32_t b0 = s0r >> 3, nblk = ((s1r + 7) >> 3) - b0;
     const int ng = (int)((nblk + TM_GROUP - 1) / TM_GROUP);
     const bool tail = s1r == base + n;                                    // the range that ends its tile also writes the tile's pad entries
     const uint32_t cbm = (1u << tg.cb_bits) - 1u;
     const int eu = lane >> 3, ec = lane & 7;
     auto nt_put = [](auto* q, auto v) { __builtin_nontemporal_store(v, q); };
-    // ---- K  (every lane loads, lanes past 33 and entries that are not there from a clamped place: loads outside branches let the
-    //          compiler count them, so that waiting for one group's data leaves the next group's in flight)
-    auto load_keys = [&](int g) -> TgKeys {
-        TgKeys r;
-        const int64_t i = (int64_t)(b0 + (uint32_t)g * TM_GROUP) * 8 - (int64_t)base + (lane < 32 ? lane : (lane == 32 ? -1 : 32));
-        const uint32_t ic = i < 0 ? 0u : (i >= (int64_t)n ? n - 1u : (uint32_t)i);
-        r.k = __builtin_nontemporal_load(tg.key + off + ic);
-        r.v = __builtin_nontemporal_load(tg.rdv + off + ic);
-        return r;
-    };
+    auto load_keys = [&](int g) -> TgKeys { return tg_load_keys(tg, (b0 + (uint32_t)g * TM_GROUP) * 8, base, off, n, lane); };
     // ---- W + E: the entries' words, what the meta word needs (its two table look-ups are ISSUED here and read an iteration later:
     //      finish_meta), the blocks' extents; the event loads.  A chunk is fetched whole from the caller's array, so what it holds beside the
     //      entry's own events (the read's neighbouring segment) is cleared before it crosses the LDS tile: lh keeps, per block, the
@@ -855,7 +860,6 @@ __device__ __forceinline__ void tg_range(const CountArgs& a, const TmArgs& tm, c
     tg_u32x4 chunk[TM_GROUP];
     uint32_t lh = 0, xe = 0;
     TgPre pre;
-    TgKeys K = load_keys(0);
     words_events(0, K, chunk, pre, lh, xe);
     K = load_keys(ng > 1 ? 1 : 0);
     for (int g = 0; g < ng; ++g) {
@@ -909,16 +913,22 @@ __global__ __launch_bounds__(TMW_WAVES * 64) __attribute__((amdgpu_waves_per_eu(
         __syncthreads();
         const uint32_t ck = rl(s_ck, 0);
         if (ck >= nchunks) break;
-        const uint32_t jx_end = rl(tm.chunk_start[ck + 1], 0);
-        for (uint32_t jx = rl(tm.chunk_start[ck], 0); jx < jx_end; ++jx) {
-            uint32_t jw = 0;
-            if (lane < 8) jw = reinterpret_cast<const uint32_t*>(tm.jobs + jx)[lane];
-            const uint32_t e0 = rl(jw, 0), e1 = rl(jw, 1), w0 = rl(jw, 2), slab = rl(jw, 3), nj = rl(jw, 4), tcnt = rl(jw, 5), tile = rl(jw, 6), emid = rl(jw, 7);
+        const uint32_t jx_end = rl(tm.chunk_start[ck + 1], 0), jx0 = rl(tm.chunk_start[ck], 0);
+        if (jx0 >= jx_end) continue;
+        // A job's record holds everything its workgroup needs (lsg_ctx.h TmJob); the NEXT job's record is requested when this one's has
+        // been read, and the keys of the next job's first group when this job's entries are done - a job starts with its data on the way
+        // instead of four dependent round trips (chunk -> job -> tile offsets -> keys)
+        uint32_t jw = 0;
+        if (lane < TM_JOB_WORDS) jw = reinterpret_cast<const uint32_t*>(tm.jobs + jx0)[lane];
+        uint32_t e0 = rl(jw, 0), e1 = rl(jw, 1), w0 = rl(jw, 2), slab = rl(jw, 3), nj = rl(jw, 4), tcnt = rl(jw, 5), tile = rl(jw, 6), emid = rl(jw, 7), base = rl(jw, 8), off = rl(jw, 9);
+        int32_t tstart = (int32_t)rl(jw, 10); int tid = (int)rl(jw, 11);
+        TgKeys K0 = tg_load_keys(tg, ((wv ? emid : e0) >> 3) * 8, base, off, tcnt, lane);
+        for (uint32_t jx = jx0; jx < jx_end; ++jx) {
+            {   // (every lane loads - a clamped place past the chunk's last job - so that nothing here has to wait)
+                const uint32_t jn = jx + 1 < jx_end ? jx + 1 : jx;
+                jw = reinterpret_cast<const uint32_t*>(tm.jobs + jn)[lane < TM_JOB_WORDS ? lane : 0];
+            }
             const bool in_region = tile >= a.tile_lo && tile < a.tile_hi, counting = in_region && !(nj & TMJ_WIDE);
-            const uint32_t base = rl(tg.blk_off[tile], 0) * 8u, off = rl(tg.tile_off[tile], 0);
-            const int2 geom = a.ne_geom[w0];
-            const int tid = rl((uint32_t)geom.y, 0) & 0xffffff;
-            const int32_t tstart = (int32_t)rl((uint32_t)geom.x, 0);
             int refb = 'N';
             if (nj == 1 && counting) { const int64_t pos = (int64_t)tstart + lane; if (pos >= 1 && pos < a.contig_len[tid]) refb = a.ref_ptr[tid][pos]; }
             __syncthreads();                                   // both waves are done with the job before
@@ -931,12 +941,17 @@ __global__ __launch_bounds__(TMW_WAVES * 64) __attribute__((amdgpu_waves_per_eu(
             TmState st; st.nc = 0; st.mask = 0;
             const uint32_t s0r = wv ? emid : e0, s1r = wv ? e1 : emid;
             if (s1r > s0r) {
-                tg_range(a, tm, tg, st, stat, s0r, s1r, base, off, tcnt, in_region, counting, thr, pkl0, one, lane, xts[wv], tmask);
+                tg_range(a, tm, tg, st, stat, s0r, s1r, base, off, tcnt, in_region, counting, thr, pkl0, one, lane, xts[wv], tmask, K0);
                 if (counting) {
                     if (st.nc & 0xffffu) atomicAdd(&nc_sh[0][lane], st.nc & 0xffffu);
                     if (st.nc >> 16) atomicAdd(&nc_sh[1][lane], st.nc >> 16);
                 }
             }
+            // this job's fields for the emission below; then the next job's (its record has arrived long ago) and its first keys
+            const uint32_t c_w0 = w0, c_slab = slab, c_nj = nj, c_tcnt = tcnt; const int32_t c_tstart = tstart; const int c_tid = tid;
+            e0 = rl(jw, 0); e1 = rl(jw, 1); w0 = rl(jw, 2); slab = rl(jw, 3); nj = rl(jw, 4); tcnt = rl(jw, 5); tile = rl(jw, 6); emid = rl(jw, 7); base = rl(jw, 8); off = rl(jw, 9);
+            tstart = (int32_t)rl(jw, 10); tid = (int)rl(jw, 11);
+            K0 = tg_load_keys(tg, ((wv ? emid : e0) >> 3) * 8, base, off, tcnt, lane);
             __syncthreads();
             const int ct = tm.ct_base + wv;
             if (counting && ct < a.n_ct) {                   // the tile's units of this pass: wave = cell type (as in k_tm_walk)
@@ -945,11 +960,11 @@ __global__ __launch_bounds__(TMW_WAVES * 64) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
                 for (int k = 0; k < 8; ++k) dp += pc[512 + k * 64 + lane] & 0xffffu;
                 const TmCounters tot{pc, lane, dp - nc_sh[wv][lane]};
-                if (nj == 1) {
-                    if (tcnt <= 256u) emit_unit<TmCounters, true>(a, tot, w0 + ct, ct, tid, tstart, lane, &book, false, refb, 0);
-                    else emit_unit<TmCounters, false>(a, tot, w0 + ct, ct, tid, tstart, lane, &book, false, refb, 1);
+                if (c_nj == 1) {
+                    if (c_tcnt <= 256u) emit_unit<TmCounters, true>(a, tot, c_w0 + ct, ct, c_tid, c_tstart, lane, &book, false, refb, 0);
+                    else emit_unit<TmCounters, false>(a, tot, c_w0 + ct, ct, c_tid, c_tstart, lane, &book, false, refb, 1);
                 } else {
-                    uint32_t* dst = a.macc + (uint64_t)(slab + (uint32_t)ct * nj) * (NCTR * 64);
+                    uint32_t* dst = a.macc + (uint64_t)(c_slab + (uint32_t)ct * c_nj) * (NCTR * 64);
                     dst[lane] = tot.NCDUP();
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {

@@ -726,8 +726,8 @@ __global__ void k_tm_tiles(const uint32_t* cap, uint32_t n_tiles, int n_ct, uint
 // job j of J of a tile of n entries at `base`: [first run start at or after n j / J, first run start at or after n (j + 1) / J)
 // (run starts: the store's s0 words, or - before the gather has written them - the sorted keys' barcodes; RunSrc)
 struct RunSrc { const uint32_t* s0; const uint64_t* key; uint32_t cbm; };
-__device__ __forceinline__ void tm_make_job(const RunSrc& rs, uint64_t base, uint32_t off, uint32_t n, uint32_t J, uint32_t j, uint32_t w0, uint32_t slab, uint32_t tile, TmJob* out,
-                                            uint32_t* n_wide) {
+__device__ __forceinline__ void tm_make_job(const RunSrc& rs, uint64_t base, uint32_t off, uint32_t n, uint32_t J, uint32_t j, uint32_t w0, uint32_t slab, uint32_t tile, int2 geom,
+                                            TmJob* out, uint32_t* n_wide) {
     auto starts = [&](uint32_t x) -> bool {
         if (!rs.key) return (rs.s0[base + x] & TM_RUNSTART) != 0;
         return x == 0 || (((uint32_t)rs.key[off + x] ^ (uint32_t)rs.key[off + x - 1]) & rs.cbm) != 0;
@@ -739,6 +739,7 @@ __device__ __forceinline__ void tm_make_job(const RunSrc& rs, uint64_t base, uin
     TmJob jb;
     jb.e0 = (uint32_t)(base + e0); jb.e1 = (uint32_t)(base + e1); jb.w0 = w0;
     jb.slab = J > 1 ? slab : 0xFFFFFFFFu; jb.nj = J; jb.cnt = n; jb.tile = tile;
+    jb.base = (uint32_t)base; jb.off = off; jb.tstart = geom.x; jb.tid = geom.y & 0xffffff;
     // two waves share the job: the second starts at the run start at or after its middle (short jobs: one wave)
     uint32_t mid = e1;
     if (e1 - e0 >= 64u) { mid = cut(e0 + (e1 - e0) / 2u); if (mid > e1) mid = e1; }
@@ -768,20 +769,21 @@ __global__ void k_tm_jobs(const uint32_t* tile_base, int n_contigs, int n_ct, Ru
         if (J > 1) multi[multi_off[t] * (uint32_t)n_ct + ct] = w;
     }
     if (J > 1) return;                                   // its jobs: k_tm_jobs_multi (a lane per job; here one thread would walk them one after the other)
-    tm_make_job(rs, base, tile_off[t], n, 1u, 0u, ord * (uint32_t)n_ct, 0xFFFFFFFFu, t, jobs + job_off[t], n_wide);
+    tm_make_job(rs, base, tile_off[t], n, 1u, 0u, ord * (uint32_t)n_ct, 0xFFFFFFFFu, t, make_int2(tstart, tid), jobs + job_off[t], n_wide);
 }
 // the jobs of the tiles cut into several: a wave per tile, a lane per job (a job's ends are run starts found from its own nominal ends:
 // no job waits for the one before it)
 __global__ __launch_bounds__(64) void k_tm_jobs_multi(int n_ct, RunSrc rs, const uint32_t* tile_off, const uint32_t* cap, const uint32_t* blk_off, const uint32_t* ne_off, const uint32_t* nj,
-                                                      const uint32_t* job_off, const uint32_t* slab_off, const uint32_t* multi, const uint32_t* ne_units, uint32_t n_mt, TmJob* jobs,
-                                                      uint32_t* n_wide) {
+                                                      const uint32_t* job_off, const uint32_t* slab_off, const uint32_t* multi, const uint32_t* ne_units, const int2* ne_geom, uint32_t n_mt,
+                                                      TmJob* jobs, uint32_t* n_wide) {
     const uint32_t i = blockIdx.x;
     if (i >= n_mt) return;
-    const uint32_t t = ne_units[multi[(size_t)i * (uint32_t)n_ct]] / (uint32_t)n_ct;
+    const uint32_t w = multi[(size_t)i * (uint32_t)n_ct], t = ne_units[w] / (uint32_t)n_ct;
     const uint32_t n = cap[t], J = nj[t];
+    const int2 geom = ne_geom[w];                        // (k_tm_jobs wrote the tile's units before this kernel started)
     const uint64_t base = (uint64_t)blk_off[t] * 8;
     for (uint32_t j = threadIdx.x; j < J; j += 64u)
-        tm_make_job(rs, base, tile_off[t], n, J, j, ne_off[t] * (uint32_t)n_ct, slab_off[t] + j, t, jobs + job_off[t] + j, n_wide);
+        tm_make_job(rs, base, tile_off[t], n, J, j, ne_off[t] * (uint32_t)n_ct, slab_off[t] + j, t, geom, jobs + job_off[t] + j, n_wide);
 }
 struct TmJobWork {
     const TmJob* jobs;
@@ -847,7 +849,7 @@ static int plan_jobs(lsg_ctx* c, bool finish, const uint64_t* skey, int cb_bits)
                        c->tm[TM_JOBS].as<TmJob>(), c->tm[TM_NE_UNITS].as<uint32_t>(), c->tm[TM_NE_GEOM].as<int2>(), c->tm[TM_NE_NSLOT].as<uint32_t>(),
                        c->tm[TM_NE_ACC].as<uint32_t>(), c->tm[TM_MULTI].as<uint32_t>(), d_misc);
     if (n_mt) hipLaunchKernelGGL(k_tm_jobs_multi, dim3(n_mt), dim3(64), 0, st, c->n_ct, rs, c->d_tile_off.as<uint32_t>(), c->d_tile_cap.as<uint32_t>(), c->tm[TM_BLK_OFF].as<uint32_t>(),
-                                 ne_off, nj, job_off, slab_off, c->tm[TM_MULTI].as<uint32_t>(), c->tm[TM_NE_UNITS].as<uint32_t>(), n_mt, c->tm[TM_JOBS].as<TmJob>(), d_misc);
+                                 ne_off, nj, job_off, slab_off, c->tm[TM_MULTI].as<uint32_t>(), c->tm[TM_NE_UNITS].as<uint32_t>(), c->tm[TM_NE_GEOM].as<int2>(), n_mt, c->tm[TM_JOBS].as<TmJob>(), d_misc);
     {   // static work-balanced chunks of the job list; every workgroup of the walk should get several: a small load is cut finer
         DevBuf& pex = c->bt[BT_PEX];
         const uint64_t total_work = c->tm_np + (uint64_t)njobs * TM_JOB_W0;
