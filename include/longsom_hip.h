@@ -232,6 +232,11 @@ int64_t lsg_max_live_reads_all(lsg_ctx* ctx);
  * POS >= START and POS < END test (BaseCellCounter.py:200).  tid_hi == n_contigs, pos_hi == 0
  * means "to the end".  Reset with (0,0,n_contigs,0). */
 int lsg_set_region(lsg_ctx* ctx, int32_t tid_lo, int64_t pos_lo, int32_t tid_hi, int64_t pos_hi);
+/* The reference's pileup windows (BaseCellCounter.py --bin, default 50000; MakeWindows :81-113 cuts [1, 1 + bin), [1 + bin, ...) per contig
+ * and run_interval opens a fresh bam.pileup per window, :185-191).  Result-neutral for the counts except through max_depth: every window's
+ * pileup has a buffer of its own, so lsg_pileup_count replays the cap per window, and the loads that follow never let a resident entry
+ * cross a window edge (a read dropped in one window may be counted in the next).  window >= 64; default 50000. */
+int lsg_set_pileup_window(lsg_ctx* ctx, int32_t window);
 /* One pass for a BAM's load AND its first count.  A rule of the reference counts every BAM exactly once
  * (bam.pileup over all windows, BaseCellCounter.py:182-320, after SplitBamCellTypes.py:65-124 routed the reads); when the
  * count's parameters are known while the reads are loaded - they are in every fused rule - the loads that follow

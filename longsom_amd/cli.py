@@ -105,8 +105,11 @@ def base_cell_counter(argv=None):
         if a.chrom != "all":
             tid = dec.contig_names.index(a.chrom)
             eng.set_region(tid, 0, tid + 1, 0)
+        eng.set_pileup_window(max(64, a.bin))             # --bin: the windows whose pileups each have a max_depth buffer of their own (:185-191)
+        cp = CountParams.longsom_defaults(min_bq=a.min_bq, min_mq=a.min_mq, min_dp=a.min_dp, min_cc=a.min_cc)
+        eng.set_count_at_load(cp)                         # this script counts its BAM once: in the pass that loads it
         eng.load_reads(dec.records)
-        eng.pileup_count(CountParams.longsom_defaults(min_bq=a.min_bq, min_mq=a.min_mq, min_dp=a.min_dp, min_cc=a.min_cc))
+        eng.pileup_count(cp)
         k, r, c = eng.fetch_counts(0)
     if a.bed or a.bed_out:                                # MakeWindows' interval arithmetic (BaseCellCounter.py:88-106): only rows inside are written
         keep = bed_mask(k, dec.contig_names, [len(seq_of[n]) for n in dec.contig_names], a.bed, a.bed_out)

@@ -112,22 +112,27 @@ __global__ void k_read_end_init(const int32_t* read_pos, int64_t n_reads, int32_
     if (r < n_reads) read_end[r] = read_pos[r] + 1;
 }
 
-// bam.pileup(..., max_depth) as htslib applies it (sam.c bam_plp_push / bam_plp_next; BaseCellCounter.py:191), per cell type's read
-// stream.  Stream of cell type c = the records SplitBamCellTypes wrote to its BAM (barcode of that type, MAPQ >= min_mq) that the
-// pileup's read filter lets in (flag_exclude without the supplementary bit, which only BaseCellCounter.py:249 tests later;
-// ignore_orphans; min_mq).  In coordinate order: the first read of a start position P always enters the buffer; every later read
-// starting at P is dropped iff (reads buffered, i.e. entered and ending at or after P) + 1 > max_depth — mp->cnt counts the spare
-// tail node, and reads whose last column was P - 1 are only freed while column P is swept.  Sequential by nature (what was dropped
-// decides what is buffered), so it runs on the host — but only when lsg_max_live_reads() says a buffer can reach max_depth at all.
+// bam.pileup(CHROM, START, END, ..., max_depth) as htslib applies it (sam.c bam_plp_push / bam_plp_next), per cell type's read stream
+// AND per window of the reference (BaseCellCounter.py:185-191: a fresh pileup for every [1 + k W, 1 + (k + 1) W), W = --bin 50000).
+// Stream of cell type c = the records SplitBamCellTypes wrote to its BAM (barcode of that type, MAPQ >= min_mq) that the pileup's read
+// filter lets in (flag_exclude without the supplementary bit, which only BaseCellCounter.py:249 tests later; ignore_orphans; min_mq);
+// pool of a window = the stream's reads overlapping it (the index fetch), in coordinate order: the first read of a start position P
+// always enters the buffer; every later read starting at P is dropped iff (reads buffered, i.e. entered and ending at or after P) + 1 >
+// max_depth — mp->cnt counts the spare tail node, and reads whose last column was P - 1 are only freed while column P is swept.  A read
+// that overlaps two windows passes through two buffers and may be dropped by one and counted by the other (the second window's buffer
+// never held the reads that ended before it): the verdict is per (read, window), and the store's entries never cross a window edge.
+// Sequential by nature (what was dropped decides what is buffered), so it runs on the host — but only when lsg_max_live_reads() says a
+// buffer can reach max_depth at all.  Result: d_read_drop[r] = 1 dropped in every window r overlaps, 2 in some of them, listed as
+// (r << 32 | window of its contig) in d_drop_pairs (sorted); pileup.hip k_read_stats / k_tm_resolve apply them.
 int depth_cap_drops(lsg_ctx* c, const lsg_count_params* p) {
-    c->has_drops = false; c->n_depth_dropped = 0;
+    c->has_drops = false; c->n_depth_dropped = 0; c->n_drop_pairs = 0;
     if (p->max_depth <= 0 || c->rd.n_reads <= 0 || c->n_ct <= 0) return 0;
     if (live_read_bound_all(c)) return -1;
     if (c->max_live_all + 1 <= (int64_t)p->max_depth) return 0;           // not even all reads together fill a buffer: nothing is ever dropped
     if (live_read_bound(c)) return -1;
     if (c->max_live_reads + 1 <= (int64_t)p->max_depth) return 0;          // no cell type's buffer can exceed the cap
     hipStream_t st = c->stream;
-    const int64_t R = c->rd.n_reads, S = c->rd.n_segs;
+    const int64_t R = c->rd.n_reads, S = c->rd.n_segs, W = c->st_window;
     DevBuf d_end;
     if (d_end.reserve((size_t)R * 4)) return -1;
     hipLaunchKernelGGL(k_read_end_init, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, c->rd.read_pos, R, d_end.as<int32_t>());
@@ -146,32 +151,64 @@ int depth_cap_drops(lsg_ctx* c, const lsg_count_params* p) {
     bool sorted = true;
     for (int64_t i = 1; i < R && sorted; ++i) sorted = key((uint32_t)(i - 1)) <= key((uint32_t)i);
     if (!sorted) std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return key(a) < key(b); });
-    std::vector<uint8_t> drop((size_t)R, 0);
+    std::vector<uint16_t> n_over((size_t)R, 0), n_drop((size_t)R, 0);      // windows a read overlaps / is dropped in (a read reaches over a handful at most)
+    std::vector<uint64_t> pairs;
     const uint32_t pool_flags = p->flag_exclude & ~0x800u;
-    int64_t n_drop = 0;
+    std::vector<uint32_t> stream, pool, carry;
+    std::vector<int32_t> heap;                                             // min-heap of the buffered reads' ends
+    auto cmp = [](int32_t a, int32_t b) { return a > b; };
     for (int ct = 0; ct < c->n_ct; ++ct) {
-        std::vector<int32_t> heap;                                         // min-heap of the buffered reads' ends
-        auto cmp = [](int32_t a, int32_t b) { return a > b; };
-        int32_t cur_tid = -1, cur_pos = -1; bool first_here = true;
-        for (int64_t k = 0; k < R; ++k) {
-            const uint32_t i = order[(size_t)k];
-            if (tid[i] < 0 || tid[i] >= c->n_contigs || cb[i] < 0 || cb[i] >= c->n_cb || ctof[(size_t)cb[i]] != ct) continue;
-            if ((int)mapq[i] < p->min_mq || (flag[i] & pool_flags)) continue;
-            if (p->ignore_orphans && (flag[i] & 1u) && !(flag[i] & 2u)) continue;
-            if (tid[i] != cur_tid) { heap.clear(); cur_tid = tid[i]; cur_pos = -1; }
-            if (pos[i] != cur_pos) {
-                cur_pos = pos[i]; first_here = true;
-                while (!heap.empty() && heap.front() < cur_pos) { std::pop_heap(heap.begin(), heap.end(), cmp); heap.pop_back(); }      // ended before P: freed
+        int64_t k0 = 0;
+        while (k0 < R) {                                                   // one contig of the coordinate order at a time
+            const int32_t t = tid[order[(size_t)k0]];
+            int64_t k1 = k0;
+            stream.clear();
+            for (; k1 < R && tid[order[(size_t)k1]] == t; ++k1) {
+                const uint32_t i = order[(size_t)k1];
+                if (t < 0 || t >= c->n_contigs || cb[i] < 0 || cb[i] >= c->n_cb || ctof[(size_t)cb[i]] != ct) continue;
+                if ((int)mapq[i] < p->min_mq || (flag[i] & pool_flags)) continue;
+                if (p->ignore_orphans && (flag[i] & 1u) && !(flag[i] & 2u)) continue;
+                stream.push_back(i);
             }
-            if (!first_here && (int64_t)heap.size() + 1 > (int64_t)p->max_depth) { drop[i] = 1; ++n_drop; continue; }
-            first_here = false;
-            heap.push_back(end[i]); std::push_heap(heap.begin(), heap.end(), cmp);
+            k0 = k1;
+            size_t nxt = 0;
+            carry.clear();
+            int64_t w = 0;
+            while (nxt < stream.size() || !carry.empty()) {
+                if (carry.empty()) { const int64_t p0 = pos[stream[nxt]]; const int64_t wn = p0 >= 1 ? (p0 - 1) / W : 0; if (wn > w) w = wn; }      // nothing reaches into the windows in between
+                const int64_t ws = 1 + W * w, we = ws + W;
+                pool.assign(carry.begin(), carry.end());                  // (reads of earlier windows that reach into this one, in order) + the reads starting below its end
+                while (nxt < stream.size() && (int64_t)pos[stream[nxt]] < we) { if ((int64_t)end[stream[nxt]] > ws) pool.push_back(stream[nxt]); ++nxt; }
+                heap.clear();
+                int32_t cur_pos = -1; bool first_here = true;
+                for (uint32_t i : pool) {
+                    ++n_over[i];
+                    if (pos[i] != cur_pos) {
+                        cur_pos = pos[i]; first_here = true;
+                        while (!heap.empty() && heap.front() < cur_pos) { std::pop_heap(heap.begin(), heap.end(), cmp); heap.pop_back(); }      // ended before P: freed
+                    }
+                    if (!first_here && (int64_t)heap.size() + 1 > (int64_t)p->max_depth) { ++n_drop[i]; pairs.push_back(((uint64_t)i << 32) | (uint64_t)w); continue; }
+                    first_here = false;
+                    heap.push_back(end[i]); std::push_heap(heap.begin(), heap.end(), cmp);
+                }
+                carry.clear();
+                for (uint32_t i : pool) if ((int64_t)end[i] > we) carry.push_back(i);
+                ++w;
+            }
         }
     }
-    if (n_drop == 0) return 0;
-    if (c->d_read_drop.reserve((size_t)R)) return -1;
-    if (hipMemcpyAsync(c->d_read_drop.p, drop.data(), (size_t)R, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { set_error("depth cap: upload failed"); return -1; }
-    c->has_drops = true; c->n_depth_dropped = n_drop;
+    if (pairs.empty()) return 0;
+    std::vector<uint8_t> drop((size_t)R, 0);
+    int64_t n_dropped = 0;
+    for (int64_t i = 0; i < R; ++i) if (n_drop[(size_t)i]) { drop[(size_t)i] = n_drop[(size_t)i] == n_over[(size_t)i] ? 1 : 2; ++n_dropped; }
+    std::vector<uint64_t> some;
+    for (uint64_t pr : pairs) if (drop[(size_t)(pr >> 32)] == 2) some.push_back(pr);
+    std::sort(some.begin(), some.end());
+    if (c->d_read_drop.reserve((size_t)R) || c->d_drop_pairs.reserve((some.size() + 1) * 8)) return -1;
+    if (hipMemcpyAsync(c->d_read_drop.p, drop.data(), (size_t)R, hipMemcpyHostToDevice, st) != hipSuccess ||
+        (!some.empty() && hipMemcpyAsync(c->d_drop_pairs.p, some.data(), some.size() * 8, hipMemcpyHostToDevice, st) != hipSuccess) ||
+        hipStreamSynchronize(st) != hipSuccess) { set_error("depth cap: upload failed"); return -1; }
+    c->has_drops = true; c->n_depth_dropped = n_dropped; c->n_drop_pairs = (int64_t)some.size();
     return 0;
 }
 

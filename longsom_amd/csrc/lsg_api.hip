@@ -80,7 +80,7 @@ void lsg_destroy(lsg_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->d_tile_base, &c->d_contig_len, &c->d_ref_ptrs, &c->d_celltype_of, &c->d_ct_rank, &c->b_read_tid, &c->b_read_pos,
                       &c->b_read_flag, &c->b_read_mapq, &c->b_read_cb, &c->b_seg_read, &c->b_seg_start, &c->b_seg_len,
-                      &c->b_seg_ev_off, &c->b_events, &c->d_read_key, &c->d_read_drop, &c->d_read_adm,
+                      &c->b_seg_ev_off, &c->b_events, &c->d_read_key, &c->d_read_drop, &c->d_drop_pairs, &c->d_read_adm,
                       &c->d_ne_units, &c->d_ne_mask, &c->d_ne_rowbase, &c->d_ne_rowoff,
                       &c->d_scalars, &c->d_cub_tmp, &c->d_ix_stat, &c->d_tile_cap, &c->d_tile_off, &c->d_calls, &c->d_site_off, &c->d_tail_table, &c->d_pass_list};
     for (auto* b : bufs) b->release();
@@ -208,6 +208,12 @@ int lsg_set_keep_reads(lsg_ctx* c, int32_t keep) {
     return 0;
 }
 
+int lsg_set_pileup_window(lsg_ctx* c, int32_t window) {
+    if (!c || window < 64) { set_error("lsg_set_pileup_window: the window must be at least 64 positions"); return -2; }
+    c->plp_window = window;
+    return 0;
+}
+
 int lsg_set_count_at_load(lsg_ctx* c, const lsg_count_params* params) {
     if (!c) { set_error("lsg_set_count_at_load: NULL handle"); return -2; }
     c->cal_enabled = params != nullptr;
@@ -236,7 +242,7 @@ int lsg_load_reads(lsg_ctx* c, const lsg_reads* r) {
     if (!c || !r) { set_error("lsg_load_reads: bad arguments"); return -2; }
     if (c->n_contigs <= 0) { set_error("lsg_load_reads: set the contigs first (the store is laid out over their tiles)"); return -2; }
     if (r->n_reads < 0 || r->n_segs < 0 || r->n_events < 0) { set_error("lsg_load_reads: negative sizes"); return -2; }
-    if (r->n_segs >= 0xFFFFFFF0ll || r->n_reads >= (1ll << 30)) { set_error("lsg_load_reads: more than 2^32 segments or 2^30 reads; load in windows"); return -2; }
+    if (r->n_segs >= 0xFFFFFFF0ll || r->n_reads >= (1ll << 29)) { set_error("lsg_load_reads: more than 2^32 segments or 2^29 reads; load in windows"); return -2; }
     if (r->n_events >= (1ll << 40)) { set_error("lsg_load_reads: more than 2^40 events"); return -2; }
     LSG_HIP(hipSetDevice(c->device));
     lsg::drop_store(c);

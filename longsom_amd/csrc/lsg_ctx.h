@@ -64,12 +64,15 @@ enum { WS_NE_NSLOT = 0, WS_NE_ACC, WS_NE_GEOM, WS_MULTI_LIST, WS_MACC, WS_EXPORT
 // The resident form of the reads' events: every (segment x 64-position tile) ENTRY of a read that carries a barcode, the entries of a
 // tile adjacent and sorted by barcode, eight entries to a 1 KB block held transposed ([position 0..63][entry 0..7], 16 bytes per
 // position), every tile padded to whole blocks.  Independent of count parameters and of the barcode -> cell-type table.
-//   s0[p]  cb [0..23] | forward << 30 | first entry of its barcode's run in the tile << 31          (pad entries: cb = CB_MASK, run start)
+//   s0[p]  cb [0..23] | upper pileup window << 29 | forward << 30 | first entry of its barcode's run in the tile << 31   (pad entries: cb = CB_MASK, run start)
+//          An entry never crosses an edge of the reference's pileup windows ([1, 50001), [50001, ...: BaseCellCounter.py:81-113,185-191): in
+//          the one tile per window edge a segment makes two entries, and bit 29 says the entry lies in the window that starts inside its
+//          tile (what the per-window max_depth rule needs: layout.hip depth_cap_drops)
 //   b[p]   events - 1 [0..5] | first entry of its segment << 6 | run of exactly one entry << 7
 //   rd[p]  owning read: admission under a count's read filters (SAM flag, MAPQ) and the pileup's max_depth rule are decided per READ
 //          (a bit per read, made per count: pileup.hip k_read_admit) and looked up through it
 constexpr uint32_t CB_MASK = 0x00FFFFFFu;
-constexpr uint32_t TM_RUNSTART = 1u << 31, TM_FWD = 1u << 30;
+constexpr uint32_t TM_RUNSTART = 1u << 31, TM_FWD = 1u << 30, TM_WHI = 1u << 29;
 constexpr uint32_t TM_PAD_S0 = CB_MASK | TM_RUNSTART;
 constexpr int TM_GROUP = 4;                 // blocks a wave of the walk loads per group: the arrays are padded by one group
 enum { TM_STORE = 0, TM_S0, TM_B, TM_RD, TM_META, TM_BLK_TILE, TM_BLK_OFF, TM_EXT,                                // per load
@@ -129,6 +132,7 @@ struct lsg_ctx {
     lsg_reads rd{};                       // device pointers
     lsg::DevBuf b_read_tid, b_read_pos, b_read_flag, b_read_mapq, b_read_cb;
     lsg::DevBuf b_seg_read, b_seg_start, b_seg_len, b_seg_ev_off, b_events;
+    int32_t plp_window = 50000, st_window = 50000;        // lsg_set_pileup_window: the reference's pileup windows (--bin) for the next loads / of the resident store
     int32_t lf_min_mq = 0, lf_ignore_orphans = 0; uint32_t lf_flag_exclude = 0;      // lsg_set_load_filter: reads failing it are not stored by the next loads
     int32_t st_min_mq = 0, st_ignore_orphans = 0; uint32_t st_flag_exclude = 0;      // ... and the filter the resident store was built under
     bool keep_reads = false;              // lsg_set_keep_reads: the compact events stay resident beside the store (rd.events; tests, sampling)
@@ -154,7 +158,8 @@ struct lsg_ctx {
     float build_ms[4] = {0, 0, 0, 0};     // HIP-event times of the last build: capacities + scatter, sort, fill, gather
     int64_t max_live_reads = -1;          // layout.hip: bound on the reads live at once in the reference's pileup buffer (-1 = stale)
     int64_t max_live_all = -1;            // the same over all reads with a barcode: table-independent, cached per load
-    lsg::DevBuf d_read_drop;              // layout.hip: per read, 1 = dropped by the pileup's max_depth rule under the last count's parameters
+    lsg::DevBuf d_read_drop;              // layout.hip: per read, the pileup's max_depth rule under the last count's parameters: 1 = dropped in every window it overlaps, 2 = in some (d_drop_pairs)
+    lsg::DevBuf d_drop_pairs; int64_t n_drop_pairs = 0;      // sorted (read << 32 | window of its contig) of the reads dropped in some windows only
     lsg::DevBuf d_read_adm;               // pileup.hip: a bit per read, admitted under the current count's read filters (made only when some stored read can fail them)
     bool has_drops = false;
     int64_t n_depth_dropped = 0;

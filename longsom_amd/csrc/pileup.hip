@@ -48,7 +48,9 @@ struct CountArgs {
     // params
     int32_t min_bq, min_mq, min_dp, min_cc, ignore_orphans;
     uint32_t flag_exclude;
-    const uint8_t* read_drop;             // reads the pileup's max_depth rule drops (layout.hip depth_cap_drops), or null
+    const uint8_t* read_drop;             // the pileup's max_depth rule per read (layout.hip depth_cap_drops): 1 dropped in every window it overlaps, 2 in some; or null
+    const unsigned long long* drop_pairs; int64_t n_drop_pairs;      // ... which: sorted (read << 32 | window of its contig)
+    const uint32_t* tile_base; int32_t window;                       // first tile of every contig; the reference's pileup windows
     unsigned long long* adm;              // a bit per read: admitted under THIS count's read filters and not dropped (k_read_stats writes it, k_tm_resolve looks the
                                           // entries' reads up in it), or null when every stored read is admitted: the load filter already was this count's filter and nothing is dropped
     // units of the plan (copies the call stage and the exports read), rows
@@ -78,7 +80,7 @@ __global__ __launch_bounds__(256) void k_read_stats(CountArgs a) {
         const int32_t cb = a.read_cb[r], tid = a.read_tid[r];
         bool pass = (flag & a.flag_exclude) == 0 && (int)a.read_mapq[r] >= a.min_mq;
         if (pass && a.ignore_orphans && (flag & 0x1) && !(flag & 0x2)) pass = false;
-        if (pass && a.read_drop && a.read_drop[r]) pass = false;          // bam.pileup(..., max_depth): never entered the pileup buffer
+        if (pass && a.read_drop && a.read_drop[r] == 1) pass = false;     // bam.pileup(..., max_depth): never entered the buffer of any window it overlaps
         if (a.adm) {
             const unsigned long long m = __ballot(pass);
             if ((threadIdx.x & 63) == 0) a.adm[r >> 6] = m;
@@ -305,6 +307,8 @@ static void fill_args(lsg_ctx* c, const lsg_count_params* p, CountArgs& a) {
     a.min_bq = p->min_bq; a.min_mq = p->min_mq; a.min_dp = p->min_dp; a.min_cc = p->min_cc;
     a.ignore_orphans = p->ignore_orphans; a.flag_exclude = p->flag_exclude;
     a.read_drop = c->has_drops ? c->d_read_drop.as<uint8_t>() : nullptr;
+    a.drop_pairs = c->has_drops && c->n_drop_pairs ? c->d_drop_pairs.as<unsigned long long>() : nullptr; a.n_drop_pairs = c->n_drop_pairs;
+    a.tile_base = c->d_tile_base.as<uint32_t>(); a.window = c->st_window;
     // every stored read passed the load filter: a count under exactly that filter, with nothing dropped, admits them all
     const bool all_in = !c->has_drops && p->min_mq <= c->st_min_mq && (p->flag_exclude & ~c->st_flag_exclude) == 0 && (!p->ignore_orphans || c->st_ignore_orphans);
     a.adm = all_in ? nullptr : c->d_read_adm.as<unsigned long long>();
@@ -352,6 +356,19 @@ struct TmArgs {
     int32_t ct_base;                      // the pass counts cell types ct_base and ct_base + 1
 };
 
+// the pileup's depth cap dropped read r in SOME of the windows it overlaps (read_drop[r] == 2): in the one this entry lies in?  An entry never
+// crosses a window edge (store.hip): its window is the one its tile starts in, or - bit TM_WHI of s0 - the one that starts inside the tile.
+__device__ __noinline__ bool tm_dropped_here(const CountArgs& a, uint32_t r, uint32_t tile, uint32_t s0word) {
+    int lo = 0, hi = a.n_contigs;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (a.tile_base[mid] <= tile) lo = mid; else hi = mid; }
+    const int64_t tstart = (int64_t)(tile - a.tile_base[lo]) << 6;
+    const uint64_t w = (uint64_t)((tstart >= 1 ? (tstart - 1) / a.window : 0) + ((s0word & TM_WHI) ? 1 : 0));
+    const unsigned long long key = ((unsigned long long)r << 32) | w;
+    int64_t b = 0, e = a.n_drop_pairs;
+    while (b < e) { const int64_t m = (b + e) >> 1; if (a.drop_pairs[m] < key) b = m + 1; else e = m; }
+    return b < a.n_drop_pairs && a.drop_pairs[b] == key;
+}
+
 // per count and pass: the word the walk reads per entry.  Admission under THIS count's parameters (the entry's read: its bit of
 // k_read_stats' bitmap - SAM flag, MAPQ, the depth cap's drops), cell type under THIS barcode table, region.
 __global__ __launch_bounds__(256) void k_tm_resolve(CountArgs a, TmArgs tm, unsigned long long* stat_slots) {
@@ -382,6 +399,7 @@ __global__ __launch_bounds__(256) void k_tm_resolve(CountArgs a, TmArgs tm, unsi
                 cls = 2;
                 bool ok = cb < (uint32_t)a.n_cb;             // (pad entries carry CB_MASK)
                 if (ok && a.adm) ok = (reinterpret_cast<const uint32_t*>(a.adm)[rv[u] >> 5] >> (rv[u] & 31u)) & 1u;
+                if (ok && a.drop_pairs && a.read_drop[rv[u]] == 2) ok = !tm_dropped_here(a, rv[u], tile, s);
                 if (ok) { const uint32_t ct = a.celltype_of[cb]; if (ct < (uint32_t)a.n_ct && (ct >> 1) == (uint32_t)(tm.ct_base >> 1)) cls = ct & 1u; }
             }
             if (cls < 2) { ev += (b8 & 63u) + 1u; sg += (b8 >> 6) & 1u; ++ne; }
@@ -705,7 +723,7 @@ struct TgArgs {
 };
 typedef uint32_t tg_u32x4 __attribute__((ext_vector_type(4)));
 struct __attribute__((packed, aligned(2))) TgU4A2 { tg_u32x4 v; };
-constexpr uint32_t TG_RV_SEGFIRST = 1u << 30, TG_RV_FWD = 1u << 31, TG_RV_READ = TG_RV_SEGFIRST - 1u;      // (store.hip RV_*)
+constexpr uint32_t TG_RV_WHI = 1u << 29, TG_RV_SEGFIRST = 1u << 30, TG_RV_FWD = 1u << 31, TG_RV_READ = TG_RV_WHI - 1u;      // (store.hip RV_*)
 struct TgKeys { uint64_t k; uint32_t v; };
 struct TgStat { uint32_t ev, sg, ne; };
 struct TgPre { uint32_t bits, ctv, admw; };      // an entry's meta word in the making: flags | bit of its read | events, and the two table words looked up for it
@@ -748,7 +766,7 @@ __device__ __forceinline__ void tg_range(const CountArgs& a, const TmArgs& tm, c
         const bool single = rs && (i + 1 == n || cb_next != cb);
         const bool own = valid && p >= s0r && p < s1r;
         if (own) {
-            nt_put(tg.s0 + p, cb | ((K.v & TG_RV_FWD) ? TM_FWD : 0u) | (rs ? TM_RUNSTART : 0u));
+            nt_put(tg.s0 + p, cb | ((K.v & TG_RV_FWD) ? TM_FWD : 0u) | ((K.v & TG_RV_WHI) ? TM_WHI : 0u) | (rs ? TM_RUNSTART : 0u));
             nt_put(tg.b8 + p, (uint8_t)((nev - 1u) | ((K.v & TG_RV_SEGFIRST) ? 64u : 0u) | (single ? 128u : 0u)));
             nt_put(tg.rd + p, K.v & TG_RV_READ);
         } else if (lane < 32 && !valid && tail && p < (b0 + nblk) * 8) {
@@ -1019,6 +1037,7 @@ __device__ __forceinline__ uint32_t tm_meta_one(const CountArgs& a, const TmArgs
     uint32_t cls = 2;
     bool ok = cb < (uint32_t)a.n_cb;
     if (ok && a.adm) { const uint32_t r = tm.rd[p]; ok = (reinterpret_cast<const uint32_t*>(a.adm)[r >> 5] >> (r & 31u)) & 1u; }
+    if (ok && a.drop_pairs && a.read_drop[tm.rd[p]] == 2) ok = !tm_dropped_here(a, tm.rd[p], tm.blk_tile[p >> 3], s);
     if (ok) { const uint32_t ct = a.celltype_of[cb]; if (ct < (uint32_t)a.n_ct && (ct >> 1) == (uint32_t)(tm.ct_base >> 1)) cls = ct & 1u; }
     uint32_t m = cls < 2 ? (cls ? (TMM_CT4 | TMM_CT12) : 0u) | ((s & TM_FWD) ? TMM_FWD : 0u) | ((b8 & 128u) ? TMM_SINGLE : 0u) : TMM_SKIP;
     if (s & TM_RUNSTART) m |= TMM_RS;

@@ -30,8 +30,9 @@ constexpr uint32_t KEY_INVALID = 0xFFFFFFFFu;
 
 // An entry on its way through the sort.  Key (64 bits): barcode [0 .. cb_bits) | first position in the tile, 6 bits | events - 1, 6 bits |
 // offset of its first event in the caller's array, the remaining 52 - cb_bits bits (build_store checks that the events fit).  Only the
-// barcode bits are sorted on.  Value (32 bits): owning read [0 .. 30) | first entry of its segment << 30 | forward strand << 31.
-constexpr uint32_t RV_SEGFIRST = 1u << 30, RV_FWD = 1u << 31, RV_READ = RV_SEGFIRST - 1u;
+// barcode bits are sorted on.  Value (32 bits): owning read [0 .. 29) | upper pileup window of its tile << 29 | first entry of its segment << 30 |
+// forward strand << 31.
+constexpr uint32_t RV_WHI = 1u << 29, RV_SEGFIRST = 1u << 30, RV_FWD = 1u << 31, RV_READ = RV_WHI - 1u;
 __host__ __device__ __forceinline__ uint64_t sort_key(uint32_t cb, uint32_t first, uint32_t nev1, uint64_t src, int cb_bits) {
     return (uint64_t)cb | ((uint64_t)(first | (nev1 << 6) ) << cb_bits) | (src << (cb_bits + 12));
 }
@@ -53,7 +54,18 @@ struct BuildArgs {
     unsigned long long* n_ev;             // events of the statically admitted segments = events the store will hold
     int32_t* span_diff;                   // [n_tiles + 1] marks of the reads' spans (the depth cap's bound), or null
     int32_t* cap_diff;                    // [n_tiles + 1] marks of the admitted segments' tile ranges: +1 at the first tile, -1 past the last; their running sum = entries per tile
+    int32_t window;                       // the reference's pileup windows [1 + k W, 1 + (k + 1) W): an entry never crosses an edge of one
 };
+
+// The edges of the reference's pileup windows (BaseCellCounter.py:81-113: [1, 50001), [50001, 100001), ...) that lie INSIDE a tile cut
+// the segments crossing them: the tile gets two entries of such a segment, one per window, because with max_depth every window is a
+// pileup of its own (:185-191) and a read may be dropped in one and counted in the next.  First edge after position x:
+__device__ __forceinline__ int64_t win_edge_after(int64_t x, int32_t W) { return 1 + (int64_t)W * ((x >= 1 ? (x - 1) / W : 0) + 1); }
+// the edge strictly inside the tile that starts at tstart (W >= 64: at most one), or -1
+__device__ __forceinline__ int64_t win_edge_in_tile(int64_t tstart, int32_t W) {
+    const int64_t b = win_edge_after(tstart, W);
+    return b < tstart + TILE_W ? b : -1;
+}
 
 // Static admission of a segment: its read carries a barcode, passes the load filter and lies on a contig, the segment lies inside the
 // contig (what ANY count parameters or barcode table can admit; malformed segments are never counted).  Also the load's validation of
@@ -64,7 +76,7 @@ struct BuildArgs {
 // The tiles' CAPACITIES come out of the same pass the same way: a segment's entries are the tiles of one contiguous range, so +1 at its
 // first tile and -1 past its last one, summed along the tiles, is the number of entries of every tile — two marks per segment where a
 // counting pass over the entries (0.9 ms of LDS atomics for C2's 185 M entries) made one per entry.
-constexpr int SEG_THREADS = 256, SEG_H = 2048, SEG_MAX_SINCE = 24;       // (24 x 512 marks of one sign at most per half word)
+constexpr int SEG_THREADS = 256, SEG_H = 4096, SEG_MAX_SINCE = 24, SEG_MARKS = 6;       // (24 x 1024 marks of one sign at most per half word; 6 marks per segment: 2 + 2, 2 at a window edge)
 __global__ __launch_bounds__(SEG_THREADS) void k_seg_static(BuildArgs a) {
     __shared__ uint32_t hkey[SEG_H];
     __shared__ int32_t hval[SEG_H];       // both sums of a tile in one word: span marks in the low half, capacity marks x 65536 (each at most 512 in size per batch, SEG_MAX_SINCE batches per flush)
@@ -73,7 +85,7 @@ __global__ __launch_bounds__(SEG_THREADS) void k_seg_static(BuildArgs a) {
     for (int i = threadIdx.x; i < SEG_H; i += SEG_THREADS) { hkey[i] = KEY_INVALID; hval[i] = 0; }
     if (threadIdx.x == 0) { s_ev = 0; s_new = 0; s_flush = 0; }
     auto slot = [&](uint32_t t) {
-        uint32_t h = (t * 2654435761u) >> 21;
+        uint32_t h = (t * 2654435761u) >> 20;
         while (true) {
             const uint32_t prev = atomicCAS(&hkey[h], KEY_INVALID, t);
             if (prev == KEY_INVALID) { atomicAdd(&s_new, 1u); break; }
@@ -115,6 +127,15 @@ __global__ __launch_bounds__(SEG_THREADS) void k_seg_static(BuildArgs a) {
                         n_ev += (unsigned long long)ln;
                         mark_cap(tb + ((uint32_t)st >> 6), 1);
                         mark_cap(tb + ((uint32_t)(st + ln - 1) >> 6) + 1, -1);
+                        // one more entry in the tile of every window edge strictly inside the segment (the first one through the hash, further
+                        // ones - a segment longer than a window - straight to memory: the hash is sized for SEG_MARKS marks per segment)
+                        int nb = 0;
+                        for (int64_t b = win_edge_after(st, a.window); b < st + ln; b += a.window) {
+                            if ((b & 63) == 0) continue;                     // (an edge on a tile boundary cuts nothing)
+                            const uint32_t t = tb + (uint32_t)(b >> 6);
+                            if (nb++ == 0) { mark_cap(t, 1); mark_cap(t + 1, -1); }
+                            else { atomicAdd(a.cap_diff + t, 1); atomicAdd(a.cap_diff + t + 1, -1); }
+                        }
                     }
                 }
                 if (a.span_diff && on_contig && cb >= 0) {          // (every read with a barcode, whatever the load filter: a bound never under-counts)
@@ -135,7 +156,7 @@ __global__ __launch_bounds__(SEG_THREADS) void k_seg_static(BuildArgs a) {
         ++since;
         __syncthreads();                                  // the batch's marks are in
         if (threadIdx.x == 0) {
-            s_flush = (bt + 1 == b_hi || s_new + 4 * SEG_THREADS > SEG_H * 3 / 4 || since >= SEG_MAX_SINCE) ? 1u : 0u;
+            s_flush = (bt + 1 == b_hi || s_new + SEG_MARKS * SEG_THREADS > SEG_H * 3 / 4 || since >= SEG_MAX_SINCE) ? 1u : 0u;
             if (s_flush) s_new = 0;
         }
         __syncthreads();                                  // every thread sees the same decision; nobody marks meanwhile
@@ -171,7 +192,7 @@ constexpr int BIN_SUPER = 16;          // batches per dequeue
 constexpr int BIN_MAXI = 32;           // items per chunk
 constexpr uint32_t BIN_FILL = BIN_H * 5 / 8;
 
-struct BinSeg { uint32_t key, tb, t0, rd; int32_t st, ln, ntile; int64_t evoff; };
+struct BinSeg { uint32_t key, tb, t0, rd; int32_t st, ln, ntile; int64_t evoff; };      // ntile: ENTRIES of the segment = tiles it touches + window edges that cut it inside a tile
 
 __device__ __forceinline__ BinSeg bin_load(const BuildArgs& a, int64_t s) {
     BinSeg g; g.key = KEY_INVALID; g.tb = 0; g.t0 = 0; g.rd = 0; g.st = 0; g.ln = 0; g.ntile = 0; g.evoff = 0;
@@ -183,9 +204,33 @@ __device__ __forceinline__ BinSeg bin_load(const BuildArgs& a, int64_t s) {
             g.evoff = a.seg_ev_off[s]; g.rd = a.seg_read[s];
             g.t0 = g.tb + ((uint32_t)g.st >> 6);
             g.ntile = (int)(((uint32_t)(g.st + g.ln - 1) >> 6) - ((uint32_t)g.st >> 6)) + 1;
+            for (int64_t b = win_edge_after(g.st, a.window); b < (int64_t)g.st + g.ln; b += a.window) g.ntile += (b & 63) != 0;
         }
     }
     return g;
+}
+// entry k of a segment, in position order: its tile (relative to the segment's first) and its positions [lo, hi)
+__device__ __forceinline__ void bin_piece(const BinSeg& g, int32_t W, int k, uint32_t& tile_rel, int32_t& lo, int32_t& hi) {
+    const int32_t en = g.st + g.ln;
+    int shift = 0;
+    for (int64_t b = win_edge_after(g.st, W); b < en; b += W) {
+        if ((b & 63) == 0) continue;
+        const int idx = (int)((b >> 6) - (g.st >> 6)) + shift + 1;             // the entry that STARTS at this edge
+        if (k < idx) break;
+        if (k == idx) {
+            tile_rel = (uint32_t)((b >> 6) - (g.st >> 6)); lo = (int32_t)b;
+            const int32_t tend = (int32_t)(((b >> 6) + 1) << 6);
+            hi = en < tend ? en : tend;
+            return;
+        }
+        ++shift;
+    }
+    tile_rel = (uint32_t)(k - shift);
+    const int32_t tstart = (int32_t)((((uint32_t)g.st >> 6) + tile_rel) << 6);
+    lo = g.st > tstart ? g.st : tstart;
+    hi = en < tstart + TILE_W ? en : tstart + TILE_W;
+    const int64_t b = win_edge_after(lo, W);                                  // an edge inside the rest of the tile ends the entry
+    if (b < hi && (b & 63) != 0) hi = (int32_t)b;
 }
 
 __global__ __launch_bounds__(BIN_THREADS) void k_bin(BuildArgs a) {
@@ -228,7 +273,9 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(BuildArgs a) {
                     for (int j = 0; j < BIN_TPR; ++j) {
                         const int k = r * BIN_TPR + j;
                         if (k < g.ntile) {
-                            const uint32_t x = g.t0 + (uint32_t)k;
+                            uint32_t trel; int32_t lo_, hi_;
+                            bin_piece(g, a.window, k, trel, lo_, hi_);
+                            const uint32_t x = g.t0 + trel;
                             uint32_t h = (x * 2654435761u) >> HSHIFT;
                             while (true) {
                                 uint32_t prev = atomicCAS(&hkey[h], KEY_INVALID, x);
@@ -267,19 +314,20 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(BuildArgs a) {
                     for (int j = 0; j < BIN_TPR; ++j) {
                         const int k = rr * BIN_TPR + j;
                         if (k < g.ntile) {
-                            const uint32_t x = g.t0 + (uint32_t)k;
+                            uint32_t trel; int32_t lo, hi;
+                            bin_piece(g, a.window, k, trel, lo, hi);
+                            const uint32_t x = g.t0 + trel;
                             uint32_t h = (x * 2654435761u) >> HSHIFT;
                             while (hkey[h] != x) h = (h + 1) & (BIN_H - 1);
                             const uint32_t pos = atomicAdd(&hcnt[h], 1u);
                             const int32_t tstart = (int32_t)((x - g.tb) << 6);
-                            const int32_t lo = g.st > tstart ? g.st : tstart;
-                            const int32_t hi = g.st + g.ln < tstart + TILE_W ? g.st + g.ln : tstart + TILE_W;
+                            const int64_t edge = win_edge_in_tile(tstart, a.window);              // the entry lies in the window that starts inside its tile
                             const uint64_t src = (uint64_t)(g.evoff + (lo - g.st));             // the entry's first event in the caller's array
                             // everything the gather needs of an entry travels THROUGH the sort (no record fetched through the sort's
                             // permutation afterwards): key = barcode | first position in the tile | events - 1 | source of the events,
                             // sorted on its barcode bits only; value = owning read | first of its segment | forward strand
                             a.key[pos] = sort_key(g.key & CB_MASK, (uint32_t)(lo - tstart), (uint32_t)(hi - lo - 1), src, a.cb_bits);
-                            a.rdv[pos] = g.rd | (lo == g.st ? RV_SEGFIRST : 0u) | (((g.key >> 24) & 1u) ? 0u : RV_FWD);
+                            a.rdv[pos] = g.rd | (lo == g.st ? RV_SEGFIRST : 0u) | (((g.key >> 24) & 1u) ? 0u : RV_FWD) | (edge >= 0 && lo >= edge ? RV_WHI : 0u);
                         }
                     }
                 }
@@ -361,7 +409,7 @@ __global__ __launch_bounds__(TMG_WAVES * 64) void k_tm_gather(const uint16_t* ev
                 const bool single = rs && (i + 1 == n || ((uint32_t)key[j + 1] & cbm) != k);
                 const uint32_t geom = (uint32_t)(k64 >> cb_bits), first = geom & 63u, nev1 = (geom >> 6) & 63u;
                 const uint64_t src = k64 >> (cb_bits + 12);
-                put(s0 + p, k | ((v & RV_FWD) ? TM_FWD : 0u) | (rs ? TM_RUNSTART : 0u));
+                put(s0 + p, k | ((v & RV_FWD) ? TM_FWD : 0u) | ((v & RV_WHI) ? TM_WHI : 0u) | (rs ? TM_RUNSTART : 0u));
                 put(b8 + p, (uint8_t)(nev1 | ((v & RV_SEGFIRST) ? 64u : 0u) | (single ? 128u : 0u)));
                 put(rd + p, v & RV_READ);
                 e_src = (uint32_t)src; e_info = (uint32_t)(src >> 32) | (first << 8) | ((nev1 + 1u) << 16);
@@ -484,6 +532,7 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
     a.tile_base = c->d_tile_base.as<uint32_t>(); a.contig_len = c->d_contig_len.as<int64_t>(); a.n_contigs = c->n_contigs; a.n_tiles = T;
     a.seg_info = c->ws[WS_SEG_INFO].as<uint2>(); a.tile_cap = c->d_tile_cap.as<uint32_t>();
     a.lf_min_mq = c->lf_min_mq; a.lf_flag_exclude = c->lf_flag_exclude; a.lf_ignore_orphans = c->lf_ignore_orphans;
+    a.window = c->plp_window; c->st_window = c->plp_window;
     a.qhead = c->d_scalars.as<unsigned long long>(); a.bad = reinterpret_cast<uint32_t*>(c->d_scalars.as<unsigned long long>() + 2);
     a.n_ev = c->d_scalars.as<unsigned long long>() + 3;
     if (c->bt[BT_SPAN].reserve(((size_t)T + 2) * 4) || c->bt[BT_SPAN_RUN].reserve(((size_t)T + 2) * 4)) return -1;

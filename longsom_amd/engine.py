@@ -101,6 +101,11 @@ class Engine:
         BAM); later counts must be at least as strict.  Default: no filter (lsg_set_load_filter)."""
         _lib.check(self._lib.lsg_set_load_filter(self._h, int(min_mq), int(flag_exclude), int(ignore_orphans)), "lsg_set_load_filter")
 
+    def set_pileup_window(self, window: int = 50000):
+        """the reference's pileup windows (BaseCellCounter.py --bin): the loads that follow cut their entries at the window edges, the depth
+        cap of a count is replayed per window (lsg_set_pileup_window)"""
+        _lib.check(self._lib.lsg_set_pileup_window(self._h, int(window)), "lsg_set_pileup_window")
+
     def set_count_at_load(self, params=None):
         """The loads that follow also make the first count under `params` (a CountParams), in the pass that builds the store; the
         first pileup_count(params) after such a load returns that count without another pass.  None switches it off

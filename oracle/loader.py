@@ -31,8 +31,9 @@ def plp_set_legacy_del_merge(on):
     lib().plp_set_legacy_del_merge(C.c_int(1 if on else 0))
 
 
-def plp_count(bam_path, barcodes, celltype_of, ct, contig_len, refs, min_bq=20, min_mq=60, min_dp=5, min_cc=5, max_depth=200000):
-    """BAM-level column-major oracle (oracle/plp_oracle.c).  Returns keys, ref, counts[n,42]."""
+def plp_count(bam_path, barcodes, celltype_of, ct, contig_len, refs, min_bq=20, min_mq=60, min_dp=5, min_cc=5, max_depth=200000, window=50000):
+    """BAM-level column-major oracle (oracle/plp_oracle.c).  Returns keys, ref, counts[n,42].  window: the reference's pileup windows
+    (--bin 50000): with a depth cap every window is a pileup of its own (BaseCellCounter.py:185-191)."""
     L = lib()
     L.plp_count.restype = C.c_int64
     contig_len = np.ascontiguousarray(contig_len, np.int64)
@@ -43,7 +44,7 @@ def plp_count(bam_path, barcodes, celltype_of, ct, contig_len, refs, min_bq=20, 
     keys = np.zeros(cap, np.int64); ref = np.zeros(cap, np.uint8); counts = np.zeros((cap, 42), np.uint32)
     n = L.plp_count(os.fsencode(bam_path), "\n".join(barcodes).encode(), C.c_int32(len(barcodes)), _p(celltype_of), C.c_int32(ct),
                     C.c_int32(len(contig_len)), _p(contig_len), ref_ptrs, C.c_int32(min_bq), C.c_int32(min_mq), C.c_int32(min_dp),
-                    C.c_int32(min_cc), _p(keys), _p(ref), _p(counts), C.c_int64(cap), C.c_int32(max_depth))
+                    C.c_int32(min_cc), _p(keys), _p(ref), _p(counts), C.c_int64(cap), C.c_int32(max_depth), C.c_int32(window))
     if n < 0:
         raise RuntimeError("plp_count failed on %s" % bam_path)
     return keys[:n].copy(), ref[:n].copy(), counts[:n].copy()

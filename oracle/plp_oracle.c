@@ -18,7 +18,10 @@
  * answers in tests/golden/kat_pileup.json and by the tables the reference's own BaseCellCounter.py wrote over the column-replay
  * stand-in (tests/golden/pileup.*, tests/test_pileup_refgolden.py).  max_depth (BaseCellCounter.py:191: 200000) is
  * htslib's bam_plp_push rule: a read that starts at the iterator's current column — i.e. any read but the first of its start
- * position — is dropped while the buffer (reads not yet freed + the spare tail node) exceeds max_depth.
+ * position — is dropped while the buffer (reads not yet freed + the spare tail node) exceeds max_depth.  The reference opens a fresh
+ * pileup per 50 kb window (BaseCellCounter.py:185-191, windows [1, 50001), [50001, 100001), ... from MakeWindows :81-113) over the reads
+ * the index fetch returns for it, so with a cap the sweep below is made per window: its pool = the reads overlapping the window, its
+ * columns = the window's (:200); without a cap the windows are result-neutral and one sweep per file is made.
  */
 #include <stdint.h>
 #include <stdio.h>
@@ -98,9 +101,11 @@ static void resolve(read_t* r, int64_t pos, uint32_t* qpos, int* is_del, int* is
             if (op == 1 || op == 4) r->y += CLN(c);
         }
         r->k = (int32_t)k;
-    } else {
+    }
+    {
         uint32_t c = rd32(cg + 4 * r->k), l = CLN(c);
-        if (pos - r->x >= (int64_t)l) {               /* the column left this operation: move to the next M/D/N/=/X */
+        while (pos - r->x >= (int64_t)l) {            /* the column left this operation: move to the next M/D/N/=/X (several, when columns
+                                                         nobody looks at were skipped: the windowed sweep below) */
             if (match_op(COP(c))) r->y += l;
             r->x += l;
             uint32_t k;
@@ -110,6 +115,7 @@ static void resolve(read_t* r, int64_t pos, uint32_t* qpos, int* is_del, int* is
                 if (op2 == 1 || op2 == 4) r->y += CLN(c2);
             }
             r->k = (int32_t)k;
+            c = rd32(cg + 4 * r->k); l = CLN(c);
         }
     }
     uint32_t c = rd32(cg + 4 * r->k), op = COP(c), l = CLN(c);
@@ -161,7 +167,7 @@ static int easy_read_pileup(const read_t* r, uint32_t qpos, int is_del, int is_r
 int64_t plp_count(const char* bam_path, const char* barcodes, int32_t n_cb, const uint8_t* celltype_of, int32_t ct,
                   int32_t n_contigs, const int64_t* contig_len, const uint8_t* const* ref,
                   int32_t min_bq, int32_t min_mq, int32_t min_dp, int32_t min_cc,
-                  int64_t* out_keys, uint8_t* out_ref, uint32_t* out_counts, int64_t capacity, int32_t max_depth)
+                  int64_t* out_keys, uint8_t* out_ref, uint32_t* out_counts, int64_t capacity, int32_t max_depth, int32_t window)
 {
     size_t len = 0;
     uint8_t* d = inflate_all(bam_path, &len);
@@ -211,31 +217,58 @@ int64_t plp_count(const char* bam_path, const char* barcodes, int32_t n_cb, cons
         if (n == cap) { cap *= 2; rd = (read_t*)realloc(rd, sizeof(read_t) * cap); }
         rd[n++] = t;
     }
-    /* column sweep (input is coordinate sorted) */
+    /* column sweeps (input is coordinate sorted): one per pileup call of the reference */
     int64_t n_rows = 0;
-    size_t head = 0;
     read_t** act = (read_t**)malloc(sizeof(read_t*) * (n ? n : 1));
+    read_t** L = (read_t**)malloc(sizeof(read_t*) * (n ? n : 1));
     int32_t* cells = (int32_t*)malloc(sizeof(int32_t) * (n ? n : 1));
     int* syms = (int*)malloc(sizeof(int) * (n ? n : 1));
     uint32_t* quals = (uint32_t*)malloc(sizeof(uint32_t) * (n ? n : 1));
-    size_t n_act = 0;
-    int32_t cur_tid = -1; int64_t pos = 0;
-    while (head < n || n_act) {
-        if (!n_act) { cur_tid = rd[head].tid; pos = rd[head].pos; }
+    const int per_window = max_depth > 0 && window > 0;
+    size_t c0 = 0;                                                       /* first read of the current contig */
+    for (int32_t wt = 0; wt < (per_window ? n_contigs : 1); ++wt) {
+      while (per_window && c0 < n && rd[c0].tid < wt) ++c0;
+      size_t c1 = c0; while (per_window && c1 < n && rd[c1].tid == wt) ++c1;
+      const int64_t wlen = per_window ? contig_len[wt] : 0;
+      for (int64_t ws = 1; per_window ? ws < wlen : ws == 1; ws += (per_window ? window : 1)) {
+        const int64_t elo = per_window ? ws : 1, ehi = per_window ? ws + window : INT64_MAX;
+        size_t nl = 0;
+        if (per_window) { for (size_t i = c0; i < c1 && rd[i].pos < ehi; ++i) if (rd[i].end > elo) L[nl++] = &rd[i]; }      /* the index fetch: reads overlapping [ws, we) */
+        else for (size_t i = 0; i < n; ++i) L[nl++] = &rd[i];
+        if (!nl) continue;
+        size_t head = 0, n_act = 0;
+        int32_t cur_tid = -1; int64_t pos = 0;
+        for (size_t i = 0; i < nl; ++i) L[i]->k = -1;                  /* fresh pileup: the reads' CIGAR cursors start over */
+    while (head < nl || n_act) {
+        if (!n_act) { cur_tid = L[head]->tid; pos = L[head]->pos; }
         {   /* bam_plp_push: the first read of a start position always enters; later ones only while mp->cnt (= buffered + 1) <= maxcnt.
                The buffer still holds the reads that ended on the previous column (freed by the sweep below). */
             int first_here = 1;
-            while (head < n && rd[head].tid == cur_tid && rd[head].pos <= pos) {
-                if (max_depth > 0 && rd[head].pos == pos && !first_here && (int64_t)n_act + 1 > (int64_t)max_depth) { ++head; continue; }
+            while (head < nl && L[head]->tid == cur_tid && L[head]->pos <= pos) {
+                if (max_depth > 0 && L[head]->pos == pos && !first_here && (int64_t)n_act + 1 > (int64_t)max_depth) { ++head; continue; }
                 first_here = 0;
-                act[n_act++] = &rd[head++];
+                act[n_act++] = L[head++];
             }
         }
         /* drop finished reads */
         size_t w = 0;
         for (size_t i = 0; i < n_act; ++i) if (act[i]->end > pos) act[w++] = act[i];
         n_act = w;
-        if (!n_act) { if (head < n && rd[head].tid == cur_tid && rd[head].pos > pos) pos = rd[head].pos; else if (head < n) { cur_tid = -1; } continue; }
+        if (!n_act) { if (head < nl && L[head]->tid == cur_tid && L[head]->pos > pos) pos = L[head]->pos; else if (head < nl) { cur_tid = -1; } continue; }
+        /* Columns below the window are yielded by pysam and skipped by the script (:200): nothing of them is looked at but what the
+           buffer holds when the next read is pushed, so the sweep jumps to the next read's start (or the window's) - the reads that end
+           in between are freed before that push exactly as the skipped columns would have freed them.  Past the window nothing is left to do. */
+        if (pos >= ehi) break;
+        if (pos < elo) {
+            int64_t nx = elo;
+            if (head < nl && L[head]->tid == cur_tid && L[head]->pos < nx) nx = L[head]->pos;
+            if (nx <= pos) nx = pos + 1;
+            pos = nx;
+            w = 0;
+            for (size_t i = 0; i < n_act; ++i) if (act[i]->end > pos - 1) act[w++] = act[i];
+            n_act = w;
+            continue;
+        }
         /* one pileup column */
         int m = 0;
         for (size_t i = 0; i < n_act; ++i) {
@@ -249,7 +282,7 @@ int64_t plp_count(const char* bam_path, const char* barcodes, int32_t n_cb, cons
         int64_t clen = (cur_tid < n_contigs) ? contig_len[cur_tid] : 0;
         uint8_t refb = (ref && cur_tid < n_contigs && ref[cur_tid] && pos < clen) ? ref[cur_tid][pos] : (uint8_t)'?';
         int non_na = 0; for (int i = 0; i < m; ++i) non_na += syms[i] != 15;
-        if (pos >= 1 && pos < clen && m >= min_dp && refb != 'N' && non_na >= min_dp) {
+        if (pos >= elo && pos < ehi && pos < clen && m >= min_dp && refb != 'N' && non_na >= min_dp) {
             uint32_t bcn[8] = {0}, bq[8] = {0}, bcf[8] = {0}, bcr[8] = {0}, cc[8] = {0}, count = 0;
             for (int i = 0; i < m; ++i) {
                 read_t* r = act[cells[i]];
@@ -282,6 +315,9 @@ int64_t plp_count(const char* bam_path, const char* barcodes, int32_t n_cb, cons
         }
         ++pos;
     }
+      }
+    }
+    free(L);
     free(act); free(cells); free(syms); free(quals); free(rd); free(bc); free(bl); free(d);
     return n_rows;
 }

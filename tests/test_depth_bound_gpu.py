@@ -95,3 +95,35 @@ def test_count_with_a_depth_cap_equals_the_bam_level_oracle(engine, deep_sample,
         assert dp < dp_uncapped                                   # the cap really dropped reads
     else:
         assert dp <= dp_uncapped
+
+
+@pytest.mark.parametrize("window,max_depth", [(150, 37), (64, 5), (1000, 150)])
+def test_the_cap_is_replayed_per_pileup_window(engine, deep_sample, window, max_depth):
+    """every window [1 + k W, 1 + (k + 1) W) is a pileup of its own (BaseCellCounter.py:185-191): narrow windows put an edge into most tiles
+    of the deep genes - entries cut at the edges, reads dropped in one window and counted in the next - and the counts equal the
+    BAM-level oracle's, which sweeps window by window"""
+    from longsom_amd import tsvio
+    from longsom_amd._lib import CountParams
+    from oracle import loader
+    m, bam, fa, bct = deep_sample
+    engine.set_pileup_window(window)
+    try:
+        res = pipeline.load_sample(bam, bct, fa, engine, 60)
+        names, seqs = tsvio.read_fasta(fa)
+        engine.pileup_count(CountParams.longsom_defaults(max_depth=max_depth))
+        differs = False
+        for ct in range(2):
+            k, r, c = engine.fetch_counts(ct)
+            ok, orf, oc = loader.plp_count(bam, res.table.barcodes, res.table.celltype_of, ct, [len(s) for s in seqs], seqs, max_depth=max_depth, window=window)
+            assert np.array_equal(k, ok) and np.array_equal(r, orf) and np.array_equal(c, oc), "cell type %d" % ct
+            k1, _, c1 = loader.plp_count(bam, res.table.barcodes, res.table.celltype_of, ct, [len(s) for s in seqs], seqs, max_depth=max_depth, window=0)
+            differs |= not (np.array_equal(k, k1) and np.array_equal(c, c1))
+        assert differs                                            # one stream per contig would have counted something else
+        # without a cap the windows change nothing: the rows of the entries cut at the edges equal the events-level oracle's
+        engine.pileup_count(CountParams.longsom_defaults(max_depth=0))
+        for ct in range(2):
+            k, r, c = engine.fetch_counts(ct)
+            ok, orf, oc = loader.plp_count(bam, res.table.barcodes, res.table.celltype_of, ct, [len(s) for s in seqs], seqs, max_depth=0)
+            assert np.array_equal(k, ok) and np.array_equal(c, oc)
+    finally:
+        engine.set_pileup_window(50000)

@@ -141,3 +141,17 @@ def test_region_and_device_arrays(engine):
             np.testing.assert_array_equal(np.concatenate([parts[0][2][ct][j], parts[1][2][ct][j]]), ref_rows[ct][j])
     rows, cols = engine.pileup_count(p)                       # the whole genome over the store the second (regional) load wrote
     assert (rows, cols) == whole
+
+
+def test_entries_cut_at_pileup_window_edges_count_the_same(engine):
+    """narrow pileup windows (an edge inside most tiles): the entries are cut at the edges, the counts are not"""
+    lens = [4000, 2000]
+    rec, refs, ct_of = make_case(3, 30000, lens, 3000, hot_regions=[(0, 1000, 1100), (1, 500, 520)], hot_frac=0.9)
+    engine.set_pileup_window(100)
+    try:
+        fused_vs_oracle(engine, rec, lens, refs, ct_of, 2, CountParams.longsom_defaults())
+        n_cut = engine.store_shape()[0]
+    finally:
+        engine.set_pileup_window(50000)
+    fused_vs_oracle(engine, rec, lens, refs, ct_of, 2, CountParams.longsom_defaults())
+    assert n_cut > engine.store_shape()[0]                        # more entries, same rows

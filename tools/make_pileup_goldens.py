@@ -250,6 +250,28 @@ def main():
         tables_u, _ = run_chain(split, counter, bam, bc, os.path.join(OUT, "pileup.rand.fa"), "s", os.path.join(work, "cap_u"))
         open(os.path.join(OUT, "pileup.capoff.Cancer.tsv"), "w").write(strip_date(tables_u["Cancer"]))
         print("cap rows", tables["Cancer"].count("\n") - 9, "uncapped", tables_u["Cancer"].count("\n") - 9)
+        # ---- 3b. a capped pile that STRADDLES the 50 001 window edge (max_depth = 8): the reference opens a pileup per 50 kb window
+        # (BaseCellCounter.py:185-191), so the columns below 50 001 are counted out of window 1's buffer - long and short reads that
+        # start just before the edge - and the columns from 50 001 on out of window 2's, which only ever holds the long ones: reads the
+        # first pileup drops are counted by the second
+        capw_reads = []
+        for i in range(48):
+            pos = 49_960 + (i // 6) * 4                   # six reads at each of 49960, 49964, ... 49988 (0-based)
+            ln = 110 if i % 3 == 0 else 12                # every third one reaches over the edge, the others end before it
+            capw_reads.append(dict(tid=0, pos=pos, cigar="%dM" % ln, seq=seqs["chr1"][pos:pos + ln].upper().replace("N", "A"), qual=[30] * ln, flag=0x10 if i % 4 == 0 else 0,
+                                   mapq=60, tags={"CB": cells[i % 14]}, name="w%d" % i))
+        for i in range(12):
+            pos = 50_002 + i
+            capw_reads.append(dict(tid=0, pos=pos, cigar="40M", seq=seqs["chr1"][pos:pos + 40].upper().replace("N", "A"), qual=[30] * 40, flag=0, mapq=60,
+                                   tags={"CB": cells[(i * 5) % 14]}, name="x%d" % i))
+        capw_reads.sort(key=lambda r: (r["tid"], r["pos"]))
+        bam = os.path.join(OUT, "pileup.capw.bam")
+        bamwrite.write_bam(bam, contigs, capw_reads)
+        tables, report = run_chain(split, counter, bam, bc, os.path.join(OUT, "pileup.rand.fa"), "s", os.path.join(work, "capw"), max_depth=8)
+        open(os.path.join(OUT, "pileup.capw.Cancer.tsv"), "w").write(strip_date(tables["Cancer"]))
+        tables_u, _ = run_chain(split, counter, bam, bc, os.path.join(OUT, "pileup.rand.fa"), "s", os.path.join(work, "capw_u"))
+        open(os.path.join(OUT, "pileup.capwoff.Cancer.tsv"), "w").write(strip_date(tables_u["Cancer"]))
+        print("capw rows", tables["Cancer"].count("\n") - 9, "uncapped", tables_u["Cancer"].count("\n") - 9)
         # ---- 4. per-cell genotyping at target sites: HCCVSingleCellGenotype.py on the unsplit BAMs
         geno = load("CellTypeReannotation/HCCVSingleCellGenotype.py", "ref_genotype")
         rng = np.random.default_rng(7)
