@@ -76,7 +76,24 @@ def host_cores(cap=16):
     return max(1, min(n, int(os.environ.get("LSG_HOST_CORES", cap))))
 
 
-def cpu_baseline(eng, model, target_reads=150_000, call_sites=10_000):
+_CALL_STATE = {}
+
+
+def _call_span(span):
+    """one process of the CPU baseline's step 1: merge + calling_oracle.step1 over the sites in [lo, hi) (forked: the rows are inherited)"""
+    from oracle import calling_oracle
+    from longsom_amd import tsvio
+    lo, hi = span
+    sub = []
+    for k, r, c in _CALL_STATE["per_ct"]:
+        a, b = np.searchsorted(k, lo), np.searchsorted(k, hi)
+        sub.append((k[a:b], r[a:b], c[a:b]))
+    merged = tsvio.format_merged_tsv(sub, _CALL_STATE["names"], ["Cancer", "Non-Cancer"])
+    out = calling_oracle.step1(merged, _CALL_STATE["fasta"], info_lines=tsvio.STEP1_INFO_LINES)
+    return sum(1 for l in out.split("\n") if l and not l.startswith("#"))
+
+
+def cpu_baseline(eng, model, target_reads=150_000):
     """The CPU side of BASELINE.md §3 on this box's host cores, bounded to ~20 s:
       cpu_native  oracle/count_oracle.c (region-parallel, ALL host cores) on a contiguous-gene sample of the C2 workload, plus the
                   step-1 oracle (Python + scipy, one process, as the reference's step 1 is) scaled from a bounded number of sites;
@@ -116,17 +133,23 @@ def cpu_baseline(eng, model, target_reads=150_000, call_sites=10_000):
     t0 = time.time()
     cols1 = sum(loader.count(third, model.contig_len, refs, model.celltype_of, ct)[3] for ct in range(2))
     t_count1 = time.time() - t0
-    # step 1 on a bounded number of merged sites (scipy betabinom per alt, as the reference does)
-    sub = [(k[:call_sites], r[:call_sites], c[:call_sites]) for k, r, c in per_ct]
-    merged = tsvio.format_merged_tsv(sub, model.contig_names, ["Cancer", "Non-Cancer"])
-    n_call = sum(1 for l in merged.split("\n") if l and not l.startswith("#"))
+    # step 1 of EVERY merged site of the sample (scipy betabinom per alt, as the reference does), measured: `cores` processes, each over a
+    # contiguous range of the sites (the reference's step 1 is one process; an all-cores baseline gives it the same cores as the count)
+    import multiprocessing as mp
+    keys = np.unique(np.concatenate([p[0] for p in per_ct])) if n_cols else np.zeros(0, np.int64)
+    n_merged = int(len(keys))
     fasta = {model.contig_names[t]: refs[t].tobytes().decode() for t in tids}
+    _CALL_STATE.update(per_ct=per_ct, names=model.contig_names, fasta=fasta)
+    n_chunks = max(1, cores * 4)
+    cuts = [int(keys[min(n_merged - 1, n_merged * i // n_chunks)]) for i in range(n_chunks)] + [int(keys[-1]) + 1] if n_merged else [0, 0]
+    spans = [(cuts[i], cuts[i + 1]) for i in range(len(cuts) - 1) if cuts[i + 1] > cuts[i]]
     t0 = time.time()
-    calling_oracle.step1(merged, fasta, info_lines=tsvio.STEP1_INFO_LINES)
-    t_call_site = (time.time() - t0) / max(1, n_call)
-    n_merged = len(np.unique(np.concatenate([p[0] for p in per_ct]))) if n_cols else 0
-    # step 1 as `cores` processes would run it (the reference's step 1 is one process; an all-cores baseline gives it the same cores)
-    t_total = t_count + t_call_site * n_merged / cores
+    with mp.get_context("fork").Pool(cores) as pool:
+        n_call = sum(pool.imap_unordered(_call_span, spans))
+    t_call = time.time() - t0
+    assert n_call == n_merged, "the step-1 oracle's processes did not cover the sample's merged sites"
+    t_call_site = t_call * cores / max(1, n_call)                   # CPU time per site
+    t_total = t_count + t_call
     # cpu_pyloop on C1 (chr22-only, 50 k reads, 200 barcodes): the reference's loop structure on its 50 kb windows
     c1 = synth.named("C1")
     rec1 = hostio.synth_records(c1)
@@ -149,12 +172,11 @@ def cpu_baseline(eng, model, target_reads=150_000, call_sites=10_000):
     return {"value": n_cols / t_total if t_total > 0 else 0.0, "unit": "sites/s", "cores": cores, "kind": "port",
             "count_only": {"unit": "sites/s", "all_cores": n_cols / t_count if t_count > 0 else 0.0, "one_core": cols1 / t_count1 if t_count1 > 0 else 0.0,
                            "what": "oracle/count_oracle.c alone (lso_count_mt on %d threads / lso_count on one), no step 1" % cores},
-            "step1_only": {"unit": "merged sites/s", "one_process": 1.0 / t_call_site if t_call_site > 0 else 0.0,
-                           "what": "oracle/calling_oracle.py step1 (Python + scipy.stats.betabinom, as BaseCellCalling.step1.py:196-201), one process"},
-            "sample": "cpu_native: %d reads of %d contiguous genes of the C2 workload (%d events, %d columns): oracle/count_oracle.c (lso_count_mt) on %d "
-                      "threads (%.1f s) + oracle/calling_oracle.py step1 timed in one process on %d merged sites (%.2f ms/site), scaled to the sample's %d sites "
-                      "spread over the same cores"
-                      % (rec.n_reads, g_hi - g_lo, rec.n_events, n_cols, cores, t_count, n_call, t_call_site * 1e3, n_merged),
+            "step1_only": {"unit": "merged sites/s", "all_cores": n_call / t_call if t_call > 0 else 0.0, "per_process": 1.0 / t_call_site if t_call_site > 0 else 0.0,
+                           "what": "oracle/calling_oracle.py step1 (Python + scipy.stats.betabinom, as BaseCellCalling.step1.py:196-201), %d processes over contiguous site ranges" % cores},
+            "sample": "cpu_native: %d reads of %d contiguous genes of the C2 workload (%d events, %d columns), both stages MEASURED on %d cores: oracle/count_oracle.c "
+                      "(lso_count_mt, %d threads, %.1f s) + merge and oracle/calling_oracle.py step1 of all %d merged sites in %d processes (%.1f s)"
+                      % (rec.n_reads, g_hi - g_lo, rec.n_events, n_cols, cores, cores, t_count, n_merged, cores, t_call),
             "native_1core": {"value": cols1 / (t_count1 + t_call_site * n_merged / 3) if t_count1 > 0 else 0.0, "unit": "sites/s",
                              "sample": "%d reads (a third of the sample), lso_count single-threaded %.1f s" % (third.n_reads, t_count1)},
             "pyloop": {"kind": "port", "unit": "sites/s", "workload": "C1 (chr22-only, 50 k reads, 200 barcodes), the busiest 50 kb windows x 2 cell types",

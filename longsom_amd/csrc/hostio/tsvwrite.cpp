@@ -13,6 +13,9 @@
 #include <cstring>
 #include <string>
 #include <thread>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <unistd.h>
 #include <vector>
 
 #include "../../../include/longsom_hip.h"
@@ -29,20 +32,41 @@ const uint32_t SF_CANDIDATE = 1u << 31;
 thread_local char g_err[256] = "";
 void set_err(const char* m) { snprintf(g_err, sizeof(g_err), "%s", m); }
 
-inline void put_u64(std::string& s, uint64_t v) {
-    char b[24]; int n = 0;
-    do { b[n++] = (char)('0' + v % 10); v /= 10; } while (v);
-    while (n) s.push_back(b[--n]);
+// threads a writer starts by default: the cores this process may really use (its cgroup's CPU quota: the GPU box shows 256 cores and
+// grants 16), at most 32
+int default_threads() {
+    unsigned n = std::max(1u, std::thread::hardware_concurrency());
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[32]; long long per = 0;
+        if (fscanf(f, "%31s %lld", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0) { const long long c = (atoll(q) + per - 1) / per; if (c > 0 && (unsigned)c < n) n = (unsigned)c; }
+        fclose(f);
+    }
+    return (int)std::min(32u, n);
 }
+
+// decimal digits two at a time, written backwards into a small buffer; ONE append per number (per row in put_row): a push_back per
+// character (a capacity check each) was what the 16 GB of tables at C2 spent most of their time in
+static const char DIG2[] = "0001020304050607080910111213141516171819202122232425262728293031323334353637383940414243444546474849"
+                           "5051525354555657585960616263646566676869707172737475767778798081828384858687888990919293949596979899";
+inline char* fmt_u64(char* p, uint64_t v) {            // writes the digits of v at p, returns the end
+    char b[24]; int n = 0;
+    while (v >= 100) { const uint64_t q = v / 100; const unsigned r = (unsigned)(v - q * 100); b[n++] = DIG2[2 * r + 1]; b[n++] = DIG2[2 * r]; v = q; }
+    if (v >= 10) { b[n++] = DIG2[2 * v + 1]; b[n++] = DIG2[2 * v]; } else b[n++] = (char)('0' + v);
+    while (n) *p++ = b[--n];
+    return p;
+}
+inline void put_u64(std::string& s, uint64_t v) { char b[24]; s.append(b, (size_t)(fmt_u64(b, v) - b)); }
 inline void put_i64(std::string& s, int64_t v) { if (v < 0) { s.push_back('-'); put_u64(s, (uint64_t)(-v)); } else put_u64(s, (uint64_t)v); }
 
-// 'DP|NC|CC|BC|BQ|BCf|BCr' values of one 42-word row: six printed classes per vector
+// 'DP|NC|CC|BC|BQ|BCf|BCr' values of one 42-word row: six printed classes per vector (32 numbers of at most 10 digits and their separators)
 inline void put_row(std::string& s, const uint32_t* c) {
-    put_u64(s, c[0]); s.push_back('|'); put_u64(s, c[1]);
+    char buf[32 * 11 + 8]; char* p = buf;
+    p = fmt_u64(p, c[0]); *p++ = '|'; p = fmt_u64(p, c[1]);
     for (int o : {2, 10, 18, 26, 34}) {
-        s.push_back('|');
-        for (int k = 0; k < 6; ++k) { if (k) s.push_back(':'); put_u64(s, c[o + k]); }
+        *p++ = '|';
+        for (int k = 0; k < 6; ++k) { if (k) *p++ = ':'; p = fmt_u64(p, c[o + k]); }
     }
+    s.append(buf, (size_t)(p - buf));
 }
 
 // repr(k / 10000.0) for the integer k = round(p, 4) * 1e4 (0 <= k): shortest text, at least one decimal
@@ -95,40 +119,58 @@ inline void contig_range(const int64_t* keys, int64_t n, int tid, int64_t& lo, i
 // appends the texts to `path` in order.
 template <class F>
 int write_chunks(const char* path, const std::vector<int64_t>& order, int n_threads, F fmt) {
-    FILE* f = fopen(path, "ab");
-    if (!f) { set_err("cannot open the output file"); return -1; }
+    const int fd = open(path, O_WRONLY | O_CREAT, 0644);
+    if (fd < 0) { set_err("cannot open the output file"); return -1; }
+    off_t at = lseek(fd, 0, SEEK_END);                  // (the caller has written the header lines: rows are appended)
     const int64_t n = (int64_t)order.size();
-    const int T = n_threads > 0 ? n_threads : (int)std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    const int T = n_threads > 0 ? n_threads : default_threads();
     const int64_t CH = 16384;
     const int64_t n_chunks = (n + CH - 1) / CH;
-    // a batch of chunks is formatted by the threads while the batch before it is being written (one writer: the file's order)
+    // A batch of chunks is formatted by the threads; their sizes give every chunk its place in the file, and the same threads write their
+    // chunks there at once (pwrite): the copy into the page cache runs on every thread, not on one writer (2.6 GB/s for the 16 GB of C2's tables).
     std::atomic<bool> ok{true};
-    std::thread writer;
-    std::vector<std::string> writing;
+    bool use_mmap = getenv("LONGSOM_TABLES_MMAP") != nullptr;      // (measured on the GPU box: the page faults of a shared mapping cost more than the inode lock of pwrite; kept for file systems where they do not)
     for (int64_t c0 = 0; c0 < n_chunks && ok; c0 += (int64_t)T * 4) {
         const int64_t c1 = std::min(n_chunks, c0 + (int64_t)T * 4);
         std::vector<std::string> text((size_t)(c1 - c0));
-        std::atomic<int64_t> next(c0);
-        std::vector<std::thread> th;
-        for (int t = 0; t < T; ++t)
-            th.emplace_back([&]() {
-                for (int64_t c = next.fetch_add(1); c < c1; c = next.fetch_add(1)) {
-                    std::string& s = text[(size_t)(c - c0)];
-                    s.reserve(1u << 22);
-                    const int64_t e = std::min(n, (c + 1) * CH);
-                    for (int64_t i = c * CH; i < e; ++i) fmt(order[(size_t)i], s);
-                }
-            });
-        for (auto& t : th) t.join();
-        if (writer.joinable()) writer.join();
-        writing.swap(text);
-        writer = std::thread([&writing, &ok, f]() {
-            for (auto& s : writing)
-                if (!s.empty() && fwrite(s.data(), 1, s.size(), f) != s.size()) ok = false;
+        std::vector<off_t> where((size_t)(c1 - c0));
+        auto run = [&](auto&& body) {
+            std::atomic<int64_t> next(c0);
+            std::vector<std::thread> th;
+            for (int t = 0; t < T; ++t)
+                th.emplace_back([&]() { for (int64_t c = next.fetch_add(1); c < c1; c = next.fetch_add(1)) body(c); });
+            for (auto& t : th) t.join();
+        };
+        run([&](int64_t c) {
+            std::string& s = text[(size_t)(c - c0)];
+            s.reserve(1u << 22);
+            const int64_t e = std::min(n, (c + 1) * CH);
+            for (int64_t i = c * CH; i < e; ++i) fmt(order[(size_t)i], s);
         });
+        const off_t batch_at = at;
+        for (size_t i = 0; i < text.size(); ++i) { where[i] = at; at += (off_t)text[i].size(); }
+        // Buffered writes to ONE file serialise on its inode (one thread's copy into the page cache: ~1 GB/s on the GPU box); with
+        // LONGSOM_TABLES_MMAP=1 the pages of a shared mapping are faulted in and filled by every thread at once instead (slower there).
+        char* map = nullptr; size_t map_len = 0; off_t map_off = 0;
+        if (use_mmap && at > batch_at && ftruncate(fd, at) == 0) {
+            const long pg = sysconf(_SC_PAGESIZE);
+            map_off = batch_at / pg * pg; map_len = (size_t)(at - map_off);
+            void* m = mmap(nullptr, map_len, PROT_READ | PROT_WRITE, MAP_SHARED, fd, map_off);
+            if (m != MAP_FAILED) map = (char*)m; else use_mmap = false;
+        } else if (at > batch_at) use_mmap = false;
+        run([&](int64_t c) {
+            const std::string& s = text[(size_t)(c - c0)];
+            if (map) { memcpy(map + (where[(size_t)(c - c0)] - map_off), s.data(), s.size()); return; }
+            size_t done = 0;
+            while (done < s.size()) {
+                const ssize_t w = pwrite(fd, s.data() + done, s.size() - done, where[(size_t)(c - c0)] + (off_t)done);
+                if (w <= 0) { ok = false; return; }
+                done += (size_t)w;
+            }
+        });
+        if (map && munmap(map, map_len) != 0) ok = false;
     }
-    if (writer.joinable()) writer.join();
-    if (fclose(f) != 0) ok = false;
+    if (close(fd) != 0) ok = false;
     if (!ok) { set_err("write failed"); return -1; }
     return 0;
 }
@@ -172,6 +214,31 @@ bool keys_ok(const int64_t* keys, int64_t n, int n_contigs) {
 extern "C" {
 
 const char* lsio_tsv_last_error(void) { return g_err; }
+
+// A whole file from a buffer, the copy into the page cache spread over the threads (a shared mapping of the file: buffered writes to one
+// file serialise on its inode); the step-2 table of C2 is 2.7 GB.  Replaces the file.
+int lsio_write_bytes(const char* path, const char* data, int64_t n, int32_t n_threads) {
+    const int fd = open(path, O_RDWR | O_CREAT | O_TRUNC, 0644);
+    if (fd < 0) { set_err("cannot open the output file"); return -1; }
+    bool ok = true;
+    if (n > 0) {
+        void* m = (getenv("LONGSOM_TABLES_MMAP") != nullptr && ftruncate(fd, (off_t)n) == 0) ? mmap(nullptr, (size_t)n, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0) : MAP_FAILED;
+        if (m != MAP_FAILED) {
+            const int T = n_threads > 0 ? n_threads : default_threads();
+            const int64_t piece = std::max<int64_t>(1 << 22, (n + T - 1) / T);
+            std::vector<std::thread> th;
+            for (int64_t a = 0; a < n; a += piece) th.emplace_back([=]() { memcpy((char*)m + a, data + a, (size_t)std::min(piece, n - a)); });
+            for (auto& t : th) t.join();
+            if (munmap(m, (size_t)n) != 0) ok = false;
+        } else {
+            int64_t done = 0;
+            while (done < n) { const ssize_t w = pwrite(fd, data + done, (size_t)std::min<int64_t>(n - done, 1 << 30), (off_t)done); if (w <= 0) { ok = false; break; } done += w; }
+        }
+    }
+    if (close(fd) != 0) ok = false;
+    if (!ok) { set_err("write failed"); return -1; }
+    return 0;
+}
 void lsio_free_text(char* p) { free(p); }
 
 int lsio_write_count_rows(const char* path, const char* contig_names, int32_t n_contigs, const int64_t* keys, const uint8_t* refs,
@@ -238,8 +305,11 @@ int lsio_write_step1_rows(const char* path, const char* contig_names, int32_t n_
     for (size_t r = 0; r < order.size(); ++r) rank[(size_t)order[r]] = (int64_t)r;
     std::vector<std::string> cand_rows((size_t)((n_calls + 16383) / 16384));
     // (a chunk is formatted by exactly one thread: its candidate buffer needs no lock)
-    const int rc = write_chunks(path, order, n_threads, [&](int64_t i, std::string& s) {
+    const bool kept_only = path == nullptr || !*path;      // only the rows step 2 keeps are wanted: the others are not even formatted
+    const bool collect = cand_text != nullptr;
+    auto fmt_row = [&](int64_t i, std::string& s) {
         const lsg_call& c = calls[i];
+        if (kept_only && !(c.site_filter & SF_CANDIDATE)) return;      // (a row without an ALT is dropped by step 2's awk filter, step2.py:23)
         const int64_t k = c.key;
         const size_t row_start = s.size();
         s += names[(size_t)(k >> 32)]; s.push_back('\t');
@@ -303,9 +373,28 @@ int lsio_write_step1_rows(const char* path, const char* contig_names, int32_t n_
             if (r < 0) s += "NA"; else put_row(s, counts[ct] + r * LSG_ROW_WORDS);
         }
         s.push_back('\n');
-        if (is_cand_row) cand_rows[(size_t)(rank[(size_t)i] / 16384)].append(s, row_start, std::string::npos);
-    });
-    if (rc) return rc;
+        if (kept_only) { if (!is_cand_row) s.resize(row_start); return; }
+        if (is_cand_row && collect) cand_rows[(size_t)(rank[(size_t)i] / 16384)].append(s, row_start, std::string::npos);
+    };
+    if (kept_only) {
+        // the kept rows alone, chunk by chunk on the threads, straight into the chunks' candidate buffers
+        const int T = n_threads > 0 ? n_threads : default_threads();
+        std::atomic<int64_t> next(0);
+        const int64_t n_chunks = (n_calls + 16383) / 16384;
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; ++t)
+            th.emplace_back([&]() {
+                for (int64_t ch = next.fetch_add(1); ch < n_chunks; ch = next.fetch_add(1)) {
+                    std::string& s = cand_rows[(size_t)ch];
+                    const int64_t e = std::min<int64_t>(n_calls, (ch + 1) * 16384);
+                    for (int64_t r = ch * 16384; r < e; ++r) fmt_row(order[(size_t)r], s);
+                }
+            });
+        for (auto& t : th) t.join();
+    } else {
+        const int rc = write_chunks(path, order, n_threads, fmt_row);
+        if (rc) return rc;
+    }
     if (cand_text) {
         size_t tot = 0; for (auto& r : cand_rows) tot += r.size();
         char* out = (char*)malloc(tot + 1);

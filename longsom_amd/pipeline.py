@@ -231,11 +231,13 @@ def chain_step1(res: Resident, celltype_of: np.ndarray, celltype_names: List[str
         tsvio.write_merged_tsv(out.merged, per_ct, contig_names, celltype_names, date)
     header = [l + "\n" for l in tsvio.merged_header(celltype_names, date).split("\n") if l.startswith("##")]
     if background_tables:
-        # the per-cell-type and merged tables are written by a thread of their own (native writers, no GIL) beside the step-1 table
-        # (step 2 waits for its kept rows) and steps 2 and 3: the caller joins it (SnvOutputs.wait_for_tables)
+        # Steps 2 and 3 only need the rows step 2 keeps: those are formatted first (a third of the step-1 table's rows, nothing written);
+        # the per-cell-type and merged tables and the step-1 table itself are written by threads of their own (native writers, no GIL)
+        # beside steps 2 and 3 - the box's disk takes several files at once faster than one: the caller joins them (SnvOutputs.wait_for_tables)
+        s1 = tsvio.step1_kept_rows(calls, per_ct, contig_names, celltype_names, header, as_bytes=True)
         out.start_background(count_tables)
-        s1 = tsvio.write_step1_tsv(out.step1, calls, per_ct, contig_names, celltype_names, header, as_bytes=True)
-        t["write_tables"] = time.time() - t0
+        out.start_background(lambda: tsvio.write_step1_tsv(out.step1, calls, per_ct, contig_names, celltype_names, header, collect=False))
+        t["write_tables"] = time.time() - t0          # (what the chain waited for: the kept rows; tables_wait is what was left of the writers at the end)
         return out, s1, calls, t
     count_tables()
     s1 = tsvio.write_step1_tsv(out.step1, calls, per_ct, contig_names, celltype_names, header, as_bytes=True)      # s1 = header + the rows step 2 keeps
@@ -257,7 +259,7 @@ def run_chain(res: Resident, celltype_of: np.ndarray, celltype_names: List[str],
     af = calling.open_gnomad(gnomad_af_json)              # a JSON table or a gnomad_db directory / sqlite file
     s2 = calling.step2_bytes(s1, eng, contig_names, keys[0], keys[1], keys[2], params.min_distance, af, params.max_gnomad_vaf)
     out.step2 = os.path.join(d["BaseCellCalling"], sample_id + ".calling.step2.tsv")
-    open(out.step2, "wb").write(s2)
+    tsvio.write_bytes(out.step2, s2)
     t["step2"] = time.time() - t0
     if not step3:
         t["tables_wait"] = out.wait_for_tables()
@@ -267,8 +269,8 @@ def run_chain(res: Resident, celltype_of: np.ndarray, celltype_names: List[str],
     final, unfiltered = calling.step3_bytes(s2, params.delta_vaf, params.delta_mcf, params.min_ac_reads, params.min_ac_cells, params.clust_dist)
     out.step3 = os.path.join(d["BaseCellCalling"], sample_id + ".calling.step3.tsv")
     out.step3_unfiltered = os.path.join(d["BaseCellCalling"], sample_id + ".calling.step3.unfiltered.tsv")
-    open(out.step3, "wb").write(final)
-    open(out.step3_unfiltered, "wb").write(unfiltered)
+    tsvio.write_bytes(out.step3, final)
+    tsvio.write_bytes(out.step3_unfiltered, unfiltered)
     t["step3"] = time.time() - t0
     t["tables_wait"] = out.wait_for_tables()              # (what of the background writers' time steps 2 and 3 did not cover)
     out.timings = t

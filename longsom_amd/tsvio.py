@@ -258,6 +258,20 @@ def gather_lines(text: bytes, off: np.ndarray, length: np.ndarray, blank_na: boo
         lib.lsio_free_text(txt)
 
 
+def write_bytes(path: str, data: bytes, threads: int = 0) -> None:
+    """data -> path (replacing it), the copy into the page cache spread over the host's threads (lsio_write_bytes): the step-2 table of a
+    10 M-read sample is 2.7 GB, and one thread's write() moves about 1 GB/s"""
+    import ctypes as C
+    lib = _io()
+    lib.lsio_write_bytes.restype = C.c_int
+    lib.lsio_write_bytes.argtypes = [C.c_char_p, C.c_char_p, C.c_int64, C.c_int32]
+    if len(data) < (1 << 24):
+        with open(path, "wb") as f:
+            f.write(data)
+        return
+    _check(lib, lib.lsio_write_bytes(os.fsencode(path), data, len(data), threads), "lsio_write_bytes")
+
+
 def _take_bytes(ptr, n: int) -> bytes:
     """n bytes at ptr as a bytes object (ctypes.string_at takes a C int: the kept rows of a 10 M-read step-1 table are 2.7 GB)"""
     import ctypes as C
@@ -318,25 +332,37 @@ def write_merged_tsv(path, per_ct, contig_names, celltype_names, date_line=None,
 
 
 def write_step1_tsv(path, calls, per_ct, contig_names, celltype_names, header_lines: List[str], threads: int = 0, header: bool = True,
-                    as_bytes: bool = False):
+                    as_bytes: bool = False, collect: bool = True):
     """format_step1_tsv straight to `path`.  Returns the SMALL text step 2 needs: the comment lines, the column header and the
     rows its awk filter keeps (ALT != "." and FILTER != ".", BaseCellCalling.step2.py:23); header=False: the file gets the rows only
-    and the kept rows come back without the header; as_bytes: as bytes (what calling.step2_bytes takes), not str."""
+    and the kept rows come back without the header; as_bytes: as bytes (what calling.step2_bytes takes), not str.  collect=False: the
+    table is written and nothing comes back (the kept rows were taken earlier: step1_kept_rows).  path=None: nothing is written, only
+    the kept rows are formatted."""
     import ctypes as C
     lib = _io()
     head = step1_header(header_lines, celltype_names) if header else ""
-    with open(path, "w") as f:
-        f.write(head)
+    if path is not None:
+        with open(path, "w") as f:
+            f.write(head)
     ks, rs, cs, pk, pr, pc, n = _per_ct_ptrs(per_ct)
     calls = np.ascontiguousarray(calls)
     txt = C.c_void_p(); ln = C.c_int64(0)
-    _check(lib, lib.lsio_write_step1_rows(os.fsencode(path), "\n".join(contig_names).encode(), len(contig_names), len(per_ct), "\n".join(celltype_names).encode(),
-                                          calls.ctypes.data, len(calls), pk, pc, n.ctypes.data, threads, C.byref(txt), C.byref(ln)), "lsio_write_step1_rows")
+    _check(lib, lib.lsio_write_step1_rows(os.fsencode(path) if path is not None else None, "\n".join(contig_names).encode(), len(contig_names), len(per_ct),
+                                          "\n".join(celltype_names).encode(), calls.ctypes.data, len(calls), pk, pc, n.ctypes.data, threads,
+                                          C.byref(txt) if collect else None, C.byref(ln) if collect else None), "lsio_write_step1_rows")
+    if not collect:
+        return None
     try:
         rows = _take_bytes(txt.value, ln.value)
     finally:
         lib.lsio_free_text(txt)
     return head.encode() + rows if as_bytes else head + rows.decode()
+
+
+def step1_kept_rows(calls, per_ct, contig_names, celltype_names, header_lines: List[str], threads: int = 0, as_bytes: bool = True):
+    """what write_step1_tsv returns - header + the rows step 2 keeps - without writing the table: only those rows are formatted (a third
+    of C2's 23.9 M), so steps 2 and 3 start while the tables are still on their way to the disk"""
+    return write_step1_tsv(None, calls, per_ct, contig_names, celltype_names, header_lines, threads=threads, as_bytes=as_bytes)
 
 
 def _p(k: int) -> str:

@@ -95,6 +95,11 @@ def test_step1_rows(tmp_path, n_ct):
     keep = [l for l in want.split("\n") if l and (l.startswith("#") or (l.split("\t")[4] != "." and l.split("\t")[5] != "."))]
     assert small == "\n".join(keep) + "\n"
     assert sum(1 for l in keep if not l.startswith("#")) > 100
+    # the kept rows alone (nothing written, the other rows not formatted) and the table alone (nothing returned): what the fused chain uses
+    assert tsvio.step1_kept_rows(calls, per_ct, NAMES, cts, header, threads=3, as_bytes=False) == small
+    p2 = str(tmp_path / "s1b.tsv")
+    assert tsvio.write_step1_tsv(p2, calls, per_ct, NAMES, cts, header, threads=4, collect=False) is None
+    assert open(p2).read() == want
 
 
 def test_ratio_and_p_text_match_python():
