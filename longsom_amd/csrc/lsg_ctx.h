@@ -110,6 +110,7 @@ struct lsg_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t copy_stream = nullptr;      // the load's copies of the caller's device arrays run here, beside the build's first kernels
     hipEvent_t ev_copy = nullptr;
+    hipEvent_t ev_blk = nullptr;            // store.hip: the blocks' tiles are made on the copy stream
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t evb[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};      // store.hip: the build's phases
 

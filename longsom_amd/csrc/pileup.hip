@@ -371,6 +371,8 @@ __device__ __noinline__ bool tm_dropped_here(const CountArgs& a, uint32_t r, uin
 
 // per count and pass: the word the walk reads per entry.  Admission under THIS count's parameters (the entry's read: its bit of
 // k_read_stats' bitmap - SAM flag, MAPQ, the depth cap's drops), cell type under THIS barcode table, region.
+// DROPS: some reads are dropped by the depth cap in SOME of their windows (the look-up is a call: kept out of the common instantiation)
+template <bool DROPS>
 __global__ __launch_bounds__(256) void k_tm_resolve(CountArgs a, TmArgs tm, unsigned long long* stat_slots) {
     __shared__ unsigned long long s_stat[3];
     if (threadIdx.x == 0) { s_stat[0] = 0; s_stat[1] = 0; s_stat[2] = 0; }
@@ -399,7 +401,7 @@ __global__ __launch_bounds__(256) void k_tm_resolve(CountArgs a, TmArgs tm, unsi
                 cls = 2;
                 bool ok = cb < (uint32_t)a.n_cb;             // (pad entries carry CB_MASK)
                 if (ok && a.adm) ok = (reinterpret_cast<const uint32_t*>(a.adm)[rv[u] >> 5] >> (rv[u] & 31u)) & 1u;
-                if (ok && a.drop_pairs && a.read_drop[rv[u]] == 2) ok = !tm_dropped_here(a, rv[u], tile, s);
+                if (DROPS) { if (ok && a.read_drop[rv[u]] == 2) ok = !tm_dropped_here(a, rv[u], tile, s); }
                 if (ok) { const uint32_t ct = a.celltype_of[cb]; if (ct < (uint32_t)a.n_ct && (ct >> 1) == (uint32_t)(tm.ct_base >> 1)) cls = ct & 1u; }
             }
             if (cls < 2) { ev += (b8 & 63u) + 1u; sg += (b8 >> 6) & 1u; ++ne; }
@@ -1171,7 +1173,8 @@ static int count_passes(lsg_ctx* c, CountLaunch& L, int first_pass, bool wide_of
         if (wide_only && !grid_wide) continue;
         L.tm.ct_base = 2 * pass;
         if (pass) LSG_HIP(hipMemsetAsync(L.a.scalars + SC_QWALK, 0, 8, st));          // the walk's chunk queue starts over
-        hipLaunchKernelGGL(k_tm_resolve, dim3((c->tm_nblk + 255) / 256), dim3(256), 0, st, L.a, L.tm, wide_only ? (unsigned long long*)nullptr : c->d_ix_stat.as<unsigned long long>());
+        if (L.a.drop_pairs) hipLaunchKernelGGL(k_tm_resolve<true>, dim3((c->tm_nblk + 255) / 256), dim3(256), 0, st, L.a, L.tm, wide_only ? (unsigned long long*)nullptr : c->d_ix_stat.as<unsigned long long>());
+        else hipLaunchKernelGGL(k_tm_resolve<false>, dim3((c->tm_nblk + 255) / 256), dim3(256), 0, st, L.a, L.tm, wide_only ? (unsigned long long*)nullptr : c->d_ix_stat.as<unsigned long long>());
         if (pass == 0) { LSG_HIP(hipEventRecord(c->ev[1], st)); LSG_HIP(hipEventRecord(c->ev[3], st)); }
         if (c->tm_njobs && !wide_only) hipLaunchKernelGGL(k_tm_walk, dim3(L.grid_walk), dim3(TMW_WAVES * 64), 0, st, L.a, L.tm);
         if (pass == 0) LSG_HIP(hipEventRecord(c->ev[4], st));

@@ -60,7 +60,8 @@ struct BuildArgs {
 // The edges of the reference's pileup windows (BaseCellCounter.py:81-113: [1, 50001), [50001, 100001), ...) that lie INSIDE a tile cut
 // the segments crossing them: the tile gets two entries of such a segment, one per window, because with max_depth every window is a
 // pileup of its own (:185-191) and a read may be dropped in one and counted in the next.  First edge after position x:
-__device__ __forceinline__ int64_t win_edge_after(int64_t x, int32_t W) { return 1 + (int64_t)W * ((x >= 1 ? (x - 1) / W : 0) + 1); }
+// (positions are below 2^31: one 32-bit division)
+__device__ __forceinline__ int64_t win_edge_after(int64_t x, int32_t W) { return 1 + (int64_t)W * (int64_t)((x >= 1 ? (uint32_t)(x - 1) / (uint32_t)W : 0u) + 1u); }
 // the edge strictly inside the tile that starts at tstart (W >= 64: at most one), or -1
 __device__ __forceinline__ int64_t win_edge_in_tile(int64_t tstart, int32_t W) {
     const int64_t b = win_edge_after(tstart, W);
@@ -76,7 +77,7 @@ __device__ __forceinline__ int64_t win_edge_in_tile(int64_t tstart, int32_t W) {
 // The tiles' CAPACITIES come out of the same pass the same way: a segment's entries are the tiles of one contiguous range, so +1 at its
 // first tile and -1 past its last one, summed along the tiles, is the number of entries of every tile — two marks per segment where a
 // counting pass over the entries (0.9 ms of LDS atomics for C2's 185 M entries) made one per entry.
-constexpr int SEG_THREADS = 256, SEG_H = 4096, SEG_MAX_SINCE = 24, SEG_MARKS = 6;       // (24 x 1024 marks of one sign at most per half word; 6 marks per segment: 2 + 2, 2 at a window edge)
+constexpr int SEG_THREADS = 256, SEG_H = 2048, SEG_MAX_SINCE = 24, SEG_MARKS = 4;       // (24 x 512 marks of one sign at most per half word; 4 marks per segment go through the hash)
 __global__ __launch_bounds__(SEG_THREADS) void k_seg_static(BuildArgs a) {
     __shared__ uint32_t hkey[SEG_H];
     __shared__ int32_t hval[SEG_H];       // both sums of a tile in one word: span marks in the low half, capacity marks x 65536 (each at most 512 in size per batch, SEG_MAX_SINCE batches per flush)
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(SEG_THREADS) void k_seg_static(BuildArgs a) {
     for (int i = threadIdx.x; i < SEG_H; i += SEG_THREADS) { hkey[i] = KEY_INVALID; hval[i] = 0; }
     if (threadIdx.x == 0) { s_ev = 0; s_new = 0; s_flush = 0; }
     auto slot = [&](uint32_t t) {
-        uint32_t h = (t * 2654435761u) >> 20;
+        uint32_t h = (t * 2654435761u) >> 21;
         while (true) {
             const uint32_t prev = atomicCAS(&hkey[h], KEY_INVALID, t);
             if (prev == KEY_INVALID) { atomicAdd(&s_new, 1u); break; }
@@ -107,6 +108,7 @@ __global__ __launch_bounds__(SEG_THREADS) void k_seg_static(BuildArgs a) {
     __syncthreads();
     for (int64_t bt = b_lo; bt < b_hi; ++bt) {
         const int64_t s = bt * SEG_THREADS + threadIdx.x;
+        uint32_t edge_tile = KEY_INVALID;                   // tile of the first window edge inside this thread's segment
         if (s < a.n_segs) {
             const uint32_t r = a.seg_read[s];
             uint32_t key = KEY_INVALID, tb = 0;
@@ -127,13 +129,14 @@ __global__ __launch_bounds__(SEG_THREADS) void k_seg_static(BuildArgs a) {
                         n_ev += (unsigned long long)ln;
                         mark_cap(tb + ((uint32_t)st >> 6), 1);
                         mark_cap(tb + ((uint32_t)(st + ln - 1) >> 6) + 1, -1);
-                        // one more entry in the tile of every window edge strictly inside the segment (the first one through the hash, further
-                        // ones - a segment longer than a window - straight to memory: the hash is sized for SEG_MARKS marks per segment)
+                        // one more entry in the tile of every window edge strictly inside the segment: rare (one segment in forty), so not
+                        // through the hash - the first edge's tile is handed to the wave below (neighbouring segments of a deep gene cross
+                        // the SAME edge: one atomic per distinct tile and wave), further ones (a segment longer than a window) straight to memory
                         int nb = 0;
                         for (int64_t b = win_edge_after(st, a.window); b < st + ln; b += a.window) {
                             if ((b & 63) == 0) continue;                     // (an edge on a tile boundary cuts nothing)
                             const uint32_t t = tb + (uint32_t)(b >> 6);
-                            if (nb++ == 0) { mark_cap(t, 1); mark_cap(t + 1, -1); }
+                            if (nb++ == 0) edge_tile = t;
                             else { atomicAdd(a.cap_diff + t, 1); atomicAdd(a.cap_diff + t + 1, -1); }
                         }
                     }
@@ -152,6 +155,12 @@ __global__ __launch_bounds__(SEG_THREADS) void k_seg_static(BuildArgs a) {
                 }
             }
             a.seg_info[s] = make_uint2(key, tb);
+        }
+        for (unsigned long long todo = __ballot(edge_tile != KEY_INVALID); todo;) {      // (every lane of the wave is here)
+            const uint32_t lt = (uint32_t)__shfl((int)edge_tile, __ffsll((long long)todo) - 1);
+            const unsigned long long same = __ballot(edge_tile == lt);
+            if ((threadIdx.x & 63) == (unsigned)(__ffsll((long long)todo) - 1)) { const int n = __popcll(same); atomicAdd(a.cap_diff + lt, n); atomicAdd(a.cap_diff + lt + 1, -n); }
+            todo &= ~same;
         }
         ++since;
         __syncthreads();                                  // the batch's marks are in
@@ -192,10 +201,10 @@ constexpr int BIN_SUPER = 16;          // batches per dequeue
 constexpr int BIN_MAXI = 32;           // items per chunk
 constexpr uint32_t BIN_FILL = BIN_H * 5 / 8;
 
-struct BinSeg { uint32_t key, tb, t0, rd; int32_t st, ln, ntile; int64_t evoff; };      // ntile: ENTRIES of the segment = tiles it touches + window edges that cut it inside a tile
+struct BinSeg { uint32_t key, tb, t0, rd; int32_t st, ln, ntile; int64_t evoff, b1; };      // ntile: ENTRIES of the segment = tiles it touches + window edges that cut it inside a tile; b1: the first window edge after its start
 
 __device__ __forceinline__ BinSeg bin_load(const BuildArgs& a, int64_t s) {
-    BinSeg g; g.key = KEY_INVALID; g.tb = 0; g.t0 = 0; g.rd = 0; g.st = 0; g.ln = 0; g.ntile = 0; g.evoff = 0;
+    BinSeg g; g.key = KEY_INVALID; g.tb = 0; g.t0 = 0; g.rd = 0; g.b1 = 0; g.st = 0; g.ln = 0; g.ntile = 0; g.evoff = 0;
     if (s < a.n_segs) {
         const uint2 info = a.seg_info[s];
         g.key = info.x; g.tb = info.y;
@@ -204,7 +213,8 @@ __device__ __forceinline__ BinSeg bin_load(const BuildArgs& a, int64_t s) {
             g.evoff = a.seg_ev_off[s]; g.rd = a.seg_read[s];
             g.t0 = g.tb + ((uint32_t)g.st >> 6);
             g.ntile = (int)(((uint32_t)(g.st + g.ln - 1) >> 6) - ((uint32_t)g.st >> 6)) + 1;
-            for (int64_t b = win_edge_after(g.st, a.window); b < (int64_t)g.st + g.ln; b += a.window) g.ntile += (b & 63) != 0;
+            g.b1 = win_edge_after(g.st, a.window);
+            for (int64_t b = g.b1; b < (int64_t)g.st + g.ln; b += a.window) g.ntile += (b & 63) != 0;
         }
     }
     return g;
@@ -213,7 +223,8 @@ __device__ __forceinline__ BinSeg bin_load(const BuildArgs& a, int64_t s) {
 __device__ __forceinline__ void bin_piece(const BinSeg& g, int32_t W, int k, uint32_t& tile_rel, int32_t& lo, int32_t& hi) {
     const int32_t en = g.st + g.ln;
     int shift = 0;
-    for (int64_t b = win_edge_after(g.st, W); b < en; b += W) {
+    int64_t b = g.b1;                                        // (almost always past the segment: no edge, no loop turn, no division)
+    for (; b < en; b += W) {
         if ((b & 63) == 0) continue;
         const int idx = (int)((b >> 6) - (g.st >> 6)) + shift + 1;             // the entry that STARTS at this edge
         if (k < idx) break;
@@ -229,8 +240,7 @@ __device__ __forceinline__ void bin_piece(const BinSeg& g, int32_t W, int k, uin
     const int32_t tstart = (int32_t)((((uint32_t)g.st >> 6) + tile_rel) << 6);
     lo = g.st > tstart ? g.st : tstart;
     hi = en < tstart + TILE_W ? en : tstart + TILE_W;
-    const int64_t b = win_edge_after(lo, W);                                  // an edge inside the rest of the tile ends the entry
-    if (b < hi && (b & 63) != 0) hi = (int32_t)b;
+    if (b < hi && b > lo && (b & 63) != 0) hi = (int32_t)b;   // the next edge (the one the loop stopped at) inside the rest of the tile ends the entry
 }
 
 __global__ __launch_bounds__(BIN_THREADS) void k_bin(BuildArgs a) {
@@ -321,7 +331,10 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(BuildArgs a) {
                             while (hkey[h] != x) h = (h + 1) & (BIN_H - 1);
                             const uint32_t pos = atomicAdd(&hcnt[h], 1u);
                             const int32_t tstart = (int32_t)((x - g.tb) << 6);
-                            const int64_t edge = win_edge_in_tile(tstart, a.window);              // the entry lies in the window that starts inside its tile
+                            // the entry lies in the window that STARTS inside its tile: an edge in (tstart, lo].  Edges the segment crosses are
+                            // known (b1, b1 + W, ...); a segment that starts behind its tile's edge finds it one window before b1
+                            int64_t edge = -1;
+                            { int64_t e = g.b1 - a.window; while (e + a.window <= lo) e += a.window; if (e > tstart && e <= lo && e > 1) edge = e; }
                             const uint64_t src = (uint64_t)(g.evoff + (lo - g.st));             // the entry's first event in the caller's array
                             // everything the gather needs of an entry travels THROUGH the sort (no record fetched through the sort's
                             // permutation afterwards): key = barcode | first position in the tile | events - 1 | source of the events,
@@ -590,13 +603,7 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
     hipLaunchKernelGGL(k_tile_blocks, dim3((T + 256) / 256), dim3(256), 0, st, c->d_tile_cap.as<uint32_t>(), T, c->bt[BT_BLK].as<uint32_t>());
     SCAN_U32(c->bt[BT_BLK].as<uint32_t>(), blk_off, T + 1);
     uint32_t total = 0, bad = 0, n_netile = 0, nblk = 0; int32_t max_cb = 0, max_live = 0;
-    LSG_HIP(hipMemcpyAsync(&n_netile, d_small + 1, 4, hipMemcpyDeviceToHost, st));
-    LSG_HIP(hipMemcpyAsync(&nblk, blk_off + T, 4, hipMemcpyDeviceToHost, st));
-    LSG_HIP(hipMemcpyAsync(&max_live, d_small + 3, 4, hipMemcpyDeviceToHost, st));
     unsigned long long n_ev = 0, sum = 0;
-    LSG_HIP(hipMemcpyAsync(&n_ev, a.n_ev, 8, hipMemcpyDeviceToHost, st));
-    LSG_HIP(hipMemcpyAsync(&bad, a.bad, 4, hipMemcpyDeviceToHost, st));
-    if (R > 0) LSG_HIP(hipMemcpyAsync(&max_cb, d_small + 2, 4, hipMemcpyDeviceToHost, st));
     // (a total of 2^32 or more wraps the 32-bit scan: the per-tile capacities are summed in 64 bits to tell)
     {
         unsigned long long* d_sum = c->d_scalars.as<unsigned long long>() + 8;
@@ -606,9 +613,18 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
         if (tmp.reserve(tb + 256)) return -1;
         tb = tmp.cap;
         LSG_HIP(hipcub::DeviceReduce::Sum(tmp.p, tb, it, d_sum, (int)T, st));
-        LSG_HIP(hipMemcpyAsync(&sum, d_sum, 8, hipMemcpyDeviceToHost, st));
     }
-    LSG_HIP(hipStreamSynchronize(st));                    // the load's first look at the device: sizes of everything that follows
+    // the load's first look at the device: the sizes of everything that follows, in TWO small copies to pinned memory (the scalars'
+    // block, and the number of blocks where the scan left it) - seven separate copies were seven commands of ~20 us each on the stream
+    LSG_HIP(hipMemcpyAsync(c->h_pin, c->d_scalars.p, 9 * 8, hipMemcpyDeviceToHost, st));
+    LSG_HIP(hipMemcpyAsync(c->h_pin + 16, blk_off + T, 4, hipMemcpyDeviceToHost, st));
+    LSG_HIP(hipStreamSynchronize(st));
+    {
+        const unsigned long long* hp = c->h_pin;
+        const uint32_t* hs = reinterpret_cast<const uint32_t*>(hp + 4);      // d_small[0..3]
+        bad = (uint32_t)hp[2]; n_ev = hp[3]; n_netile = hs[1]; max_cb = R > 0 ? (int32_t)hs[2] : 0; max_live = (int32_t)hs[3]; sum = hp[8];
+        nblk = (uint32_t)hp[16];
+    }
     if (bad & 2u) { set_error("lsg_load_reads: a segment's read index lies outside the read arrays"); return -2; }
     if (bad & 1u) { set_error("lsg_load_reads: a segment's event range lies outside the events array"); return -2; }
     if (sum >= 0x7FFFFFF0ull) { set_error("lsg_load_reads: %llu tile entries exceed the 31-bit entry index; load the reads in windows", sum); return -2; }
@@ -668,15 +684,18 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
     if (c->tm[TM_S0].reserve((np + 16) * 4) || c->tm[TM_B].reserve(np + 16) ||
         c->tm[TM_RD].reserve((np + 16) * 4) || c->tm[TM_META].reserve((np + 8 * (TM_GROUP + 1)) * 4) ||
         c->tm[TM_BLK_TILE].reserve(((size_t)nblk + 2) * 4) || c->tm[TM_EXT].reserve(((size_t)nblk + TM_GROUP + 2) * 2)) return -1;
-    {
+    {   // the tile of every block (the re-counts' resolve and the plain gather read it; the fused pass does not): beside the scatter and the
+        // sort, on the copy stream - it follows from the capacities alone
+        hipStream_t bs = c->copy_stream;
         uint32_t* bt_ = c->tm[TM_BLK_TILE].as<uint32_t>();
-        LSG_HIP(hipMemsetAsync(bt_, 0, (size_t)nblk * 4, st));
-        hipLaunchKernelGGL(k_tm_blk_mark, dim3((T + 255) / 256), dim3(256), 0, st, c->d_tile_cap.as<uint32_t>(), blk_off, T, bt_);
+        LSG_HIP(hipMemsetAsync(bt_, 0, (size_t)nblk * 4, bs));
+        hipLaunchKernelGGL(k_tm_blk_mark, dim3((T + 255) / 256), dim3(256), 0, bs, c->d_tile_cap.as<uint32_t>(), blk_off, T, bt_);
         size_t tb = 0;
-        LSG_HIP(hipcub::DeviceScan::InclusiveScan(nullptr, tb, bt_, bt_, hipcub::Max(), (int)nblk, st));
-        if (tmp.reserve(tb + 256)) return -1;
-        tb = tmp.cap;
-        LSG_HIP(hipcub::DeviceScan::InclusiveScan(tmp.p, tb, bt_, bt_, hipcub::Max(), (int)nblk, st));
+        LSG_HIP(hipcub::DeviceScan::InclusiveScan(nullptr, tb, bt_, bt_, hipcub::Max(), (int)nblk, bs));
+        if (c->d_cub_tmp.reserve(tb + 256)) return -1;
+        tb = c->d_cub_tmp.cap;
+        LSG_HIP(hipcub::DeviceScan::InclusiveScan(c->d_cub_tmp.p, tb, bt_, bt_, hipcub::Max(), (int)nblk, bs));
+        LSG_HIP(hipEventRecord(c->ev_blk, bs));
     }
     LSG_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c->tm[TM_S0].as<uint32_t>() + np), (int)TM_PAD_S0, 16, st));       // (what the walk's group loads and the run flags' neighbours see past the end)
     LSG_HIP(hipMemsetAsync(c->tm[TM_B].as<uint8_t>() + np, 0, 16, st));
@@ -723,6 +742,7 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
         c->counted_at_load = rc == 0;                         // (a count that could not be kept - rows outgrew their buffer - is made again on request; the store is whole either way)
         if (rc) c->counted = false;
     } else {
+    LSG_HIP(hipStreamWaitEvent(st, c->ev_blk, 0));                  // (the blocks' tiles, made on the copy stream)
     const bool plan_early = c->n_ct > 0 && c->copy_stream && c->ev_copy;
     if (plan_early) LSG_HIP(hipEventRecord(c->ev_copy, st));       // everything the gather waits for is what the plan's tile-level half waits for
     {
