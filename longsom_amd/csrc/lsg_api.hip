@@ -60,7 +60,7 @@ int lsg_create(int device_id, lsg_ctx** out) {
     lsg_ctx* c = new lsg_ctx();
     c->device = device_id;
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) c->n_cus = prop.multiProcessorCount; }
-    if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_blk, hipEventDisableTiming) != hipSuccess ||
+    if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_blk, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_lpt, hipEventDisableTiming) != hipSuccess ||
         hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
         set_error("lsg_create: hipStreamCreate failed"); delete c; return -1;
     }
@@ -98,6 +98,7 @@ void lsg_destroy(lsg_ctx* c) {
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->ev_copy) (void)hipEventDestroy(c->ev_copy);
     if (c->ev_blk) (void)hipEventDestroy(c->ev_blk);
+    if (c->ev_lpt) (void)hipEventDestroy(c->ev_lpt);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     delete c;
 }

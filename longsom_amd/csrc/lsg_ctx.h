@@ -111,6 +111,7 @@ struct lsg_ctx {
     hipStream_t copy_stream = nullptr;      // the load's copies of the caller's device arrays run here, beside the build's first kernels
     hipEvent_t ev_copy = nullptr;
     hipEvent_t ev_blk = nullptr;            // store.hip: the blocks' tiles are made on the copy stream
+    hipEvent_t ev_lpt = nullptr;            // ... and the sort's segments ordered deepest first
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t evb[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};      // store.hip: the build's phases
 
@@ -140,7 +141,7 @@ struct lsg_ctx {
     // tile store (see above) and the plan of a count over it
     lsg::DevBuf d_tile_cap, d_tile_off;   // entries per tile and their exclusive prefix
     lsg::DevBuf tm[lsg::TM_NBUF];
-    lsg::DevBuf bt[16];                   // temporaries of the build (kept while they are small against the device: allocation is what a rebuild would wait for)
+    lsg::DevBuf bt[18];                   // temporaries of the build (kept while they are small against the device: allocation is what a rebuild would wait for)
     uint64_t tm_n = 0;                    // entries
     int64_t tm_events = 0;                // events they hold
     uint64_t tm_np = 0;                   // padded entries = 8 x blocks

@@ -366,6 +366,10 @@ __global__ void k_seg_bounds(const uint32_t* netile, uint32_t n, const uint32_t*
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { const uint32_t t = netile[i]; begin[i] = tile_off[t]; end[i] = tile_off[t + 1]; }
 }
+__global__ void k_tile_caps(const uint32_t* tiles, uint32_t n, const uint32_t* cap, uint32_t* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = cap[tiles[i]] >> 11;
+}
 // the tile of every block: a non-empty tile writes its number at its first block, a running maximum over the blocks carries it on
 // (the tiles' numbers grow with the blocks; a binary search per block over the tiles' offsets took 0.27 ms at C2)
 __global__ void k_tm_blk_mark(const uint32_t* cap, const uint32_t* blk_off, uint32_t n_tiles, uint32_t* blk_tile) {
@@ -485,7 +489,7 @@ __global__ __launch_bounds__(TMG_WAVES * 64) void k_tm_gather(const uint16_t* ev
         LSG_HIP(hipcub::DeviceScan::ExclusiveSum(c->d_cub_tmp.p, tb_, (in), (out), (int)(n), st));       \
     } while (0)
 
-enum { BT_KEY_A = 0, BT_KEY_B, BT_VAL_A, BT_VAL_B, BT_PEX, BT_NETILE, BT_SEG_BEGIN, BT_SEG_END, BT_TMP, BT_PER_TILE, BT_OFFS, BT_SPAN, BT_SPAN_RUN, BT_BLK, BT_CURSOR, BT_N };
+enum { BT_KEY_A = 0, BT_KEY_B, BT_VAL_A, BT_VAL_B, BT_PEX, BT_NETILE, BT_SEG_BEGIN, BT_SEG_END, BT_TMP, BT_PER_TILE, BT_OFFS, BT_SPAN, BT_SPAN_RUN, BT_BLK, BT_CURSOR, BT_LPT, BT_COPY_TMP, BT_N };
 
 void drop_store(lsg_ctx* c) {
     c->tm_valid = false; c->plan_n_ct = 0; c->plan1_n_ct = 0; c->tm_n = 0; c->tm_events = 0; c->tm_np = 0; c->tm_nblk = 0; c->tm_njobs = 0; c->tm_nchunks = 0;
@@ -633,6 +637,42 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
     c->tm_n = N; c->tm_events = (int64_t)n_ev;
     c->max_live_all = max_live > 0 ? max_live : 0;
     if (N == 0) return finish();
+    // ---- beside the scatter, on the copy stream: what follows from the capacities alone
+    if (c->tm[TM_BLK_TILE].reserve(((size_t)nblk + 2) * 4)) return -1;
+    bool lpt = false;
+    const uint32_t* lpt_tiles = nullptr;
+    {
+        hipStream_t bs = c->copy_stream;
+        const bool want_lpt = n_netile > 1 && !getenv("LSG_NO_LPT");
+        DevBuf& lk = c->bt[BT_LPT];
+        const size_t lpt_pitch = ((size_t)n_netile + 64) & ~(size_t)63;            // (every array on a 256-byte boundary)
+        if (want_lpt && lk.reserve(lpt_pitch * 4 * 3)) return -1;
+        uint32_t* k_in = lk.as<uint32_t>(); uint32_t* k_out = k_in + lpt_pitch; uint32_t* t_out = k_out + lpt_pitch;
+        uint32_t* bt_ = c->tm[TM_BLK_TILE].as<uint32_t>();
+        // (the scratch of both is sized BEFORE either is queued: growing a buffer frees it, and work queued on this stream may still be reading it)
+        size_t tb_lpt = 0, tb_blk = 0;
+        if (want_lpt) LSG_HIP(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tb_lpt, k_in, k_out, c->bt[BT_NETILE].as<uint32_t>(), t_out, (int)n_netile, 0, 21, bs));
+        LSG_HIP(hipcub::DeviceScan::InclusiveScan(nullptr, tb_blk, bt_, bt_, hipcub::Max(), (int)nblk, bs));
+        if (c->bt[BT_COPY_TMP].reserve((tb_lpt > tb_blk ? tb_lpt : tb_blk) + 256)) return -1;
+        void* scratch = c->bt[BT_COPY_TMP].p;
+        if (want_lpt) {
+            // The sort's segments deepest first: rocprim gives every segment beyond its block sort to ONE workgroup, and the deepest tiles
+            // (chrM: the last contig) would start last - their workgroups' tail is then hidden behind the rest.  A stable radix sort of the
+            // non-empty tiles by capacity >> 11 (what lies above the block sort's 2048: the shallower ones keep their order).  The keys are
+            // shifted by k_tile_caps and sorted from bit 0: rocprim 7.2's radix sort with begin_bit > 0 returns wrong pairs below ~1M items.
+            hipLaunchKernelGGL(k_tile_caps, dim3((n_netile + 255) / 256), dim3(256), 0, bs, c->bt[BT_NETILE].as<uint32_t>(), n_netile, c->d_tile_cap.as<uint32_t>(), k_in);
+            size_t tb = c->bt[BT_COPY_TMP].cap;
+            LSG_HIP(hipcub::DeviceRadixSort::SortPairsDescending(scratch, tb, k_in, k_out, c->bt[BT_NETILE].as<uint32_t>(), t_out, (int)n_netile, 0, 21, bs));
+            LSG_HIP(hipEventRecord(c->ev_lpt, bs));
+            lpt = true; lpt_tiles = t_out;
+        }
+        // the tile of every block (the re-counts' resolve and the plain gather read it; the fused pass does not)
+        LSG_HIP(hipMemsetAsync(bt_, 0, (size_t)nblk * 4, bs));
+        hipLaunchKernelGGL(k_tm_blk_mark, dim3((T + 255) / 256), dim3(256), 0, bs, c->d_tile_cap.as<uint32_t>(), blk_off, T, bt_);
+        size_t tb = c->bt[BT_COPY_TMP].cap;
+        LSG_HIP(hipcub::DeviceScan::InclusiveScan(scratch, tb, bt_, bt_, hipcub::Max(), (int)nblk, bs));
+        LSG_HIP(hipEventRecord(c->ev_blk, bs));
+    }
     // ---- 2. scatter
     DevBuf &key_a = c->bt[BT_KEY_A], &key_b = c->bt[BT_KEY_B], &val_a = c->bt[BT_VAL_A], &val_b = c->bt[BT_VAL_B];
     int bits = 1; while (bits < 24 && (1ll << bits) <= (long long)max_cb) ++bits;
@@ -651,7 +691,8 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
     // ---- 3. every tile's entries by barcode
     if (n_netile) {
         if (c->bt[BT_SEG_BEGIN].reserve(((size_t)n_netile + 1) * 4) || c->bt[BT_SEG_END].reserve(((size_t)n_netile + 1) * 4)) return -1;
-        hipLaunchKernelGGL(k_seg_bounds, dim3((n_netile + 255) / 256), dim3(256), 0, st, c->bt[BT_NETILE].as<uint32_t>(), n_netile, c->d_tile_off.as<uint32_t>(),
+        if (lpt) LSG_HIP(hipStreamWaitEvent(st, c->ev_lpt, 0));
+        hipLaunchKernelGGL(k_seg_bounds, dim3((n_netile + 255) / 256), dim3(256), 0, st, lpt ? lpt_tiles : c->bt[BT_NETILE].as<uint32_t>(), n_netile, c->d_tile_off.as<uint32_t>(),
                            c->bt[BT_SEG_BEGIN].as<uint32_t>(), c->bt[BT_SEG_END].as<uint32_t>());
         size_t tb = 0;
         // (64-bit keys sorted on their barcode bits only, begin_bit 0 .. end_bit `bits`: the rest of the key is payload)
@@ -684,19 +725,6 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
     if (c->tm[TM_S0].reserve((np + 16) * 4) || c->tm[TM_B].reserve(np + 16) ||
         c->tm[TM_RD].reserve((np + 16) * 4) || c->tm[TM_META].reserve((np + 8 * (TM_GROUP + 1)) * 4) ||
         c->tm[TM_BLK_TILE].reserve(((size_t)nblk + 2) * 4) || c->tm[TM_EXT].reserve(((size_t)nblk + TM_GROUP + 2) * 2)) return -1;
-    {   // the tile of every block (the re-counts' resolve and the plain gather read it; the fused pass does not): beside the scatter and the
-        // sort, on the copy stream - it follows from the capacities alone
-        hipStream_t bs = c->copy_stream;
-        uint32_t* bt_ = c->tm[TM_BLK_TILE].as<uint32_t>();
-        LSG_HIP(hipMemsetAsync(bt_, 0, (size_t)nblk * 4, bs));
-        hipLaunchKernelGGL(k_tm_blk_mark, dim3((T + 255) / 256), dim3(256), 0, bs, c->d_tile_cap.as<uint32_t>(), blk_off, T, bt_);
-        size_t tb = 0;
-        LSG_HIP(hipcub::DeviceScan::InclusiveScan(nullptr, tb, bt_, bt_, hipcub::Max(), (int)nblk, bs));
-        if (c->d_cub_tmp.reserve(tb + 256)) return -1;
-        tb = c->d_cub_tmp.cap;
-        LSG_HIP(hipcub::DeviceScan::InclusiveScan(c->d_cub_tmp.p, tb, bt_, bt_, hipcub::Max(), (int)nblk, bs));
-        LSG_HIP(hipEventRecord(c->ev_blk, bs));
-    }
     LSG_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c->tm[TM_S0].as<uint32_t>() + np), (int)TM_PAD_S0, 16, st));       // (what the walk's group loads and the run flags' neighbours see past the end)
     LSG_HIP(hipMemsetAsync(c->tm[TM_B].as<uint8_t>() + np, 0, 16, st));
     // ---- 5. the per-entry words and the events.  The blocks are the load's largest allocation (C4: 124 GB beside 106 GB of the caller's

@@ -1,7 +1,9 @@
-"""Development aid: per-rank count + call time of the sharded C2 job, emulated on ONE GPU (one shard after another, no collective;
-the shard's load is outside the timed loop here — bench.py times it).  max over ranks of a given N predicts the re-count part of
-bench.py --gpus N minus the all-gather."""
-import sys, time
+"""Per-rank time of ONE STEP of the sharded C2 job as bench.py --gpus N times it - the rank's load (its tile store, which also makes
+its count: lsg_set_count_at_load), the count's hand-over, merge + step-1 call, export of its PASS-candidate rows into the send buffer -
+emulated on ONE GPU: one shard after another, no collective.  max over the ranks of a given N predicts bench.py --gpus N minus the
+all-gather (a few hundred rows over xGMI) and whatever eight processes sharing one host cost.  Writes gpurun_out/shard_perf.json.
+usage: python tools/shard_perf.py [n_reads] [worlds, e.g. 1,2,4,8]"""
+import json, os, sys, time
 sys.path.insert(0, ".")
 import numpy as np
 import torch
@@ -16,24 +18,38 @@ model = synth.named("C2", n_reads=n_reads)
 eng = Engine(0, stream=torch.cuda.current_stream().cuda_stream)
 eng.set_contigs(model.contig_len); eng.synth_reference(model.seed); eng.set_barcodes(model.celltype_of, 2)
 cp, kp = CountParams.longsom_defaults(), CallParams.longsom_defaults()
+eng.set_load_filter(cp.min_mq, cp.flag_exclude, cp.ignore_orphans)
+eng.set_count_at_load(cp)
 buf = torch.zeros(64 << 20, dtype=torch.uint8, device="cuda")
+out = {"workload": "C2 at %d reads, one step = load (+ count in the same pass) + call + export per rank, ranks emulated one after another on one GPU" % n_reads, "worlds": {}}
 for world in worlds:
-    worst = 0.0
+    per_rank = []
     for rank, (lo, hi, g_lo, g_hi) in enumerate(region_shards(model, world)):
-        eng.synth_reads(sub_model(model, g_lo, g_hi) if world > 1 else model)
+        reads = eng.synth_generate(sub_model(model, g_lo, g_hi) if world > 1 else model)      # the rank's compact arrays, resident (untimed)
         eng.set_region(lo[0], lo[1], hi[0], hi[1])
+
         def step():
+            eng.load_reads_struct(reads)
             rows, cols = eng.pileup_count(cp)
             ns, nc = eng.call_step1(kp)
             npass = eng.export_calls(2, buf.data_ptr(), buf.numel() // CALL_BYTES)      # as bench.py does: rows straight into the send buffer
             return cols, ns, nc, npass
-        step(); torch.cuda.synchronize()
+        step(); step(); torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(3):
+        for _ in range(5):
             cols, ns, nc, npass = step()
         torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / 3 * 1e3
-        st = eng.count_stats()
-        worst = max(worst, ms)
-        print(f"N={world} rank={rank}: {ms:.2f} ms  reads {eng.reads_shape()[0]} cols {cols} sites {ns} cand {nc} pass {npass} | count ms_total {st.ms_total:.2f} walk {st.ms_walk:.2f}", flush=True)
+        ms = (time.perf_counter() - t0) / 5 * 1e3
+        st = eng.count_stats(); bt = eng.build_times()
+        per_rank.append({"rank": rank, "ms_per_step": round(ms, 3), "reads": int(reads.n_reads), "columns": int(cols), "merged_sites": int(ns), "pass_rows": int(npass),
+                         "load_kernels_ms": [round(float(x), 3) for x in bt], "count_kernel_ms": round(float(st.ms_walk), 3), "fused": eng.layout_info()[0] == 3})
+        print(f"N={world} rank={rank}: {ms:.2f} ms  reads {reads.n_reads} cols {cols} sites {ns} cand {nc} pass {npass} | build {[round(float(x), 2) for x in bt]} count kernel {st.ms_walk:.2f}", flush=True)
+    worst = max(r["ms_per_step"] for r in per_rank)
+    out["worlds"][str(world)] = {"slowest_rank_ms": worst, "ranks": per_rank}
     print(f"N={world}: slowest rank {worst:.2f} ms", flush=True)
+w1 = out["worlds"].get("1", {}).get("slowest_rank_ms")
+if w1:
+    out["predicted_speedup_vs_1"] = {k: round(w1 / v["slowest_rank_ms"], 2) for k, v in out["worlds"].items()}
+    print("predicted speed-up (slowest rank, no collective):", out["predicted_speedup_vs_1"], flush=True)
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump(out, open("gpurun_out/shard_perf.json", "w"), indent=1)
