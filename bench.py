@@ -230,7 +230,7 @@ def end_to_end(n_reads):
 
 
 # rocprofv3's names of the candidates for "dominant kernel"
-PMC_KERNEL = {"k_tm_walk": "lsg::k_tm_walk", "k_tm_gather": "lsg::k_tm_gather", "k_tm_gather_count": "lsg::k_tm_gather_count"}
+PMC_KERNEL = {"k_tm_walk": "lsg::k_tm_walk", "k_tm_gather": "lsg::k_tm_gather", "k_tm_gather_count": "lsg::k_tm_gather_count", "k_tm_count_direct": "lsg::k_tm_count_direct"}
 # kernels that are not part of a step (the generator, the memo table of the call stage: once per process)
 NOT_IN_A_STEP = ("k_synth", "k_tail_table", "calib_")
 
@@ -338,8 +338,13 @@ def main():
     eng.set_load_filter(cp.min_mq, cp.flag_exclude, cp.ignore_orphans)
     # ... and, as in every fused rule, the count's parameters are known when the reads are loaded: the load makes the BAM's one count in the
     # pass that builds the store (lsg_set_count_at_load); LSG_BENCH_TWO_PASS=1 keeps the load and the count apart (round 3's step)
+    # ... and a BAM is counted once: the load keeps no tile store (lsg_set_store_policy; the count reads the events where they lie).
+    # LSG_BENCH_KEEP_STORE=1: the load also writes the store a later count would work on (k_tm_gather_count)
+    keep_store = os.environ.get("LSG_BENCH_KEEP_STORE") == "1"
     if os.environ.get("LSG_BENCH_TWO_PASS") != "1":
         eng.set_count_at_load(cp)
+        if not keep_store:
+            eng.set_store_policy(eng.STORE_SKIP_WHEN_COUNTED)
     # N > 1: ONE all-gather per step.  Every rank sends a message of the same agreed size: a header slot holding its number of
     # PASS-candidate rows, then room for cap_rows rows (SURVEY §8e's counts-then-buffers exchange needs two collectives and a host
     # read between them on every step).  The capacity is agreed during warm-up (the headers are read there) and checked once more
@@ -399,12 +404,13 @@ def main():
     t0 = time.perf_counter()
     walk_ms, walk_bytes, path_bytes, gather_ms, gather_bytes = 0.0, 0.0, 0.0, 0.0, 0.0
     build_ms = np.zeros(4)
-    fused = False
+    fused, direct = False, False
     for _ in range(args.steps):
         rows, cols, n_sites, n_cand, n_pass = step()
         st = eng.count_stats()
         bt = eng.build_times()
-        fused = eng.layout_info()[0] == 3                          # the load made the count (k_tm_gather_count)
+        path = eng.layout_info()[0]
+        fused, direct = path in (3, 4), path == 4                  # the load made the count (3: k_tm_gather_count, writing the store as well; 4: k_tm_count_direct, no store)
         walk_ms += st.ms_walk                                      # HIP events around the counting kernel: k_tm_gather_count, or k_tm_walk after a plain load
         # 2 B per admitted event + 24 B per admitted read + 168 B per emitted row - the counting kernel reads every event of
         # the counted region once and emits the rows of the single-job tiles; the plain gather (two-pass loads) reads every stored event once
@@ -423,6 +429,13 @@ def main():
     t_re = time.perf_counter()
     n_re = 0 if args.no_recount else 5
     re_walk_ms = 0.0
+    store_build_ms = None
+    if n_re and direct:                                             # the timed loads kept no store: one load that does, for the re-counts
+        eng.set_store_policy(eng.STORE_KEEP)
+        eng.load_reads_struct(reads)
+        eng.set_store_policy(eng.STORE_SKIP_WHEN_COUNTED)
+        store_build_ms = eng.layout_info()[1]
+        t_re = time.perf_counter()
     for _ in range(n_re):
         re_rows, re_cols, re_sites, re_cand, _ = step(load=False)
         re_walk_ms += eng.count_stats().ms_walk
@@ -454,7 +467,7 @@ def main():
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         sites = tot[1]
-        count_kernel = "k_tm_gather_count" if fused else "k_tm_walk"
+        count_kernel = "k_tm_count_direct" if direct else "k_tm_gather_count" if fused else "k_tm_walk"
         kernels = {count_kernel: {"avg_launch_ms": walk_ms / args.steps, "algorithmic_bytes_per_launch": walk_bytes / args.steps,
                                   "achieved_GBps": walk_bytes / max(walk_ms, 1e-9) / 1e6,
                                   "what": "SURVEY 8(d) bytes of the count it makes: 2 B x admitted events + 24 B x admitted reads + 168 B x rows it emits"}}
@@ -477,8 +490,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": "C2: whole-genome synthetic long-read workload (hg38/10 + chrM), %d reads x %d barcodes, 2 cell types; one step = "
-                                   "one BAM's one-shot pass: device load of the compact read-record arrays (tile store build) + pileup count + merge + step-1 call%s"
-                                   % (model.n_reads, model.n_cb, " + RCCL all-gather of PASS-candidate call rows" if world > 1 else ""),
+                                   "one BAM's one-shot pass: device load of the compact read-record arrays (entries binned per tile and sorted by barcode%s) + pileup count + merge + step-1 call%s"
+                                   % (model.n_reads, model.n_cb, "; no tile store kept" if direct else ", tile store written", " + RCCL all-gather of PASS-candidate call rows" if world > 1 else ""),
                        "reads": model.n_reads, "barcodes": model.n_cb, "reads_loaded_all_ranks": int(tot[4]), "events_loaded_all_ranks": int(tot[5]),
                        "sites_counted": int(sites), "rows_emitted": int(tot[6]), "merged_sites": int(tot[2]), "step1_candidates": int(tot[3]),
                        "sharding": "genomic regions balanced by estimated work" if world > 1 else "none",
@@ -490,7 +503,8 @@ def main():
                                                ("build_plan_gather_count" if fused else "build_gather"): round(float(bm[3]), 2),
                                                ("count_kernel_inside_the_load" if fused else "count_walk"): round(float(st.ms_walk), 2),
                                                "count_total": round(float(st.ms_total), 2)},
-                       "one_pass_load_and_count": bool(fused),
+                       "one_pass_load_and_count": bool(fused), "store_kept_by_the_timed_loads": not direct,
+                       "load_that_also_writes_the_store_ms": None if store_build_ms is None else round(store_build_ms, 2),
                        "recount_ms": None if recount_ms is None else round(recount_ms, 2),                 # count + call over the SAME resident store: NOT what value is computed from
                        "resident_GB_rank0": round(layout_bytes / 1e9, 2),     # store + per-read / per-segment arrays + cached build temporaries
                        "store_entries_rank0": eng.store_shape()[0], "store_events_rank0": eng.store_shape()[2],

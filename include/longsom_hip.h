@@ -247,6 +247,16 @@ int lsg_set_pileup_window(lsg_ctx* ctx, int32_t window);
  * lsg_pileup_count after the load with EQUAL parameters, the same barcode table and region returns that count's result without
  * another pass; any other call counts over the resident store as always.  params == NULL switches it off (default). */
 int lsg_set_count_at_load(lsg_ctx* ctx, const lsg_count_params* params);
+/* What the loads that follow keep beside the count they make (lsg_set_count_at_load).  LSG_STORE_KEEP (default): the tile store, the
+ * resident form every later count, region, barcode table and genotyping pass works on.  LSG_STORE_SKIP_WHEN_COUNTED: a rule of the
+ * reference reads a BAM, counts it once and is done (BaseCellCounter.py:182-320: one bam.pileup per window, nothing is kept) - when the
+ * load can make its count in its own pass (the conditions of lsg_set_count_at_load) it counts straight from the caller's events and
+ * writes no store: what derives from that count (lsg_fetch_counts, the exports, lsg_call_step1 ...) works as always, lsg_pileup_count
+ * with the load's parameters returns it, and everything that needs the store (another count, lsg_genotype_cells) fails with a message
+ * until reads are loaded again.  A load that cannot make its count (the depth cap could fire, more than two cell types) builds the
+ * store as under LSG_STORE_KEEP. */
+enum { LSG_STORE_KEEP = 0, LSG_STORE_SKIP_WHEN_COUNTED = 1 };
+int lsg_set_store_policy(lsg_ctx* ctx, int32_t policy);
 
 /* ---- hot path -------------------------------------------------------------------------------*/
 /* Per-cell-type pileup base counting over every covered column of the loaded reads; replaces
@@ -343,7 +353,7 @@ typedef struct {
 int lsg_get_count_stats(lsg_ctx* ctx, lsg_count_stats* out);
 
 /* What the load's tile store cost.  path: 2 = the store was built by the load alone, 3 = in the pass that also made the first count
- * (lsg_set_count_at_load).  build_ms: wall time
+ * (lsg_set_count_at_load), 4 = the load made its count and kept no store (lsg_set_store_policy).  build_ms: wall time
  * lsg_load_reads spent building the store (device kernels + their host synchronisations).  store_bytes: device memory the store, its
  * per-read / per-segment arrays, kept events and cached build temporaries hold.  No reference counterpart: the reference re-reads
  * the BAM per window (BaseCellCounter.py:198-225). */

@@ -142,6 +142,7 @@ int run_genotype(lsg_ctx* c, const lsg_genotype_params* p, int64_t n_sites, cons
     const size_t cells = (size_t)n_sites * (size_t)c->n_cb;
     DevBuf d_keys, d_alt_sym, d_dp, d_alt;
     auto done = [&](int rc) { d_keys.release(); d_alt_sym.release(); d_dp.release(); d_alt.release(); return rc; };
+    if (c->store_skipped) { set_error("lsg_genotype_cells: the load kept no store (lsg_set_store_policy): load the reads again with LSG_STORE_KEEP"); return -2; }
     if (!c->tm_valid) { set_error("lsg_genotype_cells: no reads loaded"); return -2; }
     GenoArgs a{};
     a.store = c->tm[TM_STORE].as<uint4>(); a.ext = c->tm[TM_EXT].as<uint16_t>(); a.s0 = c->tm[TM_S0].as<uint32_t>(); a.read_flag = c->rd.read_flag; a.read_mapq = c->rd.read_mapq;

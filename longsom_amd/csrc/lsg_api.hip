@@ -223,6 +223,13 @@ int lsg_set_count_at_load(lsg_ctx* c, const lsg_count_params* params) {
     return 0;
 }
 
+int lsg_set_store_policy(lsg_ctx* c, int32_t policy) {
+    if (!c) { set_error("lsg_set_store_policy: NULL handle"); return -2; }
+    if (policy != LSG_STORE_KEEP && policy != LSG_STORE_SKIP_WHEN_COUNTED) { set_error("lsg_set_store_policy: unknown policy %d", (int)policy); return -2; }
+    c->store_policy = policy;
+    return 0;
+}
+
 int lsg_set_load_filter(lsg_ctx* c, int32_t min_mq, uint32_t flag_exclude, int32_t ignore_orphans) {
     if (!c) { set_error("lsg_set_load_filter: NULL handle"); return -2; }
     c->lf_min_mq = min_mq; c->lf_flag_exclude = flag_exclude; c->lf_ignore_orphans = ignore_orphans ? 1 : 0;
@@ -308,7 +315,8 @@ int lsg_pileup_count(lsg_ctx* c, const lsg_count_params* params, int64_t* n_rows
     LSG_HIP(hipSetDevice(c->device));
     if (int rc = check_load_filter(c, "lsg_pileup_count", params->min_mq, params->flag_exclude, params->ignore_orphans)) return rc;
     // the load made this very count while it built the store (lsg_set_count_at_load): it is handed out once, a later call counts again
-    const bool have = c->counted && c->counted_at_load && memcmp(params, &c->last_params, sizeof(*params)) == 0;
+    // (a load that kept no store: its count is all there is, and stays until something invalidates it)
+    const bool have = c->counted && (c->counted_at_load || c->store_skipped) && memcmp(params, &c->last_params, sizeof(*params)) == 0;
     c->counted_at_load = false;
     if (!have) { int rc = run_count(c, params); if (rc) return rc; }
     if (n_rows) for (int i = 0; i < c->n_ct; ++i) n_rows[i] = c->n_rows[i];
@@ -358,7 +366,7 @@ int lsg_get_count_stats(lsg_ctx* c, lsg_count_stats* out) {
 
 int lsg_get_layout_info(lsg_ctx* c, int32_t* path, double* build_ms, int64_t* store_bytes) {
     if (!c) { set_error("lsg_get_layout_info: NULL handle"); return -2; }
-    if (path) *path = c->load_was_fused ? 3 : 2;       // 3: the load's gather also made the first count (lsg_set_count_at_load)
+    if (path) *path = c->store_skipped ? 4 : c->load_was_fused ? 3 : 2;       // 3: the load's gather also made the first count (lsg_set_count_at_load)
     if (build_ms) *build_ms = c->layout_build_ms;
     if (store_bytes) {
         int64_t b = 0;

@@ -101,7 +101,7 @@ __global__ void k_read_end(const uint32_t* seg_read, const int32_t* seg_start, c
 __global__ void k_read_end_init(const int32_t* read_pos, int64_t n_reads, int32_t* read_end);
 int depth_cap_drops(lsg_ctx* c, const lsg_count_params* p);   // layout.hip: htslib's max_depth rule -> d_read_drop (or none)
 struct GatherCountSrc { const uint16_t* events; int64_t n_events; const uint64_t* key; const uint32_t* rdv; int32_t cb_bits; };
-int run_gather_count(lsg_ctx* c, const lsg_count_params* p, const GatherCountSrc& src);      // pileup.hip: the load's gather and the first count in one pass (k_tm_gather_count)
+int run_gather_count(lsg_ctx* c, const lsg_count_params* p, const GatherCountSrc& src, bool direct);      // pileup.hip: the load's gather and the first count in one pass (k_tm_gather_count), or the count alone from the caller's events (k_tm_count_direct)
 }
 
 struct lsg_ctx {
@@ -156,6 +156,8 @@ struct lsg_ctx {
     bool counted_at_load = false;         // the resident count is that one and nobody has asked for it yet
     bool load_was_fused = false;          // the last load built its store in the pass that counted (lsg_get_layout_info path 3)
     bool tm_valid = false;
+    int32_t store_policy = 0;             // lsg_set_store_policy: LSG_STORE_KEEP / LSG_STORE_SKIP_WHEN_COUNTED
+    bool store_skipped = false;           // the last load made its count and kept no store: what needs one fails
     double layout_build_ms = 0;           // wall time of the last build (lsg_get_layout_info)
     float build_ms[4] = {0, 0, 0, 0};     // HIP-event times of the last build: capacities + scatter, sort, fill, gather
     int64_t max_live_reads = -1;          // layout.hip: bound on the reads live at once in the reference's pileup buffer (-1 = stale)

@@ -1021,6 +1021,214 @@ __global__ __launch_bounds__(TMW_WAVES * 64) __attribute__((amdgpu_waves_per_eu(
     }
 }
 
+// ================================================================================================
+// The load's count WITHOUT a store (lsg_set_store_policy(LSG_STORE_SKIP_WHEN_COUNTED)): a rule that counts a BAM once and never again
+// needs no resident form of the events - the 24 GB of transposed blocks k_tm_gather_count writes at C2 are as much traffic as the
+// events themselves.  Same plan, jobs, planes, run logic and rows; a wave reads an entry's events where the caller left them:
+// lane = position of the tile, ONE 2-byte buffer load per entry through a descriptor of its own (base = the entry's first event,
+// num_records = its events' bytes, offset = 2 (lane - first position): the lanes outside the entry get zeros without a memory request,
+// and nothing beside the entry's own events is ever fetched - no edge cases at the ends of the array).  Per group of 32 entries:
+//   K  the sorted keys and values (lanes 0..31, the neighbours in lanes 32 / 33), two groups ahead
+//   W  per lane: the entry's address | bytes | first position (two words, read lane by lane into SGPRs when the entry's load is
+//      issued), and what its meta word needs (admission bit of its read, cell type of its barcode: issued here, read a group later)
+//   E  the loads of a group's second half and of the next group's first half are in flight while 16 entries are counted
+struct TdW { uint32_t lo, hi; };     // hi: address bits 32..47 | 2 * events << 16 | 2 * first position << 24
+__device__ __forceinline__ void td_range(const CountArgs& a, const TmArgs& tm, const TgArgs& tg, TmState& st, TgStat& stat, uint32_t i0, uint32_t i1, uint32_t off, uint32_t n,
+                                         uint32_t thr, uint32_t pkl0, uint32_t one, int lane, TgKeys K) {
+    const int ng = (int)((i1 - i0 + 31u) >> 5);
+    const uint32_t cbm = (1u << tg.cb_bits) - 1u;
+    const uint32_t lane2 = 2u * (uint32_t)lane;
+    const uint64_t evb = (uint64_t)(uintptr_t)tg.events;
+    const uint32_t* admp = a.adm ? reinterpret_cast<const uint32_t*>(a.adm) : reinterpret_cast<const uint32_t*>(a.celltype_of);
+    const uint32_t adm_all = a.adm ? 0u : 0xffffffffu;
+    auto load_keys = [&](int g) -> TgKeys { return tg_load_keys(tg, i0 + 32u * (uint32_t)g, 0u, off, n, lane); };
+    auto words = [&](int g, const TgKeys& K, TdW& w, TgPre& pre) {
+        const uint32_t i = i0 + 32u * (uint32_t)g + (uint32_t)lane;
+        const bool valid = lane < 32 && i < i1;
+        const uint32_t cb = (uint32_t)K.k & cbm;
+        const uint32_t cb_prev = (uint32_t)__shfl((int)cb, lane == 0 ? 32 : lane - 1), cb_next = (uint32_t)__shfl((int)cb, lane == 31 ? 33 : lane + 1);
+        const uint32_t geom = (uint32_t)(K.k >> tg.cb_bits), first = geom & 63u, nev = valid ? ((geom >> 6) & 63u) + 1u : 0u;
+        const uint64_t addr = evb + 2ull * (K.k >> (tg.cb_bits + 12));
+        const bool rs = i == 0 || cb_prev != cb;
+        const bool single = rs && (i + 1 == n || cb_next != cb);
+        w.lo = (uint32_t)addr; w.hi = ((uint32_t)(addr >> 32) & 0xffffu) | (nev << 17) | (first << 25);
+        const uint32_t r = K.v & TG_RV_READ;
+        pre.ctv = reinterpret_cast<const uint32_t*>(a.celltype_of)[(cb < (uint32_t)a.n_cb ? cb : 0u) >> 2];
+        pre.admw = admp[a.adm && r < (uint32_t)a.n_reads ? r >> 5 : 0u] | adm_all;
+        pre.bits = (valid ? 1u : 0u) | (cb < (uint32_t)a.n_cb ? 2u : 0u) | ((K.v & TG_RV_FWD) ? 4u : 0u) | (single ? 8u : 0u) | (rs ? 16u : 0u) |
+                   ((r & 31u) << 8) | (nev << 16) | ((K.v & TG_RV_SEGFIRST) ? (1u << 24) : 0u) | ((cb & 3u) << 26);
+    };
+    auto finish_meta = [&](const TgPre& pre) -> uint32_t {                  // (what k_tm_resolve writes for the entry under this count)
+        if (!(pre.bits & 1u)) return TMM_SKIP;
+        uint32_t cls = 2;
+        const bool ok = (pre.bits & 2u) != 0 && ((pre.admw >> ((pre.bits >> 8) & 31u)) & 1u);
+        if (ok) { const uint32_t ct = (pre.ctv >> (((pre.bits >> 26) & 3u) * 8u)) & 0xffu; if (ct < (uint32_t)a.n_ct && (ct >> 1) == (uint32_t)(tm.ct_base >> 1)) cls = ct & 1u; }
+        if (cls < 2) { stat.ev += (pre.bits >> 16) & 0xffu; stat.sg += (pre.bits >> 24) & 1u; ++stat.ne; }
+        uint32_t M = cls < 2 ? (cls ? (TMM_CT4 | TMM_CT12) : 0u) | ((pre.bits & 4u) ? TMM_FWD : 0u) | ((pre.bits & 8u) ? TMM_SINGLE : 0u) : TMM_SKIP;
+        if (pre.bits & 16u) M |= TMM_RS;
+        return M;
+    };
+    uint32_t open_in = 0;
+    auto verdicts = [&](uint32_t M) -> uint32_t {                           // (as in tm_walk_range)
+        const bool there = !(M & TMM_SKIP), multi = there && !(M & TMM_SINGLE), rs = (M & TMM_RS) != 0;
+        const uint32_t A = (uint32_t)__ballot(lane < 32 && multi), R = (uint32_t)__ballot(lane < 32 && rs);
+        const uint32_t below = lane < 32 ? (1u << lane) - 1u : 0xffffffffu;
+        const uint32_t rb = R & below;
+        const uint32_t seg = rb ? below & ~((1u << (31 - __clz(rb))) - 1u) : below;
+        const bool ob = (A & seg) != 0u || (!rb && open_in);
+        if (rs && ob) M |= TMM_CLOSE;
+        if (multi && (rs || !ob)) M |= TMM_FIRST;
+        const uint32_t segl = R ? ~((1u << (31 - __clz(R))) - 1u) : 0xffffffffu;
+        open_in = ((A & segl) != 0u || (!R && open_in)) ? 1u : 0u;
+        return M;
+    };
+    // entries 16 h .. 16 h + 15 of a group: every load is issued (an entry that is not there has no bytes: no request leaves the CU),
+    // so that the compiler counts the loads in flight instead of waiting for all of them where branches meet
+    auto issue = [&](const TdW& w, int h, uint32_t (&E)[16]) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const uint32_t lo = rl(w.lo, h * 16 + u), hi = rl(w.hi, h * 16 + u);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>((uintptr_t)(((uint64_t)(hi & 0xffffu) << 32) | lo)), 0, (int)((hi >> 16) & 0xffu), 0x00020000);
+            E[u] = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rs, (int)(lane2 - (hi >> 24)), 0, 0);
+        }
+    };
+    auto consume = [&](const uint32_t (&E)[16], int h, uint32_t M) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) tm_add<false>(st, rl(M, h * 16 + u), E[u], thr, pkl0, one);
+    };
+    uint32_t EA[16], EB[16];
+    TdW w; TgPre pre;
+    // (the fences pin the ORDER the loads are issued in - look-ups, keys, first half, second half - in the prologue as in the loop: the
+    // counter of loads in flight is in-order, and where two orders meet at the loop's head the compiler waits for everything)
+    words(0, K, w, pre);
+    asm volatile("" ::: "memory");
+    K = load_keys(ng > 1 ? 1 : 0);
+    asm volatile("" ::: "memory");
+    issue(w, 0, EA);
+    asm volatile("" ::: "memory");
+    issue(w, 1, EB);
+    asm volatile("" ::: "memory");
+    for (int g = 0; g < ng; ++g) {
+        const uint32_t Mc = verdicts(finish_meta(pre));
+        words(g + 1, K, w, pre);                              // (past the range's last group: entries that are not there)
+        asm volatile("" ::: "memory");
+        K = load_keys(g + 2 < ng ? g + 2 : ng - 1);
+        asm volatile("" ::: "memory");
+        consume(EA, 0, Mc);
+        issue(w, 0, EA);
+        consume(EB, 1, Mc);
+        issue(w, 1, EB);
+    }
+    st.nc += st.mask & 0x10001u; st.mask = 0;
+}
+
+__global__ __launch_bounds__(TMW_WAVES * 64) __attribute__((amdgpu_waves_per_eu(6))) void k_tm_count_direct(CountArgs a, TmArgs tm, TgArgs tg) {
+    __shared__ __attribute__((aligned(8192))) uint32_t planes[2][2][8 * 64];
+    __shared__ uint32_t nc_sh[2][64];
+    __shared__ WaveBook books[TMW_WAVES];
+    __shared__ uint32_t s_ck;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint32_t* pl = &planes[0][0][0];
+    WaveBook& book = books[wv];
+    book_init(book, lane);
+    if (lane == 0) book.src = 1;
+    const uint32_t thr = bq_threshold(a), pkl0 = lds_addr(pl + lane);
+    uint32_t one = 1u;
+    asm volatile("" : "+v"(one));
+    const uint32_t nchunks = rl(*tg.nchunks, 0);
+    TgStat stat; stat.ev = 0; stat.sg = 0; stat.ne = 0;
+    for (bool first = true;; first = false) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_ck = first ? blockIdx.x : (uint32_t)atomicAdd(&a.scalars[SC_QWALK], 1ull) + gridDim.x;
+        __syncthreads();
+        const uint32_t ck = rl(s_ck, 0);
+        if (ck >= nchunks) break;
+        const uint32_t jx_end = rl(tm.chunk_start[ck + 1], 0), jx0 = rl(tm.chunk_start[ck], 0);
+        if (jx0 >= jx_end) continue;
+        // (the job records and the first keys of the next job travel while this job is counted: as in k_tm_gather_count)
+        uint32_t jw = 0;
+        if (lane < TM_JOB_WORDS) jw = reinterpret_cast<const uint32_t*>(tm.jobs + jx0)[lane];
+        uint32_t e0 = rl(jw, 0), e1 = rl(jw, 1), w0 = rl(jw, 2), slab = rl(jw, 3), nj = rl(jw, 4), tcnt = rl(jw, 5), tile = rl(jw, 6), emid = rl(jw, 7), base = rl(jw, 8), off = rl(jw, 9);
+        int32_t tstart = (int32_t)rl(jw, 10); int tid = (int)rl(jw, 11);
+        TgKeys K0 = tg_load_keys(tg, (wv ? emid : e0) - base, 0u, off, tcnt, lane);
+        for (uint32_t jx = jx0; jx < jx_end; ++jx) {
+            {
+                const uint32_t jn = jx + 1 < jx_end ? jx + 1 : jx;
+                jw = reinterpret_cast<const uint32_t*>(tm.jobs + jn)[lane < TM_JOB_WORDS ? lane : 0];
+            }
+            const bool counting = tile >= a.tile_lo && tile < a.tile_hi && !(nj & TMJ_WIDE);      // (the wide jobs: k_tm_walk_wide_direct)
+            int refb = 'N';
+            if (nj == 1 && counting) { const int64_t pos = (int64_t)tstart + lane; if (pos >= 1 && pos < a.contig_len[tid]) refb = a.ref_ptr[tid][pos]; }
+            __syncthreads();                                   // both waves are done with the job before
+            if (counting) {
+#pragma unroll
+                for (int i = 0; i < 2 * 2 * 8 * 64 / (4 * TMW_WAVES * 64); ++i) reinterpret_cast<uint4*>(pl)[i * (TMW_WAVES * 64) + threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);
+                (&nc_sh[0][0])[threadIdx.x] = 0;
+            }
+            __syncthreads();
+            // the tile's entries [i0, i1) of this wave, as indices into the tile's part of the sort's output (the plan cuts jobs in padded
+            // store indices: base is the tile's first one)
+            const uint32_t s0r = wv ? emid : e0, s1r = wv ? e1 : emid;
+            const uint32_t i0 = s0r - base, i1 = s1r - base < tcnt ? s1r - base : tcnt;
+            if (counting && i1 > i0) {
+                TmState st; st.nc = 0; st.mask = 0;
+                td_range(a, tm, tg, st, stat, i0, i1, off, tcnt, thr, pkl0, one, lane, K0);
+                if (st.nc & 0xffffu) atomicAdd(&nc_sh[0][lane], st.nc & 0xffffu);
+                if (st.nc >> 16) atomicAdd(&nc_sh[1][lane], st.nc >> 16);
+            }
+            const uint32_t c_w0 = w0, c_slab = slab, c_nj = nj, c_tcnt = tcnt; const int32_t c_tstart = tstart; const int c_tid = tid;
+            e0 = rl(jw, 0); e1 = rl(jw, 1); w0 = rl(jw, 2); slab = rl(jw, 3); nj = rl(jw, 4); tcnt = rl(jw, 5); tile = rl(jw, 6); emid = rl(jw, 7); base = rl(jw, 8); off = rl(jw, 9);
+            tstart = (int32_t)rl(jw, 10); tid = (int)rl(jw, 11);
+            K0 = tg_load_keys(tg, (wv ? emid : e0) - base, 0u, off, tcnt, lane);
+            __syncthreads();
+            const int ct = tm.ct_base + wv;
+            if (counting && ct < a.n_ct) {                   // the tile's units of this pass: wave = cell type (as in k_tm_walk)
+                const uint32_t* pc = pl + wv * 1024;
+                uint32_t dp = 0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) dp += pc[512 + k * 64 + lane] & 0xffffu;
+                const TmCounters tot{pc, lane, dp - nc_sh[wv][lane]};
+                if (c_nj == 1) {
+                    if (c_tcnt <= 256u) emit_unit<TmCounters, true>(a, tot, c_w0 + ct, ct, c_tid, c_tstart, lane, &book, false, refb, 0);
+                    else emit_unit<TmCounters, false>(a, tot, c_w0 + ct, ct, c_tid, c_tstart, lane, &book, false, refb, 1);
+                } else {
+                    uint32_t* dst = a.macc + (uint64_t)(c_slab + (uint32_t)ct * c_nj) * (NCTR * 64);
+                    dst[lane] = tot.NCDUP();
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const uint32_t lo = pc[k * 64 + lane], hi = pc[512 + k * 64 + lane];
+                        dst[(1 + k) * 64 + lane] = hi >> 16; dst[(9 + k) * 64 + lane] = hi & 0xffffu;
+                        dst[(17 + k) * 64 + lane] = lo & 0xfffffu; dst[(25 + k) * 64 + lane] = lo >> 20;
+                    }
+                }
+            }
+        }
+    }
+    lds_fence();
+    __syncthreads();
+    {
+        unsigned long long ev = stat.ev, sg = stat.sg, ne = stat.ne;
+        for (int o = 32; o > 0; o >>= 1) { ev += __shfl_down(ev, o); sg += __shfl_down(sg, o); ne += __shfl_down(ne, o); }
+        if (lane == 0 && ne) {
+            unsigned long long* slot = tg.stat_slots + (size_t)((blockIdx.x * TMW_WAVES + wv) % IX_STAT_SLOTS) * 8;
+            atomicAdd(&slot[0], ev); atomicAdd(&slot[1], sg); atomicAdd(&slot[2], ne);
+        }
+    }
+    if (threadIdx.x < 64) {
+        uint32_t rt = 0, cols = 0, rsrc = 0;
+        for (int w = 0; w < TMW_WAVES; ++w) {
+            const WaveBook& b = books[w];
+            if (lane < a.n_ct) rt += b.rows_true[lane];
+            cols += b.cols; rsrc += b.rows_src;
+        }
+        if (lane < a.n_ct && rt) atomicAdd(&a.scalars[SC_ROWS + lane], (unsigned long long)rt);
+        if (lane == 0) {
+            if (cols) atomicAdd(&a.scalars[SC_COLS], (unsigned long long)cols);
+            if (rsrc) atomicAdd(&a.scalars[SC_ROWS_SRC + 1], (unsigned long long)rsrc);
+        }
+    }
+}
+
 // A job longer than TM_JOB_LIMIT entries (a single barcode owning thousands of a tile's entries: its run cannot be cut) does not fit the
 // packed planes of k_tm_walk.  One wave per such job, 32-bit planes (quality sum, forward, count, duplicates per symbol and cell type),
 // the run logic spelled out: a run start closes the run before it; an entry that is there adds its event where the lane counts it and
@@ -1101,6 +1309,78 @@ __global__ __launch_bounds__(64) void k_tm_walk_wide(CountArgs a, TmArgs tm, con
                 }
             }
         }
+    }
+    book_flush(a, book, lane);
+}
+
+// ... and after a load that kept no store: the entry's words from the sort's output, its events from the caller's array
+__global__ __launch_bounds__(64) void k_tm_walk_wide_direct(CountArgs a, TmArgs tm, TgArgs tg, const uint32_t* n_wide) {
+    __shared__ uint32_t pl[2][4][8 * 64];
+    __shared__ WaveBook book;
+    const int lane = threadIdx.x;
+    if (n_wide && rl(*n_wide, 0) == 0u) return;
+    book_init(book, lane);
+    if (lane == 0) book.src = 2;
+    const uint32_t thr = bq_threshold(a), cbm = (1u << tg.cb_bits) - 1u;
+    unsigned long long s_ev = 0, s_sg = 0, s_ne = 0;
+    for (uint32_t jx = blockIdx.x; jx < tm.njobs; jx += gridDim.x) {
+        const TmJob jb = tm.jobs[jx];
+        if (!(jb.nj & TMJ_WIDE) || jb.tile < a.tile_lo || jb.tile >= a.tile_hi) continue;
+        const uint32_t nj = jb.nj & ~TMJ_WIDE;
+        lds_fence();
+        for (int i = lane; i < 2 * 4 * 8 * 64; i += 64) (&pl[0][0][0])[i] = 0;
+        lds_fence();
+        uint32_t nc[2] = {0u, 0u}, mask = 0, run_ct = 0;
+        for (uint32_t p = jb.e0; p < jb.e1 && p - jb.base < jb.cnt; ++p) {
+            const uint32_t i = p - jb.base;
+            const uint64_t k = tg.key[jb.off + i];
+            const uint32_t v = tg.rdv[jb.off + i], cb = (uint32_t)k & cbm, r = v & TG_RV_READ;
+            const bool rs = i == 0 || ((uint32_t)tg.key[jb.off + i - 1] & cbm) != cb;
+            const uint32_t geom = (uint32_t)(k >> tg.cb_bits), first = geom & 63u, nev = ((geom >> 6) & 63u) + 1u;
+            const uint64_t src = k >> (tg.cb_bits + 12);
+            uint32_t cls = 2;
+            bool ok = cb < (uint32_t)a.n_cb;
+            if (ok && a.adm) ok = (reinterpret_cast<const uint32_t*>(a.adm)[r >> 5] >> (r & 31u)) & 1u;
+            if (ok) { const uint32_t ct = a.celltype_of[cb]; if (ct < (uint32_t)a.n_ct && (ct >> 1) == (uint32_t)(tm.ct_base >> 1)) cls = ct & 1u; }
+            if (rs) { nc[run_ct] += mask ? 1u : 0u; mask = 0; }
+            if (cls >= 2) continue;
+            s_ev += nev; s_sg += (v & TG_RV_SEGFIRST) ? 1u : 0u; ++s_ne;
+            run_ct = cls;
+            const uint32_t ev = (uint32_t)lane - first < nev ? tg.events[src + ((uint32_t)lane - first)] : 0u;
+            if ((ev & 0x8ffu) >= thr) {
+                const uint32_t sym = (ev >> 8) & 7u;
+                uint32_t* q = &pl[run_ct][0][sym * 64 + lane];
+                q[0] += ev & 0xffu; q[512] += (v & TG_RV_FWD) ? 1u : 0u; q[1024] += 1u; q[1536] += (mask >> sym) & 1u;
+                mask |= 1u << sym;
+            }
+        }
+        nc[run_ct] += mask ? 1u : 0u;
+        lds_fence();
+        const int2 geom = a.ne_geom[jb.w0];
+        const int tid = geom.y & 0xffffff;
+        for (int v = 0; v < 2; ++v) {
+            const int ct = tm.ct_base + v;
+            if (ct >= a.n_ct) break;
+            const uint32_t* pc = &pl[v][0][0];
+            uint32_t dp = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) dp += pc[1024 + k * 64 + lane];
+            const WideCounters tot{pc, lane, dp - nc[v]};
+            if (nj == 1) emit_unit<WideCounters, false>(a, tot, jb.w0 + ct, ct, tid, geom.x, lane, &book, false);
+            else {
+                uint32_t* dst = a.macc + (uint64_t)(jb.slab + (uint32_t)ct * nj) * (NCTR * 64);
+                dst[lane] = tot.NCDUP();
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    dst[(1 + k) * 64 + lane] = tot.DUP(k); dst[(9 + k) * 64 + lane] = tot.BC(k);
+                    dst[(17 + k) * 64 + lane] = tot.BQ(k); dst[(25 + k) * 64 + lane] = tot.BCF(k);
+                }
+            }
+        }
+    }
+    if (lane == 0 && s_ne) {
+        unsigned long long* slot = tg.stat_slots + (size_t)(blockIdx.x % IX_STAT_SLOTS) * 8;
+        atomicAdd(&slot[0], s_ev); atomicAdd(&slot[1], s_sg); atomicAdd(&slot[2], s_ne);
     }
     book_flush(a, book, lane);
 }
@@ -1221,7 +1501,7 @@ static int count_finish(lsg_ctx* c, const lsg_count_params* p, CountLaunch& L) {
 // The fused pass of a load (store.hip build_store when lsg_set_count_at_load is on): the plan is made (its chunk and wide-job counters
 // still on the device), the sort's output lies in src; queues everything a count queues around k_tm_gather_count and ends with the
 // count's one synchronisation.  At most two cell types (one pass), no depth-cap drops (the caller has checked the bound).
-int run_gather_count(lsg_ctx* c, const lsg_count_params* p, const GatherCountSrc& src) {
+int run_gather_count(lsg_ctx* c, const lsg_count_params* p, const GatherCountSrc& src, bool direct) {
     hipStream_t st = c->stream;
     c->has_drops = false; c->n_depth_dropped = 0;
     CountLaunch L;
@@ -1238,6 +1518,17 @@ int run_gather_count(lsg_ctx* c, const lsg_count_params* p, const GatherCountSrc
     auto stage = [&](const char* what) { if (dbg) { const hipError_t e = hipStreamSynchronize(st); fprintf(stderr, "[lsg] fused load: %s: %s\n", what, hipGetErrorString(e)); fflush(stderr); } };
     stage("count prepared");
     LSG_HIP(hipEventRecord(c->ev[1], st)); LSG_HIP(hipEventRecord(c->ev[3], st));
+    if (direct) {
+        // no store (lsg_set_store_policy): 80 registers per lane -> 6 waves per SIMD = 12 workgroups per CU
+        const unsigned grid = (unsigned)(c->n_cus * tune_int("LSG_GRID_TD", 12));
+        hipLaunchKernelGGL(k_tm_count_direct, dim3(grid), dim3(TMW_WAVES * 64), 0, st, L.a, L.tm, tg);
+        LSG_HIP(hipEventRecord(c->ev[4], st));
+        LSG_HIP(hipEventRecord(c->evb[4], st));
+        stage("k_tm_count_direct");
+        hipLaunchKernelGGL(k_tm_walk_wide_direct, dim3((unsigned)(c->n_cus * 2)), dim3(64), 0, st, L.a, L.tm, tg, (const uint32_t*)c->d_plan_misc);
+        stage("wide walk");
+        return count_finish(c, p, L);
+    }
     // 17 KB of LDS per workgroup (planes + the two waves' transposition tiles): 9 workgroups per CU
     const unsigned grid = (unsigned)(c->n_cus * tune_int("LSG_GRID_TG", 9));
     hipLaunchKernelGGL(k_tm_gather_count, dim3(grid), dim3(TMW_WAVES * 64), 0, st, L.a, L.tm, tg);
@@ -1253,6 +1544,7 @@ int run_gather_count(lsg_ctx* c, const lsg_count_params* p, const GatherCountSrc
 int run_count(lsg_ctx* c, const lsg_count_params* p) {
     if (c->n_contigs <= 0) { set_error("lsg_pileup_count: no contigs set"); return -2; }
     if (c->n_ct <= 0) { set_error("lsg_pileup_count: no barcodes set"); return -2; }
+    if (c->store_skipped) { set_error("lsg_pileup_count: the load kept no store (lsg_set_store_policy): only the count it made is there - load the reads again to count with other parameters, tables or regions"); return -2; }
     if (!c->tm_valid) { set_error("lsg_pileup_count: no reads loaded"); return -2; }
     for (int t = 0; t < c->n_contigs; ++t)
         if (!c->ref_ptr[t]) { set_error("lsg_pileup_count: reference of contig %d not loaded", t); return -2; }

@@ -495,7 +495,7 @@ void drop_store(lsg_ctx* c) {
     c->tm_valid = false; c->plan_n_ct = 0; c->plan1_n_ct = 0; c->tm_n = 0; c->tm_events = 0; c->tm_np = 0; c->tm_nblk = 0; c->tm_njobs = 0; c->tm_nchunks = 0;
     c->tm_n_ne = 0; c->tm_n_multi = 0; c->tm_n_slabs = 0; c->tm_n_wide = 0;
     c->max_live_reads = -1; c->max_live_all = -1; c->has_drops = false;
-    c->counted = c->called = false; c->counted_at_load = false; c->load_was_fused = false;
+    c->counted = c->called = false; c->counted_at_load = false; c->load_was_fused = false; c->store_skipped = false;
 }
 
 // the build's temporaries stay in the context (grow-only): allocating ~9 GB per load costs more wall time than the build's kernels —
@@ -722,6 +722,7 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
     // ---- 4. blocks and the per-entry words (the blocks' offsets and their number came with the load's early look)
     const uint64_t np = (uint64_t)nblk * 8;
     c->tm_np = np; c->tm_nblk = nblk;
+    auto reserve_store = [&]() -> int {
     if (c->tm[TM_S0].reserve((np + 16) * 4) || c->tm[TM_B].reserve(np + 16) ||
         c->tm[TM_RD].reserve((np + 16) * 4) || c->tm[TM_META].reserve((np + 8 * (TM_GROUP + 1)) * 4) ||
         c->tm[TM_BLK_TILE].reserve(((size_t)nblk + 2) * 4) || c->tm[TM_EXT].reserve(((size_t)nblk + TM_GROUP + 2) * 2)) return -1;
@@ -737,6 +738,8 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
         }
         if (c->tm[TM_STORE].reserve(((size_t)nblk + TM_GROUP) * 1024)) return -1;
     }
+    return 0;
+    };
     LSG_HIP(hipEventRecord(c->evb[3], st));
     // The first count in the same pass (lsg_set_count_at_load): when its parameters and the barcode table are known now, the depth cap
     // cannot fire (the all-reads bound came with the early look) and one pass covers the cell types, the gather below is replaced by
@@ -748,11 +751,11 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
         if (q.max_depth > 0 && c->max_live_all + 1 > (int64_t)q.max_depth) fused = false;                                                                 // (the depth cap may drop reads: decided per count)
         for (int t = 0; t < c->n_contigs && fused; ++t) if (!c->ref_ptr[t]) fused = false;
     }
-    if (fused) {
-        // the plan: its tile-level half on the copy stream while the scatter and the sort are at work (two small host round trips that
-        // wait for the copy stream only), its job-level half behind the sort - the jobs are cut at run starts read from the sorted keys
-        const bool dbg = getenv("LSG_DEBUG_SYNC") != nullptr;
-        auto stage = [&](const char* what) { if (dbg) { const hipError_t e = hipStreamSynchronize(st); fprintf(stderr, "[lsg] fused load: %s: %s\n", what, hipGetErrorString(e)); fflush(stderr); } };
+    const bool dbg = getenv("LSG_DEBUG_SYNC") != nullptr;
+    auto stage = [&](const char* what) { if (dbg) { const hipError_t e = hipStreamSynchronize(st); fprintf(stderr, "[lsg] fused load: %s: %s\n", what, hipGetErrorString(e)); fflush(stderr); } };
+    // the plan: its tile-level half on the copy stream while the scatter and the sort are at work (two small host round trips that
+    // wait for the copy stream only), its job-level half behind the sort - the jobs are cut at run starts read from the sorted keys
+    auto fused_plan = [&]() -> int {
         stage("scatter + sort + block tables");
         int rc = plan_tiles(c, c->copy_stream);
         if (rc) return rc;
@@ -760,9 +763,35 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
         c->tm_np = np; c->tm_nblk = nblk;
         if ((rc = plan_jobs(c, false, key_b.as<uint64_t>(), bits))) return rc;
         stage("plan");
+        return 0;
+    };
+    const GatherCountSrc gsrc{events, n_events, key_b.as<uint64_t>(), val_b.as<uint32_t>(), bits};
+    bool planned = false;
+    if (fused && c->store_policy == LSG_STORE_SKIP_WHEN_COUNTED && !getenv("LSG_NO_DIRECT_COUNT")) {
+        // A load that is counted once and never again (lsg_set_store_policy): the count alone, from the caller's events through the
+        // sort's output - no blocks, no per-entry words.  What needs a store afterwards is refused until the next load.
+        if (int rc = fused_plan()) return rc;
+        planned = true;
+        const int rc = run_gather_count(c, &c->cal_params, gsrc, true);
+        LSG_HIP(hipStreamSynchronize(st));
+        if (hipGetLastError() != hipSuccess) { set_error("lsg_load_reads: the count pass failed"); return -1; }
+        if (rc == 0) {
+            plan_finish(c);
+            LSG_HIP(hipStreamSynchronize(c->copy_stream));     // (the blocks' tiles: nobody reads them, nothing may still be writing them)
+            c->load_was_fused = true; c->counted_at_load = true; c->store_skipped = true;
+            for (int i = 0; i < 4; ++i) { float ms = 0; if (hipEventElapsedTime(&ms, c->evb[i], c->evb[i + 1]) == hipSuccess) c->build_ms[i] = ms; }
+            settle_temporaries(c);
+            c->layout_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_wall).count();
+            return 0;                                             // (tm_valid stays false: there is no store)
+        }
+        c->counted = false;                                       // rows outgrew their buffer: the store is built after all, the count is made on request
+        fused = false;
+    }
+    if (int rc = reserve_store()) return rc;
+    if (fused) {
+        if (int rc = fused_plan()) return rc;
         c->tm_valid = true;                                   // (what the count's preparation looks at; the blocks are written by the pass itself)
-        const GatherCountSrc src{events, n_events, key_b.as<uint64_t>(), val_b.as<uint32_t>(), bits};
-        rc = run_gather_count(c, &c->cal_params, src);
+        int rc = run_gather_count(c, &c->cal_params, gsrc, false);
         LSG_HIP(hipStreamSynchronize(st));
         if (hipGetLastError() != hipSuccess) { c->tm_valid = false; set_error("lsg_load_reads: the fused gather + count pass failed"); return -1; }
         plan_finish(c);
@@ -771,7 +800,7 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
         if (rc) c->counted = false;
     } else {
     LSG_HIP(hipStreamWaitEvent(st, c->ev_blk, 0));                  // (the blocks' tiles, made on the copy stream)
-    const bool plan_early = c->n_ct > 0 && c->copy_stream && c->ev_copy;
+    const bool plan_early = c->n_ct > 0 && c->copy_stream && c->ev_copy && !planned;      // (planned: a count without a store was tried and its rows did not fit)
     if (plan_early) LSG_HIP(hipEventRecord(c->ev_copy, st));       // everything the gather waits for is what the plan's tile-level half waits for
     {
         const dim3 grid((unsigned)(((((uint64_t)nblk + TMG_BLOCKS - 1) / TMG_BLOCKS + TMG_WAVES - 1) / TMG_WAVES + 7) / 8 * 8));
@@ -794,7 +823,7 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
     LSG_HIP(hipStreamSynchronize(st));
     if (plan_early) LSG_HIP(hipStreamSynchronize(c->copy_stream));
     if (plan_rc) return plan_rc;
-    if (plan_early) plan_finish(c);
+    if (plan_early || planned) plan_finish(c);
     }
     for (int i = 0; i < 4; ++i) { float ms = 0; if (hipEventElapsedTime(&ms, c->evb[i], c->evb[i + 1]) == hipSuccess) c->build_ms[i] = ms; }
     settle_temporaries(c);

@@ -113,6 +113,15 @@ class Engine:
         import ctypes as C
         _lib.check(self._lib.lsg_set_count_at_load(self._h, C.byref(params) if params is not None else None), "lsg_set_count_at_load")
 
+    STORE_KEEP, STORE_SKIP_WHEN_COUNTED = 0, 1
+
+    def set_store_policy(self, policy: int):
+        """STORE_SKIP_WHEN_COUNTED: a load that makes its count in its own pass (set_count_at_load) counts straight from the caller's
+        events and keeps no tile store - for a BAM that is counted once (the reference's BaseCellCounter rule); anything that needs
+        the store afterwards (another count, genotype_cells) raises until reads are loaded again.  STORE_KEEP is the default
+        (lsg_set_store_policy)."""
+        _lib.check(self._lib.lsg_set_store_policy(self._h, int(policy)), "lsg_set_store_policy")
+
     def unload_reads(self):
         """give the device memory of the resident load (reads, store, rows, call records, cached temporaries) back: lsg_unload_reads"""
         _lib.check(self._lib.lsg_unload_reads(self._h), "lsg_unload_reads")
@@ -319,7 +328,7 @@ class Engine:
         return s
 
     def layout_info(self):
-        """(path, build_ms, store_bytes): path 2 = the load built the store alone, 3 = in the pass that also made the first count (set_count_at_load); wall time the last load spent building the
+        """(path, build_ms, store_bytes): path 2 = the load built the store alone, 3 = in the pass that also made the first count (set_count_at_load), 4 = the load counted and kept no store (set_store_policy); wall time the last load spent building the
         store; device bytes the store and what belongs to it hold (lsg_get_layout_info)"""
         path = C.c_int32(0); ms = C.c_double(0.0); nbytes = C.c_int64(0)
         _lib.check(self._lib.lsg_get_layout_info(self._h, C.byref(path), C.byref(ms), C.byref(nbytes)), "lsg_get_layout_info")

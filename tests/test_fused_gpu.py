@@ -1,7 +1,8 @@
 """GPU: a load that also makes the first count (lsg_set_count_at_load: pileup.hip k_tm_gather_count builds the store's blocks and adds
 their events into the counters in one pass) — the count it hands out, AND every later count over the store it wrote, equal the
 events-level CPU oracle bit for bit; loads it cannot serve (more than two cell types, a depth cap that could fire) take the plain
-gather and count on request."""
+gather and count on request.  Every case is loaded a second time under LSG_STORE_SKIP_WHEN_COUNTED (pileup.hip k_tm_count_direct:
+the same count straight from the caller's events, no store written)."""
 import numpy as np
 import pytest
 
@@ -50,6 +51,32 @@ def fused_vs_oracle(engine, rec, lens, refs, ct_of, n_ct, p, expect_fused=True, 
         for ct in range(n_ct):
             k, rf, c = engine.fetch_counts(ct)
             np.testing.assert_array_equal(k, w2[ct][0]); np.testing.assert_array_equal(c, w2[ct][2])
+    stats_keep = engine.count_stats() if not recount_params else None
+    # ... and the same load keeping NO store (lsg_set_store_policy: k_tm_count_direct reads the events where the caller left them)
+    engine.set_count_at_load(p)
+    engine.set_store_policy(engine.STORE_SKIP_WHEN_COUNTED)
+    try:
+        engine.load_reads(rec)
+    finally:
+        engine.set_count_at_load(None)
+        engine.set_store_policy(engine.STORE_KEEP)
+    assert engine.layout_info()[0] == (4 if expect_fused else 2)
+    for what in ("the count made by the load that kept no store", "the same count asked for again"):
+        rows, cols = engine.pileup_count(p)
+        assert cols == want_cols, what
+        for ct in range(n_ct):
+            k, rf, c = engine.fetch_counts(ct)
+            assert rows[ct] == len(want[ct][0]), what
+            np.testing.assert_array_equal(k, want[ct][0], err_msg=what); np.testing.assert_array_equal(rf, want[ct][1], err_msg=what)
+            np.testing.assert_array_equal(c, want[ct][2], err_msg=what)
+    if expect_fused:
+        if stats_keep is not None:
+            st = engine.count_stats()
+            for f in ("n_reads_admitted", "n_segs_admitted", "n_events_admitted", "n_entries", "n_units", "n_deep_units"):
+                assert getattr(st, f) == getattr(stats_keep, f), f
+        other = CountParams.longsom_defaults(min_bq=p.min_bq + 1)
+        with pytest.raises(RuntimeError, match="kept no store"):
+            engine.pileup_count(other)
     return rows, cols
 
 
@@ -123,22 +150,25 @@ def test_region_and_device_arrays(engine):
     whole = engine.pileup_count(p)
     ref_rows = [engine.fetch_counts(ct) for ct in range(2)]
     mid = int(m.contig_len[0]) // 2 // 64 * 64
-    parts = []
-    for lo, hi in (((0, 0), (0, mid)), ((0, mid), (len(m.contig_len), 0))):
-        engine.set_region(lo[0], lo[1], hi[0], hi[1])
-        engine.set_count_at_load(p)
-        try:
-            engine.synth_reads(m)
-        finally:
-            engine.set_count_at_load(None)
-        assert engine.layout_info()[0] == 3
-        rows, cols = engine.pileup_count(p)
-        parts.append((rows, cols, [engine.fetch_counts(ct) for ct in range(2)]))
+    for policy, path in ((engine.STORE_SKIP_WHEN_COUNTED, 4), (engine.STORE_KEEP, 3)):
+        parts = []
+        for lo, hi in (((0, 0), (0, mid)), ((0, mid), (len(m.contig_len), 0))):
+            engine.set_region(lo[0], lo[1], hi[0], hi[1])
+            engine.set_count_at_load(p)
+            engine.set_store_policy(policy)
+            try:
+                engine.synth_reads(m)
+            finally:
+                engine.set_count_at_load(None)
+                engine.set_store_policy(engine.STORE_KEEP)
+            assert engine.layout_info()[0] == path
+            rows, cols = engine.pileup_count(p)
+            parts.append((rows, cols, [engine.fetch_counts(ct) for ct in range(2)]))
+        assert parts[0][1] + parts[1][1] == whole[1]
+        for ct in range(2):
+            for j in range(3):
+                np.testing.assert_array_equal(np.concatenate([parts[0][2][ct][j], parts[1][2][ct][j]]), ref_rows[ct][j])
     engine.set_region()
-    assert parts[0][1] + parts[1][1] == whole[1]
-    for ct in range(2):
-        for j in range(3):
-            np.testing.assert_array_equal(np.concatenate([parts[0][2][ct][j], parts[1][2][ct][j]]), ref_rows[ct][j])
     rows, cols = engine.pileup_count(p)                       # the whole genome over the store the second (regional) load wrote
     assert (rows, cols) == whole
 
