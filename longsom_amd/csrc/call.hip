@@ -42,7 +42,7 @@ static_assert(sizeof(CandCt) == 56, "CandCt layout");
 
 // counter words of the call stage; the ones the kernels allocate from while they run sit on cache lines of their own (atomics on one
 // line serialise at ~90 per microsecond whichever of its words they name)
-enum { CT_CAND = 0, CT_NCAND = 1, CT_HEADS = 4, CT_PASS = 6, CT_LIGHT = 16, CT_HEAVY = 32, CT_QTAIL = 48, CT_WORDS = 64 };
+enum { CT_CAND = 0, CT_NCAND = 1, CT_HEADS = 4, CT_PASS = 6, CT_LIGHT = 16, CT_HEAVY = 32, CT_QTAIL = 48, CT_DEFER = 64, CT_WORDS = 80 };
 struct CallArgs {
     const uint32_t* ne_units; const uint64_t* ne_mask; const uint32_t* ne_rowbase; const int2* ne_geom;
     uint32_t n_ne; int32_t n_ct;
@@ -59,6 +59,8 @@ struct CallArgs {
     uint32_t arena_waves;             // waves of k_call_gather (each owns chunk number `wave` of every arena list)
     const uint32_t* heads;            // units that are the first of a tile with at least one site
     uint32_t* head_recs;              // 16 words per head: unit, first site index, tile start, tid, masks[4] (lo, hi), row bases[4]
+    uint32_t* defer_list;             // sites with a tail still to be computed (k_call_gather appends, counters[CT_DEFER] counts): k_call_finish's work
+    uint64_t defer_cap;
 };
 
 // log of the beta-binomial pmf at m (scipy betabinom._logpmf written with lgamma)
@@ -180,9 +182,10 @@ __global__ void k_head_recs(CallArgs a) {
 // per-workgroup atomics would cap the kernel).  Task arenas are split across chunks so that only the LAST chunk of a
 // wave has unused slots; those are written as null tasks (dst = 0) which the tail kernels skip.
 constexpr int GATHER_WAVES = 4;
-constexpr uint32_t CAND_CHUNK = 256, TASK_CHUNK = 512, HEAVY_CHUNK = 32;   // heavy tasks are rare and a null heavy slot costs a wave a memory round trip
+constexpr uint32_t CAND_CHUNK = 256, TASK_CHUNK = 64, HEAVY_CHUNK = 16;   // heavy tasks are rare and a null heavy slot costs a wave a memory round trip
+// (127 registers per lane at two cell types: 4 waves per SIMD.  Capped at 96 / 80 registers the spills cost more than the fifth and sixth wave hide: 2.2 -> 2.5 / 3.1 ms)
 template <int NCT>
-__global__ __launch_bounds__(GATHER_WAVES * 64) void k_call_gather(CallArgs a) {
+__global__ __launch_bounds__(GATHER_WAVES * 64) __attribute__((amdgpu_waves_per_eu(NCT <= 2 ? 4 : 3))) void k_call_gather(CallArgs a) {
     const int lane = threadIdx.x & 63;
     const uint32_t wave = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const uint32_t n_waves = (uint32_t)(((uint64_t)gridDim.x * blockDim.x) >> 6);
@@ -332,6 +335,10 @@ __global__ __launch_bounds__(GATHER_WAVES * 64) void k_call_gather(CallArgs a) {
     }
     int lc_up = 0, lc_down = 0;
     SiteRec* srp = &a.sites[idx];
+    // every tail of this site came out of the table (n <= TAIL_NT: all but the deepest sites): its filter chains are finished right here;
+    // the others are listed for k_call_finish, which runs when the tail kernels have written their values
+    const bool all_known = (n_light | n_heavy) == 0u;
+    int f_pass = 0, f_nonsig = 0, f_with = 0; bool f_multi = false;
 
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) {
@@ -381,6 +388,20 @@ __global__ __launch_bounds__(GATHER_WAVES * 64) void k_call_gather(CallArgs a) {
                 }
             }
         }
+        if (all_known && cd.n_alt > 0) {                                               // the per-cell-type chain (:263-277; k_call_finish's, same order)
+            int32_t min_pbc = 100000, min_pcc = 100000;
+#pragma unroll
+            for (int q = 0; q < LSG_CALL_MAX_ALT; ++q) if (q < (int)cd.n_alt) { min_pbc = cd.p_bc[q] < min_pbc ? cd.p_bc[q] : min_pbc; min_pcc = cd.p_cc[q] < min_pcc ? cd.p_cc[q] : min_pcc; }
+            uint8_t f;
+            if (min_pbc >= 500 || min_pcc >= 500) f = LSG_CF_NONSIG;
+            else if ((min_pbc > 10 && min_pbc < 500) || (min_pcc > 10 && min_pcc < 500)) f = LSG_CF_LOWSIG;
+            else if (cd.n_alt > 1) f = LSG_CF_MULTI;
+            else if ((int)cd.alt_cc[0] < P.min_ac_cells) f = LSG_CF_LOW_CELLS;
+            else if ((int)cd.alt_bc[0] < P.min_ac_reads) f = LSG_CF_LOW_READS;
+            else f = LSG_CF_PASS;
+            cd.ct_filter = f;
+            ++f_with; f_pass += f == LSG_CF_PASS; f_nonsig += f == LSG_CF_NONSIG; f_multi |= f == LSG_CF_MULTI;
+        }
         if (cdp) *cdp = cd;
     }
     sr.cell_types_min = (uint8_t)n_considered;
@@ -401,8 +422,31 @@ __global__ __launch_bounds__(GATHER_WAVES * 64) void k_call_gather(CallArgs a) {
         if (have_ctx && lc_up >= 4) sf |= LSG_SF_LC_UP;                        // :347-354
         if (have_ctx && lc_down >= 4) sf |= LSG_SF_LC_DOWN;
     }
+    bool pass_site = false;
+    if (all_known) {                                                           // the site's chain (k_call_finish's)
+        const int32_t npb = sr.noise_p_bc, npc = sr.noise_p_cc;
+        if (sr.has_cand) {
+            if (f_pass > P.max_cell_types) sf |= LSG_SF_MULTIPLE_CELL_TYPES;       // :309
+            if (f_multi) sf |= LSG_SF_MULTI_ALLELIC;                               // :314
+            if (f_with - f_pass - f_nonsig > 0) sf |= LSG_SF_CELL_TYPE_NOISE;      // :322
+            if (s_alts_bc > 0 && ((npb >= 0 && npb < 500) || (npc >= 0 && npc < 500))) sf |= LSG_SF_NOISY_SITE;   // :342
+            pass_site = sf == (uint32_t)LSG_SF_CANDIDATE && f_pass > 0;
+        } else if (s_alts_bc > 0 && ((npb >= 0 && npb < 10) || (npc >= 0 && npc < 10))) sf |= LSG_SF_NOISY_SITE;   // :440-442
+    }
     sr.site_filter = sf;
     *srp = sr;
+    if (pass_site) {                                                           // (a few hundred per sample)
+        const unsigned long long q = atomicAdd(&a.counters[CT_PASS], 1ull);
+        if (q < PASS_CAP) a.pass_list[q] = (uint32_t)idx;
+    }
+    const unsigned long long dm = __ballot(!all_known);
+    if (dm) {
+        unsigned long long q0 = 0;
+        if (lane == __ffsll((long long)dm) - 1) q0 = atomicAdd(&a.counters[CT_DEFER], (unsigned long long)__popcll(dm));
+        q0 = ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(q0 >> 32), __ffsll((long long)dm) - 1) << 32) | (uint32_t)__shfl((int)(uint32_t)q0, __ffsll((long long)dm) - 1);
+        const unsigned long long q = q0 + __popcll(dm & below);
+        if (!all_known && q < a.defer_cap) a.defer_list[q] = (uint32_t)idx;
+    }
     }
     // unused tail of the wave's last task chunks: null tasks
     TailTask nul; nul.k = 0; nul.n = 0; nul.dst = 0;
@@ -529,8 +573,10 @@ __global__ __launch_bounds__(256) void k_call_tails_heavy(CallArgs a) {
 }
 
 __global__ void k_call_finish(CallArgs a, uint32_t n_sites) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_sites) return;
+    const unsigned long long n_def = a.counters[CT_DEFER] < a.defer_cap ? a.counters[CT_DEFER] : a.defer_cap;
+    for (unsigned long long j = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; j < n_def; j += (unsigned long long)gridDim.x * blockDim.x) {
+    const uint32_t i = a.defer_list[j];
+    if (i >= n_sites) continue;
     SiteRec s = a.sites[i];
     const lsg_call_params& P = a.p;
     const int32_t npb = s.noise_p_bc, npc = s.noise_p_cc;
@@ -566,7 +612,8 @@ __global__ void k_call_finish(CallArgs a, uint32_t n_sites) {
     } else if (s.sum_alts_bc > 0 && (bc_lt001 || cc_lt001)) {
         sf |= LSG_SF_NOISY_SITE;                                               // :440-442
     }
-    if (sf != s.site_filter) a.sites[i].site_filter = sf;        // most sites keep the flags the gather kernel gave them
+    if (sf != s.site_filter) a.sites[i].site_filter = sf;
+    }
 }
 
 // Expansion of compact records into the C-ABI's lsg_call; kind selects rows (see lsg_export_calls).
@@ -736,9 +783,9 @@ int run_call(lsg_ctx* c, const lsg_call_params* p) {
     const uint32_t n_sites = *reinterpret_cast<const uint32_t*>(c->h_pin);
     if (n_sites > 0) {
         if (c->d_calls.reserve((size_t)n_sites * sizeof(SiteRec))) return -1;
-        if (c->ws[WS_CALL_CANDS].reserve(((size_t)n_sites + (size_t)2 * c->n_cus * 4 * GATHER_WAVES * CAND_CHUNK) * sizeof(CandCt) * (size_t)c->n_ct)) return -1;   // every site could be a candidate + arena slack
         const unsigned gather_grid = (unsigned)(c->n_cus * 4);
         const uint64_t gather_waves = (uint64_t)gather_grid * GATHER_WAVES;
+        if (c->ws[WS_CALL_CANDS].reserve(((size_t)n_sites + (size_t)2 * gather_waves * CAND_CHUNK) * sizeof(CandCt) * (size_t)c->n_ct)) return -1;   // every site could be a candidate + arena slack
         a.arena_waves = (uint32_t)gather_waves;
         a.sites = c->d_calls.as<SiteRec>(); a.cands = c->ws[WS_CALL_CANDS].as<CandCt>(); a.cand_cap = n_sites + 2 * gather_waves * CAND_CHUNK;
         // at most 2 tails per alt (<= 4 alts) per cell type + 2 noise tails per site
@@ -749,6 +796,9 @@ int run_call(lsg_ctx* c, const lsg_call_params* p) {
         a.task_cap += gather_waves * TASK_CHUNK * 3;                                  // arena slack (first chunks + last partial chunks)
         if (c->ws[WS_CALL_TASKS].reserve((size_t)a.task_cap * sizeof(TailTask) * 2)) return -1;
         a.light = c->ws[WS_CALL_TASKS].as<TailTask>(); a.heavy = a.light + a.task_cap;
+        a.defer_cap = n_sites;                                                        // (a site is listed once)
+        if (c->d_defer_list.reserve((size_t)a.defer_cap * 4 + 64)) return -1;
+        a.defer_list = c->d_defer_list.as<uint32_t>();
         switch (c->n_ct) {                                                            // the cell-type loops are compile-time
             case 1: hipLaunchKernelGGL(k_call_gather<1>, dim3(gather_grid), dim3(GATHER_WAVES * 64), 0, st, a); break;
             case 2: hipLaunchKernelGGL(k_call_gather<2>, dim3(gather_grid), dim3(GATHER_WAVES * 64), 0, st, a); break;
@@ -757,7 +807,7 @@ int run_call(lsg_ctx* c, const lsg_call_params* p) {
         }
         hipLaunchKernelGGL(k_call_tails, dim3((unsigned)(c->n_cus * 16)), dim3(256), 0, st, a);
         hipLaunchKernelGGL(k_call_tails_heavy, dim3((unsigned)(c->n_cus * 8)), dim3(256), 0, st, a);
-        hipLaunchKernelGGL(k_call_finish, dim3((n_sites + 255) / 256), dim3(256), 0, st, a, n_sites);
+        hipLaunchKernelGGL(k_call_finish, dim3((unsigned)(c->n_cus * 2)), dim3(256), 0, st, a, n_sites);        // (the listed sites only: the deepest few thousand)
         LSG_HIP(hipGetLastError());
     }
     unsigned long long cnt4[CT_WORDS];

@@ -18,6 +18,6 @@ for d in sorted(glob.glob("gpurun_out/sq/s*/")):
             k = r["Kernel_Name"].split("(")[0]
             acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[(k, r["Counter_Name"])] += 1
         for k in acc:
-            if "tm_walk" in k or "tm_resolve" in k or "tm_gather" in k or "tm_fill" in k or "k_bin" in k or "call_gather" in k or "k_seg_static" in k or "segmented" in k[:400]:
+            if "tm_walk" in k or "tm_resolve" in k or "tm_gather" in k or "tm_count" in k or "tm_fill" in k or "k_bin" in k or "call_gather" in k or "k_seg_static" in k or "segmented" in k[:400]:
                 print(k, {c: round(v / n[(k, c)]) for c, v in acc[k].items()})
 PY
