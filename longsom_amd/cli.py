@@ -107,7 +107,8 @@ def base_cell_counter(argv=None):
             eng.set_region(tid, 0, tid + 1, 0)
         eng.set_pileup_window(max(64, a.bin))             # --bin: the windows whose pileups each have a max_depth buffer of their own (:185-191)
         cp = CountParams.longsom_defaults(min_bq=a.min_bq, min_mq=a.min_mq, min_dp=a.min_dp, min_cc=a.min_cc)
-        eng.set_count_at_load(cp)                         # this script counts its BAM once: in the pass that loads it
+        eng.set_count_at_load(cp)                         # this script counts its BAM once: in the pass that loads it,
+        eng.set_store_policy(eng.STORE_SKIP_WHEN_COUNTED)  # and keeps no store for another count
         eng.load_reads(dec.records)
         eng.pileup_count(cp)
         k, r, c = eng.fetch_counts(0)

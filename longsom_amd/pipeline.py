@@ -115,18 +115,22 @@ PILEUP_MAX_DEPTH = 200000   # bam.pileup(..., max_depth = 200000), BaseCellCount
 
 
 def load_sample(bam: str, barcodes_tsv: str, ref_fasta: str, engine: Engine, min_mapq: int, allow_depth_overflow: Optional[bool] = None,
-                ingest: Optional[str] = None, count_params: Optional[CountParams] = None) -> Resident:
+                ingest: Optional[str] = None, count_params: Optional[CountParams] = None, keep_store: bool = True) -> Resident:
     """count_params: the parameters of the count that follows, when the caller knows them (every fused rule does): the load then makes
     that count in the pass that builds the store (Engine.set_count_at_load) and the first pileup_count under them costs nothing.
+    keep_store=False (with count_params): that count is the only one the caller will ask for - the load writes no tile store
+    (Engine.set_store_policy); another count or a genotyping pass on these reads then raises.
     ingest: "device" = the BAM's bytes go to the GPU and are inflated, decoded and laid out there (lsg_load_bam); "host" = the host
     decoder (liblongsom_io) + lsg_load_reads; "auto" (default, or LONGSOM_INGEST) = device, and host for a BAM whose records are not
     aligned to its BGZF blocks (not written by htslib).  Same store, same report either way (tests/test_ingest_gpu.py)."""
     ingest = ingest or os.environ.get("LONGSOM_INGEST", "auto")
     engine.set_count_at_load(count_params)
+    engine.set_store_policy(engine.STORE_KEEP if keep_store or count_params is None else engine.STORE_SKIP_WHEN_COUNTED)
     try:
         return _load_sample(bam, barcodes_tsv, ref_fasta, engine, min_mapq, ingest)
     finally:
         engine.set_count_at_load(None)
+        engine.set_store_policy(engine.STORE_KEEP)
 
 
 def _load_sample(bam: str, barcodes_tsv: str, ref_fasta: str, engine: Engine, min_mapq: int, ingest: str) -> Resident:
@@ -294,7 +298,8 @@ def run_snv(bam: str, barcodes_tsv: str, ref_fasta: str, out_dir: str, sample_id
                              "use one or the other" % comm.world)
         if comm.world > 1 or window_bytes:
             return _run_snv_regions(bam, barcodes_tsv, ref_fasta, out_dir, sample_id, params, editing, pon_sr, pon_lr, gnomad_af_json, eng, comm, window_bytes)
-        res = load_sample(bam, barcodes_tsv, ref_fasta, eng, params.min_mapping_quality, count_params=params.count())
+        # (the chain counts its sample once: an engine of our own keeps no store for counts nobody will ask for)
+        res = load_sample(bam, barcodes_tsv, ref_fasta, eng, params.min_mapping_quality, count_params=params.count(), keep_store=not own)
         return run_chain(res, res.table.celltype_of, res.table.celltype_names, res.dec.report, out_dir, sample_id, params, editing, pon_sr, pon_lr,
                          gnomad_af_json)
     finally:
