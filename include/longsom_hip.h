@@ -255,6 +255,13 @@ int lsg_set_count_at_load(lsg_ctx* ctx, const lsg_count_params* params);
  * with the load's parameters returns it, and everything that needs the store (another count, lsg_genotype_cells) fails with a message
  * until reads are loaded again.  A load that cannot make its count (the depth cap could fire, more than two cell types) builds the
  * store as under LSG_STORE_KEEP. */
+/* The BAM loads that follow (lsg_load_bam, lsg_load_bam_range) keep the reads without a CB tag or with a barcode that is not listed
+ * (cb = -1) instead of dropping them at decode time.  Such a read is never counted (SplitBamCellTypes.py:74-90 routes it nowhere), but
+ * the per-cell genotyping piles up the UNSPLIT BAM (HCCVSingleCellGenotype.py:121-122): every read that passes that pileup's own
+ * filters takes a place in its max_depth buffer, listed or not, and lsg_genotype_cells_grouped replays the buffer over the resident
+ * reads.  Default off (the counting rules never see these reads; their events cost memory).  The host decoder's twin is
+ * lsio_set_keep_unlisted. */
+int lsg_set_keep_unlisted(lsg_ctx* ctx, int32_t on);
 enum { LSG_STORE_KEEP = 0, LSG_STORE_SKIP_WHEN_COUNTED = 1 };
 int lsg_set_store_policy(lsg_ctx* ctx, int32_t policy);
 

@@ -137,6 +137,7 @@ SIGNATURES = {
     "lsg_set_region": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int64]),
     "lsg_set_count_at_load": (C.c_int, [C.c_void_p, C.c_void_p]),
     "lsg_set_store_policy": (C.c_int, [C.c_void_p, C.c_int32]),
+    "lsg_set_keep_unlisted": (C.c_int, [C.c_void_p, C.c_int32]),
     "lsg_set_pileup_window": (C.c_int, [C.c_void_p, C.c_int32]),
     "lsg_synth_reference": (C.c_int, [C.c_void_p, C.c_uint64]),
     "lsg_synth_reads": (C.c_int, [C.c_void_p, C.c_void_p]),

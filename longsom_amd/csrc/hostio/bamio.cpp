@@ -50,6 +50,7 @@ struct Local {   // per-thread decode output
 // htslib <= 1.10: the last column of a D operation followed by another D is a deletion anchor too ("1D2D": 'D' where htslib >= 1.11
 // gives 'O'); lsio_set_legacy_del_merge, default off = htslib >= 1.11
 std::atomic<int> g_legacy_del_merge{0};
+std::atomic<int> g_keep_unlisted{0};      // lsio_set_keep_unlisted: reads without a listed barcode stay in the arrays (cb = -1)
 
 inline bool is_ref_op(uint32_t op) { return op == 0 || op == 2 || op == 3 || op == 7 || op == 8; }
 
@@ -119,17 +120,27 @@ void decode_record(const uint8_t* rec, uint32_t len, const std::unordered_map<st
         if (sz > (size_t)(end - aux)) break;                  // a field that claims more bytes than the record has
         aux += sz;
     }
-    if (!cb) { ++L.cb_not_found; return; }
-    size_t clean = 0; while (clean < cb_len && cb[clean] != '-') ++clean;          // barcode.split("-")[0] (:83)
-    auto it = cbmap.find(std::string(cb, clean));
-    if (it == cbmap.end()) { ++L.cb_not_matched; return; }
-    if ((int)mapq < min_mapq) ++L.mapq; else ++L.pass;                             // report only; the device re-applies min_mq
-    if ((size_t)it->second < L.cb_pass.size()) { if ((int)mapq < min_mapq) ++L.cb_low[(size_t)it->second]; else ++L.cb_pass[(size_t)it->second]; }
+    // A read without a listed barcode is never counted, but it takes a place in the buffer of a pileup over the UNSPLIT BAM
+    // (HCCVSingleCellGenotype.py:121-122: max_depth is about every read that passes the pileup's own filters): lsio_set_keep_unlisted
+    // keeps it, with cb = -1, for the replay of that rule (genotype.hip)
+    int32_t cb_id = -1; size_t clean = 0;
+    if (!cb) ++L.cb_not_found;
+    else {
+        while (clean < cb_len && cb[clean] != '-') ++clean;                          // barcode.split("-")[0] (:83)
+        auto it = cbmap.find(std::string(cb, clean));
+        if (it == cbmap.end()) ++L.cb_not_matched;
+        else {
+            cb_id = it->second;
+            if ((int)mapq < min_mapq) ++L.mapq; else ++L.pass;                       // report only; the device re-applies min_mq
+            if ((size_t)cb_id < L.cb_pass.size()) { if ((int)mapq < min_mapq) ++L.cb_low[(size_t)cb_id]; else ++L.cb_pass[(size_t)cb_id]; }
+        }
+    }
+    if (cb_id < 0 && !g_keep_unlisted.load(std::memory_order_relaxed)) return;
     if ((flag & 0x4) || n_cigar == 0) return;                                      // no alignment: nothing to pile up
     const uint32_t r = (uint32_t)L.read_tid.size();
     // SAM flags use 12 bits; bit 15 records that the raw CB carried a "-suffix" (the genotyping script looks the RAW tag up, lsg_genotype_cells)
-    L.read_tid.push_back(tid); L.read_pos.push_back(pos); L.read_flag.push_back((uint16_t)((flag & 0x0fffu) | (clean < cb_len ? LSG_FLAG_CB_SUFFIX : 0u))); L.read_mapq.push_back((uint8_t)mapq);
-    L.read_cb.push_back(it->second);
+    L.read_tid.push_back(tid); L.read_pos.push_back(pos); L.read_flag.push_back((uint16_t)((flag & 0x0fffu) | (cb_id >= 0 && clean < cb_len ? LSG_FLAG_CB_SUFFIX : 0u))); L.read_mapq.push_back((uint8_t)mapq);
+    L.read_cb.push_back(cb_id);
     // CIGAR walk (htslib resolve_cigar2 semantics)
     int64_t x = pos; uint32_t y = 0;
     int64_t last_pos = -2;
@@ -206,6 +217,8 @@ typedef struct {
 const char* lsio_last_error(void) { return g_err; }
 void lsio_set_legacy_del_merge(int on) { g_legacy_del_merge.store(on ? 1 : 0); }
 int lsio_get_legacy_del_merge(void) { return g_legacy_del_merge.load(); }
+void lsio_set_keep_unlisted(int on) { g_keep_unlisted.store(on ? 1 : 0); }
+int lsio_get_keep_unlisted(void) { return g_keep_unlisted.load(); }
 
 void lsio_free_decoded(lsio_decoded* d) {
     if (!d) return;

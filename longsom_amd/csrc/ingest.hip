@@ -83,7 +83,7 @@ __global__ void k_rec_list(const uint8_t* u, const IngBlk* blk, uint32_t n_blk, 
 
 struct RecArgs {
     const uint8_t* u; uint64_t total; const uint64_t* rec_off; uint64_t n_rec;
-    int32_t n_ref; const int64_t* ref_len; lsr::CbTable cbt; int32_t min_mapq, legacy;
+    int32_t n_ref; const int64_t* ref_len; lsr::CbTable cbt; int32_t min_mapq, legacy, keep_unlisted;
     uint8_t* keep; int32_t* cb; uint32_t* nseg; uint32_t* nev;
     unsigned long long* counters;         // total, pass, cb_not_found, cb_not_matched, mapq
     unsigned long long* cb_pass; unsigned long long* cb_low; int64_t n_tally;
@@ -118,10 +118,13 @@ __global__ void k_rec_info(RecArgs a) {
                     const bool low = (int)mapq < a.min_mapq;                                 // report only: the store's load filter / the counts re-apply min_mq
                     if (low) c_low += mine; else c_pass += mine;
                     if (mine && (int64_t)id < a.n_tally) atomicAdd(low ? &a.cb_low[id] : &a.cb_pass[id], 1ull);
+                }
+                // (a read without a listed barcode stays, with cb = -1, when lsg_set_keep_unlisted asks: the pool of the genotyping pileup)
+                if (id >= 0 || a.keep_unlisted) {
                     if (!(flag & 0x4) && n_cigar) {
                         const lsr::Shape sh = lsr::walk<false>(rec, a.legacy, 0, 1, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr);
                         if (sh.n_events >= (1ull << 31)) atomicOr(a.status, 16u);
-                        else { keep = (uint8_t)(1u | (clean < raw ? 2u : 0u)); nseg = sh.n_segs; nev = (uint32_t)sh.n_events; }
+                        else { keep = (uint8_t)(1u | (id >= 0 && clean < raw ? 2u : 0u)); nseg = sh.n_segs; nev = (uint32_t)sh.n_events; }
                     }
                 }
             }
@@ -333,7 +336,7 @@ static int load_bam_impl(lsg_ctx* c, const uint8_t* file, int64_t n_bytes, int64
         RecArgs ra{};
         ra.u = u; ra.total = utotal; ra.rec_off = d_recoff.as<uint64_t>(); ra.n_rec = n_rec; ra.n_ref = c->n_contigs; ra.ref_len = c->d_contig_len.as<int64_t>();
         ra.cbt = lsr::CbTable{d_h.as<uint64_t>(), d_id.as<int32_t>(), d_so.as<uint32_t>(), d_sl.as<uint32_t>(), d_str.as<uint8_t>(), cbt.mask};
-        ra.min_mapq = min_mapq; ra.legacy = legacy_del_merge ? 1 : 0;
+        ra.min_mapq = min_mapq; ra.legacy = legacy_del_merge ? 1 : 0; ra.keep_unlisted = c->keep_unlisted ? 1 : 0;
         ra.keep = d_keep.as<uint8_t>(); ra.cb = d_cb.as<int32_t>(); ra.nseg = d_nseg.as<uint32_t>(); ra.nev = d_nev.as<uint32_t>();
         ra.counters = d_cnt.as<unsigned long long>(); ra.cb_pass = d_tpass.as<unsigned long long>(); ra.cb_low = d_tlow.as<unsigned long long>(); ra.n_tally = n_tally;
         ra.status = status;

@@ -223,6 +223,12 @@ int lsg_set_count_at_load(lsg_ctx* c, const lsg_count_params* params) {
     return 0;
 }
 
+int lsg_set_keep_unlisted(lsg_ctx* c, int32_t on) {
+    if (!c) { set_error("lsg_set_keep_unlisted: NULL handle"); return -2; }
+    c->keep_unlisted = on != 0;
+    return 0;
+}
+
 int lsg_set_store_policy(lsg_ctx* c, int32_t policy) {
     if (!c) { set_error("lsg_set_store_policy: NULL handle"); return -2; }
     if (policy != LSG_STORE_KEEP && policy != LSG_STORE_SKIP_WHEN_COUNTED) { set_error("lsg_set_store_policy: unknown policy %d", (int)policy); return -2; }

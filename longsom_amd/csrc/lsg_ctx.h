@@ -137,6 +137,7 @@ struct lsg_ctx {
     int32_t plp_window = 50000, st_window = 50000;        // lsg_set_pileup_window: the reference's pileup windows (--bin) for the next loads / of the resident store
     int32_t lf_min_mq = 0, lf_ignore_orphans = 0; uint32_t lf_flag_exclude = 0;      // lsg_set_load_filter: reads failing it are not stored by the next loads
     int32_t st_min_mq = 0, st_ignore_orphans = 0; uint32_t st_flag_exclude = 0;      // ... and the filter the resident store was built under
+    bool keep_unlisted = false;           // lsg_set_keep_unlisted: the BAM loads keep reads without a listed barcode (cb = -1; never counted, but in the genotyping pileup's buffer)
     bool keep_reads = false;              // lsg_set_keep_reads: the compact events stay resident beside the store (rd.events; tests, sampling)
     // tile store (see above) and the plan of a count over it
     lsg::DevBuf d_tile_cap, d_tile_off;   // entries per tile and their exclusive prefix

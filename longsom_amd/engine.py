@@ -113,6 +113,11 @@ class Engine:
         import ctypes as C
         _lib.check(self._lib.lsg_set_count_at_load(self._h, C.byref(params) if params is not None else None), "lsg_set_count_at_load")
 
+    def set_keep_unlisted(self, on: bool):
+        """The BAM loads that follow keep reads without a listed barcode (cb = -1): never counted, but part of the buffer the per-cell
+        genotyping's pileup of the unsplit BAM fills (HCCVSingleCellGenotype.py:121-122; lsg_set_keep_unlisted)."""
+        _lib.check(self._lib.lsg_set_keep_unlisted(self._h, 1 if on else 0), "lsg_set_keep_unlisted")
+
     STORE_KEEP, STORE_SKIP_WHEN_COUNTED = 0, 1
 
     def set_store_policy(self, policy: int):

@@ -58,6 +58,8 @@ def load():
         lib.lsio_build_bai.argtypes = [C.c_char_p, C.c_char_p]
         lib.lsio_set_legacy_del_merge.argtypes = [C.c_int]
         lib.lsio_get_legacy_del_merge.restype = C.c_int
+        lib.lsio_set_keep_unlisted.argtypes = [C.c_int]
+        lib.lsio_get_keep_unlisted.restype = C.c_int
         _lib = lib
         if os.environ.get("LONGSOM_HTSLIB_LEGACY_DEL_MERGE", "0") == "1":
             lib.lsio_set_legacy_del_merge(1)
@@ -73,6 +75,16 @@ def set_legacy_del_merge(on: bool) -> bool:
     lib = load()
     old = bool(lib.lsio_get_legacy_del_merge())
     lib.lsio_set_legacy_del_merge(1 if on else 0)
+    return old
+
+
+def set_keep_unlisted(on: bool) -> bool:
+    """The host decoder keeps reads without a CB tag or with an unlisted barcode (cb = -1) instead of dropping them (process-wide; returns
+    the previous setting).  They are never counted, but the per-cell genotyping piles up the UNSPLIT BAM (HCCVSingleCellGenotype.py:121-122)
+    and its max_depth buffer holds every read that passes the pileup's own filters.  Engine.set_keep_unlisted is the device decoder's twin."""
+    lib = load()
+    old = bool(lib.lsio_get_keep_unlisted())
+    lib.lsio_set_keep_unlisted(1 if on else 0)
     return old
 
 

@@ -115,22 +115,28 @@ PILEUP_MAX_DEPTH = 200000   # bam.pileup(..., max_depth = 200000), BaseCellCount
 
 
 def load_sample(bam: str, barcodes_tsv: str, ref_fasta: str, engine: Engine, min_mapq: int, allow_depth_overflow: Optional[bool] = None,
-                ingest: Optional[str] = None, count_params: Optional[CountParams] = None, keep_store: bool = True) -> Resident:
+                ingest: Optional[str] = None, count_params: Optional[CountParams] = None, keep_store: bool = True, keep_unlisted: bool = False) -> Resident:
     """count_params: the parameters of the count that follows, when the caller knows them (every fused rule does): the load then makes
     that count in the pass that builds the store (Engine.set_count_at_load) and the first pileup_count under them costs nothing.
     keep_store=False (with count_params): that count is the only one the caller will ask for - the load writes no tile store
     (Engine.set_store_policy); another count or a genotyping pass on these reads then raises.
+    keep_unlisted: the reads without a listed barcode stay resident (never counted): the per-cell genotyping's pileup of the unsplit BAM
+    holds them in its max_depth buffer (HCCVSingleCellGenotype.py:121-122); the chains that genotype pass True.
     ingest: "device" = the BAM's bytes go to the GPU and are inflated, decoded and laid out there (lsg_load_bam); "host" = the host
     decoder (liblongsom_io) + lsg_load_reads; "auto" (default, or LONGSOM_INGEST) = device, and host for a BAM whose records are not
     aligned to its BGZF blocks (not written by htslib).  Same store, same report either way (tests/test_ingest_gpu.py)."""
     ingest = ingest or os.environ.get("LONGSOM_INGEST", "auto")
     engine.set_count_at_load(count_params)
     engine.set_store_policy(engine.STORE_KEEP if keep_store or count_params is None else engine.STORE_SKIP_WHEN_COUNTED)
+    engine.set_keep_unlisted(keep_unlisted)
+    old_keep = hostio.set_keep_unlisted(keep_unlisted)
     try:
         return _load_sample(bam, barcodes_tsv, ref_fasta, engine, min_mapq, ingest)
     finally:
         engine.set_count_at_load(None)
         engine.set_store_policy(engine.STORE_KEEP)
+        engine.set_keep_unlisted(False)
+        hostio.set_keep_unlisted(old_keep)
 
 
 def _load_sample(bam: str, barcodes_tsv: str, ref_fasta: str, engine: Engine, min_mapq: int, ingest: str) -> Resident:
@@ -706,7 +712,7 @@ def run_reannotation(bam: str, barcodes_tsv: str, ref_fasta: str, out_dir: str, 
     eng = engine or Engine(device)
     t = {}
     try:
-        res = load_sample(bam, barcodes_tsv, ref_fasta, eng, rp.chain.min_mapping_quality)
+        res = load_sample(bam, barcodes_tsv, ref_fasta, eng, rp.chain.min_mapping_quality, keep_unlisted=True)      # (the genotyping pileup's buffer holds every read)
         d1 = os.path.join(out_dir, "CellTypeReannotation")
         p1 = run_chain(res, res.table.celltype_of, res.table.celltype_names, res.dec.report, d1, sample_id, rp.chain, editing, pon_sr, pon_lr, gnomad_af_json,
                        step3=pass1_step3)
@@ -762,7 +768,13 @@ def _run_reannotation_ranks(bam, barcodes_tsv, ref_fasta, out_dir, sample_id, rp
         raise ValueError("the two passes must share min_mapping_quality to share one decode (SplitBam report)")
     t: Dict[str, float] = {}
     d1 = os.path.join(out_dir, "CellTypeReannotation")
-    p1 = _run_snv_regions(bam, barcodes_tsv, ref_fasta, d1, sample_id, rp.chain, editing, pon_sr, pon_lr, gnomad_af_json, eng, comm, None, step3=pass1_step3)
+    eng.set_keep_unlisted(True)                             # (the genotyping pileup's buffer holds every read, listed or not: HCCVSingleCellGenotype.py:121-122)
+    old_keep = hostio.set_keep_unlisted(True)
+    try:
+        p1 = _run_snv_regions(bam, barcodes_tsv, ref_fasta, d1, sample_id, rp.chain, editing, pon_sr, pon_lr, gnomad_af_json, eng, comm, None, step3=pass1_step3)
+    finally:
+        eng.set_keep_unlisted(False)
+        hostio.set_keep_unlisted(old_keep)
     state = p1.resident
     table, dec = state["table"], state["dec"]
     hccv = os.path.join(d1, "HCCV", sample_id + ".HCCV.tsv")

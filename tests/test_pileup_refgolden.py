@@ -257,6 +257,82 @@ def test_gpu_genotype_table_equals_the_reference_file(engine, tmp_path, tag, fla
     assert open(out).read() == want
 
 
+# ---- the genotyping pileup's buffer holds reads WITHOUT a listed barcode too (HCCVSingleCellGenotype.py:121-122 piles up the unsplit BAM):
+# tests/golden/pileup.capu.* (tools/make_genotype_cap_golden.py: the reference run with max_depth = 8 on a pile of mostly unlisted reads)
+def capu_sites(names):
+    tid_of = {n: i for i, n in enumerate(names)}
+    rows = [l.rstrip("\n").split("\t") for l in open(os.path.join(G, "pileup.capu.HCCV.tsv")) if not l.startswith("#")]
+    sites = {(tid_of[r[0]] << 32) | (int(r[1]) - 1): r for r in rows}
+    return np.asarray(sorted(sites), np.int64), sites
+
+
+@pytest.mark.parametrize("keep", [True, False])
+def test_unlisted_reads_fill_the_genotyping_buffer_oracle(keep):
+    from oracle import genotype_oracle as go
+    from longsom_amd.reanno import SYM_OF_BASE
+    bc, names, refs = rand_inputs("rand")
+    old = hostio.set_keep_unlisted(keep)
+    try:
+        dec = hostio.decode_bam(os.path.join(G, "pileup.capu.bam"), bc.barcodes, min_mapq=0)
+    finally:
+        hostio.set_keep_unlisted(old)
+    assert dec.records.n_reads == (57 if keep else 27)
+    keys, sites = capu_sites(names)
+    alt_sym = np.asarray([SYM_OF_BASE.get(sites[k][4].split(",")[0], 255) for k in keys.tolist()], np.uint8)
+    got = {}
+    for tag, cap in (("capu", 8), ("capuoff", 200000)):
+        dp, alt = go.genotype(dec.records, [len(r) for r in refs], bc.celltype_of, keys, alt_sym, min_bq=30, min_mq=60,
+                              group_off=np.asarray([0, len(keys)], np.int64), max_depth=cap)
+        rows = set()
+        for i, k in enumerate(keys.tolist()):
+            r = sites[k]
+            for b, name in enumerate(bc.barcodes):
+                rows.add(go.cell_row(r[0], k & 0xFFFFFFFF, r[3], r[4].split(",")[0], r[6], r[13], name, bc.celltype_names[int(bc.celltype_of[b])], int(dp[i, b]), int(alt[i, b]),
+                                     0.260288007167716, 173.94711910763732, 0.01, "True"))
+        want = {l for l in open(os.path.join(G, "pileup.%s.genotype.All.tsv" % tag)).read().split("\n")[1:] if l}
+        got[tag] = rows == want
+    assert got["capuoff"]                                          # nothing dropped: the unlisted reads do not matter
+    assert got["capu"] == keep                                     # capped: only a pool that holds them drops what the reference drops
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ingest", ["host", "device"])
+def test_gpu_genotype_buffer_holds_unlisted_reads(engine, tmp_path, ingest):
+    from longsom_amd import reanno
+    bc, names, refs = rand_inputs("rand")
+    bam = os.path.join(G, "pileup.capu.bam")
+    engine.set_contigs([len(r) for r in refs])
+    engine.set_barcodes(bc.celltype_of, 2); engine.set_region()
+    texts = {}
+    for keep in (True, False):
+        if ingest == "host":
+            old = hostio.set_keep_unlisted(keep)
+            try:
+                dec = hostio.decode_bam(bam, bc.barcodes, min_mapq=0)
+            finally:
+                hostio.set_keep_unlisted(old)
+            engine.load_reads(dec.records)
+        else:
+            for t, r in enumerate(refs):
+                engine.load_reference(t, r)
+            engine.set_keep_unlisted(keep)
+            try:
+                info, _, _ = engine.load_bam(bam, bc.barcodes, min_mapq=0, first_record_offset=hostio.bam_header(bam)[2])
+            finally:
+                engine.set_keep_unlisted(False)
+            assert int(info["total_reads"]) == 57 and int(info["cb_not_found"]) + int(info["cb_not_matched"]) == 30
+        assert engine.store_shape()[0] > 0
+        for tag, cap in (("capu", 8), ("capuoff", 200000)):
+            out = str(tmp_path / ("%s_%d.tsv" % (tag, keep)))
+            reanno.single_cell_genotype(engine, os.path.join(G, "pileup.capu.HCCV.tsv"), bc, names, out, alt_flag="All", min_bq=30, min_mq=60, max_depth=cap)
+            texts[(tag, keep)] = open(out).read()
+    for tag in ("capu", "capuoff"):
+        want = open(os.path.join(G, "pileup.%s.genotype.All.tsv" % tag)).read()
+        assert texts[(tag, True)] == want, tag
+    assert texts[("capuoff", False)] == open(os.path.join(G, "pileup.capuoff.genotype.All.tsv")).read()
+    assert texts[("capu", False)] != texts[("capu", True)]           # without the unlisted reads the buffer never fills
+
+
 # ---- GPU ------------------------------------------------------------------------------------------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", sorted(K.CASES))
