@@ -1027,97 +1027,119 @@ __global__ __launch_bounds__(TMW_WAVES * 64) __attribute__((amdgpu_waves_per_eu(
 // events themselves.  Same plan, jobs, planes, run logic and rows; a wave reads an entry's events where the caller left them:
 // lane = position of the tile, ONE 2-byte buffer load per entry through a descriptor of its own (base = the entry's first event,
 // num_records = its events' bytes, offset = 2 (lane - first position): the lanes outside the entry get zeros without a memory request,
-// and nothing beside the entry's own events is ever fetched - no edge cases at the ends of the array).  Per group of 32 entries:
-//   K  the sorted keys and values (lanes 0..31, the neighbours in lanes 32 / 33), two groups ahead
+// and nothing beside the entry's own events is ever fetched - no edge cases at the ends of the array).  Per group of entries:
+//   K  the sorted keys and values, two groups ahead
 //   W  per lane: the entry's address | bytes | first position (two words, read lane by lane into SGPRs when the entry's load is
 //      issued), and what its meta word needs (admission bit of its read, cell type of its barcode: issued here, read a group later)
-//   E  the loads of a group's second half and of the next group's first half are in flight while 16 entries are counted
+//   E  the events, sixteen entries to a batch of loads
+// (an event is SIGN-extended into its register: the compiler keeps that out of the loop, where a zero-extension of the 2-byte load's
+// value was an operation per entry that waits for the load wherever it is placed; tm_add<false> reads the register's low half only)
 struct TdW { uint32_t lo, hi; };     // hi: address bits 32..47 | 2 * events << 16 | 2 * first position << 24
-__device__ __forceinline__ void td_range(const CountArgs& a, const TmArgs& tm, const TgArgs& tg, TmState& st, TgStat& stat, uint32_t i0, uint32_t i1, uint32_t off, uint32_t n,
-                                         uint32_t thr, uint32_t pkl0, uint32_t one, int lane, TgKeys K) {
-    const int ng = (int)((i1 - i0 + 31u) >> 5);
+// 64 entries to a group, one per lane: what a group costs beside its entries (the keys' way into words, the meta words, the run verdicts:
+// ~130 vector operations) is paid once per 64 entries (32 to a group, with the neighbours' keys in two spare lanes: 8.65 ms at C2; 64: 8.4).
+// The barcode BEFORE the group travels as a scalar from the group before (the range's first one: a load of its own), the one AFTER it is
+// lane 0 of the next group's keys, which have arrived when the group's meta words are finished (an iteration after its words were made).
+// Four quarters of 16 entries alternate between two sets of registers: 16 to 32 loads are in flight while 16 entries are counted.
+// The fences pin the ORDER the loads are issued in - look-ups, keys, quarter by quarter - in the prologue as in the loop: the counter of
+// loads in flight is in-order, and where two orders meet at the loop's head the compiler waits for everything.
+struct TdKeys64 { uint64_t k; uint32_t v; };
+__device__ __forceinline__ TdKeys64 td_load_keys64(const TgArgs& tg, uint32_t i_first, uint32_t off, uint32_t n, int lane) {
+    TdKeys64 r;
+    const uint32_t i = i_first + (uint32_t)lane, ic = i < n ? i : n - 1u;       // (past the tile's end: its last entry, which is never used)
+    r.k = __builtin_nontemporal_load(tg.key + off + ic);
+    r.v = __builtin_nontemporal_load(tg.rdv + off + ic);
+    return r;
+}
+__device__ __forceinline__ void td_range64(const CountArgs& a, const TmArgs& tm, const TgArgs& tg, TmState& st, TgStat& stat, uint32_t i0, uint32_t i1, uint32_t off, uint32_t n,
+                                           uint32_t thr, uint32_t pkl0, uint32_t one, int lane, TdKeys64 K, uint64_t key_before) {
+    const int ng = (int)((i1 - i0 + 63u) >> 6);
     const uint32_t cbm = (1u << tg.cb_bits) - 1u;
     const uint32_t lane2 = 2u * (uint32_t)lane;
     const uint64_t evb = (uint64_t)(uintptr_t)tg.events;
     const uint32_t* admp = a.adm ? reinterpret_cast<const uint32_t*>(a.adm) : reinterpret_cast<const uint32_t*>(a.celltype_of);
     const uint32_t adm_all = a.adm ? 0u : 0xffffffffu;
-    auto load_keys = [&](int g) -> TgKeys { return tg_load_keys(tg, i0 + 32u * (uint32_t)g, 0u, off, n, lane); };
-    auto words = [&](int g, const TgKeys& K, TdW& w, TgPre& pre) {
-        const uint32_t i = i0 + 32u * (uint32_t)g + (uint32_t)lane;
-        const bool valid = lane < 32 && i < i1;
+    uint32_t cb_carry = rl((uint32_t)key_before & cbm, 0);             // barcode of the entry before the group (i0 == 0: not looked at)
+    uint32_t cb_last = 0;                                              // barcode of the last entry of the group whose meta words are pending
+    auto words = [&](int g, const TdKeys64& K, TdW& w, TgPre& pre) {
+        const uint32_t i = i0 + 64u * (uint32_t)g + (uint32_t)lane;
+        const bool valid = i < i1;
         const uint32_t cb = (uint32_t)K.k & cbm;
-        const uint32_t cb_prev = (uint32_t)__shfl((int)cb, lane == 0 ? 32 : lane - 1), cb_next = (uint32_t)__shfl((int)cb, lane == 31 ? 33 : lane + 1);
+        const uint32_t up = (uint32_t)__shfl_up((int)cb, 1), dn = (uint32_t)__shfl_down((int)cb, 1);
+        const uint32_t cb_prev = lane == 0 ? cb_carry : up;
         const uint32_t geom = (uint32_t)(K.k >> tg.cb_bits), first = geom & 63u, nev = valid ? ((geom >> 6) & 63u) + 1u : 0u;
         const uint64_t addr = evb + 2ull * (K.k >> (tg.cb_bits + 12));
         const bool rs = i == 0 || cb_prev != cb;
-        const bool single = rs && (i + 1 == n || cb_next != cb);
+        const bool nd = i + 1 == n || (lane < 63 && dn != cb);           // the next entry is another barcode's (lane 63: decided when the next keys are there)
         w.lo = (uint32_t)addr; w.hi = ((uint32_t)(addr >> 32) & 0xffffu) | (nev << 17) | (first << 25);
         const uint32_t r = K.v & TG_RV_READ;
         pre.ctv = reinterpret_cast<const uint32_t*>(a.celltype_of)[(cb < (uint32_t)a.n_cb ? cb : 0u) >> 2];
         pre.admw = admp[a.adm && r < (uint32_t)a.n_reads ? r >> 5 : 0u] | adm_all;
-        pre.bits = (valid ? 1u : 0u) | (cb < (uint32_t)a.n_cb ? 2u : 0u) | ((K.v & TG_RV_FWD) ? 4u : 0u) | (single ? 8u : 0u) | (rs ? 16u : 0u) |
+        pre.bits = (valid ? 1u : 0u) | (cb < (uint32_t)a.n_cb ? 2u : 0u) | ((K.v & TG_RV_FWD) ? 4u : 0u) | (nd ? 8u : 0u) | (rs ? 16u : 0u) |
                    ((r & 31u) << 8) | (nev << 16) | ((K.v & TG_RV_SEGFIRST) ? (1u << 24) : 0u) | ((cb & 3u) << 26);
+        cb_last = cb_carry = rl(cb, 63);
     };
-    auto finish_meta = [&](const TgPre& pre) -> uint32_t {                  // (what k_tm_resolve writes for the entry under this count)
+    // cb_after: barcode of the entry after the group (the next group's lane 0)
+    auto finish_meta = [&](const TgPre& pre, uint32_t cb_of_last, uint32_t cb_after) -> uint32_t {
         if (!(pre.bits & 1u)) return TMM_SKIP;
         uint32_t cls = 2;
         const bool ok = (pre.bits & 2u) != 0 && ((pre.admw >> ((pre.bits >> 8) & 31u)) & 1u);
         if (ok) { const uint32_t ct = (pre.ctv >> (((pre.bits >> 26) & 3u) * 8u)) & 0xffu; if (ct < (uint32_t)a.n_ct && (ct >> 1) == (uint32_t)(tm.ct_base >> 1)) cls = ct & 1u; }
         if (cls < 2) { stat.ev += (pre.bits >> 16) & 0xffu; stat.sg += (pre.bits >> 24) & 1u; ++stat.ne; }
-        uint32_t M = cls < 2 ? (cls ? (TMM_CT4 | TMM_CT12) : 0u) | ((pre.bits & 4u) ? TMM_FWD : 0u) | ((pre.bits & 8u) ? TMM_SINGLE : 0u) : TMM_SKIP;
+        const bool nd = (pre.bits & 8u) != 0 || (lane == 63 && cb_after != cb_of_last);
+        const bool single = (pre.bits & 16u) != 0 && nd;
+        uint32_t M = cls < 2 ? (cls ? (TMM_CT4 | TMM_CT12) : 0u) | ((pre.bits & 4u) ? TMM_FWD : 0u) | (single ? TMM_SINGLE : 0u) : TMM_SKIP;
         if (pre.bits & 16u) M |= TMM_RS;
         return M;
     };
     uint32_t open_in = 0;
-    auto verdicts = [&](uint32_t M) -> uint32_t {                           // (as in tm_walk_range)
+    auto verdicts = [&](uint32_t M) -> uint32_t {                           // (tm_walk_range's, over 64 entries)
         const bool there = !(M & TMM_SKIP), multi = there && !(M & TMM_SINGLE), rs = (M & TMM_RS) != 0;
-        const uint32_t A = (uint32_t)__ballot(lane < 32 && multi), R = (uint32_t)__ballot(lane < 32 && rs);
-        const uint32_t below = lane < 32 ? (1u << lane) - 1u : 0xffffffffu;
-        const uint32_t rb = R & below;
-        const uint32_t seg = rb ? below & ~((1u << (31 - __clz(rb))) - 1u) : below;
-        const bool ob = (A & seg) != 0u || (!rb && open_in);
+        const unsigned long long A = __ballot(multi), R = __ballot(rs);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        const unsigned long long rb = R & below;
+        const unsigned long long seg = rb ? below & ~((1ull << (63 - __clzll((long long)rb))) - 1ull) : below;
+        const bool ob = (A & seg) != 0ull || (!rb && open_in);
         if (rs && ob) M |= TMM_CLOSE;
         if (multi && (rs || !ob)) M |= TMM_FIRST;
-        const uint32_t segl = R ? ~((1u << (31 - __clz(R))) - 1u) : 0xffffffffu;
-        open_in = ((A & segl) != 0u || (!R && open_in)) ? 1u : 0u;
+        const unsigned long long segl = R ? ~((1ull << (63 - __clzll((long long)R))) - 1ull) : ~0ull;
+        open_in = ((A & segl) != 0ull || (!R && open_in)) ? 1u : 0u;
         return M;
     };
-    // entries 16 h .. 16 h + 15 of a group: every load is issued (an entry that is not there has no bytes: no request leaves the CU),
-    // so that the compiler counts the loads in flight instead of waiting for all of them where branches meet
-    auto issue = [&](const TdW& w, int h, uint32_t (&E)[16]) {
+    auto issue = [&](const TdW& w, int q, uint32_t (&E)[16]) {
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
-            const uint32_t lo = rl(w.lo, h * 16 + u), hi = rl(w.hi, h * 16 + u);
+            const uint32_t lo = rl(w.lo, q * 16 + u), hi = rl(w.hi, q * 16 + u);
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>((uintptr_t)(((uint64_t)(hi & 0xffffu) << 32) | lo)), 0, (int)((hi >> 16) & 0xffu), 0x00020000);
-            E[u] = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rs, (int)(lane2 - (hi >> 24)), 0, 0);
+            E[u] = (uint32_t)(int32_t)(int16_t)__builtin_amdgcn_raw_buffer_load_b16(rs, (int)(lane2 - (hi >> 24)), 0, 0);
         }
     };
-    auto consume = [&](const uint32_t (&E)[16], int h, uint32_t M) {
+    auto consume = [&](const uint32_t (&E)[16], int q, uint32_t M) {
 #pragma unroll
-        for (int u = 0; u < 16; ++u) tm_add<false>(st, rl(M, h * 16 + u), E[u], thr, pkl0, one);
+        for (int u = 0; u < 16; ++u) tm_add<false>(st, rl(M, q * 16 + u), E[u], thr, pkl0, one);
     };
+    auto fence = []() { asm volatile("" ::: "memory"); };
     uint32_t EA[16], EB[16];
-    TdW w; TgPre pre;
-    // (the fences pin the ORDER the loads are issued in - look-ups, keys, first half, second half - in the prologue as in the loop: the
-    // counter of loads in flight is in-order, and where two orders meet at the loop's head the compiler waits for everything)
-    words(0, K, w, pre);
-    asm volatile("" ::: "memory");
-    K = load_keys(ng > 1 ? 1 : 0);
-    asm volatile("" ::: "memory");
-    issue(w, 0, EA);
-    asm volatile("" ::: "memory");
-    issue(w, 1, EB);
-    asm volatile("" ::: "memory");
+    TdW wc, wn; TgPre pre;
+    words(0, K, wc, pre);
+    fence();
+    K = td_load_keys64(tg, i0 + 64u, off, n, lane);
+    fence();
+    issue(wc, 0, EA);
+    fence();
+    issue(wc, 1, EB);
+    fence();
     for (int g = 0; g < ng; ++g) {
-        const uint32_t Mc = verdicts(finish_meta(pre));
-        words(g + 1, K, w, pre);                              // (past the range's last group: entries that are not there)
-        asm volatile("" ::: "memory");
-        K = load_keys(g + 2 < ng ? g + 2 : ng - 1);
-        asm volatile("" ::: "memory");
-        consume(EA, 0, Mc);
-        issue(w, 0, EA);
-        consume(EB, 1, Mc);
-        issue(w, 1, EB);
+        const uint32_t cb_after = rl((uint32_t)K.k & cbm, 0);               // (K: the keys of group g + 1, asked for an iteration ago)
+        const uint32_t Mc = verdicts(finish_meta(pre, cb_last, cb_after));
+        words(g + 1, K, wn, pre);                                           // (past the range's last group: entries that are not there)
+        fence();
+        K = td_load_keys64(tg, i0 + 64u * (uint32_t)(g + 2), off, n, lane);
+        fence();
+        consume(EA, 0, Mc); issue(wc, 2, EA);
+        consume(EB, 1, Mc); issue(wc, 3, EB);
+        consume(EA, 2, Mc); issue(wn, 0, EA);
+        consume(EB, 3, Mc); issue(wn, 1, EB);
+        wc = wn;
     }
     st.nc += st.mask & 0x10001u; st.mask = 0;
 }
@@ -1150,7 +1172,11 @@ __global__ __launch_bounds__(TMW_WAVES * 64) __attribute__((amdgpu_waves_per_eu(
         if (lane < TM_JOB_WORDS) jw = reinterpret_cast<const uint32_t*>(tm.jobs + jx0)[lane];
         uint32_t e0 = rl(jw, 0), e1 = rl(jw, 1), w0 = rl(jw, 2), slab = rl(jw, 3), nj = rl(jw, 4), tcnt = rl(jw, 5), tile = rl(jw, 6), emid = rl(jw, 7), base = rl(jw, 8), off = rl(jw, 9);
         int32_t tstart = (int32_t)rl(jw, 10); int tid = (int)rl(jw, 11);
-        TgKeys K0 = tg_load_keys(tg, (wv ? emid : e0) - base, 0u, off, tcnt, lane);
+        // (the first group's keys of the wave's range, and - 64 to a group - the entry before it)
+        auto first_i = [&]() -> uint32_t { return (wv ? emid : e0) - base; };
+        TdKeys64 K64{}; uint64_t kb = 0;
+        auto prefetch = [&]() { const uint32_t i = first_i(); K64 = td_load_keys64(tg, i, off, tcnt, lane); kb = __builtin_nontemporal_load(tg.key + off + (i ? i - 1u : 0u)); };
+        prefetch();
         for (uint32_t jx = jx0; jx < jx_end; ++jx) {
             {
                 const uint32_t jn = jx + 1 < jx_end ? jx + 1 : jx;
@@ -1172,14 +1198,14 @@ __global__ __launch_bounds__(TMW_WAVES * 64) __attribute__((amdgpu_waves_per_eu(
             const uint32_t i0 = s0r - base, i1 = s1r - base < tcnt ? s1r - base : tcnt;
             if (counting && i1 > i0) {
                 TmState st; st.nc = 0; st.mask = 0;
-                td_range(a, tm, tg, st, stat, i0, i1, off, tcnt, thr, pkl0, one, lane, K0);
+                td_range64(a, tm, tg, st, stat, i0, i1, off, tcnt, thr, pkl0, one, lane, K64, kb);
                 if (st.nc & 0xffffu) atomicAdd(&nc_sh[0][lane], st.nc & 0xffffu);
                 if (st.nc >> 16) atomicAdd(&nc_sh[1][lane], st.nc >> 16);
             }
             const uint32_t c_w0 = w0, c_slab = slab, c_nj = nj, c_tcnt = tcnt; const int32_t c_tstart = tstart; const int c_tid = tid;
             e0 = rl(jw, 0); e1 = rl(jw, 1); w0 = rl(jw, 2); slab = rl(jw, 3); nj = rl(jw, 4); tcnt = rl(jw, 5); tile = rl(jw, 6); emid = rl(jw, 7); base = rl(jw, 8); off = rl(jw, 9);
             tstart = (int32_t)rl(jw, 10); tid = (int)rl(jw, 11);
-            K0 = tg_load_keys(tg, (wv ? emid : e0) - base, 0u, off, tcnt, lane);
+            prefetch();
             __syncthreads();
             const int ct = tm.ct_base + wv;
             if (counting && ct < a.n_ct) {                   // the tile's units of this pass: wave = cell type (as in k_tm_walk)

@@ -362,9 +362,17 @@ struct CapNonZero {
     const uint32_t* cap;
     __host__ __device__ bool operator()(const uint32_t& t) const { return cap[t] != 0; }
 };
-__global__ void k_seg_bounds(const uint32_t* netile, uint32_t n, const uint32_t* tile_off, uint32_t* begin, uint32_t* end) {
+// split: the segments of more than SORT_LARGE entries in (begin, end), the others in (begin2, end2) - each list names every tile, a tile of
+// the other class as an empty segment (the two sorts run side by side on two streams; an empty segment costs a sort a few lanes)
+constexpr uint32_t SORT_LARGE = 256;      // rocprim's block-per-segment kernel takes the segments beyond the warp sorts' 32 x 8 items (LsgSortConfig)
+__global__ void k_seg_bounds(const uint32_t* netile, uint32_t n, const uint32_t* tile_off, uint32_t* begin, uint32_t* end, uint32_t* begin2, uint32_t* end2) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { const uint32_t t = netile[i]; begin[i] = tile_off[t]; end[i] = tile_off[t + 1]; }
+    if (i >= n) return;
+    const uint32_t t = netile[i], b = tile_off[t], e = tile_off[t + 1];
+    if (!begin2) { begin[i] = b; end[i] = e; return; }
+    const bool large = e - b > SORT_LARGE;
+    begin[i] = b; end[i] = large ? e : b;
+    begin2[i] = b; end2[i] = large ? b : e;
 }
 __global__ void k_tile_caps(const uint32_t* tiles, uint32_t n, const uint32_t* cap, uint32_t* out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -637,9 +645,24 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
     c->tm_n = N; c->tm_events = (int64_t)n_ev;
     c->max_live_all = max_live > 0 ? max_live : 0;
     if (N == 0) return finish();
+    // ---- 2. scatter (queued BEFORE the copy stream's work below: those two dozen launches are 0.3 ms of host time the scatter need not wait for)
+    int bits = 1; while (bits < 24 && (1ll << bits) <= (long long)max_cb) ++bits;      // the barcode bits of the sort key
+    DevBuf &key_a = c->bt[BT_KEY_A], &key_b = c->bt[BT_KEY_B], &val_a = c->bt[BT_VAL_A], &val_b = c->bt[BT_VAL_B];
+    if (n_events >= (1ll << (52 - bits))) {
+        set_error("lsg_load_reads: %lld events with %d-bit barcode ids do not fit the packed sort key (events < 2^%d): load the reads in windows", (long long)n_events, bits, 52 - bits);
+        return -2;
+    }
+    if (key_a.reserve(N * 8 + 16) || key_b.reserve(N * 8 + 16) || val_a.reserve(N * 4 + 16) || val_b.reserve(N * 4 + 16) ||
+        c->bt[BT_CURSOR].reserve(((size_t)T + 2) * 4)) return -1;
+    // (the cursors in a buffer of their own: the plan's tile-level half may be at work in BT_PER_TILE beside the scatter)
+    a.cursor = c->bt[BT_CURSOR].as<uint32_t>(); a.key = key_a.as<uint64_t>(); a.rdv = val_a.as<uint32_t>(); a.cb_bits = bits;
+    LSG_HIP(hipMemcpyAsync(a.cursor, c->d_tile_off.p, ((size_t)T + 1) * 4, hipMemcpyDeviceToDevice, st));
+    LSG_HIP(hipMemsetAsync(c->d_scalars.p, 0, 8, st));
+    hipLaunchKernelGGL(k_bin, dim3(g_bin), dim3(BIN_THREADS), 0, st, a);
+    LSG_HIP(hipEventRecord(c->evb[1], st));
     // ---- beside the scatter, on the copy stream: what follows from the capacities alone
     if (c->tm[TM_BLK_TILE].reserve(((size_t)nblk + 2) * 4)) return -1;
-    bool lpt = false;
+    bool lpt = false, split_sort = false;
     const uint32_t* lpt_tiles = nullptr;
     {
         hipStream_t bs = c->copy_stream;
@@ -653,7 +676,15 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
         size_t tb_lpt = 0, tb_blk = 0;
         if (want_lpt) LSG_HIP(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tb_lpt, k_in, k_out, c->bt[BT_NETILE].as<uint32_t>(), t_out, (int)n_netile, 0, 21, bs));
         LSG_HIP(hipcub::DeviceScan::InclusiveScan(nullptr, tb_blk, bt_, bt_, hipcub::Max(), (int)nblk, bs));
-        if (c->bt[BT_COPY_TMP].reserve((tb_lpt > tb_blk ? tb_lpt : tb_blk) + 256)) return -1;
+        // (... and of the sort of the shallow tiles, which runs on this stream beside the deep tiles' sort: below)
+        size_t tb_sort2 = 0;
+        if (n_netile && !getenv("LSG_NO_SPLIT_SORT"))
+            LSG_HIP((lsg_segmented_sort<7, 256, 8>(nullptr, tb_sort2, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (unsigned)N, (unsigned)n_netile,
+                                                   (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (unsigned)bits, bs, false)));
+        split_sort = tb_sort2 != 0;
+        size_t tb_max = tb_lpt > tb_blk ? tb_lpt : tb_blk;
+        if (tb_sort2 > tb_max) tb_max = tb_sort2;
+        if (c->bt[BT_COPY_TMP].reserve(tb_max + 256)) return -1;
         void* scratch = c->bt[BT_COPY_TMP].p;
         if (want_lpt) {
             // The sort's segments deepest first: rocprim gives every segment beyond its block sort to ONE workgroup, and the deepest tiles
@@ -673,33 +704,33 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
         LSG_HIP(hipcub::DeviceScan::InclusiveScan(scratch, tb, bt_, bt_, hipcub::Max(), (int)nblk, bs));
         LSG_HIP(hipEventRecord(c->ev_blk, bs));
     }
-    // ---- 2. scatter
-    DevBuf &key_a = c->bt[BT_KEY_A], &key_b = c->bt[BT_KEY_B], &val_a = c->bt[BT_VAL_A], &val_b = c->bt[BT_VAL_B];
-    int bits = 1; while (bits < 24 && (1ll << bits) <= (long long)max_cb) ++bits;
-    if (n_events >= (1ll << (52 - bits))) {
-        set_error("lsg_load_reads: %lld events with %d-bit barcode ids do not fit the packed sort key (events < 2^%d): load the reads in windows", (long long)n_events, bits, 52 - bits);
-        return -2;
-    }
-    if (key_a.reserve(N * 8 + 16) || key_b.reserve(N * 8 + 16) || val_a.reserve(N * 4 + 16) || val_b.reserve(N * 4 + 16) ||
-        c->bt[BT_CURSOR].reserve(((size_t)T + 2) * 4)) return -1;
-    // (the cursors in a buffer of their own: the plan's tile-level half may be at work in BT_PER_TILE beside the scatter)
-    a.cursor = c->bt[BT_CURSOR].as<uint32_t>(); a.key = key_a.as<uint64_t>(); a.rdv = val_a.as<uint32_t>(); a.cb_bits = bits;
-    LSG_HIP(hipMemcpyAsync(a.cursor, c->d_tile_off.p, ((size_t)T + 1) * 4, hipMemcpyDeviceToDevice, st));
-    LSG_HIP(hipMemsetAsync(c->d_scalars.p, 0, 8, st));
-    hipLaunchKernelGGL(k_bin, dim3(g_bin), dim3(BIN_THREADS), 0, st, a);
-    LSG_HIP(hipEventRecord(c->evb[1], st));
     // ---- 3. every tile's entries by barcode
     if (n_netile) {
-        if (c->bt[BT_SEG_BEGIN].reserve(((size_t)n_netile + 1) * 4) || c->bt[BT_SEG_END].reserve(((size_t)n_netile + 1) * 4)) return -1;
+        // (begin / end of the deep tiles' sort, then - split_sort - of the shallow tiles' sort: four arrays of n_netile + 1 in the two buffers)
+        const size_t seg_pitch = ((size_t)n_netile + 64) & ~(size_t)63;
+        if (c->bt[BT_SEG_BEGIN].reserve(seg_pitch * 8) || c->bt[BT_SEG_END].reserve(seg_pitch * 8)) return -1;
+        uint32_t* sb1 = c->bt[BT_SEG_BEGIN].as<uint32_t>(); uint32_t* se1 = c->bt[BT_SEG_END].as<uint32_t>();
+        uint32_t* sb2 = split_sort ? sb1 + seg_pitch : nullptr; uint32_t* se2 = split_sort ? se1 + seg_pitch : nullptr;
         if (lpt) LSG_HIP(hipStreamWaitEvent(st, c->ev_lpt, 0));
-        hipLaunchKernelGGL(k_seg_bounds, dim3((n_netile + 255) / 256), dim3(256), 0, st, lpt ? lpt_tiles : c->bt[BT_NETILE].as<uint32_t>(), n_netile, c->d_tile_off.as<uint32_t>(),
-                           c->bt[BT_SEG_BEGIN].as<uint32_t>(), c->bt[BT_SEG_END].as<uint32_t>());
+        hipLaunchKernelGGL(k_seg_bounds, dim3((n_netile + 255) / 256), dim3(256), 0, st, lpt ? lpt_tiles : c->bt[BT_NETILE].as<uint32_t>(), n_netile, c->d_tile_off.as<uint32_t>(), sb1, se1, sb2, se2);
+        if (split_sort) {
+            // rocprim runs its three kernels (a block per segment beyond 256 entries: 2.7 ms at C2; the warp sorts of the segments up to 256 and up
+            // to 64: 0.55 ms) one after the other, and the first one's tail leaves most of the chip idle: the shallow tiles are sorted on the copy
+            // stream beside it (same output arrays, disjoint segments, scratch of its own)
+            hipStream_t bs = c->copy_stream;
+            LSG_HIP(hipEventRecord(c->ev_copy, st));
+            LSG_HIP(hipStreamWaitEvent(bs, c->ev_copy, 0));
+            size_t tb2 = c->bt[BT_COPY_TMP].cap;
+            LSG_HIP((lsg_segmented_sort<7, 256, 8>(c->bt[BT_COPY_TMP].p, tb2, key_a.as<uint64_t>(), key_b.as<uint64_t>(), val_a.as<uint32_t>(), val_b.as<uint32_t>(), (unsigned)N, (unsigned)n_netile,
+                                                   sb2, se2, 0u, (unsigned)bits, bs, false)));
+            LSG_HIP(hipEventRecord(c->ev_lpt, bs));            // (the event of the tiles' order: waited for above, free again)
+        }
         size_t tb = 0;
         // (64-bit keys sorted on their barcode bits only, begin_bit 0 .. end_bit `bits`: the rest of the key is payload)
         static const int cfg = getenv("LSG_SORT_CFG") ? atoi(getenv("LSG_SORT_CFG")) : 0;
         auto sort = [&](void* tmp_p, size_t& tmp_n) {
 #define LSG_SORT_CALL(RB, BS, IPT) lsg_segmented_sort<RB, BS, IPT>(tmp_p, tmp_n, key_a.as<uint64_t>(), key_b.as<uint64_t>(), val_a.as<uint32_t>(), val_b.as<uint32_t>(), (unsigned)N, (unsigned)n_netile, \
-                                                      c->bt[BT_SEG_BEGIN].as<uint32_t>(), c->bt[BT_SEG_END].as<uint32_t>(), 0u, (unsigned)bits, st, false)
+                                                      sb1, se1, 0u, (unsigned)bits, st, false)
             switch (cfg) {
                 case 1: return LSG_SORT_CALL(7, 256, 16);
                 case 2: return LSG_SORT_CALL(7, 512, 8);
@@ -717,6 +748,7 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
         if (tmp.reserve(tb + 256)) return -1;
         tb = tmp.cap;
         LSG_HIP(sort(tmp.p, tb));
+        if (split_sort) LSG_HIP(hipStreamWaitEvent(st, c->ev_lpt, 0));      // both halves of the order are there
     }
     LSG_HIP(hipEventRecord(c->evb[2], st));
     // ---- 4. blocks and the per-entry words (the blocks' offsets and their number came with the load's early look)
