@@ -4,9 +4,13 @@
   metric   genomic sites/s, pileup + call: pileup columns with >= 1 counted entry, summed over cell
            types, per second of one full ONE-SHOT pass over a BAM's worth of decoded reads, as a LongSom rule runs it
            (one count per BAM, BaseCellCounter.py:182-320):
-             lsg_load_reads on device-resident compact read-record arrays (the device half of ingest: builds the tile store)
-             -> lsg_pileup_count -> lsg_call_step1 (merge + step 1) [-> all-gather of PASS-candidate call rows when N > 1]
-           A step = one such pass on a FRESH load; the timed steps follow a warm-up load.
+             lsg_load_reads on device-resident compact read-record arrays (the device half of ingest: every (segment x 64-position
+             tile) entry binned per tile and sorted by barcode, and - lsg_set_count_at_load + lsg_set_store_policy - the BAM's one
+             count made in the same pass straight from the caller's events: a BAM that is counted once keeps no tile store)
+             -> lsg_pileup_count (hands that count over) -> lsg_call_step1 (merge + step 1) [-> all-gather of PASS-candidate call
+             rows when N > 1]
+           A step = one such pass on a FRESH load; the timed steps follow a warm-up load.  LSG_BENCH_KEEP_STORE=1: the load also writes
+           the tile store later counts would work on (k_tm_gather_count); LSG_BENCH_TWO_PASS=1: load and count apart (round 3's step).
   workload C2 (BASELINE.json configs[1]): whole-genome synthetic long-read workload, 10 M reads x 5 k
            barcodes, generated directly in HBM by the model of longsom_amd/csrc/synth_model.h
            (inputs are resident when the timed region starts: the arrays lsg_synth_generate left in HBM)
@@ -14,15 +18,16 @@
            estimated work; every rank loads the reads overlapping its region, counts only its own
            columns and the ranks all-gather their PASS-candidate call rows over RCCL.
 
-One JSON line on rank 0.  `roofline` is for the kernel that takes the most time of a step - k_tm_gather_count, the pass that lays the
-events out per column and counts them while it holds them (lsg_set_count_at_load) - priced by SURVEY 8(d)'s bytes alone: 2 B per
-admitted event + 24 B per admitted read + 168 B per row it emits (the store it also writes, sort scratch and re-reads are NOT
-algorithmic), over its HIP-event time on its own stream.  `roofline.path_frac` prices the WHOLE step the same way: (2 E + 24 R +
-168 S_emit) / ms_per_step / peak.  `roofline.step_traffic` is the fabric traffic of every kernel of a step from the newest profiles/
-file recorded for this build (sum and its ratio to the algorithmic bytes).  `config.recount_ms` is a count + call pass over the SAME
-resident store (what the second pass of the re-annotation loop pays).  `cpu_baseline` times the CPU oracle (oracle/, kind "port") on a bounded sample of the same workload on
-ALL of this box's host cores.  `roofline.traffic` is quoted from the newest profiles/ file only when that file was recorded for
-this build of the kernels (else null + traffic_stale).
+One JSON line on rank 0.  `roofline` is for the kernel that takes the most time of a step - k_tm_count_direct, the count made inside the
+load (one 2-byte load per entry and lane from the caller's events, counters in LDS) - priced by SURVEY 8(d)'s bytes alone: 2 B per
+admitted event + 24 B per admitted read + 168 B per row it emits (sort scratch and re-reads are NOT algorithmic), over its HIP-event
+time on its own stream.  `roofline.path_frac` prices the WHOLE step the same way: (2 E + 24 R + 168 S_emit) / ms_per_step / peak.
+`roofline.step_traffic` is the fabric traffic of every kernel of a step from the newest profiles/ file recorded for this build (sum and
+its ratio to the algorithmic bytes).  `config.recount_ms` is a count + call pass over a RESIDENT store (what the second pass of the
+re-annotation loop pays), measured after the clock on one extra load that keeps its store (`config.load_that_also_writes_the_store_ms`).
+`cpu_baseline` times the CPU oracle (oracle/, kind "port") on a bounded sample of the same workload on ALL of this box's host cores.
+`roofline.traffic` is quoted from the newest profiles/ file only when that file was recorded for this build of the kernels (else null +
+traffic_stale).
 """
 import argparse
 import json
@@ -500,7 +505,7 @@ def main():
                        "path_algorithmic_GBps_rank0": path_bytes / dt / 1e9,
                        "step_parts_ms_rank0": {"load_wall": round(layout_ms, 2), "build_capacities_scatter": round(float(bm[0]), 2), "build_sort": round(float(bm[1]), 2),
                                                "build_block_tables": round(float(bm[2]), 2),
-                                               ("build_plan_gather_count" if fused else "build_gather"): round(float(bm[3]), 2),
+                                               ("build_plan_count" if direct else "build_plan_gather_count" if fused else "build_gather"): round(float(bm[3]), 2),
                                                ("count_kernel_inside_the_load" if fused else "count_walk"): round(float(st.ms_walk), 2),
                                                "count_total": round(float(st.ms_total), 2)},
                        "one_pass_load_and_count": bool(fused), "store_kept_by_the_timed_loads": not direct,

@@ -1,5 +1,5 @@
-"""Per-rank time of ONE STEP of the sharded C2 job as bench.py --gpus N times it - the rank's load (its tile store, which also makes
-its count: lsg_set_count_at_load), the count's hand-over, merge + step-1 call, export of its PASS-candidate rows into the send buffer -
+"""Per-rank time of ONE STEP of the sharded C2 job as bench.py --gpus N times it - the rank's load (which makes its count in the same
+pass and keeps no store: lsg_set_count_at_load + lsg_set_store_policy), the count's hand-over, merge + step-1 call, export of its PASS-candidate rows into the send buffer -
 emulated on ONE GPU: one shard after another, no collective.  max over the ranks of a given N predicts bench.py --gpus N minus the
 all-gather (a few hundred rows over xGMI) and whatever eight processes sharing one host cost.  Writes gpurun_out/shard_perf.json.
 usage: python tools/shard_perf.py [n_reads] [worlds, e.g. 1,2,4,8]"""
@@ -20,6 +20,7 @@ eng.set_contigs(model.contig_len); eng.synth_reference(model.seed); eng.set_barc
 cp, kp = CountParams.longsom_defaults(), CallParams.longsom_defaults()
 eng.set_load_filter(cp.min_mq, cp.flag_exclude, cp.ignore_orphans)
 eng.set_count_at_load(cp)
+eng.set_store_policy(eng.STORE_SKIP_WHEN_COUNTED)      # (bench.py's step: the BAM is counted once, no store kept)
 buf = torch.zeros(64 << 20, dtype=torch.uint8, device="cuda")
 out = {"workload": "C2 at %d reads, one step = load (+ count in the same pass) + call + export per rank, ranks emulated one after another on one GPU" % n_reads, "worlds": {}}
 for world in worlds:
@@ -42,7 +43,7 @@ for world in worlds:
         ms = (time.perf_counter() - t0) / 5 * 1e3
         st = eng.count_stats(); bt = eng.build_times()
         per_rank.append({"rank": rank, "ms_per_step": round(ms, 3), "reads": int(reads.n_reads), "columns": int(cols), "merged_sites": int(ns), "pass_rows": int(npass),
-                         "load_kernels_ms": [round(float(x), 3) for x in bt], "count_kernel_ms": round(float(st.ms_walk), 3), "fused": eng.layout_info()[0] == 3})
+                         "load_kernels_ms": [round(float(x), 3) for x in bt], "count_kernel_ms": round(float(st.ms_walk), 3), "load_path": eng.layout_info()[0]})
         print(f"N={world} rank={rank}: {ms:.2f} ms  reads {reads.n_reads} cols {cols} sites {ns} cand {nc} pass {npass} | build {[round(float(x), 2) for x in bt]} count kernel {st.ms_walk:.2f}", flush=True)
     worst = max(r["ms_per_step"] for r in per_rank)
     out["worlds"][str(world)] = {"slowest_rank_ms": worst, "ranks": per_rank}
