@@ -225,6 +225,12 @@ int64_t lsg_max_live_reads(lsg_ctx* ctx);
  * genotyping pileup of the unsplit BAM can hold at once (HCCVSingleCellGenotype.py:122) — a lower bound on it, since reads without a
  * usable CB tag are dropped at decode and not resident. */
 int64_t lsg_max_live_reads_all(lsg_ctx* ctx);
+/* The same question per cell type at POSITION resolution: the largest number of reads a pileup buffer can hold when a read is pushed,
+ * counting that read (htslib refuses the push iff buffered + 1 > max_depth: a count with max_depth >= this value drops nothing).  The
+ * tile-level bounds above over-count where many reads start and end inside one 64-position tile; lsg_pileup_count and the loads ask for
+ * this one only when they cannot rule the cap out (a scan over the genome's positions per cell type: ~10 ms at C4).  Cached until the
+ * reads or the barcode table change; -1 on error. */
+int64_t lsg_max_live_reads_exact(lsg_ctx* ctx);
 /* Restrict counting to the genomic region [ (tid_lo,pos_lo), (tid_hi,pos_hi) ) in (tid,pos) order;
  * positions must be multiples of 64.  This is how windows are sharded over GPUs: every rank loads
  * the reads overlapping its region (reads crossing a boundary are loaded by both ranks) and each

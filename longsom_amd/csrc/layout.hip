@@ -100,6 +100,66 @@ static int live_read_bound_impl(lsg_ctx* c, bool by_ct, int64_t* out) {
     return fail(0);
 }
 
+// The same question at POSITION resolution, asked only when the tile-level bound cannot say no (deep samples: C4's tiles hold more than
+// 200 000 reads that its positions never do, and the host replay of the rule over 50 M reads takes seconds): per cell type, +1 at a read's
+// first column and -1 behind the column after its last one (where the buffer lets go of it), summed along every contig; the maximum
+// over positions and cell types is the largest number of reads any buffer can hold when a read is pushed, counting that read: a push is
+// refused iff (reads buffered) + 1 > max_depth, and (reads buffered) + 1 <= that maximum.  Pools ignore the read filters and the
+// pileup windows (both only shrink a pool).  One pass of atomics (the reads of a deep gene pile up on a few cache lines: merged per
+// workgroup would be the next step), a scan and a reduction over the genome's positions per cell type: ~10 ms at C4.
+__global__ void k_exact_marks(const uint32_t* seg_read, const int32_t* seg_start, const int32_t* seg_len, int64_t n_segs, const int32_t* read_tid, const int32_t* read_cb,
+                              const uint8_t* celltype_of, int32_t n_cb, int32_t ct, const int64_t* pos_base, const int64_t* contig_len, int32_t n_contigs, int32_t* diff) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_segs) return;
+    const uint32_t r = seg_read[s];
+    const int32_t tid = read_tid[r], cb = read_cb[r];
+    if (cb < 0 || cb >= n_cb || tid < 0 || tid >= n_contigs || celltype_of[cb] != ct) return;
+    const bool first = s == 0 || seg_read[s - 1] != r, last = s + 1 == n_segs || seg_read[s + 1] != r;
+    if (!first && !last) return;
+    const int64_t L = contig_len[tid], base = pos_base[tid];              // the contig's slots: positions 0 .. L + 1
+    int64_t st = seg_start[s], en = st + (seg_len[s] > 0 ? seg_len[s] : 0);
+    st = st < 0 ? 0 : (st > L ? L : st);
+    en = en < 0 ? 0 : (en > L ? L : en);
+    if (first) atomicAdd(diff + base + st, 1);
+    if (last) atomicAdd(diff + base + en + 1, -1);
+}
+
+int live_read_bound_exact(lsg_ctx* c) {
+    if (c->max_live_exact >= 0) return 0;
+    const int64_t S = c->rd.n_segs;
+    if (S <= 0 || c->n_ct <= 0 || c->n_cb <= 0) { c->max_live_exact = 0; return 0; }
+    hipStream_t st = c->stream;
+    std::vector<int64_t> base((size_t)c->n_contigs + 1, 0);
+    for (int t = 0; t < c->n_contigs; ++t) base[(size_t)t + 1] = base[(size_t)t] + c->contig_len[(size_t)t] + 2;
+    const int64_t P = base[(size_t)c->n_contigs];
+    if (P >= (1ll << 31)) {        // (the scan's 32-bit item count: a genome beyond 2^31 positions keeps the tile-level answer - the host replay decides)
+        c->max_live_exact = c->max_live_reads >= 0 ? c->max_live_reads : INT64_MAX / 2;
+        return 0;
+    }
+    DevBuf diff, run, tmp, mx, dbase;
+    auto fail = [&](int rc) { diff.release(); run.release(); tmp.release(); mx.release(); dbase.release(); return rc; };
+    if (diff.reserve((size_t)P * 4 + 64) || run.reserve((size_t)P * 4 + 64) || mx.reserve(64) || dbase.reserve(base.size() * 8)) return fail(-1);
+    size_t tb = 0, tb2 = 0;
+    if (hipcub::DeviceScan::InclusiveSum(nullptr, tb, diff.as<int32_t>(), run.as<int32_t>(), (int)P, st) != hipSuccess ||
+        hipcub::DeviceReduce::Max(nullptr, tb2, run.as<int32_t>(), mx.as<int32_t>(), (int)P, st) != hipSuccess ||
+        tmp.reserve((tb > tb2 ? tb : tb2) + 256)) return fail(-1);
+    if (hipMemcpyAsync(dbase.p, base.data(), base.size() * 8, hipMemcpyHostToDevice, st) != hipSuccess) return fail(-1);
+    int64_t best = 0;
+    for (int ct = 0; ct < c->n_ct; ++ct) {
+        if (hipMemsetAsync(diff.p, 0, (size_t)P * 4, st) != hipSuccess) { set_error("exact live bound: memset failed"); return fail(-1); }
+        hipLaunchKernelGGL(k_exact_marks, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, st, c->rd.seg_read, c->rd.seg_start, c->rd.seg_len, S, c->rd.read_tid, c->rd.read_cb,
+                           c->d_celltype_of.as<uint8_t>(), c->n_cb, ct, dbase.as<int64_t>(), c->d_contig_len.as<int64_t>(), c->n_contigs, diff.as<int32_t>());
+        tb = tb2 = tmp.cap;
+        if (hipcub::DeviceScan::InclusiveSum(tmp.p, tb, diff.as<int32_t>(), run.as<int32_t>(), (int)P, st) != hipSuccess ||
+            hipcub::DeviceReduce::Max(tmp.p, tb2, run.as<int32_t>(), mx.as<int32_t>(), (int)P, st) != hipSuccess) { set_error("exact live bound: scan failed"); return fail(-1); }
+        int32_t m = 0;
+        if (hipMemcpyAsync(&m, mx.p, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { set_error("exact live bound: %s", hipGetErrorString(hipGetLastError())); return fail(-1); }
+        if (m > best) best = m;
+    }
+    c->max_live_exact = best;
+    return fail(0);
+}
+
 // first reference position after a read's last pileup column (its last segment's end; pos + 1 without segments)
 __global__ void k_read_end(const uint32_t* seg_read, const int32_t* seg_start, const int32_t* seg_len, int64_t n_segs, int32_t* read_end) {
     const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -131,6 +191,8 @@ int depth_cap_drops(lsg_ctx* c, const lsg_count_params* p) {
     if (c->max_live_all + 1 <= (int64_t)p->max_depth) return 0;           // not even all reads together fill a buffer: nothing is ever dropped
     if (live_read_bound(c)) return -1;
     if (c->max_live_reads + 1 <= (int64_t)p->max_depth) return 0;          // no cell type's buffer can exceed the cap
+    if (live_read_bound_exact(c)) return -1;
+    if (c->max_live_exact <= (int64_t)p->max_depth) return 0;              // ... not at any POSITION (the tiles over-count): a push is refused iff buffered + 1 > max_depth
     hipStream_t st = c->stream;
     const int64_t R = c->rd.n_reads, S = c->rd.n_segs, W = c->st_window;
     DevBuf d_end;

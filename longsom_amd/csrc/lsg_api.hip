@@ -199,7 +199,7 @@ int lsg_set_barcodes(lsg_ctx* c, const uint8_t* celltype_of, int32_t n_cb, int32
     }
     LSG_HIP(hipStreamSynchronize(c->stream));
     c->n_cb = n_cb; c->n_ct = n_celltypes;
-    c->max_live_reads = -1;
+    c->max_live_reads = -1; c->max_live_exact = -1;
     c->counted = c->called = false;
     return 0;
 }
@@ -341,6 +341,13 @@ int64_t lsg_max_live_reads(lsg_ctx* c) {
     if (hipSetDevice(c->device) != hipSuccess) { set_error("lsg_max_live_reads: hipSetDevice failed"); return -1; }
     if (lsg::live_read_bound(c)) return -1;
     return c->max_live_reads;
+}
+
+int64_t lsg_max_live_reads_exact(lsg_ctx* c) {
+    if (!c) { set_error("lsg_max_live_reads_exact: bad arguments"); return -1; }
+    if (hipSetDevice(c->device) != hipSuccess) { set_error("lsg_max_live_reads_exact: hipSetDevice failed"); return -1; }
+    if (lsg::live_read_bound_exact(c)) return -1;
+    return c->max_live_exact;
 }
 
 int64_t lsg_max_live_reads_all(lsg_ctx* c) {

@@ -96,6 +96,7 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
 int ensure_plan(lsg_ctx* c);       // store.hip: jobs / units / slabs of a count over the store for the current number of cell types
 void drop_store(lsg_ctx* c);       // store.hip: new reads or contigs
 int live_read_bound(lsg_ctx* c);   // layout.hip: fills max_live_reads when it is stale (-1)
+int live_read_bound_exact(lsg_ctx* c);   // layout.hip: fills max_live_exact (per cell type, per position: the largest buffer a push can meet, counting the pushed read)
 int live_read_bound_all(lsg_ctx* c);
 __global__ void k_read_end(const uint32_t* seg_read, const int32_t* seg_start, const int32_t* seg_len, int64_t n_segs, int32_t* read_end);      // layout.hip
 __global__ void k_read_end_init(const int32_t* read_pos, int64_t n_reads, int32_t* read_end);
@@ -163,6 +164,7 @@ struct lsg_ctx {
     float build_ms[4] = {0, 0, 0, 0};     // HIP-event times of the last build: capacities + scatter, sort, fill, gather
     int64_t max_live_reads = -1;          // layout.hip: bound on the reads live at once in the reference's pileup buffer (-1 = stale)
     int64_t max_live_all = -1;            // the same over all reads with a barcode: table-independent, cached per load
+    int64_t max_live_exact = -1;          // per cell type at position resolution (asked only when the tile-level bounds cannot rule the cap out)
     lsg::DevBuf d_read_drop;              // layout.hip: per read, the pileup's max_depth rule under the last count's parameters: 1 = dropped in every window it overlaps, 2 = in some (d_drop_pairs)
     lsg::DevBuf d_drop_pairs; int64_t n_drop_pairs = 0;      // sorted (read << 32 | window of its contig) of the reads dropped in some windows only
     lsg::DevBuf d_read_adm;               // pileup.hip: a bit per read, admitted under the current count's read filters (made only when some stored read can fail them)

@@ -502,7 +502,7 @@ enum { BT_KEY_A = 0, BT_KEY_B, BT_VAL_A, BT_VAL_B, BT_PEX, BT_NETILE, BT_SEG_BEG
 void drop_store(lsg_ctx* c) {
     c->tm_valid = false; c->plan_n_ct = 0; c->plan1_n_ct = 0; c->tm_n = 0; c->tm_events = 0; c->tm_np = 0; c->tm_nblk = 0; c->tm_njobs = 0; c->tm_nchunks = 0;
     c->tm_n_ne = 0; c->tm_n_multi = 0; c->tm_n_slabs = 0; c->tm_n_wide = 0;
-    c->max_live_reads = -1; c->max_live_all = -1; c->has_drops = false;
+    c->max_live_reads = -1; c->max_live_all = -1; c->max_live_exact = -1; c->has_drops = false;
     c->counted = c->called = false; c->counted_at_load = false; c->load_was_fused = false; c->store_skipped = false;
 }
 
@@ -780,7 +780,13 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
     if (fused) {
         const lsg_count_params& q = c->cal_params;
         if (q.min_mq < c->st_min_mq || (c->st_flag_exclude & ~q.flag_exclude) != 0 || (c->st_ignore_orphans && !q.ignore_orphans)) fused = false;       // (the count would be refused)
-        if (q.max_depth > 0 && c->max_live_all + 1 > (int64_t)q.max_depth) fused = false;                                                                 // (the depth cap may drop reads: decided per count)
+        if (fused && q.max_depth > 0 && c->max_live_all + 1 > (int64_t)q.max_depth) {
+            // the tiles say the depth cap might fire: the per-position bound of this table's cell types decides (layout.hip: ~10 ms at C4,
+            // whose tiles hold more than 200 000 reads that no position does); when it can, the count is left to lsg_pileup_count
+            LSG_HIP(hipStreamSynchronize(c->copy_stream));        // (the handle's copies of the read arrays, which the bound reads, are made there)
+            if (live_read_bound_exact(c)) return -1;
+            if (c->max_live_exact > (int64_t)q.max_depth) fused = false;
+        }
         for (int t = 0; t < c->n_contigs && fused; ++t) if (!c->ref_ptr[t]) fused = false;
     }
     const bool dbg = getenv("LSG_DEBUG_SYNC") != nullptr;

@@ -357,6 +357,13 @@ class Engine:
         _lib.check(-1 if v < 0 else 0, "lsg_max_live_reads_all")
         return v
 
+    def max_live_reads_exact(self) -> int:
+        """per cell type, per POSITION: the largest buffer a pushed read can meet, itself included - a count with max_depth >= this
+        drops nothing (lsg_max_live_reads_exact)"""
+        v = int(self._lib.lsg_max_live_reads_exact(self._h))
+        _lib.check(-1 if v < 0 else 0, "lsg_max_live_reads_exact")
+        return v
+
     def call_step1(self, params: Optional[CallParams] = None):
         params = params or CallParams.longsom_defaults()
         n_sites = C.c_int64(0); n_cand = C.c_int64(0)

@@ -97,6 +97,28 @@ def test_count_with_a_depth_cap_equals_the_bam_level_oracle(engine, deep_sample,
         assert dp <= dp_uncapped
 
 
+def test_the_position_level_bound_is_where_the_cap_stops_biting(engine, deep_sample):
+    """lsg_max_live_reads_exact = B: with max_depth >= B nothing is dropped (the host replay is skipped), and the BAM-level oracle agrees
+    on both sides of B - below it the replay runs and drops what htslib drops"""
+    from longsom_amd import tsvio
+    from longsom_amd._lib import CountParams
+    from oracle import loader
+    m, bam, fa, bct = deep_sample
+    res = pipeline.load_sample(bam, bct, fa, engine, 60)
+    names, seqs = tsvio.read_fasta(fa)
+    B = engine.max_live_reads_exact()
+    assert 8 < B <= engine.max_live_reads() <= engine.max_live_reads_all()      # the tiles over-count
+    uncapped, _ = engine.pileup_count(CountParams.longsom_defaults(max_depth=0))
+    for max_depth in (B + 1, B, B - 1, B - 2, B // 2):
+        rows, _ = engine.pileup_count(CountParams.longsom_defaults(max_depth=max_depth))
+        if max_depth >= B:
+            assert rows == uncapped
+        for ct in range(2):
+            k, r, c = engine.fetch_counts(ct)
+            ok, orf, oc = loader.plp_count(bam, res.table.barcodes, res.table.celltype_of, ct, [len(s) for s in seqs], seqs, max_depth=max_depth)
+            assert np.array_equal(k, ok) and np.array_equal(r, orf) and np.array_equal(c, oc), "cell type %d, max_depth %d (B = %d)" % (ct, max_depth, B)
+
+
 @pytest.mark.parametrize("window,max_depth", [(150, 37), (64, 5), (1000, 150)])
 def test_the_cap_is_replayed_per_pileup_window(engine, deep_sample, window, max_depth):
     """every window [1 + k W, 1 + (k + 1) W) is a pileup of its own (BaseCellCounter.py:185-191): narrow windows put an edge into most tiles

@@ -18,6 +18,23 @@ print("generated and loaded in %.2f s: %d reads %d segments %d events (%.1f GB o
 print("load: %.1f ms wall in lsg_load_reads (first load of the process: allocates the store); build kernels (capacities + scatter, sort, entry words, gather) %s ms; "
       "store %s (entries, blocks, events); resident %.1f GB; free %.0f GB" %
       (eng.layout_info()[1], [round(x, 2) for x in eng.build_times()], eng.store_shape(), eng.layout_info()[2] / 1e9, torch.cuda.mem_get_info()[0] / 1e9), flush=True)
+# the first count + call of the process pays what bench.py's warm-up pays: row and call buffers, the tail table of the parameter set
+t0 = time.perf_counter(); rows, cols = eng.pileup_count(); ns, nc = eng.call_step1(); torch.cuda.synchronize()
+print("first count + call of the process (allocations, k_tail_table): %.1f ms" % ((time.perf_counter() - t0) * 1e3), flush=True)
+# ONE-SHOT steps, warm (every buffer is there), as bench.py times C2: (a) the load builds the store, the count walks it; (b) the load makes the
+# count in its own pass and keeps no store (C4's tiles hold more than max_depth = 200 000 reads, but no position does: lsg_max_live_reads_exact)
+from longsom_amd._lib import CallParams
+kp = CallParams.longsom_defaults()
+for how in ("store + count", "count at load, no store", "store + count"):
+    if how.startswith("count"):
+        eng.set_count_at_load(cp); eng.set_store_policy(eng.STORE_SKIP_WHEN_COUNTED)
+    t0 = time.perf_counter(); eng.synth_reads(model); torch.cuda.synchronize(); dt2 = time.perf_counter() - t0
+    eng.set_count_at_load(None); eng.set_store_policy(eng.STORE_KEEP)
+    load_ms = eng.layout_info()[1]
+    t0 = time.perf_counter(); rows, cols = eng.pileup_count(cp); ns, nc = eng.call_step1(kp); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print("one-shot C4 step, warm (%s; load path %d): lsg_load_reads %.1f ms (build phases %s) + count hand-over / count and call %.1f ms = %.1f ms; %.2e sites/s  [generate + load %.2f s wall]"
+          % (how, eng.layout_info()[0], load_ms, [round(x, 2) for x in eng.build_times()], dt * 1e3, load_ms + dt * 1e3, cols / ((load_ms + dt * 1e3) / 1e3), dt2), flush=True)
+print("max live reads: tiles, all reads %d; tiles, per cell type %d; positions, per cell type %d" % (eng.max_live_reads_all(), eng.max_live_reads(), eng.max_live_reads_exact()), flush=True)
 for i in range(3):
     t0 = time.perf_counter(); rows, cols = eng.pileup_count(); ns, nc = eng.call_step1(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
     s = eng.count_stats()
