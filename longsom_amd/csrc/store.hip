@@ -513,7 +513,10 @@ static void settle_temporaries(lsg_ctx* c) {
     for (auto& b : c->bt) held += b.cap;
     held += c->ws[WS_SEG_INFO].cap;
     if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) return;
-    if (held > mem_total / 8 || mem_free < mem_total / 8) { for (auto& b : c->bt) b.release(); c->ws[WS_SEG_INFO].release(); c->plan1_n_ct = 0; }      // (the plan's tile-level half lived there: the first count makes it again)
+    // (a load that kept no store holds little else: its temporaries stay while a quarter of the device is free - giving 46 GB back and
+    // asking for them again cost C4's next load 3.8 s)
+    const bool tight = c->store_skipped ? mem_free < mem_total / 4 : (held > mem_total / 8 || mem_free < mem_total / 8);
+    if (tight) { for (auto& b : c->bt) b.release(); c->ws[WS_SEG_INFO].release(); c->plan1_n_ct = 0; }      // (the plan's tile-level half lived there: the first count makes it again)
 }
 
 static int plan_tiles(lsg_ctx* c, hipStream_t st);
@@ -783,9 +786,12 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
         if (fused && q.max_depth > 0 && c->max_live_all + 1 > (int64_t)q.max_depth) {
             // the tiles say the depth cap might fire: the per-position bound of this table's cell types decides (layout.hip: ~10 ms at C4,
             // whose tiles hold more than 200 000 reads that no position does); when it can, the count is left to lsg_pileup_count
-            LSG_HIP(hipStreamSynchronize(c->copy_stream));        // (the handle's copies of the read arrays, which the bound reads, are made there)
-            if (live_read_bound_exact(c)) return -1;
-            if (c->max_live_exact > (int64_t)q.max_depth) fused = false;
+            LSG_HIP(hipStreamSynchronize(c->copy_stream));        // (the handle's copies of the read arrays, which the bounds read, are made there)
+            if (live_read_bound(c)) return -1;                      // first the tiles again, per cell type of this table (C4: 135 343 against 225 294 over all reads)
+            if (c->max_live_reads + 1 > (int64_t)q.max_depth) {
+                if (live_read_bound_exact(c)) return -1;
+                if (c->max_live_exact > (int64_t)q.max_depth) fused = false;
+            }
         }
         for (int t = 0; t < c->n_contigs && fused; ++t) if (!c->ref_ptr[t]) fused = false;
     }

@@ -12,34 +12,42 @@ eng.set_contigs(model.contig_len); eng.synth_reference(model.seed); eng.set_barc
 from longsom_amd._lib import CountParams
 cp = CountParams.longsom_defaults()
 eng.set_load_filter(cp.min_mq, cp.flag_exclude, cp.ignore_orphans)          # as the product's decode and bench.py do
+if len(sys.argv) > 2 and sys.argv[2] == "direct":
+    # ONE-SHOT steps as bench.py times C2: the load makes the BAM's one count in its own pass and keeps no store (C4's 64-position tiles hold
+    # more than max_depth = 200 000 reads, but no position does: lsg_max_live_reads_exact lets the load count).  Step 0 allocates and makes the
+    # tail table of the parameter set (what bench.py's warm-up pays); the later ones are the figure.
+    from longsom_amd._lib import CallParams
+    kp = CallParams.longsom_defaults()
+    eng.set_region()
+    eng.set_count_at_load(cp); eng.set_store_policy(eng.STORE_SKIP_WHEN_COUNTED)
+    for i in range(3):
+        t0 = time.perf_counter(); eng.synth_reads(model); torch.cuda.synchronize(); dt2 = time.perf_counter() - t0
+        load_ms = eng.layout_info()[1]
+        t0 = time.perf_counter(); rows, cols = eng.pileup_count(cp); ns, nc = eng.call_step1(kp); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        st = eng.count_stats()
+        print("one-shot C4 step %d (load path %d): lsg_load_reads %.1f ms (build phases %s, count kernel %.1f) + count hand-over and call %.1f ms = %.1f ms; %.3e sites/s; rows %s cols %d sites %d cand %d  [generate + load %.2f s wall]"
+              % (i, eng.layout_info()[0], load_ms, [round(x, 2) for x in eng.build_times()], st.ms_walk, dt * 1e3, load_ms + dt * 1e3, cols / ((load_ms + dt * 1e3) / 1e3), rows, cols, ns, nc, dt2), flush=True)
+    print("max live reads: tiles, all reads %d; tiles, per cell type %d; positions, per cell type %d; resident %.1f GB" % (eng.max_live_reads_all(), eng.max_live_reads(), eng.max_live_reads_exact(), eng.layout_info()[2] / 1e9), flush=True)
+    sys.exit(0)
 t0 = time.perf_counter(); eng.synth_reads(model); torch.cuda.synchronize(); dt = time.perf_counter() - t0      # generate + load + give the generated arrays back
 n_reads, n_segs, n_events = eng.reads_shape()
 print("generated and loaded in %.2f s: %d reads %d segments %d events (%.1f GB of compact events, not kept)" % (dt, n_reads, n_segs, n_events, n_events * 2 / 1e9), flush=True)
 print("load: %.1f ms wall in lsg_load_reads (first load of the process: allocates the store); build kernels (capacities + scatter, sort, entry words, gather) %s ms; "
       "store %s (entries, blocks, events); resident %.1f GB; free %.0f GB" %
       (eng.layout_info()[1], [round(x, 2) for x in eng.build_times()], eng.store_shape(), eng.layout_info()[2] / 1e9, torch.cuda.mem_get_info()[0] / 1e9), flush=True)
+# the same load again, warm (every buffer of the store and of the build is there): what one more C4 BAM costs this process
+t0 = time.perf_counter(); eng.synth_reads(model); torch.cuda.synchronize(); dt2 = time.perf_counter() - t0
+load_warm_ms = eng.layout_info()[1]
+print("second load (warm): generate + load %.2f s; lsg_load_reads %.1f ms wall, build kernels %s ms" % (dt2, load_warm_ms, [round(x, 2) for x in eng.build_times()]), flush=True)
 # the first count + call of the process pays what bench.py's warm-up pays: row and call buffers, the tail table of the parameter set
 t0 = time.perf_counter(); rows, cols = eng.pileup_count(); ns, nc = eng.call_step1(); torch.cuda.synchronize()
-print("first count + call of the process (allocations, k_tail_table): %.1f ms" % ((time.perf_counter() - t0) * 1e3), flush=True)
-# ONE-SHOT steps, warm (every buffer is there), as bench.py times C2: (a) the load builds the store, the count walks it; (b) the load makes the
-# count in its own pass and keeps no store (C4's tiles hold more than max_depth = 200 000 reads, but no position does: lsg_max_live_reads_exact)
-from longsom_amd._lib import CallParams
-kp = CallParams.longsom_defaults()
-for how in ("store + count", "count at load, no store", "store + count"):
-    if how.startswith("count"):
-        eng.set_count_at_load(cp); eng.set_store_policy(eng.STORE_SKIP_WHEN_COUNTED)
-    t0 = time.perf_counter(); eng.synth_reads(model); torch.cuda.synchronize(); dt2 = time.perf_counter() - t0
-    eng.set_count_at_load(None); eng.set_store_policy(eng.STORE_KEEP)
-    load_ms = eng.layout_info()[1]
-    t0 = time.perf_counter(); rows, cols = eng.pileup_count(cp); ns, nc = eng.call_step1(kp); torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    print("one-shot C4 step, warm (%s; load path %d): lsg_load_reads %.1f ms (build phases %s) + count hand-over / count and call %.1f ms = %.1f ms; %.2e sites/s  [generate + load %.2f s wall]"
-          % (how, eng.layout_info()[0], load_ms, [round(x, 2) for x in eng.build_times()], dt * 1e3, load_ms + dt * 1e3, cols / ((load_ms + dt * 1e3) / 1e3), dt2), flush=True)
-print("max live reads: tiles, all reads %d; tiles, per cell type %d; positions, per cell type %d" % (eng.max_live_reads_all(), eng.max_live_reads(), eng.max_live_reads_exact()), flush=True)
+print("first count + call of the process (allocations, k_tail_table: what a warm-up pays): %.1f ms" % ((time.perf_counter() - t0) * 1e3), flush=True)
 for i in range(3):
     t0 = time.perf_counter(); rows, cols = eng.pileup_count(); ns, nc = eng.call_step1(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
     s = eng.count_stats()
     print("pass %d (count + call over the resident store): %.1f ms  rows %s cols %d sites %d cand %d | events %d entries %d units %d multi-job %d | resolve %.1f walk %.1f count %.1f ms | resident %.1f GB" %
           (i, dt * 1e3, rows, cols, ns, nc, s.n_events_admitted, s.n_entries, s.n_units, s.n_deep_units, s.ms_bin, s.ms_walk, s.ms_total, eng.layout_info()[2] / 1e9), flush=True)
+print("one-shot C4 step through the store, warm = lsg_load_reads %.1f ms + count and call %.1f ms = %.1f ms (parts timed apart: a third load does not fit beside the rows; `tools/c4_run.py 5e7 direct` times the one-shot steps that keep no store)" % (load_warm_ms, dt * 1e3, load_warm_ms + dt * 1e3), flush=True)
 full = (rows, cols, ns)
 # property: counting two halves of the genome separately gives the same totals
 tid_mid = len(model.contig_len) // 2
