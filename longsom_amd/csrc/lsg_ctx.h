@@ -188,7 +188,7 @@ struct lsg_ctx {
     lsg::DevBuf d_calls, d_site_off, d_tail_table;      // d_tail_table: call.hip, memo of the small-n beta-binomial tails
     double tail_table_key[4] = {0, 0, 0, 0}; bool tail_table_valid = false;
     int64_t n_sites = 0, n_cand = 0, n_pass = -1;      // n_pass: PASS candidates listed by k_call_finish (-1: no list)
-    lsg::DevBuf d_pass_list, d_defer_list;
+    lsg::DevBuf d_pass_list, d_defer_list, d_xcd_queues;
     bool called = false;
 
     lsg::PosSet posset[3];

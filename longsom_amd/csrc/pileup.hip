@@ -720,6 +720,7 @@ struct TgArgs {
     const uint32_t* tile_off; const uint32_t* blk_off;
     uint32_t* s0; uint8_t* b8; uint32_t* rd; uint4* store; uint16_t* ext;
     const uint32_t* nchunks;                                          // the plan's number of chunks, still on the device
+    unsigned long long* queues;                                       // k_tm_count_direct: the XCDs' job queues, 128 bytes apart (zeroed before the launch)
     int dbg;                                                          // timing experiments (LSG_TG_DEBUG; results are wrong): 1 no counting, 2 no block stores, 4 no event loads, 8 no LDS crossing
     unsigned long long* stat_slots;
 };
@@ -1148,7 +1149,7 @@ __global__ __launch_bounds__(TMW_WAVES * 64) __attribute__((amdgpu_waves_per_eu(
     __shared__ __attribute__((aligned(8192))) uint32_t planes[2][2][8 * 64];
     __shared__ uint32_t nc_sh[2][64];
     __shared__ WaveBook books[TMW_WAVES];
-    __shared__ uint32_t s_ck;
+    __shared__ uint32_t s_q[4];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     uint32_t* pl = &planes[0][0][0];
     WaveBook& book = books[wv];
@@ -1157,35 +1158,59 @@ __global__ __launch_bounds__(TMW_WAVES * 64) __attribute__((amdgpu_waves_per_eu(
     const uint32_t thr = bq_threshold(a), pkl0 = lds_addr(pl + lane);
     uint32_t one = 1u;
     asm volatile("" : "+v"(one));
-    const uint32_t nchunks = rl(*tg.nchunks, 0);
     TgStat stat; stat.ev = 0; stat.sg = 0; stat.ne = 0;
-    for (bool first = true;; first = false) {
-        __syncthreads();
-        if (threadIdx.x == 0) s_ck = first ? blockIdx.x : (uint32_t)atomicAdd(&a.scalars[SC_QWALK], 1ull) + gridDim.x;
-        __syncthreads();
-        const uint32_t ck = rl(s_ck, 0);
-        if (ck >= nchunks) break;
-        const uint32_t jx_end = rl(tm.chunk_start[ck + 1], 0), jx0 = rl(tm.chunk_start[ck], 0);
-        if (jx0 >= jx_end) continue;
-        // (the job records and the first keys of the next job travel while this job is counted: as in k_tm_gather_count)
+    // WHO takes WHICH job.  The jobs lie in tile order, and a segment's entries in two adjacent tiles are adjacent in the caller's array: the
+    // 128-byte line that holds the end of the one holds the start of the other, and the fabric moves 1.77 lines per entry (44.9 GB a launch
+    // for 19.9 GB of events and keys) where 0.8 would do if every line were fetched once.  The jobs are dealt in blocks of 64 consecutive
+    // ones to the eight XCDs, and the workgroups of an XCD take the jobs of its blocks ONE BY ONE off the XCD's queue, so that at any moment
+    // an XCD works on a few hundred consecutive tiles, started a fraction of a microsecond apart, whose shared lines could meet in its L2.
+    // Measured: they mostly do not (42.1 GB; 12 % of the L2's read requests hit) - a job lasts ~50 us, the two tiles' runs through the
+    // same barcodes drift apart by more than the ~6 us a line stays in 4 MB of L2 - but the finer hand-out balances the tail better than
+    // chunks did (8.4 -> 8.2 ms with twelve workgroups per CU), so it stays.  A workgroup whose XCD has run dry helps the next one.  The id
+    // of the job after next is asked for (one atomic of thread 0) while this job is counted; the next job's record and first keys travel
+    // as before.
+    const uint32_t njobs = tm.njobs, nblocks = (njobs + 63u) >> 6;
+    const uint32_t xcd = blockIdx.x & 7u;      // (workgroups are dealt to the XCDs round-robin)
+    constexpr uint32_t NO_JOB = 0xffffffffu;
+    uint32_t steal = 0;                                                                   // (thread 0's: queues it has found empty)
+    auto job_of = [&](uint32_t q, uint32_t n) -> uint32_t {                               // n-th job of XCD q's blocks, or NO_JOB past them
+        const uint32_t blk = 8u * (n >> 6) + q;
+        const uint32_t jx = (blk << 6) + (n & 63u);
+        return blk < nblocks && jx < njobs ? jx : NO_JOB;
+    };
+    auto take = [&]() -> uint32_t {                                                       // (thread 0)
+        while (steal < 8u) {
+            const uint32_t q = (xcd + steal) & 7u;
+            const uint32_t n = (uint32_t)atomicAdd(tg.queues + q * 16u, 1ull);
+            const uint32_t jx = job_of(q, n);
+            if (jx != NO_JOB) return jx;
+            if (8u * (n >> 6) + q >= nblocks) ++steal;                                    // (past the queue's last block; a short last block: ask again)
+        }
+        return NO_JOB;
+    };
+    if (threadIdx.x == 0) { s_q[0] = take(); s_q[1] = take(); }
+    __syncthreads();
+    uint32_t cur = rl(s_q[0], 0), nxt = rl(s_q[1], 0);
+    if (cur != NO_JOB) {
         uint32_t jw = 0;
-        if (lane < TM_JOB_WORDS) jw = reinterpret_cast<const uint32_t*>(tm.jobs + jx0)[lane];
+        if (lane < TM_JOB_WORDS) jw = reinterpret_cast<const uint32_t*>(tm.jobs + cur)[lane];
         uint32_t e0 = rl(jw, 0), e1 = rl(jw, 1), w0 = rl(jw, 2), slab = rl(jw, 3), nj = rl(jw, 4), tcnt = rl(jw, 5), tile = rl(jw, 6), emid = rl(jw, 7), base = rl(jw, 8), off = rl(jw, 9);
         int32_t tstart = (int32_t)rl(jw, 10); int tid = (int)rl(jw, 11);
-        // (the first group's keys of the wave's range, and - 64 to a group - the entry before it)
+        // (the first group's keys of the wave's range, and the entry before it)
         auto first_i = [&]() -> uint32_t { return (wv ? emid : e0) - base; };
         TdKeys64 K64{}; uint64_t kb = 0;
         auto prefetch = [&]() { const uint32_t i = first_i(); K64 = td_load_keys64(tg, i, off, tcnt, lane); kb = __builtin_nontemporal_load(tg.key + off + (i ? i - 1u : 0u)); };
         prefetch();
-        for (uint32_t jx = jx0; jx < jx_end; ++jx) {
-            {
-                const uint32_t jn = jx + 1 < jx_end ? jx + 1 : jx;
-                jw = reinterpret_cast<const uint32_t*>(tm.jobs + jn)[lane < TM_JOB_WORDS ? lane : 0];
-            }
+        while (true) {
+            jw = reinterpret_cast<const uint32_t*>(tm.jobs + (nxt != NO_JOB ? nxt : cur))[lane < TM_JOB_WORDS ? lane : 0];      // (every lane loads: nothing here waits)
             const bool counting = tile >= a.tile_lo && tile < a.tile_hi && !(nj & TMJ_WIDE);      // (the wide jobs: k_tm_walk_wide_direct)
             int refb = 'N';
             if (nj == 1 && counting) { const int64_t pos = (int64_t)tstart + lane; if (pos >= 1 && pos < a.contig_len[tid]) refb = a.ref_ptr[tid][pos]; }
             __syncthreads();                                   // both waves are done with the job before
+            // the job after next: the fast way is ONE atomic whose answer is looked at after this job's entries (a queue that has run dry is rare)
+            uint32_t q_n = 0;
+            const uint32_t q_q = (xcd + steal) & 7u;
+            if (threadIdx.x == 0 && steal < 8u) q_n = (uint32_t)atomicAdd(tg.queues + q_q * 16u, 1ull);
             if (counting) {
 #pragma unroll
                 for (int i = 0; i < 2 * 2 * 8 * 64 / (4 * TMW_WAVES * 64); ++i) reinterpret_cast<uint4*>(pl)[i * (TMW_WAVES * 64) + threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);
@@ -1202,11 +1227,20 @@ __global__ __launch_bounds__(TMW_WAVES * 64) __attribute__((amdgpu_waves_per_eu(
                 if (st.nc & 0xffffu) atomicAdd(&nc_sh[0][lane], st.nc & 0xffffu);
                 if (st.nc >> 16) atomicAdd(&nc_sh[1][lane], st.nc >> 16);
             }
+            if (threadIdx.x == 0) {
+                uint32_t jn2 = NO_JOB;
+                if (steal < 8u) {
+                    jn2 = job_of(q_q, q_n);
+                    if (jn2 == NO_JOB) { if (8u * (q_n >> 6) + q_q >= nblocks) ++steal; jn2 = take(); }
+                }
+                s_q[2] = jn2;
+            }
             const uint32_t c_w0 = w0, c_slab = slab, c_nj = nj, c_tcnt = tcnt; const int32_t c_tstart = tstart; const int c_tid = tid;
             e0 = rl(jw, 0); e1 = rl(jw, 1); w0 = rl(jw, 2); slab = rl(jw, 3); nj = rl(jw, 4); tcnt = rl(jw, 5); tile = rl(jw, 6); emid = rl(jw, 7); base = rl(jw, 8); off = rl(jw, 9);
             tstart = (int32_t)rl(jw, 10); tid = (int)rl(jw, 11);
             prefetch();
             __syncthreads();
+            const uint32_t nn = rl(s_q[2], 0);
             const int ct = tm.ct_base + wv;
             if (counting && ct < a.n_ct) {                   // the tile's units of this pass: wave = cell type (as in k_tm_walk)
                 const uint32_t* pc = pl + wv * 1024;
@@ -1228,6 +1262,8 @@ __global__ __launch_bounds__(TMW_WAVES * 64) __attribute__((amdgpu_waves_per_eu(
                     }
                 }
             }
+            if (nxt == NO_JOB) break;
+            cur = nxt; nxt = nn;
         }
     }
     lds_fence();
@@ -1545,8 +1581,11 @@ int run_gather_count(lsg_ctx* c, const lsg_count_params* p, const GatherCountSrc
     stage("count prepared");
     LSG_HIP(hipEventRecord(c->ev[1], st)); LSG_HIP(hipEventRecord(c->ev[3], st));
     if (direct) {
-        // no store (lsg_set_store_policy): 80 registers per lane: up to 6 waves per SIMD; 10 workgroups per CU measured best (8: 9.3 ms, 10: 8.7, 12: 8.9)
-        const unsigned grid = (unsigned)(c->n_cus * tune_int("LSG_GRID_TD", 10));
+        // no store (lsg_set_store_policy): 80 registers per lane: 6 waves per SIMD = 12 workgroups per CU (8: 9.3 ms, 10: 8.5, 12: 8.2)
+        if (c->d_xcd_queues.reserve(8 * 128)) return -1;
+        LSG_HIP(hipMemsetAsync(c->d_xcd_queues.p, 0, 8 * 128, st));
+        tg.queues = c->d_xcd_queues.as<unsigned long long>();
+        const unsigned grid = (unsigned)(c->n_cus * tune_int("LSG_GRID_TD", 12));
         hipLaunchKernelGGL(k_tm_count_direct, dim3(grid), dim3(TMW_WAVES * 64), 0, st, L.a, L.tm, tg);
         LSG_HIP(hipEventRecord(c->ev[4], st));
         LSG_HIP(hipEventRecord(c->evb[4], st));
