@@ -3,8 +3,10 @@
 // Replaces the reads of the reference's pysam.AlignmentFile (htslib bgzf + zlib inflate + bam_read1) in split_bam's fetch loop
 // (workflow/scripts/PreProcessing/SplitBamCellTypes.py:51-124) and behind bam.pileup (SNVCalling/BaseCellCounter.py:190-216):
 //   host    walks the BGZF block headers (18 bytes each), copies the file to the device
-//   k_inflate_wave one WAVE per BGZF block: raw DEFLATE (inflate_core.h) decoded uniformly by the lanes, the last 32 KB of output in an
-//                  LDS ring, match copies spread over the lanes, 4 KB chunks flushed to HBM
+//   k_inflate      one LANE per BGZF block: raw DEFLATE (inflate_core.h), a wave's 64 decoding tables side by side in LDS; every lane takes
+//                  its next block off one queue.  (One WAVE per block with an LDS ring was built and measured: 5-8 x slower, below.)
+//                  A block's ISIZE is checked against what it inflates to; its CRC32 is NOT (htslib checks it: a block whose corrupted
+//                  payload still inflates to ISIZE bytes is caught here only by the records' validation, bamrec_core.h validate()).
 //   k_chain        records are a chain (block_size -> next record) through the uncompressed stream; htslib starts every BGZF block on
 //                  a record boundary unless a record is longer than a block, so every block's lane walks its own records from the
 //                  block's first byte; k_chain_fix hands every block the place where its predecessor's chain really landed, and the

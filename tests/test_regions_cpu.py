@@ -191,6 +191,36 @@ def test_bai_plan_regions_and_slices():
     assert one.bounds == [(0, 0), (3, 0)]
 
 
+def test_the_guessed_end_of_a_slice_is_checked_on_the_host():
+    """regions._last_key_of_block: the key of the last record that starts in the BGZF block a virtual offset points into (what ingest_slice
+    looks at before it sends a slice to the device), against a walk over the whole inflated file"""
+    import gzip
+    import mmap
+    import struct
+    bam = os.path.join(G, "pileup.rand.bam")
+    _, _, first = hostio.bam_header(bam)
+    data = gzip.open(bam).read()
+    with open(bam, "rb") as f, mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ) as mm:
+        coff, ubase, n_checked = 0, 0, 0
+        u = first
+        while coff < len(mm):
+            end = regions._bgzf_block_end(mm, coff)
+            isize = struct.unpack("<I", mm[end - 4:end])[0]
+            if isize and u < ubase + isize:
+                v = (coff << 16) | (u - ubase)                 # a record starts here: what a linear-index entry looks like
+                last = None
+                while u < ubase + isize:                       # (the walk over the whole file knows every record; the helper only what its block holds)
+                    bs, tid, pos = struct.unpack_from("<Iii", data, u)
+                    if u + 12 <= ubase + isize:
+                        last = (1 << 62) if tid < 0 else (tid << 32) | max(pos, 0)
+                    u += 4 + bs
+                assert regions._last_key_of_block(mm, v) == last
+                n_checked += 1
+            coff, ubase = end, ubase + isize
+        assert n_checked >= 2
+        assert regions._last_key_of_block(mm, (7 << 16)) is None      # not a block: no guess, the device ingest decides
+
+
 def test_an_index_older_than_its_bam_is_not_used(tmp_path, capsys):
     from longsom_amd import hostio
     bam, bai = tmp_path / "a.bam", tmp_path / "a.bam.bai"
