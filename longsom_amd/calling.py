@@ -387,15 +387,19 @@ def _step3_survivors(text: bytes, i_ct: int) -> Optional[bytes]:
     return tsvio.gather_lines(text, sc.off[keep], sc.len[keep])[0]
 
 
-def step3_bytes(step2_text, delta_vaf: float, delta_mcf: float, min_ac_reads: int, min_ac_cells: int, clust_dist: int):
+def step3_bytes(step2_text, delta_vaf: float, delta_mcf: float, min_ac_reads: int, min_ac_cells: int, clust_dist: int, all_kinds=None, full_text=None):
     """step3 with both tables as bytes (what the fused pipeline writes: at C2's size the unfiltered table is 0.8 GB, not worth a decode
-    and an encode)"""
-    final, unfiltered = step3(step2_text, delta_vaf, delta_mcf, min_ac_reads, min_ac_cells, clust_dist, _as_bytes=True)
+    and an encode).  all_kinds / full_text: see step3."""
+    final, unfiltered = step3(step2_text, delta_vaf, delta_mcf, min_ac_reads, min_ac_cells, clust_dist, _as_bytes=True, all_kinds=all_kinds, full_text=full_text)
     return (final if isinstance(final, bytes) else final.encode()), (unfiltered if isinstance(unfiltered, bytes) else unfiltered.encode())
 
 
-def step3(step2_text, delta_vaf: float, delta_mcf: float, min_ac_reads: int, min_ac_cells: int, clust_dist: int, _as_bytes: bool = False):
-    """Returns (text of .calling.step3.tsv, text of .calling.step3.unfiltered.tsv).  step2_text: str or bytes."""
+def step3(step2_text, delta_vaf: float, delta_mcf: float, min_ac_reads: int, min_ac_cells: int, clust_dist: int, _as_bytes: bool = False,
+          all_kinds=None, full_text=None):
+    """Returns (text of .calling.step3.tsv, text of .calling.step3.unfiltered.tsv).  step2_text: str or bytes.
+    all_kinds: tsvio.column_kinds of the WHOLE step-2 table when step2_text holds only a part of its rows (the survivors the ranks of a
+    sharded run send to rank 0); full_text: a callable that returns the whole table then - called only when that table's printed form
+    depends on pandas' dtypes (a table this package did not write), to be parsed whole as the reference does."""
     as_bytes = isinstance(step2_text, (bytes, bytearray, memoryview))
     comments, cols = [], None
     at = 0
@@ -414,10 +418,31 @@ def step3(step2_text, delta_vaf: float, delta_mcf: float, min_ac_reads: int, min
         at = e + 1
     head = "".join(comments) + FINAL_FILTER_LINE
     # Only the rows that survive step 3's FILTER patterns (below) are parsed: a numeric field of this table is the shortest repr of
-    # its value (Python's str() in step 1, pandas' in the reference's step 2), which pandas prints back unchanged whatever dtype the
-    # column got, and "NA" / empty fields print as "" either way, so the dtypes pandas would infer from the dropped rows do not reach
-    # the output.  LONGSOM_STEP3_FULL_PARSE=1 parses every row like the reference does (tests compare the two).
-    if os.environ.get("LONGSOM_STEP3_FULL_PARSE", "0") != "1":
+    # its value (Python's str() in step 1, pandas' in the reference's step 2), which pandas prints back unchanged - PROVIDED the column's
+    # dtype is what the surviving rows alone would give it.  pandas infers dtypes over the whole file, so the kinds of cell of EVERY row
+    # are collected first (tsvio.column_kinds: one native pass over the text): a column of integers that holds a missing or a float cell
+    # in some dropped row would print "12.0", and such a table - none this package writes - is parsed whole, as the reference does.
+    # LONGSOM_STEP3_FULL_PARSE=1 parses every row in any case (tests compare the two).
+    full_parse = os.environ.get("LONGSOM_STEP3_FULL_PARSE", "0") == "1"
+    dtypes = None
+    if not full_parse and cols:
+        from . import tsvio as _tsvio
+        if all_kinds is None:
+            all_kinds = _tsvio.column_kinds(step2_text if as_bytes else step2_text.encode(), len(cols))
+        k = np.asarray(all_kinds, np.uint8)
+        numeric = (k & _tsvio.KIND_OTHER) == 0
+        if np.any(numeric & ((k & _tsvio.KIND_ODD) != 0)):
+            # a number pandas reads but would not print back as it stands, somewhere in a numeric column: parse the whole table
+            full_parse = True
+            if full_text is not None:
+                step2_text = full_text()
+                as_bytes = isinstance(step2_text, (bytes, bytearray, memoryview))
+        else:
+            # the dtypes pandas infers over the WHOLE table, for a parse of the surviving rows alone: a column with a string anywhere is a
+            # column of strings, one with a float or a missing cell anywhere is float64 (its integers print "12.0"), the rest int64
+            dtypes = {cols[c]: (str if not numeric[c] else "int64" if (k[c] & (_tsvio.KIND_NA | _tsvio.KIND_FLOAT)) == 0 and (k[c] & _tsvio.KIND_INT) else "float64")
+                      for c in range(len(cols))}
+    if not full_parse:
         i_ct = cols.index("Cell_types") if cols and "Cell_types" in cols else 6
         survivors = None
         if os.environ.get("LONGSOM_STEP3_ROW_PATH", "0") != "1":
@@ -443,13 +468,14 @@ def step3(step2_text, delta_vaf: float, delta_mcf: float, min_ac_reads: int, min
             # the row functions, the drops, the cluster filter and the two tables natively (csrc/hostio/tsvstep3.cpp); None = a table whose
             # printed form could depend on pandas' dtypes, or on which a row function raises: the pandas path below decides
             from . import tsvio
-            done = tsvio.step3_rows(survivors, cols, delta_vaf, delta_mcf, min_ac_reads, min_ac_cells, clust_dist)
+            done = tsvio.step3_rows(survivors, cols, delta_vaf, delta_mcf, min_ac_reads, min_ac_cells, clust_dist, all_kinds=all_kinds)
             if done is not None:
                 header = head + "\t".join(cols + ["STEP3FILTER", "INDEX"]) + "\n"
                 if _as_bytes:
                     return header.encode() + done[1], header.encode() + done[0]
                 return header + done[1].decode(), header + done[0].decode()
-    df = pd.read_csv(io.BytesIO(step2_text) if as_bytes else io.StringIO(step2_text), sep="\t", comment="#", names=cols)
+    df = pd.read_csv(io.BytesIO(step2_text) if as_bytes else io.StringIO(step2_text), sep="\t", comment="#", names=cols,
+                     dtype=None if full_parse else dtypes)
     df = df[df["Cell_types"] != "Non-Cancer"]
     out_cols = cols + ["STEP3FILTER", "INDEX"]
     if len(df) == 0:

@@ -177,8 +177,58 @@ const char* lsio_step3_last_error(void) { return g_s3_err; }
 // REF, ALT, FILTER, Cell_types, Dp, Nc, Bc, Cc, VAF, MCF, Cell_type_Filter, Cancer, Non-Cancer are (Non-Cancer may be -1).
 // out_all / out_pass: the rows of .calling.step3.unfiltered.tsv / .calling.step3.tsv (lsio_free_text).  Returns 0, 1 = this table is
 // for the pandas path (see the head of the file), < 0 = error.
+// Per column of a whole table (comment lines skipped, every row looked at - also the rows step 3 drops before it parses anything): which
+// kinds of cell it holds, as bits 1 NA, 2 integer, 4 float, 8 a number pandas would print differently, 16 anything else.  pandas infers a
+// column's dtype over ALL rows of the step-2 table (step3.py reads the whole file): an integer column of the surviving rows becomes
+// float64 - and prints "12.0" - when a dropped row holds a missing or a float cell there.  lsio_step3_rows takes these bits as
+// `all_kinds` and hands such a table to the pandas path.  Columns of strings stop being classified at their first string.
+int lsio_step3_column_kinds(const char* text, int64_t n_bytes, int32_t n_cols, uint8_t* kinds) {
+    if (n_bytes < 0 || n_cols < 1 || n_cols > 4096 || !kinds) { snprintf(g_s3_err, sizeof g_s3_err, "lsio_step3_column_kinds: bad arguments"); return -1; }
+    try {
+        const sv all(text, (size_t)n_bytes);
+        const unsigned T = all.size() < (1u << 22) ? 1u : std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+        std::vector<size_t> cut(T + 1, all.size());
+        cut[0] = 0;
+        for (unsigned t = 1; t < T; ++t) {
+            size_t c = std::max(cut[t - 1], all.size() * t / T);
+            const size_t nl = c < all.size() ? all.find('\n', c) : sv::npos;
+            cut[t] = nl == sv::npos ? all.size() : nl + 1;
+        }
+        std::vector<std::vector<uint8_t>> part(T, std::vector<uint8_t>((size_t)n_cols, 0));
+        parallel_rows(T, [&](size_t lo, size_t hi) {
+            for (size_t t = lo; t < hi; ++t) {
+                std::vector<uint8_t>& k = part[t];
+                for (size_t a = cut[t]; a < cut[t + 1];) {
+                    size_t e = all.find('\n', a);
+                    if (e == sv::npos || e > cut[t + 1]) e = cut[t + 1];
+                    if (e > a && all[a] != '#') {
+                        size_t f0 = a;
+                        for (int32_t c = 0; c < n_cols && f0 <= e; ++c) {
+                            size_t f1 = all.find('\t', f0);
+                            if (f1 == sv::npos || f1 > e) f1 = e;
+                            if (!(k[(size_t)c] & 16)) {
+                                switch (classify(all.substr(f0, f1 - f0))) {
+                                    case K_NA: k[(size_t)c] |= 1; break;
+                                    case K_INT: k[(size_t)c] |= 2; break;
+                                    case K_FLOAT: k[(size_t)c] |= 4; break;
+                                    case K_NUM_ODD: k[(size_t)c] |= 8; break;
+                                    default: k[(size_t)c] |= 16;
+                                }
+                            }
+                            f0 = f1 + 1;
+                        }
+                    }
+                    a = e + 1;
+                }
+            }
+        }, T);
+        for (int32_t c = 0; c < n_cols; ++c) { uint8_t v = 0; for (unsigned t = 0; t < T; ++t) v |= part[t][(size_t)c]; kinds[c] = v; }
+        return 0;
+    } catch (...) { snprintf(g_s3_err, sizeof g_s3_err, "lsio_step3_column_kinds: failed"); return -2; }
+}
+
 int lsio_step3_rows(const char* text, int64_t n_bytes, int32_t n_cols, const int32_t* col, double delta_vaf, double delta_mcf, int64_t min_ac_reads,
-                    int64_t min_ac_cells, int64_t clust_dist, char** out_all, int64_t* out_all_len, char** out_pass, int64_t* out_pass_len) {
+                    int64_t min_ac_cells, int64_t clust_dist, const uint8_t* all_kinds, char** out_all, int64_t* out_all_len, char** out_pass, int64_t* out_pass_len) {
     *out_all = *out_pass = nullptr; *out_all_len = *out_pass_len = 0;
     if (n_bytes < 0 || n_cols < 7 || n_cols > 4096) { snprintf(g_s3_err, sizeof g_s3_err, "lsio_step3_rows: bad arguments"); return -1; }
     for (int i = 0; i < N_COLS_USED; ++i)
@@ -241,6 +291,11 @@ int lsio_step3_rows(const char* text, int64_t n_bytes, int32_t n_cols, const int
             seen_lock = 0;
         });
         if (ragged) return 1;
+        if (all_kinds)                                       // what the rows the caller dropped hold (lsio_step3_column_kinds over the whole table)
+            for (int32_t c = 0; c < n_cols; ++c) {
+                Seen& a = seen[(size_t)c]; const uint8_t k = all_kinds[c];
+                a.na |= (k & 1) != 0; a.i |= (k & 2) != 0; a.f |= (k & 4) != 0; a.odd |= (k & 8) != 0; a.other |= (k & 16) != 0;
+            }
         for (const Seen& a : seen)
             if (!a.other && (a.odd || (a.i && (a.na || a.f)))) return 1;
         auto F = [&](const Row& r, Col c) -> sv { return col[c] < 0 ? sv() : r.f[(size_t)col[c]]; };

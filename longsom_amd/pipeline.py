@@ -587,6 +587,9 @@ def _run_snv_regions(bam, barcodes_tsv, ref_fasta, out_dir, sample_id, params, e
                   rows2 = step2_piece(rows1) if rows1 else b""
                   with open(regions.piece_path(tmp, chrom, start1, "step2"), "wb") as f:
                       f.write(rows2)
+                  if rows2:      # what pandas' dtype inference over the WHOLE step-2 table will see in this piece's rows (calling.step3, all_kinds)
+                      kk = tsvio.column_kinds(rows2, rows2[:rows2.index(b"\n")].count(b"\t") + 1)
+                      s2_state["kinds"] = kk if "kinds" not in s2_state or len(s2_state["kinds"]) != len(kk) else (s2_state["kinds"] | kk)
                   surv = calling._step3_survivors(rows2, 6) if rows2 and os.environ.get("LONGSOM_STEP3_FULL_PARSE", "0") != "1" else None
                   kept[(chrom, start1)] = rows2 if surv is None else surv      # (Cell_types is column 6 of the step-1 / step-2 tables)
                   t["step2"] = t.get("step2", 0.0) + time.time() - t1
@@ -602,6 +605,12 @@ def _run_snv_regions(bam, barcodes_tsv, ref_fasta, out_dir, sample_id, params, e
     names = contig["names"]
     # the candidate rows of every region on every rank (RCCL all-gather over xGMI when world > 1); then the pieces are complete
     payloads = comm.allgather_bytes(regions.pack_rows(kept))
+    kinds_all = None
+    if local_step2:                                    # the kinds of cell every rank saw in its rows of the step-2 table, OR-ed
+        for blob in comm.allgather_bytes(s2_state["kinds"].tobytes() if "kinds" in s2_state else b""):
+            if blob:
+                kb = np.frombuffer(blob, np.uint8)
+                kinds_all = kb.copy() if kinds_all is None or len(kinds_all) != len(kb) else (kinds_all | kb)
     comm.barrier()
     out = SnvOutputs(report=os.path.join(d["SplitBam"], sample_id + ".report.txt"), counts={}, merged="", step1="", step2="", step3="", step3_unfiltered="")
     for name in cts:
@@ -639,7 +648,11 @@ def _run_snv_regions(bam, barcodes_tsv, ref_fasta, out_dir, sample_id, params, e
             t["step2"] = time.time() - t0
         if step3:
             t0 = time.time()
-            final, unfiltered = calling.step3_bytes(s2, params.delta_vaf, params.delta_mcf, params.min_ac_reads, params.min_ac_cells, params.clust_dist)
+            # (s2 holds the survivors of every region when step 2 ran where the rows are: the whole table's dtypes come with kinds_all, the
+            # whole table itself - should a foreign cell make its printed form depend on them - from the file rank 0 has just assembled)
+            final, unfiltered = calling.step3_bytes(s2, params.delta_vaf, params.delta_mcf, params.min_ac_reads, params.min_ac_cells, params.clust_dist,
+                                                    all_kinds=kinds_all if local_step2 else None,
+                                                    full_text=(lambda: open(out.step2, "rb").read()) if local_step2 else None)
             open(out.step3, "wb").write(final)
             open(out.step3_unfiltered, "wb").write(unfiltered)
             t["step3"] = time.time() - t0

@@ -167,8 +167,10 @@ def _io():
         lib.lsio_free_row_scan.argtypes = [C.c_void_p]
         lib.lsio_step3_last_error.restype = C.c_char_p
         lib.lsio_step3_rows.restype = C.c_int
-        lib.lsio_step3_rows.argtypes = [C.c_char_p, C.c_int64, C.c_int32, C.c_void_p, C.c_double, C.c_double, C.c_int64, C.c_int64, C.c_int64,
+        lib.lsio_step3_rows.argtypes = [C.c_char_p, C.c_int64, C.c_int32, C.c_void_p, C.c_double, C.c_double, C.c_int64, C.c_int64, C.c_int64, C.c_void_p,
                                         C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+        lib.lsio_step3_column_kinds.restype = C.c_int
+        lib.lsio_step3_column_kinds.argtypes = [C.c_char_p, C.c_int64, C.c_int32, C.c_void_p]
         lib.lsio_gather_lines.restype = C.c_int
         lib.lsio_gather_lines.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_void_p]
         lib._tsv_ready = True
@@ -213,9 +215,30 @@ def scan_rows(text: bytes, contig_names, patterns_a: str = "", patterns_b: str =
 STEP3_COLUMNS = ("#CHROM", "Start", "REF", "ALT", "FILTER", "Cell_types", "Dp", "Nc", "Bc", "Cc", "VAF", "MCF", "Cell_type_Filter", "Cancer", "Non-Cancer")
 
 
-def step3_rows(rows: bytes, cols, delta_vaf: float, delta_mcf: float, min_ac_reads: int, min_ac_cells: int, clust_dist: int):
+KIND_NA, KIND_INT, KIND_FLOAT, KIND_ODD, KIND_OTHER = 1, 2, 4, 8, 16
+
+
+def column_kinds(text: bytes, n_cols: int) -> np.ndarray:
+    """per column of a whole table (comment lines skipped): OR of KIND_* over every row's cell (lsio_step3_column_kinds) - what pandas'
+    dtype inference over the WHOLE step-2 table sees, also in the rows step 3 drops before it parses anything"""
+    lib = _io()
+    out = np.zeros(int(n_cols), np.uint8)
+    if lib.lsio_step3_column_kinds(text, len(text), int(n_cols), out.ctypes.data) != 0:
+        raise RuntimeError(lib.lsio_step3_last_error().decode("utf-8", "replace"))
+    return out
+
+
+def kinds_dtype_sensitive(kinds: np.ndarray) -> bool:
+    """a column pandas reads as numbers whose printed form depends on the dtype: an odd number, or integers beside missing / float cells"""
+    k = np.asarray(kinds, np.uint8)
+    num = (k & KIND_OTHER) == 0
+    return bool(np.any(num & (((k & KIND_ODD) != 0) | (((k & KIND_INT) != 0) & ((k & (KIND_NA | KIND_FLOAT)) != 0)))))
+
+
+def step3_rows(rows: bytes, cols, delta_vaf: float, delta_mcf: float, min_ac_reads: int, min_ac_cells: int, clust_dist: int, all_kinds=None):
     """lsio_step3_rows (csrc/hostio/tsvstep3.cpp) over the surviving rows of a step-2 table whose header is `cols`: (rows of the
-    unfiltered table, rows of the final table) as bytes, or None when the table is one for the pandas path."""
+    unfiltered table, rows of the final table) as bytes, or None when the table is one for the pandas path.  all_kinds: column_kinds of
+    the WHOLE table the rows were taken from (the dropped rows' cells decide pandas' dtypes too)."""
     import ctypes as C
     lib = _io()
     idx = []
@@ -228,8 +251,11 @@ def step3_rows(rows: bytes, cols, delta_vaf: float, delta_mcf: float, min_ac_rea
             return None
     col = (C.c_int32 * len(idx))(*idx)
     a = C.c_void_p(); na = C.c_int64(0); b = C.c_void_p(); nb = C.c_int64(0)
+    kinds = None if all_kinds is None else np.ascontiguousarray(all_kinds, np.uint8)
+    if kinds is not None and len(kinds) != len(cols):
+        raise ValueError("all_kinds has %d entries for %d columns" % (len(kinds), len(cols)))
     rc = lib.lsio_step3_rows(rows, len(rows), len(cols), col, float(delta_vaf), float(delta_mcf), int(min_ac_reads), int(min_ac_cells), int(clust_dist),
-                             C.byref(a), C.byref(na), C.byref(b), C.byref(nb))
+                             None if kinds is None else kinds.ctypes.data, C.byref(a), C.byref(na), C.byref(b), C.byref(nb))
     if rc == 1:
         return None
     if rc != 0:

@@ -15,7 +15,8 @@ struct lsio_row_scan { int64_t n_rows, n_comment_lines; int64_t* off; int64_t* k
 int lsio_scan_rows(const char*, int64_t, const char*, int32_t, const char*, const char*, int32_t, const char*, int32_t, lsio_row_scan*);
 void lsio_free_row_scan(lsio_row_scan*);
 int lsio_gather_lines(const char*, const int64_t*, const int32_t*, int64_t, int32_t, int32_t, char**, int64_t*, int64_t*);
-int lsio_step3_rows(const char*, int64_t, int32_t, const int32_t*, double, double, int64_t, int64_t, int64_t, char**, int64_t*, char**, int64_t*);
+int lsio_step3_rows(const char*, int64_t, int32_t, const int32_t*, double, double, int64_t, int64_t, int64_t, const uint8_t*, char**, int64_t*, char**, int64_t*);
+int lsio_step3_column_kinds(const char*, int64_t, int32_t, uint8_t*);
 void lsio_free_text(char*);
 }
 
@@ -66,7 +67,11 @@ int main(int argc, char** argv) {
             lsio_free_row_scan(&sc);
         }
         char *a = nullptr, *b = nullptr; int64_t na = 0, nb = 0;
-        const int rc = lsio_step3_rows(t.data(), (int64_t)t.size(), (int32_t)cols.size(), col, 0.05, 0.3, 3, 2, 1 + (int64_t)(rnd() % 20000), &a, &na, &b, &nb);
+        // the kinds of cell of every column over the whole (damaged) table, handed on as the dtypes' evidence every other time
+        std::vector<uint8_t> kinds(cols.size(), 0);
+        const bool have_kinds = lsio_step3_column_kinds(t.data(), (int64_t)t.size(), (int32_t)cols.size(), kinds.data()) == 0;
+        const int rc = lsio_step3_rows(t.data(), (int64_t)t.size(), (int32_t)cols.size(), col, 0.05, 0.3, 3, 2, 1 + (int64_t)(rnd() % 20000),
+                                       have_kinds && (rnd() & 1) ? kinds.data() : nullptr, &a, &na, &b, &nb);
         if (rc == 0) { ++handled; lsio_free_text(a); lsio_free_text(b); } else if (rc == 1) ++handed_back; else ++errors;
     }
     printf("fuzz_tsv: %d tables handled, %d handed back, %d errors\n", handled, handed_back, errors);

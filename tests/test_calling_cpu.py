@@ -244,13 +244,46 @@ def test_step3_native_differential_fuzz(monkeypatch):
         if rng.random() < 0.3:
             rows = ["\t".join(["chrM"] + l.split("\t")[1:]) for l in rows]
         t = "\n".join(head + rows) + "\n"
-        monkeypatch.setenv("LONGSOM_STEP3_PANDAS", "1")
+        monkeypatch.setenv("LONGSOM_STEP3_FULL_PARSE", "1")      # every row through pandas, as the reference reads the table: the ground truth
         want = outcome(t)
+        monkeypatch.setenv("LONGSOM_STEP3_FULL_PARSE", "0")
+        monkeypatch.setenv("LONGSOM_STEP3_PANDAS", "1")          # pandas over the surviving rows, with the whole table's dtypes
+        assert outcome(t) == want, "seed %d (pandas over the survivors)" % seed
         monkeypatch.setenv("LONGSOM_STEP3_PANDAS", "0")
         assert outcome(t) == want, "seed %d" % seed
         sv = calling._step3_survivors(t.encode(), hdr.index("Cell_types"))
         handled += bool(sv) and tsvio.step3_rows(sv, hdr, *args) is not None
     assert handled > 60                                  # (most of the tables are the native path's own)
+
+
+def test_step3_dtypes_come_from_every_row_of_the_table(monkeypatch):
+    """pandas infers a column's dtype over the WHOLE step-2 table: a missing or a float cell in a row step 3 DROPS (Non-Cancer, or dead by its
+    FILTER) turns an integer column into float64 and its surviving cells into "12.0"; a string there turns it into a column of strings.
+    The paths that parse only the survivors must print what the full parse prints."""
+    texts, _, _, _ = _step3_tables()
+    args = (0.05, 0.3, 3, 2, 10000)
+    lines = texts[0].split("\n")
+    head = [l for l in lines if l.startswith("#")]
+    rows = [l.split("\t") for l in lines if l and not l.startswith("#")]
+    hdr = [l for l in head if l.startswith("#CHROM")][0].split("\t")
+    i_ct, i_f = hdr.index("Cell_types"), hdr.index("FILTER")
+    victims = [r for r in rows if r[i_ct] == "Non-Cancer"][:2]
+    assert len(victims) == 2
+    n_diff = 0
+    for col, cell in (("End", "NA"), ("End", "7.5"), ("Start", "x1"), ("N_ALT", ""), ("Dp", "3.0")):
+        saved = [list(v) for v in victims]
+        victims[0][hdr.index(col)] = cell
+        t = "\n".join(head + ["\t".join(r) for r in rows]) + "\n"
+        for v, sv_ in zip(victims, saved):
+            v[:] = sv_
+        monkeypatch.setenv("LONGSOM_STEP3_FULL_PARSE", "1")
+        want = calling.step3(t, *args)
+        monkeypatch.setenv("LONGSOM_STEP3_FULL_PARSE", "0")
+        for pandas_only in ("1", "0"):
+            monkeypatch.setenv("LONGSOM_STEP3_PANDAS", pandas_only)
+            assert calling.step3(t, *args) == want, (col, cell, pandas_only)
+        n_diff += want != calling.step3(texts[0], *args)
+    assert n_diff >= 2                                    # (the dropped row's cell really changed what the survivors print)
 
 
 def test_step2_scanned_differential_fuzz(monkeypatch):
