@@ -665,8 +665,21 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
     LSG_HIP(hipEventRecord(c->evb[1], st));
     // ---- beside the scatter, on the copy stream: what follows from the capacities alone
     if (c->tm[TM_BLK_TILE].reserve(((size_t)nblk + 2) * 4)) return -1;
-    bool lpt = false, split_sort = false;
+    bool lpt = false, split_sort = false, blk_tiles_made = false;
     const uint32_t* lpt_tiles = nullptr;
+    const bool may_skip_store = c->cal_enabled && c->store_policy == LSG_STORE_SKIP_WHEN_COUNTED && !getenv("LSG_NO_DIRECT_COUNT");
+    // (the scratch is BT_COPY_TMP, sized below before anything is queued on the copy stream; on the main stream - the fall-back - the
+    // copy stream has been waited for)
+    auto blk_tiles = [&](hipStream_t s_) -> int {
+        uint32_t* bt_ = c->tm[TM_BLK_TILE].as<uint32_t>();
+        LSG_HIP(hipMemsetAsync(bt_, 0, (size_t)nblk * 4, s_));
+        hipLaunchKernelGGL(k_tm_blk_mark, dim3((T + 255) / 256), dim3(256), 0, s_, c->d_tile_cap.as<uint32_t>(), blk_off, T, bt_);
+        size_t tb = c->bt[BT_COPY_TMP].cap;
+        LSG_HIP(hipcub::DeviceScan::InclusiveScan(c->bt[BT_COPY_TMP].p, tb, bt_, bt_, hipcub::Max(), (int)nblk, s_));
+        LSG_HIP(hipEventRecord(c->ev_blk, s_));
+        blk_tiles_made = true;
+        return 0;
+    };
     {
         hipStream_t bs = c->copy_stream;
         const bool want_lpt = n_netile > 1 && !getenv("LSG_NO_LPT");
@@ -700,12 +713,9 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
             LSG_HIP(hipEventRecord(c->ev_lpt, bs));
             lpt = true; lpt_tiles = t_out;
         }
-        // the tile of every block (the re-counts' resolve and the plain gather read it; the fused pass does not)
-        LSG_HIP(hipMemsetAsync(bt_, 0, (size_t)nblk * 4, bs));
-        hipLaunchKernelGGL(k_tm_blk_mark, dim3((T + 255) / 256), dim3(256), 0, bs, c->d_tile_cap.as<uint32_t>(), blk_off, T, bt_);
-        size_t tb = c->bt[BT_COPY_TMP].cap;
-        LSG_HIP(hipcub::DeviceScan::InclusiveScan(scratch, tb, bt_, bt_, hipcub::Max(), (int)nblk, bs));
-        LSG_HIP(hipEventRecord(c->ev_blk, bs));
+        // the tile of every block (the re-counts' resolve and the plain gather read it; the fused pass does not) - left out when the load is
+        // to keep no store (should it build one after all, blk_tiles() runs then)
+        if (!may_skip_store) { if (int rc = blk_tiles(bs)) return rc; }
     }
     // ---- 3. every tile's entries by barcode
     if (n_netile) {
@@ -716,18 +726,7 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
         uint32_t* sb2 = split_sort ? sb1 + seg_pitch : nullptr; uint32_t* se2 = split_sort ? se1 + seg_pitch : nullptr;
         if (lpt) LSG_HIP(hipStreamWaitEvent(st, c->ev_lpt, 0));
         hipLaunchKernelGGL(k_seg_bounds, dim3((n_netile + 255) / 256), dim3(256), 0, st, lpt ? lpt_tiles : c->bt[BT_NETILE].as<uint32_t>(), n_netile, c->d_tile_off.as<uint32_t>(), sb1, se1, sb2, se2);
-        if (split_sort) {
-            // rocprim runs its three kernels (a block per segment beyond 256 entries: 2.7 ms at C2; the warp sorts of the segments up to 256 and up
-            // to 64: 0.55 ms) one after the other, and the first one's tail leaves most of the chip idle: the shallow tiles are sorted on the copy
-            // stream beside it (same output arrays, disjoint segments, scratch of its own)
-            hipStream_t bs = c->copy_stream;
-            LSG_HIP(hipEventRecord(c->ev_copy, st));
-            LSG_HIP(hipStreamWaitEvent(bs, c->ev_copy, 0));
-            size_t tb2 = c->bt[BT_COPY_TMP].cap;
-            LSG_HIP((lsg_segmented_sort<7, 256, 8>(c->bt[BT_COPY_TMP].p, tb2, key_a.as<uint64_t>(), key_b.as<uint64_t>(), val_a.as<uint32_t>(), val_b.as<uint32_t>(), (unsigned)N, (unsigned)n_netile,
-                                                   sb2, se2, 0u, (unsigned)bits, bs, false)));
-            LSG_HIP(hipEventRecord(c->ev_lpt, bs));            // (the event of the tiles' order: waited for above, free again)
-        }
+        if (split_sort) LSG_HIP(hipEventRecord(c->ev_copy, st));      // (the second sort, queued below, starts here)
         size_t tb = 0;
         // (64-bit keys sorted on their barcode bits only, begin_bit 0 .. end_bit `bits`: the rest of the key is payload)
         static const int cfg = getenv("LSG_SORT_CFG") ? atoi(getenv("LSG_SORT_CFG")) : 0;
@@ -751,6 +750,18 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
         if (tmp.reserve(tb + 256)) return -1;
         tb = tmp.cap;
         LSG_HIP(sort(tmp.p, tb));
+        if (split_sort) {
+            // rocprim runs its three kernels (a block per segment beyond 256 entries: 2.7 ms at C2; the warp sorts of the segments up to 256 and up
+            // to 64: 0.55 ms) one after the other, and the first one's tail leaves most of the chip idle: the shallow tiles are sorted on the copy
+            // stream beside it (same output arrays, disjoint segments, scratch of its own); queued AFTER the deep tiles' sort so that the
+            // main stream does not wait for these launches
+            hipStream_t bs = c->copy_stream;
+            LSG_HIP(hipStreamWaitEvent(bs, c->ev_copy, 0));
+            size_t tb2 = c->bt[BT_COPY_TMP].cap;
+            LSG_HIP((lsg_segmented_sort<7, 256, 8>(c->bt[BT_COPY_TMP].p, tb2, key_a.as<uint64_t>(), key_b.as<uint64_t>(), val_a.as<uint32_t>(), val_b.as<uint32_t>(), (unsigned)N, (unsigned)n_netile,
+                                                   sb2, se2, 0u, (unsigned)bits, bs, false)));
+            LSG_HIP(hipEventRecord(c->ev_lpt, bs));            // (the event of the tiles' order: waited for above, free again)
+        }
         if (split_sort) LSG_HIP(hipStreamWaitEvent(st, c->ev_lpt, 0));      // both halves of the order are there
     }
     LSG_HIP(hipEventRecord(c->evb[2], st));
@@ -832,6 +843,10 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
         fused = false;
     }
     if (int rc = reserve_store()) return rc;
+    if (!blk_tiles_made) {                                       // (a load that was to keep no store builds one after all)
+        LSG_HIP(hipStreamSynchronize(c->copy_stream));
+        if (int rc = blk_tiles(st)) return rc;
+    }
     if (fused) {
         if (int rc = fused_plan()) return rc;
         c->tm_valid = true;                                   // (what the count's preparation looks at; the blocks are written by the pass itself)
