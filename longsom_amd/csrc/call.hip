@@ -16,6 +16,7 @@
 // Device storage is compact (48 B per site + 56 B per (candidate site, cell type)); lsg_fetch_calls /
 // lsg_export_calls expand it into the C-ABI's lsg_call records.
 #include "lsg_ctx.h"
+#include <cstdio>
 #include <cstring>
 #include <cstdlib>
 #include <hipcub/hipcub.hpp>
@@ -807,13 +808,15 @@ int run_call(lsg_ctx* c, const lsg_call_params* p) {
         }
         hipLaunchKernelGGL(k_call_tails, dim3((unsigned)(c->n_cus * 16)), dim3(256), 0, st, a);
         hipLaunchKernelGGL(k_call_tails_heavy, dim3((unsigned)(c->n_cus * 8)), dim3(256), 0, st, a);
-        hipLaunchKernelGGL(k_call_finish, dim3((unsigned)(c->n_cus * 2)), dim3(256), 0, st, a, n_sites);        // (the listed sites only: the deepest few thousand)
+        hipLaunchKernelGGL(k_call_finish, dim3((unsigned)(c->n_cus * 2)), dim3(256), 0, st, a, n_sites);        // (the listed sites only: C2: 294 k of 23.9 M)
         LSG_HIP(hipGetLastError());
     }
     unsigned long long cnt4[CT_WORDS];
     LSG_HIP(hipMemcpyAsync(c->h_pin, a.counters, CT_WORDS * 8, hipMemcpyDeviceToHost, st));
     LSG_HIP(hipStreamSynchronize(st));
     memcpy(cnt4, c->h_pin, CT_WORDS * 8);
+    if (getenv("LSG_TIMING")) fprintf(stderr, "[lsg] call: %u sites, light task slots %llu (+%llu of the first chunks), heavy %llu (+%llu), sites that waited for a tail %llu, PASS %llu\n", n_sites,
+                                      cnt4[CT_LIGHT], (unsigned long long)a.arena_waves * TASK_CHUNK, cnt4[CT_HEAVY], (unsigned long long)a.arena_waves * HEAVY_CHUNK, cnt4[CT_DEFER], cnt4[CT_PASS]);
     c->n_pass = (int64_t)cnt4[CT_PASS];
     const unsigned long long cand = cnt4[CT_NCAND];
     if (n_sites > 0 && (cnt4[CT_LIGHT] + (uint64_t)a.arena_waves * TASK_CHUNK > a.task_cap || cnt4[CT_HEAVY] + (uint64_t)a.arena_waves * HEAVY_CHUNK > a.task_cap)) { set_error("lsg_call_step1: tail task buffer too small (%llu/%llu tasks)", cnt4[CT_LIGHT], cnt4[CT_HEAVY]); return -3; }
