@@ -1043,6 +1043,14 @@ struct TdW { uint32_t lo, hi; };     // hi: address bits 32..47 | 2 * events << 
 // Four quarters of 16 entries alternate between two sets of registers: 16 to 32 loads are in flight while 16 entries are counted.
 // The fences pin the ORDER the loads are issued in - look-ups, keys, quarter by quarter - in the prologue as in the loop: the counter of
 // loads in flight is in-order, and where two orders meet at the loop's head the compiler waits for everything.
+#ifndef LSG_TD_Q
+#define LSG_TD_Q 16
+#endif
+#ifndef LSG_TD_WAVES
+#define LSG_TD_WAVES 6
+#endif
+constexpr int TD_Q = LSG_TD_Q, TD_NQ = 64 / TD_Q;      // entries to a batch of loads (two batches of registers alternate), batches to a group.
+// (8 to a batch fit 64 registers and 8 waves per SIMD, 16 workgroups per CU: 8.1-8.8 ms, no better than 16 to a batch at 6 waves: 8.0-8.2)
 struct TdKeys64 { uint64_t k; uint32_t v; };
 __device__ __forceinline__ TdKeys64 td_load_keys64(const TgArgs& tg, uint32_t i_first, uint32_t off, uint32_t n, int lane) {
     TdKeys64 r;
@@ -1106,20 +1114,20 @@ __device__ __forceinline__ void td_range64(const CountArgs& a, const TmArgs& tm,
         open_in = ((A & segl) != 0ull || (!R && open_in)) ? 1u : 0u;
         return M;
     };
-    auto issue = [&](const TdW& w, int q, uint32_t (&E)[16]) {
+    auto issue = [&](const TdW& w, int q, uint32_t (&E)[TD_Q]) {
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const uint32_t lo = rl(w.lo, q * 16 + u), hi = rl(w.hi, q * 16 + u);
+        for (int u = 0; u < TD_Q; ++u) {
+            const uint32_t lo = rl(w.lo, q * TD_Q + u), hi = rl(w.hi, q * TD_Q + u);
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>((uintptr_t)(((uint64_t)(hi & 0xffffu) << 32) | lo)), 0, (int)((hi >> 16) & 0xffu), 0x00020000);
             E[u] = (uint32_t)(int32_t)(int16_t)__builtin_amdgcn_raw_buffer_load_b16(rs, (int)(lane2 - (hi >> 24)), 0, 0);
         }
     };
-    auto consume = [&](const uint32_t (&E)[16], int q, uint32_t M) {
+    auto consume = [&](const uint32_t (&E)[TD_Q], int q, uint32_t M) {
 #pragma unroll
-        for (int u = 0; u < 16; ++u) tm_add<false>(st, rl(M, q * 16 + u), E[u], thr, pkl0, one);
+        for (int u = 0; u < TD_Q; ++u) tm_add<false>(st, rl(M, q * TD_Q + u), E[u], thr, pkl0, one);
     };
     auto fence = []() { asm volatile("" ::: "memory"); };
-    uint32_t EA[16], EB[16];
+    uint32_t EA[TD_Q], EB[TD_Q];
     TdW wc, wn; TgPre pre;
     words(0, K, wc, pre);
     fence();
@@ -1136,16 +1144,17 @@ __device__ __forceinline__ void td_range64(const CountArgs& a, const TmArgs& tm,
         fence();
         K = td_load_keys64(tg, i0 + 64u * (uint32_t)(g + 2), off, n, lane);
         fence();
-        consume(EA, 0, Mc); issue(wc, 2, EA);
-        consume(EB, 1, Mc); issue(wc, 3, EB);
-        consume(EA, 2, Mc); issue(wn, 0, EA);
-        consume(EB, 3, Mc); issue(wn, 1, EB);
+#pragma unroll
+        for (int sb = 0; sb < TD_NQ; sb += 2) {                // batch sb is counted while sb + 1 is in flight; its registers take batch sb + 2's loads
+            consume(EA, sb, Mc); issue(sb + 2 < TD_NQ ? wc : wn, (sb + 2) % TD_NQ, EA);
+            consume(EB, sb + 1, Mc); issue(sb + 3 < TD_NQ ? wc : wn, (sb + 3) % TD_NQ, EB);
+        }
         wc = wn;
     }
     st.nc += st.mask & 0x10001u; st.mask = 0;
 }
 
-__global__ __launch_bounds__(TMW_WAVES * 64) __attribute__((amdgpu_waves_per_eu(6))) void k_tm_count_direct(CountArgs a, TmArgs tm, TgArgs tg) {
+__global__ __launch_bounds__(TMW_WAVES * 64) __attribute__((amdgpu_waves_per_eu(LSG_TD_WAVES))) void k_tm_count_direct(CountArgs a, TmArgs tm, TgArgs tg) {
     __shared__ __attribute__((aligned(8192))) uint32_t planes[2][2][8 * 64];
     __shared__ uint32_t nc_sh[2][64];
     __shared__ WaveBook books[TMW_WAVES];
