@@ -19,6 +19,7 @@
 #include <string>
 #include <string_view>
 #include <atomic>
+#include <chrono>
 #include <thread>
 #include <unordered_set>
 #include <vector>
@@ -149,6 +150,17 @@ int actg(char c) { const char* p = strchr("ACTG", c); if (!p || !c) throw NotHan
 int64_t need_int(sv s) { int64_t v; if (!to_i64(s, &v)) throw NotHandled{}; return v; }
 double need_float(sv s) { double v; if (is_na(s) || !to_f64(s, &v)) throw NotHandled{}; return v; }
 sv need(const std::vector<sv>& v, size_t i) { if (i >= v.size()) throw NotHandled{}; return v[i]; }
+// field n of s split at sep, without a vector (the row functions ran out of time in malloc); a field that is not there: NotHandled
+sv nth(sv s, char sep, size_t n) {
+    size_t a = 0;
+    for (size_t k = 0;; ++k) {
+        const size_t e = s.find(sep, a);
+        if (k == n) return s.substr(a, e == sv::npos ? sv::npos : e - a);
+        if (e == sv::npos) throw NotHandled{};
+        a = e + 1;
+    }
+}
+size_t n_fields(sv s, char sep) { size_t n = 1; for (char c : s) n += c == sep; return n; }
 
 // fn(lo, hi) over [0, n) in up to 16 threads; an exception in a worker is a NotHandled for the whole call
 template <class F>
@@ -235,7 +247,10 @@ int lsio_step3_rows(const char* text, int64_t n_bytes, int32_t n_cols, const int
         if (col[i] >= n_cols || (col[i] < 0 && i != C_NONCANCER)) return 1;
     try {
         const sv all(text, (size_t)n_bytes);
-        if (all.find_first_of("#\"\r") != sv::npos) return 1;
+        const bool s3_timing = getenv("LONGSOM_STEP3_TIMING") != nullptr;
+        auto s3_t0 = std::chrono::steady_clock::now();
+        auto lap = [&](const char* what) { if (s3_timing) { auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[step3] %s: %.3f s\n", what, std::chrono::duration<double>(t - s3_t0).count()); s3_t0 = t; } };
+        std::atomic<bool> odd_char{false};                       // a '#', a quote or a carriage return anywhere: the pandas path's table (looked for by the threads below)
         std::vector<sv> lines;
         {   // the lines, found by the threads in pieces of the text cut at newlines
             const unsigned T = all.size() < (1u << 22) ? 1u : std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
@@ -248,18 +263,22 @@ int lsio_step3_rows(const char* text, int64_t n_bytes, int32_t n_cols, const int
             }
             std::vector<std::vector<sv>> part(T);
             parallel_rows(T, [&](size_t lo, size_t hi) {
-                for (size_t t = lo; t < hi; ++t)
+                for (size_t t = lo; t < hi; ++t) {
+                    if (all.substr(cut[t], cut[t + 1] - cut[t]).find_first_of("#\"\r") != sv::npos) { odd_char = true; return; }
                     for (size_t a = cut[t]; a < cut[t + 1];) {
                         const void* nl = memchr(all.data() + a, '\n', cut[t + 1] - a);
                         const size_t e = nl ? (size_t)((const char*)nl - all.data()) : cut[t + 1];
                         if (e > a) part[t].push_back(all.substr(a, e - a));
                         a = e + 1;
                     }
+                }
             }, T);
+            if (odd_char) return 1;
             size_t n = 0; for (auto& v : part) n += v.size();
             lines.reserve(n);
             for (auto& v : part) lines.insert(lines.end(), v.begin(), v.end());
         }
+        lap("lines");
         std::vector<Row> rows(lines.size());
         // ---- the fields, and what pandas' dtypes could change (see the head of the file): per column, which kinds of cell it holds
         struct Seen { bool other = false, na = false, i = false, f = false, odd = false; };
@@ -290,6 +309,7 @@ int lsio_step3_rows(const char* text, int64_t n_bytes, int32_t n_cols, const int
             }
             seen_lock = 0;
         });
+        lap("split + kinds");
         if (ragged) return 1;
         if (all_kinds)                                       // what the rows the caller dropped hold (lsio_step3_column_kinds over the whole table)
             for (int32_t c = 0; c < n_cols; ++c) {
@@ -348,18 +368,23 @@ int lsio_step3_rows(const char* text, int64_t n_bytes, int32_t n_cols, const int
                     r.bc = std::to_string(bc_c); r.cc = std::to_string(cc_c); r.vaf = ratio4(bc_c, d); r.mcf = ratio4(cc_c, n);
                 }
             }
-            const std::string alt = r.rewritten ? r.alt : std::string(alt0);
-            const std::string filt = r.rewritten ? r.filter : (is_na(filt0) ? std::string() : std::string(filt0));
+            const sv alt = r.rewritten ? sv(r.alt) : alt0;
+            const sv filt = r.rewritten ? sv(r.filter) : (is_na(filt0) ? sv() : filt0);
             if (!r.rewritten && is_na(filt0)) throw NotHandled{};          // .str.contains on a missing FILTER gives NaN, the boolean index raises
-            r.index = std::string(chrom) + ":" + std::string(F(r, C_START)) + ":" + alt.substr(0, alt.find(','));
+            {
+                const sv start = F(r, C_START), a1 = alt.substr(0, alt.find(','));
+                r.index.reserve(chrom.size() + start.size() + a1.size() + 2);
+                r.index.assign(chrom.data(), chrom.size()); r.index.push_back(':'); r.index.append(start.data(), start.size()); r.index.push_back(':'); r.index.append(a1.data(), a1.size());
+            }
             const sv vaf = r.rewritten ? sv(r.vaf) : F(r, C_VAF), mcf = r.rewritten ? sv(r.mcf) : F(r, C_MCF);
-            const auto ctypes = split(ct, ',');
+            const size_t n_ctypes = n_fields(ct, ',');
+            const sv ctype0 = ct.substr(0, ct.find(','));
             if (r.is_m) {
                 for (const char* p : {"Min", "LR", "gnomAD", "LC", "RNA"}) if (contains(filt, p)) r.dropped = true;
                 if (r.dropped) continue;
                 // chrM_filtering
-                if (ctypes.size() > 1) {
-                    const int i_c = ctypes[0] == "Cancer" ? 0 : 1, i_n = 1 - i_c;
+                if (n_ctypes > 1) {
+                    const int i_c = ctype0 == "Cancer" ? 0 : 1, i_n = 1 - i_c;
                     const auto d = split(F(r, C_DP), ',');
                     if (d.size() != 2) throw NotHandled{};
                     if (need_int(d[0]) < 100 || need_int(d[1]) < 100) r.s3 = tag(r.s3, "LowDepth");
@@ -383,25 +408,25 @@ int lsio_step3_rows(const char* text, int64_t n_bytes, int32_t n_cols, const int
                 const int i_alt = actg(alt.empty() ? 0 : alt[0]);
                 if (is_na(F(r, C_CANCER))) r.s3 = tag(r.s3, "NoCov");
                 else {
-                    const auto info = split(F(r, C_CANCER), '|');
-                    if (need_int(need(split(need(info, 3), ':'), (size_t)i_alt)) < min_ac_reads || need_int(need(split(need(info, 2), ':'), (size_t)i_alt)) < min_ac_cells)
+                    const sv info = F(r, C_CANCER);
+                    if (need_int(nth(nth(info, '|', 3), ':', (size_t)i_alt)) < min_ac_reads || need_int(nth(nth(info, '|', 2), ':', (size_t)i_alt)) < min_ac_cells)
                         r.s3 = tag(r.s3, "LowDepth");
                 }
                 // BetaBino_filtering
                 const sv flt = F(r, C_CTF);
                 auto weak = [](sv x) { return x == "Non-Significant" || x == "Low-Significance"; };
-                if (ctypes.size() == 1) { if (!is_na(flt) && weak(flt)) r.s3 = tag(r.s3, "CancerNonSig"); }
+                if (n_ctypes == 1) { if (!is_na(flt) && weak(flt)) r.s3 = tag(r.s3, "CancerNonSig"); }
                 else {
                     if (is_na(flt)) throw NotHandled{};
-                    const int i_c = ctypes[0] == "Cancer" ? 0 : 1, i_n = 1 - i_c;
-                    const auto f = split(flt, ',');
-                    if (weak(need(f, (size_t)i_c))) r.s3 = tag(r.s3, "CancerNonSig");
-                    else if (need(f, (size_t)i_n) == "PASS" || need(f, (size_t)i_n) == "Low-Significance") r.s3 = tag(r.s3, "NonCancerSig");
+                    const int i_c = ctype0 == "Cancer" ? 0 : 1, i_n = 1 - i_c;
+                    if (weak(nth(flt, ',', (size_t)i_c))) r.s3 = tag(r.s3, "CancerNonSig");
+                    else if (nth(flt, ',', (size_t)i_n) == "PASS" || nth(flt, ',', (size_t)i_n) == "Low-Significance") r.s3 = tag(r.s3, "NonCancerSig");
                 }
                 for (const char* p : {"Noisy_site", "LC_Upstream", "LC_Downstream", "RNA_editing_db", "PoN", "Cell_type_noise", "gnomAD"}) if (contains(filt, p)) r.dropped = true;
             }
         }
         });
+        lap("row functions");
         // ---- the table's order: the other contigs' rows, then chrM's (pd.concat([df, chrm]))
         std::vector<const Row*> order;
         for (const Row& r : rows) if (!r.dropped && !r.is_m) order.push_back(&r);
@@ -418,11 +443,11 @@ int lsio_step3_rows(const char* text, int64_t n_bytes, int32_t n_cols, const int
                 const int64_t p1 = need_int(idx[i].p), p2 = need_int(idx[i + 1].p);
                 if (std::llabs(p1 - p2) < clust_dist) { trash.insert(*idx[i].index); trash.insert(*idx[i + 1].index); }
             }
+        lap("order + cluster filter");
         const std::string ctag = "Clust_dist_" + std::to_string(clust_dist);
         const size_t CH = 4096, n_ch = (order.size() + CH - 1) / CH;
         std::vector<std::string> all_ch(n_ch), pass_ch(n_ch);
         parallel_rows(n_ch, [&](size_t lo, size_t hi) {
-            std::string line;
             for (size_t ch = lo; ch < hi; ++ch) {
                 std::string& all_txt = all_ch[ch]; std::string& pass_txt = pass_ch[ch];
                 { size_t est = 0; for (size_t k = ch * CH; k < std::min(order.size(), (ch + 1) * CH); ++k) for (const sv& f : order[k]->f) est += f.size() + 1; all_txt.reserve(est + CH * 64); }
@@ -430,23 +455,24 @@ int lsio_step3_rows(const char* text, int64_t n_bytes, int32_t n_cols, const int
                     const Row* r = order[k];
                     std::string s3 = r->s3;
                     if (trash.count(r->index)) s3 = tag(s3, ctag.c_str());
-                    line.clear();
+                    // (straight into the chunk's text; a PASS row - a few hundred per sample - is copied from there)
+                    const size_t at0 = all_txt.size();
                     for (int32_t c = 0; c < n_cols; ++c) {
-                        if (c) line.push_back('\t');
-                        if (r->rewritten && c == col[C_ALT]) line += r->alt;
-                        else if (r->rewritten && c == col[C_FILTER]) line += r->filter;
-                        else if (r->rewritten && c == col[C_BC]) line += r->bc;
-                        else if (r->rewritten && c == col[C_CC]) line += r->cc;
-                        else if (r->rewritten && c == col[C_VAF]) line += r->vaf;
-                        else if (r->rewritten && c == col[C_MCF]) line += r->mcf;
-                        else if (!is_na(r->f[(size_t)c])) line.append(r->f[(size_t)c].data(), r->f[(size_t)c].size());
+                        if (c) all_txt.push_back('\t');
+                        if (r->rewritten && c == col[C_ALT]) all_txt += r->alt;
+                        else if (r->rewritten && c == col[C_FILTER]) all_txt += r->filter;
+                        else if (r->rewritten && c == col[C_BC]) all_txt += r->bc;
+                        else if (r->rewritten && c == col[C_CC]) all_txt += r->cc;
+                        else if (r->rewritten && c == col[C_VAF]) all_txt += r->vaf;
+                        else if (r->rewritten && c == col[C_MCF]) all_txt += r->mcf;
+                        else if (!is_na(r->f[(size_t)c])) all_txt.append(r->f[(size_t)c].data(), r->f[(size_t)c].size());
                     }
-                    line.push_back('\t'); line += s3; line.push_back('\t'); line += r->index; line.push_back('\n');
-                    all_txt += line;
-                    if (s3 == "PASS") pass_txt += line;
+                    all_txt.push_back('\t'); all_txt += s3; all_txt.push_back('\t'); all_txt += r->index; all_txt.push_back('\n');
+                    if (s3 == "PASS") pass_txt.append(all_txt, at0, std::string::npos);
                 }
             }
-        });
+        }, (unsigned)std::min<size_t>(16, std::max<size_t>(1, std::min<size_t>(n_ch, std::thread::hardware_concurrency()))));      // (chunks, not rows: parallel_rows' own guard would run a few hundred of them on one thread)
+        lap("format");
         size_t na = 0, np = 0;
         for (auto& x : all_ch) na += x.size();
         for (auto& x : pass_ch) np += x.size();
@@ -460,6 +486,7 @@ int lsio_step3_rows(const char* text, int64_t n_bytes, int32_t n_cols, const int
             }, 16);
         }
         { size_t at = 0; for (auto& x : pass_ch) { memcpy(op + at, x.data(), x.size()); at += x.size(); } }
+        lap("assemble");
         *out_all = oa; *out_all_len = (int64_t)na; *out_pass = op; *out_pass_len = (int64_t)np;
         return 0;
     } catch (const NotHandled&) {
