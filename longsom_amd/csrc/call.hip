@@ -727,7 +727,18 @@ struct HasSites {
     __host__ __device__ bool operator()(const uint32_t& w) const { return cnt[w] != 0; }
 };
 
+static int run_call_sized(lsg_ctx* c, const lsg_call_params* p, uint32_t tasks_per_site);
+// The tail tasks' buffers are sized for ONE task per merged site (C2 makes 0.08: the table answers the rest; 8 per site, the old
+// size, was 6 GB of a fresh handle's first call); a sample that needs more is called again with the bound no site can exceed.
 int run_call(lsg_ctx* c, const lsg_call_params* p) {
+    int rc = run_call_sized(c, p, c->call_tasks_per_site);
+    if (rc == -3) {
+        c->call_tasks_per_site = (uint32_t)(8 * c->n_ct + 2);
+        rc = run_call_sized(c, p, c->call_tasks_per_site);
+    }
+    return rc;
+}
+static int run_call_sized(lsg_ctx* c, const lsg_call_params* p, uint32_t tasks_per_site) {
     if (!c->counted) { set_error("lsg_call_step1: call lsg_pileup_count first"); return -2; }
     hipStream_t st = c->stream;
     const uint32_t n_ne = c->n_ne;
@@ -791,9 +802,8 @@ int run_call(lsg_ctx* c, const lsg_call_params* p) {
         a.sites = c->d_calls.as<SiteRec>(); a.cands = c->ws[WS_CALL_CANDS].as<CandCt>(); a.cand_cap = n_sites + 2 * gather_waves * CAND_CHUNK;
         // at most 2 tails per alt (<= 4 alts) per cell type + 2 noise tails per site
         a.task_cap = (uint64_t)n_sites * (uint64_t)(8 * c->n_ct + 2);
+        if (a.task_cap > (uint64_t)n_sites * tasks_per_site + 1024) a.task_cap = (uint64_t)n_sites * tasks_per_site + 1024;      // (checked below: run_call sizes again when it was too small)
         if (a.task_cap > 0x7fffffffull) a.task_cap = 0x7fffffffull;
-        // candidates rarely exceed a few tasks per site: size for 8 per site, checked below
-        if (a.task_cap > (uint64_t)n_sites * 8 + 1024) a.task_cap = (uint64_t)n_sites * 8 + 1024;
         a.task_cap += gather_waves * TASK_CHUNK * 3;                                  // arena slack (first chunks + last partial chunks)
         if (c->ws[WS_CALL_TASKS].reserve((size_t)a.task_cap * sizeof(TailTask) * 2)) return -1;
         a.light = c->ws[WS_CALL_TASKS].as<TailTask>(); a.heavy = a.light + a.task_cap;

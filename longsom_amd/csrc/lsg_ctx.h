@@ -189,6 +189,7 @@ struct lsg_ctx {
     double tail_table_key[4] = {0, 0, 0, 0}; bool tail_table_valid = false;
     int64_t n_sites = 0, n_cand = 0, n_pass = -1;      // n_pass: PASS candidates listed by k_call_finish (-1: no list)
     lsg::DevBuf d_pass_list, d_defer_list, d_xcd_queues;
+    uint32_t call_tasks_per_site = 1;     // call.hip: how the tail tasks' buffers are sized (grown on demand)
     bool called = false;
 
     lsg::PosSet posset[3];
