@@ -151,8 +151,12 @@ def _step2_scanned(text: bytes, engine, contig_names, editing_keys, pon_sr_keys,
             close[:-1] += near(i[:-1], i[:-1] + 1)
             close[0] += near(np.array([0]), np.array([2]))[0]                                      # the first row's window is rows 0..2
     tagged = np.nonzero(hits[0] | hits[1] | hits[2] | (close > 0))[0]
-    body, new_off = tsvio.gather_lines(text, sc.off[kept], sc.len[kept], blank_na=True)
+    # (the table's head travels in front of the rows from the start, and the few tagged rows are spliced in between VIEWS of the others:
+    # one copy of the table's 2.7 GB at C2 where `head + join(slices)` made three)
+    hdr = b"\n".join(comments + [headers[-1]]) + b"\n"
+    body, new_off = tsvio.gather_lines(text, sc.off[kept], sc.len[kept], blank_na=True, prefix=hdr)
     if len(tagged):
+        mv, base = memoryview(body), len(hdr)
         pieces, at = [], 0
         for i in tagged.tolist():
             r = int(kept[i])
@@ -162,12 +166,12 @@ def _step2_scanned(text: bytes, engine, contig_names, editing_keys, pon_sr_keys,
             for on, t in ((hits[0][i], b"RNA_editing_db"), (close[i] > 0, b"Clustered"), (hits[1][i], b"PoN_SR"), (hits[2][i], b"PoN_LR")):
                 if on:
                     F = t if F == b"PASS" else F + b"," + t
-            pieces.append(body[at:int(new_off[i])])
+            pieces.append(mv[at:base + int(new_off[i])])
             pieces.append(_blank_na_fields(line[:fo] + F + line[fo + fl:]) + b"\n")
-            at = int(new_off[i + 1])
-        pieces.append(body[at:])
+            at = base + int(new_off[i + 1])
+        pieces.append(mv[at:])
         body = b"".join(pieces)
-    return b"\n".join(comments + [headers[-1]]) + b"\n" + body
+    return body
 
 
 def step2_bytes(step1_text: bytes, engine, contig_names: Sequence[str], editing_keys, pon_sr_keys, pon_lr_keys, distance: int = 0,
@@ -468,12 +472,12 @@ def step3(step2_text, delta_vaf: float, delta_mcf: float, min_ac_reads: int, min
             # the row functions, the drops, the cluster filter and the two tables natively (csrc/hostio/tsvstep3.cpp); None = a table whose
             # printed form could depend on pandas' dtypes, or on which a row function raises: the pandas path below decides
             from . import tsvio
-            done = tsvio.step3_rows(survivors, cols, delta_vaf, delta_mcf, min_ac_reads, min_ac_cells, clust_dist, all_kinds=all_kinds)
+            header = head + "\t".join(cols + ["STEP3FILTER", "INDEX"]) + "\n"
+            done = tsvio.step3_rows(survivors, cols, delta_vaf, delta_mcf, min_ac_reads, min_ac_cells, clust_dist, all_kinds=all_kinds, prefix=header.encode())
             if done is not None:
-                header = head + "\t".join(cols + ["STEP3FILTER", "INDEX"]) + "\n"
                 if _as_bytes:
-                    return header.encode() + done[1], header.encode() + done[0]
-                return header + done[1].decode(), header + done[0].decode()
+                    return done[1], done[0]
+                return done[1].decode(), done[0].decode()
     df = pd.read_csv(io.BytesIO(step2_text) if as_bytes else io.StringIO(step2_text), sep="\t", comment="#", names=cols,
                      dtype=None if full_parse else dtypes)
     df = df[df["Cell_types"] != "Non-Cancer"]

@@ -235,7 +235,7 @@ def kinds_dtype_sensitive(kinds: np.ndarray) -> bool:
     return bool(np.any(num & (((k & KIND_ODD) != 0) | (((k & KIND_INT) != 0) & ((k & (KIND_NA | KIND_FLOAT)) != 0)))))
 
 
-def step3_rows(rows: bytes, cols, delta_vaf: float, delta_mcf: float, min_ac_reads: int, min_ac_cells: int, clust_dist: int, all_kinds=None):
+def step3_rows(rows: bytes, cols, delta_vaf: float, delta_mcf: float, min_ac_reads: int, min_ac_cells: int, clust_dist: int, all_kinds=None, prefix: bytes = b""):
     """lsio_step3_rows (csrc/hostio/tsvstep3.cpp) over the surviving rows of a step-2 table whose header is `cols`: (rows of the
     unfiltered table, rows of the final table) as bytes, or None when the table is one for the pandas path.  all_kinds: column_kinds of
     the WHOLE table the rows were taken from (the dropped rows' cells decide pandas' dtypes too)."""
@@ -261,14 +261,15 @@ def step3_rows(rows: bytes, cols, delta_vaf: float, delta_mcf: float, min_ac_rea
     if rc != 0:
         raise RuntimeError(lib.lsio_step3_last_error().decode("utf-8", "replace"))
     try:
-        return _take_bytes(a.value, na.value), _take_bytes(b.value, nb.value)
+        return _take_bytes(a.value, na.value, prefix), _take_bytes(b.value, nb.value, prefix)       # (prefix: the tables' header, so that nobody concatenates a gigabyte afterwards)
     finally:
         lib.lsio_free_text(a); lib.lsio_free_text(b)
 
 
-def gather_lines(text: bytes, off: np.ndarray, length: np.ndarray, blank_na: bool = False, threads: int = 0):
-    """(the lines text[off[i] : off[i] + length[i]] + b"\\n", concatenated; start of every line in the result, n + 1 entries).
-    blank_na: fields other than a line's first that are exactly "NA" come out empty (lsio_gather_lines)."""
+def gather_lines(text: bytes, off: np.ndarray, length: np.ndarray, blank_na: bool = False, threads: int = 0, prefix: bytes = b""):
+    """(prefix + the lines text[off[i] : off[i] + length[i]] + b"\\n", concatenated; start of every line BEHIND the prefix, n + 1 entries).
+    blank_na: fields other than a line's first that are exactly "NA" come out empty (lsio_gather_lines).  prefix: a table's header, so
+    that nobody concatenates gigabytes to it afterwards."""
     import ctypes as C
     lib = _io()
     off = np.ascontiguousarray(off, np.int64); length = np.ascontiguousarray(length, np.int32)
@@ -279,7 +280,7 @@ def gather_lines(text: bytes, off: np.ndarray, length: np.ndarray, blank_na: boo
     if rc != 0:
         raise RuntimeError("lsio_gather_lines: %s" % lib.lsio_scan_last_error().decode("utf-8", "replace"))
     try:
-        return _take_bytes(txt.value, ln.value), new_off
+        return _take_bytes(txt.value, ln.value, prefix), new_off
     finally:
         lib.lsio_free_text(txt)
 
@@ -298,12 +299,29 @@ def write_bytes(path: str, data: bytes, threads: int = 0) -> None:
     _check(lib, lib.lsio_write_bytes(os.fsencode(path), data, len(data), threads), "lsio_write_bytes")
 
 
-def _take_bytes(ptr, n: int) -> bytes:
-    """n bytes at ptr as a bytes object (ctypes.string_at takes a C int: the kept rows of a 10 M-read step-1 table are 2.7 GB)"""
+def _take_bytes(ptr, n: int, prefix: bytes = b"") -> bytes:
+    """prefix + the n bytes at ptr as a bytes object (ctypes.string_at takes a C int: the kept rows of a 10 M-read step-1 table are
+    2.7 GB).  Large ones are copied by the host's threads into a bytes object made for them (lsio_copy_bytes): one thread's copy of 2.7 GB
+    into fresh pages is a second of wall, and a `header + rows` afterwards another."""
     import ctypes as C
     if not n:
-        return b""
-    return bytes(memoryview((C.c_char * n).from_address(ptr)))
+        return bytes(prefix)
+    if n < (1 << 24):
+        return bytes(prefix) + bytes(memoryview((C.c_char * n).from_address(ptr)))
+    lib = _io()
+    api = C.pythonapi
+    api.PyBytes_FromStringAndSize.restype = C.py_object
+    api.PyBytes_FromStringAndSize.argtypes = [C.c_void_p, C.c_ssize_t]
+    api.PyBytes_AsString.restype = C.c_void_p
+    api.PyBytes_AsString.argtypes = [C.py_object]
+    out = api.PyBytes_FromStringAndSize(None, len(prefix) + n)            # (uninitialised: filled below before anybody else sees it)
+    at = api.PyBytes_AsString(out)
+    if prefix:
+        C.memmove(at, prefix, len(prefix))
+    lib.lsio_copy_bytes.restype = C.c_int
+    lib.lsio_copy_bytes.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
+    lib.lsio_copy_bytes(at + len(prefix), ptr, n, 0)
+    return out
 
 
 def _check(lib, rc, what):
@@ -379,10 +397,10 @@ def write_step1_tsv(path, calls, per_ct, contig_names, celltype_names, header_li
     if not collect:
         return None
     try:
-        rows = _take_bytes(txt.value, ln.value)
+        rows = _take_bytes(txt.value, ln.value, head.encode() if as_bytes else b"")      # (the header in front from the start: no `head + 2.7 GB` afterwards)
     finally:
         lib.lsio_free_text(txt)
-    return head.encode() + rows if as_bytes else head + rows.decode()
+    return rows if as_bytes else head + rows.decode()
 
 
 def step1_kept_rows(calls, per_ct, contig_names, celltype_names, header_lines: List[str], threads: int = 0, as_bytes: bool = True):
