@@ -391,6 +391,30 @@ def _step3_survivors(text: bytes, i_ct: int) -> Optional[bytes]:
     return tsvio.gather_lines(text, sc.off[keep], sc.len[keep])[0]
 
 
+class _SurvivorsAhead:
+    """_step3_survivors of a table on a thread of its own, started before the caller knows whether it will want them"""
+
+    def __init__(self, text: bytes, cols):
+        import threading
+        self.i_ct = cols.index("Cell_types") if cols and "Cell_types" in cols else 6
+        self.out, self.err = None, None
+
+        def work():
+            try:
+                self.out = _step3_survivors(text, self.i_ct)
+            except BaseException as e:                        # noqa: BLE001 - raised again in result()
+                self.err = e
+        self.th = threading.Thread(target=work, daemon=True)
+        self.th.start()
+
+    def result(self, i_ct: int):
+        self.th.join()
+        if self.err is not None:
+            raise self.err
+        assert i_ct == self.i_ct
+        return self.out
+
+
 def step3_bytes(step2_text, delta_vaf: float, delta_mcf: float, min_ac_reads: int, min_ac_cells: int, clust_dist: int, all_kinds=None, full_text=None):
     """step3 with both tables as bytes (what the fused pipeline writes: at C2's size the unfiltered table is 0.8 GB, not worth a decode
     and an encode).  all_kinds / full_text: see step3."""
@@ -431,8 +455,13 @@ def step3(step2_text, delta_vaf: float, delta_mcf: float, min_ac_reads: int, min
     dtypes = None
     if not full_parse and cols:
         from . import tsvio as _tsvio
+        early_survivors = None
         if all_kinds is None:
-            all_kinds = _tsvio.column_kinds(step2_text if as_bytes else step2_text.encode(), len(cols))
+            # (the survivors of the table - what the common case parses next - are found beside this pass, on a thread of their own: both are
+            # native passes over the same gigabytes that leave the interpreter alone)
+            tb = step2_text if as_bytes else step2_text.encode()
+            early_survivors = _SurvivorsAhead(tb, cols) if len(tb) > int(os.environ.get("LONGSOM_STEP3_AHEAD_MIN", str(1 << 26))) and os.environ.get("LONGSOM_STEP3_ROW_PATH", "0") != "1" else None
+            all_kinds = _tsvio.column_kinds(tb, len(cols))
         k = np.asarray(all_kinds, np.uint8)
         numeric = (k & _tsvio.KIND_OTHER) == 0
         if np.any(numeric & ((k & _tsvio.KIND_ODD) != 0)):
@@ -450,7 +479,7 @@ def step3(step2_text, delta_vaf: float, delta_mcf: float, min_ac_reads: int, min
         i_ct = cols.index("Cell_types") if cols and "Cell_types" in cols else 6
         survivors = None
         if os.environ.get("LONGSOM_STEP3_ROW_PATH", "0") != "1":
-            survivors = _step3_survivors(step2_text if as_bytes else step2_text.encode(), i_ct)
+            survivors = early_survivors.result(i_ct) if cols and early_survivors is not None else _step3_survivors(step2_text if as_bytes else step2_text.encode(), i_ct)
         if survivors is None:
             dead_m, dead_o = re.compile(_DEAD_M), re.compile(_DEAD_O)
             keep_lines = []
