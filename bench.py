@@ -447,7 +447,7 @@ def main():
         re_walk_ms += eng.count_stats().ms_walk
     torch.cuda.synchronize()
     recount_ms = (time.perf_counter() - t_re) / max(n_re, 1) * 1e3 if n_re else None
-    if n_re and not os.environ.get("LSG_TG_DEBUG"):                 # (kernel timing experiments give wrong counts on purpose)
+    if n_re:
         assert (re_rows, re_cols, re_sites, re_cand) == (rows, cols, n_sites, n_cand), "a re-count of the resident store differs from the first count"
     if os.environ.get("LSG_BENCH_STATS"):                           # the last step's counters, for whoever tunes the kernels
         print({f: (list(getattr(st, f)) if f.endswith("by_kernel") else getattr(st, f)) for f, _ in st._fields_ if f != "pad_"}, file=sys.stderr)

@@ -721,7 +721,6 @@ struct TgArgs {
     uint32_t* s0; uint8_t* b8; uint32_t* rd; uint4* store; uint16_t* ext;
     const uint32_t* nchunks;                                          // the plan's number of chunks, still on the device
     unsigned long long* queues;                                       // k_tm_count_direct: the XCDs' job queues, 128 bytes apart (zeroed before the launch)
-    int dbg;                                                          // timing experiments (LSG_TG_DEBUG; results are wrong): 1 no counting, 2 no block stores, 4 no event loads, 8 no LDS crossing
     unsigned long long* stat_slots;
 };
 typedef uint32_t tg_u32x4 __attribute__((ext_vector_type(4)));
@@ -805,7 +804,7 @@ __device__ __forceinline__ void tg_range(const CountArgs& a, const TmArgs& tm, c
             const int64_t A = (int64_t)(int8_t)(inf & 0xffu) * (1ll << 32) + (int64_t)lo32 + c8;      // (abase may be a little below zero: its bits 32..39 sign-extended)
             if (__builtin_expect(!edge, 1)) {
                 // chunks nobody needs read the array's first line (one cached line, no branch: the compiler can count the loads in flight)
-                chunk[q] = reinterpret_cast<const TgU4A2*>(tg.events + (need && !(tg.dbg & 4) ? A : 0))->v;
+                chunk[q] = reinterpret_cast<const TgU4A2*>(tg.events + (need ? A : 0))->v;
             } else {
                 uint32_t w[4] = {0u, 0u, 0u, 0u};
                 if (need)
@@ -845,7 +844,7 @@ __device__ __forceinline__ void tg_range(const CountArgs& a, const TmArgs& tm, c
 #pragma unroll
         for (int uu = 0; uu < 8; ++uu) e[uu] = xt[q][uu][lane];
         const tg_u32x4 row = {e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16)};
-        if ((b0 + blk) * 8 >= s0r && !(tg.dbg & 2)) {                     // this range writes the block: the rows of its extent
+        if ((b0 + blk) * 8 >= s0r) {                     // this range writes the block: the rows of its extent
             const uint32_t x = rl(xe, q * 8), first = x & 0xffu, last = x >> 8;
             if ((uint32_t)lane - first < last - first) __builtin_nontemporal_store(row, reinterpret_cast<tg_u32x4*>(tg.store) + (uint64_t)(b0 + blk) * 64 + lane);
             if (lane == 0) tg.ext[b0 + blk] = (uint16_t)x;
@@ -895,7 +894,7 @@ __device__ __forceinline__ void tg_range(const CountArgs& a, const TmArgs& tm, c
         for (int q = 0; q < TM_GROUP; ++q) {
             if ((uint32_t)g * TM_GROUP + q >= nblk) break;
             const tg_u32x4 row = block_row(g, q, xe_g);
-            if (counting && !(tg.dbg & 1)) consume_block(q, row, Mc);
+            if (counting) consume_block(q, row, Mc);
         }
         lds_fence();                                          // the tile is read before the next group's chunks are written into it
     }
@@ -1583,7 +1582,6 @@ int run_gather_count(lsg_ctx* c, const lsg_count_params* p, const GatherCountSrc
     tg.s0 = c->tm[TM_S0].as<uint32_t>(); tg.b8 = c->tm[TM_B].as<uint8_t>(); tg.rd = c->tm[TM_RD].as<uint32_t>();
     tg.store = c->tm[TM_STORE].as<uint4>(); tg.ext = c->tm[TM_EXT].as<uint16_t>();
     tg.nchunks = c->d_plan_misc + 1; tg.stat_slots = c->d_ix_stat.as<unsigned long long>();
-    tg.dbg = getenv("LSG_TG_DEBUG") ? atoi(getenv("LSG_TG_DEBUG")) : 0;
     L.tm.ct_base = 0;
     const bool dbg = getenv("LSG_DEBUG_SYNC") != nullptr;
     auto stage = [&](const char* what) { if (dbg) { const hipError_t e = hipStreamSynchronize(st); fprintf(stderr, "[lsg] fused load: %s: %s\n", what, hipGetErrorString(e)); fflush(stderr); } };

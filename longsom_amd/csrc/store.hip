@@ -729,22 +729,11 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
         if (split_sort) LSG_HIP(hipEventRecord(c->ev_copy, st));      // (the second sort, queued below, starts here)
         size_t tb = 0;
         // (64-bit keys sorted on their barcode bits only, begin_bit 0 .. end_bit `bits`: the rest of the key is payload)
-        static const int cfg = getenv("LSG_SORT_CFG") ? atoi(getenv("LSG_SORT_CFG")) : 0;
+        // (one configuration: 7 bits per pass, 256 x 8 items in the block sort - the sweep over 512 / 1024 threads, 4-16 items and 8 bits per pass
+        // that used to be selectable here found nothing faster, and cost a minute of compile time)
         auto sort = [&](void* tmp_p, size_t& tmp_n) {
-#define LSG_SORT_CALL(RB, BS, IPT) lsg_segmented_sort<RB, BS, IPT>(tmp_p, tmp_n, key_a.as<uint64_t>(), key_b.as<uint64_t>(), val_a.as<uint32_t>(), val_b.as<uint32_t>(), (unsigned)N, (unsigned)n_netile, \
-                                                      sb1, se1, 0u, (unsigned)bits, st, false)
-            switch (cfg) {
-                case 1: return LSG_SORT_CALL(7, 256, 16);
-                case 2: return LSG_SORT_CALL(7, 512, 8);
-                case 3: return LSG_SORT_CALL(7, 512, 16);
-                case 4: return LSG_SORT_CALL(7, 1024, 8);
-                case 5: return LSG_SORT_CALL(8, 256, 16);
-                case 6: return LSG_SORT_CALL(8, 512, 8);
-                case 7: return LSG_SORT_CALL(7, 1024, 4);
-                case 8: return LSG_SORT_CALL(8, 256, 8);
-                default: return LSG_SORT_CALL(7, 256, 8);
-            }
-#undef LSG_SORT_CALL
+            return lsg_segmented_sort<7, 256, 8>(tmp_p, tmp_n, key_a.as<uint64_t>(), key_b.as<uint64_t>(), val_a.as<uint32_t>(), val_b.as<uint32_t>(), (unsigned)N, (unsigned)n_netile,
+                                                 sb1, se1, 0u, (unsigned)bits, st, false);
         };
         LSG_HIP(sort(nullptr, tb));
         if (tmp.reserve(tb + 256)) return -1;
