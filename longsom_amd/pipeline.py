@@ -237,19 +237,32 @@ def chain_step1(res: Resident, celltype_of: np.ndarray, celltype_names: List[str
 
     def count_tables():
         for ct, name in enumerate(celltype_names):
+            t1 = time.time()
             tsvio.write_counts_tsv(out.counts[name], *per_ct[ct], contig_names, "%s.%s" % (sample_id, name), date)
+            t["table_counts_" + name] = time.time() - t1        # (seconds of the writer itself, in the background when background_tables)
+
+    def merged_table():
+        t1 = time.time()
         tsvio.write_merged_tsv(out.merged, per_ct, contig_names, celltype_names, date)
+        t["table_merged"] = time.time() - t1
     header = [l + "\n" for l in tsvio.merged_header(celltype_names, date).split("\n") if l.startswith("##")]
     if background_tables:
         # Steps 2 and 3 only need the rows step 2 keeps: those are formatted first (a third of the step-1 table's rows, nothing written);
         # the per-cell-type and merged tables and the step-1 table itself are written by threads of their own (native writers, no GIL)
         # beside steps 2 and 3 - the box's disk takes several files at once faster than one: the caller joins them (SnvOutputs.wait_for_tables)
         s1 = tsvio.step1_kept_rows(calls, per_ct, contig_names, celltype_names, header, as_bytes=True)
-        out.start_background(count_tables)
-        out.start_background(lambda: tsvio.write_step1_tsv(out.step1, calls, per_ct, contig_names, celltype_names, header, collect=False))
+        # (the merged table behind the count tables on ONE thread: a third writer beside steps 2 and 3 made every one of them slower - the
+        # host's threads are all busy - and the run no shorter)
+        out.start_background(lambda: (count_tables(), merged_table()))
+        def step1_table():
+            t1 = time.time()
+            tsvio.write_step1_tsv(out.step1, calls, per_ct, contig_names, celltype_names, header, collect=False)
+            t["table_step1"] = time.time() - t1
+        out.start_background(step1_table)
         t["write_tables"] = time.time() - t0          # (what the chain waited for: the kept rows; tables_wait is what was left of the writers at the end)
         return out, s1, calls, t
     count_tables()
+    merged_table()
     s1 = tsvio.write_step1_tsv(out.step1, calls, per_ct, contig_names, celltype_names, header, as_bytes=True)      # s1 = header + the rows step 2 keeps
     t["write_tables"] = time.time() - t0
     return out, s1, calls, t
