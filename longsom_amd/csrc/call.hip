@@ -59,7 +59,8 @@ struct CallArgs {
     unsigned long long* counters;     // CT_*: candidate blocks allocated, candidate sites (exact), light / heavy tail task slots, heads, ...
     uint32_t arena_waves;             // waves of k_call_gather (each owns chunk number `wave` of every arena list)
     const uint32_t* heads;            // units that are the first of a tile with at least one site
-    uint32_t* head_recs;              // 16 words per head: unit, first site index, tile start, tid, masks[4] (lo, hi), row bases[4]
+    uint64_t* head_ref;               // the head's contig's reference bases (address), prefetched beside its record
+    uint32_t* head_recs;              // 16 words per head: contig length, first site index, tile start, tid, masks[4] (lo, hi), row bases[4]
     uint32_t* defer_list;             // sites with a tail still to be computed (k_call_gather appends, counters[CT_DEFER] counts): k_call_finish's work
     uint64_t defer_cap;
 };
@@ -173,8 +174,9 @@ __global__ void k_head_recs(CallArgs a) {
         mask[ct] = a.ne_mask[q]; rbase[ct] = a.ne_rowbase[q];
     }
     const int2 geom = a.ne_geom[w];
+    a.head_ref[i] = (uint64_t)(uintptr_t)a.ref_ptr[geom.y & 0xffffff];
     uint32_t* r = a.head_recs + (uint64_t)i * 16;
-    r[0] = w; r[1] = a.site_off[w]; r[2] = (uint32_t)geom.x; r[3] = (uint32_t)geom.y;
+    r[0] = (uint32_t)a.contig_len[geom.y & 0xffffff]; r[1] = a.site_off[w]; r[2] = (uint32_t)geom.x; r[3] = (uint32_t)geom.y;
     for (int ct = 0; ct < LSG_MAX_CELLTYPES; ++ct) { r[4 + 2 * ct] = (uint32_t)mask[ct]; r[5 + 2 * ct] = (uint32_t)(mask[ct] >> 32); r[12 + ct] = rbase[ct]; }
 }
 
@@ -188,7 +190,7 @@ constexpr uint32_t CAND_CHUNK = 256, TASK_CHUNK = 64, HEAVY_CHUNK = 16;   // hea
 template <int NCT>
 __global__ __launch_bounds__(GATHER_WAVES * 64) __attribute__((amdgpu_waves_per_eu(NCT <= 2 ? 4 : 3))) void k_call_gather(CallArgs a) {
     const int lane = threadIdx.x & 63;
-    const uint32_t wave = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6));   // (uniform, and known to be: the head records below are scalar loads)
     const uint32_t n_waves = (uint32_t)(((uint64_t)gridDim.x * blockDim.x) >> 6);
     const uint32_t n_heads = (uint32_t)a.counters[CT_HEADS];
     // arenas: every wave starts with chunk number `wave` of each list (no storm of same-line atomics at launch); the
@@ -199,11 +201,14 @@ __global__ __launch_bounds__(GATHER_WAVES * 64) __attribute__((amdgpu_waves_per_
     uint32_t n_cand_exact = 0;
     typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
     const __attribute__((address_space(4))) u32x16* H = (const __attribute__((address_space(4))) u32x16*)(uintptr_t)a.head_recs;
+    const __attribute__((address_space(4))) uint64_t* HR = (const __attribute__((address_space(4))) uint64_t*)(uintptr_t)a.head_ref;
     u32x16 nxt = {};
-    if (wave < n_heads) nxt = H[wave];
+    uint64_t ref_nxt = 0;
+    if (wave < n_heads) { nxt = H[wave]; ref_nxt = HR[wave]; }
     for (uint32_t hi_ = wave; hi_ < n_heads; hi_ += n_waves) {
     const u32x16 rec = nxt;
-    if (hi_ + n_waves < n_heads) nxt = H[hi_ + n_waves];      // the next tile's record travels while this tile is worked on
+    const uint8_t* ref = reinterpret_cast<const uint8_t*>((uintptr_t)ref_nxt);
+    if (hi_ + n_waves < n_heads) { nxt = H[hi_ + n_waves]; ref_nxt = HR[hi_ + n_waves]; }      // the next tile's record travels while this tile is worked on
     uint64_t mask[NCT];
     uint32_t rbase[NCT];
     uint64_t any = 0;
@@ -215,38 +220,68 @@ __global__ __launch_bounds__(GATHER_WAVES * 64) __attribute__((amdgpu_waves_per_
     const int2 geom = make_int2((int)rec[2], (int)rec[3]);
     const int tid = geom.y & 0xffffff;
     const int64_t pos = (int64_t)geom.x + lane;
-    const uint8_t* ref = a.ref_ptr[tid];
-    const uint8_t refb = site ? ref[pos] : (uint8_t)'N';
+    // Every load of the tile is issued here, before anything is waited for (they used to sit in branches and loops that each
+    // ended in a wait: reference base, one cell type's rows, the other's, then the ten context bytes one round trip at a time).
+    // The reference: lane l reads the base of its own position, lanes 0..9 also the five bases either side of the tile; the
+    // homopolymer context of every lane (step1.py:95-107) is cut from those 74 bases below without another load.
+    const int64_t clen = (int64_t)rec[0];
+    const int64_t gx = (int64_t)geom.x;
+    const int64_t xpos = lane < 5 ? gx - 5 + lane : gx + 59 + lane;          // lanes 5..9: gx + 64 .. gx + 68
+    const bool r0_ok = pos < clen, r1_ok = lane < 10 && xpos >= 0 && xpos < clen;
+    const uint8_t r0_raw = ref[r0_ok ? pos : 0], r1_raw = ref[r1_ok ? xpos : 0];
+    // rows: planes 0..15 = DP, NC, CC[0..7], BC[0..5] in four 16-byte loads (quad k at 256 words from quad k - 1); a narrow row
+    // (small unit) holds the same planes as 16-bit values, 8 bytes a quad at 128 words: read with the same 16-byte loads (the
+    // upper half is not used).  A lane without a row reads row `lane` of block 0, so that no load sits in a branch.
+    struct __attribute__((packed, aligned(4))) Quad { uint32_t x, y, z, w; };
+    Quad q[NCT][4];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+        const bool has_row = site && ((mask[ct] >> lane) & 1ull);
+        const uint64_t row = has_row ? (uint64_t)(rbase[ct] & ~ROW_NARROW) + __popcll(mask[ct] & below) : (uint64_t)lane;
+        const bool narrow = has_row && (rbase[ct] & ROW_NARROW);
+        const char* R = reinterpret_cast<const char*>(a.rows[ct] + (row >> 6) * ROW_BLOCK_WORDS) + (narrow ? (row & 63) * 8 : (row & 63) * 16);
+        const uint32_t stride = narrow ? 512u : 1024u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q[ct][k] = *reinterpret_cast<const Quad*>(R + k * stride);
+    }
+    const uint8_t r0 = r0_ok ? r0_raw : (uint8_t)0, r1 = r1_ok ? r1_raw : (uint8_t)0;
+    const uint8_t refb = site ? r0 : (uint8_t)'N';
     const int rsym = sym_of_ref(refb);
     const lsg_call_params& P = a.p;
     const int order[4] = {0, 1, 3, 2};              // letter order A < C < G < T over classes (A,C,T,G) = (0,1,2,3)
-
-    // all loads first (independent, one latency): DP, NC, CC[0..5], BC[0..5] of every present cell type
     uint32_t v_dp[NCT], v_nc[NCT], v_cc[NCT][6], v_bc[NCT][6];
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) {
-        v_dp[ct] = 0; v_nc[ct] = 0;
-#pragma unroll
-        for (int s = 0; s < 6; ++s) { v_cc[ct][s] = 0; v_bc[ct][s] = 0; }
-        if (site && ((mask[ct] >> lane) & 1ull)) {
-            const uint64_t row = (uint64_t)(rbase[ct] & ~ROW_NARROW) + __popcll(mask[ct] & below);
-            // planes 0..15 of the row = DP, NC, CC[0..7], BC[0..5] in four 16-byte loads (quad q at 256 words from quad q - 1);
-            // a narrow row (small unit): the same planes as 16-bit values, four 8-byte loads
-            uint4 q0, q1, q2, q3;
-            if (rbase[ct] & ROW_NARROW) {
-                const uint2* R = reinterpret_cast<const uint2*>(a.rows[ct] + (row >> 6) * ROW_BLOCK_WORDS) + (row & 63);
-                const uint2 h0 = R[0], h1 = R[64], h2 = R[128], h3 = R[192];
-                q0 = make_uint4(h0.x & 0xffffu, h0.x >> 16, h0.y & 0xffffu, h0.y >> 16); q1 = make_uint4(h1.x & 0xffffu, h1.x >> 16, h1.y & 0xffffu, h1.y >> 16);
-                q2 = make_uint4(h2.x & 0xffffu, h2.x >> 16, h2.y & 0xffffu, h2.y >> 16); q3 = make_uint4(h3.x & 0xffffu, h3.x >> 16, h3.y & 0xffffu, h3.y >> 16);
-            } else {
-                const uint4* R = reinterpret_cast<const uint4*>(a.rows[ct] + row_word(row, 0));
-                q0 = R[0]; q1 = R[64]; q2 = R[128]; q3 = R[192];
-            }
-            v_dp[ct] = q0.x; v_nc[ct] = q0.y;
-            v_cc[ct][0] = q0.z; v_cc[ct][1] = q0.w; v_cc[ct][2] = q1.x; v_cc[ct][3] = q1.y; v_cc[ct][4] = q1.z; v_cc[ct][5] = q1.w;
-            v_bc[ct][0] = q2.z; v_bc[ct][1] = q2.w; v_bc[ct][2] = q3.x; v_bc[ct][3] = q3.y; v_bc[ct][4] = q3.z; v_bc[ct][5] = q3.w;
+        uint4 q0 = make_uint4(q[ct][0].x, q[ct][0].y, q[ct][0].z, q[ct][0].w), q1 = make_uint4(q[ct][1].x, q[ct][1].y, q[ct][1].z, q[ct][1].w);
+        uint4 q2 = make_uint4(q[ct][2].x, q[ct][2].y, q[ct][2].z, q[ct][2].w), q3 = make_uint4(q[ct][3].x, q[ct][3].y, q[ct][3].z, q[ct][3].w);
+        if (rbase[ct] & ROW_NARROW) {
+            q0 = make_uint4(q0.x & 0xffffu, q0.x >> 16, q0.y & 0xffffu, q0.y >> 16); q1 = make_uint4(q1.x & 0xffffu, q1.x >> 16, q1.y & 0xffffu, q1.y >> 16);
+            q2 = make_uint4(q2.x & 0xffffu, q2.x >> 16, q2.y & 0xffffu, q2.y >> 16); q3 = make_uint4(q3.x & 0xffffu, q3.x >> 16, q3.y & 0xffffu, q3.y >> 16);
         }
+        v_dp[ct] = q0.x; v_nc[ct] = q0.y;
+        v_cc[ct][0] = q0.z; v_cc[ct][1] = q0.w; v_cc[ct][2] = q1.x; v_cc[ct][3] = q1.y; v_cc[ct][4] = q1.z; v_cc[ct][5] = q1.w;
+        v_bc[ct][0] = q2.z; v_bc[ct][1] = q2.w; v_bc[ct][2] = q3.x; v_bc[ct][3] = q3.y; v_bc[ct][4] = q3.z; v_bc[ct][5] = q3.w;
     }
+    // the context: E bit i says "the base at gx - 5 + i equals the one before it" (wave-uniform, 74 bits); a lane's upstream
+    // five are positions pos-5..pos-1 (comparisons E[lane+1..lane+4]), its downstream five pos+1..pos+5 (E[lane+7..lane+10])
+    const uint32_t prev0 = (uint32_t)__shfl_up((int)r0, 1), prev1 = (uint32_t)__shfl_up((int)r1, 1), next0 = (uint32_t)__shfl_down((int)r0, 1);
+    const uint64_t eq0 = __ballot(lane > 0 && r0 == (uint8_t)prev0), eq1 = __ballot(lane > 0 && lane != 5 && lane < 10 && r1 == (uint8_t)prev1);
+    const uint32_t r1_4 = (uint32_t)__builtin_amdgcn_readlane((int)r1, 4), r1_5 = (uint32_t)__builtin_amdgcn_readlane((int)r1, 5);
+    const uint32_t r0_0 = (uint32_t)__builtin_amdgcn_readlane((int)r0, 0), r0_63 = (uint32_t)__builtin_amdgcn_readlane((int)r0, 63);
+    // X = E >> 1 as (xlo, xhi): bit j of X is E[j + 1]
+    const uint64_t e_lo = (eq1 & 0x1eull) | ((uint64_t)(r0_0 == r1_4) << 5) | (eq0 << 5);                       // E[0..63]: eq0 bit l -> i = l + 5
+    const uint64_t e_hi = (eq0 >> 59) | ((uint64_t)(r1_5 == r0_63) << 5) | (((eq1 >> 6) & 0xfull) << 6);        // E[64..73]: i - 64
+    const uint64_t xlo = (e_lo >> 1) | (e_hi << 63), xhi = e_hi >> 1;
+    const uint32_t xw = (uint32_t)((xlo >> lane) | (lane ? xhi << (64 - lane) : 0ull));                         // bit j = E[lane + 1 + j]
+    const bool have_ctx = pos >= 5;
+    int down_len = (int)((clen - (pos + 1)) < 5 ? (clen - (pos + 1)) : 5);
+    if (down_len < 0) down_len = 0;
+    const uint32_t ue = xw & 15u;                                             // up[1]==up[0], .., up[4]==up[3]
+    const uint32_t de = down_len > 0 ? (xw >> 6) & ((1u << (down_len - 1)) - 1u) : 0u;   // down[1]==down[0], .. (only inside the contig)
+    auto longest = [](uint32_t m) { const uint32_t m2 = m & (m >> 1), m3 = m2 & (m >> 2), m4 = m3 & (m >> 3); return (int)((m != 0) + (m2 != 0) + (m3 != 0) + (m4 != 0)); };
+    const int up_best = 1 + longest(ue), up_run = 1 + (int)__builtin_clz((((~ue) & 15u) << 28) | (1u << 27));    // run that ends in up[4]
+    const int dn_best = 1 + longest(de), dn_run = 1 + (int)__builtin_ctz((~de) | 16u);                         // run that starts at down[0]
+    const uint8_t up4 = lane ? (uint8_t)prev0 : (uint8_t)r1_4, dn0 = lane < 63 ? (uint8_t)next0 : (uint8_t)r1_5;
     // pass 1: candidate? number of tail tasks?  (one wave-aggregated allocation each)
     bool has_any = false;
     uint32_t n_light = 0, n_heavy = 0;
@@ -278,9 +313,11 @@ __global__ __launch_bounds__(GATHER_WAVES * 64) __attribute__((amdgpu_waves_per_
     }
     const unsigned long long cm = __ballot(has_any);
     // wave-inclusive prefix sums of the task counts
-    uint32_t pl = n_light, ph = n_heavy;
-    for (int o = 1; o < 64; o <<= 1) { const uint32_t vl = __shfl_up(pl, o), vh = __shfl_up(ph, o); if (lane >= o) { pl += vl; ph += vh; } }
-    const uint32_t tot_l = __shfl(pl, 63), tot_h = __shfl(ph, 63);
+    uint32_t pl = n_light, ph = n_heavy, tot_l = 0, tot_h = 0;
+    if (__ballot((n_light | n_heavy) != 0u)) {                 // (most tiles ask the table only)
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t vl = __shfl_up(pl, o), vh = __shfl_up(ph, o); if (lane >= o) { pl += vl; ph += vh; } }
+        tot_l = __shfl(pl, 63); tot_h = __shfl(ph, 63);
+    }
     // wave-private arenas
     const uint32_t n_c = (uint32_t)__popcll(cm);
     n_cand_exact += n_c;
@@ -309,8 +346,26 @@ __global__ __launch_bounds__(GATHER_WAVES * 64) __attribute__((amdgpu_waves_per_
     const uint32_t cand = cbase + (uint32_t)__popcll(cm & below);
     uint32_t li = pl - n_light, hi = ph - n_heavy;           // this lane's first slot, as an offset into the wave's request
     // loc = the field of the record still being assembled in registers (stored whole afterwards), dst = the same field in memory
-    auto emit_task = [&](uint32_t k, uint32_t n, int set, int16_t* dst, int16_t* loc) {
-        if (tail_in_table(k, n)) { *loc = a.tail_table[(uint32_t)set * TAIL_ENTRIES + tail_index(k, n)]; return; }
+    // every tail the table can answer is read here, all of them at once (looked up where they are used, each was a round trip of
+    // its own: up to 18 in a row); a pair outside the table reads entry 0 and becomes a task below
+    const int16_t* TT = a.tail_table;
+    auto table_at = [&](uint32_t k, uint32_t n, int set) { return TT[tail_in_table(k, n) ? (uint32_t)set * TAIL_ENTRIES + tail_index(k, n) : 0u]; };
+    int16_t t_bc[NCT][4], t_cc[NCT][4];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { t_bc[ct][s] = 0; t_cc[ct][s] = 0; }
+    }
+    if (cm) {                                                  // (a tile without a candidate has only the noise tails to ask for)
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) { t_bc[ct][s] = table_at(v_bc[ct][s], v_dp[ct], 0); t_cc[ct][s] = table_at(v_cc[ct][s], v_nc[ct], 1); }
+        }
+    }
+    const int16_t t_nb = table_at((uint32_t)s_alts_bc, (uint32_t)s_dp, 0), t_nc = table_at((uint32_t)s_alts_cc, (uint32_t)s_nc, 1);
+    auto emit_task = [&](uint32_t k, uint32_t n, int set, int16_t* dst, int16_t* loc, int16_t from_table) {
+        if (tail_in_table(k, n)) { *loc = from_table; return; }
         TailTask t; t.k = k; t.n = n; t.dst = (uint64_t)dst | (uint64_t)set;
         if (tail_work(k, n) > 64) { const uint32_t p = hi < h_room ? h_old + hi : h_new + (hi - h_room); if (p < a.task_cap) a.heavy[p] = t; ++hi; }
         else { const uint32_t p = li < l_room ? l_old + li : l_new + (li - l_room); if (p < a.task_cap) a.light[p] = t; ++li; }
@@ -323,17 +378,6 @@ __global__ __launch_bounds__(GATHER_WAVES * 64) __attribute__((amdgpu_waves_per_
     int n_considered = 0;
     bool alts_differ = false;
     uint32_t first_altset = 0; bool have_first = false;
-    // homopolymer context (step1.py:95-107): up = ref[pos-5..pos-1], down = ref[pos+1..pos+5]
-    const int64_t clen = a.contig_len[tid];
-    const bool have_ctx = pos >= 5;
-    uint8_t up[5] = {0, 0, 0, 0, 0}, down[5] = {0, 0, 0, 0, 0};
-    int down_len = 0;
-    if (have_ctx) {
-        for (int i = 0; i < 5; ++i) up[i] = ref[pos - 5 + i];
-        down_len = (int)((clen - (pos + 1)) < 5 ? (clen - (pos + 1)) : 5);
-        if (down_len < 0) down_len = 0;
-        for (int i = 0; i < down_len; ++i) down[i] = ref[pos + 1 + i];
-    }
     int lc_up = 0, lc_down = 0;
     SiteRec* srp = &a.sites[idx];
     // every tail of this site came out of the table (n <= TAIL_NT: all but the deepest sites): its filter chains are finished right here;
@@ -364,7 +408,7 @@ __global__ __launch_bounds__(GATHER_WAVES * 64) __attribute__((amdgpu_waves_per_
                     const uint32_t c = v_cc[ct][s];
                     if (na < LSG_CALL_MAX_ALT) {
                         cd.alt[na] = (uint8_t)s; cd.alt_bc[na] = b; cd.alt_cc[na] = c;
-                        if (cdp) { emit_task(b, dp, 0, &cdp->p_bc[na], &cd.p_bc[na]); emit_task(c, nc, 1, &cdp->p_cc[na], &cd.p_cc[na]); }
+                        if (cdp) { emit_task(b, dp, 0, &cdp->p_bc[na], &cd.p_bc[na], t_bc[ct][s]); emit_task(c, nc, 1, &cdp->p_cc[na], &cd.p_cc[na], t_cc[ct][s]); }
                     }
                     ++na; altset |= 1u << s;
                 }
@@ -377,14 +421,12 @@ __global__ __launch_bounds__(GATHER_WAVES * 64) __attribute__((amdgpu_waves_per_
                     if (have_ctx) {
                         int first_s = -1, last_s = -1;
                         for (int oi = 0; oi < 4; ++oi) { const int s = order[oi]; if ((altset >> s) & 1u) { if (first_s < 0) first_s = s; last_s = s; } }
-                        int best = 1, run = 1;                                     // upstream: longestRun(up + x)
-                        for (int i = 1; i < 5; ++i) { run = up[i] == up[i - 1] ? run + 1 : 1; best = run > best ? run : best; }
-                        run = base_of_sym(first_s) == up[4] ? run + 1 : 1; best = run > best ? run : best;
-                        lc_up = best > lc_up ? best : lc_up;
-                        best = 1; run = 1;                                         // downstream: longestRun(x + down)
-                        uint8_t prev = base_of_sym(last_s);
-                        for (int i = 0; i < down_len; ++i) { run = down[i] == prev ? run + 1 : 1; best = run > best ? run : best; prev = down[i]; }
-                        lc_down = best > lc_down ? best : lc_down;
+                        const int u = base_of_sym(first_s) == up4 ? up_run + 1 : 1;             // upstream: longestRun(up + x)
+                        const int ub = u > up_best ? u : up_best;
+                        lc_up = ub > lc_up ? ub : lc_up;
+                        int db = 1;                                                               // downstream: longestRun(x + down)
+                        if (down_len > 0) { const int d = base_of_sym(last_s) == dn0 ? dn_run + 1 : 1; db = d > dn_best ? d : dn_best; }
+                        lc_down = db > lc_down ? db : lc_down;
                     }
                 }
             }
@@ -411,8 +453,8 @@ __global__ __launch_bounds__(GATHER_WAVES * 64) __attribute__((amdgpu_waves_per_
     sr.noise_p_bc = -1; sr.noise_p_cc = -1;
     if (s_alts_bc > 0) {
         sr.noise_p_bc = -2; sr.noise_p_cc = -2;
-        if (s_dp >= 0) emit_task((uint32_t)s_alts_bc, (uint32_t)s_dp, 0, &srp->noise_p_bc, &sr.noise_p_bc);
-        if (s_nc >= 0 && s_alts_cc >= 0) emit_task((uint32_t)s_alts_cc, (uint32_t)s_nc, 1, &srp->noise_p_cc, &sr.noise_p_cc);
+        if (s_dp >= 0) emit_task((uint32_t)s_alts_bc, (uint32_t)s_dp, 0, &srp->noise_p_bc, &sr.noise_p_bc, t_nb);
+        if (s_nc >= 0 && s_alts_cc >= 0) emit_task((uint32_t)s_alts_cc, (uint32_t)s_nc, 1, &srp->noise_p_cc, &sr.noise_p_cc, t_nc);
     }
     // flags that do not depend on p-values; k_call_finish adds the rest
     uint32_t sf = 0;
@@ -744,12 +786,13 @@ static int run_call_sized(lsg_ctx* c, const lsg_call_params* p, uint32_t tasks_p
     const uint32_t n_ne = c->n_ne;
     c->n_sites = 0; c->n_cand = 0; c->n_pass = -1;
     if (n_ne == 0) { c->called = true; return 0; }
-    if (c->d_site_off.reserve((size_t)(n_ne + 2) * 12 + 128 + CT_WORDS * 8 + (size_t)n_ne * 64 + 64)) return -1;     // site_cnt, site_off, counters, heads, head records
+    if (c->d_site_off.reserve((size_t)(n_ne + 2) * 12 + 128 + CT_WORDS * 8 + (size_t)n_ne * 72 + 64)) return -1;     // site_cnt, site_off, counters, heads, head records, their reference pointers
     CallArgs a{};
     a.ne_units = c->d_ne_units.as<uint32_t>(); a.ne_mask = c->d_ne_mask.as<uint64_t>(); a.ne_rowbase = c->d_ne_rowbase.as<uint32_t>();
     a.ne_geom = c->ws[WS_NE_GEOM].as<int2>();
     a.n_ne = n_ne; a.n_ct = c->n_ct;
     for (int i = 0; i < LSG_MAX_CELLTYPES; ++i) a.rows[i] = c->d_rows[i].as<uint32_t>();
+    for (int i = 0; i < c->n_ct; ++i) if (!a.rows[i] || c->d_rows[i].cap < ROW_BLOCK_WORDS * 4) { set_error("lsg_call_step1: a cell type has no row block"); return -2; }   // (k_call_gather reads block 0 for lanes without a row)
     a.row_cap = c->row_cap;
     a.ref_ptr = c->d_ref_ptrs.as<const uint8_t*>(); a.contig_len = c->d_contig_len.as<int64_t>();
     a.p = *p;
@@ -772,6 +815,7 @@ static int run_call_sized(lsg_ctx* c, const lsg_call_params* p, uint32_t tasks_p
     uint32_t* heads = reinterpret_cast<uint32_t*>(a.counters + CT_WORDS);
     a.heads = heads;
     a.head_recs = reinterpret_cast<uint32_t*>((reinterpret_cast<uintptr_t>(heads + n_ne) + 63) & ~(uintptr_t)63);
+    a.head_ref = reinterpret_cast<uint64_t*>(a.head_recs + (size_t)n_ne * 16);
     LSG_HIP(hipMemsetAsync(a.counters, 0, CT_WORDS * 8, st));
     hipLaunchKernelGGL(k_site_count, dim3((n_ne + 256) / 256), dim3(256), 0, st, a);
     size_t tb = 0;

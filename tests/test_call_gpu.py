@@ -108,3 +108,57 @@ def test_step1_other_cell_type_counts_match_oracle(engine, n_ct):
         g = g[:-1]
     bad = [(a, b) for a, b in zip(g, w) if a != b]
     assert len(g) == len(w) and not bad, "first mismatch:\n%s\n%s" % (bad[0] if bad else (len(g), len(w)))
+
+
+def test_homopolymer_context_at_tile_and_contig_edges(engine):
+    """The LC_Upstream / LC_Downstream flags (step1.py:95-107, :347-354) read five reference bases either side of a site.
+    k_call_gather cuts them from one load per 64-position tile plus five bases either side of it: runs that straddle tile
+    borders, sites in the first and last five bases of a contig, contigs shorter than a tile and of exactly a tile."""
+    from oracle import calling_oracle
+    rng = np.random.default_rng(77)
+    lens = [197, 70, 6, 64, 129, 11, 65, 63]
+    names = ["c%d" % i for i in range(len(lens))]
+    seqs = []
+    for L in lens:
+        s, cur = [], rng.integers(0, 4)
+        for _ in range(L):
+            if rng.random() > 0.62:
+                cur = rng.integers(0, 4)
+            s.append("ACGT"[cur])
+        seqs.append(np.frombuffer("".join(s).encode(), np.uint8).copy())
+    engine.set_contigs(lens)
+    for t, s in enumerate(seqs):
+        engine.load_reference(t, s)
+    cls_of = {ord("A"): 0, ord("C"): 1, ord("T"): 2, ord("G"): 3}
+    per_ct = []
+    for ct in range(2):
+        keys, refs, rows = [], [], []
+        for t, L in enumerate(lens):
+            for pos in range(L):
+                if rng.random() < 0.2:
+                    continue
+                r = np.zeros(42, np.uint32)
+                rc = cls_of[int(seqs[t][pos])]
+                bc = np.zeros(8, np.int64); bc[rc] = rng.integers(15, 60)
+                for alt in rng.permutation([c for c in range(4) if c != rc])[:rng.integers(0, 3)]:
+                    bc[alt] = rng.integers(1, 12)
+                cc = np.minimum(bc, rng.integers(1, 9, 8)) * (bc > 0)
+                r[0] = bc.sum(); r[1] = max(5, int(cc.max()) + 3); r[2:10] = cc; r[10:18] = bc; r[26:34] = bc
+                keys.append((t << 32) | pos); refs.append(int(seqs[t][pos])); rows.append(r)
+        per_ct.append((np.asarray(keys, np.int64), np.asarray(refs, np.uint8), np.stack(rows)))
+    ct_names = ["Cancer", "Non-Cancer"]
+    engine.load_counts([p[0] for p in per_ct], [p[2] for p in per_ct])
+    n_sites, _ = engine.call_step1()
+    calls = engine.fetch_calls()
+    assert len(calls) == n_sites
+    merged = tsvio.format_merged_tsv(per_ct, names, ct_names)
+    header = [l + "\n" for l in merged.split("\n") if l.startswith("##")]
+    got = tsvio.format_step1_tsv(calls, per_ct, names, ct_names, header)
+    want = neg_zero(calling_oracle.step1(merged, dict(zip(names, [s.tobytes().decode() for s in seqs])), info_lines=tsvio.STEP1_INFO_LINES))
+    g, w = strip_date(got).split("\n"), strip_date(want).split("\n")
+    if w and w[-1] != "" and g and g[-1] == "":
+        g = g[:-1]
+    bad = [(a, b) for a, b in zip(g, w) if a != b]
+    assert len(g) == len(w) and not bad, "first mismatch:\n%s\n%s" % (bad[0] if bad else (len(g), len(w)))
+    n_up, n_down = sum("LC_Upstream" in l for l in w), sum("LC_Downstream" in l for l in w)
+    assert n_up > 20 and n_down > 20, (n_up, n_down)
