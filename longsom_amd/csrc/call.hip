@@ -282,33 +282,52 @@ __global__ __launch_bounds__(GATHER_WAVES * 64) __attribute__((amdgpu_waves_per_
     const int up_best = 1 + longest(ue), up_run = 1 + (int)__builtin_clz((((~ue) & 15u) << 28) | (1u << 27));    // run that ends in up[4]
     const int dn_best = 1 + longest(de), dn_run = 1 + (int)__builtin_ctz((~de) | 16u);                         // run that starts at down[0]
     const uint8_t up4 = lane ? (uint8_t)prev0 : (uint8_t)r1_4, dn0 = lane < 63 ? (uint8_t)next0 : (uint8_t)r1_5;
-    // pass 1: candidate? number of tail tasks?  (one wave-aggregated allocation each)
-    bool has_any = false;
+    // pass 1: candidate?  the Rest_* sums; does any tail of the site lie outside the table?  (selects, no branches: the lanes of a
+    // tile disagree at every one of these tests)
+    bool has_any = false, off_table = false;
     uint32_t n_light = 0, n_heavy = 0;
     int32_t s_alts_bc = 0, s_alts_cc = 0, s_dp = 0, s_nc = 0;
     if (site) {
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) {
-            if (!((mask[ct] >> lane) & 1ull)) continue;
             const uint32_t dp = v_dp[ct], nc = v_nc[ct];
-            if (!((int)dp >= P.min_cov && (int)nc >= P.min_cells)) continue;
-            s_dp += (int32_t)dp; s_nc += (int32_t)nc;
+            const bool ok = ((mask[ct] >> lane) & 1ull) && (int)dp >= P.min_cov && (int)nc >= P.min_cells;
+            s_dp += ok ? (int32_t)dp : 0; s_nc += ok ? (int32_t)nc : 0;
 #pragma unroll
             for (int s = 0; s < 6; ++s) {
-                const uint32_t b = v_bc[ct][s], c = v_cc[ct][s];
-                if (s == rsym) continue;
-                s_alts_bc += (int32_t)b; s_alts_cc += (int32_t)c;
-                if (s < 4 && b > 0) {
-                    has_any = true;
-                    s_dp -= (int32_t)b; s_nc -= (int32_t)c; s_alts_bc -= (int32_t)b; s_alts_cc -= (int32_t)c;
+                const bool nr = ok && s != rsym;
+                const uint32_t b = nr ? v_bc[ct][s] : 0u, c = nr ? v_cc[ct][s] : 0u;
+                const bool alt = s < 4 && b > 0;
+                has_any |= alt;
+                s_alts_bc += alt ? 0 : (int32_t)b; s_alts_cc += alt ? 0 : (int32_t)c;
+                s_dp -= alt ? (int32_t)b : 0; s_nc -= alt ? (int32_t)c : 0;
+                off_table |= alt && !(tail_in_table(b, dp) && tail_in_table(c, nc));
+            }
+        }
+        if (s_alts_bc > 0) {
+            off_table |= s_dp >= 0 && !tail_in_table((uint32_t)s_alts_bc, (uint32_t)s_dp);
+            off_table |= s_nc >= 0 && s_alts_cc >= 0 && !tail_in_table((uint32_t)s_alts_cc, (uint32_t)s_nc);
+        }
+    }
+    if (__ballot(off_table)) {                                  // (the deepest sites only) how many tasks, of which kind
+        if (site) {
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                if (!((mask[ct] >> lane) & 1ull)) continue;
+                const uint32_t dp = v_dp[ct], nc = v_nc[ct];
+                if (!((int)dp >= P.min_cov && (int)nc >= P.min_cells)) continue;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const uint32_t b = v_bc[ct][s], c = v_cc[ct][s];
+                    if (s == rsym || b == 0) continue;
                     if (!tail_in_table(b, dp)) { if (tail_work(b, dp) > 64) ++n_heavy; else ++n_light; }
                     if (!tail_in_table(c, nc)) { if (tail_work(c, nc) > 64) ++n_heavy; else ++n_light; }
                 }
             }
-        }
-        if (s_alts_bc > 0) {
-            if (s_dp >= 0 && !tail_in_table((uint32_t)s_alts_bc, (uint32_t)s_dp)) { if (tail_work((uint32_t)s_alts_bc, (uint32_t)s_dp) > 64) ++n_heavy; else ++n_light; }
-            if (s_nc >= 0 && s_alts_cc >= 0 && !tail_in_table((uint32_t)s_alts_cc, (uint32_t)s_nc)) { if (tail_work((uint32_t)s_alts_cc, (uint32_t)s_nc) > 64) ++n_heavy; else ++n_light; }
+            if (s_alts_bc > 0) {
+                if (s_dp >= 0 && !tail_in_table((uint32_t)s_alts_bc, (uint32_t)s_dp)) { if (tail_work((uint32_t)s_alts_bc, (uint32_t)s_dp) > 64) ++n_heavy; else ++n_light; }
+                if (s_nc >= 0 && s_alts_cc >= 0 && !tail_in_table((uint32_t)s_alts_cc, (uint32_t)s_nc)) { if (tail_work((uint32_t)s_alts_cc, (uint32_t)s_nc) > 64) ++n_heavy; else ++n_light; }
+            }
         }
     }
     const unsigned long long cm = __ballot(has_any);

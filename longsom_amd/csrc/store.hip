@@ -648,6 +648,15 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
     c->tm_n = N; c->tm_events = (int64_t)n_ev;
     c->max_live_all = max_live > 0 ? max_live : 0;
     if (N == 0) return finish();
+    if (getenv("LSG_TILE_HIST")) {                                   // (diagnostic: how the entries spread over tile sizes; C2: DESIGN.md section 9)
+        std::vector<uint32_t> caps(T);
+        LSG_HIP(hipMemcpy(caps.data(), c->d_tile_cap.p, (size_t)T * 4, hipMemcpyDeviceToHost));
+        unsigned long long nt[8] = {0}, ne[8] = {0}; uint32_t mx = 0;
+        const uint32_t lim[7] = {64, 256, 2048, 8192, 32768, 131072, 524288};
+        for (uint32_t i = 0; i < T; ++i) { const uint32_t v = caps[i]; if (!v) continue; int k = 0; while (k < 7 && v > lim[k]) ++k; ++nt[k]; ne[k] += v; if (v > mx) mx = v; }
+        for (int k = 0; k < 8; ++k) fprintf(stderr, "tiles <= %u: %llu tiles, %llu entries\n", k < 7 ? lim[k] : 0xffffffffu, nt[k], ne[k]);
+        fprintf(stderr, "largest tile: %u entries\n", mx);
+    }
     // ---- 2. scatter (queued BEFORE the copy stream's work below: those two dozen launches are 0.3 ms of host time the scatter need not wait for)
     int bits = 1; while (bits < 24 && (1ll << bits) <= (long long)max_cb) ++bits;      // the barcode bits of the sort key
     DevBuf &key_a = c->bt[BT_KEY_A], &key_b = c->bt[BT_KEY_B], &val_a = c->bt[BT_VAL_A], &val_b = c->bt[BT_VAL_B];
