@@ -164,6 +164,7 @@ struct lsg_ctx {
     float build_ms[4] = {0, 0, 0, 0};     // HIP-event times of the last build: capacities + scatter, sort, fill, gather
     int64_t max_live_reads = -1;          // layout.hip: bound on the reads live at once in the reference's pileup buffer (-1 = stale)
     int64_t max_live_all = -1;            // the same over all reads with a barcode: table-independent, cached per load
+    bool keys_only_off = false;           // build_store: this load sorts values with its keys (set while a load of keys alone is made again)
     int64_t max_live_exact = -1;          // per cell type at position resolution (asked only when the tile-level bounds cannot rule the cap out)
     lsg::DevBuf d_read_drop;              // layout.hip: per read, the pileup's max_depth rule under the last count's parameters: 1 = dropped in every window it overlaps, 2 = in some (d_drop_pairs)
     lsg::DevBuf d_drop_pairs; int64_t n_drop_pairs = 0;      // sorted (read << 32 | window of its contig) of the reads dropped in some windows only

@@ -717,6 +717,7 @@ __global__ __launch_bounds__(TMW_WAVES * 64) __attribute__((amdgpu_waves_per_eu(
 struct TgArgs {
     const uint16_t* events; int64_t n_events;
     const uint64_t* key; const uint32_t* rdv; int32_t cb_bits;      // the sort's output (store.hip sort_key): read in place
+    uint64_t src_mask;                                                // the bits of the key's source field (a load that sorts keys alone - rdv null - keeps the entry's two flags above them)
     const uint32_t* tile_off; const uint32_t* blk_off;
     uint32_t* s0; uint8_t* b8; uint32_t* rd; uint4* store; uint16_t* ext;
     const uint32_t* nchunks;                                          // the plan's number of chunks, still on the device
@@ -1051,13 +1052,18 @@ struct TdW { uint32_t lo, hi; };     // hi: address bits 32..47 | 2 * events << 
 constexpr int TD_Q = LSG_TD_Q, TD_NQ = 64 / TD_Q;      // entries to a batch of loads (two batches of registers alternate), batches to a group.
 // (8 to a batch fit 64 registers and 8 waves per SIMD, 16 workgroups per CU: 8.1-8.8 ms, no better than 16 to a batch at 6 waves: 8.0-8.2)
 struct TdKeys64 { uint64_t k; uint32_t v; };
+// KO: the sort carried keys alone (store.hip build_store, keys_only): forward strand and first-of-segment are bits 63 and 62 of the key,
+// where RV_FWD and RV_SEGFIRST sit in the upper word; no read index (every stored read is admitted: run_gather_count checks)
+template <bool KO>
 __device__ __forceinline__ TdKeys64 td_load_keys64(const TgArgs& tg, uint32_t i_first, uint32_t off, uint32_t n, int lane) {
     TdKeys64 r;
     const uint32_t i = i_first + (uint32_t)lane, ic = i < n ? i : n - 1u;       // (past the tile's end: its last entry, which is never used)
     r.k = __builtin_nontemporal_load(tg.key + off + ic);
-    r.v = __builtin_nontemporal_load(tg.rdv + off + ic);
+    if (KO) r.v = (uint32_t)(r.k >> 32) & (TG_RV_FWD | TG_RV_SEGFIRST);
+    else r.v = __builtin_nontemporal_load(tg.rdv + off + ic);
     return r;
 }
+template <bool KO>
 __device__ __forceinline__ void td_range64(const CountArgs& a, const TmArgs& tm, const TgArgs& tg, TmState& st, TgStat& stat, uint32_t i0, uint32_t i1, uint32_t off, uint32_t n,
                                            uint32_t thr, uint32_t pkl0, uint32_t one, int lane, TdKeys64 K, uint64_t key_before) {
     const int ng = (int)((i1 - i0 + 63u) >> 6);
@@ -1075,7 +1081,7 @@ __device__ __forceinline__ void td_range64(const CountArgs& a, const TmArgs& tm,
         const uint32_t up = (uint32_t)__shfl_up((int)cb, 1), dn = (uint32_t)__shfl_down((int)cb, 1);
         const uint32_t cb_prev = lane == 0 ? cb_carry : up;
         const uint32_t geom = (uint32_t)(K.k >> tg.cb_bits), first = geom & 63u, nev = valid ? ((geom >> 6) & 63u) + 1u : 0u;
-        const uint64_t addr = evb + 2ull * (K.k >> (tg.cb_bits + 12));
+        const uint64_t addr = evb + 2ull * (KO ? (K.k >> (tg.cb_bits + 12)) & tg.src_mask : K.k >> (tg.cb_bits + 12));
         const bool rs = i == 0 || cb_prev != cb;
         const bool nd = i + 1 == n || (lane < 63 && dn != cb);           // the next entry is another barcode's (lane 63: decided when the next keys are there)
         w.lo = (uint32_t)addr; w.hi = ((uint32_t)(addr >> 32) & 0xffffu) | (nev << 17) | (first << 25);
@@ -1130,7 +1136,7 @@ __device__ __forceinline__ void td_range64(const CountArgs& a, const TmArgs& tm,
     TdW wc, wn; TgPre pre;
     words(0, K, wc, pre);
     fence();
-    K = td_load_keys64(tg, i0 + 64u, off, n, lane);
+    K = td_load_keys64<KO>(tg, i0 + 64u, off, n, lane);
     fence();
     issue(wc, 0, EA);
     fence();
@@ -1141,7 +1147,7 @@ __device__ __forceinline__ void td_range64(const CountArgs& a, const TmArgs& tm,
         const uint32_t Mc = verdicts(finish_meta(pre, cb_last, cb_after));
         words(g + 1, K, wn, pre);                                           // (past the range's last group: entries that are not there)
         fence();
-        K = td_load_keys64(tg, i0 + 64u * (uint32_t)(g + 2), off, n, lane);
+        K = td_load_keys64<KO>(tg, i0 + 64u * (uint32_t)(g + 2), off, n, lane);
         fence();
 #pragma unroll
         for (int sb = 0; sb < TD_NQ; sb += 2) {                // batch sb is counted while sb + 1 is in flight; its registers take batch sb + 2's loads
@@ -1153,6 +1159,7 @@ __device__ __forceinline__ void td_range64(const CountArgs& a, const TmArgs& tm,
     st.nc += st.mask & 0x10001u; st.mask = 0;
 }
 
+template <bool KO>
 __global__ __launch_bounds__(TMW_WAVES * 64) __attribute__((amdgpu_waves_per_eu(LSG_TD_WAVES))) void k_tm_count_direct(CountArgs a, TmArgs tm, TgArgs tg) {
     __shared__ __attribute__((aligned(8192))) uint32_t planes[2][2][8 * 64];
     __shared__ uint32_t nc_sh[2][64];
@@ -1207,7 +1214,7 @@ __global__ __launch_bounds__(TMW_WAVES * 64) __attribute__((amdgpu_waves_per_eu(
         // (the first group's keys of the wave's range, and the entry before it)
         auto first_i = [&]() -> uint32_t { return (wv ? emid : e0) - base; };
         TdKeys64 K64{}; uint64_t kb = 0;
-        auto prefetch = [&]() { const uint32_t i = first_i(); K64 = td_load_keys64(tg, i, off, tcnt, lane); kb = __builtin_nontemporal_load(tg.key + off + (i ? i - 1u : 0u)); };
+        auto prefetch = [&]() { const uint32_t i = first_i(); K64 = td_load_keys64<KO>(tg, i, off, tcnt, lane); kb = __builtin_nontemporal_load(tg.key + off + (i ? i - 1u : 0u)); };
         prefetch();
         while (true) {
             jw = reinterpret_cast<const uint32_t*>(tm.jobs + (nxt != NO_JOB ? nxt : cur))[lane < TM_JOB_WORDS ? lane : 0];      // (every lane loads: nothing here waits)
@@ -1231,7 +1238,7 @@ __global__ __launch_bounds__(TMW_WAVES * 64) __attribute__((amdgpu_waves_per_eu(
             const uint32_t i0 = s0r - base, i1 = s1r - base < tcnt ? s1r - base : tcnt;
             if (counting && i1 > i0) {
                 TmState st; st.nc = 0; st.mask = 0;
-                td_range64(a, tm, tg, st, stat, i0, i1, off, tcnt, thr, pkl0, one, lane, K64, kb);
+                td_range64<KO>(a, tm, tg, st, stat, i0, i1, off, tcnt, thr, pkl0, one, lane, K64, kb);
                 if (st.nc & 0xffffu) atomicAdd(&nc_sh[0][lane], st.nc & 0xffffu);
                 if (st.nc >> 16) atomicAdd(&nc_sh[1][lane], st.nc >> 16);
             }
@@ -1404,10 +1411,10 @@ __global__ __launch_bounds__(64) void k_tm_walk_wide_direct(CountArgs a, TmArgs 
         for (uint32_t p = jb.e0; p < jb.e1 && p - jb.base < jb.cnt; ++p) {
             const uint32_t i = p - jb.base;
             const uint64_t k = tg.key[jb.off + i];
-            const uint32_t v = tg.rdv[jb.off + i], cb = (uint32_t)k & cbm, r = v & TG_RV_READ;
+            const uint32_t v = tg.rdv ? tg.rdv[jb.off + i] : (uint32_t)(k >> 32) & (TG_RV_FWD | TG_RV_SEGFIRST), cb = (uint32_t)k & cbm, r = v & TG_RV_READ;
             const bool rs = i == 0 || ((uint32_t)tg.key[jb.off + i - 1] & cbm) != cb;
             const uint32_t geom = (uint32_t)(k >> tg.cb_bits), first = geom & 63u, nev = ((geom >> 6) & 63u) + 1u;
-            const uint64_t src = k >> (tg.cb_bits + 12);
+            const uint64_t src = (k >> (tg.cb_bits + 12)) & tg.src_mask;
             uint32_t cls = 2;
             bool ok = cb < (uint32_t)a.n_cb;
             if (ok && a.adm) ok = (reinterpret_cast<const uint32_t*>(a.adm)[r >> 5] >> (r & 31u)) & 1u;
@@ -1578,6 +1585,8 @@ int run_gather_count(lsg_ctx* c, const lsg_count_params* p, const GatherCountSrc
     if (int rc = count_prepare(c, p, L)) return rc;
     TgArgs tg{};
     tg.events = src.events; tg.n_events = src.n_events; tg.key = src.key; tg.rdv = src.rdv; tg.cb_bits = src.cb_bits;
+    tg.src_mask = (1ull << ((src.rdv ? 52 : 50) - src.cb_bits)) - 1ull;
+    if (!src.rdv && (!direct || L.a.adm)) return 1;      // (keys alone carry no read index: a count that looks reads up is made from a load that kept them; build_store loads again)
     tg.tile_off = c->d_tile_off.as<uint32_t>(); tg.blk_off = c->tm[TM_BLK_OFF].as<uint32_t>();
     tg.s0 = c->tm[TM_S0].as<uint32_t>(); tg.b8 = c->tm[TM_B].as<uint8_t>(); tg.rd = c->tm[TM_RD].as<uint32_t>();
     tg.store = c->tm[TM_STORE].as<uint4>(); tg.ext = c->tm[TM_EXT].as<uint16_t>();
@@ -1593,7 +1602,8 @@ int run_gather_count(lsg_ctx* c, const lsg_count_params* p, const GatherCountSrc
         LSG_HIP(hipMemsetAsync(c->d_xcd_queues.p, 0, 8 * 128, st));
         tg.queues = c->d_xcd_queues.as<unsigned long long>();
         const unsigned grid = (unsigned)(c->n_cus * tune_int("LSG_GRID_TD", 12));
-        hipLaunchKernelGGL(k_tm_count_direct, dim3(grid), dim3(TMW_WAVES * 64), 0, st, L.a, L.tm, tg);
+        if (tg.rdv) hipLaunchKernelGGL(k_tm_count_direct<false>, dim3(grid), dim3(TMW_WAVES * 64), 0, st, L.a, L.tm, tg);
+        else hipLaunchKernelGGL(k_tm_count_direct<true>, dim3(grid), dim3(TMW_WAVES * 64), 0, st, L.a, L.tm, tg);
         LSG_HIP(hipEventRecord(c->ev[4], st));
         LSG_HIP(hipEventRecord(c->evb[4], st));
         stage("k_tm_count_direct");

@@ -339,8 +339,10 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(BuildArgs a) {
                             // everything the gather needs of an entry travels THROUGH the sort (no record fetched through the sort's
                             // permutation afterwards): key = barcode | first position in the tile | events - 1 | source of the events,
                             // sorted on its barcode bits only; value = owning read | first of its segment | forward strand
-                            a.key[pos] = sort_key(g.key & CB_MASK, (uint32_t)(lo - tstart), (uint32_t)(hi - lo - 1), src, a.cb_bits);
-                            a.rdv[pos] = g.rd | (lo == g.st ? RV_SEGFIRST : 0u) | (((g.key >> 24) & 1u) ? 0u : RV_FWD) | (edge >= 0 && lo >= edge ? RV_WHI : 0u);
+                            const uint64_t key = sort_key(g.key & CB_MASK, (uint32_t)(lo - tstart), (uint32_t)(hi - lo - 1), src, a.cb_bits);
+                            const uint32_t flags = (lo == g.st ? RV_SEGFIRST : 0u) | (((g.key >> 24) & 1u) ? 0u : RV_FWD);
+                            if (a.rdv) { a.key[pos] = key; a.rdv[pos] = g.rd | flags | (edge >= 0 && lo >= edge ? RV_WHI : 0u); }
+                            else a.key[pos] = key | ((uint64_t)flags << 32);      // keys alone (build_store, keys_only): the two flags a count needs above the source field, bits 62 and 63
                         }
                     }
                 }
@@ -532,6 +534,8 @@ template <unsigned RB, unsigned BS = 256, unsigned IPT = 8>
 using LsgSortConfig = rocprim::segmented_radix_sort_config<RB, rocprim::kernel_config<BS, IPT>, rocprim::WarpSortConfig<16, 4, 256, 64, 32, 8, 256>>;
 template <unsigned RB, unsigned BS, unsigned IPT, class... Args>
 static hipError_t lsg_segmented_sort(Args&&... args) { return rocprim::segmented_radix_sort_pairs<LsgSortConfig<RB, BS, IPT>>(std::forward<Args>(args)...); }
+template <unsigned RB, unsigned BS, unsigned IPT, class... Args>
+static hipError_t lsg_segmented_sort_keys(Args&&... args) { return rocprim::segmented_radix_sort_keys<LsgSortConfig<RB, BS, IPT>>(std::forward<Args>(args)...); }
 
 int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int64_t* seg_ev_off, const lsg_reads* src) {
     drop_store(c);
@@ -664,10 +668,23 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
         set_error("lsg_load_reads: %lld events with %d-bit barcode ids do not fit the packed sort key (events < 2^%d): load the reads in windows", (long long)n_events, bits, 52 - bits);
         return -2;
     }
-    if (key_a.reserve(N * 8 + 16) || key_b.reserve(N * 8 + 16) || val_a.reserve(N * 4 + 16) || val_b.reserve(N * 4 + 16) ||
+    // A load that is counted once, without a store, by a count that admits every stored read (the filters of the load) and whose depth cap
+    // cannot fire needs nothing of an entry's value but two flags: they ride in the key (bits 62, 63, above a source field two bits
+    // narrower) and the scatter, the sort and the count move 8 bytes an entry instead of 12.  Should the count not be made that way after
+    // all (its rows outgrow their buffer), the load starts again with values (keys_only_off).
+    bool keys_only = c->cal_enabled && c->store_policy == LSG_STORE_SKIP_WHEN_COUNTED && !getenv("LSG_NO_DIRECT_COUNT") && !getenv("LSG_NO_FUSED_LOAD") &&
+                     !getenv("LSG_NO_KEYS_ONLY") && !c->keys_only_off && c->n_ct >= 1 && c->n_ct <= 2 && c->n_cb > 0 && c->copy_stream && n_events >= 64 &&
+                     n_events < (1ll << 39) && n_events < (1ll << (50 - bits));
+    if (keys_only) {
+        const lsg_count_params& q = c->cal_params;
+        if (q.min_mq != c->st_min_mq || q.flag_exclude != c->st_flag_exclude || (q.ignore_orphans != 0) != (c->st_ignore_orphans != 0)) keys_only = false;
+        if (q.max_depth > 0 && c->max_live_all + 1 > (int64_t)q.max_depth) keys_only = false;
+        for (int t = 0; t < c->n_contigs && keys_only; ++t) if (!c->ref_ptr[t]) keys_only = false;
+    }
+    if (key_a.reserve(N * 8 + 16) || key_b.reserve(N * 8 + 16) || (!keys_only && (val_a.reserve(N * 4 + 16) || val_b.reserve(N * 4 + 16))) ||
         c->bt[BT_CURSOR].reserve(((size_t)T + 2) * 4)) return -1;
     // (the cursors in a buffer of their own: the plan's tile-level half may be at work in BT_PER_TILE beside the scatter)
-    a.cursor = c->bt[BT_CURSOR].as<uint32_t>(); a.key = key_a.as<uint64_t>(); a.rdv = val_a.as<uint32_t>(); a.cb_bits = bits;
+    a.cursor = c->bt[BT_CURSOR].as<uint32_t>(); a.key = key_a.as<uint64_t>(); a.rdv = keys_only ? nullptr : val_a.as<uint32_t>(); a.cb_bits = bits;
     LSG_HIP(hipMemcpyAsync(a.cursor, c->d_tile_off.p, ((size_t)T + 1) * 4, hipMemcpyDeviceToDevice, st));
     LSG_HIP(hipMemsetAsync(c->d_scalars.p, 0, 8, st));
     hipLaunchKernelGGL(k_bin, dim3(g_bin), dim3(BIN_THREADS), 0, st, a);
@@ -703,9 +720,11 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
         LSG_HIP(hipcub::DeviceScan::InclusiveScan(nullptr, tb_blk, bt_, bt_, hipcub::Max(), (int)nblk, bs));
         // (... and of the sort of the shallow tiles, which runs on this stream beside the deep tiles' sort: below)
         size_t tb_sort2 = 0;
-        if (n_netile && !getenv("LSG_NO_SPLIT_SORT"))
-            LSG_HIP((lsg_segmented_sort<7, 256, 8>(nullptr, tb_sort2, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (unsigned)N, (unsigned)n_netile,
-                                                   (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (unsigned)bits, bs, false)));
+        if (n_netile && !getenv("LSG_NO_SPLIT_SORT")) {
+            if (keys_only) LSG_HIP((lsg_segmented_sort_keys<7, 256, 8>(nullptr, tb_sort2, (uint64_t*)nullptr, (uint64_t*)nullptr, (unsigned)N, (unsigned)n_netile, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (unsigned)bits, bs, false)));
+            else LSG_HIP((lsg_segmented_sort<7, 256, 8>(nullptr, tb_sort2, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (unsigned)N, (unsigned)n_netile,
+                                                        (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (unsigned)bits, bs, false)));
+        }
         split_sort = tb_sort2 != 0;
         size_t tb_max = tb_lpt > tb_blk ? tb_lpt : tb_blk;
         if (tb_sort2 > tb_max) tb_max = tb_sort2;
@@ -741,6 +760,7 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
         // (one configuration: 7 bits per pass, 256 x 8 items in the block sort - the sweep over 512 / 1024 threads, 4-16 items and 8 bits per pass
         // that used to be selectable here found nothing faster, and cost a minute of compile time)
         auto sort = [&](void* tmp_p, size_t& tmp_n) {
+            if (keys_only) return lsg_segmented_sort_keys<7, 256, 8>(tmp_p, tmp_n, key_a.as<uint64_t>(), key_b.as<uint64_t>(), (unsigned)N, (unsigned)n_netile, sb1, se1, 0u, (unsigned)bits, st, false);
             return lsg_segmented_sort<7, 256, 8>(tmp_p, tmp_n, key_a.as<uint64_t>(), key_b.as<uint64_t>(), val_a.as<uint32_t>(), val_b.as<uint32_t>(), (unsigned)N, (unsigned)n_netile,
                                                  sb1, se1, 0u, (unsigned)bits, st, false);
         };
@@ -756,8 +776,9 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
             hipStream_t bs = c->copy_stream;
             LSG_HIP(hipStreamWaitEvent(bs, c->ev_copy, 0));
             size_t tb2 = c->bt[BT_COPY_TMP].cap;
-            LSG_HIP((lsg_segmented_sort<7, 256, 8>(c->bt[BT_COPY_TMP].p, tb2, key_a.as<uint64_t>(), key_b.as<uint64_t>(), val_a.as<uint32_t>(), val_b.as<uint32_t>(), (unsigned)N, (unsigned)n_netile,
-                                                   sb2, se2, 0u, (unsigned)bits, bs, false)));
+            if (keys_only) LSG_HIP((lsg_segmented_sort_keys<7, 256, 8>(c->bt[BT_COPY_TMP].p, tb2, key_a.as<uint64_t>(), key_b.as<uint64_t>(), (unsigned)N, (unsigned)n_netile, sb2, se2, 0u, (unsigned)bits, bs, false)));
+            else LSG_HIP((lsg_segmented_sort<7, 256, 8>(c->bt[BT_COPY_TMP].p, tb2, key_a.as<uint64_t>(), key_b.as<uint64_t>(), val_a.as<uint32_t>(), val_b.as<uint32_t>(), (unsigned)N, (unsigned)n_netile,
+                                                        sb2, se2, 0u, (unsigned)bits, bs, false)));
             LSG_HIP(hipEventRecord(c->ev_lpt, bs));            // (the event of the tiles' order: waited for above, free again)
         }
         if (split_sort) LSG_HIP(hipStreamWaitEvent(st, c->ev_lpt, 0));      // both halves of the order are there
@@ -818,7 +839,14 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
         stage("plan");
         return 0;
     };
-    const GatherCountSrc gsrc{events, n_events, key_b.as<uint64_t>(), val_b.as<uint32_t>(), bits};
+    const GatherCountSrc gsrc{events, n_events, key_b.as<uint64_t>(), keys_only ? nullptr : val_b.as<uint32_t>(), bits};
+    auto load_again_with_values = [&]() -> int {                 // (a load of keys alone that is not counted that way after all)
+        LSG_HIP(hipStreamSynchronize(st)); LSG_HIP(hipStreamSynchronize(c->copy_stream));
+        c->keys_only_off = true;
+        const int rc = build_store(c, events, n_events, seg_ev_off, src);
+        c->keys_only_off = false;
+        return rc;
+    };
     bool planned = false;
     if (fused && c->store_policy == LSG_STORE_SKIP_WHEN_COUNTED && !getenv("LSG_NO_DIRECT_COUNT")) {
         // A load that is counted once and never again (lsg_set_store_policy): the count alone, from the caller's events through the
@@ -840,6 +868,7 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
         c->counted = false;                                       // rows outgrew their buffer: the store is built after all, the count is made on request
         fused = false;
     }
+    if (keys_only) return load_again_with_values();
     if (int rc = reserve_store()) return rc;
     if (!blk_tiles_made) {                                       // (a load that was to keep no store builds one after all)
         LSG_HIP(hipStreamSynchronize(c->copy_stream));
