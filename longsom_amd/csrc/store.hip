@@ -681,6 +681,7 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
         if (q.max_depth > 0 && c->max_live_all + 1 > (int64_t)q.max_depth) keys_only = false;
         for (int t = 0; t < c->n_contigs && keys_only; ++t) if (!c->ref_ptr[t]) keys_only = false;
     }
+    if (keys_only && getenv("LSG_TIMING")) fprintf(stderr, "[lsg] load: keys alone through the scatter and the sort (8 bytes an entry)\n");
     if (key_a.reserve(N * 8 + 16) || key_b.reserve(N * 8 + 16) || (!keys_only && (val_a.reserve(N * 4 + 16) || val_b.reserve(N * 4 + 16))) ||
         c->bt[BT_CURSOR].reserve(((size_t)T + 2) * 4)) return -1;
     // (the cursors in a buffer of their own: the plan's tile-level half may be at work in BT_PER_TILE beside the scatter)
@@ -842,12 +843,14 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
     const GatherCountSrc gsrc{events, n_events, key_b.as<uint64_t>(), keys_only ? nullptr : val_b.as<uint32_t>(), bits};
     auto load_again_with_values = [&]() -> int {                 // (a load of keys alone that is not counted that way after all)
         LSG_HIP(hipStreamSynchronize(st)); LSG_HIP(hipStreamSynchronize(c->copy_stream));
+        if (getenv("LSG_TIMING")) fprintf(stderr, "[lsg] load: the count from keys alone was not made, loading again with values\n");
         c->keys_only_off = true;
         const int rc = build_store(c, events, n_events, seg_ev_off, src);
         c->keys_only_off = false;
         return rc;
     };
     bool planned = false;
+    if (keys_only && getenv("LSG_TEST_KEYS_ONLY_REFUSED")) return load_again_with_values();      // (test hook: the way a refused count of keys alone takes)
     if (fused && c->store_policy == LSG_STORE_SKIP_WHEN_COUNTED && !getenv("LSG_NO_DIRECT_COUNT")) {
         // A load that is counted once and never again (lsg_set_store_policy): the count alone, from the caller's events through the
         // sort's output - no blocks, no per-entry words.  What needs a store afterwards is refused until the next load.

@@ -185,3 +185,34 @@ def test_entries_cut_at_pileup_window_edges_count_the_same(engine):
         engine.set_pileup_window(50000)
     fused_vs_oracle(engine, rec, lens, refs, ct_of, 2, CountParams.longsom_defaults())
     assert n_cut > engine.store_shape()[0]                        # more entries, same rows
+
+
+def test_loads_that_sort_keys_alone(engine, monkeypatch, capfd):
+    """A load that keeps no store and is counted under its own read filters carries keys alone through the scatter and the sort
+    (store.hip build_store, keys_only; pileup.hip k_tm_count_direct<true>): deep tiles cut into jobs, a tile left to the wide walk,
+    and a load whose count from keys alone is refused (the test hook) and that is made again with values."""
+    monkeypatch.setenv("LSG_TIMING", "1")
+    p = CountParams.longsom_defaults()
+    engine.set_load_filter(p.min_mq, p.flag_exclude, p.ignore_orphans)           # every stored read is admitted by the count
+    try:
+        lens = [4000, 2000]
+        rec, refs, ct_of = make_case(3, 30000, lens, 3000, hot_regions=[(0, 1000, 1100), (1, 500, 520)], hot_frac=0.9)
+        capfd.readouterr()
+        fused_vs_oracle(engine, rec, lens, refs, ct_of, 2, p)
+        assert "keys alone through the scatter" in capfd.readouterr().err
+        assert engine.count_stats().n_deep_units > 0
+        lens = [2500]
+        rec, refs, ct_of = make_case(14, 30000, lens, 30, hot_regions=[(0, 700, 760)], hot_frac=0.97, cb_skew=0.9)
+        ct_of[0] = 0
+        fused_vs_oracle(engine, rec, lens, refs, ct_of, 2, p)
+        assert "keys alone through the scatter" in capfd.readouterr().err
+        one = np.zeros(len(ct_of), np.uint8); one[3] = 255
+        fused_vs_oracle(engine, rec, lens, refs, one, 1, p)
+        monkeypatch.setenv("LSG_TEST_KEYS_ONLY_REFUSED", "1")
+        lens = [5000, 1200, 70]
+        rec, refs, ct_of = make_case(1, 3000, lens, 50)
+        capfd.readouterr()
+        fused_vs_oracle(engine, rec, lens, refs, ct_of, 2, p)
+        assert "loading again with values" in capfd.readouterr().err
+    finally:
+        engine.set_load_filter()
