@@ -261,7 +261,7 @@ def recorded_traffic(kernel):
     f = files[-1]
     try:
         d = json.load(open(f))
-        k = next((v for n, v in d["kernels"].items() if n.split("#")[0] == PMC_KERNEL[kernel]), None)
+        k = next((v for n, v in d["kernels"].items() if n.split("#")[0].split("<")[0] == PMC_KERNEL[kernel]), None)
         rel = os.path.relpath(f, ROOT)
         if d.get("_csrc_sha1") != csrc_digest():
             return None, "%s was recorded for another build of longsom_amd/csrc (sha1 %s)" % (rel, str(d.get("_csrc_sha1"))[:12]), True, None
