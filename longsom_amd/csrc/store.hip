@@ -77,55 +77,88 @@ __device__ __forceinline__ int64_t win_edge_in_tile(int64_t tstart, int32_t W) {
 // The tiles' CAPACITIES come out of the same pass the same way: a segment's entries are the tiles of one contiguous range, so +1 at its
 // first tile and -1 past its last one, summed along the tiles, is the number of entries of every tile — two marks per segment where a
 // counting pass over the entries (0.9 ms of LDS atomics for C2's 185 M entries) made one per entry.
-constexpr int SEG_THREADS = 256, SEG_H = 2048, SEG_MAX_SINCE = 24, SEG_MARKS = 4;       // (24 x 512 marks of one sign at most per half word; 4 marks per segment go through the hash)
+// The pass waits for memory (a segment's arrays, then its read's, then its contig's: three dependent trips; 84 % of its wave-cycles were
+// spent waiting with one segment per thread): a thread takes SEG_U segments of a batch and issues each level's loads for all of them
+// before it looks at any.
+constexpr int SEG_THREADS = 256, SEG_U = 4, SEG_H = 2048, SEG_MAX_SINCE = 6, SEG_MARKS = 4;       // (6 x 2048 marks of one sign at most per half word; 4 marks per segment go through the hash)
 __global__ __launch_bounds__(SEG_THREADS) void k_seg_static(BuildArgs a) {
     __shared__ uint32_t hkey[SEG_H];
-    __shared__ int32_t hval[SEG_H];       // both sums of a tile in one word: span marks in the low half, capacity marks x 65536 (each at most 512 in size per batch, SEG_MAX_SINCE batches per flush)
+    __shared__ int32_t hval[SEG_H];       // both sums of a tile in one word: span marks in the low half, capacity marks x 65536 (each at most 2048 in size per batch, SEG_MAX_SINCE batches per flush)
     __shared__ unsigned long long s_ev;
     __shared__ uint32_t s_new, s_flush;        // tiles in the hash since its last flush; this batch ends with one
     for (int i = threadIdx.x; i < SEG_H; i += SEG_THREADS) { hkey[i] = KEY_INVALID; hval[i] = 0; }
     if (threadIdx.x == 0) { s_ev = 0; s_new = 0; s_flush = 0; }
-    auto slot = [&](uint32_t t) {
+    // a tile's slot in the hash, or -1 when sixteen probes find none (a batch marks 4096 tiles at worst, the hash holds 2048 and is
+    // flushed when half full: the marks of a batch that scatters that widely go straight to memory, as they would from a full hash)
+    auto slot = [&](uint32_t t) -> int {
         uint32_t h = (t * 2654435761u) >> 21;
-        while (true) {
+        for (int tries = 0; tries < 16; ++tries) {
             const uint32_t prev = atomicCAS(&hkey[h], KEY_INVALID, t);
-            if (prev == KEY_INVALID) { atomicAdd(&s_new, 1u); break; }
-            if (prev == t) break;
+            if (prev == KEY_INVALID) { atomicAdd(&s_new, 1u); return (int)h; }
+            if (prev == t) return (int)h;
             h = (h + 1) & (SEG_H - 1);
         }
-        return h;
+        return -1;
     };
-    auto mark = [&](uint32_t t, int32_t v) { atomicAdd(&hval[slot(t)], v); };
-    auto mark_cap = [&](uint32_t t, int32_t v) { atomicAdd(&hval[slot(t)], v * 65536); };
+    auto mark = [&](uint32_t t, int32_t v) { const int h = slot(t); if (h >= 0) atomicAdd(&hval[h], v); else atomicAdd(a.span_diff + t, v); };
+    auto mark_cap = [&](uint32_t t, int32_t v) { const int h = slot(t); if (h >= 0) atomicAdd(&hval[h], v * 65536); else atomicAdd(a.cap_diff + t, v); };
     unsigned long long n_ev = 0;
     // A workgroup takes CONSECUTIVE batches (the segments of a coordinate-sorted BAM arrive gene by gene: the next batch marks the same
-    // few tiles) and flushes the hash only when the next batch might not fit any more (4 marks per segment at worst), or after
-    // SEG_MAX_SINCE batches (the packed sums stay inside their 16 bits), or at its end.
-    const int64_t n_batches = (a.n_segs + SEG_THREADS - 1) / SEG_THREADS;
+    // few tiles) and flushes the hash only when the next batch might not fit any more, or after SEG_MAX_SINCE batches (the packed sums
+    // stay inside their 16 bits), or at its end.
+    constexpr int64_t BATCH = (int64_t)SEG_THREADS * SEG_U;
+    const int64_t n_batches = (a.n_segs + BATCH - 1) / BATCH;
     const int64_t per_wg = (n_batches + gridDim.x - 1) / gridDim.x;
     const int64_t b_lo = (int64_t)blockIdx.x * per_wg, b_hi = b_lo + per_wg < n_batches ? b_lo + per_wg : n_batches;
+    const int64_t last_seg = a.n_segs - 1;
     int since = 0;
     __syncthreads();
     for (int64_t bt = b_lo; bt < b_hi; ++bt) {
-        const int64_t s = bt * SEG_THREADS + threadIdx.x;
+        // level 1: the segments' own arrays (a segment past the end reads the last one and is not looked at)
+        int64_t sg[SEG_U], st_[SEG_U], ln_[SEG_U], of_[SEG_U]; uint32_t rd_[SEG_U], rp_[SEG_U], rn_[SEG_U]; bool in_[SEG_U];
+#pragma unroll
+        for (int u = 0; u < SEG_U; ++u) {
+            sg[u] = bt * BATCH + (int64_t)u * SEG_THREADS + threadIdx.x;
+            in_[u] = sg[u] < a.n_segs;
+            const int64_t si = in_[u] ? sg[u] : last_seg;
+            rd_[u] = a.seg_read[si]; st_[u] = a.seg_start[si]; ln_[u] = a.seg_len[si]; of_[u] = a.seg_ev_off[si];
+            rp_[u] = a.seg_read[si > 0 ? si - 1 : 0]; rn_[u] = a.seg_read[si < last_seg ? si + 1 : last_seg];
+        }
+        // level 2: their reads'
+        int32_t tid_[SEG_U], cb_[SEG_U]; uint32_t flag_[SEG_U], mq_[SEG_U];
+#pragma unroll
+        for (int u = 0; u < SEG_U; ++u) {
+            const int64_t ri = (int64_t)rd_[u] < a.n_reads ? (int64_t)rd_[u] : 0;
+            tid_[u] = a.read_tid[ri]; cb_[u] = a.read_cb[ri]; flag_[u] = a.read_flag[ri]; mq_[u] = (uint32_t)a.read_mapq[ri];
+        }
+        // level 3: their contigs'
+        int64_t clen_[SEG_U]; uint32_t tb_[SEG_U], te_[SEG_U];
+#pragma unroll
+        for (int u = 0; u < SEG_U; ++u) {
+            const int ti = tid_[u] >= 0 && tid_[u] < a.n_contigs ? tid_[u] : 0;
+            clen_[u] = a.contig_len[ti]; tb_[u] = a.tile_base[ti]; te_[u] = a.tile_base[ti + 1];
+        }
+#pragma unroll
+        for (int u = 0; u < SEG_U; ++u) {
+        const int64_t s = sg[u];
         uint32_t edge_tile = KEY_INVALID;                   // tile of the first window edge inside this thread's segment
-        if (s < a.n_segs) {
-            const uint32_t r = a.seg_read[s];
+        if (in_[u]) {
+            const uint32_t r = rd_[u];
             uint32_t key = KEY_INVALID, tb = 0;
             if ((int64_t)r >= a.n_reads) atomicOr(a.bad, 2u);
             else {
-                const int64_t st = a.seg_start[s], ln = a.seg_len[s], o = a.seg_ev_off[s];
-                const int32_t tid = a.read_tid[r], cb = a.read_cb[r];
+                const int64_t st = st_[u], ln = ln_[u], o = of_[u];
+                const int32_t tid = tid_[u], cb = cb_[u];
                 const bool on_contig = tid >= 0 && tid < a.n_contigs;
                 if (ln > 0 && (o < 0 || o + ln > a.n_events)) atomicOr(a.bad, 1u);
                 else {
-                    const uint32_t flag = a.read_flag[r];
+                    const uint32_t flag = flag_[u];
                     // the load filter: what SplitBamCellTypes.py:110-113 does to the BAM before BaseCellCounter ever sees it
-                    bool pool = (int)a.read_mapq[r] >= a.lf_min_mq && (flag & a.lf_flag_exclude) == 0;
+                    bool pool = (int)mq_[u] >= a.lf_min_mq && (flag & a.lf_flag_exclude) == 0;
                     if (pool && a.lf_ignore_orphans && (flag & 1u) && !(flag & 2u)) pool = false;
-                    if (pool && on_contig && cb >= 0 && (uint32_t)cb < CB_MASK && !(st < 0 || ln <= 0 || st + ln > a.contig_len[tid])) {
+                    if (pool && on_contig && cb >= 0 && (uint32_t)cb < CB_MASK && !(st < 0 || ln <= 0 || st + ln > clen_[u])) {
                         key = (uint32_t)cb | (((flag >> 4) & 1u) << 24);
-                        tb = a.tile_base[tid];
+                        tb = tb_[u];
                         n_ev += (unsigned long long)ln;
                         mark_cap(tb + ((uint32_t)st >> 6), 1);
                         mark_cap(tb + ((uint32_t)(st + ln - 1) >> 6) + 1, -1);
@@ -142,8 +175,8 @@ __global__ __launch_bounds__(SEG_THREADS) void k_seg_static(BuildArgs a) {
                     }
                 }
                 if (a.span_diff && on_contig && cb >= 0) {          // (every read with a barcode, whatever the load filter: a bound never under-counts)
-                    const bool first = s == 0 || a.seg_read[s - 1] != r, last = s + 1 == a.n_segs || a.seg_read[s + 1] != r;
-                    const uint32_t t0 = a.tile_base[tid], te = a.tile_base[tid + 1];
+                    const bool first = s == 0 || rp_[u] != r, last = s + 1 == a.n_segs || rn_[u] != r;
+                    const uint32_t t0 = tb_[u], te = te_[u];
                     if ((first || last) && te > t0) {
                         // the read is still buffered while the column AFTER its last one is entered (freed by that column's sweep): span end inclusive;
                         // both marks are clamped into the contig so that every +1 has its -1
@@ -162,10 +195,11 @@ __global__ __launch_bounds__(SEG_THREADS) void k_seg_static(BuildArgs a) {
             if ((threadIdx.x & 63) == (unsigned)(__ffsll((long long)todo) - 1)) { const int n = __popcll(same); atomicAdd(a.cap_diff + lt, n); atomicAdd(a.cap_diff + lt + 1, -n); }
             todo &= ~same;
         }
+        }
         ++since;
         __syncthreads();                                  // the batch's marks are in
         if (threadIdx.x == 0) {
-            s_flush = (bt + 1 == b_hi || s_new + SEG_MARKS * SEG_THREADS > SEG_H * 3 / 4 || since >= SEG_MAX_SINCE) ? 1u : 0u;
+            s_flush = (bt + 1 == b_hi || s_new > SEG_H / 2 || since >= SEG_MAX_SINCE) ? 1u : 0u;
             if (s_flush) s_new = 0;
         }
         __syncthreads();                                  // every thread sees the same decision; nobody marks meanwhile
@@ -574,7 +608,7 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
     DevBuf& tmp = c->bt[BT_TMP];
     LSG_HIP(hipEventRecord(c->evb[0], st));
     // ---- 1. static admission + capacities
-    unsigned g_seg = (unsigned)((S + 255) / 256); if (g_seg > (unsigned)(c->n_cus * 16)) g_seg = (unsigned)(c->n_cus * 16);
+    unsigned g_seg = (unsigned)((S + 256 * SEG_U - 1) / (256 * SEG_U)); if (g_seg > (unsigned)(c->n_cus * 16)) g_seg = (unsigned)(c->n_cus * 16);
     unsigned g_bin = (unsigned)((S + 256 * BIN_SUPER - 1) / (256 * BIN_SUPER)); if (g_bin > (unsigned)(c->n_cus * 8)) g_bin = (unsigned)(c->n_cus * 8);
     if (c->bt[BT_PER_TILE].reserve(((size_t)T + 2) * 4)) return -1;
     LSG_HIP(hipMemsetAsync(c->bt[BT_PER_TILE].p, 0, ((size_t)T + 2) * 4, st));
