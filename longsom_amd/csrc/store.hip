@@ -239,18 +239,19 @@ struct BinSeg { uint32_t key, tb, t0, rd; int32_t st, ln, ntile; int64_t evoff, 
 
 __device__ __forceinline__ BinSeg bin_load(const BuildArgs& a, int64_t s) {
     BinSeg g; g.key = KEY_INVALID; g.tb = 0; g.t0 = 0; g.rd = 0; g.b1 = 0; g.st = 0; g.ln = 0; g.ntile = 0; g.evoff = 0;
-    if (s < a.n_segs) {
-        const uint2 info = a.seg_info[s];
+    // (all five loads at once, whatever the segment's admission says: a segment past the end reads the last one)
+    const int64_t si = s < a.n_segs ? s : a.n_segs - 1;
+    const uint2 info = a.seg_info[si];
+    const int64_t st = a.seg_start[si], ln = a.seg_len[si], evoff = a.seg_ev_off[si];
+    const uint32_t rd = a.seg_read[si];
+    if (s < a.n_segs && info.x != KEY_INVALID) {
         g.key = info.x; g.tb = info.y;
-        if (g.key != KEY_INVALID) {
-            g.st = a.seg_start[s]; g.ln = a.seg_len[s];
-            g.evoff = a.seg_ev_off[s]; g.rd = a.seg_read[s];
-            g.t0 = g.tb + ((uint32_t)g.st >> 6);
-            g.ntile = (int)(((uint32_t)(g.st + g.ln - 1) >> 6) - ((uint32_t)g.st >> 6)) + 1;
-            g.b1 = win_edge_after(g.st, a.window);
-            for (int64_t b = g.b1; b < (int64_t)g.st + g.ln; b += a.window) g.ntile += (b & 63) != 0;
-        }
-    }
+        g.st = (int32_t)st; g.ln = (int32_t)ln; g.evoff = evoff; g.rd = rd;
+        g.t0 = g.tb + ((uint32_t)g.st >> 6);
+        g.ntile = (int)(((uint32_t)(g.st + g.ln - 1) >> 6) - ((uint32_t)g.st >> 6)) + 1;
+        g.b1 = win_edge_after(g.st, a.window);
+        for (int64_t b = g.b1; b < (int64_t)g.st + g.ln; b += a.window) g.ntile += (b & 63) != 0;
+    } else if (s < a.n_segs) g.tb = info.y;
     return g;
 }
 // entry k of a segment, in position order: its tile (relative to the segment's first) and its positions [lo, hi)
