@@ -260,7 +260,9 @@ int lsg_set_count_at_load(lsg_ctx* ctx, const lsg_count_params* params);
  * writes no store: what derives from that count (lsg_fetch_counts, the exports, lsg_call_step1 ...) works as always, lsg_pileup_count
  * with the load's parameters returns it, and everything that needs the store (another count, lsg_genotype_cells) fails with a message
  * until reads are loaded again.  A load that cannot make its count (the depth cap could fire, more than two cell types) builds the
- * store as under LSG_STORE_KEEP. */
+ * store as under LSG_STORE_KEEP.  When the count's read filters are the load's (lsg_set_load_filter with the count's min_mq,
+ * flag_exclude and ignore_orphans: every stored read is admitted) and the tiles rule the depth cap out, such a load carries 8-byte keys
+ * alone through its scatter and sort instead of 12-byte key + value pairs (store.hip keys_only): the same count, a tenth faster. */
 /* The BAM loads that follow (lsg_load_bam, lsg_load_bam_range) keep the reads without a CB tag or with a barcode that is not listed
  * (cb = -1) instead of dropping them at decode time.  Such a read is never counted (SplitBamCellTypes.py:74-90 routes it nowhere), but
  * the per-cell genotyping piles up the UNSPLIT BAM (HCCVSingleCellGenotype.py:121-122): every read that passes that pileup's own

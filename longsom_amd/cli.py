@@ -109,6 +109,7 @@ def base_cell_counter(argv=None):
         cp = CountParams.longsom_defaults(min_bq=a.min_bq, min_mq=a.min_mq, min_dp=a.min_dp, min_cc=a.min_cc)
         eng.set_count_at_load(cp)                         # this script counts its BAM once: in the pass that loads it,
         eng.set_store_policy(eng.STORE_SKIP_WHEN_COUNTED)  # and keeps no store for another count
+        eng.set_load_filter(cp.min_mq, cp.flag_exclude, cp.ignore_orphans)      # (reads the count would refuse are not stored: keys alone through the sort)
         eng.load_reads(dec.records)
         eng.pileup_count(cp)
         k, r, c = eng.fetch_counts(0)

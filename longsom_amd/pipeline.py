@@ -130,9 +130,16 @@ def load_sample(bam: str, barcodes_tsv: str, ref_fasta: str, engine: Engine, min
     engine.set_store_policy(engine.STORE_KEEP if keep_store or count_params is None else engine.STORE_SKIP_WHEN_COUNTED)
     engine.set_keep_unlisted(keep_unlisted)
     old_keep = hostio.set_keep_unlisted(keep_unlisted)
+    # a BAM that is counted once under known parameters: the reads that count's own filters would refuse are not stored at all (what
+    # SplitBamCellTypes.py:110-113 does to the BAM a rule counts) - every stored read is then admitted, and the load sorts keys alone
+    once = count_params is not None and not keep_store and not keep_unlisted
+    if once:
+        engine.set_load_filter(count_params.min_mq, count_params.flag_exclude, count_params.ignore_orphans)
     try:
         return _load_sample(bam, barcodes_tsv, ref_fasta, engine, min_mapq, ingest)
     finally:
+        if once:
+            engine.set_load_filter()
         engine.set_count_at_load(None)
         engine.set_store_policy(engine.STORE_KEEP)
         engine.set_keep_unlisted(False)
