@@ -80,7 +80,7 @@ __device__ __forceinline__ int64_t win_edge_in_tile(int64_t tstart, int32_t W) {
 // The pass waits for memory (a segment's arrays, then its read's, then its contig's: three dependent trips; 84 % of its wave-cycles were
 // spent waiting with one segment per thread): a thread takes SEG_U segments of a batch and issues each level's loads for all of them
 // before it looks at any.
-constexpr int SEG_THREADS = 256, SEG_U = 4, SEG_H = 2048, SEG_MAX_SINCE = 6, SEG_MARKS = 4;       // (6 x 2048 marks of one sign at most per half word; 4 marks per segment go through the hash)
+constexpr int SEG_THREADS = 256, SEG_U = 4, SEG_H = 2048, SEG_MAX_SINCE = 6;       // (6 x 2048 marks of one sign at most per half word)
 __global__ __launch_bounds__(SEG_THREADS) void k_seg_static(BuildArgs a) {
     __shared__ uint32_t hkey[SEG_H];
     __shared__ int32_t hval[SEG_H];       // both sums of a tile in one word: span marks in the low half, capacity marks x 65536 (each at most 2048 in size per batch, SEG_MAX_SINCE batches per flush)
@@ -390,6 +390,156 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(BuildArgs a) {
     }
 }
 
+// ---- the tiles' tables in five launches ---------------------------------------------------------------
+// What follows from the range marks k_seg_static left: entries per tile (running sum of cap_diff), their offsets, the largest running
+// sum of the span marks (the depth cap's all-reads bound), the non-empty tiles in order, blocks per tile and their offsets, the 64-bit
+// total.  As library calls that was five scans, five reductions, a select and a transform over all tiles of the genome - some twenty
+// launches, 0.26 ms whatever the load's size (a rank's eighth of a sample pays it in full).  Here: every workgroup owns a contiguous
+// chunk of tiles; k_tt_marks sums its marks, k_tt_scan1 (one workgroup) turns the chunks' sums into their starting values,
+// k_tt_caps writes the capacities and sums what derives from them, k_tt_scan2 again, k_tt_offsets writes the offsets and the list.
+constexpr int TT_THREADS = 256, TT_SUB = TT_THREADS * 4, TT_MAX_CHUNKS = 1024;
+struct TtAgg1 { int32_t d, s, smax, pad; };
+struct TtAgg2 { unsigned long long c; uint32_t b, ne; };
+struct TtArgs {
+    const int32_t* cap_diff; const int32_t* span_diff; uint32_t T; uint32_t chunk;       // chunk: tiles per workgroup, a multiple of TT_SUB; indices 0 .. T
+    uint32_t n_chunks;
+    TtAgg1* agg1; int32_t* din; TtAgg2* agg2; TtAgg2* in2;
+    uint32_t* cap; uint32_t* tile_off; uint32_t* blk_off; uint32_t* netile;
+    uint32_t* d_small; unsigned long long* d_sum;          // [1] non-empty tiles, [3] the live-reads bound; the 64-bit total
+};
+// exclusive prefix of v over the workgroup's threads (NT of them) and the total; two barriers
+template <int NT, class V>
+__device__ __forceinline__ V tt_wg_exscan(V v, V& total, V* sh /* NT / 64 + 1 */) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    V inc = v;
+    for (int o = 1; o < 64; o <<= 1) { const V u = __shfl_up(inc, o); if (lane >= o) inc += u; }
+    __syncthreads();                                   // (sh may still be read from the call before)
+    if (lane == 63) sh[wv] = inc;
+    __syncthreads();
+    V base = 0, tot = 0;
+    for (int w = 0; w < NT / 64; ++w) { const V x = sh[w]; if (w < wv) base += x; tot += x; }
+    total = tot;
+    return base + inc - v;
+}
+__global__ __launch_bounds__(TT_THREADS) void k_tt_marks(TtArgs a) {
+    __shared__ int32_t sh[TT_THREADS / 64 + 1];
+    __shared__ int32_t sh_max[TT_THREADS / 64];
+    const uint32_t lo = blockIdx.x * a.chunk, hi = lo + a.chunk < a.T + 1 ? lo + a.chunk : a.T + 1;
+    int32_t dsum = 0, srun = 0, smax = INT32_MIN;
+    for (uint32_t b0 = lo; b0 < hi; b0 += TT_SUB) {
+        const uint32_t i0 = b0 + threadIdx.x * 4;
+        int32_t d[4], sp[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const bool in = i0 + k < hi; d[k] = in ? a.cap_diff[i0 + k] : 0; sp[k] = in && a.span_diff ? a.span_diff[i0 + k] : 0; }
+        int32_t ds = d[0] + d[1] + d[2] + d[3];
+        // the largest running sum of the span marks inside the thread's four, relative to the thread's start
+        int32_t r = 0, m = INT32_MIN;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { r += sp[k]; if (i0 + k < hi) m = r > m ? r : m; }
+        int32_t tot_s; const int32_t ex = tt_wg_exscan<TT_THREADS>(r, tot_s, sh);
+        if (m != INT32_MIN) { const int32_t v = srun + ex + m; smax = v > smax ? v : smax; }
+        srun += tot_s; dsum += ds;
+    }
+    for (int o = 32; o > 0; o >>= 1) { const int32_t u = __shfl_down(smax, o); smax = u > smax ? u : smax; dsum += __shfl_down(dsum, o); }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { sh_max[threadIdx.x >> 6] = smax; sh[threadIdx.x >> 6] = dsum; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int32_t m = INT32_MIN, dd = 0;
+        for (int w = 0; w < TT_THREADS / 64; ++w) { m = sh_max[w] > m ? sh_max[w] : m; dd += sh[w]; }
+        a.agg1[blockIdx.x] = TtAgg1{dd, srun, m, 0};
+    }
+}
+__global__ __launch_bounds__(TT_MAX_CHUNKS) void k_tt_scan1(TtArgs a) {
+    __shared__ int32_t sh[TT_MAX_CHUNKS / 64 + 1];
+    __shared__ int32_t sh_max[TT_MAX_CHUNKS / 64];
+    const uint32_t i = threadIdx.x;
+    TtAgg1 g{0, 0, INT32_MIN, 0};
+    if (i < a.n_chunks) g = a.agg1[i];
+    int32_t tot;
+    const int32_t din = tt_wg_exscan<TT_MAX_CHUNKS>(g.d, tot, sh);
+    const int32_t sin = tt_wg_exscan<TT_MAX_CHUNKS>(g.s, tot, sh);
+    if (i < a.n_chunks) a.din[i] = din;
+    int32_t m = i < a.n_chunks && g.smax != INT32_MIN ? sin + g.smax : INT32_MIN;
+    for (int o = 32; o > 0; o >>= 1) { const int32_t u = __shfl_down(m, o); m = u > m ? u : m; }
+    __syncthreads();
+    if ((i & 63) == 0) sh_max[i >> 6] = m;
+    __syncthreads();
+    if (i == 0) { int32_t mm = INT32_MIN; for (int w = 0; w < TT_MAX_CHUNKS / 64; ++w) mm = sh_max[w] > mm ? sh_max[w] : mm; a.d_small[3] = (uint32_t)mm; }
+}
+__global__ __launch_bounds__(TT_THREADS) void k_tt_caps(TtArgs a) {
+    __shared__ int32_t sh[TT_THREADS / 64 + 1];
+    __shared__ unsigned long long sh_c[TT_THREADS / 64];
+    __shared__ uint32_t sh_b[TT_THREADS / 64], sh_n[TT_THREADS / 64];
+    const uint32_t lo = blockIdx.x * a.chunk, hi = lo + a.chunk < a.T + 1 ? lo + a.chunk : a.T + 1;
+    int32_t run = a.din[blockIdx.x];
+    unsigned long long csum = 0; uint32_t bsum = 0, nsum = 0;
+    for (uint32_t b0 = lo; b0 < hi; b0 += TT_SUB) {
+        const uint32_t i0 = b0 + threadIdx.x * 4;
+        int32_t d[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) d[k] = i0 + k < hi ? a.cap_diff[i0 + k] : 0;
+        int32_t tot; const int32_t ex = tt_wg_exscan<TT_THREADS>(d[0] + d[1] + d[2] + d[3], tot, sh);
+        int32_t r = run + ex;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            r += d[k];
+            if (i0 + k < hi) {
+                a.cap[i0 + k] = (uint32_t)r;
+                if (i0 + k < a.T) { const uint32_t cv = (uint32_t)r; csum += cv; bsum += (cv + 7u) / 8u; nsum += cv != 0u; }
+            }
+        }
+        run += tot;
+    }
+    for (int o = 32; o > 0; o >>= 1) { csum += __shfl_down(csum, o); bsum += __shfl_down(bsum, o); nsum += __shfl_down(nsum, o); }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { sh_c[threadIdx.x >> 6] = csum; sh_b[threadIdx.x >> 6] = bsum; sh_n[threadIdx.x >> 6] = nsum; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        TtAgg2 g{0, 0, 0};
+        for (int w = 0; w < TT_THREADS / 64; ++w) { g.c += sh_c[w]; g.b += sh_b[w]; g.ne += sh_n[w]; }
+        a.agg2[blockIdx.x] = g;
+    }
+}
+__global__ __launch_bounds__(TT_MAX_CHUNKS) void k_tt_scan2(TtArgs a) {
+    __shared__ unsigned long long sh64[TT_MAX_CHUNKS / 64 + 1];
+    __shared__ uint32_t sh32[TT_MAX_CHUNKS / 64 + 1];
+    const uint32_t i = threadIdx.x;
+    TtAgg2 g{0, 0, 0};
+    if (i < a.n_chunks) g = a.agg2[i];
+    unsigned long long tc; uint32_t tb, tn;
+    TtAgg2 in;
+    in.c = tt_wg_exscan<TT_MAX_CHUNKS>(g.c, tc, sh64);
+    in.b = tt_wg_exscan<TT_MAX_CHUNKS>(g.b, tb, sh32);
+    in.ne = tt_wg_exscan<TT_MAX_CHUNKS>(g.ne, tn, sh32);
+    if (i < a.n_chunks) a.in2[i] = in;
+    if (i == 0) { *a.d_sum = tc; a.d_small[1] = tn; }
+}
+__global__ __launch_bounds__(TT_THREADS) void k_tt_offsets(TtArgs a) {
+    __shared__ uint32_t sh[TT_THREADS / 64 + 1];
+    const uint32_t lo = blockIdx.x * a.chunk, hi = lo + a.chunk < a.T + 1 ? lo + a.chunk : a.T + 1;
+    const TtAgg2 in = a.in2[blockIdx.x];
+    uint32_t crun = (uint32_t)in.c, brun = in.b, nrun = in.ne;
+    for (uint32_t b0 = lo; b0 < hi; b0 += TT_SUB) {
+        const uint32_t i0 = b0 + threadIdx.x * 4;
+        uint32_t cv[4], bv[4], nv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { cv[k] = i0 + k < hi && i0 + k < a.T ? a.cap[i0 + k] : 0u; bv[k] = (cv[k] + 7u) / 8u; nv[k] = cv[k] != 0u; }
+        uint32_t tc, tb, tn;
+        uint32_t ec = crun + tt_wg_exscan<TT_THREADS>(cv[0] + cv[1] + cv[2] + cv[3], tc, sh);
+        uint32_t eb = brun + tt_wg_exscan<TT_THREADS>(bv[0] + bv[1] + bv[2] + bv[3], tb, sh);
+        uint32_t en = nrun + tt_wg_exscan<TT_THREADS>(nv[0] + nv[1] + nv[2] + nv[3], tn, sh);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (i0 + k < hi) {
+                a.tile_off[i0 + k] = ec; a.blk_off[i0 + k] = eb;
+                if (nv[k]) a.netile[en] = i0 + k;
+            }
+            ec += cv[k]; eb += bv[k]; en += nv[k];
+        }
+        crun += tc; brun += tb; nrun += tn;
+    }
+}
 // per tile: blocks, and a flag for the non-empty ones
 __global__ void k_tile_blocks(const uint32_t* cap, uint32_t n_tiles, uint32_t* blk) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -615,6 +765,36 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
     LSG_HIP(hipMemsetAsync(c->bt[BT_PER_TILE].p, 0, ((size_t)T + 2) * 4, st));
     a.cap_diff = c->bt[BT_PER_TILE].as<int32_t>();
     hipLaunchKernelGGL(k_seg_static, dim3(g_seg), dim3(256), 0, st, a);
+    if (c->bt[BT_NETILE].reserve(((size_t)T + 2) * 4) || c->bt[BT_BLK].reserve(((size_t)T + 2) * 4) || c->tm[TM_BLK_OFF].reserve(((size_t)T + 2) * 4)) return -1;
+    uint32_t* blk_off = c->tm[TM_BLK_OFF].as<uint32_t>();
+    unsigned long long* d_sum = c->d_scalars.as<unsigned long long>() + 8;
+    {
+        size_t tb = 0;
+        LSG_HIP(hipcub::DeviceReduce::Max(nullptr, tb, in.read_cb, reinterpret_cast<int32_t*>(d_small + 2), (int)(R > 0 ? R : 1), st));
+        if (tmp.reserve(tb + 256 + 64 * 1024)) return -1;
+        tb = tmp.cap;
+        if (R > 0) LSG_HIP(hipcub::DeviceReduce::Max(tmp.p, tb, in.read_cb, reinterpret_cast<int32_t*>(d_small + 2), (int)R, st));
+    }
+    if (!getenv("LSG_NO_TILE_TABLES")) {
+        // everything that follows from the range marks, in five launches (k_tt_*): the sizes below reach the host in the load's ONE early
+        // look (the scatter, the sort and the gather are then queued without waiting for one another)
+        if (c->d_cub_tmp.reserve(64 * 1024)) return -1;
+        TtArgs ta{};
+        ta.cap_diff = a.cap_diff; ta.span_diff = a.span_diff; ta.T = T;
+        const uint64_t per = ((uint64_t)T + 1 + TT_MAX_CHUNKS - 1) / TT_MAX_CHUNKS;
+        ta.chunk = (uint32_t)((per + TT_SUB - 1) / TT_SUB * TT_SUB);
+        ta.n_chunks = (uint32_t)(((uint64_t)T + 1 + ta.chunk - 1) / ta.chunk);
+        char* scratch = reinterpret_cast<char*>(c->d_cub_tmp.p);          // (a buffer nothing else on this stream holds across these launches)
+        ta.agg1 = reinterpret_cast<TtAgg1*>(scratch); ta.agg2 = reinterpret_cast<TtAgg2*>(scratch + 16 * 1024); ta.in2 = reinterpret_cast<TtAgg2*>(scratch + 32 * 1024);
+        ta.din = reinterpret_cast<int32_t*>(scratch + 48 * 1024);
+        ta.cap = c->d_tile_cap.as<uint32_t>(); ta.tile_off = c->d_tile_off.as<uint32_t>(); ta.blk_off = blk_off; ta.netile = c->bt[BT_NETILE].as<uint32_t>();
+        ta.d_small = d_small; ta.d_sum = d_sum;
+        hipLaunchKernelGGL(k_tt_marks, dim3(ta.n_chunks), dim3(TT_THREADS), 0, st, ta);
+        hipLaunchKernelGGL(k_tt_scan1, dim3(1), dim3(TT_MAX_CHUNKS), 0, st, ta);
+        hipLaunchKernelGGL(k_tt_caps, dim3(ta.n_chunks), dim3(TT_THREADS), 0, st, ta);
+        hipLaunchKernelGGL(k_tt_scan2, dim3(1), dim3(TT_MAX_CHUNKS), 0, st, ta);
+        hipLaunchKernelGGL(k_tt_offsets, dim3(ta.n_chunks), dim3(TT_THREADS), 0, st, ta);
+    } else {
     {   // entries per tile = running sum of the segments' range marks
         size_t tb = 0;
         int32_t* cap = reinterpret_cast<int32_t*>(c->d_tile_cap.as<uint32_t>());
@@ -634,16 +814,8 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
         LSG_HIP(hipcub::DeviceScan::InclusiveSum(tmp.p, tb, a.span_diff, run, (int)(T + 1), st));
         LSG_HIP(hipcub::DeviceReduce::Max(tmp.p, tb2, run, reinterpret_cast<int32_t*>(d_small + 3), (int)(T + 1), st));
     }
-    {
-        size_t tb = 0;
-        LSG_HIP(hipcub::DeviceReduce::Max(nullptr, tb, in.read_cb, reinterpret_cast<int32_t*>(d_small + 2), (int)(R > 0 ? R : 1), st));
-        if (tmp.reserve(tb + 256)) return -1;
-        tb = tmp.cap;
-        if (R > 0) LSG_HIP(hipcub::DeviceReduce::Max(tmp.p, tb, in.read_cb, reinterpret_cast<int32_t*>(d_small + 2), (int)R, st));
-    }
     // the non-empty tiles (the sort's segments) and the blocks of every tile: all of it follows from the capacities, so the sizes below
     // reach the host in the load's ONE early look (the scatter, the sort and the gather are then queued without waiting for one another)
-    if (c->bt[BT_NETILE].reserve(((size_t)T + 2) * 4) || c->bt[BT_BLK].reserve(((size_t)T + 2) * 4) || c->tm[TM_BLK_OFF].reserve(((size_t)T + 2) * 4)) return -1;
     {
         hipcub::CountingInputIterator<uint32_t> tile_it(0);
         CapNonZero pred{c->d_tile_cap.as<uint32_t>()};
@@ -653,14 +825,10 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
         tb = tmp.cap;
         LSG_HIP(hipcub::DeviceSelect::If(tmp.p, tb, tile_it, c->bt[BT_NETILE].as<uint32_t>(), d_small + 1, (int)T, pred, st));
     }
-    uint32_t* blk_off = c->tm[TM_BLK_OFF].as<uint32_t>();
     hipLaunchKernelGGL(k_tile_blocks, dim3((T + 256) / 256), dim3(256), 0, st, c->d_tile_cap.as<uint32_t>(), T, c->bt[BT_BLK].as<uint32_t>());
     SCAN_U32(c->bt[BT_BLK].as<uint32_t>(), blk_off, T + 1);
-    uint32_t total = 0, bad = 0, n_netile = 0, nblk = 0; int32_t max_cb = 0, max_live = 0;
-    unsigned long long n_ev = 0, sum = 0;
     // (a total of 2^32 or more wraps the 32-bit scan: the per-tile capacities are summed in 64 bits to tell)
     {
-        unsigned long long* d_sum = c->d_scalars.as<unsigned long long>() + 8;
         size_t tb = 0;
         hipcub::TransformInputIterator<unsigned long long, hipcub::CastOp<unsigned long long>, const uint32_t*> it(c->d_tile_cap.as<uint32_t>(), hipcub::CastOp<unsigned long long>());
         LSG_HIP(hipcub::DeviceReduce::Sum(nullptr, tb, it, d_sum, (int)T, st));
@@ -668,6 +836,9 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
         tb = tmp.cap;
         LSG_HIP(hipcub::DeviceReduce::Sum(tmp.p, tb, it, d_sum, (int)T, st));
     }
+    }
+    uint32_t total = 0, bad = 0, n_netile = 0, nblk = 0; int32_t max_cb = 0, max_live = 0;
+    unsigned long long n_ev = 0, sum = 0;
     // the load's first look at the device: the sizes of everything that follows, in TWO small copies to pinned memory (the scalars'
     // block, and the number of blocks where the scan left it) - seven separate copies were seven commands of ~20 us each on the stream
     LSG_HIP(hipMemcpyAsync(c->h_pin, c->d_scalars.p, 9 * 8, hipMemcpyDeviceToHost, st));
