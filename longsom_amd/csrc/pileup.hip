@@ -1466,6 +1466,19 @@ __global__ __launch_bounds__(64) void k_tm_walk_wide_direct(CountArgs a, TmArgs 
 // buffers, zeroed counters, the kernels' arguments; k_read_stats is queued (the admitted reads, and the bit per read the entries'
 // admission is looked up in when some stored read can fail THIS count's read filters).
 struct CountLaunch { CountArgs a; TmArgs tm; unsigned grid_walk, grid_fin; int n_pass; };
+// a handful of fills and copies in one launch (count_prepare): word granularity, every buffer a device allocation of its own
+struct PrepOp { void* dst; const void* src; uint64_t words; };      // src null: zeros
+struct PrepArgs { PrepOp op[10]; int n; };
+__global__ __launch_bounds__(256) void k_prep_ops(PrepArgs a) {
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, gs = (uint64_t)gridDim.x * blockDim.x;
+    for (int k = 0; k < a.n; ++k) {
+        uint32_t* d = reinterpret_cast<uint32_t*>(a.op[k].dst);
+        const uint32_t* sp = reinterpret_cast<const uint32_t*>(a.op[k].src);
+        const uint64_t nq = a.op[k].words / 4;
+        for (uint64_t i = g; i < nq; i += gs) reinterpret_cast<uint4*>(d)[i] = sp ? reinterpret_cast<const uint4*>(sp)[i] : make_uint4(0u, 0u, 0u, 0u);
+        for (uint64_t i = nq * 4 + g; i < a.op[k].words; i += gs) d[i] = sp ? sp[i] : 0u;
+    }
+}
 static int count_prepare(lsg_ctx* c, const lsg_count_params* p, CountLaunch& L) {
     hipStream_t st = c->stream;
     const uint32_t n_ne = c->tm_n_ne;
@@ -1504,17 +1517,23 @@ static int count_prepare(lsg_ctx* c, const lsg_count_params* p, CountLaunch& L) 
     tm.meta = c->tm[TM_META].as<uint32_t>(); tm.blk_tile = c->tm[TM_BLK_TILE].as<uint32_t>(); tm.jobs = c->tm[TM_JOBS].as<TmJob>(); tm.np = c->tm_np; tm.nblk = c->tm_nblk;
     tm.njobs = c->tm_njobs; tm.nchunks = c->tm_nchunks; tm.chunk_start = c->tm[TM_CHUNKS].as<uint32_t>(); tm.ext = c->tm[TM_EXT].as<uint16_t>();
     LSG_HIP(hipEventRecord(c->ev[0], st));
-    LSG_HIP(hipMemsetAsync(c->d_scalars.p, 0, SC_COUNT * 8, st));
-    LSG_HIP(hipMemsetAsync(c->d_ix_stat.p, 0, IX_STAT_SLOTS * 64, st));
-    if (n_ne) {
-        // the static unit tables in the places the call stage and the exports read
-        LSG_HIP(hipMemcpyAsync(c->d_ne_units.p, c->tm[TM_NE_UNITS].p, (size_t)n_ne * 4, hipMemcpyDeviceToDevice, st));
-        LSG_HIP(hipMemcpyAsync(c->ws[WS_NE_GEOM].p, c->tm[TM_NE_GEOM].p, (size_t)n_ne * 8, hipMemcpyDeviceToDevice, st));
-        LSG_HIP(hipMemcpyAsync(c->ws[WS_NE_NSLOT].p, c->tm[TM_NE_NSLOT].p, ((size_t)n_ne + 1) * 4, hipMemcpyDeviceToDevice, st));
-        LSG_HIP(hipMemcpyAsync(c->ws[WS_NE_ACC].p, c->tm[TM_NE_ACC].p, ((size_t)n_ne + 1) * 4, hipMemcpyDeviceToDevice, st));
-        if (c->tm_n_multi) LSG_HIP(hipMemcpyAsync(c->ws[WS_MULTI_LIST].p, c->tm[TM_MULTI].p, (size_t)c->tm_n_multi * 4, hipMemcpyDeviceToDevice, st));
-        LSG_HIP(hipMemsetAsync(c->d_ne_mask.p, 0, ((size_t)n_ne + 1) * 8, st));
-        LSG_HIP(hipMemsetAsync(c->d_ne_rowbase.p, 0, ((size_t)n_ne + 1) * 4, st));
+    {   // zeroed counters, and the static unit tables in the places the call stage and the exports read: ONE launch (nine fills and copies of
+        // a few megabytes were nine commands, ~10 us each with the gaps between them, in front of every count)
+        PrepArgs pa{}; int k = 0;
+        auto op = [&](void* dst, const void* src, size_t bytes) { if (bytes) { pa.op[k].dst = dst; pa.op[k].src = src; pa.op[k].words = (bytes + 3) / 4; ++k; } };
+        op(c->d_scalars.p, nullptr, SC_COUNT * 8);
+        op(c->d_ix_stat.p, nullptr, IX_STAT_SLOTS * 64);
+        if (n_ne) {
+            op(c->d_ne_units.p, c->tm[TM_NE_UNITS].p, (size_t)n_ne * 4);
+            op(c->ws[WS_NE_GEOM].p, c->tm[TM_NE_GEOM].p, (size_t)n_ne * 8);
+            op(c->ws[WS_NE_NSLOT].p, c->tm[TM_NE_NSLOT].p, ((size_t)n_ne + 1) * 4);
+            op(c->ws[WS_NE_ACC].p, c->tm[TM_NE_ACC].p, ((size_t)n_ne + 1) * 4);
+            if (c->tm_n_multi) op(c->ws[WS_MULTI_LIST].p, c->tm[TM_MULTI].p, (size_t)c->tm_n_multi * 4);
+            op(c->d_ne_mask.p, nullptr, ((size_t)n_ne + 1) * 8);
+            op(c->d_ne_rowbase.p, nullptr, ((size_t)n_ne + 1) * 4);
+        }
+        pa.n = k;
+        hipLaunchKernelGGL(k_prep_ops, dim3((unsigned)(c->n_cus * 4)), dim3(256), 0, st, pa);
     }
     const int64_t R = c->rd.n_reads;
     if (R > 0) { unsigned g = (unsigned)((R + 255) / 256); if (g > (unsigned)(c->n_cus * 8)) g = (unsigned)(c->n_cus * 8); hipLaunchKernelGGL(k_read_stats, dim3(g), dim3(256), 0, st, L.a); }
