@@ -216,3 +216,19 @@ def test_loads_that_sort_keys_alone(engine, monkeypatch, capfd):
         assert "loading again with values" in capfd.readouterr().err
     finally:
         engine.set_load_filter()
+
+
+def test_library_paths_behind_the_switches_still_count_the_same(engine, monkeypatch):
+    """The tiles' tables as library calls (LSG_NO_TILE_TABLES), the 256-thread sort of a small load (LSG_SORT_BIG_BLOCKS=0) and a load that
+    carries values although it could sort keys alone (LSG_NO_KEYS_ONLY): the paths the defaults replaced, against the oracle."""
+    p = CountParams.longsom_defaults()
+    lens = [4000, 2000]
+    rec, refs, ct_of = make_case(3, 30000, lens, 3000, hot_regions=[(0, 1000, 1100), (1, 500, 520)], hot_frac=0.9)
+    engine.set_load_filter(p.min_mq, p.flag_exclude, p.ignore_orphans)
+    try:
+        for name, val in (("LSG_NO_TILE_TABLES", "1"), ("LSG_SORT_BIG_BLOCKS", "0"), ("LSG_NO_KEYS_ONLY", "1")):
+            monkeypatch.setenv(name, val)
+            fused_vs_oracle(engine, rec, lens, refs, ct_of, 2, p)
+            monkeypatch.delenv(name)
+    finally:
+        engine.set_load_filter()
