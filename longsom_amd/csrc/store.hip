@@ -967,11 +967,12 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
         // (one configuration: 7 bits per pass, 256 x 8 items in the block sort - the sweep over 512 / 1024 threads, 4-16 items and 8 bits per pass
         // that used to be selectable here found nothing faster, and cost a minute of compile time)
         const char* bb_env = getenv("LSG_SORT_BIG_BLOCKS");
-        const bool big_blocks = bb_env ? atoi(bb_env) != 0 : N < (32ull << 20);       // (C2 in eight shards: 23 M entries a rank, deep tiles sort 0.71 -> 0.55 ms; in four: 46 M, where it already loses)
+        const bool big_blocks = bb_env ? atoi(bb_env) != 0 : N < (64ull << 20);       // (C2: 23 M entries a rank in eight shards, 46 M in four, 92 M in two - where the big workgroups already lose)
         auto sort = [&](void* tmp_p, size_t& tmp_n) {
             // (a small load - a rank's share of a sharded sample - is bound by ONE workgroup working through its deepest tile, 2048 entries
-            // an iteration: 1024 threads take 8192; a whole sample is bound by throughput, where the small workgroups win)
-            if (keys_only && big_blocks) return lsg_segmented_sort_keys<7, 1024, 8>(tmp_p, tmp_n, key_a.as<uint64_t>(), key_b.as<uint64_t>(), (unsigned)N, (unsigned)n_netile, sb1, se1, 0u, (unsigned)bits, st, false);
+            // an iteration: 512 threads take 4096 - C2 in eight shards 0.71 -> 0.42-0.55 ms, in four 0.76 -> 0.69; 1024 threads gain on the
+            // deepest tiles and lose on all others; a whole sample is bound by throughput, where the small workgroups win)
+            if (keys_only && big_blocks) return lsg_segmented_sort_keys<7, 512, 8>(tmp_p, tmp_n, key_a.as<uint64_t>(), key_b.as<uint64_t>(), (unsigned)N, (unsigned)n_netile, sb1, se1, 0u, (unsigned)bits, st, false);
             if (keys_only) return lsg_segmented_sort_keys<7, 256, 8>(tmp_p, tmp_n, key_a.as<uint64_t>(), key_b.as<uint64_t>(), (unsigned)N, (unsigned)n_netile, sb1, se1, 0u, (unsigned)bits, st, false);
             return lsg_segmented_sort<7, 256, 8>(tmp_p, tmp_n, key_a.as<uint64_t>(), key_b.as<uint64_t>(), val_a.as<uint32_t>(), val_b.as<uint32_t>(), (unsigned)N, (unsigned)n_netile,
                                                  sb1, se1, 0u, (unsigned)bits, st, false);
