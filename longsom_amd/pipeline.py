@@ -226,16 +226,6 @@ def chain_step1(res: Resident, celltype_of: np.ndarray, celltype_names: List[str
         t["fetch"] = time.time() - t0
         return out, None, calls, t
     per_ct = [eng.fetch_counts(ct) for ct in range(len(celltype_names))]
-    calls = eng.fetch_calls()
-    t["fetch"] = time.time() - t0
-    if params.row_digests:
-        import xxhash
-        t0 = time.time()
-        out.row_digests = {"rows": [int(x) for x in n_rows], "columns": int(n_cols), "merged_sites": int(n_sites), "candidate_rows": int(n_cand)}
-        for ct in range(len(celltype_names)):
-            out.row_digests["ct%d" % ct] = [xxhash.xxh64(np.ascontiguousarray(x).tobytes() if x.size < (1 << 20) else memoryview(np.ascontiguousarray(x)).cast("B")).hexdigest() for x in per_ct[ct]]
-        t["row_digests"] = time.time() - t0
-    t0 = time.time()
     date = tsvio.file_date()
     for ct, name in enumerate(celltype_names):
         out.counts[name] = os.path.join(d["BaseCellCounter/" + sample_id], "%s.%s.tsv" % (sample_id, name))
@@ -252,15 +242,27 @@ def chain_step1(res: Resident, celltype_of: np.ndarray, celltype_names: List[str
         t1 = time.time()
         tsvio.write_merged_tsv(out.merged, per_ct, contig_names, celltype_names, date)
         t["table_merged"] = time.time() - t1
+    if background_tables:
+        # the per-cell-type and the merged table need the count rows only: their writer starts while the call records are still on their
+        # way from the device (the merged table behind the count tables on ONE thread: a third writer beside steps 2 and 3 made every one
+        # of them slower - the host's threads are all busy - and the run no shorter)
+        out.start_background(lambda: (count_tables(), merged_table()))
+    calls = eng.fetch_calls()
+    t["fetch"] = time.time() - t0
+    if params.row_digests:
+        import xxhash
+        t0 = time.time()
+        out.row_digests = {"rows": [int(x) for x in n_rows], "columns": int(n_cols), "merged_sites": int(n_sites), "candidate_rows": int(n_cand)}
+        for ct in range(len(celltype_names)):
+            out.row_digests["ct%d" % ct] = [xxhash.xxh64(np.ascontiguousarray(x).tobytes() if x.size < (1 << 20) else memoryview(np.ascontiguousarray(x)).cast("B")).hexdigest() for x in per_ct[ct]]
+        t["row_digests"] = time.time() - t0
+    t0 = time.time()
     header = [l + "\n" for l in tsvio.merged_header(celltype_names, date).split("\n") if l.startswith("##")]
     if background_tables:
         # Steps 2 and 3 only need the rows step 2 keeps: those are formatted first (a third of the step-1 table's rows, nothing written);
         # the per-cell-type and merged tables and the step-1 table itself are written by threads of their own (native writers, no GIL)
         # beside steps 2 and 3 - the box's disk takes several files at once faster than one: the caller joins them (SnvOutputs.wait_for_tables)
         s1 = tsvio.step1_kept_rows(calls, per_ct, contig_names, celltype_names, header, as_bytes=True)
-        # (the merged table behind the count tables on ONE thread: a third writer beside steps 2 and 3 made every one of them slower - the
-        # host's threads are all busy - and the run no shorter)
-        out.start_background(lambda: (count_tables(), merged_table()))
         def step1_table():
             t1 = time.time()
             tsvio.write_step1_tsv(out.step1, calls, per_ct, contig_names, celltype_names, header, collect=False)
