@@ -225,7 +225,10 @@ def chain_step1(res: Resident, celltype_of: np.ndarray, celltype_names: List[str
         calls = eng.fetch_calls(candidates_only=True)
         t["fetch"] = time.time() - t0
         return out, None, calls, t
-    per_ct = [eng.fetch_counts(ct) for ct in range(len(celltype_names))]
+    import threading
+    per_ct: List = [None] * len(celltype_names)
+    arrived = [threading.Event() for _ in celltype_names]          # a cell type's count rows are on the host
+    failed: List[BaseException] = []                               # ... or will never be
     date = tsvio.file_date()
     for ct, name in enumerate(celltype_names):
         out.counts[name] = os.path.join(d["BaseCellCounter/" + sample_id], "%s.%s.tsv" % (sample_id, name))
@@ -234,19 +237,34 @@ def chain_step1(res: Resident, celltype_of: np.ndarray, celltype_names: List[str
 
     def count_tables():
         for ct, name in enumerate(celltype_names):
+            arrived[ct].wait()
+            if failed:
+                return
             t1 = time.time()
             tsvio.write_counts_tsv(out.counts[name], *per_ct[ct], contig_names, "%s.%s" % (sample_id, name), date)
             t["table_counts_" + name] = time.time() - t1        # (seconds of the writer itself, in the background when background_tables)
 
     def merged_table():
+        if failed:
+            return
         t1 = time.time()
         tsvio.write_merged_tsv(out.merged, per_ct, contig_names, celltype_names, date)
         t["table_merged"] = time.time() - t1
-    if background_tables:
-        # the per-cell-type and the merged table need the count rows only: their writer starts while the call records are still on their
-        # way from the device (the merged table behind the count tables on ONE thread: a third writer beside steps 2 and 3 made every one
-        # of them slower - the host's threads are all busy - and the run no shorter)
-        out.start_background(lambda: (count_tables(), merged_table()))
+    try:
+        for ct in range(len(celltype_names)):
+            per_ct[ct] = eng.fetch_counts(ct)
+            arrived[ct].set()
+            if ct == 0 and background_tables:
+                # the per-cell-type and the merged table need the count rows only: their writer starts with the first cell type's rows, while
+                # the others' and the call records are still on their way from the device (the merged table behind the count tables on ONE
+                # thread: a third writer beside steps 2 and 3 made every one of them slower - the host's threads are all busy - and the run
+                # no shorter)
+                out.start_background(lambda: (count_tables(), merged_table()))
+    except BaseException as e:                                   # (the writer must not wait for rows that will never come)
+        failed.append(e)
+        for ev in arrived:
+            ev.set()
+        raise
     calls = eng.fetch_calls()
     t["fetch"] = time.time() - t0
     if params.row_digests:
