@@ -6,7 +6,8 @@
            (one count per BAM, BaseCellCounter.py:182-320):
              lsg_load_reads on device-resident compact read-record arrays (the device half of ingest: every (segment x 64-position
              tile) entry binned per tile and sorted by barcode, and - lsg_set_count_at_load + lsg_set_store_policy - the BAM's one
-             count made in the same pass straight from the caller's events: a BAM that is counted once keeps no tile store)
+             count made in the same pass straight from the caller's events: a BAM that is counted once keeps no tile store, and - its reads
+             loaded under the count's own read filters, lsg_set_load_filter - carries 8-byte keys alone through the scatter and the sort)
              -> lsg_pileup_count (hands that count over) -> lsg_call_step1 (merge + step 1) [-> all-gather of PASS-candidate call
              rows when N > 1]
            A step = one such pass on a FRESH load; the timed steps follow a warm-up load.  LSG_BENCH_KEEP_STORE=1: the load also writes
