@@ -323,7 +323,11 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     kw = {} if args.reads is None else {"n_reads": int(args.reads)}
-    model = synth.named("C2", **kw)
+    # the compact arrays as this package's own decoder (csrc/ingest.hip) leaves them in HBM: tile-phased (LSG_LAYOUT_PHASED,
+    # include/longsom_hip.h) - a read's events inside one 64-position tile lie inside one aligned 128-byte line; LSG_BENCH_COMPACT=1:
+    # segment after segment without gaps (round 4's input)
+    phased = os.environ.get("LSG_BENCH_COMPACT") != "1"
+    model = synth.named("C2", layout=1 if phased else 0, **kw)
     eng = Engine(local_rank, stream=torch.cuda.current_stream().cuda_stream)
     eng.set_contigs(model.contig_len)
     eng.synth_reference(model.seed)
@@ -337,7 +341,11 @@ def main():
     # the rank's compact read-record arrays, generated once in HBM (untimed): what a device-resident decode of its share of the BAM hands over
     reads = eng.synth_generate(sub_model(model, g_lo, g_hi) if world > 1 else model)
     eng.set_region(lo[0], lo[1], hi[0], hi[1])
-    n_reads, n_segs, n_events = int(reads.n_reads), int(reads.n_segs), int(reads.n_events)
+    n_reads, n_segs, n_events = int(reads.n_reads), int(reads.n_segs), int(reads.n_events)      # (n_events: the event array's extent, gaps included)
+
+    class _SegLen:                                                 # the generated seg_len array where it lies, for one sum
+        __cuda_array_interface__ = {"shape": (n_segs,), "typestr": "<i4", "data": (int(reads.seg_len), False), "version": 2}
+    reads_events_sum = int(torch.as_tensor(_SegLen(), device=dev).sum(dtype=torch.int64).item()) if n_segs else 0
     cp, kp = CountParams.longsom_defaults(), CallParams.longsom_defaults()
     # the load drops what SplitBam's MAPQ filter and the pileup's read filter drop (SplitBamCellTypes.py:110-113, BaseCellCounter.py:191,249):
     # in the product the host decode does (hostio.decode_bam(min_mapq=...)); the generated arrays hold every read of the BAM
@@ -410,13 +418,13 @@ def main():
     t0 = time.perf_counter()
     walk_ms, walk_bytes, path_bytes, gather_ms, gather_bytes = 0.0, 0.0, 0.0, 0.0, 0.0
     build_ms = np.zeros(4)
-    fused, direct = False, False
+    fused, direct, lines = False, False, False
     for _ in range(args.steps):
         rows, cols, n_sites, n_cand, n_pass = step()
         st = eng.count_stats()
         bt = eng.build_times()
         path = eng.layout_info()[0]
-        fused, direct = path in (3, 4), path == 4                  # the load made the count (3: k_tm_gather_count, writing the store as well; 4: k_tm_count_direct, no store)
+        fused, direct, lines = path in (3, 4, 5), path in (4, 5), path == 5      # the load made the count (3: k_tm_gather_count, writing the store as well; 4: k_tm_count_direct, no store; 5: the same, every entry fetched as its one 128-byte line)
         walk_ms += st.ms_walk                                      # HIP events around the counting kernel: k_tm_gather_count, or k_tm_walk after a plain load
         # 2 B per admitted event + 24 B per admitted read + 168 B per emitted row - the counting kernel reads every event of
         # the counted region once and emits the rows of the single-job tiles; the plain gather (two-pass loads) reads every stored event once
@@ -461,7 +469,8 @@ def main():
         if max(counts) > gather["cap"]:
             raise RuntimeError("PASS-candidate rows outgrew the agreed all-gather capacity during the timed steps: %s > %d" % (counts, gather["cap"]))
         gather["counts"] = counts
-    vals = torch.tensor([dt, float(cols), float(n_sites), float(n_cand), float(n_reads), float(n_events), float(sum(rows))],
+    n_real_events = int(reads_events_sum)
+    vals = torch.tensor([dt, float(cols), float(n_sites), float(n_cand), float(n_reads), float(n_events), float(sum(rows)), float(n_real_events)],
                         dtype=torch.float64, device=dev)
     if dist_on:
         if backend != "nccl":
@@ -499,7 +508,10 @@ def main():
             "config": {"workload": "C2: whole-genome synthetic long-read workload (hg38/10 + chrM), %d reads x %d barcodes, 2 cell types; one step = "
                                    "one BAM's one-shot pass: device load of the compact read-record arrays (entries binned per tile and sorted by barcode%s) + pileup count + merge + step-1 call%s"
                                    % (model.n_reads, model.n_cb, "; no tile store kept" if direct else ", tile store written", " + RCCL all-gather of PASS-candidate call rows" if world > 1 else ""),
-                       "reads": model.n_reads, "barcodes": model.n_cb, "reads_loaded_all_ranks": int(tot[4]), "events_loaded_all_ranks": int(tot[5]),
+                       "reads": model.n_reads, "barcodes": model.n_cb, "reads_loaded_all_ranks": int(tot[4]), "events_loaded_all_ranks": int(tot[7]),
+                       "input_layout": ("tile-phased (LSG_LAYOUT_PHASED): every segment at an event offset congruent to its reference start modulo 64, gaps of zeros; "
+                                        "event array %.2f GB for %.2f GB of events" % (2 * tot[5] / 1e9, 2 * tot[7] / 1e9)) if phased else "compact: segment after segment",
+                       "count_reads_whole_lines": bool(lines),
                        "sites_counted": int(sites), "rows_emitted": int(tot[6]), "merged_sites": int(tot[2]), "step1_candidates": int(tot[3]),
                        "sharding": "genomic regions balanced by estimated work" if world > 1 else "none",
                        "pass_rows_gathered": int(sum(gather["counts"])) if dist_on and gather["counts"] else None,

@@ -57,6 +57,15 @@ enum { LSG_SYM_A = 0, LSG_SYM_C = 1, LSG_SYM_T = 2, LSG_SYM_G = 3, LSG_SYM_I = 4
  * quality follow htslib bam_plp + pysam PileupColumn semantics as used by BaseCellCounter.py:191-216
  * (anchor base of an indel -> I / D, interior deletion column -> O with the quality of the next
  * query base). */
+/* Where a segment's events lie in `events` is the producer's choice (seg_ev_off; n_events = the array's extent, gaps are never read).
+ * Two layouts are made by this library's own producers (the device BAM decoder, the synthetic generators):
+ *   LSG_LAYOUT_COMPACT  segment after segment, no gaps;
+ *   LSG_LAYOUT_PHASED   "tile-phased": every read's region starts at a multiple of 64 events and every segment at an offset congruent
+ *                       to its reference start modulo 64 (gaps hold 0), so that the events a read has inside one 64-position tile of the
+ *                       pileup lie inside ONE aligned 128-byte line of the array: the count fetches every line once.
+ * lsg_load_reads recognises the second by looking (every admitted segment's (seg_ev_off - seg_start) is a multiple of 64, `events` is
+ * 128-byte aligned); a caller's own arrays may use either, or anything else. */
+enum { LSG_LAYOUT_COMPACT = 0, LSG_LAYOUT_PHASED = 1 };
 typedef struct {
     int64_t n_reads;
     int64_t n_segs;
@@ -368,7 +377,8 @@ typedef struct {
 int lsg_get_count_stats(lsg_ctx* ctx, lsg_count_stats* out);
 
 /* What the load's tile store cost.  path: 2 = the store was built by the load alone, 3 = in the pass that also made the first count
- * (lsg_set_count_at_load), 4 = the load made its count and kept no store (lsg_set_store_policy).  build_ms: wall time
+ * (lsg_set_count_at_load), 4 = the load made its count and kept no store (lsg_set_store_policy), 5 = the same over tile-phased events
+ * (LSG_LAYOUT_PHASED: every entry fetched as its one 128-byte line).  build_ms: wall time
  * lsg_load_reads spent building the store (device kernels + their host synchronisations).  store_bytes: device memory the store, its
  * per-read / per-segment arrays, kept events and cached build temporaries hold.  No reference counterpart: the reference re-reads
  * the BAM per window (BaseCellCounter.py:198-225). */
@@ -398,6 +408,8 @@ typedef struct {
     const int32_t* exon_cum;        /* transcript coordinate of the exon's first base */
     const int64_t* gene_read_off;   /* [G+1] reads [off[g], off[g+1]) belong to gene g */
     const uint8_t* celltype_of;     /* [n_cb] 0 = Cancer                     */
+    int32_t  layout;                /* where the generated events lie: LSG_LAYOUT_COMPACT or LSG_LAYOUT_PHASED (lsg_reads above) */
+    int32_t  pad_;
 } lsg_synth_model;
 
 /* Fills the reference of every contig with the model's synthetic genome, in HBM. */

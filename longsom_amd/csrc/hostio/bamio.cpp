@@ -804,13 +804,18 @@ int lsio_synth_records(const lsg_synth_model* m, lsio_decoded** out) {
         L.read_tid.push_back(r.tid); L.read_pos.push_back(m->exon_start[r.e0] + (r.t_off - m->exon_cum[r.e0]));
         L.read_flag.push_back(r.flag); L.read_mapq.push_back(r.mapq); L.read_cb.push_back(r.cb >= 0 ? r.cb : -1);
         const int32_t end = r.t_off + r.t_len;
+        const bool phased = m->layout == LSG_LAYOUT_PHASED;                  // (include/longsom_hip.h: the gaps hold 0)
+        const size_t base = L.events.size();
         for (int32_t x = r.e0; x <= r.e1; ++x) {
             const int32_t xt0 = m->exon_cum[x], xt1 = xt0 + m->exon_len[x];
             const int32_t lo = r.t_off > xt0 ? r.t_off : xt0, hi = end < xt1 ? end : xt1;
-            L.seg_read.push_back((uint32_t)i); L.seg_start.push_back(m->exon_start[x] + (lo - xt0)); L.seg_len.push_back(hi - lo);
+            const int32_t st = m->exon_start[x] + (lo - xt0);
+            if (phased) L.events.resize(base + (size_t)sm_phase_place((int64_t)(L.events.size() - base), st), 0);
+            L.seg_read.push_back((uint32_t)i); L.seg_start.push_back(st); L.seg_len.push_back(hi - lo);
             L.seg_ev_off.push_back((int64_t)L.events.size());
             for (int32_t j = lo; j < hi; ++j) L.events.push_back(sm_event(m, ig, &r, j, xt0, xt1, m->exon_start[x]));
         }
+        if (phased) L.events.resize(base + (((L.events.size() - base) + 63) & ~(size_t)63), 0);
     }
     lsio_decoded* o = (lsio_decoded*)calloc(1, sizeof(lsio_decoded));
     o->n_reads = (int64_t)L.read_tid.size(); o->n_segs = (int64_t)L.seg_read.size(); o->n_events = (int64_t)L.events.size();

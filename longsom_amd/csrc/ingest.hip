@@ -85,7 +85,7 @@ __global__ void k_rec_list(const uint8_t* u, const IngBlk* blk, uint32_t n_blk, 
 
 struct RecArgs {
     const uint8_t* u; uint64_t total; const uint64_t* rec_off; uint64_t n_rec;
-    int32_t n_ref; const int64_t* ref_len; lsr::CbTable cbt; int32_t min_mapq, legacy, keep_unlisted;
+    int32_t n_ref; const int64_t* ref_len; lsr::CbTable cbt; int32_t min_mapq, legacy, keep_unlisted, phased;
     uint8_t* keep; int32_t* cb; uint32_t* nseg; uint32_t* nev;
     unsigned long long* counters;         // total, pass, cb_not_found, cb_not_matched, mapq
     unsigned long long* cb_pass; unsigned long long* cb_low; int64_t n_tally;
@@ -124,7 +124,7 @@ __global__ void k_rec_info(RecArgs a) {
                 // (a read without a listed barcode stays, with cb = -1, when lsg_set_keep_unlisted asks: the pool of the genotyping pileup)
                 if (id >= 0 || a.keep_unlisted) {
                     if (!(flag & 0x4) && n_cigar) {
-                        const lsr::Shape sh = lsr::walk<false>(rec, a.legacy, 0, 1, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr);
+                        const lsr::Shape sh = lsr::walk<false>(rec, a.legacy, 0, 1, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, a.phased != 0);
                         if (sh.n_events >= (1ull << 31)) atomicOr(a.status, 16u);
                         else { keep = (uint8_t)(1u | (id >= 0 && clean < raw ? 2u : 0u)); nseg = sh.n_segs; nev = (uint32_t)sh.n_events; }
                     }
@@ -152,7 +152,7 @@ struct KeepFlag { const uint8_t* k; __host__ __device__ uint32_t operator()(cons
 struct Widen { const uint32_t* v; __host__ __device__ unsigned long long operator()(const uint32_t& i) const { return (unsigned long long)v[i]; } };
 
 struct EmitArgs {
-    const uint8_t* u; const uint64_t* rec_off; uint64_t n_rec; int32_t legacy;
+    const uint8_t* u; const uint64_t* rec_off; uint64_t n_rec; int32_t legacy, phased;
     const uint8_t* keep; const int32_t* cb; const uint32_t* ridx; const uint32_t* soff; const unsigned long long* eoff;
     int32_t* read_tid; int32_t* read_pos; uint16_t* read_flag; uint8_t* read_mapq; int32_t* read_cb;
     uint32_t* seg_read; int32_t* seg_start; int32_t* seg_len; int64_t* seg_ev_off; uint16_t* events;
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void k_rec_emit(EmitArgs a) {
             a.read_flag[r] = (uint16_t)((flag & 0x0fffu) | ((k & 2u) ? LSG_FLAG_CB_SUFFIX : 0u)); a.read_mapq[r] = rec[9]; a.read_cb[r] = a.cb[i];
         }
         const uint32_t s0 = a.soff[i];
-        (void)lsr::walk<true>(rec, a.legacy, lane, 64u, r, a.seg_read + s0, a.seg_start + s0, a.seg_len + s0, a.seg_ev_off + s0, (int64_t)a.eoff[i], a.events);
+        (void)lsr::walk<true>(rec, a.legacy, lane, 64u, r, a.seg_read + s0, a.seg_start + s0, a.seg_len + s0, a.seg_ev_off + s0, (int64_t)a.eoff[i], a.events, a.phased != 0);
     }
 }
 
@@ -328,6 +328,8 @@ static int load_bam_impl(lsg_ctx* c, const uint8_t* file, int64_t n_bytes, int64
         ING_HIP(hipMemcpyAsync(&n_rec32, d_base.as<uint32_t>() + n_blk, 4, hipMemcpyDeviceToHost, st));
         ING_HIP(hipStreamSynchronize(st));
     }
+    // the events in the tile-phased layout (LSG_LAYOUT_PHASED): the count then fetches every entry as ONE 128-byte line; LSG_INGEST_COMPACT=1: segment after segment
+    const int32_t phased = getenv("LSG_INGEST_COMPACT") ? 0 : 1;
     const uint64_t n_rec = n_rec32;
     if (n_rec >= 0x7fffff00ull) { set_error("lsg_load_bam: more than 2^31 records; load the file in windows on the host"); return done_ev(-2); }
     if (d_recoff.reserve((n_rec + 1) * 8) || d_keep.reserve(n_rec + 16) || d_cb.reserve((n_rec + 1) * 4) || d_nseg.reserve((n_rec + 2) * 4) || d_nev.reserve((n_rec + 2) * 4) ||
@@ -338,7 +340,7 @@ static int load_bam_impl(lsg_ctx* c, const uint8_t* file, int64_t n_bytes, int64
         RecArgs ra{};
         ra.u = u; ra.total = utotal; ra.rec_off = d_recoff.as<uint64_t>(); ra.n_rec = n_rec; ra.n_ref = c->n_contigs; ra.ref_len = c->d_contig_len.as<int64_t>();
         ra.cbt = lsr::CbTable{d_h.as<uint64_t>(), d_id.as<int32_t>(), d_so.as<uint32_t>(), d_sl.as<uint32_t>(), d_str.as<uint8_t>(), cbt.mask};
-        ra.min_mapq = min_mapq; ra.legacy = legacy_del_merge ? 1 : 0; ra.keep_unlisted = c->keep_unlisted ? 1 : 0;
+        ra.min_mapq = min_mapq; ra.legacy = legacy_del_merge ? 1 : 0; ra.keep_unlisted = c->keep_unlisted ? 1 : 0; ra.phased = phased;
         ra.keep = d_keep.as<uint8_t>(); ra.cb = d_cb.as<int32_t>(); ra.nseg = d_nseg.as<uint32_t>(); ra.nev = d_nev.as<uint32_t>();
         ra.counters = d_cnt.as<unsigned long long>(); ra.cb_pass = d_tpass.as<unsigned long long>(); ra.cb_low = d_tlow.as<unsigned long long>(); ra.n_tally = n_tally;
         ra.status = status;
@@ -390,9 +392,10 @@ static int load_bam_impl(lsg_ctx* c, const uint8_t* file, int64_t n_bytes, int64
     if (o_tid.reserve(((size_t)R + 1) * 4) || o_pos.reserve(((size_t)R + 1) * 4) || o_flag.reserve(((size_t)R + 1) * 2) || o_mapq.reserve((size_t)R + 1) || o_cb.reserve(((size_t)R + 1) * 4) ||
         o_sread.reserve(((size_t)S + 1) * 4) || o_sstart.reserve(((size_t)S + 1) * 4) || o_slen.reserve(((size_t)S + 1) * 4) || o_sevoff.reserve(((size_t)S + 1) * 8) ||
         o_events.reserve(((size_t)E + 1) * 2)) return done_ev(-1);
+    if (phased && E) ING_HIP(hipMemsetAsync(o_events.p, 0, (size_t)E * 2, st));      // (the gaps between the segments hold 0)
     if (R) {
         EmitArgs ea{};
-        ea.u = u; ea.rec_off = d_recoff.as<uint64_t>(); ea.n_rec = n_rec; ea.legacy = legacy_del_merge ? 1 : 0;
+        ea.u = u; ea.rec_off = d_recoff.as<uint64_t>(); ea.n_rec = n_rec; ea.legacy = legacy_del_merge ? 1 : 0; ea.phased = phased;
         ea.keep = d_keep.as<uint8_t>(); ea.cb = d_cb.as<int32_t>(); ea.ridx = d_ridx.as<uint32_t>(); ea.soff = d_soff.as<uint32_t>(); ea.eoff = d_eoff.as<unsigned long long>();
         ea.read_tid = o_tid.as<int32_t>(); ea.read_pos = o_pos.as<int32_t>(); ea.read_flag = o_flag.as<uint16_t>(); ea.read_mapq = o_mapq.as<uint8_t>(); ea.read_cb = o_cb.as<int32_t>();
         ea.seg_read = o_sread.as<uint32_t>(); ea.seg_start = o_sstart.as<int32_t>(); ea.seg_len = o_slen.as<int32_t>(); ea.seg_ev_off = o_sevoff.as<int64_t>(); ea.events = o_events.as<uint16_t>();

@@ -379,7 +379,7 @@ int lsg_get_count_stats(lsg_ctx* c, lsg_count_stats* out) {
 
 int lsg_get_layout_info(lsg_ctx* c, int32_t* path, double* build_ms, int64_t* store_bytes) {
     if (!c) { set_error("lsg_get_layout_info: NULL handle"); return -2; }
-    if (path) *path = c->store_skipped ? 4 : c->load_was_fused ? 3 : 2;       // 3: the load's gather also made the first count (lsg_set_count_at_load)
+    if (path) *path = c->store_skipped ? (c->line_loads ? 5 : 4) : c->load_was_fused ? 3 : 2;       // 3: the load's gather also made the first count (lsg_set_count_at_load)
     if (build_ms) *build_ms = c->layout_build_ms;
     if (store_bytes) {
         int64_t b = 0;

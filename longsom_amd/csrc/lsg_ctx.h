@@ -101,7 +101,7 @@ int live_read_bound_all(lsg_ctx* c);
 __global__ void k_read_end(const uint32_t* seg_read, const int32_t* seg_start, const int32_t* seg_len, int64_t n_segs, int32_t* read_end);      // layout.hip
 __global__ void k_read_end_init(const int32_t* read_pos, int64_t n_reads, int32_t* read_end);
 int depth_cap_drops(lsg_ctx* c, const lsg_count_params* p);   // layout.hip: htslib's max_depth rule -> d_read_drop (or none)
-struct GatherCountSrc { const uint16_t* events; int64_t n_events; const uint64_t* key; const uint32_t* rdv; int32_t cb_bits; };
+struct GatherCountSrc { const uint16_t* events; int64_t n_events; const uint64_t* key; const uint32_t* rdv; int32_t cb_bits; int32_t src_shift; };
 int run_gather_count(lsg_ctx* c, const lsg_count_params* p, const GatherCountSrc& src, bool direct);      // pileup.hip: the load's gather and the first count in one pass (k_tm_gather_count), or the count alone from the caller's events (k_tm_count_direct)
 }
 
@@ -164,6 +164,8 @@ struct lsg_ctx {
     float build_ms[4] = {0, 0, 0, 0};     // HIP-event times of the last build: capacities + scatter, sort, fill, gather
     int64_t max_live_reads = -1;          // layout.hip: bound on the reads live at once in the reference's pileup buffer (-1 = stale)
     int64_t max_live_all = -1;            // the same over all reads with a barcode: table-independent, cached per load
+    bool src_phased = false;              // build_store: the last load's events were tile-phased (LSG_LAYOUT_PHASED): an entry = one 128-byte line
+    bool line_loads = false;              // pileup.hip run_gather_count: the last direct count fetched every entry as its one 128-byte line (tile-phased events)
     bool keys_only_off = false;           // build_store: this load sorts values with its keys (set while a load of keys alone is made again)
     int64_t max_live_exact = -1;          // per cell type at position resolution (asked only when the tile-level bounds cannot rule the cap out)
     lsg::DevBuf d_read_drop;              // layout.hip: per read, the pileup's max_depth rule under the last count's parameters: 1 = dropped in every window it overlaps, 2 = in some (d_drop_pairs)

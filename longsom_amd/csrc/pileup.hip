@@ -448,16 +448,22 @@ constexpr uint32_t TMM_FIRST = 1u << 28;      // first entry that is there of a 
 // selected with EXEC (all lanes are active around the block).  A run of one entry: 7 vector operations; first entry of a longer
 // run 8 (+3 when it closes the run before it); others 10.
 constexpr bool TM_ASM = LSG_TM_ASM;
-template <bool HI>
+// AL (k_tm_count_direct over tile-phased events): the lane's event register was loaded from the entry's whole 128-byte LINE, so the lanes
+// outside the entry's positions [first, end) hold somebody else's events: the meta word carries first in its bits 0..5 and 64 - end in its
+// bits 13..18 (its cell-type bit moves from bit 4 to bit 10, TMM_CT10) and EXEC is cut to the entry's lanes before the lanes that count are selected; thr is
+// the base quality itself, compared with the event's low byte in one operation (an event that is not there is 0: include/longsom_hip.h).
+constexpr uint32_t TMM_CT10 = 1u << 10;
+template <bool HI, bool AL = false>
 __device__ __forceinline__ void tm_add(TmState& s, uint32_t m, uint32_t evw, uint32_t thr, uint32_t pkl0, uint32_t one) {
     if (!TM_ASM) {                                   // the same in plain C++ (what the asm block is checked against when it is touched)
         const uint32_t ev = HI ? evw >> 16 : evw & 0xffffu;
         if (m & TMM_CLOSE) { s.nc += s.mask & 0x10001u; s.mask = 0; }
         if (m & TMM_SKIP) return;
-        const bool counted = (ev & 0x8ffu) >= thr;
+        const uint32_t al_lane = threadIdx.x & 63u, al_end = 64u - ((m >> 13) & 63u);
+        const bool counted = AL ? (ev & 0xffu) >= thr && al_lane >= (m & 63u) && al_lane < al_end : (ev & 0x8ffu) >= thr;
         const uint32_t addr = (pkl0 | (ev & 0x700u)) + (m & TMM_CT12);
         const uint32_t lo = (ev & 0xffu) | (m & TMM_FWD);
-        const uint32_t sym8 = (ev >> 8) & 15u, ctone = 1u << (m & TMM_CT4);
+        const uint32_t sym8 = (ev >> 8) & 15u, ctone = AL ? 1u << ((m >> 6) & 16u) : 1u << (m & TMM_CT4);
         if (m & TMM_SINGLE) {
             if (counted) { tm_lds_add(addr, lo); tm_lds_add(addr + 2048u, 1u); s.nc += ctone; }
         } else if (m & TMM_FIRST) {
@@ -469,7 +475,7 @@ __device__ __forceinline__ void tm_add(TmState& s, uint32_t m, uint32_t evw, uin
         }
         return;
     }
-    uint32_t t0, t1, addr, lo, sa, sb;
+    uint32_t t0, t1, addr, lo, sa, sb; unsigned long long xm;
 #define LSG_TM_ADD(WSEL, BSEL, SYMPOS)                                                                                               \
     asm volatile(                                                                                                                    \
         "s_bitcmp1_b32 %[m], 27\n\t"                                                                                                  \
@@ -517,8 +523,63 @@ __device__ __forceinline__ void tm_add(TmState& s, uint32_t m, uint32_t evw, uin
           [mask] "+v"(s.mask), [nc] "+v"(s.nc)                                                                                       \
         : [ev] "v"(evw), [m] "s"(m), [thr] "s"(thr), [c700] "s"(0x700u), [k8ff] "s"(0x8ffu), [one] "v"(one), [pkl] "v"(pkl0)           \
         : "scc", "vcc", "memory")
-    if (HI) LSG_TM_ADD("WORD_1", "BYTE_2", "24"); else LSG_TM_ADD("WORD_0", "BYTE_0", "8");
+    // the same for an entry of tile-phased events (AL, above): no mask of the event (the compare reads its low byte), EXEC cut to the
+    // entry's lanes [first, end) by two shifts that take their amounts from the meta word (first: bits 0..5; 64 - end: bits 13..18),
+    // the cell type's bit 10 shifted down to make 0 or 16
+#define LSG_TM_ADD_AL(WSEL, BSEL, SYMPOS)                                                                                            \
+    asm volatile(                                                                                                                    \
+        "s_bitcmp1_b32 %[m], 27\n\t"                                                                                                  \
+        "s_cbranch_scc0 1f\n\t"                                                                                                       \
+        "v_and_b32 %[t1], 0x10001, %[mask]\n\t"                                                                                       \
+        "v_add_u32 %[nc], %[nc], %[t1]\n\t"                                                                                           \
+        "v_mov_b32 %[mask], 0\n"                                                                                                      \
+        "1:\n\t"                                                                                                                      \
+        "s_bitcmp1_b32 %[m], 29\n\t"                                                                                                  \
+        "s_cbranch_scc1 5f\n\t"                                                                                                       \
+        "s_and_b32 %[sa], %[m], 0x1000\n\t"                                                                                           \
+        "v_and_b32_sdwa %[addr], %[c700], %[ev] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:" WSEL "\n\t"             \
+        "s_lshr_b32 %[sb], %[m], 13\n\t"                                                                                              \
+        "v_or3_b32 %[addr], %[addr], %[pkl], %[sa]\n\t"                                                                               \
+        "s_lshl_b64 %[xm], -1, %[m]\n\t"                          /* the lanes from the entry's first position upwards ... */      \
+        "s_lshr_b64 exec, -1, %[sb]\n\t"                          /* ... and below its end */                                      \
+        "s_and_b32 %[sb], %[m], 0x100000\n\t"                                                                                         \
+        "s_and_b64 exec, exec, %[xm]\n\t"                                                                                             \
+        "v_or_b32_sdwa %[lo], %[sb], %[ev] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:" BSEL "\n\t"                  \
+        "s_lshr_b32 %[sa], %[m], 6\n\t"                                                                                               \
+        "v_cmpx_le_u32_sdwa vcc, %[thr], %[ev] src0_sel:DWORD src1_sel:" BSEL "\n\t"   /* EXEC = the lanes that count this event */ \
+        "s_lshl_b32 %[sa], 1, %[sa]\n\t"                                                                                              \
+        "s_bitcmp1_b32 %[m], 30\n\t"                                                                                                  \
+        "s_cbranch_scc0 2f\n\t"                                                                                                       \
+        "ds_add_u32 %[addr], %[lo]\n\t"                                                                                               \
+        "ds_add_u32 %[addr], %[one] offset:2048\n\t"                                                                                  \
+        "v_add_u32 %[nc], %[sa], %[nc]\n\t"                                                                                           \
+        "s_branch 4f\n"                                                                                                               \
+        "2:\n\t"                                                                                                                      \
+        "v_bfe_u32 %[t1], %[ev], " SYMPOS ", 4\n\t"                                                                                   \
+        "s_bitcmp1_b32 %[m], 28\n\t"                                                                                                  \
+        "s_cbranch_scc0 3f\n\t"                                                                                                       \
+        "ds_add_u32 %[addr], %[lo]\n\t"                                                                                               \
+        "ds_add_u32 %[addr], %[one] offset:2048\n\t"                                                                                  \
+        "v_lshl_or_b32 %[mask], %[one], %[t1], %[sa]\n\t"                                                                             \
+        "s_branch 4f\n"                                                                                                               \
+        "3:\n\t"                                                                                                                      \
+        "v_bfe_u32 %[t0], %[mask], %[t1], 1\n\t"                                                                                      \
+        "v_lshl_or_b32 %[t0], %[t0], 16, %[one]\n\t"                                                                                  \
+        "ds_add_u32 %[addr], %[lo]\n\t"                                                                                               \
+        "ds_add_u32 %[addr], %[t0] offset:2048\n\t"                                                                                   \
+        "v_lshl_or_b32 %[t1], %[one], %[t1], %[sa]\n\t"                                                                               \
+        "v_or_b32 %[mask], %[mask], %[t1]\n"                                                                                          \
+        "4:\n\t"                                                                                                                      \
+        "s_mov_b64 exec, -1\n"                                                                                                        \
+        "5:"                                                                                                                          \
+        : [t0] "=&v"(t0), [t1] "=&v"(t1), [addr] "=&v"(addr), [lo] "=&v"(lo), [sa] "=&s"(sa), [sb] "=&s"(sb), [xm] "=&s"(xm),        \
+          [mask] "+v"(s.mask), [nc] "+v"(s.nc)                                                                                       \
+        : [ev] "v"(evw), [m] "s"(m), [thr] "s"(thr), [c700] "s"(0x700u), [one] "v"(one), [pkl] "v"(pkl0)                              \
+        : "scc", "vcc", "memory")
+    if (AL) { if (HI) LSG_TM_ADD_AL("WORD_1", "BYTE_2", "24"); else LSG_TM_ADD_AL("WORD_0", "BYTE_0", "8"); }
+    else if (HI) LSG_TM_ADD("WORD_1", "BYTE_2", "24"); else LSG_TM_ADD("WORD_0", "BYTE_0", "8");
 #undef LSG_TM_ADD
+#undef LSG_TM_ADD_AL
 }
 struct TmCounters {
     const uint32_t* pl; int lane; uint32_t ncdup;
@@ -718,6 +779,7 @@ struct TgArgs {
     const uint16_t* events; int64_t n_events;
     const uint64_t* key; const uint32_t* rdv; int32_t cb_bits;      // the sort's output (store.hip sort_key): read in place
     uint64_t src_mask;                                                // the bits of the key's source field (a load that sorts keys alone - rdv null - keeps the entry's two flags above them)
+    int32_t src_shift;                                                // 6: tile-phased events (LSG_LAYOUT_PHASED) - the source field is the entry's 128-byte line, the event index = line << 6 | first position; 0: the event index itself
     const uint32_t* tile_off; const uint32_t* blk_off;
     uint32_t* s0; uint8_t* b8; uint32_t* rd; uint4* store; uint16_t* ext;
     const uint32_t* nchunks;                                          // the plan's number of chunks, still on the device
@@ -764,7 +826,7 @@ __device__ __forceinline__ void tg_range(const CountArgs& a, const TmArgs& tm, c
         const uint32_t cb = (uint32_t)K.k & cbm;
         const uint32_t cb_prev = (uint32_t)__shfl((int)cb, lane == 0 ? 32 : lane - 1), cb_next = (uint32_t)__shfl((int)cb, lane == 31 ? 33 : lane + 1);
         const uint32_t geom = (uint32_t)(K.k >> tg.cb_bits), first = valid ? geom & 63u : 0u, nev = valid ? ((geom >> 6) & 63u) + 1u : 0u;
-        const uint64_t src = K.k >> (tg.cb_bits + 12);
+        const uint64_t src = ((K.k >> (tg.cb_bits + 12)) << tg.src_shift) | (tg.src_shift ? geom & 63u : 0u);
         const bool rs = i == 0 || cb_prev != cb;
         const bool single = rs && (i + 1 == n || cb_next != cb);
         const bool own = valid && p >= s0r && p < s1r;
@@ -1063,7 +1125,7 @@ __device__ __forceinline__ TdKeys64 td_load_keys64(const TgArgs& tg, uint32_t i_
     else r.v = __builtin_nontemporal_load(tg.rdv + off + ic);
     return r;
 }
-template <bool KO>
+template <bool KO, bool AL>
 __device__ __forceinline__ void td_range64(const CountArgs& a, const TmArgs& tm, const TgArgs& tg, TmState& st, TgStat& stat, uint32_t i0, uint32_t i1, uint32_t off, uint32_t n,
                                            uint32_t thr, uint32_t pkl0, uint32_t one, int lane, TdKeys64 K, uint64_t key_before) {
     const int ng = (int)((i1 - i0 + 63u) >> 6);
@@ -1081,15 +1143,20 @@ __device__ __forceinline__ void td_range64(const CountArgs& a, const TmArgs& tm,
         const uint32_t up = (uint32_t)__shfl_up((int)cb, 1), dn = (uint32_t)__shfl_down((int)cb, 1);
         const uint32_t cb_prev = lane == 0 ? cb_carry : up;
         const uint32_t geom = (uint32_t)(K.k >> tg.cb_bits), first = geom & 63u, nev = valid ? ((geom >> 6) & 63u) + 1u : 0u;
-        const uint64_t addr = evb + 2ull * (KO ? (K.k >> (tg.cb_bits + 12)) & tg.src_mask : K.k >> (tg.cb_bits + 12));
+        const uint64_t fld = KO ? (K.k >> (tg.cb_bits + 12)) & tg.src_mask : K.k >> (tg.cb_bits + 12);
+        // AL: the address of the entry's LINE: every lane loads its two bytes of it (one request, inside the array: a line that holds an
+        // event of the array lies in that event's page), the lanes outside the entry are left out by tm_add<.., true>
+        const uint64_t addr = AL ? evb + (fld << 7) : evb + 2ull * ((fld << tg.src_shift) | (tg.src_shift ? first : 0u));
         const bool rs = i == 0 || cb_prev != cb;
         const bool nd = i + 1 == n || (lane < 63 && dn != cb);           // the next entry is another barcode's (lane 63: decided when the next keys are there)
-        w.lo = (uint32_t)addr; w.hi = ((uint32_t)(addr >> 32) & 0xffffu) | (nev << 17) | (first << 25);
+        w.lo = (uint32_t)addr;
+        w.hi = AL ? (uint32_t)(addr >> 32) : ((uint32_t)(addr >> 32) & 0xffffu) | (nev << 17) | (first << 25);
         const uint32_t r = K.v & TG_RV_READ;
         pre.ctv = reinterpret_cast<const uint32_t*>(a.celltype_of)[(cb < (uint32_t)a.n_cb ? cb : 0u) >> 2];
         pre.admw = admp[a.adm && r < (uint32_t)a.n_reads ? r >> 5 : 0u] | adm_all;
         pre.bits = (valid ? 1u : 0u) | (cb < (uint32_t)a.n_cb ? 2u : 0u) | ((K.v & TG_RV_FWD) ? 4u : 0u) | (nd ? 8u : 0u) | (rs ? 16u : 0u) |
                    ((r & 31u) << 8) | (nev << 16) | ((K.v & TG_RV_SEGFIRST) ? (1u << 24) : 0u) | ((cb & 3u) << 26);
+        if (AL) pre.bits |= ((first & 7u) << 5) | ((first >> 3) << 13);      // (the meta word's low six bits, finish_meta)
         cb_last = cb_carry = rl(cb, 63);
     };
     // cb_after: barcode of the entry after the group (the next group's lane 0)
@@ -1101,7 +1168,11 @@ __device__ __forceinline__ void td_range64(const CountArgs& a, const TmArgs& tm,
         if (cls < 2) { stat.ev += (pre.bits >> 16) & 0xffu; stat.sg += (pre.bits >> 24) & 1u; ++stat.ne; }
         const bool nd = (pre.bits & 8u) != 0 || (lane == 63 && cb_after != cb_of_last);
         const bool single = (pre.bits & 16u) != 0 && nd;
-        uint32_t M = cls < 2 ? (cls ? (TMM_CT4 | TMM_CT12) : 0u) | ((pre.bits & 4u) ? TMM_FWD : 0u) | (single ? TMM_SINGLE : 0u) : TMM_SKIP;
+        uint32_t M = cls < 2 ? (cls ? ((AL ? TMM_CT10 : TMM_CT4) | TMM_CT12) : 0u) | ((pre.bits & 4u) ? TMM_FWD : 0u) | (single ? TMM_SINGLE : 0u) : TMM_SKIP;
+        if (AL && cls < 2) {                                                                  // the entry's lanes: first, 64 - end
+            const uint32_t first = ((pre.bits >> 5) & 7u) | (((pre.bits >> 13) & 7u) << 3), nev = (pre.bits >> 16) & 0xffu;
+            M |= first | (((64u - first - nev) & 63u) << 13);
+        }
         if (pre.bits & 16u) M |= TMM_RS;
         return M;
     };
@@ -1127,9 +1198,27 @@ __device__ __forceinline__ void td_range64(const CountArgs& a, const TmArgs& tm,
             E[u] = (uint32_t)(int32_t)(int16_t)__builtin_amdgcn_raw_buffer_load_b16(rs, (int)(lane2 - (hi >> 24)), 0, 0);
         }
     };
+    // AL: a scalar base per entry, the lane's 32-bit offset the same for all - `global_load_sshort v, v_off, s[base]`, which the compiler
+    // selects only while it sees the offset's zero-extension beside the load (hoisted out of the loop as a 64-bit pair it becomes a
+    // 64-bit vector add per entry: the offset is made opaque once per batch)
+    auto issue_line = [&](const TdW& w, int q, uint32_t (&E)[TD_Q]) {
+        uint32_t off = lane2;
+        asm volatile("" : "+v"(off));
+        // (eight bases first, then their eight loads: a base fresh from v_readlane needs five wait states before a load may read it)
+#pragma unroll
+        for (int u0 = 0; u0 < TD_Q; u0 += 8) {
+            uint64_t base[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) base[u] = ((uint64_t)rl(w.hi, q * TD_Q + u0 + u) << 32) | rl(w.lo, q * TD_Q + u0 + u);
+            asm volatile("" : "+s"(base[0]), "+s"(base[1]), "+s"(base[2]), "+s"(base[3]), "+s"(base[4]), "+s"(base[5]), "+s"(base[6]), "+s"(base[7]));
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                E[u0 + u] = (uint32_t)(int32_t)*(const __attribute__((address_space(1))) int16_t*)((const __attribute__((address_space(1))) char*)(uintptr_t)base[u] + (uint64_t)off);
+        }
+    };
     auto consume = [&](const uint32_t (&E)[TD_Q], int q, uint32_t M) {
 #pragma unroll
-        for (int u = 0; u < TD_Q; ++u) tm_add<false>(st, rl(M, q * TD_Q + u), E[u], thr, pkl0, one);
+        for (int u = 0; u < TD_Q; ++u) tm_add<false, AL>(st, rl(M, q * TD_Q + u), E[u], thr, pkl0, one);
     };
     auto fence = []() { asm volatile("" ::: "memory"); };
     uint32_t EA[TD_Q], EB[TD_Q];
@@ -1138,9 +1227,9 @@ __device__ __forceinline__ void td_range64(const CountArgs& a, const TmArgs& tm,
     fence();
     K = td_load_keys64<KO>(tg, i0 + 64u, off, n, lane);
     fence();
-    issue(wc, 0, EA);
+    if (AL) issue_line(wc, 0, EA); else issue(wc, 0, EA);
     fence();
-    issue(wc, 1, EB);
+    if (AL) issue_line(wc, 1, EB); else issue(wc, 1, EB);
     fence();
     for (int g = 0; g < ng; ++g) {
         const uint32_t cb_after = rl((uint32_t)K.k & cbm, 0);               // (K: the keys of group g + 1, asked for an iteration ago)
@@ -1151,15 +1240,17 @@ __device__ __forceinline__ void td_range64(const CountArgs& a, const TmArgs& tm,
         fence();
 #pragma unroll
         for (int sb = 0; sb < TD_NQ; sb += 2) {                // batch sb is counted while sb + 1 is in flight; its registers take batch sb + 2's loads
-            consume(EA, sb, Mc); issue(sb + 2 < TD_NQ ? wc : wn, (sb + 2) % TD_NQ, EA);
-            consume(EB, sb + 1, Mc); issue(sb + 3 < TD_NQ ? wc : wn, (sb + 3) % TD_NQ, EB);
+            consume(EA, sb, Mc);
+            if (AL) issue_line(sb + 2 < TD_NQ ? wc : wn, (sb + 2) % TD_NQ, EA); else issue(sb + 2 < TD_NQ ? wc : wn, (sb + 2) % TD_NQ, EA);
+            consume(EB, sb + 1, Mc);
+            if (AL) issue_line(sb + 3 < TD_NQ ? wc : wn, (sb + 3) % TD_NQ, EB); else issue(sb + 3 < TD_NQ ? wc : wn, (sb + 3) % TD_NQ, EB);
         }
         wc = wn;
     }
     st.nc += st.mask & 0x10001u; st.mask = 0;
 }
 
-template <bool KO>
+template <bool KO, bool AL>
 __global__ __launch_bounds__(TMW_WAVES * 64) __attribute__((amdgpu_waves_per_eu(LSG_TD_WAVES))) void k_tm_count_direct(CountArgs a, TmArgs tm, TgArgs tg) {
     __shared__ __attribute__((aligned(8192))) uint32_t planes[2][2][8 * 64];
     __shared__ uint32_t nc_sh[2][64];
@@ -1170,7 +1261,7 @@ __global__ __launch_bounds__(TMW_WAVES * 64) __attribute__((amdgpu_waves_per_eu(
     WaveBook& book = books[wv];
     book_init(book, lane);
     if (lane == 0) book.src = 1;
-    const uint32_t thr = bq_threshold(a), pkl0 = lds_addr(pl + lane);
+    const uint32_t thr = AL ? (uint32_t)a.min_bq : bq_threshold(a), pkl0 = lds_addr(pl + lane);      // (AL: 1 <= min_bq <= 255, run_gather_count)
     uint32_t one = 1u;
     asm volatile("" : "+v"(one));
     TgStat stat; stat.ev = 0; stat.sg = 0; stat.ne = 0;
@@ -1238,7 +1329,7 @@ __global__ __launch_bounds__(TMW_WAVES * 64) __attribute__((amdgpu_waves_per_eu(
             const uint32_t i0 = s0r - base, i1 = s1r - base < tcnt ? s1r - base : tcnt;
             if (counting && i1 > i0) {
                 TmState st; st.nc = 0; st.mask = 0;
-                td_range64<KO>(a, tm, tg, st, stat, i0, i1, off, tcnt, thr, pkl0, one, lane, K64, kb);
+                td_range64<KO, AL>(a, tm, tg, st, stat, i0, i1, off, tcnt, thr, pkl0, one, lane, K64, kb);
                 if (st.nc & 0xffffu) atomicAdd(&nc_sh[0][lane], st.nc & 0xffffu);
                 if (st.nc >> 16) atomicAdd(&nc_sh[1][lane], st.nc >> 16);
             }
@@ -1414,7 +1505,7 @@ __global__ __launch_bounds__(64) void k_tm_walk_wide_direct(CountArgs a, TmArgs 
             const uint32_t v = tg.rdv ? tg.rdv[jb.off + i] : (uint32_t)(k >> 32) & (TG_RV_FWD | TG_RV_SEGFIRST), cb = (uint32_t)k & cbm, r = v & TG_RV_READ;
             const bool rs = i == 0 || ((uint32_t)tg.key[jb.off + i - 1] & cbm) != cb;
             const uint32_t geom = (uint32_t)(k >> tg.cb_bits), first = geom & 63u, nev = ((geom >> 6) & 63u) + 1u;
-            const uint64_t src = (k >> (tg.cb_bits + 12)) & tg.src_mask;
+            const uint64_t src = (((k >> (tg.cb_bits + 12)) & tg.src_mask) << tg.src_shift) | (tg.src_shift ? first : 0u);
             uint32_t cls = 2;
             bool ok = cb < (uint32_t)a.n_cb;
             if (ok && a.adm) ok = (reinterpret_cast<const uint32_t*>(a.adm)[r >> 5] >> (r & 31u)) & 1u;
@@ -1604,7 +1695,7 @@ int run_gather_count(lsg_ctx* c, const lsg_count_params* p, const GatherCountSrc
     if (int rc = count_prepare(c, p, L)) return rc;
     TgArgs tg{};
     tg.events = src.events; tg.n_events = src.n_events; tg.key = src.key; tg.rdv = src.rdv; tg.cb_bits = src.cb_bits;
-    tg.src_mask = (1ull << ((src.rdv ? 52 : 50) - src.cb_bits)) - 1ull;
+    tg.src_mask = (1ull << ((src.rdv ? 52 : 50) - src.cb_bits)) - 1ull; tg.src_shift = src.src_shift;
     if (!src.rdv && (!direct || L.a.adm)) return 1;      // (keys alone carry no read index: a count that looks reads up is made from a load that kept them; build_store loads again)
     tg.tile_off = c->d_tile_off.as<uint32_t>(); tg.blk_off = c->tm[TM_BLK_OFF].as<uint32_t>();
     tg.s0 = c->tm[TM_S0].as<uint32_t>(); tg.b8 = c->tm[TM_B].as<uint8_t>(); tg.rd = c->tm[TM_RD].as<uint32_t>();
@@ -1621,8 +1712,13 @@ int run_gather_count(lsg_ctx* c, const lsg_count_params* p, const GatherCountSrc
         LSG_HIP(hipMemsetAsync(c->d_xcd_queues.p, 0, 8 * 128, st));
         tg.queues = c->d_xcd_queues.as<unsigned long long>();
         const unsigned grid = (unsigned)(c->n_cus * tune_int("LSG_GRID_TD", 12));
-        if (tg.rdv) hipLaunchKernelGGL(k_tm_count_direct<false>, dim3(grid), dim3(TMW_WAVES * 64), 0, st, L.a, L.tm, tg);
-        else hipLaunchKernelGGL(k_tm_count_direct<true>, dim3(grid), dim3(TMW_WAVES * 64), 0, st, L.a, L.tm, tg);
+        // tile-phased events: an entry is fetched as its one 128-byte line (tm_add<.., true>: the quality compare reads the event's low byte)
+        const bool al = tg.src_shift == 6 && p->min_bq >= 1 && p->min_bq <= 255 && !getenv("LSG_NO_LINE_LOADS");
+        c->line_loads = al;
+        if (tg.rdv && al) hipLaunchKernelGGL((k_tm_count_direct<false, true>), dim3(grid), dim3(TMW_WAVES * 64), 0, st, L.a, L.tm, tg);
+        else if (tg.rdv) hipLaunchKernelGGL((k_tm_count_direct<false, false>), dim3(grid), dim3(TMW_WAVES * 64), 0, st, L.a, L.tm, tg);
+        else if (al) hipLaunchKernelGGL((k_tm_count_direct<true, true>), dim3(grid), dim3(TMW_WAVES * 64), 0, st, L.a, L.tm, tg);
+        else hipLaunchKernelGGL((k_tm_count_direct<true, false>), dim3(grid), dim3(TMW_WAVES * 64), 0, st, L.a, L.tm, tg);
         LSG_HIP(hipEventRecord(c->ev[4], st));
         LSG_HIP(hipEventRecord(c->evb[4], st));
         stage("k_tm_count_direct");

@@ -50,11 +50,12 @@ struct BuildArgs {
     int32_t cb_bits;                      // bits of the largest barcode id
     unsigned long long* qhead;            // work queue head of the binning pass
     int32_t lf_min_mq, lf_ignore_orphans; uint32_t lf_flag_exclude;      // the load filter (lsg_set_load_filter)
-    uint32_t* bad;                        // bit 0: a segment's event range lies outside the events; bit 1: a segment's read index outside the reads
+    uint32_t* bad;                        // bit 0: a segment's event range lies outside the events; bit 1: a segment's read index outside the reads; bit 2: an admitted segment whose events are not tile-phased ((seg_ev_off - seg_start) % 64 != 0)
     unsigned long long* n_ev;             // events of the statically admitted segments = events the store will hold
     int32_t* span_diff;                   // [n_tiles + 1] marks of the reads' spans (the depth cap's bound), or null
     int32_t* cap_diff;                    // [n_tiles + 1] marks of the admitted segments' tile ranges: +1 at the first tile, -1 past the last; their running sum = entries per tile
     int32_t window;                       // the reference's pileup windows [1 + k W, 1 + (k + 1) W): an entry never crosses an edge of one
+    int32_t src_shift;                    // 6 when the caller's events are tile-phased (LSG_LAYOUT_PHASED: the key's source field is the entry's 128-byte LINE, its low six bits being the entry's first position), else 0
 };
 
 // The edges of the reference's pileup windows (BaseCellCounter.py:81-113: [1, 50001), [50001, 100001), ...) that lie INSIDE a tile cut
@@ -103,6 +104,7 @@ __global__ __launch_bounds__(SEG_THREADS) void k_seg_static(BuildArgs a) {
     auto mark = [&](uint32_t t, int32_t v) { const int h = slot(t); if (h >= 0) atomicAdd(&hval[h], v); else atomicAdd(a.span_diff + t, v); };
     auto mark_cap = [&](uint32_t t, int32_t v) { const int h = slot(t); if (h >= 0) atomicAdd(&hval[h], v * 65536); else atomicAdd(a.cap_diff + t, v); };
     unsigned long long n_ev = 0;
+    bool unphased = false;
     // A workgroup takes CONSECUTIVE batches (the segments of a coordinate-sorted BAM arrive gene by gene: the next batch marks the same
     // few tiles) and flushes the hash only when the next batch might not fit any more, or after SEG_MAX_SINCE batches (the packed sums
     // stay inside their 16 bits), or at its end.
@@ -160,6 +162,7 @@ __global__ __launch_bounds__(SEG_THREADS) void k_seg_static(BuildArgs a) {
                         key = (uint32_t)cb | (((flag >> 4) & 1u) << 24);
                         tb = tb_[u];
                         n_ev += (unsigned long long)ln;
+                        unphased |= ((o - st) & 63) != 0;
                         mark_cap(tb + ((uint32_t)st >> 6), 1);
                         mark_cap(tb + ((uint32_t)(st + ln - 1) >> 6) + 1, -1);
                         // one more entry in the tile of every window edge strictly inside the segment: rare (one segment in forty), so not
@@ -220,6 +223,7 @@ __global__ __launch_bounds__(SEG_THREADS) void k_seg_static(BuildArgs a) {
     if ((threadIdx.x & 63) == 0 && n_ev) atomicAdd(&s_ev, n_ev);
     __syncthreads();
     if (threadIdx.x == 0 && s_ev) atomicAdd(a.n_ev, s_ev);
+    if (__syncthreads_or(unphased ? 1 : 0) && threadIdx.x == 0) atomicOr(a.bad, 4u);
 }
 
 // The scatter of the (segment, tile) entries into their tiles' regions, with the atomics aggregated per workgroup in an LDS hash.  The
@@ -370,7 +374,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(BuildArgs a) {
                             // known (b1, b1 + W, ...); a segment that starts behind its tile's edge finds it one window before b1
                             int64_t edge = -1;
                             { int64_t e = g.b1 - a.window; while (e + a.window <= lo) e += a.window; if (e > tstart && e <= lo && e > 1) edge = e; }
-                            const uint64_t src = (uint64_t)(g.evoff + (lo - g.st));             // the entry's first event in the caller's array
+                            const uint64_t src = (uint64_t)(g.evoff + (lo - g.st)) >> a.src_shift;      // the entry's first event in the caller's array (tile-phased events: its line)
                             // everything the gather needs of an entry travels THROUGH the sort (no record fetched through the sort's
                             // permutation afterwards): key = barcode | first position in the tile | events - 1 | source of the events,
                             // sorted on its barcode bits only; value = owning read | first of its segment | forward strand
@@ -584,7 +588,7 @@ __global__ void k_tm_blk_mark(const uint32_t* cap, const uint32_t* blk_off, uint
 constexpr int TMG_BLOCKS = 4, TMG_WAVES = 4;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 struct __attribute__((packed, aligned(2))) U4A2 { u32x4 v; };
-__global__ __launch_bounds__(TMG_WAVES * 64) void k_tm_gather(const uint16_t* events, int64_t n_events, const uint64_t* key, const uint32_t* rdv, int cb_bits,
+__global__ __launch_bounds__(TMG_WAVES * 64) void k_tm_gather(const uint16_t* events, int64_t n_events, const uint64_t* key, const uint32_t* rdv, int cb_bits, int src_shift,
                                                                const uint32_t* tile_off, const uint32_t* blk_off, const uint32_t* blk_tile, uint32_t nblk,
                                                                uint32_t* s0, uint8_t* b8, uint32_t* rd, uint4* store, uint16_t* ext) {
     __shared__ __attribute__((aligned(16))) uint16_t lds[TMG_WAVES][TMG_BLOCKS][8][64];
@@ -620,7 +624,7 @@ __global__ __launch_bounds__(TMG_WAVES * 64) void k_tm_gather(const uint16_t* ev
                 const bool rs = i == 0 || ((uint32_t)key[j - 1] & cbm) != k;
                 const bool single = rs && (i + 1 == n || ((uint32_t)key[j + 1] & cbm) != k);
                 const uint32_t geom = (uint32_t)(k64 >> cb_bits), first = geom & 63u, nev1 = (geom >> 6) & 63u;
-                const uint64_t src = k64 >> (cb_bits + 12);
+                const uint64_t src = ((k64 >> (cb_bits + 12)) << src_shift) | (src_shift ? first : 0u);
                 put(s0 + p, k | ((v & RV_FWD) ? TM_FWD : 0u) | ((v & RV_WHI) ? TM_WHI : 0u) | (rs ? TM_RUNSTART : 0u));
                 put(b8 + p, (uint8_t)(nev1 | ((v & RV_SEGFIRST) ? 64u : 0u) | (single ? 128u : 0u)));
                 put(rd + p, v & RV_READ);
@@ -850,6 +854,9 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
         bad = (uint32_t)hp[2]; n_ev = hp[3]; n_netile = hs[1]; max_cb = R > 0 ? (int32_t)hs[2] : 0; max_live = (int32_t)hs[3]; sum = hp[8];
         nblk = (uint32_t)hp[16];
     }
+    // tile-phased events (LSG_LAYOUT_PHASED): every entry lies inside one aligned 128-byte line of the caller's array; the key carries the line
+    const int src_shift = !(bad & 4u) && ((uintptr_t)events & 127u) == 0 && !getenv("LSG_NO_PHASED") ? 6 : 0;
+    c->src_phased = src_shift != 0;
     if (bad & 2u) { set_error("lsg_load_reads: a segment's read index lies outside the read arrays"); return -2; }
     if (bad & 1u) { set_error("lsg_load_reads: a segment's event range lies outside the events array"); return -2; }
     if (sum >= 0x7FFFFFF0ull) { set_error("lsg_load_reads: %llu tile entries exceed the 31-bit entry index; load the reads in windows", sum); return -2; }
@@ -870,8 +877,8 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
     // ---- 2. scatter (queued BEFORE the copy stream's work below: those two dozen launches are 0.3 ms of host time the scatter need not wait for)
     int bits = 1; while (bits < 24 && (1ll << bits) <= (long long)max_cb) ++bits;      // the barcode bits of the sort key
     DevBuf &key_a = c->bt[BT_KEY_A], &key_b = c->bt[BT_KEY_B], &val_a = c->bt[BT_VAL_A], &val_b = c->bt[BT_VAL_B];
-    if (n_events >= (1ll << (52 - bits))) {
-        set_error("lsg_load_reads: %lld events with %d-bit barcode ids do not fit the packed sort key (events < 2^%d): load the reads in windows", (long long)n_events, bits, 52 - bits);
+    if ((n_events >> src_shift) >= (1ll << (52 - bits))) {
+        set_error("lsg_load_reads: %lld events with %d-bit barcode ids do not fit the packed sort key (events < 2^%d): load the reads in windows", (long long)n_events, bits, 52 - bits + src_shift);
         return -2;
     }
     // A load that is counted once, without a store, by a count that admits every stored read (the filters of the load) and whose depth cap
@@ -880,7 +887,7 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
     // all (its rows outgrow their buffer), the load starts again with values (keys_only_off).
     bool keys_only = c->cal_enabled && c->store_policy == LSG_STORE_SKIP_WHEN_COUNTED && !getenv("LSG_NO_DIRECT_COUNT") && !getenv("LSG_NO_FUSED_LOAD") &&
                      !getenv("LSG_NO_KEYS_ONLY") && !c->keys_only_off && c->n_ct >= 1 && c->n_ct <= 2 && c->n_cb > 0 && c->copy_stream && n_events >= 64 &&
-                     n_events < (1ll << 39) && n_events < (1ll << (50 - bits));
+                     n_events < (1ll << 39) && (n_events >> src_shift) < (1ll << (50 - bits));
     if (keys_only) {
         const lsg_count_params& q = c->cal_params;
         if (q.min_mq != c->st_min_mq || q.flag_exclude != c->st_flag_exclude || (q.ignore_orphans != 0) != (c->st_ignore_orphans != 0)) keys_only = false;
@@ -891,7 +898,7 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
     if (key_a.reserve(N * 8 + 16) || key_b.reserve(N * 8 + 16) || (!keys_only && (val_a.reserve(N * 4 + 16) || val_b.reserve(N * 4 + 16))) ||
         c->bt[BT_CURSOR].reserve(((size_t)T + 2) * 4)) return -1;
     // (the cursors in a buffer of their own: the plan's tile-level half may be at work in BT_PER_TILE beside the scatter)
-    a.cursor = c->bt[BT_CURSOR].as<uint32_t>(); a.key = key_a.as<uint64_t>(); a.rdv = keys_only ? nullptr : val_a.as<uint32_t>(); a.cb_bits = bits;
+    a.cursor = c->bt[BT_CURSOR].as<uint32_t>(); a.key = key_a.as<uint64_t>(); a.rdv = keys_only ? nullptr : val_a.as<uint32_t>(); a.cb_bits = bits; a.src_shift = src_shift;
     LSG_HIP(hipMemcpyAsync(a.cursor, c->d_tile_off.p, ((size_t)T + 1) * 4, hipMemcpyDeviceToDevice, st));
     LSG_HIP(hipMemsetAsync(c->d_scalars.p, 0, 8, st));
     hipLaunchKernelGGL(k_bin, dim3(g_bin), dim3(BIN_THREADS), 0, st, a);
@@ -1052,7 +1059,7 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
         stage("plan");
         return 0;
     };
-    const GatherCountSrc gsrc{events, n_events, key_b.as<uint64_t>(), keys_only ? nullptr : val_b.as<uint32_t>(), bits};
+    const GatherCountSrc gsrc{events, n_events, key_b.as<uint64_t>(), keys_only ? nullptr : val_b.as<uint32_t>(), bits, src_shift};
     auto load_again_with_values = [&]() -> int {                 // (a load of keys alone that is not counted that way after all)
         LSG_HIP(hipStreamSynchronize(st)); LSG_HIP(hipStreamSynchronize(c->copy_stream));
         if (getenv("LSG_TIMING")) fprintf(stderr, "[lsg] load: the count from keys alone was not made, loading again with values\n");
@@ -1106,7 +1113,7 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
     {
         const dim3 grid((unsigned)(((((uint64_t)nblk + TMG_BLOCKS - 1) / TMG_BLOCKS + TMG_WAVES - 1) / TMG_WAVES + 7) / 8 * 8));
         hipLaunchKernelGGL(k_tm_gather, grid, dim3(TMG_WAVES * 64), 0, st,
-                           events, n_events, key_b.as<uint64_t>(), val_b.as<uint32_t>(), bits, c->d_tile_off.as<uint32_t>(), blk_off, c->tm[TM_BLK_TILE].as<uint32_t>(), nblk,
+                           events, n_events, key_b.as<uint64_t>(), val_b.as<uint32_t>(), bits, src_shift, c->d_tile_off.as<uint32_t>(), blk_off, c->tm[TM_BLK_TILE].as<uint32_t>(), nblk,
                            c->tm[TM_S0].as<uint32_t>(), c->tm[TM_B].as<uint8_t>(), c->tm[TM_RD].as<uint32_t>(),
                            c->tm[TM_STORE].as<uint4>(), c->tm[TM_EXT].as<uint16_t>());
     }

@@ -18,7 +18,7 @@ __global__ void k_synth_header(lsg_synth_model m, int32_t* read_tid, int32_t* re
     read_flag[i] = r.flag;
     read_mapq[i] = r.mapq;
     read_cb[i] = r.cb >= 0 ? r.cb : -1;
-    ev_cnt[i] = r.t_len;
+    ev_cnt[i] = sm_read_region(&m, &r);
     seg_cnt[i] = (uint32_t)(r.e1 - r.e0 + 1);
 }
 
@@ -33,20 +33,30 @@ __global__ __launch_bounds__(256) void k_synth_fill(lsg_synth_model m, const int
         const int64_t eo = ev_off[i];
         const uint32_t so = seg_off[i];
         const int32_t end = r.t_off + r.t_len;
+        const bool phased = m.layout == LSG_LAYOUT_PHASED;
         if ((int)threadIdx.x <= r.e1 - r.e0) {
-            const int32_t x = r.e0 + (int)threadIdx.x;
-            const int32_t xt0 = m.exon_cum[x], xt1 = xt0 + m.exon_len[x];
-            const int32_t lo = r.t_off > xt0 ? r.t_off : xt0, hi = end < xt1 ? end : xt1;
+            int32_t st = 0, ln = 0; int64_t cur = 0, at = 0;
+            for (int32_t k = 0; k <= (int)threadIdx.x; ++k) { sm_read_segment(&m, &r, k, &st, &ln); at = phased ? sm_phase_place(cur, st) : cur; cur = at + ln; }
             seg_read[so + threadIdx.x] = (uint32_t)i;
-            seg_start[so + threadIdx.x] = m.exon_start[x] + (lo - xt0);
-            seg_len[so + threadIdx.x] = hi - lo;
-            seg_ev_off[so + threadIdx.x] = eo + (lo - r.t_off);
+            seg_start[so + threadIdx.x] = st;
+            seg_len[so + threadIdx.x] = ln;
+            seg_ev_off[so + threadIdx.x] = eo + at;
         }
-        int32_t x = r.e0;
+        // (the events: a thread walks the exons its transcript coordinates fall into, and with them the segments' places)
+        int32_t x = r.e0, st = 0, ln = 0; int64_t at = 0;
+        sm_read_segment(&m, &r, 0, &st, &ln);
+        if (phased) at = sm_phase_place(0, st);
+        int32_t seg_t0 = r.t_off;                                   // transcript coordinate of the segment's first event
         for (int32_t j = r.t_off + (int)threadIdx.x; j < end; j += (int)blockDim.x) {
-            while (m.exon_cum[x] + m.exon_len[x] <= j) ++x;
+            while (m.exon_cum[x] + m.exon_len[x] <= j) {
+                ++x;
+                const int64_t cur = at + ln;
+                seg_t0 += ln;
+                sm_read_segment(&m, &r, x - r.e0, &st, &ln);
+                at = phased ? sm_phase_place(cur, st) : cur;
+            }
             const int32_t xt0 = m.exon_cum[x];
-            events[eo + (j - r.t_off)] = sm_event(&m, ig, &r, j, xt0, xt0 + m.exon_len[x], m.exon_start[x]);
+            events[eo + at + (j - seg_t0)] = sm_event(&m, ig, &r, j, xt0, xt0 + m.exon_len[x], m.exon_start[x]);
         }
     }
 }
@@ -126,6 +136,7 @@ int lsg_synth_generate(lsg_ctx* c, const lsg_synth_model* hm, lsg_reads* out) {
     LSG_HIP(hipStreamSynchronize(st));
     if (o_sread.reserve(((size_t)S + 1) * 4) || o_sstart.reserve(((size_t)S + 1) * 4) || o_slen.reserve(((size_t)S + 1) * 4) ||
         o_sevoff.reserve(((size_t)S + 1) * 8) || o_events.reserve(((size_t)E + 1) * 2)) return -1;
+    if (m.layout == LSG_LAYOUT_PHASED && E > 0) LSG_HIP(hipMemsetAsync(o_events.p, 0, (size_t)E * 2, st));      // (the gaps hold 0)
     if (R > 0) {
         unsigned grid = (unsigned)(R < 65536 * 16 ? R : 65536 * 16);
         hipLaunchKernelGGL(k_synth_fill, dim3(grid), dim3(256), 0, st, m, evoff.as<int64_t>(), segoff.as<uint32_t>(),

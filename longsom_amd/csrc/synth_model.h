@@ -94,6 +94,23 @@ LSG_HD void sm_read_header(const lsg_synth_model* m, int64_t i, sm_read* r) {
     if (sm_hash(m->seed, (uint64_t)i, 3, SM_D_CLIP) & 1ull) r->clip3 = 0;
 }
 
+/* Segment k of a read = its part of exon e0 + k: reference start and length. */
+LSG_HD void sm_read_segment(const lsg_synth_model* m, const sm_read* r, int32_t k, int32_t* start, int32_t* len) {
+    const int32_t x = r->e0 + k, xt0 = m->exon_cum[x], xt1 = xt0 + m->exon_len[x], end = r->t_off + r->t_len;
+    const int32_t lo = r->t_off > xt0 ? r->t_off : xt0, hi = end < xt1 ? end : xt1;
+    *start = m->exon_start[x] + (lo - xt0); *len = hi - lo;
+}
+/* LSG_LAYOUT_PHASED (include/longsom_hip.h): the place of a segment that starts at reference position `start`, behind `cur` events of its
+ * read's region (the region itself starts at a multiple of 64): the next offset congruent to start modulo 64. */
+LSG_HD int64_t sm_phase_place(int64_t cur, int32_t start) { return cur + (((int64_t)start - cur) & 63); }
+/* Events of a read's region under the model's layout: compact = its t_len events; phased = its segments at their phases, rounded up to 64. */
+LSG_HD int64_t sm_read_region(const lsg_synth_model* m, const sm_read* r) {
+    if (m->layout != LSG_LAYOUT_PHASED) return r->t_len;
+    int64_t cur = 0;
+    for (int32_t k = 0; k <= r->e1 - r->e0; ++k) { int32_t st, ln; sm_read_segment(m, r, k, &st, &ln); cur = sm_phase_place(cur, st) + ln; }
+    return (cur + 63) & ~(int64_t)63;
+}
+
 /* indel carried by block blk (transcript coords [8blk, 8blk+8)) of read i: 0 none, >0 deletion of
  * that many bases after offset 1, <0 insertion of that many bases after offset 3.  [lo,hi) is the
  * transcript interval in which the block must lie entirely (read span intersected with the exon). */

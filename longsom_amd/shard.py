@@ -60,7 +60,7 @@ def sub_model(model, g_lo: int, g_hi: int):
     return synth.SynthModel(model.seed, model.contig_names, model.contig_len, model.gene_tid[g_lo:g_hi].copy(),
                             (model.gene_exon_off[g_lo:g_hi + 1] - x0).astype(np.int32), model.exon_start[x0:x1].copy(),
                             model.exon_len[x0:x1].copy(), model.exon_cum[x0:x1].copy(), offr.astype(np.int64), model.celltype_of,
-                            int(offr[-1]) if len(offr) else 0, model.n_cb, model.snp_mod, int(model.read_base + model.gene_read_off[g_lo]))
+                            int(offr[-1]) if len(offr) else 0, model.n_cb, model.snp_mod, int(model.read_base + model.gene_read_off[g_lo]), model.layout)
 
 
 def in_region(keys: np.ndarray, lo, hi) -> np.ndarray:

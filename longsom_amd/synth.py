@@ -33,6 +33,7 @@ class SynthModelC(C.Structure):
         ("n_genes", C.c_int32), ("n_cb", C.c_int32), ("n_contigs", C.c_int32), ("snp_mod", C.c_int32),
         ("gene_tid", C.c_void_p), ("gene_exon_off", C.c_void_p), ("exon_start", C.c_void_p), ("exon_len", C.c_void_p),
         ("exon_cum", C.c_void_p), ("gene_read_off", C.c_void_p), ("celltype_of", C.c_void_p),
+        ("layout", C.c_int32), ("pad_", C.c_int32),
     ]
 
 
@@ -52,6 +53,7 @@ class SynthModel:
     n_cb: int
     snp_mod: int = 15000
     read_base: int = 0
+    layout: int = 0             # LSG_LAYOUT_COMPACT; 1 = LSG_LAYOUT_PHASED (include/longsom_hip.h: every read-in-a-tile inside one 128-byte line)
 
     @property
     def n_genes(self): return len(self.gene_tid)
@@ -60,7 +62,7 @@ class SynthModel:
         p = lambda a: a.ctypes.data_as(C.c_void_p)
         return SynthModelC(self.seed, self.n_reads, self.read_base, self.n_genes, self.n_cb, len(self.contig_len), self.snp_mod,
                            p(self.gene_tid), p(self.gene_exon_off), p(self.exon_start), p(self.exon_len), p(self.exon_cum),
-                           p(self.gene_read_off), p(self.celltype_of))
+                           p(self.gene_read_off), p(self.celltype_of), int(self.layout), 0)
 
 
 def build_model(seed, contigs, scale, n_genes, n_reads, n_cb, chrm_share, cancer_frac=0.4, depth_cap=150_000,
@@ -128,9 +130,11 @@ def build_model(seed, contigs, scale, n_genes, n_reads, n_cb, chrm_share, cancer
                       celltype_of, int(n_reads), int(n_cb), int(snp_mod))
 
 
-def named(config: str, **override) -> SynthModel:
+def named(config: str, layout: int = 0, **override) -> SynthModel:
     kw = dict(CONFIGS[config]); kw.update(override)
-    return build_model(**kw)
+    m = build_model(**kw)
+    m.layout = int(layout)
+    return m
 
 
 def shard_reads(model: SynthModel, rank: int, world: int) -> SynthModel:
@@ -148,4 +152,4 @@ def shard_reads(model: SynthModel, rank: int, world: int) -> SynthModel:
                       (model.gene_exon_off[g_lo:g_hi + 1] - x0).astype(np.int32), model.exon_start[x0:x1].copy(),
                       model.exon_len[x0:x1].copy(), model.exon_cum[x0:x1].copy(), off.astype(np.int64),
                       model.celltype_of, int(off[-1]) if len(off) else 0, model.n_cb, model.snp_mod,
-                      int(model.read_base + model.gene_read_off[g_lo]))
+                      int(model.read_base + model.gene_read_off[g_lo]), model.layout)

@@ -11,6 +11,7 @@ from longsom_amd._lib import CountParams
 from longsom_amd.synth_simple import random_records, random_reference
 from tests.test_count_gpu import make_case
 from tests.test_fuzz_gpu import draw
+from tests.util import phased_records
 
 pytestmark = pytest.mark.gpu
 
@@ -25,6 +26,14 @@ def oracle_rows(rec, lens, refs, ct_of, n_ct, p):
 
 
 def fused_vs_oracle(engine, rec, lens, refs, ct_of, n_ct, p, expect_fused=True, recount_params=()):
+    """... and all of it once more with the same events laid out tile-phased (LSG_LAYOUT_PHASED: what the device BAM decoder hands over):
+    the keys then carry an entry's 128-byte line, and the load that keeps no store fetches every entry as that one line (path 5)"""
+    out = _fused_vs_oracle(engine, rec, lens, refs, ct_of, n_ct, p, expect_fused, recount_params, direct_path=4)
+    assert _fused_vs_oracle(engine, phased_records(rec), lens, refs, ct_of, n_ct, p, expect_fused, recount_params, direct_path=5 if 1 <= p.min_bq <= 255 else 4) == out
+    return out
+
+
+def _fused_vs_oracle(engine, rec, lens, refs, ct_of, n_ct, p, expect_fused, recount_params, direct_path):
     engine.set_contigs(lens)
     for t, r in enumerate(refs):
         engine.load_reference(t, r)
@@ -60,7 +69,7 @@ def fused_vs_oracle(engine, rec, lens, refs, ct_of, n_ct, p, expect_fused=True, 
     finally:
         engine.set_count_at_load(None)
         engine.set_store_policy(engine.STORE_KEEP)
-    assert engine.layout_info()[0] == (4 if expect_fused else 2)
+    assert engine.layout_info()[0] == (direct_path if expect_fused else 2)
     for what in ("the count made by the load that kept no store", "the same count asked for again"):
         rows, cols = engine.pileup_count(p)
         assert cols == want_cols, what

@@ -34,6 +34,26 @@ def test_bam_roundtrip_equals_model_records(tmp_path):
     assert dec.report["CB_not_found"] == int((rec.read_cb < 0).sum()) - dec.report["CB_not_matched"]
 
 
+def test_tile_phased_layout_of_the_model_records():
+    """LSG_LAYOUT_PHASED (include/longsom_hip.h): the same reads, segments and events; every segment at an offset congruent to its reference
+    start modulo 64, every read's region a multiple of 64 events, zeros between the segments; the events-level oracle counts them the same"""
+    from tests.util import assert_same_records, phased_records
+    m = synth.named("C1", n_reads=1500, n_genes=40, n_cb=60)
+    compact = hostio.synth_records(m)
+    m.layout = 1
+    phased = hostio.synth_records(m)
+    assert_same_records(phased, compact, phased_a=True)
+    assert phased.n_events > compact.n_events
+    again = phased_records(compact)                    # (the test helper that lays any compact arrays out the same way)
+    np.testing.assert_array_equal(again.seg_ev_off, phased.seg_ev_off); np.testing.assert_array_equal(again.events, phased.events)
+    refs = [hostio.ref_bases(m.seed, t, int(l)) for t, l in enumerate(m.contig_len)]
+    for ct in range(2):
+        a, b = loader.count(compact, m.contig_len, refs, m.celltype_of, ct), loader.count(phased, m.contig_len, refs, m.celltype_of, ct)
+        for x, y in zip(a[:3], b[:3]):
+            np.testing.assert_array_equal(x, y)
+        assert a[3] == b[3]
+
+
 def test_plp_oracle_matches_decoder_path_on_model_bam(tmp_path):
     m = small_model()
     bam = str(tmp_path / "s.bam")

@@ -8,12 +8,13 @@ import pytest
 
 from longsom_amd import hostio, synth
 from longsom_amd._lib import CountParams, LsgError
+from tests.util import assert_same_records
 
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def both_ways(engine, bam, barcodes, celltype_of, refs, min_mapq=60):
+def both_ways(engine, bam, barcodes, celltype_of, refs, min_mapq=60, compact=False):
     """loads `bam` on the device and through the host decoder; returns (device info, cb_pass, cb_low, DecodedBam)"""
     names, lens, first = hostio.bam_header(bam)
     dec = hostio.decode_bam(bam, barcodes, min_mapq=min_mapq)
@@ -34,8 +35,11 @@ def both_ways(engine, bam, barcodes, celltype_of, refs, min_mapq=60):
         rep["MAPQ"] = info["mapq_filtered"]
     assert rep == dec.report
     np.testing.assert_array_equal(cb_pass, dec.cb_pass); np.testing.assert_array_equal(cb_low, dec.cb_low)
-    for name, _ in dev._SPEC:
-        np.testing.assert_array_equal(getattr(dev, name), getattr(dec.records, name), err_msg=name)
+    if compact:                                                  # (LSG_INGEST_COMPACT: the host decoder's layout, array for array)
+        for name, _ in dev._SPEC:
+            np.testing.assert_array_equal(getattr(dev, name), getattr(dec.records, name), err_msg=name)
+    else:                                                        # the device decoder lays the events out tile-phased (LSG_LAYOUT_PHASED)
+        assert_same_records(dev, dec.records, phased_a=True)
     rows_dev = (engine.pileup_count(), [engine.fetch_counts(ct) for ct in range(2)])
     engine.load_reads(dec.records)
     rows_host = (engine.pileup_count(), [engine.fetch_counts(ct) for ct in range(2)])
@@ -78,7 +82,10 @@ def test_legacy_del_merge_and_low_mapq(engine, tmp_path):
     old = hostio.set_legacy_del_merge(True)
     try:
         both_ways(engine, bam, barcodes, m.celltype_of, refs, min_mapq=30)
+        os.environ["LSG_INGEST_COMPACT"] = "1"                   # the device decoder's compact layout: the host decoder's arrays exactly
+        both_ways(engine, bam, barcodes, m.celltype_of, refs, min_mapq=30, compact=True)
     finally:
+        os.environ.pop("LSG_INGEST_COMPACT", None)
         hostio.set_legacy_del_merge(old)
 
 
