@@ -214,8 +214,13 @@ int lsio_step3_column_kinds(const char* text, int64_t n_bytes, int32_t n_cols, u
                     size_t e = all.find('\n', a);
                     if (e == sv::npos || e > cut[t + 1]) e = cut[t + 1];
                     if (e > a && all[a] != '#') {
+                        // (pandas.read_csv(comment='#') cuts a line at a '#' in its middle too, and gives the columns a short row lacks a
+                        // missing value: both are part of what it infers a column's dtype from)
+                        const size_t line_end = e;
+                        { const void* h = memchr(all.data() + a, '#', e - a); if (h) e = (size_t)((const char*)h - all.data()); }
                         size_t f0 = a;
-                        for (int32_t c = 0; c < n_cols && f0 <= e; ++c) {
+                        for (int32_t c = 0; c < n_cols; ++c) {
+                            if (f0 > e) { k[(size_t)c] |= 1; continue; }               // past the row's last field: NA
                             size_t f1 = all.find('\t', f0);
                             if (f1 == sv::npos || f1 > e) f1 = e;
                             if (!(k[(size_t)c] & 16)) {
@@ -229,6 +234,7 @@ int lsio_step3_column_kinds(const char* text, int64_t n_bytes, int32_t n_cols, u
                             }
                             f0 = f1 + 1;
                         }
+                        e = line_end;
                     }
                     a = e + 1;
                 }

@@ -82,7 +82,7 @@ void lsg_destroy(lsg_ctx* c) {
                       &c->b_read_flag, &c->b_read_mapq, &c->b_read_cb, &c->b_seg_read, &c->b_seg_start, &c->b_seg_len,
                       &c->b_seg_ev_off, &c->b_events, &c->d_read_key, &c->d_read_drop, &c->d_drop_pairs, &c->d_read_adm,
                       &c->d_ne_units, &c->d_ne_mask, &c->d_ne_rowbase, &c->d_ne_rowoff,
-                      &c->d_scalars, &c->d_cub_tmp, &c->d_ix_stat, &c->d_tile_cap, &c->d_tile_off, &c->d_calls, &c->d_site_off, &c->d_tail_table, &c->d_pass_list};
+                      &c->d_scalars, &c->d_cub_tmp, &c->d_ix_stat, &c->d_tile_cap, &c->d_tile_off, &c->d_calls, &c->d_site_off, &c->d_tail_table, &c->d_pass_list, &c->d_defer_list, &c->d_xcd_queues};
     for (auto* b : bufs) b->release();
     for (auto& b : c->d_rows) b.release();
     for (auto& b : c->ref) b.release();
@@ -109,7 +109,7 @@ int lsg_unload_reads(lsg_ctx* c) {
     LSG_HIP(hipStreamSynchronize(c->stream));
     DevBuf* bufs[] = {&c->b_read_tid, &c->b_read_pos, &c->b_read_flag, &c->b_read_mapq, &c->b_read_cb, &c->b_seg_read, &c->b_seg_start, &c->b_seg_len,
                       &c->b_seg_ev_off, &c->b_events, &c->d_read_key, &c->d_read_drop, &c->d_read_adm, &c->d_ne_units, &c->d_ne_mask, &c->d_ne_rowbase, &c->d_ne_rowoff,
-                      &c->d_cub_tmp, &c->d_ix_stat, &c->d_tile_cap, &c->d_tile_off, &c->d_calls, &c->d_site_off, &c->d_pass_list};
+                      &c->d_cub_tmp, &c->d_ix_stat, &c->d_tile_cap, &c->d_tile_off, &c->d_calls, &c->d_site_off, &c->d_pass_list, &c->d_defer_list};
     for (auto* b : bufs) b->release();
     for (auto& b : c->d_rows) b.release();
     for (auto& b : c->gen) b.release();
@@ -186,6 +186,10 @@ int lsg_set_barcodes(lsg_ctx* c, const uint8_t* celltype_of, int32_t n_cb, int32
     if (n_celltypes <= 0 || n_celltypes > LSG_MAX_CELLTYPES) { set_error("lsg_set_barcodes: n_celltypes %d not in [1,%d]", n_celltypes, LSG_MAX_CELLTYPES); return -2; }
     if (n_cb > 0x00FFFFFF) { set_error("lsg_set_barcodes: more than 2^24-1 barcodes"); return -2; }
     LSG_HIP(hipSetDevice(c->device));
+    // the table that is already set stays as it is (setting one drops the resident count: the one a load made under lsg_set_count_at_load
+    // would be made again) - decided HERE, against what the context holds (lsg_load_counts changes n_ct behind any caller's cache)
+    if (c->n_cb == n_cb && c->n_ct == n_celltypes && c->h_celltype_of.size() == (size_t)n_cb && memcmp(c->h_celltype_of.data(), celltype_of, (size_t)n_cb) == 0) return 0;
+    c->h_celltype_of.assign(celltype_of, celltype_of + n_cb);
     if (c->d_celltype_of.reserve((size_t)n_cb)) return -1;
     LSG_HIP(hipMemcpyAsync(c->d_celltype_of.p, celltype_of, (size_t)n_cb, hipMemcpyHostToDevice, c->stream));
     {

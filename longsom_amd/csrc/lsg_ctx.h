@@ -129,6 +129,7 @@ struct lsg_ctx {
     // barcodes
     int32_t n_cb = 0, n_ct = 0;
     lsg::DevBuf d_celltype_of, d_ct_rank;   // ct_rank[cb] = rank of the barcode within its cell type
+    std::vector<uint8_t> h_celltype_of;     // the table as it was set (lsg_set_barcodes leaves an identical one alone)
     uint32_t ct_size[LSG_MAX_CELLTYPES] = {0, 0, 0, 0};
 
     // reads

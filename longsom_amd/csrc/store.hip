@@ -1078,6 +1078,7 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
         const int rc = run_gather_count(c, &c->cal_params, gsrc, true);
         LSG_HIP(hipStreamSynchronize(st));
         if (hipGetLastError() != hipSuccess) { set_error("lsg_load_reads: the count pass failed"); return -1; }
+        if (rc < 0 && rc != -3) return rc;                        // a failure (allocation, HIP) is one: only rows that outgrew their buffer (-3) or a refused count of keys alone (1) load again
         if (rc == 0) {
             plan_finish(c);
             LSG_HIP(hipStreamSynchronize(c->copy_stream));     // (the blocks' tiles: nobody reads them, nothing may still be writing them)
@@ -1102,6 +1103,7 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
         int rc = run_gather_count(c, &c->cal_params, gsrc, false);
         LSG_HIP(hipStreamSynchronize(st));
         if (hipGetLastError() != hipSuccess) { c->tm_valid = false; set_error("lsg_load_reads: the fused gather + count pass failed"); return -1; }
+        if (rc < 0 && rc != -3) { c->tm_valid = false; return rc; }      // (as above: -3 = the rows outgrew their buffer, the store is whole and counted on request)
         plan_finish(c);
         c->load_was_fused = true;
         c->counted_at_load = rc == 0;                         // (a count that could not be kept - rows outgrew their buffer - is made again on request; the store is whole either way)

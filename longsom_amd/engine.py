@@ -91,6 +91,7 @@ class Engine:
         self.n_ct = 0
         self.n_contigs = 0
         self.contig_len = None
+        self._load_settings = {"load_filter": (0, 0, 0), "count_at_load": None, "store_policy": 0, "keep_unlisted": False}      # the library's defaults
         if stream is not None:
             self.set_stream(stream)
         if keep_reads:
@@ -100,6 +101,7 @@ class Engine:
         """Reads failing these are not stored by the next loads (what SplitBamCellTypes.py:110-113 does before BaseCellCounter sees the
         BAM); later counts must be at least as strict.  Default: no filter (lsg_set_load_filter)."""
         _lib.check(self._lib.lsg_set_load_filter(self._h, int(min_mq), int(flag_exclude), int(ignore_orphans)), "lsg_set_load_filter")
+        self._load_settings["load_filter"] = (int(min_mq), int(flag_exclude), int(ignore_orphans))
 
     def set_pileup_window(self, window: int = 50000):
         """the reference's pileup windows (BaseCellCounter.py --bin): the loads that follow cut their entries at the window edges, the depth
@@ -112,11 +114,13 @@ class Engine:
         (lsg_set_count_at_load).  Barcodes, references and region must be set before the load."""
         import ctypes as C
         _lib.check(self._lib.lsg_set_count_at_load(self._h, C.byref(params) if params is not None else None), "lsg_set_count_at_load")
+        self._load_settings["count_at_load"] = params
 
     def set_keep_unlisted(self, on: bool):
         """The BAM loads that follow keep reads without a listed barcode (cb = -1): never counted, but part of the buffer the per-cell
         genotyping's pileup of the unsplit BAM fills (HCCVSingleCellGenotype.py:121-122; lsg_set_keep_unlisted)."""
         _lib.check(self._lib.lsg_set_keep_unlisted(self._h, 1 if on else 0), "lsg_set_keep_unlisted")
+        self._load_settings["keep_unlisted"] = bool(on)
 
     STORE_KEEP, STORE_SKIP_WHEN_COUNTED = 0, 1
 
@@ -126,6 +130,18 @@ class Engine:
         the store afterwards (another count, genotype_cells) raises until reads are loaded again.  STORE_KEEP is the default
         (lsg_set_store_policy)."""
         _lib.check(self._lib.lsg_set_store_policy(self._h, int(policy)), "lsg_set_store_policy")
+        self._load_settings["store_policy"] = int(policy)
+
+    def load_settings(self) -> dict:
+        """what the next loads will do, as this wrapper last set it (load filter, count at load, store policy, unlisted reads): a caller that
+        changes them for one load puts them back with restore_load_settings"""
+        return dict(self._load_settings)
+
+    def restore_load_settings(self, saved: dict):
+        self.set_load_filter(*saved["load_filter"])
+        self.set_count_at_load(saved["count_at_load"])
+        self.set_store_policy(saved["store_policy"])
+        self.set_keep_unlisted(saved["keep_unlisted"])
 
     def unload_reads(self):
         """give the device memory of the resident load (reads, store, rows, call records, cached temporaries) back: lsg_unload_reads"""
@@ -176,13 +192,9 @@ class Engine:
 
     def set_barcodes(self, celltype_of, n_celltypes: int):
         ct = np.ascontiguousarray(celltype_of, dtype=np.uint8)
-        # the table that is already set stays as it is (setting one drops the resident count: the one a load made under
-        # set_count_at_load would be counted again)
-        last = getattr(self, "_table", None)
-        if last is not None and last[1] == int(n_celltypes) and np.array_equal(last[0], ct):
-            return
+        # (a table identical to the one the handle holds is left alone by the library itself: setting one drops the resident count, and the one
+        # a load made under set_count_at_load would be counted again)
         _lib.check(self._lib.lsg_set_barcodes(self._h, _ptr(ct), len(ct), int(n_celltypes)), "lsg_set_barcodes")
-        self._table = (ct.copy(), int(n_celltypes))
         self.n_ct = int(n_celltypes)
         self.n_cb = len(ct)
 

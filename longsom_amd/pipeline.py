@@ -126,6 +126,7 @@ def load_sample(bam: str, barcodes_tsv: str, ref_fasta: str, engine: Engine, min
     decoder (liblongsom_io) + lsg_load_reads; "auto" (default, or LONGSOM_INGEST) = device, and host for a BAM whose records are not
     aligned to its BGZF blocks (not written by htslib).  Same store, same report either way (tests/test_ingest_gpu.py)."""
     ingest = ingest or os.environ.get("LONGSOM_INGEST", "auto")
+    saved = engine.load_settings()                 # (a caller's own engine keeps the load filter / store policy it came with)
     engine.set_count_at_load(count_params)
     engine.set_store_policy(engine.STORE_KEEP if keep_store or count_params is None else engine.STORE_SKIP_WHEN_COUNTED)
     engine.set_keep_unlisted(keep_unlisted)
@@ -138,11 +139,7 @@ def load_sample(bam: str, barcodes_tsv: str, ref_fasta: str, engine: Engine, min
     try:
         return _load_sample(bam, barcodes_tsv, ref_fasta, engine, min_mapq, ingest)
     finally:
-        if once:
-            engine.set_load_filter()
-        engine.set_count_at_load(None)
-        engine.set_store_policy(engine.STORE_KEEP)
-        engine.set_keep_unlisted(False)
+        engine.restore_load_settings(saved)
         hostio.set_keep_unlisted(old_keep)
 
 
@@ -480,12 +477,17 @@ def _run_snv_regions(bam, barcodes_tsv, ref_fasta, out_dir, sample_id, params, e
                 got, ok, fatal = None, 1, None
                 try:
                     # the rank's region and the count's parameters are known before its slice is loaded: the load counts in the same pass
+                    # (and it is the slice's only count: under the count's own read filters, no tile store kept - what load_sample does for one GPU)
                     eng.set_region(lo[0], lo[1], hi[0], hi[1])
-                    eng.set_count_at_load(params.count())
+                    saved = eng.load_settings()
+                    cp_slice = params.count()
+                    eng.set_count_at_load(cp_slice)
+                    eng.set_load_filter(cp_slice.min_mq, cp_slice.flag_exclude, cp_slice.ignore_orphans)
+                    eng.set_store_policy(eng.STORE_SKIP_WHEN_COUNTED)
                     try:
                         got = regions.ingest_slice(eng, bam, plan, lo, hi, bc.barcodes, params.min_mapping_quality)
                     finally:
-                        eng.set_count_at_load(None)
+                        eng.restore_load_settings(saved)
                 except _lib.LsgError as e:
                     if "straddle" in str(e):
                         ok = 0

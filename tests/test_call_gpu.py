@@ -162,3 +162,24 @@ def test_homopolymer_context_at_tile_and_contig_edges(engine):
     assert len(g) == len(w) and not bad, "first mismatch:\n%s\n%s" % (bad[0] if bad else (len(g), len(w)))
     n_up, n_down = sum("LC_Upstream" in l for l in w), sum("LC_Downstream" in l for l in w)
     assert n_up > 20 and n_down > 20, (n_up, n_down)
+
+
+def test_a_table_set_again_after_installed_counts_is_set(engine):
+    """lsg_load_counts changes the handle's number of cell types: the table it held before is not 'the table already set' any more, and
+    setting it again takes effect (the same-table shortcut is decided inside the library, against what the handle holds)"""
+    import numpy as np
+    from longsom_amd import synth
+    m = synth.named("C1", n_reads=4000, n_genes=60, n_cb=50)
+    engine.set_contigs(m.contig_len); engine.synth_reference(m.seed); engine.set_barcodes(m.celltype_of, 2)
+    engine.set_region()
+    engine.synth_reads(m)
+    rows, cols = engine.pileup_count()
+    k0, r0, c0 = engine.fetch_counts(0)
+    engine.load_counts([k0], [c0])                                # one cell type installed: n_ct = 1 inside the handle
+    assert engine.n_ct == 1
+    engine.set_barcodes(m.celltype_of, 2)                         # the very table of before
+    assert engine.n_ct == 2
+    engine.synth_reads(m)
+    assert engine.pileup_count() == (rows, cols)
+    k1, r1, c1 = engine.fetch_counts(1)
+    assert len(k1) == rows[1]

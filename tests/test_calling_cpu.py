@@ -287,6 +287,17 @@ def test_step3_dtypes_come_from_every_row_of_the_table(monkeypatch):
     assert n_diff >= 2                                    # (the dropped row's cell really changed what the survivors print)
 
 
+def test_column_kinds_of_short_rows_and_of_a_comment_in_mid_line():
+    """what pandas infers a dtype from: a row with fewer fields than columns gives the missing ones NA; read_csv(comment='#') cuts a line at a
+    '#' anywhere, so the cells behind it are missing too and the cell it cuts is what is left of it"""
+    K_NA, K_INT, K_FLOAT, K_OTHER = 1, 2, 4, 16
+    t = b"#h\n1\t2\t3\n4\t5\n7\t8#x\t9.5\n"
+    k = tsvio.column_kinds(t, 3)
+    assert list(k) == [K_INT, K_INT, K_INT | K_NA]          # row 2 lacks column 3; row 3 is cut behind "8": its 9.5 is never seen
+    k = tsvio.column_kinds(b"1\tx\n2\t3.5\n", 2)
+    assert list(k) == [K_INT, K_OTHER | K_FLOAT] or list(k) == [K_INT, K_OTHER]
+
+
 def test_step2_scanned_differential_fuzz(monkeypatch):
     """random subsets of the golden step-1 rows with cells replaced by missing values, dots, odd numbers and unknown contigs, blank and
     stray comment lines, with and without a final newline, four distances: the scanned path (or whatever it hands back) gives the

@@ -165,3 +165,36 @@ def test_slices_of_an_indexed_bam_add_up_to_the_whole(engine, tmp_path, source, 
     for ct in range(2):
         for j in range(3):
             np.testing.assert_array_equal(np.concatenate([x[j] for x in parts[ct]]), whole[ct][j])
+
+
+def test_the_whole_device_ingest_path_at_scale(engine, tmp_path):
+    """C2 at 1.5 M reads written as a BAM (1.5 GB, 24 k BGZF blocks) -> pipeline.run_snv, whose default is the device ingest (inflate, record
+    chain, decode, tile-phased events, the count inside the load, no store): the count rows == the digests the CPU oracle wrote for this
+    workload (tests/golden/rows_hash_oracle_c2_1500000.json: tools/oracle_hashes.py over hostio.synth_records), and the read-record arrays
+    the device decoder leaves == the host decoder's for the same file, read for read and event for event"""
+    import json
+    from longsom_amd import pipeline
+    m = synth.named("C2", n_reads=1_500_000)
+    bam, fa, bct = str(tmp_path / "S.bam"), str(tmp_path / "ref.fa"), str(tmp_path / "bc.tsv")
+    hostio.synth_bam(m, bam, fa)
+    barcodes = hostio.synth_barcodes(m)
+    hostio.write_barcodes_tsv(bct, barcodes, m.celltype_of, ["Cancer", "Non-Cancer"])
+    out = pipeline.run_snv(bam, bct, fa, str(tmp_path / "out"), "S", params=pipeline.SnvParams(row_digests=True), engine=engine)
+    assert any(k.startswith("ingest_") for k in out.timings), "the run took the host decoder"
+    want = json.load(open(os.path.join(G, "rows_hash_oracle_c2_1500000.json")))
+    got = out.row_digests
+    assert got["rows"] == want["rows"] and got["columns"] == want["columns"]
+    for ct in range(2):
+        assert got["ct%d" % ct] == want["ct%d" % ct], "count rows of cell type %d differ from the CPU oracle's" % ct
+    # the arrays themselves, device decoder against host decoder
+    names, lens, first = hostio.bam_header(bam)
+    engine.set_keep_reads(True)
+    try:
+        info, _, _ = engine.load_bam(bam, barcodes, min_mapq=60, first_record_offset=first)
+        dev = engine.reads_to_host()
+    finally:
+        engine.set_keep_reads(False)
+    dec = hostio.decode_bam(bam, barcodes, min_mapq=60)
+    assert info["n_records"] == 1_500_000 and dev.n_reads == dec.records.n_reads
+    assert_same_records(dev, dec.records, phased_a=True)
+    engine.unload_reads()

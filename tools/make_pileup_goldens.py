@@ -18,10 +18,17 @@ Writes under tests/golden/:
   pileup.randsfx.*             the same reads with "-1"-suffixed CB tags and barcodes.tsv entries
   pileup.cap.*                 a small deep pile counted with max_depth = 8 (reference's pileup call patched ONLY in that
                                one keyword through the stand-in, see run_counter(max_depth=...))
+  (--check-with-real-pysam, below, writes nothing there)
   pileup.rand.HCCV.tsv, pileup.rand.genotype.{All,Alt}.tsv, pileup.randsfx.genotype.All.tsv
                                per-cell genotyping: the reference's HCCVSingleCellGenotype.py run on the UNSPLIT
                                random BAM at target sites drawn from its own count tables (every printed class as the expected
                                alt, chrM sites, sites either side of the 50 kb bin edge)
+
+--check-with-real-pysam: ONE command away from a real pin of SURVEY §8a rows a4-a5.  Where `import pysam` and `import pybedtools`
+succeed (they do not in the build container: exit status 3 and a message), the SAME driver runs over the real libraries instead of
+tools/minipysam.py, writes into a scratch directory and compares every file with the committed one under tests/golden/: exit status 0
+when all agree, 1 with the list of those that differ.  The fixtures whose pile is capped (pileup.cap*, made by passing another
+max_depth to the stand-in's pileup call) are left out: a Cython method cannot be patched without touching the reference's source.
 """
 import contextlib
 import importlib.util
@@ -44,6 +51,8 @@ OUT = os.path.join(ROOT, "tests", "golden")
 
 import minipysam  # noqa: E402
 from longsom_amd import bamwrite  # noqa: E402
+
+REAL_PYSAM = False          # --check-with-real-pysam: the reference's imports resolve to the installed pysam / pybedtools
 from tests import kat_pileup_cases as K  # noqa: E402
 
 
@@ -77,6 +86,9 @@ def run_chain(split, counter, bam, barcodes_tsv, fasta, sample, work, min_mq=60,
         argv = ["BaseCellCounter.py", "--bam", os.path.join(sdir, "%s.%s.bam" % (sample, ct)), "--ref", fasta, "--chrom", "all",
                 "--out_folder", odir, "--nprocs", "1", "--min_mq", str(min_mq), "--tmp_dir", tmp] + list(extra)
         old_argv, old_pileup = sys.argv, minipysam.AlignmentFile.pileup
+        if max_depth is not None and REAL_PYSAM:   # (a Cython method cannot be patched: the capped tables are not made over the real pysam)
+            tables[ct] = None
+            continue
         if max_depth is not None:          # the reference hard-codes max_depth = 200000 (BaseCellCounter.py:191): the cap fixture lowers it
             def capped(self, *a, **k):
                 k["max_depth"] = max_depth
@@ -171,8 +183,41 @@ def random_reads(rng, contigs, seqs, barcodes, n_clusters=9, per_cluster=34):
     return reads
 
 
-def main():
-    minipysam.install()
+def check_with_real_pysam():
+    """the driver over the real pysam / pybedtools, compared with the committed fixtures; see the header"""
+    global OUT, REAL_PYSAM
+    try:
+        import pysam            # noqa: F401
+        import pybedtools       # noqa: F401
+    except ImportError as e:
+        print("make_pileup_goldens.py --check-with-real-pysam: %s - pysam and pybedtools (with the bedtools binary) are needed for this check; "
+              "nothing was run, the committed fixtures stay pinned by tools/minipysam.py only" % e, file=sys.stderr)
+        return 3
+    import filecmp
+    committed = OUT
+    OUT = tempfile.mkdtemp(prefix="plpgold_real_")
+    REAL_PYSAM = True
+    try:
+        for f in os.listdir(committed):                 # inputs the later stages read back from OUT (BAMs the driver wrote are rewritten identically)
+            if f.startswith("pileup.") and f.endswith((".fa", ".fa.fai")):
+                shutil.copy(os.path.join(committed, f), os.path.join(OUT, f))
+        skipped = ["pileup.cap.Cancer.tsv, pileup.capw.Cancer.tsv (and the capped genotype table of tools/make_genotype_cap_golden.py): max_depth is hard-coded in the reference"]
+        main(install_stand_in=False)
+        made = sorted(f for f in os.listdir(OUT) if os.path.isfile(os.path.join(OUT, f)))
+        differ = [f for f in made if not f.endswith((".bai", ".fai")) and (not os.path.exists(os.path.join(committed, f)) or not filecmp.cmp(os.path.join(OUT, f), os.path.join(committed, f), shallow=False))]
+        print("compared %d files written over the real pysam with tests/golden/: %d differ%s" % (len(made), len(differ), (": " + ", ".join(differ)) if differ else ""))
+        for why in skipped:
+            print("not made:", why)
+        return 1 if differ else 0
+    finally:
+        shutil.rmtree(OUT, ignore_errors=True)
+        OUT = committed
+        REAL_PYSAM = False
+
+
+def main(install_stand_in=True):
+    if install_stand_in:
+        minipysam.install()
     split = load("PreProcessing/SplitBamCellTypes.py", "ref_splitbam")
     counter = load("SNVCalling/BaseCellCounter.py", "ref_counter")
     os.makedirs(OUT, exist_ok=True)
@@ -246,10 +291,11 @@ def main():
         bamwrite.write_bam(bam, contigs, cap_reads)
         bc = os.path.join(OUT, "pileup.rand.barcodes.tsv")
         tables, report = run_chain(split, counter, bam, bc, os.path.join(OUT, "pileup.rand.fa"), "s", os.path.join(work, "cap"), max_depth=8)
-        open(os.path.join(OUT, "pileup.cap.Cancer.tsv"), "w").write(strip_date(tables["Cancer"]))
+        if not REAL_PYSAM:
+            open(os.path.join(OUT, "pileup.cap.Cancer.tsv"), "w").write(strip_date(tables["Cancer"]))
         tables_u, _ = run_chain(split, counter, bam, bc, os.path.join(OUT, "pileup.rand.fa"), "s", os.path.join(work, "cap_u"))
         open(os.path.join(OUT, "pileup.capoff.Cancer.tsv"), "w").write(strip_date(tables_u["Cancer"]))
-        print("cap rows", tables["Cancer"].count("\n") - 9, "uncapped", tables_u["Cancer"].count("\n") - 9)
+        print("cap rows", None if REAL_PYSAM else tables["Cancer"].count("\n") - 9, "uncapped", tables_u["Cancer"].count("\n") - 9)
         # ---- 3b. a capped pile that STRADDLES the 50 001 window edge (max_depth = 8): the reference opens a pileup per 50 kb window
         # (BaseCellCounter.py:185-191), so the columns below 50 001 are counted out of window 1's buffer - long and short reads that
         # start just before the edge - and the columns from 50 001 on out of window 2's, which only ever holds the long ones: reads the
@@ -268,10 +314,11 @@ def main():
         bam = os.path.join(OUT, "pileup.capw.bam")
         bamwrite.write_bam(bam, contigs, capw_reads)
         tables, report = run_chain(split, counter, bam, bc, os.path.join(OUT, "pileup.rand.fa"), "s", os.path.join(work, "capw"), max_depth=8)
-        open(os.path.join(OUT, "pileup.capw.Cancer.tsv"), "w").write(strip_date(tables["Cancer"]))
+        if not REAL_PYSAM:
+            open(os.path.join(OUT, "pileup.capw.Cancer.tsv"), "w").write(strip_date(tables["Cancer"]))
         tables_u, _ = run_chain(split, counter, bam, bc, os.path.join(OUT, "pileup.rand.fa"), "s", os.path.join(work, "capw_u"))
         open(os.path.join(OUT, "pileup.capwoff.Cancer.tsv"), "w").write(strip_date(tables_u["Cancer"]))
-        print("capw rows", tables["Cancer"].count("\n") - 9, "uncapped", tables_u["Cancer"].count("\n") - 9)
+        print("capw rows", None if REAL_PYSAM else tables["Cancer"].count("\n") - 9, "uncapped", tables_u["Cancer"].count("\n") - 9)
         # ---- 4. per-cell genotyping at target sites: HCCVSingleCellGenotype.py on the unsplit BAMs
         geno = load("CellTypeReannotation/HCCVSingleCellGenotype.py", "ref_genotype")
         rng = np.random.default_rng(7)
@@ -311,4 +358,6 @@ def main():
 
 
 if __name__ == "__main__":
+    if "--check-with-real-pysam" in sys.argv[1:]:
+        sys.exit(check_with_real_pysam())
     main()
