@@ -236,7 +236,8 @@ def end_to_end(n_reads):
 
 
 # rocprofv3's names of the candidates for "dominant kernel"
-PMC_KERNEL = {"k_tm_walk": "lsg::k_tm_walk", "k_tm_gather": "lsg::k_tm_gather", "k_tm_gather_count": "lsg::k_tm_gather_count", "k_tm_count_direct": "lsg::k_tm_count_direct"}
+PMC_KERNEL = {"k_tm_walk": "lsg::k_tm_walk", "k_tm_gather": "lsg::k_tm_gather", "k_tm_gather_count": "lsg::k_tm_gather_count", "k_tm_count_direct": "lsg::k_tm_count_direct",
+              "k_tm_count_win": "lsg::k_tm_count_win"}
 # kernels that are not part of a step (the generator, the memo table of the call stage: once per process)
 NOT_IN_A_STEP = ("k_synth", "k_tail_table", "calib_")
 
@@ -418,13 +419,13 @@ def main():
     t0 = time.perf_counter()
     walk_ms, walk_bytes, path_bytes, gather_ms, gather_bytes = 0.0, 0.0, 0.0, 0.0, 0.0
     build_ms = np.zeros(4)
-    fused, direct, lines = False, False, False
+    fused, direct, lines, windows = False, False, False, False
     for _ in range(args.steps):
         rows, cols, n_sites, n_cand, n_pass = step()
         st = eng.count_stats()
         bt = eng.build_times()
         path = eng.layout_info()[0]
-        fused, direct, lines = path in (3, 4, 5), path in (4, 5), path == 5      # the load made the count (3: k_tm_gather_count, writing the store as well; 4: k_tm_count_direct, no store; 5: the same, every entry fetched as its one 128-byte line)
+        fused, direct, lines, windows = path in (3, 4, 5, 6), path in (4, 5, 6), path in (5, 6), path == 6      # the load made the count (3: k_tm_gather_count, writing the store as well; 4: k_tm_count_direct, no store; 5: the same, every entry fetched as its one 128-byte line)
         walk_ms += st.ms_walk                                      # HIP events around the counting kernel: k_tm_gather_count, or k_tm_walk after a plain load
         # 2 B per admitted event + 24 B per admitted read + 168 B per emitted row - the counting kernel reads every event of
         # the counted region once and emits the rows of the single-job tiles; the plain gather (two-pass loads) reads every stored event once
@@ -483,7 +484,7 @@ def main():
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         sites = tot[1]
-        count_kernel = "k_tm_count_direct" if direct else "k_tm_gather_count" if fused else "k_tm_walk"
+        count_kernel = "k_tm_count_win" if windows else "k_tm_count_direct" if direct else "k_tm_gather_count" if fused else "k_tm_walk"
         kernels = {count_kernel: {"avg_launch_ms": walk_ms / args.steps, "algorithmic_bytes_per_launch": walk_bytes / args.steps,
                                   "achieved_GBps": walk_bytes / max(walk_ms, 1e-9) / 1e6,
                                   "what": "SURVEY 8(d) bytes of the count it makes: 2 B x admitted events + 24 B x admitted reads + 168 B x rows it emits"}}
@@ -511,7 +512,7 @@ def main():
                        "reads": model.n_reads, "barcodes": model.n_cb, "reads_loaded_all_ranks": int(tot[4]), "events_loaded_all_ranks": int(tot[7]),
                        "input_layout": ("tile-phased (LSG_LAYOUT_PHASED): every segment at an event offset congruent to its reference start modulo 64, gaps of zeros; "
                                         "event array %.2f GB for %.2f GB of events" % (2 * tot[5] / 1e9, 2 * tot[7] / 1e9)) if phased else "compact: segment after segment",
-                       "count_reads_whole_lines": bool(lines),
+                       "count_reads_whole_lines": bool(lines), "entries_binned_by_128_position_windows": bool(windows),
                        "sites_counted": int(sites), "rows_emitted": int(tot[6]), "merged_sites": int(tot[2]), "step1_candidates": int(tot[3]),
                        "sharding": "genomic regions balanced by estimated work" if world > 1 else "none",
                        "pass_rows_gathered": int(sum(gather["counts"])) if dist_on and gather["counts"] else None,

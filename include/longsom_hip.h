@@ -60,11 +60,14 @@ enum { LSG_SYM_A = 0, LSG_SYM_C = 1, LSG_SYM_T = 2, LSG_SYM_G = 3, LSG_SYM_I = 4
 /* Where a segment's events lie in `events` is the producer's choice (seg_ev_off; n_events = the array's extent, gaps are never read).
  * Two layouts are made by this library's own producers (the device BAM decoder, the synthetic generators):
  *   LSG_LAYOUT_COMPACT  segment after segment, no gaps;
- *   LSG_LAYOUT_PHASED   "tile-phased": every read's region starts at a multiple of 64 events and every segment at an offset congruent
- *                       to its reference start modulo 64 (gaps hold 0), so that the events a read has inside one 64-position tile of the
- *                       pileup lie inside ONE aligned 128-byte line of the array: the count fetches every line once.
- * lsg_load_reads recognises the second by looking (every admitted segment's (seg_ev_off - seg_start) is a multiple of 64, `events` is
- * 128-byte aligned); a caller's own arrays may use either, or anything else. */
+ *   LSG_LAYOUT_PHASED   "tile-phased": every read's region starts at a multiple of 128 events and every segment at an offset congruent
+ *                       to its reference start modulo 128 (gaps hold 0), so that the events a read has inside one 128-position window of the
+ *                       pileup (tiles 2 w and 2 w + 1) lie inside ONE aligned 256-byte block of the array, and those inside one 64-position
+ *                       tile inside one aligned 128-byte line: the count fetches every block once, with one load instruction.
+ * lsg_load_reads recognises a phased array by looking (every admitted segment's (seg_ev_off - seg_start) is a multiple of 64 / 128, `events`
+ * is 128 / 256-byte aligned).  Whether it bins a load by windows or by tiles has to be decided before it has looked, though: a caller whose
+ * arrays are phased modulo 128 says so with lsg_set_events_layout (this library's own producers do); a load that finds the claim wrong
+ * starts again by tiles.  A caller's own arrays may use either layout, or anything else. */
 enum { LSG_LAYOUT_COMPACT = 0, LSG_LAYOUT_PHASED = 1 };
 typedef struct {
     int64_t n_reads;
@@ -183,6 +186,10 @@ int lsg_load_reads(lsg_ctx* ctx, const lsg_reads* reads);
  * stored and any count parameters can be resolved later; with a filter the store is smaller by the dropped reads' share and a count or
  * genotyping pass whose own filters would admit a dropped read is refused.  The per-read arrays (depth cap, statistics) keep every read. */
 int lsg_set_load_filter(lsg_ctx* ctx, int32_t min_mq, uint32_t flag_exclude, int32_t ignore_orphans);
+/* What the caller knows about where the events of the NEXT lsg_load_reads calls lie: LSG_LAYOUT_PHASED = phased modulo 128 (lsg_reads above),
+ * LSG_LAYOUT_COMPACT (default) = no promise.  A promise lets a load that keeps no store (lsg_set_store_policy) bin its entries by
+ * 128-position windows; it is checked, and a load that finds it broken falls back by itself.  No reference counterpart. */
+int lsg_set_events_layout(lsg_ctx* ctx, int32_t layout);
 /* Device-side ingest of a whole BAM: the file's bytes in (host memory), the tile store out — BGZF inflate, record
  * chain, CB lookup, SplitBam's counters and the CIGAR walk all run on the GPU (csrc/ingest.hip), then lsg_load_reads on the device
  * arrays.  Replaces pysam.AlignmentFile + infile.fetch() + read.opt("CB") + the MAPQ counters of split_bam

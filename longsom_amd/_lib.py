@@ -166,6 +166,7 @@ SIGNATURES = {
     "lsg_load_bam": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_char_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(BamInfo), C.c_void_p, C.c_void_p, C.c_int64]),
     "lsg_load_bam_range": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_char_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.POINTER(BamInfo), C.c_void_p, C.c_void_p, C.c_int64]),
     "lsg_set_load_filter": (C.c_int, [C.c_void_p, C.c_int32, C.c_uint32, C.c_int32]),
+    "lsg_set_events_layout": (C.c_int, [C.c_void_p, C.c_int32]),
     "lsg_max_live_reads_all": (C.c_int64, [C.c_void_p]),
     "lsg_max_live_reads_exact": (C.c_int64, [C.c_void_p]),
     "lsg_synth_generate": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Reads)]),

@@ -134,9 +134,9 @@ struct Shape { uint32_t n_segs; uint64_t n_events; };
 //   EMIT = false: only the shape (segments, events).
 //   EMIT = true:  lane `lane` of `nlanes` writes the events i = lane, lane + nlanes, ... of every operation (coalesced across a wave);
 //                 lane 0 writes the segments.  seg_* / events are the record's own places in the output arrays.
-//   phased:       the record's events in the tile-phased layout (LSG_LAYOUT_PHASED, include/longsom_hip.h): ev_base is a multiple of 64, every
-//                 segment lies at an offset congruent to its reference start modulo 64 (the gaps are the caller's to zero), the shape's
-//                 n_events is the record's region: its last segment's end rounded up to 64.
+//   phased:       the record's events in the tile-phased layout (LSG_LAYOUT_PHASED, include/longsom_hip.h): ev_base is a multiple of 128, every
+//                 segment lies at an offset congruent to its reference start modulo 128 (the gaps are the caller's to zero), the shape's
+//                 n_events is the record's region: its last segment's end rounded up to 128.
 template <bool EMIT>
 LSR_FN Shape walk(const uint8_t* rec, int legacy_del_merge, uint32_t lane, uint32_t nlanes, uint32_t read_index,
                   uint32_t* seg_read, int32_t* seg_start, int32_t* seg_len, int64_t* seg_ev_off, int64_t ev_base, uint16_t* events, bool phased = false) {
@@ -150,7 +150,7 @@ LSR_FN Shape walk(const uint8_t* rec, int legacy_del_merge, uint32_t lane, uint3
     uint64_t ne = 0;
     auto open = [&](int64_t p0, uint64_t c) {            // c consecutive positions from p0 are emitted next
         if (p0 != last_pos + 1 || n_segs == 0) {
-            if (phased) ne += (uint64_t)((p0 - (int64_t)ne) & 63);
+            if (phased) ne += (uint64_t)((p0 - (int64_t)ne) & 127);
             if (EMIT && lane == 0) { seg_read[n_segs] = read_index; seg_start[n_segs] = (int32_t)p0; seg_len[n_segs] = 0; seg_ev_off[n_segs] = ev_base + (int64_t)ne; }
             ++n_segs;
         }
@@ -198,7 +198,7 @@ LSR_FN Shape walk(const uint8_t* rec, int legacy_del_merge, uint32_t lane, uint3
             x += L;
         }
     }
-    return Shape{n_segs, phased ? (ne + 63u) & ~(uint64_t)63 : ne};
+    return Shape{n_segs, phased ? (ne + 127u) & ~(uint64_t)127 : ne};
 }
 
 } // namespace lsr

@@ -815,7 +815,7 @@ int lsio_synth_records(const lsg_synth_model* m, lsio_decoded** out) {
             L.seg_ev_off.push_back((int64_t)L.events.size());
             for (int32_t j = lo; j < hi; ++j) L.events.push_back(sm_event(m, ig, &r, j, xt0, xt1, m->exon_start[x]));
         }
-        if (phased) L.events.resize(base + (((L.events.size() - base) + 63) & ~(size_t)63), 0);
+        if (phased) L.events.resize(base + (((L.events.size() - base) + 127) & ~(size_t)127), 0);
     }
     lsio_decoded* o = (lsio_decoded*)calloc(1, sizeof(lsio_decoded));
     o->n_reads = (int64_t)L.read_tid.size(); o->n_segs = (int64_t)L.seg_read.size(); o->n_events = (int64_t)L.events.size();

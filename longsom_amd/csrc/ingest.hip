@@ -424,8 +424,10 @@ static int load_bam_impl(lsg_ctx* c, const uint8_t* file, int64_t n_bytes, int64
     g.n_reads = R; g.n_segs = S; g.n_events = (int64_t)E; g.on_device = 1;
     g.read_tid = o_tid.as<int32_t>(); g.read_pos = o_pos.as<int32_t>(); g.read_flag = o_flag.as<uint16_t>(); g.read_mapq = o_mapq.as<uint8_t>(); g.read_cb = o_cb.as<int32_t>();
     g.seg_read = o_sread.as<uint32_t>(); g.seg_start = o_sstart.as<int32_t>(); g.seg_len = o_slen.as<int32_t>(); g.seg_ev_off = o_sevoff.as<int64_t>(); g.events = o_events.as<uint16_t>();
+    c->hint_phased_events = phased ? o_events.p : nullptr;
     const auto t_store = std::chrono::steady_clock::now();
     const int rc = lsg_load_reads(c, &g);
+    c->hint_phased_events = nullptr;
     for (auto& b : c->gen) b.release();
     if (rc) return done_ev(rc);
     info->total_reads = (int64_t)cnt[0]; info->pass_reads = (int64_t)cnt[1]; info->cb_not_found = (int64_t)cnt[2]; info->cb_not_matched = (int64_t)cnt[3]; info->mapq_filtered = (int64_t)cnt[4];

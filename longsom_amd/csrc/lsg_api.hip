@@ -146,7 +146,9 @@ int lsg_set_contigs(lsg_ctx* c, int32_t n_contigs, const int64_t* lengths) {
     for (int i = 0; i < n_contigs; ++i) {
         if (lengths[i] < 0 || lengths[i] > 0x7fffffffll) { set_error("lsg_set_contigs: contig %d length %lld unsupported", i, (long long)lengths[i]); return -2; }
         c->tile_base[i] = (uint32_t)t;
-        t += (uint64_t)((lengths[i] + TILE_W - 1) / TILE_W);
+        // (an EVEN number of tiles per contig: a 128-position window - store.hip's bins of a load that keeps no store - is then tiles
+        // (2 w, 2 w + 1) of the same contig everywhere; a contig's odd last tile is followed by one that holds no position)
+        t += (uint64_t)(((lengths[i] + TILE_W - 1) / TILE_W + 1) & ~1ll);
     }
     if (t * LSG_MAX_CELLTYPES >= 0x7fffffffull) { set_error("lsg_set_contigs: genome too large (%llu tiles)", (unsigned long long)t); return -2; }
     c->tile_base[n_contigs] = (uint32_t)t;
@@ -211,6 +213,12 @@ int lsg_set_barcodes(lsg_ctx* c, const uint8_t* celltype_of, int32_t n_cb, int32
 int lsg_set_keep_reads(lsg_ctx* c, int32_t keep) {
     if (!c) { set_error("lsg_set_keep_reads: NULL handle"); return -2; }
     c->keep_reads = keep != 0;
+    return 0;
+}
+
+int lsg_set_events_layout(lsg_ctx* c, int32_t layout) {
+    if (!c || (layout != LSG_LAYOUT_COMPACT && layout != LSG_LAYOUT_PHASED)) { set_error("lsg_set_events_layout: bad arguments"); return -2; }
+    c->events_layout = layout;
     return 0;
 }
 
@@ -294,6 +302,7 @@ int lsg_load_reads(lsg_ctx* c, const lsg_reads* r) {
     const uint16_t* ev = in.events; const int64_t* evo = in.seg_ev_off;
     const bool staged = !d || c->keep_reads;
     if (staged && (put(c, c->b_seg_ev_off, evo, in.seg_ev_off, in.n_segs, d) || put(c, c->b_events, ev, in.events, in.n_events, d))) { c->rd = lsg_reads{}; return -1; }
+    if (staged && in.events && c->hint_phased_events == (const void*)in.events) c->hint_phased_events = ev;      // (what this library's producer said about the array holds for its copy)
     const int rc = lsg::build_store(c, ev, in.n_events, evo, cs ? &in : nullptr);
     if (cs) LSG_HIP(hipStreamSynchronize(cs));                 // the handle's copies are whole before anyone counts (or the caller frees its arrays)
     if (rc) { c->rd = lsg_reads{}; lsg::drop_store(c); return rc; }      // a refused load leaves no reads behind
@@ -383,7 +392,7 @@ int lsg_get_count_stats(lsg_ctx* c, lsg_count_stats* out) {
 
 int lsg_get_layout_info(lsg_ctx* c, int32_t* path, double* build_ms, int64_t* store_bytes) {
     if (!c) { set_error("lsg_get_layout_info: NULL handle"); return -2; }
-    if (path) *path = c->store_skipped ? (c->line_loads ? 5 : 4) : c->load_was_fused ? 3 : 2;       // 3: the load's gather also made the first count (lsg_set_count_at_load)
+    if (path) *path = c->store_skipped ? (c->wsh ? 6 : c->line_loads ? 5 : 4) : c->load_was_fused ? 3 : 2;       // 3: the load's gather also made the first count (lsg_set_count_at_load)
     if (build_ms) *build_ms = c->layout_build_ms;
     if (store_bytes) {
         int64_t b = 0;

@@ -101,7 +101,7 @@ int live_read_bound_all(lsg_ctx* c);
 __global__ void k_read_end(const uint32_t* seg_read, const int32_t* seg_start, const int32_t* seg_len, int64_t n_segs, int32_t* read_end);      // layout.hip
 __global__ void k_read_end_init(const int32_t* read_pos, int64_t n_reads, int32_t* read_end);
 int depth_cap_drops(lsg_ctx* c, const lsg_count_params* p);   // layout.hip: htslib's max_depth rule -> d_read_drop (or none)
-struct GatherCountSrc { const uint16_t* events; int64_t n_events; const uint64_t* key; const uint32_t* rdv; int32_t cb_bits; int32_t src_shift; };
+struct GatherCountSrc { const uint16_t* events; int64_t n_events; const uint64_t* key; const uint32_t* rdv; int32_t cb_bits; int32_t src_shift; int32_t wsh; };
 int run_gather_count(lsg_ctx* c, const lsg_count_params* p, const GatherCountSrc& src, bool direct);      // pileup.hip: the load's gather and the first count in one pass (k_tm_gather_count), or the count alone from the caller's events (k_tm_count_direct)
 }
 
@@ -165,6 +165,10 @@ struct lsg_ctx {
     float build_ms[4] = {0, 0, 0, 0};     // HIP-event times of the last build: capacities + scatter, sort, fill, gather
     int64_t max_live_reads = -1;          // layout.hip: bound on the reads live at once in the reference's pileup buffer (-1 = stale)
     int64_t max_live_all = -1;            // the same over all reads with a barcode: table-independent, cached per load
+    int32_t wsh = 0;                      // build_store: the bins of the last load's entries - 0: the 64-position tiles, 1: 128-position windows (a load that kept no store)
+    bool win_off = false;                 // ... set while a load that could not be made by windows after all is made again by tiles
+    int32_t events_layout = 0;            // lsg_set_events_layout: what the caller says about the events of the next loads (LSG_LAYOUT_*)
+    const void* hint_phased_events = nullptr;      // the events array this library's own producer (synth.hip, ingest.hip) last laid out phased modulo 128
     bool src_phased = false;              // build_store: the last load's events were tile-phased (LSG_LAYOUT_PHASED): an entry = one 128-byte line
     bool line_loads = false;              // pileup.hip run_gather_count: the last direct count fetched every entry as its one 128-byte line (tile-phased events)
     bool keys_only_off = false;           // build_store: this load sorts values with its keys (set while a load of keys alone is made again)

@@ -1111,6 +1111,9 @@ struct TdW { uint32_t lo, hi; };     // hi: address bits 32..47 | 2 * events << 
 #ifndef LSG_TD_WAVES
 #define LSG_TD_WAVES 6
 #endif
+#ifndef LSG_TW_WAVES
+#define LSG_TW_WAVES 5
+#endif
 constexpr int TD_Q = LSG_TD_Q, TD_NQ = 64 / TD_Q;      // entries to a batch of loads (two batches of registers alternate), batches to a group.
 // (8 to a batch fit 64 registers and 8 waves per SIMD, 16 workgroups per CU: 8.1-8.8 ms, no better than 16 to a batch at 6 waves: 8.0-8.2)
 struct TdKeys64 { uint64_t k; uint32_t v; };
@@ -1397,6 +1400,394 @@ __global__ __launch_bounds__(TMW_WAVES * 64) __attribute__((amdgpu_waves_per_eu(
     }
 }
 
+// One entry of a 128-position WINDOW at the lane's two positions (k_tm_count_win below): what two tm_add<.., true> calls do - the lane's
+// even position from the low half-word of ev, its odd position from the high one, each with a run state of its own - with ONE pass
+// through the entry's scalar decisions (close / not there / run of one / first of a run / further entry of a run: the same for both
+// positions) and ONE 64-bit LDS atomic per position instead of two 32-bit ones (an LDS instruction costs a CU ~4.3 cycles whatever its
+// width up to 32 bits, 6.3 at 64: tools/lds_rate.hip).  A counter is 8 bytes: low word quality sum [0..19] | forward count [20..31], high word
+// count [0..15] | duplicates [16..31]; byte address = parity << 13 | cell type << 12 | tile << 11 | symbol << 8 | (position >> 1) << 3.
+// m: the entry's meta word (TMM_CLOSE, TMM_FIRST, TMM_SKIP, TMM_SINGLE, TMM_CT10, TMM_CT12, TMM_FWD); r: the lanes of its positions -
+// even ones [r & 63, 64 - (r >> 8 & 63)), odd ones [r >> 16 & 63, 64 - (r >> 24 & 63)).  The atomics' data are register PAIRS, which inline
+// asm can only name by number: v[92:93] = {low word, 1} (v93 holds 1 throughout: `one`), v[94:95] = {low word, 1 | seen << 16}.
+__device__ __forceinline__ void tw_add(TmState& s0, TmState& s1, uint32_t m, uint32_t r, uint32_t ev, uint32_t thr, uint32_t pk0, uint32_t pk1, uint32_t one) {
+    if (!TM_ASM) {                                   // the same in plain C++
+        const uint32_t ln = threadIdx.x & 63u;
+        auto half = [&](TmState& s, uint32_t e, uint32_t f, uint32_t inv, uint32_t pk) {
+            if (m & TMM_CLOSE) { s.nc += s.mask & 0x10001u; s.mask = 0; }
+            if (m & TMM_SKIP) return;
+            const bool counted = (e & 0xffu) >= thr && ln >= f && ln < 64u - inv;
+            if (!counted) return;
+            const uint32_t addr = (pk | (e & 0x700u)) + (m & TMM_CT12);
+            const uint32_t sym8 = (e >> 8) & 15u, ctone = 1u << ((m >> 6) & 16u);
+            uint32_t hi = 1u;
+            if (m & TMM_SINGLE) s.nc += ctone;
+            else if (m & TMM_FIRST) s.mask = (1u << sym8) | ctone;
+            else { hi |= ((s.mask >> sym8) & 1u) << 16; s.mask |= (1u << sym8) | ctone; }
+            __hip_atomic_fetch_add((LSG_AS3 unsigned long long*)(uintptr_t)addr, ((unsigned long long)hi << 32) | ((e & 0xffu) | (m & TMM_FWD)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        };
+        half(s0, ev & 0xffffu, r & 63u, (r >> 8) & 63u, pk0);
+        half(s1, ev >> 16, (r >> 16) & 63u, (r >> 24) & 63u, pk1);
+        return;
+    }
+    uint32_t t0, t1, addr, dlo, elo, ehi, sa, sb, sc, st; unsigned long long xm;
+    // the lanes of a half's positions into EXEC (whole: nothing of the half before is left in it)
+#define TW_RANGE0 "s_lshr_b32 %[st], %[r], 8\n\ts_lshl_b64 %[xm], -1, %[r]\n\ts_lshr_b64 exec, -1, %[st]\n\ts_and_b64 exec, exec, %[xm]\n\t"
+#define TW_RANGE1 "s_lshr_b32 %[st], %[r], 16\n\ts_lshl_b64 %[xm], -1, %[st]\n\ts_lshr_b32 %[st], %[r], 24\n\ts_lshr_b64 exec, -1, %[st]\n\ts_and_b64 exec, exec, %[xm]\n\t"
+    // address of the position's counter, low word of the atomic's data (into DLO), EXEC = the lanes that count this event
+#define TW_HEAD(WSEL, BSEL, PK, DLO)                                                                                                 \
+        "v_and_b32_sdwa %[addr], %[c700], %[ev] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:" WSEL "\n\t"           \
+        "v_or3_b32 %[addr], %[addr], " PK ", %[sa]\n\t"                                                                             \
+        "v_or_b32_sdwa " DLO ", %[sb], %[ev] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:" BSEL "\n\t"              \
+        "v_cmpx_le_u32_sdwa vcc, %[thr], %[ev] src0_sel:DWORD src1_sel:" BSEL "\n\t"
+    asm volatile(
+        "s_bitcmp1_b32 %[m], 27\n\t"
+        "s_cbranch_scc0 1f\n\t"
+        "v_and_b32 %[t0], 0x10001, %[mask0]\n\t"                    /* close the run of several entries before this one, both positions */
+        "v_and_b32 %[t1], 0x10001, %[mask1]\n\t"
+        "v_add_u32 %[nc0], %[nc0], %[t0]\n\t"
+        "v_add_u32 %[nc1], %[nc1], %[t1]\n\t"
+        "v_mov_b32 %[mask0], 0\n\t"
+        "v_mov_b32 %[mask1], 0\n"
+        "1:\n\t"
+        "s_bitcmp1_b32 %[m], 29\n\t"
+        "s_cbranch_scc1 9f\n\t"                                     /* not counted / not there */
+        "s_and_b32 %[sa], %[m], 0x1000\n\t"                         /* the cell type's counters */
+        "s_lshr_b32 %[sc], %[m], 6\n\t"
+        "s_and_b32 %[sb], %[m], 0x100000\n\t"                       /* forward strand */
+        "s_lshl_b32 %[sc], 1, %[sc]\n\t"                            /* bit 0 or bit 16: the cell type's run counter */
+        "s_bitcmp1_b32 %[m], 30\n\t"
+        "s_cbranch_scc0 2f\n\t"
+        TW_RANGE0                                                   /* ---- a run of one entry */
+        TW_HEAD("WORD_0", "BYTE_0", "%[pk0]", "v92")
+        "ds_add_u64 %[addr], v[92:93]\n\t"
+        "v_add_u32 %[nc0], %[sc], %[nc0]\n\t"
+        TW_RANGE1
+        TW_HEAD("WORD_1", "BYTE_2", "%[pk1]", "v92")
+        "ds_add_u64 %[addr], v[92:93]\n\t"
+        "v_add_u32 %[nc1], %[sc], %[nc1]\n\t"
+        "s_branch 8f\n"
+        "2:\n\t"
+        "s_bitcmp1_b32 %[m], 28\n\t"
+        "s_cbranch_scc0 3f\n\t"
+        TW_RANGE0                                                   /* ---- first entry of a longer run that is there */
+        TW_HEAD("WORD_0", "BYTE_0", "%[pk0]", "v92")
+        "v_bfe_u32 %[t1], %[ev], 8, 4\n\t"                          /* 8 + class */
+        "ds_add_u64 %[addr], v[92:93]\n\t"
+        "v_lshl_or_b32 %[mask0], %[one], %[t1], %[sc]\n\t"
+        TW_RANGE1
+        TW_HEAD("WORD_1", "BYTE_2", "%[pk1]", "v92")
+        "v_bfe_u32 %[t1], %[ev], 24, 4\n\t"
+        "ds_add_u64 %[addr], v[92:93]\n\t"
+        "v_lshl_or_b32 %[mask1], %[one], %[t1], %[sc]\n\t"
+        "s_branch 8f\n"
+        "3:\n\t"
+        TW_RANGE0                                                   /* ---- a further entry of the run: its symbol seen before = a duplicate */
+        TW_HEAD("WORD_0", "BYTE_0", "%[pk0]", "v94")
+        "v_bfe_u32 %[t1], %[ev], 8, 4\n\t"
+        "v_bfe_u32 %[t0], %[mask0], %[t1], 1\n\t"
+        "v_lshl_or_b32 v95, %[t0], 16, %[one]\n\t"
+        "v_lshl_or_b32 %[t1], %[one], %[t1], %[sc]\n\t"
+        "ds_add_u64 %[addr], v[94:95]\n\t"
+        "v_or_b32 %[mask0], %[mask0], %[t1]\n\t"
+        TW_RANGE1
+        TW_HEAD("WORD_1", "BYTE_2", "%[pk1]", "v94")
+        "v_bfe_u32 %[t1], %[ev], 24, 4\n\t"
+        "v_bfe_u32 %[t0], %[mask1], %[t1], 1\n\t"
+        "v_lshl_or_b32 v95, %[t0], 16, %[one]\n\t"
+        "v_lshl_or_b32 %[t1], %[one], %[t1], %[sc]\n\t"
+        "ds_add_u64 %[addr], v[94:95]\n\t"
+        "v_or_b32 %[mask1], %[mask1], %[t1]\n"
+        "8:\n\t"
+        "s_mov_b64 exec, -1\n"
+        "9:"
+        : [t0] "=&v"(t0), [t1] "=&v"(t1), [addr] "=&v"(addr), [dlo] "=&{v92}"(dlo), [elo] "=&{v94}"(elo), [ehi] "=&{v95}"(ehi),
+          [sa] "=&s"(sa), [sb] "=&s"(sb), [sc] "=&s"(sc), [st] "=&s"(st), [xm] "=&s"(xm),
+          [mask0] "+v"(s0.mask), [nc0] "+v"(s0.nc), [mask1] "+v"(s1.mask), [nc1] "+v"(s1.nc)
+        : [ev] "v"(ev), [m] "s"(m), [r] "s"(r), [thr] "s"(thr), [c700] "s"(0x700u), [one] "{v93}"(one), [pk0] "v"(pk0), [pk1] "v"(pk1)
+        : "scc", "vcc", "memory");
+#undef TW_RANGE0
+#undef TW_RANGE1
+#undef TW_HEAD
+}
+
+// ================================================================================================
+// The same count over entries binned by 128-position WINDOWS (store.hip build_store, wsh = 1: events phased modulo 128, keys alone, no
+// store).  An entry = (segment x window), its events one aligned 256-byte block of the caller's array: ONE `global_load_dword` per entry -
+// lane l gets the events of window positions 2 l and 2 l + 1, so lanes 0..31 hold tile 2 w and lanes 32..63 tile 2 w + 1 - where the tiles'
+// count asks for two 128-byte lines with two instructions.  What that buys is in the memory system (tools/block_rate.hip: scattered
+// aligned 256-byte blocks arrive at 23 G/s = 5.9 TB/s, scattered 128-byte lines at 29 G/s = 3.7 TB/s, whatever asks for them) and in the
+// load's first half (0.58 x the entries through the scatter and the sort).  The counting body is tw_add (above): the lane's even position
+// from the low half-word of the register, its odd position from the high one.  A group is 32 entries, one per lane of either half of the
+// wave (both halves make the same words: the group's keys are loaded twice over).  Planes: tw_add's (16 KB a workgroup).
+struct TwCounters {      // the 8-byte counters of one (tile, cell type) read by position (emit_unit's lane); pl: their words at parity 0, symbol 0, position pair 0
+    const uint32_t* pl; int lane; uint32_t ncdup;
+    __device__ __forceinline__ uint32_t lo(int k) const { return pl[(lane & 1) * 2048 + k * 64 + (lane >> 1) * 2]; }
+    __device__ __forceinline__ uint32_t hi(int k) const { return pl[(lane & 1) * 2048 + k * 64 + (lane >> 1) * 2 + 1]; }
+    __device__ __forceinline__ uint32_t BC(int k) const { return hi(k) & 0xffffu; }
+    __device__ __forceinline__ uint32_t DUP(int k) const { return hi(k) >> 16; }
+    __device__ __forceinline__ uint32_t BQ(int k) const { return lo(k) & 0xfffffu; }
+    __device__ __forceinline__ uint32_t BCF(int k) const { return lo(k) >> 20; }
+    __device__ __forceinline__ uint32_t NCDUP() const { return ncdup; }
+};
+struct TwPre { uint32_t bits, ctv, rng; };
+__device__ __forceinline__ void tw_range(const CountArgs& a, const TmArgs& tm, const TgArgs& tg, TmState& st0, TmState& st1, TgStat& stat, uint32_t i0, uint32_t i1, uint32_t off, uint32_t n,
+                                         uint32_t thr, uint32_t pkl0, uint32_t one, int lane, uint64_t K, uint64_t key_before) {
+    const int ng = (int)((i1 - i0 + 31u) >> 5);
+    const uint32_t cbm = (1u << tg.cb_bits) - 1u;
+    const int e = lane & 31;                                               // the lane's entry of a group (both halves of the wave work the same words out)
+    const uint32_t lane4 = 4u * (uint32_t)lane;
+    const uint32_t pkl1 = pkl0 | 8192u;                                    // (the odd positions' counters)
+    const uint64_t evb = (uint64_t)(uintptr_t)tg.events;
+    auto load_keys = [&](uint32_t i_first) -> uint64_t {
+        const uint32_t i = i_first + (uint32_t)e, ic = i < n ? i : n - 1u;
+        return __builtin_nontemporal_load(tg.key + off + ic);
+    };
+    uint32_t cb_carry = rl((uint32_t)key_before & cbm, 0);
+    uint32_t cb_last = 0;
+    auto words = [&](int g, uint64_t Kk, TdW& w, TwPre& pre) {
+        const uint32_t i = i0 + 32u * (uint32_t)g + (uint32_t)e;
+        const bool valid = i < i1;
+        const uint32_t cb = (uint32_t)Kk & cbm;
+        const uint32_t up = (uint32_t)__shfl((int)cb, e ? lane - 1 : lane), dn = (uint32_t)__shfl((int)cb, e < 31 ? lane + 1 : lane);
+        const uint32_t cb_prev = e == 0 ? cb_carry : up;
+        const uint32_t geom = (uint32_t)(Kk >> tg.cb_bits), first = geom & 127u, nev = valid ? ((geom >> 7) & 127u) + 1u : 0u, end = first + nev;
+        const uint64_t fld = (Kk >> (tg.cb_bits + 14)) & tg.src_mask;
+        const uint64_t addr = evb + (fld << 8);                           // the entry's 256-byte block
+        const bool rs = i == 0 || cb_prev != cb;
+        const bool nd = i + 1 == n || (e < 31 && dn != cb);
+        w.lo = (uint32_t)addr; w.hi = (uint32_t)(addr >> 32);
+        const uint32_t kv = (uint32_t)(Kk >> 32) & (TG_RV_FWD | TG_RV_SEGFIRST);
+        pre.ctv = reinterpret_cast<const uint32_t*>(a.celltype_of)[(cb < (uint32_t)a.n_cb ? cb : 0u) >> 2];
+        pre.bits = (valid ? 1u : 0u) | (cb < (uint32_t)a.n_cb ? 2u : 0u) | ((kv & TG_RV_FWD) ? 4u : 0u) | (nd ? 8u : 0u) | (rs ? 16u : 0u) |
+                   (nev << 16) | ((kv & TG_RV_SEGFIRST) ? (1u << 24) : 0u) | ((cb & 3u) << 26);
+        // the lanes of the entry's positions: even positions 2 j in [first, end) <=> j in [ceil(first / 2), ceil(end / 2)); odd ones
+        // 2 j + 1 <=> j in [first / 2, end / 2).  None: the range [63, 1)
+        uint32_t f0 = (first + 1u) >> 1, e0 = (end + 1u) >> 1, f1 = first >> 1, e1 = end >> 1;
+        if (f0 >= e0) { f0 = 63u; e0 = 1u; }
+        if (f1 >= e1) { f1 = 63u; e1 = 1u; }
+        pre.rng = f0 | (((64u - e0) & 63u) << 8) | (f1 << 16) | (((64u - e1) & 63u) << 24);
+        cb_last = cb_carry = rl(cb, 31);
+    };
+    auto finish_meta = [&](const TwPre& pre, uint32_t cb_of_last, uint32_t cb_after) -> uint32_t {
+        if (!(pre.bits & 1u)) return TMM_SKIP;
+        uint32_t cls = 2;
+        if (pre.bits & 2u) { const uint32_t ct = (pre.ctv >> (((pre.bits >> 26) & 3u) * 8u)) & 0xffu; if (ct < (uint32_t)a.n_ct && (ct >> 1) == (uint32_t)(tm.ct_base >> 1)) cls = ct & 1u; }
+        if (cls < 2 && lane < 32) { stat.ev += (pre.bits >> 16) & 0xffu; stat.sg += (pre.bits >> 24) & 1u; ++stat.ne; }
+        const bool nd = (pre.bits & 8u) != 0 || (e == 31 && cb_after != cb_of_last);
+        const bool single = (pre.bits & 16u) != 0 && nd;
+        uint32_t M = cls < 2 ? (cls ? (TMM_CT10 | TMM_CT12) : 0u) | ((pre.bits & 4u) ? TMM_FWD : 0u) | (single ? TMM_SINGLE : 0u) : TMM_SKIP;
+        if (pre.bits & 16u) M |= TMM_RS;
+        return M;
+    };
+    uint32_t open_in = 0;
+    auto verdicts = [&](uint32_t M) -> uint32_t {                           // (tm_walk_range's, over the group's 32 entries; both halves of the wave come to the same)
+        const bool there = !(M & TMM_SKIP), multi = there && !(M & TMM_SINGLE), rs = (M & TMM_RS) != 0;
+        const uint32_t A = (uint32_t)__ballot(lane < 32 && multi), R = (uint32_t)__ballot(lane < 32 && rs);
+        const uint32_t below = (1u << e) - 1u;
+        const uint32_t rb = R & below;
+        const uint32_t seg = rb ? below & ~((1u << (31 - __clz(rb))) - 1u) : below;
+        const bool ob = (A & seg) != 0u || (!rb && open_in);
+        if (rs && ob) M |= TMM_CLOSE;
+        if (multi && (rs || !ob)) M |= TMM_FIRST;
+        const uint32_t segl = R ? ~((1u << (31 - __clz(R))) - 1u) : 0xffffffffu;
+        open_in = ((A & segl) != 0u || (!R && open_in)) ? 1u : 0u;
+        return M;
+    };
+    auto issue_block = [&](const TdW& w, int q, uint32_t (&E)[TD_Q]) {      // (td_range64's issue_line with four bytes a lane)
+        uint32_t o = lane4;
+        asm volatile("" : "+v"(o));
+#pragma unroll
+        for (int u0 = 0; u0 < TD_Q; u0 += 8) {
+            uint64_t base[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) base[u] = ((uint64_t)rl(w.hi, q * TD_Q + u0 + u) << 32) | rl(w.lo, q * TD_Q + u0 + u);
+            asm volatile("" : "+s"(base[0]), "+s"(base[1]), "+s"(base[2]), "+s"(base[3]), "+s"(base[4]), "+s"(base[5]), "+s"(base[6]), "+s"(base[7]));
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                E[u0 + u] = *(const __attribute__((address_space(1))) uint32_t*)((const __attribute__((address_space(1))) char*)(uintptr_t)base[u] + (uint64_t)o);
+        }
+    };
+    auto consume = [&](const uint32_t (&E)[TD_Q], int q, uint32_t M, uint32_t Rg) {
+#pragma unroll
+        for (int u = 0; u < TD_Q; ++u) tw_add(st0, st1, rl(M, q * TD_Q + u), rl(Rg, q * TD_Q + u), E[u], thr, pkl0, pkl1, one);
+    };
+    static_assert(TD_Q == 16, "a group of 32 entries is two batches");
+    auto fence = []() { asm volatile("" ::: "memory"); };
+    uint32_t EA[TD_Q], EB[TD_Q];
+    TdW wc, wn; TwPre pre;
+    words(0, K, wc, pre);
+    fence();
+    K = load_keys(i0 + 32u);
+    fence();
+    issue_block(wc, 0, EA);
+    fence();
+    issue_block(wc, 1, EB);
+    fence();
+    for (int g = 0; g < ng; ++g) {
+        const uint32_t cb_after = rl((uint32_t)K & cbm, 0);
+        const uint32_t Mc = verdicts(finish_meta(pre, cb_last, cb_after)), Rc = pre.rng;
+        words(g + 1, K, wn, pre);
+        fence();
+        K = load_keys(i0 + 32u * (uint32_t)(g + 2));
+        fence();
+        consume(EA, 0, Mc, Rc); issue_block(wn, 0, EA);
+        consume(EB, 1, Mc, Rc); issue_block(wn, 1, EB);
+        wc = wn;
+    }
+    st0.nc += st0.mask & 0x10001u; st0.mask = 0;
+    st1.nc += st1.mask & 0x10001u; st1.mask = 0;
+}
+
+__global__ __launch_bounds__(TMW_WAVES * 64) __attribute__((amdgpu_waves_per_eu(LSG_TW_WAVES))) void k_tm_count_win(CountArgs a, TmArgs tm, TgArgs tg) {
+    __shared__ __attribute__((aligned(16384))) uint32_t planes[2][2][2][8][32][2];    // tw_add's counters: [parity of the position][cell type of the pass][tile][symbol][position >> 1][low, high word]
+    __shared__ uint32_t nc_sh[2][2][64];                                              // [cell type][tile][position]: runs that counted an event
+    __shared__ WaveBook books[TMW_WAVES];
+    __shared__ uint32_t s_q[4];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint32_t* pl = &planes[0][0][0][0][0][0];
+    WaveBook& book = books[wv];
+    book_init(book, lane);
+    if (lane == 0) book.src = 1;
+    const uint32_t thr = (uint32_t)a.min_bq;                                          // (1 <= min_bq <= 255: build_store)
+    const uint32_t pkl0 = lds_addr(pl) | ((uint32_t)(lane >> 5) << 11) | ((uint32_t)(lane & 31) << 3);      // (the lane's tile and position pair)
+    uint32_t one = 1u;
+    asm volatile("" : "+v"(one));
+    TgStat stat; stat.ev = 0; stat.sg = 0; stat.ne = 0;
+    // (who takes which job: k_tm_count_direct's queues, a job = a window or a run-aligned piece of a deep one)
+    const uint32_t njobs = tm.njobs, nblocks = (njobs + 63u) >> 6;
+    const uint32_t xcd = blockIdx.x & 7u;
+    constexpr uint32_t NO_JOB = 0xffffffffu;
+    uint32_t steal = 0;
+    auto job_of = [&](uint32_t q, uint32_t nn) -> uint32_t {
+        const uint32_t blk = 8u * (nn >> 6) + q;
+        const uint32_t jx = (blk << 6) + (nn & 63u);
+        return blk < nblocks && jx < njobs ? jx : NO_JOB;
+    };
+    auto take = [&]() -> uint32_t {
+        while (steal < 8u) {
+            const uint32_t q = (xcd + steal) & 7u;
+            const uint32_t nn = (uint32_t)atomicAdd(tg.queues + q * 16u, 1ull);
+            const uint32_t jx = job_of(q, nn);
+            if (jx != NO_JOB) return jx;
+            if (8u * (nn >> 6) + q >= nblocks) ++steal;
+        }
+        return NO_JOB;
+    };
+    if (threadIdx.x == 0) { s_q[0] = take(); s_q[1] = take(); }
+    __syncthreads();
+    uint32_t cur = rl(s_q[0], 0), nxt = rl(s_q[1], 0);
+    if (cur != NO_JOB) {
+        uint32_t jw = 0;
+        if (lane < TM_JOB_WORDS) jw = reinterpret_cast<const uint32_t*>(tm.jobs + cur)[lane];
+        uint32_t e0 = rl(jw, 0), e1 = rl(jw, 1), w0 = rl(jw, 2), slab = rl(jw, 3), nj = rl(jw, 4), tcnt = rl(jw, 5), win = rl(jw, 6), emid = rl(jw, 7), base = rl(jw, 8), off = rl(jw, 9);
+        int32_t tstart = (int32_t)rl(jw, 10); int tid = (int)rl(jw, 11);
+        auto first_i = [&]() -> uint32_t { return (wv ? emid : e0) - base; };
+        uint64_t K64 = 0, kb = 0;
+        auto prefetch = [&]() {
+            const uint32_t i = first_i(), ie = i + (uint32_t)(lane & 31), ic = ie < tcnt ? ie : tcnt - 1u;
+            K64 = __builtin_nontemporal_load(tg.key + off + ic); kb = __builtin_nontemporal_load(tg.key + off + (i ? i - 1u : 0u));
+        };
+        prefetch();
+        while (true) {
+            jw = reinterpret_cast<const uint32_t*>(tm.jobs + (nxt != NO_JOB ? nxt : cur))[lane < TM_JOB_WORDS ? lane : 0];
+            // the wave's tile of the window: tile 2 win + wv, whose units this wave finishes
+            const uint32_t my_tile = 2u * win + (uint32_t)wv;
+            const bool in_a = 2u * win >= a.tile_lo && 2u * win < a.tile_hi, in_b = 2u * win + 1u >= a.tile_lo && 2u * win + 1u < a.tile_hi;
+            const bool counting = (in_a || in_b) && !(nj & TMJ_WIDE);
+            const bool mine = counting && (wv ? in_b : in_a);
+            int refb = 'N';
+            if (nj == 1 && mine) { const int64_t pos = (int64_t)tstart + 64 * wv + lane; if (pos >= 1 && pos < a.contig_len[tid]) refb = a.ref_ptr[tid][pos]; }
+            __syncthreads();
+            uint32_t q_n = 0;
+            const uint32_t q_q = (xcd + steal) & 7u;
+            if (threadIdx.x == 0 && steal < 8u) q_n = (uint32_t)atomicAdd(tg.queues + q_q * 16u, 1ull);
+            if (counting) {
+#pragma unroll
+                for (int i = 0; i < 2 * 2 * 2 * 8 * 64 / (4 * TMW_WAVES * 64); ++i) reinterpret_cast<uint4*>(pl)[i * (TMW_WAVES * 64) + threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);
+                (&nc_sh[0][0][0])[threadIdx.x] = 0; (&nc_sh[0][0][0])[TMW_WAVES * 64 + threadIdx.x] = 0;
+            }
+            __syncthreads();
+            const uint32_t s0r = wv ? emid : e0, s1r = wv ? e1 : emid;
+            const uint32_t i0 = s0r - base, i1 = s1r - base < tcnt ? s1r - base : tcnt;
+            if (counting && i1 > i0) {
+                TmState st0, st1; st0.nc = 0; st0.mask = 0; st1.nc = 0; st1.mask = 0;
+                tw_range(a, tm, tg, st0, st1, stat, i0, i1, off, tcnt, thr, pkl0, one, lane, K64, kb);
+                // the lane's positions: 2 (lane & 31) and the one after it, of tile lane >> 5
+                uint32_t* nq = &nc_sh[0][lane >> 5][2 * (lane & 31)];
+                if (st0.nc & 0xffffu) atomicAdd(nq, st0.nc & 0xffffu);
+                if (st0.nc >> 16) atomicAdd(nq + 128, st0.nc >> 16);
+                if (st1.nc & 0xffffu) atomicAdd(nq + 1, st1.nc & 0xffffu);
+                if (st1.nc >> 16) atomicAdd(nq + 129, st1.nc >> 16);
+            }
+            if (threadIdx.x == 0) {
+                uint32_t jn2 = NO_JOB;
+                if (steal < 8u) {
+                    jn2 = job_of(q_q, q_n);
+                    if (jn2 == NO_JOB) { if (8u * (q_n >> 6) + q_q >= nblocks) ++steal; jn2 = take(); }
+                }
+                s_q[2] = jn2;
+            }
+            const uint32_t c_w0 = w0, c_slab = slab, c_nj = nj, c_tcnt = tcnt; const int32_t c_tstart = tstart; const int c_tid = tid;
+            e0 = rl(jw, 0); e1 = rl(jw, 1); w0 = rl(jw, 2); slab = rl(jw, 3); nj = rl(jw, 4); tcnt = rl(jw, 5); win = rl(jw, 6); emid = rl(jw, 7); base = rl(jw, 8); off = rl(jw, 9);
+            tstart = (int32_t)rl(jw, 10); tid = (int)rl(jw, 11);
+            prefetch();
+            __syncthreads();
+            const uint32_t nn = rl(s_q[2], 0);
+            (void)my_tile;
+            if (mine) {                                   // the units of the wave's tile, cell type by cell type
+                for (int v = 0; v < 2; ++v) {
+                    const int ct = tm.ct_base + v;
+                    if (ct >= a.n_ct) break;
+                    const uint32_t* pc = pl + v * 1024 + wv * 512;
+                    uint32_t dp = 0;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) dp += pc[(lane & 1) * 2048 + k * 64 + (lane >> 1) * 2 + 1] & 0xffffu;
+                    const TwCounters tot{pc, lane, dp - nc_sh[v][wv][lane]};
+                    const uint32_t unit = c_w0 + (uint32_t)wv * (uint32_t)a.n_ct + (uint32_t)ct;
+                    if (c_nj == 1) {
+                        // (the wave writes both cell types' rows, narrow and wide: an arena per cell type and format)
+                        if (c_tcnt <= 256u) emit_unit<TwCounters, true>(a, tot, unit, ct, c_tid, c_tstart + 64 * wv, lane, &book, false, refb, 2 * v);
+                        else emit_unit<TwCounters, false>(a, tot, unit, ct, c_tid, c_tstart + 64 * wv, lane, &book, false, refb, 2 * v + 1);
+                    } else {
+                        uint32_t* dst = a.macc + (uint64_t)(c_slab + ((uint32_t)wv * (uint32_t)a.n_ct + (uint32_t)ct) * c_nj) * (NCTR * 64);
+                        dst[lane] = tot.NCDUP();
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            dst[(1 + k) * 64 + lane] = tot.DUP(k); dst[(9 + k) * 64 + lane] = tot.BC(k);
+                            dst[(17 + k) * 64 + lane] = tot.BQ(k); dst[(25 + k) * 64 + lane] = tot.BCF(k);
+                        }
+                    }
+                }
+            }
+            if (nxt == NO_JOB) break;
+            cur = nxt; nxt = nn;
+        }
+    }
+    lds_fence();
+    __syncthreads();
+    {
+        unsigned long long ev = stat.ev, sg = stat.sg, ne = stat.ne;
+        for (int o = 32; o > 0; o >>= 1) { ev += __shfl_down(ev, o); sg += __shfl_down(sg, o); ne += __shfl_down(ne, o); }
+        if (lane == 0 && ne) {
+            unsigned long long* slot = tg.stat_slots + (size_t)((blockIdx.x * TMW_WAVES + wv) % IX_STAT_SLOTS) * 8;
+            atomicAdd(&slot[0], ev); atomicAdd(&slot[1], sg); atomicAdd(&slot[2], ne);
+        }
+    }
+    if (threadIdx.x < 64) {
+        uint32_t rt = 0, cols = 0, rsrc = 0;
+        for (int w = 0; w < TMW_WAVES; ++w) {
+            const WaveBook& b = books[w];
+            if (lane < a.n_ct) rt += b.rows_true[lane];
+            cols += b.cols; rsrc += b.rows_src;
+        }
+        if (lane < a.n_ct && rt) atomicAdd(&a.scalars[SC_ROWS + lane], (unsigned long long)rt);
+        if (lane == 0) {
+            if (cols) atomicAdd(&a.scalars[SC_COLS], (unsigned long long)cols);
+            if (rsrc) atomicAdd(&a.scalars[SC_ROWS_SRC + 1], (unsigned long long)rsrc);
+        }
+    }
+}
+
 // A job longer than TM_JOB_LIMIT entries (a single barcode owning thousands of a tile's entries: its run cannot be cut) does not fit the
 // packed planes of k_tm_walk.  One wave per such job, 32-bit planes (quality sum, forward, count, duplicates per symbol and cell type),
 // the run logic spelled out: a run start closes the run before it; an entry that is there adds its event where the lane counts it and
@@ -1553,6 +1944,83 @@ __global__ __launch_bounds__(64) void k_tm_walk_wide_direct(CountArgs a, TmArgs 
     book_flush(a, book, lane);
 }
 
+// ... and its wide walk (k_tm_walk_wide_direct over windows: an entry is up to 128 events, the lane takes its position in either tile)
+__global__ __launch_bounds__(64) void k_tm_walk_wide_win(CountArgs a, TmArgs tm, TgArgs tg, const uint32_t* n_wide) {
+    __shared__ uint32_t pl[2][2][4][8 * 64];               // [tile of the window][cell type][quality sum, forward, count, duplicates][symbol x position]
+    __shared__ WaveBook book;
+    const int lane = threadIdx.x;
+    if (n_wide && rl(*n_wide, 0) == 0u) return;
+    book_init(book, lane);
+    if (lane == 0) book.src = 2;
+    const uint32_t thr = bq_threshold(a), cbm = (1u << tg.cb_bits) - 1u;
+    unsigned long long s_ev = 0, s_sg = 0, s_ne = 0;
+    for (uint32_t jx = blockIdx.x; jx < tm.njobs; jx += gridDim.x) {
+        const TmJob jb = tm.jobs[jx];
+        const uint32_t t0 = 2u * jb.tile;
+        const bool in_t[2] = {t0 >= a.tile_lo && t0 < a.tile_hi, t0 + 1u >= a.tile_lo && t0 + 1u < a.tile_hi};
+        if (!(jb.nj & TMJ_WIDE) || !(in_t[0] || in_t[1])) continue;
+        const uint32_t nj = jb.nj & ~TMJ_WIDE;
+        lds_fence();
+        for (int i = lane; i < 2 * 2 * 4 * 8 * 64; i += 64) (&pl[0][0][0][0])[i] = 0;
+        lds_fence();
+        uint32_t nc[2][2] = {{0u, 0u}, {0u, 0u}}, mask[2] = {0u, 0u}, run_ct = 0;      // [tile][cell type]; the open run's symbols per tile
+        for (uint32_t p = jb.e0; p < jb.e1 && p - jb.base < jb.cnt; ++p) {
+            const uint32_t i = p - jb.base;
+            const uint64_t k = tg.key[jb.off + i];
+            const uint32_t v = (uint32_t)(k >> 32) & (TG_RV_FWD | TG_RV_SEGFIRST), cb = (uint32_t)k & cbm;
+            const bool rs = i == 0 || ((uint32_t)tg.key[jb.off + i - 1] & cbm) != cb;
+            const uint32_t geom = (uint32_t)(k >> tg.cb_bits), first = geom & 127u, nev = ((geom >> 7) & 127u) + 1u;
+            const uint64_t src = (((k >> (tg.cb_bits + 14)) & tg.src_mask) << 7) | first;
+            uint32_t cls = 2;
+            if (cb < (uint32_t)a.n_cb) { const uint32_t ct = a.celltype_of[cb]; if (ct < (uint32_t)a.n_ct && (ct >> 1) == (uint32_t)(tm.ct_base >> 1)) cls = ct & 1u; }
+            if (rs) { for (int h = 0; h < 2; ++h) { nc[h][run_ct] += mask[h] ? 1u : 0u; mask[h] = 0; } }
+            if (cls >= 2) continue;
+            s_ev += nev; s_sg += (v & TG_RV_SEGFIRST) ? 1u : 0u; ++s_ne;
+            run_ct = cls;
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t q = (uint32_t)(64 * h + lane) - first;
+                const uint32_t ev = q < nev ? tg.events[src + q] : 0u;
+                if ((ev & 0x8ffu) >= thr) {
+                    const uint32_t sym = (ev >> 8) & 7u;
+                    uint32_t* w = &pl[h][run_ct][0][sym * 64 + lane];
+                    w[0] += ev & 0xffu; w[512] += (v & TG_RV_FWD) ? 1u : 0u; w[1024] += 1u; w[1536] += (mask[h] >> sym) & 1u;
+                    mask[h] |= 1u << sym;
+                }
+            }
+        }
+        for (int h = 0; h < 2; ++h) nc[h][run_ct] += mask[h] ? 1u : 0u;
+        lds_fence();
+        for (int h = 0; h < 2; ++h) {
+            if (!in_t[h]) continue;
+            for (int v = 0; v < 2; ++v) {
+                const int ct = tm.ct_base + v;
+                if (ct >= a.n_ct) break;
+                const uint32_t* pc = &pl[h][v][0][0];
+                uint32_t dp = 0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) dp += pc[1024 + k * 64 + lane];
+                const WideCounters tot{pc, lane, dp - nc[h][v]};
+                const uint32_t unit = jb.w0 + (uint32_t)h * (uint32_t)a.n_ct + (uint32_t)ct;
+                if (nj == 1) emit_unit<WideCounters, false>(a, tot, unit, ct, jb.tid, jb.tstart + 64 * h, lane, &book, false, -1, v);
+                else {
+                    uint32_t* dst = a.macc + (uint64_t)(jb.slab + ((uint32_t)h * (uint32_t)a.n_ct + (uint32_t)ct) * nj) * (NCTR * 64);
+                    dst[lane] = tot.NCDUP();
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        dst[(1 + k) * 64 + lane] = tot.DUP(k); dst[(9 + k) * 64 + lane] = tot.BC(k);
+                        dst[(17 + k) * 64 + lane] = tot.BQ(k); dst[(25 + k) * 64 + lane] = tot.BCF(k);
+                    }
+                }
+            }
+        }
+    }
+    if (lane == 0 && s_ne) {
+        unsigned long long* slot = tg.stat_slots + (size_t)(blockIdx.x % IX_STAT_SLOTS) * 8;
+        atomicAdd(&slot[0], s_ev); atomicAdd(&slot[1], s_sg); atomicAdd(&slot[2], s_ne);
+    }
+    book_flush(a, book, lane);
+}
+
 // Everything a count needs before its first kernel: the plan's unit tables where the call stage and the exports read them, row
 // buffers, zeroed counters, the kernels' arguments; k_read_stats is queued (the admitted reads, and the bit per read the entries'
 // admission is looked up in when some stored read can fail THIS count's read filters).
@@ -1590,7 +2058,7 @@ static int count_prepare(lsg_ctx* c, const lsg_count_params* p, CountLaunch& L) 
             const uint64_t by_depth = (uint64_t)c->rd.n_events / (uint64_t)p->min_dp + 64;
             if (by_depth < want_rows) want_rows = by_depth;
         }
-        const uint64_t emitters = (uint64_t)L.grid_walk * TMW_WAVES * 2 + L.grid_fin + (uint64_t)c->n_cus * 4;
+        const uint64_t emitters = (uint64_t)L.grid_walk * TMW_WAVES * 2 + L.grid_fin + (uint64_t)c->n_cus * 4 + (c->wsh ? (uint64_t)c->n_cus * 16 * TMW_WAVES * 4 : 0u);      // (the windows' count: four arenas a wave)
         uint64_t arena = want_rows / (emitters * 8) / ARENA * ARENA;
         c->arena = (uint32_t)(arena < (uint64_t)ARENA ? (uint64_t)ARENA : (arena > 8ull * ARENA ? 8ull * ARENA : arena));
         want_rows += emitters * c->arena + 64;
@@ -1711,6 +2179,20 @@ int run_gather_count(lsg_ctx* c, const lsg_count_params* p, const GatherCountSrc
         if (c->d_xcd_queues.reserve(8 * 128)) return -1;
         LSG_HIP(hipMemsetAsync(c->d_xcd_queues.p, 0, 8 * 128, st));
         tg.queues = c->d_xcd_queues.as<unsigned long long>();
+        if (src.wsh) {
+            // entries binned by 128-position windows (store.hip build_store): one 256-byte block per entry; 17 KB of LDS a workgroup: 9 per CU
+            if (tg.rdv || L.a.adm || p->min_bq < 1 || p->min_bq > 255 || tg.src_shift != 7) return 1;      // (build_store makes such a load by tiles)
+            tg.src_mask = (1ull << (48 - src.cb_bits)) - 1ull;      // (seven bits each for the first position and the events - 1)
+            c->line_loads = true;
+            const unsigned gridw = (unsigned)(c->n_cus * tune_int("LSG_GRID_TW", 9));
+            hipLaunchKernelGGL(k_tm_count_win, dim3(gridw), dim3(TMW_WAVES * 64), 0, st, L.a, L.tm, tg);
+            LSG_HIP(hipEventRecord(c->ev[4], st));
+            LSG_HIP(hipEventRecord(c->evb[4], st));
+            stage("k_tm_count_win");
+            hipLaunchKernelGGL(k_tm_walk_wide_win, dim3((unsigned)(c->n_cus * 2)), dim3(64), 0, st, L.a, L.tm, tg, (const uint32_t*)c->d_plan_misc);
+            stage("wide walk");
+            return count_finish(c, p, L);
+        }
         const unsigned grid = (unsigned)(c->n_cus * tune_int("LSG_GRID_TD", 12));
         // tile-phased events: an entry is fetched as its one 128-byte line (tm_add<.., true>: the quality compare reads the event's low byte)
         const bool al = tg.src_shift == 6 && p->min_bq >= 1 && p->min_bq <= 255 && !getenv("LSG_NO_LINE_LOADS");

@@ -33,8 +33,9 @@ constexpr uint32_t KEY_INVALID = 0xFFFFFFFFu;
 // barcode bits are sorted on.  Value (32 bits): owning read [0 .. 29) | upper pileup window of its tile << 29 | first entry of its segment << 30 |
 // forward strand << 31.
 constexpr uint32_t RV_WHI = 1u << 29, RV_SEGFIRST = 1u << 30, RV_FWD = 1u << 31, RV_READ = RV_WHI - 1u;
-__host__ __device__ __forceinline__ uint64_t sort_key(uint32_t cb, uint32_t first, uint32_t nev1, uint64_t src, int cb_bits) {
-    return (uint64_t)cb | ((uint64_t)(first | (nev1 << 6) ) << cb_bits) | (src << (cb_bits + 12));
+// (wsh = 1: the bins are 128-position windows - first position and events - 1 take seven bits each)
+__host__ __device__ __forceinline__ uint64_t sort_key(uint32_t cb, uint32_t first, uint32_t nev1, uint64_t src, int cb_bits, int wsh = 0) {
+    return (uint64_t)cb | ((uint64_t)(first | (nev1 << (6 + wsh))) << cb_bits) | (src << (cb_bits + 12 + 2 * wsh));
 }
 
 struct BuildArgs {
@@ -55,6 +56,9 @@ struct BuildArgs {
     int32_t* span_diff;                   // [n_tiles + 1] marks of the reads' spans (the depth cap's bound), or null
     int32_t* cap_diff;                    // [n_tiles + 1] marks of the admitted segments' tile ranges: +1 at the first tile, -1 past the last; their running sum = entries per tile
     int32_t window;                       // the reference's pileup windows [1 + k W, 1 + (k + 1) W): an entry never crosses an edge of one
+    int32_t wsh;                          // 0: the bins the entries are sorted into are the 64-position tiles; 1: 128-position WINDOWS, tiles (2 w, 2 w + 1) - a load that keeps
+                                          // no store over events phased modulo 128: an entry is then one aligned 256-byte block, which the memory system delivers at
+                                          // 23 G blocks/s where it delivers single 128-byte lines at 29 G/s (tools/block_rate.hip), and there are 0.58 x as many
     int32_t src_shift;                    // 6 when the caller's events are tile-phased (LSG_LAYOUT_PHASED: the key's source field is the entry's 128-byte LINE, its low six bits being the entry's first position), else 0
 };
 
@@ -162,16 +166,16 @@ __global__ __launch_bounds__(SEG_THREADS) void k_seg_static(BuildArgs a) {
                         key = (uint32_t)cb | (((flag >> 4) & 1u) << 24);
                         tb = tb_[u];
                         n_ev += (unsigned long long)ln;
-                        unphased |= ((o - st) & 63) != 0;
-                        mark_cap(tb + ((uint32_t)st >> 6), 1);
-                        mark_cap(tb + ((uint32_t)(st + ln - 1) >> 6) + 1, -1);
+                        unphased |= ((o - st) & (int64_t)((64 << a.wsh) - 1)) != 0;
+                        mark_cap((tb + ((uint32_t)st >> 6)) >> a.wsh, 1);
+                        mark_cap(((tb + ((uint32_t)(st + ln - 1) >> 6)) >> a.wsh) + 1, -1);
                         // one more entry in the tile of every window edge strictly inside the segment: rare (one segment in forty), so not
                         // through the hash - the first edge's tile is handed to the wave below (neighbouring segments of a deep gene cross
                         // the SAME edge: one atomic per distinct tile and wave), further ones (a segment longer than a window) straight to memory
                         int nb = 0;
                         for (int64_t b = win_edge_after(st, a.window); b < st + ln; b += a.window) {
-                            if ((b & 63) == 0) continue;                     // (an edge on a tile boundary cuts nothing)
-                            const uint32_t t = tb + (uint32_t)(b >> 6);
+                            if ((b & (int64_t)((64 << a.wsh) - 1)) == 0) continue;       // (an edge on a bin's boundary cuts nothing)
+                            const uint32_t t = (tb + (uint32_t)(b >> 6)) >> a.wsh;
                             if (nb++ == 0) edge_tile = t;
                             else { atomicAdd(a.cap_diff + t, 1); atomicAdd(a.cap_diff + t + 1, -1); }
                         }
@@ -185,8 +189,8 @@ __global__ __launch_bounds__(SEG_THREADS) void k_seg_static(BuildArgs a) {
                         // both marks are clamped into the contig so that every +1 has its -1
                         int64_t b = st < 0 ? 0 : st, e = st + (ln > 0 ? ln : 0);
                         if (e < 0) e = 0;
-                        if (first) { uint32_t t = t0 + (uint32_t)(b >> 6); if (t >= te) t = te - 1; mark(t, 1); }
-                        if (last) { uint32_t t = t0 + (uint32_t)(e >> 6) + 1; if (t > te) t = te; mark(t, -1); }
+                        if (first) { uint32_t t = t0 + (uint32_t)(b >> 6); if (t >= te) t = te - 1; mark(t >> a.wsh, 1); }
+                        if (last) { uint32_t t = t0 + (uint32_t)(e >> 6); if (t >= te) t = te - 1; mark((t >> a.wsh) + 1, -1); }      // (past the last bin it touches)
                     }
                 }
             }
@@ -248,38 +252,40 @@ __device__ __forceinline__ BinSeg bin_load(const BuildArgs& a, int64_t s) {
     const uint2 info = a.seg_info[si];
     const int64_t st = a.seg_start[si], ln = a.seg_len[si], evoff = a.seg_ev_off[si];
     const uint32_t rd = a.seg_read[si];
+    const int bs = 6 + a.wsh;                            // positions per bin: 1 << bs (a contig's first tile is even: its bins are its positions >> bs)
     if (s < a.n_segs && info.x != KEY_INVALID) {
-        g.key = info.x; g.tb = info.y;
+        g.key = info.x; g.tb = info.y >> a.wsh;
         g.st = (int32_t)st; g.ln = (int32_t)ln; g.evoff = evoff; g.rd = rd;
-        g.t0 = g.tb + ((uint32_t)g.st >> 6);
-        g.ntile = (int)(((uint32_t)(g.st + g.ln - 1) >> 6) - ((uint32_t)g.st >> 6)) + 1;
+        g.t0 = g.tb + ((uint32_t)g.st >> bs);
+        g.ntile = (int)(((uint32_t)(g.st + g.ln - 1) >> bs) - ((uint32_t)g.st >> bs)) + 1;
         g.b1 = win_edge_after(g.st, a.window);
-        for (int64_t b = g.b1; b < (int64_t)g.st + g.ln; b += a.window) g.ntile += (b & 63) != 0;
-    } else if (s < a.n_segs) g.tb = info.y;
+        for (int64_t b = g.b1; b < (int64_t)g.st + g.ln; b += a.window) g.ntile += (b & (int64_t)((1 << bs) - 1)) != 0;
+    } else if (s < a.n_segs) g.tb = info.y >> a.wsh;
     return g;
 }
 // entry k of a segment, in position order: its tile (relative to the segment's first) and its positions [lo, hi)
-__device__ __forceinline__ void bin_piece(const BinSeg& g, int32_t W, int k, uint32_t& tile_rel, int32_t& lo, int32_t& hi) {
+__device__ __forceinline__ void bin_piece(const BinSeg& g, int32_t W, int bs, int k, uint32_t& tile_rel, int32_t& lo, int32_t& hi) {
     const int32_t en = g.st + g.ln;
+    const int64_t bmask = (int64_t)((1 << bs) - 1);
     int shift = 0;
     int64_t b = g.b1;                                        // (almost always past the segment: no edge, no loop turn, no division)
     for (; b < en; b += W) {
-        if ((b & 63) == 0) continue;
-        const int idx = (int)((b >> 6) - (g.st >> 6)) + shift + 1;             // the entry that STARTS at this edge
+        if ((b & bmask) == 0) continue;
+        const int idx = (int)((b >> bs) - (g.st >> bs)) + shift + 1;           // the entry that STARTS at this edge
         if (k < idx) break;
         if (k == idx) {
-            tile_rel = (uint32_t)((b >> 6) - (g.st >> 6)); lo = (int32_t)b;
-            const int32_t tend = (int32_t)(((b >> 6) + 1) << 6);
+            tile_rel = (uint32_t)((b >> bs) - (g.st >> bs)); lo = (int32_t)b;
+            const int32_t tend = (int32_t)(((b >> bs) + 1) << bs);
             hi = en < tend ? en : tend;
             return;
         }
         ++shift;
     }
     tile_rel = (uint32_t)(k - shift);
-    const int32_t tstart = (int32_t)((((uint32_t)g.st >> 6) + tile_rel) << 6);
+    const int32_t tstart = (int32_t)((((uint32_t)g.st >> bs) + tile_rel) << bs);
     lo = g.st > tstart ? g.st : tstart;
-    hi = en < tstart + TILE_W ? en : tstart + TILE_W;
-    if (b < hi && b > lo && (b & 63) != 0) hi = (int32_t)b;   // the next edge (the one the loop stopped at) inside the rest of the tile ends the entry
+    hi = en < tstart + (1 << bs) ? en : tstart + (1 << bs);
+    if (b < hi && b > lo && (b & bmask) != 0) hi = (int32_t)b;   // the next edge (the one the loop stopped at) inside the rest of the bin ends the entry
 }
 
 __global__ __launch_bounds__(BIN_THREADS) void k_bin(BuildArgs a) {
@@ -323,7 +329,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(BuildArgs a) {
                         const int k = r * BIN_TPR + j;
                         if (k < g.ntile) {
                             uint32_t trel; int32_t lo_, hi_;
-                            bin_piece(g, a.window, k, trel, lo_, hi_);
+                            bin_piece(g, a.window, 6 + a.wsh, k, trel, lo_, hi_);
                             const uint32_t x = g.t0 + trel;
                             uint32_t h = (x * 2654435761u) >> HSHIFT;
                             while (true) {
@@ -364,12 +370,12 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(BuildArgs a) {
                         const int k = rr * BIN_TPR + j;
                         if (k < g.ntile) {
                             uint32_t trel; int32_t lo, hi;
-                            bin_piece(g, a.window, k, trel, lo, hi);
+                            bin_piece(g, a.window, 6 + a.wsh, k, trel, lo, hi);
                             const uint32_t x = g.t0 + trel;
                             uint32_t h = (x * 2654435761u) >> HSHIFT;
                             while (hkey[h] != x) h = (h + 1) & (BIN_H - 1);
                             const uint32_t pos = atomicAdd(&hcnt[h], 1u);
-                            const int32_t tstart = (int32_t)((x - g.tb) << 6);
+                            const int32_t tstart = (int32_t)((x - g.tb) << (6 + a.wsh));
                             // the entry lies in the window that STARTS inside its tile: an edge in (tstart, lo].  Edges the segment crosses are
                             // known (b1, b1 + W, ...); a segment that starts behind its tile's edge finds it one window before b1
                             int64_t edge = -1;
@@ -378,7 +384,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(BuildArgs a) {
                             // everything the gather needs of an entry travels THROUGH the sort (no record fetched through the sort's
                             // permutation afterwards): key = barcode | first position in the tile | events - 1 | source of the events,
                             // sorted on its barcode bits only; value = owning read | first of its segment | forward strand
-                            const uint64_t key = sort_key(g.key & CB_MASK, (uint32_t)(lo - tstart), (uint32_t)(hi - lo - 1), src, a.cb_bits);
+                            const uint64_t key = sort_key(g.key & CB_MASK, (uint32_t)(lo - tstart), (uint32_t)(hi - lo - 1), src, a.cb_bits, a.wsh);
                             const uint32_t flags = (lo == g.st ? RV_SEGFIRST : 0u) | (((g.key >> 24) & 1u) ? 0u : RV_FWD);
                             if (a.rdv) { a.key[pos] = key; a.rdv[pos] = g.rd | flags | (edge >= 0 && lo >= edge ? RV_WHI : 0u); }
                             else a.key[pos] = key | ((uint64_t)flags << 32);      // keys alone (build_store, keys_only): the two flags a count needs above the source field, bits 62 and 63
@@ -730,7 +736,26 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
     drop_store(c);
     hipStream_t st = c->stream;
     const int64_t S = c->rd.n_segs, R = c->rd.n_reads;
-    const uint32_t T = c->n_tiles;
+    // WINDOWS.  A load that will keep no store and sort keys alone (below), over events its producer says are phased modulo 128
+    // (lsg_set_events_layout; this library's own producers say so themselves), bins its entries by 128-position windows - tiles (2 w, 2 w + 1) -
+    // instead of tiles: 0.58 x as many entries through the scatter and the sort, and every entry one aligned 256-byte block for the count
+    // (k_tm_count_win).  Everything here that is "per tile" is then per window (T bins); the count's units stay the tiles'.  Should the early
+    // look say otherwise (events not phased after all, a depth cap that could fire, ...), the load starts again by tiles (win_off).
+    const bool win = c->cal_enabled && c->store_policy == LSG_STORE_SKIP_WHEN_COUNTED && !getenv("LSG_NO_DIRECT_COUNT") && !getenv("LSG_NO_FUSED_LOAD") && !getenv("LSG_NO_KEYS_ONLY") &&
+                     !getenv("LSG_NO_WINDOWS") && !c->keys_only_off && !c->win_off && c->n_ct >= 1 && c->n_ct <= 2 && c->n_cb > 0 && c->copy_stream && n_events >= 128 && n_events < (1ll << 39) &&
+                     (c->events_layout == LSG_LAYOUT_PHASED || (c->hint_phased_events && c->hint_phased_events == (const void*)events)) && ((uintptr_t)events & 255u) == 0 && c->plp_window >= 128 &&
+                     c->cal_params.min_bq >= 1 && c->cal_params.min_bq <= 255 && (c->n_tiles & 1u) == 0;
+    const int wsh = win ? 1 : 0;
+    c->wsh = wsh;
+    auto start_again_by_tiles = [&]() -> int {
+        LSG_HIP(hipStreamSynchronize(st)); LSG_HIP(hipStreamSynchronize(c->copy_stream));
+        if (getenv("LSG_TIMING")) fprintf(stderr, "[lsg] load: not a load for 128-position windows after all, starting again by tiles\n");
+        c->win_off = true;
+        const int rc = build_store(c, events, n_events, seg_ev_off, src);
+        c->win_off = false;
+        return rc;
+    };
+    const uint32_t T = c->n_tiles >> wsh;
     const auto t_wall = std::chrono::steady_clock::now();
     auto finish = [&]() {
         c->layout_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_wall).count();
@@ -753,7 +778,7 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
     a.tile_base = c->d_tile_base.as<uint32_t>(); a.contig_len = c->d_contig_len.as<int64_t>(); a.n_contigs = c->n_contigs; a.n_tiles = T;
     a.seg_info = c->ws[WS_SEG_INFO].as<uint2>(); a.tile_cap = c->d_tile_cap.as<uint32_t>();
     a.lf_min_mq = c->lf_min_mq; a.lf_flag_exclude = c->lf_flag_exclude; a.lf_ignore_orphans = c->lf_ignore_orphans;
-    a.window = c->plp_window; c->st_window = c->plp_window;
+    a.window = c->plp_window; c->st_window = c->plp_window; a.wsh = wsh;
     a.qhead = c->d_scalars.as<unsigned long long>(); a.bad = reinterpret_cast<uint32_t*>(c->d_scalars.as<unsigned long long>() + 2);
     a.n_ev = c->d_scalars.as<unsigned long long>() + 3;
     if (c->bt[BT_SPAN].reserve(((size_t)T + 2) * 4) || c->bt[BT_SPAN_RUN].reserve(((size_t)T + 2) * 4)) return -1;
@@ -855,7 +880,9 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
         nblk = (uint32_t)hp[16];
     }
     // tile-phased events (LSG_LAYOUT_PHASED): every entry lies inside one aligned 128-byte line of the caller's array; the key carries the line
-    const int src_shift = !(bad & 4u) && ((uintptr_t)events & 127u) == 0 && !getenv("LSG_NO_PHASED") ? 6 : 0;
+    // (k_seg_static looked at the phase modulo the bins' width: 64, or 128 for windows)
+    if (win && (bad & 4u) && !(bad & 3u)) return start_again_by_tiles();
+    const int src_shift = !(bad & 4u) && ((uintptr_t)events & (wsh ? 255u : 127u)) == 0 && !getenv("LSG_NO_PHASED") ? 6 + wsh : 0;
     c->src_phased = src_shift != 0;
     if (bad & 2u) { set_error("lsg_load_reads: a segment's read index lies outside the read arrays"); return -2; }
     if (bad & 1u) { set_error("lsg_load_reads: a segment's event range lies outside the events array"); return -2; }
@@ -877,7 +904,7 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
     // ---- 2. scatter (queued BEFORE the copy stream's work below: those two dozen launches are 0.3 ms of host time the scatter need not wait for)
     int bits = 1; while (bits < 24 && (1ll << bits) <= (long long)max_cb) ++bits;      // the barcode bits of the sort key
     DevBuf &key_a = c->bt[BT_KEY_A], &key_b = c->bt[BT_KEY_B], &val_a = c->bt[BT_VAL_A], &val_b = c->bt[BT_VAL_B];
-    if ((n_events >> src_shift) >= (1ll << (52 - bits))) {
+    if ((n_events >> src_shift) >= (1ll << (52 - bits - 2 * wsh))) {
         set_error("lsg_load_reads: %lld events with %d-bit barcode ids do not fit the packed sort key (events < 2^%d): load the reads in windows", (long long)n_events, bits, 52 - bits + src_shift);
         return -2;
     }
@@ -887,14 +914,31 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
     // all (its rows outgrow their buffer), the load starts again with values (keys_only_off).
     bool keys_only = c->cal_enabled && c->store_policy == LSG_STORE_SKIP_WHEN_COUNTED && !getenv("LSG_NO_DIRECT_COUNT") && !getenv("LSG_NO_FUSED_LOAD") &&
                      !getenv("LSG_NO_KEYS_ONLY") && !c->keys_only_off && c->n_ct >= 1 && c->n_ct <= 2 && c->n_cb > 0 && c->copy_stream && n_events >= 64 &&
-                     n_events < (1ll << 39) && (n_events >> src_shift) < (1ll << (50 - bits));
+                     n_events < (1ll << 39) && (n_events >> src_shift) < (1ll << (50 - bits - 2 * wsh));
+    // Can the depth cap of the count this load is to make fire at all?  The all-reads bound per tile (window) came with the early look; when it
+    // cannot say no, the per-position bound of this table's cell types decides (layout.hip: ~10 ms at C4, whose tiles hold more than 200 000
+    // reads that no position does) - here, before the scatter, because a count whose cap cannot fire may sort keys alone.
+    bool cap_out = true;
+    if (c->cal_enabled && c->cal_params.max_depth > 0 && c->max_live_all + 1 > (int64_t)c->cal_params.max_depth) {
+        cap_out = false;
+        if (c->n_ct >= 1 && c->n_ct <= 2 && c->n_cb > 0 && c->copy_stream && !getenv("LSG_NO_FUSED_LOAD")) {
+            LSG_HIP(hipStreamSynchronize(c->copy_stream));          // (the handle's copies of the read arrays, which the bounds read, are made there)
+            if (live_read_bound(c)) return -1;                      // first the tiles again, per cell type of this table (C4: 135 343 against 225 294 over all reads)
+            cap_out = c->max_live_reads + 1 <= (int64_t)c->cal_params.max_depth;
+            if (!cap_out) {
+                if (live_read_bound_exact(c)) return -1;
+                cap_out = c->max_live_exact <= (int64_t)c->cal_params.max_depth;
+            }
+        }
+    }
     if (keys_only) {
         const lsg_count_params& q = c->cal_params;
         if (q.min_mq != c->st_min_mq || q.flag_exclude != c->st_flag_exclude || (q.ignore_orphans != 0) != (c->st_ignore_orphans != 0)) keys_only = false;
-        if (q.max_depth > 0 && c->max_live_all + 1 > (int64_t)q.max_depth) keys_only = false;
+        if (!cap_out) keys_only = false;
         for (int t = 0; t < c->n_contigs && keys_only; ++t) if (!c->ref_ptr[t]) keys_only = false;
     }
-    if (keys_only && getenv("LSG_TIMING")) fprintf(stderr, "[lsg] load: keys alone through the scatter and the sort (8 bytes an entry)\n");
+    if (win && !keys_only) return start_again_by_tiles();
+    if (keys_only && getenv("LSG_TIMING")) fprintf(stderr, "[lsg] load: keys alone through the scatter and the sort (8 bytes an entry)%s\n", win ? ", entries binned by 128-position windows" : "");
     if (key_a.reserve(N * 8 + 16) || key_b.reserve(N * 8 + 16) || (!keys_only && (val_a.reserve(N * 4 + 16) || val_b.reserve(N * 4 + 16))) ||
         c->bt[BT_CURSOR].reserve(((size_t)T + 2) * 4)) return -1;
     // (the cursors in a buffer of their own: the plan's tile-level half may be at work in BT_PER_TILE beside the scatter)
@@ -1033,16 +1077,7 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
     if (fused) {
         const lsg_count_params& q = c->cal_params;
         if (q.min_mq < c->st_min_mq || (c->st_flag_exclude & ~q.flag_exclude) != 0 || (c->st_ignore_orphans && !q.ignore_orphans)) fused = false;       // (the count would be refused)
-        if (fused && q.max_depth > 0 && c->max_live_all + 1 > (int64_t)q.max_depth) {
-            // the tiles say the depth cap might fire: the per-position bound of this table's cell types decides (layout.hip: ~10 ms at C4,
-            // whose tiles hold more than 200 000 reads that no position does); when it can, the count is left to lsg_pileup_count
-            LSG_HIP(hipStreamSynchronize(c->copy_stream));        // (the handle's copies of the read arrays, which the bounds read, are made there)
-            if (live_read_bound(c)) return -1;                      // first the tiles again, per cell type of this table (C4: 135 343 against 225 294 over all reads)
-            if (c->max_live_reads + 1 > (int64_t)q.max_depth) {
-                if (live_read_bound_exact(c)) return -1;
-                if (c->max_live_exact > (int64_t)q.max_depth) fused = false;
-            }
-        }
+        if (fused && !cap_out) fused = false;                     // the depth cap might fire (decided before the scatter, above): the count is left to lsg_pileup_count
         for (int t = 0; t < c->n_contigs && fused; ++t) if (!c->ref_ptr[t]) fused = false;
     }
     const bool dbg = getenv("LSG_DEBUG_SYNC") != nullptr;
@@ -1059,7 +1094,7 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
         stage("plan");
         return 0;
     };
-    const GatherCountSrc gsrc{events, n_events, key_b.as<uint64_t>(), keys_only ? nullptr : val_b.as<uint32_t>(), bits, src_shift};
+    const GatherCountSrc gsrc{events, n_events, key_b.as<uint64_t>(), keys_only ? nullptr : val_b.as<uint32_t>(), bits, src_shift, wsh};
     auto load_again_with_values = [&]() -> int {                 // (a load of keys alone that is not counted that way after all)
         LSG_HIP(hipStreamSynchronize(st)); LSG_HIP(hipStreamSynchronize(c->copy_stream));
         if (getenv("LSG_TIMING")) fprintf(stderr, "[lsg] load: the count from keys alone was not made, loading again with values\n");
@@ -1069,7 +1104,8 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
         return rc;
     };
     bool planned = false;
-    if (keys_only && getenv("LSG_TEST_KEYS_ONLY_REFUSED")) return load_again_with_values();      // (test hook: the way a refused count of keys alone takes)
+    if (win && !fused) return start_again_by_tiles();
+    if (keys_only && getenv("LSG_TEST_KEYS_ONLY_REFUSED")) return win ? start_again_by_tiles() : load_again_with_values();      // (test hook: the way a refused count of keys alone takes)
     if (fused && c->store_policy == LSG_STORE_SKIP_WHEN_COUNTED && !getenv("LSG_NO_DIRECT_COUNT")) {
         // A load that is counted once and never again (lsg_set_store_policy): the count alone, from the caller's events through the
         // sort's output - no blocks, no per-entry words.  What needs a store afterwards is refused until the next load.
@@ -1091,6 +1127,7 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
         c->counted = false;                                       // rows outgrew their buffer: the store is built after all, the count is made on request
         fused = false;
     }
+    if (win) return start_again_by_tiles();                  // (the windows' count was not made: rows outgrew their buffer, a count that is not the load's ...)
     if (keys_only) return load_again_with_values();
     if (int rc = reserve_store()) return rc;
     if (!blk_tiles_made) {                                       // (a load that was to keep no store builds one after all)
@@ -1152,12 +1189,13 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
 constexpr uint32_t TM_CHUNK_WORK = 4096, TM_JOB_W0 = 32;      // a workgroup dequeues at most this much work (entries + a constant per job) at a time
 
 // per tile: non-empty, jobs, slabs, multi-job (inputs of four exclusive scans)
-__global__ void k_tm_tiles(const uint32_t* cap, uint32_t n_tiles, int n_ct, uint32_t job_tgt, uint32_t* ne, uint32_t* nj, uint32_t* slabs, uint32_t* multi) {
+// (H: tiles per bin - 2 when the bins are 128-position windows: a non-empty window has the units of BOTH its tiles)
+__global__ void k_tm_tiles(const uint32_t* cap, uint32_t n_tiles, int n_ct, uint32_t job_tgt, uint32_t H, uint32_t* ne, uint32_t* nj, uint32_t* slabs, uint32_t* multi) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t > n_tiles) return;
     const uint32_t n = t < n_tiles ? cap[t] : 0u;
     const uint32_t j = n == 0 ? 0u : (n <= job_tgt ? 1u : (n + job_tgt - 1) / job_tgt);
-    ne[t] = n ? 1u : 0u; nj[t] = j; slabs[t] = j > 1 ? j * (uint32_t)n_ct : 0u; multi[t] = j > 1 ? 1u : 0u;
+    ne[t] = n ? H : 0u; nj[t] = j; slabs[t] = j > 1 ? j * (uint32_t)n_ct * H : 0u; multi[t] = j > 1 ? H : 0u;
 }
 // job j of J of a tile of n entries at `base`: [first run start at or after n j / J, first run start at or after n (j + 1) / J)
 // (run starts: the store's s0 words, or - before the gather has written them - the sorted keys' barcodes; RunSrc)
@@ -1184,7 +1222,8 @@ __device__ __forceinline__ void tm_make_job(const RunSrc& rs, uint64_t base, uin
     *out = jb;
 }
 // per non-empty tile: its units (one per cell type) and, for a tile that is one job, the job
-__global__ void k_tm_jobs(const uint32_t* tile_base, int n_contigs, int n_ct, RunSrc rs, const uint32_t* tile_off, const uint32_t* cap, const uint32_t* blk_off, const uint32_t* ne_off,
+// (wsh = 1: t is a window; its units are those of tiles 2 t and 2 t + 1, tile by tile)
+__global__ void k_tm_jobs(const uint32_t* tile_base, int n_contigs, int n_ct, int wsh, RunSrc rs, const uint32_t* tile_off, const uint32_t* cap, const uint32_t* blk_off, const uint32_t* ne_off,
                           const uint32_t* nj, const uint32_t* job_off, const uint32_t* slab_off, const uint32_t* multi_off, uint32_t n_tiles, TmJob* jobs,
                           uint32_t* ne_units, int2* ne_geom, uint32_t* ne_nslot, uint32_t* ne_acc, uint32_t* multi, uint32_t* n_wide) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1193,28 +1232,30 @@ __global__ void k_tm_jobs(const uint32_t* tile_base, int n_contigs, int n_ct, Ru
     if (!n) return;
     const uint32_t J = nj[t], ord = ne_off[t];
     const uint64_t base = (uint64_t)blk_off[t] * 8;
+    const uint32_t tile0 = t << wsh;
     int tid = 0;
-    { int lo = 0, hi = n_contigs; while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (tile_base[mid] <= t) lo = mid; else hi = mid; } tid = lo; }
-    const int32_t tstart = (int32_t)((t - tile_base[tid]) << 6);
+    { int lo = 0, hi = n_contigs; while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (tile_base[mid] <= tile0) lo = mid; else hi = mid; } tid = lo; }
+    const int32_t tstart = (int32_t)((tile0 - tile_base[tid]) << 6);
+    for (uint32_t h = 0; h < (1u << wsh); ++h)
     for (int ct = 0; ct < n_ct; ++ct) {
-        const uint32_t w = ord * (uint32_t)n_ct + ct;
-        ne_units[w] = t * (uint32_t)n_ct + ct;
-        ne_geom[w] = make_int2(tstart, tid | (ct << 24));
+        const uint32_t w = (ord + h) * (uint32_t)n_ct + ct;
+        ne_units[w] = (tile0 + h) * (uint32_t)n_ct + ct;
+        ne_geom[w] = make_int2(tstart + 64 * (int32_t)h, tid | (ct << 24));
         ne_nslot[w] = J;
-        ne_acc[w] = J > 1 ? slab_off[t] + (uint32_t)ct * J : 0u;
-        if (J > 1) multi[multi_off[t] * (uint32_t)n_ct + ct] = w;
+        ne_acc[w] = J > 1 ? slab_off[t] + (h * (uint32_t)n_ct + (uint32_t)ct) * J : 0u;
+        if (J > 1) multi[(multi_off[t] + h) * (uint32_t)n_ct + ct] = w;
     }
     if (J > 1) return;                                   // its jobs: k_tm_jobs_multi (a lane per job; here one thread would walk them one after the other)
     tm_make_job(rs, base, tile_off[t], n, 1u, 0u, ord * (uint32_t)n_ct, 0xFFFFFFFFu, t, make_int2(tstart, tid), jobs + job_off[t], n_wide);
 }
 // the jobs of the tiles cut into several: a wave per tile, a lane per job (a job's ends are run starts found from its own nominal ends:
 // no job waits for the one before it)
-__global__ __launch_bounds__(64) void k_tm_jobs_multi(int n_ct, RunSrc rs, const uint32_t* tile_off, const uint32_t* cap, const uint32_t* blk_off, const uint32_t* ne_off, const uint32_t* nj,
+__global__ __launch_bounds__(64) void k_tm_jobs_multi(int n_ct, int wsh, RunSrc rs, const uint32_t* tile_off, const uint32_t* cap, const uint32_t* blk_off, const uint32_t* ne_off, const uint32_t* nj,
                                                       const uint32_t* job_off, const uint32_t* slab_off, const uint32_t* multi, const uint32_t* ne_units, const int2* ne_geom, uint32_t n_mt,
                                                       TmJob* jobs, uint32_t* n_wide) {
     const uint32_t i = blockIdx.x;
     if (i >= n_mt) return;
-    const uint32_t w = multi[(size_t)i * (uint32_t)n_ct], t = ne_units[w] / (uint32_t)n_ct;
+    const uint32_t w = multi[((size_t)i << wsh) * (uint32_t)n_ct], t = (ne_units[w] / (uint32_t)n_ct) >> wsh;      // (the bin's first unit)
     const uint32_t n = cap[t], J = nj[t];
     const int2 geom = ne_geom[w];                        // (k_tm_jobs wrote the tile's units before this kernel started)
     const uint64_t base = (uint64_t)blk_off[t] * 8;
@@ -1239,7 +1280,7 @@ __global__ void k_tm_chunks(const uint32_t* pex, uint32_t njobs, uint32_t chunk_
 // size.  It reads the tiles' capacities only, so the load makes it on the copy stream BESIDE its gather (which then is all the device
 // is waiting for) when the number of cell types is already known; else the first count makes it.
 static int plan_tiles(lsg_ctx* c, hipStream_t st) {
-    const uint32_t T = c->n_tiles;
+    const uint32_t T = c->n_tiles >> c->wsh;      // (bins: tiles, or windows of two)
     const uint64_t N = c->tm_n;
     DevBuf &per_tile = c->bt[BT_PER_TILE], &offs = c->bt[BT_OFFS];
     if (per_tile.reserve((size_t)(T + 2) * 4 * 4) || offs.reserve((size_t)(T + 2) * 4 * 4 + 64)) return -1;
@@ -1250,7 +1291,7 @@ static int plan_tiles(lsg_ctx* c, hipStream_t st) {
     // resident pair of waves should still get several
     uint32_t job_tgt = TM_JOB_TGT;
     { const uint64_t per = N / ((uint64_t)c->n_cus * 14 * 4); if (per < job_tgt) job_tgt = (uint32_t)(per < 768 ? 768 : per); }
-    hipLaunchKernelGGL(k_tm_tiles, dim3((T + 256) / 256), dim3(256), 0, st, c->d_tile_cap.as<uint32_t>(), T, c->n_ct, job_tgt, ne, nj, slabs, multi);
+    hipLaunchKernelGGL(k_tm_tiles, dim3((T + 256) / 256), dim3(256), 0, st, c->d_tile_cap.as<uint32_t>(), T, c->n_ct, job_tgt, 1u << c->wsh, ne, nj, slabs, multi);
     SCAN_U32(ne, ne_off, T + 1); SCAN_U32(nj, job_off, T + 1); SCAN_U32(slabs, slab_off, T + 1); SCAN_U32(multi, multi_off, T + 1);
     LSG_HIP(hipMemsetAsync(d_misc, 0, 8, st));
     uint32_t* srcs[4] = {ne_off, job_off, slab_off, multi_off};
@@ -1273,19 +1314,19 @@ static int plan_tiles(lsg_ctx* c, hipStream_t st) {
 static int plan_jobs(lsg_ctx* c, bool finish, const uint64_t* skey, int cb_bits) {
     hipStream_t st = c->stream;
     const RunSrc rs{c->tm[TM_S0].as<uint32_t>(), skey, skey ? (1u << cb_bits) - 1u : 0u};
-    const uint32_t T = c->n_tiles;
+    const uint32_t T = c->n_tiles >> c->wsh;
     DevBuf &per_tile = c->bt[BT_PER_TILE], &offs = c->bt[BT_OFFS];
     uint32_t* nj = per_tile.as<uint32_t>() + (T + 2);
     uint32_t* ne_off = offs.as<uint32_t>(); uint32_t* job_off = ne_off + (T + 2); uint32_t* slab_off = job_off + (T + 2); uint32_t* multi_off = slab_off + (T + 2);
     uint32_t* d_misc = multi_off + (T + 2);          // [0] wide jobs, [1] chunks
     const uint32_t* tot = c->plan1_tot;
     const uint32_t njobs = tot[1], n_mt = tot[3];
-    hipLaunchKernelGGL(k_tm_jobs, dim3((T + 255) / 256), dim3(256), 0, st, c->d_tile_base.as<uint32_t>(), c->n_contigs, c->n_ct, rs, c->d_tile_off.as<uint32_t>(),
+    hipLaunchKernelGGL(k_tm_jobs, dim3((T + 255) / 256), dim3(256), 0, st, c->d_tile_base.as<uint32_t>(), c->n_contigs, c->n_ct, c->wsh, rs, c->d_tile_off.as<uint32_t>(),
                        c->d_tile_cap.as<uint32_t>(), c->tm[TM_BLK_OFF].as<uint32_t>(), ne_off, nj, job_off, slab_off, multi_off, T,
                        c->tm[TM_JOBS].as<TmJob>(), c->tm[TM_NE_UNITS].as<uint32_t>(), c->tm[TM_NE_GEOM].as<int2>(), c->tm[TM_NE_NSLOT].as<uint32_t>(),
                        c->tm[TM_NE_ACC].as<uint32_t>(), c->tm[TM_MULTI].as<uint32_t>(), d_misc);
-    if (n_mt) hipLaunchKernelGGL(k_tm_jobs_multi, dim3(n_mt), dim3(64), 0, st, c->n_ct, rs, c->d_tile_off.as<uint32_t>(), c->d_tile_cap.as<uint32_t>(), c->tm[TM_BLK_OFF].as<uint32_t>(),
-                                 ne_off, nj, job_off, slab_off, c->tm[TM_MULTI].as<uint32_t>(), c->tm[TM_NE_UNITS].as<uint32_t>(), c->tm[TM_NE_GEOM].as<int2>(), n_mt, c->tm[TM_JOBS].as<TmJob>(), d_misc);
+    if (n_mt) hipLaunchKernelGGL(k_tm_jobs_multi, dim3(n_mt >> c->wsh), dim3(64), 0, st, c->n_ct, c->wsh, rs, c->d_tile_off.as<uint32_t>(), c->d_tile_cap.as<uint32_t>(), c->tm[TM_BLK_OFF].as<uint32_t>(),
+                                 ne_off, nj, job_off, slab_off, c->tm[TM_MULTI].as<uint32_t>(), c->tm[TM_NE_UNITS].as<uint32_t>(), c->tm[TM_NE_GEOM].as<int2>(), n_mt >> c->wsh, c->tm[TM_JOBS].as<TmJob>(), d_misc);
     {   // static work-balanced chunks of the job list; every workgroup of the walk should get several: a small load is cut finer
         DevBuf& pex = c->bt[BT_PEX];
         const uint64_t total_work = c->tm_np + (uint64_t)njobs * TM_JOB_W0;

@@ -152,6 +152,7 @@ int lsg_synth_generate(lsg_ctx* c, const lsg_synth_model* hm, lsg_reads* out) {
     out->read_cb = o_cb.as<int32_t>(); out->seg_read = o_sread.as<uint32_t>();
     out->seg_start = o_sstart.as<int32_t>(); out->seg_len = o_slen.as<int32_t>();
     out->seg_ev_off = o_sevoff.as<int64_t>(); out->events = o_events.as<uint16_t>();
+    c->hint_phased_events = m.layout == LSG_LAYOUT_PHASED ? o_events.p : nullptr;      // (what a load of THESE arrays may take for granted, and checks: build_store)
     return 0;
 }
 

@@ -101,14 +101,14 @@ LSG_HD void sm_read_segment(const lsg_synth_model* m, const sm_read* r, int32_t 
     *start = m->exon_start[x] + (lo - xt0); *len = hi - lo;
 }
 /* LSG_LAYOUT_PHASED (include/longsom_hip.h): the place of a segment that starts at reference position `start`, behind `cur` events of its
- * read's region (the region itself starts at a multiple of 64): the next offset congruent to start modulo 64. */
-LSG_HD int64_t sm_phase_place(int64_t cur, int32_t start) { return cur + (((int64_t)start - cur) & 63); }
-/* Events of a read's region under the model's layout: compact = its t_len events; phased = its segments at their phases, rounded up to 64. */
+ * read's region (the region itself starts at a multiple of 128): the next offset congruent to start modulo 128. */
+LSG_HD int64_t sm_phase_place(int64_t cur, int32_t start) { return cur + (((int64_t)start - cur) & 127); }
+/* Events of a read's region under the model's layout: compact = its t_len events; phased = its segments at their phases, rounded up to 128. */
 LSG_HD int64_t sm_read_region(const lsg_synth_model* m, const sm_read* r) {
     if (m->layout != LSG_LAYOUT_PHASED) return r->t_len;
     int64_t cur = 0;
     for (int32_t k = 0; k <= r->e1 - r->e0; ++k) { int32_t st, ln; sm_read_segment(m, r, k, &st, &ln); cur = sm_phase_place(cur, st) + ln; }
-    return (cur + 63) & ~(int64_t)63;
+    return (cur + 127) & ~(int64_t)127;
 }
 
 /* indel carried by block blk (transcript coords [8blk, 8blk+8)) of read i: 0 none, >0 deletion of

@@ -91,6 +91,7 @@ class Engine:
         self.n_ct = 0
         self.n_contigs = 0
         self.contig_len = None
+        self.pileup_window = 50000
         self._load_settings = {"load_filter": (0, 0, 0), "count_at_load": None, "store_policy": 0, "keep_unlisted": False}      # the library's defaults
         if stream is not None:
             self.set_stream(stream)
@@ -103,10 +104,18 @@ class Engine:
         _lib.check(self._lib.lsg_set_load_filter(self._h, int(min_mq), int(flag_exclude), int(ignore_orphans)), "lsg_set_load_filter")
         self._load_settings["load_filter"] = (int(min_mq), int(flag_exclude), int(ignore_orphans))
 
+    LAYOUT_COMPACT, LAYOUT_PHASED = 0, 1
+
+    def set_events_layout(self, layout: int = 0):
+        """what the caller promises about the events of the next load_reads calls: LAYOUT_PHASED = every segment at an offset congruent to its
+        reference start modulo 128 (lsg_set_events_layout; checked by the load, which falls back by itself)"""
+        _lib.check(self._lib.lsg_set_events_layout(self._h, int(layout)), "lsg_set_events_layout")
+
     def set_pileup_window(self, window: int = 50000):
         """the reference's pileup windows (BaseCellCounter.py --bin): the loads that follow cut their entries at the window edges, the depth
         cap of a count is replayed per window (lsg_set_pileup_window)"""
         _lib.check(self._lib.lsg_set_pileup_window(self._h, int(window)), "lsg_set_pileup_window")
+        self.pileup_window = int(window)
 
     def set_count_at_load(self, params=None):
         """The loads that follow also make the first count under `params` (a CountParams), in the pass that builds the store; the

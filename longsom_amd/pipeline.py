@@ -340,7 +340,7 @@ def run_snv(bam: str, barcodes_tsv: str, ref_fasta: str, out_dir: str, sample_id
             raise ValueError("window_bytes (--window_gb) streams one process's BAM window by window; with %d ranks every rank holds its region's reads at once: "
                              "use one or the other" % comm.world)
         if comm.world > 1 or window_bytes:
-            return _run_snv_regions(bam, barcodes_tsv, ref_fasta, out_dir, sample_id, params, editing, pon_sr, pon_lr, gnomad_af_json, eng, comm, window_bytes)
+            return _run_snv_regions(bam, barcodes_tsv, ref_fasta, out_dir, sample_id, params, editing, pon_sr, pon_lr, gnomad_af_json, eng, comm, window_bytes, keep_store=not own)
         # (the chain counts its sample once: an engine of our own keeps no store for counts nobody will ask for)
         res = load_sample(bam, barcodes_tsv, ref_fasta, eng, params.min_mapping_quality, count_params=params.count(), keep_store=not own)
         return run_chain(res, res.table.celltype_of, res.table.celltype_names, res.dec.report, out_dir, sample_id, params, editing, pon_sr, pon_lr,
@@ -408,8 +408,9 @@ def _prefetch(gen, depth: int = 1):
 
 
 def _run_snv_regions(bam, barcodes_tsv, ref_fasta, out_dir, sample_id, params, editing, pon_sr, pon_lr, gnomad_af_json, eng, comm, window_bytes,
-                     step3: bool = True, resident: Optional[dict] = None, table=None) -> SnvOutputs:
-    """resident / table / step3 serve the sharded two-pass loop (run_reannotation with several ranks): `resident` = SnvOutputs.resident of
+                     step3: bool = True, resident: Optional[dict] = None, table=None, keep_store: bool = True) -> SnvOutputs:
+    """keep_store=False: a rank's slice is counted once and nothing else is asked of its reads (run_snv): the load keeps no tile store.
+    resident / table / step3 serve the sharded two-pass loop (run_reannotation with several ranks): `resident` = SnvOutputs.resident of
     an earlier call on the same engine (the rank's reads stay in HBM, nothing is ingested again), `table` = (celltype_of per barcode
     id, cell-type names, SplitBam report) of the pass, step3=False stops after the step-2 table (pass 1 of the reference has no step 3)."""
     t: Dict[str, float] = {"decode": 0.0, "load": 0.0, "gpu_count_call": 0.0, "fetch": 0.0, "write_tables": 0.0}
@@ -477,13 +478,14 @@ def _run_snv_regions(bam, barcodes_tsv, ref_fasta, out_dir, sample_id, params, e
                 got, ok, fatal = None, 1, None
                 try:
                     # the rank's region and the count's parameters are known before its slice is loaded: the load counts in the same pass
-                    # (and it is the slice's only count: under the count's own read filters, no tile store kept - what load_sample does for one GPU)
+                    # (for run_snv it is the slice's only count: under the count's own read filters, no tile store kept - what load_sample does for one GPU)
                     eng.set_region(lo[0], lo[1], hi[0], hi[1])
                     saved = eng.load_settings()
                     cp_slice = params.count()
                     eng.set_count_at_load(cp_slice)
-                    eng.set_load_filter(cp_slice.min_mq, cp_slice.flag_exclude, cp_slice.ignore_orphans)
-                    eng.set_store_policy(eng.STORE_SKIP_WHEN_COUNTED)
+                    if not keep_store:
+                        eng.set_load_filter(cp_slice.min_mq, cp_slice.flag_exclude, cp_slice.ignore_orphans)
+                        eng.set_store_policy(eng.STORE_SKIP_WHEN_COUNTED)
                     try:
                         got = regions.ingest_slice(eng, bam, plan, lo, hi, bc.barcodes, params.min_mapping_quality)
                     finally:

@@ -31,7 +31,10 @@ def test_full_size_rows_equal_the_cpu_oracle(engine, cfg, n_reads):
     # twice, each in a handle of its own (C4 fills the device either way): the load that counts in its own pass and keeps no store
     # (lsg_set_store_policy: k_tm_count_direct, what bench.py times), then the load that builds the store, counted over it (k_tm_gather /
     # k_tm_resolve / k_tm_walk) - and, on the latter, the call digest
-    for how in ("count at load, no store", "store, then count"):
+    # ... and first of all as bench.py's step makes it: the generator's events tile-phased (LSG_LAYOUT_PHASED), the entries binned by
+    # 128-position windows, one 256-byte block per entry (k_tm_count_win)
+    for how in ("count at load, no store, by windows", "count at load, no store", "store, then count"):
+      m.layout = 1 if how.endswith("windows") else 0
       with Engine(0) as eng:
         eng.set_contigs(m.contig_len); eng.synth_reference(m.seed); eng.set_barcodes(m.celltype_of, 2)
         eng.set_load_filter(p.min_mq, p.flag_exclude, p.ignore_orphans)          # as bench.py loads it
@@ -41,7 +44,7 @@ def test_full_size_rows_equal_the_cpu_oracle(engine, cfg, n_reads):
         eng.set_count_at_load(None); eng.set_store_policy(eng.STORE_KEEP)
         path = eng.layout_info()[0]
         # (C4's 64-position tiles hold more than max_depth = 200 000 reads; no position does - lsg_max_live_reads_exact -, so its load may count too)
-        assert path == (4 if how.startswith("count") else 2), (how, eng.max_live_reads_all())
+        assert path == (6 if how.endswith("windows") else 4 if how.startswith("count") else 2), (how, eng.max_live_reads_all())
         rows, cols = eng.pileup_count(p)
         assert rows == want["rows"] and cols == want["columns"], how
         for ct in range(2):

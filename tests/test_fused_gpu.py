@@ -28,12 +28,34 @@ def oracle_rows(rec, lens, refs, ct_of, n_ct, p):
 def fused_vs_oracle(engine, rec, lens, refs, ct_of, n_ct, p, expect_fused=True, recount_params=()):
     """... and all of it once more with the same events laid out tile-phased (LSG_LAYOUT_PHASED: what the device BAM decoder hands over):
     the keys then carry an entry's 128-byte line, and the load that keeps no store fetches every entry as that one line (path 5)"""
-    out = _fused_vs_oracle(engine, rec, lens, refs, ct_of, n_ct, p, expect_fused, recount_params, direct_path=4)
-    assert _fused_vs_oracle(engine, phased_records(rec), lens, refs, ct_of, n_ct, p, expect_fused, recount_params, direct_path=5 if 1 <= p.min_bq <= 255 else 4) == out
+    out = _fused_vs_oracle(engine, rec, lens, refs, ct_of, n_ct, p, expect_fused, recount_params)
+    ph = phased_records(rec)
+    assert _fused_vs_oracle(engine, ph, lens, refs, ct_of, n_ct, p, expect_fused, recount_params, phased=True) == out
+    # ... and once more with the caller SAYING that its events are phased (lsg_set_events_layout): the load that keeps no store and sorts keys
+    # alone - one whose load filter is the count's own read filter, what the product's loads set - then bins its entries by 128-position windows
+    # and fetches every entry as one 256-byte block (path 6); a claim that is wrong is found out and costs a restart
+    engine.set_events_layout(engine.LAYOUT_PHASED)
+    try:
+        assert _fused_vs_oracle(engine, ph, lens, refs, ct_of, n_ct, p, expect_fused, recount_params, phased=True, hinted=True, match_filter=True) == out
+        assert _fused_vs_oracle(engine, ph, lens, refs, ct_of, n_ct, p, expect_fused, (), phased=True, hinted=True) == out
+        assert _fused_vs_oracle(engine, rec, lens, refs, ct_of, n_ct, p, expect_fused, (), hinted=True, match_filter=True) == out      # (a wrong claim)
+    finally:
+        engine.set_events_layout(engine.LAYOUT_COMPACT)
     return out
 
 
-def _fused_vs_oracle(engine, rec, lens, refs, ct_of, n_ct, p, expect_fused, recount_params, direct_path):
+def expected_direct_path(engine, p, phased, hinted, match_filter):
+    """lsg_get_layout_info's path of a load that keeps no store: 4 = an entry's events through a descriptor of its own bytes, 5 = tile-phased
+    events, one 128-byte line per entry, 6 = entries binned by 128-position windows, one 256-byte block per entry"""
+    if not (phased and 1 <= p.min_bq <= 255):
+        return 4
+    import os
+    keys_alone = (match_filter or engine.load_settings()["load_filter"] == (p.min_mq, p.flag_exclude, p.ignore_orphans)) and not os.environ.get("LSG_TEST_KEYS_ONLY_REFUSED") and not os.environ.get("LSG_NO_KEYS_ONLY")
+    return 6 if hinted and keys_alone and engine.pileup_window >= 128 else 5
+
+
+def _fused_vs_oracle(engine, rec, lens, refs, ct_of, n_ct, p, expect_fused, recount_params, phased=False, hinted=False, match_filter=False):
+    direct_path = expected_direct_path(engine, p, phased, hinted, match_filter)
     engine.set_contigs(lens)
     for t, r in enumerate(refs):
         engine.load_reference(t, r)
@@ -62,13 +84,15 @@ def _fused_vs_oracle(engine, rec, lens, refs, ct_of, n_ct, p, expect_fused, reco
             np.testing.assert_array_equal(k, w2[ct][0]); np.testing.assert_array_equal(c, w2[ct][2])
     stats_keep = engine.count_stats() if not recount_params else None
     # ... and the same load keeping NO store (lsg_set_store_policy: k_tm_count_direct reads the events where the caller left them)
+    saved = engine.load_settings()
     engine.set_count_at_load(p)
     engine.set_store_policy(engine.STORE_SKIP_WHEN_COUNTED)
+    if match_filter:
+        engine.set_load_filter(p.min_mq, p.flag_exclude, p.ignore_orphans)
     try:
         engine.load_reads(rec)
     finally:
-        engine.set_count_at_load(None)
-        engine.set_store_policy(engine.STORE_KEEP)
+        engine.restore_load_settings(saved)
     assert engine.layout_info()[0] == (direct_path if expect_fused else 2)
     for what in ("the count made by the load that kept no store", "the same count asked for again"):
         rows, cols = engine.pileup_count(p)
@@ -81,7 +105,7 @@ def _fused_vs_oracle(engine, rec, lens, refs, ct_of, n_ct, p, expect_fused, reco
     if expect_fused:
         if stats_keep is not None:
             st = engine.count_stats()
-            for f in ("n_reads_admitted", "n_segs_admitted", "n_events_admitted", "n_entries", "n_units", "n_deep_units"):
+            for f in ("n_reads_admitted", "n_segs_admitted", "n_events_admitted") + (("n_entries", "n_units", "n_deep_units") if direct_path != 6 and not match_filter else ()):      # (windows: other entries, other units; a load filter: other jobs)
                 assert getattr(st, f) == getattr(stats_keep, f), f
         other = CountParams.longsom_defaults(min_bq=p.min_bq + 1)
         with pytest.raises(RuntimeError, match="kept no store"):

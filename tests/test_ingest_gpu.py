@@ -179,7 +179,8 @@ def test_the_whole_device_ingest_path_at_scale(engine, tmp_path):
     hostio.synth_bam(m, bam, fa)
     barcodes = hostio.synth_barcodes(m)
     hostio.write_barcodes_tsv(bct, barcodes, m.celltype_of, ["Cancer", "Non-Cancer"])
-    out = pipeline.run_snv(bam, bct, fa, str(tmp_path / "out"), "S", params=pipeline.SnvParams(row_digests=True), engine=engine)
+    engine.unload_reads()                                        # (the run below brings its own handle, as the rule's script does: room for both)
+    out = pipeline.run_snv(bam, bct, fa, str(tmp_path / "out"), "S", params=pipeline.SnvParams(row_digests=True))
     assert any(k.startswith("ingest_") for k in out.timings), "the run took the host decoder"
     want = json.load(open(os.path.join(G, "rows_hash_oracle_c2_1500000.json")))
     got = out.row_digests
@@ -188,6 +189,7 @@ def test_the_whole_device_ingest_path_at_scale(engine, tmp_path):
         assert got["ct%d" % ct] == want["ct%d" % ct], "count rows of cell type %d differ from the CPU oracle's" % ct
     # the arrays themselves, device decoder against host decoder
     names, lens, first = hostio.bam_header(bam)
+    engine.set_contigs(lens); engine.set_barcodes(m.celltype_of, 2); engine.set_region()
     engine.set_keep_reads(True)
     try:
         info, _, _ = engine.load_bam(bam, barcodes, min_mapq=60, first_record_offset=first)

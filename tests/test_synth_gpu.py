@@ -86,24 +86,36 @@ def test_device_generator_equals_host_model(engine, kept_reads):
 
 def test_tile_phased_generation_and_the_count_from_lines(engine, kept_reads):
     """LSG_LAYOUT_PHASED: the device generator == the host evaluation bit for bit (gaps are zeros); a load of such arrays that keeps no
-    store fetches every entry as its one 128-byte line (lsg_get_layout_info path 5) and counts what the oracle counts"""
+    store bins them by 128-position windows and fetches every entry as one 256-byte block (lsg_get_layout_info path 6; by tiles, as one
+    128-byte line, under LSG_NO_WINDOWS: path 5) and counts what the oracle counts"""
     from longsom_amd import hostio
     model = synth.named("C2", n_reads=40_000, n_genes=1_500, n_cb=400, layout=1)
     engine.set_contigs(model.contig_len); engine.synth_reference(model.seed); engine.set_barcodes(model.celltype_of, 2)
     cp = CountParams.longsom_defaults()
+    saved = engine.load_settings()
     engine.set_count_at_load(cp); engine.set_store_policy(engine.STORE_SKIP_WHEN_COUNTED)
+    engine.set_load_filter(cp.min_mq, cp.flag_exclude, cp.ignore_orphans)          # (the count's own read filter at load: keys alone through the sort)
     try:
         engine.synth_reads(model)
     finally:
-        engine.set_count_at_load(None); engine.set_store_policy(engine.STORE_KEEP)
-    assert engine.layout_info()[0] == 5
+        engine.restore_load_settings(saved)
+    assert engine.layout_info()[0] == 6                      # (entries binned by 128-position windows: the generator's arrays are phased modulo 128)
     dev = engine.reads_to_host()
     host = hostio.synth_records(model)
     for name, _ in dev._SPEC:
         np.testing.assert_array_equal(getattr(dev, name), getattr(host, name), err_msg=name)
-    assert (((dev.seg_ev_off - dev.seg_start) % 64) == 0).all()
+    assert (((dev.seg_ev_off - dev.seg_start) % 128) == 0).all()
     compare_with_oracle(engine, model, cp)
     assert engine.count_stats().n_deep_units > 0
+    import os
+    os.environ["LSG_NO_WINDOWS"] = "1"
+    engine.set_count_at_load(cp); engine.set_store_policy(engine.STORE_SKIP_WHEN_COUNTED)
+    try:
+        engine.synth_reads(model)
+    finally:
+        engine.set_count_at_load(None); engine.set_store_policy(engine.STORE_KEEP); os.environ.pop("LSG_NO_WINDOWS")
+    assert engine.layout_info()[0] == 5
+    compare_with_oracle(engine, model, cp)
     # the same arrays through the store-keeping forms (k_tm_gather_count, then k_tm_gather + the walk): the keys carry lines there too
     engine.set_count_at_load(cp)
     try:

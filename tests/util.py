@@ -14,7 +14,7 @@ def neg_zero(text: str) -> str:
 def assert_same_records(a, b, phased_a=False):
     """two sets of read-record arrays hold the same reads, segments and events, wherever their events lie (seg_ev_off is the producer's
     choice: include/longsom_hip.h).  phased_a: a's events are tile-phased (LSG_LAYOUT_PHASED) - every segment at an offset congruent to
-    its reference start modulo 64, every read's region a multiple of 64, zeros between the segments."""
+    its reference start modulo 128, every read's region a multiple of 128, zeros between the segments."""
     import numpy as np
     for name in ("read_tid", "read_pos", "read_flag", "read_mapq", "read_cb", "seg_read", "seg_start", "seg_len"):
         np.testing.assert_array_equal(getattr(a, name), getattr(b, name), err_msg=name)
@@ -25,11 +25,11 @@ def assert_same_records(a, b, phased_a=False):
         ia, ib = a.seg_ev_off[idx] + within, b.seg_ev_off[idx] + within
         np.testing.assert_array_equal(a.events[ia], b.events[ib], err_msg="events")
         if phased_a:
-            assert ((a.seg_ev_off - a.seg_start) % 64 == 0).all() and len(a.events) % 64 == 0
+            assert ((a.seg_ev_off - a.seg_start) % 128 == 0).all() and len(a.events) % 128 == 0
             gaps = np.ones(len(a.events), bool); gaps[ia] = False
             assert not a.events[gaps].any()
             first = np.r_[True, a.seg_read[1:] != a.seg_read[:-1]]
-            assert ((a.seg_ev_off[first] - (a.seg_start[first] % 64)) % 64 == 0).all()      # a read's region starts at a multiple of 64
+            assert ((a.seg_ev_off[first] - (a.seg_start[first] % 128)) % 128 == 0).all()      # a read's region starts at a multiple of 128
 
 
 def phased_records(rec):
@@ -45,11 +45,11 @@ def phased_records(rec):
     cur, region0 = 0, 0
     for s in range(S):
         if s == 0 or rd[s] != rd[s - 1]:
-            cur = region0 = (cur + 63) // 64 * 64
-        cur = cur + ((st[s] - (cur - region0)) % 64)
+            cur = region0 = (cur + 127) // 128 * 128
+        cur = cur + ((st[s] - (cur - region0)) % 128)
         off[s] = cur
         cur += ln[s]
-    n = (cur + 63) // 64 * 64
+    n = (cur + 127) // 128 * 128
     ev = np.zeros(n, np.uint16)
     idx = np.repeat(np.arange(S), ln)
     within = np.arange(int(ln.sum())) - np.repeat(np.cumsum(ln) - ln, ln)
