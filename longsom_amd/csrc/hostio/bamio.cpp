@@ -295,13 +295,17 @@ int inflate_batch(lsio_stream& st, size_t max_ubytes, std::vector<uint8_t>& data
             const int rc = inflate(&zs, Z_FINISH);
             inflateEnd(&zs);
             if (rc != Z_STREAM_END || zs.avail_out != 0) { bad = 1; break; }
+            // the block's CRC32 (RFC 1952 trailer: CRC32, ISIZE behind the deflate stream), as htslib's bgzf reader checks it: a payload that
+            // still inflates to ISIZE bytes but to other bytes is a corrupt file (pysam refuses it: SplitBamCellTypes.py:51,65)
+            const uint32_t want = rd32(st.file + blocks[b].off + blocks[b].csize);
+            if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), data.data() + blocks[b].uoff, blocks[b].usize) != want) { bad = 2; break; }
         }
     };
     const int T = (int)std::min<size_t>((size_t)st.n_threads, std::max<size_t>(1, blocks.size()));
     std::vector<std::thread> th;
     for (int t = 0; t < T; ++t) th.emplace_back(worker);
     for (auto& t : th) t.join();
-    if (bad) { set_err("inflate failed in %s", st.path.c_str()); return -1; }
+    if (bad) { set_err(bad == 2 ? "CRC32 mismatch in a BGZF block of %s" : "inflate failed in %s", st.path.c_str()); return -1; }
     data.resize(base + utotal);
     return 0;
 }

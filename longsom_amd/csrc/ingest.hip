@@ -5,8 +5,8 @@
 //   host    walks the BGZF block headers (18 bytes each), copies the file to the device
 //   k_inflate      one LANE per BGZF block: raw DEFLATE (inflate_core.h), a wave's 64 decoding tables side by side in LDS; every lane takes
 //                  its next block off one queue.  (One WAVE per block with an LDS ring was built and measured: 5-8 x slower, below.)
-//                  A block's ISIZE is checked against what it inflates to; its CRC32 is NOT (htslib checks it: a block whose corrupted
-//                  payload still inflates to ISIZE bytes is caught here only by the records' validation, bamrec_core.h validate()).
+//                  A block's ISIZE is checked against what it inflates to, its CRC32 by k_block_crc (below): htslib's bgzf reader checks
+//                  both, and pysam refuses a file that fails either (SplitBamCellTypes.py:51,65).
 //   k_chain        records are a chain (block_size -> next record) through the uncompressed stream; htslib starts every BGZF block on
 //                  a record boundary unless a record is longer than a block, so every block's lane walks its own records from the
 //                  block's first byte; k_chain_fix hands every block the place where its predecessor's chain really landed, and the
@@ -29,7 +29,7 @@
 
 namespace lsg {
 
-struct IngBlk { uint64_t coff, uoff; uint32_t csize, usize; };
+struct IngBlk { uint64_t coff, uoff; uint32_t csize, usize, crc, pad_; };      // crc: the block's CRC32 of its uncompressed bytes (RFC 1952 trailer)
 
 // The decoding tables of a wave's 64 streams (45 KB) live in LDS, three waves per CU; the code lengths, which only the header of a block
 // touches, in global memory (`lens_all`: T_LENS * 64 bytes per wave, lane-interleaved like the tables).
@@ -45,6 +45,59 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t* comp, const IngBl
         const int rc = lsi::inflate_raw(comp + d.coff, d.csize, ubuf + d.uoff, d.usize, lsi::Tab{tab + lane, lens + lane, 64});
         if (rc) { atomicOr(status, 1u); atomicMin(status + 1, b); }
     }
+}
+
+// CRC32 (IEEE 802.3, reflected: zlib's crc32) of every block's uncompressed bytes against the block's trailer.  One WAVE per block: lane i
+// takes the 1 KB chunk i of the block's <= 64 KB (bytewise table in LDS, 16 bytes per load), the 64 chunk CRCs are combined as zlib's
+// crc32_combine does - CRC is linear over GF(2): crc0(A || B) = shift(crc0(A), |B|) ^ crc0(B) with crc0 the register started at 0 and
+// shift(v, n) = v run through n zero bytes, done as a product with the precomputed 32 x 32 bit matrices of 2^k zero bytes (zero_ops) -
+// and the initial and final complement are put back: crc32(M) = crc0(M) ^ shift(0xffffffff, |M|) ^ 0xffffffff.
+struct CrcTables { uint32_t byte_tab[256]; uint32_t zero_ops[17][32]; };      // zero_ops[k][j]: where bit j of the register goes under 2^k zero bytes
+__device__ __forceinline__ uint32_t crc_shift(const uint32_t (*ops)[32], uint32_t v, uint32_t n_bytes) {
+    for (int k = 0; n_bytes; ++k, n_bytes >>= 1)
+        if (n_bytes & 1u) { uint32_t r = 0; for (int j = 0; j < 32; ++j) r ^= (v >> j) & 1u ? ops[k][j] : 0u; v = r; }
+    return v;
+}
+__global__ __launch_bounds__(256) void k_block_crc(const uint8_t* ubuf, const IngBlk* blk, uint32_t n_blk, const CrcTables* tabs, uint32_t* status) {
+    __shared__ uint32_t tab[256];
+    __shared__ uint32_t ops[17][32];
+    for (int i = threadIdx.x; i < 256; i += 256) tab[i] = tabs->byte_tab[i];
+    for (int i = threadIdx.x; i < 17 * 32; i += 256) (&ops[0][0])[i] = (&tabs->zero_ops[0][0])[i];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t b = blockIdx.x * 4u + (threadIdx.x >> 6); b < n_blk; b += gridDim.x * 4u) {
+        const IngBlk d = blk[b];
+        if (!d.usize) continue;
+        const uint32_t lo = lane * 1024u, hi = lo + 1024u < d.usize ? lo + 1024u : d.usize;
+        uint32_t c = 0;
+        if (lo < d.usize) {
+            const uint8_t* p = ubuf + d.uoff;
+            uint32_t i = lo;
+            for (; i < hi && ((d.uoff + i) & 15u); ++i) c = tab[(c ^ p[i]) & 0xffu] ^ (c >> 8);
+            for (; i + 16 <= hi; i += 16) {
+                const uint4 q = *reinterpret_cast<const uint4*>(p + i);
+                const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    c ^= w[k];
+                    c = tab[c & 0xffu] ^ (c >> 8); c = tab[c & 0xffu] ^ (c >> 8); c = tab[c & 0xffu] ^ (c >> 8); c = tab[c & 0xffu] ^ (c >> 8);
+                }
+            }
+            for (; i < hi; ++i) c = tab[(c ^ p[i]) & 0xffu] ^ (c >> 8);
+            c = crc_shift(ops, c, d.usize - hi);                      // ... through the bytes of the block behind this chunk
+        }
+        for (int o = 32; o > 0; o >>= 1) c ^= (uint32_t)__shfl_xor((int)c, o);
+        if (lane == 0) {
+            const uint32_t crc = c ^ crc_shift(ops, 0xffffffffu, d.usize) ^ 0xffffffffu;
+            if (crc != d.crc) { atomicOr(status, 32u); atomicMin(status + 1, b); }
+        }
+    }
+}
+static void make_crc_tables(CrcTables& t) {
+    for (uint32_t i = 0; i < 256; ++i) { uint32_t c = i; for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1; t.byte_tab[i] = c; }
+    for (int j = 0; j < 32; ++j) { uint32_t v = 1u << j; v = t.byte_tab[v & 0xffu] ^ (v >> 8); t.zero_ops[0][j] = v; }      // one zero byte
+    for (int k = 1; k < 17; ++k)                                        // the operator of 2^k zero bytes = the one of 2^(k-1) applied twice
+        for (int j = 0; j < 32; ++j) { const uint32_t v = t.zero_ops[k - 1][j]; uint32_t r = 0; for (int b = 0; b < 32; ++b) r ^= (v >> b) & 1u ? t.zero_ops[k - 1][b] : 0u; t.zero_ops[k][j] = r; }
 }
 
 // (One WAVE per block — uniform decode, a 32 KB LDS ring for the output, match copies spread over the lanes — was built and measured
@@ -212,7 +265,7 @@ static int load_bam_impl(lsg_ctx* c, const uint8_t* file, int64_t n_bytes, int64
         if (!found || bsize < xlen + 20u || off + bsize > (uint64_t)n_bytes) { set_error("lsg_load_bam: corrupt BGZF block at offset %llu", (unsigned long long)off); return -1; }
         const uint32_t usize = lsr::rd32(h + bsize - 4);
         if (usize > 65536u) { set_error("lsg_load_bam: BGZF block at offset %llu claims %u uncompressed bytes", (unsigned long long)off, usize); return -1; }
-        blocks.push_back(IngBlk{off + 12 + xlen, utotal, bsize - xlen - 20, usize});
+        blocks.push_back(IngBlk{off + 12 + xlen, utotal, bsize - xlen - 20, usize, lsr::rd32(h + bsize - 8), 0u});
         utotal += usize; off += bsize;
     }
     const uint32_t n_blk = (uint32_t)blocks.size();
@@ -284,6 +337,23 @@ static int load_bam_impl(lsg_ctx* c, const uint8_t* file, int64_t n_bytes, int64
     ING_HIP(hipStreamSynchronize(st));
     if (hstat[0] & 1u) { set_error("lsg_load_bam: inflate failed in BGZF block %u", hstat[1]); return done_ev(-1); }
     d_comp.release();
+    if (!getenv("LSG_NO_BGZF_CRC")) {                     // every block's CRC32 against its trailer (k_block_crc)
+        static CrcTables h_tabs; static bool h_tabs_made = false;
+        if (!h_tabs_made) { make_crc_tables(h_tabs); h_tabs_made = true; }
+        DevBuf d_tabs;
+        if (d_tabs.reserve(sizeof(CrcTables))) return done_ev(-1);
+        ING_HIP(hipMemcpyAsync(d_tabs.p, &h_tabs, sizeof(CrcTables), hipMemcpyHostToDevice, st));
+        ING_HIP(hipMemsetAsync(status, 0, 4, st));
+        ING_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(status + 1), (int)0x7fffffff, 1, st));
+        unsigned g = (n_blk + 3) / 4; const unsigned cap = (unsigned)(c->n_cus * 8);
+        if (g > cap) g = cap;
+        hipLaunchKernelGGL(k_block_crc, dim3(g ? g : 1), dim3(256), 0, st, d_u.as<uint8_t>(), dblk, n_blk, d_tabs.as<CrcTables>(), status);
+        ING_HIP(hipMemcpyAsync(hstat, status, 16, hipMemcpyDeviceToHost, st));
+        const hipError_t es = hipStreamSynchronize(st);
+        d_tabs.release();
+        if (es != hipSuccess) { set_error("lsg_load_bam: the CRC pass failed: %s", hipGetErrorString(es)); return done_ev(-1); }
+        if (hstat[0] & 32u) { set_error("lsg_load_bam: CRC32 mismatch in BGZF block %u", hstat[1]); return done_ev(-1); }
+    }
     // ---- the record chain
     const uint8_t* u = d_u.as<uint8_t>();
     uint64_t* in = d_in.as<uint64_t>(); uint64_t* land = d_land.as<uint64_t>();

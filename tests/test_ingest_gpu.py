@@ -200,3 +200,56 @@ def test_the_whole_device_ingest_path_at_scale(engine, tmp_path):
     assert info["n_records"] == 1_500_000 and dev.n_reads == dec.records.n_reads
     assert_same_records(dev, dec.records, phased_a=True)
     engine.unload_reads()
+
+
+def _bgzf_blocks(raw):
+    out, off = [], 0
+    while off < len(raw):
+        xlen = int.from_bytes(raw[off + 10:off + 12], "little")
+        bsize = None
+        q = off + 12
+        while q < off + 12 + xlen:
+            slen = int.from_bytes(raw[q + 2:q + 4], "little")
+            if raw[q:q + 2] == b"BC" and slen == 2:
+                bsize = int.from_bytes(raw[q + 4:q + 6], "little") + 1
+            q += 4 + slen
+        out.append((off, bsize, xlen))
+        off += bsize
+    return out
+
+
+def test_a_block_whose_payload_inflates_to_isize_with_a_wrong_crc_is_refused(engine, tmp_path):
+    """htslib checks every BGZF block's CRC32 (pysam refuses such a file: SplitBamCellTypes.py:51,65): a block whose payload was changed -
+    one quality value - and deflated again, under the OLD trailer, still inflates to ISIZE bytes; both decoders must say no, and say why"""
+    import zlib
+    src = os.path.join(G, "pileup.rand.bam")
+    raw = open(src, "rb").read()
+    bc = hostio.read_barcodes(os.path.join(G, "pileup.rand.barcodes.tsv"))
+    names, lens, first = hostio.bam_header(src)
+    blocks = _bgzf_blocks(raw)
+    off, bsize, xlen = max(blocks[:-1], key=lambda b: b[1])          # the largest block (not the EOF marker)
+    payload = raw[off + 12 + xlen:off + bsize - 8]
+    data = bytearray(zlib.decompress(payload, -15))
+    assert len(data) == int.from_bytes(raw[off + bsize - 4:off + bsize], "little") and zlib.crc32(bytes(data)) == int.from_bytes(raw[off + bsize - 8:off + bsize - 4], "little")
+    data[len(data) // 2] ^= 0x04
+    co = zlib.compressobj(6, zlib.DEFLATED, -15)
+    new_payload = co.compress(bytes(data)) + co.flush()
+    new_bsize = 12 + xlen + len(new_payload) + 8
+    head = bytearray(raw[off:off + 12 + xlen])
+    q = 12
+    while q < 12 + xlen:
+        slen = int.from_bytes(head[q + 2:q + 4], "little")
+        if head[q:q + 2] == b"BC":
+            head[q + 4:q + 6] = (new_bsize - 1).to_bytes(2, "little")
+        q += 4 + slen
+    bad = raw[:off] + bytes(head) + new_payload + raw[off + bsize - 8:off + bsize] + raw[off + bsize:]
+    p = tmp_path / "badcrc.bam"
+    p.write_bytes(bad)
+    engine.set_contigs(lens); engine.set_barcodes(bc.celltype_of, 2)
+    with pytest.raises(LsgError, match="CRC32"):
+        engine.load_bam(str(p), bc.barcodes, first_record_offset=first)
+    with pytest.raises(Exception, match="CRC32"):
+        hostio.decode_bam(str(p), bc.barcodes, min_mapq=60)
+    # ... and the untouched file still loads, on the same handle (every one of its blocks' CRCs agrees)
+    engine.load_bam(src, bc.barcodes, first_record_offset=first)
+    assert engine.reads_shape()[0] == 1333

@@ -20,7 +20,7 @@ PY
 for v in longsom_amd/lib/variants/*.so; do
   n=$(basename $v .so)
   cp $v longsom_amd/lib/liblongsom_hip.so
-  for g in "$@"; do one ${n}_g$g LSG_GRID_TD=$g; done
+  for g in "$@"; do one ${n}_g$g LSG_GRID_TD=$g LSG_GRID_TW=$g; done
 done
 cp /tmp/shipped.so longsom_amd/lib/liblongsom_hip.so
-for g in "$@"; do one shipped_g$g LSG_GRID_TD=$g; done
+for g in "$@"; do one shipped_g$g LSG_GRID_TD=$g LSG_GRID_TW=$g; done
