@@ -16,7 +16,7 @@ for f in glob.glob("profiles/%s_bench_kernel_stats.csv" % tag) + glob.glob("prof
 PY
 echo "== the store-keeping step (k_tm_gather_count) and the re-counts over its store (k_tm_resolve, k_tm_walk)"
 export LSG_BENCH_KEEP_STORE=1
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/keep -o bench -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --e2e-reads 0 > $F/${TAG}_keep_store_bench.json 2> $F/keep.err || echo "keep-store trace failed"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/keep -o bench -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --e2e-reads 0 --no-c4 > $F/${TAG}_keep_store_bench.json 2> $F/keep.err || echo "keep-store trace failed"
 unset LSG_BENCH_KEEP_STORE
 python3 - "$TAG" <<'PY'
 import csv, sys

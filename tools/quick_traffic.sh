@@ -2,7 +2,7 @@
 # Run on the GPU box: one rocprofv3 --pmc pass (read requests to the fabric by size) of a short bench run; prints the per-launch bytes of the kernels named on the command line
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/qt; rm -rf $O; mkdir -p $O
-timeout -k 10 300 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum --output-format csv -d $O -o bench -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --e2e-reads 0 --no-recount > $O/out 2> $O/err || { echo failed; tail -3 $O/err; exit 1; }
+timeout -k 10 300 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum --output-format csv -d $O -o bench -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --e2e-reads 0 --no-recount --no-c4 > $O/out 2> $O/err || { echo failed; tail -3 $O/err; exit 1; }
 python3 - "$@" <<'PY'
 import csv, glob, collections, sys
 want = sys.argv[1:] or ["count_direct"]

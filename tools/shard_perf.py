@@ -14,7 +14,7 @@ from longsom_amd.shard import region_shards, sub_model, CALL_BYTES
 
 n_reads = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10_000_000
 worlds = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 2, 4, 8]
-model = synth.named("C2", n_reads=n_reads)
+model = synth.named("C2", n_reads=n_reads, layout=0 if os.environ.get("LSG_BENCH_COMPACT") == "1" else 1)      # (as bench.py generates it: tile-phased events)
 eng = Engine(0, stream=torch.cuda.current_stream().cuda_stream)
 eng.set_contigs(model.contig_len); eng.synth_reference(model.seed); eng.set_barcodes(model.celltype_of, 2)
 cp, kp = CountParams.longsom_defaults(), CallParams.longsom_defaults()
@@ -22,6 +22,24 @@ eng.set_load_filter(cp.min_mq, cp.flag_exclude, cp.ignore_orphans)
 eng.set_count_at_load(cp)
 eng.set_store_policy(eng.STORE_SKIP_WHEN_COUNTED)      # (bench.py's step: the BAM is counted once, no store kept)
 buf = torch.zeros(64 << 20, dtype=torch.uint8, device="cuda")
+# ONE measured RCCL all-gather of bench.py's message (a header slot + 64 rows of CALL_BYTES) in a one-rank group: what the collective's own
+# launch and completion cost a rank's step (the transfer itself - a few KB over xGMI - is not what a one-rank group can show)
+coll_ms = None
+try:
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29577")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    send = torch.zeros(65 * CALL_BYTES, dtype=torch.uint8, device="cuda"); recv = torch.zeros_like(send)
+    for _ in range(5):
+        dist.all_gather_into_tensor(recv, send)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(50):
+        dist.all_gather_into_tensor(recv, send)
+    torch.cuda.synchronize(); coll_ms = (time.perf_counter() - t0) / 50 * 1e3
+    dist.destroy_process_group()
+    print("one-rank RCCL all_gather_into_tensor of %d bytes: %.3f ms" % (send.numel(), coll_ms), flush=True)
+except Exception as e:      # noqa: BLE001
+    print("RCCL one-rank group failed:", repr(e), flush=True)
 out = {"workload": "C2 at %d reads, one step = load (+ count in the same pass) + call + export per rank, ranks emulated one after another on one GPU" % n_reads, "worlds": {}}
 for world in worlds:
     per_rank = []
@@ -49,8 +67,11 @@ for world in worlds:
     out["worlds"][str(world)] = {"slowest_rank_ms": worst, "ranks": per_rank}
     print(f"N={world}: slowest rank {worst:.2f} ms", flush=True)
 w1 = out["worlds"].get("1", {}).get("slowest_rank_ms")
+out["rccl_all_gather_one_rank_ms"] = None if coll_ms is None else round(coll_ms, 4)
 if w1:
     out["predicted_speedup_vs_1"] = {k: round(w1 / v["slowest_rank_ms"], 2) for k, v in out["worlds"].items()}
+    if coll_ms is not None:
+        out["predicted_speedup_vs_1_with_the_collective"] = {k: round(w1 / (v["slowest_rank_ms"] + (coll_ms if k != "1" else 0.0)), 2) for k, v in out["worlds"].items()}
     print("predicted speed-up (slowest rank, no collective):", out["predicted_speedup_vs_1"], flush=True)
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(out, open("gpurun_out/shard_perf.json", "w"), indent=1)

@@ -3,7 +3,7 @@
 cd "$GRAFT_REPO_ROOT"
 for V in "$@"; do
   echo "== $V"
-  env $V LSG_TIMING=1 timeout -k 10 200 python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline --e2e-reads 0 > gpurun_out/sw.log 2> gpurun_out/sw.err || { echo bench failed; tail -5 gpurun_out/sw.err; continue; }
+  env $V LSG_TIMING=1 timeout -k 10 200 python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline --e2e-reads 0 --no-c4 > gpurun_out/sw.log 2> gpurun_out/sw.err || { echo bench failed; tail -5 gpurun_out/sw.err; continue; }
   python3 -c "
 import json
 d=json.loads([l for l in open('gpurun_out/sw.log') if l.startswith('{')][-1])

@@ -3,7 +3,7 @@
 # and under the LSG_GRID_TD values given on the command line; the shipped library last.
 cd "$GRAFT_REPO_ROOT"
 cp longsom_amd/lib/liblongsom_hip.so /tmp/shipped.so
-B="python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --e2e-reads 0 --no-recount"
+B="python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --e2e-reads 0 --no-recount --no-c4"
 one() {  # name, env...
   local name=$1; shift
   env "$@" timeout -k 10 300 $B > gpurun_out/v_$name.json 2> gpurun_out/v_$name.err || echo "$name failed"
