@@ -1405,11 +1405,14 @@ __global__ __launch_bounds__(TMW_WAVES * 64) __attribute__((amdgpu_waves_per_eu(
 // through the entry's scalar decisions (close / not there / run of one / first of a run / further entry of a run: the same for both
 // positions) and ONE 64-bit LDS atomic per position instead of two 32-bit ones (an LDS instruction costs a CU ~4.3 cycles whatever its
 // width up to 32 bits, 6.3 at 64: tools/lds_rate.hip).  A counter is 8 bytes: low word quality sum [0..19] | forward count [20..31], high word
-// count [0..15] | duplicates [16..31]; byte address = parity << 13 | cell type << 12 | tile << 11 | symbol << 8 | (position >> 1) << 3.
-// m: the entry's meta word (TMM_CLOSE, TMM_FIRST, TMM_SKIP, TMM_SINGLE, TMM_CT10, TMM_CT12, TMM_FWD); r: the lanes of its positions -
-// even ones [r & 63, 64 - (r >> 8 & 63)), odd ones [r >> 16 & 63, 64 - (r >> 24 & 63)).  The atomics' data are register PAIRS, which inline
+// count [0..12] | duplicates x 2^symbol [13..31] (a duplicate of symbol class c adds the run's seen-bit of that symbol, 1 << (8 + c), shifted
+// up by 5 - no normalising: a counter holds one symbol only, the emit shifts it back; <= 4095 entries a job: 12 + 7 bits);
+// byte address = parity << 13 | cell type << 12 | tile << 11 | symbol << 8 | (position >> 1) << 3.
+// m: the entry's meta word - TMM_CLOSE, TMM_FIRST, TMM_SKIP, TMM_SINGLE, TMM_CT12, TMM_FWD where tm_add has them, and in the bits between them
+// the lanes of the entry's positions: even ones [m & 63, 64 - (m >> 6 & 63)), odd ones [m >> 13 & 63, 64 - (m >> 21 & 63)) (tw_ranges).  The atomics' data are register PAIRS, which inline
 // asm can only name by number: v[92:93] = {low word, 1} (v93 holds 1 throughout: `one`), v[94:95] = {low word, 1 | seen << 16}.
-__device__ __forceinline__ void tw_add(TmState& s0, TmState& s1, uint32_t m, uint32_t r, uint32_t ev, uint32_t thr, uint32_t pk0, uint32_t pk1, uint32_t one) {
+__device__ __forceinline__ void tw_add(TmState& s0, TmState& s1, uint32_t m, uint32_t ev, uint32_t thr, uint32_t pk0, uint32_t pk1, uint32_t one) {
+    const uint32_t r = m;      // (ONE word: the decisions' bits and the lanes' ranges, TWM_* below)
     if (!TM_ASM) {                                   // the same in plain C++
         const uint32_t ln = threadIdx.x & 63u;
         auto half = [&](TmState& s, uint32_t e, uint32_t f, uint32_t inv, uint32_t pk) {
@@ -1418,21 +1421,21 @@ __device__ __forceinline__ void tw_add(TmState& s0, TmState& s1, uint32_t m, uin
             const bool counted = (e & 0xffu) >= thr && ln >= f && ln < 64u - inv;
             if (!counted) return;
             const uint32_t addr = (pk | (e & 0x700u)) + (m & TMM_CT12);
-            const uint32_t sym8 = (e >> 8) & 15u, ctone = 1u << ((m >> 6) & 16u);
+            const uint32_t sym8 = (e >> 8) & 15u, ctone = 1u << ((m >> 8) & 16u);
             uint32_t hi = 1u;
             if (m & TMM_SINGLE) s.nc += ctone;
             else if (m & TMM_FIRST) s.mask = (1u << sym8) | ctone;
-            else { hi |= ((s.mask >> sym8) & 1u) << 16; s.mask |= (1u << sym8) | ctone; }
+            else { hi |= (s.mask & (1u << sym8)) << 5; s.mask |= (1u << sym8) | ctone; }
             __hip_atomic_fetch_add((LSG_AS3 unsigned long long*)(uintptr_t)addr, ((unsigned long long)hi << 32) | ((e & 0xffu) | (m & TMM_FWD)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         };
-        half(s0, ev & 0xffffu, r & 63u, (r >> 8) & 63u, pk0);
-        half(s1, ev >> 16, (r >> 16) & 63u, (r >> 24) & 63u, pk1);
+        half(s0, ev & 0xffffu, r & 63u, (r >> 6) & 63u, pk0);
+        half(s1, ev >> 16, (r >> 13) & 63u, (r >> 21) & 63u, pk1);
         return;
     }
     uint32_t t0, t1, addr, dlo, elo, ehi, sa, sb, sc, st; unsigned long long xm;
     // the lanes of a half's positions into EXEC (whole: nothing of the half before is left in it)
-#define TW_RANGE0 "s_lshr_b32 %[st], %[r], 8\n\ts_lshl_b64 %[xm], -1, %[r]\n\ts_lshr_b64 exec, -1, %[st]\n\ts_and_b64 exec, exec, %[xm]\n\t"
-#define TW_RANGE1 "s_lshr_b32 %[st], %[r], 16\n\ts_lshl_b64 %[xm], -1, %[st]\n\ts_lshr_b32 %[st], %[r], 24\n\ts_lshr_b64 exec, -1, %[st]\n\ts_and_b64 exec, exec, %[xm]\n\t"
+#define TW_RANGE0 "s_lshr_b32 %[st], %[r], 6\n\ts_lshl_b64 %[xm], -1, %[r]\n\ts_lshr_b64 exec, -1, %[st]\n\ts_and_b64 exec, exec, %[xm]\n\t"
+#define TW_RANGE1 "s_lshr_b32 %[st], %[r], 13\n\ts_lshl_b64 %[xm], -1, %[st]\n\ts_lshr_b32 %[st], %[r], 21\n\ts_lshr_b64 exec, -1, %[st]\n\ts_and_b64 exec, exec, %[xm]\n\t"
     // address of the position's counter, low word of the atomic's data (into DLO), EXEC = the lanes that count this event
 #define TW_HEAD(WSEL, BSEL, PK, DLO)                                                                                                 \
         "v_and_b32_sdwa %[addr], %[c700], %[ev] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:" WSEL "\n\t"           \
@@ -1452,8 +1455,8 @@ __device__ __forceinline__ void tw_add(TmState& s0, TmState& s1, uint32_t m, uin
         "s_bitcmp1_b32 %[m], 29\n\t"
         "s_cbranch_scc1 9f\n\t"                                     /* not counted / not there */
         "s_and_b32 %[sa], %[m], 0x1000\n\t"                         /* the cell type's counters */
-        "s_lshr_b32 %[sc], %[m], 6\n\t"
         "s_and_b32 %[sb], %[m], 0x100000\n\t"                       /* forward strand */
+        "s_lshr_b32 %[sc], %[sa], 8\n\t"
         "s_lshl_b32 %[sc], 1, %[sc]\n\t"                            /* bit 0 or bit 16: the cell type's run counter */
         "s_bitcmp1_b32 %[m], 30\n\t"
         "s_cbranch_scc0 2f\n\t"
@@ -1483,27 +1486,25 @@ __device__ __forceinline__ void tw_add(TmState& s0, TmState& s1, uint32_t m, uin
         "3:\n\t"
         TW_RANGE0                                                   /* ---- a further entry of the run: its symbol seen before = a duplicate */
         TW_HEAD("WORD_0", "BYTE_0", "%[pk0]", "v94")
-        "v_bfe_u32 %[t1], %[ev], 8, 4\n\t"
-        "v_bfe_u32 %[t0], %[mask0], %[t1], 1\n\t"
-        "v_lshl_or_b32 v95, %[t0], 16, %[one]\n\t"
-        "v_lshl_or_b32 %[t1], %[one], %[t1], %[sc]\n\t"
+        "v_lshlrev_b32_sdwa %[t1], %[ev], %[one] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"      /* the symbol's seen-bit: 1 << (8 + class) */
+        "v_and_b32 %[t0], %[mask0], %[t1]\n\t"
+        "v_lshl_or_b32 v95, %[t0], 5, %[one]\n\t"
         "ds_add_u64 %[addr], v[94:95]\n\t"
-        "v_or_b32 %[mask0], %[mask0], %[t1]\n\t"
+        "v_or3_b32 %[mask0], %[mask0], %[t1], %[sc]\n\t"
         TW_RANGE1
         TW_HEAD("WORD_1", "BYTE_2", "%[pk1]", "v94")
-        "v_bfe_u32 %[t1], %[ev], 24, 4\n\t"
-        "v_bfe_u32 %[t0], %[mask1], %[t1], 1\n\t"
-        "v_lshl_or_b32 v95, %[t0], 16, %[one]\n\t"
-        "v_lshl_or_b32 %[t1], %[one], %[t1], %[sc]\n\t"
+        "v_lshlrev_b32_sdwa %[t1], %[ev], %[one] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+        "v_and_b32 %[t0], %[mask1], %[t1]\n\t"
+        "v_lshl_or_b32 v95, %[t0], 5, %[one]\n\t"
         "ds_add_u64 %[addr], v[94:95]\n\t"
-        "v_or_b32 %[mask1], %[mask1], %[t1]\n"
+        "v_or3_b32 %[mask1], %[mask1], %[t1], %[sc]\n"
         "8:\n\t"
         "s_mov_b64 exec, -1\n"
         "9:"
         : [t0] "=&v"(t0), [t1] "=&v"(t1), [addr] "=&v"(addr), [dlo] "=&{v92}"(dlo), [elo] "=&{v94}"(elo), [ehi] "=&{v95}"(ehi),
           [sa] "=&s"(sa), [sb] "=&s"(sb), [sc] "=&s"(sc), [st] "=&s"(st), [xm] "=&s"(xm),
           [mask0] "+v"(s0.mask), [nc0] "+v"(s0.nc), [mask1] "+v"(s1.mask), [nc1] "+v"(s1.nc)
-        : [ev] "v"(ev), [m] "s"(m), [r] "s"(r), [thr] "s"(thr), [c700] "s"(0x700u), [one] "{v93}"(one), [pk0] "v"(pk0), [pk1] "v"(pk1)
+        : [ev] "v"(ev), [m] "s"(m), [r] "s"(m), [thr] "s"(thr), [c700] "s"(0x700u), [one] "{v93}"(one), [pk0] "v"(pk0), [pk1] "v"(pk1)
         : "scc", "vcc", "memory");
 #undef TW_RANGE0
 #undef TW_RANGE1
@@ -1523,18 +1524,25 @@ struct TwCounters {      // the 8-byte counters of one (tile, cell type) read by
     const uint32_t* pl; int lane; uint32_t ncdup;
     __device__ __forceinline__ uint32_t lo(int k) const { return pl[(lane & 1) * 2048 + k * 64 + (lane >> 1) * 2]; }
     __device__ __forceinline__ uint32_t hi(int k) const { return pl[(lane & 1) * 2048 + k * 64 + (lane >> 1) * 2 + 1]; }
-    __device__ __forceinline__ uint32_t BC(int k) const { return hi(k) & 0xffffu; }
-    __device__ __forceinline__ uint32_t DUP(int k) const { return hi(k) >> 16; }
+    __device__ __forceinline__ uint32_t BC(int k) const { return hi(k) & 0x1fffu; }
+    __device__ __forceinline__ uint32_t DUP(int k) const { return hi(k) >> (13 + k); }
     __device__ __forceinline__ uint32_t BQ(int k) const { return lo(k) & 0xfffffu; }
     __device__ __forceinline__ uint32_t BCF(int k) const { return lo(k) >> 20; }
     __device__ __forceinline__ uint32_t NCDUP() const { return ncdup; }
 };
 struct TwPre { uint32_t bits, ctv, rng; };
+// TW_G: entries to a group - 64 (one per lane) or 32 (both halves of the wave work the same 32 words out: half the unrolled loop, twice the
+// words' instructions per entry)
+#ifndef LSG_TW_GROUP
+#define LSG_TW_GROUP 64
+#endif
+constexpr int TW_G = LSG_TW_GROUP, TW_NQ = TW_G / TD_Q;
+static_assert(TW_G == 32 || TW_G == 64, "a group of the windows' count is 32 or 64 entries");
 __device__ __forceinline__ void tw_range(const CountArgs& a, const TmArgs& tm, const TgArgs& tg, TmState& st0, TmState& st1, TgStat& stat, uint32_t i0, uint32_t i1, uint32_t off, uint32_t n,
                                          uint32_t thr, uint32_t pkl0, uint32_t one, int lane, uint64_t K, uint64_t key_before) {
-    const int ng = (int)((i1 - i0 + 31u) >> 5);
+    const int ng = (int)((i1 - i0 + (uint32_t)TW_G - 1u) / (uint32_t)TW_G);
     const uint32_t cbm = (1u << tg.cb_bits) - 1u;
-    const int e = lane & 31;                                               // the lane's entry of a group (both halves of the wave work the same words out)
+    const int e = lane & (TW_G - 1);                                       // the lane's entry of a group
     const uint32_t lane4 = 4u * (uint32_t)lane;
     const uint32_t pkl1 = pkl0 | 8192u;                                    // (the odd positions' counters)
     const uint64_t evb = (uint64_t)(uintptr_t)tg.events;
@@ -1545,16 +1553,16 @@ __device__ __forceinline__ void tw_range(const CountArgs& a, const TmArgs& tm, c
     uint32_t cb_carry = rl((uint32_t)key_before & cbm, 0);
     uint32_t cb_last = 0;
     auto words = [&](int g, uint64_t Kk, TdW& w, TwPre& pre) {
-        const uint32_t i = i0 + 32u * (uint32_t)g + (uint32_t)e;
+        const uint32_t i = i0 + (uint32_t)TW_G * (uint32_t)g + (uint32_t)e;
         const bool valid = i < i1;
         const uint32_t cb = (uint32_t)Kk & cbm;
-        const uint32_t up = (uint32_t)__shfl((int)cb, e ? lane - 1 : lane), dn = (uint32_t)__shfl((int)cb, e < 31 ? lane + 1 : lane);
+        const uint32_t up = (uint32_t)__shfl((int)cb, e ? lane - 1 : lane), dn = (uint32_t)__shfl((int)cb, e < TW_G - 1 ? lane + 1 : lane);
         const uint32_t cb_prev = e == 0 ? cb_carry : up;
         const uint32_t geom = (uint32_t)(Kk >> tg.cb_bits), first = geom & 127u, nev = valid ? ((geom >> 7) & 127u) + 1u : 0u, end = first + nev;
         const uint64_t fld = (Kk >> (tg.cb_bits + 14)) & tg.src_mask;
         const uint64_t addr = evb + (fld << 8);                           // the entry's 256-byte block
         const bool rs = i == 0 || cb_prev != cb;
-        const bool nd = i + 1 == n || (e < 31 && dn != cb);
+        const bool nd = i + 1 == n || (e < TW_G - 1 && dn != cb);
         w.lo = (uint32_t)addr; w.hi = (uint32_t)(addr >> 32);
         const uint32_t kv = (uint32_t)(Kk >> 32) & (TG_RV_FWD | TG_RV_SEGFIRST);
         pre.ctv = reinterpret_cast<const uint32_t*>(a.celltype_of)[(cb < (uint32_t)a.n_cb ? cb : 0u) >> 2];
@@ -1565,32 +1573,33 @@ __device__ __forceinline__ void tw_range(const CountArgs& a, const TmArgs& tm, c
         uint32_t f0 = (first + 1u) >> 1, e0 = (end + 1u) >> 1, f1 = first >> 1, e1 = end >> 1;
         if (f0 >= e0) { f0 = 63u; e0 = 1u; }
         if (f1 >= e1) { f1 = 63u; e1 = 1u; }
-        pre.rng = f0 | (((64u - e0) & 63u) << 8) | (f1 << 16) | (((64u - e1) & 63u) << 24);
-        cb_last = cb_carry = rl(cb, 31);
+        pre.rng = f0 | (((64u - e0) & 63u) << 6) | (f1 << 13) | (((64u - e1) & 63u) << 21);      // (tw_add: between the meta word's decision bits)
+        cb_last = cb_carry = rl(cb, TW_G - 1);
     };
     auto finish_meta = [&](const TwPre& pre, uint32_t cb_of_last, uint32_t cb_after) -> uint32_t {
         if (!(pre.bits & 1u)) return TMM_SKIP;
         uint32_t cls = 2;
         if (pre.bits & 2u) { const uint32_t ct = (pre.ctv >> (((pre.bits >> 26) & 3u) * 8u)) & 0xffu; if (ct < (uint32_t)a.n_ct && (ct >> 1) == (uint32_t)(tm.ct_base >> 1)) cls = ct & 1u; }
-        if (cls < 2 && lane < 32) { stat.ev += (pre.bits >> 16) & 0xffu; stat.sg += (pre.bits >> 24) & 1u; ++stat.ne; }
-        const bool nd = (pre.bits & 8u) != 0 || (e == 31 && cb_after != cb_of_last);
+        if (cls < 2 && lane < TW_G) { stat.ev += (pre.bits >> 16) & 0xffu; stat.sg += (pre.bits >> 24) & 1u; ++stat.ne; }
+        const bool nd = (pre.bits & 8u) != 0 || (e == TW_G - 1 && cb_after != cb_of_last);
         const bool single = (pre.bits & 16u) != 0 && nd;
-        uint32_t M = cls < 2 ? (cls ? (TMM_CT10 | TMM_CT12) : 0u) | ((pre.bits & 4u) ? TMM_FWD : 0u) | (single ? TMM_SINGLE : 0u) : TMM_SKIP;
+        uint32_t M = cls < 2 ? (cls ? TMM_CT12 : 0u) | ((pre.bits & 4u) ? TMM_FWD : 0u) | (single ? TMM_SINGLE : 0u) | pre.rng : TMM_SKIP;
         if (pre.bits & 16u) M |= TMM_RS;
         return M;
     };
     uint32_t open_in = 0;
-    auto verdicts = [&](uint32_t M) -> uint32_t {                           // (tm_walk_range's, over the group's 32 entries; both halves of the wave come to the same)
+    auto verdicts = [&](uint32_t M) -> uint32_t {                           // (td_range64's / tm_walk_range's, over the group's entries)
         const bool there = !(M & TMM_SKIP), multi = there && !(M & TMM_SINGLE), rs = (M & TMM_RS) != 0;
-        const uint32_t A = (uint32_t)__ballot(lane < 32 && multi), R = (uint32_t)__ballot(lane < 32 && rs);
-        const uint32_t below = (1u << e) - 1u;
-        const uint32_t rb = R & below;
-        const uint32_t seg = rb ? below & ~((1u << (31 - __clz(rb))) - 1u) : below;
-        const bool ob = (A & seg) != 0u || (!rb && open_in);
+        const unsigned long long gm = TW_G == 64 ? ~0ull : 0xffffffffull;
+        const unsigned long long A = __ballot(multi) & gm, R = __ballot(rs) & gm;
+        const unsigned long long below = (1ull << e) - 1ull;
+        const unsigned long long rb = R & below;
+        const unsigned long long seg = rb ? below & ~((1ull << (63 - __clzll((long long)rb))) - 1ull) : below;
+        const bool ob = (A & seg) != 0ull || (!rb && open_in);
         if (rs && ob) M |= TMM_CLOSE;
         if (multi && (rs || !ob)) M |= TMM_FIRST;
-        const uint32_t segl = R ? ~((1u << (31 - __clz(R))) - 1u) : 0xffffffffu;
-        open_in = ((A & segl) != 0u || (!R && open_in)) ? 1u : 0u;
+        const unsigned long long segl = R ? ~((1ull << (63 - __clzll((long long)R))) - 1ull) : ~0ull;
+        open_in = ((A & segl & gm) != 0ull || (!R && open_in)) ? 1u : 0u;
         return M;
     };
     auto issue_block = [&](const TdW& w, int q, uint32_t (&E)[TD_Q]) {      // (td_range64's issue_line with four bytes a lane)
@@ -1607,17 +1616,16 @@ __device__ __forceinline__ void tw_range(const CountArgs& a, const TmArgs& tm, c
                 E[u0 + u] = *(const __attribute__((address_space(1))) uint32_t*)((const __attribute__((address_space(1))) char*)(uintptr_t)base[u] + (uint64_t)o);
         }
     };
-    auto consume = [&](const uint32_t (&E)[TD_Q], int q, uint32_t M, uint32_t Rg) {
+    auto consume = [&](const uint32_t (&E)[TD_Q], int q, uint32_t M) {
 #pragma unroll
-        for (int u = 0; u < TD_Q; ++u) tw_add(st0, st1, rl(M, q * TD_Q + u), rl(Rg, q * TD_Q + u), E[u], thr, pkl0, pkl1, one);
+        for (int u = 0; u < TD_Q; ++u) tw_add(st0, st1, rl(M, q * TD_Q + u), E[u], thr, pkl0, pkl1, one);
     };
-    static_assert(TD_Q == 16, "a group of 32 entries is two batches");
     auto fence = []() { asm volatile("" ::: "memory"); };
     uint32_t EA[TD_Q], EB[TD_Q];
     TdW wc, wn; TwPre pre;
     words(0, K, wc, pre);
     fence();
-    K = load_keys(i0 + 32u);
+    K = load_keys(i0 + (uint32_t)TW_G);
     fence();
     issue_block(wc, 0, EA);
     fence();
@@ -1625,13 +1633,16 @@ __device__ __forceinline__ void tw_range(const CountArgs& a, const TmArgs& tm, c
     fence();
     for (int g = 0; g < ng; ++g) {
         const uint32_t cb_after = rl((uint32_t)K & cbm, 0);
-        const uint32_t Mc = verdicts(finish_meta(pre, cb_last, cb_after)), Rc = pre.rng;
+        const uint32_t Mc = verdicts(finish_meta(pre, cb_last, cb_after));
         words(g + 1, K, wn, pre);
         fence();
-        K = load_keys(i0 + 32u * (uint32_t)(g + 2));
+        K = load_keys(i0 + (uint32_t)TW_G * (uint32_t)(g + 2));
         fence();
-        consume(EA, 0, Mc, Rc); issue_block(wn, 0, EA);
-        consume(EB, 1, Mc, Rc); issue_block(wn, 1, EB);
+#pragma unroll
+        for (int sb = 0; sb < TW_NQ; sb += 2) {                // (td_range64's alternation of the two batches of registers)
+            consume(EA, sb, Mc); issue_block(sb + 2 < TW_NQ ? wc : wn, (sb + 2) % TW_NQ, EA);
+            consume(EB, sb + 1, Mc); issue_block(sb + 3 < TW_NQ ? wc : wn, (sb + 3) % TW_NQ, EB);
+        }
         wc = wn;
     }
     st0.nc += st0.mask & 0x10001u; st0.mask = 0;
@@ -1684,7 +1695,7 @@ __global__ __launch_bounds__(TMW_WAVES * 64) __attribute__((amdgpu_waves_per_eu(
         auto first_i = [&]() -> uint32_t { return (wv ? emid : e0) - base; };
         uint64_t K64 = 0, kb = 0;
         auto prefetch = [&]() {
-            const uint32_t i = first_i(), ie = i + (uint32_t)(lane & 31), ic = ie < tcnt ? ie : tcnt - 1u;
+            const uint32_t i = first_i(), ie = i + (uint32_t)(lane & (TW_G - 1)), ic = ie < tcnt ? ie : tcnt - 1u;
             K64 = __builtin_nontemporal_load(tg.key + off + ic); kb = __builtin_nontemporal_load(tg.key + off + (i ? i - 1u : 0u));
         };
         prefetch();
@@ -1741,7 +1752,7 @@ __global__ __launch_bounds__(TMW_WAVES * 64) __attribute__((amdgpu_waves_per_eu(
                     const uint32_t* pc = pl + v * 1024 + wv * 512;
                     uint32_t dp = 0;
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) dp += pc[(lane & 1) * 2048 + k * 64 + (lane >> 1) * 2 + 1] & 0xffffu;
+                    for (int k = 0; k < 8; ++k) dp += pc[(lane & 1) * 2048 + k * 64 + (lane >> 1) * 2 + 1] & 0x1fffu;
                     const TwCounters tot{pc, lane, dp - nc_sh[v][wv][lane]};
                     const uint32_t unit = c_w0 + (uint32_t)wv * (uint32_t)a.n_ct + (uint32_t)ct;
                     if (c_nj == 1) {
