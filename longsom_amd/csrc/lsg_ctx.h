@@ -6,6 +6,7 @@
 #include <string>
 #include <vector>
 #include "../../include/longsom_hip.h"
+#include "../../include/longsom_synth.h"
 
 namespace lsg {
 

@@ -29,7 +29,7 @@
 #define LSG_HD static inline
 #endif
 
-#include "../../include/longsom_hip.h"   /* lsg_synth_model */
+#include "../../include/longsom_synth.h"   /* lsg_synth_model */
 
 typedef struct {
     int32_t gene, tid, t_off, t_len, e0, e1, cb, clip5, clip3;

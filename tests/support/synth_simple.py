@@ -6,7 +6,7 @@ kernel, the deep kernel's staged passes and its stream mode are all exercised.
 """
 import numpy as np
 
-from .engine import ReadRecords
+from longsom_amd.engine import ReadRecords
 
 
 def random_reference(rng, length, n_frac=0.01):

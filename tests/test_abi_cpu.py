@@ -1,5 +1,5 @@
-"""CPU: the C-ABI library loads and exports every symbol include/longsom_hip.h declares, and the ctypes binding declares the
-same set (no compute call: there is no GPU here)."""
+"""CPU: the C-ABI library loads and exports every symbol include/*.h declares (longsom_hip.h: the boundary; longsom_synth.h: measurement and
+test support), and the ctypes binding declares the same set (no compute call: there is no GPU here)."""
 import ctypes
 import os
 import re
@@ -7,16 +7,22 @@ import re
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HEADER = os.path.join(ROOT, "include", "longsom_hip.h")
+HEADERS = [os.path.join(ROOT, "include", h) for h in ("longsom_hip.h", "longsom_synth.h")]
 LIB = os.path.join(ROOT, "longsom_amd", "lib", "liblongsom_hip.so")
 IO_LIB = os.path.join(ROOT, "longsom_amd", "lib", "liblongsom_io.so")
 
 
 def declared_functions():
-    text = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    text = re.sub(r"/\*.*?\*/", "", "\n".join(open(h).read() for h in HEADERS), flags=re.S)
     names = re.findall(r"^\s*(?:const\s+char\s*\*|int|void|int64_t)\s+(lsg_[a-z0-9_]+)\s*\(", text, flags=re.M)
     assert len(names) >= 25
     return sorted(set(names))
+
+
+def test_the_boundary_header_declares_nothing_synthetic():
+    """what a rule's script binds (include/longsom_hip.h) has no generator and no read-back of resident arrays in it"""
+    text = re.sub(r"/\*.*?\*/", "", open(HEADERS[0]).read(), flags=re.S)
+    assert "lsg_synth" not in text and "lsg_copy_reads_to_host" not in text
 
 
 def test_header_symbols_are_exported():

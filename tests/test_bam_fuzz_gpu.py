@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from longsom_amd import bamwrite
+from tests.support import bamwrite
 from oracle import loader
 from tests.test_ingest_gpu import both_ways
 

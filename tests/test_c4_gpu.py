@@ -8,7 +8,8 @@ import time
 import numpy as np
 import pytest
 
-from longsom_amd import possets, synth
+from longsom_amd import synth
+from tests.support import possets
 
 pytestmark = pytest.mark.gpu
 

@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 
 from longsom_amd._lib import CountParams
-from longsom_amd.synth_simple import random_records, random_reference
+from tests.support.synth_simple import random_records, random_reference
 
 pytestmark = pytest.mark.gpu
 

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from longsom_amd import hostio, pipeline, synth
-from longsom_amd.synth_simple import random_records, random_reference
+from tests.support.synth_simple import random_records, random_reference
 
 pytestmark = pytest.mark.gpu
 

@@ -8,7 +8,7 @@ import pytest
 
 from longsom_amd import synth
 from longsom_amd._lib import CountParams
-from longsom_amd.synth_simple import random_records, random_reference
+from tests.support.synth_simple import random_records, random_reference
 from tests.test_count_gpu import make_case
 from tests.test_fuzz_gpu import draw
 from tests.util import phased_records

@@ -9,7 +9,7 @@ from tests.util import neg_zero
 
 from longsom_amd import tsvio
 from longsom_amd._lib import CallParams, CountParams
-from longsom_amd.synth_simple import random_records, random_reference
+from tests.support.synth_simple import random_records, random_reference
 from tests.test_count_gpu import run_both
 
 pytestmark = pytest.mark.gpu

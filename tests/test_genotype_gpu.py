@@ -12,7 +12,7 @@ import pytest
 
 from longsom_amd import hostio, reanno, synth
 from longsom_amd._lib import GenotypeParams
-from longsom_amd.synth_simple import random_records
+from tests.support.synth_simple import random_records
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -8,7 +8,8 @@ import os
 import numpy as np
 import pytest
 
-from longsom_amd import bamwrite, hostio
+from longsom_amd import hostio
+from tests.support import bamwrite
 from longsom_amd._lib import CountParams
 from oracle import loader
 from tests import kat_pileup_cases as K

@@ -13,7 +13,8 @@ import os
 import numpy as np
 import pytest
 
-from longsom_amd import bamwrite, hostio, tsvio
+from longsom_amd import hostio, tsvio
+from tests.support import bamwrite
 from longsom_amd._lib import CountParams
 from oracle import loader
 from tests import kat_pileup_cases as K

@@ -61,7 +61,7 @@ print("split totals", tot_rows, tot_cols, tot_sites, "match" if (tot_rows == lis
 # tests, BaseCellCalling.step2.py:142-158).  Queries and hits stay on the device; the probe is timed with CUDA events on the engine's stream.
 import json
 import numpy as np
-from longsom_amd import possets
+from tests.support import possets
 eng.set_region()
 rows, cols = eng.pileup_count(); ns, nc = eng.call_step1()
 n_q = eng.export_calls(1)

@@ -27,7 +27,8 @@ OUT = os.path.join(ROOT, "tests", "golden")
 
 import minipysam  # noqa: E402
 import make_pileup_goldens as M  # noqa: E402
-from longsom_amd import bamwrite, tsvio  # noqa: E402
+from longsom_amd import tsvio  # noqa: E402
+from tests.support import bamwrite  # noqa: E402
 
 
 def main():

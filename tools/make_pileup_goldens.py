@@ -50,7 +50,7 @@ REF = "/root/reference/workflow/scripts"
 OUT = os.path.join(ROOT, "tests", "golden")
 
 import minipysam  # noqa: E402
-from longsom_amd import bamwrite  # noqa: E402
+from tests.support import bamwrite  # noqa: E402
 
 REAL_PYSAM = False          # --check-with-real-pysam: the reference's imports resolve to the installed pysam / pybedtools
 from tests import kat_pileup_cases as K  # noqa: E402

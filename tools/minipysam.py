@@ -247,7 +247,7 @@ class AlignmentFile:
 
     def close(self):
         if self.mode.startswith("w") and self._out is not None:
-            from longsom_amd.bamwrite import _bgzf_block
+            from tests.support.bamwrite import _bgzf_block
             blob = self._header_bytes + b"".join(struct.pack("<I", len(r)) + r for r in self._out)
             with open(self.path, "wb") as f:
                 for i in range(0, len(blob), 0xFF00):
