@@ -1003,6 +1003,15 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
         // to keep no store (should it build one after all, blk_tiles() runs then)
         if (!may_skip_store) { if (int rc = blk_tiles(bs)) return rc; }
     }
+    // The plan's tile-level half (units, jobs and slabs per bin and their totals: it reads the capacities only) on the copy stream NOW, beside
+    // the scatter - it ends in a host round trip that used to wait for the shallow bins' sort on that stream (0.25 ms of nothing between the
+    // sort and the count for a rank's eighth of a sample) - whenever the load is to make its count
+    bool tiles_planned = false;
+    if (c->cal_enabled && c->n_ct >= 1 && c->n_ct <= 2 && c->n_cb > 0 && c->copy_stream && !getenv("LSG_NO_FUSED_LOAD") && !getenv("LSG_LATE_PLAN")) {
+        if (int rc = plan_tiles(c, c->copy_stream)) return rc;
+        plan_finish_tiles(c);
+        tiles_planned = true;
+    }
     // ---- 3. every tile's entries by barcode
     if (n_netile) {
         // (begin / end of the deep tiles' sort, then - split_sort - of the shallow tiles' sort: four arrays of n_netile + 1 in the two buffers)
@@ -1086,9 +1095,11 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
     // wait for the copy stream only), its job-level half behind the sort - the jobs are cut at run starts read from the sorted keys
     auto fused_plan = [&]() -> int {
         stage("scatter + sort + block tables");
-        int rc = plan_tiles(c, c->copy_stream);
-        if (rc) return rc;
-        plan_finish_tiles(c);
+        int rc = 0;
+        if (!tiles_planned) {
+            if ((rc = plan_tiles(c, c->copy_stream))) return rc;
+            plan_finish_tiles(c);
+        }
         c->tm_np = np; c->tm_nblk = nblk;
         if ((rc = plan_jobs(c, false, key_b.as<uint64_t>(), bits))) return rc;
         stage("plan");
@@ -1161,7 +1172,7 @@ int build_store(lsg_ctx* c, const uint16_t* events, int64_t n_events, const int6
     int plan_rc = 0;
     if (plan_early) {       // beside the gather, on the copy stream: a dozen small kernels and two host round trips that the first count would otherwise pay
         LSG_HIP(hipStreamWaitEvent(c->copy_stream, c->ev_copy, 0));
-        plan_rc = plan_tiles(c, c->copy_stream);
+        plan_rc = tiles_planned ? 0 : plan_tiles(c, c->copy_stream);
         if (!plan_rc) {        // ... and its job-level half right behind the gather: the load's last synchronisation is the plan's too
             c->tm_np = np; c->tm_nblk = nblk;
             plan_rc = plan_jobs(c, false);
