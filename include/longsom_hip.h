@@ -321,6 +321,30 @@ int lsg_fetch_calls(lsg_ctx* ctx, lsg_call* out, int64_t capacity, int32_t candi
  * NULL to only count; *n_out receives the number of selected rows. */
 int lsg_export_calls(lsg_ctx* ctx, int32_t kind, void* dst_device, int64_t capacity, int64_t* n_out);
 
+/* ---- the tables' text, printed on the device -------------------------------------------------------
+ * The rows of the reference's three big tables, byte for byte what its writers print:
+ *   LSG_TABLE_COUNTS + c  <sample>.<cell type c>.tsv rows       BaseCellCounter.py:300-308 (one row per count row of cell type c)
+ *   LSG_TABLE_MERGED      BaseCellCounts.AllCellTypes.tsv rows  MergeBaseCellCounts.py:59-84,116-204 (outer join, "NA" for an absent cell type)
+ *   LSG_TABLE_STEP1       calling.step1.tsv rows                BaseCellCalling.step1.py:430-476 (one row per merged site)
+ *   LSG_TABLE_STEP1_KEPT  the rows of that table step 2's awk filter keeps (ALT != "." and FILTER != ".", BaseCellCalling.step2.py:23)
+ * Rows only (the header lines are the caller's), in the reference's order: contigs in Python string order, positions ascending.
+ * At 24 M sites these are 17 GB of text: a kernel prints them from the count rows and call records where they lie (two passes:
+ * lengths, then bytes), the host only moves bytes.  The merged and step-1 tables need lsg_call_step1 (its merged site list). */
+enum lsg_table { LSG_TABLE_COUNTS = 0, LSG_TABLE_MERGED = LSG_MAX_CELLTYPES, LSG_TABLE_STEP1, LSG_TABLE_STEP1_KEPT, LSG_TABLE_SLOTS };
+/* Names the rows print: contig_names / celltype_names are '\n'-joined, in lsg_set_contigs / cell-type index order. */
+int lsg_set_table_names(lsg_ctx* ctx, int32_t n_contigs, const char* contig_names, int32_t n_celltypes, const char* celltype_names);
+/* Prints one table into a device buffer the handle keeps for it (until lsg_free_table or the next format of the same table);
+ * *n_bytes = size of the text.  The text is a snapshot: later counts and calls do not change it. */
+int lsg_format_table(lsg_ctx* ctx, int32_t table, int64_t* n_bytes);
+/* The formatted text into host memory (capacity >= its size). */
+int lsg_copy_table(lsg_ctx* ctx, int32_t table, char* dst_host, int64_t capacity);
+/* Appends the formatted text to the file at `path` (created if absent): device -> pinned staging -> pwrite, pipelined on a stream of
+ * its own.  Only reads the table's buffer: may run on another host thread beside any other call on the handle except
+ * lsg_format_table / lsg_free_table of the same table and lsg_destroy. */
+int lsg_append_table(lsg_ctx* ctx, int32_t table, const char* path);
+/* Frees one table's text (table < 0: every table's, and the flat row copies they were printed from). */
+int lsg_free_table(lsg_ctx* ctx, int32_t table);
+
 /* Position sets (RNA-editing / PoN_SR / PoN_LR; build_dict, BaseCellCalling.step2.py:197-221):
  * sorted unique keys (tid<<32)|pos1 resident in HBM; kind in [0,3). */
 int lsg_load_posset(lsg_ctx* ctx, int32_t kind, const int64_t* keys, int64_t n, int32_t on_device);

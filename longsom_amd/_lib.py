@@ -150,6 +150,11 @@ SIGNATURES = {
     "lsg_call_step1": (C.c_int, [C.c_void_p, C.POINTER(CallParams), C.c_void_p, C.c_void_p]),
     "lsg_fetch_calls": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
     "lsg_export_calls": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
+    "lsg_set_table_names": (C.c_int, [C.c_void_p, C.c_int32, C.c_char_p, C.c_int32, C.c_char_p]),
+    "lsg_format_table": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "lsg_copy_table": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]),
+    "lsg_append_table": (C.c_int, [C.c_void_p, C.c_int32, C.c_char_p]),
+    "lsg_free_table": (C.c_int, [C.c_void_p, C.c_int32]),
     "lsg_load_posset": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int32]),
     "lsg_probe_posset": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32]),
     "lsg_genotype_cells": (C.c_int, [C.c_void_p, C.POINTER(GenotypeParams), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),

@@ -16,30 +16,13 @@
 // Device storage is compact (48 B per site + 56 B per (candidate site, cell type)); lsg_fetch_calls /
 // lsg_export_calls expand it into the C-ABI's lsg_call records.
 #include "lsg_ctx.h"
+#include "call_rec.h"
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
 #include <hipcub/hipcub.hpp>
 
 namespace lsg {
-
-struct SiteRec {                      // every merged site
-    int64_t key;
-    uint8_t ref, present, considered, has_cand;
-    uint32_t site_filter;
-    int32_t sum_alts_bc, sum_dp, sum_alts_cc, sum_nc;
-    int16_t noise_p_bc, noise_p_cc;
-    uint8_t cell_types_min, pad[3];
-    uint32_t cand;                    // index of the candidate detail block
-    uint32_t pad2;
-};
-static_assert(sizeof(SiteRec) == 48, "SiteRec layout");
-struct CandCt {                       // one per (candidate site, cell type)
-    uint8_t n_alt, ct_filter, alt[LSG_CALL_MAX_ALT], pad[2];
-    uint32_t alt_bc[LSG_CALL_MAX_ALT], alt_cc[LSG_CALL_MAX_ALT];
-    int16_t p_bc[LSG_CALL_MAX_ALT], p_cc[LSG_CALL_MAX_ALT];
-};
-static_assert(sizeof(CandCt) == 56, "CandCt layout");
 
 // counter words of the call stage; the ones the kernels allocate from while they run sit on cache lines of their own (atomics on one
 // line serialise at ~90 per microsecond whichever of its words they name)

@@ -66,6 +66,7 @@ int install_counts(lsg_ctx* c, int32_t n_ct, const int64_t* const* keys, const u
     c->n_columns = 0;
     c->last_params = lsg_count_params{};
     c->counted = true;
+    ++c->count_serial;
     c->called = false;
     return 0;
 }

@@ -16,6 +16,11 @@ int run_call(lsg_ctx* c, const lsg_call_params* p);
 int run_fetch_calls(lsg_ctx* c, lsg_call* out, int64_t capacity, int candidates_only, int64_t* n_out);
 int run_select_calls(lsg_ctx* c, int kind, lsg_call* dst_device, int64_t capacity, int64_t* n_out);
 int run_probe(lsg_ctx* c, int kind, const int64_t* keys, int64_t n, uint8_t* hits, int on_device);
+int run_set_table_names(lsg_ctx* c, int32_t n_contigs, const char* contig_names, int32_t n_ct, const char* ct_names);
+int run_format_table(lsg_ctx* c, int32_t table, int64_t* n_bytes);
+int run_copy_table(lsg_ctx* c, int32_t table, char* dst, int64_t capacity);
+int run_append_table(lsg_ctx* c, int32_t table, const char* path);
+int run_free_table(lsg_ctx* c, int32_t table);
 int run_genotype(lsg_ctx* c, const lsg_genotype_params* p, int64_t n_sites, const int64_t* site_keys, const uint8_t* alt_sym,
                  uint32_t* dp, uint32_t* alt, int on_device, int32_t max_depth, int64_t n_groups, const int64_t* group_off);
 int run_sf4(lsg_ctx* c, int64_t items, const uint32_t* k, const uint32_t* n, double al, double be, int32_t* out, double* raw);
@@ -89,6 +94,8 @@ void lsg_destroy(lsg_ctx* c) {
     for (auto& s : c->posset) s.keys.release();
     for (auto& b : c->syn) b.release();
     for (auto& b : c->gen) b.release();
+    (void)run_free_table(c, -1);
+    c->tab_names.release();
     for (auto& b : c->ws) b.release();
     for (auto& b : c->tm) b.release();
     for (auto& b : c->bt) b.release();
@@ -426,6 +433,31 @@ int lsg_export_calls(lsg_ctx* c, int32_t kind, void* dst_device, int64_t capacit
     if (!c || kind < 0 || kind > 2) { set_error("lsg_export_calls: bad arguments"); return -2; }
     LSG_HIP(hipSetDevice(c->device));
     return run_select_calls(c, kind, reinterpret_cast<lsg_call*>(dst_device), capacity, n_out);
+}
+
+int lsg_set_table_names(lsg_ctx* c, int32_t n_contigs, const char* contig_names, int32_t n_celltypes, const char* celltype_names) {
+    if (!c || n_contigs < 0 || !contig_names || !celltype_names) { set_error("lsg_set_table_names: bad arguments"); return -2; }
+    LSG_HIP(hipSetDevice(c->device));
+    return run_set_table_names(c, n_contigs, contig_names, n_celltypes, celltype_names);
+}
+int lsg_format_table(lsg_ctx* c, int32_t table, int64_t* n_bytes) {
+    if (!c) { set_error("lsg_format_table: bad arguments"); return -2; }
+    LSG_HIP(hipSetDevice(c->device));
+    return run_format_table(c, table, n_bytes);
+}
+int lsg_copy_table(lsg_ctx* c, int32_t table, char* dst_host, int64_t capacity) {
+    if (!c || (!dst_host && capacity > 0) || capacity < 0) { set_error("lsg_copy_table: bad arguments"); return -2; }
+    LSG_HIP(hipSetDevice(c->device));
+    return run_copy_table(c, table, dst_host, capacity);
+}
+int lsg_append_table(lsg_ctx* c, int32_t table, const char* path) {
+    if (!c || !path || !*path) { set_error("lsg_append_table: bad arguments"); return -2; }
+    return run_append_table(c, table, path);
+}
+int lsg_free_table(lsg_ctx* c, int32_t table) {
+    if (!c) { set_error("lsg_free_table: bad arguments"); return -2; }
+    LSG_HIP(hipSetDevice(c->device));
+    return run_free_table(c, table);
 }
 
 int lsg_load_posset(lsg_ctx* c, int32_t kind, const int64_t* keys, int64_t n, int32_t on_device) {

@@ -201,6 +201,14 @@ struct lsg_ctx {
     uint32_t call_tasks_per_site = 1;     // call.hip: how the tail tasks' buffers are sized (grown on demand)
     bool called = false;
 
+    // the tables' text (tables.hip): flat copies of the count rows, the names the rows print, one device buffer per table
+    lsg::DevBuf tab_keys[LSG_MAX_CELLTYPES], tab_refs[LSG_MAX_CELLTYPES], tab_rows[LSG_MAX_CELLTYPES], tab_names, tab_scratch;
+    uint64_t tab_rows_serial[LSG_MAX_CELLTYPES] = {0, 0, 0, 0};      // count_serial the flat copy was made of (0 = none)
+    uint64_t count_serial = 0;            // bumped by every count / lsg_load_counts
+    lsg::DevBuf tab_text[LSG_TABLE_SLOTS];
+    int64_t tab_bytes[LSG_TABLE_SLOTS] = {-1, -1, -1, -1, -1, -1, -1};      // -1: not formatted
+    int32_t tab_n_contigs = 0, tab_n_ct = 0; uint32_t tab_ct_off_at = 0, tab_order_at = 0, tab_ct_txt_at = 0, tab_contig_txt_at = 0;
+
     lsg::PosSet posset[3];
     lsg::DevBuf syn[12];                  // synthetic-model tables + scan scratch (synth.hip)
     lsg::DevBuf gen[10];                  // the arrays lsg_synth_generate last produced

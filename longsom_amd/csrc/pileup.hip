@@ -2161,6 +2161,7 @@ static int count_finish(lsg_ctx* c, const lsg_count_params* p, CountLaunch& L) {
     c->last_params = *p;
     c->counted = true;
     c->called = false;
+    ++c->count_serial;
     return 0;
 }
 
@@ -2284,11 +2285,10 @@ __global__ void k_export_rows(CountArgs a, int ct, const uint32_t* rowoff, int64
         counts[dst * LSG_ROW_WORDS + 34 + sy] = counts[dst * LSG_ROW_WORDS + 10 + sy] - counts[dst * LSG_ROW_WORDS + 26 + sy];
 }
 
-int run_fetch_counts(lsg_ctx* c, int ct, int64_t* keys, uint8_t* ref, uint32_t* counts, int64_t capacity) {
-    if (!c->counted) { set_error("lsg_fetch_counts: call lsg_pileup_count first"); return -2; }
-    if (ct < 0 || ct >= c->n_ct) { set_error("lsg_fetch_counts: bad cell type %d", ct); return -2; }
+// The count rows of one cell type as flat device arrays (keys (tid << 32) | pos0, reference bases, LSG_ROW_WORDS counters per row), in
+// genomic order: what lsg_fetch_counts copies to the host and tables.hip prints.
+int run_export_rows(lsg_ctx* c, int ct, DevBuf& dk, DevBuf& dr, DevBuf& dc) {
     int64_t n = c->n_rows[ct];
-    if (capacity < n) { set_error("lsg_fetch_counts: capacity %lld < %lld rows", (long long)capacity, (long long)n); return -2; }
     if (n == 0) return 0;
     hipStream_t st = c->stream;
     CountArgs a{};
@@ -2299,11 +2299,23 @@ int run_fetch_counts(lsg_ctx* c, int ct, int64_t* keys, uint8_t* ref, uint32_t* 
     uint32_t* off = cnt + (n_ne + 2);
     hipLaunchKernelGGL(k_unit_rowcount, dim3((n_ne + 256) / 256), dim3(256), 0, st, a.ne_units, a.ne_mask, n_ne, c->n_ct, ct, cnt);
     SCAN_U32(cnt, off, n_ne + 1);
-    DevBuf &dk = c->ws[WS_EXPORT_K], &dr = c->ws[WS_EXPORT_R], &dc = c->ws[WS_EXPORT_C];
     if (dk.reserve((size_t)n * 8) || dr.reserve((size_t)n) || dc.reserve((size_t)n * LSG_ROW_WORDS * 4)) return -1;
     uint64_t threads = (uint64_t)n_ne * 64;
     hipLaunchKernelGGL(k_export_rows, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, a, ct, off,
                        dk.as<int64_t>(), dr.as<uint8_t>(), dc.as<uint32_t>());
+    LSG_HIP(hipGetLastError());
+    return 0;
+}
+
+int run_fetch_counts(lsg_ctx* c, int ct, int64_t* keys, uint8_t* ref, uint32_t* counts, int64_t capacity) {
+    if (!c->counted) { set_error("lsg_fetch_counts: call lsg_pileup_count first"); return -2; }
+    if (ct < 0 || ct >= c->n_ct) { set_error("lsg_fetch_counts: bad cell type %d", ct); return -2; }
+    int64_t n = c->n_rows[ct];
+    if (capacity < n) { set_error("lsg_fetch_counts: capacity %lld < %lld rows", (long long)capacity, (long long)n); return -2; }
+    if (n == 0) return 0;
+    hipStream_t st = c->stream;
+    DevBuf &dk = c->ws[WS_EXPORT_K], &dr = c->ws[WS_EXPORT_R], &dc = c->ws[WS_EXPORT_C];
+    if (int rc = run_export_rows(c, ct, dk, dr, dc)) return rc;
     LSG_HIP(hipMemcpyAsync(keys, dk.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
     LSG_HIP(hipMemcpyAsync(ref, dr.p, (size_t)n, hipMemcpyDeviceToHost, st));
     LSG_HIP(hipMemcpyAsync(counts, dc.p, (size_t)n * LSG_ROW_WORDS * 4, hipMemcpyDeviceToHost, st));

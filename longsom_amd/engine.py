@@ -407,6 +407,44 @@ class Engine:
                                               int(capacity), C.byref(n_out)), "lsg_export_calls")
         return int(n_out.value)
 
+    # ---- the tables' text, printed on the device (include/longsom_hip.h: enum lsg_table) ----
+    TABLE_COUNTS, TABLE_MERGED, TABLE_STEP1, TABLE_STEP1_KEPT = 0, 4, 5, 6
+
+    def set_table_names(self, contig_names, celltype_names) -> None:
+        """Names the rows print (contigs in set_contigs order, cell types in index order)."""
+        _lib.check(self._lib.lsg_set_table_names(self._h, len(contig_names), "\n".join(contig_names).encode(), len(celltype_names),
+                                                 "\n".join(celltype_names).encode()), "lsg_set_table_names")
+
+    def format_table(self, table: int) -> int:
+        """Prints the rows of one table (TABLE_COUNTS + cell type, TABLE_MERGED, TABLE_STEP1, TABLE_STEP1_KEPT) into a device buffer the
+        engine keeps; returns the size of the text."""
+        n = C.c_int64(0)
+        _lib.check(self._lib.lsg_format_table(self._h, int(table), C.byref(n)), "lsg_format_table")
+        return int(n.value)
+
+    def table_bytes(self, table: int, n_bytes: int, prefix: bytes = b"") -> bytes:
+        """prefix + the formatted text as one bytes object."""
+        api = C.pythonapi
+        api.PyBytes_FromStringAndSize.restype = C.py_object
+        api.PyBytes_FromStringAndSize.argtypes = [C.c_void_p, C.c_ssize_t]
+        api.PyBytes_AsString.restype = C.c_void_p
+        api.PyBytes_AsString.argtypes = [C.py_object]
+        out = api.PyBytes_FromStringAndSize(None, len(prefix) + n_bytes)      # (uninitialised: filled below before anybody else sees it)
+        at = api.PyBytes_AsString(out)
+        if prefix:
+            C.memmove(at, prefix, len(prefix))
+        _lib.check(self._lib.lsg_copy_table(self._h, int(table), C.c_void_p(at + len(prefix)), n_bytes), "lsg_copy_table")
+        return out
+
+    def append_table(self, table: int, path: str) -> None:
+        """Appends the formatted text to `path`; may run on a thread of its own beside other calls (not beside format_table / free_table
+        of the same table)."""
+        import os
+        _lib.check(self._lib.lsg_append_table(self._h, int(table), os.fsencode(path)), "lsg_append_table")
+
+    def free_table(self, table: int = -1) -> None:
+        _lib.check(self._lib.lsg_free_table(self._h, int(table)), "lsg_free_table")
+
     def load_posset(self, kind: int, keys, on_device: bool = False, n: Optional[int] = None):
         if on_device:
             _lib.check(self._lib.lsg_load_posset(self._h, kind, C.c_void_p(int(keys)), int(n), 1), "lsg_load_posset")
