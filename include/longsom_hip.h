@@ -327,10 +327,14 @@ int lsg_export_calls(lsg_ctx* ctx, int32_t kind, void* dst_device, int64_t capac
  *   LSG_TABLE_MERGED      BaseCellCounts.AllCellTypes.tsv rows  MergeBaseCellCounts.py:59-84,116-204 (outer join, "NA" for an absent cell type)
  *   LSG_TABLE_STEP1       calling.step1.tsv rows                BaseCellCalling.step1.py:430-476 (one row per merged site)
  *   LSG_TABLE_STEP1_KEPT  the rows of that table step 2's awk filter keeps (ALT != "." and FILTER != ".", BaseCellCalling.step2.py:23)
+ *   LSG_TABLE_STEP2       calling.step2.tsv rows when step 2 has no gnomAD source and --min_distance 0 (LongSom's setting): the kept rows,
+ *                         FILTER tagged "RNA_editing_db" / "PoN_SR" / "PoN_LR" by the resident position sets (lsg_load_posset; GetExtraFilters,
+ *                         BaseCellCalling.step2.py:142-158; a tag replaces a bare "PASS"), "NA" cells empty (step2.py's pandas round trip)
+ *   LSG_TABLE_STEP3_ROWS  the rows of LSG_TABLE_STEP2 step 3 can keep (made by lsg_step2_summary, not by lsg_format_table)
  * Rows only (the header lines are the caller's), in the reference's order: contigs in Python string order, positions ascending.
  * At 24 M sites these are 17 GB of text: a kernel prints them from the count rows and call records where they lie (two passes:
  * lengths, then bytes), the host only moves bytes.  The merged and step-1 tables need lsg_call_step1 (its merged site list). */
-enum lsg_table { LSG_TABLE_COUNTS = 0, LSG_TABLE_MERGED = LSG_MAX_CELLTYPES, LSG_TABLE_STEP1, LSG_TABLE_STEP1_KEPT, LSG_TABLE_SLOTS };
+enum lsg_table { LSG_TABLE_COUNTS = 0, LSG_TABLE_MERGED = LSG_MAX_CELLTYPES, LSG_TABLE_STEP1, LSG_TABLE_STEP1_KEPT, LSG_TABLE_STEP2, LSG_TABLE_STEP3_ROWS, LSG_TABLE_SLOTS };
 /* Names the rows print: contig_names / celltype_names are '\n'-joined, in lsg_set_contigs / cell-type index order. */
 int lsg_set_table_names(lsg_ctx* ctx, int32_t n_contigs, const char* contig_names, int32_t n_celltypes, const char* celltype_names);
 /* Prints one table into a device buffer the handle keeps for it (until lsg_free_table or the next format of the same table);
@@ -342,6 +346,13 @@ int lsg_copy_table(lsg_ctx* ctx, int32_t table, char* dst_host, int64_t capacity
  * its own.  Only reads the table's buffer: may run on another host thread beside any other call on the handle except
  * lsg_format_table / lsg_free_table of the same table and lsg_destroy. */
 int lsg_append_table(lsg_ctx* ctx, int32_t table, const char* path);
+/* What BaseCellCalling.step3.py needs of the whole step-2 table before it parses anything, read off LSG_TABLE_STEP2's text on the device
+ * (directly after its lsg_format_table): kinds[c] = which kinds of cell column c of n_cols holds over ALL rows, as the bits 1 missing
+ * value, 2 integer, 4 float, 8 a number pandas would print differently, 16 anything else (pandas infers a column's dtype over the whole
+ * file: step3.py:41 reads it all; bits other than 16 mean nothing in a column that has 16); and, as table LSG_TABLE_STEP3_ROWS of
+ * *n_survivor_bytes bytes, the rows whose FILTER holds none of the patterns step 3 drops rows by (step3.py:49-52 for chrM rows, :60-84
+ * for the others) and whose Cell_types is not "Non-Cancer" - the only rows step 3 has to parse. */
+int lsg_step2_summary(lsg_ctx* ctx, int32_t n_cols, uint8_t* kinds, int64_t* n_survivor_bytes);
 /* Frees one table's text (table < 0: every table's, and the flat row copies they were printed from). */
 int lsg_free_table(lsg_ctx* ctx, int32_t table);
 

@@ -155,6 +155,7 @@ SIGNATURES = {
     "lsg_copy_table": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]),
     "lsg_append_table": (C.c_int, [C.c_void_p, C.c_int32, C.c_char_p]),
     "lsg_free_table": (C.c_int, [C.c_void_p, C.c_int32]),
+    "lsg_step2_summary": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "lsg_load_posset": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int32]),
     "lsg_probe_posset": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32]),
     "lsg_genotype_cells": (C.c_int, [C.c_void_p, C.POINTER(GenotypeParams), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),

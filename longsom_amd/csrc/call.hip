@@ -871,7 +871,7 @@ static int run_call_sized(lsg_ctx* c, const lsg_call_params* p, uint32_t tasks_p
     LSG_HIP(hipMemcpyAsync(c->h_pin, a.counters, CT_WORDS * 8, hipMemcpyDeviceToHost, st));
     LSG_HIP(hipStreamSynchronize(st));
     memcpy(cnt4, c->h_pin, CT_WORDS * 8);
-    if (getenv("LSG_TIMING")) fprintf(stderr, "[lsg] call: %u sites, light task slots %llu (+%llu of the first chunks), heavy %llu (+%llu), sites that waited for a tail %llu, PASS %llu\n", n_sites,
+    if (getenv("LSG_TIMING")) fprintf(stderr, "[lsg] call: %u sites in %llu tiles, light task slots %llu (+%llu of the first chunks), heavy %llu (+%llu), sites that waited for a tail %llu, PASS %llu\n", n_sites, cnt4[CT_HEADS],
                                       cnt4[CT_LIGHT], (unsigned long long)a.arena_waves * TASK_CHUNK, cnt4[CT_HEAVY], (unsigned long long)a.arena_waves * HEAVY_CHUNK, cnt4[CT_DEFER], cnt4[CT_PASS]);
     c->n_pass = (int64_t)cnt4[CT_PASS];
     const unsigned long long cand = cnt4[CT_NCAND];

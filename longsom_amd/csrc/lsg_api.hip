@@ -21,6 +21,7 @@ int run_format_table(lsg_ctx* c, int32_t table, int64_t* n_bytes);
 int run_copy_table(lsg_ctx* c, int32_t table, char* dst, int64_t capacity);
 int run_append_table(lsg_ctx* c, int32_t table, const char* path);
 int run_free_table(lsg_ctx* c, int32_t table);
+int run_step2_summary(lsg_ctx* c, int32_t n_cols, uint8_t* kinds, int64_t* n_survivor_bytes);
 int run_genotype(lsg_ctx* c, const lsg_genotype_params* p, int64_t n_sites, const int64_t* site_keys, const uint8_t* alt_sym,
                  uint32_t* dp, uint32_t* alt, int on_device, int32_t max_depth, int64_t n_groups, const int64_t* group_off);
 int run_sf4(lsg_ctx* c, int64_t items, const uint32_t* k, const uint32_t* n, double al, double be, int32_t* out, double* raw);
@@ -147,6 +148,7 @@ int lsg_set_contigs(lsg_ctx* c, int32_t n_contigs, const int64_t* lengths) {
     if (!c || n_contigs <= 0 || !lengths) { set_error("lsg_set_contigs: bad arguments"); return -2; }
     LSG_HIP(hipSetDevice(c->device));
     c->n_contigs = n_contigs;
+    c->tab_n_contigs = 0;                 // (the names the tables print belong to the contig table they were set for)
     c->contig_len.assign(lengths, lengths + n_contigs);
     c->tile_base.assign(n_contigs + 1, 0);
     uint64_t t = 0;
@@ -453,6 +455,11 @@ int lsg_copy_table(lsg_ctx* c, int32_t table, char* dst_host, int64_t capacity) 
 int lsg_append_table(lsg_ctx* c, int32_t table, const char* path) {
     if (!c || !path || !*path) { set_error("lsg_append_table: bad arguments"); return -2; }
     return run_append_table(c, table, path);
+}
+int lsg_step2_summary(lsg_ctx* c, int32_t n_cols, uint8_t* kinds, int64_t* n_survivor_bytes) {
+    if (!c || !kinds) { set_error("lsg_step2_summary: bad arguments"); return -2; }
+    LSG_HIP(hipSetDevice(c->device));
+    return run_step2_summary(c, n_cols, kinds, n_survivor_bytes);
 }
 int lsg_free_table(lsg_ctx* c, int32_t table) {
     if (!c) { set_error("lsg_free_table: bad arguments"); return -2; }

@@ -202,11 +202,12 @@ struct lsg_ctx {
     bool called = false;
 
     // the tables' text (tables.hip): flat copies of the count rows, the names the rows print, one device buffer per table
-    lsg::DevBuf tab_keys[LSG_MAX_CELLTYPES], tab_refs[LSG_MAX_CELLTYPES], tab_rows[LSG_MAX_CELLTYPES], tab_names, tab_scratch;
+    lsg::DevBuf tab_keys[LSG_MAX_CELLTYPES], tab_refs[LSG_MAX_CELLTYPES], tab_rows[LSG_MAX_CELLTYPES], tab_names, tab_scratch, tab_scratch2;
+    int32_t tab_scratch_table = -1; int64_t tab_scratch_rows = 0;      // whose rows' lengths and places tab_scratch holds
     uint64_t tab_rows_serial[LSG_MAX_CELLTYPES] = {0, 0, 0, 0};      // count_serial the flat copy was made of (0 = none)
     uint64_t count_serial = 0;            // bumped by every count / lsg_load_counts
     lsg::DevBuf tab_text[LSG_TABLE_SLOTS];
-    int64_t tab_bytes[LSG_TABLE_SLOTS] = {-1, -1, -1, -1, -1, -1, -1};      // -1: not formatted
+    int64_t tab_bytes[LSG_TABLE_SLOTS] = {-1, -1, -1, -1, -1, -1, -1, -1, -1};      // -1: not formatted
     int32_t tab_n_contigs = 0, tab_n_ct = 0; uint32_t tab_ct_off_at = 0, tab_order_at = 0, tab_ct_txt_at = 0, tab_contig_txt_at = 0;
 
     lsg::PosSet posset[3];

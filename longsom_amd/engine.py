@@ -408,7 +408,7 @@ class Engine:
         return int(n_out.value)
 
     # ---- the tables' text, printed on the device (include/longsom_hip.h: enum lsg_table) ----
-    TABLE_COUNTS, TABLE_MERGED, TABLE_STEP1, TABLE_STEP1_KEPT = 0, 4, 5, 6
+    TABLE_COUNTS, TABLE_MERGED, TABLE_STEP1, TABLE_STEP1_KEPT, TABLE_STEP2, TABLE_STEP3_ROWS = 0, 4, 5, 6, 7, 8
 
     def set_table_names(self, contig_names, celltype_names) -> None:
         """Names the rows print (contigs in set_contigs order, cell types in index order)."""
@@ -441,6 +441,14 @@ class Engine:
         of the same table)."""
         import os
         _lib.check(self._lib.lsg_append_table(self._h, int(table), os.fsencode(path)), "lsg_append_table")
+
+    def step2_summary(self, n_cols: int):
+        """After format_table(TABLE_STEP2): (kinds of cell per column over all its rows - the bits of tsvio.column_kinds -, size of the rows
+        step 3 can keep, which are table TABLE_STEP3_ROWS now)."""
+        kinds = np.zeros(int(n_cols), np.uint8)
+        n = C.c_int64(0)
+        _lib.check(self._lib.lsg_step2_summary(self._h, int(n_cols), _ptr(kinds), C.byref(n)), "lsg_step2_summary")
+        return kinds, int(n.value)
 
     def free_table(self, table: int = -1) -> None:
         _lib.check(self._lib.lsg_free_table(self._h, int(table)), "lsg_free_table")

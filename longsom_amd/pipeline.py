@@ -222,15 +222,17 @@ def chain_step1(res: Resident, celltype_of: np.ndarray, celltype_names: List[str
         calls = eng.fetch_calls(candidates_only=True)
         t["fetch"] = time.time() - t0
         return out, None, calls, t
-    import threading
-    per_ct: List = [None] * len(celltype_names)
-    arrived = [threading.Event() for _ in celltype_names]          # a cell type's count rows are on the host
-    failed: List[BaseException] = []                               # ... or will never be
     date = tsvio.file_date()
     for ct, name in enumerate(celltype_names):
         out.counts[name] = os.path.join(d["BaseCellCounter/" + sample_id], "%s.%s.tsv" % (sample_id, name))
     out.merged = os.path.join(d["MergeCounts"], sample_id + ".BaseCellCounts.AllCellTypes.tsv")
     out.step1 = os.path.join(d["BaseCellCalling"], sample_id + ".calling.step1.tsv")
+    if os.environ.get("LONGSOM_HOST_TABLES", "0") != "1":
+        return _device_tables(eng, out, contig_names, celltype_names, sample_id, params, date, background_tables, t, t0, (n_rows, n_cols, n_sites, n_cand))
+    import threading
+    per_ct: List = [None] * len(celltype_names)
+    arrived = [threading.Event() for _ in celltype_names]          # a cell type's count rows are on the host
+    failed: List[BaseException] = []                               # ... or will never be
 
     def count_tables():
         for ct, name in enumerate(celltype_names):
@@ -265,11 +267,8 @@ def chain_step1(res: Resident, celltype_of: np.ndarray, celltype_names: List[str
     calls = eng.fetch_calls()
     t["fetch"] = time.time() - t0
     if params.row_digests:
-        import xxhash
         t0 = time.time()
-        out.row_digests = {"rows": [int(x) for x in n_rows], "columns": int(n_cols), "merged_sites": int(n_sites), "candidate_rows": int(n_cand)}
-        for ct in range(len(celltype_names)):
-            out.row_digests["ct%d" % ct] = [xxhash.xxh64(np.ascontiguousarray(x).tobytes() if x.size < (1 << 20) else memoryview(np.ascontiguousarray(x)).cast("B")).hexdigest() for x in per_ct[ct]]
+        out.row_digests = _row_digests(eng, len(celltype_names), (n_rows, n_cols, n_sites, n_cand), per_ct)
         t["row_digests"] = time.time() - t0
     t0 = time.time()
     header = [l + "\n" for l in tsvio.merged_header(celltype_names, date).split("\n") if l.startswith("##")]
@@ -292,6 +291,60 @@ def chain_step1(res: Resident, celltype_of: np.ndarray, celltype_names: List[str
     return out, s1, calls, t
 
 
+def _row_digests(eng, n_ct: int, shape, per_ct=None) -> dict:
+    """SnvParams.row_digests: rows, columns and xxhash of (keys, reference bases, counters) per cell type, as tools/oracle_hashes.py writes them"""
+    import xxhash
+    n_rows, n_cols, n_sites, n_cand = shape
+    out = {"rows": [int(x) for x in n_rows], "columns": int(n_cols), "merged_sites": int(n_sites), "candidate_rows": int(n_cand)}
+    for ct in range(n_ct):
+        rows = per_ct[ct] if per_ct is not None else eng.fetch_counts(ct)
+        out["ct%d" % ct] = [xxhash.xxh64(np.ascontiguousarray(x).tobytes() if x.size < (1 << 20) else memoryview(np.ascontiguousarray(x)).cast("B")).hexdigest() for x in rows]
+    return out
+
+
+def _device_tables(eng, out: "SnvOutputs", contig_names, celltype_names, sample_id, params, date, background: bool, t, t0, shape):
+    """The tables of chain_step1 printed on the device (Engine.format_table: csrc/tables.hip, byte for byte the host writers' text) and
+    streamed into their files (Engine.append_table), one thread per file; the count rows never come to the host.  The rows step 2 keeps
+    come first - steps 2 and 3 wait for nothing else.  LONGSOM_HOST_TABLES=1 keeps the host writers (csrc/hostio/tsvwrite.cpp)."""
+    import threading
+    eng.set_table_names(contig_names, celltype_names)
+    header = [l + "\n" for l in tsvio.merged_header(celltype_names, date).split("\n") if l.startswith("##")]
+    head1 = tsvio.step1_header(header, celltype_names)
+    n = eng.format_table(eng.TABLE_STEP1_KEPT)
+    s1 = eng.table_bytes(eng.TABLE_STEP1_KEPT, n, prefix=head1.encode())
+    eng.free_table(eng.TABLE_STEP1_KEPT)
+    t["fetch"] = time.time() - t0                    # (what came to the host: the kept rows' text)
+    t0 = time.time()
+    files = [(ct, out.counts[name], tsvio.counts_header("%s.%s" % (sample_id, name), date)) for ct, name in enumerate(celltype_names)]
+    files += [(eng.TABLE_MERGED, out.merged, tsvio.merged_header(celltype_names, date)), (eng.TABLE_STEP1, out.step1, head1)]
+    sizes = {}
+    for table, path, head in files:
+        with open(path, "w") as f:
+            f.write(head)
+        sizes[table] = eng.format_table(table)
+    t["format_tables"] = time.time() - t0
+    t0 = time.time()
+
+    def stream(table, path):
+        t1 = time.time()
+        eng.append_table(table, path)
+        eng.free_table(table)
+        t["table_%d" % table] = time.time() - t1
+    if background:
+        for table, path, _ in files:                  # (the box's file system takes several files at once faster than one)
+            out.start_background(lambda table=table, path=path: stream(table, path))
+    else:
+        for table, path, _ in files:
+            stream(table, path)
+    t["write_tables"] = time.time() - t0
+    if params.row_digests:
+        t1 = time.time()
+        out.row_digests = _row_digests(eng, len(celltype_names), shape)
+        t["row_digests"] = time.time() - t1
+    calls = None if background else eng.fetch_calls()
+    return out, s1, calls, t
+
+
 def run_chain(res: Resident, celltype_of: np.ndarray, celltype_names: List[str], report: Dict[str, int], out_dir: str, sample_id: str,
               params: SnvParams, editing: Optional[str] = None, pon_sr: Optional[str] = None, pon_lr: Optional[str] = None,
               gnomad_af_json: Optional[str] = None, step3: bool = True) -> SnvOutputs:
@@ -300,6 +353,17 @@ def run_chain(res: Resident, celltype_of: np.ndarray, celltype_names: List[str],
     step 2, as pass 1 of the reference does (rules/CellTypeReannotation.smk has no step-3 rule: HCCV reads calling.step2.tsv)."""
     eng, contig_names = res.engine, res.contig_names
     out, s1, _, t = chain_step1(res, celltype_of, celltype_names, report, out_dir, sample_id, params, background_tables=True)
+    try:
+        return _chain_steps23(out, s1, t, eng, contig_names, out_dir, sample_id, params, editing, pon_sr, pon_lr, gnomad_af_json, step3)
+    except BaseException:
+        try:                                   # (the writers stream from the engine: nobody may close it under them)
+            out.wait_for_tables()
+        except BaseException:                  # noqa: BLE001 - the first error is the one to report
+            pass
+        raise
+
+
+def _chain_steps23(out, s1, t, eng, contig_names, out_dir, sample_id, params, editing, pon_sr, pon_lr, gnomad_af_json, step3):
     d = {"BaseCellCalling": os.path.join(out_dir, "BaseCellCalling")}
     t0 = time.time()
     keys = [calling.read_posset_keys(p, contig_names, params.reference_gz_compat) for p in (editing, pon_sr, pon_lr)]

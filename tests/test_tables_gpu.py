@@ -29,6 +29,29 @@ def host_tables(tmp, per_ct, calls, names, ct_names):
     return out
 
 
+def step2_on_device_equals_host(engine, names, ct_names, kept_rows: bytes, possets):
+    """table TABLE_STEP2 and lsg_step2_summary against calling._step2_scanned / tsvio.column_kinds / calling._step3_survivors over the text
+    of the kept rows the host holds"""
+    from longsom_amd import calling
+    head = tsvio.step1_header(["##fileDate=01/01/2000\n"], ct_names).encode()
+    want2 = calling._step2_scanned(head + kept_rows, engine, names, possets[0], possets[1], possets[2], 0)      # (loads the position sets)
+    assert want2 is not None
+    cols = head.decode().split("\n")[-2].split("\t")
+    hdr = b"".join(l + b"\n" for l in head.split(b"\n") if l.startswith(b"#"))
+    assert want2.startswith(hdr)
+    n = engine.format_table(engine.TABLE_STEP2)
+    got2 = engine.table_bytes(engine.TABLE_STEP2, n)
+    assert got2 == want2[len(hdr):], "step-2 rows"
+    kinds, n_surv = engine.step2_summary(len(cols))
+    want_kinds = tsvio.column_kinds(want2, len(cols))
+    other = (want_kinds & tsvio.KIND_OTHER) != 0
+    assert ((kinds & tsvio.KIND_OTHER) != 0).tolist() == other.tolist()
+    assert kinds[~other].tolist() == want_kinds[~other].tolist(), (kinds, want_kinds)       # (a column of strings stops being classified on the host)
+    want_surv = calling._step3_survivors(want2, 6)
+    assert engine.table_bytes(engine.TABLE_STEP3_ROWS, n_surv) == want_surv, "survivors"
+    return got2, want_surv
+
+
 def device_tables(engine, names, ct_names, n_ct, tmp):
     engine.set_table_names(names, ct_names)
     out = {}
@@ -73,7 +96,15 @@ def test_tables_of_installed_counts(engine, tmp_path, n_ct):
     assert n_cand > 0
     calls = engine.fetch_calls()
     per_ct = [engine.fetch_counts(ct) for ct in range(n_ct)]                # (the REF column is the loaded reference's)
-    same_tables(device_tables(engine, names, ct_names, n_ct, str(tmp_path)), host_tables(str(tmp_path), per_ct, calls, names, ct_names))
+    want = host_tables(str(tmp_path), per_ct, calls, names, ct_names)
+    same_tables(device_tables(engine, names, ct_names, n_ct, str(tmp_path)), want)
+    # step 2 on the device: a third of the candidate sites in each position set (some in two)
+    cand = np.ascontiguousarray(calls["key"][(calls["site_filter"] >> 31) != 0]) + 1
+    possets = [np.sort(rng.choice(cand, len(cand) // 3, replace=False)) for _ in range(3)]
+    s2, surv = step2_on_device_equals_host(engine, names, ct_names, want[6], possets)
+    assert b"RNA_editing_db" in s2 and b"PoN_SR" in s2 and b",PoN_LR" in s2
+    if n_ct > 1:
+        assert b"\t\t" in s2 or s2.endswith(b"\t\n") or b"\t\n" in s2           # NA cells went blank
 
 
 def test_contig_order_context_edges_and_rounding_ties(engine, tmp_path):
@@ -130,6 +161,8 @@ def test_contig_order_context_edges_and_rounding_ties(engine, tmp_path):
     order = [l.split("\t")[0] for l in want[4].decode().split("\n") if l]
     assert [c for i, c in enumerate(order) if i == 0 or order[i - 1] != c] == sorted(set(order)) and len(set(order)) == 8
     same_tables(device_tables(engine, names, ct_names, 2, str(tmp_path)), want)
+    s2, surv = step2_on_device_equals_host(engine, names, ct_names, want[6], [np.zeros(0, np.int64)] * 3)
+    assert len(surv) > 0 and any(l.startswith(b"chrM\t") for l in surv.split(b"\n"))
 
 
 def test_tables_of_a_counted_sample(engine, tmp_path):
@@ -146,7 +179,44 @@ def test_tables_of_a_counted_sample(engine, tmp_path):
     ct_names = ["Cancer", "Non-Cancer"]
     calls = engine.fetch_calls()
     per_ct = [engine.fetch_counts(ct) for ct in range(2)]
-    same_tables(device_tables(engine, names, ct_names, 2, str(tmp_path)), host_tables(str(tmp_path), per_ct, calls, names, ct_names))
+    want = host_tables(str(tmp_path), per_ct, calls, names, ct_names)
+    same_tables(device_tables(engine, names, ct_names, 2, str(tmp_path)), want)
+    cand = np.ascontiguousarray(calls["key"][(calls["site_filter"] >> 31) != 0]) + 1
+    step2_on_device_equals_host(engine, names, ct_names, want[6], [cand[::7], cand[::5], np.zeros(0, np.int64)])
+
+
+def test_the_cell_classifier_on_odd_text(engine, tmp_path):
+    """lsg_step2_summary's kinds of cell against tsvio.column_kinds on cells no table of this package holds: the classifier is the
+    host's rule for rule, strtod's grammar included (cell-type names are printed as they are: they carry the odd text into column 6 and
+    into the last columns' header-less cells)"""
+    names, seqs = tsvio.read_fasta(os.path.join(G, "calling.ref.fa"))
+    engine.set_contigs([len(s) for s in seqs])
+    for t, s in enumerate(seqs):
+        engine.load_reference(t, s)
+    k, r, c = tsvio.parse_counts_tsv(os.path.join(G, "counts.sample.Cancer.tsv"), names)[:3]
+    odd = ["1e5", "0x1F", "0x", "0x.8p-1", " 12", "12 ", "+5", "-0", "007", "1.50", "0.00001", "1234567890123456.5", ".5", "5.", "inf", "-inf", "Infinity", "infinit",
+           "nan(abc_1)", "nan(", "NaN", "-nan", "N/A", "n/a", "None", "True", "false", "1,2", "1|2", "1e", "1e+", "0.0", "-0.0", "00.5", "1234567890123456789",
+           "i", "I", "n", "N", ".", "-", "+", " ", "1.#IND", "<NA>", "0x1p", "1.5e3 ", "  7", "1_000", "٣"]
+    odd += ["#N/A", "a#b", "#NA", "12#3"]
+    engine.load_counts([k], [c])
+    engine.call_step1()
+    for kind in range(3):
+        engine.load_posset(kind, np.zeros(0, np.int64))
+    seen = set()
+    for name in odd:
+        engine.set_table_names(names, [name])
+        n = engine.format_table(engine.TABLE_STEP2)
+        text = engine.table_bytes(engine.TABLE_STEP2, n)
+        assert ("\t%s\t" % name).encode() in text
+        n_cols = 26
+        kinds, _ = engine.step2_summary(n_cols)
+        want_kinds = tsvio.column_kinds(text, n_cols)
+        other = (want_kinds & tsvio.KIND_OTHER) != 0
+        assert ((kinds & tsvio.KIND_OTHER) != 0).tolist() == other.tolist(), (name, kinds, want_kinds)
+        assert kinds[~other].tolist() == want_kinds[~other].tolist(), (name, kinds, want_kinds)
+        seen.add(int(want_kinds[6]))
+    assert {tsvio.KIND_NA, tsvio.KIND_INT, tsvio.KIND_FLOAT, tsvio.KIND_ODD, tsvio.KIND_OTHER} <= seen, seen
+    engine.free_table()
 
 
 def test_table_calls_refuse_what_they_cannot_print(engine):
