@@ -201,7 +201,7 @@ def _load_sample(bam: str, barcodes_tsv: str, ref_fasta: str, engine: Engine, mi
 
 
 def chain_step1(res: Resident, celltype_of: np.ndarray, celltype_names: List[str], report: Dict[str, int], out_dir: str, sample_id: str,
-                params: SnvParams, write_tables: bool = True, background_tables: bool = False):
+                params: SnvParams, write_tables: bool = True, background_tables: bool = False, kept_rows: bool = True):
     """SplitBam report -> BaseCellCounter -> MergeCounts -> BaseCellCalling step 1 over the resident reads.  Returns (outputs, text of
     the rows step 2 keeps, call records, timings); write_tables=False keeps everything off the disk except the report."""
     eng, contig_names = res.engine, res.contig_names
@@ -228,7 +228,7 @@ def chain_step1(res: Resident, celltype_of: np.ndarray, celltype_names: List[str
     out.merged = os.path.join(d["MergeCounts"], sample_id + ".BaseCellCounts.AllCellTypes.tsv")
     out.step1 = os.path.join(d["BaseCellCalling"], sample_id + ".calling.step1.tsv")
     if os.environ.get("LONGSOM_HOST_TABLES", "0") != "1":
-        return _device_tables(eng, out, contig_names, celltype_names, sample_id, params, date, background_tables, t, t0, (n_rows, n_cols, n_sites, n_cand))
+        return _device_tables(eng, out, contig_names, celltype_names, sample_id, params, date, background_tables, t, t0, (n_rows, n_cols, n_sites, n_cand), kept_rows)
     import threading
     per_ct: List = [None] * len(celltype_names)
     arrived = [threading.Event() for _ in celltype_names]          # a cell type's count rows are on the host
@@ -302,7 +302,7 @@ def _row_digests(eng, n_ct: int, shape, per_ct=None) -> dict:
     return out
 
 
-def _device_tables(eng, out: "SnvOutputs", contig_names, celltype_names, sample_id, params, date, background: bool, t, t0, shape):
+def _device_tables(eng, out: "SnvOutputs", contig_names, celltype_names, sample_id, params, date, background: bool, t, t0, shape, kept_rows: bool = True):
     """The tables of chain_step1 printed on the device (Engine.format_table: csrc/tables.hip, byte for byte the host writers' text) and
     streamed into their files (Engine.append_table), one thread per file; the count rows never come to the host.  The rows step 2 keeps
     come first - steps 2 and 3 wait for nothing else.  LONGSOM_HOST_TABLES=1 keeps the host writers (csrc/hostio/tsvwrite.cpp)."""
@@ -310,9 +310,11 @@ def _device_tables(eng, out: "SnvOutputs", contig_names, celltype_names, sample_
     eng.set_table_names(contig_names, celltype_names)
     header = [l + "\n" for l in tsvio.merged_header(celltype_names, date).split("\n") if l.startswith("##")]
     head1 = tsvio.step1_header(header, celltype_names)
-    n = eng.format_table(eng.TABLE_STEP1_KEPT)
-    s1 = eng.table_bytes(eng.TABLE_STEP1_KEPT, n, prefix=head1.encode())
-    eng.free_table(eng.TABLE_STEP1_KEPT)
+    s1 = head1.encode()
+    if kept_rows:                                    # (kept_rows=False: the caller runs step 2 on the device too and wants the header alone)
+        n = eng.format_table(eng.TABLE_STEP1_KEPT)
+        s1 = eng.table_bytes(eng.TABLE_STEP1_KEPT, n, prefix=s1)
+        eng.free_table(eng.TABLE_STEP1_KEPT)
     t["fetch"] = time.time() - t0                    # (what came to the host: the kept rows' text)
     t0 = time.time()
     files = [(ct, out.counts[name], tsvio.counts_header("%s.%s" % (sample_id, name), date)) for ct, name in enumerate(celltype_names)]
@@ -352,8 +354,16 @@ def run_chain(res: Resident, celltype_of: np.ndarray, celltype_names: List[str],
     resident reads (celltype_of[barcode id] = index into celltype_names, 255 = barcode not listed).  step3=False stops after
     step 2, as pass 1 of the reference does (rules/CellTypeReannotation.smk has no step-3 rule: HCCV reads calling.step2.tsv)."""
     eng, contig_names = res.engine, res.contig_names
-    out, s1, _, t = chain_step1(res, celltype_of, celltype_names, report, out_dir, sample_id, params, background_tables=True)
+    # Step 2 without a gnomAD source and with --min_distance 0 (LongSom's own setting) tags rows by position sets and blanks NA cells: the
+    # device prints that table itself and tells step 3 what it needs of it (_device_steps23); any other step 2 runs on the host over the
+    # text of the rows it keeps.  LONGSOM_HOST_TABLES=1 / LONGSOM_HOST_STEP2=1 keep the host paths.
+    device23 = (os.environ.get("LONGSOM_HOST_TABLES", "0") != "1" and os.environ.get("LONGSOM_HOST_STEP2", "0") != "1" and not gnomad_af_json
+                and int(params.min_distance) == 0 and len(set(contig_names)) == len(contig_names)
+                and not any(ch in n for n in list(contig_names) + list(celltype_names) for ch in "\t\n"))
+    out, s1, _, t = chain_step1(res, celltype_of, celltype_names, report, out_dir, sample_id, params, background_tables=True, kept_rows=not device23)
     try:
+        if device23:
+            return _device_steps23(out, s1, t, eng, contig_names, out_dir, sample_id, params, editing, pon_sr, pon_lr, step3)
         return _chain_steps23(out, s1, t, eng, contig_names, out_dir, sample_id, params, editing, pon_sr, pon_lr, gnomad_af_json, step3)
     except BaseException:
         try:                                   # (the writers stream from the engine: nobody may close it under them)
@@ -361,6 +371,47 @@ def run_chain(res: Resident, celltype_of: np.ndarray, celltype_names: List[str],
         except BaseException:                  # noqa: BLE001 - the first error is the one to report
             pass
         raise
+
+
+def _device_steps23(out, head1: bytes, t, eng, contig_names, out_dir, sample_id, params, editing, pon_sr, pon_lr, step3):
+    """Steps 2 and 3 of run_chain with the step-2 table printed on the device (Engine.TABLE_STEP2: csrc/tables.hip): its text goes from
+    the device straight into its file; the host sees the kinds of cell of its columns and the rows step 3 can keep
+    (Engine.step2_summary), which is all calling.step3 reads of a table this large."""
+    t0 = time.time()
+    keys = [calling.read_posset_keys(p, contig_names, params.reference_gz_compat) for p in (editing, pon_sr, pon_lr)]
+    for kind, k in zip((calling.KIND_EDITING, calling.KIND_PON_SR, calling.KIND_PON_LR), keys):
+        eng.load_posset(kind, k)
+    # the table's head as step 2 writes it: the comment lines, then the column header (calling._step2_scanned)
+    lines = [l for l in head1.split(b"\n") if l]
+    hdr = b"\n".join([l for l in lines if b"#CHROM" not in l] + [[l for l in lines if b"#CHROM" in l][-1]]) + b"\n"
+    cols = hdr.decode().split("\n")[-2].split("\t")
+    out.step2 = os.path.join(out_dir, "BaseCellCalling", sample_id + ".calling.step2.tsv")
+    with open(out.step2, "wb") as f:
+        f.write(hdr)
+    n2 = eng.format_table(eng.TABLE_STEP2)
+    kinds, n_surv = eng.step2_summary(len(cols))
+    survivors = eng.table_bytes(eng.TABLE_STEP3_ROWS, n_surv, prefix=hdr)
+    eng.free_table(eng.TABLE_STEP3_ROWS)
+    out.start_background(lambda: eng.append_table(eng.TABLE_STEP2, out.step2))
+    t["step2"] = time.time() - t0
+    try:
+        if step3:
+            t0 = time.time()
+            final, unfiltered = calling.step3_bytes(survivors, params.delta_vaf, params.delta_mcf, params.min_ac_reads, params.min_ac_cells, params.clust_dist,
+                                                    all_kinds=kinds, full_text=lambda: eng.table_bytes(eng.TABLE_STEP2, n2, prefix=hdr))
+            out.step3 = os.path.join(out_dir, "BaseCellCalling", sample_id + ".calling.step3.tsv")
+            out.step3_unfiltered = os.path.join(out_dir, "BaseCellCalling", sample_id + ".calling.step3.unfiltered.tsv")
+            tsvio.write_bytes(out.step3, final)
+            tsvio.write_bytes(out.step3_unfiltered, unfiltered)
+            t["step3"] = time.time() - t0
+        t["tables_wait"] = out.wait_for_tables()
+    finally:
+        try:
+            out.wait_for_tables()
+        finally:
+            eng.free_table(eng.TABLE_STEP2)
+    out.timings = t
+    return out
 
 
 def _chain_steps23(out, s1, t, eng, contig_names, out_dir, sample_id, params, editing, pon_sr, pon_lr, gnomad_af_json, step3):

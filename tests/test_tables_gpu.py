@@ -237,3 +237,43 @@ def test_table_calls_refuse_what_they_cannot_print(engine):
         engine.table_bytes(engine.TABLE_STEP1, 10)
     assert engine.format_table(0) > 0
     engine.free_table()
+
+
+def test_the_chain_with_device_tables_writes_the_host_paths_files(engine, tmp_path, monkeypatch):
+    """pipeline.run_snv end to end on a synthetic BAM (C2's model, 200 k reads, editing / PoN files that hit candidate sites): the run that
+    prints its tables and runs step 2 on the device (the default) leaves, byte for byte, the eight files of the run that takes the host
+    writers and the host's step 2 (LONGSOM_HOST_TABLES=1: csrc/hostio, pinned to the reference's goldens); so does the run that prints
+    on the device but leaves step 2 to the host (LONGSOM_HOST_STEP2=1)"""
+    from longsom_amd import hostio, pipeline, synth
+    m = synth.named("C2", n_reads=200_000)
+    bam, fa, bct = str(tmp_path / "S.bam"), str(tmp_path / "ref.fa"), str(tmp_path / "bc.tsv")
+    hostio.synth_bam(m, bam, fa)
+    hostio.write_barcodes_tsv(bct, hostio.synth_barcodes(m), m.celltype_of, ["Cancer", "Non-Cancer"])
+    engine.unload_reads()
+    monkeypatch.setenv("LONGSOM_HOST_TABLES", "1")
+    host = pipeline.run_snv(bam, bct, fa, str(tmp_path / "host0"), "S")
+    # position-set files from the candidates the first run found (chrom, 1-based pos)
+    rows = [l.split("\t")[:2] for l in open(host.step2).read().split("\n") if l and not l.startswith("#")]
+    assert len(rows) > 1000
+    files = {}
+    for name, step in (("editing", 11), ("pon_sr", 7), ("pon_lr", 5)):
+        files[name] = str(tmp_path / (name + ".tsv"))
+        with open(files[name], "w") as f:
+            f.write("#chrom\tpos\n" + "".join("%s\t%s\n" % (c, p) for c, p in rows[::step]))
+    kw = dict(editing=files["editing"], pon_sr=files["pon_sr"], pon_lr=files["pon_lr"])
+    host = pipeline.run_snv(bam, bct, fa, str(tmp_path / "host"), "S", **kw)
+    monkeypatch.delenv("LONGSOM_HOST_TABLES")
+    dev = pipeline.run_snv(bam, bct, fa, str(tmp_path / "dev"), "S", **kw)
+    monkeypatch.setenv("LONGSOM_HOST_STEP2", "1")
+    mixed = pipeline.run_snv(bam, bct, fa, str(tmp_path / "mixed"), "S", **kw)
+    assert "format_tables" in dev.timings and "format_tables" in mixed.timings and "format_tables" not in host.timings
+    def files_of(o):
+        return list(o.counts.values()) + [o.merged, o.step1, o.step2, o.step3, o.step3_unfiltered]
+    for a, b, c in zip(files_of(host), files_of(dev), files_of(mixed)):
+        want = open(a, "rb").read()
+        assert len(want) > 200 and os.path.basename(a) == os.path.basename(b)
+        assert open(b, "rb").read() == want, os.path.basename(a)
+        assert open(c, "rb").read() == want, os.path.basename(a) + " (host step 2)"
+    s2 = open(host.step2).read()
+    assert "RNA_editing_db" in s2 and "PoN_SR" in s2 and "PoN_LR" in s2
+    assert sum(1 for l in open(host.step3_unfiltered) if not l.startswith("#")) > 10
