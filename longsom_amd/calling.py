@@ -415,19 +415,23 @@ class _SurvivorsAhead:
         return self.out
 
 
-def step3_bytes(step2_text, delta_vaf: float, delta_mcf: float, min_ac_reads: int, min_ac_cells: int, clust_dist: int, all_kinds=None, full_text=None):
+def step3_bytes(step2_text, delta_vaf: float, delta_mcf: float, min_ac_reads: int, min_ac_cells: int, clust_dist: int, all_kinds=None, full_text=None,
+                survivors_only: bool = False):
     """step3 with both tables as bytes (what the fused pipeline writes: at C2's size the unfiltered table is 0.8 GB, not worth a decode
-    and an encode).  all_kinds / full_text: see step3."""
-    final, unfiltered = step3(step2_text, delta_vaf, delta_mcf, min_ac_reads, min_ac_cells, clust_dist, _as_bytes=True, all_kinds=all_kinds, full_text=full_text)
+    and an encode).  all_kinds / full_text / survivors_only: see step3."""
+    final, unfiltered = step3(step2_text, delta_vaf, delta_mcf, min_ac_reads, min_ac_cells, clust_dist, _as_bytes=True, all_kinds=all_kinds, full_text=full_text,
+                              survivors_only=survivors_only)
     return (final if isinstance(final, bytes) else final.encode()), (unfiltered if isinstance(unfiltered, bytes) else unfiltered.encode())
 
 
 def step3(step2_text, delta_vaf: float, delta_mcf: float, min_ac_reads: int, min_ac_cells: int, clust_dist: int, _as_bytes: bool = False,
-          all_kinds=None, full_text=None):
+          all_kinds=None, full_text=None, survivors_only: bool = False):
     """Returns (text of .calling.step3.tsv, text of .calling.step3.unfiltered.tsv).  step2_text: str or bytes.
     all_kinds: tsvio.column_kinds of the WHOLE step-2 table when step2_text holds only a part of its rows (the survivors the ranks of a
     sharded run send to rank 0); full_text: a callable that returns the whole table then - called only when that table's printed form
-    depends on pandas' dtypes (a table this package did not write), to be parsed whole as the reference does."""
+    depends on pandas' dtypes (a table this package did not write), to be parsed whole as the reference does.  survivors_only (with
+    all_kinds): the rows of step2_text ARE the survivors of step 3's FILTER patterns and Cell_types test already (Engine.step2_summary
+    picked them on the device by the same rules), they are not looked for again."""
     as_bytes = isinstance(step2_text, (bytes, bytearray, memoryview))
     comments, cols = [], None
     at = 0
@@ -477,8 +481,10 @@ def step3(step2_text, delta_vaf: float, delta_mcf: float, min_ac_reads: int, min
                       for c in range(len(cols))}
     if not full_parse:
         i_ct = cols.index("Cell_types") if cols and "Cell_types" in cols else 6
-        survivors = None
-        if os.environ.get("LONGSOM_STEP3_ROW_PATH", "0") != "1":
+        survivors, skip = None, 0
+        if survivors_only and as_bytes and all_kinds is not None and os.environ.get("LONGSOM_STEP3_RESCAN", "0") != "1":
+            survivors, skip = step2_text, at                  # (`at`: the end of the comment lines, found above)
+        elif os.environ.get("LONGSOM_STEP3_ROW_PATH", "0") != "1":
             survivors = early_survivors.result(i_ct) if cols and early_survivors is not None else _step3_survivors(step2_text if as_bytes else step2_text.encode(), i_ct)
         if survivors is None:
             dead_m, dead_o = re.compile(_DEAD_M), re.compile(_DEAD_O)
@@ -492,7 +498,7 @@ def step3(step2_text, delta_vaf: float, delta_mcf: float, min_ac_reads: int, min
                 if (dead_m if el[0] == "chrM" else dead_o).search(el[5]) is None:
                     keep_lines.append(line)
             survivors = ("\n".join(keep_lines) + "\n").encode() if keep_lines else b""
-        if not survivors:
+        if len(survivors) <= skip:
             empty = head + "\t".join(cols + ["STEP3FILTER", "INDEX"]) + "\n"
             return empty, empty
         step2_text = survivors
@@ -502,7 +508,7 @@ def step3(step2_text, delta_vaf: float, delta_mcf: float, min_ac_reads: int, min
             # printed form could depend on pandas' dtypes, or on which a row function raises: the pandas path below decides
             from . import tsvio
             header = head + "\t".join(cols + ["STEP3FILTER", "INDEX"]) + "\n"
-            done = tsvio.step3_rows(survivors, cols, delta_vaf, delta_mcf, min_ac_reads, min_ac_cells, clust_dist, all_kinds=all_kinds, prefix=header.encode())
+            done = tsvio.step3_rows(survivors, cols, delta_vaf, delta_mcf, min_ac_reads, min_ac_cells, clust_dist, all_kinds=all_kinds, prefix=header.encode(), skip=skip)
             if done is not None:
                 if _as_bytes:
                     return done[1], done[0]

@@ -296,7 +296,7 @@ int lsio_step3_rows(const char* text, int64_t n_bytes, int32_t n_cols, const int
             for (size_t i = lo; i < hi; ++i) {
                 rows[i].f = split(lines[i], '\t');
                 if ((int32_t)rows[i].f.size() != n_cols) { ragged = true; return; }
-                for (int32_t c = 0; c < n_cols; ++c) {
+                for (int32_t c = 0; c < n_cols && !all_kinds; ++c) {      // (all_kinds: the kinds of cell of the WHOLE table, these rows' among them)
                     Seen& m = mine[(size_t)c];
                     if (m.other) continue;                       // a column of strings: every cell prints as it came (a missing one as "")
                     switch (classify(rows[i].f[(size_t)c])) {

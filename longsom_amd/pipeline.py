@@ -398,7 +398,7 @@ def _device_steps23(out, head1: bytes, t, eng, contig_names, out_dir, sample_id,
         if step3:
             t0 = time.time()
             final, unfiltered = calling.step3_bytes(survivors, params.delta_vaf, params.delta_mcf, params.min_ac_reads, params.min_ac_cells, params.clust_dist,
-                                                    all_kinds=kinds, full_text=lambda: eng.table_bytes(eng.TABLE_STEP2, n2, prefix=hdr))
+                                                    all_kinds=kinds, full_text=lambda: eng.table_bytes(eng.TABLE_STEP2, n2, prefix=hdr), survivors_only=True)
             out.step3 = os.path.join(out_dir, "BaseCellCalling", sample_id + ".calling.step3.tsv")
             out.step3_unfiltered = os.path.join(out_dir, "BaseCellCalling", sample_id + ".calling.step3.unfiltered.tsv")
             tsvio.write_bytes(out.step3, final)

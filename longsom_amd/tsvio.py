@@ -167,7 +167,7 @@ def _io():
         lib.lsio_free_row_scan.argtypes = [C.c_void_p]
         lib.lsio_step3_last_error.restype = C.c_char_p
         lib.lsio_step3_rows.restype = C.c_int
-        lib.lsio_step3_rows.argtypes = [C.c_char_p, C.c_int64, C.c_int32, C.c_void_p, C.c_double, C.c_double, C.c_int64, C.c_int64, C.c_int64, C.c_void_p,
+        lib.lsio_step3_rows.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_double, C.c_double, C.c_int64, C.c_int64, C.c_int64, C.c_void_p,
                                         C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
         lib.lsio_step3_column_kinds.restype = C.c_int
         lib.lsio_step3_column_kinds.argtypes = [C.c_char_p, C.c_int64, C.c_int32, C.c_void_p]
@@ -235,12 +235,15 @@ def kinds_dtype_sensitive(kinds: np.ndarray) -> bool:
     return bool(np.any(num & (((k & KIND_ODD) != 0) | (((k & KIND_INT) != 0) & ((k & (KIND_NA | KIND_FLOAT)) != 0)))))
 
 
-def step3_rows(rows: bytes, cols, delta_vaf: float, delta_mcf: float, min_ac_reads: int, min_ac_cells: int, clust_dist: int, all_kinds=None, prefix: bytes = b""):
+def step3_rows(rows: bytes, cols, delta_vaf: float, delta_mcf: float, min_ac_reads: int, min_ac_cells: int, clust_dist: int, all_kinds=None, prefix: bytes = b"",
+               skip: int = 0):
     """lsio_step3_rows (csrc/hostio/tsvstep3.cpp) over the surviving rows of a step-2 table whose header is `cols`: (rows of the
     unfiltered table, rows of the final table) as bytes, or None when the table is one for the pandas path.  all_kinds: column_kinds of
-    the WHOLE table the rows were taken from (the dropped rows' cells decide pandas' dtypes too)."""
+    the WHOLE table the rows were taken from (the dropped rows' cells decide pandas' dtypes too).  skip: the rows start at rows[skip] (a
+    header in front of a gigabyte is not worth a copy of it)."""
     import ctypes as C
     lib = _io()
+    rows = rows if isinstance(rows, bytes) else bytes(rows)
     idx = []
     for name in STEP3_COLUMNS:
         if name in cols:
@@ -254,7 +257,7 @@ def step3_rows(rows: bytes, cols, delta_vaf: float, delta_mcf: float, min_ac_rea
     kinds = None if all_kinds is None else np.ascontiguousarray(all_kinds, np.uint8)
     if kinds is not None and len(kinds) != len(cols):
         raise ValueError("all_kinds has %d entries for %d columns" % (len(kinds), len(cols)))
-    rc = lib.lsio_step3_rows(rows, len(rows), len(cols), col, float(delta_vaf), float(delta_mcf), int(min_ac_reads), int(min_ac_cells), int(clust_dist),
+    rc = lib.lsio_step3_rows(C.cast(C.c_char_p(rows), C.c_void_p).value + int(skip), len(rows) - int(skip), len(cols), col, float(delta_vaf), float(delta_mcf), int(min_ac_reads), int(min_ac_cells), int(clust_dist),
                              None if kinds is None else kinds.ctypes.data, C.byref(a), C.byref(na), C.byref(b), C.byref(nb))
     if rc == 1:
         return None

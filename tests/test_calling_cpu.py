@@ -167,6 +167,30 @@ def test_step3_native_rows_equal_the_pandas_path(monkeypatch):
             assert calling.step3(t.encode(), *args) == want
 
 
+def test_step3_over_survivors_and_the_whole_tables_kinds():
+    """what the fused chain hands step 3 when the device printed the step-2 table: header + the rows its FILTER patterns and Cell_types
+    test let through + the kinds of cell of every column over the WHOLE table (survivors_only: the rows are not looked for again, their
+    cells not classified again) - the same two tables as step 3 over the whole text"""
+    texts, _, _, _ = _step3_tables()
+    for t in texts:
+        tb = t.encode()
+        head = b"".join(l + b"\n" for l in tb.split(b"\n") if l.startswith(b"#"))
+        cols = [l for l in t.split("\n") if l.startswith("#CHROM")][0].split("\t")
+        kinds = tsvio.column_kinds(tb, len(cols))
+        part = head + calling._step3_survivors(tb, 6)
+        for clust in (10000, 150):
+            args = (0.05, 0.3, 3, 2, clust)
+            want = calling.step3_bytes(tb, *args)
+            assert calling.step3_bytes(part, *args, all_kinds=kinds, survivors_only=True) == want
+            assert calling.step3_bytes(part, *args, all_kinds=kinds) == want
+    # no survivors at all: header-only tables
+    t = texts[0]
+    head = "".join(l + "\n" for l in t.split("\n") if l.startswith("#")).encode()
+    cols = [l for l in t.split("\n") if l.startswith("#CHROM")][0].split("\t")
+    empty = calling.step3_bytes(head, 0.05, 0.3, 3, 2, 10000, all_kinds=np.zeros(len(cols), np.uint8), survivors_only=True)
+    assert empty[0] == empty[1] and empty[0].endswith(b"STEP3FILTER\tINDEX\n")
+
+
 def test_step3_native_hands_back_what_pandas_dtypes_could_change(monkeypatch):
     """an integer column with a missing value (pandas prints 12.0), a number that is not its own shortest repr, a '#', a quote, a row
     function that raises in Python: tsvstep3.cpp returns 'not mine' and the result (or the exception) is the pandas path's"""
