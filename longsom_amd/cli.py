@@ -112,12 +112,20 @@ def base_cell_counter(argv=None):
         eng.set_load_filter(cp.min_mq, cp.flag_exclude, cp.ignore_orphans)      # (reads the count would refuse are not stored: keys alone through the sort)
         eng.load_reads(dec.records)
         eng.pileup_count(cp)
+        out = os.path.join(a.out_folder, sid + ".tsv")
+        print("Outfile: ", out, "\n")
+        if not (a.bed or a.bed_out) and os.environ.get("LONGSOM_HOST_TABLES", "0") != "1":
+            # the table is printed where its rows lie and streamed into the file (csrc/tables.hip; the same bytes as the writer below)
+            eng.set_table_names(dec.contig_names, [sid])
+            eng.format_table(eng.TABLE_COUNTS)
+            with open(out, "w") as f:
+                f.write(tsvio.counts_header(sid))
+            eng.append_table(eng.TABLE_COUNTS, out)
+            return
         k, r, c = eng.fetch_counts(0)
     if a.bed or a.bed_out:                                # MakeWindows' interval arithmetic (BaseCellCounter.py:88-106): only rows inside are written
         keep = bed_mask(k, dec.contig_names, [len(seq_of[n]) for n in dec.contig_names], a.bed, a.bed_out)
         k, r, c = k[keep], r[keep], c[keep]
-    out = os.path.join(a.out_folder, sid + ".tsv")
-    print("Outfile: ", out, "\n")
     tsvio.write_counts_tsv(out, k, r, c, dec.contig_names, sid)
 
 
@@ -160,6 +168,13 @@ def calling_step1(argv=None):
         eng.call_step1(CallParams.longsom_defaults(alpha1=a.alpha1, beta1=a.beta1, alpha2=a.alpha2, beta2=a.beta2, min_cov=a.min_cov,
                                                    min_cells=a.min_cells, min_ac_cells=a.min_ac_cells, min_ac_reads=a.min_ac_reads,
                                                    max_cell_types=a.max_cell_types, min_cell_types=a.min_cell_types))
+        if os.environ.get("LONGSOM_HOST_TABLES", "0") != "1" and not any(ch in n for n in list(names) + list(cts) for ch in "\t\n"):
+            eng.set_table_names(names, cts)
+            eng.format_table(eng.TABLE_STEP1)
+            with open(a.outfile + ".calling.step1.tsv", "w") as f:
+                f.write(tsvio.step1_header(header, cts))
+            eng.append_table(eng.TABLE_STEP1, a.outfile + ".calling.step1.tsv")
+            return
         calls = eng.fetch_calls()
     tsvio.write_step1_tsv(a.outfile + ".calling.step1.tsv", calls, per_ct, names, cts, header)
 

@@ -137,8 +137,16 @@ std::string tag(const std::string& cur, const char* t) { return cur == "PASS" ? 
 
 enum Col { C_CHROM, C_START, C_REF, C_ALT, C_FILTER, C_CT, C_DP, C_NC, C_BC, C_CC, C_VAF, C_MCF, C_CTF, C_CANCER, C_NONCANCER, N_COLS_USED };
 
+struct Fields {                                             // a row's fields: n_cols views in one array shared by all rows (a vector per row was a malloc per row, on 16 threads)
+    const sv* p = nullptr; size_t n = 0;
+    const sv& operator[](size_t i) const { return p[i]; }
+    size_t size() const { return n; }
+    const sv* begin() const { return p; }
+    const sv* end() const { return p + n; }
+};
+
 struct Row {
-    std::vector<sv> f;                                      // the fields as they came
+    Fields f;                                               // the fields as they came
     std::string alt, filter, bc, cc, vaf, mcf;              // the rewritten ones of a multi-allelic row
     bool rewritten = false, is_m = false, dropped = false;
     std::string s3, index;
@@ -291,11 +299,22 @@ int lsio_step3_rows(const char* text, int64_t n_bytes, int32_t n_cols, const int
         std::vector<Seen> seen((size_t)n_cols);
         std::atomic<bool> ragged{false};
         std::atomic<unsigned> seen_lock{0};
+        std::vector<sv> flat(rows.size() * (size_t)n_cols);
         parallel_rows(rows.size(), [&](size_t lo, size_t hi) {
             std::vector<Seen> mine((size_t)n_cols);
             for (size_t i = lo; i < hi; ++i) {
-                rows[i].f = split(lines[i], '\t');
-                if ((int32_t)rows[i].f.size() != n_cols) { ragged = true; return; }
+                sv* f = flat.data() + i * (size_t)n_cols;
+                const sv line = lines[i];
+                size_t a = 0; int32_t nf = 0;
+                while (true) {
+                    const size_t e = line.find('\t', a);
+                    if (nf < n_cols) f[nf] = line.substr(a, e == sv::npos ? sv::npos : e - a);
+                    ++nf;
+                    if (e == sv::npos) break;
+                    a = e + 1;
+                }
+                if (nf != n_cols) { ragged = true; return; }
+                rows[i].f = Fields{f, (size_t)n_cols};
                 for (int32_t c = 0; c < n_cols && !all_kinds; ++c) {      // (all_kinds: the kinds of cell of the WHOLE table, these rows' among them)
                     Seen& m = mine[(size_t)c];
                     if (m.other) continue;                       // a column of strings: every cell prints as it came (a missing one as "")
