@@ -784,6 +784,8 @@ int run_call(lsg_ctx* c, const lsg_call_params* p) {
 }
 static int run_call_sized(lsg_ctx* c, const lsg_call_params* p, uint32_t tasks_per_site) {
     if (!c->counted) { set_error("lsg_call_step1: call lsg_pileup_count first"); return -2; }
+    for (int t = 0; t < c->n_contigs; ++t)          // (the kernels read the sites' reference bases and contexts: installed count rows come without a check of their own)
+        if (!c->ref_ptr[t]) { set_error("lsg_call_step1: reference of contig %d not loaded", t); return -2; }
     hipStream_t st = c->stream;
     const uint32_t n_ne = c->n_ne;
     c->n_sites = 0; c->n_cand = 0; c->n_pass = -1;

@@ -533,6 +533,8 @@ int run_format_table(lsg_ctx* c, int32_t table, int64_t* n_bytes) {
     const bool counts = table < LSG_TABLE_MERGED;
     if (counts && table >= c->n_ct) { set_error("lsg_format_table: no cell type %d", table); return -2; }
     if (!counts && !c->called) { set_error("lsg_format_table: the merged and step-1 tables need lsg_call_step1 (its merged site list)"); return -2; }
+    for (int t = 0; t < c->n_contigs; ++t)          // (REF of the count rows, the step-1 rows' contexts)
+        if (!c->ref_ptr[t]) { set_error("lsg_format_table: reference of contig %d not loaded", t); return -2; }
     hipStream_t st = c->stream;
     // flat copies of the rows the table prints (kept until the next count)
     for (int ct = counts ? table : 0; ct < (counts ? table + 1 : c->n_ct); ++ct) {

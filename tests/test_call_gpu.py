@@ -183,3 +183,22 @@ def test_a_table_set_again_after_installed_counts_is_set(engine):
     assert engine.pileup_count() == (rows, cols)
     k1, r1, c1 = engine.fetch_counts(1)
     assert len(k1) == rows[1]
+
+
+def test_call_and_tables_refuse_a_contig_without_its_reference(engine):
+    """installed count rows (lsg_load_counts) come without the count's own check: the call reads every site's reference base and its
+    context, the tables print them - a contig whose bases were never loaded is an error, not a fault on the device"""
+    names, seqs = tsvio.read_fasta(os.path.join(G, "calling.ref.fa"))
+    engine.set_contigs([len(s) for s in seqs])                      # (a new contig table: no references yet)
+    k, r, c = tsvio.parse_counts_tsv(os.path.join(G, "counts.sample.Cancer.tsv"), names)[:3]
+    engine.load_counts([k], [c])
+    with pytest.raises(RuntimeError, match="reference of contig 0 not loaded"):
+        engine.call_step1()
+    engine.set_table_names(names, ["Cancer"])
+    with pytest.raises(RuntimeError, match="reference of contig 0 not loaded"):
+        engine.format_table(0)
+    for t, s in enumerate(seqs):
+        engine.load_reference(t, s)
+    engine.load_counts([k], [c])                                     # (a new reference drops the counts made against the old one)
+    assert engine.call_step1()[0] > 0 and engine.format_table(0) > 0
+    engine.free_table()
