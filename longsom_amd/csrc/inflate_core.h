@@ -19,21 +19,32 @@
 namespace lsi {
 
 constexpr int MAXBITS = 15, MAXLCODES = 286, MAXDCODES = 30, FIXLCODES = 288, MAXCODES = MAXLCODES + MAXDCODES;
-// per-thread table storage, every element at [index * stride]: T_WORDS uint16_t
-//   [0, 288)    lit/len symbols in code order      [288, 318)  distance symbols in code order
-//   [318, 334)  count per length (construction)    [334, 350)  next offset per length (construction)
-// and T_LENS bytes: the code lengths being read (dynamic header) / scratch.  1020 bytes per thread: two waves of 64 threads per CU.
-constexpr int T_LSYM = 0, T_DSYM = 288, T_CNT = 318, T_OFFS = 334, T_WORDS = 350, T_LENS = 320;
+// per-thread table storage, every element at [index * stride].
+//   sym (T_SYM bytes; device: LDS, [index][lane]): the decoding tables proper, all a symbol's decode reads
+//     [0, 288)    low bytes of the lit/len symbols in code order      [288, 324)  their ninth bits (symbols 256..285), one bit a symbol
+//     [324, 356)  distance symbols in code order (and, while a dynamic header is read, the code-length code's)
+//   lens (T_LENS bytes; device: global memory): what only the head of a block touches
+//     [0, 320)    the code lengths being read      [320, 384)  count per length and next offset per length, 16-bit little endian
+// 356 bytes of LDS per thread: seven waves of 64 threads per CU (a 16-bit word per symbol was 700: three waves, a SIMD without a wave).
+constexpr int T_LLO = 0, T_LHI = 288, T_DSYM = 324, T_SYM = 356, T_W = 320, T_CNT = 0, T_OFFS = 16, T_LENS = 384;
 
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
 
 struct Tab {
-    uint16_t* base; uint8_t* lens; int stride;
-    LSI_FN uint16_t get(int i) const { return base[(size_t)i * stride]; }
-    LSI_FN void set(int i, uint16_t v) const { base[(size_t)i * stride] = v; }
+    uint8_t* sym; uint8_t* lens; int stride;
+    LSI_FN uint32_t lsym(int i) const { return (uint32_t)sym[(size_t)(T_LLO + i) * stride] | ((((uint32_t)sym[(size_t)(T_LHI + (i >> 3)) * stride] >> (i & 7)) & 1u) << 8); }
+    LSI_FN void set_lsym(int i, uint32_t v) const {
+        sym[(size_t)(T_LLO + i) * stride] = (uint8_t)v;
+        if (v & 256u) { uint8_t* h = sym + (size_t)(T_LHI + (i >> 3)) * stride; *h = (uint8_t)(*h | (1u << (i & 7))); }
+    }
+    LSI_FN void clear_lhi() const { for (int i = T_LHI; i < T_DSYM; ++i) sym[(size_t)i * stride] = 0; }
+    LSI_FN uint32_t dsym(int i) const { return sym[(size_t)(T_DSYM + i) * stride]; }
+    LSI_FN void set_dsym(int i, uint32_t v) const { sym[(size_t)(T_DSYM + i) * stride] = (uint8_t)v; }
     LSI_FN uint32_t len(int i) const { return lens[(size_t)i * stride]; }
     LSI_FN void set_len(int i, uint32_t v) const { lens[(size_t)i * stride] = (uint8_t)v; }
+    LSI_FN uint16_t get(int i) const { return (uint16_t)(lens[(size_t)(T_W + 2 * i) * stride] | (lens[(size_t)(T_W + 2 * i + 1) * stride] << 8)); }      // the construction's 16-bit words
+    LSI_FN void set(int i, uint16_t v) const { lens[(size_t)(T_W + 2 * i) * stride] = (uint8_t)v; lens[(size_t)(T_W + 2 * i + 1) * stride] = (uint8_t)(v >> 8); }
 };
 
 // Where the compressed bytes come from.  PlainIn: memory the thread reads directly.  csrc/ingest.hip has a second one (a wave's LDS
@@ -74,9 +85,11 @@ struct Bits {
 
 struct Counts { uint16_t c[MAXBITS + 1]; };          // codes per length (kept in registers: the decode loop is fully unrolled)
 
-// builds the canonical decoding tables of n symbols whose code lengths are lens[first .. first + n): symbols in code order at
-// tab[sym_at ..], counts per length in *cnt.  Returns 0 for a complete code, > 0 incomplete, < 0 over-subscribed (as zlib's puff).
-LSI_FN int construct(const Tab& t, int first, int n, int sym_at, Counts* cnt) {
+// builds the canonical decoding tables of n symbols whose code lengths are lens[first .. first + n): symbols in code order in the
+// lit/len table (LIT) or the distance table, counts per length in *cnt.  Returns 0 for a complete code, > 0 incomplete, < 0 over-subscribed (as zlib's puff).
+template <bool LIT>
+LSI_FN int construct(const Tab& t, int first, int n, Counts* cnt) {
+    if (LIT) t.clear_lhi();
     for (int len = 0; len <= MAXBITS; ++len) t.set(T_CNT + len, 0);
     for (int s = 0; s < n; ++s) { const int l = (int)(t.len(first + s) & 15u); t.set(T_CNT + l, (uint16_t)(t.get(T_CNT + l) + 1)); }
     int left = 1;
@@ -86,56 +99,87 @@ LSI_FN int construct(const Tab& t, int first, int n, int sym_at, Counts* cnt) {
     for (int len = 1; len < MAXBITS; ++len) { off = (uint16_t)(off + t.get(T_CNT + len)); t.set(T_OFFS + len + 1, off); }
     for (int s = 0; s < n; ++s) {
         const int l = (int)(t.len(first + s) & 15u);
-        if (l) { const uint16_t o = t.get(T_OFFS + l); t.set(sym_at + o, (uint16_t)s); t.set(T_OFFS + l, (uint16_t)(o + 1)); }
+        if (l) { const uint16_t o = t.get(T_OFFS + l); if (LIT) t.set_lsym(o, (uint32_t)s); else t.set_dsym(o, (uint32_t)s); t.set(T_OFFS + l, (uint16_t)(o + 1)); }
     }
     for (int len = 0; len <= MAXBITS; ++len) cnt->c[len] = t.get(T_CNT + len);
     return left;
 }
 
-// one symbol of the code described by (cnt, symbols at sym_at); -1 when the bits run out or no code matches
-template <class In>
-LSI_FN int decode(Bits<In>& b, const Tab& t, const Counts& cnt, int sym_at) {
+// one symbol of the code described by (cnt, the lit/len or the distance table); -1 when the bits run out or no code matches
+template <bool LIT, class In>
+LSI_FN int decode(Bits<In>& b, const Tab& t, const Counts& cnt) {
     int code = 0, first = 0, index = 0;
 #pragma unroll
     for (int len = 1; len <= MAXBITS; ++len) {
         code |= (int)b.take(1);
         const int count = cnt.c[len];
-        if (code - count < first) return b.bad ? -1 : (int)t.get(sym_at + index + (code - first));
+        if (code - count < first) return b.bad ? -1 : (int)(LIT ? t.lsym(index + (code - first)) : t.dsym(index + (code - first)));
         index += count; first += count; first <<= 1; code <<= 1;
     }
     return -1;
 }
 
-// Where the decoded bytes go.  PlainOut: a buffer of exactly n_out bytes (one thread per stream; host tests).  csrc/ingest.hip has a
-// second one (a wave's LDS ring, flushed to global memory in chunks, with the match copies spread over the wave's lanes).
+// Where the decoded bytes go.  PlainOut: a buffer of exactly n_out bytes (one thread per stream).
 struct PlainOut {
     uint8_t* out; size_t n_out, pos;
+    uint64_t stage; uint32_t ns;               // (wide build) the last ns < 8 literals, bytes [pos - ns, pos), not yet in memory
     LSI_FN bool room(uint32_t len) const { return pos + len <= n_out; }
+#if defined(__HIP_DEVICE_COMPILE__) || defined(LSI_WIDE_COPY)          // (LSI_WIDE_COPY: the host test runs the device's code under ASan)
+    // A lane per stream: every store and every load of a lane is a memory request of its own (64 lanes, 64 different lines), and the
+    // memory system takes ~30 G scattered requests a second whatever their size - the decoder was bound by their NUMBER (more waves per
+    // CU did not make it faster).  So literals are gathered eight to a store, and a match moves eight bytes a request even when it is
+    // shorter (what lands behind its end is written again by whatever the stream produces next: a block fills its n_out bytes exactly).
+    static LSI_FN void st8(uint8_t* d, uint64_t v) { *reinterpret_cast<u64_unaligned*>(d) = v; }
+    static LSI_FN uint64_t ld8(const uint8_t* s) { return *reinterpret_cast<const u64_unaligned*>(s); }
+    LSI_FN void lit(uint8_t v) {
+        stage |= (uint64_t)v << (8 * ns); ++ns; ++pos;
+        if (ns == 8) { st8(out + pos - 8, stage); stage = 0; ns = 0; }
+    }
+    LSI_FN void flush() {
+        if (!ns) return;
+        uint8_t* d = out + pos - ns;
+        if (pos - ns + 8 <= n_out) st8(d, stage);
+        else for (uint32_t i = 0; i < ns; ++i) d[i] = (uint8_t)(stage >> (8 * i));
+        stage = 0; ns = 0;
+    }
+    LSI_FN bool copy(uint32_t dist, uint32_t len) {
+        if (dist > pos) return false;
+        flush();
+        uint8_t* d = out + pos; const uint8_t* s = d - dist;
+        uint8_t* const end8 = out + n_out - (n_out < 8 ? n_out : 8);      // the last place an 8-byte store may start (n_out >= 8)
+        pos += len;
+        if (dist >= 8) {
+            if (dist >= len)                                              // the whole match lies behind the write position: four chunks in flight
+                for (; len >= 32; len -= 32, s += 32, d += 32) {
+                    const uint64_t a = ld8(s), b = ld8(s + 8), c = ld8(s + 16), e = ld8(s + 24);
+                    st8(d, a); st8(d + 8, b); st8(d + 16, c); st8(d + 24, e);
+                }
+            for (; len >= 8; len -= 8, s += 8, d += 8) st8(d, ld8(s));
+            if (len && n_out >= 8 && d <= end8) { st8(d, ld8(s)); len = 0; }
+        } else if (n_out >= 8 && d <= end8) {
+            // a source less than eight bytes behind: the match repeats a pattern of `dist` bytes.  One word holds the pattern from its
+            // first byte; it is stored every `step` = the largest multiple of dist <= 8 bytes
+            uint64_t v = ld8(s);
+            if (dist < 8) v &= (1ull << (8 * dist)) - 1ull;
+            for (uint32_t have = dist; have < 8; have *= 2) v |= v << (8 * have);
+            const uint32_t step = (8u / dist) * dist;
+            for (; len >= step && d <= end8; len -= step, d += step) st8(d, v);
+            if (len && d <= end8) { st8(d, v); len = 0; }
+            s = d - dist;
+        }
+        for (; len; --len) *d++ = *s++;
+        return true;
+    }
+    LSI_FN bool done() { flush(); return pos == n_out; }
+#else
     LSI_FN void lit(uint8_t v) { out[pos++] = v; }
     LSI_FN bool copy(uint32_t dist, uint32_t len) {
         if (dist > pos) return false;
-#if defined(__HIP_DEVICE_COMPILE__) || defined(LSI_WIDE_COPY)          // (LSI_WIDE_COPY: the host test runs the device's copy under ASan)
-        // A lane per stream: the lanes of a wave wait for the longest copy among them at every turn, and a byte-by-byte copy pays a
-        // memory round trip per byte.  Eight bytes a turn when the source lies at least eight behind (a chunk then never overlaps its
-        // own destination), four such chunks in flight when the whole match lies behind the write position.
-        uint8_t* d = out + pos; const uint8_t* s = d - dist;
-        pos += len;
-        if (dist >= len)
-            for (; len >= 32; len -= 32, s += 32, d += 32) {
-                const uint64_t a = *reinterpret_cast<const u64_unaligned*>(s), b = *reinterpret_cast<const u64_unaligned*>(s + 8),
-                               c = *reinterpret_cast<const u64_unaligned*>(s + 16), e = *reinterpret_cast<const u64_unaligned*>(s + 24);
-                *reinterpret_cast<u64_unaligned*>(d) = a; *reinterpret_cast<u64_unaligned*>(d + 8) = b;
-                *reinterpret_cast<u64_unaligned*>(d + 16) = c; *reinterpret_cast<u64_unaligned*>(d + 24) = e;
-            }
-        if (dist >= 8)
-            for (; len >= 8; len -= 8, s += 8, d += 8) *reinterpret_cast<u64_unaligned*>(d) = *reinterpret_cast<const u64_unaligned*>(s);
-        for (; len; --len) *d++ = *s++;
-#else
         for (uint32_t i = 0; i < len; ++i) { out[pos] = out[pos - dist]; ++pos; }
-#endif
         return true;
     }
     LSI_FN bool done() const { return pos == n_out; }
+#endif
 };
 
 // Inflates the raw DEFLATE stream in[0, n_in) into `o`: the stream must produce EXACTLY the bytes o has room for (BGZF's ISIZE).
@@ -169,9 +213,9 @@ LSI_FN int inflate_to(In src, size_t n_in, Out& o, const Tab& t) {
             for (int s = 144; s < 256; ++s) t.set_len(s, 9);
             for (int s = 256; s < 280; ++s) t.set_len(s, 7);
             for (int s = 280; s < FIXLCODES; ++s) t.set_len(s, 8);
-            construct(t, 0, FIXLCODES, T_LSYM, &lc);
+            construct<true>(t, 0, FIXLCODES, &lc);
             for (int s = 0; s < MAXDCODES; ++s) t.set_len(s, 5);
-            construct(t, 0, MAXDCODES, T_DSYM, &dc);
+            construct<false>(t, 0, MAXDCODES, &dc);
         } else {                                           // dynamic codes
             const int nlen = (int)b.take(5) + 257, ndist = (int)b.take(5) + 1, ncode = (int)b.take(4) + 4;
             if (b.bad || nlen > MAXLCODES || ndist > MAXDCODES) return -5;
@@ -179,11 +223,11 @@ LSI_FN int inflate_to(In src, size_t n_in, Out& o, const Tab& t) {
             for (int i = 0; i < ncode; ++i) t.set_len(order[i], b.take(3));
             if (b.bad) return -1;
             Counts cc;
-            if (construct(t, 0, 19, T_DSYM, &cc) != 0) return -6;                  // the code-length code must be complete (its symbols borrow the distance table's place)
+            if (construct<false>(t, 0, 19, &cc) != 0) return -6;                  // the code-length code must be complete (its symbols borrow the distance table's place)
             int idx = 0;
             while (idx < nlen + ndist) {
                 b.fill();
-                int sym = decode(b, t, cc, T_DSYM);
+                int sym = decode<false>(b, t, cc);
                 if (sym < 0) return -7;
                 if (sym < 16) { t.set_len(idx, (uint32_t)sym); ++idx; }
                 else {
@@ -196,14 +240,14 @@ LSI_FN int inflate_to(In src, size_t n_in, Out& o, const Tab& t) {
                 }
             }
             if (t.len(256) == 0) return -10;                             // no end-of-block code
-            int err = construct(t, 0, nlen, T_LSYM, &lc);
+            int err = construct<true>(t, 0, nlen, &lc);
             if (err < 0 || (err > 0 && nlen - (int)lc.c[0] != 1)) return -11;        // incomplete only for a single code
-            err = construct(t, nlen, ndist, T_DSYM, &dc);
+            err = construct<false>(t, nlen, ndist, &dc);
             if (err < 0 || (err > 0 && ndist - (int)dc.c[0] != 1)) return -12;
         }
         for (;;) {                                         // every turn writes at least one byte or ends the block
             b.fill();
-            int sym = decode(b, t, lc, T_LSYM);
+            int sym = decode<true>(b, t, lc);
             if (sym < 0) return -13;
             if (sym < 256) { if (!o.room(1)) return -3; o.lit((uint8_t)sym); continue; }
             if (sym == 256) break;
@@ -211,7 +255,7 @@ LSI_FN int inflate_to(In src, size_t n_in, Out& o, const Tab& t) {
             if (sym >= 29) return -14;
             const uint32_t len = lbase[sym] + b.take(lext[sym]);
             b.fill();
-            const int ds = decode(b, t, dc, T_DSYM);
+            const int ds = decode<false>(b, t, dc);
             if (ds < 0 || ds >= 30) return -15;
             const uint32_t dist = dbase[ds] + b.take(dext[ds]);
             if (b.bad) return -1;
@@ -224,7 +268,7 @@ LSI_FN int inflate_to(In src, size_t n_in, Out& o, const Tab& t) {
 
 // one thread, a plain output buffer
 LSI_FN int inflate_raw(const uint8_t* in, size_t n_in, uint8_t* out, size_t n_out, const Tab& t) {
-    PlainOut o{out, n_out, 0};
+    PlainOut o{out, n_out, 0, 0, 0};
     return inflate_to(PlainIn{in}, n_in, o, t);
 }
 

@@ -31,10 +31,11 @@ namespace lsg {
 
 struct IngBlk { uint64_t coff, uoff; uint32_t csize, usize, crc, pad_; };      // crc: the block's CRC32 of its uncompressed bytes (RFC 1952 trailer)
 
-// The decoding tables of a wave's 64 streams (45 KB) live in LDS, three waves per CU; the code lengths, which only the header of a block
-// touches, in global memory (`lens_all`: T_LENS * 64 bytes per wave, lane-interleaved like the tables).
+// The decoding tables of a wave's 64 streams (22.8 KB: a byte per symbol, the lit/len symbols' ninth bits apart) live in LDS, seven waves
+// per CU; the code lengths and the construction's counters, which only the header of a block touches, in global memory (`lens_all`:
+// T_LENS * 64 bytes per wave, lane-interleaved like the tables).
 __global__ __launch_bounds__(64) void k_inflate(const uint8_t* comp, const IngBlk* blk, uint32_t n_blk, uint8_t* ubuf, uint32_t* status, uint8_t* lens_all) {
-    __shared__ uint16_t tab[lsi::T_WORDS * 64];
+    __shared__ uint8_t tab[lsi::T_SYM * 64];
     uint8_t* lens = lens_all + (size_t)blockIdx.x * (lsi::T_LENS * 64);
     const int lane = threadIdx.x;
     // every lane takes its next block from one queue (status[8]) the moment it has finished one: a wave lasts as long as its slowest
@@ -324,8 +325,9 @@ static int load_bam_impl(lsg_ctx* c, const uint8_t* file, int64_t n_bytes, int64
     // ---- inflate
     const IngBlk* dblk = d_blk.as<IngBlk>();
     uint32_t* status = d_status.as<uint32_t>();
-    {                                                        // a lane per block; 45 KB of LDS tables per wave: three waves per CU
-        unsigned g = (n_blk + 63) / 64; const unsigned cap = (unsigned)(c->n_cus * 3);
+    {                                                        // a lane per block; 22.8 KB of LDS tables per wave: seven waves per CU
+        static const unsigned per_cu = getenv("LSG_INFLATE_WAVES") ? (unsigned)atoi(getenv("LSG_INFLATE_WAVES")) : 7u;
+        unsigned g = (n_blk + 63) / 64; const unsigned cap = (unsigned)c->n_cus * (per_cu ? per_cu : 7u);
         if (g > cap) g = cap;
         if (!g) g = 1;
         if (d_tmp.reserve((size_t)g * lsi::T_LENS * 64)) return done_ev(-3);

@@ -41,7 +41,7 @@ int main(int argc, char** argv) {
     std::ifstream f(argv[1], std::ios::binary); std::stringstream ss; ss << f.rdbuf(); const std::string file = ss.str();
     const uint8_t* d = (const uint8_t*)file.data();
     // BGZF blocks -> one uncompressed stream through the device's inflate
-    std::vector<uint8_t> u; std::vector<uint16_t> tab(lsi::T_WORDS); std::vector<uint8_t> tlens(lsi::T_LENS); lsi::Tab t{tab.data(), tlens.data(), 1};
+    std::vector<uint8_t> u; std::vector<uint8_t> tab(lsi::T_SYM); std::vector<uint8_t> tlens(lsi::T_LENS); lsi::Tab t{tab.data(), tlens.data(), 1};
     for (size_t off = 0; off + 18 <= file.size();) {
         const uint32_t xlen = lsr::rd16(d + off + 10), bsize = lsr::rd16(d + off + 16) + 1u, usize = lsr::rd32(d + off + bsize - 4);
         const size_t at = u.size(); u.resize(at + usize);

@@ -36,7 +36,7 @@ static std::vector<uint8_t> make_data(int kind, size_t n) {
 }
 
 int main() {
-    std::vector<uint16_t> tab(lsi::T_WORDS); std::vector<uint8_t> lens(lsi::T_LENS);
+    std::vector<uint8_t> tab(lsi::T_SYM); std::vector<uint8_t> lens(lsi::T_LENS);
     lsi::Tab t{tab.data(), lens.data(), 1};
     long n_ok = 0, n_bad = 0;
     const size_t sizes[] = {0, 1, 2, 17, 255, 4096, 65280, 65536};
@@ -71,12 +71,12 @@ int main() {
                 }
     // the strided table layout the device uses ([index][lane], stride 64): same result through lane 37 of a 64-lane image
     {
-        std::vector<uint16_t> img((size_t)lsi::T_WORDS * 64, 0xABCD); std::vector<uint8_t> limg((size_t)lsi::T_LENS * 64, 0xAB);
+        std::vector<uint8_t> img((size_t)lsi::T_SYM * 64, 0xCD); std::vector<uint8_t> limg((size_t)lsi::T_LENS * 64, 0xAB);
         lsi::Tab ts{img.data() + 37, limg.data() + 37, 64};
         const std::vector<uint8_t> src = make_data(4, 60000), z = deflate_raw(src, 6, Z_DEFAULT_STRATEGY);
         std::vector<uint8_t> out(src.size());
         if (lsi::inflate_raw(z.data(), z.size(), out.data(), out.size(), ts) != 0 || out != src) { fprintf(stderr, "strided tables failed\n"); return 1; }
-        for (size_t i = 0; i < img.size(); ++i) if ((i & 63) != 37 && img[i] != 0xABCD) { fprintf(stderr, "strided tables wrote another lane's word\n"); return 1; }
+        for (size_t i = 0; i < img.size(); ++i) if ((i & 63) != 37 && img[i] != 0xCD) { fprintf(stderr, "strided tables wrote another lane's word\n"); return 1; }
         for (size_t i = 0; i < limg.size(); ++i) if ((i & 63) != 37 && limg[i] != 0xAB) { fprintf(stderr, "strided tables wrote another lane's byte\n"); return 1; }
     }
     printf("inflate ok: %ld streams equal zlib, %ld corrupted streams handled\n", n_ok, n_bad);
