@@ -105,18 +105,28 @@ LSI_FN int construct(const Tab& t, int first, int n, Counts* cnt) {
     return left;
 }
 
-// one symbol of the code described by (cnt, the lit/len or the distance table); -1 when the bits run out or no code matches
+// one symbol of the code described by (cnt, the lit/len or the distance table); -1 when the bits run out or no code matches.
+// The canonical walk over the code lengths (first code and first symbol index of every length, as zlib's puff does it bit by bit) runs
+// over fifteen PEEKED bits without a branch - every length is looked at, the first that fits is kept by selects - and the buffer gives
+// up the code's bits once: a lane per stream executes what ANY lane of its wave needs, so a loop that left early for short codes
+// still ran to the longest code among 64 lanes, paid a taken branch a length, and a refill test a bit.
 template <bool LIT, class In>
 LSI_FN int decode(Bits<In>& b, const Tab& t, const Counts& cnt) {
-    int code = 0, first = 0, index = 0;
+    if (b.cnt < MAXBITS) { b.fill(); if (b.cnt < MAXBITS) b.fill(); }          // (the stream's end may leave fewer: the bits beyond are zeros)
+    const uint32_t peek = (uint32_t)b.buf;
+    int code = 0, first = 0, index = 0, got = 0, at = 0;
 #pragma unroll
     for (int len = 1; len <= MAXBITS; ++len) {
-        code |= (int)b.take(1);
+        code |= (int)((peek >> (len - 1)) & 1u);
         const int count = cnt.c[len];
-        if (code - count < first) return b.bad ? -1 : (int)(LIT ? t.lsym(index + (code - first)) : t.dsym(index + (code - first)));
+        const bool hit = got == 0 && code - count < first;
+        got = hit ? len : got;
+        at = hit ? index + (code - first) : at;
         index += count; first += count; first <<= 1; code <<= 1;
     }
-    return -1;
+    if (got == 0 || got > b.cnt) { if (got > b.cnt) b.bad = 1; return -1; }
+    b.buf >>= got; b.cnt -= got;
+    return (int)(LIT ? t.lsym(at) : t.dsym(at));
 }
 
 // Where the decoded bytes go.  PlainOut: a buffer of exactly n_out bytes (one thread per stream).
