@@ -23,13 +23,27 @@ constexpr int MAXBITS = 15, MAXLCODES = 286, MAXDCODES = 30, FIXLCODES = 288, MA
 //   sym (T_SYM bytes; device: LDS, [index][lane]): the decoding tables proper, all a symbol's decode reads
 //     [0, 288)    low bytes of the lit/len symbols in code order      [288, 324)  their ninth bits (symbols 256..285), one bit a symbol
 //     [324, 356)  distance symbols in code order (and, while a dynamic header is read, the code-length code's)
+//     [356, 388)  lit/len: per code length, (index of the length's first symbol) - (its first code), 16-bit little endian
+//     [388, 420)  the same for the distance code (the code-length code's while a header is read)
 //   lens (T_LENS bytes; device: global memory): what only the head of a block touches
 //     [0, 320)    the code lengths being read      [320, 384)  count per length and next offset per length, 16-bit little endian
-// 356 bytes of LDS per thread: seven waves of 64 threads per CU (a 16-bit word per symbol was 700: three waves, a SIMD without a wave).
-constexpr int T_LLO = 0, T_LHI = 288, T_DSYM = 324, T_SYM = 356, T_W = 320, T_CNT = 0, T_OFFS = 16, T_LENS = 384;
+// 420 bytes of LDS per thread: five waves of 64 threads per CU (a 16-bit word per symbol was 700: three waves, a SIMD without a wave).
+constexpr int T_LLO = 0, T_LHI = 288, T_DSYM = 324, T_LBASE = 356, T_DBASE = 388, T_SYM = 420, T_W = 320, T_CNT = 0, T_OFFS = 16, T_LENS = 384;
 
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
+
+LSI_FN uint32_t brev32(uint32_t v) {
+#if defined(__clang__)
+    return __builtin_bitreverse32(v);
+#else
+    v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1);
+    v = ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);
+    v = ((v >> 4) & 0x0f0f0f0fu) | ((v & 0x0f0f0f0fu) << 4);
+    v = ((v >> 8) & 0x00ff00ffu) | ((v & 0x00ff00ffu) << 8);
+    return (v >> 16) | (v << 16);
+#endif
+}
 
 struct Tab {
     uint8_t* sym; uint8_t* lens; int stride;
@@ -41,6 +55,8 @@ struct Tab {
     LSI_FN void clear_lhi() const { for (int i = T_LHI; i < T_DSYM; ++i) sym[(size_t)i * stride] = 0; }
     LSI_FN uint32_t dsym(int i) const { return sym[(size_t)(T_DSYM + i) * stride]; }
     LSI_FN void set_dsym(int i, uint32_t v) const { sym[(size_t)(T_DSYM + i) * stride] = (uint8_t)v; }
+    LSI_FN int base(int at, int l) const { return (int)(int16_t)(uint16_t)(sym[(size_t)(at + 2 * l) * stride] | (sym[(size_t)(at + 2 * l + 1) * stride] << 8)); }
+    LSI_FN void set_base(int at, int l, int v) const { sym[(size_t)(at + 2 * l) * stride] = (uint8_t)v; sym[(size_t)(at + 2 * l + 1) * stride] = (uint8_t)((uint32_t)v >> 8); }
     LSI_FN uint32_t len(int i) const { return lens[(size_t)i * stride]; }
     LSI_FN void set_len(int i, uint32_t v) const { lens[(size_t)i * stride] = (uint8_t)v; }
     LSI_FN uint16_t get(int i) const { return (uint16_t)(lens[(size_t)(T_W + 2 * i) * stride] | (lens[(size_t)(T_W + 2 * i + 1) * stride] << 8)); }      // the construction's 16-bit words
@@ -83,7 +99,10 @@ struct Bits {
     }
 };
 
-struct Counts { uint16_t c[MAXBITS + 1]; };          // codes per length (kept in registers: the decode loop is fully unrolled)
+// What a symbol's decode compares against, in registers (the comparisons are unrolled): lim[l] = the end of the length-l codes' range when
+// every code is written left-justified in fifteen bits (codes of a canonical code grow with their length: the ranges follow each other,
+// an empty length's end is its predecessor's); zeros = the symbols without a code.
+struct Counts { uint16_t lim[MAXBITS + 1]; uint16_t zeros; };
 
 // builds the canonical decoding tables of n symbols whose code lengths are lens[first .. first + n): symbols in code order in the
 // lit/len table (LIT) or the distance table, counts per length in *cnt.  Returns 0 for a complete code, > 0 incomplete, < 0 over-subscribed (as zlib's puff).
@@ -101,31 +120,35 @@ LSI_FN int construct(const Tab& t, int first, int n, Counts* cnt) {
         const int l = (int)(t.len(first + s) & 15u);
         if (l) { const uint16_t o = t.get(T_OFFS + l); if (LIT) t.set_lsym(o, (uint32_t)s); else t.set_dsym(o, (uint32_t)s); t.set(T_OFFS + l, (uint16_t)(o + 1)); }
     }
-    for (int len = 0; len <= MAXBITS; ++len) cnt->c[len] = t.get(T_CNT + len);
+    {
+        int fst = 0, index = 0;
+        for (int len = 1; len <= MAXBITS; ++len) {
+            const int count = (int)t.get(T_CNT + len);
+            const int lim = (fst + count) << (MAXBITS - len);
+            cnt->lim[len] = (uint16_t)(lim > 0xffff ? 0xffff : lim);           // (an over-subscribed code - refused by the caller - could pass 2^15)
+            t.set_base(LIT ? T_LBASE : T_DBASE, len, index - fst);
+            index += count; fst = (fst + count) << 1;
+        }
+        cnt->lim[0] = 0; cnt->zeros = t.get(T_CNT + 0);
+    }
     return left;
 }
 
 // one symbol of the code described by (cnt, the lit/len or the distance table); -1 when the bits run out or no code matches.
-// The canonical walk over the code lengths (first code and first symbol index of every length, as zlib's puff does it bit by bit) runs
-// over fifteen PEEKED bits without a branch - every length is looked at, the first that fits is kept by selects - and the buffer gives
-// up the code's bits once: a lane per stream executes what ANY lane of its wave needs, so a loop that left early for short codes
-// still ran to the longest code among 64 lanes, paid a taken branch a length, and a refill test a bit.
+// Fifteen PEEKED bits, reversed into a left-justified code, are compared with the lengths' range ends: the code's length is one more
+// than the number of ends it has reached - no loop, no branch; its symbol sits at base[length] + the code.  (A lane per stream executes
+// what ANY lane of its wave needs: the bit-by-bit walk left early for a short code in one lane, but the wave ran to the longest code
+// among 64, paid a taken branch a length and a refill test a bit.)
 template <bool LIT, class In>
 LSI_FN int decode(Bits<In>& b, const Tab& t, const Counts& cnt) {
     if (b.cnt < MAXBITS) { b.fill(); if (b.cnt < MAXBITS) b.fill(); }          // (the stream's end may leave fewer: the bits beyond are zeros)
-    const uint32_t peek = (uint32_t)b.buf;
-    int code = 0, first = 0, index = 0, got = 0, at = 0;
+    const uint32_t c15 = brev32((uint32_t)b.buf) >> 17;
+    int len = 1;
 #pragma unroll
-    for (int len = 1; len <= MAXBITS; ++len) {
-        code |= (int)((peek >> (len - 1)) & 1u);
-        const int count = cnt.c[len];
-        const bool hit = got == 0 && code - count < first;
-        got = hit ? len : got;
-        at = hit ? index + (code - first) : at;
-        index += count; first += count; first <<= 1; code <<= 1;
-    }
-    if (got == 0 || got > b.cnt) { if (got > b.cnt) b.bad = 1; return -1; }
-    b.buf >>= got; b.cnt -= got;
+    for (int l = 1; l < MAXBITS; ++l) len += c15 >= cnt.lim[l] ? 1 : 0;
+    if (c15 >= cnt.lim[MAXBITS] || len > b.cnt) { if (c15 < cnt.lim[MAXBITS]) b.bad = 1; return -1; }
+    b.buf >>= len; b.cnt -= len;
+    const int at = t.base(LIT ? T_LBASE : T_DBASE, len) + (int)(c15 >> (MAXBITS - len));
     return (int)(LIT ? t.lsym(at) : t.dsym(at));
 }
 
@@ -251,9 +274,9 @@ LSI_FN int inflate_to(In src, size_t n_in, Out& o, const Tab& t) {
             }
             if (t.len(256) == 0) return -10;                             // no end-of-block code
             int err = construct<true>(t, 0, nlen, &lc);
-            if (err < 0 || (err > 0 && nlen - (int)lc.c[0] != 1)) return -11;        // incomplete only for a single code
+            if (err < 0 || (err > 0 && nlen - (int)lc.zeros != 1)) return -11;        // incomplete only for a single code
             err = construct<false>(t, nlen, ndist, &dc);
-            if (err < 0 || (err > 0 && ndist - (int)dc.c[0] != 1)) return -12;
+            if (err < 0 || (err > 0 && ndist - (int)dc.zeros != 1)) return -12;
         }
         for (;;) {                                         // every turn writes at least one byte or ends the block
             b.fill();

@@ -31,7 +31,7 @@ namespace lsg {
 
 struct IngBlk { uint64_t coff, uoff; uint32_t csize, usize, crc, pad_; };      // crc: the block's CRC32 of its uncompressed bytes (RFC 1952 trailer)
 
-// The decoding tables of a wave's 64 streams (22.8 KB: a byte per symbol, the lit/len symbols' ninth bits apart) live in LDS, seven waves
+// The decoding tables of a wave's 64 streams (26.9 KB: a byte per symbol, the lit/len symbols' ninth bits apart) live in LDS, five waves
 // per CU; the code lengths and the construction's counters, which only the header of a block touches, in global memory (`lens_all`:
 // T_LENS * 64 bytes per wave, lane-interleaved like the tables).
 __global__ __launch_bounds__(64) void k_inflate(const uint8_t* comp, const IngBlk* blk, uint32_t n_blk, uint8_t* ubuf, uint32_t* status, uint8_t* lens_all) {
@@ -325,9 +325,9 @@ static int load_bam_impl(lsg_ctx* c, const uint8_t* file, int64_t n_bytes, int64
     // ---- inflate
     const IngBlk* dblk = d_blk.as<IngBlk>();
     uint32_t* status = d_status.as<uint32_t>();
-    {                                                        // a lane per block; 22.8 KB of LDS tables per wave: seven waves per CU
-        static const unsigned per_cu = getenv("LSG_INFLATE_WAVES") ? (unsigned)atoi(getenv("LSG_INFLATE_WAVES")) : 7u;
-        unsigned g = (n_blk + 63) / 64; const unsigned cap = (unsigned)c->n_cus * (per_cu ? per_cu : 7u);
+    {                                                        // a lane per block; 26.9 KB of LDS tables per wave: five waves per CU
+        static const unsigned per_cu = getenv("LSG_INFLATE_WAVES") ? (unsigned)atoi(getenv("LSG_INFLATE_WAVES")) : 5u;
+        unsigned g = (n_blk + 63) / 64; const unsigned cap = (unsigned)c->n_cus * (per_cu ? per_cu : 5u);
         if (g > cap) g = cap;
         if (!g) g = 1;
         if (d_tmp.reserve((size_t)g * lsi::T_LENS * 64)) return done_ev(-3);
