@@ -5,7 +5,6 @@ set -e
 TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 F=gpurun_out/final; rm -rf $F; mkdir -p $F
-echo "== default bench"; timeout -k 10 500 python3 bench.py > $F/${TAG}_bench_default_run.json 2> $F/bench_default.err; tail -c 600 $F/${TAG}_bench_default_run.json; echo
 echo "== rocprof passes"; bash tools/collect_profiles.sh > $F/collect.log 2>&1
 mkdir -p $F/p; python3 - "$TAG" <<'PY'
 import subprocess, sys, shutil, glob, os
@@ -14,6 +13,8 @@ subprocess.check_call([sys.executable, "tools/summarize_profiles.py", tag])
 for f in glob.glob("profiles/%s_bench_kernel_stats.csv" % tag) + glob.glob("profiles/%s_bench_under_rocprof.json" % tag) + glob.glob("profiles/%s_pmc_traffic.json" % tag):
     shutil.copy(f, "gpurun_out/final/")
 PY
+# (after the counter passes: bench.py quotes roofline.traffic from the profiles/${TAG}_pmc_traffic.json the lines above just wrote for this build)
+echo "== default bench"; timeout -k 10 500 python3 bench.py > $F/${TAG}_bench_default_run.json 2> $F/bench_default.err; tail -c 600 $F/${TAG}_bench_default_run.json; echo
 echo "== the store-keeping step (k_tm_gather_count) and the re-counts over its store (k_tm_resolve, k_tm_walk)"
 export LSG_BENCH_KEEP_STORE=1
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/keep -o bench -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --e2e-reads 0 --no-c4 > $F/${TAG}_keep_store_bench.json 2> $F/keep.err || echo "keep-store trace failed"
