@@ -51,6 +51,21 @@ def candidate_text_digest(eng, m, candidates_only=False):
             sub.append((k[keep], r[keep], c[keep]))
         per_ct = sub
     text = tsvio.write_step1_tsv("/dev/null", calls, per_ct, m.contig_names, ["Cancer", "Non-Cancer"], [], header=False, as_bytes=True)
+    return text_digest(text, m)
+
+
+def device_text_digest(eng, m):
+    """the same digest of the same rows as the DEVICE prints them (csrc/tables.hip: table TABLE_STEP1_KEPT, what the fused chain's step 2
+    starts from): its text never passes through the host writer"""
+    eng.set_table_names(m.contig_names, ["Cancer", "Non-Cancer"])
+    n = eng.format_table(eng.TABLE_STEP1_KEPT)
+    text = eng.table_bytes(eng.TABLE_STEP1_KEPT, n)
+    eng.free_table()
+    return text_digest(text, m)
+
+
+def text_digest(text, m):
+    from longsom_amd import tsvio
     sc = tsvio.scan_rows(text, m.contig_names)
     tid = sc.key >> 32
     out = {}
@@ -70,6 +85,7 @@ def test_candidate_call_records_equal_the_cpu_oracles_small(engine):
     engine.synth_reads(m)
     engine.pileup_count(); engine.call_step1()
     assert candidate_text_digest(engine, m) == oracle_calls("c1_20000")
+    assert device_text_digest(engine, m) == oracle_calls("c1_20000")
 
 
 def test_two_counts_of_the_same_reads_are_identical(engine):
@@ -104,6 +120,7 @@ def test_two_counts_of_the_same_reads_are_identical(engine):
     want_calls = oracle_calls("c4_2500000")
     assert candidate_text_digest(engine, m) == want_calls
     assert candidate_text_digest(engine, m, candidates_only=True) == want_calls          # (the form the full-size test uses)
+    assert device_text_digest(engine, m) == want_calls                                   # (and as the device prints the rows)
     # (the digest of the raw call records the HIP path itself wrote in round 1: kept as a cross-build check)
     if os.environ.get("LSG_WRITE_PIN") == "1":
         json.dump({"calls": d["calls"]}, open(PIN, "w"), indent=1)

@@ -57,8 +57,10 @@ def test_full_size_rows_equal_the_cpu_oracle(engine, cfg, n_reads):
             # ... and merge + step 1 of the FULL workload: the step-1 text of every row step 2 keeps (7.69 M candidate rows of C2's 23.9 M merged
             # sites) hashes, contig by contig, to what the CPU oracles wrote (count_oracle.c + calling_oracle.py step 1 with scipy's betabinom
             # over 40 region shards: tools/oracle_call_hash.py C2 1e7 6 40, 27 min of the build container's CPU); nothing the GPU wrote is in the pin
-            from tests.test_determinism_gpu import candidate_text_digest, oracle_calls
+            from tests.test_determinism_gpu import candidate_text_digest, device_text_digest, oracle_calls
             n_sites, n_cand = eng.call_step1()
             pin = json.load(open(calls_pin))
             assert n_sites == pin["merged_sites"] and n_cand == pin["candidate_rows"]
             assert candidate_text_digest(eng, m, candidates_only=True) == oracle_calls("%s_%d" % (cfg.lower(), n_reads))
+            # ... and the text of the same rows as the DEVICE prints it (csrc/tables.hip; what the fused chain writes and step 2 reads)
+            assert device_text_digest(eng, m) == oracle_calls("%s_%d" % (cfg.lower(), n_reads)), "device-printed step-1 rows (%s)" % how
